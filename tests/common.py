@@ -1,0 +1,89 @@
+"""Shared helpers for the parity tests: load a golden fixture, rebuild its closed-form
+weights / inputs / noise, and compare a forward result against it."""
+import json
+import os.path as osp
+
+import numpy as np
+import torch
+
+from genesis_amd import testing as T
+
+GOLDEN = osp.join(osp.dirname(osp.abspath(__file__)), 'golden')
+ALL_CASES = ['tiny', 'tiny_b3k3', 'tiny_noar', 'tiny_klm', 'tiny_nosemi', 'tiny_laplacian',
+             'tiny_epanechnikov', 'metric', 'cfg2', 'cfg5']
+
+
+class Golden(object):
+    def __init__(self, name):
+        self.name = name
+        self.g = np.load(osp.join(GOLDEN, 'v2_%s.npz' % name), allow_pickle=False)
+        self.cfg = json.loads(str(self.g['cfg_json']))
+        self.cfg['pixel_std2'] = self.cfg['pixel_std1']
+        self.B = int(self.g['B'])
+        self.K = self.cfg['K_steps']
+        self.S = self.cfg['img_size']
+        self.D = self.cfg['feat_dim']
+
+    def inputs(self):
+        x = T.make_input(int(self.g['x_seed']), self.B, self.S)
+        rand_pixel, eps_k = T.draw_noise(int(self.g['noise_seed']), self.B, self.S, self.D, self.K)
+        # the stored summaries pin that the regenerated inputs are the reference's
+        T.check_summary('in/x', x, self.g, 0, 0, self.name)
+        T.check_summary('in/rand_pixel', rand_pixel, self.g, 0, 0, self.name)
+        T.check_summary('in/eps', torch.stack(eps_k), self.g, 0, 0, self.name)
+        return x, rand_pixel, eps_k
+
+    def noise(self, seed_offset):
+        return T.draw_noise(int(self.g['noise_seed']) + seed_offset, self.B, self.S, self.D, self.K)
+
+    def weights(self, template):
+        keys = [str(k) for k in self.g['sd_keys']]
+        assert list(template.keys()) == keys, 'state_dict key order differs from reference'
+        numel = [int(v.numel()) for v in template.values()]
+        assert numel == [int(n) for n in self.g['sd_numel']]
+        return T.formula_state_dict(template)
+
+    def check(self, key, tensor, rtol, atol):
+        full = 'out/' + key
+        if full in self.g.files:
+            np.testing.assert_allclose(tensor.detach().cpu().float().numpy(), self.g[full],
+                                       rtol=rtol, atol=atol, err_msg='%s %s' % (self.name, key))
+        else:
+            T.check_summary(full, tensor, self.g, rtol, atol, self.name)
+
+    def has(self, key):
+        return ('out/' + key) in self.g.files or ('out/%s/n' % key) in self.g.files
+
+    def check_forward(self, recon, losses, stats, att, comp, rtol=1e-4, atol=1e-5):
+        st = lambda l: torch.stack(list(l))  # noqa: E731
+        seed_idx = torch.stack([i.cpu() for i in att['seed_idx']]).numpy()
+        np.testing.assert_array_equal(seed_idx, self.g['seed_idx'], err_msg='seed pixels')
+        self.check('err', losses['err'], rtol, atol)
+        self.check('kl_l_k', st(losses['kl_l_k']), rtol, 10 * atol)
+        if 'kl_m' in losses:
+            self.check('kl_m', losses['kl_m'], rtol, atol)
+        self.check('recon', recon, rtol, atol)
+        self.check('log_m_k', st(stats['log_m_k']), rtol, atol)
+        self.check('log_s_k', st(stats['log_s_k']), rtol, atol)
+        self.check('x_r_k', st(stats['x_r_k']), rtol, atol)
+        self.check('log_m_r_k', st(stats['log_m_r_k']), rtol, atol)
+        self.check('colour', att['colour'], rtol, atol)
+        self.check('seeds', st(att['seeds']), rtol, atol)
+        self.check('mu_k', st(comp['mu_k']), rtol, atol)
+        self.check('sigma_k', st(comp['sigma_k']), rtol, atol)
+        self.check('z_k', st(comp['z_k']), rtol, atol)
+        assert int(stats['instance_seg'].sum().item()) == int(self.g['instance_seg_sum'])
+
+    def check_grads(self, named_grads, rtol=2e-3, atol_frac=1e-3):
+        """named_grads: iterable of (name, grad tensor) in state_dict order.  Tolerances are
+        relative to each tensor's own gradient scale (norm / sqrt(n))."""
+        norms = self.g['grad_norms']
+        big = float(np.max(norms))  # floor for analytically-zero grads (pure cancellation noise)
+        for i, (name, g) in enumerate(named_grads):
+            n = max(1, g.numel())
+            scale = float(norms[i]) / np.sqrt(n)
+            got = float(g.double().norm().item())
+            assert abs(got - float(norms[i])) <= rtol * float(norms[i]) + 2e-5 + 1e-6 * big, \
+                '%s grad norm %s: %r vs %r' % (self.name, name, got, float(norms[i]))
+            T.check_summary('grad/' + name, g, self.g, rtol, atol_frac * scale + 5e-6 + 1e-7 * big,
+                            self.name)

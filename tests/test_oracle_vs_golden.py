@@ -1,0 +1,88 @@
+"""Pins the oracle (oracle/v2_oracle.py) against golden vectors captured from the real
+reference, and -- when /root/reference is present -- against the live import."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import v2_oracle as O
+from oracle import ref_import as R
+from tests.common import ALL_CASES, Golden
+
+
+def _params(gold, requires_grad=False):
+    tmpl = O.template_state_dict(gold.cfg)
+    sd = gold.weights(tmpl)
+    return {k: v.clone().requires_grad_(requires_grad) for k, v in sd.items()}
+
+
+@pytest.mark.parametrize('case', ALL_CASES)
+@pytest.mark.parametrize('reference_form', [True, False])
+def test_forward_and_grads(case, reference_form):
+    if case == 'cfg5' and reference_form:
+        pytest.skip('128x128 K=11 reference-form covered by the deduplicated form')
+    gold = Golden(case)
+    p = _params(gold, True)
+    x, rand_pixel, eps_k = gold.inputs()
+    recon, losses, stats, att, comp = O.v2_forward(
+        p, x, gold.cfg, rand_pixel, eps_k, reference_form=reference_form)
+    gold.check_forward(recon, losses, stats, att, comp, rtol=2e-5, atol=2e-6)
+    err, kl_l, kl_m = O.aggregate_losses(losses)
+    assert abs(float(err) - float(gold.g['loss/err'])) <= 1e-5 * abs(float(err))
+    (err + kl_l + kl_m).backward()
+    grads = [(k, v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in p.items()]
+    gold.check_grads(grads)
+
+
+@pytest.mark.parametrize('case', ['tiny', 'tiny_klm', 'metric'])
+def test_train_steps(case):
+    gold = Golden(case)
+    p = _params(gold, True)
+    x, _, _ = gold.inputs()
+    geco = O.make_geco(gold.S)
+    opt = torch.optim.Adam(list(p.values()), 1e-4)
+    hist = gold.g['train_hist']
+    for it in range(3):
+        rp, eps = gold.noise(1 + it)
+        elbo, err, kl, beta = O.train_step(p, opt, geco, x, gold.cfg, rp, eps)
+        np.testing.assert_allclose([elbo, err, kl, beta], hist[it, :4], rtol=1e-3)
+        assert abs(elbo - hist[it, 0]) <= 1e-3 * abs(hist[it, 0])  # north_star ELBO bound
+    assert abs(float(geco.beta) - float(gold.g['train_beta_final'])) <= 1e-5
+
+
+def test_masks_sum_to_one():
+    """The one numerical invariant the reference itself pins: utils/misc.py:258-270."""
+    gold = Golden('tiny')
+    p = _params(gold)
+    x, rp, eps = gold.inputs()
+    _, _, stats, _, _ = O.v2_forward(p, x, gold.cfg, rp, eps)
+    for key in ('log_m_k', 'log_m_r_k'):
+        s = torch.stack(stats[key], 4).exp().sum(4)
+        assert float((s - 1).abs().max()) < 1e-3
+
+
+@pytest.mark.skipif(not R.reference_available(), reason='reference tree not present')
+def test_live_against_reference_import():
+    mods = R.import_reference()
+    cfgd = O.make_cfg(K_steps=5, img_size=32, feat_dim=16)
+    cfg = R.reference_cfg(**cfgd)
+    torch.manual_seed(3)
+    model = mods['genesisv2_config'].load(cfg)
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(O.param_shapes(cfgd).keys())
+    for k, (shape, dt) in O.param_shapes(cfgd).items():
+        assert tuple(sd[k].shape) == tuple(shape) and sd[k].dtype == dt, k
+    assert torch.equal(sd['att_process.log_sigma'], O.default_log_sigma(cfgd).double())
+    with torch.no_grad():
+        sd['att_process.colour_head.gate.gate'].fill_(0.4)
+    model.load_state_dict(sd)
+    x = torch.rand(3, 3, 32, 32)
+    torch.manual_seed(5)
+    r_recon, r_losses, r_stats, _, r_comp = model(x)
+    torch.manual_seed(5)  # oracle draws its own noise in the same order
+    recon, losses, stats, _, comp = O.v2_forward({k: v for k, v in sd.items()}, x, cfgd)
+    assert torch.allclose(recon, r_recon, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(losses['err'], r_losses['err'], rtol=1e-6)
+    for a, b in zip(losses['kl_l_k'], r_losses['kl_l_k']):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)
+    for a, b in zip(comp['z_k'], r_comp['z_k']):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
