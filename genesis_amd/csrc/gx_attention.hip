@@ -1,0 +1,291 @@
+// GENESIS-V2 Instance-Colouring Stick-Breaking Process (IC-SBP), forward + backward.
+//
+// Reference: modules/attention.py:162-226 (InstanceColouringSBP.forward),
+//            modules/blocks.py:63-71 (squared_distance), :18-20 (clamp_preserve_gradients).
+//
+// Forward (one workgroup per image -- the K-1 steps are sequential through the scope, and each
+// step needs an argmax over the whole image, resolved with wavefront shuffles + one LDS hop):
+//   scope = exp(log_s); idx = first argmax_hw(rand * scope); seed = colour[:, idx]
+//   d = sum_c (colour_c - seed_c)^2 ; alpha = kernel(d, sigma) ; alpha_c = ST-clamp(alpha, .01, .99)
+//   log_m_t = log_s + log(alpha_c) ; log_s <- log_s + log(1 - alpha_c) ; last mask = last scope.
+// log_s lives in registers across steps; colour (C*HW*4 B per image, L2 resident) is re-read per
+// step.  HBM-bound: algorithmic bytes (C + 1 + 2K) * HW * 4 per image.
+//
+// Backward is per-pixel independent apart from the seed-gradient reduction: the gradient w.r.t.
+// the scope entering step t is the suffix sum of the mask gradients, so one sweep t = K-2..0 per
+// pixel yields d colour, and block reductions (fixed tree, deterministic) yield the gradient that
+// flows through the gathered seed (scatter-add into the seed pixel -- the reference's CopySlices)
+// and d log_sigma.
+#include "gx_common.h"
+
+namespace {
+
+enum { KERNEL_GAUSSIAN = 0, KERNEL_LAPLACIAN = 1, KERNEL_EPANECHNIKOV = 2 };
+constexpr int MAXC = 8;      // colour channels supported (reference hard-codes colour_dim=8, genesisv2_config.py:74)
+constexpr int MAXPPT = 16;   // HW <= 1024 * 16 floats of LDS state per image
+
+__device__ __forceinline__ float st_clamp(float a, float lo, float hi) {
+    const float c = fminf(fmaxf(a, lo), hi);
+    return a + (c - a);  // value of x + (clamp(x) - x).detach()
+}
+
+__global__ void __launch_bounds__(1024)
+icsbp_fwd_kernel(const float* __restrict__ colour, const double* __restrict__ log_sigma,
+                 const float* __restrict__ rand_pixel, const int64_t* __restrict__ seed_idx_in,
+                 int B, int C, int HW, int K, int kernel_type,
+                 float* __restrict__ log_m, float* __restrict__ log_s_out,
+                 float* __restrict__ seeds, int64_t* __restrict__ seed_idx_out) {
+    __shared__ float red_v[16];
+    __shared__ int red_i[16];
+    __shared__ float seed_sh[MAXC];
+    __shared__ int idx_sh;
+    const int b = blockIdx.x;
+    const int T = blockDim.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = T >> 6;
+    const float* col = colour + (size_t)b * C * HW;
+    const float* rnd = rand_pixel + (size_t)b * HW;
+    const float sigma = (float)exp(*log_sigma);  // 0-dim fp64 parameter enters fp32 math as a scalar
+    const size_t kstride = (size_t)B * HW;
+
+    // log-scope of this image, carried across the K-1 steps in LDS (each thread only ever touches
+    // its own pixels p = tid + q*T, so no barrier is needed around it)
+    extern __shared__ __attribute__((aligned(16))) float ls[];
+    for (int p = tid; p < HW; p += T) {
+        ls[p] = 0.f;
+        log_s_out[(size_t)b * HW + p] = 0.f;
+    }
+
+    for (int t = 0; t < K - 1; ++t) {
+        int best_i;
+        if (seed_idx_in) {
+            best_i = (int)seed_idx_in[(size_t)t * B + b];
+        } else {
+            float best_v = -INFINITY;
+            best_i = 0x7fffffff;
+            for (int p = tid; p < HW; p += T) {
+                const float v = rnd[p] * expf(ls[p]);
+                if (v > best_v) { best_v = v; best_i = p; }  // ascending p: keeps the first max
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const float ov = __shfl_xor(best_v, off, 64);
+                const int oi = __shfl_xor(best_i, off, 64);
+                if (ov > best_v || (ov == best_v && oi < best_i)) { best_v = ov; best_i = oi; }
+            }
+            __syncthreads();
+            if (lane == 0) { red_v[wave] = best_v; red_i[wave] = best_i; }
+            __syncthreads();
+            if (tid == 0) {
+                float bv = red_v[0]; int bi = red_i[0];
+                for (int w = 1; w < nw; ++w)
+                    if (red_v[w] > bv || (red_v[w] == bv && red_i[w] < bi)) { bv = red_v[w]; bi = red_i[w]; }
+                idx_sh = bi;
+            }
+            __syncthreads();
+            best_i = idx_sh;
+        }
+        __syncthreads();
+        if (tid < C) {
+            const float sv = col[(size_t)tid * HW + best_i];
+            seed_sh[tid] = sv;
+            seeds[((size_t)t * B + b) * C + tid] = sv;
+        }
+        if (tid == 0) seed_idx_out[(size_t)t * B + b] = best_i;
+        __syncthreads();
+        for (int p = tid; p < HW; p += T) {
+            {
+                float d = 0.f;
+                for (int c = 0; c < C; ++c) {
+                    const float df = col[(size_t)c * HW + p] - seed_sh[c];
+                    d += df * df;
+                }
+                float alpha;
+                if (kernel_type == KERNEL_GAUSSIAN) {
+                    alpha = expf(-d / sigma);
+                } else if (kernel_type == KERNEL_LAPLACIAN) {
+                    alpha = expf(-sqrtf(st_clamp(d, 1e-10f, 1e10f)) / sigma);
+                } else {
+                    alpha = fmaxf(1.f - d / sigma, 0.f);
+                }
+                alpha = st_clamp(alpha, 0.01f, 0.99f);
+                const float log_a = logf(alpha);
+                const float log_na = logf(1.f - alpha);
+                const float lsp = ls[p];
+                log_m[t * kstride + (size_t)b * HW + p] = lsp + log_a;
+                ls[p] = lsp + log_na;
+                log_s_out[(t + 1) * kstride + (size_t)b * HW + p] = lsp + log_na;
+            }
+        }
+    }
+    for (int p = tid; p < HW; p += T) log_m[(K - 1) * kstride + (size_t)b * HW + p] = ls[p];
+}
+
+__device__ __forceinline__ double block_sum_d1024(double v, double* red) {
+    v = gx_wave_sum_d(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int i = 0; i < nw; ++i) s += red[i];
+    return s;
+}
+
+// g_m: gradient w.r.t. the K stacked log-masks [K,B,HW].  dcolour must be zero-initialised? No: it is
+// fully written here (first touched step writes, later steps accumulate).
+__global__ void __launch_bounds__(1024)
+icsbp_bwd_kernel(const float* __restrict__ colour, const double* __restrict__ log_sigma,
+                 const float* __restrict__ seeds, const int64_t* __restrict__ seed_idx,
+                 const float* __restrict__ g_m, int B, int C, int HW, int K, int kernel_type,
+                 float* __restrict__ dcolour, double* __restrict__ dlog_sigma_part) {
+    __shared__ double red[16];
+    __shared__ float seed_sh[MAXC];
+    __shared__ float seed_grad[16][MAXC];  // K-1 <= 16
+    const int b = blockIdx.x, T = blockDim.x, tid = threadIdx.x;
+    const float* col = colour + (size_t)b * C * HW;
+    float* dcol = dcolour + (size_t)b * C * HW;
+    const float sigma = (float)exp(*log_sigma);
+    const size_t kstride = (size_t)B * HW;
+
+    // gradient w.r.t. the scope leaving step t (suffix sum of mask grads), per pixel, in LDS
+    extern __shared__ __attribute__((aligned(16))) float gs[];
+    for (int p = tid; p < HW; p += T) gs[p] = g_m[(K - 1) * kstride + (size_t)b * HW + p];
+    double dsig = 0.0;
+
+    for (int t = K - 2; t >= 0; --t) {
+        __syncthreads();
+        if (tid < C) seed_sh[tid] = seeds[((size_t)t * B + b) * C + tid];
+        __syncthreads();
+        float gseed[MAXC];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) gseed[c] = 0.f;
+        for (int p = tid; p < HW; p += T) {
+            {
+                float diff[MAXC];
+                float d = 0.f;
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c) {
+                    if (c < C) {
+                        diff[c] = col[(size_t)c * HW + p] - seed_sh[c];
+                        d += diff[c] * diff[c];
+                    } else {
+                        diff[c] = 0.f;
+                    }
+                }
+                float alpha, dalpha_dd, dalpha_dsig;  // unclamped alpha and its partials
+                if (kernel_type == KERNEL_GAUSSIAN) {
+                    alpha = expf(-d / sigma);
+                    dalpha_dd = -alpha / sigma;
+                    dalpha_dsig = alpha * d / (sigma * sigma);
+                } else if (kernel_type == KERNEL_LAPLACIAN) {
+                    const float dist = sqrtf(st_clamp(d, 1e-10f, 1e10f));
+                    alpha = expf(-dist / sigma);
+                    dalpha_dd = -alpha / sigma * (0.5f / dist);
+                    dalpha_dsig = alpha * dist / (sigma * sigma);
+                } else {
+                    const float u = 1.f - d / sigma;
+                    alpha = fmaxf(u, 0.f);
+                    const float on = u > 0.f ? 1.f : 0.f;
+                    dalpha_dd = -on / sigma;
+                    dalpha_dsig = on * d / (sigma * sigma);
+                }
+                const float ac = st_clamp(alpha, 0.01f, 0.99f);
+                const float gm_t = g_m[t * kstride + (size_t)b * HW + p];
+                // log_m_t = s_t + log(ac); s_{t+1} = s_t + log(1-ac); straight-through: d ac / d alpha = 1
+                const float gsp = gs[p];
+                const float galpha = gm_t / ac - gsp / (1.f - ac);
+                gs[p] = gsp + gm_t;
+                const float gd = galpha * dalpha_dd;
+                dsig += (double)(galpha * dalpha_dsig);
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c) {
+                    if (c < C) {
+                        const float gc = 2.f * gd * diff[c];
+                        float* dp = dcol + (size_t)c * HW + p;
+                        if (t == K - 2) *dp = gc; else *dp += gc;
+                        gseed[c] -= gc;
+                    }
+                }
+            }
+        }
+        for (int c = 0; c < C; ++c) {
+            float v = 0.f;
+#pragma unroll
+            for (int cc = 0; cc < MAXC; ++cc) if (cc == c) v = gseed[cc];
+            const double s = block_sum_d1024((double)v, red);
+            if (tid == 0) seed_grad[t][c] = (float)s;
+        }
+    }
+    if (K < 2) {
+        // no SBP step ran: colour receives no gradient
+        for (int p = tid; p < HW; p += T)
+            for (int c = 0; c < C; ++c) dcol[(size_t)c * HW + p] = 0.f;
+    }
+    const double ds = block_sum_d1024(dsig, red);
+    __syncthreads();
+    if (tid == 0) {
+        // d log_sigma = d sigma * sigma   (sigma = exp(log_sigma))
+        dlog_sigma_part[b] = ds * (double)sigma;
+        // gradient through the gathered seed: scatter-add into the seed pixel (modules/attention.py:190-193)
+        for (int t = 0; t < K - 1; ++t) {
+            const int idx = (int)seed_idx[(size_t)t * B + b];
+            for (int c = 0; c < C; ++c) dcol[(size_t)c * HW + idx] += seed_grad[t][c];
+        }
+    }
+}
+
+__global__ void sum_double_kernel(const double* __restrict__ part, int n, double* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += part[i];
+        *out = s;
+    }
+}
+
+int threads_for(int HW) {
+    int T = HW < 1024 ? HW : 1024;
+    if (T < 64) T = 64;
+    return T;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gx_icsbp_fwd(const float* colour, const double* log_sigma, const float* rand_pixel, const int64_t* seed_idx_in,
+                 int B, int C, int H, int W, int K, int kernel_type, float* log_m, float* log_s, float* seeds,
+                 int64_t* seed_idx_out, gx_stream_t stream) {
+    GX_CHECK_ARG(colour && log_sigma && rand_pixel && log_m && log_s && seeds && seed_idx_out,
+                 "gx_icsbp_fwd: null pointer");
+    const int HW = H * W;
+    GX_CHECK_ARG(B > 0 && C > 0 && C <= MAXC && K >= 1 && K <= 17, "gx_icsbp_fwd: bad B/C/K (C<=8, K<=17)");
+    GX_CHECK_ARG(gx_is_pow2(HW) && HW >= 64 && HW <= 1024 * MAXPPT, "gx_icsbp_fwd: H*W must be a power of two in [64,16384]");
+    GX_CHECK_ARG(kernel_type >= 0 && kernel_type <= 2, "gx_icsbp_fwd: no valid kernel");
+    hipLaunchKernelGGL(icsbp_fwd_kernel, dim3(B), dim3(threads_for(HW)), HW * sizeof(float), (hipStream_t)stream, colour, log_sigma,
+                       rand_pixel, seed_idx_in, B, C, HW, K, kernel_type, log_m, log_s, seeds, seed_idx_out);
+    GX_CHECK_LAUNCH("gx_icsbp_fwd");
+    return GX_OK;
+}
+
+size_t gx_icsbp_bwd_ws_bytes(int B) { return (size_t)B * sizeof(double); }
+
+int gx_icsbp_bwd(const float* colour, const double* log_sigma, const float* seeds, const int64_t* seed_idx,
+                 const float* g_log_m, int B, int C, int H, int W, int K, int kernel_type, float* dcolour,
+                 double* dlog_sigma, void* ws, size_t ws_bytes, gx_stream_t stream) {
+    GX_CHECK_ARG(colour && log_sigma && seeds && seed_idx && g_log_m && dcolour && dlog_sigma && ws,
+                 "gx_icsbp_bwd: null pointer");
+    const int HW = H * W;
+    GX_CHECK_ARG(B > 0 && C > 0 && C <= MAXC && K >= 1 && K <= 17, "gx_icsbp_bwd: bad B/C/K (C<=8, K<=17)");
+    GX_CHECK_ARG(gx_is_pow2(HW) && HW >= 64 && HW <= 1024 * MAXPPT, "gx_icsbp_bwd: H*W must be a power of two in [64,16384]");
+    GX_CHECK_ARG(kernel_type >= 0 && kernel_type <= 2, "gx_icsbp_bwd: no valid kernel");
+    GX_CHECK_ARG(ws_bytes >= gx_icsbp_bwd_ws_bytes(B), "gx_icsbp_bwd: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(icsbp_bwd_kernel, dim3(B), dim3(threads_for(HW)), HW * sizeof(float), s, colour, log_sigma, seeds, seed_idx,
+                       g_log_m, B, C, HW, K, kernel_type, dcolour, (double*)ws);
+    GX_CHECK_LAUNCH("gx_icsbp_bwd");
+    hipLaunchKernelGGL(sum_double_kernel, dim3(1), dim3(64), 0, s, (const double*)ws, B, dlog_sigma);
+    GX_CHECK_LAUNCH("gx_icsbp_bwd(reduce)");
+    return GX_OK;
+}
+
+}  // extern "C"

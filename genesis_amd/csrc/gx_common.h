@@ -1,0 +1,51 @@
+// Shared internals of libgenesis_hip.so (not part of the public C ABI; see include/genesis_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/genesis_hip.h"
+
+// ---- error plumbing: C ABI never throws; negative return + thread-local message ----
+void gx_set_error(const char* fmt, ...);
+
+#define GX_CHECK_ARG(cond, ...)                  \
+    do {                                         \
+        if (!(cond)) {                           \
+            gx_set_error(__VA_ARGS__);           \
+            return GX_EINVAL;                    \
+        }                                        \
+    } while (0)
+
+#define GX_CHECK_LAUNCH(name)                                                   \
+    do {                                                                        \
+        hipError_t e__ = hipGetLastError();                                     \
+        if (e__ != hipSuccess) {                                                \
+            gx_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return GX_ELAUNCH;                                                  \
+        }                                                                       \
+    } while (0)
+
+static inline int gx_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+static inline int gx_ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int gx_round_up(int a, int b) { return gx_ceil_div(a, b) * b; }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// 64-lane wavefront reductions (CDNA4: wave = 64).
+__device__ __forceinline__ float gx_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double gx_wave_sum_d(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float gx_wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}

@@ -1,0 +1,484 @@
+// Per-slot feature pooling, the K-slot mixture likelihood, and the small 1x1 convolutions of the
+// GENESIS-V2 path.  All HBM-bound streaming kernels: coalesced NCHW reads (consecutive lanes =
+// consecutive pixels), wavefront shuffles + one LDS hop for the reductions, fixed reduction trees.
+//
+// Reference:
+//   masked pooling   models/genesisv2_config.py:146-152   sum_hw(m_k * f) and sum_hw(m_k)
+//   mixture / recon  models/genesisv2_config.py:212-223, models/monet_config.py:137-139 (log_softmax over K),
+//                    models/genesis_config.py:273-286 (x_loss, no log-sum-exp trick)
+//   1x1 convs        modules/blocks.py:175-178 (SemiConv: gate * conv1x1 + uv),
+//                    models/genesisv2_config.py:99 (decoder_module.13: Conv2d(64, 4, 1))
+#include "gx_common.h"
+
+namespace {
+
+constexpr int KMAX = 16;
+
+__device__ __forceinline__ float block_sum_f(float v, float* red) {
+    v = gx_wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < nw; ++i) s += red[i];
+    return s;
+}
+__device__ __forceinline__ double block_sum_dd(double v, double* red) {
+    v = gx_wave_sum_d(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int i = 0; i < nw; ++i) s += red[i];
+    return s;
+}
+
+// ------------------------------------------------------------------ masked pooling
+// S[b][k][c] = sum_p exp(log_m[k][b][p]) * f[b][c][p];   msum[b][k] = sum_p exp(log_m[k][b][p])
+// grid (B, C/4): each block reduces 4 channels x K slots over the image.
+constexpr int PCH = 4;
+__global__ void __launch_bounds__(256)
+maskpool_fwd_kernel(const float* __restrict__ f, const float* __restrict__ log_m, int B, int C, int HW, int K,
+                    float* __restrict__ S, float* __restrict__ msum) {
+    __shared__ double red[4];
+    const int b = blockIdx.x, c0 = blockIdx.y * PCH;
+    const size_t kstride = (size_t)B * HW;
+    double acc[KMAX][PCH];
+    double ms[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        ms[k] = 0.0;
+#pragma unroll
+        for (int c = 0; c < PCH; ++c) acc[k][c] = 0.0;
+    }
+    const float* fb = f + ((size_t)b * C + c0) * HW;
+    for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+        float fv[PCH];
+#pragma unroll
+        for (int c = 0; c < PCH; ++c) fv[c] = (c0 + c < C) ? fb[(size_t)c * HW + p] : 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            if (k < K) {
+                const float m = expf(log_m[k * kstride + (size_t)b * HW + p]);
+                ms[k] += (double)m;
+#pragma unroll
+                for (int c = 0; c < PCH; ++c) acc[k][c] += (double)(m * fv[c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        if (k < K) {
+#pragma unroll
+            for (int c = 0; c < PCH; ++c) {
+                const double s = block_sum_dd(acc[k][c], red);
+                if (threadIdx.x == 0 && c0 + c < C) S[((size_t)b * K + k) * C + c0 + c] = (float)s;
+            }
+            if (blockIdx.y == 0) {
+                const double s = block_sum_dd(ms[k], red);
+                if (threadIdx.x == 0) msum[(size_t)b * K + k] = (float)s;
+            }
+        }
+    }
+}
+
+// df[b][c][p]      = sum_k m_k[p] * gS[b][k][c]
+// dlog_m[k][b][p]  = m_k[p] * (sum_c gS[b][k][c] * f[b][c][p] + gmsum[b][k])
+// grid (B, HW/256): one thread per pixel; gS of the image staged in LDS.
+__global__ void __launch_bounds__(256)
+maskpool_bwd_kernel(const float* __restrict__ f, const float* __restrict__ log_m, const float* __restrict__ gS,
+                    const float* __restrict__ gmsum, int B, int C, int HW, int K, float* __restrict__ df,
+                    float* __restrict__ dlog_m) {
+    extern __shared__ __attribute__((aligned(16))) float gsh[];  // [K][C]
+    const int b = blockIdx.x;
+    const int p = blockIdx.y * blockDim.x + threadIdx.x;
+    for (int i = threadIdx.x; i < K * C; i += blockDim.x) gsh[i] = gS[(size_t)b * K * C + i];
+    __syncthreads();
+    if (p >= HW) return;
+    const size_t kstride = (size_t)B * HW;
+    float m[KMAX], a[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        m[k] = (k < K) ? expf(log_m[k * kstride + (size_t)b * HW + p]) : 0.f;
+        a[k] = 0.f;
+    }
+    const float* fb = f + (size_t)b * C * HW + p;
+    float* dfb = df + (size_t)b * C * HW + p;
+    for (int c = 0; c < C; ++c) {
+        const float fv = fb[(size_t)c * HW];
+        float d = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            if (k < K) {
+                const float g = gsh[k * C + c];
+                a[k] += g * fv;
+                d += m[k] * g;
+            }
+        }
+        dfb[(size_t)c * HW] = d;
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+        if (k < K) dlog_m[k * kstride + (size_t)b * HW + p] = m[k] * (a[k] + gmsum[(size_t)b * K + k]);
+}
+
+// ------------------------------------------------------------------ mixture likelihood
+// dec [K*B, 4, HW] slot-major (row k*B+b): channels 0..2 RGB pre-activation, 3 mask logit.
+constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
+
+template <bool BWD>
+__global__ void __launch_bounds__(256)
+mixture_kernel(const float* __restrict__ x, const float* __restrict__ dec, int B, int HW, int K, float std_,
+               int pixel_bound, float* __restrict__ recon, float* __restrict__ x_r, float* __restrict__ log_m_r,
+               float* __restrict__ err_part, const float* __restrict__ g_err, float* __restrict__ ddec) {
+    __shared__ double red[4];
+    const int b = blockIdx.x;
+    const int p = blockIdx.y * blockDim.x + threadIdx.x;
+    const float var2 = 2.f * std_ * std_;
+    const float log_std = logf(std_);
+    double err = 0.0;
+    if (p < HW) {
+        float logit[KMAX];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            if (k < K) {
+                logit[k] = dec[(((size_t)k * B + b) * 4 + 3) * HW + p];
+                mx = fmaxf(mx, logit[k]);
+            } else {
+                logit[k] = 0.f;
+            }
+        }
+        float se = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < K) se += expf(logit[k] - mx);
+        const float lse = logf(se);
+        float lm[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            lm[k] = (k < K) ? (logit[k] - mx) - lse : 0.f;   // torch log_softmax: (x - max) - log(sum exp(x - max))
+            if (!BWD && k < K) log_m_r[((size_t)k * B + b) * HW + p] = lm[k];
+        }
+        float dlogit[KMAX];
+        if (BWD) {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) dlogit[k] = 0.f;
+        }
+        const float ge = BWD ? g_err[b] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float xv = x[((size_t)b * 3 + c) * HW + p];
+            float e[KMAX], mu[KMAX];
+            float s = 0.f, rc = 0.f;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                if (k < K) {
+                    const float raw = dec[(((size_t)k * B + b) * 4 + c) * HW + p];
+                    mu[k] = pixel_bound ? 1.f / (1.f + expf(-raw)) : raw;
+                    const float dx = xv - mu[k];
+                    const float logn = -(dx * dx) / var2 - log_std - LOG_SQRT_2PI;
+                    e[k] = expf(lm[k] + logn);
+                    s += e[k];
+                    if (!BWD) {
+                        x_r[(((size_t)k * B + b) * 3 + c) * HW + p] = mu[k];
+                        rc += expf(lm[k]) * mu[k];
+                    }
+                } else { e[k] = 0.f; mu[k] = 0.f; }
+            }
+            if (!BWD) {
+                err += (double)(-logf(s));
+                recon[((size_t)b * 3 + c) * HW + p] = rc;
+            } else {
+                const float inv = 1.f / s;
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) {
+                    if (k < K) {
+                        const float w = e[k] * inv;                 // responsibility of slot k
+                        dlogit[k] -= w;                             // d err / d log_m_r_k
+                        float gmu = -w * (xv - mu[k]) / (std_ * std_);
+                        if (pixel_bound) gmu *= mu[k] * (1.f - mu[k]);
+                        ddec[(((size_t)k * B + b) * 4 + c) * HW + p] = ge * gmu;
+                    }
+                }
+            }
+        }
+        if (BWD) {
+            // through log_softmax: d/d logit_j = g_j - softmax_j * sum_k g_k
+            float gsum = 0.f;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) if (k < K) gsum += dlogit[k];
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (k < K) ddec[(((size_t)k * B + b) * 4 + 3) * HW + p] = ge * (dlogit[k] - expf(lm[k]) * gsum);
+        }
+    }
+    if (!BWD) {
+        const double s = block_sum_dd(err, red);
+        if (threadIdx.x == 0) err_part[(size_t)b * gridDim.y + blockIdx.y] = (float)s;
+    }
+}
+
+__global__ void row_sum_kernel(const float* __restrict__ part, int rows, int cols, float* __restrict__ out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    double s = 0.0;
+    for (int i = 0; i < cols; ++i) s += part[(size_t)r * cols + i];
+    out[r] = (float)s;
+}
+
+// ------------------------------------------------------------------ small 1x1 convolutions (Cout <= 8)
+// y[n][co][p] = gate * (sum_ci w[co][ci] x[n][ci][p] + b[co]) + addend[co][p]
+constexpr int COMAX = 8;
+__global__ void __launch_bounds__(256)
+conv1x1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                   const float* __restrict__ gate, const float* __restrict__ addend, int Cin, int Cout, int HW,
+                   float* __restrict__ y) {
+    const int n = blockIdx.x;
+    const int p = blockIdx.y * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    float acc[COMAX];
+#pragma unroll
+    for (int co = 0; co < COMAX; ++co) acc[co] = 0.f;
+    const float* xn = x + (size_t)n * Cin * HW + p;
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float xv = xn[(size_t)ci * HW];
+#pragma unroll
+        for (int co = 0; co < COMAX; ++co)
+            if (co < Cout) acc[co] += w[co * Cin + ci] * xv;
+    }
+    const float gt = gate ? *gate : 1.f;
+#pragma unroll
+    for (int co = 0; co < COMAX; ++co) {
+        if (co < Cout) {
+            float v = acc[co] + (bias ? bias[co] : 0.f);
+            v = gate ? gt * v : v;
+            if (addend) v += addend[(size_t)co * HW + p];
+            y[((size_t)n * Cout + co) * HW + p] = v;
+        }
+    }
+}
+
+// dx[n][ci][p] = gate * sum_co w[co][ci] dy[n][co][p]
+__global__ void __launch_bounds__(256)
+conv1x1_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, const float* __restrict__ gate,
+                     int Cin, int Cout, int HW, float* __restrict__ dx) {
+    const int n = blockIdx.x;
+    const int p = blockIdx.y * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    const float gt = gate ? *gate : 1.f;
+    float g[COMAX];
+#pragma unroll
+    for (int co = 0; co < COMAX; ++co) g[co] = (co < Cout) ? gt * dy[((size_t)n * Cout + co) * HW + p] : 0.f;
+    float* dxn = dx + (size_t)n * Cin * HW + p;
+    for (int ci = 0; ci < Cin; ++ci) {
+        float s = 0.f;
+#pragma unroll
+        for (int co = 0; co < COMAX; ++co)
+            if (co < Cout) s += w[co * Cin + ci] * g[co];
+        dxn[(size_t)ci * HW] = s;
+    }
+}
+
+// Partials per block: pw[blk][co][ci] = sum_p dy[co][p] x[ci][p]; pb[blk][co] = sum_p dy[co][p];
+// pg[blk] = sum_{co,p} dy[co][p] * (sum_ci w x + b)  (gate gradient).
+// One block per (image, 1024-pixel chunk); tiles of 64 pixels staged in LDS; thread (co, ci) accumulates.
+__global__ void __launch_bounds__(512)
+conv1x1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ w,
+                     const float* __restrict__ bias, int Cin, int Cout, int HW, int chunk,
+                     float* __restrict__ pw, float* __restrict__ pb, float* __restrict__ pg) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];
+    float* xt = sh;                    // [Cin][65]
+    float* dt = sh + Cin * 65;         // [COMAX][64]
+    float* rt = dt + COMAX * 64;       // [64] raw conv output partial per pixel (for the gate gradient)
+    __shared__ double red[8];
+    const int n = blockIdx.x;
+    const int p0 = blockIdx.y * chunk;
+    const int tid = threadIdx.x;
+    const int nthr = blockDim.x;
+    const int blk = blockIdx.x * gridDim.y + blockIdx.y;
+    // thread -> (co, ci) pairs: pair index q = tid + j*nthr
+    float acc[2] = {0.f, 0.f};
+    float accb = 0.f;
+    double accg = 0.0;
+    const int npairs = Cout * Cin;
+    for (int t0 = 0; t0 < chunk; t0 += 64) {
+        __syncthreads();
+        for (int i = tid; i < Cin * 64; i += nthr) {
+            const int ci = i >> 6, pp = i & 63;
+            const int p = p0 + t0 + pp;
+            xt[ci * 65 + pp] = (p < HW) ? x[((size_t)n * Cin + ci) * HW + p] : 0.f;
+        }
+        for (int i = tid; i < Cout * 64; i += nthr) {
+            const int co = i >> 6, pp = i & 63;
+            const int p = p0 + t0 + pp;
+            dt[co * 64 + pp] = (p < HW) ? dy[((size_t)n * Cout + co) * HW + p] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = tid + j * nthr;
+            if (q < npairs) {
+                const int co = q / Cin, ci = q - co * Cin;
+                float s = 0.f;
+                for (int pp = 0; pp < 64; ++pp) s += dt[co * 64 + pp] * xt[ci * 65 + pp];
+                acc[j] += s;
+            }
+        }
+        if (tid < Cout) {
+            float s = 0.f;
+            for (int pp = 0; pp < 64; ++pp) s += dt[tid * 64 + pp];
+            accb += s;
+        }
+        if (pg && tid >= 64 && tid < 128) {
+            // gate gradient: pixel pp = tid-64: sum_co dy[co] * (w[co].x + b[co])
+            const int pp = tid - 64;
+            float s = 0.f;
+            for (int co = 0; co < Cout; ++co) {
+                float raw = bias ? bias[co] : 0.f;
+                for (int ci = 0; ci < Cin; ++ci) raw += w[co * Cin + ci] * xt[ci * 65 + pp];
+                s += dt[co * 64 + pp] * raw;
+            }
+            accg += (double)s;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = tid + j * nthr;
+        if (q < npairs) pw[(size_t)blk * npairs + q] = acc[j];
+    }
+    if (tid < Cout) pb[(size_t)blk * Cout + tid] = accb;
+    if (pg) {
+        const double s = block_sum_dd(accg, red);
+        if (tid == 0) pg[blk] = (float)s;
+    }
+    (void)rt;
+}
+
+// out[i] = scale * sum_blk part[blk][i]
+__global__ void col_sum_kernel(const float* __restrict__ part, int nblk, int n, const float* __restrict__ gate,
+                               float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * n + i];
+    const float gt = gate ? *gate : 1.f;
+    out[i] = (float)(s * (double)gt);
+}
+
+}  // namespace
+
+extern "C" {
+
+int gx_maskpool_fwd(const float* f, const float* log_m, int B, int C, int H, int W, int K, float* S, float* msum,
+                    gx_stream_t stream) {
+    GX_CHECK_ARG(f && log_m && S && msum, "gx_maskpool_fwd: null pointer");
+    GX_CHECK_ARG(B > 0 && C > 0 && K >= 1 && K <= KMAX && H > 0 && W > 0, "gx_maskpool_fwd: bad dims (K<=16)");
+    hipLaunchKernelGGL(maskpool_fwd_kernel, dim3(B, gx_ceil_div(C, PCH)), dim3(256), 0, (hipStream_t)stream, f,
+                       log_m, B, C, H * W, K, S, msum);
+    GX_CHECK_LAUNCH("gx_maskpool_fwd");
+    return GX_OK;
+}
+
+int gx_maskpool_bwd(const float* f, const float* log_m, const float* gS, const float* gmsum, int B, int C, int H,
+                    int W, int K, float* df, float* dlog_m, gx_stream_t stream) {
+    GX_CHECK_ARG(f && log_m && gS && gmsum && df && dlog_m, "gx_maskpool_bwd: null pointer");
+    GX_CHECK_ARG(B > 0 && C > 0 && K >= 1 && K <= KMAX && H > 0 && W > 0, "gx_maskpool_bwd: bad dims (K<=16)");
+    const int HW = H * W;
+    hipLaunchKernelGGL(maskpool_bwd_kernel, dim3(B, gx_ceil_div(HW, 256)), dim3(256), (size_t)K * C * sizeof(float),
+                       (hipStream_t)stream, f, log_m, gS, gmsum, B, C, HW, K, df, dlog_m);
+    GX_CHECK_LAUNCH("gx_maskpool_bwd");
+    return GX_OK;
+}
+
+size_t gx_mixture_ws_bytes(int B, int H, int W) { return (size_t)B * gx_ceil_div(H * W, 256) * sizeof(float); }
+
+int gx_mixture_fwd(const float* x, const float* dec, int B, int H, int W, int K, float pixel_std, int pixel_bound,
+                   float* recon, float* x_r, float* log_m_r, float* err, void* ws, size_t ws_bytes,
+                   gx_stream_t stream) {
+    GX_CHECK_ARG(x && dec && recon && x_r && log_m_r && err && ws, "gx_mixture_fwd: null pointer");
+    GX_CHECK_ARG(B > 0 && K >= 1 && K <= KMAX && pixel_std > 0.f, "gx_mixture_fwd: bad dims (K<=16)");
+    GX_CHECK_ARG(ws_bytes >= gx_mixture_ws_bytes(B, H, W), "gx_mixture_fwd: workspace too small");
+    const int HW = H * W, nb = gx_ceil_div(HW, 256);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(mixture_kernel<false>, dim3(B, nb), dim3(256), 0, s, x, dec, B, HW, K, pixel_std, pixel_bound,
+                       recon, x_r, log_m_r, (float*)ws, (const float*)nullptr, (float*)nullptr);
+    GX_CHECK_LAUNCH("gx_mixture_fwd");
+    hipLaunchKernelGGL(row_sum_kernel, dim3(gx_ceil_div(B, 64)), dim3(64), 0, s, (const float*)ws, B, nb, err);
+    GX_CHECK_LAUNCH("gx_mixture_fwd(reduce)");
+    return GX_OK;
+}
+
+int gx_mixture_bwd(const float* x, const float* dec, const float* g_err, int B, int H, int W, int K,
+                   float pixel_std, int pixel_bound, float* ddec, gx_stream_t stream) {
+    GX_CHECK_ARG(x && dec && g_err && ddec, "gx_mixture_bwd: null pointer");
+    GX_CHECK_ARG(B > 0 && K >= 1 && K <= KMAX && pixel_std > 0.f, "gx_mixture_bwd: bad dims (K<=16)");
+    const int HW = H * W, nb = gx_ceil_div(HW, 256);
+    hipLaunchKernelGGL(mixture_kernel<true>, dim3(B, nb), dim3(256), 0, (hipStream_t)stream, x, dec, B, HW, K,
+                       pixel_std, pixel_bound, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                       g_err, ddec);
+    GX_CHECK_LAUNCH("gx_mixture_bwd");
+    return GX_OK;
+}
+
+int gx_conv1x1_fwd(const float* x, const float* w, const float* bias, const float* gate, const float* addend,
+                   int N, int Cin, int Cout, int H, int W, float* y, gx_stream_t stream) {
+    GX_CHECK_ARG(x && w && y, "gx_conv1x1_fwd: null pointer");
+    GX_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && Cout <= COMAX, "gx_conv1x1_fwd: Cout must be <= 8");
+    const int HW = H * W;
+    hipLaunchKernelGGL(conv1x1_fwd_kernel, dim3(N, gx_ceil_div(HW, 256)), dim3(256), 0, (hipStream_t)stream, x, w,
+                       bias, gate, addend, Cin, Cout, HW, y);
+    GX_CHECK_LAUNCH("gx_conv1x1_fwd");
+    return GX_OK;
+}
+
+static int conv1x1_chunk(int HW) { return HW < 1024 ? gx_round_up(HW, 64) : 1024; }
+
+size_t gx_conv1x1_bwd_ws_bytes(int N, int Cin, int Cout, int H, int W) {
+    const int HW = H * W;
+    const size_t nblk = (size_t)N * gx_ceil_div(HW, conv1x1_chunk(HW));
+    return nblk * ((size_t)Cout * Cin + Cout + 1) * sizeof(float);
+}
+
+int gx_conv1x1_bwd(const float* x, const float* dy, const float* w, const float* bias, const float* gate, int N,
+                   int Cin, int Cout, int H, int W, float* dx, float* dw, float* db, float* dgate, void* ws,
+                   size_t ws_bytes, gx_stream_t stream) {
+    GX_CHECK_ARG(x && dy && w && dx && dw && ws, "gx_conv1x1_bwd: null pointer");
+    GX_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && Cout <= COMAX && Cin * Cout <= 1024,
+                 "gx_conv1x1_bwd: Cout must be <= 8 and Cin*Cout <= 1024");
+    GX_CHECK_ARG((gate == nullptr) == (dgate == nullptr), "gx_conv1x1_bwd: gate and dgate go together");
+    GX_CHECK_ARG(ws_bytes >= gx_conv1x1_bwd_ws_bytes(N, Cin, Cout, H, W), "gx_conv1x1_bwd: workspace too small");
+    const int HW = H * W;
+    const int chunk = conv1x1_chunk(HW);
+    const int nchunks = gx_ceil_div(HW, chunk);
+    const int nblk = N * nchunks;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv1x1_dgrad_kernel, dim3(N, gx_ceil_div(HW, 256)), dim3(256), 0, s, dy, w, gate, Cin, Cout,
+                       HW, dx);
+    GX_CHECK_LAUNCH("gx_conv1x1_bwd(dgrad)");
+    float* pw = (float*)ws;
+    float* pb = pw + (size_t)nblk * Cout * Cin;
+    float* pg = pb + (size_t)nblk * Cout;
+    const size_t lds = (size_t)(Cin * 65 + COMAX * 64 + 64) * sizeof(float);
+    hipLaunchKernelGGL(conv1x1_wgrad_kernel, dim3(N, nchunks), dim3(512), lds, s, x, dy, w, bias, Cin, Cout, HW,
+                       chunk, pw, pb, gate ? pg : (float*)nullptr);
+    GX_CHECK_LAUNCH("gx_conv1x1_bwd(wgrad)");
+    const int npairs = Cout * Cin;
+    hipLaunchKernelGGL(col_sum_kernel, dim3(gx_ceil_div(npairs, 64)), dim3(64), 0, s, (const float*)pw, nblk, npairs,
+                       gate, dw);
+    GX_CHECK_LAUNCH("gx_conv1x1_bwd(dw)");
+    if (db) {
+        hipLaunchKernelGGL(col_sum_kernel, dim3(1), dim3(64), 0, s, (const float*)pb, nblk, Cout, gate, db);
+        GX_CHECK_LAUNCH("gx_conv1x1_bwd(db)");
+    }
+    if (dgate) {
+        hipLaunchKernelGGL(col_sum_kernel, dim3(1), dim3(64), 0, s, (const float*)pg, nblk, 1, (const float*)nullptr,
+                           dgate);
+        GX_CHECK_LAUNCH("gx_conv1x1_bwd(dgate)");
+    }
+    return GX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,255 @@
+"""Block-level torch.autograd.Function wrappers: each block's forward AND backward are sequences of
+hand-written HIP kernels (genesis_amd/hip_ops.py -> C ABI), with buffers planned by the block
+(concat buffers, resampled copies) instead of torch.cat / F.interpolate passes.
+
+Blocks (reference op groups):
+  UNetEncoderFn  modules/unet.py:69-90 (+ blocks.py:159-165)        ops 1-3
+  ConvGNReLUFn   modules/blocks.py:159-165 (seg_head / feat_head[0])  op 1
+  ICSBPFn        modules/blocks.py:167-178 + modules/attention.py:162-226   ops 4-5
+  MaskPoolFn     models/genesisv2_config.py:146-152                   op 6
+  DecoderFn      models/genesisv2_config.py:89-99 (+ blocks.py:104-130)   op 8
+  MixtureFn      models/genesisv2_config.py:212-223, genesis_config.py:273-286   op 9
+"""
+import torch
+import torch.nn.functional as F
+
+from . import hip_ops as hip
+
+GROUPS = 8
+EPS = 1e-5
+
+
+class ConvGNReLUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta):
+        x = x.contiguous()
+        y = hip.conv3x3_fwd(x, w)
+        out = torch.empty_like(y)
+        mean, rstd = hip.gn_relu_fwd(y, gamma, beta, GROUPS, EPS, (out, 0, 0))
+        ctx.save_for_backward(x, w, gamma, beta, y, mean, rstd)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, gamma, beta, y, mean, rstd = ctx.saved_tensors
+        dy, dgamma, dbeta, _ = hip.gn_relu_bwd(y, gamma, beta, mean, rstd, GROUPS, (g.contiguous(), 0, 0))
+        dw = hip.conv3x3_wgrad(x, dy)
+        dx = hip.conv3x3_dgrad(dy, w) if ctx.needs_input_grad[0] else None
+        return dx, dw, dgamma, dbeta
+
+
+class UNetEncoderFn(torch.autograd.Function):
+    """args: x, nb, then 3*nb down params (w, gamma, beta), 3*nb up params, 6 MLP params."""
+
+    @staticmethod
+    def forward(ctx, x, nb, *params):
+        x = x.contiguous()
+        down = [params[3 * i:3 * i + 3] for i in range(nb)]
+        up = [params[3 * nb + 3 * j:3 * nb + 3 * j + 3] for j in range(nb)]
+        mlp = params[6 * nb:6 * nb + 6]
+        N, _, S, _ = x.shape
+        dev = x.device
+        # concat buffers for the up path: cat_j = [x_up (Cx_j) | skip from down block nb-1-j]
+        cats = []
+        for j in range(nb):
+            cin = up[j][0].shape[1]
+            res = S >> (nb - 1 - j)
+            cats.append(torch.empty(N, cin, res, res, device=dev))
+        saved_down = []
+        cur = x
+        mlp_in = None
+        for i in range(nb):
+            w, gamma, beta = down[i]
+            y = hip.conv3x3_fwd(cur, w)
+            C = y.shape[1]
+            j = nb - 1 - i
+            cx = cats[j].shape[1] - C
+            if i < nb - 1:
+                nxt = torch.empty(N, C, y.shape[2] // 2, y.shape[3] // 2, device=dev)
+                mean, rstd = hip.gn_relu_fwd(y, gamma, beta, GROUPS, EPS, (cats[j], cx, 0), (nxt, 0, 2))
+            else:
+                nxt = torch.empty(N, C, y.shape[2], y.shape[3], device=dev)
+                mean, rstd = hip.gn_relu_fwd(y, gamma, beta, GROUPS, EPS, (cats[j], cx, 0), (nxt, 0, 0))
+                mlp_in = nxt
+            saved_down.append((cur, y, mean, rstd))
+            cur = nxt
+        # bottleneck MLP (tiny dense layers; torch/rocBLAS for now -- see DESIGN.md "not yet native")
+        with torch.enable_grad():
+            mlp_leaf = mlp_in.detach().requires_grad_(True)
+            mlp_p = [p.detach().requires_grad_(True) for p in mlp]
+            h = mlp_leaf.reshape(N, -1)
+            for q in range(3):
+                h = F.relu(F.linear(h, mlp_p[2 * q], mlp_p[2 * q + 1]))
+        fs = mlp_in.shape[2]
+        cx0 = cats[0].shape[1] - mlp_in.shape[1]
+        cats[0][:, :cx0].copy_(h.detach().view(N, cx0, fs, fs))
+        saved_up = []
+        out = None
+        for j in range(nb):
+            w, gamma, beta = up[j]
+            y = hip.conv3x3_fwd(cats[j], w)
+            if j < nb - 1:
+                mean, rstd = hip.gn_relu_fwd(y, gamma, beta, GROUPS, EPS, (cats[j + 1], 0, 1))
+            else:
+                out = torch.empty_like(y)
+                mean, rstd = hip.gn_relu_fwd(y, gamma, beta, GROUPS, EPS, (out, 0, 0))
+            saved_up.append((y, mean, rstd))
+        ctx.nb = nb
+        ctx.params = params
+        ctx.cats = cats
+        ctx.saved_down = saved_down
+        ctx.saved_up = saved_up
+        ctx.mlp = (mlp_leaf, mlp_p, h)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        nb = ctx.nb
+        params = ctx.params
+        down = [params[3 * i:3 * i + 3] for i in range(nb)]
+        up = [params[3 * nb + 3 * j:3 * nb + 3 * j + 3] for j in range(nb)]
+        cats = ctx.cats
+        g_down = [None] * nb
+        g_up = [None] * nb
+        dcat = [None] * nb
+        gsrc = (g_out.contiguous(), 0, 0)
+        for j in reversed(range(nb)):
+            w, gamma, beta = up[j]
+            y, mean, rstd = ctx.saved_up[j]
+            dy, dgamma, dbeta, _ = hip.gn_relu_bwd(y, gamma, beta, mean, rstd, GROUPS, gsrc)
+            dw = hip.conv3x3_wgrad(cats[j], dy)
+            dcat[j] = hip.conv3x3_dgrad(dy, w)
+            g_up[j] = (dw, dgamma, dbeta)
+            gsrc = (dcat[j], 0, 1)   # block j-1's output was 2x up-sampled into cat_j[:, :Cx]
+        # MLP backward
+        mlp_leaf, mlp_p, h = ctx.mlp
+        cx0 = h.shape[1] // (mlp_leaf.shape[2] * mlp_leaf.shape[3])
+        g_h = dcat[0][:, :cx0].reshape(h.shape)
+        grads = torch.autograd.grad(h, [mlp_leaf] + mlp_p, g_h)
+        d_mlp_in = grads[0].contiguous()
+        g_mlp = grads[1:]
+        d_next = None
+        dx = None
+        for i in reversed(range(nb)):
+            w, gamma, beta = down[i]
+            cur, y, mean, rstd = ctx.saved_down[i]
+            j = nb - 1 - i
+            C = y.shape[1]
+            cx = cats[j].shape[1] - C
+            g0 = (dcat[j], cx, 0)
+            g1 = (d_mlp_in, 0, 0) if i == nb - 1 else (d_next, 0, 2)
+            dy, dgamma, dbeta, _ = hip.gn_relu_bwd(y, gamma, beta, mean, rstd, GROUPS, g0, g1)
+            dw = hip.conv3x3_wgrad(cur, dy)
+            g_down[i] = (dw, dgamma, dbeta)
+            if i > 0:
+                d_next = hip.conv3x3_dgrad(dy, w)
+            elif ctx.needs_input_grad[0]:
+                dx = hip.conv3x3_dgrad(dy, w)
+        flat = []
+        for t in g_down + g_up:
+            flat.extend(t)
+        flat.extend(g_mlp)
+        return (dx, None) + tuple(flat)
+
+
+class ICSBPFn(torch.autograd.Function):
+    """colour head (SemiConv or plain 1x1 conv) + IC-SBP.  Returns
+    (log_m [K,B,1,H,W], log_s [K,B,1,H,W], colour [B,8,H,W], seeds [K-1,B,8], seed_idx [K-1,B])."""
+
+    @staticmethod
+    def forward(ctx, feat, conv_w, conv_b, gate, uv, log_sigma, rand_pixel, K, kernel, seed_idx):
+        feat = feat.contiguous()
+        colour = hip.conv1x1_fwd(feat, conv_w, conv_b, gate, uv)
+        log_m, log_s, seeds, idx = hip.icsbp_fwd(colour, log_sigma, rand_pixel.contiguous(), K, kernel, seed_idx)
+        ctx.save_for_backward(feat, conv_w, conv_b, gate, log_sigma, colour, seeds, idx)
+        ctx.kernel = kernel
+        ctx.mark_non_differentiable(log_s, colour, seeds, idx)
+        return log_m, log_s, colour, seeds, idx
+
+    @staticmethod
+    def backward(ctx, g_log_m, *unused):
+        feat, conv_w, conv_b, gate, log_sigma, colour, seeds, idx = ctx.saved_tensors
+        dcolour, dls = hip.icsbp_bwd(colour, log_sigma, seeds, idx, g_log_m.contiguous(), ctx.kernel)
+        dfeat, dw, db, dgate = hip.conv1x1_bwd(feat, dcolour, conv_w, conv_b, gate)
+        return dfeat, dw, db, dgate, None, dls, None, None, None, None
+
+
+class MaskPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, f, log_m):
+        f = f.contiguous()
+        log_m = log_m.contiguous()
+        S, msum = hip.maskpool_fwd(f, log_m)
+        ctx.save_for_backward(f, log_m)
+        return S, msum
+
+    @staticmethod
+    def backward(ctx, gS, gmsum):
+        f, log_m = ctx.saved_tensors
+        df, dlog_m = hip.maskpool_bwd(f, log_m, gS.contiguous(), gmsum.contiguous())
+        return df, dlog_m
+
+
+class DecoderFn(torch.autograd.Function):
+    """args: z [K*B, D], coords [1,2,d,d], then 4 x (deconv w, deconv b, gn gamma, gn beta), out w, out b."""
+
+    @staticmethod
+    def forward(ctx, z, coords, *params):
+        N, D = z.shape
+        d = coords.shape[-1]
+        h = torch.cat((z.view(N, D, 1, 1).expand(-1, -1, d, d), coords.expand(N, -1, -1, -1)), 1).contiguous()
+        saved = []
+        for l in range(4):
+            w, b, gamma, beta = params[4 * l:4 * l + 4]
+            y = hip.deconv5x5s2_fwd(h, w, b)
+            a = torch.empty_like(y)
+            mean, rstd = hip.gn_relu_fwd(y, gamma, beta, GROUPS, EPS, (a, 0, 0))
+            saved.append((h, y, mean, rstd))
+            h = a
+        ow, ob = params[16], params[17]
+        out = hip.conv1x1_fwd(h, ow, ob)
+        ctx.saved = saved
+        ctx.last = h
+        ctx.params = params
+        ctx.D = D
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        params = ctx.params
+        ow, ob = params[16], params[17]
+        da, dow, dob, _ = hip.conv1x1_bwd(ctx.last, g.contiguous(), ow, ob)
+        grads = [None] * 18
+        grads[16], grads[17] = dow, dob
+        for l in reversed(range(4)):
+            w, b, gamma, beta = params[4 * l:4 * l + 4]
+            h, y, mean, rstd = ctx.saved[l]
+            dy, dgamma, dbeta, dbias = hip.gn_relu_bwd(y, gamma, beta, mean, rstd, GROUPS, (da, 0, 0), None, True)
+            dw = hip.deconv5x5s2_wgrad(h, dy)
+            # the first layer's input is the broadcast latent + 2 coordinate channels: only the D latent
+            # channels need a gradient
+            da = hip.deconv5x5s2_dgrad(dy, w, ctx.D if l == 0 else None)
+            grads[4 * l:4 * l + 4] = [dw, dbias, dgamma, dbeta]
+        dz = da.sum((2, 3))
+        return (dz, None) + tuple(grads)
+
+
+class MixtureFn(torch.autograd.Function):
+    """returns (err [B], recon [B,3,H,W], x_r [K,B,3,H,W], log_m_r [K,B,1,H,W])."""
+
+    @staticmethod
+    def forward(ctx, x, dec, K, pixel_std, pixel_bound):
+        x = x.contiguous()
+        dec = dec.contiguous()
+        err, recon, x_r, log_m_r = hip.mixture_fwd(x, dec, K, pixel_std, pixel_bound)
+        ctx.save_for_backward(x, dec)
+        ctx.cfg = (K, pixel_std, pixel_bound)
+        ctx.mark_non_differentiable(recon, x_r, log_m_r)
+        return err, recon, x_r, log_m_r
+
+    @staticmethod
+    def backward(ctx, g_err, *unused):
+        x, dec = ctx.saved_tensors
+        K, pixel_std, pixel_bound = ctx.cfg
+        ddec = hip.mixture_bwd(x, dec, g_err.contiguous(), K, pixel_std, pixel_bound)
+        return None, ddec, None, None, None

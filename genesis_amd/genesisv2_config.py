@@ -1,0 +1,354 @@
+"""GENESIS-V2 model config -- MI355X-native drop-in for the reference's
+`models/genesisv2_config.py` (flags :35-42, `load(cfg)` :45-46, `GenesisV2` :49-256).
+
+Same Forge-style contract: importing this file registers the model flags, `load(cfg)` returns an
+`nn.Module` whose `forward(x) -> (recon, losses, stats, att_stats, comp_stats)` and
+`sample(batch_size, K_steps)` match the reference's signatures, attribute names and `state_dict`
+layout (78 tensors for feat_dim 64 / 64x64, identical keys / shapes / dtypes, `att_process.log_sigma`
+fp64), so `train.py` and the visualise / compute_* scripts drop in unchanged.
+
+Underneath, every spatial op group runs as hand-written gfx950 HIP kernels behind the C ABI
+(include/genesis_hip.h) -- see genesis_amd/functions.py.  The torch.nn layer classes used below are
+parameter containers only (they give the reference's parameter names, shapes and default
+initialisation order); their own forward()s are never called for the conv / norm / attention path.
+There is no CPU path: calling forward on CPU tensors raises.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.distributions.normal import Normal
+
+from genesis_amd import compat as _compat
+
+_compat.install()
+
+from attrdict import AttrDict  # noqa: E402
+from forge import flags  # noqa: E402
+
+from genesis_amd import functions as fn  # noqa: E402
+from genesis_amd import hip_ops as hip  # noqa: E402
+
+# Architecture (models/genesisv2_config.py:35-42)
+flags.DEFINE_integer('feat_dim', 64, 'Number of features and latents.')
+# Segmentation
+flags.DEFINE_string('kernel', 'gaussian', '{laplacian, gaussian, epanechnikov')
+flags.DEFINE_boolean('semiconv', True, 'Use semi-convolutional embeddings.')
+flags.DEFINE_boolean('dynamic_K', False, 'Dynamic K.')
+# Auxiliary mask consistency loss
+flags.DEFINE_boolean('klm_loss', False, 'KL mask regulariser.')
+flags.DEFINE_boolean('detach_mr_in_klm', True, 'Detach reconstructed masks.')
+# Flags the reference inherits from models/genesis_config.py:33-52 (imported by genesisv2_config.py:27)
+flags.DEFINE_boolean('autoreg_prior', True, 'Autoregressive prior.')
+flags.DEFINE_boolean('pixel_bound', True, 'Bound pixel values to [0, 1].')
+flags.DEFINE_float('pixel_std1', 0.7, 'StdDev of reconstructed pixels.')
+flags.DEFINE_float('pixel_std2', 0.7, 'StdDev of reconstructed pixels.')
+
+
+def load(cfg):
+    return GenesisV2(cfg)
+
+
+def _cfg_get(cfg, name, default):
+    try:
+        return cfg[name]
+    except (KeyError, TypeError):
+        return getattr(cfg, name, default)
+
+
+def pixel_coords(size):
+    """Row grid then column grid, linspace(-1, 1): modules/blocks.py:42-47 ('ij' meshgrid)."""
+    lin = torch.linspace(-1, 1, size)
+    return torch.stack((lin.view(size, 1).expand(size, size), lin.view(1, size).expand(size, size)), 0).unsqueeze(0)
+
+
+class _ConvGNReLU(nn.Sequential):
+    """Parameter container with the key layout of modules/blocks.py:159-165."""
+
+    def __init__(self, nin, nout):
+        super().__init__(nn.Conv2d(nin, nout, 3, 1, 1, bias=False), nn.GroupNorm(8, nout), nn.ReLU(inplace=True))
+
+    def params(self):
+        return (self[0].weight, self[1].weight, self[1].bias)
+
+
+class _UNetParams(nn.Module):
+    """Parameter container with the key layout / init order of modules/unet.py:23-67."""
+
+    def __init__(self, num_blocks, img_size, filter_start, in_chnls, out_chnls):
+        super().__init__()
+        c = filter_start
+        if num_blocks == 4:
+            enc_in, enc_out = [in_chnls, c, 2 * c, 2 * c], [c, 2 * c, 2 * c, 2 * c]
+            dec_in, dec_out = [4 * c, 4 * c, 4 * c, 2 * c], [2 * c, 2 * c, c, c]
+        elif num_blocks == 5:
+            enc_in, enc_out = [in_chnls, c, c, 2 * c, 2 * c], [c, c, 2 * c, 2 * c, 2 * c]
+            dec_in, dec_out = [4 * c, 4 * c, 4 * c, 2 * c, 2 * c], [2 * c, 2 * c, c, c, c]
+        elif num_blocks == 6:
+            enc_in, enc_out = [in_chnls, c, c, c, 2 * c, 2 * c], [c, c, c, 2 * c, 2 * c, 2 * c]
+            dec_in, dec_out = [4 * c, 4 * c, 4 * c, 2 * c, 2 * c, 2 * c], [2 * c, 2 * c, c, c, c, c]
+        else:
+            raise ValueError('UNet supports 4, 5 or 6 blocks (img_size 32, 64, 128)')
+        self.num_blocks = num_blocks
+        self.down = nn.ModuleList([_ConvGNReLU(i, o) for i, o in zip(enc_in, enc_out)])
+        self.up = nn.ModuleList([_ConvGNReLU(i, o) for i, o in zip(dec_in, dec_out)])
+        self.featuremap_size = img_size // 2 ** (num_blocks - 1)
+        flat = 2 * c * self.featuremap_size ** 2
+        self.mlp = nn.Sequential(nn.Flatten(), nn.Linear(flat, 128), nn.ReLU(), nn.Linear(128, 128), nn.ReLU(),
+                                 nn.Linear(128, flat), nn.ReLU())
+        # the reference builds final_conv (consuming init RNG) and then replaces it by Identity
+        # (models/genesisv2_config.py:70)
+        nn.Conv2d(c, out_chnls, 1)
+        self.final_conv = nn.Identity()
+
+    def flat_params(self):
+        p = []
+        for blk in list(self.down) + list(self.up):
+            p.extend(blk.params())
+        for j in (1, 3, 5):
+            p.extend((self.mlp[j].weight, self.mlp[j].bias))
+        return p
+
+
+class _ScalarGate(nn.Module):
+    def __init__(self, init=0.0):
+        super().__init__()
+        self.gate = nn.Parameter(torch.tensor(init))
+
+
+class _SemiConvParams(nn.Module):
+    def __init__(self, nin, nout):
+        super().__init__()
+        self.conv = nn.Conv2d(nin, nout, 1)
+        self.gate = _ScalarGate()
+
+
+class _ICSBPParams(nn.Module):
+    """modules/attention.py:138-160."""
+
+    def __init__(self, kernel, K_steps, feat_dim, semiconv, colour_dim=8):
+        super().__init__()
+        if kernel == 'laplacian':
+            sigma_init = 1.0 / (np.sqrt(K_steps) * np.log(2))
+        elif kernel == 'gaussian':
+            sigma_init = 1.0 / (K_steps * np.log(2))
+        elif kernel == 'epanechnikov':
+            sigma_init = 2.0 / K_steps
+        else:
+            raise ValueError('No valid kernel.')
+        self.kernel = kernel
+        self.colour_dim = colour_dim
+        self.log_sigma = nn.Parameter(torch.tensor(sigma_init).log())  # float64 0-dim, as in the reference
+        self.semiconv = semiconv
+        if semiconv:
+            self.colour_head = _SemiConvParams(feat_dim, colour_dim)
+        else:
+            self.colour_head = nn.Conv2d(feat_dim, colour_dim, 1)
+
+
+class GenesisV2(nn.Module):
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.K_steps = cfg.K_steps
+        self.img_size = cfg.img_size
+        self.pixel_bound = _cfg_get(cfg, 'pixel_bound', True)
+        self.feat_dim = cfg.feat_dim
+        self.klm_loss = _cfg_get(cfg, 'klm_loss', False)
+        self.detach_mr_in_klm = _cfg_get(cfg, 'detach_mr_in_klm', True)
+        self.dynamic_K = _cfg_get(cfg, 'dynamic_K', False)
+        self.debug = _cfg_get(cfg, 'debug', False)
+        self.multi_gpu = _cfg_get(cfg, 'multi_gpu', False)
+        if self.dynamic_K:
+            raise NotImplementedError('dynamic_K (non-default, models/genesisv2_config.py:39) is not on the HIP path')
+        D = cfg.feat_dim
+        self.encoder = _UNetParams(int(np.log2(cfg.img_size) - 1), cfg.img_size, min(D, 64), 3, D)
+        self.att_process = _ICSBPParams(_cfg_get(cfg, 'kernel', 'gaussian'), self.K_steps, D,
+                                        _cfg_get(cfg, 'semiconv', True))
+        self.seg_head = _ConvGNReLU(D, D)
+        self.feat_head = nn.Sequential(_ConvGNReLU(D, D), nn.Conv2d(D, 2 * D, 1))
+        self.z_head = nn.Sequential(nn.LayerNorm(2 * D), nn.Linear(2 * D, 2 * D), nn.ReLU(inplace=True),
+                                    nn.Linear(2 * D, 2 * D))
+        c = D
+        cm = min(c, 64)
+        self.decoder_module = nn.Sequential(
+            nn.Identity(),  # BroadcastLayer(img_size // 16): no parameters (modules/blocks.py:104-117)
+            nn.ConvTranspose2d(D + 2, c, 5, 2, 2, 1), nn.GroupNorm(8, c), nn.ReLU(inplace=True),
+            nn.ConvTranspose2d(c, c, 5, 2, 2, 1), nn.GroupNorm(8, c), nn.ReLU(inplace=True),
+            nn.ConvTranspose2d(c, cm, 5, 2, 2, 1), nn.GroupNorm(8, cm), nn.ReLU(inplace=True),
+            nn.ConvTranspose2d(cm, cm, 5, 2, 2, 1), nn.GroupNorm(8, cm), nn.ReLU(inplace=True),
+            nn.Conv2d(cm, 4, 1))
+        self.autoreg_prior = _cfg_get(cfg, 'autoreg_prior', True)
+        self.prior_lstm, self.prior_linear = None, None
+        if self.autoreg_prior and self.K_steps > 1:
+            self.prior_lstm = nn.LSTM(D, 4 * D)
+            self.prior_linear = nn.Linear(4 * D, 2 * D)
+        assert _cfg_get(cfg, 'pixel_std1', 0.7) == _cfg_get(cfg, 'pixel_std2', 0.7)
+        self.std = _cfg_get(cfg, 'pixel_std1', 0.7)
+        # coordinate grids are plain attributes, not buffers (modules/blocks.py:123-126,172-174):
+        # they never enter the state_dict.  Cached per device.
+        self._grids = {}
+
+    # ------------------------------------------------------------------ helpers
+    def _grid(self, device):
+        key = str(device)
+        if key not in self._grids:
+            S, cd = self.img_size, self.att_process.colour_dim
+            uv = torch.cat((torch.zeros(1, cd - 2, S, S), pixel_coords(S)), 1)[0].contiguous()
+            dec_coords = pixel_coords(self.img_size // 16).contiguous()
+            self._grids[key] = (uv.to(device), dec_coords.to(device))
+        return self._grids[key]
+
+    def _decoder_params(self):
+        p = []
+        for ci, gi in ((1, 2), (4, 5), (7, 8), (10, 11)):
+            p.extend((self.decoder_module[ci].weight, self.decoder_module[ci].bias,
+                      self.decoder_module[gi].weight, self.decoder_module[gi].bias))
+        p.extend((self.decoder_module[13].weight.view(4, -1), self.decoder_module[13].bias))
+        return p
+
+    def _decode(self, z_kbd, x=None):
+        """z [K,B,D] -> (dec [K*B,4,H,W]) -> mixture.  Returns (err, recon, x_r [K,...], log_m_r [K,...])."""
+        K, B, D = z_kbd.shape
+        _, dec_coords = self._grid(z_kbd.device)
+        dec = fn.DecoderFn.apply(z_kbd.reshape(K * B, D), dec_coords, *self._decoder_params())
+        if x is None:
+            x = torch.zeros(B, 3, self.img_size, self.img_size, device=z_kbd.device)
+        return fn.MixtureFn.apply(x, dec, K, float(self.std), bool(self.pixel_bound))
+
+    def _prior(self, z_kbd):
+        """AR prior over slot latents, models/genesis_config.py:288-331 (LSTM from the zero state over
+        z_1..z_{K-1}; first slot N(0,1)).  Tiny [B,64]-row dense ops: torch for now."""
+        K, B, D = z_kbd.shape
+        w_ih, w_hh = self.prior_lstm.weight_ih_l0, self.prior_lstm.weight_hh_l0
+        b_ih, b_hh = self.prior_lstm.bias_ih_l0, self.prior_lstm.bias_hh_l0
+        H = w_hh.shape[1]
+        h = z_kbd.new_zeros(B, H)
+        c = z_kbd.new_zeros(B, H)
+        gx = F.linear(z_kbd[:-1], w_ih, b_ih)  # [K-1,B,4H]
+        outs = []
+        for t in range(K - 1):
+            gates = gx[t] + F.linear(h, w_hh, b_hh)
+            i, f, g, o = gates.chunk(4, 1)
+            c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+            h = torch.sigmoid(o) * torch.tanh(c)
+            outs.append(h)
+        lin = self.prior_linear(torch.stack(outs, 0))
+        mu_raw, sig_raw = lin.chunk(2, dim=2)
+        return torch.tanh(mu_raw), torch.sigmoid(sig_raw + 4.0) + 1e-4
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, rand_pixel=None, eps=None, seed_idx=None):
+        """x [B,3,H,W] in [0,1] on the GPU.  The optional arguments inject the noise the reference draws
+        internally (rand_pixel [B,1,H,W] uniform, modules/attention.py:177-178; eps [K,B,D] standard
+        normal, models/genesisv2_config.py:157) and, for tie-break tests, the seed pixels [K-1,B]."""
+        B, _, H, W = x.shape
+        K, D = self.K_steps, self.feat_dim
+        dev = x.device
+        uv, _ = self._grid(dev)
+        # --- Extract features (F.relu on the ReLU'd UNet output, genesisv2_config.py:115, is the identity)
+        enc_feat = fn.UNetEncoderFn.apply(x, self.encoder.num_blocks, *self.encoder.flat_params())
+        # --- Predict attention masks
+        seg = fn.ConvGNReLUFn.apply(enc_feat, *self.seg_head.params())
+        if rand_pixel is None:
+            rand_pixel = torch.rand(B, 1, H, W, device=dev)
+        ap = self.att_process
+        if ap.semiconv:
+            cw, cb, gate, addend = ap.colour_head.conv.weight, ap.colour_head.conv.bias, ap.colour_head.gate.gate, uv
+        else:
+            cw, cb, gate, addend = ap.colour_head.weight, ap.colour_head.bias, None, None
+        log_m, log_s, colour, seeds, idx = fn.ICSBPFn.apply(
+            seg, cw.view(cw.shape[0], -1), cb, gate, addend, ap.log_sigma, rand_pixel, K, ap.kernel, seed_idx)
+        # --- Object features: feat_head[0] once (the reference recomputes it K times, :149), pooled per
+        #     slot; the 1x1 conv feat_head[1] commutes with the masked sum and is applied to the pooled sums.
+        f = fn.ConvGNReLUFn.apply(enc_feat, *self.feat_head[0].params())
+        S, msum = fn.MaskPoolFn.apply(f, log_m)                      # [B,K,D], [B,K]
+        w1 = self.feat_head[1].weight.view(2 * D, D)
+        obj = (F.linear(S, w1) + msum.unsqueeze(-1) * self.feat_head[1].bias) / (msum.unsqueeze(-1) + 1e-5)
+        # --- Posterior
+        mu, sigma_ps = self.z_head(obj).chunk(2, dim=-1)             # [B,K,D] each
+        sigma = F.softplus(sigma_ps + 0.5) + 1e-8
+        mu, sigma = mu.transpose(0, 1), sigma.transpose(0, 1)        # [K,B,D]
+        if eps is None:
+            eps = torch.randn(K, B, D, device=dev)
+        z = mu + sigma * eps
+        # --- Decode latents, reconstruction loss
+        err, recon, x_r, log_m_r = self._decode(z, x)
+        losses = AttrDict()
+        losses['err'] = err
+        log_m_k = list(log_m.unbind(0))
+        log_s_k = list(log_s.unbind(0))
+        x_r_k = list(x_r.unbind(0))
+        log_m_r_k = list(log_m_r.unbind(0))
+        mx_r_k = list((x_r * log_m_r.exp()).unbind(0))
+        # -- Optional: Attention mask loss (MONet.kl_m_loss, models/monet_config.py:157-170)
+        if self.klm_loss:
+            if not self.detach_mr_in_klm:
+                raise NotImplementedError('klm_loss with detach_mr_in_klm=False is not on the HIP path')
+            q = log_m.squeeze(2).exp().clamp_min(1e-5)               # [K,B,H,W]
+            p_ = log_m_r.squeeze(2).exp().clamp_min(1e-5)
+            q = q / q.sum(0, keepdim=True)
+            p_ = p_ / p_.sum(0, keepdim=True)
+            losses['kl_m'] = (q * (q.log() - p_.log())).sum(0).flatten(1).sum(1)
+        # -- Component KL (Genesis.mask_latent_loss, models/genesis_config.py:288-343)
+        log_q = Normal(mu, sigma).log_prob(z).sum(2)                 # [K,B]
+        if self.prior_lstm is not None:
+            mu_p, sig_p = self._prior(z)
+            log_p0 = Normal(0., 1.).log_prob(z[:1]).sum(2)
+            log_p = torch.cat((log_p0, Normal(mu_p, sig_p).log_prob(z[1:]).sum(2)), 0)
+        else:
+            log_p = Normal(0., 1.).log_prob(z).sum(2)
+        losses['kl_l_k'] = list((log_q - log_p).unbind(0))
+
+        stats = AttrDict(
+            recon=recon, log_m_k=log_m_k, log_s_k=log_s_k, x_r_k=x_r_k, log_m_r_k=log_m_r_k, mx_r_k=mx_r_k,
+            instance_seg=torch.argmax(log_m.squeeze(2), dim=0),
+            instance_seg_r=torch.argmax(log_m_r.squeeze(2), dim=0))
+        delta = (colour[:, -2:] - uv[-2:]) if ap.semiconv else None
+        att_stats = AttrDict()
+        att_stats.update({'colour': colour, 'delta': delta, 'seeds': list(seeds.unbind(0)),
+                          'seed_idx': list(idx.unbind(0))})
+        comp_stats = AttrDict(mu_k=list(mu.unbind(0)), sigma_k=list(sigma.unbind(0)), z_k=list(z.unbind(0)),
+                              kl_l_k=[], q_z_k=[Normal(m, s) for m, s in zip(mu.unbind(0), sigma.unbind(0))])
+        if self.multi_gpu:
+            del comp_stats['q_z_k']
+        return recon, losses, stats, att_stats, comp_stats
+
+    def decode_latents(self, z_k):
+        """models/genesisv2_config.py:205-225."""
+        _, recon, x_r, log_m_r = self._decode(torch.stack(list(z_k), 0))
+        return recon, list(x_r.unbind(0)), list(log_m_r.unbind(0))
+
+    @torch.no_grad()
+    def sample(self, batch_size, K_steps=None):
+        """models/genesisv2_config.py:227-256: AR-prior rollout, then decode."""
+        K_steps = self.K_steps if K_steps is None else K_steps
+        dev = self.decoder_module[13].weight.device
+        D = self.feat_dim
+        if self.autoreg_prior and self.prior_lstm is not None:
+            z_k = [torch.randn(batch_size, D, device=dev)]
+            w_ih, w_hh = self.prior_lstm.weight_ih_l0, self.prior_lstm.weight_hh_l0
+            b_ih, b_hh = self.prior_lstm.bias_ih_l0, self.prior_lstm.bias_hh_l0
+            h = torch.zeros(batch_size, w_hh.shape[1], device=dev)
+            c = torch.zeros_like(h)
+            for _ in range(1, K_steps):
+                gates = F.linear(z_k[-1], w_ih, b_ih) + F.linear(h, w_hh, b_hh)
+                i, f, g, o = gates.chunk(4, 1)
+                c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+                h = torch.sigmoid(o) * torch.tanh(c)
+                mu_raw, sig_raw = self.prior_linear(h).chunk(2, dim=1)
+                mu, sigma = torch.tanh(mu_raw), torch.sigmoid(sig_raw + 4.0) + 1e-4
+                z_k.append(mu + sigma * torch.randn_like(mu))
+        else:
+            z_k = [torch.randn(batch_size, D, device=dev) for _ in range(K_steps)]
+        recon, x_r_k, log_m_r_k = self.decode_latents(z_k)
+        stats = AttrDict(x_k=x_r_k, log_m_k=log_m_r_k, mx_k=[x * m.exp() for x, m in zip(x_r_k, log_m_r_k)])
+        return recon, stats
+
+    def get_features(self, image_batch):
+        """models/genesis_config.py:427-436 (same accessor the other model configs expose)."""
+        with torch.no_grad():
+            _, _, _, _, comp_stats = self.forward(image_batch)
+            return torch.cat(comp_stats.z_k, dim=1)

@@ -1,0 +1,252 @@
+"""Raw (non-autograd) Python entry points of the HIP kernels: torch tensors in, torch tensors out,
+every call goes through the C ABI in include/genesis_hip.h on torch's current HIP stream.
+
+PyTorch is used for device memory (caching allocator) and streams only.  There is no CPU or eager
+fallback: non-HIP tensors raise."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import GenesisHipError
+
+F32 = torch.float32
+KERNELS = {'gaussian': 0, 'laplacian': 1, 'epanechnikov': 2}
+
+
+def _chk(t, name, dtype=F32):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise GenesisHipError('%s: the HIP hot path needs device tensors (got %s); there is no CPU fallback'
+                              % (name, t.device))
+    if t.dtype != dtype:
+        raise GenesisHipError('%s: expected %s, got %s' % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise GenesisHipError('%s: tensor must be contiguous' % name)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------ conv3x3
+def conv3x3_fwd(x, w):
+    _chk(x, 'conv3x3_fwd.x'); _chk(w, 'conv3x3_fwd.w')
+    N, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    assert w.shape == (Cout, Cin, 3, 3), (w.shape, x.shape)
+    y = torch.empty(N, Cout, H, W, dtype=F32, device=x.device)
+    nb = _lib.query('gx_conv3x3_ws_bytes', N, Cin, Cout, H, W)
+    ws = _ws(nb, x.device)
+    _lib.call('gx_conv3x3_fwd', _p(x), _p(w), _p(y), N, Cin, Cout, H, W, _p(ws), nb, _stream())
+    return y
+
+
+def conv3x3_dgrad(dy, w):
+    _chk(dy, 'conv3x3_dgrad.dy'); _chk(w, 'conv3x3_dgrad.w')
+    N, Cout, H, W = dy.shape
+    Cin = w.shape[1]
+    assert w.shape == (Cout, Cin, 3, 3)
+    dx = torch.empty(N, Cin, H, W, dtype=F32, device=dy.device)
+    nb = _lib.query('gx_conv3x3_ws_bytes', N, Cin, Cout, H, W)
+    ws = _ws(nb, dy.device)
+    _lib.call('gx_conv3x3_dgrad', _p(dy), _p(w), _p(dx), N, Cin, Cout, H, W, _p(ws), nb, _stream())
+    return dx
+
+
+def conv3x3_wgrad(x, dy):
+    _chk(x, 'conv3x3_wgrad.x'); _chk(dy, 'conv3x3_wgrad.dy')
+    N, Cin, H, W = x.shape
+    Cout = dy.shape[1]
+    assert dy.shape == (N, Cout, H, W)
+    dw = torch.empty(Cout, Cin, 3, 3, dtype=F32, device=x.device)
+    nb = _lib.query('gx_conv3x3_wgrad_ws_bytes', N, Cin, Cout, H, W)
+    ws = _ws(nb, x.device)
+    _lib.call('gx_conv3x3_wgrad', _p(x), _p(dy), _p(dw), N, Cin, Cout, H, W, _p(ws), nb, _stream())
+    return dw
+
+
+# ------------------------------------------------------------------ ConvTranspose2d k5 s2 p2 op1
+def deconv5x5s2_fwd(x, w, bias):
+    _chk(x, 'deconv.x'); _chk(w, 'deconv.w'); _chk(bias, 'deconv.bias')
+    N, Cin, H, W = x.shape
+    Cout = w.shape[1]
+    assert w.shape == (Cin, Cout, 5, 5)
+    y = torch.empty(N, Cout, 2 * H, 2 * W, dtype=F32, device=x.device)
+    nb = _lib.query('gx_deconv5x5s2_ws_bytes', N, Cin, Cout, H, W)
+    ws = _ws(nb, x.device)
+    _lib.call('gx_deconv5x5s2_fwd', _p(x), _p(w), _p(bias), _p(y), N, Cin, Cout, H, W, _p(ws), nb, _stream())
+    return y
+
+
+def deconv5x5s2_dgrad(dy, w, cin_out=None):
+    _chk(dy, 'deconv_dgrad.dy'); _chk(w, 'deconv_dgrad.w')
+    N, Cout, H2, W2 = dy.shape
+    Cin = w.shape[0]
+    assert w.shape == (Cin, Cout, 5, 5)
+    H, W = H2 // 2, W2 // 2
+    cin_out = Cin if cin_out is None else cin_out
+    dx = torch.empty(N, cin_out, H, W, dtype=F32, device=dy.device)
+    nb = _lib.query('gx_deconv5x5s2_ws_bytes', N, Cin, Cout, H, W)
+    ws = _ws(nb, dy.device)
+    _lib.call('gx_deconv5x5s2_dgrad', _p(dy), _p(w), _p(dx), N, Cin, cin_out, Cout, H, W, _p(ws), nb, _stream())
+    return dx
+
+
+def deconv5x5s2_wgrad(x, dy):
+    _chk(x, 'deconv_wgrad.x'); _chk(dy, 'deconv_wgrad.dy')
+    N, Cin, H, W = x.shape
+    Cout = dy.shape[1]
+    assert dy.shape == (N, Cout, 2 * H, 2 * W)
+    dw = torch.empty(Cin, Cout, 5, 5, dtype=F32, device=x.device)
+    nb = _lib.query('gx_deconv5x5s2_wgrad_ws_bytes', N, Cin, Cout, H, W)
+    ws = _ws(nb, x.device)
+    _lib.call('gx_deconv5x5s2_wgrad', _p(x), _p(dy), _p(dw), N, Cin, Cout, H, W, _p(ws), nb, _stream())
+    return dw
+
+
+# ------------------------------------------------------------------ GroupNorm + ReLU (+ resample / concat placement)
+def _view_args(v, name):
+    """v = (buffer [N,ctot,Hd,Wd], c0, mode) or None."""
+    if v is None:
+        return [None, 0, 0, 0]
+    buf, c0, mode = v
+    _chk(buf, name)
+    return [_p(buf), int(buf.shape[1]), int(c0), int(mode)]
+
+
+def gn_relu_fwd(y, gamma, beta, groups, eps, dst0, dst1=None):
+    _chk(y, 'gn.y'); _chk(gamma, 'gn.gamma'); _chk(beta, 'gn.beta')
+    N, C, H, W = y.shape
+    mean = torch.empty(N * groups, dtype=F32, device=y.device)
+    rstd = torch.empty(N * groups, dtype=F32, device=y.device)
+    _lib.call('gx_gn_relu_fwd', _p(y), _p(gamma), _p(beta), N, C, H, W, groups, float(eps),
+              *(_view_args(dst0, 'gn.dst0') + _view_args(dst1, 'gn.dst1')), _p(mean), _p(rstd), _stream())
+    return mean, rstd
+
+
+def gn_relu_bwd(y, gamma, beta, mean, rstd, groups, g0, g1=None, want_dbias=False):
+    _chk(y, 'gn_bwd.y')
+    N, C, H, W = y.shape
+    dy = torch.empty_like(y)
+    dgamma = torch.empty(C, dtype=F32, device=y.device)
+    dbeta = torch.empty(C, dtype=F32, device=y.device)
+    dbias = torch.empty(C, dtype=F32, device=y.device) if want_dbias else None
+    nb = _lib.query('gx_gn_relu_bwd_ws_bytes', N, C)
+    ws = _ws(nb, y.device)
+    _lib.call('gx_gn_relu_bwd', _p(y), _p(gamma), _p(beta), _p(mean), _p(rstd), N, C, H, W, groups,
+              *(_view_args(g0, 'gn_bwd.g0') + _view_args(g1, 'gn_bwd.g1')), _p(dy), _p(dgamma), _p(dbeta),
+              _p(dbias), _p(ws), nb, _stream())
+    return dy, dgamma, dbeta, dbias
+
+
+# ------------------------------------------------------------------ IC-SBP
+def icsbp_fwd(colour, log_sigma, rand_pixel, K, kernel='gaussian', seed_idx=None):
+    _chk(colour, 'icsbp.colour'); _chk(rand_pixel, 'icsbp.rand_pixel')
+    _chk(log_sigma, 'icsbp.log_sigma', torch.float64)
+    _chk(seed_idx, 'icsbp.seed_idx', torch.int64)
+    B, C, H, W = colour.shape
+    dev = colour.device
+    log_m = torch.empty(K, B, 1, H, W, dtype=F32, device=dev)
+    log_s = torch.empty(K, B, 1, H, W, dtype=F32, device=dev)
+    seeds = torch.empty(max(K - 1, 0), B, C, dtype=F32, device=dev)
+    idx = torch.empty(max(K - 1, 0), B, dtype=torch.int64, device=dev)
+    _lib.call('gx_icsbp_fwd', _p(colour), _p(log_sigma), _p(rand_pixel), _p(seed_idx), B, C, H, W, K,
+              KERNELS[kernel], _p(log_m), _p(log_s), _p(seeds), _p(idx), _stream())
+    return log_m, log_s, seeds, idx
+
+
+def icsbp_bwd(colour, log_sigma, seeds, idx, g_log_m, kernel='gaussian'):
+    _chk(g_log_m, 'icsbp_bwd.g_log_m')
+    B, C, H, W = colour.shape
+    K = g_log_m.shape[0]
+    dcolour = torch.empty_like(colour)
+    dls = torch.empty((), dtype=torch.float64, device=colour.device)
+    nb = _lib.query('gx_icsbp_bwd_ws_bytes', B)
+    ws = _ws(nb, colour.device)
+    _lib.call('gx_icsbp_bwd', _p(colour), _p(log_sigma), _p(seeds), _p(idx), _p(g_log_m), B, C, H, W, K,
+              KERNELS[kernel], _p(dcolour), _p(dls), _p(ws), nb, _stream())
+    return dcolour, dls
+
+
+# ------------------------------------------------------------------ masked pooling
+def maskpool_fwd(f, log_m):
+    _chk(f, 'maskpool.f'); _chk(log_m, 'maskpool.log_m')
+    B, C, H, W = f.shape
+    K = log_m.shape[0]
+    S = torch.empty(B, K, C, dtype=F32, device=f.device)
+    msum = torch.empty(B, K, dtype=F32, device=f.device)
+    _lib.call('gx_maskpool_fwd', _p(f), _p(log_m), B, C, H, W, K, _p(S), _p(msum), _stream())
+    return S, msum
+
+
+def maskpool_bwd(f, log_m, gS, gmsum):
+    _chk(gS, 'maskpool_bwd.gS'); _chk(gmsum, 'maskpool_bwd.gmsum')
+    B, C, H, W = f.shape
+    K = log_m.shape[0]
+    df = torch.empty_like(f)
+    dlog_m = torch.empty_like(log_m)
+    _lib.call('gx_maskpool_bwd', _p(f), _p(log_m), _p(gS), _p(gmsum), B, C, H, W, K, _p(df), _p(dlog_m), _stream())
+    return df, dlog_m
+
+
+# ------------------------------------------------------------------ mixture likelihood
+def mixture_fwd(x, dec, K, pixel_std, pixel_bound=True):
+    _chk(x, 'mixture.x'); _chk(dec, 'mixture.dec')
+    B, _, H, W = x.shape
+    assert dec.shape == (K * B, 4, H, W), dec.shape
+    dev = x.device
+    recon = torch.empty(B, 3, H, W, dtype=F32, device=dev)
+    x_r = torch.empty(K, B, 3, H, W, dtype=F32, device=dev)
+    log_m_r = torch.empty(K, B, 1, H, W, dtype=F32, device=dev)
+    err = torch.empty(B, dtype=F32, device=dev)
+    nb = _lib.query('gx_mixture_ws_bytes', B, H, W)
+    ws = _ws(nb, dev)
+    _lib.call('gx_mixture_fwd', _p(x), _p(dec), B, H, W, K, float(pixel_std), int(bool(pixel_bound)), _p(recon),
+              _p(x_r), _p(log_m_r), _p(err), _p(ws), nb, _stream())
+    return err, recon, x_r, log_m_r
+
+
+def mixture_bwd(x, dec, g_err, K, pixel_std, pixel_bound=True):
+    _chk(g_err, 'mixture_bwd.g_err')
+    B, _, H, W = x.shape
+    ddec = torch.empty_like(dec)
+    _lib.call('gx_mixture_bwd', _p(x), _p(dec), _p(g_err), B, H, W, K, float(pixel_std), int(bool(pixel_bound)),
+              _p(ddec), _stream())
+    return ddec
+
+
+# ------------------------------------------------------------------ small 1x1 conv
+def conv1x1_fwd(x, w, bias, gate=None, addend=None):
+    _chk(x, 'conv1x1.x'); _chk(w, 'conv1x1.w'); _chk(bias, 'conv1x1.bias')
+    _chk(gate, 'conv1x1.gate'); _chk(addend, 'conv1x1.addend')
+    N, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    y = torch.empty(N, Cout, H, W, dtype=F32, device=x.device)
+    _lib.call('gx_conv1x1_fwd', _p(x), _p(w), _p(bias), _p(gate), _p(addend), N, Cin, Cout, H, W, _p(y), _stream())
+    return y
+
+
+def conv1x1_bwd(x, dy, w, bias, gate=None):
+    _chk(dy, 'conv1x1_bwd.dy')
+    N, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    dev = x.device
+    dx = torch.empty_like(x)
+    dw = torch.empty(Cout, Cin, dtype=F32, device=dev)
+    db = torch.empty(Cout, dtype=F32, device=dev) if bias is not None else None
+    dgate = torch.empty((), dtype=F32, device=dev) if gate is not None else None
+    nb = _lib.query('gx_conv1x1_bwd_ws_bytes', N, Cin, Cout, H, W)
+    ws = _ws(nb, dev)
+    _lib.call('gx_conv1x1_bwd', _p(x), _p(dy), _p(w), _p(bias), _p(gate), N, Cin, Cout, H, W, _p(dx), _p(dw),
+              _p(db), _p(dgate), _p(ws), nb, _stream())
+    return dx, dw.view(w.shape), db, dgate

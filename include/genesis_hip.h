@@ -1,0 +1,124 @@
+/* libgenesis_hip.so -- C ABI of the MI355X-native GENESIS-V2 hot path.
+ *
+ * The reference (applied-ai-lab/genesis) is pure Python/PyTorch: it has NO native/FFI
+ * boundary.  The drop-in boundary is therefore the reference's Python interface
+ * (models/genesisv2_config.py:45-46 `load(cfg)`, :110-203 `forward(x)`), mirrored by
+ * genesis_amd/genesisv2_config.py; this library sits UNDER that module and each entry
+ * point replaces the ATen op group the reference executes at the cited file:line.
+ *
+ * Conventions:
+ *   - arguments are raw device pointers + explicit sizes; tensors are contiguous NCHW fp32;
+ *   - the caller (PyTorch caching allocator) owns every buffer, including workspaces, whose
+ *     required size is returned by the matching *_ws_bytes() query;
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t); no allocation, no sync;
+ *   - return 0 on success, negative GX_E* on error (gx_last_error() gives the message,
+ *     thread-local); nothing throws across the boundary.
+ */
+#ifndef GENESIS_HIP_H
+#define GENESIS_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* gx_stream_t; /* hipStream_t */
+
+#define GX_OK 0
+#define GX_EINVAL (-1)  /* bad argument / unsupported shape */
+#define GX_ELAUNCH (-2) /* kernel launch failed */
+
+const char* gx_last_error(void);
+int gx_version(void);
+
+/* ---- conv3x3 stride 1 pad 1, no bias: modules/blocks.py:159-165 (ConvGNReLU[0]);
+ *      UNet blocks modules/unet.py:53-56, seg_head/feat_head models/genesisv2_config.py:78-80.
+ *      w is the nn.Conv2d weight [Cout,Cin,3,3]. fwd/dgrad repack w into `ws`. */
+size_t gx_conv3x3_ws_bytes(int N, int Cin, int Cout, int H, int W);
+int gx_conv3x3_fwd(const float* x, const float* w, float* y, int N, int Cin, int Cout, int H, int W,
+                   void* ws, size_t ws_bytes, gx_stream_t stream);
+int gx_conv3x3_dgrad(const float* dy, const float* w, float* dx, int N, int Cin, int Cout, int H, int W,
+                     void* ws, size_t ws_bytes, gx_stream_t stream);
+size_t gx_conv3x3_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W);
+int gx_conv3x3_wgrad(const float* x, const float* dy, float* dw, int N, int Cin, int Cout, int H, int W,
+                     void* ws, size_t ws_bytes, gx_stream_t stream);
+
+/* ---- ConvTranspose2d(k=5, s=2, p=2, output_padding=1) + bias:
+ *      models/genesisv2_config.py:90-98 (decoder_module.{1,4,7,10}).
+ *      w is the nn.ConvTranspose2d weight [Cin,Cout,5,5]; x [N,Cin,Hin,Win]; y [N,Cout,2Hin,2Win].
+ *      dgrad writes only the first Cin_out channels of dx ([N,Cin_out,Hin,Win]). */
+size_t gx_deconv5x5s2_ws_bytes(int N, int Cin, int Cout, int Hin, int Win);
+int gx_deconv5x5s2_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int Cout,
+                       int Hin, int Win, void* ws, size_t ws_bytes, gx_stream_t stream);
+int gx_deconv5x5s2_dgrad(const float* dy, const float* w, float* dx, int N, int Cin, int Cin_out, int Cout,
+                         int Hin, int Win, void* ws, size_t ws_bytes, gx_stream_t stream);
+size_t gx_deconv5x5s2_wgrad_ws_bytes(int N, int Cin, int Cout, int Hin, int Win);
+int gx_deconv5x5s2_wgrad(const float* x, const float* dy, float* dw, int N, int Cin, int Cout, int Hin, int Win,
+                         void* ws, size_t ws_bytes, gx_stream_t stream);
+
+/* ---- GroupNorm(groups, eps, affine) + ReLU: modules/blocks.py:159-165, models/genesisv2_config.py:91-98;
+ *      fused with the UNet's nearest resampling + torch.cat placement (modules/unet.py:78,86,89).
+ *      A "view" (ptr, ctot, c0, mode) names channels [c0, c0+C) of a buffer [N, ctot, Hd, Wd]:
+ *      mode 0 same size, 1 buffer is 2x up-sampled (nearest), 2 buffer is 2x down-sampled ([::2, ::2]).
+ *      fwd writes relu(gn(y)) to dst0 (and dst1 if non-NULL), and mean/rstd [N*groups].
+ *      bwd reads d(out) from g0 (+ g1 if non-NULL), writes dy [N,C,H,W], dgamma/dbeta [C] and, if
+ *      dbias != NULL, sum_{n,hw} dy (the gradient of a per-channel bias added before the norm). */
+int gx_gn_relu_fwd(const float* y, const float* gamma, const float* beta, int N, int C, int H, int W, int groups,
+                   float eps, float* dst0, int dst0_ctot, int dst0_c0, int dst0_mode, float* dst1, int dst1_ctot,
+                   int dst1_c0, int dst1_mode, float* mean, float* rstd, gx_stream_t stream);
+size_t gx_gn_relu_bwd_ws_bytes(int N, int C);
+int gx_gn_relu_bwd(const float* y, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                   int N, int C, int H, int W, int groups, const float* g0, int g0_ctot, int g0_c0, int g0_mode,
+                   const float* g1, int g1_ctot, int g1_c0, int g1_mode, float* dy, float* dgamma, float* dbeta,
+                   float* dbias, void* ws, size_t ws_bytes, gx_stream_t stream);
+
+/* ---- Instance-Colouring stick-breaking attention: modules/attention.py:162-226.
+ *      colour [B,C<=8,H,W]; log_sigma: device pointer to the fp64 0-dim parameter; rand_pixel [B,1,H,W];
+ *      seed_idx_in: NULL (argmax of rand*scope, first max) or [K-1,B] int64 seeds to force.
+ *      kernel_type 0 gaussian, 1 laplacian, 2 epanechnikov.
+ *      Outputs: log_m [K,B,1,H,W], log_s [K,B,1,H,W], seeds [K-1,B,C], seed_idx_out [K-1,B] int64.
+ *      bwd: g_log_m [K,B,1,H,W] -> dcolour [B,C,H,W] (fully written), dlog_sigma (fp64 scalar). */
+int gx_icsbp_fwd(const float* colour, const double* log_sigma, const float* rand_pixel, const int64_t* seed_idx_in,
+                 int B, int C, int H, int W, int K, int kernel_type, float* log_m, float* log_s, float* seeds,
+                 int64_t* seed_idx_out, gx_stream_t stream);
+size_t gx_icsbp_bwd_ws_bytes(int B);
+int gx_icsbp_bwd(const float* colour, const double* log_sigma, const float* seeds, const int64_t* seed_idx,
+                 const float* g_log_m, int B, int C, int H, int W, int K, int kernel_type, float* dcolour,
+                 double* dlog_sigma, void* ws, size_t ws_bytes, gx_stream_t stream);
+
+/* ---- masked slot pooling: models/genesisv2_config.py:146-152.
+ *      S[b,k,c] = sum_hw exp(log_m[k,b]) * f[b,c];  msum[b,k] = sum_hw exp(log_m[k,b]).
+ *      (feat_head's 1x1 conv commutes with the pooling and is applied to S by the caller.) */
+int gx_maskpool_fwd(const float* f, const float* log_m, int B, int C, int H, int W, int K, float* S, float* msum,
+                    gx_stream_t stream);
+int gx_maskpool_bwd(const float* f, const float* log_m, const float* gS, const float* gmsum, int B, int C, int H,
+                    int W, int K, float* df, float* dlog_m, gx_stream_t stream);
+
+/* ---- mixture likelihood + reconstruction: models/genesisv2_config.py:212-223,
+ *      models/monet_config.py:137-139, models/genesis_config.py:273-286.
+ *      dec [K*B,4,H,W] (slot-major rows k*B+b; ch 0-2 RGB pre-activation, ch 3 mask logit), x [B,3,H,W].
+ *      Outputs recon [B,3,H,W], x_r [K,B,3,H,W], log_m_r [K,B,1,H,W], err [B].
+ *      bwd: g_err [B] -> ddec [K*B,4,H,W]. */
+size_t gx_mixture_ws_bytes(int B, int H, int W);
+int gx_mixture_fwd(const float* x, const float* dec, int B, int H, int W, int K, float pixel_std, int pixel_bound,
+                   float* recon, float* x_r, float* log_m_r, float* err, void* ws, size_t ws_bytes,
+                   gx_stream_t stream);
+int gx_mixture_bwd(const float* x, const float* dec, const float* g_err, int B, int H, int W, int K,
+                   float pixel_std, int pixel_bound, float* ddec, gx_stream_t stream);
+
+/* ---- 1x1 convolution with Cout <= 8: y = gate * (W x + b) + addend.
+ *      modules/blocks.py:175-178 (SemiConv: gate = ScalarGate parameter on device, addend = uv [Cout,H,W]),
+ *      models/genesisv2_config.py:99 (decoder_module.13; gate = addend = NULL).
+ *      bwd writes dx, dw [Cout,Cin], db [Cout] (if non-NULL) and dgate (iff gate given). */
+int gx_conv1x1_fwd(const float* x, const float* w, const float* bias, const float* gate, const float* addend,
+                   int N, int Cin, int Cout, int H, int W, float* y, gx_stream_t stream);
+size_t gx_conv1x1_bwd_ws_bytes(int N, int Cin, int Cout, int H, int W);
+int gx_conv1x1_bwd(const float* x, const float* dy, const float* w, const float* bias, const float* gate, int N,
+                   int Cin, int Cout, int H, int W, float* dx, float* dw, float* db, float* dgate, void* ws,
+                   size_t ws_bytes, gx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GENESIS_HIP_H */

@@ -1,0 +1,251 @@
+"""Per-kernel parity: every HIP entry point (called through the C ABI) against the plain PyTorch fp32
+CPU op it replaces, on seeded inputs, fp32 tolerances stated per test."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+hip = pytest.importorskip('genesis_amd.hip_ops')
+DEV = 'cuda'
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def close(a, b, rtol=1e-4, atol=1e-4, msg=''):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item()
+    assert err <= atol + rtol * ref, '%s max err %.3e (ref max %.3e)' % (msg, err, ref)
+
+
+CONV_CASES = [  # N, Cin, Cout, H, W
+    (2, 3, 64, 64, 64), (2, 64, 64, 32, 32), (3, 128, 128, 8, 8), (2, 256, 128, 4, 4),
+    (2, 128, 64, 64, 64), (1, 64, 64, 128, 128), (5, 16, 32, 16, 16), (2, 8, 8, 2, 2), (33, 32, 16, 4, 4),
+]
+
+
+@pytest.mark.parametrize('N,Cin,Cout,H,W', CONV_CASES)
+def test_conv3x3(N, Cin, Cout, H, W):
+    x = rnd(N, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=1.0 / np.sqrt(Cin * 9))
+    dy = rnd(N, Cout, H, W, seed=3)
+    xr = x.clone().requires_grad_()
+    wr = w.clone().requires_grad_()
+    y_ref = F.conv2d(xr, wr, None, 1, 1)
+    y_ref.backward(dy)
+    y = hip.conv3x3_fwd(x.to(DEV), w.to(DEV))
+    close(y, y_ref, 2e-5, 2e-5, 'fwd')
+    dx = hip.conv3x3_dgrad(dy.to(DEV), w.to(DEV))
+    close(dx, xr.grad, 2e-5, 2e-5, 'dgrad')
+    dw = hip.conv3x3_wgrad(x.to(DEV), dy.to(DEV))
+    close(dw, wr.grad, 1e-4, 1e-4, 'wgrad')
+
+
+DECONV_CASES = [  # N, Cin, Cout, Hin
+    (2, 66, 64, 4), (3, 64, 64, 8), (2, 64, 64, 32), (1, 64, 64, 64), (6, 18, 16, 2), (5, 16, 16, 16), (14, 66, 64, 4),
+]
+
+
+@pytest.mark.parametrize('N,Cin,Cout,Hin', DECONV_CASES)
+def test_deconv5x5s2(N, Cin, Cout, Hin):
+    x = rnd(N, Cin, Hin, Hin, seed=4)
+    w = rnd(Cin, Cout, 5, 5, seed=5, scale=1.0 / np.sqrt(Cin * 6.25))
+    b = rnd(Cout, seed=6)
+    dy = rnd(N, Cout, 2 * Hin, 2 * Hin, seed=7)
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    y_ref = F.conv_transpose2d(xr, wr, br, 2, 2, 1)
+    y_ref.backward(dy)
+    y = hip.deconv5x5s2_fwd(x.to(DEV), w.to(DEV), b.to(DEV))
+    close(y, y_ref, 2e-5, 2e-5, 'fwd')
+    dx = hip.deconv5x5s2_dgrad(dy.to(DEV), w.to(DEV))
+    close(dx, xr.grad, 2e-5, 2e-5, 'dgrad')
+    if Cin > 2:
+        dx2 = hip.deconv5x5s2_dgrad(dy.to(DEV), w.to(DEV), Cin - 2)
+        close(dx2, xr.grad[:, :Cin - 2], 2e-5, 2e-5, 'dgrad(cin_out)')
+    dw = hip.deconv5x5s2_wgrad(x.to(DEV), dy.to(DEV))
+    close(dw, wr.grad, 1e-4, 1e-4, 'wgrad')
+
+
+@pytest.mark.parametrize('N,C,H,W,groups', [(2, 64, 64, 64, 8), (3, 128, 8, 8, 8), (2, 16, 4, 4, 8), (2, 8, 32, 32, 8),
+                                            (1, 64, 128, 128, 8), (4, 32, 2, 2, 8)])
+def test_gn_relu_plain(N, C, H, W, groups):
+    y = rnd(N, C, H, W, seed=8, scale=2.0) + 0.3
+    gamma = 1 + 0.3 * rnd(C, seed=9)
+    beta = 0.2 * rnd(C, seed=10)
+    g = rnd(N, C, H, W, seed=11)
+    yr, gr, br = y.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    ref = F.relu(F.group_norm(yr, groups, gr, br, 1e-5))
+    ref.backward(g)
+    yd = y.to(DEV)
+    out = torch.empty(N, C, H, W, device=DEV)
+    mean, rstd = hip.gn_relu_fwd(yd, gamma.to(DEV), beta.to(DEV), groups, 1e-5, (out, 0, 0))
+    close(out, ref, 1e-5, 1e-5, 'fwd')
+    dy, dgamma, dbeta, dbias = hip.gn_relu_bwd(yd, gamma.to(DEV), beta.to(DEV), mean, rstd, groups,
+                                               (g.to(DEV), 0, 0), None, True)
+    close(dy, yr.grad, 1e-4, 1e-5, 'dy')
+    close(dgamma, gr.grad, 1e-4, 1e-4, 'dgamma')
+    close(dbeta, br.grad, 1e-4, 1e-4, 'dbeta')
+    close(dbias, yr.grad.sum((0, 2, 3)), 1e-4, 1e-4, 'dbias')
+
+
+def test_gn_relu_views():
+    """Destinations: skip slice of a concat buffer + 2x down-sampled copy; up-sampled slice.
+    Gradients gathered from the same views (modules/unet.py:78,86,89)."""
+    N, C, H, W = 2, 16, 8, 8
+    y = rnd(N, C, H, W, seed=12, scale=2.0)
+    gamma, beta = 1 + 0.3 * rnd(C, seed=13), 0.2 * rnd(C, seed=14)
+    yr = y.clone().requires_grad_()
+    a = F.relu(F.group_norm(yr, 8, gamma, beta, 1e-5))
+    cat = torch.cat([torch.zeros(N, 5, H, W), a], 1)
+    down = F.interpolate(a, scale_factor=0.5, mode='nearest')
+    up = F.interpolate(a, scale_factor=2.0, mode='nearest')
+    g_cat, g_down, g_up = rnd(N, 5 + C, H, W, seed=15), rnd(N, C, H // 2, W // 2, seed=16), rnd(N, C + 3, 2 * H, 2 * W, seed=17)
+    up_cat = torch.cat([up, torch.zeros(N, 3, 2 * H, 2 * W)], 1)
+    ((cat * g_cat).sum() + (down * g_down).sum()).backward(retain_graph=True)
+    grad_cd = yr.grad.clone()
+    yr.grad = None
+    (up_cat * g_up).sum().backward()
+    grad_up = yr.grad.clone()
+
+    yd, gd, bd = y.to(DEV), gamma.to(DEV), beta.to(DEV)
+    cat_d = torch.zeros(N, 5 + C, H, W, device=DEV)
+    down_d = torch.zeros(N, C, H // 2, W // 2, device=DEV)
+    mean, rstd = hip.gn_relu_fwd(yd, gd, bd, 8, 1e-5, (cat_d, 5, 0), (down_d, 0, 2))
+    close(cat_d, cat, 1e-5, 1e-5, 'cat')
+    close(down_d, down, 1e-5, 1e-5, 'down')
+    up_d = torch.zeros(N, C + 3, 2 * H, 2 * W, device=DEV)
+    hip.gn_relu_fwd(yd, gd, bd, 8, 1e-5, (up_d, 0, 1))
+    close(up_d, up_cat, 1e-5, 1e-5, 'up')
+    dy, _, _, _ = hip.gn_relu_bwd(yd, gd, bd, mean, rstd, 8, (g_cat.to(DEV), 5, 0), (g_down.to(DEV), 0, 2))
+    close(dy, grad_cd, 1e-4, 1e-5, 'dy(cat+down)')
+    dy, _, _, _ = hip.gn_relu_bwd(yd, gd, bd, mean, rstd, 8, (g_up.to(DEV), 0, 1))
+    close(dy, grad_up, 1e-4, 1e-5, 'dy(up)')
+
+
+def _icsbp_ref(colour, log_sigma, rand_pixel, K, kernel, seed_idx=None):
+    from oracle import v2_oracle as O
+    return O.ic_sbp(colour, log_sigma, K - 1, rand_pixel, kernel, seed_idx)
+
+
+@pytest.mark.parametrize('kernel', ['gaussian', 'laplacian', 'epanechnikov'])
+@pytest.mark.parametrize('B,S,K', [(3, 32, 4), (2, 64, 7), (1, 128, 11), (2, 16, 3)])
+def test_icsbp(kernel, B, S, K):
+    colour = rnd(B, 8, S, S, seed=18, scale=0.7)
+    colour[:, -2:] += torch.stack(torch.meshgrid(torch.linspace(-1, 1, S), torch.linspace(-1, 1, S), indexing='ij'))
+    rand_pixel = torch.rand(B, 1, S, S, generator=torch.Generator().manual_seed(19))
+    log_sigma = torch.tensor(1.0 / (K * np.log(2)), dtype=torch.float64).log()
+    cr = colour.clone().requires_grad_()
+    lsr = log_sigma.clone().requires_grad_()
+    log_m_k, log_s_k, seeds, idxs = _icsbp_ref(cr, lsr, rand_pixel, K, kernel)
+    g = rnd(K, B, 1, S, S, seed=20)
+    (torch.stack(log_m_k) * g).sum().backward()
+
+    cd, ld, rd = colour.to(DEV), log_sigma.to(DEV), rand_pixel.to(DEV)
+    log_m, log_s, seeds_d, idx_d = hip.icsbp_fwd(cd, ld, rd, K, kernel)
+    ref_idx = torch.stack(idxs)
+    if not torch.equal(idx_d.cpu(), ref_idx):
+        # near-tie in the discontinuous argmax: replay with the oracle's seeds
+        log_m, log_s, seeds_d, idx_d = hip.icsbp_fwd(cd, ld, rd, K, kernel, ref_idx.to(DEV))
+    close(log_m, torch.stack(log_m_k), 1e-5, 2e-5, 'log_m')
+    close(log_s, torch.stack(log_s_k), 1e-5, 2e-5, 'log_s')
+    close(seeds_d, torch.stack(seeds), 0, 0, 'seeds')
+    s = log_m.exp().sum(0)
+    assert float((s - 1).abs().max()) < 1e-3  # the reference's own invariant (utils/misc.py:258-270)
+    dcol, dls = hip.icsbp_bwd(cd, ld, seeds_d, idx_d, g.to(DEV), kernel)
+    close(dcol, cr.grad, 2e-4, 2e-4, 'dcolour')
+    close(dls, lsr.grad, 2e-4, 1e-5, 'dlog_sigma')
+
+
+def test_icsbp_forced_seed_and_first_max():
+    B, S, K = 2, 16, 3
+    colour = rnd(B, 8, S, S, seed=21)
+    rand_pixel = torch.full((B, 1, S, S), 0.5)  # all ties -> first pixel must win (torch.argmax semantics)
+    ls = torch.tensor(0.2, dtype=torch.float64).log()
+    _, _, _, idx = hip.icsbp_fwd(colour.to(DEV), ls.to(DEV), rand_pixel.to(DEV), K)
+    assert idx[0].tolist() == [0, 0]
+    forced = torch.tensor([[5, 7], [100, 3]], dtype=torch.int64)
+    _, _, seeds, idx = hip.icsbp_fwd(colour.to(DEV), ls.to(DEV), rand_pixel.to(DEV), K, 'gaussian', forced.to(DEV))
+    assert torch.equal(idx.cpu(), forced)
+    close(seeds[1, 0], colour.flatten(2)[0, :, 100], 0, 0)
+
+
+@pytest.mark.parametrize('B,C,S,K', [(2, 64, 64, 7), (3, 16, 32, 4), (1, 64, 128, 11), (2, 8, 32, 3)])
+def test_maskpool(B, C, S, K):
+    f = rnd(B, C, S, S, seed=22).relu()
+    log_m = torch.log_softmax(rnd(K, B, 1, S, S, seed=23, scale=3.0), 0)
+    fr, lr = f.clone().requires_grad_(), log_m.clone().requires_grad_()
+    m = lr.exp()
+    S_ref = torch.stack([(m[k] * fr).sum((2, 3)) for k in range(K)], 1)
+    ms_ref = torch.stack([m[k].sum((1, 2, 3)) for k in range(K)], 1)
+    gS, gms = rnd(B, K, C, seed=24), rnd(B, K, seed=25)
+    ((S_ref * gS).sum() + (ms_ref * gms).sum()).backward()
+    Sd, msd = hip.maskpool_fwd(f.to(DEV), log_m.to(DEV))
+    close(Sd, S_ref, 1e-5, 1e-5, 'S')
+    close(msd, ms_ref, 1e-5, 1e-5, 'msum')
+    df, dlm = hip.maskpool_bwd(f.to(DEV), log_m.to(DEV), gS.to(DEV), gms.to(DEV))
+    close(df, fr.grad, 1e-5, 1e-5, 'df')
+    close(dlm, lr.grad, 1e-5, 1e-5, 'dlog_m')
+
+
+@pytest.mark.parametrize('pixel_bound', [True, False])
+@pytest.mark.parametrize('B,S,K', [(2, 64, 7), (3, 32, 4), (1, 128, 11), (2, 8, 1)])
+def test_mixture(pixel_bound, B, S, K):
+    from oracle import v2_oracle as O
+    x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(26))
+    dec = rnd(K * B, 4, S, S, seed=27, scale=2.0)
+    dr = dec.clone().requires_grad_()
+    chunks = dr.chunk(K, 0)
+    x_r_k = [c[:, :3] for c in chunks]
+    if pixel_bound:
+        x_r_k = [torch.sigmoid(t) for t in x_r_k]
+    lm = torch.log_softmax(torch.stack([c[:, 3:] for c in chunks], 4), 4)
+    lm_k = [lm[..., k] for k in range(K)]
+    err_ref = O.x_loss(x, lm_k, x_r_k, 0.7)
+    recon_ref = (torch.stack(lm_k, 4).exp() * torch.stack(x_r_k, 4)).sum(4)
+    g = rnd(B, seed=28) + 1.5
+    (err_ref * g).sum().backward()
+    err, recon, x_r, log_m_r = hip.mixture_fwd(x.to(DEV), dec.to(DEV), K, 0.7, pixel_bound)
+    close(err, err_ref, 2e-6, 1e-3, 'err')
+    close(recon, recon_ref, 1e-5, 1e-5, 'recon')
+    close(x_r, torch.stack(x_r_k), 1e-5, 1e-5, 'x_r')
+    close(log_m_r, torch.stack(lm_k), 1e-5, 1e-5, 'log_m_r')
+    ddec = hip.mixture_bwd(x.to(DEV), dec.to(DEV), g.to(DEV), K, 0.7, pixel_bound)
+    close(ddec, dr.grad, 1e-4, 1e-5, 'ddec')
+
+
+@pytest.mark.parametrize('N,Cin,Cout,S,gated', [(2, 64, 8, 64, True), (3, 64, 4, 32, False), (2, 16, 8, 32, True),
+                                                (7, 64, 4, 64, False), (1, 64, 8, 128, True), (2, 8, 8, 8, False)])
+def test_conv1x1(N, Cin, Cout, S, gated):
+    x = rnd(N, Cin, S, S, seed=29)
+    w = rnd(Cout, Cin, 1, 1, seed=30, scale=0.2)
+    b = rnd(Cout, seed=31)
+    gate = torch.tensor(0.35) if gated else None
+    addend = rnd(Cout, S, S, seed=32) if gated else None
+    dy = rnd(N, Cout, S, S, seed=33)
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    gr = gate.clone().requires_grad_() if gated else None
+    y_ref = F.conv2d(xr, wr, br)
+    if gated:
+        y_ref = gr * y_ref + addend
+    y_ref.backward(dy)
+    to = lambda t: None if t is None else t.to(DEV)  # noqa: E731
+    y = hip.conv1x1_fwd(to(x), to(w), to(b), to(gate), to(addend))
+    close(y, y_ref, 1e-5, 1e-5, 'fwd')
+    dx, dw, db, dgate = hip.conv1x1_bwd(to(x), to(dy), to(w), to(b), to(gate))
+    close(dx, xr.grad, 1e-5, 1e-5, 'dx')
+    close(dw, wr.grad, 1e-4, 1e-4, 'dw')
+    close(db, br.grad, 1e-4, 1e-4, 'db')
+    if gated:
+        close(dgate, gr.grad, 1e-4, 1e-3, 'dgate')
+
+
+def test_no_cpu_fallback():
+    from genesis_amd._lib import GenesisHipError
+    with pytest.raises(GenesisHipError):
+        hip.conv3x3_fwd(torch.zeros(1, 3, 8, 8), torch.zeros(4, 3, 3, 3))
