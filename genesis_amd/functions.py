@@ -160,6 +160,10 @@ class ICSBPFn(torch.autograd.Function):
     def forward(ctx, feat, conv_w, conv_b, gate, uv, log_sigma, rand_pixel, K, kernel, seed_idx):
         feat = feat.contiguous()
         colour = hip.conv1x1_fwd(feat, conv_w, conv_b, gate, uv)
+        # the kernel takes the bandwidth as an fp64 device scalar (it is an fp64 parameter for the default
+        # kernel, modules/attention.py:150,155; fp32 only for epanechnikov)
+        ctx.ls_dtype = log_sigma.dtype
+        log_sigma = log_sigma.detach().to(torch.float64)
         log_m, log_s, seeds, idx = hip.icsbp_fwd(colour, log_sigma, rand_pixel.contiguous(), K, kernel, seed_idx)
         ctx.save_for_backward(feat, conv_w, conv_b, gate, log_sigma, colour, seeds, idx)
         ctx.kernel = kernel
@@ -171,7 +175,7 @@ class ICSBPFn(torch.autograd.Function):
         feat, conv_w, conv_b, gate, log_sigma, colour, seeds, idx = ctx.saved_tensors
         dcolour, dls = hip.icsbp_bwd(colour, log_sigma, seeds, idx, g_log_m.contiguous(), ctx.kernel)
         dfeat, dw, db, dgate = hip.conv1x1_bwd(feat, dcolour, conv_w, conv_b, gate)
-        return dfeat, dw, db, dgate, None, dls, None, None, None, None
+        return dfeat, dw, db, dgate, None, dls.to(ctx.ls_dtype), None, None, None, None
 
 
 class MaskPoolFn(torch.autograd.Function):

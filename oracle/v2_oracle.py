@@ -79,7 +79,7 @@ def semiconv(p, feat, img_size, semiconv_on=True, prefix='att_process.colour_hea
     delta = out[:, -2:]
     nout = out.size(1)
     uv = torch.cat((torch.zeros(1, nout - 2, img_size, img_size),
-                    pixel_coords(img_size)), dim=1)
+                    pixel_coords(img_size)), dim=1).to(out.dtype)
     return out + uv, delta
 
 
@@ -157,7 +157,7 @@ def decoder(p, z, img_size, prefix='decoder_module'):
     B = z.size(0)
     d = img_size // 16
     h = z.view(B, -1, 1, 1).expand(-1, -1, d, d)
-    coords = pixel_coords(d).expand(B, -1, -1, -1)
+    coords = pixel_coords(d).expand(B, -1, -1, -1).to(z.dtype)
     h = torch.cat((h, coords), dim=1)
     for conv_i, gn_i in ((1, 2), (4, 5), (7, 8), (10, 11)):
         h = F.conv_transpose2d(h, p['%s.%d.weight' % (prefix, conv_i)],
@@ -202,8 +202,8 @@ def mask_latent_loss(p, mu_k, sigma_k, z_k, autoreg_prior=True):
     if autoreg_prior and K > 1:
         seq = torch.stack(z_k[:-1], 0)  # [K-1,B,D]
         H = p['prior_lstm.weight_hh_l0'].size(1)
-        h = torch.zeros(B, H)
-        c = torch.zeros(B, H)
+        h = torch.zeros(B, H, dtype=seq.dtype)
+        c = torch.zeros(B, H, dtype=seq.dtype)
         outs = []
         for t in range(K - 1):
             gates = F.linear(seq[t], p['prior_lstm.weight_ih_l0'], p['prior_lstm.bias_ih_l0']) \
@@ -448,7 +448,8 @@ def param_shapes(cfg):
 
 
 def default_log_sigma(cfg):
-    """modules/attention.py:145-155: float64 0-dim log of the kernel bandwidth."""
+    """modules/attention.py:145-155: 0-dim log of the kernel bandwidth; float64 for the gaussian /
+    laplacian kernels (numpy scalars), float32 for epanechnikov (python float)."""
     import numpy as np
     K = cfg['K_steps']
     kern = cfg.get('kernel', 'gaussian')
@@ -458,14 +459,15 @@ def default_log_sigma(cfg):
         s = 1.0 / (K * np.log(2))
     elif kern == 'epanechnikov':
         s = 2.0 / K
+        return torch.tensor(float(s)).log()  # python float -> float32 parameter (attention.py:149)
     else:
         raise ValueError('No valid kernel.')
-    return torch.tensor(s).log()
+    return torch.tensor(s).log()  # numpy float64 -> float64 parameter
 
 
 def template_state_dict(cfg):
     sd = {}
     for name, (shape, dt) in param_shapes(cfg).items():
         sd[name] = torch.zeros(shape, dtype=dt)
-    sd['att_process.log_sigma'] = default_log_sigma(cfg).to(torch.float64)
+    sd['att_process.log_sigma'] = default_log_sigma(cfg)
     return sd

@@ -54,7 +54,8 @@ class Golden(object):
     def has(self, key):
         return ('out/' + key) in self.g.files or ('out/%s/n' % key) in self.g.files
 
-    def check_forward(self, recon, losses, stats, att, comp, rtol=1e-4, atol=1e-5):
+    def check_forward(self, recon, losses, stats, att, comp, rtol=1e-4, atol=1e-5, mask_atol=None):
+        mask_atol = atol if mask_atol is None else mask_atol
         st = lambda l: torch.stack(list(l))  # noqa: E731
         seed_idx = torch.stack([i.cpu() for i in att['seed_idx']]).numpy()
         np.testing.assert_array_equal(seed_idx, self.g['seed_idx'], err_msg='seed pixels')
@@ -63,8 +64,8 @@ class Golden(object):
         if 'kl_m' in losses:
             self.check('kl_m', losses['kl_m'], rtol, atol)
         self.check('recon', recon, rtol, atol)
-        self.check('log_m_k', st(stats['log_m_k']), rtol, atol)
-        self.check('log_s_k', st(stats['log_s_k']), rtol, atol)
+        self.check('log_m_k', st(stats['log_m_k']), rtol, mask_atol)
+        self.check('log_s_k', st(stats['log_s_k']), rtol, mask_atol)
         self.check('x_r_k', st(stats['x_r_k']), rtol, atol)
         self.check('log_m_r_k', st(stats['log_m_r_k']), rtol, atol)
         self.check('colour', att['colour'], rtol, atol)
@@ -74,16 +75,25 @@ class Golden(object):
         self.check('z_k', st(comp['z_k']), rtol, atol)
         assert int(stats['instance_seg'].sum().item()) == int(self.g['instance_seg_sum'])
 
-    def check_grads(self, named_grads, rtol=2e-3, atol_frac=1e-3):
-        """named_grads: iterable of (name, grad tensor) in state_dict order.  Tolerances are
-        relative to each tensor's own gradient scale (norm / sqrt(n))."""
+    def check_grads(self, named_grads, rtol=2e-3, l2_tol=1e-2):
+        """named_grads: iterable of (name, grad tensor) in state_dict order.
+
+        Gradients are compared in relative L2 (norm and strided samples), not element-wise: the ReLU
+        derivative is discontinuous, so one borderline pre-activation (|pre| ~ 1e-7, a handful among
+        the ~1e7 activations of a step) that flips sign between two correct fp32 implementations
+        perturbs every upstream gradient by ~1/sqrt(n) ~ 1e-4..1e-3 relative (measured on the GPU:
+        tools/diag_model_decoder.py; the CPU fp32 path shows the same effect against fp64).  The
+        per-kernel tests pin the arithmetic itself at 1e-5..1e-4."""
         norms = self.g['grad_norms']
         big = float(np.max(norms))  # floor for analytically-zero grads (pure cancellation noise)
         for i, (name, g) in enumerate(named_grads):
-            n = max(1, g.numel())
-            scale = float(norms[i]) / np.sqrt(n)
             got = float(g.double().norm().item())
             assert abs(got - float(norms[i])) <= rtol * float(norms[i]) + 2e-5 + 1e-6 * big, \
                 '%s grad norm %s: %r vs %r' % (self.name, name, got, float(norms[i]))
-            T.check_summary('grad/' + name, g, self.g, rtol, atol_frac * scale + 5e-6 + 1e-7 * big,
-                            self.name)
+            s = T.summarize(g)
+            ref = self.g['grad/%s/samples' % name].astype(np.float64)
+            assert int(self.g['grad/%s/n' % name]) == int(s['n']), name
+            diff = np.linalg.norm(s['samples'].astype(np.float64) - ref)
+            floor = (2e-5 + 1e-6 * big) * np.sqrt(len(ref) / max(1, int(s['n'])))
+            assert diff <= l2_tol * np.linalg.norm(ref) + floor, \
+                '%s grad %s: sample rel-L2 %.3e' % (self.name, name, diff / (np.linalg.norm(ref) + 1e-30))
