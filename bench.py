@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""bench.py -- training images/sec (fwd + bwd + GECO step + Adam) of GENESIS-V2 K=7 64x64 on N MI355X.
+
+    python bench.py --gpus 1 --steps 100 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one synthetic batch already resident in HBM: zero grads,
+GenesisV2.forward (HIP kernels), loss aggregation, GECO, backward (HIP kernels), [RCCL all-reduce of the
+flat gradient bucket], fused Adam.  Weak scaling: per-GPU batch fixed (default 32, train.py:48).
+Rank 0 prints ONE JSON line; besides the driver's contract it carries
+  roofline     -- the dominant kernel's achieved rate from HIP events recorded around every launch of it
+                  during extra profiled steps in this same process (gx_profile_*), vs the gfx950 peak;
+  cpu_baseline -- the oracle (CPU restatement of the reference, reference-equivalent form) timed on this
+                  host's cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# algorithmic work per image, fwd+bwd (feat_head counted once)
+FLOP_PER_IMG = {(7, 64): 11.02e9, (5, 64): 9.34e9, (11, 128): 56.55e9}
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=32, help='per-GPU batch (train.py:48 default 32)')
+    ap.add_argument('--K', type=int, default=7)
+    ap.add_argument('--img', type=int, default=64)
+    ap.add_argument('--feat_dim', type=int, default=64)
+    ap.add_argument('--no-graph', action='store_true', help='eager launches instead of HIP-graph replay')
+    ap.add_argument('--profile-steps', type=int, default=3)
+    ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU baseline leg (0 = skip)')
+    return ap.parse_args()
+
+
+def build_model(args, device):
+    import genesis_amd.genesisv2_config as G
+    from genesis_amd.compat.attrdict import AttrDict
+    cfg = AttrDict(K_steps=args.K, img_size=args.img, feat_dim=args.feat_dim, kernel='gaussian', semiconv=True,
+                   dynamic_K=False, klm_loss=False, detach_mr_in_klm=True, pixel_bound=True, autoreg_prior=True,
+                   pixel_std1=0.7, pixel_std2=0.7, debug=False, multi_gpu=False)
+    torch.manual_seed(0)
+    return G.load(cfg).to(device).train()
+
+
+def cpu_baseline(args):
+    """Oracle (reference-equivalent form: per-slot loops, K-fold feat_head) full training step on host cores."""
+    from oracle import v2_oracle as O
+    cfg = O.make_cfg(K_steps=args.K, img_size=args.img, feat_dim=args.feat_dim)
+    torch.manual_seed(0)
+    sd = O.template_state_dict(cfg)
+    p = {}
+    for k, v in sd.items():
+        if v.dim() >= 2:
+            fan_in = v[0].numel()
+            t = (torch.rand_like(v) * 2 - 1) / fan_in ** 0.5
+        elif k.endswith('log_sigma'):
+            t = v.clone()
+        elif k.endswith('.bias') or 'bias_' in k or k.endswith('gate.gate'):
+            t = torch.zeros_like(v)
+        else:
+            t = torch.ones_like(v)
+        p[k] = t.requires_grad_(True)
+    opt = torch.optim.Adam(list(p.values()), 1e-4)
+    geco = O.make_geco(args.img)
+    x = torch.rand(args.batch, 3, args.img, args.img, generator=torch.Generator().manual_seed(1234))
+    cores = torch.get_num_threads()
+    O.train_step(p, opt, geco, x, cfg)          # warm-up
+    t0 = time.time()
+    n = 0
+    while True:
+        O.train_step(p, opt, geco, x, cfg)
+        n += 1
+        if time.time() - t0 >= args.cpu_seconds or n >= 8:
+            break
+    dt = time.time() - t0
+    return {'value': args.batch * n / dt, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': '%d timed steps (+1 warm-up) of the full training step, batch %d, K=%d, %dx%d, oracle in '
+                      'reference-equivalent form (per-slot loops, K-fold feat_head), torch CPU fp32, %d threads'
+                      % (n, args.batch, args.K, args.img, args.img, cores)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        dist.init_process_group('nccl', init_method='env://')
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+
+    from genesis_amd.trainer import TrainStep
+    from genesis_amd import profiling
+    model = build_model(args, device)
+    ts = TrainStep(model, args.img, lr=1e-4, graph=(world == 1 and not args.no_graph))
+    g = torch.Generator().manual_seed(1234 + rank)
+    batches = [torch.rand(args.batch, 3, args.img, args.img, generator=g).to(device) for _ in range(4)]
+
+    for i in range(args.warmup):
+        ts.step(batches[i % 4])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = ts.step(batches[i % 4])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    elbo = float(out[0])
+
+    result = None
+    if rank == 0:
+        value = world * args.batch * args.steps / dt
+        flop_img = FLOP_PER_IMG.get((args.K, args.img))
+        result = {
+            'metric': 'training images/sec (fwd+bwd+GECO step), GENESIS-V2 K=%d %dx%d' % (args.K, args.img, args.img),
+            'value': value, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'GENESIS-V2 (genesisv2_config) K=%d, %dx%dx3 synthetic uniform batches, '
+                                   'feat_dim %d, per-GPU batch %d, GECO + Adam(1e-4), random-init weights'
+                                   % (args.K, args.img, args.img, args.feat_dim, args.batch),
+                       'global_batch': world * args.batch, 'per_gpu_batch': args.batch,
+                       'parallelism': 'dp%d' % world, 'launch': 'hip-graph' if ts.graph is not None else 'eager'},
+            'final_elbo': elbo,
+        }
+        if flop_img:
+            result['step_fraction_of_fp32_mfma_peak'] = value / world * flop_img / (PEAK_FP32_MFMA_TFLOPS * 1e12)
+
+    # ---- roofline leg: HIP events around every kernel launch, eager steps, same process (rank 0)
+    if rank == 0 and args.profile_steps > 0 and world == 1:
+        ts.use_graph = False
+        ts._iteration(batches[0])  # eager warm-up after graph mode
+        torch.cuda.synchronize()
+        profiling.enable(True)
+        for i in range(args.profile_steps):
+            ts._iteration(batches[i % 4])
+        torch.cuda.synchronize()
+        rows = profiling.collect()
+        profiling.enable(False)
+        total_ms = sum(r['ms'] for r in rows)
+        rows.sort(key=lambda r: -r['ms'])
+        table = []
+        for r in rows:
+            sec = r['ms'] * 1e-3
+            table.append({'kernel': r['name'], 'launches_per_step': r['launches'] / args.profile_steps,
+                          'avg_us': 1e3 * r['ms'] / r['launches'], 'share': r['ms'] / total_ms,
+                          'tflops': r['flops'] / sec / 1e12 if r['flops'] else None,
+                          'gbs': r['bytes'] / sec / 1e9})
+        dom = rows[0]
+        sec = dom['ms'] * 1e-3
+        if dom['flops'] > 0:
+            ach = dom['flops'] / sec / 1e12
+            roof = {'bound': 'mfma', 'kernel': dom['name'], 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS,
+                    'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_MFMA_TFLOPS}
+        else:
+            ach = dom['bytes'] / sec / 1e9
+            roof = {'bound': 'hbm', 'kernel': dom['name'], 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                    'frac': ach / PEAK_HBM_GBS}
+        roof.update({'traffic': None, 'avg_launch_us': 1e3 * dom['ms'] / dom['launches'],
+                     'launches_per_step': dom['launches'] / args.profile_steps,
+                     'share_of_kernel_time': dom['ms'] / total_ms,
+                     'kernel_ms_per_step': total_ms / args.profile_steps})
+        result['roofline'] = roof
+        result['kernels'] = table[:12]
+
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        result['cpu_baseline'] = cpu_baseline(args)
+        result['speedup_vs_cpu_baseline'] = result['value'] / result['cpu_baseline']['value']
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -6,6 +6,10 @@ import os
 import os.path as osp
 import re
 
+# torch bundles its own libamdhip64.so.7; import it FIRST so that libgenesis_hip.so (same SONAME dependency)
+# binds to the HIP runtime torch's streams and allocations live in, not to a second copy from /opt/rocm.
+import torch  # noqa: F401
+
 _HERE = osp.dirname(osp.abspath(__file__))
 LIB_PATH = osp.join(_HERE, 'libgenesis_hip.so')
 HEADER_PATH = osp.join(osp.dirname(_HERE), 'include', 'genesis_hip.h')

@@ -2,6 +2,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <vector>
+
 #include "gx_common.h"
 
 static thread_local char g_err[512] = "";
@@ -13,7 +15,62 @@ void gx_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+bool g_gx_prof_on = false;
+
+namespace {
+struct ProfEntry { int kid; hipEvent_t a, b; double flops, bytes; };
+std::vector<ProfEntry> g_entries;
+const char* const kKernelNames[KID_COUNT] = {
+    "tapconv_kernel<0>", "tapconv_kernel<1>", "tapconv_kernel<2>", "tapconv_kernel<3>", "pack_weights_kernel",
+    "wgrad_kernel<0>", "wgrad_kernel<1>", "wgrad_kernel<2>", "wgrad_kernel<3>", "wgrad_kernel<4>",
+    "wgrad_reduce_kernel", "gn_relu_fwd_kernel", "gn_relu_bwd_kernel", "gn_param_reduce_kernel",
+    "icsbp_fwd_kernel", "icsbp_bwd_kernel", "maskpool_fwd_kernel", "maskpool_bwd_kernel",
+    "mixture_kernel<false>", "mixture_kernel<true>", "conv1x1_fwd_kernel", "conv1x1_dgrad_kernel",
+    "conv1x1_wgrad_kernel", "small_reduce_kernels", "adam_kernel", "geco_update_kernel", "splitk_reduce_kernel"};
+}  // namespace
+
+void gx_prof_begin(int kid, hipStream_t s, double flops, double bytes) {
+    ProfEntry e;
+    e.kid = kid; e.flops = flops; e.bytes = bytes;
+    (void)hipEventCreate(&e.a);
+    (void)hipEventCreate(&e.b);
+    (void)hipEventRecord(e.a, s);
+    g_entries.push_back(e);
+}
+
+void gx_prof_end(hipStream_t s) {
+    if (!g_entries.empty()) (void)hipEventRecord(g_entries.back().b, s);
+}
+
 extern "C" {
+int gx_profile_enable(int on) {
+    g_gx_prof_on = on != 0;
+    return GX_OK;
+}
+
+int gx_profile_num_kernels(void) { return KID_COUNT; }
+
+const char* gx_profile_kernel_name(int kid) { return (kid >= 0 && kid < KID_COUNT) ? kKernelNames[kid] : ""; }
+
+/* Waits for the recorded events, ACCUMULATES per kernel id into the caller's arrays (each of length
+ * gx_profile_num_kernels()) and clears the record list. */
+int gx_profile_collect(double* total_ms, double* launches, double* flops, double* bytes) {
+    GX_CHECK_ARG(total_ms && launches && flops && bytes, "gx_profile_collect: null pointer");
+    for (ProfEntry& e : g_entries) {
+        float ms = 0.f;
+        if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            total_ms[e.kid] += ms;
+            launches[e.kid] += 1.0;
+            flops[e.kid] += e.flops;
+            bytes[e.kid] += e.bytes;
+        }
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    g_entries.clear();
+    return GX_OK;
+}
+
 const char* gx_last_error(void) { return g_err; }
 int gx_version(void) { return 1; }
 }

@@ -261,8 +261,12 @@ int gx_icsbp_fwd(const float* colour, const double* log_sigma, const float* rand
     GX_CHECK_ARG(B > 0 && C > 0 && C <= MAXC && K >= 1 && K <= 17, "gx_icsbp_fwd: bad B/C/K (C<=8, K<=17)");
     GX_CHECK_ARG(gx_is_pow2(HW) && HW >= 64 && HW <= 1024 * MAXPPT, "gx_icsbp_fwd: H*W must be a power of two in [64,16384]");
     GX_CHECK_ARG(kernel_type >= 0 && kernel_type <= 2, "gx_icsbp_fwd: no valid kernel");
-    hipLaunchKernelGGL(icsbp_fwd_kernel, dim3(B), dim3(threads_for(HW)), HW * sizeof(float), (hipStream_t)stream, colour, log_sigma,
-                       rand_pixel, seed_idx_in, B, C, HW, K, kernel_type, log_m, log_s, seeds, seed_idx_out);
+    {
+        GxProf pf(KID_ICSBP_FWD, (hipStream_t)stream, 0.0, 4.0 * B * HW * (C + 1.0 + 2.0 * K));
+        hipLaunchKernelGGL(icsbp_fwd_kernel, dim3(B), dim3(threads_for(HW)), HW * sizeof(float), (hipStream_t)stream,
+                           colour, log_sigma, rand_pixel, seed_idx_in, B, C, HW, K, kernel_type, log_m, log_s, seeds,
+                           seed_idx_out);
+    }
     GX_CHECK_LAUNCH("gx_icsbp_fwd");
     return GX_OK;
 }
@@ -280,10 +284,16 @@ int gx_icsbp_bwd(const float* colour, const double* log_sigma, const float* seed
     GX_CHECK_ARG(kernel_type >= 0 && kernel_type <= 2, "gx_icsbp_bwd: no valid kernel");
     GX_CHECK_ARG(ws_bytes >= gx_icsbp_bwd_ws_bytes(B), "gx_icsbp_bwd: workspace too small");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(icsbp_bwd_kernel, dim3(B), dim3(threads_for(HW)), HW * sizeof(float), s, colour, log_sigma, seeds, seed_idx,
-                       g_log_m, B, C, HW, K, kernel_type, dcolour, (double*)ws);
+    {
+        GxProf pf(KID_ICSBP_BWD, s, 0.0, 4.0 * B * HW * (2.0 * C + K));
+        hipLaunchKernelGGL(icsbp_bwd_kernel, dim3(B), dim3(threads_for(HW)), HW * sizeof(float), s, colour, log_sigma,
+                           seeds, seed_idx, g_log_m, B, C, HW, K, kernel_type, dcolour, (double*)ws);
+    }
     GX_CHECK_LAUNCH("gx_icsbp_bwd");
-    hipLaunchKernelGGL(sum_double_kernel, dim3(1), dim3(64), 0, s, (const double*)ws, B, dlog_sigma);
+    {
+        GxProf pf(KID_SMALL_REDUCE, s, 0.0, 8.0 * B);
+        hipLaunchKernelGGL(sum_double_kernel, dim3(1), dim3(64), 0, s, (const double*)ws, B, dlog_sigma);
+    }
     GX_CHECK_LAUNCH("gx_icsbp_bwd(reduce)");
     return GX_OK;
 }

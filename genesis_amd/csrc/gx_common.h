@@ -26,6 +26,26 @@ void gx_set_error(const char* fmt, ...);
         }                                                                       \
     } while (0)
 
+// ---- per-kernel live profiling (HIP events on the launch stream; off unless gx_profile_enable(1)) ----
+enum GxKernelId {
+    KID_TAPCONV_C3 = 0, KID_TAPCONV_DT0, KID_TAPCONV_DT1, KID_TAPCONV_DG, KID_PACK_WEIGHTS,
+    KID_WGRAD_C3, KID_WGRAD_D00, KID_WGRAD_D01, KID_WGRAD_D10, KID_WGRAD_D11, KID_WGRAD_REDUCE,
+    KID_GN_FWD, KID_GN_BWD, KID_GN_PARAM_REDUCE, KID_ICSBP_FWD, KID_ICSBP_BWD, KID_MASKPOOL_FWD,
+    KID_MASKPOOL_BWD, KID_MIXTURE_FWD, KID_MIXTURE_BWD, KID_CONV1X1_FWD, KID_CONV1X1_DGRAD,
+    KID_CONV1X1_WGRAD, KID_SMALL_REDUCE, KID_ADAM, KID_GECO, KID_SPLITK_REDUCE, KID_COUNT
+};
+extern bool g_gx_prof_on;
+void gx_prof_begin(int kid, hipStream_t s, double flops, double bytes);
+void gx_prof_end(hipStream_t s);
+// RAII: brackets ONE kernel launch with two events when profiling is on; a flag test otherwise.
+struct GxProf {
+    hipStream_t s; bool on;
+    GxProf(int kid, hipStream_t s_, double flops, double bytes) : s(s_), on(g_gx_prof_on) {
+        if (on) gx_prof_begin(kid, s, flops, bytes);
+    }
+    ~GxProf() { if (on) gx_prof_end(s); }
+};
+
 static inline int gx_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static inline int gx_ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int gx_round_up(int a, int b) { return gx_ceil_div(a, b) * b; }

@@ -17,6 +17,10 @@
 //   K = KC input channels per staged chunk x NT taps.  The input halo tile is staged ONCE
 //   per chunk and re-used by all NT taps from LDS (9-25x re-use); each wave owns a
 //   64(M) x 64(N) sub-tile = 2x2 MFMA 32x32 accumulators (per output parity class).
+//   The chunk loop is software-pipelined: chunk c+1 is prefetched global->registers while chunk c's
+//   MFMAs run out of a double-buffered LDS tile (one barrier per chunk).  Layers with too few
+//   (pixel-tile x channel-tile) workgroups to fill 256 CUs split the channel reduction over
+//   gridDim.z and a small deterministic reduce kernel sums the partial outputs.
 // Weight-gradient kernels (wgrad) use the transposed mapping M = Cout, N = Cin, K = pixels
 // with deterministic split-K partials + a reduce kernel.
 //
@@ -39,14 +43,14 @@ template <> struct TapCfg<M_C3> {
 // ConvTranspose k5 s2 p2 op1: out[2r+a][2c+b] += x[r+dr][c+dc] * W[kh][kw] with kh = a (mod 2),
 // dr = (a+2-kh)/2, i.e. halo row offset ro = dr+1 = 2 - kh/2 (same for columns).
 template <> struct TapCfg<M_DT0> {
-    static constexpr int NT = 15, NCLS = 2, KC = 8, PLANES = 1;
+    static constexpr int NT = 15, NCLS = 2, KC = 4, PLANES = 1;
     __host__ __device__ static constexpr int ro(int t) { return 2 - t / 5; }        // kh = 2*(t/5)
     __host__ __device__ static constexpr int co(int t) { return 2 - (t % 5) / 2; }  // kw = t%5
     __host__ __device__ static constexpr int cls(int t) { return (t % 5) & 1; }
     __host__ __device__ static constexpr int plane(int) { return 0; }
 };
 template <> struct TapCfg<M_DT1> {
-    static constexpr int NT = 10, NCLS = 2, KC = 8, PLANES = 1;
+    static constexpr int NT = 10, NCLS = 2, KC = 4, PLANES = 1;
     __host__ __device__ static constexpr int ro(int t) { return 2 - t / 5; }        // kh = 2*(t/5)+1
     __host__ __device__ static constexpr int co(int t) { return 2 - (t % 5) / 2; }
     __host__ __device__ static constexpr int cls(int t) { return (t % 5) & 1; }
@@ -55,7 +59,7 @@ template <> struct TapCfg<M_DT1> {
 // dgrad of the deconv: dx[r][c] = sum dy[2r-2+kh][2c-2+kw] W[kh][kw]; plane = (kh&1, kw&1),
 // in-plane offset (kh/2, kw/2).
 template <> struct TapCfg<M_DG> {
-    static constexpr int NT = 25, NCLS = 1, KC = 4, PLANES = 4;
+    static constexpr int NT = 25, NCLS = 1, KC = 2, PLANES = 4;
     __host__ __device__ static constexpr int ro(int t) { return (t / 5) / 2; }
     __host__ __device__ static constexpr int co(int t) { return (t % 5) / 2; }
     __host__ __device__ static constexpr int cls(int) { return 0; }
@@ -73,18 +77,18 @@ struct ConvGeom {
     int lTH, lTW, lG; // log2 of tile rows / cols / images per tile
     int tiles_h, tiles_w;
     int par_a;        // deconv fwd: output row parity handled by this launch
+    int nsplit;       // split of the channel reduction over gridDim.z (partials written when > 1)
+    int chunks_per_split;
 };
 
-// halo-tile positions staged per thread per channel (tile <= MAXPOS*256 floats / channel)
-template <int MODE> struct MaxPos { static constexpr int V = (MODE == M_DG) ? 16 : 8; };
-
-template <int MODE>
+// NPOS = halo-tile positions staged per thread per channel (tile <= NPOS*256 floats per channel).
+template <int MODE, int NPOS>
 __global__ void __launch_bounds__(256, 2)
 tapconv_kernel(const float* __restrict__ in, const float* __restrict__ wp,
                const float* __restrict__ bias, float* __restrict__ out, ConvGeom g) {
     using TC = TapCfg<MODE>;
     constexpr int NT = TC::NT, NCLS = TC::NCLS, KC = TC::KC, PLANES = TC::PLANES;
-    constexpr int MAXPOS = MaxPos<MODE>::V;
+    constexpr int NW4 = (NT * KC * 16 + 255) / 256;   // float4 weight loads per thread per chunk
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x;
@@ -94,8 +98,7 @@ tapconv_kernel(const float* __restrict__ in, const float* __restrict__ wp,
     const int HS = TW + 2;                         // halo row stride
     const int PLS = G * (TH + 2) * HS;             // one plane of the halo tile
     const int CHS = PLANES * PLS;                  // per-channel LDS stride
-    float* in_tile = lds;                          // [KC][CHS]
-    float* w_tile = lds + KC * CHS;                // [NT][KC][64]
+    const int BUF = KC * CHS + NT * KC * 64;       // floats per pipeline stage: [KC][CHS] input + [NT][KC][64] weights
 
     // ---- which tile ----
     int tile = blockIdx.x;
@@ -110,9 +113,9 @@ tapconv_kernel(const float* __restrict__ in, const float* __restrict__ wp,
     const int HiWi = g.Hi * g.Wi;
 
     // ---- per-thread staging positions (computed once; only the channel term changes) ----
-    int goff[MAXPOS];
+    int goff[NPOS];
 #pragma unroll
-    for (int q = 0; q < MAXPOS; ++q) {
+    for (int q = 0; q < NPOS; ++q) {
         const int pos = tid + q * 256;
         int off = -1;
         if (pos < CHS) {
@@ -137,7 +140,7 @@ tapconv_kernel(const float* __restrict__ in, const float* __restrict__ wp,
 
     // ---- per-lane fragment offsets ----
     // A (weights): lane -> w_tile[t][2kk + (lane>>5)][mi*32 + (lane&31)]
-    const int a_off = (lane >> 5) * 64 + (lane & 31);
+    const int a_off = KC * CHS + (lane >> 5) * 64 + (lane & 31);
     // B (input):   lane -> in_tile[2kk + (lane>>5)][plane][halo(pixel) + tap]
     int b_off[2];
 #pragma unroll
@@ -159,48 +162,71 @@ tapconv_kernel(const float* __restrict__ in, const float* __restrict__ wp,
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[c][i][j][e] = 0.f;
 
-    for (int ch0 = 0; ch0 < g.Kpad; ch0 += KC) {
-        __syncthreads();
-        // stage the halo tile of KC channels
-#pragma unroll
-        for (int ch = 0; ch < KC; ++ch) {
-            const bool chv = (ch0 + ch) < g.K;
-            const float* src = in_blk + (size_t)(ch0 + ch) * HiWi;
-#pragma unroll
-            for (int q = 0; q < MAXPOS; ++q) {
-                const int pos = tid + q * 256;
-                if (pos < CHS) {
-                    float v = 0.f;
-                    if (chv && goff[q] >= 0) v = src[goff[q]];
-                    in_tile[ch * CHS + pos] = v;
-                }
-            }
-        }
-        // stage the weight slab: w_tile[t][kc][0..63] <- Wp[t][ch0+kc][m0..m0+63]
-        for (int i4 = tid; i4 < NT * KC * 16; i4 += 256) {
-            const int q = i4 & 15;
-            const int kc = (i4 >> 4) & (KC - 1);
-            const int t = i4 / (16 * KC);
-            const float4 v = *reinterpret_cast<const float4*>(
-                wp + ((size_t)t * g.Kpad + ch0 + kc) * g.Mpad + m0 + q * 4);
-            *reinterpret_cast<float4*>(w_tile + (t * KC + kc) * 64 + q * 4) = v;
-        }
-        __syncthreads();
+    // ---- software pipeline over channel chunks ----
+    float xin[KC][NPOS];
+    f32x4 wreg[NW4];
+    const int nchunks = g.Kpad / KC;
+    const int c_begin = blockIdx.z * g.chunks_per_split;
+    int c_end = c_begin + g.chunks_per_split;
+    if (c_end > nchunks) c_end = nchunks;
 
+// (macros, not lambdas: capturing the register arrays by reference sends them to scratch)
+#define GX_TAP_PREFETCH(chunk)                                                                              \
+    {                                                                                                       \
+        const int ch0_ = (chunk) * KC;                                                                      \
+        _Pragma("unroll") for (int ch = 0; ch < KC; ++ch) {                                                 \
+            const bool chv = (ch0_ + ch) < g.K;                                                             \
+            const float* src = in_blk + (size_t)(ch0_ + ch) * HiWi;                                         \
+            _Pragma("unroll") for (int q = 0; q < NPOS; ++q) {                                              \
+                float v = 0.f;                                                                              \
+                if (chv && goff[q] >= 0) v = src[goff[q]];                                                  \
+                xin[ch][q] = v;                                                                             \
+            }                                                                                               \
+        }                                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < NW4; ++i) {                                                   \
+            const int i4 = tid + i * 256;                                                                   \
+            if (i4 < NT * KC * 16) {                                                                        \
+                const int q4 = i4 & 15;                                                                     \
+                const int kc = (i4 >> 4) & (KC - 1);                                                        \
+                const int t_ = i4 / (16 * KC);                                                              \
+                wreg[i] = *reinterpret_cast<const f32x4*>(wp + ((size_t)t_ * g.Kpad + ch0_ + kc) * g.Mpad +  \
+                                                          m0 + q4 * 4);                                     \
+            }                                                                                               \
+        }                                                                                                   \
+    }
+#define GX_TAP_COMMIT(buf)                                                                                  \
+    {                                                                                                       \
+        _Pragma("unroll") for (int ch = 0; ch < KC; ++ch)                                                   \
+            _Pragma("unroll") for (int q = 0; q < NPOS; ++q) {                                              \
+                const int pos = tid + q * 256;                                                              \
+                if (pos < CHS) (buf)[ch * CHS + pos] = xin[ch][q];                                          \
+            }                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < NW4; ++i) {                                                   \
+            const int i4 = tid + i * 256;                                                                   \
+            if (i4 < NT * KC * 16) *reinterpret_cast<f32x4*>((buf) + KC * CHS + i4 * 4) = wreg[i];          \
+        }                                                                                                   \
+    }
+
+    if (c_begin < c_end) GX_TAP_PREFETCH(c_begin)
+    for (int c = c_begin; c < c_end; ++c) {
+        float* buf = lds + ((c - c_begin) & 1) * BUF;
+        GX_TAP_COMMIT(buf)
+        __syncthreads();
+        if (c + 1 < c_end) GX_TAP_PREFETCH(c + 1)
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int toff = TC::plane(t) * PLS + TC::ro(t) * HS + TC::co(t);
 #pragma unroll
             for (int kk = 0; kk < KC / 2; ++kk) {
-                const float a0 = w_tile[(t * KC + 2 * kk) * 64 + a_off];
-                const float a1 = w_tile[(t * KC + 2 * kk) * 64 + a_off + 32];
-                const float b0 = in_tile[2 * kk * CHS + b_off[0] + toff];
-                const float b1 = in_tile[2 * kk * CHS + b_off[1] + toff];
-                const int c = TC::cls(t);
-                acc[c][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[c][0][0], 0, 0, 0);
-                acc[c][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[c][0][1], 0, 0, 0);
-                acc[c][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[c][1][0], 0, 0, 0);
-                acc[c][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[c][1][1], 0, 0, 0);
+                const float a0 = buf[(t * KC + 2 * kk) * 64 + a_off];
+                const float a1 = buf[(t * KC + 2 * kk) * 64 + a_off + 32];
+                const float b0 = buf[2 * kk * CHS + b_off[0] + toff];
+                const float b1 = buf[2 * kk * CHS + b_off[1] + toff];
+                const int cl = TC::cls(t);
+                acc[cl][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[cl][0][0], 0, 0, 0);
+                acc[cl][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[cl][0][1], 0, 0, 0);
+                acc[cl][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[cl][1][0], 0, 0, 0);
+                acc[cl][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[cl][1][1], 0, 0, 0);
             }
         }
     }
@@ -208,6 +234,8 @@ tapconv_kernel(const float* __restrict__ in, const float* __restrict__ wp,
     // ---- epilogue: C/D layout col = lane&31 (pixel), row = (reg&3)+8*(reg>>2)+4*(lane>>5) (channel) ----
     const size_t out_img_stride = (size_t)g.M * g.Ho * g.Wo;
     const int HoWo = g.Ho * g.Wo;
+    float* outz = out + (size_t)blockIdx.z * g.N * out_img_stride;   // partial slab when nsplit > 1
+    const bool add_bias = bias != nullptr && g.nsplit == 1;
 #pragma unroll
     for (int nj = 0; nj < 2; ++nj) {
         const int p = wave * 64 + nj * 32 + (lane & 31);
@@ -219,14 +247,14 @@ tapconv_kernel(const float* __restrict__ in, const float* __restrict__ wp,
         int orow, ocol;
         if (NCLS == 2) { orow = 2 * (R0 + r) + g.par_a; ocol = 2 * (C0 + c); }
         else { orow = R0 + r; ocol = C0 + c; }
-        float* obase = out + (size_t)n * out_img_stride + (size_t)orow * g.Wo + ocol;
+        float* obase = outz + (size_t)n * out_img_stride + (size_t)orow * g.Wo + ocol;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int m = m0 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
                 if (m < g.M) {
-                    const float bv = bias ? bias[m] : 0.f;
+                    const float bv = add_bias ? bias[m] : 0.f;
                     if (NCLS == 2) {
                         float2 v;
                         v.x = acc[0][mi][nj][reg] + bv;
@@ -238,6 +266,24 @@ tapconv_kernel(const float* __restrict__ in, const float* __restrict__ wp,
                 }
             }
         }
+    }
+}
+
+// out[i] = sum_z part[z][i] (+ bias[channel]); fixed summation order.
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                     float* __restrict__ out, size_t total, int nsplit, int M, int HoWo) {
+    const size_t n4 = total >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 s = reinterpret_cast<const float4*>(part)[i];
+        for (int z = 1; z < nsplit; ++z) {
+            const float4 v = reinterpret_cast<const float4*>(part + (size_t)z * total)[i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        if (bias) {
+            const float b = bias[((i * 4) / HoWo) % M];   // HoWo is a multiple of 4
+            s.x += b; s.y += b; s.z += b; s.w += b;
+        }
+        reinterpret_cast<float4*>(out)[i] = s;
     }
 }
 
@@ -439,37 +485,105 @@ void pick_tile(int Hb, int Wb, int npix, int* lTH, int* lTW, int* lG) {
     *lTH = ilog2(TH); *lTW = ilog2(TW); *lG = ilog2(G);
 }
 
-template <int MODE>
-int launch_tapconv(const float* in, const float* wp, const float* bias, float* out, int N, int K, int M,
-                   int Hb, int Wb, int Hi, int Wi, int Ho, int Wo, int par_a, hipStream_t s, const char* name) {
-    using TC = TapCfg<MODE>;
+struct TapPlan {
     ConvGeom g;
+    int npos;          // template NPOS to use
+    size_t lds_bytes;
+    size_t out_elems;  // N*M*Ho*Wo
+    dim3 grid;
+};
+
+template <int MODE>
+int plan_tapconv(int N, int K, int M, int Mpad_pack, int Hb, int Wb, int Hi, int Wi, int Ho, int Wo, int par_a,
+                 TapPlan* pl, const char* name) {
+    using TC = TapCfg<MODE>;
+    ConvGeom& g = pl->g;
     g.N = N; g.K = K; g.M = M;
-    g.Kpad = gx_round_up(K, 8); g.Mpad = gx_round_up(M, 64);
+    g.Kpad = gx_round_up(K, 8); g.Mpad = Mpad_pack;
     g.Hb = Hb; g.Wb = Wb; g.Hi = Hi; g.Wi = Wi; g.Ho = Ho; g.Wo = Wo; g.par_a = par_a;
     pick_tile(Hb, Wb, 256, &g.lTH, &g.lTW, &g.lG);
     const int TH = 1 << g.lTH, TW = 1 << g.lTW, G = 1 << g.lG;
     g.tiles_h = Hb / TH; g.tiles_w = Wb / TW;
     const int CHS = TC::PLANES * G * (TH + 2) * (TW + 2);
-    if (CHS > MaxPos<MODE>::V * 256) { gx_set_error("%s: halo tile too large (%d)", name, CHS); return GX_EINVAL; }
-    const size_t lds = (size_t)(TC::KC * CHS + TC::NT * TC::KC * 64) * sizeof(float);
-    if (lds > 160 * 1024) { gx_set_error("%s: LDS %zu > 160KiB", name, lds); return GX_EINVAL; }
-    static bool attr_set[4] = {false, false, false, false};
-    if (!attr_set[MODE]) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_kernel<MODE>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set[MODE] = true;
+    const int need = gx_ceil_div(CHS, 256);
+    const int lo = (MODE == M_DG) ? 8 : 2;
+    pl->npos = need <= lo ? lo : 2 * lo;
+    if (need > 2 * lo) { gx_set_error("%s: halo tile too large (%d floats/channel)", name, CHS); return GX_EINVAL; }
+    pl->lds_bytes = (size_t)2 * (TC::KC * CHS + TC::NT * TC::KC * 64) * sizeof(float);
+    if (pl->lds_bytes > 160 * 1024) { gx_set_error("%s: LDS %zu > 160KiB", name, pl->lds_bytes); return GX_EINVAL; }
+    const int ptiles = g.tiles_h * g.tiles_w * gx_ceil_div(N, G);
+    const int mtiles = gx_ceil_div(M, 64);
+    const int nchunks = g.Kpad / TC::KC;
+    // split the channel reduction when the (pixel-tile x channel-tile) grid cannot fill 256 CUs x 2
+    int nsplit = 1;
+    const int base = ptiles * mtiles;
+    if (base < 384) {
+        nsplit = gx_ceil_div(512, base);
+        const int max_split = nchunks / 2 > 0 ? nchunks / 2 : 1;   // at least 2 chunks per split
+        if (nsplit > max_split) nsplit = max_split;
+        if (nsplit > 64) nsplit = 64;
+        if (nsplit < 1) nsplit = 1;
     }
-    dim3 grid(g.tiles_h * g.tiles_w * gx_ceil_div(N, G), g.Mpad / 64);
-    hipLaunchKernelGGL(tapconv_kernel<MODE>, grid, dim3(256), lds, s, in, wp, bias, out, g);
+    g.chunks_per_split = gx_ceil_div(nchunks, nsplit);
+    nsplit = gx_ceil_div(nchunks, g.chunks_per_split);
+    g.nsplit = nsplit;
+    pl->out_elems = (size_t)N * M * Ho * Wo;
+    pl->grid = dim3(ptiles, mtiles, nsplit);
+    return GX_OK;
+}
+
+template <int MODE, int NPOS>
+void launch_tapconv_inst(const float* in, const float* wp, const float* bias, float* out, const TapPlan& pl,
+                         hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_kernel<MODE, NPOS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((tapconv_kernel<MODE, NPOS>), pl.grid, dim3(256), pl.lds_bytes, s, in, wp, bias, out, pl.g);
+}
+
+// `dst` = final output when nsplit == 1, else the partial slabs [nsplit][N,M,Ho,Wo]
+template <int MODE>
+int launch_tapconv(const float* in, const float* wp, const float* bias, float* dst, const TapPlan& pl, hipStream_t s,
+                   const char* name) {
+    using TC = TapCfg<MODE>;
+    const ConvGeom& g = pl.g;
+    {
+        // algorithmic work: every tap counted (zero-padding taps included), useful channels only
+        const double flops = 2.0 * g.N * (double)g.M * g.K * TC::NT * g.Hb * g.Wb;
+        const double bytes = 4.0 * ((double)g.N * g.K * g.Hi * g.Wi + (double)g.N * g.M * g.Ho * g.Wo / TC::NCLS +
+                                    (double)TC::NT * g.K * g.M);
+        GxProf pf(KID_TAPCONV_C3 + MODE, s, flops, bytes);
+        constexpr int LO = (MODE == M_DG) ? 8 : 2;
+        if (pl.npos == LO) launch_tapconv_inst<MODE, LO>(in, wp, bias, dst, pl, s);
+        else launch_tapconv_inst<MODE, 2 * LO>(in, wp, bias, dst, pl, s);
+    }
     GX_CHECK_LAUNCH(name);
+    return GX_OK;
+}
+
+int launch_splitk_reduce(const float* part, const float* bias, float* out, const TapPlan& pl, hipStream_t s) {
+    const size_t total = pl.out_elems;
+    size_t blocks = (total / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    {
+        GxProf pf(KID_SPLITK_REDUCE, s, 0.0, 4.0 * (pl.g.nsplit + 1.0) * (double)total);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, part, bias, out, total,
+                           pl.g.nsplit, pl.g.M, pl.g.Ho * pl.g.Wo);
+    }
+    GX_CHECK_LAUNCH("splitk_reduce");
     return GX_OK;
 }
 
 int launch_pack(const float* w, float* wp, int pack, int Co, int Ci, int NT, int Kpad, int Mpad, hipStream_t s) {
     const int total = NT * Kpad * Mpad;
     const int blocks = gx_ceil_div(total, 256) > 1024 ? 1024 : gx_ceil_div(total, 256);
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, s, w, wp, pack, Co, Ci, NT, Kpad, Mpad);
+    {
+        GxProf pf(KID_PACK_WEIGHTS, s, 0.0, 8.0 * total);
+        hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, s, w, wp, pack, Co, Ci, NT, Kpad, Mpad);
+    }
     GX_CHECK_LAUNCH("pack_weights");
     return GX_OK;
 }
@@ -490,8 +604,10 @@ int plan_wgrad(int N, int CA, int CB, int Hb, int Wb, int SA, int Ttot, int ncls
     const int TH = 1 << g.lTH, TW = 1 << g.lTW, G = 1 << g.lG;
     g.tiles_h = Hb / TH; g.tiles_w = Wb / TW;
     g.ntiles = g.tiles_h * g.tiles_w * gx_ceil_div(N, G);
-    const int chan_blocks = (g.CApad / 64) * (g.CBpad / 64) * ncls_launches;
-    int nsplit = gx_ceil_div(768, chan_blocks);
+    // one workgroup per CU is resident (LDS-bound, 1 wave/SIMD): size each launch to ~one wave of 256 CUs
+    (void)ncls_launches;
+    const int chan_blocks = (g.CApad / 64) * (g.CBpad / 64);
+    int nsplit = gx_ceil_div(256, chan_blocks);
     if (nsplit > g.ntiles) nsplit = g.ntiles;
     if (nsplit < 1) nsplit = 1;
     g.nsplit = nsplit;
@@ -512,7 +628,15 @@ int launch_wgrad(const float* a, const float* b, float* partial, const WgradPlan
         attr_set = true;
     }
     dim3 grid(pl.g.nsplit, (pl.g.CApad / 64) * (pl.g.CBpad / 64));
-    hipLaunchKernelGGL(wgrad_kernel<WM>, grid, dim3(256), pl.lds_bytes, s, a, b, partial, pl.g);
+    {
+        using WT = WTap<WM>;
+        const WgradGeom& g = pl.g;
+        const double flops = 2.0 * g.N * (double)g.CA * g.CB * WT::NT * g.Hb * g.Wb;
+        const double bytes = 4.0 * ((double)g.N * g.CA * g.Hb * g.Wb + (double)g.N * g.CB * g.Hb * g.Wb +
+                                    (double)g.nsplit * WT::NT * g.CApad * g.CBpad);
+        GxProf pf(KID_WGRAD_C3 + WM, s, flops, bytes);
+        hipLaunchKernelGGL(wgrad_kernel<WM>, grid, dim3(256), pl.lds_bytes, s, a, b, partial, pl.g);
+    }
     GX_CHECK_LAUNCH(name);
     return GX_OK;
 }
@@ -520,8 +644,11 @@ int launch_wgrad(const float* a, const float* b, float* partial, const WgradPlan
 int launch_wgrad_reduce(const float* partial, float* dw, const WgradPlan& pl, int layout, hipStream_t s) {
     const int total = pl.g.Ttot * pl.g.CA * pl.g.CB;
     const int blocks = gx_ceil_div(total, 256) > 2048 ? 2048 : gx_ceil_div(total, 256);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, partial, dw, pl.g.nsplit, pl.g.Ttot,
-                       pl.g.CA, pl.g.CB, pl.g.CApad, pl.g.CBpad, layout);
+    {
+        GxProf pf(KID_WGRAD_REDUCE, s, 0.0, 4.0 * ((double)pl.g.nsplit + 1.0) * total);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, partial, dw, pl.g.nsplit, pl.g.Ttot,
+                           pl.g.CA, pl.g.CB, pl.g.CApad, pl.g.CBpad, layout);
+    }
     GX_CHECK_LAUNCH("wgrad_reduce");
     return GX_OK;
 }
@@ -538,12 +665,21 @@ int check_dims(const char* name, int N, int Cin, int Cout, int H, int W) {
 // =================================================================== C ABI
 extern "C" {
 
-size_t gx_conv3x3_ws_bytes(int N, int Cin, int Cout, int H, int W) {
-    (void)N; (void)H; (void)W;
-    // packed weights for fwd (k=Cin, m=Cout) or dgrad (k=Cout, m=Cin): take the max
+// workspace = packed weights (+ split-K partial slabs when the plan splits the reduction)
+static size_t conv3x3_pack_floats(int Cin, int Cout) {
     size_t f = (size_t)9 * gx_round_up(Cin, 8) * gx_round_up(Cout, 64);
     size_t d = (size_t)9 * gx_round_up(Cout, 8) * gx_round_up(Cin, 64);
-    return (f > d ? f : d) * sizeof(float);
+    return f > d ? f : d;
+}
+
+size_t gx_conv3x3_ws_bytes(int N, int Cin, int Cout, int H, int W) {
+    TapPlan pf, pd;
+    size_t part = 0;
+    if (plan_tapconv<M_C3>(N, Cin, Cout, gx_round_up(Cout, 64), H, W, H, W, H, W, 0, &pf, "ws") == GX_OK && pf.g.nsplit > 1)
+        part = pf.g.nsplit * pf.out_elems;
+    if (plan_tapconv<M_C3>(N, Cout, Cin, gx_round_up(Cin, 64), H, W, H, W, H, W, 0, &pd, "ws") == GX_OK && pd.g.nsplit > 1)
+        part = part > pd.g.nsplit * pd.out_elems ? part : pd.g.nsplit * pd.out_elems;
+    return (conv3x3_pack_floats(Cin, Cout) + part) * sizeof(float);
 }
 
 int gx_conv3x3_fwd(const float* x, const float* w, float* y, int N, int Cin, int Cout, int H, int W,
@@ -551,13 +687,20 @@ int gx_conv3x3_fwd(const float* x, const float* w, float* y, int N, int Cin, int
     int rc = check_dims("gx_conv3x3_fwd", N, Cin, Cout, H, W);
     if (rc) return rc;
     GX_CHECK_ARG(x && w && y && ws, "gx_conv3x3_fwd: null pointer");
+    GX_CHECK_ARG(ws_bytes >= gx_conv3x3_ws_bytes(N, Cin, Cout, H, W), "gx_conv3x3_fwd: workspace too small");
     const int Kpad = gx_round_up(Cin, 8), Mpad = gx_round_up(Cout, 64);
-    GX_CHECK_ARG(ws_bytes >= (size_t)9 * Kpad * Mpad * sizeof(float), "gx_conv3x3_fwd: workspace too small");
     hipStream_t s = (hipStream_t)stream;
-    rc = launch_pack(w, (float*)ws, 0, Cout, Cin, 9, Kpad, Mpad, s);
+    TapPlan pl;
+    rc = plan_tapconv<M_C3>(N, Cin, Cout, Mpad, H, W, H, W, H, W, 0, &pl, "gx_conv3x3_fwd");
     if (rc) return rc;
-    return launch_tapconv<M_C3>(x, (const float*)ws, nullptr, y, N, Cin, Cout, H, W, H, W, H, W, 0, s,
-                                "gx_conv3x3_fwd");
+    float* wp = (float*)ws;
+    float* part = wp + conv3x3_pack_floats(Cin, Cout);
+    rc = launch_pack(w, wp, 0, Cout, Cin, 9, Kpad, Mpad, s);
+    if (rc) return rc;
+    rc = launch_tapconv<M_C3>(x, wp, nullptr, pl.g.nsplit > 1 ? part : y, pl, s, "gx_conv3x3_fwd");
+    if (rc) return rc;
+    if (pl.g.nsplit > 1) return launch_splitk_reduce(part, nullptr, y, pl, s);
+    return GX_OK;
 }
 
 int gx_conv3x3_dgrad(const float* dy, const float* w, float* dx, int N, int Cin, int Cout, int H, int W,
@@ -565,13 +708,20 @@ int gx_conv3x3_dgrad(const float* dy, const float* w, float* dx, int N, int Cin,
     int rc = check_dims("gx_conv3x3_dgrad", N, Cin, Cout, H, W);
     if (rc) return rc;
     GX_CHECK_ARG(dy && w && dx && ws, "gx_conv3x3_dgrad: null pointer");
+    GX_CHECK_ARG(ws_bytes >= gx_conv3x3_ws_bytes(N, Cin, Cout, H, W), "gx_conv3x3_dgrad: workspace too small");
     const int Kpad = gx_round_up(Cout, 8), Mpad = gx_round_up(Cin, 64);
-    GX_CHECK_ARG(ws_bytes >= (size_t)9 * Kpad * Mpad * sizeof(float), "gx_conv3x3_dgrad: workspace too small");
     hipStream_t s = (hipStream_t)stream;
-    rc = launch_pack(w, (float*)ws, 1, Cout, Cin, 9, Kpad, Mpad, s);
+    TapPlan pl;
+    rc = plan_tapconv<M_C3>(N, Cout, Cin, Mpad, H, W, H, W, H, W, 0, &pl, "gx_conv3x3_dgrad");
     if (rc) return rc;
-    return launch_tapconv<M_C3>(dy, (const float*)ws, nullptr, dx, N, Cout, Cin, H, W, H, W, H, W, 0, s,
-                                "gx_conv3x3_dgrad");
+    float* wp = (float*)ws;
+    float* part = wp + conv3x3_pack_floats(Cin, Cout);
+    rc = launch_pack(w, wp, 1, Cout, Cin, 9, Kpad, Mpad, s);
+    if (rc) return rc;
+    rc = launch_tapconv<M_C3>(dy, wp, nullptr, pl.g.nsplit > 1 ? part : dx, pl, s, "gx_conv3x3_dgrad");
+    if (rc) return rc;
+    if (pl.g.nsplit > 1) return launch_splitk_reduce(part, nullptr, dx, pl, s);
+    return GX_OK;
 }
 
 size_t gx_conv3x3_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W) {
@@ -594,12 +744,23 @@ int gx_conv3x3_wgrad(const float* x, const float* dy, float* dw, int N, int Cin,
     return launch_wgrad_reduce((const float*)ws, dw, pl, 0, s);
 }
 
-size_t gx_deconv5x5s2_ws_bytes(int N, int Cin, int Cout, int Hin, int Win) {
-    (void)N; (void)Hin; (void)Win;
+static size_t deconv_pack_floats(int Cin, int Cout) {
     // fwd: two row-parity packs (15 + 10 taps, k=Cin, m=Cout); dgrad: 25 taps (k=Cout, m=Cin)
     size_t f = (size_t)25 * gx_round_up(Cin, 8) * gx_round_up(Cout, 64);
     size_t d = (size_t)25 * gx_round_up(Cout, 8) * gx_round_up(Cin, 64);
-    return (f > d ? f : d) * sizeof(float);
+    return f > d ? f : d;
+}
+
+size_t gx_deconv5x5s2_ws_bytes(int N, int Cin, int Cout, int Hin, int Win) {
+    TapPlan pf, pd;
+    size_t part = 0;
+    if (plan_tapconv<M_DT0>(N, Cin, Cout, gx_round_up(Cout, 64), Hin, Win, Hin, Win, 2 * Hin, 2 * Win, 0, &pf, "ws") == GX_OK &&
+        pf.g.nsplit > 1)
+        part = pf.g.nsplit * pf.out_elems;
+    if (plan_tapconv<M_DG>(N, Cout, Cin, gx_round_up(Cin, 64), Hin, Win, 2 * Hin, 2 * Win, Hin, Win, 0, &pd, "ws") == GX_OK &&
+        pd.g.nsplit > 1)
+        part = part > pd.g.nsplit * pd.out_elems ? part : pd.g.nsplit * pd.out_elems;
+    return (deconv_pack_floats(Cin, Cout) + part) * sizeof(float);
 }
 
 int gx_deconv5x5s2_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int Cout,
@@ -607,20 +768,29 @@ int gx_deconv5x5s2_fwd(const float* x, const float* w, const float* bias, float*
     int rc = check_dims("gx_deconv5x5s2_fwd", N, Cin, Cout, Hin, Win);
     if (rc) return rc;
     GX_CHECK_ARG(x && w && y && ws, "gx_deconv5x5s2_fwd: null pointer");
+    GX_CHECK_ARG(ws_bytes >= gx_deconv5x5s2_ws_bytes(N, Cin, Cout, Hin, Win), "gx_deconv5x5s2_fwd: workspace too small");
     const int Kpad = gx_round_up(Cin, 8), Mpad = gx_round_up(Cout, 64);
-    GX_CHECK_ARG(ws_bytes >= (size_t)25 * Kpad * Mpad * sizeof(float), "gx_deconv5x5s2_fwd: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     float* wp0 = (float*)ws;
     float* wp1 = wp0 + (size_t)15 * Kpad * Mpad;
+    float* part = wp0 + deconv_pack_floats(Cin, Cout);
     rc = launch_pack(w, wp0, 2, Cout, Cin, 15, Kpad, Mpad, s);
     if (rc) return rc;
     rc = launch_pack(w, wp1, 3, Cout, Cin, 10, Kpad, Mpad, s);
     if (rc) return rc;
-    rc = launch_tapconv<M_DT0>(x, wp0, bias, y, N, Cin, Cout, Hin, Win, Hin, Win, 2 * Hin, 2 * Win, 0, s,
-                               "gx_deconv5x5s2_fwd(a=0)");
+    // both row parities share one split plan (same channel chunking) so that one reduce finishes the layer
+    TapPlan p0, p1;
+    rc = plan_tapconv<M_DT0>(N, Cin, Cout, Mpad, Hin, Win, Hin, Win, 2 * Hin, 2 * Win, 0, &p0, "gx_deconv5x5s2_fwd");
     if (rc) return rc;
-    return launch_tapconv<M_DT1>(x, wp1, bias, y, N, Cin, Cout, Hin, Win, Hin, Win, 2 * Hin, 2 * Win, 1, s,
-                                 "gx_deconv5x5s2_fwd(a=1)");
+    rc = plan_tapconv<M_DT1>(N, Cin, Cout, Mpad, Hin, Win, Hin, Win, 2 * Hin, 2 * Win, 1, &p1, "gx_deconv5x5s2_fwd");
+    if (rc) return rc;
+    float* dst = p0.g.nsplit > 1 ? part : y;
+    rc = launch_tapconv<M_DT0>(x, wp0, bias, dst, p0, s, "gx_deconv5x5s2_fwd(a=0)");
+    if (rc) return rc;
+    rc = launch_tapconv<M_DT1>(x, wp1, bias, dst, p1, s, "gx_deconv5x5s2_fwd(a=1)");
+    if (rc) return rc;
+    if (p0.g.nsplit > 1) return launch_splitk_reduce(part, bias, y, p0, s);
+    return GX_OK;
 }
 
 int gx_deconv5x5s2_dgrad(const float* dy, const float* w, float* dx, int N, int Cin, int Cin_out, int Cout,
@@ -629,34 +799,21 @@ int gx_deconv5x5s2_dgrad(const float* dy, const float* w, float* dx, int N, int 
     if (rc) return rc;
     GX_CHECK_ARG(dy && w && dx && ws, "gx_deconv5x5s2_dgrad: null pointer");
     GX_CHECK_ARG(Cin_out > 0 && Cin_out <= Cin, "gx_deconv5x5s2_dgrad: Cin_out out of range");
+    GX_CHECK_ARG(ws_bytes >= gx_deconv5x5s2_ws_bytes(N, Cin, Cout, Hin, Win), "gx_deconv5x5s2_dgrad: workspace too small");
     // only the first Cin_out input channels get a gradient (the decoder's coordinate channels need none);
-    // weights are packed with the full Cin so that W's row stride is right, m is masked at Cin_out.
+    // weights are packed with the full Cin (so W's row stride is right), output channels are masked at Cin_out.
     const int Kpad = gx_round_up(Cout, 8), Mpad = gx_round_up(Cin, 64);
-    GX_CHECK_ARG(ws_bytes >= (size_t)25 * Kpad * Mpad * sizeof(float), "gx_deconv5x5s2_dgrad: workspace too small");
     hipStream_t s = (hipStream_t)stream;
-    rc = launch_pack(w, (float*)ws, 4, Cout, Cin, 25, Kpad, Mpad, s);
+    float* wp = (float*)ws;
+    float* part = wp + deconv_pack_floats(Cin, Cout);
+    rc = launch_pack(w, wp, 4, Cout, Cin, 25, Kpad, Mpad, s);
     if (rc) return rc;
-    // launch with M = Cin_out but Mpad of the pack: build geometry by hand
-    using TC = TapCfg<M_DG>;
-    ConvGeom g;
-    g.N = N; g.K = Cout; g.M = Cin_out; g.Kpad = Kpad; g.Mpad = Mpad;
-    g.Hb = Hin; g.Wb = Win; g.Hi = 2 * Hin; g.Wi = 2 * Win; g.Ho = Hin; g.Wo = Win; g.par_a = 0;
-    pick_tile(Hin, Win, 256, &g.lTH, &g.lTW, &g.lG);
-    const int TH = 1 << g.lTH, TW = 1 << g.lTW, G = 1 << g.lG;
-    g.tiles_h = Hin / TH; g.tiles_w = Win / TW;
-    const int CHS = TC::PLANES * G * (TH + 2) * (TW + 2);
-    GX_CHECK_ARG(CHS <= MaxPos<M_DG>::V * 256, "gx_deconv5x5s2_dgrad: halo tile too large");
-    const size_t lds = (size_t)(TC::KC * CHS + TC::NT * TC::KC * 64) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_kernel<M_DG>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    dim3 grid(g.tiles_h * g.tiles_w * gx_ceil_div(N, G), gx_ceil_div(Cin_out, 64));
-    hipLaunchKernelGGL(tapconv_kernel<M_DG>, grid, dim3(256), lds, s, dy, (const float*)ws, (const float*)nullptr,
-                       dx, g);
-    GX_CHECK_LAUNCH("gx_deconv5x5s2_dgrad");
+    TapPlan pl;
+    rc = plan_tapconv<M_DG>(N, Cout, Cin_out, Mpad, Hin, Win, 2 * Hin, 2 * Win, Hin, Win, 0, &pl, "gx_deconv5x5s2_dgrad");
+    if (rc) return rc;
+    rc = launch_tapconv<M_DG>(dy, wp, nullptr, pl.g.nsplit > 1 ? part : dx, pl, s, "gx_deconv5x5s2_dgrad");
+    if (rc) return rc;
+    if (pl.g.nsplit > 1) return launch_splitk_reduce(part, nullptr, dx, pl, s);
     return GX_OK;
 }
 

@@ -211,8 +211,14 @@ int gx_gn_relu_fwd(const float* y, const float* gamma, const float* beta, int N,
     if (dst1) { rc = check_view("gx_gn_relu_fwd", d1, C); if (rc) return rc; }
     const int m = (C / groups) * H * W;
     const int threads = m >= 2048 ? 512 : 256;
-    hipLaunchKernelGGL(gn_relu_fwd_kernel, dim3(N * groups), dim3(threads), 0, (hipStream_t)stream, y, gamma, beta,
-                       C, H, W, groups, eps, d0, d1, mean, rstd);
+    {
+        // algorithmic bytes: read y once, write each destination view once
+        auto vw = [](int mode) { return mode == 1 ? 4.0 : (mode == 2 ? 0.25 : 1.0); };
+        const double el = (double)N * C * H * W;
+        GxProf pf(KID_GN_FWD, (hipStream_t)stream, 8.0 * el, 4.0 * el * (1.0 + vw(dst0_mode) + (dst1 ? vw(dst1_mode) : 0.0)));
+        hipLaunchKernelGGL(gn_relu_fwd_kernel, dim3(N * groups), dim3(threads), 0, (hipStream_t)stream, y, gamma,
+                           beta, C, H, W, groups, eps, d0, d1, mean, rstd);
+    }
     GX_CHECK_LAUNCH("gx_gn_relu_fwd");
     return GX_OK;
 }
@@ -236,11 +242,19 @@ int gx_gn_relu_bwd(const float* y, const float* gamma, const float* beta, const 
     const int m = (C / groups) * H * W;
     const int threads = m >= 2048 ? 512 : 256;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_relu_bwd_kernel, dim3(N * groups), dim3(threads), 0, s, y, gamma, beta, mean, rstd, C, H,
-                       W, groups, v0, v1, dy, (float*)ws);
+    {
+        auto vw = [](int mode) { return mode == 1 ? 4.0 : (mode == 2 ? 0.25 : 1.0); };
+        const double el = (double)N * C * H * W;
+        GxProf pf(KID_GN_BWD, s, 16.0 * el, 4.0 * el * (2.0 + vw(g0_mode) + (g1 ? vw(g1_mode) : 0.0)));
+        hipLaunchKernelGGL(gn_relu_bwd_kernel, dim3(N * groups), dim3(threads), 0, s, y, gamma, beta, mean, rstd, C,
+                           H, W, groups, v0, v1, dy, (float*)ws);
+    }
     GX_CHECK_LAUNCH("gx_gn_relu_bwd");
-    hipLaunchKernelGGL(gn_param_reduce_kernel, dim3(gx_ceil_div(C, 64)), dim3(64), 0, s, (const float*)ws, N, C,
-                       dgamma, dbeta, dbias);
+    {
+        GxProf pf(KID_GN_PARAM_REDUCE, s, 0.0, 12.0 * N * C);
+        hipLaunchKernelGGL(gn_param_reduce_kernel, dim3(gx_ceil_div(C, 64)), dim3(64), 0, s, (const float*)ws, N, C,
+                           dgamma, dbeta, dbias);
+    }
     GX_CHECK_LAUNCH("gx_gn_relu_bwd(reduce)");
     return GX_OK;
 }

@@ -1,0 +1,103 @@
+// Optimiser-side kernels of the training step: fused flat-buffer Adam and the GECO multiplier update.
+//
+// Reference: train.py:174-175,262-263 (torch.optim.Adam(lr=1e-4), betas (0.9, 0.999), eps 1e-8, no weight
+// decay) and utils/geco.py:35-51.  Both read their step-dependent scalars from device memory so a whole
+// training step can be replayed from a HIP graph without host round-trips (the reference's
+// `constraint.item()` at geco.py:45 is a device->host sync every iteration).
+#include "gx_common.h"
+
+namespace {
+
+// p, g, m, v: flat buffers of n elements.  step: device int64 counter, already incremented for this
+// update (t >= 1).  gscale multiplies the gradient first (1/world_size for data-parallel averaging).
+template <typename T>
+__global__ void __launch_bounds__(256)
+adam_kernel(T* __restrict__ p, const T* __restrict__ g, T* __restrict__ m, T* __restrict__ v, size_t n,
+            const int64_t* __restrict__ step, float lr, float b1, float b2, float eps, float gscale) {
+    const double t = (double)(*step);
+    const double bc1 = 1.0 - pow((double)b1, t);
+    const double bc2 = 1.0 - pow((double)b2, t);
+    const T step_size = (T)((double)lr / bc1);
+    const T bc2_sqrt = (T)sqrt(bc2);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const T gi = g[i] * (T)gscale;
+        const T mi = m[i] + (gi - m[i]) * (T)(1.f - b1);           // torch: exp_avg.lerp_(grad, 1 - beta1)
+        const T vi = v[i] * (T)b2 + gi * gi * (T)(1.f - b2);       // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+        const T denom = sqrt(vi) / bc2_sqrt + (T)eps;
+        p[i] = p[i] - step_size * (mi / denom);
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+__global__ void step_inc_kernel(int64_t* step) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1;
+}
+
+// state = {beta, err_ema, initialised (0/1)}.  err: device scalar (batch-mean reconstruction error of
+// THIS step, already averaged over ranks).  utils/geco.py:39-49.
+__global__ void geco_update_kernel(float* __restrict__ state, const float* __restrict__ err, float goal,
+                                   float step_size, float alpha, float speedup, int use_speedup,
+                                   float beta_min, float beta_max) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float e = *err;
+    float ema = state[1];
+    if (state[2] == 0.f) { ema = e; state[2] = 1.f; }
+    else ema = (1.0f - alpha) * e + alpha * ema;
+    const float constraint = goal - ema;
+    float factor;
+    if (use_speedup && constraint > 0.f) factor = expf(speedup * step_size * constraint);
+    else factor = expf(step_size * constraint);
+    float beta = factor * state[0];
+    beta = fminf(fmaxf(beta, beta_min), beta_max);
+    state[0] = beta;
+    state[1] = ema;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gx_adam_step(void* p, const void* g, void* m, void* v, size_t n, int is_f64, int64_t* step, float lr,
+                 float beta1, float beta2, float eps, float grad_scale, gx_stream_t stream) {
+    GX_CHECK_ARG(p && g && m && v && step, "gx_adam_step: null pointer");
+    if (n == 0) return GX_OK;
+    hipStream_t s = (hipStream_t)stream;
+    size_t blocks = (n + 1023) / 1024;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    {
+        GxProf pf(KID_ADAM, s, 0.0, (is_f64 ? 8.0 : 4.0) * 7.0 * (double)n);  // read p,g,m,v; write p,m,v
+        if (is_f64)
+            hipLaunchKernelGGL(adam_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, s, (double*)p,
+                               (const double*)g, (double*)m, (double*)v, n, (const int64_t*)step, lr, beta1, beta2,
+                               eps, grad_scale);
+        else
+            hipLaunchKernelGGL(adam_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (float*)p,
+                               (const float*)g, (float*)m, (float*)v, n, (const int64_t*)step, lr, beta1, beta2, eps,
+                               grad_scale);
+    }
+    GX_CHECK_LAUNCH("gx_adam_step");
+    return GX_OK;
+}
+
+int gx_step_increment(int64_t* step, gx_stream_t stream) {
+    GX_CHECK_ARG(step, "gx_step_increment: null pointer");
+    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step);
+    GX_CHECK_LAUNCH("gx_step_increment");
+    return GX_OK;
+}
+
+int gx_geco_update(float* state, const float* err, float goal, float step_size, float alpha, float speedup,
+                   int use_speedup, float beta_min, float beta_max, gx_stream_t stream) {
+    GX_CHECK_ARG(state && err, "gx_geco_update: null pointer");
+    {
+        GxProf pf(KID_GECO, (hipStream_t)stream, 0.0, 16.0);
+        hipLaunchKernelGGL(geco_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, err, goal, step_size,
+                           alpha, speedup, use_speedup, beta_min, beta_max);
+    }
+    GX_CHECK_LAUNCH("gx_geco_update");
+    return GX_OK;
+}
+
+}  // extern "C"

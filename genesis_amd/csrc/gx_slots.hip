@@ -376,8 +376,11 @@ int gx_maskpool_fwd(const float* f, const float* log_m, int B, int C, int H, int
                     gx_stream_t stream) {
     GX_CHECK_ARG(f && log_m && S && msum, "gx_maskpool_fwd: null pointer");
     GX_CHECK_ARG(B > 0 && C > 0 && K >= 1 && K <= KMAX && H > 0 && W > 0, "gx_maskpool_fwd: bad dims (K<=16)");
-    hipLaunchKernelGGL(maskpool_fwd_kernel, dim3(B, gx_ceil_div(C, PCH)), dim3(256), 0, (hipStream_t)stream, f,
-                       log_m, B, C, H * W, K, S, msum);
+    {
+        GxProf pf(KID_MASKPOOL_FWD, (hipStream_t)stream, 2.0 * B * K * C * H * W, 4.0 * B * H * W * (C + K));
+        hipLaunchKernelGGL(maskpool_fwd_kernel, dim3(B, gx_ceil_div(C, PCH)), dim3(256), 0, (hipStream_t)stream, f,
+                           log_m, B, C, H * W, K, S, msum);
+    }
     GX_CHECK_LAUNCH("gx_maskpool_fwd");
     return GX_OK;
 }
@@ -387,8 +390,12 @@ int gx_maskpool_bwd(const float* f, const float* log_m, const float* gS, const f
     GX_CHECK_ARG(f && log_m && gS && gmsum && df && dlog_m, "gx_maskpool_bwd: null pointer");
     GX_CHECK_ARG(B > 0 && C > 0 && K >= 1 && K <= KMAX && H > 0 && W > 0, "gx_maskpool_bwd: bad dims (K<=16)");
     const int HW = H * W;
-    hipLaunchKernelGGL(maskpool_bwd_kernel, dim3(B, gx_ceil_div(HW, 256)), dim3(256), (size_t)K * C * sizeof(float),
-                       (hipStream_t)stream, f, log_m, gS, gmsum, B, C, HW, K, df, dlog_m);
+    {
+        GxProf pf(KID_MASKPOOL_BWD, (hipStream_t)stream, 4.0 * B * K * C * HW, 4.0 * B * HW * (2.0 * C + 2.0 * K));
+        hipLaunchKernelGGL(maskpool_bwd_kernel, dim3(B, gx_ceil_div(HW, 256)), dim3(256),
+                           (size_t)K * C * sizeof(float), (hipStream_t)stream, f, log_m, gS, gmsum, B, C, HW, K, df,
+                           dlog_m);
+    }
     GX_CHECK_LAUNCH("gx_maskpool_bwd");
     return GX_OK;
 }
@@ -403,10 +410,17 @@ int gx_mixture_fwd(const float* x, const float* dec, int B, int H, int W, int K,
     GX_CHECK_ARG(ws_bytes >= gx_mixture_ws_bytes(B, H, W), "gx_mixture_fwd: workspace too small");
     const int HW = H * W, nb = gx_ceil_div(HW, 256);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(mixture_kernel<false>, dim3(B, nb), dim3(256), 0, s, x, dec, B, HW, K, pixel_std, pixel_bound,
-                       recon, x_r, log_m_r, (float*)ws, (const float*)nullptr, (float*)nullptr);
+    {
+        // read x (3) + dec (4K); write recon (3), x_r (3K), log_m_r (K)
+        GxProf pf(KID_MIXTURE_FWD, s, 0.0, 4.0 * B * HW * (6.0 + 8.0 * K));
+        hipLaunchKernelGGL(mixture_kernel<false>, dim3(B, nb), dim3(256), 0, s, x, dec, B, HW, K, pixel_std,
+                           pixel_bound, recon, x_r, log_m_r, (float*)ws, (const float*)nullptr, (float*)nullptr);
+    }
     GX_CHECK_LAUNCH("gx_mixture_fwd");
-    hipLaunchKernelGGL(row_sum_kernel, dim3(gx_ceil_div(B, 64)), dim3(64), 0, s, (const float*)ws, B, nb, err);
+    {
+        GxProf pf(KID_SMALL_REDUCE, s, 0.0, 4.0 * B * nb);
+        hipLaunchKernelGGL(row_sum_kernel, dim3(gx_ceil_div(B, 64)), dim3(64), 0, s, (const float*)ws, B, nb, err);
+    }
     GX_CHECK_LAUNCH("gx_mixture_fwd(reduce)");
     return GX_OK;
 }
@@ -416,9 +430,12 @@ int gx_mixture_bwd(const float* x, const float* dec, const float* g_err, int B, 
     GX_CHECK_ARG(x && dec && g_err && ddec, "gx_mixture_bwd: null pointer");
     GX_CHECK_ARG(B > 0 && K >= 1 && K <= KMAX && pixel_std > 0.f, "gx_mixture_bwd: bad dims (K<=16)");
     const int HW = H * W, nb = gx_ceil_div(HW, 256);
-    hipLaunchKernelGGL(mixture_kernel<true>, dim3(B, nb), dim3(256), 0, (hipStream_t)stream, x, dec, B, HW, K,
-                       pixel_std, pixel_bound, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
-                       g_err, ddec);
+    {
+        GxProf pf(KID_MIXTURE_BWD, (hipStream_t)stream, 0.0, 4.0 * B * HW * (3.0 + 8.0 * K));
+        hipLaunchKernelGGL(mixture_kernel<true>, dim3(B, nb), dim3(256), 0, (hipStream_t)stream, x, dec, B, HW, K,
+                           pixel_std, pixel_bound, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                           g_err, ddec);
+    }
     GX_CHECK_LAUNCH("gx_mixture_bwd");
     return GX_OK;
 }
@@ -428,8 +445,11 @@ int gx_conv1x1_fwd(const float* x, const float* w, const float* bias, const floa
     GX_CHECK_ARG(x && w && y, "gx_conv1x1_fwd: null pointer");
     GX_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && Cout <= COMAX, "gx_conv1x1_fwd: Cout must be <= 8");
     const int HW = H * W;
-    hipLaunchKernelGGL(conv1x1_fwd_kernel, dim3(N, gx_ceil_div(HW, 256)), dim3(256), 0, (hipStream_t)stream, x, w,
-                       bias, gate, addend, Cin, Cout, HW, y);
+    {
+        GxProf pf(KID_CONV1X1_FWD, (hipStream_t)stream, 2.0 * N * Cin * Cout * HW, 4.0 * N * HW * (Cin + Cout));
+        hipLaunchKernelGGL(conv1x1_fwd_kernel, dim3(N, gx_ceil_div(HW, 256)), dim3(256), 0, (hipStream_t)stream, x, w,
+                           bias, gate, addend, Cin, Cout, HW, y);
+    }
     GX_CHECK_LAUNCH("gx_conv1x1_fwd");
     return GX_OK;
 }
@@ -455,15 +475,21 @@ int gx_conv1x1_bwd(const float* x, const float* dy, const float* w, const float*
     const int nchunks = gx_ceil_div(HW, chunk);
     const int nblk = N * nchunks;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv1x1_dgrad_kernel, dim3(N, gx_ceil_div(HW, 256)), dim3(256), 0, s, dy, w, gate, Cin, Cout,
-                       HW, dx);
+    {
+        GxProf pf(KID_CONV1X1_DGRAD, s, 2.0 * N * Cin * Cout * HW, 4.0 * N * HW * (Cin + Cout));
+        hipLaunchKernelGGL(conv1x1_dgrad_kernel, dim3(N, gx_ceil_div(HW, 256)), dim3(256), 0, s, dy, w, gate, Cin,
+                           Cout, HW, dx);
+    }
     GX_CHECK_LAUNCH("gx_conv1x1_bwd(dgrad)");
     float* pw = (float*)ws;
     float* pb = pw + (size_t)nblk * Cout * Cin;
     float* pg = pb + (size_t)nblk * Cout;
     const size_t lds = (size_t)(Cin * 65 + COMAX * 64 + 64) * sizeof(float);
-    hipLaunchKernelGGL(conv1x1_wgrad_kernel, dim3(N, nchunks), dim3(512), lds, s, x, dy, w, bias, Cin, Cout, HW,
-                       chunk, pw, pb, gate ? pg : (float*)nullptr);
+    {
+        GxProf pf(KID_CONV1X1_WGRAD, s, 2.0 * N * Cin * Cout * HW, 4.0 * N * HW * (Cin + Cout));
+        hipLaunchKernelGGL(conv1x1_wgrad_kernel, dim3(N, nchunks), dim3(512), lds, s, x, dy, w, bias, Cin, Cout, HW,
+                           chunk, pw, pb, gate ? pg : (float*)nullptr);
+    }
     GX_CHECK_LAUNCH("gx_conv1x1_bwd(wgrad)");
     const int npairs = Cout * Cin;
     hipLaunchKernelGGL(col_sum_kernel, dim3(gx_ceil_div(npairs, 64)), dim3(64), 0, s, (const float*)pw, nblk, npairs,

@@ -58,6 +58,17 @@ def _cfg_get(cfg, name, default):
         return getattr(cfg, name, default)
 
 
+_LOG_SQRT_2PI = math.log(math.sqrt(2 * math.pi))
+
+
+def _normal_log_prob(x, mu, sigma):
+    """torch.distributions.Normal.log_prob without the constructor's argument validation (a device->host
+    sync that cannot be captured in a HIP graph)."""
+    if torch.is_tensor(sigma):
+        return -((x - mu) ** 2) / (2 * sigma ** 2) - sigma.log() - _LOG_SQRT_2PI
+    return -((x - mu) ** 2) / (2 * sigma ** 2) - math.log(sigma) - _LOG_SQRT_2PI
+
+
 def pixel_coords(size):
     """Row grid then column grid, linspace(-1, 1): modules/blocks.py:42-47 ('ij' meshgrid)."""
     lin = torch.linspace(-1, 1, size)
@@ -293,13 +304,13 @@ class GenesisV2(nn.Module):
             p_ = p_ / p_.sum(0, keepdim=True)
             losses['kl_m'] = (q * (q.log() - p_.log())).sum(0).flatten(1).sum(1)
         # -- Component KL (Genesis.mask_latent_loss, models/genesis_config.py:288-343)
-        log_q = Normal(mu, sigma).log_prob(z).sum(2)                 # [K,B]
+        log_q = _normal_log_prob(z, mu, sigma).sum(2)                # [K,B]
         if self.prior_lstm is not None:
             mu_p, sig_p = self._prior(z)
-            log_p0 = Normal(0., 1.).log_prob(z[:1]).sum(2)
-            log_p = torch.cat((log_p0, Normal(mu_p, sig_p).log_prob(z[1:]).sum(2)), 0)
+            log_p0 = _normal_log_prob(z[:1], 0., 1.).sum(2)
+            log_p = torch.cat((log_p0, _normal_log_prob(z[1:], mu_p, sig_p).sum(2)), 0)
         else:
-            log_p = Normal(0., 1.).log_prob(z).sum(2)
+            log_p = _normal_log_prob(z, 0., 1.).sum(2)
         losses['kl_l_k'] = list((log_q - log_p).unbind(0))
 
         stats = AttrDict(
@@ -311,7 +322,8 @@ class GenesisV2(nn.Module):
         att_stats.update({'colour': colour, 'delta': delta, 'seeds': list(seeds.unbind(0)),
                           'seed_idx': list(idx.unbind(0))})
         comp_stats = AttrDict(mu_k=list(mu.unbind(0)), sigma_k=list(sigma.unbind(0)), z_k=list(z.unbind(0)),
-                              kl_l_k=[], q_z_k=[Normal(m, s) for m, s in zip(mu.unbind(0), sigma.unbind(0))])
+                              kl_l_k=[], q_z_k=[Normal(m, s, validate_args=False)
+                                                for m, s in zip(mu.unbind(0), sigma.unbind(0))])
         if self.multi_gpu:
             del comp_stats['q_z_k']
         return recon, losses, stats, att_stats, comp_stats

@@ -1,0 +1,161 @@
+"""One training iteration of the reference's loop (train.py:215-263: zero_grad, forward, loss aggregation,
+GECO, backward, Adam) as a device-resident step: flat parameter / gradient / Adam-state buffers, a fused
+HIP Adam kernel, the on-device GECO update, optional HIP-graph replay of the whole step, and -- with one
+process per GPU -- a single RCCL all-reduce of the flat gradient bucket (the batch-mean err / KL ride in
+its tail so every rank applies the identical GECO update)."""
+import ctypes
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .geco import make_geco
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class TrainStep(object):
+
+    def __init__(self, model, img_size, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, geco=None, use_geco=True,
+                 beta_fixed=0.5, process_group=None, graph=False):
+        self.model = model
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.device = next(model.parameters()).device
+        if self.device.type != 'cuda':
+            raise _lib.GenesisHipError('TrainStep needs the model on a HIP device; there is no CPU path')
+        self.geco = geco if geco is not None else (make_geco(img_size, device=self.device) if use_geco else None)
+        self.beta_fixed = beta_fixed
+        self._beta_fixed_t = torch.tensor(float(beta_fixed), device=self.device)
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self._flatten()
+        self.step_t = torch.zeros((), dtype=torch.int64, device=self.device)
+        self.graph = None
+        self.use_graph = graph
+        self._static_x = None
+        self._out = None
+        self.iters = 0
+
+    # ------------------------------------------------------------------ flat buffers
+    def _flatten(self):
+        p32 = [p for p in self.model.parameters() if p.dtype == torch.float32]
+        p64 = [p for p in self.model.parameters() if p.dtype == torch.float64]
+        others = [p for p in self.model.parameters() if p.dtype not in (torch.float32, torch.float64)]
+        assert not others
+        n32 = sum(p.numel() for p in p32)
+        n64 = sum(p.numel() for p in p64)
+        dev = self.device
+        self.n32, self.n64 = n32, n64
+        self.flat_p = torch.empty(n32, dtype=torch.float32, device=dev)
+        # gradient bucket: [fp32 grads | err | kl]  (2 piggy-backed scalars)
+        self.flat_g = torch.zeros(n32 + 2, dtype=torch.float32, device=dev)
+        self.m32 = torch.zeros(n32, dtype=torch.float32, device=dev)
+        self.v32 = torch.zeros(n32, dtype=torch.float32, device=dev)
+        self.flat_p64 = torch.empty(max(n64, 1), dtype=torch.float64, device=dev)
+        self.flat_g64 = torch.zeros(max(n64, 1), dtype=torch.float64, device=dev)
+        self.m64 = torch.zeros(max(n64, 1), dtype=torch.float64, device=dev)
+        self.v64 = torch.zeros(max(n64, 1), dtype=torch.float64, device=dev)
+        for plist, fp, fg in ((p32, self.flat_p, self.flat_g), (p64, self.flat_p64, self.flat_g64)):
+            off = 0
+            for p in plist:
+                n = p.numel()
+                fp[off:off + n].copy_(p.data.reshape(-1))
+                p.data = fp[off:off + n].view(p.shape)
+                p.grad = fg[off:off + n].view(p.shape)
+                off += n
+        self._params = p32 + p64
+
+    def _check_grad_views(self):
+        lo, hi = self.flat_g.data_ptr(), self.flat_g.data_ptr() + self.flat_g.numel() * 4
+        for p in self._params:
+            if p.dtype == torch.float32:
+                assert p.grad is not None and lo <= p.grad.data_ptr() < hi, 'gradient left the flat bucket'
+
+    # ------------------------------------------------------------------ one iteration
+    def _iteration(self, x, **forward_kwargs):
+        self.flat_g.zero_()
+        if self.n64:
+            self.flat_g64.zero_()
+        recon, losses, stats, att_stats, comp_stats = self.model(x, **forward_kwargs)
+        err = losses.err.mean(0)
+        kl = torch.stack(losses.kl_l_k, dim=1).mean(dim=0).sum()
+        if 'kl_m' in losses:
+            kl = kl + losses.kl_m.mean(0)
+        if self.geco is not None:
+            beta = self.geco.state[0].clone()
+        else:
+            beta = self._beta_fixed_t
+        loss = err + beta * kl
+        loss.backward()
+        with torch.no_grad():
+            self.flat_g[self.n32] = err.detach()
+            self.flat_g[self.n32 + 1] = kl.detach()
+            gscale = 1.0
+            if self.world > 1:
+                dist.all_reduce(self.flat_g, group=self.pg)
+                if self.n64:
+                    dist.all_reduce(self.flat_g64, group=self.pg)
+                gscale = 1.0 / self.world
+            tail = self.flat_g[self.n32:] * gscale          # global batch-mean err, kl
+            if self.geco is not None:
+                self.geco.update(tail[0])
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _lib.call('gx_step_increment', _p(self.step_t), stream)
+            _lib.call('gx_adam_step', _p(self.flat_p), _p(self.flat_g), _p(self.m32), _p(self.v32), self.n32, 0,
+                      _p(self.step_t), self.lr, self.betas[0], self.betas[1], self.eps, gscale, stream)
+            if self.n64:
+                _lib.call('gx_adam_step', _p(self.flat_p64), _p(self.flat_g64), _p(self.m64), _p(self.v64),
+                          self.n64, 1, _p(self.step_t), self.lr, self.betas[0], self.betas[1], self.eps, gscale,
+                          stream)
+            return torch.stack((tail[0] + tail[1], tail[0], tail[1], beta.detach()))  # elbo, err, kl, beta used
+
+    def _capture(self, x):
+        """Warm up (kernel attributes, allocator pools), capture one iteration into a HIP graph, restore the
+        pre-warm-up training state and replay once: the call is exactly one training step."""
+        self._static_x = x.clone()
+        state = [self.flat_p, self.flat_p64, self.m32, self.v32, self.m64, self.v64, self.step_t]
+        if self.geco is not None:
+            state.append(self.geco.state)
+        snap = [t.clone() for t in state]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                self._out = self._iteration(self._static_x)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._out = self._iteration(self._static_x)
+        with torch.no_grad():
+            for t, s in zip(state, snap):
+                t.copy_(s)
+        self.graph.replay()
+        self.iters += 1
+
+    def step(self, x, **forward_kwargs):
+        """x [B,3,S,S] on the device.  Returns a device tensor [elbo, err, kl, beta_used] (no host sync).
+        forward_kwargs (rand_pixel / eps / seed_idx injection, parity tests) force the eager path."""
+        if self.use_graph and self.world == 1 and not forward_kwargs:
+            if self.graph is None:
+                self._capture(x)
+                return self._out
+            self._static_x.copy_(x)
+            self.graph.replay()
+            self.iters += 1
+            return self._out
+        out = self._iteration(x, **forward_kwargs)
+        if self.iters == 0:
+            self._check_grad_views()
+        self.iters += 1
+        return out
+
+    # ------------------------------------------------------------------ checkpoint (train.py:410-420 wire format)
+    def state_dict(self, iter_idx):
+        return {'model_state_dict': self.model.state_dict(),
+                'optimiser_state_dict': {'m32': self.m32, 'v32': self.v32, 'm64': self.m64, 'v64': self.v64,
+                                         'step': self.step_t, 'lr': self.lr, 'betas': self.betas, 'eps': self.eps},
+                'beta': self.geco.beta if self.geco is not None else self.beta_fixed,
+                'err_ema': self.geco.err_ema if self.geco is not None else None,
+                'iter_idx': iter_idx}

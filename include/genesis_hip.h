@@ -118,6 +118,26 @@ int gx_conv1x1_bwd(const float* x, const float* dy, const float* w, const float*
                    int Cin, int Cout, int H, int W, float* dx, float* dw, float* db, float* dgate, void* ws,
                    size_t ws_bytes, gx_stream_t stream);
 
+/* ---- optimiser side of the training step.
+ *      gx_adam_step: torch.optim.Adam update (train.py:174-175,263) on flat buffers p/g/m/v of n elements
+ *      (fp32, or fp64 when is_f64 -- att_process.log_sigma is an fp64 parameter); `step` is a device int64
+ *      holding t (>= 1, bump it with gx_step_increment first); the gradient is multiplied by grad_scale.
+ *      gx_geco_update: utils/geco.py:39-49 on device; state = {beta, err_ema, initialised}; err = device
+ *      scalar with the batch-mean reconstruction error; no host sync (the reference calls .item()). */
+int gx_adam_step(void* p, const void* g, void* m, void* v, size_t n, int is_f64, int64_t* step, float lr,
+                 float beta1, float beta2, float eps, float grad_scale, gx_stream_t stream);
+int gx_step_increment(int64_t* step, gx_stream_t stream);
+int gx_geco_update(float* state, const float* err, float goal, float step_size, float alpha, float speedup,
+                   int use_speedup, float beta_min, float beta_max, gx_stream_t stream);
+
+/* ---- live per-kernel profiling (bench.py's roofline leg): when enabled every kernel launch is bracketed
+ *      by two HIP events on its launch stream and tagged with its ALGORITHMIC flops / bytes
+ *      (DESIGN.md "kernels and rooflines"); gx_profile_collect accumulates per kernel symbol. */
+int gx_profile_enable(int on);
+int gx_profile_num_kernels(void);
+const char* gx_profile_kernel_name(int kid);
+int gx_profile_collect(double* total_ms, double* launches, double* flops, double* bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,7 +46,7 @@ def test_forward_and_grads_vs_golden(case):
     x, rand_pixel, eps_k = gold.inputs()
     recon, losses, stats, att, comp = run(model, gold, x, rand_pixel, eps_k)
     # log-masks accumulate K-1 stick-breaking steps of log(1-alpha) (slope up to 100 at the 0.99 clamp)
-    gold.check_forward(recon, losses, stats, att, comp, rtol=1e-4, atol=2e-5, mask_atol=3e-4)
+    gold.check_forward(recon, losses, stats, att, comp, rtol=1e-4, atol=2e-5, mask_atol=1e-3)
     err = losses.err.mean(0)
     kl = torch.stack(losses.kl_l_k, dim=1).mean(dim=0).sum()
     if 'kl_m' in losses:
