@@ -99,7 +99,7 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    if world > 1 or os.environ.get('GENESIS_FORCE_ALLREDUCE'):
         dist.init_process_group('nccl', init_method='env://')
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
     torch.cuda.set_device(local_rank)
@@ -108,7 +108,8 @@ def main():
     from genesis_amd.trainer import TrainStep
     from genesis_amd import profiling
     model = build_model(args, device)
-    ts = TrainStep(model, args.img, lr=1e-4, graph=(world == 1 and not args.no_graph))
+    ts = TrainStep(model, args.img, lr=1e-4,
+                   graph=(world == 1 and not args.no_graph and not os.environ.get('GENESIS_FORCE_ALLREDUCE')))
     g = torch.Generator().manual_seed(1234 + rank)
     batches = [torch.rand(args.batch, 3, args.img, args.img, generator=g).to(device) for _ in range(4)]
 
@@ -193,7 +194,7 @@ def main():
         result['speedup_vs_cpu_baseline'] = result['value'] / result['cpu_baseline']['value']
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -9,6 +9,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
+from .dp import FlatBucket
 from .geco import make_geco
 
 
@@ -40,44 +41,19 @@ class TrainStep(object):
 
     # ------------------------------------------------------------------ flat buffers
     def _flatten(self):
-        p32 = [p for p in self.model.parameters() if p.dtype == torch.float32]
-        p64 = [p for p in self.model.parameters() if p.dtype == torch.float64]
-        others = [p for p in self.model.parameters() if p.dtype not in (torch.float32, torch.float64)]
-        assert not others
-        n32 = sum(p.numel() for p in p32)
-        n64 = sum(p.numel() for p in p64)
-        dev = self.device
-        self.n32, self.n64 = n32, n64
-        self.flat_p = torch.empty(n32, dtype=torch.float32, device=dev)
-        # gradient bucket: [fp32 grads | err | kl]  (2 piggy-backed scalars)
-        self.flat_g = torch.zeros(n32 + 2, dtype=torch.float32, device=dev)
-        self.m32 = torch.zeros(n32, dtype=torch.float32, device=dev)
-        self.v32 = torch.zeros(n32, dtype=torch.float32, device=dev)
-        self.flat_p64 = torch.empty(max(n64, 1), dtype=torch.float64, device=dev)
-        self.flat_g64 = torch.zeros(max(n64, 1), dtype=torch.float64, device=dev)
-        self.m64 = torch.zeros(max(n64, 1), dtype=torch.float64, device=dev)
-        self.v64 = torch.zeros(max(n64, 1), dtype=torch.float64, device=dev)
-        for plist, fp, fg in ((p32, self.flat_p, self.flat_g), (p64, self.flat_p64, self.flat_g64)):
-            off = 0
-            for p in plist:
-                n = p.numel()
-                fp[off:off + n].copy_(p.data.reshape(-1))
-                p.data = fp[off:off + n].view(p.shape)
-                p.grad = fg[off:off + n].view(p.shape)
-                off += n
-        self._params = p32 + p64
+        self.bucket = FlatBucket(self.model.parameters(), n_tail=2)
+        b = self.bucket
+        self.n32, self.n64 = b.n32, b.n64
+        self.flat_p, self.flat_g, self.flat_p64, self.flat_g64 = b.flat_p, b.flat_g, b.flat_p64, b.flat_g64
+        self.m32, self.v32 = torch.zeros_like(b.flat_p), torch.zeros_like(b.flat_p)
+        self.m64, self.v64 = torch.zeros_like(b.flat_p64), torch.zeros_like(b.flat_p64)
 
     def _check_grad_views(self):
-        lo, hi = self.flat_g.data_ptr(), self.flat_g.data_ptr() + self.flat_g.numel() * 4
-        for p in self._params:
-            if p.dtype == torch.float32:
-                assert p.grad is not None and lo <= p.grad.data_ptr() < hi, 'gradient left the flat bucket'
+        assert self.bucket.grads_in_bucket(), 'a gradient left the flat bucket'
 
     # ------------------------------------------------------------------ one iteration
     def _iteration(self, x, **forward_kwargs):
-        self.flat_g.zero_()
-        if self.n64:
-            self.flat_g64.zero_()
+        self.bucket.zero_grad()
         recon, losses, stats, att_stats, comp_stats = self.model(x, **forward_kwargs)
         err = losses.err.mean(0)
         kl = torch.stack(losses.kl_l_k, dim=1).mean(dim=0).sum()
@@ -90,15 +66,9 @@ class TrainStep(object):
         loss = err + beta * kl
         loss.backward()
         with torch.no_grad():
-            self.flat_g[self.n32] = err.detach()
-            self.flat_g[self.n32 + 1] = kl.detach()
-            gscale = 1.0
-            if self.world > 1:
-                dist.all_reduce(self.flat_g, group=self.pg)
-                if self.n64:
-                    dist.all_reduce(self.flat_g64, group=self.pg)
-                gscale = 1.0 / self.world
-            tail = self.flat_g[self.n32:] * gscale          # global batch-mean err, kl
+            self.bucket.set_tail(err, kl)
+            gscale = self.bucket.all_reduce(self.pg)
+            tail = self.bucket.tail(gscale)                 # global batch-mean err, kl
             if self.geco is not None:
                 self.geco.update(tail[0])
             stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,91 @@
+"""N>1 path on CPU: world_size-2 `gloo` run of the data-parallel bucket (genesis_amd/dp.py).  Each rank
+computes the oracle's gradients on its shard of the batch; after ONE all-reduce of the flat bucket every
+rank must hold (a) the full-batch gradient and (b) the global batch-mean err / KL in the bucket tail --
+what the GECO + Adam update consumes -- identical on both ranks."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import v2_oracle as O
+from genesis_amd import testing as T
+from genesis_amd.dp import FlatBucket
+
+CFG = O.make_cfg(K_steps=3, img_size=32, feat_dim=8)
+B = 4
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _local_grads(x, rp, eps):
+    sd = T.formula_state_dict(O.template_state_dict(CFG))
+    params = [torch.nn.Parameter(v.clone()) for v in sd.values()]
+    bucket = FlatBucket(params, n_tail=2)
+    p = dict(zip(sd.keys(), params))
+    bucket.zero_grad()
+    _, losses, _, _, _ = O.v2_forward(p, x, CFG, rp, eps, reference_form=False)
+    err, kl, _ = O.aggregate_losses(losses)
+    (err + kl).backward()
+    assert bucket.grads_in_bucket()
+    bucket.set_tail(err, kl)
+    return bucket
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    x = T.make_input(3, B, 32)
+    rp, eps = T.draw_noise(4, B, 32, 8, 3)
+    sl = slice(rank * B // world, (rank + 1) * B // world)
+    bucket = _local_grads(x[sl], rp[sl], [e[sl] for e in eps])
+    scale = bucket.all_reduce()
+    torch.save({'g': bucket.flat_g * scale, 'g64': bucket.flat_g64 * scale}, os.path.join(out_dir, 'r%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_bucket_equals_full_batch(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(str(tmp_path), 'r0.pt'))
+    r1 = torch.load(os.path.join(str(tmp_path), 'r1.pt'))
+    assert torch.equal(r0['g'], r1['g']) and torch.equal(r0['g64'], r1['g64'])   # identical update on all ranks
+    x = T.make_input(3, B, 32)
+    rp, eps = T.draw_noise(4, B, 32, 8, 3)
+    full = _local_grads(x, rp, eps)
+    ref = full.flat_g.detach()
+    got = r0['g']
+    rel = float((got - ref).norm() / ref.norm())
+    assert rel < 1e-4, rel
+    np.testing.assert_allclose(got[-2:].numpy(), ref[-2:].numpy(), rtol=1e-5)      # global err, kl in the tail
+    np.testing.assert_allclose(r0['g64'].numpy(), full.flat_g64.detach().numpy(), rtol=1e-4, atol=1e-7)
+
+
+def test_bucket_views_track_parameters():
+    params = [torch.nn.Parameter(torch.randn(3, 4)), torch.nn.Parameter(torch.randn(5)),
+              torch.nn.Parameter(torch.randn((), dtype=torch.float64))]
+    before = [p.detach().clone() for p in params]
+    b = FlatBucket(params, n_tail=2)
+    assert b.n32 == 17 and b.n64 == 1 and b.flat_g.numel() == 19
+    for p, q in zip(params, before):
+        assert torch.equal(p.detach(), q)
+    (params[0].sum() * 2 + params[1].sum() * 3 + params[2] * 4).backward()
+    assert b.grads_in_bucket()
+    assert torch.equal(b.flat_g[:12], torch.full((12,), 2.0)) and torch.equal(b.flat_g[12:17], torch.full((5,), 3.0))
+    assert float(b.flat_g64[0]) == 4.0
+    b.flat_p.mul_(0)          # the optimiser writes the flat buffer; parameters are views of it
+    assert float(params[0].abs().sum()) == 0.0
