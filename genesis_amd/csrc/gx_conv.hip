@@ -353,23 +353,26 @@ struct WgradGeom {
     int Ttot;            // taps in the partial buffer (9 or 25)
 };
 
+// A operand (dy) goes global -> registers directly: the k (pixel) slots of the MFMA are assigned so that
+// lane-half k owns a contiguous half of the pixel tile, i.e. every lane streams one channel row with
+// 16-byte loads (the pairing of pixels to k slots is free as long as A and B agree).  Only the B operand
+// (x with its 1-pixel halo, re-used by all taps) is staged in LDS: double-buffered, prefetched
+// global -> registers one tile ahead while the current tile's MFMAs run; one barrier per tile.
 template <int WM>
 __global__ void __launch_bounds__(256, 1)
 wgrad_kernel(const float* __restrict__ a_src, const float* __restrict__ b_src,
              float* __restrict__ partial, WgradGeom g) {
     using WT = WTap<WM>;
     constexpr int NT = WT::NT;
+    constexpr int NPOS = 2;              // halo tile <= 512 floats per channel
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int TH = 1 << g.lTH, TW = 1 << g.lTW, G = 1 << g.lG;
     const int PT = TH * TW * G;          // pixels per tile (64 or 128)
-    const int lPT = g.lTH + g.lTW + g.lG;
-    const int AS = PT + 1;               // padded A row stride (conflict-free column reads)
     const int HS = TW + 2;
     const int CHS = G * (TH + 2) * HS;
-    const int BS = CHS | 1;              // odd B channel stride
-    float* a_tile = lds;                 // [64][AS]
-    float* b_tile = lds + 64 * AS;       // [64][BS]
+    const int BS = CHS | 1;              // odd B channel stride: lanes = channels read conflict-free
+    const int BUF = 64 * BS;
 
     const int nbt = g.CBpad / 64;
     const int ca0 = (blockIdx.y / nbt) * 64;
@@ -386,63 +389,116 @@ wgrad_kernel(const float* __restrict__ a_src, const float* __restrict__ b_src,
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
-    const int a_row = (wm * 32 + (lane & 31)) * AS;
+    const int ca_l = ca0 + wm * 32 + (lane & 31);     // this lane's A channel
+    const bool ca_ok = ca_l < g.CA;
+    const int khalf = lane >> 5;                       // k slot of this lane
     const int b_row = (wn * 32 + (lane & 31)) * BS;
 
-    for (int tile = blockIdx.x; tile < g.ntiles; tile += g.nsplit) {
-        int tt = tile;
-        const int tw_i = tt % g.tiles_w; tt /= g.tiles_w;
-        const int th_i = tt % g.tiles_h; tt /= g.tiles_h;
-        const int img0 = tt * G;
-        const int R0 = th_i * TH, C0 = tw_i * TW;
-        __syncthreads();
-        // stage A: a_tile[ch][p] = dy[n][ca0+ch][SA*(R0+r)+PA][SA*(C0+c)+PB]
-        for (int idx = tid; idx < 64 * PT; idx += 256) {
-            const int p = idx & (PT - 1);
-            const int ch = idx >> lPT;
-            const int c = p & (TW - 1);
-            const int r = (p >> g.lTW) & (TH - 1);
-            const int gi = p >> (g.lTW + g.lTH);
-            const int n = img0 + gi;
-            float v = 0.f;
-            if (n < g.N && ca0 + ch < g.CA)
-                v = a_src[(size_t)n * a_img + (size_t)(ca0 + ch) * HaWa +
-                          (WT::SA * (R0 + r) + WT::PA) * g.Wa + WT::SA * (C0 + c) + WT::PB];
-            a_tile[ch * AS + p] = v;
-        }
-        // stage B: halo tile of 64 channels
-        for (int pos = tid; pos < CHS; pos += 256) {
-            int rem = pos;
-            const int gi = rem / ((TH + 2) * HS); rem -= gi * (TH + 2) * HS;
-            const int i = rem / HS;
-            const int j = rem - i * HS;
-            const int row = R0 - 1 + i, col = C0 - 1 + j;
-            const int n = img0 + gi;
-            const bool ok = (n < g.N && row >= 0 && row < g.Hb && col >= 0 && col < g.Wb);
-            const float* src = b_src + (size_t)n * b_img + (size_t)cb0 * HbWb + row * g.Wb + col;
-            for (int ch = 0; ch < 64; ++ch) {
-                float v = 0.f;
-                if (ok && cb0 + ch < g.CB) v = src[(size_t)ch * HbWb];
-                b_tile[ch * BS + pos] = v;
+    float xin[64][NPOS];
+
+#define GX_WG_TILE_ORIGIN(tile_, img0_, R0_, C0_)                      \
+    int img0_, R0_, C0_;                                               \
+    {                                                                  \
+        int tt_ = (tile_);                                             \
+        const int tw_i_ = tt_ % g.tiles_w; tt_ /= g.tiles_w;           \
+        const int th_i_ = tt_ % g.tiles_h; tt_ /= g.tiles_h;           \
+        img0_ = tt_ * G; R0_ = th_i_ * TH; C0_ = tw_i_ * TW;           \
+    }
+#define GX_WG_PREFETCH(tile_)                                                                        \
+    {                                                                                                \
+        GX_WG_TILE_ORIGIN(tile_, pi0, pR0, pC0)                                                      \
+        _Pragma("unroll") for (int q = 0; q < NPOS; ++q) {                                           \
+            const int pos = tid + q * 256;                                                           \
+            int off = -1;                                                                            \
+            if (pos < CHS) {                                                                         \
+                int rem = pos;                                                                       \
+                const int gi = rem / ((TH + 2) * HS); rem -= gi * (TH + 2) * HS;                     \
+                const int i = rem / HS;                                                              \
+                const int jj = rem - i * HS;                                                         \
+                const int row = pR0 - 1 + i, col = pC0 - 1 + jj;                                     \
+                if (pi0 + gi < g.N && row >= 0 && row < g.Hb && col >= 0 && col < g.Wb)              \
+                    off = gi * (int)b_img + row * g.Wb + col;                                        \
+            }                                                                                        \
+            const float* src = b_src + (size_t)pi0 * b_img + (size_t)cb0 * HbWb;                     \
+            _Pragma("unroll") for (int ch = 0; ch < 64; ++ch) {                                      \
+                float v = 0.f;                                                                       \
+                if (off >= 0 && cb0 + ch < g.CB) v = src[(size_t)ch * HbWb + off];                   \
+                xin[ch][q] = v;                                                                      \
+            }                                                                                        \
+        }                                                                                            \
+    }
+
+    int tile = blockIdx.x;
+    if (tile < g.ntiles) GX_WG_PREFETCH(tile)
+    int it = 0;
+    for (; tile < g.ntiles; tile += g.nsplit, ++it) {
+        float* buf = lds + (it & 1) * BUF;
+#pragma unroll
+        for (int q = 0; q < NPOS; ++q) {
+            const int pos = tid + q * 256;
+            if (pos < CHS) {
+#pragma unroll
+                for (int ch = 0; ch < 64; ++ch) buf[ch * BS + pos] = xin[ch][q];
             }
         }
         __syncthreads();
-        // K loop over pixel pairs
-#pragma unroll 2
-        for (int kk = 0; kk < PT / 2; ++kk) {
-            const int p = 2 * kk + (lane >> 5);
-            const int c = p & (TW - 1);
-            const int r = (p >> g.lTW) & (TH - 1);
-            const int gi = p >> (g.lTW + g.lTH);
-            const float a = a_tile[a_row + p];
-            const float* bp = b_tile + b_row + (gi * (TH + 2) + r) * HS + c;
+        if (tile + g.nsplit < g.ntiles) GX_WG_PREFETCH(tile + g.nsplit)
+
+        GX_WG_TILE_ORIGIN(tile, img0, R0, C0)
+        // ---- K loop: this lane's k slot covers pixels [khalf*PT/2, (khalf+1)*PT/2) of the tile, 4 at a time
+        const int ngroups = PT >> 3;
+        for (int kg = 0; kg < ngroups; ++kg) {
+            const int j0 = khalf * (PT >> 1) + 4 * kg;
+            float av[4];
+            int halo[4];
+            if (TW >= 4) {
+                const int c = j0 & (TW - 1);
+                const int r = (j0 >> g.lTW) & (TH - 1);
+                const int gi = j0 >> (g.lTW + g.lTH);
+                const int n = img0 + gi;
+                const bool ok = ca_ok && n < g.N;
+                const float* ap = a_src + (size_t)(ok ? n : 0) * a_img + (size_t)(ok ? ca_l : 0) * HaWa +
+                                  (size_t)(WT::SA * (R0 + r) + WT::PA) * g.Wa + WT::SA * (C0 + c);
+                if (WT::SA == 1) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(ap);
+                    av[0] = v[0]; av[1] = v[1]; av[2] = v[2]; av[3] = v[3];
+                } else {
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(ap);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(ap + 4);
+                    av[0] = v0[WT::PB]; av[1] = v0[WT::PB + 2]; av[2] = v1[WT::PB]; av[3] = v1[WT::PB + 2];
+                }
+                if (!ok) { av[0] = 0.f; av[1] = 0.f; av[2] = 0.f; av[3] = 0.f; }
+                const int h0 = (gi * (TH + 2) + r) * HS + c;
+                halo[0] = h0; halo[1] = h0 + 1; halo[2] = h0 + 2; halo[3] = h0 + 3;
+            } else {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const float b = bp[WT::ro(t) * HS + WT::co(t)];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+                for (int u = 0; u < 4; ++u) {
+                    const int jx = j0 + u;
+                    const int c = jx & (TW - 1);
+                    const int r = (jx >> g.lTW) & (TH - 1);
+                    const int gi = jx >> (g.lTW + g.lTH);
+                    const int n = img0 + gi;
+                    float v = 0.f;
+                    if (ca_ok && n < g.N)
+                        v = a_src[(size_t)n * a_img + (size_t)ca_l * HaWa +
+                                  (size_t)(WT::SA * (R0 + r) + WT::PA) * g.Wa + WT::SA * (C0 + c) + WT::PB];
+                    av[u] = v;
+                    halo[u] = (gi * (TH + 2) + r) * HS + c;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* bp = buf + b_row + halo[u];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float b = bp[WT::ro(t) * HS + WT::co(t)];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], b, acc[t], 0, 0, 0);
+                }
             }
         }
     }
+#undef GX_WG_PREFETCH
+#undef GX_WG_TILE_ORIGIN
     // partial[split][gt][ca][cb]
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -457,19 +513,34 @@ wgrad_kernel(const float* __restrict__ a_src, const float* __restrict__ b_src,
 }
 
 // dW = sum over splits.  layout 0: W[ca][cb][T] (conv3x3: ca=co, cb=ci); layout 1: W[cb][ca][T] (deconv).
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int nsplit,
-                                    int Ttot, int CA, int CB, int CApad, int CBpad, int layout) {
+// Block = 64 consecutive (t, ca, cb) elements x 4 interleaved split groups (fixed summation order).
+__global__ void __launch_bounds__(256)
+wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int nsplit,
+                    int Ttot, int CA, int CB, int CApad, int CBpad, int layout) {
+    __shared__ float red[4][64];
     const int total = Ttot * CA * CB;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        const int cb = idx % CB;
-        const int ca = (idx / CB) % CA;
-        const int t = idx / (CB * CA);
+    const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + e;
+    float s = 0.f;
+    int cb = 0, ca = 0, t = 0;
+    if (idx < total) {
+        cb = idx % CB;
+        ca = (idx / CB) % CA;
+        t = idx / (CB * CA);
         const size_t stride = (size_t)Ttot * CApad * CBpad;
         const float* p = partial + ((size_t)t * CApad + ca) * CBpad + cb;
-        float s = 0.f;
-        for (int sp = 0; sp < nsplit; ++sp) s += p[sp * stride];
-        if (layout == 0) dw[((size_t)ca * CB + cb) * Ttot + t] = s;
-        else dw[((size_t)cb * CA + ca) * Ttot + t] = s;
+        float s0 = 0.f, s1 = 0.f;
+        int sp = grp;
+        for (; sp + 4 < nsplit; sp += 8) { s0 += p[sp * stride]; s1 += p[(sp + 4) * stride]; }
+        if (sp < nsplit) s0 += p[sp * stride];
+        s = s0 + s1;
+    }
+    red[grp][e] = s;
+    __syncthreads();
+    if (grp == 0 && idx < total) {
+        const float r = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        if (layout == 0) dw[((size_t)ca * CB + cb) * Ttot + t] = r;
+        else dw[((size_t)cb * CA + ca) * Ttot + t] = r;
     }
 }
 
@@ -613,7 +684,7 @@ int plan_wgrad(int N, int CA, int CB, int Hb, int Wb, int SA, int Ttot, int ncls
     g.nsplit = nsplit;
     g.Ttot = Ttot;
     const int CHS = G * (TH + 2) * (TW + 2);
-    pl->lds_bytes = (size_t)(64 * (npix + 1) + 64 * (CHS | 1)) * sizeof(float);
+    pl->lds_bytes = (size_t)2 * 64 * (CHS | 1) * sizeof(float);   // double-buffered B (x halo) tile
     pl->ws_floats = (size_t)nsplit * Ttot * g.CApad * g.CBpad;
     return GX_OK;
 }
@@ -643,7 +714,7 @@ int launch_wgrad(const float* a, const float* b, float* partial, const WgradPlan
 
 int launch_wgrad_reduce(const float* partial, float* dw, const WgradPlan& pl, int layout, hipStream_t s) {
     const int total = pl.g.Ttot * pl.g.CA * pl.g.CB;
-    const int blocks = gx_ceil_div(total, 256) > 2048 ? 2048 : gx_ceil_div(total, 256);
+    const int blocks = gx_ceil_div(total, 64);
     {
         GxProf pf(KID_WGRAD_REDUCE, s, 0.0, 4.0 * ((double)pl.g.nsplit + 1.0) * total);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, partial, dw, pl.g.nsplit, pl.g.Ttot,

@@ -62,58 +62,148 @@ __device__ __forceinline__ float load_view(const View& v, int n, int c, int r, i
     }
 }
 
-__global__ void __launch_bounds__(512)
+// Reduces NV per-thread doubles over the block at once: wave shuffles, one LDS hop, result broadcast.
+template <int NV>
+__device__ __forceinline__ void block_sum_multi(double (&v)[NV], double* red /* [16][NV] + [NV] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = gx_wave_sum_d(v[i]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) red[wave * NV + i] = v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double s = 0.0;
+        for (int w = 0; w < nw; ++w) s += red[w * NV + threadIdx.x];
+        red[16 * NV + threadIdx.x] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = red[16 * NV + i];
+}
+
+__device__ __forceinline__ void store_view4(const View& v, int n, int c, int r, int col, int H, int W, f32x4 val) {
+    // col is a multiple of 4
+    if (v.mode == 0) {
+        *reinterpret_cast<f32x4*>(v.ptr + (((size_t)n * v.ctot + v.c0 + c) * H + r) * W + col) = val;
+    } else if (v.mode == 1) {
+        float* p = v.ptr + (((size_t)n * v.ctot + v.c0 + c) * (2 * H) + 2 * r) * (2 * W) + 2 * col;
+        f32x4 lo, hi;
+        lo[0] = val[0]; lo[1] = val[0]; lo[2] = val[1]; lo[3] = val[1];
+        hi[0] = val[2]; hi[1] = val[2]; hi[2] = val[3]; hi[3] = val[3];
+        *reinterpret_cast<f32x4*>(p) = lo;
+        *reinterpret_cast<f32x4*>(p + 4) = hi;
+        *reinterpret_cast<f32x4*>(p + 2 * W) = lo;
+        *reinterpret_cast<f32x4*>(p + 2 * W + 4) = hi;
+    } else {
+        if ((r & 1) == 0) {
+            float2 o = make_float2(val[0], val[2]);
+            *reinterpret_cast<float2*>(v.ptr + (((size_t)n * v.ctot + v.c0 + c) * (H >> 1) + (r >> 1)) * (W >> 1) +
+                                       (col >> 1)) = o;
+        }
+    }
+}
+
+__device__ __forceinline__ f32x4 load_view4(const View& v, int n, int c, int r, int col, int H, int W) {
+    f32x4 o;
+    if (v.mode == 0) {
+        o = *reinterpret_cast<const f32x4*>(v.ptr + (((size_t)n * v.ctot + v.c0 + c) * H + r) * W + col);
+    } else if (v.mode == 1) {
+        const float* p = v.ptr + (((size_t)n * v.ctot + v.c0 + c) * (2 * H) + 2 * r) * (2 * W) + 2 * col;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(p), a1 = *reinterpret_cast<const f32x4*>(p + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p + 2 * W), b1 = *reinterpret_cast<const f32x4*>(p + 2 * W + 4);
+        o[0] = (a0[0] + a0[1]) + (b0[0] + b0[1]);
+        o[1] = (a0[2] + a0[3]) + (b0[2] + b0[3]);
+        o[2] = (a1[0] + a1[1]) + (b1[0] + b1[1]);
+        o[3] = (a1[2] + a1[3]) + (b1[2] + b1[3]);
+    } else {
+        o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f;
+        if ((r & 1) == 0) {
+            const float2 t = *reinterpret_cast<const float2*>(
+                v.ptr + (((size_t)n * v.ctot + v.c0 + c) * (H >> 1) + (r >> 1)) * (W >> 1) + (col >> 1));
+            o[0] = t.x; o[2] = t.y;
+        }
+    }
+    return o;
+}
+
+// VEC: 16-byte accesses along W (needs W % 4 == 0); scalar otherwise (W == 2).
+template <bool VEC>
+__global__ void __launch_bounds__(1024)
 gn_relu_fwd_kernel(const float* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ beta,
                    int C, int H, int W, int groups, float eps, View d0, View d1,
                    float* __restrict__ mean_out, float* __restrict__ rstd_out) {
-    __shared__ double red[16];
+    __shared__ double red[16 * 2 + 2];
     const int n = blockIdx.x / groups, gidx = blockIdx.x % groups;
     const int cpg = C / groups, HW = H * W;
     const int m = cpg * HW;
     const float* slab = y + ((size_t)n * C + (size_t)gidx * cpg) * HW;
-    double s = 0.0, ss = 0.0;
-    if ((m & 3) == 0) {
-        const float4* s4 = reinterpret_cast<const float4*>(slab);
+    double acc[2] = {0.0, 0.0};
+    if (VEC) {
+        const f32x4* s4 = reinterpret_cast<const f32x4*>(slab);
         for (int i = threadIdx.x; i < (m >> 2); i += blockDim.x) {
-            const float4 v = s4[i];
-            s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
-            ss += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+            const f32x4 v = s4[i];
+            acc[0] += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
+            acc[1] += ((double)v[0] * v[0] + (double)v[1] * v[1]) + ((double)v[2] * v[2] + (double)v[3] * v[3]);
         }
     } else {
         for (int i = threadIdx.x; i < m; i += blockDim.x) {
             const float v = slab[i];
-            s += v; ss += (double)v * v;
+            acc[0] += v; acc[1] += (double)v * v;
         }
     }
-    s = block_sum_d(s, red);
-    ss = block_sum_d(ss, red);
-    const double mean = s / m;
-    double var = ss / m - mean * mean;
+    block_sum_multi<2>(acc, red);
+    const double mean = acc[0] / m;
+    double var = acc[1] / m - mean * mean;
     if (var < 0.0) var = 0.0;
     const float meanf = (float)mean;
     const float rstdf = (float)(1.0 / sqrt(var + (double)eps));
     if (threadIdx.x == 0) { mean_out[blockIdx.x] = meanf; rstd_out[blockIdx.x] = rstdf; }
     const int lW = __ffs(W) - 1, lHW = __ffs(HW) - 1;
-    for (int i = threadIdx.x; i < m; i += blockDim.x) {
-        const int cl = i >> lHW, hw = i & (HW - 1);
-        const int c = gidx * cpg + cl;
-        const int r = hw >> lW, col = hw & (W - 1);
-        float v = (slab[i] - meanf) * rstdf * gamma[c] + beta[c];
-        v = v > 0.f ? v : 0.f;
-        store_view(d0, n, c, r, col, H, W, v);
-        if (d1.ptr) store_view(d1, n, c, r, col, H, W, v);
+    if (VEC) {
+        const f32x4* s4 = reinterpret_cast<const f32x4*>(slab);
+        for (int i = threadIdx.x; i < (m >> 2); i += blockDim.x) {
+            const int e = i << 2;
+            const int cl = e >> lHW, hw = e & (HW - 1);
+            const int c = gidx * cpg + cl;
+            const int r = hw >> lW, col = hw & (W - 1);
+            const float gm = gamma[c], bt = beta[c];
+            const f32x4 v = s4[i];
+            f32x4 o;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float t = (v[u] - meanf) * rstdf * gm + bt;
+                o[u] = t > 0.f ? t : 0.f;
+            }
+            store_view4(d0, n, c, r, col, H, W, o);
+            if (d1.ptr) store_view4(d1, n, c, r, col, H, W, o);
+        }
+    } else {
+        for (int i = threadIdx.x; i < m; i += blockDim.x) {
+            const int cl = i >> lHW, hw = i & (HW - 1);
+            const int c = gidx * cpg + cl;
+            const int r = hw >> lW, col = hw & (W - 1);
+            float v = (slab[i] - meanf) * rstdf * gamma[c] + beta[c];
+            v = v > 0.f ? v : 0.f;
+            store_view(d0, n, c, r, col, H, W, v);
+            if (d1.ptr) store_view(d1, n, c, r, col, H, W, v);
+        }
     }
 }
 
 // Backward.  part[n][c][3] = (sum dpre*xhat, sum dpre, sum dy) per (image, channel); a second kernel
-// reduces over n in a fixed order.
-__global__ void __launch_bounds__(512)
+// reduces over n in a fixed order.  Channels of the group are processed 8 at a time so that one
+// multi-value block reduction serves 8 channels.
+constexpr int GCH = 8;
+template <bool VEC>
+__global__ void __launch_bounds__(1024)
 gn_relu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ beta,
                    const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                    int C, int H, int W, int groups, View g0, View g1,
                    float* __restrict__ dy, float* __restrict__ part) {
-    __shared__ double red[16];
-    __shared__ float ch_part[64][2];  // per channel of the group: sum dpre*xhat, sum dpre  (cpg <= 64)
+    __shared__ double red[16 * 2 * GCH + 2 * GCH];
     const int n = blockIdx.x / groups, gidx = blockIdx.x % groups;
     const int cpg = C / groups, HW = H * W;
     const int m = cpg * HW;
@@ -121,71 +211,131 @@ gn_relu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
     float* dslab = dy + ((size_t)n * C + (size_t)gidx * cpg) * HW;
     const float meanf = mean_in[blockIdx.x], rstdf = rstd_in[blockIdx.x];
     const int lW = __ffs(W) - 1;
-    // pass 1: per channel sums (channels processed one after another so each needs one block reduction)
-    double s1 = 0.0, s2 = 0.0;  // sum dxhat, sum dxhat*xhat over the slab
-    for (int cl = 0; cl < cpg; ++cl) {
-        const int c = gidx * cpg + cl;
-        const float gm = gamma[c], bt = beta[c];
-        double a = 0.0, b = 0.0;
-        for (int hw = threadIdx.x; hw < HW; hw += blockDim.x) {
-            const float xh = (slab[cl * HW + hw] - meanf) * rstdf;
-            const float pre = xh * gm + bt;
-            if (pre > 0.f) {
-                const int r = hw >> lW, col = hw & (W - 1);
-                float g = load_view(g0, n, c, r, col, H, W);
-                if (g1.ptr) g += load_view(g1, n, c, r, col, H, W);
-                a += (double)g * xh;
-                b += (double)g;
+    constexpr int VW = VEC ? 4 : 1;
+    // ---- pass 1: per channel a = sum dpre*xhat, b = sum dpre; slab sums s1 = sum dxhat, s2 = sum dxhat*xhat
+    double s1 = 0.0, s2 = 0.0;
+    for (int cb = 0; cb < cpg; cb += GCH) {
+        double ab[2 * GCH];
+#pragma unroll
+        for (int i = 0; i < 2 * GCH; ++i) ab[i] = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < GCH; ++cc) {
+            const int cl = cb + cc;
+            if (cl < cpg) {
+                const int c = gidx * cpg + cl;
+                const float gm = gamma[c], bt = beta[c];
+                for (int hw = threadIdx.x * VW; hw < HW; hw += blockDim.x * VW) {
+                    const int r = hw >> lW, col = hw & (W - 1);
+                    float xv[4], gv[4];
+                    if (VEC) {
+                        const f32x4 t = *reinterpret_cast<const f32x4*>(slab + cl * HW + hw);
+                        f32x4 g = load_view4(g0, n, c, r, col, H, W);
+                        if (g1.ptr) { const f32x4 g2 = load_view4(g1, n, c, r, col, H, W); g += g2; }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { xv[u] = t[u]; gv[u] = g[u]; }
+                    } else {
+                        xv[0] = slab[cl * HW + hw];
+                        gv[0] = load_view(g0, n, c, r, col, H, W);
+                        if (g1.ptr) gv[0] += load_view(g1, n, c, r, col, H, W);
+                    }
+#pragma unroll
+                    for (int u = 0; u < VW; ++u) {
+                        const float xh = (xv[u] - meanf) * rstdf;
+                        const float pre = xh * gm + bt;
+                        if (pre > 0.f) {
+                            ab[2 * cc] += (double)gv[u] * xh;
+                            ab[2 * cc + 1] += (double)gv[u];
+                        }
+                    }
+                }
             }
         }
-        a = block_sum_d(a, red);
-        b = block_sum_d(b, red);
-        if (threadIdx.x == 0) { ch_part[cl][0] = (float)a; ch_part[cl][1] = (float)b; }
-        s1 += b * gm;
-        s2 += a * gm;
+        block_sum_multi<2 * GCH>(ab, red);
+#pragma unroll
+        for (int cc = 0; cc < GCH; ++cc) {
+            const int cl = cb + cc;
+            if (cl < cpg) {
+                const int c = gidx * cpg + cl;
+                const float gm = gamma[c];
+                s1 += ab[2 * cc + 1] * gm;
+                s2 += ab[2 * cc] * gm;
+                if (threadIdx.x == 0) {
+                    float* p = part + ((size_t)n * C + c) * 3;
+                    p[0] = (float)ab[2 * cc]; p[1] = (float)ab[2 * cc + 1];
+                }
+            }
+        }
     }
     const float k1 = (float)(s1 / m), k2 = (float)(s2 / m);
-    __syncthreads();
-    // pass 2: dy = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat*xhat)); per-channel sum of dy (conv bias grad)
-    for (int cl = 0; cl < cpg; ++cl) {
-        const int c = gidx * cpg + cl;
-        const float gm = gamma[c], bt = beta[c];
-        double sdy = 0.0;
-        for (int hw = threadIdx.x; hw < HW; hw += blockDim.x) {
-            const float xh = (slab[cl * HW + hw] - meanf) * rstdf;
-            const float pre = xh * gm + bt;
-            float dxh = 0.f;
-            if (pre > 0.f) {
-                const int r = hw >> lW, col = hw & (W - 1);
-                float g = load_view(g0, n, c, r, col, H, W);
-                if (g1.ptr) g += load_view(g1, n, c, r, col, H, W);
-                dxh = g * gm;
+    // ---- pass 2: dy = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat*xhat)); per-channel sum of dy
+    for (int cb = 0; cb < cpg; cb += GCH) {
+        double sd[GCH];
+#pragma unroll
+        for (int i = 0; i < GCH; ++i) sd[i] = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < GCH; ++cc) {
+            const int cl = cb + cc;
+            if (cl < cpg) {
+                const int c = gidx * cpg + cl;
+                const float gm = gamma[c], bt = beta[c];
+                for (int hw = threadIdx.x * VW; hw < HW; hw += blockDim.x * VW) {
+                    const int r = hw >> lW, col = hw & (W - 1);
+                    float xv[4], gv[4], ov[4];
+                    if (VEC) {
+                        const f32x4 t = *reinterpret_cast<const f32x4*>(slab + cl * HW + hw);
+                        f32x4 g = load_view4(g0, n, c, r, col, H, W);
+                        if (g1.ptr) { const f32x4 g2 = load_view4(g1, n, c, r, col, H, W); g += g2; }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { xv[u] = t[u]; gv[u] = g[u]; }
+                    } else {
+                        xv[0] = slab[cl * HW + hw];
+                        gv[0] = load_view(g0, n, c, r, col, H, W);
+                        if (g1.ptr) gv[0] += load_view(g1, n, c, r, col, H, W);
+                    }
+#pragma unroll
+                    for (int u = 0; u < VW; ++u) {
+                        const float xh = (xv[u] - meanf) * rstdf;
+                        const float pre = xh * gm + bt;
+                        const float dxh = pre > 0.f ? gv[u] * gm : 0.f;
+                        const float d = rstdf * (dxh - k1 - xh * k2);
+                        ov[u] = d;
+                        sd[cc] += d;
+                    }
+                    if (VEC) {
+                        f32x4 o; o[0] = ov[0]; o[1] = ov[1]; o[2] = ov[2]; o[3] = ov[3];
+                        *reinterpret_cast<f32x4*>(dslab + cl * HW + hw) = o;
+                    } else {
+                        dslab[cl * HW + hw] = ov[0];
+                    }
+                }
             }
-            const float d = rstdf * (dxh - k1 - xh * k2);
-            dslab[cl * HW + hw] = d;
-            sdy += d;
         }
-        sdy = block_sum_d(sdy, red);
+        block_sum_multi<GCH>(sd, red);
         if (threadIdx.x == 0) {
-            float* p = part + ((size_t)n * C + c) * 3;
-            p[0] = ch_part[cl][0]; p[1] = ch_part[cl][1]; p[2] = (float)sdy;
+#pragma unroll
+            for (int cc = 0; cc < GCH; ++cc)
+                if (cb + cc < cpg) part[((size_t)n * C + gidx * cpg + cb + cc) * 3 + 2] = (float)sd[cc];
         }
     }
 }
 
-__global__ void gn_param_reduce_kernel(const float* __restrict__ part, int N, int C,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       float* __restrict__ dbias) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double a = 0.0, b = 0.0, d = 0.0;
-    for (int n = 0; n < N; ++n) {
+// one block per channel: sums part[n][c][0..2] over n in a fixed tree
+__global__ void __launch_bounds__(256)
+gn_param_reduce_kernel(const float* __restrict__ part, int N, int C,
+                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias) {
+    __shared__ double red[16 * 3 + 3];
+    const int c = blockIdx.x;
+    double v[3] = {0.0, 0.0, 0.0};
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
         const float* p = part + ((size_t)n * C + c) * 3;
-        a += p[0]; b += p[1]; d += p[2];
+        v[0] += p[0]; v[1] += p[1]; v[2] += p[2];
     }
-    dgamma[c] = (float)a;
-    dbeta[c] = (float)b;
-    if (dbias) dbias[c] = (float)d;
+    block_sum_multi<3>(v, red);
+    if (threadIdx.x == 0) {
+        dgamma[c] = (float)v[0];
+        dbeta[c] = (float)v[1];
+        if (dbias) dbias[c] = (float)v[2];
+    }
 }
 
 int check_view(const char* name, const View& v, int C) {
@@ -210,14 +360,19 @@ int gx_gn_relu_fwd(const float* y, const float* gamma, const float* beta, int N,
     if (rc) return rc;
     if (dst1) { rc = check_view("gx_gn_relu_fwd", d1, C); if (rc) return rc; }
     const int m = (C / groups) * H * W;
-    const int threads = m >= 2048 ? 512 : 256;
+    const int threads = m >= 16384 ? 1024 : (m >= 2048 ? 512 : 256);
+    const bool vec = (W % 4) == 0;
     {
         // algorithmic bytes: read y once, write each destination view once
         auto vw = [](int mode) { return mode == 1 ? 4.0 : (mode == 2 ? 0.25 : 1.0); };
         const double el = (double)N * C * H * W;
         GxProf pf(KID_GN_FWD, (hipStream_t)stream, 8.0 * el, 4.0 * el * (1.0 + vw(dst0_mode) + (dst1 ? vw(dst1_mode) : 0.0)));
-        hipLaunchKernelGGL(gn_relu_fwd_kernel, dim3(N * groups), dim3(threads), 0, (hipStream_t)stream, y, gamma,
-                           beta, C, H, W, groups, eps, d0, d1, mean, rstd);
+        if (vec)
+            hipLaunchKernelGGL(gn_relu_fwd_kernel<true>, dim3(N * groups), dim3(threads), 0, (hipStream_t)stream, y,
+                               gamma, beta, C, H, W, groups, eps, d0, d1, mean, rstd);
+        else
+            hipLaunchKernelGGL(gn_relu_fwd_kernel<false>, dim3(N * groups), dim3(threads), 0, (hipStream_t)stream, y,
+                               gamma, beta, C, H, W, groups, eps, d0, d1, mean, rstd);
     }
     GX_CHECK_LAUNCH("gx_gn_relu_fwd");
     return GX_OK;
@@ -231,28 +386,33 @@ int gx_gn_relu_bwd(const float* y, const float* gamma, const float* beta, const 
                    float* dbias, void* ws, size_t ws_bytes, gx_stream_t stream) {
     GX_CHECK_ARG(y && gamma && beta && mean && rstd && g0 && dy && dgamma && dbeta && ws,
                  "gx_gn_relu_bwd: null pointer");
-    GX_CHECK_ARG(N > 0 && C > 0 && groups > 0 && C % groups == 0 && C / groups <= 64,
-                 "gx_gn_relu_bwd: bad N/C/groups (channels per group must be <= 64)");
+    GX_CHECK_ARG(N > 0 && C > 0 && groups > 0 && C % groups == 0,
+                 "gx_gn_relu_bwd: bad N/C/groups");
     GX_CHECK_ARG(gx_is_pow2(H) && gx_is_pow2(W) && W >= 2 && H >= 2, "gx_gn_relu_bwd: H,W must be powers of two >= 2");
     GX_CHECK_ARG(ws_bytes >= gx_gn_relu_bwd_ws_bytes(N, C), "gx_gn_relu_bwd: workspace too small");
     View v0{const_cast<float*>(g0), g0_ctot, g0_c0, g0_mode}, v1{const_cast<float*>(g1), g1_ctot, g1_c0, g1_mode};
     int rc = check_view("gx_gn_relu_bwd", v0, C);
     if (rc) return rc;
     if (g1) { rc = check_view("gx_gn_relu_bwd", v1, C); if (rc) return rc; }
-    const int m = (C / groups) * H * W;
-    const int threads = m >= 2048 ? 512 : 256;
+    const int hw = H * W;
+    const bool vec = (W % 4) == 0;
+    const int threads = hw >= 4096 ? 1024 : (hw >= 1024 ? 256 : 64);
     hipStream_t s = (hipStream_t)stream;
     {
         auto vw = [](int mode) { return mode == 1 ? 4.0 : (mode == 2 ? 0.25 : 1.0); };
         const double el = (double)N * C * H * W;
         GxProf pf(KID_GN_BWD, s, 16.0 * el, 4.0 * el * (2.0 + vw(g0_mode) + (g1 ? vw(g1_mode) : 0.0)));
-        hipLaunchKernelGGL(gn_relu_bwd_kernel, dim3(N * groups), dim3(threads), 0, s, y, gamma, beta, mean, rstd, C,
-                           H, W, groups, v0, v1, dy, (float*)ws);
+        if (vec)
+            hipLaunchKernelGGL(gn_relu_bwd_kernel<true>, dim3(N * groups), dim3(threads), 0, s, y, gamma, beta, mean,
+                               rstd, C, H, W, groups, v0, v1, dy, (float*)ws);
+        else
+            hipLaunchKernelGGL(gn_relu_bwd_kernel<false>, dim3(N * groups), dim3(threads), 0, s, y, gamma, beta, mean,
+                               rstd, C, H, W, groups, v0, v1, dy, (float*)ws);
     }
     GX_CHECK_LAUNCH("gx_gn_relu_bwd");
     {
         GxProf pf(KID_GN_PARAM_REDUCE, s, 0.0, 12.0 * N * C);
-        hipLaunchKernelGGL(gn_param_reduce_kernel, dim3(gx_ceil_div(C, 64)), dim3(64), 0, s, (const float*)ws, N, C,
+        hipLaunchKernelGGL(gn_param_reduce_kernel, dim3(C), dim3(N >= 128 ? 256 : 64), 0, s, (const float*)ws, N, C,
                            dgamma, dbeta, dbias);
     }
     GX_CHECK_LAUNCH("gx_gn_relu_bwd(reduce)");

@@ -357,15 +357,19 @@ conv1x1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, 
     (void)rt;
 }
 
-// out[i] = scale * sum_blk part[blk][i]
-__global__ void col_sum_kernel(const float* __restrict__ part, int nblk, int n, const float* __restrict__ gate,
-                               float* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// out[i] = scale * sum_blk part[blk][i]; one block per output element, fixed reduction tree
+__global__ void __launch_bounds__(256)
+col_sum_kernel(const float* __restrict__ part, int nblk, int n, const float* __restrict__ gate,
+               float* __restrict__ out) {
+    __shared__ double red[4];
+    const int i = blockIdx.x;
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * n + i];
-    const float gt = gate ? *gate : 1.f;
-    out[i] = (float)(s * (double)gt);
+    for (int b = threadIdx.x; b < nblk; b += blockDim.x) s += part[(size_t)b * n + i];
+    s = block_sum_dd(s, red);
+    if (threadIdx.x == 0) {
+        const float gt = gate ? *gate : 1.f;
+        out[i] = (float)(s * (double)gt);
+    }
 }
 
 }  // namespace
@@ -492,15 +496,15 @@ int gx_conv1x1_bwd(const float* x, const float* dy, const float* w, const float*
     }
     GX_CHECK_LAUNCH("gx_conv1x1_bwd(wgrad)");
     const int npairs = Cout * Cin;
-    hipLaunchKernelGGL(col_sum_kernel, dim3(gx_ceil_div(npairs, 64)), dim3(64), 0, s, (const float*)pw, nblk, npairs,
+    hipLaunchKernelGGL(col_sum_kernel, dim3(npairs), dim3(256), 0, s, (const float*)pw, nblk, npairs,
                        gate, dw);
     GX_CHECK_LAUNCH("gx_conv1x1_bwd(dw)");
     if (db) {
-        hipLaunchKernelGGL(col_sum_kernel, dim3(1), dim3(64), 0, s, (const float*)pb, nblk, Cout, gate, db);
+        hipLaunchKernelGGL(col_sum_kernel, dim3(Cout), dim3(256), 0, s, (const float*)pb, nblk, Cout, gate, db);
         GX_CHECK_LAUNCH("gx_conv1x1_bwd(db)");
     }
     if (dgate) {
-        hipLaunchKernelGGL(col_sum_kernel, dim3(1), dim3(64), 0, s, (const float*)pg, nblk, 1, (const float*)nullptr,
+        hipLaunchKernelGGL(col_sum_kernel, dim3(1), dim3(256), 0, s, (const float*)pg, nblk, 1, (const float*)nullptr,
                            dgate);
         GX_CHECK_LAUNCH("gx_conv1x1_bwd(dgate)");
     }
