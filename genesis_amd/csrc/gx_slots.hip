@@ -261,100 +261,121 @@ conv1x1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, con
     }
 }
 
-// dx[n][ci][p] = gate * sum_co w[co][ci] dy[n][co][p]
+// dx[n][ci][p] = gate * sum_co w[co][ci] dy[n][co][p];  pb[blk][co] = sum_p dy[n][co][p] (ungated, per block)
 __global__ void __launch_bounds__(256)
 conv1x1_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, const float* __restrict__ gate,
-                     int Cin, int Cout, int HW, float* __restrict__ dx) {
+                     int Cin, int Cout, int HW, float* __restrict__ dx, float* __restrict__ pb) {
+    __shared__ double red[4];
     const int n = blockIdx.x;
     const int p = blockIdx.y * blockDim.x + threadIdx.x;
-    if (p >= HW) return;
     const float gt = gate ? *gate : 1.f;
-    float g[COMAX];
+    float raw[COMAX], g[COMAX];
 #pragma unroll
-    for (int co = 0; co < COMAX; ++co) g[co] = (co < Cout) ? gt * dy[((size_t)n * Cout + co) * HW + p] : 0.f;
-    float* dxn = dx + (size_t)n * Cin * HW + p;
-    for (int ci = 0; ci < Cin; ++ci) {
-        float s = 0.f;
+    for (int co = 0; co < COMAX; ++co) {
+        raw[co] = (co < Cout && p < HW) ? dy[((size_t)n * Cout + co) * HW + p] : 0.f;
+        g[co] = gt * raw[co];
+    }
+    if (p < HW) {
+        float* dxn = dx + (size_t)n * Cin * HW + p;
+        for (int ci = 0; ci < Cin; ++ci) {
+            float s = 0.f;
 #pragma unroll
-        for (int co = 0; co < COMAX; ++co)
-            if (co < Cout) s += w[co * Cin + ci] * g[co];
-        dxn[(size_t)ci * HW] = s;
+            for (int co = 0; co < COMAX; ++co)
+                if (co < Cout) s += w[co * Cin + ci] * g[co];
+            dxn[(size_t)ci * HW] = s;
+        }
+    }
+    const int blk = blockIdx.x * gridDim.y + blockIdx.y;
+#pragma unroll
+    for (int co = 0; co < COMAX; ++co) {
+        if (co < Cout) {
+            const double sum = block_sum_dd((double)raw[co], red);
+            if (threadIdx.x == 0) pb[(size_t)blk * Cout + co] = (float)sum;
+        }
     }
 }
 
-// Partials per block: pw[blk][co][ci] = sum_p dy[co][p] x[ci][p]; pb[blk][co] = sum_p dy[co][p];
-// pg[blk] = sum_{co,p} dy[co][p] * (sum_ci w x + b)  (gate gradient).
-// One block per (image, 1024-pixel chunk); tiles of 64 pixels staged in LDS; thread (co, ci) accumulates.
-__global__ void __launch_bounds__(512)
-conv1x1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ w,
-                     const float* __restrict__ bias, int Cin, int Cout, int HW, int chunk,
-                     float* __restrict__ pw, float* __restrict__ pb, float* __restrict__ pg) {
-    extern __shared__ __attribute__((aligned(16))) float sh[];
-    float* xt = sh;                    // [Cin][65]
-    float* dt = sh + Cin * 65;         // [COMAX][64]
-    float* rt = dt + COMAX * 64;       // [64] raw conv output partial per pixel (for the gate gradient)
-    __shared__ double red[8];
-    const int n = blockIdx.x;
-    const int p0 = blockIdx.y * chunk;
-    const int tid = threadIdx.x;
-    const int nthr = blockDim.x;
-    const int blk = blockIdx.x * gridDim.y + blockIdx.y;
-    // thread -> (co, ci) pairs: pair index q = tid + j*nthr
-    float acc[2] = {0.f, 0.f};
-    float accb = 0.f;
-    double accg = 0.0;
+// Weight gradient of the small 1x1 conv on the fp32 matrix cores (v_mfma_f32_16x16x4_f32):
+//   D[co (16, Cout <= 8 valid)][ci 16-tile] += A[co][k] * B[k][ci],  k = 4 pixel slots.
+// HBM-bound (x is read exactly once).  Both operands go global -> registers: k slot q of a wave owns 16
+// contiguous pixels of the wave's 64-pixel chunk, so each lane streams one channel row with 16-byte loads.
+// pw[blk][co][ci] (ungated partial per block; the 4 waves of a block are combined through LDS).
+template <int CIT>   // ci tiles of 16 (Cin <= 16*CIT)
+__global__ void __launch_bounds__(256)
+conv1x1_wgrad_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dy, int N, int Cin, int Cout,
+                          int HW, float* __restrict__ pw) {
+    __shared__ float red[4][16][16 * CIT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = lane & 15, q = lane >> 4;
+    const int chunks_per_img = HW >> 6;
+    const int nchunks = N * chunks_per_img;
+    f32x4 acc[CIT];
+#pragma unroll
+    for (int t = 0; t < CIT; ++t) { acc[t][0] = 0.f; acc[t][1] = 0.f; acc[t][2] = 0.f; acc[t][3] = 0.f; }
+    for (int c = blockIdx.x * 4 + wave; c < nchunks; c += gridDim.x * 4) {
+        const int n = c / chunks_per_img;
+        const int p0 = (c - n * chunks_per_img) * 64 + q * 16;
+        f32x4 av[4], bv[CIT][4];
+        const bool a_ok = row < Cout;
+        const float* ap = dy + ((size_t)n * Cout + (a_ok ? row : 0)) * HW + p0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            av[i] = *reinterpret_cast<const f32x4*>(ap + 4 * i);
+            if (!a_ok) { av[i][0] = 0.f; av[i][1] = 0.f; av[i][2] = 0.f; av[i][3] = 0.f; }
+        }
+#pragma unroll
+        for (int t = 0; t < CIT; ++t) {
+            const int ci = t * 16 + row;
+            const bool b_ok = ci < Cin;
+            const float* bp = x + ((size_t)n * Cin + (b_ok ? ci : 0)) * HW + p0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bv[t][i] = *reinterpret_cast<const f32x4*>(bp + 4 * i);
+                if (!b_ok) { bv[t][i][0] = 0.f; bv[t][i][1] = 0.f; bv[t][i][2] = 0.f; bv[t][i][3] = 0.f; }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int t = 0; t < CIT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][u], bv[t][i][u], acc[t], 0, 0, 0);
+    }
+    // C/D layout (16x16): col = lane & 15 (ci), row = (lane >> 4) * 4 + reg (co)
+#pragma unroll
+    for (int t = 0; t < CIT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][q * 4 + r][t * 16 + row] = acc[t][r];
+    __syncthreads();
+    for (int i = threadIdx.x; i < Cout * Cin; i += blockDim.x) {
+        const int co = i / Cin, ci = i - co * Cin;
+        pw[(size_t)blockIdx.x * Cout * Cin + i] = (red[0][co][ci] + red[1][co][ci]) + (red[2][co][ci] + red[3][co][ci]);
+    }
+}
+
+// raw = [dw_raw (Cout*Cin) | db_raw (Cout)] (ungated sums).  dgate = <w, dw_raw> + <b, db_raw>
+// (since sum_p dy*(W x + b) = sum_ci w * (sum_p dy x) + b * sum_p dy); dw = gate*dw_raw; db = gate*db_raw.
+__global__ void __launch_bounds__(256)
+conv1x1_finalize_kernel(const float* __restrict__ raw, const float* __restrict__ w, const float* __restrict__ bias,
+                        const float* __restrict__ gate, int Cin, int Cout, float* __restrict__ dw,
+                        float* __restrict__ db, float* __restrict__ dgate) {
+    __shared__ double red[4];
     const int npairs = Cout * Cin;
-    for (int t0 = 0; t0 < chunk; t0 += 64) {
-        __syncthreads();
-        for (int i = tid; i < Cin * 64; i += nthr) {
-            const int ci = i >> 6, pp = i & 63;
-            const int p = p0 + t0 + pp;
-            xt[ci * 65 + pp] = (p < HW) ? x[((size_t)n * Cin + ci) * HW + p] : 0.f;
-        }
-        for (int i = tid; i < Cout * 64; i += nthr) {
-            const int co = i >> 6, pp = i & 63;
-            const int p = p0 + t0 + pp;
-            dt[co * 64 + pp] = (p < HW) ? dy[((size_t)n * Cout + co) * HW + p] : 0.f;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int q = tid + j * nthr;
-            if (q < npairs) {
-                const int co = q / Cin, ci = q - co * Cin;
-                float s = 0.f;
-                for (int pp = 0; pp < 64; ++pp) s += dt[co * 64 + pp] * xt[ci * 65 + pp];
-                acc[j] += s;
-            }
-        }
-        if (tid < Cout) {
-            float s = 0.f;
-            for (int pp = 0; pp < 64; ++pp) s += dt[tid * 64 + pp];
-            accb += s;
-        }
-        if (pg && tid >= 64 && tid < 128) {
-            // gate gradient: pixel pp = tid-64: sum_co dy[co] * (w[co].x + b[co])
-            const int pp = tid - 64;
-            float s = 0.f;
-            for (int co = 0; co < Cout; ++co) {
-                float raw = bias ? bias[co] : 0.f;
-                for (int ci = 0; ci < Cin; ++ci) raw += w[co * Cin + ci] * xt[ci * 65 + pp];
-                s += dt[co * 64 + pp] * raw;
-            }
-            accg += (double)s;
-        }
+    const float gt = gate ? *gate : 1.f;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < npairs; i += blockDim.x) {
+        const float r = raw[i];
+        dw[i] = gt * r;
+        s += (double)r * w[i];
     }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int q = tid + j * nthr;
-        if (q < npairs) pw[(size_t)blk * npairs + q] = acc[j];
+    for (int i = threadIdx.x; i < Cout; i += blockDim.x) {
+        const float r = raw[npairs + i];
+        if (db) db[i] = gt * r;
+        if (bias) s += (double)r * bias[i];
     }
-    if (tid < Cout) pb[(size_t)blk * Cout + tid] = accb;
-    if (pg) {
-        const double s = block_sum_dd(accg, red);
-        if (tid == 0) pg[blk] = (float)s;
-    }
-    (void)rt;
+    s = block_sum_dd(s, red);
+    if (threadIdx.x == 0 && dgate) *dgate = (float)s;
 }
 
 // out[i] = scale * sum_blk part[blk][i]; one block per output element, fixed reduction tree
@@ -458,56 +479,60 @@ int gx_conv1x1_fwd(const float* x, const float* w, const float* bias, const floa
     return GX_OK;
 }
 
-static int conv1x1_chunk(int HW) { return HW < 1024 ? gx_round_up(HW, 64) : 1024; }
+static int conv1x1_wgrad_blocks(int N, int HW) {
+    const int nchunks = N * (HW / 64);
+    int b = gx_ceil_div(nchunks, 4);
+    return b > 1024 ? 1024 : (b < 1 ? 1 : b);
+}
 
 size_t gx_conv1x1_bwd_ws_bytes(int N, int Cin, int Cout, int H, int W) {
     const int HW = H * W;
-    const size_t nblk = (size_t)N * gx_ceil_div(HW, conv1x1_chunk(HW));
-    return nblk * ((size_t)Cout * Cin + Cout + 1) * sizeof(float);
+    const size_t nblkw = conv1x1_wgrad_blocks(N, HW);
+    const size_t nblkd = (size_t)N * gx_ceil_div(HW, 256);
+    return (nblkw * Cout * Cin + nblkd * Cout + (size_t)Cout * Cin + Cout) * sizeof(float);
 }
 
 int gx_conv1x1_bwd(const float* x, const float* dy, const float* w, const float* bias, const float* gate, int N,
                    int Cin, int Cout, int H, int W, float* dx, float* dw, float* db, float* dgate, void* ws,
                    size_t ws_bytes, gx_stream_t stream) {
     GX_CHECK_ARG(x && dy && w && dx && dw && ws, "gx_conv1x1_bwd: null pointer");
-    GX_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && Cout <= COMAX && Cin * Cout <= 1024,
-                 "gx_conv1x1_bwd: Cout must be <= 8 and Cin*Cout <= 1024");
+    GX_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && Cout <= COMAX && Cin <= 128,
+                 "gx_conv1x1_bwd: Cout must be <= 8 and Cin <= 128");
     GX_CHECK_ARG((gate == nullptr) == (dgate == nullptr), "gx_conv1x1_bwd: gate and dgate go together");
-    GX_CHECK_ARG(ws_bytes >= gx_conv1x1_bwd_ws_bytes(N, Cin, Cout, H, W), "gx_conv1x1_bwd: workspace too small");
     const int HW = H * W;
-    const int chunk = conv1x1_chunk(HW);
-    const int nchunks = gx_ceil_div(HW, chunk);
-    const int nblk = N * nchunks;
+    GX_CHECK_ARG(HW % 64 == 0, "gx_conv1x1_bwd: H*W must be a multiple of 64");
+    GX_CHECK_ARG(ws_bytes >= gx_conv1x1_bwd_ws_bytes(N, Cin, Cout, H, W), "gx_conv1x1_bwd: workspace too small");
+    const int nblkw = conv1x1_wgrad_blocks(N, HW);
+    const int nblkd = N * gx_ceil_div(HW, 256);
+    const int npairs = Cout * Cin;
+    float* pw = (float*)ws;
+    float* pb = pw + (size_t)nblkw * npairs;
+    float* raw = pb + (size_t)nblkd * Cout;
     hipStream_t s = (hipStream_t)stream;
     {
         GxProf pf(KID_CONV1X1_DGRAD, s, 2.0 * N * Cin * Cout * HW, 4.0 * N * HW * (Cin + Cout));
         hipLaunchKernelGGL(conv1x1_dgrad_kernel, dim3(N, gx_ceil_div(HW, 256)), dim3(256), 0, s, dy, w, gate, Cin,
-                           Cout, HW, dx);
+                           Cout, HW, dx, pb);
     }
     GX_CHECK_LAUNCH("gx_conv1x1_bwd(dgrad)");
-    float* pw = (float*)ws;
-    float* pb = pw + (size_t)nblk * Cout * Cin;
-    float* pg = pb + (size_t)nblk * Cout;
-    const size_t lds = (size_t)(Cin * 65 + COMAX * 64 + 64) * sizeof(float);
     {
         GxProf pf(KID_CONV1X1_WGRAD, s, 2.0 * N * Cin * Cout * HW, 4.0 * N * HW * (Cin + Cout));
-        hipLaunchKernelGGL(conv1x1_wgrad_kernel, dim3(N, nchunks), dim3(512), lds, s, x, dy, w, bias, Cin, Cout, HW,
-                           chunk, pw, pb, gate ? pg : (float*)nullptr);
+        if (Cin <= 64)
+            hipLaunchKernelGGL(conv1x1_wgrad_mfma_kernel<4>, dim3(nblkw), dim3(256), 0, s, x, dy, N, Cin, Cout, HW, pw);
+        else
+            hipLaunchKernelGGL(conv1x1_wgrad_mfma_kernel<8>, dim3(nblkw), dim3(256), 0, s, x, dy, N, Cin, Cout, HW, pw);
     }
     GX_CHECK_LAUNCH("gx_conv1x1_bwd(wgrad)");
-    const int npairs = Cout * Cin;
-    hipLaunchKernelGGL(col_sum_kernel, dim3(npairs), dim3(256), 0, s, (const float*)pw, nblk, npairs,
-                       gate, dw);
-    GX_CHECK_LAUNCH("gx_conv1x1_bwd(dw)");
-    if (db) {
-        hipLaunchKernelGGL(col_sum_kernel, dim3(Cout), dim3(256), 0, s, (const float*)pb, nblk, Cout, gate, db);
-        GX_CHECK_LAUNCH("gx_conv1x1_bwd(db)");
+    {
+        GxProf pf(KID_SMALL_REDUCE, s, 0.0, 4.0 * ((double)nblkw * npairs + (double)nblkd * Cout));
+        hipLaunchKernelGGL(col_sum_kernel, dim3(npairs), dim3(256), 0, s, (const float*)pw, nblkw, npairs,
+                           (const float*)nullptr, raw);
+        hipLaunchKernelGGL(col_sum_kernel, dim3(Cout), dim3(256), 0, s, (const float*)pb, nblkd, Cout,
+                           (const float*)nullptr, raw + npairs);
+        hipLaunchKernelGGL(conv1x1_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)raw, w, bias, gate, Cin,
+                           Cout, dw, db, dgate);
     }
-    if (dgate) {
-        hipLaunchKernelGGL(col_sum_kernel, dim3(1), dim3(256), 0, s, (const float*)pg, nblk, 1, (const float*)nullptr,
-                           dgate);
-        GX_CHECK_LAUNCH("gx_conv1x1_bwd(dgate)");
-    }
+    GX_CHECK_LAUNCH("gx_conv1x1_bwd(finalize)");
     return GX_OK;
 }
 
