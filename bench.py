@@ -57,6 +57,22 @@ def build_model(args, device):
     return G.load(cfg).to(device).train()
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    in separate runs of this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM'); None if absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_hbm_traffic.json')
+    if not os.path.exists(path):
+        return None
+    data = json.load(open(path))
+    stem = kernel.rstrip('>')          # 'tapconv_kernel<0' matches 'tapconv_kernel<0, 2>' and '<0, 4>'
+    tot, n = 0.0, 0
+    for name, v in data.items():
+        if name == kernel or name.startswith(stem + ',') or name.startswith(stem + '>') or name.startswith(stem + '<'):
+            tot += v['hbm_bytes_per_launch_corrected'] * v['launches']
+            n += v['launches']
+    return tot / n if n else None
+
+
 def cpu_baseline(args):
     """Oracle (reference-equivalent form: per-slot loops, K-fold feat_head) full training step on host cores."""
     from oracle import v2_oracle as O
@@ -182,7 +198,9 @@ def main():
             ach = dom['bytes'] / sec / 1e9
             roof = {'bound': 'hbm', 'kernel': dom['name'], 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                     'frac': ach / PEAK_HBM_GBS}
-        roof.update({'traffic': None, 'avg_launch_us': 1e3 * dom['ms'] / dom['launches'],
+        roof.update({'traffic': pmc_traffic(dom['name']), 'traffic_unit': 'bytes/launch (PMC, separate pass)',
+                     'algorithmic_bytes_per_launch': dom['bytes'] / dom['launches'],
+                     'avg_launch_us': 1e3 * dom['ms'] / dom['launches'],
                      'launches_per_step': dom['launches'] / args.profile_steps,
                      'share_of_kernel_time': dom['ms'] / total_ms,
                      'kernel_ms_per_step': total_ms / args.profile_steps})

@@ -590,8 +590,7 @@ int plan_tapconv(int N, int K, int M, int Mpad_pack, int Hb, int Wb, int Hi, int
     const int base = ptiles * mtiles;
     if (base < 384) {
         nsplit = gx_ceil_div(512, base);
-        const int max_split = nchunks / 2 > 0 ? nchunks / 2 : 1;   // at least 2 chunks per split
-        if (nsplit > max_split) nsplit = max_split;
+        if (nsplit > nchunks) nsplit = nchunks;
         if (nsplit > 64) nsplit = 64;
         if (nsplit < 1) nsplit = 1;
     }
