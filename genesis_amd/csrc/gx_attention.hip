@@ -120,117 +120,126 @@ icsbp_fwd_kernel(const float* __restrict__ colour, const double* __restrict__ lo
     for (int p = tid; p < HW; p += T) log_m[(K - 1) * kstride + (size_t)b * HW + p] = ls[p];
 }
 
-__device__ __forceinline__ double block_sum_d1024(double v, double* red) {
-    v = gx_wave_sum_d(v);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+// Reduces NV per-thread doubles over the block at once (wave shuffles + one LDS hop), result broadcast.
+template <int NV>
+__device__ __forceinline__ void block_sum_multi(double (&v)[NV], double* red /* [16][NV] + [NV] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = gx_wave_sum_d(v[i]);
     __syncthreads();
-    if (lane == 0) red[wave] = v;
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) red[wave * NV + i] = v[i];
+    }
     __syncthreads();
-    double s = 0.0;
-    for (int i = 0; i < nw; ++i) s += red[i];
-    return s;
+    if (threadIdx.x < NV) {
+        double s = 0.0;
+        for (int w = 0; w < nw; ++w) s += red[w * NV + threadIdx.x];
+        red[16 * NV + threadIdx.x] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = red[16 * NV + i];
 }
 
-// g_m: gradient w.r.t. the K stacked log-masks [K,B,HW].  dcolour must be zero-initialised? No: it is
-// fully written here (first touched step writes, later steps accumulate).
-__global__ void __launch_bounds__(1024)
+// Backward, stage 1: one thread per pixel (the recursion is per-pixel independent: the gradient w.r.t. the
+// scope leaving step t is the suffix sum of the mask gradients).  grid (B, HW/T).  Writes d colour for the
+// direct path and, per (image, chunk, step), the block-reduced seed gradient [C] and d sigma:
+// part[b][chunk][t][0..C-1] = -sum_p 2 gd diff_c,  part[...][MAXC] = sum_p galpha * d alpha / d sigma.
+__global__ void __launch_bounds__(256)
 icsbp_bwd_kernel(const float* __restrict__ colour, const double* __restrict__ log_sigma,
-                 const float* __restrict__ seeds, const int64_t* __restrict__ seed_idx,
-                 const float* __restrict__ g_m, int B, int C, int HW, int K, int kernel_type,
-                 float* __restrict__ dcolour, double* __restrict__ dlog_sigma_part) {
-    __shared__ double red[16];
-    __shared__ float seed_sh[MAXC];
-    __shared__ float seed_grad[16][MAXC];  // K-1 <= 16
-    const int b = blockIdx.x, T = blockDim.x, tid = threadIdx.x;
-    const float* col = colour + (size_t)b * C * HW;
-    float* dcol = dcolour + (size_t)b * C * HW;
+                 const float* __restrict__ seeds, const float* __restrict__ g_m, int B, int C, int HW, int K,
+                 int kernel_type, float* __restrict__ dcolour, double* __restrict__ part) {
+    __shared__ double red[16 * (MAXC + 1) + (MAXC + 1)];
+    __shared__ float seed_sh[16][MAXC];   // K-1 <= 16
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int p = blockIdx.y * blockDim.x + tid;
+    const bool ok = p < HW;
     const float sigma = (float)exp(*log_sigma);
     const size_t kstride = (size_t)B * HW;
-
-    // gradient w.r.t. the scope leaving step t (suffix sum of mask grads), per pixel, in LDS
-    extern __shared__ __attribute__((aligned(16))) float gs[];
-    for (int p = tid; p < HW; p += T) gs[p] = g_m[(K - 1) * kstride + (size_t)b * HW + p];
-    double dsig = 0.0;
-
+    for (int i = tid; i < (K - 1) * C; i += blockDim.x) seed_sh[i / C][i % C] = seeds[((size_t)(i / C) * B + b) * C + i % C];
+    float col[MAXC], dcol[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        col[c] = (ok && c < C) ? colour[((size_t)b * C + c) * HW + p] : 0.f;
+        dcol[c] = 0.f;
+    }
+    float gs = ok ? g_m[(K - 1) * kstride + (size_t)b * HW + p] : 0.f;
+    __syncthreads();
     for (int t = K - 2; t >= 0; --t) {
-        __syncthreads();
-        if (tid < C) seed_sh[tid] = seeds[((size_t)t * B + b) * C + tid];
-        __syncthreads();
-        float gseed[MAXC];
+        double vals[MAXC + 1];
+        float diff[MAXC];
+        float d = 0.f;
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) gseed[c] = 0.f;
-        for (int p = tid; p < HW; p += T) {
-            {
-                float diff[MAXC];
-                float d = 0.f;
-#pragma unroll
-                for (int c = 0; c < MAXC; ++c) {
-                    if (c < C) {
-                        diff[c] = col[(size_t)c * HW + p] - seed_sh[c];
-                        d += diff[c] * diff[c];
-                    } else {
-                        diff[c] = 0.f;
-                    }
-                }
-                float alpha, dalpha_dd, dalpha_dsig;  // unclamped alpha and its partials
-                if (kernel_type == KERNEL_GAUSSIAN) {
-                    alpha = expf(-d / sigma);
-                    dalpha_dd = -alpha / sigma;
-                    dalpha_dsig = alpha * d / (sigma * sigma);
-                } else if (kernel_type == KERNEL_LAPLACIAN) {
-                    const float dist = sqrtf(st_clamp(d, 1e-10f, 1e10f));
-                    alpha = expf(-dist / sigma);
-                    dalpha_dd = -alpha / sigma * (0.5f / dist);
-                    dalpha_dsig = alpha * dist / (sigma * sigma);
-                } else {
-                    const float u = 1.f - d / sigma;
-                    alpha = fmaxf(u, 0.f);
-                    const float on = u > 0.f ? 1.f : 0.f;
-                    dalpha_dd = -on / sigma;
-                    dalpha_dsig = on * d / (sigma * sigma);
-                }
-                const float ac = st_clamp(alpha, 0.01f, 0.99f);
-                const float gm_t = g_m[t * kstride + (size_t)b * HW + p];
-                // log_m_t = s_t + log(ac); s_{t+1} = s_t + log(1-ac); straight-through: d ac / d alpha = 1
-                const float gsp = gs[p];
-                const float galpha = gm_t / ac - gsp / (1.f - ac);
-                gs[p] = gsp + gm_t;
-                const float gd = galpha * dalpha_dd;
-                dsig += (double)(galpha * dalpha_dsig);
-#pragma unroll
-                for (int c = 0; c < MAXC; ++c) {
-                    if (c < C) {
-                        const float gc = 2.f * gd * diff[c];
-                        float* dp = dcol + (size_t)c * HW + p;
-                        if (t == K - 2) *dp = gc; else *dp += gc;
-                        gseed[c] -= gc;
-                    }
-                }
-            }
+        for (int c = 0; c < MAXC; ++c) {
+            diff[c] = (c < C) ? col[c] - seed_sh[t][c] : 0.f;
+            d += diff[c] * diff[c];
         }
-        for (int c = 0; c < C; ++c) {
-            float v = 0.f;
-#pragma unroll
-            for (int cc = 0; cc < MAXC; ++cc) if (cc == c) v = gseed[cc];
-            const double s = block_sum_d1024((double)v, red);
-            if (tid == 0) seed_grad[t][c] = (float)s;
+        float alpha, dalpha_dd, dalpha_dsig;  // unclamped alpha and its partials
+        if (kernel_type == KERNEL_GAUSSIAN) {
+            alpha = expf(-d / sigma);
+            dalpha_dd = -alpha / sigma;
+            dalpha_dsig = alpha * d / (sigma * sigma);
+        } else if (kernel_type == KERNEL_LAPLACIAN) {
+            const float dist = sqrtf(st_clamp(d, 1e-10f, 1e10f));
+            alpha = expf(-dist / sigma);
+            dalpha_dd = -alpha / sigma * (0.5f / dist);
+            dalpha_dsig = alpha * dist / (sigma * sigma);
+        } else {
+            const float u = 1.f - d / sigma;
+            alpha = fmaxf(u, 0.f);
+            const float on = u > 0.f ? 1.f : 0.f;
+            dalpha_dd = -on / sigma;
+            dalpha_dsig = on * d / (sigma * sigma);
         }
+        const float ac = st_clamp(alpha, 0.01f, 0.99f);
+        const float gm_t = ok ? g_m[t * kstride + (size_t)b * HW + p] : 0.f;
+        // log_m_t = s_t + log(ac); s_{t+1} = s_t + log(1-ac); straight-through: d ac / d alpha = 1
+        const float galpha = gm_t / ac - gs / (1.f - ac);
+        gs += gm_t;
+        const float gd = galpha * dalpha_dd;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const float gc = 2.f * gd * diff[c];
+            dcol[c] += gc;
+            vals[c] = ok ? -(double)gc : 0.0;
+        }
+        vals[MAXC] = ok ? (double)(galpha * dalpha_dsig) : 0.0;
+        block_sum_multi<MAXC + 1>(vals, red);
+        if (tid <= MAXC)
+            part[(((size_t)b * gridDim.y + blockIdx.y) * (K - 1) + t) * (MAXC + 1) + tid] = vals[tid < MAXC ? tid : MAXC];
     }
-    if (K < 2) {
-        // no SBP step ran: colour receives no gradient
-        for (int p = tid; p < HW; p += T)
-            for (int c = 0; c < C; ++c) dcol[(size_t)c * HW + p] = 0.f;
+    if (ok) {
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < C) dcolour[((size_t)b * C + c) * HW + p] = dcol[c];
     }
-    const double ds = block_sum_d1024(dsig, red);
+}
+
+// Stage 2 (grid B): sums the per-chunk partials in a fixed order, scatter-adds the gradient that flows through
+// the gathered seed into the seed pixel (modules/attention.py:190-193), and emits d log_sigma per image.
+__global__ void __launch_bounds__(256)
+icsbp_bwd_finalize_kernel(const double* __restrict__ part, const int64_t* __restrict__ seed_idx,
+                          const double* __restrict__ log_sigma, int B, int C, int HW, int K, int nchunks,
+                          float* __restrict__ dcolour, double* __restrict__ dlog_sigma_part) {
+    __shared__ double sums[16][MAXC + 1];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = (K - 1) * (MAXC + 1);
+    for (int i = tid; i < n; i += blockDim.x) {
+        const int t = i / (MAXC + 1), c = i % (MAXC + 1);
+        double s = 0.0;
+        for (int ch = 0; ch < nchunks; ++ch) s += part[(((size_t)b * nchunks + ch) * (K - 1) + t) * (MAXC + 1) + c];
+        sums[t][c] = s;
+    }
     __syncthreads();
     if (tid == 0) {
-        // d log_sigma = d sigma * sigma   (sigma = exp(log_sigma))
-        dlog_sigma_part[b] = ds * (double)sigma;
-        // gradient through the gathered seed: scatter-add into the seed pixel (modules/attention.py:190-193)
+        double ds = 0.0;
         for (int t = 0; t < K - 1; ++t) {
+            ds += sums[t][MAXC];
             const int idx = (int)seed_idx[(size_t)t * B + b];
-            for (int c = 0; c < C; ++c) dcol[(size_t)c * HW + idx] += seed_grad[t][c];
+            for (int c = 0; c < C; ++c) dcolour[((size_t)b * C + c) * HW + idx] += (float)sums[t][c];
         }
+        dlog_sigma_part[b] = ds * exp(*log_sigma);   // d log_sigma = d sigma * sigma
     }
 }
 
@@ -271,7 +280,13 @@ int gx_icsbp_fwd(const float* colour, const double* log_sigma, const float* rand
     return GX_OK;
 }
 
-size_t gx_icsbp_bwd_ws_bytes(int B) { return (size_t)B * sizeof(double); }
+static int icsbp_bwd_threads(int HW) { return HW < 256 ? HW : 256; }
+
+size_t gx_icsbp_bwd_ws_bytes(int B, int H, int W, int K) {
+    const int HW = H * W;
+    const int nch = gx_ceil_div(HW, icsbp_bwd_threads(HW));
+    return ((size_t)B * nch * (K > 1 ? K - 1 : 1) * (MAXC + 1) + B) * sizeof(double);
+}
 
 int gx_icsbp_bwd(const float* colour, const double* log_sigma, const float* seeds, const int64_t* seed_idx,
                  const float* g_log_m, int B, int C, int H, int W, int K, int kernel_type, float* dcolour,
@@ -282,19 +297,25 @@ int gx_icsbp_bwd(const float* colour, const double* log_sigma, const float* seed
     GX_CHECK_ARG(B > 0 && C > 0 && C <= MAXC && K >= 1 && K <= 17, "gx_icsbp_bwd: bad B/C/K (C<=8, K<=17)");
     GX_CHECK_ARG(gx_is_pow2(HW) && HW >= 64 && HW <= 1024 * MAXPPT, "gx_icsbp_bwd: H*W must be a power of two in [64,16384]");
     GX_CHECK_ARG(kernel_type >= 0 && kernel_type <= 2, "gx_icsbp_bwd: no valid kernel");
-    GX_CHECK_ARG(ws_bytes >= gx_icsbp_bwd_ws_bytes(B), "gx_icsbp_bwd: workspace too small");
+    GX_CHECK_ARG(ws_bytes >= gx_icsbp_bwd_ws_bytes(B, H, W, K), "gx_icsbp_bwd: workspace too small");
     hipStream_t s = (hipStream_t)stream;
+    const int T = icsbp_bwd_threads(HW);
+    const int nch = gx_ceil_div(HW, T);
+    double* part = (double*)ws;
+    double* per_img = part + (size_t)B * nch * (K > 1 ? K - 1 : 1) * (MAXC + 1);
     {
         GxProf pf(KID_ICSBP_BWD, s, 0.0, 4.0 * B * HW * (2.0 * C + K));
-        hipLaunchKernelGGL(icsbp_bwd_kernel, dim3(B), dim3(threads_for(HW)), HW * sizeof(float), s, colour, log_sigma,
-                           seeds, seed_idx, g_log_m, B, C, HW, K, kernel_type, dcolour, (double*)ws);
+        hipLaunchKernelGGL(icsbp_bwd_kernel, dim3(B, nch), dim3(T), 0, s, colour, log_sigma, seeds, g_log_m, B, C, HW,
+                           K, kernel_type, dcolour, part);
     }
     GX_CHECK_LAUNCH("gx_icsbp_bwd");
     {
-        GxProf pf(KID_SMALL_REDUCE, s, 0.0, 8.0 * B);
-        hipLaunchKernelGGL(sum_double_kernel, dim3(1), dim3(64), 0, s, (const double*)ws, B, dlog_sigma);
+        GxProf pf(KID_SMALL_REDUCE, s, 0.0, 8.0 * B * nch * K * (MAXC + 1));
+        hipLaunchKernelGGL(icsbp_bwd_finalize_kernel, dim3(B), dim3(256), 0, s, (const double*)part, seed_idx,
+                           log_sigma, B, C, HW, K, nch, dcolour, per_img);
+        hipLaunchKernelGGL(sum_double_kernel, dim3(1), dim3(64), 0, s, (const double*)per_img, B, dlog_sigma);
     }
-    GX_CHECK_LAUNCH("gx_icsbp_bwd(reduce)");
+    GX_CHECK_LAUNCH("gx_icsbp_bwd(finalize)");
     return GX_OK;
 }
 

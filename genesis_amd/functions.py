@@ -18,6 +18,23 @@ from . import hip_ops as hip
 GROUPS = 8
 EPS = 1e-5
 
+# When True (set by TrainStep around its iteration: the flat gradient bucket is zeroed every step and every
+# parameter is used once), weight-gradient kernels write straight into `param.grad` and the Functions return
+# None for those parameters -- no AccumulateGrad `grad += new` launch per parameter.
+DIRECT_PARAM_GRADS = False
+
+
+def _gout(p):
+    """Destination for a parameter gradient: p.grad if direct writes are on and it is a usable buffer."""
+    if DIRECT_PARAM_GRADS and isinstance(p, torch.nn.Parameter) and p.grad is not None and p.grad.is_contiguous():
+        return p.grad
+    return None
+
+
+def _ret(out, value):
+    """What a Function returns for a parameter: None if the kernel already wrote into p.grad."""
+    return None if out is not None else value
+
 
 class ConvGNReLUFn(torch.autograd.Function):
     @staticmethod
@@ -26,16 +43,20 @@ class ConvGNReLUFn(torch.autograd.Function):
         y = hip.conv3x3_fwd(x, w)
         out = torch.empty_like(y)
         mean, rstd = hip.gn_relu_fwd(y, gamma, beta, GROUPS, EPS, (out, 0, 0))
-        ctx.save_for_backward(x, w, gamma, beta, y, mean, rstd)
+        ctx.save_for_backward(x, y, mean, rstd)
+        ctx.params = (w, gamma, beta)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, w, gamma, beta, y, mean, rstd = ctx.saved_tensors
-        dy, dgamma, dbeta, _ = hip.gn_relu_bwd(y, gamma, beta, mean, rstd, GROUPS, (g.contiguous(), 0, 0))
-        dw = hip.conv3x3_wgrad(x, dy)
+        x, y, mean, rstd = ctx.saved_tensors
+        w, gamma, beta = ctx.params
+        ow, og, ob = _gout(w), _gout(gamma), _gout(beta)
+        dy, dgamma, dbeta, _ = hip.gn_relu_bwd(y, gamma, beta, mean, rstd, GROUPS, (g.contiguous(), 0, 0),
+                                               out=(og, ob, None))
+        dw = hip.conv3x3_wgrad(x, dy, out=ow)
         dx = hip.conv3x3_dgrad(dy, w) if ctx.needs_input_grad[0] else None
-        return dx, dw, dgamma, dbeta
+        return dx, _ret(ow, dw), _ret(og, dgamma), _ret(ob, dbeta)
 
 
 class UNetEncoderFn(torch.autograd.Function):
@@ -116,10 +137,11 @@ class UNetEncoderFn(torch.autograd.Function):
         for j in reversed(range(nb)):
             w, gamma, beta = up[j]
             y, mean, rstd = ctx.saved_up[j]
-            dy, dgamma, dbeta, _ = hip.gn_relu_bwd(y, gamma, beta, mean, rstd, GROUPS, gsrc)
-            dw = hip.conv3x3_wgrad(cats[j], dy)
+            ow, og, ob = _gout(w), _gout(gamma), _gout(beta)
+            dy, dgamma, dbeta, _ = hip.gn_relu_bwd(y, gamma, beta, mean, rstd, GROUPS, gsrc, out=(og, ob, None))
+            dw = hip.conv3x3_wgrad(cats[j], dy, out=ow)
             dcat[j] = hip.conv3x3_dgrad(dy, w)
-            g_up[j] = (dw, dgamma, dbeta)
+            g_up[j] = (_ret(ow, dw), _ret(og, dgamma), _ret(ob, dbeta))
             gsrc = (dcat[j], 0, 1)   # block j-1's output was 2x up-sampled into cat_j[:, :Cx]
         # MLP backward
         mlp_leaf, mlp_p, h = ctx.mlp
@@ -138,9 +160,10 @@ class UNetEncoderFn(torch.autograd.Function):
             cx = cats[j].shape[1] - C
             g0 = (dcat[j], cx, 0)
             g1 = (d_mlp_in, 0, 0) if i == nb - 1 else (d_next, 0, 2)
-            dy, dgamma, dbeta, _ = hip.gn_relu_bwd(y, gamma, beta, mean, rstd, GROUPS, g0, g1)
-            dw = hip.conv3x3_wgrad(cur, dy)
-            g_down[i] = (dw, dgamma, dbeta)
+            ow, og, ob = _gout(w), _gout(gamma), _gout(beta)
+            dy, dgamma, dbeta, _ = hip.gn_relu_bwd(y, gamma, beta, mean, rstd, GROUPS, g0, g1, out=(og, ob, None))
+            dw = hip.conv3x3_wgrad(cur, dy, out=ow)
+            g_down[i] = (_ret(ow, dw), _ret(og, dgamma), _ret(ob, dbeta))
             if i > 0:
                 d_next = hip.conv3x3_dgrad(dy, w)
             elif ctx.needs_input_grad[0]:
@@ -228,12 +251,14 @@ class DecoderFn(torch.autograd.Function):
         for l in reversed(range(4)):
             w, b, gamma, beta = params[4 * l:4 * l + 4]
             h, y, mean, rstd = ctx.saved[l]
-            dy, dgamma, dbeta, dbias = hip.gn_relu_bwd(y, gamma, beta, mean, rstd, GROUPS, (da, 0, 0), None, True)
-            dw = hip.deconv5x5s2_wgrad(h, dy)
+            ow, obias, og, ob = _gout(w), _gout(b), _gout(gamma), _gout(beta)
+            dy, dgamma, dbeta, dbias = hip.gn_relu_bwd(y, gamma, beta, mean, rstd, GROUPS, (da, 0, 0), None, True,
+                                                       out=(og, ob, obias))
+            dw = hip.deconv5x5s2_wgrad(h, dy, out=ow)
             # the first layer's input is the broadcast latent + 2 coordinate channels: only the D latent
             # channels need a gradient
             da = hip.deconv5x5s2_dgrad(dy, w, ctx.D if l == 0 else None)
-            grads[4 * l:4 * l + 4] = [dw, dbias, dgamma, dbeta]
+            grads[4 * l:4 * l + 4] = [_ret(ow, dw), _ret(obias, dbias), _ret(og, dgamma), _ret(ob, dbeta)]
         dz = da.sum((2, 3))
         return (dz, None) + tuple(grads)
 

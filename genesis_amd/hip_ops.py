@@ -63,12 +63,13 @@ def conv3x3_dgrad(dy, w):
     return dx
 
 
-def conv3x3_wgrad(x, dy):
+def conv3x3_wgrad(x, dy, out=None):
     _chk(x, 'conv3x3_wgrad.x'); _chk(dy, 'conv3x3_wgrad.dy')
     N, Cin, H, W = x.shape
     Cout = dy.shape[1]
     assert dy.shape == (N, Cout, H, W)
-    dw = torch.empty(Cout, Cin, 3, 3, dtype=F32, device=x.device)
+    dw = out if out is not None else torch.empty(Cout, Cin, 3, 3, dtype=F32, device=x.device)
+    assert dw.shape == (Cout, Cin, 3, 3) and dw.is_contiguous()
     nb = _lib.query('gx_conv3x3_wgrad_ws_bytes', N, Cin, Cout, H, W)
     ws = _ws(nb, x.device)
     _lib.call('gx_conv3x3_wgrad', _p(x), _p(dy), _p(dw), N, Cin, Cout, H, W, _p(ws), nb, _stream())
@@ -102,12 +103,13 @@ def deconv5x5s2_dgrad(dy, w, cin_out=None):
     return dx
 
 
-def deconv5x5s2_wgrad(x, dy):
+def deconv5x5s2_wgrad(x, dy, out=None):
     _chk(x, 'deconv_wgrad.x'); _chk(dy, 'deconv_wgrad.dy')
     N, Cin, H, W = x.shape
     Cout = dy.shape[1]
     assert dy.shape == (N, Cout, 2 * H, 2 * W)
-    dw = torch.empty(Cin, Cout, 5, 5, dtype=F32, device=x.device)
+    dw = out if out is not None else torch.empty(Cin, Cout, 5, 5, dtype=F32, device=x.device)
+    assert dw.shape == (Cin, Cout, 5, 5) and dw.is_contiguous()
     nb = _lib.query('gx_deconv5x5s2_wgrad_ws_bytes', N, Cin, Cout, H, W)
     ws = _ws(nb, x.device)
     _lib.call('gx_deconv5x5s2_wgrad', _p(x), _p(dy), _p(dw), N, Cin, Cout, H, W, _p(ws), nb, _stream())
@@ -134,13 +136,15 @@ def gn_relu_fwd(y, gamma, beta, groups, eps, dst0, dst1=None):
     return mean, rstd
 
 
-def gn_relu_bwd(y, gamma, beta, mean, rstd, groups, g0, g1=None, want_dbias=False):
+def gn_relu_bwd(y, gamma, beta, mean, rstd, groups, g0, g1=None, want_dbias=False, out=None):
+    """out = (dgamma, dbeta, dbias) preallocated [C] buffers (entries may be None) to write into."""
     _chk(y, 'gn_bwd.y')
     N, C, H, W = y.shape
     dy = torch.empty_like(y)
-    dgamma = torch.empty(C, dtype=F32, device=y.device)
-    dbeta = torch.empty(C, dtype=F32, device=y.device)
-    dbias = torch.empty(C, dtype=F32, device=y.device) if want_dbias else None
+    o = out or (None, None, None)
+    dgamma = o[0] if o[0] is not None else torch.empty(C, dtype=F32, device=y.device)
+    dbeta = o[1] if o[1] is not None else torch.empty(C, dtype=F32, device=y.device)
+    dbias = (o[2] if o[2] is not None else torch.empty(C, dtype=F32, device=y.device)) if want_dbias else None
     nb = _lib.query('gx_gn_relu_bwd_ws_bytes', N, C)
     ws = _ws(nb, y.device)
     _lib.call('gx_gn_relu_bwd', _p(y), _p(gamma), _p(beta), _p(mean), _p(rstd), N, C, H, W, groups,
@@ -171,7 +175,7 @@ def icsbp_bwd(colour, log_sigma, seeds, idx, g_log_m, kernel='gaussian'):
     K = g_log_m.shape[0]
     dcolour = torch.empty_like(colour)
     dls = torch.empty((), dtype=torch.float64, device=colour.device)
-    nb = _lib.query('gx_icsbp_bwd_ws_bytes', B)
+    nb = _lib.query('gx_icsbp_bwd_ws_bytes', B, H, W, K)
     ws = _ws(nb, colour.device)
     _lib.call('gx_icsbp_bwd', _p(colour), _p(log_sigma), _p(seeds), _p(idx), _p(g_log_m), B, C, H, W, K,
               KERNELS[kernel], _p(dcolour), _p(dls), _p(ws), nb, _stream())

@@ -9,6 +9,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
+from . import functions as _fn
 from .dp import FlatBucket
 from .geco import make_geco
 
@@ -54,6 +55,13 @@ class TrainStep(object):
     # ------------------------------------------------------------------ one iteration
     def _iteration(self, x, **forward_kwargs):
         self.bucket.zero_grad()
+        _fn.DIRECT_PARAM_GRADS = True    # bucket zeroed above; kernels write weight grads straight into it
+        try:
+            return self._iteration_body(x, **forward_kwargs)
+        finally:
+            _fn.DIRECT_PARAM_GRADS = False
+
+    def _iteration_body(self, x, **forward_kwargs):
         recon, losses, stats, att_stats, comp_stats = self.model(x, **forward_kwargs)
         err = losses.err.mean(0)
         kl = torch.stack(losses.kl_l_k, dim=1).mean(dim=0).sum()

@@ -82,7 +82,7 @@ int gx_gn_relu_bwd(const float* y, const float* gamma, const float* beta, const 
 int gx_icsbp_fwd(const float* colour, const double* log_sigma, const float* rand_pixel, const int64_t* seed_idx_in,
                  int B, int C, int H, int W, int K, int kernel_type, float* log_m, float* log_s, float* seeds,
                  int64_t* seed_idx_out, gx_stream_t stream);
-size_t gx_icsbp_bwd_ws_bytes(int B);
+size_t gx_icsbp_bwd_ws_bytes(int B, int H, int W, int K);
 int gx_icsbp_bwd(const float* colour, const double* log_sigma, const float* seeds, const int64_t* seed_idx,
                  const float* g_log_m, int B, int C, int H, int W, int K, int kernel_type, float* dcolour,
                  double* dlog_sigma, void* ws, size_t ws_bytes, gx_stream_t stream);

@@ -27,7 +27,10 @@ def test_three_steps_vs_reference(case):
         elbo, err, kl, beta = [float(v) for v in out]
         assert abs(elbo - hist[it, 0]) <= 1e-3 * abs(hist[it, 0]), (it, elbo, hist[it])   # north_star bound
         np.testing.assert_allclose([elbo, err, beta], hist[it, [0, 1, 3]], rtol=2e-4)
-        np.testing.assert_allclose(kl, hist[it, 2], rtol=5e-3)
+        # Adam's first steps move every parameter by ~lr whatever the gradient magnitude, so parameters whose
+        # gradient is pure round-off noise drift differently between two fp32 implementations: the small KL
+        # term is compared with an absolute floor tied to the ELBO scale
+        np.testing.assert_allclose(kl, hist[it, 2], rtol=5e-3, atol=2e-5 * abs(hist[it, 0]))
     assert abs(float(ts.geco.beta) - float(gold.g['train_beta_final'])) <= 1e-5
     assert abs(float(ts.geco.err_ema) - hist[2, 4]) <= 1e-4 * abs(hist[2, 4])
     assert int(ts.step_t) == 3
