@@ -364,7 +364,7 @@ wgrad_kernel(const float* __restrict__ a_src, const float* __restrict__ b_src,
              float* __restrict__ partial, WgradGeom g) {
     using WT = WTap<WM>;
     constexpr int NT = WT::NT;
-    constexpr int NPOS = 2;              // halo tile <= 512 floats per channel
+    constexpr int NPOS = 1;              // halo tile <= 256 floats per channel (plan_wgrad picks tiles so)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int TH = 1 << g.lTH, TW = 1 << g.lTW, G = 1 << g.lG;
@@ -428,6 +428,54 @@ wgrad_kernel(const float* __restrict__ a_src, const float* __restrict__ b_src,
         }                                                                                            \
     }
 
+    // one batch of A values: 4 groups x 4 consecutive k-steps; halo = LDS offset of each group's first pixel
+    // (hx: per-element extra offsets, only used by the scalar path for TW < 4)
+    struct ABatch { float v[4][4]; int halo[4]; int hx[4][4]; };
+    ABatch acur, anxt;
+#define GX_WG_LOAD_A(tile_, bt_, dst_)                                                                        \
+    {                                                                                                          \
+        GX_WG_TILE_ORIGIN(tile_, ai0, aR0, aC0)                                                                \
+        _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                                     \
+            const int j0 = khalf * (PT >> 1) + 4 * (4 * (bt_) + gq);                                           \
+            if (TW >= 4) {                                                                                     \
+                const int c = j0 & (TW - 1);                                                                   \
+                const int r = (j0 >> g.lTW) & (TH - 1);                                                        \
+                const int gi = j0 >> (g.lTW + g.lTH);                                                          \
+                const int n = ai0 + gi;                                                                        \
+                const bool ok = ca_ok && n < g.N;                                                              \
+                const float* ap = a_src + (size_t)(ok ? n : 0) * a_img + (size_t)(ok ? ca_l : 0) * HaWa +      \
+                                  (size_t)(WT::SA * (aR0 + r) + WT::PA) * g.Wa + WT::SA * (aC0 + c);           \
+                if (WT::SA == 1) {                                                                             \
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(ap);                                       \
+                    dst_.v[gq][0] = ok ? v[0] : 0.f; dst_.v[gq][1] = ok ? v[1] : 0.f;                          \
+                    dst_.v[gq][2] = ok ? v[2] : 0.f; dst_.v[gq][3] = ok ? v[3] : 0.f;                          \
+                } else {                                                                                       \
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(ap);                                      \
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(ap + 4);                                  \
+                    dst_.v[gq][0] = ok ? v0[WT::PB] : 0.f; dst_.v[gq][1] = ok ? v0[WT::PB + 2] : 0.f;          \
+                    dst_.v[gq][2] = ok ? v1[WT::PB] : 0.f; dst_.v[gq][3] = ok ? v1[WT::PB + 2] : 0.f;          \
+                }                                                                                              \
+                dst_.halo[gq] = (gi * (TH + 2) + r) * HS + c;                                                  \
+                dst_.hx[gq][0] = 0; dst_.hx[gq][1] = 0; dst_.hx[gq][2] = 0; dst_.hx[gq][3] = 0;                \
+            } else {                                                                                           \
+                dst_.halo[gq] = 0;                                                                             \
+                _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                \
+                    const int jx = j0 + u;                                                                     \
+                    const int c = jx & (TW - 1);                                                               \
+                    const int r = (jx >> g.lTW) & (TH - 1);                                                    \
+                    const int gi = jx >> (g.lTW + g.lTH);                                                      \
+                    const int n = ai0 + gi;                                                                    \
+                    float v = 0.f;                                                                             \
+                    if (ca_ok && n < g.N)                                                                      \
+                        v = a_src[(size_t)n * a_img + (size_t)ca_l * HaWa +                                    \
+                                  (size_t)(WT::SA * (aR0 + r) + WT::PA) * g.Wa + WT::SA * (aC0 + c) + WT::PB]; \
+                    dst_.v[gq][u] = v;                                                                         \
+                    dst_.hx[gq][u] = (gi * (TH + 2) + r) * HS + c;                                             \
+                }                                                                                              \
+            }                                                                                                  \
+        }                                                                                                      \
+    }
+
     int tile = blockIdx.x;
     if (tile < g.ntiles) GX_WG_PREFETCH(tile)
     int it = 0;
@@ -444,60 +492,30 @@ wgrad_kernel(const float* __restrict__ a_src, const float* __restrict__ b_src,
         __syncthreads();
         if (tile + g.nsplit < g.ntiles) GX_WG_PREFETCH(tile + g.nsplit)
 
-        GX_WG_TILE_ORIGIN(tile, img0, R0, C0)
-        // ---- K loop: this lane's k slot covers pixels [khalf*PT/2, (khalf+1)*PT/2) of the tile, 4 at a time
-        const int ngroups = PT >> 3;
-        for (int kg = 0; kg < ngroups; ++kg) {
-            const int j0 = khalf * (PT >> 1) + 4 * kg;
-            float av[4];
-            int halo[4];
-            if (TW >= 4) {
-                const int c = j0 & (TW - 1);
-                const int r = (j0 >> g.lTW) & (TH - 1);
-                const int gi = j0 >> (g.lTW + g.lTH);
-                const int n = img0 + gi;
-                const bool ok = ca_ok && n < g.N;
-                const float* ap = a_src + (size_t)(ok ? n : 0) * a_img + (size_t)(ok ? ca_l : 0) * HaWa +
-                                  (size_t)(WT::SA * (R0 + r) + WT::PA) * g.Wa + WT::SA * (C0 + c);
-                if (WT::SA == 1) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(ap);
-                    av[0] = v[0]; av[1] = v[1]; av[2] = v[2]; av[3] = v[3];
-                } else {
-                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(ap);
-                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(ap + 4);
-                    av[0] = v0[WT::PB]; av[1] = v0[WT::PB + 2]; av[2] = v1[WT::PB]; av[3] = v1[WT::PB + 2];
-                }
-                if (!ok) { av[0] = 0.f; av[1] = 0.f; av[2] = 0.f; av[3] = 0.f; }
-                const int h0 = (gi * (TH + 2) + r) * HS + c;
-                halo[0] = h0; halo[1] = h0 + 1; halo[2] = h0 + 2; halo[3] = h0 + 3;
-            } else {
+        // ---- K loop: this lane's k slot covers pixels [khalf*PT/2, (khalf+1)*PT/2) of the tile.  A values are
+        //      fetched global -> registers one batch (4 groups = 16 k-steps = 16*NT MFMAs) ahead of their use.
+        const int nbatches = PT >> 5;
+        if (it == 0) GX_WG_LOAD_A(tile, 0, acur)
+        for (int bt = 0; bt < nbatches; ++bt) {
+            if (bt + 1 < nbatches) GX_WG_LOAD_A(tile, bt + 1, anxt)
+            else if (tile + g.nsplit < g.ntiles) GX_WG_LOAD_A(tile + g.nsplit, 0, anxt)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int jx = j0 + u;
-                    const int c = jx & (TW - 1);
-                    const int r = (jx >> g.lTW) & (TH - 1);
-                    const int gi = jx >> (g.lTW + g.lTH);
-                    const int n = img0 + gi;
-                    float v = 0.f;
-                    if (ca_ok && n < g.N)
-                        v = a_src[(size_t)n * a_img + (size_t)ca_l * HaWa +
-                                  (size_t)(WT::SA * (R0 + r) + WT::PA) * g.Wa + WT::SA * (C0 + c) + WT::PB];
-                    av[u] = v;
-                    halo[u] = (gi * (TH + 2) + r) * HS + c;
+                    const float* bp = buf + b_row + acur.halo[gq] + ((TW >= 4) ? u : 0) + acur.hx[gq][(TW >= 4) ? 0 : u];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const float b = bp[WT::ro(t) * HS + WT::co(t)];
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur.v[gq][u], b, acc[t], 0, 0, 0);
+                    }
                 }
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float* bp = buf + b_row + halo[u];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const float b = bp[WT::ro(t) * HS + WT::co(t)];
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], b, acc[t], 0, 0, 0);
-                }
-            }
+            acur = anxt;
         }
     }
 #undef GX_WG_PREFETCH
+#undef GX_WG_LOAD_A
 #undef GX_WG_TILE_ORIGIN
     // partial[split][gt][ca][cb]
 #pragma unroll
@@ -669,9 +687,16 @@ int plan_wgrad(int N, int CA, int CB, int Hb, int Wb, int SA, int Ttot, int ncls
     g.N = N; g.CA = CA; g.CB = CB;
     g.CApad = gx_round_up(CA, 64); g.CBpad = gx_round_up(CB, 64);
     g.Hb = Hb; g.Wb = Wb; g.Ha = SA * Hb; g.Wa = SA * Wb;
-    const int npix = (Wb <= 2) ? 64 : 128;
-    pick_tile(Hb, Wb, npix, &g.lTH, &g.lTW, &g.lG);
-    const int TH = 1 << g.lTH, TW = 1 << g.lTW, G = 1 << g.lG;
+    // pixel tile: 128 pixels (64 for tiny grids) as G images x TH rows x TW<=32 cols, chosen so that the halo
+    // tile has <= 256 positions per channel (one staged element per thread per channel)
+    int npix = 128, TW = 0, TH = 0, G = 0;
+    for (;; npix >>= 1) {
+        TW = Wb < 32 ? Wb : 32;
+        TH = npix / TW; if (TH > Hb) TH = Hb;
+        G = npix / (TH * TW);
+        if (G * (TH + 2) * (TW + 2) <= 256 || npix <= 32) break;
+    }
+    g.lTH = ilog2(TH); g.lTW = ilog2(TW); g.lG = ilog2(G);
     g.tiles_h = Hb / TH; g.tiles_w = Wb / TW;
     g.ntiles = g.tiles_h * g.tiles_w * gx_ceil_div(N, G);
     // one workgroup per CU is resident (LDS-bound, 1 wave/SIMD): size each launch to ~one wave of 256 CUs

@@ -47,6 +47,13 @@ flags.DEFINE_float('pixel_std1', 0.7, 'StdDev of reconstructed pixels.')
 flags.DEFINE_float('pixel_std2', 0.7, 'StdDev of reconstructed pixels.')
 
 
+import os as _os
+
+# The AR prior's LSTM is a plain library op (MIOpen through torch.nn.LSTM): one fused call per direction
+# instead of ~12 pointwise launches per step.  GENESIS_LIBRARY_LSTM=0 selects the explicit cell loop.
+USE_LIBRARY_LSTM = _os.environ.get('GENESIS_LIBRARY_LSTM', '1') == '1'
+
+
 def load(cfg):
     return GenesisV2(cfg)
 
@@ -233,6 +240,12 @@ class GenesisV2(nn.Module):
         """AR prior over slot latents, models/genesis_config.py:288-331 (LSTM from the zero state over
         z_1..z_{K-1}; first slot N(0,1)).  Tiny [B,64]-row dense ops: torch for now."""
         K, B, D = z_kbd.shape
+        if USE_LIBRARY_LSTM:
+            # plain library LSTM (MIOpen via torch): one fused call instead of ~12 pointwise launches per step
+            out, _ = self.prior_lstm(z_kbd[:-1].contiguous())
+            lin = self.prior_linear(out)
+            mu_raw, sig_raw = lin.chunk(2, dim=2)
+            return torch.tanh(mu_raw), torch.sigmoid(sig_raw + 4.0) + 1e-4
         w_ih, w_hh = self.prior_lstm.weight_ih_l0, self.prior_lstm.weight_hh_l0
         b_ih, b_hh = self.prior_lstm.bias_ih_l0, self.prior_lstm.bias_hh_l0
         H = w_hh.shape[1]
