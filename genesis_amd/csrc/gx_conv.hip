@@ -79,7 +79,14 @@ struct ConvGeom {
     int par_a;        // deconv fwd: output row parity handled by this launch
     int nsplit;       // split of the channel reduction over gridDim.z (partials written when > 1)
     int chunks_per_split;
+    int act;          // epilogue activation after the bias: 0 none, 1 ReLU, 2 ELU (applied only when nsplit == 1)
 };
+
+__device__ __forceinline__ float gx_act(float v, int act) {
+    if (act == 1) return v > 0.f ? v : 0.f;
+    if (act == 2) return v > 0.f ? v : expm1f(v);
+    return v;
+}
 
 // NPOS = halo-tile positions staged per thread per channel (tile <= NPOS*256 floats per channel).
 template <int MODE, int NPOS>
@@ -236,6 +243,7 @@ tapconv_kernel(const float* __restrict__ in, const float* __restrict__ wp,
     const int HoWo = g.Ho * g.Wo;
     float* outz = out + (size_t)blockIdx.z * g.N * out_img_stride;   // partial slab when nsplit > 1
     const bool add_bias = bias != nullptr && g.nsplit == 1;
+    const int act = g.nsplit == 1 ? g.act : 0;
 #pragma unroll
     for (int nj = 0; nj < 2; ++nj) {
         const int p = wave * 64 + nj * 32 + (lane & 31);
@@ -243,7 +251,7 @@ tapconv_kernel(const float* __restrict__ in, const float* __restrict__ wp,
         const int r = (p >> g.lTW) & (TH - 1);
         const int gi = p >> (g.lTW + g.lTH);
         const int n = img0 + gi;
-        if (n >= g.N) continue;
+        if (n >= g.N || R0 + r >= g.Hb || C0 + c >= g.Wb) continue;   // partial tiles of non-power-of-two grids
         int orow, ocol;
         if (NCLS == 2) { orow = 2 * (R0 + r) + g.par_a; ocol = 2 * (C0 + c); }
         else { orow = R0 + r; ocol = C0 + c; }
@@ -257,11 +265,11 @@ tapconv_kernel(const float* __restrict__ in, const float* __restrict__ wp,
                     const float bv = add_bias ? bias[m] : 0.f;
                     if (NCLS == 2) {
                         float2 v;
-                        v.x = acc[0][mi][nj][reg] + bv;
-                        v.y = acc[NCLS - 1][mi][nj][reg] + bv;
+                        v.x = gx_act(acc[0][mi][nj][reg] + bv, act);
+                        v.y = gx_act(acc[NCLS - 1][mi][nj][reg] + bv, act);
                         *reinterpret_cast<float2*>(obase + (size_t)m * HoWo) = v;
                     } else {
-                        obase[(size_t)m * HoWo] = acc[0][mi][nj][reg] + bv;
+                        obase[(size_t)m * HoWo] = gx_act(acc[0][mi][nj][reg] + bv, act);
                     }
                 }
             }
@@ -271,7 +279,7 @@ tapconv_kernel(const float* __restrict__ in, const float* __restrict__ wp,
 
 // out[i] = sum_z part[z][i] (+ bias[channel]); fixed summation order.
 __global__ void splitk_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
-                                     float* __restrict__ out, size_t total, int nsplit, int M, int HoWo) {
+                                     float* __restrict__ out, size_t total, int nsplit, int M, int HoWo, int act) {
     const size_t n4 = total >> 2;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 s = reinterpret_cast<const float4*>(part)[i];
@@ -283,6 +291,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, const float
             const float b = bias[((i * 4) / HoWo) % M];   // HoWo is a multiple of 4
             s.x += b; s.y += b; s.z += b; s.w += b;
         }
+        s.x = gx_act(s.x, act); s.y = gx_act(s.y, act); s.z = gx_act(s.z, act); s.w = gx_act(s.w, act);
         reinterpret_cast<float4*>(out)[i] = s;
     }
 }
@@ -395,6 +404,9 @@ wgrad_kernel(const float* __restrict__ a_src, const float* __restrict__ b_src,
     const int b_row = (wn * 32 + (lane & 31)) * BS;
 
     float xin[64][NPOS];
+    // 16-byte A loads need 4 consecutive pixels inside one row: tiles >= 4 wide on a grid whose width is a
+    // multiple of 4 (all power-of-two layers, the 72-wide broadcast canvas); scalar loads otherwise
+    const bool vecA = TW >= 4 && (g.Wb & 3) == 0;
 
 #define GX_WG_TILE_ORIGIN(tile_, img0_, R0_, C0_)                      \
     int img0_, R0_, C0_;                                               \
@@ -437,14 +449,15 @@ wgrad_kernel(const float* __restrict__ a_src, const float* __restrict__ b_src,
         GX_WG_TILE_ORIGIN(tile_, ai0, aR0, aC0)                                                                \
         _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                                     \
             const int j0 = khalf * (PT >> 1) + 4 * (4 * (bt_) + gq);                                           \
-            if (TW >= 4) {                                                                                     \
+            if (vecA) {                                                                                        \
                 const int c = j0 & (TW - 1);                                                                   \
                 const int r = (j0 >> g.lTW) & (TH - 1);                                                        \
                 const int gi = j0 >> (g.lTW + g.lTH);                                                          \
                 const int n = ai0 + gi;                                                                        \
-                const bool ok = ca_ok && n < g.N;                                                              \
-                const float* ap = a_src + (size_t)(ok ? n : 0) * a_img + (size_t)(ok ? ca_l : 0) * HaWa +      \
-                                  (size_t)(WT::SA * (aR0 + r) + WT::PA) * g.Wa + WT::SA * (aC0 + c);           \
+                const bool ok = ca_ok && n < g.N && aR0 + r < g.Hb && aC0 + c < g.Wb;                          \
+                const float* ap = ok ? a_src + (size_t)n * a_img + (size_t)ca_l * HaWa +                        \
+                                           (size_t)(WT::SA * (aR0 + r) + WT::PA) * g.Wa + WT::SA * (aC0 + c)    \
+                                     : a_src;                                                                  \
                 if (WT::SA == 1) {                                                                             \
                     const f32x4 v = *reinterpret_cast<const f32x4*>(ap);                                       \
                     dst_.v[gq][0] = ok ? v[0] : 0.f; dst_.v[gq][1] = ok ? v[1] : 0.f;                          \
@@ -466,7 +479,7 @@ wgrad_kernel(const float* __restrict__ a_src, const float* __restrict__ b_src,
                     const int gi = jx >> (g.lTW + g.lTH);                                                      \
                     const int n = ai0 + gi;                                                                    \
                     float v = 0.f;                                                                             \
-                    if (ca_ok && n < g.N)                                                                      \
+                    if (ca_ok && n < g.N && aR0 + r < g.Hb && aC0 + c < g.Wb)                                  \
                         v = a_src[(size_t)n * a_img + (size_t)ca_l * HaWa +                                    \
                                   (size_t)(WT::SA * (aR0 + r) + WT::PA) * g.Wa + WT::SA * (aC0 + c) + WT::PB]; \
                     dst_.v[gq][u] = v;                                                                         \
@@ -503,7 +516,7 @@ wgrad_kernel(const float* __restrict__ a_src, const float* __restrict__ b_src,
             for (int gq = 0; gq < 4; ++gq) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const float* bp = buf + b_row + acur.halo[gq] + ((TW >= 4) ? u : 0) + acur.hx[gq][(TW >= 4) ? 0 : u];
+                    const float* bp = buf + b_row + acur.halo[gq] + (vecA ? u : 0) + acur.hx[gq][vecA ? 0 : u];
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         const float b = bp[WT::ro(t) * HS + WT::co(t)];
@@ -565,13 +578,23 @@ wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, i
 // ------------------------------------------------------------------ host-side geometry
 int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
-// pixel tile of `npix` (256 for tapconv) over a Hb x Wb base grid of N images
-void pick_tile(int Hb, int Wb, int npix, int* lTH, int* lTW, int* lG) {
-    int TW = Wb < 64 ? Wb : 64;
-    if (TW > npix) TW = npix;
-    int TH = npix / TW; if (TH > Hb) TH = Hb;
-    int G = npix / (TH * TW);
-    *lTH = ilog2(TH); *lTW = ilog2(TW); *lG = ilog2(G);
+// pixel tile of `npix` (256 for tapconv) over a Hb x Wb base grid of N images: power-of-two TH x TW x G
+// maximising the fraction of useful pixels (1.0 for power-of-two grids; 72x72 -> 8x8 tiles of 4 images), then
+// the widest rows (coalescing) among ties; the halo tile must fit `max_chs` floats per channel per plane.
+void pick_tile(int Hb, int Wb, int npix, int planes, int max_chs, int* lTH, int* lTW, int* lG) {
+    double best_eff = -1.0;
+    int bTW = 1, bTH = 1;
+    for (int TW = 1; TW <= npix && TW <= 64; TW <<= 1) {
+        if (TW > 1 && (TW >> 1) >= Wb) break;               // no wider than needed
+        for (int TH = 1; TH * TW <= npix; TH <<= 1) {
+            if (TH > 1 && (TH >> 1) >= Hb) break;
+            const int G = npix / (TH * TW);
+            if (planes * G * (TH + 2) * (TW + 2) > max_chs) continue;
+            const double eff = (double)Hb * Wb / ((double)gx_ceil_div(Wb, TW) * TW * gx_ceil_div(Hb, TH) * TH);
+            if (eff > best_eff + 1e-9 || (eff > best_eff - 1e-9 && TW > bTW)) { best_eff = eff; bTW = TW; bTH = TH; }
+        }
+    }
+    *lTW = ilog2(bTW); *lTH = ilog2(bTH); *lG = ilog2(npix / (bTW * bTH));
 }
 
 struct TapPlan {
@@ -590,9 +613,11 @@ int plan_tapconv(int N, int K, int M, int Mpad_pack, int Hb, int Wb, int Hi, int
     g.N = N; g.K = K; g.M = M;
     g.Kpad = gx_round_up(K, 8); g.Mpad = Mpad_pack;
     g.Hb = Hb; g.Wb = Wb; g.Hi = Hi; g.Wi = Wi; g.Ho = Ho; g.Wo = Wo; g.par_a = par_a;
-    pick_tile(Hb, Wb, 256, &g.lTH, &g.lTW, &g.lG);
+    constexpr int LO_ = (MODE == M_DG) ? 8 : 2;
+    pick_tile(Hb, Wb, 256, TC::PLANES, 2 * LO_ * 256, &g.lTH, &g.lTW, &g.lG);
     const int TH = 1 << g.lTH, TW = 1 << g.lTW, G = 1 << g.lG;
-    g.tiles_h = Hb / TH; g.tiles_w = Wb / TW;
+    g.tiles_h = gx_ceil_div(Hb, TH); g.tiles_w = gx_ceil_div(Wb, TW);
+    g.act = 0;
     const int CHS = TC::PLANES * G * (TH + 2) * (TW + 2);
     const int need = gx_ceil_div(CHS, 256);
     const int lo = (MODE == M_DG) ? 8 : 2;
@@ -659,7 +684,7 @@ int launch_splitk_reduce(const float* part, const float* bias, float* out, const
     {
         GxProf pf(KID_SPLITK_REDUCE, s, 0.0, 4.0 * (pl.g.nsplit + 1.0) * (double)total);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, part, bias, out, total,
-                           pl.g.nsplit, pl.g.M, pl.g.Ho * pl.g.Wo);
+                           pl.g.nsplit, pl.g.M, pl.g.Ho * pl.g.Wo, pl.g.act);
     }
     GX_CHECK_LAUNCH("splitk_reduce");
     return GX_OK;
@@ -687,17 +712,30 @@ int plan_wgrad(int N, int CA, int CB, int Hb, int Wb, int SA, int Ttot, int ncls
     g.N = N; g.CA = CA; g.CB = CB;
     g.CApad = gx_round_up(CA, 64); g.CBpad = gx_round_up(CB, 64);
     g.Hb = Hb; g.Wb = Wb; g.Ha = SA * Hb; g.Wa = SA * Wb;
-    // pixel tile: 128 pixels (64 for tiny grids) as G images x TH rows x TW<=32 cols, chosen so that the halo
-    // tile has <= 256 positions per channel (one staged element per thread per channel)
-    int npix = 128, TW = 0, TH = 0, G = 0;
-    for (;; npix >>= 1) {
-        TW = Wb < 32 ? Wb : 32;
-        TH = npix / TW; if (TH > Hb) TH = Hb;
-        G = npix / (TH * TW);
-        if (G * (TH + 2) * (TW + 2) <= 256 || npix <= 32) break;
+    // pixel tile: 128 pixels (fewer for tiny grids) as G images x TH rows x TW<=32 cols with a halo tile of
+    // <= 256 positions per channel (one staged element per thread per channel); power-of-two tile dims, any grid
+    int TW = 1, TH = 1, G = 1;
+    {
+        double best_eff = -1.0;
+        int best_np = 0;
+        for (int npix = 128; npix >= 32; npix >>= 1) {
+            for (int tw = 1; tw <= 32 && tw <= npix; tw <<= 1) {
+                if (tw > 1 && (tw >> 1) >= Wb) break;
+                for (int th = 1; th * tw <= npix; th <<= 1) {
+                    if (th > 1 && (th >> 1) >= Hb) break;
+                    const int gg = npix / (th * tw);
+                    if (gg * (th + 2) * (tw + 2) > 256) continue;
+                    const double eff = (double)Hb * Wb / ((double)gx_ceil_div(Wb, tw) * tw * gx_ceil_div(Hb, th) * th);
+                    const bool better = eff > best_eff + 1e-9 ||
+                                        (eff > best_eff - 1e-9 && (npix > best_np || (npix == best_np && tw > TW)));
+                    if (better) { best_eff = eff; best_np = npix; TW = tw; TH = th; G = gg; }
+                }
+            }
+            if (best_eff > 0.999) break;   // a full-size tile that wastes nothing: keep the largest
+        }
     }
     g.lTH = ilog2(TH); g.lTW = ilog2(TW); g.lG = ilog2(G);
-    g.tiles_h = Hb / TH; g.tiles_w = Wb / TW;
+    g.tiles_h = gx_ceil_div(Hb, TH); g.tiles_w = gx_ceil_div(Wb, TW);
     g.ntiles = g.tiles_h * g.tiles_w * gx_ceil_div(N, G);
     // one workgroup per CU is resident (LDS-bound, 1 wave/SIMD): size each launch to ~one wave of 256 CUs
     (void)ncls_launches;
@@ -750,8 +788,8 @@ int launch_wgrad_reduce(const float* partial, float* dw, const WgradPlan& pl, in
 
 int check_dims(const char* name, int N, int Cin, int Cout, int H, int W) {
     GX_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0, "%s: bad N/C (%d,%d,%d)", name, N, Cin, Cout);
-    GX_CHECK_ARG(gx_is_pow2(H) && gx_is_pow2(W) && H >= 2 && W >= 2 && H <= 1024 && W <= 1024,
-                 "%s: H,W must be powers of two in [2,1024] (got %dx%d)", name, H, W);
+    GX_CHECK_ARG(H >= 1 && W >= 2 && H <= 4096 && W <= 4096 && (H * W) % 4 == 0,
+                 "%s: H in [1,4096], W in [2,4096], H*W a multiple of 4 (got %dx%d)", name, H, W);
     return GX_OK;
 }
 
@@ -777,8 +815,22 @@ size_t gx_conv3x3_ws_bytes(int N, int Cin, int Cout, int H, int W) {
     return (conv3x3_pack_floats(Cin, Cout) + part) * sizeof(float);
 }
 
+static int conv3x3_fwd_impl(const float* x, const float* w, const float* bias, int act, float* y, int N, int Cin,
+                            int Cout, int H, int W, void* ws, size_t ws_bytes, gx_stream_t stream);
+
 int gx_conv3x3_fwd(const float* x, const float* w, float* y, int N, int Cin, int Cout, int H, int W,
                    void* ws, size_t ws_bytes, gx_stream_t stream) {
+    return conv3x3_fwd_impl(x, w, nullptr, 0, y, N, Cin, Cout, H, W, ws, ws_bytes, stream);
+}
+
+int gx_conv3x3_bias_act_fwd(const float* x, const float* w, const float* bias, int act, float* y, int N, int Cin,
+                            int Cout, int H, int W, void* ws, size_t ws_bytes, gx_stream_t stream) {
+    GX_CHECK_ARG(act >= 0 && act <= 2, "gx_conv3x3_bias_act_fwd: act must be 0 (none), 1 (ReLU) or 2 (ELU)");
+    return conv3x3_fwd_impl(x, w, bias, act, y, N, Cin, Cout, H, W, ws, ws_bytes, stream);
+}
+
+static int conv3x3_fwd_impl(const float* x, const float* w, const float* bias, int act, float* y, int N, int Cin,
+                            int Cout, int H, int W, void* ws, size_t ws_bytes, gx_stream_t stream) {
     int rc = check_dims("gx_conv3x3_fwd", N, Cin, Cout, H, W);
     if (rc) return rc;
     GX_CHECK_ARG(x && w && y && ws, "gx_conv3x3_fwd: null pointer");
@@ -790,11 +842,12 @@ int gx_conv3x3_fwd(const float* x, const float* w, float* y, int N, int Cin, int
     if (rc) return rc;
     float* wp = (float*)ws;
     float* part = wp + conv3x3_pack_floats(Cin, Cout);
+    pl.g.act = act;
     rc = launch_pack(w, wp, 0, Cout, Cin, 9, Kpad, Mpad, s);
     if (rc) return rc;
-    rc = launch_tapconv<M_C3>(x, wp, nullptr, pl.g.nsplit > 1 ? part : y, pl, s, "gx_conv3x3_fwd");
+    rc = launch_tapconv<M_C3>(x, wp, bias, pl.g.nsplit > 1 ? part : y, pl, s, "gx_conv3x3_fwd");
     if (rc) return rc;
-    if (pl.g.nsplit > 1) return launch_splitk_reduce(part, nullptr, y, pl, s);
+    if (pl.g.nsplit > 1) return launch_splitk_reduce(part, bias, y, pl, s);
     return GX_OK;
 }
 

@@ -132,12 +132,13 @@ template <bool BWD>
 __global__ void __launch_bounds__(256)
 mixture_kernel(const float* __restrict__ x, const float* __restrict__ dec, int B, int HW, int K, float std_,
                int pixel_bound, float* __restrict__ recon, float* __restrict__ x_r, float* __restrict__ log_m_r,
-               float* __restrict__ err_part, const float* __restrict__ g_err, float* __restrict__ ddec) {
+               float* __restrict__ err_part, const float* __restrict__ g_err, float* __restrict__ ddec,
+               const float* __restrict__ log_w, float* __restrict__ dlog_w, float std_first) {
+    // log_w != NULL (MONet, models/monet_config.py:94-105): the mixing log-weights are the ATTENTION masks
+    // [K,B,HW] instead of log_softmax(logits); the first slot may use its own pixel std (std_first).
     __shared__ double red[4];
     const int b = blockIdx.x;
     const int p = blockIdx.y * blockDim.x + threadIdx.x;
-    const float var2 = 2.f * std_ * std_;
-    const float log_std = logf(std_);
     double err = 0.0;
     if (p < HW) {
         float logit[KMAX];
@@ -160,7 +161,8 @@ mixture_kernel(const float* __restrict__ x, const float* __restrict__ dec, int B
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
             lm[k] = (k < K) ? (logit[k] - mx) - lse : 0.f;   // torch log_softmax: (x - max) - log(sum exp(x - max))
-            if (!BWD && k < K) log_m_r[((size_t)k * B + b) * HW + p] = lm[k];
+            if (!BWD && k < K && log_m_r) log_m_r[((size_t)k * B + b) * HW + p] = lm[k];
+            if (log_w && k < K) lm[k] = log_w[((size_t)k * B + b) * HW + p];
         }
         float dlogit[KMAX];
         if (BWD) {
@@ -179,7 +181,8 @@ mixture_kernel(const float* __restrict__ x, const float* __restrict__ dec, int B
                     const float raw = dec[(((size_t)k * B + b) * 4 + c) * HW + p];
                     mu[k] = pixel_bound ? 1.f / (1.f + expf(-raw)) : raw;
                     const float dx = xv - mu[k];
-                    const float logn = -(dx * dx) / var2 - log_std - LOG_SQRT_2PI;
+                    const float sd = (k == 0) ? std_first : std_;
+                    const float logn = -(dx * dx) / (2.f * sd * sd) - logf(sd) - LOG_SQRT_2PI;
                     e[k] = expf(lm[k] + logn);
                     s += e[k];
                     if (!BWD) {
@@ -198,7 +201,8 @@ mixture_kernel(const float* __restrict__ x, const float* __restrict__ dec, int B
                     if (k < K) {
                         const float w = e[k] * inv;                 // responsibility of slot k
                         dlogit[k] -= w;                             // d err / d log_m_r_k
-                        float gmu = -w * (xv - mu[k]) / (std_ * std_);
+                        const float sd = (k == 0) ? std_first : std_;
+                        float gmu = -w * (xv - mu[k]) / (sd * sd);
                         if (pixel_bound) gmu *= mu[k] * (1.f - mu[k]);
                         ddec[(((size_t)k * B + b) * 4 + c) * HW + p] = ge * gmu;
                     }
@@ -211,8 +215,16 @@ mixture_kernel(const float* __restrict__ x, const float* __restrict__ dec, int B
 #pragma unroll
             for (int k = 0; k < KMAX; ++k) if (k < K) gsum += dlogit[k];
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k)
-                if (k < K) ddec[(((size_t)k * B + b) * 4 + 3) * HW + p] = ge * (dlogit[k] - expf(lm[k]) * gsum);
+            for (int k = 0; k < KMAX; ++k) {
+                if (k < K) {
+                    if (log_w) {
+                        dlog_w[((size_t)k * B + b) * HW + p] = ge * dlogit[k];
+                        ddec[(((size_t)k * B + b) * 4 + 3) * HW + p] = 0.f;
+                    } else {
+                        ddec[(((size_t)k * B + b) * 4 + 3) * HW + p] = ge * (dlogit[k] - expf(lm[k]) * gsum);
+                    }
+                }
+            }
         }
     }
     if (!BWD) {
@@ -427,10 +439,10 @@ int gx_maskpool_bwd(const float* f, const float* log_m, const float* gS, const f
 
 size_t gx_mixture_ws_bytes(int B, int H, int W) { return (size_t)B * gx_ceil_div(H * W, 256) * sizeof(float); }
 
-int gx_mixture_fwd(const float* x, const float* dec, int B, int H, int W, int K, float pixel_std, int pixel_bound,
-                   float* recon, float* x_r, float* log_m_r, float* err, void* ws, size_t ws_bytes,
-                   gx_stream_t stream) {
-    GX_CHECK_ARG(x && dec && recon && x_r && log_m_r && err && ws, "gx_mixture_fwd: null pointer");
+static int mixture_fwd_impl(const float* x, const float* dec, const float* log_w, int B, int H, int W, int K,
+                            float std_first, float pixel_std, int pixel_bound, float* recon, float* x_r,
+                            float* log_m_r, float* err, void* ws, size_t ws_bytes, gx_stream_t stream) {
+    GX_CHECK_ARG(x && dec && recon && x_r && err && ws, "gx_mixture_fwd: null pointer");
     GX_CHECK_ARG(B > 0 && K >= 1 && K <= KMAX && pixel_std > 0.f, "gx_mixture_fwd: bad dims (K<=16)");
     GX_CHECK_ARG(ws_bytes >= gx_mixture_ws_bytes(B, H, W), "gx_mixture_fwd: workspace too small");
     const int HW = H * W, nb = gx_ceil_div(HW, 256);
@@ -439,7 +451,8 @@ int gx_mixture_fwd(const float* x, const float* dec, int B, int H, int W, int K,
         // read x (3) + dec (4K); write recon (3), x_r (3K), log_m_r (K)
         GxProf pf(KID_MIXTURE_FWD, s, 0.0, 4.0 * B * HW * (6.0 + 8.0 * K));
         hipLaunchKernelGGL(mixture_kernel<false>, dim3(B, nb), dim3(256), 0, s, x, dec, B, HW, K, pixel_std,
-                           pixel_bound, recon, x_r, log_m_r, (float*)ws, (const float*)nullptr, (float*)nullptr);
+                           pixel_bound, recon, x_r, log_m_r, (float*)ws, (const float*)nullptr, (float*)nullptr,
+                           log_w, (float*)nullptr, std_first);
     }
     GX_CHECK_LAUNCH("gx_mixture_fwd");
     {
@@ -450,8 +463,9 @@ int gx_mixture_fwd(const float* x, const float* dec, int B, int H, int W, int K,
     return GX_OK;
 }
 
-int gx_mixture_bwd(const float* x, const float* dec, const float* g_err, int B, int H, int W, int K,
-                   float pixel_std, int pixel_bound, float* ddec, gx_stream_t stream) {
+static int mixture_bwd_impl(const float* x, const float* dec, const float* log_w, const float* g_err, int B, int H,
+                            int W, int K, float std_first, float pixel_std, int pixel_bound, float* ddec,
+                            float* dlog_w, gx_stream_t stream) {
     GX_CHECK_ARG(x && dec && g_err && ddec, "gx_mixture_bwd: null pointer");
     GX_CHECK_ARG(B > 0 && K >= 1 && K <= KMAX && pixel_std > 0.f, "gx_mixture_bwd: bad dims (K<=16)");
     const int HW = H * W, nb = gx_ceil_div(HW, 256);
@@ -459,10 +473,40 @@ int gx_mixture_bwd(const float* x, const float* dec, const float* g_err, int B, 
         GxProf pf(KID_MIXTURE_BWD, (hipStream_t)stream, 0.0, 4.0 * B * HW * (3.0 + 8.0 * K));
         hipLaunchKernelGGL(mixture_kernel<true>, dim3(B, nb), dim3(256), 0, (hipStream_t)stream, x, dec, B, HW, K,
                            pixel_std, pixel_bound, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
-                           g_err, ddec);
+                           g_err, ddec, log_w, dlog_w, std_first);
     }
     GX_CHECK_LAUNCH("gx_mixture_bwd");
     return GX_OK;
+}
+
+int gx_mixture_fwd(const float* x, const float* dec, int B, int H, int W, int K, float pixel_std, int pixel_bound,
+                   float* recon, float* x_r, float* log_m_r, float* err, void* ws, size_t ws_bytes,
+                   gx_stream_t stream) {
+    GX_CHECK_ARG(log_m_r, "gx_mixture_fwd: null pointer");
+    return mixture_fwd_impl(x, dec, nullptr, B, H, W, K, pixel_std, pixel_std, pixel_bound, recon, x_r, log_m_r, err,
+                            ws, ws_bytes, stream);
+}
+
+int gx_mixture_bwd(const float* x, const float* dec, const float* g_err, int B, int H, int W, int K,
+                   float pixel_std, int pixel_bound, float* ddec, gx_stream_t stream) {
+    return mixture_bwd_impl(x, dec, nullptr, g_err, B, H, W, K, pixel_std, pixel_std, pixel_bound, ddec, nullptr,
+                            stream);
+}
+
+int gx_mixture_w_fwd(const float* x, const float* dec, const float* log_w, int B, int H, int W, int K,
+                     float pixel_std1, float pixel_std2, int pixel_bound, float* recon, float* x_r, float* err,
+                     void* ws, size_t ws_bytes, gx_stream_t stream) {
+    GX_CHECK_ARG(log_w, "gx_mixture_w_fwd: null pointer");
+    return mixture_fwd_impl(x, dec, log_w, B, H, W, K, pixel_std1, pixel_std2, pixel_bound, recon, x_r, nullptr, err,
+                            ws, ws_bytes, stream);
+}
+
+int gx_mixture_w_bwd(const float* x, const float* dec, const float* log_w, const float* g_err, int B, int H, int W,
+                     int K, float pixel_std1, float pixel_std2, int pixel_bound, float* ddec, float* dlog_w,
+                     gx_stream_t stream) {
+    GX_CHECK_ARG(log_w && dlog_w, "gx_mixture_w_bwd: null pointer");
+    return mixture_bwd_impl(x, dec, log_w, g_err, B, H, W, K, pixel_std1, pixel_std2, pixel_bound, ddec, dlog_w,
+                            stream);
 }
 
 int gx_conv1x1_fwd(const float* x, const float* w, const float* bias, const float* gate, const float* addend,

@@ -254,3 +254,90 @@ def conv1x1_bwd(x, dy, w, bias, gate=None):
     _lib.call('gx_conv1x1_bwd', _p(x), _p(dy), _p(w), _p(bias), _p(gate), N, Cin, Cout, H, W, _p(dx), _p(dw),
               _p(db), _p(dgate), _p(ws), nb, _stream())
     return dx, dw.view(w.shape), db, dgate
+
+
+# ------------------------------------------------------------------ ComponentVAE / MONet path
+ACTS = {None: 0, 'none': 0, 'relu': 1, 'elu': 2}
+
+
+def conv3x3_bias_act_fwd(x, w, bias, act):
+    """act(conv3x3 s1 p1 (x, w) + bias) on any HxW grid (W*H % 4 == 0)."""
+    _chk(x, 'conv3x3_bias_act.x'); _chk(w, 'conv3x3_bias_act.w'); _chk(bias, 'conv3x3_bias_act.bias')
+    N, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    assert w.shape == (Cout, Cin, 3, 3)
+    y = torch.empty(N, Cout, H, W, dtype=F32, device=x.device)
+    nb = _lib.query('gx_conv3x3_ws_bytes', N, Cin, Cout, H, W)
+    ws = _ws(nb, x.device)
+    _lib.call('gx_conv3x3_bias_act_fwd', _p(x), _p(w), _p(bias), ACTS[act], _p(y), N, Cin, Cout, H, W, _p(ws), nb,
+              _stream())
+    return y
+
+
+def bias_act_bwd(out, g, act, want_dbias=True, dbias_out=None):
+    """dy = g * act'(out) (derivative expressed through the output), dbias[c] = sum_{n,hw} dy."""
+    _chk(out, 'bias_act_bwd.out'); _chk(g, 'bias_act_bwd.g')
+    N, C, H, W = out.shape
+    dy = torch.empty_like(out)
+    dbias = None
+    if want_dbias:
+        dbias = dbias_out if dbias_out is not None else torch.empty(C, dtype=F32, device=out.device)
+    nb = _lib.query('gx_bias_act_bwd_ws_bytes', N, C)
+    ws = _ws(nb, out.device)
+    _lib.call('gx_bias_act_bwd', _p(out), _p(g), N, C, H, W, ACTS[act], _p(dy), _p(dbias), _p(ws), nb, _stream())
+    return dy, dbias
+
+
+def conv2d_direct_fwd(x, w, bias, act, stride, pad):
+    _chk(x, 'conv2d_direct.x'); _chk(w, 'conv2d_direct.w'); _chk(bias, 'conv2d_direct.bias')
+    N, Cin, H, W = x.shape
+    Cout, _, k, _ = w.shape
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    y = torch.empty(N, Cout, Ho, Wo, dtype=F32, device=x.device)
+    _lib.call('gx_conv2d_direct_fwd', _p(x), _p(w), _p(bias), ACTS[act], _p(y), N, Cin, Cout, H, W, k, stride, pad,
+              _stream())
+    return y
+
+
+def conv2d_direct_dgrad(dy, w, H, W, stride, pad):
+    _chk(dy, 'conv2d_direct_dgrad.dy'); _chk(w, 'conv2d_direct_dgrad.w')
+    N = dy.shape[0]
+    Cout, Cin, k, _ = w.shape
+    dx = torch.empty(N, Cin, H, W, dtype=F32, device=dy.device)
+    _lib.call('gx_conv2d_direct_dgrad', _p(dy), _p(w), _p(dx), N, Cin, Cout, H, W, k, stride, pad, _stream())
+    return dx
+
+
+def conv2d_direct_wgrad(x, dy, k, stride, pad, out=None):
+    _chk(x, 'conv2d_direct_wgrad.x'); _chk(dy, 'conv2d_direct_wgrad.dy')
+    N, Cin, H, W = x.shape
+    Cout = dy.shape[1]
+    dw = out if out is not None else torch.empty(Cout, Cin, k, k, dtype=F32, device=x.device)
+    _lib.call('gx_conv2d_direct_wgrad', _p(x), _p(dy), _p(dw), N, Cin, Cout, H, W, k, stride, pad, _stream())
+    return dw
+
+
+def mixture_w_fwd(x, dec, log_w, K, std1, std2, pixel_bound=True):
+    """Mixture likelihood with external mixing log-weights log_w [K,B,1,H,W] (MONet)."""
+    _chk(x, 'mixture_w.x'); _chk(dec, 'mixture_w.dec'); _chk(log_w, 'mixture_w.log_w')
+    B, _, H, W = x.shape
+    assert dec.shape == (K * B, 4, H, W) and log_w.shape == (K, B, 1, H, W)
+    dev = x.device
+    recon = torch.empty(B, 3, H, W, dtype=F32, device=dev)
+    x_r = torch.empty(K, B, 3, H, W, dtype=F32, device=dev)
+    err = torch.empty(B, dtype=F32, device=dev)
+    nb = _lib.query('gx_mixture_ws_bytes', B, H, W)
+    ws = _ws(nb, dev)
+    _lib.call('gx_mixture_w_fwd', _p(x), _p(dec), _p(log_w), B, H, W, K, float(std1), float(std2),
+              int(bool(pixel_bound)), _p(recon), _p(x_r), _p(err), _p(ws), nb, _stream())
+    return err, recon, x_r
+
+
+def mixture_w_bwd(x, dec, log_w, g_err, K, std1, std2, pixel_bound=True):
+    _chk(g_err, 'mixture_w_bwd.g_err')
+    B, _, H, W = x.shape
+    ddec = torch.empty_like(dec)
+    dlog_w = torch.empty_like(log_w)
+    _lib.call('gx_mixture_w_bwd', _p(x), _p(dec), _p(log_w), _p(g_err), B, H, W, K, float(std1), float(std2),
+              int(bool(pixel_bound)), _p(ddec), _p(dlog_w), _stream())
+    return ddec, dlog_w

@@ -138,6 +138,35 @@ int gx_profile_num_kernels(void);
 const char* gx_profile_kernel_name(int kid);
 int gx_profile_collect(double* total_ms, double* launches, double* flops, double* bytes);
 
+/* ---- ComponentVAE / MONet path (modules/component_vae.py:45-93, modules/encoders.py:31-37,
+ *      modules/decoders.py:25-32, models/monet_config.py:74-128).
+ *      gx_conv3x3_bias_act_fwd: conv3x3 s1 p1 + bias + activation (act 0 none, 1 ReLU, 2 ELU) on any HxW grid.
+ *      The BroadcastDecoder's VALID 3x3 convs run as this 'same' conv on the (img+2L)^2 broadcast canvas: the
+ *      centre crop after L layers equals the valid-conv chain exactly (border pollution advances one pixel per
+ *      layer and is cropped; its gradients are identically zero).
+ *      gx_bias_act_bwd: dy = g * act'(out) (derivative from the OUTPUT) and dbias[c] = sum dy (NULL to skip).
+ *      gx_conv2d_direct_*: generic k<=5 / stride / pad direct convolution for the tiny stride-2 encoder convs.
+ *      gx_mixture_w_*: mixture likelihood with EXTERNAL mixing log-weights log_w [K,B,1,H,W] (MONet mixes with
+ *      the attention masks, not with log_softmax(logits)) and a separate std for the first slot; bwd also
+ *      returns dlog_w; the logit channel of ddec is zero. */
+int gx_conv3x3_bias_act_fwd(const float* x, const float* w, const float* bias, int act, float* y, int N, int Cin,
+                            int Cout, int H, int W, void* ws, size_t ws_bytes, gx_stream_t stream);
+size_t gx_bias_act_bwd_ws_bytes(int N, int C);
+int gx_bias_act_bwd(const float* out, const float* g, int N, int C, int H, int W, int act, float* dy, float* dbias,
+                    void* ws, size_t ws_bytes, gx_stream_t stream);
+int gx_conv2d_direct_fwd(const float* x, const float* w, const float* bias, int act, float* y, int N, int Cin,
+                         int Cout, int H, int W, int k, int stride, int pad, gx_stream_t stream);
+int gx_conv2d_direct_dgrad(const float* dy, const float* w, float* dx, int N, int Cin, int Cout, int H, int W, int k,
+                           int stride, int pad, gx_stream_t stream);
+int gx_conv2d_direct_wgrad(const float* x, const float* dy, float* dw, int N, int Cin, int Cout, int H, int W, int k,
+                           int stride, int pad, gx_stream_t stream);
+int gx_mixture_w_fwd(const float* x, const float* dec, const float* log_w, int B, int H, int W, int K,
+                     float pixel_std1, float pixel_std2, int pixel_bound, float* recon, float* x_r, float* err,
+                     void* ws, size_t ws_bytes, gx_stream_t stream);
+int gx_mixture_w_bwd(const float* x, const float* dec, const float* log_w, const float* g_err, int B, int H, int W,
+                     int K, float pixel_std1, float pixel_std2, int pixel_bound, float* ddec, float* dlog_w,
+                     gx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -249,3 +249,104 @@ def test_no_cpu_fallback():
     from genesis_amd._lib import GenesisHipError
     with pytest.raises(GenesisHipError):
         hip.conv3x3_fwd(torch.zeros(1, 3, 8, 8), torch.zeros(4, 3, 3, 3))
+
+
+# ------------------------------------------------------------------ ComponentVAE / MONet kernels
+@pytest.mark.parametrize('N,Cin,Cout,H,W,act', [(3, 18, 32, 72, 72, 'relu'), (2, 32, 32, 72, 72, 'elu'),
+                                                  (2, 16, 8, 40, 40, 'relu'), (5, 8, 16, 12, 20, None),
+                                                  (2, 64, 64, 64, 64, 'relu')])
+def test_conv3x3_any_grid_bias_act(N, Cin, Cout, H, W, act):
+    """conv3x3 + bias + activation on non-power-of-two grids (the 72x72 BroadcastDecoder canvas)."""
+    x = rnd(N, Cin, H, W, seed=41)
+    w = rnd(Cout, Cin, 3, 3, seed=42, scale=1.0 / np.sqrt(Cin * 9))
+    b = rnd(Cout, seed=43, scale=0.3)
+    g = rnd(N, Cout, H, W, seed=44)
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    pre = F.conv2d(xr, wr, br, 1, 1)
+    ref = {'relu': F.relu, 'elu': F.elu, None: lambda t: t}[act](pre)
+    ref.backward(g)
+    y = hip.conv3x3_bias_act_fwd(x.to(DEV), w.to(DEV), b.to(DEV), act)
+    close(y, ref, 2e-5, 2e-5, 'fwd')
+    dy, db = hip.bias_act_bwd(y, g.to(DEV), act)
+    close(db, br.grad, 1e-4, 1e-4, 'dbias')
+    dx = hip.conv3x3_dgrad(dy, w.to(DEV))
+    close(dx, xr.grad, 1e-4, 2e-5, 'dgrad')
+    dw = hip.conv3x3_wgrad(x.to(DEV), dy)
+    close(dw, wr.grad, 1e-4, 1e-4, 'wgrad')
+
+
+def test_valid_conv_chain_equals_same_conv_on_canvas():
+    """modules/decoders.py:25-32: L valid 3x3 convs on the (S+2L)^2 broadcast == 'same' convs on the canvas + crop."""
+    L, S, N = 4, 16, 2
+    x = rnd(N, 6, S + 2 * L, S + 2 * L, seed=45)
+    ws = [rnd(8 if i else 8, 6 if i == 0 else 8, 3, 3, seed=46 + i, scale=0.2) for i in range(L)]
+    bs = [rnd(8, seed=56 + i, scale=0.2) for i in range(L)]
+    ref = x
+    for w, b in zip(ws, bs):
+        ref = F.relu(F.conv2d(ref, w, b))           # valid
+    h = x.to(DEV)
+    for w, b in zip(ws, bs):
+        h = hip.conv3x3_bias_act_fwd(h, w.to(DEV), b.to(DEV), 'relu')
+    close(h[:, :, L:-L, L:-L], ref, 2e-5, 2e-5, 'valid chain')
+
+
+@pytest.mark.parametrize('N,Cin,Cout,S,k,stride,pad,act', [(3, 4, 32, 64, 3, 2, 1, 'relu'), (2, 32, 64, 16, 3, 2, 1, 'elu'),
+                                                            (2, 64, 64, 8, 3, 2, 1, 'relu'), (2, 5, 7, 10, 5, 1, 2, None),
+                                                            (2, 3, 6, 9, 3, 1, 0, 'relu')])
+def test_conv2d_direct(N, Cin, Cout, S, k, stride, pad, act):
+    x = rnd(N, Cin, S, S, seed=61)
+    w = rnd(Cout, Cin, k, k, seed=62, scale=1.0 / np.sqrt(Cin * k * k))
+    b = rnd(Cout, seed=63, scale=0.3)
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    pre = F.conv2d(xr, wr, br, stride, pad)
+    ref = {'relu': F.relu, 'elu': F.elu, None: lambda t: t}[act](pre)
+    g = rnd(*ref.shape, seed=64)
+    ref.backward(g)
+    y = hip.conv2d_direct_fwd(x.to(DEV), w.to(DEV), b.to(DEV), act, stride, pad)
+    close(y, ref, 2e-5, 2e-5, 'fwd')
+    dy, db = hip.bias_act_bwd(y, g.to(DEV), act)
+    close(db, br.grad, 1e-4, 1e-4, 'dbias')
+    dx = hip.conv2d_direct_dgrad(dy, w.to(DEV), S, S, stride, pad)
+    close(dx, xr.grad, 1e-4, 2e-5, 'dgrad')
+    dw = hip.conv2d_direct_wgrad(x.to(DEV), dy, k, stride, pad)
+    close(dw, wr.grad, 1e-4, 1e-4, 'wgrad')
+
+
+@pytest.mark.parametrize('B,S,K,std1', [(2, 64, 7, 0.7), (3, 32, 4, 0.5)])
+def test_mixture_external_weights(B, S, K, std1):
+    """MONet: mixing weights are the attention masks; first slot may use its own std (monet_config.py:69-72)."""
+    from oracle import v2_oracle as O
+    x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(71))
+    dec = rnd(K * B, 4, S, S, seed=72, scale=2.0)
+    log_w = torch.log_softmax(rnd(K, B, 1, S, S, seed=73, scale=3.0), 0)
+    std = 0.7 * torch.ones(1, 1, 1, 1, K)
+    std[..., 0] = std1
+    dr, lr = dec.clone().requires_grad_(), log_w.clone().requires_grad_()
+    x_r_k = [torch.sigmoid(c[:, :3]) for c in dr.chunk(K, 0)]
+    err_ref = O.x_loss(x, list(lr.unbind(0)), x_r_k, std)
+    recon_ref = (torch.stack(list(lr.unbind(0)), 4).exp() * torch.stack(x_r_k, 4)).sum(4)
+    g = rnd(B, seed=74) + 1.5
+    (err_ref * g).sum().backward()
+    err, recon, x_r = hip.mixture_w_fwd(x.to(DEV), dec.to(DEV), log_w.to(DEV), K, std1, 0.7, True)
+    close(err, err_ref, 2e-6, 1e-3, 'err')
+    close(recon, recon_ref, 1e-5, 1e-5, 'recon')
+    ddec, dlw = hip.mixture_w_bwd(x.to(DEV), dec.to(DEV), log_w.to(DEV), g.to(DEV), K, std1, 0.7, True)
+    close(ddec, dr.grad, 1e-4, 1e-5, 'ddec')
+    close(dlw, lr.grad, 1e-4, 1e-5, 'dlog_w')
+
+
+@pytest.mark.parametrize('N,C,S', [(3, 32, 16), (2, 64, 64), (2, 128, 4)])
+def test_instance_norm_is_groupnorm_with_c_groups(N, C, S):
+    """ConvINReLU (modules/blocks.py:151-157): InstanceNorm2d(affine) == GroupNorm with groups = C."""
+    y = rnd(N, C, S, S, seed=81, scale=2.0) + 0.2
+    gamma, beta, g = 1 + 0.3 * rnd(C, seed=82), 0.2 * rnd(C, seed=83), rnd(N, C, S, S, seed=84)
+    yr, gr, br = y.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    ref = F.relu(F.instance_norm(yr, weight=gr, bias=br, eps=1e-5))
+    ref.backward(g)
+    out = torch.empty(N, C, S, S, device=DEV)
+    mean, rstd = hip.gn_relu_fwd(y.to(DEV), gamma.to(DEV), beta.to(DEV), C, 1e-5, (out, 0, 0))
+    close(out, ref, 1e-5, 1e-5, 'fwd')
+    dy, dgamma, dbeta, _ = hip.gn_relu_bwd(y.to(DEV), gamma.to(DEV), beta.to(DEV), mean, rstd, C, (g.to(DEV), 0, 0))
+    close(dy, yr.grad, 1e-4, 1e-5, 'dy')
+    close(dgamma, gr.grad, 1e-4, 1e-4, 'dgamma')
+    close(dbeta, br.grad, 1e-4, 1e-4, 'dbeta')
