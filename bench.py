@@ -41,6 +41,8 @@ def parse():
     ap.add_argument('--K', type=int, default=7)
     ap.add_argument('--img', type=int, default=64)
     ap.add_argument('--feat_dim', type=int, default=64)
+    ap.add_argument('--model', default='genesisv2', choices=['genesisv2', 'monet'],
+                    help='genesisv2 = the BASELINE metric; monet = BASELINE config 4 (informational)')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of HIP-graph replay')
     ap.add_argument('--profile-steps', type=int, default=3)
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU baseline leg (0 = skip)')
@@ -48,8 +50,14 @@ def parse():
 
 
 def build_model(args, device):
-    import genesis_amd.genesisv2_config as G
     from genesis_amd.compat.attrdict import AttrDict
+    if args.model == 'monet':
+        import genesis_amd.monet_config as GM
+        from oracle import monet_oracle  # only for its default-flag table (no arithmetic)
+        cfg = AttrDict(dict(monet_oracle.make_cfg(K_steps=args.K, img_size=args.img), debug=False, multi_gpu=False))
+        torch.manual_seed(0)
+        return GM.load(cfg).to(device).train()
+    import genesis_amd.genesisv2_config as G
     cfg = AttrDict(K_steps=args.K, img_size=args.img, feat_dim=args.feat_dim, kernel='gaussian', semiconv=True,
                    dynamic_K=False, klm_loss=False, detach_mr_in_klm=True, pixel_bound=True, autoreg_prior=True,
                    pixel_std1=0.7, pixel_std2=0.7, debug=False, multi_gpu=False)
@@ -166,9 +174,10 @@ def main():
     result = None
     if rank == 0:
         value = world * args.batch * args.steps / dt
-        flop_img = FLOP_PER_IMG.get((args.K, args.img))
+        flop_img = FLOP_PER_IMG.get((args.K, args.img)) if args.model == 'genesisv2' else None
         result = {
-            'metric': 'training images/sec (fwd+bwd+GECO step), GENESIS-V2 K=%d %dx%d' % (args.K, args.img, args.img),
+            'metric': 'training images/sec (fwd+bwd+GECO step), %s K=%d %dx%d'
+                      % ('GENESIS-V2' if args.model == 'genesisv2' else 'MONet', args.K, args.img, args.img),
             'value': value, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
@@ -221,7 +230,7 @@ def main():
         result['roofline'] = roof
         result['kernels'] = table[:12]
 
-    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+    if rank == 0 and world == 1 and args.cpu_seconds > 0 and args.model == 'genesisv2':
         result['cpu_baseline'] = cpu_baseline(args)
         result['speedup_vs_cpu_baseline'] = result['value'] / result['cpu_baseline']['value']
     if rank == 0:

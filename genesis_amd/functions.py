@@ -22,11 +22,21 @@ EPS = 1e-5
 # parameter is used once), weight-gradient kernels write straight into `param.grad` and the Functions return
 # None for those parameters -- no AccumulateGrad `grad += new` launch per parameter.
 DIRECT_PARAM_GRADS = False
+_DIRECT_WRITTEN = set()     # ids of parameters whose .grad was already written directly this iteration
+
+
+def begin_direct_grads():
+    """TrainStep calls this right after zeroing the bucket."""
+    _DIRECT_WRITTEN.clear()
 
 
 def _gout(p):
-    """Destination for a parameter gradient: p.grad if direct writes are on and it is a usable buffer."""
-    if DIRECT_PARAM_GRADS and isinstance(p, torch.nn.Parameter) and p.grad is not None and p.grad.is_contiguous():
+    """Destination for a parameter gradient: p.grad if direct writes are on and it is a usable buffer.  Only the
+    FIRST gradient of a parameter in an iteration is written directly (it overwrites the zeroed bucket); a parameter
+    that is used again (MONet's recurrent UNet shares its weights over K-1 passes) accumulates through autograd."""
+    if DIRECT_PARAM_GRADS and isinstance(p, torch.nn.Parameter) and p.grad is not None and p.grad.is_contiguous() \
+            and id(p) not in _DIRECT_WRITTEN:
+        _DIRECT_WRITTEN.add(id(p))
         return p.grad
     return None
 
@@ -60,10 +70,14 @@ class ConvGNReLUFn(torch.autograd.Function):
 
 
 class UNetEncoderFn(torch.autograd.Function):
-    """args: x, nb, then 3*nb down params (w, gamma, beta), 3*nb up params, 6 MLP params."""
+    """args: x, nb, norm_groups (8 = GroupNorm(8); 0 = InstanceNorm, i.e. one group per channel), then 3*nb down
+    params (w, gamma, beta), 3*nb up params, 6 MLP params."""
 
     @staticmethod
-    def forward(ctx, x, nb, *params):
+    def forward(ctx, x, nb, norm_groups, *params):
+        def ngroups(C):
+            return C if norm_groups == 0 else norm_groups
+        ctx.ngroups = ngroups
         x = x.contiguous()
         down = [params[3 * i:3 * i + 3] for i in range(nb)]
         up = [params[3 * nb + 3 * j:3 * nb + 3 * j + 3] for j in range(nb)]
@@ -87,10 +101,10 @@ class UNetEncoderFn(torch.autograd.Function):
             cx = cats[j].shape[1] - C
             if i < nb - 1:
                 nxt = torch.empty(N, C, y.shape[2] // 2, y.shape[3] // 2, device=dev)
-                mean, rstd = hip.gn_relu_fwd(y, gamma, beta, GROUPS, EPS, (cats[j], cx, 0), (nxt, 0, 2))
+                mean, rstd = hip.gn_relu_fwd(y, gamma, beta, ngroups(C), EPS, (cats[j], cx, 0), (nxt, 0, 2))
             else:
                 nxt = torch.empty(N, C, y.shape[2], y.shape[3], device=dev)
-                mean, rstd = hip.gn_relu_fwd(y, gamma, beta, GROUPS, EPS, (cats[j], cx, 0), (nxt, 0, 0))
+                mean, rstd = hip.gn_relu_fwd(y, gamma, beta, ngroups(C), EPS, (cats[j], cx, 0), (nxt, 0, 0))
                 mlp_in = nxt
             saved_down.append((cur, y, mean, rstd))
             cur = nxt
@@ -110,10 +124,10 @@ class UNetEncoderFn(torch.autograd.Function):
             w, gamma, beta = up[j]
             y = hip.conv3x3_fwd(cats[j], w)
             if j < nb - 1:
-                mean, rstd = hip.gn_relu_fwd(y, gamma, beta, GROUPS, EPS, (cats[j + 1], 0, 1))
+                mean, rstd = hip.gn_relu_fwd(y, gamma, beta, ngroups(y.shape[1]), EPS, (cats[j + 1], 0, 1))
             else:
                 out = torch.empty_like(y)
-                mean, rstd = hip.gn_relu_fwd(y, gamma, beta, GROUPS, EPS, (out, 0, 0))
+                mean, rstd = hip.gn_relu_fwd(y, gamma, beta, ngroups(y.shape[1]), EPS, (out, 0, 0))
             saved_up.append((y, mean, rstd))
         ctx.nb = nb
         ctx.params = params
@@ -138,7 +152,8 @@ class UNetEncoderFn(torch.autograd.Function):
             w, gamma, beta = up[j]
             y, mean, rstd = ctx.saved_up[j]
             ow, og, ob = _gout(w), _gout(gamma), _gout(beta)
-            dy, dgamma, dbeta, _ = hip.gn_relu_bwd(y, gamma, beta, mean, rstd, GROUPS, gsrc, out=(og, ob, None))
+            dy, dgamma, dbeta, _ = hip.gn_relu_bwd(y, gamma, beta, mean, rstd, ctx.ngroups(y.shape[1]), gsrc,
+                                                   out=(og, ob, None))
             dw = hip.conv3x3_wgrad(cats[j], dy, out=ow)
             dcat[j] = hip.conv3x3_dgrad(dy, w)
             g_up[j] = (_ret(ow, dw), _ret(og, dgamma), _ret(ob, dbeta))
@@ -161,7 +176,8 @@ class UNetEncoderFn(torch.autograd.Function):
             g0 = (dcat[j], cx, 0)
             g1 = (d_mlp_in, 0, 0) if i == nb - 1 else (d_next, 0, 2)
             ow, og, ob = _gout(w), _gout(gamma), _gout(beta)
-            dy, dgamma, dbeta, _ = hip.gn_relu_bwd(y, gamma, beta, mean, rstd, GROUPS, g0, g1, out=(og, ob, None))
+            dy, dgamma, dbeta, _ = hip.gn_relu_bwd(y, gamma, beta, mean, rstd, ctx.ngroups(C), g0, g1,
+                                                   out=(og, ob, None))
             dw = hip.conv3x3_wgrad(cur, dy, out=ow)
             g_down[i] = (_ret(ow, dw), _ret(og, dgamma), _ret(ob, dbeta))
             if i > 0:
@@ -172,7 +188,7 @@ class UNetEncoderFn(torch.autograd.Function):
         for t in g_down + g_up:
             flat.extend(t)
         flat.extend(g_mlp)
-        return (dx, None) + tuple(flat)
+        return (dx, None, None) + tuple(flat)
 
 
 class ICSBPFn(torch.autograd.Function):
@@ -282,3 +298,116 @@ class MixtureFn(torch.autograd.Function):
         K, pixel_std, pixel_bound = ctx.cfg
         ddec = hip.mixture_bwd(x, dec, g_err.contiguous(), K, pixel_std, pixel_bound)
         return None, ddec, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------- MONet / ComponentVAE
+class Conv1x1Fn(torch.autograd.Function):
+    """Small 1x1 conv with bias (Cout <= 8): the MONet UNet's final_conv (modules/unet.py:66,90)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = x.contiguous()
+        w2 = w.reshape(w.shape[0], -1)
+        ctx.save_for_backward(x, w2, b)
+        ctx.wshape = w.shape
+        return hip.conv1x1_fwd(x, w2, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w2, b = ctx.saved_tensors
+        dx, dw, db, _ = hip.conv1x1_bwd(x, g.contiguous(), w2, b)
+        return dx, dw.view(ctx.wshape), db
+
+
+class DirectConvActFn(torch.autograd.Function):
+    """act(conv2d(x, w, b, stride, pad)) through the generic direct kernel (MONetCompEncoder's stride-2 convs,
+    modules/encoders.py:31-34)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, act):
+        x = x.contiguous()
+        y = hip.conv2d_direct_fwd(x, w, b, act, stride, pad)
+        ctx.save_for_backward(x, y)
+        ctx.params = (w, b)
+        ctx.cfg = (stride, pad, act)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        w, b = ctx.params
+        stride, pad, act = ctx.cfg
+        ow, ob = _gout(w), _gout(b)
+        dy, db = hip.bias_act_bwd(y, g.contiguous(), act, True, ob)
+        dw = hip.conv2d_direct_wgrad(x, dy, w.shape[2], stride, pad, out=ow)
+        dx = hip.conv2d_direct_dgrad(dy, w, x.shape[2], x.shape[3], stride, pad) if ctx.needs_input_grad[0] else None
+        return dx, _ret(ow, dw), _ret(ob, db), None, None, None
+
+
+class BroadcastDecoderFn(torch.autograd.Function):
+    """BroadcastDecoder (modules/decoders.py:21-35): z [N, L] -> [N, out, S, S].
+    args: z, coords [1,2,S+2L,S+2L], act, then L x (w [h,cin,3,3], b [h]), out_w [out, h], out_b.
+    The L VALID 3x3 convs run as 'same' convs on the (S+2L)^2 canvas on the fp32 MFMA tap-conv kernel; the centre
+    crop of the final 1x1 conv equals the valid chain exactly (and so do all gradients: positions polluted by the
+    canvas border never reach the crop)."""
+
+    @staticmethod
+    def forward(ctx, z, coords, act, *params):
+        nl = (len(params) - 2) // 2
+        N, L = z.shape
+        d = coords.shape[-1]
+        S = d - 2 * nl
+        h = torch.cat((z.view(N, L, 1, 1).expand(-1, -1, d, d), coords.expand(N, -1, -1, -1)), 1).contiguous()
+        acts = []
+        for l in range(nl):
+            w, b = params[2 * l], params[2 * l + 1]
+            y = hip.conv3x3_bias_act_fwd(h, w, b, act)
+            acts.append((h, y))
+            h = y
+        ow, ob = params[2 * nl], params[2 * nl + 1]
+        full = hip.conv1x1_fwd(h, ow, ob)
+        ctx.acts, ctx.params, ctx.cfg = acts, params, (nl, S, L, act)
+        return full[:, :, nl:nl + S, nl:nl + S].contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        nl, S, L, act = ctx.cfg
+        params = ctx.params
+        ow, ob = params[2 * nl], params[2 * nl + 1]
+        last = ctx.acts[-1][1]
+        gfull = torch.zeros(last.shape[0], ow.shape[0], last.shape[2], last.shape[3], device=g.device)
+        gfull[:, :, nl:nl + S, nl:nl + S] = g
+        da, dow, dob, _ = hip.conv1x1_bwd(last, gfull, ow, ob)
+        grads = [None] * len(params)
+        grads[2 * nl], grads[2 * nl + 1] = dow, dob
+        for l in reversed(range(nl)):
+            w, b = params[2 * l], params[2 * l + 1]
+            h, y = ctx.acts[l]
+            gw, gb = _gout(w), _gout(b)
+            dy, db = hip.bias_act_bwd(y, da, act, True, gb)
+            dw = hip.conv3x3_wgrad(h, dy, out=gw)
+            da = hip.conv3x3_dgrad(dy, w)
+            grads[2 * l], grads[2 * l + 1] = _ret(gw, dw), _ret(gb, db)
+        dz = da[:, :L].sum((2, 3))
+        return (dz, None, None) + tuple(grads)
+
+
+class MixtureWFn(torch.autograd.Function):
+    """Mixture likelihood with the ATTENTION masks as mixing weights (models/monet_config.py:94-105).
+    returns (err [B], recon [B,3,H,W], x_r [K,B,3,H,W]); differentiable w.r.t. dec and log_w."""
+
+    @staticmethod
+    def forward(ctx, x, dec, log_w, K, std1, std2, pixel_bound):
+        x, dec, log_w = x.contiguous(), dec.contiguous(), log_w.contiguous()
+        err, recon, x_r = hip.mixture_w_fwd(x, dec, log_w, K, std1, std2, pixel_bound)
+        ctx.save_for_backward(x, dec, log_w)
+        ctx.cfg = (K, std1, std2, pixel_bound)
+        ctx.mark_non_differentiable(recon, x_r)
+        return err, recon, x_r
+
+    @staticmethod
+    def backward(ctx, g_err, *unused):
+        x, dec, log_w = ctx.saved_tensors
+        K, std1, std2, pixel_bound = ctx.cfg
+        ddec, dlog_w = hip.mixture_w_bwd(x, dec, log_w, g_err.contiguous(), K, std1, std2, pixel_bound)
+        return None, ddec, dlog_w, None, None, None, None

@@ -83,10 +83,11 @@ def pixel_coords(size):
 
 
 class _ConvGNReLU(nn.Sequential):
-    """Parameter container with the key layout of modules/blocks.py:159-165."""
+    """Parameter container with the key layout of modules/blocks.py:159-165 (ConvGNReLU) / :151-157 (ConvINReLU)."""
 
-    def __init__(self, nin, nout):
-        super().__init__(nn.Conv2d(nin, nout, 3, 1, 1, bias=False), nn.GroupNorm(8, nout), nn.ReLU(inplace=True))
+    def __init__(self, nin, nout, norm='gn'):
+        layer = nn.GroupNorm(8, nout) if norm == 'gn' else nn.InstanceNorm2d(nout, affine=True)
+        super().__init__(nn.Conv2d(nin, nout, 3, 1, 1, bias=False), layer, nn.ReLU(inplace=True))
 
     def params(self):
         return (self[0].weight, self[1].weight, self[1].bias)
@@ -95,7 +96,7 @@ class _ConvGNReLU(nn.Sequential):
 class _UNetParams(nn.Module):
     """Parameter container with the key layout / init order of modules/unet.py:23-67."""
 
-    def __init__(self, num_blocks, img_size, filter_start, in_chnls, out_chnls):
+    def __init__(self, num_blocks, img_size, filter_start, in_chnls, out_chnls, norm='gn', keep_final_conv=False):
         super().__init__()
         c = filter_start
         if num_blocks == 4:
@@ -110,16 +111,16 @@ class _UNetParams(nn.Module):
         else:
             raise ValueError('UNet supports 4, 5 or 6 blocks (img_size 32, 64, 128)')
         self.num_blocks = num_blocks
-        self.down = nn.ModuleList([_ConvGNReLU(i, o) for i, o in zip(enc_in, enc_out)])
-        self.up = nn.ModuleList([_ConvGNReLU(i, o) for i, o in zip(dec_in, dec_out)])
+        self.down = nn.ModuleList([_ConvGNReLU(i, o, norm) for i, o in zip(enc_in, enc_out)])
+        self.up = nn.ModuleList([_ConvGNReLU(i, o, norm) for i, o in zip(dec_in, dec_out)])
         self.featuremap_size = img_size // 2 ** (num_blocks - 1)
         flat = 2 * c * self.featuremap_size ** 2
         self.mlp = nn.Sequential(nn.Flatten(), nn.Linear(flat, 128), nn.ReLU(), nn.Linear(128, 128), nn.ReLU(),
                                  nn.Linear(128, flat), nn.ReLU())
         # the reference builds final_conv (consuming init RNG) and then replaces it by Identity
         # (models/genesisv2_config.py:70)
-        nn.Conv2d(c, out_chnls, 1)
-        self.final_conv = nn.Identity()
+        final = nn.Conv2d(c, out_chnls, 1)
+        self.final_conv = final if keep_final_conv else nn.Identity()
 
     def flat_params(self):
         p = []
@@ -273,7 +274,7 @@ class GenesisV2(nn.Module):
         dev = x.device
         uv, _ = self._grid(dev)
         # --- Extract features (F.relu on the ReLU'd UNet output, genesisv2_config.py:115, is the identity)
-        enc_feat = fn.UNetEncoderFn.apply(x, self.encoder.num_blocks, *self.encoder.flat_params())
+        enc_feat = fn.UNetEncoderFn.apply(x, self.encoder.num_blocks, 8, *self.encoder.flat_params())
         # --- Predict attention masks
         seg = fn.ConvGNReLUFn.apply(enc_feat, *self.seg_head.params())
         if rand_pixel is None:

@@ -25,7 +25,9 @@ def formula_state_dict(template):
     out = {}
     for i, (name, v) in enumerate(template.items()):
         shape = tuple(v.shape)
-        if name.endswith('log_sigma'):
+        if name == 'std':
+            out[name] = v.detach().clone()      # MONet's registered pixel-std buffer: not a weight
+        elif name.endswith('log_sigma'):
             out[name] = (v.detach().clone().double() + 0.1).to(v.dtype)
         elif name.endswith('gate.gate'):
             out[name] = torch.tensor(0.35, dtype=v.dtype)

@@ -56,6 +56,7 @@ class TrainStep(object):
     def _iteration(self, x, **forward_kwargs):
         self.bucket.zero_grad()
         _fn.DIRECT_PARAM_GRADS = True    # bucket zeroed above; kernels write weight grads straight into it
+        _fn.begin_direct_grads()
         try:
             return self._iteration_body(x, **forward_kwargs)
         finally:

@@ -27,11 +27,14 @@ import torch.nn.functional as F
 
 
 # --------------------------------------------------------------------------- helpers
-def conv_gn_relu(p, prefix, x, groups=8):
-    """ConvGNReLU: conv3x3 s1 p1 no-bias -> GroupNorm(8, eps=1e-5, affine) -> ReLU.
-    modules/blocks.py:159-165."""
+def conv_gn_relu(p, prefix, x, groups=8, norm='gn'):
+    """ConvGNReLU: conv3x3 s1 p1 no-bias -> GroupNorm(8, eps=1e-5, affine) -> ReLU, modules/blocks.py:159-165;
+    norm='in': ConvINReLU with InstanceNorm2d(affine=True), modules/blocks.py:151-157."""
     y = F.conv2d(x, p[prefix + '.0.weight'], None, 1, 1)
-    y = F.group_norm(y, groups, p[prefix + '.1.weight'], p[prefix + '.1.bias'], 1e-5)
+    if norm == 'in':
+        y = F.instance_norm(y, weight=p[prefix + '.1.weight'], bias=p[prefix + '.1.bias'], eps=1e-5)
+    else:
+        y = F.group_norm(y, groups, p[prefix + '.1.weight'], p[prefix + '.1.bias'], 1e-5)
     return F.relu(y)
 
 
@@ -44,14 +47,14 @@ def pixel_coords(size, dtype=torch.float32):
     return torch.stack((g_row, g_col), 0).unsqueeze(0).contiguous()  # [1,2,S,S]
 
 
-def unet_forward(p, x, num_blocks, prefix='encoder'):
-    """UNet.forward, modules/unet.py:69-90, with final_conv = Identity
-    (models/genesisv2_config.py:70)."""
+def unet_forward(p, x, num_blocks, prefix='encoder', norm='gn', final_conv=False):
+    """UNet.forward, modules/unet.py:69-90.  GENESIS-V2 replaces final_conv by Identity
+    (models/genesisv2_config.py:70); MONet keeps the 1x1 final_conv and uses norm='in'."""
     B = x.size(0)
     skip = []
     act = x
     for i in range(num_blocks):
-        act = conv_gn_relu(p, '%s.down.%d' % (prefix, i), act)
+        act = conv_gn_relu(p, '%s.down.%d' % (prefix, i), act, norm=norm)
         skip.append(act)
         if i < num_blocks - 1:
             act = F.interpolate(act, scale_factor=0.5, mode='nearest')
@@ -63,9 +66,11 @@ def unet_forward(p, x, num_blocks, prefix='encoder'):
     x_up = h.view(B, -1, fs, fs)
     for i in range(num_blocks):
         feat = torch.cat([x_up, skip[-1 - i]], dim=1)
-        x_up = conv_gn_relu(p, '%s.up.%d' % (prefix, i), feat)
+        x_up = conv_gn_relu(p, '%s.up.%d' % (prefix, i), feat, norm=norm)
         if i < num_blocks - 1:
             x_up = F.interpolate(x_up, scale_factor=2.0, mode='nearest')
+    if final_conv:
+        x_up = F.conv2d(x_up, p[prefix + '.final_conv.weight'], p[prefix + '.final_conv.bias'])
     return x_up
 
 

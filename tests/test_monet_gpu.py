@@ -1,0 +1,79 @@
+"""MONet (BASELINE config 4) on the HIP path vs golden vectors captured from the real reference: forward tensors,
+parameter gradients, three GECO + Adam steps, output contract."""
+import numpy as np
+import pytest
+import torch
+
+from tests.test_monet_oracle import CASES, MonetGolden
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def build(gold):
+    import genesis_amd.monet_config as G
+    from genesis_amd.compat.attrdict import AttrDict
+    cfg = AttrDict(dict(gold.cfg, debug=False, multi_gpu=False))
+    torch.manual_seed(0)
+    model = G.load(cfg)
+    model.load_state_dict(gold.weights(model.state_dict()))
+    return model.to(DEV).train()
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_forward_and_grads_vs_golden(case):
+    gold = MonetGolden(case)
+    model = build(gold)
+    x, eps = gold.inputs()
+    recon, losses, stats, _, comp = model(x.to(DEV), eps.to(DEV))
+    gold.check_forward(recon, losses, stats, comp, rtol=1e-4, atol=2e-5, mask_atol=1e-3)
+    err = losses.err.mean(0)
+    kl = torch.stack(losses.kl_l_k, dim=1).mean(dim=0).sum() + losses.kl_m.mean(0)
+    elbo_ref = float(gold.g['loss/err']) + float(gold.g['loss/kl'])
+    assert abs(float(err + kl) - elbo_ref) <= 1e-3 * abs(elbo_ref)
+    assert abs(float(err + kl) - elbo_ref) <= 5e-5 * abs(elbo_ref)
+    (err + kl).backward()
+    # the recurrent UNet(IN) attention (K-1 shared-weight passes) is ill-conditioned in fp32: against the fp64
+    # oracle BOTH the HIP path and the CPU-fp32 path sit at 0.3-3 % relative L2 on its gradients at 64x64 / K=7
+    # (tools/diag_monet3.py), while the ComponentVAE gradients agree to 1e-7..1e-5
+    gold.check_grads([(n, p.grad if p.grad is not None else torch.zeros_like(p)) for n, p in model.named_parameters()],
+                     rtol=4e-2, l2_tol=6e-2)
+    for key in ('log_m_k', 'log_m_r_k'):
+        assert float((torch.stack(stats[key], 4).exp().sum(4) - 1).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize('case', ['tiny', 'cfg4'])
+def test_three_training_steps(case):
+    from genesis_amd.trainer import TrainStep
+    gold = MonetGolden(case)
+    model = build(gold)
+    ts = TrainStep(model, gold.S, lr=1e-4, graph=False)
+    x, _ = gold.inputs()
+    hist = gold.g['train_hist']
+    for it in range(3):
+        _, eps = gold.inputs(1 + it)
+        out = ts.step(x.to(DEV), eps=eps.to(DEV)).cpu().numpy()
+        elbo, err, kl, beta = [float(v) for v in out]
+        # step 0 is a pure forward comparison; later steps inherit the fp32 conditioning of the attention UNet's
+        # gradients (see above) through Adam's sign-like first updates
+        tol = 1e-4 if it == 0 else 1e-3
+        assert abs(elbo - hist[it, 0]) <= tol * abs(hist[it, 0]), (it, elbo, hist[it])
+        np.testing.assert_allclose([err, beta], hist[it, [1, 3]], rtol=5e-4)
+    assert abs(float(ts.geco.beta) - float(gold.g['train_beta_final'])) <= 1e-5
+
+
+def test_output_contract_and_sample():
+    gold = MonetGolden('tiny')
+    model = build(gold)
+    B, K, S, L = gold.B, gold.K, gold.S, gold.L
+    x, _ = gold.inputs()
+    recon, losses, stats, att_stats, comp_stats = model(x.to(DEV))
+    assert recon.shape == (B, 3, S, S) and losses.err.shape == (B,) and losses.kl_m.shape == (B,)
+    assert len(losses.kl_l_k) == K and torch.stack(losses.kl_l_k, dim=1).shape == (B, K)
+    assert torch.cat(stats.log_m_k, 1).shape == (B, K, S, S) and len(stats.log_s_k) == K
+    assert len(comp_stats.z_k) == K and comp_stats.z_k[0].shape == (B, L)
+    assert model.get_features(x.to(DEV)).shape == (B, K * L)
+    img, st = model.sample(3)
+    assert img.shape == (3, 3, S, S) and len(st.x_k) == K
+    assert float((torch.stack(st.log_m_k, 4).exp().sum(4) - 1).abs().max()) < 1e-3
+    assert list(model.state_dict().keys())[0] == 'std'
