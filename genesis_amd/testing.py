@@ -25,8 +25,12 @@ def formula_state_dict(template):
     out = {}
     for i, (name, v) in enumerate(template.items()):
         shape = tuple(v.shape)
-        if name == 'std':
-            out[name] = v.detach().clone()      # MONet's registered pixel-std buffer: not a weight
+        if name == 'std' or name.endswith('num_batches_tracked'):
+            out[name] = v.detach().clone()      # registered buffers that are not weights
+        elif name.endswith('running_var'):
+            out[name] = formula_tensor(i, shape, v.dtype, 'scale')
+        elif name.endswith('running_mean'):
+            out[name] = formula_tensor(i, shape, v.dtype, 'bias')
         elif name.endswith('log_sigma'):
             out[name] = (v.detach().clone().double() + 0.1).to(v.dtype)
         elif name.endswith('gate.gate'):
