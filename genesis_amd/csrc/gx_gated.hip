@@ -1,0 +1,256 @@
+// Gated (de)convolution unit of the sylvester VAE: out = norm_h(h + b_h) * sigmoid(norm_g(g + b_g)), where
+// [h | g] = chunk(conv output [N, 2C, H, W], 2, dim=1) and norm is BatchNorm2d (training-mode batch statistics),
+// InstanceNorm2d(affine) or nothing.  Reference: third_party/sylvester/layers.py:40-54,87-101.
+//
+// HBM-bound.  Statistics are per "unit": a channel over (N, H, W) for BatchNorm, an (image, channel) plane for
+// InstanceNorm; one workgroup per unit, fp64 accumulation, fixed reduction trees (deterministic).
+#include "gx_common.h"
+
+namespace {
+
+enum { NORM_NONE = 0, NORM_BN = 1, NORM_IN = 2 };
+
+template <int NV>
+__device__ __forceinline__ void block_sum_multi(double (&v)[NV], double* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = gx_wave_sum_d(v[i]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) red[wave * NV + i] = v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double s = 0.0;
+        for (int w = 0; w < nw; ++w) s += red[w * NV + threadIdx.x];
+        red[16 * NV + threadIdx.x] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = red[16 * NV + i];
+}
+
+// unit u -> (channel ch in [0, 2C), first image n0, image count): BN: u = ch, all N images; IN: u = n*2C + ch.
+__device__ __forceinline__ void unit_decode(int u, int norm, int N, int C2, int* ch, int* n0, int* ncount) {
+    if (norm == NORM_BN) { *ch = u; *n0 = 0; *ncount = N; }
+    else { *ch = u % C2; *n0 = u / C2; *ncount = 1; }
+}
+
+// stats[u] = {mean, rstd} of (y + bias) over the unit
+__global__ void __launch_bounds__(256)
+gated_stats_kernel(const float* __restrict__ y, const float* __restrict__ bias, int N, int C2, int HW, int norm,
+                   float eps, float* __restrict__ stats) {
+    __shared__ double red[16 * 2 + 2];
+    int ch, n0, nc;
+    unit_decode(blockIdx.x, norm, N, C2, &ch, &n0, &nc);
+    const float b = bias ? bias[ch] : 0.f;
+    double acc[2] = {0.0, 0.0};
+    for (int n = n0; n < n0 + nc; ++n) {
+        const float* p = y + ((size_t)n * C2 + ch) * HW;
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+            const double v = (double)(p[i] + b);
+            acc[0] += v; acc[1] += v * v;
+        }
+    }
+    block_sum_multi<2>(acc, red);
+    const double m = (double)nc * HW;
+    const double mean = acc[0] / m;
+    double var = acc[1] / m - mean * mean;
+    if (var < 0.0) var = 0.0;
+    if (threadIdx.x == 0) {
+        stats[2 * blockIdx.x] = (float)mean;
+        stats[2 * blockIdx.x + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        // biased variance kept for the caller's running_var update (BatchNorm uses the unbiased one there)
+    }
+}
+
+__device__ __forceinline__ void unit_stats(const float* stats, int norm, int n, int ch, int C2, float* mean, float* rstd) {
+    if (norm == NORM_NONE) { *mean = 0.f; *rstd = 1.f; return; }
+    const int u = (norm == NORM_BN) ? ch : n * C2 + ch;
+    *mean = stats[2 * u]; *rstd = stats[2 * u + 1];
+}
+
+// out[n][c][p] = A_h * sigmoid(A_g),  A = ((y + b) - mean) * rstd * gamma + beta
+__global__ void __launch_bounds__(256)
+gated_apply_kernel(const float* __restrict__ y, const float* __restrict__ bias, const float* __restrict__ stats,
+                   const float* __restrict__ gh, const float* __restrict__ bh, const float* __restrict__ gg,
+                   const float* __restrict__ bg, int N, int C, int HW, int norm, float* __restrict__ out) {
+    const int plane = blockIdx.x;           // n * C + c
+    const int n = plane / C, c = plane % C;
+    const int C2 = 2 * C;
+    float mh, rh, mg, rg;
+    unit_stats(stats, norm, n, c, C2, &mh, &rh);
+    unit_stats(stats, norm, n, C + c, C2, &mg, &rg);
+    const float b_h = bias ? bias[c] : 0.f, b_g = bias ? bias[C + c] : 0.f;
+    const float g_h = gh ? gh[c] : 1.f, be_h = bh ? bh[c] : 0.f, g_g = gg ? gg[c] : 1.f, be_g = bg ? bg[c] : 0.f;
+    const float* ph = y + ((size_t)n * C2 + c) * HW;
+    const float* pg = y + ((size_t)n * C2 + C + c) * HW;
+    float* po = out + (size_t)plane * HW;
+    for (int i = threadIdx.x + blockIdx.y * blockDim.x; i < HW; i += blockDim.x * gridDim.y) {
+        const float ah = ((ph[i] + b_h) - mh) * rh * g_h + be_h;
+        const float ag = ((pg[i] + b_g) - mg) * rg * g_g + be_g;
+        po[i] = ah * (1.f / (1.f + expf(-ag)));
+    }
+}
+
+// Backward pass 1: per unit sums  S1 = sum dA, S2 = sum dA * xhat  (dA = gradient w.r.t. the affine-norm output).
+// sums[u] = {S1, S2}.  dA_h = dout * sig;  dA_g = dout * A_h * sig * (1 - sig).
+__global__ void __launch_bounds__(256)
+gated_bwd_sums_kernel(const float* __restrict__ y, const float* __restrict__ bias, const float* __restrict__ stats,
+                      const float* __restrict__ gh, const float* __restrict__ bh, const float* __restrict__ gg,
+                      const float* __restrict__ bg, const float* __restrict__ dout, int N, int C, int HW, int norm,
+                      float* __restrict__ sums) {
+    __shared__ double red[16 * 2 + 2];
+    const int C2 = 2 * C;
+    // with no norm the "unit" is still a channel over all images (only S1 = bias gradient is needed)
+    int ch, n0, nc;
+    unit_decode(blockIdx.x, norm == NORM_NONE ? NORM_BN : norm, N, C2, &ch, &n0, &nc);
+    const bool is_g = ch >= C;
+    const int c = is_g ? ch - C : ch;
+    const float b_h = bias ? bias[c] : 0.f, b_g = bias ? bias[C + c] : 0.f;
+    const float g_h = gh ? gh[c] : 1.f, be_h = bh ? bh[c] : 0.f, g_g = gg ? gg[c] : 1.f, be_g = bg ? bg[c] : 0.f;
+    double acc[2] = {0.0, 0.0};
+    for (int n = n0; n < n0 + nc; ++n) {
+        float mh, rh, mg, rg;
+        unit_stats(stats, norm, n, c, C2, &mh, &rh);
+        unit_stats(stats, norm, n, C + c, C2, &mg, &rg);
+        const float* ph = y + ((size_t)n * C2 + c) * HW;
+        const float* pg = y + ((size_t)n * C2 + C + c) * HW;
+        const float* pd = dout + ((size_t)n * C + c) * HW;
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+            const float xh = ((ph[i] + b_h) - mh) * rh, xg = ((pg[i] + b_g) - mg) * rg;
+            const float ah = xh * g_h + be_h, ag = xg * g_g + be_g;
+            const float sg = 1.f / (1.f + expf(-ag));
+            const float dA = is_g ? pd[i] * ah * sg * (1.f - sg) : pd[i] * sg;
+            acc[0] += (double)dA;
+            acc[1] += (double)dA * (is_g ? xg : xh);
+        }
+    }
+    block_sum_multi<2>(acc, red);
+    if (threadIdx.x == 0) { sums[2 * blockIdx.x] = (float)acc[0]; sums[2 * blockIdx.x + 1] = (float)acc[1]; }
+}
+
+// Backward pass 2: dy[n][ch][p] = rstd * gamma * (dA - S1/m - xhat * S2/m)   (norm none: dy = dA)
+__global__ void __launch_bounds__(256)
+gated_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ bias, const float* __restrict__ stats,
+                       const float* __restrict__ gh, const float* __restrict__ bh, const float* __restrict__ gg,
+                       const float* __restrict__ bg, const float* __restrict__ dout, const float* __restrict__ sums,
+                       int N, int C, int HW, int norm, float* __restrict__ dy) {
+    const int plane = blockIdx.x;           // n * C + c
+    const int n = plane / C, c = plane % C;
+    const int C2 = 2 * C;
+    float mh, rh, mg, rg;
+    unit_stats(stats, norm, n, c, C2, &mh, &rh);
+    unit_stats(stats, norm, n, C + c, C2, &mg, &rg);
+    const float b_h = bias ? bias[c] : 0.f, b_g = bias ? bias[C + c] : 0.f;
+    const float g_h = gh ? gh[c] : 1.f, be_h = bh ? bh[c] : 0.f, g_g = gg ? gg[c] : 1.f, be_g = bg ? bg[c] : 0.f;
+    float k1h = 0.f, k2h = 0.f, k1g = 0.f, k2g = 0.f;
+    if (norm != NORM_NONE) {
+        const float m = (norm == NORM_BN) ? (float)N * HW : (float)HW;
+        const int uh = (norm == NORM_BN) ? c : n * C2 + c, ug = (norm == NORM_BN) ? C + c : n * C2 + C + c;
+        k1h = sums[2 * uh] / m; k2h = sums[2 * uh + 1] / m;
+        k1g = sums[2 * ug] / m; k2g = sums[2 * ug + 1] / m;
+    }
+    const float* ph = y + ((size_t)n * C2 + c) * HW;
+    const float* pg = y + ((size_t)n * C2 + C + c) * HW;
+    const float* pd = dout + (size_t)plane * HW;
+    float* dh = dy + ((size_t)n * C2 + c) * HW;
+    float* dg = dy + ((size_t)n * C2 + C + c) * HW;
+    for (int i = threadIdx.x + blockIdx.y * blockDim.x; i < HW; i += blockDim.x * gridDim.y) {
+        const float xh = ((ph[i] + b_h) - mh) * rh, xg = ((pg[i] + b_g) - mg) * rg;
+        const float ah = xh * g_h + be_h, ag = xg * g_g + be_g;
+        const float sg = 1.f / (1.f + expf(-ag));
+        const float dAh = pd[i] * sg, dAg = pd[i] * ah * sg * (1.f - sg);
+        if (norm == NORM_NONE) { dh[i] = dAh; dg[i] = dAg; }
+        else {
+            dh[i] = rh * g_h * (dAh - k1h - xh * k2h);
+            dg[i] = rg * g_g * (dAg - k1g - xg * k2g);
+        }
+    }
+}
+
+// Parameter gradients from the per-unit sums: dgamma = sum S2, dbeta = sum S1 (over images for IN); the conv
+// bias gradient is sum dy = 0 under a norm (it cancels in the normalisation) and S1 with no norm.
+__global__ void gated_param_kernel(const float* __restrict__ sums, int N, int C, int norm, float* __restrict__ dgh,
+                                   float* __restrict__ dbh, float* __restrict__ dgg, float* __restrict__ dbg,
+                                   float* __restrict__ dbias) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;   // [0, 2C)
+    const int C2 = 2 * C;
+    if (ch >= C2) return;
+    double s1 = 0.0, s2 = 0.0;
+    if (norm == NORM_IN) {
+        for (int n = 0; n < N; ++n) { s1 += sums[2 * (n * C2 + ch)]; s2 += sums[2 * (n * C2 + ch) + 1]; }
+    } else {
+        s1 = sums[2 * ch]; s2 = sums[2 * ch + 1];
+    }
+    const bool is_g = ch >= C;
+    const int c = is_g ? ch - C : ch;
+    if (norm != NORM_NONE) {
+        if (is_g) { if (dgg) dgg[c] = (float)s2; if (dbg) dbg[c] = (float)s1; }
+        else { if (dgh) dgh[c] = (float)s2; if (dbh) dbh[c] = (float)s1; }
+    }
+    if (dbias) dbias[ch] = (norm == NORM_NONE) ? (float)s1 : 0.f;
+}
+
+int nunits(int norm, int N, int C) { return norm == NORM_IN ? N * 2 * C : 2 * C; }
+
+}  // namespace
+
+extern "C" {
+
+size_t gx_gated_stats_floats(int norm, int N, int C) { return (size_t)2 * nunits(norm, N, C); }
+
+int gx_gated_norm_fwd(const float* y, const float* bias, int norm, const float* gamma_h, const float* beta_h,
+                      const float* gamma_g, const float* beta_g, int N, int C, int H, int W, float eps, float* out,
+                      float* stats, gx_stream_t stream) {
+    GX_CHECK_ARG(y && out && stats, "gx_gated_norm_fwd: null pointer");
+    GX_CHECK_ARG(N > 0 && C > 0 && H > 0 && W > 0 && norm >= 0 && norm <= 2, "gx_gated_norm_fwd: bad dims / norm");
+    hipStream_t s = (hipStream_t)stream;
+    const int HW = H * W;
+    if (norm != NORM_NONE) {
+        GxProf pf(KID_GATED, s, 0.0, 4.0 * N * 2.0 * C * HW);
+        hipLaunchKernelGGL(gated_stats_kernel, dim3(nunits(norm, N, C)), dim3(256), 0, s, y, bias, N, 2 * C, HW, norm,
+                           eps, stats);
+        GX_CHECK_LAUNCH("gx_gated_norm_fwd(stats)");
+    }
+    {
+        GxProf pf(KID_GATED, s, 0.0, 4.0 * N * 3.0 * C * HW);
+        hipLaunchKernelGGL(gated_apply_kernel, dim3(N * C, gx_ceil_div(HW, 1024)), dim3(256), 0, s, y, bias,
+                           (const float*)stats, gamma_h, beta_h, gamma_g, beta_g, N, C, HW, norm, out);
+    }
+    GX_CHECK_LAUNCH("gx_gated_norm_fwd");
+    return GX_OK;
+}
+
+size_t gx_gated_norm_bwd_ws_bytes(int norm, int N, int C) { return (size_t)2 * nunits(norm, N, C) * sizeof(float); }
+
+int gx_gated_norm_bwd(const float* y, const float* bias, int norm, const float* gamma_h, const float* beta_h,
+                      const float* gamma_g, const float* beta_g, const float* stats, const float* dout, int N, int C,
+                      int H, int W, float* dy, float* dgamma_h, float* dbeta_h, float* dgamma_g, float* dbeta_g,
+                      float* dbias, void* ws, size_t ws_bytes, gx_stream_t stream) {
+    GX_CHECK_ARG(y && stats && dout && dy && ws, "gx_gated_norm_bwd: null pointer");
+    GX_CHECK_ARG(N > 0 && C > 0 && H > 0 && W > 0 && norm >= 0 && norm <= 2, "gx_gated_norm_bwd: bad dims / norm");
+    GX_CHECK_ARG(ws_bytes >= gx_gated_norm_bwd_ws_bytes(norm, N, C), "gx_gated_norm_bwd: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int HW = H * W;
+    float* sums = (float*)ws;
+    {
+        GxProf pf(KID_GATED, s, 0.0, 4.0 * N * 3.0 * C * HW);
+        hipLaunchKernelGGL(gated_bwd_sums_kernel, dim3(nunits(norm, N, C)), dim3(256), 0, s, y, bias, stats, gamma_h,
+                           beta_h, gamma_g, beta_g, dout, N, C, HW, norm, sums);
+    }
+    GX_CHECK_LAUNCH("gx_gated_norm_bwd(sums)");
+    {
+        GxProf pf(KID_GATED, s, 0.0, 4.0 * N * 5.0 * C * HW);
+        hipLaunchKernelGGL(gated_bwd_apply_kernel, dim3(N * C, gx_ceil_div(HW, 1024)), dim3(256), 0, s, y, bias, stats,
+                           gamma_h, beta_h, gamma_g, beta_g, dout, (const float*)sums, N, C, HW, norm, dy);
+    }
+    GX_CHECK_LAUNCH("gx_gated_norm_bwd(apply)");
+    hipLaunchKernelGGL(gated_param_kernel, dim3(gx_ceil_div(2 * C, 64)), dim3(64), 0, s, (const float*)sums, N, C, norm,
+                       dgamma_h, dbeta_h, dgamma_g, dbeta_g, dbias);
+    GX_CHECK_LAUNCH("gx_gated_norm_bwd(params)");
+    return GX_OK;
+}
+
+}  // extern "C"

@@ -133,7 +133,8 @@ __global__ void __launch_bounds__(256)
 mixture_kernel(const float* __restrict__ x, const float* __restrict__ dec, int B, int HW, int K, float std_,
                int pixel_bound, float* __restrict__ recon, float* __restrict__ x_r, float* __restrict__ log_m_r,
                float* __restrict__ err_part, const float* __restrict__ g_err, float* __restrict__ ddec,
-               const float* __restrict__ log_w, float* __restrict__ dlog_w, float std_first) {
+               const float* __restrict__ log_w, float* __restrict__ dlog_w, float std_first, int DC) {
+    // DC = channels of `dec` per slot: 4 (RGB + mask logit) or 3 (GENESIS: RGB only, needs log_w)
     // log_w != NULL (MONet, models/monet_config.py:94-105): the mixing log-weights are the ATTENTION masks
     // [K,B,HW] instead of log_softmax(logits); the first slot may use its own pixel std (std_first).
     __shared__ double red[4];
@@ -146,7 +147,7 @@ mixture_kernel(const float* __restrict__ x, const float* __restrict__ dec, int B
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
             if (k < K) {
-                logit[k] = dec[(((size_t)k * B + b) * 4 + 3) * HW + p];
+                logit[k] = (DC == 4) ? dec[(((size_t)k * B + b) * 4 + 3) * HW + p] : 0.f;
                 mx = fmaxf(mx, logit[k]);
             } else {
                 logit[k] = 0.f;
@@ -178,7 +179,7 @@ mixture_kernel(const float* __restrict__ x, const float* __restrict__ dec, int B
 #pragma unroll
             for (int k = 0; k < KMAX; ++k) {
                 if (k < K) {
-                    const float raw = dec[(((size_t)k * B + b) * 4 + c) * HW + p];
+                    const float raw = dec[(((size_t)k * B + b) * DC + c) * HW + p];
                     mu[k] = pixel_bound ? 1.f / (1.f + expf(-raw)) : raw;
                     const float dx = xv - mu[k];
                     const float sd = (k == 0) ? std_first : std_;
@@ -204,7 +205,7 @@ mixture_kernel(const float* __restrict__ x, const float* __restrict__ dec, int B
                         const float sd = (k == 0) ? std_first : std_;
                         float gmu = -w * (xv - mu[k]) / (sd * sd);
                         if (pixel_bound) gmu *= mu[k] * (1.f - mu[k]);
-                        ddec[(((size_t)k * B + b) * 4 + c) * HW + p] = ge * gmu;
+                        ddec[(((size_t)k * B + b) * DC + c) * HW + p] = ge * gmu;
                     }
                 }
             }
@@ -219,7 +220,7 @@ mixture_kernel(const float* __restrict__ x, const float* __restrict__ dec, int B
                 if (k < K) {
                     if (log_w) {
                         dlog_w[((size_t)k * B + b) * HW + p] = ge * dlogit[k];
-                        ddec[(((size_t)k * B + b) * 4 + 3) * HW + p] = 0.f;
+                        if (DC == 4) ddec[(((size_t)k * B + b) * 4 + 3) * HW + p] = 0.f;
                     } else {
                         ddec[(((size_t)k * B + b) * 4 + 3) * HW + p] = ge * (dlogit[k] - expf(lm[k]) * gsum);
                     }
@@ -439,7 +440,7 @@ int gx_maskpool_bwd(const float* f, const float* log_m, const float* gS, const f
 
 size_t gx_mixture_ws_bytes(int B, int H, int W) { return (size_t)B * gx_ceil_div(H * W, 256) * sizeof(float); }
 
-static int mixture_fwd_impl(const float* x, const float* dec, const float* log_w, int B, int H, int W, int K,
+static int mixture_fwd_impl(const float* x, const float* dec, const float* log_w, int dec_ch, int B, int H, int W, int K,
                             float std_first, float pixel_std, int pixel_bound, float* recon, float* x_r,
                             float* log_m_r, float* err, void* ws, size_t ws_bytes, gx_stream_t stream) {
     GX_CHECK_ARG(x && dec && recon && x_r && err && ws, "gx_mixture_fwd: null pointer");
@@ -452,7 +453,7 @@ static int mixture_fwd_impl(const float* x, const float* dec, const float* log_w
         GxProf pf(KID_MIXTURE_FWD, s, 0.0, 4.0 * B * HW * (6.0 + 8.0 * K));
         hipLaunchKernelGGL(mixture_kernel<false>, dim3(B, nb), dim3(256), 0, s, x, dec, B, HW, K, pixel_std,
                            pixel_bound, recon, x_r, log_m_r, (float*)ws, (const float*)nullptr, (float*)nullptr,
-                           log_w, (float*)nullptr, std_first);
+                           log_w, (float*)nullptr, std_first, dec_ch);
     }
     GX_CHECK_LAUNCH("gx_mixture_fwd");
     {
@@ -463,8 +464,8 @@ static int mixture_fwd_impl(const float* x, const float* dec, const float* log_w
     return GX_OK;
 }
 
-static int mixture_bwd_impl(const float* x, const float* dec, const float* log_w, const float* g_err, int B, int H,
-                            int W, int K, float std_first, float pixel_std, int pixel_bound, float* ddec,
+static int mixture_bwd_impl(const float* x, const float* dec, const float* log_w, const float* g_err, int dec_ch,
+                            int B, int H, int W, int K, float std_first, float pixel_std, int pixel_bound, float* ddec,
                             float* dlog_w, gx_stream_t stream) {
     GX_CHECK_ARG(x && dec && g_err && ddec, "gx_mixture_bwd: null pointer");
     GX_CHECK_ARG(B > 0 && K >= 1 && K <= KMAX && pixel_std > 0.f, "gx_mixture_bwd: bad dims (K<=16)");
@@ -473,7 +474,7 @@ static int mixture_bwd_impl(const float* x, const float* dec, const float* log_w
         GxProf pf(KID_MIXTURE_BWD, (hipStream_t)stream, 0.0, 4.0 * B * HW * (3.0 + 8.0 * K));
         hipLaunchKernelGGL(mixture_kernel<true>, dim3(B, nb), dim3(256), 0, (hipStream_t)stream, x, dec, B, HW, K,
                            pixel_std, pixel_bound, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
-                           g_err, ddec, log_w, dlog_w, std_first);
+                           g_err, ddec, log_w, dlog_w, std_first, dec_ch);
     }
     GX_CHECK_LAUNCH("gx_mixture_bwd");
     return GX_OK;
@@ -483,29 +484,29 @@ int gx_mixture_fwd(const float* x, const float* dec, int B, int H, int W, int K,
                    float* recon, float* x_r, float* log_m_r, float* err, void* ws, size_t ws_bytes,
                    gx_stream_t stream) {
     GX_CHECK_ARG(log_m_r, "gx_mixture_fwd: null pointer");
-    return mixture_fwd_impl(x, dec, nullptr, B, H, W, K, pixel_std, pixel_std, pixel_bound, recon, x_r, log_m_r, err,
+    return mixture_fwd_impl(x, dec, nullptr, 4, B, H, W, K, pixel_std, pixel_std, pixel_bound, recon, x_r, log_m_r, err,
                             ws, ws_bytes, stream);
 }
 
 int gx_mixture_bwd(const float* x, const float* dec, const float* g_err, int B, int H, int W, int K,
                    float pixel_std, int pixel_bound, float* ddec, gx_stream_t stream) {
-    return mixture_bwd_impl(x, dec, nullptr, g_err, B, H, W, K, pixel_std, pixel_std, pixel_bound, ddec, nullptr,
+    return mixture_bwd_impl(x, dec, nullptr, g_err, 4, B, H, W, K, pixel_std, pixel_std, pixel_bound, ddec, nullptr,
                             stream);
 }
 
-int gx_mixture_w_fwd(const float* x, const float* dec, const float* log_w, int B, int H, int W, int K,
+int gx_mixture_w_fwd(const float* x, const float* dec, const float* log_w, int dec_ch, int B, int H, int W, int K,
                      float pixel_std1, float pixel_std2, int pixel_bound, float* recon, float* x_r, float* err,
                      void* ws, size_t ws_bytes, gx_stream_t stream) {
-    GX_CHECK_ARG(log_w, "gx_mixture_w_fwd: null pointer");
-    return mixture_fwd_impl(x, dec, log_w, B, H, W, K, pixel_std1, pixel_std2, pixel_bound, recon, x_r, nullptr, err,
+    GX_CHECK_ARG(log_w && (dec_ch == 3 || dec_ch == 4), "gx_mixture_w_fwd: null pointer / dec_ch must be 3 or 4");
+    return mixture_fwd_impl(x, dec, log_w, dec_ch, B, H, W, K, pixel_std1, pixel_std2, pixel_bound, recon, x_r, nullptr, err,
                             ws, ws_bytes, stream);
 }
 
-int gx_mixture_w_bwd(const float* x, const float* dec, const float* log_w, const float* g_err, int B, int H, int W,
-                     int K, float pixel_std1, float pixel_std2, int pixel_bound, float* ddec, float* dlog_w,
-                     gx_stream_t stream) {
-    GX_CHECK_ARG(log_w && dlog_w, "gx_mixture_w_bwd: null pointer");
-    return mixture_bwd_impl(x, dec, log_w, g_err, B, H, W, K, pixel_std1, pixel_std2, pixel_bound, ddec, dlog_w,
+int gx_mixture_w_bwd(const float* x, const float* dec, const float* log_w, const float* g_err, int dec_ch, int B,
+                     int H, int W, int K, float pixel_std1, float pixel_std2, int pixel_bound, float* ddec,
+                     float* dlog_w, gx_stream_t stream) {
+    GX_CHECK_ARG(log_w && dlog_w && (dec_ch == 3 || dec_ch == 4), "gx_mixture_w_bwd: null pointer / dec_ch");
+    return mixture_bwd_impl(x, dec, log_w, g_err, dec_ch, B, H, W, K, pixel_std1, pixel_std2, pixel_bound, ddec, dlog_w,
                             stream);
 }
 

@@ -1,0 +1,191 @@
+"""GENESIS (v1) model config (BASELINE config 3) -- mirror of the reference's `models/genesis_config.py` (flags
+:33-52, `load(cfg)` :55-56, `Genesis` :59-436) on the HIP path for the default configuration (two_stage,
+autoreg_prior, comp_prior, comp_symmetric=False, K_steps > 1): same `state_dict` (root buffer `std`,
+`att_process.core.*` sylvester VAE with BatchNorm / InstanceNorm, `att_process.{lstm,linear}`, `comp_vae.*`,
+`prior_lstm`, `prior_linear`, `prior_mlp`), same forward 5-tuple with losses {err, kl_m_k, kl_l_k}.
+
+HIP mapping: LatentSBP's gated-conv attention VAE (modules/attention.py:84-133) runs on the direct (de)conv +
+fused gated-norm kernels (genesis_amd/sylvester.py); the ComponentVAE (ELU) on the direct-conv encoder kernels and
+the MFMA BroadcastDecoder canvas; the mixture likelihood on gx_mixture_w_* (RGB-only decoder output, attention
+masks as mixing weights).  LSTMs / Linears / pointwise stick-breaking are library or torch ops."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from genesis_amd import compat as _compat
+
+_compat.install()
+
+from attrdict import AttrDict  # noqa: E402
+from forge import flags  # noqa: E402
+
+from genesis_amd import functions as fn  # noqa: E402
+from genesis_amd.genesisv2_config import _cfg_get, _normal_log_prob, pixel_coords  # noqa: E402
+from genesis_amd.monet_config import _ComponentVAEParams  # noqa: E402
+from genesis_amd.sylvester import SylvesterVAE  # noqa: E402
+
+# models/genesis_config.py:33-52
+flags.DEFINE_boolean('two_stage', True, 'Use two stages if two, else only one.')
+flags.DEFINE_boolean('autoreg_prior', True, 'Autoregressive prior.')
+flags.DEFINE_boolean('comp_prior', True, 'Component prior.')
+flags.DEFINE_integer('attention_latents', 64, 'Latent dimension.')
+flags.DEFINE_string('enc_norm', 'bn', '{bn, in} - norm type in encoder.')
+flags.DEFINE_string('dec_norm', 'bn', '{bn, in} - norm type in decoder.')
+flags.DEFINE_integer('comp_enc_channels', 32, 'Starting number of channels.')
+flags.DEFINE_integer('comp_ldim', 16, 'Latent dimension of the VAE.')
+flags.DEFINE_integer('comp_dec_channels', 32, 'Num channels in Broadcast Decoder.')
+flags.DEFINE_integer('comp_dec_layers', 4, 'Num layers in Broadcast Decoder.')
+flags.DEFINE_boolean('comp_symmetric', False, 'Use same encoder/decoder as in attention VAE.')
+flags.DEFINE_boolean('pixel_bound', True, 'Bound pixel values to [0, 1].')
+flags.DEFINE_float('pixel_std1', 0.7, 'StdDev of reconstructed pixels.')
+flags.DEFINE_float('pixel_std2', 0.7, 'StdDev of reconstructed pixels.')
+flags.DEFINE_boolean('montecarlo_kl', True, 'Evaluate KL via MC samples.')
+
+
+def load(cfg):
+    return Genesis(cfg)
+
+
+class _LatentSBPParams(nn.Module):
+    """attention.LatentSBP (modules/attention.py:77-82): core VAE + LSTM(z+256 -> 2z) + Linear(2z -> 2z)."""
+
+    def __init__(self, core):
+        super().__init__()
+        self.core = core
+        self.lstm = nn.LSTM(core.z_size + 256, 2 * core.z_size)
+        self.linear = nn.Linear(2 * core.z_size, 2 * core.z_size)
+
+
+def _lstm_cell(lstm, inp, state):
+    H = lstm.weight_hh_l0.shape[1]
+    if state is None:
+        state = (inp.new_zeros(inp.shape[0], H), inp.new_zeros(inp.shape[0], H))
+    h, c = state
+    gates = F.linear(inp, lstm.weight_ih_l0, lstm.bias_ih_l0) + F.linear(h, lstm.weight_hh_l0, lstm.bias_hh_l0)
+    i, f, g, o = gates.chunk(4, 1)
+    c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+    h = torch.sigmoid(o) * torch.tanh(c)
+    return h, (h, c)
+
+
+class Genesis(nn.Module):
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.K_steps = cfg.K_steps
+        self.img_size = cfg.img_size
+        self.two_stage = _cfg_get(cfg, 'two_stage', True)
+        self.autoreg_prior = _cfg_get(cfg, 'autoreg_prior', True)
+        self.comp_prior = _cfg_get(cfg, 'comp_prior', True)
+        self.ldim = _cfg_get(cfg, 'attention_latents', 64)
+        self.pixel_bound = _cfg_get(cfg, 'pixel_bound', True)
+        self.debug = _cfg_get(cfg, 'debug', False)
+        if not (self.two_stage and self.autoreg_prior and self.comp_prior and self.K_steps > 1) or \
+                _cfg_get(cfg, 'comp_symmetric', False) or not _cfg_get(cfg, 'montecarlo_kl', True):
+            raise NotImplementedError('Genesis HIP path: default flags only (two_stage, autoreg_prior, comp_prior, '
+                                      'comp_symmetric=False, montecarlo_kl, K_steps > 1)')
+        att_core = SylvesterVAE(self.ldim, [3, cfg.img_size, cfg.img_size], 1, _cfg_get(cfg, 'enc_norm', 'bn'),
+                                _cfg_get(cfg, 'dec_norm', 'bn'))
+        self.att_steps = self.K_steps
+        self.att_process = _LatentSBPParams(att_core)
+        self.comp_vae = _ComponentVAEParams(cfg, nout=3)
+        self.comp_vae.pixel_bound = self.pixel_bound
+        self.prior_lstm = nn.LSTM(self.ldim, 256)
+        self.prior_linear = nn.Linear(256, 2 * self.ldim)
+        self.prior_mlp = nn.Sequential(nn.Linear(self.ldim, 256), nn.ELU(), nn.Linear(256, 256), nn.ELU(),
+                                       nn.Linear(256, 2 * cfg.comp_ldim))
+        std = _cfg_get(cfg, 'pixel_std2', 0.7) * torch.ones(1, 1, 1, 1, self.K_steps)
+        std[0, 0, 0, 0, 0] = _cfg_get(cfg, 'pixel_std1', 0.7)
+        self.register_buffer('std', std)
+        self._std12 = (float(_cfg_get(cfg, 'pixel_std1', 0.7)), float(_cfg_get(cfg, 'pixel_std2', 0.7)))
+        self._coords = {}
+
+    def _canvas_coords(self, device):
+        key = str(device)
+        if key not in self._coords:
+            d = self.img_size + 2 * self.comp_vae.decoder_module.num_layers
+            self._coords[key] = pixel_coords(d).contiguous().to(device)
+        return self._coords[key]
+
+    def _attention(self, x, eps_m):
+        """LatentSBP.forward (modules/attention.py:84-133) + the K+1 -> K mask fix-up (genesis_config.py:167-169)."""
+        K, B = self.K_steps, x.shape[0]
+        ap, core = self.att_process, self.att_process.core
+        h = core.encode_features(x)
+        mean, var = core.posterior(h)
+        mu_k, sigma_k = [mean], [var.sqrt()]
+        z_k = [mean + sigma_k[0] * eps_m[0]]
+        state = None
+        for step in range(1, K):
+            out, state = _lstm_cell(ap.lstm, torch.cat([h, z_k[-1]], 1), state)
+            mean_k, var_raw = ap.linear(out).chunk(2, dim=1)
+            sig = F.softplus(var_raw + 0.5) + 1e-8           # sqrt(to_var(x)) == to_sigma(x)
+            mu_k.append(mean_k); sigma_k.append(sig); z_k.append(mean_k + sig * eps_m[step])
+        logits = core.decode(torch.cat(z_k, 0)).view(K, B, 1, self.img_size, self.img_size)
+        log_s_k = [torch.zeros_like(x[:, :1])]
+        log_m_k = []
+        for step in range(K):
+            log_m_k.append(log_s_k[step] + F.logsigmoid(logits[step]))
+            log_s_k.append(log_s_k[step] + F.logsigmoid(-logits[step]))
+        log_m_k[K - 1] = log_s_k[K - 1]
+        return log_m_k, log_s_k, mu_k, sigma_k, z_k
+
+    def _prior_m(self, z_kbd):
+        out, _ = self.prior_lstm(z_kbd[:-1].contiguous())
+        mu_raw, sig_raw = self.prior_linear(out).chunk(2, dim=2)
+        return torch.tanh(mu_raw), torch.sigmoid(sig_raw + 4.0) + 1e-4
+
+    def forward(self, x, eps_m=None, eps_c=None):
+        """x [B,3,S,S] on the GPU.  eps_m: K x [B, ldim], eps_c: [K*B, comp_ldim] inject the rsample noise."""
+        if not x.is_cuda:
+            from genesis_amd._lib import GenesisHipError
+            raise GenesisHipError('Genesis: the HIP path needs device tensors; there is no CPU fallback')
+        B, K = x.shape[0], self.K_steps
+        Lc = self.comp_vae.ldim
+        if eps_m is None:
+            eps_m = list(torch.randn(K, B, self.ldim, device=x.device).unbind(0))
+        log_m_k, log_s_k, mu_k, sigma_k, z_k = self._attention(x, eps_m)
+        log_m = torch.stack(log_m_k, 0)
+        # --- ComponentVAE (ELU), slot-major batch, mask as first channel
+        inp = torch.cat((log_m.flatten(0, 1), x.repeat(K, 1, 1, 1)), 1)
+        em = self.comp_vae.encoder_module.module
+        h = inp
+        for i in (0, 2, 4, 6):
+            h = fn.DirectConvActFn.apply(h, em[i].weight, em[i].bias, 2, 1, 'elu')
+        h = F.elu(em[9](h.flatten(1)))
+        mu_c, sig_ps = em[11](h).chunk(2, dim=1)
+        sig_c = F.softplus(sig_ps + 0.5) + 1e-8
+        if eps_c is None:
+            eps_c = torch.randn(K * B, Lc, device=x.device)
+        z_c = mu_c + sig_c * eps_c
+        dm = self.comp_vae.decoder_module
+        dec = fn.BroadcastDecoderFn.apply(z_c, self._canvas_coords(x.device), 'elu', *dm.flat_params())   # [K*B,3,S,S]
+        err, recon, x_r = fn.MixtureWFn.apply(x, dec, log_m, K, self._std12[0], self._std12[1], bool(self.pixel_bound))
+        losses = AttrDict()
+        losses['err'] = err
+        # -- Attention mask KL (mask_latent_loss, genesis_config.py:288-343)
+        z = torch.stack(z_k, 0)
+        mu, sigma = torch.stack(mu_k, 0), torch.stack(sigma_k, 0)
+        mu_p, sig_p = self._prior_m(z)
+        log_q = _normal_log_prob(z, mu, sigma).sum(2)
+        log_p = torch.cat((_normal_log_prob(z[:1], 0., 1.).sum(2), _normal_log_prob(z[1:], mu_p, sig_p).sum(2)), 0)
+        losses['kl_m_k'] = list((log_q - log_p).unbind(0))
+        # -- Component KL with the learned component prior (genesis_config.py:229-247)
+        o = self.prior_mlp(z.flatten(0, 1))                       # [K*B, 2*Lc], slot-major like z_c
+        pm, ps = o.chunk(2, dim=1)
+        pm, ps = torch.tanh(pm), torch.sigmoid(ps + 4.0) + 1e-4
+        kl_l = (_normal_log_prob(z_c, mu_c, sig_c) - _normal_log_prob(z_c, pm, ps)).sum(1)
+        losses['kl_l_k'] = list(kl_l.view(K, B).unbind(0))
+        x_r_k = list(x_r.unbind(0))
+        stats = AttrDict(recon=recon, log_m_k=log_m_k, log_s_k=log_s_k, x_r_k=x_r_k,
+                         mx_r_k=list((x_r * log_m.exp()).unbind(0)))
+        att_stats = AttrDict(mu_k=mu_k, sigma_k=sigma_k, z_k=z_k, pmu_k=[torch.zeros_like(mu_k[0])] + list(mu_p.unbind(0)),
+                             psigma_k=[torch.ones_like(mu_k[0])] + list(sig_p.unbind(0)))
+        comp_stats = AttrDict(mu_k=mu_c.chunk(K, 0), sigma_k=sig_c.chunk(K, 0), z_k=z_c.chunk(K, 0),
+                              pmu_k=pm.chunk(K, 0), psigma_k=ps.chunk(K, 0))
+        return recon, losses, stats, att_stats, comp_stats
+
+    def get_features(self, image_batch):
+        with torch.no_grad():
+            _, _, _, _, comp_stats = self.forward(image_batch)
+            return torch.cat(comp_stats.z_k, dim=1)

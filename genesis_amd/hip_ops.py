@@ -321,14 +321,15 @@ def mixture_w_fwd(x, dec, log_w, K, std1, std2, pixel_bound=True):
     """Mixture likelihood with external mixing log-weights log_w [K,B,1,H,W] (MONet)."""
     _chk(x, 'mixture_w.x'); _chk(dec, 'mixture_w.dec'); _chk(log_w, 'mixture_w.log_w')
     B, _, H, W = x.shape
-    assert dec.shape == (K * B, 4, H, W) and log_w.shape == (K, B, 1, H, W)
+    DC = dec.shape[1]
+    assert dec.shape == (K * B, DC, H, W) and DC in (3, 4) and log_w.shape == (K, B, 1, H, W)
     dev = x.device
     recon = torch.empty(B, 3, H, W, dtype=F32, device=dev)
     x_r = torch.empty(K, B, 3, H, W, dtype=F32, device=dev)
     err = torch.empty(B, dtype=F32, device=dev)
     nb = _lib.query('gx_mixture_ws_bytes', B, H, W)
     ws = _ws(nb, dev)
-    _lib.call('gx_mixture_w_fwd', _p(x), _p(dec), _p(log_w), B, H, W, K, float(std1), float(std2),
+    _lib.call('gx_mixture_w_fwd', _p(x), _p(dec), _p(log_w), DC, B, H, W, K, float(std1), float(std2),
               int(bool(pixel_bound)), _p(recon), _p(x_r), _p(err), _p(ws), nb, _stream())
     return err, recon, x_r
 
@@ -338,6 +339,41 @@ def mixture_w_bwd(x, dec, log_w, g_err, K, std1, std2, pixel_bound=True):
     B, _, H, W = x.shape
     ddec = torch.empty_like(dec)
     dlog_w = torch.empty_like(log_w)
-    _lib.call('gx_mixture_w_bwd', _p(x), _p(dec), _p(log_w), _p(g_err), B, H, W, K, float(std1), float(std2),
+    _lib.call('gx_mixture_w_bwd', _p(x), _p(dec), _p(log_w), _p(g_err), int(dec.shape[1]), B, H, W, K, float(std1), float(std2),
               int(bool(pixel_bound)), _p(ddec), _p(dlog_w), _stream())
     return ddec, dlog_w
+
+
+# ------------------------------------------------------------------ sylvester gated unit
+NORMS = {None: 0, 'none': 0, 'bn': 1, 'in': 2}
+
+
+def gated_norm_fwd(y, bias, norm, gh, bh, gg, bg, eps=1e-5):
+    """out = norm_h(h + b_h) * sigmoid(norm_g(g + b_g)) for y = [h | g] (third_party/sylvester/layers.py:40-54)."""
+    _chk(y, 'gated.y'); _chk(bias, 'gated.bias')
+    N, C2, H, W = y.shape
+    C = C2 // 2
+    out = torch.empty(N, C, H, W, dtype=F32, device=y.device)
+    stats = torch.empty(max(_lib.query('gx_gated_stats_floats', NORMS[norm], N, C), 2), dtype=F32, device=y.device)
+    _lib.call('gx_gated_norm_fwd', _p(y), _p(bias), NORMS[norm], _p(gh), _p(bh), _p(gg), _p(bg), N, C, H, W,
+              float(eps), _p(out), _p(stats), _stream())
+    return out, stats
+
+
+def gated_norm_bwd(y, bias, norm, gh, bh, gg, bg, stats, dout):
+    _chk(dout, 'gated_bwd.dout')
+    N, C2, H, W = y.shape
+    C = C2 // 2
+    dev = y.device
+    dy = torch.empty_like(y)
+    has = NORMS[norm] != 0
+    dgh = torch.empty(C, dtype=F32, device=dev) if has else None
+    dbh = torch.empty(C, dtype=F32, device=dev) if has else None
+    dgg = torch.empty(C, dtype=F32, device=dev) if has else None
+    dbg = torch.empty(C, dtype=F32, device=dev) if has else None
+    dbias = torch.empty(C2, dtype=F32, device=dev) if bias is not None else None
+    nb = _lib.query('gx_gated_norm_bwd_ws_bytes', NORMS[norm], N, C)
+    ws = _ws(nb, dev)
+    _lib.call('gx_gated_norm_bwd', _p(y), _p(bias), NORMS[norm], _p(gh), _p(bh), _p(gg), _p(bg), _p(stats), _p(dout),
+              N, C, H, W, _p(dy), _p(dgh), _p(dbh), _p(dgg), _p(dbg), _p(dbias), _p(ws), nb, _stream())
+    return dy, dgh, dbh, dgg, dbg, dbias

@@ -1,0 +1,172 @@
+"""Gated-convolution VAE of third_party/sylvester (VAE.py:36-168, layers.py:11-101) on the HIP path: parameter
+containers with the reference's key layout / init order, and the autograd Functions that run its layers through the
+C ABI (direct (de)convolution kernels + the fused gated-norm kernel; the two 'fc' layers -- a kfc x kfc valid conv
+from a kfc x kfc map and its transpose from a 1x1 map -- are plain GEMMs and go through the library)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import hip_ops as hip
+from .functions import _gout, _ret
+
+
+def vae_geometry(img_size):
+    """VAE.py:56-69 -> (last_kernel_size, strides)."""
+    table = {32: (8, [1, 2, 1, 2, 1]), 64: (16, [1, 2, 1, 2, 1]), 128: (16, [2, 2, 2, 1, 1]), 256: (16, [2, 2, 2, 2, 1])}
+    if img_size not in table:
+        raise ValueError('Invalid input size.')
+    return table[img_size]
+
+
+# ------------------------------------------------------------------ parameter containers
+class _Gated(nn.Module):
+    def __init__(self, conv, cout, h_norm, g_norm):
+        super().__init__()
+        self.conv = conv
+        self.norm = h_norm if h_norm in ('bn', 'in') else None
+        mk = {'bn': lambda: nn.BatchNorm2d(cout), 'in': lambda: nn.InstanceNorm2d(cout, affine=True)}
+        self.h_norm = mk[h_norm]() if h_norm in mk else None
+        self.g_norm = mk[g_norm]() if g_norm in mk else None
+
+
+def GatedConv2d(cin, cout, k, s, p, h_norm=None, g_norm=None):
+    return _Gated(nn.Conv2d(cin, 2 * cout, k, s, p), cout, h_norm, g_norm)
+
+
+def GatedConvTranspose2d(cin, cout, k, s, p, op=0, h_norm=None, g_norm=None):
+    return _Gated(nn.ConvTranspose2d(cin, 2 * cout, k, s, p, op), cout, h_norm, g_norm)
+
+
+class _ToVar(nn.Module):
+    pass
+
+
+class SylvesterVAE(nn.Module):
+    """Parameter container + HIP forward for sylvester.VAE (construction order of VAE.py:73-83)."""
+
+    def __init__(self, z_size, input_size, nout, enc_norm=None, dec_norm=None):
+        super().__init__()
+        self.z_size = z_size
+        self.img_size = input_size[1]
+        self.nout = nout if nout is not None else input_size[0]
+        self.enc_norm, self.dec_norm = enc_norm, dec_norm
+        self.last_kernel_size, strides = vae_geometry(self.img_size)
+        self.strides = strides
+        cin, cout = [input_size[0], 32, 32, 64, 64], [32, 32, 64, 64, 64]
+        layers = [GatedConv2d(i, o, 5, s, 2, enc_norm, enc_norm) for i, o, s in zip(cin, cout, strides)]
+        layers.append(GatedConv2d(cout[-1], 256, self.last_kernel_size, 1, 0))
+        self.q_z_nn = nn.Sequential(*layers)
+        self.q_z_mean = nn.Linear(256, z_size)
+        self.q_z_var = nn.Sequential(nn.Linear(256, z_size), _ToVar())
+        cin, cout = [64, 64, 32, 32, 32], [64, 32, 32, 32, 32]
+        rs = list(reversed(strides))
+        layers = [GatedConvTranspose2d(z_size, cin[0], self.last_kernel_size, 1, 0)]
+        layers += [GatedConvTranspose2d(i, o, 5, s, 2, s - 1, dec_norm, dec_norm) for i, o, s in zip(cin, cout, rs)]
+        self.p_x_nn = nn.Sequential(*layers)
+        self.p_x_mean = nn.Conv2d(cout[-1], self.nout, 1, 1, 0)
+
+    # -------------------------------------------------------------- HIP forward pieces
+    def _gate(self, unit, y):
+        """norm_h(h + b) * sigmoid(norm_g(g + b)); BatchNorm running statistics are updated like nn.BatchNorm2d."""
+        norm = unit.norm
+        if norm == 'bn' and not self.training:
+            # evaluation mode: running statistics (not the training hot path): plain pointwise ops
+            h, g = (y + unit.conv.bias.view(1, -1, 1, 1)).chunk(2, 1)
+            return unit.h_norm(h) * torch.sigmoid(unit.g_norm(g))
+        args = (unit.h_norm.weight, unit.h_norm.bias, unit.g_norm.weight, unit.g_norm.bias) if norm else (None,) * 4
+        out, stats = GatedNormFn.apply(y, unit.conv.bias, norm, *args)
+        if norm == 'bn':
+            with torch.no_grad():
+                C = out.shape[1]
+                m = y.shape[0] * y.shape[2] * y.shape[3]
+                st = stats.view(-1, 2)
+                mean, var = st[:, 0], (1.0 / st[:, 1] ** 2 - 1e-5) * (m / max(m - 1, 1))
+                for bn, sl in ((unit.h_norm, slice(0, C)), (unit.g_norm, slice(C, 2 * C))):
+                    bn.running_mean.mul_(0.9).add_(0.1 * mean[sl])
+                    bn.running_var.mul_(0.9).add_(0.1 * var[sl])
+                    bn.num_batches_tracked.add_(1)
+        return out
+
+    def encode_features(self, x):
+        """q_z_nn -> [N, 256]."""
+        h = x
+        for l, s in enumerate(self.strides):
+            unit = self.q_z_nn[l]
+            h = self._gate(unit, DirectConvFn.apply(h, unit.conv.weight, 'conv', s, 2, 0))
+        unit = self.q_z_nn[len(self.strides)]
+        y = F.linear(h.flatten(1), unit.conv.weight.flatten(1)).view(h.shape[0], -1, 1, 1)
+        return self._gate(unit, y).flatten(1)
+
+    def posterior(self, h):
+        mean = self.q_z_mean(h)
+        var = (F.softplus(self.q_z_var[0](h) + 0.5) + 1e-8) ** 2     # ToVar: to_sigma(x)**2 (blocks.py:22-26)
+        return mean, var
+
+    def decode(self, z):
+        unit = self.p_x_nn[0]
+        k = self.last_kernel_size
+        w = unit.conv.weight                                           # [z, 128, k, k]
+        y = (z @ w.flatten(1)).view(z.shape[0], w.shape[1], k, k)
+        h = self._gate(unit, y)
+        for l, s in enumerate(reversed(self.strides)):
+            unit = self.p_x_nn[l + 1]
+            h = self._gate(unit, DirectConvFn.apply(h, unit.conv.weight, 'deconv', s, 2, s - 1))
+        from .functions import Conv1x1Fn
+        return Conv1x1Fn.apply(h, self.p_x_mean.weight, self.p_x_mean.bias)
+
+
+# ------------------------------------------------------------------ autograd Functions
+class DirectConvFn(torch.autograd.Function):
+    """Bias-free Conv2d / ConvTranspose2d through the generic direct kernels.  A ConvTranspose2d (weight
+    [Cin, Cout, k, k]) is the data-gradient of the Conv2d with the same weight tensor, and vice versa."""
+
+    @staticmethod
+    def forward(ctx, x, w, kind, stride, pad, out_pad):
+        x = x.contiguous()
+        k = w.shape[2]
+        if kind == 'conv':
+            y = hip.conv2d_direct_fwd(x, w, None, None, stride, pad)
+        else:
+            H, W = x.shape[2], x.shape[3]
+            Ho, Wo = (H - 1) * stride - 2 * pad + k + out_pad, (W - 1) * stride - 2 * pad + k + out_pad
+            y = hip.conv2d_direct_dgrad(x, w, Ho, Wo, stride, pad)
+        ctx.save_for_backward(x)
+        ctx.w = w
+        ctx.cfg = (kind, stride, pad, k)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        w = ctx.w
+        kind, stride, pad, k = ctx.cfg
+        g = g.contiguous()
+        ow = _gout(w)
+        if kind == 'conv':
+            dw = hip.conv2d_direct_wgrad(x, g, k, stride, pad, out=ow)
+            dx = hip.conv2d_direct_dgrad(g, w, x.shape[2], x.shape[3], stride, pad) if ctx.needs_input_grad[0] else None
+        else:
+            dw = hip.conv2d_direct_wgrad(g, x, k, stride, pad, out=ow)
+            dx = hip.conv2d_direct_fwd(g, w, None, None, stride, pad) if ctx.needs_input_grad[0] else None
+        return dx, _ret(ow, dw), None, None, None, None
+
+
+class GatedNormFn(torch.autograd.Function):
+    """returns (out [N,C,H,W], stats); stats ({mean, rstd} per unit) is non-differentiable."""
+
+    @staticmethod
+    def forward(ctx, y, bias, norm, gh, bh, gg, bg):
+        y = y.contiguous()
+        out, stats = hip.gated_norm_fwd(y, bias, norm, gh, bh, gg, bg)
+        ctx.save_for_backward(y, stats)
+        ctx.params = (bias, gh, bh, gg, bg)
+        ctx.norm = norm
+        ctx.mark_non_differentiable(stats)
+        return out, stats
+
+    @staticmethod
+    def backward(ctx, g, _unused):
+        y, stats = ctx.saved_tensors
+        bias, gh, bh, gg, bg = ctx.params
+        dy, dgh, dbh, dgg, dbg, dbias = hip.gated_norm_bwd(y, bias, ctx.norm, gh, bh, gg, bg, stats, g.contiguous())
+        return dy, dbias, None, dgh, dbh, dgg, dbg

@@ -64,10 +64,17 @@ class TrainStep(object):
 
     def _iteration_body(self, x, **forward_kwargs):
         recon, losses, stats, att_stats, comp_stats = self.model(x, **forward_kwargs)
+        # loss aggregation of train.py:226-242 (every model family: kl_m | kl_m_k, kl_l | kl_l_k)
         err = losses.err.mean(0)
-        kl = torch.stack(losses.kl_l_k, dim=1).mean(dim=0).sum()
+        kl = err.new_zeros(())
         if 'kl_m' in losses:
             kl = kl + losses.kl_m.mean(0)
+        elif 'kl_m_k' in losses:
+            kl = kl + torch.stack(losses.kl_m_k, dim=1).mean(dim=0).sum()
+        if 'kl_l' in losses:
+            kl = kl + losses.kl_l.mean(0)
+        elif 'kl_l_k' in losses:
+            kl = kl + torch.stack(losses.kl_l_k, dim=1).mean(dim=0).sum()
         if self.geco is not None:
             beta = self.geco.state[0].clone()
         else:

@@ -1,0 +1,72 @@
+"""BaselineVAE model config (BASELINE config 1) -- mirror of the reference's `models/vae_config.py` (flags :28-33,
+`load(cfg)` :36-37, `BaselineVAE` :40-101) on the HIP path: same `state_dict` (`vae.*`), same
+`forward(x) -> (recon, {err, kl_l}, stats, None, None)`, `sample`, `get_features`."""
+import math
+
+import torch
+import torch.nn as nn
+
+from genesis_amd import compat as _compat
+
+_compat.install()
+
+from attrdict import AttrDict  # noqa: E402
+from forge import flags  # noqa: E402
+
+from genesis_amd.genesisv2_config import _cfg_get, _normal_log_prob  # noqa: E402
+from genesis_amd.sylvester import SylvesterVAE  # noqa: E402
+
+# GatedConvVAE (models/vae_config.py:28-33)
+flags.DEFINE_integer('latent_dimension', 64, 'Latent channels.')
+flags.DEFINE_boolean('broadcast_decoder', False, 'Use broadcast decoder instead of deconv.')
+flags.DEFINE_boolean('pixel_bound', True, 'Bound pixel values to [0, 1].')
+flags.DEFINE_float('pixel_std', 0.7, 'StdDev of reconstructed pixels.')
+
+
+def load(cfg):
+    return BaselineVAE(cfg)
+
+
+class BaselineVAE(nn.Module):
+
+    def __init__(self, cfg):
+        super().__init__()
+        cfg.K_steps = None                    # vae_config.py:44
+        self.ldim = cfg.latent_dimension
+        self.pixel_std = _cfg_get(cfg, 'pixel_std', 0.7)
+        self.pixel_bound = _cfg_get(cfg, 'pixel_bound', True)
+        self.debug = _cfg_get(cfg, 'debug', False)
+        if _cfg_get(cfg, 'broadcast_decoder', False):
+            raise NotImplementedError('broadcast_decoder=True (non-default, vae_config.py:53-61) is not on the HIP path')
+        self.vae = SylvesterVAE(self.ldim, [3, cfg.img_size, cfg.img_size], 3)
+
+    def forward(self, x, eps=None):
+        """x [B,3,S,S] on the GPU; eps [B, ldim] injects the rsample noise (VAE.py:131-132)."""
+        if not x.is_cuda:
+            from genesis_amd._lib import GenesisHipError
+            raise GenesisHipError('BaselineVAE: the HIP path needs device tensors; there is no CPU fallback')
+        h = self.vae.encode_features(x)
+        mu, var = self.vae.posterior(h)
+        sigma = var.sqrt()
+        if eps is None:
+            eps = torch.randn_like(mu)
+        z = mu + sigma * eps
+        x_mean = self.vae.decode(z)
+        recon = torch.sigmoid(x_mean) if self.pixel_bound else x_mean
+        err = -_normal_log_prob(x, recon, float(self.pixel_std)).sum(dim=(1, 2, 3))
+        kl = (_normal_log_prob(z, mu, sigma) - _normal_log_prob(z, 0., 1.)).sum(dim=1)
+        stats = AttrDict(x=x_mean, mu=mu, sigma=sigma, z=z)
+        return recon, AttrDict(err=err, kl_l=kl), stats, None, None
+
+    @torch.no_grad()
+    def sample(self, batch_size, *args, **kwargs):
+        z = torch.randn(batch_size, self.ldim, device=self.vae.p_x_mean.weight.device)
+        x = self.vae.decode(z)
+        if self.pixel_bound:
+            x = torch.sigmoid(x)
+        return x, AttrDict(z=z)
+
+    def get_features(self, image_batch):
+        with torch.no_grad():
+            _, _, stats, _, _ = self.forward(image_batch)
+        return stats.z

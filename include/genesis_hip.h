@@ -147,8 +147,9 @@ int gx_profile_collect(double* total_ms, double* launches, double* flops, double
  *      gx_bias_act_bwd: dy = g * act'(out) (derivative from the OUTPUT) and dbias[c] = sum dy (NULL to skip).
  *      gx_conv2d_direct_*: generic k<=5 / stride / pad direct convolution for the tiny stride-2 encoder convs.
  *      gx_mixture_w_*: mixture likelihood with EXTERNAL mixing log-weights log_w [K,B,1,H,W] (MONet mixes with
- *      the attention masks, not with log_softmax(logits)) and a separate std for the first slot; bwd also
- *      returns dlog_w; the logit channel of ddec is zero. */
+ *      the attention masks, not with log_softmax(logits)) and a separate std for the first slot; dec has dec_ch
+ *      channels per slot: 4 (RGB + logit, MONet) or 3 (RGB, GENESIS); bwd also returns dlog_w; the logit channel
+ *      of ddec (if any) is zero. */
 int gx_conv3x3_bias_act_fwd(const float* x, const float* w, const float* bias, int act, float* y, int N, int Cin,
                             int Cout, int H, int W, void* ws, size_t ws_bytes, gx_stream_t stream);
 size_t gx_bias_act_bwd_ws_bytes(int N, int C);
@@ -160,12 +161,27 @@ int gx_conv2d_direct_dgrad(const float* dy, const float* w, float* dx, int N, in
                            int stride, int pad, gx_stream_t stream);
 int gx_conv2d_direct_wgrad(const float* x, const float* dy, float* dw, int N, int Cin, int Cout, int H, int W, int k,
                            int stride, int pad, gx_stream_t stream);
-int gx_mixture_w_fwd(const float* x, const float* dec, const float* log_w, int B, int H, int W, int K,
+int gx_mixture_w_fwd(const float* x, const float* dec, const float* log_w, int dec_ch, int B, int H, int W, int K,
                      float pixel_std1, float pixel_std2, int pixel_bound, float* recon, float* x_r, float* err,
                      void* ws, size_t ws_bytes, gx_stream_t stream);
-int gx_mixture_w_bwd(const float* x, const float* dec, const float* log_w, const float* g_err, int B, int H, int W,
-                     int K, float pixel_std1, float pixel_std2, int pixel_bound, float* ddec, float* dlog_w,
-                     gx_stream_t stream);
+int gx_mixture_w_bwd(const float* x, const float* dec, const float* log_w, const float* g_err, int dec_ch, int B,
+                     int H, int W, int K, float pixel_std1, float pixel_std2, int pixel_bound, float* ddec,
+                     float* dlog_w, gx_stream_t stream);
+
+/* ---- gated (de)convolution unit of the sylvester VAE (third_party/sylvester/layers.py:40-54,87-101):
+ *      out = norm_h(h + b_h) * sigmoid(norm_g(g + b_g)), [h | g] = the two channel halves of y [N,2C,H,W];
+ *      norm 0 none, 1 BatchNorm2d with training-mode batch statistics, 2 InstanceNorm2d(affine); `bias` [2C] is the
+ *      (de)conv bias, folded in here.  stats: gx_gated_stats_floats() floats ({mean, rstd} per unit), kept for bwd
+ *      (and for the caller's running-statistics update).  bwd returns dy [N,2C,H,W] and the affine / bias grads. */
+size_t gx_gated_stats_floats(int norm, int N, int C);
+int gx_gated_norm_fwd(const float* y, const float* bias, int norm, const float* gamma_h, const float* beta_h,
+                      const float* gamma_g, const float* beta_g, int N, int C, int H, int W, float eps, float* out,
+                      float* stats, gx_stream_t stream);
+size_t gx_gated_norm_bwd_ws_bytes(int norm, int N, int C);
+int gx_gated_norm_bwd(const float* y, const float* bias, int norm, const float* gamma_h, const float* beta_h,
+                      const float* gamma_g, const float* beta_g, const float* stats, const float* dout, int N, int C,
+                      int H, int W, float* dy, float* dgamma_h, float* dbeta_h, float* dgamma_g, float* dbeta_g,
+                      float* dbias, void* ws, size_t ws_bytes, gx_stream_t stream);
 
 #ifdef __cplusplus
 }

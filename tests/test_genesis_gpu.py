@@ -1,0 +1,87 @@
+"""BaselineVAE (BASELINE config 1) and GENESIS v1 (config 3) on the HIP path vs golden vectors captured from the
+real reference: forward tensors, parameter gradients, three GECO + Adam steps."""
+import numpy as np
+import pytest
+import torch
+
+from tests.test_genesis_oracle import GEN_CASES, VAE_CASES, Gold
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def build(gold, mod):
+    from genesis_amd.compat.attrdict import AttrDict
+    cfg = AttrDict(dict(gold.cfg, debug=False, multi_gpu=False))
+    torch.manual_seed(0)
+    model = mod.load(cfg)
+    model.load_state_dict(gold.weights(model.state_dict()))
+    return model.to(DEV).train()
+
+
+def grads(model):
+    return [(n, p.grad if p.grad is not None else torch.zeros_like(p)) for n, p in model.named_parameters()]
+
+
+@pytest.mark.parametrize('case', VAE_CASES)
+def test_vae_forward_grads_and_steps(case):
+    import genesis_amd.vae_config as G
+    from genesis_amd.trainer import TrainStep
+    gold = Gold('vae', case)
+    model = build(gold, G)
+    x = gold.x()
+    L = gold.cfg['latent_dimension']
+    (eps,) = gold.replay([(gold.B, L)])
+    recon, losses, stats, _, _ = model(x.to(DEV), eps.to(DEV))
+    for k, t in (('err', losses.err), ('kl_l', losses.kl_l), ('recon', recon), ('mu', stats.mu), ('z', stats.z)):
+        gold.check(k, t, 1e-4, 2e-5)
+    (losses.err.mean(0) + losses.kl_l.mean(0)).backward()
+    gold.check_grads(grads(model), rtol=5e-3, l2_tol=1e-2)
+    model = build(gold, G)
+    ts = TrainStep(model, gold.S, lr=1e-4)
+    hist = gold.g['train_hist']
+    for it in range(3):
+        (e,) = gold.replay([(gold.B, L)], 1 + it)
+        out = ts.step(x.to(DEV), eps=e.to(DEV)).cpu().numpy()
+        assert abs(out[0] - hist[it, 0]) <= 1e-3 * abs(hist[it, 0]), (it, out, hist[it])
+        np.testing.assert_allclose(out[[1, 3]], hist[it, [1, 3]], rtol=5e-4)
+    img, st = model.sample(3)
+    assert img.shape == (3, 3, gold.S, gold.S) and model.get_features(x.to(DEV)).shape == (gold.B, L)
+
+
+@pytest.mark.parametrize('case', GEN_CASES)
+def test_genesis_forward_grads_and_steps(case):
+    import genesis_amd.genesis_config as G
+    from genesis_amd.trainer import TrainStep
+    gold = Gold('genesis', case)
+    cfg = gold.cfg
+    K, L, Lc = cfg['K_steps'], cfg['attention_latents'], cfg['comp_ldim']
+    model = build(gold, G)
+    x = gold.x()
+    noise = gold.replay([(gold.B, L)] * K + [(K * gold.B, Lc)])
+    recon, losses, stats, att, comp = model(x.to(DEV), [n.to(DEV) for n in noise[:K]], noise[K].to(DEV))
+    st = lambda l: torch.stack(list(l))  # noqa: E731
+    gold.check('err', losses.err, 1e-4, 1e-3)
+    gold.check('kl_m_k', st(losses.kl_m_k), 1e-3, 5e-3)
+    gold.check('kl_l_k', st(losses.kl_l_k), 1e-3, 5e-3)
+    gold.check('recon', recon, 1e-4, 2e-5)
+    gold.check('log_m_k', st(stats.log_m_k), 1e-4, 1e-3)
+    gold.check('x_r_k', st(stats.x_r_k), 1e-4, 2e-5)
+    gold.check('att_z_k', st(att.z_k), 1e-4, 5e-5)
+    gold.check('comp_z_k', st(comp.z_k), 1e-4, 5e-5)
+    err = losses.err.mean(0)
+    kl = torch.stack(losses.kl_m_k, 1).mean(0).sum() + torch.stack(losses.kl_l_k, 1).mean(0).sum()
+    elbo_ref = float(gold.g['loss/err']) + float(gold.g['loss/kl'])
+    assert abs(float(err + kl) - elbo_ref) <= 1e-4 * abs(elbo_ref)
+    (err + kl).backward()
+    gold.check_grads(grads(model), rtol=2e-2, l2_tol=5e-2)
+    assert float((torch.stack(stats.log_m_k, 4).exp().sum(4) - 1).abs().max()) < 1e-3
+    # three training steps (BatchNorm running statistics restart from the fixture's values)
+    model = build(gold, G)
+    ts = TrainStep(model, gold.S, lr=1e-4)
+    hist = gold.g['train_hist']
+    for it in range(3):
+        nz = gold.replay([(gold.B, L)] * K + [(K * gold.B, Lc)], 1 + it)
+        out = ts.step(x.to(DEV), eps_m=[n.to(DEV) for n in nz[:K]], eps_c=nz[K].to(DEV)).cpu().numpy()
+        assert abs(out[0] - hist[it, 0]) <= 1e-3 * abs(hist[it, 0]), (it, out, hist[it])
+    assert int(model.att_process.core.q_z_nn[0].h_norm.num_batches_tracked) == 3 if cfg['enc_norm'] == 'bn' else True

@@ -350,3 +350,54 @@ def test_instance_norm_is_groupnorm_with_c_groups(N, C, S):
     close(dy, yr.grad, 1e-4, 1e-5, 'dy')
     close(dgamma, gr.grad, 1e-4, 1e-4, 'dgamma')
     close(dbeta, br.grad, 1e-4, 1e-4, 'dbeta')
+
+
+@pytest.mark.parametrize('norm', ['bn', 'in', None])
+@pytest.mark.parametrize('N,C,S', [(4, 32, 16), (3, 64, 8), (6, 32, 64)])
+def test_gated_norm(norm, N, C, S):
+    """sylvester gated unit (layers.py:40-54): norm_h(h) * sigmoid(norm_g(g)), BatchNorm in training mode."""
+    y = rnd(N, 2 * C, S, S, seed=91, scale=2.0)
+    bias = rnd(2 * C, seed=92, scale=0.5)
+    prm = [1 + 0.3 * rnd(C, seed=93), 0.2 * rnd(C, seed=94), 1 + 0.3 * rnd(C, seed=95), 0.2 * rnd(C, seed=96)]
+    g = rnd(N, C, S, S, seed=97)
+    yr, br = y.clone().requires_grad_(), bias.clone().requires_grad_()
+    pr = [t.clone().requires_grad_() for t in prm]
+    h, gt = (yr + br.view(1, -1, 1, 1)).chunk(2, 1)
+    if norm == 'bn':
+        h = F.batch_norm(h, None, None, pr[0], pr[1], True, 0.1, 1e-5)
+        gt = F.batch_norm(gt, None, None, pr[2], pr[3], True, 0.1, 1e-5)
+    elif norm == 'in':
+        h = F.instance_norm(h, weight=pr[0], bias=pr[1], eps=1e-5)
+        gt = F.instance_norm(gt, weight=pr[2], bias=pr[3], eps=1e-5)
+    ref = h * torch.sigmoid(gt)
+    ref.backward(g)
+    to = lambda t: t.to(DEV)  # noqa: E731
+    args = [to(t) for t in prm] if norm else [None] * 4
+    out, stats = hip.gated_norm_fwd(to(y), to(bias), norm, *args)
+    close(out, ref, 1e-5, 1e-5, 'fwd')
+    dy, dgh, dbh, dgg, dbg, dbias = hip.gated_norm_bwd(to(y), to(bias), norm, *args, stats, to(g))
+    close(dy, yr.grad, 1e-4, 1e-5, 'dy')
+    if norm:
+        for got, r, nm in ((dgh, pr[0], 'dgamma_h'), (dbh, pr[1], 'dbeta_h'), (dgg, pr[2], 'dgamma_g'), (dbg, pr[3], 'dbeta_g')):
+            close(got, r.grad, 1e-4, 1e-4, nm)
+    # under a norm the conv-bias gradient is analytically zero (the reference carries ~1e-4 of cancellation noise)
+    close(dbias, br.grad, 1e-4, 1e-3 if norm else 1e-4, 'dbias')
+
+
+def test_mixture_external_weights_rgb_only():
+    """GENESIS: decoder emits RGB only (3 channels per slot), masks come from the attention process."""
+    from oracle import v2_oracle as O
+    B, S, K = 2, 32, 3
+    x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(75))
+    dec = rnd(K * B, 3, S, S, seed=76, scale=2.0)
+    log_w = torch.log_softmax(rnd(K, B, 1, S, S, seed=77, scale=3.0), 0)
+    std = 0.7 * torch.ones(1, 1, 1, 1, K)
+    dr, lr = dec.clone().requires_grad_(), log_w.clone().requires_grad_()
+    x_r_k = [torch.sigmoid(c) for c in dr.chunk(K, 0)]
+    err_ref = O.x_loss(x, list(lr.unbind(0)), x_r_k, std)
+    (err_ref * 1.3).sum().backward()
+    err, recon, x_r = hip.mixture_w_fwd(x.to(DEV), dec.to(DEV), log_w.to(DEV), K, 0.7, 0.7, True)
+    close(err, err_ref, 2e-6, 1e-3, 'err')
+    ddec, dlw = hip.mixture_w_bwd(x.to(DEV), dec.to(DEV), log_w.to(DEV), torch.full((B,), 1.3, device=DEV), K, 0.7, 0.7, True)
+    close(ddec, dr.grad, 1e-4, 1e-5, 'ddec')
+    close(dlw, lr.grad, 1e-4, 1e-5, 'dlog_w')
