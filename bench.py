@@ -41,8 +41,8 @@ def parse():
     ap.add_argument('--K', type=int, default=7)
     ap.add_argument('--img', type=int, default=64)
     ap.add_argument('--feat_dim', type=int, default=64)
-    ap.add_argument('--model', default='genesisv2', choices=['genesisv2', 'monet'],
-                    help='genesisv2 = the BASELINE metric; monet = BASELINE config 4 (informational)')
+    ap.add_argument('--model', default='genesisv2', choices=['genesisv2', 'monet', 'genesis', 'vae'],
+                    help='genesisv2 = the BASELINE metric; monet / genesis / vae = BASELINE configs 4 / 3 / 1 (informational)')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of HIP-graph replay')
     ap.add_argument('--profile-steps', type=int, default=3)
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU baseline leg (0 = skip)')
@@ -57,6 +57,18 @@ def build_model(args, device):
         cfg = AttrDict(dict(monet_oracle.make_cfg(K_steps=args.K, img_size=args.img), debug=False, multi_gpu=False))
         torch.manual_seed(0)
         return GM.load(cfg).to(device).train()
+    if args.model == 'genesis':
+        import genesis_amd.genesis_config as GG
+        from oracle import genesis_oracle  # default-flag table only
+        cfg = AttrDict(dict(genesis_oracle.make_cfg(K_steps=args.K, img_size=args.img), debug=False, multi_gpu=False))
+        torch.manual_seed(0)
+        return GG.load(cfg).to(device).train()
+    if args.model == 'vae':
+        import genesis_amd.vae_config as GV
+        from oracle import vae_oracle  # default-flag table only
+        cfg = AttrDict(dict(vae_oracle.make_cfg(img_size=args.img), debug=False, multi_gpu=False))
+        torch.manual_seed(0)
+        return GV.load(cfg).to(device).train()
     import genesis_amd.genesisv2_config as G
     cfg = AttrDict(K_steps=args.K, img_size=args.img, feat_dim=args.feat_dim, kernel='gaussian', semiconv=True,
                    dynamic_K=False, klm_loss=False, detach_mr_in_klm=True, pixel_bound=True, autoreg_prior=True,
@@ -177,7 +189,8 @@ def main():
         flop_img = FLOP_PER_IMG.get((args.K, args.img)) if args.model == 'genesisv2' else None
         result = {
             'metric': 'training images/sec (fwd+bwd+GECO step), %s K=%d %dx%d'
-                      % ('GENESIS-V2' if args.model == 'genesisv2' else 'MONet', args.K, args.img, args.img),
+                      % ({'genesisv2': 'GENESIS-V2', 'monet': 'MONet', 'genesis': 'GENESIS', 'vae': 'BaselineVAE'}[args.model],
+                         args.K, args.img, args.img),
             'value': value, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',

@@ -27,8 +27,11 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_argument_validation_needs_no_gpu():
+    with pytest.raises(_lib.GenesisHipError, match='H in'):
+        _lib.call('gx_conv3x3_fwd', None, None, None, 1, 3, 8, 0, 6, None, 0, None)
     with pytest.raises(_lib.GenesisHipError, match='powers of two'):
-        _lib.call('gx_conv3x3_fwd', None, None, None, 1, 3, 8, 6, 6, None, 0, None)
+        _lib.call('gx_gn_relu_fwd', ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8), 1, 8, 6, 6, 8,
+                  ctypes.c_float(1e-5), ctypes.c_void_p(8), 8, 0, 0, None, 0, 0, 0, ctypes.c_void_p(8), ctypes.c_void_p(8), None)
     with pytest.raises(_lib.GenesisHipError, match='null pointer'):
         _lib.call('gx_mixture_fwd', None, None, 1, 8, 8, 3, ctypes.c_float(0.7), 1, None, None, None, None, None, 0, None)
     assert _lib.query('gx_conv3x3_ws_bytes', 32, 64, 64, 64, 64) >= 9 * 64 * 64 * 4
