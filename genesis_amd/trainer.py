@@ -21,7 +21,7 @@ def _p(t):
 class TrainStep(object):
 
     def __init__(self, model, img_size, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, geco=None, use_geco=True,
-                 beta_fixed=0.5, process_group=None, graph=False):
+                 beta_fixed=0.5, process_group=None, graph=False, async_wgrad=False):
         self.model = model
         self.lr, self.betas, self.eps = lr, betas, eps
         self.device = next(model.parameters()).device
@@ -29,6 +29,7 @@ class TrainStep(object):
             raise _lib.GenesisHipError('TrainStep needs the model on a HIP device; there is no CPU path')
         self.geco = geco if geco is not None else (make_geco(img_size, device=self.device) if use_geco else None)
         self.beta_fixed = beta_fixed
+        self.async_wgrad = async_wgrad
         self._beta_fixed_t = torch.tensor(float(beta_fixed), device=self.device)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
@@ -57,10 +58,12 @@ class TrainStep(object):
         self.bucket.zero_grad()
         _fn.DIRECT_PARAM_GRADS = True    # bucket zeroed above; kernels write weight grads straight into it
         _fn.begin_direct_grads()
+        _fn.ASYNC_WGRAD = self.async_wgrad
         try:
             return self._iteration_body(x, **forward_kwargs)
         finally:
             _fn.DIRECT_PARAM_GRADS = False
+            _fn.ASYNC_WGRAD = False
 
     def _iteration_body(self, x, **forward_kwargs):
         recon, losses, stats, att_stats, comp_stats = self.model(x, **forward_kwargs)
@@ -81,6 +84,7 @@ class TrainStep(object):
             beta = self._beta_fixed_t
         loss = err + beta * kl
         loss.backward()
+        _fn.join_side_stream()     # weight-gradient kernels forked onto the side stream
         with torch.no_grad():
             self.bucket.set_tail(err, kl)
             gscale = self.bucket.all_reduce(self.pg)
