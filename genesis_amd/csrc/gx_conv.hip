@@ -580,7 +580,7 @@ int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 // pixel tile of `npix` (256 for tapconv) over a Hb x Wb base grid of N images: power-of-two TH x TW x G
 // maximising the fraction of useful pixels (1.0 for power-of-two grids; 72x72 -> 8x8 tiles of 4 images), then
-// the widest rows (coalescing) among ties; the halo tile must fit `max_chs` floats per channel per plane.
+// the widest rows (coalescing) and tallest tiles among ties; the halo tile must fit `max_chs` floats per channel per plane.
 void pick_tile(int Hb, int Wb, int npix, int planes, int max_chs, int* lTH, int* lTW, int* lG) {
     double best_eff = -1.0;
     int bTW = 1, bTH = 1;
@@ -591,7 +591,10 @@ void pick_tile(int Hb, int Wb, int npix, int planes, int max_chs, int* lTH, int*
             const int G = npix / (TH * TW);
             if (planes * G * (TH + 2) * (TW + 2) > max_chs) continue;
             const double eff = (double)Hb * Wb / ((double)gx_ceil_div(Wb, TW) * TW * gx_ceil_div(Hb, TH) * TH);
-            if (eff > best_eff + 1e-9 || (eff > best_eff - 1e-9 && TW > bTW)) { best_eff = eff; bTW = TW; bTH = TH; }
+            // ties: widest rows, then tallest tile (fewest images per tile = smallest halo)
+            if (eff > best_eff + 1e-9 || (eff > best_eff - 1e-9 && (TW > bTW || (TW == bTW && TH > bTH)))) {
+                best_eff = eff; bTW = TW; bTH = TH;
+            }
         }
     }
     *lTW = ilog2(bTW); *lTH = ilog2(bTH); *lG = ilog2(npix / (bTW * bTH));
@@ -727,7 +730,8 @@ int plan_wgrad(int N, int CA, int CB, int Hb, int Wb, int SA, int Ttot, int ncls
                     if (gg * (th + 2) * (tw + 2) > 256) continue;
                     const double eff = (double)Hb * Wb / ((double)gx_ceil_div(Wb, tw) * tw * gx_ceil_div(Hb, th) * th);
                     const bool better = eff > best_eff + 1e-9 ||
-                                        (eff > best_eff - 1e-9 && (npix > best_np || (npix == best_np && tw > TW)));
+                                        (eff > best_eff - 1e-9 &&
+                                         (npix > best_np || (npix == best_np && (tw > TW || (tw == TW && th > TH)))));
                     if (better) { best_eff = eff; best_np = npix; TW = tw; TH = th; G = gg; }
                 }
             }

@@ -5,7 +5,9 @@
 // modules/unet.py:78,86,89 (F.interpolate nearest 0.5 / 2.0, torch.cat([x_up, skip])),
 // models/genesisv2_config.py:91-98 (decoder GroupNorm + ReLU).
 //
-// HBM-bound.  One workgroup per (image, group) slab of cpg*H*W floats (<= 512 KiB, L2 resident):
+// HBM-bound.  One workgroup per (image, group) slab of cpg*H*W floats.  Slabs of up to 32 K floats
+// with H*W >= 256 are held in registers and read from HBM once (gn_relu_*_reg_kernel below); other
+// shapes use the two-pass kernels (<= 512 KiB slab, L2 resident):
 // pass 1 accumulates sum / sum-of-squares in fp64 (so mean/var are exact to fp32 rounding and
 // independent of the reduction tree), pass 2 re-reads the slab from L2 and writes the normalised,
 // rectified tensor straight into up to two destination "views" (a channel slice of a concat
@@ -338,6 +340,216 @@ gn_param_reduce_kernel(const float* __restrict__ part, int N, int C,
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Register-resident variants: the (image, group) slab is read from HBM exactly once.
+// A channel is cut into P parts of HW/P pixels; a "unit" is one part.  Every wave owns UPW units
+// and every lane holds F float4 of each unit (F = HW / (256 P)), so per-channel sums are wave
+// reductions (no barrier) and only the group statistics cross waves.  Used when HW >= 256 and the
+// slab fits (UPW * F <= 8 float4 per lane and tensor); other shapes take the two-pass kernels.
+struct RegPlan { int P, F, UPW, threads; bool ok; };
+
+RegPlan plan_reg(int cpg, int H, int W) {
+    RegPlan p{1, 1, 1, 64, false};
+    const int HW = H * W;
+    if ((W % 4) != 0 || HW < 256 || !gx_is_pow2(cpg)) return p;
+    p.P = 1;
+    while (HW / (256 * p.P) > 8) p.P *= 2;
+    p.F = HW / (256 * p.P);
+    const int U = cpg * p.P;
+    p.UPW = 1;
+    while (U / p.UPW > 16) p.UPW *= 2;
+    if (p.UPW * p.F > 8 || p.UPW > 2) return p;
+    p.threads = 64 * (U / p.UPW);
+    p.ok = true;
+    return p;
+}
+
+template <int F, int UPW>
+__global__ void __launch_bounds__(1024)
+gn_relu_fwd_reg_kernel(const float* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ beta,
+                       int C, int H, int W, int groups, int P, float eps, View d0, View d1,
+                       float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    __shared__ double red[16 * 2 + 2];
+    const int n = blockIdx.x / groups, gidx = blockIdx.x % groups;
+    const int cpg = C / groups, HW = H * W;
+    const int m = cpg * HW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q4 = (HW >> 2) / P;  // float4 per unit
+    const f32x4* slab4 = reinterpret_cast<const f32x4*>(y + ((size_t)n * C + (size_t)gidx * cpg) * HW);
+    f32x4 xr[UPW][F];
+    double acc[2] = {0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < UPW; ++u) {
+        const int unit = wave * UPW + u;
+        const int cl = unit / P, part = unit - cl * P;
+#pragma unroll
+        for (int j = 0; j < F; ++j) xr[u][j] = slab4[cl * (HW >> 2) + part * q4 + j * 64 + lane];
+    }
+#pragma unroll
+    for (int u = 0; u < UPW; ++u)
+#pragma unroll
+        for (int j = 0; j < F; ++j) {
+            const f32x4 v = xr[u][j];
+            acc[0] += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
+            acc[1] += ((double)v[0] * v[0] + (double)v[1] * v[1]) + ((double)v[2] * v[2] + (double)v[3] * v[3]);
+        }
+    block_sum_multi<2>(acc, red);
+    const double mean = acc[0] / m;
+    double var = acc[1] / m - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float meanf = (float)mean;
+    const float rstdf = (float)(1.0 / sqrt(var + (double)eps));
+    if (threadIdx.x == 0) { mean_out[blockIdx.x] = meanf; rstd_out[blockIdx.x] = rstdf; }
+    const int lW = __ffs(W) - 1;
+#pragma unroll
+    for (int u = 0; u < UPW; ++u) {
+        const int unit = wave * UPW + u;
+        const int cl = unit / P, part = unit - cl * P;
+        const int c = gidx * cpg + cl;
+        const float gm = gamma[c], bt = beta[c];
+#pragma unroll
+        for (int j = 0; j < F; ++j) {
+            const int hw = (part * q4 + j * 64 + lane) << 2;
+            const int r = hw >> lW, col = hw & (W - 1);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = (xr[u][j][e] - meanf) * rstdf * gm + bt;
+                o[e] = t > 0.f ? t : 0.f;
+            }
+            store_view4(d0, n, c, r, col, H, W, o);
+            if (d1.ptr) store_view4(d1, n, c, r, col, H, W, o);
+        }
+    }
+}
+
+template <int F, int UPW>
+__global__ void __launch_bounds__(1024)
+gn_relu_bwd_reg_kernel(const float* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ beta,
+                       const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                       int C, int H, int W, int groups, int P, View g0, View g1,
+                       float* __restrict__ dy, float* __restrict__ part_out) {
+    __shared__ double uab[32 * 2];  // per unit: sum dpre*xhat, sum dpre
+    __shared__ double usd[32];      // per unit: sum dy
+    const int n = blockIdx.x / groups, gidx = blockIdx.x % groups;
+    const int cpg = C / groups, HW = H * W;
+    const int m = cpg * HW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q4 = (HW >> 2) / P;
+    const int U = cpg * P;
+    const size_t slab_off = ((size_t)n * C + (size_t)gidx * cpg) * HW;
+    const f32x4* slab4 = reinterpret_cast<const f32x4*>(y + slab_off);
+    f32x4* dslab4 = reinterpret_cast<f32x4*>(dy + slab_off);
+    const float meanf = mean_in[blockIdx.x], rstdf = rstd_in[blockIdx.x];
+    const int lW = __ffs(W) - 1;
+    f32x4 xr[UPW][F], gr[UPW][F];
+#pragma unroll
+    for (int u = 0; u < UPW; ++u) {
+        const int unit = wave * UPW + u;
+        const int cl = unit / P, part = unit - cl * P;
+        const int c = gidx * cpg + cl;
+#pragma unroll
+        for (int j = 0; j < F; ++j) {
+            const int i4 = part * q4 + j * 64 + lane;
+            const int hw = i4 << 2;
+            const int r = hw >> lW, col = hw & (W - 1);
+            xr[u][j] = slab4[cl * (HW >> 2) + i4];
+            f32x4 g = load_view4(g0, n, c, r, col, H, W);
+            if (g1.ptr) { const f32x4 g2 = load_view4(g1, n, c, r, col, H, W); g += g2; }
+            gr[u][j] = g;
+        }
+    }
+    // pass 1 (registers): xr <- xhat, gr <- dpre = g * [pre > 0]
+#pragma unroll
+    for (int u = 0; u < UPW; ++u) {
+        const int unit = wave * UPW + u;
+        const int cl = unit / P;
+        const int c = gidx * cpg + cl;
+        const float gm = gamma[c], bt = beta[c];
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int j = 0; j < F; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (xr[u][j][e] - meanf) * rstdf;
+                const float pre = xh * gm + bt;
+                const float gv = pre > 0.f ? gr[u][j][e] : 0.f;
+                xr[u][j][e] = xh;
+                gr[u][j][e] = gv;
+                a += (double)gv * xh;
+                b += (double)gv;
+            }
+        a = gx_wave_sum_d(a);
+        b = gx_wave_sum_d(b);
+        if (lane == 0) { uab[2 * unit] = a; uab[2 * unit + 1] = b; }
+    }
+    __syncthreads();
+    double s1 = 0.0, s2 = 0.0;
+    for (int cl = 0; cl < cpg; ++cl) {
+        double a = 0.0, b = 0.0;
+        for (int p = 0; p < P; ++p) { a += uab[2 * (cl * P + p)]; b += uab[2 * (cl * P + p) + 1]; }
+        const float gm = gamma[gidx * cpg + cl];
+        s1 += b * gm;
+        s2 += a * gm;
+        if ((int)threadIdx.x == cl) {
+            float* pp = part_out + ((size_t)n * C + gidx * cpg + cl) * 3;
+            pp[0] = (float)a; pp[1] = (float)b;
+        }
+    }
+    const float k1 = (float)(s1 / m), k2 = (float)(s2 / m);
+    // pass 2 (registers)
+#pragma unroll
+    for (int u = 0; u < UPW; ++u) {
+        const int unit = wave * UPW + u;
+        const int cl = unit / P, part = unit - cl * P;
+        const float gm = gamma[gidx * cpg + cl];
+        double sd = 0.0;
+#pragma unroll
+        for (int j = 0; j < F; ++j) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = rstdf * (gr[u][j][e] * gm - k1 - xr[u][j][e] * k2);
+                o[e] = d;
+                sd += d;
+            }
+            dslab4[cl * (HW >> 2) + part * q4 + j * 64 + lane] = o;
+        }
+        sd = gx_wave_sum_d(sd);
+        if (lane == 0) usd[unit] = sd;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < cpg) {
+        double s = 0.0;
+        for (int p = 0; p < P; ++p) s += usd[threadIdx.x * P + p];
+        part_out[((size_t)n * C + gidx * cpg + threadIdx.x) * 3 + 2] = (float)s;
+    }
+    (void)U;
+}
+
+template <int F, int UPW, typename... Args>
+void launch_fwd_reg(dim3 grid, dim3 block, hipStream_t s, Args... args) {
+    hipLaunchKernelGGL((gn_relu_fwd_reg_kernel<F, UPW>), grid, block, 0, s, args...);
+}
+template <int F, int UPW, typename... Args>
+void launch_bwd_reg(dim3 grid, dim3 block, hipStream_t s, Args... args) {
+    hipLaunchKernelGGL((gn_relu_bwd_reg_kernel<F, UPW>), grid, block, 0, s, args...);
+}
+
+#define GX_GN_REG_DISPATCH(LAUNCH, pl, ...)                                      \
+    do {                                                                         \
+        if (pl.UPW == 1) {                                                       \
+            if (pl.F == 1) LAUNCH<1, 1>(__VA_ARGS__);                            \
+            else if (pl.F == 2) LAUNCH<2, 1>(__VA_ARGS__);                       \
+            else if (pl.F == 4) LAUNCH<4, 1>(__VA_ARGS__);                       \
+            else LAUNCH<8, 1>(__VA_ARGS__);                                      \
+        } else {                                                                 \
+            if (pl.F == 1) LAUNCH<1, 2>(__VA_ARGS__);                            \
+            else if (pl.F == 2) LAUNCH<2, 2>(__VA_ARGS__);                       \
+            else LAUNCH<4, 2>(__VA_ARGS__);                                      \
+        }                                                                        \
+    } while (0)
+
 int check_view(const char* name, const View& v, int C) {
     GX_CHECK_ARG(v.mode >= 0 && v.mode <= 2, "%s: bad view mode %d", name, v.mode);
     GX_CHECK_ARG(v.c0 >= 0 && v.c0 + C <= v.ctot, "%s: view slice [%d,%d) outside %d channels", name, v.c0,
@@ -367,7 +579,11 @@ int gx_gn_relu_fwd(const float* y, const float* gamma, const float* beta, int N,
         auto vw = [](int mode) { return mode == 1 ? 4.0 : (mode == 2 ? 0.25 : 1.0); };
         const double el = (double)N * C * H * W;
         GxProf pf(KID_GN_FWD, (hipStream_t)stream, 8.0 * el, 4.0 * el * (1.0 + vw(dst0_mode) + (dst1 ? vw(dst1_mode) : 0.0)));
-        if (vec)
+        const RegPlan pl = plan_reg(C / groups, H, W);
+        if (pl.ok)
+            GX_GN_REG_DISPATCH(launch_fwd_reg, pl, dim3(N * groups), dim3(pl.threads), (hipStream_t)stream, y, gamma,
+                               beta, C, H, W, groups, pl.P, eps, d0, d1, mean, rstd);
+        else if (vec)
             hipLaunchKernelGGL(gn_relu_fwd_kernel<true>, dim3(N * groups), dim3(threads), 0, (hipStream_t)stream, y,
                                gamma, beta, C, H, W, groups, eps, d0, d1, mean, rstd);
         else
@@ -402,7 +618,11 @@ int gx_gn_relu_bwd(const float* y, const float* gamma, const float* beta, const 
         auto vw = [](int mode) { return mode == 1 ? 4.0 : (mode == 2 ? 0.25 : 1.0); };
         const double el = (double)N * C * H * W;
         GxProf pf(KID_GN_BWD, s, 16.0 * el, 4.0 * el * (2.0 + vw(g0_mode) + (g1 ? vw(g1_mode) : 0.0)));
-        if (vec)
+        const RegPlan pl = plan_reg(C / groups, H, W);
+        if (pl.ok)
+            GX_GN_REG_DISPATCH(launch_bwd_reg, pl, dim3(N * groups), dim3(pl.threads), s, y, gamma, beta, mean, rstd,
+                               C, H, W, groups, pl.P, v0, v1, dy, (float*)ws);
+        else if (vec)
             hipLaunchKernelGGL(gn_relu_bwd_kernel<true>, dim3(N * groups), dim3(threads), 0, s, y, gamma, beta, mean,
                                rstd, C, H, W, groups, v0, v1, dy, (float*)ws);
         else
