@@ -450,3 +450,43 @@ class MixtureWFn(torch.autograd.Function):
         K, std1, std2, pixel_bound = ctx.cfg
         ddec, dlog_w = hip.mixture_w_bwd(x, dec, log_w, g_err.contiguous(), K, std1, std2, pixel_bound)
         return None, ddec, dlog_w, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------- slot latents
+def _c(t):
+    return None if t is None else t.contiguous()
+
+
+class PosteriorFn(torch.autograd.Function):
+    """zh [B,K,2D] = z_head(obj), eps [K,B,D] -> (z, mu, sigma [K,B,D], log_q [K,B]): to_sigma, rsample and
+    q_z.log_prob(z).sum(1) of models/genesisv2_config.py:154-160 / models/genesis_config.py:329 in one launch."""
+
+    @staticmethod
+    def forward(ctx, zh, eps):
+        zh, eps = zh.contiguous(), eps.contiguous()
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(zh, eps)
+        return hip.latent_posterior_fwd(zh, eps)
+
+    @staticmethod
+    def backward(ctx, gz, gmu, gsigma, glogq):
+        zh, eps = ctx.saved_tensors
+        return hip.latent_posterior_bwd(zh, eps, _c(gz), _c(gmu), _c(gsigma), _c(glogq)), None
+
+
+class PriorLogPFn(torch.autograd.Function):
+    """z [K,B,D], lin [K-1,B,2D] (or None) -> log_p [K,B] under N(0,1) for the first slot and
+    N(tanh(lin[:D]), sigmoid(lin[D:] + 4) + 1e-4) for the others (models/genesis_config.py:297-330)."""
+
+    @staticmethod
+    def forward(ctx, z, lin):
+        z = z.contiguous()
+        lin = None if lin is None else lin.contiguous()
+        ctx.save_for_backward(z, lin)
+        return hip.latent_prior_logp_fwd(z, lin)
+
+    @staticmethod
+    def backward(ctx, glogp):
+        z, lin = ctx.saved_tensors
+        dz, dlin = hip.latent_prior_logp_bwd(z, lin, glogp.contiguous())
+        return dz, dlin

@@ -237,16 +237,13 @@ class GenesisV2(nn.Module):
             x = torch.zeros(B, 3, self.img_size, self.img_size, device=z_kbd.device)
         return fn.MixtureFn.apply(x, dec, K, float(self.std), bool(self.pixel_bound))
 
-    def _prior(self, z_kbd):
-        """AR prior over slot latents, models/genesis_config.py:288-331 (LSTM from the zero state over
-        z_1..z_{K-1}; first slot N(0,1)).  Tiny [B,64]-row dense ops: torch for now."""
+    def _prior_hidden(self, z_kbd):
+        """LSTM of the AR prior from the zero state over z_1..z_{K-1} (models/genesis_config.py:297-307)."""
         K, B, D = z_kbd.shape
         if USE_LIBRARY_LSTM:
             # plain library LSTM (MIOpen via torch): one fused call instead of ~12 pointwise launches per step
-            out, _ = self.prior_lstm(z_kbd[:-1].contiguous())
-            lin = self.prior_linear(out)
-            mu_raw, sig_raw = lin.chunk(2, dim=2)
-            return torch.tanh(mu_raw), torch.sigmoid(sig_raw + 4.0) + 1e-4
+            out, _ = self.prior_lstm(z_kbd[:-1])
+            return out
         w_ih, w_hh = self.prior_lstm.weight_ih_l0, self.prior_lstm.weight_hh_l0
         b_ih, b_hh = self.prior_lstm.bias_ih_l0, self.prior_lstm.bias_hh_l0
         H = w_hh.shape[1]
@@ -260,9 +257,7 @@ class GenesisV2(nn.Module):
             c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
             h = torch.sigmoid(o) * torch.tanh(c)
             outs.append(h)
-        lin = self.prior_linear(torch.stack(outs, 0))
-        mu_raw, sig_raw = lin.chunk(2, dim=2)
-        return torch.tanh(mu_raw), torch.sigmoid(sig_raw + 4.0) + 1e-4
+        return torch.stack(outs, 0)
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, rand_pixel=None, eps=None, seed_idx=None):
@@ -293,12 +288,9 @@ class GenesisV2(nn.Module):
         w1 = self.feat_head[1].weight.view(2 * D, D)
         obj = (F.linear(S, w1) + msum.unsqueeze(-1) * self.feat_head[1].bias) / (msum.unsqueeze(-1) + 1e-5)
         # --- Posterior
-        mu, sigma_ps = self.z_head(obj).chunk(2, dim=-1)             # [B,K,D] each
-        sigma = F.softplus(sigma_ps + 0.5) + 1e-8
-        mu, sigma = mu.transpose(0, 1), sigma.transpose(0, 1)        # [K,B,D]
         if eps is None:
             eps = torch.randn(K, B, D, device=dev)
-        z = mu + sigma * eps
+        z, mu, sigma, log_q = fn.PosteriorFn.apply(self.z_head(obj), eps)   # [K,B,D] x3, [K,B]
         # --- Decode latents, reconstruction loss
         err, recon, x_r, log_m_r = self._decode(z, x)
         losses = AttrDict()
@@ -318,13 +310,10 @@ class GenesisV2(nn.Module):
             p_ = p_ / p_.sum(0, keepdim=True)
             losses['kl_m'] = (q * (q.log() - p_.log())).sum(0).flatten(1).sum(1)
         # -- Component KL (Genesis.mask_latent_loss, models/genesis_config.py:288-343)
-        log_q = _normal_log_prob(z, mu, sigma).sum(2)                # [K,B]
+        lin = None
         if self.prior_lstm is not None:
-            mu_p, sig_p = self._prior(z)
-            log_p0 = _normal_log_prob(z[:1], 0., 1.).sum(2)
-            log_p = torch.cat((log_p0, _normal_log_prob(z[1:], mu_p, sig_p).sum(2)), 0)
-        else:
-            log_p = _normal_log_prob(z, 0., 1.).sum(2)
+            lin = self.prior_linear(self._prior_hidden(z))          # [K-1,B,2D]
+        log_p = fn.PriorLogPFn.apply(z, lin)
         losses['kl_l_k'] = list((log_q - log_p).unbind(0))
 
         stats = AttrDict(

@@ -377,3 +377,49 @@ def gated_norm_bwd(y, bias, norm, gh, bh, gg, bg, stats, dout):
     _lib.call('gx_gated_norm_bwd', _p(y), _p(bias), NORMS[norm], _p(gh), _p(bh), _p(gg), _p(bg), _p(stats), _p(dout),
               N, C, H, W, _p(dy), _p(dgh), _p(dbh), _p(dgg), _p(dbg), _p(dbias), _p(ws), nb, _stream())
     return dy, dgh, dbh, dgg, dbg, dbias
+
+
+# ---------------------------------------------------------------------------------------------- slot latents
+def latent_posterior_fwd(zh, eps):
+    """zh [B,K,2D] (z_head output), eps [K,B,D] -> z, mu, sigma [K,B,D], log_q [K,B]
+    (models/genesisv2_config.py:154-160, models/genesis_config.py:329)."""
+    _chk(zh, 'latent.zh'); _chk(eps, 'latent.eps')
+    B, K, D2 = zh.shape
+    D = D2 // 2
+    if tuple(eps.shape) != (K, B, D):
+        raise GenesisHipError('latent_posterior_fwd: eps must be [K,B,D] = %s, got %s' % ((K, B, D), tuple(eps.shape)))
+    z = torch.empty(K, B, D, dtype=F32, device=zh.device)
+    mu, sigma = torch.empty_like(z), torch.empty_like(z)
+    log_q = torch.empty(K, B, dtype=F32, device=zh.device)
+    _lib.call('gx_latent_posterior_fwd', _p(zh), _p(eps), B, K, D, _p(z), _p(mu), _p(sigma), _p(log_q), _stream())
+    return z, mu, sigma, log_q
+
+
+def latent_posterior_bwd(zh, eps, gz, gmu, gsigma, glogq):
+    for t, n in ((gz, 'gz'), (gmu, 'gmu'), (gsigma, 'gsigma'), (glogq, 'glogq')):
+        _chk(t, 'latent_bwd.' + n)
+    B, K, D2 = zh.shape
+    dzh = torch.empty_like(zh)
+    _lib.call('gx_latent_posterior_bwd', _p(zh), _p(eps), _p(gz), _p(gmu), _p(gsigma), _p(glogq), B, K, D2 // 2,
+              _p(dzh), _stream())
+    return dzh
+
+
+def latent_prior_logp_fwd(z, lin):
+    """z [K,B,D], lin [K-1,B,2D] or None -> log_p [K,B] (models/genesis_config.py:297-330)."""
+    _chk(z, 'prior.z'); _chk(lin, 'prior.lin')
+    K, B, D = z.shape
+    if lin is not None and tuple(lin.shape) != (K - 1, B, 2 * D):
+        raise GenesisHipError('latent_prior_logp_fwd: lin must be [K-1,B,2D]')
+    log_p = torch.empty(K, B, dtype=F32, device=z.device)
+    _lib.call('gx_latent_prior_logp_fwd', _p(z), _p(lin), B, K, D, _p(log_p), _stream())
+    return log_p
+
+
+def latent_prior_logp_bwd(z, lin, glogp):
+    _chk(glogp, 'prior_bwd.glogp')
+    K, B, D = z.shape
+    dz = torch.empty_like(z)
+    dlin = torch.empty_like(lin) if lin is not None else None
+    _lib.call('gx_latent_prior_logp_bwd', _p(z), _p(lin), _p(glogp), B, K, D, _p(dz), _p(dlin), _stream())
+    return dz, dlin

@@ -183,6 +183,25 @@ int gx_gated_norm_bwd(const float* y, const float* bias, int norm, const float* 
                       int H, int W, float* dy, float* dgamma_h, float* dbeta_h, float* dgamma_g, float* dbeta_g,
                       float* dbias, void* ws, size_t ws_bytes, gx_stream_t stream);
 
+/* ---- slot-latent head: reparameterised posterior sample + Monte-Carlo KL terms
+ *      (models/genesisv2_config.py:154-160: mu, sigma_ps = z_head(obj).chunk(2); sigma = to_sigma(sigma_ps);
+ *      z = Normal(mu, sigma).rsample(); modules/blocks.py:22-23 to_sigma = softplus(x + 0.5) + 1e-8, :28-36
+ *      to_prior_sigma = sigmoid(x + 4) + 1e-4; models/genesis_config.py:288-343 mask_latent_loss:
+ *      log_q = q_z_k.log_prob(z_k).sum(1), log_p under N(0,1) for the first slot and under
+ *      N(tanh(lin[:D]), to_prior_sigma(lin[D:])) for later slots, lin = prior_linear(prior_lstm(z_{<k}))).
+ *      zh [B,K,2D] = z_head output (mu | sigma_ps), eps [K,B,D] standard normal; z, mu, sigma [K,B,D] slot-major,
+ *      log_q / log_p [K,B].  lin [K-1,B,2D], or NULL for the standard-normal prior on every slot.
+ *      bwd: incoming gradients gz / gmu / gsigma [K,B,D], glogq [K,B] may each be NULL (= zero). */
+int gx_latent_posterior_fwd(const float* zh, const float* eps, int B, int K, int D, float* z, float* mu,
+                            float* sigma, float* log_q, gx_stream_t stream);
+int gx_latent_posterior_bwd(const float* zh, const float* eps, const float* gz, const float* gmu,
+                            const float* gsigma, const float* glogq, int B, int K, int D, float* dzh,
+                            gx_stream_t stream);
+int gx_latent_prior_logp_fwd(const float* z, const float* lin, int B, int K, int D, float* log_p,
+                             gx_stream_t stream);
+int gx_latent_prior_logp_bwd(const float* z, const float* lin, const float* glogp, int B, int K, int D, float* dz,
+                             float* dlin, gx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -401,3 +401,58 @@ def test_mixture_external_weights_rgb_only():
     ddec, dlw = hip.mixture_w_bwd(x.to(DEV), dec.to(DEV), log_w.to(DEV), torch.full((B,), 1.3, device=DEV), K, 0.7, 0.7, True)
     close(ddec, dr.grad, 1e-4, 1e-5, 'ddec')
     close(dlw, lr.grad, 1e-4, 1e-5, 'dlog_w')
+
+
+@pytest.mark.parametrize('B,K,D,prior', [(32, 7, 64, True), (3, 5, 16, True), (4, 1, 64, False), (2, 3, 80, True)])
+def test_latent_posterior_and_prior(B, K, D, prior):
+    """Posterior sample / log_q / log_p launches vs the torch ops of models/genesisv2_config.py:154-160 and
+    models/genesis_config.py:288-343 (Normal.log_prob, to_sigma, to_prior_sigma); fp32, rtol 1e-5 on values,
+    1e-4 on gradients."""
+    from torch.distributions import Normal
+    from genesis_amd import functions as fn
+    zh = rnd(B, K, 2 * D, seed=1, scale=2.0)
+    eps = torch.randn(K, B, D, generator=torch.Generator().manual_seed(2))
+    lin = rnd(K - 1, B, 2 * D, seed=3, scale=2.0) if (prior and K > 1) else None
+    w = [rnd(K, B, D, seed=4), rnd(K, B, D, seed=5), rnd(K, B, D, seed=6), rnd(K, B, seed=7), rnd(K, B, seed=8)]
+
+    def ref(zh_, lin_):
+        mu, sp = zh_.chunk(2, dim=-1)
+        sigma = F.softplus(sp + 0.5) + 1e-8
+        mu, sigma = mu.transpose(0, 1), sigma.transpose(0, 1)
+        z = mu + sigma * eps.to(zh_.dtype)
+        log_q = Normal(mu, sigma).log_prob(z).sum(2)
+        if lin_ is not None:
+            mr, sr = lin_.chunk(2, dim=2)
+            lp = Normal(torch.tanh(mr), torch.sigmoid(sr + 4.0) + 1e-4).log_prob(z[1:]).sum(2)
+            log_p = torch.cat((Normal(0., 1.).log_prob(z[:1]).sum(2), lp), 0)
+        else:
+            log_p = Normal(0., 1.).log_prob(z).sum(2)
+        return z, mu, sigma, log_q, log_p
+
+    zr = zh.double().requires_grad_()
+    lr = lin.double().requires_grad_() if lin is not None else None
+    outs_ref = ref(zr, lr)
+    loss_ref = sum((o * wi.double()).sum() for o, wi in zip(outs_ref, w))
+    loss_ref.backward()
+
+    zg = zh.to(DEV).requires_grad_()
+    lg = lin.to(DEV).requires_grad_() if lin is not None else None
+    z, mu, sigma, log_q = fn.PosteriorFn.apply(zg, eps.to(DEV))
+    log_p = fn.PriorLogPFn.apply(z, lg)
+    outs = (z, mu, sigma, log_q, log_p)
+    for o, r, name in zip(outs, outs_ref, ('z', 'mu', 'sigma', 'log_q', 'log_p')):
+        close(o, r, rtol=1e-5, atol=1e-5, msg=name)
+    loss = sum((o * wi.to(DEV)).sum() for o, wi in zip(outs, w))
+    loss.backward()
+    close(zg.grad, zr.grad, rtol=1e-4, atol=1e-5, msg='dzh')
+    if lin is not None:
+        close(lg.grad, lr.grad, rtol=1e-4, atol=1e-5, msg='dlin')
+
+    # only z and log_q used (the training step): the unused outputs' gradients arrive as None
+    zg2 = zh.to(DEV).requires_grad_()
+    z2, _, _, lq2 = fn.PosteriorFn.apply(zg2, eps.to(DEV))
+    ((z2 * w[0].to(DEV)).sum() + (lq2 * w[3].to(DEV)).sum()).backward()
+    zr2 = zh.double().requires_grad_()
+    o2 = ref(zr2, None)
+    ((o2[0] * w[0].double()).sum() + (o2[3] * w[3].double()).sum()).backward()
+    close(zg2.grad, zr2.grad, rtol=1e-4, atol=1e-5, msg='dzh (z, log_q only)')
