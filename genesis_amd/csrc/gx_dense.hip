@@ -1,0 +1,186 @@
+// Small dense layers (nn.Linear) of the hot path: the UNet bottleneck MLP (modules/unet.py:58-62), z_head
+// (models/genesisv2_config.py:76-80), feat_head[1] applied to the pooled slot sums, prior_linear
+// (models/genesis_config.py:106).  Rows M are 32..224 and the feature dims 64..2048: 7-17 MFLOP per layer, i.e.
+// pure latency.  The BLAS library picks 128x224 / 256x192 macro tiles for them -- a single workgroup walking the
+// whole K loop, 15-70 us per call, ~0.8 ms per training step.  Here every 16x16 output tile is its own workgroup,
+// the contraction is split over the workgroup's 4-16 waves (fp32 MFMA 16x16x4, exact fp32 products) and the
+// per-wave partial tiles are summed through LDS in a fixed order (deterministic); bias, ReLU, the ReLU mask of
+// the backward pass and the bias gradient are fused, so a layer is 1 launch forward and 2 backward.
+#include "gx_common.h"
+
+namespace {
+
+// C[I,J] = sum_kk A(i,kk) B(kk,j).
+//   A_KC: A(i,kk) = a[i*lda + kk] (contraction contiguous)   else a[kk*lda + i]
+//   B_KC: B(kk,j) = b[j*ldb + kk]                            else b[kk*ldb + j]
+//   MASK: A(i,kk) is multiplied by [mask(i,kk) > 0] (mask has A's layout): the ReLU derivative from the layer output
+//   ROWSUM: also emits rs[i] = sum_kk A(i,kk) (bias gradient), by the workgroups of the first column tile
+// Lane (idx = lane & 15, kq = lane >> 4) owns contraction indices k16 + 4 kq + {0..3}; MFMA step jj consumes index
+// 4 kq + jj from every kq -- a permutation of the 16 indices that A and B share, so contiguous operands load float4.
+template <bool A_KC, bool B_KC, bool MASK, bool ROWSUM>
+__global__ void __launch_bounds__(1024)
+dense_kernel(const float* __restrict__ a, int lda, const float* __restrict__ mask, const float* __restrict__ b,
+             int ldb, const float* __restrict__ bias, int act, float* __restrict__ c, int ldc, int I, int J, int Kc,
+             float* __restrict__ rs, int vec_a, int vec_b) {
+    __shared__ float part[16][256];
+    __shared__ float rpart[16][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int idx = lane & 15, kq = lane >> 4;
+    const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+    const int ai = i0 + idx, bj = j0 + idx;
+    const bool a_ok = ai < I, b_ok = bj < J;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float rsum = 0.f;
+#pragma unroll 2
+    for (int k16 = wave * 16; k16 < Kc; k16 += nw * 16) {
+        const int kb = k16 + 4 * kq;
+        float av[4], bv[4];
+        if (A_KC) {
+            if (vec_a) {
+                f32x4 t = {0.f, 0.f, 0.f, 0.f}, m = {1.f, 1.f, 1.f, 1.f};
+                if (a_ok && kb < Kc) {
+                    t = *reinterpret_cast<const f32x4*>(a + (size_t)ai * lda + kb);
+                    if (MASK) m = *reinterpret_cast<const f32x4*>(mask + (size_t)ai * lda + kb);
+                }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) av[jj] = (!MASK || m[jj] > 0.f) ? t[jj] : 0.f;
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    float t = 0.f;
+                    if (a_ok && kb + jj < Kc) {
+                        t = a[(size_t)ai * lda + kb + jj];
+                        if (MASK && !(mask[(size_t)ai * lda + kb + jj] > 0.f)) t = 0.f;
+                    }
+                    av[jj] = t;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                float t = 0.f;
+                if (a_ok && kb + jj < Kc) {
+                    t = a[(size_t)(kb + jj) * lda + ai];
+                    if (MASK && !(mask[(size_t)(kb + jj) * lda + ai] > 0.f)) t = 0.f;
+                }
+                av[jj] = t;
+            }
+        }
+        if (B_KC) {
+            if (vec_b) {
+                f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                if (b_ok && kb < Kc) t = *reinterpret_cast<const f32x4*>(b + (size_t)bj * ldb + kb);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) bv[jj] = t[jj];
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    bv[jj] = (b_ok && kb + jj < Kc) ? b[(size_t)bj * ldb + kb + jj] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                bv[jj] = (b_ok && kb + jj < Kc) ? b[(size_t)(kb + jj) * ldb + bj] : 0.f;
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj], bv[jj], acc, 0, 0, 0);
+            if (ROWSUM) rsum += av[jj];
+        }
+    }
+    // C/D layout (16x16): col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[wave][(kq * 4 + r) * 16 + idx] = acc[r];
+    if (ROWSUM) {
+        rsum += __shfl_xor(rsum, 16, 64);
+        rsum += __shfl_xor(rsum, 32, 64);
+        if (kq == 0) rpart[wave][idx] = rsum;
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const int t = threadIdx.x;
+        float s = part[0][t];
+        for (int w = 1; w < nw; ++w) s += part[w][t];
+        const int ci = i0 + (t >> 4), cj = j0 + (t & 15);
+        if (ci < I && cj < J) {
+            if (bias) s += bias[cj];
+            if (act == 1) s = s > 0.f ? s : 0.f;
+            c[(size_t)ci * ldc + cj] = s;
+        }
+    }
+    if (ROWSUM && blockIdx.x == 0 && threadIdx.x < 16 && i0 + (int)threadIdx.x < I) {
+        float s = rpart[0][threadIdx.x];
+        for (int w = 1; w < nw; ++w) s += rpart[w][threadIdx.x];
+        rs[i0 + threadIdx.x] = s;
+    }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline int dense_threads(int Kc) { return Kc >= 1024 ? 1024 : 256; }
+
+}  // namespace
+
+extern "C" {
+
+int gx_linear_fwd(const float* x, const float* w, const float* b, int act, float* y, int M, int N, int K,
+                  gx_stream_t stream) {
+    GX_CHECK_ARG(x && w && y, "gx_linear_fwd: null pointer");
+    GX_CHECK_ARG(M > 0 && N > 0 && K > 0, "gx_linear_fwd: bad M/N/K (%d,%d,%d)", M, N, K);
+    GX_CHECK_ARG(act == 0 || act == 1, "gx_linear_fwd: act must be 0 (none) or 1 (ReLU)");
+    hipStream_t s = (hipStream_t)stream;
+    const int vec = (K % 4 == 0) && aligned16(x) && aligned16(w);
+    {
+        GxProf pf(KID_DENSE, s, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+        hipLaunchKernelGGL((dense_kernel<true, true, false, false>), dim3(gx_ceil_div(N, 16), gx_ceil_div(M, 16)),
+                           dim3(dense_threads(K)), 0, s, x, K, (const float*)nullptr, w, K, b, act, y, N, M, N, K,
+                           (float*)nullptr, vec, vec);
+    }
+    GX_CHECK_LAUNCH("gx_linear_fwd");
+    return GX_OK;
+}
+
+int gx_linear_bwd(const float* x, const float* w, const float* y, const float* g, int act, float* dx, float* dw,
+                  float* db, int M, int N, int K, gx_stream_t stream) {
+    GX_CHECK_ARG(x && w && g, "gx_linear_bwd: null pointer");
+    GX_CHECK_ARG(M > 0 && N > 0 && K > 0, "gx_linear_bwd: bad M/N/K (%d,%d,%d)", M, N, K);
+    GX_CHECK_ARG(act == 0 || (act == 1 && y), "gx_linear_bwd: act 1 (ReLU) needs the layer output y");
+    GX_CHECK_ARG(dw || !db, "gx_linear_bwd: db is produced together with dw");
+    hipStream_t s = (hipStream_t)stream;
+    if (dx) {   // dx[M,K] = dpre[M,N] w[N,K]
+        const int vec = (N % 4 == 0) && aligned16(g) && (act == 0 || aligned16(y));
+        GxProf pf(KID_DENSE, s, 2.0 * M * N * K, 4.0 * (2.0 * M * N + (double)N * K + (double)M * K));
+        const dim3 grid(gx_ceil_div(K, 16), gx_ceil_div(M, 16)), block(dense_threads(N));
+        if (act == 1)
+            hipLaunchKernelGGL((dense_kernel<true, false, true, false>), grid, block, 0, s, g, N, y, w, K,
+                               (const float*)nullptr, 0, dx, K, M, K, N, (float*)nullptr, vec, 0);
+        else
+            hipLaunchKernelGGL((dense_kernel<true, false, false, false>), grid, block, 0, s, g, N,
+                               (const float*)nullptr, w, K, (const float*)nullptr, 0, dx, K, M, K, N,
+                               (float*)nullptr, vec, 0);
+    }
+    GX_CHECK_LAUNCH("gx_linear_bwd(dx)");
+    if (dw) {   // dw[N,K] = dpre^T[N,M] x[M,K];  db[N] = row sums of dpre^T
+        GxProf pf(KID_DENSE, s, 2.0 * M * N * K, 4.0 * (2.0 * M * N + (double)M * K + (double)N * K));
+        const dim3 grid(gx_ceil_div(K, 16), gx_ceil_div(N, 16)), block(dense_threads(M));
+        if (act == 1) {
+            if (db)
+                hipLaunchKernelGGL((dense_kernel<false, false, true, true>), grid, block, 0, s, g, N, y, x, K,
+                                   (const float*)nullptr, 0, dw, K, N, K, M, db, 0, 0);
+            else
+                hipLaunchKernelGGL((dense_kernel<false, false, true, false>), grid, block, 0, s, g, N, y, x, K,
+                                   (const float*)nullptr, 0, dw, K, N, K, M, (float*)nullptr, 0, 0);
+        } else {
+            if (db)
+                hipLaunchKernelGGL((dense_kernel<false, false, false, true>), grid, block, 0, s, g, N,
+                                   (const float*)nullptr, x, K, (const float*)nullptr, 0, dw, K, N, K, M, db, 0, 0);
+            else
+                hipLaunchKernelGGL((dense_kernel<false, false, false, false>), grid, block, 0, s, g, N,
+                                   (const float*)nullptr, x, K, (const float*)nullptr, 0, dw, K, N, K, M,
+                                   (float*)nullptr, 0, 0);
+        }
+    }
+    GX_CHECK_LAUNCH("gx_linear_bwd(dw)");
+    return GX_OK;
+}
+
+}  // extern "C"

@@ -147,16 +147,16 @@ class UNetEncoderFn(torch.autograd.Function):
                 mlp_in = nxt
             saved_down.append((cur, y, mean, rstd))
             cur = nxt
-        # bottleneck MLP (tiny dense layers; torch/rocBLAS for now -- see DESIGN.md "not yet native")
-        with torch.enable_grad():
-            mlp_leaf = mlp_in.detach().requires_grad_(True)
-            mlp_p = [p.detach().requires_grad_(True) for p in mlp]
-            h = mlp_leaf.reshape(N, -1)
-            for q in range(3):
-                h = F.relu(F.linear(h, mlp_p[2 * q], mlp_p[2 * q + 1]))
+        # bottleneck MLP: three Linear+ReLU on the dense MFMA kernel (modules/unet.py:58-62,83)
+        h = mlp_in.view(N, -1)
+        mlp_acts = []
+        for q in range(3):
+            y_ = hip.linear_fwd(h, mlp[2 * q], mlp[2 * q + 1], 'relu')
+            mlp_acts.append((h, y_))
+            h = y_
         fs = mlp_in.shape[2]
         cx0 = cats[0].shape[1] - mlp_in.shape[1]
-        cats[0][:, :cx0].copy_(h.detach().view(N, cx0, fs, fs))
+        cats[0][:, :cx0].copy_(h.view(N, cx0, fs, fs))
         saved_up = []
         out = None
         for j in range(nb):
@@ -173,7 +173,7 @@ class UNetEncoderFn(torch.autograd.Function):
         ctx.cats = cats
         ctx.saved_down = saved_down
         ctx.saved_up = saved_up
-        ctx.mlp = (mlp_leaf, mlp_p, h)
+        ctx.mlp = (mlp, mlp_acts, mlp_in.shape)
         return out
 
     @staticmethod
@@ -198,12 +198,17 @@ class UNetEncoderFn(torch.autograd.Function):
             g_up[j] = (_ret(ow, dw), _ret(og, dgamma), _ret(ob, dbeta))
             gsrc = (dcat[j], 0, 1)   # block j-1's output was 2x up-sampled into cat_j[:, :Cx]
         # MLP backward
-        mlp_leaf, mlp_p, h = ctx.mlp
-        cx0 = h.shape[1] // (mlp_leaf.shape[2] * mlp_leaf.shape[3])
-        g_h = dcat[0][:, :cx0].reshape(h.shape)
-        grads = torch.autograd.grad(h, [mlp_leaf] + mlp_p, g_h)
-        d_mlp_in = grads[0].contiguous()
-        g_mlp = grads[1:]
+        mlp, mlp_acts, mlp_in_shape = ctx.mlp
+        cx0 = cats[0].shape[1] - mlp_in_shape[1]
+        g_h = dcat[0][:, :cx0].reshape(mlp_acts[2][1].shape).contiguous()
+        g_mlp = [None] * 6
+        for q in reversed(range(3)):
+            w_, b_ = mlp[2 * q], mlp[2 * q + 1]
+            h_in, y_ = mlp_acts[q]
+            ow, ob = _gout(w_), _gout(b_)
+            g_h, dw, db = hip.linear_bwd(h_in, w_, y_, g_h, 'relu', out_dw=ow, out_db=ob)
+            g_mlp[2 * q], g_mlp[2 * q + 1] = _ret(ow, dw), _ret(ob, db)
+        d_mlp_in = g_h.view(mlp_in_shape)
         d_next = None
         dx = None
         for i in reversed(range(nb)):
@@ -490,3 +495,37 @@ class PriorLogPFn(torch.autograd.Function):
         z, lin = ctx.saved_tensors
         dz, dlin = hip.latent_prior_logp_bwd(z, lin, glogp.contiguous())
         return dz, dlin
+
+
+# ---------------------------------------------------------------------------------------------- dense layers
+class LinearFn(torch.autograd.Function):
+    """act(F.linear(x, w, b)) on the 16x16-tile fp32 MFMA dense kernel; x [..., K] (leading dims flattened)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        x2 = x.contiguous().view(-1, x.shape[-1])
+        y = hip.linear_fwd(x2, w.view(w.shape[0], -1), b, act)   # w may be a 1x1 conv weight [N,K,1,1]
+        ctx.save_for_backward(x2, y if act else None)
+        ctx.params = (w, b)
+        ctx.act = act
+        ctx.xshape = x.shape
+        return y.view(x.shape[:-1] + (w.shape[0],))
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, y = ctx.saved_tensors
+        w, b = ctx.params
+        g2 = g.contiguous().view(-1, w.shape[0])
+        need_w = ctx.needs_input_grad[1]
+        ow = _gout(w) if need_w else None
+        ob = _gout(b) if (need_w and b is not None) else None
+        dx, dw, db = hip.linear_bwd(x2, w.view(w.shape[0], -1), y, g2, ctx.act, need_dx=ctx.needs_input_grad[0],
+                                    need_dw=need_w, need_db=b is not None and need_w, out_dw=ow, out_db=ob)
+        if dw is not None and ow is None:
+            dw = dw.view(w.shape)
+        return (dx.view(ctx.xshape) if dx is not None else None, _ret(ow, dw) if need_w else None,
+                _ret(ob, db) if (b is not None and need_w) else None, None)
+
+
+def linear(x, w, b=None, act=None):
+    return LinearFn.apply(x, w, b, act)

@@ -285,12 +285,15 @@ class GenesisV2(nn.Module):
         #     slot; the 1x1 conv feat_head[1] commutes with the masked sum and is applied to the pooled sums.
         f = fn.ConvGNReLUFn.apply(enc_feat, *self.feat_head[0].params())
         S, msum = fn.MaskPoolFn.apply(f, log_m)                      # [B,K,D], [B,K]
-        w1 = self.feat_head[1].weight.view(2 * D, D)
-        obj = (F.linear(S, w1) + msum.unsqueeze(-1) * self.feat_head[1].bias) / (msum.unsqueeze(-1) + 1e-5)
+        obj = (fn.linear(S, self.feat_head[1].weight) + msum.unsqueeze(-1) * self.feat_head[1].bias) \
+            / (msum.unsqueeze(-1) + 1e-5)
         # --- Posterior
         if eps is None:
             eps = torch.randn(K, B, D, device=dev)
-        z, mu, sigma, log_q = fn.PosteriorFn.apply(self.z_head(obj), eps)   # [K,B,D] x3, [K,B]
+        zh = self.z_head[0](obj)                                              # LayerNorm
+        zh = fn.linear(zh, self.z_head[1].weight, self.z_head[1].bias, 'relu')
+        zh = fn.linear(zh, self.z_head[3].weight, self.z_head[3].bias)
+        z, mu, sigma, log_q = fn.PosteriorFn.apply(zh, eps)                  # [K,B,D] x3, [K,B]
         # --- Decode latents, reconstruction loss
         err, recon, x_r, log_m_r = self._decode(z, x)
         losses = AttrDict()
@@ -312,7 +315,7 @@ class GenesisV2(nn.Module):
         # -- Component KL (Genesis.mask_latent_loss, models/genesis_config.py:288-343)
         lin = None
         if self.prior_lstm is not None:
-            lin = self.prior_linear(self._prior_hidden(z))          # [K-1,B,2D]
+            lin = fn.linear(self._prior_hidden(z), self.prior_linear.weight, self.prior_linear.bias)  # [K-1,B,2D]
         log_p = fn.PriorLogPFn.apply(z, lin)
         losses['kl_l_k'] = list((log_q - log_p).unbind(0))
 

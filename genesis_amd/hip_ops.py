@@ -423,3 +423,29 @@ def latent_prior_logp_bwd(z, lin, glogp):
     dlin = torch.empty_like(lin) if lin is not None else None
     _lib.call('gx_latent_prior_logp_bwd', _p(z), _p(lin), _p(glogp), B, K, D, _p(dz), _p(dlin), _stream())
     return dz, dlin
+
+
+# ---------------------------------------------------------------------------------------------- dense layers
+def linear_fwd(x, w, b=None, act=None):
+    """act(x [M,K] @ w[N,K]^T + b) (nn.Linear (+ReLU))."""
+    _chk(x, 'linear.x'); _chk(w, 'linear.w'); _chk(b, 'linear.b')
+    M, K = x.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise GenesisHipError('linear_fwd: x is [%d,%d] but w is %s' % (M, K, tuple(w.shape)))
+    y = torch.empty(M, N, dtype=F32, device=x.device)
+    _lib.call('gx_linear_fwd', _p(x), _p(w), _p(b), ACTS[act], _p(y), M, N, K, _stream())
+    return y
+
+
+def linear_bwd(x, w, y, g, act=None, need_dx=True, need_dw=True, need_db=True, out_dw=None, out_db=None):
+    """Returns (dx, dw, db); out_dw / out_db: write the parameter gradients into these buffers."""
+    _chk(g, 'linear_bwd.g')
+    M, K = x.shape
+    N = w.shape[0]
+    dev = x.device
+    dx = torch.empty(M, K, dtype=F32, device=dev) if need_dx else None
+    dw = (out_dw if out_dw is not None else torch.empty(N, K, dtype=F32, device=dev)) if need_dw else None
+    db = (out_db if out_db is not None else torch.empty(N, dtype=F32, device=dev)) if (need_db and need_dw) else None
+    _lib.call('gx_linear_bwd', _p(x), _p(w), _p(y), _p(g), ACTS[act], _p(dx), _p(dw), _p(db), M, N, K, _stream())
+    return dx, dw, db

@@ -202,6 +202,17 @@ int gx_latent_prior_logp_fwd(const float* z, const float* lin, int B, int K, int
 int gx_latent_prior_logp_bwd(const float* z, const float* lin, const float* glogp, int B, int K, int D, float* dz,
                              float* dlin, gx_stream_t stream);
 
+/* ---- small dense layers (nn.Linear: modules/unet.py:58-62 bottleneck MLP, models/genesisv2_config.py:76-80
+ *      z_head, :73 feat_head[1] on the pooled slot sums, models/genesis_config.py:106 prior_linear).
+ *      y[M,N] = act(x[M,K] w[N,K]^T + b[N]), act 0 none / 1 ReLU, b may be NULL.
+ *      bwd: g = dL/dy; dpre = g * [y > 0] for act 1 (y = the layer OUTPUT, may be NULL for act 0);
+ *      dx[M,K] = dpre w, dw[N,K] = dpre^T x, db[N] = column sums of dpre; each of dx / dw / db may be NULL to skip
+ *      (db needs dw).  Row-major contiguous; fixed reduction order. */
+int gx_linear_fwd(const float* x, const float* w, const float* b, int act, float* y, int M, int N, int K,
+                  gx_stream_t stream);
+int gx_linear_bwd(const float* x, const float* w, const float* y, const float* g, int act, float* dx, float* dw,
+                  float* db, int M, int N, int K, gx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

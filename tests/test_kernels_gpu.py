@@ -456,3 +456,31 @@ def test_latent_posterior_and_prior(B, K, D, prior):
     o2 = ref(zr2, None)
     ((o2[0] * w[0].double()).sum() + (o2[3] * w[3].double()).sum()).backward()
     close(zg2.grad, zr2.grad, rtol=1e-4, atol=1e-5, msg='dzh (z, log_q only)')
+
+
+@pytest.mark.parametrize('M,N,K,act,bias', [
+    (32, 128, 2048, 'relu', True), (32, 2048, 128, 'relu', True), (224, 128, 128, 'relu', True),
+    (224, 128, 64, None, False), (192, 128, 256, None, True), (7, 5, 3, None, True), (33, 17, 70, 'relu', True),
+    (16, 16, 16, None, False)])
+def test_linear(M, N, K, act, bias):
+    """Dense-layer kernels vs F.linear (+ReLU) and its autograd in fp64; fp32 MFMA, rtol 1e-5 fwd, 1e-4 grads."""
+    from genesis_amd import functions as fn
+    x = rnd(M, K, seed=1)
+    w = rnd(N, K, seed=2, scale=1.0 / np.sqrt(K))
+    b = rnd(N, seed=3) if bias else None
+    g = rnd(M, N, seed=4)
+    xr, wr = x.double().requires_grad_(), w.double().requires_grad_()
+    br = b.double().requires_grad_() if bias else None
+    yr = F.linear(xr, wr, br)
+    if act == 'relu':
+        yr = F.relu(yr)
+    (yr * g.double()).sum().backward()
+    xg, wg = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_()
+    bg = b.to(DEV).requires_grad_() if bias else None
+    y = fn.linear(xg, wg, bg, act)
+    close(y, yr, rtol=1e-5, atol=1e-5, msg='y')
+    (y * g.to(DEV)).sum().backward()
+    close(xg.grad, xr.grad, rtol=1e-4, atol=1e-5, msg='dx')
+    close(wg.grad, wr.grad, rtol=1e-4, atol=1e-5, msg='dw')
+    if bias:
+        close(bg.grad, br.grad, rtol=1e-4, atol=1e-5, msg='db')
