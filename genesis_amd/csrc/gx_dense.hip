@@ -115,6 +115,119 @@ dense_kernel(const float* __restrict__ a, int lda, const float* __restrict__ mas
     }
 }
 
+// ------------------------------------------------------------------------------------------------ LSTM cell
+// nn.LSTM (single layer, gate order i, f, g, o) unrolled by the caller, one launch per time step: the recurrent
+// GEMM h_prev w_hh^T of a 16 (batch) x 16 (hidden units) tile for all four gates, then the cell update in the
+// epilogue.  The library path issues ~8 launches per step (GEMM, bias, gate slicing, pointwise update).
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ void __launch_bounds__(256)
+lstm_step_fwd_kernel(const float* __restrict__ gx, const float* __restrict__ h_prev,
+                     const float* __restrict__ c_prev, const float* __restrict__ w_hh,
+                     const float* __restrict__ b_hh, int B, int H, float* __restrict__ act,
+                     float* __restrict__ c_out, float* __restrict__ h_out) {
+    __shared__ float part[4][4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int idx = lane & 15, kq = lane >> 4;
+    const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+    const bool a_ok = i0 + idx < B;
+    f32x4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { acc[q][0] = 0.f; acc[q][1] = 0.f; acc[q][2] = 0.f; acc[q][3] = 0.f; }
+    if (h_prev) {
+        for (int k16 = wave * 16; k16 < H; k16 += 64) {
+            const int kb = k16 + 4 * kq;
+            f32x4 av = {0.f, 0.f, 0.f, 0.f};
+            if (a_ok) av = *reinterpret_cast<const f32x4*>(h_prev + (size_t)(i0 + idx) * H + kb);
+            f32x4 bv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                bv[q] = *reinterpret_cast<const f32x4*>(w_hh + (size_t)(q * H + j0 + idx) * H + kb);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj], bv[q][jj], acc[q], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[wave][q][(kq * 4 + r) * 16 + idx] = acc[q][r];
+    __syncthreads();
+    const int t = threadIdx.x;
+    const int b = i0 + (t >> 4), u = j0 + (t & 15);
+    if (b < B) {
+        float pre[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float s = part[0][q][t];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) s += part[w][q][t];
+            pre[q] = s + gx[(size_t)b * 4 * H + q * H + u] + b_hh[q * H + u];
+        }
+        const float ig = sigmoid_f(pre[0]), fg = sigmoid_f(pre[1]), gg = tanhf(pre[2]), og = sigmoid_f(pre[3]);
+        const float cp = c_prev ? c_prev[(size_t)b * H + u] : 0.f;
+        const float cn = fg * cp + ig * gg;
+        float* ar = act + (size_t)b * 4 * H + u;
+        ar[0] = ig; ar[H] = fg; ar[2 * H] = gg; ar[3 * H] = og;
+        c_out[(size_t)b * H + u] = cn;
+        h_out[(size_t)b * H + u] = og * tanhf(cn);
+    }
+}
+
+// dh = g_h + dgates_next w_hh; dc = dc_next + dh o (1 - tanh(c)^2); dgates = (dc g i(1-i), dc c_prev f(1-f),
+// dc i (1-g^2), dh tanh(c) o(1-o)); dc_prev = dc f.
+__global__ void __launch_bounds__(1024)
+lstm_step_bwd_kernel(const float* __restrict__ g_h, const float* __restrict__ dgates_next,
+                     const float* __restrict__ w_hh, const float* __restrict__ act, const float* __restrict__ c,
+                     const float* __restrict__ c_prev, const float* __restrict__ dc_next, int B, int H,
+                     float* __restrict__ dgates, float* __restrict__ dc_prev) {
+    __shared__ float part[16][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int idx = lane & 15, kq = lane >> 4;
+    const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+    const bool a_ok = i0 + idx < B;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (dgates_next) {
+        const int Kc = 4 * H;
+        for (int k16 = wave * 16; k16 < Kc; k16 += nw * 16) {
+            const int kb = k16 + 4 * kq;
+            f32x4 av = {0.f, 0.f, 0.f, 0.f};
+            if (a_ok) av = *reinterpret_cast<const f32x4*>(dgates_next + (size_t)(i0 + idx) * Kc + kb);
+            float bv[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) bv[jj] = w_hh[(size_t)(kb + jj) * H + j0 + idx];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj], bv[jj], acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[wave][(kq * 4 + r) * 16 + idx] = acc[r];
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const int t = threadIdx.x;
+        const int b = i0 + (t >> 4), u = j0 + (t & 15);
+        if (b < B) {
+            float dh = part[0][t];
+            for (int w = 1; w < nw; ++w) dh += part[w][t];
+            if (g_h) dh += g_h[(size_t)b * H + u];
+            const float* ar = act + (size_t)b * 4 * H + u;
+            const float ig = ar[0], fg = ar[H], gg = ar[2 * H], og = ar[3 * H];
+            const float tc = tanhf(c[(size_t)b * H + u]);
+            const float cp = c_prev ? c_prev[(size_t)b * H + u] : 0.f;
+            const float dc = (dc_next ? dc_next[(size_t)b * H + u] : 0.f) + dh * og * (1.f - tc * tc);
+            float* dr = dgates + (size_t)b * 4 * H + u;
+            dr[0] = dc * gg * ig * (1.f - ig);
+            dr[H] = dc * cp * fg * (1.f - fg);
+            dr[2 * H] = dc * ig * (1.f - gg * gg);
+            dr[3 * H] = dh * tc * og * (1.f - og);
+            dc_prev[(size_t)b * H + u] = dc * fg;
+        }
+    }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline int dense_threads(int Kc) { return Kc >= 1024 ? 1024 : 256; }
 
@@ -180,6 +293,39 @@ int gx_linear_bwd(const float* x, const float* w, const float* y, const float* g
         }
     }
     GX_CHECK_LAUNCH("gx_linear_bwd(dw)");
+    return GX_OK;
+}
+
+int gx_lstm_step_fwd(const float* gx, const float* h_prev, const float* c_prev, const float* w_hh,
+                     const float* b_hh, int B, int H, float* act, float* c, float* h, gx_stream_t stream) {
+    GX_CHECK_ARG(gx && w_hh && b_hh && act && c && h, "gx_lstm_step_fwd: null pointer");
+    GX_CHECK_ARG(B > 0 && H > 0 && H % 16 == 0, "gx_lstm_step_fwd: H must be a multiple of 16 (B=%d, H=%d)", B, H);
+    GX_CHECK_ARG((h_prev == nullptr) == (c_prev == nullptr), "gx_lstm_step_fwd: h_prev and c_prev go together");
+    GX_CHECK_ARG(aligned16(w_hh) && (!h_prev || aligned16(h_prev)), "gx_lstm_step_fwd: 16-byte alignment");
+    hipStream_t s = (hipStream_t)stream;
+    {
+        GxProf pf(KID_DENSE, s, h_prev ? 8.0 * B * H * H : 0.0, 4.0 * (4.0 * H * H + 12.0 * B * H));
+        hipLaunchKernelGGL(lstm_step_fwd_kernel, dim3(H / 16, gx_ceil_div(B, 16)), dim3(256), 0, s, gx, h_prev,
+                           c_prev, w_hh, b_hh, B, H, act, c, h);
+    }
+    GX_CHECK_LAUNCH("gx_lstm_step_fwd");
+    return GX_OK;
+}
+
+int gx_lstm_step_bwd(const float* g_h, const float* dgates_next, const float* w_hh, const float* act,
+                     const float* c, const float* c_prev, const float* dc_next, int B, int H, float* dgates,
+                     float* dc_prev, gx_stream_t stream) {
+    GX_CHECK_ARG(w_hh && act && c && dgates && dc_prev, "gx_lstm_step_bwd: null pointer");
+    GX_CHECK_ARG(g_h || dgates_next, "gx_lstm_step_bwd: no incoming gradient");
+    GX_CHECK_ARG(B > 0 && H > 0 && H % 16 == 0, "gx_lstm_step_bwd: H must be a multiple of 16 (B=%d, H=%d)", B, H);
+    GX_CHECK_ARG(!dgates_next || aligned16(dgates_next), "gx_lstm_step_bwd: 16-byte alignment");
+    hipStream_t s = (hipStream_t)stream;
+    {
+        GxProf pf(KID_DENSE, s, dgates_next ? 8.0 * B * H * H : 0.0, 4.0 * (4.0 * H * H + 14.0 * B * H));
+        hipLaunchKernelGGL(lstm_step_bwd_kernel, dim3(H / 16, gx_ceil_div(B, 16)), dim3(1024), 0, s, g_h,
+                           dgates_next, w_hh, act, c, c_prev, dc_next, B, H, dgates, dc_prev);
+    }
+    GX_CHECK_LAUNCH("gx_lstm_step_bwd");
     return GX_OK;
 }
 

@@ -19,27 +19,34 @@ class FlatBucket(object):
     fp32 params -> flat_p / flat_g (+ `n_tail` piggy-backed scalars at the end of flat_g);
     fp64 params (att_process.log_sigma) -> flat_p64 / flat_g64 (a separate 8-byte message)."""
 
-    def __init__(self, params, n_tail=2):
+    def __init__(self, params, n_tail=2, align=16):
         params = list(params)
         self.p32 = [p for p in params if p.dtype == torch.float32]
         self.p64 = [p for p in params if p.dtype == torch.float64]
         assert len(self.p32) + len(self.p64) == len(params), 'only fp32 / fp64 parameters are supported'
         dev = params[0].device
-        self.n32 = sum(p.numel() for p in self.p32)
+        # every parameter starts on a 64-byte boundary of the flat buffer (16-byte vector loads in the dense / LSTM
+        # kernels need aligned rows); the padding stays zero in parameters, gradients and Adam state
+        self.align = align
+        self.n32 = sum(self._pad(p.numel()) for p in self.p32)
         self.n64 = sum(p.numel() for p in self.p64)
         self.n_tail = n_tail
-        self.flat_p = torch.empty(self.n32, dtype=torch.float32, device=dev)
+        self.flat_p = torch.zeros(self.n32, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(self.n32 + n_tail, dtype=torch.float32, device=dev)
-        self.flat_p64 = torch.empty(max(self.n64, 1), dtype=torch.float64, device=dev)
+        self.flat_p64 = torch.zeros(max(self.n64, 1), dtype=torch.float64, device=dev)
         self.flat_g64 = torch.zeros(max(self.n64, 1), dtype=torch.float64, device=dev)
-        for plist, fp, fg in ((self.p32, self.flat_p, self.flat_g), (self.p64, self.flat_p64, self.flat_g64)):
+        for plist, fp, fg, padded in ((self.p32, self.flat_p, self.flat_g, True),
+                                      (self.p64, self.flat_p64, self.flat_g64, False)):
             off = 0
             for p in plist:
                 n = p.numel()
                 fp[off:off + n].copy_(p.data.reshape(-1))
                 p.data = fp[off:off + n].view(p.shape)
                 p.grad = fg[off:off + n].view(p.shape)
-                off += n
+                off += self._pad(n) if padded else n
+
+    def _pad(self, n):
+        return (n + self.align - 1) // self.align * self.align
 
     def zero_grad(self):
         self.flat_g.zero_()

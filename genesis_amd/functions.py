@@ -529,3 +529,52 @@ class LinearFn(torch.autograd.Function):
 
 def linear(x, w, b=None, act=None):
     return LinearFn.apply(x, w, b, act)
+
+
+class LSTMFn(torch.autograd.Function):
+    """nn.LSTM (one layer, zero initial state) over x [T,B,D] -> h [T,B,H]: input projection for all steps on the
+    dense kernel, then one fused (recurrent GEMM + cell update) launch per step; backward mirrors it
+    (models/genesis_config.py:297-307 prior_lstm)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
+        x = x.contiguous()
+        T, B, D = x.shape
+        H = w_hh.shape[1]
+        dev = x.device
+        gx = hip.linear_fwd(x.view(T * B, D), w_ih, b_ih)                    # [T*B, 4H]
+        act = torch.empty(T, B, 4 * H, device=dev)
+        c = torch.empty(T, B, H, device=dev)
+        h = torch.empty(T, B, H, device=dev)
+        gx3 = gx.view(T, B, 4 * H)
+        for t in range(T):
+            hip.lstm_step_fwd(gx3[t], h[t - 1] if t else None, c[t - 1] if t else None, w_hh, b_hh, act[t], c[t], h[t])
+        ctx.save_for_backward(x, act, c, h)
+        ctx.params = (w_ih, w_hh, b_ih, b_hh)
+        return h
+
+    @staticmethod
+    def backward(ctx, g):
+        x, act, c, h = ctx.saved_tensors
+        w_ih, w_hh, b_ih, b_hh = ctx.params
+        T, B, D = x.shape
+        H = w_hh.shape[1]
+        g = g.contiguous()
+        dgates = torch.empty(T, B, 4 * H, device=x.device)
+        dc = [torch.empty(B, H, device=x.device), torch.empty(B, H, device=x.device)]
+        for t in reversed(range(T)):
+            hip.lstm_step_bwd(g[t], dgates[t + 1] if t + 1 < T else None, w_hh, act[t], c[t],
+                              c[t - 1] if t else None, dc[(t + 1) & 1] if t + 1 < T else None, dgates[t], dc[t & 1])
+        o_wih, o_whh, o_bih, o_bhh = _gout(w_ih), _gout(w_hh), _gout(b_ih), _gout(b_hh)
+        dg2 = dgates.view(T * B, 4 * H)
+        dx, dw_ih, db = hip.linear_bwd(x.view(T * B, D), w_ih, None, dg2, None, need_dx=ctx.needs_input_grad[0],
+                                       out_dw=o_wih, out_db=o_bih)
+        if T > 1:
+            _, dw_hh, _ = hip.linear_bwd(h[:-1].view((T - 1) * B, H), w_hh, None, dgates[1:].view((T - 1) * B, 4 * H),
+                                         None, need_dx=False, need_db=False, out_dw=o_whh)
+        else:
+            dw_hh = torch.zeros_like(w_hh) if o_whh is None else o_whh.zero_()
+        if o_bhh is not None:
+            o_bhh.copy_(db)
+        return (dx.view(T, B, D) if dx is not None else None, _ret(o_wih, dw_ih), _ret(o_whh, dw_hh), _ret(o_bih, db),
+                _ret(o_bhh, db))

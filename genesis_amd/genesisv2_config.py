@@ -51,7 +51,7 @@ import os as _os
 
 # The AR prior's LSTM is a plain library op (MIOpen through torch.nn.LSTM): one fused call per direction
 # instead of ~12 pointwise launches per step.  GENESIS_LIBRARY_LSTM=0 selects the explicit cell loop.
-USE_LIBRARY_LSTM = _os.environ.get('GENESIS_LIBRARY_LSTM', '1') == '1'
+USE_FUSED_LSTM = _os.environ.get('GENESIS_FUSED_LSTM', '1') == '1'   # 0: unrolled torch ops (debug)
 
 
 def load(cfg):
@@ -240,10 +240,9 @@ class GenesisV2(nn.Module):
     def _prior_hidden(self, z_kbd):
         """LSTM of the AR prior from the zero state over z_1..z_{K-1} (models/genesis_config.py:297-307)."""
         K, B, D = z_kbd.shape
-        if USE_LIBRARY_LSTM:
-            # plain library LSTM (MIOpen via torch): one fused call instead of ~12 pointwise launches per step
-            out, _ = self.prior_lstm(z_kbd[:-1])
-            return out
+        if USE_FUSED_LSTM:
+            L = self.prior_lstm
+            return fn.LSTMFn.apply(z_kbd[:-1], L.weight_ih_l0, L.weight_hh_l0, L.bias_ih_l0, L.bias_hh_l0)
         w_ih, w_hh = self.prior_lstm.weight_ih_l0, self.prior_lstm.weight_hh_l0
         b_ih, b_hh = self.prior_lstm.bias_ih_l0, self.prior_lstm.bias_hh_l0
         H = w_hh.shape[1]

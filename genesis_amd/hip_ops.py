@@ -449,3 +449,22 @@ def linear_bwd(x, w, y, g, act=None, need_dx=True, need_dw=True, need_db=True, o
     db = (out_db if out_db is not None else torch.empty(N, dtype=F32, device=dev)) if (need_db and need_dw) else None
     _lib.call('gx_linear_bwd', _p(x), _p(w), _p(y), _p(g), ACTS[act], _p(dx), _p(dw), _p(db), M, N, K, _stream())
     return dx, dw, db
+
+
+def lstm_step_fwd(gx, h_prev, c_prev, w_hh, b_hh, act, c, h):
+    """One LSTM cell step into preallocated act [B,4H], c, h [B,H] (views of the per-sequence buffers)."""
+    B, H4 = gx.shape
+    for t, n in ((gx, 'gx'), (h_prev, 'h_prev'), (c_prev, 'c_prev'), (w_hh, 'w_hh'), (b_hh, 'b_hh'), (act, 'act'),
+                 (c, 'c'), (h, 'h')):
+        _chk(t, 'lstm_step_fwd.' + n)
+    _lib.call('gx_lstm_step_fwd', _p(gx), _p(h_prev), _p(c_prev), _p(w_hh), _p(b_hh), B, H4 // 4, _p(act), _p(c),
+              _p(h), _stream())
+
+
+def lstm_step_bwd(g_h, dgates_next, w_hh, act, c, c_prev, dc_next, dgates, dc_prev):
+    B, H4 = act.shape
+    for t, n in ((g_h, 'g_h'), (dgates_next, 'dgates_next'), (act, 'act'), (c, 'c'), (c_prev, 'c_prev'),
+                 (dc_next, 'dc_next'), (dgates, 'dgates'), (dc_prev, 'dc_prev')):
+        _chk(t, 'lstm_step_bwd.' + n)
+    _lib.call('gx_lstm_step_bwd', _p(g_h), _p(dgates_next), _p(w_hh), _p(act), _p(c), _p(c_prev), _p(dc_next), B,
+              H4 // 4, _p(dgates), _p(dc_prev), _stream())

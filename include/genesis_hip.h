@@ -213,6 +213,20 @@ int gx_linear_fwd(const float* x, const float* w, const float* b, int act, float
 int gx_linear_bwd(const float* x, const float* w, const float* y, const float* g, int act, float* dx, float* dw,
                   float* db, int M, int N, int K, gx_stream_t stream);
 
+/* ---- LSTM cell step (nn.LSTM, one layer, gate order i, f, g, o: models/genesis_config.py:105 prior_lstm, :297-307;
+ *      modules/attention.py LatentSBP core).  The caller computes gx = x w_ih^T + b_ih for all steps with
+ *      gx_linear_fwd and unrolls time:
+ *      pre = gx[B,4H] + h_prev[B,H] w_hh[4H,H]^T + b_hh; act[B,4H] = (sigm i | sigm f | tanh g | sigm o);
+ *      c = f c_prev + i g; h = o tanh(c).  h_prev = c_prev = NULL: zero initial state.
+ *      bwd of one step: dh = g_h[B,H] (NULL = 0) + dgates_next[B,4H] w_hh (NULL at the last step);
+ *      dc = dc_next (NULL = 0) + dh o (1 - tanh(c)^2); dgates[B,4H] = pre-activation gradients; dc_prev = dc f.
+ *      Weight gradients follow from gx_linear_bwd on the stacked dgates.  H % 16 == 0. */
+int gx_lstm_step_fwd(const float* gx, const float* h_prev, const float* c_prev, const float* w_hh,
+                     const float* b_hh, int B, int H, float* act, float* c, float* h, gx_stream_t stream);
+int gx_lstm_step_bwd(const float* g_h, const float* dgates_next, const float* w_hh, const float* act,
+                     const float* c, const float* c_prev, const float* dc_next, int B, int H, float* dgates,
+                     float* dc_prev, gx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,12 +80,14 @@ def test_bucket_views_track_parameters():
               torch.nn.Parameter(torch.randn((), dtype=torch.float64))]
     before = [p.detach().clone() for p in params]
     b = FlatBucket(params, n_tail=2)
-    assert b.n32 == 17 and b.n64 == 1 and b.flat_g.numel() == 19
+    assert b.n32 == 32 and b.n64 == 1 and b.flat_g.numel() == 34          # 12 -> 16, 5 -> 16 (64-byte aligned slots)
+    assert all(p.data_ptr() % 64 == 0 for p in params[:2])
     for p, q in zip(params, before):
         assert torch.equal(p.detach(), q)
     (params[0].sum() * 2 + params[1].sum() * 3 + params[2] * 4).backward()
     assert b.grads_in_bucket()
-    assert torch.equal(b.flat_g[:12], torch.full((12,), 2.0)) and torch.equal(b.flat_g[12:17], torch.full((5,), 3.0))
+    assert torch.equal(b.flat_g[:12], torch.full((12,), 2.0)) and torch.equal(b.flat_g[16:21], torch.full((5,), 3.0))
+    assert float(b.flat_g[12:16].abs().sum()) == 0.0 and float(b.flat_g[21:32].abs().sum()) == 0.0
     assert float(b.flat_g64[0]) == 4.0
     b.flat_p.mul_(0)          # the optimiser writes the flat buffer; parameters are views of it
     assert float(params[0].abs().sum()) == 0.0

@@ -484,3 +484,28 @@ def test_linear(M, N, K, act, bias):
     close(wg.grad, wr.grad, rtol=1e-4, atol=1e-5, msg='dw')
     if bias:
         close(bg.grad, br.grad, rtol=1e-4, atol=1e-5, msg='db')
+
+
+@pytest.mark.parametrize('T,B,D,H', [(6, 32, 64, 256), (1, 3, 16, 16), (4, 17, 8, 32)])
+def test_lstm(T, B, D, H):
+    """Fused LSTM (dense input projection + one launch per step) vs nn.LSTM in fp64; rtol 1e-5 fwd, 1e-4 grads."""
+    from genesis_amd import functions as fn
+    ref = torch.nn.LSTM(D, H).double()
+    g0 = torch.Generator().manual_seed(5)
+    for p in ref.parameters():
+        p.data.copy_((torch.rand(p.shape, generator=g0) * 2 - 1) * 0.3)
+    x = rnd(T, B, D, seed=1)
+    g = rnd(T, B, H, seed=2)
+    xr = x.double().requires_grad_()
+    out_ref, _ = ref(xr)
+    (out_ref * g.double()).sum().backward()
+    ps = [p.detach().float().to(DEV).requires_grad_() for p in
+          (ref.weight_ih_l0, ref.weight_hh_l0, ref.bias_ih_l0, ref.bias_hh_l0)]
+    xg = x.to(DEV).requires_grad_()
+    out = fn.LSTMFn.apply(xg, *ps)
+    close(out, out_ref, rtol=1e-5, atol=1e-5, msg='h')
+    (out * g.to(DEV)).sum().backward()
+    close(xg.grad, xr.grad, rtol=1e-4, atol=1e-5, msg='dx')
+    for p, r, name in zip(ps, (ref.weight_ih_l0, ref.weight_hh_l0, ref.bias_ih_l0, ref.bias_hh_l0),
+                          ('dw_ih', 'dw_hh', 'db_ih', 'db_hh')):
+        close(p.grad, r.grad, rtol=1e-4, atol=1e-5, msg=name)
