@@ -2,7 +2,7 @@
 // log-density under the autoregressive prior -- the Monte-Carlo KL of Genesis.mask_latent_loss.
 //
 // Reference: models/genesisv2_config.py:154-160 (mu, sigma_ps = z_head(obj).chunk(2); sigma = to_sigma(sigma_ps);
-// z = Normal(mu, sigma).rsample()), modules/blocks.py:36-41 (to_sigma = softplus(x + 0.5) + 1e-8,
+// z = Normal(mu, sigma).rsample()), modules/blocks.py:22-23,28-36 (to_sigma = softplus(x + 0.5) + 1e-8,
 // to_prior_sigma = sigmoid(x + 4.0) + 1e-4), models/genesis_config.py:288-343 (log_q, log_p per slot; first slot
 // N(0,1), later slots N(tanh(lin[:D]), to_prior_sigma(lin[D:])) with lin = prior_linear(prior_lstm(z_{<k}))).
 // Normal.log_prob(v) = -(v - loc)^2 / (2 scale^2) - log(scale) - log(sqrt(2 pi)), evaluated in that operation order.
@@ -84,8 +84,8 @@ posterior_bwd_kernel(const float* __restrict__ zh, const float* __restrict__ eps
 
 // z [K,B,D], lin [K-1,B,2D] (null: standard-normal prior for every slot) -> log_p [K,B]
 __global__ void __launch_bounds__(256)
-prior_logp_fwd_kernel(const float* __restrict__ z, const float* __restrict__ lin, int B, int K, int D,
-                      float* __restrict__ log_p) {
+prior_logp_fwd_kernel(const float* __restrict__ z, const float* __restrict__ lin,
+                      const float* __restrict__ log_q, int B, int K, int D, float* __restrict__ log_p) {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= K * B) return;
     const int lane = threadIdx.x & 63;
@@ -107,12 +107,12 @@ prior_logp_fwd_kernel(const float* __restrict__ z, const float* __restrict__ lin
         acc += (double)lp;
     }
     acc = gx_wave_sum_d(acc);
-    if (lane == 0) log_p[row] = (float)acc;
+    if (lane == 0) log_p[row] = log_q ? log_q[row] - (float)acc : (float)acc;   // KL sample log_q - log_p, or log_p
 }
 
 __global__ void __launch_bounds__(256)
 prior_logp_bwd_kernel(const float* __restrict__ z, const float* __restrict__ lin, const float* __restrict__ glogp,
-                      int B, int K, int D, float* __restrict__ dz, float* __restrict__ dlin) {
+                      float sign, int B, int K, int D, float* __restrict__ dz, float* __restrict__ dlin) {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= K * B) return;
     const int lane = threadIdx.x & 63;
@@ -120,7 +120,7 @@ prior_logp_bwd_kernel(const float* __restrict__ z, const float* __restrict__ lin
     const bool ar = lin != nullptr && k > 0;
     const float* lr = ar ? lin + (size_t)(row - B) * 2 * D : nullptr;
     float* dl = ar ? dlin + (size_t)(row - B) * 2 * D : nullptr;
-    const float g = glogp[row];
+    const float g = sign * glogp[row];
     for (int d = lane; d < D; d += 64) {
         const size_t i = (size_t)row * D + d;
         const float zz = z[i];
@@ -137,6 +137,116 @@ prior_logp_bwd_kernel(const float* __restrict__ z, const float* __restrict__ lin
             dz[i] = g * (-zz);
         }
     }
+}
+
+// ---- loss aggregation (train.py:226-242) + the GECO-weighted objective, one workgroup ----
+// out = (loss = err_mean + beta kl_mean, elbo = err_mean + kl_mean, err_mean, kl_mean, beta)
+__global__ void __launch_bounds__(256)
+elbo_fwd_kernel(const float* __restrict__ err, const float* __restrict__ kl, const float* __restrict__ beta,
+                int B, int R, float* __restrict__ out, float* __restrict__ tail) {
+    __shared__ double red[2][4];
+    double se = 0.0, sk = 0.0;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) se += (double)err[i];
+    for (int i = threadIdx.x; i < R * B; i += blockDim.x) sk += (double)kl[i];
+    se = gx_wave_sum_d(se); sk = gx_wave_sum_d(sk);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = se; red[1][wave] = sk; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double e = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / B;
+        const double k = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / B;
+        const float ef = (float)e, kf = (float)k, bt = *beta;
+        out[0] = ef + bt * kf; out[1] = ef + kf; out[2] = ef; out[3] = kf; out[4] = bt;
+        if (tail) { tail[0] = ef; tail[1] = kf; }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+elbo_bwd_kernel(const float* __restrict__ g, const float* __restrict__ beta, int B, int R,
+                float* __restrict__ d_err, float* __restrict__ d_kl) {
+    const float ge = g[0] / B, gk = g[0] * (*beta) / B;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) d_err[i] = ge;
+    if (i < R * B) d_kl[i] = gk;
+}
+
+// ---- pooled slot features -> z_head's LayerNorm input (models/genesisv2_config.py:146-154, :76) ----
+// obj = (lin + msum fbias) / (msum + 1e-5)  [feat_head[1] applied to the pooled sums, normalised by the mask
+// mass], y = LayerNorm(obj; gamma, beta, eps).  One wave per row; row statistics in fp64.
+__global__ void __launch_bounds__(256)
+pooled_head_fwd_kernel(const float* __restrict__ lin, const float* __restrict__ msum,
+                       const float* __restrict__ fbias, const float* __restrict__ gamma,
+                       const float* __restrict__ beta, float eps, int R, int C, float* __restrict__ y,
+                       float* __restrict__ stats /* [R][2] mean, rstd */) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const int lane = threadIdx.x & 63;
+    const float m = msum[row];
+    const float den = m + 1e-5f;
+    double s1 = 0.0, s2 = 0.0;
+    for (int j = lane; j < C; j += 64) {
+        const float o = (lin[(size_t)row * C + j] + m * fbias[j]) / den;
+        s1 += (double)o; s2 += (double)o * o;
+    }
+    s1 = gx_wave_sum_d(s1); s2 = gx_wave_sum_d(s2);
+    const double mean = s1 / C;
+    double var = s2 / C - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float meanf = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
+    for (int j = lane; j < C; j += 64) {
+        const float o = (lin[(size_t)row * C + j] + m * fbias[j]) / den;
+        y[(size_t)row * C + j] = (o - meanf) * rstd * gamma[j] + beta[j];
+    }
+    if (lane == 0) { stats[2 * row] = meanf; stats[2 * row + 1] = rstd; }
+}
+
+// g [R,C] -> dlin [R,C], dmsum [R]; per-row column terms cols[R][3][C] = (g xhat, g, dobj m/den) for the
+// parameter gradients (summed over rows by pooled_head_cols_kernel in a fixed order)
+__global__ void __launch_bounds__(256)
+pooled_head_bwd_kernel(const float* __restrict__ lin, const float* __restrict__ msum,
+                       const float* __restrict__ fbias, const float* __restrict__ gamma,
+                       const float* __restrict__ stats, const float* __restrict__ g, int R, int C,
+                       float* __restrict__ dlin, float* __restrict__ dmsum, float* __restrict__ cols) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const int lane = threadIdx.x & 63;
+    const float m = msum[row];
+    const float den = m + 1e-5f;
+    const float meanf = stats[2 * row], rstd = stats[2 * row + 1];
+    double a = 0.0, b = 0.0;   // sum dxhat, sum dxhat * xhat
+    for (int j = lane; j < C; j += 64) {
+        const float o = (lin[(size_t)row * C + j] + m * fbias[j]) / den;
+        const float xh = (o - meanf) * rstd;
+        const float dxh = g[(size_t)row * C + j] * gamma[j];
+        a += (double)dxh; b += (double)dxh * xh;
+    }
+    a = gx_wave_sum_d(a); b = gx_wave_sum_d(b);
+    const float k1 = (float)(a / C), k2 = (float)(b / C);
+    double dm = 0.0;
+    for (int j = lane; j < C; j += 64) {
+        const float num = lin[(size_t)row * C + j] + m * fbias[j];
+        const float o = num / den;
+        const float xh = (o - meanf) * rstd;
+        const float gv = g[(size_t)row * C + j];
+        const float dobj = rstd * (gv * gamma[j] - k1 - xh * k2);
+        dlin[(size_t)row * C + j] = dobj / den;
+        dm += (double)dobj * ((double)fbias[j] / den - (double)num / ((double)den * den));
+        float* cr = cols + (size_t)row * 3 * C;
+        cr[j] = gv * xh; cr[C + j] = gv; cr[2 * C + j] = dobj * (m / den);
+    }
+    dm = gx_wave_sum_d(dm);
+    if (lane == 0) dmsum[row] = (float)dm;
+}
+
+__global__ void __launch_bounds__(256)
+pooled_head_cols_kernel(const float* __restrict__ cols, int R, int C, float* __restrict__ dgamma,
+                        float* __restrict__ dbeta, float* __restrict__ dfbias) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over 3*C
+    if (i >= 3 * C) return;
+    double s = 0.0;
+    for (int r = 0; r < R; ++r) s += (double)cols[(size_t)r * 3 * C + i];
+    const int which = i / C, j = i - which * C;
+    (which == 0 ? dgamma : (which == 1 ? dbeta : dfbias))[j] = (float)s;
 }
 
 int check_bkd(const char* name, int B, int K, int D) {
@@ -179,23 +289,25 @@ int gx_latent_posterior_bwd(const float* zh, const float* eps, const float* gz, 
     return GX_OK;
 }
 
-int gx_latent_prior_logp_fwd(const float* z, const float* lin, int B, int K, int D, float* log_p,
-                             gx_stream_t stream) {
+int gx_latent_prior_logp_fwd(const float* z, const float* lin, const float* log_q, int B, int K, int D,
+                             float* out, gx_stream_t stream) {
+    float* log_p = out;
     int rc = check_bkd("gx_latent_prior_logp_fwd", B, K, D);
     if (rc) return rc;
     GX_CHECK_ARG(z && log_p, "gx_latent_prior_logp_fwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
     {
         GxProf pf(KID_LATENT, s, 0.0, 4.0 * (3.0 * K * B * D + K * B));
-        hipLaunchKernelGGL(prior_logp_fwd_kernel, dim3(gx_ceil_div(K * B, 4)), dim3(256), 0, s, z, lin, B, K, D,
-                           log_p);
+        hipLaunchKernelGGL(prior_logp_fwd_kernel, dim3(gx_ceil_div(K * B, 4)), dim3(256), 0, s, z, lin, log_q, B, K,
+                           D, log_p);
     }
     GX_CHECK_LAUNCH("gx_latent_prior_logp_fwd");
     return GX_OK;
 }
 
-int gx_latent_prior_logp_bwd(const float* z, const float* lin, const float* glogp, int B, int K, int D, float* dz,
-                             float* dlin, gx_stream_t stream) {
+int gx_latent_prior_logp_bwd(const float* z, const float* lin, const float* g_out, int kl_mode, int B, int K,
+                             int D, float* dz, float* dlin, gx_stream_t stream) {
+    const float* glogp = g_out;
     int rc = check_bkd("gx_latent_prior_logp_bwd", B, K, D);
     if (rc) return rc;
     GX_CHECK_ARG(z && glogp && dz, "gx_latent_prior_logp_bwd: null pointer");
@@ -203,10 +315,77 @@ int gx_latent_prior_logp_bwd(const float* z, const float* lin, const float* glog
     hipStream_t s = (hipStream_t)stream;
     {
         GxProf pf(KID_LATENT, s, 0.0, 4.0 * (6.0 * K * B * D + K * B));
-        hipLaunchKernelGGL(prior_logp_bwd_kernel, dim3(gx_ceil_div(K * B, 4)), dim3(256), 0, s, z, lin, glogp, B, K,
-                           D, dz, dlin);
+        hipLaunchKernelGGL(prior_logp_bwd_kernel, dim3(gx_ceil_div(K * B, 4)), dim3(256), 0, s, z, lin, glogp,
+                           kl_mode ? -1.f : 1.f, B, K, D, dz, dlin);
     }
     GX_CHECK_LAUNCH("gx_latent_prior_logp_bwd");
+    return GX_OK;
+}
+
+int gx_elbo_fwd(const float* err, const float* kl, const float* beta, int B, int R, float* out, float* tail,
+                gx_stream_t stream) {
+    GX_CHECK_ARG(err && beta && out, "gx_elbo_fwd: null pointer");
+    GX_CHECK_ARG(B > 0 && R >= 0 && (R == 0 || kl), "gx_elbo_fwd: bad B/R (%d,%d) or missing kl", B, R);
+    hipStream_t s = (hipStream_t)stream;
+    {
+        GxProf pf(KID_LATENT, s, 0.0, 4.0 * (B + (double)R * B));
+        hipLaunchKernelGGL(elbo_fwd_kernel, dim3(1), dim3(256), 0, s, err, kl, beta, B, R, out, tail);
+    }
+    GX_CHECK_LAUNCH("gx_elbo_fwd");
+    return GX_OK;
+}
+
+int gx_elbo_bwd(const float* g_loss, const float* beta, int B, int R, float* d_err, float* d_kl,
+                gx_stream_t stream) {
+    GX_CHECK_ARG(g_loss && beta && d_err, "gx_elbo_bwd: null pointer");
+    GX_CHECK_ARG(B > 0 && R >= 0 && (R == 0 || d_kl), "gx_elbo_bwd: bad B/R (%d,%d) or missing d_kl", B, R);
+    hipStream_t s = (hipStream_t)stream;
+    const int n = R > 0 ? R * B : B;
+    {
+        GxProf pf(KID_LATENT, s, 0.0, 4.0 * (B + (double)R * B));
+        hipLaunchKernelGGL(elbo_bwd_kernel, dim3(gx_ceil_div(n, 256)), dim3(256), 0, s, g_loss, beta, B, R, d_err,
+                           d_kl);
+    }
+    GX_CHECK_LAUNCH("gx_elbo_bwd");
+    return GX_OK;
+}
+
+int gx_pooled_head_fwd(const float* lin, const float* msum, const float* fbias, const float* gamma,
+                       const float* beta, float eps, int R, int C, float* y, float* stats, gx_stream_t stream) {
+    GX_CHECK_ARG(lin && msum && fbias && gamma && beta && y && stats, "gx_pooled_head_fwd: null pointer");
+    GX_CHECK_ARG(R > 0 && C > 0, "gx_pooled_head_fwd: bad R/C (%d,%d)", R, C);
+    hipStream_t s = (hipStream_t)stream;
+    {
+        GxProf pf(KID_LATENT, s, 0.0, 8.0 * R * C);
+        hipLaunchKernelGGL(pooled_head_fwd_kernel, dim3(gx_ceil_div(R, 4)), dim3(256), 0, s, lin, msum, fbias, gamma,
+                           beta, eps, R, C, y, stats);
+    }
+    GX_CHECK_LAUNCH("gx_pooled_head_fwd");
+    return GX_OK;
+}
+
+size_t gx_pooled_head_bwd_ws_bytes(int R, int C) { return (size_t)R * 3 * C * sizeof(float); }
+
+int gx_pooled_head_bwd(const float* lin, const float* msum, const float* fbias, const float* gamma,
+                       const float* stats, const float* g, int R, int C, float* dlin, float* dmsum, float* dfbias,
+                       float* dgamma, float* dbeta, void* ws, size_t ws_bytes, gx_stream_t stream) {
+    GX_CHECK_ARG(lin && msum && fbias && gamma && stats && g && dlin && dmsum && dfbias && dgamma && dbeta && ws,
+                 "gx_pooled_head_bwd: null pointer");
+    GX_CHECK_ARG(R > 0 && C > 0, "gx_pooled_head_bwd: bad R/C (%d,%d)", R, C);
+    GX_CHECK_ARG(ws_bytes >= gx_pooled_head_bwd_ws_bytes(R, C), "gx_pooled_head_bwd: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    {
+        GxProf pf(KID_LATENT, s, 0.0, 4.0 * 6.0 * R * C);
+        hipLaunchKernelGGL(pooled_head_bwd_kernel, dim3(gx_ceil_div(R, 4)), dim3(256), 0, s, lin, msum, fbias, gamma,
+                           stats, g, R, C, dlin, dmsum, (float*)ws);
+    }
+    GX_CHECK_LAUNCH("gx_pooled_head_bwd");
+    {
+        GxProf pf(KID_LATENT, s, 0.0, 4.0 * 3.0 * R * C);
+        hipLaunchKernelGGL(pooled_head_cols_kernel, dim3(gx_ceil_div(3 * C, 256)), dim3(256), 0, s,
+                           (const float*)ws, R, C, dgamma, dbeta, dfbias);
+    }
+    GX_CHECK_LAUNCH("gx_pooled_head_bwd(cols)");
     return GX_OK;
 }
 

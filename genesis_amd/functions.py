@@ -480,21 +480,71 @@ class PosteriorFn(torch.autograd.Function):
 
 
 class PriorLogPFn(torch.autograd.Function):
-    """z [K,B,D], lin [K-1,B,2D] (or None) -> log_p [K,B] under N(0,1) for the first slot and
-    N(tanh(lin[:D]), sigmoid(lin[D:] + 4) + 1e-4) for the others (models/genesis_config.py:297-330)."""
+    """z [K,B,D], lin [K-1,B,2D] (or None), log_q [K,B] (or None) -> log_p [K,B] under N(0,1) for the first slot and
+    N(tanh(lin[:D]), sigmoid(lin[D:] + 4) + 1e-4) for the others (models/genesis_config.py:297-330); with log_q the
+    Monte-Carlo KL sample log_q - log_p of :329-331 (one launch for the whole KL term)."""
 
     @staticmethod
-    def forward(ctx, z, lin):
+    def forward(ctx, z, lin, log_q=None):
         z = z.contiguous()
         lin = None if lin is None else lin.contiguous()
+        log_q = None if log_q is None else log_q.contiguous()
         ctx.save_for_backward(z, lin)
-        return hip.latent_prior_logp_fwd(z, lin)
+        ctx.kl_mode = log_q is not None
+        return hip.latent_prior_logp_fwd(z, lin, log_q)
 
     @staticmethod
-    def backward(ctx, glogp):
+    def backward(ctx, g):
         z, lin = ctx.saved_tensors
-        dz, dlin = hip.latent_prior_logp_bwd(z, lin, glogp.contiguous())
-        return dz, dlin
+        g = g.contiguous()
+        dz, dlin = hip.latent_prior_logp_bwd(z, lin, g, ctx.kl_mode)
+        return dz, dlin, (g if ctx.kl_mode else None)
+
+
+class ElboFn(torch.autograd.Function):
+    """Loss aggregation of train.py:226-242: (err [B], kl [R,B] | None, beta [1] device scalar) ->
+    out[5] = (err_mean + beta kl_mean, err_mean + kl_mean, err_mean, kl_mean, beta); out[0] is the objective."""
+
+    @staticmethod
+    def forward(ctx, err, kl, beta, tail):
+        err = err.contiguous()
+        kl = None if kl is None else kl.contiguous()
+        ctx.beta = beta
+        ctx.dims = (err.numel(), 0 if kl is None else kl.numel() // err.numel())
+        ctx.kl_shape = None if kl is None else kl.shape
+        return hip.elbo_fwd(err, kl, beta, tail)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, R = ctx.dims
+        d_err, d_kl = hip.elbo_bwd(g[:1].contiguous(), ctx.beta, B, R)
+        return d_err, (d_kl.view(ctx.kl_shape) if d_kl is not None else None), None, None
+
+
+class PooledHeadFn(torch.autograd.Function):
+    """(lin [R,C], msum [R], feat_head[1].bias, LayerNorm weight, bias, eps) -> LayerNorm((lin + msum b)/(msum+1e-5))
+    (models/genesisv2_config.py:146-154 and z_head[0], :76), one launch forward, two backward."""
+
+    @staticmethod
+    def forward(ctx, lin, msum, fbias, gamma, beta, eps):
+        shape = lin.shape
+        lin2 = lin.contiguous().view(-1, shape[-1])
+        msum1 = msum.contiguous().view(-1)
+        y, stats = hip.pooled_head_fwd(lin2, msum1, fbias, gamma, beta, eps)
+        ctx.save_for_backward(lin2, msum1, stats)
+        ctx.params = (fbias, gamma, beta)
+        ctx.shapes = (shape, msum.shape)
+        return y.view(shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        lin2, msum1, stats = ctx.saved_tensors
+        fbias, gamma, beta = ctx.params
+        outs = (_gout(fbias), _gout(gamma), _gout(beta))
+        dlin, dmsum, dfb, dga, dbe = hip.pooled_head_bwd(lin2, msum1, fbias, gamma, stats,
+                                                         g.contiguous().view(lin2.shape), out=outs)
+        return (dlin.view(ctx.shapes[0]), dmsum.view(ctx.shapes[1]), _ret(outs[0], dfb), _ret(outs[1], dga),
+                _ret(outs[2], dbe), None)
 
 
 # ---------------------------------------------------------------------------------------------- dense layers

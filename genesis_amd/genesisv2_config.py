@@ -29,6 +29,7 @@ from attrdict import AttrDict  # noqa: E402
 from forge import flags  # noqa: E402
 
 from genesis_amd import functions as fn  # noqa: E402
+from genesis_amd.lazy import Lazy, LazyAttrDict, SlotList  # noqa: E402
 from genesis_amd import hip_ops as hip  # noqa: E402
 
 # Architecture (models/genesisv2_config.py:35-42)
@@ -284,12 +285,12 @@ class GenesisV2(nn.Module):
         #     slot; the 1x1 conv feat_head[1] commutes with the masked sum and is applied to the pooled sums.
         f = fn.ConvGNReLUFn.apply(enc_feat, *self.feat_head[0].params())
         S, msum = fn.MaskPoolFn.apply(f, log_m)                      # [B,K,D], [B,K]
-        obj = (fn.linear(S, self.feat_head[1].weight) + msum.unsqueeze(-1) * self.feat_head[1].bias) \
-            / (msum.unsqueeze(-1) + 1e-5)
+        ln = self.z_head[0]
+        zh = fn.PooledHeadFn.apply(fn.linear(S, self.feat_head[1].weight), msum, self.feat_head[1].bias,
+                                   ln.weight, ln.bias, ln.eps)              # (pooled / mask mass) -> LayerNorm
         # --- Posterior
         if eps is None:
             eps = torch.randn(K, B, D, device=dev)
-        zh = self.z_head[0](obj)                                              # LayerNorm
         zh = fn.linear(zh, self.z_head[1].weight, self.z_head[1].bias, 'relu')
         zh = fn.linear(zh, self.z_head[3].weight, self.z_head[3].bias)
         z, mu, sigma, log_q = fn.PosteriorFn.apply(zh, eps)                  # [K,B,D] x3, [K,B]
@@ -301,7 +302,6 @@ class GenesisV2(nn.Module):
         log_s_k = list(log_s.unbind(0))
         x_r_k = list(x_r.unbind(0))
         log_m_r_k = list(log_m_r.unbind(0))
-        mx_r_k = list((x_r * log_m_r.exp()).unbind(0))
         # -- Optional: Attention mask loss (MONet.kl_m_loss, models/monet_config.py:157-170)
         if self.klm_loss:
             if not self.detach_mr_in_klm:
@@ -315,17 +315,19 @@ class GenesisV2(nn.Module):
         lin = None
         if self.prior_lstm is not None:
             lin = fn.linear(self._prior_hidden(z), self.prior_linear.weight, self.prior_linear.bias)  # [K-1,B,2D]
-        log_p = fn.PriorLogPFn.apply(z, lin)
-        losses['kl_l_k'] = list((log_q - log_p).unbind(0))
+        kl = fn.PriorLogPFn.apply(z, lin, log_q)                    # [K,B]: log_q - log_p per slot
+        losses['kl_l_k'] = SlotList(kl.unbind(0), stacked=kl)
 
-        stats = AttrDict(
-            recon=recon, log_m_k=log_m_k, log_s_k=log_s_k, x_r_k=x_r_k, log_m_r_k=log_m_r_k, mx_r_k=mx_r_k,
-            instance_seg=torch.argmax(log_m.squeeze(2), dim=0),
-            instance_seg_r=torch.argmax(log_m_r.squeeze(2), dim=0))
-        delta = (colour[:, -2:] - uv[-2:]) if ap.semiconv else None
-        att_stats = AttrDict()
-        att_stats.update({'colour': colour, 'delta': delta, 'seeds': list(seeds.unbind(0)),
-                          'seed_idx': list(idx.unbind(0))})
+        # derived visualisation outputs are evaluated on first access (a training step never reads them)
+        stats = LazyAttrDict(
+            recon=recon, log_m_k=log_m_k, log_s_k=log_s_k, x_r_k=x_r_k, log_m_r_k=log_m_r_k,
+            mx_r_k=Lazy(lambda: list((x_r * log_m_r.exp()).unbind(0))),
+            instance_seg=Lazy(lambda: torch.argmax(log_m.squeeze(2), dim=0)),
+            instance_seg_r=Lazy(lambda: torch.argmax(log_m_r.squeeze(2), dim=0)))
+        att_stats = LazyAttrDict()
+        att_stats.update({'colour': colour,
+                          'delta': Lazy(lambda: colour[:, -2:] - uv[-2:]) if ap.semiconv else None,
+                          'seeds': list(seeds.unbind(0)), 'seed_idx': list(idx.unbind(0))})
         comp_stats = AttrDict(mu_k=list(mu.unbind(0)), sigma_k=list(sigma.unbind(0)), z_k=list(z.unbind(0)),
                               kl_l_k=[], q_z_k=[Normal(m, s, validate_args=False)
                                                 for m, s in zip(mu.unbind(0), sigma.unbind(0))])

@@ -405,24 +405,72 @@ def latent_posterior_bwd(zh, eps, gz, gmu, gsigma, glogq):
     return dzh
 
 
-def latent_prior_logp_fwd(z, lin):
-    """z [K,B,D], lin [K-1,B,2D] or None -> log_p [K,B] (models/genesis_config.py:297-330)."""
-    _chk(z, 'prior.z'); _chk(lin, 'prior.lin')
+def latent_prior_logp_fwd(z, lin, log_q=None):
+    """z [K,B,D], lin [K-1,B,2D] or None -> log_p [K,B] (models/genesis_config.py:297-330); with log_q [K,B] the
+    per-slot KL sample log_q - log_p (:329-331)."""
+    _chk(z, 'prior.z'); _chk(lin, 'prior.lin'); _chk(log_q, 'prior.log_q')
     K, B, D = z.shape
     if lin is not None and tuple(lin.shape) != (K - 1, B, 2 * D):
         raise GenesisHipError('latent_prior_logp_fwd: lin must be [K-1,B,2D]')
-    log_p = torch.empty(K, B, dtype=F32, device=z.device)
-    _lib.call('gx_latent_prior_logp_fwd', _p(z), _p(lin), B, K, D, _p(log_p), _stream())
-    return log_p
+    out = torch.empty(K, B, dtype=F32, device=z.device)
+    _lib.call('gx_latent_prior_logp_fwd', _p(z), _p(lin), _p(log_q), B, K, D, _p(out), _stream())
+    return out
 
 
-def latent_prior_logp_bwd(z, lin, glogp):
-    _chk(glogp, 'prior_bwd.glogp')
+def latent_prior_logp_bwd(z, lin, g_out, kl_mode=False):
+    _chk(g_out, 'prior_bwd.g_out')
     K, B, D = z.shape
     dz = torch.empty_like(z)
     dlin = torch.empty_like(lin) if lin is not None else None
-    _lib.call('gx_latent_prior_logp_bwd', _p(z), _p(lin), _p(glogp), B, K, D, _p(dz), _p(dlin), _stream())
+    _lib.call('gx_latent_prior_logp_bwd', _p(z), _p(lin), _p(g_out), int(kl_mode), B, K, D, _p(dz), _p(dlin),
+              _stream())
     return dz, dlin
+
+
+def elbo_fwd(err, kl, beta, tail=None):
+    """err [B], kl [R,B] or None, beta: 1-element device tensor -> out[5] = (loss, elbo, err_mean, kl_mean, beta)
+    (train.py:226-242).  tail: 2-element slice of the gradient bucket receiving (err_mean, kl_mean)."""
+    _chk(err, 'elbo.err'); _chk(kl, 'elbo.kl'); _chk(beta, 'elbo.beta'); _chk(tail, 'elbo.tail')
+    B = err.numel()
+    R = 0 if kl is None else kl.numel() // B
+    out = torch.empty(5, dtype=F32, device=err.device)
+    _lib.call('gx_elbo_fwd', _p(err), _p(kl), _p(beta), B, R, _p(out), _p(tail), _stream())
+    return out
+
+
+def elbo_bwd(g_loss, beta, B, R):
+    _chk(g_loss, 'elbo_bwd.g')
+    d_err = torch.empty(B, dtype=F32, device=g_loss.device)
+    d_kl = torch.empty(R, B, dtype=F32, device=g_loss.device) if R else None
+    _lib.call('gx_elbo_bwd', _p(g_loss), _p(beta), B, R, _p(d_err), _p(d_kl), _stream())
+    return d_err, d_kl
+
+
+def pooled_head_fwd(lin, msum, fbias, gamma, beta, eps):
+    """(lin + msum fbias) / (msum + 1e-5) -> LayerNorm (models/genesisv2_config.py:146-154, :76)."""
+    for t, n in ((lin, 'lin'), (msum, 'msum'), (fbias, 'fbias'), (gamma, 'gamma'), (beta, 'beta')):
+        _chk(t, 'pooled_head.' + n)
+    R, C = lin.shape
+    y = torch.empty_like(lin)
+    stats = torch.empty(R, 2, dtype=F32, device=lin.device)
+    _lib.call('gx_pooled_head_fwd', _p(lin), _p(msum), _p(fbias), _p(gamma), _p(beta), float(eps), R, C, _p(y),
+              _p(stats), _stream())
+    return y, stats
+
+
+def pooled_head_bwd(lin, msum, fbias, gamma, stats, g, out=(None, None, None)):
+    """Returns dlin [R,C], dmsum [R], dfbias, dgamma, dbeta [C]; out = (dfbias, dgamma, dbeta) destination buffers."""
+    _chk(g, 'pooled_head_bwd.g')
+    R, C = lin.shape
+    dev = lin.device
+    dlin = torch.empty_like(lin)
+    dmsum = torch.empty(R, dtype=F32, device=dev)
+    dfb, dga, dbe = [o if o is not None else torch.empty(C, dtype=F32, device=dev) for o in out]
+    nb = _lib.query('gx_pooled_head_bwd_ws_bytes', R, C)
+    ws = _ws(nb, dev)
+    _lib.call('gx_pooled_head_bwd', _p(lin), _p(msum), _p(fbias), _p(gamma), _p(stats), _p(g), R, C, _p(dlin),
+              _p(dmsum), _p(dfb), _p(dga), _p(dbe), _p(ws), ws.numel(), _stream())
+    return dlin, dmsum, dfb, dga, dbe
 
 
 # ---------------------------------------------------------------------------------------------- dense layers

@@ -68,27 +68,43 @@ class TrainStep(object):
     def _iteration_body(self, x, **forward_kwargs):
         recon, losses, stats, att_stats, comp_stats = self.model(x, **forward_kwargs)
         # loss aggregation of train.py:226-242 (every model family: kl_m | kl_m_k, kl_l | kl_l_k)
-        err = losses.err.mean(0)
-        kl = err.new_zeros(())
-        if 'kl_m' in losses:
-            kl = kl + losses.kl_m.mean(0)
-        elif 'kl_m_k' in losses:
-            kl = kl + torch.stack(losses.kl_m_k, dim=1).mean(dim=0).sum()
-        if 'kl_l' in losses:
-            kl = kl + losses.kl_l.mean(0)
-        elif 'kl_l_k' in losses:
-            kl = kl + torch.stack(losses.kl_l_k, dim=1).mean(dim=0).sum()
-        if self.geco is not None:
-            beta = self.geco.state[0].clone()
+        beta_t = self.geco.state[0:1] if self.geco is not None else self._beta_fixed_t.view(1)
+        keys = [k for k in ('kl_m', 'kl_m_k', 'kl_l', 'kl_l_k') if k in losses]
+        fused, kl_rows = len(keys) <= 1 and losses.err.dim() == 1, None
+        if fused and keys:
+            v = dict.__getitem__(losses, keys[0])
+            if keys[0].endswith('_k'):
+                kl_rows = getattr(v, 'stacked', None)        # [K,B] tensor the per-slot list was unbound from
+                fused = kl_rows is not None
+            else:
+                kl_rows = v.view(1, -1)
+        if fused:
+            # one launch: batch means, the GECO-weighted objective, and (err, kl) straight into the bucket tail
+            out5 = _fn.ElboFn.apply(losses.err, kl_rows, beta_t, self.bucket.flat_g[self.n32:self.n32 + 2])
+            out5[0].backward()
         else:
-            beta = self._beta_fixed_t
-        loss = err + beta * kl
-        loss.backward()
+            err = losses.err.mean(0)
+            kl = err.new_zeros(())
+            if 'kl_m' in losses:
+                kl = kl + losses.kl_m.mean(0)
+            elif 'kl_m_k' in losses:
+                kl = kl + torch.stack(losses.kl_m_k, dim=1).mean(dim=0).sum()
+            if 'kl_l' in losses:
+                kl = kl + losses.kl_l.mean(0)
+            elif 'kl_l_k' in losses:
+                kl = kl + torch.stack(losses.kl_l_k, dim=1).mean(dim=0).sum()
+            beta = beta_t[0].clone()
+            loss = err + beta * kl
+            loss.backward()
         _fn.join_side_stream()     # weight-gradient kernels forked onto the side stream
         with torch.no_grad():
-            self.bucket.set_tail(err, kl)
+            if not fused:
+                self.bucket.set_tail(err, kl)
             gscale = self.bucket.all_reduce(self.pg)
-            tail = self.bucket.tail(gscale)                 # global batch-mean err, kl
+            if fused and self.world == 1:
+                tail = self.bucket.flat_g[self.n32:]            # already the global batch means
+            else:
+                tail = self.bucket.tail(gscale)                 # global batch-mean err, kl
             if self.geco is not None:
                 self.geco.update(tail[0])
             stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -99,7 +115,10 @@ class TrainStep(object):
                 _lib.call('gx_adam_step', _p(self.flat_p64), _p(self.flat_g64), _p(self.m64), _p(self.v64),
                           self.n64, 1, _p(self.step_t), self.lr, self.betas[0], self.betas[1], self.eps, gscale,
                           stream)
-            return torch.stack((tail[0] + tail[1], tail[0], tail[1], beta.detach()))  # elbo, err, kl, beta used
+            if fused and self.world == 1:
+                return out5.detach()[1:5]                       # elbo, err, kl, beta used
+            beta_used = out5.detach()[4] if fused else beta.detach()
+            return torch.stack((tail[0] + tail[1], tail[0], tail[1], beta_used))
 
     def _capture(self, x):
         """Warm up (kernel attributes, allocator pools), capture one iteration into a HIP graph, restore the

@@ -191,16 +191,39 @@ int gx_gated_norm_bwd(const float* y, const float* bias, int norm, const float* 
  *      N(tanh(lin[:D]), to_prior_sigma(lin[D:])) for later slots, lin = prior_linear(prior_lstm(z_{<k}))).
  *      zh [B,K,2D] = z_head output (mu | sigma_ps), eps [K,B,D] standard normal; z, mu, sigma [K,B,D] slot-major,
  *      log_q / log_p [K,B].  lin [K-1,B,2D], or NULL for the standard-normal prior on every slot.
+ *      gx_latent_prior_logp_fwd writes out = log_p, or the KL sample log_q - log_p when log_q is given
+ *      (kl_mode = 1 in bwd: g_out is then dL/d(log_q - log_p)).
  *      bwd: incoming gradients gz / gmu / gsigma [K,B,D], glogq [K,B] may each be NULL (= zero). */
 int gx_latent_posterior_fwd(const float* zh, const float* eps, int B, int K, int D, float* z, float* mu,
                             float* sigma, float* log_q, gx_stream_t stream);
 int gx_latent_posterior_bwd(const float* zh, const float* eps, const float* gz, const float* gmu,
                             const float* gsigma, const float* glogq, int B, int K, int D, float* dzh,
                             gx_stream_t stream);
-int gx_latent_prior_logp_fwd(const float* z, const float* lin, int B, int K, int D, float* log_p,
-                             gx_stream_t stream);
-int gx_latent_prior_logp_bwd(const float* z, const float* lin, const float* glogp, int B, int K, int D, float* dz,
-                             float* dlin, gx_stream_t stream);
+int gx_latent_prior_logp_fwd(const float* z, const float* lin, const float* log_q, int B, int K, int D,
+                             float* out, gx_stream_t stream);
+int gx_latent_prior_logp_bwd(const float* z, const float* lin, const float* g_out, int kl_mode, int B, int K,
+                             int D, float* dz, float* dlin, gx_stream_t stream);
+
+/* ---- loss aggregation of the training loop (train.py:226-242) with GECO's beta (utils/geco.py:47-49):
+ *      err_mean = mean_b err[b]; kl_mean = sum_r mean_b kl[r][b] (kl [R,B], R = 0 / NULL: no KL term);
+ *      out[5] = (loss = err_mean + beta kl_mean, err_mean + kl_mean, err_mean, kl_mean, beta); beta is read from
+ *      device memory (GECO state); tail (NULL to skip) receives (err_mean, kl_mean) -- the gradient bucket's
+ *      piggy-backed scalars.  bwd: d_err[b] = g/B, d_kl[r][b] = g beta / B for the scalar g = dL/d loss. */
+int gx_elbo_fwd(const float* err, const float* kl, const float* beta, int B, int R, float* out, float* tail,
+                gx_stream_t stream);
+int gx_elbo_bwd(const float* g_loss, const float* beta, int B, int R, float* d_err, float* d_kl,
+                gx_stream_t stream);
+
+/* ---- pooled slot features -> z_head[0] (models/genesisv2_config.py:146-154: obj_feat = feat_head(enc) * mask
+ *      summed over pixels / (mask.sum + 1e-5); :76 nn.LayerNorm(2 feat_dim)).  lin [R,C] = pooled sums through
+ *      feat_head[1]'s weight (gx_linear_fwd), msum [R] mask mass, fbias [C] feat_head[1].bias:
+ *      obj = (lin + msum fbias) / (msum + 1e-5); y = LayerNorm(obj; gamma, beta, eps); stats [R,2] = (mean, rstd). */
+int gx_pooled_head_fwd(const float* lin, const float* msum, const float* fbias, const float* gamma,
+                       const float* beta, float eps, int R, int C, float* y, float* stats, gx_stream_t stream);
+size_t gx_pooled_head_bwd_ws_bytes(int R, int C);
+int gx_pooled_head_bwd(const float* lin, const float* msum, const float* fbias, const float* gamma,
+                       const float* stats, const float* g, int R, int C, float* dlin, float* dmsum, float* dfbias,
+                       float* dgamma, float* dbeta, void* ws, size_t ws_bytes, gx_stream_t stream);
 
 /* ---- small dense layers (nn.Linear: modules/unet.py:58-62 bottleneck MLP, models/genesisv2_config.py:76-80
  *      z_head, :73 feat_head[1] on the pooled slot sums, models/genesis_config.py:106 prior_linear).

@@ -439,6 +439,8 @@ def test_latent_posterior_and_prior(B, K, D, prior):
     lg = lin.to(DEV).requires_grad_() if lin is not None else None
     z, mu, sigma, log_q = fn.PosteriorFn.apply(zg, eps.to(DEV))
     log_p = fn.PriorLogPFn.apply(z, lg)
+    kl = fn.PriorLogPFn.apply(z.detach(), None if lg is None else lg.detach(), log_q.detach())
+    close(kl, outs_ref[3] - outs_ref[4], rtol=1e-5, atol=1e-4, msg='kl = log_q - log_p')
     outs = (z, mu, sigma, log_q, log_p)
     for o, r, name in zip(outs, outs_ref, ('z', 'mu', 'sigma', 'log_q', 'log_p')):
         close(o, r, rtol=1e-5, atol=1e-5, msg=name)
@@ -509,3 +511,57 @@ def test_lstm(T, B, D, H):
     for p, r, name in zip(ps, (ref.weight_ih_l0, ref.weight_hh_l0, ref.bias_ih_l0, ref.bias_hh_l0),
                           ('dw_ih', 'dw_hh', 'db_ih', 'db_hh')):
         close(p.grad, r.grad, rtol=1e-4, atol=1e-5, msg=name)
+
+
+def test_kl_mode_gradients():
+    """PriorLogPFn with log_q returns log_q - log_p and routes +g to log_q, -g into the prior terms."""
+    from genesis_amd import functions as fn
+    K, B, D = 4, 5, 16
+    z = rnd(K, B, D, seed=1).to(DEV).requires_grad_()
+    lin = rnd(K - 1, B, 2 * D, seed=2).to(DEV).requires_grad_()
+    lq = rnd(K, B, seed=3).to(DEV).requires_grad_()
+    w = rnd(K, B, seed=4).to(DEV)
+    (fn.PriorLogPFn.apply(z, lin, lq) * w).sum().backward()
+    gz, gl, gq = z.grad.clone(), lin.grad.clone(), lq.grad.clone()
+    z.grad = lin.grad = lq.grad = None
+    ((lq - fn.PriorLogPFn.apply(z, lin)) * w).sum().backward()
+    close(gz, z.grad, rtol=1e-6, atol=1e-7, msg='dz'); close(gl, lin.grad, rtol=1e-6, atol=1e-7, msg='dlin')
+    close(gq, lq.grad, rtol=0, atol=0, msg='dlog_q')
+
+
+@pytest.mark.parametrize('B,R', [(32, 7), (5, 0), (3, 1)])
+def test_elbo(B, R):
+    """Loss aggregation launch vs train.py:226-242 in torch fp64."""
+    from genesis_amd import functions as fn
+    err = (rnd(B, seed=1) * 100 + 500).to(DEV).requires_grad_()
+    kl = (rnd(R, B, seed=2) * 10).to(DEV).requires_grad_() if R else None
+    beta = torch.tensor([0.37], device=DEV)
+    tail = torch.zeros(2, device=DEV)
+    out = fn.ElboFn.apply(err, kl, beta, tail)
+    e = err.detach().cpu().double().mean()
+    k = kl.detach().cpu().double().mean(1).sum() if R else torch.zeros((), dtype=torch.float64)
+    close(out, torch.stack((e + 0.37 * k, e + k, e, k, torch.tensor(0.37, dtype=torch.float64))), rtol=1e-6, atol=1e-6)
+    close(tail, torch.stack((e, k)), rtol=1e-6, atol=1e-6)
+    out[0].backward()
+    close(err.grad, torch.full((B,), 1.0 / B), rtol=1e-6, atol=0)
+    if R:
+        close(kl.grad, torch.full((R, B), 0.37 / B), rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize('R,C', [(224, 128), (6, 32), (5, 200)])
+def test_pooled_head(R, C):
+    """(lin + msum b)/(msum + 1e-5) -> LayerNorm, vs the torch ops of models/genesisv2_config.py:146-154 + z_head[0]
+    in fp64; rtol 1e-5 forward, 1e-4 gradients."""
+    from genesis_amd import functions as fn
+    lin, msum = rnd(R, C, seed=1, scale=30.0), rnd(R, seed=2).abs() * 50 + 0.01
+    fb, ga, be, g = rnd(C, seed=3), rnd(C, seed=4) + 1.5, rnd(C, seed=5), rnd(R, C, seed=6)
+    ref = [t.double().requires_grad_() for t in (lin, msum, fb, ga, be)]
+    obj = (ref[0] + ref[1].unsqueeze(-1) * ref[2]) / (ref[1].unsqueeze(-1) + 1e-5)
+    yr = F.layer_norm(obj, (C,), ref[3], ref[4], 1e-5)
+    (yr * g.double()).sum().backward()
+    dev = [t.to(DEV).requires_grad_() for t in (lin, msum, fb, ga, be)]
+    y = fn.PooledHeadFn.apply(*dev, 1e-5)
+    close(y, yr, rtol=1e-5, atol=1e-5, msg='y')
+    (y * g.to(DEV)).sum().backward()
+    for a, b, n in zip(dev, ref, ('dlin', 'dmsum', 'dfbias', 'dgamma', 'dbeta')):
+        close(a.grad, b.grad, rtol=1e-4, atol=1e-5, msg=n)
