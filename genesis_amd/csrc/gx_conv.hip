@@ -28,6 +28,8 @@
 // what the stated fp32 parity tolerance of the path needs (no bf16/xf32 shortcuts).
 #include "gx_common.h"
 
+#include <vector>
+
 namespace {
 
 enum { M_C3 = 0, M_DT0 = 1, M_DT1 = 2, M_DG = 3 };
@@ -302,6 +304,22 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, const float
 //   pack 1: conv3x3 dgrad  W[co][ci][3][3]  -> m=ci, k=co, t=(kh,kw) reads W[..][2-kh][2-kw]
 //   pack 2/3: deconv fwd rows a=0/1, W[ci][co][5][5] -> m=co, k=ci, t=khi*5+kw, kh=2*khi+a
 //   pack 4: deconv dgrad   W[ci][co][5][5]  -> m=ci, k=co, t=kh*5+kw
+__device__ __forceinline__ float pack_weight_value(const float* __restrict__ w, int pack, int Co, int Ci, int m,
+                                                   int k, int t) {
+    float v = 0.f;
+    if (pack == 0) {
+        if (m < Co && k < Ci) v = w[((size_t)m * Ci + k) * 9 + t];
+    } else if (pack == 1) {
+        if (m < Ci && k < Co) v = w[((size_t)k * Ci + m) * 9 + (8 - t)];
+    } else if (pack == 2 || pack == 3) {
+        const int kh = 2 * (t / 5) + (pack - 2), kw = t % 5;
+        if (m < Co && k < Ci) v = w[((size_t)k * Co + m) * 25 + kh * 5 + kw];
+    } else {
+        if (m < Ci && k < Co) v = w[((size_t)m * Co + k) * 25 + t];
+    }
+    return v;
+}
+
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int pack,
                                     int Co, int Ci, int NT, int Kpad, int Mpad) {
     const int total = NT * Kpad * Mpad;
@@ -309,18 +327,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
         const int m = idx % Mpad;
         const int k = (idx / Mpad) % Kpad;
         const int t = idx / (Mpad * Kpad);
-        float v = 0.f;
-        if (pack == 0) {
-            if (m < Co && k < Ci) v = w[((size_t)m * Ci + k) * 9 + t];
-        } else if (pack == 1) {
-            if (m < Ci && k < Co) v = w[((size_t)k * Ci + m) * 9 + (8 - t)];
-        } else if (pack == 2 || pack == 3) {
-            const int kh = 2 * (t / 5) + (pack - 2), kw = t % 5;
-            if (m < Co && k < Ci) v = w[((size_t)k * Co + m) * 25 + kh * 5 + kw];
-        } else {
-            if (m < Ci && k < Co) v = w[((size_t)m * Co + k) * 25 + t];
-        }
-        wp[idx] = v;
+        wp[idx] = pack_weight_value(w, pack, Co, Ci, m, k, t);
     }
 }
 
@@ -693,7 +700,56 @@ int launch_splitk_reduce(const float* part, const float* bias, float* out, const
     return GX_OK;
 }
 
-int launch_pack(const float* w, float* wp, int pack, int Co, int Ci, int NT, int Kpad, int Mpad, hipStream_t s) {
+// ---- packed-weight cache -------------------------------------------------------------------------------
+// Weights change once per optimiser step but every conv entry point re-packs its weight tensor (35 launches of
+// ~5 us per training step).  A cache (one per training loop) records the (weight pointer, pack mode) pairs seen
+// during one recorded iteration; afterwards gx_weight_cache_refresh() re-packs all of them in ONE launch at the
+// start of an iteration and the conv entry points are served from the cache until gx_weight_cache_release().
+struct PackEntry {
+    const float* w; float* wp;
+    int pack, Co, Ci, NT, Kpad, Mpad;
+};
+struct PackCache {
+    std::vector<PackEntry> entries;
+    PackEntry* dev = nullptr;
+    bool alive = false;
+};
+std::vector<PackCache> g_caches;
+int g_cache_recording = -1;   // cache id being recorded, or -1
+int g_cache_active = -1;      // cache id conv calls are served from, or -1
+
+__global__ void pack_weights_batch_kernel(const PackEntry* __restrict__ entries) {
+    const PackEntry e = entries[blockIdx.y];
+    const int total = e.NT * e.Kpad * e.Mpad;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int m = idx % e.Mpad;
+        const int k = (idx / e.Mpad) % e.Kpad;
+        const int t = idx / (e.Mpad * e.Kpad);
+        e.wp[idx] = pack_weight_value(e.w, e.pack, e.Co, e.Ci, m, k, t);
+    }
+}
+
+// Packs w into `wp` (caller workspace) -- or, inside a refreshed cache window, returns the cached packing.
+int launch_pack(const float* w, float* wp, int pack, int Co, int Ci, int NT, int Kpad, int Mpad, hipStream_t s,
+                const float** wp_used) {
+    *wp_used = wp;
+    if (g_cache_active >= 0) {
+        for (const PackEntry& e : g_caches[g_cache_active].entries)
+            if (e.w == w && e.pack == pack && e.Co == Co && e.Ci == Ci) { *wp_used = e.wp; return GX_OK; }
+    }
+    if (g_cache_recording >= 0) {
+        PackCache& c = g_caches[g_cache_recording];
+        bool found = false;
+        for (const PackEntry& e : c.entries) found = found || (e.w == w && e.pack == pack && e.Co == Co && e.Ci == Ci);
+        if (!found) {
+            PackEntry e{w, nullptr, pack, Co, Ci, NT, Kpad, Mpad};
+            if (hipMalloc((void**)&e.wp, (size_t)NT * Kpad * Mpad * sizeof(float)) != hipSuccess) {
+                gx_set_error("weight cache: hipMalloc failed");
+                return GX_ELAUNCH;
+            }
+            c.entries.push_back(e);
+        }
+    }
     const int total = NT * Kpad * Mpad;
     const int blocks = gx_ceil_div(total, 256) > 1024 ? 1024 : gx_ceil_div(total, 256);
     {
@@ -809,6 +865,78 @@ static size_t conv3x3_pack_floats(int Cin, int Cout) {
     return f > d ? f : d;
 }
 
+int gx_weight_cache_create(void) {
+    for (size_t i = 0; i < g_caches.size(); ++i)
+        if (!g_caches[i].alive) { g_caches[i] = PackCache(); g_caches[i].alive = true; return (int)i; }
+    g_caches.emplace_back();
+    g_caches.back().alive = true;
+    return (int)g_caches.size() - 1;
+}
+
+static int cache_check(const char* name, int id) {
+    GX_CHECK_ARG(id >= 0 && id < (int)g_caches.size() && g_caches[id].alive, "%s: bad cache id %d", name, id);
+    return GX_OK;
+}
+
+int gx_weight_cache_record(int id, int on) {
+    int rc = cache_check("gx_weight_cache_record", id);
+    if (rc) return rc;
+    PackCache& c = g_caches[id];
+    if (on) { g_cache_recording = id; return GX_OK; }
+    g_cache_recording = -1;
+    if (c.dev) { (void)hipFree(c.dev); c.dev = nullptr; }
+    if (!c.entries.empty()) {
+        const size_t bytes = c.entries.size() * sizeof(PackEntry);
+        if (hipMalloc((void**)&c.dev, bytes) != hipSuccess ||
+            hipMemcpy(c.dev, c.entries.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
+            gx_set_error("gx_weight_cache_record: table upload failed");
+            return GX_ELAUNCH;
+        }
+    }
+    return GX_OK;
+}
+
+int gx_weight_cache_size(int id) {
+    return (id >= 0 && id < (int)g_caches.size() && g_caches[id].alive) ? (int)g_caches[id].entries.size() : -1;
+}
+
+int gx_weight_cache_refresh(int id, gx_stream_t stream) {
+    int rc = cache_check("gx_weight_cache_refresh", id);
+    if (rc) return rc;
+    PackCache& c = g_caches[id];
+    GX_CHECK_ARG(g_cache_recording != id, "gx_weight_cache_refresh: cache %d is still recording", id);
+    if (c.entries.empty()) { g_cache_active = -1; return GX_OK; }
+    hipStream_t s = (hipStream_t)stream;
+    {
+        double bytes = 0.0;
+        for (const PackEntry& e : c.entries) bytes += 8.0 * e.NT * e.Kpad * e.Mpad;
+        GxProf pf(KID_PACK_WEIGHTS, s, 0.0, bytes);
+        hipLaunchKernelGGL(pack_weights_batch_kernel, dim3(32, (unsigned)c.entries.size()), dim3(256), 0, s,
+                           (const PackEntry*)c.dev);
+    }
+    GX_CHECK_LAUNCH("gx_weight_cache_refresh");
+    g_cache_active = id;
+    return GX_OK;
+}
+
+int gx_weight_cache_release(void) {
+    g_cache_active = -1;
+    return GX_OK;
+}
+
+int gx_weight_cache_destroy(int id) {
+    int rc = cache_check("gx_weight_cache_destroy", id);
+    if (rc) return rc;
+    PackCache& c = g_caches[id];
+    for (PackEntry& e : c.entries) (void)hipFree(e.wp);
+    if (c.dev) (void)hipFree(c.dev);
+    c = PackCache();
+    if (g_cache_active == id) g_cache_active = -1;
+    if (g_cache_recording == id) g_cache_recording = -1;
+    return GX_OK;
+}
+
+
 size_t gx_conv3x3_ws_bytes(int N, int Cin, int Cout, int H, int W) {
     TapPlan pf, pd;
     size_t part = 0;
@@ -847,9 +975,10 @@ static int conv3x3_fwd_impl(const float* x, const float* w, const float* bias, i
     float* wp = (float*)ws;
     float* part = wp + conv3x3_pack_floats(Cin, Cout);
     pl.g.act = act;
-    rc = launch_pack(w, wp, 0, Cout, Cin, 9, Kpad, Mpad, s);
+    const float* wpu;
+    rc = launch_pack(w, wp, 0, Cout, Cin, 9, Kpad, Mpad, s, &wpu);
     if (rc) return rc;
-    rc = launch_tapconv<M_C3>(x, wp, bias, pl.g.nsplit > 1 ? part : y, pl, s, "gx_conv3x3_fwd");
+    rc = launch_tapconv<M_C3>(x, wpu, bias, pl.g.nsplit > 1 ? part : y, pl, s, "gx_conv3x3_fwd");
     if (rc) return rc;
     if (pl.g.nsplit > 1) return launch_splitk_reduce(part, bias, y, pl, s);
     return GX_OK;
@@ -868,9 +997,10 @@ int gx_conv3x3_dgrad(const float* dy, const float* w, float* dx, int N, int Cin,
     if (rc) return rc;
     float* wp = (float*)ws;
     float* part = wp + conv3x3_pack_floats(Cin, Cout);
-    rc = launch_pack(w, wp, 1, Cout, Cin, 9, Kpad, Mpad, s);
+    const float* wpu;
+    rc = launch_pack(w, wp, 1, Cout, Cin, 9, Kpad, Mpad, s, &wpu);
     if (rc) return rc;
-    rc = launch_tapconv<M_C3>(dy, wp, nullptr, pl.g.nsplit > 1 ? part : dx, pl, s, "gx_conv3x3_dgrad");
+    rc = launch_tapconv<M_C3>(dy, wpu, nullptr, pl.g.nsplit > 1 ? part : dx, pl, s, "gx_conv3x3_dgrad");
     if (rc) return rc;
     if (pl.g.nsplit > 1) return launch_splitk_reduce(part, nullptr, dx, pl, s);
     return GX_OK;
@@ -926,9 +1056,10 @@ int gx_deconv5x5s2_fwd(const float* x, const float* w, const float* bias, float*
     float* wp0 = (float*)ws;
     float* wp1 = wp0 + (size_t)15 * Kpad * Mpad;
     float* part = wp0 + deconv_pack_floats(Cin, Cout);
-    rc = launch_pack(w, wp0, 2, Cout, Cin, 15, Kpad, Mpad, s);
+    const float *wpu0, *wpu1;
+    rc = launch_pack(w, wp0, 2, Cout, Cin, 15, Kpad, Mpad, s, &wpu0);
     if (rc) return rc;
-    rc = launch_pack(w, wp1, 3, Cout, Cin, 10, Kpad, Mpad, s);
+    rc = launch_pack(w, wp1, 3, Cout, Cin, 10, Kpad, Mpad, s, &wpu1);
     if (rc) return rc;
     // both row parities share one split plan (same channel chunking) so that one reduce finishes the layer
     TapPlan p0, p1;
@@ -937,9 +1068,9 @@ int gx_deconv5x5s2_fwd(const float* x, const float* w, const float* bias, float*
     rc = plan_tapconv<M_DT1>(N, Cin, Cout, Mpad, Hin, Win, Hin, Win, 2 * Hin, 2 * Win, 1, &p1, "gx_deconv5x5s2_fwd");
     if (rc) return rc;
     float* dst = p0.g.nsplit > 1 ? part : y;
-    rc = launch_tapconv<M_DT0>(x, wp0, bias, dst, p0, s, "gx_deconv5x5s2_fwd(a=0)");
+    rc = launch_tapconv<M_DT0>(x, wpu0, bias, dst, p0, s, "gx_deconv5x5s2_fwd(a=0)");
     if (rc) return rc;
-    rc = launch_tapconv<M_DT1>(x, wp1, bias, dst, p1, s, "gx_deconv5x5s2_fwd(a=1)");
+    rc = launch_tapconv<M_DT1>(x, wpu1, bias, dst, p1, s, "gx_deconv5x5s2_fwd(a=1)");
     if (rc) return rc;
     if (p0.g.nsplit > 1) return launch_splitk_reduce(part, bias, y, p0, s);
     return GX_OK;
@@ -958,12 +1089,13 @@ int gx_deconv5x5s2_dgrad(const float* dy, const float* w, float* dx, int N, int 
     hipStream_t s = (hipStream_t)stream;
     float* wp = (float*)ws;
     float* part = wp + deconv_pack_floats(Cin, Cout);
-    rc = launch_pack(w, wp, 4, Cout, Cin, 25, Kpad, Mpad, s);
+    const float* wpu;
+    rc = launch_pack(w, wp, 4, Cout, Cin, 25, Kpad, Mpad, s, &wpu);
     if (rc) return rc;
     TapPlan pl;
     rc = plan_tapconv<M_DG>(N, Cout, Cin_out, Mpad, Hin, Win, 2 * Hin, 2 * Win, Hin, Win, 0, &pl, "gx_deconv5x5s2_dgrad");
     if (rc) return rc;
-    rc = launch_tapconv<M_DG>(dy, wp, nullptr, pl.g.nsplit > 1 ? part : dx, pl, s, "gx_deconv5x5s2_dgrad");
+    rc = launch_tapconv<M_DG>(dy, wpu, nullptr, pl.g.nsplit > 1 ? part : dx, pl, s, "gx_deconv5x5s2_dgrad");
     if (rc) return rc;
     if (pl.g.nsplit > 1) return launch_splitk_reduce(part, nullptr, dx, pl, s);
     return GX_OK;

@@ -21,7 +21,7 @@ def _p(t):
 class TrainStep(object):
 
     def __init__(self, model, img_size, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, geco=None, use_geco=True,
-                 beta_fixed=0.5, process_group=None, graph=False, async_wgrad=False):
+                 beta_fixed=0.5, process_group=None, graph=False, async_wgrad=False, weight_cache=True):
         self.model = model
         self.lr, self.betas, self.eps = lr, betas, eps
         self.device = next(model.parameters()).device
@@ -34,6 +34,8 @@ class TrainStep(object):
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self._flatten()
+        self._wcache = _lib.query('gx_weight_cache_create') if weight_cache else None
+        self._wcache_ready = False
         self.step_t = torch.zeros((), dtype=torch.int64, device=self.device)
         self.graph = None
         self.use_graph = graph
@@ -59,11 +61,36 @@ class TrainStep(object):
         _fn.DIRECT_PARAM_GRADS = True    # bucket zeroed above; kernels write weight grads straight into it
         _fn.begin_direct_grads()
         _fn.ASYNC_WGRAD = self.async_wgrad
+        # packed-weight cache: the first (never graph-captured) iteration records which weight tensors the conv
+        # entry points pack; later iterations re-pack all of them in one launch up front
+        recording = False
+        if self._wcache is not None:
+            if not self._wcache_ready:
+                if not torch.cuda.is_current_stream_capturing():
+                    _lib.call('gx_weight_cache_record', self._wcache, 1)
+                    recording = True
+            else:
+                _lib.call('gx_weight_cache_refresh', self._wcache,
+                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         try:
             return self._iteration_body(x, **forward_kwargs)
         finally:
             _fn.DIRECT_PARAM_GRADS = False
             _fn.ASYNC_WGRAD = False
+            if self._wcache is not None:
+                if recording:
+                    _lib.call('gx_weight_cache_record', self._wcache, 0)
+                    self._wcache_ready = True
+                else:
+                    _lib.call('gx_weight_cache_release')
+
+    def __del__(self):
+        try:
+            if getattr(self, '_wcache', None) is not None:
+                _lib.call('gx_weight_cache_destroy', self._wcache)
+                self._wcache = None
+        except Exception:
+            pass
 
     def _iteration_body(self, x, **forward_kwargs):
         recon, losses, stats, att_stats, comp_stats = self.model(x, **forward_kwargs)

@@ -250,6 +250,20 @@ int gx_lstm_step_bwd(const float* g_h, const float* dgates_next, const float* w_
                      const float* c, const float* c_prev, const float* dc_next, int B, int H, float* dgates,
                      float* dc_prev, gx_stream_t stream);
 
+/* ---- packed-weight cache.  The conv / deconv entry points above re-pack their weight tensor into the MFMA
+ *      operand layout on every call; inside a training loop the weights change once per optimiser step, so:
+ *      id = gx_weight_cache_create(); gx_weight_cache_record(id, 1); <one iteration>; gx_weight_cache_record(id, 0)
+ *      registers every (weight pointer, layout) the iteration used (device buffers are allocated here -- do not
+ *      record inside a stream capture).  From then on gx_weight_cache_refresh(id, stream) re-packs all of them in
+ *      ONE launch and the entry points are served from the cache (matching weight pointer and shape) until
+ *      gx_weight_cache_release().  The caller guarantees the weights do not change inside that window. */
+int gx_weight_cache_create(void);
+int gx_weight_cache_record(int id, int on);
+int gx_weight_cache_size(int id);
+int gx_weight_cache_refresh(int id, gx_stream_t stream);
+int gx_weight_cache_release(void);
+int gx_weight_cache_destroy(int id);
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,3 +100,26 @@ def test_profile_collect():
     names = {r['name'] for r in rows}
     assert {'tapconv_kernel<0>', 'wgrad_kernel<0>', 'gn_relu_fwd_kernel', 'icsbp_fwd_kernel', 'adam_kernel'} <= names
     assert all(r['ms'] > 0 for r in rows)
+
+
+def test_weight_cache_matches_per_call_packing():
+    """The packed-weight cache (one batched re-pack per iteration) must not change a single bit of the training
+    trajectory relative to per-call packing."""
+    from genesis_amd import _lib
+    from genesis_amd.trainer import TrainStep
+    gold = Golden('tiny')
+    x, _, _ = gold.inputs()
+    xd = x.to(DEV)
+    outs = []
+    for cache in (False, True):
+        model = build(gold)
+        ts = TrainStep(model, gold.S, lr=1e-4, graph=False, weight_cache=cache)
+        res = []
+        for it in range(4):
+            rp, eps = gold.noise(1 + it % 3)
+            res.append(ts.step(xd, rand_pixel=rp.to(DEV), eps=torch.stack(eps).to(DEV)).clone())
+        outs.append((torch.stack(res), ts.flat_p.clone()))
+        if cache:
+            assert _lib.query('gx_weight_cache_size', ts._wcache) > 10
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
