@@ -92,13 +92,13 @@ __device__ __forceinline__ float gx_act(float v, int act) {
 
 // NPOS = halo-tile positions staged per thread per channel (tile <= NPOS*256 floats per channel).
 template <int MODE, int NPOS>
-__global__ void __launch_bounds__(256, 2)
-tapconv_kernel(const float* __restrict__ in, const float* __restrict__ wp,
-               const float* __restrict__ bias, float* __restrict__ out, ConvGeom g) {
+__device__ __forceinline__ void tapconv_body(const float* __restrict__ in, const float* __restrict__ wp,
+                                             const float* __restrict__ bias, float* __restrict__ out,
+                                             const ConvGeom& g, float* lds, const int bx, const int by, const int bz,
+                                             const int par_a) {
     using TC = TapCfg<MODE>;
     constexpr int NT = TC::NT, NCLS = TC::NCLS, KC = TC::KC, PLANES = TC::PLANES;
     constexpr int NW4 = (NT * KC * 16 + 255) / 256;   // float4 weight loads per thread per chunk
-    extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -110,12 +110,12 @@ tapconv_kernel(const float* __restrict__ in, const float* __restrict__ wp,
     const int BUF = KC * CHS + NT * KC * 64;       // floats per pipeline stage: [KC][CHS] input + [NT][KC][64] weights
 
     // ---- which tile ----
-    int tile = blockIdx.x;
+    int tile = bx;
     const int tw_i = tile % g.tiles_w; tile /= g.tiles_w;
     const int th_i = tile % g.tiles_h; tile /= g.tiles_h;
     const int img0 = tile * G;
     const int R0 = th_i * TH, C0 = tw_i * TW;
-    const int m0 = blockIdx.y * 64;
+    const int m0 = by * 64;
 
     const size_t in_img_stride = (size_t)g.K * g.Hi * g.Wi;
     const float* in_blk = in + (size_t)img0 * in_img_stride;
@@ -175,7 +175,7 @@ tapconv_kernel(const float* __restrict__ in, const float* __restrict__ wp,
     float xin[KC][NPOS];
     f32x4 wreg[NW4];
     const int nchunks = g.Kpad / KC;
-    const int c_begin = blockIdx.z * g.chunks_per_split;
+    const int c_begin = bz * g.chunks_per_split;
     int c_end = c_begin + g.chunks_per_split;
     if (c_end > nchunks) c_end = nchunks;
 
@@ -243,7 +243,7 @@ tapconv_kernel(const float* __restrict__ in, const float* __restrict__ wp,
     // ---- epilogue: C/D layout col = lane&31 (pixel), row = (reg&3)+8*(reg>>2)+4*(lane>>5) (channel) ----
     const size_t out_img_stride = (size_t)g.M * g.Ho * g.Wo;
     const int HoWo = g.Ho * g.Wo;
-    float* outz = out + (size_t)blockIdx.z * g.N * out_img_stride;   // partial slab when nsplit > 1
+    float* outz = out + (size_t)bz * g.N * out_img_stride;   // partial slab when nsplit > 1
     const bool add_bias = bias != nullptr && g.nsplit == 1;
     const int act = g.nsplit == 1 ? g.act : 0;
 #pragma unroll
@@ -255,7 +255,7 @@ tapconv_kernel(const float* __restrict__ in, const float* __restrict__ wp,
         const int n = img0 + gi;
         if (n >= g.N || R0 + r >= g.Hb || C0 + c >= g.Wb) continue;   // partial tiles of non-power-of-two grids
         int orow, ocol;
-        if (NCLS == 2) { orow = 2 * (R0 + r) + g.par_a; ocol = 2 * (C0 + c); }
+        if (NCLS == 2) { orow = 2 * (R0 + r) + par_a; ocol = 2 * (C0 + c); }
         else { orow = R0 + r; ocol = C0 + c; }
         float* obase = outz + (size_t)n * out_img_stride + (size_t)orow * g.Wo + ocol;
 #pragma unroll
@@ -277,6 +277,28 @@ tapconv_kernel(const float* __restrict__ in, const float* __restrict__ wp,
             }
         }
     }
+}
+
+template <int MODE, int NPOS>
+__global__ void __launch_bounds__(256, 2)
+tapconv_kernel(const float* __restrict__ in, const float* __restrict__ wp,
+               const float* __restrict__ bias, float* __restrict__ out, ConvGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    tapconv_body<MODE, NPOS>(in, wp, bias, out, g, lds, blockIdx.x, blockIdx.y, blockIdx.z, g.par_a);
+}
+
+// Both output-row parities of the transposed conv in one launch: blockIdx.y = 2 * channel_tile + parity.  Twice
+// the workgroups of a single-parity launch, so mid-sized layers fill the chip without splitting the channel
+// reduction (and without the partial-sum traffic and reduce pass that come with it).
+template <int NPOS>
+__global__ void __launch_bounds__(256, 2)
+tapconv_dt_kernel(const float* __restrict__ in, const float* __restrict__ wp0, const float* __restrict__ wp1,
+                  const float* __restrict__ bias, float* __restrict__ out, ConvGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (blockIdx.y & 1)
+        tapconv_body<M_DT1, NPOS>(in, wp1, bias, out, g, lds, blockIdx.x, blockIdx.y >> 1, blockIdx.z, 1);
+    else
+        tapconv_body<M_DT0, NPOS>(in, wp0, bias, out, g, lds, blockIdx.x, blockIdx.y >> 1, blockIdx.z, 0);
 }
 
 // out[i] = sum_z part[z][i] (+ bias[channel]); fixed summation order.
@@ -365,8 +387,9 @@ struct WgradGeom {
     int Ha, Wa;          // A spatial dims (= SA * base)
     int lTH, lTW, lG;
     int tiles_h, tiles_w, ntiles;
-    int nsplit;
+    int nsplit;          // partial slabs (max over classes for the merged deconv launch)
     int Ttot;            // taps in the partial buffer (9 or 25)
+    int cls_begin[5];    // merged deconv launch: blockIdx.x range of parity class c is [cls_begin[c], cls_begin[c+1])
 };
 
 // A operand (dy) goes global -> registers directly: the k (pixel) slots of the MFMA are assigned so that
@@ -374,14 +397,14 @@ struct WgradGeom {
 // 16-byte loads (the pairing of pixels to k slots is free as long as A and B agree).  Only the B operand
 // (x with its 1-pixel halo, re-used by all taps) is staged in LDS: double-buffered, prefetched
 // global -> registers one tile ahead while the current tile's MFMAs run; one barrier per tile.
+// sp / nsp: this workgroup's split index and the number of splits of its class (tiles sp, sp+nsp, ...)
 template <int WM>
-__global__ void __launch_bounds__(256, 1)
-wgrad_kernel(const float* __restrict__ a_src, const float* __restrict__ b_src,
-             float* __restrict__ partial, WgradGeom g) {
+__device__ __forceinline__ void wgrad_body(const float* __restrict__ a_src, const float* __restrict__ b_src,
+                                           float* __restrict__ partial, const WgradGeom& g, float* lds,
+                                           const int sp, const int nsp) {
     using WT = WTap<WM>;
     constexpr int NT = WT::NT;
     constexpr int NPOS = 1;              // halo tile <= 256 floats per channel (plan_wgrad picks tiles so)
-    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int TH = 1 << g.lTH, TW = 1 << g.lTW, G = 1 << g.lG;
     const int PT = TH * TW * G;          // pixels per tile (64 or 128)
@@ -496,10 +519,10 @@ wgrad_kernel(const float* __restrict__ a_src, const float* __restrict__ b_src,
         }                                                                                                      \
     }
 
-    int tile = blockIdx.x;
+    int tile = sp;
     if (tile < g.ntiles) GX_WG_PREFETCH(tile)
     int it = 0;
-    for (; tile < g.ntiles; tile += g.nsplit, ++it) {
+    for (; tile < g.ntiles; tile += nsp, ++it) {
         float* buf = lds + (it & 1) * BUF;
 #pragma unroll
         for (int q = 0; q < NPOS; ++q) {
@@ -510,7 +533,7 @@ wgrad_kernel(const float* __restrict__ a_src, const float* __restrict__ b_src,
             }
         }
         __syncthreads();
-        if (tile + g.nsplit < g.ntiles) GX_WG_PREFETCH(tile + g.nsplit)
+        if (tile + nsp < g.ntiles) GX_WG_PREFETCH(tile + nsp)
 
         // ---- K loop: this lane's k slot covers pixels [khalf*PT/2, (khalf+1)*PT/2) of the tile.  A values are
         //      fetched global -> registers one batch (4 groups = 16 k-steps = 16*NT MFMAs) ahead of their use.
@@ -518,7 +541,7 @@ wgrad_kernel(const float* __restrict__ a_src, const float* __restrict__ b_src,
         if (it == 0) GX_WG_LOAD_A(tile, 0, acur)
         for (int bt = 0; bt < nbatches; ++bt) {
             if (bt + 1 < nbatches) GX_WG_LOAD_A(tile, bt + 1, anxt)
-            else if (tile + g.nsplit < g.ntiles) GX_WG_LOAD_A(tile + g.nsplit, 0, anxt)
+            else if (tile + nsp < g.ntiles) GX_WG_LOAD_A(tile + nsp, 0, anxt)
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
 #pragma unroll
@@ -540,7 +563,7 @@ wgrad_kernel(const float* __restrict__ a_src, const float* __restrict__ b_src,
     // partial[split][gt][ca][cb]
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        float* dst = partial + (((size_t)blockIdx.x * g.Ttot + WT::gt(t)) * g.CApad + ca0 + wm * 32) * g.CBpad +
+        float* dst = partial + (((size_t)sp * g.Ttot + WT::gt(t)) * g.CApad + ca0 + wm * 32) * g.CBpad +
                      cb0 + wn * 32 + (lane & 31);
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
@@ -550,11 +573,37 @@ wgrad_kernel(const float* __restrict__ a_src, const float* __restrict__ b_src,
     }
 }
 
+template <int WM>
+__global__ void __launch_bounds__(256, 1)
+wgrad_kernel(const float* __restrict__ a_src, const float* __restrict__ b_src,
+             float* __restrict__ partial, WgradGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    wgrad_body<WM>(a_src, b_src, partial, g, lds, blockIdx.x, g.nsplit);
+}
+
+// All four output-parity classes of the transposed conv's weight gradient in ONE launch: blockIdx.x ranges are
+// assigned per class in proportion to its taps (9 : 6 : 6 : 4) so that every workgroup does about the same work,
+// and the 9-tap class is dispatched first.
+__global__ void __launch_bounds__(256, 1)
+wgrad_deconv_kernel(const float* __restrict__ a_src, const float* __restrict__ b_src,
+                    float* __restrict__ partial, WgradGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int bx = blockIdx.x;
+    if (bx < g.cls_begin[1])
+        wgrad_body<W_D00>(a_src, b_src, partial, g, lds, bx, g.cls_begin[1]);
+    else if (bx < g.cls_begin[2])
+        wgrad_body<W_D01>(a_src, b_src, partial, g, lds, bx - g.cls_begin[1], g.cls_begin[2] - g.cls_begin[1]);
+    else if (bx < g.cls_begin[3])
+        wgrad_body<W_D10>(a_src, b_src, partial, g, lds, bx - g.cls_begin[2], g.cls_begin[3] - g.cls_begin[2]);
+    else
+        wgrad_body<W_D11>(a_src, b_src, partial, g, lds, bx - g.cls_begin[3], g.cls_begin[4] - g.cls_begin[3]);
+}
+
 // dW = sum over splits.  layout 0: W[ca][cb][T] (conv3x3: ca=co, cb=ci); layout 1: W[cb][ca][T] (deconv).
 // Block = 64 consecutive (t, ca, cb) elements x 4 interleaved split groups (fixed summation order).
 __global__ void __launch_bounds__(256)
-wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int nsplit,
-                    int Ttot, int CA, int CB, int CApad, int CBpad, int layout) {
+wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int nsplit_all,
+                    int Ttot, int CA, int CB, int CApad, int CBpad, int layout, int ns0, int ns1, int ns2, int ns3) {
     __shared__ float red[4][64];
     const int total = Ttot * CA * CB;
     const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -565,6 +614,12 @@ wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, i
         cb = idx % CB;
         ca = (idx / CB) % CA;
         t = idx / (CB * CA);
+        // merged deconv launch: the splits of tap t are those of its parity class (kh & 1, kw & 1)
+        int nsplit = nsplit_all;
+        if (ns0 > 0) {
+            const int cls = ((t / 5) & 1) * 2 + ((t % 5) & 1);
+            nsplit = cls == 0 ? ns0 : (cls == 1 ? ns1 : (cls == 2 ? ns2 : ns3));
+        }
         const size_t stride = (size_t)Ttot * CApad * CBpad;
         const float* p = partial + ((size_t)t * CApad + ca) * CBpad + cb;
         float s0 = 0.f, s1 = 0.f;
@@ -617,7 +672,7 @@ struct TapPlan {
 
 template <int MODE>
 int plan_tapconv(int N, int K, int M, int Mpad_pack, int Hb, int Wb, int Hi, int Wi, int Ho, int Wo, int par_a,
-                 TapPlan* pl, const char* name) {
+                 TapPlan* pl, const char* name, int ymult = 1) {
     using TC = TapCfg<MODE>;
     ConvGeom& g = pl->g;
     g.N = N; g.K = K; g.M = M;
@@ -640,7 +695,7 @@ int plan_tapconv(int N, int K, int M, int Mpad_pack, int Hb, int Wb, int Hi, int
     const int nchunks = g.Kpad / TC::KC;
     // split the channel reduction when the (pixel-tile x channel-tile) grid cannot fill 256 CUs x 2
     int nsplit = 1;
-    const int base = ptiles * mtiles;
+    const int base = ptiles * mtiles * ymult;   // ymult: parity classes sharing the launch
     if (base < 384) {
         nsplit = gx_ceil_div(512, base);
         if (nsplit > nchunks) nsplit = nchunks;
@@ -798,13 +853,38 @@ int plan_wgrad(int N, int CA, int CB, int Hb, int Wb, int SA, int Ttot, int ncls
     g.tiles_h = gx_ceil_div(Hb, TH); g.tiles_w = gx_ceil_div(Wb, TW);
     g.ntiles = g.tiles_h * g.tiles_w * gx_ceil_div(N, G);
     // one workgroup per CU is resident (LDS-bound, 1 wave/SIMD): size each launch to ~one wave of 256 CUs
-    (void)ncls_launches;
     const int chan_blocks = (g.CApad / 64) * (g.CBpad / 64);
     int nsplit = gx_ceil_div(256, chan_blocks);
     if (nsplit > g.ntiles) nsplit = g.ntiles;
     if (nsplit < 1) nsplit = 1;
     g.nsplit = nsplit;
     g.Ttot = Ttot;
+    for (int c = 0; c < 5; ++c) g.cls_begin[c] = 0;
+    // (the merged kernel carries four unrolled bodies, ~140 KB of code: it thrashes the 64 KB instruction cache once
+    //  the classes run long enough to matter, so it is used only where a class launch cannot fill the chip)
+    if (ncls_launches == 4 && g.ntiles < 256) {
+        // merged launch: hand the ~256/chan_blocks workgroup budget to the classes greedily so that the largest
+        // per-workgroup cost taps_c * ceil(ntiles / splits_c) is minimised
+        const int taps[4] = {9, 6, 6, 4};
+        int sp[4] = {1, 1, 1, 1};
+        int budget = gx_ceil_div(256, chan_blocks) - 4;
+        auto cost = [&](int c, int k) { return taps[c] * gx_ceil_div(g.ntiles, k); };
+        while (budget > 0) {
+            int worst = 0;
+            for (int c = 1; c < 4; ++c) if (cost(c, sp[c]) > cost(worst, sp[worst])) worst = c;
+            if (sp[worst] >= g.ntiles) break;
+            // next split count that actually lowers this class's cost
+            int k = sp[worst] + 1;
+            while (k < g.ntiles && cost(worst, k) == cost(worst, sp[worst])) ++k;
+            if (k - sp[worst] > budget) break;
+            budget -= k - sp[worst];
+            sp[worst] = k;
+        }
+        int mx = 0;
+        for (int c = 0; c < 4; ++c) { g.cls_begin[c + 1] = g.cls_begin[c] + sp[c]; mx = sp[c] > mx ? sp[c] : mx; }
+        g.nsplit = mx;
+        nsplit = mx;
+    }
     const int CHS = G * (TH + 2) * (TW + 2);
     pl->lds_bytes = (size_t)2 * 64 * (CHS | 1) * sizeof(float);   // double-buffered B (x halo) tile
     pl->ws_floats = (size_t)nsplit * Ttot * g.CApad * g.CBpad;
@@ -834,13 +914,38 @@ int launch_wgrad(const float* a, const float* b, float* partial, const WgradPlan
     return GX_OK;
 }
 
+int launch_wgrad_deconv(const float* a, const float* b, float* partial, const WgradPlan& pl, hipStream_t s,
+                        const char* name) {
+    if (pl.lds_bytes > 160 * 1024) { gx_set_error("%s: LDS %zu > 160KiB", name, pl.lds_bytes); return GX_EINVAL; }
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_deconv_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const WgradGeom& g = pl.g;
+    dim3 grid(g.cls_begin[4], (g.CApad / 64) * (g.CBpad / 64));
+    {
+        const double flops = 2.0 * g.N * (double)g.CA * g.CB * 25 * g.Hb * g.Wb;
+        const double bytes = 4.0 * ((double)g.N * g.CA * g.Ha * g.Wa + (double)g.N * g.CB * g.Hb * g.Wb +
+                                    (double)g.cls_begin[4] * 6.25 * g.CApad * g.CBpad);
+        GxProf pf(KID_WGRAD_D00, s, flops, bytes);
+        hipLaunchKernelGGL(wgrad_deconv_kernel, grid, dim3(256), pl.lds_bytes, s, a, b, partial, pl.g);
+    }
+    GX_CHECK_LAUNCH(name);
+    return GX_OK;
+}
+
 int launch_wgrad_reduce(const float* partial, float* dw, const WgradPlan& pl, int layout, hipStream_t s) {
     const int total = pl.g.Ttot * pl.g.CA * pl.g.CB;
     const int blocks = gx_ceil_div(total, 64);
     {
         GxProf pf(KID_WGRAD_REDUCE, s, 0.0, 4.0 * ((double)pl.g.nsplit + 1.0) * total);
+        const int* cb = pl.g.cls_begin;
+        const bool merged = cb[4] > 0;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, partial, dw, pl.g.nsplit, pl.g.Ttot,
-                           pl.g.CA, pl.g.CB, pl.g.CApad, pl.g.CBpad, layout);
+                           pl.g.CA, pl.g.CB, pl.g.CApad, pl.g.CBpad, layout, merged ? cb[1] - cb[0] : 0,
+                           merged ? cb[2] - cb[1] : 0, merged ? cb[3] - cb[2] : 0, merged ? cb[4] - cb[3] : 0);
     }
     GX_CHECK_LAUNCH("wgrad_reduce");
     return GX_OK;
@@ -1061,17 +1166,38 @@ int gx_deconv5x5s2_fwd(const float* x, const float* w, const float* bias, float*
     if (rc) return rc;
     rc = launch_pack(w, wp1, 3, Cout, Cin, 10, Kpad, Mpad, s, &wpu1);
     if (rc) return rc;
-    // both row parities share one split plan (same channel chunking) so that one reduce finishes the layer
-    TapPlan p0, p1;
-    rc = plan_tapconv<M_DT0>(N, Cin, Cout, Mpad, Hin, Win, Hin, Win, 2 * Hin, 2 * Win, 0, &p0, "gx_deconv5x5s2_fwd");
-    if (rc) return rc;
-    rc = plan_tapconv<M_DT1>(N, Cin, Cout, Mpad, Hin, Win, Hin, Win, 2 * Hin, 2 * Win, 1, &p1, "gx_deconv5x5s2_fwd");
+    // both row parities in one launch (they share the pixel tiling and the channel split, so one reduce
+    // finishes the layer)
+    TapPlan p0;
+    rc = plan_tapconv<M_DT0>(N, Cin, Cout, Mpad, Hin, Win, Hin, Win, 2 * Hin, 2 * Win, 0, &p0, "gx_deconv5x5s2_fwd", 2);
     if (rc) return rc;
     float* dst = p0.g.nsplit > 1 ? part : y;
-    rc = launch_tapconv<M_DT0>(x, wpu0, bias, dst, p0, s, "gx_deconv5x5s2_fwd(a=0)");
-    if (rc) return rc;
-    rc = launch_tapconv<M_DT1>(x, wpu1, bias, dst, p1, s, "gx_deconv5x5s2_fwd(a=1)");
-    if (rc) return rc;
+    {
+        const ConvGeom& g = p0.g;
+        const double flops = 2.0 * g.N * (double)g.M * g.K * 25 * g.Hb * g.Wb;
+        const double bytes = 4.0 * ((double)g.N * g.K * g.Hi * g.Wi + (double)g.N * g.M * g.Ho * g.Wo +
+                                    25.0 * g.K * g.M);
+        GxProf pf(KID_TAPCONV_DT0, s, flops, bytes);
+        dim3 grid(p0.grid.x, p0.grid.y * 2, p0.grid.z);
+        if (p0.npos == 2) {
+            static bool attr2 = false;
+            if (!attr2) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_dt_kernel<2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr2 = true;
+            }
+            hipLaunchKernelGGL((tapconv_dt_kernel<2>), grid, dim3(256), p0.lds_bytes, s, x, wpu0, wpu1, bias, dst, p0.g);
+        } else {
+            static bool attr4 = false;
+            if (!attr4) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_dt_kernel<4>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr4 = true;
+            }
+            hipLaunchKernelGGL((tapconv_dt_kernel<4>), grid, dim3(256), p0.lds_bytes, s, x, wpu0, wpu1, bias, dst, p0.g);
+        }
+    }
+    GX_CHECK_LAUNCH("gx_deconv5x5s2_fwd");
     if (p0.g.nsplit > 1) return launch_splitk_reduce(part, bias, y, p0, s);
     return GX_OK;
 }
@@ -1117,10 +1243,15 @@ int gx_deconv5x5s2_wgrad(const float* x, const float* dy, float* dw, int N, int 
     GX_CHECK_ARG(ws_bytes >= pl.ws_floats * sizeof(float), "gx_deconv5x5s2_wgrad: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     float* part = (float*)ws;
-    rc = launch_wgrad<W_D00>(dy, x, part, pl, s, "gx_deconv5x5s2_wgrad(0,0)"); if (rc) return rc;
-    rc = launch_wgrad<W_D01>(dy, x, part, pl, s, "gx_deconv5x5s2_wgrad(0,1)"); if (rc) return rc;
-    rc = launch_wgrad<W_D10>(dy, x, part, pl, s, "gx_deconv5x5s2_wgrad(1,0)"); if (rc) return rc;
-    rc = launch_wgrad<W_D11>(dy, x, part, pl, s, "gx_deconv5x5s2_wgrad(1,1)"); if (rc) return rc;
+    if (pl.g.cls_begin[4] > 0) {
+        rc = launch_wgrad_deconv(dy, x, part, pl, s, "gx_deconv5x5s2_wgrad");
+        if (rc) return rc;
+    } else {
+        rc = launch_wgrad<W_D00>(dy, x, part, pl, s, "gx_deconv5x5s2_wgrad(0,0)"); if (rc) return rc;
+        rc = launch_wgrad<W_D01>(dy, x, part, pl, s, "gx_deconv5x5s2_wgrad(0,1)"); if (rc) return rc;
+        rc = launch_wgrad<W_D10>(dy, x, part, pl, s, "gx_deconv5x5s2_wgrad(1,0)"); if (rc) return rc;
+        rc = launch_wgrad<W_D11>(dy, x, part, pl, s, "gx_deconv5x5s2_wgrad(1,1)"); if (rc) return rc;
+    }
     return launch_wgrad_reduce(part, dw, pl, 1, s);
 }
 

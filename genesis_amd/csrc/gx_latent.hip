@@ -238,15 +238,24 @@ pooled_head_bwd_kernel(const float* __restrict__ lin, const float* __restrict__ 
     if (lane == 0) dmsum[row] = (float)dm;
 }
 
+// 32 columns x 8 row groups per block; row groups are combined through LDS in a fixed order
 __global__ void __launch_bounds__(256)
 pooled_head_cols_kernel(const float* __restrict__ cols, int R, int C, float* __restrict__ dgamma,
                         float* __restrict__ dbeta, float* __restrict__ dfbias) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over 3*C
-    if (i >= 3 * C) return;
+    __shared__ double red[8][32];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + cl;   // over 3*C
     double s = 0.0;
-    for (int r = 0; r < R; ++r) s += (double)cols[(size_t)r * 3 * C + i];
-    const int which = i / C, j = i - which * C;
-    (which == 0 ? dgamma : (which == 1 ? dbeta : dfbias))[j] = (float)s;
+    if (i < 3 * C)
+        for (int r = rg; r < R; r += 8) s += (double)cols[(size_t)r * 3 * C + i];
+    red[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && i < 3 * C) {
+        double t = red[0][cl];
+        for (int q = 1; q < 8; ++q) t += red[q][cl];
+        const int which = i / C, j = i - which * C;
+        (which == 0 ? dgamma : (which == 1 ? dbeta : dfbias))[j] = (float)t;
+    }
 }
 
 int check_bkd(const char* name, int B, int K, int D) {
@@ -382,7 +391,7 @@ int gx_pooled_head_bwd(const float* lin, const float* msum, const float* fbias, 
     GX_CHECK_LAUNCH("gx_pooled_head_bwd");
     {
         GxProf pf(KID_LATENT, s, 0.0, 4.0 * 3.0 * R * C);
-        hipLaunchKernelGGL(pooled_head_cols_kernel, dim3(gx_ceil_div(3 * C, 256)), dim3(256), 0, s,
+        hipLaunchKernelGGL(pooled_head_cols_kernel, dim3(gx_ceil_div(3 * C, 32)), dim3(256), 0, s,
                            (const float*)ws, R, C, dgamma, dbeta, dfbias);
     }
     GX_CHECK_LAUNCH("gx_pooled_head_bwd(cols)");
