@@ -28,6 +28,7 @@
 // what the stated fp32 parity tolerance of the path needs (no bf16/xf32 shortcuts).
 #include "gx_common.h"
 
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -581,6 +582,179 @@ wgrad_kernel(const float* __restrict__ a_src, const float* __restrict__ b_src,
     wgrad_body<WM>(a_src, b_src, partial, g, lds, blockIdx.x, g.nsplit);
 }
 
+// ---- lean variant for the common case (tile width >= 4, grid width a multiple of 4) ------------------------
+// PMC on the kernel above (64->64 @64x64, B=32): 3.4 non-MFMA VALU + 1.3 SALU + 0.8 LDS instructions per MFMA and
+// one wave per SIMD: the wave cannot issue them all under a 64-cycle MFMA, the matrix pipe sits at 62 %.  Here the
+// per-lane A offsets and LDS halo offsets of every (batch, group) are computed ONCE per kernel (the pixel -> k-slot
+// assignment does not depend on the tile), the tile width is a template parameter so that every tap / pixel offset
+// of the LDS reads is an instruction immediate, and the batch loop is unrolled with two alternating A buffers (no
+// register copies): ~1 VALU per MFMA is left.
+template <int WM, int LTW>
+__global__ void __launch_bounds__(256, 1)
+wgrad_fast_kernel(const float* __restrict__ a_src, const float* __restrict__ b_src,
+                  float* __restrict__ partial, const float* __restrict__ zeros, WgradGeom g) {
+    using WT = WTap<WM>;
+    constexpr int NT = WT::NT;
+    constexpr int TW = 1 << LTW, HS = TW + 2;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int TH = 1 << g.lTH, G = 1 << g.lG;
+    const int PT = TH * TW * G;          // pixels per tile (32, 64 or 128)
+    const int nb = PT >> 5;              // A batches per tile (1, 2 or 4)
+    const int CHS = G * (TH + 2) * HS;
+    const int BS = CHS | 1;
+    const int BUF = 64 * BS;
+    const int sp = blockIdx.x, nsp = g.nsplit;
+
+    const int nbt = g.CBpad / 64;
+    const int ca0 = (blockIdx.y / nbt) * 64;
+    const int cb0 = (blockIdx.y % nbt) * 64;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int a_img = g.CA * g.Ha * g.Wa;             // the host dispatch guarantees these fit 31 bits
+    const int b_img = g.CB * g.Hb * g.Wb;
+    const int HaWa = g.Ha * g.Wa, HbWb = g.Hb * g.Wb;
+    const int nvalid_ch = g.CB - cb0 < 64 ? g.CB - cb0 : 64;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    const int ca_l = ca0 + wm * 32 + (lane & 31);
+    const bool ca_ok = ca_l < g.CA;
+    const int khalf = lane >> 5;
+    const int b_row = (wn * 32 + (lane & 31)) * BS;
+    const float* a_lane = a_src + (size_t)(ca_ok ? ca_l : 0) * HaWa + WT::PA * g.Wa;
+    const bool exact = (g.tiles_h << g.lTH) == g.Hb && g.tiles_w * TW == g.Wb && (g.N & (G - 1)) == 0;
+    const int jlane = khalf * (PT >> 1);               // first pixel of this lane's k slot
+
+#define GX_WF_ORIGIN(tile_, img0_, R0_, C0_)                           \
+    int img0_, R0_, C0_;                                               \
+    {                                                                  \
+        int tt_ = (tile_);                                             \
+        const int tw_i_ = tt_ % g.tiles_w; tt_ /= g.tiles_w;           \
+        const int th_i_ = tt_ % g.tiles_h; tt_ /= g.tiles_h;           \
+        img0_ = tt_ * G; R0_ = th_i_ << g.lTH; C0_ = tw_i_ * TW;       \
+    }
+    // B (x halo tile) goes global -> LDS directly (LDS-DMA): thread `tid` owns halo position `tid` of every channel;
+    // positions outside the image (and channels beyond CB) are fetched from a zero page so that no lane needs a
+    // register, a select or an LDS store.  Destination: wave-uniform base + lane * 4 bytes.
+#define GX_WF_PREFETCH_B(tile_, dstbuf_)                                                             \
+    {                                                                                                \
+        GX_WF_ORIGIN(tile_, pi0, pR0, pC0)                                                           \
+        if (tid < CHS) {                                                                             \
+            int rem = tid;                                                                           \
+            const int gi = rem / ((TH + 2) * HS); rem -= gi * (TH + 2) * HS;                         \
+            const int i = rem / HS;                                                                  \
+            const int jj = rem - i * HS;                                                             \
+            const int row = pR0 - 1 + i, col = pC0 - 1 + jj;                                         \
+            const bool inb = pi0 + gi < g.N && row >= 0 && row < g.Hb && col >= 0 && col < g.Wb;     \
+            const float* lp = inb ? b_src + (size_t)(pi0 + gi) * b_img + (size_t)cb0 * HbWb + row * g.Wb + col \
+                                  : zeros;                                                           \
+            float* ldst = (dstbuf_) + wave * 64;                                                     \
+            _Pragma("unroll") for (int ch = 0; ch < 64; ++ch) {                                      \
+                const float* gp = (ch < nvalid_ch ? lp : zeros) + (size_t)ch * HbWb;                 \
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,  \
+                                                 (__attribute__((address_space(3))) void*)(ldst + ch * BS), \
+                                                 4, 0, 0);                                           \
+            }                                                                                        \
+        }                                                                                            \
+    }
+    // one batch of A: 4 groups x 4 consecutive pixels of this lane's channel row
+#define GX_WF_LOAD_A(tile_, bt_, dst_)                                                               \
+    {                                                                                                \
+        GX_WF_ORIGIN(tile_, ai0, aR0, aC0)                                                           \
+        const float* abase = a_lane + (size_t)ai0 * a_img + (size_t)(WT::SA * aR0) * g.Wa + WT::SA * aC0; \
+        _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                           \
+            const int j0 = jlane + 4 * (4 * (bt_) + gq);                                             \
+            const int c = j0 & (TW - 1);                                                             \
+            const int r = (j0 >> LTW) & (TH - 1);                                                    \
+            const int gi = j0 >> (LTW + g.lTH);                                                      \
+            bool ok = ca_ok;                                                                         \
+            if (!exact) ok = ok && ai0 + gi < g.N && aR0 + r < g.Hb && aC0 + c < g.Wb;               \
+            const float* ap = ok ? abase + (gi * a_img + WT::SA * r * g.Wa + WT::SA * c) : a_src;    \
+            if (WT::SA == 1) {                                                                       \
+                const f32x4 v = *reinterpret_cast<const f32x4*>(ap);                                 \
+                dst_[gq][0] = ok ? v[0] : 0.f; dst_[gq][1] = ok ? v[1] : 0.f;                        \
+                dst_[gq][2] = ok ? v[2] : 0.f; dst_[gq][3] = ok ? v[3] : 0.f;                        \
+            } else {                                                                                 \
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(ap);                                \
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(ap + 4);                            \
+                dst_[gq][0] = ok ? v0[WT::PB] : 0.f; dst_[gq][1] = ok ? v0[WT::PB + 2] : 0.f;        \
+                dst_[gq][2] = ok ? v1[WT::PB] : 0.f; dst_[gq][3] = ok ? v1[WT::PB + 2] : 0.f;        \
+            }                                                                                        \
+        }                                                                                            \
+    }
+#define GX_WF_COMPUTE(bt_, src_)                                                                     \
+    {                                                                                                \
+        _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                           \
+            const int j0 = jlane + 4 * (4 * (bt_) + gq);                                             \
+            const int c = j0 & (TW - 1);                                                             \
+            const int r = (j0 >> LTW) & (TH - 1);                                                    \
+            const int gi = j0 >> (LTW + g.lTH);                                                      \
+            const float* bp = buf + b_row + (gi * (TH + 2) + r) * HS + c;                            \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                          \
+                _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                     \
+                    const float b = bp[WT::ro(t) * HS + WT::co(t) + u];                              \
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(src_[gq][u], b, acc[t], 0, 0, 0);  \
+                }                                                                                    \
+            }                                                                                        \
+        }                                                                                            \
+    }
+
+    float a0[4][4], a1[4][4];
+    int tile = sp;
+    if (tile < g.ntiles) {
+        GX_WF_PREFETCH_B(tile, lds)
+        GX_WF_LOAD_A(tile, 0, a0)
+    }
+    int it = 0;
+    for (; tile < g.ntiles; tile += nsp, ++it) {
+        float* buf = lds + (it & 1) * BUF;
+        __syncthreads();     // this tile's B has landed (vmcnt drained before the barrier); the other buffer is free
+        const bool more = tile + nsp < g.ntiles;
+        if (more) GX_WF_PREFETCH_B(tile + nsp, lds + ((it + 1) & 1) * BUF)
+        if (nb == 4) {
+            GX_WF_LOAD_A(tile, 1, a1)
+            GX_WF_COMPUTE(0, a0)
+            GX_WF_LOAD_A(tile, 2, a0)
+            GX_WF_COMPUTE(1, a1)
+            GX_WF_LOAD_A(tile, 3, a1)
+            GX_WF_COMPUTE(2, a0)
+            if (more) GX_WF_LOAD_A(tile + nsp, 0, a0)
+            GX_WF_COMPUTE(3, a1)
+        } else if (nb == 2) {
+            GX_WF_LOAD_A(tile, 1, a1)
+            GX_WF_COMPUTE(0, a0)
+            if (more) GX_WF_LOAD_A(tile + nsp, 0, a0)
+            GX_WF_COMPUTE(1, a1)
+        } else {
+            if (more) GX_WF_LOAD_A(tile + nsp, 0, a1)
+            GX_WF_COMPUTE(0, a0)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a0[gq][u] = a1[gq][u];
+        }
+    }
+#undef GX_WF_ORIGIN
+#undef GX_WF_PREFETCH_B
+#undef GX_WF_LOAD_A
+#undef GX_WF_COMPUTE
+    // partial[split][gt][ca][cb]
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        float* dst = partial + (((size_t)sp * g.Ttot + WT::gt(t)) * g.CApad + ca0 + wm * 32) * g.CBpad +
+                     cb0 + wn * 32 + (lane & 31);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            dst[(size_t)row * g.CBpad] = acc[t][reg];
+        }
+    }
+}
+
 // All four output-parity classes of the transposed conv's weight gradient in ONE launch: blockIdx.x ranges are
 // assigned per class in proportion to its taps (9 : 6 : 6 : 4) so that every workgroup does about the same work,
 // and the 9-tap class is dispatched first.
@@ -891,6 +1065,33 @@ int plan_wgrad(int N, int CA, int CB, int Hb, int Wb, int SA, int Ttot, int ncls
     return GX_OK;
 }
 
+// zero page for the LDS-DMA halo loads: 64 channels x (Hb*Wb <= 65536) floats, allocated at first use
+constexpr size_t kZeroFloats = (size_t)64 * 65536;
+const float* g_zero_page = nullptr;
+
+const float* zero_page(hipStream_t s) {
+    if (g_zero_page) return g_zero_page;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
+    float* p = nullptr;
+    if (hipMalloc((void**)&p, kZeroFloats * sizeof(float)) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, kZeroFloats * sizeof(float)) != hipSuccess) { (void)hipFree(p); return nullptr; }
+    g_zero_page = p;
+    return g_zero_page;
+}
+
+template <int WM, int LTW>
+void launch_wgrad_fast(dim3 grid, size_t lds_bytes, hipStream_t s, const float* a, const float* b, float* partial,
+                       const float* zeros, const WgradGeom& g) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_fast_kernel<WM, LTW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad_fast_kernel<WM, LTW>), grid, dim3(256), lds_bytes, s, a, b, partial, zeros, g);
+}
+
 template <int WM>
 int launch_wgrad(const float* a, const float* b, float* partial, const WgradPlan& pl, hipStream_t s, const char* name) {
     if (pl.lds_bytes > 160 * 1024) { gx_set_error("%s: LDS %zu > 160KiB", name, pl.lds_bytes); return GX_EINVAL; }
@@ -908,7 +1109,22 @@ int launch_wgrad(const float* a, const float* b, float* partial, const WgradPlan
         const double bytes = 4.0 * ((double)g.N * g.CA * g.Hb * g.Wb + (double)g.N * g.CB * g.Hb * g.Wb +
                                     (double)g.nsplit * WT::NT * g.CApad * g.CBpad);
         GxProf pf(KID_WGRAD_C3 + WM, s, flops, bytes);
-        hipLaunchKernelGGL(wgrad_kernel<WM>, grid, dim3(256), pl.lds_bytes, s, a, b, partial, pl.g);
+        // lean kernel: 16-byte A loads (tile width >= 4 on a grid whose width is a multiple of 4), 31-bit offsets
+        const bool fast = g.lTW >= 2 && g.lTW <= 5 && (g.Wb & 3) == 0 && g.Hb < 1024 && g.Wb < 1024 &&
+                          (double)(1 << g.lG) * g.CA * g.Ha * g.Wa < 2.0e9 &&
+                          (double)(1 << g.lG) * g.CB * g.Hb * g.Wb < 2.0e9 && g.Hb * g.Wb <= 65536 &&
+                          !getenv("GENESIS_WGRAD_LEGACY");
+        const float* zeros = fast ? zero_page(s) : nullptr;
+        if (fast && zeros) {
+            switch (g.lTW) {
+                case 2: launch_wgrad_fast<WM, 2>(grid, pl.lds_bytes, s, a, b, partial, zeros, pl.g); break;
+                case 3: launch_wgrad_fast<WM, 3>(grid, pl.lds_bytes, s, a, b, partial, zeros, pl.g); break;
+                case 4: launch_wgrad_fast<WM, 4>(grid, pl.lds_bytes, s, a, b, partial, zeros, pl.g); break;
+                default: launch_wgrad_fast<WM, 5>(grid, pl.lds_bytes, s, a, b, partial, zeros, pl.g); break;
+            }
+        } else {
+            hipLaunchKernelGGL(wgrad_kernel<WM>, grid, dim3(256), pl.lds_bytes, s, a, b, partial, pl.g);
+        }
     }
     GX_CHECK_LAUNCH(name);
     return GX_OK;
