@@ -628,21 +628,30 @@ wgrad_fast_kernel(const float* __restrict__ a_src, const float* __restrict__ b_s
     const float* a_lane = a_src + (size_t)(ca_ok ? ca_l : 0) * HaWa + WT::PA * g.Wa;
     const bool exact = (g.tiles_h << g.lTH) == g.Hb && g.tiles_w * TW == g.Wb && (g.N & (G - 1)) == 0;
     const int jlane = khalf * (PT >> 1);               // first pixel of this lane's k slot
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // LDS-DMA bases are wave-uniform: keep them scalar
 
-#define GX_WF_ORIGIN(tile_, img0_, R0_, C0_)                           \
-    int img0_, R0_, C0_;                                               \
-    {                                                                  \
-        int tt_ = (tile_);                                             \
-        const int tw_i_ = tt_ % g.tiles_w; tt_ /= g.tiles_w;           \
-        const int th_i_ = tt_ % g.tiles_h; tt_ /= g.tiles_h;           \
-        img0_ = tt_ * G; R0_ = th_i_ << g.lTH; C0_ = tw_i_ * TW;       \
+    // tile origin (image, row, col) of the current and the next tile of this workgroup, advanced by carries
+    // (all wave-uniform SALU work; no per-tile integer divisions)
+    struct Org { int img, th, tw; };
+    const int d_tw = nsp % g.tiles_w, d_th = (nsp / g.tiles_w) % g.tiles_h, d_img = nsp / (g.tiles_w * g.tiles_h);
+    Org cur, nxt;
+    cur.tw = sp % g.tiles_w; cur.th = (sp / g.tiles_w) % g.tiles_h; cur.img = sp / (g.tiles_w * g.tiles_h);
+#define GX_WF_ADVANCE(dst_, src_)                                                    \
+    {                                                                                \
+        int tw_ = src_.tw + d_tw, th_ = src_.th + d_th, im_ = src_.img + d_img;      \
+        if (tw_ >= g.tiles_w) { tw_ -= g.tiles_w; ++th_; }                           \
+        if (th_ >= g.tiles_h) { th_ -= g.tiles_h; ++im_; }                           \
+        dst_.tw = tw_; dst_.th = th_; dst_.img = im_;                                \
     }
+    GX_WF_ADVANCE(nxt, cur)
+#define GX_WF_ORIGIN(org_, img0_, R0_, C0_) \
+    const int img0_ = org_.img * G, R0_ = org_.th << g.lTH, C0_ = org_.tw * TW;
     // B (x halo tile) goes global -> LDS directly (LDS-DMA): thread `tid` owns halo position `tid` of every channel;
     // positions outside the image (and channels beyond CB) are fetched from a zero page so that no lane needs a
     // register, a select or an LDS store.  Destination: wave-uniform base + lane * 4 bytes.
-#define GX_WF_PREFETCH_B(tile_, dstbuf_)                                                             \
+#define GX_WF_PREFETCH_B(org_, dstbuf_)                                                             \
     {                                                                                                \
-        GX_WF_ORIGIN(tile_, pi0, pR0, pC0)                                                           \
+        GX_WF_ORIGIN(org_, pi0, pR0, pC0)                                                           \
         if (tid < CHS) {                                                                             \
             int rem = tid;                                                                           \
             const int gi = rem / ((TH + 2) * HS); rem -= gi * (TH + 2) * HS;                         \
@@ -652,19 +661,25 @@ wgrad_fast_kernel(const float* __restrict__ a_src, const float* __restrict__ b_s
             const bool inb = pi0 + gi < g.N && row >= 0 && row < g.Hb && col >= 0 && col < g.Wb;     \
             const float* lp = inb ? b_src + (size_t)(pi0 + gi) * b_img + (size_t)cb0 * HbWb + row * g.Wb + col \
                                   : zeros;                                                           \
-            float* ldst = (dstbuf_) + wave * 64;                                                     \
-            _Pragma("unroll") for (int ch = 0; ch < 64; ++ch) {                                      \
-                const float* gp = (ch < nvalid_ch ? lp : zeros) + (size_t)ch * HbWb;                 \
+            float* ldst = (dstbuf_) + wave_u * 64;                                                     \
+            const float* gp = lp;                                                                    \
+            int ch = 0;                                                                              \
+            _Pragma("unroll 4") for (; ch < nvalid_ch; ++ch) {   /* rolled: one live pointer pair */ \
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,  \
-                                                 (__attribute__((address_space(3))) void*)(ldst + ch * BS), \
-                                                 4, 0, 0);                                           \
+                                                 (__attribute__((address_space(3))) void*)ldst, 4, 0, 0); \
+                gp += HbWb; ldst += BS;                                                              \
+            }                                                                                        \
+            for (; ch < 64; ++ch) {                               /* channels beyond CB: zeros */    \
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)zeros, \
+                                                 (__attribute__((address_space(3))) void*)ldst, 4, 0, 0); \
+                ldst += BS;                                                                          \
             }                                                                                        \
         }                                                                                            \
     }
     // one batch of A: 4 groups x 4 consecutive pixels of this lane's channel row
-#define GX_WF_LOAD_A(tile_, bt_, dst_)                                                               \
+#define GX_WF_LOAD_A(org_, bt_, dst_)                                                               \
     {                                                                                                \
-        GX_WF_ORIGIN(tile_, ai0, aR0, aC0)                                                           \
+        GX_WF_ORIGIN(org_, ai0, aR0, aC0)                                                           \
         const float* abase = a_lane + (size_t)ai0 * a_img + (size_t)(WT::SA * aR0) * g.Wa + WT::SA * aC0; \
         _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                           \
             const int j0 = jlane + 4 * (4 * (bt_) + gq);                                             \
@@ -686,62 +701,91 @@ wgrad_fast_kernel(const float* __restrict__ a_src, const float* __restrict__ b_s
             }                                                                                        \
         }                                                                                            \
     }
+    // B values of one group: the taps of 4 consecutive pixels touch (rows used) x (cols used + 3) halo floats; they
+    // are read one group AHEAD of the MFMAs that consume them (two alternating register sets), so the LDS latency
+    // hides under the previous group's 4 * NT MFMAs instead of stalling the only wave of the SIMD.
+    constexpr int RO0 = WT::ro(NT - 1) < WT::ro(0) ? WT::ro(NT - 1) : WT::ro(0);
+    constexpr int RO1 = WT::ro(NT - 1) < WT::ro(0) ? WT::ro(0) : WT::ro(NT - 1);
+    constexpr int CO0 = WT::co(NT - 1) < WT::co(0) ? WT::co(NT - 1) : WT::co(0);
+    constexpr int CO1 = WT::co(NT - 1) < WT::co(0) ? WT::co(0) : WT::co(NT - 1);
+    constexpr int NRO = RO1 - RO0 + 1, NCO = CO1 - CO0 + 4;
+    float bva[NRO][NCO], bvb[NRO][NCO];
+#define GX_WF_LOAD_B(bt_, gq_, dst_)                                                                 \
+    {                                                                                                \
+        const int j0 = jlane + 4 * (4 * (bt_) + (gq_));                                              \
+        const int c = j0 & (TW - 1);                                                                 \
+        const int r = (j0 >> LTW) & (TH - 1);                                                        \
+        const int gi = j0 >> (LTW + g.lTH);                                                          \
+        const float* bp = buf + b_row + (gi * (TH + 2) + r) * HS + c;                                \
+        _Pragma("unroll") for (int rr = 0; rr < NRO; ++rr)                                           \
+            _Pragma("unroll") for (int cc = 0; cc < NCO; ++cc)                                       \
+                dst_[rr][cc] = bp[(RO0 + rr) * HS + CO0 + cc];                                       \
+    }
+#define GX_WF_MMA(src_, gq_, bv_)                                                                    \
+    {                                                                                                \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                              \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t)                                           \
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(src_[gq_][u],                          \
+                                                              bv_[WT::ro(t) - RO0][WT::co(t) - CO0 + u], \
+                                                              acc[t], 0, 0, 0);                      \
+        }                                                                                            \
+    }
 #define GX_WF_COMPUTE(bt_, src_)                                                                     \
     {                                                                                                \
-        _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                           \
-            const int j0 = jlane + 4 * (4 * (bt_) + gq);                                             \
-            const int c = j0 & (TW - 1);                                                             \
-            const int r = (j0 >> LTW) & (TH - 1);                                                    \
-            const int gi = j0 >> (LTW + g.lTH);                                                      \
-            const float* bp = buf + b_row + (gi * (TH + 2) + r) * HS + c;                            \
-            _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                          \
-                _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                     \
-                    const float b = bp[WT::ro(t) * HS + WT::co(t) + u];                              \
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(src_[gq][u], b, acc[t], 0, 0, 0);  \
-                }                                                                                    \
-            }                                                                                        \
-        }                                                                                            \
+        GX_WF_LOAD_B(bt_, 0, bva)                                                                    \
+        GX_WF_LOAD_B(bt_, 1, bvb)                                                                    \
+        GX_WF_MMA(src_, 0, bva)                                                                      \
+        GX_WF_LOAD_B(bt_, 2, bva)                                                                    \
+        GX_WF_MMA(src_, 1, bvb)                                                                      \
+        GX_WF_LOAD_B(bt_, 3, bvb)                                                                    \
+        GX_WF_MMA(src_, 2, bva)                                                                      \
+        GX_WF_MMA(src_, 3, bvb)                                                                      \
     }
 
     float a0[4][4], a1[4][4];
     int tile = sp;
     if (tile < g.ntiles) {
-        GX_WF_PREFETCH_B(tile, lds)
-        GX_WF_LOAD_A(tile, 0, a0)
+        GX_WF_PREFETCH_B(cur, lds)
+        GX_WF_LOAD_A(cur, 0, a0)
     }
     int it = 0;
     for (; tile < g.ntiles; tile += nsp, ++it) {
         float* buf = lds + (it & 1) * BUF;
         __syncthreads();     // this tile's B has landed (vmcnt drained before the barrier); the other buffer is free
         const bool more = tile + nsp < g.ntiles;
-        if (more) GX_WF_PREFETCH_B(tile + nsp, lds + ((it + 1) & 1) * BUF)
+        if (more) GX_WF_PREFETCH_B(nxt, lds + ((it + 1) & 1) * BUF)
         if (nb == 4) {
-            GX_WF_LOAD_A(tile, 1, a1)
+            GX_WF_LOAD_A(cur, 1, a1)
             GX_WF_COMPUTE(0, a0)
-            GX_WF_LOAD_A(tile, 2, a0)
+            GX_WF_LOAD_A(cur, 2, a0)
             GX_WF_COMPUTE(1, a1)
-            GX_WF_LOAD_A(tile, 3, a1)
+            GX_WF_LOAD_A(cur, 3, a1)
             GX_WF_COMPUTE(2, a0)
-            if (more) GX_WF_LOAD_A(tile + nsp, 0, a0)
+            if (more) GX_WF_LOAD_A(nxt, 0, a0)
             GX_WF_COMPUTE(3, a1)
         } else if (nb == 2) {
-            GX_WF_LOAD_A(tile, 1, a1)
+            GX_WF_LOAD_A(cur, 1, a1)
             GX_WF_COMPUTE(0, a0)
-            if (more) GX_WF_LOAD_A(tile + nsp, 0, a0)
+            if (more) GX_WF_LOAD_A(nxt, 0, a0)
             GX_WF_COMPUTE(1, a1)
         } else {
-            if (more) GX_WF_LOAD_A(tile + nsp, 0, a1)
+            if (more) GX_WF_LOAD_A(nxt, 0, a1)
             GX_WF_COMPUTE(0, a0)
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) a0[gq][u] = a1[gq][u];
         }
+        cur = nxt;
+        GX_WF_ADVANCE(nxt, cur)
     }
+#undef GX_WF_ADVANCE
 #undef GX_WF_ORIGIN
 #undef GX_WF_PREFETCH_B
 #undef GX_WF_LOAD_A
 #undef GX_WF_COMPUTE
+#undef GX_WF_LOAD_B
+#undef GX_WF_MMA
     // partial[split][gt][ca][cb]
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
