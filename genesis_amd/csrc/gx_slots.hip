@@ -274,6 +274,56 @@ conv1x1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, con
     }
 }
 
+// 4 pixels per thread (16-byte accesses), channel loop unrolled by 8 so that 8 independent loads are in flight per
+// thread: the op is a pure stream of x (Cin/Cout = 16x more bytes in than out).  The weights sit zero-padded to
+// COMAX output channels in LDS (broadcast reads, no per-channel predicates in the loop).
+__global__ void __launch_bounds__(256)
+conv1x1_fwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                       const float* __restrict__ gate, const float* __restrict__ addend, int Cin, int Cout, int HW,
+                       float* __restrict__ y) {
+    __shared__ __attribute__((aligned(16))) float ws[128 * COMAX];   // [ci][co], Cin <= 128
+    for (int i = threadIdx.x; i < Cin * COMAX; i += blockDim.x) {
+        const int ci = i / COMAX, co = i - ci * COMAX;
+        ws[i] = co < Cout ? w[co * Cin + ci] : 0.f;
+    }
+    __syncthreads();
+    const int n = blockIdx.x;
+    const int p = (blockIdx.y * blockDim.x + threadIdx.x) * 4;
+    if (p >= HW) return;
+    f32x4 acc[COMAX];
+#pragma unroll
+    for (int co = 0; co < COMAX; ++co) { acc[co][0] = 0.f; acc[co][1] = 0.f; acc[co][2] = 0.f; acc[co][3] = 0.f; }
+    const float* xn = x + (size_t)n * Cin * HW + p;
+    int ci = 0;
+    for (; ci + 8 <= Cin; ci += 8) {
+        f32x4 xv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv[j] = *reinterpret_cast<const f32x4*>(xn + (size_t)(ci + j) * HW);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(ws + (ci + j) * COMAX);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(ws + (ci + j) * COMAX + 4);
+#pragma unroll
+            for (int co = 0; co < 4; ++co) { acc[co] += w0[co] * xv[j]; acc[co + 4] += w1[co] * xv[j]; }
+        }
+    }
+    for (; ci < Cin; ++ci) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(xn + (size_t)ci * HW);
+#pragma unroll
+        for (int co = 0; co < COMAX; ++co) acc[co] += ws[ci * COMAX + co] * xv;
+    }
+    const float gt = gate ? *gate : 1.f;
+#pragma unroll
+    for (int co = 0; co < COMAX; ++co) {
+        if (co < Cout) {
+            f32x4 v = acc[co] + (bias ? bias[co] : 0.f);
+            if (gate) v = gt * v;
+            if (addend) v += *reinterpret_cast<const f32x4*>(addend + (size_t)co * HW + p);
+            *reinterpret_cast<f32x4*>(y + ((size_t)n * Cout + co) * HW + p) = v;
+        }
+    }
+}
+
 // dx[n][ci][p] = gate * sum_co w[co][ci] dy[n][co][p];  pb[blk][co] = sum_p dy[n][co][p] (ungated, per block)
 __global__ void __launch_bounds__(256)
 conv1x1_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, const float* __restrict__ gate,
@@ -517,8 +567,14 @@ int gx_conv1x1_fwd(const float* x, const float* w, const float* bias, const floa
     const int HW = H * W;
     {
         GxProf pf(KID_CONV1X1_FWD, (hipStream_t)stream, 2.0 * N * Cin * Cout * HW, 4.0 * N * HW * (Cin + Cout));
-        hipLaunchKernelGGL(conv1x1_fwd_kernel, dim3(N, gx_ceil_div(HW, 256)), dim3(256), 0, (hipStream_t)stream, x, w,
-                           bias, gate, addend, Cin, Cout, HW, y);
+        const bool vec = (HW % 4) == 0 && Cin <= 128 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
+                         (!addend || ((uintptr_t)addend % 16) == 0);
+        if (vec)
+            hipLaunchKernelGGL(conv1x1_fwd_vec_kernel, dim3(N, gx_ceil_div(HW, 1024)), dim3(256), 0,
+                               (hipStream_t)stream, x, w, bias, gate, addend, Cin, Cout, HW, y);
+        else
+            hipLaunchKernelGGL(conv1x1_fwd_kernel, dim3(N, gx_ceil_div(HW, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                               w, bias, gate, addend, Cin, Cout, HW, y);
     }
     GX_CHECK_LAUNCH("gx_conv1x1_fwd");
     return GX_OK;
