@@ -159,7 +159,8 @@ def main():
     from genesis_amd import profiling
     model = build_model(args, device)
     ts = TrainStep(model, args.img, lr=1e-4,
-                   graph=(world == 1 and not args.no_graph and not os.environ.get('GENESIS_FORCE_ALLREDUCE')))
+                   graph=not args.no_graph,
+                   async_wgrad=bool(os.environ.get('GENESIS_ASYNC_WGRAD')))
     g = torch.Generator().manual_seed(1234 + rank)
     batches = [torch.rand(args.batch, 3, args.img, args.img, generator=g).to(device) for _ in range(4)]
 
@@ -198,7 +199,8 @@ def main():
                                    'feat_dim %d, per-GPU batch %d, GECO + Adam(1e-4), random-init weights'
                                    % (args.K, args.img, args.img, args.feat_dim, args.batch),
                        'global_batch': world * args.batch, 'per_gpu_batch': args.batch,
-                       'parallelism': 'dp%d' % world, 'launch': 'hip-graph' if ts.graph is not None else 'eager'},
+                       'parallelism': 'dp%d' % world, 'launch': ('hip-graph' if not ts._split else 'hip-graph(fwd+bwd) | rccl all-reduce | hip-graph(geco+adam)')
+                       if ts.graph is not None else 'eager'},
             'final_elbo': elbo,
         }
         if flop_img:

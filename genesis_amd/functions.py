@@ -50,6 +50,7 @@ def _gout(p):
 # MEASURED (round 1, B=32 K=7 64x64): 4066 -> 3464 img/s with the fork on -- the 131 KB-LDS wgrad workgroups and
 # the 62 KB tap-conv workgroups evict each other from the CUs and both are MFMA-bound -- so TrainStep leaves it OFF.
 ASYNC_WGRAD = False
+ASYNC_WGRAD_MAX_PIXELS = int(__import__('os').environ.get('GENESIS_ASYNC_WGRAD_MAX_PIXELS', 1 << 62))
 _side_stream = None
 _keep_alive = []
 
@@ -63,7 +64,9 @@ def _side():
 
 def _wgrad(fn_, out, *reads):
     """Runs fn_() (a weight-gradient launch writing into `out`) on the side stream when allowed, else inline."""
-    if ASYNC_WGRAD and out is not None:
+    # only layers whose kernels cannot fill the chip are forked (ASYNC_WGRAD_MAX_PIXELS images*H*W of the layer input)
+    if ASYNC_WGRAD and out is not None and reads and \
+            reads[0].shape[0] * reads[0].shape[2] * reads[0].shape[3] <= ASYNC_WGRAD_MAX_PIXELS:
         side = _side()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

@@ -38,6 +38,8 @@ class TrainStep(object):
         self._wcache_ready = False
         self.step_t = torch.zeros((), dtype=torch.int64, device=self.device)
         self.graph = None
+        self.graph2 = None
+        self._split = False
         self.use_graph = graph
         self._static_x = None
         self._out = None
@@ -93,6 +95,13 @@ class TrainStep(object):
             pass
 
     def _iteration_body(self, x, **forward_kwargs):
+        st = self._forward_backward(x, **forward_kwargs)
+        with torch.no_grad():
+            gscale = self.bucket.all_reduce(self.pg)
+            return self._update(st, gscale)
+
+    def _forward_backward(self, x, **forward_kwargs):
+        """zero-grad'ed bucket -> forward -> loss -> backward; leaves (err, kl) batch means in the bucket tail."""
         recon, losses, stats, att_stats, comp_stats = self.model(x, **forward_kwargs)
         # loss aggregation of train.py:226-242 (every model family: kl_m | kl_m_k, kl_l | kl_l_k)
         beta_t = self.geco.state[0:1] if self.geco is not None else self._beta_fixed_t.view(1)
@@ -109,6 +118,7 @@ class TrainStep(object):
             # one launch: batch means, the GECO-weighted objective, and (err, kl) straight into the bucket tail
             out5 = _fn.ElboFn.apply(losses.err, kl_rows, beta_t, self.bucket.flat_g[self.n32:self.n32 + 2])
             out5[0].backward()
+            beta_used = out5.detach()
         else:
             err = losses.err.mean(0)
             kl = err.new_zeros(())
@@ -123,33 +133,53 @@ class TrainStep(object):
             beta = beta_t[0].clone()
             loss = err + beta * kl
             loss.backward()
-        _fn.join_side_stream()     # weight-gradient kernels forked onto the side stream
-        with torch.no_grad():
-            if not fused:
+            with torch.no_grad():
                 self.bucket.set_tail(err, kl)
-            gscale = self.bucket.all_reduce(self.pg)
-            if fused and self.world == 1:
-                tail = self.bucket.flat_g[self.n32:]            # already the global batch means
-            else:
-                tail = self.bucket.tail(gscale)                 # global batch-mean err, kl
-            if self.geco is not None:
-                self.geco.update(tail[0])
-            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-            _lib.call('gx_step_increment', _p(self.step_t), stream)
-            _lib.call('gx_adam_step', _p(self.flat_p), _p(self.flat_g), _p(self.m32), _p(self.v32), self.n32, 0,
-                      _p(self.step_t), self.lr, self.betas[0], self.betas[1], self.eps, gscale, stream)
-            if self.n64:
-                _lib.call('gx_adam_step', _p(self.flat_p64), _p(self.flat_g64), _p(self.m64), _p(self.v64),
-                          self.n64, 1, _p(self.step_t), self.lr, self.betas[0], self.betas[1], self.eps, gscale,
-                          stream)
-            if fused and self.world == 1:
-                return out5.detach()[1:5]                       # elbo, err, kl, beta used
-            beta_used = out5.detach()[4] if fused else beta.detach()
-            return torch.stack((tail[0] + tail[1], tail[0], tail[1], beta_used))
+            beta_used = beta.detach()
+        _fn.join_side_stream()     # weight-gradient kernels forked onto the side stream
+        return fused, beta_used
+
+    def _update(self, st, gscale):
+        """(all-reduced) bucket -> device GECO update -> fused Adam; returns [elbo, err, kl, beta used]."""
+        fused, beta_used = st
+        local = fused and gscale == 1.0
+        tail = self.bucket.flat_g[self.n32:] if gscale == 1.0 else self.bucket.tail(gscale)   # global batch means
+        if self.geco is not None:
+            self.geco.update(tail[0])
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.call('gx_step_increment', _p(self.step_t), stream)
+        _lib.call('gx_adam_step', _p(self.flat_p), _p(self.flat_g), _p(self.m32), _p(self.v32), self.n32, 0,
+                  _p(self.step_t), self.lr, self.betas[0], self.betas[1], self.eps, gscale, stream)
+        if self.n64:
+            _lib.call('gx_adam_step', _p(self.flat_p64), _p(self.flat_g64), _p(self.m64), _p(self.v64),
+                      self.n64, 1, _p(self.step_t), self.lr, self.betas[0], self.betas[1], self.eps, gscale,
+                      stream)
+        if local:
+            return beta_used[1:5]                            # ElboFn's (elbo, err, kl, beta used)
+        bu = beta_used[4] if fused else beta_used
+        return torch.stack((tail[0] + tail[1], tail[0], tail[1], bu))
+
+    # ------------------------------------------------------------------ HIP-graph replay
+    def _begin(self):
+        self.bucket.zero_grad()
+        _fn.DIRECT_PARAM_GRADS = True
+        _fn.begin_direct_grads()
+        _fn.ASYNC_WGRAD = self.async_wgrad
+        if self._wcache is not None and self._wcache_ready:
+            _lib.call('gx_weight_cache_refresh', self._wcache,
+                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+    def _end(self):
+        _fn.DIRECT_PARAM_GRADS = False
+        _fn.ASYNC_WGRAD = False
+        if self._wcache is not None and self._wcache_ready:
+            _lib.call('gx_weight_cache_release')
 
     def _capture(self, x):
-        """Warm up (kernel attributes, allocator pools), capture one iteration into a HIP graph, restore the
-        pre-warm-up training state and replay once: the call is exactly one training step."""
+        """Warm up (kernel attributes, allocator pools, weight-cache recording), capture the iteration into HIP
+        graphs, restore the pre-warm-up training state and replay once: the call is exactly one training step.
+        One process: a single graph.  Several ranks: two graphs (forward+backward | GECO+Adam) with the RCCL
+        all-reduce of the gradient bucket issued between the two replays -- nothing else runs on the host."""
         self._static_x = x.clone()
         state = [self.flat_p, self.flat_p64, self.m32, self.v32, self.m64, self.v64, self.step_t]
         if self.geco is not None:
@@ -161,24 +191,51 @@ class TrainStep(object):
             for _ in range(3):
                 self._out = self._iteration(self._static_x)
         torch.cuda.current_stream().wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self._out = self._iteration(self._static_x)
+        self._split = self._needs_collective()
+        if not self._split:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._out = self._iteration(self._static_x)
+        else:
+            self._gscale = 1.0 / self.world
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._begin()
+                try:
+                    self._st = self._forward_backward(self._static_x)
+                finally:
+                    self._end()
+            self.graph2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph2, pool=self.graph.pool()):
+                with torch.no_grad():
+                    self._out = self._update(self._st, self._gscale)
         with torch.no_grad():
             for t, s in zip(state, snap):
                 t.copy_(s)
-        self.graph.replay()
+        self._replay()
         self.iters += 1
+
+    def _needs_collective(self):
+        import os
+        return dist.is_available() and dist.is_initialized() and \
+            (self.world > 1 or bool(os.environ.get('GENESIS_FORCE_ALLREDUCE')))
+
+    def _replay(self):
+        self.graph.replay()
+        if self._split:
+            with torch.no_grad():
+                self.bucket.all_reduce(self.pg)
+            self.graph2.replay()
 
     def step(self, x, **forward_kwargs):
         """x [B,3,S,S] on the device.  Returns a device tensor [elbo, err, kl, beta_used] (no host sync).
         forward_kwargs (rand_pixel / eps / seed_idx injection, parity tests) force the eager path."""
-        if self.use_graph and self.world == 1 and not forward_kwargs:
+        if self.use_graph and not forward_kwargs:
             if self.graph is None:
                 self._capture(x)
                 return self._out
             self._static_x.copy_(x)
-            self.graph.replay()
+            self._replay()
             self.iters += 1
             return self._out
         out = self._iteration(x, **forward_kwargs)

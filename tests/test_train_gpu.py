@@ -123,3 +123,30 @@ def test_weight_cache_matches_per_call_packing():
             assert _lib.query('gx_weight_cache_size', ts._wcache) > 10
     assert torch.equal(outs[0][0], outs[1][0])
     assert torch.equal(outs[0][1], outs[1][1])
+
+
+def test_split_graph_with_rccl_allreduce_matches_single_graph(monkeypatch):
+    """Multi-rank launch mode on one GPU: forward+backward graph | RCCL all-reduce of the bucket | GECO+Adam graph
+    (world_size 1 process group, collective forced) must reproduce the single-graph trajectory bit for bit."""
+    import torch.distributed as dist
+    from genesis_amd.trainer import TrainStep
+    gold = Golden('tiny')
+    x, _, _ = gold.inputs()
+    xd = x.to(DEV)
+
+    def run(ts):
+        torch.manual_seed(7)                      # the model draws rand_pixel / eps from the device RNG
+        torch.cuda.manual_seed(7)
+        return torch.stack([ts.step(xd).clone() for _ in range(4)]), ts.flat_p.clone()
+
+    ref = run(TrainStep(build(gold), gold.S, lr=1e-4, graph=True))
+    monkeypatch.setenv('GENESIS_FORCE_ALLREDUCE', '1')
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29533', rank=0, world_size=1)
+    try:
+        ts = TrainStep(build(gold), gold.S, lr=1e-4, graph=True)
+        got = run(ts)
+        assert ts._split and ts.graph2 is not None
+    finally:
+        dist.destroy_process_group()
+    assert torch.equal(ref[0], got[0])
+    assert torch.equal(ref[1], got[1])
