@@ -53,20 +53,23 @@ def build_model(args, device):
     from genesis_amd.compat.attrdict import AttrDict
     if args.model == 'monet':
         import genesis_amd.monet_config as GM
-        from oracle import monet_oracle  # only for its default-flag table (no arithmetic)
-        cfg = AttrDict(dict(monet_oracle.make_cfg(K_steps=args.K, img_size=args.img), debug=False, multi_gpu=False))
+        cfg = AttrDict(filter_start=32, prior_mode='softmax', comp_enc_channels=32, comp_ldim=16, comp_dec_channels=32,
+                       comp_dec_layers=4, montecarlo_kl=True, pixel_bound=True, pixel_std1=0.7, pixel_std2=0.7,
+                       K_steps=args.K, img_size=args.img, debug=False, multi_gpu=False)   # the reference's flag defaults
         torch.manual_seed(0)
         return GM.load(cfg).to(device).train()
     if args.model == 'genesis':
         import genesis_amd.genesis_config as GG
-        from oracle import genesis_oracle  # default-flag table only
-        cfg = AttrDict(dict(genesis_oracle.make_cfg(K_steps=args.K, img_size=args.img), debug=False, multi_gpu=False))
+        cfg = AttrDict(two_stage=True, autoreg_prior=True, comp_prior=True, attention_latents=64, enc_norm='bn',
+                       dec_norm='bn', comp_enc_channels=32, comp_ldim=16, comp_dec_channels=32, comp_dec_layers=4,
+                       comp_symmetric=False, pixel_bound=True, pixel_std1=0.7, pixel_std2=0.7, montecarlo_kl=True,
+                       K_steps=args.K, img_size=args.img, debug=False, multi_gpu=False)
         torch.manual_seed(0)
         return GG.load(cfg).to(device).train()
     if args.model == 'vae':
         import genesis_amd.vae_config as GV
-        from oracle import vae_oracle  # default-flag table only
-        cfg = AttrDict(dict(vae_oracle.make_cfg(img_size=args.img), debug=False, multi_gpu=False))
+        cfg = AttrDict(latent_dimension=64, broadcast_decoder=False, pixel_bound=True, pixel_std=0.7,
+                       img_size=args.img, debug=False, multi_gpu=False)
         torch.manual_seed(0)
         return GV.load(cfg).to(device).train()
     import genesis_amd.genesisv2_config as G

@@ -28,6 +28,7 @@ class FlatBucket(object):
         # every parameter starts on a 64-byte boundary of the flat buffer (16-byte vector loads in the dense / LSTM
         # kernels need aligned rows); the padding stays zero in parameters, gradients and Adam state
         self.align = align
+        self.slot = {}
         self.n32 = sum(self._pad(p.numel()) for p in self.p32)
         self.n64 = sum(p.numel() for p in self.p64)
         self.n_tail = n_tail
@@ -40,6 +41,7 @@ class FlatBucket(object):
             off = 0
             for p in plist:
                 n = p.numel()
+                self.slot[id(p)] = (not padded, off, n)        # (is fp64, offset in its flat buffer, numel)
                 fp[off:off + n].copy_(p.data.reshape(-1))
                 p.data = fp[off:off + n].view(p.shape)
                 p.grad = fg[off:off + n].view(p.shape)

@@ -245,10 +245,61 @@ class TrainStep(object):
         return out
 
     # ------------------------------------------------------------------ checkpoint (train.py:410-420 wire format)
+    def _adam_slices(self, p):
+        is64, off, n = self.bucket.slot[id(p)]
+        m, v = (self.m64, self.v64) if is64 else (self.m32, self.v32)
+        return m[off:off + n].view(p.shape), v[off:off + n].view(p.shape)
+
     def state_dict(self, iter_idx):
+        """The reference's checkpoint dict (train.py:405-420): `optimiser_state_dict` is a genuine
+        torch.optim.Adam state_dict over model.parameters() in order (exp_avg / exp_avg_sq / step per parameter), so
+        a checkpoint written here resumes in the reference's loop (train.py:179-207) and vice versa."""
+        params = list(self.model.parameters())
+        opt = torch.optim.Adam(params, self.lr, betas=self.betas, eps=self.eps)
+        step = int(self.step_t)
+        if step > 0:
+            for p in params:
+                m, v = self._adam_slices(p)
+                opt.state[p] = {'step': torch.tensor(float(step)), 'exp_avg': m.clone(), 'exp_avg_sq': v.clone()}
         return {'model_state_dict': self.model.state_dict(),
-                'optimiser_state_dict': {'m32': self.m32, 'v32': self.v32, 'm64': self.m64, 'v64': self.v64,
-                                         'step': self.step_t, 'lr': self.lr, 'betas': self.betas, 'eps': self.eps},
-                'beta': self.geco.beta if self.geco is not None else self.beta_fixed,
-                'err_ema': self.geco.err_ema if self.geco is not None else None,
+                'optimiser_state_dict': opt.state_dict(),
+                'beta': self.geco.beta.detach().clone() if self.geco is not None else self.beta_fixed,
+                'err_ema': (self.geco.err_ema.detach().clone() if self.geco.err_ema is not None else None)
+                if self.geco is not None else None,
                 'iter_idx': iter_idx}
+
+    def load_state_dict(self, ckpt):
+        """Restores model, Adam moments / step, GECO state from a checkpoint of the reference's format; returns the
+        iteration to continue from (train.py:207).  Parameters keep living in the flat bucket."""
+        sd = dict(ckpt['model_state_dict'])
+        sd.pop('comp_vae.decoder_module.seq.0.pixel_coords.g_1', None)     # legacy entries, train.py:191-192
+        sd.pop('comp_vae.decoder_module.seq.0.pixel_coords.g_2', None)
+        self.model.load_state_dict(sd)
+        assert self.bucket.grads_in_bucket()
+        osd = ckpt['optimiser_state_dict']
+        params = list(self.model.parameters())
+        ids = [i for g in osd['param_groups'] for i in g['params']]
+        if len(ids) != len(params):
+            raise ValueError('optimiser state has %d parameters, the model %d' % (len(ids), len(params)))
+        steps = set()
+        with torch.no_grad():
+            self.m32.zero_(); self.v32.zero_(); self.m64.zero_(); self.v64.zero_()
+            for i, p in zip(ids, params):
+                st = osd['state'].get(i)
+                if st is None:
+                    continue
+                m, v = self._adam_slices(p)
+                m.copy_(st['exp_avg']); v.copy_(st['exp_avg_sq'])
+                steps.add(int(st['step']))
+            if len(steps) > 1:
+                raise ValueError('per-parameter Adam step counts differ: %s' % sorted(steps))
+            self.step_t.fill_(steps.pop() if steps else 0)
+        g0 = osd['param_groups'][0]
+        self.lr, self.betas, self.eps = g0['lr'], tuple(g0['betas']), g0['eps']
+        if self.geco is not None:
+            if ckpt.get('beta') is not None:
+                self.geco.beta = ckpt['beta']
+            if ckpt.get('err_ema') is not None:
+                self.geco.err_ema = ckpt['err_ema']
+        self.graph = self.graph2 = None          # re-capture: lr / betas are baked into the captured launches
+        return ckpt['iter_idx'] + 1

@@ -150,3 +150,53 @@ def test_split_graph_with_rccl_allreduce_matches_single_graph(monkeypatch):
         dist.destroy_process_group()
     assert torch.equal(ref[0], got[0])
     assert torch.equal(ref[1], got[1])
+
+
+def test_checkpoint_is_the_reference_wire_format(tmp_path):
+    """TrainStep.state_dict() is the dict train.py:405-420 saves: its optimiser_state_dict loads into a genuine
+    torch.optim.Adam (the reference's resume path, train.py:179-207), one torch-Adam step from there equals the next
+    TrainStep step, and TrainStep.load_state_dict() resumes bit-exactly."""
+    from genesis_amd.trainer import TrainStep
+    gold = Golden('tiny')
+    x, _, _ = gold.inputs()
+    xd = x.to(DEV)
+    noise = [gold.noise(1 + it) for it in range(3)]
+
+    def kw(it):
+        rp, eps = noise[it]
+        return dict(rand_pixel=rp.to(DEV), eps=torch.stack(eps).to(DEV))
+
+    ts = TrainStep(build(gold), gold.S, lr=1e-4, graph=False)
+    for it in range(2):
+        ts.step(xd, **kw(it))
+    ckpt = ts.state_dict(1)
+    f = tmp_path / 'model.ckpt-1'
+    torch.save(ckpt, f)
+    ckpt = torch.load(f, map_location='cuda', weights_only=False)
+    assert set(ckpt) == {'model_state_dict', 'optimiser_state_dict', 'beta', 'err_ema', 'iter_idx'}
+    third = ts.step(xd, **kw(2)).clone()
+    p_after = [p.detach().clone() for p in ts.model.parameters()]
+
+    # (a) the reference's resume path: plain model + torch.optim.Adam
+    model2 = build(gold)
+    opt = torch.optim.Adam(model2.parameters(), 1e-4)
+    model2.load_state_dict(ckpt['model_state_dict'])
+    import copy
+    opt.load_state_dict(copy.deepcopy(ckpt['optimiser_state_dict']))   # (torch adopts the tensors it is given)
+    _, losses, _, _, _ = model2(xd, **kw(2))
+    err = losses.err.mean(0)
+    kl = torch.stack(losses.kl_l_k, dim=1).mean(dim=0).sum()
+    opt.zero_grad()
+    (err + float(ckpt['beta']) * kl).backward()
+    opt.step()
+    assert abs(float((err + kl).detach()) - float(third[0])) <= 1e-5 * abs(float(third[0]))
+    for a, b in zip(model2.parameters(), p_after):
+        assert torch.allclose(a.detach(), b, rtol=1e-4, atol=2e-6)
+
+    # (b) round trip through TrainStep.load_state_dict: bit-exact continuation
+    ts2 = TrainStep(build(gold), gold.S, lr=1e-4, graph=False)
+    assert ts2.load_state_dict(ckpt) == 2
+    third2 = ts2.step(xd, **kw(2))
+    assert torch.equal(third, third2)
+    for a, b in zip(ts2.model.parameters(), p_after):
+        assert torch.equal(a.detach(), b)
