@@ -1196,6 +1196,119 @@ int launch_wgrad_deconv(const float* a, const float* b, float* partial, const Wg
     return GX_OK;
 }
 
+// ---- conv3x3 weight gradient for very few input channels (Cin * 9 <= 32: the UNet's RGB input layer) -----------
+// The generic kernel pads Cin to a 64-channel block (21x wasted MFMA work: 3 -> 64 @64x64 took 111 us for 0.45
+// GFLOP).  Here the (ci, tap) pairs ARE the N dimension: D[co][j = ci*9 + tap] += dy[co][p] * x[ci][p + tap] on
+// mfma_f32_16x16x4f32, contraction over pixels; every wave streams 64-pixel row segments (dy with 16-byte loads, the
+// shifted x values with bounds-checked scalar loads: x is tiny and cache resident); per-block partials
+// pw[blk][co][32] are summed by wgrad_smallcin_reduce_kernel in a fixed order.
+__global__ void __launch_bounds__(256)
+wgrad_smallcin_kernel(const float* __restrict__ x, const float* __restrict__ dy, int N, int Cin, int Cout, int H,
+                      int W, float* __restrict__ pw) {
+    __shared__ float red[4][64][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = lane & 15, q = lane >> 4;
+    const int HW = H * W;
+    const int chunks_per_img = HW >> 6;
+    const int nchunks = N * chunks_per_img;
+    const int co0 = blockIdx.y * 64;
+    const int J = Cin * 9;
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { acc[c][t][0] = 0.f; acc[c][t][1] = 0.f; acc[c][t][2] = 0.f; acc[c][t][3] = 0.f; }
+    // this lane's two (ci, tap) columns
+    int jci[2], jdy[2], jdx[2];
+    bool jok[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int j = t * 16 + row;
+        jok[t] = j < J;
+        jci[t] = jok[t] ? j / 9 : 0;
+        const int tap = jok[t] ? j % 9 : 4;
+        jdy[t] = tap / 3 - 1; jdx[t] = tap % 3 - 1;
+    }
+    for (int c = blockIdx.x * 4 + wave; c < nchunks; c += gridDim.x * 4) {
+        const int n = c / chunks_per_img;
+        const int p0 = (c - n * chunks_per_img) * 64 + q * 16;     // 16 consecutive pixels of one image row
+        const int py = p0 / W, px0 = p0 - py * W;
+        f32x4 av[4][4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            const int co = co0 + ct * 16 + row;
+            const bool ok = co < Cout;
+            const float* ap = dy + ((size_t)n * Cout + (ok ? co : 0)) * HW + p0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                av[ct][i] = *reinterpret_cast<const f32x4*>(ap + 4 * i);
+                if (!ok) { av[ct][i][0] = 0.f; av[ct][i][1] = 0.f; av[ct][i][2] = 0.f; av[ct][i][3] = 0.f; }
+            }
+        }
+        float bv[2][16];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int yy = py + jdy[t];
+            const bool rok = jok[t] && yy >= 0 && yy < H;
+            const float* bp = x + ((size_t)n * Cin + jci[t]) * HW + (size_t)(rok ? yy : 0) * W;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int xx = px0 + e + jdx[t];
+                bv[t][e] = (rok && xx >= 0 && xx < W) ? bp[xx] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        acc[ct][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct][i][u], bv[t][4 * i + u], acc[ct][t],
+                                                                          0, 0, 0);
+    }
+    // C/D layout (16x16): col = lane & 15 (j), row = (lane >> 4) * 4 + reg (co)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][ct * 16 + q * 4 + r][t * 16 + row] = acc[ct][t][r];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 32; i += blockDim.x) {
+        const int co = i >> 5, j = i & 31;
+        pw[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 64 + co) * 32 + j] =
+            (red[0][co][j] + red[1][co][j]) + (red[2][co][j] + red[3][co][j]);
+    }
+}
+
+// dw[co][ci][tap] = sum over blocks; one workgroup per output channel: 32 columns x 8 block groups
+__global__ void __launch_bounds__(256)
+wgrad_smallcin_reduce_kernel(const float* __restrict__ pw, int nblk, int Cout, int J, float* __restrict__ dw) {
+    __shared__ float red[8][32];
+    const int co = blockIdx.x;
+    const int j = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int mt = co >> 6, cl = co & 63;
+    float s = 0.f;
+    for (int b = grp; b < nblk; b += 8) s += pw[((size_t)(mt * nblk + b) * 64 + cl) * 32 + j];
+    red[grp][j] = s;
+    __syncthreads();
+    if (grp == 0 && j < J) {
+        float t = red[0][j];
+#pragma unroll
+        for (int g2 = 1; g2 < 8; ++g2) t += red[g2][j];
+        dw[(size_t)co * J + j] = t;
+    }
+}
+
+inline bool smallcin_ok(int Cin, int H, int W) { return Cin * 9 <= 32 && (W % 16) == 0 && ((H * W) % 64) == 0; }
+inline int smallcin_blocks(int N, int H, int W) {
+    const int nchunks = N * ((H * W) >> 6);
+    const int b = gx_ceil_div(nchunks, 4);
+    return b > 1024 ? 1024 : (b < 1 ? 1 : b);
+}
+
 int launch_wgrad_reduce(const float* partial, float* dw, const WgradPlan& pl, int layout, hipStream_t s) {
     const int total = pl.g.Ttot * pl.g.CA * pl.g.CB;
     const int blocks = gx_ceil_div(total, 64);
@@ -1374,7 +1487,12 @@ int gx_conv3x3_dgrad(const float* dy, const float* w, float* dx, int N, int Cin,
 size_t gx_conv3x3_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W) {
     WgradPlan pl;
     plan_wgrad(N, Cout, Cin, H, W, 1, 9, 1, &pl);
-    return pl.ws_floats * sizeof(float);
+    size_t f = pl.ws_floats;
+    if (smallcin_ok(Cin, H, W)) {
+        const size_t f2 = (size_t)smallcin_blocks(N, H, W) * gx_ceil_div(Cout, 64) * 64 * 32;
+        f = f2 > f ? f2 : f;
+    }
+    return f * sizeof(float);
 }
 
 int gx_conv3x3_wgrad(const float* x, const float* dy, float* dw, int N, int Cin, int Cout, int H, int W,
@@ -1384,8 +1502,25 @@ int gx_conv3x3_wgrad(const float* x, const float* dy, float* dw, int N, int Cin,
     GX_CHECK_ARG(x && dy && dw && ws, "gx_conv3x3_wgrad: null pointer");
     WgradPlan pl;
     plan_wgrad(N, Cout, Cin, H, W, 1, 9, 1, &pl);
-    GX_CHECK_ARG(ws_bytes >= pl.ws_floats * sizeof(float), "gx_conv3x3_wgrad: workspace too small");
+    GX_CHECK_ARG(ws_bytes >= gx_conv3x3_wgrad_ws_bytes(N, Cin, Cout, H, W), "gx_conv3x3_wgrad: workspace too small");
     hipStream_t s = (hipStream_t)stream;
+    if (smallcin_ok(Cin, H, W) && !getenv("GENESIS_WGRAD_LEGACY")) {
+        const int nblk = smallcin_blocks(N, H, W), mt = gx_ceil_div(Cout, 64);
+        {
+            GxProf pf(KID_WGRAD_C3, s, 2.0 * N * (double)Cout * Cin * 9 * H * W,
+                      4.0 * ((double)N * Cout * H * W + (double)N * Cin * H * W));
+            hipLaunchKernelGGL(wgrad_smallcin_kernel, dim3(nblk, mt), dim3(256), 0, s, x, dy, N, Cin, Cout, H, W,
+                               (float*)ws);
+        }
+        GX_CHECK_LAUNCH("gx_conv3x3_wgrad(small Cin)");
+        {
+            GxProf pf(KID_WGRAD_REDUCE, s, 0.0, 4.0 * nblk * mt * 64 * 32);
+            hipLaunchKernelGGL(wgrad_smallcin_reduce_kernel, dim3(Cout), dim3(256), 0, s, (const float*)ws, nblk, Cout,
+                               Cin * 9, dw);
+        }
+        GX_CHECK_LAUNCH("gx_conv3x3_wgrad(small Cin reduce)");
+        return GX_OK;
+    }
     rc = launch_wgrad<W_C3>(dy, x, (float*)ws, pl, s, "gx_conv3x3_wgrad");
     if (rc) return rc;
     return launch_wgrad_reduce((const float*)ws, dw, pl, 0, s);
