@@ -74,3 +74,48 @@ int gx_profile_collect(double* total_ms, double* launches, double* flops, double
 const char* gx_last_error(void) { return g_err; }
 int gx_version(void) { return 1; }
 }
+
+// ---- deferred parameter-gradient reductions -------------------------------------------------------------
+// Weight gradients and GroupNorm affine gradients only feed the optimiser, yet each of them ends in its own small
+// reduce launch (32 per training step).  With deferral on, those entry points queue the reduce instead; one
+// launch per kind (gx_defer_flush) finishes all of them after the backward pass.  The caller keeps the queued
+// workspaces alive until the flush.
+bool g_gx_defer_on = false;
+namespace {
+constexpr int kMaxDefer = 48;
+GxWgradRed g_wq[kMaxDefer];
+GxGnRed g_gq[kMaxDefer];
+int g_nw = 0, g_ng = 0;
+}  // namespace
+bool gx_defer_push_wgrad(const GxWgradRed& r) {
+    if (g_nw >= kMaxDefer) return false;
+    g_wq[g_nw++] = r;
+    return true;
+}
+bool gx_defer_push_gn(const GxGnRed& r) {
+    if (g_ng >= kMaxDefer) return false;
+    g_gq[g_ng++] = r;
+    return true;
+}
+
+extern "C" {
+
+int gx_defer_enable(int on) {
+    g_gx_defer_on = on > 0;
+    if (on < 0) { g_nw = 0; g_ng = 0; }   // discard whatever is queued (error recovery)
+    return GX_OK;
+}
+
+int gx_defer_pending(void) { return g_nw + g_ng; }
+
+int gx_defer_flush(gx_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    int rc = GX_OK;
+    if (g_nw) rc = gx_defer_flush_wgrad(g_wq, g_nw, s);
+    g_nw = 0;
+    if (rc == GX_OK && g_ng) rc = gx_defer_flush_gn(g_gq, g_ng, s);
+    g_ng = 0;
+    return rc;
+}
+
+}  // extern "C"

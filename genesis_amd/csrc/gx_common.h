@@ -46,6 +46,15 @@ struct GxProf {
     ~GxProf() { if (on) gx_prof_end(s); }
 };
 
+// ---- deferred parameter-gradient reductions (gx_defer_*; gx_api.cpp owns the queue) ----
+struct GxWgradRed { const float* partial; float* dw; int nsplit, Ttot, CA, CB, CApad, CBpad, layout, ns0, ns1, ns2, ns3; };
+struct GxGnRed { const float* part; float* dgamma; float* dbeta; float* dbias; int N, C; };
+extern bool g_gx_defer_on;
+bool gx_defer_push_wgrad(const GxWgradRed& r);   // false: queue full (caller reduces immediately)
+bool gx_defer_push_gn(const GxGnRed& r);
+int gx_defer_flush_wgrad(const GxWgradRed* items, int n, hipStream_t s);   // gx_conv.hip
+int gx_defer_flush_gn(const GxGnRed* items, int n, hipStream_t s);         // gx_norm.hip
+
 static inline int gx_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static inline int gx_ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int gx_round_up(int a, int b) { return gx_ceil_div(a, b) * b; }

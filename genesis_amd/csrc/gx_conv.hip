@@ -855,6 +855,46 @@ wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, i
     }
 }
 
+// all queued weight-gradient reductions in one launch: blockIdx.y = queue entry (table passed by value)
+struct WgradRedTable { GxWgradRed e[48]; };
+__global__ void __launch_bounds__(256)
+wgrad_reduce_batch_kernel(const WgradRedTable tab) {
+    const GxWgradRed& r = tab.e[blockIdx.y];
+    __shared__ float red[4][64];
+    const int total = r.Ttot * r.CA * r.CB;
+    if ((int)blockIdx.x * 64 >= total) return;
+    const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + e;
+    float s = 0.f;
+    int cb = 0, ca = 0, t = 0;
+    if (idx < total) {
+        cb = idx % r.CB;
+        ca = (idx / r.CB) % r.CA;
+        t = idx / (r.CB * r.CA);
+        int nsplit = r.nsplit;
+        if (r.ns0 > 0) {
+            const int cls = ((t / 5) & 1) * 2 + ((t % 5) & 1);
+            nsplit = cls == 0 ? r.ns0 : (cls == 1 ? r.ns1 : (cls == 2 ? r.ns2 : r.ns3));
+        }
+        const size_t stride = (size_t)r.Ttot * r.CApad * r.CBpad;
+        const float* p = r.partial + ((size_t)t * r.CApad + ca) * r.CBpad + cb;
+        float s0 = 0.f, s1 = 0.f;
+        int sp = grp;
+        for (; sp + 4 < nsplit; sp += 8) { s0 += p[sp * stride]; s1 += p[(sp + 4) * stride]; }
+        if (sp < nsplit) s0 += p[sp * stride];
+        s = s0 + s1;
+    }
+    red[grp][e] = s;
+    __syncthreads();
+    if (grp == 0 && idx < total) {
+        const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        // ACCUMULATES: the destination is a zeroed gradient buffer; a parameter used more than once per iteration
+        // (MONet's recurrent UNet) has received its other contributions by the time the queue is flushed
+        if (r.layout == 0) r.dw[((size_t)ca * r.CB + cb) * r.Ttot + t] += v;
+        else r.dw[((size_t)cb * r.CA + ca) * r.Ttot + t] += v;
+    }
+}
+
 // ------------------------------------------------------------------ host-side geometry
 int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
@@ -1310,6 +1350,14 @@ inline int smallcin_blocks(int N, int H, int W) {
 }
 
 int launch_wgrad_reduce(const float* partial, float* dw, const WgradPlan& pl, int layout, hipStream_t s) {
+    if (g_gx_defer_on) {
+        const int* cb = pl.g.cls_begin;
+        const bool merged = cb[4] > 0;
+        GxWgradRed r{partial, dw, pl.g.nsplit, pl.g.Ttot, pl.g.CA, pl.g.CB, pl.g.CApad, pl.g.CBpad, layout,
+                     merged ? cb[1] - cb[0] : 0, merged ? cb[2] - cb[1] : 0, merged ? cb[3] - cb[2] : 0,
+                     merged ? cb[4] - cb[3] : 0};
+        if (gx_defer_push_wgrad(r)) return GX_OK;
+    }
     const int total = pl.g.Ttot * pl.g.CA * pl.g.CB;
     const int blocks = gx_ceil_div(total, 64);
     {
@@ -1334,6 +1382,24 @@ int check_dims(const char* name, int N, int Cin, int Cout, int H, int W) {
 }  // namespace
 
 // =================================================================== C ABI
+int gx_defer_flush_wgrad(const GxWgradRed* items, int n, hipStream_t s) {
+    WgradRedTable tab;
+    int maxblocks = 1;
+    double bytes = 0.0;
+    for (int i = 0; i < n; ++i) {
+        tab.e[i] = items[i];
+        const int total = items[i].Ttot * items[i].CA * items[i].CB;
+        maxblocks = gx_ceil_div(total, 64) > maxblocks ? gx_ceil_div(total, 64) : maxblocks;
+        bytes += 4.0 * (items[i].nsplit + 1.0) * total;
+    }
+    {
+        GxProf pf(KID_WGRAD_REDUCE, s, 0.0, bytes);
+        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(maxblocks, n), dim3(256), 0, s, tab);
+    }
+    GX_CHECK_LAUNCH("gx_defer_flush(wgrad)");
+    return GX_OK;
+}
+
 extern "C" {
 
 // workspace = packed weights (+ split-K partial slabs when the plan splits the reduction)

@@ -550,6 +550,26 @@ void launch_bwd_reg(dim3 grid, dim3 block, hipStream_t s, Args... args) {
         }                                                                        \
     } while (0)
 
+struct GnRedTable { GxGnRed e[48]; };
+__global__ void __launch_bounds__(256)
+gn_param_reduce_batch_kernel(const GnRedTable tab) {
+    const GxGnRed& r = tab.e[blockIdx.y];
+    const int c = blockIdx.x;
+    if (c >= r.C) return;
+    __shared__ double red[16 * 3 + 3];
+    double v[3] = {0.0, 0.0, 0.0};
+    for (int n = threadIdx.x; n < r.N; n += blockDim.x) {
+        const float* p = r.part + ((size_t)n * r.C + c) * 3;
+        v[0] += p[0]; v[1] += p[1]; v[2] += p[2];
+    }
+    block_sum_multi<3>(v, red);
+    if (threadIdx.x == 0) {   // accumulates into the zeroed gradient buffers (see wgrad_reduce_batch_kernel)
+        r.dgamma[c] += (float)v[0];
+        r.dbeta[c] += (float)v[1];
+        if (r.dbias) r.dbias[c] += (float)v[2];
+    }
+}
+
 int check_view(const char* name, const View& v, int C) {
     GX_CHECK_ARG(v.mode >= 0 && v.mode <= 2, "%s: bad view mode %d", name, v.mode);
     GX_CHECK_ARG(v.c0 >= 0 && v.c0 + C <= v.ctot, "%s: view slice [%d,%d) outside %d channels", name, v.c0,
@@ -558,6 +578,23 @@ int check_view(const char* name, const View& v, int C) {
 }
 
 }  // namespace
+
+int gx_defer_flush_gn(const GxGnRed* items, int n, hipStream_t s) {
+    GnRedTable tab;
+    int maxc = 1;
+    double bytes = 0.0;
+    for (int i = 0; i < n; ++i) {
+        tab.e[i] = items[i];
+        maxc = items[i].C > maxc ? items[i].C : maxc;
+        bytes += 12.0 * items[i].N * items[i].C;
+    }
+    {
+        GxProf pf(KID_GN_PARAM_REDUCE, s, 0.0, bytes);
+        hipLaunchKernelGGL(gn_param_reduce_batch_kernel, dim3(maxc, n), dim3(256), 0, s, tab);
+    }
+    GX_CHECK_LAUNCH("gx_defer_flush(gn)");
+    return GX_OK;
+}
 
 extern "C" {
 
@@ -630,6 +667,7 @@ int gx_gn_relu_bwd(const float* y, const float* gamma, const float* beta, const 
                                rstd, C, H, W, groups, v0, v1, dy, (float*)ws);
     }
     GX_CHECK_LAUNCH("gx_gn_relu_bwd");
+    if (g_gx_defer_on && gx_defer_push_gn(GxGnRed{(const float*)ws, dgamma, dbeta, dbias, N, C})) return GX_OK;
     {
         GxProf pf(KID_GN_PARAM_REDUCE, s, 0.0, 12.0 * N * C);
         hipLaunchKernelGGL(gn_param_reduce_kernel, dim3(C), dim3(N >= 128 ? 256 : 64), 0, s, (const float*)ws, N, C,

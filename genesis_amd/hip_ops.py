@@ -38,6 +38,42 @@ def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
+# ---- deferred parameter-gradient reductions (gx_defer_*): TrainStep turns this on for one backward pass; calls that
+# write a parameter gradient into a caller-provided buffer then queue their final reduce, and defer_flush() finishes
+# all of them in one launch per kind.  Workspaces of queued calls are kept alive here until the flush.
+DEFER_REDUCES = False
+_DEFER_KEEP = []
+
+
+class _deferring(object):
+    def __init__(self, active, *keep):
+        self.active = bool(active) and DEFER_REDUCES
+        self.keep = keep
+
+    def __enter__(self):
+        if self.active:
+            _lib.call('gx_defer_enable', 1)
+        return self
+
+    def __exit__(self, *exc):
+        if self.active:
+            _lib.call('gx_defer_enable', 0)
+            _DEFER_KEEP.extend(self.keep)
+        return False
+
+
+def defer_flush():
+    if _lib.query('gx_defer_pending'):
+        _lib.call('gx_defer_flush', _stream())
+    del _DEFER_KEEP[:]
+
+
+def defer_discard():
+    """Drops queued reductions without running them (an exception interrupted the backward pass)."""
+    _lib.call('gx_defer_enable', -1)
+    del _DEFER_KEEP[:]
+
+
 # ------------------------------------------------------------------ conv3x3
 def conv3x3_fwd(x, w):
     _chk(x, 'conv3x3_fwd.x'); _chk(w, 'conv3x3_fwd.w')
@@ -72,7 +108,8 @@ def conv3x3_wgrad(x, dy, out=None):
     assert dw.shape == (Cout, Cin, 3, 3) and dw.is_contiguous()
     nb = _lib.query('gx_conv3x3_wgrad_ws_bytes', N, Cin, Cout, H, W)
     ws = _ws(nb, x.device)
-    _lib.call('gx_conv3x3_wgrad', _p(x), _p(dy), _p(dw), N, Cin, Cout, H, W, _p(ws), nb, _stream())
+    with _deferring(out is not None, ws):
+        _lib.call('gx_conv3x3_wgrad', _p(x), _p(dy), _p(dw), N, Cin, Cout, H, W, _p(ws), nb, _stream())
     return dw
 
 
@@ -112,7 +149,8 @@ def deconv5x5s2_wgrad(x, dy, out=None):
     assert dw.shape == (Cin, Cout, 5, 5) and dw.is_contiguous()
     nb = _lib.query('gx_deconv5x5s2_wgrad_ws_bytes', N, Cin, Cout, H, W)
     ws = _ws(nb, x.device)
-    _lib.call('gx_deconv5x5s2_wgrad', _p(x), _p(dy), _p(dw), N, Cin, Cout, H, W, _p(ws), nb, _stream())
+    with _deferring(out is not None, ws):
+        _lib.call('gx_deconv5x5s2_wgrad', _p(x), _p(dy), _p(dw), N, Cin, Cout, H, W, _p(ws), nb, _stream())
     return dw
 
 
@@ -147,9 +185,11 @@ def gn_relu_bwd(y, gamma, beta, mean, rstd, groups, g0, g1=None, want_dbias=Fals
     dbias = (o[2] if o[2] is not None else torch.empty(C, dtype=F32, device=y.device)) if want_dbias else None
     nb = _lib.query('gx_gn_relu_bwd_ws_bytes', N, C)
     ws = _ws(nb, y.device)
-    _lib.call('gx_gn_relu_bwd', _p(y), _p(gamma), _p(beta), _p(mean), _p(rstd), N, C, H, W, groups,
-              *(_view_args(g0, 'gn_bwd.g0') + _view_args(g1, 'gn_bwd.g1')), _p(dy), _p(dgamma), _p(dbeta),
-              _p(dbias), _p(ws), nb, _stream())
+    direct = o[0] is not None and o[1] is not None and (not want_dbias or o[2] is not None)
+    with _deferring(direct, ws):
+        _lib.call('gx_gn_relu_bwd', _p(y), _p(gamma), _p(beta), _p(mean), _p(rstd), N, C, H, W, groups,
+                  *(_view_args(g0, 'gn_bwd.g0') + _view_args(g1, 'gn_bwd.g1')), _p(dy), _p(dgamma), _p(dbeta),
+                  _p(dbias), _p(ws), nb, _stream())
     return dy, dgamma, dbeta, dbias
 
 

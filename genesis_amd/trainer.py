@@ -10,6 +10,7 @@ import torch.distributed as dist
 
 from . import _lib
 from . import functions as _fn
+from . import hip_ops as _hip
 from .dp import FlatBucket
 from .geco import make_geco
 
@@ -21,7 +22,7 @@ def _p(t):
 class TrainStep(object):
 
     def __init__(self, model, img_size, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, geco=None, use_geco=True,
-                 beta_fixed=0.5, process_group=None, graph=False, async_wgrad=False, weight_cache=True):
+                 beta_fixed=0.5, process_group=None, graph=False, async_wgrad=False, weight_cache=True, defer_reduces=True):
         self.model = model
         self.lr, self.betas, self.eps = lr, betas, eps
         self.device = next(model.parameters()).device
@@ -30,6 +31,7 @@ class TrainStep(object):
         self.geco = geco if geco is not None else (make_geco(img_size, device=self.device) if use_geco else None)
         self.beta_fixed = beta_fixed
         self.async_wgrad = async_wgrad
+        self.defer_reduces = defer_reduces
         self._beta_fixed_t = torch.tensor(float(beta_fixed), device=self.device)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
@@ -62,6 +64,7 @@ class TrainStep(object):
         self.bucket.zero_grad()
         _fn.DIRECT_PARAM_GRADS = True    # bucket zeroed above; kernels write weight grads straight into it
         _fn.begin_direct_grads()
+        _hip.DEFER_REDUCES = self.defer_reduces
         _fn.ASYNC_WGRAD = self.async_wgrad
         # packed-weight cache: the first (never graph-captured) iteration records which weight tensors the conv
         # entry points pack; later iterations re-pack all of them in one launch up front
@@ -79,6 +82,8 @@ class TrainStep(object):
         finally:
             _fn.DIRECT_PARAM_GRADS = False
             _fn.ASYNC_WGRAD = False
+            _hip.DEFER_REDUCES = False
+            _hip.defer_discard()       # no-op after a completed iteration (the queue was flushed)
             if self._wcache is not None:
                 if recording:
                     _lib.call('gx_weight_cache_record', self._wcache, 0)
@@ -137,6 +142,7 @@ class TrainStep(object):
                 self.bucket.set_tail(err, kl)
             beta_used = beta.detach()
         _fn.join_side_stream()     # weight-gradient kernels forked onto the side stream
+        _hip.defer_flush()         # all queued weight-gradient / GroupNorm-affine reductions: one launch per kind
         return fused, beta_used
 
     def _update(self, st, gscale):
@@ -164,6 +170,7 @@ class TrainStep(object):
         self.bucket.zero_grad()
         _fn.DIRECT_PARAM_GRADS = True
         _fn.begin_direct_grads()
+        _hip.DEFER_REDUCES = self.defer_reduces
         _fn.ASYNC_WGRAD = self.async_wgrad
         if self._wcache is not None and self._wcache_ready:
             _lib.call('gx_weight_cache_refresh', self._wcache,
@@ -172,6 +179,8 @@ class TrainStep(object):
     def _end(self):
         _fn.DIRECT_PARAM_GRADS = False
         _fn.ASYNC_WGRAD = False
+        _hip.DEFER_REDUCES = False
+        _hip.defer_discard()
         if self._wcache is not None and self._wcache_ready:
             _lib.call('gx_weight_cache_release')
 

@@ -264,6 +264,17 @@ int gx_weight_cache_refresh(int id, gx_stream_t stream);
 int gx_weight_cache_release(void);
 int gx_weight_cache_destroy(int id);
 
+/* ---- deferred parameter-gradient reductions.  gx_conv3x3_wgrad, gx_deconv5x5s2_wgrad and gx_gn_relu_bwd each end
+ *      in a small reduce launch whose result (dw / dgamma, dbeta) only the optimiser reads.  While
+ *      gx_defer_enable(1) is in effect those calls queue that reduce instead (up to 48 of each kind; beyond that they
+ *      reduce immediately) and gx_defer_flush(stream) finishes all queued ones in one launch per kind, ADDING each
+ *      result to its destination (which the caller has zeroed: a gradient bucket).  Contract: the
+ *      workspaces and output buffers handed to the queued calls stay valid and untouched until the flush.
+ *      gx_defer_enable(-1) switches deferral off and discards the queue without running it (error recovery). */
+int gx_defer_enable(int on);
+int gx_defer_pending(void);
+int gx_defer_flush(gx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -103,8 +103,8 @@ def test_profile_collect():
 
 
 def test_weight_cache_matches_per_call_packing():
-    """The packed-weight cache (one batched re-pack per iteration) must not change a single bit of the training
-    trajectory relative to per-call packing."""
+    """The packed-weight cache (one batched re-pack per iteration) and the deferred, batched parameter-gradient
+    reductions must not change a single bit of the training trajectory relative to per-call packing / reducing."""
     from genesis_amd import _lib
     from genesis_amd.trainer import TrainStep
     gold = Golden('tiny')
@@ -113,7 +113,7 @@ def test_weight_cache_matches_per_call_packing():
     outs = []
     for cache in (False, True):
         model = build(gold)
-        ts = TrainStep(model, gold.S, lr=1e-4, graph=False, weight_cache=cache)
+        ts = TrainStep(model, gold.S, lr=1e-4, graph=False, weight_cache=cache, defer_reduces=cache)
         res = []
         for it in range(4):
             rp, eps = gold.noise(1 + it % 3)
