@@ -527,6 +527,132 @@ gn_relu_bwd_reg_kernel(const float* __restrict__ y, const float* __restrict__ ga
     (void)U;
 }
 
+// ---- tiny slabs (H*W < 256, e.g. the UNet's 4x4 / 8x8 levels): one float4 per thread, the whole (image, group)
+// slab lives in the registers of one small workgroup; per-channel sums go through LDS in a fixed order.  The generic
+// two-pass kernel needs ~28 us for these (a single wave walking the channels serially); this one ~5 us.
+__global__ void __launch_bounds__(1024)
+gn_relu_fwd_small_kernel(const float* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ beta,
+                         int C, int H, int W, int groups, float eps, View d0, View d1,
+                         float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    __shared__ double red[16 * 2 + 2];
+    const int n = blockIdx.x / groups, gidx = blockIdx.x % groups;
+    const int cpg = C / groups, HW = H * W;
+    const int m = cpg * HW;
+    const int e = threadIdx.x * 4;
+    const bool act = e < m;
+    const f32x4* slab4 = reinterpret_cast<const f32x4*>(y + ((size_t)n * C + (size_t)gidx * cpg) * HW);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (act) v = slab4[threadIdx.x];
+    double acc[2];
+    acc[0] = ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
+    acc[1] = ((double)v[0] * v[0] + (double)v[1] * v[1]) + ((double)v[2] * v[2] + (double)v[3] * v[3]);
+    block_sum_multi<2>(acc, red);
+    const double mean = acc[0] / m;
+    double var = acc[1] / m - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float meanf = (float)mean;
+    const float rstdf = (float)(1.0 / sqrt(var + (double)eps));
+    if (threadIdx.x == 0) { mean_out[blockIdx.x] = meanf; rstd_out[blockIdx.x] = rstdf; }
+    if (act) {
+        const int cl = e / HW, hw = e - cl * HW;
+        const int c = gidx * cpg + cl;
+        const int r = hw / W, col = hw - r * W;
+        const float gm = gamma[c], bt = beta[c];
+        f32x4 o;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float t = (v[u] - meanf) * rstdf * gm + bt;
+            o[u] = t > 0.f ? t : 0.f;
+        }
+        store_view4(d0, n, c, r, col, H, W, o);
+        if (d1.ptr) store_view4(d1, n, c, r, col, H, W, o);
+    }
+}
+
+__global__ void __launch_bounds__(1024)
+gn_relu_bwd_small_kernel(const float* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ beta,
+                         const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                         int C, int H, int W, int groups, View g0, View g1,
+                         float* __restrict__ dy, float* __restrict__ part_out) {
+    __shared__ double ta[1024], tb[1024];     // per-thread partials
+    __shared__ double ca[64], cb[64];         // per-channel sums (cpg <= 64)
+    const int n = blockIdx.x / groups, gidx = blockIdx.x % groups;
+    const int cpg = C / groups, HW = H * W;
+    const int m = cpg * HW;
+    const int tpc = HW >> 2;                  // threads per channel
+    const int e = threadIdx.x * 4;
+    const bool act = e < m;
+    const size_t slab_off = ((size_t)n * C + (size_t)gidx * cpg) * HW;
+    const float meanf = mean_in[blockIdx.x], rstdf = rstd_in[blockIdx.x];
+    int cl = 0, c = gidx * cpg, r = 0, col = 0;
+    f32x4 xh = {0.f, 0.f, 0.f, 0.f}, gv = {0.f, 0.f, 0.f, 0.f};
+    float gm = 0.f;
+    double a = 0.0, b = 0.0;
+    if (act) {
+        cl = e / HW;
+        const int hw = e - cl * HW;
+        c = gidx * cpg + cl;
+        r = hw / W; col = hw - r * W;
+        const f32x4 xv = reinterpret_cast<const f32x4*>(y + slab_off)[threadIdx.x];
+        f32x4 g = load_view4(g0, n, c, r, col, H, W);
+        if (g1.ptr) { const f32x4 g2 = load_view4(g1, n, c, r, col, H, W); g += g2; }
+        gm = gamma[c];
+        const float bt = beta[c];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float h = (xv[u] - meanf) * rstdf;
+            const float pre = h * gm + bt;
+            const float gg = pre > 0.f ? g[u] : 0.f;
+            xh[u] = h; gv[u] = gg;
+            a += (double)gg * h;
+            b += (double)gg;
+        }
+    }
+    ta[threadIdx.x] = a; tb[threadIdx.x] = b;
+    __syncthreads();
+    if ((int)threadIdx.x < cpg) {
+        double sa = 0.0, sb = 0.0;
+        for (int i = 0; i < tpc; ++i) { sa += ta[threadIdx.x * tpc + i]; sb += tb[threadIdx.x * tpc + i]; }
+        ca[threadIdx.x] = sa; cb[threadIdx.x] = sb;
+        float* pp = part_out + ((size_t)n * C + gidx * cpg + threadIdx.x) * 3;
+        pp[0] = (float)sa; pp[1] = (float)sb;
+    }
+    __syncthreads();
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < cpg; ++i) {
+        const float gi = gamma[gidx * cpg + i];
+        s1 += cb[i] * gi;
+        s2 += ca[i] * gi;
+    }
+    const float k1 = (float)(s1 / m), k2 = (float)(s2 / m);
+    double sd = 0.0;
+    if (act) {
+        f32x4 o;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float d = rstdf * (gv[u] * gm - k1 - xh[u] * k2);
+            o[u] = d;
+            sd += d;
+        }
+        reinterpret_cast<f32x4*>(dy + slab_off)[threadIdx.x] = o;
+    }
+    __syncthreads();            // ta is re-used for the per-thread dy sums
+    ta[threadIdx.x] = sd;
+    __syncthreads();
+    if ((int)threadIdx.x < cpg) {
+        double s = 0.0;
+        for (int i = 0; i < tpc; ++i) s += ta[threadIdx.x * tpc + i];
+        part_out[((size_t)n * C + gidx * cpg + threadIdx.x) * 3 + 2] = (float)s;
+    }
+}
+
+// threads for the tiny-slab kernels, or 0 if the shape does not qualify
+int small_threads(int cpg, int H, int W) {
+    const int HW = H * W, m = cpg * HW;
+    if (HW >= 256 || (W % 4) != 0 || cpg > 64 || m > 4096) return 0;
+    return gx_round_up(m / 4, 64);
+}
+
 template <int F, int UPW, typename... Args>
 void launch_fwd_reg(dim3 grid, dim3 block, hipStream_t s, Args... args) {
     hipLaunchKernelGGL((gn_relu_fwd_reg_kernel<F, UPW>), grid, block, 0, s, args...);
@@ -617,9 +743,13 @@ int gx_gn_relu_fwd(const float* y, const float* gamma, const float* beta, int N,
         const double el = (double)N * C * H * W;
         GxProf pf(KID_GN_FWD, (hipStream_t)stream, 8.0 * el, 4.0 * el * (1.0 + vw(dst0_mode) + (dst1 ? vw(dst1_mode) : 0.0)));
         const RegPlan pl = plan_reg(C / groups, H, W);
+        const int st = small_threads(C / groups, H, W);
         if (pl.ok)
             GX_GN_REG_DISPATCH(launch_fwd_reg, pl, dim3(N * groups), dim3(pl.threads), (hipStream_t)stream, y, gamma,
                                beta, C, H, W, groups, pl.P, eps, d0, d1, mean, rstd);
+        else if (st)
+            hipLaunchKernelGGL(gn_relu_fwd_small_kernel, dim3(N * groups), dim3(st), 0, (hipStream_t)stream, y, gamma,
+                               beta, C, H, W, groups, eps, d0, d1, mean, rstd);
         else if (vec)
             hipLaunchKernelGGL(gn_relu_fwd_kernel<true>, dim3(N * groups), dim3(threads), 0, (hipStream_t)stream, y,
                                gamma, beta, C, H, W, groups, eps, d0, d1, mean, rstd);
@@ -656,9 +786,13 @@ int gx_gn_relu_bwd(const float* y, const float* gamma, const float* beta, const 
         const double el = (double)N * C * H * W;
         GxProf pf(KID_GN_BWD, s, 16.0 * el, 4.0 * el * (2.0 + vw(g0_mode) + (g1 ? vw(g1_mode) : 0.0)));
         const RegPlan pl = plan_reg(C / groups, H, W);
+        const int st = small_threads(C / groups, H, W);
         if (pl.ok)
             GX_GN_REG_DISPATCH(launch_bwd_reg, pl, dim3(N * groups), dim3(pl.threads), s, y, gamma, beta, mean, rstd,
                                C, H, W, groups, pl.P, v0, v1, dy, (float*)ws);
+        else if (st)
+            hipLaunchKernelGGL(gn_relu_bwd_small_kernel, dim3(N * groups), dim3(st), 0, s, y, gamma, beta, mean, rstd,
+                               C, H, W, groups, v0, v1, dy, (float*)ws);
         else if (vec)
             hipLaunchKernelGGL(gn_relu_bwd_kernel<true>, dim3(N * groups), dim3(threads), 0, s, y, gamma, beta, mean,
                                rstd, C, H, W, groups, v0, v1, dy, (float*)ws);

@@ -73,7 +73,8 @@ def test_deconv5x5s2(N, Cin, Cout, Hin):
 
 
 @pytest.mark.parametrize('N,C,H,W,groups', [(2, 64, 64, 64, 8), (3, 128, 8, 8, 8), (2, 16, 4, 4, 8), (2, 8, 32, 32, 8),
-                                            (1, 64, 128, 128, 8), (4, 32, 2, 2, 8)])
+                                            (1, 64, 128, 128, 8), (4, 32, 2, 2, 8), (5, 64, 8, 8, 8), (2, 128, 4, 4, 8),
+                                            (2, 16, 8, 8, 16), (3, 24, 4, 8, 8)])
 def test_gn_relu_plain(N, C, H, W, groups):
     y = rnd(N, C, H, W, seed=8, scale=2.0) + 0.3
     gamma = 1 + 0.3 * rnd(C, seed=9)
