@@ -143,7 +143,7 @@ prior_logp_bwd_kernel(const float* __restrict__ z, const float* __restrict__ lin
 // out = (loss = err_mean + beta kl_mean, elbo = err_mean + kl_mean, err_mean, kl_mean, beta)
 __global__ void __launch_bounds__(256)
 elbo_fwd_kernel(const float* __restrict__ err, const float* __restrict__ kl, const float* __restrict__ beta,
-                int B, int R, float* __restrict__ out, float* __restrict__ tail) {
+                int B, int R, float* __restrict__ out, float* __restrict__ tail, float* __restrict__ loss) {
     __shared__ double red[2][4];
     double se = 0.0, sk = 0.0;
     for (int i = threadIdx.x; i < B; i += blockDim.x) se += (double)err[i];
@@ -158,6 +158,7 @@ elbo_fwd_kernel(const float* __restrict__ err, const float* __restrict__ kl, con
         const float ef = (float)e, kf = (float)k, bt = *beta;
         out[0] = ef + bt * kf; out[1] = ef + kf; out[2] = ef; out[3] = kf; out[4] = bt;
         if (tail) { tail[0] = ef; tail[1] = kf; }
+        if (loss) loss[0] = out[0];
     }
 }
 
@@ -332,13 +333,13 @@ int gx_latent_prior_logp_bwd(const float* z, const float* lin, const float* g_ou
 }
 
 int gx_elbo_fwd(const float* err, const float* kl, const float* beta, int B, int R, float* out, float* tail,
-                gx_stream_t stream) {
+                float* loss, gx_stream_t stream) {
     GX_CHECK_ARG(err && beta && out, "gx_elbo_fwd: null pointer");
     GX_CHECK_ARG(B > 0 && R >= 0 && (R == 0 || kl), "gx_elbo_fwd: bad B/R (%d,%d) or missing kl", B, R);
     hipStream_t s = (hipStream_t)stream;
     {
         GxProf pf(KID_LATENT, s, 0.0, 4.0 * (B + (double)R * B));
-        hipLaunchKernelGGL(elbo_fwd_kernel, dim3(1), dim3(256), 0, s, err, kl, beta, B, R, out, tail);
+        hipLaunchKernelGGL(elbo_fwd_kernel, dim3(1), dim3(256), 0, s, err, kl, beta, B, R, out, tail, loss);
     }
     GX_CHECK_LAUNCH("gx_elbo_fwd");
     return GX_OK;

@@ -254,11 +254,14 @@ class ICSBPFn(torch.autograd.Function):
         ctx.save_for_backward(feat, conv_w, conv_b, gate, log_sigma, colour, seeds, idx)
         ctx.kernel = kernel
         ctx.mark_non_differentiable(log_s, colour, seeds, idx)
+        ctx.set_materialize_grads(False)   # no zero-filled gradients for the outputs nobody differentiates
         return log_m, log_s, colour, seeds, idx
 
     @staticmethod
     def backward(ctx, g_log_m, *unused):
         feat, conv_w, conv_b, gate, log_sigma, colour, seeds, idx = ctx.saved_tensors
+        if g_log_m is None:       # log_m unused downstream
+            g_log_m = colour.new_zeros(seeds.shape[0] + 1, colour.shape[0], 1, colour.shape[2], colour.shape[3])
         dcolour, dls = hip.icsbp_bwd(colour, log_sigma, seeds, idx, g_log_m.contiguous(), ctx.kernel)
         dfeat, dw, db, dgate = hip.conv1x1_bwd(feat, dcolour, conv_w, conv_b, gate)
         return dfeat, dw, db, dgate, None, dls.to(ctx.ls_dtype), None, None, None, None
@@ -337,12 +340,15 @@ class MixtureFn(torch.autograd.Function):
         ctx.save_for_backward(x, dec)
         ctx.cfg = (K, pixel_std, pixel_bound)
         ctx.mark_non_differentiable(recon, x_r, log_m_r)
+        ctx.set_materialize_grads(False)
         return err, recon, x_r, log_m_r
 
     @staticmethod
     def backward(ctx, g_err, *unused):
         x, dec = ctx.saved_tensors
         K, pixel_std, pixel_bound = ctx.cfg
+        if g_err is None:
+            g_err = x.new_zeros(x.shape[0])
         ddec = hip.mixture_bwd(x, dec, g_err.contiguous(), K, pixel_std, pixel_bound)
         return None, ddec, None, None, None
 
@@ -450,12 +456,15 @@ class MixtureWFn(torch.autograd.Function):
         ctx.save_for_backward(x, dec, log_w)
         ctx.cfg = (K, std1, std2, pixel_bound)
         ctx.mark_non_differentiable(recon, x_r)
+        ctx.set_materialize_grads(False)
         return err, recon, x_r
 
     @staticmethod
     def backward(ctx, g_err, *unused):
         x, dec, log_w = ctx.saved_tensors
         K, std1, std2, pixel_bound = ctx.cfg
+        if g_err is None:
+            g_err = x.new_zeros(x.shape[0])
         ddec, dlog_w = hip.mixture_w_bwd(x, dec, log_w, g_err.contiguous(), K, std1, std2, pixel_bound)
         return None, ddec, dlog_w, None, None, None, None
 
@@ -506,7 +515,8 @@ class PriorLogPFn(torch.autograd.Function):
 
 class ElboFn(torch.autograd.Function):
     """Loss aggregation of train.py:226-242: (err [B], kl [R,B] | None, beta [1] device scalar) ->
-    out[5] = (err_mean + beta kl_mean, err_mean + kl_mean, err_mean, kl_mean, beta); out[0] is the objective."""
+    (loss [1] = err_mean + beta kl_mean, out5 = (loss, err_mean + kl_mean, err_mean, kl_mean, beta), not differentiable).
+    `loss` is its own one-element tensor so that loss.backward() starts the backward pass without a select/scatter."""
 
     @staticmethod
     def forward(ctx, err, kl, beta, tail):
@@ -515,12 +525,15 @@ class ElboFn(torch.autograd.Function):
         ctx.beta = beta
         ctx.dims = (err.numel(), 0 if kl is None else kl.numel() // err.numel())
         ctx.kl_shape = None if kl is None else kl.shape
-        return hip.elbo_fwd(err, kl, beta, tail)
+        loss, out5 = hip.elbo_fwd(err, kl, beta, tail)
+        ctx.mark_non_differentiable(out5)
+        ctx.set_materialize_grads(False)
+        return loss, out5
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _unused):
         B, R = ctx.dims
-        d_err, d_kl = hip.elbo_bwd(g[:1].contiguous(), ctx.beta, B, R)
+        d_err, d_kl = hip.elbo_bwd(g.contiguous(), ctx.beta, B, R)
         return d_err, (d_kl.view(ctx.kl_shape) if d_kl is not None else None), None, None
 
 

@@ -474,8 +474,9 @@ def elbo_fwd(err, kl, beta, tail=None):
     B = err.numel()
     R = 0 if kl is None else kl.numel() // B
     out = torch.empty(5, dtype=F32, device=err.device)
-    _lib.call('gx_elbo_fwd', _p(err), _p(kl), _p(beta), B, R, _p(out), _p(tail), _stream())
-    return out
+    loss = torch.empty(1, dtype=F32, device=err.device)
+    _lib.call('gx_elbo_fwd', _p(err), _p(kl), _p(beta), B, R, _p(out), _p(tail), _p(loss), _stream())
+    return loss, out
 
 
 def elbo_bwd(g_loss, beta, B, R):

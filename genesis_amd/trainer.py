@@ -121,8 +121,8 @@ class TrainStep(object):
                 kl_rows = v.view(1, -1)
         if fused:
             # one launch: batch means, the GECO-weighted objective, and (err, kl) straight into the bucket tail
-            out5 = _fn.ElboFn.apply(losses.err, kl_rows, beta_t, self.bucket.flat_g[self.n32:self.n32 + 2])
-            out5[0].backward()
+            loss, out5 = _fn.ElboFn.apply(losses.err, kl_rows, beta_t, self.bucket.flat_g[self.n32:self.n32 + 2])
+            loss.backward()
             beta_used = out5.detach()
         else:
             err = losses.err.mean(0)

@@ -208,9 +208,9 @@ int gx_latent_prior_logp_bwd(const float* z, const float* lin, const float* g_ou
  *      err_mean = mean_b err[b]; kl_mean = sum_r mean_b kl[r][b] (kl [R,B], R = 0 / NULL: no KL term);
  *      out[5] = (loss = err_mean + beta kl_mean, err_mean + kl_mean, err_mean, kl_mean, beta); beta is read from
  *      device memory (GECO state); tail (NULL to skip) receives (err_mean, kl_mean) -- the gradient bucket's
- *      piggy-backed scalars.  bwd: d_err[b] = g/B, d_kl[r][b] = g beta / B for the scalar g = dL/d loss. */
+ *      piggy-backed scalars; loss (NULL to skip) receives out[0] again (a separate one-element objective tensor).  bwd: d_err[b] = g/B, d_kl[r][b] = g beta / B for the scalar g = dL/d loss. */
 int gx_elbo_fwd(const float* err, const float* kl, const float* beta, int B, int R, float* out, float* tail,
-                gx_stream_t stream);
+                float* loss, gx_stream_t stream);
 int gx_elbo_bwd(const float* g_loss, const float* beta, int B, int R, float* d_err, float* d_kl,
                 gx_stream_t stream);
 

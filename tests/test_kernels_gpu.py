@@ -538,12 +538,13 @@ def test_elbo(B, R):
     kl = (rnd(R, B, seed=2) * 10).to(DEV).requires_grad_() if R else None
     beta = torch.tensor([0.37], device=DEV)
     tail = torch.zeros(2, device=DEV)
-    out = fn.ElboFn.apply(err, kl, beta, tail)
+    loss, out = fn.ElboFn.apply(err, kl, beta, tail)
     e = err.detach().cpu().double().mean()
     k = kl.detach().cpu().double().mean(1).sum() if R else torch.zeros((), dtype=torch.float64)
     close(out, torch.stack((e + 0.37 * k, e + k, e, k, torch.tensor(0.37, dtype=torch.float64))), rtol=1e-6, atol=1e-6)
     close(tail, torch.stack((e, k)), rtol=1e-6, atol=1e-6)
-    out[0].backward()
+    assert float(loss) == float(out[0])
+    loss.backward()
     close(err.grad, torch.full((B,), 1.0 / B), rtol=1e-6, atol=0)
     if R:
         close(kl.grad, torch.full((R, B), 0.37 / B), rtol=1e-6, atol=0)
