@@ -83,6 +83,7 @@ struct ConvGeom {
     int nsplit;       // split of the channel reduction over gridDim.z (partials written when > 1)
     int chunks_per_split;
     int act;          // epilogue activation after the bias: 0 none, 1 ReLU, 2 ELU (applied only when nsplit == 1)
+    const float* zeros;   // zero page for the LDS-DMA staging path (NULL: stage through registers)
 };
 
 __device__ __forceinline__ float gx_act(float v, int act) {
@@ -92,7 +93,7 @@ __device__ __forceinline__ float gx_act(float v, int act) {
 }
 
 // NPOS = halo-tile positions staged per thread per channel (tile <= NPOS*256 floats per channel).
-template <int MODE, int NPOS>
+template <int MODE, int NPOS, bool DMA>
 __device__ __forceinline__ void tapconv_body(const float* __restrict__ in, const float* __restrict__ wp,
                                              const float* __restrict__ bias, float* __restrict__ out,
                                              const ConvGeom& g, float* lds, const int bx, const int by, const int bz,
@@ -217,12 +218,51 @@ __device__ __forceinline__ void tapconv_body(const float* __restrict__ in, const
         }                                                                                                   \
     }
 
-    if (c_begin < c_end) GX_TAP_PREFETCH(c_begin)
+    // LDS-DMA staging (global_load_lds): halo positions outside the image / channels beyond K come from a zero page,
+    // so a chunk costs no staging VGPRs, no selects and no ds_write; destination = wave-uniform base + lane * size.
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+#define GX_TAP_ISSUE(chunk, buf)                                                                            \
+    {                                                                                                       \
+        const int ch0_ = (chunk) * KC;                                                                      \
+        _Pragma("unroll") for (int ch = 0; ch < KC; ++ch) {                                                 \
+            const bool chv = (ch0_ + ch) < g.K;                                                             \
+            const float* src = in_blk + (size_t)(ch0_ + ch) * HiWi;                                         \
+            _Pragma("unroll") for (int q = 0; q < NPOS; ++q) {                                              \
+                if (tid + q * 256 < CHS) {                                                                  \
+                    const float* gp = (chv && goff[q] >= 0) ? src + goff[q] : g.zeros;                      \
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,     \
+                        (__attribute__((address_space(3))) void*)((buf) + ch * CHS + q * 256 + wave_u * 64), 4, 0, 0); \
+                }                                                                                           \
+            }                                                                                               \
+        }                                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < NW4; ++i) {                                                   \
+            const int i4 = tid + i * 256;                                                                   \
+            if (i4 < NT * KC * 16) {                                                                        \
+                const int q4 = i4 & 15;                                                                     \
+                const int kc = (i4 >> 4) & (KC - 1);                                                        \
+                const int t_ = i4 / (16 * KC);                                                              \
+                const float* gp = wp + ((size_t)t_ * g.Kpad + ch0_ + kc) * g.Mpad + m0 + q4 * 4;            \
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,         \
+                    (__attribute__((address_space(3))) void*)((buf) + KC * CHS + (i * 256 + wave_u * 64) * 4), 16, 0, 0); \
+            }                                                                                               \
+        }                                                                                                   \
+    }
+
+    if (DMA) {
+        if (c_begin < c_end) GX_TAP_ISSUE(c_begin, lds)
+    } else {
+        if (c_begin < c_end) GX_TAP_PREFETCH(c_begin)
+    }
     for (int c = c_begin; c < c_end; ++c) {
         float* buf = lds + ((c - c_begin) & 1) * BUF;
-        GX_TAP_COMMIT(buf)
-        __syncthreads();
-        if (c + 1 < c_end) GX_TAP_PREFETCH(c + 1)
+        if (DMA) {
+            __syncthreads();      // this chunk has landed (vmcnt drained before the barrier); the other buffer is free
+            if (c + 1 < c_end) GX_TAP_ISSUE(c + 1, lds + ((c + 1 - c_begin) & 1) * BUF)
+        } else {
+            GX_TAP_COMMIT(buf)
+            __syncthreads();
+            if (c + 1 < c_end) GX_TAP_PREFETCH(c + 1)
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int toff = TC::plane(t) * PLS + TC::ro(t) * HS + TC::co(t);
@@ -280,26 +320,26 @@ __device__ __forceinline__ void tapconv_body(const float* __restrict__ in, const
     }
 }
 
-template <int MODE, int NPOS>
+template <int MODE, int NPOS, bool DMA>
 __global__ void __launch_bounds__(256, 2)
 tapconv_kernel(const float* __restrict__ in, const float* __restrict__ wp,
                const float* __restrict__ bias, float* __restrict__ out, ConvGeom g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    tapconv_body<MODE, NPOS>(in, wp, bias, out, g, lds, blockIdx.x, blockIdx.y, blockIdx.z, g.par_a);
+    tapconv_body<MODE, NPOS, DMA>(in, wp, bias, out, g, lds, blockIdx.x, blockIdx.y, blockIdx.z, g.par_a);
 }
 
 // Both output-row parities of the transposed conv in one launch: blockIdx.y = 2 * channel_tile + parity.  Twice
 // the workgroups of a single-parity launch, so mid-sized layers fill the chip without splitting the channel
 // reduction (and without the partial-sum traffic and reduce pass that come with it).
-template <int NPOS>
+template <int NPOS, bool DMA>
 __global__ void __launch_bounds__(256, 2)
 tapconv_dt_kernel(const float* __restrict__ in, const float* __restrict__ wp0, const float* __restrict__ wp1,
                   const float* __restrict__ bias, float* __restrict__ out, ConvGeom g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (blockIdx.y & 1)
-        tapconv_body<M_DT1, NPOS>(in, wp1, bias, out, g, lds, blockIdx.x, blockIdx.y >> 1, blockIdx.z, 1);
+        tapconv_body<M_DT1, NPOS, DMA>(in, wp1, bias, out, g, lds, blockIdx.x, blockIdx.y >> 1, blockIdx.z, 1);
     else
-        tapconv_body<M_DT0, NPOS>(in, wp0, bias, out, g, lds, blockIdx.x, blockIdx.y >> 1, blockIdx.z, 0);
+        tapconv_body<M_DT0, NPOS, DMA>(in, wp0, bias, out, g, lds, blockIdx.x, blockIdx.y >> 1, blockIdx.z, 0);
 }
 
 // out[i] = sum_z part[z][i] (+ bias[channel]); fixed summation order.
@@ -941,6 +981,7 @@ int plan_tapconv(int N, int K, int M, int Mpad_pack, int Hb, int Wb, int Hi, int
     const int TH = 1 << g.lTH, TW = 1 << g.lTW, G = 1 << g.lG;
     g.tiles_h = gx_ceil_div(Hb, TH); g.tiles_w = gx_ceil_div(Wb, TW);
     g.act = 0;
+    g.zeros = nullptr;
     const int CHS = TC::PLANES * G * (TH + 2) * (TW + 2);
     const int need = gx_ceil_div(CHS, 256);
     const int lo = (MODE == M_DG) ? 8 : 2;
@@ -968,16 +1009,43 @@ int plan_tapconv(int N, int K, int M, int Mpad_pack, int Hb, int Wb, int Hi, int
     return GX_OK;
 }
 
-template <int MODE, int NPOS>
-void launch_tapconv_inst(const float* in, const float* wp, const float* bias, float* out, const TapPlan& pl,
-                         hipStream_t s) {
+template <int MODE, int NPOS, bool DMA>
+void launch_tapconv_inst2(const float* in, const float* wp, const float* bias, float* out, const ConvGeom& g,
+                          dim3 grid, size_t lds_bytes, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_kernel<MODE, NPOS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_kernel<MODE, NPOS, DMA>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((tapconv_kernel<MODE, NPOS>), pl.grid, dim3(256), pl.lds_bytes, s, in, wp, bias, out, pl.g);
+    hipLaunchKernelGGL((tapconv_kernel<MODE, NPOS, DMA>), grid, dim3(256), lds_bytes, s, in, wp, bias, out, g);
+}
+
+const float* zero_page(hipStream_t s);
+
+template <int MODE, int NPOS>
+void launch_tapconv_inst(const float* in, const float* wp, const float* bias, float* out, const TapPlan& pl,
+                         hipStream_t s) {
+    ConvGeom g = pl.g;
+    // LDS-DMA staging measured per mode (B=32, K=7): transposed conv fwd 32->64 481 -> 431 us, its dgrad 462 -> 454,
+    // conv3x3 1-2 % slower -> on for the 5x5 modes, off for conv3x3 (GENESIS_TAPCONV_DMA=0/1 forces all modes)
+    static const char* dma_env = getenv("GENESIS_TAPCONV_DMA");
+    const bool dma = dma_env ? dma_env[0] == '1' : MODE != M_C3;
+    g.zeros = dma ? zero_page(s) : nullptr;
+    if (g.zeros) launch_tapconv_inst2<MODE, NPOS, true>(in, wp, bias, out, g, pl.grid, pl.lds_bytes, s);
+    else launch_tapconv_inst2<MODE, NPOS, false>(in, wp, bias, out, g, pl.grid, pl.lds_bytes, s);
+}
+
+template <int NPOS, bool DMA>
+void launch_dt(dim3 grid, size_t lds_bytes, hipStream_t s, const float* x, const float* wp0, const float* wp1,
+               const float* bias, float* dst, const ConvGeom& g) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_dt_kernel<NPOS, DMA>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((tapconv_dt_kernel<NPOS, DMA>), grid, dim3(256), lds_bytes, s, x, wp0, wp1, bias, dst, g);
 }
 
 // `dst` = final output when nsplit == 1, else the partial slabs [nsplit][N,M,Ho,Wo]
@@ -1640,22 +1708,15 @@ int gx_deconv5x5s2_fwd(const float* x, const float* w, const float* bias, float*
                                     25.0 * g.K * g.M);
         GxProf pf(KID_TAPCONV_DT0, s, flops, bytes);
         dim3 grid(p0.grid.x, p0.grid.y * 2, p0.grid.z);
-        if (p0.npos == 2) {
-            static bool attr2 = false;
-            if (!attr2) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_dt_kernel<2>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                attr2 = true;
-            }
-            hipLaunchKernelGGL((tapconv_dt_kernel<2>), grid, dim3(256), p0.lds_bytes, s, x, wpu0, wpu1, bias, dst, p0.g);
+        ConvGeom gg = p0.g;
+        static const char* dma_env = getenv("GENESIS_TAPCONV_DMA");
+        gg.zeros = (dma_env ? dma_env[0] == '1' : true) ? zero_page(s) : nullptr;
+        if (gg.zeros) {
+            if (p0.npos == 2) launch_dt<2, true>(grid, p0.lds_bytes, s, x, wpu0, wpu1, bias, dst, gg);
+            else launch_dt<4, true>(grid, p0.lds_bytes, s, x, wpu0, wpu1, bias, dst, gg);
         } else {
-            static bool attr4 = false;
-            if (!attr4) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_dt_kernel<4>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                attr4 = true;
-            }
-            hipLaunchKernelGGL((tapconv_dt_kernel<4>), grid, dim3(256), p0.lds_bytes, s, x, wpu0, wpu1, bias, dst, p0.g);
+            if (p0.npos == 2) launch_dt<2, false>(grid, p0.lds_bytes, s, x, wpu0, wpu1, bias, dst, gg);
+            else launch_dt<4, false>(grid, p0.lds_bytes, s, x, wpu0, wpu1, bias, dst, gg);
         }
     }
     GX_CHECK_LAUNCH("gx_deconv5x5s2_fwd");

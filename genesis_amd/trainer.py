@@ -203,19 +203,20 @@ class TrainStep(object):
         self._split = self._needs_collective()
         if not self._split:
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
                 self._out = self._iteration(self._static_x)
         else:
             self._gscale = 1.0 / self.world
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            # thread_local: the process group's watchdog thread polls events while we capture
+            with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
                 self._begin()
                 try:
                     self._st = self._forward_backward(self._static_x)
                 finally:
                     self._end()
             self.graph2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph2, pool=self.graph.pool()):
+            with torch.cuda.graph(self.graph2, pool=self.graph.pool(), capture_error_mode='thread_local'):
                 with torch.no_grad():
                     self._out = self._update(self._st, self._gscale)
         with torch.no_grad():
