@@ -10,6 +10,8 @@
 //                    models/genesisv2_config.py:99 (decoder_module.13: Conv2d(64, 4, 1))
 #include "gx_common.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int KMAX = 16;
@@ -417,6 +419,78 @@ conv1x1_wgrad_mfma_kernel(const float* __restrict__ x, const float* __restrict__
     }
 }
 
+// LDS-staged variant (Cin <= 64, H*W a multiple of 256).  The direct-from-global kernel above is bound by the
+// MFMA operand layout: lanes of one load differ by channel (16 KB apart) and pixel slot, so every load instruction
+// is a 64-line gather (2.2 TB/s on the 235 MB decoder activation).  Here a workgroup stages a 256-pixel tile of all
+// channels with fully coalesced 16-byte loads (one channel row segment = 1 KiB per wave instruction; the next tile is
+// prefetched into registers while the current one is consumed), and the MFMA fragments are read from LDS
+// (row stride 260 floats: the 64 lanes of a fragment read spread over all banks twice = conflict-free).
+constexpr int C1_TP = 256, C1_LS = 260;
+__global__ void __launch_bounds__(256)
+conv1x1_wgrad_lds_kernel(const float* __restrict__ x, const float* __restrict__ dy, int N, int Cin, int Cout,
+                         int HW, float* __restrict__ pw) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* xs = sm;                       // [64][C1_LS]
+    float* ds = sm + 64 * C1_LS;          // [8][C1_LS]
+    float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(sm);   // epilogue re-uses the tile memory
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int idx = lane & 15, kq = lane >> 4;
+    const int tiles_per_img = HW / C1_TP;
+    const int ntiles = N * tiles_per_img;
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { acc[t][0] = 0.f; acc[t][1] = 0.f; acc[t][2] = 0.f; acc[t][3] = 0.f; }
+    f32x4 xr[16], dr[2];
+#define C1_LOAD(tile_)                                                                              \
+    {                                                                                               \
+        const int n_ = (tile_) / tiles_per_img;                                                     \
+        const int p0_ = ((tile_) - n_ * tiles_per_img) * C1_TP + 4 * lane;                          \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                            \
+            const int ch = wave + 4 * i;                                                            \
+            if (ch < Cin) xr[i] = *reinterpret_cast<const f32x4*>(x + ((size_t)n_ * Cin + ch) * HW + p0_); \
+            else { xr[i][0] = 0.f; xr[i][1] = 0.f; xr[i][2] = 0.f; xr[i][3] = 0.f; }                \
+        }                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                             \
+            const int co = wave + 4 * i;                                                            \
+            if (co < Cout) dr[i] = *reinterpret_cast<const f32x4*>(dy + ((size_t)n_ * Cout + co) * HW + p0_); \
+            else { dr[i][0] = 0.f; dr[i][1] = 0.f; dr[i][2] = 0.f; dr[i][3] = 0.f; }                \
+        }                                                                                           \
+    }
+    int tile = blockIdx.x;
+    if (tile < ntiles) C1_LOAD(tile)
+    for (; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();                  // previous tile fully consumed
+#pragma unroll
+        for (int i = 0; i < 16; ++i) *reinterpret_cast<f32x4*>(xs + (wave + 4 * i) * C1_LS + 4 * lane) = xr[i];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(ds + (wave + 4 * i) * C1_LS + 4 * lane) = dr[i];
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) C1_LOAD(tile + gridDim.x)
+        const float* ap = ds + (idx & 7) * C1_LS + 64 * wave + kq;
+        const float* bp = xs + idx * C1_LS + 64 * wave + kq;
+        const bool a_ok = idx < 8;
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            const float a = a_ok ? ap[4 * st] : 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp[t * 16 * C1_LS + 4 * st], acc[t], 0, 0, 0);
+        }
+    }
+#undef C1_LOAD
+    __syncthreads();
+    // C/D layout (16x16): col = lane & 15 (ci), row = (lane >> 4) * 4 + reg (co)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][kq * 4 + r][t * 16 + idx] = acc[t][r];
+    __syncthreads();
+    for (int i = tid; i < Cout * Cin; i += blockDim.x) {
+        const int co = i / Cin, ci = i - co * Cin;
+        pw[(size_t)blockIdx.x * Cout * Cin + i] = (red[0][co][ci] + red[1][co][ci]) + (red[2][co][ci] + red[3][co][ci]);
+    }
+}
+
 // raw = [dw_raw (Cout*Cin) | db_raw (Cout)] (ungated sums).  dgate = <w, dw_raw> + <b, db_raw>
 // (since sum_p dy*(W x + b) = sum_ci w * (sum_p dy x) + b * sum_p dy); dw = gate*dw_raw; db = gate*db_raw.
 __global__ void __launch_bounds__(256)
@@ -618,7 +692,17 @@ int gx_conv1x1_bwd(const float* x, const float* dy, const float* w, const float*
     GX_CHECK_LAUNCH("gx_conv1x1_bwd(dgrad)");
     {
         GxProf pf(KID_CONV1X1_WGRAD, s, 2.0 * N * Cin * Cout * HW, 4.0 * N * HW * (Cin + Cout));
-        if (Cin <= 64)
+        static const bool legacy = getenv("GENESIS_CONV1X1_WGRAD_LEGACY") != nullptr;
+        if (Cin <= 64 && (HW % C1_TP) == 0 && !legacy) {
+            static bool attr_set = false;
+            const size_t lds = (size_t)(64 + 8) * C1_LS * sizeof(float);
+            if (!attr_set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_wgrad_lds_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(conv1x1_wgrad_lds_kernel, dim3(nblkw), dim3(256), lds, s, x, dy, N, Cin, Cout, HW, pw);
+        } else if (Cin <= 64)
             hipLaunchKernelGGL(conv1x1_wgrad_mfma_kernel<4>, dim3(nblkw), dim3(256), 0, s, x, dy, N, Cin, Cout, HW, pw);
         else
             hipLaunchKernelGGL(conv1x1_wgrad_mfma_kernel<8>, dim3(nblkw), dim3(256), 0, s, x, dy, N, Cin, Cout, HW, pw);
