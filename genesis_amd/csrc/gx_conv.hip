@@ -1560,7 +1560,8 @@ size_t gx_conv3x3_ws_bytes(int N, int Cin, int Cout, int H, int W) {
 }
 
 static int conv3x3_fwd_impl(const float* x, const float* w, const float* bias, int act, float* y, int N, int Cin,
-                            int Cout, int H, int W, void* ws, size_t ws_bytes, gx_stream_t stream);
+                            int Cout, int H, int W, void* ws, size_t ws_bytes, gx_stream_t stream,
+                            const float** parts_out = nullptr, int* nsplit_out = nullptr);
 
 int gx_conv3x3_fwd(const float* x, const float* w, float* y, int N, int Cin, int Cout, int H, int W,
                    void* ws, size_t ws_bytes, gx_stream_t stream) {
@@ -1573,8 +1574,16 @@ int gx_conv3x3_bias_act_fwd(const float* x, const float* w, const float* bias, i
     return conv3x3_fwd_impl(x, w, bias, act, y, N, Cin, Cout, H, W, ws, ws_bytes, stream);
 }
 
+int gx_conv3x3_fwd_parts(const float* x, const float* w, float* y, int N, int Cin, int Cout, int H, int W, void* ws,
+                         size_t ws_bytes, const float** parts, int* nsplit, size_t* split_stride, gx_stream_t stream) {
+    GX_CHECK_ARG(parts && nsplit && split_stride, "gx_conv3x3_fwd_parts: null out-parameter");
+    *split_stride = (size_t)N * Cout * H * W;
+    return conv3x3_fwd_impl(x, w, nullptr, 0, y, N, Cin, Cout, H, W, ws, ws_bytes, stream, parts, nsplit);
+}
+
 static int conv3x3_fwd_impl(const float* x, const float* w, const float* bias, int act, float* y, int N, int Cin,
-                            int Cout, int H, int W, void* ws, size_t ws_bytes, gx_stream_t stream) {
+                            int Cout, int H, int W, void* ws, size_t ws_bytes, gx_stream_t stream,
+                            const float** parts_out, int* nsplit_out) {
     int rc = check_dims("gx_conv3x3_fwd", N, Cin, Cout, H, W);
     if (rc) return rc;
     GX_CHECK_ARG(x && w && y && ws, "gx_conv3x3_fwd: null pointer");
@@ -1592,6 +1601,11 @@ static int conv3x3_fwd_impl(const float* x, const float* w, const float* bias, i
     if (rc) return rc;
     rc = launch_tapconv<M_C3>(x, wpu, bias, pl.g.nsplit > 1 ? part : y, pl, s, "gx_conv3x3_fwd");
     if (rc) return rc;
+    if (parts_out) {          // the consumer (gx_gn_relu_fwd_parts) sums the split-K slabs itself
+        *parts_out = pl.g.nsplit > 1 ? part : y;
+        *nsplit_out = pl.g.nsplit;
+        return GX_OK;
+    }
     if (pl.g.nsplit > 1) return launch_splitk_reduce(part, bias, y, pl, s);
     return GX_OK;
 }
@@ -1679,8 +1693,26 @@ size_t gx_deconv5x5s2_ws_bytes(int N, int Cin, int Cout, int Hin, int Win) {
     return (deconv_pack_floats(Cin, Cout) + part) * sizeof(float);
 }
 
+static int deconv_fwd_impl(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int Cout,
+                           int Hin, int Win, void* ws, size_t ws_bytes, gx_stream_t stream, const float** parts_out,
+                           int* nsplit_out);
+
 int gx_deconv5x5s2_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int Cout,
                        int Hin, int Win, void* ws, size_t ws_bytes, gx_stream_t stream) {
+    return deconv_fwd_impl(x, w, bias, y, N, Cin, Cout, Hin, Win, ws, ws_bytes, stream, nullptr, nullptr);
+}
+
+int gx_deconv5x5s2_fwd_parts(const float* x, const float* w, float* y, int N, int Cin, int Cout, int Hin, int Win,
+                             void* ws, size_t ws_bytes, const float** parts, int* nsplit, size_t* split_stride,
+                             gx_stream_t stream) {
+    GX_CHECK_ARG(parts && nsplit && split_stride, "gx_deconv5x5s2_fwd_parts: null out-parameter");
+    *split_stride = (size_t)N * Cout * 4 * Hin * Win;
+    return deconv_fwd_impl(x, w, nullptr, y, N, Cin, Cout, Hin, Win, ws, ws_bytes, stream, parts, nsplit);
+}
+
+static int deconv_fwd_impl(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int Cout,
+                           int Hin, int Win, void* ws, size_t ws_bytes, gx_stream_t stream, const float** parts_out,
+                           int* nsplit_out) {
     int rc = check_dims("gx_deconv5x5s2_fwd", N, Cin, Cout, Hin, Win);
     if (rc) return rc;
     GX_CHECK_ARG(x && w && y && ws, "gx_deconv5x5s2_fwd: null pointer");
@@ -1720,6 +1752,11 @@ int gx_deconv5x5s2_fwd(const float* x, const float* w, const float* bias, float*
         }
     }
     GX_CHECK_LAUNCH("gx_deconv5x5s2_fwd");
+    if (parts_out) {
+        *parts_out = p0.g.nsplit > 1 ? part : y;
+        *nsplit_out = p0.g.nsplit;
+        return GX_OK;
+    }
     if (p0.g.nsplit > 1) return launch_splitk_reduce(part, bias, y, p0, s);
     return GX_OK;
 }

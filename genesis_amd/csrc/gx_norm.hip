@@ -24,6 +24,32 @@ struct View {
     int mode;     // 0: same size; 1: buffer is 2x larger (nearest up); 2: buffer is 2x smaller (picks [::2, ::2])
 };
 
+// Input of the forward kernels: the conv output, possibly still as `nsplit` split-K partial slabs (summed here in
+// slab order, exactly as the stand-alone reduce would) plus the conv bias; the summed tensor is written to `ysum`
+// (the backward pass needs it).  nsplit == 1, no bias, no ysum: a plain tensor.
+struct InSrc {
+    const float* p;
+    int nsplit;
+    size_t stride;        // floats between partial slabs
+    const float* bias;    // per channel, may be null
+    float* ysum;          // may be null iff nsplit == 1 and bias == null
+};
+
+__device__ __forceinline__ f32x4 load_in4(const InSrc& s, size_t off, int c) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(s.p + off);
+    for (int z = 1; z < s.nsplit; ++z) v += *reinterpret_cast<const f32x4*>(s.p + (size_t)z * s.stride + off);
+    if (s.bias) v += s.bias[c];
+    if (s.ysum) *reinterpret_cast<f32x4*>(s.ysum + off) = v;
+    return v;
+}
+__device__ __forceinline__ float load_in1(const InSrc& s, size_t off, int c) {
+    float v = s.p[off];
+    for (int z = 1; z < s.nsplit; ++z) v += s.p[(size_t)z * s.stride + off];
+    if (s.bias) v += s.bias[c];
+    if (s.ysum) s.ysum[off] = v;
+    return v;
+}
+
 __device__ __forceinline__ double block_sum_d(double v, double* red) {
     v = gx_wave_sum_d(v);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -134,25 +160,26 @@ __device__ __forceinline__ f32x4 load_view4(const View& v, int n, int c, int r, 
 // VEC: 16-byte accesses along W (needs W % 4 == 0); scalar otherwise (W == 2).
 template <bool VEC>
 __global__ void __launch_bounds__(1024)
-gn_relu_fwd_kernel(const float* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ beta,
+gn_relu_fwd_kernel(const InSrc src, const float* __restrict__ gamma, const float* __restrict__ beta,
                    int C, int H, int W, int groups, float eps, View d0, View d1,
                    float* __restrict__ mean_out, float* __restrict__ rstd_out) {
     __shared__ double red[16 * 2 + 2];
     const int n = blockIdx.x / groups, gidx = blockIdx.x % groups;
     const int cpg = C / groups, HW = H * W;
     const int m = cpg * HW;
-    const float* slab = y + ((size_t)n * C + (size_t)gidx * cpg) * HW;
+    const size_t slab_off = ((size_t)n * C + (size_t)gidx * cpg) * HW;
+    // pass 2 re-reads what pass 1 produced: the summed tensor if one was written (same thread, same elements)
+    const float* slab = (src.ysum ? src.ysum : src.p) + slab_off;
     double acc[2] = {0.0, 0.0};
     if (VEC) {
-        const f32x4* s4 = reinterpret_cast<const f32x4*>(slab);
         for (int i = threadIdx.x; i < (m >> 2); i += blockDim.x) {
-            const f32x4 v = s4[i];
+            const f32x4 v = load_in4(src, slab_off + 4 * (size_t)i, gidx * cpg + (4 * i) / HW);
             acc[0] += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
             acc[1] += ((double)v[0] * v[0] + (double)v[1] * v[1]) + ((double)v[2] * v[2] + (double)v[3] * v[3]);
         }
     } else {
         for (int i = threadIdx.x; i < m; i += blockDim.x) {
-            const float v = slab[i];
+            const float v = load_in1(src, slab_off + i, gidx * cpg + i / HW);
             acc[0] += v; acc[1] += (double)v * v;
         }
     }
@@ -366,7 +393,7 @@ RegPlan plan_reg(int cpg, int H, int W) {
 
 template <int F, int UPW>
 __global__ void __launch_bounds__(1024)
-gn_relu_fwd_reg_kernel(const float* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ beta,
+gn_relu_fwd_reg_kernel(const InSrc src, const float* __restrict__ gamma, const float* __restrict__ beta,
                        int C, int H, int W, int groups, int P, float eps, View d0, View d1,
                        float* __restrict__ mean_out, float* __restrict__ rstd_out) {
     __shared__ double red[16 * 2 + 2];
@@ -375,7 +402,7 @@ gn_relu_fwd_reg_kernel(const float* __restrict__ y, const float* __restrict__ ga
     const int m = cpg * HW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q4 = (HW >> 2) / P;  // float4 per unit
-    const f32x4* slab4 = reinterpret_cast<const f32x4*>(y + ((size_t)n * C + (size_t)gidx * cpg) * HW);
+    const size_t slab_off = ((size_t)n * C + (size_t)gidx * cpg) * HW;
     f32x4 xr[UPW][F];
     double acc[2] = {0.0, 0.0};
 #pragma unroll
@@ -383,7 +410,9 @@ gn_relu_fwd_reg_kernel(const float* __restrict__ y, const float* __restrict__ ga
         const int unit = wave * UPW + u;
         const int cl = unit / P, part = unit - cl * P;
 #pragma unroll
-        for (int j = 0; j < F; ++j) xr[u][j] = slab4[cl * (HW >> 2) + part * q4 + j * 64 + lane];
+        for (int j = 0; j < F; ++j)
+            xr[u][j] = load_in4(src, slab_off + (size_t)cl * HW + 4 * (size_t)(part * q4 + j * 64 + lane),
+                                gidx * cpg + cl);
     }
 #pragma unroll
     for (int u = 0; u < UPW; ++u)
@@ -531,7 +560,7 @@ gn_relu_bwd_reg_kernel(const float* __restrict__ y, const float* __restrict__ ga
 // slab lives in the registers of one small workgroup; per-channel sums go through LDS in a fixed order.  The generic
 // two-pass kernel needs ~28 us for these (a single wave walking the channels serially); this one ~5 us.
 __global__ void __launch_bounds__(1024)
-gn_relu_fwd_small_kernel(const float* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ beta,
+gn_relu_fwd_small_kernel(const InSrc src, const float* __restrict__ gamma, const float* __restrict__ beta,
                          int C, int H, int W, int groups, float eps, View d0, View d1,
                          float* __restrict__ mean_out, float* __restrict__ rstd_out) {
     __shared__ double red[16 * 2 + 2];
@@ -540,9 +569,9 @@ gn_relu_fwd_small_kernel(const float* __restrict__ y, const float* __restrict__ 
     const int m = cpg * HW;
     const int e = threadIdx.x * 4;
     const bool act = e < m;
-    const f32x4* slab4 = reinterpret_cast<const f32x4*>(y + ((size_t)n * C + (size_t)gidx * cpg) * HW);
+    const size_t slab_off = ((size_t)n * C + (size_t)gidx * cpg) * HW;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (act) v = slab4[threadIdx.x];
+    if (act) v = load_in4(src, slab_off + e, gidx * cpg + e / HW);
     double acc[2];
     acc[0] = ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
     acc[1] = ((double)v[0] * v[0] + (double)v[1] * v[1]) + ((double)v[2] * v[2] + (double)v[3] * v[3]);
@@ -724,9 +753,35 @@ int gx_defer_flush_gn(const GxGnRed* items, int n, hipStream_t s) {
 
 extern "C" {
 
+static int gn_relu_fwd_impl(const InSrc& src, const float* gamma, const float* beta, int N, int C, int H, int W,
+                            int groups, float eps, float* dst0, int dst0_ctot, int dst0_c0, int dst0_mode,
+                            float* dst1, int dst1_ctot, int dst1_c0, int dst1_mode, float* mean, float* rstd,
+                            gx_stream_t stream);
+
 int gx_gn_relu_fwd(const float* y, const float* gamma, const float* beta, int N, int C, int H, int W, int groups,
                    float eps, float* dst0, int dst0_ctot, int dst0_c0, int dst0_mode, float* dst1, int dst1_ctot,
                    int dst1_c0, int dst1_mode, float* mean, float* rstd, gx_stream_t stream) {
+    const InSrc src{y, 1, 0, nullptr, nullptr};
+    return gn_relu_fwd_impl(src, gamma, beta, N, C, H, W, groups, eps, dst0, dst0_ctot, dst0_c0, dst0_mode, dst1,
+                            dst1_ctot, dst1_c0, dst1_mode, mean, rstd, stream);
+}
+
+int gx_gn_relu_fwd_parts(const float* parts, int nsplit, size_t split_stride, const float* conv_bias, float* y_sum,
+                         const float* gamma, const float* beta, int N, int C, int H, int W, int groups, float eps,
+                         float* dst0, int dst0_ctot, int dst0_c0, int dst0_mode, float* dst1, int dst1_ctot,
+                         int dst1_c0, int dst1_mode, float* mean, float* rstd, gx_stream_t stream) {
+    GX_CHECK_ARG(nsplit >= 1, "gx_gn_relu_fwd_parts: nsplit must be >= 1");
+    GX_CHECK_ARG(y_sum || (nsplit == 1 && !conv_bias), "gx_gn_relu_fwd_parts: y_sum is required when summing / biasing");
+    const InSrc src{parts, nsplit, split_stride, conv_bias, y_sum};
+    return gn_relu_fwd_impl(src, gamma, beta, N, C, H, W, groups, eps, dst0, dst0_ctot, dst0_c0, dst0_mode, dst1,
+                            dst1_ctot, dst1_c0, dst1_mode, mean, rstd, stream);
+}
+
+static int gn_relu_fwd_impl(const InSrc& src, const float* gamma, const float* beta, int N, int C, int H, int W,
+                            int groups, float eps, float* dst0, int dst0_ctot, int dst0_c0, int dst0_mode,
+                            float* dst1, int dst1_ctot, int dst1_c0, int dst1_mode, float* mean, float* rstd,
+                            gx_stream_t stream) {
+    const float* y = src.p;
     GX_CHECK_ARG(y && gamma && beta && dst0 && mean && rstd, "gx_gn_relu_fwd: null pointer");
     GX_CHECK_ARG(N > 0 && C > 0 && groups > 0 && C % groups == 0, "gx_gn_relu_fwd: bad N/C/groups");
     GX_CHECK_ARG(gx_is_pow2(H) && gx_is_pow2(W) && W >= 2 && H >= 2, "gx_gn_relu_fwd: H,W must be powers of two >= 2");
@@ -741,20 +796,21 @@ int gx_gn_relu_fwd(const float* y, const float* gamma, const float* beta, int N,
         // algorithmic bytes: read y once, write each destination view once
         auto vw = [](int mode) { return mode == 1 ? 4.0 : (mode == 2 ? 0.25 : 1.0); };
         const double el = (double)N * C * H * W;
-        GxProf pf(KID_GN_FWD, (hipStream_t)stream, 8.0 * el, 4.0 * el * (1.0 + vw(dst0_mode) + (dst1 ? vw(dst1_mode) : 0.0)));
+        GxProf pf(KID_GN_FWD, (hipStream_t)stream, 8.0 * el,
+                  4.0 * el * (src.nsplit + (src.ysum ? 1.0 : 0.0) + vw(dst0_mode) + (dst1 ? vw(dst1_mode) : 0.0)));
         const RegPlan pl = plan_reg(C / groups, H, W);
         const int st = small_threads(C / groups, H, W);
         if (pl.ok)
-            GX_GN_REG_DISPATCH(launch_fwd_reg, pl, dim3(N * groups), dim3(pl.threads), (hipStream_t)stream, y, gamma,
+            GX_GN_REG_DISPATCH(launch_fwd_reg, pl, dim3(N * groups), dim3(pl.threads), (hipStream_t)stream, src, gamma,
                                beta, C, H, W, groups, pl.P, eps, d0, d1, mean, rstd);
         else if (st)
-            hipLaunchKernelGGL(gn_relu_fwd_small_kernel, dim3(N * groups), dim3(st), 0, (hipStream_t)stream, y, gamma,
+            hipLaunchKernelGGL(gn_relu_fwd_small_kernel, dim3(N * groups), dim3(st), 0, (hipStream_t)stream, src, gamma,
                                beta, C, H, W, groups, eps, d0, d1, mean, rstd);
         else if (vec)
-            hipLaunchKernelGGL(gn_relu_fwd_kernel<true>, dim3(N * groups), dim3(threads), 0, (hipStream_t)stream, y,
+            hipLaunchKernelGGL(gn_relu_fwd_kernel<true>, dim3(N * groups), dim3(threads), 0, (hipStream_t)stream, src,
                                gamma, beta, C, H, W, groups, eps, d0, d1, mean, rstd);
         else
-            hipLaunchKernelGGL(gn_relu_fwd_kernel<false>, dim3(N * groups), dim3(threads), 0, (hipStream_t)stream, y,
+            hipLaunchKernelGGL(gn_relu_fwd_kernel<false>, dim3(N * groups), dim3(threads), 0, (hipStream_t)stream, src,
                                gamma, beta, C, H, W, groups, eps, d0, d1, mean, rstd);
     }
     GX_CHECK_LAUNCH("gx_gn_relu_fwd");

@@ -92,9 +92,8 @@ class ConvGNReLUFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, gamma, beta):
         x = x.contiguous()
-        y = hip.conv3x3_fwd(x, w)
-        out = torch.empty_like(y)
-        mean, rstd = hip.gn_relu_fwd(y, gamma, beta, GROUPS, EPS, (out, 0, 0))
+        out = torch.empty(x.shape[0], w.shape[0], x.shape[2], x.shape[3], device=x.device)
+        y, mean, rstd = hip.conv3x3_gn_relu_fwd(x, w, gamma, beta, GROUPS, EPS, (out, 0, 0))
         ctx.save_for_backward(x, y, mean, rstd)
         ctx.params = (w, gamma, beta)
         return out
@@ -137,16 +136,17 @@ class UNetEncoderFn(torch.autograd.Function):
         mlp_in = None
         for i in range(nb):
             w, gamma, beta = down[i]
-            y = hip.conv3x3_fwd(cur, w)
-            C = y.shape[1]
+            C, Hc, Wc = w.shape[0], cur.shape[2], cur.shape[3]
             j = nb - 1 - i
             cx = cats[j].shape[1] - C
             if i < nb - 1:
-                nxt = torch.empty(N, C, y.shape[2] // 2, y.shape[3] // 2, device=dev)
-                mean, rstd = hip.gn_relu_fwd(y, gamma, beta, ngroups(C), EPS, (cats[j], cx, 0), (nxt, 0, 2))
+                nxt = torch.empty(N, C, Hc // 2, Wc // 2, device=dev)
+                y, mean, rstd = hip.conv3x3_gn_relu_fwd(cur, w, gamma, beta, ngroups(C), EPS, (cats[j], cx, 0),
+                                                        (nxt, 0, 2))
             else:
-                nxt = torch.empty(N, C, y.shape[2], y.shape[3], device=dev)
-                mean, rstd = hip.gn_relu_fwd(y, gamma, beta, ngroups(C), EPS, (cats[j], cx, 0), (nxt, 0, 0))
+                nxt = torch.empty(N, C, Hc, Wc, device=dev)
+                y, mean, rstd = hip.conv3x3_gn_relu_fwd(cur, w, gamma, beta, ngroups(C), EPS, (cats[j], cx, 0),
+                                                        (nxt, 0, 0))
                 mlp_in = nxt
             saved_down.append((cur, y, mean, rstd))
             cur = nxt
@@ -164,12 +164,13 @@ class UNetEncoderFn(torch.autograd.Function):
         out = None
         for j in range(nb):
             w, gamma, beta = up[j]
-            y = hip.conv3x3_fwd(cats[j], w)
             if j < nb - 1:
-                mean, rstd = hip.gn_relu_fwd(y, gamma, beta, ngroups(y.shape[1]), EPS, (cats[j + 1], 0, 1))
+                y, mean, rstd = hip.conv3x3_gn_relu_fwd(cats[j], w, gamma, beta, ngroups(w.shape[0]), EPS,
+                                                        (cats[j + 1], 0, 1))
             else:
-                out = torch.empty_like(y)
-                mean, rstd = hip.gn_relu_fwd(y, gamma, beta, ngroups(y.shape[1]), EPS, (out, 0, 0))
+                out = torch.empty(N, w.shape[0], cats[j].shape[2], cats[j].shape[3], device=dev)
+                y, mean, rstd = hip.conv3x3_gn_relu_fwd(cats[j], w, gamma, beta, ngroups(w.shape[0]), EPS,
+                                                        (out, 0, 0))
             saved_up.append((y, mean, rstd))
         ctx.nb = nb
         ctx.params = params
@@ -294,9 +295,8 @@ class DecoderFn(torch.autograd.Function):
         saved = []
         for l in range(4):
             w, b, gamma, beta = params[4 * l:4 * l + 4]
-            y = hip.deconv5x5s2_fwd(h, w, b)
-            a = torch.empty_like(y)
-            mean, rstd = hip.gn_relu_fwd(y, gamma, beta, GROUPS, EPS, (a, 0, 0))
+            a = torch.empty(N, w.shape[1], 2 * h.shape[2], 2 * h.shape[3], device=h.device)
+            y, mean, rstd = hip.deconv5x5s2_gn_relu_fwd(h, w, b, gamma, beta, GROUPS, EPS, (a, 0, 0))
             saved.append((h, y, mean, rstd))
             h = a
         ow, ob = params[16], params[17]

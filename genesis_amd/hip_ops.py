@@ -4,6 +4,7 @@ every call goes through the C ABI in include/genesis_hip.h on torch's current HI
 PyTorch is used for device memory (caching allocator) and streams only.  There is no CPU or eager
 fallback: non-HIP tensors raise."""
 import ctypes
+import os
 
 import torch
 
@@ -172,6 +173,54 @@ def gn_relu_fwd(y, gamma, beta, groups, eps, dst0, dst1=None):
     _lib.call('gx_gn_relu_fwd', _p(y), _p(gamma), _p(beta), N, C, H, W, groups, float(eps),
               *(_view_args(dst0, 'gn.dst0') + _view_args(dst1, 'gn.dst1')), _p(mean), _p(rstd), _stream())
     return mean, rstd
+
+
+# ------------------------------------------------------------------ conv -> GroupNorm+ReLU without the split-K reduce pass
+# Measured (B=32, K=7): letting GroupNorm sum the split-K slabs itself removes 10 reduce launches per step but makes
+# the norm kernels' loads serial -- 5470 vs 5490 img/s -- so the stand-alone reduce stays the default.
+FUSE_SPLITK_INTO_GN = os.environ.get('GENESIS_FUSE_SPLITK_GN', '0') == '1'
+
+
+def _conv_gn(kind, x, w, bias, gamma, beta, groups, eps, dst0, dst1):
+    if not FUSE_SPLITK_INTO_GN:
+        y = conv3x3_fwd(x, w) if kind == 'conv3x3' else deconv5x5s2_fwd(x, w, bias)
+        mean, rstd = gn_relu_fwd(y, gamma, beta, groups, eps, dst0, dst1)
+        return y, mean, rstd
+    N, Cin, H, W = x.shape
+    if kind == 'conv3x3':
+        Cout, Ho, Wo = w.shape[0], H, W
+        nb = _lib.query('gx_conv3x3_ws_bytes', N, Cin, Cout, H, W)
+    else:
+        Cout, Ho, Wo = w.shape[1], 2 * H, 2 * W
+        nb = _lib.query('gx_deconv5x5s2_ws_bytes', N, Cin, Cout, H, W)
+    y = torch.empty(N, Cout, Ho, Wo, dtype=F32, device=x.device)
+    ws = _ws(nb, x.device)
+    parts, nsplit, stride = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_size_t()
+    _lib.call('gx_conv3x3_fwd_parts' if kind == 'conv3x3' else 'gx_deconv5x5s2_fwd_parts', _p(x), _p(w), _p(y), N, Cin,
+              Cout, H, W, _p(ws), nb, ctypes.byref(parts), ctypes.byref(nsplit), ctypes.byref(stride), _stream())
+    mean = torch.empty(N * groups, dtype=F32, device=x.device)
+    rstd = torch.empty(N * groups, dtype=F32, device=x.device)
+    need_sum = nsplit.value > 1 or bias is not None
+    _lib.call('gx_gn_relu_fwd_parts', parts, nsplit.value, stride.value, _p(bias), _p(y) if need_sum else None,
+              _p(gamma), _p(beta), N, Cout, Ho, Wo, groups, float(eps),
+              *(_view_args(dst0, 'gn.dst0') + _view_args(dst1, 'gn.dst1')), _p(mean), _p(rstd), _stream())
+    return y, mean, rstd       # (ws, holding the partial slabs, is released only now)
+
+
+def conv3x3_gn_relu_fwd(x, w, gamma, beta, groups, eps, dst0, dst1=None):
+    """conv3x3 (no bias) -> GroupNorm+ReLU into the destination views (modules/blocks.py:159-165); returns the
+    pre-norm conv output y (saved for backward) and the group statistics."""
+    _chk(x, 'conv_gn.x'); _chk(w, 'conv_gn.w'); _chk(gamma, 'conv_gn.gamma'); _chk(beta, 'conv_gn.beta')
+    assert w.shape[1:] == (x.shape[1], 3, 3), (w.shape, x.shape)
+    return _conv_gn('conv3x3', x, w, None, gamma, beta, groups, eps, dst0, dst1)
+
+
+def deconv5x5s2_gn_relu_fwd(x, w, bias, gamma, beta, groups, eps, dst0, dst1=None):
+    """ConvTranspose2d(k5,s2,p2,op1) + bias -> GroupNorm+ReLU (models/genesisv2_config.py:90-98)."""
+    _chk(x, 'deconv_gn.x'); _chk(w, 'deconv_gn.w'); _chk(bias, 'deconv_gn.bias')
+    _chk(gamma, 'deconv_gn.gamma'); _chk(beta, 'deconv_gn.beta')
+    assert w.shape[0] == x.shape[1] and w.shape[2:] == (5, 5)
+    return _conv_gn('deconv', x, w, bias, gamma, beta, groups, eps, dst0, dst1)
 
 
 def gn_relu_bwd(y, gamma, beta, mean, rstd, groups, g0, g1=None, want_dbias=False, out=None):

@@ -275,6 +275,23 @@ int gx_defer_enable(int on);
 int gx_defer_pending(void);
 int gx_defer_flush(gx_stream_t stream);
 
+/* ---- conv -> GroupNorm without the split-K reduce pass.  Layers that cannot fill the chip split the channel
+ *      reduction into `nsplit` partial output slabs which a small reduce kernel normally sums.  The *_parts variants
+ *      stop before that reduce and report where the slabs are (*parts: inside ws when *nsplit > 1, else = y, already
+ *      complete; *split_stride floats apart; no bias applied); gx_gn_relu_fwd_parts sums them while it reads its
+ *      input (same order as the reduce kernel: identical bits), adds the conv bias (may be NULL), writes the summed
+ *      pre-norm tensor to y_sum (the backward pass needs it; may alias parts when nsplit == 1) and continues as
+ *      gx_gn_relu_fwd.  ws must stay untouched until gx_gn_relu_fwd_parts has run. */
+int gx_conv3x3_fwd_parts(const float* x, const float* w, float* y, int N, int Cin, int Cout, int H, int W, void* ws,
+                         size_t ws_bytes, const float** parts, int* nsplit, size_t* split_stride, gx_stream_t stream);
+int gx_deconv5x5s2_fwd_parts(const float* x, const float* w, float* y, int N, int Cin, int Cout, int Hin, int Win,
+                             void* ws, size_t ws_bytes, const float** parts, int* nsplit, size_t* split_stride,
+                             gx_stream_t stream);
+int gx_gn_relu_fwd_parts(const float* parts, int nsplit, size_t split_stride, const float* conv_bias, float* y_sum,
+                         const float* gamma, const float* beta, int N, int C, int H, int W, int groups, float eps,
+                         float* dst0, int dst0_ctot, int dst0_c0, int dst0_mode, float* dst1, int dst1_ctot,
+                         int dst1_c0, int dst1_mode, float* mean, float* rstd, gx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -567,3 +567,28 @@ def test_pooled_head(R, C):
     (y * g.to(DEV)).sum().backward()
     for a, b, n in zip(dev, ref, ('dlin', 'dmsum', 'dfbias', 'dgamma', 'dbeta')):
         close(a.grad, b.grad, rtol=1e-4, atol=1e-5, msg=n)
+
+
+@pytest.mark.parametrize('kind,N,Cin,Cout,S', [('conv3x3', 4, 128, 128, 8), ('conv3x3', 2, 64, 64, 32),
+                                                 ('conv3x3', 2, 64, 64, 64), ('deconv', 8, 64, 64, 8),
+                                                 ('deconv', 3, 66, 64, 4)])
+def test_groupnorm_sums_splitk_partials_bitwise(kind, N, Cin, Cout, S, monkeypatch):
+    """gx_*_fwd_parts + gx_gn_relu_fwd_parts (GroupNorm sums the split-K slabs and adds the bias while reading) must
+    give the same bits as conv (+ reduce kernel) followed by gx_gn_relu_fwd."""
+    x = rnd(N, Cin, S, S, seed=1).to(DEV)
+    gamma, beta = (rnd(Cout, seed=4) + 1.5).to(DEV), rnd(Cout, seed=5).to(DEV)
+    outs = []
+    for fused in (False, True):
+        monkeypatch.setattr(hip, 'FUSE_SPLITK_INTO_GN', fused)
+        if kind == 'conv3x3':
+            w = (rnd(Cout, Cin, 3, 3, seed=2) * 0.05).to(DEV)
+            d = torch.empty(N, Cout, S, S, device=DEV)
+            y, mean, rstd = hip.conv3x3_gn_relu_fwd(x, w, gamma, beta, 8, 1e-5, (d, 0, 0))
+        else:
+            w = (rnd(Cin, Cout, 5, 5, seed=2) * 0.05).to(DEV)
+            b = rnd(Cout, seed=3).to(DEV)
+            d = torch.empty(N, Cout, 2 * S, 2 * S, device=DEV)
+            y, mean, rstd = hip.deconv5x5s2_gn_relu_fwd(x, w, b, gamma, beta, 8, 1e-5, (d, 0, 0))
+        outs.append((y.clone(), mean.clone(), rstd.clone(), d.clone()))
+    for a, b_ in zip(*outs):
+        assert torch.equal(a, b_)
