@@ -1,0 +1,312 @@
+// Generic strided convolution (any k <= 5, stride, pad) as an implicit GEMM on the fp32 matrix cores: the sylvester
+// gated 5x5 (de)convolutions of GENESIS / BaselineVAE (third_party/sylvester/layers.py:11-101, VAE.py:85-168) and
+// the stride-2 3x3 encoder convs of the ComponentVAE (modules/encoders.py:31-34).  Replaces the first-round direct
+// kernels (one pixel x 8 channels per thread, weights re-read from global: ~5 TF/s) behind the same entry points.
+//
+//   MODE 0  forward   C[co][(img,oh,ow)] = sum_{ci,kh,kw} w[co][ci][kh][kw] * x[img][ci][oh s - p + kh][ow s - p + kw]
+//   MODE 1  dgrad     C[ci][(img,ih,iw)] = sum_{co,kh,kw} w[co][ci][kh][kw] * dy[img][co][(ih + p - kh)/s][(iw + p - kw)/s]
+//   MODE 2  wgrad     C[co][(ci,kh,kw)]  = sum_{img,oh,ow} dy[img][co][oh][ow] * x[img][ci][oh s - p + kh][ow s - p + kw]
+//
+// Workgroup tile 64 (M) x 128 (N), K chunks of 16; 4 waves of 32 x 64 (two mfma_f32_32x32x2f32 accumulators); both
+// operands are gathered global -> registers one chunk ahead and staged in double-buffered LDS as [k][m] / [k][n] (the
+// MFMA fragment reads are unit-stride).  The contraction index of a wave's loads is wave-uniform, so its (ci,kh,kw)
+// / (img,oh,ow) decomposition runs on the scalar unit with host-precomputed magic divisors; the tile-column
+// decomposition of a thread is done once.  wgrad splits K over gridDim.z into partial slabs + a fixed-order reduce.
+#include "gx_common.h"
+
+namespace {
+
+struct FastDiv {   // n / d for 0 <= n < 2^31 via one mul_hi (Granlund-Montgomery round-up)
+    unsigned mul, shift, d;
+};
+FastDiv make_fastdiv(unsigned d) {
+    FastDiv f;
+    f.d = d;
+    if (d == 1) { f.mul = 0; f.shift = 0; return f; }
+    unsigned s = 0;
+    while ((1u << s) < d) ++s;                 // s = ceil(log2 d)
+    const unsigned long long m = ((1ull << (32 + s)) + d - 1) / d - (1ull << 32);   // 33-bit magic minus 2^32
+    f.mul = (unsigned)m;
+    f.shift = s;
+    return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
+    if (f.d == 1) return n;
+    const unsigned t = __umulhi(n, f.mul);
+    return (t + ((n - t) >> 1)) >> (f.shift - 1);
+}
+
+struct IG {
+    int N, Cin, Cout, H, W, Ho, Wo, k, stride, pad;
+    int M, Ncols, K;            // GEMM dims of this mode
+    int chunks_per_split;       // K chunks (of 16) per gridDim.z slice
+    FastDiv d_kk, d_k;          // / (k*k), / k
+    FastDiv d_how, d_wo;        // / (Ho*Wo), / Wo     (mode 2 contraction index)
+};
+
+constexpr int BM = 64, BN = 128, BK = 16;
+
+template <int MODE>
+__global__ void __launch_bounds__(256)
+igemm_kernel(const float* __restrict__ a_src, const float* __restrict__ b_src, const float* __restrict__ bias,
+             int act, float* __restrict__ out, IG g) {
+    __shared__ float As[2][BK][BM];
+    __shared__ float Bs[2][BK][BN];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kk2 = g.k * g.k;
+    const int HW = g.H * g.W, HoWo = g.Ho * g.Wo;
+
+    // ---- per-thread tile columns (fixed for the whole kernel) ----
+    // A: row m = m0 + (tid & 63), k slots kg*4 .. kg*4+3 with kg = wave          (64 x 16 tile, 4 per thread)
+    // B: cols n = n0 + (tid & 63) and n + 64, same k slots                        (128 x 16 tile, 8 per thread)
+    const int am = m0 + (tid & 63);
+    const bool am_ok = am < g.M;
+    int bcol_base[2], bc_a[2], bc_b[2];     // per-mode meaning, see below
+    bool bn_ok[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int n = n0 + (tid & 63) + 64 * h;
+        bn_ok[h] = n < g.Ncols;
+        const int nn = bn_ok[h] ? n : 0;
+        if (MODE == 0) {            // n = (img, oh, ow): base = img*Cin*HW, a = oh*s - p, b = ow*s - p
+            const int img = nn / HoWo, p = nn - img * HoWo;
+            const int oh = p / g.Wo, ow = p - oh * g.Wo;
+            bcol_base[h] = img * g.Cin * HW; bc_a[h] = oh * g.stride - g.pad; bc_b[h] = ow * g.stride - g.pad;
+        } else if (MODE == 1) {     // n = (img, ih, iw): base = img*Cout*HoWo, a = ih + p, b = iw + p
+            const int img = nn / HW, p = nn - img * HW;
+            const int ih = p / g.W, iw = p - ih * g.W;
+            bcol_base[h] = img * g.Cout * HoWo; bc_a[h] = ih + g.pad; bc_b[h] = iw + g.pad;
+        } else {                    // n = (ci, kh, kw): base = ci*HW, a = kh - p, b = kw - p
+            const int ci = nn / kk2, r = nn - ci * kk2;
+            const int kh = r / g.k, kw = r - kh * g.k;
+            bcol_base[h] = ci * HW; bc_a[h] = kh - g.pad; bc_b[h] = kw - g.pad;
+        }
+    }
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+    const int nchunks = (g.K + BK - 1) / BK;
+    const int c_begin = blockIdx.z * g.chunks_per_split;
+    int c_end = c_begin + g.chunks_per_split;
+    if (c_end > nchunks) c_end = nchunks;
+
+    float ra[4], rb[2][4];
+// one chunk of both operands into registers; the 4 contraction indices of this wave are wave-uniform
+#define IG_LOAD(chunk)                                                                                          \
+    {                                                                                                           \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
+            const int kk = (chunk) * BK + wave * 4 + j;                                                         \
+            const bool kv = kk < g.K;                                                                           \
+            const unsigned kq = kv ? (unsigned)kk : 0u;                                                         \
+            float av = 0.f, bv0 = 0.f, bv1 = 0.f;                                                               \
+            if (MODE == 0) {                                                                                    \
+                const int ci = (int)fdiv(kq, g.d_kk), r = (int)kq - ci * kk2;                                   \
+                const int kh = (int)fdiv((unsigned)r, g.d_k), kw = r - kh * g.k;                                \
+                if (kv && am_ok) av = a_src[(size_t)am * g.K + kq];                                             \
+                const int koff = ci * HW + kh * g.W + kw;                                                       \
+                const int ih0 = bc_a[0] + kh, iw0 = bc_b[0] + kw, ih1 = bc_a[1] + kh, iw1 = bc_b[1] + kw;       \
+                if (kv && bn_ok[0] && ih0 >= 0 && ih0 < g.H && iw0 >= 0 && iw0 < g.W)                           \
+                    bv0 = b_src[(size_t)bcol_base[0] + koff + bc_a[0] * g.W + bc_b[0]];                         \
+                if (kv && bn_ok[1] && ih1 >= 0 && ih1 < g.H && iw1 >= 0 && iw1 < g.W)                           \
+                    bv1 = b_src[(size_t)bcol_base[1] + koff + bc_a[1] * g.W + bc_b[1]];                         \
+            } else if (MODE == 1) {                                                                             \
+                const int co = (int)fdiv(kq, g.d_kk), r = (int)kq - co * kk2;                                   \
+                const int kh = (int)fdiv((unsigned)r, g.d_k), kw = r - kh * g.k;                                \
+                if (kv && am_ok) av = a_src[((size_t)co * g.Cin + am) * kk2 + r];                               \
+                _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                 \
+                    const int th = bc_a[h] - kh, tw = bc_b[h] - kw;                                             \
+                    float v = 0.f;                                                                              \
+                    if (kv && bn_ok[h] && th >= 0 && tw >= 0) {                                                 \
+                        const int oh = th / g.stride, ow = tw / g.stride;                                       \
+                        if (oh * g.stride == th && ow * g.stride == tw && oh < g.Ho && ow < g.Wo)               \
+                            v = b_src[(size_t)bcol_base[h] + (size_t)co * HoWo + oh * g.Wo + ow];               \
+                    }                                                                                           \
+                    if (h == 0) bv0 = v; else bv1 = v;                                                          \
+                }                                                                                               \
+            } else {                                                                                            \
+                const int img = (int)fdiv(kq, g.d_how), p = (int)kq - img * HoWo;                               \
+                const int oh = (int)fdiv((unsigned)p, g.d_wo), ow = p - oh * g.Wo;                              \
+                if (kv && am_ok) av = a_src[((size_t)img * g.Cout + am) * HoWo + p];                            \
+                const int ihb = oh * g.stride, iwb = ow * g.stride;                                             \
+                _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                 \
+                    const int ih = ihb + bc_a[h], iw = iwb + bc_b[h];                                           \
+                    float v = 0.f;                                                                              \
+                    if (kv && bn_ok[h] && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W)                           \
+                        v = b_src[(size_t)img * g.Cin * HW + bcol_base[h] + ih * g.W + iw];                     \
+                    if (h == 0) bv0 = v; else bv1 = v;                                                          \
+                }                                                                                               \
+            }                                                                                                   \
+            ra[j] = av; rb[0][j] = bv0; rb[1][j] = bv1;                                                         \
+        }                                                                                                       \
+    }
+#define IG_COMMIT(buf)                                                                                          \
+    {                                                                                                           \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
+            As[buf][wave * 4 + j][tid & 63] = ra[j];                                                            \
+            Bs[buf][wave * 4 + j][tid & 63] = rb[0][j];                                                         \
+            Bs[buf][wave * 4 + j][(tid & 63) + 64] = rb[1][j];                                                  \
+        }                                                                                                       \
+    }
+
+    if (c_begin < c_end) IG_LOAD(c_begin)
+    for (int c = c_begin; c < c_end; ++c) {
+        const int buf = (c - c_begin) & 1;
+        IG_COMMIT(buf)
+        __syncthreads();
+        if (c + 1 < c_end) IG_LOAD(c + 1)
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks) {
+            const float a = As[buf][2 * ks + (lane >> 5)][wm * 32 + (lane & 31)];
+            const float b0 = Bs[buf][2 * ks + (lane >> 5)][wn * 64 + (lane & 31)];
+            const float b1 = Bs[buf][2 * ks + (lane >> 5)][wn * 64 + 32 + (lane & 31)];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+        }
+    }
+#undef IG_LOAD
+#undef IG_COMMIT
+
+    // ---- epilogue: C/D layout col = lane & 31 (n), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (m) ----
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+        if (n >= g.Ncols) continue;
+        size_t obase;       // address of (m = 0, n); consecutive m are `mstride` apart
+        size_t mstride;
+        if (MODE == 2) {
+            obase = (size_t)blockIdx.z * g.M * g.Ncols + n; mstride = g.Ncols;
+        } else {
+            const int P = MODE == 0 ? HoWo : HW;
+            const int img = n / P, p = n - img * P;
+            obase = (size_t)img * g.M * P + p; mstride = P;
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int m = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            if (m < g.M) {
+                float v = acc[j][reg];
+                if (MODE == 0) {
+                    if (bias) v += bias[m];
+                    if (act == 1) v = v > 0.f ? v : 0.f;
+                    else if (act == 2) v = v > 0.f ? v : expm1f(v);
+                }
+                out[obase + (size_t)m * mstride] = v;
+            }
+        }
+    }
+}
+
+// dw[i] = sum_z partial[z][i], fixed order
+__global__ void __launch_bounds__(256)
+igemm_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int total, int nsplit) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    float s = partial[i];
+    for (int z = 1; z < nsplit; ++z) s += partial[(size_t)z * total + i];
+    out[i] = s;
+}
+
+int ig_geom(const char* name, IG* g, int mode, int N, int Cin, int Cout, int H, int W, int k, int stride, int pad) {
+    GX_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "%s: bad dims", name);
+    GX_CHECK_ARG(k >= 1 && k <= 5 && stride >= 1 && pad >= 0, "%s: kernel <= 5x5, stride >= 1", name);
+    g->N = N; g->Cin = Cin; g->Cout = Cout; g->H = H; g->W = W; g->k = k; g->stride = stride; g->pad = pad;
+    g->Ho = (H + 2 * pad - k) / stride + 1;
+    g->Wo = (W + 2 * pad - k) / stride + 1;
+    GX_CHECK_ARG(g->Ho > 0 && g->Wo > 0, "%s: empty output", name);
+    const double big = 2.0e9;
+    GX_CHECK_ARG((double)N * Cin * H * W < big && (double)N * Cout * g->Ho * g->Wo < big, "%s: tensor too large", name);
+    if (mode == 0) { g->M = Cout; g->Ncols = N * g->Ho * g->Wo; g->K = Cin * k * k; }
+    else if (mode == 1) { g->M = Cin; g->Ncols = N * H * W; g->K = Cout * k * k; }
+    else { g->M = Cout; g->Ncols = Cin * k * k; g->K = N * g->Ho * g->Wo; }
+    g->d_kk = make_fastdiv(k * k); g->d_k = make_fastdiv(k);
+    g->d_how = make_fastdiv(g->Ho * g->Wo); g->d_wo = make_fastdiv(g->Wo);
+    g->chunks_per_split = gx_ceil_div(g->K, BK);
+    return GX_OK;
+}
+
+int wgrad_splits(const IG& g) {
+    const int tiles = gx_ceil_div(g.M, BM) * gx_ceil_div(g.Ncols, BN);
+    const int nchunks = gx_ceil_div(g.K, BK);
+    int nsplit = gx_ceil_div(768, tiles);
+    if (nsplit > nchunks) nsplit = nchunks;
+    if (nsplit > 256) nsplit = 256;
+    return nsplit < 1 ? 1 : nsplit;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gx_conv2d_direct_fwd(const float* x, const float* w, const float* bias, int act, float* y, int N, int Cin,
+                         int Cout, int H, int W, int k, int stride, int pad, gx_stream_t stream) {
+    GX_CHECK_ARG(x && w && y && act >= 0 && act <= 2, "gx_conv2d_direct_fwd: null pointer / bad act");
+    IG g;
+    int rc = ig_geom("gx_conv2d_direct_fwd", &g, 0, N, Cin, Cout, H, W, k, stride, pad);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    {
+        GxProf pf(KID_DCONV, s, 2.0 * N * Cout * Cin * k * k * g.Ho * g.Wo, 4.0 * N * (Cin * H * W + Cout * g.Ho * g.Wo));
+        hipLaunchKernelGGL(igemm_kernel<0>, dim3(gx_ceil_div(g.Ncols, BN), gx_ceil_div(g.M, BM), 1), dim3(256), 0, s, w,
+                           x, bias, act, y, g);
+    }
+    GX_CHECK_LAUNCH("gx_conv2d_direct_fwd");
+    return GX_OK;
+}
+
+int gx_conv2d_direct_dgrad(const float* dy, const float* w, float* dx, int N, int Cin, int Cout, int H, int W, int k,
+                           int stride, int pad, gx_stream_t stream) {
+    GX_CHECK_ARG(dy && w && dx, "gx_conv2d_direct_dgrad: null pointer");
+    IG g;
+    int rc = ig_geom("gx_conv2d_direct_dgrad", &g, 1, N, Cin, Cout, H, W, k, stride, pad);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    {
+        GxProf pf(KID_DCONV, s, 2.0 * N * Cout * Cin * k * k * g.Ho * g.Wo, 4.0 * N * (Cin * H * W + Cout * g.Ho * g.Wo));
+        hipLaunchKernelGGL(igemm_kernel<1>, dim3(gx_ceil_div(g.Ncols, BN), gx_ceil_div(g.M, BM), 1), dim3(256), 0, s, w,
+                           dy, (const float*)nullptr, 0, dx, g);
+    }
+    GX_CHECK_LAUNCH("gx_conv2d_direct_dgrad");
+    return GX_OK;
+}
+
+size_t gx_conv2d_direct_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W, int k, int stride, int pad) {
+    IG g;
+    if (ig_geom("gx_conv2d_direct_wgrad_ws_bytes", &g, 2, N, Cin, Cout, H, W, k, stride, pad) != GX_OK) return 0;
+    return (size_t)wgrad_splits(g) * g.M * g.Ncols * sizeof(float);
+}
+
+int gx_conv2d_direct_wgrad(const float* x, const float* dy, float* dw, int N, int Cin, int Cout, int H, int W, int k,
+                           int stride, int pad, void* ws, size_t ws_bytes, gx_stream_t stream) {
+    GX_CHECK_ARG(x && dy && dw && ws, "gx_conv2d_direct_wgrad: null pointer");
+    IG g;
+    int rc = ig_geom("gx_conv2d_direct_wgrad", &g, 2, N, Cin, Cout, H, W, k, stride, pad);
+    if (rc) return rc;
+    const int nsplit = wgrad_splits(g);
+    GX_CHECK_ARG(ws_bytes >= (size_t)nsplit * g.M * g.Ncols * sizeof(float), "gx_conv2d_direct_wgrad: workspace too small");
+    g.chunks_per_split = gx_ceil_div(gx_ceil_div(g.K, BK), nsplit);
+    const int zs = gx_ceil_div(gx_ceil_div(g.K, BK), g.chunks_per_split);
+    hipStream_t s = (hipStream_t)stream;
+    {
+        GxProf pf(KID_DCONV, s, 2.0 * N * Cout * Cin * k * k * g.Ho * g.Wo, 4.0 * N * (Cin * H * W + Cout * g.Ho * g.Wo));
+        hipLaunchKernelGGL(igemm_kernel<2>, dim3(gx_ceil_div(g.Ncols, BN), gx_ceil_div(g.M, BM), zs), dim3(256), 0, s, dy,
+                           x, (const float*)nullptr, 0, (float*)ws, g);
+    }
+    GX_CHECK_LAUNCH("gx_conv2d_direct_wgrad");
+    {
+        const int total = g.M * g.Ncols;
+        GxProf pf(KID_SMALL_REDUCE, s, 0.0, 4.0 * (zs + 1.0) * total);
+        hipLaunchKernelGGL(igemm_reduce_kernel, dim3(gx_ceil_div(total, 256)), dim3(256), 0, s, (const float*)ws, dw, total,
+                           zs);
+    }
+    GX_CHECK_LAUNCH("gx_conv2d_direct_wgrad(reduce)");
+    return GX_OK;
+}
+
+}  // extern "C"

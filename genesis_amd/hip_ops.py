@@ -402,7 +402,10 @@ def conv2d_direct_wgrad(x, dy, k, stride, pad, out=None):
     N, Cin, H, W = x.shape
     Cout = dy.shape[1]
     dw = out if out is not None else torch.empty(Cout, Cin, k, k, dtype=F32, device=x.device)
-    _lib.call('gx_conv2d_direct_wgrad', _p(x), _p(dy), _p(dw), N, Cin, Cout, H, W, k, stride, pad, _stream())
+    nb = _lib.query('gx_conv2d_direct_wgrad_ws_bytes', N, Cin, Cout, H, W, k, stride, pad)
+    ws = _ws(nb, x.device)
+    _lib.call('gx_conv2d_direct_wgrad', _p(x), _p(dy), _p(dw), N, Cin, Cout, H, W, k, stride, pad, _p(ws), nb,
+              _stream())
     return dw
 
 

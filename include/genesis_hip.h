@@ -145,7 +145,9 @@ int gx_profile_collect(double* total_ms, double* launches, double* flops, double
  *      centre crop after L layers equals the valid-conv chain exactly (border pollution advances one pixel per
  *      layer and is cropped; its gradients are identically zero).
  *      gx_bias_act_bwd: dy = g * act'(out) (derivative from the OUTPUT) and dbias[c] = sum dy (NULL to skip).
- *      gx_conv2d_direct_*: generic k<=5 / stride / pad direct convolution for the tiny stride-2 encoder convs.
+ *      gx_conv2d_direct_*: generic k<=5 / stride / pad convolution (implicit GEMM on the fp32 matrix cores, operands
+ *      gathered; split-K + fixed-order reduce for the weight gradient): the stride-2 encoder convs here and the
+ *      sylvester 5x5 gated (de)convolutions below.
  *      gx_mixture_w_*: mixture likelihood with EXTERNAL mixing log-weights log_w [K,B,1,H,W] (MONet mixes with
  *      the attention masks, not with log_softmax(logits)) and a separate std for the first slot; dec has dec_ch
  *      channels per slot: 4 (RGB + logit, MONet) or 3 (RGB, GENESIS); bwd also returns dlog_w; the logit channel
@@ -159,8 +161,9 @@ int gx_conv2d_direct_fwd(const float* x, const float* w, const float* bias, int 
                          int Cout, int H, int W, int k, int stride, int pad, gx_stream_t stream);
 int gx_conv2d_direct_dgrad(const float* dy, const float* w, float* dx, int N, int Cin, int Cout, int H, int W, int k,
                            int stride, int pad, gx_stream_t stream);
+size_t gx_conv2d_direct_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W, int k, int stride, int pad);
 int gx_conv2d_direct_wgrad(const float* x, const float* dy, float* dw, int N, int Cin, int Cout, int H, int W, int k,
-                           int stride, int pad, gx_stream_t stream);
+                           int stride, int pad, void* ws, size_t ws_bytes, gx_stream_t stream);
 int gx_mixture_w_fwd(const float* x, const float* dec, const float* log_w, int dec_ch, int B, int H, int W, int K,
                      float pixel_std1, float pixel_std2, int pixel_bound, float* recon, float* x_r, float* err,
                      void* ws, size_t ws_bytes, gx_stream_t stream);
