@@ -37,32 +37,56 @@ __device__ __forceinline__ void unit_decode(int u, int norm, int N, int C2, int*
     else { *ch = u % C2; *n0 = u / C2; *ncount = 1; }
 }
 
-// stats[u] = {mean, rstd} of (y + bias) over the unit
+// Per-unit statistics in two steps so that a BatchNorm channel (all N images) is read by many workgroups:
+// part[(u * nchunk + z)] = {sum, sum of squares} of (y + bias) over the images of chunk z (fp64), then
+// stats[u] = {mean, rstd} from the chunk partials in a fixed order.
 __global__ void __launch_bounds__(256)
-gated_stats_kernel(const float* __restrict__ y, const float* __restrict__ bias, int N, int C2, int HW, int norm,
-                   float eps, float* __restrict__ stats) {
+gated_stats_partial_kernel(const float* __restrict__ y, const float* __restrict__ bias, int N, int C2, int HW,
+                           int norm, int nchunk, double* __restrict__ part) {
     __shared__ double red[16 * 2 + 2];
     int ch, n0, nc;
     unit_decode(blockIdx.x, norm, N, C2, &ch, &n0, &nc);
+    const int per = (nc + nchunk - 1) / nchunk;
+    const int na = n0 + blockIdx.y * per;
+    int nb = na + per;
+    if (nb > n0 + nc) nb = n0 + nc;
     const float b = bias ? bias[ch] : 0.f;
     double acc[2] = {0.0, 0.0};
-    for (int n = n0; n < n0 + nc; ++n) {
+    for (int n = na; n < nb; ++n) {
         const float* p = y + ((size_t)n * C2 + ch) * HW;
-        for (int i = threadIdx.x; i < HW; i += blockDim.x) {
-            const double v = (double)(p[i] + b);
-            acc[0] += v; acc[1] += v * v;
+        if ((HW & 3) == 0) {
+            const f32x4* p4 = reinterpret_cast<const f32x4*>(p);
+            for (int i = threadIdx.x; i < (HW >> 2); i += blockDim.x) {
+                const f32x4 t = p4[i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const double v = (double)(t[e] + b); acc[0] += v; acc[1] += v * v; }
+            }
+        } else {
+            for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+                const double v = (double)(p[i] + b);
+                acc[0] += v; acc[1] += v * v;
+            }
         }
     }
     block_sum_multi<2>(acc, red);
-    const double m = (double)nc * HW;
-    const double mean = acc[0] / m;
-    double var = acc[1] / m - mean * mean;
-    if (var < 0.0) var = 0.0;
     if (threadIdx.x == 0) {
-        stats[2 * blockIdx.x] = (float)mean;
-        stats[2 * blockIdx.x + 1] = (float)(1.0 / sqrt(var + (double)eps));
-        // biased variance kept for the caller's running_var update (BatchNorm uses the unbiased one there)
+        part[2 * ((size_t)blockIdx.x * nchunk + blockIdx.y)] = acc[0];
+        part[2 * ((size_t)blockIdx.x * nchunk + blockIdx.y) + 1] = acc[1];
     }
+}
+
+__global__ void gated_stats_finalize_kernel(const double* __restrict__ part, int units, int nchunk, double m, float eps,
+                                            float* __restrict__ stats) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= units) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int z = 0; z < nchunk; ++z) { s1 += part[2 * ((size_t)u * nchunk + z)]; s2 += part[2 * ((size_t)u * nchunk + z) + 1]; }
+    const double mean = s1 / m;
+    double var = s2 / m - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[2 * u] = (float)mean;
+    stats[2 * u + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    // biased variance kept for the caller's running_var update (BatchNorm uses the unbiased one there)
 }
 
 __device__ __forceinline__ void unit_stats(const float* stats, int norm, int n, int ch, int C2, float* mean, float* rstd) {
@@ -100,18 +124,22 @@ __global__ void __launch_bounds__(256)
 gated_bwd_sums_kernel(const float* __restrict__ y, const float* __restrict__ bias, const float* __restrict__ stats,
                       const float* __restrict__ gh, const float* __restrict__ bh, const float* __restrict__ gg,
                       const float* __restrict__ bg, const float* __restrict__ dout, int N, int C, int HW, int norm,
-                      float* __restrict__ sums) {
+                      int nchunk, double* __restrict__ part) {
     __shared__ double red[16 * 2 + 2];
     const int C2 = 2 * C;
     // with no norm the "unit" is still a channel over all images (only S1 = bias gradient is needed)
     int ch, n0, nc;
     unit_decode(blockIdx.x, norm == NORM_NONE ? NORM_BN : norm, N, C2, &ch, &n0, &nc);
+    const int per = (nc + nchunk - 1) / nchunk;
+    const int na = n0 + blockIdx.y * per;
+    int nb = na + per;
+    if (nb > n0 + nc) nb = n0 + nc;
     const bool is_g = ch >= C;
     const int c = is_g ? ch - C : ch;
     const float b_h = bias ? bias[c] : 0.f, b_g = bias ? bias[C + c] : 0.f;
     const float g_h = gh ? gh[c] : 1.f, be_h = bh ? bh[c] : 0.f, g_g = gg ? gg[c] : 1.f, be_g = bg ? bg[c] : 0.f;
     double acc[2] = {0.0, 0.0};
-    for (int n = n0; n < n0 + nc; ++n) {
+    for (int n = na; n < nb; ++n) {
         float mh, rh, mg, rg;
         unit_stats(stats, norm, n, c, C2, &mh, &rh);
         unit_stats(stats, norm, n, C + c, C2, &mg, &rg);
@@ -128,7 +156,19 @@ gated_bwd_sums_kernel(const float* __restrict__ y, const float* __restrict__ bia
         }
     }
     block_sum_multi<2>(acc, red);
-    if (threadIdx.x == 0) { sums[2 * blockIdx.x] = (float)acc[0]; sums[2 * blockIdx.x + 1] = (float)acc[1]; }
+    if (threadIdx.x == 0) {
+        part[2 * ((size_t)blockIdx.x * nchunk + blockIdx.y)] = acc[0];
+        part[2 * ((size_t)blockIdx.x * nchunk + blockIdx.y) + 1] = acc[1];
+    }
+}
+
+__global__ void gated_sums_finalize_kernel(const double* __restrict__ part, int units, int nchunk,
+                                           float* __restrict__ sums) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= units) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int z = 0; z < nchunk; ++z) { s1 += part[2 * ((size_t)u * nchunk + z)]; s2 += part[2 * ((size_t)u * nchunk + z) + 1]; }
+    sums[2 * u] = (float)s1; sums[2 * u + 1] = (float)s2;
 }
 
 // Backward pass 2: dy[n][ch][p] = rstd * gamma * (dA - S1/m - xhat * S2/m)   (norm none: dy = dA)
@@ -194,12 +234,22 @@ __global__ void gated_param_kernel(const float* __restrict__ sums, int N, int C,
 }
 
 int nunits(int norm, int N, int C) { return norm == NORM_IN ? N * 2 * C : 2 * C; }
+// image chunks per unit: a BatchNorm channel spans all N images -> spread it over ~1024 workgroups
+int nchunks(int norm, int N, int C) {
+    if (norm == NORM_IN) return 1;
+    int z = 1024 / (2 * C);
+    if (z < 1) z = 1;
+    return z > N ? N : z;
+}
 
 }  // namespace
 
 extern "C" {
 
-size_t gx_gated_stats_floats(int norm, int N, int C) { return (size_t)2 * nunits(norm, N, C); }
+// {mean, rstd} per unit, followed by the fp64 chunk partials of the statistics pass (scratch)
+size_t gx_gated_stats_floats(int norm, int N, int C) {
+    return (size_t)2 * nunits(norm, N, C) + (size_t)4 * nunits(norm, N, C) * nchunks(norm, N, C);
+}
 
 int gx_gated_norm_fwd(const float* y, const float* bias, int norm, const float* gamma_h, const float* beta_h,
                       const float* gamma_g, const float* beta_g, int N, int C, int H, int W, float eps, float* out,
@@ -210,9 +260,15 @@ int gx_gated_norm_fwd(const float* y, const float* bias, int norm, const float* 
     const int HW = H * W;
     if (norm != NORM_NONE) {
         GxProf pf(KID_GATED, s, 0.0, 4.0 * N * 2.0 * C * HW);
-        hipLaunchKernelGGL(gated_stats_kernel, dim3(nunits(norm, N, C)), dim3(256), 0, s, y, bias, N, 2 * C, HW, norm,
-                           eps, stats);
+        const int units = nunits(norm, N, C), nz = nchunks(norm, N, C);
+        double* part = reinterpret_cast<double*>(stats + 2 * (size_t)units);
+        hipLaunchKernelGGL(gated_stats_partial_kernel, dim3(units, nz), dim3(256), 0, s, y, bias, N, 2 * C, HW, norm,
+                           nz, part);
         GX_CHECK_LAUNCH("gx_gated_norm_fwd(stats)");
+        const double m = (norm == NORM_BN) ? (double)N * HW : (double)HW;
+        hipLaunchKernelGGL(gated_stats_finalize_kernel, dim3(gx_ceil_div(units, 256)), dim3(256), 0, s,
+                           (const double*)part, units, nz, m, eps, stats);
+        GX_CHECK_LAUNCH("gx_gated_norm_fwd(stats finalize)");
     }
     {
         GxProf pf(KID_GATED, s, 0.0, 4.0 * N * 3.0 * C * HW);
@@ -223,7 +279,10 @@ int gx_gated_norm_fwd(const float* y, const float* bias, int norm, const float* 
     return GX_OK;
 }
 
-size_t gx_gated_norm_bwd_ws_bytes(int norm, int N, int C) { return (size_t)2 * nunits(norm, N, C) * sizeof(float); }
+size_t gx_gated_norm_bwd_ws_bytes(int norm, int N, int C) {
+    const int nb = norm == NORM_NONE ? NORM_BN : norm;
+    return ((size_t)2 * nunits(norm, N, C) + (size_t)4 * nunits(norm, N, C) * nchunks(nb, N, C)) * sizeof(float);
+}
 
 int gx_gated_norm_bwd(const float* y, const float* bias, int norm, const float* gamma_h, const float* beta_h,
                       const float* gamma_g, const float* beta_g, const float* stats, const float* dout, int N, int C,
@@ -237,8 +296,12 @@ int gx_gated_norm_bwd(const float* y, const float* bias, int norm, const float* 
     float* sums = (float*)ws;
     {
         GxProf pf(KID_GATED, s, 0.0, 4.0 * N * 3.0 * C * HW);
-        hipLaunchKernelGGL(gated_bwd_sums_kernel, dim3(nunits(norm, N, C)), dim3(256), 0, s, y, bias, stats, gamma_h,
-                           beta_h, gamma_g, beta_g, dout, N, C, HW, norm, sums);
+        const int units = nunits(norm, N, C), nz = nchunks(norm == NORM_NONE ? NORM_BN : norm, N, C);
+        double* part = reinterpret_cast<double*>(sums + 2 * (size_t)units);
+        hipLaunchKernelGGL(gated_bwd_sums_kernel, dim3(units, nz), dim3(256), 0, s, y, bias, stats, gamma_h, beta_h,
+                           gamma_g, beta_g, dout, N, C, HW, norm, nz, part);
+        hipLaunchKernelGGL(gated_sums_finalize_kernel, dim3(gx_ceil_div(units, 256)), dim3(256), 0, s,
+                           (const double*)part, units, nz, sums);
     }
     GX_CHECK_LAUNCH("gx_gated_norm_bwd(sums)");
     {

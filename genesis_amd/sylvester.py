@@ -79,7 +79,7 @@ class SylvesterVAE(nn.Module):
             with torch.no_grad():
                 C = out.shape[1]
                 m = y.shape[0] * y.shape[2] * y.shape[3]
-                st = stats.view(-1, 2)
+                st = stats[:4 * C].view(-1, 2)       # {mean, rstd} per unit (2C units); the rest of the buffer is scratch
                 mean, var = st[:, 0], (1.0 / st[:, 1] ** 2 - 1e-5) * (m / max(m - 1, 1))
                 for bn, sl in ((unit.h_norm, slice(0, C)), (unit.g_norm, slice(C, 2 * C))):
                     bn.running_mean.mul_(0.9).add_(0.1 * mean[sl])
