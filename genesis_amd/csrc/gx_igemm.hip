@@ -124,7 +124,10 @@ igemm_kernel(const float* __restrict__ a_src, const float* __restrict__ b_src, c
                     const int th = bc_a[h] - kh, tw = bc_b[h] - kw;                                             \
                     float v = 0.f;                                                                              \
                     if (kv && bn_ok[h] && th >= 0 && tw >= 0) {                                                 \
-                        const int oh = th / g.stride, ow = tw / g.stride;                                       \
+                        int oh, ow;                                                                             \
+                        if (g.stride == 1) { oh = th; ow = tw; }                                                \
+                        else if (g.stride == 2) { oh = th >> 1; ow = tw >> 1; }                                 \
+                        else { oh = th / g.stride; ow = tw / g.stride; }                                        \
                         if (oh * g.stride == th && ow * g.stride == tw && oh < g.Ho && ow < g.Wo)               \
                             v = b_src[(size_t)bcol_base[h] + (size_t)co * HoWo + oh * g.Wo + ow];               \
                     }                                                                                           \
