@@ -131,8 +131,9 @@ class Genesis(nn.Module):
         return log_m_k, log_s_k, mu_k, sigma_k, z_k
 
     def _prior_m(self, z_kbd):
-        out, _ = self.prior_lstm(z_kbd[:-1].contiguous())
-        mu_raw, sig_raw = self.prior_linear(out).chunk(2, dim=2)
+        L = self.prior_lstm
+        out = fn.LSTMFn.apply(z_kbd[:-1], L.weight_ih_l0, L.weight_hh_l0, L.bias_ih_l0, L.bias_hh_l0)
+        mu_raw, sig_raw = fn.linear(out, self.prior_linear.weight, self.prior_linear.bias).chunk(2, dim=2)
         return torch.tanh(mu_raw), torch.sigmoid(sig_raw + 4.0) + 1e-4
 
     def forward(self, x, eps_m=None, eps_c=None):
@@ -152,8 +153,8 @@ class Genesis(nn.Module):
         h = inp
         for i in (0, 2, 4, 6):
             h = fn.DirectConvActFn.apply(h, em[i].weight, em[i].bias, 2, 1, 'elu')
-        h = F.elu(em[9](h.flatten(1)))
-        mu_c, sig_ps = em[11](h).chunk(2, dim=1)
+        h = F.elu(fn.linear(h.flatten(1), em[9].weight, em[9].bias))
+        mu_c, sig_ps = fn.linear(h, em[11].weight, em[11].bias).chunk(2, dim=1)
         sig_c = F.softplus(sig_ps + 0.5) + 1e-8
         if eps_c is None:
             eps_c = torch.randn(K * B, Lc, device=x.device)
@@ -171,7 +172,10 @@ class Genesis(nn.Module):
         log_p = torch.cat((_normal_log_prob(z[:1], 0., 1.).sum(2), _normal_log_prob(z[1:], mu_p, sig_p).sum(2)), 0)
         losses['kl_m_k'] = list((log_q - log_p).unbind(0))
         # -- Component KL with the learned component prior (genesis_config.py:229-247)
-        o = self.prior_mlp(z.flatten(0, 1))                       # [K*B, 2*Lc], slot-major like z_c
+        pm_ = self.prior_mlp
+        o = F.elu(fn.linear(z.flatten(0, 1), pm_[0].weight, pm_[0].bias))
+        o = F.elu(fn.linear(o, pm_[2].weight, pm_[2].bias))
+        o = fn.linear(o, pm_[4].weight, pm_[4].bias)              # [K*B, 2*Lc], slot-major like z_c
         pm, ps = o.chunk(2, dim=1)
         pm, ps = torch.tanh(pm), torch.sigmoid(ps + 4.0) + 1e-4
         kl_l = (_normal_log_prob(z_c, mu_c, sig_c) - _normal_log_prob(z_c, pm, ps)).sum(1)

@@ -50,8 +50,8 @@ flags.DEFINE_float('pixel_std2', 0.7, 'StdDev of reconstructed pixels.')
 
 import os as _os
 
-# The AR prior's LSTM is a plain library op (MIOpen through torch.nn.LSTM): one fused call per direction
-# instead of ~12 pointwise launches per step.  GENESIS_LIBRARY_LSTM=0 selects the explicit cell loop.
+# The AR prior's LSTM runs on the fused HIP cell kernels (functions.LSTMFn: dense input projection + one
+# recurrent-GEMM/cell launch per step).  GENESIS_FUSED_LSTM=0 selects an explicit torch cell loop (debugging aid).
 USE_FUSED_LSTM = _os.environ.get('GENESIS_FUSED_LSTM', '1') == '1'   # 0: unrolled torch ops (debug)
 
 

@@ -154,8 +154,8 @@ class MONet(nn.Module):
         h = inp
         for i in (0, 2, 4, 6):
             h = fn.DirectConvActFn.apply(h, em[i].weight, em[i].bias, 2, 1, 'relu')
-        h = F.relu(em[9](h.flatten(1)))
-        mu, sigma_ps = em[11](h).chunk(2, dim=1)
+        h = fn.linear(h.flatten(1), em[9].weight, em[9].bias, 'relu')
+        mu, sigma_ps = fn.linear(h, em[11].weight, em[11].bias).chunk(2, dim=1)
         sigma = F.softplus(sigma_ps + 0.5) + 1e-8
         if eps is None:
             eps = torch.randn(K * B, L, device=x.device)

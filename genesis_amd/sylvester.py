@@ -7,6 +7,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import hip_ops as hip
+from . import functions as fn
 from .functions import _gout, _ret
 
 
@@ -94,12 +95,12 @@ class SylvesterVAE(nn.Module):
             unit = self.q_z_nn[l]
             h = self._gate(unit, DirectConvFn.apply(h, unit.conv.weight, 'conv', s, 2, 0))
         unit = self.q_z_nn[len(self.strides)]
-        y = F.linear(h.flatten(1), unit.conv.weight.flatten(1)).view(h.shape[0], -1, 1, 1)
+        y = fn.linear(h.flatten(1), unit.conv.weight.flatten(1)).view(h.shape[0], -1, 1, 1)
         return self._gate(unit, y).flatten(1)
 
     def posterior(self, h):
-        mean = self.q_z_mean(h)
-        var = (F.softplus(self.q_z_var[0](h) + 0.5) + 1e-8) ** 2     # ToVar: to_sigma(x)**2 (blocks.py:22-26)
+        mean = fn.linear(h, self.q_z_mean.weight, self.q_z_mean.bias)
+        var = (F.softplus(fn.linear(h, self.q_z_var[0].weight, self.q_z_var[0].bias) + 0.5) + 1e-8) ** 2     # ToVar: to_sigma(x)**2 (blocks.py:22-26)
         return mean, var
 
     def decode(self, z):
