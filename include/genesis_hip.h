@@ -295,6 +295,13 @@ int gx_gn_relu_fwd_parts(const float* parts, int nsplit, size_t split_stride, co
                          float* dst0, int dst0_ctot, int dst0_c0, int dst0_mode, float* dst1, int dst1_ctot,
                          int dst1_c0, int dst1_mode, float* mean, float* rstd, gx_stream_t stream);
 
+/* ---- segmentation metrics on the device (utils/misc.py:101-114 average_ari, :173-235 average_segcover):
+ *      counts[b][i][j] = #{p : segA[b][p] == i and segB[b][p] == j}, int32 [B, KA, KB+1]; column KB collects segB labels
+ *      outside [0,KB); pixels with segA outside [0,KA) (negative = ignore regions) are skipped.  Labels are int64
+ *      [B, HW] as the reference's instance maps / argmax outputs are.  Bit-exact integer work. */
+int gx_label_contingency(const long long* segA, const long long* segB, int B, int HW, int KA, int KB, int* counts,
+                         gx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
