@@ -302,6 +302,12 @@ int gx_gn_relu_fwd_parts(const float* parts, int nsplit, size_t split_stride, co
 int gx_label_contingency(const long long* segA, const long long* segB, int B, int HW, int KA, int KB, int* counts,
                          gx_stream_t stream);
 
+/* ---- input feeder (datasets/multid_config.py:131-135 ToTensor + F.interpolate(size), multi_object_config.py:176-186):
+ *      uint8 frames [B, Hs, Ws, C] (HWC, as stored) -> fp32 [B, C, H, W] = value / 255, nearest-neighbour resampled to
+ *      H x W when the stored size differs (F.interpolate's default mode).  Bit-exact against the torch ops. */
+int gx_u8hwc_to_f32chw(const unsigned char* src, float* dst, int B, int Hs, int Ws, int C, int H, int W,
+                       gx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
