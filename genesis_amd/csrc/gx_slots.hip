@@ -44,7 +44,7 @@ constexpr int PCH = 4;
 __global__ void __launch_bounds__(256)
 maskpool_fwd_kernel(const float* __restrict__ f, const float* __restrict__ log_m, int B, int C, int HW, int K,
                     float* __restrict__ S, float* __restrict__ msum) {
-    __shared__ double red[4];
+    __shared__ double wred[4][KMAX * (PCH + 1)];
     const int b = blockIdx.x, c0 = blockIdx.y * PCH;
     const size_t kstride = (size_t)B * HW;
     double acc[KMAX][PCH];
@@ -56,32 +56,67 @@ maskpool_fwd_kernel(const float* __restrict__ f, const float* __restrict__ log_m
         for (int c = 0; c < PCH; ++c) acc[k][c] = 0.0;
     }
     const float* fb = f + ((size_t)b * C + c0) * HW;
-    for (int p = threadIdx.x; p < HW; p += blockDim.x) {
-        float fv[PCH];
+    if ((HW & 3) == 0) {
+        // 16-byte loads, 4 pixels per thread and iteration: 4x fewer serial load -> use steps (the loop is latency-bound)
+        for (int p4 = threadIdx.x; p4 < (HW >> 2); p4 += blockDim.x) {
+            f32x4 fv[PCH];
 #pragma unroll
-        for (int c = 0; c < PCH; ++c) fv[c] = (c0 + c < C) ? fb[(size_t)c * HW + p] : 0.f;
+            for (int c = 0; c < PCH; ++c) {
+                if (c0 + c < C) fv[c] = *reinterpret_cast<const f32x4*>(fb + (size_t)c * HW + 4 * p4);
+                else { fv[c][0] = 0.f; fv[c][1] = 0.f; fv[c][2] = 0.f; fv[c][3] = 0.f; }
+            }
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            if (k < K) {
-                const float m = expf(log_m[k * kstride + (size_t)b * HW + p]);
-                ms[k] += (double)m;
+            for (int k = 0; k < KMAX; ++k) {
+                if (k < K) {
+                    const f32x4 lm = *reinterpret_cast<const f32x4*>(log_m + k * kstride + (size_t)b * HW + 4 * p4);
 #pragma unroll
-                for (int c = 0; c < PCH; ++c) acc[k][c] += (double)(m * fv[c]);
+                    for (int e = 0; e < 4; ++e) {
+                        const float m = expf(lm[e]);
+                        ms[k] += (double)m;
+#pragma unroll
+                        for (int c = 0; c < PCH; ++c) acc[k][c] += (double)(m * fv[c][e]);
+                    }
+                }
+            }
+        }
+    } else {
+        for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+            float fv[PCH];
+#pragma unroll
+            for (int c = 0; c < PCH; ++c) fv[c] = (c0 + c < C) ? fb[(size_t)c * HW + p] : 0.f;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                if (k < K) {
+                    const float m = expf(log_m[k * kstride + (size_t)b * HW + p]);
+                    ms[k] += (double)m;
+#pragma unroll
+                    for (int c = 0; c < PCH; ++c) acc[k][c] += (double)(m * fv[c]);
+                }
             }
         }
     }
+    // one multi-value block reduction (wave shuffles, a single LDS hop) instead of K * (PCH + 1) serial ones
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
         if (k < K) {
 #pragma unroll
             for (int c = 0; c < PCH; ++c) {
-                const double s = block_sum_dd(acc[k][c], red);
-                if (threadIdx.x == 0 && c0 + c < C) S[((size_t)b * K + k) * C + c0 + c] = (float)s;
+                const double v = gx_wave_sum_d(acc[k][c]);
+                if (lane == 0) wred[wave][k * (PCH + 1) + c] = v;
             }
-            if (blockIdx.y == 0) {
-                const double s = block_sum_dd(ms[k], red);
-                if (threadIdx.x == 0) msum[(size_t)b * K + k] = (float)s;
-            }
+            const double v = gx_wave_sum_d(ms[k]);
+            if (lane == 0) wred[wave][k * (PCH + 1) + PCH] = v;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * (PCH + 1); i += blockDim.x) {
+        const double s = (wred[0][i] + wred[1][i]) + (wred[2][i] + wred[3][i]);
+        const int k = i / (PCH + 1), c = i - k * (PCH + 1);
+        if (c < PCH) {
+            if (c0 + c < C) S[((size_t)b * K + k) * C + c0 + c] = (float)s;
+        } else if (blockIdx.y == 0) {
+            msum[(size_t)b * K + k] = (float)s;
         }
     }
 }
@@ -108,7 +143,8 @@ maskpool_bwd_kernel(const float* __restrict__ f, const float* __restrict__ log_m
     }
     const float* fb = f + (size_t)b * C * HW + p;
     float* dfb = df + (size_t)b * C * HW + p;
-    for (int c = 0; c < C; ++c) {
+#pragma unroll 8
+    for (int c = 0; c < C; ++c) {       // (8 independent loads in flight per thread)
         const float fv = fb[(size_t)c * HW];
         float d = 0.f;
 #pragma unroll
@@ -124,6 +160,71 @@ maskpool_bwd_kernel(const float* __restrict__ f, const float* __restrict__ log_m
 #pragma unroll
     for (int k = 0; k < KMAX; ++k)
         if (k < K) dlog_m[k * kstride + (size_t)b * HW + p] = m[k] * (a[k] + gmsum[(size_t)b * K + k]);
+}
+
+// 4 pixels per thread (16-byte accesses); the 4 waves of a workgroup share the same 256 pixels and split the channels
+// (the per-pixel channel loop is a chain of dependent load -> store steps: a quarter of the channels per wave and 4x
+// the waves in flight); their partial sum_c gS*f are combined through LDS in wave order.
+__global__ void __launch_bounds__(256)
+maskpool_bwd_vec_kernel(const float* __restrict__ f, const float* __restrict__ log_m, const float* __restrict__ gS,
+                        const float* __restrict__ gmsum, int B, int C, int HW, int K, float* __restrict__ df,
+                        float* __restrict__ dlog_m) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* gsh = sm;                                                    // [K][C]
+    f32x4* ared = reinterpret_cast<f32x4*>(sm + ((K * C + 3) & ~3));    // [4 waves][K][64 lanes]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x;
+    const int p = (blockIdx.y * 64 + lane) * 4;
+    for (int i = threadIdx.x; i < K * C; i += blockDim.x) gsh[i] = gS[(size_t)b * K * C + i];
+    __syncthreads();
+    const bool act = p < HW;
+    const size_t kstride = (size_t)B * HW;
+    f32x4 m[KMAX], a[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        a[k][0] = 0.f; a[k][1] = 0.f; a[k][2] = 0.f; a[k][3] = 0.f;
+        m[k] = a[k];
+        if (k < K && act) {
+            const f32x4 lm = *reinterpret_cast<const f32x4*>(log_m + k * kstride + (size_t)b * HW + p);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[k][e] = expf(lm[e]);
+        }
+    }
+    const int cper = (C + 3) / 4;
+    const int cbeg = wave * cper, cend = (cbeg + cper < C) ? cbeg + cper : C;
+    if (act) {
+        const float* fb = f + (size_t)b * C * HW + p;
+        float* dfb = df + (size_t)b * C * HW + p;
+#pragma unroll 4
+        for (int c = cbeg; c < cend; ++c) {
+            const f32x4 fv = *reinterpret_cast<const f32x4*>(fb + (size_t)c * HW);
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                if (k < K) {
+                    const float g = gsh[k * C + c];
+                    a[k] += g * fv;
+                    d += m[k] * g;
+                }
+            }
+            *reinterpret_cast<f32x4*>(dfb + (size_t)c * HW) = d;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+        if (k < K) ared[(wave * K + k) * 64 + lane] = a[k];
+    __syncthreads();
+    if (wave == 0 && act) {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            if (k < K) {
+                const f32x4 t = (ared[(0 * K + k) * 64 + lane] + ared[(1 * K + k) * 64 + lane]) +
+                                (ared[(2 * K + k) * 64 + lane] + ared[(3 * K + k) * 64 + lane]);
+                *reinterpret_cast<f32x4*>(dlog_m + k * kstride + (size_t)b * HW + p) =
+                    m[k] * (t + gmsum[(size_t)b * K + k]);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------ mixture likelihood
@@ -554,9 +655,14 @@ int gx_maskpool_bwd(const float* f, const float* log_m, const float* gS, const f
     const int HW = H * W;
     {
         GxProf pf(KID_MASKPOOL_BWD, (hipStream_t)stream, 4.0 * B * K * C * HW, 4.0 * B * HW * (2.0 * C + 2.0 * K));
-        hipLaunchKernelGGL(maskpool_bwd_kernel, dim3(B, gx_ceil_div(HW, 256)), dim3(256),
-                           (size_t)K * C * sizeof(float), (hipStream_t)stream, f, log_m, gS, gmsum, B, C, HW, K, df,
-                           dlog_m);
+        if ((HW & 3) == 0)
+            hipLaunchKernelGGL(maskpool_bwd_vec_kernel, dim3(B, gx_ceil_div(HW, 256)), dim3(256),
+                               (size_t)(((K * C + 3) & ~3) + 4 * K * 64 * 4) * sizeof(float), (hipStream_t)stream, f,
+                               log_m, gS, gmsum, B, C, HW, K, df, dlog_m);
+        else
+            hipLaunchKernelGGL(maskpool_bwd_kernel, dim3(B, gx_ceil_div(HW, 256)), dim3(256),
+                               (size_t)K * C * sizeof(float), (hipStream_t)stream, f, log_m, gS, gmsum, B, C, HW, K, df,
+                               dlog_m);
     }
     GX_CHECK_LAUNCH("gx_maskpool_bwd");
     return GX_OK;
