@@ -1414,7 +1414,7 @@ inline bool smallcin_ok(int Cin, int H, int W) { return Cin * 9 <= 32 && (W % 16
 inline int smallcin_blocks(int N, int H, int W) {
     const int nchunks = N * ((H * W) >> 6);
     const int b = gx_ceil_div(nchunks, 4);
-    return b > 1024 ? 1024 : (b < 1 ? 1 : b);
+    return b > 512 ? 512 : (b < 1 ? 1 : b);     // 512 partial tables: the reduce reads 4 MB instead of 8
 }
 
 int launch_wgrad_reduce(const float* partial, float* dw, const WgradPlan& pl, int layout, hipStream_t s) {
