@@ -93,7 +93,9 @@ __device__ __forceinline__ float gx_act(float v, int act) {
 }
 
 // NPOS = halo-tile positions staged per thread per channel (tile <= NPOS*256 floats per channel).
-template <int MODE, int NPOS, bool DMA>
+// MW = waves along M: 1 -> the 4 waves tile 256 pixels (64 each) and all 64 channels; 2 -> a 128-pixel tile, waves 2 x 2
+// (32 channels x 64 pixels each): twice the workgroups for grids that cannot fill the chip with 256-pixel tiles.
+template <int MODE, int NPOS, bool DMA, int MW = 1>
 __device__ __forceinline__ void tapconv_body(const float* __restrict__ in, const float* __restrict__ wp,
                                              const float* __restrict__ bias, float* __restrict__ out,
                                              const ConvGeom& g, float* lds, const int bx, const int by, const int bz,
@@ -151,23 +153,26 @@ __device__ __forceinline__ void tapconv_body(const float* __restrict__ in, const
 
     // ---- per-lane fragment offsets ----
     // A (weights): lane -> w_tile[t][2kk + (lane>>5)][mi*32 + (lane&31)]
-    const int a_off = KC * CHS + (lane >> 5) * 64 + (lane & 31);
+    constexpr int MI = 2 / MW;                     // 32-channel MFMA tiles per wave
+    const int wm = MW == 2 ? (wave >> 1) : 0;      // channel half of this wave (MW == 2)
+    const int wn = MW == 2 ? (wave & 1) : wave;    // 64-pixel group of this wave
+    const int a_off = KC * CHS + (lane >> 5) * 64 + (lane & 31) + wm * 32;
     // B (input):   lane -> in_tile[2kk + (lane>>5)][plane][halo(pixel) + tap]
     int b_off[2];
 #pragma unroll
     for (int nj = 0; nj < 2; ++nj) {
-        const int p = wave * 64 + nj * 32 + (lane & 31);
+        const int p = wn * 64 + nj * 32 + (lane & 31);
         const int c = p & (TW - 1);
         const int r = (p >> g.lTW) & (TH - 1);
         const int gi = p >> (g.lTW + g.lTH);
         b_off[nj] = (lane >> 5) * CHS + (gi * (TH + 2) + r) * HS + c;
     }
 
-    f32x16 acc[NCLS][2][2];
+    f32x16 acc[NCLS][MI][2];
 #pragma unroll
     for (int c = 0; c < NCLS; ++c)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -269,14 +274,16 @@ __device__ __forceinline__ void tapconv_body(const float* __restrict__ in, const
 #pragma unroll
             for (int kk = 0; kk < KC / 2; ++kk) {
                 const float a0 = buf[(t * KC + 2 * kk) * 64 + a_off];
-                const float a1 = buf[(t * KC + 2 * kk) * 64 + a_off + 32];
                 const float b0 = buf[2 * kk * CHS + b_off[0] + toff];
                 const float b1 = buf[2 * kk * CHS + b_off[1] + toff];
                 const int cl = TC::cls(t);
                 acc[cl][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[cl][0][0], 0, 0, 0);
                 acc[cl][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[cl][0][1], 0, 0, 0);
-                acc[cl][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[cl][1][0], 0, 0, 0);
-                acc[cl][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[cl][1][1], 0, 0, 0);
+                if (MI == 2) {
+                    const float a1 = buf[(t * KC + 2 * kk) * 64 + a_off + 32];
+                    acc[cl][MI - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[cl][MI - 1][0], 0, 0, 0);
+                    acc[cl][MI - 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[cl][MI - 1][1], 0, 0, 0);
+                }
             }
         }
     }
@@ -289,7 +296,7 @@ __device__ __forceinline__ void tapconv_body(const float* __restrict__ in, const
     const int act = g.nsplit == 1 ? g.act : 0;
 #pragma unroll
     for (int nj = 0; nj < 2; ++nj) {
-        const int p = wave * 64 + nj * 32 + (lane & 31);
+        const int p = wn * 64 + nj * 32 + (lane & 31);
         const int c = p & (TW - 1);
         const int r = (p >> g.lTW) & (TH - 1);
         const int gi = p >> (g.lTW + g.lTH);
@@ -300,10 +307,10 @@ __device__ __forceinline__ void tapconv_body(const float* __restrict__ in, const
         else { orow = R0 + r; ocol = C0 + c; }
         float* obase = outz + (size_t)n * out_img_stride + (size_t)orow * g.Wo + ocol;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int m = m0 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                const int m = m0 + (mi + wm) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
                 if (m < g.M) {
                     const float bv = add_bias ? bias[m] : 0.f;
                     if (NCLS == 2) {
@@ -320,12 +327,12 @@ __device__ __forceinline__ void tapconv_body(const float* __restrict__ in, const
     }
 }
 
-template <int MODE, int NPOS, bool DMA>
+template <int MODE, int NPOS, bool DMA, int MW = 1>
 __global__ void __launch_bounds__(256, 2)
 tapconv_kernel(const float* __restrict__ in, const float* __restrict__ wp,
                const float* __restrict__ bias, float* __restrict__ out, ConvGeom g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    tapconv_body<MODE, NPOS, DMA>(in, wp, bias, out, g, lds, blockIdx.x, blockIdx.y, blockIdx.z, g.par_a);
+    tapconv_body<MODE, NPOS, DMA, MW>(in, wp, bias, out, g, lds, blockIdx.x, blockIdx.y, blockIdx.z, g.par_a);
 }
 
 // Both output-row parities of the transposed conv in one launch: blockIdx.y = 2 * channel_tile + parity.  Twice
@@ -962,6 +969,7 @@ void pick_tile(int Hb, int Wb, int npix, int planes, int max_chs, int* lTH, int*
 
 struct TapPlan {
     ConvGeom g;
+    int mw;            // 1: 256-pixel tile, 2: 128-pixel tile (waves 2 x 2)
     int npos;          // template NPOS to use
     size_t lds_bytes;
     size_t out_elems;  // N*M*Ho*Wo
@@ -970,14 +978,15 @@ struct TapPlan {
 
 template <int MODE>
 int plan_tapconv(int N, int K, int M, int Mpad_pack, int Hb, int Wb, int Hi, int Wi, int Ho, int Wo, int par_a,
-                 TapPlan* pl, const char* name, int ymult = 1) {
+                 TapPlan* pl, const char* name, int ymult = 1, int npix = 256) {
     using TC = TapCfg<MODE>;
     ConvGeom& g = pl->g;
     g.N = N; g.K = K; g.M = M;
     g.Kpad = gx_round_up(K, 8); g.Mpad = Mpad_pack;
     g.Hb = Hb; g.Wb = Wb; g.Hi = Hi; g.Wi = Wi; g.Ho = Ho; g.Wo = Wo; g.par_a = par_a;
     constexpr int LO_ = (MODE == M_DG) ? 8 : 2;
-    pick_tile(Hb, Wb, 256, TC::PLANES, 2 * LO_ * 256, &g.lTH, &g.lTW, &g.lG);
+    pick_tile(Hb, Wb, npix, TC::PLANES, 2 * LO_ * 256, &g.lTH, &g.lTW, &g.lG);
+    pl->mw = 256 / npix;
     const int TH = 1 << g.lTH, TW = 1 << g.lTW, G = 1 << g.lG;
     g.tiles_h = gx_ceil_div(Hb, TH); g.tiles_w = gx_ceil_div(Wb, TW);
     g.act = 0;
@@ -1032,6 +1041,18 @@ void launch_tapconv_inst(const float* in, const float* wp, const float* bias, fl
     static const char* dma_env = getenv("GENESIS_TAPCONV_DMA");
     const bool dma = dma_env ? dma_env[0] == '1' : MODE != M_C3;
     g.zeros = dma ? zero_page(s) : nullptr;
+    if (MODE == M_C3 && pl.mw == 2) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_kernel<M_C3, NPOS, false, 2>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        g.zeros = nullptr;
+        hipLaunchKernelGGL((tapconv_kernel<M_C3, NPOS, false, 2>), pl.grid, dim3(256), pl.lds_bytes, s, in, wp, bias, out,
+                           g);
+        return;
+    }
     if (g.zeros) launch_tapconv_inst2<MODE, NPOS, true>(in, wp, bias, out, g, pl.grid, pl.lds_bytes, s);
     else launch_tapconv_inst2<MODE, NPOS, false>(in, wp, bias, out, g, pl.grid, pl.lds_bytes, s);
 }
@@ -1139,6 +1160,20 @@ int launch_pack(const float* w, float* wp, int pack, int Co, int Ci, int NT, int
     }
     GX_CHECK_LAUNCH("pack_weights");
     return GX_OK;
+}
+
+// conv3x3 plan: 256-pixel tiles; grids that would have to split the channel reduction use 128-pixel tiles instead
+// (twice the workgroups, half the partial slabs or none).  Measured on all eight under-filled UNet layers (B=32):
+// 5-25 % faster each, 739 -> 690 us forward and 711 -> 660 us dgrad per step.  GENESIS_TAPCONV_MW2=0 disables.
+int plan_c3(int N, int K, int M, int Mpad, int H, int W, TapPlan* pl, const char* name) {
+    int rc = plan_tapconv<M_C3>(N, K, M, Mpad, H, W, H, W, H, W, 0, pl, name);
+    if (rc || pl->g.nsplit == 1) return rc;
+    static const char* env = getenv("GENESIS_TAPCONV_MW2");
+    if (env && env[0] == '0') return rc;
+    TapPlan p2;
+    if (plan_tapconv<M_C3>(N, K, M, Mpad, H, W, H, W, H, W, 0, &p2, name, 1, 128) != GX_OK) return rc;
+    *pl = p2;
+    return rc;
 }
 
 struct WgradPlan {
@@ -1591,7 +1626,7 @@ static int conv3x3_fwd_impl(const float* x, const float* w, const float* bias, i
     const int Kpad = gx_round_up(Cin, 8), Mpad = gx_round_up(Cout, 64);
     hipStream_t s = (hipStream_t)stream;
     TapPlan pl;
-    rc = plan_tapconv<M_C3>(N, Cin, Cout, Mpad, H, W, H, W, H, W, 0, &pl, "gx_conv3x3_fwd");
+    rc = plan_c3(N, Cin, Cout, Mpad, H, W, &pl, "gx_conv3x3_fwd");
     if (rc) return rc;
     float* wp = (float*)ws;
     float* part = wp + conv3x3_pack_floats(Cin, Cout);
@@ -1619,7 +1654,7 @@ int gx_conv3x3_dgrad(const float* dy, const float* w, float* dx, int N, int Cin,
     const int Kpad = gx_round_up(Cout, 8), Mpad = gx_round_up(Cin, 64);
     hipStream_t s = (hipStream_t)stream;
     TapPlan pl;
-    rc = plan_tapconv<M_C3>(N, Cout, Cin, Mpad, H, W, H, W, H, W, 0, &pl, "gx_conv3x3_dgrad");
+    rc = plan_c3(N, Cout, Cin, Mpad, H, W, &pl, "gx_conv3x3_dgrad");
     if (rc) return rc;
     float* wp = (float*)ws;
     float* part = wp + conv3x3_pack_floats(Cin, Cout);
