@@ -338,15 +338,15 @@ tapconv_kernel(const float* __restrict__ in, const float* __restrict__ wp,
 // Both output-row parities of the transposed conv in one launch: blockIdx.y = 2 * channel_tile + parity.  Twice
 // the workgroups of a single-parity launch, so mid-sized layers fill the chip without splitting the channel
 // reduction (and without the partial-sum traffic and reduce pass that come with it).
-template <int NPOS, bool DMA>
+template <int NPOS, bool DMA, int MW = 1>
 __global__ void __launch_bounds__(256, 2)
 tapconv_dt_kernel(const float* __restrict__ in, const float* __restrict__ wp0, const float* __restrict__ wp1,
                   const float* __restrict__ bias, float* __restrict__ out, ConvGeom g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (blockIdx.y & 1)
-        tapconv_body<M_DT1, NPOS, DMA>(in, wp1, bias, out, g, lds, blockIdx.x, blockIdx.y >> 1, blockIdx.z, 1);
+        tapconv_body<M_DT1, NPOS, DMA, MW>(in, wp1, bias, out, g, lds, blockIdx.x, blockIdx.y >> 1, blockIdx.z, 1);
     else
-        tapconv_body<M_DT0, NPOS, DMA>(in, wp0, bias, out, g, lds, blockIdx.x, blockIdx.y >> 1, blockIdx.z, 0);
+        tapconv_body<M_DT0, NPOS, DMA, MW>(in, wp0, bias, out, g, lds, blockIdx.x, blockIdx.y >> 1, blockIdx.z, 0);
 }
 
 // out[i] = sum_z part[z][i] (+ bias[channel]); fixed summation order.
@@ -1041,15 +1041,15 @@ void launch_tapconv_inst(const float* in, const float* wp, const float* bias, fl
     static const char* dma_env = getenv("GENESIS_TAPCONV_DMA");
     const bool dma = dma_env ? dma_env[0] == '1' : MODE != M_C3;
     g.zeros = dma ? zero_page(s) : nullptr;
-    if (MODE == M_C3 && pl.mw == 2) {
+    if ((MODE == M_C3 || MODE == M_DG) && pl.mw == 2) {
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_kernel<M_C3, NPOS, false, 2>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_kernel<MODE, NPOS, false, 2>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
         g.zeros = nullptr;
-        hipLaunchKernelGGL((tapconv_kernel<M_C3, NPOS, false, 2>), pl.grid, dim3(256), pl.lds_bytes, s, in, wp, bias, out,
+        hipLaunchKernelGGL((tapconv_kernel<MODE, NPOS, false, 2>), pl.grid, dim3(256), pl.lds_bytes, s, in, wp, bias, out,
                            g);
         return;
     }
@@ -1057,16 +1057,16 @@ void launch_tapconv_inst(const float* in, const float* wp, const float* bias, fl
     else launch_tapconv_inst2<MODE, NPOS, false>(in, wp, bias, out, g, pl.grid, pl.lds_bytes, s);
 }
 
-template <int NPOS, bool DMA>
+template <int NPOS, bool DMA, int MW = 1>
 void launch_dt(dim3 grid, size_t lds_bytes, hipStream_t s, const float* x, const float* wp0, const float* wp1,
                const float* bias, float* dst, const ConvGeom& g) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_dt_kernel<NPOS, DMA>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_dt_kernel<NPOS, DMA, MW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((tapconv_dt_kernel<NPOS, DMA>), grid, dim3(256), lds_bytes, s, x, wp0, wp1, bias, dst, g);
+    hipLaunchKernelGGL((tapconv_dt_kernel<NPOS, DMA, MW>), grid, dim3(256), lds_bytes, s, x, wp0, wp1, bias, dst, g);
 }
 
 // `dst` = final output when nsplit == 1, else the partial slabs [nsplit][N,M,Ho,Wo]
@@ -1767,6 +1767,13 @@ static int deconv_fwd_impl(const float* x, const float* w, const float* bias, fl
     TapPlan p0;
     rc = plan_tapconv<M_DT0>(N, Cin, Cout, Mpad, Hin, Win, Hin, Win, 2 * Hin, 2 * Win, 0, &p0, "gx_deconv5x5s2_fwd", 2);
     if (rc) return rc;
+    static const char* mw_env = getenv("GENESIS_TAPCONV_MW2");
+    if (p0.g.nsplit > 1 && !(mw_env && mw_env[0] == '0')) {   // 128-pixel tiles for under-filled grids (see plan_c3)
+        TapPlan p2;
+        if (plan_tapconv<M_DT0>(N, Cin, Cout, Mpad, Hin, Win, Hin, Win, 2 * Hin, 2 * Win, 0, &p2, "gx_deconv5x5s2_fwd",
+                                2, 128) == GX_OK)
+            p0 = p2;
+    }
     float* dst = p0.g.nsplit > 1 ? part : y;
     {
         const ConvGeom& g = p0.g;
@@ -1778,7 +1785,11 @@ static int deconv_fwd_impl(const float* x, const float* w, const float* bias, fl
         ConvGeom gg = p0.g;
         static const char* dma_env = getenv("GENESIS_TAPCONV_DMA");
         gg.zeros = (dma_env ? dma_env[0] == '1' : true) ? zero_page(s) : nullptr;
-        if (gg.zeros) {
+        if (p0.mw == 2) {
+            gg.zeros = nullptr;
+            if (p0.npos == 2) launch_dt<2, false, 2>(grid, p0.lds_bytes, s, x, wpu0, wpu1, bias, dst, gg);
+            else launch_dt<4, false, 2>(grid, p0.lds_bytes, s, x, wpu0, wpu1, bias, dst, gg);
+        } else if (gg.zeros) {
             if (p0.npos == 2) launch_dt<2, true>(grid, p0.lds_bytes, s, x, wpu0, wpu1, bias, dst, gg);
             else launch_dt<4, true>(grid, p0.lds_bytes, s, x, wpu0, wpu1, bias, dst, gg);
         } else {
@@ -1815,6 +1826,13 @@ int gx_deconv5x5s2_dgrad(const float* dy, const float* w, float* dx, int N, int 
     TapPlan pl;
     rc = plan_tapconv<M_DG>(N, Cout, Cin_out, Mpad, Hin, Win, 2 * Hin, 2 * Win, Hin, Win, 0, &pl, "gx_deconv5x5s2_dgrad");
     if (rc) return rc;
+    static const char* mw_env = getenv("GENESIS_TAPCONV_MW2");
+    if (pl.g.nsplit > 1 && !(mw_env && mw_env[0] == '0')) {
+        TapPlan p2;
+        if (plan_tapconv<M_DG>(N, Cout, Cin_out, Mpad, Hin, Win, 2 * Hin, 2 * Win, Hin, Win, 0, &p2,
+                               "gx_deconv5x5s2_dgrad", 1, 128) == GX_OK)
+            pl = p2;
+    }
     rc = launch_tapconv<M_DG>(dy, wpu, nullptr, pl.g.nsplit > 1 ? part : dx, pl, s, "gx_deconv5x5s2_dgrad");
     if (rc) return rc;
     if (pl.g.nsplit > 1) return launch_splitk_reduce(part, nullptr, dx, pl, s);
