@@ -157,6 +157,9 @@ __device__ __forceinline__ void tapconv_body(const float* __restrict__ in, const
     const int wm = MW == 2 ? (wave >> 1) : 0;      // channel half of this wave (MW == 2)
     const int wn = MW == 2 ? (wave & 1) : wave;    // 64-pixel group of this wave
     const int a_off = KC * CHS + (lane >> 5) * 64 + (lane & 31) + wm * 32;
+    // output channels 32..63 of this workgroup's tile exist?  (32-channel layers -- MONet's UNet ends and its
+    // BroadcastDecoder -- skip the upper MFMA tile instead of computing padding)
+    const bool hi_half = m0 + 32 < g.M;
     // B (input):   lane -> in_tile[2kk + (lane>>5)][plane][halo(pixel) + tap]
     int b_off[2];
 #pragma unroll
@@ -279,7 +282,7 @@ __device__ __forceinline__ void tapconv_body(const float* __restrict__ in, const
                 const int cl = TC::cls(t);
                 acc[cl][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[cl][0][0], 0, 0, 0);
                 acc[cl][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[cl][0][1], 0, 0, 0);
-                if (MI == 2) {
+                if (MI == 2 && hi_half) {
                     const float a1 = buf[(t * KC + 2 * kk) * 64 + a_off + 32];
                     acc[cl][MI - 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[cl][MI - 1][0], 0, 0, 0);
                     acc[cl][MI - 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[cl][MI - 1][1], 0, 0, 0);
