@@ -225,6 +225,23 @@ class TrainStep(object):
         self._replay()
         self.iters += 1
 
+    def prepare(self, x):
+        """Builds everything a first step() would (weight-cache recording, kernel attributes, graph capture) WITHOUT
+        advancing the training state: parameters, Adam moments, step counter and GECO state are restored afterwards."""
+        if not self.use_graph or self.graph is not None:
+            return
+        state = [self.flat_p, self.flat_p64, self.m32, self.v32, self.m64, self.v64, self.step_t]
+        if self.geco is not None:
+            state.append(self.geco.state)
+        snap = [t.clone() for t in state]
+        iters = self.iters
+        self._capture(x)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            for t, s in zip(state, snap):
+                t.copy_(s)
+        self.iters = iters
+
     def _needs_collective(self):
         import os
         return dist.is_available() and dist.is_initialized() and \

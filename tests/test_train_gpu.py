@@ -85,6 +85,24 @@ def test_graph_replay_matches_eager():
     assert float((pa - pb).abs().max()) < 5e-3
 
 
+def test_prepare_captures_without_advancing_state():
+    """prepare() is set-up (graph capture): parameters, Adam moments, step counter and GECO state stay untouched."""
+    from genesis_amd.trainer import TrainStep
+    gold = Golden('tiny')
+    x, _, _ = gold.inputs()
+    xd = x.to(DEV)
+    model = build(gold)
+    ts = TrainStep(model, gold.S, graph=True)
+    before = [t.clone() for t in (ts.flat_p, ts.flat_p64, ts.m32, ts.v32, ts.step_t, ts.geco.state)]
+    ts.prepare(xd)
+    assert ts.graph is not None and ts.iters == 0
+    after = (ts.flat_p, ts.flat_p64, ts.m32, ts.v32, ts.step_t, ts.geco.state)
+    assert all(torch.equal(a, b) for a, b in zip(before, after))
+    out = ts.step(xd)
+    assert torch.isfinite(out).all() and int(ts.step_t) == 1 and ts.iters == 1
+    assert not torch.equal(before[0], ts.flat_p)
+
+
 def test_profile_collect():
     from genesis_amd import profiling
     from genesis_amd.trainer import TrainStep
