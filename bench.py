@@ -152,11 +152,11 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 or os.environ.get('GENESIS_FORCE_ALLREDUCE'):
-        dist.init_process_group('nccl', init_method='env://')
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
+    if world > 1 or os.environ.get('GENESIS_FORCE_ALLREDUCE'):
+        dist.init_process_group('nccl', init_method='env://', device_id=device)   # binds the communicator to this GPU
 
     from genesis_amd.trainer import TrainStep
     from genesis_amd import profiling
