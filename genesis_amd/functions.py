@@ -246,6 +246,8 @@ class ICSBPFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, conv_w, conv_b, gate, uv, log_sigma, rand_pixel, K, kernel, seed_idx):
         feat = feat.contiguous()
+        ctx.params = (conv_w, conv_b, gate, log_sigma)
+        conv_w = conv_w.detach().view(conv_w.shape[0], -1)
         colour = hip.conv1x1_fwd(feat, conv_w, conv_b, gate, uv)
         # the kernel takes the bandwidth as an fp64 device scalar (it is an fp64 parameter for the default
         # kernel, modules/attention.py:150,155; fp32 only for epanechnikov)
@@ -263,9 +265,13 @@ class ICSBPFn(torch.autograd.Function):
         feat, conv_w, conv_b, gate, log_sigma, colour, seeds, idx = ctx.saved_tensors
         if g_log_m is None:       # log_m unused downstream
             g_log_m = colour.new_zeros(seeds.shape[0] + 1, colour.shape[0], 1, colour.shape[2], colour.shape[3])
-        dcolour, dls = hip.icsbp_bwd(colour, log_sigma, seeds, idx, g_log_m.contiguous(), ctx.kernel)
-        dfeat, dw, db, dgate = hip.conv1x1_bwd(feat, dcolour, conv_w, conv_b, gate)
-        return dfeat, dw, db, dgate, None, dls.to(ctx.ls_dtype), None, None, None, None
+        pw, pb, pg, pls = ctx.params
+        ow, ob, og = _gout(pw), _gout(pb), (_gout(pg) if pg is not None else None)
+        ols = _gout(pls) if ctx.ls_dtype == torch.float64 and pls.dim() == 0 else None
+        dcolour, dls = hip.icsbp_bwd(colour, log_sigma, seeds, idx, g_log_m.contiguous(), ctx.kernel, out_dls=ols)
+        dfeat, dw, db, dgate = hip.conv1x1_bwd(feat, dcolour, conv_w, conv_b, gate, out=(ow, ob, og))
+        return (dfeat, _ret(ow, dw.view(pw.shape)), _ret(ob, db), _ret(og, dgate), None,
+                _ret(ols, dls.to(ctx.ls_dtype)), None, None, None, None)
 
 
 class MaskPoolFn(torch.autograd.Function):
@@ -300,7 +306,7 @@ class DecoderFn(torch.autograd.Function):
             saved.append((h, y, mean, rstd))
             h = a
         ow, ob = params[16], params[17]
-        out = hip.conv1x1_fwd(h, ow, ob)
+        out = hip.conv1x1_fwd(h, ow.detach().view(ow.shape[0], -1), ob)
         ctx.saved = saved
         ctx.last = h
         ctx.params = params
@@ -311,9 +317,11 @@ class DecoderFn(torch.autograd.Function):
     def backward(ctx, g):
         params = ctx.params
         ow, ob = params[16], params[17]
-        da, dow, dob, _ = hip.conv1x1_bwd(ctx.last, g.contiguous(), ow, ob)
+        gow, gob = _gout(ow), _gout(ob)
+        da, dow, dob, _ = hip.conv1x1_bwd(ctx.last, g.contiguous(), ow.detach().view(ow.shape[0], -1), ob,
+                                          out=(gow, gob, None))
         grads = [None] * 18
-        grads[16], grads[17] = dow, dob
+        grads[16], grads[17] = _ret(gow, dow.view(ow.shape)), _ret(gob, dob)
         for l in reversed(range(4)):
             w, b, gamma, beta = params[4 * l:4 * l + 4]
             h, y, mean, rstd = ctx.saved[l]

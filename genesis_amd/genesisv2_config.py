@@ -226,7 +226,7 @@ class GenesisV2(nn.Module):
         for ci, gi in ((1, 2), (4, 5), (7, 8), (10, 11)):
             p.extend((self.decoder_module[ci].weight, self.decoder_module[ci].bias,
                       self.decoder_module[gi].weight, self.decoder_module[gi].bias))
-        p.extend((self.decoder_module[13].weight.view(4, -1), self.decoder_module[13].bias))
+        p.extend((self.decoder_module[13].weight, self.decoder_module[13].bias))
         return p
 
     def _decode(self, z_kbd, x=None):
@@ -280,7 +280,7 @@ class GenesisV2(nn.Module):
         else:
             cw, cb, gate, addend = ap.colour_head.weight, ap.colour_head.bias, None, None
         log_m, log_s, colour, seeds, idx = fn.ICSBPFn.apply(
-            seg, cw.view(cw.shape[0], -1), cb, gate, addend, ap.log_sigma, rand_pixel, K, ap.kernel, seed_idx)
+            seg, cw, cb, gate, addend, ap.log_sigma, rand_pixel, K, ap.kernel, seed_idx)
         # --- Object features: feat_head[0] once (the reference recomputes it K times, :149), pooled per
         #     slot; the 1x1 conv feat_head[1] commutes with the masked sum and is applied to the pooled sums.
         f = fn.ConvGNReLUFn.apply(enc_feat, *self.feat_head[0].params())

@@ -258,12 +258,13 @@ def icsbp_fwd(colour, log_sigma, rand_pixel, K, kernel='gaussian', seed_idx=None
     return log_m, log_s, seeds, idx
 
 
-def icsbp_bwd(colour, log_sigma, seeds, idx, g_log_m, kernel='gaussian'):
+def icsbp_bwd(colour, log_sigma, seeds, idx, g_log_m, kernel='gaussian', out_dls=None):
     _chk(g_log_m, 'icsbp_bwd.g_log_m')
     B, C, H, W = colour.shape
     K = g_log_m.shape[0]
     dcolour = torch.empty_like(colour)
-    dls = torch.empty((), dtype=torch.float64, device=colour.device)
+    dls = out_dls if out_dls is not None else torch.empty((), dtype=torch.float64, device=colour.device)
+    _chk(dls, 'icsbp_bwd.dls', torch.float64)
     nb = _lib.query('gx_icsbp_bwd_ws_bytes', B, H, W, K)
     ws = _ws(nb, colour.device)
     _lib.call('gx_icsbp_bwd', _p(colour), _p(log_sigma), _p(seeds), _p(idx), _p(g_log_m), B, C, H, W, K,
@@ -329,20 +330,24 @@ def conv1x1_fwd(x, w, bias, gate=None, addend=None):
     return y
 
 
-def conv1x1_bwd(x, dy, w, bias, gate=None):
+def conv1x1_bwd(x, dy, w, bias, gate=None, out=None):
+    """out = (dw, db, dgate) preallocated destinations (entries may be None), e.g. the parameters' .grad buffers."""
     _chk(dy, 'conv1x1_bwd.dy')
     N, Cin, H, W = x.shape
     Cout = w.shape[0]
     dev = x.device
+    o = out or (None, None, None)
     dx = torch.empty_like(x)
-    dw = torch.empty(Cout, Cin, dtype=F32, device=dev)
-    db = torch.empty(Cout, dtype=F32, device=dev) if bias is not None else None
-    dgate = torch.empty((), dtype=F32, device=dev) if gate is not None else None
+    dw = o[0] if o[0] is not None else torch.empty(Cout, Cin, dtype=F32, device=dev)
+    db = (o[1] if o[1] is not None else torch.empty(Cout, dtype=F32, device=dev)) if bias is not None else None
+    dgate = (o[2] if o[2] is not None else torch.empty((), dtype=F32, device=dev)) if gate is not None else None
+    _chk(dw, 'conv1x1_bwd.dw'); _chk(db, 'conv1x1_bwd.db'); _chk(dgate, 'conv1x1_bwd.dgate')
+    assert dw.numel() == Cout * Cin
     nb = _lib.query('gx_conv1x1_bwd_ws_bytes', N, Cin, Cout, H, W)
     ws = _ws(nb, dev)
     _lib.call('gx_conv1x1_bwd', _p(x), _p(dy), _p(w), _p(bias), _p(gate), N, Cin, Cout, H, W, _p(dx), _p(dw),
               _p(db), _p(dgate), _p(ws), nb, _stream())
-    return dx, dw.view(w.shape), db, dgate
+    return dx, (dw.view(w.shape) if o[0] is None else dw), db, dgate
 
 
 # ------------------------------------------------------------------ ComponentVAE / MONet path
