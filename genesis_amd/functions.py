@@ -83,6 +83,40 @@ def join_side_stream():
     _keep_alive.clear()
 
 
+# ---- the AR-prior branch on the side stream ----------------------------------------------------------------
+# z -> LSTM -> linear -> log p(z) -> KL is a chain of ~12 launch-latency-bound kernels (32 workgroups each) that
+# depends only on the posterior sample and joins the main path again at the loss; forward and backward (autograd runs
+# a node's backward on its forward's stream) it can run in the shadow of the decoder's chip-filling kernels.  Inside
+# the captured step it becomes a parallel branch of the HIP graph.
+# MEASURED (round 1, B=32 K=7 64x64, A/B in one session): 5710 img/s without, 5640 with the fork -- the graph's
+# fork/join synchronisation costs more than the ~150 us of tiny kernels it hides -- so TrainStep leaves it OFF
+# (GENESIS_SIDE_PRIOR=1 / TrainStep(side_prior=True) turns it on).
+SIDE_PRIOR = False
+
+
+class side_branch(object):
+    """with side_branch(*tensors_read_inside): ...   -- forks the body onto the side stream; join_branch() before the
+    results are consumed on the main stream.  Tensors read inside are kept alive until join_side_stream()."""
+
+    def __init__(self, *reads):
+        self.reads = reads
+
+    def __enter__(self):
+        side = _side()
+        side.wait_stream(torch.cuda.current_stream())
+        _keep_alive.extend(self.reads)
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        return self.ctx.__exit__(*exc)
+
+
+def join_branch():
+    torch.cuda.current_stream().wait_stream(_side())
+
+
 def _ret(out, value):
     """What a Function returns for a parameter: None if the kernel already wrote into p.grad."""
     return None if out is not None else value

@@ -259,6 +259,13 @@ class GenesisV2(nn.Module):
             outs.append(h)
         return torch.stack(outs, 0)
 
+    def _component_kl(self, z, log_q):
+        """[K,B]: log q(z_k|x) - log p(z_k|z_<k) per slot (Genesis.mask_latent_loss, models/genesis_config.py:288-343)."""
+        lin = None
+        if self.prior_lstm is not None:
+            lin = fn.linear(self._prior_hidden(z), self.prior_linear.weight, self.prior_linear.bias)  # [K-1,B,2D]
+        return fn.PriorLogPFn.apply(z, lin, log_q)
+
     # ------------------------------------------------------------------ forward
     def forward(self, x, rand_pixel=None, eps=None, seed_idx=None):
         """x [B,3,H,W] in [0,1] on the GPU.  The optional arguments inject the noise the reference draws
@@ -294,8 +301,18 @@ class GenesisV2(nn.Module):
         zh = fn.linear(zh, self.z_head[1].weight, self.z_head[1].bias, 'relu')
         zh = fn.linear(zh, self.z_head[3].weight, self.z_head[3].bias)
         z, mu, sigma, log_q = fn.PosteriorFn.apply(zh, eps)                  # [K,B,D] x3, [K,B]
+        # --- Component KL (Genesis.mask_latent_loss, models/genesis_config.py:288-343); optionally forked onto the
+        #     side stream so that its chain of tiny kernels runs beside the decoder (fn.SIDE_PRIOR)
+        forked = fn.SIDE_PRIOR and self.prior_lstm is not None and torch.is_grad_enabled()
+        if forked:
+            with fn.side_branch(z, log_q):
+                kl = self._component_kl(z, log_q)
         # --- Decode latents, reconstruction loss
         err, recon, x_r, log_m_r = self._decode(z, x)
+        if forked:
+            fn.join_branch()
+        else:
+            kl = self._component_kl(z, log_q)
         losses = AttrDict()
         losses['err'] = err
         log_m_k = list(log_m.unbind(0))
@@ -311,11 +328,6 @@ class GenesisV2(nn.Module):
             q = q / q.sum(0, keepdim=True)
             p_ = p_ / p_.sum(0, keepdim=True)
             losses['kl_m'] = (q * (q.log() - p_.log())).sum(0).flatten(1).sum(1)
-        # -- Component KL (Genesis.mask_latent_loss, models/genesis_config.py:288-343)
-        lin = None
-        if self.prior_lstm is not None:
-            lin = fn.linear(self._prior_hidden(z), self.prior_linear.weight, self.prior_linear.bias)  # [K-1,B,2D]
-        kl = fn.PriorLogPFn.apply(z, lin, log_q)                    # [K,B]: log_q - log_p per slot
         losses['kl_l_k'] = SlotList(kl.unbind(0), stacked=kl)
 
         # derived visualisation outputs are evaluated on first access (a training step never reads them)

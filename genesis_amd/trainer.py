@@ -4,6 +4,7 @@ HIP Adam kernel, the on-device GECO update, optional HIP-graph replay of the who
 process per GPU -- a single RCCL all-reduce of the flat gradient bucket (the batch-mean err / KL ride in
 its tail so every rank applies the identical GECO update)."""
 import ctypes
+import os
 
 import torch
 import torch.distributed as dist
@@ -22,7 +23,8 @@ def _p(t):
 class TrainStep(object):
 
     def __init__(self, model, img_size, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, geco=None, use_geco=True,
-                 beta_fixed=0.5, process_group=None, graph=False, async_wgrad=False, weight_cache=True, defer_reduces=True):
+                 beta_fixed=0.5, process_group=None, graph=False, async_wgrad=False, weight_cache=True, defer_reduces=True,
+                 side_prior=None):
         self.model = model
         self.lr, self.betas, self.eps = lr, betas, eps
         self.device = next(model.parameters()).device
@@ -31,6 +33,7 @@ class TrainStep(object):
         self.geco = geco if geco is not None else (make_geco(img_size, device=self.device) if use_geco else None)
         self.beta_fixed = beta_fixed
         self.async_wgrad = async_wgrad
+        self.side_prior = (os.environ.get('GENESIS_SIDE_PRIOR', '0') == '1') if side_prior is None else side_prior
         self.defer_reduces = defer_reduces
         self._beta_fixed_t = torch.tensor(float(beta_fixed), device=self.device)
         self.pg = process_group
@@ -66,6 +69,7 @@ class TrainStep(object):
         _fn.begin_direct_grads()
         _hip.DEFER_REDUCES = self.defer_reduces
         _fn.ASYNC_WGRAD = self.async_wgrad
+        _fn.SIDE_PRIOR = self.side_prior
         # packed-weight cache: the first (never graph-captured) iteration records which weight tensors the conv
         # entry points pack; later iterations re-pack all of them in one launch up front
         recording = False
@@ -82,6 +86,7 @@ class TrainStep(object):
         finally:
             _fn.DIRECT_PARAM_GRADS = False
             _fn.ASYNC_WGRAD = False
+            _fn.SIDE_PRIOR = False
             _hip.DEFER_REDUCES = False
             _hip.defer_discard()       # no-op after a completed iteration (the queue was flushed)
             if self._wcache is not None:
@@ -122,7 +127,9 @@ class TrainStep(object):
         if fused:
             # one launch: batch means, the GECO-weighted objective, and (err, kl) straight into the bucket tail
             loss, out5 = _fn.ElboFn.apply(losses.err, kl_rows, beta_t, self.bucket.flat_g[self.n32:self.n32 + 2])
-            loss.backward()
+            if getattr(self, '_one', None) is None or self._one.shape != loss.shape:
+                self._one = torch.ones_like(loss)
+            torch.autograd.backward([loss], [self._one])      # (no ones_like fill launch per step)
             beta_used = out5.detach()
         else:
             err = losses.err.mean(0)
@@ -172,6 +179,7 @@ class TrainStep(object):
         _fn.begin_direct_grads()
         _hip.DEFER_REDUCES = self.defer_reduces
         _fn.ASYNC_WGRAD = self.async_wgrad
+        _fn.SIDE_PRIOR = self.side_prior
         if self._wcache is not None and self._wcache_ready:
             _lib.call('gx_weight_cache_refresh', self._wcache,
                       ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
@@ -179,6 +187,7 @@ class TrainStep(object):
     def _end(self):
         _fn.DIRECT_PARAM_GRADS = False
         _fn.ASYNC_WGRAD = False
+        _fn.SIDE_PRIOR = False
         _hip.DEFER_REDUCES = False
         _hip.defer_discard()
         if self._wcache is not None and self._wcache_ready:
