@@ -18,15 +18,14 @@ namespace {
 // Lane (idx = lane & 15, kq = lane >> 4) owns contraction indices k16 + 4 kq + {0..3}; MFMA step jj consumes index
 // 4 kq + jj from every kq -- a permutation of the 16 indices that A and B share, so contiguous operands load float4.
 template <bool A_KC, bool B_KC, bool MASK, bool ROWSUM>
-__global__ void __launch_bounds__(1024)
-dense_kernel(const float* __restrict__ a, int lda, const float* __restrict__ mask, const float* __restrict__ b,
-             int ldb, const float* __restrict__ bias, int act, float* __restrict__ c, int ldc, int I, int J, int Kc,
-             float* __restrict__ rs, int vec_a, int vec_b) {
-    __shared__ float part[16][256];
-    __shared__ float rpart[16][16];
+__device__ __forceinline__ void
+dense_tile(float (*part)[256], float (*rpart)[16], int bx, int by, const float* __restrict__ a, int lda,
+           const float* __restrict__ mask, const float* __restrict__ b, int ldb, const float* __restrict__ bias,
+           int act, float* __restrict__ c, int ldc, int I, int J, int Kc, float* __restrict__ rs, int vec_a,
+           int vec_b) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int idx = lane & 15, kq = lane >> 4;
-    const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+    const int i0 = by * 16, j0 = bx * 16;
     const int ai = i0 + idx, bj = j0 + idx;
     const bool a_ok = ai < I, b_ok = bj < J;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -108,11 +107,39 @@ dense_kernel(const float* __restrict__ a, int lda, const float* __restrict__ mas
             c[(size_t)ci * ldc + cj] = s;
         }
     }
-    if (ROWSUM && blockIdx.x == 0 && threadIdx.x < 16 && i0 + (int)threadIdx.x < I) {
+    if (ROWSUM && bx == 0 && threadIdx.x < 16 && i0 + (int)threadIdx.x < I) {
         float s = rpart[0][threadIdx.x];
         for (int w = 1; w < nw; ++w) s += rpart[w][threadIdx.x];
         rs[i0 + threadIdx.x] = s;
     }
+}
+
+template <bool A_KC, bool B_KC, bool MASK, bool ROWSUM>
+__global__ void __launch_bounds__(1024)
+dense_kernel(const float* __restrict__ a, int lda, const float* __restrict__ mask, const float* __restrict__ b,
+             int ldb, const float* __restrict__ bias, int act, float* __restrict__ c, int ldc, int I, int J, int Kc,
+             float* __restrict__ rs, int vec_a, int vec_b) {
+    __shared__ float part[16][256];
+    __shared__ float rpart[16][16];
+    dense_tile<A_KC, B_KC, MASK, ROWSUM>(part, rpart, blockIdx.x, blockIdx.y, a, lda, mask, b, ldb, bias, act, c, ldc,
+                                         I, J, Kc, rs, vec_a, vec_b);
+}
+
+// Both halves of a layer's backward in one launch (they are independent, and a kernel boundary costs more than
+// either): rows [0, gy_dx) of the grid compute dx[M,K] = dpre[M,N] w[N,K], the rest dw[N,K] = dpre^T x (+ db).
+template <bool MASK, bool ROWSUM>
+__global__ void __launch_bounds__(1024)
+dense_bwd_pair_kernel(const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ w,
+                      const float* __restrict__ x, float* __restrict__ dx, float* __restrict__ dw,
+                      float* __restrict__ db, int M, int N, int K, int gy_dx, int vec) {
+    __shared__ float part[16][256];
+    __shared__ float rpart[16][16];
+    if ((int)blockIdx.y < gy_dx)
+        dense_tile<true, false, MASK, false>(part, rpart, blockIdx.x, blockIdx.y, g, N, y, w, K, nullptr, 0, dx, K, M,
+                                             K, N, nullptr, vec, 0);
+    else
+        dense_tile<false, false, MASK, ROWSUM>(part, rpart, blockIdx.x, blockIdx.y - gy_dx, g, N, y, x, K, nullptr, 0,
+                                               dw, K, N, K, M, db, 0, 0);
 }
 
 // ------------------------------------------------------------------------------------------------ LSTM cell
@@ -259,6 +286,21 @@ int gx_linear_bwd(const float* x, const float* w, const float* y, const float* g
     GX_CHECK_ARG(act == 0 || (act == 1 && y), "gx_linear_bwd: act 1 (ReLU) needs the layer output y");
     GX_CHECK_ARG(dw || !db, "gx_linear_bwd: db is produced together with dw");
     hipStream_t s = (hipStream_t)stream;
+    if (dx && dw) {   // one launch for both
+        const int vec = (N % 4 == 0) && aligned16(g) && (act == 0 || aligned16(y));
+        GxProf pf(KID_DENSE, s, 4.0 * M * N * K, 4.0 * (4.0 * M * N + 2.0 * N * K + 2.0 * M * K));
+        const int gy_dx = gx_ceil_div(M, 16);
+        const dim3 grid(gx_ceil_div(K, 16), gy_dx + gx_ceil_div(N, 16)), block(dense_threads(M > N ? M : N));
+        const float* mask = act == 1 ? y : nullptr;
+#define GX_PAIR(MASK, ROWSUM)                                                                                        \
+        hipLaunchKernelGGL((dense_bwd_pair_kernel<MASK, ROWSUM>), grid, block, 0, s, g, mask, w, x, dx, dw, db, M, N, \
+                           K, gy_dx, vec)
+        if (act == 1) { if (db) GX_PAIR(true, true); else GX_PAIR(true, false); }
+        else          { if (db) GX_PAIR(false, true); else GX_PAIR(false, false); }
+#undef GX_PAIR
+        GX_CHECK_LAUNCH("gx_linear_bwd(dx+dw)");
+        return GX_OK;
+    }
     if (dx) {   // dx[M,K] = dpre[M,N] w[N,K]
         const int vec = (N % 4 == 0) && aligned16(g) && (act == 0 || aligned16(y));
         GxProf pf(KID_DENSE, s, 2.0 * M * N * K, 4.0 * (2.0 * M * N + (double)N * K + (double)M * K));
