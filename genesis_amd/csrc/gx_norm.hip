@@ -22,6 +22,10 @@ struct View {
     int ctot;     // channels of the destination / source buffer
     int c0;       // first channel of this tensor's slice
     int mode;     // 0: same size; 1: buffer is 2x larger (nearest up); 2: buffer is 2x smaller (picks [::2, ::2])
+                  // 3 (gradient source only): ptr is the gradient of a following 1x1 conv's OUTPUT [N, ctot, H, W]
+                  //   and the view's value is its data gradient sum_o proj[o][c] * ptr[n][o][r][col], formed on load
+    const float* proj;   // mode 3: the 1x1 conv weight [ctot, C]
+    int projC;           // mode 3: C (row length of proj)
 };
 
 // Input of the forward kernels: the conv output, possibly still as `nsplit` split-K partial slabs (summed here in
@@ -83,10 +87,15 @@ __device__ __forceinline__ float load_view(const View& v, int n, int c, int r, i
         const float2 a = *reinterpret_cast<const float2*>(p);
         const float2 b = *reinterpret_cast<const float2*>(p + 2 * W);
         return (a.x + a.y) + (b.x + b.y);
-    } else {
+    } else if (v.mode == 2) {
         if (((r | col) & 1) == 0)
             return v.ptr[(((size_t)n * v.ctot + v.c0 + c) * (H >> 1) + (r >> 1)) * (W >> 1) + (col >> 1)];
         return 0.f;
+    } else {
+        float s = 0.f;
+        for (int o = 0; o < v.ctot; ++o)
+            s += v.proj[o * v.projC + c] * v.ptr[(((size_t)n * v.ctot + o) * H + r) * W + col];
+        return s;
     }
 }
 
@@ -146,13 +155,18 @@ __device__ __forceinline__ f32x4 load_view4(const View& v, int n, int c, int r, 
         o[1] = (a0[2] + a0[3]) + (b0[2] + b0[3]);
         o[2] = (a1[0] + a1[1]) + (b1[0] + b1[1]);
         o[3] = (a1[2] + a1[3]) + (b1[2] + b1[3]);
-    } else {
+    } else if (v.mode == 2) {
         o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f;
         if ((r & 1) == 0) {
             const float2 t = *reinterpret_cast<const float2*>(
                 v.ptr + (((size_t)n * v.ctot + v.c0 + c) * (H >> 1) + (r >> 1)) * (W >> 1) + (col >> 1));
             o[0] = t.x; o[2] = t.y;
         }
+    } else {
+        o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f;
+        for (int q = 0; q < v.ctot; ++q)
+            o += v.proj[q * v.projC + c] *
+                 *reinterpret_cast<const f32x4*>(v.ptr + (((size_t)n * v.ctot + q) * H + r) * W + col);
     }
     return o;
 }
@@ -190,6 +204,7 @@ gn_relu_fwd_kernel(const InSrc src, const float* __restrict__ gamma, const float
     const float meanf = (float)mean;
     const float rstdf = (float)(1.0 / sqrt(var + (double)eps));
     if (threadIdx.x == 0) { mean_out[blockIdx.x] = meanf; rstd_out[blockIdx.x] = rstdf; }
+    if (!d0.ptr) return;                   // statistics only (the consumer normalises on the fly)
     const int lW = __ffs(W) - 1, lHW = __ffs(HW) - 1;
     if (VEC) {
         const f32x4* s4 = reinterpret_cast<const f32x4*>(slab);
@@ -429,6 +444,7 @@ gn_relu_fwd_reg_kernel(const InSrc src, const float* __restrict__ gamma, const f
     const float meanf = (float)mean;
     const float rstdf = (float)(1.0 / sqrt(var + (double)eps));
     if (threadIdx.x == 0) { mean_out[blockIdx.x] = meanf; rstd_out[blockIdx.x] = rstdf; }
+    if (!d0.ptr) return;                   // statistics only
     const int lW = __ffs(W) - 1;
 #pragma unroll
     for (int u = 0; u < UPW; ++u) {
@@ -582,7 +598,7 @@ gn_relu_fwd_small_kernel(const InSrc src, const float* __restrict__ gamma, const
     const float meanf = (float)mean;
     const float rstdf = (float)(1.0 / sqrt(var + (double)eps));
     if (threadIdx.x == 0) { mean_out[blockIdx.x] = meanf; rstd_out[blockIdx.x] = rstdf; }
-    if (act) {
+    if (act && d0.ptr) {
         const int cl = e / HW, hw = e - cl * HW;
         const int c = gidx * cpg + cl;
         const int r = hw / W, col = hw - r * W;
@@ -782,11 +798,12 @@ static int gn_relu_fwd_impl(const InSrc& src, const float* gamma, const float* b
                             float* dst1, int dst1_ctot, int dst1_c0, int dst1_mode, float* mean, float* rstd,
                             gx_stream_t stream) {
     const float* y = src.p;
-    GX_CHECK_ARG(y && gamma && beta && dst0 && mean && rstd, "gx_gn_relu_fwd: null pointer");
+    GX_CHECK_ARG(y && gamma && beta && mean && rstd, "gx_gn_relu_fwd: null pointer");
+    GX_CHECK_ARG(dst0 || !dst1, "gx_gn_relu_fwd: dst1 without dst0");
     GX_CHECK_ARG(N > 0 && C > 0 && groups > 0 && C % groups == 0, "gx_gn_relu_fwd: bad N/C/groups");
     GX_CHECK_ARG(gx_is_pow2(H) && gx_is_pow2(W) && W >= 2 && H >= 2, "gx_gn_relu_fwd: H,W must be powers of two >= 2");
-    View d0{dst0, dst0_ctot, dst0_c0, dst0_mode}, d1{dst1, dst1_ctot, dst1_c0, dst1_mode};
-    int rc = check_view("gx_gn_relu_fwd", d0, C);
+    View d0{dst0, dst0_ctot, dst0_c0, dst0_mode, nullptr, 0}, d1{dst1, dst1_ctot, dst1_c0, dst1_mode, nullptr, 0};
+    int rc = dst0 ? check_view("gx_gn_relu_fwd", d0, C) : GX_OK;    // dst0 == NULL: statistics only
     if (rc) return rc;
     if (dst1) { rc = check_view("gx_gn_relu_fwd", d1, C); if (rc) return rc; }
     const int m = (C / groups) * H * W;
@@ -797,7 +814,8 @@ static int gn_relu_fwd_impl(const InSrc& src, const float* gamma, const float* b
         auto vw = [](int mode) { return mode == 1 ? 4.0 : (mode == 2 ? 0.25 : 1.0); };
         const double el = (double)N * C * H * W;
         GxProf pf(KID_GN_FWD, (hipStream_t)stream, 8.0 * el,
-                  4.0 * el * (src.nsplit + (src.ysum ? 1.0 : 0.0) + vw(dst0_mode) + (dst1 ? vw(dst1_mode) : 0.0)));
+                  4.0 * el * (src.nsplit + (src.ysum ? 1.0 : 0.0) + (dst0 ? vw(dst0_mode) : 0.0) +
+                              (dst1 ? vw(dst1_mode) : 0.0)));
         const RegPlan pl = plan_reg(C / groups, H, W);
         const int st = small_threads(C / groups, H, W);
         if (pl.ok)
@@ -819,26 +837,55 @@ static int gn_relu_fwd_impl(const InSrc& src, const float* gamma, const float* b
 
 size_t gx_gn_relu_bwd_ws_bytes(int N, int C) { return (size_t)N * C * 3 * sizeof(float); }
 
+static int gn_relu_bwd_impl(const float* y, const float* gamma, const float* beta, const float* mean,
+                            const float* rstd, int N, int C, int H, int W, int groups, const View& v0, const View& v1,
+                            float* dy, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
+                            gx_stream_t stream);
+
 int gx_gn_relu_bwd(const float* y, const float* gamma, const float* beta, const float* mean, const float* rstd,
                    int N, int C, int H, int W, int groups, const float* g0, int g0_ctot, int g0_c0, int g0_mode,
                    const float* g1, int g1_ctot, int g1_c0, int g1_mode, float* dy, float* dgamma, float* dbeta,
                    float* dbias, void* ws, size_t ws_bytes, gx_stream_t stream) {
-    GX_CHECK_ARG(y && gamma && beta && mean && rstd && g0 && dy && dgamma && dbeta && ws,
+    GX_CHECK_ARG(g0, "gx_gn_relu_bwd: null pointer");
+    View v0{const_cast<float*>(g0), g0_ctot, g0_c0, g0_mode, nullptr, 0},
+         v1{const_cast<float*>(g1), g1_ctot, g1_c0, g1_mode, nullptr, 0};
+    int rc = check_view("gx_gn_relu_bwd", v0, C);
+    if (rc) return rc;
+    if (g1) { rc = check_view("gx_gn_relu_bwd", v1, C); if (rc) return rc; }
+    return gn_relu_bwd_impl(y, gamma, beta, mean, rstd, N, C, H, W, groups, v0, v1, dy, dgamma, dbeta, dbias, ws,
+                            ws_bytes, stream);
+}
+
+int gx_gn_relu_bwd_proj(const float* y, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                        int N, int C, int H, int W, int groups, const float* g_out, int Cout, const float* w,
+                        float* dy, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
+                        gx_stream_t stream) {
+    GX_CHECK_ARG(g_out && w, "gx_gn_relu_bwd_proj: null pointer");
+    GX_CHECK_ARG(Cout >= 1 && Cout <= 8, "gx_gn_relu_bwd_proj: Cout must be 1..8 (got %d)", Cout);
+    GX_CHECK_ARG((W % 4) == 0 && ((uintptr_t)g_out % 16) == 0, "gx_gn_relu_bwd_proj: W %% 4 == 0 and 16-byte alignment");
+    View v0{const_cast<float*>(g_out), Cout, 0, 3, w, C}, v1{nullptr, 0, 0, 0, nullptr, 0};
+    return gn_relu_bwd_impl(y, gamma, beta, mean, rstd, N, C, H, W, groups, v0, v1, dy, dgamma, dbeta, dbias, ws,
+                            ws_bytes, stream);
+}
+
+static int gn_relu_bwd_impl(const float* y, const float* gamma, const float* beta, const float* mean,
+                            const float* rstd, int N, int C, int H, int W, int groups, const View& v0, const View& v1,
+                            float* dy, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
+                            gx_stream_t stream) {
+    const float* g1 = v1.ptr;
+    const int g0_mode = v0.mode, g1_mode = v1.mode;
+    GX_CHECK_ARG(y && gamma && beta && mean && rstd && dy && dgamma && dbeta && ws,
                  "gx_gn_relu_bwd: null pointer");
     GX_CHECK_ARG(N > 0 && C > 0 && groups > 0 && C % groups == 0,
                  "gx_gn_relu_bwd: bad N/C/groups");
     GX_CHECK_ARG(gx_is_pow2(H) && gx_is_pow2(W) && W >= 2 && H >= 2, "gx_gn_relu_bwd: H,W must be powers of two >= 2");
     GX_CHECK_ARG(ws_bytes >= gx_gn_relu_bwd_ws_bytes(N, C), "gx_gn_relu_bwd: workspace too small");
-    View v0{const_cast<float*>(g0), g0_ctot, g0_c0, g0_mode}, v1{const_cast<float*>(g1), g1_ctot, g1_c0, g1_mode};
-    int rc = check_view("gx_gn_relu_bwd", v0, C);
-    if (rc) return rc;
-    if (g1) { rc = check_view("gx_gn_relu_bwd", v1, C); if (rc) return rc; }
     const int hw = H * W;
     const bool vec = (W % 4) == 0;
     const int threads = hw >= 4096 ? 1024 : (hw >= 1024 ? 256 : 64);
     hipStream_t s = (hipStream_t)stream;
     {
-        auto vw = [](int mode) { return mode == 1 ? 4.0 : (mode == 2 ? 0.25 : 1.0); };
+        auto vw = [](int mode) { return mode == 1 ? 4.0 : (mode == 2 ? 0.25 : (mode == 3 ? 0.0 : 1.0)); };
         const double el = (double)N * C * H * W;
         GxProf pf(KID_GN_BWD, s, 16.0 * el, 4.0 * el * (2.0 + vw(g0_mode) + (g1 ? vw(g1_mode) : 0.0)));
         const RegPlan pl = plan_reg(C / groups, H, W);

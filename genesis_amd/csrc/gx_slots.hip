@@ -345,6 +345,30 @@ __global__ void row_sum_kernel(const float* __restrict__ part, int rows, int col
     out[r] = (float)s;
 }
 
+// Input of a 1x1 conv that is still the PRE-norm tensor y of a GroupNorm+ReLU layer: relu(gn(y)) is formed on load
+// (same expression as the norm kernels, gx_norm.hip) so that the normalised activation never exists in memory.
+// mean == nullptr: plain input.
+struct NormIn {
+    const float* mean;    // [N*groups]
+    const float* rstd;    // [N*groups]
+    const float* gamma;   // [C]
+    const float* beta;    // [C]
+    int groups;
+    int cpg;              // channels per group
+};
+
+__device__ __forceinline__ f32x4 norm_relu4(const NormIn& nin, f32x4 v, int n, int c) {
+    const int g = n * nin.groups + c / nin.cpg;
+    const float meanf = nin.mean[g], rstdf = nin.rstd[g], gm = nin.gamma[c], bt = nin.beta[c];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float t = (v[e] - meanf) * rstdf * gm + bt;
+        o[e] = t > 0.f ? t : 0.f;
+    }
+    return o;
+}
+
 // ------------------------------------------------------------------ small 1x1 convolutions (Cout <= 8)
 // y[n][co][p] = gate * (sum_ci w[co][ci] x[n][ci][p] + b[co]) + addend[co][p]
 constexpr int COMAX = 8;
@@ -383,7 +407,7 @@ conv1x1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, con
 __global__ void __launch_bounds__(256)
 conv1x1_fwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                        const float* __restrict__ gate, const float* __restrict__ addend, int Cin, int Cout, int HW,
-                       float* __restrict__ y) {
+                       float* __restrict__ y, const NormIn nin) {
     __shared__ __attribute__((aligned(16))) float ws[128 * COMAX];   // [ci][co], Cin <= 128
     for (int i = threadIdx.x; i < Cin * COMAX; i += blockDim.x) {
         const int ci = i / COMAX, co = i - ci * COMAX;
@@ -402,6 +426,10 @@ conv1x1_fwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ w,
         f32x4 xv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) xv[j] = *reinterpret_cast<const f32x4*>(xn + (size_t)(ci + j) * HW);
+        if (nin.mean) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xv[j] = norm_relu4(nin, xv[j], n, ci + j);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const f32x4 w0 = *reinterpret_cast<const f32x4*>(ws + (ci + j) * COMAX);
@@ -411,7 +439,8 @@ conv1x1_fwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ w,
         }
     }
     for (; ci < Cin; ++ci) {
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(xn + (size_t)ci * HW);
+        f32x4 xv = *reinterpret_cast<const f32x4*>(xn + (size_t)ci * HW);
+        if (nin.mean) xv = norm_relu4(nin, xv, n, ci);
 #pragma unroll
         for (int co = 0; co < COMAX; ++co) acc[co] += ws[ci * COMAX + co] * xv;
     }
@@ -526,10 +555,13 @@ conv1x1_wgrad_mfma_kernel(const float* __restrict__ x, const float* __restrict__
 // channels with fully coalesced 16-byte loads (one channel row segment = 1 KiB per wave instruction; the next tile is
 // prefetched into registers while the current one is consumed), and the MFMA fragments are read from LDS
 // (row stride 260 floats: the 64 lanes of a fragment read spread over all banks twice = conflict-free).
+// NORM: x is a pre-norm tensor (NormIn), normalised while it is staged; the kernel then also emits the bias
+// gradient partials pb[block][co] = sum_p dy (the plain path gets them from the data-gradient kernel).
 constexpr int C1_TP = 256, C1_LS = 260;
+template <bool NORM>
 __global__ void __launch_bounds__(256)
 conv1x1_wgrad_lds_kernel(const float* __restrict__ x, const float* __restrict__ dy, int N, int Cin, int Cout,
-                         int HW, float* __restrict__ pw) {
+                         int HW, float* __restrict__ pw, const NormIn nin, float* __restrict__ pb) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* xs = sm;                       // [64][C1_LS]
     float* ds = sm + 64 * C1_LS;          // [8][C1_LS]
@@ -542,14 +574,17 @@ conv1x1_wgrad_lds_kernel(const float* __restrict__ x, const float* __restrict__ 
 #pragma unroll
     for (int t = 0; t < 4; ++t) { acc[t][0] = 0.f; acc[t][1] = 0.f; acc[t][2] = 0.f; acc[t][3] = 0.f; }
     f32x4 xr[16], dr[2];
+    f32x4 dbs[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #define C1_LOAD(tile_)                                                                              \
     {                                                                                               \
         const int n_ = (tile_) / tiles_per_img;                                                     \
         const int p0_ = ((tile_) - n_ * tiles_per_img) * C1_TP + 4 * lane;                          \
         _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                            \
             const int ch = wave + 4 * i;                                                            \
-            if (ch < Cin) xr[i] = *reinterpret_cast<const f32x4*>(x + ((size_t)n_ * Cin + ch) * HW + p0_); \
-            else { xr[i][0] = 0.f; xr[i][1] = 0.f; xr[i][2] = 0.f; xr[i][3] = 0.f; }                \
+            if (ch < Cin) {                                                                         \
+                xr[i] = *reinterpret_cast<const f32x4*>(x + ((size_t)n_ * Cin + ch) * HW + p0_);    \
+                if (NORM) xr[i] = norm_relu4(nin, xr[i], n_, ch);                                   \
+            } else { xr[i][0] = 0.f; xr[i][1] = 0.f; xr[i][2] = 0.f; xr[i][3] = 0.f; }              \
         }                                                                                           \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                             \
             const int co = wave + 4 * i;                                                            \
@@ -564,7 +599,10 @@ conv1x1_wgrad_lds_kernel(const float* __restrict__ x, const float* __restrict__ 
 #pragma unroll
         for (int i = 0; i < 16; ++i) *reinterpret_cast<f32x4*>(xs + (wave + 4 * i) * C1_LS + 4 * lane) = xr[i];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(ds + (wave + 4 * i) * C1_LS + 4 * lane) = dr[i];
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<f32x4*>(ds + (wave + 4 * i) * C1_LS + 4 * lane) = dr[i];
+            if (NORM) dbs[i] += dr[i];
+        }
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) C1_LOAD(tile + gridDim.x)
         const float* ap = ds + (idx & 7) * C1_LS + 64 * wave + kq;
@@ -579,6 +617,16 @@ conv1x1_wgrad_lds_kernel(const float* __restrict__ x, const float* __restrict__ 
         }
     }
 #undef C1_LOAD
+    if (NORM) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int co = wave + 4 * i;
+            float v = (dbs[i][0] + dbs[i][1]) + (dbs[i][2] + dbs[i][3]);
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0 && co < Cout) pb[(size_t)blockIdx.x * Cout + co] = v;
+        }
+    }
     __syncthreads();
     // C/D layout (16x16): col = lane & 15 (ci), row = (lane >> 4) * 4 + reg (co)
 #pragma unroll
@@ -616,18 +664,22 @@ conv1x1_finalize_kernel(const float* __restrict__ raw, const float* __restrict__
     if (threadIdx.x == 0 && dgate) *dgate = (float)s;
 }
 
-// out[i] = scale * sum_blk part[blk][i]; one block per output element, fixed reduction tree
+// the two partial-sum tables of the 1x1-conv backward (weight pairs, bias) in one launch: blocks [0, n0) reduce
+// part0 into out0, blocks [n0, n0 + n1) reduce part1 into out1
 __global__ void __launch_bounds__(256)
-col_sum_kernel(const float* __restrict__ part, int nblk, int n, const float* __restrict__ gate,
-               float* __restrict__ out) {
+col_sum2_kernel(const float* __restrict__ part0, int nblk0, int n0, float* __restrict__ out0,
+                const float* __restrict__ part1, int nblk1, int n1, float* __restrict__ out1) {
     __shared__ double red[4];
-    const int i = blockIdx.x;
+    const bool first = (int)blockIdx.x < n0;
+    const int i = first ? blockIdx.x : blockIdx.x - n0;
+    const float* part = first ? part0 : part1;
+    const int nblk = first ? nblk0 : nblk1, n = first ? n0 : n1;
     double s = 0.0;
     for (int b = threadIdx.x; b < nblk; b += blockDim.x) s += part[(size_t)b * n + i];
     s = block_sum_dd(s, red);
     if (threadIdx.x == 0) {
-        const float gt = gate ? *gate : 1.f;
-        out[i] = (float)(s * (double)gt);
+        float* out = first ? out0 : out1;
+        if (out) out[i] = (float)s;
     }
 }
 
@@ -751,7 +803,8 @@ int gx_conv1x1_fwd(const float* x, const float* w, const float* bias, const floa
                          (!addend || ((uintptr_t)addend % 16) == 0);
         if (vec)
             hipLaunchKernelGGL(conv1x1_fwd_vec_kernel, dim3(N, gx_ceil_div(HW, 1024)), dim3(256), 0,
-                               (hipStream_t)stream, x, w, bias, gate, addend, Cin, Cout, HW, y);
+                               (hipStream_t)stream, x, w, bias, gate, addend, Cin, Cout, HW, y,
+                               NormIn{nullptr, nullptr, nullptr, nullptr, 1, 1});
         else
             hipLaunchKernelGGL(conv1x1_fwd_kernel, dim3(N, gx_ceil_div(HW, 256)), dim3(256), 0, (hipStream_t)stream, x,
                                w, bias, gate, addend, Cin, Cout, HW, y);
@@ -803,11 +856,12 @@ int gx_conv1x1_bwd(const float* x, const float* dy, const float* w, const float*
             static bool attr_set = false;
             const size_t lds = (size_t)(64 + 8) * C1_LS * sizeof(float);
             if (!attr_set) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_wgrad_lds_kernel),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_wgrad_lds_kernel<false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 attr_set = true;
             }
-            hipLaunchKernelGGL(conv1x1_wgrad_lds_kernel, dim3(nblkw), dim3(256), lds, s, x, dy, N, Cin, Cout, HW, pw);
+            hipLaunchKernelGGL(conv1x1_wgrad_lds_kernel<false>, dim3(nblkw), dim3(256), lds, s, x, dy, N, Cin, Cout,
+                               HW, pw, NormIn{nullptr, nullptr, nullptr, nullptr, 1, 1}, (float*)nullptr);
         } else if (Cin <= 64)
             hipLaunchKernelGGL(conv1x1_wgrad_mfma_kernel<4>, dim3(nblkw), dim3(256), 0, s, x, dy, N, Cin, Cout, HW, pw);
         else
@@ -816,14 +870,78 @@ int gx_conv1x1_bwd(const float* x, const float* dy, const float* w, const float*
     GX_CHECK_LAUNCH("gx_conv1x1_bwd(wgrad)");
     {
         GxProf pf(KID_SMALL_REDUCE, s, 0.0, 4.0 * ((double)nblkw * npairs + (double)nblkd * Cout));
-        hipLaunchKernelGGL(col_sum_kernel, dim3(npairs), dim3(256), 0, s, (const float*)pw, nblkw, npairs,
-                           (const float*)nullptr, raw);
-        hipLaunchKernelGGL(col_sum_kernel, dim3(Cout), dim3(256), 0, s, (const float*)pb, nblkd, Cout,
-                           (const float*)nullptr, raw + npairs);
-        hipLaunchKernelGGL(conv1x1_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)raw, w, bias, gate, Cin,
-                           Cout, dw, db, dgate);
+        if (!gate) {   // no gate: the column sums ARE dw and db
+            hipLaunchKernelGGL(col_sum2_kernel, dim3(npairs + Cout), dim3(256), 0, s, (const float*)pw, nblkw, npairs,
+                               dw, (const float*)pb, nblkd, Cout, db);
+        } else {       // dgate = <raw dw, w> + <raw db, bias> needs all sums: second launch
+            hipLaunchKernelGGL(col_sum2_kernel, dim3(npairs + Cout), dim3(256), 0, s, (const float*)pw, nblkw, npairs,
+                               raw, (const float*)pb, nblkd, Cout, raw + npairs);
+            hipLaunchKernelGGL(conv1x1_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)raw, w, bias, gate,
+                               Cin, Cout, dw, db, dgate);
+        }
     }
     GX_CHECK_LAUNCH("gx_conv1x1_bwd(finalize)");
+    return GX_OK;
+}
+
+// ---- 1x1 conv on a GroupNorm+ReLU layer that is never materialised (decoder_module.12-13)
+int gx_conv1x1_gn_fwd(const float* y_pre, const float* mean, const float* rstd, const float* gamma,
+                      const float* beta, int groups, const float* w, const float* bias, int N, int Cin, int Cout,
+                      int H, int W, float* out, gx_stream_t stream) {
+    GX_CHECK_ARG(y_pre && mean && rstd && gamma && beta && w && out, "gx_conv1x1_gn_fwd: null pointer");
+    GX_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && Cout <= COMAX && Cin <= 128 && groups > 0 && Cin % groups == 0,
+                 "gx_conv1x1_gn_fwd: Cout <= 8, Cin <= 128, Cin %% groups == 0");
+    const int HW = H * W;
+    GX_CHECK_ARG((HW % 4) == 0 && ((uintptr_t)y_pre % 16) == 0 && ((uintptr_t)out % 16) == 0,
+                 "gx_conv1x1_gn_fwd: H*W %% 4 == 0 and 16-byte aligned tensors");
+    {
+        GxProf pf(KID_CONV1X1_FWD, (hipStream_t)stream, 2.0 * N * Cin * Cout * HW, 4.0 * N * HW * (Cin + Cout));
+        hipLaunchKernelGGL(conv1x1_fwd_vec_kernel, dim3(N, gx_ceil_div(HW, 1024)), dim3(256), 0, (hipStream_t)stream,
+                           y_pre, w, bias, (const float*)nullptr, (const float*)nullptr, Cin, Cout, HW, out,
+                           NormIn{mean, rstd, gamma, beta, groups, Cin / groups});
+    }
+    GX_CHECK_LAUNCH("gx_conv1x1_gn_fwd");
+    return GX_OK;
+}
+
+size_t gx_conv1x1_gn_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W) {
+    const size_t nblkw = conv1x1_wgrad_blocks(N, H * W);
+    return nblkw * ((size_t)Cout * Cin + Cout) * sizeof(float);
+}
+
+int gx_conv1x1_gn_wgrad(const float* y_pre, const float* mean, const float* rstd, const float* gamma,
+                        const float* beta, int groups, const float* g_out, int N, int Cin, int Cout, int H, int W,
+                        float* dw, float* db, void* ws, size_t ws_bytes, gx_stream_t stream) {
+    GX_CHECK_ARG(y_pre && mean && rstd && gamma && beta && g_out && dw && ws, "gx_conv1x1_gn_wgrad: null pointer");
+    GX_CHECK_ARG(N > 0 && Cin > 0 && Cin <= 64 && Cout > 0 && Cout <= COMAX && groups > 0 && Cin % groups == 0,
+                 "gx_conv1x1_gn_wgrad: Cout <= 8, Cin <= 64, Cin %% groups == 0");
+    const int HW = H * W;
+    GX_CHECK_ARG(HW % C1_TP == 0, "gx_conv1x1_gn_wgrad: H*W must be a multiple of 256");
+    GX_CHECK_ARG(ws_bytes >= gx_conv1x1_gn_wgrad_ws_bytes(N, Cin, Cout, H, W), "gx_conv1x1_gn_wgrad: workspace too small");
+    const int nblkw = conv1x1_wgrad_blocks(N, HW);
+    const int npairs = Cout * Cin;
+    float* pw = (float*)ws;
+    float* pb = pw + (size_t)nblkw * npairs;
+    hipStream_t s = (hipStream_t)stream;
+    {
+        GxProf pf(KID_CONV1X1_WGRAD, s, 2.0 * N * Cin * Cout * HW, 4.0 * N * HW * (Cin + Cout));
+        static bool attr_set = false;
+        const size_t lds = (size_t)(64 + 8) * C1_LS * sizeof(float);
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_wgrad_lds_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(conv1x1_wgrad_lds_kernel<true>, dim3(nblkw), dim3(256), lds, s, y_pre, g_out, N, Cin, Cout,
+                           HW, pw, NormIn{mean, rstd, gamma, beta, groups, Cin / groups}, pb);
+    }
+    GX_CHECK_LAUNCH("gx_conv1x1_gn_wgrad");
+    {
+        GxProf pf(KID_SMALL_REDUCE, s, 0.0, 4.0 * (double)nblkw * (npairs + Cout));
+        hipLaunchKernelGGL(col_sum2_kernel, dim3(npairs + Cout), dim3(256), 0, s, (const float*)pw, nblkw, npairs, dw,
+                           (const float*)pb, nblkw, Cout, db);
+    }
+    GX_CHECK_LAUNCH("gx_conv1x1_gn_wgrad(reduce)");
     return GX_OK;
 }
 

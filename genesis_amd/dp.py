@@ -33,9 +33,13 @@ class FlatBucket(object):
         self.n64 = sum(p.numel() for p in self.p64)
         self.n_tail = n_tail
         self.flat_p = torch.zeros(self.n32, dtype=torch.float32, device=dev)
-        self.flat_g = torch.zeros(self.n32 + n_tail, dtype=torch.float32, device=dev)
         self.flat_p64 = torch.zeros(max(self.n64, 1), dtype=torch.float64, device=dev)
-        self.flat_g64 = torch.zeros(max(self.n64, 1), dtype=torch.float64, device=dev)
+        # both gradient buffers are views of ONE allocation: zero_grad() is a single fill
+        nb32 = 4 * (self.n32 + n_tail)
+        off64 = (nb32 + 63) // 64 * 64
+        self._graw = torch.zeros(off64 + 8 * max(self.n64, 1), dtype=torch.uint8, device=dev)
+        self.flat_g = self._graw[:nb32].view(torch.float32)
+        self.flat_g64 = self._graw[off64:].view(torch.float64)
         for plist, fp, fg, padded in ((self.p32, self.flat_p, self.flat_g, True),
                                       (self.p64, self.flat_p64, self.flat_g64, False)):
             off = 0
@@ -51,9 +55,7 @@ class FlatBucket(object):
         return (n + self.align - 1) // self.align * self.align
 
     def zero_grad(self):
-        self.flat_g.zero_()
-        if self.n64:
-            self.flat_g64.zero_()
+        self._graw.zero_()
 
     def set_tail(self, *scalars):
         for i, s in enumerate(scalars):

@@ -324,6 +324,10 @@ class MaskPoolFn(torch.autograd.Function):
         return df, dlog_m
 
 
+# last decoder stage without its normalised activation in memory (GENESIS_FUSE_DEC_HEAD=0: the unfused kernels)
+FUSE_DECODER_HEAD = __import__('os').environ.get('GENESIS_FUSE_DEC_HEAD', '1') == '1'
+
+
 class DecoderFn(torch.autograd.Function):
     """args: z [K*B, D], coords [1,2,d,d], then 4 x (deconv w, deconv b, gn gamma, gn beta), out w, out b."""
 
@@ -333,14 +337,27 @@ class DecoderFn(torch.autograd.Function):
         d = coords.shape[-1]
         h = torch.cat((z.view(N, D, 1, 1).expand(-1, -1, d, d), coords.expand(N, -1, -1, -1)), 1).contiguous()
         saved = []
+        ow, ob = params[16], params[17]
+        ow2 = ow.detach().view(ow.shape[0], -1)
+        # last stage: the normalised 64-channel full-resolution activation (the largest tensor of the model) is never
+        # written -- the output conv normalises the pre-norm tensor on load, forward and backward
+        Cl, Sl = params[12].shape[1], 16 * h.shape[2]
+        ctx.fused_head = FUSE_DECODER_HEAD and Cl <= 64 and Cl % GROUPS == 0 and (Sl * Sl) % 256 == 0 \
+            and ow.shape[0] <= 8
         for l in range(4):
             w, b, gamma, beta = params[4 * l:4 * l + 4]
+            if l == 3 and ctx.fused_head:
+                y, mean, rstd = hip.deconv5x5s2_gn_relu_fwd(h, w, b, gamma, beta, GROUPS, EPS, None)
+                saved.append((h, y, mean, rstd))
+                out = hip.conv1x1_gn_fwd(y, mean, rstd, gamma, beta, GROUPS, ow2, ob)
+                h = None
+                break
             a = torch.empty(N, w.shape[1], 2 * h.shape[2], 2 * h.shape[3], device=h.device)
             y, mean, rstd = hip.deconv5x5s2_gn_relu_fwd(h, w, b, gamma, beta, GROUPS, EPS, (a, 0, 0))
             saved.append((h, y, mean, rstd))
             h = a
-        ow, ob = params[16], params[17]
-        out = hip.conv1x1_fwd(h, ow.detach().view(ow.shape[0], -1), ob)
+        if not ctx.fused_head:
+            out = hip.conv1x1_fwd(h, ow2, ob)
         ctx.saved = saved
         ctx.last = h
         ctx.params = params
@@ -352,16 +369,26 @@ class DecoderFn(torch.autograd.Function):
         params = ctx.params
         ow, ob = params[16], params[17]
         gow, gob = _gout(ow), _gout(ob)
-        da, dow, dob, _ = hip.conv1x1_bwd(ctx.last, g.contiguous(), ow.detach().view(ow.shape[0], -1), ob,
-                                          out=(gow, gob, None))
+        ow2 = ow.detach().view(ow.shape[0], -1)
+        g = g.contiguous()
+        if ctx.fused_head:
+            _, y3, mean3, rstd3 = ctx.saved[3]
+            dow, dob = hip.conv1x1_gn_wgrad(y3, mean3, rstd3, params[14], params[15], GROUPS, g, out=(gow, gob))
+            da = None
+        else:
+            da, dow, dob, _ = hip.conv1x1_bwd(ctx.last, g, ow2, ob, out=(gow, gob, None))
         grads = [None] * 18
         grads[16], grads[17] = _ret(gow, dow.view(ow.shape)), _ret(gob, dob)
         for l in reversed(range(4)):
             w, b, gamma, beta = params[4 * l:4 * l + 4]
             h, y, mean, rstd = ctx.saved[l]
             ow, obias, og, ob = _gout(w), _gout(b), _gout(gamma), _gout(beta)
-            dy, dgamma, dbeta, dbias = hip.gn_relu_bwd(y, gamma, beta, mean, rstd, GROUPS, (da, 0, 0), None, True,
-                                                       out=(og, ob, obias))
+            if l == 3 and ctx.fused_head:
+                dy, dgamma, dbeta, dbias = hip.gn_relu_bwd_proj(y, gamma, beta, mean, rstd, GROUPS, g, ow2, True,
+                                                                out=(og, ob, obias))
+            else:
+                dy, dgamma, dbeta, dbias = hip.gn_relu_bwd(y, gamma, beta, mean, rstd, GROUPS, (da, 0, 0), None, True,
+                                                           out=(og, ob, obias))
             dw = _wgrad(lambda h=h, dy=dy, ow=ow: hip.deconv5x5s2_wgrad(h, dy, out=ow), ow, h, dy)
             # the first layer's input is the broadcast latent + 2 coordinate channels: only the D latent
             # channels need a gradient

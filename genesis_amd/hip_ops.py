@@ -166,6 +166,7 @@ def _view_args(v, name):
 
 
 def gn_relu_fwd(y, gamma, beta, groups, eps, dst0, dst1=None):
+    """dst0 None: group statistics only (the consumer normalises on load, conv1x1_gn_fwd)."""
     _chk(y, 'gn.y'); _chk(gamma, 'gn.gamma'); _chk(beta, 'gn.beta')
     N, C, H, W = y.shape
     mean = torch.empty(N * groups, dtype=F32, device=y.device)
@@ -614,3 +615,54 @@ def lstm_step_bwd(g_h, dgates_next, w_hh, act, c, c_prev, dc_next, dgates, dc_pr
         _chk(t, 'lstm_step_bwd.' + n)
     _lib.call('gx_lstm_step_bwd', _p(g_h), _p(dgates_next), _p(w_hh), _p(act), _p(c), _p(c_prev), _p(dc_next), B,
               H4 // 4, _p(dgates), _p(dc_prev), _stream())
+
+
+# ------------------------------------------------------------------ 1x1 conv on a never-materialised GroupNorm+ReLU
+def conv1x1_gn_fwd(y_pre, mean, rstd, gamma, beta, groups, w, bias):
+    """conv1x1(relu(gn(y_pre))): the normalised activation is formed on load."""
+    _chk(y_pre, 'conv1x1_gn.y'); _chk(mean, 'conv1x1_gn.mean'); _chk(rstd, 'conv1x1_gn.rstd')
+    _chk(gamma, 'conv1x1_gn.gamma'); _chk(beta, 'conv1x1_gn.beta'); _chk(w, 'conv1x1_gn.w'); _chk(bias, 'conv1x1_gn.bias')
+    N, Cin, H, W = y_pre.shape
+    Cout = w.shape[0]
+    out = torch.empty(N, Cout, H, W, dtype=F32, device=y_pre.device)
+    _lib.call('gx_conv1x1_gn_fwd', _p(y_pre), _p(mean), _p(rstd), _p(gamma), _p(beta), groups, _p(w), _p(bias), N, Cin,
+              Cout, H, W, _p(out), _stream())
+    return out
+
+
+def conv1x1_gn_wgrad(y_pre, mean, rstd, gamma, beta, groups, g_out, out=None):
+    """(dw [Cout,Cin], db [Cout]) of conv1x1(relu(gn(y_pre))); out = (dw, db) destinations or None."""
+    _chk(y_pre, 'conv1x1_gn_wgrad.y'); _chk(g_out, 'conv1x1_gn_wgrad.g')
+    N, Cin, H, W = y_pre.shape
+    Cout = g_out.shape[1]
+    o = out or (None, None)
+    dw = o[0] if o[0] is not None else torch.empty(Cout, Cin, dtype=F32, device=y_pre.device)
+    db = o[1] if o[1] is not None else torch.empty(Cout, dtype=F32, device=y_pre.device)
+    _chk(dw, 'conv1x1_gn_wgrad.dw'); _chk(db, 'conv1x1_gn_wgrad.db')
+    assert dw.numel() == Cout * Cin and db.numel() == Cout
+    nb = _lib.query('gx_conv1x1_gn_wgrad_ws_bytes', N, Cin, Cout, H, W)
+    ws = _ws(nb, y_pre.device)
+    _lib.call('gx_conv1x1_gn_wgrad', _p(y_pre), _p(mean), _p(rstd), _p(gamma), _p(beta), groups, _p(g_out), N, Cin,
+              Cout, H, W, _p(dw), _p(db), _p(ws), nb, _stream())
+    return dw, db
+
+
+def gn_relu_bwd_proj(y, gamma, beta, mean, rstd, groups, g_out, w, want_dbias=False, out=None):
+    """gn_relu_bwd whose incoming gradient is the data gradient of a following 1x1 conv (weight w [Cout,C], output
+    gradient g_out [N,Cout,H,W]), formed on load."""
+    _chk(y, 'gn_bwd_proj.y'); _chk(g_out, 'gn_bwd_proj.g'); _chk(w, 'gn_bwd_proj.w')
+    N, C, H, W = y.shape
+    dy = torch.empty_like(y)
+    o = out or (None, None, None)
+    dgamma = o[0] if o[0] is not None else torch.empty(C, dtype=F32, device=y.device)
+    dbeta = o[1] if o[1] is not None else torch.empty(C, dtype=F32, device=y.device)
+    dbias = (o[2] if o[2] is not None else torch.empty(C, dtype=F32, device=y.device)) if want_dbias else None
+    nb = _lib.query('gx_gn_relu_bwd_ws_bytes', N, C)
+    ws = _ws(nb, y.device)
+    direct = o[0] is not None and o[1] is not None and (not want_dbias or o[2] is not None)
+    with _deferring(direct, ws):
+        _lib.call('gx_gn_relu_bwd_proj', _p(y), _p(gamma), _p(beta), _p(mean), _p(rstd), N, C, H, W, groups,
+                  _p(g_out), int(g_out.shape[1]), _p(w), _p(dy), _p(dgamma), _p(dbeta), _p(dbias), _p(ws), nb,
+                  _stream())
+    return dy, dgamma, dbeta, dbias
+

@@ -63,7 +63,11 @@ int gx_deconv5x5s2_wgrad(const float* x, const float* dy, float* dw, int N, int 
  *      mode 0 same size, 1 buffer is 2x up-sampled (nearest), 2 buffer is 2x down-sampled ([::2, ::2]).
  *      fwd writes relu(gn(y)) to dst0 (and dst1 if non-NULL), and mean/rstd [N*groups].
  *      bwd reads d(out) from g0 (+ g1 if non-NULL), writes dy [N,C,H,W], dgamma/dbeta [C] and, if
- *      dbias != NULL, sum_{n,hw} dy (the gradient of a per-channel bias added before the norm). */
+ *      dbias != NULL, sum_{n,hw} dy (the gradient of a per-channel bias added before the norm).
+ *      fwd with dst0 == NULL computes the statistics only: the consumer (gx_conv1x1_gn_fwd) normalises on load.
+ *      gx_gn_relu_bwd_proj is the matching backward: d(out) is not read from memory but formed on load as the data
+ *      gradient of the following 1x1 conv, sum_o w[o][c] g_out[n][o][h][w] (g_out [N,Cout,H,W], w [Cout,C], Cout <= 8):
+ *      the [N,C,H,W] activation and its gradient never exist in memory (genesisv2_config.py:97-98, last decoder stage). */
 int gx_gn_relu_fwd(const float* y, const float* gamma, const float* beta, int N, int C, int H, int W, int groups,
                    float eps, float* dst0, int dst0_ctot, int dst0_c0, int dst0_mode, float* dst1, int dst1_ctot,
                    int dst1_c0, int dst1_mode, float* mean, float* rstd, gx_stream_t stream);
@@ -72,6 +76,10 @@ int gx_gn_relu_bwd(const float* y, const float* gamma, const float* beta, const 
                    int N, int C, int H, int W, int groups, const float* g0, int g0_ctot, int g0_c0, int g0_mode,
                    const float* g1, int g1_ctot, int g1_c0, int g1_mode, float* dy, float* dgamma, float* dbeta,
                    float* dbias, void* ws, size_t ws_bytes, gx_stream_t stream);
+int gx_gn_relu_bwd_proj(const float* y, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                        int N, int C, int H, int W, int groups, const float* g_out, int Cout, const float* w,
+                        float* dy, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
+                        gx_stream_t stream);
 
 /* ---- Instance-Colouring stick-breaking attention: modules/attention.py:162-226.
  *      colour [B,C<=8,H,W]; log_sigma: device pointer to the fp64 0-dim parameter; rand_pixel [B,1,H,W];
@@ -117,6 +125,16 @@ size_t gx_conv1x1_bwd_ws_bytes(int N, int Cin, int Cout, int H, int W);
 int gx_conv1x1_bwd(const float* x, const float* dy, const float* w, const float* bias, const float* gate, int N,
                    int Cin, int Cout, int H, int W, float* dx, float* dw, float* db, float* dgate, void* ws,
                    size_t ws_bytes, gx_stream_t stream);
+/*      The same 1x1 conv reading the PRE-norm tensor y of the GroupNorm+ReLU layer in front of it (statistics from
+ *      gx_gn_relu_fwd with dst0 == NULL): relu(gn(y)) is formed on load, forward and in the weight gradient; the data
+ *      gradient is folded into gx_gn_relu_bwd_proj.  Cin <= 64 (wgrad), H*W % 256 == 0. */
+int gx_conv1x1_gn_fwd(const float* y_pre, const float* mean, const float* rstd, const float* gamma,
+                      const float* beta, int groups, const float* w, const float* bias, int N, int Cin, int Cout,
+                      int H, int W, float* out, gx_stream_t stream);
+size_t gx_conv1x1_gn_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W);
+int gx_conv1x1_gn_wgrad(const float* y_pre, const float* mean, const float* rstd, const float* gamma,
+                        const float* beta, int groups, const float* g_out, int N, int Cin, int Cout, int H, int W,
+                        float* dw, float* db, void* ws, size_t ws_bytes, gx_stream_t stream);
 
 /* ---- optimiser side of the training step.
  *      gx_adam_step: torch.optim.Adam update (train.py:174-175,263) on flat buffers p/g/m/v of n elements

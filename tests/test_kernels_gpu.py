@@ -592,3 +592,32 @@ def test_groupnorm_sums_splitk_partials_bitwise(kind, N, Cin, Cout, S, monkeypat
         outs.append((y.clone(), mean.clone(), rstd.clone(), d.clone()))
     for a, b_ in zip(*outs):
         assert torch.equal(a, b_)
+
+
+@pytest.mark.parametrize('N,C,Cout,S,groups', [(3, 64, 4, 64, 8), (2, 32, 4, 16, 8), (5, 64, 8, 32, 8), (2, 16, 3, 16, 8)])
+def test_conv1x1_on_unmaterialised_groupnorm(N, C, Cout, S, groups):
+    """Last decoder stage (genesisv2_config.py:97-99): GroupNorm statistics only, the 1x1 conv normalises on load, its
+    data gradient is folded into the norm backward -- against the three separate torch ops."""
+    y = rnd(N, C, S, S, seed=31, scale=2.0) + 0.2
+    gamma = 1 + 0.3 * rnd(C, seed=32)
+    beta = 0.2 * rnd(C, seed=33)
+    w = rnd(Cout, C, seed=34, scale=0.3)
+    b = rnd(Cout, seed=35, scale=0.1)
+    g = rnd(N, Cout, S, S, seed=36)
+    yr, gr, br, wr, bbr = [t.clone().requires_grad_() for t in (y, gamma, beta, w, b)]
+    ref = F.conv2d(F.relu(F.group_norm(yr, groups, gr, br, 1e-5)), wr.view(Cout, C, 1, 1), bbr)
+    ref.backward(g)
+    yd, gd, bd, wd, bbd, gg = [t.to(DEV) for t in (y, gamma, beta, w, b, g)]
+    mean, rstd = hip.gn_relu_fwd(yd, gd, bd, groups, 1e-5, None)            # statistics only
+    full_mean, full_rstd = hip.gn_relu_fwd(yd, gd, bd, groups, 1e-5, (torch.empty_like(yd), 0, 0))
+    assert torch.equal(mean, full_mean) and torch.equal(rstd, full_rstd)
+    out = hip.conv1x1_gn_fwd(yd, mean, rstd, gd, bd, groups, wd, bbd)
+    close(out, ref, 1e-5, 1e-5, 'fwd')
+    dw, db = hip.conv1x1_gn_wgrad(yd, mean, rstd, gd, bd, groups, gg)
+    close(dw, wr.grad, 1e-4, 1e-4, 'dw')
+    close(db, bbr.grad, 1e-4, 1e-4, 'db')
+    dy, dgamma, dbeta, dbias = hip.gn_relu_bwd_proj(yd, gd, bd, mean, rstd, groups, gg, wd, True)
+    close(dy, yr.grad, 1e-4, 1e-5, 'dy')
+    close(dgamma, gr.grad, 1e-4, 1e-4, 'dgamma')
+    close(dbeta, br.grad, 1e-4, 1e-4, 'dbeta')
+    close(dbias, yr.grad.sum((0, 2, 3)), 1e-4, 1e-4, 'dbias')
