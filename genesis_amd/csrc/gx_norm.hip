@@ -468,7 +468,16 @@ gn_relu_fwd_reg_kernel(const InSrc src, const float* __restrict__ gamma, const f
     }
 }
 
-template <int F, int UPW>
+// sum_q pw[q] * gs[q][i4] from the staged [ctot][HW] output gradient of the following 1x1 conv
+__device__ __forceinline__ f32x4 staged_grad(const float* gsl, const float (&pw)[8], int ctot, int HW, int i4) {
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+        if (q < ctot) g += pw[q] * reinterpret_cast<const f32x4*>(gsl)[q * (HW >> 2) + i4];
+    return g;
+}
+
+template <int F, int UPW, bool STAGE>
 __global__ void __launch_bounds__(1024)
 gn_relu_bwd_reg_kernel(const float* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ beta,
                        const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
@@ -476,6 +485,7 @@ gn_relu_bwd_reg_kernel(const float* __restrict__ y, const float* __restrict__ ga
                        float* __restrict__ dy, float* __restrict__ part_out) {
     __shared__ double uab[32 * 2];  // per unit: sum dpre*xhat, sum dpre
     __shared__ double usd[32];      // per unit: sum dy
+    extern __shared__ __attribute__((aligned(16))) float gsl[];   // stage != 0: g0.ptr[n] ([ctot][HW]) of a mode-3 view
     const int n = blockIdx.x / groups, gidx = blockIdx.x % groups;
     const int cpg = C / groups, HW = H * W;
     const int m = cpg * HW;
@@ -488,20 +498,50 @@ gn_relu_bwd_reg_kernel(const float* __restrict__ y, const float* __restrict__ ga
     const float meanf = mean_in[blockIdx.x], rstdf = rstd_in[blockIdx.x];
     const int lW = __ffs(W) - 1;
     f32x4 xr[UPW][F], gr[UPW][F];
+    if (STAGE) {
+        // the 1x1 conv's output gradient of this image is shared by all channels of the group: once through LDS
+        // instead of cpg times through the caches (the y loads are issued first and fly meanwhile)
 #pragma unroll
-    for (int u = 0; u < UPW; ++u) {
-        const int unit = wave * UPW + u;
-        const int cl = unit / P, part = unit - cl * P;
-        const int c = gidx * cpg + cl;
+        for (int u = 0; u < UPW; ++u) {
+            const int unit = wave * UPW + u;
+            const int cl = unit / P, part = unit - cl * P;
 #pragma unroll
-        for (int j = 0; j < F; ++j) {
-            const int i4 = part * q4 + j * 64 + lane;
-            const int hw = i4 << 2;
-            const int r = hw >> lW, col = hw & (W - 1);
-            xr[u][j] = slab4[cl * (HW >> 2) + i4];
-            f32x4 g = load_view4(g0, n, c, r, col, H, W);
-            if (g1.ptr) { const f32x4 g2 = load_view4(g1, n, c, r, col, H, W); g += g2; }
-            gr[u][j] = g;
+            for (int j = 0; j < F; ++j) xr[u][j] = slab4[cl * (HW >> 2) + part * q4 + j * 64 + lane];
+        }
+        const f32x4* src4 = reinterpret_cast<const f32x4*>(g0.ptr + (size_t)n * g0.ctot * HW);
+        for (int i = threadIdx.x; i < (g0.ctot * HW) >> 2; i += blockDim.x)
+            reinterpret_cast<f32x4*>(gsl)[i] = src4[i];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < UPW; ++u) {
+            const int unit = wave * UPW + u;
+            const int cl = unit / P, part = unit - cl * P;
+            const int c = gidx * cpg + cl;
+            float pw[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)    // wave-uniform (c depends on the wave only): keep them in scalar registers
+                pw[q] = q < g0.ctot ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(
+                                          int, g0.proj[q * g0.projC + c])))
+                                    : 0.f;
+#pragma unroll
+            for (int j = 0; j < F; ++j) gr[u][j] = staged_grad(gsl, pw, g0.ctot, HW, part * q4 + j * 64 + lane);
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < UPW; ++u) {
+            const int unit = wave * UPW + u;
+            const int cl = unit / P, part = unit - cl * P;
+            const int c = gidx * cpg + cl;
+#pragma unroll
+            for (int j = 0; j < F; ++j) {
+                const int i4 = part * q4 + j * 64 + lane;
+                const int hw = i4 << 2;
+                const int r = hw >> lW, col = hw & (W - 1);
+                xr[u][j] = slab4[cl * (HW >> 2) + i4];
+                f32x4 g = load_view4(g0, n, c, r, col, H, W);
+                if (g1.ptr) { const f32x4 g2 = load_view4(g1, n, c, r, col, H, W); g += g2; }
+                gr[u][j] = g;
+            }
         }
     }
     // pass 1 (registers): xr <- xhat, gr <- dpre = g * [pre > 0]
@@ -703,8 +743,18 @@ void launch_fwd_reg(dim3 grid, dim3 block, hipStream_t s, Args... args) {
     hipLaunchKernelGGL((gn_relu_fwd_reg_kernel<F, UPW>), grid, block, 0, s, args...);
 }
 template <int F, int UPW, typename... Args>
-void launch_bwd_reg(dim3 grid, dim3 block, hipStream_t s, Args... args) {
-    hipLaunchKernelGGL((gn_relu_bwd_reg_kernel<F, UPW>), grid, block, 0, s, args...);
+void launch_bwd_reg(dim3 grid, dim3 block, hipStream_t s, size_t lds, Args... args) {
+    if (!lds) {
+        hipLaunchKernelGGL((gn_relu_bwd_reg_kernel<F, UPW, false>), grid, block, 0, s, args...);
+        return;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_relu_bwd_reg_kernel<F, UPW, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gn_relu_bwd_reg_kernel<F, UPW, true>), grid, block, lds, s, args...);
 }
 
 #define GX_GN_REG_DISPATCH(LAUNCH, pl, ...)                                      \
@@ -890,9 +940,12 @@ static int gn_relu_bwd_impl(const float* y, const float* gamma, const float* bet
         GxProf pf(KID_GN_BWD, s, 16.0 * el, 4.0 * el * (2.0 + vw(g0_mode) + (g1 ? vw(g1_mode) : 0.0)));
         const RegPlan pl = plan_reg(C / groups, H, W);
         const int st = small_threads(C / groups, H, W);
-        if (pl.ok)
-            GX_GN_REG_DISPATCH(launch_bwd_reg, pl, dim3(N * groups), dim3(pl.threads), s, y, gamma, beta, mean, rstd,
-                               C, H, W, groups, pl.P, v0, v1, dy, (float*)ws);
+        if (pl.ok) {
+            // projected-gradient source: stage the image's [Cout][H*W] output gradient in LDS when it fits
+            const size_t stage = (v0.mode == 3 && (size_t)v0.ctot * hw * 4 <= 128 * 1024) ? (size_t)v0.ctot * hw * 4 : 0;
+            GX_GN_REG_DISPATCH(launch_bwd_reg, pl, dim3(N * groups), dim3(pl.threads), s, stage, y, gamma, beta, mean,
+                               rstd, C, H, W, groups, pl.P, v0, v1, dy, (float*)ws);
+        }
         else if (st)
             hipLaunchKernelGGL(gn_relu_bwd_small_kernel, dim3(N * groups), dim3(st), 0, s, y, gamma, beta, mean, rstd,
                                C, H, W, groups, v0, v1, dy, (float*)ws);
