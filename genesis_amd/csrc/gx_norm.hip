@@ -26,6 +26,7 @@ struct View {
                   //   and the view's value is its data gradient sum_o proj[o][c] * ptr[n][o][r][col], formed on load
     const float* proj;   // mode 3: the 1x1 conv weight [ctot, C]
     int projC;           // mode 3: C (row length of proj)
+    const float* pgate;  // mode 3: optional device scalar multiplying the conv output (SemiConv gate), or null
 };
 
 // Input of the forward kernels: the conv output, possibly still as `nsplit` split-K partial slabs (summed here in
@@ -95,7 +96,7 @@ __device__ __forceinline__ float load_view(const View& v, int n, int c, int r, i
         float s = 0.f;
         for (int o = 0; o < v.ctot; ++o)
             s += v.proj[o * v.projC + c] * v.ptr[(((size_t)n * v.ctot + o) * H + r) * W + col];
-        return s;
+        return v.pgate ? *v.pgate * s : s;
     }
 }
 
@@ -167,6 +168,7 @@ __device__ __forceinline__ f32x4 load_view4(const View& v, int n, int c, int r, 
         for (int q = 0; q < v.ctot; ++q)
             o += v.proj[q * v.projC + c] *
                  *reinterpret_cast<const f32x4*>(v.ptr + (((size_t)n * v.ctot + q) * H + r) * W + col);
+        if (v.pgate) o = *v.pgate * o;
     }
     return o;
 }
@@ -518,10 +520,11 @@ gn_relu_bwd_reg_kernel(const float* __restrict__ y, const float* __restrict__ ga
             const int cl = unit / P, part = unit - cl * P;
             const int c = gidx * cpg + cl;
             float pw[8];
+            const float gt = g0.pgate ? *g0.pgate : 1.f;
 #pragma unroll
             for (int q = 0; q < 8; ++q)    // wave-uniform (c depends on the wave only): keep them in scalar registers
                 pw[q] = q < g0.ctot ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(
-                                          int, g0.proj[q * g0.projC + c])))
+                                          int, gt * g0.proj[q * g0.projC + c])))
                                     : 0.f;
 #pragma unroll
             for (int j = 0; j < F; ++j) gr[u][j] = staged_grad(gsl, pw, g0.ctot, HW, part * q4 + j * 64 + lane);
@@ -852,7 +855,8 @@ static int gn_relu_fwd_impl(const InSrc& src, const float* gamma, const float* b
     GX_CHECK_ARG(dst0 || !dst1, "gx_gn_relu_fwd: dst1 without dst0");
     GX_CHECK_ARG(N > 0 && C > 0 && groups > 0 && C % groups == 0, "gx_gn_relu_fwd: bad N/C/groups");
     GX_CHECK_ARG(gx_is_pow2(H) && gx_is_pow2(W) && W >= 2 && H >= 2, "gx_gn_relu_fwd: H,W must be powers of two >= 2");
-    View d0{dst0, dst0_ctot, dst0_c0, dst0_mode, nullptr, 0}, d1{dst1, dst1_ctot, dst1_c0, dst1_mode, nullptr, 0};
+    View d0{dst0, dst0_ctot, dst0_c0, dst0_mode, nullptr, 0, nullptr},
+         d1{dst1, dst1_ctot, dst1_c0, dst1_mode, nullptr, 0, nullptr};
     int rc = dst0 ? check_view("gx_gn_relu_fwd", d0, C) : GX_OK;    // dst0 == NULL: statistics only
     if (rc) return rc;
     if (dst1) { rc = check_view("gx_gn_relu_fwd", d1, C); if (rc) return rc; }
@@ -897,8 +901,8 @@ int gx_gn_relu_bwd(const float* y, const float* gamma, const float* beta, const 
                    const float* g1, int g1_ctot, int g1_c0, int g1_mode, float* dy, float* dgamma, float* dbeta,
                    float* dbias, void* ws, size_t ws_bytes, gx_stream_t stream) {
     GX_CHECK_ARG(g0, "gx_gn_relu_bwd: null pointer");
-    View v0{const_cast<float*>(g0), g0_ctot, g0_c0, g0_mode, nullptr, 0},
-         v1{const_cast<float*>(g1), g1_ctot, g1_c0, g1_mode, nullptr, 0};
+    View v0{const_cast<float*>(g0), g0_ctot, g0_c0, g0_mode, nullptr, 0, nullptr},
+         v1{const_cast<float*>(g1), g1_ctot, g1_c0, g1_mode, nullptr, 0, nullptr};
     int rc = check_view("gx_gn_relu_bwd", v0, C);
     if (rc) return rc;
     if (g1) { rc = check_view("gx_gn_relu_bwd", v1, C); if (rc) return rc; }
@@ -908,12 +912,12 @@ int gx_gn_relu_bwd(const float* y, const float* gamma, const float* beta, const 
 
 int gx_gn_relu_bwd_proj(const float* y, const float* gamma, const float* beta, const float* mean, const float* rstd,
                         int N, int C, int H, int W, int groups, const float* g_out, int Cout, const float* w,
-                        float* dy, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
-                        gx_stream_t stream) {
+                        const float* gate, float* dy, float* dgamma, float* dbeta, float* dbias, void* ws,
+                        size_t ws_bytes, gx_stream_t stream) {
     GX_CHECK_ARG(g_out && w, "gx_gn_relu_bwd_proj: null pointer");
     GX_CHECK_ARG(Cout >= 1 && Cout <= 8, "gx_gn_relu_bwd_proj: Cout must be 1..8 (got %d)", Cout);
     GX_CHECK_ARG((W % 4) == 0 && ((uintptr_t)g_out % 16) == 0, "gx_gn_relu_bwd_proj: W %% 4 == 0 and 16-byte alignment");
-    View v0{const_cast<float*>(g_out), Cout, 0, 3, w, C}, v1{nullptr, 0, 0, 0, nullptr, 0};
+    View v0{const_cast<float*>(g_out), Cout, 0, 3, w, C, gate}, v1{nullptr, 0, 0, 0, nullptr, 0, nullptr};
     return gn_relu_bwd_impl(y, gamma, beta, mean, rstd, N, C, H, W, groups, v0, v1, dy, dgamma, dbeta, dbias, ws,
                             ws_bytes, stream);
 }

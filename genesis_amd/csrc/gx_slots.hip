@@ -886,18 +886,19 @@ int gx_conv1x1_bwd(const float* x, const float* dy, const float* w, const float*
 
 // ---- 1x1 conv on a GroupNorm+ReLU layer that is never materialised (decoder_module.12-13)
 int gx_conv1x1_gn_fwd(const float* y_pre, const float* mean, const float* rstd, const float* gamma,
-                      const float* beta, int groups, const float* w, const float* bias, int N, int Cin, int Cout,
-                      int H, int W, float* out, gx_stream_t stream) {
+                      const float* beta, int groups, const float* w, const float* bias, const float* gate,
+                      const float* addend, int N, int Cin, int Cout, int H, int W, float* out, gx_stream_t stream) {
     GX_CHECK_ARG(y_pre && mean && rstd && gamma && beta && w && out, "gx_conv1x1_gn_fwd: null pointer");
     GX_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && Cout <= COMAX && Cin <= 128 && groups > 0 && Cin % groups == 0,
                  "gx_conv1x1_gn_fwd: Cout <= 8, Cin <= 128, Cin %% groups == 0");
     const int HW = H * W;
-    GX_CHECK_ARG((HW % 4) == 0 && ((uintptr_t)y_pre % 16) == 0 && ((uintptr_t)out % 16) == 0,
+    GX_CHECK_ARG((HW % 4) == 0 && ((uintptr_t)y_pre % 16) == 0 && ((uintptr_t)out % 16) == 0 &&
+                     (!addend || ((uintptr_t)addend % 16) == 0),
                  "gx_conv1x1_gn_fwd: H*W %% 4 == 0 and 16-byte aligned tensors");
     {
         GxProf pf(KID_CONV1X1_FWD, (hipStream_t)stream, 2.0 * N * Cin * Cout * HW, 4.0 * N * HW * (Cin + Cout));
         hipLaunchKernelGGL(conv1x1_fwd_vec_kernel, dim3(N, gx_ceil_div(HW, 1024)), dim3(256), 0, (hipStream_t)stream,
-                           y_pre, w, bias, (const float*)nullptr, (const float*)nullptr, Cin, Cout, HW, out,
+                           y_pre, w, bias, gate, addend, Cin, Cout, HW, out,
                            NormIn{mean, rstd, gamma, beta, groups, Cin / groups});
     }
     GX_CHECK_LAUNCH("gx_conv1x1_gn_fwd");
@@ -906,13 +907,16 @@ int gx_conv1x1_gn_fwd(const float* y_pre, const float* mean, const float* rstd, 
 
 size_t gx_conv1x1_gn_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W) {
     const size_t nblkw = conv1x1_wgrad_blocks(N, H * W);
-    return nblkw * ((size_t)Cout * Cin + Cout) * sizeof(float);
+    return (nblkw + 1) * ((size_t)Cout * Cin + Cout) * sizeof(float);
 }
 
 int gx_conv1x1_gn_wgrad(const float* y_pre, const float* mean, const float* rstd, const float* gamma,
-                        const float* beta, int groups, const float* g_out, int N, int Cin, int Cout, int H, int W,
-                        float* dw, float* db, void* ws, size_t ws_bytes, gx_stream_t stream) {
+                        const float* beta, int groups, const float* g_out, const float* w, const float* bias,
+                        const float* gate, int N, int Cin, int Cout, int H, int W, float* dw, float* db,
+                        float* dgate, void* ws, size_t ws_bytes, gx_stream_t stream) {
     GX_CHECK_ARG(y_pre && mean && rstd && gamma && beta && g_out && dw && ws, "gx_conv1x1_gn_wgrad: null pointer");
+    GX_CHECK_ARG((gate == nullptr) == (dgate == nullptr) && (!gate || w),
+                 "gx_conv1x1_gn_wgrad: gate, dgate (and w) go together");
     GX_CHECK_ARG(N > 0 && Cin > 0 && Cin <= 64 && Cout > 0 && Cout <= COMAX && groups > 0 && Cin % groups == 0,
                  "gx_conv1x1_gn_wgrad: Cout <= 8, Cin <= 64, Cin %% groups == 0");
     const int HW = H * W;
@@ -938,8 +942,16 @@ int gx_conv1x1_gn_wgrad(const float* y_pre, const float* mean, const float* rstd
     GX_CHECK_LAUNCH("gx_conv1x1_gn_wgrad");
     {
         GxProf pf(KID_SMALL_REDUCE, s, 0.0, 4.0 * (double)nblkw * (npairs + Cout));
-        hipLaunchKernelGGL(col_sum2_kernel, dim3(npairs + Cout), dim3(256), 0, s, (const float*)pw, nblkw, npairs, dw,
-                           (const float*)pb, nblkw, Cout, db);
+        if (!gate) {
+            hipLaunchKernelGGL(col_sum2_kernel, dim3(npairs + Cout), dim3(256), 0, s, (const float*)pw, nblkw, npairs,
+                               dw, (const float*)pb, nblkw, Cout, db);
+        } else {
+            float* raw = pb + (size_t)nblkw * Cout;
+            hipLaunchKernelGGL(col_sum2_kernel, dim3(npairs + Cout), dim3(256), 0, s, (const float*)pw, nblkw, npairs,
+                               raw, (const float*)pb, nblkw, Cout, raw + npairs);
+            hipLaunchKernelGGL(conv1x1_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)raw, w, bias, gate,
+                               Cin, Cout, dw, db, dgate);
+        }
     }
     GX_CHECK_LAUNCH("gx_conv1x1_gn_wgrad(reduce)");
     return GX_OK;

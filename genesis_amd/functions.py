@@ -308,6 +308,59 @@ class ICSBPFn(torch.autograd.Function):
                 _ret(ols, dls.to(ctx.ls_dtype)), None, None, None, None)
 
 
+# seg_head's GroupNorm+ReLU output is consumed by the colour head's 1x1 conv only: keep it out of memory (as the
+# decoder head; GENESIS_FUSE_SEG_HEAD=0 restores ConvGNReLUFn + ICSBPFn)
+FUSE_SEG_HEAD = __import__('os').environ.get('GENESIS_FUSE_SEG_HEAD', '1') == '1'
+
+
+def seg_head_fusable(enc_feat, seg_w, conv_w):
+    C, HW = seg_w.shape[0], enc_feat.shape[2] * enc_feat.shape[3]
+    return FUSE_SEG_HEAD and C <= 64 and C % GROUPS == 0 and HW % 256 == 0 and conv_w.shape[0] <= 8
+
+
+class SegICSBPFn(torch.autograd.Function):
+    """seg_head (conv3x3 -> GroupNorm -> ReLU, genesisv2_config.py:66) + colour head + IC-SBP with the normalised
+    seg_head activation never written: statistics only, the 1x1 conv normalises on load, its data gradient is formed
+    inside the norm backward.  Same outputs as ConvGNReLUFn + ICSBPFn."""
+
+    @staticmethod
+    def forward(ctx, enc_feat, seg_w, seg_gamma, seg_beta, conv_w, conv_b, gate, uv, log_sigma, rand_pixel, K, kernel,
+                seed_idx):
+        x = enc_feat.contiguous()
+        ctx.params = (seg_w, seg_gamma, seg_beta, conv_w, conv_b, gate, log_sigma)
+        w2 = conv_w.detach().view(conv_w.shape[0], -1)
+        y, mean, rstd = hip.conv3x3_gn_relu_fwd(x, seg_w, seg_gamma, seg_beta, GROUPS, EPS, None)
+        colour = hip.conv1x1_gn_fwd(y, mean, rstd, seg_gamma, seg_beta, GROUPS, w2, conv_b, gate, uv)
+        ctx.ls_dtype = log_sigma.dtype
+        ls64 = log_sigma.detach().to(torch.float64)
+        log_m, log_s, seeds, idx = hip.icsbp_fwd(colour, ls64, rand_pixel.contiguous(), K, kernel, seed_idx)
+        ctx.save_for_backward(x, y, mean, rstd, ls64, colour, seeds, idx)
+        ctx.kernel = kernel
+        ctx.mark_non_differentiable(log_s, colour, seeds, idx)
+        ctx.set_materialize_grads(False)
+        return log_m, log_s, colour, seeds, idx
+
+    @staticmethod
+    def backward(ctx, g_log_m, *unused):
+        x, y, mean, rstd, ls64, colour, seeds, idx = ctx.saved_tensors
+        seg_w, seg_gamma, seg_beta, conv_w, conv_b, gate, log_sigma = ctx.params
+        if g_log_m is None:
+            g_log_m = colour.new_zeros(seeds.shape[0] + 1, colour.shape[0], 1, colour.shape[2], colour.shape[3])
+        ols = _gout(log_sigma) if ctx.ls_dtype == torch.float64 and log_sigma.dim() == 0 else None
+        dcolour, dls = hip.icsbp_bwd(colour, ls64, seeds, idx, g_log_m.contiguous(), ctx.kernel, out_dls=ols)
+        w2 = conv_w.detach().view(conv_w.shape[0], -1)
+        ow, ob, og = _gout(conv_w), _gout(conv_b), (_gout(gate) if gate is not None else None)
+        dw, db, dgate = hip.conv1x1_gn_wgrad(y, mean, rstd, seg_gamma, seg_beta, GROUPS, dcolour, w2, conv_b, gate,
+                                             out=(ow, ob, og))
+        osw, osg, osb = _gout(seg_w), _gout(seg_gamma), _gout(seg_beta)
+        dy, dgamma, dbeta, _ = hip.gn_relu_bwd_proj(y, seg_gamma, seg_beta, mean, rstd, GROUPS, dcolour, w2, False,
+                                                    out=(osg, osb, None), gate=gate)
+        dsw = _wgrad(lambda: hip.conv3x3_wgrad(x, dy, out=osw), osw, x, dy)
+        dx = hip.conv3x3_dgrad(dy, seg_w) if ctx.needs_input_grad[0] else None
+        return (dx, _ret(osw, dsw), _ret(osg, dgamma), _ret(osb, dbeta), _ret(ow, dw.view(conv_w.shape)), _ret(ob, db),
+                _ret(og, dgate), None, _ret(ols, dls.to(ctx.ls_dtype)), None, None, None, None)
+
+
 class MaskPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, f, log_m):
@@ -373,7 +426,7 @@ class DecoderFn(torch.autograd.Function):
         g = g.contiguous()
         if ctx.fused_head:
             _, y3, mean3, rstd3 = ctx.saved[3]
-            dow, dob = hip.conv1x1_gn_wgrad(y3, mean3, rstd3, params[14], params[15], GROUPS, g, out=(gow, gob))
+            dow, dob, _ = hip.conv1x1_gn_wgrad(y3, mean3, rstd3, params[14], params[15], GROUPS, g, out=(gow, gob, None))
             da = None
         else:
             da, dow, dob, _ = hip.conv1x1_bwd(ctx.last, g, ow2, ob, out=(gow, gob, None))

@@ -278,7 +278,6 @@ class GenesisV2(nn.Module):
         # --- Extract features (F.relu on the ReLU'd UNet output, genesisv2_config.py:115, is the identity)
         enc_feat = fn.UNetEncoderFn.apply(x, self.encoder.num_blocks, 8, *self.encoder.flat_params())
         # --- Predict attention masks
-        seg = fn.ConvGNReLUFn.apply(enc_feat, *self.seg_head.params())
         if rand_pixel is None:
             rand_pixel = torch.rand(B, 1, H, W, device=dev)
         ap = self.att_process
@@ -286,8 +285,14 @@ class GenesisV2(nn.Module):
             cw, cb, gate, addend = ap.colour_head.conv.weight, ap.colour_head.conv.bias, ap.colour_head.gate.gate, uv
         else:
             cw, cb, gate, addend = ap.colour_head.weight, ap.colour_head.bias, None, None
-        log_m, log_s, colour, seeds, idx = fn.ICSBPFn.apply(
-            seg, cw, cb, gate, addend, ap.log_sigma, rand_pixel, K, ap.kernel, seed_idx)
+        seg_params = self.seg_head.params()
+        if fn.seg_head_fusable(enc_feat, seg_params[0], cw):
+            log_m, log_s, colour, seeds, idx = fn.SegICSBPFn.apply(
+                enc_feat, *seg_params, cw, cb, gate, addend, ap.log_sigma, rand_pixel, K, ap.kernel, seed_idx)
+        else:
+            seg = fn.ConvGNReLUFn.apply(enc_feat, *seg_params)
+            log_m, log_s, colour, seeds, idx = fn.ICSBPFn.apply(
+                seg, cw, cb, gate, addend, ap.log_sigma, rand_pixel, K, ap.kernel, seed_idx)
         # --- Object features: feat_head[0] once (the reference recomputes it K times, :149), pooled per
         #     slot; the 1x1 conv feat_head[1] commutes with the masked sum and is applied to the pooled sums.
         f = fn.ConvGNReLUFn.apply(enc_feat, *self.feat_head[0].params())

@@ -618,36 +618,39 @@ def lstm_step_bwd(g_h, dgates_next, w_hh, act, c, c_prev, dc_next, dgates, dc_pr
 
 
 # ------------------------------------------------------------------ 1x1 conv on a never-materialised GroupNorm+ReLU
-def conv1x1_gn_fwd(y_pre, mean, rstd, gamma, beta, groups, w, bias):
-    """conv1x1(relu(gn(y_pre))): the normalised activation is formed on load."""
+def conv1x1_gn_fwd(y_pre, mean, rstd, gamma, beta, groups, w, bias, gate=None, addend=None):
+    """gate * conv1x1(relu(gn(y_pre))) + addend: the normalised activation is formed on load."""
     _chk(y_pre, 'conv1x1_gn.y'); _chk(mean, 'conv1x1_gn.mean'); _chk(rstd, 'conv1x1_gn.rstd')
     _chk(gamma, 'conv1x1_gn.gamma'); _chk(beta, 'conv1x1_gn.beta'); _chk(w, 'conv1x1_gn.w'); _chk(bias, 'conv1x1_gn.bias')
+    _chk(gate, 'conv1x1_gn.gate'); _chk(addend, 'conv1x1_gn.addend')
     N, Cin, H, W = y_pre.shape
     Cout = w.shape[0]
     out = torch.empty(N, Cout, H, W, dtype=F32, device=y_pre.device)
-    _lib.call('gx_conv1x1_gn_fwd', _p(y_pre), _p(mean), _p(rstd), _p(gamma), _p(beta), groups, _p(w), _p(bias), N, Cin,
-              Cout, H, W, _p(out), _stream())
+    _lib.call('gx_conv1x1_gn_fwd', _p(y_pre), _p(mean), _p(rstd), _p(gamma), _p(beta), groups, _p(w), _p(bias),
+              _p(gate), _p(addend), N, Cin, Cout, H, W, _p(out), _stream())
     return out
 
 
-def conv1x1_gn_wgrad(y_pre, mean, rstd, gamma, beta, groups, g_out, out=None):
-    """(dw [Cout,Cin], db [Cout]) of conv1x1(relu(gn(y_pre))); out = (dw, db) destinations or None."""
+def conv1x1_gn_wgrad(y_pre, mean, rstd, gamma, beta, groups, g_out, w=None, bias=None, gate=None, out=None):
+    """(dw [Cout,Cin], db [Cout], dgate) of gate * conv1x1(relu(gn(y_pre))); out = (dw, db, dgate) destinations or
+    None.  w, bias are only read for the gate gradient."""
     _chk(y_pre, 'conv1x1_gn_wgrad.y'); _chk(g_out, 'conv1x1_gn_wgrad.g')
     N, Cin, H, W = y_pre.shape
     Cout = g_out.shape[1]
-    o = out or (None, None)
+    o = out or (None, None, None)
     dw = o[0] if o[0] is not None else torch.empty(Cout, Cin, dtype=F32, device=y_pre.device)
     db = o[1] if o[1] is not None else torch.empty(Cout, dtype=F32, device=y_pre.device)
-    _chk(dw, 'conv1x1_gn_wgrad.dw'); _chk(db, 'conv1x1_gn_wgrad.db')
+    dgate = (o[2] if o[2] is not None else torch.empty((), dtype=F32, device=y_pre.device)) if gate is not None else None
+    _chk(dw, 'conv1x1_gn_wgrad.dw'); _chk(db, 'conv1x1_gn_wgrad.db'); _chk(dgate, 'conv1x1_gn_wgrad.dgate')
     assert dw.numel() == Cout * Cin and db.numel() == Cout
     nb = _lib.query('gx_conv1x1_gn_wgrad_ws_bytes', N, Cin, Cout, H, W)
     ws = _ws(nb, y_pre.device)
-    _lib.call('gx_conv1x1_gn_wgrad', _p(y_pre), _p(mean), _p(rstd), _p(gamma), _p(beta), groups, _p(g_out), N, Cin,
-              Cout, H, W, _p(dw), _p(db), _p(ws), nb, _stream())
-    return dw, db
+    _lib.call('gx_conv1x1_gn_wgrad', _p(y_pre), _p(mean), _p(rstd), _p(gamma), _p(beta), groups, _p(g_out), _p(w),
+              _p(bias), _p(gate), N, Cin, Cout, H, W, _p(dw), _p(db), _p(dgate), _p(ws), nb, _stream())
+    return dw, db, dgate
 
 
-def gn_relu_bwd_proj(y, gamma, beta, mean, rstd, groups, g_out, w, want_dbias=False, out=None):
+def gn_relu_bwd_proj(y, gamma, beta, mean, rstd, groups, g_out, w, want_dbias=False, out=None, gate=None):
     """gn_relu_bwd whose incoming gradient is the data gradient of a following 1x1 conv (weight w [Cout,C], output
     gradient g_out [N,Cout,H,W]), formed on load."""
     _chk(y, 'gn_bwd_proj.y'); _chk(g_out, 'gn_bwd_proj.g'); _chk(w, 'gn_bwd_proj.w')
@@ -662,7 +665,7 @@ def gn_relu_bwd_proj(y, gamma, beta, mean, rstd, groups, g_out, w, want_dbias=Fa
     direct = o[0] is not None and o[1] is not None and (not want_dbias or o[2] is not None)
     with _deferring(direct, ws):
         _lib.call('gx_gn_relu_bwd_proj', _p(y), _p(gamma), _p(beta), _p(mean), _p(rstd), N, C, H, W, groups,
-                  _p(g_out), int(g_out.shape[1]), _p(w), _p(dy), _p(dgamma), _p(dbeta), _p(dbias), _p(ws), nb,
-                  _stream())
+                  _p(g_out), int(g_out.shape[1]), _p(w), _p(gate), _p(dy), _p(dgamma), _p(dbeta), _p(dbias), _p(ws),
+                  nb, _stream())
     return dy, dgamma, dbeta, dbias
 

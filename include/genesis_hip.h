@@ -66,7 +66,8 @@ int gx_deconv5x5s2_wgrad(const float* x, const float* dy, float* dw, int N, int 
  *      dbias != NULL, sum_{n,hw} dy (the gradient of a per-channel bias added before the norm).
  *      fwd with dst0 == NULL computes the statistics only: the consumer (gx_conv1x1_gn_fwd) normalises on load.
  *      gx_gn_relu_bwd_proj is the matching backward: d(out) is not read from memory but formed on load as the data
- *      gradient of the following 1x1 conv, sum_o w[o][c] g_out[n][o][h][w] (g_out [N,Cout,H,W], w [Cout,C], Cout <= 8):
+ *      gradient of the following 1x1 conv, gate * sum_o w[o][c] g_out[n][o][h][w] (g_out [N,Cout,H,W], w [Cout,C],
+ *      Cout <= 8, gate an optional device scalar):
  *      the [N,C,H,W] activation and its gradient never exist in memory (genesisv2_config.py:97-98, last decoder stage). */
 int gx_gn_relu_fwd(const float* y, const float* gamma, const float* beta, int N, int C, int H, int W, int groups,
                    float eps, float* dst0, int dst0_ctot, int dst0_c0, int dst0_mode, float* dst1, int dst1_ctot,
@@ -78,8 +79,8 @@ int gx_gn_relu_bwd(const float* y, const float* gamma, const float* beta, const 
                    float* dbias, void* ws, size_t ws_bytes, gx_stream_t stream);
 int gx_gn_relu_bwd_proj(const float* y, const float* gamma, const float* beta, const float* mean, const float* rstd,
                         int N, int C, int H, int W, int groups, const float* g_out, int Cout, const float* w,
-                        float* dy, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
-                        gx_stream_t stream);
+                        const float* gate, float* dy, float* dgamma, float* dbeta, float* dbias, void* ws,
+                        size_t ws_bytes, gx_stream_t stream);
 
 /* ---- Instance-Colouring stick-breaking attention: modules/attention.py:162-226.
  *      colour [B,C<=8,H,W]; log_sigma: device pointer to the fp64 0-dim parameter; rand_pixel [B,1,H,W];
@@ -129,12 +130,13 @@ int gx_conv1x1_bwd(const float* x, const float* dy, const float* w, const float*
  *      gx_gn_relu_fwd with dst0 == NULL): relu(gn(y)) is formed on load, forward and in the weight gradient; the data
  *      gradient is folded into gx_gn_relu_bwd_proj.  Cin <= 64 (wgrad), H*W % 256 == 0. */
 int gx_conv1x1_gn_fwd(const float* y_pre, const float* mean, const float* rstd, const float* gamma,
-                      const float* beta, int groups, const float* w, const float* bias, int N, int Cin, int Cout,
-                      int H, int W, float* out, gx_stream_t stream);
+                      const float* beta, int groups, const float* w, const float* bias, const float* gate,
+                      const float* addend, int N, int Cin, int Cout, int H, int W, float* out, gx_stream_t stream);
 size_t gx_conv1x1_gn_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W);
 int gx_conv1x1_gn_wgrad(const float* y_pre, const float* mean, const float* rstd, const float* gamma,
-                        const float* beta, int groups, const float* g_out, int N, int Cin, int Cout, int H, int W,
-                        float* dw, float* db, void* ws, size_t ws_bytes, gx_stream_t stream);
+                        const float* beta, int groups, const float* g_out, const float* w, const float* bias,
+                        const float* gate, int N, int Cin, int Cout, int H, int W, float* dw, float* db,
+                        float* dgate, void* ws, size_t ws_bytes, gx_stream_t stream);
 
 /* ---- optimiser side of the training step.
  *      gx_adam_step: torch.optim.Adam update (train.py:174-175,263) on flat buffers p/g/m/v of n elements

@@ -613,7 +613,7 @@ def test_conv1x1_on_unmaterialised_groupnorm(N, C, Cout, S, groups):
     assert torch.equal(mean, full_mean) and torch.equal(rstd, full_rstd)
     out = hip.conv1x1_gn_fwd(yd, mean, rstd, gd, bd, groups, wd, bbd)
     close(out, ref, 1e-5, 1e-5, 'fwd')
-    dw, db = hip.conv1x1_gn_wgrad(yd, mean, rstd, gd, bd, groups, gg)
+    dw, db, _ = hip.conv1x1_gn_wgrad(yd, mean, rstd, gd, bd, groups, gg)
     close(dw, wr.grad, 1e-4, 1e-4, 'dw')
     close(db, bbr.grad, 1e-4, 1e-4, 'db')
     dy, dgamma, dbeta, dbias = hip.gn_relu_bwd_proj(yd, gd, bd, mean, rstd, groups, gg, wd, True)
@@ -621,3 +621,32 @@ def test_conv1x1_on_unmaterialised_groupnorm(N, C, Cout, S, groups):
     close(dgamma, gr.grad, 1e-4, 1e-4, 'dgamma')
     close(dbeta, br.grad, 1e-4, 1e-4, 'dbeta')
     close(dbias, yr.grad.sum((0, 2, 3)), 1e-4, 1e-4, 'dbias')
+
+
+def test_gated_conv1x1_on_unmaterialised_groupnorm():
+    """SemiConv colour head on seg_head's never-written activation: gate * conv1x1(relu(gn(y))) + uv and all its
+    gradients (gate included) against torch."""
+    N, C, Cout, S, groups = 3, 64, 8, 32, 8
+    y = rnd(N, C, S, S, seed=41, scale=2.0) - 0.1
+    gamma = 1 + 0.3 * rnd(C, seed=42)
+    beta = 0.2 * rnd(C, seed=43)
+    w = rnd(Cout, C, seed=44, scale=0.3)
+    b = rnd(Cout, seed=45, scale=0.1)
+    gate = torch.tensor(0.37)
+    uv = rnd(Cout, S, S, seed=46)
+    g = rnd(N, Cout, S, S, seed=47)
+    yr, gr, br, wr, bbr, gtr = [t.clone().requires_grad_() for t in (y, gamma, beta, w, b, gate)]
+    ref = gtr * F.conv2d(F.relu(F.group_norm(yr, groups, gr, br, 1e-5)), wr.view(Cout, C, 1, 1), bbr) + uv
+    ref.backward(g)
+    yd, gd, bd, wd, bbd, gg, gtd, uvd = [t.to(DEV) for t in (y, gamma, beta, w, b, g, gate, uv)]
+    mean, rstd = hip.gn_relu_fwd(yd, gd, bd, groups, 1e-5, None)
+    out = hip.conv1x1_gn_fwd(yd, mean, rstd, gd, bd, groups, wd, bbd, gtd, uvd)
+    close(out, ref, 1e-5, 1e-5, 'fwd')
+    dw, db, dgate = hip.conv1x1_gn_wgrad(yd, mean, rstd, gd, bd, groups, gg, wd, bbd, gtd)
+    close(dw, wr.grad, 1e-4, 1e-4, 'dw')
+    close(db, bbr.grad, 1e-4, 1e-4, 'db')
+    close(dgate, gtr.grad, 1e-4, 1e-4, 'dgate')
+    dy, dgamma, dbeta, _ = hip.gn_relu_bwd_proj(yd, gd, bd, mean, rstd, groups, gg, wd, False, gate=gtd)
+    close(dy, yr.grad, 1e-4, 1e-5, 'dy')
+    close(dgamma, gr.grad, 1e-4, 1e-4, 'dgamma')
+    close(dbeta, br.grad, 1e-4, 1e-4, 'dbeta')
