@@ -484,9 +484,11 @@ __global__ void __launch_bounds__(1024)
 gn_relu_bwd_reg_kernel(const float* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ beta,
                        const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                        int C, int H, int W, int groups, int P, View g0, View g1,
-                       float* __restrict__ dy, float* __restrict__ part_out) {
+                       float* __restrict__ dy, float* __restrict__ part_out, float* __restrict__ wpart,
+                       float* __restrict__ bpart) {
     __shared__ double uab[32 * 2];  // per unit: sum dpre*xhat, sum dpre
     __shared__ double usd[32];      // per unit: sum dy
+    __shared__ float uw[32][8];     // STAGE + wpart: per unit, sum_p g_out[q][p] * relu(gn(y))[c][p]
     extern __shared__ __attribute__((aligned(16))) float gsl[];   // stage != 0: g0.ptr[n] ([ctot][HW]) of a mode-3 view
     const int n = blockIdx.x / groups, gidx = blockIdx.x % groups;
     const int cpg = C / groups, HW = H * W;
@@ -528,6 +530,48 @@ gn_relu_bwd_reg_kernel(const float* __restrict__ y, const float* __restrict__ ga
                                     : 0.f;
 #pragma unroll
             for (int j = 0; j < F; ++j) gr[u][j] = staged_grad(gsl, pw, g0.ctot, HW, part * q4 + j * 64 + lane);
+            if (wpart) {
+                // the following 1x1 conv's weight gradient for this channel: its input relu(gn(y)) exists only here
+                const float gm = gamma[c], bt = beta[c];
+                float wacc[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) wacc[q] = 0.f;
+#pragma unroll
+                for (int j = 0; j < F; ++j) {
+                    f32x4 a;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = (xr[u][j][e] - meanf) * rstdf * gm + bt;
+                        a[e] = t > 0.f ? t : 0.f;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (q < g0.ctot) {
+                            const f32x4 gq = reinterpret_cast<const f32x4*>(gsl)[q * (HW >> 2) + part * q4 + j * 64 + lane];
+                            wacc[q] += (gq[0] * a[0] + gq[1] * a[1]) + (gq[2] * a[2] + gq[3] * a[3]);
+                        }
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (q < g0.ctot) {
+                        float v = wacc[q];
+#pragma unroll
+                        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+                        if (lane == 0) uw[unit][q] = v;
+                    }
+            }
+        }
+        if (bpart && gidx == 0) {   // bias gradient partial of the 1x1 conv: sum_p g_out[q][p], one wave per row q
+            for (int q = wave; q < g0.ctot; q += (int)(blockDim.x >> 6)) {
+                float v = 0.f;
+                for (int i = lane; i < (HW >> 2); i += 64) {
+                    const f32x4 t = reinterpret_cast<const f32x4*>(gsl)[q * (HW >> 2) + i];
+                    v += (t[0] + t[1]) + (t[2] + t[3]);
+                }
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+                if (lane == 0) bpart[(size_t)n * g0.ctot + q] = v;
+            }
         }
     } else {
 #pragma unroll
@@ -572,6 +616,14 @@ gn_relu_bwd_reg_kernel(const float* __restrict__ y, const float* __restrict__ ga
         if (lane == 0) { uab[2 * unit] = a; uab[2 * unit + 1] = b; }
     }
     __syncthreads();
+    if (STAGE && wpart) {
+        for (int t = threadIdx.x; t < cpg * g0.ctot; t += blockDim.x) {
+            const int cl = t / g0.ctot, q = t - cl * g0.ctot;
+            float v = 0.f;
+            for (int p = 0; p < P; ++p) v += uw[cl * P + p][q];
+            wpart[((size_t)n * g0.ctot + q) * C + gidx * cpg + cl] = v;
+        }
+    }
     double s1 = 0.0, s2 = 0.0;
     for (int cl = 0; cl < cpg; ++cl) {
         double a = 0.0, b = 0.0;
@@ -894,7 +946,7 @@ size_t gx_gn_relu_bwd_ws_bytes(int N, int C) { return (size_t)N * C * 3 * sizeof
 static int gn_relu_bwd_impl(const float* y, const float* gamma, const float* beta, const float* mean,
                             const float* rstd, int N, int C, int H, int W, int groups, const View& v0, const View& v1,
                             float* dy, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
-                            gx_stream_t stream);
+                            gx_stream_t stream, float* wpart = nullptr, float* bpart = nullptr);
 
 int gx_gn_relu_bwd(const float* y, const float* gamma, const float* beta, const float* mean, const float* rstd,
                    int N, int C, int H, int W, int groups, const float* g0, int g0_ctot, int g0_c0, int g0_mode,
@@ -912,20 +964,28 @@ int gx_gn_relu_bwd(const float* y, const float* gamma, const float* beta, const 
 
 int gx_gn_relu_bwd_proj(const float* y, const float* gamma, const float* beta, const float* mean, const float* rstd,
                         int N, int C, int H, int W, int groups, const float* g_out, int Cout, const float* w,
-                        const float* gate, float* dy, float* dgamma, float* dbeta, float* dbias, void* ws,
-                        size_t ws_bytes, gx_stream_t stream) {
+                        const float* gate, float* dy, float* dgamma, float* dbeta, float* dbias, float* wpart,
+                        float* bpart, void* ws, size_t ws_bytes, gx_stream_t stream) {
     GX_CHECK_ARG(g_out && w, "gx_gn_relu_bwd_proj: null pointer");
+    GX_CHECK_ARG((wpart == nullptr) == (bpart == nullptr), "gx_gn_relu_bwd_proj: wpart and bpart go together");
     GX_CHECK_ARG(Cout >= 1 && Cout <= 8, "gx_gn_relu_bwd_proj: Cout must be 1..8 (got %d)", Cout);
     GX_CHECK_ARG((W % 4) == 0 && ((uintptr_t)g_out % 16) == 0, "gx_gn_relu_bwd_proj: W %% 4 == 0 and 16-byte alignment");
     View v0{const_cast<float*>(g_out), Cout, 0, 3, w, C, gate}, v1{nullptr, 0, 0, 0, nullptr, 0, nullptr};
     return gn_relu_bwd_impl(y, gamma, beta, mean, rstd, N, C, H, W, groups, v0, v1, dy, dgamma, dbeta, dbias, ws,
-                            ws_bytes, stream);
+                            ws_bytes, stream, wpart, bpart);
+}
+
+// whether gx_gn_relu_bwd_proj can also produce the 1x1 conv's weight-gradient partials (wpart / bpart)
+int gx_gn_relu_bwd_proj_fuses_wgrad(int C, int H, int W, int groups, int Cout) {
+    if (C <= 0 || groups <= 0 || C % groups || Cout < 1 || Cout > 8 || (C / groups) * Cout > 1024) return 0;
+    if (!gx_is_pow2(H) || !gx_is_pow2(W)) return 0;
+    return plan_reg(C / groups, H, W).ok && (size_t)Cout * H * W * 4 <= 128 * 1024;
 }
 
 static int gn_relu_bwd_impl(const float* y, const float* gamma, const float* beta, const float* mean,
                             const float* rstd, int N, int C, int H, int W, int groups, const View& v0, const View& v1,
                             float* dy, float* dgamma, float* dbeta, float* dbias, void* ws, size_t ws_bytes,
-                            gx_stream_t stream) {
+                            gx_stream_t stream, float* wpart, float* bpart) {
     const float* g1 = v1.ptr;
     const int g0_mode = v0.mode, g1_mode = v1.mode;
     GX_CHECK_ARG(y && gamma && beta && mean && rstd && dy && dgamma && dbeta && ws,
@@ -947,9 +1007,12 @@ static int gn_relu_bwd_impl(const float* y, const float* gamma, const float* bet
         if (pl.ok) {
             // projected-gradient source: stage the image's [Cout][H*W] output gradient in LDS when it fits
             const size_t stage = (v0.mode == 3 && (size_t)v0.ctot * hw * 4 <= 128 * 1024) ? (size_t)v0.ctot * hw * 4 : 0;
+            GX_CHECK_ARG(!wpart || stage, "gx_gn_relu_bwd_proj: fused 1x1 weight gradient unsupported for this shape");
             GX_GN_REG_DISPATCH(launch_bwd_reg, pl, dim3(N * groups), dim3(pl.threads), s, stage, y, gamma, beta, mean,
-                               rstd, C, H, W, groups, pl.P, v0, v1, dy, (float*)ws);
+                               rstd, C, H, W, groups, pl.P, v0, v1, dy, (float*)ws, wpart, bpart);
         }
+        else if (wpart)
+            GX_CHECK_ARG(false, "gx_gn_relu_bwd_proj: fused 1x1 weight gradient unsupported for this shape");
         else if (st)
             hipLaunchKernelGGL(gn_relu_bwd_small_kernel, dim3(N * groups), dim3(st), 0, s, y, gamma, beta, mean, rstd,
                                C, H, W, groups, v0, v1, dy, (float*)ws);

@@ -957,4 +957,36 @@ int gx_conv1x1_gn_wgrad(const float* y_pre, const float* mean, const float* rstd
     return GX_OK;
 }
 
+// Finishes the 1x1 conv's parameter gradients from the per-image partials gx_gn_relu_bwd_proj produced
+// (wpart [N][Cout][Cin], bpart [N][Cout]): fixed-order sums over the images, then the gate handling of gx_conv1x1_bwd.
+size_t gx_conv1x1_gn_wgrad_finish_ws_bytes(int Cin, int Cout) { return ((size_t)Cout * Cin + Cout) * sizeof(float); }
+
+int gx_conv1x1_gn_wgrad_finish(const float* wpart, const float* bpart, int N, int Cin, int Cout, const float* w,
+                               const float* bias, const float* gate, float* dw, float* db, float* dgate, void* ws,
+                               size_t ws_bytes, gx_stream_t stream) {
+    GX_CHECK_ARG(wpart && bpart && dw, "gx_conv1x1_gn_wgrad_finish: null pointer");
+    GX_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && Cout <= COMAX, "gx_conv1x1_gn_wgrad_finish: bad N/Cin/Cout");
+    GX_CHECK_ARG((gate == nullptr) == (dgate == nullptr) && (!gate || (w && ws)),
+                 "gx_conv1x1_gn_wgrad_finish: gate, dgate (and w, ws) go together");
+    GX_CHECK_ARG(!gate || ws_bytes >= gx_conv1x1_gn_wgrad_finish_ws_bytes(Cin, Cout),
+                 "gx_conv1x1_gn_wgrad_finish: workspace too small");
+    const int npairs = Cout * Cin;
+    hipStream_t s = (hipStream_t)stream;
+    {
+        GxProf pf(KID_SMALL_REDUCE, s, 0.0, 4.0 * (double)N * (npairs + Cout));
+        if (!gate) {
+            hipLaunchKernelGGL(col_sum2_kernel, dim3(npairs + Cout), dim3(256), 0, s, wpart, N, npairs, dw, bpart, N,
+                               Cout, db);
+        } else {
+            float* raw = (float*)ws;
+            hipLaunchKernelGGL(col_sum2_kernel, dim3(npairs + Cout), dim3(256), 0, s, wpart, N, npairs, raw, bpart, N,
+                               Cout, raw + npairs);
+            hipLaunchKernelGGL(conv1x1_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)raw, w, bias, gate,
+                               Cin, Cout, dw, db, dgate);
+        }
+    }
+    GX_CHECK_LAUNCH("gx_conv1x1_gn_wgrad_finish");
+    return GX_OK;
+}
+
 }  // extern "C"

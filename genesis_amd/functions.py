@@ -350,11 +350,16 @@ class SegICSBPFn(torch.autograd.Function):
         dcolour, dls = hip.icsbp_bwd(colour, ls64, seeds, idx, g_log_m.contiguous(), ctx.kernel, out_dls=ols)
         w2 = conv_w.detach().view(conv_w.shape[0], -1)
         ow, ob, og = _gout(conv_w), _gout(conv_b), (_gout(gate) if gate is not None else None)
-        dw, db, dgate = hip.conv1x1_gn_wgrad(y, mean, rstd, seg_gamma, seg_beta, GROUPS, dcolour, w2, conv_b, gate,
-                                             out=(ow, ob, og))
         osw, osg, osb = _gout(seg_w), _gout(seg_gamma), _gout(seg_beta)
-        dy, dgamma, dbeta, _ = hip.gn_relu_bwd_proj(y, seg_gamma, seg_beta, mean, rstd, GROUPS, dcolour, w2, False,
-                                                    out=(osg, osb, None), gate=gate)
+        fused = hip.conv1x1_gn_bwd_fused(y, seg_gamma, seg_beta, mean, rstd, GROUPS, dcolour, w2, conv_b, gate, False,
+                                         out_gn=(osg, osb, None), out_conv=(ow, ob, og))
+        if fused is not None:
+            dy, (dgamma, dbeta, _), (dw, db, dgate) = fused
+        else:
+            dw, db, dgate = hip.conv1x1_gn_wgrad(y, mean, rstd, seg_gamma, seg_beta, GROUPS, dcolour, w2, conv_b, gate,
+                                                 out=(ow, ob, og))
+            dy, dgamma, dbeta, _ = hip.gn_relu_bwd_proj(y, seg_gamma, seg_beta, mean, rstd, GROUPS, dcolour, w2, False,
+                                                        out=(osg, osb, None), gate=gate)
         dsw = _wgrad(lambda: hip.conv3x3_wgrad(x, dy, out=osw), osw, x, dy)
         dx = hip.conv3x3_dgrad(dy, seg_w) if ctx.needs_input_grad[0] else None
         return (dx, _ret(osw, dsw), _ret(osg, dgamma), _ret(osb, dbeta), _ret(ow, dw.view(conv_w.shape)), _ret(ob, db),
@@ -424,9 +429,20 @@ class DecoderFn(torch.autograd.Function):
         gow, gob = _gout(ow), _gout(ob)
         ow2 = ow.detach().view(ow.shape[0], -1)
         g = g.contiguous()
+        head = None
         if ctx.fused_head:
+            # norm backward, the conv's data gradient (formed on load) and its weight gradient behind ONE pass over y
             _, y3, mean3, rstd3 = ctx.saved[3]
-            dow, dob, _ = hip.conv1x1_gn_wgrad(y3, mean3, rstd3, params[14], params[15], GROUPS, g, out=(gow, gob, None))
+            o3 = (_gout(params[14]), _gout(params[15]), _gout(params[13]))
+            head = hip.conv1x1_gn_bwd_fused(y3, params[14], params[15], mean3, rstd3, GROUPS, g, ow2, ob, None, True,
+                                            out_gn=o3, out_conv=(gow, gob, None))
+            if head is None:
+                dow, dob, _ = hip.conv1x1_gn_wgrad(y3, mean3, rstd3, params[14], params[15], GROUPS, g,
+                                                   out=(gow, gob, None))
+                head = hip.gn_relu_bwd_proj(y3, params[14], params[15], mean3, rstd3, GROUPS, g, ow2, True, out=o3)
+                head = (head[0], head[1:], None)
+            else:
+                dow, dob = head[2][0], head[2][1]
             da = None
         else:
             da, dow, dob, _ = hip.conv1x1_bwd(ctx.last, g, ow2, ob, out=(gow, gob, None))
@@ -435,11 +451,11 @@ class DecoderFn(torch.autograd.Function):
         for l in reversed(range(4)):
             w, b, gamma, beta = params[4 * l:4 * l + 4]
             h, y, mean, rstd = ctx.saved[l]
-            ow, obias, og, ob = _gout(w), _gout(b), _gout(gamma), _gout(beta)
             if l == 3 and ctx.fused_head:
-                dy, dgamma, dbeta, dbias = hip.gn_relu_bwd_proj(y, gamma, beta, mean, rstd, GROUPS, g, ow2, True,
-                                                                out=(og, ob, obias))
+                ow, (og, ob, obias) = _gout(w), o3
+                dy, (dgamma, dbeta, dbias) = head[0], head[1]
             else:
+                ow, obias, og, ob = _gout(w), _gout(b), _gout(gamma), _gout(beta)
                 dy, dgamma, dbeta, dbias = hip.gn_relu_bwd(y, gamma, beta, mean, rstd, GROUPS, (da, 0, 0), None, True,
                                                            out=(og, ob, obias))
             dw = _wgrad(lambda h=h, dy=dy, ow=ow: hip.deconv5x5s2_wgrad(h, dy, out=ow), ow, h, dy)

@@ -650,7 +650,34 @@ def conv1x1_gn_wgrad(y_pre, mean, rstd, gamma, beta, groups, g_out, w=None, bias
     return dw, db, dgate
 
 
-def gn_relu_bwd_proj(y, gamma, beta, mean, rstd, groups, g_out, w, want_dbias=False, out=None, gate=None):
+def conv1x1_gn_bwd_fused(y, gamma, beta, mean, rstd, groups, g_out, w, bias, gate=None, want_dbias=False,
+                         out_gn=None, out_conv=None):
+    """Whole backward of gate * conv1x1(relu(gn(y))) behind ONE pass over y: dy, the norm's (dgamma, dbeta, dbias) and
+    the conv's (dw, db, dgate).  out_gn = (dgamma, dbeta, dbias), out_conv = (dw, db, dgate) destinations or None.
+    Returns None when the shape is not supported by the fused kernel (use gn_relu_bwd_proj + conv1x1_gn_wgrad)."""
+    N, C, H, W = y.shape
+    Cout = int(g_out.shape[1])
+    if not _lib.query('gx_gn_relu_bwd_proj_fuses_wgrad', C, H, W, groups, Cout):
+        return None
+    wpart = torch.empty(N, Cout, C, dtype=F32, device=y.device)
+    bpart = torch.empty(N, Cout, dtype=F32, device=y.device)
+    dy, dgamma, dbeta, dbias = gn_relu_bwd_proj(y, gamma, beta, mean, rstd, groups, g_out, w, want_dbias, out_gn, gate,
+                                                parts=(wpart, bpart))
+    o = out_conv or (None, None, None)
+    dw = o[0] if o[0] is not None else torch.empty(Cout, C, dtype=F32, device=y.device)
+    db = o[1] if o[1] is not None else torch.empty(Cout, dtype=F32, device=y.device)
+    dgate = (o[2] if o[2] is not None else torch.empty((), dtype=F32, device=y.device)) if gate is not None else None
+    _chk(dw, 'conv1x1_gn_bwd.dw'); _chk(db, 'conv1x1_gn_bwd.db'); _chk(dgate, 'conv1x1_gn_bwd.dgate')
+    assert dw.numel() == Cout * C and db.numel() == Cout
+    nb = _lib.query('gx_conv1x1_gn_wgrad_finish_ws_bytes', C, Cout)
+    ws = _ws(nb, y.device)
+    _lib.call('gx_conv1x1_gn_wgrad_finish', _p(wpart), _p(bpart), N, C, Cout, _p(w), _p(bias), _p(gate), _p(dw), _p(db),
+              _p(dgate), _p(ws), nb, _stream())
+    return dy, (dgamma, dbeta, dbias), (dw, db, dgate)
+
+
+def gn_relu_bwd_proj(y, gamma, beta, mean, rstd, groups, g_out, w, want_dbias=False, out=None, gate=None,
+                     parts=(None, None)):
     """gn_relu_bwd whose incoming gradient is the data gradient of a following 1x1 conv (weight w [Cout,C], output
     gradient g_out [N,Cout,H,W]), formed on load."""
     _chk(y, 'gn_bwd_proj.y'); _chk(g_out, 'gn_bwd_proj.g'); _chk(w, 'gn_bwd_proj.w')
@@ -665,7 +692,7 @@ def gn_relu_bwd_proj(y, gamma, beta, mean, rstd, groups, g_out, w, want_dbias=Fa
     direct = o[0] is not None and o[1] is not None and (not want_dbias or o[2] is not None)
     with _deferring(direct, ws):
         _lib.call('gx_gn_relu_bwd_proj', _p(y), _p(gamma), _p(beta), _p(mean), _p(rstd), N, C, H, W, groups,
-                  _p(g_out), int(g_out.shape[1]), _p(w), _p(gate), _p(dy), _p(dgamma), _p(dbeta), _p(dbias), _p(ws),
-                  nb, _stream())
+                  _p(g_out), int(g_out.shape[1]), _p(w), _p(gate), _p(dy), _p(dgamma), _p(dbeta), _p(dbias),
+                  _p(parts[0]), _p(parts[1]), _p(ws), nb, _stream())
     return dy, dgamma, dbeta, dbias
 

@@ -79,8 +79,12 @@ int gx_gn_relu_bwd(const float* y, const float* gamma, const float* beta, const 
                    float* dbias, void* ws, size_t ws_bytes, gx_stream_t stream);
 int gx_gn_relu_bwd_proj(const float* y, const float* gamma, const float* beta, const float* mean, const float* rstd,
                         int N, int C, int H, int W, int groups, const float* g_out, int Cout, const float* w,
-                        const float* gate, float* dy, float* dgamma, float* dbeta, float* dbias, void* ws,
-                        size_t ws_bytes, gx_stream_t stream);
+                        const float* gate, float* dy, float* dgamma, float* dbeta, float* dbias, float* wpart,
+                        float* bpart, void* ws, size_t ws_bytes, gx_stream_t stream);
+/*      wpart [N,Cout,C] / bpart [N,Cout] (both or neither; allowed when gx_gn_relu_bwd_proj_fuses_wgrad(...) != 0): the
+ *      kernel also emits the per-image partials of the 1x1 conv's weight / bias gradient (its input exists only inside
+ *      this kernel); gx_conv1x1_gn_wgrad_finish sums them over the images -- no separate weight-gradient pass over y. */
+int gx_gn_relu_bwd_proj_fuses_wgrad(int C, int H, int W, int groups, int Cout);
 
 /* ---- Instance-Colouring stick-breaking attention: modules/attention.py:162-226.
  *      colour [B,C<=8,H,W]; log_sigma: device pointer to the fp64 0-dim parameter; rand_pixel [B,1,H,W];
@@ -137,6 +141,10 @@ int gx_conv1x1_gn_wgrad(const float* y_pre, const float* mean, const float* rstd
                         const float* beta, int groups, const float* g_out, const float* w, const float* bias,
                         const float* gate, int N, int Cin, int Cout, int H, int W, float* dw, float* db,
                         float* dgate, void* ws, size_t ws_bytes, gx_stream_t stream);
+size_t gx_conv1x1_gn_wgrad_finish_ws_bytes(int Cin, int Cout);
+int gx_conv1x1_gn_wgrad_finish(const float* wpart, const float* bpart, int N, int Cin, int Cout, const float* w,
+                               const float* bias, const float* gate, float* dw, float* db, float* dgate, void* ws,
+                               size_t ws_bytes, gx_stream_t stream);
 
 /* ---- optimiser side of the training step.
  *      gx_adam_step: torch.optim.Adam update (train.py:174-175,263) on flat buffers p/g/m/v of n elements

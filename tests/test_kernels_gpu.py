@@ -621,6 +621,14 @@ def test_conv1x1_on_unmaterialised_groupnorm(N, C, Cout, S, groups):
     close(dgamma, gr.grad, 1e-4, 1e-4, 'dgamma')
     close(dbeta, br.grad, 1e-4, 1e-4, 'dbeta')
     close(dbias, yr.grad.sum((0, 2, 3)), 1e-4, 1e-4, 'dbias')
+    fused = hip.conv1x1_gn_bwd_fused(yd, gd, bd, mean, rstd, groups, gg, wd, bbd, None, True)
+    if S * S * Cout * 4 <= 128 * 1024 and S * S >= 256:
+        assert fused is not None                       # one pass over y: norm backward + conv weight gradient
+    if fused is not None:
+        dy2, (dgamma2, dbeta2, dbias2), (dw2, db2, _) = fused
+        assert torch.equal(dy2, dy) and torch.equal(dgamma2, dgamma) and torch.equal(dbias2, dbias)
+        close(dw2, wr.grad, 1e-4, 1e-4, 'dw (fused)')
+        close(db2, bbr.grad, 1e-4, 1e-4, 'db (fused)')
 
 
 def test_gated_conv1x1_on_unmaterialised_groupnorm():
@@ -650,3 +658,10 @@ def test_gated_conv1x1_on_unmaterialised_groupnorm():
     close(dy, yr.grad, 1e-4, 1e-5, 'dy')
     close(dgamma, gr.grad, 1e-4, 1e-4, 'dgamma')
     close(dbeta, br.grad, 1e-4, 1e-4, 'dbeta')
+    fused = hip.conv1x1_gn_bwd_fused(yd, gd, bd, mean, rstd, groups, gg, wd, bbd, gtd, False)
+    assert fused is not None
+    dy2, (dgamma2, dbeta2, _), (dw2, db2, dgate2) = fused
+    assert torch.equal(dy2, dy) and torch.equal(dbeta2, dbeta)
+    close(dw2, wr.grad, 1e-4, 1e-4, 'dw (fused)')
+    close(db2, bbr.grad, 1e-4, 1e-4, 'db (fused)')
+    close(dgate2, gtr.grad, 1e-4, 1e-4, 'dgate (fused)')
