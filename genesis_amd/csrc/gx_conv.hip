@@ -84,6 +84,9 @@ struct ConvGeom {
     int chunks_per_split;
     int act;          // epilogue activation after the bias: 0 none, 1 ReLU, 2 ELU (applied only when nsplit == 1)
     const float* zeros;   // zero page for the LDS-DMA staging path (NULL: stage through registers)
+    float* stats;         // STATS kernels: per-workgroup (sum, sum of squares) of every 8-channel block of the output,
+                          // [N][stats_parts][M/8][2] (GroupNorm statistics without a pass over the output)
+    int stats_parts;      // workgroups per image = tiles_h * tiles_w * row parities
 };
 
 __device__ __forceinline__ float gx_act(float v, int act) {
@@ -95,7 +98,7 @@ __device__ __forceinline__ float gx_act(float v, int act) {
 // NPOS = halo-tile positions staged per thread per channel (tile <= NPOS*256 floats per channel).
 // MW = waves along M: 1 -> the 4 waves tile 256 pixels (64 each) and all 64 channels; 2 -> a 128-pixel tile, waves 2 x 2
 // (32 channels x 64 pixels each): twice the workgroups for grids that cannot fill the chip with 256-pixel tiles.
-template <int MODE, int NPOS, bool DMA, int MW = 1>
+template <int MODE, int NPOS, bool DMA, int MW = 1, bool STATS = false>
 __device__ __forceinline__ void tapconv_body(const float* __restrict__ in, const float* __restrict__ wp,
                                              const float* __restrict__ bias, float* __restrict__ out,
                                              const ConvGeom& g, float* lds, const int bx, const int by, const int bz,
@@ -297,6 +300,30 @@ __device__ __forceinline__ void tapconv_body(const float* __restrict__ in, const
     float* outz = out + (size_t)bz * g.N * out_img_stride;   // partial slab when nsplit > 1
     const bool add_bias = bias != nullptr && g.nsplit == 1;
     const int act = g.nsplit == 1 ? g.act : 0;
+    static_assert(!STATS || (MW == 1 && NCLS == 2), "output statistics: full 64-channel workgroups of the deconv only");
+    float st_s[STATS ? MI * 4 : 1], st_q[STATS ? MI * 4 : 1];   // per 8-channel block (mi, reg >> 2): sum, sum of squares
+    if (STATS) {
+#pragma unroll
+        for (int i = 0; i < MI * 4; ++i) { st_s[i] = 0.f; st_q[i] = 0.f; }
+    }
+    // the lane's 4-channel runs of the bias, loaded once (the channel index does not depend on the pixel block)
+    f32x4 bvec[MI][4];
+    {
+        const bool vec_ok = add_bias && (reinterpret_cast<uintptr_t>(bias) & 15) == 0;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int mb = m0 + (mi + wm) * 32 + 8 * q + 4 * (lane >> 5);
+                f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                if (vec_ok && mb + 3 < g.M) t = *reinterpret_cast<const f32x4*>(bias + mb);
+                else if (add_bias) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = mb + e < g.M ? bias[mb + e] : 0.f;
+                }
+                bvec[mi][q] = t;
+            }
+    }
 #pragma unroll
     for (int nj = 0; nj < 2; ++nj) {
         const int p = wn * 64 + nj * 32 + (lane & 31);
@@ -315,17 +342,64 @@ __device__ __forceinline__ void tapconv_body(const float* __restrict__ in, const
             for (int reg = 0; reg < 16; ++reg) {
                 const int m = m0 + (mi + wm) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
                 if (m < g.M) {
-                    const float bv = add_bias ? bias[m] : 0.f;
+                    const float bv = bvec[mi][reg >> 2][reg & 3];
                     if (NCLS == 2) {
                         float2 v;
                         v.x = gx_act(acc[0][mi][nj][reg] + bv, act);
                         v.y = gx_act(acc[NCLS - 1][mi][nj][reg] + bv, act);
                         *reinterpret_cast<float2*>(obase + (size_t)m * HoWo) = v;
+
                     } else {
                         obase[(size_t)m * HoWo] = gx_act(acc[0][mi][nj][reg] + bv, act);
                     }
                 }
             }
+        }
+    }
+    if constexpr (STATS) {
+        // (a second walk over the accumulators, after the stores: the store loop stays the plain kernel's)
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) {
+            const int p = wn * 64 + nj * 32 + (lane & 31);
+            const int c = p & (TW - 1);
+            const int r = (p >> g.lTW) & (TH - 1);
+            const bool ok = img0 + (p >> (g.lTW + g.lTH)) < g.N && R0 + r < g.Hb && C0 + c < g.Wb;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int m = m0 + (mi + wm) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                    const float bv = bvec[mi][reg >> 2][reg & 3];
+                    const float vx = (ok && m < g.M) ? acc[0][mi][nj][reg] + bv : 0.f;
+                    const float vy = (ok && m < g.M) ? acc[NCLS - 1][mi][nj][reg] + bv : 0.f;
+                    st_s[mi * 4 + (reg >> 2)] += vx + vy;
+                    st_q[mi * 4 + (reg >> 2)] += vx * vx + vy * vy;
+                }
+        }
+        // all 256 threads hold the same 8 channel blocks (x their own pixels): transpose through LDS (the tiles are
+        // dead by now) so that 16 threads own each of the 16 values, then a 16-lane sum; fixed order throughout
+        static_assert(!STATS || MI * 4 == 8, "8 channel blocks per workgroup");
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { lds[i * 256 + tid] = st_s[i]; lds[(8 + i) * 256 + tid] = st_q[i]; }
+        __syncthreads();
+        const int vi = tid >> 4, sub = tid & 15;
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x4 r = *reinterpret_cast<const f32x4*>(lds + vi * 256 + sub * 16 + 4 * k);
+            v += (r[0] + r[1]) + (r[2] + r[3]);
+        }
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 1, 64);
+        if (sub == 0) {
+            const int part = (th_i * g.tiles_w + tw_i) * 2 + par_a;
+            const int nblk = g.M >> 3;
+            const int blk = (m0 >> 3) + (vi & 7);
+            if (blk < nblk && img0 < g.N)
+                g.stats[(((size_t)img0 * g.stats_parts + part) * nblk + blk) * 2 + (vi >> 3)] = v;
         }
     }
 }
@@ -341,15 +415,37 @@ tapconv_kernel(const float* __restrict__ in, const float* __restrict__ wp,
 // Both output-row parities of the transposed conv in one launch: blockIdx.y = 2 * channel_tile + parity.  Twice
 // the workgroups of a single-parity launch, so mid-sized layers fill the chip without splitting the channel
 // reduction (and without the partial-sum traffic and reduce pass that come with it).
-template <int NPOS, bool DMA, int MW = 1>
+template <int NPOS, bool DMA, int MW = 1, bool STATS = false>
 __global__ void __launch_bounds__(256, 2)
 tapconv_dt_kernel(const float* __restrict__ in, const float* __restrict__ wp0, const float* __restrict__ wp1,
                   const float* __restrict__ bias, float* __restrict__ out, ConvGeom g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (blockIdx.y & 1)
-        tapconv_body<M_DT1, NPOS, DMA, MW>(in, wp1, bias, out, g, lds, blockIdx.x, blockIdx.y >> 1, blockIdx.z, 1);
+        tapconv_body<M_DT1, NPOS, DMA, MW, STATS>(in, wp1, bias, out, g, lds, blockIdx.x, blockIdx.y >> 1, blockIdx.z, 1);
     else
-        tapconv_body<M_DT0, NPOS, DMA, MW>(in, wp0, bias, out, g, lds, blockIdx.x, blockIdx.y >> 1, blockIdx.z, 0);
+        tapconv_body<M_DT0, NPOS, DMA, MW, STATS>(in, wp0, bias, out, g, lds, blockIdx.x, blockIdx.y >> 1, blockIdx.z, 0);
+}
+
+// GroupNorm statistics from the per-workgroup block sums the STATS epilogue wrote: stats [N][parts][nblk][2],
+// group g of image n = blocks [g*bpg, (g+1)*bpg); fp64 from here on, fixed order.
+__global__ void __launch_bounds__(64)
+gn_stats_finalize_kernel(const float* __restrict__ stats, int N, int groups, int parts, int nblk, int bpg, double m,
+                         float eps, float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * groups) return;
+    const int n = i / groups, g = i - n * groups;
+    double s = 0.0, q = 0.0;
+    for (int p = 0; p < parts; ++p)
+        for (int b = 0; b < bpg; ++b) {
+            const float* e = stats + (((size_t)n * parts + p) * nblk + g * bpg + b) * 2;
+            s += (double)e[0];
+            q += (double)e[1];
+        }
+    const double mean = s / m;
+    double var = q / m - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mean_out[i] = (float)mean;
+    rstd_out[i] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
 // out[i] = sum_z part[z][i] (+ bias[channel]); fixed summation order.
@@ -994,6 +1090,8 @@ int plan_tapconv(int N, int K, int M, int Mpad_pack, int Hb, int Wb, int Hi, int
     g.tiles_h = gx_ceil_div(Hb, TH); g.tiles_w = gx_ceil_div(Wb, TW);
     g.act = 0;
     g.zeros = nullptr;
+    g.stats = nullptr;
+    g.stats_parts = 0;
     const int CHS = TC::PLANES * G * (TH + 2) * (TW + 2);
     const int need = gx_ceil_div(CHS, 256);
     const int lo = (MODE == M_DG) ? 8 : 2;
@@ -1060,16 +1158,17 @@ void launch_tapconv_inst(const float* in, const float* wp, const float* bias, fl
     else launch_tapconv_inst2<MODE, NPOS, false>(in, wp, bias, out, g, pl.grid, pl.lds_bytes, s);
 }
 
-template <int NPOS, bool DMA, int MW = 1>
+template <int NPOS, bool DMA, int MW = 1, bool STATS = false>
 void launch_dt(dim3 grid, size_t lds_bytes, hipStream_t s, const float* x, const float* wp0, const float* wp1,
                const float* bias, float* dst, const ConvGeom& g) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_dt_kernel<NPOS, DMA, MW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_dt_kernel<NPOS, DMA, MW, STATS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((tapconv_dt_kernel<NPOS, DMA, MW>), grid, dim3(256), lds_bytes, s, x, wp0, wp1, bias, dst, g);
+    hipLaunchKernelGGL((tapconv_dt_kernel<NPOS, DMA, MW, STATS>), grid, dim3(256), lds_bytes, s, x, wp0, wp1, bias,
+                       dst, g);
 }
 
 // `dst` = final output when nsplit == 1, else the partial slabs [nsplit][N,M,Ho,Wo]
@@ -1733,7 +1832,7 @@ size_t gx_deconv5x5s2_ws_bytes(int N, int Cin, int Cout, int Hin, int Win) {
 
 static int deconv_fwd_impl(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int Cout,
                            int Hin, int Win, void* ws, size_t ws_bytes, gx_stream_t stream, const float** parts_out,
-                           int* nsplit_out);
+                           int* nsplit_out, float* stats = nullptr, int* stats_parts_out = nullptr);
 
 int gx_deconv5x5s2_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int Cout,
                        int Hin, int Win, void* ws, size_t ws_bytes, gx_stream_t stream) {
@@ -1748,9 +1847,44 @@ int gx_deconv5x5s2_fwd_parts(const float* x, const float* w, float* y, int N, in
     return deconv_fwd_impl(x, w, nullptr, y, N, Cin, Cout, Hin, Win, ws, ws_bytes, stream, parts, nsplit);
 }
 
+// upper bound of the epilogue-statistics scratch: one (sum, sumsq) pair per 8-channel block per 128-pixel tile per parity
+static size_t deconv_stats_floats(int N, int Cout, int Hin, int Win) {
+    return (size_t)N * (size_t)(gx_ceil_div(Hin * Win, 128) * 2 + 2) * (size_t)gx_ceil_div(Cout, 8) * 2;
+}
+
+size_t gx_deconv5x5s2_gn_stats_ws_bytes(int N, int Cin, int Cout, int Hin, int Win) {
+    return gx_deconv5x5s2_ws_bytes(N, Cin, Cout, Hin, Win) + deconv_stats_floats(N, Cout, Hin, Win) * sizeof(float);
+}
+
+int gx_deconv5x5s2_gn_stats_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int Cout,
+                                int Hin, int Win, int groups, float eps, float* mean, float* rstd, int* fused,
+                                void* ws, size_t ws_bytes, gx_stream_t stream) {
+    GX_CHECK_ARG(mean && rstd && ws, "gx_deconv5x5s2_gn_stats_fwd: null pointer");
+    GX_CHECK_ARG(groups > 0 && Cout % groups == 0, "gx_deconv5x5s2_gn_stats_fwd: Cout %% groups != 0");
+    GX_CHECK_ARG(ws_bytes >= gx_deconv5x5s2_gn_stats_ws_bytes(N, Cin, Cout, Hin, Win),
+                 "gx_deconv5x5s2_gn_stats_fwd: workspace too small");
+    const size_t conv_ws = gx_deconv5x5s2_ws_bytes(N, Cin, Cout, Hin, Win);
+    float* stats = (float*)((char*)ws + conv_ws);
+    const int cpg = Cout / groups;
+    int parts = 0;
+    int rc = deconv_fwd_impl(x, w, bias, y, N, Cin, Cout, Hin, Win, ws, conv_ws, stream, nullptr, nullptr,
+                             (cpg % 8) == 0 ? stats : nullptr, &parts);
+    if (rc) return rc;
+    if (fused) *fused = parts > 0;
+    if (!parts) return GX_OK;          // the caller runs the stand-alone statistics pass (gx_gn_relu_fwd, dst0 = NULL)
+    {
+        GxProf pf(KID_SMALL_REDUCE, (hipStream_t)stream, 0.0, 8.0 * N * parts * (Cout / 8));
+        hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3(gx_ceil_div(N * groups, 64)), dim3(64), 0,
+                           (hipStream_t)stream, (const float*)stats, N, groups, parts, Cout / 8, cpg / 8,
+                           (double)cpg * 4.0 * Hin * Win, eps, mean, rstd);
+    }
+    GX_CHECK_LAUNCH("gx_deconv5x5s2_gn_stats_fwd(finalize)");
+    return GX_OK;
+}
+
 static int deconv_fwd_impl(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int Cout,
                            int Hin, int Win, void* ws, size_t ws_bytes, gx_stream_t stream, const float** parts_out,
-                           int* nsplit_out) {
+                           int* nsplit_out, float* stats, int* stats_parts_out) {
     int rc = check_dims("gx_deconv5x5s2_fwd", N, Cin, Cout, Hin, Win);
     if (rc) return rc;
     GX_CHECK_ARG(x && w && y && ws, "gx_deconv5x5s2_fwd: null pointer");
@@ -1778,6 +1912,7 @@ static int deconv_fwd_impl(const float* x, const float* w, const float* bias, fl
             p0 = p2;
     }
     float* dst = p0.g.nsplit > 1 ? part : y;
+    if (stats_parts_out) *stats_parts_out = 0;
     {
         const ConvGeom& g = p0.g;
         const double flops = 2.0 * g.N * (double)g.M * g.K * 25 * g.Hb * g.Wb;
@@ -1793,7 +1928,14 @@ static int deconv_fwd_impl(const float* x, const float* w, const float* bias, fl
             if (p0.npos == 2) launch_dt<2, false, 2>(grid, p0.lds_bytes, s, x, wpu0, wpu1, bias, dst, gg);
             else launch_dt<4, false, 2>(grid, p0.lds_bytes, s, x, wpu0, wpu1, bias, dst, gg);
         } else if (gg.zeros) {
-            if (p0.npos == 2) launch_dt<2, true>(grid, p0.lds_bytes, s, x, wpu0, wpu1, bias, dst, gg);
+            // output statistics in the epilogue: one image per tile, no channel split, 8-channel blocks
+            const bool st_ok = stats && p0.npos == 2 && gg.nsplit == 1 && gg.lG == 0 && (Cout % 8) == 0;
+            if (st_ok) {
+                gg.stats = stats;
+                gg.stats_parts = gg.tiles_h * gg.tiles_w * 2;
+                if (stats_parts_out) *stats_parts_out = gg.stats_parts;
+                launch_dt<2, true, 1, true>(grid, p0.lds_bytes, s, x, wpu0, wpu1, bias, dst, gg);
+            } else if (p0.npos == 2) launch_dt<2, true>(grid, p0.lds_bytes, s, x, wpu0, wpu1, bias, dst, gg);
             else launch_dt<4, true>(grid, p0.lds_bytes, s, x, wpu0, wpu1, bias, dst, gg);
         } else {
             if (p0.npos == 2) launch_dt<2, false>(grid, p0.lds_bytes, s, x, wpu0, wpu1, bias, dst, gg);

@@ -384,6 +384,8 @@ class MaskPoolFn(torch.autograd.Function):
 
 # last decoder stage without its normalised activation in memory (GENESIS_FUSE_DEC_HEAD=0: the unfused kernels)
 FUSE_DECODER_HEAD = __import__('os').environ.get('GENESIS_FUSE_DEC_HEAD', '1') == '1'
+# its GroupNorm statistics out of the transposed conv's epilogue instead of a statistics-only pass over the output
+EPILOGUE_STATS = __import__('os').environ.get('GENESIS_DECONV_STATS', '1') == '1'
 
 
 class DecoderFn(torch.autograd.Function):
@@ -405,7 +407,10 @@ class DecoderFn(torch.autograd.Function):
         for l in range(4):
             w, b, gamma, beta = params[4 * l:4 * l + 4]
             if l == 3 and ctx.fused_head:
-                y, mean, rstd = hip.deconv5x5s2_gn_relu_fwd(h, w, b, gamma, beta, GROUPS, EPS, None)
+                if EPILOGUE_STATS:
+                    y, mean, rstd = hip.deconv5x5s2_gn_stats_fwd(h, w, b, gamma, beta, GROUPS, EPS)
+                else:
+                    y, mean, rstd = hip.deconv5x5s2_gn_relu_fwd(h, w, b, gamma, beta, GROUPS, EPS, None)
                 saved.append((h, y, mean, rstd))
                 out = hip.conv1x1_gn_fwd(y, mean, rstd, gamma, beta, GROUPS, ow2, ob)
                 h = None

@@ -224,6 +224,27 @@ def deconv5x5s2_gn_relu_fwd(x, w, bias, gamma, beta, groups, eps, dst0, dst1=Non
     return _conv_gn('deconv', x, w, bias, gamma, beta, groups, eps, dst0, dst1)
 
 
+def deconv5x5s2_gn_stats_fwd(x, w, bias, gamma, beta, groups, eps):
+    """ConvTranspose2d(k5,s2,p2,op1) + bias and the GroupNorm statistics of its output (the normalised tensor itself
+    is never written: conv1x1_gn_fwd consumes y).  The statistics come out of the conv epilogue when the shape is
+    eligible, else from a statistics-only pass over y."""
+    _chk(x, 'deconv_stats.x'); _chk(w, 'deconv_stats.w'); _chk(bias, 'deconv_stats.bias')
+    N, Cin, H, W = x.shape
+    Cout = w.shape[1]
+    assert w.shape[0] == Cin and w.shape[2:] == (5, 5)
+    y = torch.empty(N, Cout, 2 * H, 2 * W, dtype=F32, device=x.device)
+    mean = torch.empty(N * groups, dtype=F32, device=x.device)
+    rstd = torch.empty(N * groups, dtype=F32, device=x.device)
+    nb = _lib.query('gx_deconv5x5s2_gn_stats_ws_bytes', N, Cin, Cout, H, W)
+    ws = _ws(nb, x.device)
+    fused = ctypes.c_int(0)
+    _lib.call('gx_deconv5x5s2_gn_stats_fwd', _p(x), _p(w), _p(bias), _p(y), N, Cin, Cout, H, W, groups, float(eps),
+              _p(mean), _p(rstd), ctypes.byref(fused), _p(ws), nb, _stream())
+    if not fused.value:
+        mean, rstd = gn_relu_fwd(y, gamma, beta, groups, eps, None)
+    return y, mean, rstd
+
+
 def gn_relu_bwd(y, gamma, beta, mean, rstd, groups, g0, g1=None, want_dbias=False, out=None):
     """out = (dgamma, dbeta, dbias) preallocated [C] buffers (entries may be None) to write into."""
     _chk(y, 'gn_bwd.y')

@@ -51,6 +51,14 @@ int gx_conv3x3_wgrad(const float* x, const float* dy, float* dw, int N, int Cin,
 size_t gx_deconv5x5s2_ws_bytes(int N, int Cin, int Cout, int Hin, int Win);
 int gx_deconv5x5s2_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int Cout,
                        int Hin, int Win, void* ws, size_t ws_bytes, gx_stream_t stream);
+/*      Forward + the GroupNorm statistics of its output (mean, rstd [N*groups], as gx_gn_relu_fwd with dst0 == NULL
+ *      would compute them) without a pass over y: the conv epilogue sums every 8-channel block per workgroup, a tiny
+ *      kernel finishes in fp64.  *fused = 0 (shape not eligible: channel split, several images per tile, groups not
+ *      multiples of 8 channels): y is written, mean / rstd are NOT -- run gx_gn_relu_fwd(dst0 = NULL). */
+size_t gx_deconv5x5s2_gn_stats_ws_bytes(int N, int Cin, int Cout, int Hin, int Win);
+int gx_deconv5x5s2_gn_stats_fwd(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int Cout,
+                                int Hin, int Win, int groups, float eps, float* mean, float* rstd, int* fused,
+                                void* ws, size_t ws_bytes, gx_stream_t stream);
 int gx_deconv5x5s2_dgrad(const float* dy, const float* w, float* dx, int N, int Cin, int Cin_out, int Cout,
                          int Hin, int Win, void* ws, size_t ws_bytes, gx_stream_t stream);
 size_t gx_deconv5x5s2_wgrad_ws_bytes(int N, int Cin, int Cout, int Hin, int Win);

@@ -665,3 +665,23 @@ def test_gated_conv1x1_on_unmaterialised_groupnorm():
     close(dw2, wr.grad, 1e-4, 1e-4, 'dw (fused)')
     close(db2, bbr.grad, 1e-4, 1e-4, 'db (fused)')
     close(dgate2, gtr.grad, 1e-4, 1e-4, 'dgate (fused)')
+
+
+@pytest.mark.parametrize('N,Cin,Cout,Hin', [(9, 64, 64, 32), (3, 64, 64, 16), (2, 66, 64, 4), (5, 32, 16, 32)])
+def test_deconv_epilogue_groupnorm_statistics(N, Cin, Cout, Hin):
+    """Transposed conv whose epilogue also produces the GroupNorm statistics of its output (or, for shapes the
+    epilogue path does not take, a statistics-only pass): same y, mean / rstd as F.group_norm's."""
+    groups = 8
+    x = rnd(N, Cin, Hin, Hin, seed=51)
+    w = rnd(Cin, Cout, 5, 5, seed=52, scale=0.05)
+    b = rnd(Cout, seed=53, scale=0.3)
+    gamma, beta = 1 + 0.2 * rnd(Cout, seed=54), 0.1 * rnd(Cout, seed=55)
+    ref = F.conv_transpose2d(x, w, b, 2, 2, 1)
+    y, mean, rstd = hip.deconv5x5s2_gn_stats_fwd(x.to(DEV), w.to(DEV), b.to(DEV), gamma.to(DEV), beta.to(DEV), groups, 1e-5)
+    close(y, ref, 2e-5, 2e-5, 'y')
+    rg = ref.double().view(N, groups, -1)
+    np.testing.assert_allclose(mean.cpu().double().numpy(), rg.mean(2).flatten().numpy(), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(rstd.cpu().double().numpy(), (rg.var(2, unbiased=False) + 1e-5).rsqrt().flatten().numpy(),
+                               rtol=2e-5)
+    y2 = hip.deconv5x5s2_fwd(x.to(DEV), w.to(DEV), b.to(DEV))
+    assert torch.equal(y, y2)
