@@ -32,7 +32,7 @@ enum GxKernelId {
     KID_WGRAD_C3, KID_WGRAD_D00, KID_WGRAD_D01, KID_WGRAD_D10, KID_WGRAD_D11, KID_WGRAD_REDUCE,
     KID_GN_FWD, KID_GN_BWD, KID_GN_PARAM_REDUCE, KID_ICSBP_FWD, KID_ICSBP_BWD, KID_MASKPOOL_FWD,
     KID_MASKPOOL_BWD, KID_MIXTURE_FWD, KID_MIXTURE_BWD, KID_CONV1X1_FWD, KID_CONV1X1_DGRAD,
-    KID_CONV1X1_WGRAD, KID_SMALL_REDUCE, KID_ADAM, KID_GECO, KID_SPLITK_REDUCE, KID_BIAS_ACT_BWD, KID_DCONV, KID_GATED, KID_LATENT, KID_DENSE, KID_COUNT
+    KID_CONV1X1_WGRAD, KID_SMALL_REDUCE, KID_ADAM, KID_GECO, KID_SPLITK_REDUCE, KID_BIAS_ACT_BWD, KID_DCONV, KID_GATED, KID_LATENT, KID_DENSE, KID_WINO, KID_COUNT
 };
 extern bool g_gx_prof_on;
 void gx_prof_begin(int kid, hipStream_t s, double flops, double bytes);
@@ -78,3 +78,37 @@ __device__ __forceinline__ float gx_wave_max(float v) {
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
     return v;
 }
+
+// ---- Winograd F(2x2,3x3) weight operand (gx_wino.hip; also produced by the packed-weight cache of gx_conv.hip) ----
+// (G g G^T)[xi][nu], p = 4 xi + nu, for output channel m / reduction channel k.  mode 0: g = w[m][k] (forward);
+// mode 1: g = w[k][m] rotated by 180 degrees (data gradient).  w is [Co][Ci][3][3].
+__device__ __forceinline__ float gx_wino_u_value(const float* __restrict__ w, int mode, int Co, int Ci, int m, int k,
+                                                 int p) {
+    const int Mact = mode == 0 ? Co : Ci, Kact = mode == 0 ? Ci : Co;
+    if (m >= Mact || k >= Kact) return 0.f;
+    const int xi = p >> 2, nu = p & 3;
+    float t[3];   // row xi of G g
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        float g0, g1, g2;
+        if (mode == 0) {
+            const float* q = w + ((size_t)m * Ci + k) * 9 + b;
+            g0 = q[0]; g1 = q[3]; g2 = q[6];
+        } else {
+            const float* q = w + ((size_t)k * Ci + m) * 9 + (2 - b);
+            g0 = q[6]; g1 = q[3]; g2 = q[0];
+        }
+        t[b] = xi == 0 ? g0 : (xi == 1 ? 0.5f * (g0 + g1 + g2) : (xi == 2 ? 0.5f * (g0 - g1 + g2) : g2));
+    }
+    return nu == 0 ? t[0] : (nu == 1 ? 0.5f * (t[0] + t[1] + t[2]) : (nu == 2 ? 0.5f * (t[0] - t[1] + t[2]) : t[2]));
+}
+// position of U(p, k, m) in the conv kernel's operand order:
+// [m tile][chunk of 8 k][position][lane = 32 (k & 1) + (m & 31)][2 (k % 8 / 2) + ((m >> 5) & 1)]
+__host__ __device__ __forceinline__ size_t gx_wino_u_slot(int m, int k, int p, int Kpad) {
+    const size_t base = ((size_t)(m >> 6) * (Kpad >> 3) + (k >> 3)) * 16 + p;
+    return base * 512 + (size_t)(((((k & 1) << 5) | (m & 31)) << 3) | (((k & 7) >> 1) << 1) | ((m >> 5) & 1));
+}
+// conv with an already packed U (16 * Kpad * Mpad floats): out[N,M,H,W] from in[N,K,H,W]
+bool gx_wino_eligible(int N, int K, int M, int H, int W);
+int gx_wino_launch(const float* in, const float* U, float* out, int N, int K, int M, int H, int W, hipStream_t s);
+

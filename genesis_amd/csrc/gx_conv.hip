@@ -483,10 +483,16 @@ __device__ __forceinline__ float pack_weight_value(const float* __restrict__ w, 
     } else if (pack == 2 || pack == 3) {
         const int kh = 2 * (t / 5) + (pack - 2), kw = t % 5;
         if (m < Co && k < Ci) v = w[((size_t)k * Co + m) * 25 + kh * 5 + kw];
-    } else {
+    } else if (pack == 4) {
         if (m < Ci && k < Co) v = w[((size_t)m * Co + k) * 25 + t];
+    } else {   // 5 / 6: Winograd operands of the conv3x3 forward / data gradient (t = position)
+        v = gx_wino_u_value(w, pack - 5, Co, Ci, m, k, t);
     }
     return v;
+}
+// destination of element (t, k, m): [t][k][m] for the tap-conv kernels, the operand order of gx_wino.hip for packs 5 / 6
+__device__ __forceinline__ size_t pack_dest(int pack, int idx, int m, int k, int t, int Kpad) {
+    return pack >= 5 ? gx_wino_u_slot(m, k, t, Kpad) : (size_t)idx;
 }
 
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int pack,
@@ -496,7 +502,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
         const int m = idx % Mpad;
         const int k = (idx / Mpad) % Kpad;
         const int t = idx / (Mpad * Kpad);
-        wp[idx] = pack_weight_value(w, pack, Co, Ci, m, k, t);
+        wp[pack_dest(pack, idx, m, k, t, Kpad)] = pack_weight_value(w, pack, Co, Ci, m, k, t);
     }
 }
 
@@ -1229,7 +1235,7 @@ __global__ void pack_weights_batch_kernel(const PackEntry* __restrict__ entries)
         const int m = idx % e.Mpad;
         const int k = (idx / e.Mpad) % e.Kpad;
         const int t = idx / (e.Mpad * e.Kpad);
-        e.wp[idx] = pack_weight_value(e.w, e.pack, e.Co, e.Ci, m, k, t);
+        e.wp[pack_dest(e.pack, idx, m, k, t, e.Kpad)] = pack_weight_value(e.w, e.pack, e.Co, e.Ci, m, k, t);
     }
 }
 
@@ -1609,8 +1615,9 @@ extern "C" {
 
 // workspace = packed weights (+ split-K partial slabs when the plan splits the reduction)
 static size_t conv3x3_pack_floats(int Cin, int Cout) {
-    size_t f = (size_t)9 * gx_round_up(Cin, 8) * gx_round_up(Cout, 64);
-    size_t d = (size_t)9 * gx_round_up(Cout, 8) * gx_round_up(Cin, 64);
+    // 16 positions: room for the Winograd operands (gx_wino.hip) as well as the 9 taps
+    size_t f = (size_t)16 * gx_round_up(Cin, 8) * gx_round_up(Cout, 64);
+    size_t d = (size_t)16 * gx_round_up(Cout, 8) * gx_round_up(Cin, 64);
     return f > d ? f : d;
 }
 
@@ -1734,6 +1741,14 @@ static int conv3x3_fwd_impl(const float* x, const float* w, const float* bias, i
     float* part = wp + conv3x3_pack_floats(Cin, Cout);
     pl.g.act = act;
     const float* wpu;
+    if (!bias && act == 0 && gx_wino_eligible(N, Cin, Cout, H, W)) {   // Winograd F(2x2,3x3): 2.25x fewer MFMA passes
+        rc = launch_pack(w, wp, 5, Cout, Cin, 16, Kpad, Mpad, s, &wpu);
+        if (rc) return rc;
+        rc = gx_wino_launch(x, wpu, y, N, Cin, Cout, H, W, s);
+        if (rc) return rc;
+        if (parts_out) { *parts_out = y; *nsplit_out = 1; }
+        return GX_OK;
+    }
     rc = launch_pack(w, wp, 0, Cout, Cin, 9, Kpad, Mpad, s, &wpu);
     if (rc) return rc;
     rc = launch_tapconv<M_C3>(x, wpu, bias, pl.g.nsplit > 1 ? part : y, pl, s, "gx_conv3x3_fwd");
@@ -1761,6 +1776,11 @@ int gx_conv3x3_dgrad(const float* dy, const float* w, float* dx, int N, int Cin,
     float* wp = (float*)ws;
     float* part = wp + conv3x3_pack_floats(Cin, Cout);
     const float* wpu;
+    if (gx_wino_eligible(N, Cout, Cin, H, W)) {
+        rc = launch_pack(w, wp, 6, Cout, Cin, 16, Kpad, Mpad, s, &wpu);
+        if (rc) return rc;
+        return gx_wino_launch(dy, wpu, dx, N, Cout, Cin, H, W, s);
+    }
     rc = launch_pack(w, wp, 1, Cout, Cin, 9, Kpad, Mpad, s, &wpu);
     if (rc) return rc;
     rc = launch_tapconv<M_C3>(dy, wpu, nullptr, pl.g.nsplit > 1 ? part : dx, pl, s, "gx_conv3x3_dgrad");

@@ -1,0 +1,285 @@
+// 3x3 / stride 1 / pad 1 convolution by Winograd F(2x2, 3x3) on the fp32 matrix cores (modules/blocks.py:159-165,
+// modules/unet.py:33-57 -- the UNet's and the heads' conv layers at 32x32 and 64x64; forward and data gradient).
+//
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A      per 4x4 input patch d -> 2x2 outputs: 16 multiplies instead of 36,
+// i.e. 16 independent GEMMs  M_p[cout][tile] = sum_cin U_p[cout][cin] V_p[cin][tile]  (p = 4 xi + nu), 2.25x fewer
+// MFMA passes than the direct tap loop of gx_conv.hip.  fp32 throughout; the transforms only add / subtract (B, A) and
+// scale by 1/2, 1/4 (G), so the result differs from the direct sum by ordinary fp32 rounding (measured ~1e-6 relative).
+//
+// Workgroup = 64 output channels x (8 rows x 16 cols of output = 4 x 8 = 32 Winograd tiles) of one image, 4 waves;
+// wave xi owns the four positions (xi, 0..3): 4 positions x 64 channels x 32 tiles = 128 accumulator registers.
+// Per chunk of 8 input channels: the raw 10x18 halo patch is staged global -> registers -> LDS (prefetched during the
+// previous chunk's MFMAs; even / odd columns in separate planes so that the transform's stride-2 reads are
+// conflict-free); 256 threads = 8 channels x 32 tiles each transform their 4x4 patch (B^T d B: 32 adds) into V in
+// LDS (double-buffered: two barriers per chunk); then 32 MFMA 32x32x2 per wave.  The weight operands are NOT staged
+// in LDS: a wave only ever needs its own four positions, so U is packed per (channel tile, chunk, position, lane) and
+// each lane loads its 8 values per position with two 16-byte loads straight into the MFMA operand registers.
+// Epilogue: each wave reduces its row of positions over nu (A on the right), the four waves' rows are combined through
+// LDS (A^T on the left) and written as float2 pairs.
+#include <stdlib.h>
+
+#include "gx_common.h"
+
+namespace {
+
+constexpr int WKC = 8;                 // input channels per chunk
+constexpr int WTH = 4, WTW = 8;        // Winograd tiles per workgroup (rows x cols) -> 8 x 16 output pixels
+constexpr int WNT = WTH * WTW;         // 32 tiles = one MFMA N block
+constexpr int PR = 2 * WTH + 2, PC = 2 * WTW + 2;   // raw patch 10 x 18
+constexpr int PLANE = 10;              // floats per (row, column parity) plane row: 9 used; 4 * PLANE = 8 (mod 32)
+constexpr int PPITCH = PR * 2 * PLANE; // floats per channel of the raw patch (200)
+constexpr int RAW_FLOATS = WKC * PPITCH;            // 1600
+constexpr int V_FLOATS = 16 * WKC * WNT;            // 4096 per buffer, two buffers
+constexpr int RAW_PER_THREAD = (WKC * PR * PC + 255) / 256;   // 6
+
+struct WinoGeom {
+    int N, K, M;          // images, reduction channels, output channels
+    int Kpad, Mpad;       // packed weight dims (Kpad % 8 == 0, Mpad % 64 == 0)
+    int H, W;             // H % 8 == 0, W % 16 == 0
+    int tiles_h, tiles_w; // H / 8, W / 16
+};
+
+// U in the conv kernel's operand order (gx_common.h: gx_wino_u_value / gx_wino_u_slot)
+__global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ U, int mode, int Co, int Ci, int Kpad,
+                                 int Mpad) {
+    const int total = 16 * Kpad * Mpad;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int m = idx % Mpad, k = (idx / Mpad) % Kpad, p = idx / (Mpad * Kpad);
+        U[gx_wino_u_slot(m, k, p, Kpad)] = gx_wino_u_value(w, mode, Co, Ci, m, k, p);
+    }
+}
+
+__global__ void __launch_bounds__(256, 2)
+wino_conv_kernel(const float* __restrict__ in, const float* __restrict__ U, float* __restrict__ out, const WinoGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* raw = lds;                       // [WKC][PR][2][PLANE]
+    float* V = lds + RAW_FLOATS;            // [2][16][WKC][WNT]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    int tile = blockIdx.x;
+    const int tw_i = tile % g.tiles_w; tile /= g.tiles_w;
+    const int th_i = tile % g.tiles_h; tile /= g.tiles_h;
+    const int n = tile;
+    const int R0 = th_i * (2 * WTH), C0 = tw_i * (2 * WTW);
+    const int m0 = blockIdx.y * 64;
+    const int HW = g.H * g.W;
+    const float* in_n = in + (size_t)n * g.K * HW;
+    const int nchunks = g.Kpad / WKC;
+
+    // raw-patch staging slots of this thread: element e = tid + 256 q of [WKC][PR][PC], packed into one register each:
+    // bits 0..14 pixel offset r * W + c, bit 15 inside the image, bits 16..26 LDS offset, bits 27..29 channel, bit 30 used
+    int rinfo[RAW_PER_THREAD];
+#pragma unroll
+    for (int q = 0; q < RAW_PER_THREAD; ++q) {
+        const int e = tid + 256 * q;
+        int info = 0;
+        if (e < WKC * PR * PC) {
+            const int ch = e / (PR * PC), rem = e - ch * (PR * PC);
+            const int pr = rem / PC, pc = rem - pr * PC;
+            const int r = R0 - 1 + pr, c = C0 - 1 + pc;
+            info = (1 << 30) | (ch << 27) | ((ch * PPITCH + (pr * 2 + (pc & 1)) * PLANE + (pc >> 1)) << 16);
+            if (r >= 0 && r < g.H && c >= 0 && c < g.W) info |= (1 << 15) | (r * g.W + c);
+        }
+        rinfo[q] = info;
+    }
+    float rawr[RAW_PER_THREAD];
+    auto load_raw = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < RAW_PER_THREAD; ++q) {
+            float v = 0.f;
+            const int ch = (rinfo[q] >> 27) & 7;
+            if ((rinfo[q] & (1 << 15)) && k0 + ch < g.K) v = in_n[(size_t)(k0 + ch) * HW + (rinfo[q] & 0x7fff)];
+            rawr[q] = v;
+        }
+    };
+    // this wave's weight operands: [m tile][chunk][position 4 wave + nu][lane][8]
+    const float* Uw = U + (((size_t)blockIdx.y * nchunks) * 16 + 4 * wave) * 512 + lane * 8;
+
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    f32x16 acc[4][2];     // [nu][mi]: one 32x32 accumulator tile each
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[a][b][c] = 0.f;
+
+    // transform role: channel tk, tile (tty, ttx); patch element (i, j) sits at row 2 tty + i, column 2 ttx + j
+    const int tk = tid >> 5, tt = tid & 31;
+    const int tty = tt >> 3, ttx = tt & 7;
+    const float* tsrc = raw + tk * PPITCH + (2 * tty) * 2 * PLANE + ttx;
+
+    const int bn = lane & 31, kh = lane >> 5;
+
+    load_raw(0);
+    for (int c = 0; c < nchunks; ++c) {
+        float* Vc = V + (c & 1) * V_FLOATS;
+#pragma unroll
+        for (int q = 0; q < RAW_PER_THREAD; ++q)
+            if (rinfo[q] & (1 << 30)) raw[(rinfo[q] >> 16) & 0x7ff] = rawr[q];
+        // weight operands of this chunk: consumed after the transform, which hides their latency
+        f32x4 ua[4][2];
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) {
+            ua[nu][0] = *reinterpret_cast<const f32x4*>(Uw + ((size_t)c * 16 + nu) * 512);
+            ua[nu][1] = *reinterpret_cast<const f32x4*>(Uw + ((size_t)c * 16 + nu) * 512 + 4);
+        }
+        __syncthreads();                      // raw patch of chunk c complete
+        {
+            // V = B^T d B for this thread's (channel, tile); column j of the patch: plane (j & 1), index ttx + (j >> 1)
+            float d[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[i][j] = tsrc[(i * 2 + (j & 1)) * PLANE + (j >> 1)];
+            float t[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t[0][j] = d[0][j] - d[2][j];
+                t[1][j] = d[1][j] + d[2][j];
+                t[2][j] = d[2][j] - d[1][j];
+                t[3][j] = d[1][j] - d[3][j];
+            }
+            float* tdst = Vc + tk * WNT + tt;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                tdst[(4 * i + 0) * (WKC * WNT)] = t[i][0] - t[i][2];
+                tdst[(4 * i + 1) * (WKC * WNT)] = t[i][1] + t[i][2];
+                tdst[(4 * i + 2) * (WKC * WNT)] = t[i][2] - t[i][1];
+                tdst[(4 * i + 3) * (WKC * WNT)] = t[i][1] - t[i][3];
+            }
+        }
+        __syncthreads();                      // V of chunk c complete; the raw buffer is free again
+        if (c + 1 < nchunks) load_raw((c + 1) * WKC);   // flies during the MFMAs
+#pragma unroll
+        for (int kk = 0; kk < WKC / 2; ++kk) {
+            const int k = 2 * kk + kh;
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) {
+                const float b = Vc[((4 * wave + nu) * WKC + k) * WNT + bn];
+                const float a0 = ua[nu][kk >> 1][(kk & 1) * 2];
+                const float a1 = ua[nu][kk >> 1][(kk & 1) * 2 + 1];
+                acc[nu][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[nu][0], 0, 0, 0);
+                acc[nu][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[nu][1], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- output transform.  This wave holds M[xi][nu] (xi = wave): right-multiply by A -> two columns
+    //      q0 = M0 + M1 + M2, q1 = M1 - M2 - M3, exchanged through LDS; then Y[0][b] = q(xi=0) + q(1) + q(2),
+    //      Y[1][b] = q(1) - q(2) - q(3).  One 32-channel half (mi) at a time: E[xi][b][32 m][32 n] = 32 KB.
+    float* E = lds;
+    const size_t out_n = (size_t)n * g.M * HW;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        __syncthreads();
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = e + 8 * r4 + 4 * kh;      // C/D layout: row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+                const int rg = 4 * r4 + e;
+                const float q0 = acc[0][mi][rg] + acc[1][mi][rg] + acc[2][mi][rg];
+                const float q1 = acc[1][mi][rg] - acc[2][mi][rg] - acc[3][mi][rg];
+                E[((wave * 2 + 0) * 32 + row) * 32 + bn] = q0;
+                E[((wave * 2 + 1) * 32 + row) * 32 + bn] = q1;
+            }
+        __syncthreads();
+        // 1024 (m, tile) pairs, 4 per thread: thread -> tile = tid & 31, m = (tid >> 5) + 8 j
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ml = (tid >> 5) + 8 * j;
+            const int m = m0 + mi * 32 + ml;
+            if (m >= g.M) continue;
+            const int ty = tt >> 3, tx = tt & 7;
+            float q[4][2];
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi) {
+                q[xi][0] = E[((xi * 2 + 0) * 32 + ml) * 32 + tt];
+                q[xi][1] = E[((xi * 2 + 1) * 32 + ml) * 32 + tt];
+            }
+            float2 y0, y1;
+            y0.x = q[0][0] + q[1][0] + q[2][0];
+            y0.y = q[0][1] + q[1][1] + q[2][1];
+            y1.x = q[1][0] - q[2][0] - q[3][0];
+            y1.y = q[1][1] - q[2][1] - q[3][1];
+            float* o = out + out_n + (size_t)m * HW + (size_t)(R0 + 2 * ty) * g.W + C0 + 2 * tx;
+            *reinterpret_cast<float2*>(o) = y0;
+            *reinterpret_cast<float2*>(o + g.W) = y1;
+        }
+    }
+}
+
+}  // namespace
+
+static bool wino_shape_ok(int N, int K, int M, int H, int W) {
+    return N > 0 && K >= 16 && M >= 16 && H >= 8 && W >= 16 && (H % 8) == 0 && (W % 16) == 0 && H * W <= 32768;
+}
+
+// used by gx_conv3x3_fwd / _dgrad: Winograd where the shape allows it AND the grid fills the chip without a channel
+// split (under-filled layers stay on the direct kernels, which split the reduction).  GENESIS_WINOGRAD=0 disables.
+bool gx_wino_eligible(int N, int K, int M, int H, int W) {
+    static const char* env = getenv("GENESIS_WINOGRAD");
+    if (env && env[0] == '0') return false;
+    return wino_shape_ok(N, K, M, H, W) && N * (H / 8) * (W / 16) * gx_ceil_div(M, 64) >= 256;
+}
+
+int gx_wino_launch(const float* in, const float* U, float* out, int N, int K, int M, int H, int W, hipStream_t s) {
+    WinoGeom g;
+    g.N = N; g.H = H; g.W = W; g.K = K; g.M = M;
+    g.Kpad = gx_round_up(K, WKC);
+    g.Mpad = gx_round_up(M, 64);
+    g.tiles_h = H / (2 * WTH);
+    g.tiles_w = W / (2 * WTW);
+    static bool attr_set = false;
+    const size_t lds = (size_t)(RAW_FLOATS + 2 * V_FLOATS) * sizeof(float);
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    {
+        const double flops = 2.0 * N * (double)M * K * 9 * H * W;    // algorithmic (direct-sum) flops
+        const double bytes = 4.0 * ((double)N * K * H * W + (double)N * M * H * W + 9.0 * K * M);
+        GxProf pf(KID_WINO, s, flops, bytes);
+        hipLaunchKernelGGL(wino_conv_kernel, dim3(N * g.tiles_h * g.tiles_w, g.Mpad / 64), dim3(256), lds, s, in, U, out,
+                           g);
+    }
+    GX_CHECK_LAUNCH("winograd conv3x3");
+    return GX_OK;
+}
+
+extern "C" {
+
+int gx_conv3x3_wino_supported(int N, int Cin, int Cout, int H, int W) { return wino_shape_ok(N, Cin, Cout, H, W); }
+
+size_t gx_conv3x3_wino_ws_bytes(int N, int Cin, int Cout, int H, int W) {
+    (void)N; (void)H; (void)W;
+    const int c = Cin > Cout ? Cin : Cout;
+    return (size_t)16 * gx_round_up(c, 8) * gx_round_up(c, 64) * sizeof(float);
+}
+
+// mode 0: y[N,Cout,H,W] = conv3x3(x[N,Cin,H,W], w[Cout,Cin,3,3]); mode 1: dx[N,Cin,H,W] from dy[N,Cout,H,W] (same w)
+int gx_conv3x3_wino(const float* x, const float* w, float* y, int N, int Cin, int Cout, int H, int W, int mode,
+                    void* ws, size_t ws_bytes, gx_stream_t stream) {
+    GX_CHECK_ARG(x && w && y && ws, "gx_conv3x3_wino: null pointer");
+    GX_CHECK_ARG(mode == 0 || mode == 1, "gx_conv3x3_wino: mode must be 0 (forward) or 1 (data gradient)");
+    GX_CHECK_ARG(wino_shape_ok(N, Cin, Cout, H, W),
+                 "gx_conv3x3_wino: needs H %% 8 == 0, W %% 16 == 0, channels >= 16 (N=%d Cin=%d Cout=%d H=%d W=%d)", N, Cin,
+                 Cout, H, W);
+    GX_CHECK_ARG(ws_bytes >= gx_conv3x3_wino_ws_bytes(N, Cin, Cout, H, W), "gx_conv3x3_wino: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int K = mode == 0 ? Cin : Cout, M = mode == 0 ? Cout : Cin;
+    const int Kpad = gx_round_up(K, WKC), Mpad = gx_round_up(M, 64);
+    float* U = (float*)ws;
+    {
+        const int total = 16 * Kpad * Mpad;
+        GxProf pf(KID_PACK_WEIGHTS, s, 0.0, 8.0 * total);
+        hipLaunchKernelGGL(wino_pack_kernel, dim3(gx_ceil_div(total, 256)), dim3(256), 0, s, w, U, mode, Cout, Cin, Kpad,
+                           Mpad);
+    }
+    GX_CHECK_LAUNCH("gx_conv3x3_wino(pack)");
+    return gx_wino_launch(x, U, y, N, K, M, H, W, s);
+}
+
+}  // extern "C"

@@ -718,3 +718,15 @@ def gn_relu_bwd_proj(y, gamma, beta, mean, rstd, groups, g_out, w, want_dbias=Fa
                   _p(parts[0]), _p(parts[1]), _p(ws), nb, _stream())
     return dy, dgamma, dbeta, dbias
 
+
+def conv3x3_wino(x, w, mode=0):
+    """Winograd F(2x2,3x3) conv3x3: mode 0 forward (x [N,Cin,H,W]), mode 1 data gradient (x = dy [N,Cout,H,W])."""
+    _chk(x, 'wino.x'); _chk(w, 'wino.w')
+    N, _, H, W = x.shape
+    Cout, Cin = w.shape[0], w.shape[1]
+    y = torch.empty(N, Cout if mode == 0 else Cin, H, W, dtype=F32, device=x.device)
+    nb = _lib.query('gx_conv3x3_wino_ws_bytes', N, Cin, Cout, H, W)
+    ws = _ws(nb, x.device)
+    _lib.call('gx_conv3x3_wino', _p(x), _p(w), _p(y), N, Cin, Cout, H, W, mode, _p(ws), nb, _stream())
+    return y
+

@@ -44,6 +44,14 @@ size_t gx_conv3x3_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W);
 int gx_conv3x3_wgrad(const float* x, const float* dy, float* dw, int N, int Cin, int Cout, int H, int W,
                      void* ws, size_t ws_bytes, gx_stream_t stream);
 
+/* ---- the same 3x3 convolution by Winograd F(2x2,3x3) (2.25x fewer multiplies; fp32, ordinary rounding differences
+ *      against the direct sum).  mode 0: forward y = conv(x, w); mode 1: data gradient dx from dy (same w [Cout,Cin,3,3]).
+ *      Eligible shapes: gx_conv3x3_wino_supported (H % 8 == 0, W % 16 == 0, >= 16 channels). */
+int gx_conv3x3_wino_supported(int N, int Cin, int Cout, int H, int W);
+size_t gx_conv3x3_wino_ws_bytes(int N, int Cin, int Cout, int H, int W);
+int gx_conv3x3_wino(const float* x, const float* w, float* y, int N, int Cin, int Cout, int H, int W, int mode,
+                    void* ws, size_t ws_bytes, gx_stream_t stream);
+
 /* ---- ConvTranspose2d(k=5, s=2, p=2, output_padding=1) + bias:
  *      models/genesisv2_config.py:90-98 (decoder_module.{1,4,7,10}).
  *      w is the nn.ConvTranspose2d weight [Cin,Cout,5,5]; x [N,Cin,Hin,Win]; y [N,Cout,2Hin,2Win].
