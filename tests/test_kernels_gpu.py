@@ -685,3 +685,37 @@ def test_deconv_epilogue_groupnorm_statistics(N, Cin, Cout, Hin):
                                rtol=2e-5)
     y2 = hip.deconv5x5s2_fwd(x.to(DEV), w.to(DEV), b.to(DEV))
     assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize('N,Cin,Cout,H,W', [(2, 16, 16, 8, 16), (3, 24, 40, 32, 32), (2, 64, 64, 64, 64),
+                                            (1, 128, 72, 16, 48), (2, 70, 130, 24, 32)])
+def test_conv3x3_winograd(N, Cin, Cout, H, W):
+    """Winograd F(2x2,3x3) forward and data gradient (gx_conv3x3_wino) against F.conv2d / its autograd: same fp32
+    tolerance as the direct kernels (channel tails, several channel tiles, non-square grids)."""
+    x = rnd(N, Cin, H, W, seed=61)
+    w = rnd(Cout, Cin, 3, 3, seed=62, scale=0.1)
+    dy = rnd(N, Cout, H, W, seed=63)
+    xr = x.clone().requires_grad_()
+    ref = F.conv2d(xr, w, None, 1, 1)
+    ref.backward(dy)
+    y = hip.conv3x3_wino(x.to(DEV), w.to(DEV), 0)
+    close(y, ref, 2e-5, 2e-5, 'fwd')
+    dx = hip.conv3x3_wino(dy.to(DEV), w.to(DEV), 1)
+    close(dx, xr.grad, 2e-5, 2e-5, 'dgrad')
+
+
+def test_conv3x3_entry_points_take_the_winograd_path_when_the_grid_fills_the_chip(monkeypatch):
+    """gx_conv3x3_fwd / _dgrad dispatch: chip-filling layers run the Winograd kernel, the others the direct tap loop;
+    both agree with each other to fp32 rounding."""
+    from genesis_amd import profiling
+    x = rnd(32, 64, 32, 32, seed=64).to(DEV)
+    w = rnd(64, 64, 3, 3, seed=65, scale=0.1).to(DEV)
+    profiling.enable(True)
+    y = hip.conv3x3_fwd(x, w)
+    dx = hip.conv3x3_dgrad(x, w)
+    small = hip.conv3x3_fwd(x[:2], w)
+    rows = {r['name']: r['launches'] for r in profiling.collect()}
+    profiling.enable(False)
+    assert rows.get('wino_conv_kernel') == 2 and rows.get('tapconv_kernel<0>') == 1, rows
+    close(small, y[:2], 2e-5, 2e-5, 'winograd vs direct')
+    assert torch.isfinite(dx).all()
