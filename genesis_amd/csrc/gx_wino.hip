@@ -245,10 +245,15 @@ static bool wino_shape_ok(int N, int K, int M, int H, int W) {
 
 // used by gx_conv3x3_fwd / _dgrad: Winograd where the shape allows it AND the grid fills the chip without a channel
 // split (under-filled layers stay on the direct kernels, which split the reduction).  GENESIS_WINOGRAD=0 disables.
+static int g_wino_mode = -1;   // 0 off, 1 auto (chip-filling layers), 2 every eligible shape; -1: not yet read from the env
+
 bool gx_wino_eligible(int N, int K, int M, int H, int W) {
-    static const char* env = getenv("GENESIS_WINOGRAD");
-    if (env && env[0] == '0') return false;
-    return wino_shape_ok(N, K, M, H, W) && N * (H / 8) * (W / 16) * gx_ceil_div(M, 64) >= 256;
+    if (g_wino_mode < 0) {
+        const char* env = getenv("GENESIS_WINOGRAD");
+        g_wino_mode = env ? (env[0] == '0' ? 0 : (env[0] == '2' ? 2 : 1)) : 1;
+    }
+    if (g_wino_mode == 0 || !wino_shape_ok(N, K, M, H, W)) return false;
+    return g_wino_mode == 2 || N * (H / 8) * (W / 16) * gx_ceil_div(M, 64) >= 256;
 }
 
 int gx_wino_launch(const float* in, const float* U, float* out, int N, int K, int M, int H, int W, hipStream_t s) {
@@ -279,6 +284,13 @@ int gx_wino_launch(const float* in, const float* U, float* out, int N, int K, in
 extern "C" {
 
 int gx_conv3x3_wino_supported(int N, int Cin, int Cout, int H, int W) { return wino_shape_ok(N, Cin, Cout, H, W); }
+
+// dispatch policy of gx_conv3x3_fwd / _dgrad: 0 never, 1 layers that fill the chip (default), 2 every supported shape
+int gx_conv3x3_wino_policy(int mode) {
+    GX_CHECK_ARG(mode >= 0 && mode <= 2, "gx_conv3x3_wino_policy: mode must be 0, 1 or 2");
+    g_wino_mode = mode;
+    return GX_OK;
+}
 
 size_t gx_conv3x3_wino_ws_bytes(int N, int Cin, int Cout, int H, int W) {
     (void)N; (void)H; (void)W;

@@ -48,6 +48,9 @@ int gx_conv3x3_wgrad(const float* x, const float* dy, float* dw, int N, int Cin,
  *      against the direct sum).  mode 0: forward y = conv(x, w); mode 1: data gradient dx from dy (same w [Cout,Cin,3,3]).
  *      Eligible shapes: gx_conv3x3_wino_supported (H % 8 == 0, W % 16 == 0, >= 16 channels). */
 int gx_conv3x3_wino_supported(int N, int Cin, int Cout, int H, int W);
+/*      which layers gx_conv3x3_fwd / _dgrad send to it: 0 none, 1 those whose grid fills the chip (default; also
+ *      GENESIS_WINOGRAD=0/1/2 in the environment), 2 every supported shape. */
+int gx_conv3x3_wino_policy(int mode);
 size_t gx_conv3x3_wino_ws_bytes(int N, int Cin, int Cout, int H, int W);
 int gx_conv3x3_wino(const float* x, const float* w, float* y, int N, int Cin, int Cout, int H, int W, int mode,
                     void* ws, size_t ws_bytes, gx_stream_t stream);

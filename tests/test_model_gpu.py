@@ -158,3 +158,31 @@ def test_cpu_input_raises():
     model = build(gold)
     with pytest.raises((GenesisHipError, RuntimeError)):
         model.cpu()(torch.rand(1, 3, 32, 32))
+
+
+@pytest.mark.parametrize('case', ['metric', 'cfg5'])
+def test_golden_parity_with_every_conv3x3_on_the_winograd_kernel(case):
+    """The golden cases have B = 2, too small for the Winograd dispatch (it takes the layers that fill the chip): force
+    every eligible conv3x3 forward / data gradient onto the Winograd kernel and repeat the reference comparison."""
+    from genesis_amd import _lib, profiling
+    gold = Golden(case)
+    model = build(gold)
+    x, rand_pixel, eps_k = gold.inputs()
+    _lib.call('gx_conv3x3_wino_policy', 2)
+    try:
+        profiling.enable(True)
+        recon, losses, stats, att, comp = run(model, gold, x, rand_pixel, eps_k)
+        gold.check_forward(recon, losses, stats, att, comp, rtol=1e-4, atol=2e-5, mask_atol=1e-3)
+        err = losses.err.mean(0)
+        kl = torch.stack(losses.kl_l_k, dim=1).mean(dim=0).sum()
+        elbo_ref = float(gold.g['loss/err']) + float(gold.g['loss/kl'])
+        assert abs(float((err + kl).detach()) - elbo_ref) <= 2e-5 * abs(elbo_ref)
+        (err + kl).backward()
+        rows = {r['name']: r['launches'] for r in profiling.collect()}
+        assert rows.get('wino_conv_kernel', 0) >= 10, rows          # UNet 32x32 / 64x64 levels and both heads, fwd + dgrad
+        grads = [(n, p.grad if p.grad is not None else torch.zeros_like(p)) for n, p in model.named_parameters()]
+        gold.check_grads(grads, rtol=5e-3, l2_tol=1e-2)
+    finally:
+        profiling.enable(False)
+        _lib.call('gx_conv3x3_wino_policy', 1)
+
