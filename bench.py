@@ -46,6 +46,9 @@ def parse():
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of HIP-graph replay')
     ap.add_argument('--profile-steps', type=int, default=3)
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU baseline leg (0 = skip)')
+    ap.add_argument('--host-input-steps', type=int, default=50,
+                    help='extra leg on rank 0 at N=1: steps fed from uint8 frames in host memory through the PCIe feeder '
+                         '(reported as pcie_inclusive, never as value; 0 = skip)')
     return ap.parse_args()
 
 
@@ -254,6 +257,30 @@ def main():
                      'kernel_ms_per_step': total_ms / args.profile_steps})
         result['roofline'] = roof
         result['kernels'] = table[:12]
+
+    # ---- PCIe-inclusive leg: every batch starts as uint8 HWC frames in host memory (what a dataset yields) and
+    #      travels through genesis_amd.feeder (pinned staging, copy one batch ahead on a side stream, one conversion
+    #      launch).  Reported next to `value`, never as `value`.
+    if rank == 0 and world == 1 and args.host_input_steps > 0 and ts.graph is not None:
+        from genesis_amd.feeder import DeviceFeeder
+        ts.use_graph = True
+        n_host = args.host_input_steps + 5
+        gh = torch.Generator().manual_seed(99)
+        frames = [torch.randint(0, 256, (args.batch, args.img, args.img, 3), generator=gh, dtype=torch.uint8)
+                  for _ in range(4)]
+        feeder = DeviceFeeder((frames[i % 4] for i in range(n_host)), args.img, device=device)
+        for _ in range(5):
+            ts.step(next(feeder))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.host_input_steps):
+            ts.step(next(feeder))
+        torch.cuda.synchronize()
+        dth = time.perf_counter() - t0
+        result['pcie_inclusive'] = {'value': args.batch * args.host_input_steps / dth, 'unit': 'images/sec',
+                                    'steps': args.host_input_steps,
+                                    'input': 'uint8 HWC frames in host memory -> pinned staging -> async copy one batch '
+                                             'ahead -> one uint8->fp32 NCHW launch (genesis_amd/feeder.py)'}
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0 and args.model == 'genesisv2':
         result['cpu_baseline'] = cpu_baseline(args)
