@@ -55,9 +55,52 @@ chan_sum_kernel(const float* __restrict__ part, int N, int C, float* __restrict_
     if (threadIdx.x == 0) out[c] = (float)s;
 }
 
+// Measurement probe: nothing but v_mfma_f32_32x32x2_f32 on register operands, 8 independent accumulator tiles per
+// wave (the tap-conv / Winograd inner loops without any operand traffic).  What this sustains is the chip's practical
+// fp32-MFMA ceiling under load (clock / power), the number the conv kernels' TF/s should be read against.
+typedef float probe_f32x16 __attribute__((ext_vector_type(16)));
+__global__ void __launch_bounds__(256, 2) mfma_fp32_probe_kernel(int iters, float* __restrict__ out) {
+    probe_f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    // eight pseudo-random operand pairs per lane (full mantissa activity: constant operands would flatter the power draw)
+    float a[8], b[8];
+    unsigned h = 0x9e3779b9u * (threadIdx.x + 1u) + 0x85ebca6bu * (blockIdx.x + 1u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        h ^= h << 13; h ^= h >> 17; h ^= h << 5;
+        a[i] = (float)(h & 0xffffff) * (1.0f / 16777216.0f) - 0.5f;
+        h ^= h << 13; h ^= h >> 17; h ^= h << 5;
+        b[i] = (float)(h & 0xffffff) * (1.0f / 16777216.0f) - 0.5f;
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(i + r) & 7], b[(i + 3 * r) & 7], acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][15];
+    if (s == 123.456f) out[0] = s;      // keeps the loop alive
+}
+
 }  // namespace
 
 extern "C" {
+
+// launches `wgs` workgroups of 4 waves, each wave issuing 32 * iters MFMA 32x32x2 f32; returns the flop count through
+// *flops (the caller times the stream).  Measurement only.
+int gx_mfma_fp32_probe(int wgs, int iters, float* scratch, double* flops, gx_stream_t stream) {
+    GX_CHECK_ARG(wgs > 0 && iters > 0 && scratch && flops, "gx_mfma_fp32_probe: bad arguments");
+    hipLaunchKernelGGL(mfma_fp32_probe_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, iters, scratch);
+    GX_CHECK_LAUNCH("gx_mfma_fp32_probe");
+    *flops = (double)wgs * 4.0 * iters * 32.0 * (2.0 * 32 * 32 * 2);
+    return GX_OK;
+}
 
 size_t gx_bias_act_bwd_ws_bytes(int N, int C) { return (size_t)N * C * sizeof(float); }
 

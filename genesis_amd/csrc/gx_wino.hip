@@ -17,7 +17,8 @@
 // lane loads its 8 values per position with two 16-byte loads straight into the MFMA operand registers (refilled for
 // the next chunk as soon as a half has issued).
 // Measured (B=32): 64->64 @64x64 63 us (direct tap loop 99 us), 128->64 107 us (183 us); the MFMA instructions alone
-// (no staging, no transform) take 51 / 81 us -- the chip sustains ~105 TF/s of fp32 MFMA in this loop, not 157.
+// (no staging, no transform, only the LDS operand reads) take 51 / 81 us, i.e. ~105 TF/s on the pipe, where a pure
+// register-operand MFMA loop sustains 155 TF/s (gx_mfma_fp32_probe).
 // Epilogue: each wave reduces its row of positions over nu (A on the right), the four waves' rows are combined through
 // LDS (A^T on the left) and written as float2 pairs.
 #include <stdlib.h>

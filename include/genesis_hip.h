@@ -355,6 +355,10 @@ int gx_label_contingency(const long long* segA, const long long* segB, int B, in
 int gx_u8hwc_to_f32chw(const unsigned char* src, float* dst, int B, int Hs, int Ws, int C, int H, int W,
                        gx_stream_t stream);
 
+/* ---- measurement probe: `wgs` workgroups x 4 waves x 32 * iters v_mfma_f32_32x32x2_f32 on register operands only.
+ *      *flops = executed flops; time the stream around it (tools/mfma_peak.py): the practical fp32-MFMA ceiling. */
+int gx_mfma_fp32_probe(int wgs, int iters, float* scratch, double* flops, gx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
