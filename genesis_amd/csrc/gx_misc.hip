@@ -59,7 +59,11 @@ chan_sum_kernel(const float* __restrict__ part, int N, int C, float* __restrict_
 // wave (the tap-conv / Winograd inner loops without any operand traffic).  What this sustains is the chip's practical
 // fp32-MFMA ceiling under load (clock / power), the number the conv kernels' TF/s should be read against.
 typedef float probe_f32x16 __attribute__((ext_vector_type(16)));
+// MODE 0: register operands only.  1: the B operand of every MFMA comes from LDS (one ds_read_b32 each).
+// 2: A and B from LDS (the tap-conv pattern: two reads per MFMA).  3: as 2, plus a workgroup barrier every 32 MFMAs.
+template <int MODE>
 __global__ void __launch_bounds__(256, 2) mfma_fp32_probe_kernel(int iters, float* __restrict__ out) {
+    __shared__ float opnd[8192];
     probe_f32x16 acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -75,12 +79,34 @@ __global__ void __launch_bounds__(256, 2) mfma_fp32_probe_kernel(int iters, floa
         h ^= h << 13; h ^= h >> 17; h ^= h << 5;
         b[i] = (float)(h & 0xffffff) * (1.0f / 16777216.0f) - 0.5f;
     }
-    for (int it = 0; it < iters; ++it) {
+    if (MODE != 0) {
+        for (int i = threadIdx.x; i < 8192; i += 256) opnd[i] = a[i & 7] + 1e-3f * i;
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int it = 0; it < (MODE == 4 ? 0 : iters); ++it) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(i + r) & 7], b[(i + 3 * r) & 7], acc[i], 0, 0, 0);
+            for (int i = 0; i < 8; ++i) {
+                float av = a[(i + r) & 7], bv = b[(i + 3 * r) & 7];
+                if (MODE >= 1) bv = opnd[((wave * 32 + r * 8 + i) * 64 + lane + (it & 1) * 2048) & 8191];
+                if (MODE >= 2) av = opnd[((wave * 32 + r * 8 + i) * 64 + lane + 4096 + (it & 1) * 2048) & 8191];
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i], 0, 0, 0);
+            }
+        if (MODE == 3) __syncthreads();
+    }
+    if (MODE == 4) {   // A and B from LDS with ONE 16-byte read each per four MFMAs (k-contiguous operand layout)
+        const f32x4* o4 = reinterpret_cast<const f32x4*>(opnd);
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const f32x4 av = o4[((wave * 8 + i) * 64 + lane + (it & 1) * 512) & 2047];
+                const f32x4 bv = o4[((wave * 8 + i) * 64 + lane + 1024 + (it & 1) * 512) & 2047];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[(i + r) & 7] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[r], bv[r], acc[(i + r) & 7], 0, 0, 0);
+            }
+        }
     }
     float s = 0.f;
 #pragma unroll
@@ -94,9 +120,14 @@ extern "C" {
 
 // launches `wgs` workgroups of 4 waves, each wave issuing 32 * iters MFMA 32x32x2 f32; returns the flop count through
 // *flops (the caller times the stream).  Measurement only.
-int gx_mfma_fp32_probe(int wgs, int iters, float* scratch, double* flops, gx_stream_t stream) {
-    GX_CHECK_ARG(wgs > 0 && iters > 0 && scratch && flops, "gx_mfma_fp32_probe: bad arguments");
-    hipLaunchKernelGGL(mfma_fp32_probe_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, iters, scratch);
+int gx_mfma_fp32_probe(int wgs, int iters, int mode, float* scratch, double* flops, gx_stream_t stream) {
+    GX_CHECK_ARG(wgs > 0 && iters > 0 && scratch && flops && mode >= 0 && mode <= 4, "gx_mfma_fp32_probe: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == 0) hipLaunchKernelGGL(mfma_fp32_probe_kernel<0>, dim3(wgs), dim3(256), 0, s, iters, scratch);
+    else if (mode == 1) hipLaunchKernelGGL(mfma_fp32_probe_kernel<1>, dim3(wgs), dim3(256), 0, s, iters, scratch);
+    else if (mode == 2) hipLaunchKernelGGL(mfma_fp32_probe_kernel<2>, dim3(wgs), dim3(256), 0, s, iters, scratch);
+    else if (mode == 3) hipLaunchKernelGGL(mfma_fp32_probe_kernel<3>, dim3(wgs), dim3(256), 0, s, iters, scratch);
+    else hipLaunchKernelGGL(mfma_fp32_probe_kernel<4>, dim3(wgs), dim3(256), 0, s, iters, scratch);
     GX_CHECK_LAUNCH("gx_mfma_fp32_probe");
     *flops = (double)wgs * 4.0 * iters * 32.0 * (2.0 * 32 * 32 * 2);
     return GX_OK;

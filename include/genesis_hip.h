@@ -355,9 +355,11 @@ int gx_label_contingency(const long long* segA, const long long* segB, int B, in
 int gx_u8hwc_to_f32chw(const unsigned char* src, float* dst, int B, int Hs, int Ws, int C, int H, int W,
                        gx_stream_t stream);
 
-/* ---- measurement probe: `wgs` workgroups x 4 waves x 32 * iters v_mfma_f32_32x32x2_f32 on register operands only.
- *      *flops = executed flops; time the stream around it (tools/mfma_peak.py): the practical fp32-MFMA ceiling. */
-int gx_mfma_fp32_probe(int wgs, int iters, float* scratch, double* flops, gx_stream_t stream);
+/* ---- measurement probe: `wgs` workgroups x 4 waves x 32 * iters v_mfma_f32_32x32x2_f32.  mode 0: register operands
+ *      only (the fp32-MFMA ceiling); 1: B operand from LDS; 2: A and B from LDS (two ds_read_b32 per MFMA, the tap-conv
+ *      pattern); 3: as 2 plus a workgroup barrier every 32 MFMAs; 4: A and B from LDS with one 16-byte read per four MFMAs.  *flops = executed flops; time the stream around it
+ *      (tools/mfma_peak.py). */
+int gx_mfma_fp32_probe(int wgs, int iters, int mode, float* scratch, double* flops, gx_stream_t stream);
 
 #ifdef __cplusplus
 }
