@@ -1,0 +1,41 @@
+"""bench.py contract: ONE JSON line with the driver's keys, the roofline object (HIP events around the dominant kernel
+inside the same process) and the CPU baseline object; the timed value comes from HIP-graph replay."""
+import json
+import os
+import os.path as osp
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = osp.dirname(osp.dirname(osp.abspath(__file__)))
+
+
+@pytest.mark.timeout(600)
+def test_bench_line_contract():
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, osp.join(ROOT, 'bench.py'), '--steps', '4', '--warmup', '2', '--cpu-seconds', '2',
+                          '--profile-steps', '1', '--host-input-steps', '3'], capture_output=True, text=True, env=env,
+                         cwd=ROOT, timeout=580)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 4 and d['warmup'] == 2 and d['higher_is_better'] is True
+    assert d['unit'] == 'images/sec' and d['dtype'] == 'f32' and d['data'] == 'synthetic' and d['scaling'] == 'weak'
+    assert d['vs_baseline'] is None and 'workload' in d['config'] and d['config']['launch'] == 'hip-graph'
+    assert d['value'] > 0 and abs(d['value'] - 32 * 1e3 / d['ms_per_step']) < 1e-6 * d['value']
+    r = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel'):
+        assert k in r, k
+    assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s')
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
+    c = d['cpu_baseline']
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in c, k
+    assert c['kind'] in ('port', 'reference') and c['value'] > 0 and c['cores'] >= 1
+    assert d['pcie_inclusive']['value'] > 0
