@@ -112,3 +112,26 @@ __host__ __device__ __forceinline__ size_t gx_wino_u_slot(int m, int k, int p, i
 bool gx_wino_eligible(int N, int K, int M, int H, int W);
 int gx_wino_launch(const float* in, const float* U, float* out, int N, int K, int M, int H, int W, hipStream_t s);
 
+
+// ---- k-quad tap convolutions (gx_kq.hip): 16-byte k-contiguous MFMA operand reads for the chip-filling layers ----
+// packed-weight layout [m tile 64][chunk of 8 k][tap, phase-major][quad (k >> 2) & 1][m & 63][k & 3]
+// tap order: the [t] order of gx_conv.hip's packs, except the transposed conv's data gradient (25 taps, t = kh*5+kw),
+// whose taps are grouped by parity plane (kh & 1, kw & 1): planes of 9, 6, 6, 4 taps, (kh / 2, kw / 2) row-major inside
+__host__ __device__ __forceinline__ int gx_kq_dg_tap_slot(int t) {
+    const int kh = t / 5, kw = t % 5;
+    const int pa = kh & 1, pb = kw & 1;
+    const int p = pa * 2 + pb;
+    const int base = p == 0 ? 0 : (p == 1 ? 9 : (p == 2 ? 15 : 21));
+    return base + (kh >> 1) * (3 - pb) + (kw >> 1);
+}
+__host__ __device__ __forceinline__ size_t gx_kq_w_slot(int m, int k, int tslot, int NT, int Kpad) {
+    return ((((size_t)(m >> 6) * (Kpad >> 3) + (k >> 3)) * NT + tslot) * 2 + ((k >> 2) & 1)) * 256 + (m & 63) * 4 + (k & 3);
+}
+bool gx_kq_c3_eligible(int N, int K, int M, int H, int W);
+bool gx_kq_deconv_eligible(int N, int K, int M, int Hb, int Wb, int mult);   // mult: workgroups per (pixel, channel) tile
+int gx_kq_c3_launch(const float* in, const float* wp, const float* bias, int act, float* out, int N, int K, int M, int H,
+                    int W, hipStream_t s);
+int gx_kq_deconv_fwd_launch(const float* in, const float* wp0, const float* wp1, const float* bias, float* out, int N,
+                            int K, int M, int Hb, int Wb, float* stats, int* stats_parts, hipStream_t s);
+int gx_kq_deconv_dgrad_launch(const float* dy, const float* wp, float* dx, int N, int K, int M, int Hb, int Wb,
+                              hipStream_t s);

@@ -98,7 +98,7 @@ __device__ __forceinline__ float gx_act(float v, int act) {
 // NPOS = halo-tile positions staged per thread per channel (tile <= NPOS*256 floats per channel).
 // MW = waves along M: 1 -> the 4 waves tile 256 pixels (64 each) and all 64 channels; 2 -> a 128-pixel tile, waves 2 x 2
 // (32 channels x 64 pixels each): twice the workgroups for grids that cannot fill the chip with 256-pixel tiles.
-template <int MODE, int NPOS, bool DMA, int MW = 1, bool STATS = false>
+template <int MODE, int NPOS, bool DMA, int MW = 1, bool STATS = false, bool HH = true>
 __device__ __forceinline__ void tapconv_body(const float* __restrict__ in, const float* __restrict__ wp,
                                              const float* __restrict__ bias, float* __restrict__ out,
                                              const ConvGeom& g, float* lds, const int bx, const int by, const int bz,
@@ -161,8 +161,10 @@ __device__ __forceinline__ void tapconv_body(const float* __restrict__ in, const
     const int wn = MW == 2 ? (wave & 1) : wave;    // 64-pixel group of this wave
     const int a_off = KC * CHS + (lane >> 5) * 64 + (lane & 31) + wm * 32;
     // output channels 32..63 of this workgroup's tile exist?  (32-channel layers -- MONet's UNet ends and its
-    // BroadcastDecoder -- skip the upper MFMA tile instead of computing padding)
-    const bool hi_half = m0 + 32 < g.M;
+    // BroadcastDecoder -- skip the upper MFMA tile instead of computing padding.)  Compile-time: a runtime test in
+    // the tap loop cuts it into one basic block per tap, and the scheduler then leaves every LDS read directly in
+    // front of the two MFMAs that consume it (round-1 ISA: s_waitcnt lgkmcnt(0) every 2 MFMAs, pipe 0.56 busy).
+    constexpr bool hi_half = HH;
     // B (input):   lane -> in_tile[2kk + (lane>>5)][plane][halo(pixel) + tap]
     int b_off[2];
 #pragma unroll
@@ -404,12 +406,12 @@ __device__ __forceinline__ void tapconv_body(const float* __restrict__ in, const
     }
 }
 
-template <int MODE, int NPOS, bool DMA, int MW = 1>
+template <int MODE, int NPOS, bool DMA, int MW = 1, bool HH = true>
 __global__ void __launch_bounds__(256, 2)
 tapconv_kernel(const float* __restrict__ in, const float* __restrict__ wp,
                const float* __restrict__ bias, float* __restrict__ out, ConvGeom g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    tapconv_body<MODE, NPOS, DMA, MW>(in, wp, bias, out, g, lds, blockIdx.x, blockIdx.y, blockIdx.z, g.par_a);
+    tapconv_body<MODE, NPOS, DMA, MW, false, HH>(in, wp, bias, out, g, lds, blockIdx.x, blockIdx.y, blockIdx.z, g.par_a);
 }
 
 // Both output-row parities of the transposed conv in one launch: blockIdx.y = 2 * channel_tile + parity.  Twice
@@ -476,6 +478,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, const float
 __device__ __forceinline__ float pack_weight_value(const float* __restrict__ w, int pack, int Co, int Ci, int m,
                                                    int k, int t) {
     float v = 0.f;
+    if (pack >= 10) pack -= 10;
     if (pack == 0) {
         if (m < Co && k < Ci) v = w[((size_t)m * Ci + k) * 9 + t];
     } else if (pack == 1) {
@@ -490,8 +493,10 @@ __device__ __forceinline__ float pack_weight_value(const float* __restrict__ w, 
     }
     return v;
 }
-// destination of element (t, k, m): [t][k][m] for the tap-conv kernels, the operand order of gx_wino.hip for packs 5 / 6
-__device__ __forceinline__ size_t pack_dest(int pack, int idx, int m, int k, int t, int Kpad) {
+// destination of element (t, k, m): [t][k][m] for the tap-conv kernels, the operand order of gx_wino.hip for packs 5 / 6,
+// the k-quad order of gx_kq.hip for packs 10..14 (= packs 0..4 in that layout)
+__device__ __forceinline__ size_t pack_dest(int pack, int idx, int m, int k, int t, int Kpad, int NT) {
+    if (pack >= 10) return gx_kq_w_slot(m, k, pack == 14 ? gx_kq_dg_tap_slot(t) : t, NT, Kpad);
     return pack >= 5 ? gx_wino_u_slot(m, k, t, Kpad) : (size_t)idx;
 }
 
@@ -502,7 +507,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
         const int m = idx % Mpad;
         const int k = (idx / Mpad) % Kpad;
         const int t = idx / (Mpad * Kpad);
-        wp[pack_dest(pack, idx, m, k, t, Kpad)] = pack_weight_value(w, pack, Co, Ci, m, k, t);
+        wp[pack_dest(pack, idx, m, k, t, Kpad, NT)] = pack_weight_value(w, pack, Co, Ci, m, k, t);
     }
 }
 
@@ -1125,16 +1130,23 @@ int plan_tapconv(int N, int K, int M, int Mpad_pack, int Hb, int Wb, int Hi, int
     return GX_OK;
 }
 
-template <int MODE, int NPOS, bool DMA>
-void launch_tapconv_inst2(const float* in, const float* wp, const float* bias, float* out, const ConvGeom& g,
+template <int MODE, int NPOS, bool DMA, int MW, bool HH>
+void launch_tapconv_inst3(const float* in, const float* wp, const float* bias, float* out, const ConvGeom& g,
                           dim3 grid, size_t lds_bytes, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_kernel<MODE, NPOS, DMA>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_kernel<MODE, NPOS, DMA, MW, HH>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((tapconv_kernel<MODE, NPOS, DMA>), grid, dim3(256), lds_bytes, s, in, wp, bias, out, g);
+    hipLaunchKernelGGL((tapconv_kernel<MODE, NPOS, DMA, MW, HH>), grid, dim3(256), lds_bytes, s, in, wp, bias, out, g);
+}
+// layers of <= 32 output channels (conv3x3 only: MONet / GENESIS) skip the upper MFMA tile
+template <int MODE, int NPOS, bool DMA, int MW = 1>
+void launch_tapconv_inst2(const float* in, const float* wp, const float* bias, float* out, const ConvGeom& g,
+                          dim3 grid, size_t lds_bytes, hipStream_t s) {
+    if (MODE == M_C3 && g.M <= 32) launch_tapconv_inst3<MODE, NPOS, DMA, MW, MODE != M_C3>(in, wp, bias, out, g, grid, lds_bytes, s);
+    else launch_tapconv_inst3<MODE, NPOS, DMA, MW, true>(in, wp, bias, out, g, grid, lds_bytes, s);
 }
 
 const float* zero_page(hipStream_t s);
@@ -1149,15 +1161,8 @@ void launch_tapconv_inst(const float* in, const float* wp, const float* bias, fl
     const bool dma = dma_env ? dma_env[0] == '1' : MODE != M_C3;
     g.zeros = dma ? zero_page(s) : nullptr;
     if ((MODE == M_C3 || MODE == M_DG) && pl.mw == 2) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tapconv_kernel<MODE, NPOS, false, 2>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
         g.zeros = nullptr;
-        hipLaunchKernelGGL((tapconv_kernel<MODE, NPOS, false, 2>), pl.grid, dim3(256), pl.lds_bytes, s, in, wp, bias, out,
-                           g);
+        launch_tapconv_inst2<MODE, NPOS, false, 2>(in, wp, bias, out, g, pl.grid, pl.lds_bytes, s);
         return;
     }
     if (g.zeros) launch_tapconv_inst2<MODE, NPOS, true>(in, wp, bias, out, g, pl.grid, pl.lds_bytes, s);
@@ -1235,7 +1240,7 @@ __global__ void pack_weights_batch_kernel(const PackEntry* __restrict__ entries)
         const int m = idx % e.Mpad;
         const int k = (idx / e.Mpad) % e.Kpad;
         const int t = idx / (e.Mpad * e.Kpad);
-        e.wp[pack_dest(e.pack, idx, m, k, t, e.Kpad)] = pack_weight_value(e.w, e.pack, e.Co, e.Ci, m, k, t);
+        e.wp[pack_dest(e.pack, idx, m, k, t, e.Kpad, e.NT)] = pack_weight_value(e.w, e.pack, e.Co, e.Ci, m, k, t);
     }
 }
 
@@ -1741,7 +1746,18 @@ static int conv3x3_fwd_impl(const float* x, const float* w, const float* bias, i
     float* part = wp + conv3x3_pack_floats(Cin, Cout);
     pl.g.act = act;
     const float* wpu;
-    if (!bias && act == 0 && gx_wino_eligible(N, Cin, Cout, H, W)) {   // Winograd F(2x2,3x3): 2.25x fewer MFMA passes
+    static const char* kq_env = getenv("GENESIS_KQ");
+    const bool kq_first = kq_env && kq_env[0] == '2';        // benchmarking: the k-quad kernel ahead of Winograd
+    const bool wino_ok = !bias && act == 0 && gx_wino_eligible(N, Cin, Cout, H, W);
+    if ((kq_first || !wino_ok) && gx_kq_c3_eligible(N, Cin, Cout, H, W)) {   // 16-byte operand reads (gx_kq.hip)
+        rc = launch_pack(w, wp, 10, Cout, Cin, 9, Kpad, Mpad, s, &wpu);
+        if (rc) return rc;
+        rc = gx_kq_c3_launch(x, wpu, bias, act, y, N, Cin, Cout, H, W, s);
+        if (rc) return rc;
+        if (parts_out) { *parts_out = y; *nsplit_out = 1; }
+        return GX_OK;
+    }
+    if (wino_ok) {   // Winograd F(2x2,3x3): 2.25x fewer MFMA passes
         rc = launch_pack(w, wp, 5, Cout, Cin, 16, Kpad, Mpad, s, &wpu);
         if (rc) return rc;
         rc = gx_wino_launch(x, wpu, y, N, Cin, Cout, H, W, s);
@@ -1776,7 +1792,15 @@ int gx_conv3x3_dgrad(const float* dy, const float* w, float* dx, int N, int Cin,
     float* wp = (float*)ws;
     float* part = wp + conv3x3_pack_floats(Cin, Cout);
     const float* wpu;
-    if (gx_wino_eligible(N, Cout, Cin, H, W)) {
+    static const char* kq_env = getenv("GENESIS_KQ");
+    const bool kq_first = kq_env && kq_env[0] == '2';
+    const bool wino_ok = gx_wino_eligible(N, Cout, Cin, H, W);
+    if ((kq_first || !wino_ok) && gx_kq_c3_eligible(N, Cout, Cin, H, W)) {
+        rc = launch_pack(w, wp, 11, Cout, Cin, 9, Kpad, Mpad, s, &wpu);
+        if (rc) return rc;
+        return gx_kq_c3_launch(dy, wpu, nullptr, 0, dx, N, Cout, Cin, H, W, s);
+    }
+    if (wino_ok) {
         rc = launch_pack(w, wp, 6, Cout, Cin, 16, Kpad, Mpad, s, &wpu);
         if (rc) return rc;
         return gx_wino_launch(dy, wpu, dx, N, Cout, Cin, H, W, s);
@@ -1915,6 +1939,17 @@ static int deconv_fwd_impl(const float* x, const float* w, const float* bias, fl
     float* wp1 = wp0 + (size_t)15 * Kpad * Mpad;
     float* part = wp0 + deconv_pack_floats(Cin, Cout);
     const float *wpu0, *wpu1;
+    if (stats_parts_out) *stats_parts_out = 0;
+    if (gx_kq_deconv_eligible(N, Cin, Cout, Hin, Win, 2)) {   // chip-filling layers: 16-byte operand reads (gx_kq.hip)
+        rc = launch_pack(w, wp0, 12, Cout, Cin, 15, Kpad, Mpad, s, &wpu0);
+        if (rc) return rc;
+        rc = launch_pack(w, wp1, 13, Cout, Cin, 10, Kpad, Mpad, s, &wpu1);
+        if (rc) return rc;
+        rc = gx_kq_deconv_fwd_launch(x, wpu0, wpu1, bias, y, N, Cin, Cout, Hin, Win, stats, stats_parts_out, s);
+        if (rc) return rc;
+        if (parts_out) { *parts_out = y; *nsplit_out = 1; }
+        return GX_OK;
+    }
     rc = launch_pack(w, wp0, 2, Cout, Cin, 15, Kpad, Mpad, s, &wpu0);
     if (rc) return rc;
     rc = launch_pack(w, wp1, 3, Cout, Cin, 10, Kpad, Mpad, s, &wpu1);
@@ -1986,6 +2021,11 @@ int gx_deconv5x5s2_dgrad(const float* dy, const float* w, float* dx, int N, int 
     float* wp = (float*)ws;
     float* part = wp + deconv_pack_floats(Cin, Cout);
     const float* wpu;
+    if (gx_kq_deconv_eligible(N, Cout, Cin_out, Hin, Win, 1)) {
+        rc = launch_pack(w, wp, 14, Cout, Cin, 25, Kpad, Mpad, s, &wpu);
+        if (rc) return rc;
+        return gx_kq_deconv_dgrad_launch(dy, wpu, dx, N, Cout, Cin_out, Hin, Win, s);
+    }
     rc = launch_pack(w, wp, 4, Cout, Cin, 25, Kpad, Mpad, s, &wpu);
     if (rc) return rc;
     TapPlan pl;

@@ -1,0 +1,518 @@
+// "k-quad" tap convolutions: the chip-filling conv3x3 / transposed-conv 5x5 s2 layers (forward and data gradient) on
+// v_mfma_f32_32x32x2_f32 with k-CONTIGUOUS operands, i.e. one 16-byte LDS read feeds four MFMAs.
+//
+// Round-1 finding: the tap-conv kernels of gx_conv.hip read every MFMA operand with a 4-byte
+// ds_read and hipcc leaves those reads directly in front of their consumers (s_waitcnt lgkmcnt(0) every 2-4 MFMAs):
+// matrix pipe 0.56-0.63 busy.  Here
+//   * a chunk is 8 reduction channels = 4 MFMAs of k = 2: lane-half h of MFMA j takes channel 4h + j (the assignment
+//     of channels to k slots is free as long as A and B agree), so a lane's four A values (and its four B values) are
+//     4 CONSECUTIVE channels = one ds_read_b128 from a channel-quad-innermost LDS image:
+//         input   [quad 2][halo position][4 channels]          (staged global -> registers -> ds_write_b128)
+//         weights [tap][quad 2][64 output channels][4 channels] (pre-swizzled by the pack kernel: a straight copy)
+//     -> 4 reads per 16 MFMAs (2 x 2 tiles of 32 x 32 per wave) instead of 16;
+//   * the operand reads of tap t+1 are issued BEFORE the 16 MFMAs of tap t (two register sets, the order pinned with
+//     sched_group_barrier), so no MFMA waits on LDS latency;
+//   * no runtime branch inside a phase (one basic block per phase).
+// A chunk is processed in PHASES that partition the taps so that the LDS footprint stays small enough for two
+// workgroups per CU: transposed conv forward = one phase per kernel row kh (5 taps, the input tile is shared by the
+// chunk's phases), its data gradient = one phase per parity plane of dy (9 / 6 / 6 / 4 taps, each with its own plane),
+// conv3x3 = one phase of 9 taps.  Input tiles and weight slices are double-buffered separately; one barrier per phase.
+//
+// Reference ops: modules/blocks.py:159-165 (conv3x3), models/genesisv2_config.py:89-99 (ConvTranspose2d k5 s2 p2 op1).
+#include "gx_common.h"
+
+#include <cstdlib>
+
+namespace {
+
+enum { Q_C3 = 0, Q_DT0 = 1, Q_DT1 = 2, Q_DG = 3 };
+
+template <int MODE> struct QCfg;
+template <> struct QCfg<Q_C3> {
+    static constexpr int NPH = 1, NT = 9, MAXT = 9, NCLS = 1;
+    static constexpr bool PLANE_PER_PHASE = false;
+    __host__ __device__ static constexpr int ntaps(int) { return 9; }
+    __host__ __device__ static constexpr int tbase(int) { return 0; }
+    __host__ __device__ static constexpr int ro(int, int i) { return i / 3; }
+    __host__ __device__ static constexpr int co(int, int i) { return i % 3; }
+    __host__ __device__ static constexpr int cls(int, int) { return 0; }
+};
+// ConvTranspose k5 s2 p2 op1, output rows 2r + a: kh = 2 p + a, halo row offset 2 - p; kw = i, halo column offset
+// 2 - i / 2, output column parity i & 1 (same tap order as gx_conv.hip's packs 2 / 3).
+template <> struct QCfg<Q_DT0> {
+    static constexpr int NPH = 3, NT = 15, MAXT = 5, NCLS = 2;
+    static constexpr bool PLANE_PER_PHASE = false;
+    __host__ __device__ static constexpr int ntaps(int) { return 5; }
+    __host__ __device__ static constexpr int tbase(int p) { return 5 * p; }
+    __host__ __device__ static constexpr int ro(int p, int) { return 2 - p; }
+    __host__ __device__ static constexpr int co(int, int i) { return 2 - i / 2; }
+    __host__ __device__ static constexpr int cls(int, int i) { return i & 1; }
+};
+template <> struct QCfg<Q_DT1> {
+    static constexpr int NPH = 2, NT = 10, MAXT = 5, NCLS = 2;
+    static constexpr bool PLANE_PER_PHASE = false;
+    __host__ __device__ static constexpr int ntaps(int) { return 5; }
+    __host__ __device__ static constexpr int tbase(int p) { return 5 * p; }
+    __host__ __device__ static constexpr int ro(int p, int) { return 2 - p; }
+    __host__ __device__ static constexpr int co(int, int i) { return 2 - i / 2; }
+    __host__ __device__ static constexpr int cls(int, int i) { return i & 1; }
+};
+// data gradient of the transposed conv: dx[r][c] = sum dy[2r-2+kh][2c-2+kw] W[kh][kw]; phase p = parity plane
+// (kh & 1, kw & 1) of dy, in-plane offset (kh / 2, kw / 2); taps ordered plane-major (gx_kq_tap_slot).
+template <> struct QCfg<Q_DG> {
+    static constexpr int NPH = 4, NT = 25, MAXT = 9, NCLS = 1;
+    static constexpr bool PLANE_PER_PHASE = true;
+    __host__ __device__ static constexpr int nkw(int p) { return 3 - (p & 1); }
+    __host__ __device__ static constexpr int ntaps(int p) { return (3 - (p >> 1)) * (3 - (p & 1)); }
+    __host__ __device__ static constexpr int tbase(int p) { return p == 0 ? 0 : (p == 1 ? 9 : (p == 2 ? 15 : 21)); }
+    __host__ __device__ static constexpr int ro(int p, int i) { return i / nkw(p); }
+    __host__ __device__ static constexpr int co(int p, int i) { return i % nkw(p); }
+    __host__ __device__ static constexpr int cls(int, int) { return 0; }
+};
+
+struct QGeom {
+    int N, K, M;          // images, reduction channels (a multiple of 8), output channels
+    int nchunks;          // K / 8
+    int Hb, Wb;           // base (pixel-tile) grid
+    int Hi, Wi, Ho, Wo;   // input / output tensor dims
+    int lTH, lTW, lG, tiles_h, tiles_w;
+    int act;              // epilogue activation after the bias: 0 none, 1 ReLU, 2 ELU
+    float* stats;         // STATS: per-workgroup (sum, sum of squares) of every 8-channel block, [N][parts][M/8][2]
+    int stats_parts;
+};
+
+__device__ __forceinline__ float q_act(float v, int act) {
+    if (act == 1) return v > 0.f ? v : 0.f;
+    if (act == 2) return v > 0.f ? v : expm1f(v);
+    return v;
+}
+
+// one phase: the taps of phase PH out of the input tile `ib` and the weight slice `wb`; the operands of tap i + 1 are
+// read ahead of tap i's MFMAs (two register sets; order pinned by GX_Q_SCHED)
+template <int MODE, int PH, int NCLS>
+__device__ __forceinline__ void q_phase(f32x16 (&acc)[NCLS][2][2], const float* ib, const float* wb, const int a_lane,
+                                        const int b_lane0, const int b_lane1, const int HS4) {
+    using C = QCfg<MODE>;
+    constexpr int nt = C::ntaps(PH);
+    f32x4 fa[2][2], fb[2][2];
+#define GX_Q_READ(i_, set_)                                                                            \
+    {                                                                                                  \
+        const int toff_ = C::ro(PH, i_) * HS4 + C::co(PH, i_) * 4;                                     \
+        fa[set_][0] = *reinterpret_cast<const f32x4*>(wb + (i_) * 512 + a_lane);                       \
+        fa[set_][1] = *reinterpret_cast<const f32x4*>(wb + (i_) * 512 + a_lane + 128);                 \
+        fb[set_][0] = *reinterpret_cast<const f32x4*>(ib + b_lane0 + toff_);                           \
+        fb[set_][1] = *reinterpret_cast<const f32x4*>(ib + b_lane1 + toff_);                           \
+    }
+    GX_Q_READ(0, 0)
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int i = 0; i < nt; ++i) {
+        const int cur = i & 1;
+        if (i + 1 < nt) GX_Q_READ(i + 1, cur ^ 1)
+        const int cl = C::cls(PH, i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[cl][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][0][j], fb[cur][0][j], acc[cl][0][0], 0, 0, 0);
+            acc[cl][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][0][j], fb[cur][1][j], acc[cl][0][1], 0, 0, 0);
+            acc[cl][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][1][j], fb[cur][0][j], acc[cl][1][0], 0, 0, 0);
+            acc[cl][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][1][j], fb[cur][1][j], acc[cl][1][1], 0, 0, 0);
+        }
+        if (i + 1 < nt) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    }
+#undef GX_Q_READ
+}
+
+// NQ: (position, quad) slots staged per thread per input tile (2 * CHS <= NQ * 256)
+template <int MODE, int NQ, bool STATS>
+__device__ __forceinline__ void q_body(const float* __restrict__ in, const float* __restrict__ wp,
+                                       const float* __restrict__ bias, float* __restrict__ out, const QGeom& g,
+                                       float* lds, const int bx, const int by, const int par_a) {
+    using C = QCfg<MODE>;
+    constexpr int NPH = C::NPH, NT = C::NT, MAXT = C::MAXT, NCLS = C::NCLS;
+    constexpr int NW = (MAXT * 128 + 255) / 256;       // float4 weight loads per thread per phase
+    constexpr int WSLOT = NW * 1024;                   // floats per weight buffer (whole float4-per-thread rounds: the
+    constexpr int ISLOT = NQ * 1024;                   //   staging stores are unconditional); same for an input buffer
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int TH = 1 << g.lTH, TW = 1 << g.lTW, G = 1 << g.lG;
+    const int HS = TW + 2;
+    const int CHS = G * (TH + 2) * HS;                 // halo positions per plane
+    float* const ibuf0 = lds;
+    float* const wbuf0 = lds + 2 * ISLOT;
+
+    int tile = bx;
+    const int tw_i = tile % g.tiles_w; tile /= g.tiles_w;
+    const int th_i = tile % g.tiles_h; tile /= g.tiles_h;
+    const int img0 = tile * G;
+    const int R0 = th_i * TH, C0 = tw_i * TW;
+    const int m0 = by * 64;
+    const int HiWi = g.Hi * g.Wi;
+
+    // ---- staging slots: slot = tid + q * 256 -> (quad, position).  Loads go through buffer descriptors (wave-uniform
+    //      base, 32-bit per-lane byte offset, scalar offset for the channel / chunk): a position outside the image gets
+    //      an out-of-range offset and the hardware returns 0 -- no select, no branch, no 64-bit address per load
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(in), 0, (int)((unsigned)g.N * (unsigned)g.K * (unsigned)HiWi * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(wp), 0, (int)((unsigned)NT * (unsigned)g.K * gridDim.y * 256u), 0x00020000);
+    int voff[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int slot = tid + q * 256;
+        const int quad = slot >= CHS ? 1 : 0;
+        int rem = slot - quad * CHS;
+        bool ok = slot < 2 * CHS;
+        const int gi = rem / ((TH + 2) * HS); rem -= gi * (TH + 2) * HS;
+        const int i = rem / HS;
+        const int j = rem - i * HS;
+        int row, col;
+        if (MODE == Q_DG) { row = 2 * (R0 + i) - 2; col = 2 * (C0 + j) - 2; }
+        else { row = R0 - 1 + i; col = C0 - 1 + j; }
+        ok = ok && img0 + gi < g.N && row >= 0 && row < g.Hi && col >= 0 && col < g.Wi;
+        voff[q] = ok ? (((img0 + gi) * g.K + quad * 4) * HiWi + row * g.Wi + col) * 4 : (int)0x80000000;
+    }
+    const int w_voff = tid * 16;
+    const int w_sbase = by * g.nchunks * (NT * 2048);
+
+    // ---- per-lane operand addresses (float indices)
+    const int quad_l = lane >> 5;
+    const int a_lane = (quad_l * 64 + (lane & 31)) * 4;            // + mi * 128 + tap * 512
+    int b_lane[2];
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj) {
+        const int p = wave * 64 + nj * 32 + (lane & 31);
+        const int c = p & (TW - 1);
+        const int r = (p >> g.lTW) & (TH - 1);
+        const int gi = p >> (g.lTW + g.lTH);
+        b_lane[nj] = (quad_l * CHS + (gi * (TH + 2) + r) * HS + c) * 4;
+    }
+    const int HS4 = HS * 4;
+
+    f32x16 acc[NCLS][2][2];
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[c][i][j][e] = 0.f;
+
+    f32x4 xin[NQ];
+    f32x4 wreg[NW];
+
+    // global -> registers: the input tile of (chunk, plane) / the weight slice of (chunk, phase)
+#define GX_Q_LOAD_IN(chunk_, plane_)                                                                   \
+    {                                                                                                  \
+        const int so_ = ((chunk_) * 8 * HiWi + (MODE == Q_DG ? ((plane_) >> 1) * g.Wi + ((plane_) & 1) : 0)) * 4; \
+        _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                               \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e)                                              \
+                xin[q][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, voff[q], so_ + e * HiWi * 4, 0)); \
+        }                                                                                              \
+    }
+#define GX_Q_STORE_IN(dst_)                                                                            \
+    {                                                                                                  \
+        _Pragma("unroll") for (int q = 0; q < NQ; ++q)                                                 \
+            *reinterpret_cast<f32x4*>((dst_) + (tid + q * 256) * 4) = xin[q];                          \
+    }
+#define GX_Q_LOAD_W(chunk_, ph_)                                                                       \
+    {                                                                                                  \
+        const int so_ = w_sbase + ((chunk_) * NT + C::tbase(ph_)) * 2048;                              \
+        _Pragma("unroll") for (int i = 0; i < NW; ++i)                                                 \
+            wreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_voff + i * 4096, so_, 0)); \
+    }
+#define GX_Q_STORE_W(dst_, ph_)                                                                        \
+    {                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < NW; ++i)                                                 \
+            *reinterpret_cast<f32x4*>((dst_) + (tid + i * 256) * 4) = wreg[i];                         \
+    }
+    // ---- pipeline over (chunk, phase): stage s = chunk * NPH + phase; weights alternate per stage, input tiles per
+    //      chunk (shared by the chunk's phases) or per stage (PLANE_PER_PHASE)
+    GX_Q_LOAD_IN(0, 0)
+    GX_Q_LOAD_W(0, 0)
+    GX_Q_STORE_IN(ibuf0)
+    GX_Q_STORE_W(wbuf0, 0)
+    int s = 0;
+    for (int chunk = 0; chunk < g.nchunks; ++chunk) {
+        const bool last_chunk = chunk + 1 == g.nchunks;
+#define GX_Q_STAGE(PH_)                                                                                          \
+        {                                                                                                        \
+            constexpr int NXT = (PH_) + 1 < NPH ? (PH_) + 1 : 0;                                                 \
+            const bool more = (PH_) + 1 < NPH || !last_chunk;                                                    \
+            const int nchunk = (PH_) + 1 < NPH ? chunk : chunk + 1;                                              \
+            constexpr bool new_in = C::PLANE_PER_PHASE || NXT == 0;   /* the next stage needs a new input tile */ \
+            const int icur = C::PLANE_PER_PHASE ? (s & 1) : (chunk & 1);                                         \
+            const int inxt = C::PLANE_PER_PHASE ? ((s + 1) & 1) : ((chunk + 1) & 1);                             \
+            __syncthreads();                                                                                     \
+            if (more) {      /* issue the next stage's global loads FIRST (hipcc otherwise sinks them to the    \
+                                commit below and the phase ends on their latency) */                             \
+                if (new_in) GX_Q_LOAD_IN(nchunk, NXT)                                                            \
+                GX_Q_LOAD_W(nchunk, NXT)                                                                         \
+                __builtin_amdgcn_sched_group_barrier(0x020, (new_in ? NQ * 4 : 0) + NW, 0);                      \
+            }                                                                                                    \
+            q_phase<MODE, (PH_), NCLS>(acc, ibuf0 + icur * ISLOT, wbuf0 + (s & 1) * WSLOT, a_lane, b_lane[0],    \
+                                       b_lane[1], HS4);                                                  \
+            if (more) {                                                                                          \
+                if (new_in) GX_Q_STORE_IN(ibuf0 + inxt * ISLOT)                                                  \
+                GX_Q_STORE_W(wbuf0 + ((s + 1) & 1) * WSLOT, NXT)                                                 \
+                __builtin_amdgcn_sched_group_barrier(0x200, (new_in ? NQ : 0) + NW, 0);                          \
+            }                                                                                                    \
+            ++s;                                                                                                 \
+        }
+        GX_Q_STAGE(0)
+        if constexpr (NPH > 1) GX_Q_STAGE(1)
+        if constexpr (NPH > 2) GX_Q_STAGE(2)
+        if constexpr (NPH > 3) GX_Q_STAGE(3)
+#undef GX_Q_STAGE
+    }
+#undef GX_Q_LOAD_IN
+#undef GX_Q_STORE_IN
+#undef GX_Q_LOAD_W
+#undef GX_Q_STORE_W
+
+    // ---- epilogue: C/D layout col = lane & 31 (pixel), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (channel)
+    const size_t out_img_stride = (size_t)g.M * g.Ho * g.Wo;
+    const int HoWo = g.Ho * g.Wo;
+    const bool add_bias = bias != nullptr;
+    const int act = g.act;
+    f32x4 bvec[2][4];
+    {
+        const bool vec_ok = add_bias && (reinterpret_cast<uintptr_t>(bias) & 15) == 0;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int mb = m0 + mi * 32 + 8 * q + 4 * (lane >> 5);
+                f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                if (vec_ok && mb + 3 < g.M) t = *reinterpret_cast<const f32x4*>(bias + mb);
+                else if (add_bias) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = mb + e < g.M ? bias[mb + e] : 0.f;
+                }
+                bvec[mi][q] = t;
+            }
+    }
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj) {
+        const int p = wave * 64 + nj * 32 + (lane & 31);
+        const int c = p & (TW - 1);
+        const int r = (p >> g.lTW) & (TH - 1);
+        const int gi = p >> (g.lTW + g.lTH);
+        const int n = img0 + gi;
+        if (n >= g.N || R0 + r >= g.Hb || C0 + c >= g.Wb) continue;
+        int orow, ocol;
+        if (NCLS == 2) { orow = 2 * (R0 + r) + par_a; ocol = 2 * (C0 + c); }
+        else { orow = R0 + r; ocol = C0 + c; }
+        float* obase = out + (size_t)n * out_img_stride + (size_t)orow * g.Wo + ocol;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int m = m0 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                if (m < g.M) {
+                    const float bv = bvec[mi][reg >> 2][reg & 3];
+                    if (NCLS == 2) {
+                        float2 v;
+                        v.x = q_act(acc[0][mi][nj][reg] + bv, act);
+                        v.y = q_act(acc[NCLS - 1][mi][nj][reg] + bv, act);
+                        *reinterpret_cast<float2*>(obase + (size_t)m * HoWo) = v;
+                    } else {
+                        obase[(size_t)m * HoWo] = q_act(acc[0][mi][nj][reg] + bv, act);
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (STATS) {
+        // GroupNorm statistics of the (pre-activation) output without a pass over it: per 8-channel block sums over this
+        // workgroup's pixels, transposed through LDS and summed in a fixed order (same scheme as gx_conv.hip's STATS)
+        float st_s[8], st_q[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { st_s[i] = 0.f; st_q[i] = 0.f; }
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) {
+            const int p = wave * 64 + nj * 32 + (lane & 31);
+            const int c = p & (TW - 1);
+            const int r = (p >> g.lTW) & (TH - 1);
+            const bool ok = img0 + (p >> (g.lTW + g.lTH)) < g.N && R0 + r < g.Hb && C0 + c < g.Wb;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int m = m0 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                    const float bv = bvec[mi][reg >> 2][reg & 3];
+                    const float vx = (ok && m < g.M) ? acc[0][mi][nj][reg] + bv : 0.f;
+                    const float vy = (ok && m < g.M) ? acc[NCLS - 1][mi][nj][reg] + bv : 0.f;
+                    st_s[mi * 4 + (reg >> 2)] += vx + vy;
+                    st_q[mi * 4 + (reg >> 2)] += vx * vx + vy * vy;
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { lds[i * 256 + tid] = st_s[i]; lds[(8 + i) * 256 + tid] = st_q[i]; }
+        __syncthreads();
+        const int vi = tid >> 4, sub = tid & 15;
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x4 r = *reinterpret_cast<const f32x4*>(lds + vi * 256 + sub * 16 + 4 * k);
+            v += (r[0] + r[1]) + (r[2] + r[3]);
+        }
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 1, 64);
+        if (sub == 0) {
+            const int part = (th_i * g.tiles_w + tw_i) * 2 + par_a;
+            const int nblk = g.M >> 3;
+            const int blk = (m0 >> 3) + (vi & 7);
+            if (blk < nblk && img0 < g.N)
+                g.stats[(((size_t)img0 * g.stats_parts + part) * nblk + blk) * 2 + (vi >> 3)] = v;
+        }
+    }
+}
+
+template <int MODE, int NQ>
+__global__ void __launch_bounds__(256, 2)
+kq_kernel(const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
+          float* __restrict__ out, QGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    q_body<MODE, NQ, false>(in, wp, bias, out, g, lds, blockIdx.x, blockIdx.y, 0);
+}
+
+// both output-row parities of the transposed conv in one launch; blockIdx.y = channel tile, blockIdx.z = 0: rows 2r
+// (15 taps, dispatched first: the longer workgroups lead), 1: rows 2r + 1 (10 taps)
+template <int NQ, bool STATS>
+__global__ void __launch_bounds__(256, 2)
+kq_dt_kernel(const float* __restrict__ in, const float* __restrict__ wp0, const float* __restrict__ wp1,
+             const float* __restrict__ bias, float* __restrict__ out, QGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (blockIdx.z) q_body<Q_DT1, NQ, STATS>(in, wp1, bias, out, g, lds, blockIdx.x, blockIdx.y, 1);
+    else q_body<Q_DT0, NQ, STATS>(in, wp0, bias, out, g, lds, blockIdx.x, blockIdx.y, 0);
+}
+
+int q_ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+// 256-pixel tile over the Hb x Wb base grid: widest power-of-two rows, then tallest, images fill the rest
+bool q_plan(int N, int K, int M, int Hb, int Wb, int Hi, int Wi, int Ho, int Wo, QGeom* g, int* nq, size_t* lds_bytes,
+            int maxt) {
+    if (K % 8 != 0 || !gx_is_pow2(Hb) || !gx_is_pow2(Wb) || Hb * Wb > 65536) return false;
+    int TW = Wb < 64 ? Wb : 64;
+    int TH = 256 / TW < Hb ? 256 / TW : Hb;
+    int G = 256 / (TW * TH);
+    g->N = N; g->K = K; g->M = M; g->nchunks = K / 8;
+    g->Hb = Hb; g->Wb = Wb; g->Hi = Hi; g->Wi = Wi; g->Ho = Ho; g->Wo = Wo;
+    g->lTH = q_ilog2(TH); g->lTW = q_ilog2(TW); g->lG = q_ilog2(G);
+    g->tiles_h = Hb / TH; g->tiles_w = Wb / TW;
+    g->act = 0; g->stats = nullptr; g->stats_parts = 0;
+    const int CHS = G * (TH + 2) * (TW + 2);
+    if (2 * CHS > 4 * 256) return false;
+    *nq = 2 * CHS <= 3 * 256 ? 3 : 4;
+    if ((double)N * K * Hi * Wi * 4.0 >= 2.0e9) return false;     // 31-bit byte offsets into the input tensor
+    const int nw = (maxt * 128 + 255) / 256;
+    *lds_bytes = ((size_t)2 * *nq * 1024 + (size_t)2 * nw * 1024) * sizeof(float);
+    return *lds_bytes <= 160 * 1024;
+}
+
+int g_kq_mode = -1;   // 0 off, 1 auto (layers whose grid fills the chip), 2 every eligible shape
+
+int kq_mode() {
+    if (g_kq_mode < 0) {
+        const char* env = getenv("GENESIS_KQ");
+        g_kq_mode = env ? (env[0] == '0' ? 0 : (env[0] == '2' ? 2 : 1)) : 1;
+    }
+    return g_kq_mode;
+}
+
+bool q_fills(int N, int Hb, int Wb, int M, int mult) {
+    const long wgs = (long)gx_ceil_div(N * Hb * Wb, 256) * gx_ceil_div(M, 64) * mult;
+    return kq_mode() == 2 || wgs >= 384;
+}
+
+template <typename KernelT>
+void q_set_attr(KernelT k, bool* done) {
+    if (!*done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        *done = true;
+    }
+}
+
+}  // namespace
+
+// ---- internal API (gx_common.h) ----------------------------------------------------------------------------------
+bool gx_kq_c3_eligible(int N, int K, int M, int H, int W) {
+    QGeom g; int nq; size_t lds;
+    return kq_mode() != 0 && q_plan(N, K, M, H, W, H, W, H, W, &g, &nq, &lds, 9) && q_fills(N, H, W, M, 1);
+}
+bool gx_kq_deconv_eligible(int N, int K, int M, int Hb, int Wb, int mult) {
+    QGeom g; int nq; size_t lds;
+    return kq_mode() != 0 && q_plan(N, K, M, Hb, Wb, Hb, Wb, 2 * Hb, 2 * Wb, &g, &nq, &lds, 9) && q_fills(N, Hb, Wb, M, mult);
+}
+
+int gx_kq_c3_launch(const float* in, const float* wp, const float* bias, int act, float* out, int N, int K, int M, int H,
+                    int W, hipStream_t s) {
+    QGeom g; int nq; size_t lds;
+    if (!q_plan(N, K, M, H, W, H, W, H, W, &g, &nq, &lds, 9)) { gx_set_error("kq conv3x3: shape not eligible"); return GX_EINVAL; }
+    g.act = act;
+    dim3 grid(g.tiles_h * g.tiles_w * gx_ceil_div(N, 1 << g.lG), gx_ceil_div(M, 64));
+    {
+        GxProf pf(KID_TAPCONV_C3, s, 2.0 * N * (double)M * K * 9 * H * W,
+                  4.0 * ((double)N * K * H * W + (double)N * M * H * W + 9.0 * K * M));
+        static bool a3 = false, a4 = false;
+        if (nq == 3) { q_set_attr(&kq_kernel<Q_C3, 3>, &a3); hipLaunchKernelGGL((kq_kernel<Q_C3, 3>), grid, dim3(256), lds, s, in, wp, bias, out, g); }
+        else { q_set_attr(&kq_kernel<Q_C3, 4>, &a4); hipLaunchKernelGGL((kq_kernel<Q_C3, 4>), grid, dim3(256), lds, s, in, wp, bias, out, g); }
+    }
+    GX_CHECK_LAUNCH("kq conv3x3");
+    return GX_OK;
+}
+
+// transposed conv forward: in [N,K,Hb,Wb] -> out [N,M,2Hb,2Wb]; stats != NULL: GroupNorm block sums in the epilogue
+// (needs one image per tile: *stats_parts = 0 when the tile spans several images and nothing is written)
+int gx_kq_deconv_fwd_launch(const float* in, const float* wp0, const float* wp1, const float* bias, float* out, int N,
+                            int K, int M, int Hb, int Wb, float* stats, int* stats_parts, hipStream_t s) {
+    QGeom g; int nq; size_t lds;
+    if (!q_plan(N, K, M, Hb, Wb, Hb, Wb, 2 * Hb, 2 * Wb, &g, &nq, &lds, 5)) { gx_set_error("kq deconv fwd: shape not eligible"); return GX_EINVAL; }
+    const bool st = stats && g.lG == 0 && (M % 8) == 0;
+    if (stats_parts) *stats_parts = 0;
+    if (st) {
+        g.stats = stats;
+        g.stats_parts = g.tiles_h * g.tiles_w * 2;
+        if (stats_parts) *stats_parts = g.stats_parts;
+    }
+    dim3 grid(g.tiles_h * g.tiles_w * gx_ceil_div(N, 1 << g.lG), gx_ceil_div(M, 64), 2);
+    {
+        GxProf pf(KID_TAPCONV_DT0, s, 2.0 * N * (double)M * K * 25 * Hb * Wb,
+                  4.0 * ((double)N * K * Hb * Wb + (double)N * M * 4 * Hb * Wb + 25.0 * K * M));
+        static bool a[4] = {false, false, false, false};
+        if (nq == 3 && st) { q_set_attr(&kq_dt_kernel<3, true>, &a[0]); hipLaunchKernelGGL((kq_dt_kernel<3, true>), grid, dim3(256), lds, s, in, wp0, wp1, bias, out, g); }
+        else if (nq == 3) { q_set_attr(&kq_dt_kernel<3, false>, &a[1]); hipLaunchKernelGGL((kq_dt_kernel<3, false>), grid, dim3(256), lds, s, in, wp0, wp1, bias, out, g); }
+        else if (st) { q_set_attr(&kq_dt_kernel<4, true>, &a[2]); hipLaunchKernelGGL((kq_dt_kernel<4, true>), grid, dim3(256), lds, s, in, wp0, wp1, bias, out, g); }
+        else { q_set_attr(&kq_dt_kernel<4, false>, &a[3]); hipLaunchKernelGGL((kq_dt_kernel<4, false>), grid, dim3(256), lds, s, in, wp0, wp1, bias, out, g); }
+    }
+    GX_CHECK_LAUNCH("kq deconv fwd");
+    return GX_OK;
+}
+
+// transposed conv data gradient: dy [N,K,2Hb,2Wb] -> dx [N,M,Hb,Wb]
+int gx_kq_deconv_dgrad_launch(const float* dy, const float* wp, float* dx, int N, int K, int M, int Hb, int Wb,
+                              hipStream_t s) {
+    QGeom g; int nq; size_t lds;
+    if (!q_plan(N, K, M, Hb, Wb, 2 * Hb, 2 * Wb, Hb, Wb, &g, &nq, &lds, 9)) { gx_set_error("kq deconv dgrad: shape not eligible"); return GX_EINVAL; }
+    dim3 grid(g.tiles_h * g.tiles_w * gx_ceil_div(N, 1 << g.lG), gx_ceil_div(M, 64));
+    {
+        GxProf pf(KID_TAPCONV_DG, s, 2.0 * N * (double)M * K * 25 * Hb * Wb,
+                  4.0 * ((double)N * K * 4 * Hb * Wb + (double)N * M * Hb * Wb + 25.0 * K * M));
+        static bool a3 = false, a4 = false;
+        if (nq == 3) { q_set_attr(&kq_kernel<Q_DG, 3>, &a3); hipLaunchKernelGGL((kq_kernel<Q_DG, 3>), grid, dim3(256), lds, s, dy, wp, nullptr, dx, g); }
+        else { q_set_attr(&kq_kernel<Q_DG, 4>, &a4); hipLaunchKernelGGL((kq_kernel<Q_DG, 4>), grid, dim3(256), lds, s, dy, wp, nullptr, dx, g); }
+    }
+    GX_CHECK_LAUNCH("kq deconv dgrad");
+    return GX_OK;
+}
+
+extern "C" int gx_kq_policy(int mode) {
+    GX_CHECK_ARG(mode >= 0 && mode <= 2, "gx_kq_policy: mode must be 0 (off), 1 (chip-filling layers) or 2 (every eligible shape)");
+    g_kq_mode = mode;
+    return GX_OK;
+}

@@ -1,9 +1,10 @@
 """On-device batch feeder: the reference converts every sample to fp32 on the host
 (datasets/multid_config.py:131-135: ToTensor + F.interpolate; multi_object_config.py:176-186) and copies the fp32 batch
 to the GPU inside the training loop (train.py:218-220).  Here the uint8 HWC frames are staged in pinned memory, copied
-on a side stream one batch ahead (double buffering) and converted to the fp32 NCHW batch in [0,1] by one HIP launch,
-so the step after compute does not wait on the host."""
+on a side stream one batch ahead (a ring of slots) and converted to the fp32 NCHW batch in [0,1] by one HIP launch, so
+the step after compute does not wait on the host."""
 import ctypes
+import time
 
 import torch
 
@@ -31,30 +32,51 @@ def u8hwc_to_f32chw(frames_u8, img_size=None, out=None):
 
 class DeviceFeeder(object):
     """Iterates fp32 device batches from an iterable of uint8 HWC host batches (numpy arrays or CPU tensors
-    [B, H, W, C]).  Two pinned staging buffers and two device buffers; the host->device copy of batch i+1 runs on a
-    side stream while batch i is being consumed."""
+    [B, H, W, C]).  A ring of `depth` slots (pinned staging buffer + uint8 device buffer); the host->device copy of
+    batch i+1 runs on a side stream while batch i is being consumed, and the consumer's stream waits for it with one
+    event (copy -> compute).
 
-    def __init__(self, host_batches, img_size, device='cuda'):
+    Slot reuse.  TrainStep.step never host-syncs, so the host runs far ahead of the device: the conversion kernel that
+    reads a uint8 slot may still be queued behind many training steps when the ring comes round to that slot again.
+    A slot is therefore refilled only after the HOST has seen both of its events complete -- the copy out of its pinned
+    buffer and the conversion kernel that read its device buffer (`consumed`, recorded on the consumer's stream) -- by
+    polling; nothing on the device waits compute -> copy.  Measured on MI355X / ROCm 7 under HIP-graph replay
+    (tools/feeder_probe.py): a device-side compute -> copy event wait per batch costs 22 % img/s, and a host that blocks
+    on an event fewer than ~30 batches old starves the graph-launch queue (depth 2: 1450 img/s, depth 8: 3700, against
+    6535 resident) -- hence the deep ring: at depth 32 the poll passes immediately in steady state (64x64: 26 MB)."""
+
+    def __init__(self, host_batches, img_size, device='cuda', depth=32):
         self.it = iter(host_batches)
         self.img_size = img_size
         self.device = torch.device(device)
+        self.depth = max(2, int(depth))
         self.copy_stream = torch.cuda.Stream(device=self.device)
-        self.pinned = [None, None]
-        self.dev_u8 = [None, None]
-        self.ready = [None, None]
-        self.slot = 0
+        self.pinned = [None] * self.depth
+        self.dev_u8 = [None] * self.depth
+        self.ready = [None] * self.depth     # copy-stream event: the H2D copy into dev_u8[s] has executed
+        self.consumed = [None] * self.depth  # consumer-stream event: the conversion kernel has read dev_u8[s]
+        self.filled = [False] * self.depth
+        self.head = 0                        # slot the next __next__ consumes
+        self.tail = 0                        # slot the next prefetch fills
         self._prefetch()
+
+    @staticmethod
+    def _host_wait(ev):
+        if ev is not None:
+            while not ev.query():
+                time.sleep(2e-4)
 
     def _prefetch(self):
         try:
             nxt = next(self.it)
         except StopIteration:
-            self.ready[self.slot] = None
             return
         t = torch.as_tensor(nxt)
         if t.dtype != torch.uint8 or t.dim() != 4:
             raise GenesisHipError('feeder: host batches must be uint8 [B,H,W,C]')
-        s = self.slot
+        s = self.tail
+        self._host_wait(self.ready[s])       # pinned[s] is free: its previous copy has executed
+        self._host_wait(self.consumed[s])    # dev_u8[s] is free: the conversion kernel that read it has run
         if self.pinned[s] is None or self.pinned[s].shape != t.shape:
             self.pinned[s] = torch.empty(t.shape, dtype=torch.uint8).pin_memory()
             self.dev_u8[s] = torch.empty(t.shape, dtype=torch.uint8, device=self.device)
@@ -64,17 +86,23 @@ class DeviceFeeder(object):
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
         self.ready[s] = ev
+        self.filled[s] = True
+        self.tail = (s + 1) % self.depth
 
     def __iter__(self):
         return self
 
     def __next__(self):
-        s = self.slot
-        ev = self.ready[s]
-        if ev is None:
+        s = self.head
+        if not self.filled[s]:
             raise StopIteration
-        torch.cuda.current_stream().wait_event(ev)
+        cur = torch.cuda.current_stream()
+        cur.wait_event(self.ready[s])
         x = u8hwc_to_f32chw(self.dev_u8[s], self.img_size)
-        self.slot = 1 - s
-        self._prefetch()          # refills the OTHER slot while the caller trains on x
+        done = torch.cuda.Event()
+        done.record(cur)
+        self.consumed[s] = done
+        self.filled[s] = False
+        self.head = (s + 1) % self.depth
+        self._prefetch()          # refills the next free slot while the caller trains on x
         return x

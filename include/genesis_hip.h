@@ -51,6 +51,10 @@ int gx_conv3x3_wino_supported(int N, int Cin, int Cout, int H, int W);
 /*      which layers gx_conv3x3_fwd / _dgrad send to it: 0 none, 1 those whose grid fills the chip (default; also
  *      GENESIS_WINOGRAD=0/1/2 in the environment), 2 every supported shape. */
 int gx_conv3x3_wino_policy(int mode);
+/*      k-quad tap-conv kernels (gx_kq.hip: 16-byte k-contiguous MFMA operand reads) behind gx_conv3x3_fwd / _dgrad and
+ *      gx_deconv5x5s2_fwd / _dgrad: 0 never, 1 layers whose grid fills the chip (default; GENESIS_KQ=0/1/2 in the
+ *      environment), 2 every eligible shape (power-of-two grids, reduction channels a multiple of 8). */
+int gx_kq_policy(int mode);
 size_t gx_conv3x3_wino_ws_bytes(int N, int Cin, int Cout, int H, int W);
 int gx_conv3x3_wino(const float* x, const float* w, float* y, int N, int Cin, int Cout, int H, int W, int mode,
                     void* ws, size_t ws_bytes, gx_stream_t stream);

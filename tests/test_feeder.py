@@ -35,6 +35,25 @@ def test_feeder_double_buffering_yields_every_batch_in_order():
         assert x.shape == (4, 3, 64, 64) and torch.equal(x.cpu(), host_pipeline(b, 64))
 
 
+def test_feeder_slot_reuse_waits_for_the_compute_stream():
+    """The host runs ahead of the device in the training loop (TrainStep.step never host-syncs): the conversion of batch
+    n may still be queued behind earlier work when the copy of batch n+2 wants to overwrite its uint8 source slot.
+    A long spin kernel on the compute stream before every next() reproduces that; every batch must still come out intact."""
+    from genesis_amd.feeder import DeviceFeeder
+    rng = np.random.RandomState(1)
+    batches = [rng.randint(0, 256, (8, 64, 64, 3)).astype(np.uint8) for _ in range(7)]
+    feeder = DeviceFeeder(batches, 64)
+    out = []
+    for _ in range(len(batches)):
+        torch.cuda._sleep(40_000_000)        # ~20 ms of device time queued ahead of the conversion kernel
+        out.append(next(feeder))
+    with pytest.raises(StopIteration):
+        next(feeder)
+    torch.cuda.synchronize()
+    for x, b in zip(out, batches):
+        assert torch.equal(x.cpu(), host_pipeline(b, 64))
+
+
 def test_no_cpu_path():
     from genesis_amd.feeder import u8hwc_to_f32chw
     with pytest.raises(Exception):
