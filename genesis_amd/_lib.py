@@ -11,7 +11,8 @@ import re
 import torch  # noqa: F401
 
 _HERE = osp.dirname(osp.abspath(__file__))
-LIB_PATH = osp.join(_HERE, 'libgenesis_hip.so')
+# GENESIS_HIP_LIB: an alternative build of the same library (kernel experiments: tools/abl_build.sh)
+LIB_PATH = os.environ.get('GENESIS_HIP_LIB') or osp.join(_HERE, 'libgenesis_hip.so')
 HEADER_PATH = osp.join(osp.dirname(_HERE), 'include', 'genesis_hip.h')
 
 _CTYPES = {

@@ -887,16 +887,29 @@ wgrad_fast_kernel(const float* __restrict__ a_src, const float* __restrict__ b_s
                                                               acc[t], 0, 0, 0);                      \
         }                                                                                            \
     }
-#define GX_WF_COMPUTE(bt_, src_)                                                                     \
+    // order pinned (sched_group_barrier): the LDS reads of the NEXT group first, then this group's 4 * NT MFMAs -- hipcc
+    // otherwise sinks each read to just in front of its first use and the only wave of the SIMD waits out the LDS
+    // latency (s_waitcnt lgkmcnt(0) one MFMA after the read: round-1 ISA, matrix pipe 0.6 busy)
+    constexpr int NDS = NRO * ((NCO + 1) / 2);
+#define GX_WF_SCHED()                                                                                \
+    __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);                                             \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);
+    // one batch = 4 groups; the first group's B values were read by the previous batch (or GX_WF_LOAD_B(0, 0, bva)
+    // after the tile's barrier); lastb_: last batch of the tile (the next tile's buffer is not readable yet)
+#define GX_WF_COMPUTE(bt_, src_, lastb_)                                                             \
     {                                                                                                \
-        GX_WF_LOAD_B(bt_, 0, bva)                                                                    \
         GX_WF_LOAD_B(bt_, 1, bvb)                                                                    \
         GX_WF_MMA(src_, 0, bva)                                                                      \
+        GX_WF_SCHED()                                                                                \
         GX_WF_LOAD_B(bt_, 2, bva)                                                                    \
         GX_WF_MMA(src_, 1, bvb)                                                                      \
+        GX_WF_SCHED()                                                                                \
         GX_WF_LOAD_B(bt_, 3, bvb)                                                                    \
         GX_WF_MMA(src_, 2, bva)                                                                      \
+        GX_WF_SCHED()                                                                                \
+        if (!(lastb_)) GX_WF_LOAD_B((bt_) + 1, 0, bva)                                               \
         GX_WF_MMA(src_, 3, bvb)                                                                      \
+        GX_WF_SCHED()                                                                                \
     }
 
     float a0[4][4], a1[4][4];
@@ -911,23 +924,24 @@ wgrad_fast_kernel(const float* __restrict__ a_src, const float* __restrict__ b_s
         __syncthreads();     // this tile's B has landed (vmcnt drained before the barrier); the other buffer is free
         const bool more = tile + nsp < g.ntiles;
         if (more) GX_WF_PREFETCH_B(nxt, lds + ((it + 1) & 1) * BUF)
+        GX_WF_LOAD_B(0, 0, bva)
         if (nb == 4) {
             GX_WF_LOAD_A(cur, 1, a1)
-            GX_WF_COMPUTE(0, a0)
+            GX_WF_COMPUTE(0, a0, false)
             GX_WF_LOAD_A(cur, 2, a0)
-            GX_WF_COMPUTE(1, a1)
+            GX_WF_COMPUTE(1, a1, false)
             GX_WF_LOAD_A(cur, 3, a1)
-            GX_WF_COMPUTE(2, a0)
+            GX_WF_COMPUTE(2, a0, false)
             if (more) GX_WF_LOAD_A(nxt, 0, a0)
-            GX_WF_COMPUTE(3, a1)
+            GX_WF_COMPUTE(3, a1, true)
         } else if (nb == 2) {
             GX_WF_LOAD_A(cur, 1, a1)
-            GX_WF_COMPUTE(0, a0)
+            GX_WF_COMPUTE(0, a0, false)
             if (more) GX_WF_LOAD_A(nxt, 0, a0)
-            GX_WF_COMPUTE(1, a1)
+            GX_WF_COMPUTE(1, a1, true)
         } else {
             if (more) GX_WF_LOAD_A(nxt, 0, a1)
-            GX_WF_COMPUTE(0, a0)
+            GX_WF_COMPUTE(0, a0, true)
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq)
 #pragma unroll
@@ -941,6 +955,7 @@ wgrad_fast_kernel(const float* __restrict__ a_src, const float* __restrict__ b_s
 #undef GX_WF_PREFETCH_B
 #undef GX_WF_LOAD_A
 #undef GX_WF_COMPUTE
+#undef GX_WF_SCHED
 #undef GX_WF_LOAD_B
 #undef GX_WF_MMA
     // partial[split][gt][ca][cb]

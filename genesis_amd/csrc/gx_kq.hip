@@ -23,6 +23,16 @@
 
 #include <cstdlib>
 
+// measurement builds only (tools/abl_build.sh): 1 = no staging after the first stage (stale LDS, wrong results),
+// 2 = also no barriers -- what the MFMA loop alone sustains, 3 = the product kernel; all of them also report the shader
+// clock and the main-loop time of workgroup 0 in out[0..1]
+#ifndef GX_KQ_ABL
+#define GX_KQ_ABL 0
+#endif
+#ifndef GX_KQ_VAR
+#define GX_KQ_VAR 0
+#endif
+
 namespace {
 
 enum { Q_C3 = 0, Q_DT0 = 1, Q_DT1 = 2, Q_DG = 3 };
@@ -117,8 +127,16 @@ __device__ __forceinline__ void q_phase(f32x16 (&acc)[NCLS][2][2], const float* 
             acc[cl][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][1][j], fb[cur][0][j], acc[cl][1][0], 0, 0, 0);
             acc[cl][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][1][j], fb[cur][1][j], acc[cl][1][1], 0, 0, 0);
         }
+#if GX_KQ_VAR == 1      /* one operand read behind every fourth MFMA */
+        for (int r = 0; r < 4; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            if (i + 1 < nt) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#elif GX_KQ_VAR == 2    /* no pinning: hipcc's own placement */
+#else
         if (i + 1 < nt) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+#endif
     }
 #undef GX_Q_READ
 }
@@ -201,6 +219,10 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
 
     f32x4 xin[NQ];
     f32x4 wreg[NW];
+#if GX_KQ_ABL
+    const long long abl_c0 = __builtin_readcyclecounter();
+    const long long abl_w0 = wall_clock64();
+#endif
 
     // global -> registers: the input tile of (chunk, plane) / the weight slice of (chunk, phase)
 #define GX_Q_LOAD_IN(chunk_, plane_)                                                                   \
@@ -239,12 +261,12 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
 #define GX_Q_STAGE(PH_)                                                                                          \
         {                                                                                                        \
             constexpr int NXT = (PH_) + 1 < NPH ? (PH_) + 1 : 0;                                                 \
-            const bool more = (PH_) + 1 < NPH || !last_chunk;                                                    \
+            const bool more = (GX_KQ_ABL == 0 || GX_KQ_ABL == 3) && ((PH_) + 1 < NPH || !last_chunk);            \
             const int nchunk = (PH_) + 1 < NPH ? chunk : chunk + 1;                                              \
             constexpr bool new_in = C::PLANE_PER_PHASE || NXT == 0;   /* the next stage needs a new input tile */ \
             const int icur = C::PLANE_PER_PHASE ? (s & 1) : (chunk & 1);                                         \
             const int inxt = C::PLANE_PER_PHASE ? ((s + 1) & 1) : ((chunk + 1) & 1);                             \
-            __syncthreads();                                                                                     \
+            if (GX_KQ_ABL != 2) __syncthreads();                                                                 \
             if (more) {      /* issue the next stage's global loads FIRST (hipcc otherwise sinks them to the    \
                                 commit below and the phase ends on their latency) */                             \
                 if (new_in) GX_Q_LOAD_IN(nchunk, NXT)                                                            \
@@ -271,6 +293,10 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
 #undef GX_Q_LOAD_W
 #undef GX_Q_STORE_W
 
+#if GX_KQ_ABL
+    const long long abl_c1 = __builtin_readcyclecounter();
+    const long long abl_w1 = wall_clock64();
+#endif
     // ---- epilogue: C/D layout col = lane & 31 (pixel), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (channel)
     const size_t out_img_stride = (size_t)g.M * g.Ho * g.Wo;
     const int HoWo = g.Ho * g.Wo;
@@ -324,6 +350,13 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
             }
         }
     }
+#if GX_KQ_ABL   /* measurement build: shader-clock ticks per 100 MHz tick of workgroup 0's main loop, and its length in us */
+    if (bx == 0 && by == 0 && tid == 0 && par_a == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        out[0] = (float)((double)(abl_c1 - abl_c0) / (double)(abl_w1 - abl_w0));
+        out[1] = (float)(abl_w1 - abl_w0) * 0.01f;
+    }
+#endif
     if constexpr (STATS) {
         // GroupNorm statistics of the (pre-activation) output without a pass over it: per 8-channel block sums over this
         // workgroup's pixels, transposed through LDS and summed in a fixed order (same scheme as gx_conv.hip's STATS)
@@ -412,6 +445,8 @@ bool q_plan(int N, int K, int M, int Hb, int Wb, int Hi, int Wi, int Ho, int Wo,
     if ((double)N * K * Hi * Wi * 4.0 >= 2.0e9) return false;     // 31-bit byte offsets into the input tensor
     const int nw = (maxt * 128 + 255) / 256;
     *lds_bytes = ((size_t)2 * *nq * 1024 + (size_t)2 * nw * 1024) * sizeof(float);
+    static const char* pad_env = getenv("GENESIS_KQ_ONE_WG");     // measurement: one workgroup per CU
+    if (pad_env && pad_env[0] == '1' && *lds_bytes < 96 * 1024) *lds_bytes = 96 * 1024;
     return *lds_bytes <= 160 * 1024;
 }
 

@@ -114,6 +114,67 @@ __global__ void __launch_bounds__(256, 2) mfma_fp32_probe_kernel(int iters, floa
     if (s == 123.456f) out[0] = s;      // keeps the loop alive
 }
 
+// MODE 5 / 6: the inner loop of gx_kq.hip -- per step four 16-byte LDS operand reads (two A, two B fragments of four
+// k-contiguous values) issued one step AHEAD of the 16 MFMAs that consume them (2 x 2 tiles of 32 x 32, two register
+// sets, order pinned with sched_group_barrier).  6: 2 x 4 tiles (six reads per 32 MFMAs).  Also measures the shader
+// clock: out[1] = s_memtime ticks per 100 MHz wall-clock tick of workgroup 0.
+template <int NJ>
+__global__ void __launch_bounds__(256, 2) mfma_fp32_probe_kq_kernel(int iters, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float opnd[8192];
+    probe_f32x16 acc[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int n = 0; n < NJ; ++n)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[i][n][j] = 0.f;
+    unsigned h = 0x9e3779b9u * (threadIdx.x + 1u) + 0x85ebca6bu * (blockIdx.x + 1u);
+    for (int i = threadIdx.x; i < 8192; i += 256) {
+        h ^= h << 13; h ^= h >> 17; h ^= h << 5;
+        opnd[i] = (float)(h & 0xffffff) * (1.0f / 16777216.0f) - 0.5f;
+    }
+    __syncthreads();
+    const long long c0 = __builtin_readcyclecounter();
+    const long long w0 = wall_clock64();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const f32x4* o4 = reinterpret_cast<const f32x4*>(opnd);
+    const int a_l = lane, b_l = 1024 + wave * 64 + lane;
+    f32x4 fa[2][2], fb[2][NJ];
+#define GX_PROBE_READ(step_, set_)                                                           \
+    {                                                                                         \
+        fa[set_][0] = o4[a_l + (((step_) & 7) << 7)];                                         \
+        fa[set_][1] = o4[a_l + (((step_) & 7) << 7) + 64];                                    \
+        _Pragma("unroll") for (int n = 0; n < NJ; ++n) fb[set_][n] = o4[(b_l + (((step_) & 3) << 8) + n * 16) & 2047]; \
+    }
+    GX_PROBE_READ(0, 0)
+    for (int it = 0; it < iters; it += (NJ == 2 ? 1 : 2)) {     // 32 MFMAs per wave per unit of `iters`
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const int cur = st & 1;
+            GX_PROBE_READ(2 * it + st + 1, cur ^ 1)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < NJ; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][m][j], fb[cur][n][j], acc[m][n], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 + NJ, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8 * NJ, 0);
+        }
+    }
+#undef GX_PROBE_READ
+    const long long c1 = __builtin_readcyclecounter();
+    const long long w1 = wall_clock64();
+    float s = 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NJ; ++n) s += acc[m][n][0] + acc[m][n][15];
+    if (s == 123.456f) out[0] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[1] = (float)((double)(c1 - c0) / (double)(w1 - w0));
+}
+
 }  // namespace
 
 extern "C" {
@@ -121,13 +182,15 @@ extern "C" {
 // launches `wgs` workgroups of 4 waves, each wave issuing 32 * iters MFMA 32x32x2 f32; returns the flop count through
 // *flops (the caller times the stream).  Measurement only.
 int gx_mfma_fp32_probe(int wgs, int iters, int mode, float* scratch, double* flops, gx_stream_t stream) {
-    GX_CHECK_ARG(wgs > 0 && iters > 0 && scratch && flops && mode >= 0 && mode <= 4, "gx_mfma_fp32_probe: bad arguments");
+    GX_CHECK_ARG(wgs > 0 && iters > 0 && scratch && flops && mode >= 0 && mode <= 6, "gx_mfma_fp32_probe: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     if (mode == 0) hipLaunchKernelGGL(mfma_fp32_probe_kernel<0>, dim3(wgs), dim3(256), 0, s, iters, scratch);
     else if (mode == 1) hipLaunchKernelGGL(mfma_fp32_probe_kernel<1>, dim3(wgs), dim3(256), 0, s, iters, scratch);
     else if (mode == 2) hipLaunchKernelGGL(mfma_fp32_probe_kernel<2>, dim3(wgs), dim3(256), 0, s, iters, scratch);
     else if (mode == 3) hipLaunchKernelGGL(mfma_fp32_probe_kernel<3>, dim3(wgs), dim3(256), 0, s, iters, scratch);
-    else hipLaunchKernelGGL(mfma_fp32_probe_kernel<4>, dim3(wgs), dim3(256), 0, s, iters, scratch);
+    else if (mode == 4) hipLaunchKernelGGL(mfma_fp32_probe_kernel<4>, dim3(wgs), dim3(256), 0, s, iters, scratch);
+    else if (mode == 5) hipLaunchKernelGGL(mfma_fp32_probe_kq_kernel<2>, dim3(wgs), dim3(256), 0, s, iters & ~1, scratch);
+    else hipLaunchKernelGGL(mfma_fp32_probe_kq_kernel<4>, dim3(wgs), dim3(256), 0, s, iters & ~1, scratch);
     GX_CHECK_LAUNCH("gx_mfma_fp32_probe");
     *flops = (double)wgs * 4.0 * iters * 32.0 * (2.0 * 32 * 32 * 2);
     return GX_OK;

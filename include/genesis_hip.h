@@ -361,7 +361,9 @@ int gx_u8hwc_to_f32chw(const unsigned char* src, float* dst, int B, int Hs, int 
 
 /* ---- measurement probe: `wgs` workgroups x 4 waves x 32 * iters v_mfma_f32_32x32x2_f32.  mode 0: register operands
  *      only (the fp32-MFMA ceiling); 1: B operand from LDS; 2: A and B from LDS (two ds_read_b32 per MFMA, the tap-conv
- *      pattern); 3: as 2 plus a workgroup barrier every 32 MFMAs; 4: A and B from LDS with one 16-byte read per four MFMAs.  *flops = executed flops; time the stream around it
+ *      pattern); 3: as 2 plus a workgroup barrier every 32 MFMAs; 4: A and B from LDS with one 16-byte read per four MFMAs;
+ *      5: the gx_kq.hip inner loop (four 16-byte reads per 16 MFMAs, issued a step ahead); 6: the same on 2 x 4 tiles; 5 / 6
+ *      store the shader clock they ran at (s_memtime ticks per 100 MHz tick) in scratch[1].  *flops = executed flops; time the stream around it
  *      (tools/mfma_peak.py). */
 int gx_mfma_fp32_probe(int wgs, int iters, int mode, float* scratch, double* flops, gx_stream_t stream);
 
