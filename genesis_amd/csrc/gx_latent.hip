@@ -110,6 +110,18 @@ prior_logp_fwd_kernel(const float* __restrict__ z, const float* __restrict__ lin
     if (lane == 0) log_p[row] = log_q ? log_q[row] - (float)acc : (float)acc;   // KL sample log_q - log_p, or log_p
 }
 
+// ancestral sample of one slot from the AR prior (models/genesisv2_config.py:235-246): lin [B,2D] = prior_linear(h),
+// z = tanh(lin[:D]) + (sigmoid(lin[D:] + 4) + 1e-4) * eps -- the same mean / scale arithmetic as the log-density above
+__global__ void __launch_bounds__(256)
+prior_sample_kernel(const float* __restrict__ lin, const float* __restrict__ eps, int B, int D, float* __restrict__ z) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * D) return;
+    const int b = i / D, d = i - b * D;
+    const float mu = tanhf(lin[(size_t)b * 2 * D + d]);
+    const float sg = sigmoid_t(lin[(size_t)b * 2 * D + D + d] + 4.f) + 1e-4f;
+    z[i] = mu + sg * eps[i];
+}
+
 __global__ void __launch_bounds__(256)
 prior_logp_bwd_kernel(const float* __restrict__ z, const float* __restrict__ lin, const float* __restrict__ glogp,
                       float sign, int B, int K, int D, float* __restrict__ dz, float* __restrict__ dlin) {
@@ -312,6 +324,17 @@ int gx_latent_prior_logp_fwd(const float* z, const float* lin, const float* log_
                            D, log_p);
     }
     GX_CHECK_LAUNCH("gx_latent_prior_logp_fwd");
+    return GX_OK;
+}
+
+int gx_latent_prior_sample(const float* lin, const float* eps, int B, int D, float* z, gx_stream_t stream) {
+    GX_CHECK_ARG(lin && eps && z && B > 0 && D > 0, "gx_latent_prior_sample: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    {
+        GxProf pf(KID_LATENT, s, 0.0, 16.0 * B * D);
+        hipLaunchKernelGGL(prior_sample_kernel, dim3(gx_ceil_div(B * D, 256)), dim3(256), 0, s, lin, eps, B, D, z);
+    }
+    GX_CHECK_LAUNCH("gx_latent_prior_sample");
     return GX_OK;
 }
 

@@ -358,29 +358,38 @@ class GenesisV2(nn.Module):
         return recon, list(x_r.unbind(0)), list(log_m_r.unbind(0))
 
     @torch.no_grad()
-    def sample(self, batch_size, K_steps=None):
-        """models/genesisv2_config.py:227-256: AR-prior rollout, then decode."""
+    def sample(self, batch_size, K_steps=None, eps=None):
+        """models/genesisv2_config.py:227-256: ancestral rollout of the AR prior (LSTM cell -> prior_linear ->
+        N(tanh, to_prior_sigma) sample per slot), then decode.  The rollout runs on the training path's kernels
+        (gx_linear_fwd, gx_lstm_step_fwd, gx_latent_prior_sample); `eps` [K,B,D] injects the standard-normal draws
+        (parity tests: the reference draws them with Normal.sample in this order), default torch.randn."""
         K_steps = self.K_steps if K_steps is None else K_steps
         dev = self.decoder_module[13].weight.device
         D = self.feat_dim
+        if eps is None:
+            eps = torch.randn(K_steps, batch_size, D, device=dev)
+        eps = eps.to(dev).contiguous()
+        assert eps.shape == (K_steps, batch_size, D)
         if self.autoreg_prior and self.prior_lstm is not None:
-            z_k = [torch.randn(batch_size, D, device=dev)]
+            z_k = [eps[0]]
             w_ih, w_hh = self.prior_lstm.weight_ih_l0, self.prior_lstm.weight_hh_l0
             b_ih, b_hh = self.prior_lstm.bias_ih_l0, self.prior_lstm.bias_hh_l0
-            h = torch.zeros(batch_size, w_hh.shape[1], device=dev)
-            c = torch.zeros_like(h)
-            for _ in range(1, K_steps):
-                gates = F.linear(z_k[-1], w_ih, b_ih) + F.linear(h, w_hh, b_hh)
-                i, f, g, o = gates.chunk(4, 1)
-                c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
-                h = torch.sigmoid(o) * torch.tanh(c)
-                mu_raw, sig_raw = self.prior_linear(h).chunk(2, dim=1)
-                mu, sigma = torch.tanh(mu_raw), torch.sigmoid(sig_raw + 4.0) + 1e-4
-                z_k.append(mu + sigma * torch.randn_like(mu))
+            H = w_hh.shape[1]
+            h_prev = c_prev = None
+            for k in range(1, K_steps):
+                gx = hip.linear_fwd(z_k[-1].contiguous(), w_ih, b_ih)                  # [B, 4H]
+                act = torch.empty(batch_size, 4 * H, device=dev)
+                c = torch.empty(batch_size, H, device=dev)
+                h = torch.empty(batch_size, H, device=dev)
+                hip.lstm_step_fwd(gx, h_prev, c_prev, w_hh, b_hh, act, c, h)
+                lin = hip.linear_fwd(h, self.prior_linear.weight, self.prior_linear.bias)   # [B, 2D]
+                z_k.append(hip.latent_prior_sample(lin, eps[k]))
+                h_prev, c_prev = h, c
         else:
-            z_k = [torch.randn(batch_size, D, device=dev) for _ in range(K_steps)]
+            z_k = list(eps.unbind(0))
         recon, x_r_k, log_m_r_k = self.decode_latents(z_k)
-        stats = AttrDict(x_k=x_r_k, log_m_k=log_m_r_k, mx_k=[x * m.exp() for x, m in zip(x_r_k, log_m_r_k)])
+        stats = AttrDict(x_k=x_r_k, log_m_k=log_m_r_k, mx_k=[x * m.exp() for x, m in zip(x_r_k, log_m_r_k)],
+                         z_k=z_k)
         return recon, stats
 
     def get_features(self, image_batch):

@@ -537,6 +537,16 @@ def latent_prior_logp_fwd(z, lin, log_q=None):
     return out
 
 
+def latent_prior_sample(lin, eps):
+    """lin [B,2D] (prior_linear output), eps [B,D] -> z [B,D] ~ N(tanh(lin[:D]), to_prior_sigma(lin[D:]))."""
+    _chk(lin, 'prior_sample.lin'); _chk(eps, 'prior_sample.eps')
+    B, D = eps.shape
+    assert lin.shape == (B, 2 * D)
+    z = torch.empty(B, D, dtype=F32, device=eps.device)
+    _lib.call('gx_latent_prior_sample', _p(lin), _p(eps), B, D, _p(z), _stream())
+    return z
+
+
 def latent_prior_logp_bwd(z, lin, g_out, kl_mode=False):
     _chk(g_out, 'prior_bwd.g_out')
     K, B, D = z.shape

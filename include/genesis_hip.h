@@ -257,6 +257,9 @@ int gx_latent_prior_logp_fwd(const float* z, const float* lin, const float* log_
                              float* out, gx_stream_t stream);
 int gx_latent_prior_logp_bwd(const float* z, const float* lin, const float* g_out, int kl_mode, int B, int K,
                              int D, float* dz, float* dlin, gx_stream_t stream);
+/*      one ancestral step of GenesisV2.sample (models/genesisv2_config.py:235-246): lin [B,2D] = prior_linear(lstm out),
+ *      eps [B,D] standard normal -> z [B,D] = tanh(lin[:D]) + to_prior_sigma(lin[D:]) * eps */
+int gx_latent_prior_sample(const float* lin, const float* eps, int B, int D, float* z, gx_stream_t stream);
 
 /* ---- loss aggregation of the training loop (train.py:226-242) with GECO's beta (utils/geco.py:47-49):
  *      err_mean = mean_b err[b]; kl_mean = sum_r mean_b kl[r][b] (kl [R,B], R = 0 / NULL: no KL term);

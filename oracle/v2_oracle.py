@@ -232,6 +232,32 @@ def mask_latent_loss(p, mu_k, sigma_k, z_k, autoreg_prior=True):
     return kl_k
 
 
+def v2_sample(p, cfg, eps_k):
+    """GenesisV2.sample, models/genesisv2_config.py:227-256, with the standard-normal draws injected: eps_k is the
+    list of K [B,D] draws the reference makes in order (Normal(0,1).sample for the first slot, one p_z.sample() =
+    mu + sigma * eps per later slot).  Returns (recon, x_r_k, log_m_r_k, z_k)."""
+    K = len(eps_k)
+    B, D = eps_k[0].shape
+    if cfg['autoreg_prior']:
+        z_k = [eps_k[0]]
+        H = p['prior_lstm.weight_hh_l0'].size(1)
+        h = torch.zeros(B, H, dtype=eps_k[0].dtype)
+        c = torch.zeros(B, H, dtype=eps_k[0].dtype)
+        for k in range(1, K):
+            gates = F.linear(z_k[-1], p['prior_lstm.weight_ih_l0'], p['prior_lstm.bias_ih_l0']) \
+                + F.linear(h, p['prior_lstm.weight_hh_l0'], p['prior_lstm.bias_hh_l0'])
+            i, f, g, o = gates.chunk(4, 1)
+            c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+            h = torch.sigmoid(o) * torch.tanh(c)
+            lin = F.linear(h, p['prior_linear.weight'], p['prior_linear.bias'])
+            mu_raw, sig_raw = lin.chunk(2, dim=1)
+            z_k.append(torch.tanh(mu_raw) + to_prior_sigma(sig_raw) * eps_k[k])
+    else:
+        z_k = list(eps_k)
+    recon, x_r_k, log_m_r_k = decode_latents(p, z_k, cfg['img_size'], cfg.get('pixel_bound', True))
+    return recon, x_r_k, log_m_r_k, z_k
+
+
 def kl_m_loss(log_m_k, log_m_r_k):
     """MONet.kl_m_loss, models/monet_config.py:157-170 (Categorical KL, probs floored at
     1e-5 then renormalised by Categorical)."""

@@ -97,3 +97,37 @@ class Golden(object):
             floor = (2e-5 + 1e-6 * big) * np.sqrt(len(ref) / max(1, int(s['n'])))
             assert diff <= l2_tol * np.linalg.norm(ref) + floor, \
                 '%s grad %s: sample rel-L2 %.3e' % (self.name, name, diff / (np.linalg.norm(ref) + 1e-30))
+
+
+SAMPLE_CASES = ['tiny', 'tiny_k6', 'tiny_noar', 'metric']
+
+
+class SampleGolden(object):
+    """tests/golden/v2_sample_*.npz: GenesisV2.sample of the real reference with its standard-normal draws recorded
+    (tests/golden/make_golden_sample.py)."""
+
+    def __init__(self, name):
+        self.name = name
+        self.g = np.load(osp.join(GOLDEN, 'v2_sample_%s.npz' % name), allow_pickle=False)
+        self.cfg = json.loads(str(self.g['cfg_json']))
+        self.cfg['pixel_std2'] = self.cfg['pixel_std1']
+        self.B = int(self.g['B'])
+        self.K_arg = None if int(self.g['K_arg']) < 0 else int(self.g['K_arg'])
+        self.eps = torch.from_numpy(self.g['eps'])
+
+    def check(self, key, tensor, rtol, atol):
+        full = 'out/' + key
+        if full in self.g.files:
+            np.testing.assert_allclose(tensor.detach().cpu().float().numpy(), self.g[full], rtol=rtol, atol=atol,
+                                       err_msg='sample %s %s' % (self.name, key))
+        else:
+            T.check_summary(full, tensor, self.g, rtol, atol, 'sample ' + self.name)
+
+    def check_all(self, recon, x_k, log_m_k, z_k, rtol, atol, mx_k=None):
+        st = lambda l: torch.stack(list(l))  # noqa: E731
+        self.check('z_k', st(z_k), rtol, atol)
+        self.check('recon', recon, rtol, atol)
+        self.check('x_k', st(x_k), rtol, atol)
+        self.check('log_m_k', st(log_m_k), rtol, 10 * atol)
+        if mx_k is not None:
+            self.check('mx_k', st(mx_k), rtol, atol)

@@ -6,7 +6,7 @@ import torch
 
 from oracle import v2_oracle as O
 from oracle import ref_import as R
-from tests.common import ALL_CASES, Golden
+from tests.common import ALL_CASES, SAMPLE_CASES, Golden, SampleGolden
 
 
 def _params(gold, requires_grad=False):
@@ -58,6 +58,19 @@ def test_masks_sum_to_one():
     for key in ('log_m_k', 'log_m_r_k'):
         s = torch.stack(stats[key], 4).exp().sum(4)
         assert float((s - 1).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize('case', SAMPLE_CASES)
+def test_sample_vs_golden(case):
+    """GenesisV2.sample (models/genesisv2_config.py:227-256): the oracle's rollout + decode on the reference's recorded
+    draws against the reference's own outputs."""
+    gold = SampleGolden(case)
+    tmpl = O.template_state_dict(gold.cfg)
+    from genesis_amd import testing as T
+    p = T.formula_state_dict(tmpl)
+    recon, x_k, log_m_k, z_k = O.v2_sample(p, gold.cfg, list(gold.eps.unbind(0)))
+    gold.check_all(recon, x_k, log_m_k, z_k, rtol=2e-5, atol=2e-6,
+                   mx_k=[x * m.exp() for x, m in zip(x_k, log_m_k)])
 
 
 @pytest.mark.skipif(not R.reference_available(), reason='reference tree not present')
