@@ -395,7 +395,7 @@ class DecoderFn(torch.autograd.Function):
     def forward(ctx, z, coords, *params):
         N, D = z.shape
         d = coords.shape[-1]
-        h = torch.cat((z.view(N, D, 1, 1).expand(-1, -1, d, d), coords.expand(N, -1, -1, -1)), 1).contiguous()
+        h = hip.broadcast_concat(z.contiguous(), coords)      # BroadcastLayer + PixelCoords: one launch, no torch.cat
         saved = []
         ow, ob = params[16], params[17]
         ow2 = ow.detach().view(ow.shape[0], -1)
@@ -543,9 +543,11 @@ class DirectConvActFn(torch.autograd.Function):
 class BroadcastDecoderFn(torch.autograd.Function):
     """BroadcastDecoder (modules/decoders.py:21-35): z [N, L] -> [N, out, S, S].
     args: z, coords [1,2,S+2L,S+2L], act, then L x (w [h,cin,3,3], b [h]), out_w [out, h], out_b.
-    The L VALID 3x3 convs run as 'same' convs on the (S+2L)^2 canvas on the fp32 MFMA tap-conv kernel; the centre
-    crop of the final 1x1 conv equals the valid chain exactly (and so do all gradients: positions polluted by the
-    canvas border never reach the crop)."""
+    The L VALID 3x3 convs run as 'same' convs on the (S+2L)^2 canvas; the centre crop of the final 1x1 conv equals the
+    valid chain exactly (and so do all gradients: positions polluted by the canvas border never reach the crop).
+    The spatial broadcast + coordinate concat (modules/blocks.py:104-130) is never materialised: the first conv is
+    evaluated from z, the tap sums of its weights and the row / column coordinate vectors (gx_bcast_conv3x3_*), the
+    remaining convs on the fp32 MFMA tap-conv kernel."""
 
     @staticmethod
     def forward(ctx, z, coords, act, *params):
@@ -553,22 +555,30 @@ class BroadcastDecoderFn(torch.autograd.Function):
         N, L = z.shape
         d = coords.shape[-1]
         S = d - 2 * nl
-        h = torch.cat((z.view(N, L, 1, 1).expand(-1, -1, d, d), coords.expand(N, -1, -1, -1)), 1).contiguous()
+        z = z.contiguous()
+        rowc = coords[0, 0, :, 0].contiguous()       # g_1 varies along rows, g_2 along columns (blocks.py:121-126)
+        colc = coords[0, 1, 0, :].contiguous()
         acts = []
+        h = None
         for l in range(nl):
             w, b = params[2 * l], params[2 * l + 1]
-            y = hip.conv3x3_bias_act_fwd(h, w, b, act)
+            if l == 0:
+                y = hip.bcast_conv3x3_fwd(z, w, b, rowc, colc, act)
+            else:
+                y = hip.conv3x3_bias_act_fwd(h, w, b, act)
             acts.append((h, y))
             h = y
         ow, ob = params[2 * nl], params[2 * nl + 1]
         full = hip.conv1x1_fwd(h, ow, ob)
         ctx.acts, ctx.params, ctx.cfg = acts, params, (nl, S, L, act)
+        ctx.bc = (z, rowc, colc)
         return full[:, :, nl:nl + S, nl:nl + S].contiguous()
 
     @staticmethod
     def backward(ctx, g):
         nl, S, L, act = ctx.cfg
         params = ctx.params
+        z, rowc, colc = ctx.bc
         ow, ob = params[2 * nl], params[2 * nl + 1]
         last = ctx.acts[-1][1]
         gfull = torch.zeros(last.shape[0], ow.shape[0], last.shape[2], last.shape[3], device=g.device)
@@ -576,15 +586,19 @@ class BroadcastDecoderFn(torch.autograd.Function):
         da, dow, dob, _ = hip.conv1x1_bwd(last, gfull, ow, ob)
         grads = [None] * len(params)
         grads[2 * nl], grads[2 * nl + 1] = dow, dob
+        dz = None
         for l in reversed(range(nl)):
             w, b = params[2 * l], params[2 * l + 1]
             h, y = ctx.acts[l]
             gw, gb = _gout(w), _gout(b)
-            dy, db = hip.bias_act_bwd(y, da, act, True, gb)
-            dw = hip.conv3x3_wgrad(h, dy, out=gw)
-            da = hip.conv3x3_dgrad(dy, w)
+            if l == 0:
+                # every gradient of the broadcast layer from seven sums per (slot, channel) plane: no canvas, no dy
+                dz, dw, db = hip.bcast_conv3x3_bwd(y, da, z, w, rowc, colc, act, out=(gw, gb))
+            else:
+                dy, db = hip.bias_act_bwd(y, da, act, True, gb)
+                dw = hip.conv3x3_wgrad(h, dy, out=gw)
+                da = hip.conv3x3_dgrad(dy, w)
             grads[2 * l], grads[2 * l + 1] = _ret(gw, dw), _ret(gb, db)
-        dz = da[:, :L].sum((2, 3))
         return (dz, None, None) + tuple(grads)
 
 

@@ -377,6 +377,48 @@ def conv1x1_bwd(x, dy, w, bias, gate=None, out=None):
 ACTS = {None: 0, 'none': 0, 'relu': 1, 'elu': 2}
 
 
+def broadcast_concat(z, coords):
+    """z [N,D], coords [1,2,d,d] -> [N, D+2, d, d] (BroadcastLayer + PixelCoords, modules/blocks.py:104-130)."""
+    _chk(z, 'broadcast_concat.z'); _chk(coords, 'broadcast_concat.coords')
+    N, D = z.shape
+    d = coords.shape[-1]
+    assert coords.numel() == 2 * d * d
+    out = torch.empty(N, D + 2, d, d, dtype=F32, device=z.device)
+    _lib.call('gx_broadcast_concat', _p(z), _p(coords), _p(out), N, D, d, _stream())
+    return out
+
+
+def bcast_conv3x3_fwd(z, w, bias, rowc, colc, act):
+    """act(conv3x3([z broadcast | row coord | col coord], w) + bias) on the d x d canvas without materialising it."""
+    for t, n in ((z, 'z'), (w, 'w'), (bias, 'bias'), (rowc, 'rowc'), (colc, 'colc')):
+        _chk(t, 'bcast_conv3x3_fwd.' + n)
+    N, L = z.shape
+    Co, d = w.shape[0], rowc.numel()
+    assert w.shape == (Co, L + 2, 3, 3) and colc.numel() == d
+    out = torch.empty(N, Co, d, d, dtype=F32, device=z.device)
+    _lib.call('gx_bcast_conv3x3_fwd', _p(z), _p(w), _p(bias), _p(rowc), _p(colc), ACTS[act], _p(out), N, L, Co, d,
+              _stream())
+    return out
+
+
+def bcast_conv3x3_bwd(y, g, z, w, rowc, colc, act, out=(None, None)):
+    """-> (dz [N,L], dw [Co,L+2,3,3], db [Co]); out = preallocated (dw, db) buffers (entries may be None)."""
+    for t, n in ((y, 'y'), (g, 'g'), (z, 'z'), (w, 'w'), (rowc, 'rowc'), (colc, 'colc')):
+        _chk(t, 'bcast_conv3x3_bwd.' + n)
+    N, L = z.shape
+    Co, d = w.shape[0], rowc.numel()
+    assert y.shape == (N, Co, d, d) and g.shape == y.shape
+    dz = torch.empty(N, L, dtype=F32, device=z.device)
+    dw = out[0] if out[0] is not None else torch.empty_like(w)
+    db = out[1] if out[1] is not None else torch.empty(Co, dtype=F32, device=z.device)
+    assert dw.is_contiguous() and dw.shape == w.shape
+    nb = _lib.query('gx_bcast_conv3x3_bwd_ws_bytes', N, Co)
+    ws = _ws(nb, z.device)
+    _lib.call('gx_bcast_conv3x3_bwd', _p(y), _p(g), _p(z), _p(w), _p(rowc), _p(colc), ACTS[act], N, L, Co, d, _p(dz),
+              _p(dw), _p(db), _p(ws), nb, _stream())
+    return dz, dw, db
+
+
 def conv3x3_bias_act_fwd(x, w, bias, act):
     """act(conv3x3 s1 p1 (x, w) + bias) on any HxW grid (W*H % 4 == 0)."""
     _chk(x, 'conv3x3_bias_act.x'); _chk(w, 'conv3x3_bias_act.w'); _chk(bias, 'conv3x3_bias_act.bias')

@@ -237,6 +237,25 @@ int gx_gated_norm_bwd(const float* y, const float* bias, int norm, const float* 
                       int H, int W, float* dy, float* dgamma_h, float* dbeta_h, float* dgamma_g, float* dbeta_g,
                       float* dbias, void* ws, size_t ws_bytes, gx_stream_t stream);
 
+/* ---- spatial broadcast + coordinate channels (modules/blocks.py:104-130 BroadcastLayer / PixelCoords).
+ *      gx_broadcast_concat: out [N, D+2, d, d] = [ z[n] broadcast | coords[0] | coords[1] ], z [N,D], coords [2,d,d]
+ *      (the GENESIS-V2 decoder input, models/genesisv2_config.py:89-90).
+ *      gx_bcast_conv3x3_*: the BroadcastDecoder's first layer act(conv3x3(broadcast canvas, w) + b)
+ *      (modules/decoders.py:25-28) WITHOUT the canvas: w [Co, L+2, 3, 3]; rowc / colc [d] = the row / column
+ *      coordinate (coords[0][:, 0] / coords[1][0, :]: channel L is constant along x, channel L+1 along y);
+ *      out / y / g [N, Co, d, d] on the d x d canvas, d a multiple of 4.  Inside the canvas the result equals the
+ *      conv on the materialised canvas; the one-pixel border ring (outside the VALID conv's output) holds the
+ *      interior formula and must not be consumed.  bwd: g = dL/dout; gradients are taken over the interior
+ *      [1, d-2]^2 (the valid conv's outputs): dz [N,L], dw [Co,L+2,3,3], db [Co] (may be NULL); act 0 none, 1 ReLU,
+ *      2 ELU. */
+int gx_broadcast_concat(const float* z, const float* coords, float* out, int N, int D, int d, gx_stream_t stream);
+int gx_bcast_conv3x3_fwd(const float* z, const float* w, const float* bias, const float* rowc, const float* colc,
+                         int act, float* out, int N, int L, int Co, int d, gx_stream_t stream);
+size_t gx_bcast_conv3x3_bwd_ws_bytes(int N, int Co);
+int gx_bcast_conv3x3_bwd(const float* y, const float* g, const float* z, const float* w, const float* rowc,
+                         const float* colc, int act, int N, int L, int Co, int d, float* dz, float* dw, float* db,
+                         void* ws, size_t ws_bytes, gx_stream_t stream);
+
 /* ---- slot-latent head: reparameterised posterior sample + Monte-Carlo KL terms
  *      (models/genesisv2_config.py:154-160: mu, sigma_ps = z_head(obj).chunk(2); sigma = to_sigma(sigma_ps);
  *      z = Normal(mu, sigma).rsample(); modules/blocks.py:22-23 to_sigma = softplus(x + 0.5) + 1e-8, :28-36

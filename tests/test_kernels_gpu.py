@@ -719,3 +719,47 @@ def test_conv3x3_entry_points_take_the_winograd_path_when_the_grid_fills_the_chi
     assert rows.get('wino_conv_kernel') == 2 and rows.get('tapconv_kernel<0>') == 1, rows
     close(small, y[:2], 2e-5, 2e-5, 'winograd vs direct')
     assert torch.isfinite(dx).all()
+
+
+def _pixel_coords(d):
+    """modules/blocks.py:42-47."""
+    g1, g2 = torch.meshgrid(torch.linspace(-1, 1, d), torch.linspace(-1, 1, d), indexing='ij')
+    return torch.cat((g1.view(1, 1, d, d), g2.view(1, 1, d, d)), 1)
+
+
+@pytest.mark.parametrize('N,D,d', [(5, 64, 4), (3, 16, 8), (2, 7, 5)])
+def test_broadcast_concat(N, D, d):
+    """BroadcastLayer + PixelCoords (modules/blocks.py:104-130) in one launch: bit-exact against expand + cat."""
+    z, coords = rnd(N, D, seed=70), _pixel_coords(d)
+    ref = torch.cat((z.view(N, D, 1, 1).expand(-1, -1, d, d), coords.expand(N, -1, -1, -1)), 1)
+    got = hip.broadcast_concat(z.to(DEV), coords.to(DEV))
+    assert torch.equal(got.cpu(), ref)
+
+
+@pytest.mark.parametrize('N,L,Co,S,nl,act', [(3, 16, 32, 16, 4, 'relu'), (2, 16, 32, 64, 4, 'elu'), (5, 6, 8, 8, 2, None)])
+def test_broadcast_decoder_first_layer_without_the_canvas(N, L, Co, S, nl, act):
+    """modules/decoders.py:25-28 on the BroadcastLayer canvas (blocks.py:104-130): act(VALID conv3x3([z | g_1 | g_2]))
+    from z, the weights' tap sums and the coordinate vectors -- forward on the valid conv's output positions (the canvas
+    interior) and dz / dW / db against autograd through the materialised canvas."""
+    d = S + 2 * nl
+    z = rnd(N, L, seed=71).requires_grad_(True)
+    w = rnd(Co, L + 2, 3, 3, seed=72, scale=0.3).requires_grad_(True)
+    b = rnd(Co, seed=73, scale=0.2).requires_grad_(True)
+    coords = _pixel_coords(d)
+    canvas = torch.cat((z.view(N, L, 1, 1).expand(-1, -1, d, d), coords.expand(N, -1, -1, -1)), 1)
+    pre = F.conv2d(canvas, w, b)                                  # valid: [N, Co, d-2, d-2]
+    ref = pre if act is None else (F.relu(pre) if act == 'relu' else F.elu(pre))
+    g = rnd(N, Co, d - 2, d - 2, seed=74)
+    ref.backward(g)
+    rowc, colc = coords[0, 0, :, 0].contiguous().to(DEV), coords[0, 1, 0, :].contiguous().to(DEV)
+    zd, wd, bd = z.detach().to(DEV), w.detach().to(DEV), b.detach().to(DEV)
+    y = hip.bcast_conv3x3_fwd(zd, wd, bd, rowc, colc, act)
+    assert y.shape == (N, Co, d, d)
+    close(y[:, :, 1:-1, 1:-1], ref, 2e-5, 2e-5, 'broadcast conv fwd (interior)')
+    # the border ring of the incoming gradient must not matter: fill it with garbage
+    gfull = torch.full((N, Co, d, d), 7.5)
+    gfull[:, :, 1:-1, 1:-1] = g
+    dz, dw, db = hip.bcast_conv3x3_bwd(y, gfull.to(DEV), zd, wd, rowc, colc, act)
+    close(dz, z.grad, 1e-4, 1e-5, 'dz')
+    close(dw, w.grad, 1e-4, 1e-5, 'dw')
+    close(db, b.grad, 1e-4, 1e-5, 'db')
