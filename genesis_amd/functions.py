@@ -720,6 +720,110 @@ class PooledHeadFn(torch.autograd.Function):
                 _ret(outs[2], dbe), None)
 
 
+class SBPScanFn(torch.autograd.Function):
+    """T stick-breaking steps in log space (modules/attention.py:42-48,118-124): logits [T, ...], log_s0 [...] or None ->
+    (log_m [T, ...], log_s [T, ...] = the scope after each step); last_scope: the last mask is the remaining scope."""
+
+    @staticmethod
+    def forward(ctx, logits, log_s0, last_scope):
+        logits = logits.contiguous()
+        log_s0 = None if log_s0 is None else log_s0.contiguous()
+        ctx.save_for_backward(logits)
+        ctx.last_scope = bool(last_scope)
+        ctx.has_s0 = log_s0 is not None
+        ctx.set_materialize_grads(False)
+        return hip.sbp_scan_fwd(logits, log_s0, last_scope)
+
+    @staticmethod
+    def backward(ctx, g_m, g_s):
+        logits, = ctx.saved_tensors
+        want_s0 = ctx.has_s0 and ctx.needs_input_grad[1]
+        g_logits, g_s0 = hip.sbp_scan_bwd(logits, _c(g_m), _c(g_s), ctx.last_scope, want_s0)
+        return g_logits, g_s0, None
+
+
+class CategoricalKLFn(torch.autograd.Function):
+    """MONet.kl_m_loss (models/monet_config.py:157-170): log_m, log_m_r [K,B,1,H,W] -> kl_m [B]; the gradient reaches
+    log_m_r only if it requires one (detach_mr_in_klm = False, models/genesisv2_config.py:172-176)."""
+
+    @staticmethod
+    def forward(ctx, log_m, log_m_r):
+        log_m, log_m_r = log_m.contiguous(), log_m_r.contiguous()
+        ctx.save_for_backward(log_m, log_m_r)
+        return hip.categorical_kl_fwd(log_m, log_m_r)
+
+    @staticmethod
+    def backward(ctx, g):
+        log_m, log_m_r = ctx.saved_tensors
+        g_m, g_r = hip.categorical_kl_bwd(log_m, log_m_r, g.contiguous(), ctx.needs_input_grad[1])
+        return g_m, g_r
+
+
+class MaskReconFn(torch.autograd.Function):
+    """log_m_r as a differentiable function of the decoder output: the mixture kernel already produced the values
+    (log_softmax over K of dec's last channel, monet_config.py:137-139); this node only routes a gradient on them back
+    into dec (needed when the mask KL does not detach the reconstructed masks, genesisv2_config.py:172-176)."""
+
+    @staticmethod
+    def forward(ctx, dec, log_m_r):
+        ctx.save_for_backward(log_m_r)
+        ctx.C = dec.shape[1]
+        return log_m_r.view_as(log_m_r)
+
+    @staticmethod
+    def backward(ctx, g):
+        log_m_r, = ctx.saved_tensors
+        return hip.logsoftmax_k_bwd(log_m_r, g.contiguous(), ctx.C), None
+
+
+class LSTMCellFn(torch.autograd.Function):
+    """One nn.LSTM cell step whose input depends on the previous step's output (LatentSBP, modules/attention.py:103-110:
+    the sampled z_{k-1} is fed back): inp [B,Din], h_prev / c_prev [B,H] or None (zero state) -> (h, c).  Input
+    projection on the dense kernel, recurrent GEMM + gate / cell update in gx_lstm_step_fwd; backward = the step's
+    backward kernel + two dense backward launches."""
+
+    @staticmethod
+    def forward(ctx, inp, h_prev, c_prev, w_ih, w_hh, b_ih, b_hh):
+        inp = inp.contiguous()
+        B = inp.shape[0]
+        H = w_hh.shape[1]
+        gx = hip.linear_fwd(inp, w_ih, b_ih)
+        act = torch.empty(B, 4 * H, device=inp.device)
+        c = torch.empty(B, H, device=inp.device)
+        h = torch.empty(B, H, device=inp.device)
+        hp = None if h_prev is None else h_prev.contiguous()
+        cp = None if c_prev is None else c_prev.contiguous()
+        hip.lstm_step_fwd(gx, hp, cp, w_hh, b_hh, act, c, h)
+        ctx.save_for_backward(inp, hp, cp, act, c)
+        ctx.params = (w_ih, w_hh, b_ih, b_hh)
+        ctx.set_materialize_grads(False)
+        return h, c
+
+    @staticmethod
+    def backward(ctx, g_h, g_c):
+        inp, hp, cp, act, c = ctx.saved_tensors
+        w_ih, w_hh, b_ih, b_hh = ctx.params
+        B, H = c.shape
+        dev = inp.device
+        if g_h is None:
+            g_h = torch.zeros(B, H, device=dev)
+        dgates = torch.empty(B, 4 * H, device=dev)
+        dc_prev = torch.empty(B, H, device=dev)
+        hip.lstm_step_bwd(g_h.contiguous(), None, w_hh, act, c, cp, _c(g_c), dgates, dc_prev)
+        o_wih, o_whh, o_bih, o_bhh = _gout(w_ih), _gout(w_hh), _gout(b_ih), _gout(b_hh)
+        dinp, dw_ih, db = hip.linear_bwd(inp, w_ih, None, dgates, None, need_dx=ctx.needs_input_grad[0],
+                                         out_dw=o_wih, out_db=o_bih)
+        if hp is not None:
+            dh_prev, dw_hh, _ = hip.linear_bwd(hp, w_hh, None, dgates, None, need_dx=True, need_db=False, out_dw=o_whh)
+        else:
+            dh_prev = None
+            dw_hh = torch.zeros_like(w_hh) if o_whh is None else o_whh.zero_()
+        if o_bhh is not None:
+            o_bhh.copy_(db)
+        return (dinp, dh_prev, dc_prev if cp is not None else None, _ret(o_wih, dw_ih), _ret(o_whh, dw_hh),
+                _ret(o_bih, db), _ret(o_bhh, db))
+
+
 # ---------------------------------------------------------------------------------------------- dense layers
 class LinearFn(torch.autograd.Function):
     """act(F.linear(x, w, b)) on the 16x16-tile fp32 MFMA dense kernel; x [..., K] (leading dims flattened)."""

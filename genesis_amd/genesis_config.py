@@ -56,18 +56,6 @@ class _LatentSBPParams(nn.Module):
         self.linear = nn.Linear(2 * core.z_size, 2 * core.z_size)
 
 
-def _lstm_cell(lstm, inp, state):
-    H = lstm.weight_hh_l0.shape[1]
-    if state is None:
-        state = (inp.new_zeros(inp.shape[0], H), inp.new_zeros(inp.shape[0], H))
-    h, c = state
-    gates = F.linear(inp, lstm.weight_ih_l0, lstm.bias_ih_l0) + F.linear(h, lstm.weight_hh_l0, lstm.bias_hh_l0)
-    i, f, g, o = gates.chunk(4, 1)
-    c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
-    h = torch.sigmoid(o) * torch.tanh(c)
-    return h, (h, c)
-
-
 class Genesis(nn.Module):
 
     def __init__(self, cfg):
@@ -115,19 +103,21 @@ class Genesis(nn.Module):
         mean, var = core.posterior(h)
         mu_k, sigma_k = [mean], [var.sqrt()]
         z_k = [mean + sigma_k[0] * eps_m[0]]
-        state = None
+        L = ap.lstm
+        hs = cs = None
         for step in range(1, K):
-            out, state = _lstm_cell(ap.lstm, torch.cat([h, z_k[-1]], 1), state)
-            mean_k, var_raw = ap.linear(out).chunk(2, dim=1)
-            sig = F.softplus(var_raw + 0.5) + 1e-8           # sqrt(to_var(x)) == to_sigma(x)
-            mu_k.append(mean_k); sigma_k.append(sig); z_k.append(mean_k + sig * eps_m[step])
+            # the recurrent core on the HIP LSTM-step / dense kernels (the sampled z is fed back: one cell per step)
+            hs, cs = fn.LSTMCellFn.apply(torch.cat([h, z_k[-1]], 1), hs, cs, L.weight_ih_l0, L.weight_hh_l0,
+                                         L.bias_ih_l0, L.bias_hh_l0)
+            lin = fn.linear(hs, ap.linear.weight, ap.linear.bias)                     # (mean | var_raw) [B, 2z]
+            # sqrt(to_var(x)) == to_sigma(x) = softplus(x + 0.5) + 1e-8: the V2 posterior kernel with one slot
+            z1, mu1, sig1, _ = fn.PosteriorFn.apply(lin.unsqueeze(1), eps_m[step].unsqueeze(0))
+            mu_k.append(mu1[0]); sigma_k.append(sig1[0]); z_k.append(z1[0])
         logits = core.decode(torch.cat(z_k, 0)).view(K, B, 1, self.img_size, self.img_size)
-        log_s_k = [torch.zeros_like(x[:, :1])]
-        log_m_k = []
-        for step in range(K):
-            log_m_k.append(log_s_k[step] + F.logsigmoid(logits[step]))
-            log_s_k.append(log_s_k[step] + F.logsigmoid(-logits[step]))
-        log_m_k[K - 1] = log_s_k[K - 1]
+        # K stick-breaking steps in one launch; the last mask is the remaining scope (genesis_config.py:167-169)
+        log_m, log_s = fn.SBPScanFn.apply(logits, None, True)
+        log_m_k = list(log_m.unbind(0))
+        log_s_k = [torch.zeros_like(x[:, :1])] + list(log_s.unbind(0))
         return log_m_k, log_s_k, mu_k, sigma_k, z_k
 
     def _prior_m(self, z_kbd):

@@ -229,14 +229,19 @@ class GenesisV2(nn.Module):
         p.extend((self.decoder_module[13].weight, self.decoder_module[13].bias))
         return p
 
-    def _decode(self, z_kbd, x=None):
-        """z [K,B,D] -> (dec [K*B,4,H,W]) -> mixture.  Returns (err, recon, x_r [K,...], log_m_r [K,...])."""
+    def _decode(self, z_kbd, x=None, grad_through_masks=False):
+        """z [K,B,D] -> (dec [K*B,4,H,W]) -> mixture.  Returns (err, recon, x_r [K,...], log_m_r [K,...]).
+        grad_through_masks: log_m_r carries a gradient back into the decoder (the mixture kernel's own outputs are
+        non-differentiable by-products)."""
         K, B, D = z_kbd.shape
         _, dec_coords = self._grid(z_kbd.device)
         dec = fn.DecoderFn.apply(z_kbd.reshape(K * B, D), dec_coords, *self._decoder_params())
         if x is None:
             x = torch.zeros(B, 3, self.img_size, self.img_size, device=z_kbd.device)
-        return fn.MixtureFn.apply(x, dec, K, float(self.std), bool(self.pixel_bound))
+        err, recon, x_r, log_m_r = fn.MixtureFn.apply(x, dec, K, float(self.std), bool(self.pixel_bound))
+        if grad_through_masks:
+            log_m_r = fn.MaskReconFn.apply(dec, log_m_r)
+        return err, recon, x_r, log_m_r
 
     def _prior_hidden(self, z_kbd):
         """LSTM of the AR prior from the zero state over z_1..z_{K-1} (models/genesis_config.py:297-307)."""
@@ -313,7 +318,7 @@ class GenesisV2(nn.Module):
             with fn.side_branch(z, log_q):
                 kl = self._component_kl(z, log_q)
         # --- Decode latents, reconstruction loss
-        err, recon, x_r, log_m_r = self._decode(z, x)
+        err, recon, x_r, log_m_r = self._decode(z, x, self.klm_loss and not self.detach_mr_in_klm)
         if forked:
             fn.join_branch()
         else:
@@ -326,13 +331,8 @@ class GenesisV2(nn.Module):
         log_m_r_k = list(log_m_r.unbind(0))
         # -- Optional: Attention mask loss (MONet.kl_m_loss, models/monet_config.py:157-170)
         if self.klm_loss:
-            if not self.detach_mr_in_klm:
-                raise NotImplementedError('klm_loss with detach_mr_in_klm=False is not on the HIP path')
-            q = log_m.squeeze(2).exp().clamp_min(1e-5)               # [K,B,H,W]
-            p_ = log_m_r.squeeze(2).exp().clamp_min(1e-5)
-            q = q / q.sum(0, keepdim=True)
-            p_ = p_ / p_.sum(0, keepdim=True)
-            losses['kl_m'] = (q * (q.log() - p_.log())).sum(0).flatten(1).sum(1)
+            # genesisv2_config.py:172-176: the reconstructed masks are detached unless detach_mr_in_klm is off
+            losses['kl_m'] = fn.CategoricalKLFn.apply(log_m, log_m_r.detach() if self.detach_mr_in_klm else log_m_r)
         losses['kl_l_k'] = SlotList(kl.unbind(0), stacked=kl)
 
         # derived visualisation outputs are evaluated on first access (a training step never reads them)

@@ -419,6 +419,58 @@ def bcast_conv3x3_bwd(y, g, z, w, rowc, colc, act, out=(None, None)):
     return dz, dw, db
 
 
+def sbp_scan_fwd(logits, log_s0=None, last_scope=False):
+    """logits [T, ...] -> (log_m [T, ...], log_s [T, ...]): T stick-breaking steps in one launch."""
+    _chk(logits, 'sbp_scan_fwd.logits'); _chk(log_s0, 'sbp_scan_fwd.log_s0')
+    T = logits.shape[0]
+    P = logits[0].numel()
+    log_m, log_s = torch.empty_like(logits), torch.empty_like(logits)
+    _lib.call('gx_sbp_scan_fwd', _p(logits), _p(log_s0), T, P, int(bool(last_scope)), _p(log_m), _p(log_s), _stream())
+    return log_m, log_s
+
+
+def sbp_scan_bwd(logits, g_log_m, g_log_s, last_scope=False, want_g_s0=False):
+    _chk(logits, 'sbp_scan_bwd.logits'); _chk(g_log_m, 'sbp_scan_bwd.g_log_m'); _chk(g_log_s, 'sbp_scan_bwd.g_log_s')
+    T = logits.shape[0]
+    P = logits[0].numel()
+    g_logits = torch.empty_like(logits)
+    g_s0 = torch.empty_like(logits[0]) if want_g_s0 else None
+    _lib.call('gx_sbp_scan_bwd', _p(logits), _p(g_log_m), _p(g_log_s), T, P, int(bool(last_scope)), _p(g_logits),
+              _p(g_s0), _stream())
+    return g_logits, g_s0
+
+
+def categorical_kl_fwd(log_m, log_m_r):
+    """log_m, log_m_r [K,B,1,H,W] (slot-major) -> kl [B] (MONet.kl_m_loss)."""
+    _chk(log_m, 'categorical_kl.log_m'); _chk(log_m_r, 'categorical_kl.log_m_r')
+    K, B = log_m.shape[0], log_m.shape[1]
+    HW = log_m[0, 0].numel()
+    assert log_m_r.shape == log_m.shape
+    kl = torch.empty(B, dtype=F32, device=log_m.device)
+    _lib.call('gx_categorical_kl_fwd', _p(log_m), _p(log_m_r), K, B, HW, _p(kl), _stream())
+    return kl
+
+
+def categorical_kl_bwd(log_m, log_m_r, g_kl, want_r=False):
+    _chk(g_kl, 'categorical_kl_bwd.g_kl')
+    K, B = log_m.shape[0], log_m.shape[1]
+    HW = log_m[0, 0].numel()
+    g_m = torch.empty_like(log_m)
+    g_r = torch.empty_like(log_m_r) if want_r else None
+    _lib.call('gx_categorical_kl_bwd', _p(log_m), _p(log_m_r), _p(g_kl), K, B, HW, _p(g_m), _p(g_r), _stream())
+    return g_m, g_r
+
+
+def logsoftmax_k_bwd(log_m_r, g, C):
+    """g [K,B,1,H,W] on log_m_r = log_softmax_K(dec[:, C-1]) -> g_dec [K*B, C, H, W]."""
+    _chk(log_m_r, 'logsoftmax_k_bwd.log_m_r'); _chk(g, 'logsoftmax_k_bwd.g')
+    K, B = log_m_r.shape[0], log_m_r.shape[1]
+    H, W = log_m_r.shape[-2:]
+    g_dec = torch.empty(K * B, C, H, W, dtype=F32, device=g.device)
+    _lib.call('gx_logsoftmax_k_bwd', _p(log_m_r), _p(g), K, B, H * W, C, _p(g_dec), _stream())
+    return g_dec
+
+
 def conv3x3_bias_act_fwd(x, w, bias, act):
     """act(conv3x3 s1 p1 (x, w) + bias) on any HxW grid (W*H % 4 == 0)."""
     _chk(x, 'conv3x3_bias_act.x'); _chk(w, 'conv3x3_bias_act.w'); _chk(bias, 'conv3x3_bias_act.bias')

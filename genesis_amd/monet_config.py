@@ -137,8 +137,9 @@ class MONet(nn.Module):
         for step in range(self.K_steps - 1):
             feat = fn.UNetEncoderFn.apply(torch.cat((x, log_s_k[step]), 1), core.num_blocks, 0, *core.flat_params())
             a = fn.Conv1x1Fn.apply(feat, core.final_conv.weight, core.final_conv.bias)
-            log_m_k.append(log_s_k[step] + F.logsigmoid(a))
-            log_s_k.append(log_s_k[step] + F.logsigmoid(-a))
+            lm, ls = fn.SBPScanFn.apply(a.unsqueeze(0), log_s_k[step], False)     # one stick-breaking step, one launch
+            log_m_k.append(lm[0])
+            log_s_k.append(ls[0])
         log_m_k.append(log_s_k[-1])
         return log_m_k, log_s_k
 
@@ -167,11 +168,7 @@ class MONet(nn.Module):
         losses = AttrDict()
         losses['err'] = err
         # Categorical KL between attention and reconstructed masks (monet_config.py:157-170)
-        q = log_m.squeeze(2).exp().clamp_min(1e-5)
-        p_ = log_m_r.squeeze(2).exp().clamp_min(1e-5)
-        q = q / q.sum(0, keepdim=True)
-        p_ = p_ / p_.sum(0, keepdim=True)
-        losses['kl_m'] = (q * (q.log() - p_.log())).sum(0).flatten(1).sum(1)
+        losses['kl_m'] = fn.CategoricalKLFn.apply(log_m, log_m_r)
         # MC KL of the component latents against N(0,1) (utils/misc.py:238-255)
         kl = (_normal_log_prob(z, mu, sigma) - _normal_log_prob(z, 0., 1.)).sum(1)      # [K*B]
         losses['kl_l_k'] = list(kl.view(K, B).unbind(0))

@@ -237,6 +237,28 @@ int gx_gated_norm_bwd(const float* y, const float* bias, int norm, const float* 
                       int H, int W, float* dy, float* dgamma_h, float* dbeta_h, float* dgamma_g, float* dbeta_g,
                       float* dbias, void* ws, size_t ws_bytes, gx_stream_t stream);
 
+/* ---- stick-breaking mask recursion in log space (modules/attention.py:31-51 SimpleSBP, :118-124 LatentSBP):
+ *      log_m[t] = s_t + logsigmoid(l_t), s_{t+1} = s_t + logsigmoid(-l_t), s_0 = log_s0 (NULL: 0); logits / log_m /
+ *      log_s [T,P] (log_s[t] = the scope AFTER step t); last_scope: log_m[T-1] = s_{T-1}, the remaining scope
+ *      (genesis_config.py:167-169).  bwd: g_log_m / g_log_s [T,P] (either may be NULL) -> g_logits [T,P],
+ *      g_log_s0 [P] (may be NULL). */
+int gx_sbp_scan_fwd(const float* logits, const float* log_s0, int T, size_t P, int last_scope, float* log_m,
+                    float* log_s, gx_stream_t stream);
+int gx_sbp_scan_bwd(const float* logits, const float* g_log_m, const float* g_log_s, int T, size_t P, int last_scope,
+                    float* g_logits, float* g_log_s0, gx_stream_t stream);
+/* ---- MONet.kl_m_loss (models/monet_config.py:157-170): per image, sum over pixels of KL(Cat(q) || Cat(p)) with
+ *      q = max(exp(log_m), 1e-5), p = max(exp(log_m_r), 1e-5) renormalised over K; log_m / log_m_r [K,B,HW] slot-major,
+ *      kl [B].  bwd: g_kl [B] -> g_log_m and, when g_log_m_r != NULL (detach_mr_in_klm = False,
+ *      genesisv2_config.py:172-176), the gradient through the reconstructed masks. */
+int gx_categorical_kl_fwd(const float* log_m, const float* log_m_r, int K, int B, int HW, float* kl,
+                          gx_stream_t stream);
+int gx_categorical_kl_bwd(const float* log_m, const float* log_m_r, const float* g_kl, int K, int B, int HW,
+                          float* g_log_m, float* g_log_m_r, gx_stream_t stream);
+/*      gradient of the reconstructed masks log_m_r = log_softmax over K of the decoder's last channel
+ *      (monet_config.py:137-139) back into the decoder output: g [K,B,HW] -> g_dec [K*B, C, HW] (channels < C-1 zero) */
+int gx_logsoftmax_k_bwd(const float* log_m_r, const float* g, int K, int B, int HW, int C, float* g_dec,
+                        gx_stream_t stream);
+
 /* ---- spatial broadcast + coordinate channels (modules/blocks.py:104-130 BroadcastLayer / PixelCoords).
  *      gx_broadcast_concat: out [N, D+2, d, d] = [ z[n] broadcast | coords[0] | coords[1] ], z [N,D], coords [2,d,d]
  *      (the GENESIS-V2 decoder input, models/genesisv2_config.py:89-90).

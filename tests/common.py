@@ -9,7 +9,7 @@ import torch
 from genesis_amd import testing as T
 
 GOLDEN = osp.join(osp.dirname(osp.abspath(__file__)), 'golden')
-ALL_CASES = ['tiny', 'tiny_b3k3', 'tiny_noar', 'tiny_klm', 'tiny_nosemi', 'tiny_laplacian',
+ALL_CASES = ['tiny', 'tiny_b3k3', 'tiny_noar', 'tiny_klm', 'tiny_klm_nodetach', 'tiny_nosemi', 'tiny_laplacian',
              'tiny_epanechnikov', 'metric', 'cfg2', 'cfg5']
 
 

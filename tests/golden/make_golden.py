@@ -32,6 +32,7 @@ CASES = {
     'tiny_b3k3': (dict(K_steps=3, img_size=32, feat_dim=8), 3, 12, 22, True),
     'tiny_noar': (dict(K_steps=4, img_size=32, feat_dim=16, autoreg_prior=False), 2, 13, 23, False),
     'tiny_klm': (dict(K_steps=4, img_size=32, feat_dim=16, klm_loss=True), 2, 14, 24, False),
+    'tiny_klm_nodetach': (dict(K_steps=4, img_size=32, feat_dim=16, klm_loss=True, detach_mr_in_klm=False), 2, 31, 41, False),
     'tiny_nosemi': (dict(K_steps=4, img_size=32, feat_dim=16, semiconv=False), 2, 15, 25, False),
     'tiny_laplacian': (dict(K_steps=4, img_size=32, feat_dim=16, kernel='laplacian'), 2, 16, 26, False),
     'tiny_epanechnikov': (dict(K_steps=4, img_size=32, feat_dim=16, kernel='epanechnikov'), 2, 17, 27, False),

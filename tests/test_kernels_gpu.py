@@ -763,3 +763,94 @@ def test_broadcast_decoder_first_layer_without_the_canvas(N, L, Co, S, nl, act):
     close(dz, z.grad, 1e-4, 1e-5, 'dz')
     close(dw, w.grad, 1e-4, 1e-5, 'dw')
     close(db, b.grad, 1e-4, 1e-5, 'db')
+
+
+@pytest.mark.parametrize('T,B,S,last,with_s0', [(7, 3, 16, True, False), (1, 2, 32, False, True), (4, 2, 8, False, False)])
+def test_stick_breaking_scan(T, B, S, last, with_s0):
+    """modules/attention.py:42-48 / :118-124 (logsigmoid stick breaking), K steps in one launch, forward + backward."""
+    from genesis_amd import functions as fn
+    l = (rnd(T, B, 1, S, S, seed=80) * 4).requires_grad_(True)
+    s0 = (-rnd(B, 1, S, S, seed=81).abs()).requires_grad_(True) if with_s0 else None
+    s = torch.zeros(B, 1, S, S) if s0 is None else s0
+    ms, ss = [], []
+    for t in range(T):
+        ms.append(s if (last and t == T - 1) else s + F.logsigmoid(l[t]))
+        s = s + F.logsigmoid(-l[t])
+        ss.append(s)
+    ref_m, ref_s = torch.stack(ms), torch.stack(ss)
+    gm, gs = rnd(T, B, 1, S, S, seed=82), rnd(T, B, 1, S, S, seed=83)
+    ((ref_m * gm).sum() + (ref_s * gs).sum()).backward()
+    ld = l.detach().to(DEV).requires_grad_(True)
+    s0d = None if s0 is None else s0.detach().to(DEV).requires_grad_(True)
+    got_m, got_s = fn.SBPScanFn.apply(ld, s0d, last)
+    close(got_m, ref_m, 1e-5, 1e-5, 'log_m'); close(got_s, ref_s, 1e-5, 1e-5, 'log_s')
+    ((got_m * gm.to(DEV)).sum() + (got_s * gs.to(DEV)).sum()).backward()
+    close(ld.grad, l.grad, 1e-5, 1e-5, 'g_logits')
+    if s0 is not None:
+        close(s0d.grad, s0.grad, 1e-5, 1e-5, 'g_log_s0')
+
+
+@pytest.mark.parametrize('K,B,S,through_r', [(4, 3, 16, False), (7, 2, 32, True), (2, 2, 8, True)])
+def test_categorical_mask_kl(K, B, S, through_r):
+    """MONet.kl_m_loss (models/monet_config.py:157-170) as torch.distributions writes it, forward and both gradients
+    (the reconstructed-mask side is the detach_mr_in_klm = False branch of genesisv2_config.py:172-176)."""
+    from torch.distributions.categorical import Categorical
+    from torch.distributions.kl import kl_divergence
+    from genesis_amd import functions as fn
+    lm = F.log_softmax(rnd(K, B, 1, S, S, seed=84) * 6, 0).requires_grad_(True)       # some masks fall below 1e-5
+    lr = F.log_softmax(rnd(K, B, 1, S, S, seed=85) * 6, 0).requires_grad_(True)
+    m = torch.max(torch.stack(list(lm), 4).exp(), torch.tensor(1e-5))
+    r = torch.max(torch.stack(list(lr), 4).exp(), torch.tensor(1e-5))
+    ref = kl_divergence(Categorical(m.view(-1, K)), Categorical(r.view(-1, K))).view(B, -1).sum(1)
+    g = rnd(B, seed=86)
+    (ref * g).sum().backward()
+    lmd = lm.detach().to(DEV).requires_grad_(True)
+    lrd = lr.detach().to(DEV).requires_grad_(through_r)
+    got = fn.CategoricalKLFn.apply(lmd, lrd)
+    close(got, ref, 2e-5, 1e-4, 'kl_m')
+    (got * g.to(DEV)).sum().backward()
+    close(lmd.grad, lm.grad, 1e-4, 1e-6, 'g_log_m')
+    if through_r:
+        close(lrd.grad, lr.grad, 1e-4, 1e-6, 'g_log_m_r')
+    else:
+        assert lrd.grad is None
+
+
+def test_lstm_cell_with_fed_back_input():
+    """LatentSBP's recurrent core (modules/attention.py:103-110): the step's input depends on the previous output, so
+    each step is its own autograd node on the HIP LSTM-step kernel; against nn.LSTM stepped one token at a time."""
+    from genesis_amd import functions as fn
+    torch.manual_seed(4)
+    B, Din, H, T = 5, 48, 32, 4
+    lstm = torch.nn.LSTM(Din + H, H)
+    x0 = rnd(B, Din, seed=87)
+    proj = rnd(H, H, seed=88, scale=0.5)
+
+    def run(cell, dev):
+        inp_fixed = x0.to(dev)
+        fb = torch.zeros(B, H, device=dev)
+        state, outs = None, []
+        for _ in range(T):
+            h, state = cell(torch.cat([inp_fixed, fb], 1), state)
+            fb = torch.tanh(h @ proj.to(dev))            # the next input depends on this output
+            outs.append(h)
+        return torch.stack(outs)
+
+    def ref_cell(inp, state):
+        out, state = lstm(inp.unsqueeze(0), state)
+        return out[0], state
+    ref = run(ref_cell, 'cpu')
+    ref.square().sum().backward()
+    ref_grads = [p.grad.clone() for p in lstm.parameters()]
+    dl = torch.nn.LSTM(Din + H, H).to(DEV)
+    dl.load_state_dict(lstm.state_dict())
+
+    def hip_cell(inp, state):
+        hs, cs = (None, None) if state is None else state
+        h, c = fn.LSTMCellFn.apply(inp, hs, cs, dl.weight_ih_l0, dl.weight_hh_l0, dl.bias_ih_l0, dl.bias_hh_l0)
+        return h, (h, c)
+    got = run(hip_cell, DEV)
+    close(got, ref, 1e-5, 1e-5, 'lstm cell outputs')
+    got.square().sum().backward()
+    for p, r in zip(dl.parameters(), ref_grads):
+        close(p.grad, r, 1e-4, 1e-5, 'lstm cell parameter grad')

@@ -10,7 +10,7 @@ from tests.common import SAMPLE_CASES, Golden, SampleGolden
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 
-DEFAULT_CASES = ['tiny', 'tiny_b3k3', 'tiny_noar', 'tiny_klm', 'tiny_nosemi', 'tiny_laplacian',
+DEFAULT_CASES = ['tiny', 'tiny_b3k3', 'tiny_noar', 'tiny_klm', 'tiny_klm_nodetach', 'tiny_nosemi', 'tiny_laplacian',
                  'tiny_epanechnikov', 'metric', 'cfg2', 'cfg5']
 
 
