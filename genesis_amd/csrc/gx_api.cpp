@@ -102,16 +102,17 @@ extern "C" {
 
 int gx_defer_enable(int on) {
     g_gx_defer_on = on > 0;
-    if (on < 0) { g_nw = 0; g_ng = 0; }   // discard whatever is queued (error recovery)
+    if (on < 0) { g_nw = 0; g_ng = 0; gx_wgq_discard(); }   // discard whatever is queued (error recovery)
     return GX_OK;
 }
 
-int gx_defer_pending(void) { return g_nw + g_ng; }
+int gx_defer_pending(void) { return g_nw + g_ng + gx_wgq_pending(); }
 
 int gx_defer_flush(gx_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
-    int rc = GX_OK;
-    if (g_nw) rc = gx_defer_flush_wgrad(g_wq, g_nw, s);
+    // queued weight-gradient jobs first: grouped launches, which queue their slab reductions below
+    int rc = gx_wgq_flush(s);
+    if (rc == GX_OK && g_nw) rc = gx_defer_flush_wgrad(g_wq, g_nw, s);
     g_nw = 0;
     if (rc == GX_OK && g_ng) rc = gx_defer_flush_gn(g_gq, g_ng, s);
     g_ng = 0;

@@ -135,3 +135,18 @@ int gx_kq_deconv_fwd_launch(const float* in, const float* wp0, const float* wp1,
                             int K, int M, int Hb, int Wb, float* stats, int* stats_parts, hipStream_t s);
 int gx_kq_deconv_dgrad_launch(const float* dy, const float* wp, float* dx, int N, int K, int M, int Hb, int Wb,
                               hipStream_t s);
+
+// ---- second-generation weight gradients (gx_wgq.hip): LDS-DMA staging of both operands, grouped launches -------------
+bool gx_wgq_c3_eligible(int N, int Cin, int Cout, int H, int W);
+bool gx_wgq_deconv_eligible(int N, int Cin, int Cout, int Hb, int Wb);
+int gx_wgq_max_split(int CA, int CB);
+// ws: room for ws_slabs split-K slabs of Ttot * CApad * CBpad floats.  With deferral on (gx_defer_enable) the job is only
+// queued: gx_defer_flush launches all queued jobs in groups and then the batched slab reduce.
+int gx_wgq_c3(const float* x, const float* dy, float* dw, int N, int Cin, int Cout, int H, int W, float* ws, int ws_slabs,
+              hipStream_t s);
+int gx_wgq_deconv(const float* x, const float* dy, float* dw, int N, int Cin, int Cout, int Hb, int Wb, float* ws,
+                  int ws_slabs, hipStream_t s);
+int gx_wgq_pending(void);
+void gx_wgq_discard(void);
+int gx_wgq_flush(hipStream_t s);
+int gx_wgrad_reduce_now(const GxWgradRed& r, hipStream_t s);    // gx_conv.hip: dw = sum of the slabs (overwrites)

@@ -31,6 +31,10 @@
 #include <cstdlib>
 #include <vector>
 
+#ifndef GX_WG_ABL
+#define GX_WG_ABL 0   /* measurement builds: 1 = no B staging after the first tile, 2 = no A loads after the first, 4 = no barrier */
+#endif
+
 namespace {
 
 enum { M_C3 = 0, M_DT0 = 1, M_DT1 = 2, M_DG = 3 };
@@ -835,7 +839,7 @@ wgrad_fast_kernel(const float* __restrict__ a_src, const float* __restrict__ b_s
     }
     // one batch of A: 4 groups x 4 consecutive pixels of this lane's channel row
 #define GX_WF_LOAD_A(org_, bt_, dst_)                                                               \
-    {                                                                                                \
+    if (!(GX_WG_ABL & 2) || it == 0) {                                                               \
         GX_WF_ORIGIN(org_, ai0, aR0, aC0)                                                           \
         const float* abase = a_lane + (size_t)ai0 * a_img + (size_t)(WT::SA * aR0) * g.Wa + WT::SA * aC0; \
         _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                           \
@@ -914,16 +918,20 @@ wgrad_fast_kernel(const float* __restrict__ a_src, const float* __restrict__ b_s
 
     float a0[4][4], a1[4][4];
     int tile = sp;
+    int it = 0;
     if (tile < g.ntiles) {
         GX_WF_PREFETCH_B(cur, lds)
         GX_WF_LOAD_A(cur, 0, a0)
     }
-    int it = 0;
     for (; tile < g.ntiles; tile += nsp, ++it) {
         float* buf = lds + (it & 1) * BUF;
+#if !(GX_WG_ABL & 4)
         __syncthreads();     // this tile's B has landed (vmcnt drained before the barrier); the other buffer is free
+#endif
         const bool more = tile + nsp < g.ntiles;
+#if !(GX_WG_ABL & 1)
         if (more) GX_WF_PREFETCH_B(nxt, lds + ((it + 1) & 1) * BUF)
+#endif
         GX_WF_LOAD_B(0, 0, bva)
         if (nb == 4) {
             GX_WF_LOAD_A(cur, 1, a1)
@@ -1631,6 +1639,17 @@ int gx_defer_flush_wgrad(const GxWgradRed* items, int n, hipStream_t s) {
     return GX_OK;
 }
 
+int gx_wgrad_reduce_now(const GxWgradRed& r, hipStream_t s) {
+    const int total = r.Ttot * r.CA * r.CB;
+    {
+        GxProf pf(KID_WGRAD_REDUCE, s, 0.0, 4.0 * ((double)r.nsplit + 1.0) * total);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx_ceil_div(total, 64)), dim3(256), 0, s, r.partial, r.dw, r.nsplit,
+                           r.Ttot, r.CA, r.CB, r.CApad, r.CBpad, r.layout, r.ns0, r.ns1, r.ns2, r.ns3);
+    }
+    GX_CHECK_LAUNCH("wgrad_reduce");
+    return GX_OK;
+}
+
 extern "C" {
 
 // workspace = packed weights (+ split-K partial slabs when the plan splits the reduction)
@@ -1865,6 +1884,9 @@ int gx_conv3x3_wgrad(const float* x, const float* dy, float* dw, int N, int Cin,
         GX_CHECK_LAUNCH("gx_conv3x3_wgrad(small Cin reduce)");
         return GX_OK;
     }
+    if (gx_wgq_c3_eligible(N, Cin, Cout, H, W))      // LDS-DMA staged, grouped with the other layers when deferred
+        return gx_wgq_c3(x, dy, dw, N, Cin, Cout, H, W, (float*)ws,
+                         (int)(ws_bytes / sizeof(float) / ((size_t)9 * pl.g.CApad * pl.g.CBpad)), s);
     rc = launch_wgrad<W_C3>(dy, x, (float*)ws, pl, s, "gx_conv3x3_wgrad");
     if (rc) return rc;
     return launch_wgrad_reduce((const float*)ws, dw, pl, 0, s);
@@ -2075,6 +2097,9 @@ int gx_deconv5x5s2_wgrad(const float* x, const float* dy, float* dw, int N, int 
     GX_CHECK_ARG(ws_bytes >= pl.ws_floats * sizeof(float), "gx_deconv5x5s2_wgrad: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     float* part = (float*)ws;
+    if (gx_wgq_deconv_eligible(N, Cin, Cout, Hin, Win))
+        return gx_wgq_deconv(x, dy, dw, N, Cin, Cout, Hin, Win, part,
+                             (int)(ws_bytes / sizeof(float) / ((size_t)25 * pl.g.CApad * pl.g.CBpad)), s);
     if (pl.g.cls_begin[4] > 0) {
         rc = launch_wgrad_deconv(dy, x, part, pl, s, "gx_deconv5x5s2_wgrad");
         if (rc) return rc;

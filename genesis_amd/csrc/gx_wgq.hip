@@ -1,0 +1,459 @@
+// Weight gradients of the conv3x3 / transposed-conv 5x5 s2 layers, second generation ("wgq"): both operands staged
+// global -> LDS by LDS-DMA (16-byte pieces), many layers per launch.
+//
+//   dW[A-channel][B-channel][tap] = sum over images and pixels  dy[A-channel][pixel] * x[B-channel][pixel + tap offset]
+//   (conv3x3: A = Cout, B = Cin; transposed conv: A = Cout of dy at the output parity of the tap, B = Cin)
+//
+// Round-2 measurements on the round-1 kernel (wgrad_fast_kernel, tools/kq_time.py + ablation builds):
+//   * its A operand (dy) goes global -> registers while its B operand goes global -> LDS by LDS-DMA.  hipcc waits
+//     vmcnt(0) at the first use of a register load while a DMA is in flight, so every batch of A values drains the next
+//     tile's whole DMA: without the A loads the transposed-conv classes run 117 instead of 94 TFLOP/s, without either
+//     staging 129.
+//   * a launch costs ~34 us beyond its MFMA time (prologue, slab epilogue, reduce launch): 64 -> 64 @ 64x64 runs
+//     83 TFLOP/s at batch 32 and 111 at batch 256.
+// Here: (1) A and B tiles both arrive by LDS-DMA in 16-byte pieces (1 KiB per wave instruction, 14-18 instructions per
+// thread per tile instead of 64 + register loads), the only vmcnt wait is the one in front of the tile's barrier;
+// LDS images are XOR-swizzled per channel so that the 16-byte operand reads of 16 different channels are conflict free
+// (the swizzle is applied to the per-lane GLOBAL address, the DMA destination stays lane-linear); (2) both column
+// parities of an output-row parity of the transposed conv are accumulated by one workgroup (15 / 10 taps: the 16-byte
+// pieces of dy hold both anyway -- half the dy traffic and launches); (3) one launch takes a table of jobs (layers)
+// and hands every job a share of the 256 workgroups in proportion to its work: fewer, fatter split-K slabs and one
+// prologue / epilogue per GROUP of layers.  Jobs are queued by the deferred-reduction machinery (gx_defer_*) during
+// the backward pass and launched by gx_defer_flush.
+//
+// Workgroup = 4 waves; wave (wm, wn) owns the 32 x 32 block (A channels wm, B channels wn) of all NT taps
+// (v_mfma_f32_32x32x2_f32, k = pixels; lane-half h takes the pixels of tile half h, 4 consecutive pixels per group).
+// Tile = 64 base pixels (TH x TW, TW = 32 or 16); two LDS stages; one barrier per tile.
+#include "gx_common.h"
+
+#include <cstdlib>
+#include <vector>
+
+namespace {
+
+enum { WQ_C3 = 0, WQ_DR0 = 1, WQ_DR1 = 2 };
+
+template <int CLS> struct WqTap;
+template <> struct WqTap<WQ_C3> {
+    static constexpr int NT = 9, SA = 1, PA = 0, NPB = 1, NRO = 3, RO0 = 0;
+    __host__ __device__ static constexpr int ro(int t) { return t / 3; }
+    __host__ __device__ static constexpr int co(int t) { return t % 3; }
+    __host__ __device__ static constexpr int pb(int) { return 0; }
+    __host__ __device__ static constexpr int gt(int t) { return t; }
+};
+// transposed conv k5 s2 p2 op1, output rows 2r + PA: taps t = khi * 5 + kw, kh = 2 khi + PA; x halo offsets
+// (2 - kh / 2, 2 - kw / 2); the tap's column parity kw & 1 selects which of the two interleaved dy values is its A operand
+template <int PA_> struct WqTapDR {
+    static constexpr int NKH = PA_ ? 2 : 3;
+    static constexpr int NT = NKH * 5, SA = 2, PA = PA_, NPB = 2, NRO = NKH, RO0 = 2 - (NKH - 1);
+    __host__ __device__ static constexpr int kh(int t) { return 2 * (t / 5) + PA_; }
+    __host__ __device__ static constexpr int kw(int t) { return t % 5; }
+    __host__ __device__ static constexpr int ro(int t) { return 2 - kh(t) / 2; }
+    __host__ __device__ static constexpr int co(int t) { return 2 - kw(t) / 2; }
+    __host__ __device__ static constexpr int pb(int t) { return kw(t) & 1; }
+    __host__ __device__ static constexpr int gt(int t) { return kh(t) * 5 + kw(t); }
+};
+template <> struct WqTap<WQ_DR0> : WqTapDR<0> {};
+template <> struct WqTap<WQ_DR1> : WqTapDR<1> {};
+
+struct WqJob {
+    const float* a;      // dy [N, CA, SA*Hb, SA*Wb]
+    const float* b;      // x  [N, CB, Hb, Wb]
+    float* partial;      // split-K slabs [split][Ttot][CApad][CBpad]
+    int N, CA, CB, CApad, CBpad, Hb, Wb;
+    int tiles_h, tiles_w, ntiles;       // tiles per image column / row, total
+    int nsplit, nbt;                    // splits per channel block; B-channel blocks (CBpad / 64)
+    int wg_begin;                       // first blockIdx.x of this job
+    int Ttot;                           // taps in the slab (9 / 25)
+};
+constexpr int kMaxJobs = 12;
+struct WqTable { int njobs; WqJob job[kMaxJobs]; };
+
+constexpr int kSB = 40;     // pieces per B channel in LDS ((TH + 2) * (TW + 8) / 4, padded to a multiple of 8)
+
+template <int CLS, int LTW>
+__global__ void __launch_bounds__(256, 1)
+wgq_kernel(const WqTable tab, const float* __restrict__ zeros) {
+    using WT = WqTap<CLS>;
+    constexpr int NT = WT::NT, SA = WT::SA, NRO = WT::NRO, RO0 = WT::RO0;
+    constexpr int TW = 1 << LTW, TH = 64 >> LTW;
+    constexpr int RPA = SA * TW / 4;             // A pieces per tile row
+    constexpr int SAP = TH * RPA;                // A pieces per channel (16 or 32)
+    constexpr int RPB = (TW + 8) / 4;            // B pieces per halo row
+    constexpr int NPB_ = (TH + 2) * RPB;         // B pieces per channel actually used (<= kSB)
+    constexpr int A_PIECES = 64 * SAP, B_PIECES = 64 * kSB;
+    constexpr int STAGE = (A_PIECES + B_PIECES) * 4;          // floats per stage
+    constexpr int NI = (A_PIECES + B_PIECES) / 256;           // DMA instructions per thread per tile
+    static_assert((A_PIECES + B_PIECES) % 256 == 0 && A_PIECES % 64 == 0, "whole wave instructions");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+    // ---- which job, channel block and split (wave-uniform scalar work)
+    int j = 0;
+#pragma unroll 1
+    for (int q = 1; q < tab.njobs; ++q) j = (int)blockIdx.x >= tab.job[q].wg_begin ? q : j;
+    const WqJob& jb = tab.job[j];
+    const int local = (int)blockIdx.x - jb.wg_begin;
+    const int nsp = jb.nsplit;
+    const int blk = local / nsp, sp = local - blk * nsp;
+    const int ca0 = (blk / jb.nbt) * 64, cb0 = (blk % jb.nbt) * 64;
+    const int Hb = jb.Hb, Wb = jb.Wb, Ha = SA * Hb, Wa = SA * Wb;
+    const int HaWa = Ha * Wa, HbWb = Hb * Wb;
+
+    // ---- DMA pieces of this thread: piece L = i * 256 + tid of the stage image, fixed over tiles.
+    //      A region [ch][slot], slot = q ^ (ch & 15); B region [ch][slot], slot = q ^ ((ch >> 1) & 7): the piece that
+    //      lands in slot s is global piece q = s ^ f(ch).
+    int goff[NI];          // float offset from the tile's A / B origin
+    int info[NI];          // bit 0: never valid (padding / channel beyond the tensor); B: halo row | piece column << 8
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int L = i * 256 + tid;
+        if (L < A_PIECES) {
+            const int ch = L / SAP, s = L - ch * SAP;
+            const int q = s ^ (ch & 15);
+            const int row = q / RPA, cp = q - row * RPA;
+            goff[i] = ch * HaWa + SA * row * Wa + 4 * cp;
+            info[i] = (ca0 + ch < jb.CA) ? 0 : 1;
+        } else {
+            const int Lb = L - A_PIECES;
+            const int ch = Lb / kSB, s = Lb - ch * kSB;
+            const int q = s ^ ((ch >> 1) & 7);
+            const int ri = q / RPB, cq = q - ri * RPB;
+            goff[i] = ch * HbWb + ri * Wb + 4 * cq;
+            info[i] = ((q < NPB_ && cb0 + ch < jb.CB) ? 0 : 1) | (ri << 8) | (cq << 16);
+        }
+    }
+
+    // ---- per-lane operand read bases (float indices inside a stage)
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5;                         // tile half (= k slot) of this lane
+    const int cha = wm * 32 + (lane & 31);           // A channel of this lane inside the block
+    const int chb = wn * 32 + (lane & 31);
+    const int a_base = cha * SAP * 4, a_f = cha & 15;
+    const int b_base = A_PIECES * 4 + chb * kSB * 4, b_f = (chb >> 1) & 7;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    // tile -> (image, tile row, tile col), advanced by carries (scalar)
+    const int tpi = jb.tiles_h * jb.tiles_w;
+    int t_img = sp / tpi, t_rem = sp - t_img * tpi;
+    int t_th = t_rem / jb.tiles_w, t_tw = t_rem - t_th * jb.tiles_w;
+    const int d_img = nsp / tpi, d_rem = nsp - d_img * tpi;
+    const int d_th = d_rem / jb.tiles_w, d_tw = d_rem - d_th * jb.tiles_w;
+
+#define GX_WQ_ISSUE(stage_, img_, th_, tw_)                                                                    \
+    {                                                                                                           \
+        const int R0_ = (th_) * TH, C0_ = (tw_) * TW;                                                           \
+        const float* a_t = jb.a + ((size_t)(img_) * jb.CA + ca0) * HaWa + (size_t)(SA * R0_ + WT::PA) * Wa + SA * C0_; \
+        const float* b_t = jb.b + ((size_t)(img_) * jb.CB + cb0) * HbWb + (ptrdiff_t)(R0_ - 1) * Wb + (C0_ - 4); \
+        float* dst_ = lds + (stage_) * STAGE + wave_u * 256;                                                    \
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                                        \
+            const bool isA = i * 256 < A_PIECES;         /* whole instructions belong to one region */          \
+            bool ok = !(info[i] & 1);                                                                           \
+            if (!isA) {                                                                                         \
+                const int row_ = R0_ - 1 + ((info[i] >> 8) & 255), col_ = C0_ - 4 + 4 * (info[i] >> 16);        \
+                ok = ok && row_ >= 0 && row_ < Hb && col_ >= 0 && col_ < Wb;                                    \
+            }                                                                                                   \
+            const float* gp = ok ? (isA ? a_t : b_t) + goff[i] : zeros;                                         \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,                 \
+                (__attribute__((address_space(3))) void*)(dst_ + i * 1024), 16, 0, 0);                          \
+        }                                                                                                       \
+    }
+
+    // operand registers of one 4-pixel group: A 4 (C3) / 8 (DR) values, B NRO rows x 6 values
+    struct Grp { f32x4 a[WT::NPB]; float e0[NRO], e1[NRO]; f32x4 m[NRO]; };
+#define GX_WQ_READ(buf_, g_, dst_)                                                                              \
+    {                                                                                                           \
+        const int jpix = h * 32 + 4 * (g_);                                                                     \
+        const int r_ = jpix >> LTW, c_ = jpix & (TW - 1);                                                       \
+        const int qa = r_ * RPA + (SA * c_) / 4;                                                                \
+        _Pragma("unroll") for (int p = 0; p < WT::NPB; ++p)                                                     \
+            dst_.a[p] = *reinterpret_cast<const f32x4*>((buf_) + a_base + (((qa + p) ^ a_f) << 2));             \
+        _Pragma("unroll") for (int rr = 0; rr < NRO; ++rr) {                                                    \
+            const int qb = (r_ + RO0 + rr) * RPB + (c_ >> 2);                                                   \
+            dst_.e0[rr] = (buf_)[b_base + ((qb ^ b_f) << 2) + 3];                                               \
+            dst_.m[rr] = *reinterpret_cast<const f32x4*>((buf_) + b_base + (((qb + 1) ^ b_f) << 2));            \
+            dst_.e1[rr] = (buf_)[b_base + (((qb + 2) ^ b_f) << 2)];                                             \
+        }                                                                                                       \
+    }
+    // A value of pixel u for column parity pb: conv3x3 a[0][u]; transposed conv: element 2u + pb of the 8 values
+#define GX_WQ_AVAL(src_, pb_, u_) (SA == 1 ? src_.a[0][u_] : src_.a[(2 * (u_) + (pb_)) >> 2][(2 * (u_) + (pb_)) & 3])
+    // B value at halo column offset x (0..5) of row rr
+#define GX_WQ_BVAL(src_, rr_, x_) ((x_) == 0 ? src_.e0[rr_] : ((x_) == 5 ? src_.e1[rr_] : src_.m[rr_][(x_) - 1]))
+#define GX_WQ_MMA(src_)                                                                                         \
+    {                                                                                                           \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                           \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                      \
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(GX_WQ_AVAL(src_, WT::pb(t), u),                   \
+                                                              GX_WQ_BVAL(src_, WT::ro(t) - RO0, WT::co(t) + u), \
+                                                              acc[t], 0, 0, 0);                                 \
+    }
+    constexpr int NDS = WT::NPB + 3 * NRO;     // LDS read instructions per group
+
+    int tile = sp;
+    if (tile < jb.ntiles) GX_WQ_ISSUE(0, t_img, t_th, t_tw)
+    int it = 0;
+    for (; tile < jb.ntiles; tile += nsp, ++it) {
+        const float* buf = lds + (it & 1) * STAGE;
+        __syncthreads();          // this tile has landed (vmcnt drained in front of the barrier); the other stage is free
+        // next tile of this workgroup
+        t_tw += d_tw; t_th += d_th; t_img += d_img;
+        if (t_tw >= jb.tiles_w) { t_tw -= jb.tiles_w; ++t_th; }
+        if (t_th >= jb.tiles_h) { t_th -= jb.tiles_h; ++t_img; }
+        if (tile + nsp < jb.ntiles) GX_WQ_ISSUE((it + 1) & 1, t_img, t_th, t_tw)
+        Grp g0, g1;
+        GX_WQ_READ(buf, 0, g0)
+#pragma unroll
+        for (int g = 0; g < 8; g += 2) {
+            GX_WQ_READ(buf, g + 1, g1)
+            GX_WQ_MMA(g0)
+            __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);
+            if (g + 2 < 8) GX_WQ_READ(buf, g + 2, g0)
+            GX_WQ_MMA(g1)
+            if (g + 2 < 8) __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);
+        }
+    }
+#undef GX_WQ_ISSUE
+#undef GX_WQ_READ
+#undef GX_WQ_AVAL
+#undef GX_WQ_BVAL
+#undef GX_WQ_MMA
+
+    // ---- slab: partial[split][gt][ca][cb]  (C/D layout: col = lane & 31 -> cb, row -> ca)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        float* dst = jb.partial + (((size_t)sp * jb.Ttot + WT::gt(t)) * jb.CApad + ca0 + wm * 32) * jb.CBpad + cb0 +
+                     wn * 32 + (lane & 31);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            dst[(size_t)row * jb.CBpad] = acc[t][reg];
+        }
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+struct PendingJob {
+    WqJob job;
+    int cls, ltw;
+    float* dw; int layout;          // where the reduce writes
+    double flops;
+    int reduce_group;               // jobs of one transposed-conv layer share a reduce record (index of the first)
+};
+std::vector<PendingJob> g_jobs;
+const float* g_zero16 = nullptr;
+
+const float* zero16(hipStream_t s) {
+    if (g_zero16) return g_zero16;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
+    float* p = nullptr;
+    if (hipMalloc((void**)&p, 256) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 256) != hipSuccess) { (void)hipFree(p); return nullptr; }
+    g_zero16 = p;
+    return g_zero16;
+}
+
+template <int CLS, int LTW>
+void wgq_launch_inst(const WqTable& tab, int total_wgs, const float* zeros, hipStream_t s) {
+    using WT = WqTap<CLS>;
+    constexpr int TW = 1 << LTW, TH = 64 >> LTW;
+    constexpr size_t lds = (size_t)2 * (64 * (TH * WT::SA * TW / 4) + 64 * kSB) * 16;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgq_kernel<CLS, LTW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL((wgq_kernel<CLS, LTW>), dim3(total_wgs), dim3(256), lds, s, tab, zeros);
+}
+
+void wgq_launch(int cls, int ltw, const WqTable& tab, int total_wgs, const float* zeros, hipStream_t s) {
+    if (cls == WQ_C3) { if (ltw == 5) wgq_launch_inst<WQ_C3, 5>(tab, total_wgs, zeros, s); else wgq_launch_inst<WQ_C3, 4>(tab, total_wgs, zeros, s); }
+    else if (cls == WQ_DR0) { if (ltw == 5) wgq_launch_inst<WQ_DR0, 5>(tab, total_wgs, zeros, s); else wgq_launch_inst<WQ_DR0, 4>(tab, total_wgs, zeros, s); }
+    else { if (ltw == 5) wgq_launch_inst<WQ_DR1, 5>(tab, total_wgs, zeros, s); else wgq_launch_inst<WQ_DR1, 4>(tab, total_wgs, zeros, s); }
+}
+
+int g_wgq_mode = -1;
+int wgq_mode() {
+    if (g_wgq_mode < 0) {
+        const char* env = getenv("GENESIS_WGQ");
+        g_wgq_mode = env ? (env[0] == '0' ? 0 : 1) : 1;
+    }
+    return g_wgq_mode;
+}
+
+// fills the geometry part of a job; false if the layer is not eligible
+bool wgq_make_job(int sa, const float* a, const float* b, float* partial, int N, int CA, int CB, int Hb, int Wb, int Ttot,
+                  int max_split, WqJob* jb, int* ltw) {
+    if (!gx_is_pow2(Hb) || !gx_is_pow2(Wb) || Wb < 16) return false;
+    const int lt = Wb >= 32 ? 5 : 4;
+    const int TW = 1 << lt, TH = 64 >> lt;
+    if (Hb < TH) return false;
+    if ((double)N * CA * sa * Hb * sa * Wb >= 2.0e9 || (double)N * CB * Hb * Wb >= 2.0e9) return false;   // int offsets per job
+    jb->a = a; jb->b = b; jb->partial = partial;
+    jb->N = N; jb->CA = CA; jb->CB = CB; jb->CApad = gx_round_up(CA, 64); jb->CBpad = gx_round_up(CB, 64);
+    jb->Hb = Hb; jb->Wb = Wb;
+    jb->tiles_h = Hb / TH; jb->tiles_w = Wb / TW; jb->ntiles = N * jb->tiles_h * jb->tiles_w;
+    jb->nbt = jb->CBpad / 64;
+    jb->nsplit = max_split; jb->wg_begin = 0; jb->Ttot = Ttot;
+    *ltw = lt;
+    return true;
+}
+
+// launches the jobs [first, last) of g_jobs that share (cls, ltw) as one grid of ~budget workgroups
+int wgq_launch_group(std::vector<PendingJob*>& grp, int budget, hipStream_t s) {
+    const float* zeros = zero16(s);
+    if (!zeros) { gx_set_error("wgq: zero page unavailable (first call inside a stream capture)"); return GX_ELAUNCH; }
+    double total = 0.0;
+    for (PendingJob* p : grp) total += p->flops;
+    WqTable tab;
+    tab.njobs = (int)grp.size();
+    int wg = 0;
+    double flops = 0.0, bytes = 0.0;
+    for (size_t i = 0; i < grp.size(); ++i) {
+        PendingJob& p = *grp[i];
+        const int nblk = (p.job.CApad / 64) * (p.job.CBpad / 64);
+        int ns = (int)(budget * (p.flops / total) / nblk + 0.5);
+        if (ns < 1) ns = 1;
+        if (ns > p.job.nsplit) ns = p.job.nsplit;          // planned upper bound (workspace size)
+        if (ns > p.job.ntiles) ns = p.job.ntiles;
+        p.job.nsplit = ns;
+        p.job.wg_begin = wg;
+        wg += ns * nblk;
+        tab.job[i] = p.job;
+        flops += p.flops;
+        bytes += 4.0 * ((double)p.job.N * p.job.CB * p.job.Hb * p.job.Wb + (double)ns * nblk * 64 * 64 * WqTap<WQ_C3>::NT);
+    }
+    {
+        const int kid = grp[0]->cls == WQ_C3 ? KID_WGRAD_C3 : (grp[0]->cls == WQ_DR0 ? KID_WGRAD_D00 : KID_WGRAD_D10);
+        GxProf pf(kid, s, flops, bytes);
+        wgq_launch(grp[0]->cls, grp[0]->ltw, tab, wg, zeros, s);
+    }
+    GX_CHECK_LAUNCH("wgq (grouped weight gradients)");
+    return GX_OK;
+}
+
+}  // namespace
+
+// ---- internal API (gx_common.h) ----------------------------------------------------------------------------------
+// upper bound of the splits a job may get (sizes its slab workspace)
+int gx_wgq_max_split(int CA, int CB) {
+    const int nblk = (gx_round_up(CA, 64) / 64) * (gx_round_up(CB, 64) / 64);
+    return gx_ceil_div(256, nblk);
+}
+
+bool gx_wgq_c3_eligible(int N, int Cin, int Cout, int H, int W) {
+    WqJob jb; int ltw;
+    return wgq_mode() && Cin * 9 > 32 && wgq_make_job(1, nullptr, nullptr, nullptr, N, Cout, Cin, H, W, 9, 1, &jb, &ltw);
+}
+bool gx_wgq_deconv_eligible(int N, int Cin, int Cout, int Hb, int Wb) {
+    WqJob jb; int ltw;
+    return wgq_mode() && wgq_make_job(2, nullptr, nullptr, nullptr, N, Cout, Cin, Hb, Wb, 25, 1, &jb, &ltw);
+}
+
+static int wgq_run_or_queue(std::vector<PendingJob>& jobs, hipStream_t s) {
+    if (g_gx_defer_on && zero16(s)) {          // queued: launched in groups by gx_wgq_flush
+        for (PendingJob& p : jobs) g_jobs.push_back(p);
+        return GX_OK;
+    }
+    // immediate: each (cls) job is its own launch with the whole chip; then the reduce record
+    int rc = GX_OK;
+    for (PendingJob& p : jobs) {
+        std::vector<PendingJob*> one{&p};
+        rc = wgq_launch_group(one, 256, s);
+        if (rc) return rc;
+    }
+    PendingJob& f = jobs[0];
+    GxWgradRed r{f.job.partial, f.dw, f.job.nsplit, f.job.Ttot, f.job.CA, f.job.CB, f.job.CApad, f.job.CBpad, f.layout, 0, 0, 0, 0};
+    if (jobs.size() == 2) { r.ns0 = r.ns1 = jobs[0].job.nsplit; r.ns2 = r.ns3 = jobs[1].job.nsplit;
+                            r.nsplit = r.ns0 > r.ns2 ? r.ns0 : r.ns2; }
+    return gx_wgrad_reduce_now(r, s);          // overwrites dw (the deferred batch reduce accumulates)
+}
+
+// conv3x3: dw [Cout][Cin][3][3] from x [N,Cin,H,W], dy [N,Cout,H,W]; ws holds gx_wgq_max_split slabs
+int gx_wgq_c3(const float* x, const float* dy, float* dw, int N, int Cin, int Cout, int H, int W, float* ws,
+              int ws_slabs, hipStream_t s) {
+    PendingJob p;
+    const int cap = ws_slabs < gx_wgq_max_split(Cout, Cin) ? ws_slabs : gx_wgq_max_split(Cout, Cin);
+    if (cap < 1 || !wgq_make_job(1, dy, x, ws, N, Cout, Cin, H, W, 9, cap, &p.job, &p.ltw)) {
+        gx_set_error("wgq conv3x3: shape not eligible");
+        return GX_EINVAL;
+    }
+    p.cls = WQ_C3; p.dw = dw; p.layout = 0; p.reduce_group = -1;
+    p.flops = 2.0 * N * (double)Cout * Cin * 9 * H * W;
+    std::vector<PendingJob> v{p};
+    return wgq_run_or_queue(v, s);
+}
+
+// transposed conv: dw [Cin][Cout][5][5] from x [N,Cin,Hb,Wb], dy [N,Cout,2Hb,2Wb]
+int gx_wgq_deconv(const float* x, const float* dy, float* dw, int N, int Cin, int Cout, int Hb, int Wb, float* ws,
+                  int ws_slabs, hipStream_t s) {
+    PendingJob p0, p1;
+    const int ms = ws_slabs < gx_wgq_max_split(Cout, Cin) ? ws_slabs : gx_wgq_max_split(Cout, Cin);
+    if (ms < 1 || !wgq_make_job(2, dy, x, ws, N, Cout, Cin, Hb, Wb, 25, ms, &p0.job, &p0.ltw)) {
+        gx_set_error("wgq deconv: shape not eligible");
+        return GX_EINVAL;
+    }
+    p1 = p0;
+    p0.cls = WQ_DR0; p1.cls = WQ_DR1;
+    p0.dw = p1.dw = dw; p0.layout = p1.layout = 1;
+    p0.flops = 2.0 * N * (double)Cout * Cin * 15 * Hb * Wb;
+    p1.flops = 2.0 * N * (double)Cout * Cin * 10 * Hb * Wb;
+    p0.reduce_group = p1.reduce_group = -2;      // paired: resolved at flush by (dw, partial)
+    std::vector<PendingJob> v{p0, p1};
+    return wgq_run_or_queue(v, s);
+}
+
+int gx_wgq_pending(void) { return (int)g_jobs.size(); }
+void gx_wgq_discard(void) { g_jobs.clear(); }
+
+// launches every queued job -- one grid per (class, tile width) -- and queues the slab reductions
+int gx_wgq_flush(hipStream_t s) {
+    if (g_jobs.empty()) return GX_OK;
+    int rc = GX_OK;
+    for (int cls = 0; cls < 3 && rc == GX_OK; ++cls)
+        for (int ltw = 5; ltw >= 4 && rc == GX_OK; --ltw) {
+            std::vector<PendingJob*> grp;
+            for (PendingJob& p : g_jobs)
+                if (p.cls == cls && p.ltw == ltw) grp.push_back(&p);
+            // at most kMaxJobs per launch
+            for (size_t i = 0; i < grp.size() && rc == GX_OK; i += kMaxJobs) {
+                std::vector<PendingJob*> part(grp.begin() + i, grp.begin() + (i + kMaxJobs < grp.size() ? i + kMaxJobs : grp.size()));
+                rc = wgq_launch_group(part, 256, s);
+            }
+        }
+    if (rc == GX_OK) {
+        // reduce records: one per conv3x3 job, one per transposed-conv layer (its two row-parity jobs share the slabs)
+        for (size_t i = 0; i < g_jobs.size() && rc == GX_OK; ++i) {
+            PendingJob& p = g_jobs[i];
+            if (p.cls == WQ_DR1) continue;
+            GxWgradRed r{p.job.partial, p.dw, p.job.nsplit, p.job.Ttot, p.job.CA, p.job.CB, p.job.CApad, p.job.CBpad,
+                         p.layout, 0, 0, 0, 0};
+            if (p.cls == WQ_DR0) {
+                int ns1 = 0;
+                for (PendingJob& q : g_jobs)
+                    if (q.cls == WQ_DR1 && q.job.partial == p.job.partial) ns1 = q.job.nsplit;
+                r.ns0 = r.ns1 = p.job.nsplit; r.ns2 = r.ns3 = ns1;
+                r.nsplit = p.job.nsplit > ns1 ? p.job.nsplit : ns1;
+            }
+            if (!gx_defer_push_wgrad(r)) rc = gx_defer_flush_wgrad(&r, 1, s);
+        }
+    }
+    g_jobs.clear();
+    return rc;
+}
+
+extern "C" int gx_wgq_policy(int mode) {
+    GX_CHECK_ARG(mode == 0 || mode == 1, "gx_wgq_policy: mode must be 0 (round-1 kernels) or 1 (LDS-DMA grouped kernels)");
+    g_wgq_mode = mode;
+    return GX_OK;
+}

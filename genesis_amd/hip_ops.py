@@ -109,7 +109,7 @@ def conv3x3_wgrad(x, dy, out=None):
     assert dw.shape == (Cout, Cin, 3, 3) and dw.is_contiguous()
     nb = _lib.query('gx_conv3x3_wgrad_ws_bytes', N, Cin, Cout, H, W)
     ws = _ws(nb, x.device)
-    with _deferring(out is not None, ws):
+    with _deferring(out is not None, ws, x, dy):    # (a queued job reads x / dy at the flush: kept alive until then)
         _lib.call('gx_conv3x3_wgrad', _p(x), _p(dy), _p(dw), N, Cin, Cout, H, W, _p(ws), nb, _stream())
     return dw
 
@@ -150,7 +150,7 @@ def deconv5x5s2_wgrad(x, dy, out=None):
     assert dw.shape == (Cin, Cout, 5, 5) and dw.is_contiguous()
     nb = _lib.query('gx_deconv5x5s2_wgrad_ws_bytes', N, Cin, Cout, H, W)
     ws = _ws(nb, x.device)
-    with _deferring(out is not None, ws):
+    with _deferring(out is not None, ws, x, dy):
         _lib.call('gx_deconv5x5s2_wgrad', _p(x), _p(dy), _p(dw), N, Cin, Cout, H, W, _p(ws), nb, _stream())
     return dw
 
