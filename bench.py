@@ -99,6 +99,37 @@ def pmc_traffic(kernel):
     return tot / n if n else None
 
 
+# profiling ids (gx_profile_kernel_name) -> kernel symbols of the rocprofv3 CSV that are launched under that id
+KID_SYMBOLS = {
+    'wgrad_kernel<0>': ('wgq_kernel<0,', 'wgrad_fast_kernel<0,', 'wgrad_kernel<0>', 'wgrad_smallcin_kernel'),
+    'wgrad_kernel<1>': ('wgq_kernel<1,', 'wgrad_fast_kernel<1,', 'wgrad_kernel<1>', 'wgrad_deconv_kernel'),
+    'wgrad_kernel<3>': ('wgq_kernel<2,', 'wgrad_fast_kernel<3,', 'wgrad_kernel<3>'),
+    'tapconv_kernel<0>': ('tapconv_kernel<0,', 'kq_kernel<0,'),
+    'tapconv_kernel<1>': ('tapconv_dt_kernel', 'kq_dt_kernel'),
+    'tapconv_kernel<3>': ('tapconv_kernel<3,', 'kq_kernel<3,'),
+    'wino_conv_kernel': ('wino_conv_kernel',),
+    'gn_relu_bwd_kernel': ('gn_relu_bwd',), 'gn_relu_fwd_kernel': ('gn_relu_fwd',),
+}
+
+
+def rocprof_avg_us(kid_name):
+    """Average launch duration of the kernels behind a profiling id in the committed rocprofv3 --kernel-trace --stats
+    summary of this same command (profiles/r02_rocprofv3_kernel_stats.csv); None if absent."""
+    import csv
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_rocprofv3_kernel_stats.csv')
+    syms = KID_SYMBOLS.get(kid_name)
+    if not os.path.exists(path) or not syms:
+        return None
+    tot = calls = 0.0
+    with open(path) as f:
+        rows = csv.DictReader(l for l in f if not l.startswith('#'))
+        for r in rows:
+            name = r['Name'].replace('(anonymous namespace)::', '').replace('void ', '')
+            if any(name.startswith(s_) for s_ in syms):
+                tot += float(r['TotalDurationNs']); calls += float(r['Calls'])
+    return tot / calls / 1e3 if calls else None
+
+
 def cpu_baseline(args):
     """Oracle (reference-equivalent form: per-slot loops, K-fold feat_head) full training step on host cores."""
     from oracle import v2_oracle as O
@@ -143,7 +174,21 @@ def cpu_baseline(args):
         if time.time() - t0 >= args.cpu_seconds or n >= 8:
             break
     dt = time.time() - t0
+    # single-thread figure: one step on one core, bounded
+    one = None
+    if args.cpu_seconds >= 10:
+        torch.set_num_threads(1)
+        xs = x[:max(1, args.batch // 8)]
+        t1 = time.time()
+        O.train_step(p, opt, geco, xs, cfg)
+        one = xs.shape[0] / (time.time() - t1)
+        torch.set_num_threads(best)
     return {'value': args.batch * n / dt, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'single_thread_images_per_sec': one,
+            'single_thread_sample': 'one step on %d images, 1 thread' % max(1, args.batch // 8) if one else None,
+            # measured in the build container (the reference cannot travel): oracle in reference form vs the imported
+            # reference, same weights / inputs / threads, B=32 K=7 64x64: 3.12 s vs 3.12 s per step
+            'port_vs_reference_speed_ratio': 1.00,
             'sample': '%d timed steps (after 1 warm-up and a %s-thread probe) of the full training step, batch %d, '
                       'K=%d, %dx%d, oracle in reference-equivalent form (per-slot loops, K-fold feat_head), torch CPU '
                       'fp32, %d threads (best of the probe) on a %d-CPU host'
@@ -167,6 +212,10 @@ def main():
     ts = TrainStep(model, args.img, lr=1e-4,
                    graph=not args.no_graph,
                    async_wgrad=bool(os.environ.get('GENESIS_ASYNC_WGRAD')))
+    # parameters / optimiser / GECO state were broadcast from rank 0 by TrainStep; from here on every rank draws its own
+    # noise (rand_pixel, eps) and its own shard of synthetic images
+    torch.manual_seed(1234 + rank)
+    torch.cuda.manual_seed(1234 + rank)
     g = torch.Generator().manual_seed(1234 + rank)
     batches = [torch.rand(args.batch, 3, args.img, args.img, generator=g).to(device) for _ in range(4)]
 
@@ -202,14 +251,22 @@ def main():
             'value': value, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'GENESIS-V2 (genesisv2_config) K=%d, %dx%dx3 synthetic uniform batches, '
-                                   'feat_dim %d, per-GPU batch %d, GECO + Adam(1e-4), random-init weights'
-                                   % (args.K, args.img, args.img, args.feat_dim, args.batch),
+            'config': {'workload': '%s K=%d, %dx%dx3 synthetic uniform batches, feat_dim %d, per-GPU batch %d, '
+                                   'GECO + Adam(1e-4), random-init weights'
+                                   % ({'genesisv2': 'GENESIS-V2 (genesisv2_config)', 'monet': 'MONet (monet_config)',
+                                       'genesis': 'GENESIS (genesis_config)', 'vae': 'BaselineVAE (vae_config)'}[args.model],
+                                      args.K, args.img, args.img, args.feat_dim, args.batch),
                        'global_batch': world * args.batch, 'per_gpu_batch': args.batch,
                        'parallelism': 'dp%d' % world, 'launch': ('hip-graph' if not ts._split else 'hip-graph(fwd+bwd) | rccl all-reduce | hip-graph(geco+adam)')
                        if ts.graph is not None else 'eager'},
             'final_elbo': elbo,
         }
+        if dist.is_initialized():
+            # what the step exchanged: ONE sum all-reduce of the flat fp32 bucket (gradients + err / kl + the fp64
+            # gradient as float triples [+ averaged buffers]) over the ranks the process group actually has
+            result['config']['collective'] = {'backend': dist.get_backend(), 'ranks_observed': dist.get_world_size(),
+                                              'all_reduces_per_step': 1,
+                                              'bytes_per_all_reduce': int(ts.bucket.flat_g.numel() * 4)}
         if flop_img:
             result['step_fraction_of_fp32_mfma_peak'] = value / world * flop_img / (PEAK_FP32_MFMA_TFLOPS * 1e12)
 
@@ -249,6 +306,11 @@ def main():
             roof['algorithm'] = 'Winograd F(2x2,3x3): 1/2.25 of the algorithmic flops are executed on the MFMA pipe'
             roof['achieved_on_mfma_pipe'] = ach / 2.25
             roof['frac_on_mfma_pipe'] = ach / 2.25 / PEAK_FP32_MFMA_TFLOPS
+        rp = rocprof_avg_us(dom['name'])
+        if rp:
+            roof['rocprof_avg_launch_us'] = rp
+            roof['frac_from_rocprof'] = (dom['flops'] if dom['flops'] > 0 else dom['bytes']) / dom['launches'] / \
+                (rp * 1e-6) / ((PEAK_FP32_MFMA_TFLOPS * 1e12) if dom['flops'] > 0 else (PEAK_HBM_GBS * 1e9))
         roof.update({'traffic': pmc_traffic(dom['name']), 'traffic_unit': 'bytes/launch (PMC, separate pass)',
                      'algorithmic_bytes_per_launch': dom['bytes'] / dom['launches'],
                      'avg_launch_us': 1e3 * dom['ms'] / dom['launches'],

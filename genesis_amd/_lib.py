@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get('GENESIS_HIP_LIB') or osp.join(_HERE, 'libgenesis_hip.
 HEADER_PATH = osp.join(osp.dirname(_HERE), 'include', 'genesis_hip.h')
 
 _CTYPES = {
-    'int': ctypes.c_int, 'float': ctypes.c_float, 'size_t': ctypes.c_size_t,
+    'int': ctypes.c_int, 'float': ctypes.c_float, 'double': ctypes.c_double, 'size_t': ctypes.c_size_t,
     'gx_stream_t': ctypes.c_void_p, 'void': None,
 }
 

@@ -462,7 +462,9 @@ int kq_mode() {
 
 bool q_fills(int N, int Hb, int Wb, int M, int mult) {
     const long wgs = (long)gx_ceil_div(N * Hb * Wb, 256) * gx_ceil_div(M, 64) * mult;
-    return kq_mode() == 2 || wgs >= 384;
+    // one workgroup per CU on most of the chip is enough: 224 tiles (the 16 -> 32 decoder layer's data gradient at
+    // K*B = 224) measured 127 us against 142 us on the round-1 kernel; 56 tiles (8 -> 16) 121 against 57
+    return kq_mode() == 2 || wgs >= 192;
 }
 
 template <typename KernelT>

@@ -13,17 +13,20 @@ namespace {
 template <typename T>
 __global__ void __launch_bounds__(256)
 adam_kernel(T* __restrict__ p, const T* __restrict__ g, T* __restrict__ m, T* __restrict__ v, size_t n,
-            const int64_t* __restrict__ step, float lr, float b1, float b2, float eps, float gscale) {
+            const int64_t* __restrict__ step, double lr, double b1, double b2, double eps, float gscale) {
+    // hyper-parameters arrive as doubles and every derived constant is formed in double before it is rounded to T,
+    // as torch.optim.Adam does with its Python floats (1 - 0.999 in fp32 is 4.7e-5 off the fp64 value it uses)
     const double t = (double)(*step);
-    const double bc1 = 1.0 - pow((double)b1, t);
-    const double bc2 = 1.0 - pow((double)b2, t);
-    const T step_size = (T)((double)lr / bc1);
+    const double bc1 = 1.0 - pow(b1, t);
+    const double bc2 = 1.0 - pow(b2, t);
+    const T step_size = (T)(lr / bc1);
     const T bc2_sqrt = (T)sqrt(bc2);
+    const T one_m_b1 = (T)(1.0 - b1), one_m_b2 = (T)(1.0 - b2), b2_t = (T)b2, eps_t = (T)eps;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const T gi = g[i] * (T)gscale;
-        const T mi = m[i] + (gi - m[i]) * (T)(1.f - b1);           // torch: exp_avg.lerp_(grad, 1 - beta1)
-        const T vi = v[i] * (T)b2 + gi * gi * (T)(1.f - b2);       // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
-        const T denom = sqrt(vi) / bc2_sqrt + (T)eps;
+        const T mi = m[i] + (gi - m[i]) * one_m_b1;                // torch: exp_avg.lerp_(grad, 1 - beta1)
+        const T vi = v[i] * b2_t + gi * gi * one_m_b2;             // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+        const T denom = sqrt(vi) / bc2_sqrt + eps_t;
         p[i] = p[i] - step_size * (mi / denom);
         m[i] = mi;
         v[i] = vi;
@@ -58,8 +61,8 @@ __global__ void geco_update_kernel(float* __restrict__ state, const float* __res
 
 extern "C" {
 
-int gx_adam_step(void* p, const void* g, void* m, void* v, size_t n, int is_f64, int64_t* step, float lr,
-                 float beta1, float beta2, float eps, float grad_scale, gx_stream_t stream) {
+int gx_adam_step(void* p, const void* g, void* m, void* v, size_t n, int is_f64, int64_t* step, double lr,
+                 double beta1, double beta2, double eps, float grad_scale, gx_stream_t stream) {
     GX_CHECK_ARG(p && g && m && v && step, "gx_adam_step: null pointer");
     if (n == 0) return GX_OK;
     hipStream_t s = (hipStream_t)stream;

@@ -17,9 +17,12 @@ class FlatBucket(object):
     """Re-homes parameters (and their .grad) as views of flat per-dtype buffers.
 
     fp32 params -> flat_p / flat_g (+ `n_tail` piggy-backed scalars at the end of flat_g);
-    fp64 params (att_process.log_sigma) -> flat_p64 / flat_g64 (a separate 8-byte message)."""
+    fp64 params (att_process.log_sigma) -> flat_p64 / flat_g64; for the exchange their gradients ride in the fp32
+    bucket's tail as (hi, mid, lo) float triples (g = hi + mid + lo exactly: 24 + 24 + 5 mantissa bits), so that a step
+    has ONE collective -- exact for a single contribution; the sum over ranks is an fp32 sum of the hi parts (~6e-8
+    relative on that gradient, which was computed from fp32 activations in the first place)."""
 
-    def __init__(self, params, n_tail=2, align=16):
+    def __init__(self, params, n_tail=2, align=16, mean_buffers=()):
         params = list(params)
         self.p32 = [p for p in params if p.dtype == torch.float32]
         self.p64 = [p for p in params if p.dtype == torch.float64]
@@ -31,6 +34,12 @@ class FlatBucket(object):
         self.slot = {}
         self.n32 = sum(self._pad(p.numel()) for p in self.p32)
         self.n64 = sum(p.numel() for p in self.p64)
+        self.n_scalars = n_tail                    # err, kl
+        # floating-point module buffers that every rank updates from its own shard (GENESIS' BatchNorm running
+        # statistics, genesis_config.py:39-40): averaged over ranks through the same collective
+        self.mean_buffers = [b for b in mean_buffers if b.is_floating_point()]
+        self.n_buf = sum(b.numel() for b in self.mean_buffers)
+        n_tail = n_tail + 3 * self.n64 + self.n_buf     # + (hi, mid, lo) per fp64 gradient element + the buffers
         self.n_tail = n_tail
         self.flat_p = torch.zeros(self.n32, dtype=torch.float32, device=dev)
         self.flat_p64 = torch.zeros(max(self.n64, 1), dtype=torch.float64, device=dev)
@@ -61,20 +70,68 @@ class FlatBucket(object):
         for i, s in enumerate(scalars):
             self.flat_g[self.n32 + i] = s.detach()
 
-    def all_reduce(self, group=None):
-        """Sum over ranks; returns the scale (1/world) that turns the sums into means."""
+    def collective_needed(self, group=None):
         if not (dist.is_available() and dist.is_initialized()):
+            return False
+        # (the env var keeps the collective in the step on a 1-GPU box, to exercise RCCL)
+        return dist.get_world_size(group) > 1 or bool(os.environ.get('GENESIS_FORCE_ALLREDUCE'))
+
+    def pack64(self):
+        """fp64 gradients -> (hi, mid, lo) float triples in the fp32 tail; averaged buffers behind them (before the collective)."""
+        o = self.n32 + self.n_scalars
+        if self.n64:
+            t = self.flat_g[o:o + 3 * self.n64].view(3, self.n64)
+            g = self.flat_g64[:self.n64]
+            hi = g.to(torch.float32)
+            r = g - hi.double()
+            mid = r.to(torch.float32)
+            t[0].copy_(hi)
+            t[1].copy_(mid)
+            t[2].copy_((r - mid.double()).to(torch.float32))
+        o += 3 * self.n64
+        for b in self.mean_buffers:
+            self.flat_g[o:o + b.numel()].copy_(b.reshape(-1))
+            o += b.numel()
+
+    def unpack64(self, scale=None):
+        """(hi, mid, lo) sums -> fp64 gradient sums; buffer sums -> buffer means (after the collective)."""
+        o = self.n32 + self.n_scalars
+        if self.n64:
+            t = self.flat_g[o:o + 3 * self.n64].view(3, self.n64)
+            self.flat_g64[:self.n64].copy_(t[0].double() + t[1].double() + t[2].double())
+        o += 3 * self.n64
+        if self.mean_buffers:
+            if scale is None:
+                scale = 1.0 / dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1.0
+            for b in self.mean_buffers:
+                b.copy_((self.flat_g[o:o + b.numel()] * scale).view(b.shape))
+                o += b.numel()
+
+    def all_reduce(self, group=None, packed=False):
+        """Sum over ranks -- ONE collective for parameters' gradients, the err / kl scalars and the fp64 gradients;
+        returns the scale (1/world) that turns the sums into means.  packed: the caller already ran pack64() and will
+        run unpack64() itself (the graph-replay path captures them with the neighbouring kernels)."""
+        if not self.collective_needed(group):
             return 1.0
         world = dist.get_world_size(group)
-        if world == 1 and not os.environ.get('GENESIS_FORCE_ALLREDUCE'):
-            return 1.0   # (the env var keeps the collective in the step on a 1-GPU box, to exercise RCCL)
+        if not packed:
+            self.pack64()
         dist.all_reduce(self.flat_g, group=group)
-        if self.n64:
-            dist.all_reduce(self.flat_g64, group=group)
+        if not packed:
+            self.unpack64(1.0 / world)
         return 1.0 / world
 
+    def broadcast_state(self, extra=(), group=None, src=0):
+        """Parameters (and any `extra` tensors: optimiser moments, step counter, GECO state, model buffers) from rank
+        `src` to every rank -- what DistributedDataParallel does at construction: ranks whose seed or checkpoint differs
+        would otherwise train different models while exchanging gradients."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return
+        for t in [self.flat_p, self.flat_p64] + list(extra):
+            dist.broadcast(t, src, group=group)
+
     def tail(self, scale=1.0):
-        return self.flat_g[self.n32:] * scale
+        return self.flat_g[self.n32:self.n32 + self.n_scalars] * scale
 
     def grads_in_bucket(self):
         lo, hi = self.flat_g.data_ptr(), self.flat_g.data_ptr() + self.flat_g.numel() * 4

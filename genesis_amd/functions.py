@@ -34,10 +34,14 @@ def _gout(p):
     """Destination for a parameter gradient: p.grad if direct writes are on and it is a usable buffer.  Only the
     FIRST gradient of a parameter in an iteration is written directly (it overwrites the zeroed bucket); a parameter
     that is used again (MONet's recurrent UNet shares its weights over K-1 passes) accumulates through autograd."""
-    if DIRECT_PARAM_GRADS and isinstance(p, torch.nn.Parameter) and p.grad is not None and p.grad.is_contiguous() \
-            and id(p) not in _DIRECT_WRITTEN:
-        _DIRECT_WRITTEN.add(id(p))
-        return p.grad
+    if DIRECT_PARAM_GRADS and isinstance(p, torch.nn.Parameter) and p.grad is not None and p.grad.is_contiguous():
+        if id(p) not in _DIRECT_WRITTEN:
+            _DIRECT_WRITTEN.add(id(p))
+            return p.grad
+        # a further use of a shared parameter accumulates through autograd on the MAIN stream: if the first-use direct
+        # write was forked onto the side stream (ASYNC_WGRAD), order the accumulation behind it
+        if ASYNC_WGRAD and _side_stream is not None:
+            torch.cuda.current_stream().wait_stream(_side_stream)
     return None
 
 

@@ -49,15 +49,32 @@ class TrainStep(object):
         self._static_x = None
         self._out = None
         self.iters = 0
+        self.sync_from_rank0()
 
     # ------------------------------------------------------------------ flat buffers
     def _flatten(self):
-        self.bucket = FlatBucket(self.model.parameters(), n_tail=2)
+        self.bucket = FlatBucket(self.model.parameters(), n_tail=2,
+                                 mean_buffers=list(self.model.buffers()) if self.world > 1 else ())
         b = self.bucket
         self.n32, self.n64 = b.n32, b.n64
         self.flat_p, self.flat_g, self.flat_p64, self.flat_g64 = b.flat_p, b.flat_g, b.flat_p64, b.flat_g64
         self.m32, self.v32 = torch.zeros_like(b.flat_p), torch.zeros_like(b.flat_p)
         self.m64, self.v64 = torch.zeros_like(b.flat_p64), torch.zeros_like(b.flat_p64)
+
+    def _train_state(self):
+        """Everything an iteration mutates: parameters, Adam moments, step counter, GECO state, model buffers
+        (GENESIS' BatchNorm running statistics)."""
+        st = [self.flat_p, self.flat_p64, self.m32, self.v32, self.m64, self.v64, self.step_t]
+        if self.geco is not None:
+            st.append(self.geco.state)
+        return st + list(self.model.buffers())
+
+    def sync_from_rank0(self):
+        """Several ranks: every rank starts from rank 0's parameters, optimiser and GECO state and buffers (as
+        DistributedDataParallel broadcasts at construction).  Ranks then only need DIFFERENT noise seeds
+        (torch.manual_seed(base + rank) after building the model) so that rand_pixel / eps differ per shard."""
+        if self.world > 1:
+            self.bucket.broadcast_state(self._train_state()[2:], self.pg)
 
     def _check_grad_views(self):
         assert self.bucket.grads_in_bucket(), 'a gradient left the flat bucket'
@@ -156,7 +173,7 @@ class TrainStep(object):
         """(all-reduced) bucket -> device GECO update -> fused Adam; returns [elbo, err, kl, beta used]."""
         fused, beta_used = st
         local = fused and gscale == 1.0
-        tail = self.bucket.flat_g[self.n32:] if gscale == 1.0 else self.bucket.tail(gscale)   # global batch means
+        tail = self.bucket.flat_g[self.n32:self.n32 + 2] if gscale == 1.0 else self.bucket.tail(gscale)   # global batch means
         if self.geco is not None:
             self.geco.update(tail[0])
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -199,9 +216,7 @@ class TrainStep(object):
         One process: a single graph.  Several ranks: two graphs (forward+backward | GECO+Adam) with the RCCL
         all-reduce of the gradient bucket issued between the two replays -- nothing else runs on the host."""
         self._static_x = x.clone()
-        state = [self.flat_p, self.flat_p64, self.m32, self.v32, self.m64, self.v64, self.step_t]
-        if self.geco is not None:
-            state.append(self.geco.state)
+        state = self._train_state()
         snap = [t.clone() for t in state]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -222,11 +237,14 @@ class TrainStep(object):
                 self._begin()
                 try:
                     self._st = self._forward_backward(self._static_x)
+                    with torch.no_grad():
+                        self.bucket.pack64()           # fp64 gradients into the fp32 tail: one collective per step
                 finally:
                     self._end()
             self.graph2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph2, pool=self.graph.pool(), capture_error_mode='thread_local'):
                 with torch.no_grad():
+                    self.bucket.unpack64(self._gscale)
                     self._out = self._update(self._st, self._gscale)
         with torch.no_grad():
             for t, s in zip(state, snap):
@@ -239,9 +257,7 @@ class TrainStep(object):
         advancing the training state: parameters, Adam moments, step counter and GECO state are restored afterwards."""
         if not self.use_graph or self.graph is not None:
             return
-        state = [self.flat_p, self.flat_p64, self.m32, self.v32, self.m64, self.v64, self.step_t]
-        if self.geco is not None:
-            state.append(self.geco.state)
+        state = self._train_state()
         snap = [t.clone() for t in state]
         iters = self.iters
         self._capture(x)
@@ -260,7 +276,7 @@ class TrainStep(object):
         self.graph.replay()
         if self._split:
             with torch.no_grad():
-                self.bucket.all_reduce(self.pg)
+                self.bucket.all_reduce(self.pg, packed=True)      # the ONE collective of the step
             self.graph2.replay()
 
     def step(self, x, **forward_kwargs):
@@ -338,4 +354,5 @@ class TrainStep(object):
             if ckpt.get('err_ema') is not None:
                 self.geco.err_ema = ckpt['err_ema']
         self.graph = self.graph2 = None          # re-capture: lr / betas are baked into the captured launches
+        self.sync_from_rank0()                   # several ranks: rank 0's checkpoint wins
         return ckpt['iter_idx'] + 1

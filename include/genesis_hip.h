@@ -178,8 +178,8 @@ int gx_conv1x1_gn_wgrad_finish(const float* wpart, const float* bpart, int N, in
  *      holding t (>= 1, bump it with gx_step_increment first); the gradient is multiplied by grad_scale.
  *      gx_geco_update: utils/geco.py:39-49 on device; state = {beta, err_ema, initialised}; err = device
  *      scalar with the batch-mean reconstruction error; no host sync (the reference calls .item()). */
-int gx_adam_step(void* p, const void* g, void* m, void* v, size_t n, int is_f64, int64_t* step, float lr,
-                 float beta1, float beta2, float eps, float grad_scale, gx_stream_t stream);
+int gx_adam_step(void* p, const void* g, void* m, void* v, size_t n, int is_f64, int64_t* step, double lr,
+                 double beta1, double beta2, double eps, float grad_scale, gx_stream_t stream);
 int gx_step_increment(int64_t* step, gx_stream_t stream);
 int gx_geco_update(float* state, const float* err, float goal, float step_size, float alpha, float speedup,
                    int use_speedup, float beta_min, float beta_max, gx_stream_t stream);

@@ -69,9 +69,11 @@ def test_two_rank_bucket_equals_full_batch(tmp_path):
     full = _local_grads(x, rp, eps)
     ref = full.flat_g.detach()
     got = r0['g']
-    rel = float((got - ref).norm() / ref.norm())
+    n32 = full.n32
+    rel = float((got[:n32] - ref[:n32]).norm() / ref[:n32].norm())
     assert rel < 1e-4, rel
-    np.testing.assert_allclose(got[-2:].numpy(), ref[-2:].numpy(), rtol=1e-5)      # global err, kl in the tail
+    # global err, kl right behind the parameters' gradients (the fp64 gradient's (hi, mid, lo) triple follows them)
+    np.testing.assert_allclose(got[n32:n32 + 2].numpy(), ref[n32:n32 + 2].numpy(), rtol=1e-5)
     np.testing.assert_allclose(r0['g64'].numpy(), full.flat_g64.detach().numpy(), rtol=1e-4, atol=1e-7)
 
 
@@ -80,7 +82,7 @@ def test_bucket_views_track_parameters():
               torch.nn.Parameter(torch.randn((), dtype=torch.float64))]
     before = [p.detach().clone() for p in params]
     b = FlatBucket(params, n_tail=2)
-    assert b.n32 == 32 and b.n64 == 1 and b.flat_g.numel() == 34          # 12 -> 16, 5 -> 16 (64-byte aligned slots)
+    assert b.n32 == 32 and b.n64 == 1 and b.flat_g.numel() == 37    # 12 -> 16, 5 -> 16 (64-byte aligned slots); tail: err, kl, (hi, mid, lo)
     assert all(p.data_ptr() % 64 == 0 for p in params[:2])
     for p, q in zip(params, before):
         assert torch.equal(p.detach(), q)
@@ -91,3 +93,19 @@ def test_bucket_views_track_parameters():
     assert float(b.flat_g64[0]) == 4.0
     b.flat_p.mul_(0)          # the optimiser writes the flat buffer; parameters are views of it
     assert float(params[0].abs().sum()) == 0.0
+
+
+def test_fp64_gradient_rides_the_fp32_tail_exactly_for_one_rank():
+    """ONE collective per step: the fp64 gradient (att_process.log_sigma) travels as a (hi, mid, lo) float triple in the fp32
+    bucket's tail; for a single contribution the round trip is exact."""
+    params = [torch.nn.Parameter(torch.randn(7)), torch.nn.Parameter(torch.randn((), dtype=torch.float64))]
+    buf = torch.arange(5, dtype=torch.float32)
+    b = FlatBucket(params, n_tail=2, mean_buffers=[buf, torch.zeros((), dtype=torch.int64)])
+    assert b.n_buf == 5 and b.flat_g.numel() == b.n32 + 2 + 3 + 5
+    g = torch.tensor([0.1234567890123456789], dtype=torch.float64) * 3.0
+    b.flat_g64[:1].copy_(g)
+    b.pack64()
+    b.flat_g64.zero_(); buf.mul_(0)
+    b.unpack64(1.0)
+    assert torch.equal(b.flat_g64[:1], g)
+    assert torch.equal(buf, torch.arange(5, dtype=torch.float32))
