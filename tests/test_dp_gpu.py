@@ -113,3 +113,94 @@ def test_two_ranks_graph_mode_stays_in_lock_step(tmp_path):
     for k in ('p', 'p64', 'geco'):
         assert torch.equal(r0[k], r1[k]), k
     assert torch.isfinite(r0['p']).all()
+
+
+def _worker_diverged_start(rank, world, port, out_dir):
+    """Ranks build their models from DIFFERENT seeds (and rank 1 perturbs its GECO state): TrainStep must start every
+    rank from rank 0's parameters, optimiser and GECO state (what DistributedDataParallel's construction broadcast does)."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import genesis_amd.genesisv2_config as G
+    from genesis_amd.compat.attrdict import AttrDict
+    from genesis_amd.trainer import TrainStep
+    from genesis_amd.geco import make_geco
+    from oracle import v2_oracle as O
+    cfg = AttrDict(dict(O.make_cfg(K_steps=3, img_size=32, feat_dim=8), debug=False, multi_gpu=False))
+    torch.manual_seed(1000 + rank)                     # different initial weights per rank
+    model = G.load(cfg).cuda().train()
+    geco = make_geco(32)
+    if rank == 1:
+        geco.beta = 3.0
+    before = torch.cat([p.detach().flatten().float() for p in model.parameters()]).cpu()
+    ts = TrainStep(model, 32, geco=geco, graph=False)
+    torch.manual_seed(7 + rank)
+    x = torch.rand(2, 3, 32, 32, device='cuda')
+    ts.step(x)
+    torch.save({'before': before, 'p': ts.flat_p.cpu(), 'p64': ts.flat_p64.cpu(), 'geco': ts.geco.state.cpu(),
+                'm': ts.m32.cpu()}, os.path.join(out_dir, 'd%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_ranks_with_different_seeds_start_from_rank0(tmp_path):
+    world = 2
+    mp.spawn(_worker_diverged_start, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    d0 = torch.load(os.path.join(str(tmp_path), 'd0.pt'))
+    d1 = torch.load(os.path.join(str(tmp_path), 'd1.pt'))
+    assert not torch.equal(d0['before'], d1['before'])            # the ranks really did start apart
+    for k in ('p', 'p64', 'geco', 'm'):
+        assert torch.equal(d0[k], d1[k]), k                        # ... and are in lock-step after the first step
+
+
+def _worker_monet(rank, world, port, out_dir):
+    """BASELINE config 4 is MONet on 2 GPUs: the same lock-step property for MONet (recurrent shared-weight UNet:
+    weight gradients accumulated over K-1 passes go through the same bucket)."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from genesis_amd.trainer import TrainStep
+    from tests.test_monet_oracle import MonetGolden
+    from tests.test_monet_gpu import build
+    gold = MonetGolden('tiny')
+    model = build(gold)
+    x, _ = gold.inputs()
+    B = x.shape[0]
+    sl = slice(rank * B // world, (rank + 1) * B // world)
+    ts = TrainStep(model, gold.S, lr=1e-4, graph=False)
+    hist = []
+    K = gold.cfg['K_steps']
+    for it in range(2):
+        _, eps = gold.inputs(1 + it)
+        e = eps.view(K, B, -1)[:, sl].reshape(-1, eps.shape[-1]).contiguous()
+        hist.append(ts.step(x[sl].cuda(), eps=e.cuda()).cpu())
+    torch.save({'hist': torch.stack(hist), 'p': ts.flat_p.cpu(), 'geco': ts.geco.state.cpu()},
+               os.path.join(out_dir, 'm%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_monet_matches_full_batch(tmp_path):
+    world = 2
+    mp.spawn(_worker_monet, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    m0 = torch.load(os.path.join(str(tmp_path), 'm0.pt'))
+    m1 = torch.load(os.path.join(str(tmp_path), 'm1.pt'))
+    for k in ('hist', 'p', 'geco'):
+        assert torch.equal(m0[k], m1[k]), k
+    from genesis_amd.trainer import TrainStep
+    from tests.test_monet_oracle import MonetGolden
+    from tests.test_monet_gpu import build
+    gold = MonetGolden('tiny')
+    model = build(gold)
+    ts = TrainStep(model, gold.S, lr=1e-4, graph=False)
+    x, _ = gold.inputs()
+    ref = []
+    for it in range(2):
+        _, eps = gold.inputs(1 + it)
+        ref.append(ts.step(x.cuda(), eps=eps.cuda()).cpu())
+    ref = torch.stack(ref)
+    assert torch.allclose(m0['hist'][:, :2], ref[:, :2], rtol=1e-3), (m0['hist'], ref)
+    rel = float((m0['p'] - ts.flat_p.cpu()).norm() / ts.flat_p.cpu().norm())
+    assert rel < 1e-3, rel
