@@ -275,12 +275,12 @@ def main():
         ts.use_graph = False
         ts._iteration(batches[0])  # eager warm-up after graph mode
         torch.cuda.synchronize()
-        profiling.enable(True)
+        profiling.enable(True, ts._ctx)
         for i in range(args.profile_steps):
             ts._iteration(batches[i % 4])
         torch.cuda.synchronize()
-        rows = profiling.collect()
-        profiling.enable(False)
+        rows = profiling.collect(ts._ctx)
+        profiling.enable(False, ts._ctx)
         total_ms = sum(r['ms'] for r in rows)
         rows.sort(key=lambda r: -r['ms'])
         table = []

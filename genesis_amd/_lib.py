@@ -98,3 +98,12 @@ def call(name, *args):
 def query(name, *args):
     """Calls a size_t-returning *_ws_bytes query."""
     return int(getattr(load(), name)(*args))
+
+
+def current_ctx():
+    """Id of the calling thread's current library context (gx_ctx_*: include/genesis_hip.h)."""
+    return int(load().gx_ctx_current())
+
+
+def make_current(ctx_id):
+    call('gx_ctx_make_current', int(ctx_id))

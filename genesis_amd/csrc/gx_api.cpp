@@ -15,11 +15,22 @@ void gx_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-bool g_gx_prof_on = false;
+#include <mutex>
+
+namespace {
+thread_local int t_ctx = 0;
+std::mutex g_ctx_mutex;
+bool g_ctx_alive[kGxMaxCtx] = {true};      // context 0 always exists
+GxCtxFlags g_ctx_flags[kGxMaxCtx] = {};
+struct CtxInit { CtxInit() { for (int i = 0; i < kGxMaxCtx; ++i) g_ctx_flags[i] = GxCtxFlags{false, false, -1, -1}; } } g_ctx_init;
+}  // namespace
+int gx_cur_ctx(void) { return t_ctx; }
+GxCtxFlags& gx_ctx_flags(void) { return g_ctx_flags[t_ctx]; }
 
 namespace {
 struct ProfEntry { int kid; hipEvent_t a, b; double flops, bytes; };
-std::vector<ProfEntry> g_entries;
+std::vector<ProfEntry> g_entries_ctx[kGxMaxCtx];
+#define g_entries (g_entries_ctx[t_ctx])
 const char* const kKernelNames[KID_COUNT] = {
     "tapconv_kernel<0>", "tapconv_kernel<1>", "tapconv_kernel<2>", "tapconv_kernel<3>", "pack_weights_kernel",
     "wgrad_kernel<0>", "wgrad_kernel<1>", "wgrad_kernel<2>", "wgrad_kernel<3>", "wgrad_kernel<4>",
@@ -80,12 +91,14 @@ int gx_version(void) { return 1; }
 // reduce launch (32 per training step).  With deferral on, those entry points queue the reduce instead; one
 // launch per kind (gx_defer_flush) finishes all of them after the backward pass.  The caller keeps the queued
 // workspaces alive until the flush.
-bool g_gx_defer_on = false;
 namespace {
 constexpr int kMaxDefer = 48;
-GxWgradRed g_wq[kMaxDefer];
-GxGnRed g_gq[kMaxDefer];
-int g_nw = 0, g_ng = 0;
+struct DeferQueues { GxWgradRed wq[kMaxDefer]; GxGnRed gq[kMaxDefer]; int nw = 0, ng = 0; };
+DeferQueues g_defer[kGxMaxCtx];
+#define g_wq (g_defer[t_ctx].wq)
+#define g_gq (g_defer[t_ctx].gq)
+#define g_nw (g_defer[t_ctx].nw)
+#define g_ng (g_defer[t_ctx].ng)
 }  // namespace
 bool gx_defer_push_wgrad(const GxWgradRed& r) {
     if (g_nw >= kMaxDefer) return false;
@@ -99,6 +112,41 @@ bool gx_defer_push_gn(const GxGnRed& r) {
 }
 
 extern "C" {
+
+/* contexts (see gx_common.h): create returns an id > 0, or a negative error code */
+int gx_ctx_create(void) {
+    std::lock_guard<std::mutex> lk(g_ctx_mutex);
+    for (int i = 1; i < kGxMaxCtx; ++i)
+        if (!g_ctx_alive[i]) {
+            g_ctx_alive[i] = true;
+            g_ctx_flags[i] = GxCtxFlags{false, false, -1, -1};
+            g_defer[i].nw = g_defer[i].ng = 0;
+            return i;
+        }
+    gx_set_error("gx_ctx_create: all %d contexts are in use", kGxMaxCtx);
+    return GX_EINVAL;
+}
+
+int gx_ctx_make_current(int id) {
+    GX_CHECK_ARG(id >= 0 && id < kGxMaxCtx && g_ctx_alive[id], "gx_ctx_make_current: bad context %d", id);
+    t_ctx = id;
+    return GX_OK;
+}
+
+int gx_ctx_current(void) { return t_ctx; }
+
+int gx_ctx_destroy(int id) {
+    GX_CHECK_ARG(id > 0 && id < kGxMaxCtx && g_ctx_alive[id], "gx_ctx_destroy: bad context %d", id);
+    std::lock_guard<std::mutex> lk(g_ctx_mutex);
+    const int prev = t_ctx;
+    t_ctx = id;
+    g_nw = 0; g_ng = 0; gx_wgq_discard();
+    for (ProfEntry& e : g_entries) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    g_entries.clear();
+    g_ctx_alive[id] = false;
+    t_ctx = prev == id ? 0 : prev;
+    return GX_OK;
+}
 
 int gx_defer_enable(int on) {
     g_gx_defer_on = on > 0;

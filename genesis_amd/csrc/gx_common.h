@@ -34,7 +34,17 @@ enum GxKernelId {
     KID_MASKPOOL_BWD, KID_MIXTURE_FWD, KID_MIXTURE_BWD, KID_CONV1X1_FWD, KID_CONV1X1_DGRAD,
     KID_CONV1X1_WGRAD, KID_SMALL_REDUCE, KID_ADAM, KID_GECO, KID_SPLITK_REDUCE, KID_BIAS_ACT_BWD, KID_DCONV, KID_GATED, KID_LATENT, KID_DENSE, KID_WINO, KID_COUNT
 };
-extern bool g_gx_prof_on;
+// ---- contexts: every piece of mutable library state that outlives a call (deferred-reduction queues, queued
+// weight-gradient jobs, the packed-weight cache a step is recording / served from, the per-kernel profiling records)
+// belongs to a context.  A thread works in its CURRENT context (thread-local; context 0 until gx_ctx_make_current), so
+// two training loops -- in one thread one after the other, or in two threads -- never see each other's queues.
+// What remains process-wide is one-time initialisation (zero pages, kernel attributes) and the dispatch policies.
+constexpr int kGxMaxCtx = 32;
+int gx_cur_ctx(void);
+struct GxCtxFlags { bool prof_on, defer_on; int cache_recording, cache_active; };
+GxCtxFlags& gx_ctx_flags(void);      // of the calling thread's current context
+#define g_gx_prof_on (gx_ctx_flags().prof_on)
+#define g_gx_defer_on (gx_ctx_flags().defer_on)
 void gx_prof_begin(int kid, hipStream_t s, double flops, double bytes);
 void gx_prof_end(hipStream_t s);
 // RAII: brackets ONE kernel launch with two events when profiling is on; a flag test otherwise.
@@ -49,7 +59,6 @@ struct GxProf {
 // ---- deferred parameter-gradient reductions (gx_defer_*; gx_api.cpp owns the queue) ----
 struct GxWgradRed { const float* partial; float* dw; int nsplit, Ttot, CA, CB, CApad, CBpad, layout, ns0, ns1, ns2, ns3; };
 struct GxGnRed { const float* part; float* dgamma; float* dbeta; float* dbias; int N, C; };
-extern bool g_gx_defer_on;
 bool gx_defer_push_wgrad(const GxWgradRed& r);   // false: queue full (caller reduces immediately)
 bool gx_defer_push_gn(const GxGnRed& r);
 int gx_defer_flush_wgrad(const GxWgradRed* items, int n, hipStream_t s);   // gx_conv.hip

@@ -29,6 +29,7 @@
 #include "gx_common.h"
 
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 #ifndef GX_WG_ABL
@@ -1252,9 +1253,10 @@ struct PackCache {
     PackEntry* dev = nullptr;
     bool alive = false;
 };
-std::vector<PackCache> g_caches;
-int g_cache_recording = -1;   // cache id being recorded, or -1
-int g_cache_active = -1;      // cache id conv calls are served from, or -1
+std::vector<PackCache> g_caches;       // (created / destroyed under g_cache_mutex; a cache is used by the context that made it)
+std::mutex g_cache_mutex;
+#define g_cache_recording (gx_ctx_flags().cache_recording)   // cache id being recorded by this context, or -1
+#define g_cache_active (gx_ctx_flags().cache_active)         // cache id this context's conv calls are served from, or -1
 
 __global__ void pack_weights_batch_kernel(const PackEntry* __restrict__ entries) {
     const PackEntry e = entries[blockIdx.y];
@@ -1661,6 +1663,7 @@ static size_t conv3x3_pack_floats(int Cin, int Cout) {
 }
 
 int gx_weight_cache_create(void) {
+    std::lock_guard<std::mutex> lk(g_cache_mutex);
     for (size_t i = 0; i < g_caches.size(); ++i)
         if (!g_caches[i].alive) { g_caches[i] = PackCache(); g_caches[i].alive = true; return (int)i; }
     g_caches.emplace_back();

@@ -248,7 +248,8 @@ struct PendingJob {
     double flops;
     int reduce_group;               // jobs of one transposed-conv layer share a reduce record (index of the first)
 };
-std::vector<PendingJob> g_jobs;
+std::vector<PendingJob> g_jobs_ctx[kGxMaxCtx];      // queued jobs of each context (gx_common.h)
+#define g_jobs (g_jobs_ctx[gx_cur_ctx()])
 const float* g_zero16 = nullptr;
 
 const float* zero16(hipStream_t s) {

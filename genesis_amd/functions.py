@@ -13,6 +13,7 @@ Blocks (reference op groups):
 import torch
 import torch.nn.functional as F
 
+from . import _lib
 from . import hip_ops as hip
 
 GROUPS = 8
@@ -21,27 +22,63 @@ EPS = 1e-5
 # When True (set by TrainStep around its iteration: the flat gradient bucket is zeroed every step and every
 # parameter is used once), weight-gradient kernels write straight into `param.grad` and the Functions return
 # None for those parameters -- no AccumulateGrad `grad += new` launch per parameter.
-DIRECT_PARAM_GRADS = False
-_DIRECT_WRITTEN = set()     # ids of parameters whose .grad was already written directly this iteration
+class _StepState(object):
+    """Per-training-loop switches and bookkeeping, keyed by the library context (gx_ctx_*) the loop runs in: two
+    TrainSteps in one process never see each other's flags, queues or keep-alive lists.  Autograd runs a HIP node's
+    backward on its device thread: every Function below records the context of its forward and makes it current again
+    at the start of its backward (ctx_bound), so forward and backward of one step always share one state."""
+    __slots__ = ('direct_param_grads', 'direct_written', 'async_wgrad', 'side_prior', 'side_stream', 'keep_alive')
+
+    def __init__(self):
+        self.direct_param_grads = False
+        self.direct_written = set()    # ids of parameters whose .grad was already written directly this iteration
+        self.async_wgrad = False
+        self.side_prior = False
+        self.side_stream = None
+        self.keep_alive = []
+
+
+_STEPS = {}
+
+
+def step_state():
+    return _STEPS.setdefault(_lib.current_ctx(), _StepState())
+
+
+def ctx_bound(cls):
+    """Class decorator for the autograd Functions: backward runs in the library context of its forward."""
+    fwd, bwd = cls.forward, cls.backward
+
+    def forward(ctx, *args):
+        ctx._gx_ctx = _lib.current_ctx()
+        return fwd(ctx, *args)
+
+    def backward(ctx, *grads):
+        _lib.make_current(ctx._gx_ctx)
+        return bwd(ctx, *grads)
+    cls.forward = staticmethod(forward)
+    cls.backward = staticmethod(backward)
+    return cls
 
 
 def begin_direct_grads():
     """TrainStep calls this right after zeroing the bucket."""
-    _DIRECT_WRITTEN.clear()
+    step_state().direct_written.clear()
 
 
 def _gout(p):
     """Destination for a parameter gradient: p.grad if direct writes are on and it is a usable buffer.  Only the
     FIRST gradient of a parameter in an iteration is written directly (it overwrites the zeroed bucket); a parameter
     that is used again (MONet's recurrent UNet shares its weights over K-1 passes) accumulates through autograd."""
-    if DIRECT_PARAM_GRADS and isinstance(p, torch.nn.Parameter) and p.grad is not None and p.grad.is_contiguous():
-        if id(p) not in _DIRECT_WRITTEN:
-            _DIRECT_WRITTEN.add(id(p))
+    st = step_state()
+    if st.direct_param_grads and isinstance(p, torch.nn.Parameter) and p.grad is not None and p.grad.is_contiguous():
+        if id(p) not in st.direct_written:
+            st.direct_written.add(id(p))
             return p.grad
         # a further use of a shared parameter accumulates through autograd on the MAIN stream: if the first-use direct
-        # write was forked onto the side stream (ASYNC_WGRAD), order the accumulation behind it
-        if ASYNC_WGRAD and _side_stream is not None:
-            torch.cuda.current_stream().wait_stream(_side_stream)
+        # write was forked onto the side stream (async_wgrad), order the accumulation behind it
+        if st.async_wgrad and st.side_stream is not None:
+            torch.cuda.current_stream().wait_stream(st.side_stream)
     return None
 
 
@@ -53,38 +90,34 @@ def _gout(p):
 # optimiser.  Temporaries they read are kept alive until the join (no allocator reuse hazard across streams).
 # MEASURED (round 1, B=32 K=7 64x64): 4066 -> 3464 img/s with the fork on -- the 131 KB-LDS wgrad workgroups and
 # the 62 KB tap-conv workgroups evict each other from the CUs and both are MFMA-bound -- so TrainStep leaves it OFF.
-ASYNC_WGRAD = False
 ASYNC_WGRAD_MAX_PIXELS = int(__import__('os').environ.get('GENESIS_ASYNC_WGRAD_MAX_PIXELS', 1 << 62))
-_side_stream = None
-_keep_alive = []
-
-
 def _side():
-    global _side_stream
-    if _side_stream is None:
-        _side_stream = torch.cuda.Stream()
-    return _side_stream
+    st = step_state()
+    if st.side_stream is None:
+        st.side_stream = torch.cuda.Stream()
+    return st.side_stream
 
 
 def _wgrad(fn_, out, *reads):
     """Runs fn_() (a weight-gradient launch writing into `out`) on the side stream when allowed, else inline."""
     # only layers whose kernels cannot fill the chip are forked (ASYNC_WGRAD_MAX_PIXELS images*H*W of the layer input)
-    if ASYNC_WGRAD and out is not None and reads and \
+    if step_state().async_wgrad and out is not None and reads and \
             reads[0].shape[0] * reads[0].shape[2] * reads[0].shape[3] <= ASYNC_WGRAD_MAX_PIXELS:
         side = _side()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             r = fn_()
-        _keep_alive.extend(reads)
+        step_state().keep_alive.extend(reads)
         return r
     return fn_()
 
 
 def join_side_stream():
     """Called by TrainStep after backward: the optimiser must see every weight gradient."""
-    if _side_stream is not None:
-        torch.cuda.current_stream().wait_stream(_side_stream)
-    _keep_alive.clear()
+    st = step_state()
+    if st.side_stream is not None:
+        torch.cuda.current_stream().wait_stream(st.side_stream)
+    st.keep_alive.clear()
 
 
 # ---- the AR-prior branch on the side stream ----------------------------------------------------------------
@@ -95,7 +128,6 @@ def join_side_stream():
 # MEASURED (round 1, B=32 K=7 64x64, A/B in one session): 5710 img/s without, 5640 with the fork -- the graph's
 # fork/join synchronisation costs more than the ~150 us of tiny kernels it hides -- so TrainStep leaves it OFF
 # (GENESIS_SIDE_PRIOR=1 / TrainStep(side_prior=True) turns it on).
-SIDE_PRIOR = False
 
 
 class side_branch(object):
@@ -108,7 +140,7 @@ class side_branch(object):
     def __enter__(self):
         side = _side()
         side.wait_stream(torch.cuda.current_stream())
-        _keep_alive.extend(self.reads)
+        step_state().keep_alive.extend(self.reads)
         self.ctx = torch.cuda.stream(side)
         self.ctx.__enter__()
         return self
@@ -126,6 +158,7 @@ def _ret(out, value):
     return None if out is not None else value
 
 
+@ctx_bound
 class ConvGNReLUFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, gamma, beta):
@@ -148,6 +181,7 @@ class ConvGNReLUFn(torch.autograd.Function):
         return dx, _ret(ow, dw), _ret(og, dgamma), _ret(ob, dbeta)
 
 
+@ctx_bound
 class UNetEncoderFn(torch.autograd.Function):
     """args: x, nb, norm_groups (8 = GroupNorm(8); 0 = InstanceNorm, i.e. one group per channel), then 3*nb down
     params (w, gamma, beta), 3*nb up params, 6 MLP params."""
@@ -277,6 +311,7 @@ class UNetEncoderFn(torch.autograd.Function):
         return (dx, None, None) + tuple(flat)
 
 
+@ctx_bound
 class ICSBPFn(torch.autograd.Function):
     """colour head (SemiConv or plain 1x1 conv) + IC-SBP.  Returns
     (log_m [K,B,1,H,W], log_s [K,B,1,H,W], colour [B,8,H,W], seeds [K-1,B,8], seed_idx [K-1,B])."""
@@ -322,6 +357,7 @@ def seg_head_fusable(enc_feat, seg_w, conv_w):
     return FUSE_SEG_HEAD and C <= 64 and C % GROUPS == 0 and HW % 256 == 0 and conv_w.shape[0] <= 8
 
 
+@ctx_bound
 class SegICSBPFn(torch.autograd.Function):
     """seg_head (conv3x3 -> GroupNorm -> ReLU, genesisv2_config.py:66) + colour head + IC-SBP with the normalised
     seg_head activation never written: statistics only, the 1x1 conv normalises on load, its data gradient is formed
@@ -370,6 +406,7 @@ class SegICSBPFn(torch.autograd.Function):
                 _ret(og, dgate), None, _ret(ols, dls.to(ctx.ls_dtype)), None, None, None, None)
 
 
+@ctx_bound
 class MaskPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, f, log_m):
@@ -392,6 +429,7 @@ FUSE_DECODER_HEAD = __import__('os').environ.get('GENESIS_FUSE_DEC_HEAD', '1') =
 EPILOGUE_STATS = __import__('os').environ.get('GENESIS_DECONV_STATS', '1') == '1'
 
 
+@ctx_bound
 class DecoderFn(torch.autograd.Function):
     """args: z [K*B, D], coords [1,2,d,d], then 4 x (deconv w, deconv b, gn gamma, gn beta), out w, out b."""
 
@@ -476,6 +514,7 @@ class DecoderFn(torch.autograd.Function):
         return (dz, None) + tuple(grads)
 
 
+@ctx_bound
 class MixtureFn(torch.autograd.Function):
     """returns (err [B], recon [B,3,H,W], x_r [K,B,3,H,W], log_m_r [K,B,1,H,W])."""
 
@@ -501,6 +540,7 @@ class MixtureFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------- MONet / ComponentVAE
+@ctx_bound
 class Conv1x1Fn(torch.autograd.Function):
     """Small 1x1 conv with bias (Cout <= 8): the MONet UNet's final_conv (modules/unet.py:66,90)."""
 
@@ -519,6 +559,7 @@ class Conv1x1Fn(torch.autograd.Function):
         return dx, dw.view(ctx.wshape), db
 
 
+@ctx_bound
 class DirectConvActFn(torch.autograd.Function):
     """act(conv2d(x, w, b, stride, pad)) through the generic direct kernel (MONetCompEncoder's stride-2 convs,
     modules/encoders.py:31-34)."""
@@ -544,6 +585,7 @@ class DirectConvActFn(torch.autograd.Function):
         return dx, _ret(ow, dw), _ret(ob, db), None, None, None
 
 
+@ctx_bound
 class BroadcastDecoderFn(torch.autograd.Function):
     """BroadcastDecoder (modules/decoders.py:21-35): z [N, L] -> [N, out, S, S].
     args: z, coords [1,2,S+2L,S+2L], act, then L x (w [h,cin,3,3], b [h]), out_w [out, h], out_b.
@@ -606,6 +648,7 @@ class BroadcastDecoderFn(torch.autograd.Function):
         return (dz, None, None) + tuple(grads)
 
 
+@ctx_bound
 class MixtureWFn(torch.autograd.Function):
     """Mixture likelihood with the ATTENTION masks as mixing weights (models/monet_config.py:94-105).
     returns (err [B], recon [B,3,H,W], x_r [K,B,3,H,W]); differentiable w.r.t. dec and log_w."""
@@ -635,6 +678,7 @@ def _c(t):
     return None if t is None else t.contiguous()
 
 
+@ctx_bound
 class PosteriorFn(torch.autograd.Function):
     """zh [B,K,2D] = z_head(obj), eps [K,B,D] -> (z, mu, sigma [K,B,D], log_q [K,B]): to_sigma, rsample and
     q_z.log_prob(z).sum(1) of models/genesisv2_config.py:154-160 / models/genesis_config.py:329 in one launch."""
@@ -652,6 +696,7 @@ class PosteriorFn(torch.autograd.Function):
         return hip.latent_posterior_bwd(zh, eps, _c(gz), _c(gmu), _c(gsigma), _c(glogq)), None
 
 
+@ctx_bound
 class PriorLogPFn(torch.autograd.Function):
     """z [K,B,D], lin [K-1,B,2D] (or None), log_q [K,B] (or None) -> log_p [K,B] under N(0,1) for the first slot and
     N(tanh(lin[:D]), sigmoid(lin[D:] + 4) + 1e-4) for the others (models/genesis_config.py:297-330); with log_q the
@@ -674,6 +719,7 @@ class PriorLogPFn(torch.autograd.Function):
         return dz, dlin, (g if ctx.kl_mode else None)
 
 
+@ctx_bound
 class ElboFn(torch.autograd.Function):
     """Loss aggregation of train.py:226-242: (err [B], kl [R,B] | None, beta [1] device scalar) ->
     (loss [1] = err_mean + beta kl_mean, out5 = (loss, err_mean + kl_mean, err_mean, kl_mean, beta), not differentiable).
@@ -698,6 +744,7 @@ class ElboFn(torch.autograd.Function):
         return d_err, (d_kl.view(ctx.kl_shape) if d_kl is not None else None), None, None
 
 
+@ctx_bound
 class PooledHeadFn(torch.autograd.Function):
     """(lin [R,C], msum [R], feat_head[1].bias, LayerNorm weight, bias, eps) -> LayerNorm((lin + msum b)/(msum+1e-5))
     (models/genesisv2_config.py:146-154 and z_head[0], :76), one launch forward, two backward."""
@@ -724,6 +771,7 @@ class PooledHeadFn(torch.autograd.Function):
                 _ret(outs[2], dbe), None)
 
 
+@ctx_bound
 class SBPScanFn(torch.autograd.Function):
     """T stick-breaking steps in log space (modules/attention.py:42-48,118-124): logits [T, ...], log_s0 [...] or None ->
     (log_m [T, ...], log_s [T, ...] = the scope after each step); last_scope: the last mask is the remaining scope."""
@@ -746,6 +794,7 @@ class SBPScanFn(torch.autograd.Function):
         return g_logits, g_s0, None
 
 
+@ctx_bound
 class CategoricalKLFn(torch.autograd.Function):
     """MONet.kl_m_loss (models/monet_config.py:157-170): log_m, log_m_r [K,B,1,H,W] -> kl_m [B]; the gradient reaches
     log_m_r only if it requires one (detach_mr_in_klm = False, models/genesisv2_config.py:172-176)."""
@@ -763,6 +812,7 @@ class CategoricalKLFn(torch.autograd.Function):
         return g_m, g_r
 
 
+@ctx_bound
 class MaskReconFn(torch.autograd.Function):
     """log_m_r as a differentiable function of the decoder output: the mixture kernel already produced the values
     (log_softmax over K of dec's last channel, monet_config.py:137-139); this node only routes a gradient on them back
@@ -780,6 +830,7 @@ class MaskReconFn(torch.autograd.Function):
         return hip.logsoftmax_k_bwd(log_m_r, g.contiguous(), ctx.C), None
 
 
+@ctx_bound
 class LSTMCellFn(torch.autograd.Function):
     """One nn.LSTM cell step whose input depends on the previous step's output (LatentSBP, modules/attention.py:103-110:
     the sampled z_{k-1} is fed back): inp [B,Din], h_prev / c_prev [B,H] or None (zero state) -> (h, c).  Input
@@ -829,6 +880,7 @@ class LSTMCellFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------- dense layers
+@ctx_bound
 class LinearFn(torch.autograd.Function):
     """act(F.linear(x, w, b)) on the 16x16-tile fp32 MFMA dense kernel; x [..., K] (leading dims flattened)."""
 
@@ -862,6 +914,7 @@ def linear(x, w, b=None, act=None):
     return LinearFn.apply(x, w, b, act)
 
 
+@ctx_bound
 class LSTMFn(torch.autograd.Function):
     """nn.LSTM (one layer, zero initial state) over x [T,B,D] -> h [T,B,H]: input projection for all steps on the
     dense kernel, then one fused (recurrent GEMM + cell update) launch per step; backward mirrors it

@@ -312,8 +312,8 @@ class GenesisV2(nn.Module):
         zh = fn.linear(zh, self.z_head[3].weight, self.z_head[3].bias)
         z, mu, sigma, log_q = fn.PosteriorFn.apply(zh, eps)                  # [K,B,D] x3, [K,B]
         # --- Component KL (Genesis.mask_latent_loss, models/genesis_config.py:288-343); optionally forked onto the
-        #     side stream so that its chain of tiny kernels runs beside the decoder (fn.SIDE_PRIOR)
-        forked = fn.SIDE_PRIOR and self.prior_lstm is not None and torch.is_grad_enabled()
+        #     side stream so that its chain of tiny kernels runs beside the decoder (step_state().side_prior)
+        forked = fn.step_state().side_prior and self.prior_lstm is not None and torch.is_grad_enabled()
         if forked:
             with fn.side_branch(z, log_q):
                 kl = self._component_kl(z, log_q)

@@ -42,13 +42,25 @@ def _ws(nbytes, device):
 # ---- deferred parameter-gradient reductions (gx_defer_*): TrainStep turns this on for one backward pass; calls that
 # write a parameter gradient into a caller-provided buffer then queue their final reduce, and defer_flush() finishes
 # all of them in one launch per kind.  Workspaces of queued calls are kept alive here until the flush.
-DEFER_REDUCES = False
-_DEFER_KEEP = []
+class _DeferState(object):
+    __slots__ = ('on', 'keep')
+
+    def __init__(self):
+        self.on = False          # TrainStep turns this on for one backward pass
+        self.keep = []           # workspaces / operands of queued calls, alive until the flush
+
+
+_DEFER = {}                      # library context id -> _DeferState (one per training loop)
+
+
+def defer_state():
+    return _DEFER.setdefault(_lib.current_ctx(), _DeferState())
 
 
 class _deferring(object):
     def __init__(self, active, *keep):
-        self.active = bool(active) and DEFER_REDUCES
+        self.st = defer_state()
+        self.active = bool(active) and self.st.on
         self.keep = keep
 
     def __enter__(self):
@@ -59,20 +71,20 @@ class _deferring(object):
     def __exit__(self, *exc):
         if self.active:
             _lib.call('gx_defer_enable', 0)
-            _DEFER_KEEP.extend(self.keep)
+            self.st.keep.extend(self.keep)
         return False
 
 
 def defer_flush():
     if _lib.query('gx_defer_pending'):
         _lib.call('gx_defer_flush', _stream())
-    del _DEFER_KEEP[:]
+    del defer_state().keep[:]
 
 
 def defer_discard():
     """Drops queued reductions without running them (an exception interrupted the backward pass)."""
     _lib.call('gx_defer_enable', -1)
-    del _DEFER_KEEP[:]
+    del defer_state().keep[:]
 
 
 # ------------------------------------------------------------------ conv3x3

@@ -5,12 +5,29 @@ import ctypes
 from . import _lib
 
 
-def enable(on=True):
-    _lib.call('gx_profile_enable', int(bool(on)))
+def enable(on=True, ctx=None):
+    """Profiling records belong to a library context (gx_ctx_*): ctx = a TrainStep's context id (ts._ctx) to profile its
+    iterations, None = the calling thread's current context."""
+    if ctx is None:
+        _lib.call('gx_profile_enable', int(bool(on)))
+        return
+    prev = _lib.current_ctx()
+    _lib.make_current(ctx)
+    try:
+        _lib.call('gx_profile_enable', int(bool(on)))
+    finally:
+        _lib.make_current(prev)
 
 
-def collect():
-    """-> list of dict(name, ms, launches, flops, bytes) for kernels launched since the last collect."""
+def collect(ctx=None):
+    """-> list of dict(name, ms, launches, flops, bytes) for kernels launched (in context `ctx`) since the last collect."""
+    if ctx is not None:
+        prev = _lib.current_ctx()
+        _lib.make_current(ctx)
+        try:
+            return collect()
+        finally:
+            _lib.make_current(prev)
     lib = _lib.load()
     n = lib.gx_profile_num_kernels()
     arr = lambda: (ctypes.c_double * n)()  # noqa: E731

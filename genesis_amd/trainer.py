@@ -39,6 +39,11 @@ class TrainStep(object):
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self._flatten()
+        # this loop's library context: its deferred-reduction queues, queued weight-gradient jobs, packed-weight cache
+        # bookkeeping and step flags are its own (two TrainSteps can coexist in one process)
+        self._ctx = int(_lib.load().gx_ctx_create())
+        if self._ctx <= 0:
+            raise _lib.GenesisHipError('gx_ctx_create failed: ' + _lib.last_error())
         self._wcache = _lib.query('gx_weight_cache_create') if weight_cache else None
         self._wcache_ready = False
         self.step_t = torch.zeros((), dtype=torch.int64, device=self.device)
@@ -80,13 +85,29 @@ class TrainStep(object):
         assert self.bucket.grads_in_bucket(), 'a gradient left the flat bucket'
 
     # ------------------------------------------------------------------ one iteration
+    def _enter(self):
+        """Makes this loop's library context current and arms its step switches."""
+        self._prev_ctx = _lib.current_ctx()
+        _lib.make_current(self._ctx)
+        st = _fn.step_state()
+        st.direct_param_grads = True     # the bucket is zeroed first; kernels write weight grads straight into it
+        _fn.begin_direct_grads()
+        _hip.defer_state().on = self.defer_reduces
+        st.async_wgrad = self.async_wgrad
+        st.side_prior = self.side_prior
+
+    def _leave(self):
+        _lib.make_current(self._ctx)     # (an exception may have left another context current)
+        st = _fn.step_state()
+        st.direct_param_grads = False
+        st.async_wgrad = False
+        st.side_prior = False
+        _hip.defer_state().on = False
+        _hip.defer_discard()             # no-op after a completed iteration (the queue was flushed)
+
     def _iteration(self, x, **forward_kwargs):
         self.bucket.zero_grad()
-        _fn.DIRECT_PARAM_GRADS = True    # bucket zeroed above; kernels write weight grads straight into it
-        _fn.begin_direct_grads()
-        _hip.DEFER_REDUCES = self.defer_reduces
-        _fn.ASYNC_WGRAD = self.async_wgrad
-        _fn.SIDE_PRIOR = self.side_prior
+        self._enter()
         # packed-weight cache: the first (never graph-captured) iteration records which weight tensors the conv
         # entry points pack; later iterations re-pack all of them in one launch up front
         recording = False
@@ -101,23 +122,23 @@ class TrainStep(object):
         try:
             return self._iteration_body(x, **forward_kwargs)
         finally:
-            _fn.DIRECT_PARAM_GRADS = False
-            _fn.ASYNC_WGRAD = False
-            _fn.SIDE_PRIOR = False
-            _hip.DEFER_REDUCES = False
-            _hip.defer_discard()       # no-op after a completed iteration (the queue was flushed)
+            self._leave()
             if self._wcache is not None:
                 if recording:
                     _lib.call('gx_weight_cache_record', self._wcache, 0)
                     self._wcache_ready = True
                 else:
                     _lib.call('gx_weight_cache_release')
+            _lib.make_current(self._prev_ctx)
 
     def __del__(self):
         try:
             if getattr(self, '_wcache', None) is not None:
                 _lib.call('gx_weight_cache_destroy', self._wcache)
                 self._wcache = None
+            if getattr(self, '_ctx', 0) > 0:
+                _lib.call('gx_ctx_destroy', self._ctx)
+                self._ctx = 0
         except Exception:
             pass
 
@@ -192,23 +213,16 @@ class TrainStep(object):
     # ------------------------------------------------------------------ HIP-graph replay
     def _begin(self):
         self.bucket.zero_grad()
-        _fn.DIRECT_PARAM_GRADS = True
-        _fn.begin_direct_grads()
-        _hip.DEFER_REDUCES = self.defer_reduces
-        _fn.ASYNC_WGRAD = self.async_wgrad
-        _fn.SIDE_PRIOR = self.side_prior
+        self._enter()
         if self._wcache is not None and self._wcache_ready:
             _lib.call('gx_weight_cache_refresh', self._wcache,
                       ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
 
     def _end(self):
-        _fn.DIRECT_PARAM_GRADS = False
-        _fn.ASYNC_WGRAD = False
-        _fn.SIDE_PRIOR = False
-        _hip.DEFER_REDUCES = False
-        _hip.defer_discard()
+        self._leave()
         if self._wcache is not None and self._wcache_ready:
             _lib.call('gx_weight_cache_release')
+        _lib.make_current(self._prev_ctx)
 
     def _capture(self, x):
         """Warm up (kernel attributes, allocator pools, weight-cache recording), capture the iteration into HIP

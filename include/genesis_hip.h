@@ -365,6 +365,16 @@ int gx_weight_cache_refresh(int id, gx_stream_t stream);
 int gx_weight_cache_release(void);
 int gx_weight_cache_destroy(int id);
 
+/* ---- contexts.  Library state that outlives a call -- the deferred-reduction queues, queued weight-gradient jobs, the
+ *      packed-weight cache a step records / is served from, per-kernel profiling records -- belongs to a context; a
+ *      thread works in its current context (thread-local, context 0 by default).  One context per training loop makes
+ *      the library re-entrant: loops in different threads, or interleaved in one thread, never share a queue.
+ *      gx_ctx_create returns an id > 0 (negative: error). */
+int gx_ctx_create(void);
+int gx_ctx_make_current(int id);
+int gx_ctx_current(void);
+int gx_ctx_destroy(int id);
+
 /* ---- deferred parameter-gradient reductions.  gx_conv3x3_wgrad, gx_deconv5x5s2_wgrad and gx_gn_relu_bwd each end
  *      in a small reduce launch whose result (dw / dgamma, dbeta) only the optimiser reads.  While
  *      gx_defer_enable(1) is in effect those calls queue that reduce instead (up to 48 of each kind; beyond that they

@@ -99,3 +99,33 @@ def test_attrdict_semantics():
     assert d['x'] == 5
     with pytest.raises(AttributeError):
         d.missing
+
+
+def test_library_contexts():
+    """gx_ctx_*: per-loop library state (no hidden state shared between independent users).  Contexts are
+    created / switched / destroyed without a GPU; the deferred-reduction switch and the pending count are per context."""
+    from genesis_amd import _lib
+    lib = _lib.load()
+    assert _lib.current_ctx() == 0
+    a, b = int(lib.gx_ctx_create()), int(lib.gx_ctx_create())
+    assert a > 0 and b > 0 and a != b
+    try:
+        _lib.make_current(a)
+        assert _lib.current_ctx() == a
+        _lib.call('gx_defer_enable', 1)
+        _lib.make_current(b)
+        assert _lib.query('gx_defer_pending') == 0
+        # another thread starts in the default context, whatever this thread made current
+        import threading
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(_lib.current_ctx()))
+        t.start(); t.join()
+        assert seen == [0]
+        with pytest.raises(_lib.GenesisHipError):
+            _lib.make_current(31)                    # never created
+    finally:
+        _lib.make_current(0)
+        _lib.call('gx_ctx_destroy', a)
+        _lib.call('gx_ctx_destroy', b)
+    with pytest.raises(_lib.GenesisHipError):
+        _lib.make_current(a)                         # destroyed

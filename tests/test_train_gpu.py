@@ -111,10 +111,11 @@ def test_profile_collect():
     ts = TrainStep(model, gold.S)
     x, _, _ = gold.inputs()
     ts.step(x.to(DEV))
-    profiling.enable(True)
+    profiling.enable(True, ts._ctx)              # profiling records belong to the loop's library context
     ts.step(x.to(DEV))
-    rows = profiling.collect()
-    profiling.enable(False)
+    rows = profiling.collect(ts._ctx)
+    profiling.enable(False, ts._ctx)
+    assert profiling.collect() == []             # nothing leaked into the default context
     names = {r['name'] for r in rows}
     assert {'tapconv_kernel<0>', 'wgrad_kernel<0>', 'gn_relu_fwd_kernel', 'icsbp_fwd_kernel', 'adam_kernel'} <= names
     assert all(r['ms'] > 0 for r in rows)
@@ -218,3 +219,41 @@ def test_checkpoint_is_the_reference_wire_format(tmp_path):
     assert torch.equal(third, third2)
     for a, b in zip(ts2.model.parameters(), p_after):
         assert torch.equal(a.detach(), b)
+
+
+def test_two_training_loops_coexist():
+    """Each TrainStep owns a library context (gx_ctx_*): its deferred-reduction queues, queued weight-gradient jobs,
+    packed-weight cache bookkeeping and step switches.  Two loops stepped alternately -- one of them in graph-replay
+    mode -- must produce exactly the trajectories they produce alone."""
+    from genesis_amd.trainer import TrainStep
+    from tests.common import Golden
+    from tests.test_model_gpu import build
+
+    def traj(alone):
+        ga, gb = Golden('tiny'), Golden('tiny_b3k3')
+        tsa = TrainStep(build(ga), ga.S, lr=1e-4, graph=False)
+        tsb = TrainStep(build(gb), gb.S, lr=1e-4, graph=True)
+        assert tsa._ctx != tsb._ctx and tsa._ctx > 0 and tsb._ctx > 0
+        xa, xb = ga.inputs()[0].cuda(), gb.inputs()[0].cuda()
+        outs_a, outs_b = [], []
+
+        def step_a(it):
+            rp, eps = ga.noise(1 + it)
+            outs_a.append(tsa.step(xa, rand_pixel=rp.cuda(), eps=torch.stack(eps).cuda()).clone())
+
+        def step_b(it):
+            torch.manual_seed(50 + it); torch.cuda.manual_seed(50 + it)
+            outs_b.append(tsb.step(xb).clone())
+        if alone:
+            for it in range(3):
+                step_a(it)
+            for it in range(3):
+                step_b(it)
+        else:
+            for it in range(3):
+                step_a(it); step_b(it)
+        return torch.stack(outs_a).cpu(), torch.stack(outs_b).cpu(), tsa.flat_p.clone().cpu(), tsb.flat_p.clone().cpu()
+    ref = traj(True)
+    got = traj(False)
+    for r, g in zip(ref, got):
+        assert torch.equal(r, g)
