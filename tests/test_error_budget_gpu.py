@@ -1,0 +1,194 @@
+"""fp32 error budget against the fp64 oracle -- the rigorous form of the gradient comparison.
+
+Ground truth = the oracle run in fp64 on the same weights, inputs and noise.  Two fp32 implementations are measured
+against it: the oracle in fp32 on the host (stock ATen ops: what the reference computes) and the HIP path.  Bar:
+
+    HIP error  <=  4 x (CPU-fp32 error)  +  floor,     per forward tensor and per parameter gradient (relative L2)
+
+The floor: 2e-6 relative, and for analytically-zero gradients 2e-6 x the largest gradient norm.  (The golden-vector
+tests compare against the reference's OWN fp32 results on closed-form weights, where a ReLU pre-activation within ~1e-7
+of zero can flip sign between two correct fp32 implementations and move every upstream gradient by 1e-4 .. 1e-3
+(tools/diag_model_decoder.py); here, against fp64 on random-init weights, no such allowance is needed: RELU_FLIP = 0.)
+Shapes: the configuration of the round-1 test, the metric configuration (K=7, 64x64, feat 64) and BASELINE config 5
+(K=11, 128x128) for GENESIS-V2; MONet (config 4) and GENESIS (config 3) at tiny and BASELINE shapes."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+RELU_FLIP = 0.0      # measured: no allowance needed (worst HIP gradient error 5.6e-4 where CPU-fp32 has 7.6e-4)
+
+
+def relerr(a, ref):
+    ref = ref.detach().double().cpu()
+    return float((a.detach().double().cpu() - ref).norm()) / (float(ref.norm()) + 1e-30)
+
+
+def judge(rows_fwd, grads_hip, g32, g64, what):
+    """rows_fwd: (name, hip tensor, cpu32 tensor, fp64 tensor).  Prints the table, returns the offenders."""
+    bad, table = [], []
+    for name, got, r32, r64 in rows_fwd:
+        e_gpu, e_cpu = relerr(got, r64), relerr(r32, r64)
+        table.append((name, e_gpu, e_cpu))
+        if e_gpu > 4 * e_cpu + 2e-6:
+            bad.append(name)
+    gmax = max(float(v.norm()) for v in g64.values())
+    worst = 0.0
+    for n, got in grads_hip:
+        ref = g64[n]
+        floor = 2e-6 * gmax / (float(ref.norm()) + 1e-30)
+        e_gpu, e_cpu = relerr(got, ref), relerr(g32[n], ref)
+        table.append(('grad ' + n, e_gpu, e_cpu))
+        worst = max(worst, e_gpu - floor)
+        if e_gpu > max(4 * e_cpu + 2e-6, RELU_FLIP) + floor:
+            bad.append(n)
+    print('\n[%s] %-46s %12s %12s' % (what, 'tensor', 'hip-vs-f64', 'cpu32-vs-f64'))
+    for r in table:
+        print('%-56s %12.3e %12.3e' % r)
+    print('[%s] worst gradient error above its floor: %.3e' % (what, worst))
+    return bad
+
+
+def to_dtype(sd, dtype):
+    return {k: v.clone().to(dtype if v.dtype == torch.float32 else v.dtype).requires_grad_(v.is_floating_point())
+            for k, v in sd.items()}
+
+
+def grads_of(p):
+    return {k: (v.grad if v.grad is not None else torch.zeros_like(v)).double() for k, v in p.items() if v.requires_grad}
+
+
+def hip_grads(model):
+    return [(n, p.grad if p.grad is not None else torch.zeros_like(p)) for n, p in model.named_parameters()]
+
+
+@pytest.mark.parametrize('name,K,S,D,B', [('k5', 5, 64, 32, 4), ('metric', 7, 64, 64, 2), ('cfg5', 11, 128, 64, 1)])
+def test_genesis_v2(name, K, S, D, B):
+    from oracle import v2_oracle as O
+    import genesis_amd.genesisv2_config as G
+    from genesis_amd.compat.attrdict import AttrDict
+    from genesis_amd import testing as T
+    cfg = O.make_cfg(K_steps=K, img_size=S, feat_dim=D)
+    torch.manual_seed(7)
+    model = G.load(AttrDict(dict(cfg, debug=False, multi_gpu=False)))
+    with torch.no_grad():
+        model.att_process.colour_head.gate.gate.fill_(0.2)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    x = T.make_input(99, B, S)
+    rp, eps_k = T.draw_noise(123, B, S, D, K)
+
+    def oracle(dtype):
+        p = to_dtype(sd, dtype)
+        out = O.v2_forward(p, x.to(dtype), cfg, rp.to(dtype), [e.to(dtype) for e in eps_k], reference_form=False)
+        e, kl, _ = O.aggregate_losses(out[1])
+        (e + kl).backward()
+        return out, grads_of(p)
+    o64, g64 = oracle(torch.float64)
+    o32, g32 = oracle(torch.float32)
+    model = model.to(DEV)
+    recon, losses, stats, att, _ = model(x.to(DEV), rp.to(DEV), torch.stack(eps_k).to(DEV))
+    assert torch.equal(torch.stack(list(att['seed_idx'])).cpu(), torch.stack(o64[3]['seed_idx']))   # no fallback here
+    (losses.err.mean(0) + torch.stack(losses.kl_l_k, 1).mean(0).sum()).backward()
+    st = lambda l: torch.stack(list(l))   # noqa: E731
+    fwd = [('recon', recon, o32[0], o64[0]), ('err', losses.err, o32[1]['err'], o64[1]['err']),
+           ('log_m', st(stats.log_m_k), st(o32[2]['log_m_k']), st(o64[2]['log_m_k'])),
+           ('kl', st(losses.kl_l_k), st(o32[1]['kl_l_k']), st(o64[1]['kl_l_k']))]
+    bad = judge(fwd, hip_grads(model), g32, g64, 'GENESIS-V2 ' + name)
+    assert not bad, bad
+
+
+@pytest.mark.parametrize('case', ['metric', 'cfg2', 'cfg5'])
+def test_genesis_v2_on_the_golden_cases_weights_and_inputs(case):
+    """The golden fixtures hold the reference's fp32 gradients on closed-form weights; against those the HIP gradients
+    differ by 4e-3 .. 8e-3 at 64x64 / 128x128.  Same weights, inputs and noise against fp64: which side carries that
+    error?  (Printed: both columns; bar as everywhere, HIP <= 4 x CPU-fp32 + floor.)"""
+    from oracle import v2_oracle as O
+    from tests.common import Golden
+    from tests.test_model_gpu import build
+    gold = Golden(case)
+    model = build(gold)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    x, rp, eps_k = gold.inputs()
+    cfg = gold.cfg
+
+    def oracle(dtype):
+        p = to_dtype(sd, dtype)
+        out = O.v2_forward(p, x.to(dtype), cfg, rp.to(dtype), [e.to(dtype) for e in eps_k], reference_form=False)
+        e, kl, _ = O.aggregate_losses(out[1])
+        (e + kl).backward()
+        return out, grads_of(p)
+    o64, g64 = oracle(torch.float64)
+    o32, g32 = oracle(torch.float32)
+    seeds64 = torch.stack(o64[3]['seed_idx'])
+    recon, losses, stats, att, _ = model(x.to(DEV), rp.to(DEV), torch.stack(eps_k).to(DEV), seeds64.to(DEV))
+    (losses.err.mean(0) + torch.stack(losses.kl_l_k, 1).mean(0).sum()).backward()
+    st = lambda l: torch.stack(list(l))   # noqa: E731
+    fwd = [('recon', recon, o32[0], o64[0]), ('err', losses.err, o32[1]['err'], o64[1]['err']),
+           ('log_m', st(stats.log_m_k), st(o32[2]['log_m_k']), st(o64[2]['log_m_k']))]
+    bad = judge(fwd, hip_grads(model), g32, g64, 'GENESIS-V2 golden case ' + case)
+    assert not bad, bad
+
+
+@pytest.mark.parametrize('name,K,S,B', [('tiny', 4, 32, 2), ('cfg4', 7, 64, 2)])
+def test_monet(name, K, S, B):
+    from oracle import monet_oracle as O
+    import genesis_amd.monet_config as G
+    from genesis_amd.compat.attrdict import AttrDict
+    from genesis_amd import testing as T
+    cfg = O.make_cfg(K_steps=K, img_size=S)
+    torch.manual_seed(11)
+    model = G.load(AttrDict(dict(cfg, debug=False, multi_gpu=False)))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    x = T.make_input(98, B, S)
+    eps = torch.randn(K * B, cfg['comp_ldim'], generator=torch.Generator().manual_seed(5))
+
+    def oracle(dtype):
+        p = to_dtype(sd, dtype)
+        out = O.monet_forward(p, x.to(dtype), cfg, eps.to(dtype))
+        e, kl_l, kl_m = O.aggregate_losses(out[1])
+        (e + kl_l + kl_m).backward()
+        return out, grads_of(p)
+    o64, g64 = oracle(torch.float64)
+    o32, g32 = oracle(torch.float32)
+    model = model.to(DEV)
+    recon, losses, stats, _, _ = model(x.to(DEV), eps.to(DEV))
+    (losses.err.mean(0) + torch.stack(losses.kl_l_k, 1).mean(0).sum() + losses.kl_m.mean(0)).backward()
+    st = lambda l: torch.stack(list(l))   # noqa: E731
+    fwd = [('recon', recon, o32[0], o64[0]), ('err', losses.err, o32[1]['err'], o64[1]['err']),
+           ('kl_m', losses.kl_m, o32[1]['kl_m'], o64[1]['kl_m']),
+           ('log_m', st(stats.log_m_k), st(o32[2]['log_m_k']), st(o64[2]['log_m_k']))]
+    bad = judge(fwd, hip_grads(model), g32, g64, 'MONet ' + name)
+    assert not bad, bad
+
+
+@pytest.mark.parametrize('name,K,S,B', [('tiny', 3, 32, 2), ('cfg3', 7, 64, 2)])
+def test_genesis(name, K, S, B):
+    from oracle import genesis_oracle as O
+    import genesis_amd.genesis_config as G
+    from genesis_amd.compat.attrdict import AttrDict
+    from genesis_amd import testing as T
+    cfg = O.make_cfg(K_steps=K, img_size=S)
+    torch.manual_seed(13)
+    model = G.load(AttrDict(dict(cfg, debug=False, multi_gpu=False)))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    x = T.make_input(97, B, S)
+    gen = torch.Generator().manual_seed(6)
+    eps_m = [torch.randn(B, cfg['attention_latents'], generator=gen) for _ in range(K)]
+    eps_c = torch.randn(K * B, cfg['comp_ldim'], generator=gen)
+
+    def oracle(dtype):
+        p = to_dtype(sd, dtype)
+        out = O.genesis_forward(p, x.to(dtype), cfg, [e.to(dtype) for e in eps_m], eps_c.to(dtype))
+        e, kl_l, kl_m = O.aggregate_losses(out[1])
+        (e + kl_l + kl_m).backward()
+        return out, grads_of(p)
+    o64, g64 = oracle(torch.float64)
+    o32, g32 = oracle(torch.float32)
+    model = model.to(DEV).train()
+    recon, losses, stats, _, _ = model(x.to(DEV), [e.to(DEV) for e in eps_m], eps_c.to(DEV))
+    (losses.err.mean(0) + torch.stack(losses.kl_m_k, 1).mean(0).sum() + torch.stack(losses.kl_l_k, 1).mean(0).sum()).backward()
+    st = lambda l: torch.stack(list(l))   # noqa: E731
+    fwd = [('recon', recon, o32[0], o64[0]), ('err', losses.err, o32[1]['err'], o64[1]['err']),
+           ('log_m', st(stats.log_m_k), st(o32[2]['log_m_k']), st(o64[2]['log_m_k']))]
+    bad = judge(fwd, hip_grads(model), g32, g64, 'GENESIS ' + name)
+    assert not bad, bad

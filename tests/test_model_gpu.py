@@ -25,12 +25,18 @@ def build(gold):
     return model.to(DEV).train()
 
 
+SEED_FALLBACKS = []     # (case, number of seed pixels that differed) whenever the reference's seeds had to be injected
+
+
 def run(model, gold, x, rand_pixel, eps_k):
     eps = torch.stack(eps_k).to(DEV)
     out = model(x.to(DEV), rand_pixel.to(DEV), eps)
     seed_idx = torch.stack(list(out[3]['seed_idx'])).cpu().numpy()
     if not np.array_equal(seed_idx, gold.g['seed_idx']):
-        # near-tie in the discontinuous argmax: replay with the reference's seeds
+        # near-tie in the discontinuous argmax: replay with the reference's seeds -- recorded, and
+        # test_seed_injection_fallback_never_fires fails if it ever happens on the committed fixtures (their noise seeds
+        # were chosen with a top-2 margin > 2e-5, make_golden.py), so a systematic argmax bug cannot hide behind it
+        SEED_FALLBACKS.append((gold.name, int((seed_idx != gold.g['seed_idx']).sum())))
         assert float(gold.g['seed_margin'].min()) < 1e-3
         forced = torch.from_numpy(gold.g['seed_idx']).to(DEV)
         out = model(x.to(DEV), rand_pixel.to(DEV), eps, forced)
@@ -56,7 +62,14 @@ def test_forward_and_grads_vs_golden(case):
     assert abs(float(err + kl) - elbo_ref) <= 2e-5 * abs(elbo_ref)          # what fp32 actually gives
     (err + kl).backward()
     grads = [(n, p.grad if p.grad is not None else torch.zeros_like(p)) for n, p in model.named_parameters()]
-    gold.check_grads(grads, rtol=5e-3, l2_tol=1e-2)
+    # gradient tolerance per case, from measurements (tools/tol_probe.py, tests/test_error_budget_gpu.py): on the 32x32
+    # cases HIP and the reference agree to <= 8e-5 (1.7e-3 with the undetached mask KL); on the closed-form weights of
+    # the 64x64 / 128x128 cases fp32 ITSELF is only good to 8e-3 -- the reference's own arithmetic sits 7.9e-3 from
+    # fp64 there, the HIP path 5.6e-3 (test_genesis_v2_on_the_golden_cases_weights_and_inputs) -- so two fp32 results
+    # may differ by ~1e-2
+    big = case in ('metric', 'cfg2', 'cfg5')
+    l2 = 1e-2 if big else (4e-3 if case == 'tiny_klm_nodetach' else 5e-4)
+    gold.check_grads(grads, rtol=5e-3 if big else l2, l2_tol=l2)
     # reference's own invariant (utils/misc.py:258-270)
     for key in ('log_m_k', 'log_m_r_k'):
         s = torch.stack(stats[key], 4).exp().sum(4)
@@ -99,6 +112,18 @@ def test_no_grad_forward_vs_golden(case):
     gold.check_forward(recon, losses, stats, att, comp, rtol=1e-4, atol=2e-5, mask_atol=1e-3)
 
 
+def test_seed_injection_fallback_never_fires():
+    """Runs after the golden comparisons of this module (pytest keeps file order): none of them may have needed the
+    reference's seed pixels injected."""
+    for case in DEFAULT_CASES:
+        gold = Golden(case)
+        model = build(gold)
+        x, rand_pixel, eps_k = gold.inputs()
+        with torch.no_grad():
+            run(model, gold, x, rand_pixel, eps_k)
+    assert SEED_FALLBACKS == [], SEED_FALLBACKS
+
+
 def test_output_contract():
     """Shapes / types / access patterns train.py and the scripts rely on."""
     gold = Golden('tiny')
@@ -123,69 +148,6 @@ def test_output_contract():
     img, st = model.sample(2, K_steps=6)
     assert len(st.mx_k) == 6
     assert float((torch.stack(st.log_m_k, 4).exp().sum(4) - 1).abs().max()) < 1e-3
-
-
-def test_error_budget_vs_fp64_oracle():
-    """Rigorous fp32 check: the oracle run in fp64 is ground truth.  Forward tensors: the HIP module's
-    relative L2 error must be of the same class as the fp32 CPU oracle's own error (<= 4x + 2e-6).
-    Gradients: <= 2e-3 relative L2 -- a single ReLU pre-activation within ~1e-7 of zero flipping
-    sign (seen on both the CPU-fp32 and the HIP side, tools/diag_model_decoder.py) moves every
-    upstream gradient by ~1e-4..1e-3; the table printed below shows both columns."""
-    from oracle import v2_oracle as O
-    import genesis_amd.genesisv2_config as G
-    from genesis_amd.compat.attrdict import AttrDict
-    from genesis_amd import testing as T
-    cfg = O.make_cfg(K_steps=5, img_size=64, feat_dim=32)
-    torch.manual_seed(7)
-    model = G.load(AttrDict(dict(cfg, debug=False, multi_gpu=False)))
-    with torch.no_grad():
-        model.att_process.colour_head.gate.gate.fill_(0.2)
-    sd = {k: v.clone() for k, v in model.state_dict().items()}
-    B = 4
-    x = T.make_input(99, B, 64)
-    rp, eps_k = T.draw_noise(123, B, 64, 32, 5)
-
-    def oracle(dtype):
-        p = {k: v.clone().to(dtype if v.dtype == torch.float32 else v.dtype).requires_grad_(True)
-             for k, v in sd.items()}
-        out = O.v2_forward(p, x.to(dtype), cfg, rp.to(dtype), [e.to(dtype) for e in eps_k], reference_form=False)
-        e, kl, _ = O.aggregate_losses(out[1])
-        (e + kl).backward()
-        return out, {k: (v.grad if v.grad is not None else torch.zeros_like(v)).double() for k, v in p.items()}
-
-    o64, g64 = oracle(torch.float64)
-    o32, g32 = oracle(torch.float32)
-    model = model.to(DEV)
-    recon, losses, stats, att, _ = model(x.to(DEV), rp.to(DEV), torch.stack(eps_k).to(DEV))
-    assert torch.equal(torch.stack(list(att['seed_idx'])).cpu(), torch.stack(o64[3]['seed_idx']))
-    (losses.err.mean(0) + torch.stack(losses.kl_l_k, 1).mean(0).sum()).backward()
-
-    def relerr(a, ref):
-        return float((a.double().cpu() - ref).norm()) / (float(ref.norm()) + 1e-30)
-
-    rows = []
-    bad = []
-    pairs = [('recon', recon, o32[0], o64[0]), ('err', losses.err, o32[1]['err'], o64[1]['err']),
-             ('log_m', torch.stack(list(stats.log_m_k)), torch.stack(o32[2]['log_m_k']), torch.stack(o64[2]['log_m_k'])),
-             ('kl', torch.stack(list(losses.kl_l_k)), torch.stack(o32[1]['kl_l_k']), torch.stack(o64[1]['kl_l_k']))]
-    for name, got, r32, r64 in pairs:
-        e_gpu, e_cpu = relerr(got.detach(), r64.detach().double()), relerr(r32.detach(), r64.detach().double())
-        rows.append((name, e_gpu, e_cpu))
-        if e_gpu > 4 * e_cpu + 2e-6:
-            bad.append(name)
-    gmax = max(float(v.norm()) for v in g64.values())
-    for n, prm in model.named_parameters():
-        got = prm.grad if prm.grad is not None else torch.zeros_like(prm)
-        ref = g64[n]
-        floor = 2e-6 * gmax / (float(ref.norm()) + 1e-30)   # analytically-zero grads: absolute floor
-        e_gpu, e_cpu = relerr(got, ref), relerr(g32[n], ref)
-        rows.append(('grad ' + n, e_gpu, e_cpu))
-        if e_gpu > max(4 * e_cpu + 2e-6, 2e-3) + floor:
-            bad.append(n)
-    print('\n%-44s %12s %12s' % ('tensor', 'hip-vs-f64', 'cpu32-vs-f64'))
-    for r in rows:
-        print('%-44s %12.3e %12.3e' % r)
-    assert not bad, bad
 
 
 def test_cpu_input_raises():

@@ -22,10 +22,10 @@ DEV = 'cuda'
 NCHUNK = 16
 
 
-def _full_batch(gold):
+def _full_batch(gold, nchunk=NCHUNK):
     """32 images: chunk 0 is exactly the golden case's input and noise, the others are fresh seeds."""
     xs, rps, epss = [], [], []
-    for c in range(NCHUNK):
+    for c in range(nchunk):
         xs.append(T.make_input(int(gold.g['x_seed']) + 977 * c, gold.B, gold.S))
         rp, eps = T.draw_noise(int(gold.g['noise_seed']) + 977 * c, gold.B, gold.S, gold.D, gold.K)
         rps.append(rp)
@@ -44,15 +44,13 @@ def _grads(model):
                       for p in model.parameters()])
 
 
-@pytest.fixture(scope='module')
-def chunked():
-    """Runs the sixteen B=2 forwards/backwards once; returns everything the full-batch tests compare against."""
-    gold = Golden('metric')
-    assert (gold.B, gold.K, gold.S, gold.D) == (2, 7, 64, 64)
+def _chunked(case, nchunk, dims):
+    gold = Golden(case)
+    assert (gold.B, gold.K, gold.S, gold.D) == dims
     model = build(gold)
-    xs, rps, epss = _full_batch(gold)
+    xs, rps, epss = _full_batch(gold, nchunk)
     per = []
-    for c in range(NCHUNK):
+    for c in range(nchunk):
         model.zero_grad(set_to_none=True)
         out = model(xs[c].to(DEV), rps[c].to(DEV), epss[c].to(DEV))
         if c == 0 and not np.array_equal(torch.stack(list(out[3]['seed_idx'])).cpu().numpy(), gold.g['seed_idx']):
@@ -67,6 +65,35 @@ def chunked():
                     'log_m': torch.stack(list(stats['log_m_k'])).detach().clone(), 'grad': _grads(model)})
     model.zero_grad(set_to_none=True)
     return gold, model, xs, rps, epss, per
+
+
+@pytest.fixture(scope='module')
+def chunked():
+    """Runs the sixteen B=2 forwards/backwards once; returns everything the full-batch tests compare against."""
+    return _chunked('metric', NCHUNK, (2, 7, 64, 64))
+
+
+def test_cfg5_full_batch_equals_thirtytwo_golden_sized_chunks():
+    """BASELINE config 5 at its real per-GPU batch (B=32, K=11, 128x128): the B=32 forward / gradient against thirty-two
+    B=1 runs, the first of which is the reference's golden case `cfg5`."""
+    gold, model, xs, rps, epss, per = _chunked('cfg5', 32, (1, 11, 128, 64))
+    np.testing.assert_array_equal(per[0]['seed_idx'].cpu().numpy(), gold.g['seed_idx'])
+    np.testing.assert_allclose(per[0]['err'].cpu().numpy(), gold.g['out/err'], rtol=1e-4)
+    x, rp = torch.cat(xs).to(DEV), torch.cat(rps).to(DEV)
+    eps = torch.cat(epss, dim=1).to(DEV)
+    seeds = torch.cat([p['seed_idx'] for p in per], dim=1)
+    recon, losses, stats, att, comp = model(x, rp, eps, seeds)
+    assert recon.shape == (32, 3, 128, 128)
+    np.testing.assert_allclose(losses.err.detach().cpu().numpy(), torch.cat([p['err'] for p in per]).cpu().numpy(), rtol=2e-6)
+    np.testing.assert_allclose(recon.detach().cpu().numpy(), torch.cat([p['recon'] for p in per]).cpu().numpy(),
+                               rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(torch.stack(list(losses.kl_l_k), 1).detach().cpu().numpy(),
+                               torch.cat([p['kl'] for p in per]).cpu().numpy(), rtol=1e-4, atol=1e-5)
+    _elbo(losses).backward()
+    g = _grads(model)
+    ref = torch.stack([p['grad'] for p in per]).mean(0)
+    rel = float((g - ref).norm() / ref.norm())
+    assert rel < 1e-3, rel
 
 
 def test_full_batch_equals_sixteen_golden_sized_chunks(chunked):
