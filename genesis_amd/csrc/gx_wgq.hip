@@ -23,7 +23,7 @@
 //
 // Workgroup = 4 waves; wave (wm, wn) owns the 32 x 32 block (A channels wm, B channels wn) of all NT taps
 // (v_mfma_f32_32x32x2_f32, k = pixels; lane-half h takes the pixels of tile half h, 4 consecutive pixels per group).
-// Tile = 64 base pixels (TH x TW, TW = 32 or 16); two LDS stages; one barrier per tile.
+// Tile = 64 base pixels (TH x TW, TW = 32, 16 or 8); two LDS stages; one barrier per tile.
 #include "gx_common.h"
 
 #include <cstdlib>
@@ -71,115 +71,69 @@ struct WqTable { int njobs; WqJob job[kMaxJobs]; };
 
 constexpr int kSB = 40;     // pieces per B channel in LDS ((TH + 2) * (TW + 8) / 4, padded to a multiple of 8)
 
-template <int CLS, int LTW>
-__global__ void __launch_bounds__(256, 1)
-wgq_kernel(const WqTable tab, const float* __restrict__ zeros) {
+// per-workgroup constants of the tile loop
+struct WqW {
+    const float* a; const float* b; const float* zeros;
+    int CA, CB, ca0, cb0, Hb, Wb, Wa, HaWa, HbWb;
+    int wave_u;                                   // wave id as a scalar (DMA destinations are wave-uniform)
+    int h, a_base, a_f, b_base, b_f;              // per-lane operand read bases
+};
+
+// One tile: LDS-DMA of tile (img, th, tw) into stage `wr` (live = false: past the last tile, every piece comes from the
+// zero page -- no branch around the issue, so it shares the MFMA loop's basic block and the scheduler spreads the DMA
+// instructions between the MFMAs), operands of the current tile out of stage `rd`.  The two stages are distinct
+// __restrict__ parameters of an inlined function: that is what lets hipcc prove that the LDS reads do not touch the
+// stage the in-flight DMA writes; with plain pointer arithmetic on one LDS array it puts s_waitcnt vmcnt(0) in front
+// of the first ds_read after the DMA issue and the staging never overlaps the MFMAs.
+template <int CLS, int LTW, int NI>
+__device__ __forceinline__ void wq_issue(float* __restrict__ wr, const WqW& w, const int (&goff)[NI],
+                                         const int (&info)[NI], const int img, const int th, const int tw,
+                                         const bool live) {
     using WT = WqTap<CLS>;
-    constexpr int NT = WT::NT, SA = WT::SA, NRO = WT::NRO, RO0 = WT::RO0;
-    constexpr int TW = 1 << LTW, TH = 64 >> LTW;
-    constexpr int RPA = SA * TW / 4;             // A pieces per tile row
-    constexpr int SAP = TH * RPA;                // A pieces per channel (16 or 32)
-    constexpr int RPB = (TW + 8) / 4;            // B pieces per halo row
-    constexpr int NPB_ = (TH + 2) * RPB;         // B pieces per channel actually used (<= kSB)
-    constexpr int A_PIECES = 64 * SAP, B_PIECES = 64 * kSB;
-    constexpr int STAGE = (A_PIECES + B_PIECES) * 4;          // floats per stage
-    constexpr int NI = (A_PIECES + B_PIECES) / 256;           // DMA instructions per thread per tile
-    static_assert((A_PIECES + B_PIECES) % 256 == 0 && A_PIECES % 64 == 0, "whole wave instructions");
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-
-    // ---- which job, channel block and split (wave-uniform scalar work)
-    int j = 0;
-#pragma unroll 1
-    for (int q = 1; q < tab.njobs; ++q) j = (int)blockIdx.x >= tab.job[q].wg_begin ? q : j;
-    const WqJob& jb = tab.job[j];
-    const int local = (int)blockIdx.x - jb.wg_begin;
-    const int nsp = jb.nsplit;
-    const int blk = local / nsp, sp = local - blk * nsp;
-    const int ca0 = (blk / jb.nbt) * 64, cb0 = (blk % jb.nbt) * 64;
-    const int Hb = jb.Hb, Wb = jb.Wb, Ha = SA * Hb, Wa = SA * Wb;
-    const int HaWa = Ha * Wa, HbWb = Hb * Wb;
-
-    // ---- DMA pieces of this thread: piece L = i * 256 + tid of the stage image, fixed over tiles.
-    //      A region [ch][slot], slot = q ^ (ch & 15); B region [ch][slot], slot = q ^ ((ch >> 1) & 7): the piece that
-    //      lands in slot s is global piece q = s ^ f(ch).
-    int goff[NI];          // float offset from the tile's A / B origin
-    int info[NI];          // bit 0: never valid (padding / channel beyond the tensor); B: halo row | piece column << 8
+    constexpr int SA = WT::SA, TW = 1 << LTW, TH = 64 >> LTW;
+    constexpr int A_PIECES = 64 * TH * (SA * TW / 4);
+    const int R0 = th * TH, C0 = tw * TW;
+    const float* a_t = w.a + ((size_t)img * w.CA + w.ca0) * w.HaWa + (size_t)(SA * R0 + WT::PA) * w.Wa + SA * C0;
+    const float* b_t = w.b + ((size_t)img * w.CB + w.cb0) * w.HbWb + (ptrdiff_t)(R0 - 1) * w.Wb + (C0 - 4);
+    float* dst = wr + w.wave_u * 256;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-        const int L = i * 256 + tid;
-        if (L < A_PIECES) {
-            const int ch = L / SAP, s = L - ch * SAP;
-            const int q = s ^ (ch & 15);
-            const int row = q / RPA, cp = q - row * RPA;
-            goff[i] = ch * HaWa + SA * row * Wa + 4 * cp;
-            info[i] = (ca0 + ch < jb.CA) ? 0 : 1;
-        } else {
-            const int Lb = L - A_PIECES;
-            const int ch = Lb / kSB, s = Lb - ch * kSB;
-            const int q = s ^ ((ch >> 1) & 7);
-            const int ri = q / RPB, cq = q - ri * RPB;
-            goff[i] = ch * HbWb + ri * Wb + 4 * cq;
-            info[i] = ((q < NPB_ && cb0 + ch < jb.CB) ? 0 : 1) | (ri << 8) | (cq << 16);
+        const bool isA = i * 256 < A_PIECES;          // whole instructions belong to one region
+        bool ok = live & !(info[i] & 1);              // bitwise: no short-circuit control flow
+        if (!isA) {
+            const int row = R0 - 1 + ((info[i] >> 8) & 255), col = C0 - 4 + 4 * (info[i] >> 16);
+            ok = ok & ((unsigned)row < (unsigned)w.Hb) & ((unsigned)col < (unsigned)w.Wb);
         }
+        const float* gp = ok ? (isA ? a_t : b_t) + goff[i] : w.zeros;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                         (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
     }
+}
 
-    // ---- per-lane operand read bases (float indices inside a stage)
-    const int wm = wave >> 1, wn = wave & 1;
-    const int h = lane >> 5;                         // tile half (= k slot) of this lane
-    const int cha = wm * 32 + (lane & 31);           // A channel of this lane inside the block
-    const int chb = wn * 32 + (lane & 31);
-    const int a_base = cha * SAP * 4, a_f = cha & 15;
-    const int b_base = A_PIECES * 4 + chb * kSB * 4, b_f = (chb >> 1) & 7;
-
-    f32x16 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-
-    // tile -> (image, tile row, tile col), advanced by carries (scalar)
-    const int tpi = jb.tiles_h * jb.tiles_w;
-    int t_img = sp / tpi, t_rem = sp - t_img * tpi;
-    int t_th = t_rem / jb.tiles_w, t_tw = t_rem - t_th * jb.tiles_w;
-    const int d_img = nsp / tpi, d_rem = nsp - d_img * tpi;
-    const int d_th = d_rem / jb.tiles_w, d_tw = d_rem - d_th * jb.tiles_w;
-
-#define GX_WQ_ISSUE(stage_, img_, th_, tw_)                                                                    \
-    {                                                                                                           \
-        const int R0_ = (th_) * TH, C0_ = (tw_) * TW;                                                           \
-        const float* a_t = jb.a + ((size_t)(img_) * jb.CA + ca0) * HaWa + (size_t)(SA * R0_ + WT::PA) * Wa + SA * C0_; \
-        const float* b_t = jb.b + ((size_t)(img_) * jb.CB + cb0) * HbWb + (ptrdiff_t)(R0_ - 1) * Wb + (C0_ - 4); \
-        float* dst_ = lds + (stage_) * STAGE + wave_u * 256;                                                    \
-        _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                                        \
-            const bool isA = i * 256 < A_PIECES;         /* whole instructions belong to one region */          \
-            bool ok = !(info[i] & 1);                                                                           \
-            if (!isA) {                                                                                         \
-                const int row_ = R0_ - 1 + ((info[i] >> 8) & 255), col_ = C0_ - 4 + 4 * (info[i] >> 16);        \
-                ok = ok && row_ >= 0 && row_ < Hb && col_ >= 0 && col_ < Wb;                                    \
-            }                                                                                                   \
-            const float* gp = ok ? (isA ? a_t : b_t) + goff[i] : zeros;                                         \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,                 \
-                (__attribute__((address_space(3))) void*)(dst_ + i * 1024), 16, 0, 0);                          \
-        }                                                                                                       \
-    }
-
-    // operand registers of one 4-pixel group: A 4 (C3) / 8 (DR) values, B NRO rows x 6 values
+template <int CLS, int LTW, int NI>
+__device__ __forceinline__ void wq_tile(const float* __restrict__ rd, float* __restrict__ wr,
+                                        f32x16 (&acc)[WqTap<CLS>::NT], const WqW& w, const int (&goff)[NI],
+                                        const int (&info)[NI], const int img, const int th, const int tw,
+                                        const bool live) {
+    using WT = WqTap<CLS>;
+    constexpr int NT = WT::NT, SA = WT::SA, NRO = WT::NRO, RO0 = WT::RO0;
+    constexpr int TW = 1 << LTW;
+    constexpr int RPA = SA * TW / 4, RPB = (TW + 8) / 4;
+    wq_issue<CLS, LTW, NI>(wr, w, goff, info, img, th, tw, live);
+    // operand registers of one 4-pixel group: A 4 (conv3x3) / 8 (transposed conv) values, B NRO rows x 6 values
     struct Grp { f32x4 a[WT::NPB]; float e0[NRO], e1[NRO]; f32x4 m[NRO]; };
-#define GX_WQ_READ(buf_, g_, dst_)                                                                              \
+#define GX_WQ_READ(g_, dst_)                                                                                    \
     {                                                                                                           \
-        const int jpix = h * 32 + 4 * (g_);                                                                     \
+        const int jpix = w.h * 32 + 4 * (g_);                                                                   \
         const int r_ = jpix >> LTW, c_ = jpix & (TW - 1);                                                       \
         const int qa = r_ * RPA + (SA * c_) / 4;                                                                \
         _Pragma("unroll") for (int p = 0; p < WT::NPB; ++p)                                                     \
-            dst_.a[p] = *reinterpret_cast<const f32x4*>((buf_) + a_base + (((qa + p) ^ a_f) << 2));             \
+            dst_.a[p] = *reinterpret_cast<const f32x4*>(rd + w.a_base + (((qa + p) ^ w.a_f) << 2));             \
         _Pragma("unroll") for (int rr = 0; rr < NRO; ++rr) {                                                    \
             const int qb = (r_ + RO0 + rr) * RPB + (c_ >> 2);                                                   \
-            dst_.e0[rr] = (buf_)[b_base + ((qb ^ b_f) << 2) + 3];                                               \
-            dst_.m[rr] = *reinterpret_cast<const f32x4*>((buf_) + b_base + (((qb + 1) ^ b_f) << 2));            \
-            dst_.e1[rr] = (buf_)[b_base + (((qb + 2) ^ b_f) << 2)];                                             \
+            dst_.e0[rr] = rd[w.b_base + ((qb ^ w.b_f) << 2) + 3];                                               \
+            dst_.m[rr] = *reinterpret_cast<const f32x4*>(rd + w.b_base + (((qb + 1) ^ w.b_f) << 2));            \
+            dst_.e1[rr] = rd[w.b_base + (((qb + 2) ^ w.b_f) << 2)];                                             \
         }                                                                                                       \
     }
     // A value of pixel u for column parity pb: conv3x3 a[0][u]; transposed conv: element 2u + pb of the 8 values
@@ -195,42 +149,124 @@ wgq_kernel(const WqTable tab, const float* __restrict__ zeros) {
                                                               acc[t], 0, 0, 0);                                 \
     }
     constexpr int NDS = WT::NPB + 3 * NRO;     // LDS read instructions per group
-
-    int tile = sp;
-    if (tile < jb.ntiles) GX_WQ_ISSUE(0, t_img, t_th, t_tw)
-    int it = 0;
-    for (; tile < jb.ntiles; tile += nsp, ++it) {
-        const float* buf = lds + (it & 1) * STAGE;
-        __syncthreads();          // this tile has landed (vmcnt drained in front of the barrier); the other stage is free
-        // next tile of this workgroup
-        t_tw += d_tw; t_th += d_th; t_img += d_img;
-        if (t_tw >= jb.tiles_w) { t_tw -= jb.tiles_w; ++t_th; }
-        if (t_th >= jb.tiles_h) { t_th -= jb.tiles_h; ++t_img; }
-        if (tile + nsp < jb.ntiles) GX_WQ_ISSUE((it + 1) & 1, t_img, t_th, t_tw)
-        Grp g0, g1;
-        GX_WQ_READ(buf, 0, g0)
+    constexpr int VPG = (NI + 7) / 8;          // DMA instructions placed behind each group's MFMAs
+    Grp g0, g1;
+    GX_WQ_READ(0, g0)
 #pragma unroll
-        for (int g = 0; g < 8; g += 2) {
-            GX_WQ_READ(buf, g + 1, g1)
-            GX_WQ_MMA(g0)
-            __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);
-            if (g + 2 < 8) GX_WQ_READ(buf, g + 2, g0)
-            GX_WQ_MMA(g1)
-            if (g + 2 < 8) __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);
-        }
+    for (int g = 0; g < 8; g += 2) {
+        GX_WQ_READ(g + 1, g1)
+        GX_WQ_MMA(g0)
+        __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, VPG, 0);
+        if (g + 2 < 8) GX_WQ_READ(g + 2, g0)
+        GX_WQ_MMA(g1)
+        if (g + 2 < 8) __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, VPG, 0);
     }
-#undef GX_WQ_ISSUE
 #undef GX_WQ_READ
 #undef GX_WQ_AVAL
 #undef GX_WQ_BVAL
 #undef GX_WQ_MMA
+}
+
+template <int CLS, int LTW>
+__global__ void __launch_bounds__(256, 1)
+wgq_kernel(const WqTable tab, const float* __restrict__ zeros) {
+    using WT = WqTap<CLS>;
+    constexpr int NT = WT::NT, SA = WT::SA;
+    constexpr int TW = 1 << LTW, TH = 64 >> LTW;
+    constexpr int RPA = SA * TW / 4;             // A pieces per tile row
+    constexpr int SAP = TH * RPA;                // A pieces per channel (16 or 32)
+    constexpr int RPB = (TW + 8) / 4;            // B pieces per halo row
+    constexpr int NPB_ = (TH + 2) * RPB;         // B pieces per channel actually used (<= kSB)
+    constexpr int A_PIECES = 64 * SAP, B_PIECES = 64 * kSB;
+    constexpr int STAGE = (A_PIECES + B_PIECES) * 4;          // floats per stage
+    constexpr int NI = (A_PIECES + B_PIECES) / 256;           // DMA instructions per thread per tile
+    static_assert((A_PIECES + B_PIECES) % 256 == 0 && A_PIECES % 256 == 0, "whole wave instructions per region");
+    static_assert(NPB_ <= kSB, "B halo tile must fit its LDS slot");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // ---- which job, channel block and split (wave-uniform scalar work)
+    int j = 0;
+#pragma unroll 1
+    for (int q = 1; q < tab.njobs; ++q) j = (int)blockIdx.x >= tab.job[q].wg_begin ? q : j;
+    const WqJob& jb = tab.job[j];
+    const int local = (int)blockIdx.x - jb.wg_begin;
+    const int nsp = jb.nsplit;
+    const int blk = local / nsp, sp = local - blk * nsp;
+    WqW w;
+    w.a = jb.a; w.b = jb.b; w.zeros = zeros;
+    w.CA = jb.CA; w.CB = jb.CB;
+    w.ca0 = (blk / jb.nbt) * 64; w.cb0 = (blk % jb.nbt) * 64;
+    w.Hb = jb.Hb; w.Wb = jb.Wb; w.Wa = SA * jb.Wb;
+    w.HaWa = SA * jb.Hb * w.Wa; w.HbWb = jb.Hb * jb.Wb;
+    w.wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+    // ---- DMA pieces of this thread: piece L = i * 256 + tid of the stage image, fixed over tiles.
+    //      A region [ch][slot], slot = q ^ (ch & 15); B region [ch][slot], slot = q ^ ((ch >> 1) & 7): the piece that
+    //      lands in slot s is global piece q = s ^ f(ch).
+    int goff[NI];          // float offset from the tile's A / B origin
+    int info[NI];          // bit 0: never valid (padding / channel beyond the tensor); B: halo row << 8 | piece column << 16
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int L = i * 256 + tid;
+        if (L < A_PIECES) {
+            const int ch = L / SAP, s = L - ch * SAP;
+            const int q = s ^ (ch & 15);
+            const int row = q / RPA, cp = q - row * RPA;
+            goff[i] = ch * w.HaWa + SA * row * w.Wa + 4 * cp;
+            info[i] = (w.ca0 + ch < jb.CA) ? 0 : 1;
+        } else {
+            const int Lb = L - A_PIECES;
+            const int ch = Lb / kSB, s = Lb - ch * kSB;
+            const int q = s ^ ((ch >> 1) & 7);
+            const int ri = q / RPB, cq = q - ri * RPB;
+            goff[i] = ch * w.HbWb + ri * w.Wb + 4 * cq;
+            info[i] = ((q < NPB_ && w.cb0 + ch < jb.CB) ? 0 : 1) | (ri << 8) | (cq << 16);
+        }
+    }
+
+    // ---- per-lane operand read bases (float indices inside a stage)
+    const int wm = wave >> 1, wn = wave & 1;
+    w.h = lane >> 5;                                 // tile half (= k slot) of this lane
+    const int cha = wm * 32 + (lane & 31);           // A channel of this lane inside the block
+    const int chb = wn * 32 + (lane & 31);
+    w.a_base = cha * SAP * 4; w.a_f = cha & 15;
+    w.b_base = A_PIECES * 4 + chb * kSB * 4; w.b_f = (chb >> 1) & 7;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    // tile -> (image, tile row, tile col), advanced by carries (scalar)
+    const int tpi = jb.tiles_h * jb.tiles_w;
+    int t_img = sp / tpi, t_rem = sp - t_img * tpi;
+    int t_th = t_rem / jb.tiles_w, t_tw = t_rem - t_th * jb.tiles_w;
+    const int d_img = nsp / tpi, d_rem = nsp - d_img * tpi;
+    const int d_th = d_rem / jb.tiles_w, d_tw = d_rem - d_th * jb.tiles_w;
+
+    int tile = sp;
+    if (tile < jb.ntiles) wq_issue<CLS, LTW, NI>(lds, w, goff, info, t_img, t_th, t_tw, true);
+    int it = 0;
+    for (; tile < jb.ntiles; tile += nsp, ++it) {
+        __syncthreads();          // this tile has landed (vmcnt drained in front of the barrier); the other stage is free
+        t_tw += d_tw; t_th += d_th; t_img += d_img;          // next tile of this workgroup
+        if (t_tw >= jb.tiles_w) { t_tw -= jb.tiles_w; ++t_th; }
+        if (t_th >= jb.tiles_h) { t_th -= jb.tiles_h; ++t_img; }
+        wq_tile<CLS, LTW, NI>(lds + (it & 1) * STAGE, lds + ((it + 1) & 1) * STAGE, acc, w, goff, info, t_img, t_th, t_tw,
+                              tile + nsp < jb.ntiles);
+    }
 
     // ---- slab: partial[split][gt][ca][cb]  (C/D layout: col = lane & 31 -> cb, row -> ca)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        float* dst = jb.partial + (((size_t)sp * jb.Ttot + WT::gt(t)) * jb.CApad + ca0 + wm * 32) * jb.CBpad + cb0 +
+        float* dst = jb.partial + (((size_t)sp * jb.Ttot + WT::gt(t)) * jb.CApad + w.ca0 + wm * 32) * jb.CBpad + w.cb0 +
                      wn * 32 + (lane & 31);
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
@@ -278,9 +314,19 @@ void wgq_launch_inst(const WqTable& tab, int total_wgs, const float* zeros, hipS
 }
 
 void wgq_launch(int cls, int ltw, const WqTable& tab, int total_wgs, const float* zeros, hipStream_t s) {
-    if (cls == WQ_C3) { if (ltw == 5) wgq_launch_inst<WQ_C3, 5>(tab, total_wgs, zeros, s); else wgq_launch_inst<WQ_C3, 4>(tab, total_wgs, zeros, s); }
-    else if (cls == WQ_DR0) { if (ltw == 5) wgq_launch_inst<WQ_DR0, 5>(tab, total_wgs, zeros, s); else wgq_launch_inst<WQ_DR0, 4>(tab, total_wgs, zeros, s); }
-    else { if (ltw == 5) wgq_launch_inst<WQ_DR1, 5>(tab, total_wgs, zeros, s); else wgq_launch_inst<WQ_DR1, 4>(tab, total_wgs, zeros, s); }
+    if (cls == WQ_C3) {
+        if (ltw == 5) wgq_launch_inst<WQ_C3, 5>(tab, total_wgs, zeros, s);
+        else if (ltw == 4) wgq_launch_inst<WQ_C3, 4>(tab, total_wgs, zeros, s);
+        else wgq_launch_inst<WQ_C3, 3>(tab, total_wgs, zeros, s);
+    } else if (cls == WQ_DR0) {
+        if (ltw == 5) wgq_launch_inst<WQ_DR0, 5>(tab, total_wgs, zeros, s);
+        else if (ltw == 4) wgq_launch_inst<WQ_DR0, 4>(tab, total_wgs, zeros, s);
+        else wgq_launch_inst<WQ_DR0, 3>(tab, total_wgs, zeros, s);
+    } else {
+        if (ltw == 5) wgq_launch_inst<WQ_DR1, 5>(tab, total_wgs, zeros, s);
+        else if (ltw == 4) wgq_launch_inst<WQ_DR1, 4>(tab, total_wgs, zeros, s);
+        else wgq_launch_inst<WQ_DR1, 3>(tab, total_wgs, zeros, s);
+    }
 }
 
 int g_wgq_mode = -1;
@@ -295,8 +341,8 @@ int wgq_mode() {
 // fills the geometry part of a job; false if the layer is not eligible
 bool wgq_make_job(int sa, const float* a, const float* b, float* partial, int N, int CA, int CB, int Hb, int Wb, int Ttot,
                   int max_split, WqJob* jb, int* ltw) {
-    if (!gx_is_pow2(Hb) || !gx_is_pow2(Wb) || Wb < 16) return false;
-    const int lt = Wb >= 32 ? 5 : 4;
+    if (!gx_is_pow2(Hb) || !gx_is_pow2(Wb) || Wb < 8) return false;
+    const int lt = Wb >= 32 ? 5 : (Wb >= 16 ? 4 : 3);
     const int TW = 1 << lt, TH = 64 >> lt;
     if (Hb < TH) return false;
     if ((double)N * CA * sa * Hb * sa * Wb >= 2.0e9 || (double)N * CB * Hb * Wb >= 2.0e9) return false;   // int offsets per job
@@ -422,7 +468,7 @@ int gx_wgq_flush(hipStream_t s) {
     if (g_jobs.empty()) return GX_OK;
     int rc = GX_OK;
     for (int cls = 0; cls < 3 && rc == GX_OK; ++cls)
-        for (int ltw = 5; ltw >= 4 && rc == GX_OK; --ltw) {
+        for (int ltw = 5; ltw >= 3 && rc == GX_OK; --ltw) {
             std::vector<PendingJob*> grp;
             for (PendingJob& p : g_jobs)
                 if (p.cls == cls && p.ltw == ltw) grp.push_back(&p);

@@ -56,7 +56,7 @@ int gx_conv3x3_wino_policy(int mode);
  *      environment), 2 every eligible shape (power-of-two grids, reduction channels a multiple of 8). */
 int gx_kq_policy(int mode);
 /*      weight gradients: 1 (default; GENESIS_WGQ=0/1) = LDS-DMA staged kernels with grouped launches (gx_wgq.hip) for
- *      layers of width >= 16, 0 = the round-1 kernels everywhere. */
+ *      layers of width >= 8, 0 = the round-1 kernels everywhere. */
 int gx_wgq_policy(int mode);
 size_t gx_conv3x3_wino_ws_bytes(int N, int Cin, int Cout, int H, int W);
 int gx_conv3x3_wino(const float* x, const float* w, float* y, int N, int Cin, int Cout, int H, int W, int mode,
