@@ -87,6 +87,7 @@ struct QGeom {
     int Hi, Wi, Ho, Wo;   // input / output tensor dims
     int lTH, lTW, lG, tiles_h, tiles_w;
     int act;              // epilogue activation after the bias: 0 none, 1 ReLU, 2 ELU
+    int nfull;            // blockIdx.x < nfull: whole tiles; the rest: pairs of half-work workgroups (q_split_tail)
     float* stats;         // STATS: per-workgroup (sum, sum of squares) of every 8-channel block, [N][parts][M/8][2]
     int stats_parts;
 };
@@ -99,22 +100,22 @@ __device__ __forceinline__ float q_act(float v, int act) {
 
 // one phase: the taps of phase PH out of the input tile `ib` and the weight slice `wb`; the operands of tap i + 1 are
 // read ahead of tap i's MFMAs (two register sets; order pinned by GX_Q_SCHED)
-template <int MODE, int PH, int NCLS>
-__device__ __forceinline__ void q_phase(f32x16 (&acc)[NCLS][2][2], const float* ib, const float* wb, const int a_lane,
+template <int MODE, int PH, int NCLS, int MI>
+__device__ __forceinline__ void q_phase(f32x16 (&acc)[NCLS][MI][2], const float* ib, const float* wb, const int a_lane,
                                         const int b_lane0, const int b_lane1, const int HS4) {
     using C = QCfg<MODE>;
     constexpr int nt = C::ntaps(PH);
-    f32x4 fa[2][2], fb[2][2];
+    f32x4 fa[2][MI], fb[2][2];
 #define GX_Q_READ(i_, set_)                                                                            \
     {                                                                                                  \
         const int toff_ = C::ro(PH, i_) * HS4 + C::co(PH, i_) * 4;                                     \
-        fa[set_][0] = *reinterpret_cast<const f32x4*>(wb + (i_) * 512 + a_lane);                       \
-        fa[set_][1] = *reinterpret_cast<const f32x4*>(wb + (i_) * 512 + a_lane + 128);                 \
+        _Pragma("unroll") for (int mi_ = 0; mi_ < MI; ++mi_)                                           \
+            fa[set_][mi_] = *reinterpret_cast<const f32x4*>(wb + (i_) * 512 + a_lane + mi_ * 128);     \
         fb[set_][0] = *reinterpret_cast<const f32x4*>(ib + b_lane0 + toff_);                           \
         fb[set_][1] = *reinterpret_cast<const f32x4*>(ib + b_lane1 + toff_);                           \
     }
     GX_Q_READ(0, 0)
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 + MI, 0);
 #pragma unroll
     for (int i = 0; i < nt; ++i) {
         const int cur = i & 1;
@@ -122,10 +123,11 @@ __device__ __forceinline__ void q_phase(f32x16 (&acc)[NCLS][2][2], const float* 
         const int cl = C::cls(PH, i);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            acc[cl][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][0][j], fb[cur][0][j], acc[cl][0][0], 0, 0, 0);
-            acc[cl][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][0][j], fb[cur][1][j], acc[cl][0][1], 0, 0, 0);
-            acc[cl][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][1][j], fb[cur][0][j], acc[cl][1][0], 0, 0, 0);
-            acc[cl][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][1][j], fb[cur][1][j], acc[cl][1][1], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                acc[cl][mi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][mi][j], fb[cur][0][j], acc[cl][mi][0], 0, 0, 0);
+                acc[cl][mi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][mi][j], fb[cur][1][j], acc[cl][mi][1], 0, 0, 0);
+            }
         }
 #if GX_KQ_VAR == 1      /* one operand read behind every fourth MFMA */
         for (int r = 0; r < 4; ++r) {
@@ -134,18 +136,20 @@ __device__ __forceinline__ void q_phase(f32x16 (&acc)[NCLS][2][2], const float* 
         }
 #elif GX_KQ_VAR == 2    /* no pinning: hipcc's own placement */
 #else
-        if (i + 1 < nt) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+        if (i + 1 < nt) __builtin_amdgcn_sched_group_barrier(0x100, 2 + MI, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8 * MI, 0);
 #endif
     }
 #undef GX_Q_READ
 }
 
 // NQ: (position, quad) slots staged per thread per input tile (2 * CHS <= NQ * 256)
-template <int MODE, int NQ, bool STATS>
+// MI: 32-channel MFMA tiles per wave along M.  2 = the workgroup's whole 64-channel tile; 1 = one half (mh) of it --
+// the last tiles of a grid that does not divide the chip are split into two half-work workgroups (q_split_tail).
+template <int MODE, int NQ, bool STATS, int MI = 2>
 __device__ __forceinline__ void q_body(const float* __restrict__ in, const float* __restrict__ wp,
                                        const float* __restrict__ bias, float* __restrict__ out, const QGeom& g,
-                                       float* lds, const int bx, const int by, const int par_a) {
+                                       float* lds, const int bx, const int by, const int par_a, const int mh = 0) {
     using C = QCfg<MODE>;
     constexpr int NPH = C::NPH, NT = C::NT, MAXT = C::MAXT, NCLS = C::NCLS;
     constexpr int NW = (MAXT * 128 + 255) / 256;       // float4 weight loads per thread per phase
@@ -195,7 +199,7 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
 
     // ---- per-lane operand addresses (float indices)
     const int quad_l = lane >> 5;
-    const int a_lane = (quad_l * 64 + (lane & 31)) * 4;            // + mi * 128 + tap * 512
+    const int a_lane = (quad_l * 64 + (lane & 31)) * 4 + mh * 128;   // + mi * 128 + tap * 512
     int b_lane[2];
 #pragma unroll
     for (int nj = 0; nj < 2; ++nj) {
@@ -207,11 +211,11 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
     }
     const int HS4 = HS * 4;
 
-    f32x16 acc[NCLS][2][2];
+    f32x16 acc[NCLS][MI][2];
 #pragma unroll
     for (int c = 0; c < NCLS; ++c)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -273,7 +277,7 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
                 GX_Q_LOAD_W(nchunk, NXT)                                                                         \
                 __builtin_amdgcn_sched_group_barrier(0x020, (new_in ? NQ * 4 : 0) + NW, 0);                      \
             }                                                                                                    \
-            q_phase<MODE, (PH_), NCLS>(acc, ibuf0 + icur * ISLOT, wbuf0 + (s & 1) * WSLOT, a_lane, b_lane[0],    \
+            q_phase<MODE, (PH_), NCLS, MI>(acc, ibuf0 + icur * ISLOT, wbuf0 + (s & 1) * WSLOT, a_lane, b_lane[0],    \
                                        b_lane[1], HS4);                                                  \
             if (more) {                                                                                          \
                 if (new_in) GX_Q_STORE_IN(ibuf0 + inxt * ISLOT)                                                  \
@@ -302,14 +306,14 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
     const int HoWo = g.Ho * g.Wo;
     const bool add_bias = bias != nullptr;
     const int act = g.act;
-    f32x4 bvec[2][4];
+    f32x4 bvec[MI][4];
     {
         const bool vec_ok = add_bias && (reinterpret_cast<uintptr_t>(bias) & 15) == 0;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int mb = m0 + mi * 32 + 8 * q + 4 * (lane >> 5);
+                const int mb = m0 + (mi + mh) * 32 + 8 * q + 4 * (lane >> 5);
                 f32x4 t = {0.f, 0.f, 0.f, 0.f};
                 if (vec_ok && mb + 3 < g.M) t = *reinterpret_cast<const f32x4*>(bias + mb);
                 else if (add_bias) {
@@ -332,10 +336,10 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
         else { orow = R0 + r; ocol = C0 + c; }
         float* obase = out + (size_t)n * out_img_stride + (size_t)orow * g.Wo + ocol;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int m = m0 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                const int m = m0 + (mi + mh) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
                 if (m < g.M) {
                     const float bv = bvec[mi][reg >> 2][reg & 3];
                     if (NCLS == 2) {
@@ -360,9 +364,10 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
     if constexpr (STATS) {
         // GroupNorm statistics of the (pre-activation) output without a pass over it: per 8-channel block sums over this
         // workgroup's pixels, transposed through LDS and summed in a fixed order (same scheme as gx_conv.hip's STATS)
-        float st_s[8], st_q[8];
+        constexpr int NB = 4 * MI;          // 8-channel blocks of this workgroup
+        float st_s[NB], st_q[NB];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { st_s[i] = 0.f; st_q[i] = 0.f; }
+        for (int i = 0; i < NB; ++i) { st_s[i] = 0.f; st_q[i] = 0.f; }
 #pragma unroll
         for (int nj = 0; nj < 2; ++nj) {
             const int p = wave * 64 + nj * 32 + (lane & 31);
@@ -370,10 +375,10 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
             const int r = (p >> g.lTW) & (TH - 1);
             const bool ok = img0 + (p >> (g.lTW + g.lTH)) < g.N && R0 + r < g.Hb && C0 + c < g.Wb;
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
-                    const int m = m0 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                    const int m = m0 + (mi + mh) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
                     const float bv = bvec[mi][reg >> 2][reg & 3];
                     const float vx = (ok && m < g.M) ? acc[0][mi][nj][reg] + bv : 0.f;
                     const float vy = (ok && m < g.M) ? acc[NCLS - 1][mi][nj][reg] + bv : 0.f;
@@ -383,25 +388,27 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { lds[i * 256 + tid] = st_s[i]; lds[(8 + i) * 256 + tid] = st_q[i]; }
+        for (int i = 0; i < NB; ++i) { lds[i * 256 + tid] = st_s[i]; lds[(NB + i) * 256 + tid] = st_q[i]; }
         __syncthreads();
-        const int vi = tid >> 4, sub = tid & 15;
+        const int vi = tid >> 4, sub = tid & 15;      // 16 threads per value; rows [0, NB) sums, [NB, 2 NB) squares
         float v = 0.f;
+        if (vi < 2 * NB) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const f32x4 r = *reinterpret_cast<const f32x4*>(lds + vi * 256 + sub * 16 + 4 * k);
-            v += (r[0] + r[1]) + (r[2] + r[3]);
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 r = *reinterpret_cast<const f32x4*>(lds + vi * 256 + sub * 16 + 4 * k);
+                v += (r[0] + r[1]) + (r[2] + r[3]);
+            }
         }
         v += __shfl_xor(v, 8, 64);
         v += __shfl_xor(v, 4, 64);
         v += __shfl_xor(v, 2, 64);
         v += __shfl_xor(v, 1, 64);
-        if (sub == 0) {
+        if (sub == 0 && vi < 2 * NB) {
             const int part = (th_i * g.tiles_w + tw_i) * 2 + par_a;
             const int nblk = g.M >> 3;
-            const int blk = (m0 >> 3) + (vi & 7);
+            const int blk = (m0 >> 3) + mh * 4 + (vi % NB);
             if (blk < nblk && img0 < g.N)
-                g.stats[(((size_t)img0 * g.stats_parts + part) * nblk + blk) * 2 + (vi >> 3)] = v;
+                g.stats[(((size_t)img0 * g.stats_parts + part) * nblk + blk) * 2 + (vi / NB)] = v;
         }
     }
 }
@@ -411,7 +418,9 @@ __global__ void __launch_bounds__(256, 2)
 kq_kernel(const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
           float* __restrict__ out, QGeom g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    q_body<MODE, NQ, false>(in, wp, bias, out, g, lds, blockIdx.x, blockIdx.y, 0);
+    const int bx = blockIdx.x;
+    if (bx < g.nfull) q_body<MODE, NQ, false, 2>(in, wp, bias, out, g, lds, bx, blockIdx.y, 0);
+    else q_body<MODE, NQ, false, 1>(in, wp, bias, out, g, lds, g.nfull + ((bx - g.nfull) >> 1), blockIdx.y, 0, (bx - g.nfull) & 1);
 }
 
 // both output-row parities of the transposed conv in one launch; blockIdx.y = channel tile, blockIdx.z = 0: rows 2r
@@ -421,8 +430,15 @@ __global__ void __launch_bounds__(256, 2)
 kq_dt_kernel(const float* __restrict__ in, const float* __restrict__ wp0, const float* __restrict__ wp1,
              const float* __restrict__ bias, float* __restrict__ out, QGeom g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    if (blockIdx.z) q_body<Q_DT1, NQ, STATS>(in, wp1, bias, out, g, lds, blockIdx.x, blockIdx.y, 1);
-    else q_body<Q_DT0, NQ, STATS>(in, wp0, bias, out, g, lds, blockIdx.x, blockIdx.y, 0);
+    const int bx = blockIdx.x;
+    if (bx < g.nfull) {
+        if (blockIdx.z) q_body<Q_DT1, NQ, STATS, 2>(in, wp1, bias, out, g, lds, bx, blockIdx.y, 1);
+        else q_body<Q_DT0, NQ, STATS, 2>(in, wp0, bias, out, g, lds, bx, blockIdx.y, 0);
+    } else {
+        const int tile = g.nfull + ((bx - g.nfull) >> 1), mh = (bx - g.nfull) & 1;
+        if (blockIdx.z) q_body<Q_DT1, NQ, STATS, 1>(in, wp1, bias, out, g, lds, tile, blockIdx.y, 1, mh);
+        else q_body<Q_DT0, NQ, STATS, 1>(in, wp0, bias, out, g, lds, tile, blockIdx.y, 0, mh);
+    }
 }
 
 int q_ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
@@ -448,6 +464,20 @@ bool q_plan(int N, int K, int M, int Hb, int Wb, int Hi, int Wi, int Ho, int Wo,
     static const char* pad_env = getenv("GENESIS_KQ_ONE_WG");     // measurement: one workgroup per CU
     if (pad_env && pad_env[0] == '1' && *lds_bytes < 96 * 1024) *lds_bytes = 96 * 1024;
     return *lds_bytes <= 160 * 1024;
+}
+
+// A CU works through its workgroups almost one after the other (the older workgroup wins the matrix pipe), so a grid of
+// T equal tiles costs ceil(T / 256) rounds: 896 tiles (the 32 -> 64 decoder layer at K*B = 224) = 3.5 -> 4 rounds.
+// When the last round is at most half full, its tiles are split along M into two half-work workgroups each (32 output
+// channels): 768 whole + 256 half workgroups = 3 + ~0.6 rounds.  Returns the number of whole-tile workgroups and sets
+// the grid width.  Only for full 64-channel tiles (M % 64 == 0 or > 32 in the last tile).
+int q_split_tail(int ptiles, int M, unsigned* grid_x) {
+    static const char* env = getenv("GENESIS_KQ_TAIL");
+    const int r = ptiles % 256;
+    const bool split = !(env && env[0] == '0') && ptiles > 256 && r > 0 && r <= 128 && (M % 64 == 0 || M % 64 > 32);
+    const int nfull = split ? ptiles - r : ptiles;
+    *grid_x = (unsigned)(nfull + 2 * (ptiles - nfull));
+    return nfull;
 }
 
 int g_kq_mode = -1;   // 0 off, 1 auto (layers whose grid fills the chip), 2 every eligible shape
@@ -492,7 +522,8 @@ int gx_kq_c3_launch(const float* in, const float* wp, const float* bias, int act
     QGeom g; int nq; size_t lds;
     if (!q_plan(N, K, M, H, W, H, W, H, W, &g, &nq, &lds, 9)) { gx_set_error("kq conv3x3: shape not eligible"); return GX_EINVAL; }
     g.act = act;
-    dim3 grid(g.tiles_h * g.tiles_w * gx_ceil_div(N, 1 << g.lG), gx_ceil_div(M, 64));
+    dim3 grid(1, gx_ceil_div(M, 64));
+    g.nfull = q_split_tail(g.tiles_h * g.tiles_w * gx_ceil_div(N, 1 << g.lG), M, &grid.x);
     {
         GxProf pf(KID_TAPCONV_C3, s, 2.0 * N * (double)M * K * 9 * H * W,
                   4.0 * ((double)N * K * H * W + (double)N * M * H * W + 9.0 * K * M));
@@ -517,7 +548,8 @@ int gx_kq_deconv_fwd_launch(const float* in, const float* wp0, const float* wp1,
         g.stats_parts = g.tiles_h * g.tiles_w * 2;
         if (stats_parts) *stats_parts = g.stats_parts;
     }
-    dim3 grid(g.tiles_h * g.tiles_w * gx_ceil_div(N, 1 << g.lG), gx_ceil_div(M, 64), 2);
+    dim3 grid(1, gx_ceil_div(M, 64), 2);
+    g.nfull = q_split_tail(g.tiles_h * g.tiles_w * gx_ceil_div(N, 1 << g.lG), M, &grid.x);
     {
         GxProf pf(KID_TAPCONV_DT0, s, 2.0 * N * (double)M * K * 25 * Hb * Wb,
                   4.0 * ((double)N * K * Hb * Wb + (double)N * M * 4 * Hb * Wb + 25.0 * K * M));
@@ -536,7 +568,8 @@ int gx_kq_deconv_dgrad_launch(const float* dy, const float* wp, float* dx, int N
                               hipStream_t s) {
     QGeom g; int nq; size_t lds;
     if (!q_plan(N, K, M, Hb, Wb, 2 * Hb, 2 * Wb, Hb, Wb, &g, &nq, &lds, 9)) { gx_set_error("kq deconv dgrad: shape not eligible"); return GX_EINVAL; }
-    dim3 grid(g.tiles_h * g.tiles_w * gx_ceil_div(N, 1 << g.lG), gx_ceil_div(M, 64));
+    dim3 grid(1, gx_ceil_div(M, 64));
+    g.nfull = q_split_tail(g.tiles_h * g.tiles_w * gx_ceil_div(N, 1 << g.lG), M, &grid.x);
     {
         GxProf pf(KID_TAPCONV_DG, s, 2.0 * N * (double)M * K * 25 * Hb * Wb,
                   4.0 * ((double)N * K * 4 * Hb * Wb + (double)N * M * Hb * Wb + 25.0 * K * M));
