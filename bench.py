@@ -84,16 +84,19 @@ def build_model(args, device):
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    in separate runs of this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM'); None if absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_hbm_traffic.json')
-    if not os.path.exists(path):
+    """HBM bytes per launch of the kernels behind profiling id `kernel` from the committed PMC passes (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs of this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM');
+    None if absent."""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
+    path = next((p_ for p_ in (os.path.join(here, 'r02_pmc_hbm_traffic.json'), os.path.join(here, 'pmc_hbm_traffic.json'))
+                 if os.path.exists(p_)), None)
+    if path is None:
         return None
     data = json.load(open(path))
-    stem = kernel.rstrip('>')          # 'tapconv_kernel<0' matches 'tapconv_kernel<0, 2>' and '<0, 4>'
+    syms = tuple(s_.replace(',', '') for s_ in KID_SYMBOLS.get(kernel, (kernel,)))
     tot, n = 0.0, 0
     for name, v in data.items():
-        if name == kernel or name.startswith(stem + ',') or name.startswith(stem + '>') or name.startswith(stem + '<'):
+        if any(name.replace(', ', ',').startswith(s_) for s_ in syms):
             tot += v['hbm_bytes_per_launch_corrected'] * v['launches']
             n += v['launches']
     return tot / n if n else None

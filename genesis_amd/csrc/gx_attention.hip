@@ -29,6 +29,10 @@ __device__ __forceinline__ float st_clamp(float a, float lo, float hi) {
     return a + (c - a);  // value of x + (clamp(x) - x).detach()
 }
 
+// PPT > 0: the image has exactly PPT pixels per thread (HW = PPT * blockDim.x, PPT <= 4: 64x64 and smaller): the
+// thread's colour vectors, its random numbers and its log-scope stay in registers over the K-1 steps (the generic path
+// re-reads the colour map from L2 in every step: 54 -> 3x us at K=7, 64x64).  PPT == 0: generic (LDS scope, global colour).
+template <int PPT>
 __global__ void __launch_bounds__(1024)
 icsbp_fwd_kernel(const float* __restrict__ colour, const double* __restrict__ log_sigma,
                  const float* __restrict__ rand_pixel, const int64_t* __restrict__ seed_idx_in,
@@ -50,9 +54,23 @@ icsbp_fwd_kernel(const float* __restrict__ colour, const double* __restrict__ lo
     // log-scope of this image, carried across the K-1 steps in LDS (each thread only ever touches
     // its own pixels p = tid + q*T, so no barrier is needed around it)
     extern __shared__ __attribute__((aligned(16))) float ls[];
-    for (int p = tid; p < HW; p += T) {
-        ls[p] = 0.f;
-        log_s_out[(size_t)b * HW + p] = 0.f;
+    constexpr int NR = PPT > 0 ? PPT : 1;
+    float cv[NR][MAXC], rv[NR], lsr[NR];          // register-resident state of the thread's pixels (PPT > 0)
+    if (PPT > 0) {
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            const int p = tid + q * T;
+            rv[q] = rnd[p];
+            lsr[q] = 0.f;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) cv[q][c] = c < C ? col[(size_t)c * HW + p] : 0.f;
+            log_s_out[(size_t)b * HW + p] = 0.f;
+        }
+    } else {
+        for (int p = tid; p < HW; p += T) {
+            ls[p] = 0.f;
+            log_s_out[(size_t)b * HW + p] = 0.f;
+        }
     }
 
     for (int t = 0; t < K - 1; ++t) {
@@ -62,9 +80,17 @@ icsbp_fwd_kernel(const float* __restrict__ colour, const double* __restrict__ lo
         } else {
             float best_v = -INFINITY;
             best_i = 0x7fffffff;
-            for (int p = tid; p < HW; p += T) {
-                const float v = rnd[p] * expf(ls[p]);
-                if (v > best_v) { best_v = v; best_i = p; }  // ascending p: keeps the first max
+            if (PPT > 0) {
+#pragma unroll
+                for (int q = 0; q < NR; ++q) {
+                    const float v = rv[q] * expf(lsr[q]);
+                    if (v > best_v) { best_v = v; best_i = tid + q * T; }  // ascending p: keeps the first max
+                }
+            } else {
+                for (int p = tid; p < HW; p += T) {
+                    const float v = rnd[p] * expf(ls[p]);
+                    if (v > best_v) { best_v = v; best_i = p; }  // ascending p: keeps the first max
+                }
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
@@ -92,12 +118,22 @@ icsbp_fwd_kernel(const float* __restrict__ colour, const double* __restrict__ lo
         }
         if (tid == 0) seed_idx_out[(size_t)t * B + b] = best_i;
         __syncthreads();
-        for (int p = tid; p < HW; p += T) {
+        for (int qq = 0, p = tid; p < HW; p += T, ++qq) {
             {
                 float d = 0.f;
-                for (int c = 0; c < C; ++c) {
-                    const float df = col[(size_t)c * HW + p] - seed_sh[c];
-                    d += df * df;
+                if (PPT > 0) {
+#pragma unroll
+                    for (int c = 0; c < MAXC; ++c) {
+                        if (c < C) {
+                            const float df = cv[qq < NR ? qq : 0][c] - seed_sh[c];
+                            d += df * df;
+                        }
+                    }
+                } else {
+                    for (int c = 0; c < C; ++c) {
+                        const float df = col[(size_t)c * HW + p] - seed_sh[c];
+                        d += df * df;
+                    }
                 }
                 float alpha;
                 if (kernel_type == KERNEL_GAUSSIAN) {
@@ -110,14 +146,16 @@ icsbp_fwd_kernel(const float* __restrict__ colour, const double* __restrict__ lo
                 alpha = st_clamp(alpha, 0.01f, 0.99f);
                 const float log_a = logf(alpha);
                 const float log_na = logf(1.f - alpha);
-                const float lsp = ls[p];
+                const float lsp = PPT > 0 ? lsr[qq < NR ? qq : 0] : ls[p];
                 log_m[t * kstride + (size_t)b * HW + p] = lsp + log_a;
-                ls[p] = lsp + log_na;
+                if (PPT > 0) lsr[qq < NR ? qq : 0] = lsp + log_na;
+                else ls[p] = lsp + log_na;
                 log_s_out[(t + 1) * kstride + (size_t)b * HW + p] = lsp + log_na;
             }
         }
     }
-    for (int p = tid; p < HW; p += T) log_m[(K - 1) * kstride + (size_t)b * HW + p] = ls[p];
+    for (int qq = 0, p = tid; p < HW; p += T, ++qq)
+        log_m[(K - 1) * kstride + (size_t)b * HW + p] = PPT > 0 ? lsr[qq < NR ? qq : 0] : ls[p];
 }
 
 // Reduces NV per-thread doubles over the block at once (wave shuffles + one LDS hop), result broadcast.
@@ -272,9 +310,16 @@ int gx_icsbp_fwd(const float* colour, const double* log_sigma, const float* rand
     GX_CHECK_ARG(kernel_type >= 0 && kernel_type <= 2, "gx_icsbp_fwd: no valid kernel");
     {
         GxProf pf(KID_ICSBP_FWD, (hipStream_t)stream, 0.0, 4.0 * B * HW * (C + 1.0 + 2.0 * K));
-        hipLaunchKernelGGL(icsbp_fwd_kernel, dim3(B), dim3(threads_for(HW)), HW * sizeof(float), (hipStream_t)stream,
-                           colour, log_sigma, rand_pixel, seed_idx_in, B, C, HW, K, kernel_type, log_m, log_s, seeds,
-                           seed_idx_out);
+        const int T = threads_for(HW);
+        const int ppt = (HW % T == 0) ? HW / T : 0;
+#define GX_ICSBP_LAUNCH(P_)                                                                                          \
+        hipLaunchKernelGGL(icsbp_fwd_kernel<P_>, dim3(B), dim3(T), HW * sizeof(float), (hipStream_t)stream, colour,    \
+                           log_sigma, rand_pixel, seed_idx_in, B, C, HW, K, kernel_type, log_m, log_s, seeds, seed_idx_out)
+        if (ppt == 1) GX_ICSBP_LAUNCH(1);
+        else if (ppt == 2) GX_ICSBP_LAUNCH(2);
+        else if (ppt == 4) GX_ICSBP_LAUNCH(4);
+        else GX_ICSBP_LAUNCH(0);
+#undef GX_ICSBP_LAUNCH
     }
     GX_CHECK_LAUNCH("gx_icsbp_fwd");
     return GX_OK;
