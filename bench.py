@@ -104,7 +104,7 @@ def pmc_traffic(kernel):
 
 # profiling ids (gx_profile_kernel_name) -> kernel symbols of the rocprofv3 CSV that are launched under that id
 KID_SYMBOLS = {
-    'wgrad_kernel<0>': ('wgq_kernel<0,', 'wgrad_fast_kernel<0,', 'wgrad_kernel<0>', 'wgrad_smallcin_kernel'),
+    'wgrad_kernel<0>': ('wgq_stream_kernel', 'wgq_kernel<0,', 'wgrad_fast_kernel<0,', 'wgrad_kernel<0>', 'wgrad_smallcin_kernel'),
     'wgrad_kernel<1>': ('wgq_kernel<1,', 'wgrad_fast_kernel<1,', 'wgrad_kernel<1>', 'wgrad_deconv_kernel'),
     'wgrad_kernel<3>': ('wgq_kernel<2,', 'wgrad_fast_kernel<3,', 'wgrad_kernel<3>'),
     'tapconv_kernel<0>': ('tapconv_kernel<0,', 'kq_kernel<0,'),

@@ -57,7 +57,10 @@ struct GxProf {
 };
 
 // ---- deferred parameter-gradient reductions (gx_defer_*; gx_api.cpp owns the queue) ----
-struct GxWgradRed { const float* partial; float* dw; int nsplit, Ttot, CA, CB, CApad, CBpad, layout, ns0, ns1, ns2, ns3; };
+// ca0 / cb0 / CAf / CBf: the record covers the channel block (ca0.., cb0..) of a CAf x CBf weight (CAf == 0: the whole
+// weight, CA x CB) -- the stream-K weight-gradient kernel keeps one slab region per 64 x 64 channel block
+struct GxWgradRed { const float* partial; float* dw; int nsplit, Ttot, CA, CB, CApad, CBpad, layout, ns0, ns1, ns2, ns3,
+                    ca0, cb0, CAf, CBf; };
 struct GxGnRed { const float* part; float* dgamma; float* dbeta; float* dbias; int N, C; };
 bool gx_defer_push_wgrad(const GxWgradRed& r);   // false: queue full (caller reduces immediately)
 bool gx_defer_push_gn(const GxGnRed& r);

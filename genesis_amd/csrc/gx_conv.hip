@@ -1002,7 +1002,8 @@ wgrad_deconv_kernel(const float* __restrict__ a_src, const float* __restrict__ b
 // Block = 64 consecutive (t, ca, cb) elements x 4 interleaved split groups (fixed summation order).
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int nsplit_all,
-                    int Ttot, int CA, int CB, int CApad, int CBpad, int layout, int ns0, int ns1, int ns2, int ns3) {
+                    int Ttot, int CA, int CB, int CApad, int CBpad, int layout, int ns0, int ns1, int ns2, int ns3,
+                    int ca0 = 0, int cb0 = 0, int CAf = 0, int CBf = 0) {
     __shared__ float red[4][64];
     const int total = Ttot * CA * CB;
     const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -1031,27 +1032,33 @@ wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, i
     __syncthreads();
     if (grp == 0 && idx < total) {
         const float r = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
-        if (layout == 0) dw[((size_t)ca * CB + cb) * Ttot + t] = r;
-        else dw[((size_t)cb * CA + ca) * Ttot + t] = r;
+        if (!CAf) { CAf = CA; CBf = CB; }
+        if (layout == 0) dw[((size_t)(ca0 + ca) * CBf + cb0 + cb) * Ttot + t] = r;
+        else dw[((size_t)(cb0 + cb) * CAf + ca0 + ca) * Ttot + t] = r;
     }
 }
 
-// all queued weight-gradient reductions in one launch: blockIdx.y = queue entry (table passed by value)
-struct WgradRedTable { GxWgradRed e[48]; };
+// all queued weight-gradient reductions in one launch: blockIdx.y = queue entry (table passed by value).
+// A thread owns 4 consecutive cb of one (t, ca) row (the slabs are [split][t][CApad][CBpad], CBpad a multiple of 64:
+// 16-byte loads, 1 KB per wave and load) and every 4th split; per element the summation order is the scalar kernel's
+// (two alternating partial sums per split group, then the four groups), so both produce the same bits.
+constexpr int kRedPerLaunch = 40;      // 40 x 88 B: the table travels as a kernel argument
+struct WgradRedTable { GxWgradRed e[kRedPerLaunch]; };
 __global__ void __launch_bounds__(256)
 wgrad_reduce_batch_kernel(const WgradRedTable tab) {
     const GxWgradRed& r = tab.e[blockIdx.y];
-    __shared__ float red[4][64];
-    const int total = r.Ttot * r.CA * r.CB;
-    if ((int)blockIdx.x * 64 >= total) return;
+    __shared__ f32x4 red[4][64];
+    const int cb4n = r.CBpad >> 2;
+    const int total4 = r.Ttot * r.CA * cb4n;
+    if ((int)blockIdx.x * 64 >= total4) return;
     const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + e;
-    float s = 0.f;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
     int cb = 0, ca = 0, t = 0;
-    if (idx < total) {
-        cb = idx % r.CB;
-        ca = (idx / r.CB) % r.CA;
-        t = idx / (r.CB * r.CA);
+    if (idx < total4) {
+        cb = (idx % cb4n) << 2;
+        ca = (idx / cb4n) % r.CA;
+        t = idx / (cb4n * r.CA);
         int nsplit = r.nsplit;
         if (r.ns0 > 0) {
             const int cls = ((t / 5) & 1) * 2 + ((t % 5) & 1);
@@ -1059,20 +1066,29 @@ wgrad_reduce_batch_kernel(const WgradRedTable tab) {
         }
         const size_t stride = (size_t)r.Ttot * r.CApad * r.CBpad;
         const float* p = r.partial + ((size_t)t * r.CApad + ca) * r.CBpad + cb;
-        float s0 = 0.f, s1 = 0.f;
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
         int sp = grp;
-        for (; sp + 4 < nsplit; sp += 8) { s0 += p[sp * stride]; s1 += p[(sp + 4) * stride]; }
-        if (sp < nsplit) s0 += p[sp * stride];
+#pragma unroll 4
+        for (; sp + 4 < nsplit; sp += 8) {
+            s0 += *reinterpret_cast<const f32x4*>(p + sp * stride);
+            s1 += *reinterpret_cast<const f32x4*>(p + (sp + 4) * stride);
+        }
+        if (sp < nsplit) s0 += *reinterpret_cast<const f32x4*>(p + sp * stride);
         s = s0 + s1;
     }
     red[grp][e] = s;
     __syncthreads();
-    if (grp == 0 && idx < total) {
-        const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    if (grp == 0 && idx < total4) {
+        const f32x4 v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
         // ACCUMULATES: the destination is a zeroed gradient buffer; a parameter used more than once per iteration
         // (MONet's recurrent UNet) has received its other contributions by the time the queue is flushed
-        if (r.layout == 0) r.dw[((size_t)ca * r.CB + cb) * r.Ttot + t] += v;
-        else r.dw[((size_t)cb * r.CA + ca) * r.Ttot + t] += v;
+        const int CAf = r.CAf ? r.CAf : r.CA, CBf = r.CAf ? r.CBf : r.CB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (cb + j < r.CB) {
+                if (r.layout == 0) r.dw[((size_t)(r.ca0 + ca) * CBf + r.cb0 + cb + j) * r.Ttot + t] += v[j];
+                else r.dw[((size_t)(r.cb0 + cb + j) * CAf + r.ca0 + ca) * r.Ttot + t] += v[j];
+            }
     }
 }
 
@@ -1607,7 +1623,7 @@ int launch_wgrad_reduce(const float* partial, float* dw, const WgradPlan& pl, in
         const bool merged = cb[4] > 0;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, partial, dw, pl.g.nsplit, pl.g.Ttot,
                            pl.g.CA, pl.g.CB, pl.g.CApad, pl.g.CBpad, layout, merged ? cb[1] - cb[0] : 0,
-                           merged ? cb[2] - cb[1] : 0, merged ? cb[3] - cb[2] : 0, merged ? cb[4] - cb[3] : 0);
+                           merged ? cb[2] - cb[1] : 0, merged ? cb[3] - cb[2] : 0, merged ? cb[4] - cb[3] : 0, 0, 0, 0, 0);
     }
     GX_CHECK_LAUNCH("wgrad_reduce");
     return GX_OK;
@@ -1624,20 +1640,25 @@ int check_dims(const char* name, int N, int Cin, int Cout, int H, int W) {
 
 // =================================================================== C ABI
 int gx_defer_flush_wgrad(const GxWgradRed* items, int n, hipStream_t s) {
-    WgradRedTable tab;
-    int maxblocks = 1;
-    double bytes = 0.0;
-    for (int i = 0; i < n; ++i) {
-        tab.e[i] = items[i];
-        const int total = items[i].Ttot * items[i].CA * items[i].CB;
-        maxblocks = gx_ceil_div(total, 64) > maxblocks ? gx_ceil_div(total, 64) : maxblocks;
-        bytes += 4.0 * (items[i].nsplit + 1.0) * total;
+    for (int i0 = 0; i0 < n; i0 += kRedPerLaunch) {
+        const int m = n - i0 < kRedPerLaunch ? n - i0 : kRedPerLaunch;
+        WgradRedTable tab;
+        int maxblocks = 1;
+        double bytes = 0.0;
+        for (int i = 0; i < m; ++i) {
+            const GxWgradRed& it = items[i0 + i];
+            tab.e[i] = it;
+            const int total = it.Ttot * it.CA * it.CB;
+            const int total4 = it.Ttot * it.CA * (it.CBpad >> 2);
+            maxblocks = gx_ceil_div(total4, 64) > maxblocks ? gx_ceil_div(total4, 64) : maxblocks;
+            bytes += 4.0 * (it.nsplit + 1.0) * total;
+        }
+        {
+            GxProf pf(KID_WGRAD_REDUCE, s, 0.0, bytes);
+            hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(maxblocks, m), dim3(256), 0, s, tab);
+        }
+        GX_CHECK_LAUNCH("gx_defer_flush(wgrad)");
     }
-    {
-        GxProf pf(KID_WGRAD_REDUCE, s, 0.0, bytes);
-        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(maxblocks, n), dim3(256), 0, s, tab);
-    }
-    GX_CHECK_LAUNCH("gx_defer_flush(wgrad)");
     return GX_OK;
 }
 
@@ -1646,7 +1667,8 @@ int gx_wgrad_reduce_now(const GxWgradRed& r, hipStream_t s) {
     {
         GxProf pf(KID_WGRAD_REDUCE, s, 0.0, 4.0 * ((double)r.nsplit + 1.0) * total);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx_ceil_div(total, 64)), dim3(256), 0, s, r.partial, r.dw, r.nsplit,
-                           r.Ttot, r.CA, r.CB, r.CApad, r.CBpad, r.layout, r.ns0, r.ns1, r.ns2, r.ns3);
+                           r.Ttot, r.CA, r.CB, r.CApad, r.CBpad, r.layout, r.ns0, r.ns1, r.ns2, r.ns3, r.ca0, r.cb0, r.CAf,
+                           r.CBf);
     }
     GX_CHECK_LAUNCH("wgrad_reduce");
     return GX_OK;
@@ -1709,7 +1731,7 @@ int gx_weight_cache_refresh(int id, gx_stream_t stream) {
         double bytes = 0.0;
         for (const PackEntry& e : c.entries) bytes += 8.0 * e.NT * e.Kpad * e.Mpad;
         GxProf pf(KID_PACK_WEIGHTS, s, 0.0, bytes);
-        hipLaunchKernelGGL(pack_weights_batch_kernel, dim3(32, (unsigned)c.entries.size()), dim3(256), 0, s,
+        hipLaunchKernelGGL(pack_weights_batch_kernel, dim3(128, (unsigned)c.entries.size()), dim3(256), 0, s,
                            (const PackEntry*)c.dev);
     }
     GX_CHECK_LAUNCH("gx_weight_cache_refresh");

@@ -667,6 +667,173 @@ gn_relu_bwd_reg_kernel(const float* __restrict__ y, const float* __restrict__ ga
     (void)U;
 }
 
+// The STAGE case at one unit per wave, built for TWO workgroups per CU: only the activations stay in registers (F
+// float4), the projected gradient sum_q pw[q] * g_out[q][p] is formed from the LDS-staged rows in pass 1 AND again in
+// pass 2 (4 LDS reads + 4 FMAs per float4, cheaper than the 32 registers that would hold it), and the per-thread sums
+// run in fp32 over the thread's F float4 (per vector lane: F terms) before they are combined in double.  At <= 64
+// VGPRs the second workgroup's loads fly while the first one computes and stores; the generic kernel (128 VGPRs, one
+// workgroup per CU) runs its load, compute and store phases back to back: 176 -> see DESIGN.md section 7 (decoder, 224 images).
+template <int F, int CT, bool WP>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
+gn_relu_bwd_stage_kernel(const float* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ beta,
+                         const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                         int C, int H, int W, int groups, int P, View g0, View g1_unused,
+                         float* __restrict__ dy, float* __restrict__ part_out, float* __restrict__ wpart,
+                         float* __restrict__ bpart) {
+    __shared__ double uab[16 * 2];  // per unit: sum dpre*xhat, sum dpre
+    __shared__ double usd[16];      // per unit: sum dy
+    __shared__ float uw[16][8];     // wpart: per unit, sum_p g_out[q][p] * relu(gn(y))[c][p]
+    extern __shared__ __attribute__((aligned(16))) float gsl[];   // g0.ptr[n] ([ctot][HW])
+    (void)g1_unused;
+    const int n = blockIdx.x / groups, gidx = blockIdx.x % groups;
+    const int cpg = C / groups, HW = H * W;
+    const int m = cpg * HW;
+    const int lane = threadIdx.x & 63, unit = threadIdx.x >> 6;
+    const int q4 = (HW >> 2) / P;
+    const int cl = unit / P, part = unit - cl * P;
+    const int c = gidx * cpg + cl;
+    const size_t slab_off = ((size_t)n * C + (size_t)gidx * cpg) * HW;
+    const f32x4* src4 = reinterpret_cast<const f32x4*>(y + slab_off) + cl * (HW >> 2) + part * q4 + lane;
+    f32x4* dst4 = reinterpret_cast<f32x4*>(dy + slab_off) + cl * (HW >> 2) + part * q4 + lane;
+    const f32x4* gs4 = reinterpret_cast<const f32x4*>(gsl) + part * q4 + lane;
+    const float meanf = mean_in[blockIdx.x], rstdf = rstd_in[blockIdx.x];
+    f32x4 xr[F];
+#pragma unroll
+    for (int j = 0; j < F; ++j) xr[j] = src4[j * 64];
+    {
+        const f32x4* g4 = reinterpret_cast<const f32x4*>(g0.ptr + (size_t)n * g0.ctot * HW);
+        for (int i = threadIdx.x; i < (g0.ctot * HW) >> 2; i += blockDim.x)
+            reinterpret_cast<f32x4*>(gsl)[i] = g4[i];
+    }
+    __syncthreads();
+    float pw[CT];
+    {
+        const float gt = g0.pgate ? *g0.pgate : 1.f;
+#pragma unroll
+        for (int q = 0; q < CT; ++q)    // wave-uniform (c depends on the wave only): scalar registers
+            pw[q] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, gt * g0.proj[q * g0.projC + c])));
+    }
+    const float gm = gamma[c], bt = beta[c];
+    constexpr int ctot = CT;      // the launcher picks CT == g0.ctot: no runtime channel tests in the loops
+    const int rowq = HW >> 2;
+    // pass 1: xr <- xhat; sums of dpre * xhat and dpre; the 1x1 conv's weight gradient for this channel
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int j = 0; j < F; ++j) {
+        // one float4 at a time: the LDS offset is made to depend on the previous iteration's sums, or the compiler hoists
+        // the LDS reads of all F iterations (4 F float4 registers) and the occupancy is gone
+        int jo = j * 64;
+        asm volatile("" : "+v"(jo) : "v"(sa), "v"(sb));
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xr[j][e] = (xr[j][e] - meanf) * rstdf;
+#pragma unroll
+        for (int q = 0; q < CT; ++q) g += pw[q] * gs4[q * rowq + jo];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float pre = xr[j][e] * gm + bt;
+            g[e] = pre > 0.f ? g[e] : 0.f;
+        }
+        sa += (g[0] * xr[j][0] + g[1] * xr[j][1]) + (g[2] * xr[j][2] + g[3] * xr[j][3]);
+        sb += (g[0] + g[1]) + (g[2] + g[3]);
+    }
+    if (bpart && gidx == 0) {   // bias gradient partial of the 1x1 conv: sum_p g_out[q][p], one wave per row q
+        for (int q = unit; q < ctot; q += (int)(blockDim.x >> 6)) {
+            float v = 0.f;
+            for (int i = lane; i < rowq; i += 64) {
+                const f32x4 t = reinterpret_cast<const f32x4*>(gsl)[q * rowq + i];
+                v += (t[0] + t[1]) + (t[2] + t[3]);
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) bpart[(size_t)n * ctot + q] = v;
+        }
+    }
+    {
+        const double a = gx_wave_sum_d((double)sa);
+        const double b = gx_wave_sum_d((double)sb);
+        if (lane == 0) { uab[2 * unit] = a; uab[2 * unit + 1] = b; }
+    }
+    __syncthreads();
+    double s1 = 0.0, s2 = 0.0;
+    for (int tc = 0; tc < cpg; ++tc) {
+        double a = 0.0, b = 0.0;
+        for (int p = 0; p < P; ++p) { a += uab[2 * (tc * P + p)]; b += uab[2 * (tc * P + p) + 1]; }
+        const float gmc = gamma[gidx * cpg + tc];
+        s1 += b * gmc;
+        s2 += a * gmc;
+        if ((int)threadIdx.x == tc) {
+            float* pp = part_out + ((size_t)n * C + gidx * cpg + tc) * 3;
+            pp[0] = (float)a; pp[1] = (float)b;
+        }
+    }
+    const float k1 = (float)(s1 / m), k2 = (float)(s2 / m);
+    // pass 2: the projected gradient once more from LDS; the following 1x1 conv's weight gradient for this channel
+    // (its input relu(gn(y)) exists only here) rides on the same LDS reads
+    float sd = 0.f;
+    // opaque copies: otherwise pass 1's pre-activations and masks (4 F + registers) are kept alive for pass 2
+    float gm2 = gm, bt2 = bt;
+    asm volatile("" : "+v"(gm2), "+v"(bt2));
+    float wacc[CT];
+#pragma unroll
+    for (int q = 0; q < CT; ++q) wacc[q] = 0.f;
+#pragma unroll
+    for (int j = 0; j < F; ++j) {
+        int jo = j * 64;
+        static_assert(CT == 4, "the dependency list below names four accumulators");
+        if (WP) asm volatile("" : "+v"(jo) : "v"(sd), "v"(k1), "v"(wacc[0]), "v"(wacc[1]), "v"(wacc[2]), "v"(wacc[3]));
+        else asm volatile("" : "+v"(jo) : "v"(sd), "v"(k1));
+        f32x4 g = {0.f, 0.f, 0.f, 0.f}, o, a;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float t = xr[j][e] * gm2 + bt2;
+            a[e] = t > 0.f ? t : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < CT; ++q) {
+            const f32x4 gq = gs4[q * rowq + jo];
+            g += pw[q] * gq;
+            if (WP) wacc[q] += (gq[0] * a[0] + gq[1] * a[1]) + (gq[2] * a[2] + gq[3] * a[3]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float pre = xr[j][e] * gm2 + bt2;
+            const float gv = pre > 0.f ? g[e] : 0.f;
+            const float d = rstdf * (gv * gm2 - k1 - xr[j][e] * k2);
+            o[e] = d;
+        }
+        sd += (o[0] + o[1]) + (o[2] + o[3]);
+        dst4[j * 64] = o;
+    }
+    {
+        const double v = gx_wave_sum_d((double)sd);
+        if (lane == 0) usd[unit] = v;
+    }
+    if (WP) {
+#pragma unroll
+        for (int q = 0; q < CT; ++q) {
+            float v = wacc[q];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) uw[unit][q] = v;
+        }
+    }
+    __syncthreads();
+    if (WP) {
+        for (int t = threadIdx.x; t < cpg * ctot; t += blockDim.x) {
+            const int tc = t / ctot, q = t - tc * ctot;
+            float v = 0.f;
+            for (int p = 0; p < P; ++p) v += uw[tc * P + p][q];
+            wpart[((size_t)n * ctot + q) * C + gidx * cpg + tc] = v;
+        }
+    }
+    if ((int)threadIdx.x < cpg) {
+        double s = 0.0;
+        for (int p = 0; p < P; ++p) s += usd[threadIdx.x * P + p];
+        part_out[((size_t)n * C + gidx * cpg + threadIdx.x) * 3 + 2] = (float)s;
+    }
+}
+
 // ---- tiny slabs (H*W < 256, e.g. the UNet's 4x4 / 8x8 levels): one float4 per thread, the whole (image, group)
 // slab lives in the registers of one small workgroup; per-channel sums go through LDS in a fixed order.  The generic
 // two-pass kernel needs ~28 us for these (a single wave walking the channels serially); this one ~5 us.
@@ -797,6 +964,30 @@ template <int F, int UPW, typename... Args>
 void launch_fwd_reg(dim3 grid, dim3 block, hipStream_t s, Args... args) {
     hipLaunchKernelGGL((gn_relu_fwd_reg_kernel<F, UPW>), grid, block, 0, s, args...);
 }
+// the two-workgroups-per-CU STAGE kernel serves one unit per wave, 1024 threads and a 4-channel 1x1 conv (RGB + mask logit)
+template <int F, int UPW>
+bool launch_bwd_stage(dim3 grid, dim3 block, hipStream_t s, size_t lds, const float* y, const float* gamma,
+                      const float* beta, const float* mean, const float* rstd, int C, int H, int W, int groups, int P,
+                      View g0, View g1, float* dy, float* part, float* wpart, float* bpart) {
+    static const char* env = getenv("GENESIS_GN_STAGE2");
+    if (UPW != 1 || block.x != 1024 || g0.ctot != 4 || (env && env[0] == '0')) return false;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_relu_bwd_stage_kernel<F, 4, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_relu_bwd_stage_kernel<F, 4, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    if (wpart)
+        hipLaunchKernelGGL((gn_relu_bwd_stage_kernel<F, 4, true>), grid, block, lds, s, y, gamma, beta, mean, rstd, C, H,
+                           W, groups, P, g0, g1, dy, part, wpart, bpart);
+    else
+        hipLaunchKernelGGL((gn_relu_bwd_stage_kernel<F, 4, false>), grid, block, lds, s, y, gamma, beta, mean, rstd, C, H,
+                           W, groups, P, g0, g1, dy, part, wpart, bpart);
+    return true;
+}
+
 template <int F, int UPW, typename... Args>
 void launch_bwd_reg(dim3 grid, dim3 block, hipStream_t s, size_t lds, Args... args) {
     if (!lds) {
@@ -809,6 +1000,7 @@ void launch_bwd_reg(dim3 grid, dim3 block, hipStream_t s, size_t lds, Args... ar
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }
+    if (launch_bwd_stage<F, UPW>(grid, block, s, lds, args...)) return;
     hipLaunchKernelGGL((gn_relu_bwd_reg_kernel<F, UPW, true>), grid, block, lds, s, args...);
 }
 

@@ -171,9 +171,14 @@ __device__ __forceinline__ void wq_tile(const float* __restrict__ rd, float* __r
 #undef GX_WQ_MMA
 }
 
+// One SEGMENT: the tiles t0, t0 + tstep, ... (< tend) of one 64 x 64 channel block (ca0, cb0) of one layer, accumulated
+// in registers and written as one slab (`slab` points at [tap 0][row 0][col 0] of this workgroup's block; rows are ldc
+// floats apart, taps tstride).  The grouped kernel hands a workgroup one strided segment, the stream-K kernel one or
+// more contiguous ones.
 template <int CLS, int LTW>
-__global__ void __launch_bounds__(256, 1)
-wgq_kernel(const WqTable tab, const float* __restrict__ zeros) {
+__device__ __forceinline__ void wq_segment(const float* a, const float* b, const float* zeros, float* lds, int CA, int CB,
+                                           int ca0, int cb0, int Hb, int Wb, int tiles_h, int tiles_w, int t0, int tstep,
+                                           int tend, float* slab, int ldc, int tstride) {
     using WT = WqTap<CLS>;
     constexpr int NT = WT::NT, SA = WT::SA;
     constexpr int TW = 1 << LTW, TH = 64 >> LTW;
@@ -186,24 +191,14 @@ wgq_kernel(const WqTable tab, const float* __restrict__ zeros) {
     constexpr int NI = (A_PIECES + B_PIECES) / 256;           // DMA instructions per thread per tile
     static_assert((A_PIECES + B_PIECES) % 256 == 0 && A_PIECES % 256 == 0, "whole wave instructions per region");
     static_assert(NPB_ <= kSB, "B halo tile must fit its LDS slot");
-    extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-    // ---- which job, channel block and split (wave-uniform scalar work)
-    int j = 0;
-#pragma unroll 1
-    for (int q = 1; q < tab.njobs; ++q) j = (int)blockIdx.x >= tab.job[q].wg_begin ? q : j;
-    const WqJob& jb = tab.job[j];
-    const int local = (int)blockIdx.x - jb.wg_begin;
-    const int nsp = jb.nsplit;
-    const int blk = local / nsp, sp = local - blk * nsp;
     WqW w;
-    w.a = jb.a; w.b = jb.b; w.zeros = zeros;
-    w.CA = jb.CA; w.CB = jb.CB;
-    w.ca0 = (blk / jb.nbt) * 64; w.cb0 = (blk % jb.nbt) * 64;
-    w.Hb = jb.Hb; w.Wb = jb.Wb; w.Wa = SA * jb.Wb;
-    w.HaWa = SA * jb.Hb * w.Wa; w.HbWb = jb.Hb * jb.Wb;
+    w.a = a; w.b = b; w.zeros = zeros;
+    w.CA = CA; w.CB = CB;
+    w.ca0 = ca0; w.cb0 = cb0;
+    w.Hb = Hb; w.Wb = Wb; w.Wa = SA * Wb;
+    w.HaWa = SA * Hb * w.Wa; w.HbWb = Hb * Wb;
     w.wave_u = __builtin_amdgcn_readfirstlane(wave);
 
     // ---- DMA pieces of this thread: piece L = i * 256 + tid of the stage image, fixed over tiles.
@@ -219,14 +214,14 @@ wgq_kernel(const WqTable tab, const float* __restrict__ zeros) {
             const int q = s ^ (ch & 15);
             const int row = q / RPA, cp = q - row * RPA;
             goff[i] = ch * w.HaWa + SA * row * w.Wa + 4 * cp;
-            info[i] = (w.ca0 + ch < jb.CA) ? 0 : 1;
+            info[i] = (w.ca0 + ch < CA) ? 0 : 1;
         } else {
             const int Lb = L - A_PIECES;
             const int ch = Lb / kSB, s = Lb - ch * kSB;
             const int q = s ^ ((ch >> 1) & 7);
             const int ri = q / RPB, cq = q - ri * RPB;
             goff[i] = ch * w.HbWb + ri * w.Wb + 4 * cq;
-            info[i] = ((q < NPB_ && w.cb0 + ch < jb.CB) ? 0 : 1) | (ri << 8) | (cq << 16);
+            info[i] = ((q < NPB_ && w.cb0 + ch < CB) ? 0 : 1) | (ri << 8) | (cq << 16);
         }
     }
 
@@ -245,34 +240,119 @@ wgq_kernel(const WqTable tab, const float* __restrict__ zeros) {
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
     // tile -> (image, tile row, tile col), advanced by carries (scalar)
-    const int tpi = jb.tiles_h * jb.tiles_w;
-    int t_img = sp / tpi, t_rem = sp - t_img * tpi;
-    int t_th = t_rem / jb.tiles_w, t_tw = t_rem - t_th * jb.tiles_w;
-    const int d_img = nsp / tpi, d_rem = nsp - d_img * tpi;
-    const int d_th = d_rem / jb.tiles_w, d_tw = d_rem - d_th * jb.tiles_w;
+    const int tpi = tiles_h * tiles_w;
+    int t_img = t0 / tpi, t_rem = t0 - t_img * tpi;
+    int t_th = t_rem / tiles_w, t_tw = t_rem - t_th * tiles_w;
+    const int d_img = tstep / tpi, d_rem = tstep - d_img * tpi;
+    const int d_th = d_rem / tiles_w, d_tw = d_rem - d_th * tiles_w;
 
-    int tile = sp;
-    if (tile < jb.ntiles) wq_issue<CLS, LTW, NI>(lds, w, goff, info, t_img, t_th, t_tw, true);
+    int tile = t0;
+    if (tile < tend) wq_issue<CLS, LTW, NI>(lds, w, goff, info, t_img, t_th, t_tw, true);
     int it = 0;
-    for (; tile < jb.ntiles; tile += nsp, ++it) {
+    for (; tile < tend; tile += tstep, ++it) {
         __syncthreads();          // this tile has landed (vmcnt drained in front of the barrier); the other stage is free
         t_tw += d_tw; t_th += d_th; t_img += d_img;          // next tile of this workgroup
-        if (t_tw >= jb.tiles_w) { t_tw -= jb.tiles_w; ++t_th; }
-        if (t_th >= jb.tiles_h) { t_th -= jb.tiles_h; ++t_img; }
+        if (t_tw >= tiles_w) { t_tw -= tiles_w; ++t_th; }
+        if (t_th >= tiles_h) { t_th -= tiles_h; ++t_img; }
         wq_tile<CLS, LTW, NI>(lds + (it & 1) * STAGE, lds + ((it + 1) & 1) * STAGE, acc, w, goff, info, t_img, t_th, t_tw,
-                              tile + nsp < jb.ntiles);
+                              tile + tstep < tend);
     }
 
-    // ---- slab: partial[split][gt][ca][cb]  (C/D layout: col = lane & 31 -> cb, row -> ca)
+    // ---- slab [tap][ca][cb]  (C/D layout: col = lane & 31 -> cb, row -> ca)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        float* dst = jb.partial + (((size_t)sp * jb.Ttot + WT::gt(t)) * jb.CApad + w.ca0 + wm * 32) * jb.CBpad + w.cb0 +
-                     wn * 32 + (lane & 31);
+        // (global address space spelled out: out of line, `slab` arrives as a flat pointer)
+        auto* dst = (__attribute__((address_space(1))) float*)(slab + (size_t)WT::gt(t) * tstride +
+                                                               (size_t)(wm * 32) * ldc + wn * 32 + (lane & 31));
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-            dst[(size_t)row * jb.CBpad] = acc[t][reg];
+            dst[(size_t)row * ldc] = acc[t][reg];
         }
+    }
+}
+
+// ---- grouped launch: the jobs of one (class, tile width), every workgroup one strided segment
+template <int CLS, int LTW>
+__global__ void __launch_bounds__(256, 1)
+wgq_kernel(const WqTable tab, const float* __restrict__ zeros) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // which job, channel block and split (wave-uniform scalar work)
+    int j = 0;
+#pragma unroll 1
+    for (int q = 1; q < tab.njobs; ++q) j = (int)blockIdx.x >= tab.job[q].wg_begin ? q : j;
+    const WqJob& jb = tab.job[j];
+    const int local = (int)blockIdx.x - jb.wg_begin;
+    const int nsp = jb.nsplit;
+    const int blk = local / nsp, sp = local - blk * nsp;
+    const int ca0 = (blk / jb.nbt) * 64, cb0 = (blk % jb.nbt) * 64;
+    wq_segment<CLS, LTW>(jb.a, jb.b, zeros, lds, jb.CA, jb.CB, ca0, cb0, jb.Hb, jb.Wb, jb.tiles_h, jb.tiles_w, sp, nsp,
+                         jb.ntiles, jb.partial + ((size_t)sp * jb.Ttot * jb.CApad + ca0) * jb.CBpad + cb0, jb.CBpad,
+                         jb.CApad * jb.CBpad);
+}
+
+// ---- stream-K launch: ONE grid of G workgroups for every queued layer of every class and tile width.  The layers'
+// (channel block, tile) work items, weighted by a per-variant cost, form one line of U units; workgroup w takes the
+// units [U w / G, U (w + 1) / G), rounded down to tiles: a contiguous run of tiles that crosses into the next block /
+// layer at most a few times, one slab per (workgroup, block) it touches.  ~G + #blocks slabs per training step instead
+// of (launches x 256): the slab traffic and the reduction shrink 8-fold, and eight launch prologues / epilogues go.
+struct WsJob {
+    const float* a; const float* b; float* partial;      // partial: this block's region [slab][Ttot][64][64]
+    long long ubegin;                                    // first unit of this block on the line
+    int CA, CB, ca0, cb0, Hb, Wb, tiles_h, tiles_w, ntiles, Ttot;
+    int variant;                                         // class * 3 + (5 - log2 tile width)
+    int cost;                                            // units per tile
+    int w_first;                                         // first workgroup with tiles of this block (slab 0)
+    int pad_;
+};
+constexpr int kMaxSJobs = 36;                            // 36 x 96 B: the table travels as a kernel argument
+struct WsTable { long long U; int njobs, G; WsJob job[kMaxSJobs]; };
+
+// out-of-line copy of a variant for the stream-K kernel: nine inlined bodies in one function cost hipcc's register
+// allocator ~1.5 KB of scratch per lane; as separate functions each keeps the allocation of its own grouped kernel.
+// The LDS stage pointer is re-derived from the dynamic LDS symbol inside (a pointer parameter would arrive as a flat
+// pointer and turn every ds_read into a flat load).
+template <int CLS, int LTW>
+__device__ __attribute__((noinline)) void wq_segment_call(const float* a, const float* b, const float* zeros, int CA, int CB,
+                                                          int ca0, int cb0, int Hb, int Wb, int tiles_h, int tiles_w, int t0,
+                                                          int t1, float* slab) {
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+    wq_segment<CLS, LTW>(a, b, zeros, lds_dyn, CA, CB, ca0, cb0, Hb, Wb, tiles_h, tiles_w, t0, 1, t1, slab, 64, 4096);
+}
+
+__host__ __device__ inline void ws_locate(const WsTable& tab, long long B, int* j_out, int* t_out) {
+    if (B >= tab.U) { *j_out = tab.njobs; *t_out = 0; return; }
+    int j = 0;
+    for (int q = 1; q < tab.njobs; ++q) j = B >= tab.job[q].ubegin ? q : j;
+    *j_out = j;
+    *t_out = (int)((unsigned)(B - tab.job[j].ubegin) / (unsigned)tab.job[j].cost);
+}
+
+__global__ void __launch_bounds__(256, 1)
+wgq_stream_kernel(const WsTable tab, const float* __restrict__ zeros) {
+    const int wg = blockIdx.x;
+    int js, ts, je, te;
+    ws_locate(tab, tab.U * wg / tab.G, &js, &ts);
+    ws_locate(tab, wg + 1 == tab.G ? tab.U : tab.U * (wg + 1) / tab.G, &je, &te);
+#pragma unroll 1
+    for (int j = js; j <= je && j < tab.njobs; ++j) {
+        const WsJob& jb = tab.job[j];
+        const int t0 = j == js ? ts : 0, t1 = j == je ? te : jb.ntiles;
+        if (t0 >= t1) continue;
+        float* slab = jb.partial + (size_t)(wg - jb.w_first) * jb.Ttot * 4096;
+#define GX_WS_CASE(V_, CLS_, LTW_)                                                                                  \
+        case V_:                                                                                                    \
+            wq_segment_call<CLS_, LTW_>(jb.a, jb.b, zeros, jb.CA, jb.CB, jb.ca0, jb.cb0, jb.Hb, jb.Wb, jb.tiles_h, \
+                                        jb.tiles_w, t0, t1, slab);                                                  \
+            break;
+        switch (jb.variant) {
+            GX_WS_CASE(0, WQ_C3, 5) GX_WS_CASE(1, WQ_C3, 4) GX_WS_CASE(2, WQ_C3, 3)
+            GX_WS_CASE(3, WQ_DR0, 5) GX_WS_CASE(4, WQ_DR0, 4) GX_WS_CASE(5, WQ_DR0, 3)
+            GX_WS_CASE(6, WQ_DR1, 5) GX_WS_CASE(7, WQ_DR1, 4) GX_WS_CASE(8, WQ_DR1, 3)
+            default: break;
+        }
+#undef GX_WS_CASE
+        __syncthreads();          // the next segment's first DMA re-uses stage 0
     }
 }
 
@@ -389,6 +469,159 @@ int wgq_launch_group(std::vector<PendingJob*>& grp, int budget, hipStream_t s) {
     return GX_OK;
 }
 
+
+// ---- stream-K host side ------------------------------------------------------------------------------------------
+int g_wgq_stream = -1;
+bool wgq_stream_on() {
+    if (g_wgq_stream < 0) {
+        const char* env = getenv("GENESIS_WGQ_STREAM");
+        g_wgq_stream = (env && env[0] == '0') ? 0 : 1;
+    }
+    return g_wgq_stream != 0;
+}
+
+// units per tile of a variant (class * 3 + (5 - ltw)): ns per tile and workgroup of single-layer launches (tools/kq_time.py
+// wgrad3:256:64 wgrad3:2048:16 wgrad3:8192:8 wgrad:256:32 wgrad:1024:16 wgrad:4096:8: 10.3 us per conv3x3 tile, 26.5 us per
+// pair of transposed-conv row-parity tiles, split 15 a + b : 10 a + b), then nudged on the training step itself
+// (the stream kernel's duration over five vectors: 921 .. 972 us); GENESIS_WGQ_COST="c0,...,c8" overrides
+int g_ws_cost[9] = {10200, 10600, 11200, 16000, 16500, 18200, 11600, 12000, 13300};
+bool g_ws_cost_init = false;
+void ws_cost_init() {
+    if (g_ws_cost_init) return;
+    g_ws_cost_init = true;
+    const char* env = getenv("GENESIS_WGQ_COST");
+    if (!env) return;
+    int v[9];
+    if (sscanf(env, "%d,%d,%d,%d,%d,%d,%d,%d,%d", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6, v + 7, v + 8) == 9)
+        for (int i = 0; i < 9; ++i) if (v[i] > 0) g_ws_cost[i] = v[i];
+}
+
+struct WsSlot { PendingJob* p; int blk; int nseg; };
+
+// fills tab.job[*].ubegin / w_first and slots[*].nseg for G workgroups; false if a block would need more slabs than its
+// region holds or a workgroup boundary leaves a hole in a block's slab numbering
+bool ws_plan(WsTable& tab, std::vector<WsSlot>& slots, int G) {
+    tab.G = G;
+    const int nj = tab.njobs;
+    std::vector<int> first(nj, -1), last(nj, -1), count(nj, 0);
+    for (int w = 0; w < G; ++w) {
+        int js, ts, je, te;
+        ws_locate(tab, tab.U * w / G, &js, &ts);
+        ws_locate(tab, w + 1 == G ? tab.U : tab.U * (w + 1) / G, &je, &te);
+        for (int j = js; j <= je && j < nj; ++j) {
+            const int t0 = j == js ? ts : 0, t1 = j == je ? te : tab.job[j].ntiles;
+            if (t0 >= t1) continue;
+            if (first[j] < 0) first[j] = w;
+            last[j] = w;
+            ++count[j];
+        }
+    }
+    for (int j = 0; j < nj; ++j) {
+        if (first[j] < 0 || count[j] != last[j] - first[j] + 1) return false;
+        if (count[j] > slots[j].p->job.nsplit) return false;          // nsplit = slabs the region holds
+        tab.job[j].w_first = first[j];
+        slots[j].nseg = count[j];
+    }
+    return true;
+}
+
+// launches `jobs` (any classes / tile widths) as stream-K grids and appends their reduce records
+int wgq_launch_stream(std::vector<PendingJob*>& jobs, hipStream_t s, std::vector<GxWgradRed>& recs) {
+    const float* zeros = zero16(s);
+    if (!zeros) { gx_set_error("wgq: zero page unavailable (first call inside a stream capture)"); return GX_ELAUNCH; }
+    ws_cost_init();
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgq_stream_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    size_t i = 0;
+    while (i < jobs.size()) {
+        // a chunk: whole layers (both row parities of a transposed conv stay together) while their blocks fit the table
+        WsTable tab;
+        std::vector<WsSlot> slots;
+        tab.njobs = 0; tab.U = 0;
+        double flops = 0.0, bytes = 0.0;
+        size_t i_end = i;
+        for (; i_end < jobs.size(); ++i_end) {
+            PendingJob& p = *jobs[i_end];
+            const int nblk = (p.job.CApad / 64) * (p.job.CBpad / 64);
+            const bool pair = p.cls == WQ_DR0 && i_end + 1 < jobs.size() && jobs[i_end + 1]->cls == WQ_DR1 &&
+                              jobs[i_end + 1]->job.partial == p.job.partial;
+            if (tab.njobs + nblk * (pair ? 2 : 1) > kMaxSJobs) break;
+            for (int half = 0; half < (pair ? 2 : 1); ++half) {
+                PendingJob& q = *jobs[i_end + half];
+                for (int blk = 0; blk < nblk; ++blk) {
+                    WsJob& jb = tab.job[tab.njobs++];
+                    jb.a = q.job.a; jb.b = q.job.b;
+                    jb.partial = q.job.partial + (size_t)blk * q.job.nsplit * q.job.Ttot * 4096;
+                    jb.ubegin = tab.U;
+                    jb.CA = q.job.CA; jb.CB = q.job.CB;
+                    jb.ca0 = (blk / q.job.nbt) * 64; jb.cb0 = (blk % q.job.nbt) * 64;
+                    jb.Hb = q.job.Hb; jb.Wb = q.job.Wb;
+                    jb.tiles_h = q.job.tiles_h; jb.tiles_w = q.job.tiles_w; jb.ntiles = q.job.ntiles;
+                    jb.Ttot = q.job.Ttot;
+                    jb.variant = q.cls * 3 + (5 - q.ltw);
+                    jb.cost = g_ws_cost[jb.variant];
+                    jb.w_first = 0; jb.pad_ = 0;
+                    tab.U += (long long)jb.ntiles * jb.cost;
+                    slots.push_back(WsSlot{&q, blk, 0});
+                }
+                flops += q.flops;
+                bytes += 4.0 * ((double)q.job.N * q.job.CB * q.job.Hb * q.job.Wb +
+                                (double)q.job.N * q.job.CA * q.job.Hb * q.job.Wb * (q.cls == WQ_C3 ? 1 : 2));
+            }
+            if (pair) ++i_end;
+        }
+        if (tab.njobs == 0) { gx_set_error("wgq stream: a layer has more channel blocks than the job table"); return GX_EINVAL; }
+        // G workgroups: one per CU unless a block would need more slabs than its region holds
+        int G = 256;
+        int maxcost = 1;
+        for (int j = 0; j < tab.njobs; ++j) maxcost = tab.job[j].cost > maxcost ? tab.job[j].cost : maxcost;
+        if ((long long)G * maxcost * 2 > tab.U) G = (int)(tab.U / (2LL * maxcost));
+        if (G < 1) G = 1;
+        while (!ws_plan(tab, slots, G)) {
+            if (G == 1) { gx_set_error("wgq stream: no feasible plan"); return GX_EINVAL; }
+            G = G > 16 ? G - 16 : G - 1;
+        }
+        {
+            GxProf pf(KID_WGRAD_C3, s, flops, bytes);
+            hipLaunchKernelGGL(wgq_stream_kernel, dim3(G), dim3(256), 160 * 1024, s, tab, zeros);
+        }
+        GX_CHECK_LAUNCH("wgq (stream-K weight gradients)");
+        // reduce records: one per (layer, channel block); the two row parities of a transposed conv share the slabs
+        for (int j = 0; j < tab.njobs; ++j) {
+            PendingJob& q = *slots[j].p;
+            if (q.cls == WQ_DR1 && j > 0) {
+                bool paired = false;
+                for (int k = 0; k < j; ++k)
+                    paired = paired || (slots[k].p->cls == WQ_DR0 && slots[k].p->job.partial == q.job.partial);
+                if (paired) continue;
+            }
+            const WsJob& jb = tab.job[j];
+            const int ca_n = q.job.CA - jb.ca0 < 64 ? q.job.CA - jb.ca0 : 64;
+            const int cb_n = q.job.CB - jb.cb0 < 64 ? q.job.CB - jb.cb0 : 64;
+            GxWgradRed r{jb.partial, q.dw, slots[j].nseg, jb.Ttot, ca_n, cb_n, 64, 64, q.layout, 0, 0, 0, 0,
+                         jb.ca0, jb.cb0, q.job.CA, q.job.CB};
+            if (q.cls != WQ_C3) {
+                int n0 = q.cls == WQ_DR0 ? slots[j].nseg : 0, n1 = q.cls == WQ_DR1 ? slots[j].nseg : 0;
+                for (int k = 0; k < tab.njobs; ++k)
+                    if (k != j && tab.job[k].partial == jb.partial) {
+                        if (slots[k].p->cls == WQ_DR0) n0 = slots[k].nseg;
+                        if (slots[k].p->cls == WQ_DR1) n1 = slots[k].nseg;
+                    }
+                // taps of a row parity the launch did not cover (never the case for gx_wgq_deconv) would read slab 0
+                r.ns0 = r.ns1 = n0 > 0 ? n0 : 1; r.ns2 = r.ns3 = n1 > 0 ? n1 : 1;
+                r.nsplit = n0 > n1 ? n0 : n1;
+            }
+            recs.push_back(r);
+        }
+        i = i_end;
+    }
+    return GX_OK;
+}
+
 }  // namespace
 
 // ---- internal API (gx_common.h) ----------------------------------------------------------------------------------
@@ -412,6 +645,14 @@ static int wgq_run_or_queue(std::vector<PendingJob>& jobs, hipStream_t s) {
         for (PendingJob& p : jobs) g_jobs.push_back(p);
         return GX_OK;
     }
+    if (wgq_stream_on()) {                      // immediate: the layer alone on the chip, then its reductions (overwrite dw)
+        std::vector<PendingJob*> ptrs;
+        for (PendingJob& p : jobs) ptrs.push_back(&p);
+        std::vector<GxWgradRed> recs;
+        int rc = wgq_launch_stream(ptrs, s, recs);
+        for (size_t i = 0; i < recs.size() && rc == GX_OK; ++i) rc = gx_wgrad_reduce_now(recs[i], s);
+        return rc;
+    }
     // immediate: each (cls) job is its own launch with the whole chip; then the reduce record
     int rc = GX_OK;
     for (PendingJob& p : jobs) {
@@ -420,7 +661,8 @@ static int wgq_run_or_queue(std::vector<PendingJob>& jobs, hipStream_t s) {
         if (rc) return rc;
     }
     PendingJob& f = jobs[0];
-    GxWgradRed r{f.job.partial, f.dw, f.job.nsplit, f.job.Ttot, f.job.CA, f.job.CB, f.job.CApad, f.job.CBpad, f.layout, 0, 0, 0, 0};
+    GxWgradRed r{f.job.partial, f.dw, f.job.nsplit, f.job.Ttot, f.job.CA, f.job.CB, f.job.CApad, f.job.CBpad, f.layout, 0, 0, 0, 0,
+                 0, 0, 0, 0};
     if (jobs.size() == 2) { r.ns0 = r.ns1 = jobs[0].job.nsplit; r.ns2 = r.ns3 = jobs[1].job.nsplit;
                             r.nsplit = r.ns0 > r.ns2 ? r.ns0 : r.ns2; }
     return gx_wgrad_reduce_now(r, s);          // overwrites dw (the deferred batch reduce accumulates)
@@ -467,6 +709,16 @@ void gx_wgq_discard(void) { g_jobs.clear(); }
 int gx_wgq_flush(hipStream_t s) {
     if (g_jobs.empty()) return GX_OK;
     int rc = GX_OK;
+    if (wgq_stream_on()) {
+        std::vector<PendingJob*> ptrs;
+        for (PendingJob& p : g_jobs) ptrs.push_back(&p);
+        std::vector<GxWgradRed> recs;
+        rc = wgq_launch_stream(ptrs, s, recs);
+        for (size_t i = 0; i < recs.size() && rc == GX_OK; ++i)
+            if (!gx_defer_push_wgrad(recs[i])) rc = gx_defer_flush_wgrad(&recs[i], 1, s);
+        g_jobs.clear();
+        return rc;
+    }
     for (int cls = 0; cls < 3 && rc == GX_OK; ++cls)
         for (int ltw = 5; ltw >= 3 && rc == GX_OK; --ltw) {
             std::vector<PendingJob*> grp;
@@ -484,7 +736,7 @@ int gx_wgq_flush(hipStream_t s) {
             PendingJob& p = g_jobs[i];
             if (p.cls == WQ_DR1) continue;
             GxWgradRed r{p.job.partial, p.dw, p.job.nsplit, p.job.Ttot, p.job.CA, p.job.CB, p.job.CApad, p.job.CBpad,
-                         p.layout, 0, 0, 0, 0};
+                         p.layout, 0, 0, 0, 0, 0, 0, 0, 0};
             if (p.cls == WQ_DR0) {
                 int ns1 = 0;
                 for (PendingJob& q : g_jobs)

@@ -122,26 +122,34 @@ def test_profile_collect():
 
 
 def test_weight_cache_matches_per_call_packing():
-    """The packed-weight cache (one batched re-pack per iteration) and the deferred, batched parameter-gradient
-    reductions must not change a single bit of the training trajectory relative to per-call packing / reducing."""
+    """The packed-weight cache (one batched re-pack per iteration) must not change a single bit of the training
+    trajectory relative to per-call packing.  Deferred, batched parameter-gradient reductions launch every layer's weight
+    gradient in ONE stream-K grid, which cuts the pixel range of a layer at other places than a launch of that layer
+    alone does: the fp32 summation order differs, so that comparison is to round-off (and each mode is bit-reproducible)."""
     from genesis_amd import _lib
     from genesis_amd.trainer import TrainStep
     gold = Golden('tiny')
     x, _, _ = gold.inputs()
     xd = x.to(DEV)
-    outs = []
-    for cache in (False, True):
+    outs = {}
+    for cache, defer in ((False, True), (True, True), (True, True), (False, False)):
         model = build(gold)
-        ts = TrainStep(model, gold.S, lr=1e-4, graph=False, weight_cache=cache, defer_reduces=cache)
+        ts = TrainStep(model, gold.S, lr=1e-4, graph=False, weight_cache=cache, defer_reduces=defer)
         res = []
         for it in range(4):
             rp, eps = gold.noise(1 + it % 3)
             res.append(ts.step(xd, rand_pixel=rp.to(DEV), eps=torch.stack(eps).to(DEV)).clone())
-        outs.append((torch.stack(res), ts.flat_p.clone()))
+        out = (torch.stack(res), ts.flat_p.clone())
+        if (cache, defer) in outs:                      # the same mode twice: bit-reproducible
+            assert torch.equal(outs[(cache, defer)][0], out[0]) and torch.equal(outs[(cache, defer)][1], out[1])
+        outs[(cache, defer)] = out
         if cache:
             assert _lib.query('gx_weight_cache_size', ts._wcache) > 10
-    assert torch.equal(outs[0][0], outs[1][0])
-    assert torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[(False, True)][0], outs[(True, True)][0])
+    assert torch.equal(outs[(False, True)][1], outs[(True, True)][1])
+    a, b = outs[(True, True)], outs[(False, False)]
+    assert torch.allclose(a[0][:, :2], b[0][:, :2], rtol=2e-5), (a[0], b[0])
+    assert float((a[1] - b[1]).norm() / b[1].norm()) < 2e-5
 
 
 def test_split_graph_with_rccl_allreduce_matches_single_graph(monkeypatch):
