@@ -10,10 +10,10 @@ namespace {
 
 // p, g, m, v: flat buffers of n elements.  step: device int64 counter, already incremented for this
 // update (t >= 1).  gscale multiplies the gradient first (1/world_size for data-parallel averaging).
-template <typename T>
-__global__ void __launch_bounds__(256)
-adam_kernel(T* __restrict__ p, const T* __restrict__ g, T* __restrict__ m, T* __restrict__ v, size_t n,
-            const int64_t* __restrict__ step, double lr, double b1, double b2, double eps, float gscale) {
+template <typename T, bool ZERO_G = false>
+__device__ __forceinline__ void adam_body(T* __restrict__ p, T* __restrict__ g, T* __restrict__ m, T* __restrict__ v,
+                                          size_t n, const int64_t* __restrict__ step, double lr, double b1, double b2,
+                                          double eps, float gscale, unsigned block, unsigned nblocks) {
     // hyper-parameters arrive as doubles and every derived constant is formed in double before it is rounded to T,
     // as torch.optim.Adam does with its Python floats (1 - 0.999 in fp32 is 4.7e-5 off the fp64 value it uses)
     const double t = (double)(*step);
@@ -22,8 +22,9 @@ adam_kernel(T* __restrict__ p, const T* __restrict__ g, T* __restrict__ m, T* __
     const T step_size = (T)(lr / bc1);
     const T bc2_sqrt = (T)sqrt(bc2);
     const T one_m_b1 = (T)(1.0 - b1), one_m_b2 = (T)(1.0 - b2), b2_t = (T)b2, eps_t = (T)eps;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    for (size_t i = (size_t)block * blockDim.x + threadIdx.x; i < n; i += (size_t)nblocks * blockDim.x) {
         const T gi = g[i] * (T)gscale;
+        if (ZERO_G) g[i] = (T)0;                                   // the next iteration accumulates into a clean bucket
         const T mi = m[i] + (gi - m[i]) * one_m_b1;                // torch: exp_avg.lerp_(grad, 1 - beta1)
         const T vi = v[i] * b2_t + gi * gi * one_m_b2;             // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
         const T denom = sqrt(vi) / bc2_sqrt + eps_t;
@@ -31,6 +32,28 @@ adam_kernel(T* __restrict__ p, const T* __restrict__ g, T* __restrict__ m, T* __
         m[i] = mi;
         v[i] = vi;
     }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+adam_kernel(T* __restrict__ p, const T* __restrict__ g, T* __restrict__ m, T* __restrict__ v, size_t n,
+            const int64_t* __restrict__ step, double lr, double b1, double b2, double eps, float gscale) {
+    adam_body<T, false>(p, const_cast<T*>(g), m, v, n, step, lr, b1, b2, eps, gscale, blockIdx.x, gridDim.x);
+}
+
+// the fp32 and the fp64 parameter groups in one launch (blocks [0, nb32) / [nb32, gridDim.x)), optionally zeroing the
+// gradients they consumed: the tail of a training step is this launch and the GECO / step-counter one
+struct AdamGroup { void* p; void* g; void* m; void* v; size_t n; };
+template <bool ZERO_G>
+__global__ void __launch_bounds__(256)
+adam_pair_kernel(const AdamGroup a, const AdamGroup b, unsigned nb32, const int64_t* __restrict__ step, double lr,
+                 double b1, double b2, double eps, float gscale) {
+    if (blockIdx.x < nb32)
+        adam_body<float, ZERO_G>((float*)a.p, (float*)a.g, (float*)a.m, (float*)a.v, a.n, step, lr, b1, b2, eps, gscale,
+                                 blockIdx.x, nb32);
+    else
+        adam_body<double, ZERO_G>((double*)b.p, (double*)b.g, (double*)b.m, (double*)b.v, b.n, step, lr, b1, b2, eps,
+                                  gscale, blockIdx.x - nb32, gridDim.x - nb32);
 }
 
 __global__ void step_inc_kernel(int64_t* step) {
@@ -41,8 +64,9 @@ __global__ void step_inc_kernel(int64_t* step) {
 // THIS step, already averaged over ranks).  utils/geco.py:39-49.
 __global__ void geco_update_kernel(float* __restrict__ state, const float* __restrict__ err, float goal,
                                    float step_size, float alpha, float speedup, int use_speedup,
-                                   float beta_min, float beta_max) {
+                                   float beta_min, float beta_max, int64_t* __restrict__ step) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (step) *step += 1;          // the optimiser's step counter rides along (gx_geco_update_step)
     const float e = *err;
     float ema = state[1];
     if (state[2] == 0.f) { ema = e; state[2] = 1.f; }
@@ -97,9 +121,47 @@ int gx_geco_update(float* state, const float* err, float goal, float step_size, 
     {
         GxProf pf(KID_GECO, (hipStream_t)stream, 0.0, 16.0);
         hipLaunchKernelGGL(geco_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, err, goal, step_size,
-                           alpha, speedup, use_speedup, beta_min, beta_max);
+                           alpha, speedup, use_speedup, beta_min, beta_max, (int64_t*)nullptr);
     }
     GX_CHECK_LAUNCH("gx_geco_update");
+    return GX_OK;
+}
+
+/* gx_geco_update + gx_step_increment in one launch */
+int gx_geco_update_step(float* state, const float* err, float goal, float step_size, float alpha, float speedup,
+                        int use_speedup, float beta_min, float beta_max, int64_t* step, gx_stream_t stream) {
+    GX_CHECK_ARG(state && err && step, "gx_geco_update_step: null pointer");
+    {
+        GxProf pf(KID_GECO, (hipStream_t)stream, 0.0, 24.0);
+        hipLaunchKernelGGL(geco_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, err, goal, step_size,
+                           alpha, speedup, use_speedup, beta_min, beta_max, step);
+    }
+    GX_CHECK_LAUNCH("gx_geco_update_step");
+    return GX_OK;
+}
+
+/* gx_adam_step on an fp32 group and an fp64 group (n64 may be 0) in one launch; zero_grads != 0: the gradients are
+ * zeroed as they are consumed (replaces the bucket's zero-fill launch at the start of the next iteration) */
+int gx_adam_step_pair(float* p32, float* g32, float* m32, float* v32, size_t n32, double* p64, double* g64,
+                      double* m64, double* v64, size_t n64, int64_t* step, double lr, double beta1, double beta2,
+                      double eps, float grad_scale, int zero_grads, gx_stream_t stream) {
+    GX_CHECK_ARG(p32 && g32 && m32 && v32 && step && n32 > 0, "gx_adam_step_pair: null pointer / empty fp32 group");
+    GX_CHECK_ARG(n64 == 0 || (p64 && g64 && m64 && v64), "gx_adam_step_pair: null fp64 pointer");
+    hipStream_t s = (hipStream_t)stream;
+    size_t nb32 = (n32 + 1023) / 1024, nb64 = n64 ? (n64 + 1023) / 1024 : 0;
+    if (nb32 > 2048) nb32 = 2048;
+    if (nb64 > 256) nb64 = 256;
+    const AdamGroup a{p32, g32, m32, v32, n32}, b{p64, g64, m64, v64, n64};
+    {
+        GxProf pf(KID_ADAM, s, 0.0, 4.0 * 7.0 * (double)n32 + 8.0 * 7.0 * (double)n64);
+        if (zero_grads)
+            hipLaunchKernelGGL(adam_pair_kernel<true>, dim3((unsigned)(nb32 + nb64)), dim3(256), 0, s, a, b, (unsigned)nb32,
+                               (const int64_t*)step, lr, beta1, beta2, eps, grad_scale);
+        else
+            hipLaunchKernelGGL(adam_pair_kernel<false>, dim3((unsigned)(nb32 + nb64)), dim3(256), 0, s, a, b, (unsigned)nb32,
+                               (const int64_t*)step, lr, beta1, beta2, eps, grad_scale);
+    }
+    GX_CHECK_LAUNCH("gx_adam_step_pair");
     return GX_OK;
 }
 

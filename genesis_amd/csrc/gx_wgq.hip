@@ -26,6 +26,7 @@
 // Tile = 64 base pixels (TH x TW, TW = 32, 16 or 8); two LDS stages; one barrier per tile.
 #include "gx_common.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -584,6 +585,15 @@ int wgq_launch_stream(std::vector<PendingJob*>& jobs, hipStream_t s, std::vector
         while (!ws_plan(tab, slots, G)) {
             if (G == 1) { gx_set_error("wgq stream: no feasible plan"); return GX_EINVAL; }
             G = G > 16 ? G - 16 : G - 1;
+        }
+        static const bool dbg = getenv("GENESIS_WGQ_DEBUG") != nullptr;
+        if (dbg) {
+            fprintf(stderr, "[wgq stream] G %d, U %lld, %d block-jobs\n", G, tab.U, tab.njobs);
+            for (int j = 0; j < tab.njobs; ++j)
+                fprintf(stderr, "  job %2d variant %d  CA %3d CB %3d (block %d,%d)  %dx%d  tiles %6d  cost %5d  share %.3f  slabs %d\n",
+                        j, tab.job[j].variant, tab.job[j].CA, tab.job[j].CB, tab.job[j].ca0, tab.job[j].cb0, tab.job[j].Hb,
+                        tab.job[j].Wb, tab.job[j].ntiles, tab.job[j].cost,
+                        (double)tab.job[j].ntiles * tab.job[j].cost / (double)tab.U, slots[j].nseg);
         }
         {
             GxProf pf(KID_WGRAD_C3, s, flops, bytes);

@@ -58,13 +58,18 @@ class GECO(object):
     def to_cuda(self):
         self.state = self.state.cuda()
 
-    def update(self, err):
-        """geco.py:39-49 with `err` a device scalar (batch-mean reconstruction error)."""
+    def update(self, err, step=None):
+        """geco.py:39-49 with `err` a device scalar (batch-mean reconstruction error).  step: optional device int64
+        counter (the optimiser's) incremented by the same launch."""
         err = err.detach().reshape(1).to(torch.float32).contiguous()
-        _lib.call('gx_geco_update', ctypes.c_void_p(self.state.data_ptr()), ctypes.c_void_p(err.data_ptr()),
-                  self.goal, self.step_size, self.alpha, float(self.speedup or 0.0),
-                  int(self.speedup is not None), self._beta_min, self._beta_max,
-                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        args = (ctypes.c_void_p(self.state.data_ptr()), ctypes.c_void_p(err.data_ptr()),
+                self.goal, self.step_size, self.alpha, float(self.speedup or 0.0),
+                int(self.speedup is not None), self._beta_min, self._beta_max)
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if step is None:
+            _lib.call('gx_geco_update', *args, stream)
+        else:
+            _lib.call('gx_geco_update_step', *args, ctypes.c_void_p(step.data_ptr()), stream)
 
     def loss(self, err, kld):
         # loss with the CURRENT beta (geco.py:37), then the no-grad multiplier update

@@ -105,8 +105,14 @@ class TrainStep(object):
         _hip.defer_state().on = False
         _hip.defer_discard()             # no-op after a completed iteration (the queue was flushed)
 
+    def _zero_grads(self):
+        """The bucket must be clean before a backward pass accumulates into it.  After a completed iteration it is: the
+        fused Adam launch zeroes the gradients it consumes (no separate fill launch per step)."""
+        if not getattr(self, '_grads_clean', False):
+            self.bucket.zero_grad()
+
     def _iteration(self, x, **forward_kwargs):
-        self.bucket.zero_grad()
+        self._zero_grads()
         self._enter()
         # packed-weight cache: the first (never graph-captured) iteration records which weight tensors the conv
         # entry points pack; later iterations re-pack all of them in one launch up front
@@ -150,6 +156,7 @@ class TrainStep(object):
 
     def _forward_backward(self, x, **forward_kwargs):
         """zero-grad'ed bucket -> forward -> loss -> backward; leaves (err, kl) batch means in the bucket tail."""
+        self._grads_clean = False
         recon, losses, stats, att_stats, comp_stats = self.model(x, **forward_kwargs)
         # loss aggregation of train.py:226-242 (every model family: kl_m | kl_m_k, kl_l | kl_l_k)
         beta_t = self.geco.state[0:1] if self.geco is not None else self._beta_fixed_t.view(1)
@@ -195,16 +202,17 @@ class TrainStep(object):
         fused, beta_used = st
         local = fused and gscale == 1.0
         tail = self.bucket.flat_g[self.n32:self.n32 + 2] if gscale == 1.0 else self.bucket.tail(gscale)   # global batch means
-        if self.geco is not None:
-            self.geco.update(tail[0])
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        _lib.call('gx_step_increment', _p(self.step_t), stream)
-        _lib.call('gx_adam_step', _p(self.flat_p), _p(self.flat_g), _p(self.m32), _p(self.v32), self.n32, 0,
-                  _p(self.step_t), self.lr, self.betas[0], self.betas[1], self.eps, gscale, stream)
-        if self.n64:
-            _lib.call('gx_adam_step', _p(self.flat_p64), _p(self.flat_g64), _p(self.m64), _p(self.v64),
-                      self.n64, 1, _p(self.step_t), self.lr, self.betas[0], self.betas[1], self.eps, gscale,
-                      stream)
+        if self.geco is not None:
+            self.geco.update(tail[0], step=self.step_t)      # GECO multiplier and the optimiser's step counter: one launch
+        else:
+            _lib.call('gx_step_increment', _p(self.step_t), stream)
+        # fp32 and fp64 parameter groups in one launch; it zeroes the gradients it consumed
+        _lib.call('gx_adam_step_pair', _p(self.flat_p), _p(self.flat_g), _p(self.m32), _p(self.v32), self.n32,
+                  _p(self.flat_p64) if self.n64 else None, _p(self.flat_g64) if self.n64 else None,
+                  _p(self.m64) if self.n64 else None, _p(self.v64) if self.n64 else None, self.n64,
+                  _p(self.step_t), self.lr, self.betas[0], self.betas[1], self.eps, gscale, 1, stream)
+        self._grads_clean = True
         if local:
             return beta_used[1:5]                            # ElboFn's (elbo, err, kl, beta used)
         bu = beta_used[4] if fused else beta_used
@@ -212,7 +220,7 @@ class TrainStep(object):
 
     # ------------------------------------------------------------------ HIP-graph replay
     def _begin(self):
-        self.bucket.zero_grad()
+        self._zero_grads()
         self._enter()
         if self._wcache is not None and self._wcache_ready:
             _lib.call('gx_weight_cache_refresh', self._wcache,

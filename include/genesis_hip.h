@@ -183,6 +183,15 @@ int gx_adam_step(void* p, const void* g, void* m, void* v, size_t n, int is_f64,
 int gx_step_increment(int64_t* step, gx_stream_t stream);
 int gx_geco_update(float* state, const float* err, float goal, float step_size, float alpha, float speedup,
                    int use_speedup, float beta_min, float beta_max, gx_stream_t stream);
+/*      The tail of a training step in two launches: gx_geco_update_step = gx_geco_update + gx_step_increment;
+ *      gx_adam_step_pair = gx_adam_step on the fp32 group and on the fp64 group (n64 may be 0) and, with
+ *      zero_grads != 0, zeroes the gradients as it consumes them (the next iteration's backward accumulates into a
+ *      clean bucket without a separate fill launch). */
+int gx_geco_update_step(float* state, const float* err, float goal, float step_size, float alpha, float speedup,
+                        int use_speedup, float beta_min, float beta_max, int64_t* step, gx_stream_t stream);
+int gx_adam_step_pair(float* p32, float* g32, float* m32, float* v32, size_t n32, double* p64, double* g64,
+                      double* m64, double* v64, size_t n64, int64_t* step, double lr, double beta1, double beta2,
+                      double eps, float grad_scale, int zero_grads, gx_stream_t stream);
 
 /* ---- live per-kernel profiling (bench.py's roofline leg): when enabled every kernel launch is bracketed
  *      by two HIP events on its launch stream and tagged with its ALGORITHMIC flops / bytes
