@@ -115,10 +115,11 @@ __device__ __forceinline__ float gx_wino_u_value(const float* __restrict__ w, in
     return nu == 0 ? t[0] : (nu == 1 ? 0.5f * (t[0] + t[1] + t[2]) : (nu == 2 ? 0.5f * (t[0] - t[1] + t[2]) : t[2]));
 }
 // position of U(p, k, m) in the conv kernel's operand order:
-// [m tile][chunk of 8 k][position][lane = 32 (k & 1) + (m & 31)][2 (k % 8 / 2) + ((m >> 5) & 1)]
+// [m tile][chunk of 8 k][position][lane = 32 ((k >> 2) & 1) + (m & 31)][2 (k & 3) + ((m >> 5) & 1)]
+// (lane half h of the chunk's MFMA j multiplies channel 4 h + j: the B operand's four values are one 16-byte LDS read)
 __host__ __device__ __forceinline__ size_t gx_wino_u_slot(int m, int k, int p, int Kpad) {
     const size_t base = ((size_t)(m >> 6) * (Kpad >> 3) + (k >> 3)) * 16 + p;
-    return base * 512 + (size_t)(((((k & 1) << 5) | (m & 31)) << 3) | (((k & 7) >> 1) << 1) | ((m >> 5) & 1));
+    return base * 512 + (size_t)((((((k >> 2) & 1) << 5) | (m & 31)) << 3) | ((k & 3) << 1) | ((m >> 5) & 1));
 }
 // conv with an already packed U (16 * Kpad * Mpad floats): out[N,M,H,W] from in[N,K,H,W]
 bool gx_wino_eligible(int N, int K, int M, int H, int W);

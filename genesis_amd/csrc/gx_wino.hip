@@ -71,37 +71,36 @@ wino_conv_kernel(const float* __restrict__ in, const float* __restrict__ U, floa
     const float* in_n = in + (size_t)n * g.K * HW;
     const int nchunks = g.Kpad / WKC;
 
-    // raw-patch staging slots of this thread: element e = tid + 256 q of [WKC][PR][PC], packed into one register each:
-    // bits 0..14 pixel offset r * W + c, bit 15 inside the image, bits 16..26 LDS offset, bits 27..29 channel, bit 30 used
-    int rinfo[RAW_PER_THREAD];
+    // raw-patch staging slots of this thread: element e = tid + 256 q of [WKC][PR][PC].  The loads are raw buffer loads
+    // over this image's [K][H*W] block: voff[q] = byte offset of (channel of the chunk, pixel), or 1 GiB for a halo pixel
+    // outside the image / an unused slot; the chunk's first channel rides in the scalar offset.  Out-of-range addresses
+    // (padding pixels, channels >= K) read as 0 -- no compare / select per element.
+    int voff[RAW_PER_THREAD], loff[RAW_PER_THREAD];       // loff: LDS float offset inside a raw buffer, -1 = unused slot
 #pragma unroll
     for (int q = 0; q < RAW_PER_THREAD; ++q) {
         const int e = tid + 256 * q;
-        int info = 0;
+        voff[q] = 0x40000000; loff[q] = -1;
         if (e < WKC * PR * PC) {
             const int ch = e / (PR * PC), rem = e - ch * (PR * PC);
             const int pr = rem / PC, pc = rem - pr * PC;
             const int r = R0 - 1 + pr, c = C0 - 1 + pc;
-            info = (1 << 30) | (ch << 27) | ((ch * PPITCH + (pr * 2 + (pc & 1)) * PLANE + (pc >> 1)) << 16);
-            if (r >= 0 && r < g.H && c >= 0 && c < g.W) info |= (1 << 15) | (r * g.W + c);
+            loff[q] = ch * PPITCH + (pr * 2 + (pc & 1)) * PLANE + (pc >> 1);
+            if (r >= 0 && r < g.H && c >= 0 && c < g.W) voff[q] = (ch * HW + r * g.W + c) * 4;
         }
-        rinfo[q] = info;
     }
+    const __amdgpu_buffer_rsrc_t in_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_n), 0, g.K * HW * 4, 0x00020000);
     float rawr[RAW_PER_THREAD];
     auto load_raw = [&](int k0) {
+        const int soff = k0 * HW * 4;
 #pragma unroll
-        for (int q = 0; q < RAW_PER_THREAD; ++q) {
-            // branch-free: out-of-image / out-of-range slots read element 0 of the image and are zeroed afterwards
-            const int ch = (rinfo[q] >> 27) & 7;
-            const bool ok = (rinfo[q] & (1 << 15)) && k0 + ch < g.K;
-            const float v = in_n[ok ? (size_t)(k0 + ch) * HW + (rinfo[q] & 0x7fff) : 0];
-            rawr[q] = ok ? v : 0.f;
-        }
+        for (int q = 0; q < RAW_PER_THREAD; ++q)
+            rawr[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, voff[q], soff, 0));
     };
     auto store_raw = [&](float* rbuf) {
 #pragma unroll
         for (int q = 0; q < RAW_PER_THREAD; ++q)
-            if (rinfo[q] & (1 << 30)) rbuf[(rinfo[q] >> 16) & 0x7ff] = rawr[q];
+            if (loff[q] >= 0) rbuf[loff[q]] = rawr[q];
     };
     // this wave's weight operands: [m tile][chunk][position 4 wave + nu][lane][8]
     const float* Uw = U + (((size_t)blockIdx.y * nchunks) * 16 + 4 * wave) * 512 + lane * 8;
@@ -115,11 +114,16 @@ wino_conv_kernel(const float* __restrict__ in, const float* __restrict__ U, floa
 #pragma unroll
             for (int c = 0; c < 16; ++c) acc[a][b][c] = 0.f;
 
-    // transform role: channel tk, tile (tty, ttx); patch element (i, j) sits at row 2 tty + i, column 2 ttx + j
-    const int tk = tid >> 5, tt = tid & 31;
-    const int tty = tt >> 3, ttx = tt & 7;
+    // transform role: channel tk, tile (tty, ttx); patch element (i, j) sits at row 2 tty + i, column 2 ttx + j.
+    // A wave takes all 8 channels of one tile row: its 64 V values of a position are two runs of 32 consecutive floats
+    // (the minimum of two LDS cycles per 64-lane store) and its patch reads fall on banks 8 tk + ttx (two lanes per bank).
+    const int tk = lane & 7, ttr = wave * 8 + (lane >> 3);
+    const int tty = ttr >> 3, ttx = ttr & 7;
+    const int tt = tid & 31;              // (the epilogue's tile index)
     const int tsrc_off = tk * PPITCH + (2 * tty) * 2 * PLANE + ttx;
-    const int tdst_off = tk * WNT + tt;
+    // V [position][k quad = channel >> 2][tile][channel & 3]: the four channels a lane half feeds to four successive
+    // MFMAs are 16 contiguous bytes, one ds_read_b128 (4-byte operand reads cap the pipe at ~106 TF/s)
+    const int tdst_off = (tk >> 2) * (WNT * 4) + ttr * 4 + (tk & 3);
     // V = B^T d B for this thread's (channel, tile): column j of the patch is plane (j & 1), index ttx + (j >> 1)
     auto transform = [&](const float* rbuf, float* vbuf) {
         const float* tsrc = rbuf + tsrc_off;
@@ -157,37 +161,55 @@ wino_conv_kernel(const float* __restrict__ in, const float* __restrict__ U, floa
         ua[nu][0] = *reinterpret_cast<const f32x4*>(Uw + (size_t)nu * 512);
         ua[nu][1] = *reinterpret_cast<const f32x4*>(Uw + (size_t)nu * 512 + 4);
     }
-    load_raw(0);
-    store_raw(raw);
-    if (nchunks > 1) { load_raw(WKC); store_raw(raw + RAW_FLOATS); }
-    if (nchunks > 2) load_raw(2 * WKC);
+    {
+        // the first three chunks' patches in ONE round trip (the channel-range check of the buffer loads makes the
+        // loads of chunks that do not exist return zeros: no branches)
+        float r0[RAW_PER_THREAD], r1[RAW_PER_THREAD];
+#pragma unroll
+        for (int q = 0; q < RAW_PER_THREAD; ++q) {
+            r0[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, voff[q], 0, 0));
+            r1[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, voff[q], WKC * HW * 4, 0));
+        }
+        load_raw(2 * WKC);
+#pragma unroll
+        for (int q = 0; q < RAW_PER_THREAD; ++q)
+            if (loff[q] >= 0) { raw[loff[q]] = r0[q]; raw[RAW_FLOATS + loff[q]] = r1[q]; }
+    }
     __syncthreads();
     transform(raw, V);
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         const float* Vc = V + (c & 1) * V_FLOATS;
-        if (c + 2 < nchunks) {
+#ifndef GX_WINO_ABL
+#define GX_WINO_ABL 0          // measurement builds (tools/abl_build.sh): 1 no transform, 2 no patch staging, 4 no MFMAs
+#endif
+        if (!(GX_WINO_ABL & 2) && c + 2 < nchunks) {
             store_raw(raw + (c & 1) * RAW_FLOATS);          // chunk c + 2 (its buffer was consumed in iteration c - 1)
             if (c + 3 < nchunks) load_raw((c + 3) * WKC);
         }
+        f32x4 bq[4];          // this lane's B values of the chunk: [nu][channel & 3]
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu)
+            bq[nu] = *reinterpret_cast<const f32x4*>(Vc + (((4 * wave + nu) * 2 + kh) * WNT + bn) * 4);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
 #pragma unroll
             for (int kk2 = 0; kk2 < 2; ++kk2) {
-                const int kk = 2 * half + kk2;
-                const int k = 2 * kk + kh;
+                const int kk = 2 * half + kk2;          // MFMA kk: channel 4 kh + kk of the chunk
 #pragma unroll
                 for (int nu = 0; nu < 4; ++nu) {
-                    const float b = Vc[((4 * wave + nu) * WKC + k) * WNT + bn];
+                    const float b = bq[nu][kk];
+                    if (GX_WINO_ABL & 4) { acc[nu][0][kk] += b * ua[nu][half][kk2 * 2]; continue; }
                     acc[nu][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[nu][half][kk2 * 2], b, acc[nu][0], 0, 0, 0);
                     acc[nu][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[nu][half][kk2 * 2 + 1], b, acc[nu][1], 0, 0, 0);
                 }
             }
             if (c + 1 < nchunks) {
+                if (!(GX_WINO_ABL & 8))
 #pragma unroll
                 for (int nu = 0; nu < 4; ++nu)
                     ua[nu][half] = *reinterpret_cast<const f32x4*>(Uw + ((size_t)(c + 1) * 16 + nu) * 512 + 4 * half);
-                if (half == 0) transform(raw + ((c + 1) & 1) * RAW_FLOATS, V + ((c + 1) & 1) * V_FLOATS);
+                if (half == 0 && !(GX_WINO_ABL & 1)) transform(raw + ((c + 1) & 1) * RAW_FLOATS, V + ((c + 1) & 1) * V_FLOATS);
             }
         }
         __syncthreads();
@@ -198,6 +220,17 @@ wino_conv_kernel(const float* __restrict__ in, const float* __restrict__ U, floa
     //      Y[1][b] = q(1) - q(2) - q(3).  One 32-channel half (mi) at a time: E[xi][b][32 m][32 n] = 32 KB.
     float* E = lds;
     const size_t out_n = (size_t)n * g.M * HW;
+    if (GX_WINO_ABL & 16) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < 16; ++c) sacc += acc[a][b][c];
+        out[out_n + (size_t)(m0 + (tid >> 2)) * HW + (size_t)R0 * g.W + C0 + (tid & 3)] = sacc;
+        return;
+    }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
         __syncthreads();
