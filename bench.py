@@ -46,7 +46,7 @@ def parse():
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of HIP-graph replay')
     ap.add_argument('--profile-steps', type=int, default=3)
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU baseline leg (0 = skip)')
-    ap.add_argument('--host-input-steps', type=int, default=50,
+    ap.add_argument('--host-input-steps', type=int, default=150,
                     help='extra leg on rank 0 at N=1: steps fed from uint8 frames in host memory through the PCIe feeder '
                          '(reported as pcie_inclusive, never as value; 0 = skip)')
     return ap.parse_args()
@@ -329,12 +329,13 @@ def main():
     if rank == 0 and world == 1 and args.host_input_steps > 0 and ts.graph is not None:
         from genesis_amd.feeder import DeviceFeeder
         ts.use_graph = True
-        n_host = args.host_input_steps + 5
+        n_warm = 20            # the ring's first slots are staged while the loop already runs: let it reach steady state
+        n_host = args.host_input_steps + n_warm
         gh = torch.Generator().manual_seed(99)
         frames = [torch.randint(0, 256, (args.batch, args.img, args.img, 3), generator=gh, dtype=torch.uint8)
                   for _ in range(4)]
         feeder = DeviceFeeder((frames[i % 4] for i in range(n_host)), args.img, device=device)
-        for _ in range(5):
+        for _ in range(n_warm):
             ts.step(next(feeder))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
