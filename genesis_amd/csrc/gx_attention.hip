@@ -261,14 +261,28 @@ icsbp_bwd_finalize_kernel(const double* __restrict__ part, const int64_t* __rest
                           const double* __restrict__ log_sigma, int B, int C, int HW, int K, int nchunks,
                           float* __restrict__ dcolour, double* __restrict__ dlog_sigma_part) {
     __shared__ double sums[16][MAXC + 1];
+    __shared__ double quarter[4][16 * (MAXC + 1)];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = (K - 1) * (MAXC + 1);
-    for (int i = tid; i < n; i += blockDim.x) {
-        const int t = i / (MAXC + 1), c = i % (MAXC + 1);
-        double s = 0.0;
-        for (int ch = 0; ch < nchunks; ++ch) s += part[(((size_t)b * nchunks + ch) * (K - 1) + t) * (MAXC + 1) + c];
-        sums[t][c] = s;
+    // every 4th chunk per thread quarter (the chunk loop is a chain of dependent-latency loads: 4x shorter, and its
+    // loads independent of the running sum), the quarters combined in a fixed order
+    {
+        const int q = tid >> 6, i0 = tid & 63;
+        for (int i = i0; i < n; i += 64) {
+            const int t = i / (MAXC + 1), c = i % (MAXC + 1);
+            double s0 = 0.0, s1 = 0.0;
+            int ch = q;
+            for (; ch + 4 < nchunks; ch += 8) {
+                s0 += part[(((size_t)b * nchunks + ch) * (K - 1) + t) * (MAXC + 1) + c];
+                s1 += part[(((size_t)b * nchunks + ch + 4) * (K - 1) + t) * (MAXC + 1) + c];
+            }
+            if (ch < nchunks) s0 += part[(((size_t)b * nchunks + ch) * (K - 1) + t) * (MAXC + 1) + c];
+            quarter[q][i] = s0 + s1;
+        }
     }
+    __syncthreads();
+    for (int i = tid; i < n; i += blockDim.x)
+        sums[i / (MAXC + 1)][i % (MAXC + 1)] = (quarter[0][i] + quarter[1][i]) + (quarter[2][i] + quarter[3][i]);
     __syncthreads();
     if (tid == 0) {
         double ds = 0.0;
