@@ -3,7 +3,7 @@ import csv
 rows=list(csv.DictReader(open("/tmp/prof6/r04_kernel_trace.csv")))
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 names=[r["Kernel_Name"] for r in rows]
-idx=[i for i,n in enumerate(names) if "adam_kernel<float" in n]
+idx=[i for i,n in enumerate(names) if "adam_pair_kernel" in n or "adam_kernel<float" in n]
 a,b=idx[-2],idx[-1]
 out=open("/root/repo/gpurun_out/step_seq.txt","w")
 t0=int(rows[a]["End_Timestamp"])
