@@ -284,13 +284,17 @@ icsbp_bwd_finalize_kernel(const double* __restrict__ part, const int64_t* __rest
     for (int i = tid; i < n; i += blockDim.x)
         sums[i / (MAXC + 1)][i % (MAXC + 1)] = (quarter[0][i] + quarter[1][i]) + (quarter[2][i] + quarter[3][i]);
     __syncthreads();
-    if (tid == 0) {
-        double ds = 0.0;
+    // one thread per colour channel walks the steps in order (two steps may have drawn the same seed pixel): K - 1
+    // dependent read-modify-writes per thread instead of (K - 1) C on a single thread
+    if (tid < C) {
         for (int t = 0; t < K - 1; ++t) {
-            ds += sums[t][MAXC];
             const int idx = (int)seed_idx[(size_t)t * B + b];
-            for (int c = 0; c < C; ++c) dcolour[((size_t)b * C + c) * HW + idx] += (float)sums[t][c];
+            dcolour[((size_t)b * C + tid) * HW + idx] += (float)sums[t][tid];
         }
+    }
+    if (tid == 64) {
+        double ds = 0.0;
+        for (int t = 0; t < K - 1; ++t) ds += sums[t][MAXC];
         dlog_sigma_part[b] = ds * exp(*log_sigma);   // d log_sigma = d sigma * sigma
     }
 }

@@ -1580,23 +1580,33 @@ wgrad_smallcin_kernel(const float* __restrict__ x, const float* __restrict__ dy,
     }
 }
 
-// dw[co][ci][tap] = sum over blocks; one workgroup per output channel: 32 columns x 8 block groups
-__global__ void __launch_bounds__(256)
+// dw[co][ci][tap] = sum over blocks; one workgroup per output channel: 32 columns x 32 block groups, four loads in
+// flight per thread (with 8 groups and one running sum a thread walked 64 dependent-latency loads: 20 us)
+__global__ void __launch_bounds__(1024)
 wgrad_smallcin_reduce_kernel(const float* __restrict__ pw, int nblk, int Cout, int J, float* __restrict__ dw) {
-    __shared__ float red[8][32];
+    __shared__ float red[32][32];
     const int co = blockIdx.x;
     const int j = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int mt = co >> 6, cl = co & 63;
-    float s = 0.f;
-    for (int b = grp; b < nblk; b += 8) s += pw[((size_t)(mt * nblk + b) * 64 + cl) * 32 + j];
-    red[grp][j] = s;
+    const float* p = pw + ((size_t)mt * nblk * 64 + cl) * 32 + j;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = grp;
+    for (; b + 96 < nblk; b += 128) {
+        s0 += p[(size_t)b * 2048];
+        s1 += p[(size_t)(b + 32) * 2048];
+        s2 += p[(size_t)(b + 64) * 2048];
+        s3 += p[(size_t)(b + 96) * 2048];
+    }
+    for (; b < nblk; b += 32) s0 += p[(size_t)b * 2048];
+    red[grp][j] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (grp == 0 && j < J) {
         float t = red[0][j];
 #pragma unroll
-        for (int g2 = 1; g2 < 8; ++g2) t += red[g2][j];
+        for (int g2 = 1; g2 < 32; ++g2) t += red[g2][j];
         dw[(size_t)co * J + j] = t;
     }
+    (void)Cout;
 }
 
 inline bool smallcin_ok(int Cin, int H, int W) { return Cin * 9 <= 32 && (W % 16) == 0 && ((H * W) % 64) == 0; }
@@ -1903,7 +1913,7 @@ int gx_conv3x3_wgrad(const float* x, const float* dy, float* dw, int N, int Cin,
         GX_CHECK_LAUNCH("gx_conv3x3_wgrad(small Cin)");
         {
             GxProf pf(KID_WGRAD_REDUCE, s, 0.0, 4.0 * nblk * mt * 64 * 32);
-            hipLaunchKernelGGL(wgrad_smallcin_reduce_kernel, dim3(Cout), dim3(256), 0, s, (const float*)ws, nblk, Cout,
+            hipLaunchKernelGGL(wgrad_smallcin_reduce_kernel, dim3(Cout), dim3(1024), 0, s, (const float*)ws, nblk, Cout,
                                Cin * 9, dw);
         }
         GX_CHECK_LAUNCH("gx_conv3x3_wgrad(small Cin reduce)");
