@@ -854,3 +854,55 @@ def test_lstm_cell_with_fed_back_input():
     got.square().sum().backward()
     for p, r in zip(dl.parameters(), ref_grads):
         close(p.grad, r, 1e-4, 1e-5, 'lstm cell parameter grad')
+
+
+def test_streamk_weight_gradients_many_layers():
+    """The deferred path launches EVERY queued conv3x3 / transposed-conv weight gradient in one stream-K grid
+    (gx_wgq.hip): queue more (layer, 64x64 channel block) jobs than one launch's job table holds (36), of all three tile
+    widths, both tap classes and ragged channel counts, flush, and compare every layer with the same entry point called
+    on its own (other split points: fp32 round-off) and with PyTorch; flushing the same queue twice gives the same bits."""
+    from genesis_amd import _lib
+    layers = []   # (kind, N, Cin, Cout, H)
+    for i, (N, Cin, Cout, H) in enumerate([(4, 64, 64, 64), (3, 128, 128, 16), (5, 128, 64, 32), (7, 64, 128, 8),
+                                           (2, 96, 40, 32), (6, 128, 128, 8), (3, 128, 128, 16), (2, 64, 64, 64),
+                                           (9, 128, 128, 8), (2, 128, 128, 32)]):
+        layers.append(('c3', N, Cin, Cout, H))
+    for (N, Cin, Cout, H) in [(6, 64, 64, 32), (10, 64, 64, 16), (12, 64, 32, 8), (3, 128, 64, 16)]:
+        layers.append(('dt', N, Cin, Cout, H))
+    data = []
+    for i, (kind, N, Cin, Cout, H) in enumerate(layers):
+        x = rnd(N, Cin, H, H, seed=10 + i).to(DEV)
+        if kind == 'c3':
+            dy = rnd(N, Cout, H, H, seed=50 + i).to(DEV)
+            alone = hip.conv3x3_wgrad(x, dy)
+            ref = torch.nn.grad.conv2d_weight(x.cpu().double(), (Cout, Cin, 3, 3), dy.cpu().double(), padding=1)
+        else:
+            dy = rnd(N, Cout, 2 * H, 2 * H, seed=50 + i).to(DEV)
+            alone = hip.deconv5x5s2_wgrad(x, dy)
+            xr = x.cpu().double()
+            wr = torch.zeros(Cin, Cout, 5, 5, dtype=torch.float64, requires_grad=True)
+            F.conv_transpose2d(xr, wr, None, 2, 2, 1).backward(dy.cpu().double())
+            ref = wr.grad
+        data.append((kind, x, dy, alone, ref))
+
+    def queued():
+        outs = []
+        st = hip.defer_state()
+        st.on = True
+        try:
+            for kind, x, dy, alone, _ in data:
+                out = torch.zeros_like(alone)        # the batched reduce accumulates into a zeroed gradient
+                (hip.conv3x3_wgrad if kind == 'c3' else hip.deconv5x5s2_wgrad)(x, dy, out=out)
+                outs.append(out)
+            assert _lib.query('gx_defer_pending') == 18      # 10 + 2 x 4 layer jobs = 38 channel-block jobs (> 36)
+            hip.defer_flush()
+        finally:
+            st.on = False
+        torch.cuda.synchronize()
+        return outs
+
+    a, b = queued(), queued()
+    for (kind, x, dy, alone, ref), o, o2 in zip(data, a, b):
+        assert torch.equal(o, o2)
+        close(o, ref, rtol=2e-5, atol=1e-6 * float(ref.abs().max()), msg='stream-K %s %s' % (kind, tuple(x.shape)))
+        close(o, alone, rtol=2e-5, atol=1e-6 * float(ref.abs().max()), msg='stream-K vs alone %s' % (tuple(x.shape),))
