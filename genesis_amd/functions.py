@@ -588,7 +588,7 @@ class DirectConvActFn(torch.autograd.Function):
 @ctx_bound
 class BroadcastDecoderFn(torch.autograd.Function):
     """BroadcastDecoder (modules/decoders.py:21-35): z [N, L] -> [N, out, S, S].
-    args: z, coords [1,2,S+2L,S+2L], act, then L x (w [h,cin,3,3], b [h]), out_w [out, h], out_b.
+    args: z, coords [1,2,S+2L,S+2L], act, out_act, then L x (w [h,cin,3,3], b [h]), out_w [out, h], out_b.
     The L VALID 3x3 convs run as 'same' convs on the (S+2L)^2 canvas; the centre crop of the final 1x1 conv equals the
     valid chain exactly (and so do all gradients: positions polluted by the canvas border never reach the crop).
     The spatial broadcast + coordinate concat (modules/blocks.py:104-130) is never materialised: the first conv is
@@ -596,7 +596,9 @@ class BroadcastDecoderFn(torch.autograd.Function):
     remaining convs on the fp32 MFMA tap-conv kernel."""
 
     @staticmethod
-    def forward(ctx, z, coords, act, *params):
+    def forward(ctx, z, coords, act, out_act, *params):
+        """out_act: activation applied to the final 1x1 conv's output (None; 'elu' for BaselineVAE's broadcast decoder,
+        whose Sequential ends in nn.ELU, vae_config.py:54-60)."""
         nl = (len(params) - 2) // 2
         N, L = z.shape
         d = coords.shape[-1]
@@ -615,21 +617,34 @@ class BroadcastDecoderFn(torch.autograd.Function):
             acts.append((h, y))
             h = y
         ow, ob = params[2 * nl], params[2 * nl + 1]
-        full = hip.conv1x1_fwd(h, ow, ob)
-        ctx.acts, ctx.params, ctx.cfg = acts, params, (nl, S, L, act)
+        wide = ow.shape[0] > 8 or out_act is not None      # the small-Cout 1x1 kernel serves <= 8 output channels
+        if wide:
+            full = hip.conv2d_direct_fwd(h, ow.reshape(ow.shape[0], -1, 1, 1), ob, out_act, 1, 0)
+        else:
+            full = hip.conv1x1_fwd(h, ow, ob)
+        ctx.acts, ctx.params, ctx.cfg = acts, params, (nl, S, L, act, out_act, wide)
         ctx.bc = (z, rowc, colc)
+        ctx.full = full if wide else None
         return full[:, :, nl:nl + S, nl:nl + S].contiguous()
 
     @staticmethod
     def backward(ctx, g):
-        nl, S, L, act = ctx.cfg
+        nl, S, L, act, out_act, wide = ctx.cfg
         params = ctx.params
         z, rowc, colc = ctx.bc
         ow, ob = params[2 * nl], params[2 * nl + 1]
         last = ctx.acts[-1][1]
         gfull = torch.zeros(last.shape[0], ow.shape[0], last.shape[2], last.shape[3], device=g.device)
         gfull[:, :, nl:nl + S, nl:nl + S] = g
-        da, dow, dob, _ = hip.conv1x1_bwd(last, gfull, ow, ob)
+        if wide:
+            gow, gob = _gout(ow), _gout(ob)
+            dyo, dob = hip.bias_act_bwd(ctx.full, gfull, out_act, True, gob)
+            ow4 = ow.reshape(ow.shape[0], -1, 1, 1)
+            dow = hip.conv2d_direct_wgrad(last, dyo, 1, 1, 0, out=None if gow is None else gow.view(ow4.shape))
+            da = hip.conv2d_direct_dgrad(dyo, ow4, last.shape[2], last.shape[3], 1, 0)
+            dow, dob = _ret(gow, dow.view(ow.shape)), _ret(gob, dob)
+        else:
+            da, dow, dob, _ = hip.conv1x1_bwd(last, gfull, ow, ob)
         grads = [None] * len(params)
         grads[2 * nl], grads[2 * nl + 1] = dow, dob
         dz = None
@@ -645,7 +660,7 @@ class BroadcastDecoderFn(torch.autograd.Function):
                 dw = hip.conv3x3_wgrad(h, dy, out=gw)
                 da = hip.conv3x3_dgrad(dy, w)
             grads[2 * l], grads[2 * l + 1] = _ret(gw, dw), _ret(gb, db)
-        return (dz, None, None) + tuple(grads)
+        return (dz, None, None, None) + tuple(grads)
 
 
 @ctx_bound

@@ -150,7 +150,7 @@ class Genesis(nn.Module):
             eps_c = torch.randn(K * B, Lc, device=x.device)
         z_c = mu_c + sig_c * eps_c
         dm = self.comp_vae.decoder_module
-        dec = fn.BroadcastDecoderFn.apply(z_c, self._canvas_coords(x.device), 'elu', *dm.flat_params())   # [K*B,3,S,S]
+        dec = fn.BroadcastDecoderFn.apply(z_c, self._canvas_coords(x.device), 'elu', None, *dm.flat_params())   # [K*B,3,S,S]
         err, recon, x_r = fn.MixtureWFn.apply(x, dec, log_m, K, self._std12[0], self._std12[1], bool(self.pixel_bound))
         losses = AttrDict()
         losses['err'] = err

@@ -127,7 +127,7 @@ class MONet(nn.Module):
 
     def _decode(self, z):
         dm = self.comp_vae.decoder_module
-        return fn.BroadcastDecoderFn.apply(z, self._canvas_coords(z.device), 'relu', *dm.flat_params())
+        return fn.BroadcastDecoderFn.apply(z, self._canvas_coords(z.device), 'relu', None, *dm.flat_params())
 
     def _attention(self, x):
         """SimpleSBP.forward, modules/attention.py:31-51."""

@@ -36,9 +36,16 @@ class BaselineVAE(nn.Module):
         self.pixel_std = _cfg_get(cfg, 'pixel_std', 0.7)
         self.pixel_bound = _cfg_get(cfg, 'pixel_bound', True)
         self.debug = _cfg_get(cfg, 'debug', False)
-        if _cfg_get(cfg, 'broadcast_decoder', False):
-            raise NotImplementedError('broadcast_decoder=True (non-default, vae_config.py:53-61) is not on the HIP path')
+        self.img_size = cfg.img_size
         self.vae = SylvesterVAE(self.ldim, [3, cfg.img_size, cfg.img_size], 3)
+        self.broadcast_decoder = bool(_cfg_get(cfg, 'broadcast_decoder', False))
+        if self.broadcast_decoder:
+            # vae_config.py:53-61: the deconv decoder is REPLACED (after it was constructed: same RNG consumption) by
+            # Flatten -> BroadcastDecoder(ldim -> 64, h 64, 4 layers, ELU) -> ELU, and p_x_mean by a 64 -> 3 1x1 conv
+            from genesis_amd.monet_config import _BroadcastDecoderParams
+            self.vae.p_x_nn = nn.Sequential(nn.Flatten(), _BroadcastDecoderParams(self.ldim, 64, 64, 4), nn.ELU())
+            self.vae.p_x_mean = nn.Conv2d(64, 3, 1, 1, 0)
+            self._coords = {}
 
     def forward(self, x, eps=None):
         """x [B,3,S,S] on the GPU; eps [B, ldim] injects the rsample noise (VAE.py:131-132)."""
@@ -51,17 +58,31 @@ class BaselineVAE(nn.Module):
         if eps is None:
             eps = torch.randn_like(mu)
         z = mu + sigma * eps
-        x_mean = self.vae.decode(z)
+        x_mean = self._decode(z)
         recon = torch.sigmoid(x_mean) if self.pixel_bound else x_mean
         err = -_normal_log_prob(x, recon, float(self.pixel_std)).sum(dim=(1, 2, 3))
         kl = (_normal_log_prob(z, mu, sigma) - _normal_log_prob(z, 0., 1.)).sum(dim=1)
         stats = AttrDict(x=x_mean, mu=mu, sigma=sigma, z=z)
         return recon, AttrDict(err=err, kl_l=kl), stats, None, None
 
+    def _decode(self, z):
+        if not self.broadcast_decoder:
+            return self.vae.decode(z)
+        from genesis_amd import functions as fn
+        from genesis_amd.genesisv2_config import pixel_coords
+        dm = self.vae.p_x_nn[1]
+        key = str(z.device)
+        if key not in self._coords:
+            self._coords[key] = pixel_coords(self.img_size + 2 * dm.num_layers).contiguous().to(z.device)
+        # spatial broadcast + coordinates + 4 valid 3x3 convs (ELU) on the canvas-free HIP path; the decoder's 1x1 conv
+        # and the Sequential's trailing nn.ELU are one launch (out_act)
+        h = fn.BroadcastDecoderFn.apply(z, self._coords[key], 'elu', 'elu', *dm.flat_params())
+        return fn.Conv1x1Fn.apply(h, self.vae.p_x_mean.weight, self.vae.p_x_mean.bias)
+
     @torch.no_grad()
     def sample(self, batch_size, *args, **kwargs):
         z = torch.randn(batch_size, self.ldim, device=self.vae.p_x_mean.weight.device)
-        x = self.vae.decode(z)
+        x = self._decode(z)
         if self.pixel_bound:
             x = torch.sigmoid(x)
         return x, AttrDict(z=z)

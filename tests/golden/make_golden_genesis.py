@@ -17,7 +17,8 @@ from oracle import ref_import as R  # noqa: E402
 from oracle import genesis_oracle as GO  # noqa: E402
 from oracle import vae_oracle as VO  # noqa: E402
 
-VAE_CASES = {'tiny': (dict(img_size=32, latent_dimension=16), 2, 51, 61), 'cfg1': (dict(img_size=64), 2, 52, 62)}
+VAE_CASES = {'tiny': (dict(img_size=32, latent_dimension=16), 2, 51, 61), 'cfg1': (dict(img_size=64), 2, 52, 62),
+             'tiny_bcast': (dict(img_size=32, latent_dimension=16, broadcast_decoder=True), 2, 56, 66)}
 GEN_CASES = {'tiny': (dict(K_steps=3, img_size=32, attention_latents=16, comp_ldim=8), 2, 53, 63),
              'tiny_in': (dict(K_steps=3, img_size=32, attention_latents=16, comp_ldim=8, enc_norm='in', dec_norm='in'), 3, 54, 64),
              'cfg3': (dict(K_steps=7, img_size=64), 2, 55, 65)}
@@ -136,10 +137,10 @@ def run_gen(name, mods):
 
 if __name__ == '__main__':
     mods = R.import_reference()
-    which = sys.argv[1:] or ['vae', 'genesis']
-    if 'vae' in which:
-        for n in VAE_CASES:
+    which = sys.argv[1:] or ['vae', 'genesis']          # 'vae', 'genesis', or single cases 'vae:tiny_bcast'
+    for n in VAE_CASES:
+        if 'vae' in which or 'vae:' + n in which:
             run_vae(n, mods)
-    if 'genesis' in which:
-        for n in GEN_CASES:
+    for n in GEN_CASES:
+        if 'genesis' in which or 'genesis:' + n in which:
             run_gen(n, mods)
