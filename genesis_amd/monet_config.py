@@ -105,8 +105,8 @@ class MONet(nn.Module):
         self.mckl = _cfg_get(cfg, 'montecarlo_kl', True)
         self.debug = _cfg_get(cfg, 'debug', False)
         self.pixel_bound = _cfg_get(cfg, 'pixel_bound', True)
-        if self.prior_mode != 'softmax' or not self.mckl:
-            raise NotImplementedError('MONet HIP path: prior_mode=softmax and montecarlo_kl=True (the defaults) only')
+        if self.prior_mode not in ('softmax', 'scope'):
+            raise ValueError('No valid prior mode.')          # monet_config.py:154-155
         filter_start = _cfg_get(cfg, 'filter_start', 32)
         core = _UNetParams(int(np.log2(cfg.img_size) - 1), cfg.img_size, filter_start, 4, 1, norm='in',
                            keep_final_conv=True)
@@ -163,14 +163,23 @@ class MONet(nn.Module):
         z = mu + sigma * eps
         dec = self._decode(z)                                          # [K*B,4,H,W]
         err, recon, x_r = fn.MixtureWFn.apply(x, dec, log_m, K, self._std12[0], self._std12[1], bool(self.pixel_bound))
-        # reconstructed masks: log_softmax over K of the logit channel (monet_config.py:137-139)
-        log_m_r = F.log_softmax(dec[:, 3:].reshape(K, B, 1, *x.shape[2:]), dim=0)
+        # reconstructed masks (MONet.get_mask_recon_stack, monet_config.py:136-155): log_softmax over K of the logit
+        # channel, or (prior_mode 'scope') a stick-breaking pass over the K logits whose last mask is the remaining scope
+        logits = dec[:, 3:].reshape(K, B, 1, *x.shape[2:])
+        if self.prior_mode == 'softmax':
+            log_m_r = F.log_softmax(logits, dim=0)
+        else:
+            log_m_r, _ = fn.SBPScanFn.apply(logits, None, True)
         losses = AttrDict()
         losses['err'] = err
         # Categorical KL between attention and reconstructed masks (monet_config.py:157-170)
         losses['kl_m'] = fn.CategoricalKLFn.apply(log_m, log_m_r)
-        # MC KL of the component latents against N(0,1) (utils/misc.py:238-255)
-        kl = (_normal_log_prob(z, mu, sigma) - _normal_log_prob(z, 0., 1.)).sum(1)      # [K*B]
+        # KL of the component latents against N(0,1) (utils/misc.py:238-255): Monte-Carlo estimate at z, or
+        # (montecarlo_kl off) the closed form of kl_divergence(Normal(mu, sigma), Normal(0, 1))
+        if self.mckl:
+            kl = (_normal_log_prob(z, mu, sigma) - _normal_log_prob(z, 0., 1.)).sum(1)      # [K*B]
+        else:
+            kl = (-torch.log(sigma) + 0.5 * (sigma * sigma + mu * mu) - 0.5).sum(1)
         losses['kl_l_k'] = list(kl.view(K, B).unbind(0))
         x_r_k = list(x_r.unbind(0))
         stats = AttrDict(recon=recon, log_m_k=log_m_k, log_s_k=log_s_k, x_r_k=x_r_k,
@@ -192,6 +201,10 @@ class MONet(nn.Module):
         dec = self._decode(z)
         x0 = torch.zeros(batch_size, 3, self.img_size, self.img_size, device=dev)
         _, gen_image, x_r, log_m_r = hip.mixture_fwd(x0, dec.contiguous(), K, 0.7, bool(self.pixel_bound))
+        if self.prior_mode == 'scope':
+            logits = dec[:, 3:].reshape(K, batch_size, 1, self.img_size, self.img_size).contiguous()
+            log_m_r, _ = hip.sbp_scan_fwd(logits, None, True)
+            gen_image = (log_m_r.exp() * x_r).sum(0)
         x_r_k, log_m_r_k = list(x_r.unbind(0)), list(log_m_r.unbind(0))
         stats = AttrDict(gen_image=gen_image, x_k=x_r_k, log_m_k=log_m_r_k,
                          mx_k=[x * m.exp() for x, m in zip(x_r_k, log_m_r_k)])

@@ -87,14 +87,30 @@ def monet_forward(p, x, cfg, eps=None):
     if cfg.get('pixel_bound', True):
         x_r_k = [torch.sigmoid(t) for t in x_r_k]
     recon = (torch.stack(log_m_k, 4).exp() * torch.stack(x_r_k, 4)).sum(4)
-    log_m_r = F.log_softmax(torch.stack(logits, 4), 4)
-    log_m_r_k = [log_m_r[..., k] for k in range(K)]
+    if cfg.get('prior_mode', 'softmax') == 'softmax':
+        log_m_r = F.log_softmax(torch.stack(logits, 4), 4)
+        log_m_r_k = [log_m_r[..., k] for k in range(K)]
+    else:
+        # prior_mode == 'scope' (monet_config.py:141-153): stick-breaking over the K mask logits, last = remaining scope
+        log_m_r_k = []
+        log_s = torch.zeros_like(logits[0])
+        for step, lg in enumerate(logits):
+            if step == K - 1:
+                log_m_r_k.append(log_s)
+            else:
+                log_m_r_k.append(log_s + F.logsigmoid(lg))
+                log_s = log_s + F.logsigmoid(-lg)
     std = cfg.get('pixel_std2', 0.7) * torch.ones(1, 1, 1, 1, K, dtype=x.dtype)
     std[0, 0, 0, 0, 0] = cfg.get('pixel_std1', 0.7)
     losses = {'err': V.x_loss(x, log_m_k, x_r_k, std), 'kl_m': kl_m_loss(log_m_k, log_m_r_k)}
     mu_k, sigma_k, z_k = mu.chunk(K, 0), sigma.chunk(K, 0), z.chunk(K, 0)
-    losses['kl_l_k'] = [(V.normal_log_prob(zz, m, s) - V.normal_log_prob(zz, 0.0, 1.0)).sum(1)
-                        for zz, m, s in zip(z_k, mu_k, sigma_k)]
+    if cfg.get('montecarlo_kl', True):
+        losses['kl_l_k'] = [(V.normal_log_prob(zz, m, s) - V.normal_log_prob(zz, 0.0, 1.0)).sum(1)
+                            for zz, m, s in zip(z_k, mu_k, sigma_k)]
+    else:
+        # utils/misc.py:247: torch.distributions.kl_divergence(Normal(mu, sigma), Normal(0, 1)), summed over the latent
+        # dimension like the Monte-Carlo estimate (monet_config.py:113)
+        losses['kl_l_k'] = [(-torch.log(s) + 0.5 * (s * s + m * m) - 0.5).sum(1) for m, s in zip(mu_k, sigma_k)]
     stats = dict(recon=recon, log_m_k=log_m_k, log_s_k=log_s_k, x_r_k=x_r_k, log_m_r_k=log_m_r_k)
     comp_stats = dict(mu_k=list(mu_k), sigma_k=list(sigma_k), z_k=list(z_k))
     return recon, losses, stats, {}, comp_stats

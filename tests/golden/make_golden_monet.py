@@ -21,6 +21,7 @@ CASES = {
     'tiny': (dict(K_steps=3, img_size=32), 2, 31, 41, True),
     'tiny_k4': (dict(K_steps=4, img_size=32, filter_start=16, comp_enc_channels=16, comp_dec_channels=16, comp_ldim=8), 3, 32, 42, False),
     'cfg4': (dict(K_steps=7, img_size=64), 2, 33, 43, False),
+    'tiny_scope': (dict(K_steps=4, img_size=32, prior_mode='scope', montecarlo_kl=False), 2, 34, 44, False),
 }
 
 

@@ -12,7 +12,7 @@ from oracle import monet_oracle as M
 from oracle import ref_import as R
 
 GOLDEN = osp.join(osp.dirname(osp.abspath(__file__)), 'golden')
-CASES = ['tiny', 'tiny_k4', 'cfg4']
+CASES = ['tiny', 'tiny_k4', 'cfg4', 'tiny_scope']
 
 
 class MonetGolden(object):
