@@ -21,7 +21,7 @@ from forge import flags  # noqa: E402
 
 from genesis_amd import functions as fn  # noqa: E402
 from genesis_amd.genesisv2_config import _cfg_get, _normal_log_prob, pixel_coords  # noqa: E402
-from genesis_amd.monet_config import _ComponentVAEParams  # noqa: E402
+from genesis_amd.monet_config import _BroadcastDecoderParams, _ComponentVAEParams  # noqa: E402
 from genesis_amd.sylvester import SylvesterVAE  # noqa: E402
 
 # models/genesis_config.py:33-52
@@ -68,20 +68,35 @@ class Genesis(nn.Module):
         self.ldim = _cfg_get(cfg, 'attention_latents', 64)
         self.pixel_bound = _cfg_get(cfg, 'pixel_bound', True)
         self.debug = _cfg_get(cfg, 'debug', False)
-        if not (self.two_stage and self.autoreg_prior and self.comp_prior and self.K_steps > 1) or \
-                _cfg_get(cfg, 'comp_symmetric', False) or not _cfg_get(cfg, 'montecarlo_kl', True):
-            raise NotImplementedError('Genesis HIP path: default flags only (two_stage, autoreg_prior, comp_prior, '
-                                      'comp_symmetric=False, montecarlo_kl, K_steps > 1)')
+        # genesis_config.py:71-75: the component prior exists only in the two-stage model
+        self.comp_prior = bool(self.two_stage and self.K_steps > 1 and self.comp_prior)
+        if not _cfg_get(cfg, 'montecarlo_kl', True):
+            raise AssertionError('ALWAYS use MC for estimating KL')            # genesis_config.py:82
+        if not self.autoreg_prior:
+            # the reference's forward passes self.prior_lstm unconditionally (genesis_config.py:214-216): with
+            # autoreg_prior off that attribute does not exist and its first forward raises
+            raise AttributeError("'Genesis' object has no attribute 'prior_lstm' (autoreg_prior=False is not runnable "
+                                 'in the reference either)')
+        if self.K_steps <= 1 or _cfg_get(cfg, 'comp_symmetric', False):
+            raise NotImplementedError('Genesis HIP path: K_steps > 1 and comp_symmetric=False')
         att_core = SylvesterVAE(self.ldim, [3, cfg.img_size, cfg.img_size], 1, _cfg_get(cfg, 'enc_norm', 'bn'),
                                 _cfg_get(cfg, 'dec_norm', 'bn'))
         self.att_steps = self.K_steps
         self.att_process = _LatentSBPParams(att_core)
-        self.comp_vae = _ComponentVAEParams(cfg, nout=3)
-        self.comp_vae.pixel_bound = self.pixel_bound
+        if self.two_stage:
+            self.comp_vae = _ComponentVAEParams(cfg, nout=3)
+            self.comp_vae.pixel_bound = self.pixel_bound
+            self._dec_layers = self.comp_vae.decoder_module.num_layers
+        else:
+            # one stage (genesis_config.py:124-129): components decoded from the attention latents
+            self.decoder = _BroadcastDecoderParams(self.ldim, 3, _cfg_get(cfg, 'comp_dec_channels', 32),
+                                                   _cfg_get(cfg, 'comp_dec_layers', 4))
+            self._dec_layers = self.decoder.num_layers
         self.prior_lstm = nn.LSTM(self.ldim, 256)
         self.prior_linear = nn.Linear(256, 2 * self.ldim)
-        self.prior_mlp = nn.Sequential(nn.Linear(self.ldim, 256), nn.ELU(), nn.Linear(256, 256), nn.ELU(),
-                                       nn.Linear(256, 2 * cfg.comp_ldim))
+        if self.comp_prior:
+            self.prior_mlp = nn.Sequential(nn.Linear(self.ldim, 256), nn.ELU(), nn.Linear(256, 256), nn.ELU(),
+                                           nn.Linear(256, 2 * cfg.comp_ldim))
         std = _cfg_get(cfg, 'pixel_std2', 0.7) * torch.ones(1, 1, 1, 1, self.K_steps)
         std[0, 0, 0, 0, 0] = _cfg_get(cfg, 'pixel_std1', 0.7)
         self.register_buffer('std', std)
@@ -91,7 +106,7 @@ class Genesis(nn.Module):
     def _canvas_coords(self, device):
         key = str(device)
         if key not in self._coords:
-            d = self.img_size + 2 * self.comp_vae.decoder_module.num_layers
+            d = self.img_size + 2 * self._dec_layers
             self._coords[key] = pixel_coords(d).contiguous().to(device)
         return self._coords[key]
 
@@ -132,54 +147,68 @@ class Genesis(nn.Module):
             from genesis_amd._lib import GenesisHipError
             raise GenesisHipError('Genesis: the HIP path needs device tensors; there is no CPU fallback')
         B, K = x.shape[0], self.K_steps
-        Lc = self.comp_vae.ldim
         if eps_m is None:
             eps_m = list(torch.randn(K, B, self.ldim, device=x.device).unbind(0))
         log_m_k, log_s_k, mu_k, sigma_k, z_k = self._attention(x, eps_m)
         log_m = torch.stack(log_m_k, 0)
-        # --- ComponentVAE (ELU), slot-major batch, mask as first channel
-        inp = torch.cat((log_m.flatten(0, 1), x.repeat(K, 1, 1, 1)), 1)
-        em = self.comp_vae.encoder_module.module
-        h = inp
-        for i in (0, 2, 4, 6):
-            h = fn.DirectConvActFn.apply(h, em[i].weight, em[i].bias, 2, 1, 'elu')
-        h = F.elu(fn.linear(h.flatten(1), em[9].weight, em[9].bias))
-        mu_c, sig_ps = fn.linear(h, em[11].weight, em[11].bias).chunk(2, dim=1)
-        sig_c = F.softplus(sig_ps + 0.5) + 1e-8
-        if eps_c is None:
-            eps_c = torch.randn(K * B, Lc, device=x.device)
-        z_c = mu_c + sig_c * eps_c
-        dm = self.comp_vae.decoder_module
-        dec = fn.BroadcastDecoderFn.apply(z_c, self._canvas_coords(x.device), 'elu', None, *dm.flat_params())   # [K*B,3,S,S]
+        z = torch.stack(z_k, 0)
+        if self.two_stage:
+            # --- ComponentVAE (ELU), slot-major batch, mask as first channel
+            Lc = self.comp_vae.ldim
+            inp = torch.cat((log_m.flatten(0, 1), x.repeat(K, 1, 1, 1)), 1)
+            em = self.comp_vae.encoder_module.module
+            h = inp
+            for i in (0, 2, 4, 6):
+                h = fn.DirectConvActFn.apply(h, em[i].weight, em[i].bias, 2, 1, 'elu')
+            h = F.elu(fn.linear(h.flatten(1), em[9].weight, em[9].bias))
+            mu_c, sig_ps = fn.linear(h, em[11].weight, em[11].bias).chunk(2, dim=1)
+            sig_c = F.softplus(sig_ps + 0.5) + 1e-8
+            if eps_c is None:
+                eps_c = torch.randn(K * B, Lc, device=x.device)
+            z_c = mu_c + sig_c * eps_c
+            dm, z_dec = self.comp_vae.decoder_module, z_c
+        else:
+            # --- one stage (genesis_config.py:183-191): the components come from the attention latents
+            dm, z_dec = self.decoder, z.flatten(0, 1)
+        dec = fn.BroadcastDecoderFn.apply(z_dec, self._canvas_coords(x.device), 'elu', None, *dm.flat_params())   # [K*B,3,S,S]
         err, recon, x_r = fn.MixtureWFn.apply(x, dec, log_m, K, self._std12[0], self._std12[1], bool(self.pixel_bound))
         losses = AttrDict()
         losses['err'] = err
         # -- Attention mask KL (mask_latent_loss, genesis_config.py:288-343)
-        z = torch.stack(z_k, 0)
         mu, sigma = torch.stack(mu_k, 0), torch.stack(sigma_k, 0)
         mu_p, sig_p = self._prior_m(z)
         log_q = _normal_log_prob(z, mu, sigma).sum(2)
         log_p = torch.cat((_normal_log_prob(z[:1], 0., 1.).sum(2), _normal_log_prob(z[1:], mu_p, sig_p).sum(2)), 0)
         losses['kl_m_k'] = list((log_q - log_p).unbind(0))
-        # -- Component KL with the learned component prior (genesis_config.py:229-247)
-        pm_ = self.prior_mlp
-        o = F.elu(fn.linear(z.flatten(0, 1), pm_[0].weight, pm_[0].bias))
-        o = F.elu(fn.linear(o, pm_[2].weight, pm_[2].bias))
-        o = fn.linear(o, pm_[4].weight, pm_[4].bias)              # [K*B, 2*Lc], slot-major like z_c
-        pm, ps = o.chunk(2, dim=1)
-        pm, ps = torch.tanh(pm), torch.sigmoid(ps + 4.0) + 1e-4
-        kl_l = (_normal_log_prob(z_c, mu_c, sig_c) - _normal_log_prob(z_c, pm, ps)).sum(1)
-        losses['kl_l_k'] = list(kl_l.view(K, B).unbind(0))
+        comp_stats = None
+        if self.two_stage:
+            if self.comp_prior:
+                # -- Component KL with the learned component prior (genesis_config.py:229-247)
+                pm_ = self.prior_mlp
+                o = F.elu(fn.linear(z.flatten(0, 1), pm_[0].weight, pm_[0].bias))
+                o = F.elu(fn.linear(o, pm_[2].weight, pm_[2].bias))
+                o = fn.linear(o, pm_[4].weight, pm_[4].bias)              # [K*B, 2*Lc], slot-major like z_c
+                pm, ps = o.chunk(2, dim=1)
+                pm, ps = torch.tanh(pm), torch.sigmoid(ps + 4.0) + 1e-4
+                kl_l = (_normal_log_prob(z_c, mu_c, sig_c) - _normal_log_prob(z_c, pm, ps)).sum(1)
+            else:
+                # -- N(0, 1) component prior (genesis_config.py:248-254)
+                kl_l = (_normal_log_prob(z_c, mu_c, sig_c) - _normal_log_prob(z_c, 0., 1.)).sum(1)
+            losses['kl_l_k'] = list(kl_l.view(K, B).unbind(0))
+            comp_stats = AttrDict(mu_k=mu_c.chunk(K, 0), sigma_k=sig_c.chunk(K, 0), z_k=z_c.chunk(K, 0))
+            if self.comp_prior:
+                comp_stats['pmu_k'], comp_stats['psigma_k'] = pm.chunk(K, 0), ps.chunk(K, 0)
         x_r_k = list(x_r.unbind(0))
         stats = AttrDict(recon=recon, log_m_k=log_m_k, log_s_k=log_s_k, x_r_k=x_r_k,
                          mx_r_k=list((x_r * log_m.exp()).unbind(0)))
         att_stats = AttrDict(mu_k=mu_k, sigma_k=sigma_k, z_k=z_k, pmu_k=[torch.zeros_like(mu_k[0])] + list(mu_p.unbind(0)),
                              psigma_k=[torch.ones_like(mu_k[0])] + list(sig_p.unbind(0)))
-        comp_stats = AttrDict(mu_k=mu_c.chunk(K, 0), sigma_k=sig_c.chunk(K, 0), z_k=z_c.chunk(K, 0),
-                              pmu_k=pm.chunk(K, 0), psigma_k=ps.chunk(K, 0))
         return recon, losses, stats, att_stats, comp_stats
 
     def get_features(self, image_batch):
+        """genesis_config.py:427-436."""
         with torch.no_grad():
-            _, _, _, _, comp_stats = self.forward(image_batch)
-            return torch.cat(comp_stats.z_k, dim=1)
+            _, _, _, att_stats, comp_stats = self.forward(image_batch)
+        if self.two_stage:
+            return torch.cat([*att_stats.z_k[:self.K_steps - 1], *comp_stats.z_k], dim=1)
+        return torch.cat(list(att_stats.z_k), dim=1)

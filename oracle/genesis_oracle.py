@@ -1,7 +1,9 @@
 """ORACLE (test infrastructure) -- GENESIS (v1), BASELINE config 3: models/genesis_config.py:145-271 (forward),
 modules/attention.py:77-133 (LatentSBP), modules/component_vae.py (ComponentVAE with ELU, nout=3, pixel_bound),
 models/genesis_config.py:288-343 (mask_latent_loss), :229-247 (component prior MLP).  Default flags: two_stage,
-autoreg_prior, comp_prior, enc_norm = dec_norm = 'bn' (training-mode batch statistics over the K*B decoder batch)."""
+autoreg_prior, comp_prior, enc_norm = dec_norm = 'bn' (training-mode batch statistics over the K*B decoder batch);
+also comp_prior=False (N(0,1) component prior, :248-254) and two_stage=False (components decoded from the ATTENTION
+latents by a BroadcastDecoder, :183-191; no component KL)."""
 import math
 
 import torch
@@ -69,6 +71,20 @@ def genesis_forward(p, x, cfg, eps_m=None, eps_c=None):
     if eps_m is None:
         eps_m = [torch.normal(torch.zeros(B, L), torch.ones(B, L)) for _ in range(K)]
     log_m_k, log_s_k, mu_k, sigma_k, z_k = latent_sbp(p, x, K, cfg, eps_m)
+    std = cfg.get('pixel_std2', 0.7) * torch.ones(1, 1, 1, 1, K, dtype=x.dtype)
+    std[0, 0, 0, 0, 0] = cfg.get('pixel_std1', 0.7)
+    att_stats = dict(mu_k=mu_k, sigma_k=sigma_k, z_k=z_k)
+    if not cfg.get('two_stage', True):
+        # one stage (genesis_config.py:183-191): x_r_k from the attention latents through `decoder`
+        dec = M.broadcast_decoder(p, torch.cat(z_k, 0), S_, cfg['comp_dec_layers'], act=F.elu, prefix='decoder.seq')
+        if cfg.get('pixel_bound', True):
+            dec = torch.sigmoid(dec)
+        x_r_k = list(dec.chunk(K, 0))
+        recon = (torch.stack(log_m_k, 4).exp() * torch.stack(x_r_k, 4)).sum(4)
+        losses = {'err': V.x_loss(x, log_m_k, x_r_k, std)}
+        losses['kl_m_k'] = V.mask_latent_loss(p, mu_k, sigma_k, z_k, cfg.get('autoreg_prior', True))
+        stats = dict(recon=recon, log_m_k=log_m_k, log_s_k=log_s_k, x_r_k=x_r_k)
+        return recon, losses, stats, att_stats, None
     # ComponentVAE (ELU)
     inp = torch.cat((torch.cat(log_m_k, 0), x.repeat(K, 1, 1, 1)), 1)
     enc = M.comp_encoder(p, inp, act=F.elu)
@@ -82,8 +98,6 @@ def genesis_forward(p, x, cfg, eps_m=None, eps_c=None):
         dec = torch.sigmoid(dec)                         # comp_vae.pixel_bound (component_vae.py:89-93)
     x_r_k = list(dec.chunk(K, 0))
     recon = (torch.stack(log_m_k, 4).exp() * torch.stack(x_r_k, 4)).sum(4)
-    std = cfg.get('pixel_std2', 0.7) * torch.ones(1, 1, 1, 1, K, dtype=x.dtype)
-    std[0, 0, 0, 0, 0] = cfg.get('pixel_std1', 0.7)
     losses = {'err': V.x_loss(x, log_m_k, x_r_k, std)}
     losses['kl_m_k'] = V.mask_latent_loss(p, mu_k, sigma_k, z_k, cfg.get('autoreg_prior', True))
     mu_ck, sig_ck, z_ck = mu_c.chunk(K, 0), sig_c.chunk(K, 0), z_c.chunk(K, 0)
@@ -100,7 +114,6 @@ def genesis_forward(p, x, cfg, eps_m=None, eps_c=None):
         kl_l_k.append((V.normal_log_prob(z_ck[k], mu_ck[k], sig_ck[k]) - V.normal_log_prob(z_ck[k], pm, ps)).sum(1))
     losses['kl_l_k'] = kl_l_k
     stats = dict(recon=recon, log_m_k=log_m_k, log_s_k=log_s_k, x_r_k=x_r_k)
-    att_stats = dict(mu_k=mu_k, sigma_k=sigma_k, z_k=z_k)
     comp_stats = dict(mu_k=list(mu_ck), sigma_k=list(sig_ck), z_k=list(z_ck))
     return recon, losses, stats, att_stats, comp_stats
 
@@ -109,7 +122,7 @@ def aggregate_losses(losses):
     """train.py:226-242: kl_m from the kl_m_k list, kl_l from the kl_l_k list."""
     err = losses['err'].mean(0)
     kl_m = torch.stack(losses['kl_m_k'], dim=1).mean(0).sum()
-    kl_l = torch.stack(losses['kl_l_k'], dim=1).mean(0).sum()
+    kl_l = torch.stack(losses['kl_l_k'], dim=1).mean(0).sum() if 'kl_l_k' in losses else torch.zeros(())
     return err, kl_l, kl_m
 
 
@@ -128,8 +141,17 @@ def param_shapes(cfg):
     sh['att_process.linear.weight'] = ((2 * L, H), f32)
     sh['att_process.linear.bias'] = ((2 * L,), f32)
     mon = M.param_shapes(dict(cfg, filter_start=32))
+    two_stage = cfg.get('two_stage', True)
+    if not two_stage:
+        # `decoder` = BroadcastDecoder(ldim -> 3), registered where comp_vae would be (genesis_config.py:124-129)
+        c, nl = cfg['comp_dec_channels'], cfg['comp_dec_layers']
+        for l in range(nl):
+            sh['decoder.seq.%d.weight' % (1 + 2 * l)] = ((c, (L + 2) if l == 0 else c, 3, 3), f32)
+            sh['decoder.seq.%d.bias' % (1 + 2 * l)] = ((c,), f32)
+        sh['decoder.seq.%d.weight' % (1 + 2 * nl)] = ((3, c, 1, 1), f32)
+        sh['decoder.seq.%d.bias' % (1 + 2 * nl)] = ((3,), f32)
     for k, v in mon.items():
-        if k.startswith('comp_vae.'):
+        if two_stage and k.startswith('comp_vae.'):
             if k.endswith('decoder_module.seq.%d.weight' % (1 + 2 * cfg['comp_dec_layers'])):
                 v = ((3,) + v[0][1:], v[1])
             if k.endswith('decoder_module.seq.%d.bias' % (1 + 2 * cfg['comp_dec_layers'])):
@@ -141,9 +163,10 @@ def param_shapes(cfg):
     sh['prior_lstm.bias_hh_l0'] = ((1024,), f32)
     sh['prior_linear.weight'] = ((2 * L, 256), f32)
     sh['prior_linear.bias'] = ((2 * L,), f32)
-    for j, (o, i_) in zip((0, 2, 4), ((256, L), (256, 256), (2 * Lc, 256))):
-        sh['prior_mlp.%d.weight' % j] = ((o, i_), f32)
-        sh['prior_mlp.%d.bias' % j] = ((o,), f32)
+    if two_stage and cfg.get('comp_prior', True):
+        for j, (o, i_) in zip((0, 2, 4), ((256, L), (256, 256), (2 * Lc, 256))):
+            sh['prior_mlp.%d.weight' % j] = ((o, i_), f32)
+            sh['prior_mlp.%d.bias' % j] = ((o,), f32)
     return sh
 
 

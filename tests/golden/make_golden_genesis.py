@@ -21,7 +21,9 @@ VAE_CASES = {'tiny': (dict(img_size=32, latent_dimension=16), 2, 51, 61), 'cfg1'
              'tiny_bcast': (dict(img_size=32, latent_dimension=16, broadcast_decoder=True), 2, 56, 66)}
 GEN_CASES = {'tiny': (dict(K_steps=3, img_size=32, attention_latents=16, comp_ldim=8), 2, 53, 63),
              'tiny_in': (dict(K_steps=3, img_size=32, attention_latents=16, comp_ldim=8, enc_norm='in', dec_norm='in'), 3, 54, 64),
-             'cfg3': (dict(K_steps=7, img_size=64), 2, 55, 65)}
+             'cfg3': (dict(K_steps=7, img_size=64), 2, 55, 65),
+             'tiny_noprior': (dict(K_steps=3, img_size=32, attention_latents=16, comp_ldim=8, comp_prior=False), 2, 57, 67),
+             'tiny_onestage': (dict(K_steps=3, img_size=32, attention_latents=16, comp_ldim=8, two_stage=False), 2, 58, 68)}
 
 
 def replay(seed, shapes):
@@ -114,25 +116,35 @@ def run_gen(name, mods):
     x = T.make_input(xseed, B, S)
     out = base(cfgd, B, xseed, nseed, sd)
     T.pack_summary('in/x', x, out)
-    noise = replay(nseed, [(B, L)] * K + [(K * B, Lc)])
+    two = cfgd.get('two_stage', True)
+    noise = replay(nseed, [(B, L)] * K + ([(K * B, Lc)] if two else []))
     T.pack_summary('in/eps_m', torch.stack(noise[:K]), out)
-    T.pack_summary('in/eps_c', noise[K], out)
+    if two:
+        T.pack_summary('in/eps_c', noise[K], out)
     torch.manual_seed(nseed)
     recon, losses, stats, att, comp = model(x)
     assert torch.allclose(att.mu_k[1] + att.sigma_k[1] * noise[1], att.z_k[1], atol=1e-6), 'noise replay'
-    assert torch.allclose(torch.cat(list(comp.mu_k)) + torch.cat(list(comp.sigma_k)) * noise[K], torch.cat(list(comp.z_k)), atol=1e-6)
+    if two:
+        assert torch.allclose(torch.cat(list(comp.mu_k)) + torch.cat(list(comp.sigma_k)) * noise[K], torch.cat(list(comp.z_k)), atol=1e-6)
+    else:
+        assert comp is None and 'kl_l_k' not in losses
     model.load_state_dict(sd)     # undo the BatchNorm running-stat update of this forward
 
     def losses_fn(m, seed):
         torch.manual_seed(seed)
         _, l, _, _, _ = m(x)
-        return l['err'].mean(0), (torch.stack(list(l['kl_m_k']), 1).mean(0).sum() + torch.stack(list(l['kl_l_k']), 1).mean(0).sum())
+        kl = torch.stack(list(l['kl_m_k']), 1).mean(0).sum()
+        if 'kl_l_k' in l:
+            kl = kl + torch.stack(list(l['kl_l_k']), 1).mean(0).sum()
+        return l['err'].mean(0), kl
 
     st = lambda l: torch.stack(list(l))  # noqa: E731
-    finish('genesis', name, model, sd, x, losses_fn, out, mods['geco'], S, nseed,
-           {'err': losses['err'], 'kl_m_k': st(losses['kl_m_k']), 'kl_l_k': st(losses['kl_l_k']), 'recon': recon,
-            'log_m_k': st(stats.log_m_k), 'x_r_k': st(stats.x_r_k), 'att_mu_k': st(att.mu_k), 'att_z_k': st(att.z_k),
-            'comp_mu_k': st(comp.mu_k), 'comp_sigma_k': st(comp.sigma_k), 'comp_z_k': st(comp.z_k)})
+    named = {'err': losses['err'], 'kl_m_k': st(losses['kl_m_k']), 'recon': recon,
+             'log_m_k': st(stats.log_m_k), 'x_r_k': st(stats.x_r_k), 'att_mu_k': st(att.mu_k), 'att_z_k': st(att.z_k)}
+    if two:
+        named.update({'kl_l_k': st(losses['kl_l_k']), 'comp_mu_k': st(comp.mu_k), 'comp_sigma_k': st(comp.sigma_k),
+                      'comp_z_k': st(comp.z_k)})
+    finish('genesis', name, model, sd, x, losses_fn, out, mods['geco'], S, nseed, named)
 
 
 if __name__ == '__main__':
