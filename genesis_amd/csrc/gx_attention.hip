@@ -38,7 +38,11 @@ icsbp_fwd_kernel(const float* __restrict__ colour, const double* __restrict__ lo
                  const float* __restrict__ rand_pixel, const int64_t* __restrict__ seed_idx_in,
                  int B, int C, int HW, int K, int kernel_type,
                  float* __restrict__ log_m, float* __restrict__ log_s_out,
-                 float* __restrict__ seeds, int64_t* __restrict__ seed_idx_out) {
+                 float* __restrict__ seeds, int64_t* __restrict__ seed_idx_out,
+                 float min_mass, int* __restrict__ nsteps_out) {
+    // min_mass > 0 (dynamic_K, modules/attention.py:218-219): an image stops at the first step whose mask would hold
+    // fewer than min_mass pixels (sum of exp(log_m)); that step's mask becomes the remaining scope, later masks are
+    // -1e10 (the padding of models/genesisv2_config.py:126-130) and nsteps_out[b] = number of steps executed.
     __shared__ float red_v[16];
     __shared__ int red_i[16];
     __shared__ float seed_sh[MAXC];
@@ -73,6 +77,7 @@ icsbp_fwd_kernel(const float* __restrict__ colour, const double* __restrict__ lo
         }
     }
 
+    int n_exec = K - 1;                 // steps executed (dynamic_K may stop earlier)
     for (int t = 0; t < K - 1; ++t) {
         int best_i;
         if (seed_idx_in) {
@@ -118,6 +123,33 @@ icsbp_fwd_kernel(const float* __restrict__ colour, const double* __restrict__ lo
         }
         if (tid == 0) seed_idx_out[(size_t)t * B + b] = best_i;
         __syncthreads();
+        if (min_mass > 0.f) {
+            float mass = 0.f;
+            for (int qq = 0, p = tid; p < HW; p += T, ++qq) {
+                float d = 0.f;
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c) {
+                    if (c < C) {
+                        const float df = (PPT > 0 ? cv[qq < NR ? qq : 0][c] : col[(size_t)c * HW + p]) - seed_sh[c];
+                        d += df * df;
+                    }
+                }
+                float alpha;
+                if (kernel_type == KERNEL_GAUSSIAN) alpha = expf(-d / sigma);
+                else if (kernel_type == KERNEL_LAPLACIAN) alpha = expf(-sqrtf(st_clamp(d, 1e-10f, 1e10f)) / sigma);
+                else alpha = fmaxf(1.f - d / sigma, 0.f);
+                alpha = st_clamp(alpha, 0.01f, 0.99f);
+                mass += expf((PPT > 0 ? lsr[qq < NR ? qq : 0] : ls[p]) + logf(alpha));
+            }
+            mass = gx_wave_sum(mass);
+            __syncthreads();
+            if (lane == 0) red_v[wave] = mass;
+            __syncthreads();
+            float tot = 0.f;
+            for (int w = 0; w < nw; ++w) tot += red_v[w];
+            __syncthreads();
+            if (tot < min_mass) { n_exec = t; break; }          // uniform over the workgroup
+        }
         for (int qq = 0, p = tid; p < HW; p += T, ++qq) {
             {
                 float d = 0.f;
@@ -154,8 +186,19 @@ icsbp_fwd_kernel(const float* __restrict__ colour, const double* __restrict__ lo
             }
         }
     }
-    for (int qq = 0, p = tid; p < HW; p += T, ++qq)
-        log_m[(K - 1) * kstride + (size_t)b * HW + p] = PPT > 0 ? lsr[qq < NR ? qq : 0] : ls[p];
+    for (int qq = 0, p = tid; p < HW; p += T, ++qq) {
+        const float lsp = PPT > 0 ? lsr[qq < NR ? qq : 0] : ls[p];
+        log_m[n_exec * kstride + (size_t)b * HW + p] = lsp;                     // last mask = remaining scope
+        for (int t = n_exec + 1; t < K; ++t) {
+            log_m[t * kstride + (size_t)b * HW + p] = -1e10f;
+            log_s_out[t * kstride + (size_t)b * HW + p] = lsp;
+        }
+    }
+    for (int t = n_exec + 1; t < K - 1; ++t) {        // steps never run: no seed
+        if (tid < C) seeds[((size_t)t * B + b) * C + tid] = 0.f;
+        if (tid == 0) seed_idx_out[(size_t)t * B + b] = 0;
+    }
+    if (nsteps_out && tid == 0) nsteps_out[b] = n_exec;
 }
 
 // Reduces NV per-thread doubles over the block at once (wave shuffles + one LDS hop), result broadcast.
@@ -187,7 +230,8 @@ __device__ __forceinline__ void block_sum_multi(double (&v)[NV], double* red /* 
 __global__ void __launch_bounds__(256)
 icsbp_bwd_kernel(const float* __restrict__ colour, const double* __restrict__ log_sigma,
                  const float* __restrict__ seeds, const float* __restrict__ g_m, int B, int C, int HW, int K,
-                 int kernel_type, float* __restrict__ dcolour, double* __restrict__ part) {
+                 int kernel_type, float* __restrict__ dcolour, double* __restrict__ part,
+                 const int* __restrict__ nsteps) {
     __shared__ double red[16 * (MAXC + 1) + (MAXC + 1)];
     __shared__ float seed_sh[16][MAXC];   // K-1 <= 16
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -202,9 +246,15 @@ icsbp_bwd_kernel(const float* __restrict__ colour, const double* __restrict__ lo
         col[c] = (ok && c < C) ? colour[((size_t)b * C + c) * HW + p] : 0.f;
         dcol[c] = 0.f;
     }
-    float gs = ok ? g_m[(K - 1) * kstride + (size_t)b * HW + p] : 0.f;
+    // dynamic_K: this image ran n steps; mask n is its remaining scope, later masks are constants
+    const int n = nsteps ? nsteps[b] : K - 1;
+    float gs = ok ? g_m[n * kstride + (size_t)b * HW + p] : 0.f;
     __syncthreads();
     for (int t = K - 2; t >= 0; --t) {
+        if (t >= n) {                  // (uniform over the workgroup)
+            if (tid <= MAXC) part[(((size_t)b * gridDim.y + blockIdx.y) * (K - 1) + t) * (MAXC + 1) + tid] = 0.0;
+            continue;
+        }
         double vals[MAXC + 1];
         float diff[MAXC];
         float d = 0.f;
@@ -317,9 +367,10 @@ int threads_for(int HW) {
 
 extern "C" {
 
-int gx_icsbp_fwd(const float* colour, const double* log_sigma, const float* rand_pixel, const int64_t* seed_idx_in,
-                 int B, int C, int H, int W, int K, int kernel_type, float* log_m, float* log_s, float* seeds,
-                 int64_t* seed_idx_out, gx_stream_t stream) {
+static int icsbp_fwd_impl(const float* colour, const double* log_sigma, const float* rand_pixel,
+                          const int64_t* seed_idx_in, int B, int C, int H, int W, int K, int kernel_type, float* log_m,
+                          float* log_s, float* seeds, int64_t* seed_idx_out, float min_mass, int* nsteps_out,
+                          gx_stream_t stream) {
     GX_CHECK_ARG(colour && log_sigma && rand_pixel && log_m && log_s && seeds && seed_idx_out,
                  "gx_icsbp_fwd: null pointer");
     const int HW = H * W;
@@ -332,7 +383,8 @@ int gx_icsbp_fwd(const float* colour, const double* log_sigma, const float* rand
         const int ppt = (HW % T == 0) ? HW / T : 0;
 #define GX_ICSBP_LAUNCH(P_)                                                                                          \
         hipLaunchKernelGGL(icsbp_fwd_kernel<P_>, dim3(B), dim3(T), HW * sizeof(float), (hipStream_t)stream, colour,    \
-                           log_sigma, rand_pixel, seed_idx_in, B, C, HW, K, kernel_type, log_m, log_s, seeds, seed_idx_out)
+                           log_sigma, rand_pixel, seed_idx_in, B, C, HW, K, kernel_type, log_m, log_s, seeds, seed_idx_out,      \
+                           min_mass, nsteps_out)
         if (ppt == 1) GX_ICSBP_LAUNCH(1);
         else if (ppt == 2) GX_ICSBP_LAUNCH(2);
         else if (ppt == 4) GX_ICSBP_LAUNCH(4);
@@ -343,6 +395,24 @@ int gx_icsbp_fwd(const float* colour, const double* log_sigma, const float* rand
     return GX_OK;
 }
 
+int gx_icsbp_fwd(const float* colour, const double* log_sigma, const float* rand_pixel, const int64_t* seed_idx_in,
+                 int B, int C, int H, int W, int K, int kernel_type, float* log_m, float* log_s, float* seeds,
+                 int64_t* seed_idx_out, gx_stream_t stream) {
+    return icsbp_fwd_impl(colour, log_sigma, rand_pixel, seed_idx_in, B, C, H, W, K, kernel_type, log_m, log_s, seeds,
+                          seed_idx_out, 0.f, nullptr, stream);
+}
+
+/* dynamic_K (modules/attention.py:218-219, models/genesisv2_config.py:118-137): an image stops at the first step whose
+ * mask mass sum_p exp(log_m) is below min_mass; nsteps[b] = steps it ran (mask nsteps[b] = remaining scope, later
+ * masks -1e10, later seeds 0) */
+int gx_icsbp_fwd_dyn(const float* colour, const double* log_sigma, const float* rand_pixel, const int64_t* seed_idx_in,
+                     int B, int C, int H, int W, int K, int kernel_type, float min_mass, float* log_m, float* log_s,
+                     float* seeds, int64_t* seed_idx_out, int* nsteps, gx_stream_t stream) {
+    GX_CHECK_ARG(nsteps && min_mass > 0.f, "gx_icsbp_fwd_dyn: nsteps null or min_mass <= 0");
+    return icsbp_fwd_impl(colour, log_sigma, rand_pixel, seed_idx_in, B, C, H, W, K, kernel_type, log_m, log_s, seeds,
+                          seed_idx_out, min_mass, nsteps, stream);
+}
+
 static int icsbp_bwd_threads(int HW) { return HW < 256 ? HW : 256; }
 
 size_t gx_icsbp_bwd_ws_bytes(int B, int H, int W, int K) {
@@ -351,9 +421,9 @@ size_t gx_icsbp_bwd_ws_bytes(int B, int H, int W, int K) {
     return ((size_t)B * nch * (K > 1 ? K - 1 : 1) * (MAXC + 1) + B) * sizeof(double);
 }
 
-int gx_icsbp_bwd(const float* colour, const double* log_sigma, const float* seeds, const int64_t* seed_idx,
-                 const float* g_log_m, int B, int C, int H, int W, int K, int kernel_type, float* dcolour,
-                 double* dlog_sigma, void* ws, size_t ws_bytes, gx_stream_t stream) {
+static int icsbp_bwd_impl(const float* colour, const double* log_sigma, const float* seeds, const int64_t* seed_idx,
+                          const float* g_log_m, int B, int C, int H, int W, int K, int kernel_type, float* dcolour,
+                          double* dlog_sigma, void* ws, size_t ws_bytes, const int* nsteps, gx_stream_t stream) {
     GX_CHECK_ARG(colour && log_sigma && seeds && seed_idx && g_log_m && dcolour && dlog_sigma && ws,
                  "gx_icsbp_bwd: null pointer");
     const int HW = H * W;
@@ -369,7 +439,7 @@ int gx_icsbp_bwd(const float* colour, const double* log_sigma, const float* seed
     {
         GxProf pf(KID_ICSBP_BWD, s, 0.0, 4.0 * B * HW * (2.0 * C + K));
         hipLaunchKernelGGL(icsbp_bwd_kernel, dim3(B, nch), dim3(T), 0, s, colour, log_sigma, seeds, g_log_m, B, C, HW,
-                           K, kernel_type, dcolour, part);
+                           K, kernel_type, dcolour, part, nsteps);
     }
     GX_CHECK_LAUNCH("gx_icsbp_bwd");
     {
@@ -380,6 +450,21 @@ int gx_icsbp_bwd(const float* colour, const double* log_sigma, const float* seed
     }
     GX_CHECK_LAUNCH("gx_icsbp_bwd(finalize)");
     return GX_OK;
+}
+
+int gx_icsbp_bwd(const float* colour, const double* log_sigma, const float* seeds, const int64_t* seed_idx,
+                 const float* g_log_m, int B, int C, int H, int W, int K, int kernel_type, float* dcolour,
+                 double* dlog_sigma, void* ws, size_t ws_bytes, gx_stream_t stream) {
+    return icsbp_bwd_impl(colour, log_sigma, seeds, seed_idx, g_log_m, B, C, H, W, K, kernel_type, dcolour, dlog_sigma,
+                          ws, ws_bytes, nullptr, stream);
+}
+
+int gx_icsbp_bwd_dyn(const float* colour, const double* log_sigma, const float* seeds, const int64_t* seed_idx,
+                     const float* g_log_m, const int* nsteps, int B, int C, int H, int W, int K, int kernel_type,
+                     float* dcolour, double* dlog_sigma, void* ws, size_t ws_bytes, gx_stream_t stream) {
+    GX_CHECK_ARG(nsteps, "gx_icsbp_bwd_dyn: nsteps null");
+    return icsbp_bwd_impl(colour, log_sigma, seeds, seed_idx, g_log_m, B, C, H, W, K, kernel_type, dcolour, dlog_sigma,
+                          ws, ws_bytes, nsteps, stream);
 }
 
 }  // extern "C"

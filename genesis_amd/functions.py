@@ -317,7 +317,8 @@ class ICSBPFn(torch.autograd.Function):
     (log_m [K,B,1,H,W], log_s [K,B,1,H,W], colour [B,8,H,W], seeds [K-1,B,8], seed_idx [K-1,B])."""
 
     @staticmethod
-    def forward(ctx, feat, conv_w, conv_b, gate, uv, log_sigma, rand_pixel, K, kernel, seed_idx):
+    def forward(ctx, feat, conv_w, conv_b, gate, uv, log_sigma, rand_pixel, K, kernel, seed_idx, min_mass=0.0):
+        """min_mass > 0: dynamic_K; a sixth output nsteps [B] (int32) says how many steps each image ran."""
         feat = feat.contiguous()
         ctx.params = (conv_w, conv_b, gate, log_sigma)
         conv_w = conv_w.detach().view(conv_w.shape[0], -1)
@@ -326,11 +327,16 @@ class ICSBPFn(torch.autograd.Function):
         # kernel, modules/attention.py:150,155; fp32 only for epanechnikov)
         ctx.ls_dtype = log_sigma.dtype
         log_sigma = log_sigma.detach().to(torch.float64)
-        log_m, log_s, seeds, idx = hip.icsbp_fwd(colour, log_sigma, rand_pixel.contiguous(), K, kernel, seed_idx)
+        res = hip.icsbp_fwd(colour, log_sigma, rand_pixel.contiguous(), K, kernel, seed_idx, min_mass)
+        log_m, log_s, seeds, idx = res[:4]
+        ctx.nsteps = res[4] if min_mass > 0.0 else None
         ctx.save_for_backward(feat, conv_w, conv_b, gate, log_sigma, colour, seeds, idx)
         ctx.kernel = kernel
         ctx.mark_non_differentiable(log_s, colour, seeds, idx)
         ctx.set_materialize_grads(False)   # no zero-filled gradients for the outputs nobody differentiates
+        if ctx.nsteps is not None:
+            ctx.mark_non_differentiable(ctx.nsteps)
+            return log_m, log_s, colour, seeds, idx, ctx.nsteps
         return log_m, log_s, colour, seeds, idx
 
     @staticmethod
@@ -341,10 +347,11 @@ class ICSBPFn(torch.autograd.Function):
         pw, pb, pg, pls = ctx.params
         ow, ob, og = _gout(pw), _gout(pb), (_gout(pg) if pg is not None else None)
         ols = _gout(pls) if ctx.ls_dtype == torch.float64 and pls.dim() == 0 else None
-        dcolour, dls = hip.icsbp_bwd(colour, log_sigma, seeds, idx, g_log_m.contiguous(), ctx.kernel, out_dls=ols)
+        dcolour, dls = hip.icsbp_bwd(colour, log_sigma, seeds, idx, g_log_m.contiguous(), ctx.kernel, out_dls=ols,
+                                     nsteps=ctx.nsteps)
         dfeat, dw, db, dgate = hip.conv1x1_bwd(feat, dcolour, conv_w, conv_b, gate, out=(ow, ob, og))
         return (dfeat, _ret(ow, dw.view(pw.shape)), _ret(ob, db), _ret(og, dgate), None,
-                _ret(ols, dls.to(ctx.ls_dtype)), None, None, None, None)
+                _ret(ols, dls.to(ctx.ls_dtype)), None, None, None, None, None)
 
 
 # seg_head's GroupNorm+ReLU output is consumed by the colour head's 1x1 conv only: keep it out of memory (as the
@@ -365,7 +372,7 @@ class SegICSBPFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, enc_feat, seg_w, seg_gamma, seg_beta, conv_w, conv_b, gate, uv, log_sigma, rand_pixel, K, kernel,
-                seed_idx):
+                seed_idx, min_mass=0.0):
         x = enc_feat.contiguous()
         ctx.params = (seg_w, seg_gamma, seg_beta, conv_w, conv_b, gate, log_sigma)
         w2 = conv_w.detach().view(conv_w.shape[0], -1)
@@ -373,11 +380,16 @@ class SegICSBPFn(torch.autograd.Function):
         colour = hip.conv1x1_gn_fwd(y, mean, rstd, seg_gamma, seg_beta, GROUPS, w2, conv_b, gate, uv)
         ctx.ls_dtype = log_sigma.dtype
         ls64 = log_sigma.detach().to(torch.float64)
-        log_m, log_s, seeds, idx = hip.icsbp_fwd(colour, ls64, rand_pixel.contiguous(), K, kernel, seed_idx)
+        res = hip.icsbp_fwd(colour, ls64, rand_pixel.contiguous(), K, kernel, seed_idx, min_mass)
+        log_m, log_s, seeds, idx = res[:4]
+        ctx.nsteps = res[4] if min_mass > 0.0 else None
         ctx.save_for_backward(x, y, mean, rstd, ls64, colour, seeds, idx)
         ctx.kernel = kernel
         ctx.mark_non_differentiable(log_s, colour, seeds, idx)
         ctx.set_materialize_grads(False)
+        if ctx.nsteps is not None:
+            ctx.mark_non_differentiable(ctx.nsteps)
+            return log_m, log_s, colour, seeds, idx, ctx.nsteps
         return log_m, log_s, colour, seeds, idx
 
     @staticmethod
@@ -387,7 +399,8 @@ class SegICSBPFn(torch.autograd.Function):
         if g_log_m is None:
             g_log_m = colour.new_zeros(seeds.shape[0] + 1, colour.shape[0], 1, colour.shape[2], colour.shape[3])
         ols = _gout(log_sigma) if ctx.ls_dtype == torch.float64 and log_sigma.dim() == 0 else None
-        dcolour, dls = hip.icsbp_bwd(colour, ls64, seeds, idx, g_log_m.contiguous(), ctx.kernel, out_dls=ols)
+        dcolour, dls = hip.icsbp_bwd(colour, ls64, seeds, idx, g_log_m.contiguous(), ctx.kernel, out_dls=ols,
+                                     nsteps=ctx.nsteps)
         w2 = conv_w.detach().view(conv_w.shape[0], -1)
         ow, ob, og = _gout(conv_w), _gout(conv_b), (_gout(gate) if gate is not None else None)
         osw, osg, osb = _gout(seg_w), _gout(seg_gamma), _gout(seg_beta)
@@ -403,7 +416,7 @@ class SegICSBPFn(torch.autograd.Function):
         dsw = _wgrad(lambda: hip.conv3x3_wgrad(x, dy, out=osw), osw, x, dy)
         dx = hip.conv3x3_dgrad(dy, seg_w) if ctx.needs_input_grad[0] else None
         return (dx, _ret(osw, dsw), _ret(osg, dgamma), _ret(osb, dbeta), _ret(ow, dw.view(conv_w.shape)), _ret(ob, db),
-                _ret(og, dgate), None, _ret(ols, dls.to(ctx.ls_dtype)), None, None, None, None)
+                _ret(og, dgate), None, _ret(ols, dls.to(ctx.ls_dtype)), None, None, None, None, None)
 
 
 @ctx_bound

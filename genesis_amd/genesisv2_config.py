@@ -181,8 +181,6 @@ class GenesisV2(nn.Module):
         self.dynamic_K = _cfg_get(cfg, 'dynamic_K', False)
         self.debug = _cfg_get(cfg, 'debug', False)
         self.multi_gpu = _cfg_get(cfg, 'multi_gpu', False)
-        if self.dynamic_K:
-            raise NotImplementedError('dynamic_K (non-default, models/genesisv2_config.py:39) is not on the HIP path')
         D = cfg.feat_dim
         self.encoder = _UNetParams(int(np.log2(cfg.img_size) - 1), cfg.img_size, min(D, 64), 3, D)
         self.att_process = _ICSBPParams(_cfg_get(cfg, 'kernel', 'gaussian'), self.K_steps, D,
@@ -291,13 +289,29 @@ class GenesisV2(nn.Module):
         else:
             cw, cb, gate, addend = ap.colour_head.weight, ap.colour_head.bias, None, None
         seg_params = self.seg_head.params()
+        # dynamic_K (genesisv2_config.py:118-137, attention.py:218-219): an image stops at the first step whose mask
+        # would hold fewer than 20 pixels; the kernel does that per image of the batch in one launch
+        min_mass = 20.0 if self.dynamic_K else 0.0
         if fn.seg_head_fusable(enc_feat, seg_params[0], cw):
-            log_m, log_s, colour, seeds, idx = fn.SegICSBPFn.apply(
-                enc_feat, *seg_params, cw, cb, gate, addend, ap.log_sigma, rand_pixel, K, ap.kernel, seed_idx)
+            res = fn.SegICSBPFn.apply(enc_feat, *seg_params, cw, cb, gate, addend, ap.log_sigma, rand_pixel, K, ap.kernel,
+                                      seed_idx, min_mass)
         else:
             seg = fn.ConvGNReLUFn.apply(enc_feat, *seg_params)
-            log_m, log_s, colour, seeds, idx = fn.ICSBPFn.apply(
-                seg, cw, cb, gate, addend, ap.log_sigma, rand_pixel, K, ap.kernel, seed_idx)
+            res = fn.ICSBPFn.apply(seg, cw, cb, gate, addend, ap.log_sigma, rand_pixel, K, ap.kernel, seed_idx, min_mass)
+        log_m, log_s, colour, seeds, idx = res[:5]
+        dyn_batched = False
+        if self.dynamic_K:
+            if B == 1:
+                # one image: the reference's lists simply end early -- K shrinks for the rest of the forward pass
+                # (a host read of the step count; the reference syncs at every step's `< 20` test)
+                n = int(res[5][0])
+                K = n + 1
+                log_m, log_s = log_m[:K], log_s[:K]
+                seeds, idx = seeds[:min(n + 1, self.K_steps - 1)], idx[:min(n + 1, self.K_steps - 1)]
+                if eps is not None:
+                    eps = eps[:K]
+            else:
+                dyn_batched = True      # masks of finished images are padded with -1e10; no att_stats / log_s_k (:122)
         # --- Object features: feat_head[0] once (the reference recomputes it K times, :149), pooled per
         #     slot; the 1x1 conv feat_head[1] commutes with the masked sum and is applied to the pooled sums.
         f = fn.ConvGNReLUFn.apply(enc_feat, *self.feat_head[0].params())
@@ -326,7 +340,7 @@ class GenesisV2(nn.Module):
         losses = AttrDict()
         losses['err'] = err
         log_m_k = list(log_m.unbind(0))
-        log_s_k = list(log_s.unbind(0))
+        log_s_k = None if dyn_batched else list(log_s.unbind(0))
         x_r_k = list(x_r.unbind(0))
         log_m_r_k = list(log_m_r.unbind(0))
         # -- Optional: Attention mask loss (MONet.kl_m_loss, models/monet_config.py:157-170)
@@ -350,6 +364,8 @@ class GenesisV2(nn.Module):
                                                 for m, s in zip(mu.unbind(0), sigma.unbind(0))])
         if self.multi_gpu:
             del comp_stats['q_z_k']
+        if dyn_batched:
+            att_stats = None             # genesisv2_config.py:122
         return recon, losses, stats, att_stats, comp_stats
 
     def decode_latents(self, z_k):

@@ -278,7 +278,8 @@ def gn_relu_bwd(y, gamma, beta, mean, rstd, groups, g0, g1=None, want_dbias=Fals
 
 
 # ------------------------------------------------------------------ IC-SBP
-def icsbp_fwd(colour, log_sigma, rand_pixel, K, kernel='gaussian', seed_idx=None):
+def icsbp_fwd(colour, log_sigma, rand_pixel, K, kernel='gaussian', seed_idx=None, min_mass=0.0):
+    """min_mass > 0: dynamic_K (modules/attention.py:218-219); then also returns nsteps [B] int32."""
     _chk(colour, 'icsbp.colour'); _chk(rand_pixel, 'icsbp.rand_pixel')
     _chk(log_sigma, 'icsbp.log_sigma', torch.float64)
     _chk(seed_idx, 'icsbp.seed_idx', torch.int64)
@@ -288,12 +289,17 @@ def icsbp_fwd(colour, log_sigma, rand_pixel, K, kernel='gaussian', seed_idx=None
     log_s = torch.empty(K, B, 1, H, W, dtype=F32, device=dev)
     seeds = torch.empty(max(K - 1, 0), B, C, dtype=F32, device=dev)
     idx = torch.empty(max(K - 1, 0), B, dtype=torch.int64, device=dev)
+    if min_mass > 0.0:
+        nsteps = torch.empty(B, dtype=torch.int32, device=dev)
+        _lib.call('gx_icsbp_fwd_dyn', _p(colour), _p(log_sigma), _p(rand_pixel), _p(seed_idx), B, C, H, W, K,
+                  KERNELS[kernel], float(min_mass), _p(log_m), _p(log_s), _p(seeds), _p(idx), _p(nsteps), _stream())
+        return log_m, log_s, seeds, idx, nsteps
     _lib.call('gx_icsbp_fwd', _p(colour), _p(log_sigma), _p(rand_pixel), _p(seed_idx), B, C, H, W, K,
               KERNELS[kernel], _p(log_m), _p(log_s), _p(seeds), _p(idx), _stream())
     return log_m, log_s, seeds, idx
 
 
-def icsbp_bwd(colour, log_sigma, seeds, idx, g_log_m, kernel='gaussian', out_dls=None):
+def icsbp_bwd(colour, log_sigma, seeds, idx, g_log_m, kernel='gaussian', out_dls=None, nsteps=None):
     _chk(g_log_m, 'icsbp_bwd.g_log_m')
     B, C, H, W = colour.shape
     K = g_log_m.shape[0]
@@ -302,8 +308,13 @@ def icsbp_bwd(colour, log_sigma, seeds, idx, g_log_m, kernel='gaussian', out_dls
     _chk(dls, 'icsbp_bwd.dls', torch.float64)
     nb = _lib.query('gx_icsbp_bwd_ws_bytes', B, H, W, K)
     ws = _ws(nb, colour.device)
-    _lib.call('gx_icsbp_bwd', _p(colour), _p(log_sigma), _p(seeds), _p(idx), _p(g_log_m), B, C, H, W, K,
-              KERNELS[kernel], _p(dcolour), _p(dls), _p(ws), nb, _stream())
+    if nsteps is not None:
+        _chk(nsteps, 'icsbp_bwd.nsteps', torch.int32)
+        _lib.call('gx_icsbp_bwd_dyn', _p(colour), _p(log_sigma), _p(seeds), _p(idx), _p(g_log_m), _p(nsteps), B, C, H, W,
+                  K, KERNELS[kernel], _p(dcolour), _p(dls), _p(ws), nb, _stream())
+    else:
+        _lib.call('gx_icsbp_bwd', _p(colour), _p(log_sigma), _p(seeds), _p(idx), _p(g_log_m), B, C, H, W, K,
+                  KERNELS[kernel], _p(dcolour), _p(dls), _p(ws), nb, _stream())
     return dcolour, dls
 
 

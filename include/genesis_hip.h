@@ -125,6 +125,16 @@ size_t gx_icsbp_bwd_ws_bytes(int B, int H, int W, int K);
 int gx_icsbp_bwd(const float* colour, const double* log_sigma, const float* seeds, const int64_t* seed_idx,
                  const float* g_log_m, int B, int C, int H, int W, int K, int kernel_type, float* dcolour,
                  double* dlog_sigma, void* ws, size_t ws_bytes, gx_stream_t stream);
+/*      dynamic_K (modules/attention.py:218-219, models/genesisv2_config.py:118-137): an image stops at the first step
+ *      whose mask mass sum_p exp(log_m) falls below min_mass (the reference: 20); nsteps[b] = steps it ran; its mask
+ *      nsteps[b] is the remaining scope, later masks are -1e10 (the reference's padding), later seeds 0.  The backward
+ *      takes nsteps and treats the masks accordingly. */
+int gx_icsbp_fwd_dyn(const float* colour, const double* log_sigma, const float* rand_pixel, const int64_t* seed_idx_in,
+                     int B, int C, int H, int W, int K, int kernel_type, float min_mass, float* log_m, float* log_s,
+                     float* seeds, int64_t* seed_idx_out, int* nsteps, gx_stream_t stream);
+int gx_icsbp_bwd_dyn(const float* colour, const double* log_sigma, const float* seeds, const int64_t* seed_idx,
+                     const float* g_log_m, const int* nsteps, int B, int C, int H, int W, int K, int kernel_type,
+                     float* dcolour, double* dlog_sigma, void* ws, size_t ws_bytes, gx_stream_t stream);
 
 /* ---- masked slot pooling: models/genesisv2_config.py:146-152.
  *      S[b,k,c] = sum_hw exp(log_m[k,b]) * f[b,c];  msum[b,k] = sum_hw exp(log_m[k,b]).

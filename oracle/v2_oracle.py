@@ -93,7 +93,7 @@ def clamp_preserve_gradients(x, lo, hi):
     return x + (x.clamp(lo, hi) - x).detach()
 
 
-def ic_sbp(colour, log_sigma, steps, rand_pixel, kernel='gaussian', seed_idx=None):
+def ic_sbp(colour, log_sigma, steps, rand_pixel, kernel='gaussian', seed_idx=None, dynamic_K=False):
     """InstanceColouringSBP.forward, modules/attention.py:162-226.
 
     colour [B,C,H,W]; log_sigma 0-dim (float64 in the reference's checkpoints);
@@ -130,7 +130,11 @@ def ic_sbp(colour, log_sigma, steps, rand_pixel, kernel='gaussian', seed_idx=Non
         alpha = clamp_preserve_gradients(alpha, 0.01, 0.99)
         log_a = torch.log(alpha)
         log_neg_a = torch.log(1 - alpha)
-        log_m_k.append(log_s_k[step] + log_a)
+        log_m = log_s_k[step] + log_a
+        if dynamic_K and log_m.exp().sum() < 20:      # modules/attention.py:218-219 (one image per call, :168-169)
+            assert B == 1
+            break
+        log_m_k.append(log_m)
         log_s_k.append(log_s_k[step] + log_neg_a)
     log_m_k.append(log_s_k[-1])
     return log_m_k, log_s_k, seeds, idxs
@@ -295,9 +299,22 @@ def v2_forward(p, x, cfg, rand_pixel=None, eps_k=None, seed_idx=None,
     colour, delta = semiconv(p, seg, S, cfg.get('semiconv', True))
     if rand_pixel is None:
         rand_pixel = torch.empty(B, 1, S, S).uniform_()
-    log_m_k, log_s_k, seeds, idxs = ic_sbp(
-        colour, p['att_process.log_sigma'], K - 1, rand_pixel,
-        cfg.get('kernel', 'gaussian'), seed_idx)
+    dyn_batched = False
+    if cfg.get('dynamic_K', False) and B > 1:
+        # models/genesisv2_config.py:119-132: one image at a time, finished images padded with -1e10 masks
+        dyn_batched = True
+        log_m_k = [[] for _ in range(K)]
+        for b in range(B):
+            lm_b, _, _, _ = ic_sbp(colour[b:b + 1], p['att_process.log_sigma'], K - 1, rand_pixel[b:b + 1],
+                                   cfg.get('kernel', 'gaussian'), None, True)
+            for step in range(K):
+                log_m_k[step].append(lm_b[step] if step < len(lm_b) else -1e10 * torch.ones(1, 1, S, S))
+        log_m_k = [torch.cat(l, 0) for l in log_m_k]
+        log_s_k, seeds, idxs = None, None, None
+    else:
+        log_m_k, log_s_k, seeds, idxs = ic_sbp(
+            colour, p['att_process.log_sigma'], K - 1, rand_pixel,
+            cfg.get('kernel', 'gaussian'), seed_idx, cfg.get('dynamic_K', False))
 
     def feat_head():
         f = conv_gn_relu(p, 'feat_head.0', enc)
@@ -330,7 +347,7 @@ def v2_forward(p, x, cfg, rand_pixel=None, eps_k=None, seed_idx=None,
                  log_m_r_k=log_m_r_k,
                  instance_seg=torch.argmax(torch.cat(log_m_k, 1), 1),
                  instance_seg_r=torch.argmax(torch.cat(log_m_r_k, 1), 1))
-    att_stats = dict(colour=colour, delta=delta, seeds=seeds, seed_idx=idxs)
+    att_stats = None if dyn_batched else dict(colour=colour, delta=delta, seeds=seeds, seed_idx=idxs)
     comp_stats = dict(mu_k=mu_k, sigma_k=sigma_k, z_k=z_k)
     return recon, losses, stats, att_stats, comp_stats
 

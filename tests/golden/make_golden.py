@@ -39,6 +39,10 @@ CASES = {
     'metric': (dict(K_steps=7, img_size=64, feat_dim=64), 2, 18, 28, False),
     'cfg2': (dict(K_steps=5, img_size=64, feat_dim=64), 2, 19, 29, False),
     'cfg5': (dict(K_steps=11, img_size=128, feat_dim=64), 1, 20, 30, False),
+    # dynamic_K (genesisv2_config.py:118-137): a batch (finished images padded with -1e10 masks, no att_stats) and a
+    # single image (the lists end early)
+    'tiny_dynk': (dict(K_steps=5, img_size=32, feat_dim=16, dynamic_K=True), 3, 42, 52, True),
+    'tiny_dynk_b1': (dict(K_steps=5, img_size=32, feat_dim=16, dynamic_K=True), 1, 42, 52, True),
 }
 
 
@@ -60,9 +64,12 @@ def run_case(name, mods):
     x = T.make_input(xseed, B, S)
     # pick a noise seed whose argmax seeds are not near-ties (modules/attention.py:187-188
     # is discontinuous): first of nseed, nseed+100, ... with top-2 margin > 2e-5.
+    dyn = bool(over.get('dynamic_K', False))
     with torch.no_grad():
         for _ in range(50):
             rand_pixel, eps_k = T.draw_noise(nseed, B, S, D, K)
+            if dyn:
+                break          # (no scope list to test the margins on: att_stats / log_s_k are None for a batch)
             torch.manual_seed(nseed)
             st = model(x)[2]
             mm = min(float(top2_margin(rand_pixel, st['log_s_k'][i]).min()) for i in range(K - 1))
@@ -72,9 +79,9 @@ def run_case(name, mods):
 
     out = {}
     out['cfg_json'] = np.array(json.dumps(
-        {k: cfg[k] for k in ('K_steps', 'img_size', 'feat_dim', 'kernel', 'semiconv',
-                             'klm_loss', 'detach_mr_in_klm', 'pixel_bound',
-                             'autoreg_prior', 'pixel_std1')}))
+        dict({k: cfg[k] for k in ('K_steps', 'img_size', 'feat_dim', 'kernel', 'semiconv',
+                                  'klm_loss', 'detach_mr_in_klm', 'pixel_bound',
+                                  'autoreg_prior', 'pixel_std1')}, **({'dynamic_K': True} if dyn else {}))))
     out['B'] = np.int64(B)
     out['x_seed'] = np.int64(xseed)
     out['noise_seed'] = np.int64(nseed)
@@ -90,27 +97,37 @@ def run_case(name, mods):
     z_replay = comp['mu_k'][0] + comp['sigma_k'][0] * eps_k[0]
     assert torch.allclose(z_replay, comp['z_k'][0], atol=1e-6), 'noise replay mismatch'
 
-    seed_idx = []
-    margins = []
-    flat_rand = rand_pixel
-    for step in range(K - 1):
-        v = (flat_rand * stats['log_s_k'][step].exp()).flatten(2)
-        seed_idx.append(v.argmax(2).flatten())
-        margins.append(top2_margin(flat_rand, stats['log_s_k'][step]))
-    out['seed_idx'] = torch.stack(seed_idx).numpy()
-    out['seed_margin'] = torch.stack(margins).detach().numpy()
-
     named = {
         'err': losses['err'], 'kl_l_k': torch.stack(list(losses['kl_l_k'])),
         'recon': recon, 'log_m_k': torch.stack(list(stats['log_m_k'])),
-        'log_s_k': torch.stack(list(stats['log_s_k'])),
         'x_r_k': torch.stack(list(stats['x_r_k'])),
         'log_m_r_k': torch.stack(list(stats['log_m_r_k'])),
-        'colour': att['colour'],
-        'seeds': torch.stack(list(att['seeds'])),
         'mu_k': torch.stack(list(comp['mu_k'])), 'sigma_k': torch.stack(list(comp['sigma_k'])),
         'z_k': torch.stack(list(comp['z_k'])),
     }
+    if dyn:
+        lm = named['log_m_k']
+        out['slots'] = np.int64(lm.shape[0])
+        out['seed_margin'] = np.array([1.0])
+        print('   dynamic_K: %d mask tensors; padded (-1e10) slots per image:' % lm.shape[0],
+              (lm.flatten(2).max(2).values < -1e9).sum(0).flatten().tolist())
+    if stats['log_s_k'] is not None and att is not None and not dyn:
+        seed_idx = []
+        margins = []
+        flat_rand = rand_pixel
+        for step in range(K - 1):
+            v = (flat_rand * stats['log_s_k'][step].exp()).flatten(2)
+            seed_idx.append(v.argmax(2).flatten())
+            margins.append(top2_margin(flat_rand, stats['log_s_k'][step]))
+        out['seed_idx'] = torch.stack(seed_idx).numpy()
+        out['seed_margin'] = torch.stack(margins).detach().numpy()
+    if stats['log_s_k'] is not None:
+        named['log_s_k'] = torch.stack(list(stats['log_s_k']))
+    if att is not None:
+        named['colour'] = att['colour']
+        named['seeds'] = torch.stack(list(att['seeds']))
+    else:
+        att = {'delta': None}
     if att['delta'] is not None:
         named['delta'] = att['delta']
     if 'kl_m' in losses:

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.common import SAMPLE_CASES, Golden, SampleGolden
+from tests.common import DYN_CASES, SAMPLE_CASES, Golden, SampleGolden
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
@@ -17,7 +17,7 @@ DEFAULT_CASES = ['tiny', 'tiny_b3k3', 'tiny_noar', 'tiny_klm', 'tiny_klm_nodetac
 def build(gold):
     import genesis_amd.genesisv2_config as G
     from genesis_amd.compat.attrdict import AttrDict
-    cfg = AttrDict(dict(gold.cfg, debug=False, multi_gpu=False, dynamic_K=False))
+    cfg = AttrDict(dict(dict(dynamic_K=False), **dict(gold.cfg, debug=False, multi_gpu=False)))
     torch.manual_seed(0)
     model = G.load(cfg)
     sd = gold.weights(model.state_dict())
@@ -31,6 +31,8 @@ SEED_FALLBACKS = []     # (case, number of seed pixels that differed) whenever t
 def run(model, gold, x, rand_pixel, eps_k):
     eps = torch.stack(eps_k).to(DEV)
     out = model(x.to(DEV), rand_pixel.to(DEV), eps)
+    if out[3] is None or 'seed_idx' not in gold.g.files:       # dynamic_K cases carry no seed list
+        return out
     seed_idx = torch.stack(list(out[3]['seed_idx'])).cpu().numpy()
     if not np.array_equal(seed_idx, gold.g['seed_idx']):
         # near-tie in the discontinuous argmax: replay with the reference's seeds -- recorded, and
@@ -43,7 +45,7 @@ def run(model, gold, x, rand_pixel, eps_k):
     return out
 
 
-@pytest.mark.parametrize('case', DEFAULT_CASES)
+@pytest.mark.parametrize('case', DEFAULT_CASES + DYN_CASES)
 def test_forward_and_grads_vs_golden(case):
     gold = Golden(case)
     model = build(gold)
@@ -85,7 +87,7 @@ def test_sample_vs_golden(case):
     import genesis_amd.genesisv2_config as G
     from genesis_amd.compat.attrdict import AttrDict
     from genesis_amd import testing as T
-    cfg = AttrDict(dict(gold.cfg, debug=False, multi_gpu=False, dynamic_K=False))
+    cfg = AttrDict(dict(dict(dynamic_K=False), **dict(gold.cfg, debug=False, multi_gpu=False)))
     torch.manual_seed(0)
     model = G.load(cfg)
     model.load_state_dict(T.formula_state_dict(model.state_dict()))

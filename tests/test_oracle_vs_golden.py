@@ -6,7 +6,7 @@ import torch
 
 from oracle import v2_oracle as O
 from oracle import ref_import as R
-from tests.common import ALL_CASES, SAMPLE_CASES, Golden, SampleGolden
+from tests.common import ALL_CASES, DYN_CASES, SAMPLE_CASES, Golden, SampleGolden
 
 
 def _params(gold, requires_grad=False):
@@ -15,7 +15,7 @@ def _params(gold, requires_grad=False):
     return {k: v.clone().requires_grad_(requires_grad) for k, v in sd.items()}
 
 
-@pytest.mark.parametrize('case', ALL_CASES)
+@pytest.mark.parametrize('case', ALL_CASES + DYN_CASES)
 @pytest.mark.parametrize('reference_form', [True, False])
 def test_forward_and_grads(case, reference_form):
     if case == 'cfg5' and reference_form:
