@@ -35,7 +35,7 @@ def test_forward_and_grads_vs_golden(case):
     (err + kl).backward()
     # the recurrent UNet(IN) attention (K-1 shared-weight passes) is ill-conditioned in fp32: against the fp64
     # oracle BOTH the HIP path and the CPU-fp32 path sit at 0.3-3 % relative L2 on its gradients at 64x64 / K=7
-    # (tools/diag_monet3.py), while the ComponentVAE gradients agree to 1e-7..1e-5
+    # (tools/diag_monet.py), while the ComponentVAE gradients agree to 1e-7..1e-5
     gold.check_grads([(n, p.grad if p.grad is not None else torch.zeros_like(p)) for n, p in model.named_parameters()],
                      rtol=4e-2, l2_tol=6e-2)
     for key in ('log_m_k', 'log_m_r_k'):
