@@ -762,7 +762,9 @@ int gx_wgq_flush(hipStream_t s) {
 }
 
 extern "C" int gx_wgq_policy(int mode) {
-    GX_CHECK_ARG(mode == 0 || mode == 1, "gx_wgq_policy: mode must be 0 (round-1 kernels) or 1 (LDS-DMA grouped kernels)");
-    g_wgq_mode = mode;
+    GX_CHECK_ARG(mode >= 0 && mode <= 2, "gx_wgq_policy: mode must be 0 (round-1 kernels), 1 (LDS-DMA kernels, every queued "
+                                         "layer in one stream-K launch) or 2 (LDS-DMA kernels, one launch per class and tile width)");
+    g_wgq_mode = mode ? 1 : 0;
+    if (mode) g_wgq_stream = mode == 1 ? 1 : 0;
     return GX_OK;
 }

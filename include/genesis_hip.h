@@ -55,8 +55,9 @@ int gx_conv3x3_wino_policy(int mode);
  *      gx_deconv5x5s2_fwd / _dgrad: 0 never, 1 layers whose grid fills the chip (default; GENESIS_KQ=0/1/2 in the
  *      environment), 2 every eligible shape (power-of-two grids, reduction channels a multiple of 8). */
 int gx_kq_policy(int mode);
-/*      weight gradients: 1 (default; GENESIS_WGQ=0/1) = LDS-DMA staged kernels with grouped launches (gx_wgq.hip) for
- *      layers of width >= 8, 0 = the round-1 kernels everywhere. */
+/*      weight gradients of layers of width >= 8 (gx_wgq.hip): 1 (default; GENESIS_WGQ=0/1, GENESIS_WGQ_STREAM=0/1) =
+ *      LDS-DMA staged kernels, every queued layer in ONE stream-K launch at gx_defer_flush; 2 = the same kernels, one
+ *      launch per (tap class, tile width); 0 = the round-1 kernels everywhere. */
 int gx_wgq_policy(int mode);
 size_t gx_conv3x3_wino_ws_bytes(int N, int Cin, int Cout, int H, int W);
 int gx_conv3x3_wino(const float* x, const float* w, float* y, int N, int Cin, int Cout, int H, int W, int mode,

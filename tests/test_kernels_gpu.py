@@ -902,7 +902,13 @@ def test_streamk_weight_gradients_many_layers():
         return outs
 
     a, b = queued(), queued()
-    for (kind, x, dy, alone, ref), o, o2 in zip(data, a, b):
+    _lib.call('gx_wgq_policy', 2)          # the same kernels, one launch per (tap class, tile width)
+    try:
+        grouped = queued()
+    finally:
+        _lib.call('gx_wgq_policy', 1)
+    for (kind, x, dy, alone, ref), o, o2, og in zip(data, a, b, grouped):
         assert torch.equal(o, o2)
+        close(og, ref, rtol=2e-5, atol=1e-6 * float(ref.abs().max()), msg='grouped %s %s' % (kind, tuple(x.shape)))
         close(o, ref, rtol=2e-5, atol=1e-6 * float(ref.abs().max()), msg='stream-K %s %s' % (kind, tuple(x.shape)))
         close(o, alone, rtol=2e-5, atol=1e-6 * float(ref.abs().max()), msg='stream-K vs alone %s' % (tuple(x.shape),))
