@@ -22,7 +22,10 @@ from forge import flags  # noqa: E402
 from genesis_amd import functions as fn  # noqa: E402
 from genesis_amd.genesisv2_config import _cfg_get, _normal_log_prob, pixel_coords  # noqa: E402
 from genesis_amd.monet_config import _BroadcastDecoderParams, _ComponentVAEParams  # noqa: E402
-from genesis_amd.sylvester import SylvesterVAE  # noqa: E402
+from genesis_amd.sylvester import (GatedConv2d, GatedConvTranspose2d, SylvesterVAE, gc_decoder_forward,  # noqa: E402
+                                  gc_encoder_forward)
+
+SYM_STRIDES = [1, 2, 1, 2, 1]           # genesis_config.py:109,118
 
 # models/genesis_config.py:33-52
 flags.DEFINE_boolean('two_stage', True, 'Use two stages if two, else only one.')
@@ -77,8 +80,10 @@ class Genesis(nn.Module):
             # autoreg_prior off that attribute does not exist and its first forward raises
             raise AttributeError("'Genesis' object has no attribute 'prior_lstm' (autoreg_prior=False is not runnable "
                                  'in the reference either)')
-        if self.K_steps <= 1 or _cfg_get(cfg, 'comp_symmetric', False):
-            raise NotImplementedError('Genesis HIP path: K_steps > 1 and comp_symmetric=False')
+        if self.K_steps <= 1:
+            raise NotImplementedError('Genesis HIP path: K_steps > 1 (the reference\'s train.py cannot aggregate the '
+                                      '0-dim kl_m of its K_steps == 1 branch either)')
+        self.comp_symmetric = bool(_cfg_get(cfg, 'comp_symmetric', False)) and bool(self.two_stage)
         att_core = SylvesterVAE(self.ldim, [3, cfg.img_size, cfg.img_size], 1, _cfg_get(cfg, 'enc_norm', 'bn'),
                                 _cfg_get(cfg, 'dec_norm', 'bn'))
         self.att_steps = self.K_steps
@@ -87,6 +92,19 @@ class Genesis(nn.Module):
             self.comp_vae = _ComponentVAEParams(cfg, nout=3)
             self.comp_vae.pixel_bound = self.pixel_bound
             self._dec_layers = self.comp_vae.decoder_module.num_layers
+            if self.comp_symmetric:
+                # genesis_config.py:104-123: encoder / decoder of the component VAE REPLACED (after construction: same
+                # RNG consumption, same state_dict positions) by the attention VAE's gated-conv stacks
+                en, dn = _cfg_get(cfg, 'enc_norm', 'bn'), _cfg_get(cfg, 'dec_norm', 'bn')
+                k = att_core.last_kernel_size
+                enc = [GatedConv2d(i, o, 5, s_, 2, en, en)
+                       for i, o, s_ in zip([4, 32, 32, 64, 64], [32, 32, 64, 64, 64], SYM_STRIDES)]
+                enc.append(GatedConv2d(64, 2 * cfg.comp_ldim, k, 1, 0))
+                self.comp_vae.encoder_module = nn.Sequential(nn.Sequential(*enc), nn.Flatten())
+                dec = [GatedConvTranspose2d(cfg.comp_ldim, 64, k, 1, 0)]
+                dec += [GatedConvTranspose2d(i, o, 5, s_, 2, s_ - 1, dn, dn)
+                        for i, o, s_ in zip([64, 64, 32, 32, 32], [64, 32, 32, 32, 32], SYM_STRIDES)]
+                self.comp_vae.decoder_module = nn.Sequential(nn.Identity(), nn.Sequential(*dec), nn.Conv2d(32, 3, 1))
         else:
             # one stage (genesis_config.py:124-129): components decoded from the attention latents
             self.decoder = _BroadcastDecoderParams(self.ldim, 3, _cfg_get(cfg, 'comp_dec_channels', 32),
@@ -156,12 +174,16 @@ class Genesis(nn.Module):
             # --- ComponentVAE (ELU), slot-major batch, mask as first channel
             Lc = self.comp_vae.ldim
             inp = torch.cat((log_m.flatten(0, 1), x.repeat(K, 1, 1, 1)), 1)
-            em = self.comp_vae.encoder_module.module
-            h = inp
-            for i in (0, 2, 4, 6):
-                h = fn.DirectConvActFn.apply(h, em[i].weight, em[i].bias, 2, 1, 'elu')
-            h = F.elu(fn.linear(h.flatten(1), em[9].weight, em[9].bias))
-            mu_c, sig_ps = fn.linear(h, em[11].weight, em[11].bias).chunk(2, dim=1)
+            if self.comp_symmetric:
+                enc_out = gc_encoder_forward(self.comp_vae.encoder_module[0], inp, SYM_STRIDES, self.training)
+                mu_c, sig_ps = enc_out.chunk(2, dim=1)
+            else:
+                em = self.comp_vae.encoder_module.module
+                h = inp
+                for i in (0, 2, 4, 6):
+                    h = fn.DirectConvActFn.apply(h, em[i].weight, em[i].bias, 2, 1, 'elu')
+                h = F.elu(fn.linear(h.flatten(1), em[9].weight, em[9].bias))
+                mu_c, sig_ps = fn.linear(h, em[11].weight, em[11].bias).chunk(2, dim=1)
             sig_c = F.softplus(sig_ps + 0.5) + 1e-8
             if eps_c is None:
                 eps_c = torch.randn(K * B, Lc, device=x.device)
@@ -170,7 +192,11 @@ class Genesis(nn.Module):
         else:
             # --- one stage (genesis_config.py:183-191): the components come from the attention latents
             dm, z_dec = self.decoder, z.flatten(0, 1)
-        dec = fn.BroadcastDecoderFn.apply(z_dec, self._canvas_coords(x.device), 'elu', None, *dm.flat_params())   # [K*B,3,S,S]
+        if self.two_stage and self.comp_symmetric:
+            h = gc_decoder_forward(dm[1], z_dec, SYM_STRIDES, self.training)
+            dec = fn.Conv1x1Fn.apply(h, dm[2].weight, dm[2].bias)
+        else:
+            dec = fn.BroadcastDecoderFn.apply(z_dec, self._canvas_coords(x.device), 'elu', None, *dm.flat_params())   # [K*B,3,S,S]
         err, recon, x_r = fn.MixtureWFn.apply(x, dec, log_m, K, self._std12[0], self._std12[1], bool(self.pixel_bound))
         losses = AttrDict()
         losses['err'] = err

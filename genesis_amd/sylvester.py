@@ -68,25 +68,7 @@ class SylvesterVAE(nn.Module):
 
     # -------------------------------------------------------------- HIP forward pieces
     def _gate(self, unit, y):
-        """norm_h(h + b) * sigmoid(norm_g(g + b)); BatchNorm running statistics are updated like nn.BatchNorm2d."""
-        norm = unit.norm
-        if norm == 'bn' and not self.training:
-            # evaluation mode: running statistics (not the training hot path): plain pointwise ops
-            h, g = (y + unit.conv.bias.view(1, -1, 1, 1)).chunk(2, 1)
-            return unit.h_norm(h) * torch.sigmoid(unit.g_norm(g))
-        args = (unit.h_norm.weight, unit.h_norm.bias, unit.g_norm.weight, unit.g_norm.bias) if norm else (None,) * 4
-        out, stats = GatedNormFn.apply(y, unit.conv.bias, norm, *args)
-        if norm == 'bn':
-            with torch.no_grad():
-                C = out.shape[1]
-                m = y.shape[0] * y.shape[2] * y.shape[3]
-                st = stats[:4 * C].view(-1, 2)       # {mean, rstd} per unit (2C units); the rest of the buffer is scratch
-                mean, var = st[:, 0], (1.0 / st[:, 1] ** 2 - 1e-5) * (m / max(m - 1, 1))
-                for bn, sl in ((unit.h_norm, slice(0, C)), (unit.g_norm, slice(C, 2 * C))):
-                    bn.running_mean.mul_(0.9).add_(0.1 * mean[sl])
-                    bn.running_var.mul_(0.9).add_(0.1 * var[sl])
-                    bn.num_batches_tracked.add_(1)
-        return out
+        return gate_unit(unit, y, self.training)
 
     def encode_features(self, x):
         """q_z_nn -> [N, 256]."""
@@ -114,6 +96,51 @@ class SylvesterVAE(nn.Module):
             h = self._gate(unit, DirectConvFn.apply(h, unit.conv.weight, 'deconv', s, 2, s - 1))
         from .functions import Conv1x1Fn
         return Conv1x1Fn.apply(h, self.p_x_mean.weight, self.p_x_mean.bias)
+
+
+def gate_unit(unit, y, training):
+    """norm_h(h + b) * sigmoid(norm_g(g + b)) of one gated (de)conv unit (layers.py:40-101); BatchNorm running
+    statistics are updated like nn.BatchNorm2d."""
+    norm = unit.norm
+    if norm == 'bn' and not training:
+        # evaluation mode: running statistics (not the training hot path): plain pointwise ops
+        h, g = (y + unit.conv.bias.view(1, -1, 1, 1)).chunk(2, 1)
+        return unit.h_norm(h) * torch.sigmoid(unit.g_norm(g))
+    args = (unit.h_norm.weight, unit.h_norm.bias, unit.g_norm.weight, unit.g_norm.bias) if norm else (None,) * 4
+    out, stats = GatedNormFn.apply(y, unit.conv.bias, norm, *args)
+    if norm == 'bn':
+        with torch.no_grad():
+            C = out.shape[1]
+            m = y.shape[0] * y.shape[2] * y.shape[3]
+            st = stats[:4 * C].view(-1, 2)       # {mean, rstd} per unit (2C units); the rest of the buffer is scratch
+            mean, var = st[:, 0], (1.0 / st[:, 1] ** 2 - 1e-5) * (m / max(m - 1, 1))
+            for bn, sl in ((unit.h_norm, slice(0, C)), (unit.g_norm, slice(C, 2 * C))):
+                bn.running_mean.mul_(0.9).add_(0.1 * mean[sl])
+                bn.running_var.mul_(0.9).add_(0.1 * var[sl])
+                bn.num_batches_tracked.add_(1)
+    return out
+
+
+def gc_encoder_forward(units, x, strides, training):
+    """sylvester.build_gc_encoder (VAE.py:18-24) -> [N, cfc]: gated 5x5 convs (pad 2) + the gated 'fc' conv."""
+    h = x
+    for unit, s in zip(units, strides):
+        h = gate_unit(unit, DirectConvFn.apply(h, unit.conv.weight, 'conv', s, 2, 0), training)
+    unit = units[len(strides)]
+    y = fn.linear(h.flatten(1), unit.conv.weight.flatten(1)).view(h.shape[0], -1, 1, 1)
+    return gate_unit(unit, y, training).flatten(1)
+
+
+def gc_decoder_forward(units, z, strides, training):
+    """sylvester.build_gc_decoder (VAE.py:27-33): gated deconv kz from 1x1, then gated 5x5 deconvs (pad 2, out_pad s-1)."""
+    unit = units[0]
+    w = unit.conv.weight                                           # [z, 2c, k, k]
+    k = w.shape[2]
+    h = gate_unit(unit, (z @ w.flatten(1)).view(z.shape[0], w.shape[1], k, k), training)
+    for l, s in enumerate(strides):
+        unit = units[l + 1]
+        h = gate_unit(unit, DirectConvFn.apply(h, unit.conv.weight, 'deconv', s, 2, s - 1), training)
+    return h
 
 
 # ------------------------------------------------------------------ autograd Functions

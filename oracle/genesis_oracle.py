@@ -37,6 +37,62 @@ def _lstm_step(p, prefix, inp, state):
     return h, (h, c)
 
 
+SYM_STRIDES = [1, 2, 1, 2, 1]
+
+
+def _gc_encoder(p, x, prefix, norm):
+    """sylvester.build_gc_encoder (VAE.py:18-24) under `prefix`."""
+    h = x
+    for l, s in enumerate(SYM_STRIDES):
+        name = '%s.%d' % (prefix, l)
+        h = S.gated(p, name, F.conv2d(h, p[name + '.conv.weight'], p[name + '.conv.bias'], s, 2), norm)
+    name = '%s.%d' % (prefix, len(SYM_STRIDES))
+    h = S.gated(p, name, F.conv2d(h, p[name + '.conv.weight'], p[name + '.conv.bias'], 1, 0), None)
+    return h.reshape(h.size(0), -1)
+
+
+def _gc_decoder(p, z, prefix, norm):
+    """sylvester.build_gc_decoder (VAE.py:27-33) under `prefix`."""
+    h = z.view(z.size(0), -1, 1, 1)
+    name = prefix + '.0'
+    h = S.gated(p, name, F.conv_transpose2d(h, p[name + '.conv.weight'], p[name + '.conv.bias'], 1, 0), None)
+    for l, s in enumerate(SYM_STRIDES):
+        name = '%s.%d' % (prefix, l + 1)
+        h = S.gated(p, name, F.conv_transpose2d(h, p[name + '.conv.weight'], p[name + '.conv.bias'], s, 2, s - 1), norm)
+    return h
+
+
+def _gc_shapes(sh, enc_prefix, dec_prefix, nin, cfc, zdim, kfc, enc_norm, dec_norm):
+    f32, i64 = torch.float32, torch.int64
+
+    def norms(name, c, norm):
+        for hn in ('h_norm', 'g_norm'):
+            if norm in ('bn', 'in'):
+                sh['%s.%s.weight' % (name, hn)] = ((c,), f32)
+                sh['%s.%s.bias' % (name, hn)] = ((c,), f32)
+            if norm == 'bn':
+                sh['%s.%s.running_mean' % (name, hn)] = ((c,), f32)
+                sh['%s.%s.running_var' % (name, hn)] = ((c,), f32)
+                sh['%s.%s.num_batches_tracked' % (name, hn)] = ((), i64)
+
+    for l, (a, b) in enumerate(zip([nin, 32, 32, 64, 64], [32, 32, 64, 64, 64])):
+        name = '%s.%d' % (enc_prefix, l)
+        sh[name + '.conv.weight'] = ((2 * b, a, 5, 5), f32)
+        sh[name + '.conv.bias'] = ((2 * b,), f32)
+        norms(name, b, enc_norm)
+    name = '%s.5' % enc_prefix
+    sh[name + '.conv.weight'] = ((2 * cfc, 64, kfc, kfc), f32)
+    sh[name + '.conv.bias'] = ((2 * cfc,), f32)
+    name = dec_prefix + '.0'
+    sh[name + '.conv.weight'] = ((zdim, 128, kfc, kfc), f32)
+    sh[name + '.conv.bias'] = ((128,), f32)
+    for l, (a, b) in enumerate(zip([64, 64, 32, 32, 32], [64, 32, 32, 32, 32])):
+        name = '%s.%d' % (dec_prefix, l + 1)
+        sh[name + '.conv.weight'] = ((a, 2 * b, 5, 5), f32)
+        sh[name + '.conv.bias'] = ((2 * b,), f32)
+        norms(name, b, dec_norm)
+
+
 def latent_sbp(p, x, K, cfg, eps_m):
     """LatentSBP.forward (modules/attention.py:84-133) followed by the K+1 -> K mask correction of
     genesis_config.py:167-169.  eps_m: list of K [B, ldim] noises (one rsample per step)."""
@@ -87,13 +143,23 @@ def genesis_forward(p, x, cfg, eps_m=None, eps_c=None):
         return recon, losses, stats, att_stats, None
     # ComponentVAE (ELU)
     inp = torch.cat((torch.cat(log_m_k, 0), x.repeat(K, 1, 1, 1)), 1)
-    enc = M.comp_encoder(p, inp, act=F.elu)
+    sym = cfg.get('comp_symmetric', False)
+    if sym:
+        # comp_symmetric (genesis_config.py:104-123): gated-conv encoder / decoder as in the attention VAE, strides
+        # [1, 2, 1, 2, 1], 'fc' kernel = the attention core's last_kernel_size
+        enc = _gc_encoder(p, inp, 'comp_vae.encoder_module.0', cfg['enc_norm'])
+    else:
+        enc = M.comp_encoder(p, inp, act=F.elu)
     mu_c, sig_ps = enc.chunk(2, dim=1)
     sig_c = V.to_sigma(sig_ps)
     if eps_c is None:
         eps_c = torch.normal(torch.zeros(K * B, Lc), torch.ones(K * B, Lc))
     z_c = mu_c + sig_c * eps_c
-    dec = M.broadcast_decoder(p, z_c, S_, cfg['comp_dec_layers'], act=F.elu)
+    if sym:
+        h = _gc_decoder(p, z_c, 'comp_vae.decoder_module.1', cfg['dec_norm'])
+        dec = F.conv2d(h, p['comp_vae.decoder_module.2.weight'], p['comp_vae.decoder_module.2.bias'])
+    else:
+        dec = M.broadcast_decoder(p, z_c, S_, cfg['comp_dec_layers'], act=F.elu)
     if cfg.get('pixel_bound', True):
         dec = torch.sigmoid(dec)                         # comp_vae.pixel_bound (component_vae.py:89-93)
     x_r_k = list(dec.chunk(K, 0))
@@ -150,6 +216,13 @@ def param_shapes(cfg):
             sh['decoder.seq.%d.bias' % (1 + 2 * l)] = ((c,), f32)
         sh['decoder.seq.%d.weight' % (1 + 2 * nl)] = ((3, c, 1, 1), f32)
         sh['decoder.seq.%d.bias' % (1 + 2 * nl)] = ((3,), f32)
+    if two_stage and cfg.get('comp_symmetric', False):
+        kfc, _ = S.vae_geometry(S_)
+        _gc_shapes(sh, 'comp_vae.encoder_module.0', 'comp_vae.decoder_module.1', 4, 2 * Lc, Lc, kfc, cfg['enc_norm'],
+                   cfg['dec_norm'])
+        sh['comp_vae.decoder_module.2.weight'] = ((3, 32, 1, 1), f32)
+        sh['comp_vae.decoder_module.2.bias'] = ((3,), f32)
+        mon = {}
     for k, v in mon.items():
         if two_stage and k.startswith('comp_vae.'):
             if k.endswith('decoder_module.seq.%d.weight' % (1 + 2 * cfg['comp_dec_layers'])):

@@ -23,7 +23,8 @@ GEN_CASES = {'tiny': (dict(K_steps=3, img_size=32, attention_latents=16, comp_ld
              'tiny_in': (dict(K_steps=3, img_size=32, attention_latents=16, comp_ldim=8, enc_norm='in', dec_norm='in'), 3, 54, 64),
              'cfg3': (dict(K_steps=7, img_size=64), 2, 55, 65),
              'tiny_noprior': (dict(K_steps=3, img_size=32, attention_latents=16, comp_ldim=8, comp_prior=False), 2, 57, 67),
-             'tiny_onestage': (dict(K_steps=3, img_size=32, attention_latents=16, comp_ldim=8, two_stage=False), 2, 58, 68)}
+             'tiny_onestage': (dict(K_steps=3, img_size=32, attention_latents=16, comp_ldim=8, two_stage=False), 2, 58, 68),
+             'tiny_sym': (dict(K_steps=3, img_size=32, attention_latents=16, comp_ldim=8, comp_symmetric=True), 2, 59, 69)}
 
 
 def replay(seed, shapes):

@@ -13,7 +13,7 @@ from oracle import vae_oracle as VO
 
 GOLDEN = osp.join(osp.dirname(osp.abspath(__file__)), 'golden')
 VAE_CASES = ['tiny', 'cfg1', 'tiny_bcast']
-GEN_CASES = ['tiny', 'tiny_in', 'cfg3', 'tiny_noprior', 'tiny_onestage']
+GEN_CASES = ['tiny', 'tiny_in', 'cfg3', 'tiny_noprior', 'tiny_onestage', 'tiny_sym']
 
 
 class Gold(object):
