@@ -329,7 +329,7 @@ def main():
     if rank == 0 and world == 1 and args.host_input_steps > 0 and ts.graph is not None:
         from genesis_amd.feeder import DeviceFeeder
         ts.use_graph = True
-        n_warm = 20            # the ring's first slots are staged while the loop already runs: let it reach steady state
+        n_warm = 40            # the host has to get ~30 graph launches ahead of the device before the rate is steady
         n_seg = 3              # the host thread of a shared 256-CPU box is pre-empted now and then: best of three segments
         n_host = n_seg * args.host_input_steps + n_warm
         gh = torch.Generator().manual_seed(99)

@@ -78,8 +78,14 @@ class DeviceFeeder(object):
         self._host_wait(self.ready[s])       # pinned[s] is free: its previous copy has executed
         self._host_wait(self.consumed[s])    # dev_u8[s] is free: the conversion kernel that read it has run
         if self.pinned[s] is None or self.pinned[s].shape != t.shape:
-            self.pinned[s] = torch.empty(t.shape, dtype=torch.uint8).pin_memory()
-            self.dev_u8[s] = torch.empty(t.shape, dtype=torch.uint8, device=self.device)
+            # the whole ring at once, the first time a batch shape is seen: a pinned allocation costs ~1 ms of host time,
+            # and 32 of them spread over the first 32 steps let the device queue run dry (the host needs the whole next
+            # segment to get ahead again: 1.5 k -> 2.8 k -> 6.1 k img/s over the first 300 steps, measured)
+            for q in range(self.depth):
+                if self.pinned[q] is None or self.pinned[q].shape != t.shape:
+                    self._host_wait(self.ready[q]); self._host_wait(self.consumed[q])
+                    self.pinned[q] = torch.empty(t.shape, dtype=torch.uint8, pin_memory=True)
+                    self.dev_u8[q] = torch.empty(t.shape, dtype=torch.uint8, device=self.device)
         self.pinned[s].copy_(t)
         with torch.cuda.stream(self.copy_stream):
             self.dev_u8[s].copy_(self.pinned[s], non_blocking=True)
