@@ -75,11 +75,12 @@ wino_conv_kernel(const float* __restrict__ in, const float* __restrict__ U, floa
     // over this image's [K][H*W] block: voff[q] = byte offset of (channel of the chunk, pixel), or 1 GiB for a halo pixel
     // outside the image / an unused slot; the chunk's first channel rides in the scalar offset.  Out-of-range addresses
     // (padding pixels, channels >= K) read as 0 -- no compare / select per element.
-    int voff[RAW_PER_THREAD], loff[RAW_PER_THREAD];       // loff: LDS float offset inside a raw buffer, -1 = unused slot
+    int voff[RAW_PER_THREAD], loff[RAW_PER_THREAD];       // loff: LDS float offset inside a raw buffer; an unused slot stores
+                                                          // its zero into the spare 10th float of a plane row (never read)
 #pragma unroll
     for (int q = 0; q < RAW_PER_THREAD; ++q) {
         const int e = tid + 256 * q;
-        voff[q] = 0x40000000; loff[q] = -1;
+        voff[q] = 0x40000000; loff[q] = PLANE - 1;
         if (e < WKC * PR * PC) {
             const int ch = e / (PR * PC), rem = e - ch * (PR * PC);
             const int pr = rem / PC, pc = rem - pr * PC;
@@ -100,7 +101,7 @@ wino_conv_kernel(const float* __restrict__ in, const float* __restrict__ U, floa
     auto store_raw = [&](float* rbuf) {
 #pragma unroll
         for (int q = 0; q < RAW_PER_THREAD; ++q)
-            if (loff[q] >= 0) rbuf[loff[q]] = rawr[q];
+            rbuf[loff[q]] = rawr[q];
     };
     // this wave's weight operands: [m tile][chunk][position 4 wave + nu][lane][8]
     const float* Uw = U + (((size_t)blockIdx.y * nchunks) * 16 + 4 * wave) * 512 + lane * 8;
@@ -173,47 +174,53 @@ wino_conv_kernel(const float* __restrict__ in, const float* __restrict__ U, floa
         load_raw(2 * WKC);
 #pragma unroll
         for (int q = 0; q < RAW_PER_THREAD; ++q)
-            if (loff[q] >= 0) { raw[loff[q]] = r0[q]; raw[RAW_FLOATS + loff[q]] = r1[q]; }
+        { raw[loff[q]] = r0[q]; raw[RAW_FLOATS + loff[q]] = r1[q]; }
     }
     __syncthreads();
     transform(raw, V);
     __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const float* Vc = V + (c & 1) * V_FLOATS;
 #ifndef GX_WINO_ABL
 #define GX_WINO_ABL 0          // measurement builds (tools/abl_build.sh): 1 no transform, 2 no patch staging, 4 no MFMAs
 #endif
-        if (!(GX_WINO_ABL & 2) && c + 2 < nchunks) {
-            store_raw(raw + (c & 1) * RAW_FLOATS);          // chunk c + 2 (its buffer was consumed in iteration c - 1)
-            if (c + 3 < nchunks) load_raw((c + 3) * WKC);
-        }
-        f32x4 bq[4];          // this lane's B values of the chunk: [nu][channel & 3]
-#pragma unroll
-        for (int nu = 0; nu < 4; ++nu)
-            bq[nu] = *reinterpret_cast<const f32x4*>(Vc + (((4 * wave + nu) * 2 + kh) * WNT + bn) * 4);
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-#pragma unroll
-            for (int kk2 = 0; kk2 < 2; ++kk2) {
-                const int kk = 2 * half + kk2;          // MFMA kk: channel 4 kh + kk of the chunk
-#pragma unroll
-                for (int nu = 0; nu < 4; ++nu) {
-                    const float b = bq[nu][kk];
-                    if (GX_WINO_ABL & 4) { acc[nu][0][kk] += b * ua[nu][half][kk2 * 2]; continue; }
-                    acc[nu][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[nu][half][kk2 * 2], b, acc[nu][0], 0, 0, 0);
-                    acc[nu][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[nu][half][kk2 * 2 + 1], b, acc[nu][1], 0, 0, 0);
-                }
-            }
-            if (c + 1 < nchunks) {
-                if (!(GX_WINO_ABL & 8))
-#pragma unroll
-                for (int nu = 0; nu < 4; ++nu)
-                    ua[nu][half] = *reinterpret_cast<const f32x4*>(Uw + ((size_t)(c + 1) * 16 + nu) * 512 + 4 * half);
-                if (half == 0 && !(GX_WINO_ABL & 1)) transform(raw + ((c + 1) & 1) * RAW_FLOATS, V + ((c + 1) & 1) * V_FLOATS);
-            }
-        }
-        __syncthreads();
+    // One chunk.  H1 / H2 / H3: chunk c + 1 / c + 2 / c + 3 exists.  In the steady part of the loop they are compile-time
+    // `true`, so the body is ONE basic block and the scheduler can lay the transform's LDS / VALU work, the patch stores
+    // and the loads between the 32 MFMAs (with the runtime tests the body fell into five blocks, the transform into one
+    // without a single MFMA: the matrix pipe then depends on the partner workgroup of the CU to stay busy); the last
+    // three chunks of a tile take the same body with the runtime tests.
+#define GX_WINO_CHUNK(c, H1, H2, H3)                                                                                  \
+    {                                                                                                                 \
+        const float* Vc = V + ((c) & 1) * V_FLOATS;                                                                   \
+        if (!(GX_WINO_ABL & 2) && (H2)) {                                                                             \
+            store_raw(raw + ((c) & 1) * RAW_FLOATS);      /* chunk c + 2 (its buffer was consumed in iteration c - 1) */ \
+            if (H3) load_raw(((c) + 3) * WKC);                                                                        \
+        }                                                                                                             \
+        f32x4 bq[4];          /* this lane's B values of the chunk: [nu][channel & 3] */                               \
+        _Pragma("unroll") for (int nu = 0; nu < 4; ++nu)                                                              \
+            bq[nu] = *reinterpret_cast<const f32x4*>(Vc + (((4 * wave + nu) * 2 + kh) * WNT + bn) * 4);               \
+        _Pragma("unroll") for (int half = 0; half < 2; ++half) {                                                      \
+            _Pragma("unroll") for (int kk2 = 0; kk2 < 2; ++kk2) {                                                     \
+                const int kk = 2 * half + kk2;          /* MFMA kk: channel 4 kh + kk of the chunk */                  \
+                _Pragma("unroll") for (int nu = 0; nu < 4; ++nu) {                                                    \
+                    const float b = bq[nu][kk];                                                                       \
+                    if (GX_WINO_ABL & 4) { acc[nu][0][kk] += b * ua[nu][half][kk2 * 2]; continue; }                   \
+                    acc[nu][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[nu][half][kk2 * 2], b, acc[nu][0], 0, 0, 0); \
+                    acc[nu][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[nu][half][kk2 * 2 + 1], b, acc[nu][1], 0, 0, 0); \
+                }                                                                                                     \
+            }                                                                                                         \
+            if (H1) {                                                                                                 \
+                if (!(GX_WINO_ABL & 8))                                                                               \
+                    _Pragma("unroll") for (int nu = 0; nu < 4; ++nu)                                                  \
+                        ua[nu][half] = *reinterpret_cast<const f32x4*>(Uw + ((size_t)((c) + 1) * 16 + nu) * 512 + 4 * half); \
+                if (half == 0 && !(GX_WINO_ABL & 1))                                                                  \
+                    transform(raw + (((c) + 1) & 1) * RAW_FLOATS, V + (((c) + 1) & 1) * V_FLOATS);                    \
+            }                                                                                                         \
+        }                                                                                                             \
+        __syncthreads();                                                                                              \
     }
+    int c = 0;
+    for (; c + 3 < nchunks; ++c) GX_WINO_CHUNK(c, true, true, true)
+    for (; c < nchunks; ++c) GX_WINO_CHUNK(c, c + 1 < nchunks, c + 2 < nchunks, c + 3 < nchunks)
+#undef GX_WINO_CHUNK
 
     // ---- output transform.  This wave holds M[xi][nu] (xi = wave): right-multiply by A -> two columns
     //      q0 = M0 + M1 + M2, q1 = M1 - M2 - M3, exchanged through LDS; then Y[0][b] = q(xi=0) + q(1) + q(2),
