@@ -183,13 +183,20 @@ wino_conv_kernel(const float* __restrict__ in, const float* __restrict__ U, floa
 #define GX_WINO_ABL 0          // measurement builds (tools/abl_build.sh): 1 no transform, 2 no patch staging, 4 no MFMAs
 #endif
     // One chunk.  H1 / H2 / H3: chunk c + 1 / c + 2 / c + 3 exists.  In the steady part of the loop they are compile-time
-    // `true`, so the body is ONE basic block and the scheduler can lay the transform's LDS / VALU work, the patch stores
-    // and the loads between the 32 MFMAs (with the runtime tests the body fell into five blocks, the transform into one
-    // without a single MFMA: the matrix pipe then depends on the partner workgroup of the CU to stay busy); the last
+    // `true`, so the body is ONE basic block (with the runtime tests the body fell into five blocks, the transform into
+    // one without a single MFMA: the matrix pipe then depends on the partner workgroup of the CU to stay busy); the last
     // three chunks of a tile take the same body with the runtime tests.
+    // The 32 MFMAs go out in eight groups of four; the next chunk's transform is cut into pieces (patch reads | column
+    // pass | one output row each) that are pinned between the groups by scheduling fences, so that every piece runs in
+    // the shadow of the four MFMAs (256 pipe cycles) issued just before it.
+#define GX_WINO_FENCE __builtin_amdgcn_sched_barrier(0);
 #define GX_WINO_CHUNK(c, H1, H2, H3)                                                                                  \
     {                                                                                                                 \
         const float* Vc = V + ((c) & 1) * V_FLOATS;                                                                   \
+        const bool tr = (H1) && !(GX_WINO_ABL & 1);                                                                   \
+        const float* tsrc = raw + (((c) + 1) & 1) * RAW_FLOATS + tsrc_off;                                            \
+        float* tdst = V + (((c) + 1) & 1) * V_FLOATS + tdst_off;                                                      \
+        float td[4][4], tc[4][4];                                                                                     \
         if (!(GX_WINO_ABL & 2) && (H2)) {                                                                             \
             store_raw(raw + ((c) & 1) * RAW_FLOATS);      /* chunk c + 2 (its buffer was consumed in iteration c - 1) */ \
             if (H3) load_raw(((c) + 3) * WKC);                                                                        \
@@ -197,29 +204,46 @@ wino_conv_kernel(const float* __restrict__ in, const float* __restrict__ U, floa
         f32x4 bq[4];          /* this lane's B values of the chunk: [nu][channel & 3] */                               \
         _Pragma("unroll") for (int nu = 0; nu < 4; ++nu)                                                              \
             bq[nu] = *reinterpret_cast<const f32x4*>(Vc + (((4 * wave + nu) * 2 + kh) * WNT + bn) * 4);               \
-        _Pragma("unroll") for (int half = 0; half < 2; ++half) {                                                      \
-            _Pragma("unroll") for (int kk2 = 0; kk2 < 2; ++kk2) {                                                     \
-                const int kk = 2 * half + kk2;          /* MFMA kk: channel 4 kh + kk of the chunk */                  \
-                _Pragma("unroll") for (int nu = 0; nu < 4; ++nu) {                                                    \
-                    const float b = bq[nu][kk];                                                                       \
-                    if (GX_WINO_ABL & 4) { acc[nu][0][kk] += b * ua[nu][half][kk2 * 2]; continue; }                   \
-                    acc[nu][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[nu][half][kk2 * 2], b, acc[nu][0], 0, 0, 0); \
-                    acc[nu][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[nu][half][kk2 * 2 + 1], b, acc[nu][1], 0, 0, 0); \
+        GX_WINO_FENCE                                                                                                 \
+        _Pragma("unroll") for (int grp = 0; grp < 8; ++grp) {                                                         \
+            const int half = grp >> 2, kk2 = (grp >> 1) & 1, kk = 2 * half + kk2;   /* MFMA kk: channel 4 kh + kk */   \
+            _Pragma("unroll") for (int nu = 2 * (grp & 1); nu < 2 * (grp & 1) + 2; ++nu) {                            \
+                const float b = bq[nu][kk];                                                                           \
+                if (GX_WINO_ABL & 4) { acc[nu][0][kk] += b * ua[nu][half][kk2 * 2]; continue; }                       \
+                acc[nu][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[nu][half][kk2 * 2], b, acc[nu][0], 0, 0, 0);     \
+                acc[nu][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[nu][half][kk2 * 2 + 1], b, acc[nu][1], 0, 0, 0); \
+            }                                                                                                         \
+            GX_WINO_FENCE                                                                                             \
+            if (tr && grp == 0) {                                                                                     \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j) td[i][j] = tsrc[(i * 2 + (j & 1)) * PLANE + (j >> 1)]; \
+            }                                                                                                         \
+            if (tr && grp == 1) {                                                                                     \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                       \
+                    tc[0][j] = td[0][j] - td[2][j];                                                                   \
+                    tc[1][j] = td[1][j] + td[2][j];                                                                   \
+                    tc[2][j] = td[2][j] - td[1][j];                                                                   \
+                    tc[3][j] = td[1][j] - td[3][j];                                                                   \
                 }                                                                                                     \
             }                                                                                                         \
-            if (H1) {                                                                                                 \
-                if (!(GX_WINO_ABL & 8))                                                                               \
-                    _Pragma("unroll") for (int nu = 0; nu < 4; ++nu)                                                  \
-                        ua[nu][half] = *reinterpret_cast<const f32x4*>(Uw + ((size_t)((c) + 1) * 16 + nu) * 512 + 4 * half); \
-                if (half == 0 && !(GX_WINO_ABL & 1))                                                                  \
-                    transform(raw + (((c) + 1) & 1) * RAW_FLOATS, V + (((c) + 1) & 1) * V_FLOATS);                    \
+            if (tr && grp >= 2 && grp < 6) {                                                                          \
+                const int i = grp - 2;                                                                                \
+                tdst[(4 * i + 0) * (WKC * WNT)] = tc[i][0] - tc[i][2];                                                \
+                tdst[(4 * i + 1) * (WKC * WNT)] = tc[i][1] + tc[i][2];                                                \
+                tdst[(4 * i + 2) * (WKC * WNT)] = tc[i][2] - tc[i][1];                                                \
+                tdst[(4 * i + 3) * (WKC * WNT)] = tc[i][1] - tc[i][3];                                                \
             }                                                                                                         \
+            if ((H1) && !(GX_WINO_ABL & 8) && (grp & 3) == 3)                                                         \
+                _Pragma("unroll") for (int nu = 0; nu < 4; ++nu)                                                      \
+                    ua[nu][half] = *reinterpret_cast<const f32x4*>(Uw + ((size_t)((c) + 1) * 16 + nu) * 512 + 4 * half); \
+            GX_WINO_FENCE                                                                                             \
         }                                                                                                             \
         __syncthreads();                                                                                              \
     }
     int c = 0;
     for (; c + 3 < nchunks; ++c) GX_WINO_CHUNK(c, true, true, true)
     for (; c < nchunks; ++c) GX_WINO_CHUNK(c, c + 1 < nchunks, c + 2 < nchunks, c + 3 < nchunks)
+#undef GX_WINO_FENCE
 #undef GX_WINO_CHUNK
 
     // ---- output transform.  This wave holds M[xi][nu] (xi = wave): right-multiply by A -> two columns
