@@ -192,7 +192,6 @@ wino_conv_kernel(const float* __restrict__ in, const float* __restrict__ U, floa
 #define GX_WINO_FENCE __builtin_amdgcn_sched_barrier(0);
 #define GX_WINO_CHUNK(c, H1, H2, H3)                                                                                  \
     {                                                                                                                 \
-        const float* Vc = V + ((c) & 1) * V_FLOATS;                                                                   \
         const bool tr = (H1) && !(GX_WINO_ABL & 1);                                                                   \
         const float* tsrc = raw + (((c) + 1) & 1) * RAW_FLOATS + tsrc_off;                                            \
         float* tdst = V + (((c) + 1) & 1) * V_FLOATS + tdst_off;                                                      \
@@ -201,14 +200,12 @@ wino_conv_kernel(const float* __restrict__ in, const float* __restrict__ U, floa
             store_raw(raw + ((c) & 1) * RAW_FLOATS);      /* chunk c + 2 (its buffer was consumed in iteration c - 1) */ \
             if (H3) load_raw(((c) + 3) * WKC);                                                                        \
         }                                                                                                             \
-        f32x4 bq[4];          /* this lane's B values of the chunk: [nu][channel & 3] */                               \
-        _Pragma("unroll") for (int nu = 0; nu < 4; ++nu)                                                              \
-            bq[nu] = *reinterpret_cast<const f32x4*>(Vc + (((4 * wave + nu) * 2 + kh) * WNT + bn) * 4);               \
+        float blast[4];       /* the B values of the last two groups (bq is refilled for the next chunk before them) */ \
         GX_WINO_FENCE                                                                                                 \
         _Pragma("unroll") for (int grp = 0; grp < 8; ++grp) {                                                         \
             const int half = grp >> 2, kk2 = (grp >> 1) & 1, kk = 2 * half + kk2;   /* MFMA kk: channel 4 kh + kk */   \
             _Pragma("unroll") for (int nu = 2 * (grp & 1); nu < 2 * (grp & 1) + 2; ++nu) {                            \
-                const float b = bq[nu][kk];                                                                           \
+                const float b = grp < 6 ? bq[nu][kk] : blast[nu];                                                     \
                 if (GX_WINO_ABL & 4) { acc[nu][0][kk] += b * ua[nu][half][kk2 * 2]; continue; }                       \
                 acc[nu][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[nu][half][kk2 * 2], b, acc[nu][0], 0, 0, 0);     \
                 acc[nu][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[nu][half][kk2 * 2 + 1], b, acc[nu][1], 0, 0, 0); \
@@ -236,10 +233,21 @@ wino_conv_kernel(const float* __restrict__ in, const float* __restrict__ U, floa
             if ((H1) && !(GX_WINO_ABL & 8) && (grp & 3) == 3)                                                         \
                 _Pragma("unroll") for (int nu = 0; nu < 4; ++nu)                                                      \
                     ua[nu][half] = *reinterpret_cast<const f32x4*>(Uw + ((size_t)((c) + 1) * 16 + nu) * 512 + 4 * half); \
+            if (grp == 5) {       /* the chunk's only barrier sits HERE: V of chunk c + 1 is complete, and its B values */ \
+                _Pragma("unroll") for (int nu = 0; nu < 4; ++nu) blast[nu] = bq[nu][3];   /* are fetched in the shadow */  \
+                __syncthreads();                                                          /* of the last eight MFMAs  */  \
+                if (H1) {                                                                                             \
+                    const float* Vn = V + (((c) + 1) & 1) * V_FLOATS;                                                 \
+                    _Pragma("unroll") for (int nu = 0; nu < 4; ++nu)                                                  \
+                        bq[nu] = *reinterpret_cast<const f32x4*>(Vn + (((4 * wave + nu) * 2 + kh) * WNT + bn) * 4);   \
+                }                                                                                                     \
+            }                                                                                                         \
             GX_WINO_FENCE                                                                                             \
         }                                                                                                             \
-        __syncthreads();                                                                                              \
     }
+    f32x4 bq[4];              // this lane's B values of the current chunk: [nu][channel & 3]
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) bq[nu] = *reinterpret_cast<const f32x4*>(V + (((4 * wave + nu) * 2 + kh) * WNT + bn) * 4);
     int c = 0;
     for (; c + 3 < nchunks; ++c) GX_WINO_CHUNK(c, true, true, true)
     for (; c < nchunks; ++c) GX_WINO_CHUNK(c, c + 1 < nchunks, c + 2 < nchunks, c + 3 < nchunks)
