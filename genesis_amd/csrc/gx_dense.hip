@@ -14,7 +14,8 @@ namespace {
 //   A_KC: A(i,kk) = a[i*lda + kk] (contraction contiguous)   else a[kk*lda + i]
 //   B_KC: B(kk,j) = b[j*ldb + kk]                            else b[kk*ldb + j]
 //   MASK: A(i,kk) is multiplied by [mask(i,kk) > 0] (mask has A's layout): the ReLU derivative from the layer output
-//   ROWSUM: also emits rs[i] = sum_kk A(i,kk) (bias gradient), by the workgroups of the first column tile
+//   ROWSUM: also emits rs[i] = sum_kk A(i,kk) (bias gradient; rs2: a second copy), by the workgroups of the first
+//   column tile.  act: 0 none, 1 ReLU, 2 add to what the destination holds
 // Lane (idx = lane & 15, kq = lane >> 4) owns contraction indices k16 + 4 kq + {0..3}; MFMA step jj consumes index
 // 4 kq + jj from every kq -- a permutation of the 16 indices that A and B share, so contiguous operands load float4.
 template <bool A_KC, bool B_KC, bool MASK, bool ROWSUM>
@@ -22,7 +23,7 @@ __device__ __forceinline__ void
 dense_tile(float (*part)[256], float (*rpart)[16], int bx, int by, const float* __restrict__ a, int lda,
            const float* __restrict__ mask, const float* __restrict__ b, int ldb, const float* __restrict__ bias,
            int act, float* __restrict__ c, int ldc, int I, int J, int Kc, float* __restrict__ rs, int vec_a,
-           int vec_b) {
+           int vec_b, float* __restrict__ rs2 = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int idx = lane & 15, kq = lane >> 4;
     const int i0 = by * 16, j0 = bx * 16;
@@ -104,6 +105,7 @@ dense_tile(float (*part)[256], float (*rpart)[16], int bx, int by, const float* 
         if (ci < I && cj < J) {
             if (bias) s += bias[cj];
             if (act == 1) s = s > 0.f ? s : 0.f;
+            if (act == 2) s += c[(size_t)ci * ldc + cj];      // accumulate into the destination
             c[(size_t)ci * ldc + cj] = s;
         }
     }
@@ -111,6 +113,7 @@ dense_tile(float (*part)[256], float (*rpart)[16], int bx, int by, const float* 
         float s = rpart[0][threadIdx.x];
         for (int w = 1; w < nw; ++w) s += rpart[w][threadIdx.x];
         rs[i0 + threadIdx.x] = s;
+        if (rs2) rs2[i0 + threadIdx.x] = s;
     }
 }
 
@@ -118,28 +121,29 @@ template <bool A_KC, bool B_KC, bool MASK, bool ROWSUM>
 __global__ void __launch_bounds__(1024)
 dense_kernel(const float* __restrict__ a, int lda, const float* __restrict__ mask, const float* __restrict__ b,
              int ldb, const float* __restrict__ bias, int act, float* __restrict__ c, int ldc, int I, int J, int Kc,
-             float* __restrict__ rs, int vec_a, int vec_b) {
+             float* __restrict__ rs, int vec_a, int vec_b, float* __restrict__ rs2) {
     __shared__ float part[16][256];
     __shared__ float rpart[16][16];
     dense_tile<A_KC, B_KC, MASK, ROWSUM>(part, rpart, blockIdx.x, blockIdx.y, a, lda, mask, b, ldb, bias, act, c, ldc,
-                                         I, J, Kc, rs, vec_a, vec_b);
+                                         I, J, Kc, rs, vec_a, vec_b, rs2);
 }
 
 // Both halves of a layer's backward in one launch (they are independent, and a kernel boundary costs more than
 // either): rows [0, gy_dx) of the grid compute dx[M,K] = dpre[M,N] w[N,K], the rest dw[N,K] = dpre^T x (+ db).
 template <bool MASK, bool ROWSUM>
 __global__ void __launch_bounds__(1024)
-dense_bwd_pair_kernel(const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ w,
-                      const float* __restrict__ x, float* __restrict__ dx, float* __restrict__ dw,
-                      float* __restrict__ db, int M, int N, int K, int gy_dx, int vec) {
+dense_bwd_pair_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ y, const float* __restrict__ w,
+                      const float* __restrict__ x, int ldx, float* __restrict__ dx, int lddx, int dx_act,
+                      float* __restrict__ dw, float* __restrict__ db, float* __restrict__ db2, int M, int N, int K,
+                      int gy_dx, int vec) {
     __shared__ float part[16][256];
     __shared__ float rpart[16][16];
     if ((int)blockIdx.y < gy_dx)
-        dense_tile<true, false, MASK, false>(part, rpart, blockIdx.x, blockIdx.y, g, N, y, w, K, nullptr, 0, dx, K, M,
-                                             K, N, nullptr, vec, 0);
+        dense_tile<true, false, MASK, false>(part, rpart, blockIdx.x, blockIdx.y, g, ldg, y, w, K, nullptr, dx_act, dx,
+                                             lddx, M, K, N, nullptr, vec, 0);
     else
-        dense_tile<false, false, MASK, ROWSUM>(part, rpart, blockIdx.x, blockIdx.y - gy_dx, g, N, y, x, K, nullptr, 0,
-                                               dw, K, N, K, M, db, 0, 0);
+        dense_tile<false, false, MASK, ROWSUM>(part, rpart, blockIdx.x, blockIdx.y - gy_dx, g, ldg, y, x, ldx, nullptr,
+                                               0, dw, K, N, K, M, db, 0, 0, db2);
 }
 
 // ------------------------------------------------------------------------------------------------ LSTM cell
@@ -262,39 +266,50 @@ inline int dense_threads(int Kc) { return Kc >= 1024 ? 1024 : 256; }
 
 extern "C" {
 
-int gx_linear_fwd(const float* x, const float* w, const float* b, int act, float* y, int M, int N, int K,
-                  gx_stream_t stream) {
+int gx_linear_fwd_ld(const float* x, int ldx, const float* w, const float* b, int act, float* y, int ldy, int M,
+                     int N, int K, gx_stream_t stream) {
     GX_CHECK_ARG(x && w && y, "gx_linear_fwd: null pointer");
     GX_CHECK_ARG(M > 0 && N > 0 && K > 0, "gx_linear_fwd: bad M/N/K (%d,%d,%d)", M, N, K);
+    GX_CHECK_ARG(ldx >= K && ldy >= N, "gx_linear_fwd: row strides (%d,%d) shorter than the rows (%d,%d)", ldx, ldy, K, N);
     GX_CHECK_ARG(act == 0 || act == 1, "gx_linear_fwd: act must be 0 (none) or 1 (ReLU)");
     hipStream_t s = (hipStream_t)stream;
-    const int vec = (K % 4 == 0) && aligned16(x) && aligned16(w);
+    const int vec_w = (K % 4 == 0) && aligned16(w);
+    const int vec_x = vec_w && (ldx % 4 == 0) && aligned16(x);
     {
         GxProf pf(KID_DENSE, s, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
         hipLaunchKernelGGL((dense_kernel<true, true, false, false>), dim3(gx_ceil_div(N, 16), gx_ceil_div(M, 16)),
-                           dim3(dense_threads(K)), 0, s, x, K, (const float*)nullptr, w, K, b, act, y, N, M, N, K,
-                           (float*)nullptr, vec, vec);
+                           dim3(dense_threads(K)), 0, s, x, ldx, (const float*)nullptr, w, K, b, act, y, ldy, M, N, K,
+                           (float*)nullptr, vec_x, vec_w, (float*)nullptr);
     }
     GX_CHECK_LAUNCH("gx_linear_fwd");
     return GX_OK;
 }
 
-int gx_linear_bwd(const float* x, const float* w, const float* y, const float* g, int act, float* dx, float* dw,
-                  float* db, int M, int N, int K, gx_stream_t stream) {
+int gx_linear_fwd(const float* x, const float* w, const float* b, int act, float* y, int M, int N, int K,
+                  gx_stream_t stream) {
+    return gx_linear_fwd_ld(x, K, w, b, act, y, N, M, N, K, stream);
+}
+
+int gx_linear_bwd_ex(const float* x, int ldx, const float* w, const float* y, const float* g, int ldg, int act,
+                     float* dx, int lddx, int dx_accumulate, float* dw, float* db, float* db2, int M, int N, int K,
+                     gx_stream_t stream) {
     GX_CHECK_ARG(x && w && g, "gx_linear_bwd: null pointer");
     GX_CHECK_ARG(M > 0 && N > 0 && K > 0, "gx_linear_bwd: bad M/N/K (%d,%d,%d)", M, N, K);
+    GX_CHECK_ARG(ldx >= K && ldg >= N && (!dx || lddx >= K), "gx_linear_bwd: a row stride is shorter than its rows");
     GX_CHECK_ARG(act == 0 || (act == 1 && y), "gx_linear_bwd: act 1 (ReLU) needs the layer output y");
     GX_CHECK_ARG(dw || !db, "gx_linear_bwd: db is produced together with dw");
+    GX_CHECK_ARG(db || !db2, "gx_linear_bwd: db2 is a second copy of db");
     hipStream_t s = (hipStream_t)stream;
+    const int vec = (N % 4 == 0) && (ldg % 4 == 0) && aligned16(g) && (act == 0 || aligned16(y));
+    const int dx_act = dx_accumulate ? 2 : 0;
     if (dx && dw) {   // one launch for both
-        const int vec = (N % 4 == 0) && aligned16(g) && (act == 0 || aligned16(y));
         GxProf pf(KID_DENSE, s, 4.0 * M * N * K, 4.0 * (4.0 * M * N + 2.0 * N * K + 2.0 * M * K));
         const int gy_dx = gx_ceil_div(M, 16);
         const dim3 grid(gx_ceil_div(K, 16), gy_dx + gx_ceil_div(N, 16)), block(dense_threads(M > N ? M : N));
         const float* mask = act == 1 ? y : nullptr;
 #define GX_PAIR(MASK, ROWSUM)                                                                                        \
-        hipLaunchKernelGGL((dense_bwd_pair_kernel<MASK, ROWSUM>), grid, block, 0, s, g, mask, w, x, dx, dw, db, M, N, \
-                           K, gy_dx, vec)
+        hipLaunchKernelGGL((dense_bwd_pair_kernel<MASK, ROWSUM>), grid, block, 0, s, g, ldg, mask, w, x, ldx, dx,    \
+                           lddx, dx_act, dw, db, db2, M, N, K, gy_dx, vec)
         if (act == 1) { if (db) GX_PAIR(true, true); else GX_PAIR(true, false); }
         else          { if (db) GX_PAIR(false, true); else GX_PAIR(false, false); }
 #undef GX_PAIR
@@ -302,16 +317,15 @@ int gx_linear_bwd(const float* x, const float* w, const float* y, const float* g
         return GX_OK;
     }
     if (dx) {   // dx[M,K] = dpre[M,N] w[N,K]
-        const int vec = (N % 4 == 0) && aligned16(g) && (act == 0 || aligned16(y));
         GxProf pf(KID_DENSE, s, 2.0 * M * N * K, 4.0 * (2.0 * M * N + (double)N * K + (double)M * K));
         const dim3 grid(gx_ceil_div(K, 16), gx_ceil_div(M, 16)), block(dense_threads(N));
         if (act == 1)
-            hipLaunchKernelGGL((dense_kernel<true, false, true, false>), grid, block, 0, s, g, N, y, w, K,
-                               (const float*)nullptr, 0, dx, K, M, K, N, (float*)nullptr, vec, 0);
+            hipLaunchKernelGGL((dense_kernel<true, false, true, false>), grid, block, 0, s, g, ldg, y, w, K,
+                               (const float*)nullptr, dx_act, dx, lddx, M, K, N, (float*)nullptr, vec, 0, (float*)nullptr);
         else
-            hipLaunchKernelGGL((dense_kernel<true, false, false, false>), grid, block, 0, s, g, N,
-                               (const float*)nullptr, w, K, (const float*)nullptr, 0, dx, K, M, K, N,
-                               (float*)nullptr, vec, 0);
+            hipLaunchKernelGGL((dense_kernel<true, false, false, false>), grid, block, 0, s, g, ldg,
+                               (const float*)nullptr, w, K, (const float*)nullptr, dx_act, dx, lddx, M, K, N,
+                               (float*)nullptr, vec, 0, (float*)nullptr);
     }
     GX_CHECK_LAUNCH("gx_linear_bwd(dx)");
     if (dw) {   // dw[N,K] = dpre^T[N,M] x[M,K];  db[N] = row sums of dpre^T
@@ -319,23 +333,29 @@ int gx_linear_bwd(const float* x, const float* w, const float* y, const float* g
         const dim3 grid(gx_ceil_div(K, 16), gx_ceil_div(N, 16)), block(dense_threads(M));
         if (act == 1) {
             if (db)
-                hipLaunchKernelGGL((dense_kernel<false, false, true, true>), grid, block, 0, s, g, N, y, x, K,
-                                   (const float*)nullptr, 0, dw, K, N, K, M, db, 0, 0);
+                hipLaunchKernelGGL((dense_kernel<false, false, true, true>), grid, block, 0, s, g, ldg, y, x, ldx,
+                                   (const float*)nullptr, 0, dw, K, N, K, M, db, 0, 0, db2);
             else
-                hipLaunchKernelGGL((dense_kernel<false, false, true, false>), grid, block, 0, s, g, N, y, x, K,
-                                   (const float*)nullptr, 0, dw, K, N, K, M, (float*)nullptr, 0, 0);
+                hipLaunchKernelGGL((dense_kernel<false, false, true, false>), grid, block, 0, s, g, ldg, y, x, ldx,
+                                   (const float*)nullptr, 0, dw, K, N, K, M, (float*)nullptr, 0, 0, (float*)nullptr);
         } else {
             if (db)
-                hipLaunchKernelGGL((dense_kernel<false, false, false, true>), grid, block, 0, s, g, N,
-                                   (const float*)nullptr, x, K, (const float*)nullptr, 0, dw, K, N, K, M, db, 0, 0);
+                hipLaunchKernelGGL((dense_kernel<false, false, false, true>), grid, block, 0, s, g, ldg,
+                                   (const float*)nullptr, x, ldx, (const float*)nullptr, 0, dw, K, N, K, M, db, 0, 0,
+                                   db2);
             else
-                hipLaunchKernelGGL((dense_kernel<false, false, false, false>), grid, block, 0, s, g, N,
-                                   (const float*)nullptr, x, K, (const float*)nullptr, 0, dw, K, N, K, M,
-                                   (float*)nullptr, 0, 0);
+                hipLaunchKernelGGL((dense_kernel<false, false, false, false>), grid, block, 0, s, g, ldg,
+                                   (const float*)nullptr, x, ldx, (const float*)nullptr, 0, dw, K, N, K, M,
+                                   (float*)nullptr, 0, 0, (float*)nullptr);
         }
     }
     GX_CHECK_LAUNCH("gx_linear_bwd(dw)");
     return GX_OK;
+}
+
+int gx_linear_bwd(const float* x, const float* w, const float* y, const float* g, int act, float* dx, float* dw,
+                  float* db, int M, int N, int K, gx_stream_t stream) {
+    return gx_linear_bwd_ex(x, K, w, y, g, N, act, dx, K, 0, dw, db, nullptr, M, N, K, stream);
 }
 
 int gx_lstm_step_fwd(const float* gx, const float* h_prev, const float* c_prev, const float* w_hh,

@@ -225,13 +225,14 @@ class UNetEncoderFn(torch.autograd.Function):
         # bottleneck MLP: three Linear+ReLU on the dense MFMA kernel (modules/unet.py:58-62,83)
         h = mlp_in.view(N, -1)
         mlp_acts = []
-        for q in range(3):
-            y_ = hip.linear_fwd(h, mlp[2 * q], mlp[2 * q + 1], 'relu')
-            mlp_acts.append((h, y_))
-            h = y_
         fs = mlp_in.shape[2]
         cx0 = cats[0].shape[1] - mlp_in.shape[1]
-        cats[0][:, :cx0].copy_(h.view(N, cx0, fs, fs))
+        for q in range(3):
+            # the last layer writes straight into its channels of the first up-block's concat buffer (row-strided)
+            dst = cats[0].view(N, -1)[:, :cx0 * fs * fs] if q == 2 else None
+            y_ = hip.linear_fwd(h, mlp[2 * q], mlp[2 * q + 1], 'relu', out=dst)
+            mlp_acts.append((h, y_))
+            h = y_
         saved_up = []
         out = None
         for j in range(nb):
@@ -276,7 +277,7 @@ class UNetEncoderFn(torch.autograd.Function):
         # MLP backward
         mlp, mlp_acts, mlp_in_shape = ctx.mlp
         cx0 = cats[0].shape[1] - mlp_in_shape[1]
-        g_h = dcat[0][:, :cx0].reshape(mlp_acts[2][1].shape).contiguous()
+        g_h = dcat[0].view(dcat[0].shape[0], -1)[:, :mlp_acts[2][1].shape[1]]     # row-strided view, like the output
         g_mlp = [None] * 6
         for q in reversed(range(3)):
             w_, b_ = mlp[2 * q], mlp[2 * q + 1]
@@ -990,3 +991,62 @@ class LSTMFn(torch.autograd.Function):
             o_bhh.copy_(db)
         return (dx.view(T, B, D) if dx is not None else None, _ret(o_wih, dw_ih), _ret(o_whh, dw_hh), _ret(o_bih, db),
                 _ret(o_bhh, db))
+
+
+@ctx_bound
+class ARPriorKLFn(torch.autograd.Function):
+    """The whole autoregressive-prior KL term of GENESIS-V2 as ONE autograd node (models/genesis_config.py:297-331 with
+    prior_lstm / prior_linear): z [K,B,D], log_q [K,B] -> kl [K,B] = log_q - log p(z_k | z_<k).  Same launches as
+    LSTMFn -> LinearFn -> PriorLogPFn chained, but z's uses inside the term (LSTM input z[:-1], the Gaussian's
+    argument) no longer meet in autograd: the LSTM's input gradient is ADDED to the log-density's dz by the dense kernel
+    (no slice-backward fill + copy, no accumulation launch), and b_ih / b_hh receive their common gradient from one
+    launch."""
+
+    @staticmethod
+    def forward(ctx, z, log_q, w_ih, w_hh, b_ih, b_hh, w_lin, b_lin):
+        z = z.contiguous()
+        log_q = log_q.contiguous()
+        K, B, D = z.shape
+        T, H = K - 1, w_hh.shape[1]
+        dev = z.device
+        gx3 = hip.linear_fwd(z.view(K * B, D)[:T * B], w_ih, b_ih).view(T, B, 4 * H)
+        act = torch.empty(T, B, 4 * H, device=dev)
+        c = torch.empty(T, B, H, device=dev)
+        h = torch.empty(T, B, H, device=dev)
+        for t in range(T):
+            hip.lstm_step_fwd(gx3[t], h[t - 1] if t else None, c[t - 1] if t else None, w_hh, b_hh, act[t], c[t], h[t])
+        lin = hip.linear_fwd(h.view(T * B, H), w_lin, b_lin).view(T, B, -1)
+        kl = hip.latent_prior_logp_fwd(z, lin, log_q)
+        ctx.save_for_backward(z, act, c, h, lin)
+        ctx.params = (w_ih, w_hh, b_ih, b_hh, w_lin, b_lin)
+        return kl
+
+    @staticmethod
+    def backward(ctx, g):
+        z, act, c, h, lin = ctx.saved_tensors
+        w_ih, w_hh, b_ih, b_hh, w_lin, b_lin = ctx.params
+        K, B, D = z.shape
+        T, H = K - 1, w_hh.shape[1]
+        dev = z.device
+        g = g.contiguous()
+        dz, dlin = hip.latent_prior_logp_bwd(z, lin, g, True)
+        o_wl, o_bl = _gout(w_lin), _gout(b_lin)
+        dh, dw_lin, db_lin = hip.linear_bwd(h.view(T * B, H), w_lin, None, dlin.view(T * B, -1), None, out_dw=o_wl,
+                                            out_db=o_bl)
+        dh = dh.view(T, B, H)
+        dgates = torch.empty(T, B, 4 * H, device=dev)
+        dc = [torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)]
+        for t in reversed(range(T)):
+            hip.lstm_step_bwd(dh[t], dgates[t + 1] if t + 1 < T else None, w_hh, act[t], c[t],
+                              c[t - 1] if t else None, dc[(t + 1) & 1] if t + 1 < T else None, dgates[t], dc[t & 1])
+        o_wih, o_whh, o_bih, o_bhh = _gout(w_ih), _gout(w_hh), _gout(b_ih), _gout(b_hh)
+        _, dw_ih, db = hip.linear_bwd(z.view(K * B, D)[:T * B], w_ih, None, dgates.view(T * B, 4 * H), None,
+                                      out_dw=o_wih, out_db=o_bih, out_db2=o_bhh,
+                                      accumulate_dx=dz.view(K * B, D)[:T * B])
+        if T > 1:
+            _, dw_hh, _ = hip.linear_bwd(h[:-1].view((T - 1) * B, H), w_hh, None, dgates[1:].view((T - 1) * B, 4 * H),
+                                         None, need_dx=False, need_db=False, out_dw=o_whh)
+        else:
+            dw_hh = torch.zeros_like(w_hh) if o_whh is None else o_whh.zero_()
+        return (dz, g, _ret(o_wih, dw_ih), _ret(o_whh, dw_hh), _ret(o_bih, db), _ret(o_bhh, db), _ret(o_wl, dw_lin),
+                _ret(o_bl, db_lin))

@@ -266,6 +266,10 @@ class GenesisV2(nn.Module):
         """[K,B]: log q(z_k|x) - log p(z_k|z_<k) per slot (Genesis.mask_latent_loss, models/genesis_config.py:288-343)."""
         lin = None
         if self.prior_lstm is not None:
+            if USE_FUSED_LSTM and z.shape[0] > 1:
+                L, P = self.prior_lstm, self.prior_linear
+                return fn.ARPriorKLFn.apply(z, log_q, L.weight_ih_l0, L.weight_hh_l0, L.bias_ih_l0, L.bias_hh_l0,
+                                            P.weight, P.bias)
             lin = fn.linear(self._prior_hidden(z), self.prior_linear.weight, self.prior_linear.bias)  # [K-1,B,2D]
         return fn.PriorLogPFn.apply(z, lin, log_q)
 

@@ -722,28 +722,51 @@ def pooled_head_bwd(lin, msum, fbias, gamma, stats, g, out=(None, None, None)):
 
 
 # ---------------------------------------------------------------------------------------------- dense layers
-def linear_fwd(x, w, b=None, act=None):
-    """act(x [M,K] @ w[N,K]^T + b) (nn.Linear (+ReLU))."""
-    _chk(x, 'linear.x'); _chk(w, 'linear.w'); _chk(b, 'linear.b')
+def _rows(t, name):
+    """[M, n] tensor whose rows are contiguous (row stride >= n): returns its row stride."""
+    if t.dim() != 2 or t.stride(1) != 1 or t.stride(0) < t.shape[1] or t.dtype != F32 or not t.is_cuda:
+        raise GenesisHipError('%s: needs a float32 device matrix with contiguous rows, got %s strides %s'
+                              % (name, tuple(t.shape), tuple(t.stride())))
+    return t.stride(0)
+
+
+def linear_fwd(x, w, b=None, act=None, out=None):
+    """act(x [M,K] @ w[N,K]^T + b) (nn.Linear (+ReLU)).  x and out may be row-strided views (columns of a larger
+    buffer); out: write the result there instead of a fresh [M,N] tensor."""
+    _chk(w, 'linear.w'); _chk(b, 'linear.b')
+    ldx = _rows(x, 'linear.x')
     M, K = x.shape
     N = w.shape[0]
     if w.shape[1] != K:
         raise GenesisHipError('linear_fwd: x is [%d,%d] but w is %s' % (M, K, tuple(w.shape)))
-    y = torch.empty(M, N, dtype=F32, device=x.device)
-    _lib.call('gx_linear_fwd', _p(x), _p(w), _p(b), ACTS[act], _p(y), M, N, K, _stream())
+    y = torch.empty(M, N, dtype=F32, device=x.device) if out is None else out
+    ldy = _rows(y, 'linear.out')
+    if tuple(y.shape) != (M, N):
+        raise GenesisHipError('linear_fwd: out is %s, expected (%d, %d)' % (tuple(y.shape), M, N))
+    _lib.call('gx_linear_fwd_ld', _p(x), ldx, _p(w), _p(b), ACTS[act], _p(y), ldy, M, N, K, _stream())
     return y
 
 
-def linear_bwd(x, w, y, g, act=None, need_dx=True, need_dw=True, need_db=True, out_dw=None, out_db=None):
-    """Returns (dx, dw, db); out_dw / out_db: write the parameter gradients into these buffers."""
-    _chk(g, 'linear_bwd.g')
+def linear_bwd(x, w, y, g, act=None, need_dx=True, need_dw=True, need_db=True, out_dw=None, out_db=None,
+               out_db2=None, accumulate_dx=None):
+    """Returns (dx, dw, db); out_dw / out_db: write the parameter gradients into these buffers (out_db2: a second copy
+    of db).  x, and (y, g) with one common row stride, may be row-strided views.  accumulate_dx: a [M,K] (row-strided)
+    tensor that dx is ADDED to (returned as dx)."""
     M, K = x.shape
     N = w.shape[0]
     dev = x.device
-    dx = torch.empty(M, K, dtype=F32, device=dev) if need_dx else None
+    ldx, ldg = _rows(x, 'linear_bwd.x'), _rows(g, 'linear_bwd.g')
+    if y is not None and _rows(y, 'linear_bwd.y') != ldg:
+        raise GenesisHipError('linear_bwd: y and g must share a row stride')
+    if accumulate_dx is not None:
+        dx = accumulate_dx
+    else:
+        dx = torch.empty(M, K, dtype=F32, device=dev) if need_dx else None
+    lddx = _rows(dx, 'linear_bwd.dx') if dx is not None else K
     dw = (out_dw if out_dw is not None else torch.empty(N, K, dtype=F32, device=dev)) if need_dw else None
     db = (out_db if out_db is not None else torch.empty(N, dtype=F32, device=dev)) if (need_db and need_dw) else None
-    _lib.call('gx_linear_bwd', _p(x), _p(w), _p(y), _p(g), ACTS[act], _p(dx), _p(dw), _p(db), M, N, K, _stream())
+    _lib.call('gx_linear_bwd_ex', _p(x), ldx, _p(w), _p(y), _p(g), ldg, ACTS[act], _p(dx), lddx,
+              int(accumulate_dx is not None), _p(dw), _p(db), _p(out_db2 if db is not None else None), M, N, K, _stream())
     return dx, dw, db
 
 

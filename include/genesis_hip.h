@@ -356,6 +356,17 @@ int gx_linear_fwd(const float* x, const float* w, const float* b, int act, float
                   gx_stream_t stream);
 int gx_linear_bwd(const float* x, const float* w, const float* y, const float* g, int act, float* dx, float* dw,
                   float* db, int M, int N, int K, gx_stream_t stream);
+/*      Strided variants for operands that live inside larger buffers (the UNet bottleneck MLP writes its last
+ *      layer straight into the first up-block's concat buffer, modules/unet.py:83-84, and reads that layer's
+ *      gradient out of the concat buffer's gradient; the AR prior's LSTM input z[:-1] is the leading part of z):
+ *      ldx / ldy / ldg / lddx = row strides in floats (>= the row length); y and g of the backward share ldg.
+ *      dx_accumulate != 0: dx += dpre w (the second consumer of a tensor adds its gradient in place);
+ *      db2 (may be NULL): a second copy of db (nn.LSTM's b_ih and b_hh have the same gradient). */
+int gx_linear_fwd_ld(const float* x, int ldx, const float* w, const float* b, int act, float* y, int ldy, int M,
+                     int N, int K, gx_stream_t stream);
+int gx_linear_bwd_ex(const float* x, int ldx, const float* w, const float* y, const float* g, int ldg, int act,
+                     float* dx, int lddx, int dx_accumulate, float* dw, float* db, float* db2, int M, int N, int K,
+                     gx_stream_t stream);
 
 /* ---- LSTM cell step (nn.LSTM, one layer, gate order i, f, g, o: models/genesis_config.py:105 prior_lstm, :297-307;
  *      modules/attention.py LatentSBP core).  The caller computes gx = x w_ih^T + b_ih for all steps with

@@ -489,6 +489,63 @@ def test_linear(M, N, K, act, bias):
         close(bg.grad, br.grad, rtol=1e-4, atol=1e-5, msg='db')
 
 
+@pytest.mark.parametrize('M,N,K,act', [(32, 2048, 128, 'relu'), (192, 1024, 64, None), (7, 20, 12, 'relu')])
+def test_linear_strided_and_accumulating(M, N, K, act):
+    """gx_linear_fwd_ld / gx_linear_bwd_ex: operands that are column ranges of wider buffers (the UNet MLP's output in
+    the concat buffer, z[:-1] inside z), dx added in place, db written twice -- against the contiguous entry points,
+    which must give the same bits (same tiles, same reduction order)."""
+    from genesis_amd import hip_ops as hip
+    x = rnd(M, K, seed=1).to(DEV)
+    w = rnd(N, K, seed=2, scale=1.0 / np.sqrt(K)).to(DEV)
+    b = rnd(N, seed=3).to(DEV)
+    g = rnd(M, N, seed=4).to(DEV)
+    y0 = hip.linear_fwd(x, w, b, act)
+    wide_x = torch.full((M, K + 12), 7.0, device=DEV); wide_x[:, 4:4 + K] = x
+    wide_y = torch.full((M, N + 8), -3.0, device=DEV)
+    y1 = hip.linear_fwd(wide_x[:, 4:4 + K], w, b, act, out=wide_y[:, 8:])
+    assert torch.equal(y1, y0) and float(wide_y[:, :8].min()) == -3.0 == float(wide_y[:, :8].max())
+    dx0, dw0, db0 = hip.linear_bwd(x, w, y0 if act else None, g, act)
+    wide_g = torch.zeros(M, N + 8, device=DEV); wide_g[:, 8:] = g
+    base = rnd(M, K + 12, seed=9).to(DEV)
+    acc = base.clone()
+    db2 = torch.empty(N, device=DEV)
+    dx1, dw1, db1 = hip.linear_bwd(wide_x[:, 4:4 + K], w, wide_y[:, 8:] if act else None, wide_g[:, 8:], act,
+                                   out_db2=db2, accumulate_dx=acc[:, 4:4 + K])
+    assert torch.equal(dw1, dw0) and torch.equal(db1, db0) and torch.equal(db2, db0)
+    assert torch.equal(acc[:, 4:4 + K], base[:, 4:4 + K] + dx0)
+    assert torch.equal(acc[:, :4], base[:, :4]) and torch.equal(acc[:, 4 + K:], base[:, 4 + K:])
+    with pytest.raises(Exception):
+        hip.linear_fwd(wide_x.t()[4:4 + K].t()[:, ::2], w[:, ::2].contiguous(), b, act)      # rows not contiguous
+
+
+@pytest.mark.parametrize('K,B,D,H', [(7, 32, 64, 256), (3, 5, 16, 32), (2, 4, 8, 16)])
+def test_ar_prior_kl_node_equals_the_chained_functions(K, B, D, H):
+    """ARPriorKLFn (one autograd node for LSTM -> Linear -> log-density KL) against LSTMFn -> linear -> PriorLogPFn:
+    the same kernels in the same order, so values and parameter gradients are bit-equal; dz differs only by the order
+    in which its two contributions are added (round-off)."""
+    from genesis_amd import functions as fn
+    g0 = torch.Generator().manual_seed(3)
+    mk = lambda *s: ((torch.rand(*s, generator=g0) * 2 - 1) * 0.3).to(DEV)  # noqa: E731
+    params = [mk(4 * H, D), mk(4 * H, H), mk(4 * H), mk(4 * H), mk(2 * D, H), mk(2 * D)]
+    z, log_q, gk = rnd(K, B, D, seed=1).to(DEV), rnd(K, B, seed=2).to(DEV), rnd(K, B, seed=3).to(DEV)
+
+    def run(fused):
+        ps = [p.clone().requires_grad_() for p in params]
+        zz, lq = z.clone().requires_grad_(), log_q.clone().requires_grad_()
+        if fused:
+            kl = fn.ARPriorKLFn.apply(zz, lq, *ps)
+        else:
+            h = fn.LSTMFn.apply(zz[:-1], *ps[:4])
+            kl = fn.PriorLogPFn.apply(zz, fn.linear(h, ps[4], ps[5]), lq)
+        (kl * gk).sum().backward()
+        return [kl.detach(), zz.grad, lq.grad] + [p.grad for p in ps]
+    a, b = run(True), run(False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+    for u, v in zip(a[3:], b[3:]):
+        assert torch.equal(u, v)
+    close(a[1], b[1], rtol=1e-6, atol=1e-7, msg='dz')
+
+
 @pytest.mark.parametrize('T,B,D,H', [(6, 32, 64, 256), (1, 3, 16, 16), (4, 17, 8, 32)])
 def test_lstm(T, B, D, H):
     """Fused LSTM (dense input projection + one launch per step) vs nn.LSTM in fp64; rtol 1e-5 fwd, 1e-4 grads."""
