@@ -200,6 +200,74 @@ bcast_conv_bwd_finish_kernel(const float* __restrict__ sums, const float* __rest
     }
 }
 
+
+// ---- transposed conv (k5, s2, p2, op1) on a spatially BROADCAST input (models/genesisv2_config.py:89-90: the decoder's
+// first layer sees z[n] repeated over the d x d grid plus two coordinate channels).  Because the input is constant over
+// the pixels, out[n, co, oy, ox] = sum_ci z[n, ci] * Wz[ci][co][oy][ox] + C[co][oy][ox] with
+//   Wz[ci][co][oy][ox] = sum over the taps (kh, kw) that reach (oy, ox) from inside the grid of w[ci][co][kh][kw]
+//   C [co][oy][ox]     = b[co] + sum_c sum_taps w[D + c][co][kh][kw] * coords[c][iy][ix]       (input independent)
+// i.e. a [N, D] x [D, Cout (2d)^2] matrix product (1/(number of taps) of the multiplies, no canvas in memory, and the
+// input gradient needs no reduction over pixels).  pack builds Wz^T (nn.Linear weight layout [Cout (2d)^2, D]) and C
+// from the layer's parameters every step; unpack folds the gradients of Wz^T and C back onto w and b.
+// Tap geometry: oy = 2 iy - 2 + kh, iy in [0, d).
+__global__ void __launch_bounds__(256)
+bcast_deconv_pack_kernel(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ coords,
+                         int D, int Cout, int d, float* __restrict__ wz, float* __restrict__ bias) {
+    const int P = 4 * d * d, W2 = 2 * d;
+    const size_t total = (size_t)Cout * P * D;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int ci = (int)(idx % D);
+        const int row = (int)(idx / D);                 // co * P + oy * W2 + ox
+        const int co = row / P, pos = row - co * P, oy = pos / W2, ox = pos - oy * W2;
+        const float* wc = w + ((size_t)ci * Cout + co) * 25;
+        float s = 0.f, c0 = 0.f, c1 = 0.f;
+        for (int kh = oy & 1; kh < 5; kh += 2) {
+            const int iy = (oy + 2 - kh) >> 1;
+            if (iy < 0 || iy >= d) continue;
+            for (int kw = ox & 1; kw < 5; kw += 2) {
+                const int ix = (ox + 2 - kw) >> 1;
+                if (ix < 0 || ix >= d) continue;
+                s += wc[kh * 5 + kw];
+                if (ci == 0) {
+                    c0 += w[((size_t)D * Cout + co) * 25 + kh * 5 + kw] * coords[iy * d + ix];
+                    c1 += w[((size_t)(D + 1) * Cout + co) * 25 + kh * 5 + kw] * coords[d * d + iy * d + ix];
+                }
+            }
+        }
+        wz[idx] = s;
+        if (ci == 0) bias[row] = (b ? b[co] : 0.f) + c0 + c1;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+bcast_deconv_unpack_kernel(const float* __restrict__ dwz, const float* __restrict__ dbias,
+                           const float* __restrict__ coords, int D, int Cout, int d, float* __restrict__ dw,
+                           float* __restrict__ db) {
+    const int P = 4 * d * d, W2 = 2 * d, Dp = D + 2;
+    const int total = Dp * Cout * 25;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int ci = idx % Dp;                        // fastest: the reads of dwz are contiguous over ci
+        const int r = idx / Dp, co = r / 25, t = r - co * 25, kh = t / 5, kw = t - kh * 5;
+        float s = 0.f;
+        for (int iy = 0; iy < d; ++iy) {
+            const int oy = 2 * iy - 2 + kh;
+            if (oy < 0 || oy >= W2) continue;
+            for (int ix = 0; ix < d; ++ix) {
+                const int ox = 2 * ix - 2 + kw;
+                if (ox < 0 || ox >= W2) continue;
+                const size_t row = (size_t)co * P + oy * W2 + ox;
+                s += ci < D ? dwz[row * D + ci] : dbias[row] * coords[(ci - D) * d * d + iy * d + ix];
+            }
+        }
+        dw[((size_t)ci * Cout + co) * 25 + t] = s;
+        if (db && ci == 0 && t == 0) {
+            float sb = 0.f;
+            for (int q = 0; q < P; ++q) sb += dbias[(size_t)co * P + q];
+            db[co] = sb;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -259,4 +327,35 @@ int gx_bcast_conv3x3_bwd(const float* y, const float* g, const float* z, const f
     return GX_OK;
 }
 
+int gx_bcast_deconv5x5s2_pack(const float* w, const float* b, const float* coords, int D, int Cout, int d, float* wz,
+                              float* bias, gx_stream_t stream) {
+    GX_CHECK_ARG(w && coords && wz && bias && D > 0 && Cout > 0 && d > 0, "gx_bcast_deconv5x5s2_pack: bad arguments");
+    const size_t total = (size_t)Cout * 4 * d * d * D;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipStream_t s = (hipStream_t)stream;
+    {
+        GxProf pf(KID_PACK_WEIGHTS, s, 0.0, 4.0 * total);
+        hipLaunchKernelGGL(bcast_deconv_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, b, coords, D, Cout, d, wz,
+                           bias);
+    }
+    GX_CHECK_LAUNCH("gx_bcast_deconv5x5s2_pack");
+    return GX_OK;
+}
+
+int gx_bcast_deconv5x5s2_unpack(const float* dwz, const float* dbias, const float* coords, int D, int Cout, int d,
+                                float* dw, float* db, gx_stream_t stream) {
+    GX_CHECK_ARG(dwz && dbias && coords && dw && D > 0 && Cout > 0 && d > 0, "gx_bcast_deconv5x5s2_unpack: bad arguments");
+    const int total = (D + 2) * Cout * 25;
+    hipStream_t s = (hipStream_t)stream;
+    {
+        GxProf pf(KID_SMALL_REDUCE, s, 0.0, 4.0 * ((double)Cout * 4 * d * d * D + total));
+        hipLaunchKernelGGL(bcast_deconv_unpack_kernel, dim3(gx_ceil_div(total, 256)), dim3(256), 0, s, dwz, dbias, coords,
+                           D, Cout, d, dw, db);
+    }
+    GX_CHECK_LAUNCH("gx_bcast_deconv5x5s2_unpack");
+    return GX_OK;
+}
+
 }  // extern "C"
+

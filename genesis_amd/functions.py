@@ -441,6 +441,9 @@ class MaskPoolFn(torch.autograd.Function):
 FUSE_DECODER_HEAD = __import__('os').environ.get('GENESIS_FUSE_DEC_HEAD', '1') == '1'
 # its GroupNorm statistics out of the transposed conv's epilogue instead of a statistics-only pass over the output
 EPILOGUE_STATS = __import__('os').environ.get('GENESIS_DECONV_STATS', '1') == '1'
+# first decoder layer on the broadcast latent as one matrix product over tap-summed weights instead of a transposed conv on
+# a materialised canvas (GENESIS_BCAST_DECONV=0: canvas + the generic kernels)
+BCAST_DECONV = __import__('os').environ.get('GENESIS_BCAST_DECONV', '1') == '1'
 
 
 @ctx_bound
@@ -451,13 +454,17 @@ class DecoderFn(torch.autograd.Function):
     def forward(ctx, z, coords, *params):
         N, D = z.shape
         d = coords.shape[-1]
-        h = hip.broadcast_concat(z.contiguous(), coords)      # BroadcastLayer + PixelCoords: one launch, no torch.cat
+        z = z.contiguous()
+        ctx.bcast = BCAST_DECONV and params[0].shape[0] == D + 2
+        h = None
+        if not ctx.bcast:
+            h = hip.broadcast_concat(z, coords)      # BroadcastLayer + PixelCoords: one launch, no torch.cat
         saved = []
         ow, ob = params[16], params[17]
         ow2 = ow.detach().view(ow.shape[0], -1)
         # last stage: the normalised 64-channel full-resolution activation (the largest tensor of the model) is never
         # written -- the output conv normalises the pre-norm tensor on load, forward and backward
-        Cl, Sl = params[12].shape[1], 16 * h.shape[2]
+        Cl, Sl = params[12].shape[1], 16 * d
         ctx.fused_head = FUSE_DECODER_HEAD and Cl <= 64 and Cl % GROUPS == 0 and (Sl * Sl) % 256 == 0 \
             and ow.shape[0] <= 8
         for l in range(4):
@@ -471,6 +478,15 @@ class DecoderFn(torch.autograd.Function):
                 out = hip.conv1x1_gn_fwd(y, mean, rstd, gamma, beta, GROUPS, ow2, ob)
                 h = None
                 break
+            if l == 0 and ctx.bcast:
+                # the input is constant over the pixels: out = z @ (tap-summed weights) + (bias + coordinate channels)
+                wz, bz = hip.bcast_deconv_pack(w, b, coords)
+                y = hip.linear_fwd(z, wz, bz).view(N, w.shape[1], 2 * d, 2 * d)
+                a = torch.empty_like(y)
+                mean, rstd = hip.gn_relu_fwd(y, gamma, beta, GROUPS, EPS, (a, 0, 0))
+                saved.append(((z, wz, coords), y, mean, rstd))
+                h = a
+                continue
             a = torch.empty(N, w.shape[1], 2 * h.shape[2], 2 * h.shape[3], device=h.device)
             y, mean, rstd = hip.deconv5x5s2_gn_relu_fwd(h, w, b, gamma, beta, GROUPS, EPS, (a, 0, 0))
             saved.append((h, y, mean, rstd))
@@ -519,6 +535,14 @@ class DecoderFn(torch.autograd.Function):
                 ow, obias, og, ob = _gout(w), _gout(b), _gout(gamma), _gout(beta)
                 dy, dgamma, dbeta, dbias = hip.gn_relu_bwd(y, gamma, beta, mean, rstd, GROUPS, (da, 0, 0), None, True,
                                                            out=(og, ob, obias))
+            if l == 0 and ctx.bcast:
+                # one launch: dz = dy Wz^T, d(Wz^T) = dy^T z, d(bias map) = column sums of dy; then the tap sums are folded
+                # back onto the 5x5 weights (the bias gradient came out of the norm backward above)
+                z, wz, coords = h
+                dz, dwz, dbz = hip.linear_bwd(z, wz, None, dy.view(dy.shape[0], -1), None)
+                dw, _ = hip.bcast_deconv_unpack(dwz, dbz, coords, w.shape[1], out_dw=ow)
+                grads[0:4] = [_ret(ow, dw), _ret(obias, dbias), _ret(og, dgamma), _ret(ob, dbeta)]
+                return (dz, None) + tuple(grads)
             dw = _wgrad(lambda h=h, dy=dy, ow=ow: hip.deconv5x5s2_wgrad(h, dy, out=ow), ow, h, dy)
             # the first layer's input is the broadcast latent + 2 coordinate channels: only the D latent
             # channels need a gradient

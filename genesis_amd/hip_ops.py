@@ -730,6 +730,31 @@ def _rows(t, name):
     return t.stride(0)
 
 
+def bcast_deconv_pack(w, b, coords):
+    """First decoder layer on a broadcast input as a matrix product: w [D+2,Cout,5,5], b [Cout], coords [1,2,d,d] ->
+    (wz [Cout (2d)^2, D], bias [Cout (2d)^2]); out = linear_fwd(z, wz, bias).view(N, Cout, 2d, 2d)."""
+    _chk(w, 'bcast_deconv.w'); _chk(b, 'bcast_deconv.b'); _chk(coords, 'bcast_deconv.coords')
+    D, Cout, d = w.shape[0] - 2, w.shape[1], coords.shape[-1]
+    if tuple(w.shape[2:]) != (5, 5) or coords.numel() != 2 * d * d or D <= 0:
+        raise GenesisHipError('bcast_deconv_pack: w %s / coords %s' % (tuple(w.shape), tuple(coords.shape)))
+    rows = Cout * 4 * d * d
+    wz = torch.empty(rows, D, dtype=F32, device=w.device)
+    bias = torch.empty(rows, dtype=F32, device=w.device)
+    _lib.call('gx_bcast_deconv5x5s2_pack', _p(w), _p(b), _p(coords), D, Cout, d, _p(wz), _p(bias), _stream())
+    return wz, bias
+
+
+def bcast_deconv_unpack(dwz, dbias, coords, Cout, out_dw=None, out_db=None, want_db=False):
+    """Gradients of (wz, bias) of bcast_deconv_pack -> (dw [D+2,Cout,5,5], db [Cout] or None)."""
+    _chk(dwz, 'bcast_deconv.dwz'); _chk(dbias, 'bcast_deconv.dbias'); _chk(coords, 'bcast_deconv.coords')
+    _chk(out_dw, 'bcast_deconv.out_dw'); _chk(out_db, 'bcast_deconv.out_db')
+    D, d = dwz.shape[1], coords.shape[-1]
+    dw = out_dw if out_dw is not None else torch.empty(D + 2, Cout, 5, 5, dtype=F32, device=dwz.device)
+    db = out_db if out_db is not None else (torch.empty(Cout, dtype=F32, device=dwz.device) if want_db else None)
+    _lib.call('gx_bcast_deconv5x5s2_unpack', _p(dwz), _p(dbias), _p(coords), D, Cout, d, _p(dw), _p(db), _stream())
+    return dw, db
+
+
 def linear_fwd(x, w, b=None, act=None, out=None):
     """act(x [M,K] @ w[N,K]^T + b) (nn.Linear (+ReLU)).  x and out may be row-strided views (columns of a larger
     buffer); out: write the result there instead of a fresh [M,N] tensor."""

@@ -294,6 +294,16 @@ int gx_logsoftmax_k_bwd(const float* log_m_r, const float* g, int K, int B, int 
  *      [1, d-2]^2 (the valid conv's outputs): dz [N,L], dw [Co,L+2,3,3], db [Co] (may be NULL); act 0 none, 1 ReLU,
  *      2 ELU. */
 int gx_broadcast_concat(const float* z, const float* coords, float* out, int N, int D, int d, gx_stream_t stream);
+/*      The GENESIS-V2 decoder's first layer, ConvTranspose2d(D+2, Cout, 5, 2, 2, 1) on that broadcast input
+ *      (models/genesisv2_config.py:89-90), WITHOUT the canvas: the input is constant over the pixels, so
+ *      out[n,co,oy,ox] = sum_ci z[n,ci] Wz[ci][co][oy][ox] + C[co][oy][ox] -- one [N,D] x [D, Cout (2d)^2] product
+ *      (gx_linear_fwd / gx_linear_bwd on wz).  pack: w [D+2,Cout,5,5], b [Cout] (may be NULL), coords [2,d,d] ->
+ *      wz [Cout (2d)^2, D] (the tap sums, nn.Linear weight layout) and bias [Cout (2d)^2] (b + the coordinate
+ *      channels' contribution).  unpack: the gradients of wz and bias -> dw [D+2,Cout,5,5], db [Cout] (may be NULL). */
+int gx_bcast_deconv5x5s2_pack(const float* w, const float* b, const float* coords, int D, int Cout, int d, float* wz,
+                              float* bias, gx_stream_t stream);
+int gx_bcast_deconv5x5s2_unpack(const float* dwz, const float* dbias, const float* coords, int D, int Cout, int d,
+                                float* dw, float* db, gx_stream_t stream);
 int gx_bcast_conv3x3_fwd(const float* z, const float* w, const float* bias, const float* rowc, const float* colc,
                          int act, float* out, int N, int L, int Co, int d, gx_stream_t stream);
 size_t gx_bcast_conv3x3_bwd_ws_bytes(int N, int Co);

@@ -17,6 +17,13 @@ import torch
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 RELU_FLIP = 0.0      # measured: no allowance needed (worst HIP gradient error 5.6e-4 where CPU-fp32 has 7.6e-4)
+# The golden fixtures' closed-form weights are another matter: pre-activations sit within 1e-7 of zero there, and WHICH
+# fp32 implementation flips a ReLU is a coin toss per summation order.  Measured on golden case cfg2: CPU-fp32 itself is
+# 2.7e-3 off fp64 on decoder_module.1.weight where the HIP path is 6e-6; on cfg5 the HIP path is 2.4e-5 off on
+# decoder_module.10.weight where CPU-fp32 is 1.1e-6 (after the decoder's first layer became a matrix product over
+# tap-summed weights: same mathematics, other rounding).  A per-parameter bar of 4 x the CPU error cannot hold in both
+# directions, so that test alone grants a flip 1e-4 per parameter (a flip moves a gradient by 1e-5 .. 1e-3).
+GOLDEN_RELU_FLIP = 1e-4
 
 
 def relerr(a, ref):
@@ -24,9 +31,10 @@ def relerr(a, ref):
     return float((a.detach().double().cpu() - ref).norm()) / (float(ref.norm()) + 1e-30)
 
 
-def judge(rows_fwd, grads_hip, g32, g64, what):
+def judge(rows_fwd, grads_hip, g32, g64, what, relu_flip=None):
     """rows_fwd: (name, hip tensor, cpu32 tensor, fp64 tensor).  Prints the table, returns the offenders."""
     bad, table = [], []
+    relu_flip = RELU_FLIP if relu_flip is None else relu_flip
     for name, got, r32, r64 in rows_fwd:
         e_gpu, e_cpu = relerr(got, r64), relerr(r32, r64)
         table.append((name, e_gpu, e_cpu))
@@ -40,7 +48,7 @@ def judge(rows_fwd, grads_hip, g32, g64, what):
         e_gpu, e_cpu = relerr(got, ref), relerr(g32[n], ref)
         table.append(('grad ' + n, e_gpu, e_cpu))
         worst = max(worst, e_gpu - floor)
-        if e_gpu > max(4 * e_cpu + 2e-6, RELU_FLIP) + floor:
+        if e_gpu > max(4 * e_cpu + 2e-6, relu_flip) + floor:
             bad.append(n)
     print('\n[%s] %-46s %12s %12s' % (what, 'tensor', 'hip-vs-f64', 'cpu32-vs-f64'))
     for r in table:
@@ -125,7 +133,7 @@ def test_genesis_v2_on_the_golden_cases_weights_and_inputs(case):
     st = lambda l: torch.stack(list(l))   # noqa: E731
     fwd = [('recon', recon, o32[0], o64[0]), ('err', losses.err, o32[1]['err'], o64[1]['err']),
            ('log_m', st(stats.log_m_k), st(o32[2]['log_m_k']), st(o64[2]['log_m_k']))]
-    bad = judge(fwd, hip_grads(model), g32, g64, 'GENESIS-V2 golden case ' + case)
+    bad = judge(fwd, hip_grads(model), g32, g64, 'GENESIS-V2 golden case ' + case, relu_flip=GOLDEN_RELU_FLIP)
     assert not bad, bad
 
 

@@ -489,6 +489,33 @@ def test_linear(M, N, K, act, bias):
         close(bg.grad, br.grad, rtol=1e-4, atol=1e-5, msg='db')
 
 
+@pytest.mark.parametrize('N,D,Cout,d', [(224, 64, 64, 4), (5, 16, 24, 2), (3, 8, 16, 8), (2, 4, 8, 1)])
+def test_broadcast_deconv_as_matrix_product(N, D, Cout, d):
+    """The decoder's first layer on the broadcast latent (models/genesisv2_config.py:89-90) computed as
+    z @ (tap-summed weights) + (bias + coordinate channels), against ConvTranspose2d(k5,s2,p2,op1) on the materialised
+    canvas in fp64 -- forward, dz, dw (all D + 2 input channels) and db; rtol 1e-5 fwd, 1e-4 grads."""
+    from genesis_amd import hip_ops as hip
+    z = rnd(N, D, seed=1)
+    w = rnd(D + 2, Cout, 5, 5, seed=2, scale=0.2)
+    b = rnd(Cout, seed=3)
+    g = rnd(N, Cout, 2 * d, 2 * d, seed=4)
+    lin = torch.linspace(-1, 1, d) if d > 1 else torch.zeros(1)
+    coords = torch.stack((lin.view(d, 1).expand(d, d), lin.view(1, d).expand(d, d)), 0).unsqueeze(0).contiguous()
+    zr, wr, br = z.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+    canvas = torch.cat((zr.view(N, D, 1, 1).expand(N, D, d, d), coords.double().expand(N, 2, d, d)), 1)
+    yr = F.conv_transpose2d(canvas, wr, br, 2, 2, 1)
+    (yr * g.double()).sum().backward()
+    zg, wg, cg = z.to(DEV), w.to(DEV), coords.to(DEV)
+    wz, bz = hip.bcast_deconv_pack(wg, b.to(DEV), cg)
+    y = hip.linear_fwd(zg, wz, bz).view(N, Cout, 2 * d, 2 * d)
+    close(y, yr, rtol=1e-5, atol=1e-5, msg='y')
+    dz, dwz, dbz = hip.linear_bwd(zg, wz, None, g.to(DEV).view(N, -1), None)
+    dw, db = hip.bcast_deconv_unpack(dwz, dbz, cg, Cout, want_db=True)
+    close(dz, zr.grad, rtol=1e-4, atol=1e-5, msg='dz')
+    close(dw, wr.grad, rtol=1e-4, atol=1e-5, msg='dw')
+    close(db, br.grad, rtol=1e-4, atol=1e-5, msg='db')
+
+
 @pytest.mark.parametrize('M,N,K,act', [(32, 2048, 128, 'relu'), (192, 1024, 64, None), (7, 20, 12, 'relu')])
 def test_linear_strided_and_accumulating(M, N, K, act):
     """gx_linear_fwd_ld / gx_linear_bwd_ex: operands that are column ranges of wider buffers (the UNet MLP's output in
