@@ -39,6 +39,8 @@ constexpr int RAW_PER_THREAD = (WKC * PR * PC + 255) / 256;   // 6
 
 struct WinoGeom {
     int N, K, M;          // images, reduction channels, output channels
+    int K1, M1;           // pair variants: reduction channels [0, K1) come from `in`, the rest from `in2` (K1 % 8 == 0);
+                          // output channels [0, M1) go to `out`, the rest to `out2` (M1 % 64 == 0).  Single: K1 = Kpad, M1 = Mpad
     int Kpad, Mpad;       // packed weight dims (Kpad % 8 == 0, Mpad % 64 == 0)
     int H, W;             // H % 8 == 0, W % 16 == 0
     int tiles_h, tiles_w; // H / 8, W / 16
@@ -54,8 +56,31 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
     }
 }
 
+// Two 3x3 layers that read the SAME input (the seg_head and feat_head[0] convs on the encoder features,
+// models/genesisv2_config.py:70-73): packed as ONE layer.  Uf: forward, output channels [0, Co1) from w1, the rest from
+// w2.  Ud: data gradient, reduction channels [0, Co1) (dy of layer 1) from w1, the rest from w2 -- the sum of the two
+// layers' input gradients then happens inside the accumulators.  One launch packs both.
+__global__ void wino_pack_pair_kernel(const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ Uf,
+                                      float* __restrict__ Ud, int Co1, int Co2, int Ci, int KpadF, int MpadF, int KpadD,
+                                      int MpadD) {
+    const int totF = 16 * KpadF * MpadF, totD = 16 * KpadD * MpadD;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < totF + totD; idx += gridDim.x * blockDim.x) {
+        if (idx < totF) {
+            const int m = idx % MpadF, k = (idx / MpadF) % KpadF, p = idx / (MpadF * KpadF);
+            Uf[gx_wino_u_slot(m, k, p, KpadF)] = m < Co1 ? gx_wino_u_value(w1, 0, Co1, Ci, m, k, p)
+                                                         : gx_wino_u_value(w2, 0, Co2, Ci, m - Co1, k, p);
+        } else {
+            const int i = idx - totF;
+            const int m = i % MpadD, k = (i / MpadD) % KpadD, p = i / (MpadD * KpadD);
+            Ud[gx_wino_u_slot(m, k, p, KpadD)] = k < Co1 ? gx_wino_u_value(w1, 1, Co1, Ci, m, k, p)
+                                                         : gx_wino_u_value(w2, 1, Co2, Ci, m, k - Co1, p);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256, 2)
-wino_conv_kernel(const float* __restrict__ in, const float* __restrict__ U, float* __restrict__ out, const WinoGeom g) {
+wino_conv_kernel(const float* __restrict__ in, const float* __restrict__ in2, const float* __restrict__ U,
+                 float* __restrict__ out, float* __restrict__ out2, const WinoGeom g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* raw = lds;                       // [2][WKC][PR][2][PLANE]
     float* V = lds + 2 * RAW_FLOATS;        // [2][16][WKC][WNT]
@@ -68,7 +93,10 @@ wino_conv_kernel(const float* __restrict__ in, const float* __restrict__ U, floa
     const int R0 = th_i * (2 * WTH), C0 = tw_i * (2 * WTW);
     const int m0 = blockIdx.y * 64;
     const int HW = g.H * g.W;
-    const float* in_n = in + (size_t)n * g.K * HW;
+    // (pair data gradient: two input tensors, each with its own channel count and per-image block)
+    const int Ka = g.K1 < g.K ? g.K1 : g.K, Kb = g.K - Ka;
+    const float* in_n = in + (size_t)n * Ka * HW;
+    const float* in2_n = in2 + (size_t)n * Kb * HW;
     const int nchunks = g.Kpad / WKC;
 
     // raw-patch staging slots of this thread: element e = tid + 256 q of [WKC][PR][PC].  The loads are raw buffer loads
@@ -89,14 +117,20 @@ wino_conv_kernel(const float* __restrict__ in, const float* __restrict__ U, floa
             if (r >= 0 && r < g.H && c >= 0 && c < g.W) voff[q] = (ch * HW + r * g.W + c) * 4;
         }
     }
-    const __amdgpu_buffer_rsrc_t in_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_n), 0, g.K * HW * 4, 0x00020000);
+    // descriptor and scalar offset of the chunk that starts at channel k0 (scalar selects, no branch)
+    auto chunk_rsrc = [&](int k0, int& soff) {
+        const bool second = k0 >= g.K1;
+        soff = (second ? k0 - g.K1 : k0) * HW * 4;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(second ? in2_n : in_n), 0,
+                                                 (second ? Kb : Ka) * HW * 4, 0x00020000);
+    };
     float rawr[RAW_PER_THREAD];
     auto load_raw = [&](int k0) {
-        const int soff = k0 * HW * 4;
+        int soff;
+        const __amdgpu_buffer_rsrc_t rs = chunk_rsrc(k0, soff);
 #pragma unroll
         for (int q = 0; q < RAW_PER_THREAD; ++q)
-            rawr[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, voff[q], soff, 0));
+            rawr[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[q], soff, 0));
     };
     auto store_raw = [&](float* rbuf) {
 #pragma unroll
@@ -166,10 +200,12 @@ wino_conv_kernel(const float* __restrict__ in, const float* __restrict__ U, floa
         // the first three chunks' patches in ONE round trip (the channel-range check of the buffer loads makes the
         // loads of chunks that do not exist return zeros: no branches)
         float r0[RAW_PER_THREAD], r1[RAW_PER_THREAD];
+        int so0, so1;
+        const __amdgpu_buffer_rsrc_t rs0 = chunk_rsrc(0, so0), rs1 = chunk_rsrc(WKC, so1);
 #pragma unroll
         for (int q = 0; q < RAW_PER_THREAD; ++q) {
-            r0[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, voff[q], 0, 0));
-            r1[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, voff[q], WKC * HW * 4, 0));
+            r0[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs0, voff[q], so0, 0));
+            r1[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, voff[q], so1, 0));
         }
         load_raw(2 * WKC);
 #pragma unroll
@@ -258,7 +294,11 @@ wino_conv_kernel(const float* __restrict__ in, const float* __restrict__ U, floa
     //      q0 = M0 + M1 + M2, q1 = M1 - M2 - M3, exchanged through LDS; then Y[0][b] = q(xi=0) + q(1) + q(2),
     //      Y[1][b] = q(1) - q(2) - q(3).  One 32-channel half (mi) at a time: E[xi][b][32 m][32 n] = 32 KB.
     float* E = lds;
-    const size_t out_n = (size_t)n * g.M * HW;
+    // (pair forward: this channel tile belongs to `out` or to `out2`)
+    const bool second_out = m0 >= g.M1;
+    const int Mo = second_out ? g.M - g.M1 : (g.M1 < g.M ? g.M1 : g.M), mbase = second_out ? g.M1 : 0;
+    float* const outp = second_out ? out2 : out;
+    const size_t out_n = (size_t)n * Mo * HW;
     if (GX_WINO_ABL & 16) {
         float sacc = 0.f;
 #pragma unroll
@@ -267,7 +307,7 @@ wino_conv_kernel(const float* __restrict__ in, const float* __restrict__ U, floa
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int c = 0; c < 16; ++c) sacc += acc[a][b][c];
-        out[out_n + (size_t)(m0 + (tid >> 2)) * HW + (size_t)R0 * g.W + C0 + (tid & 3)] = sacc;
+        outp[out_n + (size_t)(m0 - mbase + (tid >> 2)) * HW + (size_t)R0 * g.W + C0 + (tid & 3)] = sacc;
         return;
     }
 #pragma unroll
@@ -303,7 +343,7 @@ wino_conv_kernel(const float* __restrict__ in, const float* __restrict__ U, floa
             y0.y = q[0][1] + q[1][1] + q[2][1];
             y1.x = q[1][0] - q[2][0] - q[3][0];
             y1.y = q[1][1] - q[2][1] - q[3][1];
-            float* o = out + out_n + (size_t)m * HW + (size_t)(R0 + 2 * ty) * g.W + C0 + 2 * tx;
+            float* o = outp + out_n + (size_t)(m - mbase) * HW + (size_t)(R0 + 2 * ty) * g.W + C0 + 2 * tx;
             *reinterpret_cast<float2*>(o) = y0;
             *reinterpret_cast<float2*>(o + g.W) = y1;
         }
@@ -329,11 +369,17 @@ bool gx_wino_eligible(int N, int K, int M, int H, int W) {
     return g_wino_mode == 2 || N * (H / 8) * (W / 16) * gx_ceil_div(M, 64) >= 256;
 }
 
-int gx_wino_launch(const float* in, const float* U, float* out, int N, int K, int M, int H, int W, hipStream_t s) {
+// in2 / K1, out2 / M1: the pair variants (WinoGeom); nullptr / 0 for one input tensor and one output tensor
+static int wino_launch(const float* in, const float* in2, int K1, const float* U, float* out, float* out2, int M1, int N,
+                       int K, int M, int H, int W, hipStream_t s) {
     WinoGeom g;
     g.N = N; g.H = H; g.W = W; g.K = K; g.M = M;
     g.Kpad = gx_round_up(K, WKC);
     g.Mpad = gx_round_up(M, 64);
+    g.K1 = in2 ? K1 : g.Kpad;
+    g.M1 = out2 ? M1 : g.Mpad;
+    if (!in2) in2 = in;
+    if (!out2) out2 = out;
     g.tiles_h = H / (2 * WTH);
     g.tiles_w = W / (2 * WTW);
     static bool attr_set = false;
@@ -347,11 +393,15 @@ int gx_wino_launch(const float* in, const float* U, float* out, int N, int K, in
         const double flops = 2.0 * N * (double)M * K * 9 * H * W;    // algorithmic (direct-sum) flops
         const double bytes = 4.0 * ((double)N * K * H * W + (double)N * M * H * W + 9.0 * K * M);
         GxProf pf(KID_WINO, s, flops, bytes);
-        hipLaunchKernelGGL(wino_conv_kernel, dim3(N * g.tiles_h * g.tiles_w, g.Mpad / 64), dim3(256), lds, s, in, U, out,
-                           g);
+        hipLaunchKernelGGL(wino_conv_kernel, dim3(N * g.tiles_h * g.tiles_w, g.Mpad / 64), dim3(256), lds, s, in, in2, U,
+                           out, out2, g);
     }
     GX_CHECK_LAUNCH("winograd conv3x3");
     return GX_OK;
+}
+
+int gx_wino_launch(const float* in, const float* U, float* out, int N, int K, int M, int H, int W, hipStream_t s) {
+    return wino_launch(in, nullptr, 0, U, out, nullptr, 0, N, K, M, H, W, s);
 }
 
 extern "C" {
@@ -394,4 +444,66 @@ int gx_conv3x3_wino(const float* x, const float* w, float* y, int N, int Cin, in
     return gx_wino_launch(x, U, y, N, K, M, H, W, s);
 }
 
+// ---- two conv3x3 layers on one input as one layer (forward: one launch writes both outputs; data gradient: one launch
+// sums both layers' input gradients).  Cin % 8 == 0, Co1 % 64 == 0, and the Winograd shape rules for (Cin, Co1 + Co2).
+int gx_conv3x3_pair_supported(int N, int Cin, int Co1, int Co2, int H, int W) {
+    return wino_shape_ok(N, Cin, Co1 + Co2, H, W) && Cin % 8 == 0 && Co1 % 64 == 0 && Co1 % 8 == 0 && Co1 > 0 && Co2 > 0;
+}
+
+size_t gx_conv3x3_pair_ws_bytes(int N, int Cin, int Co1, int Co2, int H, int W) {
+    (void)N; (void)H; (void)W;
+    const int Co = Co1 + Co2;
+    return ((size_t)16 * gx_round_up(Cin, 8) * gx_round_up(Co, 64) + (size_t)16 * gx_round_up(Co, 8) * gx_round_up(Cin, 64)) *
+           sizeof(float);
+}
+
+static void pair_u(void* ws, int Cin, int Co, float** Uf, float** Ud) {
+    *Uf = (float*)ws;
+    *Ud = *Uf + (size_t)16 * gx_round_up(Cin, 8) * gx_round_up(Co, 64);
+}
+
+// y1 [N,Co1,H,W] = conv3x3(x, w1), y2 [N,Co2,H,W] = conv3x3(x, w2); ws keeps the packed weights of BOTH directions
+// (gx_conv3x3_pair_dgrad with pack = 0 reuses them within the iteration)
+int gx_conv3x3_pair_fwd(const float* x, const float* w1, const float* w2, float* y1, float* y2, int N, int Cin, int Co1,
+                        int Co2, int H, int W, void* ws, size_t ws_bytes, gx_stream_t stream) {
+    GX_CHECK_ARG(x && w1 && w2 && y1 && y2 && ws, "gx_conv3x3_pair_fwd: null pointer");
+    GX_CHECK_ARG(gx_conv3x3_pair_supported(N, Cin, Co1, Co2, H, W), "gx_conv3x3_pair_fwd: unsupported shape");
+    GX_CHECK_ARG(ws_bytes >= gx_conv3x3_pair_ws_bytes(N, Cin, Co1, Co2, H, W), "gx_conv3x3_pair_fwd: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int Co = Co1 + Co2;
+    float *Uf, *Ud;
+    pair_u(ws, Cin, Co, &Uf, &Ud);
+    {
+        const int KpF = gx_round_up(Cin, 8), MpF = gx_round_up(Co, 64), KpD = gx_round_up(Co, 8), MpD = gx_round_up(Cin, 64);
+        const int total = 16 * (KpF * MpF + KpD * MpD);
+        GxProf pf(KID_PACK_WEIGHTS, s, 0.0, 8.0 * total);
+        hipLaunchKernelGGL(wino_pack_pair_kernel, dim3(gx_ceil_div(total, 256)), dim3(256), 0, s, w1, w2, Uf, Ud, Co1, Co2,
+                           Cin, KpF, MpF, KpD, MpD);
+    }
+    GX_CHECK_LAUNCH("gx_conv3x3_pair_fwd(pack)");
+    return wino_launch(x, nullptr, 0, Uf, y1, y2, Co1, N, Cin, Co, H, W, s);
+}
+
+// dx [N,Cin,H,W] = dgrad(dy1, w1) + dgrad(dy2, w2); pack != 0: (re)pack the weights into ws first
+int gx_conv3x3_pair_dgrad(const float* dy1, const float* dy2, const float* w1, const float* w2, float* dx, int N, int Cin,
+                          int Co1, int Co2, int H, int W, int pack, void* ws, size_t ws_bytes, gx_stream_t stream) {
+    GX_CHECK_ARG(dy1 && dy2 && w1 && w2 && dx && ws, "gx_conv3x3_pair_dgrad: null pointer");
+    GX_CHECK_ARG(gx_conv3x3_pair_supported(N, Cin, Co1, Co2, H, W), "gx_conv3x3_pair_dgrad: unsupported shape");
+    GX_CHECK_ARG(ws_bytes >= gx_conv3x3_pair_ws_bytes(N, Cin, Co1, Co2, H, W), "gx_conv3x3_pair_dgrad: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int Co = Co1 + Co2;
+    float *Uf, *Ud;
+    pair_u(ws, Cin, Co, &Uf, &Ud);
+    if (pack) {
+        const int KpF = gx_round_up(Cin, 8), MpF = gx_round_up(Co, 64), KpD = gx_round_up(Co, 8), MpD = gx_round_up(Cin, 64);
+        const int total = 16 * (KpF * MpF + KpD * MpD);
+        GxProf pf(KID_PACK_WEIGHTS, s, 0.0, 8.0 * total);
+        hipLaunchKernelGGL(wino_pack_pair_kernel, dim3(gx_ceil_div(total, 256)), dim3(256), 0, s, w1, w2, Uf, Ud, Co1, Co2,
+                           Cin, KpF, MpF, KpD, MpD);
+        GX_CHECK_LAUNCH("gx_conv3x3_pair_dgrad(pack)");
+    }
+    return wino_launch(dy1, dy2, Co1, Ud, dx, nullptr, 0, N, Co, Cin, H, W, s);
+}
+
 }  // extern "C"
+

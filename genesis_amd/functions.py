@@ -420,6 +420,85 @@ class SegICSBPFn(torch.autograd.Function):
                 _ret(og, dgate), None, _ret(ols, dls.to(ctx.ls_dtype)), None, None, None, None, None)
 
 
+PAIR_HEADS = __import__('os').environ.get('GENESIS_PAIR_HEADS', '1') == '1'
+
+
+def heads_pairable(enc_feat, seg_w, conv_w, feat_w):
+    return PAIR_HEADS and seg_head_fusable(enc_feat, seg_w, conv_w) and feat_w.shape[1:] == seg_w.shape[1:] \
+        and hip.conv3x3_pair_supported(enc_feat, seg_w, feat_w)
+
+
+@ctx_bound
+class SegFeatHeadsFn(torch.autograd.Function):
+    """SegICSBPFn and feat_head[0] (ConvGNReLUFn) as ONE node: both read the encoder features
+    (models/genesisv2_config.py:110-149), so their two conv3x3 run as one layer with 2 x 64 output channels, and -- the
+    point -- their two input gradients are one data-gradient launch over 128 reduction channels whose accumulators do
+    the summing (instead of two launches and an accumulation pass over the 33 MB feature-map gradient).
+    Returns SegICSBPFn's outputs followed by f = relu(gn(conv3x3(enc_feat, feat_w)))."""
+
+    @staticmethod
+    def forward(ctx, enc_feat, seg_w, seg_gamma, seg_beta, conv_w, conv_b, gate, uv, log_sigma, rand_pixel, K, kernel,
+                seed_idx, min_mass, feat_w, feat_gamma, feat_beta):
+        x = enc_feat.contiguous()
+        ctx.params = (seg_w, seg_gamma, seg_beta, conv_w, conv_b, gate, log_sigma, feat_w, feat_gamma, feat_beta)
+        w2 = conv_w.detach().view(conv_w.shape[0], -1)
+        y, yf, ctx.pair_ws = hip.conv3x3_pair_fwd(x, seg_w, feat_w)
+        mean, rstd = hip.gn_relu_fwd(y, seg_gamma, seg_beta, GROUPS, EPS, None)          # statistics only
+        colour = hip.conv1x1_gn_fwd(y, mean, rstd, seg_gamma, seg_beta, GROUPS, w2, conv_b, gate, uv)
+        ctx.ls_dtype = log_sigma.dtype
+        ls64 = log_sigma.detach().to(torch.float64)
+        res = hip.icsbp_fwd(colour, ls64, rand_pixel.contiguous(), K, kernel, seed_idx, min_mass)
+        log_m, log_s, seeds, idx = res[:4]
+        ctx.nsteps = res[4] if min_mass > 0.0 else None
+        f = torch.empty_like(yf)
+        meanf, rstdf = hip.gn_relu_fwd(yf, feat_gamma, feat_beta, GROUPS, EPS, (f, 0, 0))
+        ctx.save_for_backward(x, y, mean, rstd, ls64, colour, seeds, idx, yf, meanf, rstdf)
+        ctx.kernel = kernel
+        ctx.mark_non_differentiable(log_s, colour, seeds, idx)
+        ctx.set_materialize_grads(False)
+        if ctx.nsteps is not None:
+            ctx.mark_non_differentiable(ctx.nsteps)
+            return log_m, log_s, colour, seeds, idx, ctx.nsteps, f
+        return log_m, log_s, colour, seeds, idx, f
+
+    @staticmethod
+    def backward(ctx, g_log_m, *rest):
+        x, y, mean, rstd, ls64, colour, seeds, idx, yf, meanf, rstdf = ctx.saved_tensors
+        seg_w, seg_gamma, seg_beta, conv_w, conv_b, gate, log_sigma, feat_w, feat_gamma, feat_beta = ctx.params
+        g_f = rest[-1]
+        if g_log_m is None:
+            g_log_m = colour.new_zeros(seeds.shape[0] + 1, colour.shape[0], 1, colour.shape[2], colour.shape[3])
+        if g_f is None:
+            g_f = torch.zeros_like(yf)
+        # --- seg head + colour head + IC-SBP (as SegICSBPFn.backward)
+        ols = _gout(log_sigma) if ctx.ls_dtype == torch.float64 and log_sigma.dim() == 0 else None
+        dcolour, dls = hip.icsbp_bwd(colour, ls64, seeds, idx, g_log_m.contiguous(), ctx.kernel, out_dls=ols,
+                                     nsteps=ctx.nsteps)
+        w2 = conv_w.detach().view(conv_w.shape[0], -1)
+        ow, ob, og = _gout(conv_w), _gout(conv_b), (_gout(gate) if gate is not None else None)
+        osw, osg, osb = _gout(seg_w), _gout(seg_gamma), _gout(seg_beta)
+        fused = hip.conv1x1_gn_bwd_fused(y, seg_gamma, seg_beta, mean, rstd, GROUPS, dcolour, w2, conv_b, gate, False,
+                                         out_gn=(osg, osb, None), out_conv=(ow, ob, og))
+        if fused is not None:
+            dy, (dgamma, dbeta, _), (dw, db, dgate) = fused
+        else:
+            dw, db, dgate = hip.conv1x1_gn_wgrad(y, mean, rstd, seg_gamma, seg_beta, GROUPS, dcolour, w2, conv_b, gate,
+                                                 out=(ow, ob, og))
+            dy, dgamma, dbeta, _ = hip.gn_relu_bwd_proj(y, seg_gamma, seg_beta, mean, rstd, GROUPS, dcolour, w2, False,
+                                                        out=(osg, osb, None), gate=gate)
+        dsw = _wgrad(lambda: hip.conv3x3_wgrad(x, dy, out=osw), osw, x, dy)
+        # --- feat_head[0] (as ConvGNReLUFn.backward)
+        ofw, ofg, ofb = _gout(feat_w), _gout(feat_gamma), _gout(feat_beta)
+        dyf, dfgamma, dfbeta, _ = hip.gn_relu_bwd(yf, feat_gamma, feat_beta, meanf, rstdf, GROUPS, (g_f.contiguous(), 0, 0),
+                                                  out=(ofg, ofb, None))
+        dfw = _wgrad(lambda: hip.conv3x3_wgrad(x, dyf, out=ofw), ofw, x, dyf)
+        # --- both input gradients: one launch
+        dx = hip.conv3x3_pair_dgrad(dy, dyf, seg_w, feat_w, ctx.pair_ws) if ctx.needs_input_grad[0] else None
+        return (dx, _ret(osw, dsw), _ret(osg, dgamma), _ret(osb, dbeta), _ret(ow, dw.view(conv_w.shape)), _ret(ob, db),
+                _ret(og, dgate), None, _ret(ols, dls.to(ctx.ls_dtype)), None, None, None, None, None,
+                _ret(ofw, dfw), _ret(ofg, dfgamma), _ret(ofb, dfbeta))
+
+
 @ctx_bound
 class MaskPoolFn(torch.autograd.Function):
     @staticmethod

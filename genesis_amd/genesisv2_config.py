@@ -296,7 +296,13 @@ class GenesisV2(nn.Module):
         # dynamic_K (genesisv2_config.py:118-137, attention.py:218-219): an image stops at the first step whose mask
         # would hold fewer than 20 pixels; the kernel does that per image of the batch in one launch
         min_mass = 20.0 if self.dynamic_K else 0.0
-        if fn.seg_head_fusable(enc_feat, seg_params[0], cw):
+        f = None
+        if fn.heads_pairable(enc_feat, seg_params[0], cw, self.feat_head[0].params()[0]):
+            # seg_head and feat_head[0] read the same features: one conv launch forward, one data-gradient launch backward
+            res = fn.SegFeatHeadsFn.apply(enc_feat, *seg_params, cw, cb, gate, addend, ap.log_sigma, rand_pixel, K,
+                                          ap.kernel, seed_idx, min_mass, *self.feat_head[0].params())
+            res, f = res[:-1], res[-1]
+        elif fn.seg_head_fusable(enc_feat, seg_params[0], cw):
             res = fn.SegICSBPFn.apply(enc_feat, *seg_params, cw, cb, gate, addend, ap.log_sigma, rand_pixel, K, ap.kernel,
                                       seed_idx, min_mass)
         else:
@@ -318,7 +324,8 @@ class GenesisV2(nn.Module):
                 dyn_batched = True      # masks of finished images are padded with -1e10; no att_stats / log_s_k (:122)
         # --- Object features: feat_head[0] once (the reference recomputes it K times, :149), pooled per
         #     slot; the 1x1 conv feat_head[1] commutes with the masked sum and is applied to the pooled sums.
-        f = fn.ConvGNReLUFn.apply(enc_feat, *self.feat_head[0].params())
+        if f is None:
+            f = fn.ConvGNReLUFn.apply(enc_feat, *self.feat_head[0].params())
         S, msum = fn.MaskPoolFn.apply(f, log_m)                      # [B,K,D], [B,K]
         ln = self.z_head[0]
         zh = fn.PooledHeadFn.apply(fn.linear(S, self.feat_head[1].weight), msum, self.feat_head[1].bias,

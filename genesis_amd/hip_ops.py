@@ -894,6 +894,40 @@ def gn_relu_bwd_proj(y, gamma, beta, mean, rstd, groups, g_out, w, want_dbias=Fa
     return dy, dgamma, dbeta, dbias
 
 
+def conv3x3_pair_supported(x, w1, w2):
+    N, Cin, H, W = x.shape
+    return bool(_lib.query('gx_conv3x3_pair_supported', N, Cin, w1.shape[0], w2.shape[0], H, W))
+
+
+def conv3x3_pair_fwd(x, w1, w2):
+    """(conv3x3(x, w1), conv3x3(x, w2), ws) in one launch; ws = the packed weights of both directions, handed to
+    conv3x3_pair_dgrad of the same iteration."""
+    _chk(x, 'pair.x'); _chk(w1, 'pair.w1'); _chk(w2, 'pair.w2')
+    N, Cin, H, W = x.shape
+    Co1, Co2 = w1.shape[0], w2.shape[0]
+    y1 = torch.empty(N, Co1, H, W, dtype=F32, device=x.device)
+    y2 = torch.empty(N, Co2, H, W, dtype=F32, device=x.device)
+    nb = _lib.query('gx_conv3x3_pair_ws_bytes', N, Cin, Co1, Co2, H, W)
+    ws = _ws(nb, x.device)
+    _lib.call('gx_conv3x3_pair_fwd', _p(x), _p(w1), _p(w2), _p(y1), _p(y2), N, Cin, Co1, Co2, H, W, _p(ws), nb, _stream())
+    return y1, y2, ws
+
+
+def conv3x3_pair_dgrad(dy1, dy2, w1, w2, ws=None):
+    """dgrad(dy1, w1) + dgrad(dy2, w2) in one launch (ws: the forward's packed weights; None: pack here)."""
+    _chk(dy1, 'pair.dy1'); _chk(dy2, 'pair.dy2'); _chk(w1, 'pair.w1'); _chk(w2, 'pair.w2')
+    N, Co1, H, W = dy1.shape
+    Co2, Cin = dy2.shape[1], w1.shape[1]
+    dx = torch.empty(N, Cin, H, W, dtype=F32, device=dy1.device)
+    nb = _lib.query('gx_conv3x3_pair_ws_bytes', N, Cin, Co1, Co2, H, W)
+    pack = ws is None
+    if pack:
+        ws = _ws(nb, dy1.device)
+    _lib.call('gx_conv3x3_pair_dgrad', _p(dy1), _p(dy2), _p(w1), _p(w2), _p(dx), N, Cin, Co1, Co2, H, W, int(pack),
+              _p(ws), nb, _stream())
+    return dx
+
+
 def conv3x3_wino(x, w, mode=0):
     """Winograd F(2x2,3x3) conv3x3: mode 0 forward (x [N,Cin,H,W]), mode 1 data gradient (x = dy [N,Cout,H,W])."""
     _chk(x, 'wino.x'); _chk(w, 'wino.w')

@@ -62,6 +62,19 @@ int gx_wgq_policy(int mode);
 size_t gx_conv3x3_wino_ws_bytes(int N, int Cin, int Cout, int H, int W);
 int gx_conv3x3_wino(const float* x, const float* w, float* y, int N, int Cin, int Cout, int H, int W, int mode,
                     void* ws, size_t ws_bytes, gx_stream_t stream);
+/*      Two conv3x3 layers on ONE input as one layer (seg_head and feat_head[0] on the encoder features,
+ *      models/genesisv2_config.py:70-73, :110-149): forward = one launch that writes y1 [N,Co1,H,W] = conv3x3(x, w1)
+ *      and y2 [N,Co2,H,W] = conv3x3(x, w2); data gradient = one launch dx = dgrad(dy1, w1) + dgrad(dy2, w2) (the sum of
+ *      the two consumers' input gradients forms in the accumulators: no second dgrad, no accumulation pass).
+ *      Winograd kernel only: gx_conv3x3_pair_supported (Cin % 8 == 0, Co1 % 64 == 0, gx_conv3x3_wino's shape rules).
+ *      ws keeps the packed weights of both directions; dgrad with pack = 0 reuses what the forward of the same
+ *      iteration packed. */
+int gx_conv3x3_pair_supported(int N, int Cin, int Co1, int Co2, int H, int W);
+size_t gx_conv3x3_pair_ws_bytes(int N, int Cin, int Co1, int Co2, int H, int W);
+int gx_conv3x3_pair_fwd(const float* x, const float* w1, const float* w2, float* y1, float* y2, int N, int Cin, int Co1,
+                        int Co2, int H, int W, void* ws, size_t ws_bytes, gx_stream_t stream);
+int gx_conv3x3_pair_dgrad(const float* dy1, const float* dy2, const float* w1, const float* w2, float* dx, int N, int Cin,
+                          int Co1, int Co2, int H, int W, int pack, void* ws, size_t ws_bytes, gx_stream_t stream);
 
 /* ---- ConvTranspose2d(k=5, s=2, p=2, output_padding=1) + bias:
  *      models/genesisv2_config.py:90-98 (decoder_module.{1,4,7,10}).

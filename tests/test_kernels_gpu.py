@@ -489,6 +489,26 @@ def test_linear(M, N, K, act, bias):
         close(bg.grad, br.grad, rtol=1e-4, atol=1e-5, msg='db')
 
 
+@pytest.mark.parametrize('N,Cin,Co1,Co2,S', [(32, 64, 64, 64, 64), (2, 16, 64, 24, 16), (3, 24, 128, 64, 32)])
+def test_conv3x3_pair_one_launch_for_two_layers_on_one_input(N, Cin, Co1, Co2, S):
+    """gx_conv3x3_pair_fwd / _dgrad (seg_head + feat_head[0] on the encoder features as one Winograd layer): the forward
+    outputs are bit-equal to the single-layer Winograd kernel's (same chunk order per output channel); the data gradient
+    equals dgrad(dy1, w1) + dgrad(dy2, w2) against fp64 conv_transpose2d at the single kernel's accuracy."""
+    from genesis_amd import hip_ops as hip
+    x = rnd(N, Cin, S, S, seed=1).to(DEV)
+    w1 = rnd(Co1, Cin, 3, 3, seed=2, scale=0.1).to(DEV)
+    w2 = rnd(Co2, Cin, 3, 3, seed=3, scale=0.1).to(DEV)
+    assert hip.conv3x3_pair_supported(x, w1, w2)
+    y1, y2, ws = hip.conv3x3_pair_fwd(x, w1, w2)
+    assert torch.equal(y1, hip.conv3x3_wino(x, w1, 0)) and torch.equal(y2, hip.conv3x3_wino(x, w2, 0))
+    d1, d2 = rnd(N, Co1, S, S, seed=4).to(DEV), rnd(N, Co2, S, S, seed=5).to(DEV)
+    ref = F.conv_transpose2d(d1.double(), w1.double(), None, 1, 1) + F.conv_transpose2d(d2.double(), w2.double(), None, 1, 1)
+    for packed in (ws, None):
+        dx = hip.conv3x3_pair_dgrad(d1, d2, w1, w2, packed)
+        close(dx, ref, rtol=2e-5, atol=2e-5, msg='dx (packed weights %s)' % ('reused' if packed is not None else 'fresh'))
+    assert not hip.conv3x3_pair_supported(x, w1[:Co1 - 8], w2)      # the first layer must fill whole 64-channel tiles
+
+
 @pytest.mark.parametrize('N,D,Cout,d', [(224, 64, 64, 4), (5, 16, 24, 2), (3, 8, 16, 8), (2, 4, 8, 1)])
 def test_broadcast_deconv_as_matrix_product(N, D, Cout, d):
     """The decoder's first layer on the broadcast latent (models/genesisv2_config.py:89-90) computed as
