@@ -307,7 +307,7 @@ struct WsJob {
     int pad_;
 };
 constexpr int kMaxSJobs = 36;                            // 36 x 96 B: the table travels as a kernel argument
-struct WsTable { long long U; int njobs, G; WsJob job[kMaxSJobs]; };
+struct WsTable { long long U; int njobs, G; long long* times; WsJob job[kMaxSJobs]; };   // times: GENESIS_WGQ_TIMES (NULL otherwise)
 
 // out-of-line copy of a variant for the stream-K kernel: nine inlined bodies in one function cost hipcc's register
 // allocator ~1.5 KB of scratch per lane; as separate functions each keeps the allocation of its own grouped kernel.
@@ -332,6 +332,7 @@ __host__ __device__ inline void ws_locate(const WsTable& tab, long long B, int* 
 __global__ void __launch_bounds__(256, 1)
 wgq_stream_kernel(const WsTable tab, const float* __restrict__ zeros) {
     const int wg = blockIdx.x;
+    const long long t_begin = tab.times ? (long long)__builtin_amdgcn_s_memrealtime() : 0;      // 100 MHz
     int js, ts, je, te;
     ws_locate(tab, tab.U * wg / tab.G, &js, &ts);
     ws_locate(tab, wg + 1 == tab.G ? tab.U : tab.U * (wg + 1) / tab.G, &je, &te);
@@ -354,6 +355,11 @@ wgq_stream_kernel(const WsTable tab, const float* __restrict__ zeros) {
         }
 #undef GX_WS_CASE
         __syncthreads();          // the next segment's first DMA re-uses stage 0
+    }
+    if (tab.times && threadIdx.x == 0) {          // measurement: when did this workgroup start and finish
+        __builtin_amdgcn_s_waitcnt(0);
+        tab.times[2 * wg] = t_begin;
+        tab.times[2 * wg + 1] = (long long)__builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -595,11 +601,48 @@ int wgq_launch_stream(std::vector<PendingJob*>& jobs, hipStream_t s, std::vector
                         tab.job[j].Wb, tab.job[j].ntiles, tab.job[j].cost,
                         (double)tab.job[j].ntiles * tab.job[j].cost / (double)tab.U, slots[j].nseg);
         }
+        // GENESIS_WGQ_TIMES=1 (eager launches only): per-workgroup start / end times of the launch -> how well the cost
+        // table balances the 256 workgroups (printed: busy time min / mean / max and the idle share of the launch)
+        static const bool want_times = getenv("GENESIS_WGQ_TIMES") != nullptr;
+        static long long* d_times = nullptr;
+        hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
+        const bool capturing = hipStreamIsCapturing(s, &cst) != hipSuccess || cst != hipStreamCaptureStatusNone;
+        tab.times = nullptr;
+        if (want_times && !capturing) {
+            if (!d_times) (void)hipMalloc((void**)&d_times, 2 * 256 * sizeof(long long));
+            tab.times = d_times;
+        }
         {
             GxProf pf(KID_WGRAD_C3, s, flops, bytes);
             hipLaunchKernelGGL(wgq_stream_kernel, dim3(G), dim3(256), 160 * 1024, s, tab, zeros);
         }
         GX_CHECK_LAUNCH("wgq (stream-K weight gradients)");
+        if (tab.times) {
+            std::vector<long long> h(2 * G);
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(h.data(), d_times, 2 * G * sizeof(long long), hipMemcpyDeviceToHost);
+            long long t0 = h[0], t1 = h[1];
+            double busy = 0.0, bmin = 1e30, bmax = 0.0;
+            for (int w = 0; w < G; ++w) {
+                t0 = h[2 * w] < t0 ? h[2 * w] : t0; t1 = h[2 * w + 1] > t1 ? h[2 * w + 1] : t1;
+                const double b = (double)(h[2 * w + 1] - h[2 * w]) * 0.01;
+                busy += b; bmin = b < bmin ? b : bmin; bmax = b > bmax ? b : bmax;
+            }
+            const double span = (double)(t1 - t0) * 0.01;
+            fprintf(stderr, "[wgq times] G %d span %.1f us; workgroup busy min %.1f mean %.1f max %.1f us; idle share %.3f\n", G,
+                    span, bmin, busy / G, bmax, 1.0 - busy / (G * span));
+            // busy time by the job a workgroup STARTS in (same job: same kind of work)
+            for (int j = 0; j < tab.njobs; ++j) {
+                double sj = 0.0; int nj = 0;
+                for (int w = 0; w < G; ++w) {
+                    int js, ts;
+                    ws_locate(tab, tab.U * w / G, &js, &ts);
+                    if (js == j) { sj += (double)(h[2 * w + 1] - h[2 * w]) * 0.01; ++nj; }
+                }
+                if (nj) fprintf(stderr, "   workgroups starting in job %2d (variant %d, %dx%d): %3d, mean busy %.1f us\n", j,
+                                tab.job[j].variant, tab.job[j].Hb, tab.job[j].Wb, nj, sj / nj);
+            }
+        }
         // reduce records: one per (layer, channel block); the two row parities of a transposed conv share the slabs
         for (int j = 0; j < tab.njobs; ++j) {
             PendingJob& q = *slots[j].p;
