@@ -1303,21 +1303,26 @@ int launch_splitk_reduce(const float* part, const float* bias, float* out, const
 struct PackEntry {
     const float* w; float* wp;
     int pack, Co, Ci, NT, Kpad, Mpad;
+    int chunk0;             // first workgroup (chunk of kPackChunk elements) of this entry in the batched launch
 };
+constexpr int kPackChunk = 2048;
 struct PackCache {
     std::vector<PackEntry> entries;
     PackEntry* dev = nullptr;
-    bool alive = false;
+    int* dev_map = nullptr;     // entry index of every chunk (the batched launch is ONE flat grid: work per workgroup
+    int nchunks = 0;            // is the same whatever the entry's size; 128 workgroups per entry took 26 us, set by
+    bool alive = false;         // the largest Winograd packing)
 };
 std::vector<PackCache> g_caches;       // (created / destroyed under g_cache_mutex; a cache is used by the context that made it)
 std::mutex g_cache_mutex;
 #define g_cache_recording (gx_ctx_flags().cache_recording)   // cache id being recorded by this context, or -1
 #define g_cache_active (gx_ctx_flags().cache_active)         // cache id this context's conv calls are served from, or -1
 
-__global__ void pack_weights_batch_kernel(const PackEntry* __restrict__ entries) {
-    const PackEntry e = entries[blockIdx.y];
+__global__ void pack_weights_batch_kernel(const PackEntry* __restrict__ entries, const int* __restrict__ map) {
+    const PackEntry e = entries[map[blockIdx.x]];
     const int total = e.NT * e.Kpad * e.Mpad;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int begin = (blockIdx.x - e.chunk0) * kPackChunk, end = begin + kPackChunk < total ? begin + kPackChunk : total;
+    for (int idx = begin + threadIdx.x; idx < end; idx += blockDim.x) {
         const int m = idx % e.Mpad;
         const int k = (idx / e.Mpad) % e.Kpad;
         const int t = idx / (e.Mpad * e.Kpad);
@@ -1338,7 +1343,7 @@ int launch_pack(const float* w, float* wp, int pack, int Co, int Ci, int NT, int
         bool found = false;
         for (const PackEntry& e : c.entries) found = found || (e.w == w && e.pack == pack && e.Co == Co && e.Ci == Ci);
         if (!found) {
-            PackEntry e{w, nullptr, pack, Co, Ci, NT, Kpad, Mpad};
+            PackEntry e{w, nullptr, pack, Co, Ci, NT, Kpad, Mpad, 0};
             if (hipMalloc((void**)&e.wp, (size_t)NT * Kpad * Mpad * sizeof(float)) != hipSuccess) {
                 gx_set_error("weight cache: hipMalloc failed");
                 return GX_ELAUNCH;
@@ -1755,10 +1760,22 @@ int gx_weight_cache_record(int id, int on) {
     if (on) { g_cache_recording = id; return GX_OK; }
     g_cache_recording = -1;
     if (c.dev) { (void)hipFree(c.dev); c.dev = nullptr; }
+    if (c.dev_map) { (void)hipFree(c.dev_map); c.dev_map = nullptr; }
+    c.nchunks = 0;
     if (!c.entries.empty()) {
+        std::vector<int> map;
+        for (size_t i = 0; i < c.entries.size(); ++i) {
+            PackEntry& e = c.entries[i];
+            e.chunk0 = (int)map.size();
+            const int n = gx_ceil_div(e.NT * e.Kpad * e.Mpad, kPackChunk);
+            map.insert(map.end(), (size_t)n, (int)i);
+        }
+        c.nchunks = (int)map.size();
         const size_t bytes = c.entries.size() * sizeof(PackEntry);
         if (hipMalloc((void**)&c.dev, bytes) != hipSuccess ||
-            hipMemcpy(c.dev, c.entries.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
+            hipMemcpy(c.dev, c.entries.data(), bytes, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMalloc((void**)&c.dev_map, map.size() * sizeof(int)) != hipSuccess ||
+            hipMemcpy(c.dev_map, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
             gx_set_error("gx_weight_cache_record: table upload failed");
             return GX_ELAUNCH;
         }
@@ -1781,8 +1798,8 @@ int gx_weight_cache_refresh(int id, gx_stream_t stream) {
         double bytes = 0.0;
         for (const PackEntry& e : c.entries) bytes += 8.0 * e.NT * e.Kpad * e.Mpad;
         GxProf pf(KID_PACK_WEIGHTS, s, 0.0, bytes);
-        hipLaunchKernelGGL(pack_weights_batch_kernel, dim3(128, (unsigned)c.entries.size()), dim3(256), 0, s,
-                           (const PackEntry*)c.dev);
+        hipLaunchKernelGGL(pack_weights_batch_kernel, dim3((unsigned)c.nchunks), dim3(256), 0, s,
+                           (const PackEntry*)c.dev, (const int*)c.dev_map);
     }
     GX_CHECK_LAUNCH("gx_weight_cache_refresh");
     g_cache_active = id;
@@ -1800,6 +1817,7 @@ int gx_weight_cache_destroy(int id) {
     PackCache& c = g_caches[id];
     for (PackEntry& e : c.entries) (void)hipFree(e.wp);
     if (c.dev) (void)hipFree(c.dev);
+    if (c.dev_map) (void)hipFree(c.dev_map);
     c = PackCache();
     if (g_cache_active == id) g_cache_active = -1;
     if (g_cache_recording == id) g_cache_recording = -1;
