@@ -117,12 +117,16 @@ wino_conv_kernel(const float* __restrict__ in, const float* __restrict__ in2, co
             if (r >= 0 && r < g.H && c >= 0 && c < g.W) voff[q] = (ch * HW + r * g.W + c) * 4;
         }
     }
-    // descriptor and scalar offset of the chunk that starts at channel k0 (scalar selects, no branch)
+    // descriptor of the chunk that starts at channel k0: based AT that channel and as long as the channels that exist
+    // from there, so that the hardware's range check (per-lane offset against the descriptor's length; a scalar offset
+    // would not be checked) zeroes exactly the channels >= K of a ragged last chunk and everything of a chunk past the end
+    // (empty descriptor: no memory is touched).  Scalar selects, no branch.
     auto chunk_rsrc = [&](int k0, int& soff) {
         const bool second = k0 >= g.K1;
-        soff = (second ? k0 - g.K1 : k0) * HW * 4;
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(second ? in2_n : in_n), 0,
-                                                 (second ? Kb : Ka) * HW * 4, 0x00020000);
+        const int kr = second ? k0 - g.K1 : k0, left = (second ? Kb : Ka) - kr;
+        soff = 0;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((second ? in2_n : in_n) + (size_t)kr * HW), 0,
+                                                 left > 0 ? left * HW * 4 : 0, 0x00020000);
     };
     float rawr[RAW_PER_THREAD];
     auto load_raw = [&](int k0) {
@@ -197,8 +201,8 @@ wino_conv_kernel(const float* __restrict__ in, const float* __restrict__ in2, co
         ua[nu][1] = *reinterpret_cast<const f32x4*>(Uw + (size_t)nu * 512 + 4);
     }
     {
-        // the first three chunks' patches in ONE round trip (the channel-range check of the buffer loads makes the
-        // loads of chunks that do not exist return zeros: no branches)
+        // the first three chunks' patches in ONE round trip (a chunk that does not exist reads through an empty
+        // descriptor: zeros, no branches)
         float r0[RAW_PER_THREAD], r1[RAW_PER_THREAD];
         int so0, so1;
         const __amdgpu_buffer_rsrc_t rs0 = chunk_rsrc(0, so0), rs1 = chunk_rsrc(WKC, so1);
@@ -445,9 +449,9 @@ int gx_conv3x3_wino(const float* x, const float* w, float* y, int N, int Cin, in
 }
 
 // ---- two conv3x3 layers on one input as one layer (forward: one launch writes both outputs; data gradient: one launch
-// sums both layers' input gradients).  Cin % 8 == 0, Co1 % 64 == 0, and the Winograd shape rules for (Cin, Co1 + Co2).
+// sums both layers' input gradients).  Co1 % 64 == 0 and the Winograd shape rules for (Cin, Co1 + Co2).
 int gx_conv3x3_pair_supported(int N, int Cin, int Co1, int Co2, int H, int W) {
-    return wino_shape_ok(N, Cin, Co1 + Co2, H, W) && Cin % 8 == 0 && Co1 % 64 == 0 && Co1 % 8 == 0 && Co1 > 0 && Co2 > 0;
+    return Co1 > 0 && Co2 > 0 && wino_shape_ok(N, Cin, Co1 + Co2, H, W) && Co1 % 64 == 0;
 }
 
 size_t gx_conv3x3_pair_ws_bytes(int N, int Cin, int Co1, int Co2, int H, int W) {

@@ -66,7 +66,7 @@ int gx_conv3x3_wino(const float* x, const float* w, float* y, int N, int Cin, in
  *      models/genesisv2_config.py:70-73, :110-149): forward = one launch that writes y1 [N,Co1,H,W] = conv3x3(x, w1)
  *      and y2 [N,Co2,H,W] = conv3x3(x, w2); data gradient = one launch dx = dgrad(dy1, w1) + dgrad(dy2, w2) (the sum of
  *      the two consumers' input gradients forms in the accumulators: no second dgrad, no accumulation pass).
- *      Winograd kernel only: gx_conv3x3_pair_supported (Cin % 8 == 0, Co1 % 64 == 0, gx_conv3x3_wino's shape rules).
+ *      Winograd kernel only: gx_conv3x3_pair_supported (Co1 % 64 == 0, gx_conv3x3_wino's shape rules).
  *      ws keeps the packed weights of both directions; dgrad with pack = 0 reuses what the forward of the same
  *      iteration packed. */
 int gx_conv3x3_pair_supported(int N, int Cin, int Co1, int Co2, int H, int W);
