@@ -30,6 +30,8 @@ import torch.distributed as dist  # noqa: E402
 FLOP_PER_IMG = {(7, 64): 11.02e9, (5, 64): 9.34e9, (11, 128): 56.55e9}
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 (v_mfma_f32_32x32x16_bf16); the LDS-DMA weight-gradient kernels form every
+BF16X6_TERMS = 6                  # fp32 product from six bf16 piece products on that pipe (include/genesis_hip.h: gx_wgq_precision)
 
 
 def parse():
@@ -264,6 +266,11 @@ def main():
                        if ts.graph is not None else 'eager'},
             'final_elbo': elbo,
         }
+        if os.environ.get('GENESIS_WGQ_BF16X6', '1') != '0':
+            result['arithmetic'] = ('fp32 tensors and fp32 accumulation everywhere; conv / dense products on the fp32 matrix '
+                                    'pipe; weight-gradient products as six bf16 piece products per fp32 product on the bf16 '
+                                    'pipe (hi+mid+lo pieces hold all 24 mantissa bits: error vs fp64 as on the fp32 pipe; '
+                                    'GENESIS_WGQ_BF16X6=0 puts them back on the fp32 pipe)')
         if dist.is_initialized():
             # what the step exchanged: ONE sum all-reduce of the flat fp32 bucket (gradients + err / kl + the fp64
             # gradient as float triples [+ averaged buffers]) over the ranks the process group actually has
@@ -297,8 +304,19 @@ def main():
         sec = dom['ms'] * 1e-3
         if dom['flops'] > 0:
             ach = dom['flops'] / sec / 1e12
-            roof = {'bound': 'mfma', 'kernel': dom['name'], 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS,
-                    'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_MFMA_TFLOPS}
+            mfma_peak = PEAK_FP32_MFMA_TFLOPS
+            roof = {'bound': 'mfma', 'kernel': dom['name'], 'achieved': ach, 'peak': mfma_peak, 'unit': 'TFLOP/s'}
+            if dom['name'].startswith('wgrad_kernel') and os.environ.get('GENESIS_WGQ_BF16X6', '1') != '0':
+                # `achieved` counts the algorithmic fp32 flops; the kernel executes six bf16 MFMA products for each of them,
+                # so its ceiling is the bf16 pipe's dense peak / 6 -- a higher one than the fp32 pipe's 157.3 TF/s
+                mfma_peak = PEAK_BF16_MFMA_TFLOPS / BF16X6_TERMS
+                roof['peak'] = mfma_peak
+                roof['pipe'] = ('bf16 MFMA, fp32 products as %d bf16 piece products (fp32 accumulate): peak = %.0f / %d; '
+                                'against the fp32 pipe (%.1f TF/s) the same rate is frac_of_fp32_pipe'
+                                % (BF16X6_TERMS, PEAK_BF16_MFMA_TFLOPS, BF16X6_TERMS, PEAK_FP32_MFMA_TFLOPS))
+                roof['achieved_on_bf16_pipe'] = ach * BF16X6_TERMS
+                roof['frac_of_fp32_pipe'] = ach / PEAK_FP32_MFMA_TFLOPS
+            roof['frac'] = ach / mfma_peak
         else:
             ach = dom['bytes'] / sec / 1e9
             roof = {'bound': 'hbm', 'kernel': dom['name'], 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
@@ -313,7 +331,7 @@ def main():
         if rp:
             roof['rocprof_avg_launch_us'] = rp
             roof['frac_from_rocprof'] = (dom['flops'] if dom['flops'] > 0 else dom['bytes']) / dom['launches'] / \
-                (rp * 1e-6) / ((PEAK_FP32_MFMA_TFLOPS * 1e12) if dom['flops'] > 0 else (PEAK_HBM_GBS * 1e9))
+                (rp * 1e-6) / ((roof['peak'] * 1e12) if dom['flops'] > 0 else (PEAK_HBM_GBS * 1e9))
         roof.update({'traffic': pmc_traffic(dom['name']), 'traffic_unit': 'bytes/launch (PMC, separate pass)',
                      'algorithmic_bytes_per_launch': dom['bytes'] / dom['launches'],
                      'avg_launch_us': 1e3 * dom['ms'] / dom['launches'],

@@ -172,11 +172,102 @@ __device__ __forceinline__ void wq_tile(const float* __restrict__ rd, float* __r
 #undef GX_WQ_MMA
 }
 
+// ---- the same tile on the bf16 matrix pipe: fp32 products from bf16 pieces (finding 13).
+// x = x_hi + x_mid + x_lo (three bf16 values hold the 24 mantissa bits); a * b ~ the six piece products of order <= 2,
+// accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (k = 16 pixels: lane half h supplies 8 CONSECUTIVE pixels of its tile
+// half -- the contraction index of a weight gradient is the pixel, so the operand octet is 8 consecutive floats of a
+// channel row exactly as the DMA laid them down).  Six MFMAs of 32 cycles per 16 pixels and tap instead of eight of 64;
+// the splits and the tap-shifted windows are VALU work in the MFMAs' shadow.
+typedef __bf16 gx_bf16x8 __attribute__((ext_vector_type(8)));
+struct WqB3 { gx_bf16x8 h, m, l; };
+template <int N>
+__device__ __forceinline__ void wq_split(const float (&v)[N], __bf16 (&h)[N], __bf16 (&m)[N], __bf16 (&l)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        h[i] = (__bf16)v[i];
+        const float r1 = v[i] - (float)h[i];
+        m[i] = (__bf16)r1;
+        l[i] = (__bf16)(r1 - (float)m[i]);
+    }
+}
+template <int N>
+__device__ __forceinline__ WqB3 wq_octet(const __bf16 (&h)[N], const __bf16 (&m)[N], const __bf16 (&l)[N], int o) {
+    WqB3 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { r.h[i] = h[o + i]; r.m[i] = m[o + i]; r.l[i] = l[o + i]; }
+    return r;
+}
+__device__ __forceinline__ f32x16 wq_mma6(const WqB3& a, const WqB3& b, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, c, 0, 0, 0);      // small terms first
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.m, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, c, 0, 0, 0);
+    return c;
+}
+
+template <int CLS, int LTW, int NI>
+__device__ __forceinline__ void wq_tile_b6(const float* __restrict__ rd, float* __restrict__ wr,
+                                           f32x16 (&acc)[WqTap<CLS>::NT], const WqW& w, const int (&goff)[NI],
+                                           const int (&info)[NI], const int img, const int th, const int tw,
+                                           const bool live) {
+    using WT = WqTap<CLS>;
+    constexpr int NT = WT::NT, SA = WT::SA, NRO = WT::NRO, RO0 = WT::RO0;
+    constexpr int TW = 1 << LTW;
+    constexpr int RPA = SA * TW / 4, RPB = (TW + 8) / 4;
+    constexpr int NCO = NT / NRO;              // taps per halo row (3 / 5)
+    wq_issue<CLS, LTW, NI>(wr, w, goff, info, img, th, tw, live);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int jpix = w.h * 32 + 8 * g;
+        const int r_ = jpix >> LTW, c_ = jpix & (TW - 1);
+        // A: the 8 (conv3x3) / 16 (transposed conv: both column parities interleaved) dy values of these 8 base pixels
+        const int qa = r_ * RPA + (SA * c_) / 4;
+        float av[8 * SA];
+#pragma unroll
+        for (int p = 0; p < 2 * SA; ++p) {
+            const f32x4 t4 = *reinterpret_cast<const f32x4*>(rd + w.a_base + (((qa + p) ^ w.a_f) << 2));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) av[4 * p + e] = t4[e];
+        }
+        __bf16 ah[8 * SA], am[8 * SA], al[8 * SA];
+        wq_split<8 * SA>(av, ah, am, al);
+        WqB3 a3[SA];                                  // [column parity]
+#pragma unroll
+        for (int pb = 0; pb < SA; ++pb)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { a3[pb].h[i] = ah[SA * i + pb]; a3[pb].m[i] = am[SA * i + pb]; a3[pb].l[i] = al[SA * i + pb]; }
+#pragma unroll
+        for (int rr = 0; rr < NRO; ++rr) {
+            // B: halo columns c_ - 1 .. c_ + 8 of row r_ + RO0 + rr (window of 10 floats; conv3x3 offsets 0..2, the
+            // transposed conv's 0..2 as well: x halo offset 2 - kw / 2)
+            const int qb = (r_ + RO0 + rr) * RPB + (c_ >> 2);
+            float bv[10];
+            bv[0] = rd[w.b_base + ((qb ^ w.b_f) << 2) + 3];
+            const f32x4 m0 = *reinterpret_cast<const f32x4*>(rd + w.b_base + (((qb + 1) ^ w.b_f) << 2));
+            const f32x4 m1 = *reinterpret_cast<const f32x4*>(rd + w.b_base + (((qb + 2) ^ w.b_f) << 2));
+            bv[9] = rd[w.b_base + (((qb + 3) ^ w.b_f) << 2)];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { bv[1 + e] = m0[e]; bv[5 + e] = m1[e]; }
+            __bf16 bh[10], bm[10], bl[10];
+            wq_split<10>(bv, bh, bm, bl);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (WT::ro(t) - RO0 != rr) continue;
+                const WqB3 b3 = wq_octet<10>(bh, bm, bl, WT::co(t));
+                acc[t] = wq_mma6(a3[WT::pb(t)], b3, acc[t]);
+            }
+        }
+    }
+}
+
 // One SEGMENT: the tiles t0, t0 + tstep, ... (< tend) of one 64 x 64 channel block (ca0, cb0) of one layer, accumulated
 // in registers and written as one slab (`slab` points at [tap 0][row 0][col 0] of this workgroup's block; rows are ldc
 // floats apart, taps tstride).  The grouped kernel hands a workgroup one strided segment, the stream-K kernel one or
 // more contiguous ones.
-template <int CLS, int LTW>
+// B6: the tiles run on the bf16 matrix pipe (wq_tile_b6: fp32 products from six bf16 piece products) instead of the fp32 one
+template <int CLS, int LTW, bool B6>
 __device__ __forceinline__ void wq_segment(const float* a, const float* b, const float* zeros, float* lds, int CA, int CB,
                                            int ca0, int cb0, int Hb, int Wb, int tiles_h, int tiles_w, int t0, int tstep,
                                            int tend, float* slab, int ldc, int tstride) {
@@ -255,8 +346,12 @@ __device__ __forceinline__ void wq_segment(const float* a, const float* b, const
         t_tw += d_tw; t_th += d_th; t_img += d_img;          // next tile of this workgroup
         if (t_tw >= tiles_w) { t_tw -= tiles_w; ++t_th; }
         if (t_th >= tiles_h) { t_th -= tiles_h; ++t_img; }
-        wq_tile<CLS, LTW, NI>(lds + (it & 1) * STAGE, lds + ((it + 1) & 1) * STAGE, acc, w, goff, info, t_img, t_th, t_tw,
-                              tile + tstep < tend);
+        if (B6)
+            wq_tile_b6<CLS, LTW, NI>(lds + (it & 1) * STAGE, lds + ((it + 1) & 1) * STAGE, acc, w, goff, info, t_img, t_th,
+                                     t_tw, tile + tstep < tend);
+        else
+            wq_tile<CLS, LTW, NI>(lds + (it & 1) * STAGE, lds + ((it + 1) & 1) * STAGE, acc, w, goff, info, t_img, t_th,
+                                  t_tw, tile + tstep < tend);
     }
 
     // ---- slab [tap][ca][cb]  (C/D layout: col = lane & 31 -> cb, row -> ca)
@@ -274,7 +369,7 @@ __device__ __forceinline__ void wq_segment(const float* a, const float* b, const
 }
 
 // ---- grouped launch: the jobs of one (class, tile width), every workgroup one strided segment
-template <int CLS, int LTW>
+template <int CLS, int LTW, bool B6>
 __global__ void __launch_bounds__(256, 1)
 wgq_kernel(const WqTable tab, const float* __restrict__ zeros) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -287,7 +382,7 @@ wgq_kernel(const WqTable tab, const float* __restrict__ zeros) {
     const int nsp = jb.nsplit;
     const int blk = local / nsp, sp = local - blk * nsp;
     const int ca0 = (blk / jb.nbt) * 64, cb0 = (blk % jb.nbt) * 64;
-    wq_segment<CLS, LTW>(jb.a, jb.b, zeros, lds, jb.CA, jb.CB, ca0, cb0, jb.Hb, jb.Wb, jb.tiles_h, jb.tiles_w, sp, nsp,
+    wq_segment<CLS, LTW, B6>(jb.a, jb.b, zeros, lds, jb.CA, jb.CB, ca0, cb0, jb.Hb, jb.Wb, jb.tiles_h, jb.tiles_w, sp, nsp,
                          jb.ntiles, jb.partial + ((size_t)sp * jb.Ttot * jb.CApad + ca0) * jb.CBpad + cb0, jb.CBpad,
                          jb.CApad * jb.CBpad);
 }
@@ -301,7 +396,7 @@ struct WsJob {
     const float* a; const float* b; float* partial;      // partial: this block's region [slab][Ttot][64][64]
     long long ubegin;                                    // first unit of this block on the line
     int CA, CB, ca0, cb0, Hb, Wb, tiles_h, tiles_w, ntiles, Ttot;
-    int variant;                                         // class * 3 + (5 - log2 tile width)
+    int variant;                                         // class * 3 + (5 - log2 tile width); + 9: on the fp32 matrix pipe
     int cost;                                            // units per tile
     int w_first;                                         // first workgroup with tiles of this block (slab 0)
     int pad_;
@@ -313,12 +408,12 @@ struct WsTable { long long U; int njobs, G; long long* times; WsJob job[kMaxSJob
 // allocator ~1.5 KB of scratch per lane; as separate functions each keeps the allocation of its own grouped kernel.
 // The LDS stage pointer is re-derived from the dynamic LDS symbol inside (a pointer parameter would arrive as a flat
 // pointer and turn every ds_read into a flat load).
-template <int CLS, int LTW>
+template <int CLS, int LTW, bool B6>
 __device__ __attribute__((noinline)) void wq_segment_call(const float* a, const float* b, const float* zeros, int CA, int CB,
                                                           int ca0, int cb0, int Hb, int Wb, int tiles_h, int tiles_w, int t0,
                                                           int t1, float* slab) {
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
-    wq_segment<CLS, LTW>(a, b, zeros, lds_dyn, CA, CB, ca0, cb0, Hb, Wb, tiles_h, tiles_w, t0, 1, t1, slab, 64, 4096);
+    wq_segment<CLS, LTW, B6>(a, b, zeros, lds_dyn, CA, CB, ca0, cb0, Hb, Wb, tiles_h, tiles_w, t0, 1, t1, slab, 64, 4096);
 }
 
 __host__ __device__ inline void ws_locate(const WsTable& tab, long long B, int* j_out, int* t_out) {
@@ -344,8 +439,12 @@ wgq_stream_kernel(const WsTable tab, const float* __restrict__ zeros) {
         float* slab = jb.partial + (size_t)(wg - jb.w_first) * jb.Ttot * 4096;
 #define GX_WS_CASE(V_, CLS_, LTW_)                                                                                  \
         case V_:                                                                                                    \
-            wq_segment_call<CLS_, LTW_>(jb.a, jb.b, zeros, jb.CA, jb.CB, jb.ca0, jb.cb0, jb.Hb, jb.Wb, jb.tiles_h, \
-                                        jb.tiles_w, t0, t1, slab);                                                  \
+            wq_segment_call<CLS_, LTW_, true>(jb.a, jb.b, zeros, jb.CA, jb.CB, jb.ca0, jb.cb0, jb.Hb, jb.Wb,       \
+                                              jb.tiles_h, jb.tiles_w, t0, t1, slab);                                \
+            break;                                                                                                  \
+        case V_ + 9:                                                                                                \
+            wq_segment_call<CLS_, LTW_, false>(jb.a, jb.b, zeros, jb.CA, jb.CB, jb.ca0, jb.cb0, jb.Hb, jb.Wb,      \
+                                               jb.tiles_h, jb.tiles_w, t0, t1, slab);                               \
             break;
         switch (jb.variant) {
             GX_WS_CASE(0, WQ_C3, 5) GX_WS_CASE(1, WQ_C3, 4) GX_WS_CASE(2, WQ_C3, 3)
@@ -386,33 +485,50 @@ const float* zero16(hipStream_t s) {
     return g_zero16;
 }
 
-template <int CLS, int LTW>
+// which matrix pipe the weight gradients run on: 1 (default) bf16 pipe, fp32 products from six bf16 piece products
+// (wq_tile_b6); 0 the fp32 pipe.  GENESIS_WGQ_BF16X6=0 / gx_wgq_precision(0) select the latter.
+int g_wgq_b6 = -1;
+bool wgq_b6() {
+    if (g_wgq_b6 < 0) {
+        const char* env = getenv("GENESIS_WGQ_BF16X6");
+        g_wgq_b6 = (env && env[0] == '0') ? 0 : 1;
+    }
+    return g_wgq_b6 != 0;
+}
+
+template <int CLS, int LTW, bool B6>
 void wgq_launch_inst(const WqTable& tab, int total_wgs, const float* zeros, hipStream_t s) {
     using WT = WqTap<CLS>;
     constexpr int TW = 1 << LTW, TH = 64 >> LTW;
     constexpr size_t lds = (size_t)2 * (64 * (TH * WT::SA * TW / 4) + 64 * kSB) * 16;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgq_kernel<CLS, LTW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgq_kernel<CLS, LTW, B6>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    hipLaunchKernelGGL((wgq_kernel<CLS, LTW>), dim3(total_wgs), dim3(256), lds, s, tab, zeros);
+    hipLaunchKernelGGL((wgq_kernel<CLS, LTW, B6>), dim3(total_wgs), dim3(256), lds, s, tab, zeros);
+}
+
+template <int CLS, int LTW>
+void wgq_launch_pipe(const WqTable& tab, int total_wgs, const float* zeros, hipStream_t s) {
+    if (wgq_b6()) wgq_launch_inst<CLS, LTW, true>(tab, total_wgs, zeros, s);
+    else wgq_launch_inst<CLS, LTW, false>(tab, total_wgs, zeros, s);
 }
 
 void wgq_launch(int cls, int ltw, const WqTable& tab, int total_wgs, const float* zeros, hipStream_t s) {
     if (cls == WQ_C3) {
-        if (ltw == 5) wgq_launch_inst<WQ_C3, 5>(tab, total_wgs, zeros, s);
-        else if (ltw == 4) wgq_launch_inst<WQ_C3, 4>(tab, total_wgs, zeros, s);
-        else wgq_launch_inst<WQ_C3, 3>(tab, total_wgs, zeros, s);
+        if (ltw == 5) wgq_launch_pipe<WQ_C3, 5>(tab, total_wgs, zeros, s);
+        else if (ltw == 4) wgq_launch_pipe<WQ_C3, 4>(tab, total_wgs, zeros, s);
+        else wgq_launch_pipe<WQ_C3, 3>(tab, total_wgs, zeros, s);
     } else if (cls == WQ_DR0) {
-        if (ltw == 5) wgq_launch_inst<WQ_DR0, 5>(tab, total_wgs, zeros, s);
-        else if (ltw == 4) wgq_launch_inst<WQ_DR0, 4>(tab, total_wgs, zeros, s);
-        else wgq_launch_inst<WQ_DR0, 3>(tab, total_wgs, zeros, s);
+        if (ltw == 5) wgq_launch_pipe<WQ_DR0, 5>(tab, total_wgs, zeros, s);
+        else if (ltw == 4) wgq_launch_pipe<WQ_DR0, 4>(tab, total_wgs, zeros, s);
+        else wgq_launch_pipe<WQ_DR0, 3>(tab, total_wgs, zeros, s);
     } else {
-        if (ltw == 5) wgq_launch_inst<WQ_DR1, 5>(tab, total_wgs, zeros, s);
-        else if (ltw == 4) wgq_launch_inst<WQ_DR1, 4>(tab, total_wgs, zeros, s);
-        else wgq_launch_inst<WQ_DR1, 3>(tab, total_wgs, zeros, s);
+        if (ltw == 5) wgq_launch_pipe<WQ_DR1, 5>(tab, total_wgs, zeros, s);
+        else if (ltw == 4) wgq_launch_pipe<WQ_DR1, 4>(tab, total_wgs, zeros, s);
+        else wgq_launch_pipe<WQ_DR1, 3>(tab, total_wgs, zeros, s);
     }
 }
 
@@ -491,16 +607,17 @@ bool wgq_stream_on() {
 // wgrad3:256:64 wgrad3:2048:16 wgrad3:8192:8 wgrad:256:32 wgrad:1024:16 wgrad:4096:8: 10.3 us per conv3x3 tile, 26.5 us per
 // pair of transposed-conv row-parity tiles, split 15 a + b : 10 a + b), then nudged on the training step itself
 // (the stream kernel's duration over five vectors: 921 .. 972 us); GENESIS_WGQ_COST="c0,...,c8" overrides
-int g_ws_cost[9] = {10200, 10600, 11200, 16000, 16500, 18200, 11600, 12000, 13300};
+int g_ws_cost[18] = {10200, 9580, 10680, 15080, 26500, 14570, 11400, 10620, 11540,            // bf16 pipe (measured with
+                     10200, 10600, 11200, 16000, 16500, 18200, 11600, 12000, 13300};          // GENESIS_WGQ_TIMES) | fp32 pipe
 bool g_ws_cost_init = false;
 void ws_cost_init() {
     if (g_ws_cost_init) return;
     g_ws_cost_init = true;
     const char* env = getenv("GENESIS_WGQ_COST");
     if (!env) return;
-    int v[9];
+    int v[9];          // the nine costs of the pipe in use
     if (sscanf(env, "%d,%d,%d,%d,%d,%d,%d,%d,%d", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6, v + 7, v + 8) == 9)
-        for (int i = 0; i < 9; ++i) if (v[i] > 0) g_ws_cost[i] = v[i];
+        for (int i = 0; i < 9; ++i) if (v[i] > 0) g_ws_cost[(wgq_b6() ? 0 : 9) + i] = v[i];
 }
 
 struct WsSlot { PendingJob* p; int blk; int nseg; };
@@ -569,7 +686,7 @@ int wgq_launch_stream(std::vector<PendingJob*>& jobs, hipStream_t s, std::vector
                     jb.Hb = q.job.Hb; jb.Wb = q.job.Wb;
                     jb.tiles_h = q.job.tiles_h; jb.tiles_w = q.job.tiles_w; jb.ntiles = q.job.ntiles;
                     jb.Ttot = q.job.Ttot;
-                    jb.variant = q.cls * 3 + (5 - q.ltw);
+                    jb.variant = q.cls * 3 + (5 - q.ltw) + (wgq_b6() ? 0 : 9);
                     jb.cost = g_ws_cost[jb.variant];
                     jb.w_first = 0; jb.pad_ = 0;
                     tab.U += (long long)jb.ntiles * jb.cost;
@@ -802,6 +919,13 @@ int gx_wgq_flush(hipStream_t s) {
     }
     g_jobs.clear();
     return rc;
+}
+
+extern "C" int gx_wgq_precision(int mode) {
+    GX_CHECK_ARG(mode == 0 || mode == 1, "gx_wgq_precision: mode must be 0 (fp32 matrix pipe) or 1 (bf16 pipe, fp32 products "
+                                         "from six bf16 piece products)");
+    g_wgq_b6 = mode;
+    return GX_OK;
 }
 
 extern "C" int gx_wgq_policy(int mode) {

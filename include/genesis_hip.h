@@ -59,6 +59,13 @@ int gx_kq_policy(int mode);
  *      LDS-DMA staged kernels, every queued layer in ONE stream-K launch at gx_defer_flush; 2 = the same kernels, one
  *      launch per (tap class, tile width); 0 = the round-1 kernels everywhere. */
 int gx_wgq_policy(int mode);
+/*      Which matrix pipe the LDS-DMA weight-gradient kernels multiply on.  1 (default): the bf16 pipe -- every fp32
+ *      operand is split into three bf16 pieces (hi + mid + lo = all 24 mantissa bits) and a product is the six piece
+ *      products of order <= 2, accumulated in fp32 (v_mfma_f32_32x32x16_bf16): the error against fp64 is that of the
+ *      fp32 pipe (tools/bf16x6_probe.hip: 4.8e-7 vs 5.8e-7 relative L2; tests/test_kernels_gpu.py compares both pipes
+ *      with fp64), at 6 x 32 instead of 8 x 64 matrix-pipe cycles per 16 contraction steps.  0: the fp32 pipe
+ *      (v_mfma_f32_32x32x2_f32).  Environment: GENESIS_WGQ_BF16X6=0. */
+int gx_wgq_precision(int mode);
 size_t gx_conv3x3_wino_ws_bytes(int N, int Cin, int Cout, int H, int W);
 int gx_conv3x3_wino(const float* x, const float* w, float* y, int N, int Cin, int Cout, int H, int W, int mode,
                     void* ws, size_t ws_bytes, gx_stream_t stream);

@@ -489,6 +489,36 @@ def test_linear(M, N, K, act, bias):
         close(bg.grad, br.grad, rtol=1e-4, atol=1e-5, msg='db')
 
 
+@pytest.mark.parametrize('kind,N,Cin,Cout,S', [('conv3x3', 32, 64, 64, 64), ('conv3x3', 8, 128, 64, 32), ('conv3x3', 4, 40, 72, 16),
+                                                ('deconv', 56, 64, 64, 32), ('deconv', 16, 64, 64, 16), ('deconv', 9, 24, 40, 8)])
+def test_weight_gradients_on_the_bf16_pipe_keep_fp32_accuracy(kind, N, Cin, Cout, S):
+    """gx_wgq_precision: the LDS-DMA weight-gradient kernels form every fp32 product from six bf16 piece products on the
+    bf16 matrix pipe (default) or multiply on the fp32 pipe.  Both against autograd in fp64: the bf16-pipe error must
+    stay within 1.5 x the fp32-pipe error + 1e-7 (measured: equal or smaller), and within the suite's 1e-4 bar."""
+    from genesis_amd import hip_ops as hip, _lib
+    if kind == 'conv3x3':
+        x, dy = rnd(N, Cin, S, S, seed=1), rnd(N, Cout, S, S, seed=2)
+        w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+        (F.conv2d(x.double(), w, None, 1, 1) * dy.double()).sum().backward()
+        run = lambda: hip.conv3x3_wgrad(x.to(DEV), dy.to(DEV))  # noqa: E731
+    else:
+        x, dy = rnd(N, Cin, S, S, seed=1), rnd(N, Cout, 2 * S, 2 * S, seed=2)
+        w = torch.zeros(Cin, Cout, 5, 5, dtype=torch.float64, requires_grad=True)
+        (F.conv_transpose2d(x.double(), w, None, 2, 2, 1) * dy.double()).sum().backward()
+        run = lambda: hip.deconv5x5s2_wgrad(x.to(DEV), dy.to(DEV))  # noqa: E731
+    ref = w.grad
+    err = {}
+    try:
+        for mode in (0, 1):
+            _lib.call('gx_wgq_precision', mode)
+            got = run().double().cpu()
+            err[mode] = float((got - ref).norm() / ref.norm())
+    finally:
+        _lib.call('gx_wgq_precision', 1)
+    print('%s N=%d %d->%d @%d: relative L2 error fp32 pipe %.3e, bf16 pipe (6 terms) %.3e' % (kind, N, Cin, Cout, S, err[0], err[1]))
+    assert err[1] <= 1.5 * err[0] + 1e-7 and err[1] < 1e-4, err
+
+
 @pytest.mark.parametrize('N,Cin,Co1,Co2,S', [(32, 64, 64, 64, 64), (2, 16, 64, 24, 16), (3, 24, 128, 64, 32)])
 def test_conv3x3_pair_one_launch_for_two_layers_on_one_input(N, Cin, Co1, Co2, S):
     """gx_conv3x3_pair_fwd / _dgrad (seg_head + feat_head[0] on the encoder features as one Winograd layer): the forward
