@@ -148,6 +148,16 @@ int gx_kq_deconv_fwd_launch(const float* in, const float* wp0, const float* wp1,
                             int K, int M, int Hb, int Wb, float* stats, int* stats_parts, hipStream_t s);
 int gx_kq_deconv_dgrad_launch(const float* dy, const float* wp, float* dx, int N, int K, int M, int Hb, int Wb,
                               hipStream_t s);
+// ... on the bf16 matrix pipe: weights packed by kinds 22 / 23 = [channel tile][16-channel chunk][tap][piece hi|mid|lo]
+// [octet][64 output channels][8 channels] in bf16 (two per 32-bit word)
+bool gx_kq_deconv_h_eligible(int N, int K, int M, int Hb, int Wb);
+size_t gx_kq_deconv_h_pack_bytes(int K, int M, int nt);
+int gx_kq_deconv_fwd_h_launch(const float* in, const float* wp0, const float* wp1, const float* bias, float* out, int N,
+                              int K, int M, int Hb, int Wb, float* stats, int* stats_parts, hipStream_t s);
+// 32-bit word of element (m, k even, k + 1) of piece `piece` of tap t
+__host__ __device__ __forceinline__ size_t gx_kq_h_word(int m, int k, int t, int piece, int NT, int K) {
+    return ((((size_t)(m >> 6) * (K >> 4) + (k >> 4)) * NT + t) * 3 + piece) * 512 + (((k >> 3) & 1) * 64 + (m & 63)) * 4 + ((k & 7) >> 1);
+}
 
 // ---- second-generation weight gradients (gx_wgq.hip): LDS-DMA staging of both operands, grouped launches -------------
 bool gx_wgq_c3_eligible(int N, int Cin, int Cout, int H, int W);

@@ -545,6 +545,31 @@ __device__ __forceinline__ size_t pack_dest(int pack, int idx, int m, int k, int
     return pack >= 5 ? gx_wino_u_slot(m, k, t, Kpad) : (size_t)idx;
 }
 
+// packs 22 / 23 (= 2 / 3 for the bf16 matrix pipe, gx_kq.hip's QCfgDTH): every weight as three bf16 pieces, two
+// channels per 32-bit word -- the thread of an even k writes the three words of (k, k + 1), the odd one nothing
+__device__ __forceinline__ void pack_h_store(const float* __restrict__ w, float* __restrict__ wp, int pack, int Co, int Ci,
+                                             int m, int k, int t, int NT, int Kpad) {
+    if (k & 1) return;
+    unsigned wd[3];
+    float v[2] = {pack_weight_value(w, pack - 20, Co, Ci, m, k, t), pack_weight_value(w, pack - 20, Co, Ci, m, k + 1, t)};
+    unsigned short pc[2][3];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const __bf16 h = (__bf16)v[e];
+        const float r1 = v[e] - (float)h;
+        const __bf16 mm = (__bf16)r1;
+        const __bf16 l = (__bf16)(r1 - (float)mm);
+        pc[e][0] = __builtin_bit_cast(unsigned short, h);
+        pc[e][1] = __builtin_bit_cast(unsigned short, mm);
+        pc[e][2] = __builtin_bit_cast(unsigned short, l);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        wd[q] = (unsigned)pc[0][q] | ((unsigned)pc[1][q] << 16);
+        wp[gx_kq_h_word(m, k, t, q, NT, Kpad)] = __builtin_bit_cast(float, wd[q]);
+    }
+}
+
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int pack,
                                     int Co, int Ci, int NT, int Kpad, int Mpad) {
     const int total = NT * Kpad * Mpad;
@@ -552,6 +577,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
         const int m = idx % Mpad;
         const int k = (idx / Mpad) % Kpad;
         const int t = idx / (Mpad * Kpad);
+        if (pack >= 20) { pack_h_store(w, wp, pack, Co, Ci, m, k, t, NT, Kpad); continue; }
         wp[pack_dest(pack, idx, m, k, t, Kpad, NT)] = pack_weight_value(w, pack, Co, Ci, m, k, t);
     }
 }
@@ -1326,6 +1352,7 @@ __global__ void pack_weights_batch_kernel(const PackEntry* __restrict__ entries,
         const int m = idx % e.Mpad;
         const int k = (idx / e.Mpad) % e.Kpad;
         const int t = idx / (e.Mpad * e.Kpad);
+        if (e.pack >= 20) { pack_h_store(e.w, e.wp, e.pack, e.Co, e.Ci, m, k, t, e.NT, e.Kpad); continue; }
         e.wp[pack_dest(e.pack, idx, m, k, t, e.Kpad, e.NT)] = pack_weight_value(e.w, e.pack, e.Co, e.Ci, m, k, t);
     }
 }
@@ -1344,7 +1371,8 @@ int launch_pack(const float* w, float* wp, int pack, int Co, int Ci, int NT, int
         for (const PackEntry& e : c.entries) found = found || (e.w == w && e.pack == pack && e.Co == Co && e.Ci == Ci);
         if (!found) {
             PackEntry e{w, nullptr, pack, Co, Ci, NT, Kpad, Mpad, 0};
-            if (hipMalloc((void**)&e.wp, (size_t)NT * Kpad * Mpad * sizeof(float)) != hipSuccess) {
+            const size_t pbytes = pack >= 20 ? gx_kq_deconv_h_pack_bytes(Kpad, Co, NT) : (size_t)NT * Kpad * Mpad * sizeof(float);
+            if (hipMalloc((void**)&e.wp, pbytes) != hipSuccess) {
                 gx_set_error("weight cache: hipMalloc failed");
                 return GX_ELAUNCH;
             }
@@ -1989,6 +2017,9 @@ static size_t deconv_pack_floats(int Cin, int Cout) {
     // fwd: two row-parity packs (15 + 10 taps, k=Cin, m=Cout); dgrad: 25 taps (k=Cout, m=Cin)
     size_t f = (size_t)25 * gx_round_up(Cin, 8) * gx_round_up(Cout, 64);
     size_t d = (size_t)25 * gx_round_up(Cout, 8) * gx_round_up(Cin, 64);
+    // (bf16-pipe forward, packs 22 / 23: three bf16 pieces per weight = 1.5 x, + the slack of whole-phase copies)
+    const size_t h = (gx_kq_deconv_h_pack_bytes(gx_round_up(Cin, 16), Cout, 15) + gx_kq_deconv_h_pack_bytes(gx_round_up(Cin, 16), Cout, 10)) / 4;
+    f = f > h ? f : h;
     return f > d ? f : d;
 }
 
@@ -2070,6 +2101,17 @@ static int deconv_fwd_impl(const float* x, const float* w, const float* bias, fl
     float* part = wp0 + deconv_pack_floats(Cin, Cout);
     const float *wpu0, *wpu1;
     if (stats_parts_out) *stats_parts_out = 0;
+    if (gx_kq_deconv_h_eligible(N, Cin, Cout, Hin, Win)) {     // ... on the bf16 matrix pipe (fp32 products from bf16 pieces)
+        float* wh1 = wp0 + gx_kq_deconv_h_pack_bytes(Cin, Cout, 15) / 4;
+        rc = launch_pack(w, wp0, 22, Cout, Cin, 15, Cin, Mpad, s, &wpu0);
+        if (rc) return rc;
+        rc = launch_pack(w, wh1, 23, Cout, Cin, 10, Cin, Mpad, s, &wpu1);
+        if (rc) return rc;
+        rc = gx_kq_deconv_fwd_h_launch(x, wpu0, wpu1, bias, y, N, Cin, Cout, Hin, Win, stats, stats_parts_out, s);
+        if (rc) return rc;
+        if (parts_out) { *parts_out = y; *nsplit_out = 1; }
+        return GX_OK;
+    }
     if (gx_kq_deconv_eligible(N, Cin, Cout, Hin, Win, 2)) {   // chip-filling layers: 16-byte operand reads (gx_kq.hip)
         rc = launch_pack(w, wp0, 12, Cout, Cin, 15, Kpad, Mpad, s, &wpu0);
         if (rc) return rc;

@@ -35,7 +35,7 @@
 
 namespace {
 
-enum { Q_C3 = 0, Q_DT0 = 1, Q_DT1 = 2, Q_DG = 3 };
+enum { Q_C3 = 0, Q_DT0 = 1, Q_DT1 = 2, Q_DG = 3, Q_DT0H = 4, Q_DT1H = 5 };     // ..H: on the bf16 matrix pipe (q_body's B16 path)
 
 template <int MODE> struct QCfg;
 template <> struct QCfg<Q_C3> {
@@ -79,6 +79,63 @@ template <> struct QCfg<Q_DG> {
     __host__ __device__ static constexpr int co(int p, int i) { return i % nkw(p); }
     __host__ __device__ static constexpr int cls(int, int) { return 0; }
 };
+
+// The transposed conv forward on the bf16 matrix pipe (finding 13): every fp32 product from six bf16
+// piece products, v_mfma_f32_32x32x16_bf16 (k = 16 channels: lane half h supplies the 8 consecutive channels of octet h).
+// A chunk is 16 channels; the input tile is split into its three bf16 planes ONCE, by the staging
+//     input   [piece 3][octet 2][halo position][8 channels (bf16)]      single-buffered (the next chunk waits in registers)
+//     weights [tap][piece 3][octet 2][64 output channels][8 channels]   pre-split by the pack kernel (packs 22 / 23)
+// so the tap loop has no VALU work: 12 ds_read_b128 per 24 MFMAs of 32 cycles.  Phases of <= 3 taps (a kernel row kh =
+// taps {0,1,2} | {3,4}) keep input + double-buffered weights at 72 KB: two workgroups per CU as before.
+template <int PA> struct QCfgDTH {
+    static constexpr int NKH = PA ? 2 : 3;
+    static constexpr int NPH = 2 * NKH, NT = 5 * NKH, MAXT = 3, NCLS = 2;
+    static constexpr bool PLANE_PER_PHASE = false;
+    __host__ __device__ static constexpr int ntaps(int ph) { return (ph & 1) ? 2 : 3; }
+    __host__ __device__ static constexpr int tbase(int ph) { return 5 * (ph >> 1) + 3 * (ph & 1); }
+    __host__ __device__ static constexpr int ro(int ph, int) { return 2 - (ph >> 1); }
+    __host__ __device__ static constexpr int co(int ph, int j) { return 2 - (3 * (ph & 1) + j) / 2; }
+    __host__ __device__ static constexpr int cls(int ph, int j) { return (3 * (ph & 1) + j) & 1; }
+};
+template <> struct QCfg<Q_DT0H> : QCfgDTH<0> {};
+template <> struct QCfg<Q_DT1H> : QCfgDTH<1> {};
+typedef __bf16 q_bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int QH_TAP_BYTES = 3 * 2 * 64 * 16;          // one tap of one 16-channel chunk: 6144 B
+
+// one phase on the bf16 pipe: operands of (tap, mi / nj, piece) straight out of LDS
+template <int MODE, int PH, int NCLS, int MI>
+__device__ __forceinline__ void q_phase_h(f32x16 (&acc)[NCLS][MI][2], const char* ib, const char* wb, const int plane_bytes,
+                                          const int a_lane_b, const int b_lane0_b, const int b_lane1_b, const int HS16) {
+    using C = QCfg<MODE>;
+    constexpr int nt = C::ntaps(PH);
+#pragma unroll
+    for (int i = 0; i < nt; ++i) {
+        const int toff = (C::ro(PH, i) * HS16 + C::co(PH, i) * 16);
+        q_bf16x8 a[MI][3], b[2][3];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                a[mi][pc] = *reinterpret_cast<const q_bf16x8*>(wb + i * QH_TAP_BYTES + pc * 2048 + a_lane_b + mi * 512);
+            b[0][pc] = *reinterpret_cast<const q_bf16x8*>(ib + pc * plane_bytes + b_lane0_b + toff);
+            b[1][pc] = *reinterpret_cast<const q_bf16x8*>(ib + pc * plane_bytes + b_lane1_b + toff);
+        }
+        const int cl = C::cls(PH, i);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj) {
+                f32x16 c = acc[cl][mi][nj];      // pieces: 0 hi, 1 mid, 2 lo; small terms first
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[nj][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][2], b[nj][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[nj][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[nj][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[nj][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[nj][0], c, 0, 0, 0);
+                acc[cl][mi][nj] = c;
+            }
+    }
+}
 
 struct QGeom {
     int N, K, M;          // images, reduction channels (a multiple of 8), output channels
@@ -151,6 +208,7 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
                                        const float* __restrict__ bias, float* __restrict__ out, const QGeom& g,
                                        float* lds, const int bx, const int by, const int par_a, const int mh = 0) {
     using C = QCfg<MODE>;
+    constexpr bool B16 = MODE >= Q_DT0H;               // bf16 matrix pipe, 16-channel chunks (QCfgDTH)
     constexpr int NPH = C::NPH, NT = C::NT, MAXT = C::MAXT, NCLS = C::NCLS;
     constexpr int NW = (MAXT * 128 + 255) / 256;       // float4 weight loads per thread per phase
     constexpr int WSLOT = NW * 1024;                   // floats per weight buffer (whole float4-per-thread rounds: the
@@ -177,7 +235,9 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(in), 0, (int)((unsigned)g.N * (unsigned)g.K * (unsigned)HiWi * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(wp), 0, (int)((unsigned)NT * (unsigned)g.K * gridDim.y * 256u), 0x00020000);
+        const_cast<float*>(wp), 0,
+        B16 ? (int)((unsigned)NT * (unsigned)(g.K / 16) * gridDim.y * (unsigned)QH_TAP_BYTES)
+            : (int)((unsigned)NT * (unsigned)g.K * gridDim.y * 256u), 0x00020000);
     int voff[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -192,11 +252,112 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
         if (MODE == Q_DG) { row = 2 * (R0 + i) - 2; col = 2 * (C0 + j) - 2; }
         else { row = R0 - 1 + i; col = C0 - 1 + j; }
         ok = ok && img0 + gi < g.N && row >= 0 && row < g.Hi && col >= 0 && col < g.Wi;
-        voff[q] = ok ? (((img0 + gi) * g.K + quad * 4) * HiWi + row * g.Wi + col) * 4 : (int)0x80000000;
+        voff[q] = ok ? (((img0 + gi) * g.K + quad * (B16 ? 8 : 4)) * HiWi + row * g.Wi + col) * 4 : (int)0x80000000;
     }
     const int w_voff = tid * 16;
     const int w_sbase = by * g.nchunks * (NT * 2048);
 
+    f32x16 acc[NCLS][MI][2];
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[c][i][j][e] = 0.f;
+    if constexpr (B16) {
+        // ---- the bf16-pipe pipeline: chunks of 16 channels, phases of <= 3 taps
+        constexpr int NWH = (MAXT * (QH_TAP_BYTES / 16) + 255) / 256;      // 16-byte weight pieces per thread per phase
+        constexpr int WSLOTB = NWH * 256 * 16;                             // bytes per weight buffer
+        const int plane_bytes = NQ * 256 * 16;                             // bytes per input piece plane
+        char* const ibuf = reinterpret_cast<char*>(lds);
+        char* const wbufb = ibuf + 3 * plane_bytes;
+        const int quad_l = lane >> 5;
+        const int a_lane_b = (quad_l * 64 + (lane & 31)) * 16 + mh * 512;   // + mi * 512 + piece * 2048 + tap * 6144
+        int b_lane_b[2];
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) {
+            const int p = wave * 64 + nj * 32 + (lane & 31);
+            const int c = p & (TW - 1);
+            const int r = (p >> g.lTW) & (TH - 1);
+            const int gi = p >> (g.lTW + g.lTH);
+            b_lane_b[nj] = (quad_l * CHS + (gi * (TH + 2) + r) * HS + c) * 16;
+        }
+        const int HS16 = HS * 16;
+        const int nsc = g.K / 16;
+        const int w_sbase = by * nsc * (NT * QH_TAP_BYTES);
+        float xin[NQ][8];
+        f32x4 wreg[NWH];
+#define GX_QH_LOAD_IN(sc_)                                                                             \
+        {                                                                                              \
+            _Pragma("unroll") for (int q = 0; q < NQ; ++q)                                             \
+                _Pragma("unroll") for (int e = 0; e < 8; ++e)                                          \
+                    xin[q][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, voff[q], ((sc_) * 16 + e) * HiWi * 4, 0)); \
+        }
+#define GX_QH_STORE_IN()                                                                               \
+        {                                                                                              \
+            _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                           \
+                q_bf16x8 ph_, pm_, pl_;                                                                \
+                _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                        \
+                    const __bf16 h_ = (__bf16)xin[q][e];                                               \
+                    const float r1_ = xin[q][e] - (float)h_;                                           \
+                    const __bf16 m_ = (__bf16)r1_;                                                     \
+                    ph_[e] = h_; pm_[e] = m_; pl_[e] = (__bf16)(r1_ - (float)m_);                      \
+                }                                                                                      \
+                char* d_ = ibuf + (tid + q * 256) * 16;                                                \
+                *reinterpret_cast<q_bf16x8*>(d_) = ph_;                                                \
+                *reinterpret_cast<q_bf16x8*>(d_ + plane_bytes) = pm_;                                  \
+                *reinterpret_cast<q_bf16x8*>(d_ + 2 * plane_bytes) = pl_;                              \
+            }                                                                                          \
+        }
+#define GX_QH_LOAD_W(sc_, ph_)                                                                         \
+        {                                                                                              \
+            const int so_ = w_sbase + ((sc_) * NT + C::tbase(ph_)) * QH_TAP_BYTES;                     \
+            _Pragma("unroll") for (int i = 0; i < NWH; ++i)                                            \
+                wreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (tid + i * 256) * 16, so_, 0)); \
+        }
+#define GX_QH_STORE_W(dst_)                                                                            \
+        {                                                                                              \
+            _Pragma("unroll") for (int i = 0; i < NWH; ++i)                                            \
+                *reinterpret_cast<f32x4*>((dst_) + (tid + i * 256) * 16) = wreg[i];                    \
+        }
+        GX_QH_LOAD_IN(0)
+        GX_QH_LOAD_W(0, 0)
+        GX_QH_STORE_IN()
+        GX_QH_STORE_W(wbufb)
+        int s = 0;
+        for (int sc = 0; sc < nsc; ++sc) {
+            const bool last_chunk = sc + 1 == nsc;
+#define GX_QH_STAGE(PH_)                                                                                         \
+            {                                                                                                    \
+                constexpr int NXT = (PH_) + 1 < NPH ? (PH_) + 1 : 0;                                             \
+                constexpr bool last_ph = (PH_) + 1 == NPH;                                                       \
+                const bool more = !last_ph || !last_chunk;                                                       \
+                __syncthreads();                                                                                 \
+                if (more) GX_QH_LOAD_W(last_ph ? sc + 1 : sc, NXT)                                               \
+                if (last_ph && !last_chunk) GX_QH_LOAD_IN(sc + 1)                                                \
+                q_phase_h<MODE, (PH_), NCLS, MI>(acc, ibuf, wbufb + (s & 1) * WSLOTB, plane_bytes, a_lane_b,     \
+                                                 b_lane_b[0], b_lane_b[1], HS16);                                \
+                if (more) GX_QH_STORE_W(wbufb + ((s + 1) & 1) * WSLOTB)                                          \
+                if (last_ph && !last_chunk) {     /* the input tile is single-buffered: everyone is done with it */ \
+                    __syncthreads();                                                                             \
+                    GX_QH_STORE_IN()                                                                             \
+                }                                                                                                \
+                ++s;                                                                                             \
+            }
+            GX_QH_STAGE(0)
+            GX_QH_STAGE(1)
+            GX_QH_STAGE(2)
+            GX_QH_STAGE(3)
+            if constexpr (NPH > 4) { GX_QH_STAGE(4) GX_QH_STAGE(5) }
+#undef GX_QH_STAGE
+        }
+#undef GX_QH_LOAD_IN
+#undef GX_QH_STORE_IN
+#undef GX_QH_LOAD_W
+#undef GX_QH_STORE_W
+    } else {
     // ---- per-lane operand addresses (float indices)
     const int quad_l = lane >> 5;
     const int a_lane = (quad_l * 64 + (lane & 31)) * 4 + mh * 128;   // + mi * 128 + tap * 512
@@ -211,15 +372,6 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
     }
     const int HS4 = HS * 4;
 
-    f32x16 acc[NCLS][MI][2];
-#pragma unroll
-    for (int c = 0; c < NCLS; ++c)
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[c][i][j][e] = 0.f;
 
     f32x4 xin[NQ];
     f32x4 wreg[NW];
@@ -296,6 +448,7 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
 #undef GX_Q_STORE_IN
 #undef GX_Q_LOAD_W
 #undef GX_Q_STORE_W
+    }
 
 #if GX_KQ_ABL
     const long long abl_c1 = __builtin_readcyclecounter();
@@ -475,6 +628,23 @@ kq_dt_kernel(const float* __restrict__ in, const float* __restrict__ wp0, const 
     }
 }
 
+// the same launch shape on the bf16 matrix pipe (Q_DT0H / Q_DT1H)
+template <int NQ, bool STATS>
+__global__ void __launch_bounds__(256, 2)
+kq_dth_kernel(const float* __restrict__ in, const float* __restrict__ wp0, const float* __restrict__ wp1,
+              const float* __restrict__ bias, float* __restrict__ out, QGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int bx = blockIdx.x;
+    if (bx < g.nfull) {
+        if (blockIdx.z) q_body<Q_DT1H, NQ, STATS, 2>(in, wp1, bias, out, g, lds, bx, blockIdx.y, 1);
+        else q_body<Q_DT0H, NQ, STATS, 2>(in, wp0, bias, out, g, lds, bx, blockIdx.y, 0);
+    } else {
+        const int tile = g.nfull + ((bx - g.nfull) >> 1), mh = (bx - g.nfull) & 1;
+        if (blockIdx.z) q_body<Q_DT1H, NQ, STATS, 1>(in, wp1, bias, out, g, lds, tile, blockIdx.y, 1, mh);
+        else q_body<Q_DT0H, NQ, STATS, 1>(in, wp0, bias, out, g, lds, tile, blockIdx.y, 0, mh);
+    }
+}
+
 int q_ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 // 256-pixel tile over the Hb x Wb base grid: widest power-of-two rows, then tallest, images fill the rest
@@ -597,6 +767,48 @@ int gx_kq_deconv_fwd_launch(const float* in, const float* wp0, const float* wp1,
     return GX_OK;
 }
 
+// ---- the transposed conv forward on the bf16 matrix pipe (packs 22 / 23: weights pre-split into bf16 pieces)
+static int g_kq_h = -1;     // 1 (default): eligible layers run there; GENESIS_KQ_BF16X6=0 / gx_kq_precision(0): fp32 pipe
+static bool kq_h_on() {
+    if (g_kq_h < 0) { const char* e = getenv("GENESIS_KQ_BF16X6"); g_kq_h = (e && e[0] == '0') ? 0 : 1; }
+    return g_kq_h != 0;
+}
+size_t gx_kq_deconv_h_pack_bytes(int K, int M, int nt) {     // one row parity's packed weights (+ slack: whole-phase copies)
+    return (size_t)gx_ceil_div(M, 64) * (K / 16) * nt * QH_TAP_BYTES + 16384;
+}
+bool gx_kq_deconv_h_eligible(int N, int K, int M, int Hb, int Wb) {
+    if (!kq_h_on() || K % 16 != 0 || !gx_kq_deconv_eligible(N, K, M, Hb, Wb, 2)) return false;
+    QGeom g; int nq; size_t lds;
+    return q_plan(N, K, M, Hb, Wb, Hb, Wb, 2 * Hb, 2 * Wb, &g, &nq, &lds, 5) && nq == 3;
+}
+int gx_kq_deconv_fwd_h_launch(const float* in, const float* wp0, const float* wp1, const float* bias, float* out, int N,
+                              int K, int M, int Hb, int Wb, float* stats, int* stats_parts, hipStream_t s) {
+    QGeom g; int nq; size_t lds;
+    if (!q_plan(N, K, M, Hb, Wb, Hb, Wb, 2 * Hb, 2 * Wb, &g, &nq, &lds, 5) || nq != 3 || K % 16 != 0) {
+        gx_set_error("kq deconv fwd (bf16 pipe): shape not eligible"); return GX_EINVAL;
+    }
+    constexpr int NWH = (3 * (QH_TAP_BYTES / 16) + 255) / 256;
+    lds = (size_t)3 * nq * 256 * 16 + (size_t)2 * NWH * 256 * 16;          // three input piece planes + two weight buffers
+    const bool st = stats && g.lG == 0 && (M % 8) == 0;
+    if (stats_parts) *stats_parts = 0;
+    if (st) {
+        g.stats = stats;
+        g.stats_parts = g.tiles_h * g.tiles_w * 2;
+        if (stats_parts) *stats_parts = g.stats_parts;
+    }
+    dim3 grid(1, gx_ceil_div(M, 64), 2);
+    g.nfull = q_split_tail(g.tiles_h * g.tiles_w * gx_ceil_div(N, 1 << g.lG), M, &grid.x);
+    {
+        GxProf pf(KID_TAPCONV_DT0, s, 2.0 * N * (double)M * K * 25 * Hb * Wb,
+                  4.0 * ((double)N * K * Hb * Wb + (double)N * M * 4 * Hb * Wb + 25.0 * K * M));
+        static bool a[2] = {false, false};
+        if (st) { q_set_attr(&kq_dth_kernel<3, true>, &a[0]); hipLaunchKernelGGL((kq_dth_kernel<3, true>), grid, dim3(256), lds, s, in, wp0, wp1, bias, out, g); }
+        else { q_set_attr(&kq_dth_kernel<3, false>, &a[1]); hipLaunchKernelGGL((kq_dth_kernel<3, false>), grid, dim3(256), lds, s, in, wp0, wp1, bias, out, g); }
+    }
+    GX_CHECK_LAUNCH("kq deconv fwd (bf16 pipe)");
+    return GX_OK;
+}
+
 // transposed conv data gradient: dy [N,K,2Hb,2Wb] -> dx [N,M,Hb,Wb]
 int gx_kq_deconv_dgrad_launch(const float* dy, const float* wp, float* dx, int N, int K, int M, int Hb, int Wb,
                               hipStream_t s) {
@@ -612,6 +824,12 @@ int gx_kq_deconv_dgrad_launch(const float* dy, const float* wp, float* dx, int N
         else { q_set_attr(&kq_kernel<Q_DG, 4>, &a4); hipLaunchKernelGGL((kq_kernel<Q_DG, 4>), grid, dim3(256), lds, s, dy, wp, nullptr, dx, g); }
     }
     GX_CHECK_LAUNCH("kq deconv dgrad");
+    return GX_OK;
+}
+
+extern "C" int gx_kq_precision(int mode) {
+    GX_CHECK_ARG(mode == 0 || mode == 1, "gx_kq_precision: mode must be 0 (fp32 matrix pipe) or 1 (bf16 pipe, six piece products)");
+    g_kq_h = mode;
     return GX_OK;
 }
 
