@@ -152,6 +152,9 @@ int gx_kq_deconv_dgrad_launch(const float* dy, const float* wp, float* dx, int N
 // [octet][64 output channels][8 channels] in bf16 (two per 32-bit word)
 bool gx_kq_deconv_h_eligible(int N, int K, int M, int Hb, int Wb);
 size_t gx_kq_deconv_h_pack_bytes(int K, int M, int nt);
+bool gx_kq_deconv_dgrad_h_eligible(int N, int K, int M, int Hb, int Wb);      // pack 24: all 25 taps, plane-major slots
+int gx_kq_deconv_dgrad_h_launch(const float* dy, const float* wp, float* dx, int N, int K, int M, int Hb, int Wb,
+                                hipStream_t s);
 int gx_kq_deconv_fwd_h_launch(const float* in, const float* wp0, const float* wp1, const float* bias, float* out, int N,
                               int K, int M, int Hb, int Wb, float* stats, int* stats_parts, hipStream_t s);
 // 32-bit word of element (m, k even, k + 1) of piece `piece` of tap t

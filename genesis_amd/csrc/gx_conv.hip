@@ -545,7 +545,7 @@ __device__ __forceinline__ size_t pack_dest(int pack, int idx, int m, int k, int
     return pack >= 5 ? gx_wino_u_slot(m, k, t, Kpad) : (size_t)idx;
 }
 
-// packs 22 / 23 (= 2 / 3 for the bf16 matrix pipe, gx_kq.hip's QCfgDTH): every weight as three bf16 pieces, two
+// packs 22 / 23 / 24 (= 2 / 3 / 4 for the bf16 matrix pipe, gx_kq.hip's QCfgDTH / Q_DGH): every weight as three bf16 pieces, two
 // channels per 32-bit word -- the thread of an even k writes the three words of (k, k + 1), the odd one nothing
 __device__ __forceinline__ void pack_h_store(const float* __restrict__ w, float* __restrict__ wp, int pack, int Co, int Ci,
                                              int m, int k, int t, int NT, int Kpad) {
@@ -566,7 +566,7 @@ __device__ __forceinline__ void pack_h_store(const float* __restrict__ w, float*
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         wd[q] = (unsigned)pc[0][q] | ((unsigned)pc[1][q] << 16);
-        wp[gx_kq_h_word(m, k, t, q, NT, Kpad)] = __builtin_bit_cast(float, wd[q]);
+        wp[gx_kq_h_word(m, k, pack == 24 ? gx_kq_dg_tap_slot(t) : t, q, NT, Kpad)] = __builtin_bit_cast(float, wd[q]);
     }
 }
 
@@ -1371,7 +1371,7 @@ int launch_pack(const float* w, float* wp, int pack, int Co, int Ci, int NT, int
         for (const PackEntry& e : c.entries) found = found || (e.w == w && e.pack == pack && e.Co == Co && e.Ci == Ci);
         if (!found) {
             PackEntry e{w, nullptr, pack, Co, Ci, NT, Kpad, Mpad, 0};
-            const size_t pbytes = pack >= 20 ? gx_kq_deconv_h_pack_bytes(Kpad, Co, NT) : (size_t)NT * Kpad * Mpad * sizeof(float);
+            const size_t pbytes = pack >= 20 ? gx_kq_deconv_h_pack_bytes(Kpad, Mpad, NT) : (size_t)NT * Kpad * Mpad * sizeof(float);
             if (hipMalloc((void**)&e.wp, pbytes) != hipSuccess) {
                 gx_set_error("weight cache: hipMalloc failed");
                 return GX_ELAUNCH;
@@ -2020,6 +2020,8 @@ static size_t deconv_pack_floats(int Cin, int Cout) {
     // (bf16-pipe forward, packs 22 / 23: three bf16 pieces per weight = 1.5 x, + the slack of whole-phase copies)
     const size_t h = (gx_kq_deconv_h_pack_bytes(gx_round_up(Cin, 16), Cout, 15) + gx_kq_deconv_h_pack_bytes(gx_round_up(Cin, 16), Cout, 10)) / 4;
     f = f > h ? f : h;
+    const size_t dh = gx_kq_deconv_h_pack_bytes(gx_round_up(Cout, 16), Cin, 25) / 4;
+    d = d > dh ? d : dh;
     return f > d ? f : d;
 }
 
@@ -2193,6 +2195,11 @@ int gx_deconv5x5s2_dgrad(const float* dy, const float* w, float* dx, int N, int 
     float* wp = (float*)ws;
     float* part = wp + deconv_pack_floats(Cin, Cout);
     const float* wpu;
+    if (gx_kq_deconv_dgrad_h_eligible(N, Cout, Cin_out, Hin, Win)) {     // on the bf16 matrix pipe
+        rc = launch_pack(w, wp, 24, Cout, Cin, 25, Cout, Mpad, s, &wpu);
+        if (rc) return rc;
+        return gx_kq_deconv_dgrad_h_launch(dy, wpu, dx, N, Cout, Cin_out, Hin, Win, s);
+    }
     if (gx_kq_deconv_eligible(N, Cout, Cin_out, Hin, Win, 1)) {
         rc = launch_pack(w, wp, 14, Cout, Cin, 25, Kpad, Mpad, s, &wpu);
         if (rc) return rc;

@@ -35,7 +35,7 @@
 
 namespace {
 
-enum { Q_C3 = 0, Q_DT0 = 1, Q_DT1 = 2, Q_DG = 3, Q_DT0H = 4, Q_DT1H = 5 };     // ..H: on the bf16 matrix pipe (q_body's B16 path)
+enum { Q_C3 = 0, Q_DT0 = 1, Q_DT1 = 2, Q_DG = 3, Q_DT0H = 4, Q_DT1H = 5, Q_DGH = 6 };     // ..H: on the bf16 matrix pipe (q_body's B16 path)
 
 template <int MODE> struct QCfg;
 template <> struct QCfg<Q_C3> {
@@ -96,6 +96,25 @@ template <int PA> struct QCfgDTH {
     __host__ __device__ static constexpr int ro(int ph, int) { return 2 - (ph >> 1); }
     __host__ __device__ static constexpr int co(int ph, int j) { return 2 - (3 * (ph & 1) + j) / 2; }
     __host__ __device__ static constexpr int cls(int ph, int j) { return (3 * (ph & 1) + j) & 1; }
+    __host__ __device__ static constexpr int plane(int) { return 0; }
+    // the phase after `ph` needs a new input tile (here: only the next chunk's first phase)
+    __host__ __device__ static constexpr bool newin(int ph) { return ph + 1 == NPH; }
+};
+// its data gradient there: parity plane p of dy (kh & 1, kw & 1), one phase per kernel row inside the plane
+// (3 + 3 + 2 + 2 rows of 3 / 2 / 3 / 2 taps; taps plane-major as in QCfg<Q_DG>); a new input tile per plane
+template <> struct QCfg<Q_DGH> {
+    static constexpr int NPH = 10, NT = 25, MAXT = 3, NCLS = 1;
+    static constexpr bool PLANE_PER_PHASE = true;
+    __host__ __device__ static constexpr int plane(int ph) { return ph < 3 ? 0 : (ph < 6 ? 1 : (ph < 8 ? 2 : 3)); }
+    __host__ __device__ static constexpr int prow(int ph) { return ph < 3 ? ph : (ph < 6 ? ph - 3 : (ph < 8 ? ph - 6 : ph - 8)); }
+    __host__ __device__ static constexpr int nkw(int p) { return 3 - (p & 1); }
+    __host__ __device__ static constexpr int pbase(int p) { return p == 0 ? 0 : (p == 1 ? 9 : (p == 2 ? 15 : 21)); }
+    __host__ __device__ static constexpr int ntaps(int ph) { return nkw(plane(ph)); }
+    __host__ __device__ static constexpr int tbase(int ph) { return pbase(plane(ph)) + prow(ph) * nkw(plane(ph)); }
+    __host__ __device__ static constexpr int ro(int ph, int) { return prow(ph); }
+    __host__ __device__ static constexpr int co(int, int i) { return i; }
+    __host__ __device__ static constexpr int cls(int, int) { return 0; }
+    __host__ __device__ static constexpr bool newin(int ph) { return ph + 1 == NPH || plane(ph + 1) != plane(ph); }
 };
 template <> struct QCfg<Q_DT0H> : QCfgDTH<0> {};
 template <> struct QCfg<Q_DT1H> : QCfgDTH<1> {};
@@ -249,7 +268,7 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
         const int i = rem / HS;
         const int j = rem - i * HS;
         int row, col;
-        if (MODE == Q_DG) { row = 2 * (R0 + i) - 2; col = 2 * (C0 + j) - 2; }
+        if (MODE == Q_DG || MODE == Q_DGH) { row = 2 * (R0 + i) - 2; col = 2 * (C0 + j) - 2; }
         else { row = R0 - 1 + i; col = C0 - 1 + j; }
         ok = ok && img0 + gi < g.N && row >= 0 && row < g.Hi && col >= 0 && col < g.Wi;
         voff[q] = ok ? (((img0 + gi) * g.K + quad * (B16 ? 8 : 4)) * HiWi + row * g.Wi + col) * 4 : (int)0x80000000;
@@ -289,11 +308,12 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
         const int w_sbase = by * nsc * (NT * QH_TAP_BYTES);
         float xin[NQ][8];
         f32x4 wreg[NWH];
-#define GX_QH_LOAD_IN(sc_)                                                                             \
+#define GX_QH_LOAD_IN(sc_, plane_)                                                                     \
         {                                                                                              \
+            const int po_ = MODE == Q_DGH ? (((plane_) >> 1) * g.Wi + ((plane_) & 1)) * 4 : 0;         \
             _Pragma("unroll") for (int q = 0; q < NQ; ++q)                                             \
                 _Pragma("unroll") for (int e = 0; e < 8; ++e)                                          \
-                    xin[q][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, voff[q], ((sc_) * 16 + e) * HiWi * 4, 0)); \
+                    xin[q][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, voff[q], ((sc_) * 16 + e) * HiWi * 4 + po_, 0)); \
         }
 #define GX_QH_STORE_IN()                                                                               \
         {                                                                                              \
@@ -322,7 +342,7 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
             _Pragma("unroll") for (int i = 0; i < NWH; ++i)                                            \
                 *reinterpret_cast<f32x4*>((dst_) + (tid + i * 256) * 16) = wreg[i];                    \
         }
-        GX_QH_LOAD_IN(0)
+        GX_QH_LOAD_IN(0, 0)
         GX_QH_LOAD_W(0, 0)
         GX_QH_STORE_IN()
         GX_QH_STORE_W(wbufb)
@@ -334,13 +354,14 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
                 constexpr int NXT = (PH_) + 1 < NPH ? (PH_) + 1 : 0;                                             \
                 constexpr bool last_ph = (PH_) + 1 == NPH;                                                       \
                 const bool more = !last_ph || !last_chunk;                                                       \
+                const bool in_next = C::newin(PH_) && more;      /* the next phase reads another input tile */   \
                 __syncthreads();                                                                                 \
                 if (more) GX_QH_LOAD_W(last_ph ? sc + 1 : sc, NXT)                                               \
-                if (last_ph && !last_chunk) GX_QH_LOAD_IN(sc + 1)                                                \
+                if (in_next) GX_QH_LOAD_IN(last_ph ? sc + 1 : sc, C::plane(NXT))                                 \
                 q_phase_h<MODE, (PH_), NCLS, MI>(acc, ibuf, wbufb + (s & 1) * WSLOTB, plane_bytes, a_lane_b,     \
                                                  b_lane_b[0], b_lane_b[1], HS16);                                \
                 if (more) GX_QH_STORE_W(wbufb + ((s + 1) & 1) * WSLOTB)                                          \
-                if (last_ph && !last_chunk) {     /* the input tile is single-buffered: everyone is done with it */ \
+                if (in_next) {                    /* the input tile is single-buffered: everyone is done with it */ \
                     __syncthreads();                                                                             \
                     GX_QH_STORE_IN()                                                                             \
                 }                                                                                                \
@@ -351,6 +372,7 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
             GX_QH_STAGE(2)
             GX_QH_STAGE(3)
             if constexpr (NPH > 4) { GX_QH_STAGE(4) GX_QH_STAGE(5) }
+            if constexpr (NPH > 6) { GX_QH_STAGE(6) GX_QH_STAGE(7) GX_QH_STAGE(8) GX_QH_STAGE(9) }
 #undef GX_QH_STAGE
         }
 #undef GX_QH_LOAD_IN
@@ -628,6 +650,15 @@ kq_dt_kernel(const float* __restrict__ in, const float* __restrict__ wp0, const 
     }
 }
 
+template <int NQ>
+__global__ void __launch_bounds__(256, 2)
+kq_dgh_kernel(const float* __restrict__ in, const float* __restrict__ wp, float* __restrict__ out, QGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int bx = blockIdx.x;
+    if (bx < g.nfull) q_body<Q_DGH, NQ, false, 2>(in, wp, nullptr, out, g, lds, bx, blockIdx.y, 0);
+    else q_body<Q_DGH, NQ, false, 1>(in, wp, nullptr, out, g, lds, g.nfull + ((bx - g.nfull) >> 1), blockIdx.y, 0, (bx - g.nfull) & 1);
+}
+
 // the same launch shape on the bf16 matrix pipe (Q_DT0H / Q_DT1H)
 template <int NQ, bool STATS>
 __global__ void __launch_bounds__(256, 2)
@@ -806,6 +837,32 @@ int gx_kq_deconv_fwd_h_launch(const float* in, const float* wp0, const float* wp
         else { q_set_attr(&kq_dth_kernel<3, false>, &a[1]); hipLaunchKernelGGL((kq_dth_kernel<3, false>), grid, dim3(256), lds, s, in, wp0, wp1, bias, out, g); }
     }
     GX_CHECK_LAUNCH("kq deconv fwd (bf16 pipe)");
+    return GX_OK;
+}
+
+bool gx_kq_deconv_dgrad_h_eligible(int N, int K, int M, int Hb, int Wb) {
+    if (!kq_h_on() || K % 16 != 0 || !gx_kq_deconv_eligible(N, K, M, Hb, Wb, 1)) return false;
+    QGeom g; int nq; size_t lds;
+    return q_plan(N, K, M, Hb, Wb, 2 * Hb, 2 * Wb, Hb, Wb, &g, &nq, &lds, 9) && nq == 3;
+}
+int gx_kq_deconv_dgrad_h_launch(const float* dy, const float* wp, float* dx, int N, int K, int M, int Hb, int Wb,
+                                hipStream_t s) {
+    QGeom g; int nq; size_t lds;
+    if (!q_plan(N, K, M, Hb, Wb, 2 * Hb, 2 * Wb, Hb, Wb, &g, &nq, &lds, 9) || nq != 3 || K % 16 != 0) {
+        gx_set_error("kq deconv dgrad (bf16 pipe): shape not eligible"); return GX_EINVAL;
+    }
+    constexpr int NWH = (3 * (QH_TAP_BYTES / 16) + 255) / 256;
+    lds = (size_t)3 * nq * 256 * 16 + (size_t)2 * NWH * 256 * 16;
+    dim3 grid(1, gx_ceil_div(M, 64));
+    g.nfull = q_split_tail(g.tiles_h * g.tiles_w * gx_ceil_div(N, 1 << g.lG), M, &grid.x);
+    {
+        GxProf pf(KID_TAPCONV_DG, s, 2.0 * N * (double)M * K * 25 * Hb * Wb,
+                  4.0 * ((double)N * K * 4 * Hb * Wb + (double)N * M * Hb * Wb + 25.0 * K * M));
+        static bool a3 = false;
+        q_set_attr(&kq_dgh_kernel<3>, &a3);
+        hipLaunchKernelGGL((kq_dgh_kernel<3>), grid, dim3(256), lds, s, dy, wp, dx, g);
+    }
+    GX_CHECK_LAUNCH("kq deconv dgrad (bf16 pipe)");
     return GX_OK;
 }
 

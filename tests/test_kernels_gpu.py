@@ -823,10 +823,11 @@ def test_deconv_epilogue_groupnorm_statistics(N, Cin, Cout, Hin):
 
 @pytest.mark.parametrize('N,Cin,Cout,Hin', [(56, 64, 64, 32), (70, 64, 64, 32), (224, 64, 64, 16), (60, 32, 64, 32),
                                             (56, 64, 40, 32), (52, 48, 72, 32)])
-def test_transposed_conv_forward_on_the_bf16_pipe_keeps_fp32_accuracy(N, Cin, Cout, Hin):
+def test_transposed_conv_on_the_bf16_pipe_keeps_fp32_accuracy(N, Cin, Cout, Hin):
     """gx_kq_precision: chip-filling transposed-conv forward layers run on the bf16 matrix pipe (fp32 products from six
     bf16 piece products; input split once by the staging, weights by the pack) or on the fp32 pipe.  Both against
-    conv_transpose2d in fp64, with bias, with and without the GroupNorm statistics in the epilogue; shapes with a split
+    conv_transpose2d (and its autograd: the data gradient) in fp64, with bias, with and without the GroupNorm statistics
+    in the epilogue; shapes with a split
     tail (70 images), two / three / four 16-channel chunks, ragged and multi-tile output channels."""
     from genesis_amd import _lib
     groups = 8
@@ -834,12 +835,18 @@ def test_transposed_conv_forward_on_the_bf16_pipe_keeps_fp32_accuracy(N, Cin, Co
     w = rnd(Cin, Cout, 5, 5, seed=72, scale=0.05)
     b = rnd(Cout, seed=73, scale=0.3)
     gamma, beta = 1 + 0.2 * rnd(Cout, seed=74), 0.1 * rnd(Cout, seed=75)
-    ref = F.conv_transpose2d(x.double(), w.double(), b.double(), 2, 2, 1)
+    xr = x.double().requires_grad_()
+    ref = F.conv_transpose2d(xr, w.double(), b.double(), 2, 2, 1)
+    dy = rnd(N, Cout, 2 * Hin, 2 * Hin, seed=76)
+    ref.backward(dy.double())
+    ref = ref.detach()
     rg = ref.view(N, groups, -1)
-    err, errm = {}, {}
+    err, errm, errd = {}, {}, {}
     try:
         for mode in (0, 1):
             _lib.call('gx_kq_precision', mode)
+            dx = hip.deconv5x5s2_dgrad(dy.to(DEV), w.to(DEV))
+            errd[mode] = float((dx.double().cpu() - xr.grad).norm() / xr.grad.norm())
             y = hip.deconv5x5s2_fwd(x.to(DEV), w.to(DEV), b.to(DEV))
             y2, mean, rstd = hip.deconv5x5s2_gn_stats_fwd(x.to(DEV), w.to(DEV), b.to(DEV), gamma.to(DEV), beta.to(DEV), groups, 1e-5)
             assert torch.equal(y, y2)
@@ -848,9 +855,10 @@ def test_transposed_conv_forward_on_the_bf16_pipe_keeps_fp32_accuracy(N, Cin, Co
             np.testing.assert_allclose(rstd.cpu().double().numpy(), (rg.var(2, unbiased=False) + 1e-5).rsqrt().flatten().numpy(), rtol=2e-5)
     finally:
         _lib.call('gx_kq_precision', 1)
-    print('deconv fwd N=%d %d->%d @%d: relative L2 error fp32 pipe %.3e, bf16 pipe %.3e; |mean error| %.2e / %.2e'
-          % (N, Cin, Cout, Hin, err[0], err[1], errm[0], errm[1]))
+    print('deconv fwd N=%d %d->%d @%d: relative L2 error fp32 pipe %.3e, bf16 pipe %.3e; |mean error| %.2e / %.2e; '
+          'data gradient %.3e / %.3e' % (N, Cin, Cout, Hin, err[0], err[1], errm[0], errm[1], errd[0], errd[1]))
     assert err[1] <= 1.5 * err[0] + 1e-7 and err[1] < 2e-5, err
+    assert errd[1] <= 1.5 * errd[0] + 1e-7 and errd[1] < 2e-5, errd
     assert errm[1] <= 2e-6, errm
 
 
