@@ -267,10 +267,11 @@ def main():
             'final_elbo': elbo,
         }
         if os.environ.get('GENESIS_WGQ_BF16X6', '1') != '0':
-            result['arithmetic'] = ('fp32 tensors and fp32 accumulation everywhere; conv / dense products on the fp32 matrix '
-                                    'pipe; weight-gradient products as six bf16 piece products per fp32 product on the bf16 '
-                                    'pipe (hi+mid+lo pieces hold all 24 mantissa bits: error vs fp64 as on the fp32 pipe; '
-                                    'GENESIS_WGQ_BF16X6=0 puts them back on the fp32 pipe)')
+            result['arithmetic'] = ('fp32 tensors and fp32 accumulation everywhere; the weight gradients and the chip-filling '
+                                    'transposed-conv forward / data-gradient layers form every fp32 product from six bf16 piece '
+                                    'products on the bf16 matrix pipe (hi+mid+lo pieces hold all 24 mantissa bits: error vs '
+                                    'fp64 as on the fp32 pipe, tests/test_kernels_gpu.py *_bf16_pipe_*); everything else on the '
+                                    'fp32 pipe; GENESIS_WGQ_BF16X6=0 GENESIS_KQ_BF16X6=0 put all of it back there')
         if dist.is_initialized():
             # what the step exchanged: ONE sum all-reduce of the flat fp32 bucket (gradients + err / kl + the fp64
             # gradient as float triples [+ averaged buffers]) over the ranks the process group actually has

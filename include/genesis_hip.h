@@ -66,6 +66,11 @@ int gx_wgq_policy(int mode);
  *      with fp64), at 6 x 32 instead of 8 x 64 matrix-pipe cycles per 16 contraction steps.  0: the fp32 pipe
  *      (v_mfma_f32_32x32x2_f32).  Environment: GENESIS_WGQ_BF16X6=0. */
 int gx_wgq_precision(int mode);
+/*      The same choice for the chip-filling transposed-conv forward / data-gradient layers (gx_kq.hip): 1 (default)
+ *      bf16 pipe -- the staging splits the input tile into its three bf16 planes, the pack kernel the weights; needs a
+ *      multiple of 16 reduction channels and a tile of <= 384 halo positions, other layers stay on the fp32 pipe --
+ *      0 fp32 pipe.  Environment: GENESIS_KQ_BF16X6=0. */
+int gx_kq_precision(int mode);
 size_t gx_conv3x3_wino_ws_bytes(int N, int Cin, int Cout, int H, int W);
 int gx_conv3x3_wino(const float* x, const float* w, float* y, int N, int Cin, int Cout, int H, int W, int mode,
                     void* ws, size_t ws_bytes, gx_stream_t stream);
