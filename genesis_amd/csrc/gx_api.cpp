@@ -15,12 +15,13 @@ void gx_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+#include <atomic>
 #include <mutex>
 
 namespace {
 thread_local int t_ctx = 0;
 std::mutex g_ctx_mutex;
-bool g_ctx_alive[kGxMaxCtx] = {true};      // context 0 always exists
+std::atomic<bool> g_ctx_alive[kGxMaxCtx] = {{true}};      // context 0 always exists (atomic: make_current reads it unlocked)
 GxCtxFlags g_ctx_flags[kGxMaxCtx] = {};
 struct CtxInit { CtxInit() { for (int i = 0; i < kGxMaxCtx; ++i) g_ctx_flags[i] = GxCtxFlags{false, false, -1, -1}; } } g_ctx_init;
 }  // namespace

@@ -113,11 +113,13 @@ prior_logp_fwd_kernel(const float* __restrict__ z, const float* __restrict__ lin
 // ancestral sample of one slot from the AR prior (models/genesisv2_config.py:235-246): lin [B,2D] = prior_linear(h),
 // z = tanh(lin[:D]) + (sigmoid(lin[D:] + 4) + 1e-4) * eps -- the same mean / scale arithmetic as the log-density above
 __global__ void __launch_bounds__(256)
-prior_sample_kernel(const float* __restrict__ lin, const float* __restrict__ eps, int B, int D, float* __restrict__ z) {
+prior_sample_kernel(const float* __restrict__ lin, const float* __restrict__ eps, int B, int D, int tanh_mu,
+                    float* __restrict__ z) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * D) return;
     const int b = i / D, d = i - b * D;
-    const float mu = tanhf(lin[(size_t)b * 2 * D + d]);
+    const float raw = lin[(size_t)b * 2 * D + d];
+    const float mu = tanh_mu ? tanhf(raw) : raw;        // Genesis.sample's mask rollout keeps the raw mean (genesis_config.py:358)
     const float sg = sigmoid_t(lin[(size_t)b * 2 * D + D + d] + 4.f) + 1e-4f;
     z[i] = mu + sg * eps[i];
 }
@@ -328,11 +330,17 @@ int gx_latent_prior_logp_fwd(const float* z, const float* lin, const float* log_
 }
 
 int gx_latent_prior_sample(const float* lin, const float* eps, int B, int D, float* z, gx_stream_t stream) {
+    return gx_latent_prior_sample_ex(lin, eps, B, D, 1, z, stream);
+}
+
+int gx_latent_prior_sample_ex(const float* lin, const float* eps, int B, int D, int tanh_mu, float* z,
+                              gx_stream_t stream) {
     GX_CHECK_ARG(lin && eps && z && B > 0 && D > 0, "gx_latent_prior_sample: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     {
         GxProf pf(KID_LATENT, s, 0.0, 16.0 * B * D);
-        hipLaunchKernelGGL(prior_sample_kernel, dim3(gx_ceil_div(B * D, 256)), dim3(256), 0, s, lin, eps, B, D, z);
+        hipLaunchKernelGGL(prior_sample_kernel, dim3(gx_ceil_div(B * D, 256)), dim3(256), 0, s, lin, eps, B, D, tanh_mu,
+                           z);
     }
     GX_CHECK_LAUNCH("gx_latent_prior_sample");
     return GX_OK;

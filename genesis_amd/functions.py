@@ -54,11 +54,26 @@ def ctx_bound(cls):
         return fwd(ctx, *args)
 
     def backward(ctx, *grads):
+        prev = _lib.current_ctx()
         _lib.make_current(ctx._gx_ctx)
-        return bwd(ctx, *grads)
+        try:
+            return bwd(ctx, *grads)
+        finally:
+            if prev != ctx._gx_ctx:
+                try:
+                    _lib.make_current(prev)
+                except Exception:       # the previous context of this (autograd) thread was destroyed meanwhile
+                    pass
     cls.forward = staticmethod(forward)
     cls.backward = staticmethod(backward)
     return cls
+
+
+def drop_ctx_state(ctx_id):
+    """TrainStep.close(): forget the per-context Python state of a library context that is being destroyed (its id is
+    recycled by gx_ctx_create; a new loop must not inherit keep-alive tensors, a side stream or flags)."""
+    _STEPS.pop(ctx_id, None)
+    hip._DEFER.pop(ctx_id, None)
 
 
 def begin_direct_grads():

@@ -231,6 +231,90 @@ class Genesis(nn.Module):
                              psigma_k=[torch.ones_like(mu_k[0])] + list(sig_p.unbind(0)))
         return recon, losses, stats, att_stats, comp_stats
 
+    @torch.no_grad()
+    def sample(self, batch_size, K_steps=None, eps_m=None, eps_c=None):
+        """models/genesis_config.py:345-425: ancestral rollout of the mask latents through the AR prior (prior_lstm ->
+        prior_linear -> N(raw mean, to_prior_sigma): the reference's sample() does NOT squash the mean here, unlike its
+        mask_latent_loss), masks from the attention decoder + stick-breaking (LatentSBP.masks_from_zm_k,
+        modules/attention.py:53-75; last mask = remaining scope), component latents from prior_mlp(zm) (tanh mean) or
+        N(0, 1), decoded by the component decoder.  Runs on the training path's kernels (gx_linear_fwd,
+        gx_lstm_step_fwd, gx_latent_prior_sample_ex, gx_sbp_scan_fwd, the BroadcastDecoder / gated-deconv stack,
+        gx_mixture_w_fwd for sigmoid + mask-weighted sum).  `eps_m` [K,B,ldim] / `eps_c` [K,B,comp_ldim] inject the
+        standard-normal draws in the reference's order (parity tests); default torch.randn."""
+        from genesis_amd import hip_ops as hip
+        K = self.K_steps
+        K_arg = K if K_steps is None else K_steps
+        if K_arg != K:
+            # the reference rolls the masks out over self.att_steps and asserts len(zm_k) == self.K_steps
+            # (genesis_config.py:351,379-380); another K_steps only ever reaches its N(0,1) component branch, whose
+            # K_steps latents are then chunked into self.K_steps pieces and trip the next assertion
+            raise AssertionError('Genesis.sample: K_steps must equal the model\'s K_steps (%d)' % K)
+        S, B = self.img_size, batch_size
+        dev = self.prior_linear.weight.device
+        if eps_m is None:
+            eps_m = torch.randn(K, B, self.ldim, device=dev)
+        eps_m = eps_m.to(dev).contiguous()
+        assert eps_m.shape == (K, B, self.ldim)
+        # --- mask latents
+        zm_k = [eps_m[0]]
+        L = self.prior_lstm
+        H = L.weight_hh_l0.shape[1]
+        h_prev = c_prev = None
+        for k in range(1, K):
+            gx = hip.linear_fwd(zm_k[-1].contiguous(), L.weight_ih_l0, L.bias_ih_l0)
+            act = torch.empty(B, 4 * H, device=dev)
+            c = torch.empty(B, H, device=dev)
+            h = torch.empty(B, H, device=dev)
+            hip.lstm_step_fwd(gx, h_prev, c_prev, L.weight_hh_l0, L.bias_hh_l0, act, c, h)
+            lin = hip.linear_fwd(h, self.prior_linear.weight, self.prior_linear.bias)
+            zm_k.append(hip.latent_prior_sample(lin, eps_m[k], tanh_mu=False))
+            h_prev, c_prev = h, c
+        zm = torch.stack(zm_k, 0)                                                     # [K,B,ldim]
+        # --- masks: decode all K latents as one batch (the reference decodes slot by slot, modules/attention.py:60-61:
+        # the same numbers unless a training-mode BatchNorm takes its statistics over the batch it is given -- then
+        # slot by slot here too), K stick-breaking steps in one launch
+        core = self.att_process.core
+        if self.training and core.dec_norm == 'bn':
+            logits = torch.stack([core.decode(z_) for z_ in zm_k], 0).view(K, B, 1, S, S).contiguous()
+        else:
+            logits = core.decode(zm.flatten(0, 1)).view(K, B, 1, S, S).contiguous()
+        log_m, log_s = hip.sbp_scan_fwd(logits, None, True)
+        log_m_k = list(log_m.unbind(0))
+        log_s_k = [torch.zeros(B, 1, S, S, device=dev)] + list(log_s.unbind(0))
+        # --- component appearances
+        if self.two_stage:
+            Lc = self.comp_vae.ldim
+            if eps_c is None:
+                eps_c = torch.randn(K, B, Lc, device=dev)
+            eps_c = eps_c.to(dev).contiguous()
+            assert eps_c.shape == (K, B, Lc)
+            if self.comp_prior:
+                pm_ = self.prior_mlp
+                o = F.elu(hip.linear_fwd(zm.flatten(0, 1).contiguous(), pm_[0].weight, pm_[0].bias))
+                o = F.elu(hip.linear_fwd(o, pm_[2].weight, pm_[2].bias))
+                o = hip.linear_fwd(o, pm_[4].weight, pm_[4].bias)                    # [K*B, 2*Lc]
+                zc = hip.latent_prior_sample(o, eps_c.view(K * B, Lc), tanh_mu=True)
+            else:
+                zc = eps_c.view(K * B, Lc)
+            dm, z_dec = self.comp_vae.decoder_module, zc
+        else:
+            dm, z_dec = self.decoder, zm.flatten(0, 1)
+        if self.two_stage and self.comp_symmetric:
+            hd = gc_decoder_forward(dm[1], z_dec, SYM_STRIDES, self.training)
+            dec = fn.Conv1x1Fn.apply(hd, dm[2].weight, dm[2].bias)
+        else:
+            dec = fn.BroadcastDecoderFn.apply(z_dec, self._canvas_coords(dev), 'elu', None, *dm.flat_params())
+        # sigmoid (pixel_bound) + sum_k exp(log_m_k) * x_k on the mixture kernel (its likelihood output is unused)
+        x0 = torch.zeros(B, 3, S, S, device=dev)
+        _, generated_image, x_r = hip.mixture_w_fwd(x0, dec.contiguous(), log_m.contiguous(), K, self._std12[0],
+                                                    self._std12[1], bool(self.pixel_bound))
+        x_k = list(x_r.unbind(0))
+        stats = AttrDict(x_k=x_k, log_m_k=log_m_k, log_s_k=log_s_k, mx_k=[x * m.exp() for x, m in zip(x_k, log_m_k)],
+                         zm_k=zm_k)
+        if self.two_stage:
+            stats['zc_k'] = list(zc.view(K, B, -1).unbind(0))
+        return generated_image, stats
+
     def get_features(self, image_batch):
         """genesis_config.py:427-436."""
         with torch.no_grad():

@@ -48,11 +48,8 @@ flags.DEFINE_float('pixel_std1', 0.7, 'StdDev of reconstructed pixels.')
 flags.DEFINE_float('pixel_std2', 0.7, 'StdDev of reconstructed pixels.')
 
 
-import os as _os
-
 # The AR prior's LSTM runs on the fused HIP cell kernels (functions.LSTMFn: dense input projection + one
-# recurrent-GEMM/cell launch per step).  GENESIS_FUSED_LSTM=0 selects an explicit torch cell loop (debugging aid).
-USE_FUSED_LSTM = _os.environ.get('GENESIS_FUSED_LSTM', '1') == '1'   # 0: unrolled torch ops (debug)
+# recurrent-GEMM/cell launch per step); there is no torch fallback.
 
 
 def load(cfg):
@@ -244,29 +241,14 @@ class GenesisV2(nn.Module):
     def _prior_hidden(self, z_kbd):
         """LSTM of the AR prior from the zero state over z_1..z_{K-1} (models/genesis_config.py:297-307)."""
         K, B, D = z_kbd.shape
-        if USE_FUSED_LSTM:
-            L = self.prior_lstm
-            return fn.LSTMFn.apply(z_kbd[:-1], L.weight_ih_l0, L.weight_hh_l0, L.bias_ih_l0, L.bias_hh_l0)
-        w_ih, w_hh = self.prior_lstm.weight_ih_l0, self.prior_lstm.weight_hh_l0
-        b_ih, b_hh = self.prior_lstm.bias_ih_l0, self.prior_lstm.bias_hh_l0
-        H = w_hh.shape[1]
-        h = z_kbd.new_zeros(B, H)
-        c = z_kbd.new_zeros(B, H)
-        gx = F.linear(z_kbd[:-1], w_ih, b_ih)  # [K-1,B,4H]
-        outs = []
-        for t in range(K - 1):
-            gates = gx[t] + F.linear(h, w_hh, b_hh)
-            i, f, g, o = gates.chunk(4, 1)
-            c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
-            h = torch.sigmoid(o) * torch.tanh(c)
-            outs.append(h)
-        return torch.stack(outs, 0)
+        L = self.prior_lstm
+        return fn.LSTMFn.apply(z_kbd[:-1], L.weight_ih_l0, L.weight_hh_l0, L.bias_ih_l0, L.bias_hh_l0)
 
     def _component_kl(self, z, log_q):
         """[K,B]: log q(z_k|x) - log p(z_k|z_<k) per slot (Genesis.mask_latent_loss, models/genesis_config.py:288-343)."""
         lin = None
         if self.prior_lstm is not None:
-            if USE_FUSED_LSTM and z.shape[0] > 1:
+            if z.shape[0] > 1:
                 L, P = self.prior_lstm, self.prior_linear
                 return fn.ARPriorKLFn.apply(z, log_q, L.weight_ih_l0, L.weight_hh_l0, L.bias_ih_l0, L.bias_hh_l0,
                                             P.weight, P.bias)

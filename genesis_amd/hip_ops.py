@@ -654,13 +654,14 @@ def latent_prior_logp_fwd(z, lin, log_q=None):
     return out
 
 
-def latent_prior_sample(lin, eps):
-    """lin [B,2D] (prior_linear output), eps [B,D] -> z [B,D] ~ N(tanh(lin[:D]), to_prior_sigma(lin[D:]))."""
+def latent_prior_sample(lin, eps, tanh_mu=True):
+    """lin [B,2D] (prior_linear output), eps [B,D] -> z [B,D] ~ N(tanh(lin[:D]), to_prior_sigma(lin[D:]));
+    tanh_mu=False keeps the raw mean (Genesis.sample's mask rollout, models/genesis_config.py:358)."""
     _chk(lin, 'prior_sample.lin'); _chk(eps, 'prior_sample.eps')
     B, D = eps.shape
     assert lin.shape == (B, 2 * D)
     z = torch.empty(B, D, dtype=F32, device=eps.device)
-    _lib.call('gx_latent_prior_sample', _p(lin), _p(eps), B, D, _p(z), _stream())
+    _lib.call('gx_latent_prior_sample_ex', _p(lin), _p(eps), B, D, int(bool(tanh_mu)), _p(z), _stream())
     return z
 
 

@@ -193,11 +193,13 @@ class MONet(nn.Module):
             return torch.cat(comp_stats.z_k, dim=1)
 
     @torch.no_grad()
-    def sample(self, batch_size, K_steps=None):
-        """models/monet_config.py:172-198."""
+    def sample(self, batch_size, K_steps=None, eps=None):
+        """models/monet_config.py:172-198; `eps` [B*K, ldim] injects the reference's one standard-normal draw (parity
+        tests), default torch.randn."""
         K = self.K_steps if K_steps is None else K_steps
         dev = self.std.device
-        z = torch.randn(batch_size * K, self.comp_vae.ldim, device=dev)
+        z = torch.randn(batch_size * K, self.comp_vae.ldim, device=dev) if eps is None else eps.to(dev).contiguous()
+        assert z.shape == (batch_size * K, self.comp_vae.ldim)
         dec = self._decode(z)
         x0 = torch.zeros(batch_size, 3, self.img_size, self.img_size, device=dev)
         _, gen_image, x_r, log_m_r = hip.mixture_fwd(x0, dec.contiguous(), K, 0.7, bool(self.pixel_bound))

@@ -8,7 +8,7 @@ import torch.nn.functional as F
 
 from . import hip_ops as hip
 from . import functions as fn
-from .functions import _gout, _ret
+from .functions import _gout, _ret, ctx_bound
 
 
 def vae_geometry(img_size):
@@ -144,6 +144,7 @@ def gc_decoder_forward(units, z, strides, training):
 
 
 # ------------------------------------------------------------------ autograd Functions
+@ctx_bound
 class DirectConvFn(torch.autograd.Function):
     """Bias-free Conv2d / ConvTranspose2d through the generic direct kernels.  A ConvTranspose2d (weight
     [Cin, Cout, k, k]) is the data-gradient of the Conv2d with the same weight tensor, and vice versa."""
@@ -179,6 +180,7 @@ class DirectConvFn(torch.autograd.Function):
         return dx, _ret(ow, dw), None, None, None, None
 
 
+@ctx_bound
 class GatedNormFn(torch.autograd.Function):
     """returns (out [N,C,H,W], stats); stats ({mean, rstd} per unit) is non-differentiable."""
 

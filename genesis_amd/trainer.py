@@ -137,14 +137,23 @@ class TrainStep(object):
                     _lib.call('gx_weight_cache_release')
             _lib.make_current(self._prev_ctx)
 
+    def close(self):
+        """Releases the library context (at most 31 live ones), the packed-weight cache and the per-context Python
+        state.  Idempotent; __del__ calls it, but a loop that builds many TrainSteps should call it itself (a
+        reference cycle or a stored traceback can keep the object -- and its context -- alive)."""
+        if getattr(self, '_wcache', None) is not None:
+            _lib.call('gx_weight_cache_destroy', self._wcache)
+            self._wcache = None
+        ctx = getattr(self, '_ctx', 0)
+        if ctx > 0:
+            self._ctx = 0
+            self.graph = self.graph2 = None
+            _fn.drop_ctx_state(ctx)
+            _lib.call('gx_ctx_destroy', ctx)
+
     def __del__(self):
         try:
-            if getattr(self, '_wcache', None) is not None:
-                _lib.call('gx_weight_cache_destroy', self._wcache)
-                self._wcache = None
-            if getattr(self, '_ctx', 0) > 0:
-                _lib.call('gx_ctx_destroy', self._ctx)
-                self._ctx = 0
+            self.close()
         except Exception:
             pass
 
@@ -295,6 +304,12 @@ class TrainStep(object):
             (self.world > 1 or bool(os.environ.get('GENESIS_FORCE_ALLREDUCE')))
 
     def _replay(self):
+        # the captured graphs hold no bucket fill (the Adam launch zeroes what it consumed): if an eager iteration
+        # died between its backward and its Adam launch, its partial gradients are still in the bucket -- clear them
+        # here, or the replayed backward (+=) would accumulate onto them
+        if not getattr(self, '_grads_clean', False):
+            self.bucket.zero_grad()
+            self._grads_clean = True
         self.graph.replay()
         if self._split:
             with torch.no_grad():

@@ -80,8 +80,11 @@ class BaselineVAE(nn.Module):
         return fn.Conv1x1Fn.apply(h, self.vae.p_x_mean.weight, self.vae.p_x_mean.bias)
 
     @torch.no_grad()
-    def sample(self, batch_size, *args, **kwargs):
-        z = torch.randn(batch_size, self.ldim, device=self.vae.p_x_mean.weight.device)
+    def sample(self, batch_size, *args, eps=None, **kwargs):
+        """models/vae_config.py:89-96; `eps` [B, ldim] injects the standard-normal draw (parity tests)."""
+        dev = self.vae.p_x_mean.weight.device
+        z = torch.randn(batch_size, self.ldim, device=dev) if eps is None else eps.to(dev).contiguous()
+        assert z.shape == (batch_size, self.ldim)
         x = self._decode(z)
         if self.pixel_bound:
             x = torch.sigmoid(x)

@@ -359,6 +359,11 @@ int gx_latent_prior_logp_bwd(const float* z, const float* lin, const float* g_ou
 /*      one ancestral step of GenesisV2.sample (models/genesisv2_config.py:235-246): lin [B,2D] = prior_linear(lstm out),
  *      eps [B,D] standard normal -> z [B,D] = tanh(lin[:D]) + to_prior_sigma(lin[D:]) * eps */
 int gx_latent_prior_sample(const float* lin, const float* eps, int B, int D, float* z, gx_stream_t stream);
+/*      the same with the mean's tanh selectable: Genesis.sample's mask rollout (models/genesis_config.py:352-362) uses
+ *      the RAW first half of prior_linear's output as the mean (tanh_mu = 0); its component prior
+ *      (models/genesis_config.py:391-397: tanh(prior_mlp[:L]), to_prior_sigma(prior_mlp[L:])) is tanh_mu = 1 */
+int gx_latent_prior_sample_ex(const float* lin, const float* eps, int B, int D, int tanh_mu, float* z,
+                              gx_stream_t stream);
 
 /* ---- loss aggregation of the training loop (train.py:226-242) with GECO's beta (utils/geco.py:47-49):
  *      err_mean = mean_b err[b]; kl_mean = sum_r mean_b kl[r][b] (kl [R,B], R = 0 / NULL: no KL term);

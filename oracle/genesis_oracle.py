@@ -51,14 +51,15 @@ def _gc_encoder(p, x, prefix, norm):
     return h.reshape(h.size(0), -1)
 
 
-def _gc_decoder(p, z, prefix, norm):
+def _gc_decoder(p, z, prefix, norm, training=True):
     """sylvester.build_gc_decoder (VAE.py:27-33) under `prefix`."""
     h = z.view(z.size(0), -1, 1, 1)
     name = prefix + '.0'
     h = S.gated(p, name, F.conv_transpose2d(h, p[name + '.conv.weight'], p[name + '.conv.bias'], 1, 0), None)
     for l, s in enumerate(SYM_STRIDES):
         name = '%s.%d' % (prefix, l + 1)
-        h = S.gated(p, name, F.conv_transpose2d(h, p[name + '.conv.weight'], p[name + '.conv.bias'], s, 2, s - 1), norm)
+        h = S.gated(p, name, F.conv_transpose2d(h, p[name + '.conv.weight'], p[name + '.conv.bias'], s, 2, s - 1), norm,
+                    training)
     return h
 
 
@@ -182,6 +183,56 @@ def genesis_forward(p, x, cfg, eps_m=None, eps_c=None):
     stats = dict(recon=recon, log_m_k=log_m_k, log_s_k=log_s_k, x_r_k=x_r_k)
     comp_stats = dict(mu_k=list(mu_ck), sigma_k=list(sig_ck), z_k=list(z_ck))
     return recon, losses, stats, att_stats, comp_stats
+
+
+def genesis_sample(p, cfg, eps_m, eps_c=None, training=False):
+    """Genesis.sample, models/genesis_config.py:345-425, on injected standard-normal draws: eps_m K x [B, ldim] (mask
+    rollout; every torch Normal.sample is mean + std * eps), eps_c K x [B, comp_ldim] (two-stage model).  The mask
+    rollout's mean is the RAW first half of prior_linear's output (:358 -- no tanh, unlike mask_latent_loss :309);
+    masks by LatentSBP.masks_from_zm_k (modules/attention.py:53-75) + the K+1 -> K fix-up (:374-376).
+    training=False: eval-mode BatchNorm, as every caller of the reference's sample() runs it.
+    -> (generated_image, x_k, log_m_k, log_s_k, zm_k, zc_k or None)."""
+    K, S_ = cfg['K_steps'], cfg['img_size']
+    L = cfg['attention_latents']
+    zm_k = [eps_m[0]]
+    state = None
+    for k in range(1, K):
+        out, state = _lstm_step(p, 'prior_lstm', zm_k[-1], state)
+        lin = F.linear(out, p['prior_linear.weight'], p['prior_linear.bias'])
+        mu, sigma = lin[:, :L], V.to_prior_sigma(lin[:, L:])
+        zm_k.append(mu + sigma * eps_m[k])
+    B = zm_k[0].size(0)
+    log_m_k, log_s_k = [], [torch.zeros(B, 1, S_, S_, dtype=zm_k[0].dtype)]
+    for zm in zm_k:                                       # masks_from_zm_k decodes slot by slot (:60-61)
+        a = S.decode(p, zm, S_, 'att_process.core', cfg['dec_norm'], training)[:, :1]
+        log_m_k.append(log_s_k[-1] + F.logsigmoid(a))
+        log_s_k.append(log_s_k[-1] + F.logsigmoid(-a))
+    log_m_k[K - 1] = log_s_k[K - 1]                       # :374-376 (the appended (K+1)-th mask is dropped)
+    zc_k = None
+    if cfg.get('two_stage', True):
+        zc_k = []
+        for k, zm in enumerate(zm_k):
+            if cfg.get('comp_prior', True):
+                h = F.elu(F.linear(zm, p['prior_mlp.0.weight'], p['prior_mlp.0.bias']))
+                h = F.elu(F.linear(h, p['prior_mlp.2.weight'], p['prior_mlp.2.bias']))
+                o = F.linear(h, p['prior_mlp.4.weight'], p['prior_mlp.4.bias'])
+                pm, ps = o.chunk(2, dim=1)
+                zc_k.append(torch.tanh(pm) + V.to_prior_sigma(ps) * eps_c[k])
+            else:
+                zc_k.append(eps_c[k])
+        zc = torch.cat(zc_k, 0)
+        if cfg.get('comp_symmetric', False):
+            h = _gc_decoder(p, zc, 'comp_vae.decoder_module.1', cfg['dec_norm'], training)
+            dec = F.conv2d(h, p['comp_vae.decoder_module.2.weight'], p['comp_vae.decoder_module.2.bias'])
+        else:
+            dec = M.broadcast_decoder(p, zc, S_, cfg['comp_dec_layers'], act=F.elu)
+    else:
+        dec = M.broadcast_decoder(p, torch.cat(zm_k, 0), S_, cfg['comp_dec_layers'], act=F.elu, prefix='decoder.seq')
+    if cfg.get('pixel_bound', True):
+        dec = torch.sigmoid(dec)
+    x_k = list(dec.chunk(K, 0))
+    img = (torch.stack(log_m_k, 4).exp() * torch.stack(x_k, 4)).sum(4)
+    return img, x_k, log_m_k, log_s_k, zm_k, zc_k
 
 
 def aggregate_losses(losses):

@@ -116,6 +116,32 @@ def monet_forward(p, x, cfg, eps=None):
     return recon, losses, stats, {}, comp_stats
 
 
+def monet_sample(p, cfg, eps, K_steps=None):
+    """MONet.sample, models/monet_config.py:172-198: z = the one standard-normal draw eps [B*K, ldim]; decode; masks by
+    get_mask_recon_stack(log=False) (:135-155).  -> (gen_image, x_k, log_m_k)."""
+    K = cfg['K_steps'] if K_steps is None else K_steps
+    S = cfg['img_size']
+    dec = broadcast_decoder(p, eps, S, cfg['comp_dec_layers'])
+    x_r, logits = dec[:, :3], dec[:, 3:]
+    if cfg.get('pixel_bound', True):
+        x_r = torch.sigmoid(x_r)
+    x_k, logit_k = list(x_r.chunk(K, 0)), list(logits.chunk(K, 0))
+    if cfg.get('prior_mode', 'softmax') == 'softmax':
+        m_r = F.softmax(torch.stack(logit_k, 4), 4)
+    else:
+        log_m, log_s = [], torch.zeros_like(logit_k[0])
+        for step, lg in enumerate(logit_k):
+            if step == K - 1:
+                log_m.append(log_s)
+            else:
+                log_m.append(log_s + F.logsigmoid(lg))
+                log_s = log_s + F.logsigmoid(-lg)
+        m_r = torch.stack(log_m, 4).exp()
+    img = (m_r * torch.stack(x_k, 4)).sum(4)
+    log_m_k = [m_r[..., k].log() for k in range(K)]
+    return img, x_k, log_m_k
+
+
 def aggregate_losses(losses):
     """train.py:226-242."""
     err = losses['err'].mean(0)

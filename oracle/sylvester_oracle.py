@@ -31,12 +31,13 @@ def _norm(p, name, x, norm, training=True):
     return x
 
 
-def gated(p, name, y, norm):
-    """h * sigmoid(g) with optional norms on both halves (layers.py:40-54)."""
+def gated(p, name, y, norm, training=True):
+    """h * sigmoid(g) with optional norms on both halves (layers.py:40-54); training=False = eval-mode BatchNorm
+    (running statistics), as the reference's sample() callers run it (train.py:425, scripts/compute_fid.py:104)."""
     h, g = y.chunk(2, dim=1)
     if norm in ('bn', 'in'):
-        h = _norm(p, name + '.h_norm', h, norm)
-        g = _norm(p, name + '.g_norm', g, norm)
+        h = _norm(p, name + '.h_norm', h, norm, training)
+        g = _norm(p, name + '.g_norm', g, norm, training)
     return h * torch.sigmoid(g)
 
 
@@ -59,7 +60,7 @@ def posterior(p, h, prefix):
     return mean, var
 
 
-def decode(p, z, img_size, prefix, dec_norm):
+def decode(p, z, img_size, prefix, dec_norm, training=True):
     """p_x_nn + p_x_mean (VAE.py:27-33,112-124,143-152): gated deconv kz from 1x1, 5 gated 5x5 deconvs (pad 2,
     output_padding s-1) with the reversed strides, 1x1 conv."""
     kz, strides = vae_geometry(img_size)
@@ -69,7 +70,7 @@ def decode(p, z, img_size, prefix, dec_norm):
     for l, s in enumerate(reversed(strides)):
         name = '%s.p_x_nn.%d' % (prefix, l + 1)
         h = gated(p, name, F.conv_transpose2d(h, p[name + '.conv.weight'], p[name + '.conv.bias'], s, 2, s - 1),
-                  dec_norm)
+                  dec_norm, training)
     return F.conv2d(h, p[prefix + '.p_x_mean.weight'], p[prefix + '.p_x_mean.bias'])
 
 

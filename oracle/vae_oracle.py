@@ -42,6 +42,18 @@ def vae_forward(p, x, cfg, eps=None):
     return recon, {'err': err, 'kl_l': kl}, dict(mu=mu, sigma=sigma, z=z), None, None
 
 
+def vae_sample(p, cfg, eps):
+    """BaselineVAE.sample, vae_config.py:89-96: z = the standard-normal draw eps [B, ldim], decoded (the VAE has no
+    norm layers, so train / eval mode do not differ)."""
+    S_ = cfg['img_size']
+    if cfg.get('broadcast_decoder', False):
+        h = F.elu(M.broadcast_decoder(p, eps, S_, 4, act=F.elu, prefix='vae.p_x_nn.1.seq'))
+        x = F.conv2d(h, p['vae.p_x_mean.weight'], p['vae.p_x_mean.bias'])
+    else:
+        x = S.decode(p, eps, S_, 'vae', None)
+    return torch.sigmoid(x) if cfg.get('pixel_bound', True) else x
+
+
 def param_shapes(cfg):
     sh = S.param_shapes('vae', cfg['latent_dimension'], 3, cfg['img_size'], 3, None, None)
     if cfg.get('broadcast_decoder', False):

@@ -265,3 +265,36 @@ def test_two_training_loops_coexist():
     got = traj(False)
     for r, g in zip(ref, got):
         assert torch.equal(r, g)
+
+
+def test_replay_after_an_aborted_eager_iteration():
+    """The captured graphs hold no bucket fill (Adam zeroes the gradients it consumes).  An eager iteration that dies
+    between its backward and its Adam launch leaves partial gradients in the bucket: the next replay must start from a
+    clean bucket, i.e. give exactly the step a loop without the aborted iteration gives."""
+    from genesis_amd.trainer import TrainStep
+    gold = Golden('tiny')
+    x, _, _ = gold.inputs()
+    xd = x.to(DEV)
+
+    def run(abort):
+        ts = TrainStep(build(gold), gold.S, lr=1e-4, graph=True)
+        ts.prepare(xd)
+        if abort:
+            rp, eps = gold.noise(1)
+            real_update = ts._update
+
+            def dying_update(*a, **k):
+                raise RuntimeError('simulated failure after the backward pass')
+            ts._update = dying_update
+            with pytest.raises(RuntimeError):
+                ts.step(xd, rand_pixel=rp.to(DEV), eps=torch.stack(eps).to(DEV))
+            ts._update = real_update
+            torch.cuda.synchronize()
+            assert float(ts.flat_g[:ts.n32].abs().max()) > 0        # the stale gradients are really there
+        torch.manual_seed(11); torch.cuda.manual_seed(11)
+        out = ts.step(xd).clone()
+        torch.cuda.synchronize()
+        return out.cpu(), ts.flat_p.clone().cpu(), ts.m32.clone().cpu()
+    clean, dirty = run(False), run(True)
+    for a, b in zip(clean, dirty):
+        assert torch.equal(a, b)
