@@ -368,6 +368,235 @@ __device__ __forceinline__ void wq_segment(const float* a, const float* b, const
     }
 }
 
+// ---- "row ring" tiles (round 3): the operands are split into their bf16 planes ONCE, on their way into LDS ---------
+// wq_tile_b6 above keeps fp32 tiles in LDS and every lane re-splits what it reads: each dy value is split by the two
+// waves that share its channel, each x value by two waves times the taps' row overlap (3 x for a 2-row tile), and every
+// tap's column shift is a shifted window of a split 10-float halo row: 5.4 VALU instructions per MFMA on a kernel with one
+// wave per SIMD (PMC, round 2), matrix pipe 0.41 busy.  Here:
+//   * a tile is ONE base row of one image, W = the full image width (32 or 64): there is no column halo -- what lies
+//     beyond either end of the row is the layer's zero padding;
+//   * x rows live in a ring of four LDS slots that rolls down the image: stepping to the next row brings in ONE new x
+//     row (it serves three consecutive tiles) and one new dy row; between two images the ring passes through a zero
+//     row (row -1 of the next image = row H of this one), a step without MFMAs;
+//   * global -> registers -> three bf16 planes (hi / mid / lo, 8 pixels = one 16-byte piece) -> LDS: every value is
+//     split exactly once, by the thread that loaded it; ~5.5 VALU per value, ~0.8 per MFMA;
+//   * the MFMA contraction slot k <-> pixel assignment is free as long as both operands agree, so the x (B) operand is
+//     always an ALIGNED octet (one ds_read_b128 per plane) and a tap's column shift s is applied to the dy (A) operand:
+//     A[p - s .. p - s + 8) = the aligned A octet funnel-shifted by one bf16 against its left / right neighbour
+//     (4 v_alignbit per plane and shifted variant, shared by every tap row: 24 per 54 MFMAs for conv3x3, 36 per 90 for
+//     the 15-tap transposed-conv class); A rows end in a zero piece, so the shift past a row end yields the padding.
+// LDS images: A plane [64 ch][W/8 data pieces + 1 zero piece] (odd pitch: the 16 channels of a ds_read_b128 lane group
+// fall on 16 distinct 16-byte slots), B plane [64 ch][W/8 pieces], piece q of channel c at q ^ f(c) (f = (c>>1)&7 at
+// 8 pieces, (c>>2)&3 at 4).
+typedef unsigned int gx_u32x4 __attribute__((ext_vector_type(4)));
+
+template <int CLS, int W> struct WrGeo {
+    using WT = WqTap<CLS>;
+    static constexpr int SA = WT::SA, NPB = WT::NPB, NT = WT::NT, NRO = WT::NRO, RO0 = WT::RO0;
+    static constexpr int OPR = W / 8;                          // octets (16-byte pieces) per base row
+    static constexpr int NG = W / 16;                          // MFMA k-groups per tile (16 pixels each)
+    static constexpr int UPT = OPR / 4;                        // (channel, octet) units per thread: 64 * OPR / 256
+    static constexpr int CPS = 256 / OPR;                      // channels covered by one unit index
+    static constexpr int APITCH = OPR + 1;                     // pieces per channel of an A plane
+    static constexpr int A_PLANE = (64 * APITCH + 1) * 16;     // bytes (one leading zero piece)
+    static constexpr int A_BUF = NPB * 3 * A_PLANE;            // one A buffer: column parities x planes
+    static constexpr int B_PLANE = 64 * OPR * 16;
+    static constexpr int B_SLOT = 3 * B_PLANE;                 // one ring slot: three planes of one x row
+    static constexpr int RING0 = 2 * A_BUF;                    // byte offset of the ring
+    static constexpr int LDS_BYTES = RING0 + 4 * B_SLOT;
+    __host__ __device__ static constexpr int fsw(int ch) { return (ch * OPR / 16) & (OPR - 1); }
+};
+
+__device__ __forceinline__ void wr_split8(const float (&v)[8], gx_u32x4& ph, gx_u32x4& pm, gx_u32x4& pl) {
+    __bf16 h[8], m[8], l[8];
+    wq_split<8>(v, h, m, l);
+    gx_bf16x8 vh, vm, vl;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { vh[i] = h[i]; vm[i] = m[i]; vl[i] = l[i]; }
+    ph = __builtin_bit_cast(gx_u32x4, vh); pm = __builtin_bit_cast(gx_u32x4, vm); pl = __builtin_bit_cast(gx_u32x4, vl);
+}
+
+// per-thread constants of a segment
+template <int CLS, int W> struct WrT {
+    using G = WrGeo<CLS, W>;
+    const float* a; const float* b; const float* zeros;
+    int N, CA, CB, ca0, cb0, H;
+    int goffA[G::UPT], goffB[G::UPT];      // float offsets of this thread's units from the row origin
+    bool okA[G::UPT], okB[G::UPT];         // channel inside the tensor
+    int stA[G::UPT], stB[G::UPT];          // LDS byte offsets of the units' pieces inside a plane
+    int a_rd;                              // MFMA loop: byte offset of (A channel, octet h) inside an A plane
+    int b_rd[G::NG];                       //            byte offset of (B channel, octet 2g + h) inside a B plane
+};
+
+// global -> registers: the dy row of tile (img, r) and x row `xr` of image `ximg` (either may be out of range = zeros)
+template <int CLS, int W>
+__device__ __forceinline__ void wr_fetch(const WrT<CLS, W>& w, int img, int r, bool a_live, int ximg, int xr, bool b_live,
+                                         f32x4 (&pa)[WrGeo<CLS, W>::UPT][2 * WrGeo<CLS, W>::SA],
+                                         f32x4 (&pb)[WrGeo<CLS, W>::UPT][2]) {
+    using G = WrGeo<CLS, W>;
+    constexpr int SA = G::SA;
+    const size_t arow = (((size_t)img * w.CA + w.ca0) * (SA * w.H) + (size_t)(SA * r + G::WT::PA)) * (SA * W);
+    const size_t brow = (((size_t)ximg * w.CB + w.cb0) * w.H + (size_t)xr) * W;
+    const float* ab = a_live ? w.a + arow : w.zeros;
+    const float* bb = b_live ? w.b + brow : w.zeros;
+#pragma unroll
+    for (int j = 0; j < G::UPT; ++j) {
+        const float* ap = (a_live & w.okA[j]) ? ab + w.goffA[j] : w.zeros;
+        const float* bp = (b_live & w.okB[j]) ? bb + w.goffB[j] : w.zeros;
+#pragma unroll
+        for (int q = 0; q < 2 * SA; ++q) pa[j][q] = *reinterpret_cast<const f32x4*>(ap + 4 * q);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) pb[j][q] = *reinterpret_cast<const f32x4*>(bp + 4 * q);
+    }
+}
+
+// registers -> bf16 planes -> LDS: A into buffer `abuf` (byte offset), B into ring slot `bslot` (byte offset)
+template <int CLS, int W>
+__device__ __forceinline__ void wr_store(char* lds, const WrT<CLS, W>& w, int abuf, int bslot,
+                                         const f32x4 (&pa)[WrGeo<CLS, W>::UPT][2 * WrGeo<CLS, W>::SA],
+                                         const f32x4 (&pb)[WrGeo<CLS, W>::UPT][2]) {
+    using G = WrGeo<CLS, W>;
+    constexpr int SA = G::SA;
+#pragma unroll
+    for (int j = 0; j < G::UPT; ++j) {
+#pragma unroll
+        for (int par = 0; par < G::NPB; ++par) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = pa[j][(SA * i + par) >> 2][(SA * i + par) & 3];   // de-interleave the column parities
+            gx_u32x4 ph, pm, pl;
+            wr_split8(v, ph, pm, pl);
+            char* d = lds + abuf + par * 3 * G::A_PLANE + w.stA[j];
+            *reinterpret_cast<gx_u32x4*>(d) = ph;
+            *reinterpret_cast<gx_u32x4*>(d + G::A_PLANE) = pm;
+            *reinterpret_cast<gx_u32x4*>(d + 2 * G::A_PLANE) = pl;
+        }
+        {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = pb[j][i >> 2][i & 3];
+            gx_u32x4 ph, pm, pl;
+            wr_split8(v, ph, pm, pl);
+            char* d = lds + G::RING0 + bslot + w.stB[j];
+            *reinterpret_cast<gx_u32x4*>(d) = ph;
+            *reinterpret_cast<gx_u32x4*>(d + G::B_PLANE) = pm;
+            *reinterpret_cast<gx_u32x4*>(d + 2 * G::B_PLANE) = pl;
+        }
+    }
+}
+
+__device__ __forceinline__ gx_bf16x8 wr_bf(const gx_u32x4& v) { return __builtin_bit_cast(gx_bf16x8, v); }
+
+// the MFMAs of one tile: A out of buffer `abuf`, x rows out of the ring slots `bs[rr]` (byte offsets)
+template <int CLS, int W, int G0, int G1>
+__device__ __forceinline__ void wr_mma(const char* lds, const WrT<CLS, W>& w, int abuf, const int (&bs)[WrGeo<CLS, W>::NRO],
+                                       f32x16 (&acc)[WrGeo<CLS, W>::NT]) {
+    using G = WrGeo<CLS, W>;
+    using WT = typename G::WT;
+    constexpr int NT = G::NT, NRO = G::NRO, RO0 = G::RO0;
+#pragma unroll
+    for (int g = G0; g < G1; ++g) {
+        // A: octet o = 2g + h of this lane's channel, its left neighbour's last pair and its right neighbour's first pair;
+        // variants by column offset co = s + 1: co 1 aligned, co 2 (s = +1) shifted right, co 0 (s = -1) shifted left
+        WqB3 av[G::NPB][3];
+#pragma unroll
+        for (int par = 0; par < G::NPB; ++par) {
+            gx_u32x4 sh[3][3];          // [plane][co]
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const char* p = lds + abuf + (par * 3 + pl) * G::A_PLANE + w.a_rd + g * 32;
+                const gx_u32x4 c = *reinterpret_cast<const gx_u32x4*>(p);
+                const unsigned pv = *reinterpret_cast<const unsigned*>(p - 4);
+                const unsigned nx = *reinterpret_cast<const unsigned*>(p + 16);
+                sh[pl][1] = c;
+                sh[pl][2] = gx_u32x4{__builtin_amdgcn_alignbit(c[0], pv, 16), __builtin_amdgcn_alignbit(c[1], c[0], 16),
+                                     __builtin_amdgcn_alignbit(c[2], c[1], 16), __builtin_amdgcn_alignbit(c[3], c[2], 16)};
+                sh[pl][0] = gx_u32x4{__builtin_amdgcn_alignbit(c[1], c[0], 16), __builtin_amdgcn_alignbit(c[2], c[1], 16),
+                                     __builtin_amdgcn_alignbit(c[3], c[2], 16), __builtin_amdgcn_alignbit(nx, c[3], 16)};
+            }
+#pragma unroll
+            for (int co = 0; co < 3; ++co) {
+                av[par][co].h = wr_bf(sh[0][co]); av[par][co].m = wr_bf(sh[1][co]); av[par][co].l = wr_bf(sh[2][co]);
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < NRO; ++rr) {
+            const char* p = lds + G::RING0 + bs[rr] + w.b_rd[g];
+            WqB3 b3;
+            b3.h = wr_bf(*reinterpret_cast<const gx_u32x4*>(p));
+            b3.m = wr_bf(*reinterpret_cast<const gx_u32x4*>(p + G::B_PLANE));
+            b3.l = wr_bf(*reinterpret_cast<const gx_u32x4*>(p + 2 * G::B_PLANE));
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (WT::ro(t) - RO0 != rr) continue;
+                acc[t] = wq_mma6(av[WT::pb(t)][WT::co(t)], b3, acc[t]);
+            }
+        }
+    }
+}
+
+// One SEGMENT of row-ring tiles: the tiles t0 .. t1 - 1 (tile = image * H + base row) of one 64 x 64 channel block,
+// accumulated in registers and written as one slab [tap][64][64].
+template <int CLS, int W>
+__device__ __forceinline__ void wr_segment(const float* a, const float* b, const float* zeros, char* lds, int N, int CA,
+                                           int CB, int ca0, int cb0, int H, int t0, int t1, float* slab) {
+    using G = WrGeo<CLS, W>;
+    using WT = typename G::WT;
+    constexpr int NT = G::NT, NRO = G::NRO, RO0 = G::RO0, OPR = G::OPR, SA = G::SA;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    WrT<CLS, W> w;
+    w.a = a; w.b = b; w.zeros = zeros; w.N = N; w.CA = CA; w.CB = CB; w.ca0 = ca0; w.cb0 = cb0; w.H = H;
+#pragma unroll
+    for (int j = 0; j < G::UPT; ++j) {
+        const int ch = tid / OPR + j * G::CPS, o = tid % OPR;
+        w.goffA[j] = ch * (SA * H) * (SA * W) + SA * 8 * o;
+        w.goffB[j] = ch * H * W + 8 * o;
+        w.okA[j] = ca0 + ch < CA;
+        w.okB[j] = cb0 + ch < CB;
+        w.stA[j] = (1 + ch * G::APITCH + o) * 16;
+        w.stB[j] = (ch * OPR + (o ^ G::fsw(ch))) * 16;
+    }
+    const int wm = wave >> 1, wn = wave & 1, h = lane >> 5;
+    const int cha = wm * 32 + (lane & 31), chb = wn * 32 + (lane & 31);
+    w.a_rd = (1 + cha * G::APITCH + h) * 16;
+#pragma unroll
+    for (int g = 0; g < G::NG; ++g) w.b_rd[g] = (chb * OPR + ((2 * g + h) ^ G::fsw(chb))) * 16;
+
+    // zero pieces of the A planes (both buffers): the leading one and one behind every channel's row
+    for (int i = tid; i < 2 * G::NPB * 3 * 65; i += 256) {
+        const int plane = i / 65, k = i - plane * 65;
+        *reinterpret_cast<gx_u32x4*>(lds + plane * G::A_PLANE + (k == 0 ? 0 : k * G::APITCH) * 16) = gx_u32x4{0u, 0u, 0u, 0u};
+    }
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    // virtual x rows: image i contributes v = 0 (a zero row: row -1 of image i and row H of image i - 1) and v = 1..H
+    // (rows 0..H-1); V = i (H + 1) + v; the tile of (i, r) is centred on v = r + 1 and reads the virtual rows
+    // V - 1 + RO0 .. V - 2 + RO0 + NRO out of ring slots (V' & 3)
+    const int H1 = H + 1;
+    int ci = t0 / H, cv = t0 - ci * H + 1;                  // centre of the current step
+    const int ei = (t1 - 1) / H, ev = (t1 - 1) - ei * H + 1;
+    int steps = (ei - ci) * H1 + (ev - cv) + 1;
+    int V = ci * H1 + cv;
+    f32x4 pa[G::UPT][2 * SA], pb[G::UPT][2];
+    // prologue: x rows V - 1, V, V + 1 and the dy row of the first tile
+    {
+        int li = ci, lv = cv - 1;                           // cv >= 1: lv >= 0
+#pragma unroll 1
+        for (int k = -1; k <= 1; ++k) {
+            wr_fetch<CLS, W>(w, ci, cv - 1, k == -1, li, lv - 1, lv >= 1 && li < N, pa, pb);
+            wr_store<CLS, W>(lds, w, 0, ((V + k) & 3) * G::B_SLOT, pa, pb);     // (the A row is stored three times: k = -1's survives? no: see below)
+            if (++lv > H) { lv = 0; ++li; }
+        }
+    }
+    __syncthreads();
+    (void)steps;
+}
+
 // ---- grouped launch: the jobs of one (class, tile width), every workgroup one strided segment
 template <int CLS, int LTW, bool B6>
 __global__ void __launch_bounds__(256, 1)
