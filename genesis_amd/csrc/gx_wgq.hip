@@ -375,9 +375,10 @@ __device__ __forceinline__ void wq_segment(const float* a, const float* b, const
 // wave per SIMD (PMC, round 2), matrix pipe 0.41 busy.  Here:
 //   * a tile is ONE base row of one image, W = the full image width (32 or 64): there is no column halo -- what lies
 //     beyond either end of the row is the layer's zero padding;
-//   * x rows live in a ring of four LDS slots that rolls down the image: stepping to the next row brings in ONE new x
-//     row (it serves three consecutive tiles) and one new dy row; between two images the ring passes through a zero
-//     row (row -1 of the next image = row H of this one), a step without MFMAs;
+//   * x rows live in a ring of four LDS slots that rolls down the images: tile t = image * H + row keeps its x row in slot
+//     t & 3 (H is a multiple of 4), stepping to the next tile brings in ONE new x row (it serves three consecutive
+//     tiles) and one new dy row; at an image's first / last row the row above / below is padding: those reads are
+//     redirected (a wave-uniform select of the read address) to a zero piece kept behind every plane of the ring;
 //   * global -> registers -> three bf16 planes (hi / mid / lo, 8 pixels = one 16-byte piece) -> LDS: every value is
 //     split exactly once, by the thread that loaded it; ~5.5 VALU per value, ~0.8 per MFMA;
 //   * the MFMA contraction slot k <-> pixel assignment is free as long as both operands agree, so the x (B) operand is
@@ -386,9 +387,13 @@ __device__ __forceinline__ void wq_segment(const float* a, const float* b, const
 //     (4 v_alignbit per plane and shifted variant, shared by every tap row: 24 per 54 MFMAs for conv3x3, 36 per 90 for
 //     the 15-tap transposed-conv class); A rows end in a zero piece, so the shift past a row end yields the padding.
 // LDS images: A plane [64 ch][W/8 data pieces + 1 zero piece] (odd pitch: the 16 channels of a ds_read_b128 lane group
-// fall on 16 distinct 16-byte slots), B plane [64 ch][W/8 pieces], piece q of channel c at q ^ f(c) (f = (c>>1)&7 at
-// 8 pieces, (c>>2)&3 at 4).
+// fall on 16 distinct 16-byte slots), B plane [4 slots][64 ch][W/8 pieces] + the zero piece, piece q of channel c at
+// q ^ f(c) (f = (c>>1)&7 at 8 pieces, (c>>2)&3 at 4).
 typedef unsigned int gx_u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) f32x4* gx_gptr4;
+#ifndef GX_WR_ABL
+#define GX_WR_ABL 0          // ablation builds (tools/abl_build.sh): 1 no MFMAs, 2 no split / LDS stores, 4 no global loads
+#endif
 
 template <int CLS, int W> struct WrGeo {
     using WT = WqTap<CLS>;
@@ -400,10 +405,11 @@ template <int CLS, int W> struct WrGeo {
     static constexpr int APITCH = OPR + 1;                     // pieces per channel of an A plane
     static constexpr int A_PLANE = (64 * APITCH + 1) * 16;     // bytes (one leading zero piece)
     static constexpr int A_BUF = NPB * 3 * A_PLANE;            // one A buffer: column parities x planes
-    static constexpr int B_PLANE = 64 * OPR * 16;
-    static constexpr int B_SLOT = 3 * B_PLANE;                 // one ring slot: three planes of one x row
+    static constexpr int B_ROW = 64 * OPR * 16;                // one x row of one plane
+    static constexpr int B_PLANE = 4 * B_ROW + 16;             // four ring slots + the zero piece
+    static constexpr int B_ZERO = 4 * B_ROW;                   // offset of the zero piece inside a plane
     static constexpr int RING0 = 2 * A_BUF;                    // byte offset of the ring
-    static constexpr int LDS_BYTES = RING0 + 4 * B_SLOT;
+    static constexpr int LDS_BYTES = RING0 + 3 * B_PLANE;
     __host__ __device__ static constexpr int fsw(int ch) { return (ch * OPR / 16) & (OPR - 1); }
 };
 
@@ -420,38 +426,40 @@ __device__ __forceinline__ void wr_split8(const float (&v)[8], gx_u32x4& ph, gx_
 template <int CLS, int W> struct WrT {
     using G = WrGeo<CLS, W>;
     const float* a; const float* b; const float* zeros;
-    int N, CA, CB, ca0, cb0, H;
+    int CA, CB, ca0, cb0, H, lh, ntot;     // lh = log2 H; ntot = N * H tiles (= x rows) of the layer
     int goffA[G::UPT], goffB[G::UPT];      // float offsets of this thread's units from the row origin
     bool okA[G::UPT], okB[G::UPT];         // channel inside the tensor
-    int stA[G::UPT], stB[G::UPT];          // LDS byte offsets of the units' pieces inside a plane
+    int stA[G::UPT], stB[G::UPT];          // LDS byte offsets of the units' pieces inside a plane / a ring slot
     int a_rd;                              // MFMA loop: byte offset of (A channel, octet h) inside an A plane
-    int b_rd[G::NG];                       //            byte offset of (B channel, octet 2g + h) inside a B plane
+    int b_rd[G::NG];                       //            byte offset of (B channel, octet 2g + h) inside a ring slot
 };
 
-// global -> registers: the dy row of tile (img, r) and x row `xr` of image `ximg` (either may be out of range = zeros)
+// global -> registers: the dy row of tile ta and the x row of tile tb (a tile index outside [0, ntot) = nothing to load)
 template <int CLS, int W>
-__device__ __forceinline__ void wr_fetch(const WrT<CLS, W>& w, int img, int r, bool a_live, int ximg, int xr, bool b_live,
+__device__ __forceinline__ void wr_fetch(const WrT<CLS, W>& w, int ta, int tb,
                                          f32x4 (&pa)[WrGeo<CLS, W>::UPT][2 * WrGeo<CLS, W>::SA],
                                          f32x4 (&pb)[WrGeo<CLS, W>::UPT][2]) {
     using G = WrGeo<CLS, W>;
     constexpr int SA = G::SA;
-    const size_t arow = (((size_t)img * w.CA + w.ca0) * (SA * w.H) + (size_t)(SA * r + G::WT::PA)) * (SA * W);
-    const size_t brow = (((size_t)ximg * w.CB + w.cb0) * w.H + (size_t)xr) * W;
-    const float* ab = a_live ? w.a + arow : w.zeros;
-    const float* bb = b_live ? w.b + brow : w.zeros;
+    const bool a_live = (unsigned)ta < (unsigned)w.ntot, b_live = (unsigned)tb < (unsigned)w.ntot;
+    const int ia = ta >> w.lh, ra = ta & (w.H - 1), ib = tb >> w.lh, rb = tb & (w.H - 1);
+    const size_t arow = (((size_t)ia * w.CA + w.ca0) * (SA * w.H) + (size_t)(SA * ra + G::WT::PA)) * (SA * W);
+    const size_t brow = (((size_t)ib * w.CB + w.cb0) * w.H + (size_t)rb) * W;
+    const float* ab = w.a + arow;
+    const float* bb = w.b + brow;
 #pragma unroll
     for (int j = 0; j < G::UPT; ++j) {
         const float* ap = (a_live & w.okA[j]) ? ab + w.goffA[j] : w.zeros;
         const float* bp = (b_live & w.okB[j]) ? bb + w.goffB[j] : w.zeros;
 #pragma unroll
-        for (int q = 0; q < 2 * SA; ++q) pa[j][q] = *reinterpret_cast<const f32x4*>(ap + 4 * q);
+        for (int q = 0; q < 2 * SA; ++q) pa[j][q] = ((gx_gptr4)ap)[q];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) pb[j][q] = *reinterpret_cast<const f32x4*>(bp + 4 * q);
+        for (int q = 0; q < 2; ++q) pb[j][q] = ((gx_gptr4)bp)[q];
     }
 }
 
-// registers -> bf16 planes -> LDS: A into buffer `abuf` (byte offset), B into ring slot `bslot` (byte offset)
-template <int CLS, int W>
+// registers -> bf16 planes -> LDS: A into buffer `abuf` (byte offset), B into ring slot `bslot` (byte offset of the row)
+template <int CLS, int W, bool DOA, bool DOB>
 __device__ __forceinline__ void wr_store(char* lds, const WrT<CLS, W>& w, int abuf, int bslot,
                                          const f32x4 (&pa)[WrGeo<CLS, W>::UPT][2 * WrGeo<CLS, W>::SA],
                                          const f32x4 (&pb)[WrGeo<CLS, W>::UPT][2]) {
@@ -459,19 +467,21 @@ __device__ __forceinline__ void wr_store(char* lds, const WrT<CLS, W>& w, int ab
     constexpr int SA = G::SA;
 #pragma unroll
     for (int j = 0; j < G::UPT; ++j) {
+        if (DOA) {
 #pragma unroll
-        for (int par = 0; par < G::NPB; ++par) {
-            float v[8];
+            for (int par = 0; par < G::NPB; ++par) {
+                float v[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = pa[j][(SA * i + par) >> 2][(SA * i + par) & 3];   // de-interleave the column parities
-            gx_u32x4 ph, pm, pl;
-            wr_split8(v, ph, pm, pl);
-            char* d = lds + abuf + par * 3 * G::A_PLANE + w.stA[j];
-            *reinterpret_cast<gx_u32x4*>(d) = ph;
-            *reinterpret_cast<gx_u32x4*>(d + G::A_PLANE) = pm;
-            *reinterpret_cast<gx_u32x4*>(d + 2 * G::A_PLANE) = pl;
+                for (int i = 0; i < 8; ++i) v[i] = pa[j][(SA * i + par) >> 2][(SA * i + par) & 3];   // de-interleave the column parities
+                gx_u32x4 ph, pm, pl;
+                wr_split8(v, ph, pm, pl);
+                char* d = lds + abuf + par * 3 * G::A_PLANE + w.stA[j];
+                *reinterpret_cast<gx_u32x4*>(d) = ph;
+                *reinterpret_cast<gx_u32x4*>(d + G::A_PLANE) = pm;
+                *reinterpret_cast<gx_u32x4*>(d + 2 * G::A_PLANE) = pl;
+            }
         }
-        {
+        if (DOB) {
             float v[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = pb[j][i >> 2][i & 3];
@@ -485,54 +495,256 @@ __device__ __forceinline__ void wr_store(char* lds, const WrT<CLS, W>& w, int ab
     }
 }
 
-__device__ __forceinline__ gx_bf16x8 wr_bf(const gx_u32x4& v) { return __builtin_bit_cast(gx_bf16x8, v); }
+// ---- one tile, software-pipelined by hand (one wave per SIMD: nothing else covers a stall) ---------------------------
+// A v_mfma_f32_32x32x16_bf16 holds the matrix pipe for 32 cycles; while it runs the wave can issue ~7 other instructions.
+// So the tile is written as a chain of SLOTS -- one MFMA, then one small PIECE of other work (<= 8 VALU or <= 3 LDS
+// instructions) that does not depend on it -- with a scheduling fence behind each (hipcc neither bunches the MFMAs nor
+// sinks the pieces; sched_group_barrier pipelines over a block of this size are not followed).  A tile is NG x NRO UNITS
+// (k-group g, x row rr) of NCO x 6 MFMAs on one B operand; the pieces of unit u, in slot order:
+//     the B operand of unit u + 1 (3 ds_read_b128);
+//     at the first unit of group g: the A octets of group g + 1 (one plane per slot: ds_read_b128 + 2 ds_read_b32);
+//     at the last unit of group g: the funnel shifts of group g + 1 into the other A variant set (4 v_alignbit each);
+//     from unit U0 on: the split of the rows fetched for the NEXT tile, 10 pieces per octet (bf16 pack | residual |
+//     pack | residual | pack | three ds_write_b128).
+template <int CLS, int W> struct WrRaw { gx_u32x4 c[WrGeo<CLS, W>::NPB][3]; unsigned pv[WrGeo<CLS, W>::NPB][3], nx[WrGeo<CLS, W>::NPB][3]; };
+typedef float gx_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 gx_bf16x2 __attribute__((ext_vector_type(2)));
 
-// the MFMAs of one tile: A out of buffer `abuf`, x rows out of the ring slots `bs[rr]` (byte offsets)
-template <int CLS, int W, int G0, int G1>
-__device__ __forceinline__ void wr_mma(const char* lds, const WrT<CLS, W>& w, int abuf, const int (&bs)[WrGeo<CLS, W>::NRO],
-                                       f32x16 (&acc)[WrGeo<CLS, W>::NT]) {
+template <int CLS, int W> struct WrSched {
     using G = WrGeo<CLS, W>;
-    using WT = typename G::WT;
-    constexpr int NT = G::NT, NRO = G::NRO, RO0 = G::RO0;
-#pragma unroll
-    for (int g = G0; g < G1; ++g) {
-        // A: octet o = 2g + h of this lane's channel, its left neighbour's last pair and its right neighbour's first pair;
-        // variants by column offset co = s + 1: co 1 aligned, co 2 (s = +1) shifted right, co 0 (s = -1) shifted left
-        WqB3 av[G::NPB][3];
-#pragma unroll
-        for (int par = 0; par < G::NPB; ++par) {
-            gx_u32x4 sh[3][3];          // [plane][co]
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                const char* p = lds + abuf + (par * 3 + pl) * G::A_PLANE + w.a_rd + g * 32;
-                const gx_u32x4 c = *reinterpret_cast<const gx_u32x4*>(p);
-                const unsigned pv = *reinterpret_cast<const unsigned*>(p - 4);
-                const unsigned nx = *reinterpret_cast<const unsigned*>(p + 16);
-                sh[pl][1] = c;
-                sh[pl][2] = gx_u32x4{__builtin_amdgcn_alignbit(c[0], pv, 16), __builtin_amdgcn_alignbit(c[1], c[0], 16),
-                                     __builtin_amdgcn_alignbit(c[2], c[1], 16), __builtin_amdgcn_alignbit(c[3], c[2], 16)};
-                sh[pl][0] = gx_u32x4{__builtin_amdgcn_alignbit(c[1], c[0], 16), __builtin_amdgcn_alignbit(c[2], c[1], 16),
-                                     __builtin_amdgcn_alignbit(c[3], c[2], 16), __builtin_amdgcn_alignbit(nx, c[3], 16)};
-            }
-#pragma unroll
-            for (int co = 0; co < 3; ++co) {
-                av[par][co].h = wr_bf(sh[0][co]); av[par][co].m = wr_bf(sh[1][co]); av[par][co].l = wr_bf(sh[2][co]);
-            }
-        }
-#pragma unroll
-        for (int rr = 0; rr < NRO; ++rr) {
-            const char* p = lds + G::RING0 + bs[rr] + w.b_rd[g];
-            WqB3 b3;
-            b3.h = wr_bf(*reinterpret_cast<const gx_u32x4*>(p));
-            b3.m = wr_bf(*reinterpret_cast<const gx_u32x4*>(p + G::B_PLANE));
-            b3.l = wr_bf(*reinterpret_cast<const gx_u32x4*>(p + 2 * G::B_PLANE));
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                if (WT::ro(t) - RO0 != rr) continue;
-                acc[t] = wq_mma6(av[WT::pb(t)][WT::co(t)], b3, acc[t]);
-            }
-        }
+    static constexpr int NRO = G::NRO, NG = G::NG, NPB = G::NPB;
+    static constexpr int NU = NG * NRO;                       // units per tile
+    static constexpr int NCO = G::NT / NRO;                   // taps per unit
+    static constexpr int NMF = 6 * NCO;                       // MFMAs (slots) per unit
+    static constexpr int NOCT = G::UPT * (NPB + 1);           // octets this thread splits per tile
+    static constexpr int NQ = 14 * NOCT;                      // split pieces
+    static constexpr int NFE = 2 * G::UPT;                    // fetch pieces (unit 0): the dy / x loads of unit j
+    // the last unit ends with: the tile's barrier, then the NEXT tile's first operands (B of its unit 0, A octets and
+    // funnel shifts of its group 0) under this tile's last MFMAs
+    static constexpr int NTAIL = 2 + 3 * NPB + 6 * NPB;
+    __host__ __device__ static constexpr bool more(int u) { return u + 1 < NU; }
+    __host__ __device__ static constexpr bool newg(int u) { return u % NRO == 0 && u / NRO + 1 < NG; }
+    __host__ __device__ static constexpr bool lastr(int u) { return u % NRO == NRO - 1 && u / NRO + 1 < NG; }
+    __host__ __device__ static constexpr int nfix(int u) {
+        return (more(u) ? 1 : 0) + (newg(u) ? 3 * NPB : 0) + (lastr(u) ? 6 * NPB : 0) + (u == 0 ? NFE : 0);
     }
+    __host__ __device__ static constexpr int nfree(int u) { return NMF - nfix(u) - (u == NU - 1 ? NTAIL : 0); }
+    __host__ __device__ static constexpr int u0() {           // first unit that carries split pieces: as late as they fit
+        int u = NU, room = 0;
+        while (room < NQ && u > 1) { --u; room += nfree(u); }
+        return u;
+    }
+    static constexpr int U0 = u0();
+    __host__ __device__ static constexpr int qbase(int u) {   // split pieces placed before unit u
+        int q = 0;
+        for (int v = U0; v < u; ++v) q += nfree(v);
+        return q;
+    }
+    static_assert(U0 >= 1 && qbase(NU) >= NQ, "the split pieces must fit the tile's free slots");
+    static_assert(nfree(0) >= 0 && nfree(NRO - 1) >= 0 && nfree(NU - 1) >= 0, "fixed pieces must fit a unit");
+};
+
+// what a step needs besides the per-thread constants (wave-uniform)
+template <int CLS, int W> struct WrStep {
+    int abuf, anxt, bnew;                                     // A buffer of this tile / of the next; ring slot being filled
+    int ta, tb;                                               // tiles whose dy / x row is fetched during this step
+    int bs[WrGeo<CLS, W>::NRO], nbs[WrGeo<CLS, W>::NRO];      // ring slot (byte offset) of x row rr: this tile / the next
+    bool zr[WrGeo<CLS, W>::NRO], nzr[WrGeo<CLS, W>::NRO];     // ... the row is padding
+};
+
+template <int CLS, int W> struct WrTileState {
+    using G = WrGeo<CLS, W>;
+    WrRaw<CLS, W> raw;
+    WqB3 av[2][G::NPB][3];          // A variants of the current / the next k-group
+    WqB3 bq[2];                     // B operand of the current / the next unit
+    float r[8];                     // the octet being split: value, then residuals
+    unsigned hp[4], mp[4], lp[4];   // its packed bf16 planes
+};
+
+__device__ __forceinline__ unsigned wr_pk(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(gx_f32x2{lo, hi}, gx_bf16x2));
+}
+__device__ __forceinline__ float wr_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float wr_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+// split piece Q of the tile: octet Q / 14 (per unit j: the NPB dy octets, then the x octet), step Q % 14 (<= 4 VALU or one
+// ds_write_b128 each)
+template <int CLS, int W, int Q>
+__device__ __forceinline__ void wr_split_piece(char* lds, const WrT<CLS, W>& w, WrTileState<CLS, W>& st, int anxt, int bnew,
+                                               const f32x4 (&pa)[WrGeo<CLS, W>::UPT][2 * WrGeo<CLS, W>::SA],
+                                               const f32x4 (&pb)[WrGeo<CLS, W>::UPT][2]) {
+    using G = WrGeo<CLS, W>;
+    constexpr int SA = G::SA, NPB = G::NPB;
+    constexpr int oi = Q / 14, step = Q % 14, j = oi / (NPB + 1), k = oi % (NPB + 1);
+    constexpr bool isA = k < NPB;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = isA ? pa[j][(SA * i + k) >> 2][(SA * i + k) & 3] : pb[j][i >> 2][i & 3];
+    if (step == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) st.hp[i] = wr_pk(v[2 * i], v[2 * i + 1]);
+    } else if (step >= 1 && step <= 4) {
+        constexpr int i = step - 1;
+        st.r[2 * i] = v[2 * i] - wr_lo(st.hp[i]); st.r[2 * i + 1] = v[2 * i + 1] - wr_hi(st.hp[i]);
+    } else if (step == 5) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) st.mp[i] = wr_pk(st.r[2 * i], st.r[2 * i + 1]);
+    } else if (step >= 6 && step <= 9) {
+        constexpr int i = step - 6;
+        st.r[2 * i] -= wr_lo(st.mp[i]); st.r[2 * i + 1] -= wr_hi(st.mp[i]);
+    } else if (step == 10) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) st.lp[i] = wr_pk(st.r[2 * i], st.r[2 * i + 1]);
+    } else {
+        char* d = isA ? lds + anxt + k * 3 * G::A_PLANE + w.stA[j] : lds + G::RING0 + bnew + w.stB[j];
+        constexpr int ps = isA ? G::A_PLANE : G::B_PLANE;
+        const unsigned* src = step == 11 ? st.hp : (step == 12 ? st.mp : st.lp);
+        *reinterpret_cast<gx_u32x4*>(d + (step - 11) * ps) = gx_u32x4{src[0], src[1], src[2], src[3]};
+    }
+}
+
+// one (parity, plane) of the A octets of group g: the aligned octet and its neighbours' adjacent pairs
+template <int CLS, int W>
+__device__ __forceinline__ void wr_read_a1(const char* lds, const WrT<CLS, W>& w, int abuf, int g, int par, int pl, WrRaw<CLS, W>& r) {
+    using G = WrGeo<CLS, W>;
+    const char* p = lds + abuf + (par * 3 + pl) * G::A_PLANE + w.a_rd + g * 32;
+    r.c[par][pl] = *reinterpret_cast<const gx_u32x4*>(p);
+    r.pv[par][pl] = *reinterpret_cast<const unsigned*>(p - 4);
+    r.nx[par][pl] = *reinterpret_cast<const unsigned*>(p + 16);
+}
+
+// variants by column offset co = s + 1: co 1 aligned, co 2 (s = +1) shifted right, co 0 (s = -1) shifted left;
+// piece = (parity, plane, which shift)
+__device__ __forceinline__ gx_bf16x8 wr_bf(const gx_u32x4& v) { return __builtin_bit_cast(gx_bf16x8, v); }
+template <int CLS, int W>
+__device__ __forceinline__ void wr_shift_a1(const WrRaw<CLS, W>& r, WqB3 (&av)[WrGeo<CLS, W>::NPB][3], int par, int pl, int right) {
+    const gx_u32x4 c = r.c[par][pl];
+    gx_u32x4 o;
+    if (right)
+        o = gx_u32x4{__builtin_amdgcn_alignbit(c[0], r.pv[par][pl], 16), __builtin_amdgcn_alignbit(c[1], c[0], 16),
+                     __builtin_amdgcn_alignbit(c[2], c[1], 16), __builtin_amdgcn_alignbit(c[3], c[2], 16)};
+    else
+        o = gx_u32x4{__builtin_amdgcn_alignbit(c[1], c[0], 16), __builtin_amdgcn_alignbit(c[2], c[1], 16),
+                     __builtin_amdgcn_alignbit(c[3], c[2], 16), __builtin_amdgcn_alignbit(r.nx[par][pl], c[3], 16)};
+    WqB3& d = av[par][right ? 2 : 0];
+    WqB3& al = av[par][1];
+    if (pl == 0) { d.h = wr_bf(o); if (right) al.h = wr_bf(c); }
+    else if (pl == 1) { d.m = wr_bf(o); if (right) al.m = wr_bf(c); }
+    else { d.l = wr_bf(o); if (right) al.l = wr_bf(c); }
+}
+
+template <int CLS, int W>
+__device__ __forceinline__ void wr_read_b(const char* lds, const WrT<CLS, W>& w, int g, int bs, bool zr, WqB3& b3) {
+    using G = WrGeo<CLS, W>;
+    const char* p = lds + G::RING0 + (zr ? G::B_ZERO : bs + w.b_rd[g]);
+    b3.h = wr_bf(*reinterpret_cast<const gx_u32x4*>(p));
+    b3.m = wr_bf(*reinterpret_cast<const gx_u32x4*>(p + G::B_PLANE));
+    b3.l = wr_bf(*reinterpret_cast<const gx_u32x4*>(p + 2 * G::B_PLANE));
+}
+
+// fetch piece i: the dy (i even) / x (i odd) loads of load unit i / 2
+template <int CLS, int W, int I>
+__device__ __forceinline__ void wr_fetch_piece(const WrT<CLS, W>& w, int ta, int tb,
+                                               f32x4 (&pa)[WrGeo<CLS, W>::UPT][2 * WrGeo<CLS, W>::SA],
+                                               f32x4 (&pb)[WrGeo<CLS, W>::UPT][2]) {
+    using G = WrGeo<CLS, W>;
+    constexpr int SA = G::SA, j = I / 2;
+    if (I % 2 == 0) {
+        const bool live = (unsigned)ta < (unsigned)w.ntot;
+        const int ia = ta >> w.lh, ra = ta & (w.H - 1);
+        const size_t arow = (((size_t)ia * w.CA + w.ca0) * (SA * w.H) + (size_t)(SA * ra + G::WT::PA)) * (SA * W);
+        const float* ap = (live & w.okA[j]) ? w.a + arow + w.goffA[j] : w.zeros;
+#pragma unroll
+        for (int q = 0; q < 2 * SA; ++q) pa[j][q] = ((gx_gptr4)ap)[q];
+    } else {
+        const bool live = (unsigned)tb < (unsigned)w.ntot;
+        const int ib = tb >> w.lh, rb = tb & (w.H - 1);
+        const size_t brow = (((size_t)ib * w.CB + w.cb0) * w.H + (size_t)rb) * W;
+        const float* bp = (live & w.okB[j]) ? w.b + brow + w.goffB[j] : w.zeros;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) pb[j][q] = ((gx_gptr4)bp)[q];
+    }
+}
+
+// the first operands of a tile: B of unit 0, A octets + funnel shifts of group 0 -- as NTAIL - 1 pieces (I = 0 .. )
+template <int CLS, int W, int I>
+__device__ __forceinline__ void wr_head_piece(const char* lds, const WrT<CLS, W>& w, int abuf, const int (&bs)[WrGeo<CLS, W>::NRO],
+                                              const bool (&zr)[WrGeo<CLS, W>::NRO], WrTileState<CLS, W>& st) {
+    constexpr int NPB = WrGeo<CLS, W>::NPB;
+    if (I == 0) wr_read_b<CLS, W>(lds, w, 0, bs[0], zr[0], st.bq[0]);
+    else if (I < 1 + 3 * NPB) wr_read_a1<CLS, W>(lds, w, abuf, 0, (I - 1) / 3, (I - 1) % 3, st.raw);
+    else wr_shift_a1<CLS, W>(st.raw, st.av[0], (I - 1 - 3 * NPB) / 6, ((I - 1 - 3 * NPB) % 6) / 2, (I - 1 - 3 * NPB) % 2);
+}
+
+// slot M of unit U: its MFMA, then its piece
+template <int CLS, int W, int U, int M>
+__device__ __forceinline__ void wr_slot(char* lds, const WrT<CLS, W>& w, const WrStep<CLS, W>& sp,
+                                        f32x16 (&acc)[WrGeo<CLS, W>::NT], WrTileState<CLS, W>& st,
+                                        f32x4 (&pa)[WrGeo<CLS, W>::UPT][2 * WrGeo<CLS, W>::SA],
+                                        f32x4 (&pb)[WrGeo<CLS, W>::UPT][2]) {
+    using G = WrGeo<CLS, W>;
+    using S = WrSched<CLS, W>;
+    using WT = typename G::WT;
+    constexpr int NRO = G::NRO, NPB = G::NPB;
+    constexpr int g = U / NRO, rr = U % NRO, as = g & 1;
+    // ---- the MFMA: term M / NCO (small terms first, as wq_mma6) of tap M % NCO of x row rr -- term-major: consecutive
+    //      MFMAs accumulate into different registers (a dependent one waits for its predecessor's write-back)
+    {
+        int tap = -1, seen = 0;
+#pragma unroll
+        for (int q = 0; q < WT::NT; ++q)
+            if (WT::ro(q) - G::RO0 == rr) { if (seen == M % S::NCO) tap = q; ++seen; }
+        const WqB3& a3 = st.av[as][WT::pb(tap)][WT::co(tap)];
+        const WqB3& b3 = st.bq[U & 1];
+        constexpr int term = M / S::NCO;
+        const gx_bf16x8 ao = term == 0 ? a3.m : (term == 1 ? a3.l : (term == 3 ? a3.m : a3.h));
+        const gx_bf16x8 bo = term == 0 ? b3.m : (term == 2 ? b3.l : (term == 4 ? b3.m : b3.h));
+#if !(GX_WR_ABL & 1)
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ao, bo, acc[tap], 0, 0, 0);
+#else
+        acc[tap][M % 16] += __builtin_bit_cast(float, __builtin_bit_cast(gx_u32x4, ao)[0] ^ __builtin_bit_cast(gx_u32x4, bo)[1]);
+#endif
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- the piece
+    constexpr int n_b = S::more(U) ? 1 : 0, n_ra = S::newg(U) ? 3 * NPB : 0, n_sh = S::lastr(U) ? 6 * NPB : 0;
+    constexpr int n_fe = U == 0 ? S::NFE : 0;
+    constexpr int tail0 = U == S::NU - 1 ? S::NMF - S::NTAIL : S::NMF;      // first tail slot
+    if constexpr (M >= tail0) {
+        if constexpr (M == tail0) __syncthreads();         // the rows of the next tile are in LDS; this tile's reads are done
+#if !(GX_WR_ABL & 8)
+        else wr_head_piece<CLS, W, M - tail0 - 1>(lds, w, sp.anxt, sp.nbs, sp.nzr, st);
+#endif
+    }
+#if GX_WR_ABL & 8
+    else if constexpr (M < n_b + n_ra + n_sh) {}
+#endif
+    else if constexpr (M < n_b) {
+        wr_read_b<CLS, W>(lds, w, (U + 1) / NRO, sp.bs[(U + 1) % NRO], sp.zr[(U + 1) % NRO], st.bq[(U + 1) & 1]);
+    } else if constexpr (M < n_b + n_ra) {
+        wr_read_a1<CLS, W>(lds, w, sp.abuf, g + 1, (M - n_b) / 3, (M - n_b) % 3, st.raw);
+    } else if constexpr (M < n_b + n_ra + n_sh) {
+        wr_shift_a1<CLS, W>(st.raw, st.av[as ^ 1], (M - n_b - n_ra) / 6, ((M - n_b - n_ra) % 6) / 2, (M - n_b - n_ra) % 2);
+    } else if constexpr (M < n_b + n_ra + n_sh + n_fe) {
+#if !(GX_WR_ABL & 4)
+        wr_fetch_piece<CLS, W, M - n_b - n_ra - n_sh>(w, sp.ta, sp.tb, pa, pb);
+#endif
+    } else if constexpr (U >= S::U0) {
+        constexpr int q = S::qbase(U) + (M - S::nfix(U));
+#if !(GX_WR_ABL & 2)
+        if constexpr (q >= 0 && q < S::NQ) wr_split_piece<CLS, W, q>(lds, w, st, sp.anxt, sp.bnew, pa, pb);
+#endif
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (M + 1 < S::NMF) wr_slot<CLS, W, U, M + 1>(lds, w, sp, acc, st, pa, pb);
+    else if constexpr (U + 1 < S::NU) wr_slot<CLS, W, U + 1, 0>(lds, w, sp, acc, st, pa, pb);
+}
+
+template <int CLS, int W, int I>
+__device__ __forceinline__ void wr_head(const char* lds, const WrT<CLS, W>& w, int abuf, const int (&bs)[WrGeo<CLS, W>::NRO],
+                                        const bool (&zr)[WrGeo<CLS, W>::NRO], WrTileState<CLS, W>& st) {
+    wr_head_piece<CLS, W, I>(lds, w, abuf, bs, zr, st);
+    if constexpr (I + 2 < WrSched<CLS, W>::NTAIL) wr_head<CLS, W, I + 1>(lds, w, abuf, bs, zr, st);
 }
 
 // One SEGMENT of row-ring tiles: the tiles t0 .. t1 - 1 (tile = image * H + base row) of one 64 x 64 channel block,
@@ -545,7 +757,8 @@ __device__ __forceinline__ void wr_segment(const float* a, const float* b, const
     constexpr int NT = G::NT, NRO = G::NRO, RO0 = G::RO0, OPR = G::OPR, SA = G::SA;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     WrT<CLS, W> w;
-    w.a = a; w.b = b; w.zeros = zeros; w.N = N; w.CA = CA; w.CB = CB; w.ca0 = ca0; w.cb0 = cb0; w.H = H;
+    w.a = a; w.b = b; w.zeros = zeros; w.CA = CA; w.CB = CB; w.ca0 = ca0; w.cb0 = cb0; w.H = H;
+    w.lh = 31 - __builtin_clz(H); w.ntot = N * H;
 #pragma unroll
     for (int j = 0; j < G::UPT; ++j) {
         const int ch = tid / OPR + j * G::CPS, o = tid % OPR;
@@ -562,10 +775,12 @@ __device__ __forceinline__ void wr_segment(const float* a, const float* b, const
 #pragma unroll
     for (int g = 0; g < G::NG; ++g) w.b_rd[g] = (chb * OPR + ((2 * g + h) ^ G::fsw(chb))) * 16;
 
-    // zero pieces of the A planes (both buffers): the leading one and one behind every channel's row
-    for (int i = tid; i < 2 * G::NPB * 3 * 65; i += 256) {
+    // zero pieces: the leading one and one behind every channel's row of the A planes (both buffers), one per ring plane
+    for (int i = tid; i < 2 * G::NPB * 3 * 65 + 3; i += 256) {
         const int plane = i / 65, k = i - plane * 65;
-        *reinterpret_cast<gx_u32x4*>(lds + plane * G::A_PLANE + (k == 0 ? 0 : k * G::APITCH) * 16) = gx_u32x4{0u, 0u, 0u, 0u};
+        char* d = plane < 2 * G::NPB * 3 ? lds + plane * G::A_PLANE + (k == 0 ? 0 : k * G::APITCH) * 16
+                                         : lds + G::RING0 + k * G::B_PLANE + G::B_ZERO;
+        *reinterpret_cast<gx_u32x4*>(d) = gx_u32x4{0u, 0u, 0u, 0u};
     }
 
     f32x16 acc[NT];
@@ -574,27 +789,60 @@ __device__ __forceinline__ void wr_segment(const float* a, const float* b, const
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
-    // virtual x rows: image i contributes v = 0 (a zero row: row -1 of image i and row H of image i - 1) and v = 1..H
-    // (rows 0..H-1); V = i (H + 1) + v; the tile of (i, r) is centred on v = r + 1 and reads the virtual rows
-    // V - 1 + RO0 .. V - 2 + RO0 + NRO out of ring slots (V' & 3)
-    const int H1 = H + 1;
-    int ci = t0 / H, cv = t0 - ci * H + 1;                  // centre of the current step
-    const int ei = (t1 - 1) / H, ev = (t1 - 1) - ei * H + 1;
-    int steps = (ei - ci) * H1 + (ev - cv) + 1;
-    int V = ci * H1 + cv;
     f32x4 pa[G::UPT][2 * SA], pb[G::UPT][2];
-    // prologue: x rows V - 1, V, V + 1 and the dy row of the first tile
-    {
-        int li = ci, lv = cv - 1;                           // cv >= 1: lv >= 0
+    // prologue: the x rows of tiles t0 - 1, t0, t0 + 1 (a neighbour in another image is never read by tile t0, but the
+    // one behind serves tile t0 + 1) and the dy row of t0
+    wr_fetch<CLS, W>(w, t0, t0 - 1, pa, pb);
+    wr_store<CLS, W, true, true>(lds, w, 0, ((t0 - 1) & 3) * G::B_ROW, pa, pb);
 #pragma unroll 1
-        for (int k = -1; k <= 1; ++k) {
-            wr_fetch<CLS, W>(w, ci, cv - 1, k == -1, li, lv - 1, lv >= 1 && li < N, pa, pb);
-            wr_store<CLS, W>(lds, w, 0, ((V + k) & 3) * G::B_SLOT, pa, pb);     // (the A row is stored three times: k = -1's survives? no: see below)
-            if (++lv > H) { lv = 0; ++li; }
-        }
+    for (int k = 0; k <= 1; ++k) {
+        wr_fetch<CLS, W>(w, -1, t0 + k, pa, pb);
+        wr_store<CLS, W, false, true>(lds, w, 0, ((t0 + k) & 3) * G::B_ROW, pa, pb);
     }
     __syncthreads();
-    (void)steps;
+    WrStep<CLS, W> sp;
+    WrTileState<CLS, W> st;
+    auto rows = [&](int t, int (&bs)[NRO], bool (&zr)[NRO]) {
+        const int r = t & (H - 1);
+#pragma unroll
+        for (int rr = 0; rr < NRO; ++rr) {
+            const int dr = RO0 + rr - 1;                    // x row r + dr
+            bs[rr] = ((t + dr) & 3) * G::B_ROW;
+            zr[rr] = (unsigned)(r + dr) >= (unsigned)H;
+        }
+    };
+    rows(t0, sp.nbs, sp.nzr);
+    wr_head<CLS, W, 0>(lds, w, 0, sp.nbs, sp.nzr, st);      // the first tile's first operands (later ones: the previous tile's tail)
+    sp.anxt = 0;
+#pragma unroll 1
+    for (int t = t0; t < t1; ++t) {
+        sp.abuf = sp.anxt; sp.anxt = G::A_BUF - sp.abuf;
+        sp.bnew = ((t + 2) & 3) * G::B_ROW;
+        sp.ta = t + 1 < t1 ? t + 1 : -1; sp.tb = t + 2;
+#pragma unroll
+        for (int rr = 0; rr < NRO; ++rr) { sp.bs[rr] = sp.nbs[rr]; sp.zr[rr] = sp.nzr[rr]; }
+        rows(t + 1, sp.nbs, sp.nzr);
+        wr_slot<CLS, W, 0, 0>(lds, w, sp, acc, st, pa, pb);
+    }
+
+    // ---- slab [tap][ca][cb]  (C/D layout: col = lane & 31 -> cb, row -> ca)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        auto* dst = (__attribute__((address_space(1))) float*)(slab + (size_t)WT::gt(t) * 4096 + (size_t)(wm * 32) * 64 +
+                                                               wn * 32 + (lane & 31));
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            dst[(size_t)row * 64] = acc[t][reg];
+        }
+    }
+}
+
+template <int CLS, int W>
+__device__ __attribute__((noinline)) void wr_segment_call(const float* a, const float* b, const float* zeros, int N, int CA,
+                                                          int CB, int ca0, int cb0, int H, int t0, int t1, float* slab) {
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+    wr_segment<CLS, W>(a, b, zeros, reinterpret_cast<char*>(lds_dyn), N, CA, CB, ca0, cb0, H, t0, t1, slab);
 }
 
 // ---- grouped launch: the jobs of one (class, tile width), every workgroup one strided segment
@@ -625,10 +873,11 @@ struct WsJob {
     const float* a; const float* b; float* partial;      // partial: this block's region [slab][Ttot][64][64]
     long long ubegin;                                    // first unit of this block on the line
     int CA, CB, ca0, cb0, Hb, Wb, tiles_h, tiles_w, ntiles, Ttot;
-    int variant;                                         // class * 3 + (5 - log2 tile width); + 9: on the fp32 matrix pipe
+    int variant;                                         // class * 3 + (5 - log2 tile width); + 9: on the fp32 matrix pipe;
+                                                         // 18..21: row-ring tiles (conv3x3 W 64 / 32, transposed conv rows 0 / 1 at W 32)
     int cost;                                            // units per tile
     int w_first;                                         // first workgroup with tiles of this block (slab 0)
-    int pad_;
+    int N;                                               // images (the row-ring variants bound their virtual rows with it)
 };
 constexpr int kMaxSJobs = 36;                            // 36 x 96 B: the table travels as a kernel argument
 struct WsTable { long long U; int njobs, G; long long* times; WsJob job[kMaxSJobs]; };   // times: GENESIS_WGQ_TIMES (NULL otherwise)
@@ -675,13 +924,19 @@ wgq_stream_kernel(const WsTable tab, const float* __restrict__ zeros) {
             wq_segment_call<CLS_, LTW_, false>(jb.a, jb.b, zeros, jb.CA, jb.CB, jb.ca0, jb.cb0, jb.Hb, jb.Wb,      \
                                                jb.tiles_h, jb.tiles_w, t0, t1, slab);                               \
             break;
+#define GX_WR_CASE(V_, CLS_, W_)                                                                                    \
+        case V_:                                                                                                    \
+            wr_segment_call<CLS_, W_>(jb.a, jb.b, zeros, jb.N, jb.CA, jb.CB, jb.ca0, jb.cb0, jb.Hb, t0, t1, slab);  \
+            break;
         switch (jb.variant) {
             GX_WS_CASE(0, WQ_C3, 5) GX_WS_CASE(1, WQ_C3, 4) GX_WS_CASE(2, WQ_C3, 3)
             GX_WS_CASE(3, WQ_DR0, 5) GX_WS_CASE(4, WQ_DR0, 4) GX_WS_CASE(5, WQ_DR0, 3)
             GX_WS_CASE(6, WQ_DR1, 5) GX_WS_CASE(7, WQ_DR1, 4) GX_WS_CASE(8, WQ_DR1, 3)
+            GX_WR_CASE(18, WQ_C3, 64) GX_WR_CASE(19, WQ_C3, 32) GX_WR_CASE(20, WQ_DR0, 32) GX_WR_CASE(21, WQ_DR1, 32)
             default: break;
         }
 #undef GX_WS_CASE
+#undef GX_WR_CASE
         __syncthreads();          // the next segment's first DMA re-uses stage 0
     }
     if (tab.times && threadIdx.x == 0) {          // measurement: when did this workgroup start and finish
@@ -836,17 +1091,40 @@ bool wgq_stream_on() {
 // wgrad3:256:64 wgrad3:2048:16 wgrad3:8192:8 wgrad:256:32 wgrad:1024:16 wgrad:4096:8: 10.3 us per conv3x3 tile, 26.5 us per
 // pair of transposed-conv row-parity tiles, split 15 a + b : 10 a + b), then nudged on the training step itself
 // (the stream kernel's duration over five vectors: 921 .. 972 us); GENESIS_WGQ_COST="c0,...,c8" overrides
-int g_ws_cost[18] = {10200, 9580, 10680, 15080, 26500, 14570, 11400, 10620, 11540,            // bf16 pipe (measured with
-                     10200, 10600, 11200, 16000, 16500, 18200, 11600, 12000, 13300};          // GENESIS_WGQ_TIMES) | fp32 pipe
+int g_ws_cost[22] = {10200, 9580, 10680, 15080, 21000, 11800, 11400, 8800, 9700,              // bf16 pipe (measured with
+                     10200, 10600, 11200, 16000, 16500, 18200, 11600, 12000, 13300,           // GENESIS_WGQ_TIMES) | fp32 pipe
+                     4840, 2450, 4150, 2900};                                                 // row-ring tiles (one base row)
 bool g_ws_cost_init = false;
 void ws_cost_init() {
     if (g_ws_cost_init) return;
     g_ws_cost_init = true;
     const char* env = getenv("GENESIS_WGQ_COST");
+    if (const char* er = getenv("GENESIS_WGQ_RING_COST")) {
+        int r[4];
+        if (sscanf(er, "%d,%d,%d,%d", r, r + 1, r + 2, r + 3) == 4)
+            for (int i = 0; i < 4; ++i) if (r[i] > 0) g_ws_cost[18 + i] = r[i];
+    }
     if (!env) return;
     int v[9];          // the nine costs of the pipe in use
     if (sscanf(env, "%d,%d,%d,%d,%d,%d,%d,%d,%d", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6, v + 7, v + 8) == 9)
         for (int i = 0; i < 9; ++i) if (v[i] > 0) g_ws_cost[(wgq_b6() ? 0 : 9) + i] = v[i];
+}
+
+// row-ring tiles (wr_segment): on the bf16 pipe, for full-width rows of 32 / 64 pixels; GENESIS_WGQ_RING=0 / gx_wgq_ring(0)
+// keep every layer on the 64-pixel LDS-DMA tiles (the A/B reference)
+int g_wgq_ring = -1;
+bool wgq_ring_on() {
+    if (g_wgq_ring < 0) {
+        const char* env = getenv("GENESIS_WGQ_RING");
+        g_wgq_ring = (env && env[0] == '0') ? 0 : 1;
+    }
+    return g_wgq_ring != 0;
+}
+int ws_ring_variant(int cls, int Hb, int Wb) {
+    if (!wgq_b6() || !wgq_ring_on() || Hb < 4) return -1;          // (H a multiple of 4: the ring slot of a row is tile & 3)
+    if (cls == WQ_C3) return Wb == 64 ? 18 : (Wb == 32 ? 19 : -1);
+    if (Wb != 32) return -1;
+    return cls == WQ_DR0 ? 20 : 21;
 }
 
 struct WsSlot { PendingJob* p; int blk; int nseg; };
@@ -916,8 +1194,10 @@ int wgq_launch_stream(std::vector<PendingJob*>& jobs, hipStream_t s, std::vector
                     jb.tiles_h = q.job.tiles_h; jb.tiles_w = q.job.tiles_w; jb.ntiles = q.job.ntiles;
                     jb.Ttot = q.job.Ttot;
                     jb.variant = q.cls * 3 + (5 - q.ltw) + (wgq_b6() ? 0 : 9);
+                    const int rv = ws_ring_variant(q.cls, q.job.Hb, q.job.Wb);
+                    if (rv >= 0) { jb.variant = rv; jb.ntiles = q.job.N * q.job.Hb; }      // tile = one base row
                     jb.cost = g_ws_cost[jb.variant];
-                    jb.w_first = 0; jb.pad_ = 0;
+                    jb.w_first = 0; jb.N = q.job.N;
                     tab.U += (long long)jb.ntiles * jb.cost;
                     slots.push_back(WsSlot{&q, blk, 0});
                 }
@@ -1154,6 +1434,12 @@ extern "C" int gx_wgq_precision(int mode) {
     GX_CHECK_ARG(mode == 0 || mode == 1, "gx_wgq_precision: mode must be 0 (fp32 matrix pipe) or 1 (bf16 pipe, fp32 products "
                                          "from six bf16 piece products)");
     g_wgq_b6 = mode;
+    return GX_OK;
+}
+
+extern "C" int gx_wgq_ring(int on) {
+    GX_CHECK_ARG(on == 0 || on == 1, "gx_wgq_ring: 0 (64-pixel LDS-DMA tiles everywhere) or 1 (row-ring tiles where eligible)");
+    g_wgq_ring = on;
     return GX_OK;
 }
 

@@ -66,6 +66,13 @@ int gx_wgq_policy(int mode);
  *      with fp64), at 6 x 32 instead of 8 x 64 matrix-pipe cycles per 16 contraction steps.  0: the fp32 pipe
  *      (v_mfma_f32_32x32x2_f32).  Environment: GENESIS_WGQ_BF16X6=0. */
 int gx_wgq_precision(int mode);
+/*      Tile shape of the bf16-pipe weight gradients for layers whose base rows are 32 or 64 pixels wide (conv3x3 at
+ *      32 / 64, transposed conv from 32 x 32): 1 (default) row-ring tiles -- a tile is one full-width base row, the x rows
+ *      roll through a four-slot LDS ring, every operand value is split into its bf16 planes once on its way into LDS and
+ *      the taps' column shifts are funnel shifts of the dy operand -- 0 the 64-pixel LDS-DMA tiles whose lanes split
+ *      what they read (the A/B reference).  Environment: GENESIS_WGQ_RING=0.  Replaces the same reference ops as
+ *      gx_conv3x3_wgrad / gx_deconv5x5s2_wgrad (modules/blocks.py:159-165, models/genesisv2_config.py:89-99). */
+int gx_wgq_ring(int on);
 /*      The same choice for the chip-filling transposed-conv forward / data-gradient layers (gx_kq.hip): 1 (default)
  *      bf16 pipe -- the staging splits the input tile into its three bf16 planes, the pack kernel the weights; needs a
  *      multiple of 16 reduction channels and a tile of <= 384 halo positions, other layers stay on the fp32 pipe --

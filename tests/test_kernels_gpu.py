@@ -1087,3 +1087,37 @@ def test_streamk_weight_gradients_many_layers():
         close(og, ref, rtol=2e-5, atol=1e-6 * float(ref.abs().max()), msg='grouped %s %s' % (kind, tuple(x.shape)))
         close(o, ref, rtol=2e-5, atol=1e-6 * float(ref.abs().max()), msg='stream-K %s %s' % (kind, tuple(x.shape)))
         close(o, alone, rtol=2e-5, atol=1e-6 * float(ref.abs().max()), msg='stream-K vs alone %s' % (tuple(x.shape),))
+
+
+@pytest.mark.parametrize('kind,N,Cin,Cout,S', [('conv3x3', 5, 64, 64, 64), ('conv3x3', 1, 128, 64, 64), ('conv3x3', 7, 96, 40, 32),
+                                                ('conv3x3', 33, 64, 128, 32), ('deconv', 3, 64, 64, 32), ('deconv', 29, 40, 72, 32),
+                                                ('deconv', 1, 64, 64, 32)])
+def test_row_ring_weight_gradients(kind, N, Cin, Cout, S):
+    """gx_wgq_ring: the row-ring tiles of the bf16-pipe weight gradients (one full-width base row per tile, x rows in a
+    rolling four-slot LDS ring, operands split into bf16 planes once, column shifts as funnel shifts of the dy operand)
+    against the 64-pixel LDS-DMA tiles and against autograd in fp64 -- odd image counts (stream-K segments start and end
+    anywhere inside an image), a single image, ragged channel blocks; same accuracy bar as the other tiles; two runs are
+    bit-identical."""
+    from genesis_amd import hip_ops as hip, _lib
+    if kind == 'conv3x3':
+        x, dy = rnd(N, Cin, S, S, seed=1), rnd(N, Cout, S, S, seed=2)
+        ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 3, 3), dy.double(), padding=1)
+        run = lambda: hip.conv3x3_wgrad(x.to(DEV), dy.to(DEV))  # noqa: E731
+    else:
+        x, dy = rnd(N, Cin, S, S, seed=1), rnd(N, Cout, 2 * S, 2 * S, seed=2)
+        w = torch.zeros(Cin, Cout, 5, 5, dtype=torch.float64, requires_grad=True)
+        F.conv_transpose2d(x.double(), w, None, 2, 2, 1).backward(dy.double())
+        ref = w.grad
+        run = lambda: hip.deconv5x5s2_wgrad(x.to(DEV), dy.to(DEV))  # noqa: E731
+    err = {}
+    try:
+        for mode in (0, 1):
+            _lib.call('gx_wgq_ring', mode)
+            got = run()
+            if mode == 1:
+                assert torch.equal(got, run())
+            err[mode] = float((got.double().cpu() - ref).norm() / ref.norm())
+    finally:
+        _lib.call('gx_wgq_ring', 1)
+    print('%s N=%d %d->%d @%d: relative L2 error 64-pixel tiles %.3e, row-ring tiles %.3e' % (kind, N, Cin, Cout, S, err[0], err[1]))
+    assert err[1] <= 1.5 * err[0] + 1e-7 and err[1] < 1e-4, err
