@@ -48,6 +48,9 @@ def parse():
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of HIP-graph replay')
     ap.add_argument('--profile-steps', type=int, default=3)
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the CPU baseline leg (0 = skip)')
+    ap.add_argument('--fp32-pipe-steps', type=int, default=30,
+                    help='extra leg on rank 0 at N=1: steps with every product on the fp32 matrix pipe (gx_wgq_precision(0), '
+                         'gx_kq_precision(0)), reported as value_fp32_pipe_only, never as value; 0 = skip')
     ap.add_argument('--host-input-steps', type=int, default=100,
                     help='extra leg on rank 0 at N=1: steps fed from uint8 frames in host memory through the PCIe feeder '
                          '(reported as pcie_inclusive, never as value; 0 = skip)')
@@ -90,10 +93,10 @@ def pmc_traffic(kernel):
     FETCH_SIZE / WRITE_SIZE in separate runs of this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM');
     None if absent."""
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
-    path = next((p_ for p_ in (os.path.join(here, 'r02_pmc_hbm_traffic.json'), os.path.join(here, 'pmc_hbm_traffic.json'))
+    path = next((p_ for p_ in (os.path.join(here, 'r03_pmc_hbm_traffic.json'), os.path.join(here, 'r02_pmc_hbm_traffic.json'))
                  if os.path.exists(p_)), None)
     if path is None:
-        return None
+        return None, None
     data = json.load(open(path))
     syms = tuple(s_.replace(',', '') for s_ in KID_SYMBOLS.get(kernel, (kernel,)))
     tot, n = 0.0, 0
@@ -101,11 +104,12 @@ def pmc_traffic(kernel):
         if any(name.replace(', ', ',').startswith(s_) for s_ in syms):
             tot += v['hbm_bytes_per_launch_corrected'] * v['launches']
             n += v['launches']
-    return tot / n if n else None
+    return (tot / n if n else None), os.path.basename(path)
 
 
 # profiling ids (gx_profile_kernel_name) -> kernel symbols of the rocprofv3 CSV that are launched under that id
 KID_SYMBOLS = {
+    'wgq_stream_kernel': ('wgq_stream_kernel',), 'kq_dth_kernel': ('kq_dth_kernel',), 'kq_dgh_kernel': ('kq_dgh_kernel',),
     'wgrad_kernel<0>': ('wgq_stream_kernel', 'wgq_kernel<0,', 'wgrad_fast_kernel<0,', 'wgrad_kernel<0>', 'wgrad_smallcin_kernel'),
     'wgrad_kernel<1>': ('wgq_kernel<1,', 'wgrad_fast_kernel<1,', 'wgrad_kernel<1>', 'wgrad_deconv_kernel'),
     'wgrad_kernel<3>': ('wgq_kernel<2,', 'wgrad_fast_kernel<3,', 'wgrad_kernel<3>'),
@@ -121,10 +125,12 @@ def rocprof_avg_us(kid_name):
     """Average launch duration of the kernels behind a profiling id in the committed rocprofv3 --kernel-trace --stats
     summary of this same command (profiles/r02_rocprofv3_kernel_stats.csv); None if absent."""
     import csv
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_rocprofv3_kernel_stats.csv')
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
+    path = next((p_ for p_ in (os.path.join(here, 'r03_rocprofv3_kernel_stats.csv'), os.path.join(here, 'r02_rocprofv3_kernel_stats.csv'))
+                 if os.path.exists(p_)), None)
     syms = KID_SYMBOLS.get(kid_name)
-    if not os.path.exists(path) or not syms:
-        return None
+    if path is None or not syms:
+        return None, None
     tot = calls = 0.0
     with open(path) as f:
         rows = csv.DictReader(l for l in f if not l.startswith('#'))
@@ -132,7 +138,19 @@ def rocprof_avg_us(kid_name):
             name = r['Name'].replace('(anonymous namespace)::', '').replace('void ', '')
             if any(name.startswith(s_) for s_ in syms):
                 tot += float(r['TotalDurationNs']); calls += float(r['Calls'])
-    return tot / calls / 1e3 if calls else None
+    return (tot / calls / 1e3 if calls else None), os.path.basename(path)
+
+
+def port_vs_reference():
+    """profiles/cpu_port_vs_reference.json, written by tools/cpu_ratio.py in the build container (the reference cannot
+    travel to the GPU box): reference step time / oracle step time on one host, same weights, batch and threads."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'cpu_port_vs_reference.json')
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    return {'value': d['port_vs_reference_speed_ratio'], 'source': 'profiles/cpu_port_vs_reference.json (tools/cpu_ratio.py, '
+            'build container, %d threads, batch %d): reference %.2f s / oracle %.2f s per step'
+            % (d['threads'], d['batch'], min(d['reference_s_per_step']), min(d['oracle_s_per_step']))}
 
 
 def cpu_baseline(args):
@@ -191,9 +209,8 @@ def cpu_baseline(args):
     return {'value': args.batch * n / dt, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
             'single_thread_images_per_sec': one,
             'single_thread_sample': 'one step on %d images, 1 thread' % max(1, args.batch // 8) if one else None,
-            # measured in the build container (the reference cannot travel): oracle in reference form vs the imported
-            # reference, same weights / inputs / threads, B=32 K=7 64x64: 3.12 s vs 3.12 s per step
-            'port_vs_reference_speed_ratio': 1.00,
+            # measured in the build container (the reference cannot travel) by tools/cpu_ratio.py: not a number of this run
+            'port_vs_reference_speed_ratio': port_vs_reference(),
             'sample': '%d timed steps (after 1 warm-up and a %s-thread probe) of the full training step, batch %d, '
                       'K=%d, %dx%d, oracle in reference-equivalent form (per-slot loops, K-fold feat_head), torch CPU '
                       'fp32, %d threads (best of the probe) on a %d-CPU host'
@@ -262,7 +279,8 @@ def main():
                                        'genesis': 'GENESIS (genesis_config)', 'vae': 'BaselineVAE (vae_config)'}[args.model],
                                       args.K, args.img, args.img, args.feat_dim, args.batch),
                        'global_batch': world * args.batch, 'per_gpu_batch': args.batch,
-                       'parallelism': 'dp%d' % world, 'launch': ('hip-graph' if not ts._split else 'hip-graph(fwd+bwd) | rccl all-reduce | hip-graph(geco+adam)')
+                       'parallelism': 'dp%d' % world, 'launch': (('hip-graph (rccl all-reduce captured inside)' if getattr(ts, 'collective_in_graph', False) else 'hip-graph')
+                                  if not ts._split else 'hip-graph(fwd+bwd) | rccl all-reduce | hip-graph(geco+adam)')
                        if ts.graph is not None else 'eager'},
             'final_elbo': elbo,
         }
@@ -272,6 +290,8 @@ def main():
                                     'products on the bf16 matrix pipe (hi+mid+lo pieces hold all 24 mantissa bits: error vs '
                                     'fp64 as on the fp32 pipe, tests/test_kernels_gpu.py *_bf16_pipe_*); everything else on the '
                                     'fp32 pipe; GENESIS_WGQ_BF16X6=0 GENESIS_KQ_BF16X6=0 put all of it back there')
+        if getattr(ts, 'capture_fallback_reason', None):
+            result['config']['collective_capture_fallback'] = ts.capture_fallback_reason
         if dist.is_initialized():
             # what the step exchanged: ONE sum all-reduce of the flat fp32 bucket (gradients + err / kl + the fp64
             # gradient as float triples [+ averaged buffers]) over the ranks the process group actually has
@@ -307,7 +327,9 @@ def main():
             ach = dom['flops'] / sec / 1e12
             mfma_peak = PEAK_FP32_MFMA_TFLOPS
             roof = {'bound': 'mfma', 'kernel': dom['name'], 'achieved': ach, 'peak': mfma_peak, 'unit': 'TFLOP/s'}
-            if dom['name'].startswith('wgrad_kernel') and os.environ.get('GENESIS_WGQ_BF16X6', '1') != '0':
+            on_bf16 = (dom['name'] == 'wgq_stream_kernel' and os.environ.get('GENESIS_WGQ_BF16X6', '1') != '0') or \
+                      (dom['name'] in ('kq_dth_kernel', 'kq_dgh_kernel') and os.environ.get('GENESIS_KQ_BF16X6', '1') != '0')
+            if on_bf16:
                 # `achieved` counts the algorithmic fp32 flops; the kernel executes six bf16 MFMA products for each of them,
                 # so its ceiling is the bf16 pipe's dense peak / 6 -- a higher one than the fp32 pipe's 157.3 TF/s
                 mfma_peak = PEAK_BF16_MFMA_TFLOPS / BF16X6_TERMS
@@ -328,17 +350,27 @@ def main():
             roof['algorithm'] = 'Winograd F(2x2,3x3): 1/2.25 of the algorithmic flops are executed on the MFMA pipe'
             roof['achieved_on_mfma_pipe'] = ach / 2.25
             roof['frac_on_mfma_pipe'] = ach / 2.25 / PEAK_FP32_MFMA_TFLOPS
-        rp = rocprof_avg_us(dom['name'])
+        roof['frac_of_fp32_pipe'] = ach / PEAK_FP32_MFMA_TFLOPS if dom['flops'] > 0 else None
+        # numbers that are NOT of this run: read from the committed rocprofv3 / PMC passes of the same command
+        rp, rp_file = rocprof_avg_us(dom['name'])
+        tr, tr_file = pmc_traffic(dom['name'])
+        committed = {}
         if rp:
-            roof['rocprof_avg_launch_us'] = rp
-            roof['frac_from_rocprof'] = (dom['flops'] if dom['flops'] > 0 else dom['bytes']) / dom['launches'] / \
+            committed['rocprof_avg_launch_us'] = rp
+            committed['frac_from_rocprof'] = (dom['flops'] if dom['flops'] > 0 else dom['bytes']) / dom['launches'] / \
                 (rp * 1e-6) / ((roof['peak'] * 1e12) if dom['flops'] > 0 else (PEAK_HBM_GBS * 1e9))
-        roof.update({'traffic': pmc_traffic(dom['name']), 'traffic_unit': 'bytes/launch (PMC, separate pass)',
+            committed['rocprof_source'] = 'profiles/' + rp_file
+        if tr:
+            committed['traffic_source'] = 'profiles/' + tr_file
+        roof.update({'traffic': tr, 'traffic_unit': 'bytes/launch (PMC, separate pass; committed profile, not this run)',
+                     'committed_profile': committed,
                      'algorithmic_bytes_per_launch': dom['bytes'] / dom['launches'],
                      'avg_launch_us': 1e3 * dom['ms'] / dom['launches'],
                      'launches_per_step': dom['launches'] / args.profile_steps,
                      'share_of_kernel_time': dom['ms'] / total_ms,
-                     'kernel_ms_per_step': total_ms / args.profile_steps})
+                     'kernel_ms_per_step_eager': total_ms / args.profile_steps,
+                     'timing': 'HIP events around every launch, EAGER steps of this process (the timed region above '
+                               'replays one HIP graph: its ms_per_step is shorter than the eager kernel sum)'})
         result['roofline'] = roof
         result['kernels'] = table[:12]
 
@@ -370,6 +402,35 @@ def main():
                                     'input': 'uint8 HWC frames in host memory -> pinned staging -> async copy one batch '
                                              'ahead -> one uint8->fp32 NCHW launch (genesis_amd/feeder.py); best of %d '
                                              'segments of %d steps' % (n_seg, args.host_input_steps)}
+
+    # ---- fp32-pipe-only leg: the same step with the bf16-pipe kernels (six bf16 piece products per fp32 product) switched
+    #      back to v_mfma_f32_32x32x2_f32; a second TrainStep (own HIP graph) on the same model.  Last GPU leg: it re-flattens
+    #      the parameters.
+    if rank == 0 and world == 1 and args.fp32_pipe_steps > 0 and args.model == 'genesisv2' and not args.no_graph and \
+            os.environ.get('GENESIS_WGQ_BF16X6', '1') != '0' and os.environ.get('GENESIS_KQ_BF16X6', '1') != '0':
+        from genesis_amd import _lib
+        ts.close()
+        _lib.call('gx_wgq_precision', 0)
+        _lib.call('gx_kq_precision', 0)
+        try:
+            ts2 = TrainStep(model, args.img, lr=1e-4, graph=True)
+            ts2.prepare(batches[0])
+            for i in range(5):
+                ts2.step(batches[i % 4])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.fp32_pipe_steps):
+                ts2.step(batches[i % 4])
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t0
+            result['value_fp32_pipe_only'] = {'value': args.batch * args.fp32_pipe_steps / dt2, 'unit': 'images/sec',
+                                              'steps': args.fp32_pipe_steps, 'ms_per_step': 1e3 * dt2 / args.fp32_pipe_steps,
+                                              'arithmetic': 'every product on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32): '
+                                                            'gx_wgq_precision(0), gx_kq_precision(0)'}
+            ts2.close()
+        finally:
+            _lib.call('gx_wgq_precision', 1)
+            _lib.call('gx_kq_precision', 1)
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0 and args.model == 'genesisv2':
         result['cpu_baseline'] = cpu_baseline(args)

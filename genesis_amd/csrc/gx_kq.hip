@@ -830,7 +830,7 @@ int gx_kq_deconv_fwd_h_launch(const float* in, const float* wp0, const float* wp
     dim3 grid(1, gx_ceil_div(M, 64), 2);
     g.nfull = q_split_tail(g.tiles_h * g.tiles_w * gx_ceil_div(N, 1 << g.lG), M, &grid.x);
     {
-        GxProf pf(KID_TAPCONV_DT0, s, 2.0 * N * (double)M * K * 25 * Hb * Wb,
+        GxProf pf(KID_KQ_DTH, s, 2.0 * N * (double)M * K * 25 * Hb * Wb,
                   4.0 * ((double)N * K * Hb * Wb + (double)N * M * 4 * Hb * Wb + 25.0 * K * M));
         static bool a[2] = {false, false};
         if (st) { q_set_attr(&kq_dth_kernel<3, true>, &a[0]); hipLaunchKernelGGL((kq_dth_kernel<3, true>), grid, dim3(256), lds, s, in, wp0, wp1, bias, out, g); }
@@ -856,7 +856,7 @@ int gx_kq_deconv_dgrad_h_launch(const float* dy, const float* wp, float* dx, int
     dim3 grid(1, gx_ceil_div(M, 64));
     g.nfull = q_split_tail(g.tiles_h * g.tiles_w * gx_ceil_div(N, 1 << g.lG), M, &grid.x);
     {
-        GxProf pf(KID_TAPCONV_DG, s, 2.0 * N * (double)M * K * 25 * Hb * Wb,
+        GxProf pf(KID_KQ_DGH, s, 2.0 * N * (double)M * K * 25 * Hb * Wb,
                   4.0 * ((double)N * K * 4 * Hb * Wb + (double)N * M * Hb * Wb + 25.0 * K * M));
         static bool a3 = false;
         q_set_attr(&kq_dgh_kernel<3>, &a3);

@@ -1239,7 +1239,7 @@ int wgq_launch_stream(std::vector<PendingJob*>& jobs, hipStream_t s, std::vector
             tab.times = d_times;
         }
         {
-            GxProf pf(KID_WGRAD_C3, s, flops, bytes);
+            GxProf pf(KID_WGQ_STREAM, s, flops, bytes);
             hipLaunchKernelGGL(wgq_stream_kernel, dim3(G), dim3(256), 160 * 1024, s, tab, zeros);
         }
         GX_CHECK_LAUNCH("wgq (stream-K weight gradients)");

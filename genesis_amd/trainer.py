@@ -256,7 +256,33 @@ class TrainStep(object):
                 self._out = self._iteration(self._static_x)
         torch.cuda.current_stream().wait_stream(side)
         self._split = self._needs_collective()
-        if not self._split:
+        self.collective_in_graph = False
+        if self._split and os.environ.get('GENESIS_GRAPH_ALLREDUCE', '1') != '0':
+            # several ranks, first choice: the collective INSIDE the one graph (RCCL enqueues on the captured stream): no
+            # host round trip between backward and optimiser.  If this ROCm / RCCL cannot capture it, fall back to the
+            # two-graph form below.
+            self._gscale = 1.0 / self.world
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                    self._begin()
+                    try:
+                        st = self._forward_backward(self._static_x)
+                        with torch.no_grad():
+                            self.bucket.pack64()
+                            self.bucket.all_reduce(self.pg, packed=True)
+                            self.bucket.unpack64(self._gscale)
+                            self._out = self._update(st, self._gscale)
+                    finally:
+                        self._end()
+                self.graph, self._split, self.collective_in_graph = g, False, True
+            except Exception as e:          # noqa: BLE001  (whatever the capture raised: the split form is always valid)
+                self.capture_fallback_reason = '%s: %s' % (type(e).__name__, str(e)[:200])
+                torch.cuda.synchronize()
+                self._grads_clean = False
+        if self.collective_in_graph:
+            pass
+        elif not self._split:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
                 self._out = self._iteration(self._static_x)

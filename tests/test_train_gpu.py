@@ -152,9 +152,11 @@ def test_weight_cache_matches_per_call_packing():
     assert float((a[1] - b[1]).norm() / b[1].norm()) < 2e-5
 
 
-def test_split_graph_with_rccl_allreduce_matches_single_graph(monkeypatch):
-    """Multi-rank launch mode on one GPU: forward+backward graph | RCCL all-reduce of the bucket | GECO+Adam graph
-    (world_size 1 process group, collective forced) must reproduce the single-graph trajectory bit for bit."""
+def test_rccl_allreduce_in_the_step_matches_single_graph(monkeypatch):
+    """Multi-rank launch modes on one GPU (world_size 1 process group, collective forced): (a) the RCCL all-reduce of the
+    bucket captured INSIDE the step's one HIP graph (first choice), (b) forward+backward graph | RCCL all-reduce | GECO+Adam
+    graph (GENESIS_GRAPH_ALLREDUCE=0, and the fallback when the capture is refused).  Both must reproduce the
+    single-graph trajectory bit for bit."""
     import torch.distributed as dist
     from genesis_amd.trainer import TrainStep
     gold = Golden('tiny')
@@ -171,12 +173,19 @@ def test_split_graph_with_rccl_allreduce_matches_single_graph(monkeypatch):
     dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29533', rank=0, world_size=1)
     try:
         ts = TrainStep(build(gold), gold.S, lr=1e-4, graph=True)
-        got = run(ts)
-        assert ts._split and ts.graph2 is not None
+        got_in = run(ts)
+        in_graph = ts.collective_in_graph
+        print('collective captured inside the graph:', in_graph, getattr(ts, 'capture_fallback_reason', ''))
+        assert in_graph or (ts._split and ts.graph2 is not None)
+        monkeypatch.setenv('GENESIS_GRAPH_ALLREDUCE', '0')
+        ts = TrainStep(build(gold), gold.S, lr=1e-4, graph=True)
+        got_split = run(ts)
+        assert ts._split and ts.graph2 is not None and not ts.collective_in_graph
     finally:
         dist.destroy_process_group()
-    assert torch.equal(ref[0], got[0])
-    assert torch.equal(ref[1], got[1])
+    for got in (got_in, got_split):
+        assert torch.equal(ref[0], got[0])
+        assert torch.equal(ref[1], got[1])
 
 
 def test_checkpoint_is_the_reference_wire_format(tmp_path):
