@@ -257,7 +257,8 @@ class TrainStep(object):
         torch.cuda.current_stream().wait_stream(side)
         self._split = self._needs_collective()
         self.collective_in_graph = False
-        if self._split and os.environ.get('GENESIS_GRAPH_ALLREDUCE', '1') != '0':
+        # (only RCCL enqueues on the captured stream; a gloo collective inside a capture invalidates it for good)
+        if self._split and os.environ.get('GENESIS_GRAPH_ALLREDUCE', '1') != '0' and dist.get_backend(self.pg) == 'nccl':
             # several ranks, first choice: the collective INSIDE the one graph (RCCL enqueues on the captured stream): no
             # host round trip between backward and optimiser.  If this ROCm / RCCL cannot capture it, fall back to the
             # two-graph form below.
