@@ -219,6 +219,10 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
+    # the driver reads ONE JSON line from stdout; RCCL prints a version banner there when its first communicator is made:
+    # everything but the result line goes to stderr
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -436,7 +440,8 @@ def main():
         result['cpu_baseline'] = cpu_baseline(args)
         result['speedup_vs_cpu_baseline'] = result['value'] / result['cpu_baseline']['value']
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(result) + '\n').encode())
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
