@@ -11,6 +11,10 @@ from . import functions as fn
 from .functions import _gout, _ret, ctx_bound
 
 
+def _pow2(n):
+    return n > 0 and (n & (n - 1)) == 0
+
+
 def vae_geometry(img_size):
     """VAE.py:56-69 -> (last_kernel_size, strides)."""
     table = {32: (8, [1, 2, 1, 2, 1]), 64: (16, [1, 2, 1, 2, 1]), 128: (16, [2, 2, 2, 1, 1]), 256: (16, [2, 2, 2, 2, 1])}
@@ -153,30 +157,43 @@ class DirectConvFn(torch.autograd.Function):
     def forward(ctx, x, w, kind, stride, pad, out_pad):
         x = x.contiguous()
         k = w.shape[2]
+        H, W = x.shape[2], x.shape[3]
+        # the stride-2 5x5 layers of the gated stacks (VAE.py:18-33: k 5, pad 2, output_padding 1) are exactly the
+        # GENESIS-V2 decoder's transposed conv and its data gradient: they run on those MFMA kernels (gx_deconv5x5s2_*,
+        # weight gradients in the step's stream-K launch) instead of the generic implicit-GEMM kernels
+        fast = k == 5 and stride == 2 and pad == 2 and _pow2(H) and _pow2(W) and min(H, W) >= 4 and \
+            (out_pad == 1 if kind == 'deconv' else True)
         if kind == 'conv':
-            y = hip.conv2d_direct_fwd(x, w, None, None, stride, pad)
+            y = hip.deconv5x5s2_dgrad(x, w) if fast else hip.conv2d_direct_fwd(x, w, None, None, stride, pad)
         else:
-            H, W = x.shape[2], x.shape[3]
             Ho, Wo = (H - 1) * stride - 2 * pad + k + out_pad, (W - 1) * stride - 2 * pad + k + out_pad
-            y = hip.conv2d_direct_dgrad(x, w, Ho, Wo, stride, pad)
+            y = hip.deconv5x5s2_fwd(x, w, None) if fast else hip.conv2d_direct_dgrad(x, w, Ho, Wo, stride, pad)
         ctx.save_for_backward(x)
         ctx.w = w
-        ctx.cfg = (kind, stride, pad, k)
+        ctx.cfg = (kind, stride, pad, k, fast)
         return y
 
     @staticmethod
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
         w = ctx.w
-        kind, stride, pad, k = ctx.cfg
+        kind, stride, pad, k, fast = ctx.cfg
         g = g.contiguous()
         ow = _gout(w)
-        if kind == 'conv':
+        need_dx = ctx.needs_input_grad[0]
+        if fast and kind == 'conv':
+            # conv s2 = the transposed conv's data gradient with (x, dy) in each other's roles
+            dw = hip.deconv5x5s2_wgrad(g, x, out=ow)
+            dx = hip.deconv5x5s2_fwd(g, w, None) if need_dx else None
+        elif fast:
+            dw = hip.deconv5x5s2_wgrad(x, g, out=ow)
+            dx = hip.deconv5x5s2_dgrad(g, w) if need_dx else None
+        elif kind == 'conv':
             dw = hip.conv2d_direct_wgrad(x, g, k, stride, pad, out=ow)
-            dx = hip.conv2d_direct_dgrad(g, w, x.shape[2], x.shape[3], stride, pad) if ctx.needs_input_grad[0] else None
+            dx = hip.conv2d_direct_dgrad(g, w, x.shape[2], x.shape[3], stride, pad) if need_dx else None
         else:
             dw = hip.conv2d_direct_wgrad(g, x, k, stride, pad, out=ow)
-            dx = hip.conv2d_direct_fwd(g, w, None, None, stride, pad) if ctx.needs_input_grad[0] else None
+            dx = hip.conv2d_direct_fwd(g, w, None, None, stride, pad) if need_dx else None
         return dx, _ret(ow, dw), None, None, None, None
 
 
