@@ -173,6 +173,9 @@ int gx_wgq_c3(const float* x, const float* dy, float* dw, int N, int Cin, int Co
               hipStream_t s);
 int gx_wgq_deconv(const float* x, const float* dy, float* dw, int N, int Cin, int Cout, int Hb, int Wb, float* ws,
                   int ws_slabs, hipStream_t s);
+bool gx_wgq_c5_eligible(int N, int CA, int CB, int H, int W);
+int gx_wgq_c5(const float* a, const float* b, float* dw, int N, int CA, int CB, int H, int W, float* ws, int ws_slabs,
+              hipStream_t s);
 int gx_wgq_pending(void);
 void gx_wgq_discard(void);
 int gx_wgq_flush(hipStream_t s);

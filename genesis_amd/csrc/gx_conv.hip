@@ -1085,6 +1085,8 @@ wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, i
         if (ns0 > 0) {
             const int cls = ((t / 5) & 1) * 2 + ((t % 5) & 1);
             nsplit = cls == 0 ? ns0 : (cls == 1 ? ns1 : (cls == 2 ? ns2 : ns3));
+        } else if (ns0 < 0) {
+            nsplit = t < 15 ? ns1 : ns2;          // 5 x 5 stride-1 conv: kernel rows 0-2 and 3-4 were two jobs (gx_wgq_c5)
         }
         const size_t stride = (size_t)Ttot * CApad * CBpad;
         const float* p = partial + ((size_t)t * CApad + ca) * CBpad + cb;
@@ -1129,6 +1131,8 @@ wgrad_reduce_batch_kernel(const WgradRedTable tab) {
         if (r.ns0 > 0) {
             const int cls = ((t / 5) & 1) * 2 + ((t % 5) & 1);
             nsplit = cls == 0 ? r.ns0 : (cls == 1 ? r.ns1 : (cls == 2 ? r.ns2 : r.ns3));
+        } else if (r.ns0 < 0) {
+            nsplit = t < 15 ? r.ns1 : r.ns2;      // 5 x 5 stride-1 conv: kernel rows 0-2 | 3-4
         }
         const size_t stride = (size_t)r.Ttot * r.CApad * r.CBpad;
         const float* p = r.partial + ((size_t)t * r.CApad + ca) * r.CBpad + cb;
@@ -2011,6 +2015,25 @@ int gx_conv3x3_wgrad(const float* x, const float* dy, float* dw, int N, int Cin,
     rc = launch_wgrad<W_C3>(dy, x, (float*)ws, pl, s, "gx_conv3x3_wgrad");
     if (rc) return rc;
     return launch_wgrad_reduce((const float*)ws, dw, pl, 0, s);
+}
+
+/* 5 x 5 stride-1 pad-2 weight gradient on the row-ring tiles of the bf16 pipe (gx_wgq.hip): dw [CA][CB][5][5] =
+ * sum_{n,p} a[n][CA][p] * b[n][CB][p + (kh - 2, kw - 2)]; Conv2d: a = dy, b = x (dw [Cout][Cin]); ConvTranspose2d stride 1:
+ * a = x, b = dy (dw [Cin][Cout]). */
+int gx_conv5x5_wgrad_supported(int N, int CA, int CB, int H, int W) { return gx_wgq_c5_eligible(N, CA, CB, H, W) ? 1 : 0; }
+
+size_t gx_conv5x5_wgrad_ws_bytes(int N, int CA, int CB, int H, int W) {
+    (void)N; (void)H; (void)W;
+    return (size_t)gx_wgq_max_split(CA, CB) * 25 * gx_round_up(CA, 64) * gx_round_up(CB, 64) * sizeof(float);
+}
+
+int gx_conv5x5_wgrad(const float* a, const float* b, float* dw, int N, int CA, int CB, int H, int W, void* ws,
+                     size_t ws_bytes, gx_stream_t stream) {
+    GX_CHECK_ARG(a && b && dw && ws, "gx_conv5x5_wgrad: null pointer");
+    GX_CHECK_ARG(gx_wgq_c5_eligible(N, CA, CB, H, W), "gx_conv5x5_wgrad: shape not supported (rows of 32 / 64 pixels, power-of-two "
+                                                       "height >= 4, bf16-pipe row-ring tiles on)");
+    const size_t slab = (size_t)25 * gx_round_up(CA, 64) * gx_round_up(CB, 64) * sizeof(float);
+    return gx_wgq_c5(a, b, dw, N, CA, CB, H, W, (float*)ws, (int)(ws_bytes / slab), (hipStream_t)stream);
 }
 
 static size_t deconv_pack_floats(int Cin, int Cout) {

@@ -32,7 +32,7 @@
 
 namespace {
 
-enum { WQ_C3 = 0, WQ_DR0 = 1, WQ_DR1 = 2 };
+enum { WQ_C3 = 0, WQ_DR0 = 1, WQ_DR1 = 2, WQ_C5A = 3, WQ_C5B = 4 };
 
 template <int CLS> struct WqTap;
 template <> struct WqTap<WQ_C3> {
@@ -56,6 +56,25 @@ template <int PA_> struct WqTapDR {
 };
 template <> struct WqTap<WQ_DR0> : WqTapDR<0> {};
 template <> struct WqTap<WQ_DR1> : WqTapDR<1> {};
+// 5 x 5 stride-1 pad-2 conv (the gated stacks of third_party/sylvester, VAE.py:18-33), row-ring tiles only:
+// dW[a][b][kh][kw] = sum_p A[a][p] * B[b][p + (kh - 2, kw - 2)].  Kernel rows 0..2 (15 taps) and 3..4 (10 taps) are two
+// jobs, as the two output-row parities of the transposed conv are (15 / 10 taps = 240 / 160 accumulator registers).
+// ro(t) = kh; the x row of tap row index rr = ro - RO0 is r + RO0 + rr - 1, i.e. RO0 = -1: rows r-2..r; RO0 = 2: r+1, r+2.
+template <int HALF> struct WqTapC5 {
+    static constexpr int KH0 = HALF ? 3 : 0, NKH = HALF ? 2 : 3;
+    static constexpr int NT = NKH * 5, SA = 1, PA = 0, NPB = 1, NRO = NKH, RO0 = HALF ? 2 : -1;
+    __host__ __device__ static constexpr int kh(int t) { return KH0 + t / 5; }
+    __host__ __device__ static constexpr int ro(int t) { return RO0 + t / 5; }
+    __host__ __device__ static constexpr int co(int t) { return t % 5; }
+    __host__ __device__ static constexpr int pb(int) { return 0; }
+    __host__ __device__ static constexpr int gt(int t) { return kh(t) * 5 + t % 5; }
+};
+template <> struct WqTap<WQ_C5A> : WqTapC5<0> {};
+template <> struct WqTap<WQ_C5B> : WqTapC5<1> {};
+// column variants of a class: co = 0 .. NCOV-1 <-> shift s = co + CS0 of the dy operand against the aligned x octet
+template <int CLS> struct WqCols { static constexpr int NCOV = 3, CS0 = -1; };
+template <> struct WqCols<WQ_C5A> { static constexpr int NCOV = 5, CS0 = -2; };
+template <> struct WqCols<WQ_C5B> { static constexpr int NCOV = 5, CS0 = -2; };
 
 struct WqJob {
     const float* a;      // dy [N, CA, SA*Hb, SA*Wb]
@@ -377,7 +396,8 @@ __device__ __forceinline__ void wq_segment(const float* a, const float* b, const
 //     beyond either end of the row is the layer's zero padding;
 //   * x rows live in a ring of four LDS slots that rolls down the images: tile t = image * H + row keeps its x row in slot
 //     t & 3 (H is a multiple of 4), stepping to the next tile brings in ONE new x row (it serves three consecutive
-//     tiles) and one new dy row; at an image's first / last row the row above / below is padding: those reads are
+//     tiles; the 5 x 5 classes look two rows up or down) and one new dy row; at an image's first / last rows the
+//     rows above / below are padding: those reads are
 //     redirected (a wave-uniform select of the read address) to a zero piece kept behind every plane of the ring;
 //   * global -> registers -> three bf16 planes (hi / mid / lo, 8 pixels = one 16-byte piece) -> LDS: every value is
 //     split exactly once, by the thread that loaded it; ~5.5 VALU per value, ~0.8 per MFMA;
@@ -398,6 +418,9 @@ typedef const __attribute__((address_space(1))) f32x4* gx_gptr4;
 template <int CLS, int W> struct WrGeo {
     using WT = WqTap<CLS>;
     static constexpr int SA = WT::SA, NPB = WT::NPB, NT = WT::NT, NRO = WT::NRO, RO0 = WT::RO0;
+    static constexpr int NCOV = WqCols<CLS>::NCOV, CS0 = WqCols<CLS>::CS0;
+    static constexpr int DMIN = RO0 - 1, DMAX = RO0 + NRO - 2;   // x rows r + DMIN .. r + DMAX feed tile r
+    static_assert(DMAX - DMIN + 2 <= 4, "the rows in use plus the one being fetched must fit the four ring slots");
     static constexpr int OPR = W / 8;                          // octets (16-byte pieces) per base row
     static constexpr int NG = W / 16;                          // MFMA k-groups per tile (16 pixels each)
     static constexpr int UPT = OPR / 4;                        // (channel, octet) units per thread: 64 * OPR / 256
@@ -555,7 +578,7 @@ template <int CLS, int W> struct WrStep {
 template <int CLS, int W> struct WrTileState {
     using G = WrGeo<CLS, W>;
     WrRaw<CLS, W> raw;
-    WqB3 av[2][G::NPB][3];          // A variants of the current / the next k-group
+    WqB3 av[2][G::NPB][G::NCOV];    // A variants of the current / the next k-group
     WqB3 bq[2];                     // B operand of the current / the next unit
     float r[8];                     // the octet being split: value, then residuals
     unsigned hp[4], mp[4], lp[4];   // its packed bf16 planes
@@ -613,24 +636,31 @@ __device__ __forceinline__ void wr_read_a1(const char* lds, const WrT<CLS, W>& w
     r.nx[par][pl] = *reinterpret_cast<const unsigned*>(p + 16);
 }
 
-// variants by column offset co = s + 1: co 1 aligned, co 2 (s = +1) shifted right, co 0 (s = -1) shifted left;
-// piece = (parity, plane, which shift)
+// variants by column offset co = s - CS0 (conv3x3 / transposed conv: co 1 aligned, co 2 (s = +1) shifted right, co 0
+// (s = -1) shifted left; 5 x 5: co 2 aligned, and s = +-2 are whole-register shifts); piece = (parity, plane, which side)
 __device__ __forceinline__ gx_bf16x8 wr_bf(const gx_u32x4& v) { return __builtin_bit_cast(gx_bf16x8, v); }
 template <int CLS, int W>
-__device__ __forceinline__ void wr_shift_a1(const WrRaw<CLS, W>& r, WqB3 (&av)[WrGeo<CLS, W>::NPB][3], int par, int pl, int right) {
+__device__ __forceinline__ void wr_shift_a1(const WrRaw<CLS, W>& r, WqB3 (&av)[WrGeo<CLS, W>::NPB][WrGeo<CLS, W>::NCOV], int par,
+                                            int pl, int right) {
+    using G = WrGeo<CLS, W>;
+    constexpr int Z = -G::CS0;              // index of the aligned variant (s = 0)
     const gx_u32x4 c = r.c[par][pl];
-    gx_u32x4 o;
-    if (right)
-        o = gx_u32x4{__builtin_amdgcn_alignbit(c[0], r.pv[par][pl], 16), __builtin_amdgcn_alignbit(c[1], c[0], 16),
-                     __builtin_amdgcn_alignbit(c[2], c[1], 16), __builtin_amdgcn_alignbit(c[3], c[2], 16)};
-    else
-        o = gx_u32x4{__builtin_amdgcn_alignbit(c[1], c[0], 16), __builtin_amdgcn_alignbit(c[2], c[1], 16),
-                     __builtin_amdgcn_alignbit(c[3], c[2], 16), __builtin_amdgcn_alignbit(r.nx[par][pl], c[3], 16)};
-    WqB3& d = av[par][right ? 2 : 0];
-    WqB3& al = av[par][1];
-    if (pl == 0) { d.h = wr_bf(o); if (right) al.h = wr_bf(c); }
-    else if (pl == 1) { d.m = wr_bf(o); if (right) al.m = wr_bf(c); }
-    else { d.l = wr_bf(o); if (right) al.l = wr_bf(c); }
+    const unsigned pv = r.pv[par][pl], nx = r.nx[par][pl];
+    auto put = [&](int co, const gx_u32x4& v) {
+        WqB3& d = av[par][co];
+        if (pl == 0) d.h = wr_bf(v); else if (pl == 1) d.m = wr_bf(v); else d.l = wr_bf(v);
+    };
+    if (right) {
+        // s = +1: A[p - 1 ..]: the aligned octet funnel-shifted against its left neighbour's last pair
+        put(Z + 1, gx_u32x4{__builtin_amdgcn_alignbit(c[0], pv, 16), __builtin_amdgcn_alignbit(c[1], c[0], 16),
+                            __builtin_amdgcn_alignbit(c[2], c[1], 16), __builtin_amdgcn_alignbit(c[3], c[2], 16)});
+        put(Z, c);
+        if (G::NCOV == 5) put(Z + 2, gx_u32x4{pv, c[0], c[1], c[2]});         // s = +2: one pair = one register earlier
+    } else {
+        put(Z - 1, gx_u32x4{__builtin_amdgcn_alignbit(c[1], c[0], 16), __builtin_amdgcn_alignbit(c[2], c[1], 16),
+                            __builtin_amdgcn_alignbit(c[3], c[2], 16), __builtin_amdgcn_alignbit(nx, c[3], 16)});
+        if (G::NCOV == 5) put(Z - 2, gx_u32x4{c[1], c[2], c[3], nx});         // s = -2
+    }
 }
 
 template <int CLS, int W>
@@ -790,12 +820,12 @@ __device__ __forceinline__ void wr_segment(const float* a, const float* b, const
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
     f32x4 pa[G::UPT][2 * SA], pb[G::UPT][2];
-    // prologue: the x rows of tiles t0 - 1, t0, t0 + 1 (a neighbour in another image is never read by tile t0, but the
-    // one behind serves tile t0 + 1) and the dy row of t0
-    wr_fetch<CLS, W>(w, t0, t0 - 1, pa, pb);
-    wr_store<CLS, W, true, true>(lds, w, 0, ((t0 - 1) & 3) * G::B_ROW, pa, pb);
+    // prologue: the x rows of tiles t0 + DMIN .. t0 + DMAX (a neighbour in another image is never read by tile t0, but
+    // the ones behind serve tile t0 + 1) and the dy row of t0
+    wr_fetch<CLS, W>(w, t0, t0 + G::DMIN, pa, pb);
+    wr_store<CLS, W, true, true>(lds, w, 0, ((t0 + G::DMIN) & 3) * G::B_ROW, pa, pb);
 #pragma unroll 1
-    for (int k = 0; k <= 1; ++k) {
+    for (int k = G::DMIN + 1; k <= G::DMAX; ++k) {
         wr_fetch<CLS, W>(w, -1, t0 + k, pa, pb);
         wr_store<CLS, W, false, true>(lds, w, 0, ((t0 + k) & 3) * G::B_ROW, pa, pb);
     }
@@ -817,8 +847,8 @@ __device__ __forceinline__ void wr_segment(const float* a, const float* b, const
 #pragma unroll 1
     for (int t = t0; t < t1; ++t) {
         sp.abuf = sp.anxt; sp.anxt = G::A_BUF - sp.abuf;
-        sp.bnew = ((t + 2) & 3) * G::B_ROW;
-        sp.ta = t + 1 < t1 ? t + 1 : -1; sp.tb = t + 2;
+        sp.bnew = ((t + 1 + G::DMAX) & 3) * G::B_ROW;
+        sp.ta = t + 1 < t1 ? t + 1 : -1; sp.tb = t + 1 + G::DMAX;
 #pragma unroll
         for (int rr = 0; rr < NRO; ++rr) { sp.bs[rr] = sp.nbs[rr]; sp.zr[rr] = sp.nzr[rr]; }
         rows(t + 1, sp.nbs, sp.nzr);
@@ -875,6 +905,7 @@ struct WsJob {
     int CA, CB, ca0, cb0, Hb, Wb, tiles_h, tiles_w, ntiles, Ttot;
     int variant;                                         // class * 3 + (5 - log2 tile width); + 9: on the fp32 matrix pipe;
                                                          // 18..21: row-ring tiles (conv3x3 W 64 / 32, transposed conv rows 0 / 1 at W 32)
+                                                         // 22..25: row-ring tiles of the 5 x 5 stride-1 conv (rows 0-2 W 64 / 32, rows 3-4 W 64 / 32)
     int cost;                                            // units per tile
     int w_first;                                         // first workgroup with tiles of this block (slab 0)
     int N;                                               // images (the row-ring variants bound their virtual rows with it)
@@ -933,6 +964,7 @@ wgq_stream_kernel(const WsTable tab, const float* __restrict__ zeros) {
             GX_WS_CASE(3, WQ_DR0, 5) GX_WS_CASE(4, WQ_DR0, 4) GX_WS_CASE(5, WQ_DR0, 3)
             GX_WS_CASE(6, WQ_DR1, 5) GX_WS_CASE(7, WQ_DR1, 4) GX_WS_CASE(8, WQ_DR1, 3)
             GX_WR_CASE(18, WQ_C3, 64) GX_WR_CASE(19, WQ_C3, 32) GX_WR_CASE(20, WQ_DR0, 32) GX_WR_CASE(21, WQ_DR1, 32)
+            GX_WR_CASE(22, WQ_C5A, 64) GX_WR_CASE(23, WQ_C5A, 32) GX_WR_CASE(24, WQ_C5B, 64) GX_WR_CASE(25, WQ_C5B, 32)
             default: break;
         }
 #undef GX_WS_CASE
@@ -1091,9 +1123,10 @@ bool wgq_stream_on() {
 // wgrad3:256:64 wgrad3:2048:16 wgrad3:8192:8 wgrad:256:32 wgrad:1024:16 wgrad:4096:8: 10.3 us per conv3x3 tile, 26.5 us per
 // pair of transposed-conv row-parity tiles, split 15 a + b : 10 a + b), then nudged on the training step itself
 // (the stream kernel's duration over five vectors: 921 .. 972 us); GENESIS_WGQ_COST="c0,...,c8" overrides
-int g_ws_cost[22] = {10200, 9580, 10680, 15080, 21000, 11800, 11400, 8800, 9700,              // bf16 pipe (measured with
+int g_ws_cost[26] = {10200, 9580, 10680, 15080, 21000, 11800, 11400, 8800, 9700,              // bf16 pipe (measured with
                      10200, 10600, 11200, 16000, 16500, 18200, 11600, 12000, 13300,           // GENESIS_WGQ_TIMES) | fp32 pipe
-                     4840, 2450, 4150, 2900};                                                 // row-ring tiles (one base row)
+                     4840, 2450, 4150, 2900,                                                  // row-ring tiles (one base row)
+                     8000, 4100, 5400, 2800};                                                 // ... of the 5 x 5 stride-1 conv
 bool g_ws_cost_init = false;
 void ws_cost_init() {
     if (g_ws_cost_init) return;
@@ -1123,6 +1156,7 @@ bool wgq_ring_on() {
 int ws_ring_variant(int cls, int Hb, int Wb) {
     if (!wgq_b6() || !wgq_ring_on() || Hb < 4) return -1;          // (H a multiple of 4: the ring slot of a row is tile & 3)
     if (cls == WQ_C3) return Wb == 64 ? 18 : (Wb == 32 ? 19 : -1);
+    if (cls == WQ_C5A || cls == WQ_C5B) return Wb == 64 ? (cls == WQ_C5A ? 22 : 24) : (Wb == 32 ? (cls == WQ_C5A ? 23 : 25) : -1);
     if (Wb != 32) return -1;
     return cls == WQ_DR0 ? 20 : 21;
 }
@@ -1178,8 +1212,8 @@ int wgq_launch_stream(std::vector<PendingJob*>& jobs, hipStream_t s, std::vector
         for (; i_end < jobs.size(); ++i_end) {
             PendingJob& p = *jobs[i_end];
             const int nblk = (p.job.CApad / 64) * (p.job.CBpad / 64);
-            const bool pair = p.cls == WQ_DR0 && i_end + 1 < jobs.size() && jobs[i_end + 1]->cls == WQ_DR1 &&
-                              jobs[i_end + 1]->job.partial == p.job.partial;
+            const bool pair = (p.cls == WQ_DR0 || p.cls == WQ_C5A) && i_end + 1 < jobs.size() &&
+                              jobs[i_end + 1]->cls == p.cls + 1 && jobs[i_end + 1]->job.partial == p.job.partial;
             if (tab.njobs + nblk * (pair ? 2 : 1) > kMaxSJobs) break;
             for (int half = 0; half < (pair ? 2 : 1); ++half) {
                 PendingJob& q = *jobs[i_end + half];
@@ -1196,6 +1230,7 @@ int wgq_launch_stream(std::vector<PendingJob*>& jobs, hipStream_t s, std::vector
                     jb.variant = q.cls * 3 + (5 - q.ltw) + (wgq_b6() ? 0 : 9);
                     const int rv = ws_ring_variant(q.cls, q.job.Hb, q.job.Wb);
                     if (rv >= 0) { jb.variant = rv; jb.ntiles = q.job.N * q.job.Hb; }      // tile = one base row
+                    else if (q.cls >= WQ_C5A) { gx_set_error("wgq: the 5x5 classes exist as row-ring tiles only"); return GX_EINVAL; }
                     jb.cost = g_ws_cost[jb.variant];
                     jb.w_first = 0; jb.N = q.job.N;
                     tab.U += (long long)jb.ntiles * jb.cost;
@@ -1203,7 +1238,7 @@ int wgq_launch_stream(std::vector<PendingJob*>& jobs, hipStream_t s, std::vector
                 }
                 flops += q.flops;
                 bytes += 4.0 * ((double)q.job.N * q.job.CB * q.job.Hb * q.job.Wb +
-                                (double)q.job.N * q.job.CA * q.job.Hb * q.job.Wb * (q.cls == WQ_C3 ? 1 : 2));
+                                (double)q.job.N * q.job.CA * q.job.Hb * q.job.Wb * ((q.cls == WQ_DR0 || q.cls == WQ_DR1) ? 2 : 1));
             }
             if (pair) ++i_end;
         }
@@ -1272,10 +1307,10 @@ int wgq_launch_stream(std::vector<PendingJob*>& jobs, hipStream_t s, std::vector
         // reduce records: one per (layer, channel block); the two row parities of a transposed conv share the slabs
         for (int j = 0; j < tab.njobs; ++j) {
             PendingJob& q = *slots[j].p;
-            if (q.cls == WQ_DR1 && j > 0) {
+            if ((q.cls == WQ_DR1 || q.cls == WQ_C5B) && j > 0) {
                 bool paired = false;
                 for (int k = 0; k < j; ++k)
-                    paired = paired || (slots[k].p->cls == WQ_DR0 && slots[k].p->job.partial == q.job.partial);
+                    paired = paired || (slots[k].p->cls == q.cls - 1 && slots[k].p->job.partial == q.job.partial);
                 if (paired) continue;
             }
             const WsJob& jb = tab.job[j];
@@ -1284,14 +1319,16 @@ int wgq_launch_stream(std::vector<PendingJob*>& jobs, hipStream_t s, std::vector
             GxWgradRed r{jb.partial, q.dw, slots[j].nseg, jb.Ttot, ca_n, cb_n, 64, 64, q.layout, 0, 0, 0, 0,
                          jb.ca0, jb.cb0, q.job.CA, q.job.CB};
             if (q.cls != WQ_C3) {
-                int n0 = q.cls == WQ_DR0 ? slots[j].nseg : 0, n1 = q.cls == WQ_DR1 ? slots[j].nseg : 0;
+                const int c0 = q.cls >= WQ_C5A ? WQ_C5A : WQ_DR0;
+                int n0 = q.cls == c0 ? slots[j].nseg : 0, n1 = q.cls == c0 + 1 ? slots[j].nseg : 0;
                 for (int k = 0; k < tab.njobs; ++k)
                     if (k != j && tab.job[k].partial == jb.partial) {
-                        if (slots[k].p->cls == WQ_DR0) n0 = slots[k].nseg;
-                        if (slots[k].p->cls == WQ_DR1) n1 = slots[k].nseg;
+                        if (slots[k].p->cls == c0) n0 = slots[k].nseg;
+                        if (slots[k].p->cls == c0 + 1) n1 = slots[k].nseg;
                     }
-                // taps of a row parity the launch did not cover (never the case for gx_wgq_deconv) would read slab 0
-                r.ns0 = r.ns1 = n0 > 0 ? n0 : 1; r.ns2 = r.ns3 = n1 > 0 ? n1 : 1;
+                // taps of a row class the launch did not cover (never the case for gx_wgq_deconv / gx_wgq_c5) would read slab 0
+                if (c0 == WQ_DR0) { r.ns0 = r.ns1 = n0 > 0 ? n0 : 1; r.ns2 = r.ns3 = n1 > 0 ? n1 : 1; }
+                else { r.ns0 = -1; r.ns1 = n0 > 0 ? n0 : 1; r.ns2 = n1 > 0 ? n1 : 1; r.ns3 = 0; }     // 5 x 5: kernel rows 0-2 | 3-4
                 r.nsplit = n0 > n1 ? n0 : n1;
             }
             recs.push_back(r);
@@ -1377,6 +1414,31 @@ int gx_wgq_deconv(const float* x, const float* dy, float* dw, int N, int Cin, in
     p0.flops = 2.0 * N * (double)Cout * Cin * 15 * Hb * Wb;
     p1.flops = 2.0 * N * (double)Cout * Cin * 10 * Hb * Wb;
     p0.reduce_group = p1.reduce_group = -2;      // paired: resolved at flush by (dw, partial)
+    std::vector<PendingJob> v{p0, p1};
+    return wgq_run_or_queue(v, s);
+}
+
+// 5 x 5 stride-1 pad-2: dw [CA][CB][5][5] = sum_p a[CA][p] * b[CB][p + (kh - 2, kw - 2)]  (conv: a = dy, b = x -> [Cout][Cin];
+// ConvTranspose2d stride 1: a = x, b = dy -> [Cin][Cout])
+bool gx_wgq_c5_eligible(int N, int CA, int CB, int H, int W) {
+    WqJob jb; int ltw;
+    return wgq_mode() && wgq_stream_on() && ws_ring_variant(WQ_C5A, H, W) >= 0 &&
+           wgq_make_job(1, nullptr, nullptr, nullptr, N, CA, CB, H, W, 25, 1, &jb, &ltw);
+}
+int gx_wgq_c5(const float* a, const float* b, float* dw, int N, int CA, int CB, int H, int W, float* ws, int ws_slabs,
+              hipStream_t s) {
+    PendingJob p0, p1;
+    const int ms = ws_slabs < gx_wgq_max_split(CA, CB) ? ws_slabs : gx_wgq_max_split(CA, CB);
+    if (ms < 1 || !gx_wgq_c5_eligible(N, CA, CB, H, W) || !wgq_make_job(1, a, b, ws, N, CA, CB, H, W, 25, ms, &p0.job, &p0.ltw)) {
+        gx_set_error("wgq conv5x5: shape not eligible");
+        return GX_EINVAL;
+    }
+    p1 = p0;
+    p0.cls = WQ_C5A; p1.cls = WQ_C5B;
+    p0.dw = p1.dw = dw; p0.layout = p1.layout = 0;
+    p0.flops = 2.0 * N * (double)CA * CB * 15 * H * W;
+    p1.flops = 2.0 * N * (double)CA * CB * 10 * H * W;
+    p0.reduce_group = p1.reduce_group = -2;
     std::vector<PendingJob> v{p0, p1};
     return wgq_run_or_queue(v, s);
 }

@@ -554,6 +554,26 @@ def conv2d_direct_wgrad(x, dy, k, stride, pad, out=None):
     return dw
 
 
+def conv5x5_wgrad_supported(N, CA, CB, H, W):
+    return bool(_lib.query('gx_conv5x5_wgrad_supported', N, CA, CB, H, W))
+
+
+def conv5x5_wgrad(a, b, out=None):
+    """dw [CA][CB][5][5] = sum_{n,p} a[n][CA][p] * b[n][CB][p + (kh - 2, kw - 2)] (5x5, stride 1, pad 2): Conv2d with
+    (a, b) = (dy, x), stride-1 ConvTranspose2d with (a, b) = (x, dy); bf16-pipe row-ring tiles (gx_conv5x5_wgrad)."""
+    _chk(a, 'conv5x5_wgrad.a'); _chk(b, 'conv5x5_wgrad.b')
+    N, CA, H, W = a.shape
+    CB = b.shape[1]
+    assert b.shape == (N, CB, H, W)
+    dw = out if out is not None else torch.empty(CA, CB, 5, 5, dtype=F32, device=a.device)
+    assert dw.shape == (CA, CB, 5, 5) and dw.is_contiguous()
+    nb = _lib.query('gx_conv5x5_wgrad_ws_bytes', N, CA, CB, H, W)
+    ws = _ws(nb, a.device)
+    with _deferring(out is not None, ws, a, b):
+        _lib.call('gx_conv5x5_wgrad', _p(a), _p(b), _p(dw), N, CA, CB, H, W, _p(ws), nb, _stream())
+    return dw
+
+
 def mixture_w_fwd(x, dec, log_w, K, std1, std2, pixel_bound=True):
     """Mixture likelihood with external mixing log-weights log_w [K,B,1,H,W] (MONet)."""
     _chk(x, 'mixture_w.x'); _chk(dec, 'mixture_w.dec'); _chk(log_w, 'mixture_w.log_w')

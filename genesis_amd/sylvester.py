@@ -189,10 +189,16 @@ class DirectConvFn(torch.autograd.Function):
             dw = hip.deconv5x5s2_wgrad(x, g, out=ow)
             dx = hip.deconv5x5s2_dgrad(g, w) if need_dx else None
         elif kind == 'conv':
-            dw = hip.conv2d_direct_wgrad(x, g, k, stride, pad, out=ow)
+            if k == 5 and stride == 1 and pad == 2 and hip.conv5x5_wgrad_supported(x.shape[0], w.shape[0], w.shape[1], *x.shape[2:]):
+                dw = hip.conv5x5_wgrad(g, x, out=ow)          # bf16-pipe row-ring tiles, in the step's stream-K launch
+            else:
+                dw = hip.conv2d_direct_wgrad(x, g, k, stride, pad, out=ow)
             dx = hip.conv2d_direct_dgrad(g, w, x.shape[2], x.shape[3], stride, pad) if need_dx else None
         else:
-            dw = hip.conv2d_direct_wgrad(g, x, k, stride, pad, out=ow)
+            if k == 5 and stride == 1 and pad == 2 and hip.conv5x5_wgrad_supported(x.shape[0], w.shape[0], w.shape[1], *x.shape[2:]):
+                dw = hip.conv5x5_wgrad(x, g, out=ow)
+            else:
+                dw = hip.conv2d_direct_wgrad(g, x, k, stride, pad, out=ow)
             dx = hip.conv2d_direct_fwd(g, w, None, None, stride, pad) if need_dx else None
         return dx, _ret(ow, dw), None, None, None, None
 

@@ -263,6 +263,15 @@ int gx_conv3x3_bias_act_fwd(const float* x, const float* w, const float* bias, i
 size_t gx_bias_act_bwd_ws_bytes(int N, int C);
 int gx_bias_act_bwd(const float* out, const float* g, int N, int C, int H, int W, int act, float* dy, float* dbias,
                     void* ws, size_t ws_bytes, gx_stream_t stream);
+/* ---- 5 x 5 stride-1 pad-2 weight gradient of the gated stacks (third_party/sylvester/VAE.py:18-33, layers.py:40-101) on
+ *      the bf16-pipe row-ring tiles: dw [CA][CB][5][5] = sum_{n,p} a[n][CA][p] * b[n][CB][p + (kh - 2, kw - 2)].
+ *      Conv2d: a = dy, b = x -> dw [Cout][Cin][5][5]; ConvTranspose2d stride 1: a = x, b = dy -> dw [Cin][Cout][5][5].
+ *      Queued into the step's stream-K launch when deferral is on (gx_defer_*), else launched at once. */
+int gx_conv5x5_wgrad_supported(int N, int CA, int CB, int H, int W);
+size_t gx_conv5x5_wgrad_ws_bytes(int N, int CA, int CB, int H, int W);
+int gx_conv5x5_wgrad(const float* a, const float* b, float* dw, int N, int CA, int CB, int H, int W, void* ws,
+                     size_t ws_bytes, gx_stream_t stream);
+
 int gx_conv2d_direct_fwd(const float* x, const float* w, const float* bias, int act, float* y, int N, int Cin,
                          int Cout, int H, int W, int k, int stride, int pad, gx_stream_t stream);
 int gx_conv2d_direct_dgrad(const float* dy, const float* w, float* dx, int N, int Cin, int Cout, int H, int W, int k,

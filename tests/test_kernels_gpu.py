@@ -1121,3 +1121,24 @@ def test_row_ring_weight_gradients(kind, N, Cin, Cout, S):
         _lib.call('gx_wgq_ring', 1)
     print('%s N=%d %d->%d @%d: relative L2 error 64-pixel tiles %.3e, row-ring tiles %.3e' % (kind, N, Cin, Cout, S, err[0], err[1]))
     assert err[1] <= 1.5 * err[0] + 1e-7 and err[1] < 1e-4, err
+
+
+@pytest.mark.parametrize('N,CA,CB,S', [(3, 64, 32, 64), (7, 64, 64, 32), (1, 128, 64, 32), (5, 40, 24, 64), (33, 64, 32, 32)])
+def test_conv5x5_stride1_weight_gradient_on_the_row_ring_tiles(N, CA, CB, S):
+    """gx_conv5x5_wgrad (the gated 5x5 stride-1 (de)convs of third_party/sylvester): dw[a][b][kh][kw] = sum a * shifted b
+    on the bf16-pipe row-ring tiles (kernel rows 0-2 and 3-4 as two jobs of one stream-K launch) against autograd in
+    fp64, in both roles: Conv2d (a = dy, b = x) and stride-1 ConvTranspose2d (a = x, b = dy); bit-identical twice."""
+    from genesis_amd import hip_ops as hip
+    assert hip.conv5x5_wgrad_supported(N, CA, CB, S, S)
+    a, b = rnd(N, CA, S, S, seed=1), rnd(N, CB, S, S, seed=2)
+    # Conv2d: x = b [N, Cin = CB], dy = a [N, Cout = CA], weight [CA, CB, 5, 5]
+    ref = torch.nn.grad.conv2d_weight(b.double(), (CA, CB, 5, 5), a.double(), padding=2)
+    got = hip.conv5x5_wgrad(a.to(DEV), b.to(DEV))
+    assert torch.equal(got, hip.conv5x5_wgrad(a.to(DEV), b.to(DEV)))
+    err = float((got.double().cpu() - ref).norm() / ref.norm())
+    # stride-1 ConvTranspose2d: x = a [N, Cin = CA], dy = b [N, Cout = CB], weight [CA, CB, 5, 5]
+    wt = torch.zeros(CA, CB, 5, 5, dtype=torch.float64, requires_grad=True)
+    F.conv_transpose2d(a.double(), wt, None, 1, 2).backward(b.double())
+    err_t = float((got.double().cpu() - wt.grad).norm() / wt.grad.norm())
+    print('conv5x5 wgrad N=%d %dx%d @%d: relative L2 error %.3e (conv), %.3e (transposed)' % (N, CA, CB, S, err, err_t))
+    assert err < 2e-6 and err_t < 2e-6, (err, err_t)
