@@ -38,11 +38,11 @@
 
 namespace {
 
-enum { M_C3 = 0, M_DT0 = 1, M_DT1 = 2, M_DG = 3 };
+enum { M_C3 = 0, M_DT0 = 1, M_DT1 = 2, M_DG = 3, M_C5 = 4 };
 
 template <int MODE> struct TapCfg;
 template <> struct TapCfg<M_C3> {
-    static constexpr int NT = 9, NCLS = 1, KC = 8, PLANES = 1;
+    static constexpr int NT = 9, NCLS = 1, KC = 8, PLANES = 1, HALO = 1;
     __host__ __device__ static constexpr int ro(int t) { return t / 3; }
     __host__ __device__ static constexpr int co(int t) { return t % 3; }
     __host__ __device__ static constexpr int cls(int) { return 0; }
@@ -51,14 +51,14 @@ template <> struct TapCfg<M_C3> {
 // ConvTranspose k5 s2 p2 op1: out[2r+a][2c+b] += x[r+dr][c+dc] * W[kh][kw] with kh = a (mod 2),
 // dr = (a+2-kh)/2, i.e. halo row offset ro = dr+1 = 2 - kh/2 (same for columns).
 template <> struct TapCfg<M_DT0> {
-    static constexpr int NT = 15, NCLS = 2, KC = 4, PLANES = 1;
+    static constexpr int NT = 15, NCLS = 2, KC = 4, PLANES = 1, HALO = 1;
     __host__ __device__ static constexpr int ro(int t) { return 2 - t / 5; }        // kh = 2*(t/5)
     __host__ __device__ static constexpr int co(int t) { return 2 - (t % 5) / 2; }  // kw = t%5
     __host__ __device__ static constexpr int cls(int t) { return (t % 5) & 1; }
     __host__ __device__ static constexpr int plane(int) { return 0; }
 };
 template <> struct TapCfg<M_DT1> {
-    static constexpr int NT = 10, NCLS = 2, KC = 4, PLANES = 1;
+    static constexpr int NT = 10, NCLS = 2, KC = 4, PLANES = 1, HALO = 1;
     __host__ __device__ static constexpr int ro(int t) { return 2 - t / 5; }        // kh = 2*(t/5)+1
     __host__ __device__ static constexpr int co(int t) { return 2 - (t % 5) / 2; }
     __host__ __device__ static constexpr int cls(int t) { return (t % 5) & 1; }
@@ -67,11 +67,20 @@ template <> struct TapCfg<M_DT1> {
 // dgrad of the deconv: dx[r][c] = sum dy[2r-2+kh][2c-2+kw] W[kh][kw]; plane = (kh&1, kw&1),
 // in-plane offset (kh/2, kw/2).
 template <> struct TapCfg<M_DG> {
-    static constexpr int NT = 25, NCLS = 1, KC = 2, PLANES = 4;
+    static constexpr int NT = 25, NCLS = 1, KC = 2, PLANES = 4, HALO = 1;
     __host__ __device__ static constexpr int ro(int t) { return (t / 5) / 2; }
     __host__ __device__ static constexpr int co(int t) { return (t % 5) / 2; }
     __host__ __device__ static constexpr int cls(int) { return 0; }
     __host__ __device__ static constexpr int plane(int t) { return ((t / 5) & 1) * 2 + ((t % 5) & 1); }
+};
+
+// 5x5 stride-1 pad-2 conv (the gated stacks of third_party/sylvester, VAE.py:18-33): 25 taps around a 2-pixel halo
+template <> struct TapCfg<M_C5> {
+    static constexpr int NT = 25, NCLS = 1, KC = 4, PLANES = 1, HALO = 2;
+    __host__ __device__ static constexpr int ro(int t) { return t / 5; }
+    __host__ __device__ static constexpr int co(int t) { return t % 5; }
+    __host__ __device__ static constexpr int cls(int) { return 0; }
+    __host__ __device__ static constexpr int plane(int) { return 0; }
 };
 
 struct ConvGeom {
@@ -116,8 +125,9 @@ __device__ __forceinline__ void tapconv_body(const float* __restrict__ in, const
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int TH = 1 << g.lTH, TW = 1 << g.lTW, G = 1 << g.lG;
-    const int HS = TW + 2;                         // halo row stride
-    const int PLS = G * (TH + 2) * HS;             // one plane of the halo tile
+    constexpr int HL = TC::HALO;
+    const int HS = TW + 2 * HL;                    // halo row stride
+    const int PLS = G * (TH + 2 * HL) * HS;        // one plane of the halo tile
     const int CHS = PLANES * PLS;                  // per-channel LDS stride
     const int BUF = KC * CHS + NT * KC * 64;       // floats per pipeline stage: [KC][CHS] input + [NT][KC][64] weights
 
@@ -142,7 +152,7 @@ __device__ __forceinline__ void tapconv_body(const float* __restrict__ in, const
         if (pos < CHS) {
             int rem = pos;
             const int plane = rem / PLS; rem -= plane * PLS;
-            const int gi = rem / ((TH + 2) * HS); rem -= gi * (TH + 2) * HS;
+            const int gi = rem / ((TH + 2 * HL) * HS); rem -= gi * (TH + 2 * HL) * HS;
             const int i = rem / HS;
             const int j = rem - i * HS;
             int row, col;
@@ -150,8 +160,8 @@ __device__ __forceinline__ void tapconv_body(const float* __restrict__ in, const
                 row = 2 * (R0 + i) - 2 + (plane >> 1);
                 col = 2 * (C0 + j) - 2 + (plane & 1);
             } else {
-                row = R0 - 1 + i;
-                col = C0 - 1 + j;
+                row = R0 - HL + i;
+                col = C0 - HL + j;
             }
             if (img0 + gi < g.N && row >= 0 && row < g.Hi && col >= 0 && col < g.Wi)
                 off = gi * (int)in_img_stride + row * g.Wi + col;
@@ -187,7 +197,7 @@ __device__ __forceinline__ void tapconv_body(const float* __restrict__ in, const
         const int c = p & (TW - 1);
         const int r = (p >> g.lTW) & (TH - 1);
         const int gi = p >> (g.lTW + g.lTH);
-        b_off[nj] = (lane >> 5) * CHS + (gi * (TH + 2) + r) * HS + c;
+        b_off[nj] = (lane >> 5) * CHS + (gi * (TH + 2 * HL) + r) * HS + c;
     }
 
     f32x16 acc[NCLS][MI][2];
@@ -533,6 +543,10 @@ __device__ __forceinline__ float pack_weight_value(const float* __restrict__ w, 
         if (m < Co && k < Ci) v = w[((size_t)k * Co + m) * 25 + kh * 5 + kw];
     } else if (pack == 4) {
         if (m < Ci && k < Co) v = w[((size_t)m * Co + k) * 25 + t];
+    } else if (pack == 7) {   // 5x5 stride 1, cross-correlation: w [Co = M][Ci = K][5][5]
+        if (m < Co && k < Ci) v = w[((size_t)m * Ci + k) * 25 + t];
+    } else if (pack == 8) {   // 5x5 stride 1, true convolution with the channel roles swapped: w [Co = K][Ci = M][5][5]
+        if (k < Co && m < Ci) v = w[((size_t)k * Ci + m) * 25 + (24 - t)];
     } else {   // 5 / 6: Winograd operands of the conv3x3 forward / data gradient (t = position)
         v = gx_wino_u_value(w, pack - 5, Co, Ci, m, k, t);
     }
@@ -542,7 +556,7 @@ __device__ __forceinline__ float pack_weight_value(const float* __restrict__ w, 
 // the k-quad order of gx_kq.hip for packs 10..14 (= packs 0..4 in that layout)
 __device__ __forceinline__ size_t pack_dest(int pack, int idx, int m, int k, int t, int Kpad, int NT) {
     if (pack >= 10) return gx_kq_w_slot(m, k, pack == 14 ? gx_kq_dg_tap_slot(t) : t, NT, Kpad);
-    return pack >= 5 ? gx_wino_u_slot(m, k, t, Kpad) : (size_t)idx;
+    return (pack == 5 || pack == 6) ? gx_wino_u_slot(m, k, t, Kpad) : (size_t)idx;
 }
 
 // packs 22 / 23 / 24 (= 2 / 3 / 4 for the bf16 matrix pipe, gx_kq.hip's QCfgDTH / Q_DGH): every weight as three bf16 pieces, two
@@ -1168,7 +1182,7 @@ int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 // pixel tile of `npix` (256 for tapconv) over a Hb x Wb base grid of N images: power-of-two TH x TW x G
 // maximising the fraction of useful pixels (1.0 for power-of-two grids; 72x72 -> 8x8 tiles of 4 images), then
 // the widest rows (coalescing) and tallest tiles among ties; the halo tile must fit `max_chs` floats per channel per plane.
-void pick_tile(int Hb, int Wb, int npix, int planes, int max_chs, int* lTH, int* lTW, int* lG) {
+void pick_tile(int Hb, int Wb, int npix, int planes, int max_chs, int* lTH, int* lTW, int* lG, int halo = 1) {
     double best_eff = -1.0;
     int bTW = 1, bTH = 1;
     for (int TW = 1; TW <= npix && TW <= 64; TW <<= 1) {
@@ -1176,7 +1190,7 @@ void pick_tile(int Hb, int Wb, int npix, int planes, int max_chs, int* lTH, int*
         for (int TH = 1; TH * TW <= npix; TH <<= 1) {
             if (TH > 1 && (TH >> 1) >= Hb) break;
             const int G = npix / (TH * TW);
-            if (planes * G * (TH + 2) * (TW + 2) > max_chs) continue;
+            if (planes * G * (TH + 2 * halo) * (TW + 2 * halo) > max_chs) continue;
             const double eff = (double)Hb * Wb / ((double)gx_ceil_div(Wb, TW) * TW * gx_ceil_div(Hb, TH) * TH);
             // ties: widest rows, then tallest tile (fewest images per tile = smallest halo)
             if (eff > best_eff + 1e-9 || (eff > best_eff - 1e-9 && (TW > bTW || (TW == bTW && TH > bTH)))) {
@@ -1205,7 +1219,7 @@ int plan_tapconv(int N, int K, int M, int Mpad_pack, int Hb, int Wb, int Hi, int
     g.Kpad = gx_round_up(K, 8); g.Mpad = Mpad_pack;
     g.Hb = Hb; g.Wb = Wb; g.Hi = Hi; g.Wi = Wi; g.Ho = Ho; g.Wo = Wo; g.par_a = par_a;
     constexpr int LO_ = (MODE == M_DG) ? 8 : 2;
-    pick_tile(Hb, Wb, npix, TC::PLANES, 2 * LO_ * 256, &g.lTH, &g.lTW, &g.lG);
+    pick_tile(Hb, Wb, npix, TC::PLANES, 2 * LO_ * 256, &g.lTH, &g.lTW, &g.lG, TC::HALO);
     pl->mw = 256 / npix;
     const int TH = 1 << g.lTH, TW = 1 << g.lTW, G = 1 << g.lG;
     g.tiles_h = gx_ceil_div(Hb, TH); g.tiles_w = gx_ceil_div(Wb, TW);
@@ -1213,7 +1227,7 @@ int plan_tapconv(int N, int K, int M, int Mpad_pack, int Hb, int Wb, int Hi, int
     g.zeros = nullptr;
     g.stats = nullptr;
     g.stats_parts = 0;
-    const int CHS = TC::PLANES * G * (TH + 2) * (TW + 2);
+    const int CHS = TC::PLANES * G * (TH + 2 * TC::HALO) * (TW + 2 * TC::HALO);
     const int need = gx_ceil_div(CHS, 256);
     const int lo = (MODE == M_DG) ? 8 : 2;
     pl->npos = need <= lo ? lo : 2 * lo;
@@ -1303,7 +1317,7 @@ int launch_tapconv(const float* in, const float* wp, const float* bias, float* d
         const double flops = 2.0 * g.N * (double)g.M * g.K * TC::NT * g.Hb * g.Wb;
         const double bytes = 4.0 * ((double)g.N * g.K * g.Hi * g.Wi + (double)g.N * g.M * g.Ho * g.Wo / TC::NCLS +
                                     (double)TC::NT * g.K * g.M);
-        GxProf pf(KID_TAPCONV_C3 + MODE, s, flops, bytes);
+        GxProf pf(MODE == M_C5 ? KID_DCONV : KID_TAPCONV_C3 + MODE, s, flops, bytes);
         constexpr int LO = (MODE == M_DG) ? 8 : 2;
         if (pl.npos == LO) launch_tapconv_inst<MODE, LO>(in, wp, bias, dst, pl, s);
         else launch_tapconv_inst<MODE, 2 * LO>(in, wp, bias, dst, pl, s);
@@ -2015,6 +2029,47 @@ int gx_conv3x3_wgrad(const float* x, const float* dy, float* dw, int N, int Cin,
     rc = launch_wgrad<W_C3>(dy, x, (float*)ws, pl, s, "gx_conv3x3_wgrad");
     if (rc) return rc;
     return launch_wgrad_reduce((const float*)ws, dw, pl, 0, s);
+}
+
+/* 5 x 5 stride-1 pad-2 convolution on the tap-conv MFMA kernel (mode M_C5): out [N,M,H,W] from in [N,K,H,W].
+ *   flip 0: out[m] = sum_k in[k] (cross-correlated with) w[m][k]   -- w [M][K][5][5]: Conv2d forward; the data gradient of a
+ *           stride-1 ConvTranspose2d (w = its weight [Cin = M][Cout = K])
+ *   flip 1: out[m] = sum_k in[k] (convolved with) w[k][m]          -- w [K][M][5][5]: Conv2d data gradient (in = dy, w [Cout][Cin]);
+ *           stride-1 ConvTranspose2d forward (w [Cin = K][Cout = M]) */
+size_t gx_conv5x5s1_ws_bytes(int N, int K, int M, int H, int W) {
+    TapPlan pl;
+    size_t part = 0;
+    if (plan_tapconv<M_C5>(N, K, M, gx_round_up(M, 64), H, W, H, W, H, W, 0, &pl, "ws") == GX_OK && pl.g.nsplit > 1)
+        part = pl.g.nsplit * pl.out_elems;
+    return ((size_t)25 * gx_round_up(K, 8) * gx_round_up(M, 64) + part) * sizeof(float);
+}
+
+int gx_conv5x5s1_supported(int N, int K, int M, int H, int W) {
+    TapPlan pl;
+    return N > 0 && K > 0 && M > 0 && H >= 4 && W >= 4 &&
+           plan_tapconv<M_C5>(N, K, M, gx_round_up(M, 64), H, W, H, W, H, W, 0, &pl, "gx_conv5x5s1") == GX_OK;
+}
+
+int gx_conv5x5s1(const float* in, const float* w, float* out, int N, int K, int M, int H, int W, int flip, void* ws,
+                 size_t ws_bytes, gx_stream_t stream) {
+    GX_CHECK_ARG(in && w && out && ws, "gx_conv5x5s1: null pointer");
+    GX_CHECK_ARG(flip == 0 || flip == 1, "gx_conv5x5s1: flip must be 0 or 1");
+    GX_CHECK_ARG(ws_bytes >= gx_conv5x5s1_ws_bytes(N, K, M, H, W), "gx_conv5x5s1: workspace too small");
+    const int Kpad = gx_round_up(K, 8), Mpad = gx_round_up(M, 64);
+    hipStream_t s = (hipStream_t)stream;
+    TapPlan pl;
+    int rc = plan_tapconv<M_C5>(N, K, M, Mpad, H, W, H, W, H, W, 0, &pl, "gx_conv5x5s1");
+    if (rc) return rc;
+    float* wp = (float*)ws;
+    float* part = wp + (size_t)25 * Kpad * Mpad;
+    const float* wpu;
+    // pack 7: w [M][K]; pack 8: w [K][M] flipped (launch_pack's (Co, Ci) are the weight tensor's leading dimensions)
+    rc = flip ? launch_pack(w, wp, 8, K, M, 25, Kpad, Mpad, s, &wpu) : launch_pack(w, wp, 7, M, K, 25, Kpad, Mpad, s, &wpu);
+    if (rc) return rc;
+    rc = launch_tapconv<M_C5>(in, wpu, nullptr, pl.g.nsplit > 1 ? part : out, pl, s, "gx_conv5x5s1");
+    if (rc) return rc;
+    if (pl.g.nsplit > 1) return launch_splitk_reduce(part, nullptr, out, pl, s);
+    return GX_OK;
 }
 
 /* 5 x 5 stride-1 pad-2 weight gradient on the row-ring tiles of the bf16 pipe (gx_wgq.hip): dw [CA][CB][5][5] =

@@ -554,6 +554,23 @@ def conv2d_direct_wgrad(x, dy, k, stride, pad, out=None):
     return dw
 
 
+def conv5x5s1_supported(N, K, M, H, W):
+    return bool(_lib.query('gx_conv5x5s1_supported', N, K, M, H, W))
+
+
+def conv5x5s1(inp, w, M, flip):
+    """5x5 stride-1 pad-2 conv on the tap-conv MFMA kernel: flip False = cross-correlation with w [M][K][5][5], flip True =
+    convolution with w [K][M][5][5] (gx_conv5x5s1)."""
+    _chk(inp, 'conv5x5s1.in'); _chk(w, 'conv5x5s1.w')
+    N, K, H, W = inp.shape
+    assert tuple(w.shape) == ((K, M, 5, 5) if flip else (M, K, 5, 5)), (w.shape, K, M, flip)
+    out = torch.empty(N, M, H, W, dtype=F32, device=inp.device)
+    nb = _lib.query('gx_conv5x5s1_ws_bytes', N, K, M, H, W)
+    ws = _ws(nb, inp.device)
+    _lib.call('gx_conv5x5s1', _p(inp), _p(w), _p(out), N, K, M, H, W, int(bool(flip)), _p(ws), nb, _stream())
+    return out
+
+
 def conv5x5_wgrad_supported(N, CA, CB, H, W):
     return bool(_lib.query('gx_conv5x5_wgrad_supported', N, CA, CB, H, W))
 

@@ -163,21 +163,27 @@ class DirectConvFn(torch.autograd.Function):
         # weight gradients in the step's stream-K launch) instead of the generic implicit-GEMM kernels
         fast = k == 5 and stride == 2 and pad == 2 and _pow2(H) and _pow2(W) and min(H, W) >= 4 and \
             (out_pad == 1 if kind == 'deconv' else True)
+        # the stride-1 5x5 layers: the tap-conv MFMA kernel with a 25-tap table (gx_conv5x5s1)
+        Cout = w.shape[0] if kind == 'conv' else w.shape[1]
+        s1 = k == 5 and stride == 1 and pad == 2 and out_pad == 0 and hip.conv5x5s1_supported(x.shape[0], x.shape[1], Cout, H, W) \
+            and hip.conv5x5s1_supported(x.shape[0], Cout, x.shape[1], H, W)
         if kind == 'conv':
-            y = hip.deconv5x5s2_dgrad(x, w) if fast else hip.conv2d_direct_fwd(x, w, None, None, stride, pad)
+            y = hip.deconv5x5s2_dgrad(x, w) if fast else (hip.conv5x5s1(x, w, Cout, False) if s1 else
+                                                          hip.conv2d_direct_fwd(x, w, None, None, stride, pad))
         else:
             Ho, Wo = (H - 1) * stride - 2 * pad + k + out_pad, (W - 1) * stride - 2 * pad + k + out_pad
-            y = hip.deconv5x5s2_fwd(x, w, None) if fast else hip.conv2d_direct_dgrad(x, w, Ho, Wo, stride, pad)
+            y = hip.deconv5x5s2_fwd(x, w, None) if fast else (hip.conv5x5s1(x, w, Cout, True) if s1 else
+                                                              hip.conv2d_direct_dgrad(x, w, Ho, Wo, stride, pad))
         ctx.save_for_backward(x)
         ctx.w = w
-        ctx.cfg = (kind, stride, pad, k, fast)
+        ctx.cfg = (kind, stride, pad, k, fast, s1)
         return y
 
     @staticmethod
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
         w = ctx.w
-        kind, stride, pad, k, fast = ctx.cfg
+        kind, stride, pad, k, fast, s1 = ctx.cfg
         g = g.contiguous()
         ow = _gout(w)
         need_dx = ctx.needs_input_grad[0]
@@ -193,13 +199,15 @@ class DirectConvFn(torch.autograd.Function):
                 dw = hip.conv5x5_wgrad(g, x, out=ow)          # bf16-pipe row-ring tiles, in the step's stream-K launch
             else:
                 dw = hip.conv2d_direct_wgrad(x, g, k, stride, pad, out=ow)
-            dx = hip.conv2d_direct_dgrad(g, w, x.shape[2], x.shape[3], stride, pad) if need_dx else None
+            dx = (hip.conv5x5s1(g, w, x.shape[1], True) if s1 else
+                  hip.conv2d_direct_dgrad(g, w, x.shape[2], x.shape[3], stride, pad)) if need_dx else None
         else:
             if k == 5 and stride == 1 and pad == 2 and hip.conv5x5_wgrad_supported(x.shape[0], w.shape[0], w.shape[1], *x.shape[2:]):
                 dw = hip.conv5x5_wgrad(x, g, out=ow)
             else:
                 dw = hip.conv2d_direct_wgrad(g, x, k, stride, pad, out=ow)
-            dx = hip.conv2d_direct_fwd(g, w, None, None, stride, pad) if need_dx else None
+            dx = (hip.conv5x5s1(g, w, x.shape[1], False) if s1 else
+                  hip.conv2d_direct_fwd(g, w, None, None, stride, pad)) if need_dx else None
         return dx, _ret(ow, dw), None, None, None, None
 
 

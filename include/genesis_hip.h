@@ -267,6 +267,13 @@ int gx_bias_act_bwd(const float* out, const float* g, int N, int C, int H, int W
  *      the bf16-pipe row-ring tiles: dw [CA][CB][5][5] = sum_{n,p} a[n][CA][p] * b[n][CB][p + (kh - 2, kw - 2)].
  *      Conv2d: a = dy, b = x -> dw [Cout][Cin][5][5]; ConvTranspose2d stride 1: a = x, b = dy -> dw [Cin][Cout][5][5].
  *      Queued into the step's stream-K launch when deferral is on (gx_defer_*), else launched at once. */
+/*      the layers themselves on the tap-conv MFMA kernel: out [N,M,H,W] from in [N,K,H,W];
+ *      flip 0: cross-correlation with w [M][K][5][5] (Conv2d forward; data gradient of a stride-1 ConvTranspose2d),
+ *      flip 1: convolution with w [K][M][5][5] (Conv2d data gradient, in = dy; stride-1 ConvTranspose2d forward). */
+int gx_conv5x5s1_supported(int N, int K, int M, int H, int W);
+size_t gx_conv5x5s1_ws_bytes(int N, int K, int M, int H, int W);
+int gx_conv5x5s1(const float* in, const float* w, float* out, int N, int K, int M, int H, int W, int flip, void* ws,
+                 size_t ws_bytes, gx_stream_t stream);
 int gx_conv5x5_wgrad_supported(int N, int CA, int CB, int H, int W);
 size_t gx_conv5x5_wgrad_ws_bytes(int N, int CA, int CB, int H, int W);
 int gx_conv5x5_wgrad(const float* a, const float* b, float* dw, int N, int CA, int CB, int H, int W, void* ws,

@@ -1142,3 +1142,18 @@ def test_conv5x5_stride1_weight_gradient_on_the_row_ring_tiles(N, CA, CB, S):
     err_t = float((got.double().cpu() - wt.grad).norm() / wt.grad.norm())
     print('conv5x5 wgrad N=%d %dx%d @%d: relative L2 error %.3e (conv), %.3e (transposed)' % (N, CA, CB, S, err, err_t))
     assert err < 2e-6 and err_t < 2e-6, (err, err_t)
+
+
+@pytest.mark.parametrize('N,K,M,S', [(3, 32, 64, 64), (5, 64, 128, 32), (2, 3, 64, 64), (4, 40, 24, 16), (33, 64, 64, 16), (1, 32, 64, 8)])
+def test_conv5x5_stride1_on_the_tapconv_kernel(N, K, M, S):
+    """gx_conv5x5s1 (tap-conv MFMA kernel, 25-tap table, 2-pixel halo): both weight roles against fp64 torch --
+    flip 0 = F.conv2d(x, w [M,K,5,5], padding=2); flip 1 = F.conv_transpose2d(x, w [K,M,5,5], stride 1, padding 2)."""
+    from genesis_amd import hip_ops as hip
+    assert hip.conv5x5s1_supported(N, K, M, S, S)
+    x = rnd(N, K, S, S, seed=1)
+    w0 = rnd(M, K, 5, 5, seed=2, scale=0.1)
+    w1 = rnd(K, M, 5, 5, seed=3, scale=0.1)
+    close(hip.conv5x5s1(x.to(DEV), w0.to(DEV), M, False), F.conv2d(x.double(), w0.double(), None, 1, 2), rtol=2e-5, atol=2e-5,
+          msg='cross-correlation')
+    close(hip.conv5x5s1(x.to(DEV), w1.to(DEV), M, True), F.conv_transpose2d(x.double(), w1.double(), None, 1, 2), rtol=2e-5,
+          atol=2e-5, msg='convolution (transposed-conv forward)')
