@@ -139,3 +139,25 @@ class SampleGolden(object):
         self.check('log_m_k', st(log_m_k), rtol, 10 * atol)
         if mx_k is not None:
             self.check('mx_k', st(mx_k), rtol, atol)
+
+
+def fp32_budget(loss_fn, sd, is_param=lambda k: True):
+    """Per-parameter error of plain fp32 arithmetic on this problem: loss_fn(p) -> scalar, evaluated by the CPU oracle in
+    fp64 (ground truth) and in fp32 (what the reference computes); returns {name: relative L2 error of the fp32 gradient}.
+    The golden gradient comparisons derive their tolerances from it: |HIP - reference fp32| <= |HIP - fp64| + |reference -
+    fp64| <= (4 + 1) x this + floor (the HIP bar of tests/test_error_budget_gpu.py plus the reference's own error)."""
+    grads = {}
+    for dtype in (torch.float64, torch.float32):
+        p = {k: (v.clone().to(dtype if v.dtype == torch.float32 else v.dtype).requires_grad_(True) if is_param(k) and v.is_floating_point()
+                 else v.clone().to(dtype if v.dtype == torch.float32 else v.dtype)) for k, v in sd.items()}
+        loss_fn(p, dtype).backward()
+        grads[dtype] = {k: (v.grad if v.grad is not None else torch.zeros_like(v)).double() for k, v in p.items() if v.requires_grad}
+    g64, g32 = grads[torch.float64], grads[torch.float32]
+    return {k: float((g32[k] - g64[k]).norm()) / (float(g64[k].norm()) + 1e-30) for k in g64}
+
+
+def budget_tolerances(e_cpu, floor=2e-4, factor=5.0, sampling=1.5, cap=None):
+    """{name: tolerance} for a golden gradient comparison on strided samples: sampling x (factor x e_cpu) + floor, never
+    looser than `cap`.  floor: what one ReLU whose pre-activation sits within fp32 round-off of zero on the fixtures'
+    closed-form weights moves an upstream gradient by when it falls the other way (1e-4 .. 1e-3, Golden.check_grads)."""
+    return {k: min(sampling * factor * v + floor, cap if cap is not None else float('inf')) for k, v in e_cpu.items()}

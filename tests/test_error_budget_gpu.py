@@ -70,8 +70,11 @@ def hip_grads(model):
     return [(n, p.grad if p.grad is not None else torch.zeros_like(p)) for n, p in model.named_parameters()]
 
 
-@pytest.mark.parametrize('name,K,S,D,B', [('k5', 5, 64, 32, 4), ('metric', 7, 64, 64, 2), ('cfg5', 11, 128, 64, 1)])
+@pytest.mark.parametrize('name,K,S,D,B', [('k5', 5, 64, 32, 4), ('metric', 7, 64, 64, 2), ('cfg5', 11, 128, 64, 1),
+                                          ('metric_b32', 7, 64, 64, 32)])
 def test_genesis_v2(name, K, S, D, B):
+    """('metric_b32': the metric configuration at its FULL per-GPU batch -- the B = 32 dispatch: Winograd convs, row-ring
+    weight gradients on the bf16 pipe, bf16-pipe transposed convs -- against the fp64 oracle.)"""
     from oracle import v2_oracle as O
     import genesis_amd.genesisv2_config as G
     from genesis_amd.compat.attrdict import AttrDict
@@ -85,17 +88,30 @@ def test_genesis_v2(name, K, S, D, B):
     x = T.make_input(99, B, S)
     rp, eps_k = T.draw_noise(123, B, S, D, K)
 
-    def oracle(dtype):
+    def oracle(dtype, seed_idx=None):
         p = to_dtype(sd, dtype)
-        out = O.v2_forward(p, x.to(dtype), cfg, rp.to(dtype), [e.to(dtype) for e in eps_k], reference_form=False)
+        out = O.v2_forward(p, x.to(dtype), cfg, rp.to(dtype), [e.to(dtype) for e in eps_k], seed_idx=seed_idx,
+                           reference_form=False)
         e, kl, _ = O.aggregate_losses(out[1])
         (e + kl).backward()
         return out, grads_of(p)
     o64, g64 = oracle(torch.float64)
-    o32, g32 = oracle(torch.float32)
+    seeds64 = torch.stack(o64[3]['seed_idx'])
     model = model.to(DEV)
-    recon, losses, stats, att, _ = model(x.to(DEV), rp.to(DEV), torch.stack(eps_k).to(DEV))
-    assert torch.equal(torch.stack(list(att['seed_idx'])).cpu(), torch.stack(o64[3]['seed_idx']))   # no fallback here
+    if B <= 4:
+        o32, g32 = oracle(torch.float32)
+        recon, losses, stats, att, _ = model(x.to(DEV), rp.to(DEV), torch.stack(eps_k).to(DEV))
+        assert torch.equal(torch.stack(list(att['seed_idx'])).cpu(), seeds64)   # no fallback here
+    else:
+        # 32 x (K - 1) argmax decisions: a near-tie may legitimately fall the other way in fp32; the budget is about the
+        # arithmetic, so BOTH fp32 runs (host and HIP) take the fp64 run's seed pixels -- after counting the free HIP run's
+        o32, g32 = oracle(torch.float32, list(seeds64.unbind(0)))
+        with torch.no_grad():
+            free = torch.stack(list(model(x.to(DEV), rp.to(DEV), torch.stack(eps_k).to(DEV))[3]['seed_idx'])).cpu()
+        agree = float((free == seeds64).float().mean())
+        print('seed pixels of the free HIP run equal to the fp64 run: %.4f' % agree)
+        assert agree >= 0.95
+        recon, losses, stats, att, _ = model(x.to(DEV), rp.to(DEV), torch.stack(eps_k).to(DEV), seeds64.to(DEV))
     (losses.err.mean(0) + torch.stack(losses.kl_l_k, 1).mean(0).sum()).backward()
     st = lambda l: torch.stack(list(l))   # noqa: E731
     fwd = [('recon', recon, o32[0], o64[0]), ('err', losses.err, o32[1]['err'], o64[1]['err']),

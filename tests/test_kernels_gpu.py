@@ -1157,3 +1157,93 @@ def test_conv5x5_stride1_on_the_tapconv_kernel(N, K, M, S):
           msg='cross-correlation')
     close(hip.conv5x5s1(x.to(DEV), w1.to(DEV), M, True), F.conv_transpose2d(x.double(), w1.double(), None, 1, 2), rtol=2e-5,
           atol=2e-5, msg='convolution (transposed-conv forward)')
+
+
+def _stress(kind, *shape, seed=0):
+    """Operand distributions the six-bf16-piece products are sensitive to (uniform [-1, 1] is the easy case):
+    'offset'  |mean| >> std, as post-GroupNorm+ReLU activations or a head's dy (mean / std = 50);
+    'relu'    half exact zeros, the rest with mean / std ~ 20;
+    'mixed'   per-channel magnitudes log-uniform over 1e-4 .. 1e3 inside one reduction."""
+    g = torch.Generator().manual_seed(seed)
+    u = torch.randn(*shape, generator=g)
+    if kind == 'offset':
+        return 1.0 + 0.02 * u
+    if kind == 'relu':
+        return torch.relu(torch.randn(*shape, generator=g)).sign() * (2.0 + 0.1 * u)
+    if kind == 'mixed':
+        mag = 10.0 ** (torch.rand(1, shape[1], 1, 1, generator=g) * 7.0 - 4.0)
+        return u * mag
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize('dist', ['offset', 'relu', 'mixed'])
+@pytest.mark.parametrize('kind,N,Cin,Cout,S', [('conv3x3', 32, 64, 64, 64), ('conv3x3', 8, 128, 64, 32), ('deconv', 28, 64, 64, 32),
+                                                ('conv5x5', 6, 32, 64, 64)])
+def test_bf16_pipe_weight_gradients_on_hard_operands(dist, kind, N, Cin, Cout, S):
+    """The accuracy claim of the bf16-pipe kernels (fp32 products from six bf16 piece products, fp32 accumulate) on
+    operands that stress it: large common offsets (cancellation in the accumulate is the fp32 pipe's problem too -- the bar
+    stays 'no worse than 1.5 x the fp32 pipe'), exact zeros, seven decades of magnitude inside one reduction, and the
+    longest reduction of the workload (conv3x3 64 -> 64 at 64 x 64, batch 32: 131 k products per weight)."""
+    from genesis_amd import hip_ops as hip, _lib
+    x = _stress(dist, N, Cin, S, S, seed=1)
+    if kind == 'deconv':
+        dy = _stress(dist, N, Cout, 2 * S, 2 * S, seed=2)
+        w = torch.zeros(Cin, Cout, 5, 5, dtype=torch.float64, requires_grad=True)
+        F.conv_transpose2d(x.double(), w, None, 2, 2, 1).backward(dy.double())
+        ref = w.grad
+        run = lambda: hip.deconv5x5s2_wgrad(x.to(DEV), dy.to(DEV))  # noqa: E731
+    elif kind == 'conv3x3':
+        dy = _stress(dist, N, Cout, S, S, seed=2)
+        ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 3, 3), dy.double(), padding=1)
+        run = lambda: hip.conv3x3_wgrad(x.to(DEV), dy.to(DEV))  # noqa: E731
+    else:
+        dy = _stress(dist, N, Cout, S, S, seed=2)
+        ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 5, 5), dy.double(), padding=2)
+        run = lambda: hip.conv5x5_wgrad(dy.to(DEV), x.to(DEV))  # noqa: E731
+    err = {}
+    try:
+        for mode in ((1,) if kind == 'conv5x5' else (0, 1)):       # (the 5 x 5 class exists on the bf16 pipe only)
+            _lib.call('gx_wgq_precision', mode)
+            err[mode] = float((run().double().cpu() - ref).norm() / ref.norm())
+    finally:
+        _lib.call('gx_wgq_precision', 1)
+    # what plain fp32 arithmetic (torch on the host, fp32) makes of the same sums
+    if kind == 'conv3x3':
+        cpu32 = torch.nn.grad.conv2d_weight(x, (Cout, Cin, 3, 3), dy, padding=1)
+    elif kind == 'conv5x5':
+        cpu32 = torch.nn.grad.conv2d_weight(x, (Cout, Cin, 5, 5), dy, padding=2)
+    else:
+        w32 = torch.zeros(Cin, Cout, 5, 5, requires_grad=True)
+        F.conv_transpose2d(x, w32, None, 2, 2, 1).backward(dy)
+        cpu32 = w32.grad
+    e32 = float((cpu32.double() - ref).norm() / ref.norm())
+    print('%s %s N=%d %d->%d @%d: relative L2 error vs fp64: fp32 pipe %s, bf16 pipe %.3e, torch CPU fp32 %.3e'
+          % (kind, dist, N, Cin, Cout, S, ('%.3e' % err[0]) if 0 in err else 'n/a', err[1], e32))
+    bar = 1.5 * (err[0] if 0 in err else e32) + 1e-7
+    assert err[1] <= max(bar, 1.5 * e32 + 1e-7), (err, e32)
+
+
+@pytest.mark.parametrize('dist', ['offset', 'relu', 'mixed'])
+def test_bf16_pipe_transposed_conv_on_hard_operands(dist):
+    """The same stress operands through the bf16-pipe transposed-conv forward and data gradient (gx_kq.hip)."""
+    from genesis_amd import hip_ops as hip, _lib
+    N, Cin, Cout, Hin = 56, 64, 64, 32
+    x = _stress(dist, N, Cin, Hin, Hin, seed=3)
+    dy = _stress(dist, N, Cout, 2 * Hin, 2 * Hin, seed=4)
+    w = rnd(Cin, Cout, 5, 5, seed=5, scale=0.05)
+    xr = x.double().requires_grad_()
+    ref = F.conv_transpose2d(xr, w.double(), None, 2, 2, 1)
+    ref.backward(dy.double())
+    ref = ref.detach()
+    err, errd = {}, {}
+    try:
+        for mode in (0, 1):
+            _lib.call('gx_kq_precision', mode)
+            y = hip.deconv5x5s2_fwd(x.to(DEV), w.to(DEV), None)
+            dx = hip.deconv5x5s2_dgrad(dy.to(DEV), w.to(DEV))
+            err[mode] = float((y.double().cpu() - ref).norm() / ref.norm())
+            errd[mode] = float((dx.double().cpu() - xr.grad).norm() / xr.grad.norm())
+    finally:
+        _lib.call('gx_kq_precision', 1)
+    print('deconv %s: forward fp32 pipe %.3e, bf16 pipe %.3e; data gradient %.3e / %.3e' % (dist, err[0], err[1], errd[0], errd[1]))
+    assert err[1] <= 1.5 * err[0] + 1e-7 and errd[1] <= 1.5 * errd[0] + 1e-7, (err, errd)

@@ -33,11 +33,23 @@ def test_forward_and_grads_vs_golden(case):
     assert abs(float(err + kl) - elbo_ref) <= 1e-3 * abs(elbo_ref)
     assert abs(float(err + kl) - elbo_ref) <= 5e-5 * abs(elbo_ref)
     (err + kl).backward()
-    # the recurrent UNet(IN) attention (K-1 shared-weight passes) is ill-conditioned in fp32: against the fp64
-    # oracle BOTH the HIP path and the CPU-fp32 path sit at 0.3-3 % relative L2 on its gradients at 64x64 / K=7
-    # (tools/diag_monet.py), while the ComponentVAE gradients agree to 1e-7..1e-5
+    # per-parameter tolerance from the fp32 error budget of THIS case (tests.common.fp32_budget: the CPU oracle in fp32 against
+    # fp64 on the golden weights and inputs): 5 x that error (HIP's 4 x bar + the reference's own) + 1e-3.  The recurrent
+    # UNet(IN) attention (K-1 shared-weight passes) is ill-conditioned in fp32 -- 0.3-3 % for ANY fp32 implementation at
+    # 64x64 / K=7 --, the ComponentVAE gradients agree to 1e-7..1e-5: the budget gives each its own bar
+    from tests.common import budget_tolerances, fp32_budget
+    from oracle import monet_oracle as MO
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+
+    def loss_fn(p, dtype):
+        out = MO.monet_forward(p, x.to(dtype), gold.cfg, eps.to(dtype))
+        e, kl_l, kl_m = MO.aggregate_losses(out[1])
+        return e + kl_l + kl_m
+    e_cpu = fp32_budget(loss_fn, sd, is_param=lambda k: k != 'std')
+    tol = budget_tolerances(e_cpu, floor=1e-3, cap=6e-2)      # (cap: the round-2 constant; floor: ReLU flips, UNet + decoder)
+    print('MONet %s: fp32 budget per parameter: max %.3e, median %.3e' % (case, max(e_cpu.values()), sorted(e_cpu.values())[len(e_cpu) // 2]))
     gold.check_grads([(n, p.grad if p.grad is not None else torch.zeros_like(p)) for n, p in model.named_parameters()],
-                     rtol=4e-2, l2_tol=6e-2)
+                     per_param=tol)
     for key in ('log_m_k', 'log_m_r_k'):
         assert float((torch.stack(stats[key], 4).exp().sum(4) - 1).abs().max()) < 1e-3
 

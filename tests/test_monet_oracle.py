@@ -61,13 +61,16 @@ class MonetGolden(object):
         self.check('sigma_k', st(comp['sigma_k']), rtol, atol)
         self.check('z_k', st(comp['z_k']), rtol, atol)
 
-    def check_grads(self, named_grads, rtol=2e-3, l2_tol=1e-2):
+    def check_grads(self, named_grads, rtol=2e-3, l2_tol=1e-2, per_param=None):
+        """per_param: {name: tolerance} overriding rtol / l2_tol for that parameter (tests.common.budget_tolerances)."""
         names = [str(n) for n in self.g['param_names']]
         norms = self.g['grad_norms']
         big = float(np.max(norms))
         named = dict(named_grads)
         for i, name in enumerate(names):
             g = named[name]
+            if per_param is not None:
+                rtol = l2_tol = per_param[name]
             got = float(g.double().norm().item())
             assert abs(got - float(norms[i])) <= rtol * float(norms[i]) + 2e-5 + 1e-6 * big, (self.name, name, got, norms[i])
             s = T.summarize(g)

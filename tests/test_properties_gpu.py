@@ -62,7 +62,8 @@ def _chunked(case, nchunk, dims):
         _elbo(losses).backward()
         per.append({'err': losses.err.detach().clone(), 'kl': torch.stack(list(losses.kl_l_k), 1).detach().clone(),
                     'recon': recon.detach().clone(), 'seed_idx': torch.stack(list(att['seed_idx'])).clone(),
-                    'log_m': torch.stack(list(stats['log_m_k'])).detach().clone(), 'grad': _grads(model)})
+                    'log_m': torch.stack(list(stats['log_m_k'])).detach().clone(), 'grad': _grads(model),
+                    'colour': att['colour'].detach().clone()})
     model.zero_grad(set_to_none=True)
     return gold, model, xs, rps, epss, per
 
@@ -109,6 +110,13 @@ def test_full_batch_equals_sixteen_golden_sized_chunks(chunked):
     recon, losses, stats, att, comp = model(x, rp, eps)
     free = torch.stack(list(att['seed_idx']))
     assert float((free == seeds).float().mean()) > 0.97          # the argmax is discontinuous: near-ties may flip
+    # what feeds that argmax: the colour embedding of the B = 32 dispatch (Winograd / chip-filling kernels) against the
+    # B = 2 dispatches (direct kernels) -- two fp32 summation orders of the same UNet: bounded at fp32 round-off scale
+    colour_ref = torch.cat([p['colour'] for p in per])
+    dcol = float((att['colour'].detach() - colour_ref).abs().max())
+    scale = float(colour_ref.abs().max())
+    print('colour B=32 vs 16 x B=2: max abs diff %.3e (max |colour| %.3f)' % (dcol, scale))
+    assert dcol <= 2e-5 * max(scale, 1.0), (dcol, scale)
     model.zero_grad(set_to_none=True)
     recon, losses, stats, att, comp = model(x, rp, eps, seeds)
     assert recon.shape == (32, 3, 64, 64)
@@ -248,3 +256,57 @@ def test_full_size_training_is_deterministic_and_descends():
     assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
     err = runs[0][0][:, 1]
     assert float(err[-5:].mean()) < float(err[:5].mean())
+
+
+def test_bf16_pipe_weight_gradients_on_the_activations_of_a_real_step():
+    """The operands the bf16-pipe weight gradients see in training, not synthetic ones: the (x, dy) pairs of every conv3x3 /
+    transposed-conv weight gradient of one B = 32 metric-configuration step are captured on their way into the kernels, and
+    the four largest layers are recomputed in fp64 on the host: the kernel's error stays at the fp32 pipe's level."""
+    from genesis_amd import hip_ops as hip, _lib
+    from tests.common import Golden
+    from tests.test_model_gpu import build
+    gold = Golden('metric')
+    model = build(gold)
+    B = 32
+    x = torch.rand(B, 3, 64, 64, generator=torch.Generator().manual_seed(11)).to(DEV)
+    torch.manual_seed(3); torch.cuda.manual_seed(3)
+    captured = []
+    real_c3, real_dc = hip.conv3x3_wgrad, hip.deconv5x5s2_wgrad
+
+    def cap_c3(xx, dy, out=None):
+        captured.append(('conv3x3', xx.detach().clone(), dy.detach().clone()))
+        return real_c3(xx, dy, out=out)
+
+    def cap_dc(xx, dy, out=None):
+        captured.append(('deconv', xx.detach().clone(), dy.detach().clone()))
+        return real_dc(xx, dy, out=out)
+    hip.conv3x3_wgrad, hip.deconv5x5s2_wgrad = cap_c3, cap_dc
+    try:
+        recon, losses, stats, att, comp = model(x)
+        _elbo(losses).backward()
+    finally:
+        hip.conv3x3_wgrad, hip.deconv5x5s2_wgrad = real_c3, real_dc
+    assert len(captured) >= 10
+    captured.sort(key=lambda c: -c[1].numel() * c[2].shape[1])
+    import torch.nn.functional as F
+    for kind, xx, dy in captured[:4]:
+        xc, dc = xx.cpu().double(), dy.cpu().double()
+        if kind == 'conv3x3':
+            ref = torch.nn.grad.conv2d_weight(xc, (dy.shape[1], xx.shape[1], 3, 3), dc, padding=1)
+            run = lambda: real_c3(xx, dy)  # noqa: E731
+        else:
+            w = torch.zeros(xx.shape[1], dy.shape[1], 5, 5, dtype=torch.float64, requires_grad=True)
+            F.conv_transpose2d(xc, w, None, 2, 2, 1).backward(dc)
+            ref = w.grad
+            run = lambda: real_dc(xx, dy)  # noqa: E731
+        err = {}
+        try:
+            for mode in (0, 1):
+                _lib.call('gx_wgq_precision', mode)
+                err[mode] = float((run().double().cpu() - ref).norm() / ref.norm())
+        finally:
+            _lib.call('gx_wgq_precision', 1)
+        print('%s x %s dy %s (x: mean %.3f std %.3f, zeros %.2f; dy: mean %.2e std %.2e): fp32 pipe %.3e, bf16 pipe %.3e'
+              % (kind, tuple(xx.shape), tuple(dy.shape), float(xx.mean()), float(xx.std()), float((xx == 0).float().mean()),
+                 float(dy.mean()), float(dy.std()), err[0], err[1]))
+        assert err[1] <= 1.5 * err[0] + 1e-7 and err[1] < 1e-5, err
