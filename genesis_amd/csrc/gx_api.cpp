@@ -94,7 +94,7 @@ int gx_version(void) { return 1; }
 // launch per kind (gx_defer_flush) finishes all of them after the backward pass.  The caller keeps the queued
 // workspaces alive until the flush.
 namespace {
-constexpr int kMaxDefer = 48;
+constexpr int kMaxDefer = 128;     // (MONet's shared UNet queues 6 passes x 10 layers)
 struct DeferQueues { GxWgradRed wq[kMaxDefer]; GxGnRed gq[kMaxDefer]; int nw = 0, ng = 0; };
 DeferQueues g_defer[kGxMaxCtx];
 #define g_wq (g_defer[t_ctx].wq)

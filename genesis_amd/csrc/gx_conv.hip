@@ -1715,6 +1715,7 @@ int launch_wgrad_reduce(const float* partial, float* dw, const WgradPlan& pl, in
                      merged ? cb[1] - cb[0] : 0, merged ? cb[2] - cb[1] : 0, merged ? cb[3] - cb[2] : 0,
                      merged ? cb[4] - cb[3] : 0};
         if (gx_defer_push_wgrad(r)) return GX_OK;
+        return gx_defer_flush_wgrad(&r, 1, s);      // queue full: reduce now, ACCUMULATING like the batched flush
     }
     const int total = pl.g.Ttot * pl.g.CA * pl.g.CB;
     const int blocks = gx_ceil_div(total, 64);
@@ -1741,14 +1742,24 @@ int check_dims(const char* name, int N, int Cin, int Cout, int H, int W) {
 
 // =================================================================== C ABI
 int gx_defer_flush_wgrad(const GxWgradRed* items, int n, hipStream_t s) {
-    for (int i0 = 0; i0 < n; i0 += kRedPerLaunch) {
-        const int m = n - i0 < kRedPerLaunch ? n - i0 : kRedPerLaunch;
+    // the records of one launch ACCUMULATE into their destinations from different workgroups: two records of one launch
+    // must not share a destination block (a weight used several times per iteration -- MONet's recurrent UNet -- queues
+    // one record per use).  Rounds: a launch takes, in queue order, the records whose destination it does not hold yet;
+    // a destination therefore receives its contributions in queue order, one launch after the other (deterministic).
+    std::vector<int> pending(n);
+    for (int i = 0; i < n; ++i) pending[i] = i;
+    while (!pending.empty()) {
+        std::vector<int> later;
         WgradRedTable tab;
-        int maxblocks = 1;
+        int m = 0, maxblocks = 1;
         double bytes = 0.0;
-        for (int i = 0; i < m; ++i) {
-            const GxWgradRed& it = items[i0 + i];
-            tab.e[i] = it;
+        for (int idx : pending) {
+            const GxWgradRed& it = items[idx];
+            bool clash = m >= kRedPerLaunch;
+            for (int k = 0; k < m && !clash; ++k)
+                clash = tab.e[k].dw == it.dw && tab.e[k].ca0 == it.ca0 && tab.e[k].cb0 == it.cb0;
+            if (clash) { later.push_back(idx); continue; }
+            tab.e[m++] = it;
             const int total = it.Ttot * it.CA * it.CB;
             const int total4 = it.Ttot * it.CA * (it.CBpad >> 2);
             maxblocks = gx_ceil_div(total4, 64) > maxblocks ? gx_ceil_div(total4, 64) : maxblocks;
@@ -1759,6 +1770,7 @@ int gx_defer_flush_wgrad(const GxWgradRed* items, int n, hipStream_t s) {
             hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(maxblocks, m), dim3(256), 0, s, tab);
         }
         GX_CHECK_LAUNCH("gx_defer_flush(wgrad)");
+        pending.swap(later);
     }
     return GX_OK;
 }

@@ -15,6 +15,8 @@
 // exist.  Backward mirrors this: it gathers the incoming gradient from up to two views.
 #include "gx_common.h"
 
+#include <vector>
+
 namespace {
 
 struct View {
@@ -1048,19 +1050,32 @@ int check_view(const char* name, const View& v, int C) {
 }  // namespace
 
 int gx_defer_flush_gn(const GxGnRed* items, int n, hipStream_t s) {
-    GnRedTable tab;
-    int maxc = 1;
-    double bytes = 0.0;
-    for (int i = 0; i < n; ++i) {
-        tab.e[i] = items[i];
-        maxc = items[i].C > maxc ? items[i].C : maxc;
-        bytes += 12.0 * items[i].N * items[i].C;
+    constexpr int kPerLaunch = 48;      // = the table's capacity (it travels as a kernel argument)
+    // records of one launch accumulate from different workgroups: no two of them may share a destination (a GroupNorm used
+    // several times per iteration queues one record per use) -- rounds in queue order, as gx_defer_flush_wgrad
+    std::vector<int> pending(n);
+    for (int i = 0; i < n; ++i) pending[i] = i;
+    while (!pending.empty()) {
+        std::vector<int> later;
+        GnRedTable tab;
+        int cnt = 0, maxc = 1;
+        double bytes = 0.0;
+        for (int idx : pending) {
+            const GxGnRed& it = items[idx];
+            bool clash = cnt >= kPerLaunch;
+            for (int k = 0; k < cnt && !clash; ++k) clash = tab.e[k].dgamma == it.dgamma;
+            if (clash) { later.push_back(idx); continue; }
+            tab.e[cnt++] = it;
+            maxc = it.C > maxc ? it.C : maxc;
+            bytes += 12.0 * it.N * it.C;
+        }
+        {
+            GxProf pf(KID_GN_PARAM_REDUCE, s, 0.0, bytes);
+            hipLaunchKernelGGL(gn_param_reduce_batch_kernel, dim3(maxc, cnt), dim3(256), 0, s, tab);
+        }
+        GX_CHECK_LAUNCH("gx_defer_flush(gn)");
+        pending.swap(later);
     }
-    {
-        GxProf pf(KID_GN_PARAM_REDUCE, s, 0.0, bytes);
-        hipLaunchKernelGGL(gn_param_reduce_batch_kernel, dim3(maxc, n), dim3(256), 0, s, tab);
-    }
-    GX_CHECK_LAUNCH("gx_defer_flush(gn)");
     return GX_OK;
 }
 
@@ -1216,7 +1231,11 @@ static int gn_relu_bwd_impl(const float* y, const float* gamma, const float* bet
                                rstd, C, H, W, groups, v0, v1, dy, (float*)ws);
     }
     GX_CHECK_LAUNCH("gx_gn_relu_bwd");
-    if (g_gx_defer_on && gx_defer_push_gn(GxGnRed{(const float*)ws, dgamma, dbeta, dbias, N, C})) return GX_OK;
+    if (g_gx_defer_on) {
+        const GxGnRed rec{(const float*)ws, dgamma, dbeta, dbias, N, C};
+        if (gx_defer_push_gn(rec)) return GX_OK;
+        return gx_defer_flush_gn(&rec, 1, s);       // queue full: reduce now, ACCUMULATING like the batched flush
+    }
     {
         GxProf pf(KID_GN_PARAM_REDUCE, s, 0.0, 12.0 * N * C);
         hipLaunchKernelGGL(gn_param_reduce_kernel, dim3(C), dim3(N >= 128 ? 256 : 64), 0, s, (const float*)ws, N, C,

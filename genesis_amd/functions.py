@@ -81,14 +81,19 @@ def begin_direct_grads():
     step_state().direct_written.clear()
 
 
-def _gout(p):
+def _gout(p, acc=False):
     """Destination for a parameter gradient: p.grad if direct writes are on and it is a usable buffer.  Only the
     FIRST gradient of a parameter in an iteration is written directly (it overwrites the zeroed bucket); a parameter
-    that is used again (MONet's recurrent UNet shares its weights over K-1 passes) accumulates through autograd."""
+    that is used again (MONet's recurrent UNet shares its weights over K-1 passes) accumulates through autograd --
+    unless the caller's kernel finishes through the deferred reductions (acc=True: conv weight gradients and GroupNorm
+    affine gradients, whose queued reduce ADDS into the buffer): then every use goes straight into p.grad, all of them
+    in the step's one stream-K launch / batched reduce."""
     st = step_state()
     if st.direct_param_grads and isinstance(p, torch.nn.Parameter) and p.grad is not None and p.grad.is_contiguous():
         if id(p) not in st.direct_written:
             st.direct_written.add(id(p))
+            return p.grad
+        if acc and hip.defer_state().on and not st.async_wgrad:
             return p.grad
         # a further use of a shared parameter accumulates through autograd on the MAIN stream: if the first-use direct
         # write was forked onto the side stream (async_wgrad), order the accumulation behind it
@@ -282,7 +287,7 @@ class UNetEncoderFn(torch.autograd.Function):
         for j in reversed(range(nb)):
             w, gamma, beta = up[j]
             y, mean, rstd = ctx.saved_up[j]
-            ow, og, ob = _gout(w), _gout(gamma), _gout(beta)
+            ow, og, ob = _gout(w, True), _gout(gamma, True), _gout(beta, True)
             dy, dgamma, dbeta, _ = hip.gn_relu_bwd(y, gamma, beta, mean, rstd, ctx.ngroups(y.shape[1]), gsrc,
                                                    out=(og, ob, None))
             dw = _wgrad(lambda cj=cats[j], dy=dy, ow=ow: hip.conv3x3_wgrad(cj, dy, out=ow), ow, cats[j], dy)
@@ -311,7 +316,7 @@ class UNetEncoderFn(torch.autograd.Function):
             cx = cats[j].shape[1] - C
             g0 = (dcat[j], cx, 0)
             g1 = (d_mlp_in, 0, 0) if i == nb - 1 else (d_next, 0, 2)
-            ow, og, ob = _gout(w), _gout(gamma), _gout(beta)
+            ow, og, ob = _gout(w, True), _gout(gamma, True), _gout(beta, True)
             dy, dgamma, dbeta, _ = hip.gn_relu_bwd(y, gamma, beta, mean, rstd, ctx.ngroups(C), g0, g1,
                                                    out=(og, ob, None))
             dw = _wgrad(lambda cur=cur, dy=dy, ow=ow: hip.conv3x3_wgrad(cur, dy, out=ow), ow, cur, dy)

@@ -89,3 +89,42 @@ def test_output_contract_and_sample():
     assert img.shape == (3, 3, S, S) and len(st.x_k) == K
     assert float((torch.stack(st.log_m_k, 4).exp().sum(4) - 1).abs().max()) < 1e-3
     assert list(model.state_dict().keys())[0] == 'std'
+
+
+def test_shared_weights_accumulate_through_the_deferred_reductions():
+    """MONet's attention UNet is ONE set of weights used K-1 times per iteration.  Inside TrainStep every use's conv weight
+    gradient and GroupNorm affine gradient goes through the deferred reductions into the flat bucket (the queued reduces ADD;
+    records that share a destination are split over consecutive launches): the bucket must equal plain autograd's
+    accumulated gradient, bit-identically from run to run."""
+    from genesis_amd.trainer import TrainStep
+    gold = MonetGolden('tiny_k4')
+    x, eps = gold.inputs()
+    xd, ed = x.to(DEV), eps.to(DEV)
+    ref_model = build(gold)
+    recon, losses, _, _, _ = ref_model(xd, ed)
+    (losses.err.mean(0) + torch.stack(losses.kl_l_k, dim=1).mean(dim=0).sum() + losses.kl_m.mean(0)).backward()
+    ref = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).flatten() for p in ref_model.parameters()])
+    runs = []
+    for _ in range(4):
+        model = build(gold)
+        ts = TrainStep(model, gold.S, lr=1e-4, graph=False)
+        ts._zero_grads()
+        ts._enter()
+        try:
+            ts._forward_backward(xd, eps=ed)          # beta = 1 at the first iteration: the same objective
+        finally:
+            ts._leave()
+        torch.cuda.synchronize()
+        runs.append(torch.cat([p.grad.flatten() for p in model.parameters()]).clone())
+        ts.close()
+    for r in runs[1:]:
+        assert torch.equal(runs[0], r)
+    rel = float((runs[0] - ref).norm() / ref.norm())
+    assert rel < 2e-5, rel
+    # per parameter: nothing lost, nothing counted twice
+    off = 0
+    for n, p in ref_model.named_parameters():
+        a, b = runs[0][off:off + p.numel()], ref[off:off + p.numel()]
+        off += p.numel()
+        if float(b.norm()) > 1e-6 * float(ref.norm()):
+            assert float((a - b).norm()) <= 2e-4 * float(b.norm()), n
