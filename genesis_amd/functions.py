@@ -794,10 +794,28 @@ class BroadcastDecoderFn(torch.autograd.Function):
                 dz, dw, db = hip.bcast_conv3x3_bwd(y, da, z, w, rowc, colc, act, out=(gw, gb))
             else:
                 dy, db = hip.bias_act_bwd(y, da, act, True, gb)
-                dw = hip.conv3x3_wgrad(h, dy, out=gw)
+                dw = _wgrad_paired(h, dy, gw)
                 da = hip.conv3x3_dgrad(dy, w)
             grads[2 * l], grads[2 * l + 1] = _ret(gw, dw), _ret(gb, db)
         return (dz, None, None, None) + tuple(grads)
+
+
+def _wgrad_paired(h, dy, gw):
+    """conv3x3 weight gradient of a layer with <= 32 channels on both sides (the BroadcastDecoder's 32 -> 32 convs on the
+    canvas): the kernels work on 64 x 64 channel blocks, so such a layer fills a quarter of every MFMA.  Two consecutive
+    images of an NCHW tensor ARE one image of twice the channels ([N, 32, H, W] viewed as [N / 2, 64, H, W]): the 64 x 64
+    weight gradient of the paired tensors holds the even images' sum in its upper-left 32 x 32 block and the odd images'
+    in its lower-right one (the off-diagonal blocks are cross-image products nobody wants) -- half of the MFMA work is
+    useful instead of a quarter, with no kernel change.  Returns dw (or None after writing gw)."""
+    N, Ci, Co = h.shape[0], h.shape[1], dy.shape[1]
+    if N % 2 or Ci > 32 or Co > 32 or Ci != Co or Ci % 8:
+        return hip.conv3x3_wgrad(h, dy, out=gw)
+    d64 = hip.conv3x3_wgrad(h.view(N // 2, 2 * Ci, *h.shape[2:]), dy.view(N // 2, 2 * Co, *dy.shape[2:]))
+    dw = d64[:Co, :Ci] + d64[Co:, Ci:]
+    if gw is not None:
+        gw.copy_(dw)
+        return None
+    return dw
 
 
 @ctx_bound
