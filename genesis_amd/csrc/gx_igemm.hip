@@ -245,7 +245,84 @@ int wgrad_splits(const IG& g) {
 
 }  // namespace
 
+// ---- conv3x3 stride 2 pad 1: data gradient without the stride's structural zeros ---------------------------------
+// The ComponentVAE encoder's four stride-2 3x3 convs (modules/encoders.py:31-34; 4 -> 32 -> 32 -> 64 -> 64 channels on the
+// K B slot images) are 0.5 % of MONet's / GENESIS' flops, but their data gradients on the generic implicit-GEMM kernel --
+// a 64-wide output-channel tile for 4 .. 64 channels, three of four gathered taps structurally zero -- took 0.86 ms per
+// step (495 us for the first layer alone, whose dx is needed for ONE channel: the mask; the image channels carry no
+// gradient).  Here a thread owns a 2 x 2 block of dx pixels (all four stride parities: 1 + 2 + 2 + 4 = 9 taps, the same
+// work for every thread) for CIB input channels and walks the output channels: 4 dy loads feed 9 CIB FMAs, weights
+// broadcast from LDS.  Exactly the useful multiply-adds, on the vector ALUs.
+template <int CIB>
+__global__ void __launch_bounds__(256)
+conv3x3s2_dgrad_small_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int Cin,
+                             int Cout, int H, int W, int cin_n) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];       // [Cout][CIB][12]: 9 taps, padded to 3 float4
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int n = blockIdx.z, ci0 = blockIdx.y * CIB;
+    for (int e = threadIdx.x; e < Cout * CIB * 9; e += 256) {
+        const int t = e % 9, c = (e / 9) % CIB, co = e / (9 * CIB);
+        wl[(co * CIB + c) * 12 + t] = ci0 + c < Cin ? w[((size_t)co * Cin + ci0 + c) * 9 + t] : 0.f;
+    }
+    __syncthreads();
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= Ho * Wo) return;
+    const int i = p / Wo, j = p - i * Wo;
+    const bool jr = j + 1 < Wo, ir = i + 1 < Ho;
+    const float* d = dy + (size_t)n * Cout * Ho * Wo + (size_t)i * Wo + j;
+    float a00[CIB], a01[CIB], a10[CIB], a11[CIB];
+#pragma unroll
+    for (int c = 0; c < CIB; ++c) { a00[c] = 0.f; a01[c] = 0.f; a10[c] = 0.f; a11[c] = 0.f; }
+    for (int co = 0; co < Cout; ++co) {
+        const float* dc = d + (size_t)co * Ho * Wo;
+        const float d00 = dc[0];
+        const float d01 = jr ? dc[1] : 0.f;
+        const float d10 = ir ? dc[Wo] : 0.f;
+        const float d11 = (ir && jr) ? dc[Wo + 1] : 0.f;
+#pragma unroll
+        for (int c = 0; c < CIB; ++c) {
+            const f32x4* wp = reinterpret_cast<const f32x4*>(wl + (co * CIB + c) * 12);
+            const f32x4 w0 = wp[0], w1 = wp[1], w2 = wp[2];       // taps 0-3 | 4-7 | 8
+            // dx(2i + a, 2j + b) = sum over kh = (a + 1) mod 2 .., kw likewise of dy((2i + a + 1 - kh) / 2, ..) w[kh][kw]
+            a00[c] += d00 * w1[0];                                              // w[1][1]
+            a01[c] += d00 * w1[1] + d01 * w0[3];                                // w[1][2], w[1][0]
+            a10[c] += d00 * w1[3] + d10 * w0[1];                                // w[2][1], w[0][1]
+            a11[c] += d00 * w2[0] + d01 * w1[2] + d10 * w0[2] + d11 * w0[0];    // w[2][2], w[2][0], w[0][2], w[0][0]
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CIB; ++c) {
+        if (ci0 + c >= cin_n) break;
+        float* o = dx + (((size_t)n * Cin + ci0 + c) * H + 2 * i) * W + 2 * j;
+        *reinterpret_cast<float2*>(o) = make_float2(a00[c], a01[c]);
+        *reinterpret_cast<float2*>(o + W) = make_float2(a10[c], a11[c]);
+    }
+}
+
 extern "C" {
+
+/* conv3x3 stride 2 pad 1 (even H, W) data gradient on the vector ALUs: dx [N,Cin,H,W] from dy [N,Cout,H/2,W/2], w
+ * [Cout,Cin,3,3]; only the first cin_n channels of dx are computed and written (the others are left untouched). */
+int gx_conv3x3s2_dgrad_small(const float* dy, const float* w, float* dx, int N, int Cin, int Cout, int H, int W, int cin_n,
+                             gx_stream_t stream) {
+    GX_CHECK_ARG(dy && w && dx, "gx_conv3x3s2_dgrad_small: null pointer");
+    GX_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && H >= 2 && W >= 2 && !(H & 1) && !(W & 1) && N <= 65535,
+                 "gx_conv3x3s2_dgrad_small: even H, W; N <= 65535");
+    GX_CHECK_ARG(cin_n >= 1 && cin_n <= Cin && Cout * 4 * 12 * 4 <= 64 * 1024, "gx_conv3x3s2_dgrad_small: 1 <= cin_n <= Cin, Cout <= 341");
+    hipStream_t s = (hipStream_t)stream;
+    const int npix = (H / 2) * (W / 2);
+    {
+        GxProf pf(KID_DCONV, s, 2.0 * N * Cout * (double)cin_n * 9 * npix, 4.0 * N * ((double)cin_n * H * W + (double)Cout * npix));
+        if (cin_n <= 2)
+            hipLaunchKernelGGL(conv3x3s2_dgrad_small_kernel<2>, dim3(gx_ceil_div(npix, 256), gx_ceil_div(cin_n, 2), N), dim3(256),
+                               (size_t)Cout * 2 * 12 * 4, s, dy, w, dx, Cin, Cout, H, W, cin_n);
+        else
+            hipLaunchKernelGGL(conv3x3s2_dgrad_small_kernel<4>, dim3(gx_ceil_div(npix, 256), gx_ceil_div(cin_n, 4), N), dim3(256),
+                               (size_t)Cout * 4 * 12 * 4, s, dy, w, dx, Cin, Cout, H, W, cin_n);
+    }
+    GX_CHECK_LAUNCH("gx_conv3x3s2_dgrad_small");
+    return GX_OK;
+}
 
 int gx_conv2d_direct_fwd(const float* x, const float* w, const float* bias, int act, float* y, int N, int Cin,
                          int Cout, int H, int W, int k, int stride, int pad, gx_stream_t stream) {

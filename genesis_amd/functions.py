@@ -702,24 +702,32 @@ class DirectConvActFn(torch.autograd.Function):
     modules/encoders.py:31-34)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, act):
+    def forward(ctx, x, w, b, stride, pad, act, dx_channels=None):
+        """dx_channels: only the first dx_channels input channels carry a gradient (the encoder's first layer: the mask
+        channel; the image channels are data) -- the others' dx is returned as zeros."""
         x = x.contiguous()
         y = hip.conv2d_direct_fwd(x, w, b, act, stride, pad)
         ctx.save_for_backward(x, y)
         ctx.params = (w, b)
-        ctx.cfg = (stride, pad, act)
+        ctx.cfg = (stride, pad, act, dx_channels)
         return y
 
     @staticmethod
     def backward(ctx, g):
         x, y = ctx.saved_tensors
         w, b = ctx.params
-        stride, pad, act = ctx.cfg
+        stride, pad, act, dx_channels = ctx.cfg
         ow, ob = _gout(w), _gout(b)
         dy, db = hip.bias_act_bwd(y, g.contiguous(), act, True, ob)
         dw = hip.conv2d_direct_wgrad(x, dy, w.shape[2], stride, pad, out=ow)
-        dx = hip.conv2d_direct_dgrad(dy, w, x.shape[2], x.shape[3], stride, pad) if ctx.needs_input_grad[0] else None
-        return dx, _ret(ow, dw), _ret(ob, db), None, None, None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            H, W = x.shape[2], x.shape[3]
+            if w.shape[2] == 3 and stride == 2 and pad == 1 and H % 2 == 0 and W % 2 == 0 and w.shape[0] <= 256:
+                dx = hip.conv3x3s2_dgrad_small(dy, w, H, W, dx_channels)      # no structural zeros, vector ALUs
+            else:
+                dx = hip.conv2d_direct_dgrad(dy, w, H, W, stride, pad)
+        return dx, _ret(ow, dw), _ret(ob, db), None, None, None, None
 
 
 @ctx_bound

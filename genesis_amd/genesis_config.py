@@ -181,7 +181,8 @@ class Genesis(nn.Module):
                 em = self.comp_vae.encoder_module.module
                 h = inp
                 for i in (0, 2, 4, 6):
-                    h = fn.DirectConvActFn.apply(h, em[i].weight, em[i].bias, 2, 1, 'elu')
+                    # (first layer: only the mask channel of [log_m | x] carries a gradient)
+                    h = fn.DirectConvActFn.apply(h, em[i].weight, em[i].bias, 2, 1, 'elu', 1 if i == 0 else None)
                 h = F.elu(fn.linear(h.flatten(1), em[9].weight, em[9].bias))
                 mu_c, sig_ps = fn.linear(h, em[11].weight, em[11].bias).chunk(2, dim=1)
             sig_c = F.softplus(sig_ps + 0.5) + 1e-8

@@ -542,6 +542,18 @@ def conv2d_direct_dgrad(dy, w, H, W, stride, pad):
     return dx
 
 
+def conv3x3s2_dgrad_small(dy, w, H, W, cin_n=None):
+    """dx [N,Cin,H,W] of a conv3x3 stride 2 pad 1 from dy [N,Cout,H/2,W/2]; only the first cin_n channels are computed, the
+    others are zero (gx_conv3x3s2_dgrad_small)."""
+    _chk(dy, 'conv3x3s2_dgrad.dy'); _chk(w, 'conv3x3s2_dgrad.w')
+    N = dy.shape[0]
+    Cout, Cin = w.shape[0], w.shape[1]
+    cin_n = Cin if cin_n is None else int(cin_n)
+    dx = (torch.empty if cin_n == Cin else torch.zeros)(N, Cin, H, W, dtype=F32, device=dy.device)
+    _lib.call('gx_conv3x3s2_dgrad_small', _p(dy), _p(w), _p(dx), N, Cin, Cout, H, W, cin_n, _stream())
+    return dx
+
+
 def conv2d_direct_wgrad(x, dy, k, stride, pad, out=None):
     _chk(x, 'conv2d_direct_wgrad.x'); _chk(dy, 'conv2d_direct_wgrad.dy')
     N, Cin, H, W = x.shape

@@ -154,7 +154,8 @@ class MONet(nn.Module):
         em = self.comp_vae.encoder_module.module
         h = inp
         for i in (0, 2, 4, 6):
-            h = fn.DirectConvActFn.apply(h, em[i].weight, em[i].bias, 2, 1, 'relu')
+            # (first layer: only the mask channel of [log_m | x] carries a gradient)
+            h = fn.DirectConvActFn.apply(h, em[i].weight, em[i].bias, 2, 1, 'relu', 1 if i == 0 else None)
         h = fn.linear(h.flatten(1), em[9].weight, em[9].bias, 'relu')
         mu, sigma_ps = fn.linear(h, em[11].weight, em[11].bias).chunk(2, dim=1)
         sigma = F.softplus(sigma_ps + 0.5) + 1e-8

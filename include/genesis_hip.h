@@ -279,6 +279,11 @@ size_t gx_conv5x5_wgrad_ws_bytes(int N, int CA, int CB, int H, int W);
 int gx_conv5x5_wgrad(const float* a, const float* b, float* dw, int N, int CA, int CB, int H, int W, void* ws,
                      size_t ws_bytes, gx_stream_t stream);
 
+/*      conv3x3 stride 2 pad 1 data gradient (the ComponentVAE encoder, modules/encoders.py:31-34) without the stride's
+ *      structural zeros, on the vector ALUs: only the first cin_n channels of dx [N,Cin,H,W] are computed and written
+ *      (the encoder's first layer needs the mask channel's gradient alone). */
+int gx_conv3x3s2_dgrad_small(const float* dy, const float* w, float* dx, int N, int Cin, int Cout, int H, int W, int cin_n,
+                             gx_stream_t stream);
 int gx_conv2d_direct_fwd(const float* x, const float* w, const float* bias, int act, float* y, int N, int Cin,
                          int Cout, int H, int W, int k, int stride, int pad, gx_stream_t stream);
 int gx_conv2d_direct_dgrad(const float* dy, const float* w, float* dx, int N, int Cin, int Cout, int H, int W, int k,

@@ -1247,3 +1247,19 @@ def test_bf16_pipe_transposed_conv_on_hard_operands(dist):
         _lib.call('gx_kq_precision', 1)
     print('deconv %s: forward fp32 pipe %.3e, bf16 pipe %.3e; data gradient %.3e / %.3e' % (dist, err[0], err[1], errd[0], errd[1]))
     assert err[1] <= 1.5 * err[0] + 1e-7 and errd[1] <= 1.5 * errd[0] + 1e-7, (err, errd)
+
+
+@pytest.mark.parametrize('N,Cin,Cout,S,cin_n', [(5, 4, 32, 64, 1), (5, 4, 32, 64, None), (3, 32, 32, 32, None), (4, 32, 64, 16, None),
+                                                 (7, 64, 64, 8, None), (2, 6, 10, 12, 3)])
+def test_conv3x3_stride2_dgrad_on_the_vector_alus(N, Cin, Cout, S, cin_n):
+    """gx_conv3x3s2_dgrad_small (ComponentVAE encoder, modules/encoders.py:31-34): the stride-2 conv3x3 data gradient as 2 x 2
+    parity blocks on the vector ALUs against autograd in fp64; cin_n limits the computed channels (the rest stays zero)."""
+    from genesis_amd import hip_ops as hip
+    x = rnd(N, Cin, S, S, seed=1).double().requires_grad_()
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=0.2)
+    dy = rnd(N, Cout, S // 2, S // 2, seed=3)
+    F.conv2d(x, w.double(), None, 2, 1).backward(dy.double())
+    dx = hip.conv3x3s2_dgrad_small(dy.to(DEV), w.to(DEV), S, S, cin_n)
+    n = Cin if cin_n is None else cin_n
+    close(dx[:, :n], x.grad[:, :n], rtol=1e-5, atol=1e-5, msg='dx')
+    assert float(dx[:, n:].abs().sum()) == 0.0
