@@ -299,7 +299,108 @@ conv3x3s2_dgrad_small_kernel(const float* __restrict__ dy, const float* __restri
     }
 }
 
+// ---- ... and its weight gradient: dw[co][ci][kh][kw] = sum_{n,i,j} dy[n][co][i][j] x[n][ci][2i - 1 + kh][2j - 1 + kw].
+// Lanes = output pixels (coalesced dy rows, stride-2 x windows), a thread accumulates 9 taps x COB output channels of ONE
+// input channel over its pixels (9 + COB loads feed 9 COB FMAs), the workgroup's 256 partial sets are summed through LDS,
+// split-K over gridDim.x with a fixed-order final reduce (igemm_reduce_kernel).  Generic kernel: 44-157 us per layer.
+template <int COB>
+__global__ void __launch_bounds__(256)
+conv3x3s2_wgrad_small_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int N,
+                             int Cin, int Cout, int H, int W) {
+    constexpr int NV = COB * 9;
+    static_assert(NV * 2 <= 256, "one reducer thread per (value, quarter)");
+    __shared__ float red[(NV / 2) * 257];
+    __shared__ float red2[NV * 4];
+    const int Ho = H >> 1, Wo = W >> 1, HoWo = Ho * Wo;
+    const int ci = blockIdx.y, co0 = blockIdx.z * COB;
+    const int P = N * HoWo;
+    const int chunk = (P + gridDim.x - 1) / gridDim.x;
+    const int begin = blockIdx.x * chunk, end = begin + chunk < P ? begin + chunk : P;
+    float acc[COB][9];
+#pragma unroll
+    for (int c = 0; c < COB; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
+    for (int p = begin + threadIdx.x; p < end; p += 256) {
+        const int n = p / HoWo, r = p - n * HoWo;
+        const int i = r / Wo, j = r - i * Wo;
+        const float* xp = x + (((size_t)n * Cin + ci) * H + 2 * i) * W + 2 * j;          // window centre row 2i, col 2j
+        float xw[9];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const bool ok = (kh > 0 || i > 0) && (kw > 0 || j > 0);                  // row 2i - 1 / col 2j - 1 exist
+                xw[kh * 3 + kw] = ok ? xp[(kh - 1) * W + (kw - 1)] : 0.f;
+            }
+        const float* dp = dy + ((size_t)n * Cout + co0) * HoWo + r;
+#pragma unroll
+        for (int c = 0; c < COB; ++c) {
+            const float d = co0 + c < Cout ? dp[(size_t)c * HoWo] : 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[c][t] += d * xw[t];
+        }
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {              // 36 values x 256 threads per pass (37 KB of LDS)
+#pragma unroll
+        for (int c = 0; c < COB / 2; ++c)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) red[(c * 9 + t) * 257 + threadIdx.x] = acc[half * (COB / 2) + c][t];
+        __syncthreads();
+        if (threadIdx.x < NV * 2) {
+            const int v = threadIdx.x >> 2, q = threadIdx.x & 3;
+            float sum = 0.f;
+            for (int l = 0; l < 64; ++l) sum += red[v * 257 + q * 64 + ((l + 16 * q) & 63)];   // quarters on distinct banks
+            red2[half * NV * 2 + threadIdx.x] = sum;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < NV) {
+        const int c = threadIdx.x / 9, t = threadIdx.x - c * 9;
+        if (co0 + c < Cout) {
+            const float* r4 = red2 + threadIdx.x * 4;
+            part[(size_t)blockIdx.x * Cout * Cin * 9 + ((size_t)(co0 + c) * Cin + ci) * 9 + t] = (r4[0] + r4[1]) + (r4[2] + r4[3]);
+        }
+    }
+}
+
 extern "C" {
+
+size_t gx_conv3x3s2_wgrad_small_ws_bytes(int N, int Cin, int Cout, int H, int W) {
+    (void)N; (void)H; (void)W;
+    return (size_t)64 * Cout * Cin * 9 * sizeof(float);
+}
+
+/* conv3x3 stride 2 pad 1 (even H, W) weight gradient on the vector ALUs: dw [Cout,Cin,3,3] from x [N,Cin,H,W], dy
+ * [N,Cout,H/2,W/2]; ws: gx_conv3x3s2_wgrad_small_ws_bytes. */
+int gx_conv3x3s2_wgrad_small(const float* x, const float* dy, float* dw, int N, int Cin, int Cout, int H, int W, void* ws,
+                             size_t ws_bytes, gx_stream_t stream) {
+    GX_CHECK_ARG(x && dy && dw && ws, "gx_conv3x3s2_wgrad_small: null pointer");
+    GX_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && H >= 2 && W >= 2 && !(H & 1) && !(W & 1) && Cin <= 65535,
+                 "gx_conv3x3s2_wgrad_small: even H, W");
+    GX_CHECK_ARG(ws_bytes >= gx_conv3x3s2_wgrad_small_ws_bytes(N, Cin, Cout, H, W), "gx_conv3x3s2_wgrad_small: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int P = N * (H / 2) * (W / 2);
+    const int blocks = Cin * gx_ceil_div(Cout, 8);
+    int S = gx_ceil_div(2048, blocks);                  // ~8 workgroups per CU
+    if (S > 64) S = 64;
+    if (S > gx_ceil_div(P, 1024)) S = gx_ceil_div(P, 1024);
+    if (S < 1) S = 1;
+    {
+        GxProf pf(KID_DCONV, s, 2.0 * N * Cout * (double)Cin * 9 * (H / 2) * (W / 2), 4.0 * N * ((double)Cin * H * W + (double)Cout * (H / 2) * (W / 2)));
+        hipLaunchKernelGGL(conv3x3s2_wgrad_small_kernel<8>, dim3(S, Cin, gx_ceil_div(Cout, 8)), dim3(256), 0, s, x, dy, (float*)ws,
+                           N, Cin, Cout, H, W);
+    }
+    GX_CHECK_LAUNCH("gx_conv3x3s2_wgrad_small");
+    {
+        const int total = Cout * Cin * 9;
+        GxProf pf(KID_SMALL_REDUCE, s, 0.0, 4.0 * (S + 1.0) * total);
+        hipLaunchKernelGGL(igemm_reduce_kernel, dim3(gx_ceil_div(total, 256)), dim3(256), 0, s, (const float*)ws, dw, total, S);
+    }
+    GX_CHECK_LAUNCH("gx_conv3x3s2_wgrad_small(reduce)");
+    return GX_OK;
+}
 
 /* conv3x3 stride 2 pad 1 (even H, W) data gradient on the vector ALUs: dx [N,Cin,H,W] from dy [N,Cout,H/2,W/2], w
  * [Cout,Cin,3,3]; only the first cin_n channels of dx are computed and written (the others are left untouched). */

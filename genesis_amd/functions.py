@@ -719,11 +719,15 @@ class DirectConvActFn(torch.autograd.Function):
         stride, pad, act, dx_channels = ctx.cfg
         ow, ob = _gout(w), _gout(b)
         dy, db = hip.bias_act_bwd(y, g.contiguous(), act, True, ob)
-        dw = hip.conv2d_direct_wgrad(x, dy, w.shape[2], stride, pad, out=ow)
+        H, W = x.shape[2], x.shape[3]
+        s2 = w.shape[2] == 3 and stride == 2 and pad == 1 and H % 2 == 0 and W % 2 == 0
+        if s2:
+            dw = hip.conv3x3s2_wgrad_small(x, dy, out=ow)
+        else:
+            dw = hip.conv2d_direct_wgrad(x, dy, w.shape[2], stride, pad, out=ow)
         dx = None
         if ctx.needs_input_grad[0]:
-            H, W = x.shape[2], x.shape[3]
-            if w.shape[2] == 3 and stride == 2 and pad == 1 and H % 2 == 0 and W % 2 == 0 and w.shape[0] <= 256:
+            if s2 and w.shape[0] <= 256:
                 dx = hip.conv3x3s2_dgrad_small(dy, w, H, W, dx_channels)      # no structural zeros, vector ALUs
             else:
                 dx = hip.conv2d_direct_dgrad(dy, w, H, W, stride, pad)

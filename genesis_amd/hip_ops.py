@@ -554,6 +554,19 @@ def conv3x3s2_dgrad_small(dy, w, H, W, cin_n=None):
     return dx
 
 
+def conv3x3s2_wgrad_small(x, dy, out=None):
+    """dw [Cout,Cin,3,3] of a conv3x3 stride 2 pad 1 (even H, W) on the vector ALUs (gx_conv3x3s2_wgrad_small)."""
+    _chk(x, 'conv3x3s2_wgrad.x'); _chk(dy, 'conv3x3s2_wgrad.dy')
+    N, Cin, H, W = x.shape
+    Cout = dy.shape[1]
+    assert tuple(dy.shape) == (N, Cout, H // 2, W // 2), (x.shape, dy.shape)
+    dw = out if out is not None else torch.empty(Cout, Cin, 3, 3, dtype=F32, device=x.device)
+    nb = _lib.query('gx_conv3x3s2_wgrad_small_ws_bytes', N, Cin, Cout, H, W)
+    ws = _ws(nb, x.device)
+    _lib.call('gx_conv3x3s2_wgrad_small', _p(x), _p(dy), _p(dw), N, Cin, Cout, H, W, _p(ws), nb, _stream())
+    return dw
+
+
 def conv2d_direct_wgrad(x, dy, k, stride, pad, out=None):
     _chk(x, 'conv2d_direct_wgrad.x'); _chk(dy, 'conv2d_direct_wgrad.dy')
     N, Cin, H, W = x.shape

@@ -284,6 +284,11 @@ int gx_conv5x5_wgrad(const float* a, const float* b, float* dw, int N, int CA, i
  *      (the encoder's first layer needs the mask channel's gradient alone). */
 int gx_conv3x3s2_dgrad_small(const float* dy, const float* w, float* dx, int N, int Cin, int Cout, int H, int W, int cin_n,
                              gx_stream_t stream);
+/*      ... and its weight gradient dw [Cout,Cin,3,3] (lanes = output pixels, 9 taps x 8 output channels per thread, fixed-
+ *      order split reduction; ws: gx_conv3x3s2_wgrad_small_ws_bytes). */
+size_t gx_conv3x3s2_wgrad_small_ws_bytes(int N, int Cin, int Cout, int H, int W);
+int gx_conv3x3s2_wgrad_small(const float* x, const float* dy, float* dw, int N, int Cin, int Cout, int H, int W, void* ws,
+                             size_t ws_bytes, gx_stream_t stream);
 int gx_conv2d_direct_fwd(const float* x, const float* w, const float* bias, int act, float* y, int N, int Cin,
                          int Cout, int H, int W, int k, int stride, int pad, gx_stream_t stream);
 int gx_conv2d_direct_dgrad(const float* dy, const float* w, float* dx, int N, int Cin, int Cout, int H, int W, int k,

@@ -1263,3 +1263,19 @@ def test_conv3x3_stride2_dgrad_on_the_vector_alus(N, Cin, Cout, S, cin_n):
     n = Cin if cin_n is None else cin_n
     close(dx[:, :n], x.grad[:, :n], rtol=1e-5, atol=1e-5, msg='dx')
     assert float(dx[:, n:].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize('N,Cin,Cout,S', [(224, 4, 32, 64), (37, 32, 32, 32), (40, 32, 64, 16), (70, 64, 64, 8), (2, 6, 10, 12),
+                                          (1, 3, 5, 2)])
+def test_conv3x3_stride2_wgrad_on_the_vector_alus(N, Cin, Cout, S):
+    """gx_conv3x3s2_wgrad_small (ComponentVAE encoder, modules/encoders.py:31-34): lanes = output pixels, 9 taps x 8 output
+    channels per thread, fixed-order split reduction; against autograd in fp64, and bit-reproducible run to run."""
+    from genesis_amd import hip_ops as hip
+    x = rnd(N, Cin, S, S, seed=1)
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    dy = rnd(N, Cout, S // 2, S // 2, seed=3)
+    F.conv2d(x.double(), w, None, 2, 1).backward(dy.double())
+    dw = hip.conv3x3s2_wgrad_small(x.to(DEV), dy.to(DEV))
+    scale = float(w.grad.abs().max())
+    close(dw, w.grad, rtol=1e-5, atol=2e-6 * scale, msg='dw')
+    assert torch.equal(dw, hip.conv3x3s2_wgrad_small(x.to(DEV), dy.to(DEV)))
