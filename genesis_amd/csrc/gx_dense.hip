@@ -18,6 +18,9 @@ namespace {
 //   column tile.  act: 0 none, 1 ReLU, 2 add to what the destination holds
 // Lane (idx = lane & 15, kq = lane >> 4) owns contraction indices k16 + 4 kq + {0..3}; MFMA step jj consumes index
 // 4 kq + jj from every kq -- a permutation of the 16 indices that A and B share, so contiguous operands load float4.
+// derivative of the activation from the layer OUTPUT m: ReLU [m > 0]; ELU 1 where m > 0, else e^x = m + 1
+__device__ __forceinline__ float mask_factor(float m, bool elu) { return m > 0.f ? 1.f : (elu ? m + 1.f : 0.f); }
+
 template <bool A_KC, bool B_KC, bool MASK, bool ROWSUM>
 __device__ __forceinline__ void
 dense_tile(float (*part)[256], float (*rpart)[16], int bx, int by, const float* __restrict__ a, int lda,
@@ -27,6 +30,8 @@ dense_tile(float (*part)[256], float (*rpart)[16], int bx, int by, const float* 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int idx = lane & 15, kq = lane >> 4;
     const int i0 = by * 16, j0 = bx * 16;
+    const bool elu_mask = (act & 4) != 0;        // MASK: the mask is an ELU output (derivative y + 1 where y <= 0)
+    act &= 3;
     const int ai = i0 + idx, bj = j0 + idx;
     const bool a_ok = ai < I, b_ok = bj < J;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -43,14 +48,14 @@ dense_tile(float (*part)[256], float (*rpart)[16], int bx, int by, const float* 
                     if (MASK) m = *reinterpret_cast<const f32x4*>(mask + (size_t)ai * lda + kb);
                 }
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) av[jj] = (!MASK || m[jj] > 0.f) ? t[jj] : 0.f;
+                for (int jj = 0; jj < 4; ++jj) av[jj] = MASK ? t[jj] * mask_factor(m[jj], elu_mask) : t[jj];
             } else {
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     float t = 0.f;
                     if (a_ok && kb + jj < Kc) {
                         t = a[(size_t)ai * lda + kb + jj];
-                        if (MASK && !(mask[(size_t)ai * lda + kb + jj] > 0.f)) t = 0.f;
+                        if (MASK) t *= mask_factor(mask[(size_t)ai * lda + kb + jj], elu_mask);
                     }
                     av[jj] = t;
                 }
@@ -61,7 +66,7 @@ dense_tile(float (*part)[256], float (*rpart)[16], int bx, int by, const float* 
                 float t = 0.f;
                 if (a_ok && kb + jj < Kc) {
                     t = a[(size_t)(kb + jj) * lda + ai];
-                    if (MASK && !(mask[(size_t)(kb + jj) * lda + ai] > 0.f)) t = 0.f;
+                    if (MASK) t *= mask_factor(mask[(size_t)(kb + jj) * lda + ai], elu_mask);
                 }
                 av[jj] = t;
             }
@@ -106,6 +111,7 @@ dense_tile(float (*part)[256], float (*rpart)[16], int bx, int by, const float* 
             if (bias) s += bias[cj];
             if (act == 1) s = s > 0.f ? s : 0.f;
             if (act == 2) s += c[(size_t)ci * ldc + cj];      // accumulate into the destination
+            if (act == 3) s = s > 0.f ? s : expm1f(s);        // ELU (alpha 1)
             c[(size_t)ci * ldc + cj] = s;
         }
     }
@@ -143,7 +149,7 @@ dense_bwd_pair_kernel(const float* __restrict__ g, int ldg, const float* __restr
                                              lddx, M, K, N, nullptr, vec, 0);
     else
         dense_tile<false, false, MASK, ROWSUM>(part, rpart, blockIdx.x, blockIdx.y - gy_dx, g, ldg, y, x, ldx, nullptr,
-                                               0, dw, K, N, K, M, db, 0, 0, db2);
+                                               dx_act & 4, dw, K, N, K, M, db, 0, 0, db2);
 }
 
 // ------------------------------------------------------------------------------------------------ LSTM cell
@@ -271,7 +277,8 @@ int gx_linear_fwd_ld(const float* x, int ldx, const float* w, const float* b, in
     GX_CHECK_ARG(x && w && y, "gx_linear_fwd: null pointer");
     GX_CHECK_ARG(M > 0 && N > 0 && K > 0, "gx_linear_fwd: bad M/N/K (%d,%d,%d)", M, N, K);
     GX_CHECK_ARG(ldx >= K && ldy >= N, "gx_linear_fwd: row strides (%d,%d) shorter than the rows (%d,%d)", ldx, ldy, K, N);
-    GX_CHECK_ARG(act == 0 || act == 1, "gx_linear_fwd: act must be 0 (none) or 1 (ReLU)");
+    GX_CHECK_ARG(act >= 0 && act <= 2, "gx_linear_fwd: act must be 0 (none), 1 (ReLU) or 2 (ELU)");
+    if (act == 2) act = 3;      // dense_tile's epilogue codes: 2 = accumulate, 3 = ELU
     hipStream_t s = (hipStream_t)stream;
     const int vec_w = (K % 4 == 0) && aligned16(w);
     const int vec_x = vec_w && (ldx % 4 == 0) && aligned16(x);
@@ -296,12 +303,14 @@ int gx_linear_bwd_ex(const float* x, int ldx, const float* w, const float* y, co
     GX_CHECK_ARG(x && w && g, "gx_linear_bwd: null pointer");
     GX_CHECK_ARG(M > 0 && N > 0 && K > 0, "gx_linear_bwd: bad M/N/K (%d,%d,%d)", M, N, K);
     GX_CHECK_ARG(ldx >= K && ldg >= N && (!dx || lddx >= K), "gx_linear_bwd: a row stride is shorter than its rows");
-    GX_CHECK_ARG(act == 0 || (act == 1 && y), "gx_linear_bwd: act 1 (ReLU) needs the layer output y");
+    GX_CHECK_ARG(act == 0 || ((act == 1 || act == 2) && y), "gx_linear_bwd: act 1 (ReLU) / 2 (ELU) needs the layer output y");
     GX_CHECK_ARG(dw || !db, "gx_linear_bwd: db is produced together with dw");
     GX_CHECK_ARG(db || !db2, "gx_linear_bwd: db2 is a second copy of db");
     hipStream_t s = (hipStream_t)stream;
     const int vec = (N % 4 == 0) && (ldg % 4 == 0) && aligned16(g) && (act == 0 || aligned16(y));
-    const int dx_act = dx_accumulate ? 2 : 0;
+    const int elu = act == 2 ? 4 : 0;          // (bit 2 of the tile's act code: the mask is an ELU output)
+    const int dx_act = (dx_accumulate ? 2 : 0) | elu;
+    if (act == 2) act = 1;                     // masked like ReLU from here on
     if (dx && dw) {   // one launch for both
         GxProf pf(KID_DENSE, s, 4.0 * M * N * K, 4.0 * (4.0 * M * N + 2.0 * N * K + 2.0 * M * K));
         const int gy_dx = gx_ceil_div(M, 16);
@@ -334,10 +343,10 @@ int gx_linear_bwd_ex(const float* x, int ldx, const float* w, const float* y, co
         if (act == 1) {
             if (db)
                 hipLaunchKernelGGL((dense_kernel<false, false, true, true>), grid, block, 0, s, g, ldg, y, x, ldx,
-                                   (const float*)nullptr, 0, dw, K, N, K, M, db, 0, 0, db2);
+                                   (const float*)nullptr, elu, dw, K, N, K, M, db, 0, 0, db2);
             else
                 hipLaunchKernelGGL((dense_kernel<false, false, true, false>), grid, block, 0, s, g, ldg, y, x, ldx,
-                                   (const float*)nullptr, 0, dw, K, N, K, M, (float*)nullptr, 0, 0, (float*)nullptr);
+                                   (const float*)nullptr, elu, dw, K, N, K, M, (float*)nullptr, 0, 0, (float*)nullptr);
         } else {
             if (db)
                 hipLaunchKernelGGL((dense_kernel<false, false, false, true>), grid, block, 0, s, g, ldg,

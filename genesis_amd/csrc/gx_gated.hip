@@ -89,6 +89,23 @@ __global__ void gated_stats_finalize_kernel(const double* __restrict__ part, int
     // biased variance kept for the caller's running_var update (BatchNorm uses the unbiased one there)
 }
 
+// nn.BatchNorm2d's running statistics of the two norms of a gated unit from its {mean, rstd} pairs: running = (1 - mom)
+// running + mom {mean, unbiased variance}, num_batches_tracked += 1 (one launch instead of ~19 pointwise ones)
+__global__ void bn_running_update_kernel(const float* __restrict__ stats, int C, double m, double eps, float mom,
+                                         float* __restrict__ rm_h, float* __restrict__ rv_h, float* __restrict__ rm_g,
+                                         float* __restrict__ rv_g, long long* __restrict__ nbt_h, long long* __restrict__ nbt_g) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u == 0) { *nbt_h += 1; *nbt_g += 1; }
+    if (u >= 2 * C) return;
+    const float mean = stats[2 * u];
+    const double rstd = (double)stats[2 * u + 1];
+    const float var = (float)((1.0 / (rstd * rstd) - eps) * (m / (m > 1.0 ? m - 1.0 : 1.0)));
+    float* rm = u < C ? rm_h + u : rm_g + (u - C);
+    float* rv = u < C ? rv_h + u : rv_g + (u - C);
+    *rm = *rm * (1.f - mom) + mom * mean;
+    *rv = *rv * (1.f - mom) + mom * var;
+}
+
 __device__ __forceinline__ void unit_stats(const float* stats, int norm, int n, int ch, int C2, float* mean, float* rstd) {
     if (norm == NORM_NONE) { *mean = 0.f; *rstd = 1.f; return; }
     const int u = (norm == NORM_BN) ? ch : n * C2 + ch;
@@ -276,6 +293,20 @@ int gx_gated_norm_fwd(const float* y, const float* bias, int norm, const float* 
                            (const float*)stats, gamma_h, beta_h, gamma_g, beta_g, N, C, HW, norm, out);
     }
     GX_CHECK_LAUNCH("gx_gated_norm_fwd");
+    return GX_OK;
+}
+
+/* BatchNorm running statistics of a gated unit (layers.py:40-101 with nn.BatchNorm2d norms, momentum 0.1): stats = the
+ * {mean, rstd} pairs gx_gated_norm_fwd left for its 2C units, m = N H W; running_mean / running_var [C] of the h and g
+ * norms and their num_batches_tracked (int64 scalars) are updated in place. */
+int gx_bn_running_update(const float* stats, int C, double m, float eps, float momentum, float* rm_h, float* rv_h, float* rm_g,
+                         float* rv_g, long long* nbt_h, long long* nbt_g, gx_stream_t stream) {
+    GX_CHECK_ARG(stats && rm_h && rv_h && rm_g && rv_g && nbt_h && nbt_g, "gx_bn_running_update: null pointer");
+    GX_CHECK_ARG(C > 0 && m >= 1.0, "gx_bn_running_update: bad dims");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3(gx_ceil_div(2 * C, 256)), dim3(256), 0, s, stats, C, m, (double)eps,
+                       momentum, rm_h, rv_h, rm_g, rv_g, nbt_h, nbt_g);
+    GX_CHECK_LAUNCH("gx_bn_running_update");
     return GX_OK;
 }
 

@@ -85,13 +85,12 @@ posterior_bwd_kernel(const float* __restrict__ zh, const float* __restrict__ eps
 // z [K,B,D], lin [K-1,B,2D] (null: standard-normal prior for every slot) -> log_p [K,B]
 __global__ void __launch_bounds__(256)
 prior_logp_fwd_kernel(const float* __restrict__ z, const float* __restrict__ lin,
-                      const float* __restrict__ log_q, int B, int K, int D, float* __restrict__ log_p) {
+                      const float* __restrict__ log_q, int B, int K, int D, int first, float* __restrict__ log_p) {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= K * B) return;
     const int lane = threadIdx.x & 63;
-    const int k = row / B;
-    const bool ar = lin != nullptr && k > 0;
-    const float* lr = ar ? lin + (size_t)(row - B) * 2 * D : nullptr;
+    const bool ar = lin != nullptr && row >= first;      // first = B: slot 0 under N(0,1); 0: every row has its own (mean, scale)
+    const float* lr = ar ? lin + (size_t)(row - first) * 2 * D : nullptr;
     double acc = 0.0;
     for (int d = lane; d < D; d += 64) {
         const float zz = z[(size_t)row * D + d];
@@ -126,14 +125,13 @@ prior_sample_kernel(const float* __restrict__ lin, const float* __restrict__ eps
 
 __global__ void __launch_bounds__(256)
 prior_logp_bwd_kernel(const float* __restrict__ z, const float* __restrict__ lin, const float* __restrict__ glogp,
-                      float sign, int B, int K, int D, float* __restrict__ dz, float* __restrict__ dlin) {
+                      float sign, int B, int K, int D, int first, float* __restrict__ dz, float* __restrict__ dlin) {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= K * B) return;
     const int lane = threadIdx.x & 63;
-    const int k = row / B;
-    const bool ar = lin != nullptr && k > 0;
-    const float* lr = ar ? lin + (size_t)(row - B) * 2 * D : nullptr;
-    float* dl = ar ? dlin + (size_t)(row - B) * 2 * D : nullptr;
+    const bool ar = lin != nullptr && row >= first;
+    const float* lr = ar ? lin + (size_t)(row - first) * 2 * D : nullptr;
+    float* dl = ar ? dlin + (size_t)(row - first) * 2 * D : nullptr;
     const float g = sign * glogp[row];
     for (int d = lane; d < D; d += 64) {
         const size_t i = (size_t)row * D + d;
@@ -315,6 +313,11 @@ int gx_latent_posterior_bwd(const float* zh, const float* eps, const float* gz, 
 
 int gx_latent_prior_logp_fwd(const float* z, const float* lin, const float* log_q, int B, int K, int D,
                              float* out, gx_stream_t stream) {
+    return gx_latent_prior_logp_fwd_ex(z, lin, log_q, B, K, D, 0, out, stream);
+}
+
+int gx_latent_prior_logp_fwd_ex(const float* z, const float* lin, const float* log_q, int B, int K, int D, int all_slots,
+                                float* out, gx_stream_t stream) {
     float* log_p = out;
     int rc = check_bkd("gx_latent_prior_logp_fwd", B, K, D);
     if (rc) return rc;
@@ -323,7 +326,7 @@ int gx_latent_prior_logp_fwd(const float* z, const float* lin, const float* log_
     {
         GxProf pf(KID_LATENT, s, 0.0, 4.0 * (3.0 * K * B * D + K * B));
         hipLaunchKernelGGL(prior_logp_fwd_kernel, dim3(gx_ceil_div(K * B, 4)), dim3(256), 0, s, z, lin, log_q, B, K,
-                           D, log_p);
+                           D, all_slots ? 0 : B, log_p);
     }
     GX_CHECK_LAUNCH("gx_latent_prior_logp_fwd");
     return GX_OK;
@@ -348,6 +351,11 @@ int gx_latent_prior_sample_ex(const float* lin, const float* eps, int B, int D, 
 
 int gx_latent_prior_logp_bwd(const float* z, const float* lin, const float* g_out, int kl_mode, int B, int K,
                              int D, float* dz, float* dlin, gx_stream_t stream) {
+    return gx_latent_prior_logp_bwd_ex(z, lin, g_out, kl_mode, B, K, D, 0, dz, dlin, stream);
+}
+
+int gx_latent_prior_logp_bwd_ex(const float* z, const float* lin, const float* g_out, int kl_mode, int B, int K,
+                                int D, int all_slots, float* dz, float* dlin, gx_stream_t stream) {
     const float* glogp = g_out;
     int rc = check_bkd("gx_latent_prior_logp_bwd", B, K, D);
     if (rc) return rc;
@@ -357,7 +365,7 @@ int gx_latent_prior_logp_bwd(const float* z, const float* lin, const float* g_ou
     {
         GxProf pf(KID_LATENT, s, 0.0, 4.0 * (6.0 * K * B * D + K * B));
         hipLaunchKernelGGL(prior_logp_bwd_kernel, dim3(gx_ceil_div(K * B, 4)), dim3(256), 0, s, z, lin, glogp,
-                           kl_mode ? -1.f : 1.f, B, K, D, dz, dlin);
+                           kl_mode ? -1.f : 1.f, B, K, D, all_slots ? 0 : B, dz, dlin);
     }
     GX_CHECK_LAUNCH("gx_latent_prior_logp_bwd");
     return GX_OK;

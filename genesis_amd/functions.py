@@ -885,20 +885,23 @@ class PriorLogPFn(torch.autograd.Function):
     Monte-Carlo KL sample log_q - log_p of :329-331 (one launch for the whole KL term)."""
 
     @staticmethod
-    def forward(ctx, z, lin, log_q=None):
+    def forward(ctx, z, lin, log_q=None, all_slots=False):
+        """all_slots: lin [K,B,2D] -- every slot has a conditional prior (Genesis' component prior p(z_c | z_m),
+        models/genesis_config.py:229-247)."""
         z = z.contiguous()
         lin = None if lin is None else lin.contiguous()
         log_q = None if log_q is None else log_q.contiguous()
         ctx.save_for_backward(z, lin)
         ctx.kl_mode = log_q is not None
-        return hip.latent_prior_logp_fwd(z, lin, log_q)
+        ctx.all_slots = bool(all_slots)
+        return hip.latent_prior_logp_fwd(z, lin, log_q, all_slots)
 
     @staticmethod
     def backward(ctx, g):
         z, lin = ctx.saved_tensors
         g = g.contiguous()
-        dz, dlin = hip.latent_prior_logp_bwd(z, lin, g, ctx.kl_mode)
-        return dz, dlin, (g if ctx.kl_mode else None)
+        dz, dlin = hip.latent_prior_logp_bwd(z, lin, g, ctx.kl_mode, ctx.all_slots)
+        return dz, dlin, (g if ctx.kl_mode else None), None
 
 
 @ctx_bound
@@ -1156,7 +1159,9 @@ class ARPriorKLFn(torch.autograd.Function):
     launch."""
 
     @staticmethod
-    def forward(ctx, z, log_q, w_ih, w_hh, b_ih, b_hh, w_lin, b_lin):
+    def forward(ctx, z, log_q, w_ih, w_hh, b_ih, b_hh, w_lin, b_lin, want_lin=False):
+        """want_lin: also return prior_linear's output [K-1,B,2D] (not differentiable: the prior's mean / scale for the
+        returned statistics)."""
         z = z.contiguous()
         log_q = log_q.contiguous()
         K, B, D = z.shape
@@ -1172,10 +1177,14 @@ class ARPriorKLFn(torch.autograd.Function):
         kl = hip.latent_prior_logp_fwd(z, lin, log_q)
         ctx.save_for_backward(z, act, c, h, lin)
         ctx.params = (w_ih, w_hh, b_ih, b_hh, w_lin, b_lin)
+        if want_lin:
+            lin_out = lin.detach()
+            ctx.mark_non_differentiable(lin_out)
+            return kl, lin_out
         return kl
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _g_lin=None):
         z, act, c, h, lin = ctx.saved_tensors
         w_ih, w_hh, b_ih, b_hh, w_lin, b_lin = ctx.params
         K, B, D = z.shape
@@ -1202,4 +1211,4 @@ class ARPriorKLFn(torch.autograd.Function):
         else:
             dw_hh = torch.zeros_like(w_hh) if o_whh is None else o_whh.zero_()
         return (dz, g, _ret(o_wih, dw_ih), _ret(o_whh, dw_hh), _ret(o_bih, db), _ret(o_bhh, db), _ret(o_wl, dw_lin),
-                _ret(o_bl, db_lin))
+                _ret(o_bl, db_lin), None)

@@ -133,25 +133,29 @@ class Genesis(nn.Module):
         K, B = self.K_steps, x.shape[0]
         ap, core = self.att_process, self.att_process.core
         h = core.encode_features(x)
-        mean, var = core.posterior(h)
-        mu_k, sigma_k = [mean], [var.sqrt()]
-        z_k = [mean + sigma_k[0] * eps_m[0]]
+        # the first posterior N(q_z_mean(h), to_var(q_z_var(h))) and the recurrent ones through the same kernel (rsample +
+        # log q(z) in one launch): sqrt(to_var(x)) == to_sigma(x) = softplus(x + 0.5) + 1e-8 (blocks.py:22-26)
+        lin = torch.cat((fn.linear(h, core.q_z_mean.weight, core.q_z_mean.bias),
+                         fn.linear(h, core.q_z_var[0].weight, core.q_z_var[0].bias)), 1)
+        mu_k, sigma_k, z_k, log_q_k = [], [], [], []
         L = ap.lstm
         hs = cs = None
-        for step in range(1, K):
-            # the recurrent core on the HIP LSTM-step / dense kernels (the sampled z is fed back: one cell per step)
-            hs, cs = fn.LSTMCellFn.apply(torch.cat([h, z_k[-1]], 1), hs, cs, L.weight_ih_l0, L.weight_hh_l0,
-                                         L.bias_ih_l0, L.bias_hh_l0)
-            lin = fn.linear(hs, ap.linear.weight, ap.linear.bias)                     # (mean | var_raw) [B, 2z]
-            # sqrt(to_var(x)) == to_sigma(x) = softplus(x + 0.5) + 1e-8: the V2 posterior kernel with one slot
-            z1, mu1, sig1, _ = fn.PosteriorFn.apply(lin.unsqueeze(1), eps_m[step].unsqueeze(0))
-            mu_k.append(mu1[0]); sigma_k.append(sig1[0]); z_k.append(z1[0])
-        logits = core.decode(torch.cat(z_k, 0)).view(K, B, 1, self.img_size, self.img_size)
+        for step in range(K):
+            if step:
+                # the recurrent core on the HIP LSTM-step / dense kernels (the sampled z is fed back: one cell per step)
+                hs, cs = fn.LSTMCellFn.apply(torch.cat([h, z_k[-1]], 1), hs, cs, L.weight_ih_l0, L.weight_hh_l0,
+                                             L.bias_ih_l0, L.bias_hh_l0)
+                lin = fn.linear(hs, ap.linear.weight, ap.linear.bias)                     # (mean | var_raw) [B, 2z]
+            z1, mu1, sig1, lq1 = fn.PosteriorFn.apply(lin.unsqueeze(1), eps_m[step].unsqueeze(0))
+            # (views, not [0]: a select's backward is a zero fill + copy)
+            mu_k.append(mu1.view(B, -1)); sigma_k.append(sig1.view(B, -1)); z_k.append(z1.view(B, -1)); log_q_k.append(lq1)
+        z = torch.cat(z_k, 0)
+        logits = core.decode(z).view(K, B, 1, self.img_size, self.img_size)
         # K stick-breaking steps in one launch; the last mask is the remaining scope (genesis_config.py:167-169)
         log_m, log_s = fn.SBPScanFn.apply(logits, None, True)
         log_m_k = list(log_m.unbind(0))
         log_s_k = [torch.zeros_like(x[:, :1])] + list(log_s.unbind(0))
-        return log_m_k, log_s_k, mu_k, sigma_k, z_k
+        return log_m, log_m_k, log_s_k, mu_k, sigma_k, z_k, z.view(K, B, -1), torch.cat(log_q_k, 0)
 
     def _prior_m(self, z_kbd):
         L = self.prior_lstm
@@ -167,28 +171,25 @@ class Genesis(nn.Module):
         B, K = x.shape[0], self.K_steps
         if eps_m is None:
             eps_m = list(torch.randn(K, B, self.ldim, device=x.device).unbind(0))
-        log_m_k, log_s_k, mu_k, sigma_k, z_k = self._attention(x, eps_m)
-        log_m = torch.stack(log_m_k, 0)
-        z = torch.stack(z_k, 0)
+        log_m, log_m_k, log_s_k, mu_k, sigma_k, z_k, z, log_q = self._attention(x, eps_m)
         if self.two_stage:
             # --- ComponentVAE (ELU), slot-major batch, mask as first channel
             Lc = self.comp_vae.ldim
             inp = torch.cat((log_m.flatten(0, 1), x.repeat(K, 1, 1, 1)), 1)
             if self.comp_symmetric:
                 enc_out = gc_encoder_forward(self.comp_vae.encoder_module[0], inp, SYM_STRIDES, self.training)
-                mu_c, sig_ps = enc_out.chunk(2, dim=1)
             else:
                 em = self.comp_vae.encoder_module.module
                 h = inp
                 for i in (0, 2, 4, 6):
                     # (first layer: only the mask channel of [log_m | x] carries a gradient)
                     h = fn.DirectConvActFn.apply(h, em[i].weight, em[i].bias, 2, 1, 'elu', 1 if i == 0 else None)
-                h = F.elu(fn.linear(h.flatten(1), em[9].weight, em[9].bias))
-                mu_c, sig_ps = fn.linear(h, em[11].weight, em[11].bias).chunk(2, dim=1)
-            sig_c = F.softplus(sig_ps + 0.5) + 1e-8
+                h = fn.linear(h.flatten(1), em[9].weight, em[9].bias, 'elu')
+                enc_out = fn.linear(h, em[11].weight, em[11].bias)
             if eps_c is None:
                 eps_c = torch.randn(K * B, Lc, device=x.device)
-            z_c = mu_c + sig_c * eps_c
+            # (mu | sigma_ps) -> z_c = mu + to_sigma(sigma_ps) eps and log q(z_c) in one launch
+            z_c, mu_c, sig_c, log_q_c = (t.view(K * B, -1) for t in fn.PosteriorFn.apply(enc_out.unsqueeze(1), eps_c.unsqueeze(0)))
             dm, z_dec = self.comp_vae.decoder_module, z_c
         else:
             # --- one stage (genesis_config.py:183-191): the components come from the attention latents
@@ -202,25 +203,29 @@ class Genesis(nn.Module):
         losses = AttrDict()
         losses['err'] = err
         # -- Attention mask KL (mask_latent_loss, genesis_config.py:288-343)
-        mu, sigma = torch.stack(mu_k, 0), torch.stack(sigma_k, 0)
-        mu_p, sig_p = self._prior_m(z)
-        log_q = _normal_log_prob(z, mu, sigma).sum(2)
-        log_p = torch.cat((_normal_log_prob(z[:1], 0., 1.).sum(2), _normal_log_prob(z[1:], mu_p, sig_p).sum(2)), 0)
-        losses['kl_m_k'] = list((log_q - log_p).unbind(0))
+        Lm, Pm = self.prior_lstm, self.prior_linear
+        if K > 1:
+            # LSTM -> linear -> log q - log p as one autograd node (shared with GENESIS-V2)
+            kl_m, lin_p = fn.ARPriorKLFn.apply(z, log_q, Lm.weight_ih_l0, Lm.weight_hh_l0, Lm.bias_ih_l0, Lm.bias_hh_l0,
+                                               Pm.weight, Pm.bias, True)
+        else:
+            kl_m, lin_p = fn.PriorLogPFn.apply(z, None, log_q), None
+        losses['kl_m_k'] = list(kl_m.unbind(0))
         comp_stats = None
         if self.two_stage:
             if self.comp_prior:
                 # -- Component KL with the learned component prior (genesis_config.py:229-247)
                 pm_ = self.prior_mlp
-                o = F.elu(fn.linear(z.flatten(0, 1), pm_[0].weight, pm_[0].bias))
-                o = F.elu(fn.linear(o, pm_[2].weight, pm_[2].bias))
+                o = fn.linear(z.view(K * B, -1), pm_[0].weight, pm_[0].bias, 'elu')
+                o = fn.linear(o, pm_[2].weight, pm_[2].bias, 'elu')
                 o = fn.linear(o, pm_[4].weight, pm_[4].bias)              # [K*B, 2*Lc], slot-major like z_c
-                pm, ps = o.chunk(2, dim=1)
-                pm, ps = torch.tanh(pm), torch.sigmoid(ps + 4.0) + 1e-4
-                kl_l = (_normal_log_prob(z_c, mu_c, sig_c) - _normal_log_prob(z_c, pm, ps)).sum(1)
+                kl_l = fn.PriorLogPFn.apply(z_c.view(K, B, -1), o.view(K, B, -1), log_q_c.view(K, B), True)
+                with torch.no_grad():
+                    pm, ps = o.detach().chunk(2, dim=1)
+                    pm, ps = torch.tanh(pm), torch.sigmoid(ps + 4.0) + 1e-4
             else:
-                # -- N(0, 1) component prior (genesis_config.py:248-254)
-                kl_l = (_normal_log_prob(z_c, mu_c, sig_c) - _normal_log_prob(z_c, 0., 1.)).sum(1)
+                # -- N(0, 1) component prior (genesis_config.py:248-254): every row is a "first slot"
+                kl_l = fn.PriorLogPFn.apply(z_c.view(1, K * B, -1), None, log_q_c.view(1, K * B))
             losses['kl_l_k'] = list(kl_l.view(K, B).unbind(0))
             comp_stats = AttrDict(mu_k=mu_c.chunk(K, 0), sigma_k=sig_c.chunk(K, 0), z_k=z_c.chunk(K, 0))
             if self.comp_prior:
@@ -228,8 +233,14 @@ class Genesis(nn.Module):
         x_r_k = list(x_r.unbind(0))
         stats = AttrDict(recon=recon, log_m_k=log_m_k, log_s_k=log_s_k, x_r_k=x_r_k,
                          mx_r_k=list((x_r * log_m.exp()).unbind(0)))
-        att_stats = AttrDict(mu_k=mu_k, sigma_k=sigma_k, z_k=z_k, pmu_k=[torch.zeros_like(mu_k[0])] + list(mu_p.unbind(0)),
-                             psigma_k=[torch.ones_like(mu_k[0])] + list(sig_p.unbind(0)))
+        with torch.no_grad():
+            if lin_p is not None:
+                mu_p, sig_p = lin_p.chunk(2, dim=2)
+                mu_p, sig_p = list(torch.tanh(mu_p).unbind(0)), list((torch.sigmoid(sig_p + 4.0) + 1e-4).unbind(0))
+            else:
+                mu_p, sig_p = [], []
+            att_stats = AttrDict(mu_k=mu_k, sigma_k=sigma_k, z_k=z_k, pmu_k=[torch.zeros_like(mu_k[0])] + mu_p,
+                                 psigma_k=[torch.ones_like(mu_k[0])] + sig_p)
         return recon, losses, stats, att_stats, comp_stats
 
     @torch.no_grad()

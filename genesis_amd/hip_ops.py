@@ -659,18 +659,34 @@ def gated_norm_fwd(y, bias, norm, gh, bh, gg, bg, eps=1e-5):
     return out, stats
 
 
-def gated_norm_bwd(y, bias, norm, gh, bh, gg, bg, stats, dout):
+def bn_running_update(stats, C, m, h_norm, g_norm, eps=1e-5, momentum=0.1):
+    """nn.BatchNorm2d's running_mean / running_var / num_batches_tracked of a gated unit's two norms from the {mean, rstd}
+    pairs of gated_norm_fwd, in one launch (gx_bn_running_update)."""
+    bufs = (h_norm.running_mean, h_norm.running_var, g_norm.running_mean, g_norm.running_var)
+    for b in bufs:
+        _chk(b, 'bn_running_update.buffer')
+        assert b.numel() == C
+    for n in (h_norm.num_batches_tracked, g_norm.num_batches_tracked):
+        assert n.dtype == torch.int64 and n.is_cuda
+    _lib.call('gx_bn_running_update', _p(stats), C, float(m), float(eps), float(momentum), *[_p(b) for b in bufs],
+              h_norm.num_batches_tracked.data_ptr(), g_norm.num_batches_tracked.data_ptr(), _stream())
+
+
+def gated_norm_bwd(y, bias, norm, gh, bh, gg, bg, stats, dout, out=None):
+    """out: optional destinations (dgh, dbh, dgg, dbg, dbias) -- parameter gradient buffers written in place of fresh
+    tensors (any of them may be None)."""
     _chk(dout, 'gated_bwd.dout')
     N, C2, H, W = y.shape
     C = C2 // 2
     dev = y.device
     dy = torch.empty_like(y)
     has = NORMS[norm] != 0
-    dgh = torch.empty(C, dtype=F32, device=dev) if has else None
-    dbh = torch.empty(C, dtype=F32, device=dev) if has else None
-    dgg = torch.empty(C, dtype=F32, device=dev) if has else None
-    dbg = torch.empty(C, dtype=F32, device=dev) if has else None
-    dbias = torch.empty(C2, dtype=F32, device=dev) if bias is not None else None
+    o = out if out is not None else (None,) * 5
+    mk = lambda dst, n, want: (dst if dst is not None else torch.empty(n, dtype=F32, device=dev)) if want else None  # noqa: E731
+    dgh, dbh, dgg, dbg = mk(o[0], C, has), mk(o[1], C, has), mk(o[2], C, has), mk(o[3], C, has)
+    dbias = mk(o[4], C2, bias is not None)
+    for t in (dgh, dbh, dgg, dbg, dbias):
+        _chk(t, 'gated_bwd.out')
     nb = _lib.query('gx_gated_norm_bwd_ws_bytes', NORMS[norm], N, C)
     ws = _ws(nb, dev)
     _lib.call('gx_gated_norm_bwd', _p(y), _p(bias), NORMS[norm], _p(gh), _p(bh), _p(gg), _p(bg), _p(stats), _p(dout),
@@ -704,15 +720,15 @@ def latent_posterior_bwd(zh, eps, gz, gmu, gsigma, glogq):
     return dzh
 
 
-def latent_prior_logp_fwd(z, lin, log_q=None):
+def latent_prior_logp_fwd(z, lin, log_q=None, all_slots=False):
     """z [K,B,D], lin [K-1,B,2D] or None -> log_p [K,B] (models/genesis_config.py:297-330); with log_q [K,B] the
-    per-slot KL sample log_q - log_p (:329-331)."""
+    per-slot KL sample log_q - log_p (:329-331).  all_slots: lin [K,B,2D], every slot has a conditional prior."""
     _chk(z, 'prior.z'); _chk(lin, 'prior.lin'); _chk(log_q, 'prior.log_q')
     K, B, D = z.shape
-    if lin is not None and tuple(lin.shape) != (K - 1, B, 2 * D):
-        raise GenesisHipError('latent_prior_logp_fwd: lin must be [K-1,B,2D]')
+    if lin is not None and tuple(lin.shape) != (K if all_slots else K - 1, B, 2 * D):
+        raise GenesisHipError('latent_prior_logp_fwd: lin must be [%s,B,2D]' % ('K' if all_slots else 'K-1'))
     out = torch.empty(K, B, dtype=F32, device=z.device)
-    _lib.call('gx_latent_prior_logp_fwd', _p(z), _p(lin), _p(log_q), B, K, D, _p(out), _stream())
+    _lib.call('gx_latent_prior_logp_fwd_ex', _p(z), _p(lin), _p(log_q), B, K, D, int(bool(all_slots)), _p(out), _stream())
     return out
 
 
@@ -727,13 +743,13 @@ def latent_prior_sample(lin, eps, tanh_mu=True):
     return z
 
 
-def latent_prior_logp_bwd(z, lin, g_out, kl_mode=False):
+def latent_prior_logp_bwd(z, lin, g_out, kl_mode=False, all_slots=False):
     _chk(g_out, 'prior_bwd.g_out')
     K, B, D = z.shape
     dz = torch.empty_like(z)
     dlin = torch.empty_like(lin) if lin is not None else None
-    _lib.call('gx_latent_prior_logp_bwd', _p(z), _p(lin), _p(g_out), int(kl_mode), B, K, D, _p(dz), _p(dlin),
-              _stream())
+    _lib.call('gx_latent_prior_logp_bwd_ex', _p(z), _p(lin), _p(g_out), int(kl_mode), B, K, D, int(bool(all_slots)), _p(dz),
+              _p(dlin), _stream())
     return dz, dlin
 
 

@@ -157,11 +157,11 @@ class MONet(nn.Module):
             # (first layer: only the mask channel of [log_m | x] carries a gradient)
             h = fn.DirectConvActFn.apply(h, em[i].weight, em[i].bias, 2, 1, 'relu', 1 if i == 0 else None)
         h = fn.linear(h.flatten(1), em[9].weight, em[9].bias, 'relu')
-        mu, sigma_ps = fn.linear(h, em[11].weight, em[11].bias).chunk(2, dim=1)
-        sigma = F.softplus(sigma_ps + 0.5) + 1e-8
+        enc_out = fn.linear(h, em[11].weight, em[11].bias)
         if eps is None:
             eps = torch.randn(K * B, L, device=x.device)
-        z = mu + sigma * eps
+        # (mu | sigma_ps) -> z = mu + to_sigma(sigma_ps) eps and log q(z) in one launch
+        z, mu, sigma, log_q = (t.view(K * B, -1) for t in fn.PosteriorFn.apply(enc_out.unsqueeze(1), eps.unsqueeze(0)))
         dec = self._decode(z)                                          # [K*B,4,H,W]
         err, recon, x_r = fn.MixtureWFn.apply(x, dec, log_m, K, self._std12[0], self._std12[1], bool(self.pixel_bound))
         # reconstructed masks (MONet.get_mask_recon_stack, monet_config.py:136-155): log_softmax over K of the logit
@@ -178,7 +178,7 @@ class MONet(nn.Module):
         # KL of the component latents against N(0,1) (utils/misc.py:238-255): Monte-Carlo estimate at z, or
         # (montecarlo_kl off) the closed form of kl_divergence(Normal(mu, sigma), Normal(0, 1))
         if self.mckl:
-            kl = (_normal_log_prob(z, mu, sigma) - _normal_log_prob(z, 0., 1.)).sum(1)      # [K*B]
+            kl = fn.PriorLogPFn.apply(z.view(1, K * B, -1), None, log_q.view(1, K * B))    # [1, K*B]: log q - log N(0, 1)
         else:
             kl = (-torch.log(sigma) + 0.5 * (sigma * sigma + mu * mu) - 0.5).sum(1)
         losses['kl_l_k'] = list(kl.view(K, B).unbind(0))

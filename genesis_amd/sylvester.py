@@ -113,15 +113,11 @@ def gate_unit(unit, y, training):
     args = (unit.h_norm.weight, unit.h_norm.bias, unit.g_norm.weight, unit.g_norm.bias) if norm else (None,) * 4
     out, stats = GatedNormFn.apply(y, unit.conv.bias, norm, *args)
     if norm == 'bn':
-        with torch.no_grad():
-            C = out.shape[1]
-            m = y.shape[0] * y.shape[2] * y.shape[3]
-            st = stats[:4 * C].view(-1, 2)       # {mean, rstd} per unit (2C units); the rest of the buffer is scratch
-            mean, var = st[:, 0], (1.0 / st[:, 1] ** 2 - 1e-5) * (m / max(m - 1, 1))
-            for bn, sl in ((unit.h_norm, slice(0, C)), (unit.g_norm, slice(C, 2 * C))):
-                bn.running_mean.mul_(0.9).add_(0.1 * mean[sl])
-                bn.running_var.mul_(0.9).add_(0.1 * var[sl])
-                bn.num_batches_tracked.add_(1)
+        # running = 0.9 running + 0.1 {mean, unbiased variance}, num_batches_tracked += 1 (momentum None is not used by
+        # the reference's stacks)
+        assert unit.h_norm.momentum == 0.1 and unit.g_norm.momentum == 0.1
+        hip.bn_running_update(stats, out.shape[1], y.shape[0] * y.shape[2] * y.shape[3], unit.h_norm, unit.g_norm,
+                              eps=unit.h_norm.eps)
     return out
 
 
@@ -229,5 +225,7 @@ class GatedNormFn(torch.autograd.Function):
     def backward(ctx, g, _unused):
         y, stats = ctx.saved_tensors
         bias, gh, bh, gg, bg = ctx.params
-        dy, dgh, dbh, dgg, dbg, dbias = hip.gated_norm_bwd(y, bias, ctx.norm, gh, bh, gg, bg, stats, g.contiguous())
-        return dy, dbias, None, dgh, dbh, dgg, dbg
+        outs = tuple(_gout(p) if p is not None else None for p in (gh, bh, gg, bg, bias))
+        dy, dgh, dbh, dgg, dbg, dbias = hip.gated_norm_bwd(y, bias, ctx.norm, gh, bh, gg, bg, stats, g.contiguous(), out=outs)
+        return (dy, _ret(outs[4], dbias), None, _ret(outs[0], dgh), _ret(outs[1], dbh), _ret(outs[2], dgg),
+                _ret(outs[3], dbg))

@@ -312,6 +312,10 @@ size_t gx_gated_stats_floats(int norm, int N, int C);
 int gx_gated_norm_fwd(const float* y, const float* bias, int norm, const float* gamma_h, const float* beta_h,
                       const float* gamma_g, const float* beta_g, int N, int C, int H, int W, float eps, float* out,
                       float* stats, gx_stream_t stream);
+/*      nn.BatchNorm2d running statistics of a gated unit's two norms (momentum update with the unbiased variance,
+ *      num_batches_tracked += 1) from the {mean, rstd} pairs gx_gated_norm_fwd left in `stats`; m = N H W. */
+int gx_bn_running_update(const float* stats, int C, double m, float eps, float momentum, float* rm_h, float* rv_h, float* rm_g,
+                         float* rv_g, long long* nbt_h, long long* nbt_g, gx_stream_t stream);
 size_t gx_gated_norm_bwd_ws_bytes(int norm, int N, int C);
 int gx_gated_norm_bwd(const float* y, const float* bias, int norm, const float* gamma_h, const float* beta_h,
                       const float* gamma_g, const float* beta_g, const float* stats, const float* dout, int N, int C,
@@ -389,6 +393,12 @@ int gx_latent_prior_logp_fwd(const float* z, const float* lin, const float* log_
                              float* out, gx_stream_t stream);
 int gx_latent_prior_logp_bwd(const float* z, const float* lin, const float* g_out, int kl_mode, int B, int K,
                              int D, float* dz, float* dlin, gx_stream_t stream);
+/*      ..._ex with all_slots = 1: every slot has a conditional prior, lin [K,B,2D] (Genesis' component prior,
+ *      models/genesis_config.py:229-247: p(z_c | z_m) = N(tanh(mlp[:L]), to_prior_sigma(mlp[L:])) for all K slots) */
+int gx_latent_prior_logp_fwd_ex(const float* z, const float* lin, const float* log_q, int B, int K, int D, int all_slots,
+                                float* out, gx_stream_t stream);
+int gx_latent_prior_logp_bwd_ex(const float* z, const float* lin, const float* g_out, int kl_mode, int B, int K,
+                                int D, int all_slots, float* dz, float* dlin, gx_stream_t stream);
 /*      one ancestral step of GenesisV2.sample (models/genesisv2_config.py:235-246): lin [B,2D] = prior_linear(lstm out),
  *      eps [B,D] standard normal -> z [B,D] = tanh(lin[:D]) + to_prior_sigma(lin[D:]) * eps */
 int gx_latent_prior_sample(const float* lin, const float* eps, int B, int D, float* z, gx_stream_t stream);
@@ -421,8 +431,8 @@ int gx_pooled_head_bwd(const float* lin, const float* msum, const float* fbias, 
 
 /* ---- small dense layers (nn.Linear: modules/unet.py:58-62 bottleneck MLP, models/genesisv2_config.py:76-80
  *      z_head, :73 feat_head[1] on the pooled slot sums, models/genesis_config.py:106 prior_linear).
- *      y[M,N] = act(x[M,K] w[N,K]^T + b[N]), act 0 none / 1 ReLU, b may be NULL.
- *      bwd: g = dL/dy; dpre = g * [y > 0] for act 1 (y = the layer OUTPUT, may be NULL for act 0);
+ *      y[M,N] = act(x[M,K] w[N,K]^T + b[N]), act 0 none / 1 ReLU / 2 ELU, b may be NULL.
+ *      bwd: g = dL/dy; dpre = g * [y > 0] for act 1, g * (y > 0 ? 1 : y + 1) for act 2 (y = the layer OUTPUT, may be NULL for act 0);
  *      dx[M,K] = dpre w, dw[N,K] = dpre^T x, db[N] = column sums of dpre; each of dx / dw / db may be NULL to skip
  *      (db needs dw).  Row-major contiguous; fixed reduction order. */
 int gx_linear_fwd(const float* x, const float* w, const float* b, int act, float* y, int M, int N, int K,

@@ -464,7 +464,7 @@ def test_latent_posterior_and_prior(B, K, D, prior):
 @pytest.mark.parametrize('M,N,K,act,bias', [
     (32, 128, 2048, 'relu', True), (32, 2048, 128, 'relu', True), (224, 128, 128, 'relu', True),
     (224, 128, 64, None, False), (192, 128, 256, None, True), (7, 5, 3, None, True), (33, 17, 70, 'relu', True),
-    (16, 16, 16, None, False)])
+    (16, 16, 16, None, False), (224, 256, 1024, 'elu', True), (33, 17, 70, 'elu', True), (224, 128, 64, 'elu', False)])
 def test_linear(M, N, K, act, bias):
     """Dense-layer kernels vs F.linear (+ReLU) and its autograd in fp64; fp32 MFMA, rtol 1e-5 fwd, 1e-4 grads."""
     from genesis_amd import functions as fn
@@ -477,6 +477,8 @@ def test_linear(M, N, K, act, bias):
     yr = F.linear(xr, wr, br)
     if act == 'relu':
         yr = F.relu(yr)
+    if act == 'elu':
+        yr = F.elu(yr)
     (yr * g.double()).sum().backward()
     xg, wg = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_()
     bg = b.to(DEV).requires_grad_() if bias else None
@@ -566,7 +568,7 @@ def test_broadcast_deconv_as_matrix_product(N, D, Cout, d):
     close(db, br.grad, rtol=1e-4, atol=1e-5, msg='db')
 
 
-@pytest.mark.parametrize('M,N,K,act', [(32, 2048, 128, 'relu'), (192, 1024, 64, None), (7, 20, 12, 'relu')])
+@pytest.mark.parametrize('M,N,K,act', [(32, 2048, 128, 'relu'), (192, 1024, 64, None), (7, 20, 12, 'relu'), (40, 36, 20, 'elu')])
 def test_linear_strided_and_accumulating(M, N, K, act):
     """gx_linear_fwd_ld / gx_linear_bwd_ex: operands that are column ranges of wider buffers (the UNet MLP's output in
     the concat buffer, z[:-1] inside z), dx added in place, db written twice -- against the contiguous entry points,
@@ -1279,3 +1281,47 @@ def test_conv3x3_stride2_wgrad_on_the_vector_alus(N, Cin, Cout, S):
     scale = float(w.grad.abs().max())
     close(dw, w.grad, rtol=1e-5, atol=2e-6 * scale, msg='dw')
     assert torch.equal(dw, hip.conv3x3s2_wgrad_small(x.to(DEV), dy.to(DEV)))
+
+
+@pytest.mark.parametrize('K,B,D', [(7, 32, 16), (3, 5, 64), (1, 9, 7)])
+def test_prior_logp_with_a_conditional_prior_on_every_slot(K, B, D):
+    """PriorLogPFn(all_slots=True): Genesis' component prior p(z_c | z_m) = N(tanh(mlp[:L]), to_prior_sigma(mlp[L:])) for all K
+    slots (models/genesis_config.py:229-247) -- log_q - log_p and the gradients for z, lin, log_q against torch in fp64."""
+    from torch.distributions import Normal
+    from genesis_amd import functions as fn
+    z, lin, lq, w = rnd(K, B, D, seed=1, scale=2.0), rnd(K, B, 2 * D, seed=2, scale=3.0), rnd(K, B, seed=3), rnd(K, B, seed=4)
+    zr, lr, qr = z.double().requires_grad_(), lin.double().requires_grad_(), lq.double().requires_grad_()
+    mr, sr = lr.chunk(2, dim=2)
+    kl_ref = qr - Normal(torch.tanh(mr), torch.sigmoid(sr + 4.0) + 1e-4).log_prob(zr).sum(2)
+    (kl_ref * w.double()).sum().backward()
+    zg, lg, qg = z.to(DEV).requires_grad_(), lin.to(DEV).requires_grad_(), lq.to(DEV).requires_grad_()
+    kl = fn.PriorLogPFn.apply(zg, lg, qg, True)
+    (kl * w.to(DEV)).sum().backward()
+    close(kl, kl_ref, rtol=1e-5, atol=1e-4, msg='kl')
+    close(zg.grad, zr.grad, rtol=1e-4, atol=1e-5, msg='dz')
+    close(lg.grad, lr.grad, rtol=1e-4, atol=1e-5, msg='dlin')
+    close(qg.grad, qr.grad, rtol=0, atol=0, msg='dlog_q')
+
+
+@pytest.mark.parametrize('N,C,S', [(7, 32, 8), (3, 5, 4), (1, 64, 1)])
+def test_bn_running_statistics_of_a_gated_unit(N, C, S):
+    """gx_bn_running_update after GatedNormFn in 'bn' mode against two nn.BatchNorm2d in training mode (momentum 0.1,
+    unbiased running variance, num_batches_tracked)."""
+    import torch.nn as nn
+    from genesis_amd import hip_ops as hip
+    y, bias = rnd(N, 2 * C, S, S, seed=1, scale=2.0), rnd(2 * C, seed=2)
+    ref_h, ref_g = nn.BatchNorm2d(C), nn.BatchNorm2d(C)
+    dev_h, dev_g = nn.BatchNorm2d(C).to(DEV), nn.BatchNorm2d(C).to(DEV)
+    for step in range(2):
+        yy = y + step
+        if N * S * S > 1:
+            h, g = (yy + bias.view(1, -1, 1, 1)).chunk(2, 1)
+            ref_h(h); ref_g(g)
+        ones, zeros = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+        out, stats = hip.gated_norm_fwd(yy.to(DEV), bias.to(DEV), 'bn', ones, zeros, ones, zeros)
+        hip.bn_running_update(stats, C, N * S * S, dev_h, dev_g)
+    if N * S * S > 1:
+        for d, r in ((dev_h, ref_h), (dev_g, ref_g)):
+            close(d.running_mean, r.running_mean, rtol=1e-5, atol=1e-6, msg='running_mean')
+            close(d.running_var, r.running_var, rtol=1e-4, atol=1e-6, msg='running_var')
+    assert int(dev_h.num_batches_tracked) == 2 and int(dev_g.num_batches_tracked) == 2
