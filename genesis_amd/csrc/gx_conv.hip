@@ -1265,11 +1265,13 @@ void launch_tapconv_inst3(const float* in, const float* wp, const float* bias, f
     }
     hipLaunchKernelGGL((tapconv_kernel<MODE, NPOS, DMA, MW, HH>), grid, dim3(256), lds_bytes, s, in, wp, bias, out, g);
 }
-// layers of <= 32 output channels (conv3x3 only: MONet / GENESIS) skip the upper MFMA tile
+// layers of <= 32 output channels (conv3x3 and the stride-1 5x5 conv: MONet / GENESIS, e.g. the data gradients of the gated
+// 32 -> 2 x 32 stacks) skip the upper MFMA tile
 template <int MODE, int NPOS, bool DMA, int MW = 1>
 void launch_tapconv_inst2(const float* in, const float* wp, const float* bias, float* out, const ConvGeom& g,
                           dim3 grid, size_t lds_bytes, hipStream_t s) {
-    if (MODE == M_C3 && g.M <= 32) launch_tapconv_inst3<MODE, NPOS, DMA, MW, MODE != M_C3>(in, wp, bias, out, g, grid, lds_bytes, s);
+    constexpr bool LOW = MODE == M_C3 || MODE == M_C5;
+    if (LOW && g.M <= 32) launch_tapconv_inst3<MODE, NPOS, DMA, MW, !LOW>(in, wp, bias, out, g, grid, lds_bytes, s);
     else launch_tapconv_inst3<MODE, NPOS, DMA, MW, true>(in, wp, bias, out, g, grid, lds_bytes, s);
 }
 

@@ -142,20 +142,20 @@ gated_bwd_sums_kernel(const float* __restrict__ y, const float* __restrict__ bia
                       const float* __restrict__ gh, const float* __restrict__ bh, const float* __restrict__ gg,
                       const float* __restrict__ bg, const float* __restrict__ dout, int N, int C, int HW, int norm,
                       int nchunk, double* __restrict__ part) {
-    __shared__ double red[16 * 2 + 2];
+    // one workgroup per (h, g) channel PAIR: both units' sums need the same three planes (h, g, dout) and the same
+    // sigmoid, so the pair reads them once (the per-unit form read every plane twice: 1.4 TB/s on the 64 x 64 layers)
+    __shared__ double red[16 * 4 + 4];
     const int C2 = 2 * C;
-    // with no norm the "unit" is still a channel over all images (only S1 = bias gradient is needed)
-    int ch, n0, nc;
-    unit_decode(blockIdx.x, norm == NORM_NONE ? NORM_BN : norm, N, C2, &ch, &n0, &nc);
+    const int nrm = norm == NORM_NONE ? NORM_BN : norm;   // no norm: the "unit" is a channel over all images (S1 = bias gradient)
+    const int c = nrm == NORM_BN ? blockIdx.x : blockIdx.x % C;
+    const int n0 = nrm == NORM_BN ? 0 : blockIdx.x / C, nc = nrm == NORM_BN ? N : 1;
     const int per = (nc + nchunk - 1) / nchunk;
     const int na = n0 + blockIdx.y * per;
     int nb = na + per;
     if (nb > n0 + nc) nb = n0 + nc;
-    const bool is_g = ch >= C;
-    const int c = is_g ? ch - C : ch;
     const float b_h = bias ? bias[c] : 0.f, b_g = bias ? bias[C + c] : 0.f;
     const float g_h = gh ? gh[c] : 1.f, be_h = bh ? bh[c] : 0.f, g_g = gg ? gg[c] : 1.f, be_g = bg ? bg[c] : 0.f;
-    double acc[2] = {0.0, 0.0};
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};             // h: S1, S2; g: S1, S2
     for (int n = na; n < nb; ++n) {
         float mh, rh, mg, rg;
         unit_stats(stats, norm, n, c, C2, &mh, &rh);
@@ -163,19 +163,34 @@ gated_bwd_sums_kernel(const float* __restrict__ y, const float* __restrict__ bia
         const float* ph = y + ((size_t)n * C2 + c) * HW;
         const float* pg = y + ((size_t)n * C2 + C + c) * HW;
         const float* pd = dout + ((size_t)n * C + c) * HW;
-        for (int i = threadIdx.x; i < HW; i += blockDim.x) {
-            const float xh = ((ph[i] + b_h) - mh) * rh, xg = ((pg[i] + b_g) - mg) * rg;
+        auto term = [&](float vh, float vg, float vd) {
+            const float xh = ((vh + b_h) - mh) * rh, xg = ((vg + b_g) - mg) * rg;
             const float ah = xh * g_h + be_h, ag = xg * g_g + be_g;
             const float sg = 1.f / (1.f + expf(-ag));
-            const float dA = is_g ? pd[i] * ah * sg * (1.f - sg) : pd[i] * sg;
-            acc[0] += (double)dA;
-            acc[1] += (double)dA * (is_g ? xg : xh);
+            const float dAh = vd * sg, dAg = vd * ah * sg * (1.f - sg);
+            acc[0] += (double)dAh; acc[1] += (double)dAh * xh;
+            acc[2] += (double)dAg; acc[3] += (double)dAg * xg;
+        };
+        if ((HW & 3) == 0) {
+            const f32x4* ph4 = reinterpret_cast<const f32x4*>(ph);
+            const f32x4* pg4 = reinterpret_cast<const f32x4*>(pg);
+            const f32x4* pd4 = reinterpret_cast<const f32x4*>(pd);
+            for (int i = threadIdx.x; i < (HW >> 2); i += blockDim.x) {
+                const f32x4 vh = ph4[i], vg = pg4[i], vd = pd4[i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) term(vh[e], vg[e], vd[e]);
+            }
+        } else {
+            for (int i = threadIdx.x; i < HW; i += blockDim.x) term(ph[i], pg[i], pd[i]);
         }
     }
-    block_sum_multi<2>(acc, red);
+    block_sum_multi<4>(acc, red);
     if (threadIdx.x == 0) {
-        part[2 * ((size_t)blockIdx.x * nchunk + blockIdx.y)] = acc[0];
-        part[2 * ((size_t)blockIdx.x * nchunk + blockIdx.y) + 1] = acc[1];
+        const size_t uh = nrm == NORM_BN ? (size_t)c : (size_t)n0 * C2 + c, ug = uh + C;
+        part[2 * (uh * nchunk + blockIdx.y)] = acc[0];
+        part[2 * (uh * nchunk + blockIdx.y) + 1] = acc[1];
+        part[2 * (ug * nchunk + blockIdx.y)] = acc[2];
+        part[2 * (ug * nchunk + blockIdx.y) + 1] = acc[3];
     }
 }
 
@@ -251,10 +266,10 @@ __global__ void gated_param_kernel(const float* __restrict__ sums, int N, int C,
 }
 
 int nunits(int norm, int N, int C) { return norm == NORM_IN ? N * 2 * C : 2 * C; }
-// image chunks per unit: a BatchNorm channel spans all N images -> spread it over ~1024 workgroups
+// image chunks per unit: a BatchNorm channel spans all N images -> spread it over ~2048 (statistics) / ~1024 (backward sums, one per channel pair) workgroups
 int nchunks(int norm, int N, int C) {
     if (norm == NORM_IN) return 1;
-    int z = 1024 / (2 * C);
+    int z = 2048 / (2 * C);
     if (z < 1) z = 1;
     return z > N ? N : z;
 }
@@ -329,7 +344,7 @@ int gx_gated_norm_bwd(const float* y, const float* bias, int norm, const float* 
         GxProf pf(KID_GATED, s, 0.0, 4.0 * N * 3.0 * C * HW);
         const int units = nunits(norm, N, C), nz = nchunks(norm == NORM_NONE ? NORM_BN : norm, N, C);
         double* part = reinterpret_cast<double*>(sums + 2 * (size_t)units);
-        hipLaunchKernelGGL(gated_bwd_sums_kernel, dim3(units, nz), dim3(256), 0, s, y, bias, stats, gamma_h, beta_h,
+        hipLaunchKernelGGL(gated_bwd_sums_kernel, dim3(units / 2, nz), dim3(256), 0, s, y, bias, stats, gamma_h, beta_h,
                            gamma_g, beta_g, dout, N, C, HW, norm, nz, part);
         hipLaunchKernelGGL(gated_sums_finalize_kernel, dim3(gx_ceil_div(units, 256)), dim3(256), 0, s,
                            (const double*)part, units, nz, sums);
