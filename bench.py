@@ -109,7 +109,7 @@ def pmc_traffic(kernel):
 
 # profiling ids (gx_profile_kernel_name) -> kernel symbols of the rocprofv3 CSV that are launched under that id
 KID_SYMBOLS = {
-    'wgq_stream_kernel': ('wgq_stream_kernel',), 'kq_dth_kernel': ('kq_dth_kernel',), 'kq_dgh_kernel': ('kq_dgh_kernel',),
+    'wgq_stream_kernel': ('wgq_stream_kernel',), 'kq_dth_kernel': ('kq_dth_kernel',), 'kq_dgh_kernel': ('kq_dgh_kernel',), 'kq_c3h_kernel': ('kq_c3h_kernel',),
     'wgrad_kernel<0>': ('wgq_stream_kernel', 'wgq_kernel<0,', 'wgrad_fast_kernel<0,', 'wgrad_kernel<0>', 'wgrad_smallcin_kernel'),
     'wgrad_kernel<1>': ('wgq_kernel<1,', 'wgrad_fast_kernel<1,', 'wgrad_kernel<1>', 'wgrad_deconv_kernel'),
     'wgrad_kernel<3>': ('wgq_kernel<2,', 'wgrad_fast_kernel<3,', 'wgrad_kernel<3>'),
@@ -332,7 +332,7 @@ def main():
             mfma_peak = PEAK_FP32_MFMA_TFLOPS
             roof = {'bound': 'mfma', 'kernel': dom['name'], 'achieved': ach, 'peak': mfma_peak, 'unit': 'TFLOP/s'}
             on_bf16 = (dom['name'] == 'wgq_stream_kernel' and os.environ.get('GENESIS_WGQ_BF16X6', '1') != '0') or \
-                      (dom['name'] in ('kq_dth_kernel', 'kq_dgh_kernel') and os.environ.get('GENESIS_KQ_BF16X6', '1') != '0')
+                      (dom['name'] in ('kq_dth_kernel', 'kq_dgh_kernel', 'kq_c3h_kernel') and os.environ.get('GENESIS_KQ_BF16X6', '1') != '0')
             if on_bf16:
                 # `achieved` counts the algorithmic fp32 flops; the kernel executes six bf16 MFMA products for each of them,
                 # so its ceiling is the bf16 pipe's dense peak / 6 -- a higher one than the fp32 pipe's 157.3 TF/s

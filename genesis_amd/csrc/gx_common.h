@@ -33,7 +33,7 @@ enum GxKernelId {
     KID_GN_FWD, KID_GN_BWD, KID_GN_PARAM_REDUCE, KID_ICSBP_FWD, KID_ICSBP_BWD, KID_MASKPOOL_FWD,
     KID_MASKPOOL_BWD, KID_MIXTURE_FWD, KID_MIXTURE_BWD, KID_CONV1X1_FWD, KID_CONV1X1_DGRAD,
     KID_CONV1X1_WGRAD, KID_SMALL_REDUCE, KID_ADAM, KID_GECO, KID_SPLITK_REDUCE, KID_BIAS_ACT_BWD, KID_DCONV, KID_GATED, KID_LATENT, KID_DENSE, KID_WINO,
-    KID_WGQ_STREAM, KID_KQ_DTH, KID_KQ_DGH, KID_COUNT
+    KID_WGQ_STREAM, KID_KQ_DTH, KID_KQ_DGH, KID_KQ_C3H, KID_COUNT
 };
 // ---- contexts: every piece of mutable library state that outlives a call (deferred-reduction queues, queued
 // weight-gradient jobs, the packed-weight cache a step is recording / served from, the per-kernel profiling records)
@@ -159,6 +159,13 @@ int gx_kq_deconv_dgrad_h_launch(const float* dy, const float* wp, float* dx, int
 int gx_kq_deconv_fwd_h_launch(const float* in, const float* wp0, const float* wp1, const float* bias, float* out, int N,
                               int K, int M, int Hb, int Wb, float* stats, int* stats_parts, hipStream_t s);
 // 32-bit word of element (m, k even, k + 1) of piece `piece` of tap t
+// ... kinds 20 / 21 (conv3x3 forward / data gradient of <= 32-output-channel layers): 32 output channels per channel tile
+__host__ __device__ __forceinline__ size_t gx_kq_h32_word(int m, int k, int t, int piece, int NT, int K) {
+    return ((((size_t)(m >> 5) * (K >> 4) + (k >> 4)) * NT + t) * 3 + piece) * 256 + (((k >> 3) & 1) * 32 + (m & 31)) * 4 + ((k & 7) >> 1);
+}
+bool gx_kq_c3h_eligible(int N, int K, int M, int H, int W);
+int gx_kq_c3h_launch(const float* in, const float* wp, const float* bias, int act, float* out, int N, int K, int M, int H,
+                     int W, hipStream_t s);
 __host__ __device__ __forceinline__ size_t gx_kq_h_word(int m, int k, int t, int piece, int NT, int K) {
     return ((((size_t)(m >> 6) * (K >> 4) + (k >> 4)) * NT + t) * 3 + piece) * 512 + (((k >> 3) & 1) * 64 + (m & 63)) * 4 + ((k & 7) >> 1);
 }

@@ -559,7 +559,7 @@ __device__ __forceinline__ size_t pack_dest(int pack, int idx, int m, int k, int
     return (pack == 5 || pack == 6) ? gx_wino_u_slot(m, k, t, Kpad) : (size_t)idx;
 }
 
-// packs 22 / 23 / 24 (= 2 / 3 / 4 for the bf16 matrix pipe, gx_kq.hip's QCfgDTH / Q_DGH): every weight as three bf16 pieces, two
+// packs 20 / 21 (= 0 / 1, gx_kq.hip's Q_C3H) and 22 / 23 / 24 (= 2 / 3 / 4 for the bf16 matrix pipe, gx_kq.hip's QCfgDTH / Q_DGH): every weight as three bf16 pieces, two
 // channels per 32-bit word -- the thread of an even k writes the three words of (k, k + 1), the odd one nothing
 __device__ __forceinline__ void pack_h_store(const float* __restrict__ w, float* __restrict__ wp, int pack, int Co, int Ci,
                                              int m, int k, int t, int NT, int Kpad) {
@@ -580,7 +580,9 @@ __device__ __forceinline__ void pack_h_store(const float* __restrict__ w, float*
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         wd[q] = (unsigned)pc[0][q] | ((unsigned)pc[1][q] << 16);
-        wp[gx_kq_h_word(m, k, pack == 24 ? gx_kq_dg_tap_slot(t) : t, q, NT, Kpad)] = __builtin_bit_cast(float, wd[q]);
+        const size_t dst = pack <= 21 ? gx_kq_h32_word(m, k, t, q, NT, Kpad)       // 20 / 21: conv3x3, 32-channel tiles
+                                      : gx_kq_h_word(m, k, pack == 24 ? gx_kq_dg_tap_slot(t) : t, q, NT, Kpad);
+        wp[dst] = __builtin_bit_cast(float, wd[q]);
     }
 }
 
@@ -1796,7 +1798,7 @@ static size_t conv3x3_pack_floats(int Cin, int Cout) {
     // 16 positions: room for the Winograd operands (gx_wino.hip) as well as the 9 taps
     size_t f = (size_t)16 * gx_round_up(Cin, 8) * gx_round_up(Cout, 64);
     size_t d = (size_t)16 * gx_round_up(Cout, 8) * gx_round_up(Cin, 64);
-    return f > d ? f : d;
+    return (f > d ? f : d) + 4096;      // (+ the slack of the bf16-piece packings, kinds 20 / 21)
 }
 
 int gx_weight_cache_create(void) {
@@ -1936,6 +1938,14 @@ static int conv3x3_fwd_impl(const float* x, const float* w, const float* bias, i
     static const char* kq_env = getenv("GENESIS_KQ");
     const bool kq_first = kq_env && kq_env[0] == '2';        // benchmarking: the k-quad kernel ahead of Winograd
     const bool wino_ok = !bias && act == 0 && gx_wino_eligible(N, Cin, Cout, H, W);
+    if (!wino_ok && gx_kq_c3h_eligible(N, Cin, Cout, H, W)) {   // <= 32 output channels, bf16 pipe (six piece products)
+        rc = launch_pack(w, wp, 20, Cout, Cin, 9, gx_round_up(Cin, 16), Mpad, s, &wpu);
+        if (rc) return rc;
+        rc = gx_kq_c3h_launch(x, wpu, bias, act, y, N, Cin, Cout, H, W, s);
+        if (rc) return rc;
+        if (parts_out) { *parts_out = y; *nsplit_out = 1; }
+        return GX_OK;
+    }
     if ((kq_first || !wino_ok) && gx_kq_c3_eligible(N, Cin, Cout, H, W)) {   // 16-byte operand reads (gx_kq.hip)
         rc = launch_pack(w, wp, 10, Cout, Cin, 9, Kpad, Mpad, s, &wpu);
         if (rc) return rc;
@@ -1982,6 +1992,11 @@ int gx_conv3x3_dgrad(const float* dy, const float* w, float* dx, int N, int Cin,
     static const char* kq_env = getenv("GENESIS_KQ");
     const bool kq_first = kq_env && kq_env[0] == '2';
     const bool wino_ok = gx_wino_eligible(N, Cout, Cin, H, W);
+    if (!wino_ok && gx_kq_c3h_eligible(N, Cout, Cin, H, W)) {
+        rc = launch_pack(w, wp, 21, Cout, Cin, 9, gx_round_up(Cout, 16), Mpad, s, &wpu);
+        if (rc) return rc;
+        return gx_kq_c3h_launch(dy, wpu, nullptr, 0, dx, N, Cout, Cin, H, W, s);
+    }
     if ((kq_first || !wino_ok) && gx_kq_c3_eligible(N, Cout, Cin, H, W)) {
         rc = launch_pack(w, wp, 11, Cout, Cin, 9, Kpad, Mpad, s, &wpu);
         if (rc) return rc;

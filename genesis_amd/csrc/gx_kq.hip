@@ -35,7 +35,7 @@
 
 namespace {
 
-enum { Q_C3 = 0, Q_DT0 = 1, Q_DT1 = 2, Q_DG = 3, Q_DT0H = 4, Q_DT1H = 5, Q_DGH = 6 };     // ..H: on the bf16 matrix pipe (q_body's B16 path)
+enum { Q_C3 = 0, Q_DT0 = 1, Q_DT1 = 2, Q_DG = 3, Q_DT0H = 4, Q_DT1H = 5, Q_DGH = 6, Q_C3H = 7 };     // ..H: on the bf16 matrix pipe (q_body's B16 path)
 
 template <int MODE> struct QCfg;
 template <> struct QCfg<Q_C3> {
@@ -116,10 +116,27 @@ template <> struct QCfg<Q_DGH> {
     __host__ __device__ static constexpr int cls(int, int) { return 0; }
     __host__ __device__ static constexpr bool newin(int ph) { return ph + 1 == NPH || plane(ph + 1) != plane(ph); }
 };
+// conv3x3 (forward / data gradient) of layers with <= 32 output channels there (the BroadcastDecoder's 32 -> 32 convs on the
+// (S + 2L)^2 canvas, modules/decoders.py:21-35): one phase per kernel row; a workgroup owns 32 output channels (MI = 1), so the
+// weight slices are half as large ([tap][piece 3][octet 2][32 output channels][8 channels], pack kinds 20 / 21) and input
+// + weights stay at 72 KB with the 4-slot halo tiles of grids that are not powers of two (8 x 8 pixels x 4 images)
+template <> struct QCfg<Q_C3H> {
+    static constexpr int NPH = 3, NT = 9, MAXT = 3, NCLS = 1;
+    static constexpr bool PLANE_PER_PHASE = false;
+    __host__ __device__ static constexpr int ntaps(int) { return 3; }
+    __host__ __device__ static constexpr int tbase(int ph) { return 3 * ph; }
+    __host__ __device__ static constexpr int ro(int ph, int) { return ph; }
+    __host__ __device__ static constexpr int co(int, int j) { return j; }
+    __host__ __device__ static constexpr int cls(int, int) { return 0; }
+    __host__ __device__ static constexpr int plane(int) { return 0; }
+    __host__ __device__ static constexpr bool newin(int ph) { return ph + 1 == NPH; }
+};
 template <> struct QCfg<Q_DT0H> : QCfgDTH<0> {};
 template <> struct QCfg<Q_DT1H> : QCfgDTH<1> {};
 typedef __bf16 q_bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int QH_TAP_BYTES = 3 * 2 * 64 * 16;          // one tap of one 16-channel chunk: 6144 B
+// output-channel rows of a workgroup's weight slice and the bytes of one (tap, chunk) of it
+template <int MODE> struct QHLay { static constexpr int ROWS = MODE == Q_C3H ? 32 : 64, TAPB = 3 * 2 * ROWS * 16; };
 
 // one phase on the bf16 pipe: operands of (tap, mi / nj, piece) straight out of LDS
 template <int MODE, int PH, int NCLS, int MI>
@@ -135,7 +152,7 @@ __device__ __forceinline__ void q_phase_h(f32x16 (&acc)[NCLS][MI][2], const char
         for (int pc = 0; pc < 3; ++pc) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
-                a[mi][pc] = *reinterpret_cast<const q_bf16x8*>(wb + i * QH_TAP_BYTES + pc * 2048 + a_lane_b + mi * 512);
+                a[mi][pc] = *reinterpret_cast<const q_bf16x8*>(wb + i * QHLay<MODE>::TAPB + pc * (QHLay<MODE>::TAPB / 3) + a_lane_b + mi * 512);
             b[0][pc] = *reinterpret_cast<const q_bf16x8*>(ib + pc * plane_bytes + b_lane0_b + toff);
             b[1][pc] = *reinterpret_cast<const q_bf16x8*>(ib + pc * plane_bytes + b_lane1_b + toff);
         }
@@ -245,7 +262,7 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
     const int th_i = tile % g.tiles_h; tile /= g.tiles_h;
     const int img0 = tile * G;
     const int R0 = th_i * TH, C0 = tw_i * TW;
-    const int m0 = by * 64;
+    const int m0 = by * (MODE == Q_C3H ? 32 : 64);
     const int HiWi = g.Hi * g.Wi;
 
     // ---- staging slots: slot = tid + q * 256 -> (quad, position).  Loads go through buffer descriptors (wave-uniform
@@ -255,7 +272,7 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
         const_cast<float*>(in), 0, (int)((unsigned)g.N * (unsigned)g.K * (unsigned)HiWi * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(wp), 0,
-        B16 ? (int)((unsigned)NT * (unsigned)(g.K / 16) * gridDim.y * (unsigned)QH_TAP_BYTES)
+        B16 ? (int)((unsigned)NT * (unsigned)(g.K / 16) * gridDim.y * (unsigned)QHLay<MODE>::TAPB)
             : (int)((unsigned)NT * (unsigned)g.K * gridDim.y * 256u), 0x00020000);
     int voff[NQ];
 #pragma unroll
@@ -287,13 +304,14 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
                 for (int e = 0; e < 16; ++e) acc[c][i][j][e] = 0.f;
     if constexpr (B16) {
         // ---- the bf16-pipe pipeline: chunks of 16 channels, phases of <= 3 taps
-        constexpr int NWH = (MAXT * (QH_TAP_BYTES / 16) + 255) / 256;      // 16-byte weight pieces per thread per phase
+        constexpr int TAPB = QHLay<MODE>::TAPB;
+        constexpr int NWH = (MAXT * (TAPB / 16) + 255) / 256;              // 16-byte weight pieces per thread per phase
         constexpr int WSLOTB = NWH * 256 * 16;                             // bytes per weight buffer
         const int plane_bytes = NQ * 256 * 16;                             // bytes per input piece plane
         char* const ibuf = reinterpret_cast<char*>(lds);
         char* const wbufb = ibuf + 3 * plane_bytes;
         const int quad_l = lane >> 5;
-        const int a_lane_b = (quad_l * 64 + (lane & 31)) * 16 + mh * 512;   // + mi * 512 + piece * 2048 + tap * 6144
+        const int a_lane_b = (quad_l * QHLay<MODE>::ROWS + (lane & 31)) * 16 + mh * 512;   // + mi * 512 + piece * TAPB / 3 + tap * TAPB
         int b_lane_b[2];
 #pragma unroll
         for (int nj = 0; nj < 2; ++nj) {
@@ -305,7 +323,7 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
         }
         const int HS16 = HS * 16;
         const int nsc = g.K / 16;
-        const int w_sbase = by * nsc * (NT * QH_TAP_BYTES);
+        const int w_sbase = by * nsc * (NT * TAPB);
         float xin[NQ][8];
         f32x4 wreg[NWH];
 #define GX_QH_LOAD_IN(sc_, plane_)                                                                     \
@@ -333,7 +351,7 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
         }
 #define GX_QH_LOAD_W(sc_, ph_)                                                                         \
         {                                                                                              \
-            const int so_ = w_sbase + ((sc_) * NT + C::tbase(ph_)) * QH_TAP_BYTES;                     \
+            const int so_ = w_sbase + ((sc_) * NT + C::tbase(ph_)) * TAPB;                             \
             _Pragma("unroll") for (int i = 0; i < NWH; ++i)                                            \
                 wreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (tid + i * 256) * 16, so_, 0)); \
         }
@@ -370,7 +388,7 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
             GX_QH_STAGE(0)
             GX_QH_STAGE(1)
             GX_QH_STAGE(2)
-            GX_QH_STAGE(3)
+            if constexpr (NPH > 3) GX_QH_STAGE(3)
             if constexpr (NPH > 4) { GX_QH_STAGE(4) GX_QH_STAGE(5) }
             if constexpr (NPH > 6) { GX_QH_STAGE(6) GX_QH_STAGE(7) GX_QH_STAGE(8) GX_QH_STAGE(9) }
 #undef GX_QH_STAGE
@@ -659,6 +677,15 @@ kq_dgh_kernel(const float* __restrict__ in, const float* __restrict__ wp, float*
     else q_body<Q_DGH, NQ, false, 1>(in, wp, nullptr, out, g, lds, g.nfull + ((bx - g.nfull) >> 1), blockIdx.y, 0, (bx - g.nfull) & 1);
 }
 
+// conv3x3 on the bf16 pipe, 32 output channels per workgroup (blockIdx.y)
+template <int NQ>
+__global__ void __launch_bounds__(256, 2)
+kq_c3h_kernel(const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
+              float* __restrict__ out, QGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    q_body<Q_C3H, NQ, false, 1>(in, wp, bias, out, g, lds, blockIdx.x, blockIdx.y, 0, 0);
+}
+
 // the same launch shape on the bf16 matrix pipe (Q_DT0H / Q_DT1H)
 template <int NQ, bool STATS>
 __global__ void __launch_bounds__(256, 2)
@@ -837,6 +864,50 @@ int gx_kq_deconv_fwd_h_launch(const float* in, const float* wp0, const float* wp
         else { q_set_attr(&kq_dth_kernel<3, false>, &a[1]); hipLaunchKernelGGL((kq_dth_kernel<3, false>), grid, dim3(256), lds, s, in, wp0, wp1, bias, out, g); }
     }
     GX_CHECK_LAUNCH("kq deconv fwd (bf16 pipe)");
+    return GX_OK;
+}
+
+// ---- conv3x3 of <= 32-output-channel layers on the bf16 pipe (pack kinds 20 / 21); grids need not be powers of two: the
+//      256-pixel tile takes the largest power-of-two divisors of the width and height, images fill the rest
+static bool q_plan_c3h(int N, int K, int M, int H, int W, QGeom* g, int* nq, size_t* lds_bytes) {
+    if (K % 16 != 0 || H * W > 65536 || (double)N * K * H * W * 4.0 >= 2.0e9) return false;
+    int TW = 1; while (TW < 64 && W % (2 * TW) == 0) TW *= 2;
+    int TH = 1; while (TH * TW < 256 && H % (2 * TH) == 0) TH *= 2;
+    const int G = 256 / (TW * TH);
+    g->N = N; g->K = K; g->M = M; g->nchunks = K / 8;
+    g->Hb = H; g->Wb = W; g->Hi = H; g->Wi = W; g->Ho = H; g->Wo = W;
+    g->lTH = q_ilog2(TH); g->lTW = q_ilog2(TW); g->lG = q_ilog2(G);
+    g->tiles_h = H / TH; g->tiles_w = W / TW;
+    g->act = 0; g->stats = nullptr; g->stats_parts = 0; g->nfull = 0;
+    const int CHS = G * (TH + 2) * (TW + 2);
+    if (2 * CHS > 4 * 256) return false;
+    *nq = 2 * CHS <= 3 * 256 ? 3 : 4;
+    constexpr int NWH = (3 * (QHLay<Q_C3H>::TAPB / 16) + 255) / 256;
+    *lds_bytes = (size_t)3 * *nq * 256 * 16 + (size_t)2 * NWH * 256 * 16;      // three input piece planes + two weight buffers
+    return true;
+}
+bool gx_kq_c3h_eligible(int N, int K, int M, int H, int W) {
+    static const char* env = getenv("GENESIS_KQ_C3H");
+    if ((env && env[0] == '0') || !kq_h_on() || kq_mode() == 0 || M > 32) return false;
+    QGeom g; int nq; size_t lds;
+    if (!q_plan_c3h(N, K, M, H, W, &g, &nq, &lds)) return false;
+    return kq_mode() == 2 || (long)g.tiles_h * g.tiles_w * gx_ceil_div(N, 1 << g.lG) * gx_ceil_div(M, 32) >= 512;
+}
+int gx_kq_c3h_launch(const float* in, const float* wp, const float* bias, int act, float* out, int N, int K, int M, int H,
+                     int W, hipStream_t s) {
+    QGeom g; int nq; size_t lds;
+    if (!q_plan_c3h(N, K, M, H, W, &g, &nq, &lds)) { gx_set_error("kq conv3x3 (bf16 pipe): shape not eligible"); return GX_EINVAL; }
+    g.act = act;
+    const dim3 grid(g.tiles_h * g.tiles_w * gx_ceil_div(N, 1 << g.lG), gx_ceil_div(M, 32));
+    g.nfull = (int)grid.x;
+    {
+        GxProf pf(KID_KQ_C3H, s, 2.0 * N * (double)M * K * 9 * H * W,
+                  4.0 * ((double)N * K * H * W + (double)N * M * H * W + 9.0 * K * M));
+        static bool a3 = false, a4 = false;
+        if (nq == 3) { q_set_attr(&kq_c3h_kernel<3>, &a3); hipLaunchKernelGGL((kq_c3h_kernel<3>), grid, dim3(256), lds, s, in, wp, bias, out, g); }
+        else { q_set_attr(&kq_c3h_kernel<4>, &a4); hipLaunchKernelGGL((kq_c3h_kernel<4>), grid, dim3(256), lds, s, in, wp, bias, out, g); }
+    }
+    GX_CHECK_LAUNCH("kq conv3x3 (bf16 pipe)");
     return GX_OK;
 }
 

@@ -1325,3 +1325,33 @@ def test_bn_running_statistics_of_a_gated_unit(N, C, S):
             close(d.running_mean, r.running_mean, rtol=1e-5, atol=1e-6, msg='running_mean')
             close(d.running_var, r.running_var, rtol=1e-4, atol=1e-6, msg='running_var')
     assert int(dev_h.num_batches_tracked) == 2 and int(dev_g.num_batches_tracked) == 2
+
+
+@pytest.mark.parametrize('N,Cin,Cout,H,W', [(16, 32, 32, 72, 72), (5, 16, 24, 40, 24), (4, 32, 7, 16, 16), (9, 48, 32, 8, 64)])
+def test_conv3x3_to_32_channels_on_the_bf16_pipe(N, Cin, Cout, H, W):
+    """gx_kq.hip's Q_C3H (the BroadcastDecoder's canvas convs, modules/decoders.py:21-35): conv3x3 (+ bias + ELU) and its data
+    gradient of layers with <= 32 output channels, every fp32 product from six bf16 piece products, on grids that are not
+    powers of two.  Against fp64; the error must stay within 1.5 x the fp32-pipe kernels' (+ 1e-7) and the suite's 1e-4."""
+    from genesis_amd import hip_ops as hip, _lib
+    x, w, b = rnd(N, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=1.0 / np.sqrt(9 * Cin)), rnd(Cout, seed=3)
+    dy = rnd(N, Cout, H, W, seed=4)
+    xr = x.double().requires_grad_()
+    yr = F.elu(F.conv2d(xr, w.double(), b.double(), padding=1))
+    dxr, = torch.autograd.grad(F.conv2d(xr, w.double(), None, padding=1), xr, dy.double())
+    err = {}
+    _lib.call('gx_kq_policy', 2)                  # every eligible shape (the default asks for a chip-filling grid)
+    try:
+        for mode in (0, 1):
+            _lib.call('gx_kq_precision', mode)
+            y = hip.conv3x3_bias_act_fwd(x.to(DEV), w.to(DEV), b.to(DEV), 'elu')
+            dx = hip.conv3x3_dgrad(dy.to(DEV), w.to(DEV))
+            err[mode] = (float((y.double().cpu() - yr).norm() / yr.norm()), float((dx.double().cpu() - dxr).norm() / dxr.norm()))
+            if mode == 1:
+                close(y, yr, rtol=1e-5, atol=1e-5, msg='y')
+                close(dx, dxr, rtol=1e-5, atol=1e-5, msg='dx')
+    finally:
+        _lib.call('gx_kq_precision', 1)
+        _lib.call('gx_kq_policy', 1)
+    print('conv3x3 -> %d channels %dx%d: forward fp32 pipe %.3e, bf16 pipe %.3e; data gradient %.3e / %.3e'
+          % (Cout, H, W, err[0][0], err[1][0], err[0][1], err[1][1]))
+    assert err[1][0] <= 1.5 * err[0][0] + 1e-7 and err[1][1] <= 1.5 * err[0][1] + 1e-7, err
