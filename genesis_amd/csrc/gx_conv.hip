@@ -833,7 +833,12 @@ wgrad_kernel(const float* __restrict__ a_src, const float* __restrict__ b_src,
 // assignment does not depend on the tile), the tile width is a template parameter so that every tap / pixel offset
 // of the LDS reads is an instruction immediate, and the batch loop is unrolled with two alternating A buffers (no
 // register copies): ~1 VALU per MFMA is left.
-template <int WM, int LTW>
+// QUAD (layers of 32 x 32 channels, e.g. the BroadcastDecoder's canvas convs): the tensors are viewed as [N / 4, 128, H, W] -- four
+// images side by side in the channel dimension -- and wave w multiplies the dy channels of sub-image w with the x channels
+// of sub-image w (128 staged B rows): all four waves produce a 32 x 32 block that is wanted (a plain 64-channel tile of two
+// images has two useful waves, one image one), each into its own quadrant of the 64 x 64 slab; wgrad_quad_reduce_kernel sums
+// the quadrants.
+template <int WM, int LTW, bool QUAD = false>
 __global__ void __launch_bounds__(256, 1)
 wgrad_fast_kernel(const float* __restrict__ a_src, const float* __restrict__ b_src,
                   float* __restrict__ partial, const float* __restrict__ zeros, WgradGeom g) {
@@ -847,17 +852,18 @@ wgrad_fast_kernel(const float* __restrict__ a_src, const float* __restrict__ b_s
     const int nb = PT >> 5;              // A batches per tile (1, 2 or 4)
     const int CHS = G * (TH + 2) * HS;
     const int BS = CHS | 1;
-    const int BUF = 64 * BS;
+    constexpr int BROWS = QUAD ? 128 : 64;
+    const int BUF = BROWS * BS;
     const int sp = blockIdx.x, nsp = g.nsplit;
 
     const int nbt = g.CBpad / 64;
-    const int ca0 = (blockIdx.y / nbt) * 64;
-    const int cb0 = (blockIdx.y % nbt) * 64;
+    const int ca0 = QUAD ? 0 : (blockIdx.y / nbt) * 64;
+    const int cb0 = QUAD ? 0 : (blockIdx.y % nbt) * 64;
     const int wm = wave >> 1, wn = wave & 1;
     const int a_img = g.CA * g.Ha * g.Wa;             // the host dispatch guarantees these fit 31 bits
     const int b_img = g.CB * g.Hb * g.Wb;
     const int HaWa = g.Ha * g.Wa, HbWb = g.Hb * g.Wb;
-    const int nvalid_ch = g.CB - cb0 < 64 ? g.CB - cb0 : 64;
+    const int nvalid_ch = QUAD ? 128 : (g.CB - cb0 < 64 ? g.CB - cb0 : 64);
 
     f32x16 acc[NT];
 #pragma unroll
@@ -865,10 +871,10 @@ wgrad_fast_kernel(const float* __restrict__ a_src, const float* __restrict__ b_s
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
-    const int ca_l = ca0 + wm * 32 + (lane & 31);
-    const bool ca_ok = ca_l < g.CA;
+    const int ca_l = QUAD ? wave * 32 + (lane & 31) : ca0 + wm * 32 + (lane & 31);
+    const bool ca_ok = QUAD || ca_l < g.CA;
     const int khalf = lane >> 5;
-    const int b_row = (wn * 32 + (lane & 31)) * BS;
+    const int b_row = ((QUAD ? wave : wn) * 32 + (lane & 31)) * BS;
     const float* a_lane = a_src + (size_t)(ca_ok ? ca_l : 0) * HaWa + WT::PA * g.Wa;
     const bool exact = (g.tiles_h << g.lTH) == g.Hb && g.tiles_w * TW == g.Wb && (g.N & (G - 1)) == 0;
     const int jlane = khalf * (PT >> 1);               // first pixel of this lane's k slot
@@ -913,7 +919,7 @@ wgrad_fast_kernel(const float* __restrict__ a_src, const float* __restrict__ b_s
                                                  (__attribute__((address_space(3))) void*)ldst, 4, 0, 0); \
                 gp += HbWb; ldst += BS;                                                              \
             }                                                                                        \
-            for (; ch < 64; ++ch) {                               /* channels beyond CB: zeros */    \
+            for (; ch < BROWS; ++ch) {                            /* channels beyond CB: zeros */    \
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)zeros, \
                                                  (__attribute__((address_space(3))) void*)ldst, 4, 0, 0); \
                 ldst += BS;                                                                          \
@@ -1078,6 +1084,33 @@ wgrad_deconv_kernel(const float* __restrict__ a_src, const float* __restrict__ b
         wgrad_body<W_D10>(a_src, b_src, partial, g, lds, bx - g.cls_begin[2], g.cls_begin[3] - g.cls_begin[2]);
     else
         wgrad_body<W_D11>(a_src, b_src, partial, g, lds, bx - g.cls_begin[3], g.cls_begin[4] - g.cls_begin[3]);
+}
+
+// QUAD slabs [split][t][64][64] -> dw [C][C][T] (C <= 32): quadrant q = (wm, wn) holds sub-image q's 32 x 32 block.  Block =
+// 64 consecutive (t, ca, cb) outputs x the 4 quadrants; per quadrant the splits are summed in order, then the quadrants.
+__global__ void __launch_bounds__(256)
+wgrad_quad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int nsplit, int Ttot, int C) {
+    __shared__ float red[4][64];
+    const int total = Ttot * C * C;
+    const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + e;
+    float s = 0.f;
+    int cb = 0, ca = 0, t = 0;
+    if (idx < total) {
+        cb = idx % C;
+        ca = (idx / C) % C;
+        t = idx / (C * C);
+        const size_t stride = (size_t)Ttot * 64 * 64;
+        const float* p = partial + ((size_t)t * 64 + ca + 32 * (q >> 1)) * 64 + cb + 32 * (q & 1);
+        float s0 = 0.f, s1 = 0.f;
+        int sp = 0;
+        for (; sp + 1 < nsplit; sp += 2) { s0 += p[sp * stride]; s1 += p[(sp + 1) * stride]; }
+        if (sp < nsplit) s0 += p[sp * stride];
+        s = s0 + s1;
+    }
+    red[q][e] = s;
+    __syncthreads();
+    if (q == 0 && idx < total) dw[((size_t)ca * C + cb) * Ttot + t] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
 }
 
 // dW = sum over splits.  layout 0: W[ca][cb][T] (conv3x3: ca=co, cb=ci); layout 1: W[cb][ca][T] (deconv).
@@ -1431,7 +1464,8 @@ struct WgradPlan {
     size_t ws_floats;
 };
 
-int plan_wgrad(int N, int CA, int CB, int Hb, int Wb, int SA, int Ttot, int ncls_launches, WgradPlan* pl) {
+int plan_wgrad(int N, int CA, int CB, int Hb, int Wb, int SA, int Ttot, int ncls_launches, WgradPlan* pl, int max_npix = 128,
+               int b_rows = 64) {
     WgradGeom& g = pl->g;
     g.N = N; g.CA = CA; g.CB = CB;
     g.CApad = gx_round_up(CA, 64); g.CBpad = gx_round_up(CB, 64);
@@ -1442,7 +1476,7 @@ int plan_wgrad(int N, int CA, int CB, int Hb, int Wb, int SA, int Ttot, int ncls
     {
         double best_eff = -1.0;
         int best_np = 0;
-        for (int npix = 128; npix >= 32; npix >>= 1) {
+        for (int npix = max_npix; npix >= 32; npix >>= 1) {
             for (int tw = 1; tw <= 32 && tw <= npix; tw <<= 1) {
                 if (tw > 1 && (tw >> 1) >= Wb) break;
                 for (int th = 1; th * tw <= npix; th <<= 1) {
@@ -1496,7 +1530,7 @@ int plan_wgrad(int N, int CA, int CB, int Hb, int Wb, int SA, int Ttot, int ncls
         nsplit = mx;
     }
     const int CHS = G * (TH + 2) * (TW + 2);
-    pl->lds_bytes = (size_t)2 * 64 * (CHS | 1) * sizeof(float);   // double-buffered B (x halo) tile
+    pl->lds_bytes = (size_t)2 * b_rows * (CHS | 1) * sizeof(float);   // double-buffered B (x halo) tile
     pl->ws_floats = (size_t)nsplit * Ttot * g.CApad * g.CBpad;
     return GX_OK;
 }
@@ -2058,6 +2092,70 @@ int gx_conv3x3_wgrad(const float* x, const float* dy, float* dw, int N, int Cin,
     rc = launch_wgrad<W_C3>(dy, x, (float*)ws, pl, s, "gx_conv3x3_wgrad");
     if (rc) return rc;
     return launch_wgrad_reduce((const float*)ws, dw, pl, 0, s);
+}
+
+/* conv3x3 weight gradient of a layer with C <= 32 channels on both sides and N % 4 == 0 images (the BroadcastDecoder's 32 -> 32
+ * convs on the canvas, modules/decoders.py:21-35): four images per workgroup tile, one per wave (wgrad_fast_kernel QUAD). */
+static bool wgrad_quad_plan(int N, int C, int H, int W, WgradPlan* pl) {
+    if (N <= 0 || (N & 3) || C != 32 || H < 1 || W < 4 || (W & 3) || H >= 1024 || W >= 1024 || H * W > 65536) return false;
+    if (plan_wgrad(N / 4, 64, 64, H, W, 1, 9, 1, pl, 64, 128) != GX_OK) return false;
+    const WgradGeom& g = pl->g;
+    if (g.lTW < 2 || g.lTW > 5 || pl->lds_bytes > 160 * 1024) return false;
+    if ((double)(1 << g.lG) * 128 * H * W >= 2.0e9 || (size_t)128 * H * W > kZeroFloats) return false;
+    return !getenv("GENESIS_WGRAD_LEGACY") && !getenv("GENESIS_WGRAD_NOQUAD");
+}
+int gx_conv3x3_wgrad_quad_supported(int N, int C, int H, int W) {
+    WgradPlan pl;
+    return wgrad_quad_plan(N, C, H, W, &pl) ? 1 : 0;
+}
+size_t gx_conv3x3_wgrad_quad_ws_bytes(int N, int C, int H, int W) {
+    WgradPlan pl;
+    if (!wgrad_quad_plan(N, C, H, W, &pl)) return 0;
+    return pl.ws_floats * sizeof(float);
+}
+int gx_conv3x3_wgrad_quad(const float* x, const float* dy, float* dw, int N, int C, int H, int W, void* ws, size_t ws_bytes,
+                          gx_stream_t stream) {
+    GX_CHECK_ARG(x && dy && dw && ws, "gx_conv3x3_wgrad_quad: null pointer");
+    WgradPlan pl;
+    GX_CHECK_ARG(wgrad_quad_plan(N, C, H, W, &pl), "gx_conv3x3_wgrad_quad: needs 32 channels, N %% 4 == 0, W %% 4 == 0");
+    GX_CHECK_ARG(ws_bytes >= pl.ws_floats * sizeof(float), "gx_conv3x3_wgrad_quad: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const float* zeros = zero_page(s);
+    if (!zeros) { gx_set_error("gx_conv3x3_wgrad_quad: no zero page (first call inside a stream capture)"); return GX_ELAUNCH; }
+    WgradGeom g = pl.g;
+    g.CA = g.CB = 128;                     // the [N / 4, 128, H, W] view: image and channel strides of the kernel
+    const dim3 grid(g.nsplit, 1);
+    {
+        GxProf pf(KID_WGRAD_C3, s, 2.0 * N * (double)C * C * 9 * H * W,
+                  4.0 * (2.0 * N * C * H * W + (double)g.nsplit * 9 * 64 * 64));
+#define GX_QUAD_LAUNCH(LTW_)                                                                                             \
+        {                                                                                                                \
+            static bool attr = false;                                                                                    \
+            if (!attr) {                                                                                                 \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_fast_kernel<W_C3, LTW_, true>),           \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                       \
+                attr = true;                                                                                             \
+            }                                                                                                            \
+            hipLaunchKernelGGL((wgrad_fast_kernel<W_C3, LTW_, true>), grid, dim3(256), pl.lds_bytes, s, dy, x, (float*)ws, \
+                               zeros, g);                                                                                \
+        }
+        switch (g.lTW) {
+            case 2: GX_QUAD_LAUNCH(2) break;
+            case 3: GX_QUAD_LAUNCH(3) break;
+            case 4: GX_QUAD_LAUNCH(4) break;
+            default: GX_QUAD_LAUNCH(5) break;
+        }
+#undef GX_QUAD_LAUNCH
+    }
+    GX_CHECK_LAUNCH("gx_conv3x3_wgrad_quad");
+    {
+        const int total = 9 * C * C;
+        GxProf pf(KID_WGRAD_REDUCE, s, 0.0, 4.0 * (4.0 * g.nsplit + 1.0) * total);
+        hipLaunchKernelGGL(wgrad_quad_reduce_kernel, dim3(gx_ceil_div(total, 64)), dim3(256), 0, s, (const float*)ws, dw,
+                           g.nsplit, 9, C);
+    }
+    GX_CHECK_LAUNCH("gx_conv3x3_wgrad_quad(reduce)");
+    return GX_OK;
 }
 
 /* 5 x 5 stride-1 pad-2 convolution on the tap-conv MFMA kernel (mode M_C5): out [N,M,H,W] from in [N,K,H,W].

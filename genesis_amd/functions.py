@@ -820,6 +820,10 @@ def _wgrad_paired(h, dy, gw):
     in its lower-right one (the off-diagonal blocks are cross-image products nobody wants) -- half of the MFMA work is
     useful instead of a quarter, with no kernel change.  Returns dw (or None after writing gw)."""
     N, Ci, Co = h.shape[0], h.shape[1], dy.shape[1]
+    if Ci == Co and hip.conv3x3_wgrad_quad_supported(N, Ci, h.shape[2], h.shape[3]):
+        # four images per workgroup tile, one per wave: every wave's 32 x 32 block is a wanted one
+        dw = hip.conv3x3_wgrad_quad(h, dy, out=gw)
+        return None if gw is not None else dw
     if N % 2 or Ci > 32 or Co > 32 or Ci != Co or Ci % 8:
         return hip.conv3x3_wgrad(h, dy, out=gw)
     d64 = hip.conv3x3_wgrad(h.view(N // 2, 2 * Ci, *h.shape[2:]), dy.view(N // 2, 2 * Co, *dy.shape[2:]))

@@ -126,6 +126,23 @@ def conv3x3_wgrad(x, dy, out=None):
     return dw
 
 
+def conv3x3_wgrad_quad_supported(N, C, H, W):
+    return bool(_lib.query('gx_conv3x3_wgrad_quad_supported', N, C, H, W))
+
+
+def conv3x3_wgrad_quad(x, dy, out=None):
+    """conv3x3 weight gradient of a 32 -> 32 layer, four images per workgroup tile (gx_conv3x3_wgrad_quad)."""
+    _chk(x, 'conv3x3_wgrad_quad.x'); _chk(dy, 'conv3x3_wgrad_quad.dy')
+    N, C, H, W = x.shape
+    assert tuple(dy.shape) == (N, C, H, W)
+    dw = out if out is not None else torch.empty(C, C, 3, 3, dtype=F32, device=x.device)
+    assert tuple(dw.shape) == (C, C, 3, 3) and dw.is_contiguous()
+    nb = _lib.query('gx_conv3x3_wgrad_quad_ws_bytes', N, C, H, W)
+    ws = _ws(nb, x.device)
+    _lib.call('gx_conv3x3_wgrad_quad', _p(x), _p(dy), _p(dw), N, C, H, W, _p(ws), nb, _stream())
+    return dw
+
+
 # ------------------------------------------------------------------ ConvTranspose2d k5 s2 p2 op1
 def deconv5x5s2_fwd(x, w, bias):
     _chk(x, 'deconv.x'); _chk(w, 'deconv.w'); _chk(bias, 'deconv.bias')

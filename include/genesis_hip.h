@@ -267,6 +267,13 @@ int gx_bias_act_bwd(const float* out, const float* g, int N, int C, int H, int W
  *      the bf16-pipe row-ring tiles: dw [CA][CB][5][5] = sum_{n,p} a[n][CA][p] * b[n][CB][p + (kh - 2, kw - 2)].
  *      Conv2d: a = dy, b = x -> dw [Cout][Cin][5][5]; ConvTranspose2d stride 1: a = x, b = dy -> dw [Cin][Cout][5][5].
  *      Queued into the step's stream-K launch when deferral is on (gx_defer_*), else launched at once. */
+/*      conv3x3 weight gradient of a layer with 32 channels on both sides (the BroadcastDecoder's canvas convs,
+ *      modules/decoders.py:21-35) and N % 4 == 0 images: four images per workgroup, one per wave, so that every wave's
+ *      32 x 32 block is a wanted one; x, dy [N,32,H,W] -> dw [32,32,3,3] (overwritten).  H x W any grid with W % 4 == 0. */
+int gx_conv3x3_wgrad_quad_supported(int N, int C, int H, int W);
+size_t gx_conv3x3_wgrad_quad_ws_bytes(int N, int C, int H, int W);
+int gx_conv3x3_wgrad_quad(const float* x, const float* dy, float* dw, int N, int C, int H, int W, void* ws, size_t ws_bytes,
+                          gx_stream_t stream);
 /*      the layers themselves on the tap-conv MFMA kernel: out [N,M,H,W] from in [N,K,H,W];
  *      flip 0: cross-correlation with w [M][K][5][5] (Conv2d forward; data gradient of a stride-1 ConvTranspose2d),
  *      flip 1: convolution with w [K][M][5][5] (Conv2d data gradient, in = dy; stride-1 ConvTranspose2d forward). */

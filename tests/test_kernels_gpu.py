@@ -1355,3 +1355,20 @@ def test_conv3x3_to_32_channels_on_the_bf16_pipe(N, Cin, Cout, H, W):
     print('conv3x3 -> %d channels %dx%d: forward fp32 pipe %.3e, bf16 pipe %.3e; data gradient %.3e / %.3e'
           % (Cout, H, W, err[0][0], err[1][0], err[0][1], err[1][1]))
     assert err[1][0] <= 1.5 * err[0][0] + 1e-7 and err[1][1] <= 1.5 * err[0][1] + 1e-7, err
+
+
+@pytest.mark.parametrize('N,H,W', [(8, 72, 72), (4, 16, 12), (12, 8, 8), (20, 64, 64)])
+def test_conv3x3_weight_gradient_with_four_images_per_tile(N, H, W):
+    """gx_conv3x3_wgrad_quad (the BroadcastDecoder's 32 -> 32 canvas convs): four images per workgroup, one per wave, the four
+    quadrant slabs summed by the reduce.  Against autograd in fp64 and bit-reproducible."""
+    from genesis_amd import hip_ops as hip
+    assert hip.conv3x3_wgrad_quad_supported(N, 32, H, W)
+    assert not hip.conv3x3_wgrad_quad_supported(N + 1, 32, H, W) and not hip.conv3x3_wgrad_quad_supported(N, 16, H, W)
+    x, dy = rnd(N, 32, H, W, seed=1), rnd(N, 32, H, W, seed=2)
+    w = torch.zeros(32, 32, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w, None, padding=1).backward(dy.double())
+    dw = hip.conv3x3_wgrad_quad(x.to(DEV), dy.to(DEV))
+    close(dw, w.grad, rtol=1e-5, atol=2e-6 * float(w.grad.abs().max()), msg='dw')
+    out = torch.full((32, 32, 3, 3), 7.0, device=DEV)
+    hip.conv3x3_wgrad_quad(x.to(DEV), dy.to(DEV), out=out)
+    assert torch.equal(out, dw)
