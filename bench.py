@@ -88,14 +88,14 @@ def build_model(args, device):
     return G.load(cfg).to(device).train()
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, tag=''):
     """HBM bytes per launch of the kernels behind profiling id `kernel` from the committed PMC passes (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate runs of this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM');
     None if absent."""
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
     path = next((p_ for p_ in (os.path.join(here, 'r03_pmc_hbm_traffic.json'), os.path.join(here, 'r02_pmc_hbm_traffic.json'))
                  if os.path.exists(p_)), None)
-    if path is None:
+    if path is None or tag != '':          # the PMC passes exist for the default workload only
         return None, None
     data = json.load(open(path))
     syms = tuple(s_.replace(',', '') for s_ in KID_SYMBOLS.get(kernel, (kernel,)))
@@ -121,13 +121,16 @@ KID_SYMBOLS = {
 }
 
 
-def rocprof_avg_us(kid_name):
+def rocprof_avg_us(kid_name, tag=''):
     """Average launch duration of the kernels behind a profiling id in the committed rocprofv3 --kernel-trace --stats
-    summary of this same command (profiles/r02_rocprofv3_kernel_stats.csv); None if absent."""
+    summary of this same command (profiles/r03_[<model>_]rocprofv3_kernel_stats.csv); None if absent or if this run is not
+    the workload the summary was taken on (tag None)."""
     import csv
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
-    path = next((p_ for p_ in (os.path.join(here, 'r03_rocprofv3_kernel_stats.csv'), os.path.join(here, 'r02_rocprofv3_kernel_stats.csv'))
-                 if os.path.exists(p_)), None)
+    if tag is None:
+        return None, None
+    cands = ['r03_%srocprofv3_kernel_stats.csv' % tag] + (['r02_rocprofv3_kernel_stats.csv'] if tag == '' else [])
+    path = next((p_ for p_ in (os.path.join(here, c_) for c_ in cands) if os.path.exists(p_)), None)
     syms = KID_SYMBOLS.get(kid_name)
     if path is None or not syms:
         return None, None
@@ -356,8 +359,12 @@ def main():
             roof['frac_on_mfma_pipe'] = ach / 2.25 / PEAK_FP32_MFMA_TFLOPS
         roof['frac_of_fp32_pipe'] = ach / PEAK_FP32_MFMA_TFLOPS if dom['flops'] > 0 else None
         # numbers that are NOT of this run: read from the committed rocprofv3 / PMC passes of the same command
-        rp, rp_file = rocprof_avg_us(dom['name'])
-        tr, tr_file = pmc_traffic(dom['name'])
+        # (only for the workload they were taken on: the default shape of each model family, no forced collective)
+        default_shape = args.K == 7 and args.img == 64 and args.batch == 32 and args.feat_dim == 64 and world == 1 and \
+            not os.environ.get('GENESIS_FORCE_ALLREDUCE')
+        ptag = None if not default_shape else ('' if args.model == 'genesisv2' else args.model + '_')
+        rp, rp_file = rocprof_avg_us(dom['name'], ptag)
+        tr, tr_file = pmc_traffic(dom['name'], ptag)
         committed = {}
         if rp:
             committed['rocprof_avg_launch_us'] = rp
