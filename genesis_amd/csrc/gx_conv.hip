@@ -1087,12 +1087,12 @@ wgrad_deconv_kernel(const float* __restrict__ a_src, const float* __restrict__ b
 }
 
 // QUAD slabs [split][t][64][64] -> dw [C][C][T] (C <= 32): quadrant q = (wm, wn) holds sub-image q's 32 x 32 block.  Block =
-// 64 consecutive (t, ca, cb) outputs x the 4 quadrants; per quadrant the splits are summed in order, then the quadrants.
-__global__ void __launch_bounds__(256)
+// 64 consecutive (t, ca, cb) outputs x the 4 quadrants x 4 interleaved split groups; fixed summation order.
+__global__ void __launch_bounds__(1024)
 wgrad_quad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int nsplit, int Ttot, int C) {
-    __shared__ float red[4][64];
+    __shared__ float red[16][64];
     const int total = Ttot * C * C;
-    const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int e = threadIdx.x & 63, q = (threadIdx.x >> 6) & 3, grp = threadIdx.x >> 8;     // 4 interleaved split groups
     const int idx = blockIdx.x * 64 + e;
     float s = 0.f;
     int cb = 0, ca = 0, t = 0;
@@ -1103,14 +1103,19 @@ wgrad_quad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ 
         const size_t stride = (size_t)Ttot * 64 * 64;
         const float* p = partial + ((size_t)t * 64 + ca + 32 * (q >> 1)) * 64 + cb + 32 * (q & 1);
         float s0 = 0.f, s1 = 0.f;
-        int sp = 0;
-        for (; sp + 1 < nsplit; sp += 2) { s0 += p[sp * stride]; s1 += p[(sp + 1) * stride]; }
+        int sp = grp;
+        for (; sp + 4 < nsplit; sp += 8) { s0 += p[sp * stride]; s1 += p[(sp + 4) * stride]; }
         if (sp < nsplit) s0 += p[sp * stride];
         s = s0 + s1;
     }
-    red[q][e] = s;
+    red[grp * 4 + q][e] = s;
     __syncthreads();
-    if (q == 0 && idx < total) dw[((size_t)ca * C + cb) * Ttot + t] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    if (threadIdx.x < 64 && idx < total) {
+        float qs[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) qs[k] = (red[k][e] + red[4 + k][e]) + (red[8 + k][e] + red[12 + k][e]);
+        dw[((size_t)ca * C + cb) * Ttot + t] = (qs[0] + qs[1]) + (qs[2] + qs[3]);
+    }
 }
 
 // dW = sum over splits.  layout 0: W[ca][cb][T] (conv3x3: ca=co, cb=ci); layout 1: W[cb][ca][T] (deconv).
@@ -2151,7 +2156,7 @@ int gx_conv3x3_wgrad_quad(const float* x, const float* dy, float* dw, int N, int
     {
         const int total = 9 * C * C;
         GxProf pf(KID_WGRAD_REDUCE, s, 0.0, 4.0 * (4.0 * g.nsplit + 1.0) * total);
-        hipLaunchKernelGGL(wgrad_quad_reduce_kernel, dim3(gx_ceil_div(total, 64)), dim3(256), 0, s, (const float*)ws, dw,
+        hipLaunchKernelGGL(wgrad_quad_reduce_kernel, dim3(gx_ceil_div(total, 64)), dim3(1024), 0, s, (const float*)ws, dw,
                            g.nsplit, 9, C);
     }
     GX_CHECK_LAUNCH("gx_conv3x3_wgrad_quad(reduce)");

@@ -31,6 +31,7 @@ dense_tile(float (*part)[256], float (*rpart)[16], int bx, int by, const float* 
     const int idx = lane & 15, kq = lane >> 4;
     const int i0 = by * 16, j0 = bx * 16;
     const bool elu_mask = (act & 4) != 0;        // MASK: the mask is an ELU output (derivative y + 1 where y <= 0)
+    const bool acc_rs = (act & 8) != 0;          // ROWSUM: add to what rs / rs2 hold (a parameter used again in one iteration)
     act &= 3;
     const int ai = i0 + idx, bj = j0 + idx;
     const bool a_ok = ai < I, b_ok = bj < J;
@@ -118,8 +119,8 @@ dense_tile(float (*part)[256], float (*rpart)[16], int bx, int by, const float* 
     if (ROWSUM && bx == 0 && threadIdx.x < 16 && i0 + (int)threadIdx.x < I) {
         float s = rpart[0][threadIdx.x];
         for (int w = 1; w < nw; ++w) s += rpart[w][threadIdx.x];
-        rs[i0 + threadIdx.x] = s;
-        if (rs2) rs2[i0 + threadIdx.x] = s;
+        if (acc_rs) { rs[i0 + threadIdx.x] += s; if (rs2) rs2[i0 + threadIdx.x] += s; }
+        else { rs[i0 + threadIdx.x] = s; if (rs2) rs2[i0 + threadIdx.x] = s; }
     }
 }
 
@@ -145,11 +146,11 @@ dense_bwd_pair_kernel(const float* __restrict__ g, int ldg, const float* __restr
     __shared__ float part[16][256];
     __shared__ float rpart[16][16];
     if ((int)blockIdx.y < gy_dx)
-        dense_tile<true, false, MASK, false>(part, rpart, blockIdx.x, blockIdx.y, g, ldg, y, w, K, nullptr, dx_act, dx,
+        dense_tile<true, false, MASK, false>(part, rpart, blockIdx.x, blockIdx.y, g, ldg, y, w, K, nullptr, dx_act & 7, dx,
                                              lddx, M, K, N, nullptr, vec, 0);
     else
         dense_tile<false, false, MASK, ROWSUM>(part, rpart, blockIdx.x, blockIdx.y - gy_dx, g, ldg, y, x, ldx, nullptr,
-                                               dx_act & 4, dw, K, N, K, M, db, 0, 0, db2);
+                                               (dx_act & 4) | ((dx_act & 16) ? 10 : 0), dw, K, N, K, M, db, 0, 0, db2);
 }
 
 // ------------------------------------------------------------------------------------------------ LSTM cell
@@ -308,8 +309,10 @@ int gx_linear_bwd_ex(const float* x, int ldx, const float* w, const float* y, co
     GX_CHECK_ARG(db || !db2, "gx_linear_bwd: db2 is a second copy of db");
     hipStream_t s = (hipStream_t)stream;
     const int vec = (N % 4 == 0) && (ldg % 4 == 0) && aligned16(g) && (act == 0 || aligned16(y));
+    GX_CHECK_ARG(dx_accumulate >= 0 && dx_accumulate <= 3, "gx_linear_bwd: dx_accumulate is a bit mask (1: dx, 2: dw / db)");
     const int elu = act == 2 ? 4 : 0;          // (bit 2 of the tile's act code: the mask is an ELU output)
-    const int dx_act = (dx_accumulate ? 2 : 0) | elu;
+    const int dwacc = (dx_accumulate & 2) ? 10 : 0;    // dw += (epilogue code 2), db += (bit 3)
+    const int dx_act = ((dx_accumulate & 1) ? 2 : 0) | elu | ((dx_accumulate & 2) ? 16 : 0);
     if (act == 2) act = 1;                     // masked like ReLU from here on
     if (dx && dw) {   // one launch for both
         GxProf pf(KID_DENSE, s, 4.0 * M * N * K, 4.0 * (4.0 * M * N + 2.0 * N * K + 2.0 * M * K));
@@ -330,10 +333,10 @@ int gx_linear_bwd_ex(const float* x, int ldx, const float* w, const float* y, co
         const dim3 grid(gx_ceil_div(K, 16), gx_ceil_div(M, 16)), block(dense_threads(N));
         if (act == 1)
             hipLaunchKernelGGL((dense_kernel<true, false, true, false>), grid, block, 0, s, g, ldg, y, w, K,
-                               (const float*)nullptr, dx_act, dx, lddx, M, K, N, (float*)nullptr, vec, 0, (float*)nullptr);
+                               (const float*)nullptr, dx_act & 7, dx, lddx, M, K, N, (float*)nullptr, vec, 0, (float*)nullptr);
         else
             hipLaunchKernelGGL((dense_kernel<true, false, false, false>), grid, block, 0, s, g, ldg,
-                               (const float*)nullptr, w, K, (const float*)nullptr, dx_act, dx, lddx, M, K, N,
+                               (const float*)nullptr, w, K, (const float*)nullptr, dx_act & 7, dx, lddx, M, K, N,
                                (float*)nullptr, vec, 0, (float*)nullptr);
     }
     GX_CHECK_LAUNCH("gx_linear_bwd(dx)");
@@ -343,18 +346,18 @@ int gx_linear_bwd_ex(const float* x, int ldx, const float* w, const float* y, co
         if (act == 1) {
             if (db)
                 hipLaunchKernelGGL((dense_kernel<false, false, true, true>), grid, block, 0, s, g, ldg, y, x, ldx,
-                                   (const float*)nullptr, elu, dw, K, N, K, M, db, 0, 0, db2);
+                                   (const float*)nullptr, elu | dwacc, dw, K, N, K, M, db, 0, 0, db2);
             else
                 hipLaunchKernelGGL((dense_kernel<false, false, true, false>), grid, block, 0, s, g, ldg, y, x, ldx,
-                                   (const float*)nullptr, elu, dw, K, N, K, M, (float*)nullptr, 0, 0, (float*)nullptr);
+                                   (const float*)nullptr, elu | dwacc, dw, K, N, K, M, (float*)nullptr, 0, 0, (float*)nullptr);
         } else {
             if (db)
                 hipLaunchKernelGGL((dense_kernel<false, false, false, true>), grid, block, 0, s, g, ldg,
-                                   (const float*)nullptr, x, ldx, (const float*)nullptr, 0, dw, K, N, K, M, db, 0, 0,
+                                   (const float*)nullptr, x, ldx, (const float*)nullptr, dwacc, dw, K, N, K, M, db, 0, 0,
                                    db2);
             else
                 hipLaunchKernelGGL((dense_kernel<false, false, false, false>), grid, block, 0, s, g, ldg,
-                                   (const float*)nullptr, x, ldx, (const float*)nullptr, 0, dw, K, N, K, M,
+                                   (const float*)nullptr, x, ldx, (const float*)nullptr, dwacc, dw, K, N, K, M,
                                    (float*)nullptr, 0, 0, (float*)nullptr);
         }
     }

@@ -81,6 +81,19 @@ def begin_direct_grads():
     step_state().direct_written.clear()
 
 
+def _gout_acc(p):
+    """(destination, accumulate) for kernels that can ADD into the gradient buffer themselves (the dense layers): p.grad and
+    False for the parameter's first gradient of the iteration, p.grad and True for every further use (MONet's recurrent UNet
+    runs its weights K-1 times); (None, False) when direct writes are off."""
+    st = step_state()
+    if st.direct_param_grads and isinstance(p, torch.nn.Parameter) and p.grad is not None and p.grad.is_contiguous() \
+            and not st.async_wgrad:
+        first = id(p) not in st.direct_written
+        st.direct_written.add(id(p))
+        return p.grad, not first
+    return _gout(p), False
+
+
 def _gout(p, acc=False):
     """Destination for a parameter gradient: p.grad if direct writes are on and it is a usable buffer.  Only the
     FIRST gradient of a parameter in an iteration is written directly (it overwrites the zeroed bucket); a parameter
@@ -1054,16 +1067,21 @@ class LSTMCellFn(torch.autograd.Function):
         dgates = torch.empty(B, 4 * H, device=dev)
         dc_prev = torch.empty(B, H, device=dev)
         hip.lstm_step_bwd(g_h.contiguous(), None, w_hh, act, c, cp, _c(g_c), dgates, dc_prev)
-        o_wih, o_whh, o_bih, o_bhh = _gout(w_ih), _gout(w_hh), _gout(b_ih), _gout(b_hh)
+        # the cell's four parameters travel together; a cell used again in the iteration (LatentSBP's K-1 steps share one
+        # LSTM) ADDS its gradients inside the dense kernels instead of through autograd's accumulation launches
+        outs = [_gout_acc(p) for p in (w_ih, w_hh, b_ih, b_hh)]
+        acc = outs[0][1]
+        if any(o is None for o, _ in outs) or any(a != acc for _, a in outs):
+            outs, acc = [(None, False)] * 4, False
+        o_wih, o_whh, o_bih, o_bhh = (o for o, _ in outs)
         dinp, dw_ih, db = hip.linear_bwd(inp, w_ih, None, dgates, None, need_dx=ctx.needs_input_grad[0],
-                                         out_dw=o_wih, out_db=o_bih)
+                                         out_dw=o_wih, out_db=o_bih, out_db2=o_bhh, accumulate_dw=acc)
         if hp is not None:
-            dh_prev, dw_hh, _ = hip.linear_bwd(hp, w_hh, None, dgates, None, need_dx=True, need_db=False, out_dw=o_whh)
+            dh_prev, dw_hh, _ = hip.linear_bwd(hp, w_hh, None, dgates, None, need_dx=True, need_db=False, out_dw=o_whh,
+                                               accumulate_dw=acc)
         else:
             dh_prev = None
-            dw_hh = torch.zeros_like(w_hh) if o_whh is None else o_whh.zero_()
-        if o_bhh is not None:
-            o_bhh.copy_(db)
+            dw_hh = torch.zeros_like(w_hh) if o_whh is None else (o_whh if acc else o_whh.zero_())
         return (dinp, dh_prev, dc_prev if cp is not None else None, _ret(o_wih, dw_ih), _ret(o_whh, dw_hh),
                 _ret(o_bih, db), _ret(o_bhh, db))
 
@@ -1089,10 +1107,16 @@ class LinearFn(torch.autograd.Function):
         w, b = ctx.params
         g2 = g.contiguous().view(-1, w.shape[0])
         need_w = ctx.needs_input_grad[1]
-        ow = _gout(w) if need_w else None
-        ob = _gout(b) if (need_w and b is not None) else None
+        ow, acc_w = _gout_acc(w) if need_w else (None, False)
+        ob, acc_b = _gout_acc(b) if (need_w and b is not None) else (None, acc_w)
+        if acc_w != acc_b or (ow is None) != (ob is None and b is not None):
+            # (a weight and its bias always travel together; anything else goes the plain way)
+            ow = ob = None
+            acc_w = False
         dx, dw, db = hip.linear_bwd(x2, w.view(w.shape[0], -1), y, g2, ctx.act, need_dx=ctx.needs_input_grad[0],
-                                    need_dw=need_w, need_db=b is not None and need_w, out_dw=ow, out_db=ob)
+                                    need_dw=need_w, need_db=b is not None and need_w,
+                                    out_dw=ow.view(w.shape[0], -1) if ow is not None else None, out_db=ob,
+                                    accumulate_dw=acc_w)
         if dw is not None and ow is None:
             dw = dw.view(w.shape)
         return (dx.view(ctx.xshape) if dx is not None else None, _ret(ow, dw) if need_w else None,

@@ -869,10 +869,11 @@ def linear_fwd(x, w, b=None, act=None, out=None):
 
 
 def linear_bwd(x, w, y, g, act=None, need_dx=True, need_dw=True, need_db=True, out_dw=None, out_db=None,
-               out_db2=None, accumulate_dx=None):
+               out_db2=None, accumulate_dx=None, accumulate_dw=False):
     """Returns (dx, dw, db); out_dw / out_db: write the parameter gradients into these buffers (out_db2: a second copy
     of db).  x, and (y, g) with one common row stride, may be row-strided views.  accumulate_dx: a [M,K] (row-strided)
-    tensor that dx is ADDED to (returned as dx)."""
+    tensor that dx is ADDED to (returned as dx).  accumulate_dw: dw / db are ADDED to out_dw / out_db."""
+    assert not accumulate_dw or out_dw is not None
     M, K = x.shape
     N = w.shape[0]
     dev = x.device
@@ -887,7 +888,8 @@ def linear_bwd(x, w, y, g, act=None, need_dx=True, need_dw=True, need_db=True, o
     dw = (out_dw if out_dw is not None else torch.empty(N, K, dtype=F32, device=dev)) if need_dw else None
     db = (out_db if out_db is not None else torch.empty(N, dtype=F32, device=dev)) if (need_db and need_dw) else None
     _lib.call('gx_linear_bwd_ex', _p(x), ldx, _p(w), _p(y), _p(g), ldg, ACTS[act], _p(dx), lddx,
-              int(accumulate_dx is not None), _p(dw), _p(db), _p(out_db2 if db is not None else None), M, N, K, _stream())
+              int(accumulate_dx is not None) | (2 if accumulate_dw else 0), _p(dw), _p(db),
+              _p(out_db2 if db is not None else None), M, N, K, _stream())
     return dx, dw, db
 
 

@@ -450,7 +450,8 @@ int gx_linear_bwd(const float* x, const float* w, const float* y, const float* g
  *      layer straight into the first up-block's concat buffer, modules/unet.py:83-84, and reads that layer's
  *      gradient out of the concat buffer's gradient; the AR prior's LSTM input z[:-1] is the leading part of z):
  *      ldx / ldy / ldg / lddx = row strides in floats (>= the row length); y and g of the backward share ldg.
- *      dx_accumulate != 0: dx += dpre w (the second consumer of a tensor adds its gradient in place);
+ *      dx_accumulate: bit 0: dx += dpre w (the second consumer of a tensor adds its gradient in place); bit 1: dw / db / db2
+ *      += (a parameter used again in the same iteration: MONet's recurrent UNet);
  *      db2 (may be NULL): a second copy of db (nn.LSTM's b_ih and b_hh have the same gradient). */
 int gx_linear_fwd_ld(const float* x, int ldx, const float* w, const float* b, int act, float* y, int ldy, int M,
                      int N, int K, gx_stream_t stream);

@@ -593,6 +593,14 @@ def test_linear_strided_and_accumulating(M, N, K, act):
     assert torch.equal(dw1, dw0) and torch.equal(db1, db0) and torch.equal(db2, db0)
     assert torch.equal(acc[:, 4:4 + K], base[:, 4:4 + K] + dx0)
     assert torch.equal(acc[:, :4], base[:, :4]) and torch.equal(acc[:, 4 + K:], base[:, 4 + K:])
+    # dw / db / db2 added to what the destinations hold (a parameter used again in one iteration)
+    dwa, dba, db2a = torch.full((N, K), 0.5, device=DEV), torch.full((N,), -1.5, device=DEV), torch.full((N,), 2.0, device=DEV)
+    hip.linear_bwd(x, w, y0 if act else None, g, act, out_dw=dwa, out_db=dba, out_db2=db2a, accumulate_dw=True)
+    assert torch.equal(dwa, dw0 + 0.5) and torch.equal(dba, db0 - 1.5) and torch.equal(db2a, db0 + 2.0)
+    # (the launch without dx has its own workgroup size, i.e. its own summation order)
+    _, dw2, db2_ = hip.linear_bwd(x, w, y0 if act else None, g, act, need_dx=False)
+    hip.linear_bwd(x, w, y0 if act else None, g, act, need_dx=False, out_dw=dwa, out_db=dba, accumulate_dw=True)
+    assert torch.equal(dwa, (dw0 + 0.5) + dw2) and torch.equal(dba, (db0 - 1.5) + db2_)
     with pytest.raises(Exception):
         hip.linear_fwd(wide_x.t()[4:4 + K].t()[:, ::2], w[:, ::2].contiguous(), b, act)      # rows not contiguous
 
