@@ -315,8 +315,12 @@ class UNetEncoderFn(torch.autograd.Function):
         for q in reversed(range(3)):
             w_, b_ = mlp[2 * q], mlp[2 * q + 1]
             h_in, y_ = mlp_acts[q]
-            ow, ob = _gout(w_), _gout(b_)
-            g_h, dw, db = hip.linear_bwd(h_in, w_, y_, g_h, 'relu', out_dw=ow, out_db=ob)
+            # (a UNet used again in the iteration -- MONet's K-1 passes -- adds inside the dense kernel)
+            (ow, acc_w), (ob, acc_b) = _gout_acc(w_), _gout_acc(b_)
+            if ow is None or ob is None or acc_w != acc_b:
+                ow = ob = None
+                acc_w = False
+            g_h, dw, db = hip.linear_bwd(h_in, w_, y_, g_h, 'relu', out_dw=ow, out_db=ob, accumulate_dw=acc_w)
             g_mlp[2 * q], g_mlp[2 * q + 1] = _ret(ow, dw), _ret(ob, db)
         d_mlp_in = g_h.view(mlp_in_shape)
         d_next = None
