@@ -1977,7 +1977,10 @@ static int conv3x3_fwd_impl(const float* x, const float* w, const float* bias, i
     static const char* kq_env = getenv("GENESIS_KQ");
     const bool kq_first = kq_env && kq_env[0] == '2';        // benchmarking: the k-quad kernel ahead of Winograd
     const bool wino_ok = !bias && act == 0 && gx_wino_eligible(N, Cin, Cout, H, W);
-    if (!wino_ok && gx_kq_c3h_eligible(N, Cin, Cout, H, W)) {   // <= 32 output channels, bf16 pipe (six piece products)
+    // <= 32 output channels: the bf16-pipe kernel with 32-channel workgroups, ahead of Winograd (whose 64-channel tile would be
+    // half empty: MONet's UNet 64 -> 32 layer 51 -> 38 us); GENESIS_KQ_C3H_FIRST=0: only where Winograd does not apply
+    static const char* c3h_first = getenv("GENESIS_KQ_C3H_FIRST");
+    if ((!wino_ok || !(c3h_first && c3h_first[0] == '0')) && gx_kq_c3h_eligible(N, Cin, Cout, H, W)) {
         rc = launch_pack(w, wp, 20, Cout, Cin, 9, gx_round_up(Cin, 16), Mpad, s, &wpu);
         if (rc) return rc;
         rc = gx_kq_c3h_launch(x, wpu, bias, act, y, N, Cin, Cout, H, W, s);
@@ -2031,7 +2034,8 @@ int gx_conv3x3_dgrad(const float* dy, const float* w, float* dx, int N, int Cin,
     static const char* kq_env = getenv("GENESIS_KQ");
     const bool kq_first = kq_env && kq_env[0] == '2';
     const bool wino_ok = gx_wino_eligible(N, Cout, Cin, H, W);
-    if (!wino_ok && gx_kq_c3h_eligible(N, Cout, Cin, H, W)) {
+    static const char* c3h_first = getenv("GENESIS_KQ_C3H_FIRST");
+    if ((!wino_ok || !(c3h_first && c3h_first[0] == '0')) && gx_kq_c3h_eligible(N, Cout, Cin, H, W)) {
         rc = launch_pack(w, wp, 21, Cout, Cin, 9, gx_round_up(Cout, 16), Mpad, s, &wpu);
         if (rc) return rc;
         return gx_kq_c3h_launch(dy, wpu, nullptr, 0, dx, N, Cout, Cin, H, W, s);

@@ -364,6 +364,9 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
         GX_QH_LOAD_W(0, 0)
         GX_QH_STORE_IN()
         GX_QH_STORE_W(wbufb)
+        // Q_C3H: the next chunk's input loads are issued at the chunk's FIRST phase (the registers are free: 32 accumulators) --
+        // with two chunks per tile a load issued at the last phase has one phase of MFMAs to hide under
+        constexpr bool EARLY_IN = MODE == Q_C3H;
         int s = 0;
         for (int sc = 0; sc < nsc; ++sc) {
             const bool last_chunk = sc + 1 == nsc;
@@ -375,7 +378,8 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
                 const bool in_next = C::newin(PH_) && more;      /* the next phase reads another input tile */   \
                 __syncthreads();                                                                                 \
                 if (more) GX_QH_LOAD_W(last_ph ? sc + 1 : sc, NXT)                                               \
-                if (in_next) GX_QH_LOAD_IN(last_ph ? sc + 1 : sc, C::plane(NXT))                                 \
+                if (EARLY_IN) { if ((PH_) == 0 && !last_chunk) GX_QH_LOAD_IN(sc + 1, 0) }                        \
+                else if (in_next) GX_QH_LOAD_IN(last_ph ? sc + 1 : sc, C::plane(NXT))                            \
                 q_phase_h<MODE, (PH_), NCLS, MI>(acc, ibuf, wbufb + (s & 1) * WSLOTB, plane_bytes, a_lane_b,     \
                                                  b_lane_b[0], b_lane_b[1], HS16);                                \
                 if (more) GX_QH_STORE_W(wbufb + ((s + 1) & 1) * WSLOTB)                                          \
