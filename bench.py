@@ -110,7 +110,9 @@ def pmc_traffic(kernel, tag=''):
 # profiling ids (gx_profile_kernel_name) -> kernel symbols of the rocprofv3 CSV that are launched under that id
 KID_SYMBOLS = {
     'wgq_stream_kernel': ('wgq_stream_kernel',), 'kq_dth_kernel': ('kq_dth_kernel',), 'kq_dgh_kernel': ('kq_dgh_kernel',), 'kq_c3h_kernel': ('kq_c3h_kernel',),
-    'wgrad_kernel<0>': ('wgq_stream_kernel', 'wgq_kernel<0,', 'wgrad_fast_kernel<0,', 'wgrad_kernel<0>', 'wgrad_smallcin_kernel'),
+    'wgrad_kernel<0>': ('wgq_kernel<0,', 'wgrad_fast_kernel<0,', 'wgrad_kernel<0>', 'wgrad_smallcin_kernel'),
+    'dconv_kernels': ('tapconv_kernel<4,', 'igemm_kernel<', 'conv3x3s2_dgrad_small_kernel', 'conv3x3s2_wgrad_small_kernel'),
+    'gated_norm_kernels': ('gated_',),
     'wgrad_kernel<1>': ('wgq_kernel<1,', 'wgrad_fast_kernel<1,', 'wgrad_kernel<1>', 'wgrad_deconv_kernel'),
     'wgrad_kernel<3>': ('wgq_kernel<2,', 'wgrad_fast_kernel<3,', 'wgrad_kernel<3>'),
     'tapconv_kernel<0>': ('tapconv_kernel<0,', 'kq_kernel<0,'),
@@ -328,36 +330,51 @@ def main():
                           'avg_us': 1e3 * r['ms'] / r['launches'], 'share': r['ms'] / total_ms,
                           'tflops': r['flops'] / sec / 1e12 if r['flops'] else None,
                           'gbs': r['bytes'] / sec / 1e9})
-        dom = rows[0]
-        sec = dom['ms'] * 1e-3
-        if dom['flops'] > 0:
-            ach = dom['flops'] / sec / 1e12
-            mfma_peak = PEAK_FP32_MFMA_TFLOPS
-            roof = {'bound': 'mfma', 'kernel': dom['name'], 'achieved': ach, 'peak': mfma_peak, 'unit': 'TFLOP/s'}
-            on_bf16 = (dom['name'] == 'wgq_stream_kernel' and os.environ.get('GENESIS_WGQ_BF16X6', '1') != '0') or \
-                      (dom['name'] in ('kq_dth_kernel', 'kq_dgh_kernel', 'kq_c3h_kernel') and os.environ.get('GENESIS_KQ_BF16X6', '1') != '0')
-            if on_bf16:
-                # `achieved` counts the algorithmic fp32 flops; the kernel executes six bf16 MFMA products for each of them,
-                # so its ceiling is the bf16 pipe's dense peak / 6 -- a higher one than the fp32 pipe's 157.3 TF/s
-                mfma_peak = PEAK_BF16_MFMA_TFLOPS / BF16X6_TERMS
-                roof['peak'] = mfma_peak
-                roof['pipe'] = ('bf16 MFMA, fp32 products as %d bf16 piece products (fp32 accumulate): peak = %.0f / %d; '
-                                'against the fp32 pipe (%.1f TF/s) the same rate is frac_of_fp32_pipe'
-                                % (BF16X6_TERMS, PEAK_BF16_MFMA_TFLOPS, BF16X6_TERMS, PEAK_FP32_MFMA_TFLOPS))
-                roof['achieved_on_bf16_pipe'] = ach * BF16X6_TERMS
+        def roof_of(dom):
+            """Roofline entry of one profiled kernel family: ALGORITHMIC flops (or bytes) per second of its own launches
+            against the peak of the pipe it runs on."""
+            sec = dom['ms'] * 1e-3
+            if dom['flops'] > 0:
+                ach = dom['flops'] / sec / 1e12
+                mfma_peak = PEAK_FP32_MFMA_TFLOPS
+                roof = {'bound': 'mfma', 'kernel': dom['name'], 'achieved': ach, 'peak': mfma_peak, 'unit': 'TFLOP/s'}
+                on_bf16 = (dom['name'] == 'wgq_stream_kernel' and os.environ.get('GENESIS_WGQ_BF16X6', '1') != '0') or \
+                          (dom['name'] in ('kq_dth_kernel', 'kq_dgh_kernel', 'kq_c3h_kernel') and os.environ.get('GENESIS_KQ_BF16X6', '1') != '0')
+                if on_bf16:
+                    # `achieved` counts the algorithmic fp32 flops; the kernel executes six bf16 MFMA products for each of
+                    # them, so its ceiling is the bf16 pipe's dense peak / 6 -- a higher one than the fp32 pipe's 157.3 TF/s
+                    mfma_peak = PEAK_BF16_MFMA_TFLOPS / BF16X6_TERMS
+                    roof['peak'] = mfma_peak
+                    roof['pipe'] = ('bf16 MFMA, fp32 products as %d bf16 piece products (fp32 accumulate): peak = %.0f / %d; '
+                                    'against the fp32 pipe (%.1f TF/s) the same rate is frac_of_fp32_pipe'
+                                    % (BF16X6_TERMS, PEAK_BF16_MFMA_TFLOPS, BF16X6_TERMS, PEAK_FP32_MFMA_TFLOPS))
+                    roof['achieved_on_bf16_pipe'] = ach * BF16X6_TERMS
+                if dom['name'] == 'wino_conv_kernel':
+                    # `achieved` is ALGORITHMIC (direct-sum) flops / time, as for every kernel; the Winograd kernel executes
+                    # 16 multiplies where the direct sum has 36: the ceiling of the ALGORITHM on the fp32 pipe is 2.25 x the
+                    # pipe's peak, and its rate on the pipe itself is achieved / 2.25
+                    mfma_peak = 2.25 * PEAK_FP32_MFMA_TFLOPS
+                    roof['peak'] = mfma_peak
+                    roof['algorithm'] = ('Winograd F(2x2,3x3): 1/2.25 of the algorithmic flops are executed on the fp32 MFMA '
+                                         'pipe; peak = 2.25 x %.1f' % PEAK_FP32_MFMA_TFLOPS)
+                    roof['achieved_on_mfma_pipe'] = ach / 2.25
+                roof['frac'] = ach / mfma_peak
                 roof['frac_of_fp32_pipe'] = ach / PEAK_FP32_MFMA_TFLOPS
-            roof['frac'] = ach / mfma_peak
-        else:
-            ach = dom['bytes'] / sec / 1e9
-            roof = {'bound': 'hbm', 'kernel': dom['name'], 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                    'frac': ach / PEAK_HBM_GBS}
-        if dom['name'] == 'wino_conv_kernel':
-            # `achieved` is ALGORITHMIC (direct-sum) flops / time, as for every kernel; the Winograd kernel executes
-            # 16 multiplies where the direct sum has 36, so its rate on the matrix pipe itself is achieved / 2.25
-            roof['algorithm'] = 'Winograd F(2x2,3x3): 1/2.25 of the algorithmic flops are executed on the MFMA pipe'
-            roof['achieved_on_mfma_pipe'] = ach / 2.25
-            roof['frac_on_mfma_pipe'] = ach / 2.25 / PEAK_FP32_MFMA_TFLOPS
-        roof['frac_of_fp32_pipe'] = ach / PEAK_FP32_MFMA_TFLOPS if dom['flops'] > 0 else None
+            else:
+                ach = dom['bytes'] / sec / 1e9
+                roof = {'bound': 'hbm', 'kernel': dom['name'], 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                        'frac': ach / PEAK_HBM_GBS, 'frac_of_fp32_pipe': None}
+            roof['avg_launch_us'] = 1e3 * dom['ms'] / dom['launches']
+            roof['share_of_kernel_time'] = dom['ms'] / total_ms
+            return roof
+
+        dom = rows[0]
+        roof = roof_of(dom)
+        ach = roof['achieved']
+        # the other large kernels of the step, same arithmetic (the dominant one changes from run to run when two are close)
+        roof_top = [{k_: v_ for k_, v_ in roof_of(r_).items() if k_ in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac',
+                                                                            'avg_launch_us', 'share_of_kernel_time')}
+                    for r_ in rows[:6]]
         # numbers that are NOT of this run: read from the committed rocprofv3 / PMC passes of the same command
         # (only for the workload they were taken on: the default shape of each model family, no forced collective)
         default_shape = args.K == 7 and args.img == 64 and args.batch == 32 and args.feat_dim == 64 and world == 1 and \
@@ -383,6 +400,7 @@ def main():
                      'timing': 'HIP events around every launch, EAGER steps of this process (the timed region above '
                                'replays one HIP graph: its ms_per_step is shorter than the eager kernel sum)'})
         result['roofline'] = roof
+        result['roofline_top'] = roof_top
         result['kernels'] = table[:12]
 
     # ---- PCIe-inclusive leg: every batch starts as uint8 HWC frames in host memory (what a dataset yields) and
