@@ -32,6 +32,11 @@
 #ifndef GX_KQ_VAR
 #define GX_KQ_VAR 0
 #endif
+// bf16-pipe path (measurement builds, wrong results): 1 = no output stores, 2 = no input split / LDS store after a tile's first
+// chunk, 4 = no MFMAs, 8 = no input loads after the first chunk
+#ifndef GX_QH_ABL
+#define GX_QH_ABL 0
+#endif
 
 namespace {
 
@@ -162,12 +167,16 @@ __device__ __forceinline__ void q_phase_h(f32x16 (&acc)[NCLS][MI][2], const char
 #pragma unroll
             for (int nj = 0; nj < 2; ++nj) {
                 f32x16 c = acc[cl][mi][nj];      // pieces: 0 hi, 1 mid, 2 lo; small terms first
+#if GX_QH_ABL & 4
+                c[0] += (float)a[mi][0][0] * (float)b[nj][0][0] + (float)a[mi][1][1] * (float)b[nj][1][1] + (float)a[mi][2][2] * (float)b[nj][2][2];
+#else
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[nj][1], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][2], b[nj][0], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[nj][2], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[nj][0], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[nj][1], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[nj][0], c, 0, 0, 0);
+#endif
                 acc[cl][mi][nj] = c;
             }
     }
@@ -179,6 +188,7 @@ struct QGeom {
     int Hb, Wb;           // base (pixel-tile) grid
     int Hi, Wi, Ho, Wo;   // input / output tensor dims
     int lTH, lTW, lG, tiles_h, tiles_w;
+    int rt_th, rt_tw;     // Q_C3H on a grid that is not a power of two: the tile is rt_th whole rows of rt_tw = Wb pixels (0: 2^l tiles)
     int act;              // epilogue activation after the bias: 0 none, 1 ReLU, 2 ELU
     int nfull;            // blockIdx.x < nfull: whole tiles; the rest: pairs of half-work workgroups (q_split_tail)
     float* stats;         // STATS: per-workgroup (sum, sum of squares) of every 8-channel block, [N][parts][M/8][2]
@@ -251,7 +261,11 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
     constexpr int ISLOT = NQ * 1024;                   //   staging stores are unconditional); same for an input buffer
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int TH = 1 << g.lTH, TW = 1 << g.lTW, G = 1 << g.lG;
+    // row tiles (Q_C3H, grid not a power of two): rt_th whole image rows per workgroup -- every load / store instruction
+    // covers 128 contiguous bytes of a channel plane (8 x 8-pixel tiles on the 72 x 72 canvas: four 32-byte segments);
+    // pixel slots >= rt_th * rt_tw of the 256 are idle
+    const bool RT = MODE == Q_C3H && g.rt_tw > 0;
+    const int TH = RT ? g.rt_th : 1 << g.lTH, TW = RT ? g.rt_tw : 1 << g.lTW, G = RT ? 1 : 1 << g.lG;
     const int HS = TW + 2;
     const int CHS = G * (TH + 2) * HS;                 // halo positions per plane
     float* const ibuf0 = lds;
@@ -316,9 +330,10 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
 #pragma unroll
         for (int nj = 0; nj < 2; ++nj) {
             const int p = wave * 64 + nj * 32 + (lane & 31);
-            const int c = p & (TW - 1);
-            const int r = (p >> g.lTW) & (TH - 1);
-            const int gi = p >> (g.lTW + g.lTH);
+            int c = p & (TW - 1);
+            int r = (p >> g.lTW) & (TH - 1);
+            int gi = p >> (g.lTW + g.lTH);
+            if (RT) { gi = 0; r = p / TW; c = p - r * TW; if (r >= TH) { r = 0; c = 0; } }      // (idle slots read position 0)
             b_lane_b[nj] = (quad_l * CHS + (gi * (TH + 2) + r) * HS + c) * 16;
         }
         const int HS16 = HS * 16;
@@ -367,6 +382,10 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
         // Q_C3H: the next chunk's input loads are issued at the chunk's FIRST phase (the registers are free: 32 accumulators) --
         // with two chunks per tile a load issued at the last phase has one phase of MFMAs to hide under
         constexpr bool EARLY_IN = MODE == Q_C3H;
+        // Q_C3H: ONE weight buffer (a second barrier per phase instead): 36 + 12 KB of LDS = three workgroups per CU -- a tile
+        // is short (two chunks), its loads, bf16 split, MFMAs and stores barely overlap inside one workgroup, so the third
+        // workgroup is what fills the gaps
+        constexpr bool ONE_W = MODE == Q_C3H;
         int s = 0;
         for (int sc = 0; sc < nsc; ++sc) {
             const bool last_chunk = sc + 1 == nsc;
@@ -378,14 +397,19 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
                 const bool in_next = C::newin(PH_) && more;      /* the next phase reads another input tile */   \
                 __syncthreads();                                                                                 \
                 if (more) GX_QH_LOAD_W(last_ph ? sc + 1 : sc, NXT)                                               \
-                if (EARLY_IN) { if ((PH_) == 0 && !last_chunk) GX_QH_LOAD_IN(sc + 1, 0) }                        \
+                if (EARLY_IN) { if ((PH_) == 0 && !last_chunk && !(GX_QH_ABL & 8)) GX_QH_LOAD_IN(sc + 1, 0) }    \
                 else if (in_next) GX_QH_LOAD_IN(last_ph ? sc + 1 : sc, C::plane(NXT))                            \
-                q_phase_h<MODE, (PH_), NCLS, MI>(acc, ibuf, wbufb + (s & 1) * WSLOTB, plane_bytes, a_lane_b,     \
-                                                 b_lane_b[0], b_lane_b[1], HS16);                                \
+                q_phase_h<MODE, (PH_), NCLS, MI>(acc, ibuf, wbufb + (ONE_W ? 0 : (s & 1)) * WSLOTB, plane_bytes, \
+                                                 a_lane_b, b_lane_b[0], b_lane_b[1], HS16);                      \
+                if (ONE_W) {                      /* one weight buffer: everyone is done with it (and the tile) */ \
+                    if (more) { __syncthreads(); GX_QH_STORE_W(wbufb) }                                          \
+                    if (in_next && !(GX_QH_ABL & 2)) GX_QH_STORE_IN()                                            \
+                } else {                                                                                         \
                 if (more) GX_QH_STORE_W(wbufb + ((s + 1) & 1) * WSLOTB)                                          \
                 if (in_next) {                    /* the input tile is single-buffered: everyone is done with it */ \
                     __syncthreads();                                                                             \
-                    GX_QH_STORE_IN()                                                                             \
+                    if (!(GX_QH_ABL & 2)) GX_QH_STORE_IN()                                                       \
+                }                                                                                                \
                 }                                                                                                \
                 ++s;                                                                                             \
             }
@@ -522,8 +546,32 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
     }
     // interior tiles with all 32 (MI) channels of every accumulator row present (the common case: power-of-two grids,
     // M a multiple of 64) store without per-element guards -- the guarded loop costs ~1400 VALU + 48 branches per wave
-    const bool full_tile = img0 + G <= g.N && R0 + TH <= g.Hb && C0 + TW <= g.Wb && m0 + (MI + mh) * 32 <= g.M;
-    if (full_tile) {
+    const bool full_tile = !RT && img0 + G <= g.N && R0 + TH <= g.Hb && C0 + TW <= g.Wb && m0 + (MI + mh) * 32 <= g.M;
+#if GX_QH_ABL & 1
+    if (B16 && acc[0][0][0][0] != 12345.678f) return;
+#endif
+    if (RT) {
+        // row tiles: pixel slot p = row r, column c of the tile's rt_th rows; consecutive lanes = consecutive floats of a plane
+        if constexpr (NCLS == 1) {
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj) {
+                const int p = wave * 64 + nj * 32 + (lane & 31);
+                const int r = p / TW, c = p - r * TW;
+                if (r < TH && R0 + r < g.Hb) {
+                    float* obase = out + (size_t)img0 * out_img_stride + (size_t)(R0 + r) * g.Wo + c +
+                                   (size_t)(m0 + mh * 32 + 4 * (lane >> 5)) * HoWo;
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            const int mrow = mi * 32 + (reg & 3) + 8 * (reg >> 2);
+                            if (m0 + mh * 32 + 4 * (lane >> 5) + mrow < g.M)
+                                obase[(size_t)mrow * HoWo] = q_act(acc[0][mi][nj][reg] + bvec[mi][reg >> 2][reg & 3], act);
+                        }
+                }
+            }
+        }
+    } else if (full_tile) {
 #pragma unroll
         for (int nj = 0; nj < 2; ++nj) {
             const int p = wave * 64 + nj * 32 + (lane & 31);
@@ -683,11 +731,17 @@ kq_dgh_kernel(const float* __restrict__ in, const float* __restrict__ wp, float*
 
 // conv3x3 on the bf16 pipe, 32 output channels per workgroup (blockIdx.y)
 template <int NQ>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, 3)
 kq_c3h_kernel(const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
               float* __restrict__ out, QGeom g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    q_body<Q_C3H, NQ, false, 1>(in, wp, bias, out, g, lds, blockIdx.x, blockIdx.y, 0, 0);
+    // persistent workgroups (the grid is ~2 per CU): a tile's output stores drain while the next tile's loads are already in
+    // flight -- a workgroup that ends after every tile waits for its stores before its LDS / registers are handed on, and with
+    // two 16-channel chunks per tile that tail is a large part of a tile's life
+    for (int tile = blockIdx.x; tile < g.nfull; tile += gridDim.x) {
+        q_body<Q_C3H, NQ, false, 1>(in, wp, bias, out, g, lds, tile, blockIdx.y, 0, 0);
+        __syncthreads();          // the next tile's staging overwrites LDS the slowest wave may still be reading
+    }
 }
 
 // the same launch shape on the bf16 matrix pipe (Q_DT0H / Q_DT1H)
@@ -720,7 +774,7 @@ bool q_plan(int N, int K, int M, int Hb, int Wb, int Hi, int Wi, int Ho, int Wo,
     g->Hb = Hb; g->Wb = Wb; g->Hi = Hi; g->Wi = Wi; g->Ho = Ho; g->Wo = Wo;
     g->lTH = q_ilog2(TH); g->lTW = q_ilog2(TW); g->lG = q_ilog2(G);
     g->tiles_h = Hb / TH; g->tiles_w = Wb / TW;
-    g->act = 0; g->stats = nullptr; g->stats_parts = 0;
+    g->act = 0; g->stats = nullptr; g->stats_parts = 0; g->rt_th = g->rt_tw = 0;
     const int CHS = G * (TH + 2) * (TW + 2);
     if (2 * CHS > 4 * 256) return false;
     *nq = 2 * CHS <= 3 * 256 ? 3 : 4;
@@ -877,17 +931,24 @@ static bool q_plan_c3h(int N, int K, int M, int H, int W, QGeom* g, int* nq, siz
     if (K % 16 != 0 || H * W > 65536 || (double)N * K * H * W * 4.0 >= 2.0e9) return false;
     int TW = 1; while (TW < 64 && W % (2 * TW) == 0) TW *= 2;
     int TH = 1; while (TH * TW < 256 && H % (2 * TH) == 0) TH *= 2;
-    const int G = 256 / (TW * TH);
+    int G = 256 / (TW * TH);
+    g->rt_th = g->rt_tw = 0;
+    static const char* rt_env = getenv("GENESIS_KQ_C3H_ROWTILES");
+    if (!(rt_env && rt_env[0] == '0') && TW < W && TW < 32 && W <= 128 && 256 / W >= 2) {
+        // a width without a large power-of-two factor (the 72 x 72 canvas: 8): tiles of whole rows instead
+        g->rt_tw = W; g->rt_th = 256 / W;
+        TW = W; TH = g->rt_th; G = 1;
+    }
     g->N = N; g->K = K; g->M = M; g->nchunks = K / 8;
     g->Hb = H; g->Wb = W; g->Hi = H; g->Wi = W; g->Ho = H; g->Wo = W;
     g->lTH = q_ilog2(TH); g->lTW = q_ilog2(TW); g->lG = q_ilog2(G);
-    g->tiles_h = H / TH; g->tiles_w = W / TW;
+    g->tiles_h = gx_ceil_div(H, TH); g->tiles_w = W / TW;
     g->act = 0; g->stats = nullptr; g->stats_parts = 0; g->nfull = 0;
     const int CHS = G * (TH + 2) * (TW + 2);
     if (2 * CHS > 4 * 256) return false;
     *nq = 2 * CHS <= 3 * 256 ? 3 : 4;
     constexpr int NWH = (3 * (QHLay<Q_C3H>::TAPB / 16) + 255) / 256;
-    *lds_bytes = (size_t)3 * *nq * 256 * 16 + (size_t)2 * NWH * 256 * 16;      // three input piece planes + two weight buffers
+    *lds_bytes = (size_t)3 * *nq * 256 * 16 + (size_t)NWH * 256 * 16;          // three input piece planes + one weight buffer
     return true;
 }
 bool gx_kq_c3h_eligible(int N, int K, int M, int H, int W) {
@@ -902,8 +963,11 @@ int gx_kq_c3h_launch(const float* in, const float* wp, const float* bias, int ac
     QGeom g; int nq; size_t lds;
     if (!q_plan_c3h(N, K, M, H, W, &g, &nq, &lds)) { gx_set_error("kq conv3x3 (bf16 pipe): shape not eligible"); return GX_EINVAL; }
     g.act = act;
-    const dim3 grid(g.tiles_h * g.tiles_w * gx_ceil_div(N, 1 << g.lG), gx_ceil_div(M, 32));
-    g.nfull = (int)grid.x;
+    dim3 grid(g.tiles_h * g.tiles_w * gx_ceil_div(N, 1 << g.lG), gx_ceil_div(M, 32));
+    g.nfull = (int)grid.x;                               // tiles; the workgroups loop over them (kq_c3h_kernel)
+    static const char* pers_env = getenv("GENESIS_KQ_C3H_PERSIST");
+    const int per_cu = pers_env ? atoi(pers_env) : 3;
+    if (per_cu > 0 && (int)grid.x > 256 * per_cu / (int)grid.y) grid.x = 256 * per_cu / grid.y;
     {
         GxProf pf(KID_KQ_C3H, s, 2.0 * N * (double)M * K * 9 * H * W,
                   4.0 * ((double)N * K * H * W + (double)N * M * H * W + 9.0 * K * M));
