@@ -602,23 +602,35 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 // D[i = A-channel][j = B-channel] per tap, K = pixels.
 //   A source: dy sampled at (SA*row + pa, SA*col + pb)  (SA=1 conv3x3; SA=2 deconv class (pa,pb))
 //   B source: x with a 1-pixel halo on the base grid.
-enum { W_C3 = 0, W_D00 = 1, W_D01 = 2, W_D10 = 3, W_D11 = 4 };
+enum { W_C3 = 0, W_D00 = 1, W_D01 = 2, W_D10 = 3, W_D11 = 4, W_C5A = 5, W_C5B = 6, W_C5C = 7 };
 template <int WM> struct WTap;
 template <> struct WTap<W_C3> {
-    static constexpr int NT = 9, SA = 1, PA = 0, PB = 0;
+    static constexpr int NT = 9, SA = 1, PA = 0, PB = 0, HALO = 1;
     __host__ __device__ static constexpr int ro(int t) { return t / 3; }
     __host__ __device__ static constexpr int co(int t) { return t % 3; }
     __host__ __device__ static constexpr int gt(int t) { return t; }
 };
 template <int PA_, int PB_> struct WTapD {
     static constexpr int NKH = PA_ ? 2 : 3, NKW = PB_ ? 2 : 3;
-    static constexpr int NT = NKH * NKW, SA = 2, PA = PA_, PB = PB_;
+    static constexpr int NT = NKH * NKW, SA = 2, PA = PA_, PB = PB_, HALO = 1;
     __host__ __device__ static constexpr int kh(int t) { return 2 * (t / NKW) + PA_; }
     __host__ __device__ static constexpr int kw(int t) { return 2 * (t % NKW) + PB_; }
     __host__ __device__ static constexpr int ro(int t) { return 2 - kh(t) / 2; }
     __host__ __device__ static constexpr int co(int t) { return 2 - kw(t) / 2; }
     __host__ __device__ static constexpr int gt(int t) { return kh(t) * 5 + kw(t); }
 };
+// 5 x 5 stride-1 pad-2 conv (the gated stacks' layers whose rows are shorter than the row-ring tiles' 32 pixels): kernel rows
+// 0-1, 2-3 (10 taps each) and 4 (5 taps) as three launches into one slab region -- 15 accumulator tiles (240 registers) next
+// to the kernel's per-lane offset tables spill 1 KB per lane; 2-pixel halo
+template <int PART> struct WTapC5 {
+    static constexpr int NT = PART == 2 ? 5 : 10, SA = 1, PA = 0, PB = 0, HALO = 2;
+    __host__ __device__ static constexpr int ro(int t) { return t / 5 + 2 * PART; }
+    __host__ __device__ static constexpr int co(int t) { return t % 5; }
+    __host__ __device__ static constexpr int gt(int t) { return ro(t) * 5 + co(t); }
+};
+template <> struct WTap<W_C5A> : WTapC5<0> {};
+template <> struct WTap<W_C5B> : WTapC5<1> {};
+template <> struct WTap<W_C5C> : WTapC5<2> {};
 template <> struct WTap<W_D00> : WTapD<0, 0> {};
 template <> struct WTap<W_D01> : WTapD<0, 1> {};
 template <> struct WTap<W_D10> : WTapD<1, 0> {};
@@ -843,14 +855,14 @@ __global__ void __launch_bounds__(256, 1)
 wgrad_fast_kernel(const float* __restrict__ a_src, const float* __restrict__ b_src,
                   float* __restrict__ partial, const float* __restrict__ zeros, WgradGeom g) {
     using WT = WTap<WM>;
-    constexpr int NT = WT::NT;
-    constexpr int TW = 1 << LTW, HS = TW + 2;
+    constexpr int NT = WT::NT, HL = WT::HALO;
+    constexpr int TW = 1 << LTW, HS = TW + 2 * HL;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int TH = 1 << g.lTH, G = 1 << g.lG;
     const int PT = TH * TW * G;          // pixels per tile (32, 64 or 128)
     const int nb = PT >> 5;              // A batches per tile (1, 2 or 4)
-    const int CHS = G * (TH + 2) * HS;
+    const int CHS = G * (TH + 2 * HL) * HS;
     const int BS = CHS | 1;
     constexpr int BROWS = QUAD ? 128 : 64;
     const int BUF = BROWS * BS;
@@ -904,10 +916,10 @@ wgrad_fast_kernel(const float* __restrict__ a_src, const float* __restrict__ b_s
         GX_WF_ORIGIN(org_, pi0, pR0, pC0)                                                           \
         if (tid < CHS) {                                                                             \
             int rem = tid;                                                                           \
-            const int gi = rem / ((TH + 2) * HS); rem -= gi * (TH + 2) * HS;                         \
+            const int gi = rem / ((TH + 2 * HL) * HS); rem -= gi * (TH + 2 * HL) * HS;               \
             const int i = rem / HS;                                                                  \
             const int jj = rem - i * HS;                                                             \
-            const int row = pR0 - 1 + i, col = pC0 - 1 + jj;                                         \
+            const int row = pR0 - HL + i, col = pC0 - HL + jj;                                       \
             const bool inb = pi0 + gi < g.N && row >= 0 && row < g.Hb && col >= 0 && col < g.Wb;     \
             const float* lp = inb ? b_src + (size_t)(pi0 + gi) * b_img + (size_t)cb0 * HbWb + row * g.Wb + col \
                                   : zeros;                                                           \
@@ -966,7 +978,7 @@ wgrad_fast_kernel(const float* __restrict__ a_src, const float* __restrict__ b_s
         const int c = j0 & (TW - 1);                                                                 \
         const int r = (j0 >> LTW) & (TH - 1);                                                        \
         const int gi = j0 >> (LTW + g.lTH);                                                          \
-        const float* bp = buf + b_row + (gi * (TH + 2) + r) * HS + c;                                \
+        const float* bp = buf + b_row + (gi * (TH + 2 * HL) + r) * HS + c;                           \
         _Pragma("unroll") for (int rr = 0; rr < NRO; ++rr)                                           \
             _Pragma("unroll") for (int cc = 0; cc < NCO; ++cc)                                       \
                 dst_[rr][cc] = bp[(RO0 + rr) * HS + CO0 + cc];                                       \
@@ -1470,7 +1482,7 @@ struct WgradPlan {
 };
 
 int plan_wgrad(int N, int CA, int CB, int Hb, int Wb, int SA, int Ttot, int ncls_launches, WgradPlan* pl, int max_npix = 128,
-               int b_rows = 64) {
+               int b_rows = 64, int halo = 1) {
     WgradGeom& g = pl->g;
     g.N = N; g.CA = CA; g.CB = CB;
     g.CApad = gx_round_up(CA, 64); g.CBpad = gx_round_up(CB, 64);
@@ -1487,7 +1499,7 @@ int plan_wgrad(int N, int CA, int CB, int Hb, int Wb, int SA, int Ttot, int ncls
                 for (int th = 1; th * tw <= npix; th <<= 1) {
                     if (th > 1 && (th >> 1) >= Hb) break;
                     const int gg = npix / (th * tw);
-                    if (gg * (th + 2) * (tw + 2) > 256) continue;
+                    if (gg * (th + 2 * halo) * (tw + 2 * halo) > 256) continue;
                     const double eff = (double)Hb * Wb / ((double)gx_ceil_div(Wb, tw) * tw * gx_ceil_div(Hb, th) * th);
                     const bool better = eff > best_eff + 1e-9 ||
                                         (eff > best_eff - 1e-9 &&
@@ -1534,7 +1546,7 @@ int plan_wgrad(int N, int CA, int CB, int Hb, int Wb, int SA, int Ttot, int ncls
         g.nsplit = mx;
         nsplit = mx;
     }
-    const int CHS = G * (TH + 2) * (TW + 2);
+    const int CHS = G * (TH + 2 * halo) * (TW + 2 * halo);
     pl->lds_bytes = (size_t)2 * b_rows * (CHS | 1) * sizeof(float);   // double-buffered B (x halo) tile
     pl->ws_floats = (size_t)nsplit * Ttot * g.CApad * g.CBpad;
     return GX_OK;
@@ -1772,6 +1784,43 @@ int launch_wgrad_reduce(const float* partial, float* dw, const WgradPlan& pl, in
     }
     GX_CHECK_LAUNCH("wgrad_reduce");
     return GX_OK;
+}
+
+bool c5_fast_plan(int N, int CA, int CB, int H, int W, WgradPlan* pl) {
+    const char* env = getenv("GENESIS_C5_FAST");       // 0: such layers stay on the generic implicit-GEMM kernel; 2: every size
+    if (env && env[0] == '0') return false;
+    // three launches + 25-tap slabs: pays from ~8 GFLOP on (measured on one box: the N = 224 decoder layer of GENESIS 514 ->
+    // ~330 us, step + 1.5 %; the N = 32 layer of BaselineVAE three launches of ~20 us against one of 45, step - 2.4 %)
+    if (!(env && env[0] == '2') && 50.0 * N * H * W * (double)CA * CB < 8.0e9) return false;
+    if (N <= 0 || CA <= 0 || CB <= 0 || H < 4 || W < 4 || (W & 3) || H >= 1024 || W >= 1024 || H * W > 65536) return false;
+    if (plan_wgrad(N, CA, CB, H, W, 1, 25, 1, pl, 128, 64, 2) != GX_OK) return false;
+    const WgradGeom& g = pl->g;
+    return g.lTW >= 2 && g.lTW <= 5 && pl->lds_bytes <= 160 * 1024 && (double)(1 << g.lG) * CA * H * W < 2.0e9 &&
+           (double)(1 << g.lG) * CB * H * W < 2.0e9 && !getenv("GENESIS_WGRAD_LEGACY");
+}
+template <int WM, int LTW>
+void launch_c5_fast(dim3 grid, size_t lds, hipStream_t s, const float* a, const float* b, float* partial, const float* zeros,
+                           const WgradGeom& g) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_fast_kernel<WM, LTW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL((wgrad_fast_kernel<WM, LTW>), grid, dim3(256), lds, s, a, b, partial, zeros, g);
+}
+template <int WM>
+void launch_c5_cls(const WgradPlan& pl, hipStream_t s, const float* a, const float* b, float* partial, const float* zeros) {
+    const dim3 grid(pl.g.nsplit, (pl.g.CApad / 64) * (pl.g.CBpad / 64));
+    const WgradGeom& g = pl.g;
+    GxProf pf(KID_DCONV, s, 2.0 * g.N * (double)g.CA * g.CB * WTap<WM>::NT * g.Hb * g.Wb,
+              4.0 * ((double)g.N * (g.CA + g.CB) * g.Hb * g.Wb + (double)g.nsplit * WTap<WM>::NT * g.CApad * g.CBpad));
+    switch (g.lTW) {
+        case 2: launch_c5_fast<WM, 2>(grid, pl.lds_bytes, s, a, b, partial, zeros, g); break;
+        case 3: launch_c5_fast<WM, 3>(grid, pl.lds_bytes, s, a, b, partial, zeros, g); break;
+        case 4: launch_c5_fast<WM, 4>(grid, pl.lds_bytes, s, a, b, partial, zeros, g); break;
+        default: launch_c5_fast<WM, 5>(grid, pl.lds_bytes, s, a, b, partial, zeros, g); break;
+    }
 }
 
 int check_dims(const char* name, int N, int Cin, int Cout, int H, int W) {
@@ -2211,20 +2260,40 @@ int gx_conv5x5s1(const float* in, const float* w, float* out, int N, int K, int 
 /* 5 x 5 stride-1 pad-2 weight gradient on the row-ring tiles of the bf16 pipe (gx_wgq.hip): dw [CA][CB][5][5] =
  * sum_{n,p} a[n][CA][p] * b[n][CB][p + (kh - 2, kw - 2)]; Conv2d: a = dy, b = x (dw [Cout][Cin]); ConvTranspose2d stride 1:
  * a = x, b = dy (dw [Cin][Cout]). */
-int gx_conv5x5_wgrad_supported(int N, int CA, int CB, int H, int W) { return gx_wgq_c5_eligible(N, CA, CB, H, W) ? 1 : 0; }
+// ... and, where a layer's rows are shorter than the row-ring tiles' 32 pixels (the gated stacks' 16 x 16 layers), on the lean
+// fp32-pipe weight-gradient kernel with a 2-pixel halo: kernel rows 0-1, 2-3 and 4 as three launches into one slab region
+int gx_conv5x5_wgrad_supported(int N, int CA, int CB, int H, int W) {
+    WgradPlan pl;
+    return (gx_wgq_c5_eligible(N, CA, CB, H, W) || c5_fast_plan(N, CA, CB, H, W, &pl)) ? 1 : 0;
+}
 
 size_t gx_conv5x5_wgrad_ws_bytes(int N, int CA, int CB, int H, int W) {
-    (void)N; (void)H; (void)W;
-    return (size_t)gx_wgq_max_split(CA, CB) * 25 * gx_round_up(CA, 64) * gx_round_up(CB, 64) * sizeof(float);
+    size_t f = (size_t)gx_wgq_max_split(CA, CB) * 25 * gx_round_up(CA, 64) * gx_round_up(CB, 64);
+    WgradPlan pl;
+    if (!gx_wgq_c5_eligible(N, CA, CB, H, W) && c5_fast_plan(N, CA, CB, H, W, &pl)) f = pl.ws_floats > f ? pl.ws_floats : f;
+    return f * sizeof(float);
 }
 
 int gx_conv5x5_wgrad(const float* a, const float* b, float* dw, int N, int CA, int CB, int H, int W, void* ws,
                      size_t ws_bytes, gx_stream_t stream) {
     GX_CHECK_ARG(a && b && dw && ws, "gx_conv5x5_wgrad: null pointer");
-    GX_CHECK_ARG(gx_wgq_c5_eligible(N, CA, CB, H, W), "gx_conv5x5_wgrad: shape not supported (rows of 32 / 64 pixels, power-of-two "
-                                                       "height >= 4, bf16-pipe row-ring tiles on)");
-    const size_t slab = (size_t)25 * gx_round_up(CA, 64) * gx_round_up(CB, 64) * sizeof(float);
-    return gx_wgq_c5(a, b, dw, N, CA, CB, H, W, (float*)ws, (int)(ws_bytes / slab), (hipStream_t)stream);
+    GX_CHECK_ARG(ws_bytes >= gx_conv5x5_wgrad_ws_bytes(N, CA, CB, H, W), "gx_conv5x5_wgrad: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    if (gx_wgq_c5_eligible(N, CA, CB, H, W)) {
+        const size_t slab = (size_t)25 * gx_round_up(CA, 64) * gx_round_up(CB, 64) * sizeof(float);
+        return gx_wgq_c5(a, b, dw, N, CA, CB, H, W, (float*)ws, (int)(ws_bytes / slab), s);
+    }
+    WgradPlan pl;
+    GX_CHECK_ARG(c5_fast_plan(N, CA, CB, H, W, &pl), "gx_conv5x5_wgrad: shape not supported (W %% 4 == 0, H, W >= 4)");
+    const float* zeros = zero_page(s);
+    if (!zeros) { gx_set_error("gx_conv5x5_wgrad: no zero page (first call inside a stream capture)"); return GX_ELAUNCH; }
+    launch_c5_cls<W_C5A>(pl, s, a, b, (float*)ws, zeros);
+    GX_CHECK_LAUNCH("gx_conv5x5_wgrad(rows 0-1)");
+    launch_c5_cls<W_C5B>(pl, s, a, b, (float*)ws, zeros);
+    GX_CHECK_LAUNCH("gx_conv5x5_wgrad(rows 2-3)");
+    launch_c5_cls<W_C5C>(pl, s, a, b, (float*)ws, zeros);
+    GX_CHECK_LAUNCH("gx_conv5x5_wgrad(row 4)");
+    return launch_wgrad_reduce((const float*)ws, dw, pl, 0, s);
 }
 
 static size_t deconv_pack_floats(int Cin, int Cout) {

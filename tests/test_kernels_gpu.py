@@ -1,5 +1,7 @@
 """Per-kernel parity: every HIP entry point (called through the C ABI) against the plain PyTorch fp32
 CPU op it replaces, on seeded inputs, fp32 tolerances stated per test."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1133,12 +1135,22 @@ def test_row_ring_weight_gradients(kind, N, Cin, Cout, S):
     assert err[1] <= 1.5 * err[0] + 1e-7 and err[1] < 1e-4, err
 
 
-@pytest.mark.parametrize('N,CA,CB,S', [(3, 64, 32, 64), (7, 64, 64, 32), (1, 128, 64, 32), (5, 40, 24, 64), (33, 64, 32, 32)])
+@pytest.mark.parametrize('N,CA,CB,S', [(3, 64, 32, 64), (7, 64, 64, 32), (1, 128, 64, 32), (5, 40, 24, 64), (33, 64, 32, 32),
+                                        (40, 128, 64, 16), (9, 64, 128, 16), (5, 24, 40, 8), (3, 16, 16, 12), (2, 70, 33, 4)])
 def test_conv5x5_stride1_weight_gradient_on_the_row_ring_tiles(N, CA, CB, S):
     """gx_conv5x5_wgrad (the gated 5x5 stride-1 (de)convs of third_party/sylvester): dw[a][b][kh][kw] = sum a * shifted b
-    on the bf16-pipe row-ring tiles (kernel rows 0-2 and 3-4 as two jobs of one stream-K launch) against autograd in
+    on the bf16-pipe row-ring tiles (kernel rows 0-2 and 3-4 as two jobs of one stream-K launch) -- rows of < 32 pixels: on the
+    lean fp32-pipe kernel with a 2-pixel halo (kernel rows 0-1, 2-3, 4 as three launches) -- against autograd in
     fp64, in both roles: Conv2d (a = dy, b = x) and stride-1 ConvTranspose2d (a = x, b = dy); bit-identical twice."""
     from genesis_amd import hip_ops as hip
+    os.environ['GENESIS_C5_FAST'] = '2'           # every size, not only the layers it pays for
+    try:
+        _conv5x5_wgrad_case(hip, N, CA, CB, S)
+    finally:
+        del os.environ['GENESIS_C5_FAST']
+
+
+def _conv5x5_wgrad_case(hip, N, CA, CB, S):
     assert hip.conv5x5_wgrad_supported(N, CA, CB, S, S)
     a, b = rnd(N, CA, S, S, seed=1), rnd(N, CB, S, S, seed=2)
     # Conv2d: x = b [N, Cin = CB], dy = a [N, Cout = CA], weight [CA, CB, 5, 5]
