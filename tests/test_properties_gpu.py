@@ -199,6 +199,38 @@ def test_conv3x3_is_one_trilinear_form(N, Cin, Cout, S):
     assert float((lhs - rhs).abs().max()) < 2e-5 * float(rhs.abs().max())
 
 
+def test_broadcast_decoder_canvas_layer_at_full_size():
+    """The BroadcastDecoder's 32 -> 32 conv3x3 on the 72 x 72 canvas at K B = 224 (MONet / GENESIS, BASELINE configs 3 and 4):
+    the bf16-pipe conv (row tiles, persistent workgroups, three per CU), its data gradient and the four-images-per-tile weight
+    gradient are ONE trilinear form, and twenty launches of each give the same bits (a race between a tile's staging and the
+    slowest wave's reads, or between the quadrant slabs, would show here)."""
+    from genesis_amd import hip_ops as hip
+    N, C, S = 224, 32, 72
+    torch.manual_seed(5)
+    x = torch.randn(N, C, S, S, device=DEV)
+    w = torch.randn(C, C, 3, 3, device=DEV) * 0.06
+    dy = torch.randn(N, C, S, S, device=DEV)
+    assert hip.conv3x3_wgrad_quad_supported(N, C, S, S)
+    y, dx, dw = hip.conv3x3_fwd(x, w), hip.conv3x3_dgrad(dy, w), hip.conv3x3_wgrad_quad(x, dy)
+    a, b, c = _dot(y, dy), _dot(x, dx), _dot(w, dw)
+    scale = float(x.double().norm() * dy.double().norm() * w.double().norm()) / np.sqrt(x.numel())
+    assert abs(a - b) < 1e-4 * max(abs(a), 1e-3 * scale) + 1e-7 * scale, (a, b, c)
+    assert abs(a - c) < 1e-4 * max(abs(a), 1e-3 * scale) + 1e-7 * scale, (a, b, c)
+    # the same product through the other kernel families (fp32-pipe tap-conv kernel; generic weight gradient)
+    from genesis_amd import _lib
+    _lib.call('gx_kq_precision', 0)
+    try:
+        y0 = hip.conv3x3_fwd(x, w)
+    finally:
+        _lib.call('gx_kq_precision', 1)
+    assert float((y - y0).abs().max()) < 2e-5 * float(y0.abs().max())
+    dw0 = hip.conv3x3_wgrad(x, dy)
+    assert float((dw - dw0).abs().max()) < 2e-5 * float(dw0.abs().max())
+    for _ in range(20):
+        assert torch.equal(hip.conv3x3_fwd(x, w), y) and torch.equal(hip.conv3x3_dgrad(dy, w), dx)
+        assert torch.equal(hip.conv3x3_wgrad_quad(x, dy), dw)
+
+
 @pytest.mark.parametrize('N,Cin,Cout,S', [(224, 64, 64, 32), (224, 64, 64, 16), (224, 66, 64, 4)])
 def test_deconv5x5s2_is_one_trilinear_form(N, Cin, Cout, S):
     from genesis_amd import hip_ops as hip
