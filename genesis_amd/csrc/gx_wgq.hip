@@ -421,11 +421,19 @@ template <int CLS, int W> struct WrGeo {
     static constexpr int NCOV = WqCols<CLS>::NCOV, CS0 = WqCols<CLS>::CS0;
     static constexpr int DMIN = RO0 - 1, DMAX = RO0 + NRO - 2;   // x rows r + DMIN .. r + DMAX feed tile r
     static_assert(DMAX - DMIN + 2 <= 4, "the rows in use plus the one being fetched must fit the four ring slots");
-    static constexpr int OPR = W / 8;                          // octets (16-byte pieces) per base row
-    static constexpr int NG = W / 16;                          // MFMA k-groups per tile (16 pixels each)
+    // W = 16: TWO image rows per tile (R2) -- 16-pixel rows of one plane lie back to back in memory, so a pair of them is a
+    // 32-pixel row to everything but (a) the dy addresses of the transposed conv (its two dy rows are two rows apart), (b) the
+    // column shifts, which must not carry pixels across the seam: the A rows keep a zero piece between the two halves, and (c)
+    // the x operand of k-group g (= image row 2 t + g) and tap row offset d: image row 2 t + g + d = half (g + d) & 1 of the
+    // ring row t + ((g + d) >> 1).  H is then the number of row PAIRS.
+    static constexpr bool R2 = W == 16;
+    static constexpr int WE = R2 ? 32 : W;                     // pixels per tile row
+    static constexpr int OPR = WE / 8;                         // octets (16-byte pieces) per tile row
+    static constexpr int NG = WE / 16;                         // MFMA k-groups per tile (16 pixels each)
     static constexpr int UPT = OPR / 4;                        // (channel, octet) units per thread: 64 * OPR / 256
     static constexpr int CPS = 256 / OPR;                      // channels covered by one unit index
-    static constexpr int APITCH = OPR + 1;                     // pieces per channel of an A plane
+    static constexpr int APITCH = OPR + (R2 ? 3 : 1);          // pieces per channel of an A plane (odd; R2: o0 o1 Z o2 o3 Z Z)
+    static constexpr int AGS = R2 ? 48 : 32;                   // bytes from k-group g's octets to k-group g + 1's in an A row
     static constexpr int A_PLANE = (64 * APITCH + 1) * 16;     // bytes (one leading zero piece)
     static constexpr int A_BUF = NPB * 3 * A_PLANE;            // one A buffer: column parities x planes
     static constexpr int B_ROW = 64 * OPR * 16;                // one x row of one plane
@@ -434,6 +442,17 @@ template <int CLS, int W> struct WrGeo {
     static constexpr int RING0 = 2 * A_BUF;                    // byte offset of the ring
     static constexpr int LDS_BYTES = RING0 + 3 * B_PLANE;
     __host__ __device__ static constexpr int fsw(int ch) { return (ch * OPR / 16) & (OPR - 1); }
+    // float offset of the dy row of tile row `ra` of image `ia` (H tile rows per image) / of its x row
+    __device__ static size_t a_row(int ia, int CA, int ca0, int H, int ra) {
+        if (R2) return (((size_t)ia * CA + ca0) * (SA * H) + (size_t)(SA * ra)) * (SA * WE) + WT::PA * (SA * 16);
+        return (((size_t)ia * CA + ca0) * (SA * H) + (size_t)(SA * ra + WT::PA)) * (SA * WE);
+    }
+    __device__ static size_t b_row(int ib, int CB, int cb0, int H, int rb) { return (((size_t)ib * CB + cb0) * H + (size_t)rb) * WE; }
+    // R2: unit (k-group g, tap row rr) reads k-group b_g of ring row index b_rr
+    __host__ __device__ static constexpr int b_e(int g, int rr) { return g + DMIN + rr; }
+    __host__ __device__ static constexpr int b_so(int g, int rr) { return b_e(g, rr) >= 0 ? b_e(g, rr) / 2 : -((1 - b_e(g, rr)) / 2); }
+    __host__ __device__ static constexpr int b_g(int g, int rr) { return R2 ? b_e(g, rr) - 2 * b_so(g, rr) : g; }
+    __host__ __device__ static constexpr int b_rr(int g, int rr) { return R2 ? b_so(g, rr) - DMIN : rr; }
 };
 
 __device__ __forceinline__ void wr_split8(const float (&v)[8], gx_u32x4& ph, gx_u32x4& pm, gx_u32x4& pl) {
@@ -466,8 +485,8 @@ __device__ __forceinline__ void wr_fetch(const WrT<CLS, W>& w, int ta, int tb,
     constexpr int SA = G::SA;
     const bool a_live = (unsigned)ta < (unsigned)w.ntot, b_live = (unsigned)tb < (unsigned)w.ntot;
     const int ia = ta >> w.lh, ra = ta & (w.H - 1), ib = tb >> w.lh, rb = tb & (w.H - 1);
-    const size_t arow = (((size_t)ia * w.CA + w.ca0) * (SA * w.H) + (size_t)(SA * ra + G::WT::PA)) * (SA * W);
-    const size_t brow = (((size_t)ib * w.CB + w.cb0) * w.H + (size_t)rb) * W;
+    const size_t arow = G::a_row(ia, w.CA, w.ca0, w.H, ra);
+    const size_t brow = G::b_row(ib, w.CB, w.cb0, w.H, rb);
     const float* ab = w.a + arow;
     const float* bb = w.b + brow;
 #pragma unroll
@@ -630,7 +649,7 @@ __device__ __forceinline__ void wr_split_piece(char* lds, const WrT<CLS, W>& w, 
 template <int CLS, int W>
 __device__ __forceinline__ void wr_read_a1(const char* lds, const WrT<CLS, W>& w, int abuf, int g, int par, int pl, WrRaw<CLS, W>& r) {
     using G = WrGeo<CLS, W>;
-    const char* p = lds + abuf + (par * 3 + pl) * G::A_PLANE + w.a_rd + g * 32;
+    const char* p = lds + abuf + (par * 3 + pl) * G::A_PLANE + w.a_rd + g * G::AGS;
     r.c[par][pl] = *reinterpret_cast<const gx_u32x4*>(p);
     r.pv[par][pl] = *reinterpret_cast<const unsigned*>(p - 4);
     r.nx[par][pl] = *reinterpret_cast<const unsigned*>(p + 16);
@@ -682,14 +701,14 @@ __device__ __forceinline__ void wr_fetch_piece(const WrT<CLS, W>& w, int ta, int
     if (I % 2 == 0) {
         const bool live = (unsigned)ta < (unsigned)w.ntot;
         const int ia = ta >> w.lh, ra = ta & (w.H - 1);
-        const size_t arow = (((size_t)ia * w.CA + w.ca0) * (SA * w.H) + (size_t)(SA * ra + G::WT::PA)) * (SA * W);
+        const size_t arow = G::a_row(ia, w.CA, w.ca0, w.H, ra);
         const float* ap = (live & w.okA[j]) ? w.a + arow + w.goffA[j] : w.zeros;
 #pragma unroll
         for (int q = 0; q < 2 * SA; ++q) pa[j][q] = ((gx_gptr4)ap)[q];
     } else {
         const bool live = (unsigned)tb < (unsigned)w.ntot;
         const int ib = tb >> w.lh, rb = tb & (w.H - 1);
-        const size_t brow = (((size_t)ib * w.CB + w.cb0) * w.H + (size_t)rb) * W;
+        const size_t brow = G::b_row(ib, w.CB, w.cb0, w.H, rb);
         const float* bp = (live & w.okB[j]) ? w.b + brow + w.goffB[j] : w.zeros;
 #pragma unroll
         for (int q = 0; q < 2; ++q) pb[j][q] = ((gx_gptr4)bp)[q];
@@ -701,7 +720,7 @@ template <int CLS, int W, int I>
 __device__ __forceinline__ void wr_head_piece(const char* lds, const WrT<CLS, W>& w, int abuf, const int (&bs)[WrGeo<CLS, W>::NRO],
                                               const bool (&zr)[WrGeo<CLS, W>::NRO], WrTileState<CLS, W>& st) {
     constexpr int NPB = WrGeo<CLS, W>::NPB;
-    if (I == 0) wr_read_b<CLS, W>(lds, w, 0, bs[0], zr[0], st.bq[0]);
+    if (I == 0) wr_read_b<CLS, W>(lds, w, WrGeo<CLS, W>::b_g(0, 0), bs[WrGeo<CLS, W>::b_rr(0, 0)], zr[WrGeo<CLS, W>::b_rr(0, 0)], st.bq[0]);
     else if (I < 1 + 3 * NPB) wr_read_a1<CLS, W>(lds, w, abuf, 0, (I - 1) / 3, (I - 1) % 3, st.raw);
     else wr_shift_a1<CLS, W>(st.raw, st.av[0], (I - 1 - 3 * NPB) / 6, ((I - 1 - 3 * NPB) % 6) / 2, (I - 1 - 3 * NPB) % 2);
 }
@@ -750,7 +769,8 @@ __device__ __forceinline__ void wr_slot(char* lds, const WrT<CLS, W>& w, const W
     else if constexpr (M < n_b + n_ra + n_sh) {}
 #endif
     else if constexpr (M < n_b) {
-        wr_read_b<CLS, W>(lds, w, (U + 1) / NRO, sp.bs[(U + 1) % NRO], sp.zr[(U + 1) % NRO], st.bq[(U + 1) & 1]);
+        constexpr int g1 = (U + 1) / NRO, r1 = (U + 1) % NRO;
+        wr_read_b<CLS, W>(lds, w, G::b_g(g1, r1), sp.bs[G::b_rr(g1, r1)], sp.zr[G::b_rr(g1, r1)], st.bq[(U + 1) & 1]);
     } else if constexpr (M < n_b + n_ra) {
         wr_read_a1<CLS, W>(lds, w, sp.abuf, g + 1, (M - n_b) / 3, (M - n_b) % 3, st.raw);
     } else if constexpr (M < n_b + n_ra + n_sh) {
@@ -784,19 +804,21 @@ __device__ __forceinline__ void wr_segment(const float* a, const float* b, const
                                            int CB, int ca0, int cb0, int H, int t0, int t1, float* slab) {
     using G = WrGeo<CLS, W>;
     using WT = typename G::WT;
-    constexpr int NT = G::NT, NRO = G::NRO, RO0 = G::RO0, OPR = G::OPR, SA = G::SA;
+    constexpr int NT = G::NT, NRO = G::NRO, RO0 = G::RO0, OPR = G::OPR, SA = G::SA, WE = G::WE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (G::R2) H >>= 1;                     // tile rows = pairs of image rows
     WrT<CLS, W> w;
     w.a = a; w.b = b; w.zeros = zeros; w.CA = CA; w.CB = CB; w.ca0 = ca0; w.cb0 = cb0; w.H = H;
     w.lh = 31 - __builtin_clz(H); w.ntot = N * H;
 #pragma unroll
     for (int j = 0; j < G::UPT; ++j) {
         const int ch = tid / OPR + j * G::CPS, o = tid % OPR;
-        w.goffA[j] = ch * (SA * H) * (SA * W) + SA * 8 * o;
-        w.goffB[j] = ch * H * W + 8 * o;
+        // (R2: the second image row's dy starts SA image rows of SA * 16 floats further on, not right behind the first's)
+        w.goffA[j] = ch * (SA * H) * (SA * WE) + SA * 8 * o + (G::R2 && o >= 2 ? 16 * SA * (SA - 1) : 0);
+        w.goffB[j] = ch * H * WE + 8 * o;
         w.okA[j] = ca0 + ch < CA;
         w.okB[j] = cb0 + ch < CB;
-        w.stA[j] = (1 + ch * G::APITCH + o) * 16;
+        w.stA[j] = (1 + ch * G::APITCH + o + (G::R2 && o >= 2 ? 1 : 0)) * 16;
         w.stB[j] = (ch * OPR + (o ^ G::fsw(ch))) * 16;
     }
     const int wm = wave >> 1, wn = wave & 1, h = lane >> 5;
@@ -806,6 +828,11 @@ __device__ __forceinline__ void wr_segment(const float* a, const float* b, const
     for (int g = 0; g < G::NG; ++g) w.b_rd[g] = (chb * OPR + ((2 * g + h) ^ G::fsw(chb))) * 16;
 
     // zero pieces: the leading one and one behind every channel's row of the A planes (both buffers), one per ring plane
+    // (R2: the seam piece and the two behind the row as well -- the whole A buffers)
+    if (G::R2) {
+        for (int i = tid; i < 2 * G::A_BUF / 16; i += 256) *reinterpret_cast<gx_u32x4*>(lds + i * 16) = gx_u32x4{0u, 0u, 0u, 0u};
+        __syncthreads();      // (this fill covers the data pieces too: it must land before the prologue's stores of other threads)
+    }
     for (int i = tid; i < 2 * G::NPB * 3 * 65 + 3; i += 256) {
         const int plane = i / 65, k = i - plane * 65;
         char* d = plane < 2 * G::NPB * 3 ? lds + plane * G::A_PLANE + (k == 0 ? 0 : k * G::APITCH) * 16
@@ -965,6 +992,7 @@ wgq_stream_kernel(const WsTable tab, const float* __restrict__ zeros) {
             GX_WS_CASE(6, WQ_DR1, 5) GX_WS_CASE(7, WQ_DR1, 4) GX_WS_CASE(8, WQ_DR1, 3)
             GX_WR_CASE(18, WQ_C3, 64) GX_WR_CASE(19, WQ_C3, 32) GX_WR_CASE(20, WQ_DR0, 32) GX_WR_CASE(21, WQ_DR1, 32)
             GX_WR_CASE(22, WQ_C5A, 64) GX_WR_CASE(23, WQ_C5A, 32) GX_WR_CASE(24, WQ_C5B, 64) GX_WR_CASE(25, WQ_C5B, 32)
+            GX_WR_CASE(26, WQ_C3, 16) GX_WR_CASE(27, WQ_DR0, 16) GX_WR_CASE(28, WQ_DR1, 16)
             default: break;
         }
 #undef GX_WS_CASE
@@ -1123,10 +1151,11 @@ bool wgq_stream_on() {
 // wgrad3:256:64 wgrad3:2048:16 wgrad3:8192:8 wgrad:256:32 wgrad:1024:16 wgrad:4096:8: 10.3 us per conv3x3 tile, 26.5 us per
 // pair of transposed-conv row-parity tiles, split 15 a + b : 10 a + b), then nudged on the training step itself
 // (the stream kernel's duration over five vectors: 921 .. 972 us); GENESIS_WGQ_COST="c0,...,c8" overrides
-int g_ws_cost[26] = {10200, 9580, 10680, 15080, 21000, 11800, 11400, 8800, 9700,              // bf16 pipe (measured with
+int g_ws_cost[29] = {10200, 9580, 10680, 15080, 21000, 11800, 11400, 8800, 9700,              // bf16 pipe (measured with
                      10200, 10600, 11200, 16000, 16500, 18200, 11600, 12000, 13300,           // GENESIS_WGQ_TIMES) | fp32 pipe
                      4840, 2450, 4150, 2900,                                                  // row-ring tiles (one base row)
-                     8000, 4100, 5400, 2800};                                                 // ... of the 5 x 5 stride-1 conv
+                     8000, 4100, 5400, 2800,                                                  // ... of the 5 x 5 stride-1 conv
+                     2450, 4150, 2900};                                                       // ... two 16-pixel rows per tile
 bool g_ws_cost_init = false;
 void ws_cost_init() {
     if (g_ws_cost_init) return;
@@ -1136,6 +1165,11 @@ void ws_cost_init() {
         int r[4];
         if (sscanf(er, "%d,%d,%d,%d", r, r + 1, r + 2, r + 3) == 4)
             for (int i = 0; i < 4; ++i) if (r[i] > 0) g_ws_cost[18 + i] = r[i];
+    }
+    if (const char* er = getenv("GENESIS_WGQ_R2_COST")) {       // two-rows-per-tile variants: conv3x3, transposed-conv rows 0 / 1
+        int r[3];
+        if (sscanf(er, "%d,%d,%d", r, r + 1, r + 2) == 3)
+            for (int i = 0; i < 3; ++i) if (r[i] > 0) g_ws_cost[26 + i] = r[i];
     }
     if (!env) return;
     int v[9];          // the nine costs of the pipe in use
@@ -1155,6 +1189,8 @@ bool wgq_ring_on() {
 }
 int ws_ring_variant(int cls, int Hb, int Wb) {
     if (!wgq_b6() || !wgq_ring_on() || Hb < 4) return -1;          // (H a multiple of 4: the ring slot of a row is tile & 3)
+    static const char* r2env = getenv("GENESIS_WGQ_RING16");       // 0: 16-pixel rows stay on the 64-pixel LDS-DMA tiles
+    if (Wb == 16 && !(r2env && r2env[0] == '0') && Hb >= 8 && Hb % 8 == 0 && cls <= WQ_DR1) return 26 + cls;   // two image rows per tile
     if (cls == WQ_C3) return Wb == 64 ? 18 : (Wb == 32 ? 19 : -1);
     if (cls == WQ_C5A || cls == WQ_C5B) return Wb == 64 ? (cls == WQ_C5A ? 22 : 24) : (Wb == 32 ? (cls == WQ_C5A ? 23 : 25) : -1);
     if (Wb != 32) return -1;
@@ -1229,7 +1265,7 @@ int wgq_launch_stream(std::vector<PendingJob*>& jobs, hipStream_t s, std::vector
                     jb.Ttot = q.job.Ttot;
                     jb.variant = q.cls * 3 + (5 - q.ltw) + (wgq_b6() ? 0 : 9);
                     const int rv = ws_ring_variant(q.cls, q.job.Hb, q.job.Wb);
-                    if (rv >= 0) { jb.variant = rv; jb.ntiles = q.job.N * q.job.Hb; }      // tile = one base row
+                    if (rv >= 0) { jb.variant = rv; jb.ntiles = q.job.N * q.job.Hb / (rv >= 26 ? 2 : 1); }      // tile = one base row (26..28: two)
                     else if (q.cls >= WQ_C5A) { gx_set_error("wgq: the 5x5 classes exist as row-ring tiles only"); return GX_EINVAL; }
                     jb.cost = g_ws_cost[jb.variant];
                     jb.w_first = 0; jb.N = q.job.N;

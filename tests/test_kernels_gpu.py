@@ -1103,7 +1103,10 @@ def test_streamk_weight_gradients_many_layers():
 
 @pytest.mark.parametrize('kind,N,Cin,Cout,S', [('conv3x3', 5, 64, 64, 64), ('conv3x3', 1, 128, 64, 64), ('conv3x3', 7, 96, 40, 32),
                                                 ('conv3x3', 33, 64, 128, 32), ('deconv', 3, 64, 64, 32), ('deconv', 29, 40, 72, 32),
-                                                ('deconv', 1, 64, 64, 32)])
+                                                ('deconv', 1, 64, 64, 32),
+                                                # rows of 16 pixels: two image rows per tile (a zero piece at the seam)
+                                                ('conv3x3', 9, 64, 200, 16), ('conv3x3', 1, 128, 64, 16), ('deconv', 13, 64, 64, 16),
+                                                ('deconv', 1, 40, 72, 16), ('conv3x3', 3, 64, 64, 8)])
 def test_row_ring_weight_gradients(kind, N, Cin, Cout, S):
     """gx_wgq_ring: the row-ring tiles of the bf16-pipe weight gradients (one full-width base row per tile, x rows in a
     rolling four-slot LDS ring, operands split into bf16 planes once, column shifts as funnel shifts of the dy operand)
@@ -1127,7 +1130,8 @@ def test_row_ring_weight_gradients(kind, N, Cin, Cout, S):
             _lib.call('gx_wgq_ring', mode)
             got = run()
             if mode == 1:
-                assert torch.equal(got, run())
+                for _ in range(8):         # (a race between a segment's LDS fills would show as differing bits)
+                    assert torch.equal(got, run())
             err[mode] = float((got.double().cpu() - ref).norm() / ref.norm())
     finally:
         _lib.call('gx_wgq_ring', 1)
