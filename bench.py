@@ -334,7 +334,9 @@ def main():
             """Roofline entry of one profiled kernel family: ALGORITHMIC flops (or bytes) per second of its own launches
             against the peak of the pipe it runs on."""
             sec = dom['ms'] * 1e-3
-            if dom['flops'] > 0:
+            # below the machine balance (fp32 MFMA peak / HBM peak ~ 20 flop per byte) a kernel is priced against HBM
+            balance = PEAK_FP32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+            if dom['flops'] > 0 and (dom['bytes'] <= 0 or dom['flops'] / dom['bytes'] >= balance):
                 ach = dom['flops'] / sec / 1e12
                 mfma_peak = PEAK_FP32_MFMA_TFLOPS
                 roof = {'bound': 'mfma', 'kernel': dom['name'], 'achieved': ach, 'peak': mfma_peak, 'unit': 'TFLOP/s'}
@@ -385,8 +387,8 @@ def main():
         committed = {}
         if rp:
             committed['rocprof_avg_launch_us'] = rp
-            committed['frac_from_rocprof'] = (dom['flops'] if dom['flops'] > 0 else dom['bytes']) / dom['launches'] / \
-                (rp * 1e-6) / ((roof['peak'] * 1e12) if dom['flops'] > 0 else (PEAK_HBM_GBS * 1e9))
+            committed['frac_from_rocprof'] = (dom['flops'] if roof['bound'] == 'mfma' else dom['bytes']) / dom['launches'] / \
+                (rp * 1e-6) / ((roof['peak'] * 1e12) if roof['bound'] == 'mfma' else (PEAK_HBM_GBS * 1e9))
             committed['rocprof_source'] = 'profiles/' + rp_file
         if tr:
             committed['traffic_source'] = 'profiles/' + tr_file
