@@ -668,7 +668,7 @@ conv1x1_finalize_kernel(const float* __restrict__ raw, const float* __restrict__
 // part0 into out0, blocks [n0, n0 + n1) reduce part1 into out1
 __global__ void __launch_bounds__(256)
 col_sum2_kernel(const float* __restrict__ part0, int nblk0, int n0, float* __restrict__ out0,
-                const float* __restrict__ part1, int nblk1, int n1, float* __restrict__ out1) {
+                const float* __restrict__ part1, int nblk1, int n1, float* __restrict__ out1, int accumulate = 0) {
     __shared__ double red[4];
     const bool first = (int)blockIdx.x < n0;
     const int i = first ? blockIdx.x : blockIdx.x - n0;
@@ -679,7 +679,7 @@ col_sum2_kernel(const float* __restrict__ part0, int nblk0, int n0, float* __res
     s = block_sum_dd(s, red);
     if (threadIdx.x == 0) {
         float* out = first ? out0 : out1;
-        if (out) out[i] = (float)s;
+        if (out) out[i] = accumulate ? out[i] + (float)s : (float)s;      // (a parameter used again in the same iteration)
     }
 }
 
@@ -829,7 +829,14 @@ size_t gx_conv1x1_bwd_ws_bytes(int N, int Cin, int Cout, int H, int W) {
 int gx_conv1x1_bwd(const float* x, const float* dy, const float* w, const float* bias, const float* gate, int N,
                    int Cin, int Cout, int H, int W, float* dx, float* dw, float* db, float* dgate, void* ws,
                    size_t ws_bytes, gx_stream_t stream) {
+    return gx_conv1x1_bwd_ex(x, dy, w, bias, gate, N, Cin, Cout, H, W, dx, dw, db, dgate, 0, ws, ws_bytes, stream);
+}
+
+int gx_conv1x1_bwd_ex(const float* x, const float* dy, const float* w, const float* bias, const float* gate, int N,
+                      int Cin, int Cout, int H, int W, float* dx, float* dw, float* db, float* dgate, int accumulate,
+                      void* ws, size_t ws_bytes, gx_stream_t stream) {
     GX_CHECK_ARG(x && dy && w && dx && dw && ws, "gx_conv1x1_bwd: null pointer");
+    GX_CHECK_ARG(!accumulate || !gate, "gx_conv1x1_bwd_ex: accumulate is for the plain (ungated) conv");
     GX_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && Cout <= COMAX && Cin <= 128,
                  "gx_conv1x1_bwd: Cout must be <= 8 and Cin <= 128");
     GX_CHECK_ARG((gate == nullptr) == (dgate == nullptr), "gx_conv1x1_bwd: gate and dgate go together");
@@ -872,7 +879,7 @@ int gx_conv1x1_bwd(const float* x, const float* dy, const float* w, const float*
         GxProf pf(KID_SMALL_REDUCE, s, 0.0, 4.0 * ((double)nblkw * npairs + (double)nblkd * Cout));
         if (!gate) {   // no gate: the column sums ARE dw and db
             hipLaunchKernelGGL(col_sum2_kernel, dim3(npairs + Cout), dim3(256), 0, s, (const float*)pw, nblkw, npairs,
-                               dw, (const float*)pb, nblkd, Cout, db);
+                               dw, (const float*)pb, nblkd, Cout, db, accumulate ? 1 : 0);
         } else {       // dgate = <raw dw, w> + <raw db, bias> needs all sums: second launch
             hipLaunchKernelGGL(col_sum2_kernel, dim3(npairs + Cout), dim3(256), 0, s, (const float*)pw, nblkw, npairs,
                                raw, (const float*)pb, nblkd, Cout, raw + npairs);

@@ -702,15 +702,23 @@ class Conv1x1Fn(torch.autograd.Function):
     def forward(ctx, x, w, b):
         x = x.contiguous()
         w2 = w.reshape(w.shape[0], -1)
-        ctx.save_for_backward(x, w2, b)
-        ctx.wshape = w.shape
+        ctx.save_for_backward(x, w2)
+        ctx.params = (w, b)
         return hip.conv1x1_fwd(x, w2, b)
 
     @staticmethod
     def backward(ctx, g):
-        x, w2, b = ctx.saved_tensors
-        dx, dw, db, _ = hip.conv1x1_bwd(x, g.contiguous(), w2, b)
-        return dx, dw.view(ctx.wshape), db
+        x, w2 = ctx.saved_tensors
+        w, b = ctx.params
+        # weight and bias gradients straight into the bucket; a conv used again in the iteration (MONet's K-1 UNet passes
+        # share final_conv) ADDS inside the finishing kernel
+        (ow, acc_w), (ob, acc_b) = _gout_acc(w), (_gout_acc(b) if b is not None else (None, False))
+        if ow is None or (b is not None and (ob is None or acc_b != acc_w)):
+            ow = ob = None
+            acc_w = False
+        dx, dw, db, _ = hip.conv1x1_bwd(x, g.contiguous(), w2, b, out=(ow.view(w2.shape) if ow is not None else None, ob, None),
+                                        accumulate=acc_w)
+        return dx, _ret(ow, dw.view(w.shape) if ow is None else None), (_ret(ob, db) if b is not None else None)
 
 
 @ctx_bound

@@ -393,8 +393,10 @@ def conv1x1_fwd(x, w, bias, gate=None, addend=None):
     return y
 
 
-def conv1x1_bwd(x, dy, w, bias, gate=None, out=None):
-    """out = (dw, db, dgate) preallocated destinations (entries may be None), e.g. the parameters' .grad buffers."""
+def conv1x1_bwd(x, dy, w, bias, gate=None, out=None, accumulate=False):
+    """out = (dw, db, dgate) preallocated destinations (entries may be None), e.g. the parameters' .grad buffers;
+    accumulate: dw / db are ADDED to them (plain conv only)."""
+    assert not accumulate or (out is not None and out[0] is not None and gate is None)
     _chk(dy, 'conv1x1_bwd.dy')
     N, Cin, H, W = x.shape
     Cout = w.shape[0]
@@ -408,8 +410,8 @@ def conv1x1_bwd(x, dy, w, bias, gate=None, out=None):
     assert dw.numel() == Cout * Cin
     nb = _lib.query('gx_conv1x1_bwd_ws_bytes', N, Cin, Cout, H, W)
     ws = _ws(nb, dev)
-    _lib.call('gx_conv1x1_bwd', _p(x), _p(dy), _p(w), _p(bias), _p(gate), N, Cin, Cout, H, W, _p(dx), _p(dw),
-              _p(db), _p(dgate), _p(ws), nb, _stream())
+    _lib.call('gx_conv1x1_bwd_ex', _p(x), _p(dy), _p(w), _p(bias), _p(gate), N, Cin, Cout, H, W, _p(dx), _p(dw),
+              _p(db), _p(dgate), int(bool(accumulate)), _p(ws), nb, _stream())
     return dx, (dw.view(w.shape) if o[0] is None else dw), db, dgate
 
 

@@ -138,8 +138,9 @@ class MONet(nn.Module):
             feat = fn.UNetEncoderFn.apply(torch.cat((x, log_s_k[step]), 1), core.num_blocks, 0, *core.flat_params())
             a = fn.Conv1x1Fn.apply(feat, core.final_conv.weight, core.final_conv.bias)
             lm, ls = fn.SBPScanFn.apply(a.unsqueeze(0), log_s_k[step], False)     # one stick-breaking step, one launch
-            log_m_k.append(lm[0])
-            log_s_k.append(ls[0])
+            # (views, not [0]: a select's backward is a zero fill + a copy per use)
+            log_m_k.append(lm.view(lm.shape[1:]))
+            log_s_k.append(ls.view(ls.shape[1:]))
         log_m_k.append(log_s_k[-1])
         return log_m_k, log_s_k
 

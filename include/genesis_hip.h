@@ -199,6 +199,11 @@ size_t gx_conv1x1_bwd_ws_bytes(int N, int Cin, int Cout, int H, int W);
 int gx_conv1x1_bwd(const float* x, const float* dy, const float* w, const float* bias, const float* gate, int N,
                    int Cin, int Cout, int H, int W, float* dx, float* dw, float* db, float* dgate, void* ws,
                    size_t ws_bytes, gx_stream_t stream);
+/*      ..._ex with accumulate = 1: dw / db are ADDED to what the destinations hold (the MONet UNet's final_conv is used K-1
+ *      times per iteration); plain conv only (gate == NULL). */
+int gx_conv1x1_bwd_ex(const float* x, const float* dy, const float* w, const float* bias, const float* gate, int N,
+                      int Cin, int Cout, int H, int W, float* dx, float* dw, float* db, float* dgate, int accumulate,
+                      void* ws, size_t ws_bytes, gx_stream_t stream);
 /*      The same 1x1 conv reading the PRE-norm tensor y of the GroupNorm+ReLU layer in front of it (statistics from
  *      gx_gn_relu_fwd with dst0 == NULL): relu(gn(y)) is formed on load, forward and in the weight gradient; the data
  *      gradient is folded into gx_gn_relu_bwd_proj.  Cin <= 64 (wgrad), H*W % 256 == 0. */
