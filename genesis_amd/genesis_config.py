@@ -21,6 +21,7 @@ from forge import flags  # noqa: E402
 
 from genesis_amd import functions as fn  # noqa: E402
 from genesis_amd.genesisv2_config import _cfg_get, _normal_log_prob, pixel_coords  # noqa: E402
+from genesis_amd.lazy import SlotList  # noqa: E402
 from genesis_amd.monet_config import _BroadcastDecoderParams, _ComponentVAEParams  # noqa: E402
 from genesis_amd.sylvester import (GatedConv2d, GatedConvTranspose2d, SylvesterVAE, gc_decoder_forward,  # noqa: E402
                                   gc_encoder_forward)
@@ -210,7 +211,7 @@ class Genesis(nn.Module):
                                                Pm.weight, Pm.bias, True)
         else:
             kl_m, lin_p = fn.PriorLogPFn.apply(z, None, log_q), None
-        losses['kl_m_k'] = list(kl_m.unbind(0))
+        losses['kl_m_k'] = SlotList(kl_m.unbind(0), stacked=kl_m)
         comp_stats = None
         if self.two_stage:
             if self.comp_prior:
@@ -226,7 +227,8 @@ class Genesis(nn.Module):
             else:
                 # -- N(0, 1) component prior (genesis_config.py:248-254): every row is a "first slot"
                 kl_l = fn.PriorLogPFn.apply(z_c.view(1, K * B, -1), None, log_q_c.view(1, K * B))
-            losses['kl_l_k'] = list(kl_l.view(K, B).unbind(0))
+            kl_l = kl_l.view(K, B)
+            losses['kl_l_k'] = SlotList(kl_l.unbind(0), stacked=kl_l)
             comp_stats = AttrDict(mu_k=mu_c.chunk(K, 0), sigma_k=sig_c.chunk(K, 0), z_k=z_c.chunk(K, 0))
             if self.comp_prior:
                 comp_stats['pmu_k'], comp_stats['psigma_k'] = pm.chunk(K, 0), ps.chunk(K, 0)

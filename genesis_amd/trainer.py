@@ -170,14 +170,20 @@ class TrainStep(object):
         # loss aggregation of train.py:226-242 (every model family: kl_m | kl_m_k, kl_l | kl_l_k)
         beta_t = self.geco.state[0:1] if self.geco is not None else self._beta_fixed_t.view(1)
         keys = [k for k in ('kl_m', 'kl_m_k', 'kl_l', 'kl_l_k') if k in losses]
-        fused, kl_rows = len(keys) <= 1 and losses.err.dim() == 1, None
-        if fused and keys:
-            v = dict.__getitem__(losses, keys[0])
-            if keys[0].endswith('_k'):
-                kl_rows = getattr(v, 'stacked', None)        # [K,B] tensor the per-slot list was unbound from
-                fused = kl_rows is not None
-            else:
-                kl_rows = v.view(1, -1)
+        # every KL term as rows [R_i, B]: sum_k mean_b is the same for the rows of all terms stacked on top of each other,
+        # so one ElboFn launch serves MONet (kl_m + kl_l_k) and GENESIS (kl_m_k + kl_l_k) too
+        fused, rows = losses.err.dim() == 1, []
+        for k in keys:
+            v = dict.__getitem__(losses, k)
+            if k.endswith('_k'):
+                v = getattr(v, 'stacked', None)              # [K,B] tensor the per-slot list was unbound from
+                if v is None:
+                    fused = False
+                    break
+            rows.append(v.reshape(-1, losses.err.shape[0]))
+        kl_rows = None
+        if fused and rows:
+            kl_rows = rows[0] if len(rows) == 1 else torch.cat(rows, 0)
         if fused:
             # one launch: batch means, the GECO-weighted objective, and (err, kl) straight into the bucket tail
             loss, out5 = _fn.ElboFn.apply(losses.err, kl_rows, beta_t, self.bucket.flat_g[self.n32:self.n32 + 2])
