@@ -25,7 +25,7 @@ from forge import flags  # noqa: E402
 from genesis_amd import functions as fn  # noqa: E402
 from genesis_amd import hip_ops as hip  # noqa: E402
 from genesis_amd.genesisv2_config import _UNetParams, _cfg_get, _normal_log_prob, pixel_coords  # noqa: E402
-from genesis_amd.lazy import SlotList  # noqa: E402
+from genesis_amd.lazy import Lazy, LazyAttrDict, SlotList  # noqa: E402
 
 # Attention network (models/monet_config.py:36-37)
 flags.DEFINE_integer('filter_start', 32, 'Starting number of channels in UNet.')
@@ -186,8 +186,8 @@ class MONet(nn.Module):
         kl = kl.view(K, B)
         losses['kl_l_k'] = SlotList(kl.unbind(0), stacked=kl)
         x_r_k = list(x_r.unbind(0))
-        stats = AttrDict(recon=recon, log_m_k=log_m_k, log_s_k=log_s_k, x_r_k=x_r_k,
-                         log_m_r_k=list(log_m_r.unbind(0)), mx_r_k=list((x_r * log_m.exp()).unbind(0)))
+        stats = LazyAttrDict(recon=recon, log_m_k=log_m_k, log_s_k=log_s_k, x_r_k=x_r_k, log_m_r_k=list(log_m_r.unbind(0)),
+                             mx_r_k=Lazy(lambda: list((x_r * log_m.exp()).unbind(0))))      # (visualisation only: on first access)
         comp_stats = AttrDict(mu_k=mu.chunk(K, 0), sigma_k=sigma.chunk(K, 0), z_k=z.chunk(K, 0))
         return recon, losses, stats, AttrDict(), comp_stats
 

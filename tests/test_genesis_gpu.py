@@ -73,6 +73,14 @@ def test_genesis_forward_grads_and_steps(case):
     gold.check('log_m_k', st(stats.log_m_k), 1e-4, 1e-3)
     gold.check('x_r_k', st(stats.x_r_k), 1e-4, 2e-5)
     gold.check('att_z_k', st(att.z_k), 1e-4, 5e-5)
+    # the visualisation-only statistics are evaluated on first access (models/genesis_config.py:256-270 returns them eagerly)
+    mx = st(stats.mx_r_k)
+    assert torch.allclose(mx, st(stats.x_r_k) * st(stats.log_m_k).exp())
+    pmu, psig = st(att.pmu_k), st(att.psigma_k)
+    assert pmu.shape == st(att.mu_k).shape and float(pmu[0].abs().max()) == 0.0 and float((psig[0] - 1).abs().max()) == 0.0
+    assert float(pmu.abs().max()) <= 1.0 and float(psig.min()) >= 1e-4
+    if two and cfg.get('comp_prior', True):
+        assert st(comp.pmu_k).shape == st(comp.mu_k).shape and float(st(comp.psigma_k).min()) >= 1e-4
     err = losses.err.mean(0)
     kl = torch.stack(losses.kl_m_k, 1).mean(0).sum()
     if two:
