@@ -1220,6 +1220,7 @@ class ARPriorKLFn(torch.autograd.Function):
         if want_lin:
             lin_out = lin.detach()
             ctx.mark_non_differentiable(lin_out)
+            ctx.set_materialize_grads(False)  # (no zero-filled gradient tensor for `lin`)
             return kl, lin_out
         return kl
 

@@ -219,6 +219,7 @@ class GatedNormFn(torch.autograd.Function):
         ctx.params = (bias, gh, bh, gg, bg)
         ctx.norm = norm
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)      # (no zero-filled gradient tensor for `stats` in every backward)
         return out, stats
 
     @staticmethod
