@@ -17,7 +17,7 @@ HEADER_PATH = osp.join(osp.dirname(_HERE), 'include', 'genesis_hip.h')
 
 _CTYPES = {
     'int': ctypes.c_int, 'float': ctypes.c_float, 'double': ctypes.c_double, 'size_t': ctypes.c_size_t,
-    'gx_stream_t': ctypes.c_void_p, 'void': None,
+    'gx_stream_t': ctypes.c_void_p, 'void': None, 'long long': ctypes.c_longlong, 'unsigned long long': ctypes.c_ulonglong,
 }
 
 

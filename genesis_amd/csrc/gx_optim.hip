@@ -56,6 +56,53 @@ adam_pair_kernel(const AdamGroup a, const AdamGroup b, unsigned nb32, const int6
                                   gscale, blockIdx.x - nb32, gridDim.x - nb32);
 }
 
+// ---- the step's noise in one launch: counter-based (Philox4x32-10), keyed by (seed, the device-side step counter): a
+//      replayed HIP graph draws fresh numbers every step without the framework's graph-RNG bookkeeping (two offset fills
+//      and one launch per tensor).  Element i of tensor t: counter (i / 4, t, step) -> four 32-bit words.
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ void __launch_bounds__(256)
+philox_noise_kernel(float* __restrict__ u, long long nu, float* __restrict__ z, long long nz, unsigned long long seed,
+                    const long long* __restrict__ step) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // one Philox call = 4 outputs
+    const long long qu = (nu + 3) >> 2, qz = (nz + 3) >> 2;
+    if (q >= qu + qz) return;
+    const unsigned long long st = step ? (unsigned long long)*step : 0ull;
+    const bool normal = q >= qu;
+    const long long i4 = normal ? q - qu : q;
+    unsigned w[4];
+    philox4x32_10((unsigned)i4, (unsigned)(i4 >> 32) ^ (normal ? 0x80000000u : 0u), (unsigned)st, (unsigned)(st >> 32),
+                  (unsigned)seed, (unsigned)(seed >> 32), w);
+    float v[4];
+    if (!normal) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (float)(w[e] >> 8) * 5.9604644775390625e-8f;              // [0, 1): 24 bits
+    } else {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {                                                               // Box-Muller, two pairs
+            const float u1 = ((float)(w[2 * e] >> 8) + 1.f) * 5.9604644775390625e-8f;                // (0, 1]
+            const float th = (float)(w[2 * e + 1] >> 8) * (6.283185307179586f * 5.9604644775390625e-8f);
+            const float r = sqrtf(-2.f * logf(u1));
+            v[2 * e] = r * cosf(th); v[2 * e + 1] = r * sinf(th);
+        }
+    }
+    float* dst = normal ? z : u;
+    const long long n = normal ? nz : nu;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (4 * i4 + e < n) dst[4 * i4 + e] = v[e];
+}
+
 __global__ void step_inc_kernel(int64_t* step) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1;
 }
@@ -105,6 +152,20 @@ int gx_adam_step(void* p, const void* g, void* m, void* v, size_t n, int is_f64,
                                grad_scale);
     }
     GX_CHECK_LAUNCH("gx_adam_step");
+    return GX_OK;
+}
+
+/* nu uniform [0, 1) numbers into u and nz standard-normal numbers into z (either may be empty), a function of (seed, *step,
+ * position) only: torch.rand / torch.randn of a training step (modules/attention.py:177-178 rand_pixel,
+ * models/genesisv2_config.py:157 rsample) in one graph-replayable launch; step may be NULL (= 0). */
+int gx_philox_noise(float* u, long long nu, float* z, long long nz, unsigned long long seed, const int64_t* step,
+                    gx_stream_t stream) {
+    GX_CHECK_ARG(nu >= 0 && nz >= 0 && (nu == 0 || u) && (nz == 0 || z), "gx_philox_noise: bad arguments");
+    const long long calls = ((nu + 3) >> 2) + ((nz + 3) >> 2);
+    if (calls == 0) return GX_OK;
+    hipLaunchKernelGGL(philox_noise_kernel, dim3((unsigned)((calls + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u, nu, z, nz,
+                       seed, (const long long*)step);
+    GX_CHECK_LAUNCH("gx_philox_noise");
     return GX_OK;
 }
 

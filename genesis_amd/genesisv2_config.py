@@ -256,6 +256,8 @@ class GenesisV2(nn.Module):
         return fn.PriorLogPFn.apply(z, lin, log_q)
 
     # ------------------------------------------------------------------ forward
+    noise = None      # TrainStep installs its noise source here: (uniform shape, normal shape, device) -> (rand_pixel, eps)
+
     def forward(self, x, rand_pixel=None, eps=None, seed_idx=None):
         """x [B,3,H,W] in [0,1] on the GPU.  The optional arguments inject the noise the reference draws
         internally (rand_pixel [B,1,H,W] uniform, modules/attention.py:177-178; eps [K,B,D] standard
@@ -267,6 +269,9 @@ class GenesisV2(nn.Module):
         # --- Extract features (F.relu on the ReLU'd UNet output, genesisv2_config.py:115, is the identity)
         enc_feat = fn.UNetEncoderFn.apply(x, self.encoder.num_blocks, 8, *self.encoder.flat_params())
         # --- Predict attention masks
+        if rand_pixel is None and eps is None and getattr(self, 'noise', None) is not None:
+            # a training step's noise source (TrainStep: one Philox launch for both tensors, replayable in its HIP graph)
+            rand_pixel, eps = self.noise((B, 1, H, W), (K, B, D), dev)
         if rand_pixel is None:
             rand_pixel = torch.rand(B, 1, H, W, device=dev)
         ap = self.att_process

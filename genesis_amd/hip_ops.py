@@ -678,6 +678,18 @@ def gated_norm_fwd(y, bias, norm, gh, bh, gg, bg, eps=1e-5):
     return out, stats
 
 
+def philox_noise(uniform_shape, normal_shape, seed, step=None, device='cuda'):
+    """(u ~ U[0,1) of uniform_shape, z ~ N(0,1) of normal_shape) as a function of (seed, the int64 device scalar `step`,
+    position): one launch, replayable inside a HIP graph (gx_philox_noise).  Either shape may be None."""
+    u = torch.empty(uniform_shape, dtype=F32, device=device) if uniform_shape is not None else None
+    z = torch.empty(normal_shape, dtype=F32, device=device) if normal_shape is not None else None
+    if step is not None:
+        assert step.dtype == torch.int64 and step.is_cuda and step.numel() == 1
+    _lib.call('gx_philox_noise', _p(u), u.numel() if u is not None else 0, _p(z), z.numel() if z is not None else 0,
+              int(seed) & 0xFFFFFFFFFFFFFFFF, step.data_ptr() if step is not None else None, _stream())
+    return u, z
+
+
 def bn_running_update(stats, C, m, h_norm, g_norm, eps=1e-5, momentum=0.1):
     """nn.BatchNorm2d's running_mean / running_var / num_batches_tracked of a gated unit's two norms from the {mean, rstd}
     pairs of gated_norm_fwd, in one launch (gx_bn_running_update)."""

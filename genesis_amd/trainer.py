@@ -47,6 +47,14 @@ class TrainStep(object):
         self._wcache = _lib.query('gx_weight_cache_create') if weight_cache else None
         self._wcache_ready = False
         self.step_t = torch.zeros((), dtype=torch.int64, device=self.device)
+        # the step's noise (rand_pixel, eps) from one counter-based launch keyed by (torch's seed + rank, the step counter)
+        # instead of torch.rand + torch.randn and their graph-RNG bookkeeping (GENESIS_HIP_NOISE=0: torch's generators)
+        self._noise_owner = None
+        if os.environ.get('GENESIS_HIP_NOISE', '1') != '0' and hasattr(model, 'noise'):
+            import weakref
+            me = weakref.ref(self)            # (no reference cycle model -> TrainStep -> model: __del__ frees the context)
+            model.noise = lambda u, z, dev: me()._draw_noise(u, z, dev)
+            self._noise_owner = model
         self.graph = None
         self.graph2 = None
         self._split = False
@@ -137,6 +145,11 @@ class TrainStep(object):
                     _lib.call('gx_weight_cache_release')
             _lib.make_current(self._prev_ctx)
 
+    def _draw_noise(self, uniform_shape, normal_shape, device):
+        rank = dist.get_rank(self.pg) if (self.world > 1 and dist.is_initialized()) else 0
+        seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * (rank + 1)) & 0xFFFFFFFFFFFFFFFF
+        return _hip.philox_noise(uniform_shape, normal_shape, seed, self.step_t, device)
+
     def close(self):
         """Releases the library context (at most 31 live ones), the packed-weight cache and the per-context Python
         state.  Idempotent; __del__ calls it, but a loop that builds many TrainSteps should call it itself (a
@@ -144,6 +157,9 @@ class TrainStep(object):
         if getattr(self, '_wcache', None) is not None:
             _lib.call('gx_weight_cache_destroy', self._wcache)
             self._wcache = None
+        if getattr(self, '_noise_owner', None) is not None:
+            self._noise_owner.noise = None
+            self._noise_owner = None
         ctx = getattr(self, '_ctx', 0)
         if ctx > 0:
             self._ctx = 0

@@ -229,6 +229,11 @@ int gx_conv1x1_gn_wgrad_finish(const float* wpart, const float* bpart, int N, in
 int gx_adam_step(void* p, const void* g, void* m, void* v, size_t n, int is_f64, int64_t* step, double lr,
                  double beta1, double beta2, double eps, float grad_scale, gx_stream_t stream);
 int gx_step_increment(int64_t* step, gx_stream_t stream);
+/*      the step's noise (torch.rand for the IC-SBP's rand_pixel, modules/attention.py:177-178; torch.randn for the latents'
+ *      rsample, models/genesisv2_config.py:157) in one launch: Philox4x32-10 keyed by (seed, *step, position), nu uniform [0, 1)
+ *      numbers into u and nz standard normals into z; a replayed HIP graph draws fresh numbers every step. */
+int gx_philox_noise(float* u, long long nu, float* z, long long nz, unsigned long long seed, const int64_t* step,
+                    gx_stream_t stream);
 int gx_geco_update(float* state, const float* err, float goal, float step_size, float alpha, float speedup,
                    int use_speedup, float beta_min, float beta_max, gx_stream_t stream);
 /*      The tail of a training step in two launches: gx_geco_update_step = gx_geco_update + gx_step_increment;

@@ -1396,3 +1396,33 @@ def test_conv3x3_weight_gradient_with_four_images_per_tile(N, H, W):
     out = torch.full((32, 32, 3, 3), 7.0, device=DEV)
     hip.conv3x3_wgrad_quad(x.to(DEV), dy.to(DEV), out=out)
     assert torch.equal(out, dw)
+
+
+def test_philox_noise_is_a_function_of_seed_step_and_position():
+    """gx_philox_noise: the training step's rand_pixel (uniform [0, 1)) and eps (standard normal) from one counter-based launch --
+    moments and tails of 2^22 draws, reproducible for one (seed, step), different for another step / seed, and the two tensors
+    of one call are different streams."""
+    from genesis_amd import hip_ops as hip
+    step = torch.zeros((), dtype=torch.int64, device=DEV)
+    n = 1 << 22
+    u, z = hip.philox_noise((n,), (n + 3,), 1234, step)
+    u2, z2 = hip.philox_noise((n,), (n + 3,), 1234, step)
+    assert torch.equal(u, u2) and torch.equal(z, z2)
+    assert float(u.min()) >= 0.0 and float(u.max()) < 1.0
+    assert abs(float(u.double().mean()) - 0.5) < 1e-3 and abs(float(u.double().var()) - 1.0 / 12) < 1e-3
+    hist = torch.histc(u, bins=64, min=0.0, max=1.0) / n
+    assert float((hist - 1.0 / 64).abs().max()) < 5e-4
+    zd = z.double()
+    assert abs(float(zd.mean())) < 2e-3 and abs(float(zd.var()) - 1.0) < 3e-3
+    assert abs(float((zd ** 3).mean())) < 1e-2 and abs(float((zd ** 4).mean()) - 3.0) < 3e-2
+    assert 4.0 < float(zd.abs().max()) < 6.5 and bool(torch.isfinite(z).all())
+    assert abs(float((zd.abs() > 1.959964).double().mean()) - 0.05) < 1e-3
+    assert abs(float(torch.corrcoef(torch.stack((zd[:-1], zd[1:])))[0, 1])) < 2e-3       # neighbours (a Box-Muller pair) uncorrelated
+    assert abs(float(torch.corrcoef(torch.stack((u.double(), zd[:n])))[0, 1])) < 2e-3     # the two tensors are different streams
+    step.add_(1)
+    u3, z3 = hip.philox_noise((n,), (n + 3,), 1234, step)
+    u4, _ = hip.philox_noise((n,), None, 1235, step)
+    assert not torch.equal(u3, u) and not torch.equal(z3, z) and not torch.equal(u4, u3)
+    assert abs(float(torch.corrcoef(torch.stack((u.double(), u3.double())))[0, 1])) < 2e-3
+    ue, ze = hip.philox_noise((5,), (2, 3), 7, None)           # ragged ends of the 4-wide calls, no step pointer
+    assert ue.shape == (5,) and ze.shape == (2, 3) and bool(torch.isfinite(ze).all())
