@@ -2066,8 +2066,26 @@ static int conv3x3_fwd_impl(const float* x, const float* w, const float* bias, i
     return GX_OK;
 }
 
+static int conv3x3_dgrad_impl(const float* dy, const float* w, float* dx, int N, int Cin, int Cout, int H, int W, void* ws,
+                              size_t ws_bytes, gx_stream_t stream, const float** parts_out, int* nsplit_out);
+
 int gx_conv3x3_dgrad(const float* dy, const float* w, float* dx, int N, int Cin, int Cout, int H, int W,
                      void* ws, size_t ws_bytes, gx_stream_t stream) {
+    return conv3x3_dgrad_impl(dy, w, dx, N, Cin, Cout, H, W, ws, ws_bytes, stream, nullptr, nullptr);
+}
+
+/* ... without the split-K reduce launch: *parts = dx (nsplit 1) or the partial slabs inside ws, *split_stride = N Cin H W floats
+ * apart; the consumer (gx_gn_relu_bwd_parts) sums them on load in slab order.  The slabs live in the caller's workspace. */
+int gx_conv3x3_dgrad_parts(const float* dy, const float* w, float* dx, int N, int Cin, int Cout, int H, int W, void* ws,
+                           size_t ws_bytes, const float** parts, int* nsplit, size_t* split_stride, gx_stream_t stream) {
+    GX_CHECK_ARG(parts && nsplit && split_stride, "gx_conv3x3_dgrad_parts: null out-parameter");
+    *split_stride = (size_t)N * Cin * H * W;
+    return conv3x3_dgrad_impl(dy, w, dx, N, Cin, Cout, H, W, ws, ws_bytes, stream, parts, nsplit);
+}
+
+static int conv3x3_dgrad_impl(const float* dy, const float* w, float* dx, int N, int Cin, int Cout, int H, int W, void* ws,
+                              size_t ws_bytes, gx_stream_t stream, const float** parts_out, int* nsplit_out) {
+    if (parts_out) { *parts_out = dx; *nsplit_out = 1; }
     int rc = check_dims("gx_conv3x3_dgrad", N, Cin, Cout, H, W);
     if (rc) return rc;
     GX_CHECK_ARG(dy && w && dx && ws, "gx_conv3x3_dgrad: null pointer");
@@ -2103,6 +2121,10 @@ int gx_conv3x3_dgrad(const float* dy, const float* w, float* dx, int N, int Cin,
     if (rc) return rc;
     rc = launch_tapconv<M_C3>(dy, wpu, nullptr, pl.g.nsplit > 1 ? part : dx, pl, s, "gx_conv3x3_dgrad");
     if (rc) return rc;
+    if (parts_out && pl.g.nsplit > 1) {       // the consumer sums the split-K slabs itself
+        *parts_out = part; *nsplit_out = pl.g.nsplit;
+        return GX_OK;
+    }
     if (pl.g.nsplit > 1) return launch_splitk_reduce(part, nullptr, dx, pl, s);
     return GX_OK;
 }

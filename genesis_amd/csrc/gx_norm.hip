@@ -29,6 +29,8 @@ struct View {
     const float* proj;   // mode 3: the 1x1 conv weight [ctot, C]
     int projC;           // mode 3: C (row length of proj)
     const float* pgate;  // mode 3: optional device scalar multiplying the conv output (SemiConv gate), or null
+    int nsplit;          // gradient source, modes 0-2: the buffer is still `nsplit` split-K partial slabs (a data gradient whose
+    size_t sstride;      //   reduce launch was skipped), `sstride` floats apart, summed on load in slab order; 0 / 1: a plain tensor
 };
 
 // Input of the forward kernels: the conv output, possibly still as `nsplit` split-K partial slabs (summed here in
@@ -84,15 +86,27 @@ __device__ __forceinline__ void store_view(const View& v, int n, int c, int r, i
 
 __device__ __forceinline__ float load_view(const View& v, int n, int c, int r, int col, int H, int W) {
     if (v.mode == 0) {
-        return v.ptr[(((size_t)n * v.ctot + v.c0 + c) * H + r) * W + col];
+        const float* p = v.ptr + (((size_t)n * v.ctot + v.c0 + c) * H + r) * W + col;
+        float o = *p;
+        for (int z = 1; z < v.nsplit; ++z) o += p[(size_t)z * v.sstride];
+        return o;
     } else if (v.mode == 1) {
         const float* p = v.ptr + (((size_t)n * v.ctot + v.c0 + c) * (2 * H) + 2 * r) * (2 * W) + 2 * col;
-        const float2 a = *reinterpret_cast<const float2*>(p);
-        const float2 b = *reinterpret_cast<const float2*>(p + 2 * W);
+        float2 a = *reinterpret_cast<const float2*>(p);
+        float2 b = *reinterpret_cast<const float2*>(p + 2 * W);
+        for (int z = 1; z < v.nsplit; ++z) {      // (the slabs first, then the 2 x 2 sum: the order of the stand-alone reduce)
+            const float2 a2 = *reinterpret_cast<const float2*>(p + (size_t)z * v.sstride);
+            const float2 b2 = *reinterpret_cast<const float2*>(p + (size_t)z * v.sstride + 2 * W);
+            a.x += a2.x; a.y += a2.y; b.x += b2.x; b.y += b2.y;
+        }
         return (a.x + a.y) + (b.x + b.y);
     } else if (v.mode == 2) {
-        if (((r | col) & 1) == 0)
-            return v.ptr[(((size_t)n * v.ctot + v.c0 + c) * (H >> 1) + (r >> 1)) * (W >> 1) + (col >> 1)];
+        if (((r | col) & 1) == 0) {
+            const float* p = v.ptr + (((size_t)n * v.ctot + v.c0 + c) * (H >> 1) + (r >> 1)) * (W >> 1) + (col >> 1);
+            float o = *p;
+            for (int z = 1; z < v.nsplit; ++z) o += p[(size_t)z * v.sstride];
+            return o;
+        }
         return 0.f;
     } else {
         float s = 0.f;
@@ -149,11 +163,18 @@ __device__ __forceinline__ void store_view4(const View& v, int n, int c, int r, 
 __device__ __forceinline__ f32x4 load_view4(const View& v, int n, int c, int r, int col, int H, int W) {
     f32x4 o;
     if (v.mode == 0) {
-        o = *reinterpret_cast<const f32x4*>(v.ptr + (((size_t)n * v.ctot + v.c0 + c) * H + r) * W + col);
+        const float* p = v.ptr + (((size_t)n * v.ctot + v.c0 + c) * H + r) * W + col;
+        o = *reinterpret_cast<const f32x4*>(p);
+        for (int z = 1; z < v.nsplit; ++z) o += *reinterpret_cast<const f32x4*>(p + (size_t)z * v.sstride);
     } else if (v.mode == 1) {
         const float* p = v.ptr + (((size_t)n * v.ctot + v.c0 + c) * (2 * H) + 2 * r) * (2 * W) + 2 * col;
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(p), a1 = *reinterpret_cast<const f32x4*>(p + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p + 2 * W), b1 = *reinterpret_cast<const f32x4*>(p + 2 * W + 4);
+        f32x4 a0 = *reinterpret_cast<const f32x4*>(p), a1 = *reinterpret_cast<const f32x4*>(p + 4);
+        f32x4 b0 = *reinterpret_cast<const f32x4*>(p + 2 * W), b1 = *reinterpret_cast<const f32x4*>(p + 2 * W + 4);
+        for (int z = 1; z < v.nsplit; ++z) {
+            const float* q = p + (size_t)z * v.sstride;
+            a0 += *reinterpret_cast<const f32x4*>(q); a1 += *reinterpret_cast<const f32x4*>(q + 4);
+            b0 += *reinterpret_cast<const f32x4*>(q + 2 * W); b1 += *reinterpret_cast<const f32x4*>(q + 2 * W + 4);
+        }
         o[0] = (a0[0] + a0[1]) + (b0[0] + b0[1]);
         o[1] = (a0[2] + a0[3]) + (b0[2] + b0[3]);
         o[2] = (a1[0] + a1[1]) + (b1[0] + b1[1]);
@@ -161,8 +182,12 @@ __device__ __forceinline__ f32x4 load_view4(const View& v, int n, int c, int r, 
     } else if (v.mode == 2) {
         o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f;
         if ((r & 1) == 0) {
-            const float2 t = *reinterpret_cast<const float2*>(
-                v.ptr + (((size_t)n * v.ctot + v.c0 + c) * (H >> 1) + (r >> 1)) * (W >> 1) + (col >> 1));
+            const float* p = v.ptr + (((size_t)n * v.ctot + v.c0 + c) * (H >> 1) + (r >> 1)) * (W >> 1) + (col >> 1);
+            float2 t = *reinterpret_cast<const float2*>(p);
+            for (int z = 1; z < v.nsplit; ++z) {
+                const float2 t2 = *reinterpret_cast<const float2*>(p + (size_t)z * v.sstride);
+                t.x += t2.x; t.y += t2.y;
+            }
             o[0] = t.x; o[2] = t.y;
         }
     } else {
@@ -1159,9 +1184,19 @@ int gx_gn_relu_bwd(const float* y, const float* gamma, const float* beta, const 
                    int N, int C, int H, int W, int groups, const float* g0, int g0_ctot, int g0_c0, int g0_mode,
                    const float* g1, int g1_ctot, int g1_c0, int g1_mode, float* dy, float* dgamma, float* dbeta,
                    float* dbias, void* ws, size_t ws_bytes, gx_stream_t stream) {
+    return gx_gn_relu_bwd_parts(y, gamma, beta, mean, rstd, N, C, H, W, groups, g0, g0_ctot, g0_c0, g0_mode, 1, 0, g1, g1_ctot,
+                                g1_c0, g1_mode, 1, 0, dy, dgamma, dbeta, dbias, ws, ws_bytes, stream);
+}
+
+int gx_gn_relu_bwd_parts(const float* y, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                         int N, int C, int H, int W, int groups, const float* g0, int g0_ctot, int g0_c0, int g0_mode,
+                         int g0_nsplit, size_t g0_split_stride, const float* g1, int g1_ctot, int g1_c0, int g1_mode,
+                         int g1_nsplit, size_t g1_split_stride, float* dy, float* dgamma, float* dbeta, float* dbias, void* ws,
+                         size_t ws_bytes, gx_stream_t stream) {
     GX_CHECK_ARG(g0, "gx_gn_relu_bwd: null pointer");
-    View v0{const_cast<float*>(g0), g0_ctot, g0_c0, g0_mode, nullptr, 0, nullptr},
-         v1{const_cast<float*>(g1), g1_ctot, g1_c0, g1_mode, nullptr, 0, nullptr};
+    GX_CHECK_ARG(g0_nsplit >= 1 && g1_nsplit >= 1, "gx_gn_relu_bwd_parts: nsplit >= 1");
+    View v0{const_cast<float*>(g0), g0_ctot, g0_c0, g0_mode, nullptr, 0, nullptr, g0_nsplit, g0_split_stride},
+         v1{const_cast<float*>(g1), g1_ctot, g1_c0, g1_mode, nullptr, 0, nullptr, g1_nsplit, g1_split_stride};
     int rc = check_view("gx_gn_relu_bwd", v0, C);
     if (rc) return rc;
     if (g1) { rc = check_view("gx_gn_relu_bwd", v1, C); if (rc) return rc; }

@@ -304,7 +304,8 @@ class UNetEncoderFn(torch.autograd.Function):
             dy, dgamma, dbeta, _ = hip.gn_relu_bwd(y, gamma, beta, mean, rstd, ctx.ngroups(y.shape[1]), gsrc,
                                                    out=(og, ob, None))
             dw = _wgrad(lambda cj=cats[j], dy=dy, ow=ow: hip.conv3x3_wgrad(cj, dy, out=ow), ow, cats[j], dy)
-            dcat[j] = hip.conv3x3_dgrad(dy, w)
+            # (read by GroupNorm backward kernels only -- they sum split-K slabs on load; dcat[0] also feeds the MLP)
+            dcat[j] = hip.conv3x3_dgrad_parts(dy, w) if j > 0 else hip.conv3x3_dgrad(dy, w)
             g_up[j] = (_ret(ow, dw), _ret(og, dgamma), _ret(ob, dbeta))
             gsrc = (dcat[j], 0, 1)   # block j-1's output was 2x up-sampled into cat_j[:, :Cx]
         # MLP backward
@@ -339,7 +340,7 @@ class UNetEncoderFn(torch.autograd.Function):
             dw = _wgrad(lambda cur=cur, dy=dy, ow=ow: hip.conv3x3_wgrad(cur, dy, out=ow), ow, cur, dy)
             g_down[i] = (_ret(ow, dw), _ret(og, dgamma), _ret(ob, dbeta))
             if i > 0:
-                d_next = hip.conv3x3_dgrad(dy, w)
+                d_next = hip.conv3x3_dgrad_parts(dy, w)
             elif ctx.needs_input_grad[0]:
                 dx = hip.conv3x3_dgrad(dy, w)
         flat = []

@@ -112,6 +112,26 @@ def conv3x3_dgrad(dy, w):
     return dx
 
 
+def conv3x3_dgrad_parts(dy, w):
+    """conv3x3_dgrad without the split-K reduce launch: a tensor, or (the small layers, whose channel reduction is split to
+    fill the chip) a Parts object for gn_relu_bwd's gradient sources (gx_conv3x3_dgrad_parts)."""
+    if not FUSE_SPLITK_INTO_GN:
+        return conv3x3_dgrad(dy, w)
+    _chk(dy, 'conv3x3_dgrad.dy'); _chk(w, 'conv3x3_dgrad.w')
+    N, Cout, H, W = dy.shape
+    Cin = w.shape[1]
+    assert w.shape == (Cout, Cin, 3, 3)
+    dx = torch.empty(N, Cin, H, W, dtype=F32, device=dy.device)
+    nb = _lib.query('gx_conv3x3_ws_bytes', N, Cin, Cout, H, W)
+    ws = _ws(nb, dy.device)
+    parts, nsplit, stride = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_size_t()
+    _lib.call('gx_conv3x3_dgrad_parts', _p(dy), _p(w), _p(dx), N, Cin, Cout, H, W, _p(ws), nb, ctypes.byref(parts),
+              ctypes.byref(nsplit), ctypes.byref(stride), _stream())
+    if nsplit.value == 1:
+        return dx
+    return Parts(parts.value, nsplit.value, stride.value, (N, Cin, H, W), (ws, dx))
+
+
 def conv3x3_wgrad(x, dy, out=None):
     _chk(x, 'conv3x3_wgrad.x'); _chk(dy, 'conv3x3_wgrad.dy')
     N, Cin, H, W = x.shape
@@ -192,6 +212,26 @@ def _view_args(v, name):
     buf, c0, mode = v
     _chk(buf, name)
     return [_p(buf), int(buf.shape[1]), int(c0), int(mode)]
+
+
+class Parts(object):
+    """A data gradient that is still `nsplit` split-K partial slabs (conv3x3_dgrad_parts): only gn_relu_bwd reads it (it sums
+    the slabs on load, in slab order); keeps the workspace that holds the slabs alive."""
+    __slots__ = ('ptr', 'nsplit', 'stride', 'shape', 'keep')
+
+    def __init__(self, ptr, nsplit, stride, shape, keep):
+        self.ptr, self.nsplit, self.stride, self.shape, self.keep = ptr, nsplit, stride, shape, keep
+
+
+def _view_args_p(v, name):
+    """v = (tensor | Parts, c0, mode) or None -> (ptr, ctot, c0, mode, nsplit, split stride)."""
+    if v is None:
+        return [None, 0, 0, 0, 1, 0]
+    buf, c0, mode = v
+    if isinstance(buf, Parts):
+        return [ctypes.c_void_p(buf.ptr), int(buf.shape[1]), int(c0), int(mode), int(buf.nsplit), int(buf.stride)]
+    _chk(buf, name)
+    return [_p(buf), int(buf.shape[1]), int(c0), int(mode), 1, 0]
 
 
 def gn_relu_fwd(y, gamma, beta, groups, eps, dst0, dst1=None):
@@ -288,8 +328,8 @@ def gn_relu_bwd(y, gamma, beta, mean, rstd, groups, g0, g1=None, want_dbias=Fals
     ws = _ws(nb, y.device)
     direct = o[0] is not None and o[1] is not None and (not want_dbias or o[2] is not None)
     with _deferring(direct, ws):
-        _lib.call('gx_gn_relu_bwd', _p(y), _p(gamma), _p(beta), _p(mean), _p(rstd), N, C, H, W, groups,
-                  *(_view_args(g0, 'gn_bwd.g0') + _view_args(g1, 'gn_bwd.g1')), _p(dy), _p(dgamma), _p(dbeta),
+        _lib.call('gx_gn_relu_bwd_parts', _p(y), _p(gamma), _p(beta), _p(mean), _p(rstd), N, C, H, W, groups,
+                  *(_view_args_p(g0, 'gn_bwd.g0') + _view_args_p(g1, 'gn_bwd.g1')), _p(dy), _p(dgamma), _p(dbeta),
                   _p(dbias), _p(ws), nb, _stream())
     return dy, dgamma, dbeta, dbias
 

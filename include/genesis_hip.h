@@ -40,6 +40,8 @@ int gx_conv3x3_fwd(const float* x, const float* w, float* y, int N, int Cin, int
                    void* ws, size_t ws_bytes, gx_stream_t stream);
 int gx_conv3x3_dgrad(const float* dy, const float* w, float* dx, int N, int Cin, int Cout, int H, int W,
                      void* ws, size_t ws_bytes, gx_stream_t stream);
+int gx_conv3x3_dgrad_parts(const float* dy, const float* w, float* dx, int N, int Cin, int Cout, int H, int W, void* ws,
+                           size_t ws_bytes, const float** parts, int* nsplit, size_t* split_stride, gx_stream_t stream);
 size_t gx_conv3x3_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W);
 int gx_conv3x3_wgrad(const float* x, const float* dy, float* dw, int N, int Cin, int Cout, int H, int W,
                      void* ws, size_t ws_bytes, gx_stream_t stream);
@@ -136,6 +138,14 @@ int gx_gn_relu_bwd(const float* y, const float* gamma, const float* beta, const 
                    int N, int C, int H, int W, int groups, const float* g0, int g0_ctot, int g0_c0, int g0_mode,
                    const float* g1, int g1_ctot, int g1_c0, int g1_mode, float* dy, float* dgamma, float* dbeta,
                    float* dbias, void* ws, size_t ws_bytes, gx_stream_t stream);
+/*      ..._parts: a gradient source (modes 0-2) may still be the `nsplit` split-K partial slabs of the data gradient that
+ *      produced it (gx_conv3x3_dgrad_parts), `split_stride` floats apart: summed on load in slab order -- the stand-alone
+ *      reduce launch of the <= 16 x 16 layers is skipped. */
+int gx_gn_relu_bwd_parts(const float* y, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                         int N, int C, int H, int W, int groups, const float* g0, int g0_ctot, int g0_c0, int g0_mode,
+                         int g0_nsplit, size_t g0_split_stride, const float* g1, int g1_ctot, int g1_c0, int g1_mode,
+                         int g1_nsplit, size_t g1_split_stride, float* dy, float* dgamma, float* dbeta, float* dbias, void* ws,
+                         size_t ws_bytes, gx_stream_t stream);
 int gx_gn_relu_bwd_proj(const float* y, const float* gamma, const float* beta, const float* mean, const float* rstd,
                         int N, int C, int H, int W, int groups, const float* g_out, int Cout, const float* w,
                         const float* gate, float* dy, float* dgamma, float* dbeta, float* dbias, float* wpart,
