@@ -155,8 +155,14 @@ prior_logp_bwd_kernel(const float* __restrict__ z, const float* __restrict__ lin
 // out = (loss = err_mean + beta kl_mean, elbo = err_mean + kl_mean, err_mean, kl_mean, beta)
 __global__ void __launch_bounds__(256)
 elbo_fwd_kernel(const float* __restrict__ err, const float* __restrict__ kl, const float* __restrict__ beta,
-                int B, int R, float* __restrict__ out, float* __restrict__ tail, float* __restrict__ loss) {
+                int B, int R, float* __restrict__ out, float* __restrict__ tail, float* __restrict__ loss,
+                float* __restrict__ d_err = nullptr, float* __restrict__ d_kl = nullptr) {
     __shared__ double red[2][4];
+    if (d_err) {        // the objective's gradients for a unit upstream gradient (the training step's loss.backward())
+        const float ge = 1.f / B, gk = *beta / B;
+        for (int i = threadIdx.x; i < B; i += blockDim.x) d_err[i] = ge;
+        if (d_kl) for (int i = threadIdx.x; i < R * B; i += blockDim.x) d_kl[i] = gk;
+    }
     double se = 0.0, sk = 0.0;
     for (int i = threadIdx.x; i < B; i += blockDim.x) se += (double)err[i];
     for (int i = threadIdx.x; i < R * B; i += blockDim.x) sk += (double)kl[i];
@@ -381,6 +387,21 @@ int gx_elbo_fwd(const float* err, const float* kl, const float* beta, int B, int
         hipLaunchKernelGGL(elbo_fwd_kernel, dim3(1), dim3(256), 0, s, err, kl, beta, B, R, out, tail, loss);
     }
     GX_CHECK_LAUNCH("gx_elbo_fwd");
+    return GX_OK;
+}
+
+/* gx_elbo_fwd that also writes d loss / d err [B] = 1 / B and d loss / d kl [R,B] = beta / B (the gradients gx_elbo_bwd gives for
+ * an upstream gradient of one): a training step starts its backward pass from them and needs no second launch. */
+int gx_elbo_fwd_grads(const float* err, const float* kl, const float* beta, int B, int R, float* out, float* tail,
+                      float* loss, float* d_err, float* d_kl, gx_stream_t stream) {
+    GX_CHECK_ARG(err && beta && out && d_err, "gx_elbo_fwd_grads: null pointer");
+    GX_CHECK_ARG(B > 0 && R >= 0 && (R == 0 || (kl && d_kl)), "gx_elbo_fwd_grads: bad B/R (%d,%d) or missing kl / d_kl", B, R);
+    hipStream_t s = (hipStream_t)stream;
+    {
+        GxProf pf(KID_LATENT, s, 0.0, 8.0 * (B + (double)R * B));
+        hipLaunchKernelGGL(elbo_fwd_kernel, dim3(1), dim3(256), 0, s, err, kl, beta, B, R, out, tail, loss, d_err, d_kl);
+    }
+    GX_CHECK_LAUNCH("gx_elbo_fwd_grads");
     return GX_OK;
 }
 

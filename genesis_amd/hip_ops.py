@@ -836,6 +836,18 @@ def elbo_fwd(err, kl, beta, tail=None):
     return loss, out
 
 
+def elbo_fwd_grads(err, kl, beta, tail=None):
+    """elbo_fwd plus (d_err [B], d_kl [R,B] | None) for a unit upstream gradient, one launch (gx_elbo_fwd_grads)."""
+    _chk(err, 'elbo.err'); _chk(kl, 'elbo.kl'); _chk(beta, 'elbo.beta'); _chk(tail, 'elbo.tail')
+    B = err.numel()
+    R = 0 if kl is None else kl.numel() // B
+    out = torch.empty(5, dtype=F32, device=err.device)
+    d_err = torch.empty_like(err)
+    d_kl = torch.empty_like(kl) if kl is not None else None
+    _lib.call('gx_elbo_fwd_grads', _p(err), _p(kl), _p(beta), B, R, _p(out), _p(tail), None, _p(d_err), _p(d_kl), _stream())
+    return out, d_err, d_kl
+
+
 def elbo_bwd(g_loss, beta, B, R):
     _chk(g_loss, 'elbo_bwd.g')
     d_err = torch.empty(B, dtype=F32, device=g_loss.device)

@@ -202,10 +202,14 @@ class TrainStep(object):
             kl_rows = rows[0] if len(rows) == 1 else torch.cat(rows, 0)
         if fused:
             # one launch: batch means, the GECO-weighted objective, and (err, kl) straight into the bucket tail
-            loss, out5 = _fn.ElboFn.apply(losses.err, kl_rows, beta_t, self.bucket.flat_g[self.n32:self.n32 + 2])
-            if getattr(self, '_one', None) is None or self._one.shape != loss.shape:
-                self._one = torch.ones_like(loss)
-            torch.autograd.backward([loss], [self._one])      # (no ones_like fill launch per step)
+            # (the objective is linear in err / kl: its gradients 1 / B and beta / B come out of the same launch and the
+            #  backward pass starts from them -- no autograd node, no second launch)
+            err_c = losses.err.contiguous()
+            kl_c = kl_rows.contiguous() if kl_rows is not None else None
+            with torch.no_grad():
+                out5, d_err, d_kl = _hip.elbo_fwd_grads(err_c, kl_c, beta_t, self.bucket.flat_g[self.n32:self.n32 + 2])
+            roots = [(t, g) for t, g in ((err_c, d_err), (kl_c, d_kl)) if t is not None and t.requires_grad]
+            torch.autograd.backward([t for t, _ in roots], [g for _, g in roots])
             beta_used = out5.detach()
         else:
             err = losses.err.mean(0)

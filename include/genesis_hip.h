@@ -442,6 +442,9 @@ int gx_latent_prior_sample_ex(const float* lin, const float* eps, int B, int D, 
  *      piggy-backed scalars; loss (NULL to skip) receives out[0] again (a separate one-element objective tensor).  bwd: d_err[b] = g/B, d_kl[r][b] = g beta / B for the scalar g = dL/d loss. */
 int gx_elbo_fwd(const float* err, const float* kl, const float* beta, int B, int R, float* out, float* tail,
                 float* loss, gx_stream_t stream);
+/*      gx_elbo_fwd + the gradients gx_elbo_bwd returns for an upstream gradient of one, in one launch */
+int gx_elbo_fwd_grads(const float* err, const float* kl, const float* beta, int B, int R, float* out, float* tail,
+                      float* loss, float* d_err, float* d_kl, gx_stream_t stream);
 int gx_elbo_bwd(const float* g_loss, const float* beta, int B, int R, float* d_err, float* d_kl,
                 gx_stream_t stream);
 
