@@ -321,7 +321,10 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
         constexpr int TAPB = QHLay<MODE>::TAPB;
         constexpr int NWH = (MAXT * (TAPB / 16) + 255) / 256;              // 16-byte weight pieces per thread per phase
         constexpr int WSLOTB = NWH * 256 * 16;                             // bytes per weight buffer
-        const int plane_bytes = NQ * 256 * 16;                             // bytes per input piece plane
+        // four staging rounds (the 64-pixel-wide tiles of a 64 x 64 base grid: 6 x 66 halo positions): exact planes, so that three
+        // of them + the weight buffers still leave room for two workgroups per CU
+        constexpr bool TRIM = NQ == 4 && MODE != Q_C3H;
+        const int plane_bytes = TRIM ? 2 * CHS * 16 : NQ * 256 * 16;       // bytes per input piece plane
         char* const ibuf = reinterpret_cast<char*>(lds);
         char* const wbufb = ibuf + 3 * plane_bytes;
         const int quad_l = lane >> 5;
@@ -359,9 +362,11 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
                     ph_[e] = h_; pm_[e] = m_; pl_[e] = (__bf16)(r1_ - (float)m_);                      \
                 }                                                                                      \
                 char* d_ = ibuf + (tid + q * 256) * 16;                                                \
+                if (!TRIM || tid + q * 256 < 2 * CHS) {                                                \
                 *reinterpret_cast<q_bf16x8*>(d_) = ph_;                                                \
                 *reinterpret_cast<q_bf16x8*>(d_ + plane_bytes) = pm_;                                  \
                 *reinterpret_cast<q_bf16x8*>(d_ + 2 * plane_bytes) = pl_;                              \
+                }                                                                                      \
             }                                                                                          \
         }
 #define GX_QH_LOAD_W(sc_, ph_)                                                                         \
@@ -892,19 +897,29 @@ static bool kq_h_on() {
 size_t gx_kq_deconv_h_pack_bytes(int K, int M, int nt) {     // one row parity's packed weights (+ slack: whole-phase copies)
     return (size_t)gx_ceil_div(M, 64) * (K / 16) * nt * QH_TAP_BYTES + 16384;
 }
+// LDS of the bf16-pipe transposed-conv kernels: three input piece planes (exact at four staging rounds) + two weight buffers;
+// 0: the tile does not leave room for two workgroups per CU
+static size_t qh_lds(const QGeom& g, int nq) {
+    constexpr int NWH = (3 * (QH_TAP_BYTES / 16) + 255) / 256;
+    const int CHS = (1 << g.lG) * ((1 << g.lTH) + 2) * ((1 << g.lTW) + 2);
+    const size_t planes = nq == 4 ? (size_t)3 * 2 * CHS * 16 : (size_t)3 * nq * 256 * 16;
+    const size_t lds = planes + (size_t)2 * NWH * 256 * 16;
+    static const char* env = getenv("GENESIS_KQ_H_NQ4");           // 0: shapes with four staging rounds stay on the fp32 pipe
+    if (nq == 4 && env && env[0] == '0') return 0;
+    return lds <= 80 * 1024 ? lds : 0;
+}
 bool gx_kq_deconv_h_eligible(int N, int K, int M, int Hb, int Wb) {
     if (!kq_h_on() || K % 16 != 0 || !gx_kq_deconv_eligible(N, K, M, Hb, Wb, 2)) return false;
     QGeom g; int nq; size_t lds;
-    return q_plan(N, K, M, Hb, Wb, Hb, Wb, 2 * Hb, 2 * Wb, &g, &nq, &lds, 5) && nq == 3;
+    return q_plan(N, K, M, Hb, Wb, Hb, Wb, 2 * Hb, 2 * Wb, &g, &nq, &lds, 5) && qh_lds(g, nq) > 0;
 }
 int gx_kq_deconv_fwd_h_launch(const float* in, const float* wp0, const float* wp1, const float* bias, float* out, int N,
                               int K, int M, int Hb, int Wb, float* stats, int* stats_parts, hipStream_t s) {
     QGeom g; int nq; size_t lds;
-    if (!q_plan(N, K, M, Hb, Wb, Hb, Wb, 2 * Hb, 2 * Wb, &g, &nq, &lds, 5) || nq != 3 || K % 16 != 0) {
+    if (!q_plan(N, K, M, Hb, Wb, Hb, Wb, 2 * Hb, 2 * Wb, &g, &nq, &lds, 5) || qh_lds(g, nq) == 0 || K % 16 != 0) {
         gx_set_error("kq deconv fwd (bf16 pipe): shape not eligible"); return GX_EINVAL;
     }
-    constexpr int NWH = (3 * (QH_TAP_BYTES / 16) + 255) / 256;
-    lds = (size_t)3 * nq * 256 * 16 + (size_t)2 * NWH * 256 * 16;          // three input piece planes + two weight buffers
+    lds = qh_lds(g, nq);
     const bool st = stats && g.lG == 0 && (M % 8) == 0;
     if (stats_parts) *stats_parts = 0;
     if (st) {
@@ -917,9 +932,11 @@ int gx_kq_deconv_fwd_h_launch(const float* in, const float* wp0, const float* wp
     {
         GxProf pf(KID_KQ_DTH, s, 2.0 * N * (double)M * K * 25 * Hb * Wb,
                   4.0 * ((double)N * K * Hb * Wb + (double)N * M * 4 * Hb * Wb + 25.0 * K * M));
-        static bool a[2] = {false, false};
-        if (st) { q_set_attr(&kq_dth_kernel<3, true>, &a[0]); hipLaunchKernelGGL((kq_dth_kernel<3, true>), grid, dim3(256), lds, s, in, wp0, wp1, bias, out, g); }
-        else { q_set_attr(&kq_dth_kernel<3, false>, &a[1]); hipLaunchKernelGGL((kq_dth_kernel<3, false>), grid, dim3(256), lds, s, in, wp0, wp1, bias, out, g); }
+        static bool a[4] = {false, false, false, false};
+        if (nq == 3 && st) { q_set_attr(&kq_dth_kernel<3, true>, &a[0]); hipLaunchKernelGGL((kq_dth_kernel<3, true>), grid, dim3(256), lds, s, in, wp0, wp1, bias, out, g); }
+        else if (nq == 3) { q_set_attr(&kq_dth_kernel<3, false>, &a[1]); hipLaunchKernelGGL((kq_dth_kernel<3, false>), grid, dim3(256), lds, s, in, wp0, wp1, bias, out, g); }
+        else if (st) { q_set_attr(&kq_dth_kernel<4, true>, &a[2]); hipLaunchKernelGGL((kq_dth_kernel<4, true>), grid, dim3(256), lds, s, in, wp0, wp1, bias, out, g); }
+        else { q_set_attr(&kq_dth_kernel<4, false>, &a[3]); hipLaunchKernelGGL((kq_dth_kernel<4, false>), grid, dim3(256), lds, s, in, wp0, wp1, bias, out, g); }
     }
     GX_CHECK_LAUNCH("kq deconv fwd (bf16 pipe)");
     return GX_OK;
@@ -982,24 +999,23 @@ int gx_kq_c3h_launch(const float* in, const float* wp, const float* bias, int ac
 bool gx_kq_deconv_dgrad_h_eligible(int N, int K, int M, int Hb, int Wb) {
     if (!kq_h_on() || K % 16 != 0 || !gx_kq_deconv_eligible(N, K, M, Hb, Wb, 1)) return false;
     QGeom g; int nq; size_t lds;
-    return q_plan(N, K, M, Hb, Wb, 2 * Hb, 2 * Wb, Hb, Wb, &g, &nq, &lds, 9) && nq == 3;
+    return q_plan(N, K, M, Hb, Wb, 2 * Hb, 2 * Wb, Hb, Wb, &g, &nq, &lds, 9) && qh_lds(g, nq) > 0;
 }
 int gx_kq_deconv_dgrad_h_launch(const float* dy, const float* wp, float* dx, int N, int K, int M, int Hb, int Wb,
                                 hipStream_t s) {
     QGeom g; int nq; size_t lds;
-    if (!q_plan(N, K, M, Hb, Wb, 2 * Hb, 2 * Wb, Hb, Wb, &g, &nq, &lds, 9) || nq != 3 || K % 16 != 0) {
+    if (!q_plan(N, K, M, Hb, Wb, 2 * Hb, 2 * Wb, Hb, Wb, &g, &nq, &lds, 9) || qh_lds(g, nq) == 0 || K % 16 != 0) {
         gx_set_error("kq deconv dgrad (bf16 pipe): shape not eligible"); return GX_EINVAL;
     }
-    constexpr int NWH = (3 * (QH_TAP_BYTES / 16) + 255) / 256;
-    lds = (size_t)3 * nq * 256 * 16 + (size_t)2 * NWH * 256 * 16;
+    lds = qh_lds(g, nq);
     dim3 grid(1, gx_ceil_div(M, 64));
     g.nfull = q_split_tail(g.tiles_h * g.tiles_w * gx_ceil_div(N, 1 << g.lG), M, &grid.x);
     {
         GxProf pf(KID_KQ_DGH, s, 2.0 * N * (double)M * K * 25 * Hb * Wb,
                   4.0 * ((double)N * K * 4 * Hb * Wb + (double)N * M * Hb * Wb + 25.0 * K * M));
-        static bool a3 = false;
-        q_set_attr(&kq_dgh_kernel<3>, &a3);
-        hipLaunchKernelGGL((kq_dgh_kernel<3>), grid, dim3(256), lds, s, dy, wp, dx, g);
+        static bool a3 = false, a4 = false;
+        if (nq == 3) { q_set_attr(&kq_dgh_kernel<3>, &a3); hipLaunchKernelGGL((kq_dgh_kernel<3>), grid, dim3(256), lds, s, dy, wp, dx, g); }
+        else { q_set_attr(&kq_dgh_kernel<4>, &a4); hipLaunchKernelGGL((kq_dgh_kernel<4>), grid, dim3(256), lds, s, dy, wp, dx, g); }
     }
     GX_CHECK_LAUNCH("kq deconv dgrad (bf16 pipe)");
     return GX_OK;

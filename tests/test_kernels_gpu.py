@@ -834,7 +834,8 @@ def test_deconv_epilogue_groupnorm_statistics(N, Cin, Cout, Hin):
 
 
 @pytest.mark.parametrize('N,Cin,Cout,Hin', [(56, 64, 64, 32), (70, 64, 64, 32), (224, 64, 64, 16), (60, 32, 64, 32),
-                                            (56, 64, 40, 32), (52, 48, 72, 32)])
+                                            (56, 64, 40, 32), (52, 48, 72, 32),
+                                            (13, 64, 64, 64), (16, 32, 64, 64)])      # 64 x 64 base (cfg 5): four staging rounds, exact LDS planes
 def test_transposed_conv_on_the_bf16_pipe_keeps_fp32_accuracy(N, Cin, Cout, Hin):
     """gx_kq_precision: chip-filling transposed-conv forward layers run on the bf16 matrix pipe (fp32 products from six
     bf16 piece products; input split once by the staging, weights by the pack) or on the fp32 pipe.  Both against
