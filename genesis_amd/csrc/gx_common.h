@@ -186,4 +186,4 @@ int gx_wgq_c5(const float* a, const float* b, float* dw, int N, int CA, int CB, 
 int gx_wgq_pending(void);
 void gx_wgq_discard(void);
 int gx_wgq_flush(hipStream_t s);
-int gx_wgrad_reduce_now(const GxWgradRed& r, hipStream_t s);    // gx_conv.hip: dw = sum of the slabs (overwrites)
+int gx_wgrad_reduce_now(const GxWgradRed& r, hipStream_t s, int accumulate = 0);    // gx_conv.hip: dw (+)= sum of the slabs

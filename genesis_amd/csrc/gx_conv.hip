@@ -1135,7 +1135,7 @@ wgrad_quad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ 
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int nsplit_all,
                     int Ttot, int CA, int CB, int CApad, int CBpad, int layout, int ns0, int ns1, int ns2, int ns3,
-                    int ca0 = 0, int cb0 = 0, int CAf = 0, int CBf = 0) {
+                    int ca0 = 0, int cb0 = 0, int CAf = 0, int CBf = 0, int accumulate = 0) {
     __shared__ float red[4][64];
     const int total = Ttot * CA * CB;
     const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -1167,8 +1167,9 @@ wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, i
     if (grp == 0 && idx < total) {
         const float r = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
         if (!CAf) { CAf = CA; CBf = CB; }
-        if (layout == 0) dw[((size_t)(ca0 + ca) * CBf + cb0 + cb) * Ttot + t] = r;
-        else dw[((size_t)(cb0 + cb) * CAf + ca0 + ca) * Ttot + t] = r;
+        float* d = layout == 0 ? dw + ((size_t)(ca0 + ca) * CBf + cb0 + cb) * Ttot + t
+                               : dw + ((size_t)(cb0 + cb) * CAf + ca0 + ca) * Ttot + t;
+        *d = accumulate ? *d + r : r;
     }
 }
 
@@ -1729,7 +1730,7 @@ wgrad_smallcin_kernel(const float* __restrict__ x, const float* __restrict__ dy,
 // dw[co][ci][tap] = sum over blocks; one workgroup per output channel: 32 columns x 32 block groups, four loads in
 // flight per thread (with 8 groups and one running sum a thread walked 64 dependent-latency loads: 20 us)
 __global__ void __launch_bounds__(1024)
-wgrad_smallcin_reduce_kernel(const float* __restrict__ pw, int nblk, int Cout, int J, float* __restrict__ dw) {
+wgrad_smallcin_reduce_kernel(const float* __restrict__ pw, int nblk, int Cout, int J, float* __restrict__ dw, int accumulate) {
     __shared__ float red[32][32];
     const int co = blockIdx.x;
     const int j = threadIdx.x & 31, grp = threadIdx.x >> 5;
@@ -1750,7 +1751,7 @@ wgrad_smallcin_reduce_kernel(const float* __restrict__ pw, int nblk, int Cout, i
         float t = red[0][j];
 #pragma unroll
         for (int g2 = 1; g2 < 32; ++g2) t += red[g2][j];
-        dw[(size_t)co * J + j] = t;
+        dw[(size_t)co * J + j] = accumulate ? dw[(size_t)co * J + j] + t : t;      // (deferral on: ADD, like the queued reductions)
     }
     (void)Cout;
 }
@@ -1867,13 +1868,13 @@ int gx_defer_flush_wgrad(const GxWgradRed* items, int n, hipStream_t s) {
     return GX_OK;
 }
 
-int gx_wgrad_reduce_now(const GxWgradRed& r, hipStream_t s) {
+int gx_wgrad_reduce_now(const GxWgradRed& r, hipStream_t s, int accumulate) {
     const int total = r.Ttot * r.CA * r.CB;
     {
         GxProf pf(KID_WGRAD_REDUCE, s, 0.0, 4.0 * ((double)r.nsplit + 1.0) * total);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx_ceil_div(total, 64)), dim3(256), 0, s, r.partial, r.dw, r.nsplit,
                            r.Ttot, r.CA, r.CB, r.CApad, r.CBpad, r.layout, r.ns0, r.ns1, r.ns2, r.ns3, r.ca0, r.cb0, r.CAf,
-                           r.CBf);
+                           r.CBf, accumulate);
     }
     GX_CHECK_LAUNCH("wgrad_reduce");
     return GX_OK;
@@ -2160,8 +2161,10 @@ int gx_conv3x3_wgrad(const float* x, const float* dy, float* dw, int N, int Cin,
         GX_CHECK_LAUNCH("gx_conv3x3_wgrad(small Cin)");
         {
             GxProf pf(KID_WGRAD_REDUCE, s, 0.0, 4.0 * nblk * mt * 64 * 32);
+            // while deferral is on every weight-gradient call ADDS to its (zeroed) destination -- a shared parameter's
+            // second use must not overwrite the first (include/genesis_hip.h, gx_defer_enable)
             hipLaunchKernelGGL(wgrad_smallcin_reduce_kernel, dim3(Cout), dim3(1024), 0, s, (const float*)ws, nblk, Cout,
-                               Cin * 9, dw);
+                               Cin * 9, dw, g_gx_defer_on ? 1 : 0);
         }
         GX_CHECK_LAUNCH("gx_conv3x3_wgrad(small Cin reduce)");
         return GX_OK;

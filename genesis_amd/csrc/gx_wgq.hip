@@ -1397,15 +1397,18 @@ static int wgq_run_or_queue(std::vector<PendingJob>& jobs, hipStream_t s) {
         for (PendingJob& p : jobs) g_jobs.push_back(p);
         return GX_OK;
     }
-    if (wgq_stream_on()) {                      // immediate: the layer alone on the chip, then its reductions (overwrite dw)
+    // immediate.  Deferral on but no queue (zero16 unavailable: a first call inside a stream capture): the reduce ADDS, as
+    // the queued one would -- the destination is a zeroed bucket and a shared parameter may be on its second use.
+    const int acc = g_gx_defer_on ? 1 : 0;
+    if (wgq_stream_on()) {                      // the layer alone on the chip, then its reductions
         std::vector<PendingJob*> ptrs;
         for (PendingJob& p : jobs) ptrs.push_back(&p);
         std::vector<GxWgradRed> recs;
         int rc = wgq_launch_stream(ptrs, s, recs);
-        for (size_t i = 0; i < recs.size() && rc == GX_OK; ++i) rc = gx_wgrad_reduce_now(recs[i], s);
+        for (size_t i = 0; i < recs.size() && rc == GX_OK; ++i) rc = gx_wgrad_reduce_now(recs[i], s, acc);
         return rc;
     }
-    // immediate: each (cls) job is its own launch with the whole chip; then the reduce record
+    // each (cls) job is its own launch with the whole chip; then the reduce record
     int rc = GX_OK;
     for (PendingJob& p : jobs) {
         std::vector<PendingJob*> one{&p};
@@ -1417,7 +1420,7 @@ static int wgq_run_or_queue(std::vector<PendingJob>& jobs, hipStream_t s) {
                  0, 0, 0, 0};
     if (jobs.size() == 2) { r.ns0 = r.ns1 = jobs[0].job.nsplit; r.ns2 = r.ns3 = jobs[1].job.nsplit;
                             r.nsplit = r.ns0 > r.ns2 ? r.ns0 : r.ns2; }
-    return gx_wgrad_reduce_now(r, s);          // overwrites dw (the deferred batch reduce accumulates)
+    return gx_wgrad_reduce_now(r, s, acc);     // overwrites dw unless deferral is on (the deferred batch reduce accumulates)
 }
 
 // conv3x3: dw [Cout][Cin][3][3] from x [N,Cin,H,W], dy [N,Cout,H,W]; ws holds gx_wgq_max_split slabs

@@ -49,12 +49,12 @@ class TrainStep(object):
         self.step_t = torch.zeros((), dtype=torch.int64, device=self.device)
         # the step's noise (rand_pixel, eps) from one counter-based launch keyed by (torch's seed + rank, the step counter)
         # instead of torch.rand + torch.randn and their graph-RNG bookkeeping (GENESIS_HIP_NOISE=0: torch's generators)
-        self._noise_owner = None
-        if os.environ.get('GENESIS_HIP_NOISE', '1') != '0' and hasattr(model, 'noise'):
-            import weakref
-            me = weakref.ref(self)            # (no reference cycle model -> TrainStep -> model: __del__ frees the context)
-            model.noise = lambda u, z, dev: me()._draw_noise(u, z, dev)
-            self._noise_owner = model
+        # The hook is on the model only WHILE an iteration of this loop runs (_enter .. _leave): validation / visualisation
+        # forwards between two steps draw fresh torch.rand / randn like the reference's (they would otherwise all see the
+        # next training step's noise), torch.save(model) keeps working, and two loops on one model cannot clear each
+        # other's hook.
+        self._hip_noise = os.environ.get('GENESIS_HIP_NOISE', '1') != '0' and hasattr(model, 'noise')
+        self._noise_hook = None           # (set only inside an iteration: no reference cycle self -> bound method -> self)
         self.graph = None
         self.graph2 = None
         self._split = False
@@ -103,8 +103,18 @@ class TrainStep(object):
         _hip.defer_state().on = self.defer_reduces
         st.async_wgrad = self.async_wgrad
         st.side_prior = self.side_prior
+        if self._hip_noise:
+            self._noise_prev = self.model.__dict__.get('noise')
+            self._noise_hook = self._draw_noise
+            self.model.noise = self._noise_hook
 
     def _leave(self):
+        if self._noise_hook is not None and self.model.__dict__.get('noise') is self._noise_hook:
+            if getattr(self, '_noise_prev', None) is not None:
+                self.model.noise = self._noise_prev
+            else:
+                del self.model.noise            # back to the class attribute (None): torch's generators
+        self._noise_prev = self._noise_hook = None
         _lib.make_current(self._ctx)     # (an exception may have left another context current)
         st = _fn.step_state()
         st.direct_param_grads = False
@@ -157,9 +167,7 @@ class TrainStep(object):
         if getattr(self, '_wcache', None) is not None:
             _lib.call('gx_weight_cache_destroy', self._wcache)
             self._wcache = None
-        if getattr(self, '_noise_owner', None) is not None:
-            self._noise_owner.noise = None
-            self._noise_owner = None
+        self._noise_hook = None
         ctx = getattr(self, '_ctx', 0)
         if ctx > 0:
             self._ctx = 0
@@ -185,7 +193,9 @@ class TrainStep(object):
         recon, losses, stats, att_stats, comp_stats = self.model(x, **forward_kwargs)
         # loss aggregation of train.py:226-242 (every model family: kl_m | kl_m_k, kl_l | kl_l_k)
         beta_t = self.geco.state[0:1] if self.geco is not None else self._beta_fixed_t.view(1)
-        keys = [k for k in ('kl_m', 'kl_m_k', 'kl_l', 'kl_l_k') if k in losses]
+        # (if / elif per stage like the reference: a model returning both forms of a term must not be counted twice)
+        keys = [k for k in (('kl_m' if 'kl_m' in losses else 'kl_m_k'), ('kl_l' if 'kl_l' in losses else 'kl_l_k'))
+                if k in losses]
         # every KL term as rows [R_i, B]: sum_k mean_b is the same for the rows of all terms stacked on top of each other,
         # so one ElboFn launch serves MONet (kl_m + kl_l_k) and GENESIS (kl_m_k + kl_l_k) too
         fused, rows = losses.err.dim() == 1, []
@@ -196,6 +206,9 @@ class TrainStep(object):
                 if v is None:
                     fused = False
                     break
+            if v.dim() == 0 or v.numel() % losses.err.shape[0] != 0:
+                fused = False                                # (a scalar / oddly shaped KL: the plain aggregation below)
+                break
             rows.append(v.reshape(-1, losses.err.shape[0]))
         kl_rows = None
         if fused and rows:
@@ -209,7 +222,8 @@ class TrainStep(object):
             with torch.no_grad():
                 out5, d_err, d_kl = _hip.elbo_fwd_grads(err_c, kl_c, beta_t, self.bucket.flat_g[self.n32:self.n32 + 2])
             roots = [(t, g) for t, g in ((err_c, d_err), (kl_c, d_kl)) if t is not None and t.requires_grad]
-            torch.autograd.backward([t for t, _ in roots], [g for _, g in roots])
+            if roots:
+                torch.autograd.backward([t for t, _ in roots], [g for _, g in roots])
             beta_used = out5.detach()
         else:
             err = losses.err.mean(0)
@@ -284,11 +298,16 @@ class TrainStep(object):
         self._split = self._needs_collective()
         self.collective_in_graph = False
         # (only RCCL enqueues on the captured stream; a gloo collective inside a capture invalidates it for good)
-        if self._split and os.environ.get('GENESIS_GRAPH_ALLREDUCE', '1') != '0' and dist.get_backend(self.pg) == 'nccl':
-            # several ranks, first choice: the collective INSIDE the one graph (RCCL enqueues on the captured stream): no
-            # host round trip between backward and optimiser.  If this ROCm / RCCL cannot capture it, fall back to the
-            # two-graph form below.
+        # Several ranks: the default is the two-graph form below -- forward+backward | collective | GECO+Adam, three
+        # enqueue-only calls per step, no host synchronisation, valid on any RCCL.  GENESIS_GRAPH_ALLREDUCE=1 asks for the
+        # collective INSIDE the one graph (RCCL enqueues on the captured stream; saves two launch latencies): every rank
+        # attempts the capture, then the ranks agree (all-reduce MIN of a success flag, outside any capture) -- the
+        # in-graph form is used only if EVERY rank captured it, otherwise every rank takes the two-graph form, so the
+        # ranks can never issue different collective sequences.
+        want = os.environ.get('GENESIS_GRAPH_ALLREDUCE', '1' if self.world == 1 else '0') != '0'
+        if self._split and want and dist.get_backend(self.pg) == 'nccl':
             self._gscale = 1.0 / self.world
+            g, ok = None, 1
             try:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode='thread_local'):
@@ -302,11 +321,21 @@ class TrainStep(object):
                             self._out = self._update(st, self._gscale)
                     finally:
                         self._end()
-                self.graph, self._split, self.collective_in_graph = g, False, True
             except Exception as e:          # noqa: BLE001  (whatever the capture raised: the split form is always valid)
                 self.capture_fallback_reason = '%s: %s' % (type(e).__name__, str(e)[:200])
+                ok = 0
                 torch.cuda.synchronize()
                 self._grads_clean = False
+            if self.world > 1:
+                flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
+                if ok and int(flag.item()) == 0:
+                    self.capture_fallback_reason = 'another rank could not capture the collective'
+                ok = int(flag.item())
+            if ok:
+                self.graph, self._split, self.collective_in_graph = g, False, True
+            else:
+                del g
         if self.collective_in_graph:
             pass
         elif not self._split:

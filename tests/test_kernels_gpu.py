@@ -1427,3 +1427,29 @@ def test_philox_noise_is_a_function_of_seed_step_and_position():
     assert abs(float(torch.corrcoef(torch.stack((u.double(), u3.double())))[0, 1])) < 2e-3
     ue, ze = hip.philox_noise((5,), (2, 3), 7, None)           # ragged ends of the 4-wide calls, no step pointer
     assert ue.shape == (5,) and ze.shape == (2, 3) and bool(torch.isfinite(ze).all())
+
+
+@pytest.mark.parametrize('N,Cin,Cout,S', [(4, 3, 64, 64), (3, 3, 32, 32), (4, 64, 64, 32), (2, 40, 24, 16)])
+def test_deferred_weight_gradients_of_a_shared_parameter_accumulate(N, Cin, Cout, S):
+    """While gx_defer_enable(1) is in effect every conv3x3 weight-gradient call ADDS into its (zeroed) destination
+    (include/genesis_hip.h): a weight used twice in one iteration -- a shared UNet -- ends with the SUM of both uses, also on
+    the small-Cin kernel (Cin x 9 <= 32, e.g. a 3-channel input layer), whose reduce used to overwrite."""
+    from genesis_amd import _lib
+    xs = [rnd(N, Cin, S, S, seed=70 + i).to(DEV) for i in range(2)]
+    dys = [rnd(N, Cout, S, S, seed=80 + i).to(DEV) for i in range(2)]
+    ref = sum(torch.nn.grad.conv2d_weight(x.cpu().double(), (Cout, Cin, 3, 3), dy.cpu().double(), padding=1)
+              for x, dy in zip(xs, dys))
+    out = torch.zeros(Cout, Cin, 3, 3, device=DEV)
+    st = hip.defer_state()
+    st.on = True
+    try:
+        for x, dy in zip(xs, dys):
+            hip.conv3x3_wgrad(x, dy, out=out)
+        hip.defer_flush()
+    finally:
+        st.on = False
+    close(out, ref, rtol=2e-5, atol=1e-6 * float(ref.abs().max()), msg='two deferred uses')
+    # deferral off: a call overwrites (the plain entry-point contract)
+    hip.conv3x3_wgrad(xs[0], dys[0], out=out)
+    one = torch.nn.grad.conv2d_weight(xs[0].cpu().double(), (Cout, Cin, 3, 3), dys[0].cpu().double(), padding=1)
+    close(out, one, rtol=2e-5, atol=1e-6 * float(one.abs().max()), msg='plain call overwrites')

@@ -78,11 +78,11 @@ def test_graph_replay_matches_eager():
         outs.append((torch.stack(vals).cpu(), ts.flat_p.clone().cpu(), float(ts.geco.beta)))
     (a, pa, ba), (b, pb, bb) = outs
     assert torch.isfinite(a).all() and torch.isfinite(b).all()
-    # the RNG streams differ between capture and eager (philox offsets), so compare statistically stable
-    # quantities: the reconstruction error dominates the ELBO and barely depends on the noise at init
-    np.testing.assert_allclose(a[:, 1].numpy(), b[:, 1].numpy(), rtol=2e-2)
-    assert abs(ba - bb) <= 1e-3 * abs(ba)
-    assert float((pa - pb).abs().max()) < 5e-3
+    # the step's noise is one counter-based launch keyed by (torch's seed, rank, the step counter) -- the same values whether
+    # the launch is issued eagerly or replayed from the graph -- and eager and replay run the same kernels in the same order:
+    # losses and parameters agree to fp32 round-off (measured: bit-identical)
+    print('graph vs eager: max |d out| %.3e, max |d param| %.3e' % (float((a - b).abs().max()), float((pa - pb).abs().max())))
+    assert torch.equal(a, b) and ba == bb and torch.equal(pa, pb)
 
 
 def test_prepare_captures_without_advancing_state():
@@ -307,3 +307,31 @@ def test_replay_after_an_aborted_eager_iteration():
     clean, dirty = run(False), run(True)
     for a, b in zip(clean, dirty):
         assert torch.equal(a, b)
+
+
+def test_noise_hook_lives_only_inside_an_iteration():
+    """TrainStep's Philox source is on the model only while one of its iterations runs: forwards between two steps draw
+    fresh torch.rand / randn like the reference's (models/genesisv2_config.py:157, modules/attention.py:177-178) -- two
+    validation forwards differ from each other and do not replay the next training step's noise --, the model pickles, and
+    closing an older loop does not take a newer loop's source away."""
+    import io
+    from genesis_amd.trainer import TrainStep
+    gold = Golden('tiny')
+    x, _, _ = gold.inputs()
+    xd = x.to(DEV)
+    model = build(gold)
+    ts = TrainStep(model, gold.S)
+    assert model.noise is None and 'noise' not in model.__dict__
+    ts.step(xd)
+    assert model.noise is None and 'noise' not in model.__dict__
+    with torch.no_grad():
+        z1 = torch.stack(list(model(xd)[4]['z_k']))
+        z2 = torch.stack(list(model(xd)[4]['z_k']))
+    assert not torch.equal(z1, z2)                           # fresh draws per call
+    torch.save(model, io.BytesIO())                          # no lambda attribute in the way
+    # the step's noise is still the keyed one: two loops from the same state take the same step
+    ts2 = TrainStep(model, gold.S)
+    ts.close()                                               # the older loop goes away ...
+    out = ts2.step(xd)                                       # ... the newer one still draws from its Philox source
+    assert torch.isfinite(out).all() and model.noise is None
+    ts2.close()
