@@ -92,10 +92,8 @@ def pmc_traffic(kernel, tag=''):
     """HBM bytes per launch of the kernels behind profiling id `kernel` from the committed PMC passes (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate runs of this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM');
     None if absent."""
-    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
-    path = next((p_ for p_ in (os.path.join(here, 'r03_pmc_hbm_traffic.json'), os.path.join(here, 'r02_pmc_hbm_traffic.json'))
-                 if os.path.exists(p_)), None)
-    if path is None or tag != '':          # the PMC passes exist for the default workload only
+    path = newest_profile('%spmc_hbm_traffic.json' % (tag or ''))
+    if path is None or tag is None:
         return None, None
     data = json.load(open(path))
     syms = tuple(s_.replace(',', '') for s_ in KID_SYMBOLS.get(kernel, (kernel,)))
@@ -123,16 +121,22 @@ KID_SYMBOLS = {
 }
 
 
+def newest_profile(suffix):
+    """profiles/rNN_<suffix> of the latest round that has one (None if none)."""
+    import glob
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
+    cands = sorted(p_ for p_ in glob.glob(os.path.join(here, 'r[0-9][0-9]_' + suffix)))
+    return cands[-1] if cands else None
+
+
 def rocprof_avg_us(kid_name, tag=''):
     """Average launch duration of the kernels behind a profiling id in the committed rocprofv3 --kernel-trace --stats
-    summary of this same command (profiles/r03_[<model>_]rocprofv3_kernel_stats.csv); None if absent or if this run is not
+    summary of this same command (profiles/rNN_[<model>_]rocprofv3_kernel_stats.csv, latest round); None if absent or if this run is not
     the workload the summary was taken on (tag None)."""
     import csv
-    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles')
     if tag is None:
         return None, None
-    cands = ['r03_%srocprofv3_kernel_stats.csv' % tag] + (['r02_rocprofv3_kernel_stats.csv'] if tag == '' else [])
-    path = next((p_ for p_ in (os.path.join(here, c_) for c_ in cands) if os.path.exists(p_)), None)
+    path = newest_profile('%srocprofv3_kernel_stats.csv' % tag)
     syms = KID_SYMBOLS.get(kid_name)
     if path is None or not syms:
         return None, None
@@ -232,10 +236,18 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    # GENESIS_BENCH_REHEARSAL=1: the N-rank code path (rendezvous, shard seeds, split graphs around the collective, barriers,
+    # max-over-ranks timing, the JSON line) with every rank on GPU 0 and gloo carrying the bucket -- RCCL refuses two ranks on
+    # one device.  A rehearsal of the launch on a 1-GPU box (tests/test_bench_gpu.py), marked as such, never a measurement.
+    rehearsal = bool(os.environ.get('GENESIS_BENCH_REHEARSAL'))
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     if world > 1 or os.environ.get('GENESIS_FORCE_ALLREDUCE'):
-        dist.init_process_group('nccl', init_method='env://', device_id=device)   # binds the communicator to this GPU
+        if rehearsal:
+            dist.init_process_group('gloo', init_method='env://')
+        else:
+            dist.init_process_group('nccl', init_method='env://', device_id=device)   # binds the communicator to this GPU
 
     from genesis_amd.trainer import TrainStep
     from genesis_amd import profiling
@@ -271,6 +283,28 @@ def main():
     dt = float(tmax)
     elbo = float(out[0])
 
+    # a longer window of the SAME loop (SURVEY.md 8d asks for >= 100 timed steps; the driver's command times 20): every rank
+    # runs it (the collective inside the step needs all of them), bracketed like the timed region; reported as
+    # `steady_state`, never as `value`
+    long_steps = int(os.environ.get('GENESIS_BENCH_LONG_STEPS', '200'))
+    dt_long = None
+    if long_steps > args.steps:
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(long_steps):
+            ts.step(batches[i % 4])
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        tl = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+        dt_long = float(tl)
+
     result = None
     if rank == 0:
         value = world * args.batch * args.steps / dt
@@ -293,12 +327,18 @@ def main():
                        if ts.graph is not None else 'eager'},
             'final_elbo': elbo,
         }
+        if dt_long is not None:
+            result['steady_state'] = {'value': world * args.batch * long_steps / dt_long, 'unit': 'images/sec', 'steps': long_steps,
+                                      'ms_per_step': 1e3 * dt_long / long_steps,
+                                      'note': 'the same loop over a longer window, after the timed region (max over ranks)'}
         if os.environ.get('GENESIS_WGQ_BF16X6', '1') != '0':
             result['arithmetic'] = ('fp32 tensors and fp32 accumulation everywhere; the weight gradients and the chip-filling '
                                     'transposed-conv forward / data-gradient layers form every fp32 product from six bf16 piece '
                                     'products on the bf16 matrix pipe (hi+mid+lo pieces hold all 24 mantissa bits: error vs '
                                     'fp64 as on the fp32 pipe, tests/test_kernels_gpu.py *_bf16_pipe_*); everything else on the '
                                     'fp32 pipe; GENESIS_WGQ_BF16X6=0 GENESIS_KQ_BF16X6=0 put all of it back there')
+        if rehearsal:
+            result['rehearsal'] = 'all %d ranks on ONE GPU, gloo collective: exercises the launch path only, not a measurement' % world
         if getattr(ts, 'capture_fallback_reason', None):
             result['config']['collective_capture_fallback'] = ts.capture_fallback_reason
         if dist.is_initialized():
@@ -361,27 +401,35 @@ def main():
                                          'pipe; peak = 2.25 x %.1f' % PEAK_FP32_MFMA_TFLOPS)
                     roof['achieved_on_mfma_pipe'] = ach / 2.25
                 roof['frac'] = ach / mfma_peak
+                # the plain formula: algorithmic flops / time / the peak of the tensors' NATIVE pipe (fp32 MFMA, 157.3 TF/s).
+                # It exceeds 1 where the algorithm executes fewer multiplies than the direct sum (Winograd) or where the fp32
+                # products are formed on the faster bf16 pipe; `frac` above is against the ceiling of what is executed.
+                roof['frac_plain'] = ach / PEAK_FP32_MFMA_TFLOPS
                 roof['frac_of_fp32_pipe'] = ach / PEAK_FP32_MFMA_TFLOPS
             else:
                 ach = dom['bytes'] / sec / 1e9
                 roof = {'bound': 'hbm', 'kernel': dom['name'], 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                        'frac': ach / PEAK_HBM_GBS, 'frac_of_fp32_pipe': None}
+                        'frac': ach / PEAK_HBM_GBS, 'frac_plain': ach / PEAK_HBM_GBS, 'frac_of_fp32_pipe': None}
             roof['avg_launch_us'] = 1e3 * dom['ms'] / dom['launches']
             roof['share_of_kernel_time'] = dom['ms'] / total_ms
             return roof
 
-        dom = rows[0]
+        # the dominant kernel by share of the step's kernel time; families within 10 % of the largest share are a tie (they
+        # swap places from run to run), broken by the larger algorithmic work -- a static property of the workload
+        tied = [r_ for r_ in rows if r_['ms'] >= 0.9 * rows[0]['ms']]
+        dom = max(tied, key=lambda r_: (r_['flops'], r_['bytes'], r_['name']))
         roof = roof_of(dom)
         ach = roof['achieved']
         # the other large kernels of the step, same arithmetic (the dominant one changes from run to run when two are close)
         roof_top = [{k_: v_ for k_, v_ in roof_of(r_).items() if k_ in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac',
-                                                                            'avg_launch_us', 'share_of_kernel_time')}
+                                                                            'frac_plain', 'avg_launch_us', 'share_of_kernel_time')}
                     for r_ in rows[:6]]
         # numbers that are NOT of this run: read from the committed rocprofv3 / PMC passes of the same command
         # (only for the workload they were taken on: the default shape of each model family, no forced collective)
-        default_shape = args.K == 7 and args.img == 64 and args.batch == 32 and args.feat_dim == 64 and world == 1 and \
-            not os.environ.get('GENESIS_FORCE_ALLREDUCE')
-        ptag = None if not default_shape else ('' if args.model == 'genesisv2' else args.model + '_')
+        plain = args.feat_dim == 64 and world == 1 and not os.environ.get('GENESIS_FORCE_ALLREDUCE')
+        shape = (args.model, args.K, args.img, args.batch)
+        ptag = {('genesisv2', 7, 64, 32): '', ('genesisv2', 5, 64, 64): 'cfg2_', ('genesisv2', 11, 128, 32): 'cfg5_',
+                ('monet', 7, 64, 32): 'monet_', ('genesis', 7, 64, 32): 'genesis_', ('vae', 7, 64, 32): 'vae_'}.get(shape) if plain else None
         rp, rp_file = rocprof_avg_us(dom['name'], ptag)
         tr, tr_file = pmc_traffic(dom['name'], ptag)
         committed = {}
@@ -412,7 +460,7 @@ def main():
         from genesis_amd.feeder import DeviceFeeder
         ts.use_graph = True
         n_warm = 40            # the host has to get ~30 graph launches ahead of the device before the rate is steady
-        n_seg = 3              # the host thread of a shared 256-CPU box is pre-empted now and then: best of three segments
+        n_seg = 3              # the host thread of a shared 256-CPU box is pre-empted now and then: the MEDIAN of three segments
         n_host = n_seg * args.host_input_steps + n_warm
         gh = torch.Generator().manual_seed(99)
         frames = [torch.randint(0, 256, (args.batch, args.img, args.img, 3), generator=gh, dtype=torch.uint8)
@@ -428,10 +476,10 @@ def main():
                 ts.step(next(feeder))
             torch.cuda.synchronize()
             rates.append(args.batch * args.host_input_steps / (time.perf_counter() - t0))
-        result['pcie_inclusive'] = {'value': max(rates), 'unit': 'images/sec',
+        result['pcie_inclusive'] = {'value': sorted(rates)[len(rates) // 2], 'best_segment': max(rates), 'unit': 'images/sec',
                                     'steps': args.host_input_steps, 'segments': rates,
                                     'input': 'uint8 HWC frames in host memory -> pinned staging -> async copy one batch '
-                                             'ahead -> one uint8->fp32 NCHW launch (genesis_amd/feeder.py); best of %d '
+                                             'ahead -> one uint8->fp32 NCHW launch (genesis_amd/feeder.py); median of %d '
                                              'segments of %d steps' % (n_seg, args.host_input_steps)}
 
     # ---- fp32-pipe-only leg: the same step with the bf16-pipe kernels (six bf16 piece products per fp32 product) switched

@@ -266,6 +266,128 @@ lstm_step_bwd_kernel(const float* __restrict__ g_h, const float* __restrict__ dg
     }
 }
 
+
+// ---- y[M,N] = x[M,K] w[K,N], K small (a latent size), N large: one thread owns four consecutive columns and MR rows; w is
+// read with coalesced 16-byte loads (once per MR rows of x), the x values are wave-uniform (scalar loads)
+constexpr int kNN_MR = 8;
+__global__ void __launch_bounds__(256)
+matmul_nn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int M, int N, int K) {
+    const int n0 = (blockIdx.y * 256 + threadIdx.x) * 4;
+    const int m0 = blockIdx.x * kNN_MR;
+    if (n0 >= N) return;
+    float4 acc[kNN_MR];
+#pragma unroll
+    for (int r = 0; r < kNN_MR; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* xr[kNN_MR];
+#pragma unroll
+    for (int r = 0; r < kNN_MR; ++r) xr[r] = x + (size_t)(m0 + r < M ? m0 + r : M - 1) * K;     // (rows past the end: not stored)
+    for (int k = 0; k < K; ++k) {
+        const float4 w4 = *reinterpret_cast<const float4*>(w + (size_t)k * N + n0);
+#pragma unroll
+        for (int r = 0; r < kNN_MR; ++r) {
+            const float xv = xr[r][k];
+            acc[r].x = fmaf(xv, w4.x, acc[r].x); acc[r].y = fmaf(xv, w4.y, acc[r].y);
+            acc[r].z = fmaf(xv, w4.z, acc[r].z); acc[r].w = fmaf(xv, w4.w, acc[r].w);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < kNN_MR; ++r)
+        if (m0 + r < M) *reinterpret_cast<float4*>(y + (size_t)(m0 + r) * N + n0) = acc[r];
+}
+
+// dw[K,N] = sum_m x[m,k] g[m,n]: a thread owns four columns and KC rows of dw; g is read coalesced (K / KC times), x scalar
+constexpr int kNN_KC = 16;
+__global__ void __launch_bounds__(256)
+matmul_nn_dw_kernel(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ dw, int M, int N, int K) {
+    const int n0 = (blockIdx.y * 256 + threadIdx.x) * 4;
+    const int k0 = blockIdx.x * kNN_KC;
+    if (n0 >= N) return;
+    float4 acc[kNN_KC];
+#pragma unroll
+    for (int r = 0; r < kNN_KC; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int m = 0; m < M; ++m) {
+        const float4 g4 = *reinterpret_cast<const float4*>(g + (size_t)m * N + n0);
+        const float* xm = x + (size_t)m * K;
+#pragma unroll
+        for (int r = 0; r < kNN_KC; ++r) {
+            const float xv = xm[k0 + r < K ? k0 + r : K - 1];
+            acc[r].x = fmaf(xv, g4.x, acc[r].x); acc[r].y = fmaf(xv, g4.y, acc[r].y);
+            acc[r].z = fmaf(xv, g4.z, acc[r].z); acc[r].w = fmaf(xv, g4.w, acc[r].w);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < kNN_KC; ++r)
+        if (k0 + r < K) *reinterpret_cast<float4*>(dw + (size_t)(k0 + r) * N + n0) = acc[r];
+}
+
+// dx[M,K] = sum_n g[m,n] w[k,n]: the long sum over N is cut into `nchunk` contiguous column ranges (blockIdx.x); a block owns a
+// 32 x 64 tile of (m, k) (blockIdx.y: row tile, blockIdx.z: k tile), stages 64 columns of g and w at a time in LDS (coalesced
+// loads) and every thread accumulates a 2 x 4 register tile; partial[chunk][M][K] is summed by matmul_nn_dx_reduce_kernel in
+// chunk order
+__global__ void __launch_bounds__(256)
+matmul_nn_dx_kernel(const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ part, int M, int N, int K,
+                    int cols_per_chunk) {
+    __shared__ float gs[32][68], ws[64][68];
+    const int t = threadIdx.x;
+    const int m0 = blockIdx.y * 32, k0 = blockIdx.z * 64;
+    const int c_begin = blockIdx.x * cols_per_chunk;
+    const int c_end = c_begin + cols_per_chunk < N ? c_begin + cols_per_chunk : N;
+    const int mi = (t >> 4) * 2, ki = (t & 15) * 4;
+    float acc[2][4] = {};
+    for (int c0 = c_begin; c0 < c_end; c0 += 64) {
+        // stage: 32 x 64 of g, 64 x 64 of w (16 float4 per row)
+        for (int e = t; e < 32 * 16; e += 256) {
+            const int r = e >> 4, q = (e & 15) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m0 + r < M && c0 + q < c_end) v = *reinterpret_cast<const float4*>(g + (size_t)(m0 + r) * N + c0 + q);
+            *reinterpret_cast<float4*>(&gs[r][q]) = v;
+        }
+        for (int e = t; e < 64 * 16; e += 256) {
+            const int r = e >> 4, q = (e & 15) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k0 + r < K && c0 + q < c_end) v = *reinterpret_cast<const float4*>(w + (size_t)(k0 + r) * N + c0 + q);
+            *reinterpret_cast<float4*>(&ws[r][q]) = v;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int c = 0; c < 64; c += 4) {
+            float4 a[2], b[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const float4*>(&gs[mi + i][c]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const float4*>(&ws[ki + j][c]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = fmaf(a[i].x, b[j].x, fmaf(a[i].y, b[j].y, fmaf(a[i].z, b[j].z, fmaf(a[i].w, b[j].w, acc[i][j]))));
+        }
+        __syncthreads();
+    }
+    float* o = part + (size_t)blockIdx.x * M * K;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (m0 + mi + i < M && k0 + ki + j < K) o[(size_t)(m0 + mi + i) * K + k0 + ki + j] = acc[i][j];
+}
+
+__global__ void __launch_bounds__(256)
+matmul_nn_dx_reduce_kernel(const float* __restrict__ part, float* __restrict__ dx, int MK, int nchunk) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= MK) return;
+    float s0 = 0.f, s1 = 0.f;
+    int c = 0;
+    for (; c + 1 < nchunk; c += 2) { s0 += part[(size_t)c * MK + i]; s1 += part[(size_t)(c + 1) * MK + i]; }
+    if (c < nchunk) s0 += part[(size_t)c * MK + i];
+    dx[i] = s0 + s1;
+}
+
+inline int matmul_nn_chunks(int N) {
+    const int tiles = gx_ceil_div(N, 64);
+    return tiles < 128 ? tiles : 128;
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline int dense_threads(int Kc) { return Kc >= 1024 ? 1024 : 256; }
 
@@ -368,6 +490,58 @@ int gx_linear_bwd_ex(const float* x, int ldx, const float* w, const float* y, co
 int gx_linear_bwd(const float* x, const float* w, const float* y, const float* g, int act, float* dx, float* dw,
                   float* db, int M, int N, int K, gx_stream_t stream) {
     return gx_linear_bwd_ex(x, K, w, y, g, N, act, dx, K, 0, dw, db, nullptr, M, N, K, stream);
+}
+
+int gx_matmul_nn_fwd(const float* x, const float* w, float* y, int M, int N, int K, gx_stream_t stream) {
+    GX_CHECK_ARG(x && w && y, "gx_matmul_nn_fwd: null pointer");
+    GX_CHECK_ARG(M > 0 && N > 0 && K > 0 && (N % 4) == 0, "gx_matmul_nn_fwd: bad M/N/K (%d,%d,%d; N %% 4 == 0)", M, N, K);
+    GX_CHECK_ARG(aligned16(w) && aligned16(y), "gx_matmul_nn_fwd: 16-byte alignment");
+    hipStream_t s = (hipStream_t)stream;
+    {
+        GxProf pf(KID_DENSE, s, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+        hipLaunchKernelGGL(matmul_nn_fwd_kernel, dim3(gx_ceil_div(M, kNN_MR), gx_ceil_div(N, 1024)), dim3(256), 0, s, x, w, y, M,
+                           N, K);
+    }
+    GX_CHECK_LAUNCH("gx_matmul_nn_fwd");
+    return GX_OK;
+}
+
+size_t gx_matmul_nn_bwd_ws_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    return (size_t)matmul_nn_chunks(N) * M * K * sizeof(float);
+}
+
+int gx_matmul_nn_bwd(const float* x, const float* w, const float* g, float* dx, float* dw, int M, int N, int K, void* ws,
+                     size_t ws_bytes, gx_stream_t stream) {
+    GX_CHECK_ARG(x && w && g, "gx_matmul_nn_bwd: null pointer");
+    GX_CHECK_ARG(M > 0 && N > 0 && K > 0 && (N % 4) == 0, "gx_matmul_nn_bwd: bad M/N/K (%d,%d,%d; N %% 4 == 0)", M, N, K);
+    GX_CHECK_ARG(aligned16(w) && aligned16(g) && (!dw || aligned16(dw)), "gx_matmul_nn_bwd: 16-byte alignment");
+    hipStream_t s = (hipStream_t)stream;
+    if (dw) {
+        GxProf pf(KID_DENSE, s, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+        hipLaunchKernelGGL(matmul_nn_dw_kernel, dim3(gx_ceil_div(K, kNN_KC), gx_ceil_div(N, 1024)), dim3(256), 0, s, x, g, dw, M,
+                           N, K);
+        GX_CHECK_LAUNCH("gx_matmul_nn_bwd(dw)");
+    }
+    if (dx) {
+        GX_CHECK_ARG(ws && ws_bytes >= gx_matmul_nn_bwd_ws_bytes(M, N, K), "gx_matmul_nn_bwd: workspace too small");
+        const int nchunk = matmul_nn_chunks(N);
+        const int cols = gx_round_up(gx_ceil_div(N, nchunk), 64);
+        const int used = gx_ceil_div(N, cols);
+        {
+            GxProf pf(KID_DENSE, s, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+            hipLaunchKernelGGL(matmul_nn_dx_kernel, dim3(used, gx_ceil_div(M, 32), gx_ceil_div(K, 64)), dim3(256), 0, s, g, w,
+                               (float*)ws, M, N, K, cols);
+        }
+        GX_CHECK_LAUNCH("gx_matmul_nn_bwd(dx)");
+        {
+            GxProf pf(KID_SMALL_REDUCE, s, 0.0, 4.0 * (used + 1.0) * M * K);
+            hipLaunchKernelGGL(matmul_nn_dx_reduce_kernel, dim3(gx_ceil_div(M * K, 256)), dim3(256), 0, s, (const float*)ws, dx,
+                               M * K, used);
+        }
+        GX_CHECK_LAUNCH("gx_matmul_nn_bwd(dx reduce)");
+    }
+    return GX_OK;
 }
 
 int gx_lstm_step_fwd(const float* gx, const float* h_prev, const float* c_prev, const float* w_hh,

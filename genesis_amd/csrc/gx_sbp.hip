@@ -130,9 +130,38 @@ logsoftmax_k_bwd_kernel(const float* __restrict__ log_m_r, const float* __restri
     }
 }
 
+// log_m_r[k][b][p] = log_softmax over the K slots of the decoder's mask-logit channel (monet_config.py:137-139):
+// (x - max) - log(sum exp(x - max)), torch's evaluation order
+__global__ void __launch_bounds__(256)
+logsoftmax_k_fwd_kernel(const float* __restrict__ dec, int K, int B, int HW, int C, float* __restrict__ log_m_r) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * HW) return;
+    const int b = (int)(idx / HW), p = (int)(idx - (size_t)b * HW);
+    const float* x = dec + ((size_t)b * C + (C - 1)) * HW + p;
+    const size_t kstride = (size_t)B * C * HW;
+    float mx = x[0];
+    for (int k = 1; k < K; ++k) mx = fmaxf(mx, x[k * kstride]);
+    float se = 0.f;
+    for (int k = 0; k < K; ++k) se += expf(x[k * kstride] - mx);
+    const float lse = logf(se);
+    for (int k = 0; k < K; ++k) log_m_r[((size_t)k * B + b) * HW + p] = (x[k * kstride] - mx) - lse;
+}
+
 }  // namespace
 
 extern "C" {
+
+int gx_logsoftmax_k_fwd(const float* dec, int K, int B, int HW, int C, float* log_m_r, gx_stream_t stream) {
+    GX_CHECK_ARG(dec && log_m_r && K > 0 && B > 0 && HW > 0 && C > 0, "gx_logsoftmax_k_fwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    {
+        GxProf pf(KID_SMALL_REDUCE, s, 0.0, 8.0 * K * (double)B * HW);
+        hipLaunchKernelGGL(logsoftmax_k_fwd_kernel, dim3((unsigned)(((size_t)B * HW + 255) / 256)), dim3(256), 0, s, dec, K,
+                           B, HW, C, log_m_r);
+    }
+    GX_CHECK_LAUNCH("gx_logsoftmax_k_fwd");
+    return GX_OK;
+}
 
 int gx_logsoftmax_k_bwd(const float* log_m_r, const float* g, int K, int B, int HW, int C, float* g_dec,
                         gx_stream_t stream) {

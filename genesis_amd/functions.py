@@ -1141,6 +1141,84 @@ def linear(x, w, b=None, act=None):
 
 
 @ctx_bound
+class MatmulNNFn(torch.autograd.Function):
+    """x [M,K] @ w.flatten(1) [K,N] with the weight in [in, out...] layout: the gated ConvTranspose2d 'fc' layer of the
+    sylvester stacks on a 1 x 1 input (third_party/sylvester/VAE.py:27-33) as the matrix product it is (gx_matmul_nn_*)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        x2 = x.contiguous()
+        y = hip.matmul_nn_fwd(x2, w.view(w.shape[0], -1))
+        ctx.save_for_backward(x2)
+        ctx.w = w
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, = ctx.saved_tensors
+        w = ctx.w
+        need_w = ctx.needs_input_grad[1]
+        ow = _gout(w) if need_w else None
+        dx, dw = hip.matmul_nn_bwd(x2, w.view(w.shape[0], -1), g.contiguous(), need_dx=ctx.needs_input_grad[0],
+                                   out_dw=ow.view(w.shape[0], -1) if ow is not None else None, need_dw=need_w)
+        if dw is not None and ow is None:
+            dw = dw.view(w.shape)
+        return dx, (_ret(ow, dw) if need_w else None)
+
+
+@ctx_bound
+class TwoHeadLinearFn(torch.autograd.Function):
+    """(F.linear(h, w1, b1) | F.linear(h, w2, b2)) side by side in one [M, N1 + N2] buffer -- the (mean | pre-sigma) heads of
+    the sylvester posterior (VAE.py:118-121) in the layout the posterior kernel reads (gx_latent_posterior_*): both dense
+    launches write / read their columns of the shared buffer through row strides, the second backward adds its dh."""
+
+    @staticmethod
+    def forward(ctx, h, w1, b1, w2, b2):
+        h2 = h.contiguous()
+        n1, n2 = w1.shape[0], w2.shape[0]
+        out = torch.empty(h2.shape[0], n1 + n2, device=h2.device)
+        hip.linear_fwd(h2, w1, b1, None, out=out[:, :n1])
+        hip.linear_fwd(h2, w2, b2, None, out=out[:, n1:])
+        ctx.save_for_backward(h2)
+        ctx.params = (w1, b1, w2, b2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        h2, = ctx.saved_tensors
+        w1, b1, w2, b2 = ctx.params
+        g = g.contiguous()
+        n1 = w1.shape[0]
+        o1w, o1b, o2w, o2b = _gout(w1), _gout(b1), _gout(w2), _gout(b2)
+        if o1w is None or o1b is None:
+            o1w = o1b = None
+        if o2w is None or o2b is None:
+            o2w = o2b = None
+        dh, dw1, db1 = hip.linear_bwd(h2, w1, None, g[:, :n1], None, out_dw=o1w, out_db=o1b)
+        _, dw2, db2 = hip.linear_bwd(h2, w2, None, g[:, n1:], None, out_dw=o2w, out_db=o2b, accumulate_dx=dh)
+        return dh, _ret(o1w, dw1), _ret(o1b, db1), _ret(o2w, dw2), _ret(o2b, db2)
+
+
+@ctx_bound
+class LogSoftmaxKFn(torch.autograd.Function):
+    """dec [K*B, C, H, W] -> log_m_r [K,B,1,H,W] = log_softmax over the K slots of the last channel (MONet.get_mask_recon_stack,
+    models/monet_config.py:137-139)."""
+
+    @staticmethod
+    def forward(ctx, dec, K):
+        dec = dec.contiguous()
+        out = hip.logsoftmax_k_fwd(dec, K)
+        ctx.save_for_backward(out)
+        ctx.C = dec.shape[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        out, = ctx.saved_tensors
+        return hip.logsoftmax_k_bwd(out, g.contiguous(), ctx.C), None
+
+
+@ctx_bound
 class LSTMFn(torch.autograd.Function):
     """nn.LSTM (one layer, zero initial state) over x [T,B,D] -> h [T,B,H]: input projection for all steps on the
     dense kernel, then one fused (recurrent GEMM + cell update) launch per step; backward mirrors it

@@ -959,6 +959,40 @@ def linear_bwd(x, w, y, g, act=None, need_dx=True, need_dw=True, need_db=True, o
     return dx, dw, db
 
 
+def matmul_nn_fwd(x, w):
+    """x [M,K] @ w [K,N] (the weight in [in, out] layout: a ConvTranspose2d weight [z, 2c, k, k] flattened)."""
+    _chk(x, 'matmul_nn.x'); _chk(w, 'matmul_nn.w')
+    M, K = x.shape
+    if w.shape[0] != K:
+        raise GenesisHipError('matmul_nn_fwd: x is [%d,%d] but w is %s' % (M, K, tuple(w.shape)))
+    y = torch.empty(M, w.shape[1], dtype=F32, device=x.device)
+    _lib.call('gx_matmul_nn_fwd', _p(x), _p(w), _p(y), M, w.shape[1], K, _stream())
+    return y
+
+
+def matmul_nn_bwd(x, w, g, need_dx=True, out_dw=None, need_dw=True):
+    """-> (dx [M,K] = g w^T, dw [K,N] = x^T g); out_dw: write dw there."""
+    _chk(x, 'matmul_nn_bwd.x'); _chk(w, 'matmul_nn_bwd.w'); _chk(g, 'matmul_nn_bwd.g')
+    M, K = x.shape
+    N = w.shape[1]
+    dx = torch.empty(M, K, dtype=F32, device=x.device) if need_dx else None
+    dw = (out_dw if out_dw is not None else torch.empty(K, N, dtype=F32, device=x.device)) if need_dw else None
+    nb = _lib.query('gx_matmul_nn_bwd_ws_bytes', M, N, K) if need_dx else 0
+    ws = _ws(nb, x.device) if need_dx else None
+    _lib.call('gx_matmul_nn_bwd', _p(x), _p(w), _p(g), _p(dx), _p(dw), M, N, K, _p(ws), nb, _stream())
+    return dx, dw
+
+
+def logsoftmax_k_fwd(dec, K):
+    """dec [K*B, C, H, W] slot-major -> log_softmax over the K slots of the last channel, [K,B,1,H,W]."""
+    _chk(dec, 'logsoftmax_k_fwd.dec')
+    KB, C, H, W = dec.shape
+    B = KB // K
+    out = torch.empty(K, B, 1, H, W, dtype=F32, device=dec.device)
+    _lib.call('gx_logsoftmax_k_fwd', _p(dec), K, B, H * W, C, _p(out), _stream())
+    return out
+
+
 def lstm_step_fwd(gx, h_prev, c_prev, w_hh, b_hh, act, c, h):
     """One LSTM cell step into preallocated act [B,4H], c, h [B,H] (views of the per-sequence buffers)."""
     B, H4 = gx.shape

@@ -68,39 +68,30 @@ def average_ari(log_m_k, instances, foreground_only=False):
 
 def average_segcover(segA, segB, ignore_background=False):
     """utils/misc.py:173-235: covering of segA by segB, both [B,1,H,W] integer maps; negative labels in segA are
-    ignore regions.  Returns (mean_sc.mean(0), scaled_sc.mean(0)) as 0-dim float32 tensors (on the device)."""
+    ignore regions.  Returns (mean_sc.mean(0), scaled_sc.mean(0)) as 0-dim float32 tensors (on the device).
+
+    One tensor expression over the contingency table c[b,i,j] (no loop over label pairs, no host round trip):
+        |A_i| = sum_j c[b,i,:]  (column KB holds segB labels < 0),   |B_j, not ignored| = sum_i c[b,i,j],
+        IoU[b,i,j] = c / (|A_i| + |B_j| - c)  (0 where the union is empty -- the reference's -100 never wins its running
+        maximum, which starts at 0),   best[b,i] = max_j IoU,
+        mean covering = sum_i best / #{i: |A_i| > 0},   scaled covering = sum_i |A_i| best / sum_i |A_i|.
+    A label that no image of the batch holds contributes 0 to every sum, so "the labels torch.unique returns" needs no
+    separate bookkeeping; `ignore_background` drops row 0 from the covered labels (its pixels still count in |B_j|)."""
     assert segA.shape == segB.shape, '%s - %s' % (tuple(segA.shape), tuple(segB.shape))
     assert segA.shape[1] == 1 and segB.shape[1] == 1
     dev = segB.device if segB.is_cuda else segA.device
     segA, segB = segA.to(dev), segB.to(dev)
-    bsz = segA.shape[0]
-    KA, KB = _num_labels(segA), _num_labels(segB)
-    c = contingency(segA, segB, max(KA, 1), max(KB, 1)).to(torch.int64)       # [B, KA, KB+1]
-    a_i = c.sum(2)                                                            # |A == i| per image
-    n_ij = c[:, :, :KB]
-    b_j = n_ij.sum(1)                                                         # |(B == j) & (A >= 0)|
-    mean_scores = torch.zeros(bsz, device=dev)
-    N = torch.zeros(bsz, dtype=torch.int64, device=dev)
-    scaled_scores = torch.zeros(bsz, device=dev)
-    scaling_sum = torch.zeros(bsz, dtype=torch.int64, device=dev)
-    present_a = (a_i.sum(0) > 0).cpu().tolist()                               # labels torch.unique would return
-    present_b = (b_j.sum(0) > 0).cpu().tolist() if KB else []
-    neg = torch.tensor(-100.0, device=dev)
-    for i in range(1 if ignore_background else 0, KA):
-        if not present_a[i]:
-            continue
-        max_iou = torch.zeros(bsz, device=dev)
-        for j in range(KB):
-            if not present_b[j]:
-                continue
-            inter = n_ij[:, i, j]
-            union = a_i[:, i] + b_j[:, j] - inter
-            iou = torch.where(union == 0, neg, inter.float() / union.float())
-            max_iou = torch.where(iou > max_iou, iou, max_iou)
-        mean_scores = mean_scores + max_iou
-        N = torch.where(a_i[:, i] > 0, N + 1, N)
-        scaled_scores = scaled_scores + a_i[:, i].float() * max_iou
-        scaling_sum = scaling_sum + a_i[:, i]
-    mean_sc = mean_scores / torch.clamp(N, min=1).float()
-    scaled_sc = scaled_scores / torch.clamp(scaling_sum, min=1).float()
+    labels = torch.stack((segA.max(), segB.max())).clamp_min(0).tolist()      # the table's size: the one host read
+    KA, KB = int(labels[0]) + 1, int(labels[1]) + 1
+    c = contingency(segA, segB, KA, KB).to(torch.int64)                       # [B, KA, KB+1]
+    b_area = c[:, :, :KB].sum(1, keepdim=True)                                # [B, 1, KB]  (background pixels of A count)
+    if ignore_background:
+        c = c[:, 1:]                                                          # (only A's label 0 is not covered)
+    area = c.sum(2)                                                           # [B, KA']
+    inter = c[:, :, :KB]
+    union = area.unsqueeze(2) + b_area - inter
+    iou = torch.where(union == 0, torch.zeros((), device=dev), inter.float() / union.float())
+    best = iou.max(2).values if iou.shape[1] else iou.new_zeros(iou.shape[:2])
+    mean_sc = best.sum(1) / (area > 0).sum(1).clamp(min=1).float()
+    scaled_sc = (area.float() * best).sum(1) / area.sum(1).clamp(min=1).float()
     return mean_sc.mean(0), scaled_sc.mean(0)

@@ -170,7 +170,7 @@ class MONet(nn.Module):
         # channel, or (prior_mode 'scope') a stick-breaking pass over the K logits whose last mask is the remaining scope
         logits = dec[:, 3:].reshape(K, B, 1, *x.shape[2:])
         if self.prior_mode == 'softmax':
-            log_m_r = F.log_softmax(logits, dim=0)
+            log_m_r = fn.LogSoftmaxKFn.apply(dec, K)
         else:
             log_m_r, _ = fn.SBPScanFn.apply(logits, None, True)
         losses = AttrDict()

@@ -84,16 +84,24 @@ class SylvesterVAE(nn.Module):
         y = fn.linear(h.flatten(1), unit.conv.weight.flatten(1)).view(h.shape[0], -1, 1, 1)
         return self._gate(unit, y).flatten(1)
 
+    def posterior_heads(self, h):
+        """[N, 2 z]: (q_z_mean(h) | q_z_var's Linear(h)), i.e. (mu | pre-sigma) -- ToVar (to_sigma(.)**2, blocks.py:22-26) is
+        applied by the consumer: the posterior kernel forms sigma = to_sigma(pre-sigma) = sqrt(var) directly
+        (vae_config.py:66 takes var.sqrt())."""
+        return fn.TwoHeadLinearFn.apply(h, self.q_z_mean.weight, self.q_z_mean.bias, self.q_z_var[0].weight, self.q_z_var[0].bias)
+
     def posterior(self, h):
-        mean = fn.linear(h, self.q_z_mean.weight, self.q_z_mean.bias)
-        var = (F.softplus(fn.linear(h, self.q_z_var[0].weight, self.q_z_var[0].bias) + 0.5) + 1e-8) ** 2     # ToVar: to_sigma(x)**2 (blocks.py:22-26)
-        return mean, var
+        """(mean, var) of VAE.py:118-121 (the reference's encode()); the training path uses posterior_heads."""
+        zh = self.posterior_heads(h)
+        z = zh.shape[1] // 2
+        _, mean, sigma, _ = fn.PosteriorFn.apply(zh.unsqueeze(1), zh.new_zeros(1, zh.shape[0], z))
+        return mean[0], sigma[0] * sigma[0]
 
     def decode(self, z):
         unit = self.p_x_nn[0]
         k = self.last_kernel_size
         w = unit.conv.weight                                           # [z, 128, k, k]
-        y = (z @ w.flatten(1)).view(z.shape[0], w.shape[1], k, k)
+        y = fn.MatmulNNFn.apply(z, w).view(z.shape[0], w.shape[1], k, k)
         h = self._gate(unit, y)
         for l, s in enumerate(reversed(self.strides)):
             unit = self.p_x_nn[l + 1]
@@ -136,7 +144,7 @@ def gc_decoder_forward(units, z, strides, training):
     unit = units[0]
     w = unit.conv.weight                                           # [z, 2c, k, k]
     k = w.shape[2]
-    h = gate_unit(unit, (z @ w.flatten(1)).view(z.shape[0], w.shape[1], k, k), training)
+    h = gate_unit(unit, fn.MatmulNNFn.apply(z, w).view(z.shape[0], w.shape[1], k, k), training)
     for l, s in enumerate(strides):
         unit = units[l + 1]
         h = gate_unit(unit, DirectConvFn.apply(h, unit.conv.weight, 'deconv', s, 2, s - 1), training)

@@ -38,6 +38,7 @@ class BaselineVAE(nn.Module):
         self.debug = _cfg_get(cfg, 'debug', False)
         self.img_size = cfg.img_size
         self.vae = SylvesterVAE(self.ldim, [3, cfg.img_size, cfg.img_size], 3)
+        self._zero_logw = None
         self.broadcast_decoder = bool(_cfg_get(cfg, 'broadcast_decoder', False))
         if self.broadcast_decoder:
             # vae_config.py:53-61: the deconv decoder is REPLACED (after it was constructed: same RNG consumption) by
@@ -52,16 +53,24 @@ class BaselineVAE(nn.Module):
         if not x.is_cuda:
             from genesis_amd._lib import GenesisHipError
             raise GenesisHipError('BaselineVAE: the HIP path needs device tensors; there is no CPU fallback')
+        from genesis_amd import functions as fn
+        B = x.shape[0]
         h = self.vae.encode_features(x)
-        mu, var = self.vae.posterior(h)
-        sigma = var.sqrt()
+        zh = self.vae.posterior_heads(h)                               # [B, 2 ldim] = (mu | pre-sigma)
         if eps is None:
-            eps = torch.randn_like(mu)
-        z = mu + sigma * eps
+            eps = torch.randn(B, self.ldim, device=x.device)
+        # sigma = to_sigma(pre-sigma) (= sqrt(ToVar), vae_config.py:66), z = mu + sigma eps (rsample, :67) and log q(z): one launch
+        z, mu, sigma, log_q = (t[0] for t in fn.PosteriorFn.apply(zh.unsqueeze(1), eps.unsqueeze(0)))
         x_mean = self._decode(z)
-        recon = torch.sigmoid(x_mean) if self.pixel_bound else x_mean
-        err = -_normal_log_prob(x, recon, float(self.pixel_std)).sum(dim=(1, 2, 3))
-        kl = (_normal_log_prob(z, mu, sigma) - _normal_log_prob(z, 0., 1.)).sum(dim=1)
+        # likelihood (vae_config.py:72-77): one component with log-weight 0 of the mixture kernel -- -sum log N(x; recon, std),
+        # recon = sigmoid(x_mean) under pixel_bound
+        key = (B,) + tuple(x.shape[2:]) + (str(x.device),)
+        if self._zero_logw is None or self._zero_logw[0] != key:
+            self._zero_logw = (key, torch.zeros(1, B, 1, *x.shape[2:], device=x.device))
+        err, recon, _ = fn.MixtureWFn.apply(x, x_mean, self._zero_logw[1], 1, float(self.pixel_std), float(self.pixel_std),
+                                            bool(self.pixel_bound))
+        # Monte-Carlo KL against N(0, 1) at z (vae_config.py:79-81): log q(z) - log p(z)
+        kl = fn.PriorLogPFn.apply(z.unsqueeze(0), None, log_q.unsqueeze(0))[0]
         stats = AttrDict(x=x_mean, mu=mu, sigma=sigma, z=z)
         return recon, AttrDict(err=err, kl_l=kl), stats, None, None
 

@@ -366,8 +366,10 @@ int gx_categorical_kl_fwd(const float* log_m, const float* log_m_r, int K, int B
                           gx_stream_t stream);
 int gx_categorical_kl_bwd(const float* log_m, const float* log_m_r, const float* g_kl, int K, int B, int HW,
                           float* g_log_m, float* g_log_m_r, gx_stream_t stream);
-/*      gradient of the reconstructed masks log_m_r = log_softmax over K of the decoder's last channel
- *      (monet_config.py:137-139) back into the decoder output: g [K,B,HW] -> g_dec [K*B, C, HW] (channels < C-1 zero) */
+/*      the reconstructed masks log_m_r [K,B,HW] = log_softmax over the K slots of the decoder output's last channel
+ *      (MONet.get_mask_recon_stack, monet_config.py:137-139; dec [K*B, C, HW] slot-major), and their gradient back into
+ *      the decoder output: g [K,B,HW] -> g_dec [K*B, C, HW] (channels < C-1 zero) */
+int gx_logsoftmax_k_fwd(const float* dec, int K, int B, int HW, int C, float* log_m_r, gx_stream_t stream);
 int gx_logsoftmax_k_bwd(const float* log_m_r, const float* g, int K, int B, int HW, int C, float* g_dec,
                         gx_stream_t stream);
 
@@ -481,6 +483,17 @@ int gx_linear_fwd_ld(const float* x, int ldx, const float* w, const float* b, in
 int gx_linear_bwd_ex(const float* x, int ldx, const float* w, const float* y, const float* g, int ldg, int act,
                      float* dx, int lddx, int dx_accumulate, float* dw, float* db, float* db2, int M, int N, int K,
                      gx_stream_t stream);
+
+/* ---- plain matrix product with the weight in [K, N] layout: y[M,N] = x[M,K] w[K,N] -- the gated ConvTranspose2d 'fc' layer
+ *      of the sylvester stacks applied to a 1 x 1 input (third_party/sylvester/VAE.py:27-33, layers.py:62-101: the weight
+ *      [z, 2c, k, k] flattened to [z, 2c k k] IS w; no transposed copy).  K is small (the latent size), N large: an
+ *      HBM-bound product on the vector ALUs (w is read once per 8 rows of x, coalesced; x rides in scalar registers).
+ *      bwd: dw[K,N] = x^T g (dw may be NULL);  dx[M,K] = g w^T (dx may be NULL) summed over N in fixed-order partial
+ *      slabs held in ws (gx_matmul_nn_bwd_ws_bytes).  Row-major contiguous, N % 4 == 0, 16-byte aligned. */
+int gx_matmul_nn_fwd(const float* x, const float* w, float* y, int M, int N, int K, gx_stream_t stream);
+size_t gx_matmul_nn_bwd_ws_bytes(int M, int N, int K);
+int gx_matmul_nn_bwd(const float* x, const float* w, const float* g, float* dx, float* dw, int M, int N, int K,
+                     void* ws, size_t ws_bytes, gx_stream_t stream);
 
 /* ---- LSTM cell step (nn.LSTM, one layer, gate order i, f, g, o: models/genesis_config.py:105 prior_lstm, :297-307;
  *      modules/attention.py LatentSBP core).  The caller computes gx = x w_ih^T + b_ih for all steps with

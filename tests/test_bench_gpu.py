@@ -39,3 +39,28 @@ def test_bench_line_contract():
         assert k in c, k
     assert c['kind'] in ('port', 'reference') and c['value'] > 0 and c['cores'] >= 1
     assert d['pcie_inclusive']['value'] > 0
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_rank_launch_rehearsal():
+    """The driver's N > 1 command line (python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N) on the
+    1-GPU test box: GENESIS_BENCH_REHEARSAL=1 puts both ranks on GPU 0 with gloo carrying the gradient bucket (RCCL refuses
+    two ranks on one device).  Everything else is the real path: env:// rendezvous, per-rank shards and seeds, rank-0
+    broadcast, the two-graph step around the ONE collective, barriers, max-over-ranks time, one JSON line from rank 0."""
+    import socket
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, PYTHONPATH=ROOT, GENESIS_BENCH_REHEARSAL='1', GENESIS_BENCH_LONG_STEPS='0')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                          '127.0.0.1', '--master-port', str(port), osp.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4',
+                          '--warmup', '2'], capture_output=True, text=True, env=env, cwd=ROOT, timeout=880)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]                # rank 0 only
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['config']['parallelism'] == 'dp2'
+    assert d['config']['global_batch'] == 64 and d['config']['per_gpu_batch'] == 32
+    c = d['config']['collective']
+    assert c['ranks_observed'] == 2 and c['all_reduces_per_step'] == 1 and c['bytes_per_all_reduce'] > 10e6
+    assert d['config']['launch'] == 'hip-graph(fwd+bwd) | rccl all-reduce | hip-graph(geco+adam)'
+    assert 'rehearsal' in d and d['value'] > 0 and abs(d['value'] - 64 * 1e3 / d['ms_per_step']) < 1e-6 * d['value']
+    assert 'roofline' not in d and 'cpu_baseline' not in d    # rank-0-at-N=1 legs only

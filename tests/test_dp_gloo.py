@@ -109,3 +109,59 @@ def test_fp64_gradient_rides_the_fp32_tail_exactly_for_one_rank():
     b.unpack64(1.0)
     assert torch.equal(b.flat_g64[:1], g)
     assert torch.equal(buf, torch.arange(5, dtype=torch.float32))
+
+
+def _worker8(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    g = torch.Generator().manual_seed(1000 + rank)
+    params = [torch.nn.Parameter(torch.zeros(33, 7)), torch.nn.Parameter(torch.zeros(5)),
+              torch.nn.Parameter(torch.zeros((), dtype=torch.float64)), torch.nn.Parameter(torch.zeros(3, dtype=torch.float64))]
+    bn_mean, bn_var = torch.randn(6, generator=g), torch.rand(6, generator=g) + 0.5
+    tracked = torch.tensor(rank, dtype=torch.int64)           # integer buffer: not averaged
+    b = FlatBucket(params, n_tail=2, mean_buffers=[bn_mean, bn_var, tracked])
+    b.zero_grad()
+    b.flat_g[:b.n32].copy_(torch.randn(b.n32, generator=g))
+    g64 = torch.randn(4, dtype=torch.float64, generator=g) * 1e3 + 0.123456789012345
+    b.flat_g64[:4].copy_(g64)
+    err, kl = torch.tensor(8000.0 + rank), torch.tensor(20.0 + 0.5 * rank)
+    b.set_tail(err, kl)
+    local = {'g': b.flat_g[:b.n32].clone(), 'g64': g64.clone(), 'mean': bn_mean.clone(), 'var': bn_var.clone()}
+    # rank 0's state wins at start-up (TrainStep.sync_from_rank0)
+    state = torch.full((3,), float(rank))
+    b.flat_p.fill_(float(rank))
+    b.broadcast_state([state])
+    assert float(b.flat_p.abs().max()) == 0.0 and float(state.abs().max()) == 0.0
+    if rank % 2:          # the two forms of the exchange: inside all_reduce, or packed by the caller (the graph-replay path)
+        scale = b.all_reduce()
+    else:
+        b.pack64()
+        scale = b.all_reduce(packed=True)
+        b.unpack64(scale)
+    torch.save({'local': local, 'g': b.flat_g[:b.n32] * scale, 'tail': b.tail(scale), 'g64': b.flat_g64[:4] * scale,
+                'mean': bn_mean, 'var': bn_var, 'tracked': tracked, 'scale': scale}, os.path.join(out_dir, 'w%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_eight_rank_bucket_exchange(tmp_path):
+    """The 8-GPU launch's exchange step, rehearsed over gloo with 8 processes: ONE all-reduce of the flat bucket delivers to
+    every rank the same mean gradient, the global batch-mean err / KL (GECO's input: identical multiplier on all ranks), the
+    fp64 gradients (as (hi, mid, lo) float triples: 1e-7 relative after an 8-way fp32 sum of the hi parts) and the
+    rank-averaged BatchNorm running statistics; integer buffers stay local; rank 0's state wins the start-up broadcast."""
+    world = 8
+    mp.spawn(_worker8, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), 'w%d.pt' % k)) for k in range(world)]
+    for k in range(1, world):
+        for key in ('g', 'tail', 'g64', 'mean', 'var'):
+            assert torch.equal(r[0][key], r[k][key]), (key, k)       # bit-identical on every rank
+        assert int(r[k]['tracked']) == k and r[k]['scale'] == 1.0 / world
+    mean = lambda key: sum(x['local'][key].double() for x in r) / world   # noqa: E731
+    np.testing.assert_allclose(r[0]['g'].double().numpy(), mean('g').numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(r[0]['g64'].numpy(), mean('g64').numpy(), rtol=2e-7)
+    np.testing.assert_allclose(r[0]['mean'].double().numpy(), mean('mean').numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(r[0]['var'].double().numpy(), mean('var').numpy(), rtol=1e-5)
+    np.testing.assert_allclose(r[0]['tail'].numpy(), [8000.0 + 3.5, 20.0 + 0.5 * 3.5], rtol=1e-6)

@@ -1453,3 +1453,61 @@ def test_deferred_weight_gradients_of_a_shared_parameter_accumulate(N, Cin, Cout
     hip.conv3x3_wgrad(xs[0], dys[0], out=out)
     one = torch.nn.grad.conv2d_weight(xs[0].cpu().double(), (Cout, Cin, 3, 3), dys[0].cpu().double(), padding=1)
     close(out, one, rtol=2e-5, atol=1e-6 * float(one.abs().max()), msg='plain call overwrites')
+
+
+@pytest.mark.parametrize('M,K,N', [(32, 64, 32768), (224, 64, 8192), (7, 16, 1024), (3, 8, 260), (33, 70, 4100)])
+def test_matmul_with_the_weight_in_in_out_layout(M, K, N):
+    """gx_matmul_nn_*: y = x w, dx = g w^T, dw = x^T g with w [K, N] -- the sylvester stacks' gated ConvTranspose2d 'fc'
+    layer on a 1 x 1 input (VAE.py:27-33) -- against fp64; ragged M / K / N (N % 4 == 0) included."""
+    x, w, g = rnd(M, K, seed=1), rnd(K, N, seed=2, scale=1 / np.sqrt(K)), rnd(M, N, seed=3)
+    xr, wr = x.double().requires_grad_(), w.double().requires_grad_()
+    y_ref = xr @ wr
+    y_ref.backward(g.double())
+    y = hip.matmul_nn_fwd(x.to(DEV), w.to(DEV))
+    close(y, y_ref, 2e-6, 2e-6, 'fwd')
+    dx, dw = hip.matmul_nn_bwd(x.to(DEV), w.to(DEV), g.to(DEV))
+    close(dx, xr.grad, 5e-6, 5e-6, 'dx')
+    close(dw, wr.grad, 5e-6, 5e-6, 'dw')
+    # through autograd, as the gated decoders call it (4-d weight, flattened inside)
+    from genesis_amd import functions as fn
+    k = int(round((N // 4) ** 0.5))
+    if 4 * k * k == N:
+        xd, wd = x.to(DEV).requires_grad_(), w.to(DEV).view(K, 4, k, k).clone().requires_grad_()
+        out = fn.MatmulNNFn.apply(xd, wd)
+        out.backward(g.to(DEV))
+        close(out, y_ref, 2e-6, 2e-6, 'fn fwd'); close(xd.grad, xr.grad, 5e-6, 5e-6, 'fn dx')
+        close(wd.grad.view(K, N), wr.grad, 5e-6, 5e-6, 'fn dw')
+
+
+@pytest.mark.parametrize('K,B,S,C', [(7, 32, 64, 4), (3, 2, 16, 4), (1, 3, 8, 1), (5, 2, 12, 2)])
+def test_log_softmax_over_the_slots(K, B, S, C):
+    """gx_logsoftmax_k_fwd / _bwd against F.log_softmax over the K slots of the decoder output's last channel
+    (MONet.get_mask_recon_stack, monet_config.py:137-139)."""
+    from genesis_amd import functions as fn
+    dec = rnd(K * B, C, S, S, seed=5, scale=4.0)
+    g = rnd(K, B, 1, S, S, seed=6)
+    dr = dec.double().requires_grad_()
+    ref = F.log_softmax(dr[:, C - 1:].reshape(K, B, 1, S, S), dim=0)
+    ref.backward(g.double())
+    dd = dec.to(DEV).requires_grad_()
+    out = fn.LogSoftmaxKFn.apply(dd, K)
+    out.backward(g.to(DEV))
+    close(out, ref, 2e-6, 2e-6, 'fwd')
+    close(dd.grad, dr.grad, 2e-6, 2e-6, 'bwd')
+    ref32 = F.log_softmax(dec[:, C - 1:].reshape(K, B, 1, S, S), dim=0)
+    assert float((out.cpu() - ref32).abs().max()) <= 4e-7 * max(1.0, float(ref32.abs().max()))     # torch's evaluation order
+
+
+def test_two_linear_heads_in_one_buffer():
+    from genesis_amd import functions as fn
+    h, w1, b1, w2, b2 = rnd(9, 256, seed=1), rnd(64, 256, seed=2, scale=0.06), rnd(64, seed=3), rnd(64, 256, seed=4, scale=0.06), rnd(64, seed=5)
+    g = rnd(9, 128, seed=6)
+    ps = [t.double().requires_grad_() for t in (h, w1, b1, w2, b2)]
+    ref = torch.cat((F.linear(ps[0], ps[1], ps[2]), F.linear(ps[0], ps[3], ps[4])), 1)
+    ref.backward(g.double())
+    pd = [t.to(DEV).requires_grad_() for t in (h, w1, b1, w2, b2)]
+    out = fn.TwoHeadLinearFn.apply(*pd)
+    out.backward(g.to(DEV))
+    close(out, ref, 2e-6, 2e-6, 'fwd')
+    for a, b_, n in zip(pd, ps, ('dh', 'dw1', 'db1', 'dw2', 'db2')):
+        close(a.grad, b_.grad, 5e-6, 5e-6, n)
