@@ -122,7 +122,19 @@ __host__ __device__ __forceinline__ size_t gx_wino_u_slot(int m, int k, int p, i
     const size_t base = ((size_t)(m >> 6) * (Kpad >> 3) + (k >> 3)) * 16 + p;
     return base * 512 + (size_t)((((((k >> 2) & 1) << 5) | (m & 31)) << 3) | ((k & 3) << 1) | ((m >> 5) & 1));
 }
-// conv with an already packed U (16 * Kpad * Mpad floats): out[N,M,H,W] from in[N,K,H,W]
+// The same operands for the bf16 matrix pipe (gx_wino.hip: wino_conv_h_kernel): every U value as three bf16 pieces, chunks of 16
+// reduction channels.  32-bit word (two channels k even, k + 1) of piece `piece` of position p:
+// [m tile 64][chunk k >> 4][position 16][piece 3][m half (m >> 5) & 1][lane = 32 ((k >> 3) & 1) + (m & 31)][(k & 7) >> 1]
+// -- a wave's A operand of (position, piece, m half) is 1 KB, lane-linear: one 16-byte load per lane.
+__host__ __device__ __forceinline__ size_t gx_wino_h_word(int m, int k, int p, int piece, int Kpad16) {
+    return ((((((size_t)(m >> 6) * (Kpad16 >> 4) + (k >> 4)) * 16 + p) * 3 + piece) * 2 + ((m >> 5) & 1)) * 256) +
+           (size_t)((((k >> 3) & 1) * 32 + (m & 31)) * 4 + ((k & 7) >> 1));
+}
+__host__ __device__ __forceinline__ size_t gx_wino_h_bytes(int Kpad16, int Mpad) {
+    return (size_t)(Mpad >> 6) * (Kpad16 >> 4) * 16 * 6144;
+}
+bool gx_wino_h_on();     // Winograd layers on the bf16 pipe (default; gx_wino_precision(0) / GENESIS_WINO_BF16X6=0: fp32 pipe)
+// conv with an already packed U (16 * Kpad * Mpad floats; bf16 pipe: gx_wino_h_bytes): out[N,M,H,W] from in[N,K,H,W]
 bool gx_wino_eligible(int N, int K, int M, int H, int W);
 int gx_wino_launch(const float* in, const float* U, float* out, int N, int K, int M, int H, int W, hipStream_t s);
 

@@ -559,7 +559,7 @@ __device__ __forceinline__ size_t pack_dest(int pack, int idx, int m, int k, int
     return (pack == 5 || pack == 6) ? gx_wino_u_slot(m, k, t, Kpad) : (size_t)idx;
 }
 
-// packs 20 / 21 (= 0 / 1, gx_kq.hip's Q_C3H) and 22 / 23 / 24 (= 2 / 3 / 4 for the bf16 matrix pipe, gx_kq.hip's QCfgDTH / Q_DGH): every weight as three bf16 pieces, two
+// packs 25 / 26 (= 5 / 6: the Winograd operands for gx_wino.hip's bf16-pipe kernel), 20 / 21 (= 0 / 1, gx_kq.hip's Q_C3H) and 22 / 23 / 24 (= 2 / 3 / 4 for the bf16 matrix pipe, gx_kq.hip's QCfgDTH / Q_DGH): every weight as three bf16 pieces, two
 // channels per 32-bit word -- the thread of an even k writes the three words of (k, k + 1), the odd one nothing
 __device__ __forceinline__ void pack_h_store(const float* __restrict__ w, float* __restrict__ wp, int pack, int Co, int Ci,
                                              int m, int k, int t, int NT, int Kpad) {
@@ -581,7 +581,8 @@ __device__ __forceinline__ void pack_h_store(const float* __restrict__ w, float*
     for (int q = 0; q < 3; ++q) {
         wd[q] = (unsigned)pc[0][q] | ((unsigned)pc[1][q] << 16);
         const size_t dst = pack <= 21 ? gx_kq_h32_word(m, k, t, q, NT, Kpad)       // 20 / 21: conv3x3, 32-channel tiles
-                                      : gx_kq_h_word(m, k, pack == 24 ? gx_kq_dg_tap_slot(t) : t, q, NT, Kpad);
+                           : (pack >= 25 ? gx_wino_h_word(m, k, t, q, Kpad)        // 25 / 26: Winograd operands (= 5 / 6), t = position
+                                         : gx_kq_h_word(m, k, pack == 24 ? gx_kq_dg_tap_slot(t) : t, q, NT, Kpad));
         wp[dst] = __builtin_bit_cast(float, wd[q]);
     }
 }
@@ -1885,8 +1886,9 @@ extern "C" {
 // workspace = packed weights (+ split-K partial slabs when the plan splits the reduction)
 static size_t conv3x3_pack_floats(int Cin, int Cout) {
     // 16 positions: room for the Winograd operands (gx_wino.hip) as well as the 9 taps
-    size_t f = (size_t)16 * gx_round_up(Cin, 8) * gx_round_up(Cout, 64);
-    size_t d = (size_t)16 * gx_round_up(Cout, 8) * gx_round_up(Cin, 64);
+    // (24: the bf16-pipe Winograd operands are three 2-byte pieces per value on 16-channel chunks)
+    size_t f = (size_t)24 * gx_round_up(Cin, 16) * gx_round_up(Cout, 64);
+    size_t d = (size_t)24 * gx_round_up(Cout, 16) * gx_round_up(Cin, 64);
     return (f > d ? f : d) + 4096;      // (+ the slack of the bf16-piece packings, kinds 20 / 21)
 }
 
@@ -2047,7 +2049,8 @@ static int conv3x3_fwd_impl(const float* x, const float* w, const float* bias, i
         return GX_OK;
     }
     if (wino_ok) {   // Winograd F(2x2,3x3): 2.25x fewer MFMA passes
-        rc = launch_pack(w, wp, 5, Cout, Cin, 16, Kpad, Mpad, s, &wpu);
+        rc = gx_wino_h_on() ? launch_pack(w, wp, 25, Cout, Cin, 16, gx_round_up(Cin, 16), Mpad, s, &wpu)
+                            : launch_pack(w, wp, 5, Cout, Cin, 16, Kpad, Mpad, s, &wpu);
         if (rc) return rc;
         rc = gx_wino_launch(x, wpu, y, N, Cin, Cout, H, W, s);
         if (rc) return rc;
@@ -2114,7 +2117,8 @@ static int conv3x3_dgrad_impl(const float* dy, const float* w, float* dx, int N,
         return gx_kq_c3_launch(dy, wpu, nullptr, 0, dx, N, Cout, Cin, H, W, s);
     }
     if (wino_ok) {
-        rc = launch_pack(w, wp, 6, Cout, Cin, 16, Kpad, Mpad, s, &wpu);
+        rc = gx_wino_h_on() ? launch_pack(w, wp, 26, Cout, Cin, 16, gx_round_up(Cout, 16), Mpad, s, &wpu)
+                            : launch_pack(w, wp, 6, Cout, Cin, 16, Kpad, Mpad, s, &wpu);
         if (rc) return rc;
         return gx_wino_launch(dy, wpu, dx, N, Cout, Cin, H, W, s);
     }

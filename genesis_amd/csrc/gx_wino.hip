@@ -354,7 +354,322 @@ wino_conv_kernel(const float* __restrict__ in, const float* __restrict__ in2, co
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same Winograd convolution on the bf16 matrix pipe: every fp32 product U * V as six bf16 piece products accumulated
+// in fp32 (finding 13: hi + mid + lo hold all 24 mantissa bits), v_mfma_f32_32x32x16_bf16, chunks of 16
+// reduction channels: 48 MFMAs of 32 cycles per wave and chunk where the fp32 kernel above issues 64 of 64 cycles.
+//   * V never touches LDS.  Wave xi needs only row xi of B^T d, i.e. TWO rows of the raw patch; lane (tile = lane & 31,
+//     octet = lane >> 5) is exactly the B operand's (column, 8 consecutive k) slot, so it reads its own 2 x 4 patch values
+//     of its 8 channels from the raw patch in LDS (ds_read2_b32 on the even / odd column planes), forms the row
+//     combination once per chunk and, per position nu, the column combination of its 8 channels, splits those 8 values
+//     into three bf16 planes in registers and feeds them to the MFMAs.  Every V value is formed by exactly one lane.
+//   * The raw patches arrive by LDS-DMA (buffer_load ... lds: no staging registers, halo pixels outside the image and
+//     channels past the end read as zero through the descriptor's range check), channel pitch 256 floats so that a
+//     thread's patch position is the same for every channel (one offset register), double-buffered, ONE barrier per chunk.
+//   * U is pre-split by the pack kernels (gx_wino_h_word) and loaded straight into the A operand registers, one position
+//     ahead of the MFMAs that use it.
+#ifndef GX_WH_ABL
+#define GX_WH_ABL 0           // measurement builds (tools/abl_build.sh; wrong results): 1 no MFMAs, 2 no A loads after the first,
+#endif                        // 4 no transform / split (constant B), 8 no patch DMA after the first chunk, 16 no output transform
+constexpr int HKC = 16;                        // reduction channels per chunk
+typedef __bf16 w_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float w_f32x16 __attribute__((ext_vector_type(16)));
+
+// 8 fp32 values -> the three bf16 planes (hi, mid, lo) of an MFMA operand
+__device__ __forceinline__ void wino_split8(const float (&v)[8], w_bf16x8& ph, w_bf16x8& pm, w_bf16x8& pl) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 h = (__bf16)v[e];
+        const float r1 = v[e] - (float)h;
+        const __bf16 m = (__bf16)r1;
+        ph[e] = h; pm[e] = m; pl[e] = (__bf16)(r1 - (float)m);
+    }
+}
+
+// NB: 32-tile MFMA column blocks per wave.
+//   NB = 1: workgroup = 64 channels x 32 tiles (8 x 16 output pixels), 128 accumulator registers, two workgroups per CU --
+//           the layers whose grid would not fill the chip with larger tiles.
+//   NB = 2: 64 channels x 64 tiles (16 x 16 output pixels), 256 accumulator registers of the 512 a wave has to itself at one
+//           workgroup per CU.  WHY: the A operands (U, 6 bytes per value as three bf16 pieces) are 24 KB per wave and chunk;
+//           with 32 tiles per wave the four waves pull 96 KB through the CU's 64 B / clk vector-memory path per 1536 cycles of
+//           MFMAs -- the path is saturated exactly when the matrix pipe would be (measured: 48.9 us, 39.3 us without the A
+//           loads).  Twice the tiles per A operand halve that traffic per MFMA, and the register budget pays for an A
+//           prefetch three positions deep instead of one.
+template <int NB> struct WHCfg {
+    static constexpr int TROWS = 4 * NB;                  // Winograd tile rows per workgroup (8 columns)
+    static constexpr int PRH = 2 * TROWS + 2;             // raw patch rows (10 / 18), 18 columns as [parity 2][PLANE 10]
+    static constexpr int USED = PRH * 20;                 // floats per channel (200 / 360)
+    static constexpr int PITCH = NB == 1 ? 256 : 384;     // channel pitch: whole 64-lane DMA rows
+    static constexpr int ROUNDS = (USED + 255) / 256;     // patch positions per thread and channel (1 / 2)
+    static constexpr int RAW_FLOATS = HKC * PITCH;        // per buffer; two buffers
+    static constexpr int NSETS = NB == 1 ? 2 : 4;         // A register sets (position nu of a chunk uses set nu % NSETS)
+    static constexpr int LOOK = NB == 1 ? 1 : 2;          // ... loaded LOOK positions ahead (three sets live at NB = 2: 72 registers)
+    static constexpr size_t LDS_BYTES = 2 * RAW_FLOATS * 4 > 32768 ? 2 * RAW_FLOATS * 4 : 32768;    // (the epilogue's exchange buffer: 32 KB)
+};
+
+template <int NB>
+__global__ void __launch_bounds__(256, NB == 1 ? 2 : 1)
+wino_conv_h_kernel(const float* __restrict__ in, const float* __restrict__ in2, const unsigned* __restrict__ U,
+                   float* __restrict__ out, float* __restrict__ out2, const WinoGeom g) {
+    using C = WHCfg<NB>;
+    constexpr int PITCH = C::PITCH, NSETS = C::NSETS, LOOK = C::LOOK;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* raw = lds;                       // [2][HKC][PITCH]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    int tile = blockIdx.x;
+    const int tw_i = tile % g.tiles_w; tile /= g.tiles_w;
+    const int th_i = tile % g.tiles_h; tile /= g.tiles_h;
+    const int n = tile;
+    const int R0 = th_i * (2 * C::TROWS), C0 = tw_i * (2 * WTW);
+    const int m0 = blockIdx.y * 64;
+    const int HW = g.H * g.W;
+    const int Ka = g.K1 < g.K ? g.K1 : g.K, Kb = g.K - Ka;
+    const float* in_n = in + (size_t)n * Ka * HW;
+    const float* in2_n = in2 + (size_t)n * Kb * HW;
+    const int nchunks = g.Kpad / HKC;
+
+    // ---- raw-patch staging: thread t owns patch positions t (+ 256) of EVERY channel: row p / 20, column parity
+    // (p % 20) / 10, index p % 10 (9 = the spare slot of a plane row).  voff = byte offset of that pixel inside a channel
+    // plane, or 1 GiB (out of every descriptor's range: reads as zero) for halo pixels outside the image and idle slots.
+    int voff[C::ROUNDS];
+#pragma unroll
+    for (int r = 0; r < C::ROUNDS; ++r) {
+        const int p = tid + 256 * r;
+        voff[r] = 0x40000000;
+        if (p < C::USED) {
+            const int pr = p / 20, rem = p - pr * 20, par = rem / 10, idx = rem - par * 10;
+            const int rr = R0 - 1 + pr, cc = C0 - 1 + 2 * idx + par;
+            if (idx < 9 && rr >= 0 && rr < g.H && cc >= 0 && cc < g.W) voff[r] = (rr * g.W + cc) * 4;
+        }
+    }
+    auto stage = [&](int k0, float* rbuf) {       // chunk starting at channel k0 -> rbuf by LDS-DMA
+        const bool second = k0 >= g.K1;
+        const int kr = second ? k0 - g.K1 : k0, left = (second ? Kb : Ka) - kr;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>((second ? in2_n : in_n) + (size_t)kr * HW), 0, left > 0 ? left * HW * 4 : 0, 0x00020000);
+        float* dst = rbuf + __builtin_amdgcn_readfirstlane(wave) * 64;          // (the DMA adds lane * 4 itself)
+#pragma unroll
+        for (int q = 0; q < HKC; ++q)
+#pragma unroll
+            for (int r = 0; r < C::ROUNDS; ++r)
+                if (r == 0 || wave < (PITCH - 256) / 64)      // (the second round covers positions 256 .. PITCH - 1 only)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + q * PITCH + r * 256),
+                                                             4, voff[r] + q * HW * 4, 0, 0, 0);
+    };
+
+    // ---- this lane's B-operand slots: tile 32 nb + bn -> (ty, tx), channel octet kh; wave = xi
+    const int bn = lane & 31, kh = lane >> 5;
+    const int tx = bn & 7;
+    // row xi of B^T d = d[ra] + sgn d[rb]:  xi 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
+    const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1), rb = wave == 3 ? 3 : (wave == 2 ? 1 : 2);
+    const float sgn = wave == 1 ? 1.f : -1.f;
+    int ta_off[NB], tb_off[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int ty = (bn >> 3) + 4 * nb;
+        ta_off[nb] = (8 * kh) * PITCH + (2 * ty + ra) * 20 + tx;
+        tb_off[nb] = (8 * kh) * PITCH + (2 * ty + rb) * 20 + tx;
+    }
+
+    // ---- A operands: [m tile][chunk][position][piece][m half][lane][16 B]
+    const char* Uw = reinterpret_cast<const char*>(U) + ((size_t)blockIdx.y * nchunks * 16 + 4 * wave) * 6144 + lane * 16;
+    auto load_a = [&](w_bf16x8 (&a)[2][3], int c, int nu) {
+        const char* p = Uw + ((size_t)c * 16 + nu) * 6144;
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+                a[mi][pc] = *reinterpret_cast<const w_bf16x8*>(p + (pc * 2 + mi) * 1024);
+    };
+
+    w_f32x16 acc[4][2][NB];     // [nu][mi][nb]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int c = 0; c < 16; ++c) acc[a][b][nb][c] = 0.f;
+
+    w_bf16x8 as[NSETS][2][3];               // A register sets: position 4 c + nu uses set (4 c + nu) % NSETS = nu % NSETS
+#ifdef GX_WH_STAGGER
+    // the two workgroups of a CU start in the same cycle and would run in lockstep (both waiting for their first patch, both
+    // on the matrix pipe, both in the epilogue): the second one of each CU starts GX_WH_STAGGER x 64 cycles late
+    if (((blockIdx.x + gridDim.x * blockIdx.y) >> 8) & 1)
+        for (int i = 0; i < GX_WH_STAGGER; ++i) __builtin_amdgcn_s_sleep(1);
+#endif
+    stage(0, raw);
+#pragma unroll
+    for (int i = 0; i < LOOK; ++i) load_a(as[i], 0, i);       // (NSETS <= 4: positions 0 .. LOOK - 1 of chunk 0)
+
+    for (int c = 0; c < nchunks; ++c) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): this chunk's patch has landed (own DMA) ...
+        __syncthreads();                             // ... everyone's has; and everyone is done with the other buffer
+        if (c + 1 < nchunks && !(GX_WH_ABL & 8)) stage((c + 1) * HKC, raw + ((c + 1) & 1) * C::RAW_FLOATS);
+        const float* rbuf = raw + (c & 1) * C::RAW_FLOATS;
+        // row combination t[nb][ch][j], j = patch column: column j sits in plane (j & 1) at index tx + (j >> 1)
+        float t[NB][8][4];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) {
+                const float* pa = rbuf + ta_off[nb] + ch * PITCH;
+                const float* pb = rbuf + tb_off[nb] + ch * PITCH;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[nb][ch][j] = fmaf(sgn, pb[(j & 1) * 10 + (j >> 1)], pa[(j & 1) * 10 + (j >> 1)]);
+            }
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) {
+            w_bf16x8 (&acur)[2][3] = as[nu % NSETS];
+            if (!(GX_WH_ABL & 2)) {
+                // position 4 c + nu + LOOK into the set that position 4 c + nu - 1 has just finished with
+                constexpr int dummy = 0; (void)dummy;
+                const int pn = nu + LOOK;
+                if (pn < 4) load_a(as[pn % NSETS], c, pn);
+                else if (c + 1 < nchunks) load_a(as[pn % NSETS], c + 1, pn - 4);
+            }
+            w_bf16x8 b[NB][3];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                // column combination: nu 0: t0 - t2, 1: t1 + t2, 2: t2 - t1, 3: t1 - t3
+                float v[8];
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch)
+                    v[ch] = nu == 0 ? t[nb][ch][0] - t[nb][ch][2]
+                                    : (nu == 1 ? t[nb][ch][1] + t[nb][ch][2] : (nu == 2 ? t[nb][ch][2] - t[nb][ch][1] : t[nb][ch][1] - t[nb][ch][3]));
+                if (GX_WH_ABL & 4) { b[nb][0] = acur[0][0]; b[nb][1] = acur[0][1]; b[nb][2] = acur[0][2]; }
+                else wino_split8(v, b[nb][0], b[nb][1], b[nb][2]);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    w_f32x16 cc = acc[nu][mi][nb];        // pieces: 0 hi, 1 mid, 2 lo; small terms first
+                    if (GX_WH_ABL & 1) { cc[0] += (float)acur[mi][0][0] * (float)b[nb][0][0] + (float)acur[mi][1][1] * (float)b[nb][1][1] + (float)acur[mi][2][2] * (float)b[nb][2][2]; acc[nu][mi][nb] = cc; continue; }
+                    cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[mi][1], b[nb][1], cc, 0, 0, 0);
+                    cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[mi][2], b[nb][0], cc, 0, 0, 0);
+                    cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[mi][0], b[nb][2], cc, 0, 0, 0);
+                    cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[mi][1], b[nb][0], cc, 0, 0, 0);
+                    cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[mi][0], b[nb][1], cc, 0, 0, 0);
+                    cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[mi][0], b[nb][0], cc, 0, 0, 0);
+                    acc[nu][mi][nb] = cc;
+                }
+        }
+    }
+
+    // ---- output transform (as in wino_conv_kernel): right-multiply by A inside the wave, A^T across the four waves through
+    // LDS, one (32-channel half, 32-tile block) at a time
+    float* E = lds;
+    const int tt = tid & 31;
+    const bool second_out = m0 >= g.M1;
+    const int Mo = second_out ? g.M - g.M1 : (g.M1 < g.M ? g.M1 : g.M), mbase = second_out ? g.M1 : 0;
+    float* const outp = second_out ? out2 : out;
+    const size_t out_n = (size_t)n * Mo * HW;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            __syncthreads();
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = e + 8 * r4 + 4 * kh;      // C/D layout: row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+                    const int rg = 4 * r4 + e;
+                    const float q0 = acc[0][mi][nb][rg] + acc[1][mi][nb][rg] + acc[2][mi][nb][rg];
+                    const float q1 = acc[1][mi][nb][rg] - acc[2][mi][nb][rg] - acc[3][mi][nb][rg];
+                    E[((wave * 2 + 0) * 32 + row) * 32 + bn] = q0;
+                    E[((wave * 2 + 1) * 32 + row) * 32 + bn] = q1;
+                }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ml = (tid >> 5) + 8 * j;
+                const int m = m0 + mi * 32 + ml;
+                if (m >= g.M) continue;
+                const int oy = (tt >> 3) + 4 * nb, ox = tt & 7;
+                float q[4][2];
+#pragma unroll
+                for (int xi = 0; xi < 4; ++xi) {
+                    q[xi][0] = E[((xi * 2 + 0) * 32 + ml) * 32 + tt];
+                    q[xi][1] = E[((xi * 2 + 1) * 32 + ml) * 32 + tt];
+                }
+                float2 y0, y1;
+                y0.x = q[0][0] + q[1][0] + q[2][0];
+                y0.y = q[0][1] + q[1][1] + q[2][1];
+                y1.x = q[1][0] - q[2][0] - q[3][0];
+                y1.y = q[1][1] - q[2][1] - q[3][1];
+                float* o = outp + out_n + (size_t)(m - mbase) * HW + (size_t)(R0 + 2 * oy) * g.W + C0 + 2 * ox;
+                *reinterpret_cast<float2*>(o) = y0;
+                *reinterpret_cast<float2*>(o + g.W) = y1;
+            }
+        }
+}
+
+// U for the bf16 pipe: the thread of an even k writes the three words (k, k + 1) of position p
+__device__ __forceinline__ void wino_h_store(unsigned* __restrict__ U, float v0, float v1, int m, int k, int p, int Kpad16) {
+    unsigned short pc[2][3];
+    const float v[2] = {v0, v1};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const __bf16 h = (__bf16)v[e];
+        const float r1 = v[e] - (float)h;
+        const __bf16 mm = (__bf16)r1;
+        const __bf16 l = (__bf16)(r1 - (float)mm);
+        pc[e][0] = __builtin_bit_cast(unsigned short, h);
+        pc[e][1] = __builtin_bit_cast(unsigned short, mm);
+        pc[e][2] = __builtin_bit_cast(unsigned short, l);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) U[gx_wino_h_word(m, k, p, q, Kpad16)] = (unsigned)pc[0][q] | ((unsigned)pc[1][q] << 16);
+}
+
+__global__ void wino_pack_h_kernel(const float* __restrict__ w, unsigned* __restrict__ U, int mode, int Co, int Ci, int Kpad16,
+                                   int Mpad) {
+    const int total = 16 * (Kpad16 / 2) * Mpad;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int m = idx % Mpad, k = 2 * ((idx / Mpad) % (Kpad16 / 2)), p = idx / (Mpad * (Kpad16 / 2));
+        wino_h_store(U, gx_wino_u_value(w, mode, Co, Ci, m, k, p), gx_wino_u_value(w, mode, Co, Ci, m, k + 1, p), m, k, p, Kpad16);
+    }
+}
+
+// the pair variants' operands (wino_pack_pair_kernel) for the bf16 pipe
+__global__ void wino_pack_pair_h_kernel(const float* __restrict__ w1, const float* __restrict__ w2, unsigned* __restrict__ Uf,
+                                        unsigned* __restrict__ Ud, int Co1, int Co2, int Ci, int KpadF, int MpadF, int KpadD,
+                                        int MpadD) {
+    const int totF = 16 * (KpadF / 2) * MpadF, totD = 16 * (KpadD / 2) * MpadD;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < totF + totD; idx += gridDim.x * blockDim.x) {
+        if (idx < totF) {
+            const int m = idx % MpadF, k = 2 * ((idx / MpadF) % (KpadF / 2)), p = idx / (MpadF * (KpadF / 2));
+            float v[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                v[e] = m < Co1 ? gx_wino_u_value(w1, 0, Co1, Ci, m, k + e, p) : gx_wino_u_value(w2, 0, Co2, Ci, m - Co1, k + e, p);
+            wino_h_store(Uf, v[0], v[1], m, k, p, KpadF);
+        } else {
+            const int i = idx - totF;
+            const int m = i % MpadD, k = 2 * ((i / MpadD) % (KpadD / 2)), p = i / (MpadD * (KpadD / 2));
+            float v[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                v[e] = k + e < Co1 ? gx_wino_u_value(w1, 1, Co1, Ci, m, k + e, p) : gx_wino_u_value(w2, 1, Co2, Ci, m, k + e - Co1, p);
+            wino_h_store(Ud, v[0], v[1], m, k, p, KpadD);
+        }
+    }
+}
+
 }  // namespace
+
+static int g_wino_h = -1;      // 1 (default): the bf16 pipe; GENESIS_WINO_BF16X6=0 / gx_wino_precision(0): the fp32 pipe
+bool gx_wino_h_on() {
+    if (g_wino_h < 0) {
+        const char* env = getenv("GENESIS_WINO_BF16X6");
+        g_wino_h = (env && env[0] == '0') ? 0 : 1;
+    }
+    return g_wino_h == 1;
+}
 
 static bool wino_shape_ok(int N, int K, int M, int H, int W) {
     return N > 0 && K >= 16 && M >= 16 && H >= 8 && W >= 16 && (H % 8) == 0 && (W % 16) == 0 && H * W <= 32768;
@@ -376,20 +691,32 @@ bool gx_wino_eligible(int N, int K, int M, int H, int W) {
 // in2 / K1, out2 / M1: the pair variants (WinoGeom); nullptr / 0 for one input tensor and one output tensor
 static int wino_launch(const float* in, const float* in2, int K1, const float* U, float* out, float* out2, int M1, int N,
                        int K, int M, int H, int W, hipStream_t s) {
+    const bool h = gx_wino_h_on();          // (the operands in U were packed for the same pipe: wino_kpad / the pack kinds)
     WinoGeom g;
     g.N = N; g.H = H; g.W = W; g.K = K; g.M = M;
-    g.Kpad = gx_round_up(K, WKC);
+    g.Kpad = gx_round_up(K, h ? HKC : WKC);
     g.Mpad = gx_round_up(M, 64);
     g.K1 = in2 ? K1 : g.Kpad;
     g.M1 = out2 ? M1 : g.Mpad;
     if (!in2) in2 = in;
     if (!out2) out2 = out;
-    g.tiles_h = H / (2 * WTH);
+    // bf16 pipe: 32-tile workgroups, two per CU.  The 64-tile variant (one workgroup per CU, half the A-operand traffic per
+    // MFMA, A prefetch two positions deep) was measured SLOWER -- 51.1 vs 48.6 us (64 -> 64 @ 64 x 64, B = 32), 94.6 vs 83.2 us
+    // (128 -> 64): one wave per SIMD has nobody to hand the matrix pipe to while it waits -- and is kept behind
+    // GENESIS_WINO_NB=2 for measurement only.
+    static const char* nb_env = getenv("GENESIS_WINO_NB");
+    const int nb = (h && (H % 16) == 0 && nb_env && nb_env[0] == '2') ? 2 : 1;
+    g.tiles_h = H / (2 * WTH * nb);
     g.tiles_w = W / (2 * WTW);
     static bool attr_set = false;
-    const size_t lds = (size_t)(2 * RAW_FLOATS + 2 * V_FLOATS) * sizeof(float);
+    const size_t lds = h ? (nb == 2 ? WHCfg<2>::LDS_BYTES : WHCfg<1>::LDS_BYTES)
+                         : (size_t)(2 * RAW_FLOATS + 2 * V_FLOATS) * sizeof(float);
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_h_kernel<1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_h_kernel<2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
@@ -397,6 +724,13 @@ static int wino_launch(const float* in, const float* in2, int K1, const float* U
         const double flops = 2.0 * N * (double)M * K * 9 * H * W;    // algorithmic (direct-sum) flops
         const double bytes = 4.0 * ((double)N * K * H * W + (double)N * M * H * W + 9.0 * K * M);
         GxProf pf(KID_WINO, s, flops, bytes);
+        if (h && nb == 2)
+            hipLaunchKernelGGL(wino_conv_h_kernel<2>, dim3(N * g.tiles_h * g.tiles_w, g.Mpad / 64), dim3(256), lds, s, in, in2,
+                               reinterpret_cast<const unsigned*>(U), out, out2, g);
+        else if (h)
+            hipLaunchKernelGGL(wino_conv_h_kernel<1>, dim3(N * g.tiles_h * g.tiles_w, g.Mpad / 64), dim3(256), lds, s, in, in2,
+                               reinterpret_cast<const unsigned*>(U), out, out2, g);
+        else
         hipLaunchKernelGGL(wino_conv_kernel, dim3(N * g.tiles_h * g.tiles_w, g.Mpad / 64), dim3(256), lds, s, in, in2, U,
                            out, out2, g);
     }
@@ -419,10 +753,23 @@ int gx_conv3x3_wino_policy(int mode) {
     return GX_OK;
 }
 
+// bytes of one direction's packed operands (either pipe's layout fits: the bf16 one is 1.5 x the fp32 one)
+static size_t wino_u_bytes(int K, int M) {
+    const size_t f = (size_t)16 * gx_round_up(K, 8) * gx_round_up(M, 64) * sizeof(float);
+    const size_t h = gx_wino_h_bytes(gx_round_up(K, HKC), gx_round_up(M, 64));
+    return f > h ? f : h;
+}
+
+int gx_wino_precision(int mode) {
+    GX_CHECK_ARG(mode == 0 || mode == 1, "gx_wino_precision: mode must be 0 (fp32 matrix pipe) or 1 (bf16 pipe, six piece products)");
+    g_wino_h = mode;
+    return GX_OK;
+}
+
 size_t gx_conv3x3_wino_ws_bytes(int N, int Cin, int Cout, int H, int W) {
     (void)N; (void)H; (void)W;
     const int c = Cin > Cout ? Cin : Cout;
-    return (size_t)16 * gx_round_up(c, 8) * gx_round_up(c, 64) * sizeof(float);
+    return wino_u_bytes(c, c);
 }
 
 // mode 0: y[N,Cout,H,W] = conv3x3(x[N,Cin,H,W], w[Cout,Cin,3,3]); mode 1: dx[N,Cin,H,W] from dy[N,Cout,H,W] (same w)
@@ -436,11 +783,16 @@ int gx_conv3x3_wino(const float* x, const float* w, float* y, int N, int Cin, in
     GX_CHECK_ARG(ws_bytes >= gx_conv3x3_wino_ws_bytes(N, Cin, Cout, H, W), "gx_conv3x3_wino: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     const int K = mode == 0 ? Cin : Cout, M = mode == 0 ? Cout : Cin;
-    const int Kpad = gx_round_up(K, WKC), Mpad = gx_round_up(M, 64);
+    const bool h = gx_wino_h_on();
+    const int Kpad = gx_round_up(K, h ? HKC : WKC), Mpad = gx_round_up(M, 64);
     float* U = (float*)ws;
     {
         const int total = 16 * Kpad * Mpad;
         GxProf pf(KID_PACK_WEIGHTS, s, 0.0, 8.0 * total);
+        if (h)
+            hipLaunchKernelGGL(wino_pack_h_kernel, dim3(gx_ceil_div(total / 2, 256)), dim3(256), 0, s, w, (unsigned*)U, mode, Cout,
+                               Cin, Kpad, Mpad);
+        else
         hipLaunchKernelGGL(wino_pack_kernel, dim3(gx_ceil_div(total, 256)), dim3(256), 0, s, w, U, mode, Cout, Cin, Kpad,
                            Mpad);
     }
@@ -457,13 +809,29 @@ int gx_conv3x3_pair_supported(int N, int Cin, int Co1, int Co2, int H, int W) {
 size_t gx_conv3x3_pair_ws_bytes(int N, int Cin, int Co1, int Co2, int H, int W) {
     (void)N; (void)H; (void)W;
     const int Co = Co1 + Co2;
-    return ((size_t)16 * gx_round_up(Cin, 8) * gx_round_up(Co, 64) + (size_t)16 * gx_round_up(Co, 8) * gx_round_up(Cin, 64)) *
-           sizeof(float);
+    return wino_u_bytes(Cin, Co) + wino_u_bytes(Co, Cin);
 }
 
 static void pair_u(void* ws, int Cin, int Co, float** Uf, float** Ud) {
     *Uf = (float*)ws;
-    *Ud = *Uf + (size_t)16 * gx_round_up(Cin, 8) * gx_round_up(Co, 64);
+    *Ud = *Uf + wino_u_bytes(Cin, Co) / sizeof(float);
+}
+
+// both directions' operands of a layer pair in one launch, for the pipe in force
+static int pair_pack(const float* w1, const float* w2, float* Uf, float* Ud, int Cin, int Co1, int Co2, hipStream_t s) {
+    const int Co = Co1 + Co2;
+    const bool h = gx_wino_h_on();
+    const int kq = h ? HKC : WKC;
+    const int KpF = gx_round_up(Cin, kq), MpF = gx_round_up(Co, 64), KpD = gx_round_up(Co, kq), MpD = gx_round_up(Cin, 64);
+    const int total = 16 * (KpF * MpF + KpD * MpD);
+    GxProf pf(KID_PACK_WEIGHTS, s, 0.0, 8.0 * total);
+    if (h)
+        hipLaunchKernelGGL(wino_pack_pair_h_kernel, dim3(gx_ceil_div(total / 2, 256)), dim3(256), 0, s, w1, w2, (unsigned*)Uf,
+                           (unsigned*)Ud, Co1, Co2, Cin, KpF, MpF, KpD, MpD);
+    else
+        hipLaunchKernelGGL(wino_pack_pair_kernel, dim3(gx_ceil_div(total, 256)), dim3(256), 0, s, w1, w2, Uf, Ud, Co1, Co2, Cin,
+                           KpF, MpF, KpD, MpD);
+    return GX_OK;
 }
 
 // y1 [N,Co1,H,W] = conv3x3(x, w1), y2 [N,Co2,H,W] = conv3x3(x, w2); ws keeps the packed weights of BOTH directions
@@ -477,13 +845,7 @@ int gx_conv3x3_pair_fwd(const float* x, const float* w1, const float* w2, float*
     const int Co = Co1 + Co2;
     float *Uf, *Ud;
     pair_u(ws, Cin, Co, &Uf, &Ud);
-    {
-        const int KpF = gx_round_up(Cin, 8), MpF = gx_round_up(Co, 64), KpD = gx_round_up(Co, 8), MpD = gx_round_up(Cin, 64);
-        const int total = 16 * (KpF * MpF + KpD * MpD);
-        GxProf pf(KID_PACK_WEIGHTS, s, 0.0, 8.0 * total);
-        hipLaunchKernelGGL(wino_pack_pair_kernel, dim3(gx_ceil_div(total, 256)), dim3(256), 0, s, w1, w2, Uf, Ud, Co1, Co2,
-                           Cin, KpF, MpF, KpD, MpD);
-    }
+    pair_pack(w1, w2, Uf, Ud, Cin, Co1, Co2, s);
     GX_CHECK_LAUNCH("gx_conv3x3_pair_fwd(pack)");
     return wino_launch(x, nullptr, 0, Uf, y1, y2, Co1, N, Cin, Co, H, W, s);
 }
@@ -499,11 +861,7 @@ int gx_conv3x3_pair_dgrad(const float* dy1, const float* dy2, const float* w1, c
     float *Uf, *Ud;
     pair_u(ws, Cin, Co, &Uf, &Ud);
     if (pack) {
-        const int KpF = gx_round_up(Cin, 8), MpF = gx_round_up(Co, 64), KpD = gx_round_up(Co, 8), MpD = gx_round_up(Cin, 64);
-        const int total = 16 * (KpF * MpF + KpD * MpD);
-        GxProf pf(KID_PACK_WEIGHTS, s, 0.0, 8.0 * total);
-        hipLaunchKernelGGL(wino_pack_pair_kernel, dim3(gx_ceil_div(total, 256)), dim3(256), 0, s, w1, w2, Uf, Ud, Co1, Co2,
-                           Cin, KpF, MpF, KpD, MpD);
+        pair_pack(w1, w2, Uf, Ud, Cin, Co1, Co2, s);
         GX_CHECK_LAUNCH("gx_conv3x3_pair_dgrad(pack)");
     }
     return wino_launch(dy1, dy2, Co1, Ud, dx, nullptr, 0, N, Co, Cin, H, W, s);

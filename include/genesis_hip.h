@@ -53,6 +53,11 @@ int gx_conv3x3_wino_supported(int N, int Cin, int Cout, int H, int W);
 /*      which layers gx_conv3x3_fwd / _dgrad send to it: 0 none, 1 those whose grid fills the chip (default; also
  *      GENESIS_WINOGRAD=0/1/2 in the environment), 2 every supported shape. */
 int gx_conv3x3_wino_policy(int mode);
+/*      which matrix pipe the Winograd layers' products run on: 1 (default; GENESIS_WINO_BF16X6=0/1 in the environment) = the
+ *      bf16 pipe, every fp32 product U * V from six bf16 piece products accumulated in fp32 (hi + mid + lo pieces hold all 24
+ *      mantissa bits: fp32 accuracy, tests/test_kernels_gpu.py::test_conv3x3_winograd); 0 = v_mfma_f32_32x32x2_f32.  Packed
+ *      operands are laid out for the pipe in force when they were packed: switch between iterations, not inside one. */
+int gx_wino_precision(int mode);
 /*      k-quad tap-conv kernels (gx_kq.hip: 16-byte k-contiguous MFMA operand reads) behind gx_conv3x3_fwd / _dgrad and
  *      gx_deconv5x5s2_fwd / _dgrad: 0 never, 1 layers whose grid fills the chip (default; GENESIS_KQ=0/1/2 in the
  *      environment), 2 every eligible shape (power-of-two grids, reduction channels a multiple of 8). */
