@@ -332,11 +332,11 @@ def main():
                                       'ms_per_step': 1e3 * dt_long / long_steps,
                                       'note': 'the same loop over a longer window, after the timed region (max over ranks)'}
         if os.environ.get('GENESIS_WGQ_BF16X6', '1') != '0':
-            result['arithmetic'] = ('fp32 tensors and fp32 accumulation everywhere; the weight gradients and the chip-filling '
+            result['arithmetic'] = ('fp32 tensors and fp32 accumulation everywhere; the weight gradients, the Winograd conv3x3 layers and the chip-filling '
                                     'transposed-conv forward / data-gradient layers form every fp32 product from six bf16 piece '
                                     'products on the bf16 matrix pipe (hi+mid+lo pieces hold all 24 mantissa bits: error vs '
                                     'fp64 as on the fp32 pipe, tests/test_kernels_gpu.py *_bf16_pipe_*); everything else on the '
-                                    'fp32 pipe; GENESIS_WGQ_BF16X6=0 GENESIS_KQ_BF16X6=0 put all of it back there')
+                                    'fp32 pipe; GENESIS_WGQ_BF16X6=0 GENESIS_KQ_BF16X6=0 GENESIS_WINO_BF16X6=0 put all of it back there')
         if rehearsal:
             result['rehearsal'] = 'all %d ranks on ONE GPU, gloo collective: exercises the launch path only, not a measurement' % world
         if getattr(ts, 'capture_fallback_reason', None):
@@ -380,7 +380,8 @@ def main():
                 ach = dom['flops'] / sec / 1e12
                 mfma_peak = PEAK_FP32_MFMA_TFLOPS
                 roof = {'bound': 'mfma', 'kernel': dom['name'], 'achieved': ach, 'peak': mfma_peak, 'unit': 'TFLOP/s'}
-                on_bf16 = (dom['name'] == 'wgq_stream_kernel' and os.environ.get('GENESIS_WGQ_BF16X6', '1') != '0') or \
+                wino_b6 = dom['name'] == 'wino_conv_kernel' and os.environ.get('GENESIS_WINO_BF16X6', '1') != '0'
+                on_bf16 = wino_b6 or (dom['name'] == 'wgq_stream_kernel' and os.environ.get('GENESIS_WGQ_BF16X6', '1') != '0') or \
                           (dom['name'] in ('kq_dth_kernel', 'kq_dgh_kernel', 'kq_c3h_kernel') and os.environ.get('GENESIS_KQ_BF16X6', '1') != '0')
                 if on_bf16:
                     # `achieved` counts the algorithmic fp32 flops; the kernel executes six bf16 MFMA products for each of
@@ -395,11 +396,13 @@ def main():
                     # `achieved` is ALGORITHMIC (direct-sum) flops / time, as for every kernel; the Winograd kernel executes
                     # 16 multiplies where the direct sum has 36: the ceiling of the ALGORITHM on the fp32 pipe is 2.25 x the
                     # pipe's peak, and its rate on the pipe itself is achieved / 2.25
-                    mfma_peak = 2.25 * PEAK_FP32_MFMA_TFLOPS
+                    pipe_peak = PEAK_BF16_MFMA_TFLOPS / BF16X6_TERMS if wino_b6 else PEAK_FP32_MFMA_TFLOPS
+                    mfma_peak = 2.25 * pipe_peak
                     roof['peak'] = mfma_peak
-                    roof['algorithm'] = ('Winograd F(2x2,3x3): 1/2.25 of the algorithmic flops are executed on the fp32 MFMA '
-                                         'pipe; peak = 2.25 x %.1f' % PEAK_FP32_MFMA_TFLOPS)
-                    roof['achieved_on_mfma_pipe'] = ach / 2.25
+                    roof['algorithm'] = ('Winograd F(2x2,3x3): 1/2.25 of the algorithmic flops are executed as products%s; '
+                                         'peak = 2.25 x %.1f' % (', each as six bf16 piece products on the bf16 MFMA pipe (2500 / 6)'
+                                                                 if wino_b6 else ' on the fp32 MFMA pipe', pipe_peak))
+                    roof['achieved_on_mfma_pipe'] = ach / 2.25 * (BF16X6_TERMS if wino_b6 else 1)
                 roof['frac'] = ach / mfma_peak
                 # the plain formula: algorithmic flops / time / the peak of the tensors' NATIVE pipe (fp32 MFMA, 157.3 TF/s).
                 # It exceeds 1 where the algorithm executes fewer multiplies than the direct sum (Winograd) or where the fp32
@@ -491,6 +494,7 @@ def main():
         ts.close()
         _lib.call('gx_wgq_precision', 0)
         _lib.call('gx_kq_precision', 0)
+        _lib.call('gx_wino_precision', 0)
         try:
             ts2 = TrainStep(model, args.img, lr=1e-4, graph=True)
             ts2.prepare(batches[0])
@@ -505,11 +509,12 @@ def main():
             result['value_fp32_pipe_only'] = {'value': args.batch * args.fp32_pipe_steps / dt2, 'unit': 'images/sec',
                                               'steps': args.fp32_pipe_steps, 'ms_per_step': 1e3 * dt2 / args.fp32_pipe_steps,
                                               'arithmetic': 'every product on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32): '
-                                                            'gx_wgq_precision(0), gx_kq_precision(0)'}
+                                                            'gx_wgq_precision(0), gx_kq_precision(0), gx_wino_precision(0)'}
             ts2.close()
         finally:
             _lib.call('gx_wgq_precision', 1)
             _lib.call('gx_kq_precision', 1)
+            _lib.call('gx_wino_precision', 1)
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0 and args.model == 'genesisv2':
         result['cpu_baseline'] = cpu_baseline(args)
