@@ -1082,7 +1082,7 @@ def gn_relu_bwd_proj(y, gamma, beta, mean, rstd, groups, g_out, w, want_dbias=Fa
     dgamma = o[0] if o[0] is not None else torch.empty(C, dtype=F32, device=y.device)
     dbeta = o[1] if o[1] is not None else torch.empty(C, dtype=F32, device=y.device)
     dbias = (o[2] if o[2] is not None else torch.empty(C, dtype=F32, device=y.device)) if want_dbias else None
-    nb = _lib.query('gx_gn_relu_bwd_ws_bytes', N, C)
+    nb = _lib.query('gx_gn_relu_bwd_proj_ws_bytes', N, C, H, W, groups, int(g_out.shape[1]))
     ws = _ws(nb, y.device)
     direct = o[0] is not None and o[1] is not None and (not want_dbias or o[2] is not None)
     with _deferring(direct, ws):

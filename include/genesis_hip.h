@@ -159,6 +159,9 @@ int gx_gn_relu_bwd_proj(const float* y, const float* gamma, const float* beta, c
  *      kernel also emits the per-image partials of the 1x1 conv's weight / bias gradient (its input exists only inside
  *      this kernel); gx_conv1x1_gn_wgrad_finish sums them over the images -- no separate weight-gradient pass over y. */
 int gx_gn_relu_bwd_proj_fuses_wgrad(int C, int H, int W, int groups, int Cout);
+/*      workspace of gx_gn_relu_bwd_proj (>= gx_gn_relu_bwd_ws_bytes): slabs too large for one workgroup (128 x 128 images) are
+ *      processed in 4096-pixel chunks -- chunk sums, per-slab constants, chunked apply -- whose records live here */
+size_t gx_gn_relu_bwd_proj_ws_bytes(int N, int C, int H, int W, int groups, int Cout);
 
 /* ---- Instance-Colouring stick-breaking attention: modules/attention.py:162-226.
  *      colour [B,C<=8,H,W]; log_sigma: device pointer to the fp64 0-dim parameter; rand_pixel [B,1,H,W];

@@ -740,7 +740,8 @@ def test_groupnorm_sums_splitk_partials_bitwise(kind, N, Cin, Cout, S, monkeypat
         assert torch.equal(a, b_)
 
 
-@pytest.mark.parametrize('N,C,Cout,S,groups', [(3, 64, 4, 64, 8), (2, 32, 4, 16, 8), (5, 64, 8, 32, 8), (2, 16, 3, 16, 8)])
+@pytest.mark.parametrize('N,C,Cout,S,groups', [(3, 64, 4, 64, 8), (2, 32, 4, 16, 8), (5, 64, 8, 32, 8), (2, 16, 3, 16, 8),
+                                               (2, 64, 4, 128, 8), (3, 32, 7, 128, 8)])    # 128 x 128: the chunked (split) path
 def test_conv1x1_on_unmaterialised_groupnorm(N, C, Cout, S, groups):
     """Last decoder stage (genesisv2_config.py:97-99): GroupNorm statistics only, the 1x1 conv normalises on load, its
     data gradient is folded into the norm backward -- against the three separate torch ops."""
@@ -768,7 +769,7 @@ def test_conv1x1_on_unmaterialised_groupnorm(N, C, Cout, S, groups):
     close(dbeta, br.grad, 1e-4, 1e-4, 'dbeta')
     close(dbias, yr.grad.sum((0, 2, 3)), 1e-4, 1e-4, 'dbias')
     fused = hip.conv1x1_gn_bwd_fused(yd, gd, bd, mean, rstd, groups, gg, wd, bbd, None, True)
-    if S * S * Cout * 4 <= 128 * 1024 and S * S >= 256:
+    if (S * S * Cout * 4 <= 128 * 1024 and S * S >= 256) or S == 128:
         assert fused is not None                       # one pass over y: norm backward + conv weight gradient
     if fused is not None:
         dy2, (dgamma2, dbeta2, dbias2), (dw2, db2, _) = fused
@@ -777,10 +778,11 @@ def test_conv1x1_on_unmaterialised_groupnorm(N, C, Cout, S, groups):
         close(db2, bbr.grad, 1e-4, 1e-4, 'db (fused)')
 
 
-def test_gated_conv1x1_on_unmaterialised_groupnorm():
+@pytest.mark.parametrize('S', [32, 128])
+def test_gated_conv1x1_on_unmaterialised_groupnorm(S):
     """SemiConv colour head on seg_head's never-written activation: gate * conv1x1(relu(gn(y))) + uv and all its
-    gradients (gate included) against torch."""
-    N, C, Cout, S, groups = 3, 64, 8, 32, 8
+    gradients (gate included) against torch (S = 128: the chunked norm backward of the 128 x 128 configuration)."""
+    N, C, Cout, groups = 3, 64, 8, 8
     y = rnd(N, C, S, S, seed=41, scale=2.0) - 0.1
     gamma = 1 + 0.3 * rnd(C, seed=42)
     beta = 0.2 * rnd(C, seed=43)
