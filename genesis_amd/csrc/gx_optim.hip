@@ -56,6 +56,77 @@ adam_pair_kernel(const AdamGroup a, const AdamGroup b, unsigned nb32, const int6
                                   gscale, blockIdx.x - nb32, gridDim.x - nb32);
 }
 
+// torch.optim.RMSprop(lr) defaults (alpha 0.99, eps 1e-8, no momentum, not centred; train.py:171-172) and
+// torch.optim.SGD(lr, momentum 0.9) (train.py:175-176): one state buffer `m` (square average / momentum buffer, zero-initialised:
+// mu * 0 + g reproduces torch's buf = grad at the first step).  KIND 1 = RMSprop, 2 = SGD with momentum.
+template <typename T, int KIND, bool ZERO_G>
+__device__ __forceinline__ void simple_opt_body(T* __restrict__ p, T* __restrict__ g, T* __restrict__ m, size_t n, double lr,
+                                                double hp, double eps, float gscale, unsigned block, unsigned nblocks) {
+    const T lr_t = (T)lr, hp_t = (T)hp, one_m = (T)(1.0 - hp), eps_t = (T)eps;
+    for (size_t i = (size_t)block * blockDim.x + threadIdx.x; i < n; i += (size_t)nblocks * blockDim.x) {
+        const T gi = g[i] * (T)gscale;
+        if (ZERO_G) g[i] = (T)0;
+        if (KIND == 1) {
+            const T sq = m[i] * hp_t + gi * gi * one_m;            // square_avg.mul_(alpha).addcmul_(g, g, 1 - alpha)
+            m[i] = sq;
+            p[i] = p[i] - lr_t * (gi / (sqrt(sq) + eps_t));        // p.addcdiv_(g, sqrt(square_avg) + eps, -lr)
+        } else {
+            const T buf = m[i] * hp_t + gi;                        // buf.mul_(momentum).add_(g)
+            m[i] = buf;
+            p[i] = p[i] - lr_t * buf;
+        }
+    }
+}
+template <int KIND, bool ZERO_G>
+__global__ void __launch_bounds__(256)
+simple_opt_pair_kernel(const AdamGroup a, const AdamGroup b, unsigned nb32, int64_t* __restrict__ step, double lr, double hp,
+                       double eps, float gscale) {
+    (void)step;
+    if (blockIdx.x < nb32)
+        simple_opt_body<float, KIND, ZERO_G>((float*)a.p, (float*)a.g, (float*)a.m, a.n, lr, hp, eps, gscale, blockIdx.x, nb32);
+    else
+        simple_opt_body<double, KIND, ZERO_G>((double*)b.p, (double*)b.g, (double*)b.m, b.n, lr, hp, eps, gscale,
+                                              blockIdx.x - nb32, gridDim.x - nb32);
+}
+
+// beta of the fixed-beta objective with linear warm-up (train.py:252-258): beta * iter / (0.2 * train_iter) clamped to
+// [0, beta]; iter = the device step counter BEFORE this iteration's increment
+__global__ void beta_warmup_kernel(const int64_t* __restrict__ step, float beta, float warm_iters, float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float b = beta * (float)(*step) / warm_iters;
+    *out = fminf(fmaxf(b, 0.f), beta);
+}
+
+// train.py:244-246: mse_b = mean over (c, h, w) of (x - recon)^2, rmse_b = sqrt(mse_b); out = (mean_b mse_b, mean_b rmse_b).
+// One workgroup per image, then the last workgroup to finish (a counter) averages: fixed order, no float atomics.
+__global__ void __launch_bounds__(256)
+mse_rmse_kernel(const float* __restrict__ x, const float* __restrict__ r, int B, int n, float* __restrict__ per_image,
+                unsigned* __restrict__ counter, float* __restrict__ out) {
+    __shared__ double red[4];
+    __shared__ bool last;
+    const int b = blockIdx.x;
+    const float* xb = x + (size_t)b * n;
+    const float* rb = r + (size_t)b * n;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) { const float d = xb[i] - rb[i]; s += (double)d * d; }
+    s = gx_wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        per_image[b] = (float)(((red[0] + red[1]) + (red[2] + red[3])) / n);
+        __threadfence();
+        last = atomicAdd(counter, 1u) == (unsigned)(B - 1);
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence();
+        double m = 0.0, rm = 0.0;
+        for (int i = 0; i < B; ++i) { const float v = __builtin_nontemporal_load(per_image + i); m += v; rm += sqrtf(v); }
+        out[0] = (float)(m / B); out[1] = (float)(rm / B);
+        *counter = 0u;                                     // ready for the next launch (graph replay)
+    }
+}
+
 // ---- the step's noise in one launch: counter-based (Philox4x32-10), keyed by (seed, the device-side step counter): a
 //      replayed HIP graph draws fresh numbers every step without the framework's graph-RNG bookkeeping (two offset fills
 //      and one launch per tensor).  Element i of tensor t: counter (i / 4, t, step) -> four 32-bit words.
@@ -198,6 +269,52 @@ int gx_geco_update_step(float* state, const float* err, float goal, float step_s
                            alpha, speedup, use_speedup, beta_min, beta_max, step);
     }
     GX_CHECK_LAUNCH("gx_geco_update_step");
+    return GX_OK;
+}
+
+/* The other optimisers of train.py:170-176 on the same flat buffers: kind 1 = torch.optim.RMSprop(lr) (alpha 0.99, eps 1e-8),
+ * kind 2 = torch.optim.SGD(lr, momentum 0.9); m = their one state buffer (square average / momentum buffer). */
+int gx_optimiser_step_pair(int kind, float* p32, float* g32, float* m32, size_t n32, double* p64, double* g64, double* m64,
+                           size_t n64, int64_t* step, double lr, double hp, double eps, float grad_scale, int zero_grads,
+                           gx_stream_t stream) {
+    GX_CHECK_ARG(kind == 1 || kind == 2, "gx_optimiser_step_pair: kind must be 1 (RMSprop) or 2 (SGD with momentum)");
+    GX_CHECK_ARG(p32 && g32 && m32 && n32 > 0, "gx_optimiser_step_pair: null pointer / empty fp32 group");
+    GX_CHECK_ARG(n64 == 0 || (p64 && g64 && m64), "gx_optimiser_step_pair: null fp64 pointer");
+    hipStream_t s = (hipStream_t)stream;
+    size_t nb32 = (n32 + 1023) / 1024, nb64 = n64 ? (n64 + 1023) / 1024 : 0;
+    if (nb32 > 2048) nb32 = 2048;
+    if (nb64 > 256) nb64 = 256;
+    const AdamGroup a{p32, g32, m32, nullptr, n32}, b{p64, g64, m64, nullptr, n64};
+    const dim3 grid((unsigned)(nb32 + nb64));
+    {
+        GxProf pf(KID_ADAM, s, 0.0, 4.0 * 5.0 * (double)n32 + 8.0 * 5.0 * (double)n64);
+#define GX_OPT(K, Z) hipLaunchKernelGGL((simple_opt_pair_kernel<K, Z>), grid, dim3(256), 0, s, a, b, (unsigned)nb32, step, lr, hp, eps, grad_scale)
+        if (kind == 1) { if (zero_grads) GX_OPT(1, true); else GX_OPT(1, false); }
+        else { if (zero_grads) GX_OPT(2, true); else GX_OPT(2, false); }
+#undef GX_OPT
+    }
+    GX_CHECK_LAUNCH("gx_optimiser_step_pair");
+    return GX_OK;
+}
+
+int gx_beta_warmup(const int64_t* step, float beta, float warm_iters, float* out, gx_stream_t stream) {
+    GX_CHECK_ARG(step && out && warm_iters > 0.f, "gx_beta_warmup: bad arguments");
+    hipLaunchKernelGGL(beta_warmup_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step, beta, warm_iters, out);
+    GX_CHECK_LAUNCH("gx_beta_warmup");
+    return GX_OK;
+}
+
+size_t gx_mse_rmse_ws_bytes(int B) { return ((size_t)B + 4) * sizeof(float); }
+int gx_mse_rmse(const float* x, const float* recon, int B, int n, float* out, void* ws, size_t ws_bytes, gx_stream_t stream) {
+    GX_CHECK_ARG(x && recon && out && ws && B > 0 && n > 0, "gx_mse_rmse: bad arguments");
+    GX_CHECK_ARG(ws_bytes >= gx_mse_rmse_ws_bytes(B), "gx_mse_rmse: workspace too small");
+    unsigned* counter = (unsigned*)ws;                 // must be zero before the FIRST launch (the kernel re-zeroes it)
+    float* per_image = (float*)ws + 4;
+    {
+        GxProf pf(KID_SMALL_REDUCE, (hipStream_t)stream, 0.0, 8.0 * (double)B * n);
+        hipLaunchKernelGGL(mse_rmse_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, recon, B, n, per_image, counter, out);
+    }
+    GX_CHECK_LAUNCH("gx_mse_rmse");
     return GX_OK;
 }
 

@@ -22,10 +22,24 @@ def _p(t):
 
 class TrainStep(object):
 
+    OPTIMISERS = ('adam', 'rmsprop', 'sgd')       # train.py:170-176 (config.optimiser)
+
     def __init__(self, model, img_size, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, geco=None, use_geco=True,
                  beta_fixed=0.5, process_group=None, graph=False, async_wgrad=False, weight_cache=True, defer_reduces=True,
-                 side_prior=None):
+                 side_prior=None, optimiser='adam', beta_warmup=False, train_iter=None, log_mse=False):
+        """optimiser: 'adam' (torch.optim.Adam(lr); betas / eps as given), 'rmsprop' (torch.optim.RMSprop(lr): alpha 0.99,
+        eps 1e-8) or 'sgd' (torch.optim.SGD(lr, 0.9)) -- train.py:170-176.  use_geco=False: the fixed-beta objective
+        err + beta_fixed * kl, with beta_warmup the linear ramp beta_fixed * iter / (0.2 * train_iter) of train.py:252-258.
+        log_mse: step() also returns train.py:244-246's (mse, rmse) behind (elbo, err, kl, beta)."""
+        if optimiser not in self.OPTIMISERS:
+            raise ValueError('optimiser must be one of %s (train.py:170-176), got %r' % (self.OPTIMISERS, optimiser))
+        if beta_warmup and (use_geco and geco is None or geco is not None):
+            raise ValueError('beta_warmup belongs to the fixed-beta objective (use_geco=False), train.py:249-259')
+        if beta_warmup and not train_iter:
+            raise ValueError('beta_warmup needs train_iter (the ramp covers 0.2 * train_iter iterations)')
         self.model = model
+        self.optimiser = optimiser
+        self.beta_warmup, self.train_iter, self.log_mse = bool(beta_warmup), train_iter, bool(log_mse)
         self.lr, self.betas, self.eps = lr, betas, eps
         self.device = next(model.parameters()).device
         if self.device.type != 'cuda':
@@ -47,6 +61,7 @@ class TrainStep(object):
         self._wcache = _lib.query('gx_weight_cache_create') if weight_cache else None
         self._wcache_ready = False
         self.step_t = torch.zeros((), dtype=torch.int64, device=self.device)
+        self._mse_ws = self._mse_out = None
         # the step's noise (rand_pixel, eps) from one counter-based launch keyed by (torch's seed + rank, the step counter)
         # instead of torch.rand + torch.randn and their graph-RNG bookkeeping (GENESIS_HIP_NOISE=0: torch's generators)
         # The hook is on the model only WHILE an iteration of this loop runs (_enter .. _leave): validation / visualisation
@@ -190,7 +205,18 @@ class TrainStep(object):
     def _forward_backward(self, x, **forward_kwargs):
         """zero-grad'ed bucket -> forward -> loss -> backward; leaves (err, kl) batch means in the bucket tail."""
         self._grads_clean = False
+        if self.beta_warmup:       # this iteration's beta from the device step counter (= the iteration index, train.py:254)
+            _lib.call('gx_beta_warmup', _p(self.step_t), float(self.beta_fixed), 0.2 * float(self.train_iter),
+                      _p(self._beta_fixed_t), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         recon, losses, stats, att_stats, comp_stats = self.model(x, **forward_kwargs)
+        if self.log_mse:
+            with torch.no_grad():
+                xr, rr = x.detach().contiguous(), recon.detach().contiguous()
+                if self._mse_ws is None or self._mse_ws.numel() < xr.shape[0] + 4:
+                    self._mse_ws = torch.zeros(xr.shape[0] + 4, device=self.device)
+                    self._mse_out = torch.zeros(2, device=self.device)
+                _lib.call('gx_mse_rmse', _p(xr), _p(rr), xr.shape[0], xr[0].numel(), _p(self._mse_out), _p(self._mse_ws),
+                          self._mse_ws.numel() * 4, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         # loss aggregation of train.py:226-242 (every model family: kl_m | kl_m_k, kl_l | kl_l_k)
         beta_t = self.geco.state[0:1] if self.geco is not None else self._beta_fixed_t.view(1)
         # (if / elif per stage like the reference: a model returning both forms of a term must not be counted twice)
@@ -257,15 +283,24 @@ class TrainStep(object):
         else:
             _lib.call('gx_step_increment', _p(self.step_t), stream)
         # fp32 and fp64 parameter groups in one launch; it zeroes the gradients it consumed
-        _lib.call('gx_adam_step_pair', _p(self.flat_p), _p(self.flat_g), _p(self.m32), _p(self.v32), self.n32,
-                  _p(self.flat_p64) if self.n64 else None, _p(self.flat_g64) if self.n64 else None,
-                  _p(self.m64) if self.n64 else None, _p(self.v64) if self.n64 else None, self.n64,
-                  _p(self.step_t), self.lr, self.betas[0], self.betas[1], self.eps, gscale, 1, stream)
+        if self.optimiser == 'adam':
+            _lib.call('gx_adam_step_pair', _p(self.flat_p), _p(self.flat_g), _p(self.m32), _p(self.v32), self.n32,
+                      _p(self.flat_p64) if self.n64 else None, _p(self.flat_g64) if self.n64 else None,
+                      _p(self.m64) if self.n64 else None, _p(self.v64) if self.n64 else None, self.n64,
+                      _p(self.step_t), self.lr, self.betas[0], self.betas[1], self.eps, gscale, 1, stream)
+        else:
+            # RMSprop(lr): alpha 0.99, eps 1e-8; SGD(lr, momentum 0.9) -- torch's defaults as train.py:170-176 constructs them
+            kind, hp, eps = (1, 0.99, 1e-8) if self.optimiser == 'rmsprop' else (2, 0.9, 0.0)
+            _lib.call('gx_optimiser_step_pair', kind, _p(self.flat_p), _p(self.flat_g), _p(self.m32), self.n32,
+                      _p(self.flat_p64) if self.n64 else None, _p(self.flat_g64) if self.n64 else None,
+                      _p(self.m64) if self.n64 else None, self.n64, _p(self.step_t), self.lr, hp, eps, gscale, 1, stream)
         self._grads_clean = True
         if local:
-            return beta_used[1:5]                            # ElboFn's (elbo, err, kl, beta used)
-        bu = beta_used[4] if fused else beta_used
-        return torch.stack((tail[0] + tail[1], tail[0], tail[1], bu))
+            out = beta_used[1:5]                             # ElboFn's (elbo, err, kl, beta used)
+        else:
+            bu = beta_used[4] if fused else beta_used
+            out = torch.stack((tail[0] + tail[1], tail[0], tail[1], bu))
+        return torch.cat((out, self._mse_out)) if self.log_mse else out
 
     # ------------------------------------------------------------------ HIP-graph replay
     def _begin(self):
@@ -426,12 +461,22 @@ class TrainStep(object):
         torch.optim.Adam state_dict over model.parameters() in order (exp_avg / exp_avg_sq / step per parameter), so
         a checkpoint written here resumes in the reference's loop (train.py:179-207) and vice versa."""
         params = list(self.model.parameters())
-        opt = torch.optim.Adam(params, self.lr, betas=self.betas, eps=self.eps)
         step = int(self.step_t)
+        if self.optimiser == 'adam':
+            opt = torch.optim.Adam(params, self.lr, betas=self.betas, eps=self.eps)
+        elif self.optimiser == 'rmsprop':
+            opt = torch.optim.RMSprop(params, self.lr)
+        else:
+            opt = torch.optim.SGD(params, self.lr, 0.9)
         if step > 0:
             for p in params:
                 m, v = self._adam_slices(p)
-                opt.state[p] = {'step': torch.tensor(float(step)), 'exp_avg': m.clone(), 'exp_avg_sq': v.clone()}
+                if self.optimiser == 'adam':
+                    opt.state[p] = {'step': torch.tensor(float(step)), 'exp_avg': m.clone(), 'exp_avg_sq': v.clone()}
+                elif self.optimiser == 'rmsprop':
+                    opt.state[p] = {'step': torch.tensor(float(step)), 'square_avg': m.clone()}
+                else:
+                    opt.state[p] = {'momentum_buffer': m.clone()}
         return {'model_state_dict': self.model.state_dict(),
                 'optimiser_state_dict': opt.state_dict(),
                 'beta': self.geco.beta.detach().clone() if self.geco is not None else self.beta_fixed,
@@ -460,13 +505,28 @@ class TrainStep(object):
                 if st is None:
                     continue
                 m, v = self._adam_slices(p)
-                m.copy_(st['exp_avg']); v.copy_(st['exp_avg_sq'])
-                steps.add(int(st['step']))
+                if 'exp_avg' in st:
+                    kind = 'adam'
+                    m.copy_(st['exp_avg']); v.copy_(st['exp_avg_sq'])
+                elif 'square_avg' in st:
+                    kind = 'rmsprop'
+                    m.copy_(st['square_avg'])
+                else:
+                    kind = 'sgd'
+                    if st.get('momentum_buffer') is not None:
+                        m.copy_(st['momentum_buffer'])
+                if kind != self.optimiser:
+                    raise ValueError('the checkpoint holds %s state, this loop runs %s' % (kind, self.optimiser))
+                if 'step' in st:
+                    steps.add(int(st['step']))
             if len(steps) > 1:
-                raise ValueError('per-parameter Adam step counts differ: %s' % sorted(steps))
-            self.step_t.fill_(steps.pop() if steps else 0)
+                raise ValueError('per-parameter optimiser step counts differ: %s' % sorted(steps))
+            # (torch.optim.SGD keeps no step count: the iteration index of the checkpoint stands in)
+            self.step_t.fill_(steps.pop() if steps else (int(ckpt.get('iter_idx', -1)) + 1 if self.optimiser == 'sgd' else 0))
         g0 = osd['param_groups'][0]
-        self.lr, self.betas, self.eps = g0['lr'], tuple(g0['betas']), g0['eps']
+        self.lr = g0['lr']
+        if self.optimiser == 'adam':
+            self.betas, self.eps = tuple(g0['betas']), g0['eps']
         if self.geco is not None:
             if ckpt.get('beta') is not None:
                 self.geco.beta = ckpt['beta']

@@ -264,6 +264,23 @@ int gx_adam_step_pair(float* p32, float* g32, float* m32, float* v32, size_t n32
                       double* m64, double* v64, size_t n64, int64_t* step, double lr, double beta1, double beta2,
                       double eps, float grad_scale, int zero_grads, gx_stream_t stream);
 
+/*      The other branches of train.py's objective / optimiser set-up.
+ *      gx_optimiser_step_pair: kind 1 = torch.optim.RMSprop(params, lr) (alpha = hp = 0.99, eps 1e-8, no momentum;
+ *      train.py:171-172), kind 2 = torch.optim.SGD(params, lr, momentum = hp = 0.9) (:175-176); one state buffer m per group
+ *      (square average / momentum buffer, zero before the first step); fp32 + fp64 groups in one launch like
+ *      gx_adam_step_pair.
+ *      gx_beta_warmup: *out = clamp(beta * (*step) / warm_iters, 0, beta) -- the fixed-beta objective's linear warm-up over
+ *      warm_iters = 0.2 * train_iter iterations (train.py:252-258); *step = the iteration index (the optimiser's step counter
+ *      before this iteration's increment).
+ *      gx_mse_rmse: out[0] = mean_b mean_{chw} (x - recon)^2, out[1] = mean_b sqrt(mean_{chw} (x - recon)^2)
+ *      (train.py:244-246; x, recon [B, n]); ws: gx_mse_rmse_ws_bytes(B), its first 16 bytes zero before the first launch. */
+int gx_optimiser_step_pair(int kind, float* p32, float* g32, float* m32, size_t n32, double* p64, double* g64, double* m64,
+                           size_t n64, int64_t* step, double lr, double hp, double eps, float grad_scale, int zero_grads,
+                           gx_stream_t stream);
+int gx_beta_warmup(const int64_t* step, float beta, float warm_iters, float* out, gx_stream_t stream);
+size_t gx_mse_rmse_ws_bytes(int B);
+int gx_mse_rmse(const float* x, const float* recon, int B, int n, float* out, void* ws, size_t ws_bytes, gx_stream_t stream);
+
 /* ---- live per-kernel profiling (bench.py's roofline leg): when enabled every kernel launch is bracketed
  *      by two HIP events on its launch stream and tagged with its ALGORITHMIC flops / bytes
  *      (DESIGN.md "kernels and rooflines"); gx_profile_collect accumulates per kernel symbol. */
