@@ -116,7 +116,7 @@ KID_SYMBOLS = {
     'tapconv_kernel<0>': ('tapconv_kernel<0,', 'kq_kernel<0,'),
     'tapconv_kernel<1>': ('tapconv_dt_kernel', 'kq_dt_kernel'),
     'tapconv_kernel<3>': ('tapconv_kernel<3,', 'kq_kernel<3,'),
-    'wino_conv_kernel': ('wino_conv_kernel',),
+    'wino_conv_kernel': ('wino_conv_kernel', 'wino_conv_h_kernel'),
     'gn_relu_bwd_kernel': ('gn_relu_bwd',), 'gn_relu_fwd_kernel': ('gn_relu_fwd',),
 }
 
