@@ -427,7 +427,17 @@ template <int CLS, int W> struct WrGeo {
     // the x operand of k-group g (= image row 2 t + g) and tap row offset d: image row 2 t + g + d = half (g + d) & 1 of the
     // ring row t + ((g + d) >> 1).  H is then the number of row PAIRS.
     static constexpr bool R2 = W == 16;
-    static constexpr int WE = R2 ? 32 : W;                     // pixels per tile row
+    // STRIPS (round 4): a base row too wide for the ring (conv3x3 at 128 pixels, the transposed conv at 64 base pixels: the
+    // 128 x 128 model's large layers) is cut into NS = 2 column strips; a strip of an image is a "virtual image" to the tile
+    // sequence (tile = ((image * NS + strip) * H + row), so the ring still rolls down consecutive rows), its rows are PITCH
+    // pixels apart in memory, and the only thing that crosses the cut is the column shift of the dy operand: the pixel next
+    // to the strip on either side.  Those two values per (channel, parity) -- real data at the cut, padding at the image
+    // edge -- are written into bytes 14..15 / 0..1 of the piece in front of / behind the channel's A row (the piece that is
+    // all zero for full-width rows): exactly the halves the funnel shifts take from their neighbours (wr_shift_a1).
+    static constexpr int NS = (W == 128 || (SA == 2 && W == 64)) ? 2 : 1;
+    static constexpr int LNS = NS == 2 ? 1 : 0;
+    static constexpr int WE = R2 ? 32 : W / NS;                // pixels per tile row
+    static constexpr int PITCH = WE * NS;                      // pixels per base row in memory
     static constexpr int OPR = WE / 8;                         // octets (16-byte pieces) per tile row
     static constexpr int NG = WE / 16;                         // MFMA k-groups per tile (16 pixels each)
     static constexpr int UPT = OPR / 4;                        // (channel, octet) units per thread: 64 * OPR / 256
@@ -443,11 +453,14 @@ template <int CLS, int W> struct WrGeo {
     static constexpr int LDS_BYTES = RING0 + 3 * B_PLANE;
     __host__ __device__ static constexpr int fsw(int ch) { return (ch * OPR / 16) & (OPR - 1); }
     // float offset of the dy row of tile row `ra` of image `ia` (H tile rows per image) / of its x row
+    // (ia / ib: VIRTUAL image = image * NS + strip)
     __device__ static size_t a_row(int ia, int CA, int ca0, int H, int ra) {
         if (R2) return (((size_t)ia * CA + ca0) * (SA * H) + (size_t)(SA * ra)) * (SA * WE) + WT::PA * (SA * 16);
-        return (((size_t)ia * CA + ca0) * (SA * H) + (size_t)(SA * ra + WT::PA)) * (SA * WE);
+        return (((size_t)(ia >> LNS) * CA + ca0) * (SA * H) + (size_t)(SA * ra + WT::PA)) * (SA * PITCH) + (ia & (NS - 1)) * (SA * WE);
     }
-    __device__ static size_t b_row(int ib, int CB, int cb0, int H, int rb) { return (((size_t)ib * CB + cb0) * H + (size_t)rb) * WE; }
+    __device__ static size_t b_row(int ib, int CB, int cb0, int H, int rb) {
+        return (((size_t)(ib >> LNS) * CB + cb0) * H + (size_t)rb) * PITCH + (ib & (NS - 1)) * WE;
+    }
     // R2: unit (k-group g, tap row rr) reads k-group b_g of ring row index b_rr
     __host__ __device__ static constexpr int b_e(int g, int rr) { return g + DMIN + rr; }
     __host__ __device__ static constexpr int b_so(int g, int rr) { return b_e(g, rr) >= 0 ? b_e(g, rr) / 2 : -((1 - b_e(g, rr)) / 2); }
@@ -474,7 +487,35 @@ template <int CLS, int W> struct WrT {
     int stA[G::UPT], stB[G::UPT];          // LDS byte offsets of the units' pieces inside a plane / a ring slot
     int a_rd;                              // MFMA loop: byte offset of (A channel, octet h) inside an A plane
     int b_rd[G::NG];                       //            byte offset of (B channel, octet 2g + h) inside a ring slot
+    // strips: this thread's seam item (channel tid >> 2, side (tid >> 1) & 1: 0 left / 1 right, column parity tid & 1)
+    int goffS, stS, sideS;                 // float offset from the strip's dy row origin; LDS byte offset inside an A buffer
+    bool okS;
 };
+
+// the dy value next to a strip: global address select (the zero page beyond the image edge / for idle items)
+template <int CLS, int W>
+__device__ __forceinline__ float wr_seam_load(const WrT<CLS, W>& w, int ta) {
+    using G = WrGeo<CLS, W>;
+    const bool live = (unsigned)ta < (unsigned)w.ntot;
+    const int ia = ta >> w.lh, ra = ta & (w.H - 1);
+    const int strip = ia & (G::NS - 1);
+    const bool inside = w.sideS ? strip < G::NS - 1 : strip > 0;
+    const float* sp = (live & w.okS & inside) ? w.a + G::a_row(ia, w.CA, w.ca0, w.H, ra) + w.goffS : w.zeros;
+    return *(const __attribute__((address_space(1))) float*)sp;
+}
+__device__ __forceinline__ void wr_seam_split(float v, unsigned short (&b)[3]) {
+    const __bf16 h = (__bf16)v;
+    const float r1 = v - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const __bf16 l = (__bf16)(r1 - (float)m);
+    b[0] = __builtin_bit_cast(unsigned short, h); b[1] = __builtin_bit_cast(unsigned short, m); b[2] = __builtin_bit_cast(unsigned short, l);
+}
+template <int CLS, int W>
+__device__ __forceinline__ void wr_seam_store(char* lds, const WrT<CLS, W>& w, int abuf, const unsigned short (&b)[3]) {
+    using G = WrGeo<CLS, W>;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<unsigned short*>(lds + abuf + w.stS + pl * G::A_PLANE) = b[pl];
+}
 
 // global -> registers: the dy row of tile ta and the x row of tile tb (a tile index outside [0, ntot) = nothing to load)
 template <int CLS, int W>
@@ -559,8 +600,8 @@ template <int CLS, int W> struct WrSched {
     static constexpr int NCO = G::NT / NRO;                   // taps per unit
     static constexpr int NMF = 6 * NCO;                       // MFMAs (slots) per unit
     static constexpr int NOCT = G::UPT * (NPB + 1);           // octets this thread splits per tile
-    static constexpr int NQ = 14 * NOCT;                      // split pieces
-    static constexpr int NFE = 2 * G::UPT;                    // fetch pieces (unit 0): the dy / x loads of unit j
+    static constexpr int NQ = 14 * NOCT + (G::NS > 1 ? 3 : 0);     // split pieces (strips: + the seam value's split | split | stores)
+    static constexpr int NFE = 2 * G::UPT + (G::NS > 1 ? 1 : 0);   // fetch pieces (unit 0): the dy / x loads of unit j (+ the seam load)
     // the last unit ends with: the tile's barrier, then the NEXT tile's first operands (B of its unit 0, A octets and
     // funnel shifts of its group 0) under this tile's last MFMAs
     static constexpr int NTAIL = 2 + 3 * NPB + 6 * NPB;
@@ -601,6 +642,7 @@ template <int CLS, int W> struct WrTileState {
     WqB3 bq[2];                     // B operand of the current / the next unit
     float r[8];                     // the octet being split: value, then residuals
     unsigned hp[4], mp[4], lp[4];   // its packed bf16 planes
+    float sv;                       // strips: the seam value fetched for the next tile
 };
 
 __device__ __forceinline__ unsigned wr_pk(float lo, float hi) {
@@ -617,6 +659,23 @@ __device__ __forceinline__ void wr_split_piece(char* lds, const WrT<CLS, W>& w, 
                                                const f32x4 (&pb)[WrGeo<CLS, W>::UPT][2]) {
     using G = WrGeo<CLS, W>;
     constexpr int SA = G::SA, NPB = G::NPB;
+    if constexpr (Q >= 14 * G::UPT * (NPB + 1)) {          // strips: the seam value (r[0..1], hp[0..2] are free by now)
+        constexpr int step = Q - 14 * G::UPT * (NPB + 1);
+        if constexpr (step == 0) {
+            const __bf16 h = (__bf16)st.sv;
+            st.r[0] = st.sv - (float)h;
+            st.hp[0] = __builtin_bit_cast(unsigned short, h);
+        } else if constexpr (step == 1) {
+            const __bf16 m = (__bf16)st.r[0];
+            st.hp[1] = __builtin_bit_cast(unsigned short, m);
+            st.hp[2] = __builtin_bit_cast(unsigned short, (__bf16)(st.r[0] - (float)m));
+        } else {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                *reinterpret_cast<unsigned short*>(lds + anxt + w.stS + pl * G::A_PLANE) = (unsigned short)st.hp[pl];
+        }
+        return;
+    } else {
     constexpr int oi = Q / 14, step = Q % 14, j = oi / (NPB + 1), k = oi % (NPB + 1);
     constexpr bool isA = k < NPB;
     float v[8];
@@ -642,6 +701,7 @@ __device__ __forceinline__ void wr_split_piece(char* lds, const WrT<CLS, W>& w, 
         constexpr int ps = isA ? G::A_PLANE : G::B_PLANE;
         const unsigned* src = step == 11 ? st.hp : (step == 12 ? st.mp : st.lp);
         *reinterpret_cast<gx_u32x4*>(d + (step - 11) * ps) = gx_u32x4{src[0], src[1], src[2], src[3]};
+    }
     }
 }
 
@@ -695,10 +755,12 @@ __device__ __forceinline__ void wr_read_b(const char* lds, const WrT<CLS, W>& w,
 template <int CLS, int W, int I>
 __device__ __forceinline__ void wr_fetch_piece(const WrT<CLS, W>& w, int ta, int tb,
                                                f32x4 (&pa)[WrGeo<CLS, W>::UPT][2 * WrGeo<CLS, W>::SA],
-                                               f32x4 (&pb)[WrGeo<CLS, W>::UPT][2]) {
+                                               f32x4 (&pb)[WrGeo<CLS, W>::UPT][2], float& sv) {
     using G = WrGeo<CLS, W>;
     constexpr int SA = G::SA, j = I / 2;
-    if (I % 2 == 0) {
+    if constexpr (I == 2 * G::UPT) {
+        sv = wr_seam_load<CLS, W>(w, ta);
+    } else if (I % 2 == 0) {
         const bool live = (unsigned)ta < (unsigned)w.ntot;
         const int ia = ta >> w.lh, ra = ta & (w.H - 1);
         const size_t arow = G::a_row(ia, w.CA, w.ca0, w.H, ra);
@@ -777,7 +839,7 @@ __device__ __forceinline__ void wr_slot(char* lds, const WrT<CLS, W>& w, const W
         wr_shift_a1<CLS, W>(st.raw, st.av[as ^ 1], (M - n_b - n_ra) / 6, ((M - n_b - n_ra) % 6) / 2, (M - n_b - n_ra) % 2);
     } else if constexpr (M < n_b + n_ra + n_sh + n_fe) {
 #if !(GX_WR_ABL & 4)
-        wr_fetch_piece<CLS, W, M - n_b - n_ra - n_sh>(w, sp.ta, sp.tb, pa, pb);
+        wr_fetch_piece<CLS, W, M - n_b - n_ra - n_sh>(w, sp.ta, sp.tb, pa, pb, st.sv);
 #endif
     } else if constexpr (U >= S::U0) {
         constexpr int q = S::qbase(U) + (M - S::nfix(U));
@@ -809,17 +871,26 @@ __device__ __forceinline__ void wr_segment(const float* a, const float* b, const
     if (G::R2) H >>= 1;                     // tile rows = pairs of image rows
     WrT<CLS, W> w;
     w.a = a; w.b = b; w.zeros = zeros; w.CA = CA; w.CB = CB; w.ca0 = ca0; w.cb0 = cb0; w.H = H;
-    w.lh = 31 - __builtin_clz(H); w.ntot = N * H;
+    w.lh = 31 - __builtin_clz(H); w.ntot = N * G::NS * H;
 #pragma unroll
     for (int j = 0; j < G::UPT; ++j) {
         const int ch = tid / OPR + j * G::CPS, o = tid % OPR;
         // (R2: the second image row's dy starts SA image rows of SA * 16 floats further on, not right behind the first's)
-        w.goffA[j] = ch * (SA * H) * (SA * WE) + SA * 8 * o + (G::R2 && o >= 2 ? 16 * SA * (SA - 1) : 0);
-        w.goffB[j] = ch * H * WE + 8 * o;
+        w.goffA[j] = ch * (SA * H) * (SA * G::PITCH) + SA * 8 * o + (G::R2 && o >= 2 ? 16 * SA * (SA - 1) : 0);
+        w.goffB[j] = ch * H * G::PITCH + 8 * o;
         w.okA[j] = ca0 + ch < CA;
         w.okB[j] = cb0 + ch < CB;
         w.stA[j] = (1 + ch * G::APITCH + o + (G::R2 && o >= 2 ? 1 : 0)) * 16;
         w.stB[j] = (ch * OPR + (o ^ G::fsw(ch))) * 16;
+    }
+    {
+        const int ch = tid >> 2, side = (tid >> 1) & 1, par = tid & 1;
+        w.sideS = side;
+        w.okS = G::NS > 1 && par < G::NPB && ca0 + ch < CA;
+        w.goffS = ch * (SA * H) * (SA * G::PITCH) + (side ? SA * WE + par : par - SA);
+        // left of channel ch: the last bf16 of the piece in front of its row; right: the first bf16 of the piece behind it;
+        // idle items (no second parity): bytes 4..5 of the leading piece, which nothing reads
+        w.stS = par < G::NPB ? par * 3 * G::A_PLANE + (side ? (1 + ch * G::APITCH + OPR) * 16 : ch * G::APITCH * 16 + 14) : 4;
     }
     const int wm = wave >> 1, wn = wave & 1, h = lane >> 5;
     const int cha = wm * 32 + (lane & 31), chb = wn * 32 + (lane & 31);
@@ -850,6 +921,12 @@ __device__ __forceinline__ void wr_segment(const float* a, const float* b, const
     // prologue: the x rows of tiles t0 + DMIN .. t0 + DMAX (a neighbour in another image is never read by tile t0, but
     // the ones behind serve tile t0 + 1) and the dy row of t0
     wr_fetch<CLS, W>(w, t0, t0 + G::DMIN, pa, pb);
+    if constexpr (G::NS > 1) {
+        __syncthreads();      // (the seam bytes lie inside the pieces the fill above zeroes)
+        unsigned short sb[3];
+        wr_seam_split(wr_seam_load<CLS, W>(w, t0), sb);
+        wr_seam_store<CLS, W>(lds, w, 0, sb);
+    }
     wr_store<CLS, W, true, true>(lds, w, 0, ((t0 + G::DMIN) & 3) * G::B_ROW, pa, pb);
 #pragma unroll 1
     for (int k = G::DMIN + 1; k <= G::DMAX; ++k) {
@@ -993,6 +1070,7 @@ wgq_stream_kernel(const WsTable tab, const float* __restrict__ zeros) {
             GX_WR_CASE(18, WQ_C3, 64) GX_WR_CASE(19, WQ_C3, 32) GX_WR_CASE(20, WQ_DR0, 32) GX_WR_CASE(21, WQ_DR1, 32)
             GX_WR_CASE(22, WQ_C5A, 64) GX_WR_CASE(23, WQ_C5A, 32) GX_WR_CASE(24, WQ_C5B, 64) GX_WR_CASE(25, WQ_C5B, 32)
             GX_WR_CASE(26, WQ_C3, 16) GX_WR_CASE(27, WQ_DR0, 16) GX_WR_CASE(28, WQ_DR1, 16)
+            GX_WR_CASE(29, WQ_C3, 128) GX_WR_CASE(30, WQ_DR0, 64) GX_WR_CASE(31, WQ_DR1, 64)
             default: break;
         }
 #undef GX_WS_CASE
@@ -1151,11 +1229,12 @@ bool wgq_stream_on() {
 // wgrad3:256:64 wgrad3:2048:16 wgrad3:8192:8 wgrad:256:32 wgrad:1024:16 wgrad:4096:8: 10.3 us per conv3x3 tile, 26.5 us per
 // pair of transposed-conv row-parity tiles, split 15 a + b : 10 a + b), then nudged on the training step itself
 // (the stream kernel's duration over five vectors: 921 .. 972 us); GENESIS_WGQ_COST="c0,...,c8" overrides
-int g_ws_cost[29] = {10200, 9580, 10680, 15080, 21000, 11800, 11400, 8800, 9700,              // bf16 pipe (measured with
+int g_ws_cost[32] = {10200, 9580, 10680, 15080, 21000, 11800, 11400, 8800, 9700,              // bf16 pipe (measured with
                      10200, 10600, 11200, 16000, 16500, 18200, 11600, 12000, 13300,           // GENESIS_WGQ_TIMES) | fp32 pipe
                      4840, 2450, 4150, 2900,                                                  // row-ring tiles (one base row)
                      8000, 4100, 5400, 2800,                                                  // ... of the 5 x 5 stride-1 conv
-                     2450, 4150, 2900};                                                       // ... two 16-pixel rows per tile
+                     2450, 4150, 2900,                                                        // ... two 16-pixel rows per tile
+                     4900, 4200, 2950};                                                       // ... one strip (half a base row) per tile
 bool g_ws_cost_init = false;
 void ws_cost_init() {
     if (g_ws_cost_init) return;
@@ -1191,8 +1270,12 @@ int ws_ring_variant(int cls, int Hb, int Wb) {
     if (!wgq_b6() || !wgq_ring_on() || Hb < 4) return -1;          // (H a multiple of 4: the ring slot of a row is tile & 3)
     static const char* r2env = getenv("GENESIS_WGQ_RING16");       // 0: 16-pixel rows stay on the 64-pixel LDS-DMA tiles
     if (Wb == 16 && !(r2env && r2env[0] == '0') && Hb >= 8 && Hb % 8 == 0 && cls <= WQ_DR1) return 26 + cls;   // two image rows per tile
-    if (cls == WQ_C3) return Wb == 64 ? 18 : (Wb == 32 ? 19 : -1);
+    // rows too wide for the ring as two strips (the 128 x 128 model's large layers); GENESIS_WGQ_STRIPS=0: on the 64-pixel tiles
+    static const char* stenv = getenv("GENESIS_WGQ_STRIPS");
+    const bool strips = !(stenv && stenv[0] == '0');
+    if (cls == WQ_C3) return Wb == 64 ? 18 : (Wb == 32 ? 19 : (Wb == 128 && strips ? 29 : -1));
     if (cls == WQ_C5A || cls == WQ_C5B) return Wb == 64 ? (cls == WQ_C5A ? 22 : 24) : (Wb == 32 ? (cls == WQ_C5A ? 23 : 25) : -1);
+    if (Wb == 64 && strips) return cls == WQ_DR0 ? 30 : 31;
     if (Wb != 32) return -1;
     return cls == WQ_DR0 ? 20 : 21;
 }
@@ -1265,7 +1348,8 @@ int wgq_launch_stream(std::vector<PendingJob*>& jobs, hipStream_t s, std::vector
                     jb.Ttot = q.job.Ttot;
                     jb.variant = q.cls * 3 + (5 - q.ltw) + (wgq_b6() ? 0 : 9);
                     const int rv = ws_ring_variant(q.cls, q.job.Hb, q.job.Wb);
-                    if (rv >= 0) { jb.variant = rv; jb.ntiles = q.job.N * q.job.Hb / (rv >= 26 ? 2 : 1); }      // tile = one base row (26..28: two)
+                    // tile = one base row (26..28: two; 29..31: one of its two strips)
+                    if (rv >= 0) { jb.variant = rv; jb.ntiles = rv >= 29 ? q.job.N * q.job.Hb * 2 : q.job.N * q.job.Hb / (rv >= 26 ? 2 : 1); }
                     else if (q.cls >= WQ_C5A) { gx_set_error("wgq: the 5x5 classes exist as row-ring tiles only"); return GX_EINVAL; }
                     jb.cost = g_ws_cost[jb.variant];
                     jb.w_first = 0; jb.N = q.job.N;

@@ -1109,7 +1109,11 @@ def test_streamk_weight_gradients_many_layers():
                                                 ('deconv', 1, 64, 64, 32),
                                                 # rows of 16 pixels: two image rows per tile (a zero piece at the seam)
                                                 ('conv3x3', 9, 64, 200, 16), ('conv3x3', 1, 128, 64, 16), ('deconv', 13, 64, 64, 16),
-                                                ('deconv', 1, 40, 72, 16), ('conv3x3', 3, 64, 64, 8)])
+                                                ('deconv', 1, 40, 72, 16), ('conv3x3', 3, 64, 64, 8),
+                                                # rows too wide for the ring (the 128 x 128 model): two column strips per row, the
+                                                # dy values next to a strip in the seam bytes of its A rows
+                                                ('conv3x3', 3, 64, 64, 128), ('conv3x3', 1, 128, 64, 128), ('conv3x3', 2, 40, 72, 128),
+                                                ('deconv', 3, 64, 64, 64), ('deconv', 1, 40, 72, 64)])
 def test_row_ring_weight_gradients(kind, N, Cin, Cout, S):
     """gx_wgq_ring: the row-ring tiles of the bf16-pipe weight gradients (one full-width base row per tile, x rows in a
     rolling four-slot LDS ring, operands split into bf16 planes once, column shifts as funnel shifts of the dy operand)
