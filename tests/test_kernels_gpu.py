@@ -97,10 +97,10 @@ def test_gn_relu_plain(N, C, H, W, groups):
     close(dbias, yr.grad.sum((0, 2, 3)), 1e-4, 1e-4, 'dbias')
 
 
-def test_gn_relu_views():
+@pytest.mark.parametrize('N,C,H,W', [(2, 16, 8, 8), (2, 64, 128, 128)])      # 128 x 128: slabs of 512 KB (the two-pass kernels)
+def test_gn_relu_views(N, C, H, W):
     """Destinations: skip slice of a concat buffer + 2x down-sampled copy; up-sampled slice.
     Gradients gathered from the same views (modules/unet.py:78,86,89)."""
-    N, C, H, W = 2, 16, 8, 8
     y = rnd(N, C, H, W, seed=12, scale=2.0)
     gamma, beta = 1 + 0.3 * rnd(C, seed=13), 0.2 * rnd(C, seed=14)
     yr = y.clone().requires_grad_()
