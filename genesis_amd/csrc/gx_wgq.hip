@@ -415,7 +415,15 @@ typedef const __attribute__((address_space(1))) f32x4* gx_gptr4;
 #define GX_WR_ABL 0          // ablation builds (tools/abl_build.sh): 1 no MFMAs, 2 no split / LDS stores, 4 no global loads
 #endif
 
-template <int CLS, int W> struct WrGeo {
+// The second template parameter of the Wr* templates is a CODE: WC = W + 1000 * HF.
+// HF (round 4, "k-split"): a 64 x 64 channel block whose A half (HF & 1: <= 32 A channels left) and / or B half (HF & 2) is
+// empty -- the 32-channel layers of the gated stacks and the BroadcastDecoder, first layers with 3 / 4 input channels -- used
+// to keep two of the four waves multiplying zero rows.  There the waves of such a pair take the SAME 32 channels and every
+// other k-group of the tile instead (wave -> k-groups ksel, ksel + KS, ...); the pair's accumulators are summed through LDS
+// once per segment.  The tile's MFMA chain is half (a quarter) as long, its staging work unchanged.
+template <int CLS, int WC> struct WrGeo {
+    static constexpr int HF = WC / 1000, W = WC % 1000;
+    static constexpr int KS = HF == 3 ? 4 : (HF ? 2 : 1);
     using WT = WqTap<CLS>;
     static constexpr int SA = WT::SA, NPB = WT::NPB, NT = WT::NT, NRO = WT::NRO, RO0 = WT::RO0;
     static constexpr int NCOV = WqCols<CLS>::NCOV, CS0 = WqCols<CLS>::CS0;
@@ -439,11 +447,13 @@ template <int CLS, int W> struct WrGeo {
     static constexpr int WE = R2 ? 32 : W / NS;                // pixels per tile row
     static constexpr int PITCH = WE * NS;                      // pixels per base row in memory
     static constexpr int OPR = WE / 8;                         // octets (16-byte pieces) per tile row
-    static constexpr int NG = WE / 16;                         // MFMA k-groups per tile (16 pixels each)
+    static constexpr int NG = WE / 16 / KS;                    // MFMA k-groups per tile (16 pixels each) AND WAVE
+    static_assert((WE / 16) % KS == 0 && !(HF && R2), "k-split needs whole k-groups per wave (and no row pairs)");
     static constexpr int UPT = OPR / 4;                        // (channel, octet) units per thread: 64 * OPR / 256
     static constexpr int CPS = 256 / OPR;                      // channels covered by one unit index
     static constexpr int APITCH = OPR + (R2 ? 3 : 1);          // pieces per channel of an A plane (odd; R2: o0 o1 Z o2 o3 Z Z)
-    static constexpr int AGS = R2 ? 48 : 32;                   // bytes from k-group g's octets to k-group g + 1's in an A row
+    static constexpr int AGS1 = R2 ? 48 : 32;                  // bytes from a k-group's octets to the next one's in an A row
+    static constexpr int AGS = AGS1 * KS;                      // ... to this wave's next one
     static constexpr int A_PLANE = (64 * APITCH + 1) * 16;     // bytes (one leading zero piece)
     static constexpr int A_BUF = NPB * 3 * A_PLANE;            // one A buffer: column parities x planes
     static constexpr int B_ROW = 64 * OPR * 16;                // one x row of one plane
@@ -596,6 +606,11 @@ typedef __bf16 gx_bf16x2 __attribute__((ext_vector_type(2)));
 template <int CLS, int W> struct WrSched {
     using G = WrGeo<CLS, W>;
     static constexpr int NRO = G::NRO, NG = G::NG, NPB = G::NPB;
+    // ONE k-group per wave (k-split forms of the short rows): the tile's last unit works on operand set 0 -- the set the tail's
+    // head pieces would fill for the next tile (with an even group count the last group sits in set 1).  There the tail only
+    // reads the next tile's raw A octets; its B operand and the funnel shifts follow at the next tile's start (wr_tile_start).
+    static constexpr bool NG1 = NG == 1;
+    static_assert(NG == 1 || NG % 2 == 0, "the operand sets alternate by k-group");
     static constexpr int NU = NG * NRO;                       // units per tile
     static constexpr int NCO = G::NT / NRO;                   // taps per unit
     static constexpr int NMF = 6 * NCO;                       // MFMAs (slots) per unit
@@ -612,18 +627,25 @@ template <int CLS, int W> struct WrSched {
         return (more(u) ? 1 : 0) + (newg(u) ? 3 * NPB : 0) + (lastr(u) ? 6 * NPB : 0) + (u == 0 ? NFE : 0);
     }
     __host__ __device__ static constexpr int nfree(int u) { return NMF - nfix(u) - (u == NU - 1 ? NTAIL : 0); }
+    // split pieces per free slot: 1 unless the tile's MFMA chain is too short for them (the k-split forms of the 32-pixel rows)
+    __host__ __device__ static constexpr int pps() {
+        int room = 0;
+        for (int u = 1; u < NU; ++u) room += nfree(u);
+        return room > 0 ? (NQ + room - 1) / room : 1 << 20;
+    }
+    static constexpr int PPS = pps();
     __host__ __device__ static constexpr int u0() {           // first unit that carries split pieces: as late as they fit
         int u = NU, room = 0;
-        while (room < NQ && u > 1) { --u; room += nfree(u); }
+        while (room < NQ && u > 1) { --u; room += PPS * nfree(u); }
         return u;
     }
     static constexpr int U0 = u0();
     __host__ __device__ static constexpr int qbase(int u) {   // split pieces placed before unit u
         int q = 0;
-        for (int v = U0; v < u; ++v) q += nfree(v);
+        for (int v = U0; v < u; ++v) q += PPS * nfree(v);
         return q;
     }
-    static_assert(U0 >= 1 && qbase(NU) >= NQ, "the split pieces must fit the tile's free slots");
+    static_assert(U0 >= 1 && qbase(NU) >= NQ && PPS <= 8, "the split pieces must fit the tile's free slots");
     static_assert(nfree(0) >= 0 && nfree(NRO - 1) >= 0 && nfree(NU - 1) >= 0, "fixed pieces must fit a unit");
 };
 
@@ -787,6 +809,15 @@ __device__ __forceinline__ void wr_head_piece(const char* lds, const WrT<CLS, W>
     else wr_shift_a1<CLS, W>(st.raw, st.av[0], (I - 1 - 3 * NPB) / 6, ((I - 1 - 3 * NPB) % 6) / 2, (I - 1 - 3 * NPB) % 2);
 }
 
+// the split pieces Q .. Q + N - 1 (those that exist)
+template <int CLS, int W, int Q, int N>
+__device__ __forceinline__ void wr_split_pieces(char* lds, const WrT<CLS, W>& w, WrTileState<CLS, W>& st, int anxt, int bnew,
+                                                const f32x4 (&pa)[WrGeo<CLS, W>::UPT][2 * WrGeo<CLS, W>::SA],
+                                                const f32x4 (&pb)[WrGeo<CLS, W>::UPT][2]) {
+    if constexpr (Q >= 0 && Q < WrSched<CLS, W>::NQ) wr_split_piece<CLS, W, Q>(lds, w, st, anxt, bnew, pa, pb);
+    if constexpr (N > 1) wr_split_pieces<CLS, W, Q + 1, N - 1>(lds, w, st, anxt, bnew, pa, pb);
+}
+
 // slot M of unit U: its MFMA, then its piece
 template <int CLS, int W, int U, int M>
 __device__ __forceinline__ void wr_slot(char* lds, const WrT<CLS, W>& w, const WrStep<CLS, W>& sp,
@@ -824,7 +855,8 @@ __device__ __forceinline__ void wr_slot(char* lds, const WrT<CLS, W>& w, const W
     if constexpr (M >= tail0) {
         if constexpr (M == tail0) __syncthreads();         // the rows of the next tile are in LDS; this tile's reads are done
 #if !(GX_WR_ABL & 8)
-        else wr_head_piece<CLS, W, M - tail0 - 1>(lds, w, sp.anxt, sp.nbs, sp.nzr, st);
+        else if constexpr (!S::NG1 || (M - tail0 - 1 >= 1 && M - tail0 - 1 < 1 + 3 * NPB))
+            wr_head_piece<CLS, W, M - tail0 - 1>(lds, w, sp.anxt, sp.nbs, sp.nzr, st);
 #endif
     }
 #if GX_WR_ABL & 8
@@ -842,9 +874,9 @@ __device__ __forceinline__ void wr_slot(char* lds, const WrT<CLS, W>& w, const W
         wr_fetch_piece<CLS, W, M - n_b - n_ra - n_sh>(w, sp.ta, sp.tb, pa, pb, st.sv);
 #endif
     } else if constexpr (U >= S::U0) {
-        constexpr int q = S::qbase(U) + (M - S::nfix(U));
+        constexpr int q = S::qbase(U) + (M - S::nfix(U)) * S::PPS;
 #if !(GX_WR_ABL & 2)
-        if constexpr (q >= 0 && q < S::NQ) wr_split_piece<CLS, W, q>(lds, w, st, sp.anxt, sp.bnew, pa, pb);
+        wr_split_pieces<CLS, W, q, S::PPS>(lds, w, st, sp.anxt, sp.bnew, pa, pb);
 #endif
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -855,8 +887,17 @@ __device__ __forceinline__ void wr_slot(char* lds, const WrT<CLS, W>& w, const W
 template <int CLS, int W, int I>
 __device__ __forceinline__ void wr_head(const char* lds, const WrT<CLS, W>& w, int abuf, const int (&bs)[WrGeo<CLS, W>::NRO],
                                         const bool (&zr)[WrGeo<CLS, W>::NRO], WrTileState<CLS, W>& st) {
-    wr_head_piece<CLS, W, I>(lds, w, abuf, bs, zr, st);
+    constexpr int NPB = WrGeo<CLS, W>::NPB;
+    if constexpr (!WrSched<CLS, W>::NG1 || (I >= 1 && I < 1 + 3 * NPB)) wr_head_piece<CLS, W, I>(lds, w, abuf, bs, zr, st);
     if constexpr (I + 2 < WrSched<CLS, W>::NTAIL) wr_head<CLS, W, I + 1>(lds, w, abuf, bs, zr, st);
+}
+// NG1: what the tail left out -- B of unit 0 and the funnel shifts of group 0, in front of the tile's first MFMA
+template <int CLS, int W, int I>
+__device__ __forceinline__ void wr_tile_start(const char* lds, const WrT<CLS, W>& w, int abuf, const int (&bs)[WrGeo<CLS, W>::NRO],
+                                              const bool (&zr)[WrGeo<CLS, W>::NRO], WrTileState<CLS, W>& st) {
+    constexpr int NPB = WrGeo<CLS, W>::NPB;
+    if constexpr (I == 0 || I >= 1 + 3 * NPB) wr_head_piece<CLS, W, I>(lds, w, abuf, bs, zr, st);
+    if constexpr (I + 2 < WrSched<CLS, W>::NTAIL) wr_tile_start<CLS, W, I + 1>(lds, w, abuf, bs, zr, st);
 }
 
 // One SEGMENT of row-ring tiles: the tiles t0 .. t1 - 1 (tile = image * H + base row) of one 64 x 64 channel block,
@@ -893,10 +934,12 @@ __device__ __forceinline__ void wr_segment(const float* a, const float* b, const
         w.stS = par < G::NPB ? par * 3 * G::A_PLANE + (side ? (1 + ch * G::APITCH + OPR) * 16 : ch * G::APITCH * 16 + 14) : 4;
     }
     const int wm = wave >> 1, wn = wave & 1, h = lane >> 5;
-    const int cha = wm * 32 + (lane & 31), chb = wn * 32 + (lane & 31);
-    w.a_rd = (1 + cha * G::APITCH + h) * 16;
+    // k-split: which of the KS interleaved k-group sets this wave takes; the waves of a set share their channels
+    const int ksel = G::HF == 1 ? wm : (G::HF == 2 ? wn : (G::HF == 3 ? wave : 0));
+    const int cha = ((G::HF & 1) ? 0 : wm * 32) + (lane & 31), chb = ((G::HF & 2) ? 0 : wn * 32) + (lane & 31);
+    w.a_rd = (1 + cha * G::APITCH + h) * 16 + ksel * G::AGS1;
 #pragma unroll
-    for (int g = 0; g < G::NG; ++g) w.b_rd[g] = (chb * OPR + ((2 * g + h) ^ G::fsw(chb))) * 16;
+    for (int g = 0; g < G::NG; ++g) w.b_rd[g] = (chb * OPR + ((2 * (g * G::KS + ksel) + h) ^ G::fsw(chb))) * 16;
 
     // zero pieces: the leading one and one behind every channel's row of the A planes (both buffers), one per ring plane
     // (R2: the seam piece and the two behind the row as well -- the whole A buffers)
@@ -956,9 +999,39 @@ __device__ __forceinline__ void wr_segment(const float* a, const float* b, const
 #pragma unroll
         for (int rr = 0; rr < NRO; ++rr) { sp.bs[rr] = sp.nbs[rr]; sp.zr[rr] = sp.nzr[rr]; }
         rows(t + 1, sp.nbs, sp.nzr);
+        if constexpr (WrSched<CLS, W>::NG1) wr_tile_start<CLS, W, 0>(lds, w, sp.abuf, sp.bs, sp.zr, st);
         wr_slot<CLS, W, 0, 0>(lds, w, sp, acc, st, pa, pb);
     }
 
+    if constexpr (G::HF != 0) {
+        // k-split: sum the accumulators of the waves that share a 32 x 32 block (fixed order), through LDS: [sender][tap][reg][lane]
+        float* red = reinterpret_cast<float*>(lds);
+#pragma unroll 1
+        for (int round = 0; round < (G::HF == 3 ? 2 : 1); ++round) {
+            // HF 1: wave 2 + wn -> wn; HF 2: 2 wm + 1 -> 2 wm; HF 3: round 0: 1 -> 0, 3 -> 2; round 1: 2 -> 0
+            bool send, recv; int slot;
+            if (G::HF == 1) { send = wm == 1; recv = wm == 0; slot = wn; }
+            else if (G::HF == 2) { send = wn == 1; recv = wn == 0; slot = wm; }
+            else if (round == 0) { send = (wave & 1) == 1; recv = (wave & 1) == 0; slot = wave >> 1; }
+            else { send = wave == 2; recv = wave == 0; slot = 0; }
+            __syncthreads();
+            if (send) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) red[((slot * NT + t) * 16 + reg) * 64 + lane] = acc[t][reg];
+            }
+            __syncthreads();
+            if (recv) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) acc[t][reg] += red[((slot * NT + t) * 16 + reg) * 64 + lane];
+            }
+        }
+        const bool owner = G::HF == 1 ? wm == 0 : (G::HF == 2 ? wn == 0 : wave == 0);
+        if (!owner) return;
+    }
     // ---- slab [tap][ca][cb]  (C/D layout: col = lane & 31 -> cb, row -> ca)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -1071,6 +1144,12 @@ wgq_stream_kernel(const WsTable tab, const float* __restrict__ zeros) {
             GX_WR_CASE(22, WQ_C5A, 64) GX_WR_CASE(23, WQ_C5A, 32) GX_WR_CASE(24, WQ_C5B, 64) GX_WR_CASE(25, WQ_C5B, 32)
             GX_WR_CASE(26, WQ_C3, 16) GX_WR_CASE(27, WQ_DR0, 16) GX_WR_CASE(28, WQ_DR1, 16)
             GX_WR_CASE(29, WQ_C3, 128) GX_WR_CASE(30, WQ_DR0, 64) GX_WR_CASE(31, WQ_DR1, 64)
+            // k-split forms (variant + 32 * HF, width code + 1000 * HF): HF 1 = A half empty, 2 = B half empty, 3 = both
+            GX_WR_CASE(32 + 18, WQ_C3, 1064) GX_WR_CASE(32 + 19, WQ_C3, 1032) GX_WR_CASE(32 + 20, WQ_DR0, 1032) GX_WR_CASE(32 + 21, WQ_DR1, 1032)
+            GX_WR_CASE(32 + 22, WQ_C5A, 1064) GX_WR_CASE(32 + 23, WQ_C5A, 1032) GX_WR_CASE(32 + 24, WQ_C5B, 1064) GX_WR_CASE(32 + 25, WQ_C5B, 1032)
+            GX_WR_CASE(64 + 18, WQ_C3, 2064) GX_WR_CASE(64 + 19, WQ_C3, 2032) GX_WR_CASE(64 + 20, WQ_DR0, 2032) GX_WR_CASE(64 + 21, WQ_DR1, 2032)
+            GX_WR_CASE(64 + 22, WQ_C5A, 2064) GX_WR_CASE(64 + 23, WQ_C5A, 2032) GX_WR_CASE(64 + 24, WQ_C5B, 2064) GX_WR_CASE(64 + 25, WQ_C5B, 2032)
+            GX_WR_CASE(96 + 18, WQ_C3, 3064)
             default: break;
         }
 #undef GX_WS_CASE
@@ -1235,6 +1314,10 @@ int g_ws_cost[32] = {10200, 9580, 10680, 15080, 21000, 11800, 11400, 8800, 9700,
                      8000, 4100, 5400, 2800,                                                  // ... of the 5 x 5 stride-1 conv
                      2450, 4150, 2900,                                                        // ... two 16-pixel rows per tile
                      4900, 4200, 2950};                                                       // ... one strip (half a base row) per tile
+// cost of a k-split tile relative to the full one, in percent, by base variant 18..25 (one or the other half) and for both
+// halves of variant 18 (measured with GENESIS_WGQ_TIMES on the GENESIS / BaselineVAE / MONet steps: the 32-pixel rows keep one
+// k-group per wave -- their tile starts with the operand reads the tail could not take); GENESIS_WGQ_KSPLIT_COST="9 values" overrides
+int g_ws_kcost[9] = {55, 65, 65, 74, 54, 58, 56, 64, 39};
 bool g_ws_cost_init = false;
 void ws_cost_init() {
     if (g_ws_cost_init) return;
@@ -1249,6 +1332,11 @@ void ws_cost_init() {
         int r[3];
         if (sscanf(er, "%d,%d,%d", r, r + 1, r + 2) == 3)
             for (int i = 0; i < 3; ++i) if (r[i] > 0) g_ws_cost[26 + i] = r[i];
+    }
+    if (const char* er = getenv("GENESIS_WGQ_KSPLIT_COST")) {
+        int r[9];
+        if (sscanf(er, "%d,%d,%d,%d,%d,%d,%d,%d,%d", r, r + 1, r + 2, r + 3, r + 4, r + 5, r + 6, r + 7, r + 8) == 9)
+            for (int i = 0; i < 9; ++i) if (r[i] > 0) g_ws_kcost[i] = r[i];
     }
     if (!env) return;
     int v[9];          // the nine costs of the pipe in use
@@ -1280,6 +1368,14 @@ int ws_ring_variant(int cls, int Hb, int Wb) {
     return cls == WQ_DR0 ? 20 : 21;
 }
 
+// k-split form of a row-ring variant for a channel block with ca_n x cb_n channels (0: none).  GENESIS_WGQ_KSPLIT=0: off
+int ws_ksplit(int rv, int ca_n, int cb_n) {
+    static const char* env = getenv("GENESIS_WGQ_KSPLIT");
+    if ((env && env[0] == '0') || rv < 18 || rv > 25) return 0;
+    int hf = (ca_n <= 32 ? 1 : 0) | (cb_n <= 32 ? 2 : 0);
+    if (hf == 3 && rv != 18) hf = 1;          // (both halves empty: built for the 64-pixel conv3x3 rows only)
+    return hf;
+}
 struct WsSlot { PendingJob* p; int blk; int nseg; };
 
 // fills tab.job[*].ubegin / w_first and slots[*].nseg for G workgroups; false if a block would need more slabs than its
@@ -1352,6 +1448,11 @@ int wgq_launch_stream(std::vector<PendingJob*>& jobs, hipStream_t s, std::vector
                     if (rv >= 0) { jb.variant = rv; jb.ntiles = rv >= 29 ? q.job.N * q.job.Hb * 2 : q.job.N * q.job.Hb / (rv >= 26 ? 2 : 1); }
                     else if (q.cls >= WQ_C5A) { gx_set_error("wgq: the 5x5 classes exist as row-ring tiles only"); return GX_EINVAL; }
                     jb.cost = g_ws_cost[jb.variant];
+                    if (rv >= 0) {
+                        const int ca_n = q.job.CA - jb.ca0 < 64 ? q.job.CA - jb.ca0 : 64, cb_n = q.job.CB - jb.cb0 < 64 ? q.job.CB - jb.cb0 : 64;
+                        const int hf = ws_ksplit(rv, ca_n, cb_n);
+                        if (hf) { jb.variant = rv + 32 * hf; jb.cost = jb.cost * g_ws_kcost[hf == 3 ? 8 : rv - 18] / 100; }
+                    }
                     jb.w_first = 0; jb.N = q.job.N;
                     tab.U += (long long)jb.ntiles * jb.cost;
                     slots.push_back(WsSlot{&q, blk, 0});

@@ -1113,7 +1113,12 @@ def test_streamk_weight_gradients_many_layers():
                                                 # rows too wide for the ring (the 128 x 128 model): two column strips per row, the
                                                 # dy values next to a strip in the seam bytes of its A rows
                                                 ('conv3x3', 3, 64, 64, 128), ('conv3x3', 1, 128, 64, 128), ('conv3x3', 2, 40, 72, 128),
-                                                ('deconv', 3, 64, 64, 64), ('deconv', 1, 40, 72, 64)])
+                                                ('deconv', 3, 64, 64, 64), ('deconv', 1, 40, 72, 64),
+                                                # channel blocks with an empty half: the waves of a pair share 32 channels and split
+                                                # the tile's k-groups (A half, B half, both; a layer's LAST block only)
+                                                ('conv3x3', 5, 64, 32, 64), ('conv3x3', 5, 32, 64, 64), ('conv3x3', 3, 4, 32, 64),
+                                                ('conv3x3', 9, 32, 32, 32), ('conv3x3', 2, 96, 160, 64), ('deconv', 3, 32, 64, 32),
+                                                ('deconv', 5, 64, 32, 32), ('deconv', 1, 24, 96, 32)])
 def test_row_ring_weight_gradients(kind, N, Cin, Cout, S):
     """gx_wgq_ring: the row-ring tiles of the bf16-pipe weight gradients (one full-width base row per tile, x rows in a
     rolling four-slot LDS ring, operands split into bf16 planes once, column shifts as funnel shifts of the dy operand)
