@@ -1317,7 +1317,7 @@ int g_ws_cost[32] = {10200, 9580, 10680, 15080, 21000, 11800, 11400, 8800, 9700,
 // cost of a k-split tile relative to the full one, in percent, by base variant 18..25 (one or the other half) and for both
 // halves of variant 18 (measured with GENESIS_WGQ_TIMES on the GENESIS / BaselineVAE / MONet steps: the 32-pixel rows keep one
 // k-group per wave -- their tile starts with the operand reads the tail could not take); GENESIS_WGQ_KSPLIT_COST="9 values" overrides
-int g_ws_kcost[9] = {55, 65, 65, 74, 54, 58, 56, 64, 39};
+int g_ws_kcost[9] = {54, 68, 68, 78, 54, 58, 55, 65, 41};
 bool g_ws_cost_init = false;
 void ws_cost_init() {
     if (g_ws_cost_init) return;
