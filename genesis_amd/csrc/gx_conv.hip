@@ -839,6 +839,30 @@ wgrad_kernel(const float* __restrict__ a_src, const float* __restrict__ b_src,
     wgrad_body<WM>(a_src, b_src, partial, g, lds, blockIdx.x, g.nsplit);
 }
 
+// fp32 products from six bf16 piece products on v_mfma_f32_32x32x16_bf16 (finding 13; the same helpers as
+// gx_wgq.hip's wq_tile_b6): lane half h supplies 8 CONSECUTIVE contraction indices -- for a weight gradient 8 consecutive pixels
+typedef __bf16 cw_bf16x8 __attribute__((ext_vector_type(8)));
+struct CwB3 { cw_bf16x8 h, m, l; };
+template <int N>
+__device__ __forceinline__ void cw_split(const float (&v)[N], __bf16 (&h)[N], __bf16 (&m)[N], __bf16 (&l)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        h[i] = (__bf16)v[i];
+        const float r1 = v[i] - (float)h[i];
+        m[i] = (__bf16)r1;
+        l[i] = (__bf16)(r1 - (float)m[i]);
+    }
+}
+__device__ __forceinline__ f32x16 cw_mma6(const CwB3& a, const CwB3& b, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, c, 0, 0, 0);      // small terms first
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.m, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, c, 0, 0, 0);
+    return c;
+}
+
 // ---- lean variant for the common case (tile width >= 4, grid width a multiple of 4) ------------------------
 // PMC on the kernel above (64->64 @64x64, B=32): 3.4 non-MFMA VALU + 1.3 SALU + 0.8 LDS instructions per MFMA and
 // one wave per SIMD: the wave cannot issue them all under a 64-cycle MFMA, the matrix pipe sits at 62 %.  Here the
@@ -851,10 +875,14 @@ wgrad_kernel(const float* __restrict__ a_src, const float* __restrict__ b_src,
 // of sub-image w (128 staged B rows): all four waves produce a 32 x 32 block that is wanted (a plain 64-channel tile of two
 // images has two useful waves, one image one), each into its own quadrant of the 64 x 64 slab; wgrad_quad_reduce_kernel sums
 // the quadrants.
-template <int WM, int LTW, bool QUAD = false>
+// B6 (round 4; tiles at least 8 pixels wide): the same tile on the bf16 matrix pipe -- a group is 8 consecutive pixels of a tile row
+// (two of the fp32 path's 4-pixel groups), the lane splits its 8 dy values and the 3 x 10-float halo window of x into bf16 pieces
+// in registers, every tap's B operand is a shifted view of the split window: 54 MFMAs of 32 cycles per 16 pixels instead of 72 of 64.
+template <int WM, int LTW, bool QUAD = false, bool B6 = false>
 __global__ void __launch_bounds__(256, 1)
 wgrad_fast_kernel(const float* __restrict__ a_src, const float* __restrict__ b_src,
                   float* __restrict__ partial, const float* __restrict__ zeros, WgradGeom g) {
+    static_assert(!B6 || LTW >= 3, "the bf16-pipe groups are 8 consecutive pixels of a tile row");
     using WT = WTap<WM>;
     constexpr int NT = WT::NT, HL = WT::HALO;
     constexpr int TW = 1 << LTW, HS = TW + 2 * HL;
@@ -1018,6 +1046,38 @@ wgrad_fast_kernel(const float* __restrict__ a_src, const float* __restrict__ b_s
         GX_WF_SCHED()                                                                                \
     }
 
+    // bf16 pipe: one pair of groups = 8 consecutive pixels (P_ = 0, 1 within the batch)
+    constexpr int NCO8 = CO1 - CO0 + 8;
+#define GX_WF_PAIR_B6(bt_, src_, P_)                                                                   \
+    {                                                                                                \
+        float av_[8];                                                                                \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) { av_[u] = src_[2 * (P_)][u]; av_[4 + u] = src_[2 * (P_) + 1][u]; } \
+        __bf16 ah_[8], am_[8], al_[8];                                                               \
+        cw_split<8>(av_, ah_, am_, al_);                                                             \
+        CwB3 a3_;                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) { a3_.h[i] = ah_[i]; a3_.m[i] = am_[i]; a3_.l[i] = al_[i]; } \
+        const int j0 = jlane + 4 * (4 * (bt_) + 2 * (P_));                                           \
+        const int c = j0 & (TW - 1);                                                                 \
+        const int r = (j0 >> LTW) & (TH - 1);                                                        \
+        const int gi = j0 >> (LTW + g.lTH);                                                          \
+        const float* bp = buf + b_row + (gi * (TH + 2 * HL) + r) * HS + c;                           \
+        _Pragma("unroll") for (int rr = 0; rr < NRO; ++rr) {                                         \
+            float bw_[NCO8];                                                                         \
+            _Pragma("unroll") for (int cc = 0; cc < NCO8; ++cc) bw_[cc] = bp[(RO0 + rr) * HS + CO0 + cc]; \
+            __bf16 bh_[NCO8], bm_[NCO8], bl_[NCO8];                                                  \
+            cw_split<NCO8>(bw_, bh_, bm_, bl_);                                                      \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                         \
+                if (WT::ro(t) - RO0 != rr) continue;                                                 \
+                CwB3 b3_;                                                                            \
+                _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                      \
+                    b3_.h[i] = bh_[WT::co(t) - CO0 + i]; b3_.m[i] = bm_[WT::co(t) - CO0 + i]; b3_.l[i] = bl_[WT::co(t) - CO0 + i]; \
+                }                                                                                    \
+                acc[t] = cw_mma6(a3_, b3_, acc[t]);                                                  \
+            }                                                                                        \
+        }                                                                                            \
+    }
+#define GX_WF_COMPUTE_B6(bt_, src_) { GX_WF_PAIR_B6(bt_, src_, 0) GX_WF_PAIR_B6(bt_, src_, 1) }
+
     float a0[4][4], a1[4][4];
     int tile = sp;
     int it = 0;
@@ -1034,6 +1094,33 @@ wgrad_fast_kernel(const float* __restrict__ a_src, const float* __restrict__ b_s
 #if !(GX_WG_ABL & 1)
         if (more) GX_WF_PREFETCH_B(nxt, lds + ((it + 1) & 1) * BUF)
 #endif
+        if constexpr (B6) {
+            if (nb == 4) {
+                GX_WF_LOAD_A(cur, 1, a1)
+                GX_WF_COMPUTE_B6(0, a0)
+                GX_WF_LOAD_A(cur, 2, a0)
+                GX_WF_COMPUTE_B6(1, a1)
+                GX_WF_LOAD_A(cur, 3, a1)
+                GX_WF_COMPUTE_B6(2, a0)
+                if (more) GX_WF_LOAD_A(nxt, 0, a0)
+                GX_WF_COMPUTE_B6(3, a1)
+            } else if (nb == 2) {
+                GX_WF_LOAD_A(cur, 1, a1)
+                GX_WF_COMPUTE_B6(0, a0)
+                if (more) GX_WF_LOAD_A(nxt, 0, a0)
+                GX_WF_COMPUTE_B6(1, a1)
+            } else {
+                if (more) GX_WF_LOAD_A(nxt, 0, a1)
+                GX_WF_COMPUTE_B6(0, a0)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) a0[gq][u] = a1[gq][u];
+            }
+            cur = nxt;
+            GX_WF_ADVANCE(nxt, cur)
+            continue;
+        }
         GX_WF_LOAD_B(0, 0, bva)
         if (nb == 4) {
             GX_WF_LOAD_A(cur, 1, a1)
@@ -1068,6 +1155,8 @@ wgrad_fast_kernel(const float* __restrict__ a_src, const float* __restrict__ b_s
 #undef GX_WF_SCHED
 #undef GX_WF_LOAD_B
 #undef GX_WF_MMA
+#undef GX_WF_PAIR_B6
+#undef GX_WF_COMPUTE_B6
     // partial[split][gt][ca][cb]
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -2215,22 +2304,26 @@ int gx_conv3x3_wgrad_quad(const float* x, const float* dy, float* dw, int N, int
     {
         GxProf pf(KID_WGRAD_C3, s, 2.0 * N * (double)C * C * 9 * H * W,
                   4.0 * (2.0 * N * C * H * W + (double)g.nsplit * 9 * 64 * 64));
-#define GX_QUAD_LAUNCH(LTW_)                                                                                             \
+#define GX_QUAD_LAUNCH(LTW_, B6_)                                                                                        \
         {                                                                                                                \
             static bool attr = false;                                                                                    \
             if (!attr) {                                                                                                 \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_fast_kernel<W_C3, LTW_, true>),           \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_fast_kernel<W_C3, LTW_, true, B6_>),      \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                       \
                 attr = true;                                                                                             \
             }                                                                                                            \
-            hipLaunchKernelGGL((wgrad_fast_kernel<W_C3, LTW_, true>), grid, dim3(256), pl.lds_bytes, s, dy, x, (float*)ws, \
-                               zeros, g);                                                                                \
+            hipLaunchKernelGGL((wgrad_fast_kernel<W_C3, LTW_, true, B6_>), grid, dim3(256), pl.lds_bytes, s, dy, x,      \
+                               (float*)ws, zeros, g);                                                                    \
         }
+        // tiles >= 8 pixels wide: on the bf16 matrix pipe (six piece products) unless gx_wgq_precision(0) /
+        // GENESIS_WGQ_BF16X6=0 / GENESIS_WGRAD_QUAD_B6=0 keep the weight gradients on the fp32 pipe
+        static const char* b6env = getenv("GENESIS_WGRAD_QUAD_B6");
+        const bool b6 = gx_wgq_bf16_pipe() && !(b6env && b6env[0] == '0');
         switch (g.lTW) {
-            case 2: GX_QUAD_LAUNCH(2) break;
-            case 3: GX_QUAD_LAUNCH(3) break;
-            case 4: GX_QUAD_LAUNCH(4) break;
-            default: GX_QUAD_LAUNCH(5) break;
+            case 2: GX_QUAD_LAUNCH(2, false) break;
+            case 3: if (b6) GX_QUAD_LAUNCH(3, true) else GX_QUAD_LAUNCH(3, false) break;
+            case 4: if (b6) GX_QUAD_LAUNCH(4, true) else GX_QUAD_LAUNCH(4, false) break;
+            default: if (b6) GX_QUAD_LAUNCH(5, true) else GX_QUAD_LAUNCH(5, false) break;
         }
 #undef GX_QUAD_LAUNCH
     }

@@ -1667,6 +1667,7 @@ int gx_wgq_c5(const float* a, const float* b, float* dw, int N, int CA, int CB, 
     return wgq_run_or_queue(v, s);
 }
 
+bool gx_wgq_bf16_pipe(void) { return wgq_b6(); }
 int gx_wgq_pending(void) { return (int)g_jobs.size(); }
 void gx_wgq_discard(void) { g_jobs.clear(); }
 
