@@ -1119,7 +1119,7 @@ wgq_stream_kernel(const WsTable tab, const float* __restrict__ zeros) {
     ws_locate(tab, wg + 1 == tab.G ? tab.U : tab.U * (wg + 1) / tab.G, &je, &te);
 #pragma unroll 1
     for (int j = js; j <= je && j < tab.njobs; ++j) {
-        const WsJob& jb = tab.job[j];
+        const WsJob jb = tab.job[j];          // (a copy: 96 bytes of kernel-argument memory into scalar registers)
         const int t0 = j == js ? ts : 0, t1 = j == je ? te : jb.ntiles;
         if (t0 >= t1) continue;
         float* slab = jb.partial + (size_t)(wg - jb.w_first) * jb.Ttot * 4096;
@@ -1534,7 +1534,7 @@ int wgq_launch_stream(std::vector<PendingJob*>& jobs, hipStream_t s, std::vector
                     paired = paired || (slots[k].p->cls == q.cls - 1 && slots[k].p->job.partial == q.job.partial);
                 if (paired) continue;
             }
-            const WsJob& jb = tab.job[j];
+            const WsJob jb = tab.job[j];          // (a copy: 96 bytes of kernel-argument memory into scalar registers)
             const int ca_n = q.job.CA - jb.ca0 < 64 ? q.job.CA - jb.ca0 : 64;
             const int cb_n = q.job.CB - jb.cb0 < 64 ? q.job.CB - jb.cb0 : 64;
             GxWgradRed r{jb.partial, q.dw, slots[j].nseg, jb.Ttot, ca_n, cb_n, 64, 64, q.layout, 0, 0, 0, 0,
