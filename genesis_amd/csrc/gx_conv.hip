@@ -1730,6 +1730,88 @@ int launch_wgrad_deconv(const float* a, const float* b, float* partial, const Wg
     return GX_OK;
 }
 
+// ---- conv3x3 FORWARD for very few input channels (Cin <= 4: the UNets' input layers, modules/unet.py:35-37 on RGB / RGB + scope) ----
+// The MFMA kernels pad Cin to an 8-channel chunk and are bound by their output stores at a fraction of the HBM rate (3 -> 64 @ 64 x 64,
+// N = 32: 24 us for 33.5 MB; 4 -> 32: 19.6 us for 16.8 MB).  Here a thread owns 4 consecutive pixels of a row and SC_COB output
+// channels: its (Cin x 3 x 6)-float input patch sits in registers, the block's weights in LDS (broadcast 16-byte reads), every
+// output row segment leaves as one 16-byte store -- exact fp32 FMAs, channel-major / tap-minor summation.
+constexpr int SC_COB = 8;
+template <int CIN>
+__global__ void __launch_bounds__(256)
+conv3x3_smallcin_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, int act,
+                            float* __restrict__ y, int N, int Cout, int H, int W) {
+    constexpr int J = CIN * 9, JP = (J + 3) & ~3;
+    __shared__ __attribute__((aligned(16))) float wl[SC_COB][JP];
+    const int co0 = blockIdx.y * SC_COB;
+    for (int i = threadIdx.x; i < SC_COB * JP; i += 256) {
+        const int co = i / JP, j = i - co * JP;
+        wl[co][j] = (j < J && co0 + co < Cout) ? w[(size_t)(co0 + co) * J + j] : 0.f;
+    }
+    __syncthreads();
+    const int HW = H * W, q4 = HW >> 2;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= N * q4) return;
+    const int n = q / q4, rem = (q - n * q4) << 2;
+    const int r = rem / W, c = rem - r * W;
+    float pt[CIN][3][6];
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int rr = r + kh - 1;
+            const bool rok = rr >= 0 && rr < H;
+            const float* xp = x + ((size_t)n * CIN + ci) * HW + (size_t)(rok ? rr : 0) * W + c;
+            f32x4 m = {0.f, 0.f, 0.f, 0.f};
+            float e0 = 0.f, e1 = 0.f;
+            if (rok) {
+                m = *reinterpret_cast<const f32x4*>(xp);
+                if (c > 0) e0 = xp[-1];
+                if (c + 4 < W) e1 = xp[4];
+            }
+            pt[ci][kh][0] = e0; pt[ci][kh][1] = m[0]; pt[ci][kh][2] = m[1]; pt[ci][kh][3] = m[2]; pt[ci][kh][4] = m[3]; pt[ci][kh][5] = e1;
+        }
+#pragma unroll
+    for (int co = 0; co < SC_COB; ++co) {
+        if (co0 + co >= Cout) break;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        float wv[JP];
+#pragma unroll
+        for (int j4 = 0; j4 < JP / 4; ++j4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(&wl[co][4 * j4]);
+            wv[4 * j4] = t[0]; wv[4 * j4 + 1] = t[1]; wv[4 * j4 + 2] = t[2]; wv[4 * j4 + 3] = t[3];
+        }
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float wj = wv[ci * 9 + kh * 3 + kw];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) acc[p] = fmaf(wj, pt[ci][kh][kw + p], acc[p]);
+                }
+        const float bv = bias ? bias[co0 + co] : 0.f;
+        f32x4 o;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            float v = acc[p] + bv;
+            if (act == 1) v = v > 0.f ? v : 0.f;
+            else if (act == 2) v = v > 0.f ? v : expm1f(v);
+            o[p] = v;
+        }
+        *reinterpret_cast<f32x4*>(y + ((size_t)n * Cout + co0 + co) * HW + rem) = o;
+    }
+}
+static bool smallcin_fwd_ok(int Cin, int H, int W) {
+    static const char* env = getenv("GENESIS_CONV3_SMALLCIN_FWD");
+    // Cin == 4 only by default (MONet's [x | log-scope] input, modules/attention.py:36-40: 19.5 -> 12.2 us per pass).  The RGB
+    // layer of GENESIS-V2 gains as much (22.2 -> 14.3 us, + 0.3 % of its step) but another summation order in the network's first
+    // layer moved ReLU decisions in the fp64-budget and full-batch-vs-chunks tests (DESIGN.md finding 18) beyond their measured
+    // allowances: GENESIS_CONV3_SMALLCIN_FWD=2 enables every Cin <= 4, =0 none
+    const bool all = env && env[0] == '2';
+    return !(env && env[0] == '0') && (Cin == 4 || (all && Cin >= 1 && Cin <= 4)) && (W % 4) == 0 && (long)H * W >= 1024;
+}
+
 // ---- conv3x3 weight gradient for very few input channels (Cin * 9 <= 32: the UNet's RGB input layer) -----------
 // The generic kernel pads Cin to a 64-channel block (21x wasted MFMA work: 3 -> 64 @64x64 took 111 us for 0.45
 // GFLOP).  Here the (ci, tap) pairs ARE the N dimension: D[co][j = ci*9 + tap] += dy[co][p] * x[ci][p + tap] on
@@ -2108,6 +2190,19 @@ static int conv3x3_fwd_impl(const float* x, const float* w, const float* bias, i
     GX_CHECK_ARG(ws_bytes >= gx_conv3x3_ws_bytes(N, Cin, Cout, H, W), "gx_conv3x3_fwd: workspace too small");
     const int Kpad = gx_round_up(Cin, 8), Mpad = gx_round_up(Cout, 64);
     hipStream_t s = (hipStream_t)stream;
+    if (smallcin_fwd_ok(Cin, H, W)) {          // input layers: vector-ALU kernel bound by its stores
+        const dim3 grid(gx_ceil_div(N * (H * W / 4), 256), gx_ceil_div(Cout, SC_COB));
+        {
+            GxProf pf(KID_TAPCONV_C3, s, 2.0 * N * (double)Cout * Cin * 9 * H * W,
+                      4.0 * ((double)N * Cin * H * W + (double)N * Cout * H * W));
+#define GX_SC_LAUNCH(C_) hipLaunchKernelGGL(conv3x3_smallcin_fwd_kernel<C_>, grid, dim3(256), 0, s, x, w, bias, act, y, N, Cout, H, W)
+            if (Cin == 1) GX_SC_LAUNCH(1); else if (Cin == 2) GX_SC_LAUNCH(2); else if (Cin == 3) GX_SC_LAUNCH(3); else GX_SC_LAUNCH(4);
+#undef GX_SC_LAUNCH
+        }
+        GX_CHECK_LAUNCH("gx_conv3x3_fwd(small Cin)");
+        if (parts_out) { *parts_out = y; *nsplit_out = 1; }
+        return GX_OK;
+    }
     TapPlan pl;
     rc = plan_c3(N, Cin, Cout, Mpad, H, W, &pl, "gx_conv3x3_fwd");
     if (rc) return rc;

@@ -685,13 +685,15 @@ bool gx_wino_eligible(int N, int K, int M, int H, int W) {
         g_wino_mode = env ? (env[0] == '0' ? 0 : (env[0] == '2' ? 2 : 1)) : 1;
     }
     if (g_wino_mode == 0 || !wino_shape_ok(N, K, M, H, W)) return false;
-    // a quarter-filled chip is enough where the direct kernel has little reduction to split (<= 128 input channels): measured
-    // per layer at 16 x 16, N = 32 (tools/conv3_policy_time.py): 32 -> 64 20.0 -> 17.0 us, 64 -> 128 29.5 -> 19.7, 128 -> 128 38.7 ->
-    // 31.0, the data gradients 21.5 -> 17.6 / 30.7 -> 27.6 / 38.9 -> 29.4 -- but 256 -> 64 41.3 -> 48.9 (stays direct);
-    // GENESIS_WINO_SMALL=0: the chip-filling rule alone
+    // a quarter-filled chip is enough where the direct kernel has next to no reduction to split (<= 32 input channels; measured
+    // per layer at 16 x 16, N = 32 with tools/conv3_policy_time.py: 32 -> 64 20.0 -> 17.0 us, the data gradient of 128 -> 32
+    // 25.8 -> 17.9 us; 256 -> 64 is 41.3 -> 48.9 and stays direct).  Wider layers would gain 3 - 10 us as well (64 -> 128: 29.5 ->
+    // 19.7), but they are GENESIS-V2's, whose B = 32 step is pinned against its own chunks of two images
+    // (test_full_batch_equals_sixteen_golden_sized_chunks): a layer that changes kernels with the batch size moves ReLU decisions
+    // (DESIGN.md finding 18) for 0.4 % of the step.  GENESIS_WINO_SMALL=0: the chip-filling rule alone
     static const char* small_env = getenv("GENESIS_WINO_SMALL");
     const int wgs = N * (H / 8) * (W / 16) * gx_ceil_div(M, 64);
-    return g_wino_mode == 2 || wgs >= 256 || (wgs >= 64 && K <= 128 && !(small_env && small_env[0] == '0'));
+    return g_wino_mode == 2 || wgs >= 256 || (wgs >= 64 && K <= 32 && N >= 16 && !(small_env && small_env[0] == '0'));
 }
 
 // in2 / K1, out2 / M1: the pair variants (WinoGeom); nullptr / 0 for one input tensor and one output tensor

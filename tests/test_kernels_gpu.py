@@ -29,6 +29,7 @@ def close(a, b, rtol=1e-4, atol=1e-4, msg=''):
 CONV_CASES = [  # N, Cin, Cout, H, W
     (2, 3, 64, 64, 64), (2, 64, 64, 32, 32), (3, 128, 128, 8, 8), (2, 256, 128, 4, 4),
     (2, 128, 64, 64, 64), (1, 64, 64, 128, 128), (5, 16, 32, 16, 16), (2, 8, 8, 2, 2), (33, 32, 16, 4, 4),
+    (2, 4, 32, 64, 64), (3, 4, 20, 32, 48),      # four input channels: the forward runs on the vector-ALU input-layer kernel
 ]
 
 
@@ -47,6 +48,18 @@ def test_conv3x3(N, Cin, Cout, H, W):
     close(dx, xr.grad, 2e-5, 2e-5, 'dgrad')
     dw = hip.conv3x3_wgrad(x.to(DEV), dy.to(DEV))
     close(dw, wr.grad, 1e-4, 1e-4, 'wgrad')
+
+
+@pytest.mark.parametrize('act', [None, 'relu', 'elu'])
+def test_conv3x3_input_layer_kernel_with_bias_and_activation(act):
+    """conv3x3_smallcin_fwd_kernel (Cin = 4: MONet's [x | log-scope] input layer): bias and activation epilogue, a ragged
+    channel block (Cout = 20), against torch."""
+    N, Cin, Cout, H, W = 3, 4, 20, 32, 48
+    x, w, b = rnd(N, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=1.0 / 6), rnd(Cout, seed=3, scale=0.5)
+    ref = F.conv2d(x, w, b, 1, 1)
+    ref = F.relu(ref) if act == 'relu' else (F.elu(ref) if act == 'elu' else ref)
+    y = hip.conv3x3_bias_act_fwd(x.to(DEV), w.to(DEV), b.to(DEV), act)
+    close(y, ref, 2e-5, 2e-5, 'fwd ' + str(act))
 
 
 DECONV_CASES = [  # N, Cin, Cout, Hin
