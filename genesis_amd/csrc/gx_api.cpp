@@ -142,7 +142,7 @@ int gx_ctx_destroy(int id) {
     std::lock_guard<std::mutex> lk(g_ctx_mutex);
     const int prev = t_ctx;
     t_ctx = id;
-    g_nw = 0; g_ng = 0; gx_wgq_discard();
+    g_nw = 0; g_ng = 0; gx_wgq_discard(); gx_wf_discard();
     for (ProfEntry& e : g_entries) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     g_entries.clear();
     g_ctx_alive[id] = false;
@@ -152,16 +152,17 @@ int gx_ctx_destroy(int id) {
 
 int gx_defer_enable(int on) {
     g_gx_defer_on = on > 0;
-    if (on < 0) { g_nw = 0; g_ng = 0; gx_wgq_discard(); }   // discard whatever is queued (error recovery)
+    if (on < 0) { g_nw = 0; g_ng = 0; gx_wgq_discard(); gx_wf_discard(); }   // discard whatever is queued (error recovery)
     return GX_OK;
 }
 
-int gx_defer_pending(void) { return g_nw + g_ng + gx_wgq_pending(); }
+int gx_defer_pending(void) { return g_nw + g_ng + gx_wgq_pending() + gx_wf_pending(); }
 
 int gx_defer_flush(gx_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     // queued weight-gradient jobs first: grouped launches, which queue their slab reductions below
     int rc = gx_wgq_flush(s);
+    if (rc == GX_OK) rc = gx_wf_flush(s);          // queued small-layer launches, also ahead of their slab reductions
     if (rc == GX_OK && g_nw) rc = gx_defer_flush_wgrad(g_wq, g_nw, s);
     g_nw = 0;
     if (rc == GX_OK && g_ng) rc = gx_defer_flush_gn(g_gq, g_ng, s);

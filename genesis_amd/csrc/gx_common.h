@@ -199,4 +199,8 @@ bool gx_wgq_bf16_pipe(void);      // gx_wgq_precision / GENESIS_WGQ_BF16X6: weig
 int gx_wgq_pending(void);
 void gx_wgq_discard(void);
 int gx_wgq_flush(hipStream_t s);
+// gx_conv.hip: conv3x3 weight gradients of layers too small for the stream-K launch (4 x 4 grids), queued while deferral is on
+int gx_wf_flush(hipStream_t s);
+int gx_wf_pending(void);
+void gx_wf_discard(void);
 int gx_wgrad_reduce_now(const GxWgradRed& r, hipStream_t s, int accumulate = 0);    // gx_conv.hip: dw (+)= sum of the slabs

@@ -879,9 +879,9 @@ __device__ __forceinline__ f32x16 cw_mma6(const CwB3& a, const CwB3& b, f32x16 c
 // (two of the fp32 path's 4-pixel groups), the lane splits its 8 dy values and the 3 x 10-float halo window of x into bf16 pieces
 // in registers, every tap's B operand is a shifted view of the split window: 54 MFMAs of 32 cycles per 16 pixels instead of 72 of 64.
 template <int WM, int LTW, bool QUAD = false, bool B6 = false>
-__global__ void __launch_bounds__(256, 1)
-wgrad_fast_kernel(const float* __restrict__ a_src, const float* __restrict__ b_src,
-                  float* __restrict__ partial, const float* __restrict__ zeros, WgradGeom g) {
+__device__ __forceinline__ void
+wgrad_fast_body(const float* __restrict__ a_src, const float* __restrict__ b_src, float* __restrict__ partial,
+                const float* __restrict__ zeros, const WgradGeom& g, const int bx, const int by) {
     static_assert(!B6 || LTW >= 3, "the bf16-pipe groups are 8 consecutive pixels of a tile row");
     using WT = WTap<WM>;
     constexpr int NT = WT::NT, HL = WT::HALO;
@@ -895,11 +895,11 @@ wgrad_fast_kernel(const float* __restrict__ a_src, const float* __restrict__ b_s
     const int BS = CHS | 1;
     constexpr int BROWS = QUAD ? 128 : 64;
     const int BUF = BROWS * BS;
-    const int sp = blockIdx.x, nsp = g.nsplit;
+    const int sp = bx, nsp = g.nsplit;
 
     const int nbt = g.CBpad / 64;
-    const int ca0 = QUAD ? 0 : (blockIdx.y / nbt) * 64;
-    const int cb0 = QUAD ? 0 : (blockIdx.y % nbt) * 64;
+    const int ca0 = QUAD ? 0 : (by / nbt) * 64;
+    const int cb0 = QUAD ? 0 : (by % nbt) * 64;
     const int wm = wave >> 1, wn = wave & 1;
     const int a_img = g.CA * g.Ha * g.Wa;             // the host dispatch guarantees these fit 31 bits
     const int b_img = g.CB * g.Hb * g.Wb;
@@ -1168,6 +1168,28 @@ wgrad_fast_kernel(const float* __restrict__ a_src, const float* __restrict__ b_s
             dst[(size_t)row * g.CBpad] = acc[t][reg];
         }
     }
+}
+
+template <int WM, int LTW, bool QUAD = false, bool B6 = false>
+__global__ void __launch_bounds__(256, 1)
+wgrad_fast_kernel(const float* __restrict__ a_src, const float* __restrict__ b_src,
+                  float* __restrict__ partial, const float* __restrict__ zeros, WgradGeom g) {
+    wgrad_fast_body<WM, LTW, QUAD, B6>(a_src, b_src, partial, zeros, g, blockIdx.x, blockIdx.y);
+}
+
+// Several layers in one grid (blockIdx.z = job): the weight gradients of layers too small for the stream-K launch (4 x 4
+// grids) each cost a launch of ~17 us for ~40 MFLOP -- twelve per MONet step (its shared UNet runs six times), two per GENESIS-V2
+// step.  With deferral on they are queued like the stream-K jobs and launched together at the flush, in front of the batched
+// slab reduce.  (The job record is COPIED out of kernel-argument memory: DESIGN.md finding 26.)
+constexpr int kMaxWfJobs = 16;
+struct WfJob { const float* a; const float* b; float* partial; WgradGeom g; };
+struct WfTable { WfJob job[kMaxWfJobs]; };
+template <int WM, int LTW>
+__global__ void __launch_bounds__(256, 1)
+wgrad_fast_multi_kernel(const WfTable tab, const float* __restrict__ zeros) {
+    const WfJob jb = tab.job[blockIdx.z];
+    if ((int)blockIdx.x >= jb.g.nsplit || (int)blockIdx.y >= (jb.g.CApad / 64) * (jb.g.CBpad / 64)) return;
+    wgrad_fast_body<WM, LTW, false, false>(jb.a, jb.b, jb.partial, zeros, jb.g, blockIdx.x, blockIdx.y);
 }
 
 // All four output-parity classes of the transposed conv's weight gradient in ONE launch: blockIdx.x ranges are
@@ -1670,6 +1692,15 @@ void launch_wgrad_fast(dim3 grid, size_t lds_bytes, hipStream_t s, const float* 
     hipLaunchKernelGGL((wgrad_fast_kernel<WM, LTW>), grid, dim3(256), lds_bytes, s, a, b, partial, zeros, g);
 }
 
+// queued small-layer jobs of each context (conv3x3, tile width 4)
+struct WfPending { WfJob job; size_t lds; double flops; };
+std::vector<WfPending> g_wf_ctx[kGxMaxCtx];
+#define g_wf (g_wf_ctx[gx_cur_ctx()])
+bool wf_defer_on() {
+    static const char* env = getenv("GENESIS_WGRAD_SMALL_DEFER");
+    return !(env && env[0] == '0');
+}
+
 template <int WM>
 int launch_wgrad(const float* a, const float* b, float* partial, const WgradPlan& pl, hipStream_t s, const char* name) {
     if (pl.lds_bytes > 160 * 1024) { gx_set_error("%s: LDS %zu > 160KiB", name, pl.lds_bytes); return GX_EINVAL; }
@@ -1680,6 +1711,14 @@ int launch_wgrad(const float* a, const float* b, float* partial, const WgradPlan
         attr_set = true;
     }
     dim3 grid(pl.g.nsplit, (pl.g.CApad / 64) * (pl.g.CBpad / 64));
+    if (WM == W_C3 && pl.g.lTW == 2 && g_gx_defer_on && wf_defer_on() && (pl.g.Wb & 3) == 0 && pl.g.Hb * pl.g.Wb <= 65536 &&
+        (double)(1 << pl.g.lG) * pl.g.CA * pl.g.Ha * pl.g.Wa < 2.0e9 && (double)(1 << pl.g.lG) * pl.g.CB * pl.g.Hb * pl.g.Wb < 2.0e9 &&
+        !getenv("GENESIS_WGRAD_LEGACY") && zero_page(s)) {
+        // a layer too small for the stream-K launch: launched with the other queued ones at the flush (gx_wf_flush)
+        g_wf.push_back(WfPending{WfJob{a, b, partial, pl.g}, pl.lds_bytes,
+                                 2.0 * pl.g.N * (double)pl.g.CA * pl.g.CB * WTap<WM>::NT * pl.g.Hb * pl.g.Wb});
+        return GX_OK;
+    }
     {
         using WT = WTap<WM>;
         const WgradGeom& g = pl.g;
@@ -1705,6 +1744,41 @@ int launch_wgrad(const float* a, const float* b, float* partial, const WgradPlan
         }
     }
     GX_CHECK_LAUNCH(name);
+    return GX_OK;
+}
+
+int wf_flush(hipStream_t s) {
+    std::vector<WfPending>& q = g_wf;
+    if (q.empty()) return GX_OK;
+    const float* zeros = zero_page(s);
+    if (!zeros) { q.clear(); gx_set_error("wgrad (queued small layers): no zero page"); return GX_ELAUNCH; }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_fast_multi_kernel<W_C3, 2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    for (size_t i = 0; i < q.size(); i += kMaxWfJobs) {
+        const int n = (int)(q.size() - i < (size_t)kMaxWfJobs ? q.size() - i : kMaxWfJobs);
+        WfTable tab;
+        unsigned gx = 1, gy = 1; size_t lds = 0; double flops = 0.0;
+        for (int j = 0; j < n; ++j) {
+            const WfPending& p = q[i + j];
+            tab.job[j] = p.job;
+            const unsigned by = (unsigned)((p.job.g.CApad / 64) * (p.job.g.CBpad / 64));
+            gx = (unsigned)p.job.g.nsplit > gx ? (unsigned)p.job.g.nsplit : gx;
+            gy = by > gy ? by : gy;
+            lds = p.lds > lds ? p.lds : lds;
+            flops += p.flops;
+        }
+        for (int j = n; j < kMaxWfJobs; ++j) tab.job[j] = tab.job[0];
+        {
+            GxProf pf(KID_WGRAD_C3, s, flops, 0.0);
+            hipLaunchKernelGGL((wgrad_fast_multi_kernel<W_C3, 2>), dim3(gx, gy, n), dim3(256), lds, s, tab, zeros);
+        }
+        if (hipGetLastError() != hipSuccess) { q.clear(); gx_set_error("wgrad (queued small layers): launch failed"); return GX_ELAUNCH; }
+    }
+    q.clear();
     return GX_OK;
 }
 
@@ -2004,6 +2078,11 @@ int check_dims(const char* name, int N, int Cin, int Cout, int H, int W) {
 }
 
 }  // namespace
+
+// queued small-layer weight-gradient launches (gx_common.h)
+int gx_wf_flush(hipStream_t s) { return wf_flush(s); }
+int gx_wf_pending(void) { return (int)g_wf.size(); }
+void gx_wf_discard(void) { g_wf.clear(); }
 
 // =================================================================== C ABI
 int gx_defer_flush_wgrad(const GxWgradRed* items, int n, hipStream_t s) {

@@ -1453,7 +1453,8 @@ def test_philox_noise_is_a_function_of_seed_step_and_position():
     assert ue.shape == (5,) and ze.shape == (2, 3) and bool(torch.isfinite(ze).all())
 
 
-@pytest.mark.parametrize('N,Cin,Cout,S', [(4, 3, 64, 64), (3, 3, 32, 32), (4, 64, 64, 32), (2, 40, 24, 16)])
+@pytest.mark.parametrize('N,Cin,Cout,S', [(4, 3, 64, 64), (3, 3, 32, 32), (4, 64, 64, 32), (2, 40, 24, 16),
+                                           (32, 128, 64, 4), (5, 200, 72, 4)])     # 4 x 4: queued, launched together at the flush
 def test_deferred_weight_gradients_of_a_shared_parameter_accumulate(N, Cin, Cout, S):
     """While gx_defer_enable(1) is in effect every conv3x3 weight-gradient call ADDS into its (zeroed) destination
     (include/genesis_hip.h): a weight used twice in one iteration -- a shared UNet -- ends with the SUM of both uses, also on
