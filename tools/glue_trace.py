@@ -7,7 +7,7 @@ import bench
 from genesis_amd.trainer import TrainStep
 from torch.profiler import profile, ProfilerActivity
 
-sys.argv = [sys.argv[0]]
+sys.argv = [sys.argv[0]] + sys.argv[1:]          # e.g. --model monet
 args = bench.parse()
 model = bench.build_model(args, 'cuda')
 ts = TrainStep(model, args.img, lr=1e-4, graph=False)
