@@ -14,6 +14,8 @@
 // decomposition of a thread is done once.  wgrad splits K over gridDim.z into partial slabs + a fixed-order reduce.
 #include "gx_common.h"
 
+#include <cstdlib>
+
 namespace {
 
 struct FastDiv {   // n / d for 0 <= n < 2^31 via one mul_hi (Granlund-Montgomery round-up)
@@ -195,6 +197,10 @@ igemm_kernel(const float* __restrict__ a_src, const float* __restrict__ b_src, c
             const int m = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
             if (m < g.M) {
                 float v = acc[j][reg];
+                if (MODE == 0 && gridDim.z > 1) {       // split contraction: raw slab z in the output's layout (igemm_reduce_act_kernel)
+                    out[(size_t)blockIdx.z * g.M * g.Ncols + obase + (size_t)m * mstride] = v;
+                    continue;
+                }
                 if (MODE == 0) {
                     if (bias) v += bias[m];
                     if (act == 1) v = v > 0.f ? v : 0.f;
@@ -214,6 +220,32 @@ igemm_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, 
     float s = partial[i];
     for (int z = 1; z < nsplit; ++z) s += partial[(size_t)z * total + i];
     out[i] = s;
+}
+
+// y[n][m][p] = act(sum_z partial[z][n][m][p] + bias[m]), fixed order (the forward conv with a split contraction)
+__global__ void __launch_bounds__(256)
+igemm_reduce_act_kernel(const float* __restrict__ partial, const float* __restrict__ bias, int act, float* __restrict__ out,
+                        int total, int nsplit, int M, int P) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    float s = partial[i];
+    for (int z = 1; z < nsplit; ++z) s += partial[(size_t)z * total + i];
+    if (bias) s += bias[(i / P) % M];
+    if (act == 1) s = s > 0.f ? s : 0.f;
+    else if (act == 2) s = s > 0.f ? s : expm1f(s);
+    out[i] = s;
+}
+// splits of the forward conv's contraction: only where the output tiles leave most of the chip idle (the ComponentVAE encoder's
+// last stride-2 layers, modules/encoders.py:31-34, at K*B = 224 images: 64 -> 64 from 8 x 8 is 28 tiles of 36 K-chunks = 62 us)
+int fwd_splits(const IG& g) {
+    static const char* env = getenv("GENESIS_DCONV_FWD_SPLIT");
+    if (env && env[0] == '0') return 1;
+    const int tiles = gx_ceil_div(g.Ncols, BN) * gx_ceil_div(g.M, BM), nchunks = gx_ceil_div(g.K, BK);
+    if (tiles >= 128 || nchunks < 8) return 1;
+    int ns = gx_ceil_div(256, tiles);
+    if (ns > nchunks / 4) ns = nchunks / 4;
+    if (ns > 16) ns = 16;
+    return ns < 1 ? 1 : ns;
 }
 
 int ig_geom(const char* name, IG* g, int mode, int N, int Cin, int Cout, int H, int W, int k, int stride, int pad) {
@@ -422,6 +454,41 @@ int gx_conv3x3s2_dgrad_small(const float* dy, const float* w, float* dx, int N, 
                                (size_t)Cout * 4 * 12 * 4, s, dy, w, dx, Cin, Cout, H, W, cin_n);
     }
     GX_CHECK_LAUNCH("gx_conv3x3s2_dgrad_small");
+    return GX_OK;
+}
+
+size_t gx_conv2d_direct_fwd_ws_bytes(int N, int Cin, int Cout, int H, int W, int k, int stride, int pad) {
+    IG g;
+    if (ig_geom("gx_conv2d_direct_fwd_ws_bytes", &g, 0, N, Cin, Cout, H, W, k, stride, pad)) return 0;
+    const int ns = fwd_splits(g);
+    return ns > 1 ? (size_t)ns * g.M * g.Ncols * sizeof(float) : 0;
+}
+
+int gx_conv2d_direct_fwd_ws(const float* x, const float* w, const float* bias, int act, float* y, int N, int Cin,
+                            int Cout, int H, int W, int k, int stride, int pad, void* ws, size_t ws_bytes,
+                            gx_stream_t stream) {
+    GX_CHECK_ARG(x && w && y && act >= 0 && act <= 2, "gx_conv2d_direct_fwd: null pointer / bad act");
+    IG g;
+    int rc = ig_geom("gx_conv2d_direct_fwd", &g, 0, N, Cin, Cout, H, W, k, stride, pad);
+    if (rc) return rc;
+    const int ns = fwd_splits(g);
+    if (ns <= 1 || !ws || ws_bytes < (size_t)ns * g.M * g.Ncols * sizeof(float))
+        return gx_conv2d_direct_fwd(x, w, bias, act, y, N, Cin, Cout, H, W, k, stride, pad, stream);
+    hipStream_t s = (hipStream_t)stream;
+    g.chunks_per_split = gx_ceil_div(gx_ceil_div(g.K, BK), ns);
+    {
+        GxProf pf(KID_DCONV, s, 2.0 * N * Cout * Cin * k * k * g.Ho * g.Wo, 4.0 * N * (Cin * H * W + Cout * g.Ho * g.Wo));
+        hipLaunchKernelGGL(igemm_kernel<0>, dim3(gx_ceil_div(g.Ncols, BN), gx_ceil_div(g.M, BM), ns), dim3(256), 0, s, w,
+                           x, (const float*)nullptr, 0, (float*)ws, g);
+    }
+    GX_CHECK_LAUNCH("gx_conv2d_direct_fwd(split)");
+    {
+        const int total = g.M * g.Ncols;
+        GxProf pf(KID_SMALL_REDUCE, s, 0.0, 4.0 * (ns + 1.0) * total);
+        hipLaunchKernelGGL(igemm_reduce_act_kernel, dim3(gx_ceil_div(total, 256)), dim3(256), 0, s, (const float*)ws, bias, act, y,
+                           total, ns, g.M, g.Ho * g.Wo);
+    }
+    GX_CHECK_LAUNCH("gx_conv2d_direct_fwd(reduce)");
     return GX_OK;
 }
 

@@ -587,8 +587,10 @@ def conv2d_direct_fwd(x, w, bias, act, stride, pad):
     Cout, _, k, _ = w.shape
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     y = torch.empty(N, Cout, Ho, Wo, dtype=F32, device=x.device)
-    _lib.call('gx_conv2d_direct_fwd', _p(x), _p(w), _p(bias), ACTS[act], _p(y), N, Cin, Cout, H, W, k, stride, pad,
-              _stream())
+    nb = _lib.query('gx_conv2d_direct_fwd_ws_bytes', N, Cin, Cout, H, W, k, stride, pad)
+    ws = _ws(nb, x.device) if nb else None          # (under-filled grids split the contraction: partial slabs)
+    _lib.call('gx_conv2d_direct_fwd_ws', _p(x), _p(w), _p(bias), ACTS[act], _p(y), N, Cin, Cout, H, W, k, stride, pad,
+              _p(ws), nb, _stream())
     return y
 
 

@@ -343,6 +343,13 @@ int gx_conv3x3s2_wgrad_small(const float* x, const float* dy, float* dw, int N, 
                              size_t ws_bytes, gx_stream_t stream);
 int gx_conv2d_direct_fwd(const float* x, const float* w, const float* bias, int act, float* y, int N, int Cin,
                          int Cout, int H, int W, int k, int stride, int pad, gx_stream_t stream);
+/*      ... with a workspace: layers whose output tiles leave most of the chip idle (the ComponentVAE encoder's last stride-2
+ *      convs, modules/encoders.py:31-34) split the contraction over workgroups and finish in a fixed-order reduce + bias +
+ *      activation launch; ws_bytes 0 (or a NULL ws) = the single-launch form above */
+size_t gx_conv2d_direct_fwd_ws_bytes(int N, int Cin, int Cout, int H, int W, int k, int stride, int pad);
+int gx_conv2d_direct_fwd_ws(const float* x, const float* w, const float* bias, int act, float* y, int N, int Cin,
+                            int Cout, int H, int W, int k, int stride, int pad, void* ws, size_t ws_bytes,
+                            gx_stream_t stream);
 int gx_conv2d_direct_dgrad(const float* dy, const float* w, float* dx, int N, int Cin, int Cout, int H, int W, int k,
                            int stride, int pad, gx_stream_t stream);
 size_t gx_conv2d_direct_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W, int k, int stride, int pad);
