@@ -427,8 +427,12 @@ template <int CLS, int WC> struct WrGeo {
     using WT = WqTap<CLS>;
     static constexpr int SA = WT::SA, NPB = WT::NPB, NT = WT::NT, NRO = WT::NRO, RO0 = WT::RO0;
     static constexpr int NCOV = WqCols<CLS>::NCOV, CS0 = WqCols<CLS>::CS0;
-    static constexpr int DMIN = RO0 - 1, DMAX = RO0 + NRO - 2;   // x rows r + DMIN .. r + DMAX feed tile r
-    static_assert(DMAX - DMIN + 2 <= 4, "the rows in use plus the one being fetched must fit the four ring slots");
+    // x rows r + DMIN .. r + DMAX feed tile r.  (Two image rows per tile, W == 16 below: tile rows are row PAIRS -- image rows
+    // 2 r + RO0 - 1 .. 2 r + 1 + RO0 + NRO - 2 lie in the pairs floor(. / 2); for the 3 x 3 / transposed-conv classes that is the
+    // same range as in single rows, for the 5 x 5 halves it is what makes them fit: rows 0-2 -> pairs -1 .. 0, rows 3-4 -> 0 .. 1)
+    static constexpr int fdiv2(int v) { return v >= 0 ? v / 2 : -((1 - v) / 2); }
+    static constexpr int DMIN = W == 16 ? fdiv2(RO0 - 1) : RO0 - 1, DMAX = W == 16 ? fdiv2(RO0 + NRO - 1) : RO0 + NRO - 2;
+    static_assert(DMAX - DMIN + 2 <= 4 && DMAX - DMIN + 1 <= NRO, "the rows in use plus the one being fetched must fit the four ring slots");
     // W = 16: TWO image rows per tile (R2) -- 16-pixel rows of one plane lie back to back in memory, so a pair of them is a
     // 32-pixel row to everything but (a) the dy addresses of the transposed conv (its two dy rows are two rows apart), (b) the
     // column shifts, which must not carry pixels across the seam: the A rows keep a zero piece between the two halves, and (c)
@@ -472,7 +476,7 @@ template <int CLS, int WC> struct WrGeo {
         return (((size_t)(ib >> LNS) * CB + cb0) * H + (size_t)rb) * PITCH + (ib & (NS - 1)) * WE;
     }
     // R2: unit (k-group g, tap row rr) reads k-group b_g of ring row index b_rr
-    __host__ __device__ static constexpr int b_e(int g, int rr) { return g + DMIN + rr; }
+    __host__ __device__ static constexpr int b_e(int g, int rr) { return g + RO0 - 1 + rr; }          // image-row offset from row 2 t
     __host__ __device__ static constexpr int b_so(int g, int rr) { return b_e(g, rr) >= 0 ? b_e(g, rr) / 2 : -((1 - b_e(g, rr)) / 2); }
     __host__ __device__ static constexpr int b_g(int g, int rr) { return R2 ? b_e(g, rr) - 2 * b_so(g, rr) : g; }
     __host__ __device__ static constexpr int b_rr(int g, int rr) { return R2 ? b_so(g, rr) - DMIN : rr; }
@@ -983,7 +987,7 @@ __device__ __forceinline__ void wr_segment(const float* a, const float* b, const
         const int r = t & (H - 1);
 #pragma unroll
         for (int rr = 0; rr < NRO; ++rr) {
-            const int dr = RO0 + rr - 1;                    // x row r + dr
+            const int dr = G::DMIN + rr;                    // x row (row pair) r + dr; entries past DMAX are never read
             bs[rr] = ((t + dr) & 3) * G::B_ROW;
             zr[rr] = (unsigned)(r + dr) >= (unsigned)H;
         }
@@ -1144,6 +1148,7 @@ wgq_stream_kernel(const WsTable tab, const float* __restrict__ zeros) {
             GX_WR_CASE(22, WQ_C5A, 64) GX_WR_CASE(23, WQ_C5A, 32) GX_WR_CASE(24, WQ_C5B, 64) GX_WR_CASE(25, WQ_C5B, 32)
             GX_WR_CASE(26, WQ_C3, 16) GX_WR_CASE(27, WQ_DR0, 16) GX_WR_CASE(28, WQ_DR1, 16)
             GX_WR_CASE(29, WQ_C3, 128) GX_WR_CASE(30, WQ_DR0, 64) GX_WR_CASE(31, WQ_DR1, 64)
+            GX_WR_CASE(32, WQ_C5A, 16) GX_WR_CASE(33, WQ_C5B, 16)
             // k-split forms (variant + 32 * HF, width code + 1000 * HF): HF 1 = A half empty, 2 = B half empty, 3 = both
             GX_WR_CASE(32 + 18, WQ_C3, 1064) GX_WR_CASE(32 + 19, WQ_C3, 1032) GX_WR_CASE(32 + 20, WQ_DR0, 1032) GX_WR_CASE(32 + 21, WQ_DR1, 1032)
             GX_WR_CASE(32 + 22, WQ_C5A, 1064) GX_WR_CASE(32 + 23, WQ_C5A, 1032) GX_WR_CASE(32 + 24, WQ_C5B, 1064) GX_WR_CASE(32 + 25, WQ_C5B, 1032)
@@ -1308,12 +1313,13 @@ bool wgq_stream_on() {
 // wgrad3:256:64 wgrad3:2048:16 wgrad3:8192:8 wgrad:256:32 wgrad:1024:16 wgrad:4096:8: 10.3 us per conv3x3 tile, 26.5 us per
 // pair of transposed-conv row-parity tiles, split 15 a + b : 10 a + b), then nudged on the training step itself
 // (the stream kernel's duration over five vectors: 921 .. 972 us); GENESIS_WGQ_COST="c0,...,c8" overrides
-int g_ws_cost[32] = {10200, 9580, 10680, 15080, 21000, 11800, 11400, 8800, 9700,              // bf16 pipe (measured with
+int g_ws_cost[34] = {10200, 9580, 10680, 15080, 21000, 11800, 11400, 8800, 9700,              // bf16 pipe (measured with
                      10200, 10600, 11200, 16000, 16500, 18200, 11600, 12000, 13300,           // GENESIS_WGQ_TIMES) | fp32 pipe
                      4840, 2450, 4150, 2900,                                                  // row-ring tiles (one base row)
                      8000, 4100, 5400, 2800,                                                  // ... of the 5 x 5 stride-1 conv
                      2450, 4150, 2900,                                                        // ... two 16-pixel rows per tile
-                     4900, 4200, 2950};                                                       // ... one strip (half a base row) per tile
+                     4900, 4200, 2950,                                                        // ... one strip (half a base row) per tile
+                     4100, 2800};                                                             // ... 5 x 5, two 16-pixel rows per tile
 // cost of a k-split tile relative to the full one, in percent, by base variant 18..25 (one or the other half) and for both
 // halves of variant 18 (measured with GENESIS_WGQ_TIMES on the GENESIS / BaselineVAE / MONet steps: the 32-pixel rows keep one
 // k-group per wave -- their tile starts with the operand reads the tail could not take); GENESIS_WGQ_KSPLIT_COST="9 values" overrides
@@ -1358,6 +1364,7 @@ int ws_ring_variant(int cls, int Hb, int Wb) {
     if (!wgq_b6() || !wgq_ring_on() || Hb < 4) return -1;          // (H a multiple of 4: the ring slot of a row is tile & 3)
     static const char* r2env = getenv("GENESIS_WGQ_RING16");       // 0: 16-pixel rows stay on the 64-pixel LDS-DMA tiles
     if (Wb == 16 && !(r2env && r2env[0] == '0') && Hb >= 8 && Hb % 8 == 0 && cls <= WQ_DR1) return 26 + cls;   // two image rows per tile
+    if (Wb == 16 && !(r2env && r2env[0] == '0') && Hb >= 8 && Hb % 8 == 0 && (cls == WQ_C5A || cls == WQ_C5B)) return cls == WQ_C5A ? 32 : 33;
     // rows too wide for the ring as two strips (the 128 x 128 model's large layers); GENESIS_WGQ_STRIPS=0: on the 64-pixel tiles
     static const char* stenv = getenv("GENESIS_WGQ_STRIPS");
     const bool strips = !(stenv && stenv[0] == '0');
@@ -1445,7 +1452,7 @@ int wgq_launch_stream(std::vector<PendingJob*>& jobs, hipStream_t s, std::vector
                     jb.variant = q.cls * 3 + (5 - q.ltw) + (wgq_b6() ? 0 : 9);
                     const int rv = ws_ring_variant(q.cls, q.job.Hb, q.job.Wb);
                     // tile = one base row (26..28: two; 29..31: one of its two strips)
-                    if (rv >= 0) { jb.variant = rv; jb.ntiles = rv >= 29 ? q.job.N * q.job.Hb * 2 : q.job.N * q.job.Hb / (rv >= 26 ? 2 : 1); }
+                    if (rv >= 0) { jb.variant = rv; jb.ntiles = (rv >= 29 && rv <= 31) ? q.job.N * q.job.Hb * 2 : q.job.N * q.job.Hb / (rv >= 26 ? 2 : 1); }
                     else if (q.cls >= WQ_C5A) { gx_set_error("wgq: the 5x5 classes exist as row-ring tiles only"); return GX_EINVAL; }
                     jb.cost = g_ws_cost[jb.variant];
                     if (rv >= 0) {
