@@ -581,7 +581,7 @@ __device__ __forceinline__ void pack_h_store(const float* __restrict__ w, float*
     for (int q = 0; q < 3; ++q) {
         wd[q] = (unsigned)pc[0][q] | ((unsigned)pc[1][q] << 16);
         const size_t dst = pack <= 21 ? gx_kq_h32_word(m, k, t, q, NT, Kpad)       // 20 / 21: conv3x3, 32-channel tiles
-                           : (pack >= 25 ? gx_wino_h_word(m, k, t, q, Kpad)        // 25 / 26: Winograd operands (= 5 / 6), t = position
+                           : ((pack == 25 || pack == 26) ? gx_wino_h_word(m, k, t, q, Kpad)        // 25 / 26: Winograd operands (= 5 / 6), t = position; 27 / 28: 5 x 5 stride 1 (= 7 / 8)
                                          : gx_kq_h_word(m, k, pack == 24 ? gx_kq_dg_tap_slot(t) : t, q, NT, Kpad));
         wp[dst] = __builtin_bit_cast(float, wd[q]);
     }
@@ -2522,7 +2522,9 @@ size_t gx_conv5x5s1_ws_bytes(int N, int K, int M, int H, int W) {
     size_t part = 0;
     if (plan_tapconv<M_C5>(N, K, M, gx_round_up(M, 64), H, W, H, W, H, W, 0, &pl, "ws") == GX_OK && pl.g.nsplit > 1)
         part = pl.g.nsplit * pl.out_elems;
-    return ((size_t)25 * gx_round_up(K, 8) * gx_round_up(M, 64) + part) * sizeof(float);
+    size_t b = ((size_t)25 * gx_round_up(K, 8) * gx_round_up(M, 64) + part) * sizeof(float);
+    const size_t bh = gx_kq_deconv_h_pack_bytes(gx_round_up(K, 16), gx_round_up(M, 64), 25);     // the bf16-pipe packing (kinds 27 / 28)
+    return b > bh ? b : bh;
 }
 
 int gx_conv5x5s1_supported(int N, int K, int M, int H, int W) {
@@ -2544,6 +2546,12 @@ int gx_conv5x5s1(const float* in, const float* w, float* out, int N, int K, int 
     float* wp = (float*)ws;
     float* part = wp + (size_t)25 * Kpad * Mpad;
     const float* wpu;
+    if (gx_kq_c5h_eligible(N, K, M, H, W)) {       // chip-filling layers: on the bf16 matrix pipe (gx_kq.hip Q_C5H)
+        rc = flip ? launch_pack(w, wp, 28, K, M, 25, gx_round_up(K, 16), Mpad, s, &wpu)
+                  : launch_pack(w, wp, 27, M, K, 25, gx_round_up(K, 16), Mpad, s, &wpu);
+        if (rc) return rc;
+        return gx_kq_c5h_launch(in, wpu, out, N, K, M, H, W, s);
+    }
     // pack 7: w [M][K]; pack 8: w [K][M] flipped (launch_pack's (Co, Ci) are the weight tensor's leading dimensions)
     rc = flip ? launch_pack(w, wp, 8, K, M, 25, Kpad, Mpad, s, &wpu) : launch_pack(w, wp, 7, M, K, 25, Kpad, Mpad, s, &wpu);
     if (rc) return rc;

@@ -40,7 +40,7 @@
 
 namespace {
 
-enum { Q_C3 = 0, Q_DT0 = 1, Q_DT1 = 2, Q_DG = 3, Q_DT0H = 4, Q_DT1H = 5, Q_DGH = 6, Q_C3H = 7 };     // ..H: on the bf16 matrix pipe (q_body's B16 path)
+enum { Q_C3 = 0, Q_DT0 = 1, Q_DT1 = 2, Q_DG = 3, Q_DT0H = 4, Q_DT1H = 5, Q_DGH = 6, Q_C3H = 7, Q_C5H = 8 };     // ..H: on the bf16 matrix pipe (q_body's B16 path)
 
 template <int MODE> struct QCfg;
 template <> struct QCfg<Q_C3> {
@@ -132,6 +132,20 @@ template <> struct QCfg<Q_C3H> {
     __host__ __device__ static constexpr int tbase(int ph) { return 3 * ph; }
     __host__ __device__ static constexpr int ro(int ph, int) { return ph; }
     __host__ __device__ static constexpr int co(int, int j) { return j; }
+    __host__ __device__ static constexpr int cls(int, int) { return 0; }
+    __host__ __device__ static constexpr int plane(int) { return 0; }
+    __host__ __device__ static constexpr bool newin(int ph) { return ph + 1 == NPH; }
+};
+// 5 x 5 stride-1 pad-2 conv there (the gated stacks of third_party/sylvester, VAE.py:18-33: forward and data gradient are the
+// two weight packings 27 / 28 of one kernel): a 2-pixel halo, one phase per (kernel row, taps {0,1,2} | {3,4}) = 10 phases of
+// a 16-channel chunk on one input tile; 64-channel workgroups like the transposed convs
+template <> struct QCfg<Q_C5H> {
+    static constexpr int NPH = 10, NT = 25, MAXT = 3, NCLS = 1;
+    static constexpr bool PLANE_PER_PHASE = false;
+    __host__ __device__ static constexpr int ntaps(int ph) { return (ph & 1) ? 2 : 3; }
+    __host__ __device__ static constexpr int tbase(int ph) { return 5 * (ph >> 1) + 3 * (ph & 1); }
+    __host__ __device__ static constexpr int ro(int ph, int) { return ph >> 1; }
+    __host__ __device__ static constexpr int co(int ph, int j) { return 3 * (ph & 1) + j; }
     __host__ __device__ static constexpr int cls(int, int) { return 0; }
     __host__ __device__ static constexpr int plane(int) { return 0; }
     __host__ __device__ static constexpr bool newin(int ph) { return ph + 1 == NPH; }
@@ -266,8 +280,9 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
     // pixel slots >= rt_th * rt_tw of the 256 are idle
     const bool RT = MODE == Q_C3H && g.rt_tw > 0;
     const int TH = RT ? g.rt_th : 1 << g.lTH, TW = RT ? g.rt_tw : 1 << g.lTW, G = RT ? 1 : 1 << g.lG;
-    const int HS = TW + 2;
-    const int CHS = G * (TH + 2) * HS;                 // halo positions per plane
+    constexpr int HL = MODE == Q_C5H ? 2 : 1;          // halo pixels on every side
+    const int HS = TW + 2 * HL;
+    const int CHS = G * (TH + 2 * HL) * HS;            // halo positions per plane
     float* const ibuf0 = lds;
     float* const wbuf0 = lds + 2 * ISLOT;
 
@@ -295,12 +310,12 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
         const int quad = slot >= CHS ? 1 : 0;
         int rem = slot - quad * CHS;
         bool ok = slot < 2 * CHS;
-        const int gi = rem / ((TH + 2) * HS); rem -= gi * (TH + 2) * HS;
+        const int gi = rem / ((TH + 2 * HL) * HS); rem -= gi * (TH + 2 * HL) * HS;
         const int i = rem / HS;
         const int j = rem - i * HS;
         int row, col;
         if (MODE == Q_DG || MODE == Q_DGH) { row = 2 * (R0 + i) - 2; col = 2 * (C0 + j) - 2; }
-        else { row = R0 - 1 + i; col = C0 - 1 + j; }
+        else { row = R0 - HL + i; col = C0 - HL + j; }
         ok = ok && img0 + gi < g.N && row >= 0 && row < g.Hi && col >= 0 && col < g.Wi;
         voff[q] = ok ? (((img0 + gi) * g.K + quad * (B16 ? 8 : 4)) * HiWi + row * g.Wi + col) * 4 : (int)0x80000000;
     }
@@ -337,7 +352,7 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
             int r = (p >> g.lTW) & (TH - 1);
             int gi = p >> (g.lTW + g.lTH);
             if (RT) { gi = 0; r = p / TW; c = p - r * TW; if (r >= TH) { r = 0; c = 0; } }      // (idle slots read position 0)
-            b_lane_b[nj] = (quad_l * CHS + (gi * (TH + 2) + r) * HS + c) * 16;
+            b_lane_b[nj] = (quad_l * CHS + (gi * (TH + 2 * HL) + r) * HS + c) * 16;
         }
         const int HS16 = HS * 16;
         const int nsc = g.K / 16;
@@ -441,7 +456,7 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
         const int c = p & (TW - 1);
         const int r = (p >> g.lTW) & (TH - 1);
         const int gi = p >> (g.lTW + g.lTH);
-        b_lane[nj] = (quad_l * CHS + (gi * (TH + 2) + r) * HS + c) * 4;
+        b_lane[nj] = (quad_l * CHS + (gi * (TH + 2 * HL) + r) * HS + c) * 4;
     }
     const int HS4 = HS * 4;
 
@@ -749,6 +764,14 @@ kq_c3h_kernel(const float* __restrict__ in, const float* __restrict__ wp, const 
     }
 }
 
+// 5 x 5 stride-1 conv on the bf16 pipe: 16 x 16-pixel tiles (20 x 20 halo positions: four staging rounds, exact LDS planes)
+template <int NQ>
+__global__ void __launch_bounds__(256, 2)
+kq_c5h_kernel(const float* __restrict__ in, const float* __restrict__ wp, float* __restrict__ out, QGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    q_body<Q_C5H, NQ, false, 2>(in, wp, nullptr, out, g, lds, blockIdx.x, blockIdx.y, 0);
+}
+
 // the same launch shape on the bf16 matrix pipe (Q_DT0H / Q_DT1H)
 template <int NQ, bool STATS>
 __global__ void __launch_bounds__(256, 2)
@@ -993,6 +1016,40 @@ int gx_kq_c3h_launch(const float* in, const float* wp, const float* bias, int ac
         else { q_set_attr(&kq_c3h_kernel<4>, &a4); hipLaunchKernelGGL((kq_c3h_kernel<4>), grid, dim3(256), lds, s, in, wp, bias, out, g); }
     }
     GX_CHECK_LAUNCH("kq conv3x3 (bf16 pipe)");
+    return GX_OK;
+}
+
+// ---- 5 x 5 stride-1 conv on the bf16 pipe (pack kinds 27 / 28)
+static bool q_plan_c5h(int N, int K, int M, int H, int W, QGeom* g, size_t* lds_bytes) {
+    if (K % 16 != 0 || H % 16 != 0 || W % 16 != 0 || H * W > 65536 || (double)N * K * H * W * 4.0 >= 2.0e9) return false;
+    g->N = N; g->K = K; g->M = M; g->nchunks = K / 8;
+    g->Hb = H; g->Wb = W; g->Hi = H; g->Wi = W; g->Ho = H; g->Wo = W;
+    g->lTH = 4; g->lTW = 4; g->lG = 0;
+    g->tiles_h = H / 16; g->tiles_w = W / 16;
+    g->rt_th = g->rt_tw = 0; g->act = 0; g->stats = nullptr; g->stats_parts = 0;
+    g->nfull = g->tiles_h * g->tiles_w * N;
+    constexpr int NWH = (3 * (QH_TAP_BYTES / 16) + 255) / 256;
+    *lds_bytes = (size_t)3 * 2 * (20 * 20) * 16 + (size_t)2 * NWH * 256 * 16;       // exact input planes + two weight buffers
+    return *lds_bytes <= 80 * 1024;
+}
+bool gx_kq_c5h_eligible(int N, int K, int M, int H, int W) {
+    static const char* env = getenv("GENESIS_KQ_C5H");
+    if ((env && env[0] == '0') || !kq_h_on() || kq_mode() == 0) return false;
+    QGeom g; size_t lds;
+    if (!q_plan_c5h(N, K, M, H, W, &g, &lds)) return false;
+    return kq_mode() == 2 || (long)g.nfull * gx_ceil_div(M, 64) >= 192;
+}
+int gx_kq_c5h_launch(const float* in, const float* wp, float* out, int N, int K, int M, int H, int W, hipStream_t s) {
+    QGeom g; size_t lds;
+    if (!q_plan_c5h(N, K, M, H, W, &g, &lds)) { gx_set_error("kq conv5x5 (bf16 pipe): shape not eligible"); return GX_EINVAL; }
+    dim3 grid(g.nfull, gx_ceil_div(M, 64));
+    {
+        GxProf pf(KID_DCONV, s, 2.0 * N * (double)M * K * 25 * H * W, 4.0 * ((double)N * K * H * W + (double)N * M * H * W + 25.0 * K * M));
+        static bool a4 = false;
+        q_set_attr(&kq_c5h_kernel<4>, &a4);
+        hipLaunchKernelGGL((kq_c5h_kernel<4>), grid, dim3(256), lds, s, in, wp, out, g);
+    }
+    GX_CHECK_LAUNCH("kq conv5x5 (bf16 pipe)");
     return GX_OK;
 }
 

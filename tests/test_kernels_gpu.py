@@ -1195,7 +1195,9 @@ def _conv5x5_wgrad_case(hip, N, CA, CB, S):
     assert err < 2e-6 and err_t < 2e-6, (err, err_t)
 
 
-@pytest.mark.parametrize('N,K,M,S', [(3, 32, 64, 64), (5, 64, 128, 32), (2, 3, 64, 64), (4, 40, 24, 16), (33, 64, 64, 16), (1, 32, 64, 8)])
+@pytest.mark.parametrize('N,K,M,S', [(3, 32, 64, 64), (5, 64, 128, 32), (2, 3, 64, 64), (4, 40, 24, 16), (33, 64, 64, 16), (1, 32, 64, 8),
+                                     # chip-filling grids with K % 16 == 0: the bf16-pipe kernel (gx_kq.hip Q_C5H, six piece products)
+                                     (16, 32, 64, 64), (52, 64, 128, 32), (200, 64, 64, 16), (16, 32, 72, 64), (13, 48, 64, 64)])
 def test_conv5x5_stride1_on_the_tapconv_kernel(N, K, M, S):
     """gx_conv5x5s1 (tap-conv MFMA kernel, 25-tap table, 2-pixel halo): both weight roles against fp64 torch --
     flip 0 = F.conv2d(x, w [M,K,5,5], padding=2); flip 1 = F.conv_transpose2d(x, w [K,M,5,5], stride 1, padding 2)."""
