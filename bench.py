@@ -107,7 +107,7 @@ def pmc_traffic(kernel, tag=''):
 
 # profiling ids (gx_profile_kernel_name) -> kernel symbols of the rocprofv3 CSV that are launched under that id
 KID_SYMBOLS = {
-    'wgq_stream_kernel': ('wgq_stream_kernel',), 'kq_dth_kernel': ('kq_dth_kernel',), 'kq_dgh_kernel': ('kq_dgh_kernel',), 'kq_c3h_kernel': ('kq_c3h_kernel',),
+    'wgq_stream_kernel': ('wgq_stream_kernel',), 'kq_dth_kernel': ('kq_dth_kernel',), 'kq_dgh_kernel': ('kq_dgh_kernel',), 'kq_c3h_kernel': ('kq_c3h_kernel',), 'kq_c5h_kernel': ('kq_c5h_kernel',),
     'wgrad_kernel<0>': ('wgq_kernel<0,', 'wgrad_fast_kernel<0,', 'wgrad_kernel<0>', 'wgrad_smallcin_kernel'),
     'dconv_kernels': ('tapconv_kernel<4,', 'igemm_kernel<', 'conv3x3s2_dgrad_small_kernel', 'conv3x3s2_wgrad_small_kernel'),
     'gated_norm_kernels': ('gated_',),
@@ -382,7 +382,7 @@ def main():
                 roof = {'bound': 'mfma', 'kernel': dom['name'], 'achieved': ach, 'peak': mfma_peak, 'unit': 'TFLOP/s'}
                 wino_b6 = dom['name'] == 'wino_conv_kernel' and os.environ.get('GENESIS_WINO_BF16X6', '1') != '0'
                 on_bf16 = wino_b6 or (dom['name'] == 'wgq_stream_kernel' and os.environ.get('GENESIS_WGQ_BF16X6', '1') != '0') or \
-                          (dom['name'] in ('kq_dth_kernel', 'kq_dgh_kernel', 'kq_c3h_kernel') and os.environ.get('GENESIS_KQ_BF16X6', '1') != '0')
+                          (dom['name'] in ('kq_dth_kernel', 'kq_dgh_kernel', 'kq_c3h_kernel', 'kq_c5h_kernel') and os.environ.get('GENESIS_KQ_BF16X6', '1') != '0')
                 if on_bf16:
                     # `achieved` counts the algorithmic fp32 flops; the kernel executes six bf16 MFMA products for each of
                     # them, so its ceiling is the bf16 pipe's dense peak / 6 -- a higher one than the fp32 pipe's 157.3 TF/s

@@ -39,7 +39,7 @@ const char* const kKernelNames[KID_COUNT] = {
     "icsbp_fwd_kernel", "icsbp_bwd_kernel", "maskpool_fwd_kernel", "maskpool_bwd_kernel",
     "mixture_kernel<false>", "mixture_kernel<true>", "conv1x1_fwd_kernel", "conv1x1_dgrad_kernel",
     "conv1x1_wgrad_kernel", "small_reduce_kernels", "adam_kernel", "geco_update_kernel", "splitk_reduce_kernel", "bias_act_bwd_kernel", "dconv_kernels", "gated_norm_kernels", "latent_kernels", "dense_kernel", "wino_conv_kernel",
-    "wgq_stream_kernel", "kq_dth_kernel", "kq_dgh_kernel", "kq_c3h_kernel"};
+    "wgq_stream_kernel", "kq_dth_kernel", "kq_dgh_kernel", "kq_c3h_kernel", "kq_c5h_kernel"};
 }  // namespace
 
 void gx_prof_begin(int kid, hipStream_t s, double flops, double bytes) {

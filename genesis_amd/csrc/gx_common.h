@@ -33,7 +33,7 @@ enum GxKernelId {
     KID_GN_FWD, KID_GN_BWD, KID_GN_PARAM_REDUCE, KID_ICSBP_FWD, KID_ICSBP_BWD, KID_MASKPOOL_FWD,
     KID_MASKPOOL_BWD, KID_MIXTURE_FWD, KID_MIXTURE_BWD, KID_CONV1X1_FWD, KID_CONV1X1_DGRAD,
     KID_CONV1X1_WGRAD, KID_SMALL_REDUCE, KID_ADAM, KID_GECO, KID_SPLITK_REDUCE, KID_BIAS_ACT_BWD, KID_DCONV, KID_GATED, KID_LATENT, KID_DENSE, KID_WINO,
-    KID_WGQ_STREAM, KID_KQ_DTH, KID_KQ_DGH, KID_KQ_C3H, KID_COUNT
+    KID_WGQ_STREAM, KID_KQ_DTH, KID_KQ_DGH, KID_KQ_C3H, KID_KQ_C5H, KID_COUNT
 };
 // ---- contexts: every piece of mutable library state that outlives a call (deferred-reduction queues, queued
 // weight-gradient jobs, the packed-weight cache a step is recording / served from, the per-kernel profiling records)

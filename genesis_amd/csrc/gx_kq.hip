@@ -1044,7 +1044,7 @@ int gx_kq_c5h_launch(const float* in, const float* wp, float* out, int N, int K,
     if (!q_plan_c5h(N, K, M, H, W, &g, &lds)) { gx_set_error("kq conv5x5 (bf16 pipe): shape not eligible"); return GX_EINVAL; }
     dim3 grid(g.nfull, gx_ceil_div(M, 64));
     {
-        GxProf pf(KID_DCONV, s, 2.0 * N * (double)M * K * 25 * H * W, 4.0 * ((double)N * K * H * W + (double)N * M * H * W + 25.0 * K * M));
+        GxProf pf(KID_KQ_C5H, s, 2.0 * N * (double)M * K * 25 * H * W, 4.0 * ((double)N * K * H * W + (double)N * M * H * W + 25.0 * K * M));
         static bool a4 = false;
         q_set_attr(&kq_c5h_kernel<4>, &a4);
         hipLaunchKernelGGL((kq_c5h_kernel<4>), grid, dim3(256), lds, s, in, wp, out, g);
