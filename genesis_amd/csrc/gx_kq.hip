@@ -1037,7 +1037,8 @@ bool gx_kq_c5h_eligible(int N, int K, int M, int H, int W) {
     if ((env && env[0] == '0') || !kq_h_on() || kq_mode() == 0) return false;
     QGeom g; size_t lds;
     if (!q_plan_c5h(N, K, M, H, W, &g, &lds)) return false;
-    return kq_mode() == 2 || (long)g.nfull * gx_ceil_div(M, 64) >= 192;
+    static const int min_wgs = [] { const char* e = getenv("GENESIS_KQ_C5H_MIN_WGS"); return e ? atoi(e) : 192; }();
+    return kq_mode() == 2 || (long)g.nfull * gx_ceil_div(M, 64) >= min_wgs;
 }
 int gx_kq_c5h_launch(const float* in, const float* wp, float* out, int N, int K, int M, int H, int W, hipStream_t s) {
     QGeom g; size_t lds;
