@@ -177,9 +177,10 @@ __host__ __device__ __forceinline__ size_t gx_kq_h32_word(int m, int k, int t, i
 }
 bool gx_kq_c3h_eligible(int N, int K, int M, int H, int W);
 int gx_kq_c3h_launch(const float* in, const float* wp, const float* bias, int act, float* out, int N, int K, int M, int H,
-                     int W, hipStream_t s);
+                     int W, hipStream_t s, const float* mask = nullptr, int mask_act = 0);
 // 5 x 5 stride-1 conv on the bf16 pipe (pack kinds 27 / 28 = the bf16-piece forms of 7 / 8; K a multiple of 16, H and W of 16)
 bool gx_kq_c5h_eligible(int N, int K, int M, int H, int W);
+int gx_chan_sums_launch(const float* x, int N, int C, int HW, float* part, float* out, hipStream_t s);   // gx_misc.hip
 int gx_kq_c5h_launch(const float* in, const float* wp, float* out, int N, int K, int M, int H, int W, hipStream_t s);
 __host__ __device__ __forceinline__ size_t gx_kq_h_word(int m, int k, int t, int piece, int NT, int K) {
     return ((((size_t)(m >> 6) * (K >> 4) + (k >> 4)) * NT + t) * 3 + piece) * 512 + (((k >> 3) & 1) * 64 + (m & 63)) * 4 + ((k & 7) >> 1);

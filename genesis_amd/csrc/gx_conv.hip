@@ -2397,6 +2397,36 @@ static int conv3x3_dgrad_impl(const float* dy, const float* w, float* dx, int N,
     return GX_OK;
 }
 
+/* The data gradient of a conv3x3 whose INPUT is a bias + activation layer's output xout: the activation's backward in the
+ * epilogue of the bf16-pipe kernel (one more read of xout there instead of a pass that reads da and xout and writes dxa),
+ * then the bias gradient as channel sums of dxa. */
+int gx_conv3x3_dgrad_act_supported(int N, int Cin, int Cout, int H, int W) {
+    static const char* env = getenv("GENESIS_DGRAD_ACT_FUSE");
+    if (env && env[0] == '0') return 0;
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
+    return gx_kq_c3h_eligible(N, Cout, Cin, H, W) ? 1 : 0;
+}
+size_t gx_conv3x3_dgrad_act_ws_bytes(int N, int Cin, int Cout, int H, int W) {
+    return gx_round_up((long)gx_conv3x3_ws_bytes(N, Cin, Cout, H, W), 256) + (size_t)N * Cin * sizeof(float);
+}
+int gx_conv3x3_dgrad_act(const float* dy, const float* w, const float* xout, int act, float* dxa, float* dbias, int N,
+                         int Cin, int Cout, int H, int W, void* ws, size_t ws_bytes, gx_stream_t stream) {
+    int rc = check_dims("gx_conv3x3_dgrad_act", N, Cin, Cout, H, W);
+    if (rc) return rc;
+    GX_CHECK_ARG(dy && w && xout && dxa && ws, "gx_conv3x3_dgrad_act: null pointer");
+    GX_CHECK_ARG(act >= 0 && act <= 2, "gx_conv3x3_dgrad_act: bad act");
+    GX_CHECK_ARG(ws_bytes >= gx_conv3x3_dgrad_act_ws_bytes(N, Cin, Cout, H, W), "gx_conv3x3_dgrad_act: workspace too small");
+    GX_CHECK_ARG(gx_conv3x3_dgrad_act_supported(N, Cin, Cout, H, W), "gx_conv3x3_dgrad_act: shape not supported (gx_conv3x3_dgrad_act_supported)");
+    hipStream_t s = (hipStream_t)stream;
+    const float* wpu;
+    rc = launch_pack(w, (float*)ws, 21, Cout, Cin, 9, gx_round_up(Cout, 16), gx_round_up(Cin, 64), s, &wpu);
+    if (rc) return rc;
+    rc = gx_kq_c3h_launch(dy, wpu, nullptr, 0, dxa, N, Cout, Cin, H, W, s, xout, act);
+    if (rc || !dbias) return rc;
+    float* part = (float*)((char*)ws + gx_round_up((long)gx_conv3x3_ws_bytes(N, Cin, Cout, H, W), 256));
+    return gx_chan_sums_launch(dxa, N, Cin, H * W, part, dbias, s);
+}
+
 size_t gx_conv3x3_wgrad_ws_bytes(int N, int Cin, int Cout, int H, int W) {
     WgradPlan pl;
     plan_wgrad(N, Cout, Cin, H, W, 1, 9, 1, &pl);

@@ -207,12 +207,18 @@ struct QGeom {
     int nfull;            // blockIdx.x < nfull: whole tiles; the rest: pairs of half-work workgroups (q_split_tail)
     float* stats;         // STATS: per-workgroup (sum, sum of squares) of every 8-channel block, [N][parts][M/8][2]
     int stats_parts;
+    const float* mask;    // Q_C3H as a data gradient: out *= act'(mask) -- mask = the producing layer's activation OUTPUT, laid
+    int mask_act;         // out like `out` (the backward of a bias + ReLU / ELU layer without its own pass: gx_conv3x3_dgrad_act)
 };
 
 __device__ __forceinline__ float q_act(float v, int act) {
     if (act == 1) return v > 0.f ? v : 0.f;
     if (act == 2) return v > 0.f ? v : expm1f(v);
     return v;
+}
+__device__ __forceinline__ float q_dact(float o, int act) {      // act'(.) from the activation's OUTPUT (gx_misc.hip act_bwd_from_out)
+    const float neg = act == 2 ? o + 1.f : (act == 1 ? 0.f : 1.f);          // selects, no branches: 32 of these per lane and tile
+    return o > 0.f ? 1.f : neg;
 }
 
 // one phase: the taps of phase PH out of the input tile `ib` and the weight slice `wb`; the operands of tap i + 1 are
@@ -573,20 +579,48 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
     if (RT) {
         // row tiles: pixel slot p = row r, column c of the tile's rt_th rows; consecutive lanes = consecutive floats of a plane
         if constexpr (NCLS == 1) {
+            size_t ooff[2];
+            bool pok[2];
 #pragma unroll
             for (int nj = 0; nj < 2; ++nj) {
                 const int p = wave * 64 + nj * 32 + (lane & 31);
                 const int r = p / TW, c = p - r * TW;
-                if (r < TH && R0 + r < g.Hb) {
-                    float* obase = out + (size_t)img0 * out_img_stride + (size_t)(R0 + r) * g.Wo + c +
-                                   (size_t)(m0 + mh * 32 + 4 * (lane >> 5)) * HoWo;
+                pok[nj] = r < TH && R0 + r < g.Hb;
+                ooff[nj] = (size_t)img0 * out_img_stride + (size_t)(R0 + r) * g.Wo + c + (size_t)(m0 + mh * 32 + 4 * (lane >> 5)) * HoWo;
+            }
+            // Q_C3H as the data gradient behind a bias + activation layer: act'(that layer's output) for the 16 values of a
+            // pixel in one round of loads ahead of its stores -- unconditional (a guarded load is load - wait - branch, 16 times
+            // over: the address is clamped instead) and before any store (the compiler cannot prove the mask does not alias
+            // out).  (All 32 of both pixels in one round: 120 B more scratch in this 168-register kernel.)
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj) {
+                float mk[MI][16];
+                if (MODE == Q_C3H && g.mask) {
+                    const float* mbase = g.mask + (pok[nj] ? ooff[nj] : (size_t)0);
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                         for (int reg = 0; reg < 16; ++reg) {
                             const int mrow = mi * 32 + (reg & 3) + 8 * (reg >> 2);
-                            if (m0 + mh * 32 + 4 * (lane >> 5) + mrow < g.M)
-                                obase[(size_t)mrow * HoWo] = q_act(acc[0][mi][nj][reg] + bvec[mi][reg >> 2][reg & 3], act);
+                            mk[mi][reg] = mbase[pok[nj] && m0 + mh * 32 + 4 * (lane >> 5) + mrow < g.M ? (size_t)mrow * HoWo : (size_t)0];
+                        }
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) mk[mi][reg] = q_dact(mk[mi][reg], g.mask_act);
+                }
+                if (pok[nj]) {
+                    float* obase = out + ooff[nj];
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            const int mrow = mi * 32 + (reg & 3) + 8 * (reg >> 2);
+                            if (m0 + mh * 32 + 4 * (lane >> 5) + mrow < g.M) {
+                                float v = q_act(acc[0][mi][nj][reg] + bvec[mi][reg >> 2][reg & 3], act);
+                                if (MODE == Q_C3H && g.mask) v *= mk[mi][reg];
+                                obase[(size_t)mrow * HoWo] = v;
+                            }
                         }
                 }
             }
@@ -603,6 +637,19 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
             else { orow = R0 + r; ocol = C0 + c; }
             float* obase = out + (size_t)n * out_img_stride + (size_t)orow * g.Wo + ocol +
                            (size_t)(m0 + mh * 32 + 4 * (lane >> 5)) * HoWo;
+            float mk[MI][16];
+            if (MODE == Q_C3H && g.mask) {
+                const float* mbase = g.mask + (obase - out);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg)
+                        mk[mi][reg] = mbase[(size_t)(mi * 32 + (reg & 3) + 8 * (reg >> 2)) * HoWo];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) mk[mi][reg] = q_dact(mk[mi][reg], g.mask_act);
+            }
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -615,7 +662,9 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
                         v.y = q_act(acc[NCLS - 1][mi][nj][reg] + bv, act);
                         *reinterpret_cast<float2*>(o) = v;
                     } else {
-                        *o = q_act(acc[0][mi][nj][reg] + bv, act);
+                        float v = q_act(acc[0][mi][nj][reg] + bv, act);
+                        if (MODE == Q_C3H && g.mask) v *= mk[mi][reg];
+                        *o = v;
                     }
                 }
             }
@@ -633,6 +682,21 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
         if (NCLS == 2) { orow = 2 * (R0 + r) + par_a; ocol = 2 * (C0 + c); }
         else { orow = R0 + r; ocol = C0 + c; }
         float* obase = out + (size_t)n * out_img_stride + (size_t)orow * g.Wo + ocol;
+        float mk[MI][16];
+        if (MODE == Q_C3H && g.mask) {
+            const float* mbase = g.mask + (obase - out);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int m = m0 + (mi + mh) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                    mk[mi][reg] = mbase[m < g.M ? (size_t)m * HoWo : (size_t)0];
+                }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) mk[mi][reg] = q_dact(mk[mi][reg], g.mask_act);
+        }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -646,7 +710,9 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
                         v.y = q_act(acc[NCLS - 1][mi][nj][reg] + bv, act);
                         *reinterpret_cast<float2*>(obase + (size_t)m * HoWo) = v;
                     } else {
-                        obase[(size_t)m * HoWo] = q_act(acc[0][mi][nj][reg] + bv, act);
+                        float v = q_act(acc[0][mi][nj][reg] + bv, act);
+                        if (MODE == Q_C3H && g.mask) v *= mk[mi][reg];
+                        obase[(size_t)m * HoWo] = v;
                     }
                 }
             }
@@ -802,7 +868,7 @@ bool q_plan(int N, int K, int M, int Hb, int Wb, int Hi, int Wi, int Ho, int Wo,
     g->Hb = Hb; g->Wb = Wb; g->Hi = Hi; g->Wi = Wi; g->Ho = Ho; g->Wo = Wo;
     g->lTH = q_ilog2(TH); g->lTW = q_ilog2(TW); g->lG = q_ilog2(G);
     g->tiles_h = Hb / TH; g->tiles_w = Wb / TW;
-    g->act = 0; g->stats = nullptr; g->stats_parts = 0; g->rt_th = g->rt_tw = 0;
+    g->act = 0; g->stats = nullptr; g->stats_parts = 0; g->rt_th = g->rt_tw = 0; g->mask = nullptr; g->mask_act = 0;
     const int CHS = G * (TH + 2) * (TW + 2);
     if (2 * CHS > 4 * 256) return false;
     *nq = 2 * CHS <= 3 * 256 ? 3 : 4;
@@ -983,7 +1049,7 @@ static bool q_plan_c3h(int N, int K, int M, int H, int W, QGeom* g, int* nq, siz
     g->Hb = H; g->Wb = W; g->Hi = H; g->Wi = W; g->Ho = H; g->Wo = W;
     g->lTH = q_ilog2(TH); g->lTW = q_ilog2(TW); g->lG = q_ilog2(G);
     g->tiles_h = gx_ceil_div(H, TH); g->tiles_w = W / TW;
-    g->act = 0; g->stats = nullptr; g->stats_parts = 0; g->nfull = 0;
+    g->act = 0; g->stats = nullptr; g->stats_parts = 0; g->nfull = 0; g->mask = nullptr; g->mask_act = 0;
     const int CHS = G * (TH + 2) * (TW + 2);
     if (2 * CHS > 4 * 256) return false;
     *nq = 2 * CHS <= 3 * 256 ? 3 : 4;
@@ -999,10 +1065,10 @@ bool gx_kq_c3h_eligible(int N, int K, int M, int H, int W) {
     return kq_mode() == 2 || (long)g.tiles_h * g.tiles_w * gx_ceil_div(N, 1 << g.lG) * gx_ceil_div(M, 32) >= 512;
 }
 int gx_kq_c3h_launch(const float* in, const float* wp, const float* bias, int act, float* out, int N, int K, int M, int H,
-                     int W, hipStream_t s) {
+                     int W, hipStream_t s, const float* mask, int mask_act) {
     QGeom g; int nq; size_t lds;
     if (!q_plan_c3h(N, K, M, H, W, &g, &nq, &lds)) { gx_set_error("kq conv3x3 (bf16 pipe): shape not eligible"); return GX_EINVAL; }
-    g.act = act;
+    g.act = act; g.mask = mask; g.mask_act = mask_act;
     dim3 grid(g.tiles_h * g.tiles_w * gx_ceil_div(N, 1 << g.lG), gx_ceil_div(M, 32));
     g.nfull = (int)grid.x;                               // tiles; the workgroups loop over them (kq_c3h_kernel)
     static const char* pers_env = getenv("GENESIS_KQ_C3H_PERSIST");
@@ -1026,7 +1092,7 @@ static bool q_plan_c5h(int N, int K, int M, int H, int W, QGeom* g, size_t* lds_
     g->Hb = H; g->Wb = W; g->Hi = H; g->Wi = W; g->Ho = H; g->Wo = W;
     g->lTH = 4; g->lTW = 4; g->lG = 0;
     g->tiles_h = H / 16; g->tiles_w = W / 16;
-    g->rt_th = g->rt_tw = 0; g->act = 0; g->stats = nullptr; g->stats_parts = 0;
+    g->rt_th = g->rt_tw = 0; g->act = 0; g->stats = nullptr; g->stats_parts = 0; g->mask = nullptr; g->mask_act = 0;
     g->nfull = g->tiles_h * g->tiles_w * N;
     constexpr int NWH = (3 * (QH_TAP_BYTES / 16) + 255) / 256;
     *lds_bytes = (size_t)3 * 2 * (20 * 20) * 16 + (size_t)2 * NWH * 256 * 16;       // exact input planes + two weight buffers

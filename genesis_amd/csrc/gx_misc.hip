@@ -55,6 +55,24 @@ chan_sum_kernel(const float* __restrict__ part, int N, int C, float* __restrict_
     if (threadIdx.x == 0) out[c] = (float)s;
 }
 
+// part[n*C + c] = sum_hw x   (one block per plane; 16-byte loads when the plane allows)
+__global__ void __launch_bounds__(256)
+plane_sum_kernel(const float* __restrict__ x, int HW, float* __restrict__ part) {
+    __shared__ double red[4];
+    const float* p = x + (size_t)blockIdx.x * HW;
+    double s = 0.0;
+    if ((HW & 3) == 0) {
+        for (int i = threadIdx.x; i < HW / 4; i += blockDim.x) {
+            const float4 v = reinterpret_cast<const float4*>(p)[i];
+            s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+        }
+    } else {
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) s += p[i];
+    }
+    s = block_sum_d(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = (float)s;
+}
+
 // Measurement probe: nothing but v_mfma_f32_32x32x2_f32 on register operands, 8 independent accumulator tiles per
 // wave (the tap-conv / Winograd inner loops without any operand traffic).  What this sustains is the chip's practical
 // fp32-MFMA ceiling under load (clock / power), the number the conv kernels' TF/s should be read against.
@@ -176,6 +194,21 @@ __global__ void __launch_bounds__(256, 2) mfma_fp32_probe_kq_kernel(int iters, f
 }
 
 }  // namespace
+
+// out[c] = sum_{n,hw} x[n][c][hw] in two fixed-order launches (part: N*C floats of scratch)
+int gx_chan_sums_launch(const float* x, int N, int C, int HW, float* part, float* out, hipStream_t s) {
+    {
+        GxProf pf(KID_SMALL_REDUCE, s, 0.0, 4.0 * N * C * (double)HW);
+        hipLaunchKernelGGL(plane_sum_kernel, dim3(N * C), dim3(256), 0, s, x, HW, part);
+    }
+    GX_CHECK_LAUNCH("gx_chan_sums(planes)");
+    {
+        GxProf pf(KID_SMALL_REDUCE, s, 0.0, 4.0 * N * C);
+        hipLaunchKernelGGL(chan_sum_kernel, dim3(C), dim3(N >= 128 ? 256 : 64), 0, s, (const float*)part, N, C, out);
+    }
+    GX_CHECK_LAUNCH("gx_chan_sums(reduce)");
+    return GX_OK;
+}
 
 extern "C" {
 

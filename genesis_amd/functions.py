@@ -823,17 +823,25 @@ class BroadcastDecoderFn(torch.autograd.Function):
         grads = [None] * len(params)
         grads[2 * nl], grads[2 * nl + 1] = dow, dob
         dz = None
+        pre = None                 # (dy, db) of layer l, already formed by layer l + 1's data gradient (gx_conv3x3_dgrad_act)
         for l in reversed(range(nl)):
             w, b = params[2 * l], params[2 * l + 1]
             h, y = ctx.acts[l]
-            gw, gb = _gout(w), _gout(b)
+            gw = _gout(w)
+            gb = pre[2] if pre is not None else _gout(b)          # (_gout hands a parameter's buffer out once per iteration)
             if l == 0:
                 # every gradient of the broadcast layer from seven sums per (slot, channel) plane: no canvas, no dy
                 dz, dw, db = hip.bcast_conv3x3_bwd(y, da, z, w, rowc, colc, act, out=(gw, gb))
             else:
-                dy, db = hip.bias_act_bwd(y, da, act, True, gb)
+                dy, db = pre[:2] if pre is not None else hip.bias_act_bwd(y, da, act, True, gb)
+                pre = None
                 dw = _wgrad_paired(h, dy, gw)
-                da = hip.conv3x3_dgrad(dy, w)
+                if l >= 2 and hip.conv3x3_dgrad_act_supported(dy.shape[0], w.shape[1], w.shape[0], dy.shape[2], dy.shape[3]):
+                    # layer l - 1's bias + activation backward in this data gradient's epilogue (h is its output)
+                    gbp = _gout(params[2 * l - 1])
+                    pre = hip.conv3x3_dgrad_act(dy, w, h, act, gbp) + (gbp,)
+                else:
+                    da = hip.conv3x3_dgrad(dy, w)
             grads[2 * l], grads[2 * l + 1] = _ret(gw, dw), _ret(gb, db)
         return (dz, None, None, None) + tuple(grads)
 

@@ -581,6 +581,26 @@ def bias_act_bwd(out, g, act, want_dbias=True, dbias_out=None):
     return dy, dbias
 
 
+def conv3x3_dgrad_act_supported(N, Cin, Cout, H, W):
+    return bool(_lib.query('gx_conv3x3_dgrad_act_supported', N, Cin, Cout, H, W))
+
+
+def conv3x3_dgrad_act(dy, w, xout, act, dbias_out=None):
+    """dxa = conv3x3_dgrad(dy, w) * act'(xout), dbias[c] = sum_{n,hw} dxa: conv3x3_dgrad + bias_act_bwd of the layer that
+    produced xout, the activation's backward in the conv kernel's epilogue (gx_conv3x3_dgrad_act)."""
+    _chk(dy, 'conv3x3_dgrad_act.dy'); _chk(w, 'conv3x3_dgrad_act.w'); _chk(xout, 'conv3x3_dgrad_act.xout')
+    N, Cout, H, W = dy.shape
+    Cin = w.shape[1]
+    assert w.shape == (Cout, Cin, 3, 3) and xout.shape == (N, Cin, H, W)
+    dxa = torch.empty(N, Cin, H, W, dtype=F32, device=dy.device)
+    dbias = dbias_out if dbias_out is not None else torch.empty(Cin, dtype=F32, device=dy.device)
+    nb = _lib.query('gx_conv3x3_dgrad_act_ws_bytes', N, Cin, Cout, H, W)
+    ws = _ws(nb, dy.device)
+    _lib.call('gx_conv3x3_dgrad_act', _p(dy), _p(w), _p(xout), ACTS[act], _p(dxa), _p(dbias), N, Cin, Cout, H, W, _p(ws), nb,
+              _stream())
+    return dxa, dbias
+
+
 def conv2d_direct_fwd(x, w, bias, act, stride, pad):
     _chk(x, 'conv2d_direct.x'); _chk(w, 'conv2d_direct.w'); _chk(bias, 'conv2d_direct.bias')
     N, Cin, H, W = x.shape

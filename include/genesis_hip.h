@@ -308,6 +308,15 @@ int gx_conv3x3_bias_act_fwd(const float* x, const float* w, const float* bias, i
 size_t gx_bias_act_bwd_ws_bytes(int N, int C);
 int gx_bias_act_bwd(const float* out, const float* g, int N, int C, int H, int W, int act, float* dy, float* dbias,
                     void* ws, size_t ws_bytes, gx_stream_t stream);
+/*      gx_conv3x3_dgrad_act: the data gradient of a conv3x3 whose input was such a layer's output xout [N,Cin,H,W]
+ *      (modules/decoders.py:25-32: Conv2d, ReLU, Conv2d, ...): dxa = dgrad(dy, w) * act'(xout) and dbias [Cin] (NULL to
+ *      skip) = sum_{n,hw} dxa -- gx_conv3x3_dgrad followed by gx_bias_act_bwd with the activation's backward in the conv
+ *      kernel's epilogue.  Shapes of the bf16-pipe <= 32-channel kernel only: gx_conv3x3_dgrad_act_supported.
+ *      Environment: GENESIS_DGRAD_ACT_FUSE=0 (supported() answers 0: the two separate calls). */
+int gx_conv3x3_dgrad_act_supported(int N, int Cin, int Cout, int H, int W);
+size_t gx_conv3x3_dgrad_act_ws_bytes(int N, int Cin, int Cout, int H, int W);
+int gx_conv3x3_dgrad_act(const float* dy, const float* w, const float* xout, int act, float* dxa, float* dbias, int N,
+                         int Cin, int Cout, int H, int W, void* ws, size_t ws_bytes, gx_stream_t stream);
 /* ---- 5 x 5 stride-1 pad-2 weight gradient of the gated stacks (third_party/sylvester/VAE.py:18-33, layers.py:40-101) on
  *      the bf16-pipe row-ring tiles: dw [CA][CB][5][5] = sum_{n,p} a[n][CA][p] * b[n][CB][p + (kh - 2, kw - 2)].
  *      Conv2d: a = dy, b = x -> dw [Cout][Cin][5][5]; ConvTranspose2d stride 1: a = x, b = dy -> dw [Cin][Cout][5][5].

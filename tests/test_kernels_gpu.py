@@ -1408,6 +1408,36 @@ def test_conv3x3_to_32_channels_on_the_bf16_pipe(N, Cin, Cout, H, W):
     assert err[1][0] <= 1.5 * err[0][0] + 1e-7 and err[1][1] <= 1.5 * err[0][1] + 1e-7, err
 
 
+@pytest.mark.parametrize('N,Cin,Cout,H,W,act', [(16, 32, 32, 72, 72, 'relu'), (5, 24, 16, 40, 24, 'elu'), (4, 7, 32, 16, 16, 'relu'),
+                                                 (9, 32, 48, 8, 64, 'elu')])
+def test_conv3x3_data_gradient_with_the_previous_layers_activation_backward(N, Cin, Cout, H, W, act):
+    """gx_conv3x3_dgrad_act (the BroadcastDecoder's Conv2d / ReLU chain, modules/decoders.py:25-32): the data gradient of a
+    conv3x3 times act'(the producing layer's output) and that layer's bias gradient -- bit-identical to gx_conv3x3_dgrad
+    followed by gx_bias_act_bwd (the activation's backward moved into the conv kernel's epilogue), bias gradient to fp32
+    rounding of an fp64 sum; and against autograd in fp64."""
+    from genesis_amd import hip_ops as hip, _lib
+    w, dy = rnd(Cout, Cin, 3, 3, seed=2, scale=1.0 / np.sqrt(9 * Cin)), rnd(N, Cout, H, W, seed=4)
+    pre = rnd(N, Cin, H, W, seed=5)
+    xout = F.relu(pre) if act == 'relu' else F.elu(pre)
+    pr = pre.double().requires_grad_()
+    b = torch.zeros(Cin, dtype=torch.float64, requires_grad=True)
+    a = pr + b.view(1, -1, 1, 1)
+    F.conv2d(F.relu(a) if act == 'relu' else F.elu(a), w.double(), None, padding=1).backward(dy.double())
+    _lib.call('gx_kq_policy', 2)                  # every eligible shape (the default asks for a chip-filling grid)
+    try:
+        assert hip.conv3x3_dgrad_act_supported(N, Cin, Cout, H, W)
+        dxa, db = hip.conv3x3_dgrad_act(dy.to(DEV), w.to(DEV), xout.to(DEV), act)
+        da = hip.conv3x3_dgrad(dy.to(DEV), w.to(DEV))
+        dxa2, db2 = hip.bias_act_bwd(xout.to(DEV), da, act)
+    finally:
+        _lib.call('gx_kq_policy', 1)
+    assert torch.equal(dxa, dxa2)
+    close(db, db2, rtol=1e-6, atol=1e-6, msg='dbias vs the two-call form')
+    close(dxa, pr.grad, rtol=1e-5, atol=1e-5, msg='dxa')
+    close(db, b.grad, rtol=1e-5, atol=2e-6 * float(b.grad.abs().max()) + 1e-5, msg='dbias')
+    assert not hip.conv3x3_dgrad_act_supported(N, 64, Cout, H, W)
+
+
 @pytest.mark.parametrize('N,H,W', [(8, 72, 72), (4, 16, 12), (12, 8, 8), (20, 64, 64)])
 def test_conv3x3_weight_gradient_with_four_images_per_tile(N, H, W):
     """gx_conv3x3_wgrad_quad (the BroadcastDecoder's 32 -> 32 canvas convs): four images per workgroup, one per wave, the four
