@@ -457,9 +457,12 @@ conv1x1_fwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ w,
 }
 
 // dx[n][ci][p] = gate * sum_co w[co][ci] dy[n][co][p];  pb[blk][co] = sum_p dy[n][co][p] (ungated, per block)
+// ACT: dx *= act'(actx) -- actx = the conv's INPUT, the output of a bias + ReLU (1) / ELU (2) layer whose backward this is
+template <bool ACT>
 __global__ void __launch_bounds__(256)
 conv1x1_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, const float* __restrict__ gate,
-                     int Cin, int Cout, int HW, float* __restrict__ dx, float* __restrict__ pb) {
+                     int Cin, int Cout, int HW, float* __restrict__ dx, float* __restrict__ pb,
+                     const float* __restrict__ actx, int act) {
     __shared__ double red[4];
     const int n = blockIdx.x;
     const int p = blockIdx.y * blockDim.x + threadIdx.x;
@@ -472,12 +475,26 @@ conv1x1_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, 
     }
     if (p < HW) {
         float* dxn = dx + (size_t)n * Cin * HW + p;
+        if constexpr (ACT) {
+            const float* axn = actx + (size_t)n * Cin * HW + p;
+#pragma unroll 4
+            for (int ci = 0; ci < Cin; ++ci) {
+                const float o = axn[(size_t)ci * HW];
+                float s = 0.f;
+#pragma unroll
+                for (int co = 0; co < COMAX; ++co)
+                    if (co < Cout) s += w[co * Cin + ci] * g[co];
+                const float neg = act == 2 ? o + 1.f : 0.f;
+                dxn[(size_t)ci * HW] = s * (o > 0.f ? 1.f : neg);
+            }
+        } else {
         for (int ci = 0; ci < Cin; ++ci) {
             float s = 0.f;
 #pragma unroll
             for (int co = 0; co < COMAX; ++co)
                 if (co < Cout) s += w[co * Cin + ci] * g[co];
             dxn[(size_t)ci * HW] = s;
+        }
         }
     }
     const int blk = blockIdx.x * gridDim.y + blockIdx.y;
@@ -832,9 +849,34 @@ int gx_conv1x1_bwd(const float* x, const float* dy, const float* w, const float*
     return gx_conv1x1_bwd_ex(x, dy, w, bias, gate, N, Cin, Cout, H, W, dx, dw, db, dgate, 0, ws, ws_bytes, stream);
 }
 
+static int conv1x1_bwd_impl(const float* x, const float* dy, const float* w, const float* bias, const float* gate, int N,
+                            int Cin, int Cout, int H, int W, float* dx, float* dw, float* db, float* dgate, int accumulate,
+                            int act, float* dbx, void* ws, size_t ws_bytes, gx_stream_t stream);
+
 int gx_conv1x1_bwd_ex(const float* x, const float* dy, const float* w, const float* bias, const float* gate, int N,
                       int Cin, int Cout, int H, int W, float* dx, float* dw, float* db, float* dgate, int accumulate,
                       void* ws, size_t ws_bytes, gx_stream_t stream) {
+    return conv1x1_bwd_impl(x, dy, w, bias, gate, N, Cin, Cout, H, W, dx, dw, db, dgate, accumulate, 0, nullptr, ws, ws_bytes,
+                            stream);
+}
+
+/* ... of a conv whose input x is the output of a bias + activation layer: dxa = dx * act'(x) in the data-gradient kernel and
+ * that layer's bias gradient dbx [Cin] = sum_{n,hw} dxa (gx_bias_act_bwd without its pass) */
+size_t gx_conv1x1_bwd_act_ws_bytes(int N, int Cin, int Cout, int H, int W) {
+    return gx_round_up((long)gx_conv1x1_bwd_ws_bytes(N, Cin, Cout, H, W), 256) + (size_t)N * Cin * sizeof(float);
+}
+int gx_conv1x1_bwd_act(const float* x, const float* dy, const float* w, const float* bias, int N, int Cin, int Cout, int H,
+                       int W, int act, float* dxa, float* dw, float* db, float* dbx, void* ws, size_t ws_bytes,
+                       gx_stream_t stream) {
+    GX_CHECK_ARG(act == 1 || act == 2, "gx_conv1x1_bwd_act: act must be 1 (ReLU) or 2 (ELU)");
+    GX_CHECK_ARG(dbx, "gx_conv1x1_bwd_act: null pointer");
+    GX_CHECK_ARG(ws_bytes >= gx_conv1x1_bwd_act_ws_bytes(N, Cin, Cout, H, W), "gx_conv1x1_bwd_act: workspace too small");
+    return conv1x1_bwd_impl(x, dy, w, bias, nullptr, N, Cin, Cout, H, W, dxa, dw, db, nullptr, 0, act, dbx, ws, ws_bytes, stream);
+}
+
+static int conv1x1_bwd_impl(const float* x, const float* dy, const float* w, const float* bias, const float* gate, int N,
+                            int Cin, int Cout, int H, int W, float* dx, float* dw, float* db, float* dgate, int accumulate,
+                            int act, float* dbx, void* ws, size_t ws_bytes, gx_stream_t stream) {
     GX_CHECK_ARG(x && dy && w && dx && dw && ws, "gx_conv1x1_bwd: null pointer");
     GX_CHECK_ARG(!accumulate || !gate, "gx_conv1x1_bwd_ex: accumulate is for the plain (ungated) conv");
     GX_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && Cout <= COMAX && Cin <= 128,
@@ -852,8 +894,12 @@ int gx_conv1x1_bwd_ex(const float* x, const float* dy, const float* w, const flo
     hipStream_t s = (hipStream_t)stream;
     {
         GxProf pf(KID_CONV1X1_DGRAD, s, 2.0 * N * Cin * Cout * HW, 4.0 * N * HW * (Cin + Cout));
-        hipLaunchKernelGGL(conv1x1_dgrad_kernel, dim3(N, gx_ceil_div(HW, 256)), dim3(256), 0, s, dy, w, gate, Cin,
-                           Cout, HW, dx, pb);
+        if (act)
+            hipLaunchKernelGGL(conv1x1_dgrad_kernel<true>, dim3(N, gx_ceil_div(HW, 256)), dim3(256), 0, s, dy, w, gate, Cin,
+                               Cout, HW, dx, pb, x, act);
+        else
+            hipLaunchKernelGGL(conv1x1_dgrad_kernel<false>, dim3(N, gx_ceil_div(HW, 256)), dim3(256), 0, s, dy, w, gate, Cin,
+                               Cout, HW, dx, pb, (const float*)nullptr, 0);
     }
     GX_CHECK_LAUNCH("gx_conv1x1_bwd(dgrad)");
     {
@@ -888,6 +934,9 @@ int gx_conv1x1_bwd_ex(const float* x, const float* dy, const float* w, const flo
         }
     }
     GX_CHECK_LAUNCH("gx_conv1x1_bwd(finalize)");
+    if (dbx)
+        return gx_chan_sums_launch(dx, N, Cin, HW, (float*)((char*)ws + gx_round_up((long)gx_conv1x1_bwd_ws_bytes(N, Cin, Cout, H, W), 256)),
+                                   dbx, s);
     return GX_OK;
 }
 

@@ -10,6 +10,8 @@ Blocks (reference op groups):
   DecoderFn      models/genesisv2_config.py:89-99 (+ blocks.py:104-130)   op 8
   MixtureFn      models/genesisv2_config.py:212-223, genesis_config.py:273-286   op 9
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -811,6 +813,7 @@ class BroadcastDecoderFn(torch.autograd.Function):
         last = ctx.acts[-1][1]
         gfull = torch.zeros(last.shape[0], ow.shape[0], last.shape[2], last.shape[3], device=g.device)
         gfull[:, :, nl:nl + S, nl:nl + S] = g
+        pre = None                 # (dy, db, db's buffer) of layer l, already formed by the data gradient of the layer after it
         if wide:
             gow, gob = _gout(ow), _gout(ob)
             dyo, dob = hip.bias_act_bwd(ctx.full, gfull, out_act, True, gob)
@@ -818,12 +821,16 @@ class BroadcastDecoderFn(torch.autograd.Function):
             dow = hip.conv2d_direct_wgrad(last, dyo, 1, 1, 0, out=None if gow is None else gow.view(ow4.shape))
             da = hip.conv2d_direct_dgrad(dyo, ow4, last.shape[2], last.shape[3], 1, 0)
             dow, dob = _ret(gow, dow.view(ow.shape)), _ret(gob, dob)
+        elif nl >= 2 and hip.ACTS[act] in (1, 2) and os.environ.get('GENESIS_DGRAD_ACT_FUSE', '1') != '0':
+            # the last 3x3 layer's bias + activation backward inside the 1x1 conv's data gradient (`last` is its output)
+            gbp = _gout(params[2 * nl - 1])
+            dyl, dow, dob, dbl = hip.conv1x1_bwd_act(last, gfull, ow, ob, act, dbx_out=gbp)
+            pre = (dyl, dbl, gbp)
         else:
             da, dow, dob, _ = hip.conv1x1_bwd(last, gfull, ow, ob)
         grads = [None] * len(params)
         grads[2 * nl], grads[2 * nl + 1] = dow, dob
         dz = None
-        pre = None                 # (dy, db) of layer l, already formed by layer l + 1's data gradient (gx_conv3x3_dgrad_act)
         for l in reversed(range(nl)):
             w, b = params[2 * l], params[2 * l + 1]
             h, y = ctx.acts[l]

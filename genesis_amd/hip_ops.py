@@ -459,6 +459,27 @@ def conv1x1_bwd(x, dy, w, bias, gate=None, out=None, accumulate=False):
 ACTS = {None: 0, 'none': 0, 'relu': 1, 'elu': 2}
 
 
+def conv1x1_bwd_act(x, dy, w, bias, act, out=None, dbx_out=None):
+    """conv1x1_bwd of a conv whose input x is a bias + activation layer's output: returns (dxa, dw, db, dbx) with
+    dxa = dx * act'(x) and dbx[c] = sum_{n,hw} dxa, that layer's bias gradient (gx_conv1x1_bwd_act)."""
+    _chk(dy, 'conv1x1_bwd_act.dy'); _chk(x, 'conv1x1_bwd_act.x')
+    N, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    dev = x.device
+    o = out or (None, None)
+    dxa = torch.empty_like(x)
+    dw = o[0] if o[0] is not None else torch.empty(Cout, Cin, dtype=F32, device=dev)
+    db = (o[1] if o[1] is not None else torch.empty(Cout, dtype=F32, device=dev)) if bias is not None else None
+    dbx = dbx_out if dbx_out is not None else torch.empty(Cin, dtype=F32, device=dev)
+    _chk(dw, 'conv1x1_bwd_act.dw'); _chk(db, 'conv1x1_bwd_act.db'); _chk(dbx, 'conv1x1_bwd_act.dbx')
+    assert dw.numel() == Cout * Cin and dbx.numel() == Cin
+    nb = _lib.query('gx_conv1x1_bwd_act_ws_bytes', N, Cin, Cout, H, W)
+    ws = _ws(nb, dev)
+    _lib.call('gx_conv1x1_bwd_act', _p(x), _p(dy), _p(w), _p(bias), N, Cin, Cout, H, W, ACTS[act], _p(dxa), _p(dw), _p(db),
+              _p(dbx), _p(ws), nb, _stream())
+    return dxa, (dw.view(w.shape) if o[0] is None else dw), db, dbx
+
+
 def broadcast_concat(z, coords):
     """z [N,D], coords [1,2,d,d] -> [N, D+2, d, d] (BroadcastLayer + PixelCoords, modules/blocks.py:104-130)."""
     _chk(z, 'broadcast_concat.z'); _chk(coords, 'broadcast_concat.coords')

@@ -222,6 +222,13 @@ int gx_conv1x1_bwd(const float* x, const float* dy, const float* w, const float*
 int gx_conv1x1_bwd_ex(const float* x, const float* dy, const float* w, const float* bias, const float* gate, int N,
                       int Cin, int Cout, int H, int W, float* dx, float* dw, float* db, float* dgate, int accumulate,
                       void* ws, size_t ws_bytes, gx_stream_t stream);
+/*      ..._act: the conv's input x is the output of a bias + activation layer (modules/decoders.py:25-32: ..., ReLU,
+ *      Conv2d(1x1)): dxa = dx * act'(x) (act 1 ReLU, 2 ELU) in the data-gradient kernel and dbx [Cin] = sum_{n,hw} dxa, that
+ *      layer's bias gradient -- gx_conv1x1_bwd followed by gx_bias_act_bwd without the latter's pass. */
+size_t gx_conv1x1_bwd_act_ws_bytes(int N, int Cin, int Cout, int H, int W);
+int gx_conv1x1_bwd_act(const float* x, const float* dy, const float* w, const float* bias, int N, int Cin, int Cout, int H,
+                       int W, int act, float* dxa, float* dw, float* db, float* dbx, void* ws, size_t ws_bytes,
+                       gx_stream_t stream);
 /*      The same 1x1 conv reading the PRE-norm tensor y of the GroupNorm+ReLU layer in front of it (statistics from
  *      gx_gn_relu_fwd with dst0 == NULL): relu(gn(y)) is formed on load, forward and in the weight gradient; the data
  *      gradient is folded into gx_gn_relu_bwd_proj.  Cin <= 64 (wgrad), H*W % 256 == 0. */

@@ -1438,6 +1438,22 @@ def test_conv3x3_data_gradient_with_the_previous_layers_activation_backward(N, C
     assert not hip.conv3x3_dgrad_act_supported(N, 64, Cout, H, W)
 
 
+@pytest.mark.parametrize('N,Cin,Cout,H,W,act', [(6, 32, 4, 72, 72, 'relu'), (3, 24, 3, 16, 16, 'elu'), (2, 64, 8, 8, 8, 'relu')])
+def test_conv1x1_backward_with_the_previous_layers_activation_backward(N, Cin, Cout, H, W, act):
+    """gx_conv1x1_bwd_act (the BroadcastDecoder's last ReLU + 1 x 1 conv, modules/decoders.py:31-32): dxa bit-identical to
+    gx_conv1x1_bwd followed by gx_bias_act_bwd, dw / db identical, the layer's bias gradient to fp32 rounding of an fp64 sum."""
+    from genesis_amd import hip_ops as hip
+    pre = rnd(N, Cin, H, W, seed=5)
+    x = (F.relu(pre) if act == 'relu' else F.elu(pre)).to(DEV)
+    w, b, dy = rnd(Cout, Cin, seed=1).to(DEV), rnd(Cout, seed=2).to(DEV), rnd(N, Cout, H, W, seed=3).to(DEV)
+    dxa, dw, db, dbx = hip.conv1x1_bwd_act(x, dy, w, b, act)
+    dx, dw2, db2, _ = hip.conv1x1_bwd(x, dy, w, b)
+    dxa2, dbx2 = hip.bias_act_bwd(x, dx, act)
+    assert torch.equal(dxa, dxa2) and torch.equal(dw, dw2) and torch.equal(db, db2)
+    close(dbx, dbx2, rtol=1e-6, atol=1e-6, msg='dbias vs the two-call form')
+    close(dbx, dxa.double().sum((0, 2, 3)), rtol=1e-6, atol=1e-6, msg='dbias')
+
+
 @pytest.mark.parametrize('N,H,W', [(8, 72, 72), (4, 16, 12), (12, 8, 8), (20, 64, 64)])
 def test_conv3x3_weight_gradient_with_four_images_per_tile(N, H, W):
     """gx_conv3x3_wgrad_quad (the BroadcastDecoder's 32 -> 32 canvas convs): four images per workgroup, one per wave, the four
