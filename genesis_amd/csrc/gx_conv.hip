@@ -648,6 +648,8 @@ struct WgradGeom {
     int nsplit;          // partial slabs (max over classes for the merged deconv launch)
     int Ttot;            // taps in the partial buffer (9 or 25)
     int cls_begin[5];    // merged deconv launch: blockIdx.x range of parity class c is [cls_begin[c], cls_begin[c+1])
+    float* bias_part;    // QUAD on the bf16 pipe: [nsplit][256] per-thread sums of the dy values it multiplied (NULL: off) --
+                         // the layer's bias gradient rides on the weight gradient's read of dy (gx_conv3x3_wgrad_quad_bias)
 };
 
 // A operand (dy) goes global -> registers directly: the k (pixel) slots of the MFMA are assigned so that
@@ -1052,6 +1054,7 @@ wgrad_fast_body(const float* __restrict__ a_src, const float* __restrict__ b_src
     {                                                                                                \
         float av_[8];                                                                                \
         _Pragma("unroll") for (int u = 0; u < 4; ++u) { av_[u] = src_[2 * (P_)][u]; av_[4 + u] = src_[2 * (P_) + 1][u]; } \
+        if constexpr (QUAD) bsum_ += ((av_[0] + av_[1]) + (av_[2] + av_[3])) + ((av_[4] + av_[5]) + (av_[6] + av_[7])); \
         __bf16 ah_[8], am_[8], al_[8];                                                               \
         cw_split<8>(av_, ah_, am_, al_);                                                             \
         CwB3 a3_;                                                                                    \
@@ -1079,6 +1082,7 @@ wgrad_fast_body(const float* __restrict__ a_src, const float* __restrict__ b_src
 #define GX_WF_COMPUTE_B6(bt_, src_) { GX_WF_PAIR_B6(bt_, src_, 0) GX_WF_PAIR_B6(bt_, src_, 1) }
 
     float a0[4][4], a1[4][4];
+    float bsum_ = 0.f;        // QUAD && B6: sum of this lane's dy values (one channel of one sub-image, half of each tile's pixels)
     int tile = sp;
     int it = 0;
     if (tile < g.ntiles) {
@@ -1157,6 +1161,9 @@ wgrad_fast_body(const float* __restrict__ a_src, const float* __restrict__ b_src
 #undef GX_WF_MMA
 #undef GX_WF_PAIR_B6
 #undef GX_WF_COMPUTE_B6
+    if constexpr (QUAD && B6) {
+        if (g.bias_part) g.bias_part[(size_t)sp * 256 + tid] = bsum_;
+    }
     // partial[split][gt][ca][cb]
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -1211,6 +1218,22 @@ wgrad_deconv_kernel(const float* __restrict__ a_src, const float* __restrict__ b
 }
 
 // QUAD slabs [split][t][64][64] -> dw [C][C][T] (C <= 32): quadrant q = (wm, wn) holds sub-image q's 32 x 32 block.  Block =
+// db[c] = sum over the splits' 8 records per channel (4 sub-images x 2 pixel halves: thread = wave * 64 + half * 32 + c), fp64
+__global__ void __launch_bounds__(256)
+quad_bias_reduce_kernel(const float* __restrict__ part, int nsplit, float* __restrict__ db) {
+    __shared__ double red[256];
+    const int c = blockIdx.x;
+    double s = 0.0;
+    for (int r = threadIdx.x; r < nsplit * 8; r += 256) s += part[(size_t)(r >> 3) * 256 + (r & 7) * 32 + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) db[c] = (float)red[0];
+}
+
 // 64 consecutive (t, ca, cb) outputs x the 4 quadrants x 4 interleaved split groups; fixed summation order.
 __global__ void __launch_bounds__(1024)
 wgrad_quad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int nsplit, int Ttot, int C) {
@@ -1597,6 +1620,7 @@ struct WgradPlan {
 int plan_wgrad(int N, int CA, int CB, int Hb, int Wb, int SA, int Ttot, int ncls_launches, WgradPlan* pl, int max_npix = 128,
                int b_rows = 64, int halo = 1) {
     WgradGeom& g = pl->g;
+    g.bias_part = nullptr;
     g.N = N; g.CA = CA; g.CB = CB;
     g.CApad = gx_round_up(CA, 64); g.CBpad = gx_round_up(CB, 64);
     g.Hb = Hb; g.Wb = Wb; g.Ha = SA * Hb; g.Wa = SA * Wb;
@@ -2493,8 +2517,29 @@ size_t gx_conv3x3_wgrad_quad_ws_bytes(int N, int C, int H, int W) {
     if (!wgrad_quad_plan(N, C, H, W, &pl)) return 0;
     return pl.ws_floats * sizeof(float);
 }
+static int wgrad_quad_impl(const float* x, const float* dy, float* dw, float* dbias, int N, int C, int H, int W, void* ws,
+                           size_t ws_bytes, gx_stream_t stream);
 int gx_conv3x3_wgrad_quad(const float* x, const float* dy, float* dw, int N, int C, int H, int W, void* ws, size_t ws_bytes,
                           gx_stream_t stream) {
+    return wgrad_quad_impl(x, dy, dw, nullptr, N, C, H, W, ws, ws_bytes, stream);
+}
+/* ... and dbias [C] = sum_{n,hw} dy, the layer's bias gradient, from the same read of dy (bf16-pipe tiles; otherwise a plane-sum
+ * pass over dy) */
+size_t gx_conv3x3_wgrad_quad_bias_ws_bytes(int N, int C, int H, int W) {
+    WgradPlan pl;
+    if (!wgrad_quad_plan(N, C, H, W, &pl)) return 0;
+    const size_t rec = (size_t)pl.g.nsplit * 256, planes = (size_t)N * C;
+    return (pl.ws_floats + (rec > planes ? rec : planes)) * sizeof(float);
+}
+int gx_conv3x3_wgrad_quad_bias(const float* x, const float* dy, float* dw, float* dbias, int N, int C, int H, int W, void* ws,
+                               size_t ws_bytes, gx_stream_t stream) {
+    GX_CHECK_ARG(dbias, "gx_conv3x3_wgrad_quad_bias: null pointer");
+    GX_CHECK_ARG(ws_bytes >= gx_conv3x3_wgrad_quad_bias_ws_bytes(N, C, H, W) && gx_conv3x3_wgrad_quad_bias_ws_bytes(N, C, H, W) > 0,
+                 "gx_conv3x3_wgrad_quad_bias: unsupported shape or workspace too small");
+    return wgrad_quad_impl(x, dy, dw, dbias, N, C, H, W, ws, ws_bytes, stream);
+}
+static int wgrad_quad_impl(const float* x, const float* dy, float* dw, float* dbias, int N, int C, int H, int W, void* ws,
+                           size_t ws_bytes, gx_stream_t stream) {
     GX_CHECK_ARG(x && dy && dw && ws, "gx_conv3x3_wgrad_quad: null pointer");
     WgradPlan pl;
     GX_CHECK_ARG(wgrad_quad_plan(N, C, H, W, &pl), "gx_conv3x3_wgrad_quad: needs 32 channels, N %% 4 == 0, W %% 4 == 0");
@@ -2505,6 +2550,7 @@ int gx_conv3x3_wgrad_quad(const float* x, const float* dy, float* dw, int N, int
     WgradGeom g = pl.g;
     g.CA = g.CB = 128;                     // the [N / 4, 128, H, W] view: image and channel strides of the kernel
     const dim3 grid(g.nsplit, 1);
+    bool bias_in_kernel = false;
     {
         GxProf pf(KID_WGRAD_C3, s, 2.0 * N * (double)C * C * 9 * H * W,
                   4.0 * (2.0 * N * C * H * W + (double)g.nsplit * 9 * 64 * 64));
@@ -2523,6 +2569,8 @@ int gx_conv3x3_wgrad_quad(const float* x, const float* dy, float* dw, int N, int
         // GENESIS_WGQ_BF16X6=0 / GENESIS_WGRAD_QUAD_B6=0 keep the weight gradients on the fp32 pipe
         static const char* b6env = getenv("GENESIS_WGRAD_QUAD_B6");
         const bool b6 = gx_wgq_bf16_pipe() && !(b6env && b6env[0] == '0');
+        bias_in_kernel = dbias && b6 && g.lTW >= 3;
+        if (bias_in_kernel) g.bias_part = (float*)ws + pl.ws_floats;
         switch (g.lTW) {
             case 2: GX_QUAD_LAUNCH(2, false) break;
             case 3: if (b6) GX_QUAD_LAUNCH(3, true) else GX_QUAD_LAUNCH(3, false) break;
@@ -2539,6 +2587,13 @@ int gx_conv3x3_wgrad_quad(const float* x, const float* dy, float* dw, int N, int
                            g.nsplit, 9, C);
     }
     GX_CHECK_LAUNCH("gx_conv3x3_wgrad_quad(reduce)");
+    if (dbias && bias_in_kernel) {
+        GxProf pf(KID_SMALL_REDUCE, s, 0.0, 4.0 * g.nsplit * 256);
+        hipLaunchKernelGGL(quad_bias_reduce_kernel, dim3(C), dim3(256), 0, s, (const float*)g.bias_part, g.nsplit, dbias);
+        GX_CHECK_LAUNCH("gx_conv3x3_wgrad_quad_bias(reduce)");
+    } else if (dbias) {
+        return gx_chan_sums_launch(dy, N, C, H * W, (float*)ws + pl.ws_floats, dbias, s);
+    }
     return GX_OK;
 }
 

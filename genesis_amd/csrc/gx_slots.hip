@@ -869,7 +869,6 @@ int gx_conv1x1_bwd_act(const float* x, const float* dy, const float* w, const fl
                        int W, int act, float* dxa, float* dw, float* db, float* dbx, void* ws, size_t ws_bytes,
                        gx_stream_t stream) {
     GX_CHECK_ARG(act == 1 || act == 2, "gx_conv1x1_bwd_act: act must be 1 (ReLU) or 2 (ELU)");
-    GX_CHECK_ARG(dbx, "gx_conv1x1_bwd_act: null pointer");
     GX_CHECK_ARG(ws_bytes >= gx_conv1x1_bwd_act_ws_bytes(N, Cin, Cout, H, W), "gx_conv1x1_bwd_act: workspace too small");
     return conv1x1_bwd_impl(x, dy, w, bias, nullptr, N, Cin, Cout, H, W, dxa, dw, db, nullptr, 0, act, dbx, ws, ws_bytes, stream);
 }

@@ -824,7 +824,9 @@ class BroadcastDecoderFn(torch.autograd.Function):
         elif nl >= 2 and hip.ACTS[act] in (1, 2) and os.environ.get('GENESIS_DGRAD_ACT_FUSE', '1') != '0':
             # the last 3x3 layer's bias + activation backward inside the 1x1 conv's data gradient (`last` is its output)
             gbp = _gout(params[2 * nl - 1])
-            dyl, dow, dob, dbl = hip.conv1x1_bwd_act(last, gfull, ow, ob, act, dbx_out=gbp)
+            wp = params[2 * nl - 2]
+            lazy = QUAD_BIAS and wp.shape[0] == wp.shape[1] and _quad_ok(last.shape[0], wp.shape[1], last.shape[2], last.shape[3])
+            dyl, dow, dob, dbl = hip.conv1x1_bwd_act(last, gfull, ow, ob, act, dbx_out=gbp, want_dbx=not lazy)
             pre = (dyl, dbl, gbp)
         else:
             da, dow, dob, _ = hip.conv1x1_bwd(last, gfull, ow, ob)
@@ -841,19 +843,33 @@ class BroadcastDecoderFn(torch.autograd.Function):
                 dz, dw, db = hip.bcast_conv3x3_bwd(y, da, z, w, rowc, colc, act, out=(gw, gb))
             else:
                 dy, db = pre[:2] if pre is not None else hip.bias_act_bwd(y, da, act, True, gb)
+                if pre is not None and db is None:
+                    # the bias gradient was left to this layer's weight gradient (it reads all of dy anyway)
+                    db = gb if gb is not None else torch.empty(b.shape, dtype=torch.float32, device=dy.device)
+                    dw = _wgrad_paired(h, dy, gw, db)
+                else:
+                    dw = _wgrad_paired(h, dy, gw)
                 pre = None
-                dw = _wgrad_paired(h, dy, gw)
                 if l >= 2 and hip.conv3x3_dgrad_act_supported(dy.shape[0], w.shape[1], w.shape[0], dy.shape[2], dy.shape[3]):
                     # layer l - 1's bias + activation backward in this data gradient's epilogue (h is its output)
                     gbp = _gout(params[2 * l - 1])
-                    pre = hip.conv3x3_dgrad_act(dy, w, h, act, gbp) + (gbp,)
+                    wp = params[2 * l - 2]
+                    lazy = QUAD_BIAS and wp.shape[0] == wp.shape[1] and _quad_ok(h.shape[0], wp.shape[1], h.shape[2], h.shape[3])
+                    pre = hip.conv3x3_dgrad_act(dy, w, h, act, gbp, want_dbias=not lazy) + (gbp,)
                 else:
                     da = hip.conv3x3_dgrad(dy, w)
             grads[2 * l], grads[2 * l + 1] = _ret(gw, dw), _ret(gb, db)
         return (dz, None, None, None) + tuple(grads)
 
 
-def _wgrad_paired(h, dy, gw):
+QUAD_BIAS = os.environ.get('GENESIS_QUAD_WGRAD_BIAS', '1') != '0'     # 0: the fused data gradients' own plane-sum pass
+
+
+def _quad_ok(N, C, H, W):
+    return hip.conv3x3_wgrad_quad_supported(N, C, H, W)
+
+
+def _wgrad_paired(h, dy, gw, gb=None):
     """conv3x3 weight gradient of a layer with <= 32 channels on both sides (the BroadcastDecoder's 32 -> 32 convs on the
     canvas): the kernels work on 64 x 64 channel blocks, so such a layer fills a quarter of every MFMA.  Two consecutive
     images of an NCHW tensor ARE one image of twice the channels ([N, 32, H, W] viewed as [N / 2, 64, H, W]): the 64 x 64
@@ -862,9 +878,11 @@ def _wgrad_paired(h, dy, gw):
     useful instead of a quarter, with no kernel change.  Returns dw (or None after writing gw)."""
     N, Ci, Co = h.shape[0], h.shape[1], dy.shape[1]
     if Ci == Co and hip.conv3x3_wgrad_quad_supported(N, Ci, h.shape[2], h.shape[3]):
-        # four images per workgroup tile, one per wave: every wave's 32 x 32 block is a wanted one
-        dw = hip.conv3x3_wgrad_quad(h, dy, out=gw)
+        # four images per workgroup tile, one per wave: every wave's 32 x 32 block is a wanted one (gb: a [C] buffer that
+        # receives the layer's bias gradient, the channel sums of dy, from the same read of dy)
+        dw = hip.conv3x3_wgrad_quad(h, dy, out=gw, dbias_out=gb)
         return None if gw is not None else dw
+    assert gb is None, 'the bias gradient rides on the four-image weight gradient only'
     if N % 2 or Ci > 32 or Co > 32 or Ci != Co or Ci % 8:
         return hip.conv3x3_wgrad(h, dy, out=gw)
     d64 = hip.conv3x3_wgrad(h.view(N // 2, 2 * Ci, *h.shape[2:]), dy.view(N // 2, 2 * Co, *dy.shape[2:]))

@@ -150,13 +150,20 @@ def conv3x3_wgrad_quad_supported(N, C, H, W):
     return bool(_lib.query('gx_conv3x3_wgrad_quad_supported', N, C, H, W))
 
 
-def conv3x3_wgrad_quad(x, dy, out=None):
-    """conv3x3 weight gradient of a 32 -> 32 layer, four images per workgroup tile (gx_conv3x3_wgrad_quad)."""
+def conv3x3_wgrad_quad(x, dy, out=None, dbias_out=None):
+    """conv3x3 weight gradient of a 32 -> 32 layer, four images per workgroup tile (gx_conv3x3_wgrad_quad); with dbias_out [C]
+    also the layer's bias gradient sum_{n,hw} dy from the same read of dy (gx_conv3x3_wgrad_quad_bias)."""
     _chk(x, 'conv3x3_wgrad_quad.x'); _chk(dy, 'conv3x3_wgrad_quad.dy')
     N, C, H, W = x.shape
     assert tuple(dy.shape) == (N, C, H, W)
     dw = out if out is not None else torch.empty(C, C, 3, 3, dtype=F32, device=x.device)
     assert tuple(dw.shape) == (C, C, 3, 3) and dw.is_contiguous()
+    if dbias_out is not None:
+        _chk(dbias_out, 'conv3x3_wgrad_quad.dbias'); assert dbias_out.numel() == C
+        nb = _lib.query('gx_conv3x3_wgrad_quad_bias_ws_bytes', N, C, H, W)
+        ws = _ws(nb, x.device)
+        _lib.call('gx_conv3x3_wgrad_quad_bias', _p(x), _p(dy), _p(dw), _p(dbias_out), N, C, H, W, _p(ws), nb, _stream())
+        return dw
     nb = _lib.query('gx_conv3x3_wgrad_quad_ws_bytes', N, C, H, W)
     ws = _ws(nb, x.device)
     _lib.call('gx_conv3x3_wgrad_quad', _p(x), _p(dy), _p(dw), N, C, H, W, _p(ws), nb, _stream())
@@ -459,7 +466,7 @@ def conv1x1_bwd(x, dy, w, bias, gate=None, out=None, accumulate=False):
 ACTS = {None: 0, 'none': 0, 'relu': 1, 'elu': 2}
 
 
-def conv1x1_bwd_act(x, dy, w, bias, act, out=None, dbx_out=None):
+def conv1x1_bwd_act(x, dy, w, bias, act, out=None, dbx_out=None, want_dbx=True):
     """conv1x1_bwd of a conv whose input x is a bias + activation layer's output: returns (dxa, dw, db, dbx) with
     dxa = dx * act'(x) and dbx[c] = sum_{n,hw} dxa, that layer's bias gradient (gx_conv1x1_bwd_act)."""
     _chk(dy, 'conv1x1_bwd_act.dy'); _chk(x, 'conv1x1_bwd_act.x')
@@ -470,9 +477,11 @@ def conv1x1_bwd_act(x, dy, w, bias, act, out=None, dbx_out=None):
     dxa = torch.empty_like(x)
     dw = o[0] if o[0] is not None else torch.empty(Cout, Cin, dtype=F32, device=dev)
     db = (o[1] if o[1] is not None else torch.empty(Cout, dtype=F32, device=dev)) if bias is not None else None
-    dbx = dbx_out if dbx_out is not None else torch.empty(Cin, dtype=F32, device=dev)
+    dbx = None
+    if want_dbx:
+        dbx = dbx_out if dbx_out is not None else torch.empty(Cin, dtype=F32, device=dev)
     _chk(dw, 'conv1x1_bwd_act.dw'); _chk(db, 'conv1x1_bwd_act.db'); _chk(dbx, 'conv1x1_bwd_act.dbx')
-    assert dw.numel() == Cout * Cin and dbx.numel() == Cin
+    assert dw.numel() == Cout * Cin and (dbx is None or dbx.numel() == Cin)
     nb = _lib.query('gx_conv1x1_bwd_act_ws_bytes', N, Cin, Cout, H, W)
     ws = _ws(nb, dev)
     _lib.call('gx_conv1x1_bwd_act', _p(x), _p(dy), _p(w), _p(bias), N, Cin, Cout, H, W, ACTS[act], _p(dxa), _p(dw), _p(db),
@@ -606,7 +615,7 @@ def conv3x3_dgrad_act_supported(N, Cin, Cout, H, W):
     return bool(_lib.query('gx_conv3x3_dgrad_act_supported', N, Cin, Cout, H, W))
 
 
-def conv3x3_dgrad_act(dy, w, xout, act, dbias_out=None):
+def conv3x3_dgrad_act(dy, w, xout, act, dbias_out=None, want_dbias=True):
     """dxa = conv3x3_dgrad(dy, w) * act'(xout), dbias[c] = sum_{n,hw} dxa: conv3x3_dgrad + bias_act_bwd of the layer that
     produced xout, the activation's backward in the conv kernel's epilogue (gx_conv3x3_dgrad_act)."""
     _chk(dy, 'conv3x3_dgrad_act.dy'); _chk(w, 'conv3x3_dgrad_act.w'); _chk(xout, 'conv3x3_dgrad_act.xout')
@@ -614,7 +623,9 @@ def conv3x3_dgrad_act(dy, w, xout, act, dbias_out=None):
     Cin = w.shape[1]
     assert w.shape == (Cout, Cin, 3, 3) and xout.shape == (N, Cin, H, W)
     dxa = torch.empty(N, Cin, H, W, dtype=F32, device=dy.device)
-    dbias = dbias_out if dbias_out is not None else torch.empty(Cin, dtype=F32, device=dy.device)
+    dbias = None
+    if want_dbias:
+        dbias = dbias_out if dbias_out is not None else torch.empty(Cin, dtype=F32, device=dy.device)
     nb = _lib.query('gx_conv3x3_dgrad_act_ws_bytes', N, Cin, Cout, H, W)
     ws = _ws(nb, dy.device)
     _lib.call('gx_conv3x3_dgrad_act', _p(dy), _p(w), _p(xout), ACTS[act], _p(dxa), _p(dbias), N, Cin, Cout, H, W, _p(ws), nb,

@@ -223,7 +223,7 @@ int gx_conv1x1_bwd_ex(const float* x, const float* dy, const float* w, const flo
                       int Cin, int Cout, int H, int W, float* dx, float* dw, float* db, float* dgate, int accumulate,
                       void* ws, size_t ws_bytes, gx_stream_t stream);
 /*      ..._act: the conv's input x is the output of a bias + activation layer (modules/decoders.py:25-32: ..., ReLU,
- *      Conv2d(1x1)): dxa = dx * act'(x) (act 1 ReLU, 2 ELU) in the data-gradient kernel and dbx [Cin] = sum_{n,hw} dxa, that
+ *      Conv2d(1x1)): dxa = dx * act'(x) (act 1 ReLU, 2 ELU) in the data-gradient kernel and dbx [Cin] (NULL to skip) = sum_{n,hw} dxa, that
  *      layer's bias gradient -- gx_conv1x1_bwd followed by gx_bias_act_bwd without the latter's pass. */
 size_t gx_conv1x1_bwd_act_ws_bytes(int N, int Cin, int Cout, int H, int W);
 int gx_conv1x1_bwd_act(const float* x, const float* dy, const float* w, const float* bias, int N, int Cin, int Cout, int H,
@@ -335,6 +335,11 @@ int gx_conv3x3_wgrad_quad_supported(int N, int C, int H, int W);
 size_t gx_conv3x3_wgrad_quad_ws_bytes(int N, int C, int H, int W);
 int gx_conv3x3_wgrad_quad(const float* x, const float* dy, float* dw, int N, int C, int H, int W, void* ws, size_t ws_bytes,
                           gx_stream_t stream);
+/*      ..._bias: also dbias [C] = sum_{n,hw} dy -- the layer's bias gradient from the weight gradient's own read of dy (per-thread
+ *      sums inside the bf16-pipe kernel, one small reduce; a plane-sum pass over dy where that kernel is not the one that runs). */
+size_t gx_conv3x3_wgrad_quad_bias_ws_bytes(int N, int C, int H, int W);
+int gx_conv3x3_wgrad_quad_bias(const float* x, const float* dy, float* dw, float* dbias, int N, int C, int H, int W, void* ws,
+                               size_t ws_bytes, gx_stream_t stream);
 /*      the layers themselves on the tap-conv MFMA kernel: out [N,M,H,W] from in [N,K,H,W];
  *      flip 0: cross-correlation with w [M][K][5][5] (Conv2d forward; data gradient of a stride-1 ConvTranspose2d),
  *      flip 1: convolution with w [K][M][5][5] (Conv2d data gradient, in = dy; stride-1 ConvTranspose2d forward). */

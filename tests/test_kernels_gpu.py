@@ -1469,6 +1469,12 @@ def test_conv3x3_weight_gradient_with_four_images_per_tile(N, H, W):
     out = torch.full((32, 32, 3, 3), 7.0, device=DEV)
     hip.conv3x3_wgrad_quad(x.to(DEV), dy.to(DEV), out=out)
     assert torch.equal(out, dw)
+    # ... with the layer's bias gradient (the channel sums of dy) from the same read of dy: gx_conv3x3_wgrad_quad_bias
+    db = torch.full((32,), float('nan'), device=DEV)
+    out2 = hip.conv3x3_wgrad_quad(x.to(DEV), dy.to(DEV), dbias_out=db)
+    assert torch.equal(out2, dw)
+    ref = dy.double().sum((0, 2, 3))
+    close(db, ref, rtol=1e-5, atol=2e-6 * float(dy.abs().sum((0, 2, 3)).max()), msg='dbias')
 
 
 def test_philox_noise_is_a_function_of_seed_step_and_position():
