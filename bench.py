@@ -51,6 +51,9 @@ def parse():
     ap.add_argument('--fp32-pipe-steps', type=int, default=30,
                     help='extra leg on rank 0 at N=1: steps with every product on the fp32 matrix pipe (gx_wgq_precision(0), '
                          'gx_kq_precision(0)), reported as value_fp32_pipe_only, never as value; 0 = skip')
+    ap.add_argument('--extra-leg-steps', type=int, default=30,
+                    help='extra legs on rank 0 at N=1: value_as_written (the step + mse / rmse + the forward outputs no loss reads) '
+                         'and value_reference_loop (train.py:223-263 unchanged, eager, torch.optim.Adam); 0 = skip')
     ap.add_argument('--host-input-steps', type=int, default=100,
                     help='extra leg on rank 0 at N=1: steps fed from uint8 frames in host memory through the PCIe feeder '
                          '(reported as pcie_inclusive, never as value; 0 = skip)')
@@ -226,16 +229,41 @@ def cpu_baseline(args):
                       % (n, '/'.join(map(str, cands)), args.batch, args.K, args.img, args.img, cores, ncpu)}
 
 
+def self_launch_argv(n, argv):
+    """The command line `python bench.py --gpus N` turns itself into when it was not started by a launcher: the driver's own
+    N > 1 form (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    ...), rendezvous on the loopback address (the container hostname may not resolve) and a port the kernel just handed out."""
+    import socket
+    port = os.environ.get('MASTER_PORT')
+    if not port:
+        s_ = socket.socket()
+        s_.bind(('127.0.0.1', 0))
+        port = str(s_.getsockname()[1])
+        s_.close()
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+            '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     args = parse()
     # the driver reads ONE JSON line from stdout; RCCL prints a version banner there when its first communicator is made:
     # everything but the result line goes to stderr
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` by itself (the shape of the driver's 1-GPU command; the reference's multi-GPU mode is one
+        # command too, train.py:133-137,153-155): become the one-process-per-GPU launch -- exec the launcher in place of this
+        # process, so the ranks inherit stdout / stderr and rank 0's ONE JSON line is this command's stdout
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
+        os.execv(sys.executable, self_launch_argv(args.gpus, sys.argv[1:]))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    if world != args.gpus:
+        raise SystemExit('bench.py --gpus %d was started inside a %d-rank launch (WORLD_SIZE=%s): run `python bench.py --gpus %d` '
+                         'by itself, or torch.distributed.run --nproc-per-node %d'
+                         % (args.gpus, world, os.environ.get('WORLD_SIZE'), args.gpus, args.gpus))
     # GENESIS_BENCH_REHEARSAL=1: the N-rank code path (rendezvous, shard seeds, split graphs around the collective, barriers,
     # max-over-ranks timing, the JSON line) with every rank on GPU 0 and gloo carrying the bucket -- RCCL refuses two ranks on
     # one device.  A rehearsal of the launch on a 1-GPU box (tests/test_bench_gpu.py), marked as such, never a measurement.
@@ -305,6 +333,28 @@ def main():
             dist.all_reduce(tl, op=dist.ReduceOp.MAX)
         dt_long = float(tl)
 
+    # the step's ONE collective by itself: the flat bucket's all-reduce, back to back on an idle GPU (every rank takes part;
+    # the bucket is zeroed first and is clean afterwards, as the step leaves it).  In the step it is exposed by construction
+    # (DESIGN.md section 6), so this is what one step pays for it.
+    ar_ms = None
+    if dist.is_initialized():
+        with torch.no_grad():
+            ts.bucket.zero_grad()
+            for _ in range(3):
+                ts.bucket.all_reduce(ts.pg, packed=True)
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            n_ar = 20
+            ta = time.perf_counter()
+            for _ in range(n_ar):
+                ts.bucket.all_reduce(ts.pg, packed=True)
+            torch.cuda.synchronize()
+            tar = torch.tensor([(time.perf_counter() - ta) / n_ar], dtype=torch.float64, device=device)
+            dist.all_reduce(tar, op=dist.ReduceOp.MAX)
+            ar_ms = 1e3 * float(tar)
+            ts.bucket.zero_grad()
+
     result = None
     if rank == 0:
         value = world * args.batch * args.steps / dt
@@ -346,7 +396,12 @@ def main():
             # gradient as float triples [+ averaged buffers]) over the ranks the process group actually has
             result['config']['collective'] = {'backend': dist.get_backend(), 'ranks_observed': dist.get_world_size(),
                                               'all_reduces_per_step': 1,
-                                              'bytes_per_all_reduce': int(ts.bucket.flat_g.numel() * 4)}
+                                              'bytes_per_all_reduce': int(ts.bucket.flat_g.numel() * 4),
+                                              'all_reduce_ms': ar_ms,
+                                              'all_reduce_share_of_step': ar_ms / (1e3 * dt / args.steps) if ar_ms else None,
+                                              'all_reduce_timing': '20 back-to-back all-reduces of the bucket on an idle GPU after '
+                                                                   'the timed region (host clock around a synchronised loop, max '
+                                                                   'over ranks); inside the step the collective is not overlapped'}
         if flop_img:
             result['step_fraction_of_fp32_mfma_peak'] = value / world * flop_img / (PEAK_FP32_MFMA_TFLOPS * 1e12)
 
@@ -515,6 +570,83 @@ def main():
             _lib.call('gx_wgq_precision', 1)
             _lib.call('gx_kq_precision', 1)
             _lib.call('gx_wino_precision', 1)
+
+    # ---- what the timed step leaves out of the reference's iteration, priced: train.py:244-246 computes mse / rmse
+    #      every iteration and GenesisV2.forward builds mx_r_k / instance_seg / instance_seg_r (genesisv2_config.py:184-188) and
+    #      att_stats.delta unconditionally; none of them feeds the loss, `value` computes them on first access only.
+    if rank == 0 and world == 1 and args.extra_leg_steps > 0 and args.model == 'genesisv2' and not args.no_graph:
+        ts.close()
+        ts3 = TrainStep(model, args.img, lr=1e-4, graph=True, log_mse=True, materialise_stats=True)
+        ts3.prepare(batches[0])
+        for i in range(5):
+            ts3.step(batches[i % 4])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.extra_leg_steps):
+            out3 = ts3.step(batches[i % 4])
+        torch.cuda.synchronize()
+        dt3 = time.perf_counter() - t0
+        result['value_as_written'] = {'value': args.batch * args.extra_leg_steps / dt3, 'unit': 'images/sec',
+                                      'steps': args.extra_leg_steps, 'ms_per_step': 1e3 * dt3 / args.extra_leg_steps,
+                                      'mse_rmse': [float(out3[4]), float(out3[5])],
+                                      'adds': 'mse / rmse of the reconstruction (train.py:244-246: gx_mse_rmse) and the forward outputs a '
+                                              'training iteration never reads, materialised in every step: stats.mx_r_k, instance_seg, '
+                                              'instance_seg_r (genesisv2_config.py:184-188), att_stats.delta; same HIP-graph step otherwise'}
+        ts3.close()
+
+    # ---- the reference's loop UNCHANGED on the HIP model (north_star: "train.py drops in unchanged"): train.py:223-263's
+    #      statements -- optimiser.zero_grad(); model(x); err / kl aggregation with torch.stack; elbo; mse / rmse; geco.loss();
+    #      loss.backward(); torch.optim.Adam.step() -- issued eagerly from Python, one host read per iteration where
+    #      utils/geco.py:45 has its `.item()`.  What a maintainer gets WITHOUT adopting TrainStep; `value` is TrainStep's graph.
+    if rank == 0 and world == 1 and args.extra_leg_steps > 0 and args.model == 'genesisv2':
+        from genesis_amd.geco import make_geco
+        torch.cuda.synchronize()
+        model_r = build_model(args, device)
+        optimiser = torch.optim.Adam(model_r.parameters(), lr=1e-4)          # train.py:174-175
+        geco = make_geco(args.img, device=device)                            # train.py:159-167
+
+        def reference_iteration(x):
+            optimiser.zero_grad()
+            output, losses, stats, att_stats, comp_stats = model_r(x)
+            err = losses.err.mean(0)
+            kl_m, kl_l = torch.tensor(0), torch.tensor(0)
+            if 'kl_m' in losses:
+                kl_m = losses.kl_m.mean(0)
+            elif 'kl_m_k' in losses:
+                kl_m = torch.stack(losses.kl_m_k, dim=1).mean(dim=0).sum()
+            if 'kl_l' in losses:
+                kl_l = losses.kl_l.mean(0)
+            elif 'kl_l_k' in losses:
+                kl_l = torch.stack(losses.kl_l_k, dim=1).mean(dim=0).sum()
+            elbo = (err + kl_l + kl_m).detach()
+            mse_batched = ((x - output) ** 2).mean((1, 2, 3)).detach()
+            rmse_batched = mse_batched.sqrt()
+            mse, rmse = mse_batched.mean(0), rmse_batched.mean(0)
+            loss = geco.loss(err, kl_l + kl_m)
+            float(geco.state[1])           # the host read of utils/geco.py:45 (`constraint.item()`)
+            loss.backward()
+            optimiser.step()
+            return elbo, mse, rmse
+
+        for i in range(5):
+            reference_iteration(batches[i % 4])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.extra_leg_steps):
+            elbo_r, _, _ = reference_iteration(batches[i % 4])
+        torch.cuda.synchronize()
+        dtr = time.perf_counter() - t0
+        result['value_reference_loop'] = {'value': args.batch * args.extra_leg_steps / dtr, 'unit': 'images/sec',
+                                          'steps': args.extra_leg_steps, 'ms_per_step': 1e3 * dtr / args.extra_leg_steps,
+                                          'final_elbo': float(elbo_r),
+                                          'loop': 'train.py:223-263 statement for statement on genesis_amd.genesisv2_config.load(cfg): eager '
+                                                  'forward, torch autograd over the HIP Functions, genesis_amd.geco.GECO.loss + one host '
+                                                  'read per iteration (utils/geco.py:45), torch.optim.Adam.step(); no TrainStep, no HIP '
+                                                  'graph, no flat bucket, no deferred weight-gradient launch'}
+        del model_r, optimiser
+        result['config']['workload'] += ('; value = TrainStep (HIP-graph replay of the iteration; mse / rmse logging and the forward '
+                                         'outputs no loss reads are off: priced in value_as_written); the unchanged train.py loop on the '
+                                         'same model: value_reference_loop')
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0 and args.model == 'genesisv2':
         result['cpu_baseline'] = cpu_baseline(args)

@@ -107,6 +107,7 @@ bool gx_defer_push_wgrad(const GxWgradRed& r) {
     g_wq[g_nw++] = r;
     return true;
 }
+int gx_defer_wgrad_room() { return kMaxDefer - g_nw; }
 bool gx_defer_push_gn(const GxGnRed& r) {
     if (g_ng >= kMaxDefer) return false;
     g_gq[g_ng++] = r;

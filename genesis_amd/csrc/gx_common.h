@@ -64,6 +64,7 @@ struct GxWgradRed { const float* partial; float* dw; int nsplit, Ttot, CA, CB, C
                     ca0, cb0, CAf, CBf; };
 struct GxGnRed { const float* part; float* dgamma; float* dbeta; float* dbias; int N, C; };
 bool gx_defer_push_wgrad(const GxWgradRed& r);   // false: queue full (caller reduces immediately)
+int gx_defer_wgrad_room();                      // free slots of the weight-gradient reduce queue of the current context
 bool gx_defer_push_gn(const GxGnRed& r);
 int gx_defer_flush_wgrad(const GxWgradRed* items, int n, hipStream_t s);   // gx_conv.hip
 int gx_defer_flush_gn(const GxGnRed* items, int n, hipStream_t s);         // gx_norm.hip

@@ -1737,8 +1737,10 @@ int launch_wgrad(const float* a, const float* b, float* partial, const WgradPlan
     dim3 grid(pl.g.nsplit, (pl.g.CApad / 64) * (pl.g.CBpad / 64));
     if (WM == W_C3 && pl.g.lTW == 2 && g_gx_defer_on && wf_defer_on() && (pl.g.Wb & 3) == 0 && pl.g.Hb * pl.g.Wb <= 65536 &&
         (double)(1 << pl.g.lG) * pl.g.CA * pl.g.Ha * pl.g.Wa < 2.0e9 && (double)(1 << pl.g.lG) * pl.g.CB * pl.g.Hb * pl.g.Wb < 2.0e9 &&
-        !getenv("GENESIS_WGRAD_LEGACY") && zero_page(s)) {
-        // a layer too small for the stream-K launch: launched with the other queued ones at the flush (gx_wf_flush)
+        !getenv("GENESIS_WGRAD_LEGACY") && gx_defer_wgrad_room() > 0 && zero_page(s)) {
+        // a layer too small for the stream-K launch: launched with the other queued ones at the flush (gx_wf_flush).
+        // Only while the reduce queue has room for this layer's record (the caller pushes it next): with a full queue the
+        // reduce runs at once, so the slabs must have been written by then -- the immediate launch below
         g_wf.push_back(WfPending{WfJob{a, b, partial, pl.g}, pl.lds_bytes,
                                  2.0 * pl.g.N * (double)pl.g.CA * pl.g.CB * WTap<WM>::NT * pl.g.Hb * pl.g.Wb});
         return GX_OK;

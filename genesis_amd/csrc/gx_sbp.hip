@@ -52,7 +52,11 @@ sbp_scan_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ 
 // one workgroup per image: kl[b] = sum_pixels sum_k qn (log qn - log pn).  1024 threads, every mask value loaded and
 // exponentiated ONCE (the first version -- 256 threads, two passes over the K slots with 2 K exps each -- was a chain of
 // 16 dependent load rounds per thread: 72.7 us for 3.7 MB at K = 7, B = 32, 64 x 64; now 4 rounds)
+// KB = K bucket (4 / 8 / 16 register slots: a pixel loads only the bucket's slots, the ones past K from slot 0); KB = 0: any K, two
+// passes over the slots with the exps recomputed (the values and the order of every sum are the bucketed form's, so the result
+// does not depend on the bucket) -- MONet.kl_m_loss has no limit on K_steps (monet_config.py:157-170)
 constexpr int CKL_KMAX = 16;
+template <int KB>
 __global__ void __launch_bounds__(1024)
 categorical_kl_fwd_kernel(const float* __restrict__ log_m, const float* __restrict__ log_m_r, int K, int B, int HW,
                           float* __restrict__ kl) {
@@ -60,26 +64,39 @@ categorical_kl_fwd_kernel(const float* __restrict__ log_m, const float* __restri
     const int b = blockIdx.x;
     double acc = 0.0;
     for (int p = threadIdx.x; p < HW; p += blockDim.x) {
-        float q[CKL_KMAX], pn[CKL_KMAX];
-#pragma unroll
-        for (int k = 0; k < CKL_KMAX; ++k) {
-            const size_t i = ((size_t)(k < K ? k : 0) * B + b) * HW + p;
-            q[k] = log_m[i]; pn[k] = log_m_r[i];
-        }
-        float Q = 0.f, Pn = 0.f;
-#pragma unroll
-        for (int k = 0; k < CKL_KMAX; ++k)
-            if (k < K) {
-                q[k] = fmaxf(expf(q[k]), 1e-5f); pn[k] = fmaxf(expf(pn[k]), 1e-5f);
-                Q += q[k]; Pn += pn[k];
-            }
         float t = 0.f;
+        if constexpr (KB > 0) {
+            float q[KB], pn[KB];
 #pragma unroll
-        for (int k = 0; k < CKL_KMAX; ++k)
-            if (k < K) {
-                const float qn = q[k] / Q, pv = pn[k] / Pn;
+            for (int k = 0; k < KB; ++k) {
+                const size_t i = ((size_t)(k < K ? k : 0) * B + b) * HW + p;
+                q[k] = log_m[i]; pn[k] = log_m_r[i];
+            }
+            float Q = 0.f, Pn = 0.f;
+#pragma unroll
+            for (int k = 0; k < KB; ++k)
+                if (k < K) {
+                    q[k] = fmaxf(expf(q[k]), 1e-5f); pn[k] = fmaxf(expf(pn[k]), 1e-5f);
+                    Q += q[k]; Pn += pn[k];
+                }
+#pragma unroll
+            for (int k = 0; k < KB; ++k)
+                if (k < K) {
+                    const float qn = q[k] / Q, pv = pn[k] / Pn;
+                    t += qn * (logf(qn) - logf(pv));
+                }
+        } else {
+            float Q = 0.f, Pn = 0.f;
+            for (int k = 0; k < K; ++k) {
+                const size_t i = ((size_t)k * B + b) * HW + p;
+                Q += fmaxf(expf(log_m[i]), 1e-5f); Pn += fmaxf(expf(log_m_r[i]), 1e-5f);
+            }
+            for (int k = 0; k < K; ++k) {
+                const size_t i = ((size_t)k * B + b) * HW + p;
+                const float qn = fmaxf(expf(log_m[i]), 1e-5f) / Q, pv = fmaxf(expf(log_m_r[i]), 1e-5f) / Pn;
                 t += qn * (logf(qn) - logf(pv));
             }
+        }
         acc += (double)t;
     }
     acc = gx_wave_sum_d(acc);
@@ -219,11 +236,15 @@ int gx_sbp_scan_bwd(const float* logits, const float* g_log_m, const float* g_lo
 
 int gx_categorical_kl_fwd(const float* log_m, const float* log_m_r, int K, int B, int HW, float* kl,
                           gx_stream_t stream) {
-    GX_CHECK_ARG(log_m && log_m_r && kl && K > 0 && K <= CKL_KMAX && B > 0 && HW > 0, "gx_categorical_kl_fwd: bad arguments (K <= 16)");
+    GX_CHECK_ARG(log_m && log_m_r && kl && K > 0 && B > 0 && HW > 0, "gx_categorical_kl_fwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     {
         GxProf pf(KID_SMALL_REDUCE, s, 0.0, 8.0 * K * (double)B * HW);
-        hipLaunchKernelGGL(categorical_kl_fwd_kernel, dim3(B), dim3(HW >= 1024 ? 1024 : 256), 0, s, log_m, log_m_r, K, B, HW, kl);
+        const dim3 blk(HW >= 1024 ? 1024 : 256);
+        if (K <= 4) hipLaunchKernelGGL(categorical_kl_fwd_kernel<4>, dim3(B), blk, 0, s, log_m, log_m_r, K, B, HW, kl);
+        else if (K <= 8) hipLaunchKernelGGL(categorical_kl_fwd_kernel<8>, dim3(B), blk, 0, s, log_m, log_m_r, K, B, HW, kl);
+        else if (K <= CKL_KMAX) hipLaunchKernelGGL(categorical_kl_fwd_kernel<CKL_KMAX>, dim3(B), blk, 0, s, log_m, log_m_r, K, B, HW, kl);
+        else hipLaunchKernelGGL(categorical_kl_fwd_kernel<0>, dim3(B), blk, 0, s, log_m, log_m_r, K, B, HW, kl);
     }
     GX_CHECK_LAUNCH("gx_categorical_kl_fwd");
     return GX_OK;

@@ -26,11 +26,16 @@ class TrainStep(object):
 
     def __init__(self, model, img_size, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, geco=None, use_geco=True,
                  beta_fixed=0.5, process_group=None, graph=False, async_wgrad=False, weight_cache=True, defer_reduces=True,
-                 side_prior=None, optimiser='adam', beta_warmup=False, train_iter=None, log_mse=False):
+                 side_prior=None, optimiser='adam', beta_warmup=False, train_iter=None, log_mse=False,
+                 materialise_stats=False):
         """optimiser: 'adam' (torch.optim.Adam(lr); betas / eps as given), 'rmsprop' (torch.optim.RMSprop(lr): alpha 0.99,
         eps 1e-8) or 'sgd' (torch.optim.SGD(lr, 0.9)) -- train.py:170-176.  use_geco=False: the fixed-beta objective
         err + beta_fixed * kl, with beta_warmup the linear ramp beta_fixed * iter / (0.2 * train_iter) of train.py:252-258.
-        log_mse: step() also returns train.py:244-246's (mse, rmse) behind (elbo, err, kl, beta)."""
+        log_mse: step() also returns train.py:244-246's (mse, rmse) behind (elbo, err, kl, beta).
+        materialise_stats: evaluate, inside every step, the outputs of the forward that a training iteration never reads and
+        this build therefore computes on first access (stats.mx_r_k / instance_seg / instance_seg_r,
+        genesisv2_config.py:184-188; att_stats.delta) -- the reference's forward computes them unconditionally; a measurement
+        switch (bench.py: value_as_written), nothing consumes the values."""
         if optimiser not in self.OPTIMISERS:
             raise ValueError('optimiser must be one of %s (train.py:170-176), got %r' % (self.OPTIMISERS, optimiser))
         if beta_warmup and (use_geco and geco is None or geco is not None):
@@ -40,6 +45,7 @@ class TrainStep(object):
         self.model = model
         self.optimiser = optimiser
         self.beta_warmup, self.train_iter, self.log_mse = bool(beta_warmup), train_iter, bool(log_mse)
+        self.materialise_stats = bool(materialise_stats)
         self.lr, self.betas, self.eps = lr, betas, eps
         self.device = next(model.parameters()).device
         if self.device.type != 'cuda':
@@ -81,7 +87,9 @@ class TrainStep(object):
 
     # ------------------------------------------------------------------ flat buffers
     def _flatten(self):
-        self.bucket = FlatBucket(self.model.parameters(), n_tail=2,
+        # tail scalars of the exchange: the rank's batch-mean err, kl [, mse, rmse with log_mse: train.py:244-246 logs them over
+        # the WHOLE batch, so with several ranks they ride the same all-reduce as err / kl -- advisor finding, round 4]
+        self.bucket = FlatBucket(self.model.parameters(), n_tail=4 if self.log_mse else 2,
                                  mean_buffers=list(self.model.buffers()) if self.world > 1 else ())
         b = self.bucket
         self.n32, self.n64 = b.n32, b.n64
@@ -209,6 +217,9 @@ class TrainStep(object):
             _lib.call('gx_beta_warmup', _p(self.step_t), float(self.beta_fixed), 0.2 * float(self.train_iter),
                       _p(self._beta_fixed_t), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         recon, losses, stats, att_stats, comp_stats = self.model(x, **forward_kwargs)
+        if self.materialise_stats:
+            with torch.no_grad():
+                self._materialised = [d_._resolve_all() or d_ for d_ in (stats, att_stats) if hasattr(d_, '_resolve_all')]
         if self.log_mse:
             with torch.no_grad():
                 xr, rr = x.detach().contiguous(), recon.detach().contiguous()
@@ -217,6 +228,8 @@ class TrainStep(object):
                     self._mse_out = torch.zeros(2, device=self.device)
                 _lib.call('gx_mse_rmse', _p(xr), _p(rr), xr.shape[0], xr[0].numel(), _p(self._mse_out), _p(self._mse_ws),
                           self._mse_ws.numel() * 4, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                if self.bucket.collective_needed(self.pg):
+                    self.bucket.flat_g[self.n32 + 2:self.n32 + 4].copy_(self._mse_out)
         # loss aggregation of train.py:226-242 (every model family: kl_m | kl_m_k, kl_l | kl_l_k)
         beta_t = self.geco.state[0:1] if self.geco is not None else self._beta_fixed_t.view(1)
         # (if / elif per stage like the reference: a model returning both forms of a term must not be counted twice)
@@ -300,7 +313,10 @@ class TrainStep(object):
         else:
             bu = beta_used[4] if fused else beta_used
             out = torch.stack((tail[0] + tail[1], tail[0], tail[1], bu))
-        return torch.cat((out, self._mse_out)) if self.log_mse else out
+        if not self.log_mse:
+            return out
+        # (several ranks: the all-reduced sums of the ranks' shard means / world = the whole batch's mse, rmse)
+        return torch.cat((out, self._mse_out if gscale == 1.0 else self.bucket.flat_g[self.n32 + 2:self.n32 + 4] * gscale))
 
     # ------------------------------------------------------------------ HIP-graph replay
     def _begin(self):
@@ -479,10 +495,17 @@ class TrainStep(object):
                     opt.state[p] = {'momentum_buffer': m.clone()}
         return {'model_state_dict': self.model.state_dict(),
                 'optimiser_state_dict': opt.state_dict(),
-                'beta': self.geco.beta.detach().clone() if self.geco is not None else self.beta_fixed,
+                # (fixed-beta objective with the warm-up ramp: the ramp value of iteration `iter_idx`, the `beta` that
+                #  train.py:252-258 computed in the iteration whose end save_checkpoint records)
+                'beta': self.geco.beta.detach().clone() if self.geco is not None else self._current_fixed_beta(iter_idx),
                 'err_ema': (self.geco.err_ema.detach().clone() if self.geco.err_ema is not None else None)
                 if self.geco is not None else None,
                 'iter_idx': iter_idx}
+
+    def _current_fixed_beta(self, iter_idx):
+        if not self.beta_warmup:
+            return self.beta_fixed
+        return min(self.beta_fixed, max(0.0, self.beta_fixed * iter_idx / (0.2 * float(self.train_iter))))
 
     def load_state_dict(self, ckpt):
         """Restores model, Adam moments / step, GECO state from a checkpoint of the reference's format; returns the
@@ -490,14 +513,20 @@ class TrainStep(object):
         sd = dict(ckpt['model_state_dict'])
         sd.pop('comp_vae.decoder_module.seq.0.pixel_coords.g_1', None)     # legacy entries, train.py:191-192
         sd.pop('comp_vae.decoder_module.seq.0.pixel_coords.g_2', None)
-        self.model.load_state_dict(sd)
-        assert self.bucket.grads_in_bucket()
         osd = ckpt['optimiser_state_dict']
         params = list(self.model.parameters())
         ids = [i for g in osd['param_groups'] for i in g['params']]
         if len(ids) != len(params):
             raise ValueError('optimiser state has %d parameters, the model %d' % (len(ids), len(params)))
         steps = set()
+        # what the checkpoint holds is decided BEFORE anything is copied: a checkpoint of another optimiser must leave this
+        # loop's moment buffers untouched (advisor finding, round 4)
+        kinds = {('adam' if 'exp_avg' in st else 'rmsprop' if 'square_avg' in st else 'sgd')
+                 for st in (osd['state'].get(i) for i in ids) if st is not None}
+        if kinds - {self.optimiser}:
+            raise ValueError('the checkpoint holds %s state, this loop runs %s' % ('/'.join(sorted(kinds)), self.optimiser))
+        self.model.load_state_dict(sd)
+        assert self.bucket.grads_in_bucket()
         with torch.no_grad():
             self.m32.zero_(); self.v32.zero_(); self.m64.zero_(); self.v64.zero_()
             for i, p in zip(ids, params):
@@ -506,17 +535,11 @@ class TrainStep(object):
                     continue
                 m, v = self._adam_slices(p)
                 if 'exp_avg' in st:
-                    kind = 'adam'
                     m.copy_(st['exp_avg']); v.copy_(st['exp_avg_sq'])
                 elif 'square_avg' in st:
-                    kind = 'rmsprop'
                     m.copy_(st['square_avg'])
-                else:
-                    kind = 'sgd'
-                    if st.get('momentum_buffer') is not None:
-                        m.copy_(st['momentum_buffer'])
-                if kind != self.optimiser:
-                    raise ValueError('the checkpoint holds %s state, this loop runs %s' % (kind, self.optimiser))
+                elif st.get('momentum_buffer') is not None:
+                    m.copy_(st['momentum_buffer'])
                 if 'step' in st:
                     steps.add(int(st['step']))
             if len(steps) > 1:

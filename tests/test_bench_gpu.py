@@ -16,7 +16,7 @@ ROOT = osp.dirname(osp.dirname(osp.abspath(__file__)))
 def test_bench_line_contract():
     env = dict(os.environ, PYTHONPATH=ROOT)
     out = subprocess.run([sys.executable, osp.join(ROOT, 'bench.py'), '--steps', '4', '--warmup', '2', '--cpu-seconds', '2',
-                          '--profile-steps', '1', '--host-input-steps', '3'], capture_output=True, text=True, env=env,
+                          '--profile-steps', '1', '--host-input-steps', '3', '--extra-leg-steps', '3'], capture_output=True, text=True, env=env,
                          cwd=ROOT, timeout=580)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
@@ -39,6 +39,11 @@ def test_bench_line_contract():
         assert k in c, k
     assert c['kind'] in ('port', 'reference') and c['value'] > 0 and c['cores'] >= 1
     assert d['pcie_inclusive']['value'] > 0
+    # the legs that price what `value` leaves out / what the unchanged train.py loop gets (never `value`)
+    assert 0 < d['value_as_written']['value'] and len(d['value_as_written']['mse_rmse']) == 2
+    assert 0 < d['value_reference_loop']['value'] < d['value'] * 1.05
+    assert abs(d['value_reference_loop']['final_elbo'] - d['final_elbo']) < 0.2 * abs(d['final_elbo'])
+    assert 'value_reference_loop' in d['config']['workload']
 
 
 @pytest.mark.timeout(900)
@@ -64,3 +69,21 @@ def test_bench_two_rank_launch_rehearsal():
     assert d['config']['launch'] == 'hip-graph(fwd+bwd) | rccl all-reduce | hip-graph(geco+adam)'
     assert 'rehearsal' in d and d['value'] > 0 and abs(d['value'] - 64 * 1e3 / d['ms_per_step']) < 1e-6 * d['value']
     assert 'roofline' not in d and 'cpu_baseline' not in d    # rank-0-at-N=1 legs only
+    assert c['all_reduce_ms'] > 0 and 0 < c['all_reduce_share_of_step'] < 1
+
+
+@pytest.mark.timeout(900)
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` BY ITSELF -- the shape of the driver's 1-GPU command with another N (VERDICT r04, missing 1;
+    the reference's multi-GPU mode is one command as well, train.py:133-137,153-155): with no WORLD_SIZE in the environment
+    the script execs the one-process-per-GPU launcher, and the command's stdout is still rank 0's ONE JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    env.update(PYTHONPATH=ROOT, GENESIS_BENCH_REHEARSAL='1', GENESIS_BENCH_LONG_STEPS='0')
+    out = subprocess.run([sys.executable, osp.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2'],
+                         capture_output=True, text=True, env=env, cwd=ROOT, timeout=880)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['collective']['ranks_observed'] == 2 and d['config']['global_batch'] == 64
+    assert d['config']['collective']['all_reduce_ms'] > 0 and d['value'] > 0

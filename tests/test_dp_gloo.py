@@ -165,3 +165,46 @@ def test_eight_rank_bucket_exchange(tmp_path):
     np.testing.assert_allclose(r[0]['mean'].double().numpy(), mean('mean').numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(r[0]['var'].double().numpy(), mean('var').numpy(), rtol=1e-5)
     np.testing.assert_allclose(r[0]['tail'].numpy(), [8000.0 + 3.5, 20.0 + 0.5 * 3.5], rtol=1e-6)
+
+
+def test_bench_self_launch_command_line(monkeypatch):
+    """`python bench.py --gpus N` without a launcher execs the driver's own N > 1 form (one rank per GPU, loopback
+    rendezvous); inside a launch whose WORLD_SIZE disagrees with --gpus it refuses instead of timing the wrong thing."""
+    import importlib.util
+    import os
+    import sys
+    import pytest
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_under_test', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'):
+        monkeypatch.delenv(k, raising=False)
+    argv = bench.self_launch_argv(4, ['--gpus', '4', '--steps', '20', '--warmup', '5'])
+    assert argv[:3] == [sys.executable, '-m', 'torch.distributed.run']
+    assert '--nnodes=1' in argv and argv[argv.index('--nproc-per-node') + 1] == '4'
+    assert argv[argv.index('--master-addr') + 1] == '127.0.0.1' and int(argv[argv.index('--master-port') + 1]) > 0
+    i = argv.index(os.path.join(root, 'bench.py'))
+    assert argv[i + 1:] == ['--gpus', '4', '--steps', '20', '--warmup', '5']
+    seen = {}
+
+    def fake_execv(exe, args):
+        seen['argv'] = args
+        raise SystemExit(0)
+    monkeypatch.setattr(bench.os, 'execv', fake_execv)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '8', '--steps', '3', '--warmup', '1'])
+    fd1, fd2 = os.dup(1), os.dup(2)
+    try:
+        with pytest.raises(SystemExit):
+            bench.main()
+    finally:
+        os.dup2(fd1, 1); os.dup2(fd2, 2); os.close(fd1); os.close(fd2)
+    assert seen['argv'][seen['argv'].index('--nproc-per-node') + 1] == '8'
+    monkeypatch.setenv('WORLD_SIZE', '2')
+    fd1 = os.dup(1)
+    try:
+        with pytest.raises(SystemExit) as e:
+            bench.main()
+    finally:
+        os.dup2(fd1, 1); os.close(fd1)
+    assert 'WORLD_SIZE' in str(e.value)

@@ -993,7 +993,8 @@ def test_stick_breaking_scan(T, B, S, last, with_s0):
         close(s0d.grad, s0.grad, 1e-5, 1e-5, 'g_log_s0')
 
 
-@pytest.mark.parametrize('K,B,S,through_r', [(4, 3, 16, False), (7, 2, 32, True), (2, 2, 8, True)])
+@pytest.mark.parametrize('K,B,S,through_r', [(4, 3, 16, False), (7, 2, 32, True), (2, 2, 8, True), (11, 2, 32, True),
+                                             (20, 2, 32, True)])      # K > 16: the two-pass form (no limit on K_steps)
 def test_categorical_mask_kl(K, B, S, through_r):
     """MONet.kl_m_loss (models/monet_config.py:157-170) as torch.distributions writes it, forward and both gradients
     (the reconstructed-mask side is the detach_mr_in_klm = False branch of genesisv2_config.py:172-176)."""

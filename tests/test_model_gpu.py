@@ -160,7 +160,7 @@ def test_cpu_input_raises():
         model.cpu()(torch.rand(1, 3, 32, 32))
 
 
-@pytest.mark.parametrize('case', ['metric'])     # (the 128 x 128 configuration: tests/test_fullbatch_gpu.py, on well-conditioned weights)
+@pytest.mark.parametrize('case', ['metric', 'cfg5'])
 def test_golden_parity_with_every_conv3x3_on_the_winograd_kernel(case):
     """The golden cases have B = 2, too small for the Winograd dispatch (it takes the layers that fill the chip): force
     every eligible conv3x3 forward / data gradient onto the Winograd kernel and repeat the reference comparison."""
