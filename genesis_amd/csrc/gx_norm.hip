@@ -1263,6 +1263,31 @@ inline bool proj_split_ok(int C, int H, int W, int groups, int Cout) {
     return HW % kSplitPix == 0 && HW / kSplitPix >= 2 && !plan_reg(C / groups, H, W).ok;
 }
 
+// test diagnostic (gx_gn_relu_active_count): one workgroup per (image, channel) plane
+__global__ void __launch_bounds__(256)
+gn_relu_active_count_kernel(const float* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ beta,
+                            const float* __restrict__ mean, const float* __restrict__ rstd, int C, int HW, int groups,
+                            unsigned long long* __restrict__ count) {
+    const int n = blockIdx.x / C, c = blockIdx.x - n * C;
+    const int g = n * groups + c / (C / groups);
+    const float meanf = mean[g], rstdf = rstd[g], gm = gamma[c], bt = beta[c];
+    const float* p = y + (size_t)blockIdx.x * HW;
+    unsigned cnt = 0;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        const float t = (p[i] - meanf) * rstdf * gm + bt;
+        cnt += t > 0.f ? 1u : 0u;
+    }
+    __shared__ unsigned red[256];
+    red[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(count, (unsigned long long)red[0]);
+}
+
+
 }  // namespace
 
 int gx_defer_flush_gn(const GxGnRed* items, int n, hipStream_t s) {
@@ -1498,6 +1523,22 @@ static int gn_relu_bwd_impl(const float* y, const float* gamma, const float* bet
                            dgamma, dbeta, dbias);
     }
     GX_CHECK_LAUNCH("gx_gn_relu_bwd(reduce)");
+    return GX_OK;
+}
+
+
+/* gx_gn_relu_active_count: how many elements of relu(gn(y)) are > 0 -- evaluated with the expression every forward / backward
+ * kernel of this file (and the normalise-on-load 1x1 conv) uses for its ReLU decision, t = (y - mean) * rstd * gamma + beta, so the
+ * count is the KERNELS' own pattern (a test diagnostic: tests/test_fullbatch_gpu.py compares it with the reference's). */
+int gx_gn_relu_active_count(const float* y, const float* gamma, const float* beta, const float* mean, const float* rstd, int N,
+                            int C, int H, int W, int groups, unsigned long long* count, gx_stream_t stream) {
+    GX_CHECK_ARG(y && gamma && beta && mean && rstd && count && N > 0 && C > 0 && groups > 0 && C % groups == 0 && H > 0 && W > 0,
+                 "gx_gn_relu_active_count: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    hipMemsetAsync(count, 0, sizeof(unsigned long long), s);
+    hipLaunchKernelGGL(gn_relu_active_count_kernel, dim3(N * C), dim3(256), 0, s, y, gamma, beta, mean, rstd, C, H * W, groups,
+                       count);
+    GX_CHECK_LAUNCH("gx_gn_relu_active_count");
     return GX_OK;
 }
 

@@ -793,6 +793,8 @@ class BroadcastDecoderFn(torch.autograd.Function):
                 y = hip.conv3x3_bias_act_fwd(h, w, b, act)
             acts.append((h, y))
             h = y
+            # (test diagnostic: the reference's VALID conv l has the canvas minus l + 1 border pixels as its output)
+            hip._probe_act(y[:, :, l + 1:d - l - 1, l + 1:d - l - 1], b, act)
         ow, ob = params[2 * nl], params[2 * nl + 1]
         wide = ow.shape[0] > 8 or out_act is not None      # the small-Cout 1x1 kernel serves <= 8 output channels
         if wide:

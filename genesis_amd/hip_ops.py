@@ -241,6 +241,25 @@ def _view_args_p(v, name):
     return [_p(buf), int(buf.shape[1]), int(c0), int(mode), 1, 0]
 
 
+# Test diagnostic (tests/test_fullbatch_gpu.py): a list here makes every ReLU-producing forward wrapper append
+# (data_ptr of the layer's affine / bias parameter, device count of active outputs, number of outputs) -- the kernels' own
+# ReLU pattern per layer, to be compared with the reference's nn.ReLU modules.  None (default): nothing is recorded.
+RELU_PROBE = None
+
+
+def _probe_gn(y, gamma, beta, mean, rstd, groups):
+    if RELU_PROBE is not None:
+        cnt = torch.zeros(1, dtype=torch.int64, device=y.device)
+        N, C, H, W = y.shape
+        _lib.call('gx_gn_relu_active_count', _p(y), _p(gamma), _p(beta), _p(mean), _p(rstd), N, C, H, W, groups, _p(cnt), _stream())
+        RELU_PROBE.append((gamma.data_ptr(), cnt, y.numel()))
+
+
+def _probe_act(y, bias, act):
+    if RELU_PROBE is not None and act == 'relu' and bias is not None:
+        RELU_PROBE.append((bias.data_ptr(), torch.count_nonzero(y > 0).reshape(1), y.numel()))
+
+
 def gn_relu_fwd(y, gamma, beta, groups, eps, dst0, dst1=None):
     """dst0 None: group statistics only (the consumer normalises on load, conv1x1_gn_fwd)."""
     _chk(y, 'gn.y'); _chk(gamma, 'gn.gamma'); _chk(beta, 'gn.beta')
@@ -249,6 +268,7 @@ def gn_relu_fwd(y, gamma, beta, groups, eps, dst0, dst1=None):
     rstd = torch.empty(N * groups, dtype=F32, device=y.device)
     _lib.call('gx_gn_relu_fwd', _p(y), _p(gamma), _p(beta), N, C, H, W, groups, float(eps),
               *(_view_args(dst0, 'gn.dst0') + _view_args(dst1, 'gn.dst1')), _p(mean), _p(rstd), _stream())
+    _probe_gn(y, gamma, beta, mean, rstd, groups)
     return mean, rstd
 
 
@@ -282,6 +302,7 @@ def _conv_gn(kind, x, w, bias, gamma, beta, groups, eps, dst0, dst1):
     _lib.call('gx_gn_relu_fwd_parts', parts, nsplit.value, stride.value, _p(bias), _p(y) if need_sum else None,
               _p(gamma), _p(beta), N, Cout, Ho, Wo, groups, float(eps),
               *(_view_args(dst0, 'gn.dst0') + _view_args(dst1, 'gn.dst1')), _p(mean), _p(rstd), _stream())
+    _probe_gn(y, gamma, beta, mean, rstd, groups)
     return y, mean, rstd       # (ws, holding the partial slabs, is released only now)
 
 
@@ -319,6 +340,8 @@ def deconv5x5s2_gn_stats_fwd(x, w, bias, gamma, beta, groups, eps):
               _p(mean), _p(rstd), ctypes.byref(fused), _p(ws), nb, _stream())
     if not fused.value:
         mean, rstd = gn_relu_fwd(y, gamma, beta, groups, eps, None)
+    else:
+        _probe_gn(y, gamma, beta, mean, rstd, groups)
     return y, mean, rstd
 
 
@@ -643,6 +666,7 @@ def conv2d_direct_fwd(x, w, bias, act, stride, pad):
     ws = _ws(nb, x.device) if nb else None          # (under-filled grids split the contraction: partial slabs)
     _lib.call('gx_conv2d_direct_fwd_ws', _p(x), _p(w), _p(bias), ACTS[act], _p(y), N, Cin, Cout, H, W, k, stride, pad,
               _p(ws), nb, _stream())
+    _probe_act(y, bias, act)
     return y
 
 
@@ -985,6 +1009,7 @@ def linear_fwd(x, w, b=None, act=None, out=None):
     if tuple(y.shape) != (M, N):
         raise GenesisHipError('linear_fwd: out is %s, expected (%d, %d)' % (tuple(y.shape), M, N))
     _lib.call('gx_linear_fwd_ld', _p(x), ldx, _p(w), _p(b), ACTS[act], _p(y), ldy, M, N, K, _stream())
+    _probe_act(y, b, act)
     return y
 
 

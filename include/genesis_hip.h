@@ -159,6 +159,11 @@ int gx_gn_relu_bwd_proj(const float* y, const float* gamma, const float* beta, c
  *      kernel also emits the per-image partials of the 1x1 conv's weight / bias gradient (its input exists only inside
  *      this kernel); gx_conv1x1_gn_wgrad_finish sums them over the images -- no separate weight-gradient pass over y. */
 int gx_gn_relu_bwd_proj_fuses_wgrad(int C, int H, int W, int groups, int Cout);
+/*      Test diagnostic: the number of elements of relu(gn(y)) that are > 0, evaluated with the expression the kernels above use
+ *      for their ReLU decision ((y - mean) * rstd * gamma + beta > 0) -- the count the reference's nn.ReLU modules
+ *      (modules/blocks.py:164, models/genesisv2_config.py:92-98) would report for (out > 0).sum().  *count: device uint64. */
+int gx_gn_relu_active_count(const float* y, const float* gamma, const float* beta, const float* mean, const float* rstd, int N,
+                            int C, int H, int W, int groups, unsigned long long* count, gx_stream_t stream);
 /*      workspace of gx_gn_relu_bwd_proj (>= gx_gn_relu_bwd_ws_bytes): slabs too large for one workgroup (128 x 128 images) are
  *      processed in 4096-pixel chunks -- chunk sums, per-slab constants, chunked apply -- whose records live here */
 size_t gx_gn_relu_bwd_proj_ws_bytes(int N, int C, int H, int W, int groups, int Cout);

@@ -67,6 +67,37 @@ def is_param(k):
     return not (k == 'std' or k.endswith('running_mean') or k.endswith('running_var') or k.endswith('num_batches_tracked'))
 
 
+def hook_relus(model):
+    """Per-layer ReLU pattern of the reference's forward: every nn.ReLU inside an nn.Sequential gets its own instance (the
+    ComponentVAE hands ONE activation module to all of its layers, modules/component_vae.py:36-47: behaviour unchanged) and a
+    forward hook that adds (out > 0).sum() / out.numel() to the site named after the nearest parametrised sibling in front
+    of it (`encoder.down.0.1` = the GroupNorm of that block, `z_head.1` = the Linear, `comp_vae.decoder_module.seq.1` = the
+    conv).  Returns {site: [active, outputs]}, filled by the forwards that follow (summed over calls: feat_head runs K
+    times, the recurrent UNet of MONet K - 1 times)."""
+    import torch.nn as nn
+    counts = {}
+    for sname, seq in list(model.named_modules()):
+        if not isinstance(seq, nn.Sequential):
+            continue
+        for i, child in enumerate(list(seq)):
+            if not isinstance(child, nn.ReLU):
+                continue
+            j = i - 1
+            while j >= 0 and not any(True for _ in seq[j].parameters(recurse=False)):
+                j -= 1
+            assert j >= 0, (sname, i)
+            site = '%s.%d' % (sname, j)
+            fresh = nn.ReLU(inplace=child.inplace)
+            seq[i] = fresh
+            counts[site] = [0, 0]
+
+            def hook(mod, inp, out, site=site):
+                counts[site][0] += int((out > 0).sum())
+                counts[site][1] += out.numel()
+            fresh.register_forward_hook(hook)
+    return counts
+
+
 class Family(object):
     """What differs between the three model families: noise shapes, the forward call with replayed noise, the named
     outputs, the aggregation of the loss terms (train.py:226-242) and the oracle entry point."""
@@ -166,9 +197,18 @@ def run_case(name, mods):
     for i, nz in enumerate(noise):
         T.pack_summary('in/noise%d' % i, nz, out)
 
+    relu = hook_relus(model)
     torch.manual_seed(nseed)
     res = model(x)
+    relu_snapshot = {k: tuple(v) for k, v in relu.items()}
+    for v in relu.values():           # (the training steps further down run the hooks too: only this forward is recorded)
+        v[0] = v[1] = -1 << 60
     recon, losses, stats, att, comp = res
+    # the per-layer ReLU pattern of THIS forward (the GPU test grants its ReLU-decision allowance only where the HIP
+    # forward's count differs): sites in module order, active outputs, outputs
+    out['relu_sites'] = np.array(sorted(relu_snapshot) or [''])
+    out['relu_active'] = np.array([relu_snapshot[k][0] for k in sorted(relu_snapshot)], dtype=np.int64)
+    out['relu_outputs'] = np.array([relu_snapshot[k][1] for k in sorted(relu_snapshot)], dtype=np.int64)
     # the replayed noise is what the reference drew
     if fam == 'v2':
         assert torch.allclose(comp['mu_k'][1] + comp['sigma_k'][1] * noise[2], comp['z_k'][1], atol=1e-6)

@@ -12,6 +12,13 @@ strided samples: |HIP - reference| <= GRAD_FACTOR x budget + GRAD_FLOOR + RELU_F
 measured distance of the reference's OWN fp32 gradient from the fp64 gradient (same weights, inputs, noise): two correct
 fp32 implementations differ by about that much.
 
+RELU_FLIP is granted only where it applies (round 5): the fixtures carry the reference's per-layer ReLU pattern (active outputs of
+every nn.ReLU, make_golden_fullbatch.py:hook_relus) and the HIP forward reports its own per layer (hip_ops.RELU_PROBE: the kernels'
+own decision expression, gx_gn_relu_active_count; exact counts of the materialised activations elsewhere).  A parameter gets the
+allowance only if some layer DOWNSTREAM of it (a layer its gradient is back-propagated through) has a different count; every other
+parameter -- and every parameter of a model without ReLUs (GENESIS: ELU and sigmoid gates) -- is held to GRAD_FACTOR x budget +
+GRAD_FLOOR.  The test prints the differing layers and the worst error / bar either way.
+
 RELU_FLIP.  A step at these sizes evaluates ~1e8 ReLUs; a pre-activation within fp32 round-off of zero (|y| ~ 1e-7: a
 handful per step) may fall on either side in two correct fp32 evaluation orders, and ONE such decision moves every upstream
 gradient by ~1e-3 relative (measured, tools/diag_unet_masks.py: the UNet backward at B = 32 sits 1.6e-3 from the fp64
@@ -42,6 +49,49 @@ EXPECT_KERNELS = {
     'genesis_cfg3_b32': ('kq_c3h_kernel', 'wgq_stream_kernel'),
     'monet_cfg4_b32': ('kq_c3h_kernel', 'wgq_stream_kernel'),
 }
+
+
+# forward order of the parameter groups per family: a ReLU decision of a layer enters the gradient of every parameter in front
+# of it (and of the layer itself).  MONet's attention UNet is recurrent with shared weights: a decision in any pass touches all of it.
+STAGES = {
+    'v2': ('encoder.down.', 'encoder.mlp.', 'encoder.up.', 'seg_head.', 'att_process.', 'feat_head.', 'z_head.', 'decoder_module.'),
+    'monet': ('att_process.', 'comp_vae.encoder_module.module.', 'comp_vae.decoder_module.seq.'),
+    'genesis': (),
+}
+
+
+def _stage_index(fam, name):
+    """(stage number, layer index inside the stage) of a parameter / ReLU-site name."""
+    for i, pre in enumerate(STAGES[fam]):
+        if name.startswith(pre):
+            head = name[len(pre):].split('.')[0]
+            return i, (int(head) if head.isdigit() else 0)
+    return None
+
+
+def upstream_of(fam, site, pname):
+    """Does the gradient of parameter `pname` pass through the ReLU of `site`?"""
+    s_, p_ = _stage_index(fam, site), _stage_index(fam, pname)
+    if s_ is None or p_ is None:
+        return False                              # (the AR prior, the output conv behind the last ReLU: behind every ReLU)
+    if fam == 'monet' and s_[0] == 0:
+        return p_[0] == 0                         # recurrent UNet, shared weights
+    if fam == 'v2' and site.startswith('feat_head.') and (pname.startswith('seg_head.') or pname.startswith('att_process.')):
+        return False                              # parallel heads on the encoder features
+    return p_[0] < s_[0] or (p_[0] == s_[0] and p_[1] <= s_[1])
+
+
+def relu_sites_of_run(model, probe):
+    """{site: [active, outputs]} of a HIP forward from hip_ops.RELU_PROBE records (keyed by the layer's affine / bias parameter)."""
+    by_ptr = {p.data_ptr(): n for n, p in model.named_parameters()}
+    sites = {}
+    for ptr, cnt, numel in probe:
+        name = by_ptr[ptr]
+        site = name.rsplit('.', 1)[0]
+        a = sites.setdefault(site, [0, 0])
+        a[0] += int(cnt.item())
+        a[1] += int(numel)
+    return sites
 
 
 def st(l):
@@ -189,7 +239,9 @@ def test_default_dispatch_vs_reference_at_benchmark_batch(case, min_wino=0):
     gold = Full(case)
     model = gold.build()
     x, nz = gold.x(), gold.noise(check=True)
+    from genesis_amd import hip_ops
     profiling.enable(True)
+    hip_ops.RELU_PROBE = probe = []
     try:
         out = gold.forward(model, x, nz)
         flips = 0
@@ -205,7 +257,9 @@ def test_default_dispatch_vs_reference_at_benchmark_batch(case, min_wino=0):
             print('%s: seed pixels differing from the reference: %d of %d' % (case, flips, bad.size))
             if flips:
                 assert flips <= 2 and float(gold.g['seed_margin'][bad].max()) < 1e-4, (flips, gold.g['seed_margin'][bad])
+                del probe[:]
                 out = gold.forward(model, x, nz, torch.from_numpy(ref_idx).to(DEV))
+        hip_ops.RELU_PROBE = None
         recon, losses, stats, att, comp = out
         tol = FWD_TOL[gold.fam]
         for key, t in gold.named(out).items():
@@ -222,6 +276,20 @@ def test_default_dispatch_vs_reference_at_benchmark_batch(case, min_wino=0):
         rows = {r['name']: r['launches'] for r in profiling.collect()}
     finally:
         profiling.enable(False)
+        hip_ops.RELU_PROBE = None
+    # --- the ReLU pattern per layer: HIP forward against the reference's
+    ref_sites = {str(k): (int(a), int(n)) for k, a, n in zip(gold.g['relu_sites'], gold.g['relu_active'], gold.g['relu_outputs']) if str(k)}
+    got_sites = relu_sites_of_run(model, probe)
+    assert set(got_sites) == set(ref_sites), (sorted(set(got_sites) ^ set(ref_sites)))
+    differing = []
+    for site, (ra, rn) in sorted(ref_sites.items()):
+        ha, hn = got_sites[site]
+        # (feat_head runs K times in the reference and once here: compare active / outputs as exact fractions)
+        assert rn % hn == 0 or hn % rn == 0, (site, rn, hn)
+        if ra * hn != ha * rn:
+            differing.append((site, ha * rn / hn - ra))
+    print('%s: layers whose ReLU pattern differs from the reference\'s (HIP - reference active outputs): %s'
+          % (case, ', '.join('%s %+g' % d for d in differing) or 'none of %d' % len(ref_sites)))
     for kname in EXPECT_KERNELS[case]:
         assert any(k.startswith(kname) and v > 0 for k, v in rows.items()), (kname, sorted(rows))
     assert rows.get('wino_conv_kernel', 0) >= min_wino, rows
@@ -241,13 +309,14 @@ def test_default_dispatch_vs_reference_at_benchmark_batch(case, min_wino=0):
         den = max(float(gold.g['grad_norms_f64'][i]), 1e-6 * gmax) * np.sqrt(len(ref) / max(1, int(s['n'])))
         e_samples = float(np.linalg.norm(s['samples'].astype(np.float64) - ref)) / den
         e_norm = abs(float(g.double().norm()) - float(norms[i])) / max(float(gold.g['grad_norms_f64'][i]), 1e-6 * gmax)
-        bar = GRAD_FACTOR * float(budget[i]) + GRAD_FLOOR + RELU_FLIP
-        table.append((max(e_samples, e_norm) / bar, name, e_samples, e_norm, float(budget[i])))
+        flip = any(upstream_of(gold.fam, site, name) for site, _ in differing)
+        bar = GRAD_FACTOR * float(budget[i]) + GRAD_FLOOR + (RELU_FLIP if flip else 0.0)
+        table.append((max(e_samples, e_norm) / bar, name, e_samples, e_norm, float(budget[i]), flip))
         worst = max(worst, max(e_samples, e_norm) / bar)
     table.sort(reverse=True)
     print('%s: worst gradient error / bar = %.3f; the five largest (samples rel-L2, norm rel, budget):' % (case, worst))
     for r in table[:5]:
-        print('   %-52s %.2e %.2e  budget %.2e  (%.2f of the bar)' % (r[1], r[2], r[3], r[4], r[0]))
+        print('   %-52s %.2e %.2e  budget %.2e  (%.2f of the bar%s)' % (r[1], r[2], r[3], r[4], r[0], ', ReLU allowance' if r[5] else ''))
     assert worst <= 1.0, table[0]
     for key in ('log_m_k',) + (('log_m_r_k',) if gold.fam != 'genesis' else ()):
         assert float((torch.stack(list(stats[key]), 4).exp().sum(4) - 1).abs().max()) < 1e-3      # utils/misc.py:258-270
