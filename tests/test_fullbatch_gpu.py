@@ -38,7 +38,9 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 GOLDEN = osp.join(osp.dirname(osp.abspath(__file__)), 'golden')
 CASES = ['v2_metric_b32', 'v2_cfg2_b64', 'v2_cfg5_b4', 'genesis_cfg3_b32', 'monet_cfg4_b32']
-GRAD_FACTOR = 3.0
+GRAD_FACTOR = 5.0      # |HIP - reference| <= |HIP - fp64| + |reference - fp64| <= (4 + 1) x budget: the fp64 error-budget tests' own bar for the
+                       # HIP path is 4 x the CPU fp32 error (tests/test_error_budget_gpu.py); measured without any ReLU allowance: GENESIS
+                       # (no ReLU in the model) 3.5 x on one BatchNorm bias of 32 values, everything else <= 2.4 x
 GRAD_FLOOR = 5e-5
 RELU_FLIP = 3e-3
 # kernels of the chip-filling dispatch that must have run (profiling rows) per case
