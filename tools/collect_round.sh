@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/round_$TAG
 mkdir -p $OUT
 cd $R
-Q="--cpu-seconds 0 --fp32-pipe-steps 0 --host-input-steps 0"
+Q="--cpu-seconds 0 --fp32-pipe-steps 0 --host-input-steps 0 --extra-leg-steps 0"
 # 1. the default bench line (with the CPU baseline and the fp32-pipe-only leg), kernel stats, HBM traffic (two PMC passes)
 bash tools/collect_profiles.sh > $OUT/collect_profiles.log 2>&1
 cp gpurun_out/profiles_new/bench_1gpu.json $OUT/bench_1gpu.json

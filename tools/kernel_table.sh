@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d /tmp/ks -o ks --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --cpu-seconds 0 --profile-steps 0 --host-input-steps 0 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/ks -o ks --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --cpu-seconds 0 --profile-steps 0 --host-input-steps 0 --extra-leg-steps 0 > /dev/null 2>&1
 python - <<'PY'
 import csv,glob
 f=glob.glob('/tmp/ks/**/ks_kernel_stats.csv',recursive=True)[0]

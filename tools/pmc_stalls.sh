@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/profiles_new
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export GENESIS_BENCH_LONG_STEPS=0
-CMD="python $R/bench.py --steps 2 --warmup 1 --no-graph --profile-steps 0 --cpu-seconds 0 --fp32-pipe-steps 0 --host-input-steps 0 $STALL_BENCH_ARGS"
+CMD="python $R/bench.py --steps 2 --warmup 1 --no-graph --profile-steps 0 --cpu-seconds 0 --fp32-pipe-steps 0 --host-input-steps 0 --extra-leg-steps 0 $STALL_BENCH_ARGS"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --kernel-trace -d /tmp/ps1 -o s --output-format csv -- $CMD > /tmp/ps1.log 2>&1 || tail -5 /tmp/ps1.log
 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT GRBM_GUI_ACTIVE --kernel-trace -d /tmp/ps2 -o s --output-format csv -- $CMD > /tmp/ps2.log 2>&1 || tail -5 /tmp/ps2.log
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY --kernel-trace -d /tmp/ps3 -o s --output-format csv -- $CMD > /tmp/ps3.log 2>&1 || tail -5 /tmp/ps3.log

@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/tm_$M
-rocprofv3 --kernel-trace --stats -d /tmp/tm_$M -o t --output-format csv -- python $R/bench.py --model $M --steps 6 --warmup 2 --cpu-seconds 0 --profile-steps 0 --fp32-pipe-steps 0 --host-input-steps 0 "$@" > /tmp/tm_$M.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/tm_$M -o t --output-format csv -- python $R/bench.py --model $M --steps 6 --warmup 2 --cpu-seconds 0 --profile-steps 0 --fp32-pipe-steps 0 --host-input-steps 0 --extra-leg-steps 0 "$@" > /tmp/tm_$M.log 2>&1
 T=$(find /tmp/tm_$M -name "t_kernel_trace.csv" | head -1); S=$(find /tmp/tm_$M -name "t_kernel_stats.csv" | head -1)
 cp $S $R/gpurun_out/trace_${M}_kernel_stats.csv
 python - <<PY

@@ -1,4 +1,4 @@
-cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace -d /tmp/prof6 -o r04 --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --cpu-seconds 0 --profile-steps 0 --fp32-pipe-steps 0 --host-input-steps 0 > /tmp/prof6.log 2>&1; python - <<PY
+cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace -d /tmp/prof6 -o r04 --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --cpu-seconds 0 --profile-steps 0 --fp32-pipe-steps 0 --host-input-steps 0 --extra-leg-steps 0 > /tmp/prof6.log 2>&1; python - <<PY
 import csv
 rows=list(csv.DictReader(open("/tmp/prof6/r04_kernel_trace.csv")))
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
