@@ -1,0 +1,189 @@
+"""The reference's training loop UNCHANGED (train.py:223-263: optimiser.zero_grad(); model(x); ...; loss.backward();
+optimiser.step()) on the step machinery of `TrainStep`, without the loop knowing.
+
+`TrainStep` gets its speed from three things the plain autograd path does not have: every conv weight is packed ONCE per iteration
+(gx_weight_cache_*: one launch instead of one per conv call), the weight gradients of a backward pass run as ONE stream-K launch and
+their split-K / GroupNorm-affine reductions as one batched launch each (gx_defer_*), and parameter gradients are written straight
+into their buffers (no per-parameter accumulation launch).  None of this needs the loop's cooperation:
+
+  * `arm(model)` -- called by the model's own forward() in training mode with autograd on -- refreshes (first time: records) the
+    model's packed-weight cache and remembers the model;
+  * the first HIP autograd node of the following backward pass (`begin_backward`, from functions.ctx_bound) -- if every parameter's
+    .grad is None, which is what `optimiser.zero_grad()` leaves -- gives the parameters zeroed gradient views of ONE flat buffer (one
+    fill launch), switches the Functions to direct gradient writes + deferred reductions, and queues an end-of-backward callback on
+    the autograd engine (the hook DistributedDataParallel finalises its buckets with);
+  * that callback (`end_backward`) flushes the queued launches, releases the weight cache and switches everything off again.
+
+After `loss.backward()` returns, every parameter has its .grad exactly as the plain path would have left it (up to the summation
+order of the split-K slabs: the stream-K launch cuts the tile line differently from per-layer launches), and `torch.optim.*.step()`
+consumes them as usual.  Anything unusual -- gradients already present (accumulation over several backward passes), a forward
+without a backward, an exception inside backward -- falls back to the plain path: the state is reset at the next arm().
+`GENESIS_AUTOSTEP=0` switches the whole mechanism off (the plain per-call path).  Measured on the metric configuration
+(tools/ref_loop_time.py): see DESIGN.md section 7."""
+import os
+import weakref
+
+import torch
+
+from . import _lib
+from . import hip_ops as _hip
+
+ENABLED = os.environ.get('GENESIS_AUTOSTEP', '1') != '0'
+
+
+class _State(object):
+    __slots__ = ('models', 'in_pass', 'direct', 'cache_on', 'recording', 'ctx')
+
+    def __init__(self):
+        self.models = []          # weak references to the models armed since the last backward pass
+        self.in_pass = False      # a backward pass is running under this mechanism
+        self.direct = False       # ... with direct gradient writes + deferred reductions
+        self.cache_on = None      # id of the weight cache that is serving / recording
+        self.recording = False
+        self.ctx = 0
+
+
+_STATE = _State()
+
+
+def _fn():
+    from . import functions
+    return functions
+
+
+def _reset():
+    """Back to the plain path: whatever an unfinished pass left behind is dropped."""
+    st = _STATE
+    if st.direct:
+        s = _fn().step_state()
+        s.direct_param_grads = False
+        _hip.defer_state().on = False
+        _hip.defer_discard()
+    if st.cache_on is not None:
+        if st.recording:
+            _lib.call('gx_weight_cache_record', st.cache_on, 0)
+        else:
+            _lib.call('gx_weight_cache_release')
+    st.models, st.in_pass, st.direct, st.cache_on, st.recording = [], False, False, None, False
+
+
+def arm(model):
+    """Top of a model's forward().  No-op unless: enabled, training mode, autograd on, not inside a stream capture, and no TrainStep
+    (or other owner of the library's step switches) active in this library context."""
+    if not ENABLED or not model.training or not torch.is_grad_enabled():
+        return
+    if _lib.current_ctx() != 0 or _fn().step_state().direct_param_grads and not _STATE.direct:
+        return                                         # a TrainStep owns this thread's step state
+    if torch.cuda.is_current_stream_capturing():
+        return
+    st = _STATE
+    if st.in_pass or st.cache_on is not None or st.direct:
+        _reset()                                       # (a forward without a backward, or a backward that raised)
+    st.ctx = _lib.current_ctx()
+    cache = model.__dict__.get('_gx_autostep_cache')
+    key = _param_key(model)
+    if cache is not None and cache[2] != key:
+        # the parameters moved (a TrainStep re-homed them into its flat bucket, .to(), load of another state): the recorded
+        # (weight pointer, layout) pairs are stale -- start over
+        _lib.call('gx_weight_cache_destroy', cache[0])
+        cache[0], cache[1], cache[2] = int(_lib.query('gx_weight_cache_create')), False, key
+    if cache is None:
+        cache = [int(_lib.query('gx_weight_cache_create')), False, key]     # [id, recorded, parameter key]
+        model.__dict__['_gx_autostep_cache'] = cache
+        weakref.finalize(model, _destroy_cache, cache)
+    if not cache[1]:
+        _lib.call('gx_weight_cache_record', cache[0], 1)
+        st.recording = True
+    else:
+        _lib.call('gx_weight_cache_refresh', cache[0], _hip._stream())
+        st.recording = False
+    st.cache_on = cache[0]
+    st.models = [weakref.ref(model)]
+
+
+def _param_key(model):
+    ps = list(model.parameters())
+    return (len(ps), ps[0].data_ptr(), ps[-1].data_ptr(), id(ps[0]), id(ps[-1])) if ps else (0,)
+
+
+def _destroy_cache(cache):
+    try:
+        if _STATE.cache_on == cache[0]:
+            _reset()
+        _lib.call('gx_weight_cache_destroy', cache[0])
+    except Exception:       # noqa: BLE001  (interpreter shutdown)
+        pass
+
+
+def begin_backward():
+    """From the first HIP autograd node of a backward pass (functions.ctx_bound)."""
+    st = _STATE
+    if not st.models or st.in_pass:
+        return
+    st.in_pass = True
+    models = [m() for m in st.models]
+    params = [p for m in models if m is not None for p in m.parameters() if p.requires_grad]
+    if params and all(p.grad is None for p in params):
+        owner = models[0]
+        flat = owner.__dict__.get('_gx_autostep_grads')
+        key = (len(params), id(params[0]), params[0].data_ptr(), id(params[-1]), params[-1].data_ptr())
+        if flat is None or flat[0] != key:
+            # one flat buffer per dtype, every parameter's gradient a 64-byte-aligned view of it (built once per model)
+            views, bufs = [], {}
+            for dt in sorted({p.dtype for p in params}, key=str):
+                ps = [p for p in params if p.dtype == dt]
+                al = 64 // ps[0].element_size()
+                offs, n = [], 0
+                for p in ps:
+                    offs.append(n)
+                    n += (p.numel() + al - 1) // al * al
+                buf = torch.zeros(n, dtype=dt, device=ps[0].device)
+                bufs[dt] = buf
+                views.extend((p, buf[o:o + p.numel()].view(p.shape)) for p, o in zip(ps, offs))
+            flat = (key, list(bufs.values()), views)
+            owner.__dict__['_gx_autostep_grads'] = flat
+        else:
+            for b in flat[1]:
+                b.zero_()
+        for p, v in flat[2]:
+            p.grad = v
+        s = _fn().step_state()
+        s.direct_param_grads = True
+        _fn().begin_direct_grads()
+        _hip.defer_state().on = True
+        st.direct = True
+    torch.autograd.Variable._execution_engine.queue_callback(end_backward)
+
+
+def end_backward():
+    st = _STATE
+    if not st.in_pass:
+        return
+    prev = _lib.current_ctx()
+    if prev != st.ctx:
+        _lib.make_current(st.ctx)
+    try:
+        if st.direct:
+            _fn().join_side_stream()
+            _hip.defer_flush()
+            s = _fn().step_state()
+            s.direct_param_grads = False
+            _hip.defer_state().on = False
+            st.direct = False
+        if st.cache_on is not None:
+            if st.recording:
+                _lib.call('gx_weight_cache_record', st.cache_on, 0)
+                for m in st.models:
+                    m = m()
+                    if m is not None and m.__dict__.get('_gx_autostep_cache', [None])[0] == st.cache_on:
+                        m.__dict__['_gx_autostep_cache'][1] = True
+            else:
+                _lib.call('gx_weight_cache_release')
+            st.cache_on, st.recording = None, False
+    finally:
+        st.models, st.in_pass = [], False
+        if prev != st.ctx:
+            try:
+                _lib.make_current(prev)
+            except Exception:       # noqa: BLE001
+                pass

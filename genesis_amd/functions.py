@@ -16,6 +16,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib
+from . import autostep as _auto
 from . import hip_ops as hip
 
 GROUPS = 8
@@ -59,6 +60,8 @@ def ctx_bound(cls):
         prev = _lib.current_ctx()
         _lib.make_current(ctx._gx_ctx)
         try:
+            if _auto._STATE.models and not _auto._STATE.in_pass and ctx._gx_ctx == 0:
+                _auto.begin_backward()          # the unchanged train.py loop: this backward pass on the step machinery
             return bwd(ctx, *grads)
         finally:
             if prev != ctx._gx_ctx:

@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from genesis_amd import autostep
 from genesis_amd import compat as _compat
 
 _compat.install()
@@ -166,6 +167,8 @@ class Genesis(nn.Module):
 
     def forward(self, x, eps_m=None, eps_c=None):
         """x [B,3,S,S] on the GPU.  eps_m: K x [B, ldim], eps_c: [K*B, comp_ldim] inject the rsample noise."""
+        if x.is_cuda:
+            autostep.arm(self)      # the unchanged train.py loop: this iteration on TrainStep's launch structure (autostep.py)
         if not x.is_cuda:
             from genesis_amd._lib import GenesisHipError
             raise GenesisHipError('Genesis: the HIP path needs device tensors; there is no CPU fallback')

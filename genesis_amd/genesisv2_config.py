@@ -21,6 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.distributions.normal import Normal
 
+from genesis_amd import autostep
 from genesis_amd import compat as _compat
 
 _compat.install()
@@ -262,6 +263,8 @@ class GenesisV2(nn.Module):
         """x [B,3,H,W] in [0,1] on the GPU.  The optional arguments inject the noise the reference draws
         internally (rand_pixel [B,1,H,W] uniform, modules/attention.py:177-178; eps [K,B,D] standard
         normal, models/genesisv2_config.py:157) and, for tie-break tests, the seed pixels [K-1,B]."""
+        if x.is_cuda:
+            autostep.arm(self)      # the unchanged train.py loop: this iteration on TrainStep's launch structure (autostep.py)
         B, _, H, W = x.shape
         K, D = self.K_steps, self.feat_dim
         dev = x.device

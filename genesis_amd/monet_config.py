@@ -15,6 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.distributions.normal import Normal
 
+from genesis_amd import autostep
 from genesis_amd import compat as _compat
 
 _compat.install()
@@ -147,6 +148,8 @@ class MONet(nn.Module):
 
     def forward(self, x, eps=None):
         """x [B,3,H,W] on the GPU; eps [K*B, ldim] injects the rsample noise (component_vae.py:73)."""
+        if x.is_cuda:
+            autostep.arm(self)      # the unchanged train.py loop: this iteration on TrainStep's launch structure (autostep.py)
         B = x.shape[0]
         K, L = self.K_steps, self.comp_vae.ldim
         log_m_k, log_s_k = self._attention(x)

@@ -6,6 +6,7 @@ import math
 import torch
 import torch.nn as nn
 
+from genesis_amd import autostep
 from genesis_amd import compat as _compat
 
 _compat.install()
@@ -50,6 +51,8 @@ class BaselineVAE(nn.Module):
 
     def forward(self, x, eps=None):
         """x [B,3,S,S] on the GPU; eps [B, ldim] injects the rsample noise (VAE.py:131-132)."""
+        if x.is_cuda:
+            autostep.arm(self)      # the unchanged train.py loop: this iteration on TrainStep's launch structure (autostep.py)
         if not x.is_cuda:
             from genesis_amd._lib import GenesisHipError
             raise GenesisHipError('BaselineVAE: the HIP path needs device tensors; there is no CPU fallback')

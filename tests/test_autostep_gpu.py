@@ -1,0 +1,139 @@
+"""The reference's loop UNCHANGED (train.py:223-263) picks up TrainStep's launch structure by itself (genesis_amd/autostep.py):
+one packed-weight refresh per iteration, one stream-K weight-gradient launch + batched reductions per backward pass, gradients
+written straight into (zeroed) .grad views -- and leaves exactly the state the plain autograd path leaves."""
+import pytest
+import torch
+
+from tests.common import Golden
+from tests.test_model_gpu import build
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _loop(model, x, noise, steps, autostep_on, zero=True, lr=1e-4):
+    from genesis_amd import autostep
+    prev = autostep.ENABLED
+    autostep.ENABLED = autostep_on
+    try:
+        opt = torch.optim.Adam(model.parameters(), lr=lr)
+        hist, grads = [], None
+        for it in range(steps):
+            if zero:
+                opt.zero_grad()
+            rp, eps = noise[it]
+            recon, losses, stats, att, comp = model(x.to(DEV), rp.to(DEV), torch.stack(eps).to(DEV))
+            err = losses.err.mean(0)
+            kl = torch.stack(losses.kl_l_k, dim=1).mean(dim=0).sum()
+            (err + kl).backward()
+            if it == 0:
+                grads = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+            opt.step()
+            hist.append(float(err + kl))
+        return hist, grads, {n: p.detach().clone() for n, p in model.named_parameters()}
+    finally:
+        autostep.ENABLED = prev
+
+
+def _state_is_clean():
+    from genesis_amd import _lib, autostep, functions as fn, hip_ops
+    st = autostep._STATE
+    assert not st.in_pass and not st.direct and st.cache_on is None and not st.models
+    assert not fn.step_state().direct_param_grads and not hip_ops.defer_state().on
+    assert _lib.query('gx_defer_pending') == 0
+
+
+@pytest.mark.parametrize('case', ['tiny', 'metric'])
+def test_unchanged_loop_on_the_step_machinery_equals_the_plain_path(case):
+    gold = Golden(case)
+    x, _, _ = gold.inputs()
+    noise = [gold.noise(1 + it) for it in range(3)]
+    h0, g0, p0 = _loop(build(gold), x, noise, 3, False)
+    h1, g1, p1 = _loop(build(gold), x, noise, 3, True)
+    _state_is_clean()
+    # the first iteration's forward is the same launches; its gradients differ by the split-K slabs' summation order only
+    assert abs(h0[0] - h1[0]) <= 1e-6 * abs(h0[0])
+    worst = 0.0
+    for n in g0:
+        den = float(g0[n].double().norm()) + 1e-6 * max(float(v.double().norm()) for v in g0.values())
+        worst = max(worst, float((g0[n].double() - g1[n].double()).norm()) / den)
+    assert worst <= 2e-5, worst
+    for a, b in zip(h0, h1):
+        assert abs(a - b) <= 2e-4 * abs(a), (h0, h1)
+    rel = max(float((p0[n].double() - p1[n].double()).norm() / (p0[n].double().norm() + 1e-12)) for n in p0)
+    assert rel <= 1e-3, rel          # (Adam's first steps are sign-like: lr-sized differences from round-off-sized gradient ones)
+
+
+def test_launch_structure_of_the_unchanged_loop():
+    """Second iteration on: ONE batched weight packing instead of one per conv call, the weight gradients as ONE stream-K launch."""
+    from genesis_amd import profiling
+    gold = Golden('metric')
+    x, _, _ = gold.inputs()
+    model = build(gold)
+    noise = [gold.noise(1 + it) for it in range(3)]
+    _loop(model, x, noise, 1, True)                       # records the packed-weight cache
+    profiling.enable(True)
+    try:
+        _loop(model, x, noise, 1, True)
+        rows = {r['name']: r['launches'] for r in profiling.collect()}
+    finally:
+        profiling.enable(False)
+    assert rows.get('wgq_stream_kernel', 0) == 1, rows
+    assert rows.get('pack_weights_kernel', 0) <= 4, rows          # (the cache serves the conv layers; a few per-call packings remain)
+    _state_is_clean()
+
+
+def test_gradient_accumulation_and_interrupted_passes_fall_back_to_the_plain_path():
+    from genesis_amd import autostep
+    gold = Golden('tiny')
+    x, _, _ = gold.inputs()
+    noise = [gold.noise(1)] * 2
+    # two backward passes without zero_grad: the second finds gradients in place -> plain accumulation, twice the gradient
+    model = build(gold)
+    prev, autostep.ENABLED = autostep.ENABLED, True
+    try:
+        def fb():
+            rp, eps = noise[0]
+            recon, losses, *_ = model(x.to(DEV), rp.to(DEV), torch.stack(eps).to(DEV))
+            (losses.err.mean(0) + torch.stack(losses.kl_l_k, dim=1).mean(dim=0).sum()).backward()
+        fb()
+        g1 = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+        fb()
+        for n, p in model.named_parameters():
+            assert torch.allclose(p.grad, 2 * g1[n], rtol=2e-4, atol=1e-6 * float(g1[n].abs().max() + 1e-12)), n
+        _state_is_clean()
+        # a forward that is never followed by a backward, then a normal iteration
+        model.zero_grad(set_to_none=True)
+        rp, eps = noise[0]
+        model(x.to(DEV), rp.to(DEV), torch.stack(eps).to(DEV))
+        fb()
+        for n, p in model.named_parameters():
+            assert torch.allclose(p.grad, g1[n], rtol=2e-4, atol=1e-6 * float(g1[n].abs().max() + 1e-12)), n
+        _state_is_clean()
+        # evaluation forwards do not arm anything
+        with torch.no_grad():
+            model(x.to(DEV), rp.to(DEV), torch.stack(eps).to(DEV))
+        model.eval()
+        model(x.to(DEV), rp.to(DEV), torch.stack(eps).to(DEV))
+        _state_is_clean()
+    finally:
+        autostep.ENABLED = prev
+
+
+def test_trainstep_and_the_unchanged_loop_coexist():
+    """A TrainStep re-homes the parameters into its flat bucket: the loop's packed-weight cache notices the moved pointers, and a
+    TrainStep iteration is never touched by the mechanism (it runs in its own library context)."""
+    from genesis_amd.trainer import TrainStep
+    gold = Golden('tiny')
+    x, _, _ = gold.inputs()
+    noise = [gold.noise(1 + it) for it in range(2)]
+    model = build(gold)
+    _loop(model, x, noise, 1, True)
+    ts = TrainStep(model, gold.S, lr=1e-4)
+    rp, eps = noise[1]
+    out = ts.step(x.to(DEV), rand_pixel=rp.to(DEV), eps=torch.stack(eps).to(DEV))
+    assert torch.isfinite(out).all()
+    ts.close()
+    h, _, _ = _loop(model, x, noise, 1, True)
+    assert h[0] == h[0] and abs(h[0]) < 1e9
+    _state_is_clean()
