@@ -598,6 +598,7 @@ def main():
     #      statements -- optimiser.zero_grad(); model(x); err / kl aggregation with torch.stack; elbo; mse / rmse; geco.loss();
     #      loss.backward(); torch.optim.Adam.step() -- issued eagerly from Python, one host read per iteration where
     #      utils/geco.py:45 has its `.item()`.  What a maintainer gets WITHOUT adopting TrainStep; `value` is TrainStep's graph.
+    #      (genesis_amd/autostep.py gives this loop TrainStep's launch structure without the loop knowing.)
     if rank == 0 and world == 1 and args.extra_leg_steps > 0 and args.model == 'genesisv2':
         from genesis_amd.geco import make_geco
         torch.cuda.synchronize()
@@ -642,7 +643,11 @@ def main():
                                           'loop': 'train.py:223-263 statement for statement on genesis_amd.genesisv2_config.load(cfg): eager '
                                                   'forward, torch autograd over the HIP Functions, genesis_amd.geco.GECO.loss + one host '
                                                   'read per iteration (utils/geco.py:45), torch.optim.Adam.step(); no TrainStep, no HIP '
-                                                  'graph, no flat bucket, no deferred weight-gradient launch'}
+                                                  'graph.  The model itself puts the iteration on TrainStep\'s launch structure '
+                                                  '(genesis_amd/autostep.py: one packed-weight refresh, one stream-K weight-gradient launch, '
+                                                  'gradients written into .grad views; GENESIS_AUTOSTEP=0: the per-call path); the loop is '
+                                                  'bound by the host\'s launch rate, not by the GPU (tools/ref_loop_time.py)',
+                                          'autostep': bool(__import__('genesis_amd.autostep', fromlist=['x']).ENABLED)}
         del model_r, optimiser
         result['config']['workload'] += ('; value = TrainStep (HIP-graph replay of the iteration; mse / rmse logging and the forward '
                                          'outputs no loss reads are off: priced in value_as_written); the unchanged train.py loop on the '

@@ -22,7 +22,13 @@ batches = [torch.rand(32, 3, 64, 64, generator=g).cuda() for _ in range(4)]
 sync = os.environ.get('REF_LOOP_SYNC', '1') != '0'
 
 
+T = {'zero_grad': 0.0, 'forward': 0.0, 'losses': 0.0, 'backward': 0.0, 'step': 0.0}
+SECT = bool(os.environ.get('REF_LOOP_SECTIONS'))         # host-side time per section (the GPU runs behind, asynchronously)
+
+
 def iteration(x):
+    if SECT:
+        return iteration_sections(x)
     optimiser.zero_grad()
     output, losses, stats, att_stats, comp_stats = model(x)
     err = losses.err.mean(0)
@@ -38,12 +44,36 @@ def iteration(x):
     return elbo
 
 
+def iteration_sections(x):
+    t = [time.perf_counter()]
+    optimiser.zero_grad(); t.append(time.perf_counter())
+    output, losses, stats, att_stats, comp_stats = model(x); t.append(time.perf_counter())
+    err = losses.err.mean(0)
+    kl_l = torch.stack(losses.kl_l_k, dim=1).mean(dim=0).sum()
+    elbo = (err + kl_l).detach()
+    mse_batched = ((x - output) ** 2).mean((1, 2, 3)).detach()
+    mse, rmse = mse_batched.mean(0), mse_batched.sqrt().mean(0)
+    loss = geco.loss(err, kl_l)
+    if sync:
+        float(geco.state[1])
+    t.append(time.perf_counter())
+    loss.backward(); t.append(time.perf_counter())
+    optimiser.step(); t.append(time.perf_counter())
+    for k, a, b in zip(T, t[:-1], t[1:]):
+        T[k] += b - a
+    return elbo
+
+
 for i in range(5):
     iteration(batches[i % 4])
+for k in T:
+    T[k] = 0.0
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for i in range(steps):
     e = iteration(batches[i % 4])
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
+if SECT:
+    print('host time per section (ms): ' + ', '.join('%s %.3f' % (k, 1e3 * v / steps) for k, v in T.items()))
 print('reference loop: %.3f ms / iteration (%.0f img/s), host sync per iteration: %s, final ELBO %.2f' % (1e3 * dt / steps, 32 * steps / dt, sync, float(e)))
