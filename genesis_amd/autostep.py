@@ -101,8 +101,18 @@ def arm(model):
     st.models = [weakref.ref(model)]
 
 
+def _params(model):
+    """The model's parameters, listed once (walking the module tree costs ~0.2 ms per call at 78 parameters: more than the
+    launches this mechanism saves would cost on the host)."""
+    ps = model.__dict__.get('_gx_autostep_params')
+    if ps is None:
+        ps = [p for p in model.parameters()]
+        model.__dict__['_gx_autostep_params'] = ps
+    return ps
+
+
 def _param_key(model):
-    ps = list(model.parameters())
+    ps = _params(model)
     return (len(ps), ps[0].data_ptr(), ps[-1].data_ptr(), id(ps[0]), id(ps[-1])) if ps else (0,)
 
 
@@ -122,7 +132,7 @@ def begin_backward():
         return
     st.in_pass = True
     models = [m() for m in st.models]
-    params = [p for m in models if m is not None for p in m.parameters() if p.requires_grad]
+    params = [p for m in models if m is not None for p in _params(m) if p.requires_grad]
     if params and all(p.grad is None for p in params):
         owner = models[0]
         flat = owner.__dict__.get('_gx_autostep_grads')
