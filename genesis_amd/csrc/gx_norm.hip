@@ -700,7 +700,10 @@ gn_relu_bwd_reg_kernel(const float* __restrict__ y, const float* __restrict__ ga
 // run in fp32 over the thread's F float4 (per vector lane: F terms) before they are combined in double.  At <= 64
 // VGPRs the second workgroup's loads fly while the first one computes and stores; the generic kernel (128 VGPRs, one
 // workgroup per CU) runs its load, compute and store phases back to back: 176 -> see DESIGN.md section 7 (decoder, 224 images).
-template <int F, int CT, bool WP>
+// KEEP = false (round 5, finding 35): y is NOT held in registers between the two passes but read again -- at 64 registers the 32
+// values of a thread plus the passes' temporaries spill (23 registers: 153 MB of scratch written and read back per launch at
+// 224 images), and the second read of a 128 KB slab a few microseconds after the first comes out of L2 / MALL, not HBM.
+template <int F, int CT, bool WP, bool KEEP>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
 gn_relu_bwd_stage_kernel(const float* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ beta,
                          const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
@@ -724,9 +727,11 @@ gn_relu_bwd_stage_kernel(const float* __restrict__ y, const float* __restrict__ 
     f32x4* dst4 = reinterpret_cast<f32x4*>(dy + slab_off) + cl * (HW >> 2) + part * q4 + lane;
     const f32x4* gs4 = reinterpret_cast<const f32x4*>(gsl) + part * q4 + lane;
     const float meanf = mean_in[blockIdx.x], rstdf = rstd_in[blockIdx.x];
-    f32x4 xr[F];
+    f32x4 xr[KEEP ? F : 1];
+    if constexpr (KEEP) {
 #pragma unroll
-    for (int j = 0; j < F; ++j) xr[j] = src4[j * 64];
+        for (int j = 0; j < F; ++j) xr[j] = src4[j * 64];
+    }
     {
         const f32x4* g4 = reinterpret_cast<const f32x4*>(g0.ptr + (size_t)n * g0.ctot * HW);
         for (int i = threadIdx.x; i < (g0.ctot * HW) >> 2; i += blockDim.x)
@@ -752,16 +757,19 @@ gn_relu_bwd_stage_kernel(const float* __restrict__ y, const float* __restrict__ 
         int jo = j * 64;
         asm volatile("" : "+v"(jo) : "v"(sa), "v"(sb));
         f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        f32x4& xv = xr[KEEP ? j : 0];
+        if constexpr (!KEEP) xv = src4[jo];          // (jo depends on the previous iteration's sums: one load in flight per thread;
+                                                     //  a second one in flight measured the same, 153 vs 154 us)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) xr[j][e] = (xr[j][e] - meanf) * rstdf;
+        for (int e = 0; e < 4; ++e) xv[e] = (xv[e] - meanf) * rstdf;
 #pragma unroll
         for (int q = 0; q < CT; ++q) g += pw[q] * gs4[q * rowq + jo];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float pre = xr[j][e] * gm + bt;
+            const float pre = xv[e] * gm + bt;
             g[e] = pre > 0.f ? g[e] : 0.f;
         }
-        sa += (g[0] * xr[j][0] + g[1] * xr[j][1]) + (g[2] * xr[j][2] + g[3] * xr[j][3]);
+        sa += (g[0] * xv[0] + g[1] * xv[1]) + (g[2] * xv[2] + g[3] * xv[3]);
         sb += (g[0] + g[1]) + (g[2] + g[3]);
     }
     if (bpart && gidx == 0) {   // bias gradient partial of the 1x1 conv: sum_p g_out[q][p], one wave per row q
@@ -811,9 +819,15 @@ gn_relu_bwd_stage_kernel(const float* __restrict__ y, const float* __restrict__ 
         if (WP) asm volatile("" : "+v"(jo) : "v"(sd), "v"(k1), "v"(wacc[0]), "v"(wacc[1]), "v"(wacc[2]), "v"(wacc[3]));
         else asm volatile("" : "+v"(jo) : "v"(sd), "v"(k1));
         f32x4 g = {0.f, 0.f, 0.f, 0.f}, o, a;
+        f32x4& xv = xr[KEEP ? j : 0];
+        if constexpr (!KEEP) {
+            xv = src4[jo];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xv[e] = (xv[e] - meanf) * rstdf;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float t = xr[j][e] * gm2 + bt2;
+            const float t = xv[e] * gm2 + bt2;
             a[e] = t > 0.f ? t : 0.f;
         }
 #pragma unroll
@@ -824,13 +838,13 @@ gn_relu_bwd_stage_kernel(const float* __restrict__ y, const float* __restrict__ 
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float pre = xr[j][e] * gm2 + bt2;
+            const float pre = xv[e] * gm2 + bt2;
             const float gv = pre > 0.f ? g[e] : 0.f;
-            const float d = rstdf * (gv * gm2 - k1 - xr[j][e] * k2);
+            const float d = rstdf * (gv * gm2 - k1 - xv[e] * k2);
             o[e] = d;
         }
         sd += (o[0] + o[1]) + (o[2] + o[3]);
-        dst4[j * 64] = o;
+        dst4[jo] = o;
     }
     {
         const double v = gx_wave_sum_d((double)sd);
@@ -1000,18 +1014,26 @@ bool launch_bwd_stage(dim3 grid, dim3 block, hipStream_t s, size_t lds, const fl
     if (UPW != 1 || block.x != 1024 || g0.ctot != 4 || (env && env[0] == '0')) return false;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_relu_bwd_stage_kernel<F, 4, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_relu_bwd_stage_kernel<F, 4, true, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_relu_bwd_stage_kernel<F, 4, false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_relu_bwd_stage_kernel<F, 4, false, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_relu_bwd_stage_kernel<F, 4, true, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_relu_bwd_stage_kernel<F, 4, false, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }
-    if (wpart)
-        hipLaunchKernelGGL((gn_relu_bwd_stage_kernel<F, 4, true>), grid, block, lds, s, y, gamma, beta, mean, rstd, C, H,
-                           W, groups, P, g0, g1, dy, part, wpart, bpart);
-    else
-        hipLaunchKernelGGL((gn_relu_bwd_stage_kernel<F, 4, false>), grid, block, lds, s, y, gamma, beta, mean, rstd, C, H,
-                           W, groups, P, g0, g1, dy, part, wpart, bpart);
+    // slabs of F >= 8 float4 per thread re-read y in the second pass instead of spilling it (GENESIS_GN_STAGE_KEEP=1: the
+    // register-resident form)
+    static const char* keep_env = getenv("GENESIS_GN_STAGE_KEEP");
+    const bool keep = F < 8 || (keep_env && keep_env[0] == '1');
+#define GX_STAGE_LAUNCH(WP_, KEEP_)                                                                                          \
+    hipLaunchKernelGGL((gn_relu_bwd_stage_kernel<F, 4, WP_, KEEP_>), grid, block, lds, s, y, gamma, beta, mean, rstd, C, H, W, \
+                       groups, P, g0, g1, dy, part, wpart, bpart)
+    if (wpart) { if (keep) GX_STAGE_LAUNCH(true, true); else GX_STAGE_LAUNCH(true, false); }
+    else { if (keep) GX_STAGE_LAUNCH(false, true); else GX_STAGE_LAUNCH(false, false); }
+#undef GX_STAGE_LAUNCH
     return true;
 }
 
