@@ -73,6 +73,21 @@ static inline int gx_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static inline int gx_ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int gx_round_up(int a, int b) { return gx_ceil_div(a, b) * b; }
 
+// XCD-aware block -> tile map (cdna_hip_programming.md T1).  The dispatcher is observed to place block b on XCD b % 8, each XCD with
+// its own 4 MB L2: with tile = block id, spatially adjacent tiles (which share their halo rows / columns) sit on eight different
+// L2s and every halo is fetched from HBM once per tile.  This bijection hands every XCD a CONTIGUOUS run of tiles (the blocks of an
+// XCD are dispatched in increasing id, so neighbours in the run are neighbours in time).  Speed only: any placement is correct.
+#ifdef __HIPCC__
+__device__ __forceinline__ int gx_xcd_tile(int bid, int nwg) {
+#ifdef GX_NO_XCD_SWIZZLE
+    return bid;
+#else
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+#endif
+}
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -466,7 +466,7 @@ __global__ void __launch_bounds__(256, 2)
 tapconv_kernel(const float* __restrict__ in, const float* __restrict__ wp,
                const float* __restrict__ bias, float* __restrict__ out, ConvGeom g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    tapconv_body<MODE, NPOS, DMA, MW, false, HH>(in, wp, bias, out, g, lds, blockIdx.x, blockIdx.y, blockIdx.z, g.par_a);
+    tapconv_body<MODE, NPOS, DMA, MW, false, HH>(in, wp, bias, out, g, lds, gx_xcd_tile(blockIdx.x, gridDim.x), blockIdx.y, blockIdx.z, g.par_a);
 }
 
 // Both output-row parities of the transposed conv in one launch: blockIdx.y = 2 * channel_tile + parity.  Twice
@@ -478,9 +478,9 @@ tapconv_dt_kernel(const float* __restrict__ in, const float* __restrict__ wp0, c
                   const float* __restrict__ bias, float* __restrict__ out, ConvGeom g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (blockIdx.y & 1)
-        tapconv_body<M_DT1, NPOS, DMA, MW, STATS>(in, wp1, bias, out, g, lds, blockIdx.x, blockIdx.y >> 1, blockIdx.z, 1);
+        tapconv_body<M_DT1, NPOS, DMA, MW, STATS>(in, wp1, bias, out, g, lds, gx_xcd_tile(blockIdx.x, gridDim.x), blockIdx.y >> 1, blockIdx.z, 1);
     else
-        tapconv_body<M_DT0, NPOS, DMA, MW, STATS>(in, wp0, bias, out, g, lds, blockIdx.x, blockIdx.y >> 1, blockIdx.z, 0);
+        tapconv_body<M_DT0, NPOS, DMA, MW, STATS>(in, wp0, bias, out, g, lds, gx_xcd_tile(blockIdx.x, gridDim.x), blockIdx.y >> 1, blockIdx.z, 0);
 }
 
 // GroupNorm statistics from the per-workgroup block sums the STATS epilogue wrote: stats [N][parts][nblk][2],

@@ -57,7 +57,7 @@ igemm_kernel(const float* __restrict__ a_src, const float* __restrict__ b_src, c
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = blockIdx.y * BM, n0 = gx_xcd_tile(blockIdx.x, gridDim.x) * BN;     // (XCD-aware: neighbouring pixel tiles share halos)
     const int kk2 = g.k * g.k;
     const int HW = g.H * g.W, HoWo = g.Ho * g.Wo;
 

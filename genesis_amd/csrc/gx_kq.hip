@@ -783,7 +783,8 @@ __global__ void __launch_bounds__(256, 2)
 kq_kernel(const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
           float* __restrict__ out, QGeom g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int bx = blockIdx.x;
+    // (XCD-aware tile map over the whole-tile workgroups: neighbouring tiles, which share halo rows, on one XCD's L2)
+    const int bx = (int)blockIdx.x < g.nfull ? gx_xcd_tile(blockIdx.x, g.nfull) : (int)blockIdx.x;
     if (bx < g.nfull) q_body<MODE, NQ, false, 2>(in, wp, bias, out, g, lds, bx, blockIdx.y, 0);
     else q_body<MODE, NQ, false, 1>(in, wp, bias, out, g, lds, g.nfull + ((bx - g.nfull) >> 1), blockIdx.y, 0, (bx - g.nfull) & 1);
 }
@@ -795,7 +796,8 @@ __global__ void __launch_bounds__(256, 2)
 kq_dt_kernel(const float* __restrict__ in, const float* __restrict__ wp0, const float* __restrict__ wp1,
              const float* __restrict__ bias, float* __restrict__ out, QGeom g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int bx = blockIdx.x;
+    // (XCD-aware tile map over the whole-tile workgroups: neighbouring tiles, which share halo rows, on one XCD's L2)
+    const int bx = (int)blockIdx.x < g.nfull ? gx_xcd_tile(blockIdx.x, g.nfull) : (int)blockIdx.x;
     if (bx < g.nfull) {
         if (blockIdx.z) q_body<Q_DT1, NQ, STATS, 2>(in, wp1, bias, out, g, lds, bx, blockIdx.y, 1);
         else q_body<Q_DT0, NQ, STATS, 2>(in, wp0, bias, out, g, lds, bx, blockIdx.y, 0);
@@ -810,7 +812,8 @@ template <int NQ>
 __global__ void __launch_bounds__(256, 2)
 kq_dgh_kernel(const float* __restrict__ in, const float* __restrict__ wp, float* __restrict__ out, QGeom g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int bx = blockIdx.x;
+    // (XCD-aware tile map over the whole-tile workgroups: neighbouring tiles, which share halo rows, on one XCD's L2)
+    const int bx = (int)blockIdx.x < g.nfull ? gx_xcd_tile(blockIdx.x, g.nfull) : (int)blockIdx.x;
     if (bx < g.nfull) q_body<Q_DGH, NQ, false, 2>(in, wp, nullptr, out, g, lds, bx, blockIdx.y, 0);
     else q_body<Q_DGH, NQ, false, 1>(in, wp, nullptr, out, g, lds, g.nfull + ((bx - g.nfull) >> 1), blockIdx.y, 0, (bx - g.nfull) & 1);
 }
@@ -824,7 +827,8 @@ kq_c3h_kernel(const float* __restrict__ in, const float* __restrict__ wp, const 
     // persistent workgroups (the grid is ~2 per CU): a tile's output stores drain while the next tile's loads are already in
     // flight -- a workgroup that ends after every tile waits for its stores before its LDS / registers are handed on, and with
     // two 16-channel chunks per tile that tail is a large part of a tile's life
-    for (int tile = blockIdx.x; tile < g.nfull; tile += gridDim.x) {
+    for (int t = blockIdx.x; t < g.nfull; t += gridDim.x) {
+        const int tile = gx_xcd_tile(t, g.nfull);
         q_body<Q_C3H, NQ, false, 1>(in, wp, bias, out, g, lds, tile, blockIdx.y, 0, 0);
         __syncthreads();          // the next tile's staging overwrites LDS the slowest wave may still be reading
     }
@@ -835,7 +839,7 @@ template <int NQ>
 __global__ void __launch_bounds__(256, 2)
 kq_c5h_kernel(const float* __restrict__ in, const float* __restrict__ wp, float* __restrict__ out, QGeom g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    q_body<Q_C5H, NQ, false, 2>(in, wp, nullptr, out, g, lds, blockIdx.x, blockIdx.y, 0);
+    q_body<Q_C5H, NQ, false, 2>(in, wp, nullptr, out, g, lds, gx_xcd_tile(blockIdx.x, gridDim.x), blockIdx.y, 0);
 }
 
 // the same launch shape on the bf16 matrix pipe (Q_DT0H / Q_DT1H)
@@ -844,7 +848,8 @@ __global__ void __launch_bounds__(256, 2)
 kq_dth_kernel(const float* __restrict__ in, const float* __restrict__ wp0, const float* __restrict__ wp1,
               const float* __restrict__ bias, float* __restrict__ out, QGeom g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int bx = blockIdx.x;
+    // (XCD-aware tile map over the whole-tile workgroups: neighbouring tiles, which share halo rows, on one XCD's L2)
+    const int bx = (int)blockIdx.x < g.nfull ? gx_xcd_tile(blockIdx.x, g.nfull) : (int)blockIdx.x;
     if (bx < g.nfull) {
         if (blockIdx.z) q_body<Q_DT1H, NQ, STATS, 2>(in, wp1, bias, out, g, lds, bx, blockIdx.y, 1);
         else q_body<Q_DT0H, NQ, STATS, 2>(in, wp0, bias, out, g, lds, bx, blockIdx.y, 0);

@@ -513,11 +513,13 @@ gn_relu_bwd_reg_kernel(const float* __restrict__ y, const float* __restrict__ ga
                        int C, int H, int W, int groups, int P, View g0, View g1,
                        float* __restrict__ dy, float* __restrict__ part_out, float* __restrict__ wpart,
                        float* __restrict__ bpart) {
+    // XCD-aware slab map: the groups of one image -- which all read the same projected-gradient source -- on one XCD's L2
+    const int slab_id = gx_xcd_tile(blockIdx.x, gridDim.x);
     __shared__ double uab[32 * 2];  // per unit: sum dpre*xhat, sum dpre
     __shared__ double usd[32];      // per unit: sum dy
     __shared__ float uw[32][8];     // STAGE + wpart: per unit, sum_p g_out[q][p] * relu(gn(y))[c][p]
     extern __shared__ __attribute__((aligned(16))) float gsl[];   // stage != 0: g0.ptr[n] ([ctot][HW]) of a mode-3 view
-    const int n = blockIdx.x / groups, gidx = blockIdx.x % groups;
+    const int n = slab_id / groups, gidx = slab_id % groups;
     const int cpg = C / groups, HW = H * W;
     const int m = cpg * HW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -526,7 +528,7 @@ gn_relu_bwd_reg_kernel(const float* __restrict__ y, const float* __restrict__ ga
     const size_t slab_off = ((size_t)n * C + (size_t)gidx * cpg) * HW;
     const f32x4* slab4 = reinterpret_cast<const f32x4*>(y + slab_off);
     f32x4* dslab4 = reinterpret_cast<f32x4*>(dy + slab_off);
-    const float meanf = mean_in[blockIdx.x], rstdf = rstd_in[blockIdx.x];
+    const float meanf = mean_in[slab_id], rstdf = rstd_in[slab_id];
     const int lW = __ffs(W) - 1;
     f32x4 xr[UPW][F], gr[UPW][F];
     if (STAGE) {
@@ -710,12 +712,14 @@ gn_relu_bwd_stage_kernel(const float* __restrict__ y, const float* __restrict__ 
                          int C, int H, int W, int groups, int P, View g0, View g1_unused,
                          float* __restrict__ dy, float* __restrict__ part_out, float* __restrict__ wpart,
                          float* __restrict__ bpart) {
+    // XCD-aware slab map: the groups of one image -- which all read the same projected-gradient source -- on one XCD's L2
+    const int slab_id = gx_xcd_tile(blockIdx.x, gridDim.x);
     __shared__ double uab[16 * 2];  // per unit: sum dpre*xhat, sum dpre
     __shared__ double usd[16];      // per unit: sum dy
     __shared__ float uw[16][8];     // wpart: per unit, sum_p g_out[q][p] * relu(gn(y))[c][p]
     extern __shared__ __attribute__((aligned(16))) float gsl[];   // g0.ptr[n] ([ctot][HW])
     (void)g1_unused;
-    const int n = blockIdx.x / groups, gidx = blockIdx.x % groups;
+    const int n = slab_id / groups, gidx = slab_id % groups;
     const int cpg = C / groups, HW = H * W;
     const int m = cpg * HW;
     const int lane = threadIdx.x & 63, unit = threadIdx.x >> 6;
@@ -726,7 +730,7 @@ gn_relu_bwd_stage_kernel(const float* __restrict__ y, const float* __restrict__ 
     const f32x4* src4 = reinterpret_cast<const f32x4*>(y + slab_off) + cl * (HW >> 2) + part * q4 + lane;
     f32x4* dst4 = reinterpret_cast<f32x4*>(dy + slab_off) + cl * (HW >> 2) + part * q4 + lane;
     const f32x4* gs4 = reinterpret_cast<const f32x4*>(gsl) + part * q4 + lane;
-    const float meanf = mean_in[blockIdx.x], rstdf = rstd_in[blockIdx.x];
+    const float meanf = mean_in[slab_id], rstdf = rstd_in[slab_id];
     f32x4 xr[KEEP ? F : 1];
     if constexpr (KEEP) {
 #pragma unroll

@@ -86,12 +86,16 @@ wino_conv_kernel(const float* __restrict__ in, const float* __restrict__ in2, co
     float* V = lds + 2 * RAW_FLOATS;        // [2][16][WKC][WNT]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    int tile = blockIdx.x;
+    // XCD-aware (tile, channel tile) map over the whole grid: neighbouring tiles (shared halos) AND the channel tiles of one tile (the
+    // same patches) are consecutive blocks of one XCD, i.e. one L2
+    const int xcd_l = gx_xcd_tile(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);
+    const int my = xcd_l % (int)gridDim.y;
+    int tile = xcd_l / (int)gridDim.y;
     const int tw_i = tile % g.tiles_w; tile /= g.tiles_w;
     const int th_i = tile % g.tiles_h; tile /= g.tiles_h;
     const int n = tile;
     const int R0 = th_i * (2 * WTH), C0 = tw_i * (2 * WTW);
-    const int m0 = blockIdx.y * 64;
+    const int m0 = my * 64;
     const int HW = g.H * g.W;
     // (pair data gradient: two input tensors, each with its own channel count and per-image block)
     const int Ka = g.K1 < g.K ? g.K1 : g.K, Kb = g.K - Ka;
@@ -142,7 +146,7 @@ wino_conv_kernel(const float* __restrict__ in, const float* __restrict__ in2, co
             rbuf[loff[q]] = rawr[q];
     };
     // this wave's weight operands: [m tile][chunk][position 4 wave + nu][lane][8]
-    const float* Uw = U + (((size_t)blockIdx.y * nchunks) * 16 + 4 * wave) * 512 + lane * 8;
+    const float* Uw = U + (((size_t)my * nchunks) * 16 + 4 * wave) * 512 + lane * 8;
 
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     f32x16 acc[4][2];     // [nu][mi]: one 32x32 accumulator tile each
@@ -417,12 +421,16 @@ wino_conv_h_kernel(const float* __restrict__ in, const float* __restrict__ in2, 
     float* raw = lds;                       // [2][HKC][PITCH]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    int tile = blockIdx.x;
+    // XCD-aware (tile, channel tile) map over the whole grid: neighbouring tiles (shared halos) AND the channel tiles of one tile (the
+    // same patches) are consecutive blocks of one XCD, i.e. one L2
+    const int xcd_l = gx_xcd_tile(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);
+    const int my = xcd_l % (int)gridDim.y;
+    int tile = xcd_l / (int)gridDim.y;
     const int tw_i = tile % g.tiles_w; tile /= g.tiles_w;
     const int th_i = tile % g.tiles_h; tile /= g.tiles_h;
     const int n = tile;
     const int R0 = th_i * (2 * C::TROWS), C0 = tw_i * (2 * WTW);
-    const int m0 = blockIdx.y * 64;
+    const int m0 = my * 64;
     const int HW = g.H * g.W;
     const int Ka = g.K1 < g.K ? g.K1 : g.K, Kb = g.K - Ka;
     const float* in_n = in + (size_t)n * Ka * HW;
@@ -473,7 +481,7 @@ wino_conv_h_kernel(const float* __restrict__ in, const float* __restrict__ in2, 
     }
 
     // ---- A operands: [m tile][chunk][position][piece][m half][lane][16 B]
-    const char* Uw = reinterpret_cast<const char*>(U) + ((size_t)blockIdx.y * nchunks * 16 + 4 * wave) * 6144 + lane * 16;
+    const char* Uw = reinterpret_cast<const char*>(U) + ((size_t)my * nchunks * 16 + 4 * wave) * 6144 + lane * 16;
     auto load_a = [&](w_bf16x8 (&a)[2][3], int c, int nu) {
         const char* p = Uw + ((size_t)c * 16 + nu) * 6144;
 #pragma unroll
