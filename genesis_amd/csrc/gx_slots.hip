@@ -41,9 +41,13 @@ __device__ __forceinline__ double block_sum_dd(double v, double* red) {
 // S[b][k][c] = sum_p exp(log_m[k][b][p]) * f[b][c][p];   msum[b][k] = sum_p exp(log_m[k][b][p])
 // grid (B, C/4): each block reduces 4 channels x K slots over the image.
 constexpr int PCH = 4;
+// KT: the slot count at compile time (0: run time): K x 5 double accumulators instead of 16 x 5, unguarded slot loops
+template <int KT>
 __global__ void __launch_bounds__(256)
-maskpool_fwd_kernel(const float* __restrict__ f, const float* __restrict__ log_m, int B, int C, int HW, int K,
+maskpool_fwd_kernel(const float* __restrict__ f, const float* __restrict__ log_m, int B, int C, int HW, int Krt,
                     float* __restrict__ S, float* __restrict__ msum) {
+    const int K = KT ? KT : Krt;
+    constexpr int KMAX = KT ? KT : ::KMAX;
     __shared__ double wred[4][KMAX * (PCH + 1)];
     const int b = blockIdx.x, c0 = blockIdx.y * PCH;
     const size_t kstride = (size_t)B * HW;
@@ -165,10 +169,13 @@ maskpool_bwd_kernel(const float* __restrict__ f, const float* __restrict__ log_m
 // 4 pixels per thread (16-byte accesses); the 4 waves of a workgroup share the same 256 pixels and split the channels
 // (the per-pixel channel loop is a chain of dependent load -> store steps: a quarter of the channels per wave and 4x
 // the waves in flight); their partial sum_c gS*f are combined through LDS in wave order.
+template <int KT>      // (the slot count at compile time, 0: run time -- as maskpool_fwd_kernel: 2 x K float4 of state instead of 2 x 16)
 __global__ void __launch_bounds__(256)
 maskpool_bwd_vec_kernel(const float* __restrict__ f, const float* __restrict__ log_m, const float* __restrict__ gS,
-                        const float* __restrict__ gmsum, int B, int C, int HW, int K, float* __restrict__ df,
+                        const float* __restrict__ gmsum, int B, int C, int HW, int Krt, float* __restrict__ df,
                         float* __restrict__ dlog_m) {
+    const int K = KT ? KT : Krt;
+    constexpr int KMAX = KT ? KT : ::KMAX;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* gsh = sm;                                                    // [K][C]
     f32x4* ared = reinterpret_cast<f32x4*>(sm + ((K * C + 3) & ~3));    // [4 waves][K][64 lanes]
@@ -231,15 +238,20 @@ maskpool_bwd_vec_kernel(const float* __restrict__ f, const float* __restrict__ l
 // dec [K*B, 4, HW] slot-major (row k*B+b): channels 0..2 RGB pre-activation, 3 mask logit.
 constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
 
-template <bool BWD>
+// KT: the slot count as a compile-time constant (0: run time, `Krt`).  With the K < KMAX guards of the unrolled slot loops folded
+// away the 4 K + 3 loads of a pixel are independent instructions hipcc issues together; with run-time guards they are a chain of
+// guarded loads (load - wait - branch), and this one-pixel-per-thread kernel at two waves per SIMD is bound by exactly that latency.
+template <bool BWD, int KT>
 __global__ void __launch_bounds__(256)
-mixture_kernel(const float* __restrict__ x, const float* __restrict__ dec, int B, int HW, int K, float std_,
+mixture_kernel(const float* __restrict__ x, const float* __restrict__ dec, int B, int HW, int Krt, float std_,
                int pixel_bound, float* __restrict__ recon, float* __restrict__ x_r, float* __restrict__ log_m_r,
                float* __restrict__ err_part, const float* __restrict__ g_err, float* __restrict__ ddec,
                const float* __restrict__ log_w, float* __restrict__ dlog_w, float std_first, int DC) {
     // DC = channels of `dec` per slot: 4 (RGB + mask logit) or 3 (GENESIS: RGB only, needs log_w)
     // log_w != NULL (MONet, models/monet_config.py:94-105): the mixing log-weights are the ATTENTION masks
     // [K,B,HW] instead of log_softmax(logits); the first slot may use its own pixel std (std_first).
+    const int K = KT ? KT : Krt;
+    constexpr int KMAX = KT ? KT : ::KMAX;          // (shadows the file's bound: the unrolled loops run to the actual slot count)
     __shared__ double red[4];
     const int b = blockIdx.x;
     const int p = blockIdx.y * blockDim.x + threadIdx.x;
@@ -710,8 +722,11 @@ int gx_maskpool_fwd(const float* f, const float* log_m, int B, int C, int H, int
     GX_CHECK_ARG(B > 0 && C > 0 && K >= 1 && K <= KMAX && H > 0 && W > 0, "gx_maskpool_fwd: bad dims (K<=16)");
     {
         GxProf pf(KID_MASKPOOL_FWD, (hipStream_t)stream, 2.0 * B * K * C * H * W, 4.0 * B * H * W * (C + K));
-        hipLaunchKernelGGL(maskpool_fwd_kernel, dim3(B, gx_ceil_div(C, PCH)), dim3(256), 0, (hipStream_t)stream, f,
-                           log_m, B, C, H * W, K, S, msum);
+#define GX_MP_FWD(KT_)                                                                                                 \
+        hipLaunchKernelGGL(maskpool_fwd_kernel<KT_>, dim3(B, gx_ceil_div(C, PCH)), dim3(256), 0, (hipStream_t)stream, f,  \
+                           log_m, B, C, H * W, K, S, msum)
+        if (K == 7) GX_MP_FWD(7); else if (K == 5) GX_MP_FWD(5); else if (K == 11) GX_MP_FWD(11); else GX_MP_FWD(0);
+#undef GX_MP_FWD
     }
     GX_CHECK_LAUNCH("gx_maskpool_fwd");
     return GX_OK;
@@ -724,10 +739,14 @@ int gx_maskpool_bwd(const float* f, const float* log_m, const float* gS, const f
     const int HW = H * W;
     {
         GxProf pf(KID_MASKPOOL_BWD, (hipStream_t)stream, 4.0 * B * K * C * HW, 4.0 * B * HW * (2.0 * C + 2.0 * K));
-        if ((HW & 3) == 0)
-            hipLaunchKernelGGL(maskpool_bwd_vec_kernel, dim3(B, gx_ceil_div(HW, 256)), dim3(256),
-                               (size_t)(((K * C + 3) & ~3) + 4 * K * 64 * 4) * sizeof(float), (hipStream_t)stream, f,
-                               log_m, gS, gmsum, B, C, HW, K, df, dlog_m);
+        if ((HW & 3) == 0) {
+#define GX_MP_BWD(KT_)                                                                                                 \
+            hipLaunchKernelGGL(maskpool_bwd_vec_kernel<KT_>, dim3(B, gx_ceil_div(HW, 256)), dim3(256),                \
+                               (size_t)(((K * C + 3) & ~3) + 4 * K * 64 * 4) * sizeof(float), (hipStream_t)stream, f,   \
+                               log_m, gS, gmsum, B, C, HW, K, df, dlog_m)
+            if (K == 7) GX_MP_BWD(7); else if (K == 5) GX_MP_BWD(5); else if (K == 11) GX_MP_BWD(11); else GX_MP_BWD(0);
+#undef GX_MP_BWD
+        }
         else
             hipLaunchKernelGGL(maskpool_bwd_kernel, dim3(B, gx_ceil_div(HW, 256)), dim3(256),
                                (size_t)K * C * sizeof(float), (hipStream_t)stream, f, log_m, gS, gmsum, B, C, HW, K, df,
@@ -750,9 +769,12 @@ static int mixture_fwd_impl(const float* x, const float* dec, const float* log_w
     {
         // read x (3) + dec (4K); write recon (3), x_r (3K), log_m_r (K)
         GxProf pf(KID_MIXTURE_FWD, s, 0.0, 4.0 * B * HW * (6.0 + 8.0 * K));
-        hipLaunchKernelGGL(mixture_kernel<false>, dim3(B, nb), dim3(256), 0, s, x, dec, B, HW, K, pixel_std,
-                           pixel_bound, recon, x_r, log_m_r, (float*)ws, (const float*)nullptr, (float*)nullptr,
-                           log_w, (float*)nullptr, std_first, dec_ch);
+#define GX_MIX_FWD(KT_)                                                                                                \
+        hipLaunchKernelGGL((mixture_kernel<false, KT_>), dim3(B, nb), dim3(256), 0, s, x, dec, B, HW, K, pixel_std,       \
+                           pixel_bound, recon, x_r, log_m_r, (float*)ws, (const float*)nullptr, (float*)nullptr,         \
+                           log_w, (float*)nullptr, std_first, dec_ch)
+        if (K == 7) GX_MIX_FWD(7); else if (K == 5) GX_MIX_FWD(5); else if (K == 11) GX_MIX_FWD(11); else GX_MIX_FWD(0);
+#undef GX_MIX_FWD
     }
     GX_CHECK_LAUNCH("gx_mixture_fwd");
     {
@@ -771,9 +793,12 @@ static int mixture_bwd_impl(const float* x, const float* dec, const float* log_w
     const int HW = H * W, nb = gx_ceil_div(HW, 256);
     {
         GxProf pf(KID_MIXTURE_BWD, (hipStream_t)stream, 0.0, 4.0 * B * HW * (3.0 + 8.0 * K));
-        hipLaunchKernelGGL(mixture_kernel<true>, dim3(B, nb), dim3(256), 0, (hipStream_t)stream, x, dec, B, HW, K,
-                           pixel_std, pixel_bound, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
-                           g_err, ddec, log_w, dlog_w, std_first, dec_ch);
+#define GX_MIX_BWD(KT_)                                                                                                \
+        hipLaunchKernelGGL((mixture_kernel<true, KT_>), dim3(B, nb), dim3(256), 0, (hipStream_t)stream, x, dec, B, HW, K,  \
+                           pixel_std, pixel_bound, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,   \
+                           g_err, ddec, log_w, dlog_w, std_first, dec_ch)
+        if (K == 7) GX_MIX_BWD(7); else if (K == 5) GX_MIX_BWD(5); else if (K == 11) GX_MIX_BWD(11); else GX_MIX_BWD(0);
+#undef GX_MIX_BWD
     }
     GX_CHECK_LAUNCH("gx_mixture_bwd");
     return GX_OK;
