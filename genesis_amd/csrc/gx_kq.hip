@@ -892,10 +892,8 @@ bool q_plan(int N, int K, int M, int Hb, int Wb, int Hi, int Wi, int Ho, int Wo,
 // the grid width.  Only for full 64-channel tiles (M % 64 == 0 or > 32 in the last tile).
 int q_split_tail(int ptiles, int M, unsigned* grid_x) {
     static const char* env = getenv("GENESIS_KQ_TAIL");
-    static const char* half_env = getenv("GENESIS_KQ_HALF");      // experiment: grids of < 256 tiles entirely as half-work pairs
-    const bool all_half = half_env && half_env[0] == '1' && ptiles < 256 && (M % 64 == 0 || M % 64 > 32);
-    const int r = all_half ? ptiles : ptiles % 256;
-    const bool split = all_half || (!(env && env[0] == '0') && ptiles > 256 && r > 0 && r <= 128 && (M % 64 == 0 || M % 64 > 32));
+    const int r = ptiles % 256;
+    const bool split = !(env && env[0] == '0') && ptiles > 256 && r > 0 && r <= 128 && (M % 64 == 0 || M % 64 > 32);
     const int nfull = split ? ptiles - r : ptiles;
     *grid_x = (unsigned)(nfull + 2 * (ptiles - nfull));
     return nfull;
