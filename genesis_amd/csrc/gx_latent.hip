@@ -30,7 +30,7 @@ __device__ __forceinline__ float sigmoid_t(float x) { return 1.f / (1.f + expf(-
 __global__ void __launch_bounds__(256)
 posterior_fwd_kernel(const float* __restrict__ zh, const float* __restrict__ eps, int B, int K, int D,
                      float* __restrict__ z, float* __restrict__ mu_o, float* __restrict__ sigma_o,
-                     float* __restrict__ log_q) {
+                     float* __restrict__ log_q, float* __restrict__ z2, int ldz2) {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // k * B + b
     if (row >= K * B) return;
     const int lane = threadIdx.x & 63;
@@ -44,6 +44,7 @@ posterior_fwd_kernel(const float* __restrict__ zh, const float* __restrict__ eps
         const float t = zz - mu;
         const float lp = -(t * t) / (2.f * (sg * sg)) - logf(sg) - kHalfLog2Pi;
         z[(size_t)row * D + d] = zz;
+        if (z2) z2[(size_t)row * ldz2 + d] = zz;      // second copy: columns of the next recurrent step's input rows
         mu_o[(size_t)row * D + d] = mu;
         sigma_o[(size_t)row * D + d] = sg;
         acc += (double)lp;
@@ -56,7 +57,8 @@ posterior_fwd_kernel(const float* __restrict__ zh, const float* __restrict__ eps
 __global__ void __launch_bounds__(256)
 posterior_bwd_kernel(const float* __restrict__ zh, const float* __restrict__ eps, const float* __restrict__ gz,
                      const float* __restrict__ gmu, const float* __restrict__ gsigma,
-                     const float* __restrict__ glogq, int B, int K, int D, float* __restrict__ dzh) {
+                     const float* __restrict__ glogq, int B, int K, int D, float* __restrict__ dzh,
+                     const float* __restrict__ gz2, int ldgz2) {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= K * B) return;
     const int lane = threadIdx.x & 63;
@@ -74,7 +76,7 @@ posterior_bwd_kernel(const float* __restrict__ zh, const float* __restrict__ eps
         const float t = zz - mu;
         const float var = sg * sg;
         // log_q as a function of (z, mu, sigma): d/dz = -t/var, d/dmu = +t/var, d/dsigma = t^2/sigma^3 - 1/sigma
-        const float dz = (gz ? gz[i] : 0.f) + gl * (-t / var);
+        const float dz = (gz ? gz[i] : 0.f) + (gz2 ? gz2[(size_t)row * ldgz2 + d] : 0.f) + gl * (-t / var);
         const float dmu = dz + gl * (t / var) + (gmu ? gmu[i] : 0.f);
         const float dsg = dz * e + gl * ((t * t) / (var * sg) - 1.f / sg) + (gsigma ? gsigma[i] : 0.f);
         dr[d] = dmu;
@@ -288,14 +290,20 @@ extern "C" {
 
 int gx_latent_posterior_fwd(const float* zh, const float* eps, int B, int K, int D, float* z, float* mu,
                             float* sigma, float* log_q, gx_stream_t stream) {
+    return gx_latent_posterior_fwd_ex(zh, eps, B, K, D, z, mu, sigma, log_q, nullptr, 0, stream);
+}
+
+int gx_latent_posterior_fwd_ex(const float* zh, const float* eps, int B, int K, int D, float* z, float* mu,
+                               float* sigma, float* log_q, float* z2, int ldz2, gx_stream_t stream) {
     int rc = check_bkd("gx_latent_posterior_fwd", B, K, D);
     if (rc) return rc;
     GX_CHECK_ARG(zh && eps && z && mu && sigma && log_q, "gx_latent_posterior_fwd: null pointer");
+    GX_CHECK_ARG(!z2 || ldz2 >= D, "gx_latent_posterior_fwd_ex: ldz2 (%d) < D (%d)", ldz2, D);
     hipStream_t s = (hipStream_t)stream;
     {
         GxProf pf(KID_LATENT, s, 0.0, 4.0 * (6.0 * K * B * D + K * B));
         hipLaunchKernelGGL(posterior_fwd_kernel, dim3(gx_ceil_div(K * B, 4)), dim3(256), 0, s, zh, eps, B, K, D, z,
-                           mu, sigma, log_q);
+                           mu, sigma, log_q, z2, ldz2);
     }
     GX_CHECK_LAUNCH("gx_latent_posterior_fwd");
     return GX_OK;
@@ -304,14 +312,21 @@ int gx_latent_posterior_fwd(const float* zh, const float* eps, int B, int K, int
 int gx_latent_posterior_bwd(const float* zh, const float* eps, const float* gz, const float* gmu,
                             const float* gsigma, const float* glogq, int B, int K, int D, float* dzh,
                             gx_stream_t stream) {
+    return gx_latent_posterior_bwd_ex(zh, eps, gz, gmu, gsigma, glogq, nullptr, 0, B, K, D, dzh, stream);
+}
+
+int gx_latent_posterior_bwd_ex(const float* zh, const float* eps, const float* gz, const float* gmu,
+                               const float* gsigma, const float* glogq, const float* gz2, int ldgz2, int B, int K,
+                               int D, float* dzh, gx_stream_t stream) {
     int rc = check_bkd("gx_latent_posterior_bwd", B, K, D);
     if (rc) return rc;
     GX_CHECK_ARG(zh && eps && dzh, "gx_latent_posterior_bwd: null pointer");
+    GX_CHECK_ARG(!gz2 || ldgz2 >= D, "gx_latent_posterior_bwd_ex: ldgz2 (%d) < D (%d)", ldgz2, D);
     hipStream_t s = (hipStream_t)stream;
     {
         GxProf pf(KID_LATENT, s, 0.0, 4.0 * (8.0 * K * B * D + K * B));
         hipLaunchKernelGGL(posterior_bwd_kernel, dim3(gx_ceil_div(K * B, 4)), dim3(256), 0, s, zh, eps, gz, gmu,
-                           gsigma, glogq, B, K, D, dzh);
+                           gsigma, glogq, B, K, D, dzh, gz2, ldgz2);
     }
     GX_CHECK_LAUNCH("gx_latent_posterior_bwd");
     return GX_OK;

@@ -1137,6 +1137,113 @@ class LSTMCellFn(torch.autograd.Function):
                 _ret(o_bih, db), _ret(o_bhh, db))
 
 
+@ctx_bound
+class LatentSBPPosteriorFn(torch.autograd.Function):
+    """The recurrent posterior of GENESIS' LatentSBP (modules/attention.py:84-118) as ONE autograd node: encoder features h
+    [B,F], eps [K,B,D] -> (z, mu, sigma [K,B,D], log_q [K,B]).  Slot 0 from the VAE's own heads (q_z_mean | q_z_var of
+    third_party/sylvester/VAE.py:118-121), slot k >= 1 from lstm(cat(h, z_{k-1})) -> linear -> (mean | pre-sigma), every
+    slot sampled by gx_latent_posterior_fwd_ex.  Same launches per slot as LSTMCellFn -> LinearFn -> PosteriorFn chained,
+    but the uses of h (K + 1 of them), z_{k-1}, the LSTM state and the K small outputs no longer meet in autograd:
+      * the LSTM input rows [h | z_{k-1}] live in one [K-1,B,F+D] buffer (h broadcast once, the posterior kernel writes z's
+        second copy into the next row block: no torch.cat per step, no cat backward);
+      * backward is the time loop in reverse, the z columns of the input-projection gradient ADDED inside the posterior's
+        backward kernel (gz2), the recurrent dh inside gx_lstm_step_bwd -- no accumulation launches;
+      * the weight gradients of the cell and of the output linear are ONE dense launch each over all K-1 steps."""
+
+    @staticmethod
+    def forward(ctx, h, eps, w_m, b_m, w_v, b_v, w_ih, w_hh, b_ih, b_hh, w_lin, b_lin):
+        h, eps = h.contiguous(), eps.contiguous()
+        K, B, D = eps.shape
+        F_, T, H = h.shape[1], K - 1, w_hh.shape[1]
+        dev = h.device
+        lin = torch.empty(K, B, 2 * D, device=dev)
+        z, mu, sigma = (torch.empty(K, B, D, device=dev) for _ in range(3))
+        log_q = torch.empty(K, B, device=dev)
+        inp = torch.empty(max(T, 1), B, F_ + D, device=dev)
+        if T:
+            inp[:, :, :F_] = h                                                   # (one broadcast copy)
+        act = torch.empty(max(T, 1), B, 4 * H, device=dev)
+        c = torch.empty(max(T, 1), B, H, device=dev)
+        hs = torch.empty(max(T, 1), B, H, device=dev)
+        hip.linear_fwd(h, w_m, b_m, None, out=lin[0][:, :D])
+        hip.linear_fwd(h, w_v, b_v, None, out=lin[0][:, D:])
+        for k in range(K):
+            if k:
+                t = k - 1
+                gx = hip.linear_fwd(inp[t], w_ih, b_ih)
+                hip.lstm_step_fwd(gx, hs[t - 1] if t else None, c[t - 1] if t else None, w_hh, b_hh, act[t], c[t], hs[t])
+                hip.linear_fwd(hs[t], w_lin, b_lin, None, out=lin[k])
+            hip.latent_posterior_step_fwd(lin[k], eps[k], z[k], mu[k], sigma[k], log_q[k],
+                                          inp[k][:, F_:] if k < T else None)
+        ctx.save_for_backward(h, eps, lin, inp, act, c, hs)
+        ctx.params = (w_m, b_m, w_v, b_v, w_ih, w_hh, b_ih, b_hh, w_lin, b_lin)
+        ctx.set_materialize_grads(False)
+        return z, mu, sigma, log_q
+
+    @staticmethod
+    def backward(ctx, gz, gmu, gsigma, glogq):
+        h, eps, lin, inp, act, c, hs = ctx.saved_tensors
+        w_m, b_m, w_v, b_v, w_ih, w_hh, b_ih, b_hh, w_lin, b_lin = ctx.params
+        K, B, D = eps.shape
+        F_, T, H = h.shape[1], K - 1, w_hh.shape[1]
+        dev = h.device
+        gz, gmu, gsigma, glogq = _c(gz), _c(gmu), _c(gsigma), _c(glogq)
+        dlin = torch.empty(K, B, 2 * D, device=dev)
+        dinp = torch.empty(max(T, 1), B, F_ + D, device=dev)
+        dgates = torch.empty(max(T, 1), B, 4 * H, device=dev)
+        dhs = torch.empty(B, H, device=dev)
+        dc = [torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)]
+
+        def sl(g, k):
+            return None if g is None else g[k]
+        for k in reversed(range(K)):
+            # slot k's z also fed LSTM step t = k (input row block k): its input-projection gradient is in dinp[k] by now
+            hip.latent_posterior_step_bwd(lin[k], eps[k], sl(gz, k), sl(gmu, k), sl(gsigma, k), sl(glogq, k),
+                                          dinp[k][:, F_:] if k < T else None, dlin[k])
+            if k:
+                t = k - 1
+                hip.linear_bwd(hs[t], w_lin, None, dlin[k], None, need_dw=False, need_db=False, out_dx=dhs)
+                hip.lstm_step_bwd(dhs, dgates[t + 1] if t + 1 < T else None, w_hh, act[t], c[t], c[t - 1] if t else None,
+                                  dc[(t + 1) & 1] if t + 1 < T else None, dgates[t], dc[t & 1])
+                # dinp[t] = dgates[t] w_ih  (the z columns go to slot t's posterior backward, the h columns are summed below)
+                hip.linear_bwd(inp[t], w_ih, None, dgates[t], None, need_dw=False, need_db=False, out_dx=dinp[t])
+        # ---- parameter gradients: one launch per weight over all steps
+        o_wm, o_bm, o_wv, o_bv = _gout(w_m), _gout(b_m), _gout(w_v), _gout(b_v)
+        if o_wm is None or o_bm is None:
+            o_wm = o_bm = None
+        if o_wv is None or o_bv is None:
+            o_wv = o_bv = None
+        need_h = ctx.needs_input_grad[0]
+        dh = dinp[:, :, :F_].sum(0) if (T and need_h) else None
+        g0 = dlin[0]
+        dh, dw_m, db_m = hip.linear_bwd(h, w_m, None, g0[:, :D], None, need_dx=need_h, out_dw=o_wm, out_db=o_bm,
+                                        accumulate_dx=dh)
+        dh, dw_v, db_v = hip.linear_bwd(h, w_v, None, g0[:, D:], None, need_dx=need_h, out_dw=o_wv, out_db=o_bv,
+                                        accumulate_dx=dh)
+        if T:
+            o_wl, o_bl = _gout(w_lin), _gout(b_lin)
+            if o_wl is None or o_bl is None:
+                o_wl = o_bl = None
+            _, dw_lin, db_lin = hip.linear_bwd(hs.view(T * B, H), w_lin, None, dlin[1:].view(T * B, 2 * D), None,
+                                               need_dx=False, out_dw=o_wl, out_db=o_bl)
+            outs = [_gout(p) for p in (w_ih, w_hh, b_ih, b_hh)]
+            if any(o is None for o in outs):
+                outs = [None] * 4
+            o_wih, o_whh, o_bih, o_bhh = outs
+            _, dw_ih, db = hip.linear_bwd(inp.view(T * B, F_ + D), w_ih, None, dgates.view(T * B, 4 * H), None, need_dx=False,
+                                          out_dw=o_wih, out_db=o_bih, out_db2=o_bhh)
+            if T > 1:
+                _, dw_hh, _ = hip.linear_bwd(hs[:-1].view((T - 1) * B, H), w_hh, None, dgates[1:].view((T - 1) * B, 4 * H),
+                                             None, need_dx=False, need_db=False, out_dw=o_whh)
+            else:
+                dw_hh = torch.zeros_like(w_hh) if o_whh is None else o_whh.zero_()
+            rec = (_ret(o_wih, dw_ih), _ret(o_whh, dw_hh), _ret(o_bih, db), _ret(o_bhh, db), _ret(o_wl, dw_lin),
+                   _ret(o_bl, db_lin))
+        else:
+            rec = (None,) * 6
+        return (dh, None, _ret(o_wm, dw_m), _ret(o_bm, db_m), _ret(o_wv, dw_v), _ret(o_bv, db_v)) + rec
+
+
 # ---------------------------------------------------------------------------------------------- dense layers
 @ctx_bound
 class LinearFn(torch.autograd.Function):

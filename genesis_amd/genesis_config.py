@@ -135,29 +135,23 @@ class Genesis(nn.Module):
         K, B = self.K_steps, x.shape[0]
         ap, core = self.att_process, self.att_process.core
         h = core.encode_features(x)
-        # the first posterior N(q_z_mean(h), to_var(q_z_var(h))) and the recurrent ones through the same kernel (rsample +
-        # log q(z) in one launch): sqrt(to_var(x)) == to_sigma(x) = softplus(x + 0.5) + 1e-8 (blocks.py:22-26)
-        lin = torch.cat((fn.linear(h, core.q_z_mean.weight, core.q_z_mean.bias),
-                         fn.linear(h, core.q_z_var[0].weight, core.q_z_var[0].bias)), 1)
-        mu_k, sigma_k, z_k, log_q_k = [], [], [], []
+        # the first posterior N(q_z_mean(h), to_var(q_z_var(h))) and the K - 1 recurrent ones (the sampled z is fed back through
+        # lstm(cat(h, z)) -> linear: one cell per step) as one autograd node; sqrt(to_var(x)) == to_sigma(x) = softplus(x + 0.5)
+        # + 1e-8 (blocks.py:22-26)
         L = ap.lstm
-        hs = cs = None
-        for step in range(K):
-            if step:
-                # the recurrent core on the HIP LSTM-step / dense kernels (the sampled z is fed back: one cell per step)
-                hs, cs = fn.LSTMCellFn.apply(torch.cat([h, z_k[-1]], 1), hs, cs, L.weight_ih_l0, L.weight_hh_l0,
-                                             L.bias_ih_l0, L.bias_hh_l0)
-                lin = fn.linear(hs, ap.linear.weight, ap.linear.bias)                     # (mean | var_raw) [B, 2z]
-            z1, mu1, sig1, lq1 = fn.PosteriorFn.apply(lin.unsqueeze(1), eps_m[step].unsqueeze(0))
-            # (views, not [0]: a select's backward is a zero fill + copy)
-            mu_k.append(mu1.view(B, -1)); sigma_k.append(sig1.view(B, -1)); z_k.append(z1.view(B, -1)); log_q_k.append(lq1)
-        z = torch.cat(z_k, 0)
+        if not torch.is_tensor(eps_m):
+            eps_m = torch.stack(list(eps_m), 0)
+        z3, mu3, sig3, log_q = fn.LatentSBPPosteriorFn.apply(
+            h, eps_m, core.q_z_mean.weight, core.q_z_mean.bias, core.q_z_var[0].weight, core.q_z_var[0].bias,
+            L.weight_ih_l0, L.weight_hh_l0, L.bias_ih_l0, L.bias_hh_l0, ap.linear.weight, ap.linear.bias)
+        mu_k, sigma_k, z_k = list(mu3.unbind(0)), list(sig3.unbind(0)), list(z3.unbind(0))
+        z = z3.view(K * B, -1)
         logits = core.decode(z).view(K, B, 1, self.img_size, self.img_size)
         # K stick-breaking steps in one launch; the last mask is the remaining scope (genesis_config.py:167-169)
         log_m, log_s = fn.SBPScanFn.apply(logits, None, True)
         log_m_k = list(log_m.unbind(0))
         log_s_k = [torch.zeros_like(x[:, :1])] + list(log_s.unbind(0))
-        return log_m, log_m_k, log_s_k, mu_k, sigma_k, z_k, z.view(K, B, -1), torch.cat(log_q_k, 0)
+        return log_m, log_m_k, log_s_k, mu_k, sigma_k, z_k, z3, log_q
 
     def _prior_m(self, z_kbd):
         L = self.prior_lstm
@@ -174,7 +168,7 @@ class Genesis(nn.Module):
             raise GenesisHipError('Genesis: the HIP path needs device tensors; there is no CPU fallback')
         B, K = x.shape[0], self.K_steps
         if eps_m is None:
-            eps_m = list(torch.randn(K, B, self.ldim, device=x.device).unbind(0))
+            eps_m = torch.randn(K, B, self.ldim, device=x.device)
         log_m, log_m_k, log_s_k, mu_k, sigma_k, z_k, z, log_q = self._attention(x, eps_m)
         if self.two_stage:
             # --- ComponentVAE (ELU), slot-major batch, mask as first channel

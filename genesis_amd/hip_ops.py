@@ -876,6 +876,29 @@ def latent_posterior_bwd(zh, eps, gz, gmu, gsigma, glogq):
     return dzh
 
 
+def latent_posterior_step_fwd(zh, eps, z, mu, sigma, log_q, z2=None):
+    """One slot of a recurrent posterior into preallocated rows: zh [B,2D] (mean | pre-sigma), eps [B,D] -> z, mu, sigma [B,D],
+    log_q [B] (contiguous views of the per-sequence buffers); z2: a row-strided [B,D] view that receives a second copy of z
+    (the z columns of the next LSTM step's input rows: LatentSBP's torch.cat((h, z)), modules/attention.py:104)."""
+    for t, n in ((zh, 'zh'), (eps, 'eps'), (z, 'z'), (mu, 'mu'), (sigma, 'sigma'), (log_q, 'log_q')):
+        _chk(t, 'latent_step.' + n)
+    B, D2 = zh.shape
+    ld2 = _rows(z2, 'latent_step.z2') if z2 is not None else 0
+    _lib.call('gx_latent_posterior_fwd_ex', _p(zh), _p(eps), B, 1, D2 // 2, _p(z), _p(mu), _p(sigma), _p(log_q), _p(z2), ld2,
+              _stream())
+
+
+def latent_posterior_step_bwd(zh, eps, gz, gmu, gsigma, glogq, gz2, dzh):
+    """Backward of one slot: gz / gmu / gsigma [B,D], glogq [B] (each may be None), gz2: a row-strided [B,D] view ADDED to gz
+    (the LSTM input gradient's z columns) -> dzh [B,2D] (preallocated)."""
+    for t, n in ((zh, 'zh'), (eps, 'eps'), (gz, 'gz'), (gmu, 'gmu'), (gsigma, 'gsigma'), (glogq, 'glogq'), (dzh, 'dzh')):
+        _chk(t, 'latent_step_bwd.' + n)
+    B, D2 = zh.shape
+    ld2 = _rows(gz2, 'latent_step_bwd.gz2') if gz2 is not None else 0
+    _lib.call('gx_latent_posterior_bwd_ex', _p(zh), _p(eps), _p(gz), _p(gmu), _p(gsigma), _p(glogq), _p(gz2), ld2, B, 1,
+              D2 // 2, _p(dzh), _stream())
+
+
 def latent_prior_logp_fwd(z, lin, log_q=None, all_slots=False):
     """z [K,B,D], lin [K-1,B,2D] or None -> log_p [K,B] (models/genesis_config.py:297-330); with log_q [K,B] the
     per-slot KL sample log_q - log_p (:329-331).  all_slots: lin [K,B,2D], every slot has a conditional prior."""
@@ -1021,10 +1044,11 @@ def linear_fwd(x, w, b=None, act=None, out=None):
 
 
 def linear_bwd(x, w, y, g, act=None, need_dx=True, need_dw=True, need_db=True, out_dw=None, out_db=None,
-               out_db2=None, accumulate_dx=None, accumulate_dw=False):
+               out_db2=None, accumulate_dx=None, accumulate_dw=False, out_dx=None):
     """Returns (dx, dw, db); out_dw / out_db: write the parameter gradients into these buffers (out_db2: a second copy
     of db).  x, and (y, g) with one common row stride, may be row-strided views.  accumulate_dx: a [M,K] (row-strided)
-    tensor that dx is ADDED to (returned as dx).  accumulate_dw: dw / db are ADDED to out_dw / out_db."""
+    tensor that dx is ADDED to (returned as dx); out_dx: a [M,K] (row-strided) tensor dx is WRITTEN to.  accumulate_dw: dw / db
+    are ADDED to out_dw / out_db."""
     assert not accumulate_dw or out_dw is not None
     M, K = x.shape
     N = w.shape[0]
@@ -1034,8 +1058,12 @@ def linear_bwd(x, w, y, g, act=None, need_dx=True, need_dw=True, need_db=True, o
         raise GenesisHipError('linear_bwd: y and g must share a row stride')
     if accumulate_dx is not None:
         dx = accumulate_dx
+    elif out_dx is not None:
+        dx = out_dx
     else:
         dx = torch.empty(M, K, dtype=F32, device=dev) if need_dx else None
+    if dx is not None and tuple(dx.shape) != (M, K):
+        raise GenesisHipError('linear_bwd: dx is %s, expected (%d, %d)' % (tuple(dx.shape), M, K))
     lddx = _rows(dx, 'linear_bwd.dx') if dx is not None else K
     dw = (out_dw if out_dw is not None else torch.empty(N, K, dtype=F32, device=dev)) if need_dw else None
     db = (out_db if out_db is not None else torch.empty(N, dtype=F32, device=dev)) if (need_db and need_dw) else None

@@ -476,6 +476,15 @@ int gx_latent_posterior_fwd(const float* zh, const float* eps, int B, int K, int
 int gx_latent_posterior_bwd(const float* zh, const float* eps, const float* gz, const float* gmu,
                             const float* gsigma, const float* glogq, int B, int K, int D, float* dzh,
                             gx_stream_t stream);
+/* _ex: the recurrent posterior of GENESIS' LatentSBP (modules/attention.py:103-118: the sampled z_{k-1} is concatenated to
+ * the encoder features as the next LSTM input) without torch.cat -- fwd also writes z to z2 [K*B rows of ldz2 floats] (the
+ * z columns of the next step's input rows; NULL: none); bwd adds a second incoming gz2 [K*B rows of ldgz2 floats] (the
+ * input-projection gradient's z columns) to gz. */
+int gx_latent_posterior_fwd_ex(const float* zh, const float* eps, int B, int K, int D, float* z, float* mu,
+                               float* sigma, float* log_q, float* z2, int ldz2, gx_stream_t stream);
+int gx_latent_posterior_bwd_ex(const float* zh, const float* eps, const float* gz, const float* gmu,
+                               const float* gsigma, const float* glogq, const float* gz2, int ldgz2, int B, int K,
+                               int D, float* dzh, gx_stream_t stream);
 int gx_latent_prior_logp_fwd(const float* z, const float* lin, const float* log_q, int B, int K, int D,
                              float* out, gx_stream_t stream);
 int gx_latent_prior_logp_bwd(const float* z, const float* lin, const float* g_out, int kl_mode, int B, int K,

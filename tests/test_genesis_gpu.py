@@ -111,3 +111,49 @@ def test_genesis_forward_grads_and_steps(case):
         out = ts.step(x.to(DEV), eps_m=[n.to(DEV) for n in nz[:K]], eps_c=nz[K].to(DEV) if two else None).cpu().numpy()
         assert abs(out[0] - hist[it, 0]) <= 1e-3 * abs(hist[it, 0]), (it, out, hist[it])
     assert int(model.att_process.core.q_z_nn[0].h_norm.num_batches_tracked) == 3 if cfg['enc_norm'] == 'bn' else True
+
+
+@pytest.mark.parametrize('K,B,F_,D', [(7, 32, 256, 64), (2, 5, 256, 16), (1, 3, 256, 64)])
+def test_latent_sbp_posterior_node_equals_the_chained_functions(K, B, F_, D):
+    """LatentSBPPosteriorFn (the recurrent posterior of modules/attention.py:84-118 as one autograd node) against the same
+    recurrence written with one Function per op (LSTMCellFn -> LinearFn -> PosteriorFn, torch.cat between them): outputs and
+    every gradient, including h's (K + 1 uses) and the cell's parameters (K - 1 uses)."""
+    from genesis_amd import functions as fn
+    g = torch.Generator().manual_seed(3)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(DEV)      # noqa: E731
+    H = 2 * D
+    names = ['h', 'w_m', 'b_m', 'w_v', 'b_v', 'w_ih', 'w_hh', 'b_ih', 'b_hh', 'w_lin', 'b_lin']
+    vals = [r(B, F_), r(D, F_, sc=0.05), r(D, sc=0.1), r(D, F_, sc=0.05), r(D, sc=0.1), r(4 * H, F_ + D, sc=0.05),
+            r(4 * H, H, sc=0.08), r(4 * H, sc=0.1), r(4 * H, sc=0.1), r(2 * D, H, sc=0.1), r(2 * D, sc=0.1)]
+    eps = r(K, B, D)
+    cz, cl, cm, cs = r(K, B, D), r(K, B), r(K, B, D), r(K, B, D)
+
+    def chained(h, w_m, b_m, w_v, b_v, w_ih, w_hh, b_ih, b_hh, w_lin, b_lin):
+        lin = torch.cat((fn.linear(h, w_m, b_m), fn.linear(h, w_v, b_v)), 1)
+        zs, mus, sgs, lqs = [], [], [], []
+        hs = cs_ = None
+        for k in range(K):
+            if k:
+                hs, cs_ = fn.LSTMCellFn.apply(torch.cat([h, zs[-1]], 1), hs, cs_, w_ih, w_hh, b_ih, b_hh)
+                lin = fn.linear(hs, w_lin, b_lin)
+            z1, m1, s1, q1 = fn.PosteriorFn.apply(lin.unsqueeze(1), eps[k].unsqueeze(0))
+            zs.append(z1.view(B, -1)); mus.append(m1.view(B, -1)); sgs.append(s1.view(B, -1)); lqs.append(q1)
+        return torch.stack(zs), torch.stack(mus), torch.stack(sgs), torch.cat(lqs, 0)
+
+    def node(h, *params):
+        return fn.LatentSBPPosteriorFn.apply(h, eps, *params)
+
+    res = []
+    for f in (chained, node):
+        leaves = [v.clone().requires_grad_(True) for v in vals]
+        z, mu, sg, lq = f(*leaves)
+        ((z * cz).sum() + (lq * cl).sum() + (mu * cm).sum() + (sg * cs).sum()).backward()
+        res.append(([z, mu, sg, lq], [l.grad for l in leaves]))
+    for a, b_ in zip(*[r_[0] for r_ in res]):
+        torch.testing.assert_close(b_, a, rtol=1e-5, atol=1e-5)
+    for n, a, b_ in zip(names, *[r_[1] for r_ in res]):
+        if K == 1 and n in ('w_ih', 'w_hh', 'b_ih', 'b_hh', 'w_lin', 'b_lin'):
+            assert b_ is None or float(b_.abs().max()) == 0.0
+            continue
+        scale = float(a.abs().max()) + 1e-12
+        assert float((a - b_).abs().max()) <= 2e-5 * scale + 1e-6, (n, float((a - b_).abs().max()), scale)
