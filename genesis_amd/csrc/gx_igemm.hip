@@ -288,7 +288,7 @@ int wgrad_splits(const IG& g) {
 template <int CIB>
 __global__ void __launch_bounds__(256)
 conv3x3s2_dgrad_small_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int Cin,
-                             int Cout, int H, int W, int cin_n) {
+                             int Cout, int H, int W, int cin_n, int dxC) {
     extern __shared__ __attribute__((aligned(16))) float wl[];       // [Cout][CIB][12]: 9 taps, padded to 3 float4
     const int Ho = H >> 1, Wo = W >> 1;
     const int n = blockIdx.z, ci0 = blockIdx.y * CIB;
@@ -325,7 +325,7 @@ conv3x3s2_dgrad_small_kernel(const float* __restrict__ dy, const float* __restri
 #pragma unroll
     for (int c = 0; c < CIB; ++c) {
         if (ci0 + c >= cin_n) break;
-        float* o = dx + (((size_t)n * Cin + ci0 + c) * H + 2 * i) * W + 2 * j;
+        float* o = dx + (((size_t)n * dxC + ci0 + c) * H + 2 * i) * W + 2 * j;
         *reinterpret_cast<float2*>(o) = make_float2(a00[c], a01[c]);
         *reinterpret_cast<float2*>(o + W) = make_float2(a10[c], a11[c]);
     }
@@ -438,6 +438,15 @@ int gx_conv3x3s2_wgrad_small(const float* x, const float* dy, float* dw, int N, 
  * [Cout,Cin,3,3]; only the first cin_n channels of dx are computed and written (the others are left untouched). */
 int gx_conv3x3s2_dgrad_small(const float* dy, const float* w, float* dx, int N, int Cin, int Cout, int H, int W, int cin_n,
                              gx_stream_t stream) {
+    return gx_conv3x3s2_dgrad_small_ex(dy, w, dx, N, Cin, Cout, H, W, cin_n, Cin, stream);
+}
+
+/* _ex: dx has dx_channels (cin_n <= dx_channels) channels per image -- dx_channels = cin_n: a compact [N,cin_n,H,W] gradient
+ * of the leading input channels alone. */
+int gx_conv3x3s2_dgrad_small_ex(const float* dy, const float* w, float* dx, int N, int Cin, int Cout, int H, int W, int cin_n,
+                                int dx_channels, gx_stream_t stream) {
+    GX_CHECK_ARG(dx_channels >= cin_n, "gx_conv3x3s2_dgrad_small_ex: dx_channels (%d) < cin_n (%d)", dx_channels, cin_n);
+    const int dxC = dx_channels;
     GX_CHECK_ARG(dy && w && dx, "gx_conv3x3s2_dgrad_small: null pointer");
     GX_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && H >= 2 && W >= 2 && !(H & 1) && !(W & 1) && N <= 65535,
                  "gx_conv3x3s2_dgrad_small: even H, W; N <= 65535");
@@ -448,10 +457,10 @@ int gx_conv3x3s2_dgrad_small(const float* dy, const float* w, float* dx, int N, 
         GxProf pf(KID_DCONV, s, 2.0 * N * Cout * (double)cin_n * 9 * npix, 4.0 * N * ((double)cin_n * H * W + (double)Cout * npix));
         if (cin_n <= 2)
             hipLaunchKernelGGL(conv3x3s2_dgrad_small_kernel<2>, dim3(gx_ceil_div(npix, 256), gx_ceil_div(cin_n, 2), N), dim3(256),
-                               (size_t)Cout * 2 * 12 * 4, s, dy, w, dx, Cin, Cout, H, W, cin_n);
+                               (size_t)Cout * 2 * 12 * 4, s, dy, w, dx, Cin, Cout, H, W, cin_n, dxC);
         else
             hipLaunchKernelGGL(conv3x3s2_dgrad_small_kernel<4>, dim3(gx_ceil_div(npix, 256), gx_ceil_div(cin_n, 4), N), dim3(256),
-                               (size_t)Cout * 4 * 12 * 4, s, dy, w, dx, Cin, Cout, H, W, cin_n);
+                               (size_t)Cout * 4 * 12 * 4, s, dy, w, dx, Cin, Cout, H, W, cin_n, dxC);
     }
     GX_CHECK_LAUNCH("gx_conv3x3s2_dgrad_small");
     return GX_OK;

@@ -210,6 +210,19 @@ int gx_chan_sums_launch(const float* x, int N, int C, int HW, float* part, float
     return GX_OK;
 }
 
+// out [K*B, 1 + C, HW]: plane 0 of image (k, b) = mask [K,B,HW] plane (k, b), planes 1 .. C = x [B,C,HW] image b (the slot-major
+// ComponentVAE input [log_m_k | x] of modules/component_vae.py:59-66 without x.repeat(K) + torch.cat); HW % 4 == 0
+__global__ void __launch_bounds__(256)
+mask_image_stack_kernel(const float* __restrict__ mask, const float* __restrict__ x, float* __restrict__ out, int B, int C,
+                        int HW4) {
+    const int plane = blockIdx.y;                       // (k * B + b) * (1 + C) + c
+    const int img = plane / (1 + C), c = plane - img * (1 + C);
+    const int b = img % B;
+    const f32x4* src = reinterpret_cast<const f32x4*>(c == 0 ? mask + (size_t)img * HW4 * 4 : x + ((size_t)b * C + c - 1) * HW4 * 4);
+    f32x4* dst = reinterpret_cast<f32x4*>(out + (size_t)plane * HW4 * 4);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW4; i += gridDim.x * 256) dst[i] = src[i];
+}
+
 extern "C" {
 
 // launches `wgs` workgroups of 4 waves, each wave issuing 32 * iters MFMA 32x32x2 f32; returns the flop count through
@@ -247,6 +260,21 @@ int gx_bias_act_bwd(const float* out, const float* g, int N, int C, int H, int W
         hipLaunchKernelGGL(chan_sum_kernel, dim3(C), dim3(N >= 128 ? 256 : 64), 0, s, (const float*)ws, N, C, dbias);
         GX_CHECK_LAUNCH("gx_bias_act_bwd(reduce)");
     }
+    return GX_OK;
+}
+
+int gx_mask_image_stack(const float* mask, const float* x, float* out, int K, int B, int C, int H, int W, gx_stream_t stream) {
+    GX_CHECK_ARG(mask && x && out, "gx_mask_image_stack: null pointer");
+    GX_CHECK_ARG(K > 0 && B > 0 && C > 0 && H > 0 && W > 0 && (H * W) % 4 == 0 && (long long)K * B * (1 + C) <= 65535,
+                 "gx_mask_image_stack: H W %% 4 == 0, K B (1 + C) <= 65535");
+    hipStream_t s = (hipStream_t)stream;
+    const int HW4 = H * W / 4;
+    {
+        GxProf pf(KID_BIAS_ACT_BWD, s, 0.0, 8.0 * K * B * (1 + C) * H * W);
+        hipLaunchKernelGGL(mask_image_stack_kernel, dim3(gx_ceil_div(HW4, 256) > 4 ? 4 : gx_ceil_div(HW4, 256), K * B * (1 + C)),
+                           dim3(256), 0, s, mask, x, out, B, C, HW4);
+    }
+    GX_CHECK_LAUNCH("gx_mask_image_stack");
     return GX_OK;
 }
 

@@ -728,6 +728,45 @@ class Conv1x1Fn(torch.autograd.Function):
 
 
 @ctx_bound
+class MaskImageConvActFn(torch.autograd.Function):
+    """The ComponentVAE encoder's first layer on its slot-major input [log_m_k | x] (modules/component_vae.py:59-66,
+    modules/encoders.py:31-34): act(conv3x3 s2 p1(cat(log_m [K,B,1,H,W], x [B,3,H,W] repeated K times))) -> [K*B,Cout,H/2,W/2].
+    The input is stacked by one kernel (no x.repeat + torch.cat), and the backward returns the mask channel's gradient as a
+    compact [K,B,1,H,W] tensor (no zero-filled 4-channel dx whose first channel autograd then adds as a strided slice)."""
+
+    @staticmethod
+    def forward(ctx, log_m, x, w, b, act):
+        log_m, x = log_m.contiguous(), x.contiguous()
+        inp = hip.mask_image_stack(log_m, x)
+        y = hip.conv2d_direct_fwd(inp, w, b, act, 2, 1)
+        ctx.save_for_backward(inp, y)
+        ctx.params = (w, b)
+        ctx.cfg = (act, log_m.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        inp, y = ctx.saved_tensors
+        w, b = ctx.params
+        act, mshape = ctx.cfg
+        ow, ob = _gout(w), _gout(b)
+        dy, db = hip.bias_act_bwd(y, g.contiguous(), act, True, ob)
+        H, W = inp.shape[2], inp.shape[3]
+        even = H % 2 == 0 and W % 2 == 0
+        if even:
+            dw = hip.conv3x3s2_wgrad_small(inp, dy, out=ow)
+        else:
+            dw = hip.conv2d_direct_wgrad(inp, dy, 3, 2, 1, out=ow)
+        dm = None
+        if ctx.needs_input_grad[0]:
+            if even and w.shape[0] <= 256:
+                dm = hip.conv3x3s2_dgrad_lead(dy, w, H, W, 1).view(mshape)
+            else:
+                dm = hip.conv2d_direct_dgrad(dy, w, H, W, 2, 1)[:, :1].reshape(mshape)
+        return dm, None, _ret(ow, dw), _ret(ob, db), None
+
+
+@ctx_bound
 class DirectConvActFn(torch.autograd.Function):
     """act(conv2d(x, w, b, stride, pad)) through the generic direct kernel (MONetCompEncoder's stride-2 convs,
     modules/encoders.py:31-34)."""
@@ -765,6 +804,20 @@ class DirectConvActFn(torch.autograd.Function):
         return dx, _ret(ow, dw), _ret(ob, db), None, None, None, None
 
 
+_ROWCOL = {}
+
+
+def _row_col_coords(coords):
+    """(row vector, column vector) of a PixelCoords buffer [1,2,d,d], made contiguous once per buffer (it never changes)."""
+    key = (coords.data_ptr(), coords.shape[-1], str(coords.device))
+    rc = _ROWCOL.get(key)
+    if rc is None or rc[2] is not coords:
+        if len(_ROWCOL) > 64:
+            _ROWCOL.clear()
+        rc = _ROWCOL[key] = (coords[0, 0, :, 0].contiguous(), coords[0, 1, 0, :].contiguous(), coords)
+    return rc[0], rc[1]
+
+
 @ctx_bound
 class BroadcastDecoderFn(torch.autograd.Function):
     """BroadcastDecoder (modules/decoders.py:21-35): z [N, L] -> [N, out, S, S].
@@ -784,8 +837,7 @@ class BroadcastDecoderFn(torch.autograd.Function):
         d = coords.shape[-1]
         S = d - 2 * nl
         z = z.contiguous()
-        rowc = coords[0, 0, :, 0].contiguous()       # g_1 varies along rows, g_2 along columns (blocks.py:121-126)
-        colc = coords[0, 1, 0, :].contiguous()
+        rowc, colc = _row_col_coords(coords)         # g_1 varies along rows, g_2 along columns (blocks.py:121-126)
         acts = []
         h = None
         for l in range(nl):
@@ -831,10 +883,18 @@ class BroadcastDecoderFn(torch.autograd.Function):
             gbp = _gout(params[2 * nl - 1])
             wp = params[2 * nl - 2]
             lazy = QUAD_BIAS and wp.shape[0] == wp.shape[1] and _quad_ok(last.shape[0], wp.shape[1], last.shape[2], last.shape[3])
-            dyl, dow, dob, dbl = hip.conv1x1_bwd_act(last, gfull, ow, ob, act, dbx_out=gbp, want_dbx=not lazy)
+            gow, gob = _gout(ow), _gout(ob)
+            if gow is None or gob is None:
+                gow = gob = None
+            dyl, dow, dob, dbl = hip.conv1x1_bwd_act(last, gfull, ow, ob, act, out=(gow, gob), dbx_out=gbp, want_dbx=not lazy)
+            dow, dob = _ret(gow, dow), _ret(gob, dob)
             pre = (dyl, dbl, gbp)
         else:
-            da, dow, dob, _ = hip.conv1x1_bwd(last, gfull, ow, ob)
+            gow, gob = _gout(ow), _gout(ob)
+            if gow is None or gob is None:
+                gow = gob = None
+            da, dow, dob, _ = hip.conv1x1_bwd(last, gfull, ow, ob, out=(gow, gob, None))
+            dow, dob = _ret(gow, dow), _ret(gob, dob)
         grads = [None] * len(params)
         grads[2 * nl], grads[2 * nl + 1] = dow, dob
         dz = None

@@ -150,7 +150,7 @@ class Genesis(nn.Module):
         # K stick-breaking steps in one launch; the last mask is the remaining scope (genesis_config.py:167-169)
         log_m, log_s = fn.SBPScanFn.apply(logits, None, True)
         log_m_k = list(log_m.unbind(0))
-        log_s_k = [torch.zeros_like(x[:, :1])] + list(log_s.unbind(0))
+        log_s_k = Lazy(lambda: [torch.zeros_like(x[:, :1])] + list(log_s.unbind(0)))     # (a returned statistic only)
         return log_m, log_m_k, log_s_k, mu_k, sigma_k, z_k, z3, log_q
 
     def _prior_m(self, z_kbd):
@@ -173,15 +173,15 @@ class Genesis(nn.Module):
         if self.two_stage:
             # --- ComponentVAE (ELU), slot-major batch, mask as first channel
             Lc = self.comp_vae.ldim
-            inp = torch.cat((log_m.flatten(0, 1), x.repeat(K, 1, 1, 1)), 1)
             if self.comp_symmetric:
+                inp = torch.cat((log_m.flatten(0, 1), x.repeat(K, 1, 1, 1)), 1)
                 enc_out = gc_encoder_forward(self.comp_vae.encoder_module[0], inp, SYM_STRIDES, self.training)
             else:
                 em = self.comp_vae.encoder_module.module
-                h = inp
-                for i in (0, 2, 4, 6):
-                    # (first layer: only the mask channel of [log_m | x] carries a gradient)
-                    h = fn.DirectConvActFn.apply(h, em[i].weight, em[i].bias, 2, 1, 'elu', 1 if i == 0 else None)
+                # (first layer: [log_m_k | x] stacked by its own kernel; only the mask channel carries a gradient)
+                h = fn.MaskImageConvActFn.apply(log_m, x, em[0].weight, em[0].bias, 'elu')
+                for i in (2, 4, 6):
+                    h = fn.DirectConvActFn.apply(h, em[i].weight, em[i].bias, 2, 1, 'elu', None)
                 h = fn.linear(h.flatten(1), em[9].weight, em[9].bias, 'elu')
                 enc_out = fn.linear(h, em[11].weight, em[11].bias)
             if eps_c is None:

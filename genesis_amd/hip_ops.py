@@ -686,6 +686,28 @@ def conv2d_direct_dgrad(dy, w, H, W, stride, pad):
     return dx
 
 
+def mask_image_stack(mask, x):
+    """mask [K,B,1,H,W], x [B,C,H,W] -> [K*B, 1 + C, H, W] = [mask_k | x] slot-major (gx_mask_image_stack)."""
+    _chk(mask, 'mask_image_stack.mask'); _chk(x, 'mask_image_stack.x')
+    K, B = mask.shape[:2]
+    C, H, W = x.shape[1:]
+    if tuple(mask.shape) != (K, B, 1, H, W) or x.shape[0] != B:
+        raise GenesisHipError('mask_image_stack: mask %s / x %s' % (tuple(mask.shape), tuple(x.shape)))
+    out = torch.empty(K * B, 1 + C, H, W, dtype=F32, device=x.device)
+    _lib.call('gx_mask_image_stack', _p(mask), _p(x), _p(out), K, B, C, H, W, _stream())
+    return out
+
+
+def conv3x3s2_dgrad_lead(dy, w, H, W, cin_n):
+    """The compact gradient [N,cin_n,H,W] of the first cin_n input channels of a conv3x3 stride 2 pad 1 (gx_conv3x3s2_dgrad_small_ex)."""
+    _chk(dy, 'conv3x3s2_dgrad.dy'); _chk(w, 'conv3x3s2_dgrad.w')
+    N = dy.shape[0]
+    Cout, Cin = w.shape[0], w.shape[1]
+    dx = torch.empty(N, cin_n, H, W, dtype=F32, device=dy.device)
+    _lib.call('gx_conv3x3s2_dgrad_small_ex', _p(dy), _p(w), _p(dx), N, Cin, Cout, H, W, int(cin_n), int(cin_n), _stream())
+    return dx
+
+
 def conv3x3s2_dgrad_small(dy, w, H, W, cin_n=None):
     """dx [N,Cin,H,W] of a conv3x3 stride 2 pad 1 from dy [N,Cout,H/2,W/2]; only the first cin_n channels are computed, the
     others are zero (gx_conv3x3s2_dgrad_small)."""

@@ -84,7 +84,7 @@ class _BroadcastDecoderParams(nn.Module):
         for l in range(self.num_layers):
             p.extend((self.seq[1 + 2 * l].weight, self.seq[1 + 2 * l].bias))
         last = self.seq[1 + 2 * self.num_layers]
-        p.extend((last.weight.view(last.weight.shape[0], -1), last.bias))
+        p.extend((last.weight, last.bias))        # (the Parameter itself: its gradient is written straight into .grad)
         return p
 
 
@@ -155,12 +155,11 @@ class MONet(nn.Module):
         log_m_k, log_s_k = self._attention(x)
         log_m = torch.stack(log_m_k, 0)                               # [K,B,1,H,W]
         # --- ComponentVAE: K slots batched slot-major, mask as first channel (component_vae.py:59-66)
-        inp = torch.cat((log_m.flatten(0, 1), x.repeat(K, 1, 1, 1)), 1)
         em = self.comp_vae.encoder_module.module
-        h = inp
-        for i in (0, 2, 4, 6):
-            # (first layer: only the mask channel of [log_m | x] carries a gradient)
-            h = fn.DirectConvActFn.apply(h, em[i].weight, em[i].bias, 2, 1, 'relu', 1 if i == 0 else None)
+        # (first layer: [log_m_k | x] stacked by its own kernel; only the mask channel carries a gradient)
+        h = fn.MaskImageConvActFn.apply(log_m, x, em[0].weight, em[0].bias, 'relu')
+        for i in (2, 4, 6):
+            h = fn.DirectConvActFn.apply(h, em[i].weight, em[i].bias, 2, 1, 'relu', None)
         h = fn.linear(h.flatten(1), em[9].weight, em[9].bias, 'relu')
         enc_out = fn.linear(h, em[11].weight, em[11].bias)
         if eps is None:

@@ -81,7 +81,7 @@ class SylvesterVAE(nn.Module):
             unit = self.q_z_nn[l]
             h = self._gate(unit, DirectConvFn.apply(h, unit.conv.weight, 'conv', s, 2, 0))
         unit = self.q_z_nn[len(self.strides)]
-        y = fn.linear(h.flatten(1), unit.conv.weight.flatten(1)).view(h.shape[0], -1, 1, 1)
+        y = fn.linear(h.flatten(1), unit.conv.weight).view(h.shape[0], -1, 1, 1)
         return self._gate(unit, y).flatten(1)
 
     def posterior_heads(self, h):
@@ -135,7 +135,7 @@ def gc_encoder_forward(units, x, strides, training):
     for unit, s in zip(units, strides):
         h = gate_unit(unit, DirectConvFn.apply(h, unit.conv.weight, 'conv', s, 2, 0), training)
     unit = units[len(strides)]
-    y = fn.linear(h.flatten(1), unit.conv.weight.flatten(1)).view(h.shape[0], -1, 1, 1)
+    y = fn.linear(h.flatten(1), unit.conv.weight).view(h.shape[0], -1, 1, 1)
     return gate_unit(unit, y, training).flatten(1)
 
 

@@ -362,6 +362,13 @@ int gx_conv5x5_wgrad(const float* a, const float* b, float* dw, int N, int CA, i
  *      (the encoder's first layer needs the mask channel's gradient alone). */
 int gx_conv3x3s2_dgrad_small(const float* dy, const float* w, float* dx, int N, int Cin, int Cout, int H, int W, int cin_n,
                              gx_stream_t stream);
+/*      _ex: dx holds dx_channels >= cin_n channels per image (dx_channels = cin_n: the compact gradient of the mask channel). */
+int gx_conv3x3s2_dgrad_small_ex(const float* dy, const float* w, float* dx, int N, int Cin, int Cout, int H, int W, int cin_n,
+                                int dx_channels, gx_stream_t stream);
+/*      the slot-major ComponentVAE input [log_m_k | x] (modules/component_vae.py:59-66: torch.cat((log_m_k, x), 1) per slot;
+ *      models/monet_config.py / genesis_config.py batch the K slots): out [K*B, 1 + C, H, W] from mask [K,B,1,H,W] and
+ *      x [B,C,H,W] in one pass -- no x.repeat(K), no torch.cat.  H W % 4 == 0. */
+int gx_mask_image_stack(const float* mask, const float* x, float* out, int K, int B, int C, int H, int W, gx_stream_t stream);
 /*      ... and its weight gradient dw [Cout,Cin,3,3] (lanes = output pixels, 9 taps x 8 output channels per thread, fixed-
  *      order split reduction; ws: gx_conv3x3s2_wgrad_small_ws_bytes). */
 size_t gx_conv3x3s2_wgrad_small_ws_bytes(int N, int Cin, int Cout, int H, int W);
