@@ -7,10 +7,47 @@ holds the global gradient AND the global err / KL and applies the identical GECO
 The reference has no equivalent (only single-process nn.DataParallel, train.py:153-155).
 
 Device-agnostic on purpose: the same class runs under `gloo` on CPU in the world_size-2 tests."""
+import ctypes
 import os
 
 import torch
 import torch.distributed as dist
+
+
+class CabiAllReduce(object):
+    """The bucket's collective through the library's own C-ABI entry points (gx_allreduce_*, include/genesis_hip.h: RCCL
+    resolved by the library, no torch.distributed in the data path) -- what a host that is not PyTorch binds.  The 128-byte
+    RCCL unique id travels from rank 0 to the others over the process group that is already up (any backend: it is host
+    bytes); after that the group is not used for gradients.  GENESIS_CABI_ALLREDUCE=1 selects it in FlatBucket.all_reduce."""
+
+    def __init__(self, group=None, device=None):
+        from . import _lib
+        self._lib = _lib
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        nbytes = int(_lib.load().gx_allreduce_unique_id_bytes())
+        ident = ctypes.create_string_buffer(nbytes)
+        if rank == 0:
+            _lib.call('gx_allreduce_unique_id', ident, nbytes)
+        if world > 1:
+            box = [bytes(ident.raw)]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            ident = ctypes.create_string_buffer(box[0], nbytes)
+        if device is not None:
+            torch.cuda.set_device(device)
+        h = ctypes.c_void_p()
+        _lib.call('gx_allreduce_init', ident, nbytes, rank, world, ctypes.byref(h))
+        self.handle, self.rank, self.world = h, rank, world
+
+    def run(self, flat):
+        assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous()
+        self._lib.call('gx_allreduce_run', self.handle, ctypes.c_void_p(flat.data_ptr()), flat.numel(),
+                       ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self._lib.call('gx_allreduce_destroy', self.handle)
+            self.handle = None
 
 
 class FlatBucket(object):
@@ -116,7 +153,12 @@ class FlatBucket(object):
         world = dist.get_world_size(group)
         if not packed:
             self.pack64()
-        dist.all_reduce(self.flat_g, group=group)
+        if os.environ.get('GENESIS_CABI_ALLREDUCE') and self.flat_g.is_cuda:
+            if getattr(self, '_cabi', None) is None:
+                self._cabi = CabiAllReduce(group, self.flat_g.device)
+            self._cabi.run(self.flat_g)
+        else:
+            dist.all_reduce(self.flat_g, group=group)
         if not packed:
             self.unpack64(1.0 / world)
         return 1.0 / world

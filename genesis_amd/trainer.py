@@ -356,7 +356,7 @@ class TrainStep(object):
         # in-graph form is used only if EVERY rank captured it, otherwise every rank takes the two-graph form, so the
         # ranks can never issue different collective sequences.
         want = os.environ.get('GENESIS_GRAPH_ALLREDUCE', '1' if self.world == 1 else '0') != '0'
-        if self._split and want and dist.get_backend(self.pg) == 'nccl':
+        if self._split and want and (dist.get_backend(self.pg) == 'nccl' or os.environ.get('GENESIS_CABI_ALLREDUCE')):
             self._gscale = 1.0 / self.world
             g, ok = None, 1
             try:

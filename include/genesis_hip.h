@@ -648,6 +648,20 @@ int gx_label_contingency(const long long* segA, const long long* segB, int B, in
 int gx_u8hwc_to_f32chw(const unsigned char* src, float* dst, int B, int Hs, int Ws, int C, int H, int W,
                        gx_stream_t stream);
 
+/* ---- the step's one collective without PyTorch (the reference's only multi-GPU mode is nn.DataParallel,
+ *      train.py:153-155: replicas gathered on GPU 0 every iteration).  One process per GPU; each rank's flat fp32 gradient
+ *      bucket (parameters' gradients + the err / kl tail, genesis_amd/dp.py) is summed IN PLACE over the ranks by one
+ *      ncclAllReduce over RCCL / xGMI, enqueued on `stream` (capturable into the step's HIP graph).  RCCL is resolved at run
+ *      time (a copy the process already holds, else librccl.so.1; GENESIS_RCCL_LIB overrides), so the library loads without it.
+ *      Rank 0 calls gx_allreduce_unique_id and hands the gx_allreduce_unique_id_bytes() (= 128) bytes to every rank out of band
+ *      (file, socket, MPI, a torch store); every rank then calls gx_allreduce_init on its device (collective: it returns when
+ *      all `world` ranks have joined). */
+size_t gx_allreduce_unique_id_bytes(void);
+int gx_allreduce_unique_id(void* id, size_t id_bytes);
+int gx_allreduce_init(const void* id, size_t id_bytes, int rank, int world, void** comm);
+int gx_allreduce_run(void* comm, float* buf, size_t count, gx_stream_t stream);
+int gx_allreduce_destroy(void* comm);
+
 /* ---- measurement probe: `wgs` workgroups x 4 waves x 32 * iters v_mfma_f32_32x32x2_f32.  mode 0: register operands
  *      only (the fp32-MFMA ceiling); 1: B operand from LDS; 2: A and B from LDS (two ds_read_b32 per MFMA, the tap-conv
  *      pattern); 3: as 2 plus a workgroup barrier every 32 MFMAs; 4: A and B from LDS with one 16-byte read per four MFMAs;

@@ -188,6 +188,49 @@ def test_rccl_allreduce_in_the_step_matches_single_graph(monkeypatch):
         assert torch.equal(ref[1], got[1])
 
 
+def test_cabi_allreduce_in_the_step_matches_single_graph(monkeypatch):
+    """The same check with the collective going through the library's own entry points (gx_allreduce_unique_id / _init / _run /
+    _destroy: RCCL resolved by libgenesis_hip.so, no torch.distributed in the data path; the process group only carries the
+    128-byte id): a world-1 communicator, the all-reduce inside the step, bit-identical to the single-graph trajectory; and
+    the raw entry points on a plain buffer."""
+    import ctypes
+    import torch.distributed as dist
+    from genesis_amd import _lib
+    from genesis_amd.dp import CabiAllReduce
+    from genesis_amd.trainer import TrainStep
+    comm = CabiAllReduce()
+    buf = torch.arange(1000, dtype=torch.float32, device=DEV) * 0.25
+    want = buf.clone()
+    comm.run(buf)
+    torch.cuda.synchronize()
+    assert torch.equal(buf, want)
+    comm.close()
+    with pytest.raises(_lib.GenesisHipError):
+        _lib.call('gx_allreduce_init', ctypes.create_string_buffer(128), 128, 3, 2, ctypes.byref(ctypes.c_void_p()))
+    gold = Golden('tiny')
+    x, _, _ = gold.inputs()
+    xd = x.to(DEV)
+
+    def run(ts):
+        torch.manual_seed(7)
+        torch.cuda.manual_seed(7)
+        return torch.stack([ts.step(xd).clone() for _ in range(4)]), ts.flat_p.clone()
+
+    ref = run(TrainStep(build(gold), gold.S, lr=1e-4, graph=True))
+    monkeypatch.setenv('GENESIS_FORCE_ALLREDUCE', '1')
+    monkeypatch.setenv('GENESIS_CABI_ALLREDUCE', '1')
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:29534', rank=0, world_size=1)
+    try:
+        ts = TrainStep(build(gold), gold.S, lr=1e-4, graph=True)
+        got = run(ts)
+        assert ts.bucket._cabi is not None and ts.bucket._cabi.world == 1
+        print('collective captured inside the graph:', ts.collective_in_graph, getattr(ts, 'capture_fallback_reason', ''))
+        ts.bucket._cabi.close()
+    finally:
+        dist.destroy_process_group()
+    assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])
+
+
 def test_checkpoint_is_the_reference_wire_format(tmp_path):
     """TrainStep.state_dict() is the dict train.py:405-420 saves: its optimiser_state_dict loads into a genuine
     torch.optim.Adam (the reference's resume path, train.py:179-207), one torch-Adam step from there equals the next
