@@ -144,24 +144,47 @@ class FlatBucket(object):
                 b.copy_((self.flat_g[o:o + b.numel()] * scale).view(b.shape))
                 o += b.numel()
 
-    def all_reduce(self, group=None, packed=False):
+    def _sum(self, flat, group):
+        if os.environ.get('GENESIS_CABI_ALLREDUCE') and flat.is_cuda:
+            if getattr(self, '_cabi', None) is None:
+                self._cabi = CabiAllReduce(group, flat.device)
+            self._cabi.run(flat)
+        else:
+            dist.all_reduce(flat, group=group)
+
+    def all_reduce_range(self, lo, hi, group=None):
+        """Sum over ranks of flat_g[lo:hi] alone (the part of the bucket that is final early: TrainStep's early flush)."""
+        self._sum(self.flat_g[lo:hi], group)
+
+    def all_reduce(self, group=None, packed=False, done=None):
         """Sum over ranks -- ONE collective for parameters' gradients, the err / kl scalars and the fp64 gradients;
         returns the scale (1/world) that turns the sums into means.  packed: the caller already ran pack64() and will
-        run unpack64() itself (the graph-replay path captures them with the neighbouring kernels)."""
+        run unpack64() itself (the graph-replay path captures them with the neighbouring kernels).  done = (lo, hi): that
+        range was already summed by all_reduce_range -- only the rest travels now."""
         if not self.collective_needed(group):
             return 1.0
         world = dist.get_world_size(group)
         if not packed:
             self.pack64()
-        if os.environ.get('GENESIS_CABI_ALLREDUCE') and self.flat_g.is_cuda:
-            if getattr(self, '_cabi', None) is None:
-                self._cabi = CabiAllReduce(group, self.flat_g.device)
-            self._cabi.run(self.flat_g)
+        if done is None:
+            self._sum(self.flat_g, group)
         else:
-            dist.all_reduce(self.flat_g, group=group)
+            lo, hi = done
+            if lo > 0:
+                self._sum(self.flat_g[:lo], group)
+            if hi < self.flat_g.numel():
+                self._sum(self.flat_g[hi:], group)
         if not packed:
             self.unpack64(1.0 / world)
         return 1.0 / world
+
+    def param_range(self, params):
+        """(lo, hi) of flat_g covered by `params` if they are fp32 and lie back to back in the bucket, else None."""
+        slots = sorted(self.slot[id(p)] for p in params)
+        if not slots or any(s[0] for s in slots):
+            return None
+        lo, hi = slots[0][1], slots[-1][1] + self._pad(slots[-1][2])
+        return (lo, hi) if sum(self._pad(n) for _, _, n in slots) == hi - lo else None
 
     def broadcast_state(self, extra=(), group=None, src=0):
         """Parameters (and any `extra` tensors: optimiser moments, step counter, GECO state, model buffers) from rank

@@ -30,7 +30,7 @@ class _StepState(object):
     TrainSteps in one process never see each other's flags, queues or keep-alive lists.  Autograd runs a HIP node's
     backward on its device thread: every Function below records the context of its forward and makes it current again
     at the start of its backward (ctx_bound), so forward and backward of one step always share one state."""
-    __slots__ = ('direct_param_grads', 'direct_written', 'async_wgrad', 'side_prior', 'side_stream', 'keep_alive')
+    __slots__ = ('direct_param_grads', 'direct_written', 'async_wgrad', 'side_prior', 'side_stream', 'keep_alive', 'early_flush')
 
     def __init__(self):
         self.direct_param_grads = False
@@ -39,6 +39,7 @@ class _StepState(object):
         self.side_prior = False
         self.side_stream = None
         self.keep_alive = []
+        self.early_flush = None        # callable: the decoder's backward is complete (TrainStep, GENESIS_WGQ_EARLY_FLUSH=1)
 
 
 _STEPS = {}
@@ -189,6 +190,16 @@ class side_branch(object):
 
 def join_branch():
     torch.cuda.current_stream().wait_stream(_side())
+
+
+def _decoder_backward_done():
+    """End of DecoderFn.backward.  With TrainStep's early flush on (GENESIS_WGQ_EARLY_FLUSH=1) the weight-gradient / GroupNorm
+    affine jobs queued so far -- the decoder's, i.e. the first half of the bucket to become final -- are finished by a stream-K
+    launch of their own, and the loop's callback may start that half's all-reduce while the encoder's backward runs."""
+    st = step_state()
+    if st.early_flush is not None:
+        hip.defer_flush()
+        st.early_flush()
 
 
 def _ret(out, value):
@@ -664,6 +675,7 @@ class DecoderFn(torch.autograd.Function):
                 dz, dwz, dbz = hip.linear_bwd(z, wz, None, dy.view(dy.shape[0], -1), None)
                 dw, _ = hip.bcast_deconv_unpack(dwz, dbz, coords, w.shape[1], out_dw=ow)
                 grads[0:4] = [_ret(ow, dw), _ret(obias, dbias), _ret(og, dgamma), _ret(ob, dbeta)]
+                _decoder_backward_done()
                 return (dz, None) + tuple(grads)
             dw = _wgrad(lambda h=h, dy=dy, ow=ow: hip.deconv5x5s2_wgrad(h, dy, out=ow), ow, h, dy)
             # the first layer's input is the broadcast latent + 2 coordinate channels: only the D latent
@@ -671,6 +683,7 @@ class DecoderFn(torch.autograd.Function):
             da = hip.deconv5x5s2_dgrad(dy, w, ctx.D if l == 0 else None)
             grads[4 * l:4 * l + 4] = [_ret(ow, dw), _ret(obias, dbias), _ret(og, dgamma), _ret(ob, dbeta)]
         dz = da.sum((2, 3))
+        _decoder_backward_done()
         return (dz, None) + tuple(grads)
 
 

@@ -79,6 +79,17 @@ class TrainStep(object):
         self.graph = None
         self.graph2 = None
         self._split = False
+        # GENESIS_WGQ_EARLY_FLUSH=1 (GENESIS-V2): a stream-K flush of its own for the decoder's weight gradients at the end of the
+        # decoder's backward, and -- several ranks, eager or collective-in-graph launch modes -- that range of the bucket
+        # all-reduced on a second stream while the encoder's backward runs ("as soon as the last grad is
+        # written, overlapped"); the rest of the bucket follows at the end of the backward as before
+        dec = getattr(model, 'decoder_module', None)          # (GenesisV2: ConvTranspose + GroupNorm stack + the 1x1 head)
+        self._early_range = None
+        if os.environ.get('GENESIS_WGQ_EARLY_FLUSH') == '1' and isinstance(dec, torch.nn.Module):
+            self._early_range = self.bucket.param_range(list(dec.parameters()))
+        self._early_side = None
+        self._early_done = False
+        self._early_collective_ok = True      # (False while capturing the two-graph form: no collective inside those graphs)
         self.use_graph = graph
         self._static_x = None
         self._out = None
@@ -126,6 +137,7 @@ class TrainStep(object):
         _hip.defer_state().on = self.defer_reduces
         st.async_wgrad = self.async_wgrad
         st.side_prior = self.side_prior
+        st.early_flush = self._early_collective if self._early_range is not None else None
         if self._hip_noise:
             self._noise_prev = self.model.__dict__.get('noise')
             self._noise_hook = self._draw_noise
@@ -143,6 +155,7 @@ class TrainStep(object):
         st.direct_param_grads = False
         st.async_wgrad = False
         st.side_prior = False
+        st.early_flush = None
         _hip.defer_state().on = False
         _hip.defer_discard()             # no-op after a completed iteration (the queue was flushed)
 
@@ -204,15 +217,37 @@ class TrainStep(object):
         except Exception:
             pass
 
+    def _early_collective(self):
+        """DecoderFn's backward is complete and its queued weight gradients have been flushed: the decoder's range of the
+        bucket is final.  Several ranks: start its all-reduce on the second stream (a parallel branch when captured)."""
+        if not (self._early_collective_ok and self.bucket.collective_needed(self.pg)):
+            return
+        if self._early_side is None:
+            self._early_side = torch.cuda.Stream()
+        cur = torch.cuda.current_stream()
+        self._early_side.wait_stream(cur)
+        with torch.cuda.stream(self._early_side), torch.no_grad():
+            self.bucket.all_reduce_range(self._early_range[0], self._early_range[1], self.pg)
+        self._early_done = True
+
+    def _final_all_reduce(self, packed=False):
+        """The collective at the end of the backward: the whole bucket, or what the early one left."""
+        done = None
+        if self._early_done:
+            torch.cuda.current_stream().wait_stream(self._early_side)
+            done, self._early_done = self._early_range, False
+        return self.bucket.all_reduce(self.pg, packed=packed, done=done)
+
     def _iteration_body(self, x, **forward_kwargs):
         st = self._forward_backward(x, **forward_kwargs)
         with torch.no_grad():
-            gscale = self.bucket.all_reduce(self.pg)
+            gscale = self._final_all_reduce()
             return self._update(st, gscale)
 
     def _forward_backward(self, x, **forward_kwargs):
         """zero-grad'ed bucket -> forward -> loss -> backward; leaves (err, kl) batch means in the bucket tail."""
         self._grads_clean = False
+        self._early_done = False
         if self.beta_warmup:       # this iteration's beta from the device step counter (= the iteration index, train.py:254)
             _lib.call('gx_beta_warmup', _p(self.step_t), float(self.beta_fixed), 0.2 * float(self.train_iter),
                       _p(self._beta_fixed_t), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
@@ -367,7 +402,7 @@ class TrainStep(object):
                         st = self._forward_backward(self._static_x)
                         with torch.no_grad():
                             self.bucket.pack64()
-                            self.bucket.all_reduce(self.pg, packed=True)
+                            self._final_all_reduce(packed=True)
                             self.bucket.unpack64(self._gscale)
                             self._out = self._update(st, self._gscale)
                     finally:
@@ -396,6 +431,7 @@ class TrainStep(object):
         else:
             self._gscale = 1.0 / self.world
             self.graph = torch.cuda.CUDAGraph()
+            self._early_collective_ok = False      # (the early flush stays; its collective needs the eager / in-graph forms)
             # thread_local: the process group's watchdog thread polls events while we capture
             with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
                 self._begin()

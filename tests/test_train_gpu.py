@@ -231,6 +231,47 @@ def test_cabi_allreduce_in_the_step_matches_single_graph(monkeypatch):
     assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])
 
 
+def test_early_decoder_flush_and_its_collective(monkeypatch):
+    """GENESIS_WGQ_EARLY_FLUSH=1: the decoder's queued weight gradients get a stream-K launch of their own at the end of the
+    decoder's backward, and with a collective in the step that range of the bucket is all-reduced on a second stream while the
+    encoder's backward runs (a parallel branch of the captured step).  The two-flush trajectory equals the single-flush one up
+    to fp32 summation order (a stream-K launch cuts its tile line by what else is in the launch); with the (world-1) RCCL
+    collective split in two it must equal the two-flush trajectory WITHOUT a collective bit for bit."""
+    import torch.distributed as dist
+    from genesis_amd.trainer import TrainStep
+    gold = Golden('tiny')
+    x, _, _ = gold.inputs()
+    xd = x.to(DEV)
+
+    def run(ts, n=4):
+        torch.manual_seed(7)
+        torch.cuda.manual_seed(7)
+        return torch.stack([ts.step(xd).clone() for _ in range(n)]), ts.flat_p.clone()
+
+    ref = run(TrainStep(build(gold), gold.S, lr=1e-4, graph=True))
+    monkeypatch.setenv('GENESIS_WGQ_EARLY_FLUSH', '1')
+    ts = TrainStep(build(gold), gold.S, lr=1e-4, graph=True)
+    assert ts._early_range is not None and 0 < ts._early_range[1] - ts._early_range[0] < ts.n32
+    early = run(ts)
+    # (the KL of this tiny model is ~2 on an ELBO of 2000: its fifth digit moves with the gradients' summation order)
+    assert torch.allclose(early[0], ref[0], rtol=2e-4), (early[0], ref[0])
+    assert float((early[1] - ref[1]).norm() / ref[1].norm()) < 1e-5
+    monkeypatch.setenv('GENESIS_FORCE_ALLREDUCE', '1')
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29535', rank=0, world_size=1)
+    try:
+        ts = TrainStep(build(gold), gold.S, lr=1e-4, graph=True)
+        got = run(ts)
+        assert ts.collective_in_graph, getattr(ts, 'capture_fallback_reason', '')
+        assert ts._early_side is not None            # the decoder range travelled on the second stream
+        ts_e = TrainStep(build(gold), gold.S, lr=1e-4, graph=False)
+        got_eager = run(ts_e)
+        assert ts_e._early_side is not None
+    finally:
+        dist.destroy_process_group()
+    assert torch.equal(early[0], got[0]) and torch.equal(early[1], got[1])
+    assert torch.allclose(got_eager[0], early[0], rtol=2e-4)
+
+
 def test_checkpoint_is_the_reference_wire_format(tmp_path):
     """TrainStep.state_dict() is the dict train.py:405-420 saves: its optimiser_state_dict loads into a genuine
     torch.optim.Adam (the reference's resume path, train.py:179-207), one torch-Adam step from there equals the next
