@@ -49,4 +49,7 @@ done
 export RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533
 GENESIS_FORCE_ALLREDUCE=1 python bench.py --steps 50 --warmup 10 $Q 2> /dev/null > $OUT/bench_1gpu_forced_allreduce.json
 GENESIS_FORCE_ALLREDUCE=1 GENESIS_GRAPH_ALLREDUCE=0 python bench.py --steps 50 --warmup 10 $Q 2> /dev/null > $OUT/bench_1gpu_forced_allreduce_split_graphs.json
+# 6b. the same collective through the library's own entry points (gx_allreduce_*), and the early decoder flush + early collective
+GENESIS_FORCE_ALLREDUCE=1 GENESIS_CABI_ALLREDUCE=1 python bench.py --steps 50 --warmup 10 $Q 2> /dev/null > $OUT/bench_1gpu_forced_allreduce_cabi.json
+GENESIS_FORCE_ALLREDUCE=1 GENESIS_WGQ_EARLY_FLUSH=1 python bench.py --steps 50 --warmup 10 $Q 2> /dev/null > $OUT/bench_1gpu_forced_allreduce_early_flush.json
 ls -la $OUT
