@@ -129,3 +129,21 @@ def test_library_contexts():
         _lib.call('gx_ctx_destroy', b)
     with pytest.raises(_lib.GenesisHipError):
         _lib.make_current(a)                         # destroyed
+
+
+def test_allreduce_entry_points_validate_before_touching_rccl():
+    """gx_allreduce_* (the step's collective behind the C ABI, include/genesis_hip.h): the id size and the argument checks run
+    before RCCL is resolved, so they can be exercised without a GPU."""
+    import ctypes
+    from genesis_amd import _lib
+    lib = _lib.load()
+    assert int(lib.gx_allreduce_unique_id_bytes()) == 128
+    h = ctypes.c_void_p()
+    ident = ctypes.create_string_buffer(128)
+    for rank, world in ((2, 2), (-1, 1), (0, 0)):
+        assert lib.gx_allreduce_init(ident, 128, rank, world, ctypes.byref(h)) != 0
+        assert 'rank' in _lib.last_error()
+    assert lib.gx_allreduce_init(ident, 64, 0, 1, ctypes.byref(h)) != 0            # id buffer too small
+    assert lib.gx_allreduce_unique_id(ident, 16) != 0
+    assert lib.gx_allreduce_run(None, None, 0, None) != 0                            # null communicator
+    assert lib.gx_allreduce_destroy(None) == 0

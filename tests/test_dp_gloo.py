@@ -111,6 +111,47 @@ def test_fp64_gradient_rides_the_fp32_tail_exactly_for_one_rank():
     assert torch.equal(buf, torch.arange(5, dtype=torch.float32))
 
 
+def _worker_pieces(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(10 + rank)
+    params = [torch.nn.Parameter(torch.randn(*sh)) for sh in ((5, 3), (7,), (4, 4, 3, 3), (9,), (2, 33))]
+    params.append(torch.nn.Parameter(torch.randn((), dtype=torch.float64)))
+    bucket = FlatBucket(params, n_tail=2)
+    g = torch.Generator().manual_seed(20 + rank)
+    bucket.flat_g.copy_(torch.randn(bucket.flat_g.shape, generator=g))
+    bucket.flat_g64.copy_(torch.randn(bucket.flat_g64.shape, generator=g, dtype=torch.float64))
+    whole = FlatBucket([torch.nn.Parameter(p.detach().clone()) for p in params], n_tail=2)
+    whole.flat_g.copy_(bucket.flat_g)
+    whole.flat_g64.copy_(bucket.flat_g64)
+    rng = bucket.param_range(params[2:4])                # two neighbours: one contiguous slice
+    assert rng is not None and rng[1] - rng[0] == bucket._pad(144) + bucket._pad(9)
+    assert bucket.param_range([params[0], params[2]]) is None            # not back to back
+    assert bucket.param_range([params[5]]) is None                       # fp64: rides the tail
+    bucket.all_reduce_range(rng[0], rng[1])              # the early piece ...
+    s1 = bucket.all_reduce(done=rng)                     # ... and the rest
+    s2 = whole.all_reduce()
+    assert s1 == s2 == 1.0 / world
+    torch.save({'pieces': bucket.flat_g.clone(), 'whole': whole.flat_g.clone(), 'p64': bucket.flat_g64.clone(),
+                'w64': whole.flat_g64.clone()}, os.path.join(out_dir, 'p%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_bucket_reduced_in_pieces_equals_one_collective(tmp_path):
+    """TrainStep's early flush (GENESIS_WGQ_EARLY_FLUSH=1) sends the decoder's slice of the bucket first and the two remaining
+    slices at the end of the backward: FlatBucket.param_range / all_reduce_range / all_reduce(done=...) on two gloo ranks must
+    leave exactly what the single collective leaves (the same element-wise sums), fp64 triples and tail included."""
+    port = _free_port()
+    mp.spawn(_worker_pieces, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), 'p%d.pt' % r)) for r in (0, 1))
+    for r in (r0, r1):
+        assert torch.equal(r['pieces'], r['whole']) and torch.equal(r['p64'], r['w64'])
+    assert torch.equal(r0['pieces'], r1['pieces'])
+
+
 def _worker8(rank, world, port, out_dir):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
