@@ -1319,6 +1319,34 @@ def test_conv3x3_stride2_dgrad_on_the_vector_alus(N, Cin, Cout, S, cin_n):
     assert float(dx[:, n:].abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize('K,B,S,Cout,act', [(7, 32, 64, 32, 'relu'), (3, 2, 16, 8, 'elu'), (1, 5, 8, 4, 'relu')])
+def test_component_vae_first_layer_on_its_stacked_input(K, B, S, Cout, act):
+    """MaskImageConvActFn (modules/component_vae.py:59-66 + modules/encoders.py:31-34): gx_mask_image_stack writes the slot-major
+    [log_m_k | x] batch bit-exactly (it is a copy), the layer equals act(conv2d(cat(log_m_k, x), stride 2, pad 1)), and the
+    compact mask gradient (gx_conv3x3s2_dgrad_small_ex) / the parameter gradients equal autograd's through cat + repeat."""
+    from genesis_amd import functions as fn
+    log_m = (rnd(K, B, 1, S, S, seed=1) - 1.5)
+    x = rnd(B, 3, S, S, seed=2) * 0.5 + 0.5
+    w = rnd(Cout, 4, 3, 3, seed=3, scale=0.3)
+    b = rnd(Cout, seed=4, scale=0.1)
+    g = rnd(K * B, Cout, S // 2, S // 2, seed=5)
+    want = torch.cat((log_m.flatten(0, 1), x.repeat(K, 1, 1, 1)), 1)
+    assert torch.equal(hip.mask_image_stack(log_m.to(DEV), x.to(DEV)).cpu(), want)
+    lm_r, w_r, b_r = (t.double().requires_grad_() for t in (log_m, w, b))
+    inp = torch.cat((lm_r.flatten(0, 1), x.double().repeat(K, 1, 1, 1)), 1)
+    y_r = getattr(F, act)(F.conv2d(inp, w_r, b_r, 2, 1))
+    y_r.backward(g.double())
+    lm_d = log_m.to(DEV).requires_grad_()
+    w_d, b_d = w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    y = fn.MaskImageConvActFn.apply(lm_d, x.to(DEV), w_d, b_d, act)
+    close(y, y_r, rtol=1e-5, atol=1e-5, msg='y')
+    y.backward(g.to(DEV))
+    assert lm_d.grad.shape == log_m.shape and lm_d.grad.is_contiguous()
+    close(lm_d.grad, lm_r.grad, rtol=1e-5, atol=1e-5, msg='d log_m')
+    close(w_d.grad, w_r.grad, rtol=1e-5, atol=2e-6 * float(w_r.grad.abs().max()), msg='dw')
+    close(b_d.grad, b_r.grad, rtol=1e-5, atol=2e-6 * float(b_r.grad.abs().max()), msg='db')
+
+
 @pytest.mark.parametrize('N,Cin,Cout,S', [(224, 4, 32, 64), (37, 32, 32, 32), (40, 32, 64, 16), (70, 64, 64, 8), (2, 6, 10, 12),
                                           (1, 3, 5, 2)])
 def test_conv3x3_stride2_wgrad_on_the_vector_alus(N, Cin, Cout, S):
