@@ -39,6 +39,7 @@ CASES = {
     'v2_metric_b32': ('v2', dict(K_steps=7, img_size=64, feat_dim=64), 32, 118, 128),
     'v2_cfg2_b64': ('v2', dict(K_steps=5, img_size=64, feat_dim=64), 64, 119, 129),
     'v2_cfg5_b4': ('v2', dict(K_steps=11, img_size=128, feat_dim=64), 4, 120, 130),
+    'v2_cfg5_b32': ('v2', dict(K_steps=11, img_size=128, feat_dim=64), 32, 121, 131),      # config 5 at its per-GPU batch
     'genesis_cfg3_b32': ('genesis', dict(K_steps=7, img_size=64), 32, 155, 165),
     'monet_cfg4_b32': ('monet', dict(K_steps=7, img_size=64), 32, 133, 143),
 }
