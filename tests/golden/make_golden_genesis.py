@@ -18,7 +18,8 @@ from oracle import genesis_oracle as GO  # noqa: E402
 from oracle import vae_oracle as VO  # noqa: E402
 
 VAE_CASES = {'tiny': (dict(img_size=32, latent_dimension=16), 2, 51, 61), 'cfg1': (dict(img_size=64), 2, 52, 62),
-             'tiny_bcast': (dict(img_size=32, latent_dimension=16, broadcast_decoder=True), 2, 56, 66)}
+             'tiny_bcast': (dict(img_size=32, latent_dimension=16, broadcast_decoder=True), 2, 56, 66),
+             'cfg1_b32': (dict(img_size=64), 32, 152, 162)}          # BASELINE config 1 at its batch
 GEN_CASES = {'tiny': (dict(K_steps=3, img_size=32, attention_latents=16, comp_ldim=8), 2, 53, 63),
              'tiny_in': (dict(K_steps=3, img_size=32, attention_latents=16, comp_ldim=8, enc_norm='in', dec_norm='in'), 3, 54, 64),
              'cfg3': (dict(K_steps=7, img_size=64), 2, 55, 65),

@@ -12,7 +12,7 @@ from oracle import genesis_oracle as GO
 from oracle import vae_oracle as VO
 
 GOLDEN = osp.join(osp.dirname(osp.abspath(__file__)), 'golden')
-VAE_CASES = ['tiny', 'cfg1', 'tiny_bcast']
+VAE_CASES = ['tiny', 'cfg1', 'tiny_bcast', 'cfg1_b32']
 GEN_CASES = ['tiny', 'tiny_in', 'cfg3', 'tiny_noprior', 'tiny_onestage', 'tiny_sym']
 
 
