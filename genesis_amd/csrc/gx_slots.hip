@@ -61,28 +61,50 @@ maskpool_fwd_kernel(const float* __restrict__ f, const float* __restrict__ log_m
     }
     const float* fb = f + ((size_t)b * C + c0) * HW;
     if ((HW & 3) == 0) {
-        // 16-byte loads, 4 pixels per thread and iteration: 4x fewer serial load -> use steps (the loop is latency-bound)
-        for (int p4 = threadIdx.x; p4 < (HW >> 2); p4 += blockDim.x) {
-            f32x4 fv[PCH];
-#pragma unroll
-            for (int c = 0; c < PCH; ++c) {
-                if (c0 + c < C) fv[c] = *reinterpret_cast<const f32x4*>(fb + (size_t)c * HW + 4 * p4);
-                else { fv[c][0] = 0.f; fv[c][1] = 0.f; fv[c][2] = 0.f; fv[c][3] = 0.f; }
-            }
-#pragma unroll
-            for (int k = 0; k < KMAX; ++k) {
-                if (k < K) {
-                    const f32x4 lm = *reinterpret_cast<const f32x4*>(log_m + k * kstride + (size_t)b * HW + 4 * p4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float m = expf(lm[e]);
-                        ms[k] += (double)m;
-#pragma unroll
-                        for (int c = 0; c < PCH; ++c) acc[k][c] += (double)(m * fv[c][e]);
-                    }
-                }
-            }
+        // 16-byte loads, 4 pixels per thread and iteration: 4x fewer serial load -> use steps (the loop is latency-bound);
+        // the loads of iteration i + 1 are issued ahead of iteration i's sums (two register sets): at 64 x 64 a thread has four
+        // iterations, each of which used to start with its 4 + K loads' full latency
+        const int n4 = HW >> 2;
+        f32x4 fv[2][PCH], lmv[2][KMAX];
+#define GX_MP_LOAD(set_, p4_)                                                                                   \
+        {                                                                                                       \
+            _Pragma("unroll") for (int c = 0; c < PCH; ++c) {                                                   \
+                if (c0 + c < C) fv[set_][c] = *reinterpret_cast<const f32x4*>(fb + (size_t)c * HW + 4 * (p4_)); \
+                else { fv[set_][c][0] = 0.f; fv[set_][c][1] = 0.f; fv[set_][c][2] = 0.f; fv[set_][c][3] = 0.f; } \
+            }                                                                                                   \
+            _Pragma("unroll") for (int k = 0; k < KMAX; ++k)                                                    \
+                if (k < K) lmv[set_][k] = *reinterpret_cast<const f32x4*>(log_m + k * kstride + (size_t)b * HW + 4 * (p4_)); \
         }
+#define GX_MP_SUM(set_)                                                                                         \
+        {                                                                                                       \
+            /* (the products are rounded to fp32 BEFORE they are widened, like the reference's fp32 multiply: widening the  \
+               operands once and using exact fp64 products is 5 us faster -- v_cvt_f64_f32 runs at a quarter of the fp64 \
+               FMA rate -- but moves the pooled features' last bits, and with them a ReLU decision of the small golden   \
+               case: z_head.3.weight 8e-4 from the fixture against its 5e-4 bar; measured and not kept) */            \
+            _Pragma("unroll") for (int k = 0; k < KMAX; ++k) {                                                  \
+                if (k < K) {                                                                                    \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                             \
+                        const float m = expf(lmv[set_][k][e]);                                                  \
+                        ms[k] += (double)m;                                                                     \
+                        _Pragma("unroll") for (int c = 0; c < PCH; ++c) acc[k][c] += (double)(m * fv[set_][c][e]); \
+                    }                                                                                           \
+                }                                                                                               \
+            }                                                                                                   \
+        }
+        int p4 = threadIdx.x;
+        if (p4 < n4) GX_MP_LOAD(0, p4)
+        while (p4 < n4) {
+            const int q4 = p4 + (int)blockDim.x;
+            if (q4 < n4) GX_MP_LOAD(1, q4)
+            GX_MP_SUM(0)
+            if (q4 >= n4) break;
+            const int r4 = q4 + (int)blockDim.x;
+            if (r4 < n4) GX_MP_LOAD(0, r4)
+            GX_MP_SUM(1)
+            p4 = r4;
+        }
+#undef GX_MP_LOAD
+#undef GX_MP_SUM
     } else {
         for (int p = threadIdx.x; p < HW; p += blockDim.x) {
             float fv[PCH];
