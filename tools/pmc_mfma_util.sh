@@ -6,7 +6,7 @@ OUT=$R/gpurun_out/profiles_new
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export GENESIS_BENCH_LONG_STEPS=0
-CMD="python $R/bench.py --steps 2 --warmup 1 --no-graph --profile-steps 0 --cpu-seconds 0 --fp32-pipe-steps 0 --host-input-steps 0 --extra-leg-steps 0"
+CMD="python $R/bench.py $PMC_BENCH_ARGS --steps 2 --warmup 1 --no-graph --profile-steps 0 --cpu-seconds 0 --fp32-pipe-steps 0 --host-input-steps 0 --extra-leg-steps 0"      # PMC_BENCH_ARGS: another configuration (e.g. "--model monet")
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace -d /tmp/pm1 -o m --output-format csv -- $CMD > /tmp/pm1.log 2>&1
 python - <<'PY'
 import csv, glob, json, collections, os
