@@ -8,7 +8,7 @@ import sys
 HERE = osp.dirname(osp.abspath(__file__))
 CSRC = osp.join(HERE, 'csrc')
 LIB = osp.join(HERE, 'libgenesis_hip.so')
-SOURCES = ['gx_api.cpp', 'gx_comm.cpp', 'gx_conv.hip', 'gx_norm.hip', 'gx_attention.hip', 'gx_slots.hip', 'gx_optim.hip', 'gx_misc.hip', 'gx_gated.hip', 'gx_latent.hip', 'gx_dense.hip', 'gx_igemm.hip', 'gx_metrics.hip', 'gx_feed.hip', 'gx_wino.hip', 'gx_kq.hip', 'gx_bcast.hip', 'gx_sbp.hip', 'gx_wgq.hip']
+SOURCES = ['gx_api.cpp', 'gx_comm.cpp', 'gx_conv.hip', 'gx_norm.hip', 'gx_attention.hip', 'gx_slots.hip', 'gx_optim.hip', 'gx_misc.hip', 'gx_gated.hip', 'gx_latent.hip', 'gx_dense.hip', 'gx_igemm.hip', 'gx_metrics.hip', 'gx_feed.hip', 'gx_wino.hip', 'gx_kq.hip', 'gx_bcast.hip', 'gx_sbp.hip', 'gx_wgq.hip', 'gx_wstrip.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value',
          '-Wno-pass-failed']

@@ -215,6 +215,10 @@ int gx_wgq_deconv(const float* x, const float* dy, float* dw, int N, int Cin, in
 bool gx_wgq_c5_eligible(int N, int CA, int CB, int H, int W);
 int gx_wgq_c5(const float* a, const float* b, float* dw, int N, int CA, int CB, int H, int W, float* ws, int ws_slabs,
               hipStream_t s);
+// gx_wstrip.hip: the 32 -> 32 conv3x3 weight gradient as column strips (grids that are no power of two, W % 8 == 0)
+bool gx_wstrip_supported(int N, int C, int H, int W);
+size_t gx_wstrip_ws_floats(int N, int C, int H, int W);
+int gx_wstrip_launch(const float* x, const float* dy, float* dw, float* dbias, int N, int C, int H, int W, void* ws, hipStream_t s);
 bool gx_wgq_bf16_pipe(void);      // gx_wgq_precision / GENESIS_WGQ_BF16X6: weight gradients on the bf16 matrix pipe (six piece products)
 int gx_wgq_pending(void);
 void gx_wgq_discard(void);

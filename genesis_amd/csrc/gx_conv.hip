@@ -2517,7 +2517,9 @@ int gx_conv3x3_wgrad_quad_supported(int N, int C, int H, int W) {
 size_t gx_conv3x3_wgrad_quad_ws_bytes(int N, int C, int H, int W) {
     WgradPlan pl;
     if (!wgrad_quad_plan(N, C, H, W, &pl)) return 0;
-    return pl.ws_floats * sizeof(float);
+    size_t fl = pl.ws_floats;
+    if (gx_wstrip_supported(N, C, H, W) && gx_wstrip_ws_floats(N, C, H, W) > fl) fl = gx_wstrip_ws_floats(N, C, H, W);
+    return fl * sizeof(float);
 }
 static int wgrad_quad_impl(const float* x, const float* dy, float* dw, float* dbias, int N, int C, int H, int W, void* ws,
                            size_t ws_bytes, gx_stream_t stream);
@@ -2531,7 +2533,9 @@ size_t gx_conv3x3_wgrad_quad_bias_ws_bytes(int N, int C, int H, int W) {
     WgradPlan pl;
     if (!wgrad_quad_plan(N, C, H, W, &pl)) return 0;
     const size_t rec = (size_t)pl.g.nsplit * 256, planes = (size_t)N * C;
-    return (pl.ws_floats + (rec > planes ? rec : planes)) * sizeof(float);
+    size_t fl = pl.ws_floats + (rec > planes ? rec : planes);
+    if (gx_wstrip_supported(N, C, H, W) && gx_wstrip_ws_floats(N, C, H, W) > fl) fl = gx_wstrip_ws_floats(N, C, H, W);
+    return fl * sizeof(float);
 }
 int gx_conv3x3_wgrad_quad_bias(const float* x, const float* dy, float* dw, float* dbias, int N, int C, int H, int W, void* ws,
                                size_t ws_bytes, gx_stream_t stream) {
@@ -2547,6 +2551,9 @@ static int wgrad_quad_impl(const float* x, const float* dy, float* dw, float* db
     GX_CHECK_ARG(wgrad_quad_plan(N, C, H, W, &pl), "gx_conv3x3_wgrad_quad: needs 32 channels, N %% 4 == 0, W %% 4 == 0");
     GX_CHECK_ARG(ws_bytes >= pl.ws_floats * sizeof(float), "gx_conv3x3_wgrad_quad: workspace too small");
     hipStream_t s = (hipStream_t)stream;
+    // grids that are no power of two (the 72 x 72 canvas): column strips straight from global memory (gx_wstrip.hip)
+    if (!gx_is_pow2(W) && gx_wstrip_supported(N, C, H, W) && ws_bytes >= gx_wstrip_ws_floats(N, C, H, W) * sizeof(float))
+        return gx_wstrip_launch(x, dy, dw, dbias, N, C, H, W, ws, s);
     const float* zeros = zero_page(s);
     if (!zeros) { gx_set_error("gx_conv3x3_wgrad_quad: no zero page (first call inside a stream capture)"); return GX_ELAUNCH; }
     WgradGeom g = pl.g;

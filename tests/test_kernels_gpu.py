@@ -1483,7 +1483,10 @@ def test_conv1x1_backward_with_the_previous_layers_activation_backward(N, Cin, C
     close(dbx, dxa.double().sum((0, 2, 3)), rtol=1e-6, atol=1e-6, msg='dbias')
 
 
-@pytest.mark.parametrize('N,H,W', [(8, 72, 72), (4, 16, 12), (12, 8, 8), (20, 64, 64)])
+@pytest.mark.parametrize('N,H,W', [(8, 72, 72), (4, 16, 12), (12, 8, 8), (20, 64, 64),
+                                   # grids that are no power of two with W % 8 == 0: the column-strip kernel (gx_wstrip.hip) --
+                                   # odd strip counts, a segment shorter than the rest, one row segment, the workload's shape
+                                   (4, 24, 40), (8, 12, 24), (4, 72, 8), (224, 72, 72)])
 def test_conv3x3_weight_gradient_with_four_images_per_tile(N, H, W):
     """gx_conv3x3_wgrad_quad (the BroadcastDecoder's 32 -> 32 canvas convs): four images per workgroup, one per wave, the four
     quadrant slabs summed by the reduce.  Against autograd in fp64 and bit-reproducible."""
