@@ -32,6 +32,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 PEAK_HBM_GBS = 8000.0
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 (v_mfma_f32_32x32x16_bf16); the LDS-DMA weight-gradient kernels form every
 BF16X6_TERMS = 6                  # fp32 product from six bf16 piece products on that pipe (include/genesis_hip.h: gx_wgq_precision)
+F16X3_TERMS = 3                   # ... from three fp16 piece products, same pipe rate (gx_kq_precision(2): the gx_kq.hip kernels' default)
 
 
 def parse():
@@ -382,11 +383,13 @@ def main():
                                       'ms_per_step': 1e3 * dt_long / long_steps,
                                       'note': 'the same loop over a longer window, after the timed region (max over ranks)'}
         if os.environ.get('GENESIS_WGQ_BF16X6', '1') != '0':
-            result['arithmetic'] = ('fp32 tensors and fp32 accumulation everywhere; the weight gradients, the Winograd conv3x3 layers and the chip-filling '
-                                    'transposed-conv forward / data-gradient layers form every fp32 product from six bf16 piece '
-                                    'products on the bf16 matrix pipe (hi+mid+lo pieces hold all 24 mantissa bits: error vs '
-                                    'fp64 as on the fp32 pipe, tests/test_kernels_gpu.py *_bf16_pipe_*); everything else on the '
-                                    'fp32 pipe; GENESIS_WGQ_BF16X6=0 GENESIS_KQ_BF16X6=0 GENESIS_WINO_BF16X6=0 put all of it back there')
+            result['arithmetic'] = ('fp32 tensors and fp32 accumulation everywhere; the weight gradients and the Winograd conv3x3 layers '
+                                    'form every fp32 product from six bf16 piece products on the bf16 matrix pipe (hi+mid+lo pieces hold '
+                                    'all 24 mantissa bits), the chip-filling transposed-conv forward / data-gradient layers (and the '
+                                    'other gx_kq.hip kernels) from three fp16 piece products of per-tensor power-of-two-scaled operands '
+                                    '(hi+lo = 22 bits, the dropped term is 2^-22 of a product; GENESIS_KQ_F16X3=0: six bf16 ones): error '
+                                    'vs fp64 as on the fp32 pipe, tests/test_kernels_gpu.py *_bf16_pipe_* / *fp16x3*; everything else on '
+                                    'the fp32 pipe; GENESIS_WGQ_BF16X6=0 GENESIS_KQ_BF16X6=0 GENESIS_WINO_BF16X6=0 put all of it back there')
         if rehearsal:
             result['rehearsal'] = 'all %d ranks on ONE GPU, gloo collective: exercises the launch path only, not a measurement' % world
         if getattr(ts, 'capture_fallback_reason', None):
@@ -439,14 +442,18 @@ def main():
                 on_bf16 = wino_b6 or (dom['name'] == 'wgq_stream_kernel' and os.environ.get('GENESIS_WGQ_BF16X6', '1') != '0') or \
                           (dom['name'] in ('kq_dth_kernel', 'kq_dgh_kernel', 'kq_c3h_kernel', 'kq_c5h_kernel') and os.environ.get('GENESIS_KQ_BF16X6', '1') != '0')
                 if on_bf16:
-                    # `achieved` counts the algorithmic fp32 flops; the kernel executes six bf16 MFMA products for each of
-                    # them, so its ceiling is the bf16 pipe's dense peak / 6 -- a higher one than the fp32 pipe's 157.3 TF/s
-                    mfma_peak = PEAK_BF16_MFMA_TFLOPS / BF16X6_TERMS
+                    # `achieved` counts the algorithmic fp32 flops; the kernel executes six bf16 (gx_kq.hip's kernels: three
+                    # fp16) MFMA products for each of them, so its ceiling is the 16-bit pipe's dense peak / 6 (/ 3) -- a higher
+                    # one than the fp32 pipe's 157.3 TF/s
+                    f16x3 = dom['name'].startswith('kq_') and os.environ.get('GENESIS_KQ_F16X3', '1') != '0'
+                    terms = F16X3_TERMS if f16x3 else BF16X6_TERMS
+                    mfma_peak = PEAK_BF16_MFMA_TFLOPS / terms
                     roof['peak'] = mfma_peak
-                    roof['pipe'] = ('bf16 MFMA, fp32 products as %d bf16 piece products (fp32 accumulate): peak = %.0f / %d; '
+                    roof['pipe'] = ('%s MFMA, fp32 products as %d %s piece products (fp32 accumulate): peak = %.0f / %d; '
                                     'against the fp32 pipe (%.1f TF/s) the same rate is frac_of_fp32_pipe'
-                                    % (BF16X6_TERMS, PEAK_BF16_MFMA_TFLOPS, BF16X6_TERMS, PEAK_FP32_MFMA_TFLOPS))
-                    roof['achieved_on_bf16_pipe'] = ach * BF16X6_TERMS
+                                    % ('fp16' if f16x3 else 'bf16', terms, 'fp16' if f16x3 else 'bf16', PEAK_BF16_MFMA_TFLOPS, terms,
+                                       PEAK_FP32_MFMA_TFLOPS))
+                    roof['achieved_on_bf16_pipe'] = ach * terms
                 if dom['name'] == 'wino_conv_kernel':
                     # `achieved` is ALGORITHMIC (direct-sum) flops / time, as for every kernel; the Winograd kernel executes
                     # 16 multiplies where the direct sum has 36: the ceiling of the ALGORITHM on the fp32 pipe is 2.25 x the

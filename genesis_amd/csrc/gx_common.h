@@ -181,11 +181,60 @@ int gx_kq_deconv_dgrad_launch(const float* dy, const float* wp, float* dx, int N
 // [octet][64 output channels][8 channels] in bf16 (two per 32-bit word)
 bool gx_kq_deconv_h_eligible(int N, int K, int M, int Hb, int Wb);
 size_t gx_kq_deconv_h_pack_bytes(int K, int M, int nt);
+// ... or from THREE fp16 piece products (gx_kq_precision(2), DESIGN.md finding 40): x * 2^e = hi + lo (11 + 11 significant bits),
+// hi*hi + hi*lo + lo*hi; e per TENSOR from its largest magnitude so that the pieces sit inside fp16's exponent range.  Pack kinds
+// 40 / 41 / 42 / 43 / 44 / 47 / 48 = 20 / 21 / 22 / 23 / 24 / 27 / 28 as two fp16 pieces of w * 2^e (third piece slot unused); the weight tensor's amax lives in the last
+// 64 bytes of the packing's slack (written by the amax launch that precedes the pack, read by the pack and by the conv kernels).
+bool gx_kq_f16_on();
+__host__ __device__ __forceinline__ size_t gx_kq_h_amax_off(int K, int M, int nt) {      // byte offset of that float
+    return (size_t)((M + 63) / 64) * (K / 16) * nt * 6144 + 16384 - 64;
+}
+__host__ __device__ __forceinline__ int gx_f16_scale_exp(float amax) {     // amax * 2^e in [2^14, 2^15); 0 / inf / nan: e = 0
+    if (!(amax > 0.f) || amax > 3.0e38f) return 0;
+    int ex;
+    (void)frexpf(amax, &ex);
+    return 15 - ex;
+}
+// amax of a tensor (n floats) -> ws[0]; ws: gx_kq_amax_ws_floats() floats (two launches: partial maxima, then one workgroup)
+constexpr int kAmaxParts = 1024;
+__host__ __device__ __forceinline__ constexpr size_t gx_kq_amax_ws_floats() { return 16 + kAmaxParts; }
+int gx_kq_amax_launch(const float* x, size_t n, float* ws, hipStream_t s);
+#ifdef __HIPCC__
+// |.|-maximum of n floats by ONE workgroup of 1024 threads (a weight tensor: ~100 k floats; 16-byte loads, eight in flight per thread);
+// the result is valid in thread 0
+__device__ __forceinline__ float gx_wg1024_amax(const float* __restrict__ w, int n) {
+    typedef float gx_amax_f4 __attribute__((ext_vector_type(4)));
+    float m = 0.f;
+    int done = 0;
+    if ((reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+        const gx_amax_f4* w4 = reinterpret_cast<const gx_amax_f4*>(w);
+        const int n4 = n >> 2;
+#pragma unroll 8
+        for (int i = threadIdx.x; i < n4; i += 1024) {
+            const gx_amax_f4 v = w4[i];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        }
+        done = n4 << 2;
+    }
+    for (int i = done + threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float gx_amax_red[16];
+    if ((threadIdx.x & 63) == 0) gx_amax_red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    float r = gx_amax_red[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) r = fmaxf(r, gx_amax_red[i]);
+    return r;
+}
+#endif
+int gx_kq_weight_amax_launch(const float* w, int n, float* out, hipStream_t s);          // one workgroup (weights are small)
 bool gx_kq_deconv_dgrad_h_eligible(int N, int K, int M, int Hb, int Wb);      // pack 24: all 25 taps, plane-major slots
 int gx_kq_deconv_dgrad_h_launch(const float* dy, const float* wp, float* dx, int N, int K, int M, int Hb, int Wb,
-                                hipStream_t s);
+                                hipStream_t s, float* amax_ws = nullptr, const float* w_amax = nullptr);
 int gx_kq_deconv_fwd_h_launch(const float* in, const float* wp0, const float* wp1, const float* bias, float* out, int N,
-                              int K, int M, int Hb, int Wb, float* stats, int* stats_parts, hipStream_t s);
+                              int K, int M, int Hb, int Wb, float* stats, int* stats_parts, hipStream_t s,
+                              float* amax_ws = nullptr, const float* w_amax = nullptr);    // amax_ws != NULL: the fp16 x 3 form (packs 42 / 43)
 // 32-bit word of element (m, k even, k + 1) of piece `piece` of tap t
 // ... kinds 20 / 21 (conv3x3 forward / data gradient of <= 32-output-channel layers): 32 output channels per channel tile
 __host__ __device__ __forceinline__ size_t gx_kq_h32_word(int m, int k, int t, int piece, int NT, int K) {
@@ -193,11 +242,13 @@ __host__ __device__ __forceinline__ size_t gx_kq_h32_word(int m, int k, int t, i
 }
 bool gx_kq_c3h_eligible(int N, int K, int M, int H, int W);
 int gx_kq_c3h_launch(const float* in, const float* wp, const float* bias, int act, float* out, int N, int K, int M, int H,
-                     int W, hipStream_t s, const float* mask = nullptr, int mask_act = 0);
+                     int W, hipStream_t s, const float* mask = nullptr, int mask_act = 0, float* amax_ws = nullptr,
+                     const float* w_amax = nullptr);         // amax_ws != NULL: the fp16 x 3 form (packs 40 / 41)
 // 5 x 5 stride-1 conv on the bf16 pipe (pack kinds 27 / 28 = the bf16-piece forms of 7 / 8; K a multiple of 16, H and W of 16)
 bool gx_kq_c5h_eligible(int N, int K, int M, int H, int W);
 int gx_chan_sums_launch(const float* x, int N, int C, int HW, float* part, float* out, hipStream_t s);   // gx_misc.hip
-int gx_kq_c5h_launch(const float* in, const float* wp, float* out, int N, int K, int M, int H, int W, hipStream_t s);
+int gx_kq_c5h_launch(const float* in, const float* wp, float* out, int N, int K, int M, int H, int W, hipStream_t s,
+                     float* amax_ws = nullptr, const float* w_amax = nullptr);      // (packs 47 / 48)
 __host__ __device__ __forceinline__ size_t gx_kq_h_word(int m, int k, int t, int piece, int NT, int K) {
     return ((((size_t)(m >> 6) * (K >> 4) + (k >> 4)) * NT + t) * 3 + piece) * 512 + (((k >> 3) & 1) * 64 + (m & 63)) * 4 + ((k & 7) >> 1);
 }

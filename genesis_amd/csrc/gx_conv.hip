@@ -561,14 +561,25 @@ __device__ __forceinline__ size_t pack_dest(int pack, int idx, int m, int k, int
 
 // packs 25 / 26 (= 5 / 6: the Winograd operands for gx_wino.hip's bf16-pipe kernel), 20 / 21 (= 0 / 1, gx_kq.hip's Q_C3H) and 22 / 23 / 24 (= 2 / 3 / 4 for the bf16 matrix pipe, gx_kq.hip's QCfgDTH / Q_DGH): every weight as three bf16 pieces, two
 // channels per 32-bit word -- the thread of an even k writes the three words of (k, k + 1), the odd one nothing
+// packs 42 / 43 / 44: 22 / 23 / 24 as TWO fp16 pieces of w * 2^f16_exp (gx_kq.hip's fp16 x 3 form; f16_exp from the tensor's amax)
 __device__ __forceinline__ void pack_h_store(const float* __restrict__ w, float* __restrict__ wp, int pack, int Co, int Ci,
-                                             int m, int k, int t, int NT, int Kpad) {
+                                             int m, int k, int t, int NT, int Kpad, int f16_exp = 0) {
     if (k & 1) return;
+    const bool f16 = pack >= 40;
+    if (f16) pack -= 20;
     unsigned wd[3];
     float v[2] = {pack_weight_value(w, pack - 20, Co, Ci, m, k, t), pack_weight_value(w, pack - 20, Co, Ci, m, k + 1, t)};
     unsigned short pc[2][3];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
+        if (f16) {
+            const float ws = ldexpf(v[e], f16_exp);
+            const _Float16 h = (_Float16)ws;
+            pc[e][0] = __builtin_bit_cast(unsigned short, h);
+            pc[e][1] = __builtin_bit_cast(unsigned short, (_Float16)(ws - (float)h));
+            pc[e][2] = 0;
+            continue;
+        }
         const __bf16 h = (__bf16)v[e];
         const float r1 = v[e] - (float)h;
         const __bf16 mm = (__bf16)r1;
@@ -590,11 +601,12 @@ __device__ __forceinline__ void pack_h_store(const float* __restrict__ w, float*
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int pack,
                                     int Co, int Ci, int NT, int Kpad, int Mpad) {
     const int total = NT * Kpad * Mpad;
+    const int f16_exp = pack >= 40 ? gx_f16_scale_exp(*reinterpret_cast<const float*>(reinterpret_cast<const char*>(wp) + gx_kq_h_amax_off(Kpad, Mpad, NT))) : 0;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int m = idx % Mpad;
         const int k = (idx / Mpad) % Kpad;
         const int t = idx / (Mpad * Kpad);
-        if (pack >= 20) { pack_h_store(w, wp, pack, Co, Ci, m, k, t, NT, Kpad); continue; }
+        if (pack >= 20) { pack_h_store(w, wp, pack, Co, Ci, m, k, t, NT, Kpad, f16_exp); continue; }
         wp[pack_dest(pack, idx, m, k, t, Kpad, NT)] = pack_weight_value(w, pack, Co, Ci, m, k, t);
     }
 }
@@ -1552,15 +1564,26 @@ std::mutex g_cache_mutex;
 #define g_cache_recording (gx_ctx_flags().cache_recording)   // cache id being recorded by this context, or -1
 #define g_cache_active (gx_ctx_flags().cache_active)         // cache id this context's conv calls are served from, or -1
 
+// the fp16 x 3 packs' (kinds >= 40) weight tensors: largest magnitude -> the packing's trailer; one workgroup per cache entry (the
+// others return at once); 3 x 3 (kinds 40 / 41) or 5 x 5 weights: Co * Ci * 9 | 25 floats
+__global__ void __launch_bounds__(1024)
+pack_amax_batch_kernel(const PackEntry* __restrict__ entries) {
+    const PackEntry e = entries[blockIdx.x];
+    if (e.pack < 40) return;
+    const float r = gx_wg1024_amax(e.w, e.Co * e.Ci * (e.pack <= 41 ? 9 : 25));
+    if (threadIdx.x == 0) *reinterpret_cast<float*>(reinterpret_cast<char*>(e.wp) + gx_kq_h_amax_off(e.Kpad, e.Mpad, e.NT)) = r;
+}
+
 __global__ void pack_weights_batch_kernel(const PackEntry* __restrict__ entries, const int* __restrict__ map) {
     const PackEntry e = entries[map[blockIdx.x]];
     const int total = e.NT * e.Kpad * e.Mpad;
     const int begin = (blockIdx.x - e.chunk0) * kPackChunk, end = begin + kPackChunk < total ? begin + kPackChunk : total;
+    const int f16_exp = e.pack >= 40 ? gx_f16_scale_exp(*reinterpret_cast<const float*>(reinterpret_cast<const char*>(e.wp) + gx_kq_h_amax_off(e.Kpad, e.Mpad, e.NT))) : 0;
     for (int idx = begin + threadIdx.x; idx < end; idx += blockDim.x) {
         const int m = idx % e.Mpad;
         const int k = (idx / e.Mpad) % e.Kpad;
         const int t = idx / (e.Mpad * e.Kpad);
-        if (e.pack >= 20) { pack_h_store(e.w, e.wp, e.pack, e.Co, e.Ci, m, k, t, e.NT, e.Kpad); continue; }
+        if (e.pack >= 20) { pack_h_store(e.w, e.wp, e.pack, e.Co, e.Ci, m, k, t, e.NT, e.Kpad, f16_exp); continue; }
         e.wp[pack_dest(e.pack, idx, m, k, t, e.Kpad, e.NT)] = pack_weight_value(e.w, e.pack, e.Co, e.Ci, m, k, t);
     }
 }
@@ -1589,6 +1612,10 @@ int launch_pack(const float* w, float* wp, int pack, int Co, int Ci, int NT, int
     }
     const int total = NT * Kpad * Mpad;
     const int blocks = gx_ceil_div(total, 256) > 1024 ? 1024 : gx_ceil_div(total, 256);
+    if (pack >= 40) {
+        const int rc = gx_kq_weight_amax_launch(w, Co * Ci * (pack <= 41 ? 9 : 25), reinterpret_cast<float*>(reinterpret_cast<char*>(wp) + gx_kq_h_amax_off(Kpad, Mpad, NT)), s);
+        if (rc) return rc;
+    }
     {
         GxProf pf(KID_PACK_WEIGHTS, s, 0.0, 8.0 * total);
         hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, s, w, wp, pack, Co, Ci, NT, Kpad, Mpad);
@@ -2223,6 +2250,12 @@ int gx_weight_cache_refresh(int id, gx_stream_t stream) {
     GX_CHECK_ARG(g_cache_recording != id, "gx_weight_cache_refresh: cache %d is still recording", id);
     if (c.entries.empty()) { g_cache_active = -1; return GX_OK; }
     hipStream_t s = (hipStream_t)stream;
+    bool any_f16 = false;
+    for (const PackEntry& e : c.entries) any_f16 = any_f16 || e.pack >= 40;
+    if (any_f16) {
+        GxProf pf(KID_SMALL_REDUCE, s, 0.0, 0.0);
+        hipLaunchKernelGGL(pack_amax_batch_kernel, dim3((unsigned)c.entries.size()), dim3(1024), 0, s, (const PackEntry*)c.dev);
+    }
     {
         double bytes = 0.0;
         for (const PackEntry& e : c.entries) bytes += 8.0 * e.NT * e.Kpad * e.Mpad;
@@ -2261,7 +2294,7 @@ size_t gx_conv3x3_ws_bytes(int N, int Cin, int Cout, int H, int W) {
         part = pf.g.nsplit * pf.out_elems;
     if (plan_tapconv<M_C3>(N, Cout, Cin, gx_round_up(Cin, 64), H, W, H, W, H, W, 0, &pd, "ws") == GX_OK && pd.g.nsplit > 1)
         part = part > pd.g.nsplit * pd.out_elems ? part : pd.g.nsplit * pd.out_elems;
-    return (conv3x3_pack_floats(Cin, Cout) + part) * sizeof(float);
+    return (conv3x3_pack_floats(Cin, Cout) + part + gx_kq_amax_ws_floats()) * sizeof(float);    // (+ the fp16 x 3 form's amax scratch)
 }
 
 static int conv3x3_fwd_impl(const float* x, const float* w, const float* bias, int act, float* y, int N, int Cin,
@@ -2322,9 +2355,12 @@ static int conv3x3_fwd_impl(const float* x, const float* w, const float* bias, i
     // half empty: MONet's UNet 64 -> 32 layer 51 -> 38 us); GENESIS_KQ_C3H_FIRST=0: only where Winograd does not apply
     static const char* c3h_first = getenv("GENESIS_KQ_C3H_FIRST");
     if ((!wino_ok || !(c3h_first && c3h_first[0] == '0')) && gx_kq_c3h_eligible(N, Cin, Cout, H, W)) {
-        rc = launch_pack(w, wp, 20, Cout, Cin, 9, gx_round_up(Cin, 16), Mpad, s, &wpu);
+        const int f16 = gx_kq_f16_on() ? 20 : 0;       // pack 40: two fp16 pieces of w * 2^e (gx_kq_precision(2))
+        rc = launch_pack(w, wp, 20 + f16, Cout, Cin, 9, gx_round_up(Cin, 16), Mpad, s, &wpu);
         if (rc) return rc;
-        rc = gx_kq_c3h_launch(x, wpu, bias, act, y, N, Cin, Cout, H, W, s);
+        float* amax_ws = f16 ? (float*)((char*)ws + gx_conv3x3_ws_bytes(N, Cin, Cout, H, W)) - gx_kq_amax_ws_floats() : nullptr;
+        rc = gx_kq_c3h_launch(x, wpu, bias, act, y, N, Cin, Cout, H, W, s, nullptr, 0, amax_ws,
+                              f16 ? (const float*)((const char*)wpu + gx_kq_h_amax_off(gx_round_up(Cin, 16), Mpad, 9)) : nullptr);
         if (rc) return rc;
         if (parts_out) { *parts_out = y; *nsplit_out = 1; }
         return GX_OK;
@@ -2396,9 +2432,12 @@ static int conv3x3_dgrad_impl(const float* dy, const float* w, float* dx, int N,
     const bool wino_ok = gx_wino_eligible(N, Cout, Cin, H, W);
     static const char* c3h_first = getenv("GENESIS_KQ_C3H_FIRST");
     if ((!wino_ok || !(c3h_first && c3h_first[0] == '0')) && gx_kq_c3h_eligible(N, Cout, Cin, H, W)) {
-        rc = launch_pack(w, wp, 21, Cout, Cin, 9, gx_round_up(Cout, 16), Mpad, s, &wpu);
+        const int f16 = gx_kq_f16_on() ? 20 : 0;       // pack 41
+        rc = launch_pack(w, wp, 21 + f16, Cout, Cin, 9, gx_round_up(Cout, 16), Mpad, s, &wpu);
         if (rc) return rc;
-        return gx_kq_c3h_launch(dy, wpu, nullptr, 0, dx, N, Cout, Cin, H, W, s);
+        float* amax_ws = f16 ? (float*)((char*)ws + gx_conv3x3_ws_bytes(N, Cin, Cout, H, W)) - gx_kq_amax_ws_floats() : nullptr;
+        return gx_kq_c3h_launch(dy, wpu, nullptr, 0, dx, N, Cout, Cin, H, W, s, nullptr, 0, amax_ws,
+                                f16 ? (const float*)((const char*)wpu + gx_kq_h_amax_off(gx_round_up(Cout, 16), Mpad, 9)) : nullptr);
     }
     if ((kq_first || !wino_ok) && gx_kq_c3_eligible(N, Cout, Cin, H, W)) {
         rc = launch_pack(w, wp, 11, Cout, Cin, 9, Kpad, Mpad, s, &wpu);
@@ -2445,9 +2484,12 @@ int gx_conv3x3_dgrad_act(const float* dy, const float* w, const float* xout, int
     GX_CHECK_ARG(gx_conv3x3_dgrad_act_supported(N, Cin, Cout, H, W), "gx_conv3x3_dgrad_act: shape not supported (gx_conv3x3_dgrad_act_supported)");
     hipStream_t s = (hipStream_t)stream;
     const float* wpu;
-    rc = launch_pack(w, (float*)ws, 21, Cout, Cin, 9, gx_round_up(Cout, 16), gx_round_up(Cin, 64), s, &wpu);
+    const int f16 = gx_kq_f16_on() ? 20 : 0;           // pack 41
+    rc = launch_pack(w, (float*)ws, 21 + f16, Cout, Cin, 9, gx_round_up(Cout, 16), gx_round_up(Cin, 64), s, &wpu);
     if (rc) return rc;
-    rc = gx_kq_c3h_launch(dy, wpu, nullptr, 0, dxa, N, Cout, Cin, H, W, s, xout, act);
+    float* amax_ws = f16 ? (float*)((char*)ws + gx_conv3x3_ws_bytes(N, Cin, Cout, H, W)) - gx_kq_amax_ws_floats() : nullptr;
+    rc = gx_kq_c3h_launch(dy, wpu, nullptr, 0, dxa, N, Cout, Cin, H, W, s, xout, act, amax_ws,
+                          f16 ? (const float*)((const char*)wpu + gx_kq_h_amax_off(gx_round_up(Cout, 16), gx_round_up(Cin, 64), 9)) : nullptr);
     if (rc || !dbias) return rc;
     float* part = (float*)((char*)ws + gx_round_up((long)gx_conv3x3_ws_bytes(N, Cin, Cout, H, W), 256));
     return gx_chan_sums_launch(dxa, N, Cin, H * W, part, dbias, s);
@@ -2618,7 +2660,7 @@ size_t gx_conv5x5s1_ws_bytes(int N, int K, int M, int H, int W) {
         part = pl.g.nsplit * pl.out_elems;
     size_t b = ((size_t)25 * gx_round_up(K, 8) * gx_round_up(M, 64) + part) * sizeof(float);
     const size_t bh = gx_kq_deconv_h_pack_bytes(gx_round_up(K, 16), gx_round_up(M, 64), 25);     // the bf16-pipe packing (kinds 27 / 28)
-    return b > bh ? b : bh;
+    return (b > bh ? b : bh) + gx_kq_amax_ws_floats() * sizeof(float);       // (+ the fp16 x 3 form's amax scratch, at the end)
 }
 
 int gx_conv5x5s1_supported(int N, int K, int M, int H, int W) {
@@ -2641,10 +2683,13 @@ int gx_conv5x5s1(const float* in, const float* w, float* out, int N, int K, int 
     float* part = wp + (size_t)25 * Kpad * Mpad;
     const float* wpu;
     if (gx_kq_c5h_eligible(N, K, M, H, W)) {       // chip-filling layers: on the bf16 matrix pipe (gx_kq.hip Q_C5H)
-        rc = flip ? launch_pack(w, wp, 28, K, M, 25, gx_round_up(K, 16), Mpad, s, &wpu)
-                  : launch_pack(w, wp, 27, M, K, 25, gx_round_up(K, 16), Mpad, s, &wpu);
+        const int f16 = gx_kq_f16_on() ? 20 : 0;       // packs 47 / 48
+        rc = flip ? launch_pack(w, wp, 28 + f16, K, M, 25, gx_round_up(K, 16), Mpad, s, &wpu)
+                  : launch_pack(w, wp, 27 + f16, M, K, 25, gx_round_up(K, 16), Mpad, s, &wpu);
         if (rc) return rc;
-        return gx_kq_c5h_launch(in, wpu, out, N, K, M, H, W, s);
+        float* amax_ws = f16 ? (float*)((char*)ws + gx_conv5x5s1_ws_bytes(N, K, M, H, W)) - gx_kq_amax_ws_floats() : nullptr;
+        return gx_kq_c5h_launch(in, wpu, out, N, K, M, H, W, s, amax_ws,
+                                f16 ? (const float*)((const char*)wpu + gx_kq_h_amax_off(gx_round_up(K, 16), Mpad, 25)) : nullptr);
     }
     // pack 7: w [M][K]; pack 8: w [K][M] flipped (launch_pack's (Co, Ci) are the weight tensor's leading dimensions)
     rc = flip ? launch_pack(w, wp, 8, K, M, 25, Kpad, Mpad, s, &wpu) : launch_pack(w, wp, 7, M, K, 25, Kpad, Mpad, s, &wpu);
@@ -2715,7 +2760,8 @@ size_t gx_deconv5x5s2_ws_bytes(int N, int Cin, int Cout, int Hin, int Win) {
     if (plan_tapconv<M_DG>(N, Cout, Cin, gx_round_up(Cin, 64), Hin, Win, 2 * Hin, 2 * Win, Hin, Win, 0, &pd, "ws") == GX_OK &&
         pd.g.nsplit > 1)
         part = part > pd.g.nsplit * pd.out_elems ? part : pd.g.nsplit * pd.out_elems;
-    return (deconv_pack_floats(Cin, Cout) + part) * sizeof(float);
+    // (+ the amax scratch of the fp16 x 3 form, at the very end: gx_kq_amax_launch)
+    return (deconv_pack_floats(Cin, Cout) + part + gx_kq_amax_ws_floats()) * sizeof(float);
 }
 
 static int deconv_fwd_impl(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int Cout,
@@ -2786,11 +2832,14 @@ static int deconv_fwd_impl(const float* x, const float* w, const float* bias, fl
     if (stats_parts_out) *stats_parts_out = 0;
     if (gx_kq_deconv_h_eligible(N, Cin, Cout, Hin, Win)) {     // ... on the bf16 matrix pipe (fp32 products from bf16 pieces)
         float* wh1 = wp0 + gx_kq_deconv_h_pack_bytes(Cin, Cout, 15) / 4;
-        rc = launch_pack(w, wp0, 22, Cout, Cin, 15, Cin, Mpad, s, &wpu0);
+        const int f16 = gx_kq_f16_on() ? 20 : 0;       // packs 42 / 43: two fp16 pieces of w * 2^e (gx_kq_precision(2))
+        rc = launch_pack(w, wp0, 22 + f16, Cout, Cin, 15, Cin, Mpad, s, &wpu0);
         if (rc) return rc;
-        rc = launch_pack(w, wh1, 23, Cout, Cin, 10, Cin, Mpad, s, &wpu1);
+        rc = launch_pack(w, wh1, 23 + f16, Cout, Cin, 10, Cin, Mpad, s, &wpu1);
         if (rc) return rc;
-        rc = gx_kq_deconv_fwd_h_launch(x, wpu0, wpu1, bias, y, N, Cin, Cout, Hin, Win, stats, stats_parts_out, s);
+        float* amax_ws = f16 ? (float*)((char*)ws + gx_deconv5x5s2_ws_bytes(N, Cin, Cout, Hin, Win)) - gx_kq_amax_ws_floats() : nullptr;
+        rc = gx_kq_deconv_fwd_h_launch(x, wpu0, wpu1, bias, y, N, Cin, Cout, Hin, Win, stats, stats_parts_out, s, amax_ws,
+                                       f16 ? (const float*)((const char*)wpu0 + gx_kq_h_amax_off(Cin, Mpad, 15)) : nullptr);
         if (rc) return rc;
         if (parts_out) { *parts_out = y; *nsplit_out = 1; }
         return GX_OK;
@@ -2877,9 +2926,12 @@ int gx_deconv5x5s2_dgrad(const float* dy, const float* w, float* dx, int N, int 
     float* part = wp + deconv_pack_floats(Cin, Cout);
     const float* wpu;
     if (gx_kq_deconv_dgrad_h_eligible(N, Cout, Cin_out, Hin, Win)) {     // on the bf16 matrix pipe
-        rc = launch_pack(w, wp, 24, Cout, Cin, 25, Cout, Mpad, s, &wpu);
+        const int f16 = gx_kq_f16_on() ? 20 : 0;       // pack 44 (gx_kq_precision(2))
+        rc = launch_pack(w, wp, 24 + f16, Cout, Cin, 25, Cout, Mpad, s, &wpu);
         if (rc) return rc;
-        return gx_kq_deconv_dgrad_h_launch(dy, wpu, dx, N, Cout, Cin_out, Hin, Win, s);
+        float* amax_ws = f16 ? (float*)((char*)ws + gx_deconv5x5s2_ws_bytes(N, Cin, Cout, Hin, Win)) - gx_kq_amax_ws_floats() : nullptr;
+        return gx_kq_deconv_dgrad_h_launch(dy, wpu, dx, N, Cout, Cin_out, Hin, Win, s, amax_ws,
+                                           f16 ? (const float*)((const char*)wpu + gx_kq_h_amax_off(Cout, Mpad, 25)) : nullptr);
     }
     if (gx_kq_deconv_eligible(N, Cout, Cin_out, Hin, Win, 1)) {
         rc = launch_pack(w, wp, 14, Cout, Cin, 25, Kpad, Mpad, s, &wpu);

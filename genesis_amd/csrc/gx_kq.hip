@@ -153,12 +153,18 @@ template <> struct QCfg<Q_C5H> {
 template <> struct QCfg<Q_DT0H> : QCfgDTH<0> {};
 template <> struct QCfg<Q_DT1H> : QCfgDTH<1> {};
 typedef __bf16 q_bf16x8 __attribute__((ext_vector_type(8)));
+// fp16 x 3 (template parameter F16 of q_body / q_phase_h; gx_kq_precision(2), DESIGN.md finding 40): every fp32 product from THREE
+// fp16 piece products -- x * 2^sx = hi + lo (11 + 11 significant bits), hi*hi + hi*lo + lo*hi; the dropped lo*lo term is 2^-22 of the
+// product -- instead of six bf16 ones.  sx, sw: per-tensor power-of-two scales from the tensors' largest magnitudes (gx_f16_scale_exp),
+// taken out of the accumulators before the epilogue.  Same LDS layout (the third piece plane stays unused).
+typedef _Float16 q_f16x8 __attribute__((ext_vector_type(8)));
 constexpr int QH_TAP_BYTES = 3 * 2 * 64 * 16;          // one tap of one 16-channel chunk: 6144 B
+static_assert(QH_TAP_BYTES == 6144, "gx_kq_h_amax_off (gx_common.h) spells this number out");
 // output-channel rows of a workgroup's weight slice and the bytes of one (tap, chunk) of it
 template <int MODE> struct QHLay { static constexpr int ROWS = MODE == Q_C3H ? 32 : 64, TAPB = 3 * 2 * ROWS * 16; };
 
 // one phase on the bf16 pipe: operands of (tap, mi / nj, piece) straight out of LDS
-template <int MODE, int PH, int NCLS, int MI>
+template <int MODE, int PH, int NCLS, int MI, bool F16 = false>
 __device__ __forceinline__ void q_phase_h(f32x16 (&acc)[NCLS][MI][2], const char* ib, const char* wb, const int plane_bytes,
                                           const int a_lane_b, const int b_lane0_b, const int b_lane1_b, const int HS16) {
     using C = QCfg<MODE>;
@@ -168,7 +174,7 @@ __device__ __forceinline__ void q_phase_h(f32x16 (&acc)[NCLS][MI][2], const char
         const int toff = (C::ro(PH, i) * HS16 + C::co(PH, i) * 16);
         q_bf16x8 a[MI][3], b[2][3];
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) {
+        for (int pc = 0; pc < (F16 ? 2 : 3); ++pc) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
                 a[mi][pc] = *reinterpret_cast<const q_bf16x8*>(wb + i * QHLay<MODE>::TAPB + pc * (QHLay<MODE>::TAPB / 3) + a_lane_b + mi * 512);
@@ -184,12 +190,18 @@ __device__ __forceinline__ void q_phase_h(f32x16 (&acc)[NCLS][MI][2], const char
 #if GX_QH_ABL & 4
                 c[0] += (float)a[mi][0][0] * (float)b[nj][0][0] + (float)a[mi][1][1] * (float)b[nj][1][1] + (float)a[mi][2][2] * (float)b[nj][2][2];
 #else
+                if constexpr (F16) {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(q_f16x8, a[mi][1]), __builtin_bit_cast(q_f16x8, b[nj][0]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(q_f16x8, a[mi][0]), __builtin_bit_cast(q_f16x8, b[nj][1]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(q_f16x8, a[mi][0]), __builtin_bit_cast(q_f16x8, b[nj][0]), c, 0, 0, 0);
+                } else {
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[nj][1], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][2], b[nj][0], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[nj][2], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][1], b[nj][0], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[nj][1], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][0], b[nj][0], c, 0, 0, 0);
+                }
 #endif
                 acc[cl][mi][nj] = c;
             }
@@ -197,6 +209,7 @@ __device__ __forceinline__ void q_phase_h(f32x16 (&acc)[NCLS][MI][2], const char
 }
 
 struct QGeom {
+    const float* x_amax; const float* w_amax;      // fp16 x 3 form: the input tensor's / the weight tensor's largest magnitude (device)
     int N, K, M;          // images, reduction channels (a multiple of 8), output channels
     int nchunks;          // K / 8
     int Hb, Wb;           // base (pixel-tile) grid
@@ -269,7 +282,7 @@ __device__ __forceinline__ void q_phase(f32x16 (&acc)[NCLS][MI][2], const float*
 // NQ: (position, quad) slots staged per thread per input tile (2 * CHS <= NQ * 256)
 // MI: 32-channel MFMA tiles per wave along M.  2 = the workgroup's whole 64-channel tile; 1 = one half (mh) of it --
 // the last tiles of a grid that does not divide the chip are split into two half-work workgroups (q_split_tail).
-template <int MODE, int NQ, bool STATS, int MI = 2>
+template <int MODE, int NQ, bool STATS, int MI = 2, bool F16 = false>
 __device__ __forceinline__ void q_body(const float* __restrict__ in, const float* __restrict__ wp,
                                        const float* __restrict__ bias, float* __restrict__ out, const QGeom& g,
                                        float* lds, const int bx, const int by, const int par_a, const int mh = 0) {
@@ -339,6 +352,7 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
                 for (int e = 0; e < 16; ++e) acc[c][i][j][e] = 0.f;
     if constexpr (B16) {
         // ---- the bf16-pipe pipeline: chunks of 16 channels, phases of <= 3 taps
+        const int f16_sx = F16 ? gx_f16_scale_exp(*g.x_amax) : 0;
         constexpr int TAPB = QHLay<MODE>::TAPB;
         constexpr int NWH = (MAXT * (TAPB / 16) + 255) / 256;              // 16-byte weight pieces per thread per phase
         constexpr int WSLOTB = NWH * 256 * 16;                             // bytes per weight buffer
@@ -376,17 +390,27 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
         {                                                                                              \
             _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                           \
                 q_bf16x8 ph_, pm_, pl_;                                                                \
+                if (F16) {                                                                             \
+                    q_f16x8 fh_, fl_;                                                                  \
+                    _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                    \
+                        const float xs_ = ldexpf(xin[q][e], f16_sx);                                   \
+                        const _Float16 h_ = (_Float16)xs_;                                             \
+                        fh_[e] = h_; fl_[e] = (_Float16)(xs_ - (float)h_);                             \
+                    }                                                                                  \
+                    ph_ = __builtin_bit_cast(q_bf16x8, fh_); pm_ = __builtin_bit_cast(q_bf16x8, fl_);  \
+                } else {                                                                               \
                 _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                        \
                     const __bf16 h_ = (__bf16)xin[q][e];                                               \
                     const float r1_ = xin[q][e] - (float)h_;                                           \
                     const __bf16 m_ = (__bf16)r1_;                                                     \
                     ph_[e] = h_; pm_[e] = m_; pl_[e] = (__bf16)(r1_ - (float)m_);                      \
                 }                                                                                      \
+                }                                                                                      \
                 char* d_ = ibuf + (tid + q * 256) * 16;                                                \
                 if (!TRIM || tid + q * 256 < 2 * CHS) {                                                \
                 *reinterpret_cast<q_bf16x8*>(d_) = ph_;                                                \
                 *reinterpret_cast<q_bf16x8*>(d_ + plane_bytes) = pm_;                                  \
-                *reinterpret_cast<q_bf16x8*>(d_ + 2 * plane_bytes) = pl_;                              \
+                if (!F16) *reinterpret_cast<q_bf16x8*>(d_ + 2 * plane_bytes) = pl_;                    \
                 }                                                                                      \
             }                                                                                          \
         }
@@ -425,7 +449,7 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
                 if (more) GX_QH_LOAD_W(last_ph ? sc + 1 : sc, NXT)                                               \
                 if (EARLY_IN) { if ((PH_) == 0 && !last_chunk && !(GX_QH_ABL & 8)) GX_QH_LOAD_IN(sc + 1, 0) }    \
                 else if (in_next) GX_QH_LOAD_IN(last_ph ? sc + 1 : sc, C::plane(NXT))                            \
-                q_phase_h<MODE, (PH_), NCLS, MI>(acc, ibuf, wbufb + (ONE_W ? 0 : (s & 1)) * WSLOTB, plane_bytes, \
+                q_phase_h<MODE, (PH_), NCLS, MI, F16>(acc, ibuf, wbufb + (ONE_W ? 0 : (s & 1)) * WSLOTB, plane_bytes, \
                                                  a_lane_b, b_lane_b[0], b_lane_b[1], HS16);                      \
                 if (ONE_W) {                      /* one weight buffer: everyone is done with it (and the tile) */ \
                     if (more) { __syncthreads(); GX_QH_STORE_W(wbufb) }                                          \
@@ -569,6 +593,17 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
                 }
                 bvec[mi][q] = t;
             }
+    }
+    if constexpr (B16 && F16) {
+        const int de = -(gx_f16_scale_exp(*g.x_amax) + gx_f16_scale_exp(*g.w_amax));
+#pragma unroll
+        for (int c = 0; c < NCLS; ++c)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[c][i][j][e] = ldexpf(acc[c][i][j][e], de);
     }
     // interior tiles with all 32 (MI) channels of every accumulator row present (the common case: power-of-two grids,
     // M a multiple of 64) store without per-element guards -- the guarded loop costs ~1400 VALU + 48 branches per wave
@@ -808,18 +843,18 @@ kq_dt_kernel(const float* __restrict__ in, const float* __restrict__ wp0, const 
     }
 }
 
-template <int NQ>
+template <int NQ, bool F16 = false>
 __global__ void __launch_bounds__(256, 2)
 kq_dgh_kernel(const float* __restrict__ in, const float* __restrict__ wp, float* __restrict__ out, QGeom g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // (XCD-aware tile map over the whole-tile workgroups: neighbouring tiles, which share halo rows, on one XCD's L2)
     const int bx = (int)blockIdx.x < g.nfull ? gx_xcd_tile(blockIdx.x, g.nfull) : (int)blockIdx.x;
-    if (bx < g.nfull) q_body<Q_DGH, NQ, false, 2>(in, wp, nullptr, out, g, lds, bx, blockIdx.y, 0);
-    else q_body<Q_DGH, NQ, false, 1>(in, wp, nullptr, out, g, lds, g.nfull + ((bx - g.nfull) >> 1), blockIdx.y, 0, (bx - g.nfull) & 1);
+    if (bx < g.nfull) q_body<Q_DGH, NQ, false, 2, F16>(in, wp, nullptr, out, g, lds, bx, blockIdx.y, 0);
+    else q_body<Q_DGH, NQ, false, 1, F16>(in, wp, nullptr, out, g, lds, g.nfull + ((bx - g.nfull) >> 1), blockIdx.y, 0, (bx - g.nfull) & 1);
 }
 
 // conv3x3 on the bf16 pipe, 32 output channels per workgroup (blockIdx.y)
-template <int NQ>
+template <int NQ, bool F16 = false>
 __global__ void __launch_bounds__(256, 3)
 kq_c3h_kernel(const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
               float* __restrict__ out, QGeom g) {
@@ -829,21 +864,21 @@ kq_c3h_kernel(const float* __restrict__ in, const float* __restrict__ wp, const 
     // two 16-channel chunks per tile that tail is a large part of a tile's life
     for (int t = blockIdx.x; t < g.nfull; t += gridDim.x) {
         const int tile = gx_xcd_tile(t, g.nfull);
-        q_body<Q_C3H, NQ, false, 1>(in, wp, bias, out, g, lds, tile, blockIdx.y, 0, 0);
+        q_body<Q_C3H, NQ, false, 1, F16>(in, wp, bias, out, g, lds, tile, blockIdx.y, 0, 0);
         __syncthreads();          // the next tile's staging overwrites LDS the slowest wave may still be reading
     }
 }
 
 // 5 x 5 stride-1 conv on the bf16 pipe: 16 x 16-pixel tiles (20 x 20 halo positions: four staging rounds, exact LDS planes)
-template <int NQ>
+template <int NQ, bool F16 = false>
 __global__ void __launch_bounds__(256, 2)
 kq_c5h_kernel(const float* __restrict__ in, const float* __restrict__ wp, float* __restrict__ out, QGeom g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    q_body<Q_C5H, NQ, false, 2>(in, wp, nullptr, out, g, lds, gx_xcd_tile(blockIdx.x, gridDim.x), blockIdx.y, 0);
+    q_body<Q_C5H, NQ, false, 2, F16>(in, wp, nullptr, out, g, lds, gx_xcd_tile(blockIdx.x, gridDim.x), blockIdx.y, 0);
 }
 
 // the same launch shape on the bf16 matrix pipe (Q_DT0H / Q_DT1H)
-template <int NQ, bool STATS>
+template <int NQ, bool STATS, bool F16 = false>
 __global__ void __launch_bounds__(256, 2)
 kq_dth_kernel(const float* __restrict__ in, const float* __restrict__ wp0, const float* __restrict__ wp1,
               const float* __restrict__ bias, float* __restrict__ out, QGeom g) {
@@ -851,12 +886,12 @@ kq_dth_kernel(const float* __restrict__ in, const float* __restrict__ wp0, const
     // (XCD-aware tile map over the whole-tile workgroups: neighbouring tiles, which share halo rows, on one XCD's L2)
     const int bx = (int)blockIdx.x < g.nfull ? gx_xcd_tile(blockIdx.x, g.nfull) : (int)blockIdx.x;
     if (bx < g.nfull) {
-        if (blockIdx.z) q_body<Q_DT1H, NQ, STATS, 2>(in, wp1, bias, out, g, lds, bx, blockIdx.y, 1);
-        else q_body<Q_DT0H, NQ, STATS, 2>(in, wp0, bias, out, g, lds, bx, blockIdx.y, 0);
+        if (blockIdx.z) q_body<Q_DT1H, NQ, STATS, 2, F16>(in, wp1, bias, out, g, lds, bx, blockIdx.y, 1);
+        else q_body<Q_DT0H, NQ, STATS, 2, F16>(in, wp0, bias, out, g, lds, bx, blockIdx.y, 0);
     } else {
         const int tile = g.nfull + ((bx - g.nfull) >> 1), mh = (bx - g.nfull) & 1;
-        if (blockIdx.z) q_body<Q_DT1H, NQ, STATS, 1>(in, wp1, bias, out, g, lds, tile, blockIdx.y, 1, mh);
-        else q_body<Q_DT0H, NQ, STATS, 1>(in, wp0, bias, out, g, lds, tile, blockIdx.y, 0, mh);
+        if (blockIdx.z) q_body<Q_DT1H, NQ, STATS, 1, F16>(in, wp1, bias, out, g, lds, tile, blockIdx.y, 1, mh);
+        else q_body<Q_DT0H, NQ, STATS, 1, F16>(in, wp0, bias, out, g, lds, tile, blockIdx.y, 0, mh);
     }
 }
 
@@ -873,7 +908,7 @@ bool q_plan(int N, int K, int M, int Hb, int Wb, int Hi, int Wi, int Ho, int Wo,
     g->Hb = Hb; g->Wb = Wb; g->Hi = Hi; g->Wi = Wi; g->Ho = Ho; g->Wo = Wo;
     g->lTH = q_ilog2(TH); g->lTW = q_ilog2(TW); g->lG = q_ilog2(G);
     g->tiles_h = Hb / TH; g->tiles_w = Wb / TW;
-    g->act = 0; g->stats = nullptr; g->stats_parts = 0; g->rt_th = g->rt_tw = 0; g->mask = nullptr; g->mask_act = 0;
+    g->x_amax = g->w_amax = nullptr; g->act = 0; g->stats = nullptr; g->stats_parts = 0; g->rt_th = g->rt_tw = 0; g->mask = nullptr; g->mask_act = 0;
     const int CHS = G * (TH + 2) * (TW + 2);
     if (2 * CHS > 4 * 256) return false;
     *nq = 2 * CHS <= 3 * 256 ? 3 : 4;
@@ -984,9 +1019,76 @@ int gx_kq_deconv_fwd_launch(const float* in, const float* wp0, const float* wp1,
 
 // ---- the transposed conv forward on the bf16 matrix pipe (packs 22 / 23: weights pre-split into bf16 pieces)
 static int g_kq_h = -1;     // 1 (default): eligible layers run there; GENESIS_KQ_BF16X6=0 / gx_kq_precision(0): fp32 pipe
-static bool kq_h_on() {
-    if (g_kq_h < 0) { const char* e = getenv("GENESIS_KQ_BF16X6"); g_kq_h = (e && e[0] == '0') ? 0 : 1; }
-    return g_kq_h != 0;
+static void kq_h_init() {
+    if (g_kq_h >= 0) return;
+    const char* e = getenv("GENESIS_KQ_BF16X6");
+    const char* f = getenv("GENESIS_KQ_F16X3");         // 0: six bf16 piece products instead of three fp16 ones (finding 40)
+    g_kq_h = (e && e[0] == '0') ? 0 : ((f && f[0] == '0') ? 1 : 2);
+}
+static bool kq_h_on() { kq_h_init(); return g_kq_h != 0; }
+bool gx_kq_f16_on() { kq_h_init(); return g_kq_h == 2; }
+
+// ---- largest magnitude of a tensor, for the fp16 x 3 form's power-of-two scale: partial maxima (one per workgroup), then ONE
+//      workgroup over the partials -- two launches, no counter, no atomics: the workspace needs no initial state
+__global__ void __launch_bounds__(256)
+amax_partial_kernel(const float* __restrict__ x, size_t n, int vec, float* __restrict__ partials) {
+    float m = 0.f;
+    if (vec) {
+        const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+        const size_t n4 = n >> 2;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+            const f32x4 v = x4[i];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        }
+        for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    } else {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__global__ void __launch_bounds__(256)
+amax_final_kernel(const float* __restrict__ partials, int nparts, float* __restrict__ out) {
+    float m = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) m = fmaxf(m, partials[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+int gx_kq_amax_launch(const float* x, size_t n, float* ws, hipStream_t s) {
+    size_t want = (n / 4 + 2047) / 2048;               // >= 8 float4 per thread
+    const int parts = want < 1 ? 1 : (want > (size_t)kAmaxParts ? kAmaxParts : (int)want);
+    {
+        GxProf pf(KID_SMALL_REDUCE, s, 0.0, 4.0 * (double)n);
+        hipLaunchKernelGGL(amax_partial_kernel, dim3(parts), dim3(256), 0, s, x, n, (reinterpret_cast<uintptr_t>(x) & 15) == 0 ? 1 : 0, ws + 16);
+    }
+    GX_CHECK_LAUNCH("kq amax (partials)");
+    {
+        GxProf pf(KID_SMALL_REDUCE, s, 0.0, 4.0 * parts);
+        hipLaunchKernelGGL(amax_final_kernel, dim3(1), dim3(256), 0, s, (const float*)(ws + 16), parts, ws);
+    }
+    GX_CHECK_LAUNCH("kq amax");
+    return GX_OK;
+}
+__global__ void __launch_bounds__(1024)
+weight_amax_kernel(const float* __restrict__ w, int n, float* __restrict__ out) {
+    const float r = gx_wg1024_amax(w, n);
+    if (threadIdx.x == 0) out[0] = r;
+}
+int gx_kq_weight_amax_launch(const float* w, int n, float* out, hipStream_t s) {
+    {
+        GxProf pf(KID_SMALL_REDUCE, s, 0.0, 4.0 * n);
+        hipLaunchKernelGGL(weight_amax_kernel, dim3(1), dim3(1024), 0, s, w, n, out);
+    }
+    GX_CHECK_LAUNCH("kq weight amax");
+    return GX_OK;
 }
 size_t gx_kq_deconv_h_pack_bytes(int K, int M, int nt) {     // one row parity's packed weights (+ slack: whole-phase copies)
     return (size_t)gx_ceil_div(M, 64) * (K / 16) * nt * QH_TAP_BYTES + 16384;
@@ -1008,7 +1110,8 @@ bool gx_kq_deconv_h_eligible(int N, int K, int M, int Hb, int Wb) {
     return q_plan(N, K, M, Hb, Wb, Hb, Wb, 2 * Hb, 2 * Wb, &g, &nq, &lds, 5) && qh_lds(g, nq) > 0;
 }
 int gx_kq_deconv_fwd_h_launch(const float* in, const float* wp0, const float* wp1, const float* bias, float* out, int N,
-                              int K, int M, int Hb, int Wb, float* stats, int* stats_parts, hipStream_t s) {
+                              int K, int M, int Hb, int Wb, float* stats, int* stats_parts, hipStream_t s, float* amax_ws,
+                              const float* w_amax) {
     QGeom g; int nq; size_t lds;
     if (!q_plan(N, K, M, Hb, Wb, Hb, Wb, 2 * Hb, 2 * Wb, &g, &nq, &lds, 5) || qh_lds(g, nq) == 0 || K % 16 != 0) {
         gx_set_error("kq deconv fwd (bf16 pipe): shape not eligible"); return GX_EINVAL;
@@ -1021,12 +1124,21 @@ int gx_kq_deconv_fwd_h_launch(const float* in, const float* wp0, const float* wp
         g.stats_parts = g.tiles_h * g.tiles_w * 2;
         if (stats_parts) *stats_parts = g.stats_parts;
     }
+    if (amax_ws) { const int rc = gx_kq_amax_launch(in, (size_t)N * K * Hb * Wb, amax_ws, s); if (rc) return rc; }
     dim3 grid(1, gx_ceil_div(M, 64), 2);
     g.nfull = q_split_tail(g.tiles_h * g.tiles_w * gx_ceil_div(N, 1 << g.lG), M, &grid.x);
     {
         GxProf pf(KID_KQ_DTH, s, 2.0 * N * (double)M * K * 25 * Hb * Wb,
                   4.0 * ((double)N * K * Hb * Wb + (double)N * M * 4 * Hb * Wb + 25.0 * K * M));
-        static bool a[4] = {false, false, false, false};
+        static bool a[8] = {false, false, false, false, false, false, false, false};
+        if (amax_ws) {          // fp16 x 3: the input's amax (two small launches ahead of this one, outside its profiling record)
+            g.x_amax = amax_ws;
+            g.w_amax = w_amax;
+            if (nq == 3 && st) { q_set_attr(&kq_dth_kernel<3, true, true>, &a[4]); hipLaunchKernelGGL((kq_dth_kernel<3, true, true>), grid, dim3(256), lds, s, in, wp0, wp1, bias, out, g); }
+            else if (nq == 3) { q_set_attr(&kq_dth_kernel<3, false, true>, &a[5]); hipLaunchKernelGGL((kq_dth_kernel<3, false, true>), grid, dim3(256), lds, s, in, wp0, wp1, bias, out, g); }
+            else if (st) { q_set_attr(&kq_dth_kernel<4, true, true>, &a[6]); hipLaunchKernelGGL((kq_dth_kernel<4, true, true>), grid, dim3(256), lds, s, in, wp0, wp1, bias, out, g); }
+            else { q_set_attr(&kq_dth_kernel<4, false, true>, &a[7]); hipLaunchKernelGGL((kq_dth_kernel<4, false, true>), grid, dim3(256), lds, s, in, wp0, wp1, bias, out, g); }
+        } else
         if (nq == 3 && st) { q_set_attr(&kq_dth_kernel<3, true>, &a[0]); hipLaunchKernelGGL((kq_dth_kernel<3, true>), grid, dim3(256), lds, s, in, wp0, wp1, bias, out, g); }
         else if (nq == 3) { q_set_attr(&kq_dth_kernel<3, false>, &a[1]); hipLaunchKernelGGL((kq_dth_kernel<3, false>), grid, dim3(256), lds, s, in, wp0, wp1, bias, out, g); }
         else if (st) { q_set_attr(&kq_dth_kernel<4, true>, &a[2]); hipLaunchKernelGGL((kq_dth_kernel<4, true>), grid, dim3(256), lds, s, in, wp0, wp1, bias, out, g); }
@@ -1054,7 +1166,7 @@ static bool q_plan_c3h(int N, int K, int M, int H, int W, QGeom* g, int* nq, siz
     g->Hb = H; g->Wb = W; g->Hi = H; g->Wi = W; g->Ho = H; g->Wo = W;
     g->lTH = q_ilog2(TH); g->lTW = q_ilog2(TW); g->lG = q_ilog2(G);
     g->tiles_h = gx_ceil_div(H, TH); g->tiles_w = W / TW;
-    g->act = 0; g->stats = nullptr; g->stats_parts = 0; g->nfull = 0; g->mask = nullptr; g->mask_act = 0;
+    g->x_amax = g->w_amax = nullptr; g->act = 0; g->stats = nullptr; g->stats_parts = 0; g->nfull = 0; g->mask = nullptr; g->mask_act = 0;
     const int CHS = G * (TH + 2) * (TW + 2);
     if (2 * CHS > 4 * 256) return false;
     *nq = 2 * CHS <= 3 * 256 ? 3 : 4;
@@ -1070,10 +1182,11 @@ bool gx_kq_c3h_eligible(int N, int K, int M, int H, int W) {
     return kq_mode() == 2 || (long)g.tiles_h * g.tiles_w * gx_ceil_div(N, 1 << g.lG) * gx_ceil_div(M, 32) >= 512;
 }
 int gx_kq_c3h_launch(const float* in, const float* wp, const float* bias, int act, float* out, int N, int K, int M, int H,
-                     int W, hipStream_t s, const float* mask, int mask_act) {
+                     int W, hipStream_t s, const float* mask, int mask_act, float* amax_ws, const float* w_amax) {
     QGeom g; int nq; size_t lds;
     if (!q_plan_c3h(N, K, M, H, W, &g, &nq, &lds)) { gx_set_error("kq conv3x3 (bf16 pipe): shape not eligible"); return GX_EINVAL; }
     g.act = act; g.mask = mask; g.mask_act = mask_act;
+    if (amax_ws) { const int rc = gx_kq_amax_launch(in, (size_t)N * K * H * W, amax_ws, s); if (rc) return rc; }
     dim3 grid(g.tiles_h * g.tiles_w * gx_ceil_div(N, 1 << g.lG), gx_ceil_div(M, 32));
     g.nfull = (int)grid.x;                               // tiles; the workgroups loop over them (kq_c3h_kernel)
     static const char* pers_env = getenv("GENESIS_KQ_C3H_PERSIST");
@@ -1082,7 +1195,12 @@ int gx_kq_c3h_launch(const float* in, const float* wp, const float* bias, int ac
     {
         GxProf pf(KID_KQ_C3H, s, 2.0 * N * (double)M * K * 9 * H * W,
                   4.0 * ((double)N * K * H * W + (double)N * M * H * W + 9.0 * K * M));
-        static bool a3 = false, a4 = false;
+        static bool a3 = false, a4 = false, f3 = false, f4 = false;
+        if (amax_ws) {          // fp16 x 3 (packs 40 / 41)
+            g.x_amax = amax_ws; g.w_amax = w_amax;
+            if (nq == 3) { q_set_attr(&kq_c3h_kernel<3, true>, &f3); hipLaunchKernelGGL((kq_c3h_kernel<3, true>), grid, dim3(256), lds, s, in, wp, bias, out, g); }
+            else { q_set_attr(&kq_c3h_kernel<4, true>, &f4); hipLaunchKernelGGL((kq_c3h_kernel<4, true>), grid, dim3(256), lds, s, in, wp, bias, out, g); }
+        } else
         if (nq == 3) { q_set_attr(&kq_c3h_kernel<3>, &a3); hipLaunchKernelGGL((kq_c3h_kernel<3>), grid, dim3(256), lds, s, in, wp, bias, out, g); }
         else { q_set_attr(&kq_c3h_kernel<4>, &a4); hipLaunchKernelGGL((kq_c3h_kernel<4>), grid, dim3(256), lds, s, in, wp, bias, out, g); }
     }
@@ -1097,7 +1215,7 @@ static bool q_plan_c5h(int N, int K, int M, int H, int W, QGeom* g, size_t* lds_
     g->Hb = H; g->Wb = W; g->Hi = H; g->Wi = W; g->Ho = H; g->Wo = W;
     g->lTH = 4; g->lTW = 4; g->lG = 0;
     g->tiles_h = H / 16; g->tiles_w = W / 16;
-    g->rt_th = g->rt_tw = 0; g->act = 0; g->stats = nullptr; g->stats_parts = 0; g->mask = nullptr; g->mask_act = 0;
+    g->rt_th = g->rt_tw = 0; g->x_amax = g->w_amax = nullptr; g->act = 0; g->stats = nullptr; g->stats_parts = 0; g->mask = nullptr; g->mask_act = 0;
     g->nfull = g->tiles_h * g->tiles_w * N;
     constexpr int NWH = (3 * (QH_TAP_BYTES / 16) + 255) / 256;
     *lds_bytes = (size_t)3 * 2 * (20 * 20) * 16 + (size_t)2 * NWH * 256 * 16;       // exact input planes + two weight buffers
@@ -1111,15 +1229,23 @@ bool gx_kq_c5h_eligible(int N, int K, int M, int H, int W) {
     static const int min_wgs = [] { const char* e = getenv("GENESIS_KQ_C5H_MIN_WGS"); return e ? atoi(e) : 192; }();
     return kq_mode() == 2 || (long)g.nfull * gx_ceil_div(M, 64) >= min_wgs;
 }
-int gx_kq_c5h_launch(const float* in, const float* wp, float* out, int N, int K, int M, int H, int W, hipStream_t s) {
+int gx_kq_c5h_launch(const float* in, const float* wp, float* out, int N, int K, int M, int H, int W, hipStream_t s,
+                     float* amax_ws, const float* w_amax) {
     QGeom g; size_t lds;
     if (!q_plan_c5h(N, K, M, H, W, &g, &lds)) { gx_set_error("kq conv5x5 (bf16 pipe): shape not eligible"); return GX_EINVAL; }
+    if (amax_ws) { const int rc = gx_kq_amax_launch(in, (size_t)N * K * H * W, amax_ws, s); if (rc) return rc; }
     dim3 grid(g.nfull, gx_ceil_div(M, 64));
     {
         GxProf pf(KID_KQ_C5H, s, 2.0 * N * (double)M * K * 25 * H * W, 4.0 * ((double)N * K * H * W + (double)N * M * H * W + 25.0 * K * M));
-        static bool a4 = false;
+        static bool a4 = false, f4 = false;
+        if (amax_ws) {          // fp16 x 3 (packs 47 / 48)
+            g.x_amax = amax_ws; g.w_amax = w_amax;
+            q_set_attr(&kq_c5h_kernel<4, true>, &f4);
+            hipLaunchKernelGGL((kq_c5h_kernel<4, true>), grid, dim3(256), lds, s, in, wp, out, g);
+        } else {
         q_set_attr(&kq_c5h_kernel<4>, &a4);
         hipLaunchKernelGGL((kq_c5h_kernel<4>), grid, dim3(256), lds, s, in, wp, out, g);
+        }
     }
     GX_CHECK_LAUNCH("kq conv5x5 (bf16 pipe)");
     return GX_OK;
@@ -1131,18 +1257,25 @@ bool gx_kq_deconv_dgrad_h_eligible(int N, int K, int M, int Hb, int Wb) {
     return q_plan(N, K, M, Hb, Wb, 2 * Hb, 2 * Wb, Hb, Wb, &g, &nq, &lds, 9) && qh_lds(g, nq) > 0;
 }
 int gx_kq_deconv_dgrad_h_launch(const float* dy, const float* wp, float* dx, int N, int K, int M, int Hb, int Wb,
-                                hipStream_t s) {
+                                hipStream_t s, float* amax_ws, const float* w_amax) {
     QGeom g; int nq; size_t lds;
     if (!q_plan(N, K, M, Hb, Wb, 2 * Hb, 2 * Wb, Hb, Wb, &g, &nq, &lds, 9) || qh_lds(g, nq) == 0 || K % 16 != 0) {
         gx_set_error("kq deconv dgrad (bf16 pipe): shape not eligible"); return GX_EINVAL;
     }
     lds = qh_lds(g, nq);
+    if (amax_ws) { const int rc = gx_kq_amax_launch(dy, (size_t)N * K * 4 * Hb * Wb, amax_ws, s); if (rc) return rc; }
     dim3 grid(1, gx_ceil_div(M, 64));
     g.nfull = q_split_tail(g.tiles_h * g.tiles_w * gx_ceil_div(N, 1 << g.lG), M, &grid.x);
     {
         GxProf pf(KID_KQ_DGH, s, 2.0 * N * (double)M * K * 25 * Hb * Wb,
                   4.0 * ((double)N * K * 4 * Hb * Wb + (double)N * M * Hb * Wb + 25.0 * K * M));
-        static bool a3 = false, a4 = false;
+        static bool a3 = false, a4 = false, f3 = false, f4 = false;
+        if (amax_ws) {
+            g.x_amax = amax_ws;
+            g.w_amax = w_amax;
+            if (nq == 3) { q_set_attr(&kq_dgh_kernel<3, true>, &f3); hipLaunchKernelGGL((kq_dgh_kernel<3, true>), grid, dim3(256), lds, s, dy, wp, dx, g); }
+            else { q_set_attr(&kq_dgh_kernel<4, true>, &f4); hipLaunchKernelGGL((kq_dgh_kernel<4, true>), grid, dim3(256), lds, s, dy, wp, dx, g); }
+        } else
         if (nq == 3) { q_set_attr(&kq_dgh_kernel<3>, &a3); hipLaunchKernelGGL((kq_dgh_kernel<3>), grid, dim3(256), lds, s, dy, wp, dx, g); }
         else { q_set_attr(&kq_dgh_kernel<4>, &a4); hipLaunchKernelGGL((kq_dgh_kernel<4>), grid, dim3(256), lds, s, dy, wp, dx, g); }
     }
@@ -1169,8 +1302,8 @@ int gx_kq_deconv_dgrad_launch(const float* dy, const float* wp, float* dx, int N
 }
 
 extern "C" int gx_kq_precision(int mode) {
-    GX_CHECK_ARG(mode == 0 || mode == 1, "gx_kq_precision: mode must be 0 (fp32 matrix pipe) or 1 (bf16 pipe, six piece products)");
-    g_kq_h = mode;
+    GX_CHECK_ARG(mode >= -1 && mode <= 2, "gx_kq_precision: mode must be 0 (fp32 matrix pipe), 1 (bf16 pipe, six piece products), 2 (as 1, the transposed convs from three fp16 piece products) or -1 (the environment's default)");
+    g_kq_h = mode;        // (-1: kq_h_init reads GENESIS_KQ_BF16X6 / GENESIS_KQ_F16X3 again)
     return GX_OK;
 }
 

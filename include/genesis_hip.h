@@ -80,10 +80,15 @@ int gx_wgq_precision(int mode);
  *      what they read (the A/B reference).  Environment: GENESIS_WGQ_RING=0.  Replaces the same reference ops as
  *      gx_conv3x3_wgrad / gx_deconv5x5s2_wgrad (modules/blocks.py:159-165, models/genesisv2_config.py:89-99). */
 int gx_wgq_ring(int on);
-/*      The same choice for the chip-filling transposed-conv forward / data-gradient layers (gx_kq.hip): 1 (default)
+/*      The same choice for the chip-filling transposed-conv forward / data-gradient layers (gx_kq.hip): 1
  *      bf16 pipe -- the staging splits the input tile into its three bf16 planes, the pack kernel the weights; needs a
  *      multiple of 16 reduction channels and a tile of <= 384 halo positions, other layers stay on the fp32 pipe --
- *      0 fp32 pipe.  Environment: GENESIS_KQ_BF16X6=0. */
+ *      0 fp32 pipe.  Environment: GENESIS_KQ_BF16X6=0.  2: as 1, the transposed-conv forward / data gradient from THREE fp16
+ *      piece products instead (x * 2^sx = hi + lo, 22 significant bits; hi*hi + hi*lo + lo*hi), one power-of-two scale per
+ *      tensor from its largest magnitude -- the input's by two small launches ahead of the conv (scratch at the end of the
+ *      conv's workspace), the weights' at pack time; error against fp64 at or below the bf16 form's on every operand set of the
+ *      tests, two thirds of its matrix-pipe time: the DEFAULT since round 5 (GENESIS_KQ_F16X3=0: mode 1).  -1: back to the
+ *      environment's default. */
 int gx_kq_precision(int mode);
 size_t gx_conv3x3_wino_ws_bytes(int N, int Cin, int Cout, int H, int W);
 int gx_conv3x3_wino(const float* x, const float* w, float* y, int N, int Cin, int Cout, int H, int W, int mode,

@@ -871,7 +871,7 @@ def test_transposed_conv_on_the_bf16_pipe_keeps_fp32_accuracy(N, Cin, Cout, Hin)
     rg = ref.view(N, groups, -1)
     err, errm, errd = {}, {}, {}
     try:
-        for mode in (0, 1):
+        for mode in (0, 1, 2):       # 2: three fp16 piece products, per-tensor power-of-two scales (DESIGN.md finding 40)
             _lib.call('gx_kq_precision', mode)
             dx = hip.deconv5x5s2_dgrad(dy.to(DEV), w.to(DEV))
             errd[mode] = float((dx.double().cpu() - xr.grad).norm() / xr.grad.norm())
@@ -882,12 +882,13 @@ def test_transposed_conv_on_the_bf16_pipe_keeps_fp32_accuracy(N, Cin, Cout, Hin)
             errm[mode] = float((mean.double().cpu() - rg.mean(2).flatten()).abs().max())
             np.testing.assert_allclose(rstd.cpu().double().numpy(), (rg.var(2, unbiased=False) + 1e-5).rsqrt().flatten().numpy(), rtol=2e-5)
     finally:
-        _lib.call('gx_kq_precision', 1)
-    print('deconv fwd N=%d %d->%d @%d: relative L2 error fp32 pipe %.3e, bf16 pipe %.3e; |mean error| %.2e / %.2e; '
-          'data gradient %.3e / %.3e' % (N, Cin, Cout, Hin, err[0], err[1], errm[0], errm[1], errd[0], errd[1]))
-    assert err[1] <= 1.5 * err[0] + 1e-7 and err[1] < 2e-5, err
-    assert errd[1] <= 1.5 * errd[0] + 1e-7 and errd[1] < 2e-5, errd
-    assert errm[1] <= 2e-6, errm
+        _lib.call('gx_kq_precision', -1)
+    print('deconv fwd N=%d %d->%d @%d: relative L2 error fp32 pipe %.3e, bf16 x 6 %.3e, fp16 x 3 %.3e; |mean error| %.2e / %.2e / %.2e; '
+          'data gradient %.3e / %.3e / %.3e' % (N, Cin, Cout, Hin, err[0], err[1], err[2], errm[0], errm[1], errm[2], errd[0], errd[1], errd[2]))
+    for mode in (1, 2):
+        assert err[mode] <= 1.5 * err[0] + 1e-7 and err[mode] < 2e-5, err
+        assert errd[mode] <= 1.5 * errd[0] + 1e-7 and errd[mode] < 2e-5, errd
+        assert errm[mode] <= 2e-6, errm
 
 
 @pytest.mark.parametrize('N,Cin,Cout,H,W', [(2, 16, 16, 8, 16), (3, 24, 40, 32, 32), (2, 64, 64, 64, 64),
@@ -1291,16 +1292,17 @@ def test_bf16_pipe_transposed_conv_on_hard_operands(dist):
     ref = ref.detach()
     err, errd = {}, {}
     try:
-        for mode in (0, 1):
+        for mode in (0, 1, 2):
             _lib.call('gx_kq_precision', mode)
             y = hip.deconv5x5s2_fwd(x.to(DEV), w.to(DEV), None)
             dx = hip.deconv5x5s2_dgrad(dy.to(DEV), w.to(DEV))
             err[mode] = float((y.double().cpu() - ref).norm() / ref.norm())
             errd[mode] = float((dx.double().cpu() - xr.grad).norm() / xr.grad.norm())
     finally:
-        _lib.call('gx_kq_precision', 1)
-    print('deconv %s: forward fp32 pipe %.3e, bf16 pipe %.3e; data gradient %.3e / %.3e' % (dist, err[0], err[1], errd[0], errd[1]))
-    assert err[1] <= 1.5 * err[0] + 1e-7 and errd[1] <= 1.5 * errd[0] + 1e-7, (err, errd)
+        _lib.call('gx_kq_precision', -1)
+    print('deconv %s: forward fp32 pipe %.3e, bf16 x 6 %.3e, fp16 x 3 %.3e; data gradient %.3e / %.3e / %.3e' % (dist, err[0], err[1], err[2], errd[0], errd[1], errd[2]))
+    for mode in (1, 2):
+        assert err[mode] <= 1.5 * err[0] + 1e-7 and errd[mode] <= 1.5 * errd[0] + 1e-7, (err, errd)
 
 
 @pytest.mark.parametrize('N,Cin,Cout,S,cin_n', [(5, 4, 32, 64, 1), (5, 4, 32, 64, None), (3, 32, 32, 32, None), (4, 32, 64, 16, None),
@@ -1421,20 +1423,21 @@ def test_conv3x3_to_32_channels_on_the_bf16_pipe(N, Cin, Cout, H, W):
     err = {}
     _lib.call('gx_kq_policy', 2)                  # every eligible shape (the default asks for a chip-filling grid)
     try:
-        for mode in (0, 1):
+        for mode in (0, 1, 2):       # 2: three fp16 piece products (packs 40 / 41)
             _lib.call('gx_kq_precision', mode)
             y = hip.conv3x3_bias_act_fwd(x.to(DEV), w.to(DEV), b.to(DEV), 'elu')
             dx = hip.conv3x3_dgrad(dy.to(DEV), w.to(DEV))
             err[mode] = (float((y.double().cpu() - yr).norm() / yr.norm()), float((dx.double().cpu() - dxr).norm() / dxr.norm()))
-            if mode == 1:
+            if mode >= 1:
                 close(y, yr, rtol=1e-5, atol=1e-5, msg='y')
                 close(dx, dxr, rtol=1e-5, atol=1e-5, msg='dx')
     finally:
-        _lib.call('gx_kq_precision', 1)
+        _lib.call('gx_kq_precision', -1)
         _lib.call('gx_kq_policy', 1)
-    print('conv3x3 -> %d channels %dx%d: forward fp32 pipe %.3e, bf16 pipe %.3e; data gradient %.3e / %.3e'
-          % (Cout, H, W, err[0][0], err[1][0], err[0][1], err[1][1]))
-    assert err[1][0] <= 1.5 * err[0][0] + 1e-7 and err[1][1] <= 1.5 * err[0][1] + 1e-7, err
+    print('conv3x3 -> %d channels %dx%d: forward fp32 pipe %.3e, bf16 x 6 %.3e, fp16 x 3 %.3e; data gradient %.3e / %.3e / %.3e'
+          % (Cout, H, W, err[0][0], err[1][0], err[2][0], err[0][1], err[1][1], err[2][1]))
+    for mode in (1, 2):
+        assert err[mode][0] <= 1.5 * err[0][0] + 1e-7 and err[mode][1] <= 1.5 * err[0][1] + 1e-7, err
 
 
 @pytest.mark.parametrize('N,Cin,Cout,H,W,act', [(16, 32, 32, 72, 72, 'relu'), (5, 24, 16, 40, 24, 'elu'), (4, 7, 32, 16, 16, 'relu'),
@@ -1622,3 +1625,82 @@ def test_two_linear_heads_in_one_buffer():
     close(out, ref, 2e-6, 2e-6, 'fwd')
     for a, b_, n in zip(pd, ps, ('dh', 'dw1', 'db1', 'dw2', 'db2')):
         close(a.grad, b_.grad, 5e-6, 5e-6, n)
+
+
+@pytest.mark.parametrize('kind', ['wide', 'tiny', 'huge', 'zeros', 'one_large'])
+def test_fp16x3_transposed_conv_scales_follow_the_tensors(kind):
+    """gx_kq_precision(2): every fp32 product of the chip-filling transposed convs from THREE fp16 piece products of x * 2^sx and
+    w * 2^sw (hi + lo = 22 significant bits; hi*hi + hi*lo + lo*hi) with ONE power-of-two scale per tensor taken from its largest
+    magnitude on the device (two small launches ahead of the conv; the weights' at pack time).  What a per-tensor scale has to
+    survive: channels spread over 12 binary orders of magnitude with exact zeros (ReLU outputs), tensors that are tiny / huge as a
+    whole (2^-30, 2^+30: far outside fp16's own range), an all-zero input (amax 0), one element 2^20 times the rest (everything else
+    lands in fp16's subnormal range: absolute, not relative, accuracy -- still the CPU fp32 op's error against fp64 in norm)."""
+    from genesis_amd import _lib
+    N, Cin, Cout, H = 56, 64, 64, 32
+    x, w, b = rnd(N, Cin, H, H, seed=4), rnd(Cin, Cout, 5, 5, seed=5, scale=0.05), rnd(Cout, seed=6)
+    dy = rnd(N, Cout, 2 * H, 2 * H, seed=7)
+    if kind == 'wide':
+        x = torch.relu(x * torch.pow(2.0, -(torch.arange(Cin).float() % 13)).view(1, -1, 1, 1))
+        dy = dy * torch.pow(2.0, -(torch.arange(Cout).float() % 13)).view(1, -1, 1, 1)
+        w = w * torch.pow(2.0, -(torch.arange(Cout).float() % 7)).view(1, -1, 1, 1)
+    elif kind == 'tiny':
+        x, dy, w, b = x * 2.0 ** -30, dy * 2.0 ** -30, w * 2.0 ** -20, b * 2.0 ** -50
+    elif kind == 'huge':
+        x, dy, w, b = x * 2.0 ** 30, dy * 2.0 ** 30, w * 2.0 ** 20, b * 2.0 ** 50
+    elif kind == 'zeros':
+        x, dy = torch.zeros_like(x), torch.zeros_like(dy)
+    elif kind == 'one_large':
+        x[3, 5, 7, 9] = 2.0 ** 20
+        dy[2, 4, 6, 8] = -2.0 ** 20
+    out = {}
+    for dt in (torch.float64, torch.float32):
+        xr = x.to(dt).requires_grad_()
+        y = F.conv_transpose2d(xr, w.to(dt), b.to(dt), 2, 2, 1)
+        y.backward(dy.to(dt))
+        out[dt] = (y.detach(), xr.grad)
+    ref, c32 = out[torch.float64], out[torch.float32]
+    try:
+        _lib.call('gx_kq_precision', 2)
+        y = hip.deconv5x5s2_fwd(x.to(DEV), w.to(DEV), b.to(DEV))
+        dx = hip.deconv5x5s2_dgrad(dy.to(DEV), w.to(DEV))
+    finally:
+        _lib.call('gx_kq_precision', -1)
+    assert bool(torch.isfinite(y).all()) and bool(torch.isfinite(dx).all())
+
+    def rel(a, r):
+        return float((a.double().cpu() - r).norm() / (r.norm() + 1e-300))
+    e = (rel(y, ref[0]), rel(dx, ref[1]))
+    e32 = (rel(c32[0], ref[0]), rel(c32[1], ref[1]))
+    print('fp16 x 3 transposed conv, %s operands: forward %.3e (CPU fp32 %.3e), data gradient %.3e (CPU fp32 %.3e)' % (kind, e[0], e32[0], e[1], e32[1]))
+    if kind == 'zeros':
+        assert torch.equal(dx, torch.zeros_like(dx)) and e[0] < 1e-6
+    else:
+        assert e[0] <= 1.5 * e32[0] + 1e-7 and e[1] <= 1.5 * e32[1] + 1e-7, (e, e32)
+
+
+@pytest.mark.parametrize('N,K,M,S', [(16, 32, 64, 64), (52, 64, 128, 32), (200, 64, 64, 16), (13, 48, 64, 64)])
+@pytest.mark.parametrize('dist', ['uniform', 'mixed'])
+def test_fp16x3_conv5x5_stride1(N, K, M, S, dist):
+    """The 5 x 5 stride-1 convs of the gated stacks (gx_kq.hip Q_C5H) under gx_kq_precision(2): both weight roles against fp64,
+    next to the six-bf16-piece form, on uniform operands and on channels spread over seven decades."""
+    from genesis_amd import hip_ops as hip, _lib
+    x = rnd(N, K, S, S, seed=1) if dist == 'uniform' else _stress('mixed', N, K, S, S, seed=1)
+    w0 = rnd(M, K, 5, 5, seed=2, scale=0.1)
+    w1 = rnd(K, M, 5, 5, seed=3, scale=0.1)
+    r0 = F.conv2d(x.double(), w0.double(), None, 1, 2)
+    r1 = F.conv_transpose2d(x.double(), w1.double(), None, 1, 2)
+    err = {}
+    try:
+        for mode in (1, 2):
+            _lib.call('gx_kq_precision', mode)
+            y0 = hip.conv5x5s1(x.to(DEV), w0.to(DEV), M, False)
+            y1 = hip.conv5x5s1(x.to(DEV), w1.to(DEV), M, True)
+            err[mode] = (float((y0.double().cpu() - r0).norm() / r0.norm()), float((y1.double().cpu() - r1).norm() / r1.norm()))
+    finally:
+        _lib.call('gx_kq_precision', -1)
+    c32 = (float((F.conv2d(x, w0, None, 1, 2).double() - r0).norm() / r0.norm()),
+           float((F.conv_transpose2d(x, w1, None, 1, 2).double() - r1).norm() / r1.norm()))
+    print('conv5x5 %s N=%d %d->%d @%d: bf16 x 6 %.3e / %.3e, fp16 x 3 %.3e / %.3e, CPU fp32 %.3e / %.3e'
+          % (dist, N, K, M, S, err[1][0], err[1][1], err[2][0], err[2][1], c32[0], c32[1]))
+    for i in (0, 1):
+        assert err[2][i] <= 1.5 * max(err[1][i], c32[i]) + 1e-7, (err, c32)
