@@ -183,7 +183,7 @@ bool gx_kq_deconv_h_eligible(int N, int K, int M, int Hb, int Wb);
 size_t gx_kq_deconv_h_pack_bytes(int K, int M, int nt);
 // ... or from THREE fp16 piece products (gx_kq_precision(2), DESIGN.md finding 40): x * 2^e = hi + lo (11 + 11 significant bits),
 // hi*hi + hi*lo + lo*hi; e per TENSOR from its largest magnitude so that the pieces sit inside fp16's exponent range.  Pack kinds
-// 40 / 41 / 42 / 43 / 44 / 47 / 48 = 20 / 21 / 22 / 23 / 24 / 27 / 28 as two fp16 pieces of w * 2^e (third piece slot unused); the weight tensor's amax lives in the last
+// 40 / 41 / 42 / 43 / 44 / 47 / 48 = 20 / 21 / 22 / 23 / 24 / 27 / 28 as two fp16 pieces of w * 2^e (two piece slots per tap); the weight tensor's amax lives in the last
 // 64 bytes of the packing's slack (written by the amax launch that precedes the pack, read by the pack and by the conv kernels).
 bool gx_kq_f16_on();
 __host__ __device__ __forceinline__ size_t gx_kq_h_amax_off(int K, int M, int nt) {      // byte offset of that float
@@ -237,8 +237,9 @@ int gx_kq_deconv_fwd_h_launch(const float* in, const float* wp0, const float* wp
                               float* amax_ws = nullptr, const float* w_amax = nullptr);    // amax_ws != NULL: the fp16 x 3 form (packs 42 / 43)
 // 32-bit word of element (m, k even, k + 1) of piece `piece` of tap t
 // ... kinds 20 / 21 (conv3x3 forward / data gradient of <= 32-output-channel layers): 32 output channels per channel tile
-__host__ __device__ __forceinline__ size_t gx_kq_h32_word(int m, int k, int t, int piece, int NT, int K) {
-    return ((((size_t)(m >> 5) * (K >> 4) + (k >> 4)) * NT + t) * 3 + piece) * 256 + (((k >> 3) & 1) * 32 + (m & 31)) * 4 + ((k & 7) >> 1);
+// (NP: pieces per value -- 3 bf16 ones, or 2 fp16 ones in the packs 40 - 48 of the fp16 x 3 form)
+__host__ __device__ __forceinline__ size_t gx_kq_h32_word(int m, int k, int t, int piece, int NT, int K, int NP = 3) {
+    return ((((size_t)(m >> 5) * (K >> 4) + (k >> 4)) * NT + t) * NP + piece) * 256 + (((k >> 3) & 1) * 32 + (m & 31)) * 4 + ((k & 7) >> 1);
 }
 bool gx_kq_c3h_eligible(int N, int K, int M, int H, int W);
 int gx_kq_c3h_launch(const float* in, const float* wp, const float* bias, int act, float* out, int N, int K, int M, int H,
@@ -249,8 +250,8 @@ bool gx_kq_c5h_eligible(int N, int K, int M, int H, int W);
 int gx_chan_sums_launch(const float* x, int N, int C, int HW, float* part, float* out, hipStream_t s);   // gx_misc.hip
 int gx_kq_c5h_launch(const float* in, const float* wp, float* out, int N, int K, int M, int H, int W, hipStream_t s,
                      float* amax_ws = nullptr, const float* w_amax = nullptr);      // (packs 47 / 48)
-__host__ __device__ __forceinline__ size_t gx_kq_h_word(int m, int k, int t, int piece, int NT, int K) {
-    return ((((size_t)(m >> 6) * (K >> 4) + (k >> 4)) * NT + t) * 3 + piece) * 512 + (((k >> 3) & 1) * 64 + (m & 63)) * 4 + ((k & 7) >> 1);
+__host__ __device__ __forceinline__ size_t gx_kq_h_word(int m, int k, int t, int piece, int NT, int K, int NP = 3) {
+    return ((((size_t)(m >> 6) * (K >> 4) + (k >> 4)) * NT + t) * NP + piece) * 512 + (((k >> 3) & 1) * 64 + (m & 63)) * 4 + ((k & 7) >> 1);
 }
 
 // ---- second-generation weight gradients (gx_wgq.hip): LDS-DMA staging of both operands, grouped launches -------------

@@ -588,12 +588,14 @@ __device__ __forceinline__ void pack_h_store(const float* __restrict__ w, float*
         pc[e][1] = __builtin_bit_cast(unsigned short, mm);
         pc[e][2] = __builtin_bit_cast(unsigned short, l);
     }
+    const int np = f16 ? 2 : 3;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
+        if (q >= np) break;
         wd[q] = (unsigned)pc[0][q] | ((unsigned)pc[1][q] << 16);
-        const size_t dst = pack <= 21 ? gx_kq_h32_word(m, k, t, q, NT, Kpad)       // 20 / 21: conv3x3, 32-channel tiles
+        const size_t dst = pack <= 21 ? gx_kq_h32_word(m, k, t, q, NT, Kpad, np)       // 20 / 21: conv3x3, 32-channel tiles
                            : ((pack == 25 || pack == 26) ? gx_wino_h_word(m, k, t, q, Kpad)        // 25 / 26: Winograd operands (= 5 / 6), t = position; 27 / 28: 5 x 5 stride 1 (= 7 / 8)
-                                         : gx_kq_h_word(m, k, pack == 24 ? gx_kq_dg_tap_slot(t) : t, q, NT, Kpad));
+                                         : gx_kq_h_word(m, k, pack == 24 ? gx_kq_dg_tap_slot(t) : t, q, NT, Kpad, np));
         wp[dst] = __builtin_bit_cast(float, wd[q]);
     }
 }

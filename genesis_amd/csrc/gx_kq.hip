@@ -161,7 +161,8 @@ typedef _Float16 q_f16x8 __attribute__((ext_vector_type(8)));
 constexpr int QH_TAP_BYTES = 3 * 2 * 64 * 16;          // one tap of one 16-channel chunk: 6144 B
 static_assert(QH_TAP_BYTES == 6144, "gx_kq_h_amax_off (gx_common.h) spells this number out");
 // output-channel rows of a workgroup's weight slice and the bytes of one (tap, chunk) of it
-template <int MODE> struct QHLay { static constexpr int ROWS = MODE == Q_C3H ? 32 : 64, TAPB = 3 * 2 * ROWS * 16; };
+// (NP pieces per value: three bf16 ones, two fp16 ones)
+template <int MODE, bool F16 = false> struct QHLay { static constexpr int ROWS = MODE == Q_C3H ? 32 : 64, NP = F16 ? 2 : 3, TAPB = NP * 2 * ROWS * 16; };
 
 // one phase on the bf16 pipe: operands of (tap, mi / nj, piece) straight out of LDS
 template <int MODE, int PH, int NCLS, int MI, bool F16 = false>
@@ -177,7 +178,7 @@ __device__ __forceinline__ void q_phase_h(f32x16 (&acc)[NCLS][MI][2], const char
         for (int pc = 0; pc < (F16 ? 2 : 3); ++pc) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
-                a[mi][pc] = *reinterpret_cast<const q_bf16x8*>(wb + i * QHLay<MODE>::TAPB + pc * (QHLay<MODE>::TAPB / 3) + a_lane_b + mi * 512);
+                a[mi][pc] = *reinterpret_cast<const q_bf16x8*>(wb + i * QHLay<MODE, F16>::TAPB + pc * (QHLay<MODE, F16>::TAPB / QHLay<MODE, F16>::NP) + a_lane_b + mi * 512);
             b[0][pc] = *reinterpret_cast<const q_bf16x8*>(ib + pc * plane_bytes + b_lane0_b + toff);
             b[1][pc] = *reinterpret_cast<const q_bf16x8*>(ib + pc * plane_bytes + b_lane1_b + toff);
         }
@@ -320,7 +321,7 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
         const_cast<float*>(in), 0, (int)((unsigned)g.N * (unsigned)g.K * (unsigned)HiWi * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(wp), 0,
-        B16 ? (int)((unsigned)NT * (unsigned)(g.K / 16) * gridDim.y * (unsigned)QHLay<MODE>::TAPB)
+        B16 ? (int)((unsigned)NT * (unsigned)(g.K / 16) * gridDim.y * (unsigned)QHLay<MODE, F16>::TAPB)
             : (int)((unsigned)NT * (unsigned)g.K * gridDim.y * 256u), 0x00020000);
     int voff[NQ];
 #pragma unroll
@@ -353,7 +354,8 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
     if constexpr (B16) {
         // ---- the bf16-pipe pipeline: chunks of 16 channels, phases of <= 3 taps
         const int f16_sx = F16 ? gx_f16_scale_exp(*g.x_amax) : 0;
-        constexpr int TAPB = QHLay<MODE>::TAPB;
+        constexpr int TAPB = QHLay<MODE, F16>::TAPB;
+        constexpr int NPL = QHLay<MODE, F16>::NP;                          // input piece planes in LDS
         constexpr int NWH = (MAXT * (TAPB / 16) + 255) / 256;              // 16-byte weight pieces per thread per phase
         constexpr int WSLOTB = NWH * 256 * 16;                             // bytes per weight buffer
         // four staging rounds (the 64-pixel-wide tiles of a 64 x 64 base grid: 6 x 66 halo positions): exact planes, so that three
@@ -361,9 +363,9 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
         constexpr bool TRIM = NQ == 4 && MODE != Q_C3H;
         const int plane_bytes = TRIM ? 2 * CHS * 16 : NQ * 256 * 16;       // bytes per input piece plane
         char* const ibuf = reinterpret_cast<char*>(lds);
-        char* const wbufb = ibuf + 3 * plane_bytes;
+        char* const wbufb = ibuf + NPL * plane_bytes;
         const int quad_l = lane >> 5;
-        const int a_lane_b = (quad_l * QHLay<MODE>::ROWS + (lane & 31)) * 16 + mh * 512;   // + mi * 512 + piece * TAPB / 3 + tap * TAPB
+        const int a_lane_b = (quad_l * QHLay<MODE, F16>::ROWS + (lane & 31)) * 16 + mh * 512;   // + mi * 512 + piece * TAPB / 3 + tap * TAPB
         int b_lane_b[2];
 #pragma unroll
         for (int nj = 0; nj < 2; ++nj) {
@@ -1095,10 +1097,13 @@ size_t gx_kq_deconv_h_pack_bytes(int K, int M, int nt) {     // one row parity's
 }
 // LDS of the bf16-pipe transposed-conv kernels: three input piece planes (exact at four staging rounds) + two weight buffers;
 // 0: the tile does not leave room for two workgroups per CU
-static size_t qh_lds(const QGeom& g, int nq) {
-    constexpr int NWH = (3 * (QH_TAP_BYTES / 16) + 255) / 256;
+// (f16: the launch's allocation in the fp16 x 3 form -- two planes, two-piece weight taps: 48 KB at three staging rounds, i.e. THREE
+//  workgroups per CU where the registers allow it (kq_dgh_kernel<3, true>: 156); eligibility is always decided on the three-piece size)
+static size_t qh_lds(const QGeom& g, int nq, bool f16 = false) {
+    const int np = f16 ? 2 : 3;
+    const int NWH = (3 * (np * 2048 / 16) + 255) / 256;
     const int CHS = (1 << g.lG) * ((1 << g.lTH) + 2) * ((1 << g.lTW) + 2);
-    const size_t planes = nq == 4 ? (size_t)3 * 2 * CHS * 16 : (size_t)3 * nq * 256 * 16;
+    const size_t planes = nq == 4 ? (size_t)np * 2 * CHS * 16 : (size_t)np * nq * 256 * 16;
     const size_t lds = planes + (size_t)2 * NWH * 256 * 16;
     static const char* env = getenv("GENESIS_KQ_H_NQ4");           // 0: shapes with four staging rounds stay on the fp32 pipe
     if (nq == 4 && env && env[0] == '0') return 0;
@@ -1116,7 +1121,7 @@ int gx_kq_deconv_fwd_h_launch(const float* in, const float* wp0, const float* wp
     if (!q_plan(N, K, M, Hb, Wb, Hb, Wb, 2 * Hb, 2 * Wb, &g, &nq, &lds, 5) || qh_lds(g, nq) == 0 || K % 16 != 0) {
         gx_set_error("kq deconv fwd (bf16 pipe): shape not eligible"); return GX_EINVAL;
     }
-    lds = qh_lds(g, nq);
+    lds = qh_lds(g, nq, amax_ws != nullptr);
     const bool st = stats && g.lG == 0 && (M % 8) == 0;
     if (stats_parts) *stats_parts = 0;
     if (st) {
@@ -1186,7 +1191,11 @@ int gx_kq_c3h_launch(const float* in, const float* wp, const float* bias, int ac
     QGeom g; int nq; size_t lds;
     if (!q_plan_c3h(N, K, M, H, W, &g, &nq, &lds)) { gx_set_error("kq conv3x3 (bf16 pipe): shape not eligible"); return GX_EINVAL; }
     g.act = act; g.mask = mask; g.mask_act = mask_act;
-    if (amax_ws) { const int rc = gx_kq_amax_launch(in, (size_t)N * K * H * W, amax_ws, s); if (rc) return rc; }
+    if (amax_ws) {
+        constexpr int NWF = (3 * (QHLay<Q_C3H, true>::TAPB / 16) + 255) / 256;
+        lds = (size_t)2 * nq * 256 * 16 + (size_t)NWF * 256 * 16;          // two input piece planes + one two-piece weight buffer
+        const int rc = gx_kq_amax_launch(in, (size_t)N * K * H * W, amax_ws, s); if (rc) return rc;
+    }
     dim3 grid(g.tiles_h * g.tiles_w * gx_ceil_div(N, 1 << g.lG), gx_ceil_div(M, 32));
     g.nfull = (int)grid.x;                               // tiles; the workgroups loop over them (kq_c3h_kernel)
     static const char* pers_env = getenv("GENESIS_KQ_C3H_PERSIST");
@@ -1233,7 +1242,11 @@ int gx_kq_c5h_launch(const float* in, const float* wp, float* out, int N, int K,
                      float* amax_ws, const float* w_amax) {
     QGeom g; size_t lds;
     if (!q_plan_c5h(N, K, M, H, W, &g, &lds)) { gx_set_error("kq conv5x5 (bf16 pipe): shape not eligible"); return GX_EINVAL; }
-    if (amax_ws) { const int rc = gx_kq_amax_launch(in, (size_t)N * K * H * W, amax_ws, s); if (rc) return rc; }
+    if (amax_ws) {
+        constexpr int NWF = (3 * (QHLay<Q_C5H, true>::TAPB / 16) + 255) / 256;
+        lds = (size_t)2 * 2 * (20 * 20) * 16 + (size_t)2 * NWF * 256 * 16;
+        const int rc = gx_kq_amax_launch(in, (size_t)N * K * H * W, amax_ws, s); if (rc) return rc;
+    }
     dim3 grid(g.nfull, gx_ceil_div(M, 64));
     {
         GxProf pf(KID_KQ_C5H, s, 2.0 * N * (double)M * K * 25 * H * W, 4.0 * ((double)N * K * H * W + (double)N * M * H * W + 25.0 * K * M));
@@ -1262,7 +1275,7 @@ int gx_kq_deconv_dgrad_h_launch(const float* dy, const float* wp, float* dx, int
     if (!q_plan(N, K, M, Hb, Wb, 2 * Hb, 2 * Wb, Hb, Wb, &g, &nq, &lds, 9) || qh_lds(g, nq) == 0 || K % 16 != 0) {
         gx_set_error("kq deconv dgrad (bf16 pipe): shape not eligible"); return GX_EINVAL;
     }
-    lds = qh_lds(g, nq);
+    lds = qh_lds(g, nq, amax_ws != nullptr);
     if (amax_ws) { const int rc = gx_kq_amax_launch(dy, (size_t)N * K * 4 * Hb * Wb, amax_ws, s); if (rc) return rc; }
     dim3 grid(1, gx_ceil_div(M, 64));
     g.nfull = q_split_tail(g.tiles_h * g.tiles_w * gx_ceil_div(N, 1 << g.lG), M, &grid.x);
