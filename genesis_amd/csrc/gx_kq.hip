@@ -210,6 +210,7 @@ __device__ __forceinline__ void q_phase_h(f32x16 (&acc)[NCLS][MI][2], const char
 }
 
 struct QGeom {
+    int ilv;              // kq_dth_kernel: row parities interleaved along blockIdx.x (grid.z = 1)
     const float* x_amax; const float* w_amax;      // fp16 x 3 form: the input tensor's / the weight tensor's largest magnitude (device)
     int N, K, M;          // images, reduction channels (a multiple of 8), output channels
     int nchunks;          // K / 8
@@ -885,14 +886,24 @@ __global__ void __launch_bounds__(256, 2)
 kq_dth_kernel(const float* __restrict__ in, const float* __restrict__ wp0, const float* __restrict__ wp1,
               const float* __restrict__ bias, float* __restrict__ out, QGeom g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // g.ilv (finding 41): the two row parities INTERLEAVED along blockIdx.x (grid.z = 1) in groups of eight blocks -- one per XCD, so
+    // the 15-tap and the 10-tap workgroup of a tile run on the same L2 right after each other, and the workgroups sharing a CU have
+    // different lengths: they drift apart instead of storing their 128 KB tiles in lockstep (the store bursts of a grid of equal
+    // workgroups are HBM-write-bound windows between compute-only windows)
+    int bxr = (int)blockIdx.x, z = (int)blockIdx.z;
+    if (g.ilv) {
+        const int gx = (int)gridDim.x >> 1, al = gx & ~7, b = (int)blockIdx.x;
+        if (b < 2 * al) { z = (b >> 3) & 1; bxr = ((b >> 4) << 3) | (b & 7); }
+        else { const int r = b - 2 * al, rem = gx - al; z = r / rem; bxr = al + r - z * rem; }
+    }
     // (XCD-aware tile map over the whole-tile workgroups: neighbouring tiles, which share halo rows, on one XCD's L2)
-    const int bx = (int)blockIdx.x < g.nfull ? gx_xcd_tile(blockIdx.x, g.nfull) : (int)blockIdx.x;
+    const int bx = bxr < g.nfull ? gx_xcd_tile(bxr, g.nfull) : bxr;
     if (bx < g.nfull) {
-        if (blockIdx.z) q_body<Q_DT1H, NQ, STATS, 2, F16>(in, wp1, bias, out, g, lds, bx, blockIdx.y, 1);
+        if (z) q_body<Q_DT1H, NQ, STATS, 2, F16>(in, wp1, bias, out, g, lds, bx, blockIdx.y, 1);
         else q_body<Q_DT0H, NQ, STATS, 2, F16>(in, wp0, bias, out, g, lds, bx, blockIdx.y, 0);
     } else {
         const int tile = g.nfull + ((bx - g.nfull) >> 1), mh = (bx - g.nfull) & 1;
-        if (blockIdx.z) q_body<Q_DT1H, NQ, STATS, 1, F16>(in, wp1, bias, out, g, lds, tile, blockIdx.y, 1, mh);
+        if (z) q_body<Q_DT1H, NQ, STATS, 1, F16>(in, wp1, bias, out, g, lds, tile, blockIdx.y, 1, mh);
         else q_body<Q_DT0H, NQ, STATS, 1, F16>(in, wp0, bias, out, g, lds, tile, blockIdx.y, 0, mh);
     }
 }
@@ -910,7 +921,7 @@ bool q_plan(int N, int K, int M, int Hb, int Wb, int Hi, int Wi, int Ho, int Wo,
     g->Hb = Hb; g->Wb = Wb; g->Hi = Hi; g->Wi = Wi; g->Ho = Ho; g->Wo = Wo;
     g->lTH = q_ilog2(TH); g->lTW = q_ilog2(TW); g->lG = q_ilog2(G);
     g->tiles_h = Hb / TH; g->tiles_w = Wb / TW;
-    g->x_amax = g->w_amax = nullptr; g->act = 0; g->stats = nullptr; g->stats_parts = 0; g->rt_th = g->rt_tw = 0; g->mask = nullptr; g->mask_act = 0;
+    g->ilv = 0; g->x_amax = g->w_amax = nullptr; g->act = 0; g->stats = nullptr; g->stats_parts = 0; g->rt_th = g->rt_tw = 0; g->mask = nullptr; g->mask_act = 0;
     const int CHS = G * (TH + 2) * (TW + 2);
     if (2 * CHS > 4 * 256) return false;
     *nq = 2 * CHS <= 3 * 256 ? 3 : 4;
@@ -1132,6 +1143,8 @@ int gx_kq_deconv_fwd_h_launch(const float* in, const float* wp0, const float* wp
     if (amax_ws) { const int rc = gx_kq_amax_launch(in, (size_t)N * K * Hb * Wb, amax_ws, s); if (rc) return rc; }
     dim3 grid(1, gx_ceil_div(M, 64), 2);
     g.nfull = q_split_tail(g.tiles_h * g.tiles_w * gx_ceil_div(N, 1 << g.lG), M, &grid.x);
+    static const char* ilv_env = getenv("GENESIS_KQ_DTH_INTERLEAVE");       // 0: all 15-tap workgroups, then all 10-tap ones (grid.z)
+    if (!(ilv_env && ilv_env[0] == '0') && grid.y == 1) { g.ilv = 1; grid.x *= 2; grid.z = 1; }
     {
         GxProf pf(KID_KQ_DTH, s, 2.0 * N * (double)M * K * 25 * Hb * Wb,
                   4.0 * ((double)N * K * Hb * Wb + (double)N * M * 4 * Hb * Wb + 25.0 * K * M));
@@ -1171,7 +1184,7 @@ static bool q_plan_c3h(int N, int K, int M, int H, int W, QGeom* g, int* nq, siz
     g->Hb = H; g->Wb = W; g->Hi = H; g->Wi = W; g->Ho = H; g->Wo = W;
     g->lTH = q_ilog2(TH); g->lTW = q_ilog2(TW); g->lG = q_ilog2(G);
     g->tiles_h = gx_ceil_div(H, TH); g->tiles_w = W / TW;
-    g->x_amax = g->w_amax = nullptr; g->act = 0; g->stats = nullptr; g->stats_parts = 0; g->nfull = 0; g->mask = nullptr; g->mask_act = 0;
+    g->ilv = 0; g->x_amax = g->w_amax = nullptr; g->act = 0; g->stats = nullptr; g->stats_parts = 0; g->nfull = 0; g->mask = nullptr; g->mask_act = 0;
     const int CHS = G * (TH + 2) * (TW + 2);
     if (2 * CHS > 4 * 256) return false;
     *nq = 2 * CHS <= 3 * 256 ? 3 : 4;
@@ -1224,7 +1237,7 @@ static bool q_plan_c5h(int N, int K, int M, int H, int W, QGeom* g, size_t* lds_
     g->Hb = H; g->Wb = W; g->Hi = H; g->Wi = W; g->Ho = H; g->Wo = W;
     g->lTH = 4; g->lTW = 4; g->lG = 0;
     g->tiles_h = H / 16; g->tiles_w = W / 16;
-    g->rt_th = g->rt_tw = 0; g->x_amax = g->w_amax = nullptr; g->act = 0; g->stats = nullptr; g->stats_parts = 0; g->mask = nullptr; g->mask_act = 0;
+    g->rt_th = g->rt_tw = 0; g->ilv = 0; g->x_amax = g->w_amax = nullptr; g->act = 0; g->stats = nullptr; g->stats_parts = 0; g->mask = nullptr; g->mask_act = 0;
     g->nfull = g->tiles_h * g->tiles_w * N;
     constexpr int NWH = (3 * (QH_TAP_BYTES / 16) + 255) / 256;
     *lds_bytes = (size_t)3 * 2 * (20 * 20) * 16 + (size_t)2 * NWH * 256 * 16;       // exact input planes + two weight buffers
