@@ -195,9 +195,10 @@ __host__ __device__ __forceinline__ int gx_f16_scale_exp(float amax) {     // am
     (void)frexpf(amax, &ex);
     return 15 - ex;
 }
-// amax of a tensor (n floats) -> ws[0]; ws: gx_kq_amax_ws_floats() floats (two launches: partial maxima, then one workgroup)
-constexpr int kAmaxParts = 1024;
-__host__ __device__ __forceinline__ constexpr size_t gx_kq_amax_ws_floats() { return 16 + kAmaxParts; }
+// amax of a tensor (n floats) as kAmaxParts partial maxima in ws (gx_kq_amax_ws_floats() floats, 16-byte aligned): one launch; the
+// conv kernels reduce the partials themselves
+constexpr int kAmaxParts = 256;
+__host__ __device__ __forceinline__ constexpr size_t gx_kq_amax_ws_floats() { return kAmaxParts; }
 int gx_kq_amax_launch(const float* x, size_t n, float* ws, hipStream_t s);
 #ifdef __HIPCC__
 // |.|-maximum of n floats by ONE workgroup of 1024 threads (a weight tensor: ~100 k floats; 16-byte loads, eight in flight per thread);

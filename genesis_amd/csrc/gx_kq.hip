@@ -281,6 +281,16 @@ __device__ __forceinline__ void q_phase(f32x16 (&acc)[NCLS][MI][2], const float*
 #undef GX_Q_READ
 }
 
+// the input tensor's largest magnitude from gx_kq_amax_launch's kAmaxParts (= 256) partial maxima: four per lane, wave reduction
+__device__ __forceinline__ float q_amax_parts(const float* __restrict__ parts) {
+    static_assert(kAmaxParts == 256, "four per lane");
+    const float* p = parts + 4 * (threadIdx.x & 63);       // (four dword loads: the scratch is only 4-byte aligned in general)
+    float m = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m)));
+}
+
 // NQ: (position, quad) slots staged per thread per input tile (2 * CHS <= NQ * 256)
 // MI: 32-channel MFMA tiles per wave along M.  2 = the workgroup's whole 64-channel tile; 1 = one half (mh) of it --
 // the last tiles of a grid that does not divide the chip are split into two half-work workgroups (q_split_tail).
@@ -352,9 +362,10 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[c][i][j][e] = 0.f;
+    int f16_sx = 0;
+    if constexpr (B16 && F16) f16_sx = gx_f16_scale_exp(q_amax_parts(g.x_amax));
     if constexpr (B16) {
         // ---- the bf16-pipe pipeline: chunks of 16 channels, phases of <= 3 taps
-        const int f16_sx = F16 ? gx_f16_scale_exp(*g.x_amax) : 0;
         constexpr int TAPB = QHLay<MODE, F16>::TAPB;
         constexpr int NPL = QHLay<MODE, F16>::NP;                          // input piece planes in LDS
         constexpr int NWH = (MAXT * (TAPB / 16) + 255) / 256;              // 16-byte weight pieces per thread per phase
@@ -598,7 +609,7 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
             }
     }
     if constexpr (B16 && F16) {
-        const int de = -(gx_f16_scale_exp(*g.x_amax) + gx_f16_scale_exp(*g.w_amax));
+        const int de = -(f16_sx + gx_f16_scale_exp(*g.w_amax));
 #pragma unroll
         for (int c = 0; c < NCLS; ++c)
 #pragma unroll
@@ -1041,51 +1052,40 @@ static void kq_h_init() {
 static bool kq_h_on() { kq_h_init(); return g_kq_h != 0; }
 bool gx_kq_f16_on() { kq_h_init(); return g_kq_h == 2; }
 
-// ---- largest magnitude of a tensor, for the fp16 x 3 form's power-of-two scale: partial maxima (one per workgroup), then ONE
-//      workgroup over the partials -- two launches, no counter, no atomics: the workspace needs no initial state
-__global__ void __launch_bounds__(256)
+// ---- largest magnitude of a tensor, for the fp16 x 3 form's power-of-two scale: ONE launch of kAmaxParts workgroups (1024 threads:
+//      16 waves per CU keep the HBM busy) writes kAmaxParts partial maxima; the conv kernels reduce them themselves (one 16-byte load
+//      per lane and a wave reduction at the top of q_body: q_amax_parts) -- no second launch, no counter, no atomics: the workspace
+//      needs no initial state
+__global__ void __launch_bounds__(1024)
 amax_partial_kernel(const float* __restrict__ x, size_t n, int vec, float* __restrict__ partials) {
     float m = 0.f;
     if (vec) {
         const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
         const size_t n4 = n >> 2;
-        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 1024) {
             const f32x4 v = x4[i];
             m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
         }
-        for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+        for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (size_t)gridDim.x * 1024) m = fmaxf(m, fabsf(x[i]));
     } else {
-        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+        for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (size_t)gridDim.x * 1024) m = fmaxf(m, fabsf(x[i]));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    __shared__ float red[4];
+    __shared__ float red[16];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) partials[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-}
-__global__ void __launch_bounds__(256)
-amax_final_kernel(const float* __restrict__ partials, int nparts, float* __restrict__ out) {
-    float m = 0.f;
-    for (int i = threadIdx.x; i < nparts; i += 256) m = fmaxf(m, partials[i]);
+    if (threadIdx.x == 0) {
+        float r = red[0];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    __shared__ float red[4];
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) out[0] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        for (int i = 1; i < 16; ++i) r = fmaxf(r, red[i]);
+        partials[blockIdx.x] = r;
+    }
 }
 int gx_kq_amax_launch(const float* x, size_t n, float* ws, hipStream_t s) {
-    size_t want = (n / 4 + 2047) / 2048;               // >= 8 float4 per thread
-    const int parts = want < 1 ? 1 : (want > (size_t)kAmaxParts ? kAmaxParts : (int)want);
     {
         GxProf pf(KID_SMALL_REDUCE, s, 0.0, 4.0 * (double)n);
-        hipLaunchKernelGGL(amax_partial_kernel, dim3(parts), dim3(256), 0, s, x, n, (reinterpret_cast<uintptr_t>(x) & 15) == 0 ? 1 : 0, ws + 16);
-    }
-    GX_CHECK_LAUNCH("kq amax (partials)");
-    {
-        GxProf pf(KID_SMALL_REDUCE, s, 0.0, 4.0 * parts);
-        hipLaunchKernelGGL(amax_final_kernel, dim3(1), dim3(256), 0, s, (const float*)(ws + 16), parts, ws);
+        hipLaunchKernelGGL(amax_partial_kernel, dim3(kAmaxParts), dim3(1024), 0, s, x, n, (reinterpret_cast<uintptr_t>(x) & 15) == 0 ? 1 : 0, ws);
     }
     GX_CHECK_LAUNCH("kq amax");
     return GX_OK;
