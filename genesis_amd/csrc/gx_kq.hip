@@ -1149,7 +1149,7 @@ int gx_kq_deconv_fwd_h_launch(const float* in, const float* wp0, const float* wp
         GxProf pf(KID_KQ_DTH, s, 2.0 * N * (double)M * K * 25 * Hb * Wb,
                   4.0 * ((double)N * K * Hb * Wb + (double)N * M * 4 * Hb * Wb + 25.0 * K * M));
         static bool a[8] = {false, false, false, false, false, false, false, false};
-        if (amax_ws) {          // fp16 x 3: the input's amax (two small launches ahead of this one, outside its profiling record)
+        if (amax_ws) {          // fp16 x 3: the input's amax (one small launch ahead of this one, outside its profiling record)
             g.x_amax = amax_ws;
             g.w_amax = w_amax;
             if (nq == 3 && st) { q_set_attr(&kq_dth_kernel<3, true, true>, &a[4]); hipLaunchKernelGGL((kq_dth_kernel<3, true, true>), grid, dim3(256), lds, s, in, wp0, wp1, bias, out, g); }

@@ -85,7 +85,7 @@ int gx_wgq_ring(int on);
  *      multiple of 16 reduction channels and a tile of <= 384 halo positions, other layers stay on the fp32 pipe --
  *      0 fp32 pipe.  Environment: GENESIS_KQ_BF16X6=0.  2: as 1, the transposed-conv forward / data gradient from THREE fp16
  *      piece products instead (x * 2^sx = hi + lo, 22 significant bits; hi*hi + hi*lo + lo*hi), one power-of-two scale per
- *      tensor from its largest magnitude -- the input's by two small launches ahead of the conv (scratch at the end of the
+ *      tensor from its largest magnitude -- the input's by one small launch ahead of the conv (partial maxima at the end of the
  *      conv's workspace), the weights' at pack time; error against fp64 at or below the bf16 form's on every operand set of the
  *      tests, two thirds of its matrix-pipe time: the DEFAULT since round 5 (GENESIS_KQ_F16X3=0: mode 1).  -1: back to the
  *      environment's default. */

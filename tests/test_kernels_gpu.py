@@ -1631,7 +1631,7 @@ def test_two_linear_heads_in_one_buffer():
 def test_fp16x3_transposed_conv_scales_follow_the_tensors(kind):
     """gx_kq_precision(2): every fp32 product of the chip-filling transposed convs from THREE fp16 piece products of x * 2^sx and
     w * 2^sw (hi + lo = 22 significant bits; hi*hi + hi*lo + lo*hi) with ONE power-of-two scale per tensor taken from its largest
-    magnitude on the device (two small launches ahead of the conv; the weights' at pack time).  What a per-tensor scale has to
+    magnitude on the device (one small launch ahead of the conv; the weights' at pack time).  What a per-tensor scale has to
     survive: channels spread over 12 binary orders of magnitude with exact zeros (ReLU outputs), tensors that are tiny / huge as a
     whole (2^-30, 2^+30: far outside fp16's own range), an all-zero input (amax 0), one element 2^20 times the rest (everything else
     lands in fp16's subnormal range: absolute, not relative, accuracy -- still the CPU fp32 op's error against fp64 in norm)."""
