@@ -575,7 +575,7 @@ def main():
             ts2.close()
         finally:
             _lib.call('gx_wgq_precision', 1)
-            _lib.call('gx_kq_precision', 1)
+            _lib.call('gx_kq_precision', -1)        # (the environment's default: three fp16 piece products unless GENESIS_KQ_F16X3=0)
             _lib.call('gx_wino_precision', 1)
 
     # ---- what the timed step leaves out of the reference's iteration, priced: train.py:244-246 computes mse / rmse

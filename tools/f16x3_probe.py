@@ -82,4 +82,4 @@ for N, s in ((224, 16), (224, 32)):
             t = timeit(fn)
             line += ' | %s %7.1f us %6.1f TF/s' % (NAMES[mode], t, fl / t / 1e6)
         print(line, flush=True)
-_lib.call('gx_kq_precision', 1)
+_lib.call('gx_kq_precision', -1)
