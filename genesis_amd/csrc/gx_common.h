@@ -200,6 +200,21 @@ __host__ __device__ __forceinline__ int gx_f16_scale_exp(float amax) {     // am
 constexpr int kAmaxParts = 256;
 __host__ __device__ __forceinline__ constexpr size_t gx_kq_amax_ws_floats() { return kAmaxParts; }
 int gx_kq_amax_launch(const float* x, size_t n, float* ws, hipStream_t s);
+// producer -> consumer hand-over of those partial maxima (gx_kq_amax_link, include/genesis_hip.h): armed by the caller with a scratch
+// buffer; the next producer that can (the decoder head's GroupNorm backward) writes one partial maximum per workgroup of the tensor it
+// stores and records the tensor's address; the next fp16 x 3 conv whose INPUT is that address reads them instead of making its own pass.
+// One-shot, per thread; any fp16 x 3 conv call clears it.
+struct GxAmaxLink { float* parts; int capacity; const float* tensor; int n; int hits; };
+GxAmaxLink& gx_amax_link(void);          // (gx_api.cpp)
+// consumer side: partials of `x` if the armed link holds them (then *n > 0), clearing the link either way
+inline const float* gx_amax_link_take(const float* x, int* n) {
+    GxAmaxLink& L = gx_amax_link();
+    const float* p = nullptr;
+    *n = 0;
+    if (L.parts && L.tensor == x && L.n > 0) { p = L.parts; *n = L.n; ++L.hits; }
+    L.parts = nullptr; L.capacity = 0; L.tensor = nullptr; L.n = 0;
+    return p;
+}
 #ifdef __HIPCC__
 // |.|-maximum of n floats by ONE workgroup of 1024 threads (a weight tensor: ~100 k floats; 16-byte loads, eight in flight per thread);
 // the result is valid in thread 0
@@ -232,7 +247,8 @@ __device__ __forceinline__ float gx_wg1024_amax(const float* __restrict__ w, int
 int gx_kq_weight_amax_launch(const float* w, int n, float* out, hipStream_t s);          // one workgroup (weights are small)
 bool gx_kq_deconv_dgrad_h_eligible(int N, int K, int M, int Hb, int Wb);      // pack 24: all 25 taps, plane-major slots
 int gx_kq_deconv_dgrad_h_launch(const float* dy, const float* wp, float* dx, int N, int K, int M, int Hb, int Wb,
-                                hipStream_t s, float* amax_ws = nullptr, const float* w_amax = nullptr);
+                                hipStream_t s, float* amax_ws = nullptr, const float* w_amax = nullptr,
+                                const float* x_parts = nullptr, int x_nparts = 0);     // x_parts: the input's partial maxima from its producer
 int gx_kq_deconv_fwd_h_launch(const float* in, const float* wp0, const float* wp1, const float* bias, float* out, int N,
                               int K, int M, int Hb, int Wb, float* stats, int* stats_parts, hipStream_t s,
                               float* amax_ws = nullptr, const float* w_amax = nullptr);    // amax_ws != NULL: the fp16 x 3 form (packs 42 / 43)

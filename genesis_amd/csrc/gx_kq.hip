@@ -210,6 +210,7 @@ __device__ __forceinline__ void q_phase_h(f32x16 (&acc)[NCLS][MI][2], const char
 }
 
 struct QGeom {
+    int x_amax_n;         // partial maxima at x_amax (kAmaxParts from gx_kq_amax_launch, or a producer's count)
     int ilv;              // kq_dth_kernel: row parities interleaved along blockIdx.x (grid.z = 1)
     const float* x_amax; const float* w_amax;      // fp16 x 3 form: the input tensor's / the weight tensor's largest magnitude (device)
     int N, K, M;          // images, reduction channels (a multiple of 8), output channels
@@ -281,11 +282,11 @@ __device__ __forceinline__ void q_phase(f32x16 (&acc)[NCLS][MI][2], const float*
 #undef GX_Q_READ
 }
 
-// the input tensor's largest magnitude from gx_kq_amax_launch's kAmaxParts (= 256) partial maxima: four per lane, wave reduction
-__device__ __forceinline__ float q_amax_parts(const float* __restrict__ parts) {
-    static_assert(kAmaxParts == 256, "four per lane");
-    const float* p = parts + 4 * (threadIdx.x & 63);       // (four dword loads: the scratch is only 4-byte aligned in general)
-    float m = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3]));
+// the input tensor's largest magnitude from n partial maxima (gx_kq_amax_launch's kAmaxParts = 256, or one per workgroup of the kernel
+// that produced the tensor: gx_kq_amax_link): strided loads, wave reduction
+__device__ __forceinline__ float q_amax_parts(const float* __restrict__ parts, int n) {
+    float m = 0.f;
+    for (int i = threadIdx.x & 63; i < n; i += 64) m = fmaxf(m, parts[i]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m)));
@@ -363,7 +364,7 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[c][i][j][e] = 0.f;
     int f16_sx = 0;
-    if constexpr (B16 && F16) f16_sx = gx_f16_scale_exp(q_amax_parts(g.x_amax));
+    if constexpr (B16 && F16) f16_sx = gx_f16_scale_exp(q_amax_parts(g.x_amax, g.x_amax_n));
     if constexpr (B16) {
         // ---- the bf16-pipe pipeline: chunks of 16 channels, phases of <= 3 taps
         constexpr int TAPB = QHLay<MODE, F16>::TAPB;
@@ -932,7 +933,7 @@ bool q_plan(int N, int K, int M, int Hb, int Wb, int Hi, int Wi, int Ho, int Wo,
     g->Hb = Hb; g->Wb = Wb; g->Hi = Hi; g->Wi = Wi; g->Ho = Ho; g->Wo = Wo;
     g->lTH = q_ilog2(TH); g->lTW = q_ilog2(TW); g->lG = q_ilog2(G);
     g->tiles_h = Hb / TH; g->tiles_w = Wb / TW;
-    g->ilv = 0; g->x_amax = g->w_amax = nullptr; g->act = 0; g->stats = nullptr; g->stats_parts = 0; g->rt_th = g->rt_tw = 0; g->mask = nullptr; g->mask_act = 0;
+    g->ilv = 0; g->x_amax_n = kAmaxParts; g->x_amax = g->w_amax = nullptr; g->act = 0; g->stats = nullptr; g->stats_parts = 0; g->rt_th = g->rt_tw = 0; g->mask = nullptr; g->mask_act = 0;
     const int CHS = G * (TH + 2) * (TW + 2);
     if (2 * CHS > 4 * 256) return false;
     *nq = 2 * CHS <= 3 * 256 ? 3 : 4;
@@ -1184,7 +1185,7 @@ static bool q_plan_c3h(int N, int K, int M, int H, int W, QGeom* g, int* nq, siz
     g->Hb = H; g->Wb = W; g->Hi = H; g->Wi = W; g->Ho = H; g->Wo = W;
     g->lTH = q_ilog2(TH); g->lTW = q_ilog2(TW); g->lG = q_ilog2(G);
     g->tiles_h = gx_ceil_div(H, TH); g->tiles_w = W / TW;
-    g->ilv = 0; g->x_amax = g->w_amax = nullptr; g->act = 0; g->stats = nullptr; g->stats_parts = 0; g->nfull = 0; g->mask = nullptr; g->mask_act = 0;
+    g->ilv = 0; g->x_amax_n = kAmaxParts; g->x_amax = g->w_amax = nullptr; g->act = 0; g->stats = nullptr; g->stats_parts = 0; g->nfull = 0; g->mask = nullptr; g->mask_act = 0;
     const int CHS = G * (TH + 2) * (TW + 2);
     if (2 * CHS > 4 * 256) return false;
     *nq = 2 * CHS <= 3 * 256 ? 3 : 4;
@@ -1237,7 +1238,7 @@ static bool q_plan_c5h(int N, int K, int M, int H, int W, QGeom* g, size_t* lds_
     g->Hb = H; g->Wb = W; g->Hi = H; g->Wi = W; g->Ho = H; g->Wo = W;
     g->lTH = 4; g->lTW = 4; g->lG = 0;
     g->tiles_h = H / 16; g->tiles_w = W / 16;
-    g->rt_th = g->rt_tw = 0; g->ilv = 0; g->x_amax = g->w_amax = nullptr; g->act = 0; g->stats = nullptr; g->stats_parts = 0; g->mask = nullptr; g->mask_act = 0;
+    g->rt_th = g->rt_tw = 0; g->ilv = 0; g->x_amax_n = kAmaxParts; g->x_amax = g->w_amax = nullptr; g->act = 0; g->stats = nullptr; g->stats_parts = 0; g->mask = nullptr; g->mask_act = 0;
     g->nfull = g->tiles_h * g->tiles_w * N;
     constexpr int NWH = (3 * (QH_TAP_BYTES / 16) + 255) / 256;
     *lds_bytes = (size_t)3 * 2 * (20 * 20) * 16 + (size_t)2 * NWH * 256 * 16;       // exact input planes + two weight buffers
@@ -1283,13 +1284,13 @@ bool gx_kq_deconv_dgrad_h_eligible(int N, int K, int M, int Hb, int Wb) {
     return q_plan(N, K, M, Hb, Wb, 2 * Hb, 2 * Wb, Hb, Wb, &g, &nq, &lds, 9) && qh_lds(g, nq) > 0;
 }
 int gx_kq_deconv_dgrad_h_launch(const float* dy, const float* wp, float* dx, int N, int K, int M, int Hb, int Wb,
-                                hipStream_t s, float* amax_ws, const float* w_amax) {
+                                hipStream_t s, float* amax_ws, const float* w_amax, const float* x_parts, int x_nparts) {
     QGeom g; int nq; size_t lds;
     if (!q_plan(N, K, M, Hb, Wb, 2 * Hb, 2 * Wb, Hb, Wb, &g, &nq, &lds, 9) || qh_lds(g, nq) == 0 || K % 16 != 0) {
         gx_set_error("kq deconv dgrad (bf16 pipe): shape not eligible"); return GX_EINVAL;
     }
     lds = qh_lds(g, nq, amax_ws != nullptr);
-    if (amax_ws) { const int rc = gx_kq_amax_launch(dy, (size_t)N * K * 4 * Hb * Wb, amax_ws, s); if (rc) return rc; }
+    if (amax_ws && !x_parts) { const int rc = gx_kq_amax_launch(dy, (size_t)N * K * 4 * Hb * Wb, amax_ws, s); if (rc) return rc; }
     dim3 grid(1, gx_ceil_div(M, 64));
     g.nfull = q_split_tail(g.tiles_h * g.tiles_w * gx_ceil_div(N, 1 << g.lG), M, &grid.x);
     {
@@ -1297,7 +1298,8 @@ int gx_kq_deconv_dgrad_h_launch(const float* dy, const float* wp, float* dx, int
                   4.0 * ((double)N * K * 4 * Hb * Wb + (double)N * M * Hb * Wb + 25.0 * K * M));
         static bool a3 = false, a4 = false, f3 = false, f4 = false;
         if (amax_ws) {
-            g.x_amax = amax_ws;
+            g.x_amax = x_parts ? x_parts : amax_ws;
+            if (x_parts) g.x_amax_n = x_nparts;
             g.w_amax = w_amax;
             if (nq == 3) { q_set_attr(&kq_dgh_kernel<3, true>, &f3); hipLaunchKernelGGL((kq_dgh_kernel<3, true>), grid, dim3(256), lds, s, dy, wp, dx, g); }
             else { q_set_attr(&kq_dgh_kernel<4, true>, &f4); hipLaunchKernelGGL((kq_dgh_kernel<4, true>), grid, dim3(256), lds, s, dy, wp, dx, g); }

@@ -711,11 +711,12 @@ gn_relu_bwd_stage_kernel(const float* __restrict__ y, const float* __restrict__ 
                          const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                          int C, int H, int W, int groups, int P, View g0, View g1_unused,
                          float* __restrict__ dy, float* __restrict__ part_out, float* __restrict__ wpart,
-                         float* __restrict__ bpart) {
+                         float* __restrict__ bpart, float* __restrict__ amax_parts) {
     // XCD-aware slab map: the groups of one image -- which all read the same projected-gradient source -- on one XCD's L2
     const int slab_id = gx_xcd_tile(blockIdx.x, gridDim.x);
     __shared__ double uab[16 * 2];  // per unit: sum dpre*xhat, sum dpre
     __shared__ double usd[16];      // per unit: sum dy
+    __shared__ float uam[16];       // per unit: max |dy|  (amax_parts: this slab's partial maximum for the consumer's fp16 scale)
     __shared__ float uw[16][8];     // wpart: per unit, sum_p g_out[q][p] * relu(gn(y))[c][p]
     extern __shared__ __attribute__((aligned(16))) float gsl[];   // g0.ptr[n] ([ctot][HW])
     (void)g1_unused;
@@ -809,7 +810,7 @@ gn_relu_bwd_stage_kernel(const float* __restrict__ y, const float* __restrict__ 
     const float k1 = (float)(s1 / m), k2 = (float)(s2 / m);
     // pass 2: the projected gradient once more from LDS; the following 1x1 conv's weight gradient for this channel
     // (its input relu(gn(y)) exists only here) rides on the same LDS reads
-    float sd = 0.f;
+    float sd = 0.f, am = 0.f;
     // opaque copies: otherwise pass 1's pre-activations and masks (4 F + registers) are kept alive for pass 2
     float gm2 = gm, bt2 = bt;
     asm volatile("" : "+v"(gm2), "+v"(bt2));
@@ -820,8 +821,8 @@ gn_relu_bwd_stage_kernel(const float* __restrict__ y, const float* __restrict__ 
     for (int j = 0; j < F; ++j) {
         int jo = j * 64;
         static_assert(CT == 4, "the dependency list below names four accumulators");
-        if (WP) asm volatile("" : "+v"(jo) : "v"(sd), "v"(k1), "v"(wacc[0]), "v"(wacc[1]), "v"(wacc[2]), "v"(wacc[3]));
-        else asm volatile("" : "+v"(jo) : "v"(sd), "v"(k1));
+        if (WP) asm volatile("" : "+v"(jo) : "v"(sd), "v"(am), "v"(k1), "v"(wacc[0]), "v"(wacc[1]), "v"(wacc[2]), "v"(wacc[3]));
+        else asm volatile("" : "+v"(jo) : "v"(sd), "v"(am), "v"(k1));
         f32x4 g = {0.f, 0.f, 0.f, 0.f}, o, a;
         f32x4& xv = xr[KEEP ? j : 0];
         if constexpr (!KEEP) {
@@ -848,11 +849,15 @@ gn_relu_bwd_stage_kernel(const float* __restrict__ y, const float* __restrict__ 
             o[e] = d;
         }
         sd += (o[0] + o[1]) + (o[2] + o[3]);
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
         dst4[jo] = o;
     }
     {
         const double v = gx_wave_sum_d((double)sd);
         if (lane == 0) usd[unit] = v;
+#pragma unroll
+        for (int of = 32; of >= 1; of >>= 1) am = fmaxf(am, __shfl_xor(am, of, 64));
+        if (lane == 0) uam[unit] = am;
     }
     if (WP) {
 #pragma unroll
@@ -876,6 +881,12 @@ gn_relu_bwd_stage_kernel(const float* __restrict__ y, const float* __restrict__ 
         double s = 0.0;
         for (int p = 0; p < P; ++p) s += usd[threadIdx.x * P + p];
         part_out[((size_t)n * C + gidx * cpg + threadIdx.x) * 3 + 2] = (float)s;
+    }
+    if (amax_parts && threadIdx.x == 0) {
+        float r = uam[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) r = fmaxf(r, uam[i]);
+        amax_parts[blockIdx.x] = r;
     }
 }
 
@@ -1016,6 +1027,12 @@ bool launch_bwd_stage(dim3 grid, dim3 block, hipStream_t s, size_t lds, const fl
                       View g0, View g1, float* dy, float* part, float* wpart, float* bpart) {
     static const char* env = getenv("GENESIS_GN_STAGE2");
     if (UPW != 1 || block.x != 1024 || g0.ctot != 4 || (env && env[0] == '0')) return false;
+    // an armed amax link (gx_kq_amax_link): one partial maximum of dy per workgroup for the conv that reads dy next
+    float* amax_parts = nullptr;
+    {
+        GxAmaxLink& L = gx_amax_link();
+        if (L.parts && !L.tensor && (int)grid.x <= L.capacity) { amax_parts = L.parts; L.tensor = dy; L.n = (int)grid.x; }
+    }
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_relu_bwd_stage_kernel<F, 4, true, true>),
@@ -1034,7 +1051,7 @@ bool launch_bwd_stage(dim3 grid, dim3 block, hipStream_t s, size_t lds, const fl
     const bool keep = F < 8 || (keep_env && keep_env[0] == '1');
 #define GX_STAGE_LAUNCH(WP_, KEEP_)                                                                                          \
     hipLaunchKernelGGL((gn_relu_bwd_stage_kernel<F, 4, WP_, KEEP_>), grid, block, lds, s, y, gamma, beta, mean, rstd, C, H, W, \
-                       groups, P, g0, g1, dy, part, wpart, bpart)
+                       groups, P, g0, g1, dy, part, wpart, bpart, amax_parts)
     if (wpart) { if (keep) GX_STAGE_LAUNCH(true, true); else GX_STAGE_LAUNCH(true, false); }
     else { if (keep) GX_STAGE_LAUNCH(false, true); else GX_STAGE_LAUNCH(false, false); }
 #undef GX_STAGE_LAUNCH

@@ -644,6 +644,7 @@ class DecoderFn(torch.autograd.Function):
             # norm backward, the conv's data gradient (formed on load) and its weight gradient behind ONE pass over y
             _, y3, mean3, rstd3 = ctx.saved[3]
             o3 = (_gout(params[14]), _gout(params[15]), _gout(params[13]))
+            link = hip.amax_link(g.device)       # dy's partial maxima for the data gradient below (DESIGN finding 40 (a)); noqa: F841
             head = hip.conv1x1_gn_bwd_fused(y3, params[14], params[15], mean3, rstd3, GROUPS, g, ow2, ob, None, True,
                                             out_gn=o3, out_conv=(gow, gob, None))
             if head is None:

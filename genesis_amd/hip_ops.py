@@ -190,6 +190,20 @@ def deconv5x5s2_fwd(x, w, bias):
     return y
 
 
+AMAX_LINK = os.environ.get('GENESIS_AMAX_LINK', '1') != '0'
+
+
+def amax_link(device, capacity=4096):
+    """gx_kq_amax_link: arms the one-shot hand-over of a tensor's partial maxima from the kernel that writes it (the decoder head's
+    GroupNorm backward) to the fp16 x 3 conv that reads it next (gx_deconv5x5s2_dgrad) -- no second pass over a 235 MB gradient.
+    Returns the scratch buffer (keep it alive until the consumer has been enqueued)."""
+    if not AMAX_LINK:
+        return None
+    buf = torch.empty(capacity, dtype=F32, device=device)
+    _lib.call('gx_kq_amax_link', _p(buf), capacity)
+    return buf
+
+
 def deconv5x5s2_dgrad(dy, w, cin_out=None):
     _chk(dy, 'deconv_dgrad.dy'); _chk(w, 'deconv_dgrad.w')
     N, Cout, H2, W2 = dy.shape

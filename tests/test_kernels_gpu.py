@@ -1704,3 +1704,47 @@ def test_fp16x3_conv5x5_stride1(N, K, M, S, dist):
           % (dist, N, K, M, S, err[1][0], err[1][1], err[2][0], err[2][1], c32[0], c32[1]))
     for i in (0, 1):
         assert err[2][i] <= 1.5 * max(err[1][i], c32[i]) + 1e-7, (err, c32)
+
+
+def test_amax_link_hands_the_head_gradients_maximum_to_the_data_gradient():
+    """gx_kq_amax_link: the decoder head's GroupNorm backward (gx_gn_relu_bwd_proj's two-workgroups-per-CU kernel) writes one partial
+    maximum of the dy it stores per workgroup; the transposed conv's data gradient that reads dy next (fp16 x 3 form) reduces those
+    instead of launching its own pass over dy.  The maximum is the same number either way: the data gradient is bit-identical with
+    and without the link, the hand-over is counted, an unrelated tensor does not take it, and it is one-shot."""
+    from genesis_amd import _lib, hip_ops as hip
+    N, C, S, Co = 56, 64, 64, 4
+    y = rnd(N, C, S, S, seed=1, scale=2.0) + 0.3
+    gamma, beta = 1 + 0.3 * rnd(C, seed=2), 0.2 * rnd(C, seed=3)
+    g_out = rnd(N, Co, S, S, seed=4)
+    ow = rnd(Co, C, seed=5, scale=0.2)
+    w = rnd(C, C, 5, 5, seed=6, scale=0.05)
+    yd, gd, bd, god, owd, wd = (t.to(DEV) for t in (y, gamma, beta, g_out, ow, w))
+    out = torch.empty_like(yd)
+    mean, rstd = hip.gn_relu_fwd(yd, gd, bd, 8, 1e-5, (out, 0, 0))
+
+    def run(link):
+        h0 = int(_lib.query('gx_kq_amax_link_hits'))
+        buf = hip.amax_link(yd.device) if link else None
+        dy = hip.gn_relu_bwd_proj(yd, gd, bd, mean, rstd, 8, god, owd, True)[0]
+        dx = hip.deconv5x5s2_dgrad(dy, wd)
+        del buf
+        return dy, dx, int(_lib.query('gx_kq_amax_link_hits')) - h0
+    try:
+        _lib.call('gx_kq_precision', 2)
+        dy0, dx0, hits0 = run(False)
+        dy1, dx1, hits1 = run(True)
+        assert hits0 == 0 and hits1 == 1, (hits0, hits1)
+        assert torch.equal(dy0, dy1) and torch.equal(dx0, dx1)
+        # armed, but the conv's input is another tensor: not taken, and gone afterwards
+        h0 = int(_lib.query('gx_kq_amax_link_hits'))
+        buf = hip.amax_link(yd.device)
+        dy2 = hip.gn_relu_bwd_proj(yd, gd, bd, mean, rstd, 8, god, owd, True)[0]
+        other = dy2.clone()
+        dx2 = hip.deconv5x5s2_dgrad(other, wd)
+        dx3 = hip.deconv5x5s2_dgrad(dy2, wd)
+        assert int(_lib.query('gx_kq_amax_link_hits')) == h0
+        assert torch.equal(dx2, dx0) and torch.equal(dx3, dx0)
+        del buf
+    finally:
+        _lib.call('gx_kq_precision', -1)
+        _lib.call('gx_kq_amax_link', None, 0)
