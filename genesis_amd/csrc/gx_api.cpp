@@ -26,12 +26,13 @@ GxCtxFlags g_ctx_flags[kGxMaxCtx] = {};
 struct CtxInit { CtxInit() { for (int i = 0; i < kGxMaxCtx; ++i) g_ctx_flags[i] = GxCtxFlags{false, false, -1, -1}; } } g_ctx_init;
 }  // namespace
 int gx_cur_ctx(void) { return t_ctx; }
-namespace { thread_local GxAmaxLink t_amax_link = {nullptr, 0, nullptr, 0, 0}; }
+namespace { thread_local GxAmaxLink t_amax_link = {nullptr, 0, 0, nullptr, 0, 0}; }
 GxAmaxLink& gx_amax_link(void) { return t_amax_link; }
-extern "C" int gx_kq_amax_link(float* parts, int capacity) {
+extern "C" int gx_kq_amax_link(float* parts, int capacity, size_t numel) {
     GxAmaxLink& L = t_amax_link;
-    L.parts = (parts && capacity > 0) ? parts : nullptr;
+    L.parts = (parts && capacity > 0 && numel > 0) ? parts : nullptr;
     L.capacity = L.parts ? capacity : 0;
+    L.numel = L.parts ? numel : 0;
     L.tensor = nullptr; L.n = 0;
     return GX_OK;
 }

@@ -202,17 +202,18 @@ __host__ __device__ __forceinline__ constexpr size_t gx_kq_amax_ws_floats() { re
 int gx_kq_amax_launch(const float* x, size_t n, float* ws, hipStream_t s);
 // producer -> consumer hand-over of those partial maxima (gx_kq_amax_link, include/genesis_hip.h): armed by the caller with a scratch
 // buffer; the next producer that can (the decoder head's GroupNorm backward) writes one partial maximum per workgroup of the tensor it
-// stores and records the tensor's address; the next fp16 x 3 conv whose INPUT is that address reads them instead of making its own pass.
+// stores -- only a launch that covers the WHOLE tensor (numel elements: a chunked producer does not qualify) -- and records the tensor's
+// address; the next fp16 x 3 conv whose INPUT is that address (and size) reads them instead of making its own pass.
 // One-shot, per thread; any fp16 x 3 conv call clears it.
-struct GxAmaxLink { float* parts; int capacity; const float* tensor; int n; int hits; };
+struct GxAmaxLink { float* parts; int capacity; size_t numel; const float* tensor; int n; int hits; };      // numel: the WHOLE tensor's
 GxAmaxLink& gx_amax_link(void);          // (gx_api.cpp)
 // consumer side: partials of `x` if the armed link holds them (then *n > 0), clearing the link either way
-inline const float* gx_amax_link_take(const float* x, int* n) {
+inline const float* gx_amax_link_take(const float* x, size_t numel, int* n) {
     GxAmaxLink& L = gx_amax_link();
     const float* p = nullptr;
     *n = 0;
-    if (L.parts && L.tensor == x && L.n > 0) { p = L.parts; *n = L.n; ++L.hits; }
-    L.parts = nullptr; L.capacity = 0; L.tensor = nullptr; L.n = 0;
+    if (L.parts && x && L.tensor == x && L.numel == numel && L.n > 0) { p = L.parts; *n = L.n; ++L.hits; }
+    L.parts = nullptr; L.capacity = 0; L.numel = 0; L.tensor = nullptr; L.n = 0;
     return p;
 }
 #ifdef __HIPCC__
@@ -251,7 +252,8 @@ int gx_kq_deconv_dgrad_h_launch(const float* dy, const float* wp, float* dx, int
                                 const float* x_parts = nullptr, int x_nparts = 0);     // x_parts: the input's partial maxima from its producer
 int gx_kq_deconv_fwd_h_launch(const float* in, const float* wp0, const float* wp1, const float* bias, float* out, int N,
                               int K, int M, int Hb, int Wb, float* stats, int* stats_parts, hipStream_t s,
-                              float* amax_ws = nullptr, const float* w_amax = nullptr);    // amax_ws != NULL: the fp16 x 3 form (packs 42 / 43)
+                              float* amax_ws = nullptr, const float* w_amax = nullptr,    // amax_ws != NULL: the fp16 x 3 form (packs 42 / 43)
+                              const float* x_parts = nullptr, int x_nparts = 0);
 // 32-bit word of element (m, k even, k + 1) of piece `piece` of tap t
 // ... kinds 20 / 21 (conv3x3 forward / data gradient of <= 32-output-channel layers): 32 output channels per channel tile
 // (NP: pieces per value -- 3 bf16 ones, or 2 fp16 ones in the packs 40 - 48 of the fp16 x 3 form)

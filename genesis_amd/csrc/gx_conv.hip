@@ -2361,7 +2361,7 @@ static int conv3x3_fwd_impl(const float* x, const float* w, const float* bias, i
         rc = launch_pack(w, wp, 20 + f16, Cout, Cin, 9, gx_round_up(Cin, 16), Mpad, s, &wpu);
         if (rc) return rc;
         float* amax_ws = f16 ? (float*)((char*)ws + gx_conv3x3_ws_bytes(N, Cin, Cout, H, W)) - gx_kq_amax_ws_floats() : nullptr;
-        if (f16) { int unused_n; (void)gx_amax_link_take(nullptr, &unused_n); }       // (a pending amax link is not for this call)
+        if (f16) { int unused_n; (void)gx_amax_link_take(nullptr, 0, &unused_n); }       // (a pending amax link is not for this call)
         rc = gx_kq_c3h_launch(x, wpu, bias, act, y, N, Cin, Cout, H, W, s, nullptr, 0, amax_ws,
                               f16 ? (const float*)((const char*)wpu + gx_kq_h_amax_off(gx_round_up(Cin, 16), Mpad, 9)) : nullptr);
         if (rc) return rc;
@@ -2439,7 +2439,7 @@ static int conv3x3_dgrad_impl(const float* dy, const float* w, float* dx, int N,
         rc = launch_pack(w, wp, 21 + f16, Cout, Cin, 9, gx_round_up(Cout, 16), Mpad, s, &wpu);
         if (rc) return rc;
         float* amax_ws = f16 ? (float*)((char*)ws + gx_conv3x3_ws_bytes(N, Cin, Cout, H, W)) - gx_kq_amax_ws_floats() : nullptr;
-        if (f16) { int unused_n; (void)gx_amax_link_take(nullptr, &unused_n); }       // (a pending amax link is not for this call)
+        if (f16) { int unused_n; (void)gx_amax_link_take(nullptr, 0, &unused_n); }       // (a pending amax link is not for this call)
         return gx_kq_c3h_launch(dy, wpu, nullptr, 0, dx, N, Cout, Cin, H, W, s, nullptr, 0, amax_ws,
                                 f16 ? (const float*)((const char*)wpu + gx_kq_h_amax_off(gx_round_up(Cout, 16), Mpad, 9)) : nullptr);
     }
@@ -2492,7 +2492,7 @@ int gx_conv3x3_dgrad_act(const float* dy, const float* w, const float* xout, int
     rc = launch_pack(w, (float*)ws, 21 + f16, Cout, Cin, 9, gx_round_up(Cout, 16), gx_round_up(Cin, 64), s, &wpu);
     if (rc) return rc;
     float* amax_ws = f16 ? (float*)((char*)ws + gx_conv3x3_ws_bytes(N, Cin, Cout, H, W)) - gx_kq_amax_ws_floats() : nullptr;
-    if (f16) { int unused_n; (void)gx_amax_link_take(nullptr, &unused_n); }       // (a pending amax link is not for this call)
+    if (f16) { int unused_n; (void)gx_amax_link_take(nullptr, 0, &unused_n); }       // (a pending amax link is not for this call)
     rc = gx_kq_c3h_launch(dy, wpu, nullptr, 0, dxa, N, Cout, Cin, H, W, s, xout, act, amax_ws,
                           f16 ? (const float*)((const char*)wpu + gx_kq_h_amax_off(gx_round_up(Cout, 16), gx_round_up(Cin, 64), 9)) : nullptr);
     if (rc || !dbias) return rc;
@@ -2693,7 +2693,7 @@ int gx_conv5x5s1(const float* in, const float* w, float* out, int N, int K, int 
                   : launch_pack(w, wp, 27 + f16, M, K, 25, gx_round_up(K, 16), Mpad, s, &wpu);
         if (rc) return rc;
         float* amax_ws = f16 ? (float*)((char*)ws + gx_conv5x5s1_ws_bytes(N, K, M, H, W)) - gx_kq_amax_ws_floats() : nullptr;
-        if (f16) { int unused_n; (void)gx_amax_link_take(nullptr, &unused_n); }       // (a pending amax link is not for this call)
+        if (f16) { int unused_n; (void)gx_amax_link_take(nullptr, 0, &unused_n); }       // (a pending amax link is not for this call)
         return gx_kq_c5h_launch(in, wpu, out, N, K, M, H, W, s, amax_ws,
                                 f16 ? (const float*)((const char*)wpu + gx_kq_h_amax_off(gx_round_up(K, 16), Mpad, 25)) : nullptr);
     }
@@ -2844,9 +2844,11 @@ static int deconv_fwd_impl(const float* x, const float* w, const float* bias, fl
         rc = launch_pack(w, wh1, 23 + f16, Cout, Cin, 10, Cin, Mpad, s, &wpu1);
         if (rc) return rc;
         float* amax_ws = f16 ? (float*)((char*)ws + gx_deconv5x5s2_ws_bytes(N, Cin, Cout, Hin, Win)) - gx_kq_amax_ws_floats() : nullptr;
-        if (f16) { int unused_n; (void)gx_amax_link_take(nullptr, &unused_n); }       // (a pending amax link is not for this call)
+        int xn = 0;
+        const float* xparts = f16 ? gx_amax_link_take(x, (size_t)N * Cin * Hin * Win, &xn) : nullptr;      // x's partial maxima from the kernel that wrote it
         rc = gx_kq_deconv_fwd_h_launch(x, wpu0, wpu1, bias, y, N, Cin, Cout, Hin, Win, stats, stats_parts_out, s, amax_ws,
-                                       f16 ? (const float*)((const char*)wpu0 + gx_kq_h_amax_off(Cin, Mpad, 15)) : nullptr);
+                                       f16 ? (const float*)((const char*)wpu0 + gx_kq_h_amax_off(Cin, Mpad, 15)) : nullptr,
+                                       xparts, xn);
         if (rc) return rc;
         if (parts_out) { *parts_out = y; *nsplit_out = 1; }
         return GX_OK;
@@ -2938,7 +2940,7 @@ int gx_deconv5x5s2_dgrad(const float* dy, const float* w, float* dx, int N, int 
         if (rc) return rc;
         float* amax_ws = f16 ? (float*)((char*)ws + gx_deconv5x5s2_ws_bytes(N, Cin, Cout, Hin, Win)) - gx_kq_amax_ws_floats() : nullptr;
         int xn = 0;
-        const float* xparts = f16 ? gx_amax_link_take(dy, &xn) : nullptr;     // dy's partial maxima from the kernel that wrote it
+        const float* xparts = f16 ? gx_amax_link_take(dy, (size_t)N * Cout * 4 * Hin * Win, &xn) : nullptr;     // dy's partial maxima from the kernel that wrote it
         return gx_kq_deconv_dgrad_h_launch(dy, wpu, dx, N, Cout, Cin_out, Hin, Win, s, amax_ws,
                                            f16 ? (const float*)((const char*)wpu + gx_kq_h_amax_off(Cout, Mpad, 25)) : nullptr,
                                            xparts, xn);

@@ -1128,7 +1128,7 @@ bool gx_kq_deconv_h_eligible(int N, int K, int M, int Hb, int Wb) {
 }
 int gx_kq_deconv_fwd_h_launch(const float* in, const float* wp0, const float* wp1, const float* bias, float* out, int N,
                               int K, int M, int Hb, int Wb, float* stats, int* stats_parts, hipStream_t s, float* amax_ws,
-                              const float* w_amax) {
+                              const float* w_amax, const float* x_parts, int x_nparts) {
     QGeom g; int nq; size_t lds;
     if (!q_plan(N, K, M, Hb, Wb, Hb, Wb, 2 * Hb, 2 * Wb, &g, &nq, &lds, 5) || qh_lds(g, nq) == 0 || K % 16 != 0) {
         gx_set_error("kq deconv fwd (bf16 pipe): shape not eligible"); return GX_EINVAL;
@@ -1141,7 +1141,7 @@ int gx_kq_deconv_fwd_h_launch(const float* in, const float* wp0, const float* wp
         g.stats_parts = g.tiles_h * g.tiles_w * 2;
         if (stats_parts) *stats_parts = g.stats_parts;
     }
-    if (amax_ws) { const int rc = gx_kq_amax_launch(in, (size_t)N * K * Hb * Wb, amax_ws, s); if (rc) return rc; }
+    if (amax_ws && !x_parts) { const int rc = gx_kq_amax_launch(in, (size_t)N * K * Hb * Wb, amax_ws, s); if (rc) return rc; }
     dim3 grid(1, gx_ceil_div(M, 64), 2);
     g.nfull = q_split_tail(g.tiles_h * g.tiles_w * gx_ceil_div(N, 1 << g.lG), M, &grid.x);
     static const char* ilv_env = getenv("GENESIS_KQ_DTH_INTERLEAVE");       // 0: all 15-tap workgroups, then all 10-tap ones (grid.z)
@@ -1151,7 +1151,8 @@ int gx_kq_deconv_fwd_h_launch(const float* in, const float* wp0, const float* wp
                   4.0 * ((double)N * K * Hb * Wb + (double)N * M * 4 * Hb * Wb + 25.0 * K * M));
         static bool a[8] = {false, false, false, false, false, false, false, false};
         if (amax_ws) {          // fp16 x 3: the input's amax (one small launch ahead of this one, outside its profiling record)
-            g.x_amax = amax_ws;
+            g.x_amax = x_parts ? x_parts : amax_ws;
+            if (x_parts) g.x_amax_n = x_nparts;
             g.w_amax = w_amax;
             if (nq == 3 && st) { q_set_attr(&kq_dth_kernel<3, true, true>, &a[4]); hipLaunchKernelGGL((kq_dth_kernel<3, true, true>), grid, dim3(256), lds, s, in, wp0, wp1, bias, out, g); }
             else if (nq == 3) { q_set_attr(&kq_dth_kernel<3, false, true>, &a[5]); hipLaunchKernelGGL((kq_dth_kernel<3, false, true>), grid, dim3(256), lds, s, in, wp0, wp1, bias, out, g); }

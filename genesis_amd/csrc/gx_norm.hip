@@ -439,8 +439,9 @@ template <int F, int UPW>
 __global__ void __launch_bounds__(1024)
 gn_relu_fwd_reg_kernel(const InSrc src, const float* __restrict__ gamma, const float* __restrict__ beta,
                        int C, int H, int W, int groups, int P, float eps, View d0, View d1,
-                       float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+                       float* __restrict__ mean_out, float* __restrict__ rstd_out, float* __restrict__ amax_parts) {
     __shared__ double red[16 * 2 + 2];
+    __shared__ float amr[16];      // amax_parts (gx_kq_amax_link): per wave, the largest value stored
     const int n = blockIdx.x / groups, gidx = blockIdx.x % groups;
     const int cpg = C / groups, HW = H * W;
     const int m = cpg * HW;
@@ -475,6 +476,7 @@ gn_relu_fwd_reg_kernel(const InSrc src, const float* __restrict__ gamma, const f
     if (threadIdx.x == 0) { mean_out[blockIdx.x] = meanf; rstd_out[blockIdx.x] = rstdf; }
     if (!d0.ptr) return;                   // statistics only
     const int lW = __ffs(W) - 1;
+    float am = 0.f;
 #pragma unroll
     for (int u = 0; u < UPW; ++u) {
         const int unit = wave * UPW + u;
@@ -493,6 +495,18 @@ gn_relu_fwd_reg_kernel(const InSrc src, const float* __restrict__ gamma, const f
             }
             store_view4(d0, n, c, r, col, H, W, o);
             if (d1.ptr) store_view4(d1, n, c, r, col, H, W, o);
+            am = fmaxf(fmaxf(am, fmaxf(o[0], o[1])), fmaxf(o[2], o[3]));      // (o >= 0)
+        }
+    }
+    if (amax_parts) {              // (uniform) one partial maximum of the stored activation per workgroup
+#pragma unroll
+        for (int of = 32; of >= 1; of >>= 1) am = fmaxf(am, __shfl_xor(am, of, 64));
+        if (lane == 0) amr[wave] = am;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float r = 0.f;
+            for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r = fmaxf(r, amr[i]);
+            amax_parts[blockIdx.x] = r;
         }
     }
 }
@@ -512,11 +526,12 @@ gn_relu_bwd_reg_kernel(const float* __restrict__ y, const float* __restrict__ ga
                        const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                        int C, int H, int W, int groups, int P, View g0, View g1,
                        float* __restrict__ dy, float* __restrict__ part_out, float* __restrict__ wpart,
-                       float* __restrict__ bpart) {
+                       float* __restrict__ bpart, float* __restrict__ amax_parts) {
     // XCD-aware slab map: the groups of one image -- which all read the same projected-gradient source -- on one XCD's L2
     const int slab_id = gx_xcd_tile(blockIdx.x, gridDim.x);
     __shared__ double uab[32 * 2];  // per unit: sum dpre*xhat, sum dpre
     __shared__ double usd[32];      // per unit: sum dy
+    __shared__ float uam[32];       // per unit: max |dy|  (amax_parts, gx_kq_amax_link)
     __shared__ float uw[32][8];     // STAGE + wpart: per unit, sum_p g_out[q][p] * relu(gn(y))[c][p]
     extern __shared__ __attribute__((aligned(16))) float gsl[];   // stage != 0: g0.ptr[n] ([ctot][HW]) of a mode-3 view
     const int n = slab_id / groups, gidx = slab_id % groups;
@@ -673,6 +688,7 @@ gn_relu_bwd_reg_kernel(const float* __restrict__ y, const float* __restrict__ ga
         const int cl = unit / P, part = unit - cl * P;
         const float gm = gamma[gidx * cpg + cl];
         double sd = 0.0;
+        float am = 0.f;
 #pragma unroll
         for (int j = 0; j < F; ++j) {
             f32x4 o;
@@ -682,16 +698,24 @@ gn_relu_bwd_reg_kernel(const float* __restrict__ y, const float* __restrict__ ga
                 o[e] = d;
                 sd += d;
             }
+            am = fmaxf(fmaxf(am, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
             dslab4[cl * (HW >> 2) + part * q4 + j * 64 + lane] = o;
         }
         sd = gx_wave_sum_d(sd);
-        if (lane == 0) usd[unit] = sd;
+#pragma unroll
+        for (int of = 32; of >= 1; of >>= 1) am = fmaxf(am, __shfl_xor(am, of, 64));
+        if (lane == 0) { usd[unit] = sd; uam[unit] = am; }
     }
     __syncthreads();
     if ((int)threadIdx.x < cpg) {
         double s = 0.0;
         for (int p = 0; p < P; ++p) s += usd[threadIdx.x * P + p];
         part_out[((size_t)n * C + gidx * cpg + threadIdx.x) * 3 + 2] = (float)s;
+    }
+    if (amax_parts && threadIdx.x == 0) {
+        float r = 0.f;
+        for (int i = 0; i < (int)(blockDim.x >> 6) * UPW; ++i) r = fmaxf(r, uam[i]);
+        amax_parts[blockIdx.x] = r;
     }
     (void)U;
 }
@@ -1016,9 +1040,20 @@ int small_threads(int cpg, int H, int W) {
     return gx_round_up(m / 4, 64);
 }
 
-template <int F, int UPW, typename... Args>
-void launch_fwd_reg(dim3 grid, dim3 block, hipStream_t s, Args... args) {
-    hipLaunchKernelGGL((gn_relu_fwd_reg_kernel<F, UPW>), grid, block, 0, s, args...);
+// an armed amax link (gx_kq_amax_link) is served when the kernel's first destination is a whole plain tensor (no channel slice, no
+// resampling): one partial maximum of the stored activation per workgroup for the conv that reads it next
+inline float* gn_take_link_out(const float* tensor, int ctot, int c0, int mode, int C, unsigned nwg, size_t covered) {
+    GxAmaxLink& L = gx_amax_link();
+    if (!L.parts || L.tensor || !tensor || c0 != 0 || mode != 0 || ctot != C || (int)nwg > L.capacity || covered != L.numel) return nullptr;
+    L.tensor = tensor; L.n = (int)nwg;
+    return L.parts;
+}
+template <int F, int UPW>
+void launch_fwd_reg(dim3 grid, dim3 block, hipStream_t s, const InSrc src, const float* gamma, const float* beta, int C, int H,
+                    int W, int groups, int P, float eps, View d0, View d1, float* mean, float* rstd) {
+    float* ap = d1.ptr ? nullptr : gn_take_link_out(d0.ptr, d0.ctot, d0.c0, d0.mode, C, grid.x, (size_t)(grid.x / groups) * C * H * W);
+    hipLaunchKernelGGL((gn_relu_fwd_reg_kernel<F, UPW>), grid, block, 0, s, src, gamma, beta, C, H, W, groups, P, eps, d0, d1,
+                       mean, rstd, ap);
 }
 // the two-workgroups-per-CU STAGE kernel serves one unit per wave, 1024 threads and a 4-channel 1x1 conv (RGB + mask logit)
 template <int F, int UPW>
@@ -1028,11 +1063,7 @@ bool launch_bwd_stage(dim3 grid, dim3 block, hipStream_t s, size_t lds, const fl
     static const char* env = getenv("GENESIS_GN_STAGE2");
     if (UPW != 1 || block.x != 1024 || g0.ctot != 4 || (env && env[0] == '0')) return false;
     // an armed amax link (gx_kq_amax_link): one partial maximum of dy per workgroup for the conv that reads dy next
-    float* amax_parts = nullptr;
-    {
-        GxAmaxLink& L = gx_amax_link();
-        if (L.parts && !L.tensor && (int)grid.x <= L.capacity) { amax_parts = L.parts; L.tensor = dy; L.n = (int)grid.x; }
-    }
+    float* amax_parts = gn_take_link_out(dy, C, 0, 0, C, grid.x, (size_t)(grid.x / groups) * C * H * W);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_relu_bwd_stage_kernel<F, 4, true, true>),
@@ -1058,10 +1089,14 @@ bool launch_bwd_stage(dim3 grid, dim3 block, hipStream_t s, size_t lds, const fl
     return true;
 }
 
-template <int F, int UPW, typename... Args>
-void launch_bwd_reg(dim3 grid, dim3 block, hipStream_t s, size_t lds, Args... args) {
+template <int F, int UPW>
+void launch_bwd_reg(dim3 grid, dim3 block, hipStream_t s, size_t lds, const float* y, const float* gamma, const float* beta,
+                    const float* mean, const float* rstd, int C, int H, int W, int groups, int P, View g0, View g1, float* dy,
+                    float* part, float* wpart, float* bpart) {
     if (!lds) {
-        hipLaunchKernelGGL((gn_relu_bwd_reg_kernel<F, UPW, false>), grid, block, 0, s, args...);
+        float* ap = gn_take_link_out(dy, C, 0, 0, C, grid.x, (size_t)(grid.x / groups) * C * H * W);      // (an armed amax link: dy's partial maxima for its consumer)
+        hipLaunchKernelGGL((gn_relu_bwd_reg_kernel<F, UPW, false>), grid, block, 0, s, y, gamma, beta, mean, rstd, C, H, W, groups,
+                           P, g0, g1, dy, part, wpart, bpart, ap);
         return;
     }
     static bool attr_set = false;
@@ -1070,8 +1105,11 @@ void launch_bwd_reg(dim3 grid, dim3 block, hipStream_t s, size_t lds, Args... ar
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }
-    if (launch_bwd_stage<F, UPW>(grid, block, s, lds, args...)) return;
-    hipLaunchKernelGGL((gn_relu_bwd_reg_kernel<F, UPW, true>), grid, block, lds, s, args...);
+    if (launch_bwd_stage<F, UPW>(grid, block, s, lds, y, gamma, beta, mean, rstd, C, H, W, groups, P, g0, g1, dy, part, wpart, bpart))
+        return;
+    float* ap = gn_take_link_out(dy, C, 0, 0, C, grid.x, (size_t)(grid.x / groups) * C * H * W);
+    hipLaunchKernelGGL((gn_relu_bwd_reg_kernel<F, UPW, true>), grid, block, lds, s, y, gamma, beta, mean, rstd, C, H, W, groups, P,
+                       g0, g1, dy, part, wpart, bpart, ap);
 }
 
 #define GX_GN_REG_DISPATCH(LAUNCH, pl, ...)                                      \

@@ -621,7 +621,8 @@ class DecoderFn(torch.autograd.Function):
                 h = a
                 continue
             a = torch.empty(N, w.shape[1], 2 * h.shape[2], 2 * h.shape[3], device=h.device)
-            y, mean, rstd = hip.deconv5x5s2_gn_relu_fwd(h, w, b, gamma, beta, GROUPS, EPS, (a, 0, 0))
+            # (the activation's partial maxima go to the next layer's transposed conv: gx_kq_amax_link, DESIGN finding 40)
+            y, mean, rstd = hip.deconv5x5s2_gn_relu_fwd(h, w, b, gamma, beta, GROUPS, EPS, (a, 0, 0), link_out=l < 3)
             saved.append((h, y, mean, rstd))
             h = a
         if not ctx.fused_head:
@@ -644,7 +645,7 @@ class DecoderFn(torch.autograd.Function):
             # norm backward, the conv's data gradient (formed on load) and its weight gradient behind ONE pass over y
             _, y3, mean3, rstd3 = ctx.saved[3]
             o3 = (_gout(params[14]), _gout(params[15]), _gout(params[13]))
-            link = hip.amax_link(g.device)       # dy's partial maxima for the data gradient below (DESIGN finding 40 (a)); noqa: F841
+            link = hip.amax_link(g.device, ctx.saved[3][1].numel())       # dy's partial maxima for the data gradient below (DESIGN finding 40 (a)); noqa: F841
             head = hip.conv1x1_gn_bwd_fused(y3, params[14], params[15], mean3, rstd3, GROUPS, g, ow2, ob, None, True,
                                             out_gn=o3, out_conv=(gow, gob, None))
             if head is None:
@@ -667,6 +668,7 @@ class DecoderFn(torch.autograd.Function):
                 dy, (dgamma, dbeta, dbias) = head[0], head[1]
             else:
                 ow, obias, og, ob = _gout(w), _gout(b), _gout(gamma), _gout(beta)
+                link = hip.amax_link(da.device, y.numel()) if l > 0 and hip.AMAX_LINK_REG else None     # dy's partial maxima for this layer's data gradient; noqa: F841
                 dy, dgamma, dbeta, dbias = hip.gn_relu_bwd(y, gamma, beta, mean, rstd, GROUPS, (da, 0, 0), None, True,
                                                            out=(og, ob, obias))
             if l == 0 and ctx.bcast:

@@ -191,16 +191,23 @@ def deconv5x5s2_fwd(x, w, bias):
 
 
 AMAX_LINK = os.environ.get('GENESIS_AMAX_LINK', '1') != '0'
+_LINK_KEEP = []
+AMAX_LINK_REG = os.environ.get('GENESIS_AMAX_LINK_REG', '1') != '0'     # 0: only the decoder head's gradient is handed over
 
 
-def amax_link(device, capacity=4096):
+def amax_link(device, numel, capacity=4096):
     """gx_kq_amax_link: arms the one-shot hand-over of a tensor's partial maxima from the kernel that writes it (the decoder head's
     GroupNorm backward) to the fp16 x 3 conv that reads it next (gx_deconv5x5s2_dgrad) -- no second pass over a 235 MB gradient.
+    numel: the elements of that tensor (a producer launch that covers only part of it leaves the link alone).
     Returns the scratch buffer (keep it alive until the consumer has been enqueued)."""
     if not AMAX_LINK:
         return None
     buf = torch.empty(capacity, dtype=F32, device=device)
-    _lib.call('gx_kq_amax_link', _p(buf), capacity)
+    # the consumer is enqueued by a LATER call: the scratch must not go back to the allocator (and be handed to the tensors of the
+    # calls in between) before that -- the last few links' buffers are kept alive here, whatever the caller does with its reference
+    _LINK_KEEP.append(buf)
+    del _LINK_KEEP[:-4]
+    _lib.call('gx_kq_amax_link', _p(buf), capacity, int(numel))
     return buf
 
 
@@ -300,7 +307,8 @@ def gn_relu_fwd(y, gamma, beta, groups, eps, dst0, dst1=None):
 FUSE_SPLITK_INTO_GN = os.environ.get('GENESIS_FUSE_SPLITK_GN', '1') == '1'
 
 
-def _conv_gn(kind, x, w, bias, gamma, beta, groups, eps, dst0, dst1):
+def _conv_gn(kind, x, w, bias, gamma, beta, groups, eps, dst0, dst1, link_out=False):
+    # link_out: arm gx_kq_amax_link for the normalised output (dst0) -- its next reader is an fp16 x 3 conv
     if not FUSE_SPLITK_INTO_GN:
         y = conv3x3_fwd(x, w) if kind == 'conv3x3' else deconv5x5s2_fwd(x, w, bias)
         mean, rstd = gn_relu_fwd(y, gamma, beta, groups, eps, dst0, dst1)
@@ -320,6 +328,7 @@ def _conv_gn(kind, x, w, bias, gamma, beta, groups, eps, dst0, dst1):
     mean = torch.empty(N * groups, dtype=F32, device=x.device)
     rstd = torch.empty(N * groups, dtype=F32, device=x.device)
     need_sum = nsplit.value > 1 or bias is not None
+    link = amax_link(x.device, N * Cout * Ho * Wo) if link_out and AMAX_LINK_REG else None      # noqa: F841  (alive until the launch below is enqueued)
     _lib.call('gx_gn_relu_fwd_parts', parts, nsplit.value, stride.value, _p(bias), _p(y) if need_sum else None,
               _p(gamma), _p(beta), N, Cout, Ho, Wo, groups, float(eps),
               *(_view_args(dst0, 'gn.dst0') + _view_args(dst1, 'gn.dst1')), _p(mean), _p(rstd), _stream())
@@ -335,12 +344,12 @@ def conv3x3_gn_relu_fwd(x, w, gamma, beta, groups, eps, dst0, dst1=None):
     return _conv_gn('conv3x3', x, w, None, gamma, beta, groups, eps, dst0, dst1)
 
 
-def deconv5x5s2_gn_relu_fwd(x, w, bias, gamma, beta, groups, eps, dst0, dst1=None):
+def deconv5x5s2_gn_relu_fwd(x, w, bias, gamma, beta, groups, eps, dst0, dst1=None, link_out=False):
     """ConvTranspose2d(k5,s2,p2,op1) + bias -> GroupNorm+ReLU (models/genesisv2_config.py:90-98)."""
     _chk(x, 'deconv_gn.x'); _chk(w, 'deconv_gn.w'); _chk(bias, 'deconv_gn.bias')
     _chk(gamma, 'deconv_gn.gamma'); _chk(beta, 'deconv_gn.beta')
     assert w.shape[0] == x.shape[1] and w.shape[2:] == (5, 5)
-    return _conv_gn('deconv', x, w, bias, gamma, beta, groups, eps, dst0, dst1)
+    return _conv_gn('deconv', x, w, bias, gamma, beta, groups, eps, dst0, dst1, link_out)
 
 
 def deconv5x5s2_gn_stats_fwd(x, w, bias, gamma, beta, groups, eps):

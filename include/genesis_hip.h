@@ -90,13 +90,14 @@ int gx_wgq_ring(int on);
  *      tests, two thirds of its matrix-pipe time: the DEFAULT since round 5 (GENESIS_KQ_F16X3=0: mode 1).  -1: back to the
  *      environment's default. */
 int gx_kq_precision(int mode);
-/*      Mode 2's per-tensor maximum without a second pass over the tensor: gx_kq_amax_link(parts, capacity) arms a one-shot,
- *      per-thread hand-over -- the next producer that supports it (the decoder head's GroupNorm backward, gx_gn_relu_bwd_proj's
- *      two-workgroups-per-CU kernel: models/genesisv2_config.py:98-99 backward) writes one partial maximum of the gradient it stores
- *      per workgroup into `parts` (<= capacity floats) and remembers that tensor's address; the next mode-2 conv call whose input IS
- *      that address (gx_deconv5x5s2_dgrad) reduces those partials instead of launching its own pass.  Any mode-2 conv call clears
+/*      Mode 2's per-tensor maximum without a second pass over the tensor: gx_kq_amax_link(parts, capacity, numel) arms a one-shot,
+ *      per-thread hand-over -- the next producer that supports it (the register-resident GroupNorm + ReLU kernels behind gx_gn_relu_fwd_parts /
+ *      gx_gn_relu_bwd_parts and the decoder head's backward behind gx_gn_relu_bwd_proj: models/genesisv2_config.py:90-99) writes one partial maximum of the gradient it stores
+ *      per workgroup into `parts` (<= capacity floats) -- only a launch that covers all `numel` elements of the tensor: a chunked
+ *      producer leaves the link alone -- and remembers that tensor's address; the next mode-2 conv call whose input IS
+ *      that address and size (gx_deconv5x5s2_fwd* / gx_deconv5x5s2_dgrad) reduces those partials instead of launching its own pass.  Any mode-2 conv call clears
  *      the link; results are bit-identical with and without it.  gx_kq_amax_link_hits(): hand-overs taken so far (this thread). */
-int gx_kq_amax_link(float* parts, int capacity);
+int gx_kq_amax_link(float* parts, int capacity, size_t numel);
 int gx_kq_amax_link_hits(void);
 size_t gx_conv3x3_wino_ws_bytes(int N, int Cin, int Cout, int H, int W);
 int gx_conv3x3_wino(const float* x, const float* w, float* y, int N, int Cin, int Cout, int H, int W, int mode,

@@ -1724,7 +1724,7 @@ def test_amax_link_hands_the_head_gradients_maximum_to_the_data_gradient():
 
     def run(link):
         h0 = int(_lib.query('gx_kq_amax_link_hits'))
-        buf = hip.amax_link(yd.device) if link else None
+        buf = hip.amax_link(yd.device, yd.numel()) if link else None
         dy = hip.gn_relu_bwd_proj(yd, gd, bd, mean, rstd, 8, god, owd, True)[0]
         dx = hip.deconv5x5s2_dgrad(dy, wd)
         del buf
@@ -1737,7 +1737,7 @@ def test_amax_link_hands_the_head_gradients_maximum_to_the_data_gradient():
         assert torch.equal(dy0, dy1) and torch.equal(dx0, dx1)
         # armed, but the conv's input is another tensor: not taken, and gone afterwards
         h0 = int(_lib.query('gx_kq_amax_link_hits'))
-        buf = hip.amax_link(yd.device)
+        buf = hip.amax_link(yd.device, yd.numel())
         dy2 = hip.gn_relu_bwd_proj(yd, gd, bd, mean, rstd, 8, god, owd, True)[0]
         other = dy2.clone()
         dx2 = hip.deconv5x5s2_dgrad(other, wd)
@@ -1747,4 +1747,49 @@ def test_amax_link_hands_the_head_gradients_maximum_to_the_data_gradient():
         del buf
     finally:
         _lib.call('gx_kq_precision', -1)
-        _lib.call('gx_kq_amax_link', None, 0)
+        _lib.call('gx_kq_amax_link', None, 0, 0)
+
+
+def test_amax_link_from_the_groupnorm_kernels_of_the_decoder_layers():
+    """The same hand-over from the register-resident GroupNorm kernels: forward -- the normalised activation's partial maxima go to the
+    NEXT layer's transposed conv (hip.deconv5x5s2_gn_relu_fwd(link_out=True)); backward -- dy's go to the layer's data gradient.
+    Bit-identical with and without, each hand-over counted once."""
+    from genesis_amd import _lib, hip_ops as hip
+    N, C, H = 56, 64, 16
+    x = rnd(N, C, H, H, seed=1)
+    w1, b1 = rnd(C, C, 5, 5, seed=2, scale=0.05), rnd(C, seed=3, scale=0.3)
+    w2, b2 = rnd(C, C, 5, 5, seed=4, scale=0.05), rnd(C, seed=5, scale=0.3)
+    gamma, beta = 1 + 0.3 * rnd(C, seed=6), 0.2 * rnd(C, seed=7)
+    da = rnd(N, C, 2 * H, 2 * H, seed=8)
+    xd, w1d, b1d, w2d, b2d, gd, bd, dad = (t.to(DEV) for t in (x, w1, b1, w2, b2, gamma, beta, da))
+    hits = lambda: int(_lib.query('gx_kq_amax_link_hits'))      # noqa: E731
+
+    def fwd(link):
+        a = torch.empty(N, C, 2 * H, 2 * H, device=DEV)
+        y, mean, rstd = hip.deconv5x5s2_gn_relu_fwd(xd, w1d, b1d, gd, bd, 8, 1e-5, (a, 0, 0), link_out=link)
+        return a, y, mean, rstd, hip.deconv5x5s2_fwd(a, w2d, b2d)
+
+    def bwd(link, y, mean, rstd):
+        buf = hip.amax_link(dad.device, y.numel()) if link else None
+        dy = hip.gn_relu_bwd(y, gd, bd, mean, rstd, 8, (dad, 0, 0), None, True)[0]
+        dx = hip.deconv5x5s2_dgrad(dy, w1d)
+        del buf
+        return dy, dx
+    try:
+        _lib.call('gx_kq_precision', 2)
+        _lib.call('gx_kq_policy', 2)          # (the data gradient of 56 images does not fill the chip: every eligible shape)
+        h0 = hits()
+        a0, y0, mean, rstd, z0 = fwd(False)
+        assert hits() == h0
+        a1, y1, _, _, z1 = fwd(True)
+        assert hits() == h0 + 1
+        assert torch.equal(a0, a1) and torch.equal(z0, z1)
+        dy0, dx0 = bwd(False, y0, mean, rstd)
+        assert hits() == h0 + 1
+        dy1, dx1 = bwd(True, y0, mean, rstd)
+        assert hits() == h0 + 2
+        assert torch.equal(dy0, dy1) and torch.equal(dx0, dx1)
+    finally:
+        _lib.call('gx_kq_precision', -1)
+        _lib.call('gx_kq_policy', 1)
+        _lib.call('gx_kq_amax_link', None, 0, 0)
