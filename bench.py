@@ -334,6 +334,24 @@ def main():
             dist.all_reduce(tl, op=dist.ReduceOp.MAX)
         dt_long = float(tl)
 
+    # the SAME step on the structured input set of SURVEY.md 8(d): five-level flat-colour rectangles (the value distribution of
+    # Multi-dSprites, scripts/generate_multid.py:32-34,48-49,75; genesis_amd/testing.make_rect_input) instead of uniform noise --
+    # exact zeros / ones and constant regions.  Reported as `value_structured_inputs`, never as `value`; parity on this input
+    # set: tests/golden/full_v2_metric_b32_rect.npz.
+    dt_rect = None
+    if world == 1 and args.model == 'genesisv2' and args.extra_leg_steps > 0:
+        from genesis_amd.testing import make_rect_input
+        rect = [make_rect_input(4321 + i, args.batch, args.img).to(device) for i in range(4)]
+        for i in range(5):
+            ts.step(rect[i % 4])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.extra_leg_steps):
+            out_rect = ts.step(rect[i % 4])
+        torch.cuda.synchronize()
+        dt_rect = time.perf_counter() - t0
+        elbo_rect = float(out_rect[0])
+
     # the step's ONE collective by itself: the flat bucket's all-reduce, back to back on an idle GPU (every rank takes part;
     # the bucket is zeroed first and is clean afterwards, as the step leaves it).  In the step it is exposed by construction
     # (DESIGN.md section 6), so this is what one step pays for it.
@@ -382,6 +400,12 @@ def main():
             result['steady_state'] = {'value': world * args.batch * long_steps / dt_long, 'unit': 'images/sec', 'steps': long_steps,
                                       'ms_per_step': 1e3 * dt_long / long_steps,
                                       'note': 'the same loop over a longer window, after the timed region (max over ranks)'}
+        if dt_rect is not None:
+            result['value_structured_inputs'] = {'value': args.batch * args.extra_leg_steps / dt_rect, 'unit': 'images/sec',
+                                                 'steps': args.extra_leg_steps, 'ms_per_step': 1e3 * dt_rect / args.extra_leg_steps,
+                                                 'final_elbo': elbo_rect,
+                                                 'input': 'five-level flat-colour rectangles (SURVEY 8(d): the Multi-dSprites value '
+                                                          'distribution, genesis_amd/testing.make_rect_input); same HIP-graph step'}
         if os.environ.get('GENESIS_WGQ_BF16X6', '1') != '0':
             result['arithmetic'] = ('fp32 tensors and fp32 accumulation everywhere; the weight gradients and the Winograd conv3x3 layers '
                                     'form every fp32 product from six bf16 piece products on the bf16 matrix pipe (hi+mid+lo pieces hold '

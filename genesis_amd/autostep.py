@@ -21,9 +21,11 @@ without a backward, an exception inside backward -- falls back to the plain path
 `GENESIS_AUTOSTEP=0` switches the whole mechanism off (the plain per-call path).  Measured on the metric configuration
 (tools/ref_loop_time.py): see DESIGN.md section 7."""
 import os
+import threading
 import weakref
 
 import torch
+from torch.nn.parallel import DistributedDataParallel as _DDP
 
 from . import _lib
 from . import hip_ops as _hip
@@ -44,6 +46,19 @@ class _State(object):
 
 
 _STATE = _State()
+
+# Per-model bookkeeping lives HERE, keyed weakly by the model -- not in model.__dict__, which copy.deepcopy / torch.save /
+# nn.DataParallel's replicate() would duplicate together with the native cache id it holds (two models aliasing one cache, a
+# finalizer destroying a live one).  A copy of a model simply starts without an entry.
+_BOOK = weakref.WeakKeyDictionary()      # model -> {'cache': [id, recorded, key] | None, 'params': [...], 'grads': (...) | None}
+
+
+def _book(model):
+    b = _BOOK.get(model)
+    if b is None:
+        b = {'cache': None, 'params': None, 'grads': None}
+        _BOOK[model] = b
+    return b
 
 
 def _fn():
@@ -67,20 +82,47 @@ def _reset():
     st.models, st.in_pass, st.direct, st.cache_on, st.recording = [], False, False, None, False
 
 
+def _wrapped_or_threaded(model):
+    """The callers this mechanism must leave alone.
+    * nn.DataParallel (train.py --multi_gpu, train.py:153-155) runs REPLICAS on worker threads: a replica has no parameters() and
+      the packed-weight cache tables of a library context are not made for concurrent recording -- replicas and any forward off
+      the main thread take the plain per-call path, which touches no shared state.
+    * DistributedDataParallel copies p.grad into its bucket from the AccumulateGrad post-hooks, i.e. DURING the backward pass,
+      while this mechanism only finalises the conv-weight / GroupNorm-affine gradients in its end-of-backward callback: the bucket
+      would carry zeros and be copied back over the flushed gradients.  Under a DDP forward the plain path runs."""
+    if getattr(model, '_is_replica', False) or threading.current_thread() is not threading.main_thread():
+        return True
+    return _DDP._active_ddp_module is not None
+
+
 def arm(model):
-    """Top of a model's forward().  No-op unless: enabled, training mode, autograd on, not inside a stream capture, and no TrainStep
-    (or other owner of the library's step switches) active in this library context."""
-    if not ENABLED or not model.training or not torch.is_grad_enabled():
+    """Top of a model's forward().  No-op unless: enabled, training mode, autograd on, not inside a stream capture, not a
+    DataParallel replica / DDP-wrapped forward, and no TrainStep (or other owner of the library's step switches) active in this
+    library context.  Whatever an earlier, unfinished pass left behind (a training forward that never got its backward, a
+    backward that raised) is dropped FIRST, also by forwards that do not arm -- an evaluation forward must not be served packed
+    weights that were cached before an in-place weight update."""
+    if not ENABLED:
+        return
+    st = _STATE
+    if (st.in_pass or st.cache_on is not None or st.direct) and threading.current_thread() is threading.main_thread() \
+            and not torch.cuda.is_current_stream_capturing():
+        prev = _lib.current_ctx()
+        if prev != st.ctx:
+            _lib.make_current(st.ctx)
+        try:
+            _reset()
+        finally:
+            if prev != st.ctx:
+                _lib.make_current(prev)
+    if not model.training or not torch.is_grad_enabled() or _wrapped_or_threaded(model):
         return
     if _lib.current_ctx() != 0 or _fn().step_state().direct_param_grads and not _STATE.direct:
         return                                         # a TrainStep owns this thread's step state
     if torch.cuda.is_current_stream_capturing():
         return
-    st = _STATE
-    if st.in_pass or st.cache_on is not None or st.direct:
-        _reset()                                       # (a forward without a backward, or a backward that raised)
     st.ctx = _lib.current_ctx()
-    cache = model.__dict__.get('_gx_autostep_cache')
+    book = _book(model)
+    cache = book['cache']
     key = _param_key(model)
     if cache is not None and cache[2] != key:
         # the parameters moved (a TrainStep re-homed them into its flat bucket, .to(), load of another state): the recorded
@@ -89,7 +131,7 @@ def arm(model):
         cache[0], cache[1], cache[2] = int(_lib.query('gx_weight_cache_create')), False, key
     if cache is None:
         cache = [int(_lib.query('gx_weight_cache_create')), False, key]     # [id, recorded, parameter key]
-        model.__dict__['_gx_autostep_cache'] = cache
+        book['cache'] = cache
         weakref.finalize(model, _destroy_cache, cache)
     if not cache[1]:
         _lib.call('gx_weight_cache_record', cache[0], 1)
@@ -103,17 +145,31 @@ def arm(model):
 
 def _params(model):
     """The model's parameters, listed once (walking the module tree costs ~0.2 ms per call at 78 parameters: more than the
-    launches this mechanism saves would cost on the host)."""
-    ps = model.__dict__.get('_gx_autostep_params')
-    if ps is None:
-        ps = [p for p in model.parameters()]
-        model.__dict__['_gx_autostep_params'] = ps
-    return ps
+    launches this mechanism saves would cost on the host) as (owning module, name, parameter) and re-validated by identity on
+    every use (78 dictionary look-ups): a parameter that was replaced (`module.weight = nn.Parameter(...)`) rebuilds the list."""
+    book = _book(model)
+    ent = book['params']
+    if ent is not None:
+        for mod, name, p in ent:
+            if mod._parameters.get(name) is not p:
+                ent = None
+                break
+    if ent is None:
+        ent, seen = [], set()
+        for mod in model.modules():
+            for name, p in mod._parameters.items():
+                if p is not None and id(p) not in seen:
+                    seen.add(id(p))
+                    ent.append((mod, name, p))
+        book['params'] = ent
+        book['plist'] = [e[2] for e in ent]
+        book['grads'] = None
+    return book['plist']
 
 
 def _param_key(model):
     ps = _params(model)
-    return (len(ps), ps[0].data_ptr(), ps[-1].data_ptr(), id(ps[0]), id(ps[-1])) if ps else (0,)
+    return tuple((id(p), p.data_ptr()) for p in ps)
 
 
 def _destroy_cache(cache):
@@ -134,9 +190,9 @@ def begin_backward():
     models = [m() for m in st.models]
     params = [p for m in models if m is not None for p in _params(m) if p.requires_grad]
     if params and all(p.grad is None for p in params):
-        owner = models[0]
-        flat = owner.__dict__.get('_gx_autostep_grads')
-        key = (len(params), id(params[0]), params[0].data_ptr(), id(params[-1]), params[-1].data_ptr())
+        owner = _book(models[0])
+        flat = owner['grads']
+        key = tuple(id(p) for p in params) + (params[0].device,)
         if flat is None or flat[0] != key:
             # one flat buffer per dtype, every parameter's gradient a 64-byte-aligned view of it (built once per model)
             views, bufs = [], {}
@@ -151,7 +207,7 @@ def begin_backward():
                 bufs[dt] = buf
                 views.extend((p, buf[o:o + p.numel()].view(p.shape)) for p, o in zip(ps, offs))
             flat = (key, list(bufs.values()), views)
-            owner.__dict__['_gx_autostep_grads'] = flat
+            owner['grads'] = flat
         else:
             for b in flat[1]:
                 b.zero_()
@@ -185,8 +241,9 @@ def end_backward():
                 _lib.call('gx_weight_cache_record', st.cache_on, 0)
                 for m in st.models:
                     m = m()
-                    if m is not None and m.__dict__.get('_gx_autostep_cache', [None])[0] == st.cache_on:
-                        m.__dict__['_gx_autostep_cache'][1] = True
+                    c = _BOOK.get(m, {}).get('cache') if m is not None else None
+                    if c is not None and c[0] == st.cache_on:
+                        c[1] = True
             else:
                 _lib.call('gx_weight_cache_release')
             st.cache_on, st.recording = None, False

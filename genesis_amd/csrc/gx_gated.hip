@@ -89,6 +89,27 @@ __global__ void gated_stats_finalize_kernel(const double* __restrict__ part, int
     // biased variance kept for the caller's running_var update (BatchNorm uses the unbiased one there)
 }
 
+// Cross-replica BatchNorm (the SyncBN-style exchange): the statistics pass ends in raw fp64 {sum, sum of squares}
+// per channel -- what the ranks add up -- and {mean, rstd} are formed from the SUMMED pairs and the global count.
+__global__ void gated_raw_sums_kernel(const double* __restrict__ part, int units, int nchunk, double* __restrict__ sums) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= units) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int z = 0; z < nchunk; ++z) { s1 += part[2 * ((size_t)u * nchunk + z)]; s2 += part[2 * ((size_t)u * nchunk + z) + 1]; }
+    sums[2 * u] = s1; sums[2 * u + 1] = s2;
+}
+
+__global__ void gated_stats_from_sums_kernel(const double* __restrict__ sums, int units, double m, float eps,
+                                             float* __restrict__ stats) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= units) return;
+    const double mean = sums[2 * u] / m;
+    double var = sums[2 * u + 1] / m - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[2 * u] = (float)mean;
+    stats[2 * u + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
 // nn.BatchNorm2d's running statistics of the two norms of a gated unit from its {mean, rstd} pairs: running = (1 - mom)
 // running + mom {mean, unbiased variance}, num_batches_tracked += 1 (one launch instead of ~19 pointwise ones)
 __global__ void bn_running_update_kernel(const float* __restrict__ stats, int C, double m, double eps, float mom,
@@ -208,7 +229,7 @@ __global__ void __launch_bounds__(256)
 gated_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ bias, const float* __restrict__ stats,
                        const float* __restrict__ gh, const float* __restrict__ bh, const float* __restrict__ gg,
                        const float* __restrict__ bg, const float* __restrict__ dout, const float* __restrict__ sums,
-                       int N, int C, int HW, int norm, float* __restrict__ dy) {
+                       int N, int C, int HW, int norm, float m_global, float* __restrict__ dy) {
     const int plane = blockIdx.x;           // n * C + c
     const int n = plane / C, c = plane % C;
     const int C2 = 2 * C;
@@ -219,7 +240,7 @@ gated_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ bi
     const float g_h = gh ? gh[c] : 1.f, be_h = bh ? bh[c] : 0.f, g_g = gg ? gg[c] : 1.f, be_g = bg ? bg[c] : 0.f;
     float k1h = 0.f, k2h = 0.f, k1g = 0.f, k2g = 0.f;
     if (norm != NORM_NONE) {
-        const float m = (norm == NORM_BN) ? (float)N * HW : (float)HW;
+        const float m = (norm == NORM_BN) ? (m_global > 0.f ? m_global : (float)N * HW) : (float)HW;
         const int uh = (norm == NORM_BN) ? c : n * C2 + c, ug = (norm == NORM_BN) ? C + c : n * C2 + C + c;
         k1h = sums[2 * uh] / m; k2h = sums[2 * uh + 1] / m;
         k1g = sums[2 * ug] / m; k2g = sums[2 * ug + 1] / m;
@@ -353,12 +374,86 @@ int gx_gated_norm_bwd(const float* y, const float* bias, int norm, const float* 
     {
         GxProf pf(KID_GATED, s, 0.0, 4.0 * N * 5.0 * C * HW);
         hipLaunchKernelGGL(gated_bwd_apply_kernel, dim3(N * C, gx_ceil_div(HW, 1024)), dim3(256), 0, s, y, bias, stats,
-                           gamma_h, beta_h, gamma_g, beta_g, dout, (const float*)sums, N, C, HW, norm, dy);
+                           gamma_h, beta_h, gamma_g, beta_g, dout, (const float*)sums, N, C, HW, norm, 0.f, dy);
     }
     GX_CHECK_LAUNCH("gx_gated_norm_bwd(apply)");
     hipLaunchKernelGGL(gated_param_kernel, dim3(gx_ceil_div(2 * C, 64)), dim3(64), 0, s, (const float*)sums, N, C, norm,
                        dgamma_h, dbeta_h, dgamma_g, dbeta_g, dbias);
     GX_CHECK_LAUNCH("gx_gated_norm_bwd(params)");
+    return GX_OK;
+}
+
+/* ---- the same unit with the BatchNorm statistics taken over SEVERAL ranks' batches (cross-replica BatchNorm; the reference's
+ *      single-device batch statistics at the GLOBAL batch, genesis_config.py:39-40 / layers.py:26-27, when the batch is sharded):
+ *      the forward and the backward are cut where the per-channel sums exist, the caller adds them over the ranks in between. */
+size_t gx_gated_bn_sums_ws_bytes(int N, int C) { return (size_t)4 * nunits(NORM_BN, N, C) * nchunks(NORM_BN, N, C) * sizeof(float); }
+
+int gx_gated_bn_local_sums(const float* y, const float* bias, int N, int C, int H, int W, double* sums, void* ws,
+                           size_t ws_bytes, gx_stream_t stream) {
+    GX_CHECK_ARG(y && sums && ws, "gx_gated_bn_local_sums: null pointer");
+    GX_CHECK_ARG(N > 0 && C > 0 && H > 0 && W > 0, "gx_gated_bn_local_sums: bad dims");
+    GX_CHECK_ARG(ws_bytes >= gx_gated_bn_sums_ws_bytes(N, C), "gx_gated_bn_local_sums: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int units = 2 * C, nz = nchunks(NORM_BN, N, C), HW = H * W;
+    GxProf pf(KID_GATED, s, 0.0, 4.0 * N * 2.0 * C * HW);
+    hipLaunchKernelGGL(gated_stats_partial_kernel, dim3(units, nz), dim3(256), 0, s, y, bias, N, 2 * C, HW, (int)NORM_BN, nz,
+                       (double*)ws);
+    hipLaunchKernelGGL(gated_raw_sums_kernel, dim3(gx_ceil_div(units, 256)), dim3(256), 0, s, (const double*)ws, units, nz, sums);
+    GX_CHECK_LAUNCH("gx_gated_bn_local_sums");
+    return GX_OK;
+}
+
+int gx_gated_bn_apply(const float* y, const float* bias, const double* sums, double m, const float* gamma_h,
+                      const float* beta_h, const float* gamma_g, const float* beta_g, int N, int C, int H, int W, float eps,
+                      float* out, float* stats, gx_stream_t stream) {
+    GX_CHECK_ARG(y && sums && out && stats, "gx_gated_bn_apply: null pointer");
+    GX_CHECK_ARG(N > 0 && C > 0 && H > 0 && W > 0 && m >= 1.0, "gx_gated_bn_apply: bad dims");
+    hipStream_t s = (hipStream_t)stream;
+    const int HW = H * W;
+    hipLaunchKernelGGL(gated_stats_from_sums_kernel, dim3(gx_ceil_div(2 * C, 256)), dim3(256), 0, s, sums, 2 * C, m, eps, stats);
+    GxProf pf(KID_GATED, s, 0.0, 4.0 * N * 3.0 * C * HW);
+    hipLaunchKernelGGL(gated_apply_kernel, dim3(N * C, gx_ceil_div(HW, 1024)), dim3(256), 0, s, y, bias, (const float*)stats,
+                       gamma_h, beta_h, gamma_g, beta_g, N, C, HW, (int)NORM_BN, out);
+    GX_CHECK_LAUNCH("gx_gated_bn_apply");
+    return GX_OK;
+}
+
+/*      backward, first half: the rank's own {S1, S2} per channel (float [2][2C] pairs) and from them the affine / bias
+ *      gradients (LOCAL sums: the gradient all-reduce of the step adds the ranks' contributions). */
+int gx_gated_bn_bwd_local_sums(const float* y, const float* bias, const float* gamma_h, const float* beta_h,
+                               const float* gamma_g, const float* beta_g, const float* stats, const float* dout, int N, int C,
+                               int H, int W, float* sums, float* dgamma_h, float* dbeta_h, float* dgamma_g, float* dbeta_g,
+                               float* dbias, void* ws, size_t ws_bytes, gx_stream_t stream) {
+    GX_CHECK_ARG(y && stats && dout && sums && ws, "gx_gated_bn_bwd_local_sums: null pointer");
+    GX_CHECK_ARG(N > 0 && C > 0 && H > 0 && W > 0, "gx_gated_bn_bwd_local_sums: bad dims");
+    GX_CHECK_ARG(ws_bytes >= gx_gated_bn_sums_ws_bytes(N, C), "gx_gated_bn_bwd_local_sums: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int HW = H * W, units = 2 * C, nz = nchunks(NORM_BN, N, C);
+    {
+        GxProf pf(KID_GATED, s, 0.0, 4.0 * N * 3.0 * C * HW);
+        hipLaunchKernelGGL(gated_bwd_sums_kernel, dim3(units / 2, nz), dim3(256), 0, s, y, bias, stats, gamma_h, beta_h,
+                           gamma_g, beta_g, dout, N, C, HW, (int)NORM_BN, nz, (double*)ws);
+        hipLaunchKernelGGL(gated_sums_finalize_kernel, dim3(gx_ceil_div(units, 256)), dim3(256), 0, s, (const double*)ws, units,
+                           nz, sums);
+    }
+    hipLaunchKernelGGL(gated_param_kernel, dim3(gx_ceil_div(2 * C, 64)), dim3(64), 0, s, (const float*)sums, N, C, (int)NORM_BN,
+                       dgamma_h, dbeta_h, dgamma_g, dbeta_g, dbias);
+    GX_CHECK_LAUNCH("gx_gated_bn_bwd_local_sums");
+    return GX_OK;
+}
+
+/*      backward, second half: dy from the sums added over the ranks and the global count m. */
+int gx_gated_bn_bwd_apply(const float* y, const float* bias, const float* gamma_h, const float* beta_h, const float* gamma_g,
+                          const float* beta_g, const float* stats, const float* dout, const float* sums, double m, int N, int C,
+                          int H, int W, float* dy, gx_stream_t stream) {
+    GX_CHECK_ARG(y && stats && dout && sums && dy, "gx_gated_bn_bwd_apply: null pointer");
+    GX_CHECK_ARG(N > 0 && C > 0 && H > 0 && W > 0 && m >= 1.0, "gx_gated_bn_bwd_apply: bad dims");
+    hipStream_t s = (hipStream_t)stream;
+    const int HW = H * W;
+    GxProf pf(KID_GATED, s, 0.0, 4.0 * N * 5.0 * C * HW);
+    hipLaunchKernelGGL(gated_bwd_apply_kernel, dim3(N * C, gx_ceil_div(HW, 1024)), dim3(256), 0, s, y, bias, stats, gamma_h,
+                       beta_h, gamma_g, beta_g, dout, sums, N, C, HW, (int)NORM_BN, (float)m, dy);
+    GX_CHECK_LAUNCH("gx_gated_bn_bwd_apply");
     return GX_OK;
 }
 

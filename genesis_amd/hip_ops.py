@@ -895,6 +895,51 @@ def gated_norm_bwd(y, bias, norm, gh, bh, gg, bg, stats, dout, out=None):
     return dy, dgh, dbh, dgg, dbg, dbias
 
 
+def gated_bn_sync_fwd(y, bias, gh, bh, gg, bg, all_reduce_sum, world, eps=1e-5):
+    """The gated unit with BatchNorm statistics over the batches of ALL ranks (cross-replica BatchNorm):
+    local fp64 {sum, sum of squares} per channel -> `all_reduce_sum(tensor)` (in place, over the `world` ranks, which hold equal
+    shards) -> {mean, rstd} from the global sums and the global count, the unit applied.  Enqueue-only (no host read).
+    Returns (out, stats, m_global)."""
+    _chk(y, 'gated.y'); _chk(bias, 'gated.bias')
+    N, C2, H, W = y.shape
+    C = C2 // 2
+    dev = y.device
+    pack = torch.empty(4 * C, dtype=torch.float64, device=dev)           # [2C][2] sums
+    nb = _lib.query('gx_gated_bn_sums_ws_bytes', N, C)
+    ws = _ws(nb, dev)
+    _lib.call('gx_gated_bn_local_sums', _p(y), _p(bias), N, C, H, W, _p(pack), _p(ws), nb, _stream())
+    all_reduce_sum(pack)
+    m = float(N * H * W) * world
+    out = torch.empty(N, C, H, W, dtype=F32, device=dev)
+    stats = torch.empty(4 * C, dtype=F32, device=dev)
+    _lib.call('gx_gated_bn_apply', _p(y), _p(bias), _p(pack), m, _p(gh), _p(bh), _p(gg), _p(bg), N, C, H, W, float(eps),
+              _p(out), _p(stats), _stream())
+    return out, stats, m
+
+
+def gated_bn_sync_bwd(y, bias, gh, bh, gg, bg, stats, dout, m, all_reduce_sum, out=None):
+    """Backward of gated_bn_sync_fwd: the affine / bias gradients from the rank's OWN {S1, S2} (the step's gradient all-reduce
+    adds the ranks), dy from the sums added over the ranks and the global count m."""
+    _chk(dout, 'gated_bwd.dout')
+    N, C2, H, W = y.shape
+    C = C2 // 2
+    dev = y.device
+    o = out if out is not None else (None,) * 5
+    mk = lambda dst, n, want: (dst if dst is not None else torch.empty(n, dtype=F32, device=dev)) if want else None  # noqa: E731
+    dgh, dbh, dgg, dbg = mk(o[0], C, True), mk(o[1], C, True), mk(o[2], C, True), mk(o[3], C, True)
+    dbias = mk(o[4], C2, bias is not None)
+    sums = torch.empty(4 * C, dtype=F32, device=dev)
+    nb = _lib.query('gx_gated_bn_sums_ws_bytes', N, C)
+    ws = _ws(nb, dev)
+    _lib.call('gx_gated_bn_bwd_local_sums', _p(y), _p(bias), _p(gh), _p(bh), _p(gg), _p(bg), _p(stats), _p(dout), N, C, H, W,
+              _p(sums), _p(dgh), _p(dbh), _p(dgg), _p(dbg), _p(dbias), _p(ws), nb, _stream())
+    all_reduce_sum(sums)
+    dy = torch.empty_like(y)
+    _lib.call('gx_gated_bn_bwd_apply', _p(y), _p(bias), _p(gh), _p(bh), _p(gg), _p(bg), _p(stats), _p(dout), _p(sums), float(m),
+              N, C, H, W, _p(dy), _stream())
+    return dy, dgh, dbh, dgg, dbg, dbias
+
+
 # ---------------------------------------------------------------------------------------------- slot latents
 def latent_posterior_fwd(zh, eps):
     """zh [B,K,2D] (z_head output), eps [K,B,D] -> z, mu, sigma [K,B,D], log_q [K,B]

@@ -124,8 +124,10 @@ def gate_unit(unit, y, training):
         # running = 0.9 running + 0.1 {mean, unbiased variance}, num_batches_tracked += 1 (momentum None is not used by
         # the reference's stacks)
         assert unit.h_norm.momentum == 0.1 and unit.g_norm.momentum == 0.1
-        hip.bn_running_update(stats, out.shape[1], y.shape[0] * y.shape[2] * y.shape[3], unit.h_norm, unit.g_norm,
-                              eps=unit.h_norm.eps)
+        m = y.shape[0] * y.shape[2] * y.shape[3]
+        if _SYNC['on']:
+            m *= _world()      # (equal shards: the count the statistics were taken over)
+        hip.bn_running_update(stats, out.shape[1], m, unit.h_norm, unit.g_norm, eps=unit.h_norm.eps)
     return out
 
 
@@ -215,6 +217,29 @@ class DirectConvFn(torch.autograd.Function):
         return dx, _ret(ow, dw), None, None, None, None
 
 
+# Cross-replica BatchNorm (the reference's single-device batch statistics, genesis_config.py:39-40 ->
+# layers.py:26-27, at the GLOBAL batch when the batch is sharded over ranks): `sync_bn(group)` -- TrainStep calls it when
+# GENESIS_SYNC_BN=1 and the process group has more than one rank -- makes every training-mode BatchNorm of the gated stacks
+# take its statistics (forward) and its two gradient sums (backward) over all ranks: two small all-reduces per gated unit and
+# step (4C doubles, 4C floats).  Off (the default): per-replica statistics, what nn.DataParallel gives the reference
+# (train.py:153-155).
+_SYNC = {'group': None, 'on': False}
+
+
+def sync_bn(group=None, on=True):
+    _SYNC['group'], _SYNC['on'] = group, bool(on)
+
+
+def _world():
+    import torch.distributed as dist
+    return dist.get_world_size(_SYNC['group'])
+
+
+def _all_reduce_sum(t):
+    import torch.distributed as dist
+    dist.all_reduce(t, group=_SYNC['group'])
+
+
 @ctx_bound
 class GatedNormFn(torch.autograd.Function):
     """returns (out [N,C,H,W], stats); stats ({mean, rstd} per unit) is non-differentiable."""
@@ -222,7 +247,11 @@ class GatedNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, bias, norm, gh, bh, gg, bg):
         y = y.contiguous()
-        out, stats = hip.gated_norm_fwd(y, bias, norm, gh, bh, gg, bg)
+        ctx.m_global = None
+        if norm == 'bn' and _SYNC['on']:
+            out, stats, ctx.m_global = hip.gated_bn_sync_fwd(y, bias, gh, bh, gg, bg, _all_reduce_sum, _world())
+        else:
+            out, stats = hip.gated_norm_fwd(y, bias, norm, gh, bh, gg, bg)
         ctx.save_for_backward(y, stats)
         ctx.params = (bias, gh, bh, gg, bg)
         ctx.norm = norm
@@ -235,6 +264,10 @@ class GatedNormFn(torch.autograd.Function):
         y, stats = ctx.saved_tensors
         bias, gh, bh, gg, bg = ctx.params
         outs = tuple(_gout(p) if p is not None else None for p in (gh, bh, gg, bg, bias))
-        dy, dgh, dbh, dgg, dbg, dbias = hip.gated_norm_bwd(y, bias, ctx.norm, gh, bh, gg, bg, stats, g.contiguous(), out=outs)
+        if ctx.m_global is not None:
+            dy, dgh, dbh, dgg, dbg, dbias = hip.gated_bn_sync_bwd(y, bias, gh, bh, gg, bg, stats, g.contiguous(), ctx.m_global,
+                                                                  _all_reduce_sum, out=outs)
+        else:
+            dy, dgh, dbh, dgg, dbg, dbias = hip.gated_norm_bwd(y, bias, ctx.norm, gh, bh, gg, bg, stats, g.contiguous(), out=outs)
         return (dy, _ret(outs[4], dbias), None, _ret(outs[0], dgh), _ret(outs[1], dbh), _ret(outs[2], dgg),
                 _ret(outs[3], dbg))

@@ -66,6 +66,32 @@ def make_input(seed, B, S):
     return torch.rand(B, 3, S, S, generator=g)
 
 
+RECT_LEVELS = (0.0, 63.0 / 255.0, 127.0 / 255.0, 191.0 / 255.0, 1.0)
+
+
+def make_rect_input(seed, B, S):
+    """The STRUCTURED input set of SURVEY section 8(d): images with the value distribution of Multi-dSprites -- a flat background
+    and one to four flat objects, every colour channel one of the five levels {0, 63, 127, 191, 255} / 255
+    (scripts/generate_multid.py:32-34 the levels, :48-49 the flat background, :75 the / 255) -- with axis-aligned rectangles in
+    place of the dSprites shapes (which are a dataset download).  Exact zeros, exact ones and large constant regions: the
+    adversarial case for per-tensor fp16 operand scales and for ReLU decisions at pre-activation 0.  Closed form, seeded."""
+    g = torch.Generator().manual_seed(seed)
+    lv = torch.tensor(RECT_LEVELS, dtype=torch.float32)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))   # noqa: E731
+    x = torch.empty(B, 3, S, S, dtype=torch.float32)
+    for b in range(B):
+        x[b] = lv[torch.randint(0, 5, (3,), generator=g)].view(3, 1, 1)
+        for _ in range(ri(1, 4)):
+            h, w = ri(S // 8, S // 2), ri(S // 8, S // 2)
+            y0, x0 = ri(0, S - h), ri(0, S - w)
+            x[b, :, y0:y0 + h, x0:x0 + w] = lv[torch.randint(0, 5, (3,), generator=g)].view(3, 1, 1)
+    return x
+
+
+def make_input_of(kind, seed, B, S):
+    return make_rect_input(seed, B, S) if kind == 'rect' else make_input(seed, B, S)
+
+
 MAX_SAMPLES = 2048
 
 

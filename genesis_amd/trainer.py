@@ -91,6 +91,14 @@ class TrainStep(object):
         self._early_done = False
         self._early_collective_ok = True      # (False while capturing the two-graph form: no collective inside those graphs)
         self.use_graph = graph
+        # GENESIS_SYNC_BN=1, several ranks, a model with BatchNorm (GENESIS v1 / BaselineVAE: genesis_config.py:39-40): batch
+        # statistics over ALL ranks' shards (genesis_amd/sylvester.sync_bn) -- the single-device reference at the global batch;
+        # default: per-replica statistics, like the reference's own nn.DataParallel.  Its small per-layer collectives sit
+        # inside forward and backward, so the step is issued eagerly (no HIP graph around collectives in the split form).
+        self._sync_bn = (os.environ.get('GENESIS_SYNC_BN') == '1' and self.world > 1 and
+                         any(isinstance(m, torch.nn.BatchNorm2d) for m in model.modules()))
+        if self._sync_bn:
+            self.use_graph = False
         self._static_x = None
         self._out = None
         self.iters = 0
@@ -138,12 +146,18 @@ class TrainStep(object):
         st.async_wgrad = self.async_wgrad
         st.side_prior = self.side_prior
         st.early_flush = self._early_collective if self._early_range is not None else None
+        if self._sync_bn:
+            from . import sylvester
+            sylvester.sync_bn(self.pg, True)
         if self._hip_noise:
             self._noise_prev = self.model.__dict__.get('noise')
             self._noise_hook = self._draw_noise
             self.model.noise = self._noise_hook
 
     def _leave(self):
+        if self._sync_bn:
+            from . import sylvester
+            sylvester.sync_bn(None, False)
         if self._noise_hook is not None and self.model.__dict__.get('noise') is self._noise_hook:
             if getattr(self, '_noise_prev', None) is not None:
                 self.model.noise = self._noise_prev

@@ -428,6 +428,28 @@ int gx_gated_norm_bwd(const float* y, const float* bias, int norm, const float* 
                       int H, int W, float* dy, float* dgamma_h, float* dbeta_h, float* dgamma_g, float* dbeta_g,
                       float* dbias, void* ws, size_t ws_bytes, gx_stream_t stream);
 
+/* ---- the gated unit's BatchNorm over the batches of SEVERAL ranks (cross-replica BatchNorm: the reference's single-device
+ *      statistics at the global batch, models/genesis_config.py:39-40 -> third_party/sylvester/layers.py:26-27, when the batch is
+ *      sharded over GPUs).  Forward: gx_gated_bn_local_sums leaves fp64 {sum, sum of squares} of (y + bias) per
+ *      channel in sums [2C][2]; the caller adds them over the ranks; gx_gated_bn_apply forms {mean, rstd} from the summed pairs
+ *      and the GLOBAL count m = sum over ranks of N H W (written to `stats` [2C][2], kept for bwd and gx_bn_running_update) and
+ *      applies the unit.  Backward: gx_gated_bn_bwd_local_sums leaves the rank's {S1, S2} per channel (float [2C][2]) and
+ *      writes the affine / bias gradients from them (the step's gradient all-reduce adds the ranks); the caller adds the sums
+ *      over the ranks; gx_gated_bn_bwd_apply writes dy from the summed pairs and m.  ws: gx_gated_bn_sums_ws_bytes(). */
+size_t gx_gated_bn_sums_ws_bytes(int N, int C);
+int gx_gated_bn_local_sums(const float* y, const float* bias, int N, int C, int H, int W, double* sums, void* ws,
+                           size_t ws_bytes, gx_stream_t stream);
+int gx_gated_bn_apply(const float* y, const float* bias, const double* sums, double m, const float* gamma_h,
+                      const float* beta_h, const float* gamma_g, const float* beta_g, int N, int C, int H, int W, float eps,
+                      float* out, float* stats, gx_stream_t stream);
+int gx_gated_bn_bwd_local_sums(const float* y, const float* bias, const float* gamma_h, const float* beta_h,
+                               const float* gamma_g, const float* beta_g, const float* stats, const float* dout, int N, int C,
+                               int H, int W, float* sums, float* dgamma_h, float* dbeta_h, float* dgamma_g, float* dbeta_g,
+                               float* dbias, void* ws, size_t ws_bytes, gx_stream_t stream);
+int gx_gated_bn_bwd_apply(const float* y, const float* bias, const float* gamma_h, const float* beta_h, const float* gamma_g,
+                          const float* beta_g, const float* stats, const float* dout, const float* sums, double m, int N, int C,
+                          int H, int W, float* dy, gx_stream_t stream);
+
 /* ---- stick-breaking mask recursion in log space (modules/attention.py:31-51 SimpleSBP, :118-124 LatentSBP):
  *      log_m[t] = s_t + logsigmoid(l_t), s_{t+1} = s_t + logsigmoid(-l_t), s_0 = log_s0 (NULL: 0); logits / log_m /
  *      log_s [T,P] (log_s[t] = the scope AFTER step t); last_scope: log_m[T-1] = s_{T-1}, the remaining scope

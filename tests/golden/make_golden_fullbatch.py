@@ -42,7 +42,10 @@ CASES = {
     'v2_cfg5_b32': ('v2', dict(K_steps=11, img_size=128, feat_dim=64), 32, 121, 131),      # config 5 at its per-GPU batch
     'genesis_cfg3_b32': ('genesis', dict(K_steps=7, img_size=64), 32, 155, 165),
     'monet_cfg4_b32': ('monet', dict(K_steps=7, img_size=64), 32, 133, 143),
+    # the metric configuration on the STRUCTURED input set (five-level flat-colour regions, testing.make_rect_input)
+    'v2_metric_b32_rect': ('v2', dict(K_steps=7, img_size=64, feat_dim=64), 32, 218, 228),
 }
+INPUT_KIND = {'v2_metric_b32_rect': 'rect'}
 V2_GATE = 0.35
 
 
@@ -167,7 +170,7 @@ def run_case(name, mods):
             model.att_process.colour_head.gate.gate.fill_(V2_GATE)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model.train()
-    x = T.make_input(xseed, B, S)
+    x = T.make_input_of(INPUT_KIND.get(name, 'rand'), xseed, B, S)
 
     if fam == 'v2':
         # a noise seed whose K-1 x B argmax decisions are not near-ties (modules/attention.py:187-188 is discontinuous)
@@ -193,7 +196,7 @@ def run_case(name, mods):
            'sd_numel': np.array([v.numel() for v in sd.values()], dtype=np.int64),
            'sd_sum': np.array([float(v.double().sum()) for v in sd.values()]),
            'sd_asum': np.array([float(v.double().abs().sum()) for v in sd.values()]),
-           'v2_gate': np.float64(V2_GATE)}
+           'v2_gate': np.float64(V2_GATE), 'input_kind': np.array(INPUT_KIND.get(name, 'rand'))}
     T.pack_summary('in/x', x, out)
     for i, nz in enumerate(noise):
         T.pack_summary('in/noise%d' % i, nz, out)

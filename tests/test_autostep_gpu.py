@@ -137,3 +137,155 @@ def test_trainstep_and_the_unchanged_loop_coexist():
     h, _, _ = _loop(model, x, noise, 1, True)
     assert h[0] == h[0] and abs(h[0]) < 1e9
     _state_is_clean()
+
+
+def _one_iteration_grads(model, x, noise):
+    rp, eps = noise
+    model.zero_grad(set_to_none=True)
+    recon, losses, *_ = model(x.to(DEV), rp.to(DEV), torch.stack(eps).to(DEV))
+    (losses.err.mean(0) + torch.stack(losses.kl_l_k, dim=1).mean(dim=0).sum()).backward()
+    return losses
+
+
+def test_distributed_data_parallel_wrapper_takes_the_plain_path():
+    """DDP copies p.grad into its bucket from AccumulateGrad post-hooks, i.e. before the mechanism's end-of-backward flush would
+    have written the conv-weight gradients: under a DDP forward the mechanism must stay off, and the reduced gradients must be
+    the plain path's (world 1: the bucket round trip still happens)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from genesis_amd import autostep
+    gold = Golden('tiny')
+    x, _, _ = gold.inputs()
+    noise = gold.noise(1)
+    prev, autostep.ENABLED = autostep.ENABLED, False
+    try:
+        ref = build(gold)
+        _one_iteration_grads(ref, x, noise)
+        g0 = {n: p.grad.detach().clone() for n, p in ref.named_parameters()}
+        autostep.ENABLED = True
+        s = socket.socket()
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+        s.close()
+        own_group = not dist.is_initialized()
+        if own_group:
+            dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, world_size=1, rank=0)
+        try:
+            model = build(gold)
+            ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[torch.cuda.current_device()])
+            rp, eps = noise
+            recon, losses, *_ = ddp(x.to(DEV), rp.to(DEV), torch.stack(eps).to(DEV))
+            st = autostep._STATE
+            assert st.cache_on is None and not st.models          # the DDP forward armed nothing
+            (losses.err.mean(0) + torch.stack(losses.kl_l_k, dim=1).mean(dim=0).sum()).backward()
+            for n, p in model.named_parameters():
+                assert p.grad is not None, n
+                den = float(g0[n].double().norm()) + 1e-6 * max(float(v.double().norm()) for v in g0.values())
+                assert float((p.grad.double() - g0[n].double()).norm()) / den <= 2e-5, n
+            _state_is_clean()
+        finally:
+            if own_group:
+                dist.destroy_process_group()
+    finally:
+        autostep.ENABLED = prev
+
+
+def test_data_parallel_replicas_and_worker_threads_take_the_plain_path():
+    """train.py --multi_gpu (train.py:153-155) wraps the model in nn.DataParallel: replicas run on worker threads and have no
+    parameters(); they must not touch the mechanism's (process-wide) state or the library's packed-weight cache tables."""
+    import threading
+    from genesis_amd import autostep
+    gold = Golden('tiny')
+    x, _, _ = gold.inputs()
+    rp, eps = gold.noise(1)
+    prev, autostep.ENABLED = autostep.ENABLED, True
+    try:
+        model = build(gold)
+        dp = torch.nn.DataParallel(model, device_ids=[torch.cuda.current_device()])
+        # one device: DataParallel calls the module itself on the calling thread -- exercise the replica path explicitly
+        replica = torch.nn.parallel.replicate(model, [torch.cuda.current_device()])[0]
+        assert getattr(replica, '_is_replica', False)
+        seen = {}
+
+        def worker():
+            with torch.cuda.device(torch.cuda.current_device()):
+                out = replica(x.to(DEV), rp.to(DEV), torch.stack(eps).to(DEV))
+                seen['err'] = out[1].err.detach().clone()
+                seen['state'] = (autostep._STATE.cache_on, list(autostep._STATE.models))
+        t = threading.Thread(target=worker)
+        t.start()
+        t.join()
+        assert seen['state'] == (None, []), seen['state']
+        recon, losses, *_ = dp(x.to(DEV), rp.to(DEV), torch.stack(eps).to(DEV))
+        assert torch.allclose(losses.err, seen['err'], rtol=1e-6, atol=1e-6)
+        (losses.err.mean(0) + torch.stack(losses.kl_l_k, dim=1).mean(dim=0).sum()).backward()
+        _state_is_clean()
+    finally:
+        autostep.ENABLED = prev
+
+
+def test_evaluation_forward_after_an_abandoned_training_forward_sees_the_new_weights():
+    """A training forward that never gets its backward leaves the packed-weight cache serving; an in-place weight change followed
+    by an EVALUATION forward (which does not arm) must not be answered from it."""
+    from genesis_amd import autostep
+    gold = Golden('tiny')
+    x, _, _ = gold.inputs()
+    rp, eps = gold.noise(1)
+    args = (x.to(DEV), rp.to(DEV), torch.stack(eps).to(DEV))
+    prev, autostep.ENABLED = autostep.ENABLED, True
+    try:
+        model = build(gold)
+        _one_iteration_grads(model, x, (rp, eps))         # records the cache
+        model.zero_grad(set_to_none=True)
+        model(*args)                                      # armed, cache serving, no backward follows
+        with torch.no_grad():
+            for p in model.parameters():
+                if p.dim() == 4:
+                    p.mul_(1.25)
+        model.eval()
+        with torch.no_grad():
+            got = model(*args)[1].err.clone()
+        _state_is_clean()
+        autostep.ENABLED = False
+        with torch.no_grad():
+            want = model(*args)[1].err.clone()
+        assert torch.equal(got, want), (got, want)
+    finally:
+        autostep.ENABLED = prev
+
+
+def test_copies_of_a_model_do_not_share_the_native_cache():
+    import copy
+    from genesis_amd import autostep
+    gold = Golden('tiny')
+    x, _, _ = gold.inputs()
+    noise = gold.noise(1)
+    prev, autostep.ENABLED = autostep.ENABLED, True
+    try:
+        model = build(gold)
+        _one_iteration_grads(model, x, noise)
+        _one_iteration_grads(model, x, noise)
+        g = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+        twin = copy.deepcopy(model)
+        assert not any(k.startswith('_gx_autostep') for k in twin.__dict__)
+        assert autostep._BOOK.get(twin) is None
+        _one_iteration_grads(twin, x, noise)
+        _one_iteration_grads(twin, x, noise)
+        cid = autostep._BOOK[model]['cache'][0]
+        assert autostep._BOOK[twin]['cache'][0] != cid
+        del twin
+        import gc
+        gc.collect()
+        _one_iteration_grads(model, x, noise)             # the original's cache is still alive
+        for n, p in model.named_parameters():
+            assert torch.equal(p.grad, g[n]), n
+        # a replaced parameter is noticed (the cached parameter list is validated by identity)
+        w = model.seg_head.params()[0]
+        owner = [(m, k) for m in model.modules() for k, v in m._parameters.items() if v is w][0]
+        setattr(owner[0], owner[1], torch.nn.Parameter(w.detach().clone()))
+        _one_iteration_grads(model, x, noise)
+        assert getattr(owner[0], owner[1]).grad is not None
+        _state_is_clean()
+    finally:
+        autostep.ENABLED = prev

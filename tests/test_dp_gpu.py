@@ -237,3 +237,81 @@ def test_two_ranks_log_the_whole_batchs_mse(tmp_path):
     ref = _run(ts, x, noise, slice(0, x.shape[0])).cpu()
     assert torch.allclose(m0[:, 4:6], ref[:, 4:6], rtol=2e-4), (m0[:, 4:6], ref[:, 4:6])
     assert float(ref[0, 4]) > 0 and float(ref[0, 5]) > float(ref[0, 4])      # rmse > mse for errors below 1
+
+
+def _worker_genesis_syncbn(rank, world, port, out_dir):
+    """GENESIS (BASELINE config 3) with its batch sharded over two ranks and GENESIS_SYNC_BN=1: BatchNorm statistics and
+    their backward sums over BOTH shards (genesis_amd/sylvester.sync_bn) -- the reference's single-device run at the global batch
+    (models/genesis_config.py:39-40, third_party/sylvester/layers.py:26-27), i.e. tests/golden/full_genesis_cfg3_b32.npz."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['GENESIS_SYNC_BN'] = '1'
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import numpy as np
+    from genesis_amd import sylvester
+    from genesis_amd.trainer import TrainStep
+    from tests.test_fullbatch_gpu import Full, FWD_TOL, check_gradients
+    gold = Full('genesis_cfg3_b32')
+    K, B = gold.K, gold.B
+    sl = slice(rank * B // world, (rank + 1) * B // world)
+
+    def shard(nz):
+        return dict(eps_m=[n[sl].contiguous().cuda() for n in nz[:K]],
+                    eps_c=nz[K].view(K, B, -1)[:, sl].reshape(-1, nz[K].shape[-1]).contiguous().cuda())
+
+    x = gold.x()
+    # --- one forward + backward on the shards, batch statistics over both ranks
+    model = gold.build()
+    sylvester.sync_bn(None, True)
+    try:
+        recon, losses, stats, att, comp = model(x[sl].cuda(), **shard(gold.noise()))
+        err, kl = gold.aggregate(losses)
+        (err + kl).backward()
+    finally:
+        sylvester.sync_bn(None, False)
+    # per-image loss terms of this rank's images against the reference's full-batch run
+    rt, at = FWD_TOL['genesis']['err']
+    np.testing.assert_allclose(losses['err'].detach().cpu().numpy(), gold.g['out/err'][sl], rtol=rt, atol=at)
+    rt, at = FWD_TOL['genesis']['kl_l_k']
+    np.testing.assert_allclose(torch.stack(list(losses['kl_l_k'])).detach().cpu().numpy(), gold.g['out/kl_l_k'][:, sl], rtol=rt, atol=at)
+    np.testing.assert_allclose(torch.stack(list(losses['kl_m_k'])).detach().cpu().numpy(), gold.g['out/kl_m_k'][:, sl], rtol=rt, atol=at)
+    tot = torch.stack([err.detach(), kl.detach()])
+    dist.all_reduce(tot)
+    tot /= world
+    elbo_ref = float(gold.g['loss/err']) + float(gold.g['loss/kl'])
+    assert abs(float(tot.sum()) - elbo_ref) <= 1e-4 * abs(elbo_ref), (tot, elbo_ref)
+    grads = {}
+    for n, p in model.named_parameters():
+        g = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().clone()
+        dist.all_reduce(g)
+        grads[n] = g / world
+    if rank == 0:
+        check_gradients(gold, grads, [], 'genesis_cfg3_b32 on two ranks, cross-replica BatchNorm')     # (GENESIS has no ReLU: the strict bar)
+    del model
+    # --- three training steps through TrainStep (GENESIS_SYNC_BN=1 arms the same switch per iteration)
+    ts = TrainStep(gold.build(), gold.S, lr=1e-4)
+    assert ts._sync_bn and ts.world == world
+    hist = gold.g['train_hist']
+    xs = x[sl].cuda()
+    for it in range(3):
+        out = ts.step(xs, **shard(gold.noise(1 + it))).cpu().numpy()
+        elbo, err_, kl_, beta = [float(v) for v in out]
+        tol = 1e-4 if it == 0 else 5e-4
+        assert abs(elbo - hist[it, 0]) <= tol * abs(hist[it, 0]), (it, out, hist[it])
+        np.testing.assert_allclose([err_, beta], hist[it, [1, 3]], rtol=5e-4)
+    assert abs(float(ts.geco.beta) - float(gold.g['train_beta_final'])) <= 1e-5 * float(gold.g['train_beta_final'])
+    bufs = torch.cat([b.detach().double().flatten().cpu() for b in ts.model.buffers()])
+    torch.save({'p': ts.flat_p.cpu(), 'bufs': bufs, 'geco': ts.geco.state.cpu()}, os.path.join(out_dir, 'g%d.pt' % rank))
+    ts.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_genesis_with_cross_replica_batchnorm_equals_the_reference_at_global_batch(tmp_path):
+    world = 2
+    mp.spawn(_worker_genesis_syncbn, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    g0 = torch.load(os.path.join(str(tmp_path), 'g0.pt'))
+    g1 = torch.load(os.path.join(str(tmp_path), 'g1.pt'))
+    for k in ('p', 'bufs', 'geco'):
+        assert torch.equal(g0[k], g1[k]), k          # lock-step, running statistics included

@@ -37,7 +37,7 @@ from genesis_amd import testing as T
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 GOLDEN = osp.join(osp.dirname(osp.abspath(__file__)), 'golden')
-CASES = ['v2_metric_b32', 'v2_cfg2_b64', 'v2_cfg5_b4', 'v2_cfg5_b32', 'genesis_cfg3_b32', 'monet_cfg4_b32']
+CASES = ['v2_metric_b32', 'v2_cfg2_b64', 'v2_cfg5_b4', 'v2_cfg5_b32', 'genesis_cfg3_b32', 'monet_cfg4_b32', 'v2_metric_b32_rect']
 GRAD_FACTOR = 5.0      # |HIP - reference| <= |HIP - fp64| + |reference - fp64| <= (4 + 1) x budget: the fp64 error-budget tests' own bar for the
                        # HIP path is 4 x the CPU fp32 error (tests/test_error_budget_gpu.py); measured without any ReLU allowance: GENESIS
                        # (no ReLU in the model) 3.5 x on one BatchNorm bias of 32 values, everything else <= 2.4 x
@@ -51,6 +51,7 @@ EXPECT_KERNELS = {
     'v2_cfg5_b32': ('wino_conv_kernel', 'kq_dth_kernel', 'kq_dgh_kernel', 'wgq_stream_kernel'),     # BASELINE config 5 at its per-GPU batch
     'genesis_cfg3_b32': ('kq_c3h_kernel', 'wgq_stream_kernel'),
     'monet_cfg4_b32': ('kq_c3h_kernel', 'wgq_stream_kernel'),
+    'v2_metric_b32_rect': ('wino_conv_kernel', 'kq_dth_kernel', 'kq_dgh_kernel', 'wgq_stream_kernel'),  # SURVEY 8(d)'s structured inputs
 }
 
 
@@ -143,7 +144,8 @@ class Full(object):
         return model.to(DEV).train()
 
     def x(self):
-        x = T.make_input(int(self.g['x_seed']), self.B, self.S)
+        kind = str(self.g['input_kind']) if 'input_kind' in self.g.files else 'rand'
+        x = T.make_input_of(kind, int(self.g['x_seed']), self.B, self.S)
         T.check_summary('in/x', x, self.g, 0, 0, self.name)
         return x
 
@@ -223,6 +225,35 @@ FWD_TOL = {
 }
 
 
+def check_gradients(gold, grads, differing, case):
+    """Per-parameter gradients against the reference's at the fixture's own budget: |HIP - reference| <= (4 + 1) x budget + 5e-5
+    in relative L2 on the strided samples and on the norm, + the ReLU allowance ONLY for parameters in front of a layer whose
+    ReLU pattern differs (`differing`: [(site, count difference)])."""
+    names = [str(n) for n in gold.g['param_names']]
+    norms, budget = gold.g['grad_norms'], gold.g['budget']
+    gmax = float(gold.g['grad_max_f64'])
+    worst, table = 0.0, []
+    for i, name in enumerate(names):
+        g = grads[name]
+        s = T.summarize(g)
+        ref = gold.g['grad/%s/samples' % name].astype(np.float64)
+        assert int(gold.g['grad/%s/n' % name]) == int(s['n']), name
+        # the budget is relative to max(|g64|, 1e-6 gmax) over the whole tensor; the same scale for its strided samples
+        den = max(float(gold.g['grad_norms_f64'][i]), 1e-6 * gmax) * np.sqrt(len(ref) / max(1, int(s['n'])))
+        e_samples = float(np.linalg.norm(s['samples'].astype(np.float64) - ref)) / den
+        e_norm = abs(float(g.double().norm()) - float(norms[i])) / max(float(gold.g['grad_norms_f64'][i]), 1e-6 * gmax)
+        flip = any(upstream_of(gold.fam, site, name) for site, _ in differing)
+        bar = GRAD_FACTOR * float(budget[i]) + GRAD_FLOOR + (RELU_FLIP if flip else 0.0)
+        table.append((max(e_samples, e_norm) / bar, name, e_samples, e_norm, float(budget[i]), flip))
+        worst = max(worst, max(e_samples, e_norm) / bar)
+    table.sort(reverse=True)
+    print('%s: worst gradient error / bar = %.3f; the five largest (samples rel-L2, norm rel, budget):' % (case, worst))
+    for r in table[:5]:
+        print('   %-52s %.2e %.2e  budget %.2e  (%.2f of the bar%s)' % (r[1], r[2], r[3], r[4], r[0], ', ReLU allowance' if r[5] else ''))
+    assert worst <= 1.0, table[0]
+    return worst
+
+
 def test_every_eligible_conv3x3_on_the_winograd_kernel_vs_reference():
     """The Winograd kernel on EVERY layer it supports (policy 2: also the 16 x 16 ... 64 x 64 levels that the default policy leaves
     to the direct kernels at this batch) of the 128 x 128 configuration, against the reference's full-batch fixture at the same
@@ -297,30 +328,8 @@ def test_default_dispatch_vs_reference_at_benchmark_batch(case, min_wino=0):
         assert any(k.startswith(kname) and v > 0 for k, v in rows.items()), (kname, sorted(rows))
     assert rows.get('wino_conv_kernel', 0) >= min_wino, rows
     # parameter gradients
-    names = [str(n) for n in gold.g['param_names']]
-    norms, budget = gold.g['grad_norms'], gold.g['budget']
-    gmax = float(gold.g['grad_max_f64'])
     named = dict(model.named_parameters())
-    worst, table = 0.0, []
-    for i, name in enumerate(names):
-        p = named[name]
-        g = p.grad if p.grad is not None else torch.zeros_like(p)
-        s = T.summarize(g)
-        ref = gold.g['grad/%s/samples' % name].astype(np.float64)
-        assert int(gold.g['grad/%s/n' % name]) == int(s['n']), name
-        # the budget is relative to max(|g64|, 1e-6 gmax) over the whole tensor; the same scale for its strided samples
-        den = max(float(gold.g['grad_norms_f64'][i]), 1e-6 * gmax) * np.sqrt(len(ref) / max(1, int(s['n'])))
-        e_samples = float(np.linalg.norm(s['samples'].astype(np.float64) - ref)) / den
-        e_norm = abs(float(g.double().norm()) - float(norms[i])) / max(float(gold.g['grad_norms_f64'][i]), 1e-6 * gmax)
-        flip = any(upstream_of(gold.fam, site, name) for site, _ in differing)
-        bar = GRAD_FACTOR * float(budget[i]) + GRAD_FLOOR + (RELU_FLIP if flip else 0.0)
-        table.append((max(e_samples, e_norm) / bar, name, e_samples, e_norm, float(budget[i]), flip))
-        worst = max(worst, max(e_samples, e_norm) / bar)
-    table.sort(reverse=True)
-    print('%s: worst gradient error / bar = %.3f; the five largest (samples rel-L2, norm rel, budget):' % (case, worst))
-    for r in table[:5]:
-        print('   %-52s %.2e %.2e  budget %.2e  (%.2f of the bar%s)' % (r[1], r[2], r[3], r[4], r[0], ', ReLU allowance' if r[5] else ''))
-    assert worst <= 1.0, table[0]
+    check_gradients(gold, {n: (p.grad if p.grad is not None else torch.zeros_like(p)) for n, p in named.items()}, differing, case)
     for key in ('log_m_k',) + (('log_m_r_k',) if gold.fam != 'genesis' else ()):
         assert float((torch.stack(list(stats[key]), 4).exp().sum(4) - 1).abs().max()) < 1e-3      # utils/misc.py:258-270
 

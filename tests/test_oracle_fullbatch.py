@@ -29,7 +29,7 @@ def _state_dict(g, template):
     return {k: v.detach().clone() for k, v in template.items()}
 
 
-@pytest.mark.parametrize('case', ['v2_cfg5_b4', 'monet_cfg4_b32'])
+@pytest.mark.parametrize('case', ['v2_cfg5_b4', 'monet_cfg4_b32', 'v2_metric_b32_rect'])
 @pytest.mark.timeout(600)
 def test_oracle_reproduces_the_reference_at_benchmark_batch(case):
     from genesis_amd.compat.attrdict import AttrDict
@@ -49,7 +49,7 @@ def test_oracle_reproduces_the_reference_at_benchmark_batch(case):
         model = G.load(AttrDict(dict(cfg, debug=False, multi_gpu=False)))
     sd = _state_dict(g, model.state_dict())
     p = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and k != 'std' else v.clone()) for k, v in sd.items()}
-    x = T.make_input(int(g['x_seed']), B, S)
+    x = T.make_input_of(str(g['input_kind']) if 'input_kind' in g.files else 'rand', int(g['x_seed']), B, S)
     T.check_summary('in/x', x, g, 0, 0, case)
     nseed = int(g['noise_seed'])
     if fam == 'v2':

@@ -561,3 +561,136 @@ def test_mse_rmse_kernel_exact():
         _lib.call('gx_mse_rmse', ctypes.c_void_p(xd.data_ptr()), ctypes.c_void_p(rd.data_ptr()), 5, 3 * 32 * 32,
                   ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(ws.data_ptr()), ws.numel() * 4, st)
     np.testing.assert_allclose(out.cpu().numpy(), [float(mse.mean()), float(mse.sqrt().mean())], rtol=2e-6)
+
+
+def _describe_ckpt(obj, path, out):
+    """The same flattening as tests/golden/make_golden_checkpoint.py:describe (structure only)."""
+    if torch.is_tensor(obj):
+        out[path] = ('tensor', str(obj.dtype).replace('torch.', ''), list(obj.shape), obj)
+    elif isinstance(obj, dict):
+        out[path] = (type(obj).__name__, '', [len(obj)], None)
+        for k, v in obj.items():
+            _describe_ckpt(v, '%s/%s%s' % (path, 'i:' if isinstance(k, int) else '', k), out)
+    elif isinstance(obj, (list, tuple)):
+        out[path] = (type(obj).__name__, '', [len(obj)], None)
+        for i, v in enumerate(obj):
+            _describe_ckpt(v, '%s/#%d' % (path, i), out)
+    else:
+        out[path] = (type(obj).__name__, repr(obj), [], None)
+
+
+def test_checkpoint_written_by_the_reference(tmp_path):
+    """tests/golden/ckpt_v2_tiny.npz is the manifest (key paths, Python types, dtypes, shapes, tensor summaries) of a file the
+    reference's OWN save_checkpoint (train.py:410-420) wrote after two of its training iterations on the `tiny` fixture, plus
+    the third iteration the reference computed after restoring it (train.py:179-207).  TrainStep after the same two steps must
+    hold that checkpoint: the same entries of the same types with the same values; a dict of exactly the manifest's structure
+    loads through TrainStep.load_state_dict, and the next step is the reference's third iteration."""
+    import json
+    import os.path as osp
+    import numpy as np
+    from collections import OrderedDict
+    from genesis_amd import testing as T
+    from genesis_amd.trainer import TrainStep
+    from tests.common import GOLDEN
+    g = np.load(osp.join(GOLDEN, 'ckpt_v2_tiny.npz'), allow_pickle=False)
+    manifest = json.loads(str(g['manifest_json']))
+    gold = Golden('tiny')
+    x, _, _ = gold.inputs()
+    xd = x.to(DEV)
+    noise = [gold.noise(1 + it) for it in range(3)]
+
+    def kw(it):
+        rp, eps = noise[it]
+        return dict(rand_pixel=rp.to(DEV), eps=torch.stack(eps).to(DEV))
+
+    ts = TrainStep(build(gold), gold.S, lr=1e-4, graph=False)
+    hist = [ts.step(xd, **kw(it)).cpu().double().numpy() for it in range(2)]
+    for it in range(2):
+        ref = g['hist'][it]
+        assert abs(hist[it][0] - ref[0]) <= 2e-4 * abs(ref[0]) and abs(hist[it][1] - ref[1]) <= 2e-4 * abs(ref[1])
+        assert abs(hist[it][3] - ref[3]) <= 1e-5 * abs(ref[3])        # beta used in the step
+    f = tmp_path / 'model.ckpt-1'
+    torch.save(ts.state_dict(1), f)
+    mine = {}
+    _describe_ckpt(torch.load(f, map_location='cpu', weights_only=False), '', mine)
+
+    # --- structure: the same paths, container types, scalar types and values, tensor dtypes and shapes
+    ref_paths = [m[0] for m in manifest]
+    assert sorted(mine) == sorted(ref_paths), sorted(set(mine) ^ set(ref_paths))[:10]
+    # (entry order inside the dicts torch.load hands to load_state_dict: OrderedDict of the model, parameter indices)
+    assert [p for p in mine if p.startswith('/model_state_dict/')] == [p for p in ref_paths if p.startswith('/model_state_dict/')]
+    worst = 0.0
+    for path, kind, desc, shape in manifest:
+        k2, d2, s2, t = mine[path]
+        if kind == 'tensor':
+            assert (k2, d2, s2) == (kind, desc, shape), (path, (k2, d2, s2), (kind, desc, shape))
+            scalarish = path.endswith('/step') or path in ('/beta', '/err_ema')
+            # parameters after two Adam steps of 1e-4: sign-like updates, so 1e-6 absolute on O(0.1) weights is round-off of
+            # round-off; moments: relative to the tensor (exp_avg_sq is quadratic in the gradient)
+            ref_asum = float(g['t/' + path + '/asum'])
+            n = int(g['t/' + path + '/n'])
+            scale = ref_asum / max(n, 1)
+            rtol = 1e-5 if scalarish else 2e-3
+            T.check_summary('t/' + path, t.double() if t.dtype == torch.float64 else t.float(), g, rtol, rtol * scale + 1e-12, path)
+        elif kind in ('dict', 'OrderedDict', 'list', 'tuple'):
+            assert (k2, s2) == (kind, shape), (path, k2, kind, s2, shape)
+        else:
+            assert k2 == kind, (path, k2, kind)
+            if kind == 'float':
+                assert abs(float(d2) - float(desc)) <= 1e-12 * abs(float(desc)), (path, d2, desc)
+            else:
+                assert d2 == desc, (path, d2, desc)
+
+    # --- a dict of EXACTLY the manifest's structure (what torch.load returns for the reference's file), filled from this
+    #     loop's state, restores through load_state_dict; the third step is the reference's third iteration
+    def build_from_manifest():
+        root = {}
+        nodes = {'': root}
+        for path, kind, desc, shape in manifest[1:]:
+            parent, key = path.rsplit('/', 1)
+            if kind == 'tensor':
+                val = mine[path][3].clone()
+            elif kind == 'OrderedDict':
+                val = OrderedDict()
+            elif kind == 'dict':
+                val = {}
+            elif kind == 'list':
+                val = []
+            elif kind == 'tuple':
+                val = None          # filled below from its children
+            else:
+                val = {'int': int, 'float': float, 'bool': lambda s: s == 'True', 'NoneType': lambda s: None, 'str': lambda s: s[1:-1]}[kind](desc)
+            nodes[path] = val
+            cont = nodes[parent]
+            if key.startswith('#'):
+                cont.append(val)
+            else:
+                cont[int(key[2:]) if key.startswith('i:') else key] = val
+        return root
+
+    tuples = [m[0] for m in manifest if m[1] == 'tuple']
+    if tuples:
+        # tuples (Adam's betas) are rebuilt as lists first, then frozen
+        for m in manifest:
+            if m[1] == 'tuple':
+                m[1] = 'list'
+        ck = build_from_manifest()
+        for path in tuples:
+            parent, key = path.rsplit('/', 1)
+            node = ck
+            for part in parent.strip('/').split('/'):
+                node = node[int(part[1:])] if part.startswith('#') else node[int(part[2:]) if part.startswith('i:') else part]
+            node[key] = tuple(node[key])
+    else:
+        ck = build_from_manifest()
+    assert set(ck) == {'model_state_dict', 'optimiser_state_dict', 'beta', 'err_ema', 'iter_idx'}
+    ts2 = TrainStep(build(gold), gold.S, lr=1e-4, graph=False)
+    assert ts2.load_state_dict(ck) == int(g['start_iter'])
+    third = ts2.step(xd, **kw(2)).cpu().double().numpy()
+    ref = g['hist'][2]
+    assert abs(third[0] - ref[0]) <= 2e-4 * abs(ref[0]), (third, ref)
+    assert abs(third[1] - ref[1]) <= 2e-4 * abs(ref[1]), (third, ref)
+    assert abs(third[3] - ref[3]) <= 1e-5 * abs(ref[3]), (third, ref)          # GECO's beta restored from the file
+    assert abs(float(ts2.geco.err_ema) - ref[4]) <= 1e-5 * abs(ref[4])
+    after = torch.cat([p.detach().double().flatten().float().cpu() for p in ts2.model.parameters()])
+    T.check_summary('after3/params', after, g, 1e-3, 2e-6, 'parameters after the third step')
