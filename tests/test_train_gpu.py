@@ -630,7 +630,8 @@ def test_checkpoint_written_by_the_reference(tmp_path):
             ref_asum = float(g['t/' + path + '/asum'])
             n = int(g['t/' + path + '/n'])
             scale = ref_asum / max(n, 1)
-            rtol = 1e-5 if scalarish else 2e-3
+            # (element-wise: the second moment is quadratic in the gradient, so a gradient element's round-off counts twice)
+            rtol = 1e-5 if scalarish else (1e-2 if path.endswith('exp_avg_sq') else 5e-3 if path.endswith('exp_avg') else 2e-3)
             T.check_summary('t/' + path, t.double() if t.dtype == torch.float64 else t.float(), g, rtol, rtol * scale + 1e-12, path)
         elif kind in ('dict', 'OrderedDict', 'list', 'tuple'):
             assert (k2, s2) == (kind, shape), (path, k2, kind, s2, shape)
