@@ -37,6 +37,24 @@ extern "C" int gx_kq_amax_link(float* parts, int capacity, size_t numel) {
     return GX_OK;
 }
 extern "C" int gx_kq_amax_link_hits(void) { return t_amax_link.hits; }
+namespace { thread_local GxAmaxTap t_amax_tap = {nullptr, 0, 0, 0}; }
+GxAmaxTap& gx_amax_tap_state(void) { return t_amax_tap; }
+extern "C" int gx_amax_tap(float* parts, int capacity, size_t numel) {
+    t_amax_tap.parts = (parts && capacity > 0 && numel > 0) ? parts : nullptr;
+    t_amax_tap.capacity = t_amax_tap.parts ? capacity : 0;
+    t_amax_tap.numel = t_amax_tap.parts ? numel : 0;
+    t_amax_tap.n = 0;
+    return GX_OK;
+}
+extern "C" int gx_amax_parts(const float* x, size_t n, float* parts, gx_stream_t stream) {
+    GX_CHECK_ARG(x && parts && n > 0, "gx_amax_parts: null pointer / empty tensor");
+    return gx_kq_amax_launch(x, n, parts, (hipStream_t)stream);
+}
+extern "C" int gx_amax_tap_result(void) {
+    const int n = t_amax_tap.parts ? 0 : t_amax_tap.n;      // (still armed: no producer served it)
+    t_amax_tap.parts = nullptr; t_amax_tap.capacity = 0; t_amax_tap.n = 0; t_amax_tap.numel = 0;
+    return n;
+}
 GxCtxFlags& gx_ctx_flags(void) { return g_ctx_flags[t_ctx]; }
 
 namespace {

@@ -207,6 +207,27 @@ int gx_kq_amax_launch(const float* x, size_t n, float* ws, hipStream_t s);
 // One-shot, per thread; any fp16 x 3 conv call clears it.
 struct GxAmaxLink { float* parts; int capacity; size_t numel; const float* tensor; int n; int hits; };      // numel: the WHOLE tensor's
 GxAmaxLink& gx_amax_link(void);          // (gx_api.cpp)
+// TAP (round 6): the same partial maxima for ANY later reader -- the weight-gradient stream-K launch at the end of the backward
+// pass needs the scale of BOTH operands of every layer (gx_wgq_operand_amax).  gx_amax_tap(parts, capacity, numel) arms a one-shot,
+// per-thread request: the next amax-capable producer launch (whatever its destination views: channel slices of concat buffers
+// and resampled second copies hold the same values) writes one partial maximum of the values it stores per workgroup and
+// records how many; gx_amax_tap_result() returns that count (0: the launch could not serve) and disarms.
+struct GxAmaxTap { float* parts; int capacity; int n; size_t numel; };      // numel: the elements the producer launch must cover
+GxAmaxTap& gx_amax_tap_state(void);      // (gx_api.cpp)
+// producer side, both mechanisms: where the launch of `nwg` workgroups writes its partial maxima (NULL: nowhere).  link_ok: the
+// destination qualifies for the armed link (a whole plain tensor of L.numel elements).
+inline float* gx_amax_producer_out(const float* tensor, bool link_ok, unsigned nwg, size_t covered) {
+    GxAmaxTap& T = gx_amax_tap_state();
+    GxAmaxLink& L = gx_amax_link();
+    float* p = nullptr;
+    // (a launch that covers only part of the tensor -- the chunked callers -- must not serve: its maxima are not the tensor's)
+    if (T.parts && (int)nwg <= T.capacity && covered == T.numel) { p = T.parts; T.n = (int)nwg; T.parts = nullptr; }
+    if (link_ok && L.parts && !L.tensor && tensor && (p || (int)nwg <= L.capacity)) {
+        if (p) L.parts = p; else p = L.parts;      // (one set of partials serves both readers)
+        L.tensor = tensor; L.n = (int)nwg;
+    }
+    return p;
+}
 // consumer side: partials of `x` if the armed link holds them (then *n > 0), clearing the link either way
 inline const float* gx_amax_link_take(const float* x, size_t numel, int* n) {
     GxAmaxLink& L = gx_amax_link();

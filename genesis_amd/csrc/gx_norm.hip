@@ -1042,16 +1042,15 @@ int small_threads(int cpg, int H, int W) {
 
 // an armed amax link (gx_kq_amax_link) is served when the kernel's first destination is a whole plain tensor (no channel slice, no
 // resampling): one partial maximum of the stored activation per workgroup for the conv that reads it next
-inline float* gn_take_link_out(const float* tensor, int ctot, int c0, int mode, int C, unsigned nwg, size_t covered) {
+inline float* gn_take_link_out(const float* tensor, int ctot, int c0, int mode, int C, unsigned nwg, size_t covered, bool second_copy = false) {
     GxAmaxLink& L = gx_amax_link();
-    if (!L.parts || L.tensor || !tensor || c0 != 0 || mode != 0 || ctot != C || (int)nwg > L.capacity || covered != L.numel) return nullptr;
-    L.tensor = tensor; L.n = (int)nwg;
-    return L.parts;
+    const bool link_ok = !second_copy && L.parts && !L.tensor && tensor && c0 == 0 && mode == 0 && ctot == C && covered == L.numel;
+    return gx_amax_producer_out(tensor, link_ok, nwg, covered);      // (+ an armed tap, gx_amax_tap: served whatever the destination views are)
 }
 template <int F, int UPW>
 void launch_fwd_reg(dim3 grid, dim3 block, hipStream_t s, const InSrc src, const float* gamma, const float* beta, int C, int H,
                     int W, int groups, int P, float eps, View d0, View d1, float* mean, float* rstd) {
-    float* ap = d1.ptr ? nullptr : gn_take_link_out(d0.ptr, d0.ctot, d0.c0, d0.mode, C, grid.x, (size_t)(grid.x / groups) * C * H * W);
+    float* ap = d0.ptr ? gn_take_link_out(d0.ptr, d0.ctot, d0.c0, d0.mode, C, grid.x, (size_t)(grid.x / groups) * C * H * W, d1.ptr != nullptr) : nullptr;
     hipLaunchKernelGGL((gn_relu_fwd_reg_kernel<F, UPW>), grid, block, 0, s, src, gamma, beta, C, H, W, groups, P, eps, d0, d1,
                        mean, rstd, ap);
 }

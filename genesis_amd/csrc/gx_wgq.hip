@@ -421,8 +421,16 @@ typedef const __attribute__((address_space(1))) f32x4* gx_gptr4;
 // to keep two of the four waves multiplying zero rows.  There the waves of such a pair take the SAME 32 channels and every
 // other k-group of the tile instead (wave -> k-groups ksel, ksel + KS, ...); the pair's accumulators are summed through LDS
 // once per segment.  The tile's MFMA chain is half (a quarter) as long, its staging work unchanged.
+// F16 (round 6, WC += 100000): the operands as TWO fp16 pieces of x * 2^e (e per TENSOR from its largest magnitude, handed over by
+// the kernels that wrote the tensors: gx_wgq_operand_amax) instead of three bf16 ones -- hi*hi + hi*lo + lo*hi, three MFMAs per 16
+// pixels and tap instead of six (findings 40 and 42), two piece planes in LDS instead of three, a 24-VALU split
+// per octet instead of 44; the accumulators are scaled back by 2^-(eA + eB) when the slab is written.
 template <int CLS, int WC> struct WrGeo {
-    static constexpr int HF = WC / 1000, W = WC % 1000;
+    static constexpr bool F16 = WC >= 100000;
+    static constexpr int HF = (WC / 1000) % 100, W = WC % 1000;
+    static constexpr int NPL = F16 ? 2 : 3;                    // piece planes per operand
+    static constexpr int NTERM = F16 ? 3 : 6;                  // piece products per fp32 product
+    static constexpr int SPQ = F16 ? 6 : 14;                   // split pieces (slots) per octet
     static constexpr int KS = HF == 3 ? 4 : (HF ? 2 : 1);
     using WT = WqTap<CLS>;
     static constexpr int SA = WT::SA, NPB = WT::NPB, NT = WT::NT, NRO = WT::NRO, RO0 = WT::RO0;
@@ -459,12 +467,13 @@ template <int CLS, int WC> struct WrGeo {
     static constexpr int AGS1 = R2 ? 48 : 32;                  // bytes from a k-group's octets to the next one's in an A row
     static constexpr int AGS = AGS1 * KS;                      // ... to this wave's next one
     static constexpr int A_PLANE = (64 * APITCH + 1) * 16;     // bytes (one leading zero piece)
-    static constexpr int A_BUF = NPB * 3 * A_PLANE;            // one A buffer: column parities x planes
+    static constexpr int A_BUF = NPB * NPL * A_PLANE;          // one A buffer: column parities x planes
     static constexpr int B_ROW = 64 * OPR * 16;                // one x row of one plane
     static constexpr int B_PLANE = 4 * B_ROW + 16;             // four ring slots + the zero piece
     static constexpr int B_ZERO = 4 * B_ROW;                   // offset of the zero piece inside a plane
     static constexpr int RING0 = 2 * A_BUF;                    // byte offset of the ring
-    static constexpr int LDS_BYTES = RING0 + 3 * B_PLANE;
+    static constexpr int LDS_BYTES = RING0 + NPL * B_PLANE;
+    static_assert(!(F16 && NS > 1), "the strip forms (seam values) exist on the bf16 pieces only");
     __host__ __device__ static constexpr int fsw(int ch) { return (ch * OPR / 16) & (OPR - 1); }
     // float offset of the dy row of tile row `ra` of image `ia` (H tile rows per image) / of its x row
     // (ia / ib: VIRTUAL image = image * NS + strip)
@@ -491,6 +500,23 @@ __device__ __forceinline__ void wr_split8(const float (&v)[8], gx_u32x4& ph, gx_
     ph = __builtin_bit_cast(gx_u32x4, vh); pm = __builtin_bit_cast(gx_u32x4, vm); pl = __builtin_bit_cast(gx_u32x4, vl);
 }
 
+// two fp16 pieces of v * sc (sc a power of two): hi = the top 11 significant bits (a mask: exactly representable, so the residual
+// is exact and the conversion of hi cannot round), lo = the residual rounded to nearest -- 22 significant bits, error of random sign
+typedef float gx_f32p __attribute__((ext_vector_type(2)));
+typedef _Float16 gx_f16p __attribute__((ext_vector_type(2)));
+typedef _Float16 gx_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void wr_split_f16_pair(float v0, float v1, float sc, unsigned& hp, unsigned& lp) {
+    const float s0 = v0 * sc, s1 = v1 * sc;
+    const float h0 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, s0) & 0xFFFFE000u);
+    const float h1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, s1) & 0xFFFFE000u);
+    hp = __builtin_bit_cast(unsigned, __builtin_convertvector(gx_f32p{h0, h1}, gx_f16p));
+    lp = __builtin_bit_cast(unsigned, __builtin_convertvector(gx_f32p{s0 - h0, s1 - h1}, gx_f16p));
+}
+__device__ __forceinline__ void wr_split8_f16(const float (&v)[8], float sc, gx_u32x4& ph, gx_u32x4& pl) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { unsigned h, l; wr_split_f16_pair(v[2 * i], v[2 * i + 1], sc, h, l); ph[i] = h; pl[i] = l; }
+}
+
 // per-thread constants of a segment
 template <int CLS, int W> struct WrT {
     using G = WrGeo<CLS, W>;
@@ -504,6 +530,7 @@ template <int CLS, int W> struct WrT {
     // strips: this thread's seam item (channel tid >> 2, side (tid >> 1) & 1: 0 left / 1 right, column parity tid & 1)
     int goffS, stS, sideS;                 // float offset from the strip's dy row origin; LDS byte offset inside an A buffer
     bool okS;
+    float scA, scB;                        // F16: the operands' power-of-two scales 2^eA, 2^eB
 };
 
 // the dy value next to a strip: global address select (the zero page beyond the image edge / for idle items)
@@ -571,11 +598,17 @@ __device__ __forceinline__ void wr_store(char* lds, const WrT<CLS, W>& w, int ab
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = pa[j][(SA * i + par) >> 2][(SA * i + par) & 3];   // de-interleave the column parities
                 gx_u32x4 ph, pm, pl;
+                char* d = lds + abuf + par * G::NPL * G::A_PLANE + w.stA[j];
+                if constexpr (G::F16) {
+                    wr_split8_f16(v, w.scA, ph, pm);
+                    *reinterpret_cast<gx_u32x4*>(d) = ph;
+                    *reinterpret_cast<gx_u32x4*>(d + G::A_PLANE) = pm;
+                } else {
                 wr_split8(v, ph, pm, pl);
-                char* d = lds + abuf + par * 3 * G::A_PLANE + w.stA[j];
                 *reinterpret_cast<gx_u32x4*>(d) = ph;
                 *reinterpret_cast<gx_u32x4*>(d + G::A_PLANE) = pm;
                 *reinterpret_cast<gx_u32x4*>(d + 2 * G::A_PLANE) = pl;
+                }
             }
         }
         if (DOB) {
@@ -583,11 +616,17 @@ __device__ __forceinline__ void wr_store(char* lds, const WrT<CLS, W>& w, int ab
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = pb[j][i >> 2][i & 3];
             gx_u32x4 ph, pm, pl;
-            wr_split8(v, ph, pm, pl);
             char* d = lds + G::RING0 + bslot + w.stB[j];
+            if constexpr (G::F16) {
+                wr_split8_f16(v, w.scB, ph, pm);
+                *reinterpret_cast<gx_u32x4*>(d) = ph;
+                *reinterpret_cast<gx_u32x4*>(d + G::B_PLANE) = pm;
+            } else {
+            wr_split8(v, ph, pm, pl);
             *reinterpret_cast<gx_u32x4*>(d) = ph;
             *reinterpret_cast<gx_u32x4*>(d + G::B_PLANE) = pm;
             *reinterpret_cast<gx_u32x4*>(d + 2 * G::B_PLANE) = pl;
+            }
         }
     }
 }
@@ -617,18 +656,19 @@ template <int CLS, int W> struct WrSched {
     static_assert(NG == 1 || NG % 2 == 0, "the operand sets alternate by k-group");
     static constexpr int NU = NG * NRO;                       // units per tile
     static constexpr int NCO = G::NT / NRO;                   // taps per unit
-    static constexpr int NMF = 6 * NCO;                       // MFMAs (slots) per unit
+    static constexpr int NPL = G::NPL;
+    static constexpr int NMF = G::NTERM * NCO;                // MFMAs (slots) per unit
     static constexpr int NOCT = G::UPT * (NPB + 1);           // octets this thread splits per tile
-    static constexpr int NQ = 14 * NOCT + (G::NS > 1 ? 3 : 0);     // split pieces (strips: + the seam value's split | split | stores)
+    static constexpr int NQ = G::SPQ * NOCT + (G::NS > 1 ? 3 : 0); // split pieces (strips: + the seam value's split | split | stores)
     static constexpr int NFE = 2 * G::UPT + (G::NS > 1 ? 1 : 0);   // fetch pieces (unit 0): the dy / x loads of unit j (+ the seam load)
     // the last unit ends with: the tile's barrier, then the NEXT tile's first operands (B of its unit 0, A octets and
     // funnel shifts of its group 0) under this tile's last MFMAs
-    static constexpr int NTAIL = 2 + 3 * NPB + 6 * NPB;
+    static constexpr int NTAIL = 2 + NPL * NPB + 2 * NPL * NPB;
     __host__ __device__ static constexpr bool more(int u) { return u + 1 < NU; }
     __host__ __device__ static constexpr bool newg(int u) { return u % NRO == 0 && u / NRO + 1 < NG; }
     __host__ __device__ static constexpr bool lastr(int u) { return u % NRO == NRO - 1 && u / NRO + 1 < NG; }
     __host__ __device__ static constexpr int nfix(int u) {
-        return (more(u) ? 1 : 0) + (newg(u) ? 3 * NPB : 0) + (lastr(u) ? 6 * NPB : 0) + (u == 0 ? NFE : 0);
+        return (more(u) ? 1 : 0) + (newg(u) ? NPL * NPB : 0) + (lastr(u) ? 2 * NPL * NPB : 0) + (u == 0 ? NFE : 0);
     }
     __host__ __device__ static constexpr int nfree(int u) { return NMF - nfix(u) - (u == NU - 1 ? NTAIL : 0); }
     // split pieces per free slot: 1 unless the tile's MFMA chain is too short for them (the k-split forms of the 32-pixel rows)
@@ -685,8 +725,8 @@ __device__ __forceinline__ void wr_split_piece(char* lds, const WrT<CLS, W>& w, 
                                                const f32x4 (&pb)[WrGeo<CLS, W>::UPT][2]) {
     using G = WrGeo<CLS, W>;
     constexpr int SA = G::SA, NPB = G::NPB;
-    if constexpr (Q >= 14 * G::UPT * (NPB + 1)) {          // strips: the seam value (r[0..1], hp[0..2] are free by now)
-        constexpr int step = Q - 14 * G::UPT * (NPB + 1);
+    if constexpr (Q >= G::SPQ * G::UPT * (NPB + 1)) {      // strips: the seam value (r[0..1], hp[0..2] are free by now)
+        constexpr int step = Q - G::SPQ * G::UPT * (NPB + 1);
         if constexpr (step == 0) {
             const __bf16 h = (__bf16)st.sv;
             st.r[0] = st.sv - (float)h;
@@ -702,11 +742,22 @@ __device__ __forceinline__ void wr_split_piece(char* lds, const WrT<CLS, W>& w, 
         }
         return;
     } else {
-    constexpr int oi = Q / 14, step = Q % 14, j = oi / (NPB + 1), k = oi % (NPB + 1);
+    constexpr int oi = Q / G::SPQ, step = Q % G::SPQ, j = oi / (NPB + 1), k = oi % (NPB + 1);
     constexpr bool isA = k < NPB;
     float v[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = isA ? pa[j][(SA * i + k) >> 2][(SA * i + k) & 3] : pb[j][i >> 2][i & 3];
+    if constexpr (G::F16) {
+        // fp16 pieces: steps 0..3 one PAIR each (scale | mask | residual | two packed conversions: 6 VALU), 4 / 5 the two stores
+        if constexpr (step < 4) {
+            wr_split_f16_pair(v[2 * step], v[2 * step + 1], isA ? w.scA : w.scB, st.hp[step], st.mp[step]);
+        } else {
+            char* d = isA ? lds + anxt + k * G::NPL * G::A_PLANE + w.stA[j] : lds + G::RING0 + bnew + w.stB[j];
+            constexpr int ps = isA ? G::A_PLANE : G::B_PLANE;
+            const unsigned* src = step == 4 ? st.hp : st.mp;
+            *reinterpret_cast<gx_u32x4*>(d + (step - 4) * ps) = gx_u32x4{src[0], src[1], src[2], src[3]};
+        }
+    } else
     if (step == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) st.hp[i] = wr_pk(v[2 * i], v[2 * i + 1]);
@@ -735,7 +786,7 @@ __device__ __forceinline__ void wr_split_piece(char* lds, const WrT<CLS, W>& w, 
 template <int CLS, int W>
 __device__ __forceinline__ void wr_read_a1(const char* lds, const WrT<CLS, W>& w, int abuf, int g, int par, int pl, WrRaw<CLS, W>& r) {
     using G = WrGeo<CLS, W>;
-    const char* p = lds + abuf + (par * 3 + pl) * G::A_PLANE + w.a_rd + g * G::AGS;
+    const char* p = lds + abuf + (par * G::NPL + pl) * G::A_PLANE + w.a_rd + g * G::AGS;
     r.c[par][pl] = *reinterpret_cast<const gx_u32x4*>(p);
     r.pv[par][pl] = *reinterpret_cast<const unsigned*>(p - 4);
     r.nx[par][pl] = *reinterpret_cast<const unsigned*>(p + 16);
@@ -774,7 +825,7 @@ __device__ __forceinline__ void wr_read_b(const char* lds, const WrT<CLS, W>& w,
     const char* p = lds + G::RING0 + (zr ? G::B_ZERO : bs + w.b_rd[g]);
     b3.h = wr_bf(*reinterpret_cast<const gx_u32x4*>(p));
     b3.m = wr_bf(*reinterpret_cast<const gx_u32x4*>(p + G::B_PLANE));
-    b3.l = wr_bf(*reinterpret_cast<const gx_u32x4*>(p + 2 * G::B_PLANE));
+    if constexpr (!G::F16) b3.l = wr_bf(*reinterpret_cast<const gx_u32x4*>(p + 2 * G::B_PLANE));
 }
 
 // fetch piece i: the dy (i even) / x (i odd) loads of load unit i / 2
@@ -807,10 +858,10 @@ __device__ __forceinline__ void wr_fetch_piece(const WrT<CLS, W>& w, int ta, int
 template <int CLS, int W, int I>
 __device__ __forceinline__ void wr_head_piece(const char* lds, const WrT<CLS, W>& w, int abuf, const int (&bs)[WrGeo<CLS, W>::NRO],
                                               const bool (&zr)[WrGeo<CLS, W>::NRO], WrTileState<CLS, W>& st) {
-    constexpr int NPB = WrGeo<CLS, W>::NPB;
+    constexpr int NPB = WrGeo<CLS, W>::NPB, NPL = WrGeo<CLS, W>::NPL;
     if (I == 0) wr_read_b<CLS, W>(lds, w, WrGeo<CLS, W>::b_g(0, 0), bs[WrGeo<CLS, W>::b_rr(0, 0)], zr[WrGeo<CLS, W>::b_rr(0, 0)], st.bq[0]);
-    else if (I < 1 + 3 * NPB) wr_read_a1<CLS, W>(lds, w, abuf, 0, (I - 1) / 3, (I - 1) % 3, st.raw);
-    else wr_shift_a1<CLS, W>(st.raw, st.av[0], (I - 1 - 3 * NPB) / 6, ((I - 1 - 3 * NPB) % 6) / 2, (I - 1 - 3 * NPB) % 2);
+    else if (I < 1 + NPL * NPB) wr_read_a1<CLS, W>(lds, w, abuf, 0, (I - 1) / NPL, (I - 1) % NPL, st.raw);
+    else wr_shift_a1<CLS, W>(st.raw, st.av[0], (I - 1 - NPL * NPB) / (2 * NPL), ((I - 1 - NPL * NPB) % (2 * NPL)) / 2, (I - 1 - NPL * NPB) % 2);
 }
 
 // the split pieces Q .. Q + N - 1 (those that exist)
@@ -843,9 +894,13 @@ __device__ __forceinline__ void wr_slot(char* lds, const WrT<CLS, W>& w, const W
         const WqB3& a3 = st.av[as][WT::pb(tap)][WT::co(tap)];
         const WqB3& b3 = st.bq[U & 1];
         constexpr int term = M / S::NCO;
-        const gx_bf16x8 ao = term == 0 ? a3.m : (term == 1 ? a3.l : (term == 3 ? a3.m : a3.h));
-        const gx_bf16x8 bo = term == 0 ? b3.m : (term == 2 ? b3.l : (term == 4 ? b3.m : b3.h));
+        // bf16 pieces: m*m, l*h, h*l, m*h, h*m, h*h; fp16 pieces (plane 1 = lo, kept in .m): lo*hi, hi*lo, hi*hi
+        const gx_bf16x8 ao = G::F16 ? (term == 0 ? a3.m : a3.h) : (term == 0 ? a3.m : (term == 1 ? a3.l : (term == 3 ? a3.m : a3.h)));
+        const gx_bf16x8 bo = G::F16 ? (term == 1 ? b3.m : b3.h) : (term == 0 ? b3.m : (term == 2 ? b3.l : (term == 4 ? b3.m : b3.h)));
 #if !(GX_WR_ABL & 1)
+        if constexpr (G::F16)
+            acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gx_f16x8, ao), __builtin_bit_cast(gx_f16x8, bo), acc[tap], 0, 0, 0);
+        else
         acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ao, bo, acc[tap], 0, 0, 0);
 #else
         acc[tap][M % 16] += __builtin_bit_cast(float, __builtin_bit_cast(gx_u32x4, ao)[0] ^ __builtin_bit_cast(gx_u32x4, bo)[1]);
@@ -853,13 +908,14 @@ __device__ __forceinline__ void wr_slot(char* lds, const WrT<CLS, W>& w, const W
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- the piece
-    constexpr int n_b = S::more(U) ? 1 : 0, n_ra = S::newg(U) ? 3 * NPB : 0, n_sh = S::lastr(U) ? 6 * NPB : 0;
+    constexpr int NPL = G::NPL;
+    constexpr int n_b = S::more(U) ? 1 : 0, n_ra = S::newg(U) ? NPL * NPB : 0, n_sh = S::lastr(U) ? 2 * NPL * NPB : 0;
     constexpr int n_fe = U == 0 ? S::NFE : 0;
     constexpr int tail0 = U == S::NU - 1 ? S::NMF - S::NTAIL : S::NMF;      // first tail slot
     if constexpr (M >= tail0) {
         if constexpr (M == tail0) __syncthreads();         // the rows of the next tile are in LDS; this tile's reads are done
 #if !(GX_WR_ABL & 8)
-        else if constexpr (!S::NG1 || (M - tail0 - 1 >= 1 && M - tail0 - 1 < 1 + 3 * NPB))
+        else if constexpr (!S::NG1 || (M - tail0 - 1 >= 1 && M - tail0 - 1 < 1 + NPL * NPB))
             wr_head_piece<CLS, W, M - tail0 - 1>(lds, w, sp.anxt, sp.nbs, sp.nzr, st);
 #endif
     }
@@ -870,9 +926,9 @@ __device__ __forceinline__ void wr_slot(char* lds, const WrT<CLS, W>& w, const W
         constexpr int g1 = (U + 1) / NRO, r1 = (U + 1) % NRO;
         wr_read_b<CLS, W>(lds, w, G::b_g(g1, r1), sp.bs[G::b_rr(g1, r1)], sp.zr[G::b_rr(g1, r1)], st.bq[(U + 1) & 1]);
     } else if constexpr (M < n_b + n_ra) {
-        wr_read_a1<CLS, W>(lds, w, sp.abuf, g + 1, (M - n_b) / 3, (M - n_b) % 3, st.raw);
+        wr_read_a1<CLS, W>(lds, w, sp.abuf, g + 1, (M - n_b) / NPL, (M - n_b) % NPL, st.raw);
     } else if constexpr (M < n_b + n_ra + n_sh) {
-        wr_shift_a1<CLS, W>(st.raw, st.av[as ^ 1], (M - n_b - n_ra) / 6, ((M - n_b - n_ra) % 6) / 2, (M - n_b - n_ra) % 2);
+        wr_shift_a1<CLS, W>(st.raw, st.av[as ^ 1], (M - n_b - n_ra) / (2 * NPL), ((M - n_b - n_ra) % (2 * NPL)) / 2, (M - n_b - n_ra) % 2);
     } else if constexpr (M < n_b + n_ra + n_sh + n_fe) {
 #if !(GX_WR_ABL & 4)
         wr_fetch_piece<CLS, W, M - n_b - n_ra - n_sh>(w, sp.ta, sp.tb, pa, pb, st.sv);
@@ -891,16 +947,16 @@ __device__ __forceinline__ void wr_slot(char* lds, const WrT<CLS, W>& w, const W
 template <int CLS, int W, int I>
 __device__ __forceinline__ void wr_head(const char* lds, const WrT<CLS, W>& w, int abuf, const int (&bs)[WrGeo<CLS, W>::NRO],
                                         const bool (&zr)[WrGeo<CLS, W>::NRO], WrTileState<CLS, W>& st) {
-    constexpr int NPB = WrGeo<CLS, W>::NPB;
-    if constexpr (!WrSched<CLS, W>::NG1 || (I >= 1 && I < 1 + 3 * NPB)) wr_head_piece<CLS, W, I>(lds, w, abuf, bs, zr, st);
+    constexpr int NPB = WrGeo<CLS, W>::NPB, NPL = WrGeo<CLS, W>::NPL;
+    if constexpr (!WrSched<CLS, W>::NG1 || (I >= 1 && I < 1 + NPL * NPB)) wr_head_piece<CLS, W, I>(lds, w, abuf, bs, zr, st);
     if constexpr (I + 2 < WrSched<CLS, W>::NTAIL) wr_head<CLS, W, I + 1>(lds, w, abuf, bs, zr, st);
 }
 // NG1: what the tail left out -- B of unit 0 and the funnel shifts of group 0, in front of the tile's first MFMA
 template <int CLS, int W, int I>
 __device__ __forceinline__ void wr_tile_start(const char* lds, const WrT<CLS, W>& w, int abuf, const int (&bs)[WrGeo<CLS, W>::NRO],
                                               const bool (&zr)[WrGeo<CLS, W>::NRO], WrTileState<CLS, W>& st) {
-    constexpr int NPB = WrGeo<CLS, W>::NPB;
-    if constexpr (I == 0 || I >= 1 + 3 * NPB) wr_head_piece<CLS, W, I>(lds, w, abuf, bs, zr, st);
+    constexpr int NPB = WrGeo<CLS, W>::NPB, NPL = WrGeo<CLS, W>::NPL;
+    if constexpr (I == 0 || I >= 1 + NPL * NPB) wr_head_piece<CLS, W, I>(lds, w, abuf, bs, zr, st);
     if constexpr (I + 2 < WrSched<CLS, W>::NTAIL) wr_tile_start<CLS, W, I + 1>(lds, w, abuf, bs, zr, st);
 }
 
@@ -908,7 +964,8 @@ __device__ __forceinline__ void wr_tile_start(const char* lds, const WrT<CLS, W>
 // accumulated in registers and written as one slab [tap][64][64].
 template <int CLS, int W>
 __device__ __forceinline__ void wr_segment(const float* a, const float* b, const float* zeros, char* lds, int N, int CA,
-                                           int CB, int ca0, int cb0, int H, int t0, int t1, float* slab) {
+                                           int CB, int ca0, int cb0, int H, int t0, int t1, float* slab,
+                                           const float* amax2 = nullptr) {
     using G = WrGeo<CLS, W>;
     using WT = typename G::WT;
     constexpr int NT = G::NT, NRO = G::NRO, RO0 = G::RO0, OPR = G::OPR, SA = G::SA, WE = G::WE;
@@ -917,6 +974,14 @@ __device__ __forceinline__ void wr_segment(const float* a, const float* b, const
     WrT<CLS, W> w;
     w.a = a; w.b = b; w.zeros = zeros; w.CA = CA; w.CB = CB; w.ca0 = ca0; w.cb0 = cb0; w.H = H;
     w.lh = 31 - __builtin_clz(H); w.ntot = N * G::NS * H;
+    // F16: amax2 = {max |dy|, max |x|} of the two operand TENSORS (uniform loads); x * 2^e with max |x| * 2^e in [2^14, 2^15)
+    int f16_e = 0;
+    w.scA = w.scB = 1.f;
+    if constexpr (G::F16) {
+        const int ea = gx_f16_scale_exp(amax2[0]), eb = gx_f16_scale_exp(amax2[1]);
+        w.scA = ldexpf(1.f, ea); w.scB = ldexpf(1.f, eb);
+        f16_e = -(ea + eb);
+    }
 #pragma unroll
     for (int j = 0; j < G::UPT; ++j) {
         const int ch = tid / OPR + j * G::CPS, o = tid % OPR;
@@ -935,7 +1000,7 @@ __device__ __forceinline__ void wr_segment(const float* a, const float* b, const
         w.goffS = ch * (SA * H) * (SA * G::PITCH) + (side ? SA * WE + par : par - SA);
         // left of channel ch: the last bf16 of the piece in front of its row; right: the first bf16 of the piece behind it;
         // idle items (no second parity): bytes 4..5 of the leading piece, which nothing reads
-        w.stS = par < G::NPB ? par * 3 * G::A_PLANE + (side ? (1 + ch * G::APITCH + OPR) * 16 : ch * G::APITCH * 16 + 14) : 4;
+        w.stS = par < G::NPB ? par * G::NPL * G::A_PLANE + (side ? (1 + ch * G::APITCH + OPR) * 16 : ch * G::APITCH * 16 + 14) : 4;
     }
     const int wm = wave >> 1, wn = wave & 1, h = lane >> 5;
     // k-split: which of the KS interleaved k-group sets this wave takes; the waves of a set share their channels
@@ -951,10 +1016,10 @@ __device__ __forceinline__ void wr_segment(const float* a, const float* b, const
         for (int i = tid; i < 2 * G::A_BUF / 16; i += 256) *reinterpret_cast<gx_u32x4*>(lds + i * 16) = gx_u32x4{0u, 0u, 0u, 0u};
         __syncthreads();      // (this fill covers the data pieces too: it must land before the prologue's stores of other threads)
     }
-    for (int i = tid; i < 2 * G::NPB * 3 * 65 + 3; i += 256) {
+    for (int i = tid; i < 2 * G::NPB * G::NPL * 65 + G::NPL; i += 256) {
         const int plane = i / 65, k = i - plane * 65;
-        char* d = plane < 2 * G::NPB * 3 ? lds + plane * G::A_PLANE + (k == 0 ? 0 : k * G::APITCH) * 16
-                                         : lds + G::RING0 + k * G::B_PLANE + G::B_ZERO;
+        char* d = plane < 2 * G::NPB * G::NPL ? lds + plane * G::A_PLANE + (k == 0 ? 0 : k * G::APITCH) * 16
+                                              : lds + G::RING0 + k * G::B_PLANE + G::B_ZERO;
         *reinterpret_cast<gx_u32x4*>(d) = gx_u32x4{0u, 0u, 0u, 0u};
     }
 
@@ -1044,16 +1109,17 @@ __device__ __forceinline__ void wr_segment(const float* a, const float* b, const
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-            dst[(size_t)row * 64] = acc[t][reg];
+            dst[(size_t)row * 64] = G::F16 ? ldexpf(acc[t][reg], f16_e) : acc[t][reg];
         }
     }
 }
 
 template <int CLS, int W>
 __device__ __attribute__((noinline)) void wr_segment_call(const float* a, const float* b, const float* zeros, int N, int CA,
-                                                          int CB, int ca0, int cb0, int H, int t0, int t1, float* slab) {
+                                                          int CB, int ca0, int cb0, int H, int t0, int t1, float* slab,
+                                                          const float* amax2 = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
-    wr_segment<CLS, W>(a, b, zeros, reinterpret_cast<char*>(lds_dyn), N, CA, CB, ca0, cb0, H, t0, t1, slab);
+    wr_segment<CLS, W>(a, b, zeros, reinterpret_cast<char*>(lds_dyn), N, CA, CB, ca0, cb0, H, t0, t1, slab, amax2);
 }
 
 // ---- grouped launch: the jobs of one (class, tile width), every workgroup one strided segment
@@ -1090,6 +1156,7 @@ struct WsJob {
     int cost;                                            // units per tile
     int w_first;                                         // first workgroup with tiles of this block (slab 0)
     int N;                                               // images (the row-ring variants bound their virtual rows with it)
+    const float* amax2;                                  // variants 128 + ..: {max |a|, max |b|} of the operand tensors (fp16 pieces)
 };
 constexpr int kMaxSJobs = 36;                            // 36 x 96 B: the table travels as a kernel argument
 struct WsTable { long long U; int njobs, G; long long* times; WsJob job[kMaxSJobs]; };   // times: GENESIS_WGQ_TIMES (NULL otherwise)
@@ -1140,6 +1207,11 @@ wgq_stream_kernel(const WsTable tab, const float* __restrict__ zeros) {
         case V_:                                                                                                    \
             wr_segment_call<CLS_, W_>(jb.a, jb.b, zeros, jb.N, jb.CA, jb.CB, jb.ca0, jb.cb0, jb.Hb, t0, t1, slab);  \
             break;
+        // the same tiles on TWO fp16 pieces per operand (variant + 128: both operands' maxima are known)
+#define GX_WF_CASE(V_, CLS_, W_)                                                                                    \
+        case 128 + V_:                                                                                              \
+            wr_segment_call<CLS_, 100000 + W_>(jb.a, jb.b, zeros, jb.N, jb.CA, jb.CB, jb.ca0, jb.cb0, jb.Hb, t0, t1, slab, jb.amax2); \
+            break;
         switch (jb.variant) {
             GX_WS_CASE(0, WQ_C3, 5) GX_WS_CASE(1, WQ_C3, 4) GX_WS_CASE(2, WQ_C3, 3)
             GX_WS_CASE(3, WQ_DR0, 5) GX_WS_CASE(4, WQ_DR0, 4) GX_WS_CASE(5, WQ_DR0, 3)
@@ -1155,10 +1227,13 @@ wgq_stream_kernel(const WsTable tab, const float* __restrict__ zeros) {
             GX_WR_CASE(64 + 18, WQ_C3, 2064) GX_WR_CASE(64 + 19, WQ_C3, 2032) GX_WR_CASE(64 + 20, WQ_DR0, 2032) GX_WR_CASE(64 + 21, WQ_DR1, 2032)
             GX_WR_CASE(64 + 22, WQ_C5A, 2064) GX_WR_CASE(64 + 23, WQ_C5A, 2032) GX_WR_CASE(64 + 24, WQ_C5B, 2064) GX_WR_CASE(64 + 25, WQ_C5B, 2032)
             GX_WR_CASE(96 + 18, WQ_C3, 3064)
+            GX_WF_CASE(18, WQ_C3, 64) GX_WF_CASE(19, WQ_C3, 32) GX_WF_CASE(20, WQ_DR0, 32) GX_WF_CASE(21, WQ_DR1, 32)
+            GX_WF_CASE(26, WQ_C3, 16) GX_WF_CASE(27, WQ_DR0, 16) GX_WF_CASE(28, WQ_DR1, 16)
             default: break;
         }
 #undef GX_WS_CASE
 #undef GX_WR_CASE
+#undef GX_WF_CASE
         __syncthreads();          // the next segment's first DMA re-uses stage 0
     }
     if (tab.times && threadIdx.x == 0) {          // measurement: when did this workgroup start and finish
@@ -1175,6 +1250,9 @@ struct PendingJob {
     float* dw; int layout;          // where the reduce writes
     double flops;
     int reduce_group;               // jobs of one transposed-conv layer share a reduce record (index of the first)
+    // the operands' partial maxima (gx_wgq_operand_amax): a (dy) in up to two arrays, b (x) in up to two; am_out: two floats
+    // that receive {max |a|, max |b|} ahead of the stream-K launch.  am_out == NULL: unknown -> bf16 pieces
+    const float* am_p[4]; int am_n[4]; float* am_out;
 };
 std::vector<PendingJob> g_jobs_ctx[kGxMaxCtx];      // queued jobs of each context (gx_common.h)
 #define g_jobs (g_jobs_ctx[gx_cur_ctx()])
@@ -1190,6 +1268,54 @@ const float* zero16(hipStream_t s) {
     g_zero16 = p;
     return g_zero16;
 }
+
+// ---- the operands' maxima for the fp16-piece tiles (gx_wgq_operand_amax): a one-shot, per-thread hint that the NEXT weight-gradient
+// call copies into its job(s)
+struct WqAmaxHint { const float* p[4]; int n[4]; float* out; };
+thread_local WqAmaxHint t_amax_hint = {{nullptr, nullptr, nullptr, nullptr}, {0, 0, 0, 0}, nullptr};
+void wgq_take_hint(PendingJob& p) {
+    for (int i = 0; i < 4; ++i) { p.am_p[i] = t_amax_hint.p[i]; p.am_n[i] = t_amax_hint.n[i]; }
+    p.am_out = (t_amax_hint.out && t_amax_hint.n[0] > 0 && t_amax_hint.n[2] > 0) ? t_amax_hint.out : nullptr;
+    t_amax_hint.out = nullptr;
+    for (int i = 0; i < 4; ++i) { t_amax_hint.p[i] = nullptr; t_amax_hint.n[i] = 0; }
+}
+// {max |a|, max |b|} of up to kMaxFin layers from their partial maxima: one workgroup per (layer, operand)
+constexpr int kMaxFin = 40;
+struct WqFinEntry { const float* p0; const float* p1; float* out; int n0, n1; };
+struct WqFinTable { WqFinEntry e[2 * kMaxFin]; };
+__global__ void __launch_bounds__(256)
+wgq_amax_finalize_kernel(const WqFinTable tab) {
+    __shared__ float red[4];
+    const WqFinEntry e = tab.e[blockIdx.x];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < e.n0; i += 256) m = fmaxf(m, fabsf(e.p0[i]));
+    for (int i = threadIdx.x; i < e.n1; i += 256) m = fmaxf(m, fabsf(e.p1[i]));
+#pragma unroll
+    for (int of = 32; of >= 1; of >>= 1) m = fmaxf(m, __shfl_xor(m, of, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) *e.out = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// fp16 pieces where both operands' maxima are known: 1 (default); GENESIS_WGQ_F16X3=0 / gx_wgq_precision(1): bf16 pieces everywhere
+int g_wgq_f16 = -1;
+bool wgq_f16() {
+    if (g_wgq_f16 < 0) {
+        const char* env = getenv("GENESIS_WGQ_F16X3");
+        g_wgq_f16 = (env && env[0] == '0') ? 0 : 1;
+    }
+    return g_wgq_f16 != 0;
+}
+// cost of an fp16-piece tile relative to the bf16-piece tile of the same variant, in percent (GENESIS_WGQ_F16_COST overrides)
+int g_ws_f16cost = -1;
+int ws_f16cost() {
+    if (g_ws_f16cost < 0) {
+        const char* env = getenv("GENESIS_WGQ_F16_COST");
+        g_ws_f16cost = env && atoi(env) > 0 ? atoi(env) : 62;
+    }
+    return g_ws_f16cost;
+}
+bool ws_f16_variant(int rv) { return (rv >= 18 && rv <= 21) || (rv >= 26 && rv <= 28); }
 
 // which matrix pipe the weight gradients run on: 1 (default) bf16 pipe, fp32 products from six bf16 piece products
 // (wq_tile_b6); 0 the fp32 pipe.  GENESIS_WGQ_BF16X6=0 / gx_wgq_precision(0) select the latter.
@@ -1428,6 +1554,8 @@ int wgq_launch_stream(std::vector<PendingJob*>& jobs, hipStream_t s, std::vector
         // a chunk: whole layers (both row parities of a transposed conv stay together) while their blocks fit the table
         WsTable tab;
         std::vector<WsSlot> slots;
+        WqFinTable fin;
+        int nfin = 0;
         tab.njobs = 0; tab.U = 0;
         double flops = 0.0, bytes = 0.0;
         size_t i_end = i;
@@ -1461,6 +1589,17 @@ int wgq_launch_stream(std::vector<PendingJob*>& jobs, hipStream_t s, std::vector
                         if (hf) { jb.variant = rv + 32 * hf; jb.cost = jb.cost * g_ws_kcost[hf == 3 ? 8 : rv - 18] / 100; }
                     }
                     jb.w_first = 0; jb.N = q.job.N;
+                    jb.amax2 = nullptr;
+                    if (rv >= 0 && jb.variant == rv && ws_f16_variant(rv) && q.am_out && wgq_f16() && nfin < 2 * kMaxFin - 2) {
+                        // both operands' maxima are known: two fp16 pieces per value, three piece products
+                        jb.variant = rv + 128; jb.cost = jb.cost * ws_f16cost() / 100; jb.amax2 = q.am_out;
+                        bool seen = false;
+                        for (int k = 0; k < nfin; ++k) seen = seen || fin.e[k].out == q.am_out;
+                        if (!seen) {
+                            fin.e[nfin++] = WqFinEntry{q.am_p[0], q.am_p[1], q.am_out, q.am_n[0], q.am_n[1]};
+                            fin.e[nfin++] = WqFinEntry{q.am_p[2], q.am_p[3], q.am_out + 1, q.am_n[2], q.am_n[3]};
+                        }
+                    }
                     tab.U += (long long)jb.ntiles * jb.cost;
                     slots.push_back(WsSlot{&q, blk, 0});
                 }
@@ -1500,6 +1639,10 @@ int wgq_launch_stream(std::vector<PendingJob*>& jobs, hipStream_t s, std::vector
         if (want_times && !capturing) {
             if (!d_times) (void)hipMalloc((void**)&d_times, 2 * 256 * sizeof(long long));
             tab.times = d_times;
+        }
+        if (nfin) {
+            GxProf pf(KID_SMALL_REDUCE, s, 0.0, 0.0);
+            hipLaunchKernelGGL(wgq_amax_finalize_kernel, dim3(nfin), dim3(256), 0, s, fin);
         }
         {
             GxProf pf(KID_WGQ_STREAM, s, flops, bytes);
@@ -1625,6 +1768,7 @@ int gx_wgq_c3(const float* x, const float* dy, float* dw, int N, int Cin, int Co
         return GX_EINVAL;
     }
     p.cls = WQ_C3; p.dw = dw; p.layout = 0; p.reduce_group = -1;
+    wgq_take_hint(p);
     p.flops = 2.0 * N * (double)Cout * Cin * 9 * H * W;
     std::vector<PendingJob> v{p};
     return wgq_run_or_queue(v, s);
@@ -1639,6 +1783,7 @@ int gx_wgq_deconv(const float* x, const float* dy, float* dw, int N, int Cin, in
         gx_set_error("wgq deconv: shape not eligible");
         return GX_EINVAL;
     }
+    wgq_take_hint(p0);
     p1 = p0;
     p0.cls = WQ_DR0; p1.cls = WQ_DR1;
     p0.dw = p1.dw = dw; p0.layout = p1.layout = 1;
@@ -1664,6 +1809,7 @@ int gx_wgq_c5(const float* a, const float* b, float* dw, int N, int CA, int CB, 
         gx_set_error("wgq conv5x5: shape not eligible");
         return GX_EINVAL;
     }
+    wgq_take_hint(p0);
     p1 = p0;
     p0.cls = WQ_C5A; p1.cls = WQ_C5B;
     p0.dw = p1.dw = dw; p0.layout = p1.layout = 0;
@@ -1725,9 +1871,21 @@ int gx_wgq_flush(hipStream_t s) {
 }
 
 extern "C" int gx_wgq_precision(int mode) {
-    GX_CHECK_ARG(mode == 0 || mode == 1, "gx_wgq_precision: mode must be 0 (fp32 matrix pipe) or 1 (bf16 pipe, fp32 products "
-                                         "from six bf16 piece products)");
-    g_wgq_b6 = mode;
+    GX_CHECK_ARG(mode >= -1 && mode <= 2, "gx_wgq_precision: mode must be 0 (fp32 matrix pipe), 1 (bf16 pipe, fp32 products from six "
+                                          "bf16 piece products), 2 (as 1, three fp16 piece products where both operands' maxima are "
+                                          "known) or -1 (the environment's default)");
+    if (mode < 0) { g_wgq_b6 = -1; g_wgq_f16 = -1; return GX_OK; }
+    g_wgq_b6 = mode ? 1 : 0;
+    g_wgq_f16 = mode == 2 ? 1 : 0;
+    return GX_OK;
+}
+
+extern "C" int gx_wgq_operand_amax(const float* a0, int na0, const float* a1, int na1, const float* b0, int nb0, const float* b1,
+                                   int nb1, float* out2) {
+    WqAmaxHint& h = t_amax_hint;
+    h.p[0] = a0; h.n[0] = a0 ? na0 : 0; h.p[1] = a1; h.n[1] = a1 ? na1 : 0;
+    h.p[2] = b0; h.n[2] = b0 ? nb0 : 0; h.p[3] = b1; h.n[3] = b1 ? nb1 : 0;
+    h.out = out2;
     return GX_OK;
 }
 

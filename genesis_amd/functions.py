@@ -213,7 +213,9 @@ class ConvGNReLUFn(torch.autograd.Function):
     def forward(ctx, x, w, gamma, beta):
         x = x.contiguous()
         out = torch.empty(x.shape[0], w.shape[0], x.shape[2], x.shape[3], device=x.device)
+        ctx.am_x = getattr(x, '_gx_amax', None)       # (partial maxima of the input, left by the node that produced it)
         y, mean, rstd = hip.conv3x3_gn_relu_fwd(x, w, gamma, beta, GROUPS, EPS, (out, 0, 0))
+        out._gx_amax = hip.take_amax()
         ctx.save_for_backward(x, y, mean, rstd)
         ctx.params = (w, gamma, beta)
         return out
@@ -225,7 +227,8 @@ class ConvGNReLUFn(torch.autograd.Function):
         ow, og, ob = _gout(w), _gout(gamma), _gout(beta)
         dy, dgamma, dbeta, _ = hip.gn_relu_bwd(y, gamma, beta, mean, rstd, GROUPS, (g.contiguous(), 0, 0),
                                                out=(og, ob, None))
-        dw = _wgrad(lambda: hip.conv3x3_wgrad(x, dy, out=ow), ow, x, dy)
+        am = (hip.take_amax(), ctx.am_x)
+        dw = _wgrad(lambda: hip.conv3x3_wgrad(x, dy, out=ow, amax=am), ow, x, dy)
         dx = hip.conv3x3_dgrad(dy, w) if ctx.needs_input_grad[0] else None
         return dx, _ret(ow, dw), _ret(og, dgamma), _ret(ob, dbeta)
 
@@ -255,6 +258,10 @@ class UNetEncoderFn(torch.autograd.Function):
         saved_down = []
         cur = x
         mlp_in = None
+        # partial maxima of every conv input (hip_ops.Amax; None = unknown): am_in[i] of down block i's input, am_cat[j] =
+        # [of the up-sampled part, of the skip part] of concat buffer j -- for the fp16-piece weight gradients
+        am_cur = getattr(x, '_gx_amax', None)
+        am_in, am_cat = [], [[None, None] for _ in range(nb)]
         for i in range(nb):
             w, gamma, beta = down[i]
             C, Hc, Wc = w.shape[0], cur.shape[2], cur.shape[3]
@@ -269,6 +276,8 @@ class UNetEncoderFn(torch.autograd.Function):
                 y, mean, rstd = hip.conv3x3_gn_relu_fwd(cur, w, gamma, beta, ngroups(C), EPS, (cats[j], cx, 0),
                                                         (nxt, 0, 0))
                 mlp_in = nxt
+            am_in.append(am_cur)
+            am_cur = am_cat[j][1] = hip.take_amax()          # (the skip slice and the resampled copy hold the same values)
             saved_down.append((cur, y, mean, rstd))
             cur = nxt
         # bottleneck MLP: three Linear+ReLU on the dense MFMA kernel (modules/unet.py:58-62,83)
@@ -293,7 +302,12 @@ class UNetEncoderFn(torch.autograd.Function):
                 out = torch.empty(N, w.shape[0], cats[j].shape[2], cats[j].shape[3], device=dev)
                 y, mean, rstd = hip.conv3x3_gn_relu_fwd(cats[j], w, gamma, beta, ngroups(w.shape[0]), EPS,
                                                         (out, 0, 0))
+            if j < nb - 1:
+                am_cat[j + 1][0] = hip.take_amax()
+            else:
+                out._gx_amax = hip.take_amax()
             saved_up.append((y, mean, rstd))
+        ctx.am_in, ctx.am_cat = am_in, am_cat
         ctx.nb = nb
         ctx.params = params
         ctx.cats = cats
@@ -319,7 +333,8 @@ class UNetEncoderFn(torch.autograd.Function):
             ow, og, ob = _gout(w, True), _gout(gamma, True), _gout(beta, True)
             dy, dgamma, dbeta, _ = hip.gn_relu_bwd(y, gamma, beta, mean, rstd, ctx.ngroups(y.shape[1]), gsrc,
                                                    out=(og, ob, None))
-            dw = _wgrad(lambda cj=cats[j], dy=dy, ow=ow: hip.conv3x3_wgrad(cj, dy, out=ow), ow, cats[j], dy)
+            am = (hip.take_amax(), ctx.am_cat[j])
+            dw = _wgrad(lambda cj=cats[j], dy=dy, ow=ow, am=am: hip.conv3x3_wgrad(cj, dy, out=ow, amax=am), ow, cats[j], dy)
             # (read by GroupNorm backward kernels only -- they sum split-K slabs on load; dcat[0] also feeds the MLP)
             dcat[j] = hip.conv3x3_dgrad_parts(dy, w) if j > 0 else hip.conv3x3_dgrad(dy, w)
             g_up[j] = (_ret(ow, dw), _ret(og, dgamma), _ret(ob, dbeta))
@@ -353,7 +368,8 @@ class UNetEncoderFn(torch.autograd.Function):
             ow, og, ob = _gout(w, True), _gout(gamma, True), _gout(beta, True)
             dy, dgamma, dbeta, _ = hip.gn_relu_bwd(y, gamma, beta, mean, rstd, ctx.ngroups(C), g0, g1,
                                                    out=(og, ob, None))
-            dw = _wgrad(lambda cur=cur, dy=dy, ow=ow: hip.conv3x3_wgrad(cur, dy, out=ow), ow, cur, dy)
+            am = (hip.take_amax(), ctx.am_in[i])
+            dw = _wgrad(lambda cur=cur, dy=dy, ow=ow, am=am: hip.conv3x3_wgrad(cur, dy, out=ow, amax=am), ow, cur, dy)
             g_down[i] = (_ret(ow, dw), _ret(og, dgamma), _ret(ob, dbeta))
             if i > 0:
                 d_next = hip.conv3x3_dgrad_parts(dy, w)
@@ -494,6 +510,7 @@ class SegFeatHeadsFn(torch.autograd.Function):
     def forward(ctx, enc_feat, seg_w, seg_gamma, seg_beta, conv_w, conv_b, gate, uv, log_sigma, rand_pixel, K, kernel,
                 seed_idx, min_mass, feat_w, feat_gamma, feat_beta):
         x = enc_feat.contiguous()
+        ctx.am_x = getattr(enc_feat, '_gx_amax', None)
         ctx.params = (seg_w, seg_gamma, seg_beta, conv_w, conv_b, gate, log_sigma, feat_w, feat_gamma, feat_beta)
         w2 = conv_w.detach().view(conv_w.shape[0], -1)
         y, yf, ctx.pair_ws = hip.conv3x3_pair_fwd(x, seg_w, feat_w)
@@ -540,12 +557,14 @@ class SegFeatHeadsFn(torch.autograd.Function):
                                                  out=(ow, ob, og))
             dy, dgamma, dbeta, _ = hip.gn_relu_bwd_proj(y, seg_gamma, seg_beta, mean, rstd, GROUPS, dcolour, w2, False,
                                                         out=(osg, osb, None), gate=gate)
-        dsw = _wgrad(lambda: hip.conv3x3_wgrad(x, dy, out=osw), osw, x, dy)
+        am_s = (hip.take_amax(), ctx.am_x)        # (conv1x1_gn_bwd_fused ends in gn_relu_bwd_proj: the tap is its dy's)
+        dsw = _wgrad(lambda: hip.conv3x3_wgrad(x, dy, out=osw, amax=am_s), osw, x, dy)
         # --- feat_head[0] (as ConvGNReLUFn.backward)
         ofw, ofg, ofb = _gout(feat_w), _gout(feat_gamma), _gout(feat_beta)
         dyf, dfgamma, dfbeta, _ = hip.gn_relu_bwd(yf, feat_gamma, feat_beta, meanf, rstdf, GROUPS, (g_f.contiguous(), 0, 0),
                                                   out=(ofg, ofb, None))
-        dfw = _wgrad(lambda: hip.conv3x3_wgrad(x, dyf, out=ofw), ofw, x, dyf)
+        am_f = (hip.take_amax(), ctx.am_x)
+        dfw = _wgrad(lambda: hip.conv3x3_wgrad(x, dyf, out=ofw, amax=am_f), ofw, x, dyf)
         # --- both input gradients: one launch
         dx = hip.conv3x3_pair_dgrad(dy, dyf, seg_w, feat_w, ctx.pair_ws) if ctx.needs_input_grad[0] else None
         return (dx, _ret(osw, dsw), _ret(osg, dgamma), _ret(osb, dbeta), _ret(ow, dw.view(conv_w.shape)), _ret(ob, db),
@@ -600,7 +619,10 @@ class DecoderFn(torch.autograd.Function):
         Cl, Sl = params[12].shape[1], 16 * d
         ctx.fused_head = FUSE_DECODER_HEAD and Cl <= 64 and Cl % GROUPS == 0 and (Sl * Sl) % 256 == 0 \
             and ow.shape[0] <= 8
+        am_h = None           # partial maxima of the current layer's input (hip_ops.Amax), for the fp16-piece weight gradients
+        ctx.am_h = [None] * 4
         for l in range(4):
+            ctx.am_h[l] = am_h
             w, b, gamma, beta = params[4 * l:4 * l + 4]
             if l == 3 and ctx.fused_head:
                 if EPILOGUE_STATS:
@@ -617,12 +639,14 @@ class DecoderFn(torch.autograd.Function):
                 y = hip.linear_fwd(z, wz, bz).view(N, w.shape[1], 2 * d, 2 * d)
                 a = torch.empty_like(y)
                 mean, rstd = hip.gn_relu_fwd(y, gamma, beta, GROUPS, EPS, (a, 0, 0))
+                am_h = hip.take_amax()
                 saved.append(((z, wz, coords), y, mean, rstd))
                 h = a
                 continue
             a = torch.empty(N, w.shape[1], 2 * h.shape[2], 2 * h.shape[3], device=h.device)
             # (the activation's partial maxima go to the next layer's transposed conv: gx_kq_amax_link, DESIGN finding 40)
             y, mean, rstd = hip.deconv5x5s2_gn_relu_fwd(h, w, b, gamma, beta, GROUPS, EPS, (a, 0, 0), link_out=l < 3)
+            am_h = hip.take_amax()
             saved.append((h, y, mean, rstd))
             h = a
         if not ctx.fused_head:
@@ -655,6 +679,7 @@ class DecoderFn(torch.autograd.Function):
                 head = (head[0], head[1:], None)
             else:
                 dow, dob = head[2][0], head[2][1]
+            am_head = hip.take_amax()         # (both forms end in gx_gn_relu_bwd_proj: dy's partial maxima)
             da = None
         else:
             da, dow, dob, _ = hip.conv1x1_bwd(ctx.last, g, ow2, ob, out=(gow, gob, None))
@@ -666,11 +691,13 @@ class DecoderFn(torch.autograd.Function):
             if l == 3 and ctx.fused_head:
                 ow, (og, ob, obias) = _gout(w), o3
                 dy, (dgamma, dbeta, dbias) = head[0], head[1]
+                am_dy = am_head
             else:
                 ow, obias, og, ob = _gout(w), _gout(b), _gout(gamma), _gout(beta)
                 link = hip.amax_link(da.device, y.numel()) if l > 0 and hip.AMAX_LINK_REG else None     # dy's partial maxima for this layer's data gradient; noqa: F841
                 dy, dgamma, dbeta, dbias = hip.gn_relu_bwd(y, gamma, beta, mean, rstd, GROUPS, (da, 0, 0), None, True,
                                                            out=(og, ob, obias))
+                am_dy = hip.take_amax()
             if l == 0 and ctx.bcast:
                 # one launch: dz = dy Wz^T, d(Wz^T) = dy^T z, d(bias map) = column sums of dy; then the tap sums are folded
                 # back onto the 5x5 weights (the bias gradient came out of the norm backward above)
@@ -680,7 +707,8 @@ class DecoderFn(torch.autograd.Function):
                 grads[0:4] = [_ret(ow, dw), _ret(obias, dbias), _ret(og, dgamma), _ret(ob, dbeta)]
                 _decoder_backward_done()
                 return (dz, None) + tuple(grads)
-            dw = _wgrad(lambda h=h, dy=dy, ow=ow: hip.deconv5x5s2_wgrad(h, dy, out=ow), ow, h, dy)
+            am = (am_dy, ctx.am_h[l])
+            dw = _wgrad(lambda h=h, dy=dy, ow=ow, am=am: hip.deconv5x5s2_wgrad(h, dy, out=ow, amax=am), ow, h, dy)
             # the first layer's input is the broadcast latent + 2 coordinate channels: only the D latent
             # channels need a gradient
             da = hip.deconv5x5s2_dgrad(dy, w, ctx.D if l == 0 else None)

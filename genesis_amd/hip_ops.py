@@ -46,6 +46,108 @@ def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
+# ---- the operands' largest magnitudes for the fp16-piece weight gradients (gx_wgq_operand_amax, include/genesis_hip.h) ----------
+# The stream-K weight-gradient launch at the end of a backward pass forms fp32 products from three fp16 piece products where it
+# knows max |x| and max |dy| of a layer -- from the GroupNorm kernels that WROTE those tensors (gx_amax_tap: one partial maximum per
+# workgroup), never from a pass of its own.  The wrappers below tap every GroupNorm forward / backward launch whose output feeds a
+# conv (take_amax() hands the caller an `Amax`), and conv3x3_wgrad / deconv5x5s2_wgrad pass the handles of their two operands on.
+# Partial maxima live in a ring arena (one allocation per device, far larger than what one iteration produces: they are consumed by
+# the flush of the same iteration).  GENESIS_WGQ_F16X3=0: nothing is tapped, the weight gradients stay on six bf16 piece products.
+WGQ_F16 = os.environ.get('GENESIS_WGQ_F16X3', '1') != '0'
+_TAP_CAP = 8192
+_ARENA_FLOATS = 1 << 22
+_ARENA = {}                      # device index -> [tensor, base pointer, position (floats)]
+_LAST_AMAX = [None]
+
+
+class Amax(object):
+    """Partial maxima of a tensor: `n` floats at device address `ptr` (inside the arena)."""
+    __slots__ = ('ptr', 'n')
+
+    def __init__(self, ptr, n):
+        self.ptr, self.n = ptr, n
+
+
+def _amax_scratch(device, n):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    a = _ARENA.get(idx)
+    if a is None:
+        t = torch.zeros(_ARENA_FLOATS, dtype=F32, device=device)
+        a = _ARENA[idx] = [t, t.data_ptr(), 0]
+    n = (n + 3) & ~3
+    if a[2] + n > _ARENA_FLOATS:
+        a[2] = 0
+    off = a[2]
+    a[2] = off + n
+    return a[1] + 4 * off, a, off
+
+
+def take_amax():
+    """The partial maxima the LAST tapped GroupNorm launch left for the tensor it stored (None: not tapped / not served)."""
+    h = _LAST_AMAX[0]
+    _LAST_AMAX[0] = None
+    return h
+
+
+def _tap_begin(device, hw, numel):
+    if not WGQ_F16 or hw < 256:      # (the register-resident GroupNorm kernels -- the only producers -- start at 16 x 16 planes)
+        _LAST_AMAX[0] = None
+        return None
+    ptr, a, off = _amax_scratch(device, _TAP_CAP)
+    _lib.call('gx_amax_tap', ctypes.c_void_p(ptr), _TAP_CAP, int(numel))
+    return ptr, a, off
+
+
+def _tap_end(tap):
+    if tap is None:
+        return
+    ptr, a, off = tap
+    n = _lib.query('gx_amax_tap_result')
+    if a[2] == off + _TAP_CAP:
+        a[2] = off + ((n + 3) & ~3)          # give the unused part of the request back
+    _LAST_AMAX[0] = Amax(ptr, n) if n > 0 else None
+
+
+def amax_of(t):
+    """Partial maxima of any tensor by a pass of its own (gx_amax_parts: 256 floats) -- tests, and operands no producer taps."""
+    _chk(t, 'amax_of.t')
+    ptr, _, _ = _amax_scratch(t.device, 256)
+    _lib.call('gx_amax_parts', _p(t), t.numel(), ctypes.c_void_p(ptr), _stream())
+    return Amax(ptr, 256)
+
+
+class _operand_amax(object):
+    """with _operand_amax(device, amax): ... one weight-gradient call that takes the hint.  amax = (dy's Amax | [Amax, Amax],
+    x's Amax | [Amax, Amax]) or None; an operand whose maxima are not all known disables the hint."""
+
+    def __init__(self, device, amax):
+        self.on = False
+        if not WGQ_F16 or amax is None:
+            return
+        ops = []
+        for h in amax:
+            hs = list(h) if isinstance(h, (list, tuple)) else [h]
+            if not hs or len(hs) > 2 or any(x is None for x in hs):
+                return
+            ops.append(hs + [None] * (2 - len(hs)))
+        out, _, _ = _amax_scratch(device, 4)
+        args = []
+        for hs in ops:
+            for x in hs:
+                args += [ctypes.c_void_p(x.ptr) if x is not None else None, x.n if x is not None else 0]
+        self.args = args + [ctypes.c_void_p(out)]
+        self.on = True
+
+    def __enter__(self):
+        if self.on:
+            _lib.call('gx_wgq_operand_amax', *self.args)
+
+    def __exit__(self, *exc):
+        if self.on:
+            _lib.call('gx_wgq_operand_amax', None, 0, None, 0, None, 0, None, 0, None)      # (a call that queued nothing leaves it armed)
+        return False
+
+
 # ---- deferred parameter-gradient reductions (gx_defer_*): TrainStep turns this on for one backward pass; calls that
 # write a parameter gradient into a caller-provided buffer then queue their final reduce, and defer_flush() finishes
 # all of them in one launch per kind.  Workspaces of queued calls are kept alive here until the flush.
@@ -139,7 +241,8 @@ def conv3x3_dgrad_parts(dy, w):
     return Parts(parts.value, nsplit.value, stride.value, (N, Cin, H, W), (ws, dx))
 
 
-def conv3x3_wgrad(x, dy, out=None):
+def conv3x3_wgrad(x, dy, out=None, amax=None):
+    """amax = (Amax of dy, Amax of x [or a pair: a concat buffer written by two producers]): see _operand_amax."""
     _chk(x, 'conv3x3_wgrad.x'); _chk(dy, 'conv3x3_wgrad.dy')
     N, Cin, H, W = x.shape
     Cout = dy.shape[1]
@@ -148,7 +251,7 @@ def conv3x3_wgrad(x, dy, out=None):
     assert dw.shape == (Cout, Cin, 3, 3) and dw.is_contiguous()
     nb = _lib.query('gx_conv3x3_wgrad_ws_bytes', N, Cin, Cout, H, W)
     ws = _ws(nb, x.device)
-    with _deferring(out is not None, ws, x, dy):    # (a queued job reads x / dy at the flush: kept alive until then)
+    with _deferring(out is not None, ws, x, dy), _operand_amax(x.device, amax):    # (a queued job reads x / dy at the flush: kept alive until then)
         _lib.call('gx_conv3x3_wgrad', _p(x), _p(dy), _p(dw), N, Cin, Cout, H, W, _p(ws), nb, _stream())
     return dw
 
@@ -225,7 +328,7 @@ def deconv5x5s2_dgrad(dy, w, cin_out=None):
     return dx
 
 
-def deconv5x5s2_wgrad(x, dy, out=None):
+def deconv5x5s2_wgrad(x, dy, out=None, amax=None):
     _chk(x, 'deconv_wgrad.x'); _chk(dy, 'deconv_wgrad.dy')
     N, Cin, H, W = x.shape
     Cout = dy.shape[1]
@@ -234,7 +337,7 @@ def deconv5x5s2_wgrad(x, dy, out=None):
     assert dw.shape == (Cin, Cout, 5, 5) and dw.is_contiguous()
     nb = _lib.query('gx_deconv5x5s2_wgrad_ws_bytes', N, Cin, Cout, H, W)
     ws = _ws(nb, x.device)
-    with _deferring(out is not None, ws, x, dy):
+    with _deferring(out is not None, ws, x, dy), _operand_amax(x.device, amax):
         _lib.call('gx_deconv5x5s2_wgrad', _p(x), _p(dy), _p(dw), N, Cin, Cout, H, W, _p(ws), nb, _stream())
     return dw
 
@@ -294,8 +397,10 @@ def gn_relu_fwd(y, gamma, beta, groups, eps, dst0, dst1=None):
     N, C, H, W = y.shape
     mean = torch.empty(N * groups, dtype=F32, device=y.device)
     rstd = torch.empty(N * groups, dtype=F32, device=y.device)
+    tap = _tap_begin(y.device, H * W, y.numel()) if dst0 is not None else None
     _lib.call('gx_gn_relu_fwd', _p(y), _p(gamma), _p(beta), N, C, H, W, groups, float(eps),
               *(_view_args(dst0, 'gn.dst0') + _view_args(dst1, 'gn.dst1')), _p(mean), _p(rstd), _stream())
+    _tap_end(tap)
     _probe_gn(y, gamma, beta, mean, rstd, groups)
     return mean, rstd
 
@@ -329,9 +434,11 @@ def _conv_gn(kind, x, w, bias, gamma, beta, groups, eps, dst0, dst1, link_out=Fa
     rstd = torch.empty(N * groups, dtype=F32, device=x.device)
     need_sum = nsplit.value > 1 or bias is not None
     link = amax_link(x.device, N * Cout * Ho * Wo) if link_out and AMAX_LINK_REG else None      # noqa: F841  (alive until the launch below is enqueued)
+    tap = _tap_begin(x.device, Ho * Wo, N * Cout * Ho * Wo)
     _lib.call('gx_gn_relu_fwd_parts', parts, nsplit.value, stride.value, _p(bias), _p(y) if need_sum else None,
               _p(gamma), _p(beta), N, Cout, Ho, Wo, groups, float(eps),
               *(_view_args(dst0, 'gn.dst0') + _view_args(dst1, 'gn.dst1')), _p(mean), _p(rstd), _stream())
+    _tap_end(tap)
     _probe_gn(y, gamma, beta, mean, rstd, groups)
     return y, mean, rstd       # (ws, holding the partial slabs, is released only now)
 
@@ -387,10 +494,12 @@ def gn_relu_bwd(y, gamma, beta, mean, rstd, groups, g0, g1=None, want_dbias=Fals
     nb = _lib.query('gx_gn_relu_bwd_ws_bytes', N, C)
     ws = _ws(nb, y.device)
     direct = o[0] is not None and o[1] is not None and (not want_dbias or o[2] is not None)
+    tap = _tap_begin(y.device, H * W, y.numel())
     with _deferring(direct, ws):
         _lib.call('gx_gn_relu_bwd_parts', _p(y), _p(gamma), _p(beta), _p(mean), _p(rstd), N, C, H, W, groups,
                   *(_view_args_p(g0, 'gn_bwd.g0') + _view_args_p(g1, 'gn_bwd.g1')), _p(dy), _p(dgamma), _p(dbeta),
                   _p(dbias), _p(ws), nb, _stream())
+    _tap_end(tap)
     return dy, dgamma, dbeta, dbias
 
 
@@ -1289,10 +1398,12 @@ def gn_relu_bwd_proj(y, gamma, beta, mean, rstd, groups, g_out, w, want_dbias=Fa
     nb = _lib.query('gx_gn_relu_bwd_proj_ws_bytes', N, C, H, W, groups, int(g_out.shape[1]))
     ws = _ws(nb, y.device)
     direct = o[0] is not None and o[1] is not None and (not want_dbias or o[2] is not None)
+    tap = _tap_begin(y.device, H * W, y.numel())
     with _deferring(direct, ws):
         _lib.call('gx_gn_relu_bwd_proj', _p(y), _p(gamma), _p(beta), _p(mean), _p(rstd), N, C, H, W, groups,
                   _p(g_out), int(g_out.shape[1]), _p(w), _p(gate), _p(dy), _p(dgamma), _p(dbeta), _p(dbias),
                   _p(parts[0]), _p(parts[1]), _p(ws), nb, _stream())
+    _tap_end(tap)
     return dy, dgamma, dbeta, dbias
 
 

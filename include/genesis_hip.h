@@ -79,6 +79,18 @@ int gx_wgq_precision(int mode);
  *      the taps' column shifts are funnel shifts of the dy operand -- 0 the 64-pixel LDS-DMA tiles whose lanes split
  *      what they read (the A/B reference).  Environment: GENESIS_WGQ_RING=0.  Replaces the same reference ops as
  *      gx_conv3x3_wgrad / gx_deconv5x5s2_wgrad (modules/blocks.py:159-165, models/genesisv2_config.py:89-99). */
+/*      Mode 2 of gx_wgq_precision (the default since round 6; GENESIS_WGQ_F16X3=0: mode 1): the row-ring tiles form every fp32
+ *      product from THREE fp16 piece products (x * 2^e = hi + lo, one power-of-two scale per operand TENSOR) instead of six
+ *      bf16 ones -- for the layers whose operands' largest magnitudes are known without a pass over them.
+ *      gx_wgq_operand_amax(...) is the one-shot, per-thread hint the NEXT gx_conv3x3_wgrad / gx_deconv5x5s2_wgrad call takes:
+ *      partial maxima of dy in a0[0..na0) (+ a1[0..na1)), of x in b0[0..nb0) (+ b1[0..nb1): a concat buffer written by two
+ *      producers), as left by gx_amax_tap / gx_amax_parts, and out2 -- two floats that receive {max |dy|, max |x|} in a small
+ *      launch ahead of the stream-K launch.  All of them stay alive until the queued launch has run.  Layers without the hint
+ *      (or with partial maxima of only one operand) run on bf16 pieces.  Range: a value below max|tensor| * 2^-18 keeps fewer
+ *      than 22 bits (its low piece is an fp16 subnormal), below max|tensor| * 2^-40 it is flushed -- absolute accuracy
+ *      2^-40 max|tensor|; tests/test_kernels_gpu.py *fp16x3* bound the error per output channel against fp64. */
+int gx_wgq_operand_amax(const float* a0, int na0, const float* a1, int na1, const float* b0, int nb0, const float* b1,
+                        int nb1, float* out2);
 int gx_wgq_ring(int on);
 /*      The same choice for the chip-filling transposed-conv forward / data-gradient layers (gx_kq.hip): 1
  *      bf16 pipe -- the staging splits the input tile into its three bf16 planes, the pack kernel the weights; needs a
@@ -99,6 +111,17 @@ int gx_kq_precision(int mode);
  *      the link; results are bit-identical with and without it.  gx_kq_amax_link_hits(): hand-overs taken so far (this thread). */
 int gx_kq_amax_link(float* parts, int capacity, size_t numel);
 int gx_kq_amax_link_hits(void);
+/*      The same partial maxima for a LATER reader (the weight gradients' stream-K launch at the end of the backward pass,
+ *      gx_wgq_operand_amax below): gx_amax_tap(parts, capacity, numel) arms a one-shot, per-thread request -- the next producer launch
+ *      that supports it (the register-resident GroupNorm + ReLU kernels, forward and backward) writes one partial maximum of the
+ *      values it stores per workgroup into parts[0 .. n) -- provided it stores exactly `numel` values: a chunked producer does not
+ *      serve -- whatever its destination views are (the channel slice of a concat
+ *      buffer and a resampled second copy hold the same values); gx_amax_tap_result() returns n (0: that launch could not
+ *      serve, the request is void) and disarms.  The caller keeps `parts` alive until its reader has RUN.
+ *      gx_amax_parts(x, n, parts, stream): the partial maxima of any tensor by a pass of its own -- 256 floats. */
+int gx_amax_tap(float* parts, int capacity, size_t numel);
+int gx_amax_tap_result(void);
+int gx_amax_parts(const float* x, size_t n, float* parts, gx_stream_t stream);
 size_t gx_conv3x3_wino_ws_bytes(int N, int Cin, int Cout, int H, int W);
 int gx_conv3x3_wino(const float* x, const float* w, float* y, int N, int Cin, int Cout, int H, int W, int mode,
                     void* ws, size_t ws_bytes, gx_stream_t stream);

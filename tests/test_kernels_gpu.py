@@ -1793,3 +1793,124 @@ def test_amax_link_from_the_groupnorm_kernels_of_the_decoder_layers():
         _lib.call('gx_kq_precision', -1)
         _lib.call('gx_kq_policy', 1)
         _lib.call('gx_kq_amax_link', None, 0, 0)
+
+
+# ------------------------------------------------------------------------------ weight gradients on three fp16 piece products
+def _wgq_operands(kind, N, Cin, Cout, S, make_x, make_dy):
+    if kind == 'conv3x3':
+        x, dy = make_x((N, Cin, S, S)), make_dy((N, Cout, S, S))
+    else:
+        x, dy = make_x((N, Cin, S, S)), make_dy((N, Cout, 2 * S, 2 * S))
+    return x, dy
+
+
+def _wgq_fp64(kind, x, dy, chunk=8):
+    """The weight gradient in fp64 (autograd of the fp64 op), images in chunks (the long-contraction cases are GBs in fp64)."""
+    Cin, Cout = x.shape[1], dy.shape[1]
+    w = torch.zeros((Cout, Cin, 3, 3) if kind == 'conv3x3' else (Cin, Cout, 5, 5), dtype=torch.float64, requires_grad=True)
+    for i in range(0, x.shape[0], chunk):
+        xs, ds = x[i:i + chunk].double(), dy[i:i + chunk].double()
+        y = F.conv2d(xs, w, None, 1, 1) if kind == 'conv3x3' else F.conv_transpose2d(xs, w, None, 2, 2, 1)
+        (y * ds).sum().backward()
+    return w.grad
+
+
+def _wgq_run(kind, x, dy, mode, with_amax):
+    from genesis_amd import hip_ops as hip, _lib
+    _lib.call('gx_wgq_precision', mode)
+    xd, dd = x.to(DEV), dy.to(DEV)
+    am = (hip.amax_of(dd), hip.amax_of(xd)) if with_amax else None
+    fn = hip.conv3x3_wgrad if kind == 'conv3x3' else hip.deconv5x5s2_wgrad
+    return fn(xd, dd, amax=am).double().cpu()
+
+
+def _per_channel_err(got, ref, dim):
+    """relative L2 error per OUTPUT channel (dim 0 of a conv weight, dim 1 of a transposed-conv weight)."""
+    dims = [d for d in range(4) if d != dim]
+    return ((got - ref).pow(2).sum(dims).sqrt() / ref.pow(2).sum(dims).sqrt().clamp_min(1e-300))
+
+
+@pytest.mark.parametrize('kind,N,Cin,Cout,S', [('conv3x3', 32, 64, 64, 64), ('conv3x3', 8, 128, 64, 32), ('conv3x3', 16, 64, 128, 16),
+                                                ('deconv', 56, 64, 64, 32), ('deconv', 16, 64, 64, 16)])
+def test_weight_gradients_on_three_fp16_piece_products_keep_fp32_accuracy(kind, N, Cin, Cout, S):
+    """gx_wgq_precision(2) + gx_wgq_operand_amax: the row-ring tiles with two fp16 pieces per operand value (x * 2^e = hi + lo)
+    and three piece products.  Against autograd in fp64, next to the fp32 pipe and the six-bf16-piece form: the fp16 error stays
+    within 1.5 x the fp32 pipe's + 1e-7 over the whole tensor AND per output channel; without the operands' maxima the same call
+    is the bf16 form bit for bit."""
+    from genesis_amd import _lib, profiling
+    x, dy = _wgq_operands(kind, N, Cin, Cout, S, lambda s: rnd(*s, seed=1), lambda s: rnd(*s, seed=2))
+    ref = _wgq_fp64(kind, x, dy)
+    cdim = 0 if kind == 'conv3x3' else 1
+    try:
+        g32 = _wgq_run(kind, x, dy, 0, False)
+        g6 = _wgq_run(kind, x, dy, 1, False)
+        g3 = _wgq_run(kind, x, dy, 2, True)
+        g3_nohint = _wgq_run(kind, x, dy, 2, False)
+    finally:
+        _lib.call('gx_wgq_precision', -1)
+    assert torch.equal(g3_nohint, g6)
+    assert not torch.equal(g3, g6)                  # (the hint was taken: another arithmetic)
+    e = {k: float((g - ref).norm() / ref.norm()) for k, g in (('fp32', g32), ('bf16x6', g6), ('fp16x3', g3))}
+    c = {k: float(_per_channel_err(g, ref, cdim).max()) for k, g in (('fp32', g32), ('bf16x6', g6), ('fp16x3', g3))}
+    print('%s N=%d %d->%d @%d: relative L2 error %s; worst output channel %s' % (
+        kind, N, Cin, Cout, S, ' '.join('%s %.3e' % kv for kv in e.items()), ' '.join('%s %.3e' % kv for kv in c.items())))
+    assert e['fp16x3'] <= 1.5 * e['fp32'] + 1e-7 and e['fp16x3'] < 1e-4, e
+    assert c['fp16x3'] <= 1.5 * c['fp32'] + 1e-7, c
+
+
+def _flat_rect(shape, seed):
+    """Structured operand: five-level flat rectangles per (image, channel) plane (testing.make_rect_input's value distribution) --
+    exact zeros, exact ones, large constant regions."""
+    g = torch.Generator().manual_seed(seed)
+    N, C, H, W = shape
+    lv = torch.tensor([0.0, 63.0 / 255.0, 127.0 / 255.0, 191.0 / 255.0, 1.0])
+    t = lv[torch.randint(0, 5, (N, C, 1, 1), generator=g)].expand(N, C, H, W).clone()
+    for _ in range(3):
+        y0, x0 = int(torch.randint(0, H // 2, (1,), generator=g)), int(torch.randint(0, W // 2, (1,), generator=g))
+        hh, ww = int(torch.randint(H // 8, H // 2, (1,), generator=g)), int(torch.randint(W // 8, W // 2, (1,), generator=g))
+        t[:, :, y0:y0 + hh, x0:x0 + ww] = lv[torch.randint(0, 5, (N, C, 1, 1), generator=g)]
+    return t
+
+
+@pytest.mark.parametrize('case', ['randn', 'relu_like', 'flat_rect', 'weak_channel', 'one_outlier'])
+def test_long_contraction_weight_gradient_on_fp16_pieces_per_output_channel(case):
+    """The precondition for running the weight gradients on fp16 pieces (review, round 5): a contraction as long as the metric
+    step's -- N H W = 224 x 64 x 64 = 9.2e5 terms per output element (the decoder's last layer: K B = 224 images) -- on
+      randn         both operands standard normal;
+      relu_like     x >= 0 with half of it exactly zero (a post-ReLU activation), dy heavy-tailed (normal^3);
+      flat_rect     x = five-level flat rectangles (the structured input set's value distribution), dy normal;
+      weak_channel  as randn, with ONE dy channel 2^12 below the others (its gradients must be as accurate as its neighbours');
+      one_outlier   as randn, with one dy element 2^20 times the rest (the per-tensor scale follows it: everything else loses
+                    its low piece -- the documented range limit of the per-tensor scale).
+    Per OUTPUT channel, error against fp64: fp16 x 3 <= 1.5 x the fp32 pipe's + 1e-7 (one_outlier: <= 4 x + 1e-6, and reported)."""
+    from genesis_amd import _lib
+    N, Cin, Cout, S = 224, 64, 64, 64
+    shape_x, shape_d = (N, Cin, S, S), (N, Cout, S, S)
+    if case == 'randn':
+        x, dy = rnd(*shape_x, seed=11), rnd(*shape_d, seed=12)
+    elif case == 'relu_like':
+        x, dy = rnd(*shape_x, seed=13).clamp_min(0.0), rnd(*shape_d, seed=14).pow(3)
+    elif case == 'flat_rect':
+        x, dy = _flat_rect(shape_x, 15), rnd(*shape_d, seed=16)
+    elif case == 'weak_channel':
+        x, dy = rnd(*shape_x, seed=17), rnd(*shape_d, seed=18)
+        dy[:, 5] *= 2.0 ** -12
+    else:
+        x, dy = rnd(*shape_x, seed=19), rnd(*shape_d, seed=20)
+        dy[7, 3, 21, 40] = 2.0 ** 20
+    ref = _wgq_fp64('conv3x3', x, dy)
+    try:
+        g32 = _wgq_run('conv3x3', x, dy, 0, False)
+        g6 = _wgq_run('conv3x3', x, dy, 1, False)
+        g3 = _wgq_run('conv3x3', x, dy, 2, True)
+    finally:
+        _lib.call('gx_wgq_precision', -1)
+    c32, c6, c3 = (_per_channel_err(g, ref, 0) for g in (g32, g6, g3))
+    print('%s: worst output channel, relative L2 vs fp64: fp32 pipe %.3e, bf16 x 6 %.3e, fp16 x 3 %.3e; median fp32 %.3e fp16 %.3e'
+          % (case, float(c32.max()), float(c6.max()), float(c3.max()), float(c32.median()), float(c3.median())))
+    assert not torch.equal(g3, g6)
+    if case == 'one_outlier':
+        assert float((c3 / (4.0 * c32 + 1e-6)).max()) <= 1.0, (c3.max(), c32.max())
+    else:
+        worst = float((c3 / (1.5 * c32 + 1e-7)).max())
+        assert worst <= 1.0, (case, worst, float(c3.max()), float(c32.max()))
