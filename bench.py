@@ -598,9 +598,9 @@ def main():
                                                             'gx_wgq_precision(0), gx_kq_precision(0), gx_wino_precision(0)'}
             ts2.close()
         finally:
-            _lib.call('gx_wgq_precision', 1)
+            _lib.call('gx_wgq_precision', -1)
             _lib.call('gx_kq_precision', -1)        # (the environment's default: three fp16 piece products unless GENESIS_KQ_F16X3=0)
-            _lib.call('gx_wino_precision', 1)
+            _lib.call('gx_wino_precision', -1)
 
     # ---- what the timed step leaves out of the reference's iteration, priced: train.py:244-246 computes mse / rmse
     #      every iteration and GenesisV2.forward builds mx_r_k / instance_seg / instance_seg_r (genesisv2_config.py:184-188) and

@@ -603,7 +603,7 @@ __device__ __forceinline__ void pack_h_store(const float* __restrict__ w, float*
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int pack,
                                     int Co, int Ci, int NT, int Kpad, int Mpad) {
     const int total = NT * Kpad * Mpad;
-    const int f16_exp = pack >= 40 ? gx_f16_scale_exp(*reinterpret_cast<const float*>(reinterpret_cast<const char*>(wp) + gx_kq_h_amax_off(Kpad, Mpad, NT))) : 0;
+    const int f16_exp = pack >= 40 ? gx_f16_scale_exp(((pack == 45 || pack == 46) ? 2.25f : 1.f) * *reinterpret_cast<const float*>(reinterpret_cast<const char*>(wp) + gx_kq_h_amax_off(Kpad, Mpad, NT))) : 0;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int m = idx % Mpad;
         const int k = (idx / Mpad) % Kpad;
@@ -1572,7 +1572,7 @@ __global__ void __launch_bounds__(1024)
 pack_amax_batch_kernel(const PackEntry* __restrict__ entries) {
     const PackEntry e = entries[blockIdx.x];
     if (e.pack < 40) return;
-    const float r = gx_wg1024_amax(e.w, e.Co * e.Ci * (e.pack <= 41 ? 9 : 25));
+    const float r = gx_wg1024_amax(e.w, e.Co * e.Ci * ((e.pack <= 41 || e.pack == 45 || e.pack == 46) ? 9 : 25));
     if (threadIdx.x == 0) *reinterpret_cast<float*>(reinterpret_cast<char*>(e.wp) + gx_kq_h_amax_off(e.Kpad, e.Mpad, e.NT)) = r;
 }
 
@@ -1580,7 +1580,8 @@ __global__ void pack_weights_batch_kernel(const PackEntry* __restrict__ entries,
     const PackEntry e = entries[map[blockIdx.x]];
     const int total = e.NT * e.Kpad * e.Mpad;
     const int begin = (blockIdx.x - e.chunk0) * kPackChunk, end = begin + kPackChunk < total ? begin + kPackChunk : total;
-    const int f16_exp = e.pack >= 40 ? gx_f16_scale_exp(*reinterpret_cast<const float*>(reinterpret_cast<const char*>(e.wp) + gx_kq_h_amax_off(e.Kpad, e.Mpad, e.NT))) : 0;
+    // (45 / 46: the Winograd operands U = G g G^T, |U| <= 2.25 max |g|)
+    const int f16_exp = e.pack >= 40 ? gx_f16_scale_exp(((e.pack == 45 || e.pack == 46) ? 2.25f : 1.f) * *reinterpret_cast<const float*>(reinterpret_cast<const char*>(e.wp) + gx_kq_h_amax_off(e.Kpad, e.Mpad, e.NT))) : 0;
     for (int idx = begin + threadIdx.x; idx < end; idx += blockDim.x) {
         const int m = idx % e.Mpad;
         const int k = (idx / e.Mpad) % e.Kpad;
@@ -1615,7 +1616,7 @@ int launch_pack(const float* w, float* wp, int pack, int Co, int Ci, int NT, int
     const int total = NT * Kpad * Mpad;
     const int blocks = gx_ceil_div(total, 256) > 1024 ? 1024 : gx_ceil_div(total, 256);
     if (pack >= 40) {
-        const int rc = gx_kq_weight_amax_launch(w, Co * Ci * (pack <= 41 ? 9 : 25), reinterpret_cast<float*>(reinterpret_cast<char*>(wp) + gx_kq_h_amax_off(Kpad, Mpad, NT)), s);
+        const int rc = gx_kq_weight_amax_launch(w, Co * Ci * ((pack <= 41 || pack == 45 || pack == 46) ? 9 : 25), reinterpret_cast<float*>(reinterpret_cast<char*>(wp) + gx_kq_h_amax_off(Kpad, Mpad, NT)), s);
         if (rc) return rc;
     }
     {
@@ -2377,7 +2378,8 @@ static int conv3x3_fwd_impl(const float* x, const float* w, const float* bias, i
         return GX_OK;
     }
     if (wino_ok) {   // Winograd F(2x2,3x3): 2.25x fewer MFMA passes
-        rc = gx_wino_h_on() ? launch_pack(w, wp, 25, Cout, Cin, 16, gx_round_up(Cin, 16), Mpad, s, &wpu)
+        // (25: three bf16 pieces; 45: two fp16 pieces -- the input's maxima were handed in, gx_conv_input_amax)
+        rc = gx_wino_h_on() ? launch_pack(w, wp, gx_wino_f16_pending() ? 45 : 25, Cout, Cin, 16, gx_round_up(Cin, 16), Mpad, s, &wpu)
                             : launch_pack(w, wp, 5, Cout, Cin, 16, Kpad, Mpad, s, &wpu);
         if (rc) return rc;
         rc = gx_wino_launch(x, wpu, y, N, Cin, Cout, H, W, s);
@@ -2449,7 +2451,7 @@ static int conv3x3_dgrad_impl(const float* dy, const float* w, float* dx, int N,
         return gx_kq_c3_launch(dy, wpu, nullptr, 0, dx, N, Cout, Cin, H, W, s);
     }
     if (wino_ok) {
-        rc = gx_wino_h_on() ? launch_pack(w, wp, 26, Cout, Cin, 16, gx_round_up(Cout, 16), Mpad, s, &wpu)
+        rc = gx_wino_h_on() ? launch_pack(w, wp, gx_wino_f16_pending() ? 46 : 26, Cout, Cin, 16, gx_round_up(Cout, 16), Mpad, s, &wpu)
                             : launch_pack(w, wp, 6, Cout, Cin, 16, Kpad, Mpad, s, &wpu);
         if (rc) return rc;
         return gx_wino_launch(dy, wpu, dx, N, Cout, Cin, H, W, s);

@@ -1306,14 +1306,23 @@ bool wgq_f16() {
     }
     return g_wgq_f16 != 0;
 }
-// cost of an fp16-piece tile relative to the bf16-piece tile of the same variant, in percent (GENESIS_WGQ_F16_COST overrides)
-int g_ws_f16cost = -1;
-int ws_f16cost() {
-    if (g_ws_f16cost < 0) {
-        const char* env = getenv("GENESIS_WGQ_F16_COST");
-        g_ws_f16cost = env && atoi(env) > 0 ? atoi(env) : 62;
+// units per fp16-piece tile by row-ring variant 18 .. 28 (0: the variant has no fp16 form), re-fitted with GENESIS_WGQ_TIMES on the
+// metric step next to the bf16 / LDS-DMA variants of the same launch: 64 - 78 % of the bf16 tile (the 10-tap row parity gains
+// least: its split / staging work per tile is that of the 15-tap one).  GENESIS_WGQ_F16_COST="c18,c19,c20,c21,c26,c27,c28" overrides
+int g_ws_cost_f16[11] = {3040, 1760, 2650, 2315, 0, 0, 0, 0, 1870, 2700, 2380};
+bool g_ws_cost_f16_init = false;
+int ws_f16cost(int rv) {
+    if (!g_ws_cost_f16_init) {
+        g_ws_cost_f16_init = true;
+        if (const char* env = getenv("GENESIS_WGQ_F16_COST")) {
+            int v[7];
+            if (sscanf(env, "%d,%d,%d,%d,%d,%d,%d", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6) == 7) {
+                static const int idx[7] = {0, 1, 2, 3, 8, 9, 10};
+                for (int i = 0; i < 7; ++i) if (v[i] > 0) g_ws_cost_f16[idx[i]] = v[i];
+            }
+        }
     }
-    return g_ws_f16cost;
+    return g_ws_cost_f16[rv - 18];
 }
 bool ws_f16_variant(int rv) { return (rv >= 18 && rv <= 21) || (rv >= 26 && rv <= 28); }
 
@@ -1439,7 +1448,7 @@ bool wgq_stream_on() {
 // wgrad3:256:64 wgrad3:2048:16 wgrad3:8192:8 wgrad:256:32 wgrad:1024:16 wgrad:4096:8: 10.3 us per conv3x3 tile, 26.5 us per
 // pair of transposed-conv row-parity tiles, split 15 a + b : 10 a + b), then nudged on the training step itself
 // (the stream kernel's duration over five vectors: 921 .. 972 us); GENESIS_WGQ_COST="c0,...,c8" overrides
-int g_ws_cost[34] = {10200, 9580, 10680, 15080, 21000, 11800, 11400, 8800, 9700,              // bf16 pipe (measured with
+int g_ws_cost[34] = {10200, 9580, 9600, 15080, 21000, 11800, 11400, 8800, 9700,              // bf16 pipe (measured with
                      10200, 10600, 11200, 16000, 16500, 18200, 11600, 12000, 13300,           // GENESIS_WGQ_TIMES) | fp32 pipe
                      4840, 2450, 4150, 2900,                                                  // row-ring tiles (one base row)
                      8000, 4100, 5400, 2800,                                                  // ... of the 5 x 5 stride-1 conv
@@ -1592,7 +1601,7 @@ int wgq_launch_stream(std::vector<PendingJob*>& jobs, hipStream_t s, std::vector
                     jb.amax2 = nullptr;
                     if (rv >= 0 && jb.variant == rv && ws_f16_variant(rv) && q.am_out && wgq_f16() && nfin < 2 * kMaxFin - 2) {
                         // both operands' maxima are known: two fp16 pieces per value, three piece products
-                        jb.variant = rv + 128; jb.cost = jb.cost * ws_f16cost() / 100; jb.amax2 = q.am_out;
+                        jb.variant = rv + 128; jb.cost = ws_f16cost(rv); jb.amax2 = q.am_out;
                         bool seen = false;
                         for (int k = 0; k < nfin; ++k) seen = seen || fin.e[k].out == q.am_out;
                         if (!seen) {

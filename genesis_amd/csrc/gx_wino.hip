@@ -44,6 +44,10 @@ struct WinoGeom {
     int Kpad, Mpad;       // packed weight dims (Kpad % 8 == 0, Mpad % 64 == 0)
     int H, W;             // H % 8 == 0, W % 16 == 0
     int tiles_h, tiles_w; // H / 8, W / 16
+    // the fp16-piece form (wino_conv_h_kernel<NB, true>): partial maxima of the input tensor(s), as their producers left them
+    // (gx_conv_input_amax): xam0[0 .. xn0) and xam1[0 .. xn1)
+    const float* xam0; const float* xam1;
+    int xn0, xn1;
 };
 
 // U in the conv kernel's operand order (gx_common.h: gx_wino_u_value / gx_wino_u_slot)
@@ -390,6 +394,25 @@ __device__ __forceinline__ void wino_split8(const float (&v)[8], w_bf16x8& ph, w
     }
 }
 
+// 8 fp32 values -> TWO fp16 pieces of v * sc (sc a power of two): hi = the top 11 significant bits (a mask: the residual is exact),
+// lo = the residual rounded to nearest -- 22 significant bits (findings 40 and 42)
+typedef _Float16 w_f16x8 __attribute__((ext_vector_type(8)));
+typedef float w_f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 w_f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned w_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void wino_split8_f16(const float (&v)[8], float sc, w_bf16x8& ph, w_bf16x8& pl) {
+    w_u32x4 h, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float s0 = v[2 * i] * sc, s1 = v[2 * i + 1] * sc;
+        const float h0 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, s0) & 0xFFFFE000u);
+        const float h1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, s1) & 0xFFFFE000u);
+        h[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(w_f32x2{h0, h1}, w_f16x2));
+        l[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(w_f32x2{s0 - h0, s1 - h1}, w_f16x2));
+    }
+    ph = __builtin_bit_cast(w_bf16x8, h); pl = __builtin_bit_cast(w_bf16x8, l);
+}
+
 // NB: 32-tile MFMA column blocks per wave.
 //   NB = 1: workgroup = 64 channels x 32 tiles (8 x 16 output pixels), 128 accumulator registers, two workgroups per CU --
 //           the layers whose grid would not fill the chip with larger tiles.
@@ -411,11 +434,16 @@ template <int NB> struct WHCfg {
     static constexpr size_t LDS_BYTES = 2 * RAW_FLOATS * 4 > 32768 ? 2 * RAW_FLOATS * 4 : 32768;    // (the epilogue's exchange buffer: 32 KB)
 };
 
-template <int NB>
+// F16: the operands as TWO fp16 pieces (U * 2^eU packed that way: kinds 45 / 46; V * 2^eV split in registers), three piece products
+// per fp32 product instead of six -- half the MFMAs, two thirds of the A-operand traffic, a 24-VALU split per octet instead of 44.
+// eU from the weight tensor's largest magnitude (the packing's trailer; |U| <= 2.25 max |g|), eV from the INPUT tensor's, handed
+// over by the kernel that wrote it (g.xam*; |V| <= 4 max |d|); the outputs are scaled back by 2^-(eU + eV).
+template <int NB, bool F16>
 __global__ void __launch_bounds__(256, NB == 1 ? 2 : 1)
 wino_conv_h_kernel(const float* __restrict__ in, const float* __restrict__ in2, const unsigned* __restrict__ U,
                    float* __restrict__ out, float* __restrict__ out2, const WinoGeom g) {
     using C = WHCfg<NB>;
+    constexpr int NP = F16 ? 2 : 3;
     constexpr int PITCH = C::PITCH, NSETS = C::NSETS, LOOK = C::LOOK;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* raw = lds;                       // [2][HKC][PITCH]
@@ -485,7 +513,7 @@ wino_conv_h_kernel(const float* __restrict__ in, const float* __restrict__ in2, 
     auto load_a = [&](w_bf16x8 (&a)[2][3], int c, int nu) {
         const char* p = Uw + ((size_t)c * 16 + nu) * 6144;
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc)
+        for (int pc = 0; pc < NP; ++pc)
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
                 a[mi][pc] = *reinterpret_cast<const w_bf16x8*>(p + (pc * 2 + mi) * 1024);
@@ -502,6 +530,21 @@ wino_conv_h_kernel(const float* __restrict__ in, const float* __restrict__ in2, 
                 for (int c = 0; c < 16; ++c) acc[a][b][nb][c] = 0.f;
 
     w_bf16x8 as[NSETS][2][3];               // A register sets: position 4 c + nu uses set (4 c + nu) % NSETS = nu % NSETS
+    // fp16 pieces: the two scales (uniform)
+    float scV = 1.f;
+    int f16_back = 0;
+    if constexpr (F16) {
+        float xm = 0.f;
+        for (int i = lane; i < g.xn0; i += 64) xm = fmaxf(xm, fabsf(g.xam0[i]));
+        for (int i = lane; i < g.xn1; i += 64) xm = fmaxf(xm, fabsf(g.xam1[i]));
+#pragma unroll
+        for (int of = 32; of >= 1; of >>= 1) xm = fmaxf(xm, __shfl_xor(xm, of, 64));
+        const int eV = gx_f16_scale_exp(4.f * xm);
+        const float wam = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(U) + gx_kq_h_amax_off(g.Kpad, g.Mpad, 16));
+        const int eU = gx_f16_scale_exp(2.25f * wam);
+        scV = ldexpf(1.f, eV);
+        f16_back = -(eU + eV);
+    }
 #ifdef GX_WH_STAGGER
     // the two workgroups of a CU start in the same cycle and would run in lockstep (both waiting for their first patch, both
     // on the matrix pipe, both in the epilogue): the second one of each CU starts GX_WH_STAGGER x 64 cycles late
@@ -548,6 +591,7 @@ wino_conv_h_kernel(const float* __restrict__ in, const float* __restrict__ in2, 
                     v[ch] = nu == 0 ? t[nb][ch][0] - t[nb][ch][2]
                                     : (nu == 1 ? t[nb][ch][1] + t[nb][ch][2] : (nu == 2 ? t[nb][ch][2] - t[nb][ch][1] : t[nb][ch][1] - t[nb][ch][3]));
                 if (GX_WH_ABL & 4) { b[nb][0] = acur[0][0]; b[nb][1] = acur[0][1]; b[nb][2] = acur[0][2]; }
+                else if constexpr (F16) wino_split8_f16(v, scV, b[nb][0], b[nb][1]);
                 else wino_split8(v, b[nb][0], b[nb][1], b[nb][2]);
             }
 #pragma unroll
@@ -556,6 +600,13 @@ wino_conv_h_kernel(const float* __restrict__ in, const float* __restrict__ in2, 
                 for (int nb = 0; nb < NB; ++nb) {
                     w_f32x16 cc = acc[nu][mi][nb];        // pieces: 0 hi, 1 mid, 2 lo; small terms first
                     if (GX_WH_ABL & 1) { cc[0] += (float)acur[mi][0][0] * (float)b[nb][0][0] + (float)acur[mi][1][1] * (float)b[nb][1][1] + (float)acur[mi][2][2] * (float)b[nb][2][2]; acc[nu][mi][nb] = cc; continue; }
+                    if constexpr (F16) {      // pieces: 0 hi, 1 lo; small terms first
+                        cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(w_f16x8, acur[mi][1]), __builtin_bit_cast(w_f16x8, b[nb][0]), cc, 0, 0, 0);
+                        cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(w_f16x8, acur[mi][0]), __builtin_bit_cast(w_f16x8, b[nb][1]), cc, 0, 0, 0);
+                        cc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(w_f16x8, acur[mi][0]), __builtin_bit_cast(w_f16x8, b[nb][0]), cc, 0, 0, 0);
+                        acc[nu][mi][nb] = cc;
+                        continue;
+                    }
                     cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[mi][1], b[nb][1], cc, 0, 0, 0);
                     cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[mi][2], b[nb][0], cc, 0, 0, 0);
                     cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[mi][0], b[nb][2], cc, 0, 0, 0);
@@ -609,6 +660,10 @@ wino_conv_h_kernel(const float* __restrict__ in, const float* __restrict__ in2, 
                 y0.y = q[0][1] + q[1][1] + q[2][1];
                 y1.x = q[1][0] - q[2][0] - q[3][0];
                 y1.y = q[1][1] - q[2][1] - q[3][1];
+                if constexpr (F16) {
+                    y0.x = ldexpf(y0.x, f16_back); y0.y = ldexpf(y0.y, f16_back);
+                    y1.x = ldexpf(y1.x, f16_back); y1.y = ldexpf(y1.y, f16_back);
+                }
                 float* o = outp + out_n + (size_t)(m - mbase) * HW + (size_t)(R0 + 2 * oy) * g.W + C0 + 2 * ox;
                 *reinterpret_cast<float2*>(o) = y0;
                 *reinterpret_cast<float2*>(o + g.W) = y1;
@@ -617,9 +672,22 @@ wino_conv_h_kernel(const float* __restrict__ in, const float* __restrict__ in2, 
 }
 
 // U for the bf16 pipe: the thread of an even k writes the three words (k, k + 1) of position p
-__device__ __forceinline__ void wino_h_store(unsigned* __restrict__ U, float v0, float v1, int m, int k, int p, int Kpad16) {
+__device__ __forceinline__ void wino_h_store(unsigned* __restrict__ U, float v0, float v1, int m, int k, int p, int Kpad16,
+                                             bool f16 = false, int f16_exp = 0) {
     unsigned short pc[2][3];
     const float v[2] = {v0, v1};
+    if (f16) {          // two fp16 pieces of v * 2^f16_exp (piece slot 2 stays unused)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float ws = ldexpf(v[e], f16_exp);
+            const _Float16 h = (_Float16)ws;
+            pc[e][0] = __builtin_bit_cast(unsigned short, h);
+            pc[e][1] = __builtin_bit_cast(unsigned short, (_Float16)(ws - (float)h));
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) U[gx_wino_h_word(m, k, p, q, Kpad16)] = (unsigned)pc[0][q] | ((unsigned)pc[1][q] << 16);
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const __bf16 h = (__bf16)v[e];
@@ -634,20 +702,38 @@ __device__ __forceinline__ void wino_h_store(unsigned* __restrict__ U, float v0,
     for (int q = 0; q < 3; ++q) U[gx_wino_h_word(m, k, p, q, Kpad16)] = (unsigned)pc[0][q] | ((unsigned)pc[1][q] << 16);
 }
 
+// amax: non-NULL = the fp16-piece form (two pieces of U * 2^e, e from the weights' largest magnitude *amax)
 __global__ void wino_pack_h_kernel(const float* __restrict__ w, unsigned* __restrict__ U, int mode, int Co, int Ci, int Kpad16,
-                                   int Mpad) {
+                                   int Mpad, const float* __restrict__ amax) {
     const int total = 16 * (Kpad16 / 2) * Mpad;
+    const int f16_exp = amax ? gx_f16_scale_exp(2.25f * *amax) : 0;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int m = idx % Mpad, k = 2 * ((idx / Mpad) % (Kpad16 / 2)), p = idx / (Mpad * (Kpad16 / 2));
-        wino_h_store(U, gx_wino_u_value(w, mode, Co, Ci, m, k, p), gx_wino_u_value(w, mode, Co, Ci, m, k + 1, p), m, k, p, Kpad16);
+        wino_h_store(U, gx_wino_u_value(w, mode, Co, Ci, m, k, p), gx_wino_u_value(w, mode, Co, Ci, m, k + 1, p), m, k, p, Kpad16,
+                     amax != nullptr, f16_exp);
     }
 }
 
 // the pair variants' operands (wino_pack_pair_kernel) for the bf16 pipe
+// f16: two fp16 pieces of U * 2^e, e from max(|w1|, |w2|) -- the two floats wino_pair_amax_kernel left in Uf's trailer
+__global__ void __launch_bounds__(1024)
+wino_pair_amax_kernel(const float* __restrict__ w1, const float* __restrict__ w2, int n1, int n2, float* __restrict__ tf,
+                      float* __restrict__ td) {
+    const float r = gx_wg1024_amax(blockIdx.x == 0 ? w1 : w2, blockIdx.x == 0 ? n1 : n2);
+    if (threadIdx.x == 0) { tf[1 + blockIdx.x] = r; td[1 + blockIdx.x] = r; }      // (slots 1, 2 of each direction's trailer)
+}
 __global__ void wino_pack_pair_h_kernel(const float* __restrict__ w1, const float* __restrict__ w2, unsigned* __restrict__ Uf,
                                         unsigned* __restrict__ Ud, int Co1, int Co2, int Ci, int KpadF, int MpadF, int KpadD,
-                                        int MpadD) {
+                                        int MpadD, int f16) {
     const int totF = 16 * (KpadF / 2) * MpadF, totD = 16 * (KpadD / 2) * MpadD;
+    int f16_exp = 0;
+    if (f16) {
+        float* tf = reinterpret_cast<float*>(reinterpret_cast<char*>(Uf) + gx_kq_h_amax_off(KpadF, MpadF, 16));
+        float* td = reinterpret_cast<float*>(reinterpret_cast<char*>(Ud) + gx_kq_h_amax_off(KpadD, MpadD, 16));
+        const float am = fmaxf(tf[1], tf[2]);          // (slots 1, 2: the two tensors' maxima; slot 0: their maximum, what the conv kernel reads)
+        f16_exp = gx_f16_scale_exp(2.25f * am);
+        if (blockIdx.x == 0 && threadIdx.x == 0) { tf[0] = am; td[0] = am; }
+    }
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < totF + totD; idx += gridDim.x * blockDim.x) {
         if (idx < totF) {
             const int m = idx % MpadF, k = 2 * ((idx / MpadF) % (KpadF / 2)), p = idx / (MpadF * (KpadF / 2));
@@ -655,7 +741,7 @@ __global__ void wino_pack_pair_h_kernel(const float* __restrict__ w1, const floa
 #pragma unroll
             for (int e = 0; e < 2; ++e)
                 v[e] = m < Co1 ? gx_wino_u_value(w1, 0, Co1, Ci, m, k + e, p) : gx_wino_u_value(w2, 0, Co2, Ci, m - Co1, k + e, p);
-            wino_h_store(Uf, v[0], v[1], m, k, p, KpadF);
+            wino_h_store(Uf, v[0], v[1], m, k, p, KpadF, f16 != 0, f16_exp);
         } else {
             const int i = idx - totF;
             const int m = i % MpadD, k = 2 * ((i / MpadD) % (KpadD / 2)), p = i / (MpadD * (KpadD / 2));
@@ -663,7 +749,7 @@ __global__ void wino_pack_pair_h_kernel(const float* __restrict__ w1, const floa
 #pragma unroll
             for (int e = 0; e < 2; ++e)
                 v[e] = k + e < Co1 ? gx_wino_u_value(w1, 1, Co1, Ci, m, k + e, p) : gx_wino_u_value(w2, 1, Co2, Ci, m, k + e - Co1, p);
-            wino_h_store(Ud, v[0], v[1], m, k, p, KpadD);
+            wino_h_store(Ud, v[0], v[1], m, k, p, KpadD, f16 != 0, f16_exp);
         }
     }
 }
@@ -677,6 +763,25 @@ bool gx_wino_h_on() {
         g_wino_h = (env && env[0] == '0') ? 0 : 1;
     }
     return g_wino_h == 1;
+}
+
+// ---- the fp16-piece form: 2 (default) where the input tensor's partial maxima were handed in (gx_conv_input_amax);
+// GENESIS_WINO_F16X3=0 / gx_wino_precision(1): six bf16 piece products everywhere
+static int g_wino_f16 = -1;
+static bool wino_f16_on() {
+    if (g_wino_f16 < 0) {
+        const char* env = getenv("GENESIS_WINO_F16X3");
+        g_wino_f16 = (env && env[0] == '0') ? 0 : 1;
+    }
+    return g_wino_f16 == 1 && gx_wino_h_on();
+}
+namespace { struct WinoHint { const float* p0; const float* p1; int n0, n1; }; thread_local WinoHint t_wino_hint = {nullptr, nullptr, 0, 0}; }
+// true: the NEXT Winograd launch of this thread runs on fp16 pieces (the caller packs kinds 45 / 46 for it)
+bool gx_wino_f16_pending(void) { return wino_f16_on() && t_wino_hint.p0 && t_wino_hint.n0 > 0; }
+extern "C" int gx_conv_input_amax(const float* p0, int n0, const float* p1, int n1) {
+    t_wino_hint.p0 = (p0 && n0 > 0) ? p0 : nullptr; t_wino_hint.n0 = t_wino_hint.p0 ? n0 : 0;
+    t_wino_hint.p1 = (t_wino_hint.p0 && p1 && n1 > 0) ? p1 : nullptr; t_wino_hint.n1 = t_wino_hint.p1 ? n1 : 0;
+    return GX_OK;
 }
 
 static bool wino_shape_ok(int N, int K, int M, int H, int W) {
@@ -708,7 +813,11 @@ bool gx_wino_eligible(int N, int K, int M, int H, int W) {
 static int wino_launch(const float* in, const float* in2, int K1, const float* U, float* out, float* out2, int M1, int N,
                        int K, int M, int H, int W, hipStream_t s) {
     const bool h = gx_wino_h_on();          // (the operands in U were packed for the same pipe: wino_kpad / the pack kinds)
+    const bool f16 = gx_wino_f16_pending(); // (... and, with the input's maxima handed in, as fp16 pieces: the caller asked the same question)
     WinoGeom g;
+    g.xam0 = f16 ? t_wino_hint.p0 : nullptr; g.xn0 = f16 ? t_wino_hint.n0 : 0;
+    g.xam1 = f16 ? t_wino_hint.p1 : nullptr; g.xn1 = f16 ? t_wino_hint.n1 : 0;
+    t_wino_hint = WinoHint{nullptr, nullptr, 0, 0};          // one-shot
     g.N = N; g.H = H; g.W = W; g.K = K; g.M = M;
     g.Kpad = gx_round_up(K, h ? HKC : WKC);
     g.Mpad = gx_round_up(M, 64);
@@ -721,7 +830,7 @@ static int wino_launch(const float* in, const float* in2, int K1, const float* U
     // (128 -> 64): one wave per SIMD has nobody to hand the matrix pipe to while it waits -- and is kept behind
     // GENESIS_WINO_NB=2 for measurement only.
     static const char* nb_env = getenv("GENESIS_WINO_NB");
-    const int nb = (h && (H % 16) == 0 && nb_env && nb_env[0] == '2') ? 2 : 1;
+    const int nb = (h && !f16 && (H % 16) == 0 && nb_env && nb_env[0] == '2') ? 2 : 1;
     g.tiles_h = H / (2 * WTH * nb);
     g.tiles_w = W / (2 * WTW);
     static bool attr_set = false;
@@ -730,9 +839,11 @@ static int wino_launch(const float* in, const float* in2, int K1, const float* U
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_h_kernel<1>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_h_kernel<1, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_h_kernel<2>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_h_kernel<1, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_h_kernel<2, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
@@ -741,10 +852,13 @@ static int wino_launch(const float* in, const float* in2, int K1, const float* U
         const double bytes = 4.0 * ((double)N * K * H * W + (double)N * M * H * W + 9.0 * K * M);
         GxProf pf(KID_WINO, s, flops, bytes);
         if (h && nb == 2)
-            hipLaunchKernelGGL(wino_conv_h_kernel<2>, dim3(N * g.tiles_h * g.tiles_w, g.Mpad / 64), dim3(256), lds, s, in, in2,
+            hipLaunchKernelGGL((wino_conv_h_kernel<2, false>), dim3(N * g.tiles_h * g.tiles_w, g.Mpad / 64), dim3(256), lds, s, in, in2,
+                               reinterpret_cast<const unsigned*>(U), out, out2, g);
+        else if (h && f16)
+            hipLaunchKernelGGL((wino_conv_h_kernel<1, true>), dim3(N * g.tiles_h * g.tiles_w, g.Mpad / 64), dim3(256), lds, s, in, in2,
                                reinterpret_cast<const unsigned*>(U), out, out2, g);
         else if (h)
-            hipLaunchKernelGGL(wino_conv_h_kernel<1>, dim3(N * g.tiles_h * g.tiles_w, g.Mpad / 64), dim3(256), lds, s, in, in2,
+            hipLaunchKernelGGL((wino_conv_h_kernel<1, false>), dim3(N * g.tiles_h * g.tiles_w, g.Mpad / 64), dim3(256), lds, s, in, in2,
                                reinterpret_cast<const unsigned*>(U), out, out2, g);
         else
         hipLaunchKernelGGL(wino_conv_kernel, dim3(N * g.tiles_h * g.tiles_w, g.Mpad / 64), dim3(256), lds, s, in, in2, U,
@@ -772,13 +886,16 @@ int gx_conv3x3_wino_policy(int mode) {
 // bytes of one direction's packed operands (either pipe's layout fits: the bf16 one is 1.5 x the fp32 one)
 static size_t wino_u_bytes(int K, int M) {
     const size_t f = (size_t)16 * gx_round_up(K, 8) * gx_round_up(M, 64) * sizeof(float);
-    const size_t h = gx_wino_h_bytes(gx_round_up(K, HKC), gx_round_up(M, 64));
+    const size_t h = gx_wino_h_bytes(gx_round_up(K, HKC), gx_round_up(M, 64)) + 16384;      // (+ the trailer of the fp16-piece packing: the weights' largest magnitude)
     return f > h ? f : h;
 }
 
 int gx_wino_precision(int mode) {
-    GX_CHECK_ARG(mode == 0 || mode == 1, "gx_wino_precision: mode must be 0 (fp32 matrix pipe) or 1 (bf16 pipe, six piece products)");
-    g_wino_h = mode;
+    GX_CHECK_ARG(mode >= -1 && mode <= 2, "gx_wino_precision: mode must be 0 (fp32 matrix pipe), 1 (bf16 pipe, six piece products), 2 (as 1, "
+                                          "three fp16 piece products where the input's maxima are handed in) or -1 (the environment's default)");
+    if (mode < 0) { g_wino_h = -1; g_wino_f16 = -1; return GX_OK; }
+    g_wino_h = mode ? 1 : 0;
+    g_wino_f16 = mode == 2 ? 1 : 0;
     return GX_OK;
 }
 
@@ -800,14 +917,20 @@ int gx_conv3x3_wino(const float* x, const float* w, float* y, int N, int Cin, in
     hipStream_t s = (hipStream_t)stream;
     const int K = mode == 0 ? Cin : Cout, M = mode == 0 ? Cout : Cin;
     const bool h = gx_wino_h_on();
+    const bool f16 = gx_wino_f16_pending();
     const int Kpad = gx_round_up(K, h ? HKC : WKC), Mpad = gx_round_up(M, 64);
     float* U = (float*)ws;
+    float* trailer = reinterpret_cast<float*>(reinterpret_cast<char*>(U) + gx_kq_h_amax_off(Kpad, Mpad, 16));
+    if (f16) {
+        const int rc = gx_kq_weight_amax_launch(w, Cout * Cin * 9, trailer, s);
+        if (rc) return rc;
+    }
     {
         const int total = 16 * Kpad * Mpad;
         GxProf pf(KID_PACK_WEIGHTS, s, 0.0, 8.0 * total);
         if (h)
             hipLaunchKernelGGL(wino_pack_h_kernel, dim3(gx_ceil_div(total / 2, 256)), dim3(256), 0, s, w, (unsigned*)U, mode, Cout,
-                               Cin, Kpad, Mpad);
+                               Cin, Kpad, Mpad, f16 ? (const float*)trailer : (const float*)nullptr);
         else
         hipLaunchKernelGGL(wino_pack_kernel, dim3(gx_ceil_div(total, 256)), dim3(256), 0, s, w, U, mode, Cout, Cin, Kpad,
                            Mpad);
@@ -834,16 +957,23 @@ static void pair_u(void* ws, int Cin, int Co, float** Uf, float** Ud) {
 }
 
 // both directions' operands of a layer pair in one launch, for the pipe in force
-static int pair_pack(const float* w1, const float* w2, float* Uf, float* Ud, int Cin, int Co1, int Co2, hipStream_t s) {
+// f16: both directions as fp16 pieces (one scale for the pair, from max(|w1|, |w2|): an amax launch ahead of the pack)
+static int pair_pack(const float* w1, const float* w2, float* Uf, float* Ud, int Cin, int Co1, int Co2, hipStream_t s, bool f16) {
     const int Co = Co1 + Co2;
     const bool h = gx_wino_h_on();
     const int kq = h ? HKC : WKC;
     const int KpF = gx_round_up(Cin, kq), MpF = gx_round_up(Co, 64), KpD = gx_round_up(Co, kq), MpD = gx_round_up(Cin, 64);
     const int total = 16 * (KpF * MpF + KpD * MpD);
+    if (h && f16) {
+        GxProf pf(KID_SMALL_REDUCE, s, 0.0, 4.0 * 9 * Cin * Co);
+        hipLaunchKernelGGL(wino_pair_amax_kernel, dim3(2), dim3(1024), 0, s, w1, w2, Co1 * Cin * 9, Co2 * Cin * 9,
+                           reinterpret_cast<float*>(reinterpret_cast<char*>(Uf) + gx_kq_h_amax_off(KpF, MpF, 16)),
+                           reinterpret_cast<float*>(reinterpret_cast<char*>(Ud) + gx_kq_h_amax_off(KpD, MpD, 16)));
+    }
     GxProf pf(KID_PACK_WEIGHTS, s, 0.0, 8.0 * total);
     if (h)
         hipLaunchKernelGGL(wino_pack_pair_h_kernel, dim3(gx_ceil_div(total / 2, 256)), dim3(256), 0, s, w1, w2, (unsigned*)Uf,
-                           (unsigned*)Ud, Co1, Co2, Cin, KpF, MpF, KpD, MpD);
+                           (unsigned*)Ud, Co1, Co2, Cin, KpF, MpF, KpD, MpD, f16 ? 1 : 0);
     else
         hipLaunchKernelGGL(wino_pack_pair_kernel, dim3(gx_ceil_div(total, 256)), dim3(256), 0, s, w1, w2, Uf, Ud, Co1, Co2, Cin,
                            KpF, MpF, KpD, MpD);
@@ -861,7 +991,9 @@ int gx_conv3x3_pair_fwd(const float* x, const float* w1, const float* w2, float*
     const int Co = Co1 + Co2;
     float *Uf, *Ud;
     pair_u(ws, Cin, Co, &Uf, &Ud);
-    pair_pack(w1, w2, Uf, Ud, Cin, Co1, Co2, s);
+    // (an armed gx_conv_input_amax hint: BOTH directions are packed as fp16 pieces -- gx_conv3x3_pair_dgrad with pack = 0 must then
+    //  be given its inputs' maxima too, or re-pack)
+    pair_pack(w1, w2, Uf, Ud, Cin, Co1, Co2, s, gx_wino_f16_pending());
     GX_CHECK_LAUNCH("gx_conv3x3_pair_fwd(pack)");
     return wino_launch(x, nullptr, 0, Uf, y1, y2, Co1, N, Cin, Co, H, W, s);
 }
@@ -877,7 +1009,7 @@ int gx_conv3x3_pair_dgrad(const float* dy1, const float* dy2, const float* w1, c
     float *Uf, *Ud;
     pair_u(ws, Cin, Co, &Uf, &Ud);
     if (pack) {
-        pair_pack(w1, w2, Uf, Ud, Cin, Co1, Co2, s);
+        pair_pack(w1, w2, Uf, Ud, Cin, Co1, Co2, s, gx_wino_f16_pending());
         GX_CHECK_LAUNCH("gx_conv3x3_pair_dgrad(pack)");
     }
     return wino_launch(dy1, dy2, Co1, Ud, dx, nullptr, 0, N, Co, Cin, H, W, s);

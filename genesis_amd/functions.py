@@ -214,7 +214,7 @@ class ConvGNReLUFn(torch.autograd.Function):
         x = x.contiguous()
         out = torch.empty(x.shape[0], w.shape[0], x.shape[2], x.shape[3], device=x.device)
         ctx.am_x = getattr(x, '_gx_amax', None)       # (partial maxima of the input, left by the node that produced it)
-        y, mean, rstd = hip.conv3x3_gn_relu_fwd(x, w, gamma, beta, GROUPS, EPS, (out, 0, 0))
+        y, mean, rstd = hip.conv3x3_gn_relu_fwd(x, w, gamma, beta, GROUPS, EPS, (out, 0, 0), amax_in=ctx.am_x)
         out._gx_amax = hip.take_amax()
         ctx.save_for_backward(x, y, mean, rstd)
         ctx.params = (w, gamma, beta)
@@ -229,7 +229,7 @@ class ConvGNReLUFn(torch.autograd.Function):
                                                out=(og, ob, None))
         am = (hip.take_amax(), ctx.am_x)
         dw = _wgrad(lambda: hip.conv3x3_wgrad(x, dy, out=ow, amax=am), ow, x, dy)
-        dx = hip.conv3x3_dgrad(dy, w) if ctx.needs_input_grad[0] else None
+        dx = hip.conv3x3_dgrad(dy, w, amax_in=am[0]) if ctx.needs_input_grad[0] else None
         return dx, _ret(ow, dw), _ret(og, dgamma), _ret(ob, dbeta)
 
 
@@ -270,11 +270,11 @@ class UNetEncoderFn(torch.autograd.Function):
             if i < nb - 1:
                 nxt = torch.empty(N, C, Hc // 2, Wc // 2, device=dev)
                 y, mean, rstd = hip.conv3x3_gn_relu_fwd(cur, w, gamma, beta, ngroups(C), EPS, (cats[j], cx, 0),
-                                                        (nxt, 0, 2))
+                                                        (nxt, 0, 2), amax_in=am_cur)
             else:
                 nxt = torch.empty(N, C, Hc, Wc, device=dev)
                 y, mean, rstd = hip.conv3x3_gn_relu_fwd(cur, w, gamma, beta, ngroups(C), EPS, (cats[j], cx, 0),
-                                                        (nxt, 0, 0))
+                                                        (nxt, 0, 0), amax_in=am_cur)
                 mlp_in = nxt
             am_in.append(am_cur)
             am_cur = am_cat[j][1] = hip.take_amax()          # (the skip slice and the resampled copy hold the same values)
@@ -297,11 +297,11 @@ class UNetEncoderFn(torch.autograd.Function):
             w, gamma, beta = up[j]
             if j < nb - 1:
                 y, mean, rstd = hip.conv3x3_gn_relu_fwd(cats[j], w, gamma, beta, ngroups(w.shape[0]), EPS,
-                                                        (cats[j + 1], 0, 1))
+                                                        (cats[j + 1], 0, 1), amax_in=am_cat[j])
             else:
                 out = torch.empty(N, w.shape[0], cats[j].shape[2], cats[j].shape[3], device=dev)
                 y, mean, rstd = hip.conv3x3_gn_relu_fwd(cats[j], w, gamma, beta, ngroups(w.shape[0]), EPS,
-                                                        (out, 0, 0))
+                                                        (out, 0, 0), amax_in=am_cat[j])
             if j < nb - 1:
                 am_cat[j + 1][0] = hip.take_amax()
             else:
@@ -336,7 +336,7 @@ class UNetEncoderFn(torch.autograd.Function):
             am = (hip.take_amax(), ctx.am_cat[j])
             dw = _wgrad(lambda cj=cats[j], dy=dy, ow=ow, am=am: hip.conv3x3_wgrad(cj, dy, out=ow, amax=am), ow, cats[j], dy)
             # (read by GroupNorm backward kernels only -- they sum split-K slabs on load; dcat[0] also feeds the MLP)
-            dcat[j] = hip.conv3x3_dgrad_parts(dy, w) if j > 0 else hip.conv3x3_dgrad(dy, w)
+            dcat[j] = hip.conv3x3_dgrad_parts(dy, w, amax_in=am[0]) if j > 0 else hip.conv3x3_dgrad(dy, w, amax_in=am[0])
             g_up[j] = (_ret(ow, dw), _ret(og, dgamma), _ret(ob, dbeta))
             gsrc = (dcat[j], 0, 1)   # block j-1's output was 2x up-sampled into cat_j[:, :Cx]
         # MLP backward
@@ -372,9 +372,9 @@ class UNetEncoderFn(torch.autograd.Function):
             dw = _wgrad(lambda cur=cur, dy=dy, ow=ow, am=am: hip.conv3x3_wgrad(cur, dy, out=ow, amax=am), ow, cur, dy)
             g_down[i] = (_ret(ow, dw), _ret(og, dgamma), _ret(ob, dbeta))
             if i > 0:
-                d_next = hip.conv3x3_dgrad_parts(dy, w)
+                d_next = hip.conv3x3_dgrad_parts(dy, w, amax_in=am[0])
             elif ctx.needs_input_grad[0]:
-                dx = hip.conv3x3_dgrad(dy, w)
+                dx = hip.conv3x3_dgrad(dy, w, amax_in=am[0])
         flat = []
         for t in g_down + g_up:
             flat.extend(t)
@@ -513,7 +513,7 @@ class SegFeatHeadsFn(torch.autograd.Function):
         ctx.am_x = getattr(enc_feat, '_gx_amax', None)
         ctx.params = (seg_w, seg_gamma, seg_beta, conv_w, conv_b, gate, log_sigma, feat_w, feat_gamma, feat_beta)
         w2 = conv_w.detach().view(conv_w.shape[0], -1)
-        y, yf, ctx.pair_ws = hip.conv3x3_pair_fwd(x, seg_w, feat_w)
+        y, yf, ctx.pair_ws = hip.conv3x3_pair_fwd(x, seg_w, feat_w, amax_in=ctx.am_x)
         mean, rstd = hip.gn_relu_fwd(y, seg_gamma, seg_beta, GROUPS, EPS, None)          # statistics only
         colour = hip.conv1x1_gn_fwd(y, mean, rstd, seg_gamma, seg_beta, GROUPS, w2, conv_b, gate, uv)
         ctx.ls_dtype = log_sigma.dtype
@@ -566,7 +566,7 @@ class SegFeatHeadsFn(torch.autograd.Function):
         am_f = (hip.take_amax(), ctx.am_x)
         dfw = _wgrad(lambda: hip.conv3x3_wgrad(x, dyf, out=ofw, amax=am_f), ofw, x, dyf)
         # --- both input gradients: one launch
-        dx = hip.conv3x3_pair_dgrad(dy, dyf, seg_w, feat_w, ctx.pair_ws) if ctx.needs_input_grad[0] else None
+        dx = hip.conv3x3_pair_dgrad(dy, dyf, seg_w, feat_w, ctx.pair_ws, amax_in=[am_s[0], am_f[0]]) if ctx.needs_input_grad[0] else None
         return (dx, _ret(osw, dsw), _ret(osg, dgamma), _ret(osb, dbeta), _ret(ow, dw.view(conv_w.shape)), _ret(ob, db),
                 _ret(og, dgate), None, _ret(ols, dls.to(ctx.ls_dtype)), None, None, None, None, None,
                 _ret(ofw, dfw), _ret(ofg, dfgamma), _ret(ofb, dfbeta))

@@ -148,6 +148,37 @@ class _operand_amax(object):
         return False
 
 
+WINO_F16 = os.environ.get('GENESIS_WINO_F16X3', '1') != '0'
+
+
+class _input_amax(object):
+    """with _input_amax(handles): ... one conv3x3 forward / data-gradient call whose INPUT tensor's partial maxima are `handles`
+    (an Amax, or a list of up to two: a concat buffer, the pair data gradient's two tensors) -- gx_conv_input_amax: a layer that
+    takes the Winograd kernel then runs on two fp16 pieces per operand.  Any unknown part disables the hint."""
+
+    def __init__(self, handles):
+        self.on = False
+        if not WINO_F16 or handles is None:
+            return
+        hs = list(handles) if isinstance(handles, (list, tuple)) else [handles]
+        if not hs or len(hs) > 2 or any(h is None for h in hs):
+            return
+        hs = hs + [None] * (2 - len(hs))
+        self.args = [ctypes.c_void_p(hs[0].ptr), hs[0].n, ctypes.c_void_p(hs[1].ptr) if hs[1] is not None else None,
+                     hs[1].n if hs[1] is not None else 0]
+        self.on = True
+
+    def __enter__(self):
+        if self.on:
+            _lib.call('gx_conv_input_amax', *self.args)
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            _lib.call('gx_conv_input_amax', None, 0, None, 0)       # (a call that took another kernel leaves it armed)
+        return False
+
+
 # ---- deferred parameter-gradient reductions (gx_defer_*): TrainStep turns this on for one backward pass; calls that
 # write a parameter gradient into a caller-provided buffer then queue their final reduce, and defer_flush() finishes
 # all of them in one launch per kind.  Workspaces of queued calls are kept alive here until the flush.
@@ -197,7 +228,7 @@ def defer_discard():
 
 
 # ------------------------------------------------------------------ conv3x3
-def conv3x3_fwd(x, w):
+def conv3x3_fwd(x, w, amax_in=None):
     _chk(x, 'conv3x3_fwd.x'); _chk(w, 'conv3x3_fwd.w')
     N, Cin, H, W = x.shape
     Cout = w.shape[0]
@@ -205,11 +236,12 @@ def conv3x3_fwd(x, w):
     y = torch.empty(N, Cout, H, W, dtype=F32, device=x.device)
     nb = _lib.query('gx_conv3x3_ws_bytes', N, Cin, Cout, H, W)
     ws = _ws(nb, x.device)
-    _lib.call('gx_conv3x3_fwd', _p(x), _p(w), _p(y), N, Cin, Cout, H, W, _p(ws), nb, _stream())
+    with _input_amax(amax_in):
+        _lib.call('gx_conv3x3_fwd', _p(x), _p(w), _p(y), N, Cin, Cout, H, W, _p(ws), nb, _stream())
     return y
 
 
-def conv3x3_dgrad(dy, w):
+def conv3x3_dgrad(dy, w, amax_in=None):
     _chk(dy, 'conv3x3_dgrad.dy'); _chk(w, 'conv3x3_dgrad.w')
     N, Cout, H, W = dy.shape
     Cin = w.shape[1]
@@ -217,15 +249,16 @@ def conv3x3_dgrad(dy, w):
     dx = torch.empty(N, Cin, H, W, dtype=F32, device=dy.device)
     nb = _lib.query('gx_conv3x3_ws_bytes', N, Cin, Cout, H, W)
     ws = _ws(nb, dy.device)
-    _lib.call('gx_conv3x3_dgrad', _p(dy), _p(w), _p(dx), N, Cin, Cout, H, W, _p(ws), nb, _stream())
+    with _input_amax(amax_in):
+        _lib.call('gx_conv3x3_dgrad', _p(dy), _p(w), _p(dx), N, Cin, Cout, H, W, _p(ws), nb, _stream())
     return dx
 
 
-def conv3x3_dgrad_parts(dy, w):
+def conv3x3_dgrad_parts(dy, w, amax_in=None):
     """conv3x3_dgrad without the split-K reduce launch: a tensor, or (the small layers, whose channel reduction is split to
     fill the chip) a Parts object for gn_relu_bwd's gradient sources (gx_conv3x3_dgrad_parts)."""
     if not FUSE_SPLITK_INTO_GN:
-        return conv3x3_dgrad(dy, w)
+        return conv3x3_dgrad(dy, w, amax_in)
     _chk(dy, 'conv3x3_dgrad.dy'); _chk(w, 'conv3x3_dgrad.w')
     N, Cout, H, W = dy.shape
     Cin = w.shape[1]
@@ -234,8 +267,9 @@ def conv3x3_dgrad_parts(dy, w):
     nb = _lib.query('gx_conv3x3_ws_bytes', N, Cin, Cout, H, W)
     ws = _ws(nb, dy.device)
     parts, nsplit, stride = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_size_t()
-    _lib.call('gx_conv3x3_dgrad_parts', _p(dy), _p(w), _p(dx), N, Cin, Cout, H, W, _p(ws), nb, ctypes.byref(parts),
-              ctypes.byref(nsplit), ctypes.byref(stride), _stream())
+    with _input_amax(amax_in):
+        _lib.call('gx_conv3x3_dgrad_parts', _p(dy), _p(w), _p(dx), N, Cin, Cout, H, W, _p(ws), nb, ctypes.byref(parts),
+                  ctypes.byref(nsplit), ctypes.byref(stride), _stream())
     if nsplit.value == 1:
         return dx
     return Parts(parts.value, nsplit.value, stride.value, (N, Cin, H, W), (ws, dx))
@@ -412,10 +446,10 @@ def gn_relu_fwd(y, gamma, beta, groups, eps, dst0, dst1=None):
 FUSE_SPLITK_INTO_GN = os.environ.get('GENESIS_FUSE_SPLITK_GN', '1') == '1'
 
 
-def _conv_gn(kind, x, w, bias, gamma, beta, groups, eps, dst0, dst1, link_out=False):
+def _conv_gn(kind, x, w, bias, gamma, beta, groups, eps, dst0, dst1, link_out=False, amax_in=None):
     # link_out: arm gx_kq_amax_link for the normalised output (dst0) -- its next reader is an fp16 x 3 conv
     if not FUSE_SPLITK_INTO_GN:
-        y = conv3x3_fwd(x, w) if kind == 'conv3x3' else deconv5x5s2_fwd(x, w, bias)
+        y = conv3x3_fwd(x, w, amax_in) if kind == 'conv3x3' else deconv5x5s2_fwd(x, w, bias)
         mean, rstd = gn_relu_fwd(y, gamma, beta, groups, eps, dst0, dst1)
         return y, mean, rstd
     N, Cin, H, W = x.shape
@@ -428,8 +462,9 @@ def _conv_gn(kind, x, w, bias, gamma, beta, groups, eps, dst0, dst1, link_out=Fa
     y = torch.empty(N, Cout, Ho, Wo, dtype=F32, device=x.device)
     ws = _ws(nb, x.device)
     parts, nsplit, stride = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_size_t()
-    _lib.call('gx_conv3x3_fwd_parts' if kind == 'conv3x3' else 'gx_deconv5x5s2_fwd_parts', _p(x), _p(w), _p(y), N, Cin,
-              Cout, H, W, _p(ws), nb, ctypes.byref(parts), ctypes.byref(nsplit), ctypes.byref(stride), _stream())
+    with _input_amax(amax_in if kind == 'conv3x3' else None):
+        _lib.call('gx_conv3x3_fwd_parts' if kind == 'conv3x3' else 'gx_deconv5x5s2_fwd_parts', _p(x), _p(w), _p(y), N, Cin,
+                  Cout, H, W, _p(ws), nb, ctypes.byref(parts), ctypes.byref(nsplit), ctypes.byref(stride), _stream())
     mean = torch.empty(N * groups, dtype=F32, device=x.device)
     rstd = torch.empty(N * groups, dtype=F32, device=x.device)
     need_sum = nsplit.value > 1 or bias is not None
@@ -443,12 +478,12 @@ def _conv_gn(kind, x, w, bias, gamma, beta, groups, eps, dst0, dst1, link_out=Fa
     return y, mean, rstd       # (ws, holding the partial slabs, is released only now)
 
 
-def conv3x3_gn_relu_fwd(x, w, gamma, beta, groups, eps, dst0, dst1=None):
+def conv3x3_gn_relu_fwd(x, w, gamma, beta, groups, eps, dst0, dst1=None, amax_in=None):
     """conv3x3 (no bias) -> GroupNorm+ReLU into the destination views (modules/blocks.py:159-165); returns the
     pre-norm conv output y (saved for backward) and the group statistics."""
     _chk(x, 'conv_gn.x'); _chk(w, 'conv_gn.w'); _chk(gamma, 'conv_gn.gamma'); _chk(beta, 'conv_gn.beta')
     assert w.shape[1:] == (x.shape[1], 3, 3), (w.shape, x.shape)
-    return _conv_gn('conv3x3', x, w, None, gamma, beta, groups, eps, dst0, dst1)
+    return _conv_gn('conv3x3', x, w, None, gamma, beta, groups, eps, dst0, dst1, amax_in=amax_in)
 
 
 def deconv5x5s2_gn_relu_fwd(x, w, bias, gamma, beta, groups, eps, dst0, dst1=None, link_out=False):
@@ -1412,7 +1447,15 @@ def conv3x3_pair_supported(x, w1, w2):
     return bool(_lib.query('gx_conv3x3_pair_supported', N, Cin, w1.shape[0], w2.shape[0], H, W))
 
 
-def conv3x3_pair_fwd(x, w1, w2):
+class PairWs(object):
+    """The packed weights of both directions of a layer pair + the form they were packed in (fp16 pieces or bf16 pieces)."""
+    __slots__ = ('t', 'f16')
+
+    def __init__(self, t, f16):
+        self.t, self.f16 = t, f16
+
+
+def conv3x3_pair_fwd(x, w1, w2, amax_in=None):
     """(conv3x3(x, w1), conv3x3(x, w2), ws) in one launch; ws = the packed weights of both directions, handed to
     conv3x3_pair_dgrad of the same iteration."""
     _chk(x, 'pair.x'); _chk(w1, 'pair.w1'); _chk(w2, 'pair.w2')
@@ -1422,26 +1465,33 @@ def conv3x3_pair_fwd(x, w1, w2):
     y2 = torch.empty(N, Co2, H, W, dtype=F32, device=x.device)
     nb = _lib.query('gx_conv3x3_pair_ws_bytes', N, Cin, Co1, Co2, H, W)
     ws = _ws(nb, x.device)
-    _lib.call('gx_conv3x3_pair_fwd', _p(x), _p(w1), _p(w2), _p(y1), _p(y2), N, Cin, Co1, Co2, H, W, _p(ws), nb, _stream())
-    return y1, y2, ws
+    hint = _input_amax(amax_in)
+    with hint:
+        _lib.call('gx_conv3x3_pair_fwd', _p(x), _p(w1), _p(w2), _p(y1), _p(y2), N, Cin, Co1, Co2, H, W, _p(ws), nb, _stream())
+    return y1, y2, PairWs(ws, hint.on)
 
 
-def conv3x3_pair_dgrad(dy1, dy2, w1, w2, ws=None):
-    """dgrad(dy1, w1) + dgrad(dy2, w2) in one launch (ws: the forward's packed weights; None: pack here)."""
+def conv3x3_pair_dgrad(dy1, dy2, w1, w2, ws=None, amax_in=None):
+    """dgrad(dy1, w1) + dgrad(dy2, w2) in one launch (ws: the forward's packed weights -- a PairWs; None: pack here).
+    amax_in: [Amax of dy1, Amax of dy2].  The forward's packing is reused only in the form THIS call runs in."""
     _chk(dy1, 'pair.dy1'); _chk(dy2, 'pair.dy2'); _chk(w1, 'pair.w1'); _chk(w2, 'pair.w2')
     N, Co1, H, W = dy1.shape
     Co2, Cin = dy2.shape[1], w1.shape[1]
     dx = torch.empty(N, Cin, H, W, dtype=F32, device=dy1.device)
     nb = _lib.query('gx_conv3x3_pair_ws_bytes', N, Cin, Co1, Co2, H, W)
+    hint = _input_amax(amax_in)
+    if isinstance(ws, PairWs):
+        ws = ws.t if ws.f16 == hint.on else None
     pack = ws is None
     if pack:
         ws = _ws(nb, dy1.device)
-    _lib.call('gx_conv3x3_pair_dgrad', _p(dy1), _p(dy2), _p(w1), _p(w2), _p(dx), N, Cin, Co1, Co2, H, W, int(pack),
-              _p(ws), nb, _stream())
+    with hint:
+        _lib.call('gx_conv3x3_pair_dgrad', _p(dy1), _p(dy2), _p(w1), _p(w2), _p(dx), N, Cin, Co1, Co2, H, W, int(pack),
+                  _p(ws), nb, _stream())
     return dx
 
 
-def conv3x3_wino(x, w, mode=0):
+def conv3x3_wino(x, w, mode=0, amax_in=None):
     """Winograd F(2x2,3x3) conv3x3: mode 0 forward (x [N,Cin,H,W]), mode 1 data gradient (x = dy [N,Cout,H,W])."""
     _chk(x, 'wino.x'); _chk(w, 'wino.w')
     N, _, H, W = x.shape
@@ -1449,6 +1499,7 @@ def conv3x3_wino(x, w, mode=0):
     y = torch.empty(N, Cout if mode == 0 else Cin, H, W, dtype=F32, device=x.device)
     nb = _lib.query('gx_conv3x3_wino_ws_bytes', N, Cin, Cout, H, W)
     ws = _ws(nb, x.device)
-    _lib.call('gx_conv3x3_wino', _p(x), _p(w), _p(y), N, Cin, Cout, H, W, mode, _p(ws), nb, _stream())
+    with _input_amax(amax_in):
+        _lib.call('gx_conv3x3_wino', _p(x), _p(w), _p(y), N, Cin, Cout, H, W, mode, _p(ws), nb, _stream())
     return y
 

@@ -120,6 +120,14 @@ int gx_kq_amax_link_hits(void);
  *      serve, the request is void) and disarms.  The caller keeps `parts` alive until its reader has RUN.
  *      gx_amax_parts(x, n, parts, stream): the partial maxima of any tensor by a pass of its own -- 256 floats. */
 int gx_amax_tap(float* parts, int capacity, size_t numel);
+/*      The consumer side for the Winograd conv3x3 layers (gx_wino.hip; modules/blocks.py:159-165 forward and data gradient):
+ *      gx_conv_input_amax(p0, n0, p1, n1) is the one-shot, per-thread hint that the INPUT tensor of the next gx_conv3x3_fwd* /
+ *      gx_conv3x3_dgrad* / gx_conv3x3_pair_* / gx_conv3x3_wino call has its partial maxima in p0[0 .. n0) (+ p1[0 .. n1): a
+ *      concat buffer written by two producers, or the pair data gradient's second tensor).  With it -- and gx_wino_precision(2),
+ *      the default; GENESIS_WINO_F16X3=0: mode 1 -- a layer that takes the Winograd kernel forms every fp32 product from THREE
+ *      fp16 piece products (U * 2^eU packed as two pieces, eU from max |w|; V * 2^eV split in registers, eV from 4 max |x|)
+ *      instead of six bf16 ones; layers on other kernels ignore it.  NULL / 0 clears.  Same range note as gx_wgq_operand_amax. */
+int gx_conv_input_amax(const float* p0, int n0, const float* p1, int n1);
 int gx_amax_tap_result(void);
 int gx_amax_parts(const float* x, size_t n, float* parts, gx_stream_t stream);
 size_t gx_conv3x3_wino_ws_bytes(int N, int Cin, int Cout, int H, int W);

@@ -305,13 +305,13 @@ def test_bf16_pipe_weight_gradients_on_the_activations_of_a_real_step():
     captured = []
     real_c3, real_dc = hip.conv3x3_wgrad, hip.deconv5x5s2_wgrad
 
-    def cap_c3(xx, dy, out=None):
+    def cap_c3(xx, dy, out=None, amax=None):
         captured.append(('conv3x3', xx.detach().clone(), dy.detach().clone()))
-        return real_c3(xx, dy, out=out)
+        return real_c3(xx, dy, out=out, amax=amax)
 
-    def cap_dc(xx, dy, out=None):
+    def cap_dc(xx, dy, out=None, amax=None):
         captured.append(('deconv', xx.detach().clone(), dy.detach().clone()))
-        return real_dc(xx, dy, out=out)
+        return real_dc(xx, dy, out=out, amax=amax)
     hip.conv3x3_wgrad, hip.deconv5x5s2_wgrad = cap_c3, cap_dc
     try:
         recon, losses, stats, att, comp = model(x)
@@ -325,20 +325,24 @@ def test_bf16_pipe_weight_gradients_on_the_activations_of_a_real_step():
         xc, dc = xx.cpu().double(), dy.cpu().double()
         if kind == 'conv3x3':
             ref = torch.nn.grad.conv2d_weight(xc, (dy.shape[1], xx.shape[1], 3, 3), dc, padding=1)
-            run = lambda: real_c3(xx, dy)  # noqa: E731
+            run = lambda am=None: real_c3(xx, dy, amax=am)  # noqa: E731
         else:
             w = torch.zeros(xx.shape[1], dy.shape[1], 5, 5, dtype=torch.float64, requires_grad=True)
             F.conv_transpose2d(xc, w, None, 2, 2, 1).backward(dc)
             ref = w.grad
-            run = lambda: real_dc(xx, dy)  # noqa: E731
+            run = lambda am=None: real_dc(xx, dy, amax=am)  # noqa: E731
         err = {}
         try:
-            for mode in (0, 1):
+            for mode in (0, 1, 2):      # fp32 pipe | six bf16 pieces | three fp16 pieces (the operands' maxima by a pass of their own)
                 _lib.call('gx_wgq_precision', mode)
-                err[mode] = float((run().double().cpu() - ref).norm() / ref.norm())
+                am = (hip.amax_of(dy), hip.amax_of(xx)) if mode == 2 else None
+                err[mode] = float((run(am).double().cpu() - ref).norm() / ref.norm())
         finally:
-            _lib.call('gx_wgq_precision', 1)
-        print('%s x %s dy %s (x: mean %.3f std %.3f, zeros %.2f; dy: mean %.2e std %.2e): fp32 pipe %.3e, bf16 pipe %.3e'
+            _lib.call('gx_wgq_precision', -1)
+        print('%s x %s dy %s (x: mean %.3f std %.3f, zeros %.2f; dy: mean %.2e std %.2e): fp32 pipe %.3e, bf16 x 6 %.3e, fp16 x 3 %.3e'
               % (kind, tuple(xx.shape), tuple(dy.shape), float(xx.mean()), float(xx.std()), float((xx == 0).float().mean()),
-                 float(dy.mean()), float(dy.std()), err[0], err[1]))
+                 float(dy.mean()), float(dy.std()), err[0], err[1], err[2]))
+        # (fp16 pieces at this contraction length, 1.4e5 .. 9e5 terms: at most 2.5 x the fp32 pipe and never above the bf16 form,
+        #  tests/test_kernels_gpu.py::test_long_contraction_weight_gradient_on_fp16_pieces_per_output_channel)
+        assert err[2] <= 2.5 * err[0] + 1e-7 and err[2] <= 1.05 * err[1] + 1e-7 and err[2] < 1e-5, err
         assert err[1] <= 1.5 * err[0] + 1e-7 and err[1] < 1e-5, err
