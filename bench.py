@@ -407,13 +407,15 @@ def main():
                                                  'input': 'five-level flat-colour rectangles (SURVEY 8(d): the Multi-dSprites value '
                                                           'distribution, genesis_amd/testing.make_rect_input); same HIP-graph step'}
         if os.environ.get('GENESIS_WGQ_BF16X6', '1') != '0':
-            result['arithmetic'] = ('fp32 tensors and fp32 accumulation everywhere; the weight gradients and the Winograd conv3x3 layers '
-                                    'form every fp32 product from six bf16 piece products on the bf16 matrix pipe (hi+mid+lo pieces hold '
-                                    'all 24 mantissa bits), the chip-filling transposed-conv forward / data-gradient layers (and the '
-                                    'other gx_kq.hip kernels) from three fp16 piece products of per-tensor power-of-two-scaled operands '
-                                    '(hi+lo = 22 bits, the dropped term is 2^-22 of a product; GENESIS_KQ_F16X3=0: six bf16 ones): error '
-                                    'vs fp64 as on the fp32 pipe, tests/test_kernels_gpu.py *_bf16_pipe_* / *fp16x3*; everything else on '
-                                    'the fp32 pipe; GENESIS_WGQ_BF16X6=0 GENESIS_KQ_BF16X6=0 GENESIS_WINO_BF16X6=0 put all of it back there')
+            result['arithmetic'] = ('fp32 tensors and fp32 accumulation everywhere; the chip-filling transposed-conv forward / data-gradient '
+                                    'layers (gx_kq.hip), the weight gradients and the Winograd conv3x3 layers form every fp32 product from '
+                                    'THREE fp16 piece products of per-tensor power-of-two-scaled operands (hi+lo = 22 bits, the dropped '
+                                    'term is 2^-22 of a product) wherever the operand tensors\' largest magnitudes are known without a '
+                                    'pass over them -- handed over by the GroupNorm kernels that wrote them -- and from six bf16 piece '
+                                    'products (hi+mid+lo = all 24 mantissa bits) elsewhere (the <= 8 x 8 levels; GENESIS_KQ_F16X3=0 '
+                                    'GENESIS_WGQ_F16X3=0 GENESIS_WINO_F16X3=0: six bf16 ones everywhere): error vs fp64 at or below the '
+                                    'six-piece form\'s, tests/test_kernels_gpu.py *fp16*; everything else on the fp32 pipe; '
+                                    'GENESIS_WGQ_BF16X6=0 GENESIS_KQ_BF16X6=0 GENESIS_WINO_BF16X6=0 put all of it back there')
         if rehearsal:
             result['rehearsal'] = 'all %d ranks on ONE GPU, gloo collective: exercises the launch path only, not a measurement' % world
         if getattr(ts, 'capture_fallback_reason', None):
@@ -465,30 +467,42 @@ def main():
                 wino_b6 = dom['name'] == 'wino_conv_kernel' and os.environ.get('GENESIS_WINO_BF16X6', '1') != '0'
                 on_bf16 = wino_b6 or (dom['name'] == 'wgq_stream_kernel' and os.environ.get('GENESIS_WGQ_BF16X6', '1') != '0') or \
                           (dom['name'] in ('kq_dth_kernel', 'kq_dgh_kernel', 'kq_c3h_kernel', 'kq_c5h_kernel') and os.environ.get('GENESIS_KQ_BF16X6', '1') != '0')
+                wino_terms = float(BF16X6_TERMS)
                 if on_bf16:
-                    # `achieved` counts the algorithmic fp32 flops; the kernel executes six bf16 (gx_kq.hip's kernels: three
-                    # fp16) MFMA products for each of them, so its ceiling is the 16-bit pipe's dense peak / 6 (/ 3) -- a higher
-                    # one than the fp32 pipe's 157.3 TF/s
-                    f16x3 = dom['name'].startswith('kq_') and os.environ.get('GENESIS_KQ_F16X3', '1') != '0'
-                    terms = F16X3_TERMS if f16x3 else BF16X6_TERMS
+                    # `achieved` counts the algorithmic fp32 flops; the kernel executes six bf16 -- or, where the operands' maxima
+                    # are known (gx_kq.hip's kernels always; the weight gradients and the Winograd layers per layer: the library
+                    # reports the flop share, gx_wgq_last_f16_share / gx_wino_f16_share), three fp16 -- MFMA products for each of
+                    # them, so its ceiling is the 16-bit pipe's dense peak / (executed products per fp32 product) -- a higher one
+                    # than the fp32 pipe's 157.3 TF/s
+                    from genesis_amd import _lib as _L
+                    if dom['name'].startswith('kq_'):
+                        share = 1.0 if os.environ.get('GENESIS_KQ_F16X3', '1') != '0' else 0.0
+                    elif dom['name'] == 'wgq_stream_kernel':
+                        share = float(_L.load().gx_wgq_last_f16_share())
+                    else:
+                        share = float(_L.load().gx_wino_f16_share())
+                    terms = F16X3_TERMS * share + BF16X6_TERMS * (1.0 - share)
+                    wino_terms = terms
                     mfma_peak = PEAK_BF16_MFMA_TFLOPS / terms
                     roof['peak'] = mfma_peak
-                    roof['pipe'] = ('%s MFMA, fp32 products as %d %s piece products (fp32 accumulate): peak = %.0f / %d; '
-                                    'against the fp32 pipe (%.1f TF/s) the same rate is frac_of_fp32_pipe'
-                                    % ('fp16' if f16x3 else 'bf16', terms, 'fp16' if f16x3 else 'bf16', PEAK_BF16_MFMA_TFLOPS, terms,
-                                       PEAK_FP32_MFMA_TFLOPS))
+                    roof['fp16_piece_share_of_flops'] = share
+                    roof['pipe'] = ('16-bit MFMA pipe (dense peak %.0f TF/s): %.0f %% of this kernel\'s algorithmic flops as 3 fp16 '
+                                    'piece products per fp32 product, the rest as 6 bf16 ones (fp32 accumulate): %.2f executed products '
+                                    'per fp32 product, peak = %.0f / %.2f; against the fp32 pipe (%.1f TF/s) the same rate is '
+                                    'frac_of_fp32_pipe' % (PEAK_BF16_MFMA_TFLOPS, 100.0 * share, terms, PEAK_BF16_MFMA_TFLOPS, terms,
+                                                           PEAK_FP32_MFMA_TFLOPS))
                     roof['achieved_on_bf16_pipe'] = ach * terms
                 if dom['name'] == 'wino_conv_kernel':
                     # `achieved` is ALGORITHMIC (direct-sum) flops / time, as for every kernel; the Winograd kernel executes
                     # 16 multiplies where the direct sum has 36: the ceiling of the ALGORITHM on the fp32 pipe is 2.25 x the
                     # pipe's peak, and its rate on the pipe itself is achieved / 2.25
-                    pipe_peak = PEAK_BF16_MFMA_TFLOPS / BF16X6_TERMS if wino_b6 else PEAK_FP32_MFMA_TFLOPS
+                    pipe_peak = PEAK_BF16_MFMA_TFLOPS / wino_terms if wino_b6 else PEAK_FP32_MFMA_TFLOPS
                     mfma_peak = 2.25 * pipe_peak
                     roof['peak'] = mfma_peak
                     roof['algorithm'] = ('Winograd F(2x2,3x3): 1/2.25 of the algorithmic flops are executed as products%s; '
-                                         'peak = 2.25 x %.1f' % (', each as six bf16 piece products on the bf16 MFMA pipe (2500 / 6)'
-                                                                 if wino_b6 else ' on the fp32 MFMA pipe', pipe_peak))
-                    roof['achieved_on_mfma_pipe'] = ach / 2.25 * (BF16X6_TERMS if wino_b6 else 1)
+                                         'peak = 2.25 x %.1f' % (', each as %.2f piece products on the 16-bit MFMA pipe (2500 / %.2f)'
+                                                                 % (wino_terms, wino_terms) if wino_b6 else ' on the fp32 MFMA pipe', pipe_peak))
+                    roof['achieved_on_mfma_pipe'] = ach / 2.25 * (wino_terms if wino_b6 else 1)
                 roof['frac'] = ach / mfma_peak
                 # the plain formula: algorithmic flops / time / the peak of the tensors' NATIVE pipe (fp32 MFMA, 157.3 TF/s).
                 # It exceeds 1 where the algorithm executes fewer multiplies than the direct sum (Winograd) or where the fp32

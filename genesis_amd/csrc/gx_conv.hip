@@ -2276,6 +2276,16 @@ int gx_weight_cache_release(void) {
     return GX_OK;
 }
 
+// the cache's packings are served WITHOUT re-packing: the weights have not changed since the last refresh (the backward pass of
+// an iteration whose forward refreshed them; a captured backward graph that runs behind a captured forward graph)
+int gx_weight_cache_activate(int id) {
+    int rc = cache_check("gx_weight_cache_activate", id);
+    if (rc) return rc;
+    GX_CHECK_ARG(g_cache_recording != id, "gx_weight_cache_activate: cache %d is still recording", id);
+    g_cache_active = g_caches[id].entries.empty() ? -1 : id;
+    return GX_OK;
+}
+
 int gx_weight_cache_destroy(int id) {
     int rc = cache_check("gx_weight_cache_destroy", id);
     if (rc) return rc;

@@ -1298,6 +1298,7 @@ wgq_amax_finalize_kernel(const WqFinTable tab) {
 }
 
 // fp16 pieces where both operands' maxima are known: 1 (default); GENESIS_WGQ_F16X3=0 / gx_wgq_precision(1): bf16 pieces everywhere
+double g_wgq_flops_f16 = 0.0, g_wgq_flops_all = 0.0;      // of the last stream-K launch (gx_wgq_last_f16_share)
 int g_wgq_f16 = -1;
 bool wgq_f16() {
     if (g_wgq_f16 < 0) {
@@ -1565,6 +1566,7 @@ int wgq_launch_stream(std::vector<PendingJob*>& jobs, hipStream_t s, std::vector
         std::vector<WsSlot> slots;
         WqFinTable fin;
         int nfin = 0;
+        double flops_f16 = 0.0;
         tab.njobs = 0; tab.U = 0;
         double flops = 0.0, bytes = 0.0;
         size_t i_end = i;
@@ -1610,6 +1612,7 @@ int wgq_launch_stream(std::vector<PendingJob*>& jobs, hipStream_t s, std::vector
                         }
                     }
                     tab.U += (long long)jb.ntiles * jb.cost;
+                    if (jb.variant >= 128) flops_f16 += q.flops / nblk;
                     slots.push_back(WsSlot{&q, blk, 0});
                 }
                 flops += q.flops;
@@ -1649,6 +1652,7 @@ int wgq_launch_stream(std::vector<PendingJob*>& jobs, hipStream_t s, std::vector
             if (!d_times) (void)hipMalloc((void**)&d_times, 2 * 256 * sizeof(long long));
             tab.times = d_times;
         }
+        g_wgq_flops_f16 = flops_f16; g_wgq_flops_all = flops;
         if (nfin) {
             GxProf pf(KID_SMALL_REDUCE, s, 0.0, 0.0);
             hipLaunchKernelGGL(wgq_amax_finalize_kernel, dim3(nfin), dim3(256), 0, s, fin);
@@ -1888,6 +1892,8 @@ extern "C" int gx_wgq_precision(int mode) {
     g_wgq_f16 = mode == 2 ? 1 : 0;
     return GX_OK;
 }
+
+extern "C" double gx_wgq_last_f16_share(void) { return g_wgq_flops_all > 0.0 ? g_wgq_flops_f16 / g_wgq_flops_all : 0.0; }
 
 extern "C" int gx_wgq_operand_amax(const float* a0, int na0, const float* a1, int na1, const float* b0, int nb0, const float* b1,
                                    int nb1, float* out2) {

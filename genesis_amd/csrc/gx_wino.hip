@@ -767,6 +767,7 @@ bool gx_wino_h_on() {
 
 // ---- the fp16-piece form: 2 (default) where the input tensor's partial maxima were handed in (gx_conv_input_amax);
 // GENESIS_WINO_F16X3=0 / gx_wino_precision(1): six bf16 piece products everywhere
+static double g_wino_flops_f16 = 0.0, g_wino_flops_all = 0.0;      // bf16-pipe launches since the process started (gx_wino_f16_share)
 static int g_wino_f16 = -1;
 static bool wino_f16_on() {
     if (g_wino_f16 < 0) {
@@ -778,6 +779,7 @@ static bool wino_f16_on() {
 namespace { struct WinoHint { const float* p0; const float* p1; int n0, n1; }; thread_local WinoHint t_wino_hint = {nullptr, nullptr, 0, 0}; }
 // true: the NEXT Winograd launch of this thread runs on fp16 pieces (the caller packs kinds 45 / 46 for it)
 bool gx_wino_f16_pending(void) { return wino_f16_on() && t_wino_hint.p0 && t_wino_hint.n0 > 0; }
+extern "C" double gx_wino_f16_share(void) { return g_wino_flops_all > 0.0 ? g_wino_flops_f16 / g_wino_flops_all : 0.0; }
 extern "C" int gx_conv_input_amax(const float* p0, int n0, const float* p1, int n1) {
     t_wino_hint.p0 = (p0 && n0 > 0) ? p0 : nullptr; t_wino_hint.n0 = t_wino_hint.p0 ? n0 : 0;
     t_wino_hint.p1 = (t_wino_hint.p0 && p1 && n1 > 0) ? p1 : nullptr; t_wino_hint.n1 = t_wino_hint.p1 ? n1 : 0;
@@ -849,6 +851,7 @@ static int wino_launch(const float* in, const float* in2, int K1, const float* U
     }
     {
         const double flops = 2.0 * N * (double)M * K * 9 * H * W;    // algorithmic (direct-sum) flops
+        if (h) { g_wino_flops_all += flops; if (f16 && nb == 1) g_wino_flops_f16 += flops; }
         const double bytes = 4.0 * ((double)N * K * H * W + (double)N * M * H * W + 9.0 * K * M);
         GxProf pf(KID_WINO, s, flops, bytes);
         if (h && nb == 2)

@@ -264,7 +264,16 @@ class GenesisV2(nn.Module):
         internally (rand_pixel [B,1,H,W] uniform, modules/attention.py:177-178; eps [K,B,D] standard
         normal, models/genesisv2_config.py:157) and, for tie-break tests, the seed pixels [K-1,B]."""
         if x.is_cuda:
-            autostep.arm(self)      # the unchanged train.py loop: this iteration on TrainStep's launch structure (autostep.py)
+            if rand_pixel is None and eps is None and seed_idx is None:
+                # the unchanged train.py loop, third iteration on: the forward pass as ONE replayed HIP graph (autostep.py)
+                t = autostep.graph_forward(self, x)
+                if t is not None:
+                    return self._assemble(t)
+            autostep.arm(self, x if (rand_pixel is None and eps is None and seed_idx is None) else None)      # the unchanged train.py loop: this iteration on TrainStep's launch structure (autostep.py)
+        return self._assemble(self._compute(x, rand_pixel, eps, seed_idx))
+
+    def _compute(self, x, rand_pixel=None, eps=None, seed_idx=None):
+        """The tensors of a forward pass (everything that launches kernels): a dict for _assemble."""
         B, _, H, W = x.shape
         K, D = self.K_steps, self.feat_dim
         dev = x.device
@@ -338,16 +347,30 @@ class GenesisV2(nn.Module):
             fn.join_branch()
         else:
             kl = self._component_kl(z, log_q)
+        t = dict(err=err, kl=kl, recon=recon, log_m=log_m, log_s=log_s, x_r=x_r, log_m_r=log_m_r, colour=colour, seeds=seeds,
+                 idx=idx, mu=mu, sigma=sigma, z=z)
+        # -- Optional: Attention mask loss (MONet.kl_m_loss, models/monet_config.py:157-170)
+        if self.klm_loss:
+            # genesisv2_config.py:172-176: the reconstructed masks are detached unless detach_mr_in_klm is off
+            t['kl_m'] = fn.CategoricalKLFn.apply(log_m, log_m_r.detach() if self.detach_mr_in_klm else log_m_r)
+        t['dyn_batched'] = dyn_batched
+        return t
+
+    def _assemble(self, t):
+        """The reference's five return values (models/genesisv2_config.py:184-203) from the tensors of _compute: views, lists and
+        lazily evaluated visualisation outputs -- no arithmetic."""
+        err, kl, recon, log_m, log_s, x_r, log_m_r = t['err'], t['kl'], t['recon'], t['log_m'], t['log_s'], t['x_r'], t['log_m_r']
+        colour, seeds, idx, mu, sigma, z, dyn_batched = t['colour'], t['seeds'], t['idx'], t['mu'], t['sigma'], t['z'], t['dyn_batched']
+        ap = self.att_process
+        uv, _ = self._grid(recon.device)
         losses = AttrDict()
         losses['err'] = err
         log_m_k = list(log_m.unbind(0))
         log_s_k = None if dyn_batched else list(log_s.unbind(0))
         x_r_k = list(x_r.unbind(0))
         log_m_r_k = list(log_m_r.unbind(0))
-        # -- Optional: Attention mask loss (MONet.kl_m_loss, models/monet_config.py:157-170)
-        if self.klm_loss:
-            # genesisv2_config.py:172-176: the reconstructed masks are detached unless detach_mr_in_klm is off
-            losses['kl_m'] = fn.CategoricalKLFn.apply(log_m, log_m_r.detach() if self.detach_mr_in_klm else log_m_r)
+        if 'kl_m' in t:
+            losses['kl_m'] = t['kl_m']
         losses['kl_l_k'] = SlotList(kl.unbind(0), stacked=kl)
 
         # derived visualisation outputs are evaluated on first access (a training step never reads them)

@@ -91,6 +91,9 @@ int gx_wgq_precision(int mode);
  *      2^-40 max|tensor|; tests/test_kernels_gpu.py *fp16x3* bound the error per output channel against fp64. */
 int gx_wgq_operand_amax(const float* a0, int na0, const float* a1, int na1, const float* b0, int nb0, const float* b1,
                         int nb1, float* out2);
+/*      Measurement: the share of the LAST stream-K launch's algorithmic flops that ran on three fp16 piece products (the rest:
+ *      six bf16 ones) -- what bench.py prices the launch's matrix-pipe ceiling with. */
+double gx_wgq_last_f16_share(void);
 int gx_wgq_ring(int on);
 /*      The same choice for the chip-filling transposed-conv forward / data-gradient layers (gx_kq.hip): 1
  *      bf16 pipe -- the staging splits the input tile into its three bf16 planes, the pack kernel the weights; needs a
@@ -128,6 +131,8 @@ int gx_amax_tap(float* parts, int capacity, size_t numel);
  *      fp16 piece products (U * 2^eU packed as two pieces, eU from max |w|; V * 2^eV split in registers, eV from 4 max |x|)
  *      instead of six bf16 ones; layers on other kernels ignore it.  NULL / 0 clears.  Same range note as gx_wgq_operand_amax. */
 int gx_conv_input_amax(const float* p0, int n0, const float* p1, int n1);
+/*      Measurement: the share of the bf16-pipe Winograd launches' algorithmic flops (since the process started) on fp16 pieces. */
+double gx_wino_f16_share(void);
 int gx_amax_tap_result(void);
 int gx_amax_parts(const float* x, size_t n, float* parts, gx_stream_t stream);
 size_t gx_conv3x3_wino_ws_bytes(int N, int Cin, int Cout, int H, int W);
@@ -662,6 +667,9 @@ int gx_weight_cache_record(int id, int on);
 int gx_weight_cache_size(int id);
 int gx_weight_cache_refresh(int id, gx_stream_t stream);
 int gx_weight_cache_release(void);
+/*      gx_weight_cache_activate(id): serve the calls that follow from cache `id` as gx_weight_cache_refresh does, WITHOUT re-packing
+ *      -- the weights have not changed since the last refresh (a backward pass issued separately from its forward pass). */
+int gx_weight_cache_activate(int id);
 int gx_weight_cache_destroy(int id);
 
 /* ---- contexts.  Library state that outlives a call -- the deferred-reduction queues, queued weight-gradient jobs, the

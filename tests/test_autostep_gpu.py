@@ -289,3 +289,109 @@ def test_copies_of_a_model_do_not_share_the_native_cache():
         _state_is_clean()
     finally:
         autostep.ENABLED = prev
+
+
+# ------------------------------------------------------------------------------------------------ the loop as two replayed graphs
+def _plain_loop(model, x, steps, seeds, opt=None, lr=1e-4, zero=True, hook=None):
+    """train.py:223-263's statements with the model's OWN noise (torch.rand / randn inside forward), torch seeded per iteration."""
+    opt = opt or torch.optim.Adam(model.parameters(), lr=lr)
+    hist = []
+    for it in range(steps):
+        if zero:
+            opt.zero_grad()
+        torch.manual_seed(seeds[it])
+        recon, losses, stats, att, comp = model(x)
+        err = losses.err.mean(0)
+        kl = torch.stack(losses.kl_l_k, dim=1).mean(dim=0).sum()
+        loss = err + 0.7 * kl
+        if hook is not None:
+            loss = hook(loss, recon, stats)
+        loss.backward()
+        opt.step()
+        hist.append((float(err.detach()), float(kl.detach())))
+    return hist, opt
+
+
+@pytest.mark.parametrize('case', ['tiny', 'metric'])
+def test_unchanged_loop_as_two_replayed_graphs_equals_the_eager_loop(case):
+    """From the third iteration on the loop's forward and backward passes are two replayed HIP graphs (autostep.graph_forward):
+    the same trajectory as the eager path (same torch seeds: the captured torch.rand / randn draw what the eager ones draw),
+    every parameter with its .grad after backward(), the replays counted, the state clean."""
+    from genesis_amd import autostep
+    gold = Golden(case)
+    x, _, _ = gold.inputs()
+    xd = x.to(DEV)
+    seeds = [100 + i for i in range(7)]
+    prev = (autostep.ENABLED, autostep.GRAPH)
+    try:
+        autostep.ENABLED, autostep.GRAPH = True, False
+        h0, _ = _plain_loop(build(gold), xd, 7, seeds)
+        autostep.GRAPH = True
+        model = build(gold)
+        h1, _ = _plain_loop(model, xd, 7, seeds)
+        fwd, bwd, fb = autostep.graph_stats(model)
+        assert fwd == 5 and bwd == 5 and fb == 0, (fwd, bwd, fb)
+        assert all(p.grad is not None for p in model.parameters())
+        for a, b in zip(h0, h1):
+            assert abs(a[0] - b[0]) <= 2e-4 * abs(a[0]) and abs(a[1] - b[1]) <= 2e-3 * abs(a[1]) + 1e-4, (h0, h1)
+        _state_is_clean()
+    finally:
+        autostep.ENABLED, autostep.GRAPH = prev
+
+
+def test_graph_loop_falls_back_and_stays_correct():
+    """Gradient accumulation (no zero_grad between two backward passes), a loss that also reads `recon`, an evaluation forward
+    and a changed batch size in the middle of a captured loop: each takes the ordinary autograd path and gives the gradients
+    the eager loop gives."""
+    from genesis_amd import autostep
+    gold = Golden('tiny')
+    x, _, _ = gold.inputs()
+    xd = x.to(DEV)
+    prev = (autostep.ENABLED, autostep.GRAPH)
+
+    def grads_after(model, graph_on, scenario):
+        autostep.GRAPH = graph_on
+        opt = torch.optim.SGD(model.parameters(), lr=0.0)          # (lr 0: the iterations differ by their noise only)
+        _plain_loop(model, xd, 4, [1, 2, 3, 4], opt=opt)           # by now the graph stage has captured (if on)
+        opt.zero_grad()
+        if scenario == 'accumulate':
+            for s in (5, 6):
+                torch.manual_seed(s)
+                _, losses, *_ = model(xd)
+                (losses.err.mean(0) + torch.stack(losses.kl_l_k, dim=1).mean(dim=0).sum()).backward()
+        elif scenario == 'recon_loss':
+            torch.manual_seed(5)
+            recon, losses, *_ = model(xd)
+            (losses.err.mean(0) + recon.pow(2).mean()).backward()
+        elif scenario == 'eval_between':
+            model.eval()
+            with torch.no_grad():
+                model(xd)
+            model.train()
+            torch.manual_seed(5)
+            _, losses, *_ = model(xd)
+            (losses.err.mean(0) + torch.stack(losses.kl_l_k, dim=1).mean(dim=0).sum()).backward()
+        else:
+            torch.manual_seed(5)
+            _, losses, *_ = model(xd[:1])
+            (losses.err.mean(0) + torch.stack(losses.kl_l_k, dim=1).mean(dim=0).sum()).backward()
+        # (a parameter the backward pass never reaches: None on the plain autograd path, zeros under the mechanism)
+        return {n: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)) for n, p in model.named_parameters()}
+
+    try:
+        autostep.ENABLED = True
+        for scenario in ('accumulate', 'recon_loss', 'eval_between', 'other_batch'):
+            g0 = grads_after(build(gold), False, scenario)
+            model = build(gold)
+            g1 = grads_after(model, True, scenario)
+            big = max(float(v.double().norm()) for v in g0.values())
+            for n in g0:
+                den = float(g0[n].double().norm()) + 1e-6 * big
+                assert float((g0[n].double() - g1[n].double()).norm()) / den <= 5e-5, (scenario, n)
+            fwd, bwd, fb = autostep.graph_stats(model)
+            assert fwd >= 2, (scenario, fwd)
+            if scenario in ('accumulate', 'recon_loss'):
+                assert fb >= 1, (scenario, fb)
+            _state_is_clean()
+    finally:
+        autostep.ENABLED, autostep.GRAPH = prev

@@ -251,8 +251,12 @@ def _early_flush_runs(monkeypatch, in_graph):
     assert ts._early_range is not None and 0 < ts._early_range[1] - ts._early_range[0] < ts.n32
     early = run(ts)
     # (the KL of this tiny model is ~2 on an ELBO of 2000: its fifth digit moves with the gradients' summation order)
-    assert torch.allclose(early[0], ref[0], rtol=2e-4), (early[0], ref[0])
-    assert float((early[1] - ref[1]).norm() / ref[1].norm()) < 1e-5
+    # (... and after Adam's first, sign-like steps the fourth: an absolute floor tied to the ELBO's scale, as in
+    #  test_three_steps_vs_reference)
+    assert torch.allclose(early[0], ref[0], rtol=2e-4, atol=2e-6 * float(ref[0][0, 0])), (early[0], ref[0])
+    # (parameters: four Adam steps of lr 1e-4 -- a parameter whose gradient is round-off noise steps by +-lr whatever its size,
+    #  and the two-flush partition sums that noise in another order: measured 6.5e-5 of the parameter norm = ~1000 such parameters)
+    assert float((early[1] - ref[1]).norm() / ref[1].norm()) < 2e-4
     monkeypatch.setenv('GENESIS_FORCE_ALLREDUCE', '1')
     if in_graph:
         monkeypatch.setenv('GENESIS_EARLY_COLLECTIVE_IN_GRAPH', '1')
@@ -274,7 +278,7 @@ def test_early_decoder_flush_and_its_collective(monkeypatch):
     launch cuts its tile line by what else is in the launch); with the (world-1) RCCL collective split in three it must equal the
     two-flush trajectory WITHOUT a collective."""
     early, got = _early_flush_runs(monkeypatch, in_graph=False)
-    assert torch.allclose(early[0], got[0], rtol=2e-4), (early[0], got[0])
+    assert torch.allclose(early[0], got[0], rtol=2e-4, atol=2e-6 * float(early[0][0, 0])), (early[0], got[0])
     assert float((early[1] - got[1]).norm() / early[1].norm()) < 1e-5
 
 
@@ -619,20 +623,32 @@ def test_checkpoint_written_by_the_reference(tmp_path):
     assert sorted(mine) == sorted(ref_paths), sorted(set(mine) ^ set(ref_paths))[:10]
     # (entry order inside the dicts torch.load hands to load_state_dict: OrderedDict of the model, parameter indices)
     assert [p for p in mine if p.startswith('/model_state_dict/')] == [p for p in ref_paths if p.startswith('/model_state_dict/')]
-    worst = 0.0
+    # moments: relative L2 per tensor on the strided samples, with a floor relative to the LARGEST moment tensor (the gradients of
+    # conv biases in front of a norm are analytically zero: their moments are round-off of round-off in every implementation)
+    def mean_abs(path):
+        return float(g['t/' + path + '/asum']) / max(int(g['t/' + path + '/n']), 1)
+    big_m = max(mean_abs(m[0]) for m in manifest if m[1] == 'tensor' and m[0].endswith('/exp_avg'))
+    big_v = max(mean_abs(m[0]) for m in manifest if m[1] == 'tensor' and m[0].endswith('/exp_avg_sq'))
     for path, kind, desc, shape in manifest:
         k2, d2, s2, t = mine[path]
         if kind == 'tensor':
             assert (k2, d2, s2) == (kind, desc, shape), (path, (k2, d2, s2), (kind, desc, shape))
+            tt = t.double() if t.dtype == torch.float64 else t.float()
+            if path.endswith('/exp_avg') or path.endswith('/exp_avg_sq'):
+                sm = T.summarize(tt)
+                ref = g['t/' + path + '/samples'].astype(np.float64)
+                assert int(g['t/' + path + '/n']) == int(sm['n']), path
+                second = path.endswith('_sq')
+                floor = (1e-5 * big_v if second else 1e-4 * big_m) * np.sqrt(len(ref))
+                diff = float(np.linalg.norm(sm['samples'].astype(np.float64) - ref))
+                assert diff <= (1e-2 if second else 5e-3) * float(np.linalg.norm(ref)) + floor, (path, diff, float(np.linalg.norm(ref)), floor)
+                continue
             scalarish = path.endswith('/step') or path in ('/beta', '/err_ema')
             # parameters after two Adam steps of 1e-4: sign-like updates, so 1e-6 absolute on O(0.1) weights is round-off of
-            # round-off; moments: relative to the tensor (exp_avg_sq is quadratic in the gradient)
-            ref_asum = float(g['t/' + path + '/asum'])
-            n = int(g['t/' + path + '/n'])
-            scale = ref_asum / max(n, 1)
-            # (element-wise: the second moment is quadratic in the gradient, so a gradient element's round-off counts twice)
-            rtol = 1e-5 if scalarish else (1e-2 if path.endswith('exp_avg_sq') else 5e-3 if path.endswith('exp_avg') else 2e-3)
-            T.check_summary('t/' + path, t.double() if t.dtype == torch.float64 else t.float(), g, rtol, rtol * scale + 1e-12, path)
+            # round-off
+            scale = mean_abs(path)
+            rtol = 1e-5 if scalarish else 2e-3
+            T.check_summary('t/' + path, tt, g, rtol, rtol * scale + 1e-12, path)
         elif kind in ('dict', 'OrderedDict', 'list', 'tuple'):
             assert (k2, s2) == (kind, shape), (path, k2, kind, s2, shape)
         else:
