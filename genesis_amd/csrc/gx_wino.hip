@@ -422,13 +422,15 @@ __device__ __forceinline__ void wino_split8_f16(const float (&v)[8], float sc, w
 //           MFMAs -- the path is saturated exactly when the matrix pipe would be (measured: 48.9 us, 39.3 us without the A
 //           loads).  Twice the tiles per A operand halve that traffic per MFMA, and the register budget pays for an A
 //           prefetch three positions deep instead of one.
-template <int NB> struct WHCfg {
+template <int NB, bool F16 = false> struct WHCfg {
     static constexpr int TROWS = 4 * NB;                  // Winograd tile rows per workgroup (8 columns)
     static constexpr int PRH = 2 * TROWS + 2;             // raw patch rows (10 / 18), 18 columns as [parity 2][PLANE 10]
     static constexpr int USED = PRH * 20;                 // floats per channel (200 / 360)
     static constexpr int PITCH = NB == 1 ? 256 : 384;     // channel pitch: whole 64-lane DMA rows
     static constexpr int ROUNDS = (USED + 255) / 256;     // patch positions per thread and channel (1 / 2)
     static constexpr int RAW_FLOATS = HKC * PITCH;        // per buffer; two buffers
+    // (fp16 pieces, a set of 16 registers instead of 24: fetching the A operands TWO positions ahead at 32 tiles per wave as well
+    //  was built -- 84 bytes of scratch per lane at the 256 registers two workgroups per CU leave a wave; not kept)
     static constexpr int NSETS = NB == 1 ? 2 : 4;         // A register sets (position nu of a chunk uses set nu % NSETS)
     static constexpr int LOOK = NB == 1 ? 1 : 2;          // ... loaded LOOK positions ahead (three sets live at NB = 2: 72 registers)
     static constexpr size_t LDS_BYTES = 2 * RAW_FLOATS * 4 > 32768 ? 2 * RAW_FLOATS * 4 : 32768;    // (the epilogue's exchange buffer: 32 KB)
@@ -442,7 +444,7 @@ template <int NB, bool F16>
 __global__ void __launch_bounds__(256, NB == 1 ? 2 : 1)
 wino_conv_h_kernel(const float* __restrict__ in, const float* __restrict__ in2, const unsigned* __restrict__ U,
                    float* __restrict__ out, float* __restrict__ out2, const WinoGeom g) {
-    using C = WHCfg<NB>;
+    using C = WHCfg<NB, F16>;
     constexpr int NP = F16 ? 2 : 3;
     constexpr int PITCH = C::PITCH, NSETS = C::NSETS, LOOK = C::LOOK;
     extern __shared__ __attribute__((aligned(16))) float lds[];

@@ -43,6 +43,9 @@ class _StepState(object):
 
 
 _STEPS = {}
+# GENESIS_DEBUG_SYNC=1: a device synchronisation at the top of every autograd Function's forward and backward -- the step's results
+# must not depend on whether the host runs ahead of the device (tools/diag_two_proc.py)
+_DEBUG_SYNC = os.environ.get('GENESIS_DEBUG_SYNC') == '1'
 
 
 def step_state():
@@ -55,11 +58,15 @@ def ctx_bound(cls):
 
     def forward(ctx, *args):
         ctx._gx_ctx = _lib.current_ctx()
+        if _DEBUG_SYNC:
+            torch.cuda.synchronize()
         return fwd(ctx, *args)
 
     def backward(ctx, *grads):
         prev = _lib.current_ctx()
         _lib.make_current(ctx._gx_ctx)
+        if _DEBUG_SYNC:
+            torch.cuda.synchronize()
         try:
             if _auto._STATE.models and not _auto._STATE.in_pass and ctx._gx_ctx == 0:
                 _auto.begin_backward()          # the unchanged train.py loop: this backward pass on the step machinery

@@ -235,9 +235,44 @@ def _world():
     return dist.get_world_size(_SYNC['group'])
 
 
-def _all_reduce_sum(t):
+def _all_reduce_sum(t, info=None):
+    """t (a device tensor of a few hundred bytes) <- its sum over the ranks, the same bits on every rank.  A backend that carries
+    host memory (gloo: the two-ranks-on-one-GPU tests): staged explicitly -- device -> host, all_gather, the ranks' parts added in
+    RANK ORDER by every rank, host -> device.  GENESIS_SYNC_BN_DEBUG=1 sends the call site's identity along and checks that every
+    rank is at the same one."""
+    import os
     import torch.distributed as dist
-    dist.all_reduce(t, group=_SYNC['group'])
+    grp = _SYNC['group']
+    fake = os.environ.get('GENESIS_SYNC_BN_FAKE')
+    if fake:                  # (diagnosis: the partner is a copy of this rank; 2: ... behind a host-blocking barrier)
+        if fake == '2':
+            torch.cuda.synchronize()
+            dist.barrier(group=grp)
+        t.mul_(dist.get_world_size(grp))
+        return
+    if t.is_cuda and dist.get_backend(grp) != 'nccl':
+        h = t.detach().cpu().contiguous()
+        debug = os.environ.get('GENESIS_SYNC_BN_DEBUG') == '1'
+        if debug:
+            _SYNC['seq'] = _SYNC.get('seq', 0) + 1
+            tag = torch.tensor([float(_SYNC['seq'])] + [float(v) for v in (info or ())], dtype=h.dtype)
+            h = torch.cat([h.flatten(), tag])
+        parts = [torch.empty_like(h) for _ in range(dist.get_world_size(grp))]
+        dist.all_gather(parts, h, group=grp)
+        if debug:
+            n = tag.numel()
+            for r, q in enumerate(parts):
+                if not torch.equal(q[-n:], tag):
+                    print('SYNC MISMATCH: rank %d is at %s, rank %d at %s' % (dist.get_rank(grp), tag.tolist(), r, q[-n:].tolist()), flush=True)
+            parts = [q[:-n] for q in parts]
+        acc = parts[0].clone()
+        for q in parts[1:]:
+            acc += q
+        if _SYNC.get('log') is not None:
+            _SYNC['log'].append((tuple(info or ()), [float(q.double().sum()) for q in parts], float(acc.double().abs().sum())))
+        t.copy_(acc.view(t.shape))
+        return
+    dist.all_reduce(t, group=grp)
 
 
 @ctx_bound
@@ -249,7 +284,7 @@ class GatedNormFn(torch.autograd.Function):
         y = y.contiguous()
         ctx.m_global = None
         if norm == 'bn' and _SYNC['on']:
-            out, stats, ctx.m_global = hip.gated_bn_sync_fwd(y, bias, gh, bh, gg, bg, _all_reduce_sum, _world())
+            out, stats, ctx.m_global = hip.gated_bn_sync_fwd(y, bias, gh, bh, gg, bg, lambda t: _all_reduce_sum(t, (1,) + tuple(y.shape)), _world())
         else:
             out, stats = hip.gated_norm_fwd(y, bias, norm, gh, bh, gg, bg)
         ctx.save_for_backward(y, stats)
@@ -266,7 +301,7 @@ class GatedNormFn(torch.autograd.Function):
         outs = tuple(_gout(p) if p is not None else None for p in (gh, bh, gg, bg, bias))
         if ctx.m_global is not None:
             dy, dgh, dbh, dgg, dbg, dbias = hip.gated_bn_sync_bwd(y, bias, gh, bh, gg, bg, stats, g.contiguous(), ctx.m_global,
-                                                                  _all_reduce_sum, out=outs)
+                                                                  lambda t: _all_reduce_sum(t, (2,) + tuple(y.shape)), out=outs)
         else:
             dy, dgh, dbh, dgg, dbg, dbias = hip.gated_norm_bwd(y, bias, ctx.norm, gh, bh, gg, bg, stats, g.contiguous(), out=outs)
         return (dy, _ret(outs[4], dbias), None, _ret(outs[0], dgh), _ret(outs[1], dbh), _ret(outs[2], dgg),
