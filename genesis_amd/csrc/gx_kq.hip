@@ -446,7 +446,14 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
         GX_QH_STORE_W(wbufb)
         // Q_C3H: the next chunk's input loads are issued at the chunk's FIRST phase (the registers are free: 32 accumulators) --
         // with two chunks per tile a load issued at the last phase has one phase of MFMAs to hide under
-        constexpr bool EARLY_IN = MODE == Q_C3H;
+        // ... and, since round 6, the transposed-conv forward: its five phases (kernel rows) read ONE input tile per chunk, so the next
+        // chunk's loads used to be issued at the last phase with ~0.5 us of MFMAs to hide under (PMC: 48 % of the wave cycles
+        // parked); issued at the chunk's first phase they have the whole chunk (24 more live registers, still two workgroups
+        // per CU): 11 852 -> 12 004 img/s on the metric step in one A/B call (-DGX_QH_EARLY_DTH=0: the old placement)
+#ifndef GX_QH_EARLY_DTH
+#define GX_QH_EARLY_DTH 1
+#endif
+        constexpr bool EARLY_IN = MODE == Q_C3H || (GX_QH_EARLY_DTH && (MODE == Q_DT0H || MODE == Q_DT1H));
         // Q_C3H: ONE weight buffer (a second barrier per phase instead): 36 + 12 KB of LDS = three workgroups per CU -- a tile
         // is short (two chunks), its loads, bf16 split, MFMAs and stores barely overlap inside one workgroup, so the third
         // workgroup is what fills the gaps

@@ -149,6 +149,7 @@ class _operand_amax(object):
 
 
 WINO_F16 = os.environ.get('GENESIS_WINO_F16X3', '1') != '0'
+_WINO_AMAX_MAX = 1024
 
 
 class _input_amax(object):
@@ -162,6 +163,11 @@ class _input_amax(object):
             return
         hs = list(handles) if isinstance(handles, (list, tuple)) else [handles]
         if not hs or len(hs) > 2 or any(h is None for h in hs):
+            return
+        # every workgroup of the conv reduces the partial maxima itself: worth it up to ~1000 of them (GroupNorm(8) at any batch of
+        # this workload: N x 8; InstanceNorm -- MONet's UNet, one partial per (image, channel) -- has up to 8192: measured 14.7
+        # against 12.2 us per launch on its layers, so those stay on bf16 pieces)
+        if sum(h.n for h in hs) > _WINO_AMAX_MAX:
             return
         hs = hs + [None] * (2 - len(hs))
         self.args = [ctypes.c_void_p(hs[0].ptr), hs[0].n, ctypes.c_void_p(hs[1].ptr) if hs[1] is not None else None,
