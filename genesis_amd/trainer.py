@@ -236,11 +236,12 @@ class TrainStep(object):
         bucket is final.  Several ranks: start its all-reduce on the second stream (a parallel branch when captured)."""
         if not (self._early_collective_ok and self.bucket.collective_needed(self.pg)):
             return
-        if torch.cuda.is_current_stream_capturing() and os.environ.get('GENESIS_EARLY_COLLECTIVE_IN_GRAPH') != '1':
-            # a collective on a forked stream INSIDE the captured step: it replays correctly (bit-identical to the eager form,
-            # tests/test_train_gpu.py), but one of two full GPU-suite runs aborted inside hipStreamEndCapture of exactly this
-            # capture (never in eight runs of the test files on their own) -- until that is understood the captured step keeps
-            # the early flush and sends the bucket in one piece; the eager step overlaps as described
+        if torch.cuda.is_current_stream_capturing():
+            # no collective on a forked stream INSIDE the captured step: that form existed behind an opt-in in round 5 (it replayed
+            # bit-identically to the eager form), but one of two full GPU-suite runs aborted inside hipStreamEndCapture of exactly
+            # that capture and the abort was never reproduced in isolation -- an unexplained abort next to the default multi-rank
+            # path is worse than the ~40 us the fork could hide, so the path was deleted in round 6 (review item 9a).  The
+            # captured step keeps the early flush and sends the bucket in one piece; the EAGER step overlaps as described.
             return
         if self._early_side is None:
             self._early_side = torch.cuda.Stream()
