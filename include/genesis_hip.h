@@ -103,7 +103,13 @@ int gx_wgq_ring(int on);
  *      tensor from its largest magnitude -- the input's by one small launch ahead of the conv (partial maxima at the end of the
  *      conv's workspace), the weights' at pack time; error against fp64 at or below the bf16 form's on every operand set of the
  *      tests, two thirds of its matrix-pipe time: the DEFAULT since round 5 (GENESIS_KQ_F16X3=0: mode 1).  -1: back to the
- *      environment's default. */
+ *      environment's default.
+ *      RANGE of mode 2 (the same holds for gx_wgq_precision(2) and gx_wino_precision(2)): the scale is ONE power of two per tensor,
+ *      max |x| * 2^e in [2^14, 2^15).  A value keeps its 22 significant bits down to max |x| * 2^-18; below that its low piece is
+ *      an fp16 subnormal and bits drop off one by one; below max |x| * 2^-28 the high piece is subnormal too and below 2^-40 the
+ *      value is flushed -- i.e. the representation error is max(2^-23 |x|, 2^-40 max |x|): absolute, not relative, accuracy for the
+ *      smallest values of a tensor with one extreme outlier (an element 1e9 times the rest: tests/test_kernels_gpu.py
+ *      ::test_fp16x3_transposed_conv_scales_follow_the_tensors[one_huge] pins exactly that bound).  Mode 1 has fp32's range. */
 int gx_kq_precision(int mode);
 /*      Mode 2's per-tensor maximum without a second pass over the tensor: gx_kq_amax_link(parts, capacity, numel) arms a one-shot,
  *      per-thread hand-over -- the next producer that supports it (the register-resident GroupNorm + ReLU kernels behind gx_gn_relu_fwd_parts /

@@ -1627,7 +1627,7 @@ def test_two_linear_heads_in_one_buffer():
         close(a.grad, b_.grad, 5e-6, 5e-6, n)
 
 
-@pytest.mark.parametrize('kind', ['wide', 'tiny', 'huge', 'zeros', 'one_large'])
+@pytest.mark.parametrize('kind', ['wide', 'tiny', 'huge', 'zeros', 'one_large', 'one_huge'])
 def test_fp16x3_transposed_conv_scales_follow_the_tensors(kind):
     """gx_kq_precision(2): every fp32 product of the chip-filling transposed convs from THREE fp16 piece products of x * 2^sx and
     w * 2^sw (hi + lo = 22 significant bits; hi*hi + hi*lo + lo*hi) with ONE power-of-two scale per tensor taken from its largest
@@ -1652,6 +1652,12 @@ def test_fp16x3_transposed_conv_scales_follow_the_tensors(kind):
     elif kind == 'one_large':
         x[3, 5, 7, 9] = 2.0 ** 20
         dy[2, 4, 6, 8] = -2.0 ** 20
+    elif kind == 'one_huge':
+        # one element 2^30 (1e9) times the rest -- past the documented range of the per-TENSOR scale (include/genesis_hip.h,
+        # gx_kq_precision): every other element is below max * 2^-28, i.e. its low piece is flushed and its high piece is an fp16
+        # subnormal.  What must still hold is the documented ABSOLUTE accuracy 2^-40 max|tensor| per operand value.
+        x[3, 5, 7, 9] = 2.0 ** 30
+        dy[2, 4, 6, 8] = -2.0 ** 30
     out = {}
     for dt in (torch.float64, torch.float32):
         xr = x.to(dt).requires_grad_()
@@ -1674,8 +1680,23 @@ def test_fp16x3_transposed_conv_scales_follow_the_tensors(kind):
     print('fp16 x 3 transposed conv, %s operands: forward %.3e (CPU fp32 %.3e), data gradient %.3e (CPU fp32 %.3e)' % (kind, e[0], e32[0], e[1], e32[1]))
     if kind == 'zeros':
         assert torch.equal(dx, torch.zeros_like(dx)) and e[0] < 1e-6
+    elif kind == 'one_huge':
+        # per ELEMENT: the CPU fp32 op's own error + the representation floor 2^-38 max|operand| * sum |w| over a receptive field
+        # (2^-40 per value, two pieces' worth of slack); in norm the outlier's footprint dominates and hides nothing
+        wsum = float(w.abs().sum((0, 2, 3)).max()), float(w.abs().sum((1, 2, 3)).max())
+        for got, r, c, amax, ws in ((y, ref[0], c32[0], float(x.abs().max()), wsum[0]), (dx, ref[1], c32[1], float(dy.abs().max()), wsum[1])):
+            d = (got.double().cpu() - r).abs()
+            bound = 1.5 * (c.double() - r).abs().max() + 2.0 ** -38 * amax * ws
+            print('   one_huge: max abs error %.3e, bound %.3e (CPU fp32 max abs error %.3e)' % (float(d.max()), float(bound), float((c.double() - r).abs().max())))
+            assert float(d.max()) <= float(bound), (float(d.max()), float(bound))
     else:
         assert e[0] <= 1.5 * e32[0] + 1e-7 and e[1] <= 1.5 * e32[1] + 1e-7, (e, e32)
+        # ... and per OUTPUT CHANNEL (a norm over the tensor lets a weak channel hide behind the strong ones)
+        def chan(a, r):
+            return ((a.double().cpu() - r).pow(2).sum((0, 2, 3)).sqrt() / r.pow(2).sum((0, 2, 3)).sqrt().clamp_min(1e-300))
+        for got, r, c in ((y, ref[0], c32[0]), (dx, ref[1], c32[1])):
+            ch, c_ = chan(got, r), chan(c.double(), r)
+            assert float((ch / (2.0 * c_ + 1e-7)).max()) <= 1.0, (kind, float(ch.max()), float(c_.max()))
 
 
 @pytest.mark.parametrize('N,K,M,S', [(16, 32, 64, 64), (52, 64, 128, 32), (200, 64, 64, 16), (13, 48, 64, 64)])

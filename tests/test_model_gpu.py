@@ -160,11 +160,14 @@ def test_cpu_input_raises():
         model.cpu()(torch.rand(1, 3, 32, 32))
 
 
-# cfg5 (128 x 128, closed-form weights): forward tensors and ELBO at the same bars; its gradient bar is 3e-2 instead of 1e-2 -- on this
-# fixture the reference's own fp32 gradient sits 8e-3 from fp64 and the bf16-pipe Winograd kernel's (fp32-accurate, 2e-7) rounding
-# moves `encoder.down.5.0.weight` by 0.9 % (measured: norm 29.957 vs 29.678).  The same dispatch on well-conditioned weights is held
-# to 3 x budget + 5e-5 by tests/test_fullbatch_gpu.py::test_every_eligible_conv3x3_on_the_winograd_kernel_vs_reference.
-@pytest.mark.parametrize('case,l2_tol', [('metric', 1e-2), ('cfg5', 3e-2)])
+# Gradient bar of this test (review, round 5: "derived from a budget instead of the 3e-2"): per PARAMETER, from the fp32 error budget of
+# the fixture's own closed-form weights -- tests/golden/v2_<case>_budget.npz (make_golden_budget.py: how far the oracle's fp32 gradient
+# sits from its fp64 gradient; up to 8e-3 on these ill-conditioned weights, median 6e-4) --
+#     |HIP - reference| <= (4 + 1) x budget + 5e-5 + 3e-3        (relative L2 on the strided samples, and on the norm)
+# i.e. tests/test_fullbatch_gpu.py's bar: 4 x for the HIP path (the fp64 budget tests hold it to that), 1 x for the reference's own
+# distance, and the ReLU-decision allowance, which on the closed-form weights is granted to every parameter (one decoder ReLU is known
+# to move on them: DESIGN.md finding 12; the full-batch fixtures grant it per layer).
+@pytest.mark.parametrize('case,l2_tol', [('metric', None), ('cfg5', None)])
 def test_golden_parity_with_every_conv3x3_on_the_winograd_kernel(case, l2_tol):
     """The golden cases have B = 2, too small for the Winograd dispatch (it takes the layers that fill the chip): force
     every eligible conv3x3 forward / data gradient onto the Winograd kernel and repeat the reference comparison."""
@@ -184,8 +187,31 @@ def test_golden_parity_with_every_conv3x3_on_the_winograd_kernel(case, l2_tol):
         (err + kl).backward()
         rows = {r['name']: r['launches'] for r in profiling.collect()}
         assert rows.get('wino_conv_kernel', 0) >= 10, rows          # UNet 32x32 / 64x64 levels and both heads, fwd + dgrad
-        grads = [(n, p.grad if p.grad is not None else torch.zeros_like(p)) for n, p in model.named_parameters()]
-        gold.check_grads(grads, rtol=5e-3 * l2_tol / 1e-2, l2_tol=l2_tol)
+        import os.path as osp
+        import numpy as np
+        from genesis_amd import testing as T
+        from tests.common import GOLDEN
+        bud = np.load(osp.join(GOLDEN, 'v2_%s_budget.npz' % case), allow_pickle=False)
+        names = [str(n) for n in bud['param_names']]
+        gmax = float(bud['grad_max_f64'])
+        named = dict(model.named_parameters())
+        assert names == [n for n, _ in model.named_parameters()]
+        table = []
+        for i, name in enumerate(names):
+            p = named[name]
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            sm = T.summarize(g)
+            ref = gold.g['grad/%s/samples' % name].astype(np.float64)
+            den = max(float(bud['grad_norms_f64'][i]), 1e-6 * gmax)
+            e_s = float(np.linalg.norm(sm['samples'].astype(np.float64) - ref)) / (den * np.sqrt(len(ref) / max(1, int(sm['n']))))
+            e_n = abs(float(g.double().norm()) - float(gold.g['grad_norms'][i])) / den
+            bar = 5.0 * float(bud['budget'][i]) + 5e-5 + 3e-3
+            table.append((max(e_s, e_n) / bar, name, e_s, e_n, float(bud['budget'][i])))
+        table.sort(reverse=True)
+        print('%s on the Winograd kernel: worst gradient error / bar = %.3f' % (case, table[0][0]))
+        for r in table[:4]:
+            print('   %-44s samples %.2e norm %.2e budget %.2e (%.2f of the bar)' % (r[1], r[2], r[3], r[4], r[0]))
+        assert table[0][0] <= 1.0, table[0]
     finally:
         profiling.enable(False)
         _lib.call('gx_conv3x3_wino_policy', 1)
