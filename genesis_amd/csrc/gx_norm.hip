@@ -200,17 +200,33 @@ __device__ __forceinline__ f32x4 load_view4(const View& v, int n, int c, int r, 
     return o;
 }
 
+// one partial maximum per workgroup for an armed amax tap (gx_amax_tap: the generic two-pass kernels of the 128 x 128 model's
+// large slabs serve it too since round 6); am >= 0; every thread of the workgroup calls
+__device__ __forceinline__ void gn_block_amax_out(float am, float* __restrict__ amax_parts) {
+    __shared__ float amr_[16];
+#pragma unroll
+    for (int of = 32; of >= 1; of >>= 1) am = fmaxf(am, __shfl_xor(am, of, 64));
+    if ((threadIdx.x & 63) == 0) amr_[threadIdx.x >> 6] = am;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float r = 0.f;
+        for (int i = 0; i < (int)((blockDim.x + 63) >> 6); ++i) r = fmaxf(r, amr_[i]);
+        amax_parts[blockIdx.x] = r;
+    }
+}
+
 // VEC: 16-byte accesses along W (needs W % 4 == 0); scalar otherwise (W == 2).
 template <bool VEC>
 __global__ void __launch_bounds__(1024)
 gn_relu_fwd_kernel(const InSrc src, const float* __restrict__ gamma, const float* __restrict__ beta,
                    int C, int H, int W, int groups, float eps, View d0, View d1,
-                   float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+                   float* __restrict__ mean_out, float* __restrict__ rstd_out, float* __restrict__ amax_parts) {
     __shared__ double red[16 * 2 + 2];
     const int n = blockIdx.x / groups, gidx = blockIdx.x % groups;
     const int cpg = C / groups, HW = H * W;
     const int m = cpg * HW;
     const size_t slab_off = ((size_t)n * C + (size_t)gidx * cpg) * HW;
+    float am = 0.f;
     // pass 2 re-reads what pass 1 produced: the summed tensor if one was written (same thread, same elements)
     const float* slab = (src.ysum ? src.ysum : src.p) + slab_off;
     double acc[2] = {0.0, 0.0};
@@ -252,6 +268,7 @@ gn_relu_fwd_kernel(const InSrc src, const float* __restrict__ gamma, const float
             }
             store_view4(d0, n, c, r, col, H, W, o);
             if (d1.ptr) store_view4(d1, n, c, r, col, H, W, o);
+            am = fmaxf(fmaxf(am, fmaxf(o[0], o[1])), fmaxf(o[2], o[3]));
         }
     } else {
         for (int i = threadIdx.x; i < m; i += blockDim.x) {
@@ -262,8 +279,10 @@ gn_relu_fwd_kernel(const InSrc src, const float* __restrict__ gamma, const float
             v = v > 0.f ? v : 0.f;
             store_view(d0, n, c, r, col, H, W, v);
             if (d1.ptr) store_view(d1, n, c, r, col, H, W, v);
+            am = fmaxf(am, v);
         }
     }
+    if (amax_parts) gn_block_amax_out(am, amax_parts);      // (uniform)
 }
 
 // Backward.  part[n][c][3] = (sum dpre*xhat, sum dpre, sum dy) per (image, channel); a second kernel
@@ -275,8 +294,9 @@ __global__ void __launch_bounds__(1024)
 gn_relu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ beta,
                    const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                    int C, int H, int W, int groups, View g0, View g1,
-                   float* __restrict__ dy, float* __restrict__ part) {
+                   float* __restrict__ dy, float* __restrict__ part, float* __restrict__ amax_parts) {
     __shared__ double red[16 * 2 * GCH + 2 * GCH];
+    float am = 0.f;
     const int n = blockIdx.x / groups, gidx = blockIdx.x % groups;
     const int cpg = C / groups, HW = H * W;
     const int m = cpg * HW;
@@ -373,6 +393,7 @@ gn_relu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
                         const float d = rstdf * (dxh - k1 - xh * k2);
                         ov[u] = d;
                         sd[cc] += d;
+                        am = fmaxf(am, fabsf(d));
                     }
                     if (VEC) {
                         f32x4 o; o[0] = ov[0]; o[1] = ov[1]; o[2] = ov[2]; o[3] = ov[3];
@@ -390,6 +411,7 @@ gn_relu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
                 if (cb + cc < cpg) part[((size_t)n * C + gidx * cpg + cb + cc) * 3 + 2] = (float)sd[cc];
         }
     }
+    if (amax_parts) gn_block_amax_out(am, amax_parts);      // (uniform)
 }
 
 // one block per channel: sums part[n][c][0..2] over n in a fixed tree
@@ -1304,7 +1326,8 @@ template <int CT>
 __global__ void __launch_bounds__(256)
 gn_bwd_proj_split_apply_kernel(const float* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ beta,
                                const float* __restrict__ mean_in, const float* __restrict__ rstd_in, int C, int HW, int groups,
-                               View g0, const float* __restrict__ kk, float* __restrict__ dy) {
+                               View g0, const float* __restrict__ kk, float* __restrict__ dy, float* __restrict__ amax_parts) {
+    float am = 0.f;
     const int chunks = HW / kSplitPix;
     const int chunk = blockIdx.x % chunks, slab = blockIdx.x / chunks;
     const int n = slab / groups, gidx = slab % groups;
@@ -1343,10 +1366,12 @@ gn_bwd_proj_split_apply_kernel(const float* __restrict__ y, const float* __restr
                 for (int q = 0; q < CT; ++q) g = fmaf(pw[q], gq[q][j][e], g);
                 const float gv = pre > 0.f ? g : 0.f;
                 o[e] = rstdf * (gv * gm - k1 - xh * k2);
+                am = fmaxf(am, fabsf(o[e]));
             }
             d4[(size_t)cl * (HW >> 2) + 256 * j] = o;
         }
     }
+    if (amax_parts) gn_block_amax_out(am, amax_parts);      // (uniform)
 }
 
 // shapes of the split path: a projected-gradient source on slabs that the register kernels cannot hold
@@ -1471,12 +1496,17 @@ static int gn_relu_fwd_impl(const InSrc& src, const float* gamma, const float* b
         else if (st)
             hipLaunchKernelGGL(gn_relu_fwd_small_kernel, dim3(N * groups), dim3(st), 0, (hipStream_t)stream, src, gamma,
                                beta, C, H, W, groups, eps, d0, d1, mean, rstd);
-        else if (vec)
-            hipLaunchKernelGGL(gn_relu_fwd_kernel<true>, dim3(N * groups), dim3(threads), 0, (hipStream_t)stream, src,
-                               gamma, beta, C, H, W, groups, eps, d0, d1, mean, rstd);
-        else
-            hipLaunchKernelGGL(gn_relu_fwd_kernel<false>, dim3(N * groups), dim3(threads), 0, (hipStream_t)stream, src,
-                               gamma, beta, C, H, W, groups, eps, d0, d1, mean, rstd);
+        else {
+            // (an armed amax tap is served by the generic kernels too; the round-5 link is not: its readers reduce the partials per
+            //  workgroup and these launches have thousands)
+            float* ap = dst0 ? gx_amax_producer_out(dst0, false, (unsigned)(N * groups), (size_t)N * C * H * W) : nullptr;
+            if (vec)
+                hipLaunchKernelGGL(gn_relu_fwd_kernel<true>, dim3(N * groups), dim3(threads), 0, (hipStream_t)stream, src,
+                                   gamma, beta, C, H, W, groups, eps, d0, d1, mean, rstd, ap);
+            else
+                hipLaunchKernelGGL(gn_relu_fwd_kernel<false>, dim3(N * groups), dim3(threads), 0, (hipStream_t)stream, src,
+                                   gamma, beta, C, H, W, groups, eps, d0, d1, mean, rstd, ap);
+        }
     }
     GX_CHECK_LAUNCH("gx_gn_relu_fwd");
     return GX_OK;
@@ -1578,12 +1608,13 @@ static int gn_relu_bwd_impl(const float* y, const float* gamma, const float* bet
                                    groups, v0, rec);
             hipLaunchKernelGGL(gn_bwd_proj_split_combine_kernel, dim3(N * groups), dim3(64), 0, s, (const float*)rec, gamma, rstd,
                                C, hw, groups, chunks, v0.ctot, kk, (float*)ws, wpart, bpart);
+            float* ap = gx_amax_producer_out(dy, false, grid.x, (size_t)N * C * H * W);
             if (v0.ctot <= 4)
                 hipLaunchKernelGGL(gn_bwd_proj_split_apply_kernel<4>, grid, dim3(256), 0, s, y, gamma, beta, mean, rstd, C, hw,
-                                   groups, v0, (const float*)kk, dy);
+                                   groups, v0, (const float*)kk, dy, ap);
             else
                 hipLaunchKernelGGL(gn_bwd_proj_split_apply_kernel<8>, grid, dim3(256), 0, s, y, gamma, beta, mean, rstd, C, hw,
-                                   groups, v0, (const float*)kk, dy);
+                                   groups, v0, (const float*)kk, dy, ap);
         }
         else if (pl.ok) {
             // projected-gradient source: stage the image's [Cout][H*W] output gradient in LDS when it fits
@@ -1597,12 +1628,15 @@ static int gn_relu_bwd_impl(const float* y, const float* gamma, const float* bet
         else if (st)
             hipLaunchKernelGGL(gn_relu_bwd_small_kernel, dim3(N * groups), dim3(st), 0, s, y, gamma, beta, mean, rstd,
                                C, H, W, groups, v0, v1, dy, (float*)ws);
-        else if (vec)
-            hipLaunchKernelGGL(gn_relu_bwd_kernel<true>, dim3(N * groups), dim3(threads), 0, s, y, gamma, beta, mean,
-                               rstd, C, H, W, groups, v0, v1, dy, (float*)ws);
-        else
-            hipLaunchKernelGGL(gn_relu_bwd_kernel<false>, dim3(N * groups), dim3(threads), 0, s, y, gamma, beta, mean,
-                               rstd, C, H, W, groups, v0, v1, dy, (float*)ws);
+        else {
+            float* ap = gx_amax_producer_out(dy, false, (unsigned)(N * groups), (size_t)N * C * H * W);
+            if (vec)
+                hipLaunchKernelGGL(gn_relu_bwd_kernel<true>, dim3(N * groups), dim3(threads), 0, s, y, gamma, beta, mean,
+                                   rstd, C, H, W, groups, v0, v1, dy, (float*)ws, ap);
+            else
+                hipLaunchKernelGGL(gn_relu_bwd_kernel<false>, dim3(N * groups), dim3(threads), 0, s, y, gamma, beta, mean,
+                                   rstd, C, H, W, groups, v0, v1, dy, (float*)ws, ap);
+        }
     }
     GX_CHECK_LAUNCH("gx_gn_relu_bwd");
     if (g_gx_defer_on) {

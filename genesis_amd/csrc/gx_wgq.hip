@@ -473,7 +473,6 @@ template <int CLS, int WC> struct WrGeo {
     static constexpr int B_ZERO = 4 * B_ROW;                   // offset of the zero piece inside a plane
     static constexpr int RING0 = 2 * A_BUF;                    // byte offset of the ring
     static constexpr int LDS_BYTES = RING0 + NPL * B_PLANE;
-    static_assert(!(F16 && NS > 1), "the strip forms (seam values) exist on the bf16 pieces only");
     __host__ __device__ static constexpr int fsw(int ch) { return (ch * OPR / 16) & (OPR - 1); }
     // float offset of the dy row of tile row `ra` of image `ia` (H tile rows per image) / of its x row
     // (ia / ib: VIRTUAL image = image * NS + strip)
@@ -544,6 +543,14 @@ __device__ __forceinline__ float wr_seam_load(const WrT<CLS, W>& w, int ta) {
     const float* sp = (live & w.okS & inside) ? w.a + G::a_row(ia, w.CA, w.ca0, w.H, ra) + w.goffS : w.zeros;
     return *(const __attribute__((address_space(1))) float*)sp;
 }
+// (fp16 pieces: b[0] = hi, b[1] = lo of v * sc, as wr_split_f16_pair forms them)
+__device__ __forceinline__ void wr_seam_split_f16(float v, float sc, unsigned short (&b)[3]) {
+    const float s0 = v * sc;
+    const float h0 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, s0) & 0xFFFFE000u);
+    b[0] = __builtin_bit_cast(unsigned short, (_Float16)h0);
+    b[1] = __builtin_bit_cast(unsigned short, (_Float16)(s0 - h0));
+    b[2] = 0;
+}
 __device__ __forceinline__ void wr_seam_split(float v, unsigned short (&b)[3]) {
     const __bf16 h = (__bf16)v;
     const float r1 = v - (float)h;
@@ -555,7 +562,7 @@ template <int CLS, int W>
 __device__ __forceinline__ void wr_seam_store(char* lds, const WrT<CLS, W>& w, int abuf, const unsigned short (&b)[3]) {
     using G = WrGeo<CLS, W>;
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<unsigned short*>(lds + abuf + w.stS + pl * G::A_PLANE) = b[pl];
+    for (int pl = 0; pl < G::NPL; ++pl) *reinterpret_cast<unsigned short*>(lds + abuf + w.stS + pl * G::A_PLANE) = b[pl];
 }
 
 // global -> registers: the dy row of tile ta and the x row of tile tb (a tile index outside [0, ntot) = nothing to load)
@@ -727,6 +734,19 @@ __device__ __forceinline__ void wr_split_piece(char* lds, const WrT<CLS, W>& w, 
     constexpr int SA = G::SA, NPB = G::NPB;
     if constexpr (Q >= G::SPQ * G::UPT * (NPB + 1)) {      // strips: the seam value (r[0..1], hp[0..2] are free by now)
         constexpr int step = Q - G::SPQ * G::UPT * (NPB + 1);
+        if constexpr (G::F16) {
+            if constexpr (step == 0) {
+                st.r[0] = st.sv * w.scA;
+                st.r[1] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, st.r[0]) & 0xFFFFE000u);
+            } else if constexpr (step == 1) {
+                st.hp[0] = __builtin_bit_cast(unsigned short, (_Float16)st.r[1]);
+                st.hp[1] = __builtin_bit_cast(unsigned short, (_Float16)(st.r[0] - st.r[1]));
+            } else {
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    *reinterpret_cast<unsigned short*>(lds + anxt + w.stS + pl * G::A_PLANE) = (unsigned short)st.hp[pl];
+            }
+        } else
         if constexpr (step == 0) {
             const __bf16 h = (__bf16)st.sv;
             st.r[0] = st.sv - (float)h;
@@ -1036,7 +1056,8 @@ __device__ __forceinline__ void wr_segment(const float* a, const float* b, const
     if constexpr (G::NS > 1) {
         __syncthreads();      // (the seam bytes lie inside the pieces the fill above zeroes)
         unsigned short sb[3];
-        wr_seam_split(wr_seam_load<CLS, W>(w, t0), sb);
+        if constexpr (G::F16) wr_seam_split_f16(wr_seam_load<CLS, W>(w, t0), w.scA, sb);
+        else wr_seam_split(wr_seam_load<CLS, W>(w, t0), sb);
         wr_seam_store<CLS, W>(lds, w, 0, sb);
     }
     wr_store<CLS, W, true, true>(lds, w, 0, ((t0 + G::DMIN) & 3) * G::B_ROW, pa, pb);
@@ -1229,6 +1250,7 @@ wgq_stream_kernel(const WsTable tab, const float* __restrict__ zeros) {
             GX_WR_CASE(96 + 18, WQ_C3, 3064)
             GX_WF_CASE(18, WQ_C3, 64) GX_WF_CASE(19, WQ_C3, 32) GX_WF_CASE(20, WQ_DR0, 32) GX_WF_CASE(21, WQ_DR1, 32)
             GX_WF_CASE(26, WQ_C3, 16) GX_WF_CASE(27, WQ_DR0, 16) GX_WF_CASE(28, WQ_DR1, 16)
+            GX_WF_CASE(29, WQ_C3, 128) GX_WF_CASE(30, WQ_DR0, 64) GX_WF_CASE(31, WQ_DR1, 64)
             default: break;
         }
 #undef GX_WS_CASE
@@ -1310,7 +1332,8 @@ bool wgq_f16() {
 // units per fp16-piece tile by row-ring variant 18 .. 28 (0: the variant has no fp16 form), re-fitted with GENESIS_WGQ_TIMES on the
 // metric step next to the bf16 / LDS-DMA variants of the same launch: 64 - 78 % of the bf16 tile (the 10-tap row parity gains
 // least: its split / staging work per tile is that of the 15-tap one).  GENESIS_WGQ_F16_COST="c18,c19,c20,c21,c26,c27,c28" overrides
-int g_ws_cost_f16[11] = {3040, 1760, 2650, 2315, 0, 0, 0, 0, 1870, 2700, 2380};
+int g_ws_cost_f16[14] = {3040, 1760, 2650, 2315, 0, 0, 0, 0, 1870, 2700, 2380,
+                         3200, 2750, 2150};           // ... one strip per tile (the 128 x 128 model's large layers): first estimates
 bool g_ws_cost_f16_init = false;
 int ws_f16cost(int rv) {
     if (!g_ws_cost_f16_init) {
@@ -1325,7 +1348,7 @@ int ws_f16cost(int rv) {
     }
     return g_ws_cost_f16[rv - 18];
 }
-bool ws_f16_variant(int rv) { return (rv >= 18 && rv <= 21) || (rv >= 26 && rv <= 28); }
+bool ws_f16_variant(int rv) { return (rv >= 18 && rv <= 21) || (rv >= 26 && rv <= 31); }
 
 // which matrix pipe the weight gradients run on: 1 (default) bf16 pipe, fp32 products from six bf16 piece products
 // (wq_tile_b6); 0 the fp32 pipe.  GENESIS_WGQ_BF16X6=0 / gx_wgq_precision(0) select the latter.

@@ -54,7 +54,7 @@ def _ws(nbytes, device):
 # Partial maxima live in a ring arena (one allocation per device, far larger than what one iteration produces: they are consumed by
 # the flush of the same iteration).  GENESIS_WGQ_F16X3=0: nothing is tapped, the weight gradients stay on six bf16 piece products.
 WGQ_F16 = os.environ.get('GENESIS_WGQ_F16X3', '1') != '0'
-_TAP_CAP = 8192
+_TAP_CAP = 16384         # (the 128 x 128 decoder head's chunked backward: K B x 8 groups x 4 chunks = 11 264 workgroups)
 _ARENA_FLOATS = 1 << 22
 _ARENA = {}                      # device index -> [tensor, base pointer, position (floats)]
 _LAST_AMAX = [None]

@@ -1696,7 +1696,11 @@ def test_fp16x3_transposed_conv_scales_follow_the_tensors(kind):
             return ((a.double().cpu() - r).pow(2).sum((0, 2, 3)).sqrt() / r.pow(2).sum((0, 2, 3)).sqrt().clamp_min(1e-300))
         for got, r, c in ((y, ref[0], c32[0]), (dx, ref[1], c32[1])):
             ch, c_ = chan(got, r), chan(c.double(), r)
-            assert float((ch / (3.0 * c_ + 1e-7)).max()) <= 1.0, (kind, float(ch.max()), float(c_.max()))      # (measured worst: 2.2 x, the channel that holds one_large's outlier)
+            # (measured worst: 2.2 - 3.1 x on the channel under one_large's outlier, depending on which conv algorithm the host's
+            #  fp32 op picked on that box -- its own per-channel error there moves between 2.1e-7 and 3.0e-7; hence the floor)
+            floor = 2e-7 if kind == 'one_large' else 1e-7
+            assert float((ch / (3.0 * c_ + floor)).max()) <= 1.0, (kind, float(ch.max()), float(c_.max()))
+            assert float(ch.max()) <= 1.5 * float(c_.max()) + 1e-7, (kind, float(ch.max()), float(c_.max()))
 
 
 @pytest.mark.parametrize('N,K,M,S', [(16, 32, 64, 64), (52, 64, 128, 32), (200, 64, 64, 16), (13, 48, 64, 64)])
@@ -1852,7 +1856,9 @@ def _per_channel_err(got, ref, dim):
 
 
 @pytest.mark.parametrize('kind,N,Cin,Cout,S', [('conv3x3', 32, 64, 64, 64), ('conv3x3', 8, 128, 64, 32), ('conv3x3', 16, 64, 128, 16),
-                                                ('deconv', 56, 64, 64, 32), ('deconv', 16, 64, 64, 16)])
+                                                ('deconv', 56, 64, 64, 32), ('deconv', 16, 64, 64, 16),
+                                                # rows of 128 / 64 input pixels: the strip tiles (seam values in two fp16 pieces)
+                                                ('conv3x3', 4, 64, 64, 128), ('deconv', 8, 64, 64, 64)])
 def test_weight_gradients_on_three_fp16_piece_products_keep_fp32_accuracy(kind, N, Cin, Cout, S):
     """gx_wgq_precision(2) + gx_wgq_operand_amax: the row-ring tiles with two fp16 pieces per operand value (x * 2^e = hi + lo)
     and three piece products.  Against autograd in fp64, next to the fp32 pipe and the six-bf16-piece form: the fp16 error stays
