@@ -159,12 +159,28 @@ dense_bwd_pair_kernel(const float* __restrict__ g, int ldg, const float* __restr
 // epilogue.  The library path issues ~8 launches per step (GEMM, bias, gate slicing, pointwise update).
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
 
-__global__ void __launch_bounds__(256)
-lstm_step_fwd_kernel(const float* __restrict__ gx, const float* __restrict__ h_prev,
-                     const float* __restrict__ c_prev, const float* __restrict__ w_hh,
-                     const float* __restrict__ b_hh, int B, int H, float* __restrict__ act,
-                     float* __restrict__ c_out, float* __restrict__ h_out) {
-    __shared__ float part[4][4][256];
+// (one step's work of a workgroup as a device function: the per-step kernel and the whole-sequence kernel below run the SAME
+//  instruction sequence, so their results are identical bit for bit; h_prev / c_prev may have been written earlier in the same
+//  launch by other workgroups -- plain pointers, no __restrict__)
+// COH (the whole-sequence kernels): values other workgroups read / wrote inside this launch move as agent-scope relaxed atomics --
+// write-through stores and cache-bypassing loads (global_store / global_load ... sc1), no cache-wide write-back or invalidate
+__device__ __forceinline__ f32x4 lstm_load4(const float* p, bool coh) {
+    if (!coh) return *reinterpret_cast<const f32x4*>(p);
+    f32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+}
+__device__ __forceinline__ void lstm_store(float* p, float v, bool coh) {
+    if (coh) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+template <bool COH>
+__device__ __forceinline__ void
+lstm_fwd_body(float (&part)[4][4][256], const float* __restrict__ gx, const float* h_prev, const float* c_prev,
+              const float* __restrict__ w_hh, const float* __restrict__ b_hh, int B, int H, float* act, float* c_out,
+              float* h_out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int idx = lane & 15, kq = lane >> 4;
     const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
@@ -176,7 +192,7 @@ lstm_step_fwd_kernel(const float* __restrict__ gx, const float* __restrict__ h_p
         for (int k16 = wave * 16; k16 < H; k16 += 64) {
             const int kb = k16 + 4 * kq;
             f32x4 av = {0.f, 0.f, 0.f, 0.f};
-            if (a_ok) av = *reinterpret_cast<const f32x4*>(h_prev + (size_t)(i0 + idx) * H + kb);
+            if (a_ok) av = lstm_load4(h_prev + (size_t)(i0 + idx) * H + kb, COH);
             f32x4 bv[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -210,18 +226,73 @@ lstm_step_fwd_kernel(const float* __restrict__ gx, const float* __restrict__ h_p
         float* ar = act + (size_t)b * 4 * H + u;
         ar[0] = ig; ar[H] = fg; ar[2 * H] = gg; ar[3 * H] = og;
         c_out[(size_t)b * H + u] = cn;
-        h_out[(size_t)b * H + u] = og * tanhf(cn);
+        lstm_store(h_out + (size_t)b * H + u, og * tanhf(cn), COH);
     }
+}
+
+__global__ void __launch_bounds__(256)
+lstm_step_fwd_kernel(const float* __restrict__ gx, const float* __restrict__ h_prev,
+                     const float* __restrict__ c_prev, const float* __restrict__ w_hh,
+                     const float* __restrict__ b_hh, int B, int H, float* __restrict__ act,
+                     float* __restrict__ c_out, float* __restrict__ h_out) {
+    __shared__ float part[4][4][256];
+    lstm_fwd_body<false>(part, gx, h_prev, c_prev, w_hh, b_hh, B, H, act, c_out, h_out);
+}
+
+// ---- the whole sequence in ONE launch (the AR prior's LSTM: T = K - 1 = 6 steps of B = 32, H = 256 -- six launches of ~6 us each
+//      of which ~1 us is work).  Same grid as one step (H / 16 x ceil(B / 16) workgroups, all resident at once: the host refuses
+//      grids past kLstmSeqMaxWg); between two steps every workgroup needs every other's h -> a grid-wide barrier on one counter per
+//      step boundary in `bar` (kLstmSeqBar zero-initialised unsigned ints owned by the caller).  What crosses a barrier (h forward,
+//      dgates backward) is written with agent-scope write-through stores and read with agent-scope loads, addresses no cache of the
+//      reading CU / XCD has touched in this launch; the barrier itself is then: wait for this wave's stores, workgroup barrier, one
+//      atomic add, spin on agent-scope loads, workgroup barrier.  (First form, measured: release fence + acquire fence around the
+//      counter = buffer_wbl2 sc1 / buffer_inv sc1, a write-back and an invalidate of the XCD's whole L2 per step boundary: 38 us
+//      forward and 58 us backward for T = 6 -- SLOWER than the 35 + 38 us of the twelve step launches.)  The last workgroup through
+//      the final counter zeroes them all: every other workgroup has passed every barrier by then, and the next launch finds the
+//      state it needs.
+constexpr int kLstmSeqBar = 16;
+constexpr int kLstmSeqMaxWg = 128;
+
+__device__ __forceinline__ void lstm_grid_barrier(unsigned* bar, unsigned nwg) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through stores have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nwg) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void lstm_grid_finish(unsigned* bar, unsigned nwg) {
+    if (threadIdx.x == 0) {
+        const unsigned seen = __hip_atomic_fetch_add(bar + kLstmSeqBar - 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen == nwg - 1) {
+            for (int i = 0; i < kLstmSeqBar; ++i) __hip_atomic_store(bar + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+lstm_seq_fwd_kernel(const float* __restrict__ gx, const float* __restrict__ w_hh, const float* __restrict__ b_hh, int T, int B,
+                    int H, float* act, float* c, float* h, unsigned* bar) {
+    __shared__ float part[4][4][256];
+    const unsigned nwg = gridDim.x * gridDim.y;
+    const size_t sh = (size_t)B * H;
+    for (int t = 0; t < T; ++t) {
+        if (t) lstm_grid_barrier(bar + (t - 1), nwg);
+        lstm_fwd_body<true>(part, gx + (size_t)t * 4 * sh, t ? h + (size_t)(t - 1) * sh : nullptr, t ? c + (size_t)(t - 1) * sh : nullptr,
+                            w_hh, b_hh, B, H, act + (size_t)t * 4 * sh, c + (size_t)t * sh, h + (size_t)t * sh);
+    }
+    lstm_grid_finish(bar, nwg);
 }
 
 // dh = g_h + dgates_next w_hh; dc = dc_next + dh o (1 - tanh(c)^2); dgates = (dc g i(1-i), dc c_prev f(1-f),
 // dc i (1-g^2), dh tanh(c) o(1-o)); dc_prev = dc f.
-__global__ void __launch_bounds__(1024)
-lstm_step_bwd_kernel(const float* __restrict__ g_h, const float* __restrict__ dgates_next,
-                     const float* __restrict__ w_hh, const float* __restrict__ act, const float* __restrict__ c,
-                     const float* __restrict__ c_prev, const float* __restrict__ dc_next, int B, int H,
-                     float* __restrict__ dgates, float* __restrict__ dc_prev) {
-    __shared__ float part[16][256];
+template <bool COH>
+__device__ __forceinline__ void
+lstm_bwd_body(float (&part)[16][256], const float* __restrict__ g_h, const float* dgates_next, const float* __restrict__ w_hh,
+              const float* __restrict__ act, const float* __restrict__ c, const float* __restrict__ c_prev, const float* dc_next,
+              int B, int H, float* dgates, float* dc_prev) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int idx = lane & 15, kq = lane >> 4;
     const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
@@ -232,7 +303,7 @@ lstm_step_bwd_kernel(const float* __restrict__ g_h, const float* __restrict__ dg
         for (int k16 = wave * 16; k16 < Kc; k16 += nw * 16) {
             const int kb = k16 + 4 * kq;
             f32x4 av = {0.f, 0.f, 0.f, 0.f};
-            if (a_ok) av = *reinterpret_cast<const f32x4*>(dgates_next + (size_t)(i0 + idx) * Kc + kb);
+            if (a_ok) av = lstm_load4(dgates_next + (size_t)(i0 + idx) * Kc + kb, COH);
             float bv[4];
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) bv[jj] = w_hh[(size_t)(kb + jj) * H + j0 + idx];
@@ -257,13 +328,40 @@ lstm_step_bwd_kernel(const float* __restrict__ g_h, const float* __restrict__ dg
             const float cp = c_prev ? c_prev[(size_t)b * H + u] : 0.f;
             const float dc = (dc_next ? dc_next[(size_t)b * H + u] : 0.f) + dh * og * (1.f - tc * tc);
             float* dr = dgates + (size_t)b * 4 * H + u;
-            dr[0] = dc * gg * ig * (1.f - ig);
-            dr[H] = dc * cp * fg * (1.f - fg);
-            dr[2 * H] = dc * ig * (1.f - gg * gg);
-            dr[3 * H] = dh * tc * og * (1.f - og);
+            lstm_store(dr, dc * gg * ig * (1.f - ig), COH);
+            lstm_store(dr + H, dc * cp * fg * (1.f - fg), COH);
+            lstm_store(dr + 2 * H, dc * ig * (1.f - gg * gg), COH);
+            lstm_store(dr + 3 * H, dh * tc * og * (1.f - og), COH);
             dc_prev[(size_t)b * H + u] = dc * fg;
         }
     }
+}
+
+__global__ void __launch_bounds__(1024)
+lstm_step_bwd_kernel(const float* __restrict__ g_h, const float* __restrict__ dgates_next,
+                     const float* __restrict__ w_hh, const float* __restrict__ act, const float* __restrict__ c,
+                     const float* __restrict__ c_prev, const float* __restrict__ dc_next, int B, int H,
+                     float* __restrict__ dgates, float* __restrict__ dc_prev) {
+    __shared__ float part[16][256];
+    lstm_bwd_body<false>(part, g_h, dgates_next, w_hh, act, c, c_prev, dc_next, B, H, dgates, dc_prev);
+}
+
+// the backward of the whole sequence in one launch: steps T-1 .. 0, step t reads every workgroup's dgates[t + 1] (a grid barrier per
+// step boundary, as above); dc travels through two [B,H] planes of `dc2`, each element written and read by the same thread
+__global__ void __launch_bounds__(1024)
+lstm_seq_bwd_kernel(const float* __restrict__ g_h, const float* __restrict__ w_hh, const float* __restrict__ act,
+                    const float* __restrict__ c, int T, int B, int H, float* dgates, float* dc2, unsigned* bar) {
+    __shared__ float part[16][256];
+    const unsigned nwg = gridDim.x * gridDim.y;
+    const size_t sh = (size_t)B * H;
+    for (int t = T - 1; t >= 0; --t) {
+        if (t + 1 < T) lstm_grid_barrier(bar + t, nwg);
+        lstm_bwd_body<true>(part, g_h + (size_t)t * sh, t + 1 < T ? dgates + (size_t)(t + 1) * 4 * sh : nullptr, w_hh,
+                      act + (size_t)t * 4 * sh, c + (size_t)t * sh, t ? c + (size_t)(t - 1) * sh : nullptr,
+                      t + 1 < T ? dc2 + (size_t)((t + 1) & 1) * sh : nullptr, B, H, dgates + (size_t)t * 4 * sh,
+                      dc2 + (size_t)(t & 1) * sh);
+    }
+    lstm_grid_finish(bar, nwg);
 }
 
 
@@ -594,6 +692,47 @@ int gx_lstm_step_bwd(const float* g_h, const float* dgates_next, const float* w_
                            dgates_next, w_hh, act, c, c_prev, dc_next, B, H, dgates, dc_prev);
     }
     GX_CHECK_LAUNCH("gx_lstm_step_bwd");
+    return GX_OK;
+}
+
+int gx_lstm_seq_max_steps(int B, int H) {
+    if (B <= 0 || H <= 0 || H % 16 != 0) return 0;
+    return (H / 16) * gx_ceil_div(B, 16) <= kLstmSeqMaxWg ? kLstmSeqBar : 0;
+}
+
+size_t gx_lstm_seq_ws_bytes(void) { return kLstmSeqBar * sizeof(unsigned); }
+
+int gx_lstm_seq_fwd(const float* gx, const float* w_hh, const float* b_hh, int T, int B, int H, float* act, float* c,
+                    float* h, void* bar, gx_stream_t stream) {
+    GX_CHECK_ARG(gx && w_hh && b_hh && act && c && h && bar, "gx_lstm_seq_fwd: null pointer");
+    GX_CHECK_ARG(T > 0 && T <= gx_lstm_seq_max_steps(B, H),
+                 "gx_lstm_seq_fwd: T=%d steps of B=%d, H=%d do not fit one launch (gx_lstm_seq_max_steps: %d)", T, B, H,
+                 gx_lstm_seq_max_steps(B, H));
+    GX_CHECK_ARG(aligned16(w_hh) && aligned16(h) && ((size_t)B * H) % 4 == 0, "gx_lstm_seq_fwd: 16-byte alignment");
+    hipStream_t s = (hipStream_t)stream;
+    {
+        GxProf pf(KID_DENSE, s, 8.0 * (T - 1) * B * H * H, 4.0 * T * (4.0 * H * H + 12.0 * B * H));
+        hipLaunchKernelGGL(lstm_seq_fwd_kernel, dim3(H / 16, gx_ceil_div(B, 16)), dim3(256), 0, s, gx, w_hh, b_hh, T, B, H,
+                           act, c, h, (unsigned*)bar);
+    }
+    GX_CHECK_LAUNCH("gx_lstm_seq_fwd");
+    return GX_OK;
+}
+
+int gx_lstm_seq_bwd(const float* g_h, const float* w_hh, const float* act, const float* c, int T, int B, int H,
+                    float* dgates, float* dc2, void* bar, gx_stream_t stream) {
+    GX_CHECK_ARG(g_h && w_hh && act && c && dgates && dc2 && bar, "gx_lstm_seq_bwd: null pointer");
+    GX_CHECK_ARG(T > 0 && T <= gx_lstm_seq_max_steps(B, H),
+                 "gx_lstm_seq_bwd: T=%d steps of B=%d, H=%d do not fit one launch (gx_lstm_seq_max_steps: %d)", T, B, H,
+                 gx_lstm_seq_max_steps(B, H));
+    GX_CHECK_ARG(aligned16(dgates), "gx_lstm_seq_bwd: 16-byte alignment");
+    hipStream_t s = (hipStream_t)stream;
+    {
+        GxProf pf(KID_DENSE, s, 8.0 * (T - 1) * B * H * H, 4.0 * T * (4.0 * H * H + 14.0 * B * H));
+        hipLaunchKernelGGL(lstm_seq_bwd_kernel, dim3(H / 16, gx_ceil_div(B, 16)), dim3(1024), 0, s, g_h, w_hh, act, c, T, B, H,
+                           dgates, dc2, (unsigned*)bar);
+    }
+    GX_CHECK_LAUNCH("gx_lstm_seq_bwd");
     return GX_OK;
 }
 

@@ -1491,8 +1491,11 @@ class LSTMFn(torch.autograd.Function):
         c = torch.empty(T, B, H, device=dev)
         h = torch.empty(T, B, H, device=dev)
         gx3 = gx.view(T, B, 4 * H)
-        for t in range(T):
-            hip.lstm_step_fwd(gx3[t], h[t - 1] if t else None, c[t - 1] if t else None, w_hh, b_hh, act[t], c[t], h[t])
+        if 1 < T <= hip.lstm_seq_steps(B, H):
+            hip.lstm_seq_fwd(gx3, w_hh, b_hh, act, c, h)
+        else:
+            for t in range(T):
+                hip.lstm_step_fwd(gx3[t], h[t - 1] if t else None, c[t - 1] if t else None, w_hh, b_hh, act[t], c[t], h[t])
         ctx.save_for_backward(x, act, c, h)
         ctx.params = (w_ih, w_hh, b_ih, b_hh)
         return h
@@ -1505,10 +1508,13 @@ class LSTMFn(torch.autograd.Function):
         H = w_hh.shape[1]
         g = g.contiguous()
         dgates = torch.empty(T, B, 4 * H, device=x.device)
-        dc = [torch.empty(B, H, device=x.device), torch.empty(B, H, device=x.device)]
-        for t in reversed(range(T)):
-            hip.lstm_step_bwd(g[t], dgates[t + 1] if t + 1 < T else None, w_hh, act[t], c[t],
-                              c[t - 1] if t else None, dc[(t + 1) & 1] if t + 1 < T else None, dgates[t], dc[t & 1])
+        dc = torch.empty(2, B, H, device=x.device)
+        if 1 < T <= hip.lstm_seq_steps(B, H):
+            hip.lstm_seq_bwd(g, w_hh, act, c, dgates, dc)
+        else:
+            for t in reversed(range(T)):
+                hip.lstm_step_bwd(g[t], dgates[t + 1] if t + 1 < T else None, w_hh, act[t], c[t],
+                                  c[t - 1] if t else None, dc[(t + 1) & 1] if t + 1 < T else None, dgates[t], dc[t & 1])
         o_wih, o_whh, o_bih, o_bhh = _gout(w_ih), _gout(w_hh), _gout(b_ih), _gout(b_hh)
         dg2 = dgates.view(T * B, 4 * H)
         dx, dw_ih, db = hip.linear_bwd(x.view(T * B, D), w_ih, None, dg2, None, need_dx=ctx.needs_input_grad[0],
@@ -1546,8 +1552,11 @@ class ARPriorKLFn(torch.autograd.Function):
         act = torch.empty(T, B, 4 * H, device=dev)
         c = torch.empty(T, B, H, device=dev)
         h = torch.empty(T, B, H, device=dev)
-        for t in range(T):
-            hip.lstm_step_fwd(gx3[t], h[t - 1] if t else None, c[t - 1] if t else None, w_hh, b_hh, act[t], c[t], h[t])
+        if 1 < T <= hip.lstm_seq_steps(B, H):
+            hip.lstm_seq_fwd(gx3, w_hh, b_hh, act, c, h)                # (all steps in one launch)
+        else:
+            for t in range(T):
+                hip.lstm_step_fwd(gx3[t], h[t - 1] if t else None, c[t - 1] if t else None, w_hh, b_hh, act[t], c[t], h[t])
         lin = hip.linear_fwd(h.view(T * B, H), w_lin, b_lin).view(T, B, -1)
         kl = hip.latent_prior_logp_fwd(z, lin, log_q)
         ctx.save_for_backward(z, act, c, h, lin)
@@ -1573,10 +1582,13 @@ class ARPriorKLFn(torch.autograd.Function):
                                             out_db=o_bl)
         dh = dh.view(T, B, H)
         dgates = torch.empty(T, B, 4 * H, device=dev)
-        dc = [torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)]
-        for t in reversed(range(T)):
-            hip.lstm_step_bwd(dh[t], dgates[t + 1] if t + 1 < T else None, w_hh, act[t], c[t],
-                              c[t - 1] if t else None, dc[(t + 1) & 1] if t + 1 < T else None, dgates[t], dc[t & 1])
+        dc = torch.empty(2, B, H, device=dev)
+        if 1 < T <= hip.lstm_seq_steps(B, H):
+            hip.lstm_seq_bwd(dh, w_hh, act, c, dgates, dc)
+        else:
+            for t in reversed(range(T)):
+                hip.lstm_step_bwd(dh[t], dgates[t + 1] if t + 1 < T else None, w_hh, act[t], c[t],
+                                  c[t - 1] if t else None, dc[(t + 1) & 1] if t + 1 < T else None, dgates[t], dc[t & 1])
         o_wih, o_whh, o_bih, o_bhh = _gout(w_ih), _gout(w_hh), _gout(b_ih), _gout(b_hh)
         _, dw_ih, db = hip.linear_bwd(z.view(K * B, D)[:T * B], w_ih, None, dgates.view(T * B, 4 * H), None,
                                       out_dw=o_wih, out_db=o_bih, out_db2=o_bhh,

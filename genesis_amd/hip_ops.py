@@ -1366,6 +1366,52 @@ def lstm_step_bwd(g_h, dgates_next, w_hh, act, c, c_prev, dc_next, dgates, dc_pr
               H4 // 4, _p(dgates), _p(dc_prev), _stream())
 
 
+# The whole-sequence LSTM launches (gx_lstm_seq_*) are OFF by default: measured on the metric step (T = 6, B = 32, H = 256) they take
+# 42 us forward + 65 us backward against 35 + 38 us for the twelve step launches inside the replayed graph -- a grid-wide barrier
+# across the eight XCDs (store acknowledgement, atomic at the memory side, poll, loads past the L2) costs about what a launch boundary
+# inside a HIP graph costs (finding 46).  GENESIS_LSTM_SEQ=1 switches them on (tests: bit-identical).
+LSTM_SEQ = os.environ.get('GENESIS_LSTM_SEQ', '0') == '1'
+_LSTM_BAR = {}
+
+
+def _lstm_bar(device, which):
+    """The grid-barrier counters of the whole-sequence LSTM launches: zero once, left zero by every launch; one set per
+    (device, stream, direction) -- launches sharing a set must not overlap."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, which)
+    t = _LSTM_BAR.get(key)
+    if t is None:
+        t = _LSTM_BAR[key] = torch.zeros(_lib.query('gx_lstm_seq_ws_bytes') // 4, dtype=torch.int32, device=device)
+    return t
+
+
+def lstm_seq_steps(B, H):
+    """Longest sequence gx_lstm_seq_fwd / _bwd take in one launch for these sizes (0: unroll with lstm_step_*)."""
+    return lstm_seq_capacity(B, H) if LSTM_SEQ else 0
+
+
+def lstm_seq_capacity(B, H):
+    return _lib.query('gx_lstm_seq_max_steps', B, H)
+
+
+def lstm_seq_fwd(gx3, w_hh, b_hh, act, c, h):
+    """All T steps of a zero-state LSTM in one launch: gx3 [T,B,4H] -> act [T,B,4H], c, h [T,B,H] (bit-identical to T
+    lstm_step_fwd calls)."""
+    T, B, H4 = gx3.shape
+    for t, n in ((gx3, 'gx'), (w_hh, 'w_hh'), (b_hh, 'b_hh'), (act, 'act'), (c, 'c'), (h, 'h')):
+        _chk(t, 'lstm_seq_fwd.' + n)
+    _lib.call('gx_lstm_seq_fwd', _p(gx3), _p(w_hh), _p(b_hh), T, B, H4 // 4, _p(act), _p(c), _p(h),
+              _p(_lstm_bar(gx3.device, 0)), _stream())
+
+
+def lstm_seq_bwd(g_h, w_hh, act, c, dgates, dc2):
+    """Its backward in one launch: g_h [T,B,H] -> dgates [T,B,4H]; dc2 [2,B,H] scratch."""
+    T, B, H4 = act.shape
+    for t, n in ((g_h, 'g_h'), (w_hh, 'w_hh'), (act, 'act'), (c, 'c'), (dgates, 'dgates'), (dc2, 'dc2')):
+        _chk(t, 'lstm_seq_bwd.' + n)
+    _lib.call('gx_lstm_seq_bwd', _p(g_h), _p(w_hh), _p(act), _p(c), T, B, H4 // 4, _p(dgates), _p(dc2),
+              _p(_lstm_bar(act.device, 1)), _stream())
+
+
 # ------------------------------------------------------------------ 1x1 conv on a never-materialised GroupNorm+ReLU
 def conv1x1_gn_fwd(y_pre, mean, rstd, gamma, beta, groups, w, bias, gate=None, addend=None):
     """gate * conv1x1(relu(gn(y_pre))) + addend: the normalised activation is formed on load."""

@@ -660,6 +660,21 @@ int gx_lstm_step_fwd(const float* gx, const float* h_prev, const float* c_prev, 
 int gx_lstm_step_bwd(const float* g_h, const float* dgates_next, const float* w_hh, const float* act,
                      const float* c, const float* c_prev, const float* dc_next, int B, int H, float* dgates,
                      float* dc_prev, gx_stream_t stream);
+/*      the whole sequence (zero initial state) in ONE launch each way -- the same per-step arithmetic in the same order, i.e. the
+ *      results of the unrolled gx_lstm_step_* calls bit for bit; the steps are separated by grid-wide barriers inside the
+ *      kernel, so the grid (H / 16 x ceil(B / 16) workgroups) has to be resident at once: gx_lstm_seq_max_steps(B, H) is
+ *      the longest sequence one launch takes for these sizes (0: use the per-step calls).
+ *      fwd: gx [T,B,4H] (input projection of all steps) -> act [T,B,4H], c [T,B,H], h [T,B,H].
+ *      bwd: g_h [T,B,H] (dL/dh of every step), act, c of the forward -> dgates [T,B,4H]; dc2: two [B,H] planes of scratch.
+ *      bar: gx_lstm_seq_ws_bytes() bytes of device memory, ZERO before the first launch that uses it; a launch leaves it
+ *      zero again.  One `bar` must not be shared by launches that can run concurrently.
+ *      (models/genesis_config.py:297-307 prior_lstm over z_{<k}) */
+int gx_lstm_seq_max_steps(int B, int H);
+size_t gx_lstm_seq_ws_bytes(void);
+int gx_lstm_seq_fwd(const float* gx, const float* w_hh, const float* b_hh, int T, int B, int H, float* act, float* c,
+                    float* h, void* bar, gx_stream_t stream);
+int gx_lstm_seq_bwd(const float* g_h, const float* w_hh, const float* act, const float* c, int T, int B, int H,
+                    float* dgates, float* dc2, void* bar, gx_stream_t stream);
 
 /* ---- packed-weight cache.  The conv / deconv entry points above re-pack their weight tensor into the MFMA
  *      operand layout on every call; inside a training loop the weights change once per optimiser step, so:

@@ -673,6 +673,55 @@ def test_lstm(T, B, D, H):
         close(p.grad, r.grad, rtol=1e-4, atol=1e-5, msg=name)
 
 
+@pytest.mark.parametrize('T,B,D,H', [(6, 32, 64, 256), (10, 64, 64, 256), (2, 3, 16, 16), (4, 17, 8, 32), (16, 32, 8, 64)])
+def test_lstm_whole_sequence_launch_equals_the_step_launches(T, B, D, H):
+    """gx_lstm_seq_fwd / _bwd: all T steps in one launch each way (grid-wide barriers between the steps) against the T
+    gx_lstm_step_* launches they replace -- the same arithmetic in the same order: every output bit for bit.  Repeated five
+    times on the same barrier counters (a launch has to leave them zero), then 20 replays of a HIP graph holding both."""
+    from genesis_amd import hip_ops as hip
+    assert T <= hip.lstm_seq_capacity(B, H), (T, hip.lstm_seq_capacity(B, H))
+    gx3 = rnd(T, B, 4 * H, seed=1).to(DEV)
+    w_hh = rnd(4 * H, H, seed=2, scale=0.2).to(DEV)
+    b_hh = rnd(4 * H, seed=3, scale=0.2).to(DEV)
+    g = rnd(T, B, H, seed=4).to(DEV)
+
+    def buffers():
+        return [torch.full((T, B, 4 * H), float('nan'), device=DEV), torch.full((T, B, H), float('nan'), device=DEV),
+                torch.full((T, B, H), float('nan'), device=DEV), torch.full((T, B, 4 * H), float('nan'), device=DEV),
+                torch.full((2, B, H), float('nan'), device=DEV)]
+    act, c, h, dgates, dc = buffers()
+    for t in range(T):
+        hip.lstm_step_fwd(gx3[t], h[t - 1] if t else None, c[t - 1] if t else None, w_hh, b_hh, act[t], c[t], h[t])
+    for t in reversed(range(T)):
+        hip.lstm_step_bwd(g[t], dgates[t + 1] if t + 1 < T else None, w_hh, act[t], c[t], c[t - 1] if t else None,
+                          dc[(t + 1) & 1] if t + 1 < T else None, dgates[t], dc[t & 1])
+    ref = [act, c, h, dgates]
+    assert all(bool(torch.isfinite(r).all()) for r in ref)
+    for rep in range(5):
+        act2, c2, h2, dg2, dc2 = buffers()
+        hip.lstm_seq_fwd(gx3, w_hh, b_hh, act2, c2, h2)
+        hip.lstm_seq_bwd(g, w_hh, act2, c2, dg2, dc2)
+        for name, a, b in zip(('act', 'c', 'h', 'dgates'), (act2, c2, h2, dg2), ref):
+            assert torch.equal(a, b), (rep, name, float((a - b).abs().max()))
+    assert int(hip._lstm_bar(torch.device(DEV), 0).abs().sum()) == 0 and int(hip._lstm_bar(torch.device(DEV), 1).abs().sum()) == 0
+    # in a HIP graph (the training step replays it): the counters are part of the replayed state
+    side = torch.cuda.Stream()
+    act3, c3, h3, dg3, dc3 = buffers()
+    with torch.cuda.stream(side):
+        hip.lstm_seq_fwd(gx3, w_hh, b_hh, act3, c3, h3)         # (this stream's counters exist before the capture)
+        hip.lstm_seq_bwd(g, w_hh, act3, c3, dg3, dc3)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            hip.lstm_seq_fwd(gx3, w_hh, b_hh, act3, c3, h3)
+            hip.lstm_seq_bwd(g, w_hh, act3, c3, dg3, dc3)
+    for rep in range(20):
+        dg3.fill_(float('nan')); h3.fill_(float('nan'))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(h3, h) and torch.equal(dg3, dgates), rep
+
+
 def test_kl_mode_gradients():
     """PriorLogPFn with log_q returns log_q - log_p and routes +g to log_q, -g into the prior terms."""
     from genesis_amd import functions as fn
