@@ -286,7 +286,16 @@ __device__ __forceinline__ void q_phase(f32x16 (&acc)[NCLS][MI][2], const float*
 // that produced the tensor: gx_kq_amax_link): strided loads, wave reduction
 __device__ __forceinline__ float q_amax_parts(const float* __restrict__ parts, int n) {
     float m = 0.f;
-    for (int i = threadIdx.x & 63; i < n; i += 64) m = fmaxf(m, parts[i]);
+    int i0 = 0;
+    if ((reinterpret_cast<uintptr_t>(parts) & 15) == 0) {       // (thousands of partials -- the generic GroupNorm kernels': 16-byte loads)
+        const int n4 = n >> 2;
+        for (int i = threadIdx.x & 63; i < n4; i += 64) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(parts)[i];
+            m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+        }
+        i0 = n4 << 2;
+    }
+    for (int i = i0 + (threadIdx.x & 63); i < n; i += 64) m = fmaxf(m, parts[i]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m)));

@@ -1497,9 +1497,9 @@ static int gn_relu_fwd_impl(const InSrc& src, const float* gamma, const float* b
             hipLaunchKernelGGL(gn_relu_fwd_small_kernel, dim3(N * groups), dim3(st), 0, (hipStream_t)stream, src, gamma,
                                beta, C, H, W, groups, eps, d0, d1, mean, rstd);
         else {
-            // (an armed amax tap is served by the generic kernels too; the round-5 link is not: its readers reduce the partials per
-            //  workgroup and these launches have thousands)
-            float* ap = dst0 ? gx_amax_producer_out(dst0, false, (unsigned)(N * groups), (size_t)N * C * H * W) : nullptr;
+            // (an armed amax tap and the link are served by the generic kernels too -- the 128 x 128 model's decoder: K B x 8 = 2816
+            //  partial maxima, which every workgroup of the conv that reads them reduces with 16-byte loads)
+            float* ap = dst0 ? gn_take_link_out(dst0, d0.ctot, d0.c0, d0.mode, C, (unsigned)(N * groups), (size_t)N * C * H * W, dst1 != nullptr) : nullptr;
             if (vec)
                 hipLaunchKernelGGL(gn_relu_fwd_kernel<true>, dim3(N * groups), dim3(threads), 0, (hipStream_t)stream, src,
                                    gamma, beta, C, H, W, groups, eps, d0, d1, mean, rstd, ap);
@@ -1608,7 +1608,7 @@ static int gn_relu_bwd_impl(const float* y, const float* gamma, const float* bet
                                    groups, v0, rec);
             hipLaunchKernelGGL(gn_bwd_proj_split_combine_kernel, dim3(N * groups), dim3(64), 0, s, (const float*)rec, gamma, rstd,
                                C, hw, groups, chunks, v0.ctot, kk, (float*)ws, wpart, bpart);
-            float* ap = gx_amax_producer_out(dy, false, grid.x, (size_t)N * C * H * W);
+            float* ap = gn_take_link_out(dy, C, 0, 0, C, grid.x, (size_t)N * C * H * W);      // (dy: a whole plain tensor)
             if (v0.ctot <= 4)
                 hipLaunchKernelGGL(gn_bwd_proj_split_apply_kernel<4>, grid, dim3(256), 0, s, y, gamma, beta, mean, rstd, C, hw,
                                    groups, v0, (const float*)kk, dy, ap);

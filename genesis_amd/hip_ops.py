@@ -149,7 +149,8 @@ class _operand_amax(object):
 
 
 WINO_F16 = os.environ.get('GENESIS_WINO_F16X3', '1') != '0'
-_WINO_AMAX_MAX = 1024
+_AMAX_DEBUG = os.environ.get('GENESIS_AMAX_DEBUG') == '1'      # prints the partial-maxima counts every conv3x3 call was handed
+_WINO_AMAX_MAX = 1536       # (1280: the 128 x 128 model's pair data gradient -- 1024 partials of the chunked head backward + 256)
 
 
 class _input_amax(object):
@@ -159,9 +160,16 @@ class _input_amax(object):
 
     def __init__(self, handles):
         self.on = False
+        if _AMAX_DEBUG and handles is None:
+            import traceback
+            print('conv input maxima: unknown  <- %s' % ' / '.join('%s:%d' % (f.name, f.lineno) for f in traceback.extract_stack()[-4:-1]), flush=True)
         if not WINO_F16 or handles is None:
             return
         hs = list(handles) if isinstance(handles, (list, tuple)) else [handles]
+        if _AMAX_DEBUG:
+            import traceback
+            print('conv input maxima: %s  <- %s' % ([None if h is None else h.n for h in hs],
+                                                     ' / '.join('%s:%d' % (f.name, f.lineno) for f in traceback.extract_stack()[-4:-1])), flush=True)
         if not hs or len(hs) > 2 or any(h is None for h in hs):
             return
         # every workgroup of the conv reduces the partial maxima itself: worth it up to ~1000 of them (GroupNorm(8) at any batch of
@@ -338,7 +346,7 @@ _LINK_KEEP = []
 AMAX_LINK_REG = os.environ.get('GENESIS_AMAX_LINK_REG', '1') != '0'     # 0: only the decoder head's gradient is handed over
 
 
-def amax_link(device, numel, capacity=4096):
+def amax_link(device, numel, capacity=16384):
     """gx_kq_amax_link: arms the one-shot hand-over of a tensor's partial maxima from the kernel that writes it (the decoder head's
     GroupNorm backward) to the fp16 x 3 conv that reads it next (gx_deconv5x5s2_dgrad) -- no second pass over a 235 MB gradient.
     numel: the elements of that tensor (a producer launch that covers only part of it leaves the link alone).
