@@ -290,7 +290,8 @@ int gx_kq_c3h_launch(const float* in, const float* wp, const float* bias, int ac
 bool gx_kq_c5h_eligible(int N, int K, int M, int H, int W);
 int gx_chan_sums_launch(const float* x, int N, int C, int HW, float* part, float* out, hipStream_t s);   // gx_misc.hip
 int gx_kq_c5h_launch(const float* in, const float* wp, float* out, int N, int K, int M, int H, int W, hipStream_t s,
-                     float* amax_ws = nullptr, const float* w_amax = nullptr);      // (packs 47 / 48)
+                     float* amax_ws = nullptr, const float* w_amax = nullptr, const float* x_parts = nullptr,
+                     int x_nparts = 0);      // (packs 47 / 48; x_parts: the input's partial maxima, gx_kq_amax_link)
 __host__ __device__ __forceinline__ size_t gx_kq_h_word(int m, int k, int t, int piece, int NT, int K, int NP = 3) {
     return ((((size_t)(m >> 6) * (K >> 4) + (k >> 4)) * NT + t) * NP + piece) * 512 + (((k >> 3) & 1) * 64 + (m & 63)) * 4 + ((k & 7) >> 1);
 }

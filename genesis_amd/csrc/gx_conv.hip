@@ -2705,9 +2705,11 @@ int gx_conv5x5s1(const float* in, const float* w, float* out, int N, int K, int 
                   : launch_pack(w, wp, 27 + f16, M, K, 25, gx_round_up(K, 16), Mpad, s, &wpu);
         if (rc) return rc;
         float* amax_ws = f16 ? (float*)((char*)ws + gx_conv5x5s1_ws_bytes(N, K, M, H, W)) - gx_kq_amax_ws_floats() : nullptr;
-        if (f16) { int unused_n; (void)gx_amax_link_take(nullptr, 0, &unused_n); }       // (a pending amax link is not for this call)
+        int xn = 0;
+        const float* xparts = f16 ? gx_amax_link_take(in, (size_t)N * K * H * W, &xn) : nullptr;      // the input's partial maxima from the kernel that wrote it (the gated unit)
         return gx_kq_c5h_launch(in, wpu, out, N, K, M, H, W, s, amax_ws,
-                                f16 ? (const float*)((const char*)wpu + gx_kq_h_amax_off(gx_round_up(K, 16), Mpad, 25)) : nullptr);
+                                f16 ? (const float*)((const char*)wpu + gx_kq_h_amax_off(gx_round_up(K, 16), Mpad, 25)) : nullptr,
+                                xparts, xn);
     }
     // pack 7: w [M][K]; pack 8: w [K][M] flipped (launch_pack's (Co, Ci) are the weight tensor's leading dimensions)
     rc = flip ? launch_pack(w, wp, 8, K, M, 25, Kpad, Mpad, s, &wpu) : launch_pack(w, wp, 7, M, K, 25, Kpad, Mpad, s, &wpu);

@@ -133,11 +133,23 @@ __device__ __forceinline__ void unit_stats(const float* stats, int norm, int n, 
     *mean = stats[2 * u]; *rstd = stats[2 * u + 1];
 }
 
+// one partial maximum per workgroup of what it stored, for an armed amax tap / link (gx_amax_tap, gx_kq_amax_link): the 5 x 5 convs
+// that read the tensor next run on fp16 pieces and need its scale; am >= 0; every thread of the workgroup calls
+__device__ __forceinline__ void gated_block_amax_out(float am, float* __restrict__ amax_parts) {
+    __shared__ float amr_[4];
+#pragma unroll
+    for (int of = 32; of >= 1; of >>= 1) am = fmaxf(am, __shfl_xor(am, of, 64));
+    if ((threadIdx.x & 63) == 0) amr_[threadIdx.x >> 6] = am;
+    __syncthreads();
+    if (threadIdx.x == 0) amax_parts[blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(amr_[0], amr_[1]), fmaxf(amr_[2], amr_[3]));
+}
+
 // out[n][c][p] = A_h * sigmoid(A_g),  A = ((y + b) - mean) * rstd * gamma + beta
 __global__ void __launch_bounds__(256)
 gated_apply_kernel(const float* __restrict__ y, const float* __restrict__ bias, const float* __restrict__ stats,
                    const float* __restrict__ gh, const float* __restrict__ bh, const float* __restrict__ gg,
-                   const float* __restrict__ bg, int N, int C, int HW, int norm, float* __restrict__ out) {
+                   const float* __restrict__ bg, int N, int C, int HW, int norm, float* __restrict__ out,
+                   float* __restrict__ amax_parts) {
     const int plane = blockIdx.x;           // n * C + c
     const int n = plane / C, c = plane % C;
     const int C2 = 2 * C;
@@ -149,11 +161,15 @@ gated_apply_kernel(const float* __restrict__ y, const float* __restrict__ bias, 
     const float* ph = y + ((size_t)n * C2 + c) * HW;
     const float* pg = y + ((size_t)n * C2 + C + c) * HW;
     float* po = out + (size_t)plane * HW;
+    float am = 0.f;
     for (int i = threadIdx.x + blockIdx.y * blockDim.x; i < HW; i += blockDim.x * gridDim.y) {
         const float ah = ((ph[i] + b_h) - mh) * rh * g_h + be_h;
         const float ag = ((pg[i] + b_g) - mg) * rg * g_g + be_g;
-        po[i] = ah * (1.f / (1.f + expf(-ag)));
+        const float o = ah * (1.f / (1.f + expf(-ag)));
+        po[i] = o;
+        am = fmaxf(am, fabsf(o));
     }
+    if (amax_parts) gated_block_amax_out(am, amax_parts);      // (uniform)
 }
 
 // Backward pass 1: per unit sums  S1 = sum dA, S2 = sum dA * xhat  (dA = gradient w.r.t. the affine-norm output).
@@ -229,7 +245,7 @@ __global__ void __launch_bounds__(256)
 gated_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ bias, const float* __restrict__ stats,
                        const float* __restrict__ gh, const float* __restrict__ bh, const float* __restrict__ gg,
                        const float* __restrict__ bg, const float* __restrict__ dout, const float* __restrict__ sums,
-                       int N, int C, int HW, int norm, float m_global, float* __restrict__ dy) {
+                       int N, int C, int HW, int norm, float m_global, float* __restrict__ dy, float* __restrict__ amax_parts) {
     const int plane = blockIdx.x;           // n * C + c
     const int n = plane / C, c = plane % C;
     const int C2 = 2 * C;
@@ -250,17 +266,21 @@ gated_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ bi
     const float* pd = dout + (size_t)plane * HW;
     float* dh = dy + ((size_t)n * C2 + c) * HW;
     float* dg = dy + ((size_t)n * C2 + C + c) * HW;
+    float am = 0.f;
     for (int i = threadIdx.x + blockIdx.y * blockDim.x; i < HW; i += blockDim.x * gridDim.y) {
         const float xh = ((ph[i] + b_h) - mh) * rh, xg = ((pg[i] + b_g) - mg) * rg;
         const float ah = xh * g_h + be_h, ag = xg * g_g + be_g;
         const float sg = 1.f / (1.f + expf(-ag));
         const float dAh = pd[i] * sg, dAg = pd[i] * ah * sg * (1.f - sg);
-        if (norm == NORM_NONE) { dh[i] = dAh; dg[i] = dAg; }
-        else {
-            dh[i] = rh * g_h * (dAh - k1h - xh * k2h);
-            dg[i] = rg * g_g * (dAg - k1g - xg * k2g);
+        float oh = dAh, og = dAg;
+        if (norm != NORM_NONE) {
+            oh = rh * g_h * (dAh - k1h - xh * k2h);
+            og = rg * g_g * (dAg - k1g - xg * k2g);
         }
+        dh[i] = oh; dg[i] = og;
+        am = fmaxf(am, fmaxf(fabsf(oh), fabsf(og)));
     }
+    if (amax_parts) gated_block_amax_out(am, amax_parts);      // (uniform)
 }
 
 // Parameter gradients from the per-unit sums: dgamma = sum S2, dbeta = sum S1 (over images for IN); the conv
@@ -325,8 +345,10 @@ int gx_gated_norm_fwd(const float* y, const float* bias, int norm, const float* 
     }
     {
         GxProf pf(KID_GATED, s, 0.0, 4.0 * N * 3.0 * C * HW);
-        hipLaunchKernelGGL(gated_apply_kernel, dim3(N * C, gx_ceil_div(HW, 1024)), dim3(256), 0, s, y, bias,
-                           (const float*)stats, gamma_h, beta_h, gamma_g, beta_g, N, C, HW, norm, out);
+        const dim3 grid(N * C, N * C >= 2048 ? 1 : gx_ceil_div(HW, 1024));      // (many planes: one workgroup each -- and one partial maximum each)
+        float* ap = gx_amax_producer_out(out, true, grid.x * grid.y, (size_t)N * C * HW);      // (out: a whole plain tensor)
+        hipLaunchKernelGGL(gated_apply_kernel, grid, dim3(256), 0, s, y, bias,
+                           (const float*)stats, gamma_h, beta_h, gamma_g, beta_g, N, C, HW, norm, out, ap);
     }
     GX_CHECK_LAUNCH("gx_gated_norm_fwd");
     return GX_OK;
@@ -373,8 +395,10 @@ int gx_gated_norm_bwd(const float* y, const float* bias, int norm, const float* 
     GX_CHECK_LAUNCH("gx_gated_norm_bwd(sums)");
     {
         GxProf pf(KID_GATED, s, 0.0, 4.0 * N * 5.0 * C * HW);
-        hipLaunchKernelGGL(gated_bwd_apply_kernel, dim3(N * C, gx_ceil_div(HW, 1024)), dim3(256), 0, s, y, bias, stats,
-                           gamma_h, beta_h, gamma_g, beta_g, dout, (const float*)sums, N, C, HW, norm, 0.f, dy);
+        const dim3 grid(N * C, N * C >= 2048 ? 1 : gx_ceil_div(HW, 1024));
+        float* ap = gx_amax_producer_out(dy, true, grid.x * grid.y, (size_t)N * 2 * C * HW);
+        hipLaunchKernelGGL(gated_bwd_apply_kernel, grid, dim3(256), 0, s, y, bias, stats,
+                           gamma_h, beta_h, gamma_g, beta_g, dout, (const float*)sums, N, C, HW, norm, 0.f, dy, ap);
     }
     GX_CHECK_LAUNCH("gx_gated_norm_bwd(apply)");
     hipLaunchKernelGGL(gated_param_kernel, dim3(gx_ceil_div(2 * C, 64)), dim3(64), 0, s, (const float*)sums, N, C, norm,
@@ -413,7 +437,7 @@ int gx_gated_bn_apply(const float* y, const float* bias, const double* sums, dou
     hipLaunchKernelGGL(gated_stats_from_sums_kernel, dim3(gx_ceil_div(2 * C, 256)), dim3(256), 0, s, sums, 2 * C, m, eps, stats);
     GxProf pf(KID_GATED, s, 0.0, 4.0 * N * 3.0 * C * HW);
     hipLaunchKernelGGL(gated_apply_kernel, dim3(N * C, gx_ceil_div(HW, 1024)), dim3(256), 0, s, y, bias, (const float*)stats,
-                       gamma_h, beta_h, gamma_g, beta_g, N, C, HW, (int)NORM_BN, out);
+                       gamma_h, beta_h, gamma_g, beta_g, N, C, HW, (int)NORM_BN, out, (float*)nullptr);
     GX_CHECK_LAUNCH("gx_gated_bn_apply");
     return GX_OK;
 }
@@ -452,7 +476,7 @@ int gx_gated_bn_bwd_apply(const float* y, const float* bias, const float* gamma_
     const int HW = H * W;
     GxProf pf(KID_GATED, s, 0.0, 4.0 * N * 5.0 * C * HW);
     hipLaunchKernelGGL(gated_bwd_apply_kernel, dim3(N * C, gx_ceil_div(HW, 1024)), dim3(256), 0, s, y, bias, stats, gamma_h,
-                       beta_h, gamma_g, beta_g, dout, sums, N, C, HW, (int)NORM_BN, (float)m, dy);
+                       beta_h, gamma_g, beta_g, dout, sums, N, C, HW, (int)NORM_BN, (float)m, dy, (float*)nullptr);
     GX_CHECK_LAUNCH("gx_gated_bn_bwd_apply");
     return GX_OK;
 }

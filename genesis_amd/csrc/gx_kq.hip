@@ -1120,6 +1120,20 @@ int gx_kq_weight_amax_launch(const float* w, int n, float* out, hipStream_t s) {
     GX_CHECK_LAUNCH("kq weight amax");
     return GX_OK;
 }
+// a producer that left THOUSANDS of partial maxima (one per workgroup of a gated unit's or a generic GroupNorm kernel's grid): one
+// small launch folds them into one value -- every workgroup of the conv reducing them all costs more (measured: kq_c5h 147 -> 160 us
+// per launch at 10 240 partials, kq_dgh 873 -> 911 us at 11 264) than this launch does (~4 us)
+constexpr int kFoldPartsAbove = 1024;
+static int kq_fold_parts(const float** parts, int* n, float* amax_ws, hipStream_t s) {
+    if (!*parts || *n <= kFoldPartsAbove || !amax_ws) return GX_OK;
+    {
+        GxProf pf(KID_SMALL_REDUCE, s, 0.0, 4.0 * *n);
+        hipLaunchKernelGGL(weight_amax_kernel, dim3(1), dim3(1024), 0, s, *parts, *n, amax_ws);
+    }
+    GX_CHECK_LAUNCH("kq amax fold");
+    *parts = amax_ws; *n = 1;
+    return GX_OK;
+}
 size_t gx_kq_deconv_h_pack_bytes(int K, int M, int nt) {     // one row parity's packed weights (+ slack: whole-phase copies)
     return (size_t)gx_ceil_div(M, 64) * (K / 16) * nt * QH_TAP_BYTES + 16384;
 }
@@ -1158,6 +1172,7 @@ int gx_kq_deconv_fwd_h_launch(const float* in, const float* wp0, const float* wp
         if (stats_parts) *stats_parts = g.stats_parts;
     }
     if (amax_ws && !x_parts) { const int rc = gx_kq_amax_launch(in, (size_t)N * K * Hb * Wb, amax_ws, s); if (rc) return rc; }
+    else if (amax_ws) { const int rc = kq_fold_parts(&x_parts, &x_nparts, amax_ws, s); if (rc) return rc; }
     dim3 grid(1, gx_ceil_div(M, 64), 2);
     g.nfull = q_split_tail(g.tiles_h * g.tiles_w * gx_ceil_div(N, 1 << g.lG), M, &grid.x);
     static const char* ilv_env = getenv("GENESIS_KQ_DTH_INTERLEAVE");       // 0: all 15-tap workgroups, then all 10-tap ones (grid.z)
@@ -1270,20 +1285,23 @@ bool gx_kq_c5h_eligible(int N, int K, int M, int H, int W) {
     return kq_mode() == 2 || (long)g.nfull * gx_ceil_div(M, 64) >= min_wgs;
 }
 int gx_kq_c5h_launch(const float* in, const float* wp, float* out, int N, int K, int M, int H, int W, hipStream_t s,
-                     float* amax_ws, const float* w_amax) {
+                     float* amax_ws, const float* w_amax, const float* x_parts, int x_nparts) {
     QGeom g; size_t lds;
     if (!q_plan_c5h(N, K, M, H, W, &g, &lds)) { gx_set_error("kq conv5x5 (bf16 pipe): shape not eligible"); return GX_EINVAL; }
     if (amax_ws) {
         constexpr int NWF = (3 * (QHLay<Q_C5H, true>::TAPB / 16) + 255) / 256;
         lds = (size_t)2 * 2 * (20 * 20) * 16 + (size_t)2 * NWF * 256 * 16;
-        const int rc = gx_kq_amax_launch(in, (size_t)N * K * H * W, amax_ws, s); if (rc) return rc;
+        // (x_parts: the input's partial maxima from the kernel that wrote it -- no pass of our own)
+        if (!x_parts) { const int rc = gx_kq_amax_launch(in, (size_t)N * K * H * W, amax_ws, s); if (rc) return rc; }
+        else { const int rc = kq_fold_parts(&x_parts, &x_nparts, amax_ws, s); if (rc) return rc; }
     }
     dim3 grid(g.nfull, gx_ceil_div(M, 64));
     {
         GxProf pf(KID_KQ_C5H, s, 2.0 * N * (double)M * K * 25 * H * W, 4.0 * ((double)N * K * H * W + (double)N * M * H * W + 25.0 * K * M));
         static bool a4 = false, f4 = false;
         if (amax_ws) {          // fp16 x 3 (packs 47 / 48)
-            g.x_amax = amax_ws; g.w_amax = w_amax;
+            g.x_amax = x_parts ? x_parts : amax_ws; g.w_amax = w_amax;
+            if (x_parts) g.x_amax_n = x_nparts;
             q_set_attr(&kq_c5h_kernel<4, true>, &f4);
             hipLaunchKernelGGL((kq_c5h_kernel<4, true>), grid, dim3(256), lds, s, in, wp, out, g);
         } else {
@@ -1308,6 +1326,7 @@ int gx_kq_deconv_dgrad_h_launch(const float* dy, const float* wp, float* dx, int
     }
     lds = qh_lds(g, nq, amax_ws != nullptr);
     if (amax_ws && !x_parts) { const int rc = gx_kq_amax_launch(dy, (size_t)N * K * 4 * Hb * Wb, amax_ws, s); if (rc) return rc; }
+    else if (amax_ws) { const int rc = kq_fold_parts(&x_parts, &x_nparts, amax_ws, s); if (rc) return rc; }
     dim3 grid(1, gx_ceil_div(M, 64));
     g.nfull = q_split_tail(g.tiles_h * g.tiles_w * gx_ceil_div(N, 1 << g.lG), M, &grid.x);
     {

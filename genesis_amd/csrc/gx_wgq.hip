@@ -1251,6 +1251,8 @@ wgq_stream_kernel(const WsTable tab, const float* __restrict__ zeros) {
             GX_WF_CASE(18, WQ_C3, 64) GX_WF_CASE(19, WQ_C3, 32) GX_WF_CASE(20, WQ_DR0, 32) GX_WF_CASE(21, WQ_DR1, 32)
             GX_WF_CASE(26, WQ_C3, 16) GX_WF_CASE(27, WQ_DR0, 16) GX_WF_CASE(28, WQ_DR1, 16)
             GX_WF_CASE(29, WQ_C3, 128) GX_WF_CASE(30, WQ_DR0, 64) GX_WF_CASE(31, WQ_DR1, 64)
+            GX_WF_CASE(22, WQ_C5A, 64) GX_WF_CASE(23, WQ_C5A, 32) GX_WF_CASE(24, WQ_C5B, 64) GX_WF_CASE(25, WQ_C5B, 32)
+            GX_WF_CASE(32, WQ_C5A, 16) GX_WF_CASE(33, WQ_C5B, 16)
             default: break;
         }
 #undef GX_WS_CASE
@@ -1332,8 +1334,11 @@ bool wgq_f16() {
 // units per fp16-piece tile by row-ring variant 18 .. 28 (0: the variant has no fp16 form), re-fitted with GENESIS_WGQ_TIMES on the
 // metric step next to the bf16 / LDS-DMA variants of the same launch: 64 - 78 % of the bf16 tile (the 10-tap row parity gains
 // least: its split / staging work per tile is that of the 15-tap one).  GENESIS_WGQ_F16_COST="c18,c19,c20,c21,c26,c27,c28" overrides
-int g_ws_cost_f16[14] = {3040, 1760, 2650, 2315, 0, 0, 0, 0, 1870, 2700, 2380,
-                         3200, 2750, 2150};           // ... one strip per tile (the 128 x 128 model's large layers): first estimates
+int g_ws_cost_f16[16] = {3040, 1760, 2650, 2315,
+                         5300, 2700, 3560, 1850,      // ... of the 5 x 5 stride-1 conv (the gated stacks): 0.66 x the bf16 tile, estimates
+                         1870, 2700, 2380,
+                         3200, 2750, 2150,            // ... one strip per tile (the 128 x 128 model's large layers): first estimates
+                         2700, 1850};                 // ... 5 x 5, two 16-pixel rows per tile: estimates
 bool g_ws_cost_f16_init = false;
 int ws_f16cost(int rv) {
     if (!g_ws_cost_f16_init) {
@@ -1348,7 +1353,7 @@ int ws_f16cost(int rv) {
     }
     return g_ws_cost_f16[rv - 18];
 }
-bool ws_f16_variant(int rv) { return (rv >= 18 && rv <= 21) || (rv >= 26 && rv <= 31); }
+bool ws_f16_variant(int rv) { return rv >= 18 && rv <= 33; }
 
 // which matrix pipe the weight gradients run on: 1 (default) bf16 pipe, fp32 products from six bf16 piece products
 // (wq_tile_b6); 0 the fp32 pipe.  GENESIS_WGQ_BF16X6=0 / gx_wgq_precision(0) select the latter.

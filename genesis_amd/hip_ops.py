@@ -90,6 +90,7 @@ def take_amax():
 
 
 def _tap_begin(device, hw, numel):
+    # (hw: the plane size of a GroupNorm launch; the gated units' kernels tap at any size and pass 1 << 30)
     if not WGQ_F16 or hw < 256:      # (the register-resident GroupNorm kernels -- the only producers -- start at 16 x 16 planes)
         _LAST_AMAX[0] = None
         return None
@@ -947,7 +948,7 @@ def conv5x5_wgrad_supported(N, CA, CB, H, W):
     return bool(_lib.query('gx_conv5x5_wgrad_supported', N, CA, CB, H, W))
 
 
-def conv5x5_wgrad(a, b, out=None):
+def conv5x5_wgrad(a, b, out=None, amax=None):
     """dw [CA][CB][5][5] = sum_{n,p} a[n][CA][p] * b[n][CB][p + (kh - 2, kw - 2)] (5x5, stride 1, pad 2): Conv2d with
     (a, b) = (dy, x), stride-1 ConvTranspose2d with (a, b) = (x, dy); bf16-pipe row-ring tiles (gx_conv5x5_wgrad)."""
     _chk(a, 'conv5x5_wgrad.a'); _chk(b, 'conv5x5_wgrad.b')
@@ -958,7 +959,7 @@ def conv5x5_wgrad(a, b, out=None):
     assert dw.shape == (CA, CB, 5, 5) and dw.is_contiguous()
     nb = _lib.query('gx_conv5x5_wgrad_ws_bytes', N, CA, CB, H, W)
     ws = _ws(nb, a.device)
-    with _deferring(out is not None, ws, a, b):
+    with _deferring(out is not None, ws, a, b), _operand_amax(a.device, amax):       # amax = (a's Amax, b's Amax)
         _lib.call('gx_conv5x5_wgrad', _p(a), _p(b), _p(dw), N, CA, CB, H, W, _p(ws), nb, _stream())
     return dw
 
@@ -994,6 +995,9 @@ def mixture_w_bwd(x, dec, log_w, g_err, K, std1, std2, pixel_bound=True):
 NORMS = {None: 0, 'none': 0, 'bn': 1, 'in': 2}
 
 
+GATED_AMAX = os.environ.get('GENESIS_GATED_AMAX', '1') != '0'       # 0: the convs behind the gated units make their own amax passes
+
+
 def gated_norm_fwd(y, bias, norm, gh, bh, gg, bg, eps=1e-5):
     """out = norm_h(h + b_h) * sigmoid(norm_g(g + b_g)) for y = [h | g] (third_party/sylvester/layers.py:40-54)."""
     _chk(y, 'gated.y'); _chk(bias, 'gated.bias')
@@ -1001,8 +1005,13 @@ def gated_norm_fwd(y, bias, norm, gh, bh, gg, bg, eps=1e-5):
     C = C2 // 2
     out = torch.empty(N, C, H, W, dtype=F32, device=y.device)
     stats = torch.empty(max(_lib.query('gx_gated_stats_floats', NORMS[norm], N, C), 2), dtype=F32, device=y.device)
+    # the unit's output feeds a 5 x 5 conv on fp16 pieces (gx_conv5x5s1 / gx_deconv5x5s2_*) and that layer's weight gradient: its
+    # partial maxima come out of the apply kernel (link: the next conv; tap: take_amax() for the weight gradient) -- no amax pass
+    tap = _tap_begin(y.device, 1 << 30, out.numel()) if GATED_AMAX else None
+    link = amax_link(y.device, out.numel()) if GATED_AMAX else None       # noqa: F841
     _lib.call('gx_gated_norm_fwd', _p(y), _p(bias), NORMS[norm], _p(gh), _p(bh), _p(gg), _p(bg), N, C, H, W,
               float(eps), _p(out), _p(stats), _stream())
+    _tap_end(tap)
     return out, stats
 
 
@@ -1048,8 +1057,11 @@ def gated_norm_bwd(y, bias, norm, gh, bh, gg, bg, stats, dout, out=None):
         _chk(t, 'gated_bwd.out')
     nb = _lib.query('gx_gated_norm_bwd_ws_bytes', NORMS[norm], N, C)
     ws = _ws(nb, dev)
+    tap = _tap_begin(dev, 1 << 30, dy.numel()) if GATED_AMAX else None       # (dy feeds the conv's data gradient and its weight gradient)
+    link = amax_link(dev, dy.numel()) if GATED_AMAX else None       # noqa: F841
     _lib.call('gx_gated_norm_bwd', _p(y), _p(bias), NORMS[norm], _p(gh), _p(bh), _p(gg), _p(bg), _p(stats), _p(dout),
               N, C, H, W, _p(dy), _p(dgh), _p(dbh), _p(dgg), _p(dbg), _p(dbias), _p(ws), nb, _stream())
+    _tap_end(tap)
     return dy, dgh, dbh, dgg, dbg, dbias
 
 

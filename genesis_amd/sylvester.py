@@ -183,6 +183,7 @@ class DirectConvFn(torch.autograd.Function):
         ctx.save_for_backward(x)
         ctx.w = w
         ctx.cfg = (kind, stride, pad, k, fast, s1)
+        ctx.am_x = getattr(x, '_gx_amax', None)      # (partial maxima of the input, left by the gated unit that produced it)
         return y
 
     @staticmethod
@@ -190,26 +191,29 @@ class DirectConvFn(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         w = ctx.w
         kind, stride, pad, k, fast, s1 = ctx.cfg
+        am_g, am_x = getattr(g, '_gx_amax', None), ctx.am_x       # (the gated unit's backward left its dy's partial maxima on it)
         g = g.contiguous()
         ow = _gout(w)
         need_dx = ctx.needs_input_grad[0]
+        # (weight gradients: both operands' maxima known -> three fp16 piece products instead of six bf16 ones; the data
+        #  gradients below find g's maxima through the link the gated unit's backward armed)
         if fast and kind == 'conv':
             # conv s2 = the transposed conv's data gradient with (x, dy) in each other's roles
-            dw = hip.deconv5x5s2_wgrad(g, x, out=ow)
+            dw = hip.deconv5x5s2_wgrad(g, x, out=ow, amax=(am_x, am_g))
             dx = hip.deconv5x5s2_fwd(g, w, None) if need_dx else None
         elif fast:
-            dw = hip.deconv5x5s2_wgrad(x, g, out=ow)
+            dw = hip.deconv5x5s2_wgrad(x, g, out=ow, amax=(am_g, am_x))
             dx = hip.deconv5x5s2_dgrad(g, w) if need_dx else None
         elif kind == 'conv':
             if k == 5 and stride == 1 and pad == 2 and hip.conv5x5_wgrad_supported(x.shape[0], w.shape[0], w.shape[1], *x.shape[2:]):
-                dw = hip.conv5x5_wgrad(g, x, out=ow)          # bf16-pipe row-ring tiles, in the step's stream-K launch
+                dw = hip.conv5x5_wgrad(g, x, out=ow, amax=(am_g, am_x))          # row-ring tiles, in the step's stream-K launch
             else:
                 dw = hip.conv2d_direct_wgrad(x, g, k, stride, pad, out=ow)
             dx = (hip.conv5x5s1(g, w, x.shape[1], True) if s1 else
                   hip.conv2d_direct_dgrad(g, w, x.shape[2], x.shape[3], stride, pad)) if need_dx else None
         else:
             if k == 5 and stride == 1 and pad == 2 and hip.conv5x5_wgrad_supported(x.shape[0], w.shape[0], w.shape[1], *x.shape[2:]):
-                dw = hip.conv5x5_wgrad(x, g, out=ow)
+                dw = hip.conv5x5_wgrad(x, g, out=ow, amax=(am_x, am_g))
             else:
                 dw = hip.conv2d_direct_wgrad(g, x, k, stride, pad, out=ow)
             dx = (hip.conv5x5s1(g, w, x.shape[1], False) if s1 else
@@ -287,6 +291,7 @@ class GatedNormFn(torch.autograd.Function):
             out, stats, ctx.m_global = hip.gated_bn_sync_fwd(y, bias, gh, bh, gg, bg, lambda t: _all_reduce_sum(t, (1,) + tuple(y.shape)), _world())
         else:
             out, stats = hip.gated_norm_fwd(y, bias, norm, gh, bh, gg, bg)
+            out._gx_amax = hip.take_amax()
         ctx.save_for_backward(y, stats)
         ctx.params = (bias, gh, bh, gg, bg)
         ctx.norm = norm
@@ -304,5 +309,6 @@ class GatedNormFn(torch.autograd.Function):
                                                                   lambda t: _all_reduce_sum(t, (2,) + tuple(y.shape)), out=outs)
         else:
             dy, dgh, dbh, dgg, dbg, dbias = hip.gated_norm_bwd(y, bias, ctx.norm, gh, bh, gg, bg, stats, g.contiguous(), out=outs)
+            dy._gx_amax = hip.take_amax()
         return (dy, _ret(outs[4], dbias), None, _ret(outs[0], dgh), _ret(outs[1], dbh), _ret(outs[2], dgg),
                 _ret(outs[3], dbg))
