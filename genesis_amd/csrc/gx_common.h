@@ -150,6 +150,7 @@ __host__ __device__ __forceinline__ size_t gx_wino_h_bytes(int Kpad16, int Mpad)
     return (size_t)(Mpad >> 6) * (Kpad16 >> 4) * 16 * 6144;
 }
 bool gx_wino_h_on();     // Winograd layers on the bf16 pipe (default; gx_wino_precision(0) / GENESIS_WINO_BF16X6=0: fp32 pipe)
+bool gx_conv_input_hint(const float** p0, int* n0, const float** p1, int* n1);      // the armed gx_conv_input_amax hint (gx_wino.hip), not cleared
 bool gx_wino_f16_pending(void);   // ... and the NEXT launch of this thread on two fp16 pieces per operand (gx_conv_input_amax armed): pack kinds 45 / 46
 // conv with an already packed U (16 * Kpad * Mpad floats; bf16 pipe: gx_wino_h_bytes): out[N,M,H,W] from in[N,K,H,W]
 bool gx_wino_eligible(int N, int K, int M, int H, int W);

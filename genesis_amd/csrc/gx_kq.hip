@@ -1124,6 +1124,38 @@ int gx_kq_weight_amax_launch(const float* w, int n, float* out, hipStream_t s) {
 // small launch folds them into one value -- every workgroup of the conv reducing them all costs more (measured: kq_c5h 147 -> 160 us
 // per launch at 10 240 partials, kq_dgh 873 -> 911 us at 11 264) than this launch does (~4 us)
 constexpr int kFoldPartsAbove = 1024;
+__global__ void __launch_bounds__(1024)
+amax_fold2_kernel(const float* __restrict__ p0, int n0, const float* __restrict__ p1, int n1, float* __restrict__ out) {
+    __shared__ float red[16];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n0; i += 1024) m = fmaxf(m, p0[i]);
+    for (int i = threadIdx.x; i < n1; i += 1024) m = fmaxf(m, p1[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float r = red[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) r = fmaxf(r, red[i]);
+        out[0] = r;
+    }
+}
+// the armed gx_conv_input_amax hint (one tensor, or the two halves of a concat buffer) as ONE partial-maxima array for a kernel of this
+// file: a single short array as it is, anything else folded into amax_ws[0]
+static int kq_hint_parts(const float** parts, int* n, float* amax_ws, hipStream_t s) {
+    const float *p0, *p1; int n0, n1;
+    *parts = nullptr; *n = 0;
+    if (!amax_ws || !gx_conv_input_hint(&p0, &n0, &p1, &n1)) return GX_OK;
+    if (!p1 && n0 <= kFoldPartsAbove) { *parts = p0; *n = n0; return GX_OK; }
+    {
+        GxProf pf(KID_SMALL_REDUCE, s, 0.0, 4.0 * (n0 + n1));
+        hipLaunchKernelGGL(amax_fold2_kernel, dim3(1), dim3(1024), 0, s, p0, n0, p1, p1 ? n1 : 0, amax_ws);
+    }
+    GX_CHECK_LAUNCH("kq amax fold (hint)");
+    *parts = amax_ws; *n = 1;
+    return GX_OK;
+}
 static int kq_fold_parts(const float** parts, int* n, float* amax_ws, hipStream_t s) {
     if (!*parts || *n <= kFoldPartsAbove || !amax_ws) return GX_OK;
     {
@@ -1235,12 +1267,15 @@ bool gx_kq_c3h_eligible(int N, int K, int M, int H, int W) {
 int gx_kq_c3h_launch(const float* in, const float* wp, const float* bias, int act, float* out, int N, int K, int M, int H,
                      int W, hipStream_t s, const float* mask, int mask_act, float* amax_ws, const float* w_amax) {
     QGeom g; int nq; size_t lds;
+    const float* x_parts = nullptr; int x_nparts = 0;
     if (!q_plan_c3h(N, K, M, H, W, &g, &nq, &lds)) { gx_set_error("kq conv3x3 (bf16 pipe): shape not eligible"); return GX_EINVAL; }
     g.act = act; g.mask = mask; g.mask_act = mask_act;
     if (amax_ws) {
         constexpr int NWF = (3 * (QHLay<Q_C3H, true>::TAPB / 16) + 255) / 256;
         lds = (size_t)2 * nq * 256 * 16 + (size_t)NWF * 256 * 16;          // two input piece planes + one two-piece weight buffer
-        const int rc = gx_kq_amax_launch(in, (size_t)N * K * H * W, amax_ws, s); if (rc) return rc;
+        // the input's partial maxima handed in by the caller (gx_conv_input_amax: the norm kernel that wrote it), else a pass of our own
+        int rc = kq_hint_parts(&x_parts, &x_nparts, amax_ws, s); if (rc) return rc;
+        if (!x_parts) { rc = gx_kq_amax_launch(in, (size_t)N * K * H * W, amax_ws, s); if (rc) return rc; }
     }
     dim3 grid(g.tiles_h * g.tiles_w * gx_ceil_div(N, 1 << g.lG), gx_ceil_div(M, 32));
     g.nfull = (int)grid.x;                               // tiles; the workgroups loop over them (kq_c3h_kernel)
@@ -1252,7 +1287,8 @@ int gx_kq_c3h_launch(const float* in, const float* wp, const float* bias, int ac
                   4.0 * ((double)N * K * H * W + (double)N * M * H * W + 9.0 * K * M));
         static bool a3 = false, a4 = false, f3 = false, f4 = false;
         if (amax_ws) {          // fp16 x 3 (packs 40 / 41)
-            g.x_amax = amax_ws; g.w_amax = w_amax;
+            g.x_amax = x_parts ? x_parts : amax_ws; g.w_amax = w_amax;
+            if (x_parts) g.x_amax_n = x_nparts;
             if (nq == 3) { q_set_attr(&kq_c3h_kernel<3, true>, &f3); hipLaunchKernelGGL((kq_c3h_kernel<3, true>), grid, dim3(256), lds, s, in, wp, bias, out, g); }
             else { q_set_attr(&kq_c3h_kernel<4, true>, &f4); hipLaunchKernelGGL((kq_c3h_kernel<4, true>), grid, dim3(256), lds, s, in, wp, bias, out, g); }
         } else

@@ -1337,7 +1337,8 @@ bool wgq_f16() {
 int g_ws_cost_f16[16] = {3040, 1760, 2650, 2315,
                          5300, 2700, 3560, 1850,      // ... of the 5 x 5 stride-1 conv (the gated stacks): 0.66 x the bf16 tile, estimates
                          1870, 2700, 2380,
-                         3200, 2750, 2150,            // ... one strip per tile (the 128 x 128 model's large layers): first estimates
+                         3200, 2750, 2450,            // ... one strip per tile (the 128 x 128 model's large layers; fitted on the K = 11 step:
+                                                      //     workgroups of the 10-tap parity ran 15 % over the others at 2150)
                          2700, 1850};                 // ... 5 x 5, two 16-pixel rows per tile: estimates
 bool g_ws_cost_f16_init = false;
 int ws_f16cost(int rv) {

@@ -780,7 +780,17 @@ static bool wino_f16_on() {
 }
 namespace { struct WinoHint { const float* p0; const float* p1; int n0, n1; }; thread_local WinoHint t_wino_hint = {nullptr, nullptr, 0, 0}; }
 // true: the NEXT Winograd launch of this thread runs on fp16 pieces (the caller packs kinds 45 / 46 for it)
-bool gx_wino_f16_pending(void) { return wino_f16_on() && t_wino_hint.p0 && t_wino_hint.n0 > 0; }
+// (every workgroup of the Winograd kernel reduces the partial maxima itself: worth it up to ~1500 of them -- GroupNorm(8) at any batch
+//  of this workload has N x 8, the 128 x 128 model's pair data gradient 1280; InstanceNorm -- MONet's UNet, one partial per (image,
+//  channel) -- has up to 8192: measured 14.7 against 12.2 us per launch on its layers, so those stay on bf16 pieces)
+constexpr int kWinoAmaxMax = 1536;
+bool gx_wino_f16_pending(void) { return wino_f16_on() && t_wino_hint.p0 && t_wino_hint.n0 > 0 && t_wino_hint.n0 + t_wino_hint.n1 <= kWinoAmaxMax; }
+// the armed hint, for the other fp16-piece conv3x3 kernel (gx_kq.hip Q_C3H: <= 32 output channels); not cleared (the caller disarms)
+bool gx_conv_input_hint(const float** p0, int* n0, const float** p1, int* n1) {
+    if (!t_wino_hint.p0 || t_wino_hint.n0 <= 0) return false;
+    *p0 = t_wino_hint.p0; *n0 = t_wino_hint.n0; *p1 = t_wino_hint.p1; *n1 = t_wino_hint.n1;
+    return true;
+}
 extern "C" double gx_wino_f16_share(void) { return g_wino_flops_all > 0.0 ? g_wino_flops_f16 / g_wino_flops_all : 0.0; }
 extern "C" int gx_conv_input_amax(const float* p0, int n0, const float* p1, int n1) {
     t_wino_hint.p0 = (p0 && n0 > 0) ? p0 : nullptr; t_wino_hint.n0 = t_wino_hint.p0 ? n0 : 0;

@@ -151,7 +151,6 @@ class _operand_amax(object):
 
 WINO_F16 = os.environ.get('GENESIS_WINO_F16X3', '1') != '0'
 _AMAX_DEBUG = os.environ.get('GENESIS_AMAX_DEBUG') == '1'      # prints the partial-maxima counts every conv3x3 call was handed
-_WINO_AMAX_MAX = 1536       # (1280: the 128 x 128 model's pair data gradient -- 1024 partials of the chunked head backward + 256)
 
 
 class _input_amax(object):
@@ -173,11 +172,8 @@ class _input_amax(object):
                                                      ' / '.join('%s:%d' % (f.name, f.lineno) for f in traceback.extract_stack()[-4:-1])), flush=True)
         if not hs or len(hs) > 2 or any(h is None for h in hs):
             return
-        # every workgroup of the conv reduces the partial maxima itself: worth it up to ~1000 of them (GroupNorm(8) at any batch of
-        # this workload: N x 8; InstanceNorm -- MONet's UNet, one partial per (image, channel) -- has up to 8192: measured 14.7
-        # against 12.2 us per launch on its layers, so those stay on bf16 pieces)
-        if sum(h.n for h in hs) > _WINO_AMAX_MAX:
-            return
+        # (how many partial maxima a kernel takes is the library's decision: the Winograd kernel up to 1536 -- its workgroups reduce
+        #  them themselves --, the <= 32-output-channel kernel any number, folded by one small launch)
         hs = hs + [None] * (2 - len(hs))
         self.args = [ctypes.c_void_p(hs[0].ptr), hs[0].n, ctypes.c_void_p(hs[1].ptr) if hs[1] is not None else None,
                      hs[1].n if hs[1] is not None else 0]
