@@ -116,13 +116,16 @@ int gx_kq_precision(int mode);
  *      gx_gn_relu_bwd_parts and the decoder head's backward behind gx_gn_relu_bwd_proj: models/genesisv2_config.py:90-99) writes one partial maximum of the gradient it stores
  *      per workgroup into `parts` (<= capacity floats) -- only a launch that covers all `numel` elements of the tensor: a chunked
  *      producer leaves the link alone -- and remembers that tensor's address; the next mode-2 conv call whose input IS
- *      that address and size (gx_deconv5x5s2_fwd* / gx_deconv5x5s2_dgrad) reduces those partials instead of launching its own pass.  Any mode-2 conv call clears
+ *      that address and size (gx_deconv5x5s2_fwd* / gx_deconv5x5s2_dgrad / gx_conv5x5s1) reduces those partials instead of launching its own
+ *      pass (more than 1024 of them: one small launch folds them first).  Producers: the GroupNorm + ReLU kernels (every form since
+ *      round 6, the chunked decoder-head backward's apply kernel included) and the gated units' apply kernels (gx_gated_norm_fwd: out;
+ *      gx_gated_norm_bwd: dy).  Any mode-2 conv call clears
  *      the link; results are bit-identical with and without it.  gx_kq_amax_link_hits(): hand-overs taken so far (this thread). */
 int gx_kq_amax_link(float* parts, int capacity, size_t numel);
 int gx_kq_amax_link_hits(void);
 /*      The same partial maxima for a LATER reader (the weight gradients' stream-K launch at the end of the backward pass,
  *      gx_wgq_operand_amax below): gx_amax_tap(parts, capacity, numel) arms a one-shot, per-thread request -- the next producer launch
- *      that supports it (the register-resident GroupNorm + ReLU kernels, forward and backward) writes one partial maximum of the
+ *      that supports it (the GroupNorm + ReLU kernels, forward and backward; the gated units' apply kernels) writes one partial maximum of the
  *      values it stores per workgroup into parts[0 .. n) -- provided it stores exactly `numel` values: a chunked producer does not
  *      serve -- whatever its destination views are (the channel slice of a concat
  *      buffer and a resampled second copy hold the same values); gx_amax_tap_result() returns n (0: that launch could not
@@ -135,7 +138,10 @@ int gx_amax_tap(float* parts, int capacity, size_t numel);
  *      concat buffer written by two producers, or the pair data gradient's second tensor).  With it -- and gx_wino_precision(2),
  *      the default; GENESIS_WINO_F16X3=0: mode 1 -- a layer that takes the Winograd kernel forms every fp32 product from THREE
  *      fp16 piece products (U * 2^eU packed as two pieces, eU from max |w|; V * 2^eV split in registers, eV from 4 max |x|)
- *      instead of six bf16 ones; layers on other kernels ignore it.  NULL / 0 clears.  Same range note as gx_wgq_operand_amax. */
+ *      instead of six bf16 ones -- up to 1536 partial maxima (every workgroup of that kernel reduces them itself; more: six bf16
+ *      pieces).  A layer with <= 32 output channels (gx_kq.hip, mode 2 of gx_kq_precision) reads its input's scale from the same
+ *      hint instead of making its own amax pass, any count.  Layers on other kernels ignore it.  NULL / 0 clears.  Same range note
+ *      as gx_wgq_operand_amax. */
 int gx_conv_input_amax(const float* p0, int n0, const float* p1, int n1);
 /*      Measurement: the share of the bf16-pipe Winograd launches' algorithmic flops (since the process started) on fp16 pieces. */
 double gx_wino_f16_share(void);
