@@ -46,6 +46,25 @@ def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
+# GENESIS_POISON=1 (diagnosis; tools/diag_poison.py, tests/test_poison_gpu.py): every tensor allocated with torch.empty / empty_like
+# from here on -- outputs, workspaces, scratch -- starts as NaN, so a kernel that reads memory nobody wrote shows up in the results
+# instead of depending on what the allocator happened to hand out.
+if os.environ.get('GENESIS_POISON') == '1' and not getattr(torch, '_gx_poisoned', False):
+    _real_empty, _real_empty_like = torch.empty, torch.empty_like
+
+    def _poison(t):
+        if t.is_cuda and t.numel():
+            if t.is_floating_point():
+                t.fill_(float('nan'))
+            elif t.dtype == torch.uint8:
+                t.fill_(0xFF)          # (read as floats: NaN)
+        return t
+
+    torch.empty = lambda *a, **k: _poison(_real_empty(*a, **k))
+    torch.empty_like = lambda *a, **k: _poison(_real_empty_like(*a, **k))
+    torch._gx_poisoned = True
+
+
 # ---- the operands' largest magnitudes for the fp16-piece weight gradients (gx_wgq_operand_amax, include/genesis_hip.h) ----------
 # The stream-K weight-gradient launch at the end of a backward pass forms fp32 products from three fp16 piece products where it
 # knows max |x| and max |dy| of a layer -- from the GroupNorm kernels that WROTE those tensors (gx_amax_tap: one partial maximum per
