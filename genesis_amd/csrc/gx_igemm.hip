@@ -365,10 +365,44 @@ conv3x3s2_wgrad_small_kernel(const float* __restrict__ x, const float* __restric
                 const bool ok = (kh > 0 || i > 0) && (kw > 0 || j > 0);                  // row 2i - 1 / col 2j - 1 exist
                 xw[kh * 3 + kw] = ok ? xp[(kh - 1) * W + (kw - 1)] : 0.f;
             }
+#if defined(GX_DIAG_NO_OVERLAP)     /* diagnosis (tools/diag_shared_gpu2.py, DESIGN.md finding 48): the (2i+1, 2j..2j+1) pair through an explicit load.
+                                       1: destination cannot be the address pair, waited for at once; 2: destination IS the address pair, waited
+                                       for at once; 3: IS the address pair, waited for after the dy loads; 4: cannot be, waited for after them */
+        unsigned long long gx_u = reinterpret_cast<unsigned long long>(xp + W);
+        typedef float gx_f2 __attribute__((ext_vector_type(2)));
+        gx_f2 gx_pr = {0.f, 0.f};
+#if GX_DIAG_NO_OVERLAP == 1
+        asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(gx_pr) : "v"(gx_u) : "memory");
+#elif GX_DIAG_NO_OVERLAP == 2
+        asm volatile("global_load_dwordx2 %0, %0, off\n\ts_waitcnt vmcnt(0)" : "+v"(gx_u) : : "memory");
+#elif GX_DIAG_NO_OVERLAP == 3
+        asm volatile("global_load_dwordx2 %0, %0, off" : "+v"(gx_u) : : "memory");
+#else
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(gx_pr) : "v"(gx_u) : "memory");
+#endif
+#endif
         const float* dp = dy + ((size_t)n * Cout + co0) * HoWo + r;
+#if defined(GX_DIAG_NO_OVERLAP)
+        float gx_d[COB];
+#pragma unroll
+        for (int c = 0; c < COB; ++c) gx_d[c] = co0 + c < Cout ? dp[(size_t)c * HoWo] : 0.f;
+#if GX_DIAG_NO_OVERLAP == 3
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(gx_u) : : "memory");
+#elif GX_DIAG_NO_OVERLAP == 4
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(gx_pr) : : "memory");
+#endif
+#if GX_DIAG_NO_OVERLAP == 2 || GX_DIAG_NO_OVERLAP == 3
+        gx_pr[0] = __builtin_bit_cast(float, (unsigned)(gx_u & 0xffffffffu)); gx_pr[1] = __builtin_bit_cast(float, (unsigned)(gx_u >> 32));
+#endif
+        xw[7] = gx_pr[0]; xw[8] = gx_pr[1];
+#endif
 #pragma unroll
         for (int c = 0; c < COB; ++c) {
+#if defined(GX_DIAG_NO_OVERLAP)
+            const float d = gx_d[c];
+#else
             const float d = co0 + c < Cout ? dp[(size_t)c * HoWo] : 0.f;
+#endif
 #pragma unroll
             for (int t = 0; t < 9; ++t) acc[c][t] += d * xw[t];
         }
