@@ -285,18 +285,11 @@ def _worker_genesis_syncbn(rank, world, port, out_dir):
         g = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().cpu()
         dist.all_reduce(g)
         grads[n] = (g / world).to(p.device)
-    # (GENESIS has no ReLU: the strict bar.)  OPEN ISSUE, DESIGN.md section 6: two GENESIS processes that share ONE GPU and meet at
-    # a host-side barrier inside their passes -- which is what this rehearsal's gloo exchange is -- show a run-to-run variation of
-    # 1e-3 .. 1e-2 in a handful of parameter gradients in some launches (also with a dummy exchange that carries no data, never
-    # without the barriers, never in one process: tools/diag_two_proc.py); the forward pass above, the ELBO and the training
-    # trajectory below reproduce the reference in every launch.  The gradient verdict is therefore handed to the parent, which
-    # accepts the first of a few launches that meets the bar and reports all of them.
-    grad_ok, grad_msg = True, ''
+    # (GENESIS has no ReLU: the strict bar.  Until the build's pk_peephole pass this check failed in some launches: two processes
+    #  sharing one GPU is exactly the condition under which the packed-fp32 operand selection of DESIGN.md finding 48 misreads a
+    #  register -- 1e-3 .. 1e-2 in a handful of gradients.)
     if rank == 0:
-        try:
-            check_gradients(gold, grads, [], 'genesis_cfg3_b32 on two ranks, cross-replica BatchNorm')
-        except AssertionError as e:
-            grad_ok, grad_msg = False, str(e)[:300]
+        check_gradients(gold, grads, [], 'genesis_cfg3_b32 on two ranks, cross-replica BatchNorm')
     del model
     # --- three training steps through TrainStep (GENESIS_SYNC_BN=1 arms the same switch per iteration)
     ts = TrainStep(gold.build(), gold.S, lr=1e-4)
@@ -311,8 +304,7 @@ def _worker_genesis_syncbn(rank, world, port, out_dir):
         np.testing.assert_allclose([err_, beta], hist[it, [1, 3]], rtol=5e-4)
     assert abs(float(ts.geco.beta) - float(gold.g['train_beta_final'])) <= 1e-5 * float(gold.g['train_beta_final'])
     bufs = torch.cat([b.detach().double().flatten().cpu() for b in ts.model.buffers()])
-    torch.save({'p': ts.flat_p.cpu(), 'bufs': bufs, 'geco': ts.geco.state.cpu(), 'grad_ok': grad_ok, 'grad_msg': grad_msg},
-               os.path.join(out_dir, 'g%d.pt' % rank))
+    torch.save({'p': ts.flat_p.cpu(), 'bufs': bufs, 'geco': ts.geco.state.cpu()}, os.path.join(out_dir, 'g%d.pt' % rank))
     ts.close()
     dist.barrier()
     dist.destroy_process_group()
@@ -321,15 +313,8 @@ def _worker_genesis_syncbn(rank, world, port, out_dir):
 @pytest.mark.timeout(900)
 def test_two_rank_genesis_with_cross_replica_batchnorm_equals_the_reference_at_global_batch(tmp_path):
     world = 2
-    verdicts = []
-    for attempt in range(4):
-        mp.spawn(_worker_genesis_syncbn, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-        g0 = torch.load(os.path.join(str(tmp_path), 'g0.pt'))
-        g1 = torch.load(os.path.join(str(tmp_path), 'g1.pt'))
-        for k in ('p', 'bufs', 'geco'):
-            assert torch.equal(g0[k], g1[k]), k          # lock-step, running statistics included
-        verdicts.append((g0['grad_ok'], g0['grad_msg']))
-        if g0['grad_ok']:
-            break
-    print('gradient verdicts of the launches (see the OPEN ISSUE note in the worker): %s' % verdicts)
-    assert verdicts[-1][0], verdicts
+    mp.spawn(_worker_genesis_syncbn, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    g0 = torch.load(os.path.join(str(tmp_path), 'g0.pt'))
+    g1 = torch.load(os.path.join(str(tmp_path), 'g1.pt'))
+    for k in ('p', 'bufs', 'geco'):
+        assert torch.equal(g0[k], g1[k]), k          # lock-step, running statistics included
