@@ -16,7 +16,7 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-val
 
 def _deps():
     d = [osp.join(CSRC, s) for s in SOURCES if osp.exists(osp.join(CSRC, s))]
-    d += [osp.join(CSRC, 'gx_common.h'), osp.join(osp.dirname(HERE), 'include', 'genesis_hip.h')]
+    d += [osp.join(CSRC, 'gx_common.h'), osp.join(osp.dirname(HERE), 'include', 'genesis_hip.h'), osp.join(HERE, 'pk_peephole.py')]
     return d
 
 

@@ -76,7 +76,8 @@ WGQ_F16 = os.environ.get('GENESIS_WGQ_F16X3', '1') != '0'
 _TAP_CAP = 16384         # (the 128 x 128 decoder head's chunked backward: K B x 8 groups x 4 chunks = 11 264 workgroups)
 _ARENA_FLOATS = 1 << 22
 _ARENA = {}                      # device index -> [tensor, base pointer, position (floats)]
-_LAST_AMAX = [None]
+import threading as _threading
+_LAST = _threading.local()       # .amax: what the last tapped launch OF THIS THREAD left (two loops in two threads must not take each other's)
 
 
 class Amax(object):
@@ -103,15 +104,15 @@ def _amax_scratch(device, n):
 
 def take_amax():
     """The partial maxima the LAST tapped GroupNorm launch left for the tensor it stored (None: not tapped / not served)."""
-    h = _LAST_AMAX[0]
-    _LAST_AMAX[0] = None
+    h = getattr(_LAST, 'amax', None)
+    _LAST.amax = None
     return h
 
 
 def _tap_begin(device, hw, numel):
     # (hw: the plane size of a GroupNorm launch; the gated units' kernels tap at any size and pass 1 << 30)
     if not WGQ_F16 or hw < 256:      # (the register-resident GroupNorm kernels -- the only producers -- start at 16 x 16 planes)
-        _LAST_AMAX[0] = None
+        _LAST.amax = None
         return None
     ptr, a, off = _amax_scratch(device, _TAP_CAP)
     _lib.call('gx_amax_tap', ctypes.c_void_p(ptr), _TAP_CAP, int(numel))
@@ -125,7 +126,7 @@ def _tap_end(tap):
     n = _lib.query('gx_amax_tap_result')
     if a[2] == off + _TAP_CAP:
         a[2] = off + ((n + 3) & ~3)          # give the unused part of the request back
-    _LAST_AMAX[0] = Amax(ptr, n) if n > 0 else None
+    _LAST.amax = Amax(ptr, n) if n > 0 else None
 
 
 def amax_of(t):
@@ -358,7 +359,6 @@ def deconv5x5s2_fwd(x, w, bias):
 
 
 AMAX_LINK = os.environ.get('GENESIS_AMAX_LINK', '1') != '0'
-_LINK_KEEP = []
 AMAX_LINK_REG = os.environ.get('GENESIS_AMAX_LINK_REG', '1') != '0'     # 0: only the decoder head's gradient is handed over
 
 
@@ -372,8 +372,11 @@ def amax_link(device, numel, capacity=16384):
     buf = torch.empty(capacity, dtype=F32, device=device)
     # the consumer is enqueued by a LATER call: the scratch must not go back to the allocator (and be handed to the tensors of the
     # calls in between) before that -- the last few links' buffers are kept alive here, whatever the caller does with its reference
-    _LINK_KEEP.append(buf)
-    del _LINK_KEEP[:-4]
+    keep = getattr(_LAST, 'links', None)
+    if keep is None:
+        keep = _LAST.links = []          # (per thread, like the link itself)
+    keep.append(buf)
+    del keep[:-4]
     _lib.call('gx_kq_amax_link', _p(buf), capacity, int(numel))
     return buf
 

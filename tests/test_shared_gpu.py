@@ -22,3 +22,16 @@ def test_gradients_are_reproducible_beside_a_second_process(case, reps):
     print('\n'.join(lines))
     assert p.returncode == 0, out[-2000:]
     assert '%s (load: process): 0 of %d repetitions differ' % (case, reps) in out, '\n'.join(lines)[:3000]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_gradients_are_reproducible_beside_a_second_loop_in_this_process():
+    """The same with the load in ANOTHER THREAD of the process (its own HIP stream and its own library context, gx_ctx_*): the Python
+    layer's hand-over state (the last tapped launch's partial maxima, the link buffers kept alive) is per thread."""
+    env = dict(os.environ, LOAD='thread')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'diag_shared_gpu3.py'), 'v2_metric_b32', '12'], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=800)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out[-2000:]
+    assert 'v2_metric_b32 (load: thread): 0 of 12 repetitions differ' in out, out[-3000:]

@@ -11,7 +11,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests.test_fullbatch_gpu import Full  # noqa: E402
 
 
-def load(stop, ready):
+def load(stop, ready, own_ctx=False):
+    if own_ctx:       # a second loop in the same process works in a library context of its own (include/genesis_hip.h, gx_ctx_*)
+        from genesis_amd import _lib
+        _lib.make_current(int(_lib.load().gx_ctx_create()))
     with torch.cuda.stream(torch.cuda.Stream()):
         gold = Full('genesis_cfg3_b32')
         x, nz = gold.x(), gold.noise()
@@ -34,7 +37,7 @@ def main():
         worker = ctx.Process(target=load, args=(stop, ready))
     else:
         stop, ready = threading.Event(), threading.Event()
-        worker = threading.Thread(target=load, args=(stop, ready))
+        worker = threading.Thread(target=load, args=(stop, ready, os.environ.get('SHARED_CTX') != '1'))
     gold = Full(case)
     x, nz = gold.x(), gold.noise()
     body(case, reps, mode, stop, ready, worker, gold, x, nz)
