@@ -11,7 +11,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 // OP 0: v_pk_fma_f32 (r = a * b + r), 1: v_pk_mul_f32 then scalar adds, 2: v_pk_add_f32 (r = a + b, accumulated by scalar adds)
 // S0L / S1L: which half of source 0 / 1 the LOW lane takes; S0H / S1H: the HIGH lane
-#define PROBE_KERNEL(NAME, OP, S0L, S1L, S0H, S1H, ASM)                                                                             \
+#define PROBE_KERNEL2(NAME, OP, S0L, S1L, S0H, S1H, S2L, S2H, SG, ASM)                                                                             \
 template <bool FROM_MEM>                                                                                                            \
 __global__ void __launch_bounds__(256) NAME(const f2* __restrict__ src, int n, int iters, unsigned long long* bad) {                \
     const int tid = blockIdx.x * 256 + threadIdx.x;                                                                                 \
@@ -29,16 +29,33 @@ __global__ void __launch_bounds__(256) NAME(const f2* __restrict__ src, int n, i
             a[0] = a[0] * 0.999f + 0.001f; b[1] = b[1] * 0.998f - 0.002f;                                                           \
             asm volatile("" : "+v"(a), "+v"(b));                                                                                    \
         }                                                                                                                           \
+        unsigned long long a_s = 0;                                                                                                 \
+        if (SG == 1) {         /* source 0 in a scalar register pair: the wave's first lane's values */                              \
+            const unsigned lo = __builtin_amdgcn_readfirstlane(__float_as_uint(a[0])), hi = __builtin_amdgcn_readfirstlane(__float_as_uint(a[1])); \
+            a[0] = __uint_as_float(lo); a[1] = __uint_as_float(hi);                                                                 \
+            a_s = ((unsigned long long)hi << 32) | lo;                                                                              \
+        }                                                                                                                           \
+        if (SG == 2) {         /* source 1 in a scalar register pair */                                                              \
+            const unsigned lo = __builtin_amdgcn_readfirstlane(__float_as_uint(b[0])), hi = __builtin_amdgcn_readfirstlane(__float_as_uint(b[1])); \
+            b[0] = __uint_as_float(lo); b[1] = __uint_as_float(hi);                                                                 \
+            a_s = ((unsigned long long)hi << 32) | lo;                                                                              \
+        }                                                                                                                           \
         f2 r = acc;                                                                                                                 \
         float a_l, b_l, a_h, b_h;                                                                                                   \
         a_l = a[S0L]; b_l = b[S1L]; a_h = a[S0H]; b_h = b[S1H];                                                                     \
+        const float c_l = S2L ? s1 : s0, c_h = S2H ? s1 : s0;                                                                       \
         asm volatile("" : "+v"(a_l), "+v"(b_l), "+v"(a_h), "+v"(b_h));      /* scalar copies: the reference must not be re-vectorised */ \
         if (OP == 0) {                                                                                                              \
-            asm volatile(ASM : "+v"(r) : "v"(a), "v"(b));                                                                           \
-            s0 = __builtin_fmaf(a_l, b_l, s0); asm volatile("" : "+v"(s0)); s1 = __builtin_fmaf(a_h, b_h, s1);                      \
+            if (SG == 1) asm volatile(ASM : "+v"(r) : "s"(a_s), "v"(b));                                                            \
+            else if (SG == 2) asm volatile(ASM : "+v"(r) : "v"(a), "s"(a_s));                                                       \
+            else asm volatile(ASM : "+v"(r) : "v"(a), "v"(b));                                                                      \
+            float n0 = __builtin_fmaf(a_l, b_l, c_l); asm volatile("" : "+v"(n0)); float n1 = __builtin_fmaf(a_h, b_h, c_h);        \
+            asm volatile("" : "+v"(n1)); s0 = n0; s1 = n1;                                                                          \
         } else {                                                                                                                    \
             f2 m;                                                                                                                   \
-            asm volatile(ASM : "=v"(m) : "v"(a), "v"(b));                                                                           \
+            if (SG == 1) asm volatile(ASM : "=v"(m) : "s"(a_s), "v"(b));                                                            \
+            else if (SG == 2) asm volatile(ASM : "=v"(m) : "v"(a), "s"(a_s));                                                       \
+            else asm volatile(ASM : "=v"(m) : "v"(a), "v"(b));                                                                      \
             float m0 = m[0], m1 = m[1];                                                                                             \
             asm volatile("" : "+v"(m0), "+v"(m1));                                                                                  \
             r[0] = r[0] + m0; asm volatile("" : "+v"(r)); r[1] = r[1] + m1;                                                         \
@@ -64,6 +81,7 @@ __global__ void __launch_bounds__(256) NAME(const f2* __restrict__ src, int n, i
     if (nb) atomicAdd(bad, nb);                                                                                                     \
 }
 
+#define PROBE_KERNEL(NAME, OP, S0L, S1L, S0H, S1H, ASM) PROBE_KERNEL2(NAME, OP, S0L, S1L, S0H, S1H, 0, 1, 0, ASM)
 PROBE_KERNEL(k_fma_dflt, 0, 0, 0, 1, 1, "v_pk_fma_f32 %0, %1, %2, %0")
 PROBE_KERNEL(k_fma_bcast, 0, 0, 0, 0, 1, "v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]")
 PROBE_KERNEL(k_fma_01_00, 0, 0, 1, 0, 0, "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,0,1]")
@@ -76,6 +94,24 @@ PROBE_KERNEL(k_mul_01_10, 1, 0, 1, 1, 0, "v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] o
 PROBE_KERNEL(k_mul_dflt, 1, 0, 0, 1, 1, "v_pk_mul_f32 %0, %1, %2")
 PROBE_KERNEL(k_add_01_10, 2, 0, 1, 1, 0, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]")
 PROBE_KERNEL(k_add_01_11, 2, 0, 1, 1, 1, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1]")
+
+// third-source selections and a scalar register pair as source 0 (forms of conv1x1_fwd_vec_kernel)
+PROBE_KERNEL2(k_fma_h_101, 0, 0, 0, 1, 0, 0, 1, 0, "v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]")
+PROBE_KERNEL2(k_fma_h_010, 0, 0, 0, 0, 1, 0, 0, 0, "v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,0]")
+PROBE_KERNEL2(k_fma_h_110, 0, 0, 0, 1, 1, 0, 0, 0, "v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,1,0]")
+PROBE_KERNEL2(k_fma_l_001, 0, 0, 0, 1, 1, 1, 1, 0, "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,1]")
+PROBE_KERNEL2(k_fma_l_101, 0, 1, 0, 1, 1, 1, 1, 0, "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,1]")
+PROBE_KERNEL2(k_fma_l_100h110, 0, 1, 0, 1, 1, 0, 0, 0, "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,0]")
+PROBE_KERNEL2(k_mul_s_bcast, 1, 0, 0, 0, 1, 0, 1, 1, "v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]")
+PROBE_KERNEL2(k_mul_s_dflt, 1, 0, 0, 1, 1, 0, 1, 1, "v_pk_mul_f32 %0, %1, %2")
+PROBE_KERNEL2(k_fma_s_h010, 0, 0, 0, 0, 1, 0, 0, 1, "v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,0]")
+PROBE_KERNEL2(k_fma_s_bcast, 0, 0, 0, 0, 1, 0, 1, 1, "v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]")
+
+PROBE_KERNEL2(k_fma_s_l101, 0, 1, 0, 1, 1, 1, 1, 1, "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,1]")
+PROBE_KERNEL2(k_fma_vs_l011, 0, 0, 1, 1, 1, 1, 1, 2, "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,1]")
+PROBE_KERNEL2(k_mul_vs_l01, 1, 0, 1, 1, 1, 0, 1, 2, "v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]")
+PROBE_KERNEL2(k_mul_sv_l10, 1, 1, 0, 1, 1, 0, 1, 1, "v_pk_mul_f32 %0, %1, %2 op_sel:[1,0]")
+PROBE_KERNEL2(k_add_vs_h10, 2, 0, 0, 1, 0, 0, 1, 2, "v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]")
 
 template <typename K>
 static void run(const char* name, K kern, bool from_mem, const f2* src, int n, unsigned long long* d_bad, double seconds) {
@@ -113,6 +149,8 @@ int main(int argc, char** argv) {
     (void)hipMalloc((void**)&d, n * sizeof(f2)); (void)hipMalloc((void**)&d_bad, 64);
     (void)hipMemcpy(d, h.data(), n * sizeof(f2), hipMemcpyHostToDevice);
 #define RUN(K, NAME) run(NAME, K<true>, true, d, n, d_bad, seconds); run(NAME, K<false>, false, d, n, d_bad, seconds);
+    const bool only_scalar_forms = argc > 2;
+    if (!only_scalar_forms) {
     RUN(k_fma_dflt,  "v_pk_fma_f32  lo = a.lo b.lo, hi = a.hi b.hi (no op_sel)")
     RUN(k_fma_bcast, "v_pk_fma_f32  lo = a.lo b.lo, hi = a.lo b.hi")
     RUN(k_fma_01_00, "v_pk_fma_f32  lo = a.lo b.HI, hi = a.lo b.lo")
@@ -125,5 +163,21 @@ int main(int argc, char** argv) {
     RUN(k_mul_01_10, "v_pk_mul_f32  lo = a.lo b.HI, hi = a.hi b.LO")
     RUN(k_add_01_10, "v_pk_add_f32  lo = a.lo + b.HI, hi = a.hi + b.LO")
     RUN(k_add_01_11, "v_pk_add_f32  lo = a.lo + b.HI, hi = a.hi + b.hi")
+    RUN(k_fma_h_101, "v_pk_fma_f32  op_sel_hi:[1,0,1]: hi = a.hi b.LO + c.hi")
+    RUN(k_fma_h_010, "v_pk_fma_f32  op_sel_hi:[0,1,0]: hi = a.LO b.hi + c.LO")
+    RUN(k_fma_h_110, "v_pk_fma_f32  op_sel_hi:[1,1,0]: hi = a.hi b.hi + c.LO")
+    RUN(k_fma_l_001, "v_pk_fma_f32  op_sel:[0,0,1]: lo = a.lo b.lo + c.HI")
+    RUN(k_fma_l_101, "v_pk_fma_f32  op_sel:[1,0,1]: lo = a.HI b.lo + c.HI")
+    RUN(k_fma_l_100h110, "v_pk_fma_f32  op_sel:[1,0,0] op_sel_hi:[1,1,0]")
+    RUN(k_mul_s_dflt, "v_pk_mul_f32  source 0 = s[n:n+1] (no op_sel)")
+    RUN(k_mul_s_bcast, "v_pk_mul_f32  source 0 = s[n:n+1] op_sel_hi:[0,1]")
+    RUN(k_fma_s_bcast, "v_pk_fma_f32  source 0 = s[n:n+1] op_sel_hi:[0,1,1]")
+    RUN(k_fma_s_h010, "v_pk_fma_f32  source 0 = s[n:n+1] op_sel_hi:[0,1,0]")
+    }
+    RUN(k_fma_s_l101, "v_pk_fma_f32  source 0 = s[n:n+1] op_sel:[1,0,1] (lo = s.HI b.lo + c.HI)")
+    RUN(k_fma_vs_l011, "v_pk_fma_f32  source 1 = s[n:n+1] op_sel:[0,1,1] (lo = a.lo s.HI + c.HI)")
+    RUN(k_mul_vs_l01, "v_pk_mul_f32  source 1 = s[n:n+1] op_sel:[0,1] (lo = a.lo s.HI)")
+    RUN(k_mul_sv_l10, "v_pk_mul_f32  source 0 = s[n:n+1] op_sel:[1,0] (lo = s.HI b.lo)")
+    RUN(k_add_vs_h10, "v_pk_add_f32  source 1 = s[n:n+1] op_sel_hi:[1,0] (hi = a.hi + s.LO)")
     return 0;
 }

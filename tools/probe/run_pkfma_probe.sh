@@ -3,7 +3,7 @@ cd $GRAFT_REPO_ROOT
 P=tools/abl/pkfma_probe
 [ -x $P ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -ffp-contract=off -Wno-unused-value -o $P tools/probe/pkfma_probe.hip
 echo "=== alone"
-$P 1.0
+$P 0.4
 echo "=== beside another process (GENESIS training iterations)"
 python - <<'PY' &
 import sys, time, torch
@@ -13,7 +13,7 @@ gold = Full('genesis_cfg3_b32')
 x, nz = gold.x(), gold.noise()
 model = gold.build()
 t0 = time.time()
-while time.time() - t0 < 75:
+while time.time() - t0 < 150:
     out = gold.forward(model, x, nz)
     err, kl = gold.aggregate(out[1])
     (err + kl).backward()
@@ -21,5 +21,5 @@ while time.time() - t0 < 75:
 PY
 LOADPID=$!
 sleep 25
-$P 2.0
+$P 1.5
 wait $LOADPID
