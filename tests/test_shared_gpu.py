@@ -35,3 +35,16 @@ def test_gradients_are_reproducible_beside_a_second_loop_in_this_process():
     out = p.stdout.decode()
     assert p.returncode == 0, out[-2000:]
     assert 'v2_metric_b32 (load: thread): 0 of 12 repetitions differ' in out, out[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('case', ['metric', 'tiny'])
+def test_small_fixtures_are_reproducible_beside_a_second_process(case):
+    """The SMALL golden fixtures (other kernels: the vector-ALU 1 x 1 conv with a scalar-pair operand, the small GroupNorm and tap-conv
+    kernels, sample()): forward + backward + sample() beside a loading process, every output bit for bit (were 5 - 16 of 40 off)."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'diag_shared_gpu4.py'), case, '12'], cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=800)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out[-2000:]
+    assert '%s (beside a loading process): 0 of 12 repetitions differ' % case in out, out[-3000:]
