@@ -1253,6 +1253,12 @@ wgq_stream_kernel(const WsTable tab, const float* __restrict__ zeros) {
             GX_WF_CASE(29, WQ_C3, 128) GX_WF_CASE(30, WQ_DR0, 64) GX_WF_CASE(31, WQ_DR1, 64)
             GX_WF_CASE(22, WQ_C5A, 64) GX_WF_CASE(23, WQ_C5A, 32) GX_WF_CASE(24, WQ_C5B, 64) GX_WF_CASE(25, WQ_C5B, 32)
             GX_WF_CASE(32, WQ_C5A, 16) GX_WF_CASE(33, WQ_C5B, 16)
+            // ... and their k-split forms (the gated stacks' and MONet's 32-channel blocks)
+            GX_WF_CASE(32 + 18, WQ_C3, 1064) GX_WF_CASE(32 + 19, WQ_C3, 1032) GX_WF_CASE(32 + 20, WQ_DR0, 1032)
+            GX_WF_CASE(32 + 22, WQ_C5A, 1064) GX_WF_CASE(32 + 23, WQ_C5A, 1032) GX_WF_CASE(32 + 24, WQ_C5B, 1064) GX_WF_CASE(32 + 25, WQ_C5B, 1032)
+            GX_WF_CASE(64 + 18, WQ_C3, 2064) GX_WF_CASE(64 + 19, WQ_C3, 2032) GX_WF_CASE(64 + 20, WQ_DR0, 2032)
+            GX_WF_CASE(64 + 22, WQ_C5A, 2064) GX_WF_CASE(64 + 23, WQ_C5A, 2032) GX_WF_CASE(64 + 24, WQ_C5B, 2064) GX_WF_CASE(64 + 25, WQ_C5B, 2032)
+            GX_WF_CASE(96 + 18, WQ_C3, 3064)
             default: break;
         }
 #undef GX_WS_CASE
@@ -1630,9 +1636,15 @@ int wgq_launch_stream(std::vector<PendingJob*>& jobs, hipStream_t s, std::vector
                     }
                     jb.w_first = 0; jb.N = q.job.N;
                     jb.amax2 = nullptr;
-                    if (rv >= 0 && jb.variant == rv && ws_f16_variant(rv) && q.am_out && wgq_f16() && nfin < 2 * kMaxFin - 2) {
-                        // both operands' maxima are known: two fp16 pieces per value, three piece products
-                        jb.variant = rv + 128; jb.cost = ws_f16cost(rv); jb.amax2 = q.am_out;
+                    // (the k-split 10-tap row parity at 32 pixels has no fp16 form: its split pieces do not fit the tile's free slots)
+                    if (rv >= 0 && ws_f16_variant(rv) && !(jb.variant != rv && (rv == 21 || rv > 25)) && q.am_out && wgq_f16() && nfin < 2 * kMaxFin - 2) {
+                        // both operands' maxima are known: two fp16 pieces per value, three piece products (k-split forms: the fp16
+                        // tile's cost scaled like the bf16 one's)
+                        const int hfv = jb.variant - rv;            // 32 * HF
+                        // (... then fitted on the GENESIS step with GENESIS_WGQ_TIMES: the 32-pixel and 10-tap forms gain less, percent)
+                        static const int kadj[8] = {100, 100, 108, 100, 91, 109, 104, 119};      // rv 18 .. 25
+                        jb.cost = hfv ? (int)((long long)jb.cost * ws_f16cost(rv) / g_ws_cost[rv] * (rv <= 25 ? kadj[rv - 18] : 100) / 100) : ws_f16cost(rv);
+                        jb.variant = rv + hfv + 128; jb.amax2 = q.am_out;
                         bool seen = false;
                         for (int k = 0; k < nfin; ++k) seen = seen || fin.e[k].out == q.am_out;
                         if (!seen) {

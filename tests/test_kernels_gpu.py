@@ -1907,7 +1907,10 @@ def _per_channel_err(got, ref, dim):
 @pytest.mark.parametrize('kind,N,Cin,Cout,S', [('conv3x3', 32, 64, 64, 64), ('conv3x3', 8, 128, 64, 32), ('conv3x3', 16, 64, 128, 16),
                                                 ('deconv', 56, 64, 64, 32), ('deconv', 16, 64, 64, 16),
                                                 # rows of 128 / 64 input pixels: the strip tiles (seam values in two fp16 pieces)
-                                                ('conv3x3', 4, 64, 64, 128), ('deconv', 8, 64, 64, 64)])
+                                                ('conv3x3', 4, 64, 64, 128), ('deconv', 8, 64, 64, 64),
+                                                # 32-channel blocks: the k-split forms (wave pairs split the tile's pixels, finding 24)
+                                                ('conv3x3', 32, 32, 64, 64), ('conv3x3', 32, 64, 32, 32), ('conv3x3', 32, 32, 32, 64),
+                                                ('deconv', 56, 32, 64, 32)])
 def test_weight_gradients_on_three_fp16_piece_products_keep_fp32_accuracy(kind, N, Cin, Cout, S):
     """gx_wgq_precision(2) + gx_wgq_operand_amax: the row-ring tiles with two fp16 pieces per operand value (x * 2^e = hi + lo)
     and three piece products.  Against autograd in fp64, next to the fp32 pipe and the six-bf16-piece form: the fp16 error stays
