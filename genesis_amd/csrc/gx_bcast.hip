@@ -51,7 +51,7 @@ broadcast_concat_kernel(const float* __restrict__ z, const float* __restrict__ c
 __global__ void __launch_bounds__(256)
 bcast_conv_fwd_kernel(const float* __restrict__ z, const float* __restrict__ w, const float* __restrict__ bias,
                       const float* __restrict__ rowc, const float* __restrict__ colc, int L, int Co, int d, int act,
-                      float* __restrict__ out) {
+                      float* __restrict__ out, float* __restrict__ amax_parts) {
     extern __shared__ float sh[];     // A[d] | B[d]
     float* A = sh;
     float* Bc = sh + d;
@@ -90,6 +90,7 @@ bcast_conv_fwd_kernel(const float* __restrict__ z, const float* __restrict__ w, 
     const float s = s_sh;
     float* o = out + (size_t)blockIdx.x * d * d;
     const int d4 = d >> 2;     // d is a multiple of 4 (checked by the host)
+    float am = 0.f;
     for (int i = tid; i < d * d4; i += 256) {
         const int y = i / d4, x = (i - y * d4) * 4;
         const float a = s + A[y];
@@ -97,7 +98,10 @@ bcast_conv_fwd_kernel(const float* __restrict__ z, const float* __restrict__ w, 
         v[0] = b_act(a + Bc[x], act); v[1] = b_act(a + Bc[x + 1], act);
         v[2] = b_act(a + Bc[x + 2], act); v[3] = b_act(a + Bc[x + 3], act);
         *reinterpret_cast<f32x4*>(o + (size_t)y * d + x) = v;
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
     }
+    // an armed gx_amax_tap: the plane's largest magnitude for the canvas conv that reads this tensor next (its fp16 scale)
+    if (amax_parts) gx_block_amax_store(am, amax_parts, blockIdx.x);      // (uniform)
 }
 
 // seven interior sums of dy = g * act'(y) per (n, co) plane -> sums[plane][8] (D, R-1, R0, R+1, C-1, C0, C+1, 0)
@@ -294,8 +298,9 @@ int gx_bcast_conv3x3_fwd(const float* z, const float* w, const float* bias, cons
     hipStream_t s = (hipStream_t)stream;
     {
         GxProf pf(KID_CONV1X1_FWD, s, 0.0, 4.0 * N * Co * (double)d * d);
+        float* ap = gx_amax_producer_out(out, false, (unsigned)(N * Co), (size_t)N * Co * d * d);
         hipLaunchKernelGGL(bcast_conv_fwd_kernel, dim3(N * Co), dim3(256), 2 * d * sizeof(float), s, z, w, bias, rowc, colc,
-                           L, Co, d, act, out);
+                           L, Co, d, act, out, ap);
     }
     GX_CHECK_LAUNCH("gx_bcast_conv3x3_fwd");
     return GX_OK;

@@ -267,6 +267,19 @@ __device__ __forceinline__ float gx_wg1024_amax(const float* __restrict__ w, int
     for (int i = 1; i < 16; ++i) r = fmaxf(r, gx_amax_red[i]);
     return r;
 }
+// producer-side tap (gx_amax_producer_out): the workgroup's largest stored magnitude -> parts[idx]; am >= 0, every thread calls
+__device__ __forceinline__ void gx_block_amax_store(float am, float* __restrict__ parts, unsigned idx) {
+    __shared__ float gx_bam_red[16];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
+    if ((threadIdx.x & 63) == 0) gx_bam_red[threadIdx.x >> 6] = am;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float r = 0.f;
+        for (int i = 0; i < (int)((blockDim.x + 63) >> 6); ++i) r = fmaxf(r, gx_bam_red[i]);
+        parts[idx] = r;
+    }
+}
 #endif
 int gx_kq_weight_amax_launch(const float* w, int n, float* out, hipStream_t s);          // one workgroup (weights are small)
 bool gx_kq_deconv_dgrad_h_eligible(int N, int K, int M, int Hb, int Wb);      // pack 24: all 25 taps, plane-major slots

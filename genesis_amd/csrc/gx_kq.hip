@@ -225,6 +225,8 @@ struct QGeom {
     int stats_parts;
     const float* mask;    // Q_C3H as a data gradient: out *= act'(mask) -- mask = the producing layer's activation OUTPUT, laid
     int mask_act;         // out like `out` (the backward of a bias + ReLU / ELU layer without its own pass: gx_conv3x3_dgrad_act)
+    float* o_amax;        // Q_C3H as a PRODUCER (an armed gx_amax_tap): one partial maximum of |stored value| per workgroup, or NULL
+    int tap_lds_off;      //   ... its four-float LDS slot, in floats from the start of the dynamic LDS (the launch adds 16 bytes)
 };
 
 __device__ __forceinline__ float q_act(float v, int act) {
@@ -304,7 +306,7 @@ __device__ __forceinline__ float q_amax_parts(const float* __restrict__ parts, i
 // NQ: (position, quad) slots staged per thread per input tile (2 * CHS <= NQ * 256)
 // MI: 32-channel MFMA tiles per wave along M.  2 = the workgroup's whole 64-channel tile; 1 = one half (mh) of it --
 // the last tiles of a grid that does not divide the chip are split into two half-work workgroups (q_split_tail).
-template <int MODE, int NQ, bool STATS, int MI = 2, bool F16 = false>
+template <int MODE, int NQ, bool STATS, int MI = 2, bool F16 = false, bool TAP = false>
 __device__ __forceinline__ void q_body(const float* __restrict__ in, const float* __restrict__ wp,
                                        const float* __restrict__ bias, float* __restrict__ out, const QGeom& g,
                                        float* lds, const int bx, const int by, const int par_a, const int mh = 0) {
@@ -608,6 +610,7 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
     const int HoWo = g.Ho * g.Wo;
     const bool add_bias = bias != nullptr;
     const int act = g.act;
+    float omax_t = 0.f;           // Q_C3H producer tap: largest |value| this thread stores for this tile
     f32x4 bvec[MI][4];
     {
         const bool vec_ok = add_bias && (reinterpret_cast<uintptr_t>(bias) & 15) == 0;
@@ -686,6 +689,7 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
                                 float v = q_act(acc[0][mi][nj][reg] + bvec[mi][reg >> 2][reg & 3], act);
                                 if (MODE == Q_C3H && g.mask) v *= mk[mi][reg];
                                 obase[(size_t)mrow * HoWo] = v;
+                                if constexpr (TAP) omax_t = fmaxf(omax_t, fabsf(v));
                             }
                         }
                 }
@@ -731,6 +735,7 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
                         float v = q_act(acc[0][mi][nj][reg] + bv, act);
                         if (MODE == Q_C3H && g.mask) v *= mk[mi][reg];
                         *o = v;
+                        if constexpr (TAP) omax_t = fmaxf(omax_t, fabsf(v));
                     }
                 }
             }
@@ -779,11 +784,23 @@ __device__ __forceinline__ void q_body(const float* __restrict__ in, const float
                         float v = q_act(acc[0][mi][nj][reg] + bv, act);
                         if (MODE == Q_C3H && g.mask) v *= mk[mi][reg];
                         obase[(size_t)m * HoWo] = v;
+                        if constexpr (TAP) omax_t = fmaxf(omax_t, fabsf(v));
                     }
                 }
             }
         }
     }
+    }
+    if constexpr (TAP) {
+        // producer tap (TAP: a variant of its own -- the running maximum costs the untapped kernel, which sits at its register limit,
+        // 24 bytes of scratch and 10 us per launch if it is merely a run-time branch): this tile's largest stored magnitude joins the
+        // wave's running maximum in its LDS slot (behind the staging planes: no register lives across the main loop for it)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) omax_t = fmaxf(omax_t, __shfl_xor(omax_t, o, 64));
+        if (lane == 0) {
+            float* const slot = lds + g.tap_lds_off + (threadIdx.x >> 6);      // (formed here: nothing of it is live in the main loop)
+            *slot = fmaxf(*slot, omax_t);
+        }
     }
 #if GX_KQ_ABL   /* measurement build: shader-clock ticks per 100 MHz tick of workgroup 0's main loop, and its length in us */
     if (bx == 0 && by == 0 && tid == 0 && par_a == 0) {
@@ -885,18 +902,27 @@ kq_dgh_kernel(const float* __restrict__ in, const float* __restrict__ wp, float*
 }
 
 // conv3x3 on the bf16 pipe, 32 output channels per workgroup (blockIdx.y)
-template <int NQ, bool F16 = false>
+template <int NQ, bool F16 = false, bool TAP = false>
 __global__ void __launch_bounds__(256, 3)
 kq_c3h_kernel(const float* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
               float* __restrict__ out, QGeom g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // TAP (g.o_amax, an armed gx_amax_tap): four floats behind the staging planes hold the waves' running maxima of |stored value|
+    float* const tap4 = lds + g.tap_lds_off;
+    if constexpr (TAP) {
+        if ((threadIdx.x & 63) == 0) tap4[threadIdx.x >> 6] = 0.f;      // (a slot is only touched by its own wave's lane 0 until the end)
+    }
     // persistent workgroups (the grid is ~2 per CU): a tile's output stores drain while the next tile's loads are already in
     // flight -- a workgroup that ends after every tile waits for its stores before its LDS / registers are handed on, and with
     // two 16-channel chunks per tile that tail is a large part of a tile's life
     for (int t = blockIdx.x; t < g.nfull; t += gridDim.x) {
         const int tile = gx_xcd_tile(t, g.nfull);
-        q_body<Q_C3H, NQ, false, 1, F16>(in, wp, bias, out, g, lds, tile, blockIdx.y, 0, 0);
+        q_body<Q_C3H, NQ, false, 1, F16, TAP>(in, wp, bias, out, g, lds, tile, blockIdx.y, 0, 0);
         __syncthreads();          // the next tile's staging overwrites LDS the slowest wave may still be reading
+    }
+    if constexpr (TAP) {          // one partial maximum per workgroup for the tensor's next reader
+        if (threadIdx.x == 0)
+            g.o_amax[blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(tap4[0], tap4[1]), fmaxf(tap4[2], tap4[3]));
     }
 }
 
@@ -949,7 +975,7 @@ bool q_plan(int N, int K, int M, int Hb, int Wb, int Hi, int Wi, int Ho, int Wo,
     g->Hb = Hb; g->Wb = Wb; g->Hi = Hi; g->Wi = Wi; g->Ho = Ho; g->Wo = Wo;
     g->lTH = q_ilog2(TH); g->lTW = q_ilog2(TW); g->lG = q_ilog2(G);
     g->tiles_h = Hb / TH; g->tiles_w = Wb / TW;
-    g->ilv = 0; g->x_amax_n = kAmaxParts; g->x_amax = g->w_amax = nullptr; g->act = 0; g->stats = nullptr; g->stats_parts = 0; g->rt_th = g->rt_tw = 0; g->mask = nullptr; g->mask_act = 0;
+    g->ilv = 0; g->x_amax_n = kAmaxParts; g->x_amax = g->w_amax = nullptr; g->act = 0; g->stats = nullptr; g->stats_parts = 0; g->rt_th = g->rt_tw = 0; g->mask = nullptr; g->mask_act = 0; g->o_amax = nullptr; g->tap_lds_off = 0;
     const int CHS = G * (TH + 2) * (TW + 2);
     if (2 * CHS > 4 * 256) return false;
     *nq = 2 * CHS <= 3 * 256 ? 3 : 4;
@@ -1123,7 +1149,7 @@ int gx_kq_weight_amax_launch(const float* w, int n, float* out, hipStream_t s) {
 // a producer that left THOUSANDS of partial maxima (one per workgroup of a gated unit's or a generic GroupNorm kernel's grid): one
 // small launch folds them into one value -- every workgroup of the conv reducing them all costs more (measured: kq_c5h 147 -> 160 us
 // per launch at 10 240 partials, kq_dgh 873 -> 911 us at 11 264) than this launch does (~4 us)
-constexpr int kFoldPartsAbove = 1024;
+static const int kFoldPartsAbove = [] { const char* e = getenv("GENESIS_KQ_FOLD_ABOVE"); return e ? atoi(e) : 1024; }();
 __global__ void __launch_bounds__(1024)
 amax_fold2_kernel(const float* __restrict__ p0, int n0, const float* __restrict__ p1, int n1, float* __restrict__ out) {
     __shared__ float red[16];
@@ -1249,7 +1275,7 @@ static bool q_plan_c3h(int N, int K, int M, int H, int W, QGeom* g, int* nq, siz
     g->Hb = H; g->Wb = W; g->Hi = H; g->Wi = W; g->Ho = H; g->Wo = W;
     g->lTH = q_ilog2(TH); g->lTW = q_ilog2(TW); g->lG = q_ilog2(G);
     g->tiles_h = gx_ceil_div(H, TH); g->tiles_w = W / TW;
-    g->ilv = 0; g->x_amax_n = kAmaxParts; g->x_amax = g->w_amax = nullptr; g->act = 0; g->stats = nullptr; g->stats_parts = 0; g->nfull = 0; g->mask = nullptr; g->mask_act = 0;
+    g->ilv = 0; g->x_amax_n = kAmaxParts; g->x_amax = g->w_amax = nullptr; g->act = 0; g->stats = nullptr; g->stats_parts = 0; g->nfull = 0; g->mask = nullptr; g->mask_act = 0; g->o_amax = nullptr; g->tap_lds_off = 0;
     const int CHS = G * (TH + 2) * (TW + 2);
     if (2 * CHS > 4 * 256) return false;
     *nq = 2 * CHS <= 3 * 256 ? 3 : 4;
@@ -1282,6 +1308,9 @@ int gx_kq_c3h_launch(const float* in, const float* wp, const float* bias, int ac
     static const char* pers_env = getenv("GENESIS_KQ_C3H_PERSIST");
     const int per_cu = pers_env ? atoi(pers_env) : 3;
     if (per_cu > 0 && (int)grid.x > 256 * per_cu / (int)grid.y) grid.x = 256 * per_cu / grid.y;
+    // an armed gx_amax_tap: this launch writes every element of `out` -- one partial maximum per workgroup for the tensor's next
+    // reader (the next layer of a BroadcastDecoder chain, forward or backward: no amax pass of its own over a 148 MB canvas)
+    g.o_amax = amax_ws ? gx_amax_producer_out(out, false, grid.x * grid.y, (size_t)N * M * H * W) : nullptr;      // (the fp16 form only)
     {
         GxProf pf(KID_KQ_C3H, s, 2.0 * N * (double)M * K * 9 * H * W,
                   4.0 * ((double)N * K * H * W + (double)N * M * H * W + 9.0 * K * M));
@@ -1289,6 +1318,12 @@ int gx_kq_c3h_launch(const float* in, const float* wp, const float* bias, int ac
         if (amax_ws) {          // fp16 x 3 (packs 40 / 41)
             g.x_amax = x_parts ? x_parts : amax_ws; g.w_amax = w_amax;
             if (x_parts) g.x_amax_n = x_nparts;
+            static bool t3 = false, t4 = false;
+            if (g.o_amax) {         // the producer-tap variant
+                g.tap_lds_off = (int)(lds / sizeof(float));
+                if (nq == 3) { q_set_attr(&kq_c3h_kernel<3, true, true>, &t3); hipLaunchKernelGGL((kq_c3h_kernel<3, true, true>), grid, dim3(256), lds + 16, s, in, wp, bias, out, g); }
+                else { q_set_attr(&kq_c3h_kernel<4, true, true>, &t4); hipLaunchKernelGGL((kq_c3h_kernel<4, true, true>), grid, dim3(256), lds + 16, s, in, wp, bias, out, g); }
+            } else
             if (nq == 3) { q_set_attr(&kq_c3h_kernel<3, true>, &f3); hipLaunchKernelGGL((kq_c3h_kernel<3, true>), grid, dim3(256), lds, s, in, wp, bias, out, g); }
             else { q_set_attr(&kq_c3h_kernel<4, true>, &f4); hipLaunchKernelGGL((kq_c3h_kernel<4, true>), grid, dim3(256), lds, s, in, wp, bias, out, g); }
         } else
@@ -1306,7 +1341,7 @@ static bool q_plan_c5h(int N, int K, int M, int H, int W, QGeom* g, size_t* lds_
     g->Hb = H; g->Wb = W; g->Hi = H; g->Wi = W; g->Ho = H; g->Wo = W;
     g->lTH = 4; g->lTW = 4; g->lG = 0;
     g->tiles_h = H / 16; g->tiles_w = W / 16;
-    g->rt_th = g->rt_tw = 0; g->ilv = 0; g->x_amax_n = kAmaxParts; g->x_amax = g->w_amax = nullptr; g->act = 0; g->stats = nullptr; g->stats_parts = 0; g->mask = nullptr; g->mask_act = 0;
+    g->rt_th = g->rt_tw = 0; g->ilv = 0; g->x_amax_n = kAmaxParts; g->x_amax = g->w_amax = nullptr; g->act = 0; g->stats = nullptr; g->stats_parts = 0; g->mask = nullptr; g->mask_act = 0; g->o_amax = nullptr; g->tap_lds_off = 0;
     g->nfull = g->tiles_h * g->tiles_w * N;
     constexpr int NWH = (3 * (QH_TAP_BYTES / 16) + 255) / 256;
     *lds_bytes = (size_t)3 * 2 * (20 * 20) * 16 + (size_t)2 * NWH * 256 * 16;       // exact input planes + two weight buffers

@@ -496,8 +496,9 @@ template <bool ACT>
 __global__ void __launch_bounds__(256)
 conv1x1_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, const float* __restrict__ gate,
                      int Cin, int Cout, int HW, float* __restrict__ dx, float* __restrict__ pb,
-                     const float* __restrict__ actx, int act) {
+                     const float* __restrict__ actx, int act, float* __restrict__ amax_parts) {
     __shared__ double red[4];
+    float am = 0.f;               // ACT + an armed gx_amax_tap: largest |dx| this thread stores
     const int n = blockIdx.x;
     const int p = blockIdx.y * blockDim.x + threadIdx.x;
     const float gt = gate ? *gate : 1.f;
@@ -519,7 +520,9 @@ conv1x1_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, 
                 for (int co = 0; co < COMAX; ++co)
                     if (co < Cout) s += w[co * Cin + ci] * g[co];
                 const float neg = act == 2 ? o + 1.f : 0.f;
-                dxn[(size_t)ci * HW] = s * (o > 0.f ? 1.f : neg);
+                const float dv = s * (o > 0.f ? 1.f : neg);
+                dxn[(size_t)ci * HW] = dv;
+                am = fmaxf(am, fabsf(dv));
             }
         } else {
         for (int ci = 0; ci < Cin; ++ci) {
@@ -538,6 +541,9 @@ conv1x1_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, 
             const double sum = block_sum_dd((double)raw[co], red);
             if (threadIdx.x == 0) pb[(size_t)blk * Cout + co] = (float)sum;
         }
+    }
+    if constexpr (ACT) {
+        if (amax_parts) gx_block_amax_store(am, amax_parts, (unsigned)blk);      // (uniform)
     }
 }
 
@@ -940,12 +946,15 @@ static int conv1x1_bwd_impl(const float* x, const float* dy, const float* w, con
     hipStream_t s = (hipStream_t)stream;
     {
         GxProf pf(KID_CONV1X1_DGRAD, s, 2.0 * N * Cin * Cout * HW, 4.0 * N * HW * (Cin + Cout));
-        if (act)
+        if (act) {
+            // (an armed gx_amax_tap: dxa's partial maxima for the canvas conv that reads it next -- the first data gradient of a
+            //  BroadcastDecoder chain)
+            float* ap = gx_amax_producer_out(dx, false, (unsigned)nblkd, (size_t)N * Cin * HW);
             hipLaunchKernelGGL(conv1x1_dgrad_kernel<true>, dim3(N, gx_ceil_div(HW, 256)), dim3(256), 0, s, dy, w, gate, Cin,
-                               Cout, HW, dx, pb, x, act);
-        else
+                               Cout, HW, dx, pb, x, act, ap);
+        } else
             hipLaunchKernelGGL(conv1x1_dgrad_kernel<false>, dim3(N, gx_ceil_div(HW, 256)), dim3(256), 0, s, dy, w, gate, Cin,
-                               Cout, HW, dx, pb, (const float*)nullptr, 0);
+                               Cout, HW, dx, pb, (const float*)nullptr, 0, (float*)nullptr);
     }
     GX_CHECK_LAUNCH("gx_conv1x1_bwd(dgrad)");
     {

@@ -244,7 +244,16 @@ wgrad_strip_kernel(const float* __restrict__ x, const float* __restrict__ dy, fl
     }
     float* out = part + (size_t)blockIdx.x * kStripPart;
     for (int i = tid; i < kStripPart; i += 256) out[i] = red[i];
-    if (bias_part) bias_part[(size_t)blockIdx.x * 256 + tid] = bsum;
+    if (bias_part) {
+        // the workgroup's 32 channel sums of dy: the two lane halves by a shuffle, the four waves in wave order -- one 32-float record
+        // per workgroup (the per-thread records of round 4 left the final launch ONE workgroup walking 2048 records in a chain of
+        // dependent-latency loads: 60 us for 256 KB)
+        __shared__ float bred[4][32];
+        const float b2 = bsum + __shfl_xor(bsum, 32, 64);
+        if (lane < 32) bred[wave][lane] = b2;
+        __syncthreads();
+        if (tid < 32) bias_part[(size_t)blockIdx.x * 32 + tid] = (bred[0][tid] + bred[1][tid]) + (bred[2][tid] + bred[3][tid]);
+    }
 }
 
 // first level: slice `blockIdx.y` of the workgroups' partials, element by element
@@ -269,12 +278,19 @@ __global__ void __launch_bounds__(256)
 wgrad_strip_reduce2_kernel(const float* __restrict__ part2, int nslice, float* __restrict__ dw, const float* __restrict__ bias_part,
                            int nb, float* __restrict__ dbias) {
     if (blockIdx.x == kStripPart / 256) {
-        // dbias[c] = sum over workgroups, waves and lane halves of the lanes' sums: thread (c, k) takes every 8th record
+        // dbias[c] = sum over the workgroups' records: thread (c, k) takes every 8th record, four independent chains
         __shared__ float bs[8][32];
         const int c = threadIdx.x & 31, k = threadIdx.x >> 5;
-        float s = 0.f;
-        for (int rec = k; rec < nb * 8; rec += 8) s += bias_part[(size_t)rec * 32 + c];      // record = (workgroup, wave, half)
-        bs[k][c] = s;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int rec = k;
+        for (; rec + 24 < nb; rec += 32) {
+            s0 += bias_part[(size_t)rec * 32 + c];
+            s1 += bias_part[(size_t)(rec + 8) * 32 + c];
+            s2 += bias_part[(size_t)(rec + 16) * 32 + c];
+            s3 += bias_part[(size_t)(rec + 24) * 32 + c];
+        }
+        for (; rec < nb; rec += 8) s0 += bias_part[(size_t)rec * 32 + c];
+        bs[k][c] = (s0 + s1) + (s2 + s3);
         __syncthreads();
         if (threadIdx.x < 32) {
             float t = 0.f;

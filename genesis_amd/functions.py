@@ -891,12 +891,17 @@ class BroadcastDecoderFn(torch.autograd.Function):
         rowc, colc = _row_col_coords(coords)         # g_1 varies along rows, g_2 along columns (blocks.py:121-126)
         acts = []
         h = None
+        am = None                  # partial maxima of h, left by the launch that wrote it (the next layer's fp16 scale without a pass)
         for l in range(nl):
             w, b = params[2 * l], params[2 * l + 1]
             if l == 0:
-                y = hip.bcast_conv3x3_fwd(z, w, b, rowc, colc, act)
+                tap = CHAIN_TAPS and nl > 1
+                y = hip.bcast_conv3x3_fwd(z, w, b, rowc, colc, act, tap=tap)
+                am = hip.take_amax() if tap else None
             else:
-                y = hip.conv3x3_bias_act_fwd(h, w, b, act)
+                tap = CHAIN_TAPS and l + 1 < nl
+                y = hip.conv3x3_bias_act_fwd(h, w, b, act, amax_in=am, tap=tap)
+                am = hip.take_amax() if tap else None
             acts.append((h, y))
             h = y
             # (test diagnostic: the reference's VALID conv l has the canvas minus l + 1 border pixels as its output)
@@ -922,6 +927,7 @@ class BroadcastDecoderFn(torch.autograd.Function):
         gfull = torch.zeros(last.shape[0], ow.shape[0], last.shape[2], last.shape[3], device=g.device)
         gfull[:, :, nl:nl + S, nl:nl + S] = g
         pre = None                 # (dy, db, db's buffer) of layer l, already formed by the data gradient of the layer after it
+        am0 = None
         if wide:
             gow, gob = _gout(ow), _gout(ob)
             dyo, dob = hip.bias_act_bwd(ctx.full, gfull, out_act, True, gob)
@@ -937,9 +943,11 @@ class BroadcastDecoderFn(torch.autograd.Function):
             gow, gob = _gout(ow), _gout(ob)
             if gow is None or gob is None:
                 gow = gob = None
-            dyl, dow, dob, dbl = hip.conv1x1_bwd_act(last, gfull, ow, ob, act, out=(gow, gob), dbx_out=gbp, want_dbx=not lazy)
+            dyl, dow, dob, dbl = hip.conv1x1_bwd_act(last, gfull, ow, ob, act, out=(gow, gob), dbx_out=gbp, want_dbx=not lazy,
+                                                     tap=CHAIN_TAPS)
             dow, dob = _ret(gow, dow), _ret(gob, dob)
             pre = (dyl, dbl, gbp)
+            am0 = hip.take_amax() if CHAIN_TAPS else None      # (dyl's partial maxima: the first data gradient's fp16 scale)
         else:
             gow, gob = _gout(ow), _gout(ob)
             if gow is None or gob is None:
@@ -949,6 +957,7 @@ class BroadcastDecoderFn(torch.autograd.Function):
         grads = [None] * len(params)
         grads[2 * nl], grads[2 * nl + 1] = dow, dob
         dz = None
+        am = am0                   # partial maxima of the current dy (see forward)
         for l in reversed(range(nl)):
             w, b = params[2 * l], params[2 * l + 1]
             h, y = ctx.acts[l]
@@ -971,13 +980,16 @@ class BroadcastDecoderFn(torch.autograd.Function):
                     gbp = _gout(params[2 * l - 1])
                     wp = params[2 * l - 2]
                     lazy = QUAD_BIAS and wp.shape[0] == wp.shape[1] and _quad_ok(h.shape[0], wp.shape[1], h.shape[2], h.shape[3])
-                    pre = hip.conv3x3_dgrad_act(dy, w, h, act, gbp, want_dbias=not lazy) + (gbp,)
+                    pre = hip.conv3x3_dgrad_act(dy, w, h, act, gbp, want_dbias=not lazy, amax_in=am, tap=CHAIN_TAPS) + (gbp,)
+                    am = hip.take_amax() if CHAIN_TAPS else None
                 else:
-                    da = hip.conv3x3_dgrad(dy, w)
+                    da = hip.conv3x3_dgrad(dy, w, amax_in=am)
+                    am = None
             grads[2 * l], grads[2 * l + 1] = _ret(gw, dw), _ret(gb, db)
         return (dz, None, None, None) + tuple(grads)
 
 
+CHAIN_TAPS = os.environ.get('GENESIS_BCAST_CHAIN_TAPS', '1') != '0'   # 0: every canvas conv makes its own amax pass over its input
 QUAD_BIAS = os.environ.get('GENESIS_QUAD_WGRAD_BIAS', '1') != '0'     # 0: the fused data gradients' own plane-sum pass
 
 

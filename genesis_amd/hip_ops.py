@@ -696,7 +696,7 @@ def conv1x1_bwd(x, dy, w, bias, gate=None, out=None, accumulate=False):
 ACTS = {None: 0, 'none': 0, 'relu': 1, 'elu': 2}
 
 
-def conv1x1_bwd_act(x, dy, w, bias, act, out=None, dbx_out=None, want_dbx=True):
+def conv1x1_bwd_act(x, dy, w, bias, act, out=None, dbx_out=None, want_dbx=True, tap=False):
     """conv1x1_bwd of a conv whose input x is a bias + activation layer's output: returns (dxa, dw, db, dbx) with
     dxa = dx * act'(x) and dbx[c] = sum_{n,hw} dxa, that layer's bias gradient (gx_conv1x1_bwd_act)."""
     _chk(dy, 'conv1x1_bwd_act.dy'); _chk(x, 'conv1x1_bwd_act.x')
@@ -714,8 +714,11 @@ def conv1x1_bwd_act(x, dy, w, bias, act, out=None, dbx_out=None, want_dbx=True):
     assert dw.numel() == Cout * Cin and (dbx is None or dbx.numel() == Cin)
     nb = _lib.query('gx_conv1x1_bwd_act_ws_bytes', N, Cin, Cout, H, W)
     ws = _ws(nb, dev)
+    t = _tap_begin(dev, 1 << 30, dxa.numel()) if tap else None      # (tap: dxa's partial maxima, take_amax() afterwards)
     _lib.call('gx_conv1x1_bwd_act', _p(x), _p(dy), _p(w), _p(bias), N, Cin, Cout, H, W, ACTS[act], _p(dxa), _p(dw), _p(db),
               _p(dbx), _p(ws), nb, _stream())
+    if tap:
+        _tap_end(t)
     return dxa, (dw.view(w.shape) if o[0] is None else dw), db, dbx
 
 
@@ -730,7 +733,7 @@ def broadcast_concat(z, coords):
     return out
 
 
-def bcast_conv3x3_fwd(z, w, bias, rowc, colc, act):
+def bcast_conv3x3_fwd(z, w, bias, rowc, colc, act, tap=False):
     """act(conv3x3([z broadcast | row coord | col coord], w) + bias) on the d x d canvas without materialising it."""
     for t, n in ((z, 'z'), (w, 'w'), (bias, 'bias'), (rowc, 'rowc'), (colc, 'colc')):
         _chk(t, 'bcast_conv3x3_fwd.' + n)
@@ -738,8 +741,11 @@ def bcast_conv3x3_fwd(z, w, bias, rowc, colc, act):
     Co, d = w.shape[0], rowc.numel()
     assert w.shape == (Co, L + 2, 3, 3) and colc.numel() == d
     out = torch.empty(N, Co, d, d, dtype=F32, device=z.device)
+    t = _tap_begin(z.device, 1 << 30, out.numel()) if tap else None      # (tap: out's partial maxima, take_amax() afterwards)
     _lib.call('gx_bcast_conv3x3_fwd', _p(z), _p(w), _p(bias), _p(rowc), _p(colc), ACTS[act], _p(out), N, L, Co, d,
               _stream())
+    if tap:
+        _tap_end(t)
     return out
 
 
@@ -813,8 +819,10 @@ def logsoftmax_k_bwd(log_m_r, g, C):
     return g_dec
 
 
-def conv3x3_bias_act_fwd(x, w, bias, act):
-    """act(conv3x3 s1 p1 (x, w) + bias) on any HxW grid (W*H % 4 == 0)."""
+def conv3x3_bias_act_fwd(x, w, bias, act, amax_in=None, tap=False):
+    """act(conv3x3 s1 p1 (x, w) + bias) on any HxW grid (W*H % 4 == 0).  amax_in: the input's partial maxima (an Amax from the
+    kernel that wrote x); tap: ask the launch for its OUTPUT's partial maxima (take_amax() afterwards; served by the <= 32-channel
+    bf16-pipe kernel, which is also the one that would otherwise make a pass over its input)."""
     _chk(x, 'conv3x3_bias_act.x'); _chk(w, 'conv3x3_bias_act.w'); _chk(bias, 'conv3x3_bias_act.bias')
     N, Cin, H, W = x.shape
     Cout = w.shape[0]
@@ -822,8 +830,12 @@ def conv3x3_bias_act_fwd(x, w, bias, act):
     y = torch.empty(N, Cout, H, W, dtype=F32, device=x.device)
     nb = _lib.query('gx_conv3x3_ws_bytes', N, Cin, Cout, H, W)
     ws = _ws(nb, x.device)
-    _lib.call('gx_conv3x3_bias_act_fwd', _p(x), _p(w), _p(bias), ACTS[act], _p(y), N, Cin, Cout, H, W, _p(ws), nb,
-              _stream())
+    t = _tap_begin(x.device, 1 << 30, y.numel()) if tap else None
+    with _input_amax(amax_in):
+        _lib.call('gx_conv3x3_bias_act_fwd', _p(x), _p(w), _p(bias), ACTS[act], _p(y), N, Cin, Cout, H, W, _p(ws), nb,
+                  _stream())
+    if tap:
+        _tap_end(t)
     return y
 
 
@@ -845,7 +857,7 @@ def conv3x3_dgrad_act_supported(N, Cin, Cout, H, W):
     return bool(_lib.query('gx_conv3x3_dgrad_act_supported', N, Cin, Cout, H, W))
 
 
-def conv3x3_dgrad_act(dy, w, xout, act, dbias_out=None, want_dbias=True):
+def conv3x3_dgrad_act(dy, w, xout, act, dbias_out=None, want_dbias=True, amax_in=None, tap=False):
     """dxa = conv3x3_dgrad(dy, w) * act'(xout), dbias[c] = sum_{n,hw} dxa: conv3x3_dgrad + bias_act_bwd of the layer that
     produced xout, the activation's backward in the conv kernel's epilogue (gx_conv3x3_dgrad_act)."""
     _chk(dy, 'conv3x3_dgrad_act.dy'); _chk(w, 'conv3x3_dgrad_act.w'); _chk(xout, 'conv3x3_dgrad_act.xout')
@@ -858,8 +870,12 @@ def conv3x3_dgrad_act(dy, w, xout, act, dbias_out=None, want_dbias=True):
         dbias = dbias_out if dbias_out is not None else torch.empty(Cin, dtype=F32, device=dy.device)
     nb = _lib.query('gx_conv3x3_dgrad_act_ws_bytes', N, Cin, Cout, H, W)
     ws = _ws(nb, dy.device)
-    _lib.call('gx_conv3x3_dgrad_act', _p(dy), _p(w), _p(xout), ACTS[act], _p(dxa), _p(dbias), N, Cin, Cout, H, W, _p(ws), nb,
-              _stream())
+    t = _tap_begin(dy.device, 1 << 30, dxa.numel()) if tap else None      # (amax_in / tap: as conv3x3_bias_act_fwd)
+    with _input_amax(amax_in):
+        _lib.call('gx_conv3x3_dgrad_act', _p(dy), _p(w), _p(xout), ACTS[act], _p(dxa), _p(dbias), N, Cin, Cout, H, W, _p(ws), nb,
+                  _stream())
+    if tap:
+        _tap_end(t)
     return dxa, dbias
 
 
