@@ -285,41 +285,68 @@ int wgrad_splits(const IG& g) {
 // gradient).  Here a thread owns a 2 x 2 block of dx pixels (all four stride parities: 1 + 2 + 2 + 4 = 9 taps, the same
 // work for every thread) for CIB input channels and walks the output channels: 4 dy loads feed 9 CIB FMAs, weights
 // broadcast from LDS.  Exactly the useful multiply-adds, on the vector ALUs.
-template <int CIB>
+template <int CIB, int UB = 1>      // UB: output channels whose dy values are loaded ahead of their use
 __global__ void __launch_bounds__(256)
-conv3x3s2_dgrad_small_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int Cin,
+conv3x3s2_dgrad_small_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int N, int Cin,
                              int Cout, int H, int W, int cin_n, int dxC) {
     extern __shared__ __attribute__((aligned(16))) float wl[];       // [Cout][CIB][12]: 9 taps, padded to 3 float4
     const int Ho = H >> 1, Wo = W >> 1;
-    const int n = blockIdx.z, ci0 = blockIdx.y * CIB;
+    const int ci0 = blockIdx.x * CIB;          // (x: the channel blocks that read the same dy values are dispatched together)
     for (int e = threadIdx.x; e < Cout * CIB * 9; e += 256) {
         const int t = e % 9, c = (e / 9) % CIB, co = e / (9 * CIB);
         wl[(co * CIB + c) * 12 + t] = ci0 + c < Cin ? w[((size_t)co * Cin + ci0 + c) * 9 + t] : 0.f;
     }
     __syncthreads();
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= Ho * Wo) return;
+    // threads over (image, 2 x 2 block) TOGETHER: the encoder's last layers have 16 and 64 blocks per image -- one workgroup per
+    // (image, channel block) left 240 / 192 of its 256 threads idle (62 / 40 us for the 4 x 4 and 8 x 8 layers at 224 images)
+    const int q = blockIdx.y * 256 + threadIdx.x;
+    if (q >= N * Ho * Wo) return;
+    const int n = q / (Ho * Wo), p = q - n * (Ho * Wo);
     const int i = p / Wo, j = p - i * Wo;
     const bool jr = j + 1 < Wo, ir = i + 1 < Ho;
     const float* d = dy + (size_t)n * Cout * Ho * Wo + (size_t)i * Wo + j;
     float a00[CIB], a01[CIB], a10[CIB], a11[CIB];
 #pragma unroll
     for (int c = 0; c < CIB; ++c) { a00[c] = 0.f; a01[c] = 0.f; a10[c] = 0.f; a11[c] = 0.f; }
-    for (int co = 0; co < Cout; ++co) {
-        const float* dc = d + (size_t)co * Ho * Wo;
-        const float d00 = dc[0];
-        const float d01 = jr ? dc[1] : 0.f;
-        const float d10 = ir ? dc[Wo] : 0.f;
-        const float d11 = (ir && jr) ? dc[Wo + 1] : 0.f;
+    // four output channels' dy values are loaded before the first of them is used: the loop is bound by load latency, not by its
+    // 36 CIB multiply-adds per channel (the accumulation order per output value stays co = 0, 1, 2, ...)
+    // (UB = 8 for the launches of a few hundred workgroups -- the encoder's last layers: nothing else hides the latency there;
+    //  the chip-filling layers measured 10 - 15 % slower with it than with UB = 1)
+    const size_t cs = (size_t)Ho * Wo;
+    // (unconditional loads from clamped addresses, the border's zeros selected afterwards: no branch around a load)
+    const int o01 = jr ? 1 : 0, o10 = ir ? Wo : 0, o11 = o01 + o10;
+    for (int co0 = 0; co0 < Cout; co0 += UB) {
+        float dv[UB][4];
 #pragma unroll
-        for (int c = 0; c < CIB; ++c) {
-            const f32x4* wp = reinterpret_cast<const f32x4*>(wl + (co * CIB + c) * 12);
-            const f32x4 w0 = wp[0], w1 = wp[1], w2 = wp[2];       // taps 0-3 | 4-7 | 8
-            // dx(2i + a, 2j + b) = sum over kh = (a + 1) mod 2 .., kw likewise of dy((2i + a + 1 - kh) / 2, ..) w[kh][kw]
-            a00[c] += d00 * w1[0];                                              // w[1][1]
-            a01[c] += d00 * w1[1] + d01 * w0[3];                                // w[1][2], w[1][0]
-            a10[c] += d00 * w1[3] + d10 * w0[1];                                // w[2][1], w[0][1]
-            a11[c] += d00 * w2[0] + d01 * w1[2] + d10 * w0[2] + d11 * w0[0];    // w[2][2], w[2][0], w[0][2], w[0][0]
+        for (int u = 0; u < UB; ++u) {
+            const bool okc = co0 + u < Cout;
+            const float* dc = d + (size_t)(okc ? co0 + u : co0) * cs;
+            dv[u][0] = dc[0];
+            dv[u][1] = dc[o01];
+            dv[u][2] = dc[o10];
+            dv[u][3] = dc[o11];
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            dv[u][1] = jr ? dv[u][1] : 0.f;
+            dv[u][2] = ir ? dv[u][2] : 0.f;
+            dv[u][3] = (ir && jr) ? dv[u][3] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            if (co0 + u >= Cout) break;
+            const int co = co0 + u;
+            const float d00 = dv[u][0], d01 = dv[u][1], d10 = dv[u][2], d11 = dv[u][3];
+#pragma unroll
+            for (int c = 0; c < CIB; ++c) {
+                const f32x4* wp = reinterpret_cast<const f32x4*>(wl + (co * CIB + c) * 12);
+                const f32x4 w0 = wp[0], w1 = wp[1], w2 = wp[2];       // taps 0-3 | 4-7 | 8
+                // dx(2i + a, 2j + b) = sum over kh = (a + 1) mod 2 .., kw likewise of dy((2i + a + 1 - kh) / 2, ..) w[kh][kw]
+                a00[c] += d00 * w1[0];                                              // w[1][1]
+                a01[c] += d00 * w1[1] + d01 * w0[3];                                // w[1][2], w[1][0]
+                a10[c] += d00 * w1[3] + d10 * w0[1];                                // w[2][1], w[0][1]
+                a11[c] += d00 * w2[0] + d01 * w1[2] + d10 * w0[2] + d11 * w0[0];    // w[2][2], w[2][0], w[0][2], w[0][0]
+            }
         }
     }
 #pragma unroll
@@ -482,19 +509,23 @@ int gx_conv3x3s2_dgrad_small_ex(const float* dy, const float* w, float* dx, int 
     GX_CHECK_ARG(dx_channels >= cin_n, "gx_conv3x3s2_dgrad_small_ex: dx_channels (%d) < cin_n (%d)", dx_channels, cin_n);
     const int dxC = dx_channels;
     GX_CHECK_ARG(dy && w && dx, "gx_conv3x3s2_dgrad_small: null pointer");
-    GX_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && H >= 2 && W >= 2 && !(H & 1) && !(W & 1) && N <= 65535,
-                 "gx_conv3x3s2_dgrad_small: even H, W; N <= 65535");
+    GX_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && H >= 2 && W >= 2 && !(H & 1) && !(W & 1) && (double)N * H * W < 4.0 * 256 * 65535,
+                 "gx_conv3x3s2_dgrad_small: even H, W; N H W / 1024 <= 65535");
     GX_CHECK_ARG(cin_n >= 1 && cin_n <= Cin && Cout * 4 * 12 * 4 <= 64 * 1024, "gx_conv3x3s2_dgrad_small: 1 <= cin_n <= Cin, Cout <= 341");
     hipStream_t s = (hipStream_t)stream;
     const int npix = (H / 2) * (W / 2);
     {
         GxProf pf(KID_DCONV, s, 2.0 * N * Cout * (double)cin_n * 9 * npix, 4.0 * N * ((double)cin_n * H * W + (double)Cout * npix));
-        if (cin_n <= 2)
-            hipLaunchKernelGGL(conv3x3s2_dgrad_small_kernel<2>, dim3(gx_ceil_div(npix, 256), gx_ceil_div(cin_n, 2), N), dim3(256),
-                               (size_t)Cout * 2 * 12 * 4, s, dy, w, dx, Cin, Cout, H, W, cin_n, dxC);
-        else
-            hipLaunchKernelGGL(conv3x3s2_dgrad_small_kernel<4>, dim3(gx_ceil_div(npix, 256), gx_ceil_div(cin_n, 4), N), dim3(256),
-                               (size_t)Cout * 4 * 12 * 4, s, dy, w, dx, Cin, Cout, H, W, cin_n, dxC);
+        const bool few = (long)gx_ceil_div(cin_n, cin_n <= 2 ? 2 : 4) * gx_ceil_div(N * npix, 256) < 512;
+        if (cin_n <= 2) {
+            const dim3 grid(gx_ceil_div(cin_n, 2), gx_ceil_div(N * npix, 256));
+            if (few) hipLaunchKernelGGL((conv3x3s2_dgrad_small_kernel<2, 8>), grid, dim3(256), (size_t)Cout * 2 * 12 * 4, s, dy, w, dx, N, Cin, Cout, H, W, cin_n, dxC);
+            else hipLaunchKernelGGL((conv3x3s2_dgrad_small_kernel<2, 1>), grid, dim3(256), (size_t)Cout * 2 * 12 * 4, s, dy, w, dx, N, Cin, Cout, H, W, cin_n, dxC);
+        } else {
+            const dim3 grid(gx_ceil_div(cin_n, 4), gx_ceil_div(N * npix, 256));
+            if (few) hipLaunchKernelGGL((conv3x3s2_dgrad_small_kernel<4, 8>), grid, dim3(256), (size_t)Cout * 4 * 12 * 4, s, dy, w, dx, N, Cin, Cout, H, W, cin_n, dxC);
+            else hipLaunchKernelGGL((conv3x3s2_dgrad_small_kernel<4, 1>), grid, dim3(256), (size_t)Cout * 4 * 12 * 4, s, dy, w, dx, N, Cin, Cout, H, W, cin_n, dxC);
+        }
     }
     GX_CHECK_LAUNCH("gx_conv3x3s2_dgrad_small");
     return GX_OK;

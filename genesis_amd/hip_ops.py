@@ -129,6 +129,15 @@ def _tap_end(tap):
     _LAST.amax = Amax(ptr, n) if n > 0 else None
 
 
+def amax_values(h, device=None):
+    """The partial maxima behind an Amax handle as a tensor (a view of the arena: read it before the ring wraps) -- tests."""
+    idx = torch.cuda.current_device() if device is None or device.index is None else device.index
+    a = _ARENA[idx]
+    off = (h.ptr - a[1]) // 4
+    assert 0 <= off and off + h.n <= _ARENA_FLOATS, 'not an arena handle'
+    return a[0][off:off + h.n]
+
+
 def amax_of(t):
     """Partial maxima of any tensor by a pass of its own (gx_amax_parts: 256 floats) -- tests, and operands no producer taps."""
     _chk(t, 'amax_of.t')

@@ -235,6 +235,50 @@ def test_broadcast_decoder_canvas_layer_at_full_size():
         assert torch.equal(hip.conv3x3_wgrad_quad(x, dy), dw)
 
 
+def test_broadcast_decoder_chain_hands_the_exact_maxima_from_layer_to_layer():
+    """The producer taps of the BroadcastDecoder chain (modules/decoders.py:21-35 at K B = 224 on the 72 x 72 canvas): the first
+    layer's kernel, the canvas conv (forward, and as a data gradient with the activation's backward in its epilogue) and the 1 x 1
+    conv's data gradient each leave one partial maximum of |stored value| per workgroup -- their maximum IS the tensor's, bit for
+    bit -- and a canvas conv that is handed them gives the bits it gives after a pass of its own (its fp16 scale is a function of
+    that one number)."""
+    from genesis_amd import hip_ops as hip
+    N, C, S, L = 224, 32, 72, 16
+    torch.manual_seed(11)
+    z = torch.randn(N, L, device=DEV)
+    w0 = torch.randn(C, L + 2, 3, 3, device=DEV) * 0.1
+    w = torch.randn(C, C, 3, 3, device=DEV) * 0.06
+    b = torch.randn(C, device=DEV) * 0.1
+    lin = torch.linspace(-1, 1, S, device=DEV)
+
+    def taken(t):
+        h = hip.take_amax()
+        assert h is not None and h.n > 0, 'the launch did not serve the tap'
+        v = hip.amax_values(h).clone()
+        assert float(v.max()) == float(t.abs().max()) and float(v.min()) >= 0.0, (float(v.max()), float(t.abs().max()), h.n)
+        return h
+
+    h0 = hip.bcast_conv3x3_fwd(z, w0, b, lin, lin, 'relu', tap=True)
+    a0 = taken(h0)
+    h1 = hip.conv3x3_bias_act_fwd(h0, w, b, 'relu', amax_in=a0, tap=True)
+    a1 = taken(h1)
+    assert torch.equal(h1, hip.conv3x3_bias_act_fwd(h0, w, b, 'relu'))             # (own pass over h0)
+    h2 = hip.conv3x3_bias_act_fwd(h1, w, b, 'relu', amax_in=a1)
+    assert hip.take_amax() is None
+    assert torch.equal(h2, hip.conv3x3_bias_act_fwd(h1, w, b, 'relu'))
+    # backward: 1 x 1 head -> data gradient with the ReLU mask -> canvas data gradients
+    ow = torch.randn(4, C, device=DEV) * 0.2
+    ob = torch.zeros(4, device=DEV)
+    g = torch.randn(N, 4, S, S, device=DEV)
+    dy2, _, _, _ = hip.conv1x1_bwd_act(h2, g, ow, ob, 'relu', tap=True)
+    d2 = taken(dy2)
+    assert hip.conv3x3_dgrad_act_supported(N, C, C, S, S)
+    dy1, _ = hip.conv3x3_dgrad_act(dy2, w, h1, 'relu', amax_in=d2, tap=True)
+    d1 = taken(dy1)
+    ref1, _ = hip.conv3x3_dgrad_act(dy2, w, h1, 'relu')
+    assert torch.equal(dy1, ref1)
+    assert torch.equal(hip.conv3x3_dgrad(dy1, w, amax_in=d1), hip.conv3x3_dgrad(dy1, w))
+
+
 @pytest.mark.parametrize('N,Cin,Cout,S', [(224, 64, 64, 32), (224, 64, 64, 16), (224, 66, 64, 4)])
 def test_deconv5x5s2_is_one_trilinear_form(N, Cin, Cout, S):
     from genesis_amd import hip_ops as hip
