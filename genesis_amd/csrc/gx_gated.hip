@@ -144,24 +144,85 @@ __device__ __forceinline__ void gated_block_amax_out(float am, float* __restrict
     if (threadIdx.x == 0) amax_parts[blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(amr_[0], amr_[1]), fmaxf(amr_[2], amr_[3]));
 }
 
+// the fused forward (round 6): the apply kernel's workgroups form their two units' {mean, rstd} from the statistics pass's chunk
+// partials themselves (in the finalize kernel's order and arithmetic: the same bits), the first workgroup of a unit stores them to
+// `stats` (the backward pass reads them) and, under BatchNorm, applies nn.BatchNorm2d's running-statistics update -- two launches
+// less per unit (gated_stats_finalize_kernel, bn_running_update_kernel: ~5 us each, 20 of them per GENESIS step)
+struct GatedFuse {
+    const double* part;       // NULL: `stats` holds {mean, rstd} already (the cross-replica path; norm none)
+    int nchunk;
+    double m;                 // elements per unit
+    float eps;
+    float* stats_out;
+    float* rm_h; float* rv_h; float* rm_g; float* rv_g; long long* nbt_h; long long* nbt_g;     // running statistics (BatchNorm) or NULL
+    float mom;
+};
+
 // out[n][c][p] = A_h * sigmoid(A_g),  A = ((y + b) - mean) * rstd * gamma + beta
 __global__ void __launch_bounds__(256)
 gated_apply_kernel(const float* __restrict__ y, const float* __restrict__ bias, const float* __restrict__ stats,
                    const float* __restrict__ gh, const float* __restrict__ bh, const float* __restrict__ gg,
                    const float* __restrict__ bg, int N, int C, int HW, int norm, float* __restrict__ out,
-                   float* __restrict__ amax_parts) {
+                   float* __restrict__ amax_parts, const GatedFuse fu) {
     const int plane = blockIdx.x;           // n * C + c
     const int n = plane / C, c = plane % C;
     const int C2 = 2 * C;
     float mh, rh, mg, rg;
-    unit_stats(stats, norm, n, c, C2, &mh, &rh);
-    unit_stats(stats, norm, n, C + c, C2, &mg, &rg);
+    if (fu.part) {                          // (uniform)
+        __shared__ float st4[4];
+        if (threadIdx.x < 2) {
+            const int ch = threadIdx.x ? C + c : c;
+            const size_t u = norm == NORM_BN ? (size_t)ch : (size_t)n * C2 + ch;
+            double s1 = 0.0, s2 = 0.0;
+            for (int z = 0; z < fu.nchunk; ++z) { s1 += fu.part[2 * (u * fu.nchunk + z)]; s2 += fu.part[2 * (u * fu.nchunk + z) + 1]; }
+            const double mean = s1 / fu.m;
+            double var = s2 / fu.m - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float meanf = (float)mean, rstdf = (float)(1.0 / sqrt(var + (double)fu.eps));
+            st4[2 * threadIdx.x] = meanf; st4[2 * threadIdx.x + 1] = rstdf;
+            if (blockIdx.y == 0 && (norm != NORM_BN || n == 0)) {
+                fu.stats_out[2 * u] = meanf; fu.stats_out[2 * u + 1] = rstdf;
+                if (norm == NORM_BN && fu.rm_h) {       // (bn_running_update_kernel's arithmetic, from the stored pair)
+                    const double rstd = (double)rstdf, m = fu.m, eps = (double)fu.eps;
+                    const float varu = (float)((1.0 / (rstd * rstd) - eps) * (m / (m > 1.0 ? m - 1.0 : 1.0)));
+                    float* rm = threadIdx.x ? fu.rm_g + c : fu.rm_h + c;
+                    float* rv = threadIdx.x ? fu.rv_g + c : fu.rv_h + c;
+                    *rm = *rm * (1.f - fu.mom) + fu.mom * meanf;
+                    *rv = *rv * (1.f - fu.mom) + fu.mom * varu;
+                    if (c == 0 && threadIdx.x == 0) { *fu.nbt_h += 1; *fu.nbt_g += 1; }
+                }
+            }
+        }
+        __syncthreads();
+        mh = st4[0]; rh = st4[1]; mg = st4[2]; rg = st4[3];
+    } else {
+        unit_stats(stats, norm, n, c, C2, &mh, &rh);
+        unit_stats(stats, norm, n, C + c, C2, &mg, &rg);
+    }
     const float b_h = bias ? bias[c] : 0.f, b_g = bias ? bias[C + c] : 0.f;
     const float g_h = gh ? gh[c] : 1.f, be_h = bh ? bh[c] : 0.f, g_g = gg ? gg[c] : 1.f, be_g = bg ? bg[c] : 0.f;
     const float* ph = y + ((size_t)n * C2 + c) * HW;
     const float* pg = y + ((size_t)n * C2 + C + c) * HW;
     float* po = out + (size_t)plane * HW;
     float am = 0.f;
+    // 16-byte accesses where the planes allow them (every layer of the sylvester stacks): the scalar loop moved 2.5 TB/s
+    if ((HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+        const f32x4* ph4 = reinterpret_cast<const f32x4*>(ph);
+        const f32x4* pg4 = reinterpret_cast<const f32x4*>(pg);
+        f32x4* po4 = reinterpret_cast<f32x4*>(po);
+        for (int i = threadIdx.x + blockIdx.y * blockDim.x; i < (HW >> 2); i += blockDim.x * gridDim.y) {
+            const f32x4 vh = ph4[i], vg = pg4[i];
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float ah = ((vh[e] + b_h) - mh) * rh * g_h + be_h;
+                const float ag = ((vg[e] + b_g) - mg) * rg * g_g + be_g;
+                o[e] = ah * (1.f / (1.f + expf(-ag)));
+                am = fmaxf(am, fabsf(o[e]));
+            }
+            po4[i] = o;
+        }
+    } else
     for (int i = threadIdx.x + blockIdx.y * blockDim.x; i < HW; i += blockDim.x * gridDim.y) {
         const float ah = ((ph[i] + b_h) - mh) * rh * g_h + be_h;
         const float ag = ((pg[i] + b_g) - mg) * rg * g_g + be_g;
@@ -240,12 +301,21 @@ __global__ void gated_sums_finalize_kernel(const double* __restrict__ part, int 
     sums[2 * u] = (float)s1; sums[2 * u + 1] = (float)s2;
 }
 
+// the fused backward (round 6, BatchNorm): the apply kernel's workgroups fold the sums pass's chunk partials themselves and the first
+// workgroup of a channel stores the affine gradients (gated_sums_finalize_kernel + gated_param_kernel: two launches less per unit)
+struct GatedBwdFuse {
+    const double* part;       // NULL: `sums` holds the folded {S1, S2}
+    int nchunk;
+    float* dgh; float* dbh; float* dgg; float* dbg; float* dbias;
+};
+
 // Backward pass 2: dy[n][ch][p] = rstd * gamma * (dA - S1/m - xhat * S2/m)   (norm none: dy = dA)
 __global__ void __launch_bounds__(256)
 gated_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ bias, const float* __restrict__ stats,
                        const float* __restrict__ gh, const float* __restrict__ bh, const float* __restrict__ gg,
                        const float* __restrict__ bg, const float* __restrict__ dout, const float* __restrict__ sums,
-                       int N, int C, int HW, int norm, float m_global, float* __restrict__ dy, float* __restrict__ amax_parts) {
+                       int N, int C, int HW, int norm, float m_global, float* __restrict__ dy, float* __restrict__ amax_parts,
+                       const GatedBwdFuse fu) {
     const int plane = blockIdx.x;           // n * C + c
     const int n = plane / C, c = plane % C;
     const int C2 = 2 * C;
@@ -255,6 +325,24 @@ gated_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ bi
     const float b_h = bias ? bias[c] : 0.f, b_g = bias ? bias[C + c] : 0.f;
     const float g_h = gh ? gh[c] : 1.f, be_h = bh ? bh[c] : 0.f, g_g = gg ? gg[c] : 1.f, be_g = bg ? bg[c] : 0.f;
     float k1h = 0.f, k2h = 0.f, k1g = 0.f, k2g = 0.f;
+    if (fu.part) {                          // (uniform; BatchNorm) the sums pass's chunk partials, folded here
+        __shared__ float sm4[4];
+        if (threadIdx.x < 2) {
+            const size_t u = threadIdx.x ? (size_t)C + c : (size_t)c;
+            double s1 = 0.0, s2 = 0.0;
+            for (int z = 0; z < fu.nchunk; ++z) { s1 += fu.part[2 * (u * fu.nchunk + z)]; s2 += fu.part[2 * (u * fu.nchunk + z) + 1]; }
+            const float f1 = (float)s1, f2 = (float)s2;      // (gated_sums_finalize_kernel's values)
+            sm4[2 * threadIdx.x] = f1; sm4[2 * threadIdx.x + 1] = f2;
+            if (n == 0 && blockIdx.y == 0) {                 // (gated_param_kernel's stores)
+                if (threadIdx.x) { if (fu.dgg) fu.dgg[c] = f2; if (fu.dbg) fu.dbg[c] = f1; }
+                else { if (fu.dgh) fu.dgh[c] = f2; if (fu.dbh) fu.dbh[c] = f1; }
+                if (fu.dbias) fu.dbias[u] = 0.f;
+            }
+        }
+        __syncthreads();
+        const float m = m_global > 0.f ? m_global : (float)N * HW;
+        k1h = sm4[0] / m; k2h = sm4[1] / m; k1g = sm4[2] / m; k2g = sm4[3] / m;
+    } else
     if (norm != NORM_NONE) {
         const float m = (norm == NORM_BN) ? (m_global > 0.f ? m_global : (float)N * HW) : (float)HW;
         const int uh = (norm == NORM_BN) ? c : n * C2 + c, ug = (norm == NORM_BN) ? C + c : n * C2 + C + c;
@@ -267,6 +355,33 @@ gated_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ bi
     float* dh = dy + ((size_t)n * C2 + c) * HW;
     float* dg = dy + ((size_t)n * C2 + C + c) * HW;
     float am = 0.f;
+    if ((HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0) {
+        // (16-byte accesses, as in gated_apply_kernel)
+        const f32x4* ph4 = reinterpret_cast<const f32x4*>(ph);
+        const f32x4* pg4 = reinterpret_cast<const f32x4*>(pg);
+        const f32x4* pd4 = reinterpret_cast<const f32x4*>(pd);
+        f32x4* dh4 = reinterpret_cast<f32x4*>(dh);
+        f32x4* dg4 = reinterpret_cast<f32x4*>(dg);
+        for (int i = threadIdx.x + blockIdx.y * blockDim.x; i < (HW >> 2); i += blockDim.x * gridDim.y) {
+            const f32x4 vh = ph4[i], vg = pg4[i], vd = pd4[i];
+            f32x4 o_h, o_g;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = ((vh[e] + b_h) - mh) * rh, xg = ((vg[e] + b_g) - mg) * rg;
+                const float ah = xh * g_h + be_h, ag = xg * g_g + be_g;
+                const float sg = 1.f / (1.f + expf(-ag));
+                const float dAh = vd[e] * sg, dAg = vd[e] * ah * sg * (1.f - sg);
+                float oh = dAh, og = dAg;
+                if (norm != NORM_NONE) {
+                    oh = rh * g_h * (dAh - k1h - xh * k2h);
+                    og = rg * g_g * (dAg - k1g - xg * k2g);
+                }
+                o_h[e] = oh; o_g[e] = og;
+                am = fmaxf(am, fmaxf(fabsf(oh), fabsf(og)));
+            }
+            dh4[i] = o_h; dg4[i] = o_g;
+        }
+    } else
     for (int i = threadIdx.x + blockIdx.y * blockDim.x; i < HW; i += blockDim.x * gridDim.y) {
         const float xh = ((ph[i] + b_h) - mh) * rh, xg = ((pg[i] + b_g) - mg) * rg;
         const float ah = xh * g_h + be_h, ag = xg * g_g + be_g;
@@ -306,6 +421,13 @@ __global__ void gated_param_kernel(const float* __restrict__ sums, int N, int C,
     if (dbias) dbias[ch] = (norm == NORM_NONE) ? (float)s1 : 0.f;
 }
 
+struct GatedRun { float* rm_h; float* rv_h; float* rm_g; float* rv_g; long long* nbt_h; long long* nbt_g; float mom; };
+thread_local GatedRun t_gated_run = {};
+bool gated_fuse_on() {
+    static const bool on = [] { const char* e = getenv("GENESIS_GATED_FUSE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 int nunits(int norm, int N, int C) { return norm == NORM_IN ? N * 2 * C : 2 * C; }
 // image chunks per unit: a BatchNorm channel spans all N images -> spread it over ~2048 (statistics) / ~1024 (backward sums, one per channel pair) workgroups
 int nchunks(int norm, int N, int C) {
@@ -331,6 +453,9 @@ int gx_gated_norm_fwd(const float* y, const float* bias, int norm, const float* 
     GX_CHECK_ARG(N > 0 && C > 0 && H > 0 && W > 0 && norm >= 0 && norm <= 2, "gx_gated_norm_fwd: bad dims / norm");
     hipStream_t s = (hipStream_t)stream;
     const int HW = H * W;
+    GatedFuse fu = {};
+    const GatedRun run = t_gated_run;      // (one-shot: gx_gated_bn_running)
+    t_gated_run = GatedRun{};
     if (norm != NORM_NONE) {
         GxProf pf(KID_GATED, s, 0.0, 4.0 * N * 2.0 * C * HW);
         const int units = nunits(norm, N, C), nz = nchunks(norm, N, C);
@@ -339,18 +464,41 @@ int gx_gated_norm_fwd(const float* y, const float* bias, int norm, const float* 
                            nz, part);
         GX_CHECK_LAUNCH("gx_gated_norm_fwd(stats)");
         const double m = (norm == NORM_BN) ? (double)N * HW : (double)HW;
-        hipLaunchKernelGGL(gated_stats_finalize_kernel, dim3(gx_ceil_div(units, 256)), dim3(256), 0, s,
-                           (const double*)part, units, nz, m, eps, stats);
-        GX_CHECK_LAUNCH("gx_gated_norm_fwd(stats finalize)");
+        if (gated_fuse_on()) {
+            fu.part = part; fu.nchunk = nz; fu.m = m; fu.eps = eps; fu.stats_out = stats;
+            if (norm == NORM_BN && run.rm_h) {
+                fu.rm_h = run.rm_h; fu.rv_h = run.rv_h; fu.rm_g = run.rm_g; fu.rv_g = run.rv_g; fu.nbt_h = run.nbt_h; fu.nbt_g = run.nbt_g;
+                fu.mom = run.mom;
+            }
+        } else {
+            hipLaunchKernelGGL(gated_stats_finalize_kernel, dim3(gx_ceil_div(units, 256)), dim3(256), 0, s,
+                               (const double*)part, units, nz, m, eps, stats);
+            GX_CHECK_LAUNCH("gx_gated_norm_fwd(stats finalize)");
+        }
     }
     {
         GxProf pf(KID_GATED, s, 0.0, 4.0 * N * 3.0 * C * HW);
         const dim3 grid(N * C, N * C >= 2048 ? 1 : gx_ceil_div(HW, 1024));      // (many planes: one workgroup each -- and one partial maximum each)
         float* ap = gx_amax_producer_out(out, true, grid.x * grid.y, (size_t)N * C * HW);      // (out: a whole plain tensor)
         hipLaunchKernelGGL(gated_apply_kernel, grid, dim3(256), 0, s, y, bias,
-                           (const float*)stats, gamma_h, beta_h, gamma_g, beta_g, N, C, HW, norm, out, ap);
+                           (const float*)stats, gamma_h, beta_h, gamma_g, beta_g, N, C, HW, norm, out, ap, fu);
     }
     GX_CHECK_LAUNCH("gx_gated_norm_fwd");
+    if (run.rm_h && !(norm == NORM_BN && fu.part)) {
+        // an armed running-statistics update the apply kernel did not take (GENESIS_GATED_FUSE=0): the stand-alone launch
+        GX_CHECK_ARG(norm == NORM_BN, "gx_gated_bn_running is for BatchNorm units");
+        return gx_bn_running_update(stats, C, (double)N * HW, eps, run.mom, run.rm_h, run.rv_h, run.rm_g, run.rv_g, run.nbt_h,
+                                    run.nbt_g, stream);
+    }
+    return GX_OK;
+}
+
+/* one-shot, per thread: the NEXT gx_gated_norm_fwd of this thread (norm 1) also applies gx_bn_running_update to these buffers --
+ * inside its apply kernel, no launch of its own.  NULL rm_h disarms. */
+int gx_gated_bn_running(float* rm_h, float* rv_h, float* rm_g, float* rv_g, long long* nbt_h, long long* nbt_g, float momentum) {
+    if (!rm_h) { t_gated_run = GatedRun{}; return GX_OK; }
+    GX_CHECK_ARG(rv_h && rm_g && rv_g && nbt_h && nbt_g, "gx_gated_bn_running: null pointer");
+    t_gated_run = GatedRun{rm_h, rv_h, rm_g, rv_g, nbt_h, nbt_g, momentum};
     return GX_OK;
 }
 
@@ -383,14 +531,20 @@ int gx_gated_norm_bwd(const float* y, const float* bias, int norm, const float* 
     hipStream_t s = (hipStream_t)stream;
     const int HW = H * W;
     float* sums = (float*)ws;
+    GatedBwdFuse bf = {};
     {
         GxProf pf(KID_GATED, s, 0.0, 4.0 * N * 3.0 * C * HW);
         const int units = nunits(norm, N, C), nz = nchunks(norm == NORM_NONE ? NORM_BN : norm, N, C);
         double* part = reinterpret_cast<double*>(sums + 2 * (size_t)units);
         hipLaunchKernelGGL(gated_bwd_sums_kernel, dim3(units / 2, nz), dim3(256), 0, s, y, bias, stats, gamma_h, beta_h,
                            gamma_g, beta_g, dout, N, C, HW, norm, nz, part);
-        hipLaunchKernelGGL(gated_sums_finalize_kernel, dim3(gx_ceil_div(units, 256)), dim3(256), 0, s,
-                           (const double*)part, units, nz, sums);
+        if (norm == NORM_BN && gated_fuse_on()) {
+            bf.part = part; bf.nchunk = nz;
+            bf.dgh = dgamma_h; bf.dbh = dbeta_h; bf.dgg = dgamma_g; bf.dbg = dbeta_g; bf.dbias = dbias;
+        } else {
+            hipLaunchKernelGGL(gated_sums_finalize_kernel, dim3(gx_ceil_div(units, 256)), dim3(256), 0, s,
+                               (const double*)part, units, nz, sums);
+        }
     }
     GX_CHECK_LAUNCH("gx_gated_norm_bwd(sums)");
     {
@@ -398,12 +552,14 @@ int gx_gated_norm_bwd(const float* y, const float* bias, int norm, const float* 
         const dim3 grid(N * C, N * C >= 2048 ? 1 : gx_ceil_div(HW, 1024));
         float* ap = gx_amax_producer_out(dy, true, grid.x * grid.y, (size_t)N * 2 * C * HW);
         hipLaunchKernelGGL(gated_bwd_apply_kernel, grid, dim3(256), 0, s, y, bias, stats,
-                           gamma_h, beta_h, gamma_g, beta_g, dout, (const float*)sums, N, C, HW, norm, 0.f, dy, ap);
+                           gamma_h, beta_h, gamma_g, beta_g, dout, (const float*)sums, N, C, HW, norm, 0.f, dy, ap, bf);
     }
     GX_CHECK_LAUNCH("gx_gated_norm_bwd(apply)");
-    hipLaunchKernelGGL(gated_param_kernel, dim3(gx_ceil_div(2 * C, 64)), dim3(64), 0, s, (const float*)sums, N, C, norm,
-                       dgamma_h, dbeta_h, dgamma_g, dbeta_g, dbias);
-    GX_CHECK_LAUNCH("gx_gated_norm_bwd(params)");
+    if (!bf.part) {
+        hipLaunchKernelGGL(gated_param_kernel, dim3(gx_ceil_div(2 * C, 64)), dim3(64), 0, s, (const float*)sums, N, C, norm,
+                           dgamma_h, dbeta_h, dgamma_g, dbeta_g, dbias);
+        GX_CHECK_LAUNCH("gx_gated_norm_bwd(params)");
+    }
     return GX_OK;
 }
 
@@ -437,7 +593,7 @@ int gx_gated_bn_apply(const float* y, const float* bias, const double* sums, dou
     hipLaunchKernelGGL(gated_stats_from_sums_kernel, dim3(gx_ceil_div(2 * C, 256)), dim3(256), 0, s, sums, 2 * C, m, eps, stats);
     GxProf pf(KID_GATED, s, 0.0, 4.0 * N * 3.0 * C * HW);
     hipLaunchKernelGGL(gated_apply_kernel, dim3(N * C, gx_ceil_div(HW, 1024)), dim3(256), 0, s, y, bias, (const float*)stats,
-                       gamma_h, beta_h, gamma_g, beta_g, N, C, HW, (int)NORM_BN, out, (float*)nullptr);
+                       gamma_h, beta_h, gamma_g, beta_g, N, C, HW, (int)NORM_BN, out, (float*)nullptr, GatedFuse{});
     GX_CHECK_LAUNCH("gx_gated_bn_apply");
     return GX_OK;
 }
@@ -476,7 +632,7 @@ int gx_gated_bn_bwd_apply(const float* y, const float* bias, const float* gamma_
     const int HW = H * W;
     GxProf pf(KID_GATED, s, 0.0, 4.0 * N * 5.0 * C * HW);
     hipLaunchKernelGGL(gated_bwd_apply_kernel, dim3(N * C, gx_ceil_div(HW, 1024)), dim3(256), 0, s, y, bias, stats, gamma_h,
-                       beta_h, gamma_g, beta_g, dout, sums, N, C, HW, (int)NORM_BN, (float)m, dy, (float*)nullptr);
+                       beta_h, gamma_g, beta_g, dout, sums, N, C, HW, (int)NORM_BN, (float)m, dy, (float*)nullptr, GatedBwdFuse{});
     GX_CHECK_LAUNCH("gx_gated_bn_bwd_apply");
     return GX_OK;
 }

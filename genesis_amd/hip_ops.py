@@ -1070,6 +1070,19 @@ def philox_noise(uniform_shape, normal_shape, seed, step=None, device='cuda'):
     return u, z
 
 
+def gated_bn_running_arm(C, h_norm, g_norm, momentum=0.1):
+    """The next gated_norm_fwd of this thread (norm 'bn') also updates these two BatchNorm2d's running statistics, inside its
+    apply kernel (gx_gated_bn_running) -- instead of a bn_running_update launch after it."""
+    bufs = (h_norm.running_mean, h_norm.running_var, g_norm.running_mean, g_norm.running_var)
+    for b in bufs:
+        _chk(b, 'gated_bn_running.buffer')
+        assert b.numel() == C
+    for n in (h_norm.num_batches_tracked, g_norm.num_batches_tracked):
+        assert n.dtype == torch.int64 and n.is_cuda
+    _lib.call('gx_gated_bn_running', *[_p(b) for b in bufs], h_norm.num_batches_tracked.data_ptr(),
+              g_norm.num_batches_tracked.data_ptr(), float(momentum))
+
+
 def bn_running_update(stats, C, m, h_norm, g_norm, eps=1e-5, momentum=0.1):
     """nn.BatchNorm2d's running_mean / running_var / num_batches_tracked of a gated unit's two norms from the {mean, rstd}
     pairs of gated_norm_fwd, in one launch (gx_bn_running_update)."""

@@ -119,6 +119,12 @@ def gate_unit(unit, y, training):
         h, g = (y + unit.conv.bias.view(1, -1, 1, 1)).chunk(2, 1)
         return unit.h_norm(h) * torch.sigmoid(unit.g_norm(g))
     args = (unit.h_norm.weight, unit.h_norm.bias, unit.g_norm.weight, unit.g_norm.bias) if norm else (None,) * 4
+    if norm == 'bn' and not _SYNC['on']:
+        # the running statistics are updated by the unit's own apply kernel (the library falls back to a launch of its own)
+        assert unit.h_norm.momentum == 0.1 and unit.g_norm.momentum == 0.1
+        hip.gated_bn_running_arm(y.shape[1] // 2, unit.h_norm, unit.g_norm, momentum=0.1)
+        out, stats = GatedNormFn.apply(y, unit.conv.bias, norm, *args)
+        return out
     out, stats = GatedNormFn.apply(y, unit.conv.bias, norm, *args)
     if norm == 'bn':
         # running = 0.9 running + 0.1 {mean, unbiased variance}, num_batches_tracked += 1 (momentum None is not used by

@@ -470,6 +470,11 @@ int gx_gated_norm_fwd(const float* y, const float* bias, int norm, const float* 
  *      num_batches_tracked += 1) from the {mean, rstd} pairs gx_gated_norm_fwd left in `stats`; m = N H W. */
 int gx_bn_running_update(const float* stats, int C, double m, float eps, float momentum, float* rm_h, float* rv_h, float* rm_g,
                          float* rv_g, long long* nbt_h, long long* nbt_g, gx_stream_t stream);
+/*      ... or the same update without a launch of its own: gx_gated_bn_running arms a one-shot, per-thread request that the NEXT
+ *      gx_gated_norm_fwd of this thread (norm 1) applies inside its apply kernel, whose workgroups also fold the statistics pass's
+ *      partial sums themselves (two launches less per unit; GENESIS_GATED_FUSE=0: the stand-alone launches; rm_h NULL disarms).
+ *      gx_gated_norm_bwd (norm 1) folds its sums and writes the affine gradients the same way. */
+int gx_gated_bn_running(float* rm_h, float* rv_h, float* rm_g, float* rv_g, long long* nbt_h, long long* nbt_g, float momentum);
 size_t gx_gated_norm_bwd_ws_bytes(int norm, int N, int C);
 int gx_gated_norm_bwd(const float* y, const float* bias, int norm, const float* gamma_h, const float* beta_h,
                       const float* gamma_g, const float* beta_g, const float* stats, const float* dout, int N, int C,
