@@ -125,7 +125,9 @@ int gx_kq_amax_link(float* parts, int capacity, size_t numel);
 int gx_kq_amax_link_hits(void);
 /*      The same partial maxima for a LATER reader (the weight gradients' stream-K launch at the end of the backward pass,
  *      gx_wgq_operand_amax below): gx_amax_tap(parts, capacity, numel) arms a one-shot, per-thread request -- the next producer launch
- *      that supports it (the GroupNorm + ReLU kernels, forward and backward; the gated units' apply kernels) writes one partial maximum of the
+ *      that supports it (the GroupNorm + ReLU kernels, forward and backward; the gated units' apply kernels; the BroadcastDecoder
+ *      chain's producers -- gx_bcast_conv3x3_fwd, the <= 32-output-channel conv3x3 of gx_conv3x3_bias_act_fwd / gx_conv3x3_dgrad_act /
+ *      gx_conv3x3_dgrad in mode 2 of gx_kq_precision, gx_conv1x1_bwd_act's data gradient) writes one partial maximum of the
  *      values it stores per workgroup into parts[0 .. n) -- provided it stores exactly `numel` values: a chunked producer does not
  *      serve -- whatever its destination views are (the channel slice of a concat
  *      buffer and a resampled second copy hold the same values); gx_amax_tap_result() returns n (0: that launch could not
