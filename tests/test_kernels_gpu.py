@@ -1458,6 +1458,55 @@ def test_bn_running_statistics_of_a_gated_unit(N, C, S):
     assert int(dev_h.num_batches_tracked) == 2 and int(dev_g.num_batches_tracked) == 2
 
 
+@pytest.mark.parametrize('N,C,S', [(32, 32, 16), (7, 64, 8), (3, 5, 4)])
+def test_bn_running_statistics_inside_the_apply_kernel(N, C, S):
+    """gx_gated_bn_running: the running-statistics update applied by the unit's own apply kernel (whose workgroups fold the
+    statistics pass's partial sums themselves) leaves the bits of gated_norm_fwd + gx_bn_running_update -- output, {mean, rstd},
+    running means / variances, num_batches_tracked -- and matches two nn.BatchNorm2d in training mode; an armed request is
+    consumed by exactly one call.  layers.py:40-101."""
+    import torch.nn as nn
+    from genesis_amd import hip_ops as hip
+    y, bias = rnd(N, 2 * C, S, S, seed=3, scale=2.0), rnd(2 * C, seed=4)
+    ref_h, ref_g = nn.BatchNorm2d(C), nn.BatchNorm2d(C)
+    a_h, a_g = nn.BatchNorm2d(C).to(DEV), nn.BatchNorm2d(C).to(DEV)        # separate launch
+    f_h, f_g = nn.BatchNorm2d(C).to(DEV), nn.BatchNorm2d(C).to(DEV)        # inside the apply kernel
+    gh, bh = rnd(C, seed=5).to(DEV) + 1.0, rnd(C, seed=6).to(DEV)
+    gg, bg = rnd(C, seed=7).to(DEV) + 1.0, rnd(C, seed=8).to(DEV)
+    for step in range(3):
+        yy = y + 0.5 * step
+        h, g = (yy + bias.view(1, -1, 1, 1)).chunk(2, 1)
+        ref_h(h); ref_g(g)
+        out_a, st_a = hip.gated_norm_fwd(yy.to(DEV), bias.to(DEV), 'bn', gh, bh, gg, bg)
+        hip.bn_running_update(st_a, C, N * S * S, a_h, a_g)
+        hip.gated_bn_running_arm(C, f_h, f_g)
+        out_f, st_f = hip.gated_norm_fwd(yy.to(DEV), bias.to(DEV), 'bn', gh, bh, gg, bg)
+        assert torch.equal(out_a, out_f) and torch.equal(st_a[:4 * C], st_f[:4 * C])
+        out_n, _ = hip.gated_norm_fwd(yy.to(DEV), bias.to(DEV), 'bn', gh, bh, gg, bg)      # (not armed: no update)
+        assert torch.equal(out_n, out_f)
+        for a, f in ((a_h, f_h), (a_g, f_g)):
+            assert torch.equal(a.running_mean, f.running_mean) and torch.equal(a.running_var, f.running_var)
+            assert int(a.num_batches_tracked) == int(f.num_batches_tracked) == step + 1
+    for d, r in ((f_h, ref_h), (f_g, ref_g)):
+        close(d.running_mean, r.running_mean, rtol=1e-5, atol=1e-6, msg='running_mean')
+        close(d.running_var, r.running_var, rtol=1e-4, atol=1e-6, msg='running_var')
+    # the stand-alone finalize / parameter launches (GENESIS_GATED_FUSE=0) give the same bits, forward and backward
+    import os
+    dout = rnd(N, C, S, S, seed=9).to(DEV)
+    res = {}
+    for fuse in ('1', '0'):
+        os.environ['GENESIS_GATED_FUSE'] = fuse
+        try:
+            u_h, u_g = nn.BatchNorm2d(C).to(DEV), nn.BatchNorm2d(C).to(DEV)
+            hip.gated_bn_running_arm(C, u_h, u_g)
+            out, st = hip.gated_norm_fwd(y.to(DEV), bias.to(DEV), 'bn', gh, bh, gg, bg)
+            bwd = hip.gated_norm_bwd(y.to(DEV), bias.to(DEV), 'bn', gh, bh, gg, bg, st, dout)
+            res[fuse] = (out, st[:4 * C].clone(), u_h.running_mean.clone(), u_g.running_var.clone()) + tuple(bwd)
+        finally:
+            os.environ.pop('GENESIS_GATED_FUSE', None)
+    for a, b in zip(res['1'], res['0']):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('N,Cin,Cout,H,W', [(16, 32, 32, 72, 72), (5, 16, 24, 40, 24), (4, 32, 7, 16, 16), (9, 48, 32, 8, 64)])
 def test_conv3x3_to_32_channels_on_the_bf16_pipe(N, Cin, Cout, H, W):
     """gx_kq.hip's Q_C3H (the BroadcastDecoder's canvas convs, modules/decoders.py:21-35): conv3x3 (+ bias + ELU) and its data
