@@ -358,6 +358,75 @@ conv3x3s2_dgrad_small_kernel(const float* __restrict__ dy, const float* __restri
     }
 }
 
+// ---- ... its forward where the grid fills the chip (the encoder's first two layers: 4 -> 32 at 64 x 64, 32 -> 32 at 32 x 32, K B = 224
+// images): the implicit-GEMM kernel runs a 64-wide output-channel tile half empty and a contraction of 36 / 288 as 16-wide chunks
+// (36 / 47 us for 0.5 / 1.1 GFLOP).  Here a thread owns one output pixel and COB output channels and walks the input channels:
+// 9 window loads (stride-2 rows: neighbouring lanes overlap, the L1 serves them) feed 9 COB multiply-adds, weights broadcast from
+// LDS, bias + activation in the epilogue.  Bound by its stores / the window loads, not by arithmetic.
+template <int COB>
+__global__ void __launch_bounds__(256)
+conv3x3s2_fwd_small_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, int act,
+                           float* __restrict__ y, int N, int Cin, int Cout, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];       // [Cin][COB][12]: 9 taps, padded to 3 float4
+    const int Ho = H >> 1, Wo = W >> 1, HoWo = Ho * Wo;
+    const int co0 = blockIdx.x * COB;          // (x: the channel blocks that read the same windows are dispatched together)
+    for (int e = threadIdx.x; e < Cin * COB * 9; e += 256) {
+        const int t = e % 9, c = (e / 9) % COB, ci = e / (9 * COB);
+        wl[(ci * COB + c) * 12 + t] = co0 + c < Cout ? w[((size_t)(co0 + c) * Cin + ci) * 9 + t] : 0.f;
+    }
+    __syncthreads();
+    const int q = blockIdx.y * 256 + threadIdx.x;
+    if (q >= N * HoWo) return;
+    const int n = q / HoWo, p = q - n * HoWo;
+    const int i = p / Wo, j = p - i * Wo;
+    // window rows 2i - 1 .. 2i + 1, columns 2j - 1 .. 2j + 1: only the first row / column can be outside (even H, W); clamped
+    // addresses, the zeros selected afterwards
+    const bool top = i > 0, left = j > 0;
+    const float* xp = x + (size_t)n * Cin * H * W + (size_t)(2 * i) * W + 2 * j;
+    const int orow = top ? -W : 0, ocol = left ? -1 : 0;
+    float acc[COB];
+#pragma unroll
+    for (int c = 0; c < COB; ++c) acc[c] = 0.f;
+#pragma unroll 2
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float* xc = xp + (size_t)ci * H * W;
+        float xw[9];
+        xw[0] = xc[orow + ocol]; xw[1] = xc[orow]; xw[2] = xc[orow + 1];
+        xw[3] = xc[ocol];        xw[4] = xc[0];    xw[5] = xc[1];
+        xw[6] = xc[W + ocol];    xw[7] = xc[W];    xw[8] = xc[W + 1];
+        if (!top) { xw[0] = 0.f; xw[1] = 0.f; xw[2] = 0.f; }
+        if (!left) { xw[0] = 0.f; xw[3] = 0.f; xw[6] = 0.f; }
+#pragma unroll
+        for (int c = 0; c < COB; ++c) {
+            const f32x4* wp = reinterpret_cast<const f32x4*>(wl + (ci * COB + c) * 12);
+            const f32x4 w0 = wp[0], w1 = wp[1], w2 = wp[2];
+            float a = acc[c];
+            a = fmaf(xw[0], w0[0], a); a = fmaf(xw[1], w0[1], a); a = fmaf(xw[2], w0[2], a);
+            a = fmaf(xw[3], w0[3], a); a = fmaf(xw[4], w1[0], a); a = fmaf(xw[5], w1[1], a);
+            a = fmaf(xw[6], w1[2], a); a = fmaf(xw[7], w1[3], a); a = fmaf(xw[8], w2[0], a);
+            acc[c] = a;
+        }
+    }
+    float* yp = y + ((size_t)n * Cout + co0) * HoWo + p;
+#pragma unroll
+    for (int c = 0; c < COB; ++c) {
+        if (co0 + c >= Cout) break;
+        float v = acc[c] + (bias ? bias[co0 + c] : 0.f);
+        if (act == 1) v = v > 0.f ? v : 0.f;
+        else if (act == 2) v = v > 0.f ? v : expm1f(v);
+        yp[(size_t)c * HoWo] = v;
+    }
+}
+
+// the launch above where it pays: conv3x3 stride 2 pad 1 on even grids, <= 64 input channels, a grid of >= 512 workgroups
+static bool fwd_small_ok(int N, int Cin, int Cout, int H, int W, int k, int stride, int pad) {
+    static const char* env = getenv("GENESIS_DCONV_FWD_SMALL");
+    if (env && env[0] == '0') return false;
+    if (k != 3 || stride != 2 || pad != 1 || (H & 1) || (W & 1) || Cin > 64 || (double)N * H * W >= 2.0e9) return false;
+    const long wgs = (long)gx_ceil_div(Cout, 8) * gx_ceil_div(N * (H / 2) * (W / 2), 256);
+    return wgs >= 512 && gx_ceil_div(N * (H / 2) * (W / 2), 256) <= 65535;
+}
+
 // ---- ... and its weight gradient: dw[co][ci][kh][kw] = sum_{n,i,j} dy[n][co][i][j] x[n][ci][2i - 1 + kh][2j - 1 + kw].
 // Lanes = output pixels (coalesced dy rows, stride-2 x windows), a thread accumulates 9 taps x COB output channels of ONE
 // input channel over its pixels (9 + COB loads feed 9 COB FMAs), the workgroup's 256 partial sets are summed through LDS,
@@ -573,6 +642,13 @@ int gx_conv2d_direct_fwd(const float* x, const float* w, const float* bias, int 
     int rc = ig_geom("gx_conv2d_direct_fwd", &g, 0, N, Cin, Cout, H, W, k, stride, pad);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
+    if (fwd_small_ok(N, Cin, Cout, H, W, k, stride, pad)) {      // the ComponentVAE encoder's chip-filling layers: vector ALUs
+        GxProf pf(KID_DCONV, s, 2.0 * N * Cout * Cin * k * k * g.Ho * g.Wo, 4.0 * N * (Cin * H * W + Cout * g.Ho * g.Wo));
+        hipLaunchKernelGGL(conv3x3s2_fwd_small_kernel<8>, dim3(gx_ceil_div(Cout, 8), gx_ceil_div(N * (H / 2) * (W / 2), 256)), dim3(256),
+                           (size_t)Cin * 8 * 12 * 4, s, x, w, bias, act, y, N, Cin, Cout, H, W);
+        GX_CHECK_LAUNCH("gx_conv2d_direct_fwd(small)");
+        return GX_OK;
+    }
     {
         GxProf pf(KID_DCONV, s, 2.0 * N * Cout * Cin * k * k * g.Ho * g.Wo, 4.0 * N * (Cin * H * W + Cout * g.Ho * g.Wo));
         hipLaunchKernelGGL(igemm_kernel<0>, dim3(gx_ceil_div(g.Ncols, BN), gx_ceil_div(g.M, BM), 1), dim3(256), 0, s, w,
